@@ -1,0 +1,458 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the read-only reference (/root/reference).
+
+TEST INFRASTRUCTURE.  Runs only in the build container (the reference never travels to
+the GPU box); its outputs -- small .npz files of inputs/expected outputs -- are committed
+under tests/golden/ and are what pins oracle/lenv_oracle.c to the reference.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+
+Recipe = SURVEY.md Appendix C: shims for gym/seaborn/ConfigSpace on PYTHONPATH ahead of
+the reference, every RNG source pinned, RNG draws recorded as tapes.
+"""
+import contextlib
+import copy
+import io
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("LENV_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(HERE, "shims"))
+os.makedirs("/tmp/lenv_golden_cwd", exist_ok=True)
+os.chdir("/tmp/lenv_golden_cwd")  # GTN_Base creates ./results/GTN_sync relative to cwd
+
+import torch  # noqa: E402
+import yaml  # noqa: E402
+import gym  # noqa: E402  (the shim)
+from gym.utils import seeding  # noqa: E402
+
+torch.set_num_threads(1)
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def load_cfg(name):
+    with open(os.path.join(REF, name)) as f:
+        return yaml.safe_load(f)
+
+
+def seed_all(s):
+    torch.manual_seed(s)
+    np.random.seed(s)
+    random.seed(s)
+    seeding.set_counter(1000 + s)
+
+
+def pack_linear_params(state_dict, prefix):
+    """Flat fp32 vector of the nn.Linear weights/biases under `prefix`, in state-dict order
+    (W0,b0,...,Wout,bout); PReLU slopes (1-element '<idx>.weight') are skipped."""
+    parts = []
+    for k, v in state_dict.items():
+        if k.startswith(prefix) and not (k.endswith("weight") and _is_prelu_key(state_dict, k)):
+            parts.append(v.detach().cpu().numpy().astype(np.float32).reshape(-1))
+    return np.concatenate(parts)
+
+
+def _is_prelu_key(sd, k):
+    # a PReLU module has a weight but no bias sibling
+    return (k[:-len("weight")] + "bias") not in sd
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, {k: (np.asarray(v).shape) for k, v in arrays.items()})
+
+
+# ------------------------------------------------------------------------------------------------
+# G1: VirtualEnv.step through EnvWrapper.step (envs/virtual_env.py:43-54, env_wrapper.py:16-47)
+# ------------------------------------------------------------------------------------------------
+def gen_g1():
+    from envs.env_factory import EnvFactory
+    out = {}
+    cases = []
+    for env_yaml, env_name in (("default_config_cartpole_syn_env.yaml", "CartPole-v0"),
+                               ("default_config_acrobot_syn_env.yaml", "Acrobot-v1")):
+        for act in ("leakyrelu", "relu", "tanh", "prelu", "identity"):
+            for layers in (1, 2):
+                cases.append((env_yaml, env_name, act, layers))
+    for ci, (env_yaml, env_name, act, layers) in enumerate(cases):
+        cfg = load_cfg(env_yaml)
+        cfg["envs"][env_name]["activation_fn"] = act
+        cfg["envs"][env_name]["hidden_layer"] = layers
+        if layers == 2:
+            cfg["envs"][env_name]["hidden_size"] = 40 if ci % 4 == 1 else 24
+        seed_all(100 + ci)
+        with quiet():
+            fac = EnvFactory(cfg)
+            venv = fac.generate_virtual_env()
+        sd = venv.state_dict()
+        S, A = venv.get_state_dim(), venv.get_action_dim()
+        theta = np.concatenate([pack_linear_params(sd, "env.state_net."), pack_linear_params(sd, "env.reward_net."),
+                                pack_linear_params(sd, "env.done_net.")])
+        n = 12
+        states = torch.randn(n, S) * 0.7
+        actions = torch.randint(0, A, (n,))
+        ns, rw, dn = [], [], []
+        with torch.no_grad():
+            for i in range(n):
+                venv.env.state = states[i].clone()
+                a, b, c = venv.step(actions[i:i + 1].float())
+                ns.append(a.numpy().copy()); rw.append(b.numpy().copy()); dn.append(c.numpy().copy())
+        pre = "c%02d_" % ci
+        out[pre + "meta"] = np.array([S, A, cfg["envs"][env_name]["hidden_size"], layers,
+                                      ["identity", "relu", "leakyrelu", "tanh", "prelu"].index(act)], np.int64)
+        out[pre + "theta"] = theta
+        out[pre + "state"] = states.numpy()
+        out[pre + "action"] = actions.numpy().astype(np.int32)
+        out[pre + "next_state"] = np.stack(ns)
+        out[pre + "reward"] = np.concatenate(rw)
+        out[pre + "done"] = np.concatenate(dn)
+    out["n_cases"] = np.array(len(cases))
+    save("g1_virtual_env_step", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# G3: Critic_DQN forward on a batch (models/actor_critic.py:84-91)
+# ------------------------------------------------------------------------------------------------
+def gen_g3():
+    from models.actor_critic import Critic_DQN
+    out = {}
+    cases = [(4, 2, 57, 1, "tanh"), (6, 3, 112, 1, "leakyrelu"), (4, 2, 24, 2, "relu"), (6, 3, 40, 2, "tanh")]
+    for ci, (S, A, H, L, act) in enumerate(cases):
+        cfg = {"agents": {"ddqn": {"hidden_size": H, "hidden_layer": L, "activation_fn": act}}}
+        seed_all(300 + ci)
+        net = Critic_DQN(S, A, "ddqn", cfg)
+        x = torch.randn(37, S)
+        with torch.no_grad():
+            y = net(x)
+            y1 = torch.stack([net(x[i]) for i in range(5)])   # batch-1 (gemv) path
+        pre = "c%d_" % ci
+        out[pre + "meta"] = np.array([S, A, H, L, ["identity", "relu", "leakyrelu", "tanh", "prelu"].index(act)], np.int64)
+        out[pre + "params"] = pack_linear_params(net.state_dict(), "net.")
+        out[pre + "x"] = x.numpy()
+        out[pre + "y"] = y.numpy()
+        out[pre + "y_single"] = y1.numpy()
+    out["n_cases"] = np.array(len(cases))
+    save("g3_critic_dqn_forward", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# G4: DDQN.learn steps on explicit minibatches (agents/DDQN.py:60-94)
+# ------------------------------------------------------------------------------------------------
+def gen_g4():
+    from agents.DDQN import DDQN
+    from envs.env_factory import EnvFactory
+    from utils import ReplayBuffer
+    out = {}
+    variants = [("default_config_cartpole_syn_env.yaml", {}, 4),
+                ("default_config_cartpole_syn_env.yaml", {"activation_fn": "relu", "hidden_layer": 2, "hidden_size": 24, "batch_size": 64}, 3),
+                ("default_config_acrobot_syn_env.yaml", {}, 3)]
+    for vi, (yml, over, nsteps) in enumerate(variants):
+        cfg = load_cfg(yml)
+        cfg["agents"]["ddqn"].update(over)
+        seed_all(400 + vi)
+        with quiet():
+            fac = EnvFactory(cfg)
+            real_env = fac.generate_real_env()
+            agent = DDQN(env=real_env, config=cfg)
+        S, A = real_env.get_state_dim(), real_env.get_action_dim()
+        B = cfg["agents"]["ddqn"]["batch_size"]
+        rb = ReplayBuffer(state_dim=S, action_dim=1, device="cpu", max_size=600)
+        for i in range(500):
+            rb.add(torch.randn(S) * 0.5, torch.tensor([float(np.random.randint(A))]), torch.randn(S) * 0.5,
+                   torch.randn(1) * 0.3 + 0.5, torch.randn(1) * 0.2)
+        # make target differ from online so the Polyak step is exercised
+        with torch.no_grad():
+            for p in agent.model_target.parameters():
+                p.add_(torch.randn_like(p) * 0.05)
+        pre = "v%d_" % vi
+        a = cfg["agents"]["ddqn"]
+        out[pre + "meta"] = np.array([S, A, a["hidden_size"], a["hidden_layer"],
+                                      ["identity", "relu", "leakyrelu", "tanh", "prelu"].index(a["activation_fn"]), B, nsteps], np.int64)
+        out[pre + "hparams"] = np.array([a["gamma"], a["lr"], a["tau"]], np.float64)
+        out[pre + "online0"] = pack_linear_params(agent.model.state_dict(), "net.")
+        out[pre + "target0"] = pack_linear_params(agent.model_target.state_dict(), "net.")
+        idxs, rows_all, onl, tgt, losses, ms, vs = [], [], [], [], [], [], []
+        for step in range(nsteps):
+            idx = np.random.randint(0, rb.size, size=B)
+            rb.sample = lambda batch_size, _idx=idx: rb._sample_idx(_idx)
+            rows = np.concatenate([rb.state[idx].numpy(), rb.action[idx].numpy(), rb.next_state[idx].numpy(),
+                                   rb.reward[idx].numpy(), rb.done[idx].numpy()], axis=1)
+            loss = agent.learn(rb, real_env, episode=5)
+            idxs.append(idx); rows_all.append(rows); losses.append(float(loss.item()))
+            onl.append(pack_linear_params(agent.model.state_dict(), "net."))
+            tgt.append(pack_linear_params(agent.model_target.state_dict(), "net."))
+            st = agent.optimizer.state_dict()["state"]
+            order = list(range(len(st)))
+            ms.append(np.concatenate([st[i]["exp_avg"].numpy().reshape(-1) for i in order]))
+            vs.append(np.concatenate([st[i]["exp_avg_sq"].numpy().reshape(-1) for i in order]))
+        out[pre + "rows"] = np.stack(rows_all).astype(np.float32)
+        out[pre + "loss"] = np.array(losses, np.float64)
+        out[pre + "online"] = np.stack(onl)
+        out[pre + "target"] = np.stack(tgt)
+        out[pre + "adam_m"] = np.stack(ms)
+        out[pre + "adam_v"] = np.stack(vs)
+    out["n_variants"] = np.array(len(variants))
+    save("g4_ddqn_learn", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# G6: GTN_Worker noise / perturbation / mirrored pick (agents/GTN_worker.py:156-254)
+# ------------------------------------------------------------------------------------------------
+def se_theta(envw):
+    sd = envw.state_dict()
+    return np.concatenate([pack_linear_params(sd, "env.state_net."), pack_linear_params(sd, "env.reward_net."),
+                           pack_linear_params(sd, "env.done_net.")])
+
+
+def gen_g6():
+    from agents.GTN import GTN_Worker
+    cfg = load_cfg("default_config_cartpole_syn_env.yaml")
+    with quiet():
+        w = GTN_Worker(id=0, bohb_id=0)
+        seed_all(600)
+        w.config = cfg
+        w.late_init(cfg)
+        w.synthetic_env.load_state_dict(w.synthetic_env_orig.state_dict())
+        theta = se_theta(w.synthetic_env_orig)
+        w.get_random_noise()
+        eps = se_theta(w.eps)
+        w.add_noise_to_synthetic_env()
+        plus = se_theta(w.synthetic_env)
+        w.subtract_noise_from_synthetic_env()
+        minus = se_theta(w.synthetic_env)
+        cases = []
+        for add, sub in ((10.0, 20.0), (20.0, 10.0), (15.0, 15.0)):
+            w.eps.load_state_dict(_sd_from_flat(w.eps, eps))
+            w.subtract_noise_from_synthetic_env()
+            best = w.calc_best_score(score_sub=[sub], score_add=[add])
+            cases.append((add, sub, best, se_theta(w.eps), se_theta(w.synthetic_env)))
+    save("g6_worker_noise", theta=theta, eps=eps, theta_plus=plus, theta_minus=minus,
+         noise_std=np.array(cfg["agents"]["gtn"]["noise_std"]),
+         score_add=np.array([c[0] for c in cases]), score_sub=np.array([c[1] for c in cases]),
+         score_best=np.array([c[2] for c in cases]), eps_after=np.stack([c[3] for c in cases]),
+         env_after=np.stack([c[4] for c in cases]))
+
+
+def _sd_from_flat(envw, flat):
+    sd = copy.deepcopy(envw.state_dict())
+    off = 0
+    for k in sd:
+        if not _is_prelu_key(sd, k) or not k.endswith("weight"):
+            n = sd[k].numel()
+            sd[k] = torch.from_numpy(flat[off:off + n].reshape(tuple(sd[k].shape)).copy())
+            off += n
+    assert off == flat.size
+    return sd
+
+
+# ------------------------------------------------------------------------------------------------
+# G7: GTN_Master.score_transform (all types) and update_env (agents/GTN_master.py:197-298)
+# ------------------------------------------------------------------------------------------------
+def gen_g7():
+    from agents.GTN import GTN_Master
+    cfg = load_cfg("default_config_cartpole_syn_env.yaml")
+    n = 8
+    cfg["agents"]["gtn"]["num_workers"] = n
+    out = {}
+    rng = np.random.RandomState(7)
+    scores = rng.uniform(10, 200, n)
+    scores_orig = rng.uniform(10, 200, n)
+    tied = np.array([200.0, 13.0, 200.0, 57.0, 13.0, 200.0, 99.0, 57.0])
+    with quiet():
+        seed_all(700)
+        m = GTN_Master(cfg, bohb_id=0)
+        for t in range(8):
+            m.score_transform_type = t
+            m.score_list = list(scores); m.score_orig_list = list(scores_orig)
+            m.score_transform()
+            out["tf%d" % t] = np.array(m.score_transform_list, np.float64)
+            m.score_list = list(tied); m.score_orig_list = list(scores_orig)
+            m.score_transform()
+            out["tf%d_tied" % t] = np.array(m.score_transform_list, np.float64)
+        theta0 = se_theta(m.synthetic_env_orig)
+        eps = []
+        for e in m.eps_list:
+            flat = (rng.randn(theta0.size) * 0.0124).astype(np.float32)
+            e.load_state_dict(_sd_from_flat(e, flat))
+            eps.append(flat)
+        m.score_transform_type = 3
+        m.score_list = list(scores); m.score_orig_list = list(scores_orig)
+        m.score_transform()
+        w = np.array(m.score_transform_list)
+        m.update_env()
+        theta1 = se_theta(m.synthetic_env_orig)
+        m.nes_step_size = True
+        m.weight_decay = 0.01
+        m.update_env()
+        theta2 = se_theta(m.synthetic_env_orig)
+    save("g7_master", scores=scores, scores_orig=scores_orig, tied=tied, theta0=theta0, eps=np.stack(eps), weights=w,
+         step_size=np.array(cfg["agents"]["gtn"]["step_size"]), theta1=theta1, theta2=theta2, **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# G8: full GTN_Worker.calc_score with recorded RNG tapes + per-step trace (cfg 1 shapes)
+# ------------------------------------------------------------------------------------------------
+class Recorder(object):
+    def __init__(self):
+        self.eps_uniform, self.rand_action, self.replay_idx = [], [], []
+        self.resets = []          # (id(env), state)
+        self.steps = []           # dicts
+        self.losses = []
+        self.active = False
+
+
+def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml="default_config_cartpole_syn_env.yaml",
+           env_name="CartPole-v0", env_cls="CartPoleEnv"):
+    import agents.GTN_worker as gw
+    from agents.GTN import GTN_Worker
+    import gym.envs as genvs
+    import gym.spaces as gspaces
+    cfg = load_cfg(env_yaml)
+    cfg["agents"]["ddqn"]["train_episodes"] = train_episodes
+    cfg["agents"]["ddqn"]["print_rate"] = int(1e9)
+    if max_steps:
+        cfg["envs"][env_name]["max_steps"] = max_steps
+    rec = Recorder()
+
+    orig_random, orig_randint = random.random, np.random.randint
+    cls = getattr(genvs, env_cls)
+    orig_reset, orig_sample = cls.reset, gspaces.Discrete.sample
+
+    def rec_random():
+        v = orig_random()
+        if rec.active:
+            rec.eps_uniform.append(v)
+        return v
+
+    def rec_randint(*a, **k):
+        v = orig_randint(*a, **k)
+        if rec.active:
+            rec.replay_idx.append(np.asarray(v).copy())
+        return v
+
+    def rec_reset(self):
+        obs = orig_reset(self)
+        if rec.active:
+            rec.resets.append((id(self), np.array(self.state, np.float64).copy()))
+        return obs
+
+    def rec_sample(self):
+        v = orig_sample(self)
+        if rec.active:
+            rec.rand_action.append(v)
+        return v
+
+    orig_select_agent = gw.select_agent
+    holder = {}
+
+    def wrapped_select_agent(config, agent_name):
+        agent = orig_select_agent(config=config, agent_name=agent_name)
+        holder["agent"] = agent
+        holder["init"] = pack_linear_params(agent.model.state_dict(), "net.")
+        orig_learn = agent.learn
+
+        def learn(replay_buffer, env, episode):
+            loss = orig_learn(replay_buffer=replay_buffer, env=env, episode=episode)
+            rec.losses.append(float(loss.item()))
+            return loss
+
+        agent.learn = learn
+        return agent
+
+    with quiet():
+        w = GTN_Worker(id=0, bohb_id=0)
+        seed_all(seed)
+        w.config = cfg
+        w.late_init(cfg)
+        w.timeout = 1e9
+        if done_bias_shift:
+            with torch.no_grad():
+                w.synthetic_env_orig.env.done_net[-1].bias.add_(done_bias_shift)
+        theta = se_theta(w.synthetic_env_orig)
+        env = w.synthetic_env_orig
+        orig_step = env.step
+
+        def rec_step(action, state=None):
+            s_before = env.env.state.detach().numpy().copy()
+            ns, r, d = orig_step(action=action, state=state)
+            rec.steps.append(dict(state=s_before, action=int(action.item()), next_state=ns.detach().numpy().copy(),
+                                  reward=float(r.item()), done=float(d.item()), n_rand=len(rec.rand_action)))
+            return ns, r, d
+
+        env.step = rec_step
+        random.random, np.random.randint = rec_random, rec_randint
+        cls.reset, gspaces.Discrete.sample = rec_reset, rec_sample
+        gw.select_agent = wrapped_select_agent
+        train_reset_id = id(env.env.reset_env.env.unwrapped)
+        try:
+            rec.active = True
+            # replicate calc_score but keep the per-episode lists (GTN_worker.py:187-209)
+            agent = gw.select_agent(config=w.config, agent_name=w.agent_name)
+            real_env = w.env_factory.generate_real_env()
+            reward_list_train, episode_length_train, _ = agent.train(env=env, test_env=real_env, time_remaining=1e9)
+            reward_list_test, _, _ = agent.test(env=real_env, time_remaining=1e9)
+            rec.active = False
+        finally:
+            random.random, np.random.randint = orig_random, orig_randint
+            cls.reset, gspaces.Discrete.sample = orig_reset, orig_sample
+            gw.select_agent = orig_select_agent
+    import statistics
+    score = statistics.mean(reward_list_test)
+    train_reset = np.array([s for (i, s) in rec.resets if i == train_reset_id])
+    test_reset = np.array([s for (i, s) in rec.resets if i != train_reset_id])
+    a = cfg["agents"]["ddqn"]
+    B = a["batch_size"]
+    n = len(rec.steps)
+    explored = np.zeros(n, np.int32)
+    prev = 0
+    for k, st in enumerate(rec.steps):
+        explored[k] = 1 if st["n_rand"] > prev else 0
+        prev = st["n_rand"]
+    import json
+    save(name, config_json=np.array(json.dumps(cfg)),
+         theta=theta, agent_init=holder["init"],
+         train_episodes=np.array(train_episodes), max_steps=np.array(cfg["envs"][env_name]["max_steps"]),
+         tape_eps_uniform=np.array(rec.eps_uniform, np.float64), tape_rand_action=np.array(rec.rand_action, np.int32),
+         tape_replay_idx=(np.stack(rec.replay_idx).astype(np.int32) if rec.replay_idx else np.zeros((0, B), np.int32)),
+         tape_train_reset=train_reset, tape_test_reset=test_reset,
+         tr_state=np.stack([s["state"] for s in rec.steps]).astype(np.float32),
+         tr_action=np.array([s["action"] for s in rec.steps], np.int32), tr_explored=explored,
+         tr_next_state=np.stack([s["next_state"] for s in rec.steps]).astype(np.float32),
+         tr_reward=np.array([s["reward"] for s in rec.steps], np.float32),
+         tr_done=np.array([s["done"] for s in rec.steps], np.float32),
+         losses=np.array(rec.losses, np.float64),
+         reward_list_train=np.array(reward_list_train, np.float64),
+         episode_length_train=np.array(episode_length_train, np.int32),
+         reward_list_test=np.array(reward_list_test, np.float64), score=np.array(score))
+
+
+def main():
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g6", "g7", "g8"]
+    os.makedirs(OUT, exist_ok=True)
+    if "g1" in which:
+        gen_g1()
+    if "g3" in which:
+        gen_g3()
+    if "g4" in which:
+        gen_g4()
+    if "g6" in which:
+        gen_g6()
+    if "g7" in which:
+        gen_g7()
+    if "g8" in which:
+        gen_g8("g8_calc_score_cartpole_a", train_episodes=3, done_bias_shift=0.0, seed=800)
+        gen_g8("g8_calc_score_cartpole_b", train_episodes=4, done_bias_shift=0.45, seed=801, max_steps=60)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,861 @@
+/*
+ * lenv_oracle.c -- CPU ORACLE (test infrastructure; see lenv_oracle.h header comment).
+ *
+ * Every function cites the reference file:line (relative to /root/reference) it restates.
+ * Build: gcc -O2 -ffp-contract=off -mfma -fPIC -shared -pthread (oracle/Makefile).
+ * -ffp-contract=off is REQUIRED: fused multiply-adds appear only where fmaf() is written.
+ */
+#include "lenv_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * deterministic math (no libm transcendental calls: the HIP kernels implement the same
+ * polynomial sequences, so results agree bitwise between gcc/x86 and hipcc/gfx950)
+ * ---------------------------------------------------------------------------------------- */
+
+static inline float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* tanh(x) = em1/(em1+2), em1 = expm1(2|x|) = 2^k * (r*Q(r)) + (2^k - 1), |r| <= ln2/2.
+ * Replaces torch.tanh (agents' activation_fn 'tanh', models/model_utils.py:15-16);
+ * max deviation from a correctly-rounded tanh is a few ulp. */
+float orc_tanhf(float x)
+{
+    float ax = fabsf(x);
+    if (ax > 10.0f) ax = 10.0f;
+    float y = ax + ax;
+    float kf = rintf(y * 1.44269504088896341f);
+    float r = fmaf(-kf, 0.693145751953125f, y);          /* ln2 hi (exact in 16 bits) */
+    r = fmaf(-kf, 1.42860682030941723212e-6f, r);        /* ln2 lo */
+    /* Q(r) = (e^r - 1)/r, Taylor to r^7 */
+    float q = 2.48015873015873e-5f;                      /* 1/40320 */
+    q = fmaf(q, r, 1.98412698412698e-4f);                /* 1/5040 */
+    q = fmaf(q, r, 1.38888888888889e-3f);                /* 1/720 */
+    q = fmaf(q, r, 8.33333333333333e-3f);                /* 1/120 */
+    q = fmaf(q, r, 4.16666666666667e-2f);                /* 1/24 */
+    q = fmaf(q, r, 1.66666666666667e-1f);                /* 1/6 */
+    q = fmaf(q, r, 0.5f);
+    q = fmaf(q, r, 1.0f);
+    float p = r * q;
+    int k = (int)kf;
+    float s = bits_f32((uint32_t)(k + 127) << 23);       /* 2^k, 0 <= k <= 29 */
+    float em1 = fmaf(s, p, s - 1.0f);
+    float t = em1 / (em1 + 2.0f);
+    return copysignf(t, x);
+}
+
+/* sin/cos in double: Cody-Waite reduction by pi/2 (3 constants) + fdlibm kernel polynomials.
+ * Replaces math.sin/math.cos / numpy sin/cos inside gym's CartPole/Acrobot (third party). */
+static const double PIO2_1 = 1.57079632673412561417e+00;  /* first 33 bits of pi/2 */
+static const double PIO2_2 = 6.07710050630396597660e-11;  /* second 33 bits */
+static const double PIO2_3 = 2.02226624871116645580e-21;  /* third 33 bits */
+
+static inline double ksin(double x)
+{
+    double z = x * x;
+    double p = 1.58969099521155010221e-10;
+    p = fma(p, z, -2.50507602534068634195e-08);
+    p = fma(p, z, 2.75573137070700676789e-06);
+    p = fma(p, z, -1.98412698298579493134e-04);
+    p = fma(p, z, 8.33333333332248946124e-03);
+    p = fma(p, z, -1.66666666666666324348e-01);
+    return fma(x * z, p, x);
+}
+
+static inline double kcos(double x)
+{
+    double z = x * x;
+    double p = -1.13596475577881948265e-11;
+    p = fma(p, z, 2.08757232129817482790e-09);
+    p = fma(p, z, -2.75573143513906633035e-07);
+    p = fma(p, z, 2.48015872894767294178e-05);
+    p = fma(p, z, -1.38888888888741095749e-03);
+    p = fma(p, z, 4.16666666666666019037e-02);
+    /* 1 - (z/2 - z*z*p) */
+    return 1.0 - fma(-z * z, p, 0.5 * z);
+}
+
+static inline void sincos_reduce(double x, double *r, int *quadrant)
+{
+    double kf = rint(x * 6.36619772367581382433e-01); /* 2/pi */
+    double t = fma(-kf, PIO2_1, x);
+    t = fma(-kf, PIO2_2, t);
+    t = fma(-kf, PIO2_3, t);
+    *r = t;
+    *quadrant = (int)((long long)kf & 3);
+}
+
+double orc_sin(double x)
+{
+    double r; int q;
+    sincos_reduce(x, &r, &q);
+    switch (q) {
+    case 0: return ksin(r);
+    case 1: return kcos(r);
+    case 2: return -ksin(r);
+    default: return -kcos(r);
+    }
+}
+
+double orc_cos(double x)
+{
+    double r; int q;
+    sincos_reduce(x, &r, &q);
+    switch (q) {
+    case 0: return kcos(r);
+    case 1: return -ksin(r);
+    case 2: return -kcos(r);
+    default: return ksin(r);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * counter-based RNG (production mode).  The reference draws from torch / numpy / python
+ * `random` / gym np_random global streams; those cannot be
+ * reproduced on a GPU, so every stochastic input is either an explicit tape (parity mode)
+ * or value = hash(key, stream, n) with this 64-bit mixer (two rounds of the splitmix64 finaliser).
+ * ---------------------------------------------------------------------------------------- */
+uint64_t orc_mix64(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+
+uint64_t orc_chain_key(uint64_t seed, uint64_t generation, uint64_t worker, uint64_t kind)
+{
+    uint64_t k = orc_mix64(seed + 0x9e3779b97f4a7c15ULL);
+    k = orc_mix64(k ^ (generation + 0x9e3779b97f4a7c15ULL * 2));
+    k = orc_mix64(k ^ (worker * 4 + kind + 0x9e3779b97f4a7c15ULL * 3));
+    return k;
+}
+
+uint64_t orc_rng_u64(uint64_t key, uint32_t stream, uint64_t n)
+{
+    uint64_t x = key + 0x9e3779b97f4a7c15ULL * (((uint64_t)stream << 56) ^ n);
+    return orc_mix64(orc_mix64(x) ^ key);
+}
+
+enum { STREAM_EPS = 0, STREAM_ACTION = 1, STREAM_REPLAY = 2, STREAM_TRAIN_RESET = 3, STREAM_TEST_RESET = 4 };
+
+static inline double u64_to_unit(uint64_t u) { return (double)(u >> 11) * (1.0 / 9007199254740992.0); }
+static inline uint32_t u64_to_below(uint64_t u, uint32_t n) { return (uint32_t)(((u >> 32) * (uint64_t)n) >> 32); }
+
+/* ------------------------------------------------------------------------------------------
+ * MLP (models/model_utils.py:4-39)
+ * ---------------------------------------------------------------------------------------- */
+int64_t orc_mlp_num_params(const orc_mlp_desc *d)
+{
+    int64_t H = d->hidden;
+    return (int64_t)d->in_dim * H + H + (int64_t)(d->layers - 1) * (H * H + H) + H * d->out_dim + d->out_dim;
+}
+
+static inline float act_fwd(int act, float prelu, float z)
+{
+    switch (act) {
+    case ORC_ACT_RELU: return z > 0.0f ? z : 0.0f;
+    case ORC_ACT_LEAKYRELU: return z > 0.0f ? z : z * 0.01f;      /* nn.LeakyReLU() default slope */
+    case ORC_ACT_TANH: return orc_tanhf(z);
+    case ORC_ACT_PRELU: return z > 0.0f ? z : prelu * z;
+    default: return z;
+    }
+}
+
+/* derivative factor applied to the upstream gradient; z = pre-activation, a = activation */
+static inline float act_bwd(int act, float prelu, float z, float a, float g)
+{
+    switch (act) {
+    case ORC_ACT_RELU: return a > 0.0f ? g : 0.0f;                /* threshold_backward */
+    case ORC_ACT_LEAKYRELU: return z > 0.0f ? g : g * 0.01f;
+    case ORC_ACT_TANH: return g * fmaf(-a, a, 1.0f);              /* torch CPU tanh_backward (verified bitwise) */
+    case ORC_ACT_PRELU: return z > 0.0f ? g : prelu * g;
+    default: return g;
+    }
+}
+
+/* y[o] = (sum_k fmaf chain from 0) + b[o]  -- torch-CPU batched linear order */
+static inline void linear_fwd(const float *W, const float *b, int n_out, int n_in, const float *x, float *y)
+{
+    for (int o = 0; o < n_out; ++o) {
+        float acc = 0.0f;
+        const float *w = W + (int64_t)o * n_in;
+        for (int k = 0; k < n_in; ++k) acc = fmaf(x[k], w[k], acc);
+        y[o] = acc + b[o];
+    }
+}
+
+#define ORC_MAX_WIDTH 1024
+#define ORC_MAX_LAYERS 4
+
+/* single-sample forward keeping pre-activations z[l] and activations a[l] (l = 0..L-1) */
+static void mlp_forward_one(const orc_mlp_desc *d, const float *p, const float *x, float *y,
+                            float z[][ORC_MAX_WIDTH], float a[][ORC_MAX_WIDTH])
+{
+    const int H = d->hidden, L = d->layers;
+    const float *in = x;
+    int n_in = d->in_dim;
+    for (int l = 0; l < L; ++l) {
+        const float *W = p; p += (int64_t)H * n_in;
+        const float *b = p; p += H;
+        linear_fwd(W, b, H, n_in, in, z[l]);
+        for (int j = 0; j < H; ++j) a[l][j] = act_fwd(d->act, d->prelu, z[l][j]);
+        in = a[l];
+        n_in = H;
+    }
+    linear_fwd(p, p + (int64_t)d->out_dim * H, d->out_dim, H, in, y);
+}
+
+int orc_mlp_forward(const orc_mlp_desc *d, const float *params, const float *x, int64_t B, float *y, float *hidden_out)
+{
+    if (d->hidden > ORC_MAX_WIDTH || d->in_dim > ORC_MAX_WIDTH || d->layers > ORC_MAX_LAYERS || d->layers < 1) return -1;
+    float (*z)[ORC_MAX_WIDTH] = malloc(sizeof(float) * ORC_MAX_LAYERS * ORC_MAX_WIDTH);
+    float (*a)[ORC_MAX_WIDTH] = malloc(sizeof(float) * ORC_MAX_LAYERS * ORC_MAX_WIDTH);
+    for (int64_t i = 0; i < B; ++i) {
+        mlp_forward_one(d, params, x + i * d->in_dim, y + i * d->out_dim, z, a);
+        if (hidden_out) memcpy(hidden_out + i * d->hidden, a[d->layers - 1], sizeof(float) * d->hidden);
+    }
+    free(z); free(a);
+    return 0;
+}
+
+/* envs/virtual_env.py:43-54 (input = cat(action_onehot, state), three nets on the same input,
+ * reward/done see the PRE-transition state) + env_wrapper.py:20-21 (one-hot of the action index)
+ * + GTN_worker.py:165-175 (theta +/- eps). */
+int orc_se_step_population(const orc_mlp_desc *sn, const orc_mlp_desc *rn, const orc_mlp_desc *dn,
+                           const float *theta, const float *eps, const int32_t *worker, const float *sign,
+                           int64_t chains, const float *state, const int32_t *action,
+                           float *next_state, float *reward, float *done)
+{
+    const int64_t ps = orc_mlp_num_params(sn), pr = orc_mlp_num_params(rn), pd = orc_mlp_num_params(dn);
+    const int64_t P = ps + pr + pd;
+    const int S = sn->out_dim, A = sn->in_dim - S;
+    if (sn->in_dim > ORC_MAX_WIDTH) return -1;
+    float *w = malloc(sizeof(float) * P);
+    float x[ORC_MAX_WIDTH];
+    for (int64_t c = 0; c < chains; ++c) {
+        const float *e = eps ? eps + (int64_t)worker[c] * P : NULL;
+        for (int64_t i = 0; i < P; ++i) w[i] = e ? fmaf(sign[c], e[i], theta[i]) : theta[i];
+        for (int i = 0; i < A; ++i) x[i] = (i == action[c]) ? 1.0f : 0.0f;
+        for (int i = 0; i < S; ++i) x[A + i] = state[c * S + i];
+        if (orc_mlp_forward(sn, w, x, 1, next_state + c * S, NULL)) { free(w); return -1; }
+        orc_mlp_forward(rn, w + ps, x, 1, reward + c, NULL);
+        orc_mlp_forward(dn, w + ps + pr, x, 1, done + c, NULL);
+    }
+    free(w);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * real envs -- gym==0.17.3 classic_control (third party, UNPINNED)
+ * ---------------------------------------------------------------------------------------- */
+void orc_cartpole_step(double st[4], int action, double *reward, int *done)
+{
+    const double gravity = 9.8, masscart = 1.0, masspole = 0.1, length = 0.5, force_mag = 10.0, tau = 0.02;
+    const double total_mass = masspole + masscart;
+    const double polemass_length = masspole * length;
+    const double theta_thr = 12 * 2 * 3.141592653589793 / 360;
+    const double x_thr = 2.4;
+    double x = st[0], x_dot = st[1], theta = st[2], theta_dot = st[3];
+    double force = action == 1 ? force_mag : -force_mag;
+    double costheta = orc_cos(theta), sintheta = orc_sin(theta);
+    double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
+    double thetaacc = (gravity * sintheta - costheta * temp) /
+                      (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
+    double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+    x = x + tau * x_dot;
+    x_dot = x_dot + tau * xacc;
+    theta = theta + tau * theta_dot;
+    theta_dot = theta_dot + tau * thetaacc;
+    st[0] = x; st[1] = x_dot; st[2] = theta; st[3] = theta_dot;
+    *done = (x < -x_thr || x > x_thr || theta < -theta_thr || theta > theta_thr) ? 1 : 0;
+    *reward = 1.0; /* first step past the threshold still pays 1.0; the loop stops on done */
+}
+
+static void acrobot_dsdt(const double s[5], double out[5])
+{
+    const double m1 = 1., m2 = 1., l1 = 1., lc1 = .5, lc2 = .5, I1 = 1., I2 = 1., g = 9.8, pi = 3.141592653589793;
+    double a = s[4], theta1 = s[0], theta2 = s[1], dtheta1 = s[2], dtheta2 = s[3];
+    double c2 = orc_cos(theta2), s2 = orc_sin(theta2);
+    double d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * c2) + I1 + I2;
+    double d2 = m2 * (lc2 * lc2 + l1 * lc2 * c2) + I2;
+    double phi2 = m2 * lc2 * g * orc_cos(theta1 + theta2 - pi / 2.);
+    double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * s2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2 +
+                  (m1 * lc1 + m2 * l1) * g * orc_cos(theta1 - pi / 2) + phi2;
+    double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
+                      (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
+    double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
+    out[0] = dtheta1; out[1] = dtheta2; out[2] = ddtheta1; out[3] = ddtheta2; out[4] = 0.;
+}
+
+void orc_acrobot_step(double st[4], int action, double *reward, int *done)
+{
+    const double pi = 3.141592653589793, dt = .2, dt2 = .2 / 2.0;
+    const double max_vel1 = 4 * pi, max_vel2 = 9 * pi;
+    double y0[5] = { st[0], st[1], st[2], st[3], (double)(action - 1) };
+    double k1[5], k2[5], k3[5], k4[5], tmp[5], ns[5];
+    acrobot_dsdt(y0, k1);
+    for (int i = 0; i < 5; ++i) tmp[i] = y0[i] + dt2 * k1[i];
+    acrobot_dsdt(tmp, k2);
+    for (int i = 0; i < 5; ++i) tmp[i] = y0[i] + dt2 * k2[i];
+    acrobot_dsdt(tmp, k3);
+    for (int i = 0; i < 5; ++i) tmp[i] = y0[i] + dt * k3[i];
+    acrobot_dsdt(tmp, k4);
+    for (int i = 0; i < 5; ++i) ns[i] = y0[i] + dt / 6.0 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+    for (int i = 0; i < 2; ++i) {
+        double x = ns[i], diff = pi - (-pi);
+        while (x > pi) x = x - diff;
+        while (x < -pi) x = x + diff;
+        ns[i] = x;
+    }
+    ns[2] = fmin(fmax(ns[2], -max_vel1), max_vel1);
+    ns[3] = fmin(fmax(ns[3], -max_vel2), max_vel2);
+    for (int i = 0; i < 4; ++i) st[i] = ns[i];
+    int terminal = (-orc_cos(st[0]) - orc_cos(st[1] + st[0]) > 1.) ? 1 : 0;
+    *done = terminal;
+    *reward = terminal ? 0. : -1.;
+}
+
+void orc_acrobot_obs(const double st[4], double obs[6])
+{
+    obs[0] = orc_cos(st[0]); obs[1] = orc_sin(st[0]); obs[2] = orc_cos(st[1]); obs[3] = orc_sin(st[1]);
+    obs[4] = st[2]; obs[5] = st[3];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * DDQN (agents/DDQN.py:60-110)
+ * ---------------------------------------------------------------------------------------- */
+static inline int argmax_first(const float *v, int n)
+{
+    int best = 0;
+    for (int i = 1; i < n; ++i) if (v[i] > v[best]) best = i;
+    return best;
+}
+
+/* DDQN.py:79-85: q(s)[a]; a* = argmax online(s'); y = r + gamma*target(s')[a*]*(1-done) */
+int orc_qnet_td_forward(const orc_mlp_desc *q, const float *online, const float *target,
+                        const float *rows, int64_t row_stride, int64_t B, int32_t S, double gamma,
+                        float *q_sa, float *y, int32_t *argmax_next)
+{
+    if (q->hidden > ORC_MAX_WIDTH || q->layers > ORC_MAX_LAYERS) return -1;
+    float (*z)[ORC_MAX_WIDTH] = malloc(sizeof(float) * ORC_MAX_LAYERS * ORC_MAX_WIDTH);
+    float (*a)[ORC_MAX_WIDTH] = malloc(sizeof(float) * ORC_MAX_LAYERS * ORC_MAX_WIDTH);
+    float qs[ORC_MAX_WIDTH], qn[ORC_MAX_WIDTH], qt[ORC_MAX_WIDTH];
+    const float g32 = (float)gamma;
+    for (int64_t b = 0; b < B; ++b) {
+        const float *row = rows + b * row_stride;
+        const float *s = row, *s2 = row + S + 1;
+        int act = (int)row[S];
+        float r = row[2 * S + 1], d = row[2 * S + 2];
+        mlp_forward_one(q, online, s, qs, z, a);
+        mlp_forward_one(q, online, s2, qn, z, a);
+        mlp_forward_one(q, target, s2, qt, z, a);
+        int am = argmax_first(qn, q->out_dim);
+        float t1 = g32 * qt[am];
+        float t2 = 1.0f - d;
+        float t3 = t1 * t2;
+        q_sa[b] = qs[act];
+        y[b] = r + t3;
+        if (argmax_next) argmax_next[b] = am;
+    }
+    free(z); free(a);
+    return 0;
+}
+
+/* One DDQN.learn step (DDQN.py:60-94) on an explicit minibatch `rows` [B, row_stride]:
+ * MSE TD loss, backward, torch.optim.Adam single-tensor step, Polyak target update. */
+float orc_ddqn_learn(const orc_ddqn_cfg *cfg, float *online, float *target, float *adam_m, float *adam_v,
+                     int64_t step, double *b1pow, double *b2pow, const float *rows, int64_t row_stride)
+{
+    orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu };
+    const int S = cfg->state_dim, H = cfg->q_hidden, L = cfg->q_layers, A = cfg->num_actions, B = cfg->batch_size;
+    const int64_t P = orc_mlp_num_params(&qd);
+    const int chunk = cfg->grad_chunk > 0 ? cfg->grad_chunk : B;
+    float (*z)[ORC_MAX_WIDTH] = malloc(sizeof(float) * ORC_MAX_LAYERS * ORC_MAX_WIDTH);
+    float (*a)[ORC_MAX_WIDTH] = malloc(sizeof(float) * ORC_MAX_LAYERS * ORC_MAX_WIDTH);
+    float (*z2)[ORC_MAX_WIDTH] = malloc(sizeof(float) * ORC_MAX_LAYERS * ORC_MAX_WIDTH);
+    float (*a2)[ORC_MAX_WIDTH] = malloc(sizeof(float) * ORC_MAX_LAYERS * ORC_MAX_WIDTH);
+    float *grad = calloc(P, sizeof(float));      /* running sum over finished chunks */
+    float *gch = malloc(sizeof(float) * P);      /* current chunk */
+    float qs[ORC_MAX_WIDTH], qn[ORC_MAX_WIDTH], qt[ORC_MAX_WIDTH], da[ORC_MAX_WIDTH], dz[ORC_MAX_WIDTH], dprev[ORC_MAX_WIDTH];
+    const float g32 = (float)cfg->gamma;
+    const float norm = (float)(2.0 / (double)B);   /* mse_loss backward: 2/numel */
+    float loss_acc = 0.0f;
+
+    /* layer offsets */
+    int64_t offW[ORC_MAX_LAYERS + 1], offb[ORC_MAX_LAYERS + 1];
+    {
+        int64_t o = 0; int n_in = S;
+        for (int l = 0; l < L; ++l) { offW[l] = o; o += (int64_t)H * n_in; offb[l] = o; o += H; n_in = H; }
+        offW[L] = o; o += (int64_t)A * H; offb[L] = o;
+    }
+
+    int first_chunk = 1;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        int b1 = b0 + chunk < B ? b0 + chunk : B;
+        memset(gch, 0, sizeof(float) * P);
+        for (int b = b0; b < b1; ++b) {
+            const float *row = rows + (int64_t)b * row_stride;
+            const float *s = row, *s2 = row + S + 1;
+            int act = (int)row[S];
+            float r = row[2 * S + 1], d = row[2 * S + 2];
+            mlp_forward_one(&qd, online, s2, qn, z2, a2);
+            mlp_forward_one(&qd, target, s2, qt, z2, a2);
+            mlp_forward_one(&qd, online, s, qs, z, a);
+            int am = argmax_first(qn, A);
+            float t1 = g32 * qt[am];
+            float t2 = 1.0f - d;
+            float yv = r + t1 * t2;
+            float diff = qs[act] - yv;
+            loss_acc = fmaf(diff, diff, loss_acc);
+            float dq = norm * diff;
+            /* output layer: only row `act` of dQ is non-zero */
+            {
+                float *gW = gch + offW[L] + (int64_t)act * H;
+                const float *W = online + offW[L] + (int64_t)act * H;
+                for (int j = 0; j < H; ++j) {
+                    gW[j] = fmaf(dq, a[L - 1][j], gW[j]);
+                    da[j] = dq * W[j];
+                }
+                gch[offb[L] + act] = gch[offb[L] + act] + dq;
+            }
+            for (int l = L - 1; l >= 0; --l) {
+                int n_in = l == 0 ? S : H;
+                const float *inp = l == 0 ? s : a[l - 1];
+                for (int j = 0; j < H; ++j) dz[j] = act_bwd(cfg->q_act, cfg->q_prelu, z[l][j], a[l][j], da[j]);
+                float *gW = gch + offW[l];
+                float *gb = gch + offb[l];
+                for (int j = 0; j < H; ++j) {
+                    for (int i = 0; i < n_in; ++i) gW[(int64_t)j * n_in + i] = fmaf(dz[j], inp[i], gW[(int64_t)j * n_in + i]);
+                    gb[j] = gb[j] + dz[j];
+                }
+                if (l > 0) {
+                    const float *W = online + offW[l];
+                    for (int i = 0; i < n_in; ++i) {
+                        float acc = 0.0f;
+                        for (int j = 0; j < H; ++j) acc = fmaf(dz[j], W[(int64_t)j * n_in + i], acc);
+                        dprev[i] = acc;
+                    }
+                    memcpy(da, dprev, sizeof(float) * n_in);
+                }
+            }
+        }
+        if (first_chunk) { memcpy(grad, gch, sizeof(float) * P); first_chunk = 0; }
+        else for (int64_t i = 0; i < P; ++i) grad[i] = grad[i] + gch[i];
+    }
+
+    /* torch.optim.Adam (_single_tensor_adam), weight_decay 0, amsgrad False */
+    *b1pow *= cfg->adam_beta1;
+    *b2pow *= cfg->adam_beta2;
+    (void)step;
+    const double bc1 = 1.0 - *b1pow, bc2 = 1.0 - *b2pow;
+    const float neg_step = (float)(-(cfg->lr / bc1));
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - cfg->adam_beta1), w2 = (float)(1.0 - cfg->adam_beta2);
+    const float beta2 = (float)cfg->adam_beta2, eps = (float)cfg->adam_eps;
+    const float tau = (float)cfg->tau, omt = (float)(1.0 - cfg->tau);
+    for (int64_t i = 0; i < P; ++i) {
+        float g = grad[i];
+        float m = fmaf(w1, g - adam_m[i], adam_m[i]);            /* exp_avg.lerp_(grad, 1-beta1) */
+        float v = adam_v[i] * beta2;                              /* exp_avg_sq.mul_(beta2) */
+        v = fmaf(w2 * g, g, v);                                   /* .addcmul_(grad, grad, value=1-beta2) */
+        float denom = sqrtf(v) / bc2_sqrt + eps;
+        float p = online[i] + (neg_step * m) / denom;             /* param.addcdiv_(exp_avg, denom, value=-step_size) */
+        adam_m[i] = m; adam_v[i] = v; online[i] = p;
+        target[i] = tau * p + omt * target[i];                    /* DDQN.py:92-93 */
+    }
+    free(z); free(a); free(z2); free(a2); free(grad); free(gch);
+    return loss_acc / (float)B;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * One chain: GTN_Worker.calc_score (GTN_worker.py:187-221) =
+ *   select_agent -> DDQN (fresh agent, agent_init weights) ; BaseAgent.train(env=SE, test_env=real)
+ *   (base_agent.py:64-153) ; BaseAgent.test(real) (base_agent.py:155-227) ; statistics.mean.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const orc_ddqn_cfg *cfg;
+    uint64_t key;
+    const orc_tapes *tapes;
+    int64_t n_eps, n_act, n_test_ep, n_train_ep;
+    int err;
+} rng_state;
+
+static double draw_eps_uniform(rng_state *r)
+{
+    int64_t n = r->n_eps++;
+    if (r->cfg->rng_mode == ORC_RNG_TAPE) {
+        if (n >= r->tapes->n_eps_uniform) { r->err = -2; return 1.0; }
+        return r->tapes->eps_uniform[n];
+    }
+    return u64_to_unit(orc_rng_u64(r->key, STREAM_EPS, (uint64_t)n));
+}
+
+static int draw_rand_action(rng_state *r)
+{
+    int64_t n = r->n_act++;
+    if (r->cfg->rng_mode == ORC_RNG_TAPE) {
+        if (n >= r->tapes->n_rand_action) { r->err = -3; return 0; }
+        return r->tapes->rand_action[n];
+    }
+    return (int)u64_to_below(orc_rng_u64(r->key, STREAM_ACTION, (uint64_t)n), (uint32_t)r->cfg->num_actions);
+}
+
+static int draw_replay_idx(rng_state *r, int64_t learn_it, int b, int64_t size)
+{
+    int64_t n = learn_it * r->cfg->batch_size + b;
+    if (r->cfg->rng_mode == ORC_RNG_TAPE) {
+        if (n >= r->tapes->n_replay_idx) { r->err = -4; return 0; }
+        return r->tapes->replay_idx[n];
+    }
+    return (int)u64_to_below(orc_rng_u64(r->key, STREAM_REPLAY, (uint64_t)n), (uint32_t)size);
+}
+
+/* gym reset: np_random.uniform(low, high, size=(4,)) = low + (high-low)*u */
+static void draw_reset(rng_state *r, int train, int64_t ep, double st[4])
+{
+    const double lim = r->cfg->env_id == ORC_ENV_CARTPOLE ? 0.05 : 0.1;
+    if (r->cfg->rng_mode == ORC_RNG_TAPE) {
+        const double *tp = train ? r->tapes->train_reset : r->tapes->test_reset;
+        int64_t nrows = train ? r->tapes->n_train_reset : r->tapes->n_test_reset;
+        if (ep >= nrows) { r->err = -5; memset(st, 0, sizeof(double) * 4); return; }
+        memcpy(st, tp + ep * 4, sizeof(double) * 4);
+        return;
+    }
+    for (int i = 0; i < 4; ++i) {
+        double u = u64_to_unit(orc_rng_u64(r->key, train ? STREAM_TRAIN_RESET : STREAM_TEST_RESET, (uint64_t)(ep * 4 + i)));
+        st[i] = -lim + (2 * lim) * u;
+    }
+}
+
+static void real_env_obs(int env_id, const double st[4], float *obs)
+{
+    if (env_id == ORC_ENV_CARTPOLE) {
+        for (int i = 0; i < 4; ++i) obs[i] = (float)st[i];
+    } else {
+        double o[6];
+        orc_acrobot_obs(st, o);
+        for (int i = 0; i < 6; ++i) obs[i] = (float)o[i];
+    }
+}
+
+/* BaseAgent.test (base_agent.py:155-227) with DDQN.select_test_action (DDQN.py:106-110): greedy. */
+static void run_test_phase(const orc_ddqn_cfg *cfg, const orc_mlp_desc *qd, const float *online, rng_state *rng,
+                           double *returns, int64_t *test_steps, float (*z)[ORC_MAX_WIDTH], float (*a)[ORC_MAX_WIDTH])
+{
+    float obs[8], q[ORC_MAX_WIDTH];
+    for (int te = 0; te < cfg->test_episodes; ++te) {
+        double st[4];
+        draw_reset(rng, 0, rng->n_test_ep++, st);
+        float ep_reward = 0.0f;   /* fp32 tensor accumulation, base_agent.py:212 */
+        for (int t = 0; t < cfg->max_steps; ++t) {
+            real_env_obs(cfg->env_id, st, obs);
+            mlp_forward_one(qd, online, obs, q, z, a);
+            int act = argmax_first(q, cfg->num_actions);
+            double rew; int done;
+            if (cfg->env_id == ORC_ENV_CARTPOLE) orc_cartpole_step(st, act, &rew, &done);
+            else orc_acrobot_step(st, act, &rew, &done);
+            /* TimeLimit: elapsed >= max_steps -> done (the loop bound does the same) */
+            ep_reward = ep_reward + (float)rew;
+            ++*test_steps;
+            if (done) break;
+        }
+        returns[te] = (double)ep_reward;
+    }
+}
+
+static double mean_seq(const double *v, int n)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += v[i];
+    return s / (double)n;
+}
+
+int orc_ddqn_se_chain(const orc_ddqn_cfg *cfg, const float *se_params, const float *agent_init, uint64_t rng_key,
+                      const orc_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
+                      double *final_test_returns, orc_trace *trace, orc_chain_result *res)
+{
+    const int S = cfg->state_dim, A = cfg->num_actions, B = cfg->batch_size;
+    orc_mlp_desc qd = { S, cfg->q_hidden, cfg->q_layers, A, cfg->q_act, cfg->q_prelu };
+    orc_mlp_desc sn = { S + A, cfg->se_hidden, cfg->se_layers, S, cfg->se_act, cfg->se_prelu };
+    orc_mlp_desc rn = sn, dn = sn;
+    rn.out_dim = 1; dn.out_dim = 1;
+    if (cfg->env_id == ORC_ENV_CARTPOLE && S != 4) return -1;
+    if (cfg->env_id == ORC_ENV_ACROBOT && S != 6) return -1;
+    if (cfg->q_hidden > ORC_MAX_WIDTH || cfg->se_hidden > ORC_MAX_WIDTH || S + A > 64) return -1;
+    if (cfg->rng_mode == ORC_RNG_TAPE && !tapes) return -1;
+    const int64_t P = orc_mlp_num_params(&qd);
+    const int64_t ps = orc_mlp_num_params(&sn), pr = orc_mlp_num_params(&rn);
+    const int64_t row_stride = 2 * S + 3;
+    int64_t cap = (int64_t)cfg->train_episodes * cfg->max_steps;
+    if (cap > cfg->rb_size) cap = cfg->rb_size;
+    if (cap < 1) cap = 1;
+
+    float *online = malloc(sizeof(float) * P), *target = malloc(sizeof(float) * P);
+    float *am = calloc(P, sizeof(float)), *av = calloc(P, sizeof(float));
+    float *rb = malloc(sizeof(float) * cap * row_stride);
+    float *batch = malloc(sizeof(float) * (int64_t)B * row_stride);
+    float (*z)[ORC_MAX_WIDTH] = malloc(sizeof(float) * ORC_MAX_LAYERS * ORC_MAX_WIDTH);
+    float (*a)[ORC_MAX_WIDTH] = malloc(sizeof(float) * ORC_MAX_LAYERS * ORC_MAX_WIDTH);
+    double *test_returns = malloc(sizeof(double) * (cfg->test_episodes > 0 ? cfg->test_episodes : 1));
+    double *meter = malloc(sizeof(double) * (cfg->train_episodes > 0 ? cfg->train_episodes : 1));
+    memcpy(online, agent_init, sizeof(float) * P);
+    memcpy(target, agent_init, sizeof(float) * P);  /* model_target.load_state_dict(model.state_dict()) DDQN.py:35 */
+
+    rng_state rng = { cfg, rng_key, tapes, 0, 0, 0, 0, 0 };
+    int64_t rb_ptr = 0, rb_size = 0, learn_it = 0, train_steps = 0, test_steps = 0;
+    double b1pow = 1.0, b2pow = 1.0;
+    double eps = cfg->eps_init;
+    int n_meter = 0, episodes_run = 0;
+    if (trace) trace->n = 0;
+
+    for (int episode = 0; episode < cfg->train_episodes; ++episode) {
+        /* DDQN.update_parameters_per_episode (DDQN.py:112-117) */
+        if (episode == 0) eps = cfg->eps_init;
+        else { eps *= cfg->eps_decay; if (eps < cfg->eps_min) eps = cfg->eps_min; }
+
+        double st0[4];
+        float state[64], next_state[64], x[64], q[ORC_MAX_WIDTH];
+        draw_reset(&rng, 1, rng.n_train_ep++, st0);
+        real_env_obs(cfg->env_id, st0, state);   /* VirtualEnv.reset -> fp32 real-env reset state (virtual_env.py:35-41) */
+        int ep_len = 0;
+        for (int t = 0; t < cfg->max_steps; ++t) {
+            /* select_train_action (DDQN.py:97-104) */
+            int act, explored = 0;
+            double u = draw_eps_uniform(&rng);
+            if (u < eps) { act = draw_rand_action(&rng); explored = 1; }
+            else { mlp_forward_one(&qd, online, state, q, z, a); act = argmax_first(q, A); }
+            /* EnvWrapper.step -> VirtualEnv.step */
+            for (int i = 0; i < A; ++i) x[i] = (i == act) ? 1.0f : 0.0f;
+            for (int i = 0; i < S; ++i) x[A + i] = state[i];
+            float reward, done;
+            mlp_forward_one(&sn, se_params, x, next_state, z, a);
+            mlp_forward_one(&rn, se_params + ps, x, &reward, z, a);
+            mlp_forward_one(&dn, se_params + ps + pr, x, &done, z, a);
+            /* ReplayBuffer.add (utils.py:24-32) */
+            float *row = rb + rb_ptr * row_stride;
+            memcpy(row, state, sizeof(float) * S);
+            row[S] = (float)act;
+            memcpy(row + S + 1, next_state, sizeof(float) * S);
+            row[2 * S + 1] = reward; row[2 * S + 2] = done;
+            rb_ptr = (rb_ptr + 1) % cap;
+            if (rb_size < cap) ++rb_size;
+            float loss = NAN;
+            if (episode >= cfg->init_episodes) {
+                for (int b = 0; b < B; ++b) {
+                    int idx = draw_replay_idx(&rng, learn_it, b, rb_size);
+                    if (idx < 0 || idx >= rb_size) { rng.err = -6; idx = 0; }
+                    memcpy(batch + (int64_t)b * row_stride, rb + (int64_t)idx * row_stride, sizeof(float) * row_stride);
+                }
+                ++learn_it;
+                loss = orc_ddqn_learn(cfg, online, target, am, av, learn_it, &b1pow, &b2pow, batch, row_stride);
+            }
+            if (trace && trace->n < trace->cap) {
+                int64_t k = trace->n++;
+                trace->episode[k] = episode; trace->action[k] = act; trace->explored[k] = explored;
+                memcpy(trace->state + k * S, state, sizeof(float) * S);
+                memcpy(trace->next_state + k * S, next_state, sizeof(float) * S);
+                trace->reward[k] = reward; trace->done[k] = done; trace->loss[k] = loss;
+            }
+            memcpy(state, next_state, sizeof(float) * S);
+            ++ep_len; ++train_steps;
+            if (done > 0.5f) break;
+        }
+        ++episodes_run;
+        if (episode_len) episode_len[episode] = ep_len;
+        /* per-episode test on the real env (base_agent.py:134-136) */
+        run_test_phase(cfg, &qd, online, &rng, test_returns, &test_steps, z, a);
+        double tm = mean_seq(test_returns, cfg->test_episodes);
+        meter[n_meter++] = tm;
+        if (episode_test_mean) episode_test_mean[episode] = tm;
+        /* early out on the real env (base_agent.py:49-62,141-148; AverageMeter._mean utils.py:103-105) */
+        if (episode >= cfg->init_episodes) {
+            int lo = n_meter - cfg->early_out_num; if (lo < 0) lo = 0;
+            double sm = 0.0;
+            for (int i = lo; i < n_meter; ++i) sm += meter[i];
+            double avg = sm / ((double)(n_meter - lo) + 1e-9);
+            if (avg >= cfg->solved_reward) break;
+        }
+    }
+    for (int e = episodes_run; e < cfg->train_episodes; ++e) {
+        if (episode_test_mean) episode_test_mean[e] = NAN;
+        if (episode_len) episode_len[e] = 0;
+    }
+    /* final test (GTN_worker.py:199) */
+    run_test_phase(cfg, &qd, online, &rng, test_returns, &test_steps, z, a);
+    if (final_test_returns) memcpy(final_test_returns, test_returns, sizeof(double) * cfg->test_episodes);
+    if (res) {
+        res->score = mean_seq(test_returns, cfg->test_episodes);
+        res->episodes_run = episodes_run; res->train_steps = train_steps;
+        res->learn_steps = learn_it; res->test_steps = test_steps;
+    }
+    free(online); free(target); free(am); free(av); free(rb); free(batch); free(z); free(a); free(test_returns); free(meter);
+    return rng.err;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * population driver: worker p runs chains {3p: theta, 3p+1: theta+eps_p, 3p+2: theta-eps_p}
+ * (GTN_worker.py:84-102), threads over chains.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const orc_ddqn_cfg *cfg; const float *theta, *eps, *agent_init;
+    int64_t pop, p_theta, p_agent, worker_offset; uint64_t seed, generation;
+    double *scores; orc_chain_result *results;
+    int64_t next; pthread_mutex_t mu; int err;
+} pop_job;
+
+static void *pop_thread(void *arg)
+{
+    pop_job *j = (pop_job *)arg;
+    float *w = malloc(sizeof(float) * j->p_theta);
+    for (;;) {
+        pthread_mutex_lock(&j->mu);
+        int64_t c = j->next++;
+        pthread_mutex_unlock(&j->mu);
+        if (c >= 3 * j->pop) break;
+        int64_t p = c / 3; int kind = (int)(c % 3);
+        float sign = kind == 0 ? 0.0f : (kind == 1 ? 1.0f : -1.0f);
+        const float *e = j->eps + p * j->p_theta;
+        for (int64_t i = 0; i < j->p_theta; ++i) w[i] = fmaf(sign, e[i], j->theta[i]);
+        orc_chain_result r;
+        int rc = orc_ddqn_se_chain(j->cfg, w, j->agent_init + c * j->p_agent,
+                                   orc_chain_key(j->seed, j->generation, (uint64_t)(j->worker_offset + p), (uint64_t)kind),
+                                   NULL, NULL, NULL, NULL, NULL, &r);
+        if (rc) j->err = rc;
+        j->scores[c] = r.score;
+        if (j->results) j->results[c] = r;
+    }
+    free(w);
+    return NULL;
+}
+
+int orc_ddqn_se_population(const orc_ddqn_cfg *cfg, const float *theta, const float *eps, int64_t pop, int64_t p_theta,
+                           const float *agent_init, uint64_t seed, uint64_t generation, int64_t worker_offset,
+                           int threads, double *chain_scores, orc_chain_result *results)
+{
+    orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu };
+    pop_job j = { cfg, theta, eps, agent_init, pop, p_theta, orc_mlp_num_params(&qd), worker_offset, seed, generation,
+                  chain_scores, results, 0, PTHREAD_MUTEX_INITIALIZER, 0 };
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t th[256];
+    for (int t = 0; t < threads; ++t) pthread_create(&th[t], NULL, pop_thread, &j);
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    return j.err;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * NES worker / master math
+ * ---------------------------------------------------------------------------------------- */
+/* GTN_worker.py:234-254 (num_grad_evals == 1, so 'mean' and 'minmax' coincide) */
+void orc_worker_best(const double *score_add, const double *score_sub, int64_t pop, int mirrored, double *score_best, float *sign)
+{
+    for (int64_t p = 0; p < pop; ++p) {
+        if (mirrored) {
+            score_best[p] = score_add[p] > score_sub[p] ? score_add[p] : score_sub[p];
+            sign[p] = score_sub[p] > score_add[p] ? -1.0f : 1.0f;   /* invert_eps() iff sub > add; ties keep +eps */
+        } else {
+            score_best[p] = score_add[p];
+            sign[p] = 1.0f;
+        }
+    }
+}
+
+/* rank helpers with a documented stable order (np.argsort's tie order is implementation-defined,
+ * SURVEY.md Appendix A #14): among equal scores the lower index comes first. */
+static void argsort_stable(const double *v, int64_t n, int descending, int64_t *idx)
+{
+    for (int64_t i = 0; i < n; ++i) idx[i] = i;
+    for (int64_t i = 1; i < n; ++i) {           /* insertion sort: stable */
+        int64_t k = idx[i], j = i - 1;
+        while (j >= 0 && (descending ? v[idx[j]] < v[k] : v[idx[j]] > v[k])) { idx[j + 1] = idx[j]; --j; }
+        idx[j + 1] = k;
+    }
+}
+
+int orc_score_transform(int type, const double *scores_in, const double *scores_orig, int64_t n, double *out)
+{
+    double *scores = malloc(sizeof(double) * n);
+    int64_t *s = malloc(sizeof(int64_t) * n);
+    memcpy(scores, scores_in, sizeof(double) * n);
+    int rc = 0;
+    if (type == 0) {
+        double mn = scores[0], mx = scores[0];
+        for (int64_t i = 1; i < n; ++i) { if (scores[i] < mn) mn = scores[i]; if (scores[i] > mx) mx = scores[i]; }
+        for (int64_t i = 0; i < n; ++i) scores[i] = (scores[i] - mn) / (mx - mn + 1e-9);
+    } else if (type == 1) {
+        argsort_stable(scores_in, n, 0, s);
+        for (int64_t i = 0; i < n; ++i) scores[s[i]] = (double)i / (double)(n - 1);
+    } else if (type == 2 || type == 3) {
+        argsort_stable(scores_in, n, 1, s);       /* np.argsort(-scores) */
+        for (int64_t i = 0; i < n; ++i) scores[s[i]] = (double)(i + 1);
+        double lg = log((double)n / 2 + 1), sum = 0.0;
+        for (int64_t i = 0; i < n; ++i) { double u = lg - log(scores[i]); scores[i] = u > 0 ? u : 0; }
+        for (int64_t i = 0; i < n; ++i) sum += scores[i];   /* python sum(): sequential */
+        for (int64_t i = 0; i < n; ++i) scores[i] = scores[i] / sum;
+        if (type == 2) for (int64_t i = 0; i < n; ++i) scores[i] -= 1.0 / (double)n;
+        double mx = scores[0];
+        for (int64_t i = 1; i < n; ++i) if (scores[i] > mx) mx = scores[i];
+        for (int64_t i = 0; i < n; ++i) scores[i] /= mx;
+    } else if (type == 4) {
+        int64_t am = 0;
+        for (int64_t i = 1; i < n; ++i) if (scores_in[i] > scores_in[am]) am = i;
+        for (int64_t i = 0; i < n; ++i) scores[i] = i == am ? 1.0 : 0.0;
+    } else if (type == 5 || type == 6 || type == 7) {
+        /* np.mean: pairwise summation for n >= 8 blocks; for the population sizes here (<= 1024)
+         * the fixture test pins equality on non-pathological inputs */
+        double sm = 0.0;
+        for (int64_t i = 0; i < n; ++i) sm += scores_orig[i];
+        double avg = sm / (double)n;
+        int64_t cnt = 0, am = 0;
+        double mx = scores_in[0];
+        for (int64_t i = 0; i < n; ++i) { if (scores_in[i] > avg + 1e-6) ++cnt; if (scores_in[i] > mx) { mx = scores_in[i]; am = i; } }
+        if (cnt > 0) {
+            if (type == 5) {
+                for (int64_t i = 0; i < n; ++i) scores[i] = i == am ? 1.0 : 0.0;
+            } else {
+                for (int64_t i = 0; i < n; ++i) {
+                    double idx = scores_in[i] > avg + 1e-6 ? 1.0 : 0.0;
+                    scores[i] = idx * (scores_in[i] - avg) / (mx - avg + 1e-9);
+                }
+                if (type == 6) {
+                    double m2 = scores[0];
+                    for (int64_t i = 1; i < n; ++i) if (scores[i] > m2) m2 = scores[i];
+                    for (int64_t i = 0; i < n; ++i) scores[i] /= m2;
+                } else {
+                    double s2 = 0.0;
+                    for (int64_t i = 0; i < n; ++i) s2 += scores[i];
+                    for (int64_t i = 0; i < n; ++i) scores[i] /= s2;
+                }
+            }
+        } else {
+            for (int64_t i = 0; i < n; ++i) scores[i] = 0.0;
+        }
+    } else {
+        rc = -1;   /* ValueError("Unknown rank transform type") GTN_master.py:263 */
+    }
+    if (!rc) memcpy(out, scores, sizeof(double) * n);
+    free(scores); free(s);
+    return rc;
+}
+
+/* GTN_master.py:267-298 */
+void orc_update_env(float *theta, const float *eps, const float *sign, const double *weights, int64_t pop, int64_t p_theta,
+                    const uint8_t *linear_mask, double step_size, int nes_step_size, double weight_decay)
+{
+    double ss = step_size;
+    if (nes_step_size) ss = ss / (double)pop;
+    const float decay = (float)(1.0 - weight_decay);
+    for (int64_t i = 0; i < p_theta; ++i)
+        if (!linear_mask || linear_mask[i]) theta[i] = theta[i] * decay;
+    for (int64_t w = 0; w < pop; ++w) {
+        const float c = (float)(ss * weights[w]);        /* python: (ss * score_transform) * tensor */
+        const float *e = eps + w * p_theta;
+        for (int64_t i = 0; i < p_theta; ++i)
+            if (!linear_mask || linear_mask[i]) theta[i] = theta[i] + c * (sign[w] * e[i]);
+    }
+}

@@ -1,0 +1,162 @@
+/*
+ * lenv_oracle.h -- CPU ORACLE for the NES inner-loop hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the algorithm the
+ * reference (automl/learning_environments, /root/reference) runs on its NES
+ * inner loop: GTN_Worker.calc_score -> BaseAgent.train/test -> EnvWrapper.step /
+ * DDQN.learn, plus the GTN_Master aggregation.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; the product (learning_environments_amd)
+ * never does.
+ *
+ * Parity status: PINNED for everything defined by /root/reference + torch
+ * (SE/RN forward, Q-nets, DDQN.learn, NES noise/mirroring, score_transform,
+ * update_env) against golden vectors produced by importing the reference
+ * (oracle/gen_golden.py -> tests/golden/).  UNPINNED for the third-party
+ * real-env physics (gym==0.17.3 CartPole-v0 / Acrobot-v1, requirements.txt:47),
+ * whose source is not under /root/reference: restated from the published
+ * equations.
+ *
+ * Canonical floating-point order (what "bit-exact vs the oracle" means for the
+ * HIP kernels; the reference's own order is MKL/oneDNN-defined):
+ *   - every dot product is a sequential fp32 fmaf chain in index order starting
+ *     from 0.0f, bias added last with a plain add (this IS torch-CPU's batched
+ *     `linear` order for K <= 128, verified bitwise);
+ *   - batch-gradient sums are accumulated in micro-chunks of `grad_chunk`
+ *     samples (sequential fmaf inside a chunk, chunk partials added in order);
+ *   - tanh / sin / cos are the polynomial routines in this file (no libm);
+ *   - element-wise update formulas follow torch 2.10's CPU kernels op by op
+ *     (lerp = fma, addcmul = fma, addcdiv = plain, tanh' = dh*fma(-h,h,1)).
+ */
+#ifndef LENV_ORACLE_H
+#define LENV_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_ACT_IDENTITY = 0, ORC_ACT_RELU = 1, ORC_ACT_LEAKYRELU = 2, ORC_ACT_TANH = 3, ORC_ACT_PRELU = 4 };
+enum { ORC_ENV_CARTPOLE = 0, ORC_ENV_ACROBOT = 1 };
+enum { ORC_RNG_COUNTER = 0, ORC_RNG_TAPE = 1 };
+
+/* models/model_utils.py:4-39 -- Linear(in,H) act [Linear(H,H) act]x(L-1) Linear(H,out) */
+typedef struct {
+    int32_t in_dim, hidden, layers, out_dim, act;
+    float prelu; /* single shared PReLU slope (init 0.25, never perturbed) */
+} orc_mlp_desc;
+
+/* Inner-loop configuration: agents/DDQN.py:15-38 + agents/base_agent.py:9-26 + env config. */
+typedef struct {
+    int32_t env_id;
+    int32_t state_dim;
+    int32_t num_actions;
+    int32_t max_steps;
+    int32_t se_hidden, se_layers, se_act;
+    float se_prelu;
+    int32_t q_hidden, q_layers, q_act;
+    float q_prelu;
+    int32_t batch_size, rb_size;
+    int32_t train_episodes, test_episodes, init_episodes;
+    int32_t early_out_num;
+    int32_t grad_chunk;
+    int32_t rng_mode;
+    double solved_reward;
+    double gamma, lr, tau;
+    double eps_init, eps_min, eps_decay;
+    double adam_beta1, adam_beta2, adam_eps;
+} orc_ddqn_cfg;
+
+/* RNG tapes (parity mode): values the reference drew, in per-stream order. */
+typedef struct {
+    const double *eps_uniform;  int64_t n_eps_uniform;   /* random.random()            DDQN.py:98 */
+    const int32_t *rand_action; int64_t n_rand_action;   /* action_space.sample()      env_wrapper.py:88 */
+    const int32_t *replay_idx;  int64_t n_replay_idx;    /* np.random.randint          utils.py:35 */
+    const double *train_reset;  int64_t n_train_reset;   /* SE reset_env.reset() rows  virtual_env.py:36 */
+    const double *test_reset;   int64_t n_test_reset;    /* real_env.reset() rows */
+} orc_tapes;
+
+/* Optional per-step trace of the training loop (parity debugging). */
+typedef struct {
+    int64_t cap;         /* rows available */
+    int64_t n;           /* rows written */
+    int32_t *episode;    /* [cap] */
+    int32_t *action;     /* [cap] */
+    int32_t *explored;   /* [cap] 1 if random action */
+    float *state;        /* [cap,S] state before the step */
+    float *next_state;   /* [cap,S] */
+    float *reward;       /* [cap] */
+    float *done;         /* [cap] */
+    float *loss;         /* [cap] mse loss of the learn step (NaN when no learn) */
+} orc_trace;
+
+typedef struct {
+    double score;             /* statistics.mean(final test returns)  GTN_worker.py:209 */
+    int32_t episodes_run;     /* train episodes executed */
+    int64_t train_steps;      /* SE steps */
+    int64_t learn_steps;
+    int64_t test_steps;       /* real-env steps (per-episode tests + final test) */
+} orc_chain_result;
+
+/* ---- deterministic math ---- */
+float orc_tanhf(float x);
+double orc_sin(double x);
+double orc_cos(double x);
+
+/* ---- RNG (counter mode) ---- */
+uint64_t orc_mix64(uint64_t x);
+uint64_t orc_chain_key(uint64_t seed, uint64_t generation, uint64_t worker, uint64_t kind);
+uint64_t orc_rng_u64(uint64_t key, uint32_t stream, uint64_t n);
+
+/* ---- MLP ---- */
+int64_t orc_mlp_num_params(const orc_mlp_desc *d);
+/* batched forward; x [B,in], y [B,out]; hidden_out (optional) [B,H] = last hidden activations */
+int orc_mlp_forward(const orc_mlp_desc *d, const float *params, const float *x, int64_t B, float *y, float *hidden_out);
+
+/* envs/virtual_env.py:43-54 + env_wrapper.py:16-47 for a population of perturbations:
+ * W_c = theta + sign[c]*eps[worker[c]]; in = [onehot(action), state]. */
+int orc_se_step_population(const orc_mlp_desc *state_net, const orc_mlp_desc *reward_net, const orc_mlp_desc *done_net,
+                           const float *theta, const float *eps, const int32_t *worker, const float *sign,
+                           int64_t chains, const float *state, const int32_t *action,
+                           float *next_state, float *reward, float *done);
+
+/* ---- real envs (gym 0.17.3, UNPINNED) ---- */
+void orc_cartpole_step(double st[4], int action, double *reward, int *done);
+void orc_acrobot_step(double st[4], int action, double *reward, int *done);
+void orc_acrobot_obs(const double st[4], double obs[6]);
+
+/* ---- DDQN pieces (agents/DDQN.py:60-110) ---- */
+/* TD forward for a minibatch: q_sa, target y, per-sample loss term; rows = [s,a,s2,r,d] with stride row_stride */
+int orc_qnet_td_forward(const orc_mlp_desc *q, const float *online, const float *target,
+                        const float *rows, int64_t row_stride, int64_t B, int32_t S, double gamma,
+                        float *q_sa, float *y, int32_t *argmax_next);
+/* one full learn step on an explicit minibatch; updates online/target/m/v in place; returns loss */
+float orc_ddqn_learn(const orc_ddqn_cfg *cfg, float *online, float *target, float *adam_m, float *adam_v,
+                     int64_t step /*1-based*/, double *b1pow, double *b2pow,
+                     const float *rows, int64_t row_stride);
+
+/* ---- one chain = GTN_Worker.calc_score (GTN_worker.py:187-221) ---- */
+int orc_ddqn_se_chain(const orc_ddqn_cfg *cfg, const float *se_params /*perturbed, [P_theta]*/,
+                      const float *agent_init /*[P_agent]*/, uint64_t rng_key, const orc_tapes *tapes,
+                      double *episode_test_mean /*[train_episodes] or NULL*/, int32_t *episode_len /*[train_episodes] or NULL*/,
+                      double *final_test_returns /*[test_episodes] or NULL*/, orc_trace *trace, orc_chain_result *res);
+
+/* population driver (multi-threaded over chains; used by the cpu_baseline leg) */
+int orc_ddqn_se_population(const orc_ddqn_cfg *cfg, const float *theta, const float *eps, int64_t pop, int64_t p_theta,
+                           const float *agent_init /*[3*pop,P_agent]*/, uint64_t seed, uint64_t generation,
+                           int64_t worker_offset, int threads, double *chain_scores /*[3*pop]*/,
+                           orc_chain_result *results /*[3*pop] or NULL*/);
+
+/* ---- NES master/worker math ---- */
+/* GTN_worker.py:234-254: mirrored sampling pick; out[p] = {score_best, sign} */
+void orc_worker_best(const double *score_add, const double *score_sub, int64_t pop, int mirrored, double *score_best, float *sign);
+/* GTN_master.py:197-265; ties broken by lower index first (documented stable order) */
+int orc_score_transform(int type, const double *scores, const double *scores_orig, int64_t n, double *out);
+/* GTN_master.py:267-298: theta <- theta*(1-wd); theta += ss*w_i*sign_i*eps_i sequentially over i */
+void orc_update_env(float *theta, const float *eps, const float *sign, const double *weights, int64_t pop, int64_t p_theta,
+                    const uint8_t *linear_mask /*[p_theta] 1 = nn.Linear param*/, double step_size, int nes_step_size, double weight_decay);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

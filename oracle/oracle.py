@@ -1,0 +1,294 @@
+"""ctypes binding of the CPU oracle (oracle/lenv_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the learning_environments_amd package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liblenv_oracle.so")
+
+ACT = {"identity": 0, "relu": 1, "leakyrelu": 2, "tanh": 3, "prelu": 4}
+ENV = {"CartPole-v0": 0, "Acrobot-v1": 1}
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("out_dim", C.c_int32),
+                ("act", C.c_int32), ("prelu", C.c_float)]
+
+
+class DdqnCfg(C.Structure):
+    _fields_ = [("env_id", C.c_int32), ("state_dim", C.c_int32), ("num_actions", C.c_int32), ("max_steps", C.c_int32),
+                ("se_hidden", C.c_int32), ("se_layers", C.c_int32), ("se_act", C.c_int32), ("se_prelu", C.c_float),
+                ("q_hidden", C.c_int32), ("q_layers", C.c_int32), ("q_act", C.c_int32), ("q_prelu", C.c_float),
+                ("batch_size", C.c_int32), ("rb_size", C.c_int32),
+                ("train_episodes", C.c_int32), ("test_episodes", C.c_int32), ("init_episodes", C.c_int32),
+                ("early_out_num", C.c_int32), ("grad_chunk", C.c_int32), ("rng_mode", C.c_int32),
+                ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
+                ("eps_init", C.c_double), ("eps_min", C.c_double), ("eps_decay", C.c_double),
+                ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
+
+
+class Tapes(C.Structure):
+    _fields_ = [("eps_uniform", C.POINTER(C.c_double)), ("n_eps_uniform", C.c_int64),
+                ("rand_action", C.POINTER(C.c_int32)), ("n_rand_action", C.c_int64),
+                ("replay_idx", C.POINTER(C.c_int32)), ("n_replay_idx", C.c_int64),
+                ("train_reset", C.POINTER(C.c_double)), ("n_train_reset", C.c_int64),
+                ("test_reset", C.POINTER(C.c_double)), ("n_test_reset", C.c_int64)]
+
+
+class Trace(C.Structure):
+    _fields_ = [("cap", C.c_int64), ("n", C.c_int64), ("episode", C.POINTER(C.c_int32)), ("action", C.POINTER(C.c_int32)),
+                ("explored", C.POINTER(C.c_int32)), ("state", C.POINTER(C.c_float)), ("next_state", C.POINTER(C.c_float)),
+                ("reward", C.POINTER(C.c_float)), ("done", C.POINTER(C.c_float)), ("loss", C.POINTER(C.c_float))]
+
+
+class ChainResult(C.Structure):
+    _fields_ = [("score", C.c_double), ("episodes_run", C.c_int32), ("train_steps", C.c_int64),
+                ("learn_steps", C.c_int64), ("test_steps", C.c_int64)]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "lenv_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_tanhf.restype = C.c_float
+        _lib.orc_tanhf.argtypes = [C.c_float]
+        _lib.orc_sin.restype = C.c_double
+        _lib.orc_sin.argtypes = [C.c_double]
+        _lib.orc_cos.restype = C.c_double
+        _lib.orc_cos.argtypes = [C.c_double]
+        _lib.orc_mix64.restype = C.c_uint64
+        _lib.orc_mix64.argtypes = [C.c_uint64]
+        _lib.orc_chain_key.restype = C.c_uint64
+        _lib.orc_chain_key.argtypes = [C.c_uint64] * 4
+        _lib.orc_rng_u64.restype = C.c_uint64
+        _lib.orc_rng_u64.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
+        _lib.orc_mlp_num_params.restype = C.c_int64
+        _lib.orc_ddqn_learn.restype = C.c_float
+    return _lib
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def mlp_desc(in_dim, hidden, layers, out_dim, act, prelu=0.25):
+    return MlpDesc(in_dim, hidden, layers, out_dim, ACT[act] if isinstance(act, str) else act, prelu)
+
+
+def mlp_num_params(d):
+    return int(lib().orc_mlp_num_params(C.byref(d)))
+
+
+def tanhf(x):
+    x = _f32(x)
+    out = np.empty_like(x)
+    L = lib()
+    flat_in, flat_out = x.reshape(-1), out.reshape(-1)
+    for i in range(flat_in.size):
+        flat_out[i] = L.orc_tanhf(float(flat_in[i]))
+    return out
+
+
+def mlp_forward(d, params, x, want_hidden=False):
+    params, x = _f32(params), _f32(x)
+    assert params.size == mlp_num_params(d), (params.size, mlp_num_params(d))
+    x2 = x.reshape(-1, d.in_dim)
+    B = x2.shape[0]
+    y = np.empty((B, d.out_dim), np.float32)
+    h = np.empty((B, d.hidden), np.float32) if want_hidden else None
+    rc = lib().orc_mlp_forward(C.byref(d), _p(params, C.c_float), _p(x2, C.c_float), C.c_int64(B), _p(y, C.c_float),
+                               _p(h, C.c_float) if want_hidden else None)
+    assert rc == 0
+    return (y, h) if want_hidden else y
+
+
+def se_descs(S, A, hidden, layers, act, prelu=0.25):
+    return (mlp_desc(S + A, hidden, layers, S, act, prelu), mlp_desc(S + A, hidden, layers, 1, act, prelu),
+            mlp_desc(S + A, hidden, layers, 1, act, prelu))
+
+
+def se_step_population(descs, theta, eps, worker, sign, state, action):
+    sn, rn, dn = descs
+    theta = _f32(theta)
+    state = _f32(state)
+    chains, S = state.shape
+    action = np.ascontiguousarray(action, dtype=np.int32)
+    ns = np.empty((chains, S), np.float32)
+    r = np.empty(chains, np.float32)
+    d = np.empty(chains, np.float32)
+    if eps is not None:
+        eps = _f32(eps)
+        worker = np.ascontiguousarray(worker, dtype=np.int32)
+        sign = _f32(sign)
+    rc = lib().orc_se_step_population(C.byref(sn), C.byref(rn), C.byref(dn), _p(theta, C.c_float),
+                                      _p(eps, C.c_float) if eps is not None else None,
+                                      _p(worker, C.c_int32) if eps is not None else None,
+                                      _p(sign, C.c_float) if eps is not None else None,
+                                      C.c_int64(chains), _p(state, C.c_float), _p(action, C.c_int32),
+                                      _p(ns, C.c_float), _p(r, C.c_float), _p(d, C.c_float))
+    assert rc == 0
+    return ns, r, d
+
+
+def qnet_td_forward(qd, online, target, rows, S, gamma):
+    online, target, rows = _f32(online), _f32(target), _f32(rows)
+    B, stride = rows.shape
+    q_sa = np.empty(B, np.float32)
+    y = np.empty(B, np.float32)
+    am = np.empty(B, np.int32)
+    rc = lib().orc_qnet_td_forward(C.byref(qd), _p(online, C.c_float), _p(target, C.c_float), _p(rows, C.c_float),
+                                   C.c_int64(stride), C.c_int64(B), C.c_int32(S), C.c_double(gamma),
+                                   _p(q_sa, C.c_float), _p(y, C.c_float), _p(am, C.c_int32))
+    assert rc == 0
+    return q_sa, y, am
+
+
+def ddqn_learn(cfg, online, target, m, v, step, b1pow, b2pow, rows):
+    """In-place on copies; returns (loss, online, target, m, v, b1pow, b2pow)."""
+    online, target, m, v = [_f32(t).copy() for t in (online, target, m, v)]
+    rows = _f32(rows)
+    b1, b2 = C.c_double(b1pow), C.c_double(b2pow)
+    loss = lib().orc_ddqn_learn(C.byref(cfg), _p(online, C.c_float), _p(target, C.c_float), _p(m, C.c_float),
+                                _p(v, C.c_float), C.c_int64(step), C.byref(b1), C.byref(b2), _p(rows, C.c_float),
+                                C.c_int64(rows.shape[1]))
+    return float(loss), online, target, m, v, b1.value, b2.value
+
+
+def make_tapes(eps_uniform, rand_action, replay_idx, train_reset, test_reset):
+    keep = [np.ascontiguousarray(eps_uniform, np.float64), np.ascontiguousarray(rand_action, np.int32),
+            np.ascontiguousarray(replay_idx, np.int32).reshape(-1),
+            np.ascontiguousarray(train_reset, np.float64).reshape(-1, 4),
+            np.ascontiguousarray(test_reset, np.float64).reshape(-1, 4)]
+    t = Tapes(_p(keep[0], C.c_double), keep[0].size, _p(keep[1], C.c_int32), keep[1].size,
+              _p(keep[2], C.c_int32), keep[2].size, _p(keep[3], C.c_double), keep[3].shape[0],
+              _p(keep[4], C.c_double), keep[4].shape[0])
+    t._keep = keep
+    return t
+
+
+def ddqn_se_chain(cfg, se_params, agent_init, rng_key=0, tapes=None, trace_cap=0):
+    se_params, agent_init = _f32(se_params), _f32(agent_init)
+    E, T, S = cfg.train_episodes, cfg.test_episodes, cfg.state_dim
+    ep_mean = np.full(max(E, 1), np.nan)
+    ep_len = np.zeros(max(E, 1), np.int32)
+    final = np.zeros(max(T, 1))
+    res = ChainResult()
+    tr = None
+    arrs = None
+    if trace_cap:
+        arrs = dict(episode=np.zeros(trace_cap, np.int32), action=np.zeros(trace_cap, np.int32),
+                    explored=np.zeros(trace_cap, np.int32), state=np.zeros((trace_cap, S), np.float32),
+                    next_state=np.zeros((trace_cap, S), np.float32), reward=np.zeros(trace_cap, np.float32),
+                    done=np.zeros(trace_cap, np.float32), loss=np.zeros(trace_cap, np.float32))
+        tr = Trace(trace_cap, 0, _p(arrs["episode"], C.c_int32), _p(arrs["action"], C.c_int32),
+                   _p(arrs["explored"], C.c_int32), _p(arrs["state"], C.c_float), _p(arrs["next_state"], C.c_float),
+                   _p(arrs["reward"], C.c_float), _p(arrs["done"], C.c_float), _p(arrs["loss"], C.c_float))
+    rc = lib().orc_ddqn_se_chain(C.byref(cfg), _p(se_params, C.c_float), _p(agent_init, C.c_float), C.c_uint64(rng_key),
+                                 C.byref(tapes) if tapes is not None else None, _p(ep_mean, C.c_double),
+                                 _p(ep_len, C.c_int32), _p(final, C.c_double), C.byref(tr) if tr is not None else None,
+                                 C.byref(res))
+    out = dict(rc=rc, score=res.score, episodes_run=res.episodes_run, train_steps=res.train_steps,
+               learn_steps=res.learn_steps, test_steps=res.test_steps, episode_test_mean=ep_mean[:E],
+               episode_len=ep_len[:E], final_test_returns=final[:T])
+    if tr is not None:
+        n = tr.n
+        out["trace"] = {k: v[:n] for k, v in arrs.items()}
+    return out
+
+
+def ddqn_se_population(cfg, theta, eps, agent_init, seed, generation, worker_offset=0, threads=1, want_results=False):
+    theta, eps, agent_init = _f32(theta), _f32(eps), _f32(agent_init)
+    pop, p_theta = eps.shape
+    assert agent_init.shape[0] == 3 * pop
+    scores = np.zeros(3 * pop)
+    results = (ChainResult * (3 * pop))()
+    rc = lib().orc_ddqn_se_population(C.byref(cfg), _p(theta, C.c_float), _p(eps, C.c_float), C.c_int64(pop),
+                                      C.c_int64(p_theta), _p(agent_init, C.c_float), C.c_uint64(seed),
+                                      C.c_uint64(generation), C.c_int64(worker_offset), C.c_int(threads),
+                                      _p(scores, C.c_double), results)
+    assert rc == 0, rc
+    if want_results:
+        return scores, [dict(score=r.score, episodes_run=r.episodes_run, train_steps=r.train_steps,
+                             learn_steps=r.learn_steps, test_steps=r.test_steps) for r in results]
+    return scores
+
+
+def chain_key(seed, generation, worker, kind):
+    return int(lib().orc_chain_key(seed, generation, worker, kind))
+
+
+def worker_best(score_add, score_sub, mirrored=True):
+    a = np.ascontiguousarray(score_add, np.float64)
+    s = np.ascontiguousarray(score_sub, np.float64)
+    best = np.empty_like(a)
+    sign = np.empty(a.size, np.float32)
+    lib().orc_worker_best(_p(a, C.c_double), _p(s, C.c_double), C.c_int64(a.size), C.c_int(1 if mirrored else 0),
+                          _p(best, C.c_double), _p(sign, C.c_float))
+    return best, sign
+
+
+def score_transform(type_, scores, scores_orig):
+    s = np.ascontiguousarray(scores, np.float64)
+    so = np.ascontiguousarray(scores_orig, np.float64)
+    out = np.empty_like(s)
+    rc = lib().orc_score_transform(C.c_int(type_), _p(s, C.c_double), _p(so, C.c_double), C.c_int64(s.size), _p(out, C.c_double))
+    if rc:
+        raise ValueError("Unknown rank transform type: " + str(type_))
+    return out
+
+
+def update_env(theta, eps, sign, weights, step_size, nes_step_size=False, weight_decay=0.0):
+    theta = _f32(theta).copy()
+    eps = _f32(eps)
+    sign = _f32(sign)
+    w = np.ascontiguousarray(weights, np.float64)
+    pop, p_theta = eps.shape
+    lib().orc_update_env(_p(theta, C.c_float), _p(eps, C.c_float), _p(sign, C.c_float), _p(w, C.c_double),
+                         C.c_int64(pop), C.c_int64(p_theta), None, C.c_double(step_size),
+                         C.c_int(1 if nes_step_size else 0), C.c_double(weight_decay))
+    return theta
+
+
+def ddqn_cfg_from_config(config, grad_chunk=13, rng_mode=0, **overrides):
+    """Reference YAML dict -> oracle config (DDQN agent + virtual env).  Mirrors the fields read at
+    agents/DDQN.py:15-38, agents/base_agent.py:9-26, envs/env_factory.py:45-59."""
+    env_name = config["env_name"]
+    e = config["envs"][env_name]
+    a = config["agents"]["ddqn"]
+    S, A = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3)}[env_name]
+    assert a["same_action_num"] == 1, "same_action_num != 1 not supported by the oracle yet"
+    cfg = DdqnCfg(env_id=ENV[env_name], state_dim=S, num_actions=A, max_steps=int(e["max_steps"]),
+                  se_hidden=int(e["hidden_size"]), se_layers=int(e["hidden_layer"]), se_act=ACT[e["activation_fn"]],
+                  se_prelu=0.25, q_hidden=int(a["hidden_size"]), q_layers=int(a["hidden_layer"]),
+                  q_act=ACT[a["activation_fn"]], q_prelu=0.25, batch_size=int(a["batch_size"]),
+                  rb_size=int(a["rb_size"]), train_episodes=int(a["train_episodes"]),
+                  test_episodes=int(a["test_episodes"]), init_episodes=int(a["init_episodes"]),
+                  early_out_num=int(a["early_out_num"]), grad_chunk=grad_chunk, rng_mode=rng_mode,
+                  solved_reward=float(e["solved_reward"]), gamma=float(a["gamma"]), lr=float(a["lr"]),
+                  tau=float(a["tau"]), eps_init=float(a["eps_init"]), eps_min=float(a["eps_min"]),
+                  eps_decay=float(a["eps_decay"]), adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8)
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return cfg

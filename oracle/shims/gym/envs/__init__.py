@@ -1,0 +1,218 @@
+"""gym.make + classic-control envs restated from gym 0.17.3.
+Float64 python/numpy arithmetic in the published operation order."""
+import math
+import numpy as np
+from numpy import sin, cos, pi
+
+from gym.core import Env
+from gym import spaces
+from gym.utils import seeding
+
+
+class EnvSpec(object):
+    def __init__(self, id, max_episode_steps=None, reward_threshold=None):
+        self.id = id
+        self.max_episode_steps = max_episode_steps
+        self.reward_threshold = reward_threshold
+
+
+class CartPoleEnv(Env):
+    """gym/envs/classic_control/cartpole.py @0.17.3"""
+
+    def __init__(self):
+        self.gravity = 9.8
+        self.masscart = 1.0
+        self.masspole = 0.1
+        self.total_mass = (self.masspole + self.masscart)
+        self.length = 0.5  # actually half the pole's length
+        self.polemass_length = (self.masspole * self.length)
+        self.force_mag = 10.0
+        self.tau = 0.02  # seconds between state updates
+        self.kinematics_integrator = 'euler'
+        self.theta_threshold_radians = 12 * 2 * math.pi / 360
+        self.x_threshold = 2.4
+        high = np.array([self.x_threshold * 2, np.finfo(np.float32).max,
+                         self.theta_threshold_radians * 2, np.finfo(np.float32).max], dtype=np.float32)
+        self.action_space = spaces.Discrete(2)
+        self.observation_space = spaces.Box(-high, high, dtype=np.float32)
+        self.seed()
+        self.viewer = None
+        self.state = None
+        self.steps_beyond_done = None
+
+    def seed(self, seed=None):
+        self.np_random, seed = seeding.np_random(seed)
+        return [seed]
+
+    def step(self, action):
+        x, x_dot, theta, theta_dot = self.state
+        force = self.force_mag if action == 1 else -self.force_mag
+        costheta = math.cos(theta)
+        sintheta = math.sin(theta)
+        temp = (force + self.polemass_length * theta_dot ** 2 * sintheta) / self.total_mass
+        thetaacc = (self.gravity * sintheta - costheta * temp) / \
+                   (self.length * (4.0 / 3.0 - self.masspole * costheta ** 2 / self.total_mass))
+        xacc = temp - self.polemass_length * thetaacc * costheta / self.total_mass
+        x = x + self.tau * x_dot
+        x_dot = x_dot + self.tau * xacc
+        theta = theta + self.tau * theta_dot
+        theta_dot = theta_dot + self.tau * thetaacc
+        self.state = (x, x_dot, theta, theta_dot)
+        done = bool(x < -self.x_threshold or x > self.x_threshold
+                    or theta < -self.theta_threshold_radians or theta > self.theta_threshold_radians)
+        if not done:
+            reward = 1.0
+        elif self.steps_beyond_done is None:
+            self.steps_beyond_done = 0
+            reward = 1.0
+        else:
+            self.steps_beyond_done += 1
+            reward = 0.0
+        return np.array(self.state), reward, done, {}
+
+    def reset(self):
+        self.state = self.np_random.uniform(low=-0.05, high=0.05, size=(4,))
+        self.steps_beyond_done = None
+        return np.array(self.state)
+
+    def render(self, mode='human'):
+        return None
+
+
+def _wrap(x, m, M):
+    diff = M - m
+    while x > M:
+        x = x - diff
+    while x < m:
+        x = x + diff
+    return x
+
+
+def _bound(x, m, M):
+    return min(max(x, m), M)
+
+
+def _rk4(derivs, y0, t):
+    Ny = len(y0)
+    yout = np.zeros((len(t), Ny), np.float64)
+    yout[0] = y0
+    for i in np.arange(len(t) - 1):
+        thist = t[i]
+        dt = t[i + 1] - thist
+        dt2 = dt / 2.0
+        y0 = yout[i]
+        k1 = np.asarray(derivs(y0, thist))
+        k2 = np.asarray(derivs(y0 + dt2 * k1, thist + dt2))
+        k3 = np.asarray(derivs(y0 + dt2 * k2, thist + dt2))
+        k4 = np.asarray(derivs(y0 + dt * k3, thist + dt))
+        yout[i + 1] = y0 + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+    return yout
+
+
+class AcrobotEnv(Env):
+    """gym/envs/classic_control/acrobot.py @0.17.3 ("book" dynamics)"""
+    dt = .2
+    LINK_LENGTH_1 = 1.
+    LINK_LENGTH_2 = 1.
+    LINK_MASS_1 = 1.
+    LINK_MASS_2 = 1.
+    LINK_COM_POS_1 = 0.5
+    LINK_COM_POS_2 = 0.5
+    LINK_MOI = 1.
+    MAX_VEL_1 = 4 * pi
+    MAX_VEL_2 = 9 * pi
+    AVAIL_TORQUE = [-1., 0., +1]
+    torque_noise_max = 0.
+    book_or_nips = "book"
+
+    def __init__(self):
+        self.viewer = None
+        high = np.array([1.0, 1.0, 1.0, 1.0, self.MAX_VEL_1, self.MAX_VEL_2], dtype=np.float32)
+        self.observation_space = spaces.Box(low=-high, high=high, dtype=np.float32)
+        self.action_space = spaces.Discrete(3)
+        self.state = None
+        self.seed()
+
+    def seed(self, seed=None):
+        self.np_random, seed = seeding.np_random(seed)
+        return [seed]
+
+    def reset(self):
+        self.state = self.np_random.uniform(low=-0.1, high=0.1, size=(4,))
+        return self._get_ob()
+
+    def step(self, a):
+        s = self.state
+        torque = self.AVAIL_TORQUE[a]
+        s_augmented = np.append(s, torque)
+        ns = _rk4(self._dsdt, s_augmented, [0, self.dt])
+        ns = ns[-1]
+        ns = ns[:4]
+        ns[0] = _wrap(ns[0], -pi, pi)
+        ns[1] = _wrap(ns[1], -pi, pi)
+        ns[2] = _bound(ns[2], -self.MAX_VEL_1, self.MAX_VEL_1)
+        ns[3] = _bound(ns[3], -self.MAX_VEL_2, self.MAX_VEL_2)
+        self.state = ns
+        terminal = self._terminal()
+        reward = -1. if not terminal else 0.
+        return (self._get_ob(), reward, terminal, {})
+
+    def _get_ob(self):
+        s = self.state
+        return np.array([cos(s[0]), sin(s[0]), cos(s[1]), sin(s[1]), s[2], s[3]])
+
+    def _terminal(self):
+        s = self.state
+        return bool(-cos(s[0]) - cos(s[1] + s[0]) > 1.)
+
+    def _dsdt(self, s_augmented, t):
+        m1 = self.LINK_MASS_1
+        m2 = self.LINK_MASS_2
+        l1 = self.LINK_LENGTH_1
+        lc1 = self.LINK_COM_POS_1
+        lc2 = self.LINK_COM_POS_2
+        I1 = self.LINK_MOI
+        I2 = self.LINK_MOI
+        g = 9.8
+        a = s_augmented[-1]
+        s = s_augmented[:-1]
+        theta1 = s[0]
+        theta2 = s[1]
+        dtheta1 = s[2]
+        dtheta2 = s[3]
+        d1 = m1 * lc1 ** 2 + m2 * (l1 ** 2 + lc2 ** 2 + 2 * l1 * lc2 * cos(theta2)) + I1 + I2
+        d2 = m2 * (lc2 ** 2 + l1 * lc2 * cos(theta2)) + I2
+        phi2 = m2 * lc2 * g * cos(theta1 + theta2 - pi / 2.)
+        phi1 = - m2 * l1 * lc2 * dtheta2 ** 2 * sin(theta2) \
+               - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * sin(theta2) \
+               + (m1 * lc1 + m2 * l1) * g * cos(theta1 - pi / 2) + phi2
+        ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * dtheta1 ** 2 * sin(theta2) - phi2) \
+                   / (m2 * lc2 ** 2 + I2 - d2 ** 2 / d1)
+        ddtheta1 = -(d2 * ddtheta2 + phi1) / d1
+        return (dtheta1, dtheta2, ddtheta1, ddtheta2, 0.)
+
+    def render(self, mode='human'):
+        return None
+
+
+_REGISTRY = {
+    'CartPole-v0': (CartPoleEnv, EnvSpec('CartPole-v0', 200, 195.0)),
+    'CartPole-v1': (CartPoleEnv, EnvSpec('CartPole-v1', 500, 475.0)),
+    'Acrobot-v1': (AcrobotEnv, EnvSpec('Acrobot-v1', 500, -100.0)),
+}
+
+
+def register(id, entry_point, max_episode_steps=None, reward_threshold=None):
+    _REGISTRY[id] = (entry_point, EnvSpec(id, max_episode_steps, reward_threshold))
+
+
+def make(id, **kwargs):
+    from gym.wrappers import TimeLimit
+    if id not in _REGISTRY:
+        raise KeyError("gym shim: unknown env id " + str(id))
+    cls, spec = _REGISTRY[id]
+    env = cls(**kwargs)
+    env.spec = spec
+    if spec.max_episode_steps is not None:
+        env = TimeLimit(env, max_episode_steps=spec.max_episode_steps)
+    return env

@@ -1,0 +1,161 @@
+"""Pins the CPU oracle (oracle/lenv_oracle.c) to golden vectors produced by the reference itself
+(oracle/gen_golden.py imports /root/reference; the .npz files under tests/golden are its outputs).
+
+Tolerances: the oracle's batched dot-product order equals torch-CPU's (bitwise, verified), so the
+only deviations are (a) the oracle's polynomial tanh vs torch's (few ulp), (b) torch's batch-1 gemv
+order, (c) torch's batch-reduction order in backward.  All are O(1e-7) relative per op.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+ACTS = ["identity", "relu", "leakyrelu", "tanh", "prelu"]
+
+
+def test_tanh_accuracy():
+    x = np.concatenate([np.linspace(-12, 12, 20001), np.logspace(-30, 1, 4000), -np.logspace(-30, 1, 4000), [0.0]]).astype(np.float32)
+    got = orc.tanhf(x)
+    ref = np.tanh(x.astype(np.float64))
+    err = np.abs(got - ref)
+    ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+    assert np.max(err / np.maximum(ulp, 1e-45)) < 4.0
+    assert got[-1] == 0.0
+    assert np.all(np.abs(got) <= 1.0)
+
+
+def test_sincos_accuracy():
+    L = orc.lib()
+    xs = np.concatenate([np.linspace(-12, 12, 5001), np.random.RandomState(0).uniform(-0.3, 0.3, 3000)])
+    s = np.array([L.orc_sin(float(v)) for v in xs])
+    c = np.array([L.orc_cos(float(v)) for v in xs])
+    assert np.max(np.abs(s - np.sin(xs))) < 4e-16
+    assert np.max(np.abs(c - np.cos(xs))) < 4e-16
+
+
+def test_g1_virtual_env_step(golden):
+    g = golden("g1_virtual_env_step")
+    for ci in range(int(g["n_cases"])):
+        pre = "c%02d_" % ci
+        S, A, H, L, act = [int(v) for v in g[pre + "meta"]]
+        descs = orc.se_descs(S, A, H, L, ACTS[act])
+        n = g[pre + "state"].shape[0]
+        ns, r, d = orc.se_step_population(descs, g[pre + "theta"], None, None, None, g[pre + "state"], g[pre + "action"])
+        np.testing.assert_allclose(ns, g[pre + "next_state"], rtol=2e-6, atol=2e-6, err_msg=pre)
+        np.testing.assert_allclose(r, g[pre + "reward"], rtol=2e-6, atol=2e-6, err_msg=pre)
+        np.testing.assert_allclose(d, g[pre + "done"], rtol=2e-6, atol=2e-6, err_msg=pre)
+        assert ns.shape == (n, S)
+
+
+def test_g3_critic_dqn_forward(golden):
+    g = golden("g3_critic_dqn_forward")
+    for ci in range(int(g["n_cases"])):
+        pre = "c%d_" % ci
+        S, A, H, L, act = [int(v) for v in g[pre + "meta"]]
+        d = orc.mlp_desc(S, H, L, A, ACTS[act])
+        y = orc.mlp_forward(d, g[pre + "params"], g[pre + "x"])
+        if ACTS[act] != "tanh":
+            # batched linear order == torch's: bit-exact
+            assert np.array_equal(y, g[pre + "y"]), pre
+        else:
+            np.testing.assert_allclose(y, g[pre + "y"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(y[:5], g[pre + "y_single"], rtol=2e-6, atol=2e-6)
+
+
+def _cfg_for(meta, hp, grad_chunk):
+    S, A, H, L, act, B, _ = [int(v) for v in meta]
+    return orc.DdqnCfg(env_id=0 if S == 4 else 1, state_dim=S, num_actions=A, max_steps=200, se_hidden=8, se_layers=1,
+                       se_act=2, se_prelu=0.25, q_hidden=H, q_layers=L, q_act=act, q_prelu=0.25, batch_size=B,
+                       rb_size=1000, train_episodes=1, test_episodes=1, init_episodes=0, early_out_num=1,
+                       grad_chunk=grad_chunk, rng_mode=0, solved_reward=1e9, gamma=float(hp[0]), lr=float(hp[1]),
+                       tau=float(hp[2]), eps_init=1.0, eps_min=0.1, eps_decay=0.9, adam_beta1=0.9, adam_beta2=0.999,
+                       adam_eps=1e-8)
+
+
+@pytest.mark.parametrize("grad_chunk", [0, 13])
+def test_g4_ddqn_learn(golden, grad_chunk):
+    g = golden("g4_ddqn_learn")
+    for vi in range(int(g["n_variants"])):
+        pre = "v%d_" % vi
+        cfg = _cfg_for(g[pre + "meta"], g[pre + "hparams"], grad_chunk)
+        nsteps = int(g[pre + "meta"][6])
+        online, target = g[pre + "online0"].copy(), g[pre + "target0"].copy()
+        m, v = np.zeros_like(online), np.zeros_like(online)
+        b1p, b2p = 1.0, 1.0
+        for step in range(nsteps):
+            loss, online, target, m, v, b1p, b2p = orc.ddqn_learn(cfg, online, target, m, v, step + 1, b1p, b2p, g[pre + "rows"][step])
+            assert abs(loss - g[pre + "loss"][step]) <= 2e-6 * max(1.0, abs(g[pre + "loss"][step])), (pre, step)
+            np.testing.assert_allclose(m, g[pre + "adam_m"][step], rtol=2e-4, atol=2e-8, err_msg=pre + "m%d" % step)
+            np.testing.assert_allclose(v, g[pre + "adam_v"][step], rtol=2e-4, atol=1e-12, err_msg=pre + "v%d" % step)
+            # Adam's first steps move every weight by ~lr regardless of |g|; compare the parameters tightly
+            np.testing.assert_allclose(online, g[pre + "online"][step], rtol=0, atol=3e-6, err_msg=pre + "online%d" % step)
+            np.testing.assert_allclose(target, g[pre + "target"][step], rtol=0, atol=3e-6, err_msg=pre + "target%d" % step)
+
+
+def test_g6_worker_noise(golden):
+    g = golden("g6_worker_noise")
+    theta, eps = g["theta"], g["eps"]
+    P = theta.size
+    descs = orc.se_descs(4, 2, 83, 1, "leakyrelu")
+    assert sum(orc.mlp_num_params(d) for d in descs) == P
+    # theta +/- eps (GTN_worker.py:165-175) is what the population step applies: fmaf(sign, eps, theta)
+    plus = np.float32(1.0) * eps + theta
+    assert np.array_equal((theta + eps).astype(np.float32), g["theta_plus"])
+    assert np.array_equal((theta - eps).astype(np.float32), g["theta_minus"])
+    assert np.array_equal(plus.astype(np.float32), g["theta_plus"])
+    best, sign = orc.worker_best(g["score_add"], g["score_sub"], mirrored=True)
+    assert np.array_equal(best, g["score_best"])
+    for i in range(3):
+        assert np.array_equal(sign[i] * eps, g["eps_after"][i])
+        assert np.array_equal((theta + sign[i] * eps).astype(np.float32), g["env_after"][i])
+
+
+def test_g7_master(golden):
+    g = golden("g7_master")
+    for t in range(8):
+        got = orc.score_transform(t, g["scores"], g["scores_orig"])
+        np.testing.assert_allclose(got, g["tf%d" % t], rtol=1e-15, atol=1e-15, err_msg="type %d" % t)
+        tied = orc.score_transform(t, g["tied"], g["scores_orig"])
+        ref = g["tf%d_tied" % t]
+        # ties: np.argsort's order is implementation-defined; the multiset of weights and the weight of
+        # every untied entry must agree
+        np.testing.assert_allclose(np.sort(tied), np.sort(ref), rtol=1e-15, atol=1e-15, err_msg="tied type %d" % t)
+        for val in np.unique(g["tied"]):
+            sel = g["tied"] == val
+            np.testing.assert_allclose(tied[sel].sum(), ref[sel].sum(), rtol=1e-14, atol=1e-15)
+    with pytest.raises(ValueError):
+        orc.score_transform(9, g["scores"], g["scores_orig"])
+    pop = g["eps"].shape[0]
+    sign = np.ones(pop, np.float32)
+    th1 = orc.update_env(g["theta0"], g["eps"], sign, g["weights"], float(g["step_size"]))
+    assert np.array_equal(th1, g["theta1"])
+    th2 = orc.update_env(th1, g["eps"], sign, g["weights"], float(g["step_size"]), nes_step_size=True, weight_decay=0.01)
+    assert np.array_equal(th2, g["theta2"])
+
+
+@pytest.mark.parametrize("name", ["g8_calc_score_cartpole_a", "g8_calc_score_cartpole_b"])
+def test_g8_calc_score_trace(golden, name):
+    import json
+    g = golden(name)
+    cfgd = json.loads(str(g["config_json"]))
+    cfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=13, rng_mode=1, train_episodes=int(g["train_episodes"]),
+                                   max_steps=int(g["max_steps"]))
+    tapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"],
+                           g["tape_test_reset"])
+    n = g["tr_action"].size
+    out = orc.ddqn_se_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 10)
+    assert out["rc"] == 0
+    tr = out["trace"]
+    assert tr["action"].size == n
+    assert np.array_equal(tr["explored"], g["tr_explored"])
+    assert np.array_equal(tr["action"], g["tr_action"])
+    np.testing.assert_allclose(tr["state"], g["tr_state"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(tr["next_state"], g["tr_next_state"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(tr["reward"], g["tr_reward"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(tr["done"], g["tr_done"], rtol=1e-5, atol=1e-5)
+    losses = tr["loss"][~np.isnan(tr["loss"])]
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-3, atol=1e-6)
+    assert np.array_equal(out["episode_len"], g["episode_length_train"])
+    np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out["final_test_returns"], g["reward_list_test"], rtol=0, atol=1e-4)
+    assert abs(out["score"] - float(g["score"])) <= 1e-4
