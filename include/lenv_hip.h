@@ -1,0 +1,161 @@
+/*
+ * lenv_hip.h -- C-ABI of liblenv_hip.so: the MI355X (gfx950) implementation of the NES
+ * inner-loop hot path of automl/learning_environments.
+ *
+ * The reference has no FFI; its boundary for this path is the Python object API
+ * (envs/env_wrapper.py:16-70 EnvWrapper.step, agents/GTN_worker.py:76-108 GTN_Worker.run,
+ * agents/GTN_master.py:81-116 GTN_Master.run).  These entry points are what a ctypes binding
+ * added to those Python classes calls (INTEGRATION.md shows the stubs).  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked HOST;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous
+ *     on that stream, never allocate, never synchronise, and are graph-capturable;
+ *   - return value: 0 = ok, negative = LENV_ERR_* (no exceptions cross the ABI);
+ *   - no internal threads or global mutable state; re-entrant per stream.
+ *
+ * Flat parameter layout of an MLP (models/model_utils.py:4-39), identical to the reference's
+ * state-dict order with PReLU slopes removed: W0[H,in] b0[H] {W_l[H,H] b_l[H]} Wout[out,H] bout[out].
+ * SE theta = state_net | reward_net | done_net (envs/virtual_env.py:23-31).
+ */
+#ifndef LENV_HIP_H
+#define LENV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LENV_ABI_VERSION 1
+
+enum {
+    LENV_OK = 0,
+    LENV_ERR_INVALID = -1,      /* bad argument / inconsistent sizes */
+    LENV_ERR_UNSUPPORTED = -2,  /* shape or option outside what the kernels implement (NotImplementedError) */
+    LENV_ERR_WORKSPACE = -3,    /* workspace too small */
+    LENV_ERR_LAUNCH = -4,       /* HIP launch failed (hipGetLastError) */
+    LENV_ERR_NO_DEVICE = -5
+};
+
+enum { LENV_ACT_IDENTITY = 0, LENV_ACT_RELU = 1, LENV_ACT_LEAKYRELU = 2, LENV_ACT_TANH = 3, LENV_ACT_PRELU = 4 };
+enum { LENV_ENV_CARTPOLE = 0, LENV_ENV_ACROBOT = 1 };
+enum { LENV_RNG_COUNTER = 0, LENV_RNG_TAPE = 1 };
+
+/* models/model_utils.py:4-39 */
+typedef struct {
+    int32_t in_dim, hidden, layers, out_dim, act;
+    float prelu;
+} lenv_mlp_desc;
+
+/* agents/DDQN.py:15-38, agents/base_agent.py:9-26, envs/env_factory.py:45-59 */
+typedef struct {
+    int32_t env_id;
+    int32_t state_dim;
+    int32_t num_actions;
+    int32_t max_steps;
+    int32_t se_hidden, se_layers, se_act;
+    float se_prelu;
+    int32_t q_hidden, q_layers, q_act;
+    float q_prelu;
+    int32_t batch_size, rb_size;
+    int32_t train_episodes, test_episodes, init_episodes;
+    int32_t early_out_num;
+    int32_t grad_chunk;   /* samples per gradient micro-chunk; 0 = ceil(batch/16) */
+    int32_t rng_mode;
+    double solved_reward;
+    double gamma, lr, tau;
+    double eps_init, eps_min, eps_decay;
+    double adam_beta1, adam_beta2, adam_eps;
+} lenv_ddqn_cfg;
+
+/* RNG tapes (parity mode).  Per-chain rows: element [c*stride + n]; all DEVICE pointers. */
+typedef struct {
+    const double *eps_uniform;  int64_t eps_uniform_stride;   /* random.random()         agents/DDQN.py:98 */
+    const int32_t *rand_action; int64_t rand_action_stride;   /* action_space.sample()   envs/env_wrapper.py:88 */
+    const int32_t *replay_idx;  int64_t replay_idx_stride;    /* np.random.randint       utils.py:35 */
+    const double *train_reset;  int64_t train_reset_stride;   /* rows of 4 doubles       envs/virtual_env.py:36 */
+    const double *test_reset;   int64_t test_reset_stride;    /* rows of 4 doubles */
+} lenv_tapes;
+
+/* Outputs of the fused inner loop; every pointer may be NULL except `score`. */
+typedef struct {
+    double *score;              /* [chains] statistics.mean(final test returns)   GTN_worker.py:209 */
+    int64_t *stats;             /* [chains,4] episodes_run, train_steps, learn_steps, test_steps */
+    int32_t *status;            /* [chains] 0 ok, <0 tape underrun / internal error */
+    double *episode_test_mean;  /* [chains,train_episodes]  reward_list_train (NaN past early-out) */
+    int32_t *episode_len;       /* [chains,train_episodes] */
+    double *final_returns;      /* [chains,test_episodes] */
+    float *final_online;        /* [chains,P_agent] trained Q-net (canonical flat layout) */
+    /* optional per-step trace, rows [chains,trace_cap] */
+    int64_t trace_cap;
+    int32_t *trace_action;      /* action | explored<<16 */
+    float *trace_state;         /* [chains,trace_cap,S] */
+    float *trace_next_state;    /* [chains,trace_cap,S] */
+    float *trace_reward_done;   /* [chains,trace_cap,2] */
+} lenv_inner_out;
+
+int lenv_abi_version(void);
+const char *lenv_error_string(int code);
+/* number of parameters of an MLP / of the three-net SE */
+int64_t lenv_mlp_num_params(const lenv_mlp_desc *d /*HOST*/);
+
+/*
+ * Population-batched VirtualEnv step: replaces EnvWrapper.step -> VirtualEnv.step
+ * (envs/env_wrapper.py:16-47, envs/virtual_env.py:43-54) for `chains` perturbed SEs at once,
+ * W_c = theta + sign[c]*eps[worker[c]] (agents/GTN_worker.py:165-175; eps may be NULL).
+ * state [chains,n_per_chain,S], action [chains,n_per_chain] (index), outputs same leading shape.
+ */
+int lenv_se_step_population(const lenv_mlp_desc *state_net /*HOST*/, const lenv_mlp_desc *reward_net /*HOST*/,
+                            const lenv_mlp_desc *done_net /*HOST*/, const float *theta, const float *eps,
+                            const int32_t *worker, const float *sign, int64_t chains, int32_t n_per_chain,
+                            const float *state, const int32_t *action, float *next_state, float *reward,
+                            float *done, void *stream);
+
+/*
+ * DDQN TD forward over replay minibatches (agents/DDQN.py:63-85): for every chain, gathers rows
+ * idx[c,b] of its replay buffer (row = [s(S), a, s'(S), r, done], stride row_stride floats) and writes
+ * q_sa[c,b] = Q(s)[a], y[c,b] = r + gamma * Q_target(s')[argmax Q(s')] * (1 - done).
+ * online/target: [chains,P_agent] flat Critic_DQN parameters (models/actor_critic.py:84-91).
+ */
+int lenv_qnet_td_forward(const lenv_mlp_desc *qnet /*HOST*/, const float *online, const float *target,
+                         const float *replay, int64_t replay_cap, int32_t row_stride, const int32_t *idx,
+                         int64_t chains, int32_t batch, double gamma, float *q_sa, float *y, void *stream);
+
+/*
+ * Fused inner loop = GTN_Worker.calc_score (agents/GTN_worker.py:187-221) for `chains` independent
+ * chains, one workgroup per chain: fresh DDQN agent (agent_init [chains,P_agent]), BaseAgent.train on the
+ * perturbed SE with per-episode real-env tests and early-out (agents/base_agent.py:64-153), final
+ * BaseAgent.test (agents/base_agent.py:155-227).  rng_keys [chains] (counter mode) / tapes (tape mode).
+ * The replay buffers live in `workspace` (lenv_ddqn_se_workspace_bytes).
+ */
+size_t lenv_ddqn_se_workspace_bytes(const lenv_ddqn_cfg *cfg /*HOST*/, int64_t chains);
+int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg /*HOST*/, const float *theta, const float *eps,
+                            const int32_t *worker, const float *sign, const float *agent_init,
+                            const uint64_t *rng_keys, const lenv_tapes *tapes /*HOST struct of device ptrs, may be NULL*/,
+                            int64_t chains, void *workspace, size_t workspace_bytes,
+                            const lenv_inner_out *out /*HOST struct of device ptrs*/, void *stream);
+
+/* Counter-RNG key of a chain (same function as the oracle's): kind 0 = theta, 1 = theta+eps, 2 = theta-eps. HOST. */
+uint64_t lenv_chain_key(uint64_t seed, uint64_t generation, uint64_t worker, uint64_t kind);
+
+/*
+ * GTN_Worker.calc_best_score (agents/GTN_worker.py:234-254) for `pop` workers from the per-chain scores
+ * laid out [pop,3] = (orig, add, sub): result[p] = {score_best, score_orig, sign, 0} (double).
+ */
+int lenv_nes_worker_best(const double *chain_scores, int64_t pop, int32_t mirrored, double *result, void *stream);
+
+/*
+ * GTN_Master.score_transform + update_env (agents/GTN_master.py:197-298) on device.
+ * gathered [pop,4] as produced by lenv_nes_worker_best (after the all-gather); rank_table [pop] doubles =
+ * weight by rank for the rank-only transforms 1,2,3 (host-computed with the reference's numpy formulas);
+ * weights_out [pop] receives score_transform_list; theta [P] is updated in place:
+ * theta <- theta*(1-wd); for i in worker order: theta += (ss*w_i) * (sign_i*eps_i).
+ */
+int lenv_nes_rank_update(int32_t score_transform_type, const double *gathered, const double *rank_table, int64_t pop,
+                         float *theta, const float *eps, int64_t p_theta, double step_size, int32_t nes_step_size,
+                         double weight_decay, double *weights_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,109 @@
+"""ctypes loader for liblenv_hip.so (C-ABI: include/lenv_hip.h).  Fails loudly when the library is absent."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblenv_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+ACT = {"identity": 0, "relu": 1, "leakyrelu": 2, "tanh": 3, "prelu": 4}
+ENV = {"CartPole-v0": 0, "Acrobot-v1": 1}
+RNG_COUNTER, RNG_TAPE = 0, 1
+
+ERRORS = {-1: ValueError, -2: NotImplementedError, -3: ValueError, -4: RuntimeError, -5: RuntimeError}
+
+
+class LenvError(RuntimeError):
+    pass
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("out_dim", C.c_int32),
+                ("act", C.c_int32), ("prelu", C.c_float)]
+
+
+class DdqnCfg(C.Structure):
+    _fields_ = [("env_id", C.c_int32), ("state_dim", C.c_int32), ("num_actions", C.c_int32), ("max_steps", C.c_int32),
+                ("se_hidden", C.c_int32), ("se_layers", C.c_int32), ("se_act", C.c_int32), ("se_prelu", C.c_float),
+                ("q_hidden", C.c_int32), ("q_layers", C.c_int32), ("q_act", C.c_int32), ("q_prelu", C.c_float),
+                ("batch_size", C.c_int32), ("rb_size", C.c_int32),
+                ("train_episodes", C.c_int32), ("test_episodes", C.c_int32), ("init_episodes", C.c_int32),
+                ("early_out_num", C.c_int32), ("grad_chunk", C.c_int32), ("rng_mode", C.c_int32),
+                ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
+                ("eps_init", C.c_double), ("eps_min", C.c_double), ("eps_decay", C.c_double),
+                ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
+
+
+class Tapes(C.Structure):
+    _fields_ = [("eps_uniform", C.c_void_p), ("eps_uniform_stride", C.c_int64),
+                ("rand_action", C.c_void_p), ("rand_action_stride", C.c_int64),
+                ("replay_idx", C.c_void_p), ("replay_idx_stride", C.c_int64),
+                ("train_reset", C.c_void_p), ("train_reset_stride", C.c_int64),
+                ("test_reset", C.c_void_p), ("test_reset_stride", C.c_int64)]
+
+
+class InnerOut(C.Structure):
+    _fields_ = [("score", C.c_void_p), ("stats", C.c_void_p), ("status", C.c_void_p),
+                ("episode_test_mean", C.c_void_p), ("episode_len", C.c_void_p), ("final_returns", C.c_void_p),
+                ("final_online", C.c_void_p), ("trace_cap", C.c_int64), ("trace_action", C.c_void_p),
+                ("trace_state", C.c_void_p), ("trace_next_state", C.c_void_p), ("trace_reward_done", C.c_void_p)]
+
+
+EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv_se_step_population",
+           "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_inner_loop", "lenv_chain_key",
+           "lenv_nes_worker_best", "lenv_nes_rank_update"]
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 into liblenv_hip.so (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LenvError("liblenv_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
+                            "g.build()'` or `make -C learning_environments_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.lenv_abi_version.restype = C.c_int
+        L.lenv_error_string.restype = C.c_char_p
+        L.lenv_error_string.argtypes = [C.c_int]
+        L.lenv_mlp_num_params.restype = C.c_int64
+        L.lenv_mlp_num_params.argtypes = [C.POINTER(MlpDesc)]
+        L.lenv_chain_key.restype = C.c_uint64
+        L.lenv_chain_key.argtypes = [C.c_uint64] * 4
+        L.lenv_ddqn_se_workspace_bytes.restype = C.c_size_t
+        L.lenv_ddqn_se_workspace_bytes.argtypes = [C.POINTER(DdqnCfg), C.c_int64]
+        vp = C.c_void_p
+        L.lenv_se_step_population.restype = C.c_int
+        L.lenv_se_step_population.argtypes = [C.POINTER(MlpDesc)] * 3 + [vp, vp, vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp]
+        L.lenv_qnet_td_forward.restype = C.c_int
+        L.lenv_qnet_td_forward.argtypes = [C.POINTER(MlpDesc), vp, vp, vp, C.c_int64, C.c_int32, vp, C.c_int64, C.c_int32,
+                                           C.c_double, vp, vp, vp]
+        L.lenv_ddqn_se_inner_loop.restype = C.c_int
+        L.lenv_ddqn_se_inner_loop.argtypes = [C.POINTER(DdqnCfg), vp, vp, vp, vp, vp, vp, C.POINTER(Tapes), C.c_int64, vp,
+                                              C.c_size_t, C.POINTER(InnerOut), vp]
+        L.lenv_nes_worker_best.restype = C.c_int
+        L.lenv_nes_worker_best.argtypes = [vp, C.c_int64, C.c_int32, vp, vp]
+        L.lenv_nes_rank_update.restype = C.c_int
+        L.lenv_nes_rank_update.argtypes = [C.c_int32, vp, vp, C.c_int64, vp, vp, C.c_int64, C.c_double, C.c_int32,
+                                           C.c_double, vp, vp]
+        if L.lenv_abi_version() != 1:
+            raise LenvError("liblenv_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().lenv_error_string(rc).decode()
+        raise ERRORS.get(rc, LenvError)("%s: %s (%d)" % (what, msg, rc))

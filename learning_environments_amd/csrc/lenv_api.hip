@@ -1,0 +1,26 @@
+// lenv_api.hip -- ABI housekeeping entry points of liblenv_hip.so (include/lenv_hip.h).
+#include "lenv_device.cuh"
+
+extern "C" int lenv_abi_version(void) { return LENV_ABI_VERSION; }
+
+extern "C" const char *lenv_error_string(int code)
+{
+    switch (code) {
+    case LENV_OK: return "ok";
+    case LENV_ERR_INVALID: return "invalid argument";
+    case LENV_ERR_UNSUPPORTED: return "unsupported shape or option";
+    case LENV_ERR_WORKSPACE: return "workspace too small";
+    case LENV_ERR_LAUNCH: return "HIP launch failed";
+    case LENV_ERR_NO_DEVICE: return "no HIP device";
+    default: return "unknown error";
+    }
+}
+
+// same key schedule as the oracle's orc_chain_key
+extern "C" uint64_t lenv_chain_key(uint64_t seed, uint64_t generation, uint64_t worker, uint64_t kind)
+{
+    uint64_t k = lenv::mix64(seed + 0x9e3779b97f4a7c15ULL);
+    k = lenv::mix64(k ^ (generation + 0x9e3779b97f4a7c15ULL * 2));
+    k = lenv::mix64(k ^ (worker * 4 + kind + 0x9e3779b97f4a7c15ULL * 3));
+    return k;
+}

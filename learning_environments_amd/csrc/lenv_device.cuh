@@ -1,0 +1,210 @@
+// lenv_device.cuh -- device-side building blocks shared by the gfx950 kernels.
+//
+// Floating-point contract: compiled with -ffp-contract=off; an FMA exists only where
+// __builtin_fmaf/__builtin_fma is written.  '/' and sqrtf are IEEE correctly rounded (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt).  The transcendental routines below are fixed polynomial
+// sequences (no ocml calls), so a gcc/x86 build of the same sequence is bitwise identical.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lenv_hip.h"
+
+#define LENV_WAVE 64
+
+namespace lenv {
+
+__device__ __forceinline__ float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma64(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// tanh(x) = em1/(em1+2), em1 = expm1(2|x|) = 2^k*(r*Q(r)) + (2^k-1); |r| <= ln2/2, Q Taylor to r^7.
+__device__ __forceinline__ float det_tanhf(float x)
+{
+    float ax = __builtin_fabsf(x);
+    ax = ax > 10.0f ? 10.0f : ax;
+    float y = ax + ax;
+    float kf = __builtin_rintf(y * 1.44269504088896341f);
+    float r = fma32(-kf, 0.693145751953125f, y);
+    r = fma32(-kf, 1.42860682030941723212e-6f, r);
+    float q = 2.48015873015873e-5f;
+    q = fma32(q, r, 1.98412698412698e-4f);
+    q = fma32(q, r, 1.38888888888889e-3f);
+    q = fma32(q, r, 8.33333333333333e-3f);
+    q = fma32(q, r, 4.16666666666667e-2f);
+    q = fma32(q, r, 1.66666666666667e-1f);
+    q = fma32(q, r, 0.5f);
+    q = fma32(q, r, 1.0f);
+    float p = r * q;
+    int k = (int)kf;
+    float s = __int_as_float((k + 127) << 23);
+    float em1 = fma32(s, p, s - 1.0f);
+    float t = em1 / (em1 + 2.0f);
+    return __builtin_copysignf(t, x);
+}
+
+__device__ __forceinline__ double det_ksin(double x)
+{
+    double z = x * x;
+    double p = 1.58969099521155010221e-10;
+    p = fma64(p, z, -2.50507602534068634195e-08);
+    p = fma64(p, z, 2.75573137070700676789e-06);
+    p = fma64(p, z, -1.98412698298579493134e-04);
+    p = fma64(p, z, 8.33333333332248946124e-03);
+    p = fma64(p, z, -1.66666666666666324348e-01);
+    return fma64(x * z, p, x);
+}
+
+__device__ __forceinline__ double det_kcos(double x)
+{
+    double z = x * x;
+    double p = -1.13596475577881948265e-11;
+    p = fma64(p, z, 2.08757232129817482790e-09);
+    p = fma64(p, z, -2.75573143513906633035e-07);
+    p = fma64(p, z, 2.48015872894767294178e-05);
+    p = fma64(p, z, -1.38888888888741095749e-03);
+    p = fma64(p, z, 4.16666666666666019037e-02);
+    return 1.0 - fma64(-z * z, p, 0.5 * z);
+}
+
+__device__ __forceinline__ void det_reduce(double x, double &r, int &q)
+{
+    double kf = __builtin_rint(x * 6.36619772367581382433e-01);
+    double t = fma64(-kf, 1.57079632673412561417e+00, x);
+    t = fma64(-kf, 6.07710050630396597660e-11, t);
+    t = fma64(-kf, 2.02226624871116645580e-21, t);
+    r = t;
+    q = (int)((long long)kf & 3);
+}
+
+__device__ __forceinline__ double det_sin(double x)
+{
+    double r; int q;
+    det_reduce(x, r, q);
+    double s = det_ksin(r), c = det_kcos(r);
+    double v = (q & 1) ? c : s;
+    return (q & 2) ? -v : v;
+}
+
+__device__ __forceinline__ double det_cos(double x)
+{
+    double r; int q;
+    det_reduce(x, r, q);
+    double s = det_ksin(r), c = det_kcos(r);
+    double v = (q & 1) ? s : c;
+    return ((q + 1) & 2) ? -v : v;
+}
+
+// counter RNG: value = mix(mix(key + G*((stream<<56)^n)) ^ key); two splitmix64 finalisers
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+
+__host__ __device__ __forceinline__ uint64_t rng_u64(uint64_t key, uint32_t stream, uint64_t n)
+{
+    uint64_t x = key + 0x9e3779b97f4a7c15ULL * (((uint64_t)stream << 56) ^ n);
+    return mix64(mix64(x) ^ key);
+}
+
+__device__ __forceinline__ double u64_to_unit(uint64_t u) { return (double)(u >> 11) * (1.0 / 9007199254740992.0); }
+__device__ __forceinline__ uint32_t u64_to_below(uint64_t u, uint32_t n) { return (uint32_t)(((u >> 32) * (uint64_t)n) >> 32); }
+
+enum { STREAM_EPS = 0, STREAM_ACTION = 1, STREAM_REPLAY = 2, STREAM_TRAIN_RESET = 3, STREAM_TEST_RESET = 4 };
+
+__device__ __forceinline__ float act_fwd(int act, float prelu, float z)
+{
+    switch (act) {
+    case LENV_ACT_RELU: return z > 0.0f ? z : 0.0f;
+    case LENV_ACT_LEAKYRELU: return z > 0.0f ? z : z * 0.01f;
+    case LENV_ACT_TANH: return det_tanhf(z);
+    case LENV_ACT_PRELU: return z > 0.0f ? z : prelu * z;
+    default: return z;
+    }
+}
+
+// upstream gradient g through the activation, given the activation value a (sign(a) == sign(z) for the
+// piecewise-linear activations, slopes are positive)
+__device__ __forceinline__ float act_bwd(int act, float prelu, float a, float g)
+{
+    switch (act) {
+    case LENV_ACT_RELU: return a > 0.0f ? g : 0.0f;
+    case LENV_ACT_LEAKYRELU: return a > 0.0f ? g : g * 0.01f;
+    case LENV_ACT_TANH: return g * fma32(-a, a, 1.0f);
+    case LENV_ACT_PRELU: return a > 0.0f ? g : prelu * g;
+    default: return g;
+    }
+}
+
+// gym==0.17.3 CartPole-v0 dynamics (third party; oracle: orc_cartpole_step)
+__device__ __forceinline__ void cartpole_step(double st[4], int action, double &reward, int &done)
+{
+    const double gravity = 9.8, masscart = 1.0, masspole = 0.1, length = 0.5, force_mag = 10.0, tau = 0.02;
+    const double total_mass = masspole + masscart;
+    const double polemass_length = masspole * length;
+    const double theta_thr = 12 * 2 * 3.141592653589793 / 360;
+    const double x_thr = 2.4;
+    double x = st[0], x_dot = st[1], theta = st[2], theta_dot = st[3];
+    double force = action == 1 ? force_mag : -force_mag;
+    double costheta = det_cos(theta), sintheta = det_sin(theta);
+    double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
+    double thetaacc = (gravity * sintheta - costheta * temp) /
+                      (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
+    double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+    x = x + tau * x_dot;
+    x_dot = x_dot + tau * xacc;
+    theta = theta + tau * theta_dot;
+    theta_dot = theta_dot + tau * thetaacc;
+    st[0] = x; st[1] = x_dot; st[2] = theta; st[3] = theta_dot;
+    done = (x < -x_thr || x > x_thr || theta < -theta_thr || theta > theta_thr) ? 1 : 0;
+    reward = 1.0;
+}
+
+__device__ __forceinline__ void acrobot_dsdt(const double s[5], double out[5])
+{
+    const double m1 = 1., m2 = 1., l1 = 1., lc1 = .5, lc2 = .5, I1 = 1., I2 = 1., g = 9.8, pi = 3.141592653589793;
+    double a = s[4], theta1 = s[0], theta2 = s[1], dtheta1 = s[2], dtheta2 = s[3];
+    double c2 = det_cos(theta2), s2 = det_sin(theta2);
+    double d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * c2) + I1 + I2;
+    double d2 = m2 * (lc2 * lc2 + l1 * lc2 * c2) + I2;
+    double phi2 = m2 * lc2 * g * det_cos(theta1 + theta2 - pi / 2.);
+    double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * s2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2 +
+                  (m1 * lc1 + m2 * l1) * g * det_cos(theta1 - pi / 2) + phi2;
+    double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
+                      (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
+    double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
+    out[0] = dtheta1; out[1] = dtheta2; out[2] = ddtheta1; out[3] = ddtheta2; out[4] = 0.;
+}
+
+__device__ __forceinline__ void acrobot_step(double st[4], int action, double &reward, int &done)
+{
+    const double pi = 3.141592653589793, dt = .2, dt2 = .2 / 2.0;
+    const double max_vel1 = 4 * pi, max_vel2 = 9 * pi;
+    double y0[5] = { st[0], st[1], st[2], st[3], (double)(action - 1) };
+    double k1[5], k2[5], k3[5], k4[5], tmp[5], ns[5];
+    acrobot_dsdt(y0, k1);
+    for (int i = 0; i < 5; ++i) tmp[i] = y0[i] + dt2 * k1[i];
+    acrobot_dsdt(tmp, k2);
+    for (int i = 0; i < 5; ++i) tmp[i] = y0[i] + dt2 * k2[i];
+    acrobot_dsdt(tmp, k3);
+    for (int i = 0; i < 5; ++i) tmp[i] = y0[i] + dt * k3[i];
+    acrobot_dsdt(tmp, k4);
+    for (int i = 0; i < 5; ++i) ns[i] = y0[i] + dt / 6.0 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+    for (int i = 0; i < 2; ++i) {
+        double x = ns[i], diff = pi - (-pi);
+        while (x > pi) x = x - diff;
+        while (x < -pi) x = x + diff;
+        ns[i] = x;
+    }
+    ns[2] = __builtin_fmin(__builtin_fmax(ns[2], -max_vel1), max_vel1);
+    ns[3] = __builtin_fmin(__builtin_fmax(ns[3], -max_vel2), max_vel2);
+    for (int i = 0; i < 4; ++i) st[i] = ns[i];
+    int terminal = (-det_cos(st[0]) - det_cos(st[1] + st[0]) > 1.) ? 1 : 0;
+    done = terminal;
+    reward = terminal ? 0. : -1.;
+}
+
+}  // namespace lenv

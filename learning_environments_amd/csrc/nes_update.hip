@@ -1,0 +1,160 @@
+// nes_update.hip -- GTN worker/master aggregation on device (K11 + K12 of SURVEY.md §2a) for gfx950.
+//
+//   lenv_nes_worker_best : GTN_Worker.calc_best_score   agents/GTN_worker.py:234-254
+//   lenv_nes_rank_update : GTN_Master.score_transform   agents/GTN_master.py:197-265
+//                        + GTN_Master.update_env        agents/GTN_master.py:267-298
+//
+// Every rank runs these redundantly on bit-identical gathered scores, so theta stays identical on all ranks
+// with no broadcast.  Ranking is O(pop^2) compare-count with a documented stable order (ties: lower worker id
+// first); the rank-only utilities (types 1,2,3) come from a host table computed with the reference's numpy
+// formulas, score-dependent types (0,4,5,6,7) are plain fp64 arithmetic here.  The theta update streams the
+// noise tensor eps[pop,P] coalesced along P, accumulating sequentially over workers in id order in fp32,
+// exactly like the reference's python loop.
+#include "lenv_device.cuh"
+
+namespace lenv {
+
+__global__ void worker_best_kernel(const double *chain_scores, int64_t pop, int mirrored, double *result)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= pop) return;
+    const double orig = chain_scores[p * 3], add = chain_scores[p * 3 + 1], sub = chain_scores[p * 3 + 2];
+    double best = add, sign = 1.0;
+    if (mirrored) {
+        best = add > sub ? add : sub;        // max(score_add, score_sub)
+        sign = sub > add ? -1.0 : 1.0;       // invert_eps() iff score_sub > score_add
+    }
+    result[p * 4] = best; result[p * 4 + 1] = orig; result[p * 4 + 2] = sign; result[p * 4 + 3] = 0.0;
+}
+
+constexpr int RT_NT = 1024;
+
+// single workgroup: weights_out[i] = score_transform(scores)[i]
+__global__ __launch_bounds__(RT_NT) void score_transform_kernel(int type, const double *gathered, const double *rank_table,
+                                                                int64_t pop, double *weights_out)
+{
+    __shared__ double red[RT_NT];
+    __shared__ double sh[4];
+    const int tid = threadIdx.x;
+    auto score = [&](int64_t i) { return gathered[i * 4]; };
+    auto orig = [&](int64_t i) { return gathered[i * 4 + 1]; };
+
+    if (type == 1 || type == 2 || type == 3) {
+        for (int64_t i = tid; i < pop; i += RT_NT) {
+            const double si = score(i);
+            int64_t rank = 0;
+            if (type == 1) { for (int64_t j = 0; j < pop; ++j) { double sj = score(j); rank += (sj < si) || (sj == si && j < i); } }
+            else { for (int64_t j = 0; j < pop; ++j) { double sj = score(j); rank += (sj > si) || (sj == si && j < i); } }
+            weights_out[i] = rank_table[rank];
+        }
+        if (type == 1) return;
+        // types 2/3: rank_table holds the raw utilities max(0, log(n/2+1) - log(rank)); the normalisations run in
+        // worker order like the reference's `scores / sum(scores)`, `scores /= max(scores)` (GTN_master.py:221-227)
+        __syncthreads();
+        if (tid == 0) {
+            double sm = 0.0;
+            for (int64_t i = 0; i < pop; ++i) sm += weights_out[i];
+            double mx = 0.0;
+            for (int64_t i = 0; i < pop; ++i) {
+                double w = weights_out[i] / sm;
+                if (type == 2) w -= 1.0 / (double)pop;
+                weights_out[i] = w;
+                if (i == 0 || w > mx) mx = w;
+            }
+            sh[0] = mx;
+        }
+        __syncthreads();
+        const double mx = sh[0];
+        for (int64_t i = tid; i < pop; i += RT_NT) weights_out[i] = weights_out[i] / mx;
+        return;
+    }
+    // sequential reductions by thread 0 keep python's sum()/min()/max() order
+    if (tid == 0) {
+        double mn = score(0), mx = score(0), so = 0.0;
+        int64_t am = 0, cnt = 0;
+        for (int64_t i = 0; i < pop; ++i) {
+            const double s = score(i);
+            if (s < mn) mn = s;
+            if (s > mx) { mx = s; am = i; }
+            so += orig(i);
+        }
+        const double avg = so / (double)pop;
+        for (int64_t i = 0; i < pop; ++i) cnt += score(i) > avg + 1e-6;
+        sh[0] = mn; sh[1] = mx; sh[2] = avg; sh[3] = (double)am;
+        red[0] = (double)cnt;
+    }
+    __syncthreads();
+    const double mn = sh[0], mx = sh[1], avg = sh[2];
+    const int64_t am = (int64_t)sh[3], cnt = (int64_t)red[0];
+    __syncthreads();
+    if (type == 0) {
+        for (int64_t i = tid; i < pop; i += RT_NT) weights_out[i] = (score(i) - mn) / (mx - mn + 1e-9);
+    } else if (type == 4 || (type == 5 && cnt > 0)) {
+        for (int64_t i = tid; i < pop; i += RT_NT) weights_out[i] = i == am ? 1.0 : 0.0;
+    } else if ((type == 6 || type == 7) && cnt > 0) {
+        for (int64_t i = tid; i < pop; i += RT_NT) {
+            const double idx = score(i) > avg + 1e-6 ? 1.0 : 0.0;
+            weights_out[i] = idx * (score(i) - avg) / (mx - avg + 1e-9);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double m2 = weights_out[0], s2 = 0.0;
+            for (int64_t i = 0; i < pop; ++i) { double w = weights_out[i]; if (w > m2) m2 = w; s2 += w; }
+            sh[0] = type == 6 ? m2 : s2;
+        }
+        __syncthreads();
+        const double dv = sh[0];
+        for (int64_t i = tid; i < pop; i += RT_NT) weights_out[i] = weights_out[i] / dv;
+    } else {
+        for (int64_t i = tid; i < pop; i += RT_NT) weights_out[i] = 0.0;
+    }
+}
+
+__global__ void update_env_kernel(float *theta, const float *eps, const double *gathered, const double *weights, int64_t pop,
+                                  int64_t P, double ss, float decay)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float t = theta[i] * decay;                                   // weight decay, GTN_master.py:281-286
+    for (int64_t w = 0; w < pop; ++w) {
+        const float c = (float)(ss * weights[w]);                 // (ss * score_transform) * eps
+        const float sg = (float)gathered[w * 4 + 2];              // mirrored sampling: eps := -eps
+        t = t + c * (sg * eps[w * P + i]);
+    }
+    theta[i] = t;
+}
+
+}  // namespace lenv
+
+using namespace lenv;
+
+extern "C" int lenv_nes_worker_best(const double *chain_scores, int64_t pop, int32_t mirrored, double *result, void *stream)
+{
+    if (!chain_scores || !result || pop < 0) return LENV_ERR_INVALID;
+    if (pop == 0) return LENV_OK;
+    hipLaunchKernelGGL(worker_best_kernel, dim3((unsigned)((pop + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       chain_scores, pop, mirrored, result);
+    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}
+
+extern "C" int lenv_nes_rank_update(int32_t type, const double *gathered, const double *rank_table, int64_t pop, float *theta,
+                                    const float *eps, int64_t p_theta, double step_size, int32_t nes_step_size,
+                                    double weight_decay, double *weights_out, void *stream)
+{
+    if (!gathered || !weights_out || pop < 1) return LENV_ERR_INVALID;
+    if (type < 0 || type > 7) return LENV_ERR_INVALID;            // ValueError("Unknown rank transform type") GTN_master.py:263
+    if ((type >= 1 && type <= 3) && !rank_table) return LENV_ERR_INVALID;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(score_transform_kernel, dim3(1), dim3(RT_NT), 0, st, (int)type, gathered, rank_table, pop, weights_out);
+    if (hipGetLastError() != hipSuccess) return LENV_ERR_LAUNCH;
+    if (theta) {
+        if (!eps || p_theta < 1) return LENV_ERR_INVALID;
+        double ss = step_size;
+        if (nes_step_size) ss = ss / (double)pop;
+        const float decay = (float)(1.0 - weight_decay);
+        hipLaunchKernelGGL(update_env_kernel, dim3((unsigned)((p_theta + 255) / 256)), dim3(256), 0, st, theta, eps, gathered,
+                           weights_out, pop, p_theta, ss, decay);
+        if (hipGetLastError() != hipSuccess) return LENV_ERR_LAUNCH;
+    }
+    return LENV_OK;
+}

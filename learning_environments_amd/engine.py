@@ -1,0 +1,168 @@
+"""Tensor-level host wrappers over the C-ABI (torch is plumbing: device memory + streams).
+
+Every function takes/returns torch CUDA(HIP) tensors and enqueues on torch's current stream.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import DdqnCfg, InnerOut, MlpDesc, Tapes
+
+
+def require_device():
+    if not torch.cuda.is_available():
+        raise _lib.LenvError("learning_environments_amd needs a HIP device (MI355X); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise ValueError("%s must be a contiguous CUDA tensor of dtype %s" % (name, dtype))
+    return t
+
+
+def mlp_desc(in_dim, hidden, layers, out_dim, act, prelu=0.25):
+    return MlpDesc(int(in_dim), int(hidden), int(layers), int(out_dim), _lib.ACT[act] if isinstance(act, str) else int(act),
+                   float(prelu))
+
+
+def mlp_num_params(d):
+    return int(_lib.lib().lenv_mlp_num_params(C.byref(d)))
+
+
+def se_descs(S, A, hidden, layers, act, prelu=0.25):
+    return (mlp_desc(S + A, hidden, layers, S, act, prelu), mlp_desc(S + A, hidden, layers, 1, act, prelu),
+            mlp_desc(S + A, hidden, layers, 1, act, prelu))
+
+
+def se_step_population(descs, theta, eps, worker, sign, state, action):
+    """state [chains,S] or [chains,n,S]; action int32 [chains] or [chains,n].  Returns (next_state, reward, done)."""
+    dev = require_device()
+    sn, rn, dn = descs
+    squeeze = state.dim() == 2
+    if squeeze:
+        state, action = state.unsqueeze(1), action.unsqueeze(1)
+    chains, n, S = state.shape
+    _chk(theta, torch.float32, "theta"); _chk(state, torch.float32, "state"); _chk(action, torch.int32, "action")
+    _chk(eps, torch.float32, "eps"); _chk(worker, torch.int32, "worker"); _chk(sign, torch.float32, "sign")
+    ns = torch.empty((chains, n, S), dtype=torch.float32, device=dev)
+    r = torch.empty((chains, n), dtype=torch.float32, device=dev)
+    d = torch.empty((chains, n), dtype=torch.float32, device=dev)
+    rc = _lib.lib().lenv_se_step_population(C.byref(sn), C.byref(rn), C.byref(dn), _ptr(theta), _ptr(eps), _ptr(worker),
+                                            _ptr(sign), chains, n, _ptr(state), _ptr(action), _ptr(ns), _ptr(r), _ptr(d),
+                                            _stream())
+    _lib.check(rc, "lenv_se_step_population")
+    if squeeze:
+        return ns[:, 0], r[:, 0], d[:, 0]
+    return ns, r, d
+
+
+def qnet_td_forward(qd, online, target, replay, idx, gamma):
+    """online/target [chains,P]; replay [chains,cap,row_stride]; idx int32 [chains,B] -> (q_sa, y) [chains,B]."""
+    dev = require_device()
+    for t, n in ((online, "online"), (target, "target"), (replay, "replay")):
+        _chk(t, torch.float32, n)
+    _chk(idx, torch.int32, "idx")
+    chains, cap, stride = replay.shape
+    B = idx.shape[1]
+    q_sa = torch.empty((chains, B), dtype=torch.float32, device=dev)
+    y = torch.empty((chains, B), dtype=torch.float32, device=dev)
+    rc = _lib.lib().lenv_qnet_td_forward(C.byref(qd), _ptr(online), _ptr(target), _ptr(replay), cap, stride, _ptr(idx),
+                                         chains, B, float(gamma), _ptr(q_sa), _ptr(y), _stream())
+    _lib.check(rc, "lenv_qnet_td_forward")
+    return q_sa, y
+
+
+def chain_key(seed, generation, worker, kind):
+    return int(_lib.lib().lenv_chain_key(seed, generation, worker, kind))
+
+
+class InnerLoop(object):
+    """Owns the workspace/outputs of lenv_ddqn_se_inner_loop for a fixed (cfg, chains)."""
+
+    def __init__(self, cfg, chains, want_episode_stats=True, want_final_online=False, trace_cap=0):
+        self.dev = require_device()
+        self.cfg, self.chains = cfg, int(chains)
+        L = _lib.lib()
+        self.ws_bytes = int(L.lenv_ddqn_se_workspace_bytes(C.byref(cfg), self.chains))
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
+        E, T, S = cfg.train_episodes, cfg.test_episodes, cfg.state_dim
+        qd = mlp_desc(S, cfg.q_hidden, cfg.q_layers, cfg.num_actions, cfg.q_act)
+        self.p_agent = mlp_num_params(qd)
+        self.score = torch.zeros(self.chains, dtype=torch.float64, device=self.dev)
+        self.stats = torch.zeros((self.chains, 4), dtype=torch.int64, device=self.dev)
+        self.status = torch.zeros(self.chains, dtype=torch.int32, device=self.dev)
+        self.episode_test_mean = self.episode_len = self.final_returns = self.final_online = None
+        if want_episode_stats:
+            self.episode_test_mean = torch.zeros((self.chains, max(E, 1)), dtype=torch.float64, device=self.dev)
+            self.episode_len = torch.zeros((self.chains, max(E, 1)), dtype=torch.int32, device=self.dev)
+            self.final_returns = torch.zeros((self.chains, T), dtype=torch.float64, device=self.dev)
+        if want_final_online:
+            self.final_online = torch.zeros((self.chains, self.p_agent), dtype=torch.float32, device=self.dev)
+        self.trace_cap = int(trace_cap)
+        self.trace = None
+        if trace_cap:
+            self.trace = dict(action=torch.zeros((self.chains, trace_cap), dtype=torch.int32, device=self.dev),
+                              state=torch.zeros((self.chains, trace_cap, S), dtype=torch.float32, device=self.dev),
+                              next_state=torch.zeros((self.chains, trace_cap, S), dtype=torch.float32, device=self.dev),
+                              reward_done=torch.zeros((self.chains, trace_cap, 2), dtype=torch.float32, device=self.dev))
+        tr = self.trace or {}
+        self.out = InnerOut(_ptr(self.score), _ptr(self.stats), _ptr(self.status), _ptr(self.episode_test_mean),
+                            _ptr(self.episode_len), _ptr(self.final_returns), _ptr(self.final_online), self.trace_cap,
+                            _ptr(tr.get("action")), _ptr(tr.get("state")), _ptr(tr.get("next_state")),
+                            _ptr(tr.get("reward_done")))
+
+    def run(self, theta, eps, worker, sign, agent_init, rng_keys=None, tapes=None):
+        """Enqueue one fused inner loop for all chains on the current stream (asynchronous)."""
+        _chk(theta, torch.float32, "theta"); _chk(eps, torch.float32, "eps"); _chk(worker, torch.int32, "worker")
+        _chk(sign, torch.float32, "sign"); _chk(agent_init, torch.float32, "agent_init")
+        if agent_init.shape != (self.chains, self.p_agent):
+            raise ValueError("agent_init must be [chains, %d]" % self.p_agent)
+        t = None
+        if tapes is not None:
+            t = Tapes(_ptr(tapes["eps_uniform"]), tapes["eps_uniform"].shape[1],
+                      _ptr(tapes["rand_action"]), tapes["rand_action"].shape[1],
+                      _ptr(tapes["replay_idx"]), tapes["replay_idx"].shape[1],
+                      _ptr(tapes["train_reset"]), tapes["train_reset"].shape[1],
+                      _ptr(tapes["test_reset"]), tapes["test_reset"].shape[1])
+        if rng_keys is not None:
+            _chk(rng_keys, torch.int64, "rng_keys")
+        rc = _lib.lib().lenv_ddqn_se_inner_loop(C.byref(self.cfg), _ptr(theta), _ptr(eps), _ptr(worker), _ptr(sign),
+                                                _ptr(agent_init), _ptr(rng_keys), C.byref(t) if t is not None else None,
+                                                self.chains, _ptr(self.workspace), self.ws_bytes, C.byref(self.out), _stream())
+        _lib.check(rc, "lenv_ddqn_se_inner_loop")
+        return self.score
+
+
+def nes_worker_best(chain_scores, pop, mirrored=True):
+    dev = require_device()
+    _chk(chain_scores, torch.float64, "chain_scores")
+    result = torch.empty((pop, 4), dtype=torch.float64, device=dev)
+    rc = _lib.lib().lenv_nes_worker_best(_ptr(chain_scores), pop, 1 if mirrored else 0, _ptr(result), _stream())
+    _lib.check(rc, "lenv_nes_worker_best")
+    return result
+
+
+def nes_rank_update(score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size=False, weight_decay=0.0):
+    """In-place theta update; returns the score_transform weights [pop] (float64)."""
+    dev = require_device()
+    _chk(gathered, torch.float64, "gathered"); _chk(rank_table, torch.float64, "rank_table")
+    _chk(theta, torch.float32, "theta"); _chk(eps, torch.float32, "eps")
+    pop = gathered.shape[0]
+    weights = torch.empty(pop, dtype=torch.float64, device=dev)
+    rc = _lib.lib().lenv_nes_rank_update(int(score_transform_type), _ptr(gathered), _ptr(rank_table), pop, _ptr(theta),
+                                         _ptr(eps), theta.numel() if theta is not None else 0, float(step_size),
+                                         1 if nes_step_size else 0, float(weight_decay), _ptr(weights), _stream())
+    _lib.check(rc, "lenv_nes_rank_update")
+    return weights

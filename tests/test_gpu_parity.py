@@ -1,0 +1,261 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI of liblenv_hip.so) against the CPU oracle on the
+same seeded inputs, and against the committed golden vectors produced by the reference.
+
+Bar: BIT-EXACT against the oracle (the kernels implement the oracle's canonical fp32 order; integer/index
+work is exact by construction); within the fixture tolerances of tests/test_oracle_golden.py against the
+reference's own numbers (torch's summation order / tanh differ from the canonical order by O(1e-7)).
+"""
+import json
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+ACTS = ["identity", "relu", "leakyrelu", "tanh", "prelu"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from learning_environments_amd import engine
+    engine.require_device()
+    return engine
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def test_native_library_loaded(eng):
+    from learning_environments_amd import _lib
+    assert _lib.lib().lenv_abi_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "liblenv_hip.so" in f.read()
+
+
+def test_se_step_population_golden_and_oracle(eng, orc, golden):
+    g = golden("g1_virtual_env_step")
+    rng = np.random.RandomState(0)
+    for ci in range(int(g["n_cases"])):
+        pre = "c%02d_" % ci
+        S, A, H, L, act = [int(v) for v in g[pre + "meta"]]
+        theta, state, action = g[pre + "theta"], g[pre + "state"], g[pre + "action"]
+        n = state.shape[0]
+        # (a) unperturbed, against the reference's outputs and the oracle
+        ns, r, d = eng.se_step_population(eng.se_descs(S, A, H, L, ACTS[act]), dev(theta), None, None, None, dev(state), dev(action))
+        ons, orr, od = orc.se_step_population(orc.se_descs(S, A, H, L, ACTS[act]), theta, None, None, None, state, action)
+        assert np.array_equal(ns.cpu().numpy(), ons), pre
+        assert np.array_equal(r.cpu().numpy(), orr), pre
+        assert np.array_equal(d.cpu().numpy(), od), pre
+        np.testing.assert_allclose(ns.cpu().numpy(), g[pre + "next_state"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(r.cpu().numpy(), g[pre + "reward"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(d.cpu().numpy(), g[pre + "done"], rtol=2e-6, atol=2e-6)
+        # (b) perturbed population: chains = 3*pop over pop noise rows
+        pop = 4
+        eps = (rng.randn(pop, theta.size) * 0.05).astype(np.float32)
+        worker = np.repeat(np.arange(pop), 3).astype(np.int32)
+        sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), pop)
+        st = np.tile(state[:1], (3 * pop, 1)) + rng.randn(3 * pop, S).astype(np.float32) * 0.1
+        ac = rng.randint(0, A, 3 * pop).astype(np.int32)
+        ns, r, d = eng.se_step_population(eng.se_descs(S, A, H, L, ACTS[act]), dev(theta), dev(eps), dev(worker), dev(sign), dev(st), dev(ac))
+        ons, orr, od = orc.se_step_population(orc.se_descs(S, A, H, L, ACTS[act]), theta, eps, worker, sign, st, ac)
+        assert np.array_equal(ns.cpu().numpy(), ons), pre
+        assert np.array_equal(r.cpu().numpy(), orr) and np.array_equal(d.cpu().numpy(), od), pre
+
+
+def test_se_step_batched_states(eng, orc, golden):
+    # EnvWrapper.step(action, state=batched) (env_wrapper.py:33-40): several states per chain
+    g = golden("g1_virtual_env_step")
+    S, A, H, L, act = [int(v) for v in g["c00_meta"]]
+    theta, state, action = g["c00_theta"], g["c00_state"], g["c00_action"]
+    ns, r, d = eng.se_step_population(eng.se_descs(S, A, H, L, ACTS[act]), dev(theta), None, None, None,
+                                      dev(state.reshape(2, 6, S)), dev(action.reshape(2, 6)))
+    np.testing.assert_allclose(ns.cpu().numpy().reshape(-1, S), g["c00_next_state"], rtol=2e-6, atol=2e-6)
+    ons, _, _ = orc.se_step_population(orc.se_descs(S, A, H, L, ACTS[act]), theta, None, None, None, state, action)
+    assert np.array_equal(ns.cpu().numpy().reshape(-1, S), ons)
+
+
+def test_qnet_td_forward(eng, orc, golden):
+    g = golden("g4_ddqn_learn")
+    for vi in (0, 2):
+        pre = "v%d_" % vi
+        S, A, H, L, act, B, _ = [int(v) for v in g[pre + "meta"]]
+        gamma = float(g[pre + "hparams"][0])
+        rows = g[pre + "rows"][0]
+        chains, cap, stride = 3, B + 5, (2 * S + 3 + 3) & ~3
+        rng = np.random.RandomState(vi)
+        replay = np.zeros((chains, cap, stride), np.float32)
+        idx = np.zeros((chains, B), np.int32)
+        online = np.stack([g[pre + "online0"] + c * 0.01 for c in range(chains)]).astype(np.float32)
+        target = np.stack([g[pre + "target0"] - c * 0.01 for c in range(chains)]).astype(np.float32)
+        for c in range(chains):
+            perm = rng.permutation(cap)[:B]
+            replay[c, perm, :2 * S + 3] = rows
+            idx[c] = perm
+        q_sa, y = eng.qnet_td_forward(eng.mlp_desc(S, H, L, A, ACTS[act]), dev(online), dev(target), dev(replay), dev(idx), gamma)
+        for c in range(chains):
+            oq, oy, _ = orc.qnet_td_forward(orc.mlp_desc(S, H, L, A, ACTS[act]), online[c], target[c], rows, S, gamma)
+            assert np.array_equal(q_sa[c].cpu().numpy(), oq)
+            assert np.array_equal(y[c].cpu().numpy(), oy)
+
+
+def _inner_cfg(orc, cfgd, **over):
+    from learning_environments_amd import _lib
+    o = orc.ddqn_cfg_from_config(cfgd, **over)
+    c = _lib.DdqnCfg()
+    for f, _ in _lib.DdqnCfg._fields_:
+        setattr(c, f, getattr(o, f))
+    return o, c
+
+
+@pytest.mark.parametrize("name", ["g8_calc_score_cartpole_a", "g8_calc_score_cartpole_b"])
+def test_inner_loop_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
+    g = golden(name)
+    cfgd = json.loads(str(g["config_json"]))
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=13, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
+    n = g["tr_action"].size
+    otapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    o = orc.ddqn_se_chain(ocfg, g["theta"], g["agent_init"], tapes=otapes, trace_cap=n + 8)
+    chains = 2   # the same chain twice: checks chain indexing of tapes/workspace
+    tapes = dict(eps_uniform=dev(np.tile(g["tape_eps_uniform"], (chains, 1))),
+                 rand_action=dev(np.tile(g["tape_rand_action"], (chains, 1))),
+                 replay_idx=dev(np.tile(g["tape_replay_idx"].reshape(1, -1), (chains, 1))),
+                 train_reset=dev(np.tile(g["tape_train_reset"][None], (chains, 1, 1))),
+                 test_reset=dev(np.tile(g["tape_test_reset"][None], (chains, 1, 1))))
+    il = eng.InnerLoop(cfg, chains, trace_cap=n + 8)
+    il.run(dev(g["theta"]), None, None, None, dev(np.tile(g["agent_init"], (chains, 1))), tapes=tapes)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        act = il.trace["action"][c, :n].cpu().numpy()
+        # bit-exact against the oracle
+        assert np.array_equal(act & 0xFFFF, o["trace"]["action"])
+        assert np.array_equal(act >> 16, o["trace"]["explored"])
+        assert np.array_equal(il.trace["state"][c, :n].cpu().numpy(), o["trace"]["state"])
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"])
+        assert np.array_equal(il.trace["reward_done"][c, :n, 0].cpu().numpy(), o["trace"]["reward"])
+        assert np.array_equal(il.trace["reward_done"][c, :n, 1].cpu().numpy(), o["trace"]["done"])
+        assert np.array_equal(il.episode_len[c].cpu().numpy(), o["episode_len"])
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(il.final_returns[c].cpu().numpy(), o["final_test_returns"])
+        assert float(il.score[c]) == o["score"]
+        st = il.stats[c].cpu().tolist()
+        assert st == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        # against the reference's own trace / returns (tolerances of test_oracle_golden.py)
+        assert np.array_equal(act & 0xFFFF, g["tr_action"])
+        np.testing.assert_allclose(il.trace["next_state"][c, :n].cpu().numpy(), g["tr_next_state"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(il.episode_test_mean[c].cpu().numpy(), g["reward_list_train"], rtol=0, atol=1e-4)
+        assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4   # north_star: returns within 1e-4 of the reference
+
+
+@pytest.mark.parametrize("env_name,chains,episodes,max_steps,batch", [("CartPole-v0", 9, 4, 40, 199), ("CartPole-v0", 6, 3, 25, 64),
+                                                                     ("Acrobot-v1", 6, 3, 30, 149)])
+def test_inner_loop_counter_mode_vs_oracle(eng, orc, golden, env_name, chains, episodes, max_steps, batch):
+    g = golden("g8_calc_score_cartpole_a")
+    cfgd = json.loads(str(g["config_json"]))
+    if env_name == "Acrobot-v1":
+        cfgd["env_name"] = env_name
+        cfgd["envs"][env_name] = dict(cfgd["envs"]["CartPole-v0"], solved_reward=-100.0, hidden_size=64)
+        cfgd["agents"]["ddqn"].update(hidden_size=112, activation_fn="leakyrelu")
+    cfgd["agents"]["ddqn"]["batch_size"] = batch
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0 if batch != 199 else 13, rng_mode=0, train_episodes=episodes, max_steps=max_steps)
+    if ocfg.grad_chunk == 0:
+        ocfg.grad_chunk = cfg.grad_chunk = (batch + 15) // 16
+    S, A = ocfg.state_dim, ocfg.num_actions
+    rng = np.random.RandomState(5)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, ocfg.se_hidden, 1, "leakyrelu"))
+    P_q = orc.mlp_num_params(orc.mlp_desc(S, ocfg.q_hidden, 1, A, "tanh"))
+    theta = (rng.randn(P_se) * 0.15).astype(np.float32)
+    pop = chains // 3
+    eps = (rng.randn(pop, P_se) * 0.05).astype(np.float32)
+    agent_init = (rng.uniform(-0.4, 0.4, (chains, P_q))).astype(np.float32)
+    worker = np.repeat(np.arange(pop), 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), pop)
+    keys = np.array([orc.chain_key(7, 3, int(worker[c]), c % 3) for c in range(chains)], np.uint64)
+    il = eng.InnerLoop(cfg, chains, trace_cap=episodes * max_steps)
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+        o = orc.ddqn_se_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]), trace_cap=episodes * max_steps)
+        n = o["trace"]["action"].size
+        act = il.trace["action"][c, :n].cpu().numpy()
+        assert np.array_equal(act & 0xFFFF, o["trace"]["action"]), c
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"]), c
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
+        assert np.array_equal(il.final_returns[c].cpu().numpy(), o["final_test_returns"]), c
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
+def test_inner_loop_early_out(eng, orc, golden):
+    # solved_reward low enough that the real-env early-out (base_agent.py:141-148) fires after init_episodes
+    g = golden("g8_calc_score_cartpole_a")
+    cfgd = json.loads(str(g["config_json"]))
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=13, rng_mode=0, train_episodes=6, max_steps=20, solved_reward=5.0, early_out_num=2)
+    key = orc.chain_key(1, 0, 0, 0)
+    il = eng.InnerLoop(cfg, 1)
+    il.run(dev(g["theta"]), None, None, None, dev(g["agent_init"][None]), rng_keys=dev(np.array([key], np.uint64).view(np.int64)))
+    torch.cuda.synchronize()
+    o = orc.ddqn_se_chain(ocfg, g["theta"], g["agent_init"], rng_key=key)
+    assert o["episodes_run"] < 6
+    assert il.stats[0].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+    assert np.array_equal(il.episode_test_mean[0].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+    assert float(il.score[0]) == o["score"]
+
+
+def test_unsupported_shapes_raise(eng, orc, golden):
+    g = golden("g8_calc_score_cartpole_a")
+    cfgd = json.loads(str(g["config_json"]))
+    _, cfg = _inner_cfg(orc, cfgd, q_layers=2)
+    with pytest.raises(NotImplementedError):
+        il = eng.InnerLoop(cfg, 1)
+        il.run(dev(g["theta"]), None, None, None, dev(np.zeros((1, il.p_agent), np.float32)), rng_keys=dev(np.zeros(1, np.int64)))
+
+
+def test_nes_worker_best_and_rank_update(eng, orc, golden):
+    g = golden("g7_master")
+    g6 = golden("g6_worker_noise")
+    # calc_best_score (mirrored): cases from the reference
+    cs = np.stack([np.zeros(3), g6["score_add"], g6["score_sub"]], axis=1)
+    res = eng.nes_worker_best(dev(cs.reshape(-1)), 3, True).cpu().numpy()
+    assert np.array_equal(res[:, 0], g6["score_best"])
+    obest, osign = orc.worker_best(g6["score_add"], g6["score_sub"], True)
+    assert np.array_equal(res[:, 2], osign.astype(np.float64))
+    # score_transform all types + update_env against reference vectors
+    from learning_environments_amd.agents.GTN_master import rank_table
+    pop = g["scores"].size
+    for scores, key in ((g["scores"], ""), (g["tied"], "_tied")):
+        gathered = np.zeros((pop, 4))
+        gathered[:, 0], gathered[:, 1], gathered[:, 2] = scores, g["scores_orig"], 1.0
+        for t in range(8):
+            w = eng.nes_rank_update(t, dev(gathered), dev(rank_table(t, pop)), None, None, 0.0).cpu().numpy()
+            ow = orc.score_transform(t, scores, g["scores_orig"])
+            np.testing.assert_allclose(w, ow, rtol=1e-15, atol=1e-15, err_msg="type %d%s" % (t, key))
+            if key == "":
+                np.testing.assert_allclose(w, g["tf%d" % t], rtol=1e-15, atol=1e-15)
+    gathered = np.zeros((pop, 4))
+    gathered[:, 0], gathered[:, 1], gathered[:, 2] = g["scores"], g["scores_orig"], 1.0
+    theta = dev(g["theta0"].copy())
+    eng.nes_rank_update(3, dev(gathered), dev(rank_table(3, pop)), theta, dev(g["eps"]), float(g["step_size"]))
+    assert np.array_equal(theta.cpu().numpy(), g["theta1"])
+    eng.nes_rank_update(3, dev(gathered), dev(rank_table(3, pop)), theta, dev(g["eps"]), float(g["step_size"]), True, 0.01)
+    assert np.array_equal(theta.cpu().numpy(), g["theta2"])
+    # mirrored sign flips eps
+    gathered[:, 2] = np.array([1, -1, 1, -1, -1, 1, 1, -1.0])
+    theta = dev(g["theta0"].copy())
+    w = eng.nes_rank_update(3, dev(gathered), dev(rank_table(3, pop)), theta, dev(g["eps"]), float(g["step_size"])).cpu().numpy()
+    ref = orc.update_env(g["theta0"], g["eps"], gathered[:, 2].astype(np.float32), w, float(g["step_size"]))
+    assert np.array_equal(theta.cpu().numpy(), ref)
