@@ -129,11 +129,24 @@ int lenv_qnet_td_forward(const lenv_mlp_desc *qnet /*HOST*/, const float *online
  * The replay buffers live in `workspace` (lenv_ddqn_se_workspace_bytes).
  */
 size_t lenv_ddqn_se_workspace_bytes(const lenv_ddqn_cfg *cfg /*HOST*/, int64_t chains);
+/* LDS bytes one chain needs for this cfg (incl. grad_chunk), or a negative LENV_ERR_* when unsupported / > 160 KiB */
+int64_t lenv_ddqn_se_lds_bytes(const lenv_ddqn_cfg *cfg /*HOST*/);
 int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg /*HOST*/, const float *theta, const float *eps,
                             const int32_t *worker, const float *sign, const float *agent_init,
                             const uint64_t *rng_keys, const lenv_tapes *tapes /*HOST struct of device ptrs, may be NULL*/,
                             int64_t chains, void *workspace, size_t workspace_bytes,
                             const lenv_inner_out *out /*HOST struct of device ptrs*/, void *stream);
+
+/*
+ * Real-environment reset/step for n independent instances (replaces gym==0.17.3 CartPole-v0 / Acrobot-v1
+ * reset()/step() + gym.wrappers.TimeLimit behind EnvWrapper.reset/step, envs/env_wrapper.py:49-85).
+ * state [n,4] float64 (gym's internal state), elapsed [n] TimeLimit counters, obs [n,S] fp32 observations.
+ * Reset states are U(-lim,lim)^4 drawn from the counter RNG: value = f(keys[i], episode[i]).
+ */
+int lenv_real_env_reset(int32_t env_id, const uint64_t *keys, const int64_t *episode, int64_t n, double *state,
+                        float *obs, int32_t *elapsed, void *stream);
+int lenv_real_env_step(int32_t env_id, int32_t max_steps, int64_t n, const int32_t *action, double *state,
+                       int32_t *elapsed, float *obs, float *reward, float *done, void *stream);
 
 /* Counter-RNG key of a chain (same function as the oracle's): kind 0 = theta, 1 = theta+eps, 2 = theta-eps. HOST. */
 uint64_t lenv_chain_key(uint64_t seed, uint64_t generation, uint64_t worker, uint64_t kind);

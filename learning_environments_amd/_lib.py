@@ -51,8 +51,8 @@ class InnerOut(C.Structure):
 
 
 EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv_se_step_population",
-           "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_inner_loop", "lenv_chain_key",
-           "lenv_nes_worker_best", "lenv_nes_rank_update"]
+           "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_lds_bytes", "lenv_ddqn_se_inner_loop",
+           "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step"]
 
 
 def build(force=False):
@@ -92,6 +92,12 @@ def lib():
         L.lenv_ddqn_se_inner_loop.restype = C.c_int
         L.lenv_ddqn_se_inner_loop.argtypes = [C.POINTER(DdqnCfg), vp, vp, vp, vp, vp, vp, C.POINTER(Tapes), C.c_int64, vp,
                                               C.c_size_t, C.POINTER(InnerOut), vp]
+        L.lenv_ddqn_se_lds_bytes.restype = C.c_int64
+        L.lenv_ddqn_se_lds_bytes.argtypes = [C.POINTER(DdqnCfg)]
+        L.lenv_real_env_reset.restype = C.c_int
+        L.lenv_real_env_reset.argtypes = [C.c_int32, vp, vp, C.c_int64, vp, vp, vp, vp]
+        L.lenv_real_env_step.restype = C.c_int
+        L.lenv_real_env_step.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
         L.lenv_nes_worker_best.restype = C.c_int
         L.lenv_nes_worker_best.argtypes = [vp, C.c_int64, C.c_int32, vp, vp]
         L.lenv_nes_rank_update.restype = C.c_int

@@ -1,17 +1,246 @@
-"""placeholder, completed below"""
+"""GTN_Master: the NES master (reference agents/GTN_master.py:15-308), MI355X edition.
+
+Same constructor, attributes (`score_list`, `score_orig_list`, `score_transform_list`, `synthetic_env_orig`,
+`model_dir`, `model_name`) and `run()` return tuple.  What changed underneath:
+
+  * the `num_workers` GTN_Worker evaluations of a generation (3 inner loops each, agents/GTN_worker.py:84-102) run
+    as ONE fused kernel launch on this rank's share of the population -- no worker processes, no sync files;
+  * with torch.distributed initialised (one process per GPU, backend nccl == RCCL over xGMI) the population is
+    split in contiguous blocks; the only exchange is ONE all-gather of [score_best, score_orig, sign] per worker
+    (replaces write_worker_result/read_worker_results, :178-195); every rank then runs score_transform + update_env
+    redundantly on bit-identical inputs, so theta never needs a broadcast (replaces write_worker_inputs, :147-176);
+  * noise eps is one [num_workers, P] tensor drawn from a (seed, generation)-keyed device generator that every rank
+    reproduces (agents/GTN_worker.py:156-163 drew it per worker from a time-seeded global RNG);
+  * wall-clock time-outs (calc_worker_timeout, :141-145) have no counterpart: chains run to their step budgets.
+"""
+import os
+import random
+import string
+import time
+
 import numpy as np
+import torch
+import torch.distributed as dist
+
+from ..config import ddqn_cfg_from_config
+from ..envs.env_factory import EnvFactory
+from ..utils import calc_abs_param_sum
+from .GTN_base import GTN_Base
+from .nes_common import chain_keys, fresh_agent_init, linear_init_bounds, rank_table, shard_bounds
+
+__all__ = ["GTN_Master", "rank_table"]
 
 
-def rank_table(score_transform_type, n):
-    """Per-rank values consumed by lenv_nes_rank_update for the rank-only transforms
-    (reference: agents/GTN_master.py:205-227), computed with numpy exactly as the reference does.
-    type 1: final weight of ascending rank i; types 2/3: raw NES utility of descending rank i."""
-    t = np.zeros(n, np.float64)
-    if score_transform_type == 1:
-        for i in range(n):
-            t[i] = i / (n - 1)
-    elif score_transform_type in (2, 3):
-        ranks = np.arange(1, n + 1).astype(float)
-        for i in range(n):
-            t[i] = max(0, np.log(n / 2 + 1) - np.log(ranks[i]))
-    return t
+class GTN_Master(GTN_Base):
+    def __init__(self, config, bohb_id=-1, bohb_working_dir=None, engine=None, seed=0, verbose=False):
+        super().__init__(bohb_id)
+        self.config = config
+        self.device = config["device"]
+        self.env_name = config['env_name']
+
+        gtn_config = config["agents"]["gtn"]
+        self.max_iterations = gtn_config["max_iterations"]
+        self.agent_name = gtn_config["agent_name"]
+        self.num_workers = gtn_config["num_workers"]
+        self.step_size = gtn_config["step_size"]
+        self.nes_step_size = gtn_config["nes_step_size"]
+        self.weight_decay = gtn_config["weight_decay"]
+        self.score_transform_type = gtn_config["score_transform_type"]
+        self.noise_std = gtn_config["noise_std"]
+        self.mirrored_sampling = gtn_config["mirrored_sampling"]
+        self.num_grad_evals = gtn_config["num_grad_evals"]
+        self.grad_eval_type = gtn_config["grad_eval_type"]
+        self.quit_when_solved = gtn_config["quit_when_solved"]
+        self.synthetic_env_type = gtn_config["synthetic_env_type"]
+        self.unsolved_weight = gtn_config["unsolved_weight"]
+        self.seed = int(seed)
+        self.verbose = verbose
+
+        if self.score_transform_type not in range(8):
+            raise ValueError("Unknown rank transform type: " + str(self.score_transform_type))
+        if self.grad_eval_type not in ('mean', 'minmax'):
+            raise NotImplementedError('Unknown parameter for grad_eval_type: ' + str(self.grad_eval_type))
+        if self.num_grad_evals != 1:
+            raise NotImplementedError("num_grad_evals != 1")
+        if self.agent_name.lower() != "ddqn":
+            raise NotImplementedError("inner agent '%s': only DDQN has a fused kernel so far" % self.agent_name)
+
+        self.time_elapsed_list = [None] * self.num_workers
+        self.score_list = [None] * self.num_workers
+        self.score_orig_list = [None] * self.num_workers
+        self.score_transform_list = [None] * self.num_workers
+
+        if engine is None:
+            from ..engine import HipNesEngine
+            engine = HipNesEngine()     # raises without a HIP device / built library: no CPU fallback
+        self.engine = engine
+        dev = engine.device
+
+        self.env_factory = EnvFactory(config)
+        if self.synthetic_env_type == 0:
+            generate_synthetic_env_fn = self.env_factory.generate_virtual_env
+        elif self.synthetic_env_type == 1:
+            generate_synthetic_env_fn = self.env_factory.generate_reward_env
+        else:
+            raise NotImplementedError("Unknown synthetic_env_type value: " + str(self.synthetic_env_type))
+        self.synthetic_env_orig = generate_synthetic_env_fn(print_str='GTN_Base: ')
+        self.real_env = self.env_factory.generate_real_env()
+
+        # theta: one flat device buffer aliased by synthetic_env_orig's nn.Linear parameters
+        self.theta = self._flat_theta(dev)
+        self.p_theta = self.theta.numel()
+
+        # distributed layout: worker p lives on rank p // ceil(pop/world)
+        self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.w_lo, self.w_hi, self.w_per = shard_bounds(self.num_workers, self.rank, self.world)
+        self.n_local = self.w_hi - self.w_lo
+
+        self.cfg = ddqn_cfg_from_config(config) if engine.name == "hip" else engine.cfg_from_config(config)
+        S, A, Hq = self.cfg.state_dim, self.cfg.num_actions, self.cfg.q_hidden
+        self.agent_bounds = torch.from_numpy(linear_init_bounds([(S, Hq), (Hq, A)])).to(dev)
+        self.inner = engine.make_inner(self.cfg, 3 * self.n_local) if self.n_local > 0 else None
+        lw = np.arange(self.w_lo, self.w_hi)
+        self.chain_worker = torch.from_numpy(np.repeat(lw, 3).astype(np.int32)).to(dev)
+        self.chain_sign = torch.tensor([0.0, 1.0, -1.0] * self.n_local, dtype=torch.float32, device=dev)
+        self.rank_table = torch.from_numpy(rank_table(self.score_transform_type, self.num_workers)).to(dev)
+        self.eps = None
+
+        if bohb_working_dir:
+            self.model_dir = str(os.path.join(bohb_working_dir, 'GTN_models_' + self.env_name))
+        else:
+            self.model_dir = str(os.path.join(os.getcwd(), "results", 'GTN_models_' + self.env_name))
+        self.model_name = self.get_model_file_name(
+            self.env_name + '_' + ''.join(random.choices(string.ascii_uppercase + string.digits, k=6)) + '.pt')
+        self.best_score = -float('Inf')
+        os.makedirs(self.model_dir, exist_ok=True)
+
+    def _flat_theta(self, dev):
+        env = self.synthetic_env_orig.env
+        if hasattr(env, "flat_params") and self.engine.name == "hip":
+            return env.flat_params()
+        from ..models.model_utils import FlatParams
+        self._flat_holder = FlatParams(env, dev)
+        return self._flat_holder.flat
+
+    def get_model_file_name(self, file_name):
+        return os.path.join(self.model_dir, file_name)
+
+    # ---------------------------------------------------------------------------------------------
+    def evaluate_population(self, it):
+        """One generation's worker evaluations on this rank + the all-gather.  Returns gathered [num_workers,4]
+        = (score_best, score_orig, sign, 0) in worker order, identical on every rank."""
+        dev = self.engine.device
+        pop = self.num_workers
+        g = torch.Generator(device=dev)
+        g.manual_seed((self.seed * 1000003 + it) % (2 ** 63 - 1))
+        # GTN_Worker.get_random_noise (agents/GTN_worker.py:156-163): N(0,1) * noise_std, full population on every rank
+        self.eps = torch.randn((pop, self.p_theta), generator=g, device=dev, dtype=torch.float32) * self.noise_std
+        agent_init = fresh_agent_init(self.agent_bounds, 3 * pop, g, dev)
+        local = torch.zeros((self.w_per, 4), dtype=torch.float64, device=dev)
+        if self.n_local > 0:
+            lw = np.arange(self.w_lo, self.w_hi)
+            keys = chain_keys(self.seed, it, np.repeat(lw, 3), np.tile(np.arange(3), self.n_local))
+            keys_t = torch.from_numpy(keys.view(np.int64)).to(dev)
+            chain_scores = self.engine.inner_scores(self.inner, self.theta, self.eps, self.chain_worker, self.chain_sign,
+                                                    agent_init[3 * self.w_lo:3 * self.w_hi].contiguous(), keys_t)
+            local[:self.n_local] = self.engine.worker_best(chain_scores, self.n_local, self.mirrored_sampling)
+        if self.world > 1:
+            gathered = torch.empty((self.world * self.w_per, 4), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(gathered, local)      # the ONE collective of a generation (RCCL over xGMI)
+            gathered = gathered[:pop].contiguous()
+        else:
+            gathered = local[:pop]
+        return gathered
+
+    def step(self, it):
+        """One NES generation (the body of the reference's run() loop, :84-106).  Returns (mean_score_orig, solved)."""
+        t1 = time.time()
+        gathered = self.evaluate_population(it)
+        host = gathered.cpu().numpy()               # the generation's only host sync
+        if self.inner is not None and hasattr(self.engine, "check_status"):
+            self.engine.check_status(self.inner)
+        self.score_list = host[:, 0].tolist()
+        self.score_orig_list = host[:, 1].tolist()
+        self.time_elapsed_list = [time.time() - t1] * self.num_workers
+        mean_score = np.mean(self.score_orig_list)
+        solved_flag = self.save_good_model(mean_score)
+        if solved_flag and self.quit_when_solved:
+            return mean_score, True
+        self._transform_and_update(gathered)
+        if self.verbose and self.rank == 0:
+            self.print_statistics(it=it, time_elapsed=time.time() - t1)
+        return mean_score, False
+
+    def run(self):
+        mean_score_orig_list = []
+        for it in range(self.max_iterations):
+            mean_score, solved = self.step(it)
+            mean_score_orig_list.append(mean_score)
+            if solved:
+                break
+        if len(mean_score_orig_list) > 0:
+            return np.mean(self.score_orig_list), mean_score_orig_list, self.model_name
+        return 1e9, mean_score_orig_list, self.model_name
+
+    def save_good_model(self, mean_score):
+        # reference :118-131
+        if self.synthetic_env_orig.is_virtual_env():
+            if mean_score > self.real_env.get_solved_reward() and mean_score > self.best_score:
+                self.save_model()
+                self.best_score = mean_score
+                return True
+        else:
+            if mean_score > self.best_score:
+                self.save_model()
+                self.best_score = mean_score
+        return False
+
+    def save_model(self):
+        # reference :133-139 -- {'model': state_dict, 'config': config}
+        if self.rank != 0:
+            return
+        save_dict = {'model': {k: v.detach().cpu() for k, v in self.synthetic_env_orig.state_dict().items()},
+                     'config': self.config}
+        torch.save(save_dict, os.path.join(self.model_dir, self.model_name))
+
+    def score_transform(self, gathered=None):
+        """reference :197-265.  Weights are computed on device together with update_env; this method keeps the
+        reference's name and fills `score_transform_list`."""
+        if gathered is None:
+            gathered = self._gathered_from_lists()
+        self._weights = self.engine.rank_update(self.score_transform_type, gathered, self.rank_table, None, None, 0.0,
+                                                False, 0.0)
+        self.score_transform_list = self._weights.cpu().tolist()
+
+    def update_env(self, gathered=None):
+        """reference :267-298: theta <- theta*(1-wd); theta += (ss*w_i) * eps_i in worker order (eps_i sign-flipped when
+        mirrored sampling picked -eps)."""
+        if gathered is None:
+            gathered = self._gathered_from_lists()
+        self.engine.rank_update(self.score_transform_type, gathered, self.rank_table, self.theta, self.eps,
+                                self.step_size, self.nes_step_size, self.weight_decay)
+
+    def _transform_and_update(self, gathered):
+        """score_transform + update_env in one device call (one ranking pass)."""
+        self._weights = self.engine.rank_update(self.score_transform_type, gathered, self.rank_table, self.theta, self.eps,
+                                                self.step_size, self.nes_step_size, self.weight_decay)
+        self.score_transform_list = None     # materialised lazily (needs a host copy)
+
+    def get_score_transform_list(self):
+        if self.score_transform_list is None:
+            self.score_transform_list = self._weights.cpu().tolist()
+        return self.score_transform_list
+
+    def _gathered_from_lists(self):
+        g = np.zeros((self.num_workers, 4))
+        g[:, 0], g[:, 1], g[:, 2] = self.score_list, self.score_orig_list, 1.0
+        return torch.from_numpy(g).to(self.engine.device)
+
+    def print_statistics(self, it, time_elapsed):
+        print('--------------')
+        print('GTN iteration:    ' + str(it))
+        print('GTN mstr t_elaps: ' + str(time_elapsed))
+        print('GTN avg eval score:   ' + str(float(np.mean(self.score_orig_list))))
+        print('GTN |theta|_1:    ' + str(float(calc_abs_param_sum(self.synthetic_env_orig))))
+        print('--------------')

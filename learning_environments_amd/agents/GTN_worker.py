@@ -1,0 +1,206 @@
+"""GTN_Worker: one NES population member (reference agents/GTN_worker.py:15-254), MI355X edition.
+
+Kept for API/transport compatibility: same constructor, `late_init`, noise methods, `calc_score`,
+`calc_best_score`, and the file protocol of `run()` (read `<bohb_id>_<id>_input.pt`, write `..._result.pt`), so it can
+serve a reference GTN_Master.  The three inner loops of an evaluation (theta, theta+eps, theta-eps) run as ONE launch
+of the fused kernel (3 chains) instead of three sequential python training runs.  The in-process GTN_Master of this
+package does not use worker objects at all.
+"""
+import os
+import statistics
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..config import ddqn_cfg_from_config
+from ..envs.env_factory import EnvFactory
+from ..models.model_utils import linear_params
+from .GTN_base import GTN_Base
+from .nes_common import chain_keys, fresh_agent_init, linear_init_bounds
+
+
+class GTN_Worker(GTN_Base):
+    def __init__(self, id, bohb_id=-1, engine=None, seed=None):
+        super().__init__(bohb_id)
+        self.id = id
+        self.seed = int(seed) if seed is not None else int(id + bohb_id * id * 1000 + int(time.time()))
+        torch.manual_seed(self.seed)
+        self.test_counter = 0
+        self.quit_flag = False
+        self.time_sleep_worker = 3
+        self.timeout = None
+        self.engine = engine
+        self.generation = 0
+        for file in [self.get_input_file_name(self.id), self.get_input_check_file_name(self.id),
+                     self.get_result_file_name(self.id), self.get_result_check_file_name(self.id)]:
+            if os.path.isfile(file):
+                os.remove(file)
+
+    def late_init(self, config):
+        gtn_config = config["agents"]["gtn"]
+        self.noise_std = gtn_config["noise_std"]
+        self.num_grad_evals = gtn_config["num_grad_evals"]
+        self.grad_eval_type = gtn_config["grad_eval_type"]
+        self.mirrored_sampling = gtn_config["mirrored_sampling"]
+        self.time_sleep_worker = gtn_config["time_sleep_worker"]
+        self.agent_name = gtn_config["agent_name"]
+        self.synthetic_env_type = gtn_config["synthetic_env_type"]
+        self.unsolved_weight = gtn_config["unsolved_weight"]
+        if gtn_config["mode"] == 'single':
+            self.time_sleep_worker /= 10
+        if self.agent_name.lower() != "ddqn":
+            raise NotImplementedError("inner agent '%s': only DDQN has a fused kernel so far" % self.agent_name)
+        if self.engine is None:
+            from ..engine import HipNesEngine
+            self.engine = HipNesEngine()
+
+        self.config = config
+        self.env_factory = EnvFactory(config)
+        if self.synthetic_env_type == 0:
+            generate_synthetic_env_fn = self.env_factory.generate_virtual_env
+        elif self.synthetic_env_type == 1:
+            generate_synthetic_env_fn = self.env_factory.generate_reward_env
+        else:
+            raise NotImplementedError("Unknown synthetic_env_type value: " + str(self.synthetic_env_type))
+        self.synthetic_env_orig = generate_synthetic_env_fn(print_str='GTN_Base: ')
+        self.synthetic_env = generate_synthetic_env_fn(print_str='GTN_Worker' + str(id) + ': ')
+        self.eps = generate_synthetic_env_fn('GTN_Worker' + str(id) + ': ')
+        self.cfg = ddqn_cfg_from_config(config)
+        S, A, Hq = self.cfg.state_dim, self.cfg.num_actions, self.cfg.q_hidden
+        self._bounds = torch.from_numpy(linear_init_bounds([(S, Hq), (Hq, A)])).to(self.engine.device)
+        self._inner = {}
+
+    # ---- noise handling: reference :156-185, same loops over nn.Linear modules ----
+    def get_random_noise(self):
+        for l_virt, l_eps in zip(self.synthetic_env.modules(), self.eps.modules()):
+            if isinstance(l_virt, nn.Linear):
+                l_eps.weight.data.copy_(torch.normal(mean=torch.zeros_like(l_virt.weight), std=torch.ones_like(l_virt.weight)) * self.noise_std)
+                if l_eps.bias is not None:
+                    l_eps.bias.data.copy_(torch.normal(mean=torch.zeros_like(l_virt.bias), std=torch.ones_like(l_virt.bias)) * self.noise_std)
+
+    def add_noise_to_synthetic_env(self, add=True):
+        for l_orig, l_virt, l_eps in zip(self.synthetic_env_orig.modules(), self.synthetic_env.modules(), self.eps.modules()):
+            if isinstance(l_virt, nn.Linear):
+                if add:
+                    l_virt.weight.data.copy_(l_orig.weight + l_eps.weight)
+                    if l_virt.bias is not None:
+                        l_virt.bias.data.copy_(l_orig.bias + l_eps.bias)
+                else:
+                    l_virt.weight.data.copy_(l_orig.weight - l_eps.weight)
+                    if l_virt.bias is not None:
+                        l_virt.bias.data.copy_(l_orig.bias - l_eps.bias)
+
+    def subtract_noise_from_synthetic_env(self):
+        self.add_noise_to_synthetic_env(add=False)
+
+    def invert_eps(self):
+        for l_eps in self.eps.modules():
+            if isinstance(l_eps, nn.Linear):
+                l_eps.weight.data.neg_()
+                if l_eps.bias is not None:
+                    l_eps.bias.data.neg_()
+
+    # ---- scoring ----
+    def _flat(self, envw):
+        return torch.cat([p.detach().reshape(-1) for p in linear_params(envw)]).to(self.engine.device, torch.float32).contiguous()
+
+    def _run_chains(self, thetas):
+        """Scores of len(thetas) chains (each its own SE parameter vector) in one launch."""
+        n = len(thetas)
+        dev = self.engine.device
+        if n not in self._inner:
+            self._inner[n] = self.engine.make_inner(self.cfg, n)
+        inner = self._inner[n]
+        # express chain c as theta0 + 1*(theta_c - theta0)?  No: exactness matters -> run with eps rows = theta_c, theta = 0
+        zero = torch.zeros_like(thetas[0])
+        eps = torch.stack(thetas).contiguous()
+        worker = torch.arange(n, dtype=torch.int32, device=dev)
+        sign = torch.ones(n, dtype=torch.float32, device=dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed((self.seed * 1000003 + self.generation * 7919 + self.test_counter) % (2 ** 63 - 1))
+        agent_init = fresh_agent_init(self._bounds, n, g, dev)
+        keys = chain_keys(self.seed, self.generation * 1000 + self.test_counter, np.full(n, self.id), np.arange(n) % 4)
+        self.test_counter += 1
+        scores = self.engine.inner_scores(inner, zero, eps, worker, sign, agent_init,
+                                          torch.from_numpy(keys.view(np.int64)).to(dev))
+        out = scores.cpu().tolist()
+        if hasattr(self.engine, "check_status"):
+            self.engine.check_status(inner)
+        return out
+
+    def calc_score(self, env, time_remaining=1e9):
+        """reference :187-221: fresh agent, train on `env` with per-episode real-env tests, final test, mean return."""
+        if not env.is_virtual_env():
+            raise NotImplementedError("calc_score on a RewardEnv: next row of the scope table")
+        return self._run_chains([self._flat(env)])[0]
+
+    def calc_best_score(self, score_sub, score_add):
+        # reference :234-254
+        if self.grad_eval_type == 'mean':
+            score_sub = statistics.mean(score_sub)
+            score_add = statistics.mean(score_add)
+        elif self.grad_eval_type == 'minmax':
+            score_sub = min(score_sub)
+            score_add = min(score_add)
+        else:
+            raise NotImplementedError('Unknown parameter for grad_eval_type: ' + str(self.grad_eval_type))
+        if self.mirrored_sampling:
+            score_best = max(score_add, score_sub)
+            if score_sub > score_add:
+                self.invert_eps()
+            else:
+                self.add_noise_to_synthetic_env()
+        else:
+            score_best = score_add
+            self.add_noise_to_synthetic_env()
+        return score_best
+
+    def evaluate(self):
+        """One worker-evaluation (reference run() body :84-104) with the three inner loops batched in one launch."""
+        self.get_random_noise()
+        th = self._flat(self.synthetic_env_orig)
+        e = self._flat(self.eps)
+        score_orig, score_add, score_sub = self._run_chains([th, th + e, th - e])
+        self.subtract_noise_from_synthetic_env()          # state the reference is in before calc_best_score
+        score_best = self.calc_best_score(score_add=[score_add], score_sub=[score_sub])
+        return score_best, score_orig
+
+    # ---- file transport, reference :76-154 ----
+    def run(self):
+        while not self.quit_flag:
+            self.read_worker_input()
+            time_start = time.time()
+            score_best, score_orig = self.evaluate()
+            self.write_worker_result(score=score_best, score_orig=score_orig, time_elapsed=time.time() - time_start)
+            self.generation += 1
+            if self.quit_flag:
+                break
+
+    def read_worker_input(self):
+        file_name = self.get_input_file_name(id=self.id)
+        check_file_name = self.get_input_check_file_name(id=self.id)
+        while not os.path.isfile(check_file_name):
+            time.sleep(self.time_sleep_worker)
+        time.sleep(self.time_sleep_worker)
+        data = torch.load(file_name)
+        self.timeout = data['timeout']
+        self.quit_flag = data['quit_flag']
+        self.config = data['config']
+        self.late_init(self.config)
+        self.synthetic_env_orig.load_state_dict(data['synthetic_env_orig'])
+        self.synthetic_env.load_state_dict(data['synthetic_env_orig'])
+        os.remove(check_file_name)
+        os.remove(file_name)
+
+    def write_worker_result(self, score, score_orig, time_elapsed):
+        file_name = self.get_result_file_name(id=self.id)
+        check_file_name = self.get_result_check_file_name(id=self.id)
+        while os.path.isfile(file_name):
+            time.sleep(self.time_sleep_worker)
+        data = {"eps": {k: v.cpu() for k, v in self.eps.state_dict().items()},
+                "synthetic_env": {k: v.cpu() for k, v in self.synthetic_env.state_dict().items()},
+                "time_elapsed": time_elapsed, "score": score, "score_orig": score_orig}
+        torch.save(data, file_name)
+        torch.save({}, check_file_name)

@@ -1,0 +1,62 @@
+"""Shared host logic of the NES outer loop: sharding, seeds, agent initialisation, rank utilities."""
+import math
+
+import numpy as np
+import torch
+
+_G = np.uint64(0x9e3779b97f4a7c15)
+
+
+def _mix64(x):
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(30); x *= np.uint64(0xbf58476d1ce4e5b9)
+    x ^= x >> np.uint64(27); x *= np.uint64(0x94d049bb133111eb)
+    x ^= x >> np.uint64(31)
+    return x
+
+
+def chain_keys(seed, generation, workers, kinds):
+    """Vectorised lenv_chain_key (csrc/lenv_api.hip): counter-RNG key of chain (worker, kind)."""
+    with np.errstate(over="ignore"):
+        k = _mix64(np.full(len(workers), seed, np.uint64) + _G)
+        k = _mix64(k ^ (np.uint64(generation) + _G * np.uint64(2)))
+        k = _mix64(k ^ (np.asarray(workers, np.uint64) * np.uint64(4) + np.asarray(kinds, np.uint64) + _G * np.uint64(3)))
+    return k
+
+
+def shard_bounds(pop, rank, world):
+    """Workers [lo, hi) of `rank`: contiguous blocks of ceil(pop/world) (the all-gather is rank-major = worker order)."""
+    per = (pop + world - 1) // world
+    lo = min(rank * per, pop)
+    return lo, min(lo + per, pop), per
+
+
+def rank_table(score_transform_type, n):
+    """Per-rank values consumed by lenv_nes_rank_update for the rank-only transforms, computed with numpy exactly as
+    reference agents/GTN_master.py:205-227 does.  type 1: weight of ascending rank i; types 2/3: raw NES utility
+    max(0, log(n/2+1) - log(rank)) of descending rank i (the normalisations run on device in worker order)."""
+    t = np.zeros(n, np.float64)
+    if score_transform_type == 1:
+        for i in range(n):
+            t[i] = i / (n - 1)
+    elif score_transform_type in (2, 3):
+        ranks = np.arange(1, n + 1).astype(float)
+        for i in range(n):
+            t[i] = max(0, np.log(n / 2 + 1) - np.log(ranks[i]))
+    return t
+
+
+def linear_init_bounds(layer_dims):
+    """Per-parameter bound of nn.Linear's default init (kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+    for weight and bias) for an MLP given as [(fan_in, fan_out), ...], flat state-dict order."""
+    parts = []
+    for fan_in, fan_out in layer_dims:
+        b = 1.0 / math.sqrt(fan_in)
+        parts.append(np.full(fan_in * fan_out + fan_out, b, np.float32))
+    return np.concatenate(parts)
+
+
+def fresh_agent_init(bounds, chains, generator, device):
+    """`chains` freshly initialised agents (reference: select_agent -> DDQN() per calc_score, agents/agent_utils.py:15-66)."""
+    u = torch.rand((chains, bounds.numel()), generator=generator, device=device, dtype=torch.float32)
+    return (u * 2.0 - 1.0) * bounds

@@ -1,0 +1,52 @@
+"""Reference YAML config dict -> kernel configuration structs."""
+import ctypes as C
+
+from . import _lib
+
+ENV_DIMS = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3)}
+
+
+def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **overrides):
+    """Fields read at reference agents/DDQN.py:15-38, agents/base_agent.py:9-26, envs/env_factory.py:45-59.
+    grad_chunk=0 picks the smallest micro-chunk (>= ceil(batch/16)) whose LDS footprint fits one CU."""
+    env_name = config["env_name"]
+    if env_name not in ENV_DIMS:
+        raise NotImplementedError("real env '%s' has no device implementation yet" % env_name)
+    e = config["envs"][env_name]
+    a = config["agents"]["ddqn"]
+    S, A = ENV_DIMS[env_name]
+    if a["same_action_num"] != 1:
+        raise NotImplementedError("same_action_num != 1")
+
+    def val(v):  # env_factory.py:54-58: list-valued entries -> float(value[1])
+        return float(v[1]) if isinstance(v, list) else v
+
+    cfg = _lib.DdqnCfg(env_id=_lib.ENV[env_name], state_dim=S, num_actions=A, max_steps=int(val(e["max_steps"])),
+                       se_hidden=int(val(e["hidden_size"])), se_layers=int(val(e["hidden_layer"])),
+                       se_act=_lib.ACT[e["activation_fn"]], se_prelu=0.25,
+                       q_hidden=int(a["hidden_size"]), q_layers=int(a["hidden_layer"]), q_act=_lib.ACT[a["activation_fn"]],
+                       q_prelu=0.25, batch_size=int(a["batch_size"]), rb_size=int(a["rb_size"]),
+                       train_episodes=int(a["train_episodes"]), test_episodes=int(a["test_episodes"]),
+                       init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]),
+                       grad_chunk=int(grad_chunk), rng_mode=int(rng_mode), solved_reward=float(val(e["solved_reward"])),
+                       gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), eps_init=float(a["eps_init"]),
+                       eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]),
+                       adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8)
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    if cfg.grad_chunk == 0:
+        cfg.grad_chunk = pick_grad_chunk(cfg)
+    return cfg
+
+
+def pick_grad_chunk(cfg):
+    L = _lib.lib()
+    B = cfg.batch_size
+    chunk = (B + 15) // 16
+    probe = _lib.DdqnCfg.from_buffer_copy(cfg)
+    while chunk <= B:
+        probe.grad_chunk = chunk
+        if L.lenv_ddqn_se_lds_bytes(C.byref(probe)) > 0:
+            return chunk
+        chunk += 1
+    raise NotImplementedError("DDQN/SE shapes do not fit the fused kernel's LDS budget")

@@ -1,0 +1,34 @@
+"""Hyper-parameter sets of the BASELINE configurations as plain dicts (same keys as the reference's YAML files, so
+`yaml.safe_load(open('default_config_cartpole_syn_env.yaml'))` from a reference checkout is interchangeable)."""
+import copy
+
+
+def cartpole_syn_env_ddqn(num_workers=64, max_iterations=200):
+    """BASELINE configs 1/2: CartPole-v0 SE + DDQN (values = the published hyper-parameters of
+    default_config_cartpole_syn_env.yaml: gtn section :5-26, ddqn :28-46, env :124-132)."""
+    return copy.deepcopy({
+        "env_name": "CartPole-v0", "device": "cuda", "render_env": False,
+        "agents": {
+            "gtn": {"mode": "multi", "max_iterations": max_iterations, "num_threads_per_worker": 1,
+                    "num_workers": num_workers, "noise_std": 0.0124, "step_size": 0.148, "nes_step_size": False,
+                    "mirrored_sampling": True, "num_grad_evals": 1, "grad_eval_type": "mean", "weight_decay": 0.0,
+                    "time_mult": 3, "time_max": 600, "time_sleep_master": 0.2, "time_sleep_worker": 2,
+                    "score_transform_type": 3, "quit_when_solved": False, "synthetic_env_type": 0,
+                    "unsolved_weight": 10000, "agent_name": "DDQN"},
+            "ddqn": {"train_episodes": 1000, "test_episodes": 10, "init_episodes": 1, "batch_size": 199, "gamma": 0.988,
+                     "lr": 0.000304, "tau": 0.00848, "eps_init": 0.809, "eps_min": 0.0371, "eps_decay": 0.961,
+                     "rb_size": 100000, "same_action_num": 1, "activation_fn": "tanh", "hidden_size": 57,
+                     "hidden_layer": 1, "print_rate": 10, "early_out_num": 10, "early_out_virtual_diff": 0.01},
+        },
+        "envs": {"CartPole-v0": {"solved_reward": 195.0, "max_steps": 200, "activation_fn": "leakyrelu", "hidden_size": 83,
+                                 "hidden_layer": 1, "info_dim": 0, "reward_env_type": 0}},
+    })
+
+
+def fixed_work(config, train_episodes):
+    """BASELINE.md §3 fixed-work variant: early-out disabled (solved_reward=+1e9) and a fixed number of train episodes,
+    so both the GPU path and the CPU baseline do identical, data-independent amounts of work."""
+    cfg = copy.deepcopy(config)
+    cfg["agents"]["ddqn"]["train_episodes"] = train_episodes
+    cfg["envs"][cfg["env_name"]]["solved_reward"] = 1e9
+    return cfg

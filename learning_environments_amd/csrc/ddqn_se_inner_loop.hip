@@ -16,8 +16,8 @@
 // (theta + sign*eps), the Q-net, its target, and all minibatch activations live in LDS; Adam state and
 // master copies of the Q parameters live in the owning thread's registers; only the replay buffer is in
 // HBM/L2.  Per training step: wave 12 acts + steps the SE + appends the transition while waves 0-11
-// prefetch their minibatch rows; then 12 waves run the three Q forwards (thread = sample x pass), all 16
-// waves back-propagate, 16 waves reduce the batch gradient in micro-chunks, 1 thread/parameter applies Adam.
+// prefetch their minibatch rows; then 12 waves run the three Q forwards (thread = sample x pass), one thread
+// per sample forms the TD error, up to 16 waves back-propagate + reduce the batch gradient in micro-chunks, 1 thread/parameter applies Adam.
 // Arithmetic order is the oracle's canonical order (oracle/lenv_oracle.h) => results are bit-identical.
 #include "lenv_device.cuh"
 
@@ -27,6 +27,7 @@ constexpr int NT = 1024;          // threads per chain
 constexpr int NW = NT / 64;       // waves per chain
 constexpr int ENV_WAVE = 12;      // wave that plays the environment/actor role during a training step
 constexpr int MAX_B = 256;        // minibatch samples (one per thread of a 256-thread pass group)
+constexpr int PPT = 2;            // Q-net parameters owned per thread (P_agent <= PPT*NT)
 
 struct InnerArgs {
     lenv_ddqn_cfg cfg;
@@ -38,7 +39,7 @@ struct InnerArgs {
     int P_q, P_se, se_net_size[3];
     int RP, HP, chunk, n_chunks;
     // LDS offsets (floats)
-    int o_se_w0T, o_se_b0, o_se_wout, o_se_bout, o_se_h, o_q_onl, o_q_tgt, o_wscr, o_hB, o_dzB, o_sB, o_rda,
+    int o_se_w0T, o_se_b0, o_se_wout, o_se_bout, o_se_h, o_q_onl, o_q_tgt, o_wscr, o_hB, o_sB, o_rda,
         o_dqB, o_qres, o_part, o_newrow, o_ctrl, o_ret, lds_floats;
 };
 
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 
     float *se_w0T = lds + a.o_se_w0T, *se_b0 = lds + a.o_se_b0, *se_wout = lds + a.o_se_wout, *se_bout = lds + a.o_se_bout;
     float *se_h = lds + a.o_se_h, *q_onl = lds + a.o_q_onl, *q_tgt = lds + a.o_q_tgt, *wscr = lds + a.o_wscr + wave * ((Hq + 63) & ~63);
-    float *hB = lds + a.o_hB, *dzB = lds + a.o_dzB, *sB = lds + a.o_sB, *rda = lds + a.o_rda, *dqB = lds + a.o_dqB;
+    float *hB = lds + a.o_hB, *sB = lds + a.o_sB, *rda = lds + a.o_rda, *dqB = lds + a.o_dqB;
     float *qres = lds + a.o_qres, *part = lds + a.o_part, *newrow = lds + a.o_newrow;
     volatile float *ctrl = lds + a.o_ctrl;             // [0..1] done (double buffered by step parity), [2] break flag, [4..] wave step counts
     double *ret = reinterpret_cast<double *>(lds + a.o_ret);   // [test_episodes] returns
@@ -151,14 +152,21 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
         }
     }
     // ---------------- fresh DDQN agent: online = target = agent_init (DDQN.py:33-35), Adam state 0 ----------------
-    float p_onl = 0.0f, p_tgt = 0.0f, p_m = 0.0f, p_v = 0.0f;
-    int my_off = 0;
-    if (tid < P) {
-        p_onl = a.agent_init[chain * P + tid];
-        p_tgt = p_onl;
-        my_off = packed_off<S, A>(tid, Hq, RP);
-        q_onl[my_off] = p_onl;
-        q_tgt[my_off] = p_tgt;
+    // thread tid owns parameters tid and tid+NT (master copy, target, Adam m/v in registers)
+    float p_onl[PPT], p_tgt[PPT], p_m[PPT], p_v[PPT];
+    int my_off[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = tid + k * NT;
+        p_onl[k] = p_tgt[k] = p_m[k] = p_v[k] = 0.0f;
+        my_off[k] = 0;
+        if (p < P) {
+            p_onl[k] = a.agent_init[chain * P + p];
+            p_tgt[k] = p_onl[k];
+            my_off[k] = packed_off<S, A>(p, Hq, RP);
+            q_onl[my_off[k]] = p_onl[k];
+            q_tgt[my_off[k]] = p_tgt[k];
+        }
     }
     if (tid < 8) ctrl[tid] = 0.0f;
     __syncthreads();
@@ -365,7 +373,8 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     }
                 }
                 __syncthreads();                               // B2
-                if (b < B) {
+                if (tid < B) {
+                    // TD target and dLoss/dQ(s,a) per sample (DDQN.py:82-86; mse_loss backward = 2/B * diff)
                     const float r = rda[b * 4], d = rda[b * 4 + 1];
                     const int ab = (int)rda[b * 4 + 2];
                     int am = 0;
@@ -376,13 +385,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     const float t2 = 1.0f - d;
                     const float y = r + t1 * t2;
                     const float diff = qres[(0 * MAX_B + b) * A + ab] - y;
-                    const float dq = norm * diff;
-                    if (pass == 0) dqB[b] = dq;
-                    for (int j = pass; j < Hq; j += 4) {
-                        const float h = hB[b * HP + j];
-                        const float da = dq * q_onl[j * RP + S + 1 + ab];
-                        dzB[b * HP + j] = act_bwd(cfg.q_act, cfg.q_prelu, h, da);
-                    }
+                    dqB[b] = norm * diff;
                 }
                 __syncthreads();                               // B3
                 // ---- batch gradient in micro-chunks: wave c reduces samples [c*chunk, (c+1)*chunk) ----
@@ -397,10 +400,12 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 #pragma unroll
                         for (int aa = 0; aa < A; ++aa) { gW2[aa] = 0.0f; gb2[aa] = 0.0f; }
                         for (int bb = b0; bb < b1; ++bb) {
-                            const float dz = jv ? dzB[bb * HP + j] : 0.0f;
                             const float h = jv ? hB[bb * HP + j] : 0.0f;
                             const float dq = dqB[bb];
                             const int ab = (int)rda[bb * 4 + 2];
+                            // dL/dz through the output layer and the activation (only row a_b of dQ is non-zero)
+                            const float da = dq * (jv ? q_onl[j * RP + S + 1 + ab] : 0.0f);
+                            const float dz = act_bwd(cfg.q_act, cfg.q_prelu, h, da);
 #pragma unroll
                             for (int i = 0; i < S; ++i) gW1[i] = fma32(dz, sB[bb * S + i], gW1[i]);
                             gb1 = gb1 + dz;
@@ -425,20 +430,26 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 // ---- torch.optim.Adam single-tensor step + Polyak (DDQN.py:88-93), one thread per parameter ----
                 b1pow *= cfg.adam_beta1;
                 b2pow *= cfg.adam_beta2;
-                if (tid < P) {
-                    float g = part[tid];
-                    for (int c = 1; c < a.n_chunks; ++c) g = g + part[c * P + tid];
+                {
                     const double bc1 = 1.0 - b1pow, bc2 = 1.0 - b2pow;
                     const float neg_step = (float)(-(cfg.lr / bc1));
                     const float bc2_sqrt = (float)__builtin_sqrt(bc2);
-                    p_m = fma32(w1, g - p_m, p_m);
-                    p_v = p_v * beta2;
-                    p_v = fma32(w2 * g, g, p_v);
-                    const float denom = __builtin_sqrtf(p_v) / bc2_sqrt + adam_eps;
-                    p_onl = p_onl + (neg_step * p_m) / denom;
-                    p_tgt = tau * p_onl + omt * p_tgt;
-                    q_onl[my_off] = p_onl;
-                    q_tgt[my_off] = p_tgt;
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k) {
+                        const int p = tid + k * NT;
+                        if (p < P) {
+                            float g = part[p];
+                            for (int c = 1; c < a.n_chunks; ++c) g = g + part[c * P + p];
+                            p_m[k] = fma32(w1, g - p_m[k], p_m[k]);
+                            p_v[k] = p_v[k] * beta2;
+                            p_v[k] = fma32(w2 * g, g, p_v[k]);
+                            const float denom = __builtin_sqrtf(p_v[k]) / bc2_sqrt + adam_eps;
+                            p_onl[k] = p_onl[k] + (neg_step * p_m[k]) / denom;
+                            p_tgt[k] = tau * p_onl[k] + omt * p_tgt[k];
+                            q_onl[my_off[k]] = p_onl[k];
+                            q_tgt[my_off[k]] = p_tgt[k];
+                        }
+                    }
                 }
                 ++learn_it;
                 __syncthreads();                               // B5
@@ -492,7 +503,11 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
             if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = 0;
         }
     }
-    if (a.out.final_online && tid < P) a.out.final_online[chain * P + tid] = p_onl;
+    if (a.out.final_online) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            if (tid + k * NT < P) a.out.final_online[chain * P + tid + k * NT] = p_onl[k];
+    }
     if (a.out.status) {
         // any thread that saw a tape underrun reports it
         if (status != 0) atomicMin(&a.out.status[chain], status);
@@ -517,6 +532,60 @@ static int64_t inner_rb_cap(const lenv_ddqn_cfg *cfg)
 
 static int inner_row_stride(const lenv_ddqn_cfg *cfg) { return (2 * cfg->state_dim + 3 + 3) & ~3; }
 
+// LDS carve-up of one chain's workgroup; returns LENV_ERR_UNSUPPORTED when the shapes do not fit 160 KiB
+static int inner_layout(const lenv_ddqn_cfg *cfg, InnerArgs &a)
+{
+    const int S = cfg->state_dim, A = cfg->num_actions, Hq = cfg->q_hidden, Hse = cfg->se_hidden, B = cfg->batch_size;
+    a.P_q = (int)mlp_params(S, Hq, 1, A);
+    a.se_net_size[0] = (int)mlp_params(S + A, Hse, 1, S);
+    a.se_net_size[1] = a.se_net_size[2] = (int)mlp_params(S + A, Hse, 1, 1);
+    a.P_se = a.se_net_size[0] + a.se_net_size[1] + a.se_net_size[2];
+    if (a.P_q > PPT * NT) return LENV_ERR_UNSUPPORTED;
+    a.RP = (S + 1 + A + 3) & ~3;
+    a.HP = Hq | 1;
+    a.chunk = cfg->grad_chunk > 0 ? cfg->grad_chunk : (B + NW - 1) / NW;
+    a.n_chunks = (B + a.chunk - 1) / a.chunk;
+    if (a.n_chunks > NW) return LENV_ERR_UNSUPPORTED;
+    const int K = S + A, HqPad = (Hq + 63) & ~63;
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    a.o_se_w0T = take(3 * K * Hse); a.o_se_b0 = take(3 * Hse); a.o_se_wout = take((S + 2) * Hse); a.o_se_bout = take(S + 2);
+    a.o_se_h = take(3 * Hse);
+    a.o_q_onl = take(Hq * a.RP + A); a.o_q_tgt = take(Hq * a.RP + A);
+    a.o_wscr = take(NW * HqPad);
+    a.o_hB = take(B * a.HP);
+    a.o_sB = take(B * S); a.o_rda = take(B * 4); a.o_dqB = take(B);
+    a.o_qres = take(3 * MAX_B * A);
+    a.o_part = take(a.n_chunks * a.P_q);
+    a.o_newrow = take(16); a.o_ctrl = take(4 + NW);
+    a.o_ret = take(2 * cfg->test_episodes + 2);
+    a.lds_floats = o;
+    if ((size_t)o * sizeof(float) > 160 * 1024) return LENV_ERR_UNSUPPORTED;
+    return LENV_OK;
+}
+
+static int inner_check(const lenv_ddqn_cfg *cfg)
+{
+    const int S = cfg->state_dim, A = cfg->num_actions, Hq = cfg->q_hidden, Hse = cfg->se_hidden, B = cfg->batch_size;
+    if (cfg->q_layers != 1 || cfg->se_layers != 1) return LENV_ERR_UNSUPPORTED;   // hidden_layer > 1: next round
+    if (B < 1 || B > MAX_B || Hq < 1 || Hse < 1 || cfg->test_episodes < 1 || cfg->train_episodes < 0 || cfg->max_steps < 1)
+        return LENV_ERR_UNSUPPORTED;
+    if (!((cfg->env_id == LENV_ENV_CARTPOLE && S == 4 && A == 2) || (cfg->env_id == LENV_ENV_ACROBOT && S == 6 && A == 3)))
+        return LENV_ERR_UNSUPPORTED;
+    return LENV_OK;
+}
+
+extern "C" int64_t lenv_ddqn_se_lds_bytes(const lenv_ddqn_cfg *cfg)
+{
+    if (!cfg) return LENV_ERR_INVALID;
+    int rc = inner_check(cfg);
+    if (rc != LENV_OK) return rc;
+    InnerArgs a;
+    rc = inner_layout(cfg, a);
+    if (rc != LENV_OK) return rc;
+    return (int64_t)a.lds_floats * (int64_t)sizeof(float);
+}
+
 extern "C" size_t lenv_ddqn_se_workspace_bytes(const lenv_ddqn_cfg *cfg, int64_t chains)
 {
     if (!cfg || chains < 0) return 0;
@@ -535,12 +604,8 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
     if (cfg->rng_mode == LENV_RNG_TAPE && !tapes) return LENV_ERR_INVALID;
     if (cfg->rng_mode == LENV_RNG_COUNTER && !rng_keys) return LENV_ERR_INVALID;
     if (chains == 0) return LENV_OK;
-    const int S = cfg->state_dim, A = cfg->num_actions, Hq = cfg->q_hidden, Hse = cfg->se_hidden, B = cfg->batch_size;
-    if (cfg->q_layers != 1 || cfg->se_layers != 1) return LENV_ERR_UNSUPPORTED;   // hidden_layer > 1: next round
-    if (B < 1 || B > MAX_B || Hq < 1 || Hse < 1 || cfg->test_episodes < 1 || cfg->train_episodes < 0 || cfg->max_steps < 1)
-        return LENV_ERR_UNSUPPORTED;
-    if (!((cfg->env_id == LENV_ENV_CARTPOLE && S == 4 && A == 2) || (cfg->env_id == LENV_ENV_ACROBOT && S == 6 && A == 3)))
-        return LENV_ERR_UNSUPPORTED;
+    const int crc = inner_check(cfg);
+    if (crc != LENV_OK) return crc;
     if (workspace_bytes < lenv_ddqn_se_workspace_bytes(cfg, chains)) return LENV_ERR_WORKSPACE;
 
     InnerArgs a;
@@ -554,32 +619,9 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
     size_t replay_bytes = ((size_t)chains * a.rb_cap * a.row_stride * sizeof(float) + 255) & ~(size_t)255;
     a.meter = reinterpret_cast<double *>(static_cast<char *>(workspace) + replay_bytes);
     a.out = *out;
-    a.P_q = (int)mlp_params(S, Hq, 1, A);
-    a.se_net_size[0] = (int)mlp_params(S + A, Hse, 1, S);
-    a.se_net_size[1] = a.se_net_size[2] = (int)mlp_params(S + A, Hse, 1, 1);
-    a.P_se = a.se_net_size[0] + a.se_net_size[1] + a.se_net_size[2];
-    if (a.P_q > NT) return LENV_ERR_UNSUPPORTED;
-    a.RP = (S + 1 + A + 3) & ~3;
-    a.HP = Hq | 1;
-    a.chunk = cfg->grad_chunk > 0 ? cfg->grad_chunk : (B + NW - 1) / NW;
-    a.n_chunks = (B + a.chunk - 1) / a.chunk;
-    if (a.n_chunks > NW) return LENV_ERR_UNSUPPORTED;
-    const int K = S + A, HqPad = (Hq + 63) & ~63;
-    int o = 0;
-    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
-    a.o_se_w0T = take(3 * K * Hse); a.o_se_b0 = take(3 * Hse); a.o_se_wout = take((S + 2) * Hse); a.o_se_bout = take(S + 2);
-    a.o_se_h = take(3 * Hse);
-    a.o_q_onl = take(Hq * a.RP + A); a.o_q_tgt = take(Hq * a.RP + A);
-    a.o_wscr = take(NW * HqPad);
-    a.o_hB = take(B * a.HP); a.o_dzB = take(B * a.HP);
-    a.o_sB = take(B * S); a.o_rda = take(B * 4); a.o_dqB = take(B);
-    a.o_qres = take(3 * MAX_B * A);
-    a.o_part = take(a.n_chunks * a.P_q);
-    a.o_newrow = take(16); a.o_ctrl = take(4 + NW);
-    a.o_ret = take(2 * cfg->test_episodes + 2);
-    a.lds_floats = o;
-    const size_t lds_bytes = (size_t)o * sizeof(float);
-    if (lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
+    const int lrc = inner_layout(cfg, a);
+    if (lrc != LENV_OK) return lrc;
+    const size_t lds_bytes = (size_t)a.lds_floats * sizeof(float);
 
     void (*kern)(const InnerArgs) = nullptr;
     if (cfg->env_id == LENV_ENV_CARTPOLE) kern = ddqn_se_inner_kernel<LENV_ENV_CARTPOLE, 4, 2>;

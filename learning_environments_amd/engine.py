@@ -166,3 +166,29 @@ def nes_rank_update(score_transform_type, gathered, rank_table, theta, eps, step
                                          1 if nes_step_size else 0, float(weight_decay), _ptr(weights), _stream())
     _lib.check(rc, "lenv_nes_rank_update")
     return weights
+
+
+class HipNesEngine(object):
+    """The compute engine GTN_Master/GTN_Worker drive: every method is a thin call into liblenv_hip.so.
+    (tests substitute an oracle-backed object with the same methods to exercise the host/distributed logic on CPU)"""
+    name = "hip"
+
+    def __init__(self):
+        self.device = require_device()
+
+    def make_inner(self, cfg, chains, **kw):
+        return InnerLoop(cfg, chains, **kw)
+
+    def inner_scores(self, inner, theta, eps, worker, sign, agent_init, rng_keys):
+        return inner.run(theta, eps, worker, sign, agent_init, rng_keys=rng_keys)
+
+    def check_status(self, inner):
+        st = inner.status.cpu()
+        if int(st.min()) != 0:
+            raise _lib.LenvError("inner loop reported status %s" % st.tolist())
+
+    def worker_best(self, chain_scores, pop, mirrored):
+        return nes_worker_best(chain_scores, pop, mirrored)
+
+    def rank_update(self, score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size, weight_decay):
+        return nes_rank_update(score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size, weight_decay)

@@ -1,0 +1,129 @@
+"""EnvWrapper: the uniform tensor API over real / virtual envs (reference envs/env_wrapper.py:9-167).
+
+Same methods, argument meaning and return conventions: `step(action, state=None)` returns the 3-tuple
+`(next_state, reward, done)` of CPU fp32 tensors.  New (batched fast path, not in the reference):
+`step_population` evaluates many NES perturbations of a virtual env in one kernel launch.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import engine
+from ..utils import from_one_hot_encoding, to_one_hot_encoding
+from .spaces import Discrete
+from .virtual_env import VirtualEnv
+
+
+class EnvWrapper(nn.Module):
+    def __init__(self, env):
+        super().__init__()
+        self.env = env
+        self.same_action_num = 1
+
+    def step(self, action, state=None):
+        if self.is_virtual_env():
+            reward_sum = None
+            if self.has_discrete_action_space():
+                action = to_one_hot_encoding(action, self.get_action_dim())
+            for _ in range(self.same_action_num):
+                state, reward, done = self.env.step(action=action, state=state)
+                reward_sum = reward if reward_sum is None else reward_sum + reward
+            reward = reward_sum.to("cpu")
+            next_state = state.to("cpu")
+            done = done.to("cpu")
+            if self.has_discrete_state_space():
+                next_state = from_one_hot_encoding(next_state)
+            return next_state, reward, done
+        else:
+            action = action.cpu().detach().numpy()
+            if self.has_discrete_action_space():
+                action = action.astype(int)[0]
+            reward_sum = 0
+            for _ in range(self.same_action_num):
+                state, reward, done, _info = self.env.step(action)
+                reward_sum += reward
+                if done:
+                    break
+            next_state_torch = torch.tensor(state, device="cpu", dtype=torch.float32)
+            reward_torch = torch.tensor(reward_sum, device="cpu", dtype=torch.float32)
+            done_torch = torch.tensor(done, device="cpu", dtype=torch.float32)
+            if next_state_torch.dim() == 0:
+                next_state_torch = next_state_torch.unsqueeze(0)
+            return next_state_torch, reward_torch, done_torch
+
+    def step_population(self, actions, states, eps=None, worker=None, sign=None):
+        """Batched fast path: chain c steps the SE with weights theta + sign[c]*eps[worker[c]].
+        actions int32 [chains], states fp32 [chains,S] (device).  Returns device tensors."""
+        if not self.is_virtual_env():
+            raise NotImplementedError("step_population is defined for virtual envs")
+        return engine.se_step_population(self.env.descs(), self.env.flat_params(), eps, worker, sign, states, actions)
+
+    def reset(self):
+        state = self.env.reset()
+        if type(state) == np.ndarray:
+            state_torch = torch.from_numpy(state).float().cpu()
+        elif torch.is_tensor(state):
+            state_torch = state.cpu()
+        else:
+            state_torch = torch.tensor([state], device="cpu", dtype=torch.float32)
+        if self.has_discrete_state_space() and self.is_virtual_env():
+            return from_one_hot_encoding(state_torch)
+        return state_torch
+
+    def get_random_action(self):
+        space = self.env.action_space
+        if isinstance(space, Discrete):
+            return torch.tensor([int(np.random.randint(space.n))], device="cpu", dtype=torch.float32)
+        return torch.from_numpy(np.random.uniform(space.low, space.high).astype(np.float32))
+
+    def get_state_dim(self):
+        if self.env.observation_space.shape:
+            return self.env.observation_space.shape[0]
+        return self.env.observation_space.n
+
+    def get_action_dim(self):
+        if self.env.action_space.shape:
+            return self.env.action_space.shape[0]
+        return self.env.action_space.n
+
+    def get_max_action(self):
+        return 2 if self.env.env_name == 'Pendulum-v0' else 1
+
+    def get_min_action(self):
+        return 0 if self.env.env_name == 'CartPole-v0' else -self.get_max_action()
+
+    def has_discrete_action_space(self):
+        return isinstance(self.env.action_space, Discrete)
+
+    def has_discrete_state_space(self):
+        return isinstance(self.env.observation_space, Discrete)
+
+    def render(self):
+        return None
+
+    def close(self):
+        if not self.is_virtual_env():
+            return self.env.close()
+
+    def get_solved_reward(self):
+        return self.env.solved_reward
+
+    def max_episode_steps(self):
+        return self.env._max_episode_steps
+
+    def can_be_solved(self):
+        return self.env.solved_reward < 1e9
+
+    def seed(self, seed):
+        if not self.is_virtual_env():
+            return self.env.seed(seed)
+        print("Setting manuel seed not yet implemented, performance may decrease")
+        return 0
+
+    def is_virtual_env(self):
+        return isinstance(self.env, VirtualEnv)
+
+    def set_agent_params(self, same_action_num, gamma):
+        self.same_action_num = same_action_num
+        if hasattr(self.env, "set_agent_params"):
+            self.env.set_agent_params(gamma=gamma)

@@ -1,0 +1,75 @@
+"""Device-resident real environments (CartPole-v0 / Acrobot-v1 of gym==0.17.3, third party; dynamics restated in
+csrc/lenv_device.cuh and UNPINNED -- see DESIGN.md).  One instance = one environment whose float64 state lives in HBM
+and is stepped by lenv_real_env_step; the fused inner loop uses the same device functions for its scoring rollouts."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..engine import require_device, _ptr, _stream
+from .spaces import Box, Discrete
+
+_SPECS = {
+    "CartPole-v0": dict(S=4, A=2, max_steps=200,
+                        high=[4.8, np.finfo(np.float32).max, 24 * 2 * math.pi / 360, np.finfo(np.float32).max]),
+    "Acrobot-v1": dict(S=6, A=3, max_steps=500, high=[1.0, 1.0, 1.0, 1.0, 4 * math.pi, 9 * math.pi]),
+}
+
+
+class DeviceRealEnv(object):
+    """gym.Env look-alike: reset() -> obs (np.float32[S]); step(a) -> (obs, reward, done, info)."""
+
+    def __init__(self, env_name, seed=0):
+        if env_name not in _SPECS:
+            raise NotImplementedError("real env '%s' has no device implementation yet" % env_name)
+        spec = _SPECS[env_name]
+        self.env_name = env_name
+        self.env_id = _lib.ENV[env_name]
+        self.observation_space = Box(-np.asarray(spec["high"]), np.asarray(spec["high"]))
+        self.action_space = Discrete(spec["A"])
+        self._max_episode_steps = spec["max_steps"]
+        self._S = spec["S"]
+        self._seed = int(seed)
+        self._episode = 0
+        self._dev = None
+
+    def _alloc(self):
+        if self._dev is None:
+            dev = require_device()
+            self._dev = dict(state=torch.zeros(4, dtype=torch.float64, device=dev), elapsed=torch.zeros(1, dtype=torch.int32, device=dev),
+                             obs=torch.zeros(self._S, dtype=torch.float32, device=dev), reward=torch.zeros(1, device=dev),
+                             done=torch.zeros(1, device=dev), action=torch.zeros(1, dtype=torch.int32, device=dev),
+                             key=torch.zeros(1, dtype=torch.int64, device=dev), episode=torch.zeros(1, dtype=torch.int64, device=dev))
+        return self._dev
+
+    def seed(self, seed=None):
+        self._seed = int(seed or 0)
+        self._episode = 0
+        return [self._seed]
+
+    def reset(self):
+        d = self._alloc()
+        key = _lib.lib().lenv_chain_key(self._seed, 0, 0, 3)
+        d["key"].fill_(np.array([key], np.uint64).view(np.int64)[0].item())
+        d["episode"].fill_(self._episode)
+        self._episode += 1
+        rc = _lib.lib().lenv_real_env_reset(self.env_id, _ptr(d["key"]), _ptr(d["episode"]), 1, _ptr(d["state"]), _ptr(d["obs"]),
+                                            _ptr(d["elapsed"]), _stream())
+        _lib.check(rc, "lenv_real_env_reset")
+        return d["obs"].cpu().numpy()
+
+    def step(self, action):
+        d = self._alloc()
+        d["action"].fill_(int(action))
+        rc = _lib.lib().lenv_real_env_step(self.env_id, int(self._max_episode_steps), 1, _ptr(d["action"]), _ptr(d["state"]),
+                                           _ptr(d["elapsed"]), _ptr(d["obs"]), _ptr(d["reward"]), _ptr(d["done"]), _stream())
+        _lib.check(rc, "lenv_real_env_step")
+        return d["obs"].cpu().numpy(), float(d["reward"].item()), bool(d["done"].item() > 0.5), {}
+
+    def render(self, mode='human'):
+        return None
+
+    def close(self):
+        return None
