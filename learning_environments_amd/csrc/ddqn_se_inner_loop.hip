@@ -12,22 +12,38 @@
 //        early-out                            agents/base_agent.py:49-62,141-148
 //     final BaseAgent.test, statistics.mean   agents/GTN_worker.py:199-209
 //
-// Design (DESIGN.md "Kernel K-inner"): the whole chain runs inside one launch.  SE weights
+// Design (DESIGN.md "Kernel K-inner"): the whole chain runs inside one launch of 12 waves.  SE weights
 // (theta + sign*eps), the Q-net, its target, and all minibatch activations live in LDS; Adam state and
 // master copies of the Q parameters live in the owning thread's registers; only the replay buffer is in
-// HBM/L2.  Per training step: wave 12 acts + steps the SE + appends the transition while waves 0-11
-// prefetch their minibatch rows; then 12 waves run the three Q forwards (thread = sample x pass), one thread
-// per sample forms the TD error, up to 16 waves back-propagate + reduce the batch gradient in micro-chunks, 1 thread/parameter applies Adam.
+// HBM/L2.  Per training step: the last wave acts + steps the SE + appends the transition while the other waves
+// prefetch their minibatch rows; then the 3*B (sample, pass) forward items run one per thread (pass-major, dense),
+// one thread per sample forms the TD error, up to 12 waves back-propagate + reduce the batch gradient in
+// micro-chunks, one thread per parameter applies Adam + Polyak.
 // Arithmetic order is the oracle's canonical order (oracle/lenv_oracle.h) => results are bit-identical.
 #include "lenv_device.cuh"
 
+#include <type_traits>
+
 namespace lenv {
 
-constexpr int NT = 1024;          // threads per chain
+constexpr int NT = 768;           // threads per chain: 12 wave64 = 3 per SIMD, 168 VGPRs each
 constexpr int NW = NT / 64;       // waves per chain
-constexpr int ENV_WAVE = 12;      // wave that plays the environment/actor role during a training step
-constexpr int MAX_B = 256;        // minibatch samples (one per thread of a 256-thread pass group)
-constexpr int PPT = 2;            // Q-net parameters owned per thread (P_agent <= PPT*NT)
+constexpr int ENV_WAVE = NW - 1;  // wave that plays the environment/actor role during a training step
+constexpr int FWD_THREADS = NT - 64;   // threads available for (sample, pass) forward items while the env wave acts
+constexpr int MAX_B = FWD_THREADS / 3; // minibatch samples (3 forward items per sample, one item per thread)
+constexpr int MAX_PPT = 2;        // Q-net parameters owned per thread (P_agent <= MAX_PPT*NT)
+
+// Diagnostic build only (-DLENV_PHASE_TIMING): per-phase shader-clock totals of chain 0, never in the shipped library.
+#ifdef LENV_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[16];
+#define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PT_MARK(i) do { unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
+#define PT_FLUSH(first, n) do { if (chain == 0) for (int pi = 0; pi < (n); ++pi) g_phase_cycles[(first) + pi] = pt_acc[pi]; } while (0)
+#else
+#define PT_DECL
+#define PT_MARK(i)
+#define PT_FLUSH(first, n)
+#endif
 
 struct InnerArgs {
     lenv_ddqn_cfg cfg;
@@ -39,8 +55,8 @@ struct InnerArgs {
     int P_q, P_se, se_net_size[3];
     int RP, HP, chunk, n_chunks;
     // LDS offsets (floats)
-    int o_se_w0T, o_se_b0, o_se_wout, o_se_bout, o_se_h, o_q_onl, o_q_tgt, o_wscr, o_hB, o_sB, o_rda,
-        o_dqB, o_qres, o_part, o_newrow, o_ctrl, o_ret, lds_floats;
+    int o_se_w0T, o_se_b0, o_se_wout, o_se_bout, o_se_h, o_q_onl, o_q_tgt, o_q_w2, o_wscr, o_hB, o_sB, o_rda,
+        o_dqB, o_qres, o_part, o_newrow, o_ctrl, o_ret, o_tanh, o_cand, o_cur_state, lds_floats;
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -50,39 +66,120 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Q-net parameters live in LDS as PAIR records: hidden units (2q, 2q+1) share one record of PR = 2*RP floats
+//   [W1[2q][0], W1[2q+1][0], ..., W1[2q][S-1], W1[2q+1][S-1] | b1[2q], b1[2q+1] | W2[0][2q], W2[0][2q+1], ... ]
+// so one thread can evaluate two hidden units per iteration with packed fp32 math on adjacent register pairs; the
+// output biases b2 follow the last record.  Canonical parameter index p -> LDS offset:
 template <int S, int A>
-__device__ __forceinline__ int packed_off(int p, int Hq, int RP)
+__device__ __forceinline__ int packed_off(int p, int Hq, int PR)
 {
+    const int npairs = (Hq + 1) >> 1;
     const int nW1 = Hq * S;
-    if (p < nW1) { int j = p / S; return j * RP + (p - j * S); }
+    if (p < nW1) { int j = p / S, i = p - j * S; return (j >> 1) * PR + 2 * i + (j & 1); }
     p -= nW1;
-    if (p < Hq) return p * RP + S;
+    if (p < Hq) return (p >> 1) * PR + 2 * S + (p & 1);
     p -= Hq;
-    if (p < A * Hq) { int aa = p / Hq; int j = p - aa * Hq; return j * RP + S + 1 + aa; }
+    if (p < A * Hq) { int aa = p / Hq; int j = p - aa * Hq; return (j >> 1) * PR + 2 * S + 2 + 2 * aa + (j & 1); }
     p -= A * Hq;
-    return Hq * RP + p;
+    return npairs * PR + p;
 }
 
-// Batch-1 greedy action of a Critic_DQN held as packed records in LDS: one wave, lane = hidden unit.
-// Returns argmax_a Q(obs) (first maximum), identical in every lane.
-template <int S, int A>
-__device__ __forceinline__ int wave_q_argmax(const float *W, const float (&obs)[S], float *scratch, int Hq, int RP,
-                                             int act, float prelu, int lane)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd_t(const float *tanh_tab, float prelu, float z)
+{
+    if constexpr (ACT == LENV_ACT_RELU) return z > 0.0f ? z : 0.0f;
+    else if constexpr (ACT == LENV_ACT_LEAKYRELU) return z > 0.0f ? z : z * 0.01f;
+    else if constexpr (ACT == LENV_ACT_TANH) return det_tanhf(tanh_tab, z);
+    else if constexpr (ACT == LENV_ACT_PRELU) return z > 0.0f ? z : prelu * z;
+    else return z;
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_bwd_t(float prelu, float a, float g)
+{
+    if constexpr (ACT == LENV_ACT_RELU) return a > 0.0f ? g : 0.0f;
+    else if constexpr (ACT == LENV_ACT_LEAKYRELU) return a > 0.0f ? g : g * 0.01f;
+    else if constexpr (ACT == LENV_ACT_TANH) return g * fma32(-a, a, 1.0f);
+    else if constexpr (ACT == LENV_ACT_PRELU) return a > 0.0f ? g : prelu * g;
+    else return g;
+}
+
+// Two-stage activation so that the table gather of the canonical tanh can be issued one iteration ahead of its use.
+template <int ACT>
+struct ActPipe {
+    float z, t, u;
+    float4 k;
+    __device__ __forceinline__ void issue(const float *tanh_tab, float zz)
+    {
+        z = zz;
+        if constexpr (ACT == LENV_ACT_TANH) {
+            const float ax = __builtin_fabsf(zz);
+            t = ax < LENV_TANH_TMAX ? ax : LENV_TANH_TMAX;
+            const float t32 = t * 32.0f;
+            const int idx = (int)t32;
+            u = fma32(__builtin_amdgcn_fractf(t32), 0.03125f, -0.015625f);
+            k = *reinterpret_cast<const float4 *>(tanh_tab + 4 * idx);
+        }
+    }
+    __device__ __forceinline__ float finish(float prelu) const
+    {
+        if constexpr (ACT == LENV_ACT_TANH) {
+            float p = fma32(k.w, u, k.z);
+            p = fma32(p, u, k.y);
+            p = fma32(p, u, k.x);
+            const float r = __builtin_fminf(t * p, 1.0f);
+            return __builtin_copysignf(r, z);
+        } else {
+            return act_fwd_t<ACT>(nullptr, prelu, z);
+        }
+    }
+};
+
+// acc = fmaf chain over j = 0..n-1 of h[j]*w[j] in index order (the canonical order); the loads are 16-byte and
+// issued eight at a time so the chain is bound by fma latency, not by one LDS round trip per term.
+// h and w must be 16-byte aligned.
+__device__ __forceinline__ float seq_dot_lds(const float *h, const float *w, int n)
+{
+    float acc = 0.0f;
+    const float4 *h4 = reinterpret_cast<const float4 *>(h), *w4 = reinterpret_cast<const float4 *>(w);
+    const int n4 = n >> 2;
+    int q = 0;
+    for (; q + 4 <= n4; q += 4) {
+        const float4 a0 = h4[q], a1 = h4[q + 1], a2 = h4[q + 2], a3 = h4[q + 3];
+        const float4 b0 = w4[q], b1 = w4[q + 1], b2 = w4[q + 2], b3 = w4[q + 3];
+        acc = fma32(a0.x, b0.x, acc); acc = fma32(a0.y, b0.y, acc); acc = fma32(a0.z, b0.z, acc); acc = fma32(a0.w, b0.w, acc);
+        acc = fma32(a1.x, b1.x, acc); acc = fma32(a1.y, b1.y, acc); acc = fma32(a1.z, b1.z, acc); acc = fma32(a1.w, b1.w, acc);
+        acc = fma32(a2.x, b2.x, acc); acc = fma32(a2.y, b2.y, acc); acc = fma32(a2.z, b2.z, acc); acc = fma32(a2.w, b2.w, acc);
+        acc = fma32(a3.x, b3.x, acc); acc = fma32(a3.y, b3.y, acc); acc = fma32(a3.z, b3.z, acc); acc = fma32(a3.w, b3.w, acc);
+    }
+    for (; q < n4; ++q) {
+        const float4 a0 = h4[q], b0 = w4[q];
+        acc = fma32(a0.x, b0.x, acc); acc = fma32(a0.y, b0.y, acc); acc = fma32(a0.z, b0.z, acc); acc = fma32(a0.w, b0.w, acc);
+    }
+    for (int j = n4 << 2; j < n; ++j) acc = fma32(h[j], w[j], acc);
+    return acc;
+}
+
+// Batch-1 greedy action of a Critic_DQN held in LDS (pair records W + row-major output rows W2rows):
+// one wave, lane = hidden unit.  Returns argmax_a Q(obs) (first maximum), identical in every lane.
+template <int S, int A, int PR, int QACT>
+__device__ __forceinline__ int wave_q_argmax(const float *W, const float *W2rows, int HqP, const float (&obs)[S], float *scratch,
+                                             int Hq, float prelu, int lane, const float *tanh_tab)
 {
     for (int j = lane; j < Hq; j += 64) {
-        const float *rec = W + j * RP;
+        const float *rec = W + (j >> 1) * PR + (j & 1);
         float z = 0.0f;
 #pragma unroll
-        for (int i = 0; i < S; ++i) z = fma32(obs[i], rec[i], z);
-        z = z + rec[S];
-        scratch[j] = act_fwd(act, prelu, z);
+        for (int i = 0; i < S; ++i) z = fma32(obs[i], rec[2 * i], z);
+        z = z + rec[2 * S];
+        scratch[j] = act_fwd_t<QACT>(tanh_tab, prelu, z);
     }
     wave_sync();
     float q = 0.0f;
-    if (lane < A) {
-        for (int j = 0; j < Hq; ++j) q = fma32(scratch[j], W[j * RP + S + 1 + lane], q);
-        q = q + W[Hq * RP + lane];
-    }
+    if (lane < A) q = seq_dot_lds(scratch, W2rows + lane * HqP, Hq) + W[((Hq + 1) >> 1) * PR + lane];
     wave_sync();
     float best = __shfl(q, 0);
     int arg = 0;
@@ -114,23 +211,31 @@ __device__ __forceinline__ void real_env_obs(const double (&st)[4], float (&obs)
     }
 }
 
-template <int ENV, int S, int A>
+template <int ENV, int S, int A, int QACT, int PPT>
 __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 {
     extern __shared__ __align__(16) float lds[];
     const lenv_ddqn_cfg &cfg = a.cfg;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t chain = blockIdx.x;
     constexpr int K = S + A;
-    const int Hq = cfg.q_hidden, Hse = cfg.se_hidden, B = cfg.batch_size, RP = a.RP, HP = a.HP, P = a.P_q;
-    const int RS = a.row_stride;
+    constexpr int RP = (S + 1 + A + 3) & ~3;
+    constexpr int PR = 2 * RP;                        // floats per pair record
+    constexpr int RS = (2 * S + 3 + 3) & ~3;          // replay row stride (floats)
+    const int Hq = cfg.q_hidden, Hse = cfg.se_hidden, B = cfg.batch_size, HP = a.HP, P = a.P_q;
+    const int HqP = (Hq + 3) & ~3, HseP = (Hse + 3) & ~3;
 
     float *se_w0T = lds + a.o_se_w0T, *se_b0 = lds + a.o_se_b0, *se_wout = lds + a.o_se_wout, *se_bout = lds + a.o_se_bout;
-    float *se_h = lds + a.o_se_h, *q_onl = lds + a.o_q_onl, *q_tgt = lds + a.o_q_tgt, *wscr = lds + a.o_wscr + wave * ((Hq + 63) & ~63);
+    float *se_h = lds + a.o_se_h, *q_onl = lds + a.o_q_onl, *q_tgt = lds + a.o_q_tgt, *q_w2 = lds + a.o_q_w2;
+    float *wscr = lds + a.o_wscr + wave * ((Hq + 63) & ~63);
+    float *se_hw = se_h + (wave & 1) * 3 * HseP;      // per-wave SE hidden scratch (waves NW-2 / NW-1)
+    float *cand = lds + a.o_cand, *cur_state = lds + a.o_cur_state;
     float *hB = lds + a.o_hB, *sB = lds + a.o_sB, *rda = lds + a.o_rda, *dqB = lds + a.o_dqB;
     float *qres = lds + a.o_qres, *part = lds + a.o_part, *newrow = lds + a.o_newrow;
-    volatile float *ctrl = lds + a.o_ctrl;             // [0..1] done (double buffered by step parity), [2] break flag, [4..] wave step counts
+    volatile float *ctrl = lds + a.o_ctrl;   // [0..1] done (double buffered by step parity), [2] break, [3] Adam -step, [4] sqrt(bc2), [8..] wave step counts
     double *ret = reinterpret_cast<double *>(lds + a.o_ret);   // [test_episodes] returns
+    float *tanh_tab = lds + a.o_tanh;                  // LDS copy of the canonical tanh table (4.7 KB)
+    for (int i = tid; i < LENV_TANH_N * 4; i += NT) tanh_tab[i] = lenv_tanh_table[i];
 
     // ---------------- stage the perturbed SE: W = theta + sign*eps[worker]  (GTN_worker.py:165-175) ----------------
     {
@@ -146,7 +251,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
             else {
                 r -= Hse;
                 const int n_out = net == 0 ? S : 1;
-                if (r < n_out * Hse) { int o = r / Hse, j = r - o * Hse; se_wout[(orow + o) * Hse + j] = w; }
+                if (r < n_out * Hse) { int o = r / Hse, j = r - o * Hse; se_wout[(orow + o) * HseP + j] = w; }
                 else se_bout[orow + (r - n_out * Hse)] = w;
             }
         }
@@ -154,46 +259,97 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     // ---------------- fresh DDQN agent: online = target = agent_init (DDQN.py:33-35), Adam state 0 ----------------
     // thread tid owns parameters tid and tid+NT (master copy, target, Adam m/v in registers)
     float p_onl[PPT], p_tgt[PPT], p_m[PPT], p_v[PPT];
-    int my_off[PPT];
+    int my_off[PPT], my_w2[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int p = tid + k * NT;
         p_onl[k] = p_tgt[k] = p_m[k] = p_v[k] = 0.0f;
-        my_off[k] = 0;
+        my_off[k] = 0; my_w2[k] = -1;
         if (p < P) {
             p_onl[k] = a.agent_init[chain * P + p];
             p_tgt[k] = p_onl[k];
-            my_off[k] = packed_off<S, A>(p, Hq, RP);
+            my_off[k] = packed_off<S, A>(p, Hq, PR);
             q_onl[my_off[k]] = p_onl[k];
             q_tgt[my_off[k]] = p_tgt[k];
+            const int r2 = p - (Hq * S + Hq);          // row-major copy of the output layer for the batch-1 chains
+            my_w2[k] = (r2 >= 0 && r2 < A * Hq) ? (r2 / Hq) * HqP + (r2 % Hq) : -1;
+            if (my_w2[k] >= 0) q_w2[my_w2[k]] = p_onl[k];
         }
     }
-    if (tid < 8) ctrl[tid] = 0.0f;
+    if (tid < 8 + NW) ctrl[tid] = 0.0f;
     __syncthreads();
 
     const uint64_t key = a.rng_keys ? a.rng_keys[chain] : 0;
     const bool tape = cfg.rng_mode == LENV_RNG_TAPE;
     int status = 0;
-    int64_t n_eps = 0, n_act = 0, n_test_ep = 0, learn_it = 0, rb_ptr = 0, rb_size = 0, n_trace = 0;
-    int64_t train_steps = 0, test_steps = 0;
-    double b1pow = 1.0, b2pow = 1.0, eps_g = cfg.eps_init;
+    // counters (all uniform): one eps-uniform draw and one replay append per train step
+    int train_steps = 0, n_act = 0, learn_it = 0, n_test_ep = 0, test_steps = 0;
+    double eps_g = cfg.eps_init;
+    double b1pow = 1.0, b2pow = 1.0;                   // maintained by thread 0 only
     float *rb = a.replay + chain * a.rb_cap * RS;
+    const int rb_cap = (int)a.rb_cap;
     double *meter = a.meter + chain * cfg.train_episodes;
     const double reset_lim = ENV == LENV_ENV_CARTPOLE ? 0.05 : 0.1;
-    const float g32 = (float)cfg.gamma, norm = (float)(2.0 / (double)B);
-    const float w1 = (float)(1.0 - cfg.adam_beta1), w2 = (float)(1.0 - cfg.adam_beta2), beta2 = (float)cfg.adam_beta2;
-    const float adam_eps = (float)cfg.adam_eps, tau = (float)cfg.tau, omt = (float)(1.0 - cfg.tau);
-    int episodes_run = 0, n_meter = 0;
+    int episodes_run = 0;
     float state[S];
 #pragma unroll
     for (int i = 0; i < S; ++i) state[i] = 0.0f;
 
-    // one real-env test phase (BaseAgent.test + DDQN.select_test_action): wave w plays test episode w (+16 per round)
+    // forward work item of this thread: item = pass*B + b (pass-major, dense over the first 3*B threads)
+    const int fwd_pass = tid < B ? 0 : (tid < 2 * B ? 1 : 2);
+    const int fwd_b = tid - fwd_pass * B;
+    const bool fwd_active = tid < 3 * B;
+
+    // speculation layout: waves without forward items (at most the last two) evaluate the SE for every action of the
+    // NEXT step while the other waves run the minibatch forwards; the env wave then only has to pick a candidate.
+    const int n_fwd_waves = (3 * B + 63) >> 6;
+    const int first_spec = n_fwd_waves > NW - 2 ? n_fwd_waves : NW - 2;
+    const int n_spec = NW - first_spec;                 // 0, 1 or 2 (uniform)
+    bool spec_valid = false;
+
+    // EnvWrapper.step -> VirtualEnv.step for ONE wave: x = [onehot(action), st]; returns output `lane` (< S+2) of
+    // [next_state(S), reward, done] in lane `lane`.  Lane = hidden unit; outputs are sequential fmaf chains.
+    auto se_eval = [&](float *hbuf, const float (&st)[S], int action) -> float {
+        float x[K];
+#pragma unroll
+        for (int k = 0; k < A; ++k) x[k] = (k == action) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int i = 0; i < S; ++i) x[A + i] = st[i];
+        auto se_hidden = [&](auto act_tag) {
+            constexpr int SEACT = decltype(act_tag)::value;
+            for (int uu = lane; uu < 3 * Hse; uu += 64) {
+                const int net = uu / Hse, j = uu - net * Hse;
+                const float *w = se_w0T + net * K * Hse + j;
+                float z = 0.0f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) z = fma32(x[k], w[k * Hse], z);
+                z = z + se_b0[uu];
+                hbuf[net * HseP + j] = act_fwd_t<SEACT>(tanh_tab, cfg.se_prelu, z);
+            }
+        };
+        switch (cfg.se_act) {
+        case LENV_ACT_RELU: se_hidden(std::integral_constant<int, LENV_ACT_RELU>{}); break;
+        case LENV_ACT_LEAKYRELU: se_hidden(std::integral_constant<int, LENV_ACT_LEAKYRELU>{}); break;
+        case LENV_ACT_TANH: se_hidden(std::integral_constant<int, LENV_ACT_TANH>{}); break;
+        case LENV_ACT_PRELU: se_hidden(std::integral_constant<int, LENV_ACT_PRELU>{}); break;
+        default: se_hidden(std::integral_constant<int, LENV_ACT_IDENTITY>{}); break;
+        }
+        wave_sync();
+        float acc = 0.0f;
+        if (lane < S + 2) {
+            const int net = lane < S ? 0 : (lane == S ? 1 : 2);
+            acc = seq_dot_lds(hbuf + net * HseP, se_wout + lane * HseP, Hse) + se_bout[lane];
+        }
+        wave_sync();
+        return acc;
+    };
+
+    // one real-env test phase (BaseAgent.test + DDQN.select_test_action): wave w plays test episodes w, w+NW, ...
     auto test_phase = [&]() {
         int my_steps = 0;
         for (int te = wave; te < cfg.test_episodes; te += NW) {
             double st[4];
-            const int64_t row = n_test_ep + te;
+            const int64_t row = (int64_t)n_test_ep + te;
             if (tape) {
                 if (row >= a.tapes.test_reset_stride) { status = -5; for (int i = 0; i < 4; ++i) st[i] = 0.0; }
                 else for (int i = 0; i < 4; ++i) st[i] = a.tapes.test_reset[(chain * a.tapes.test_reset_stride + row) * 4 + i];
@@ -205,7 +361,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
             for (int t = 0; t < cfg.max_steps; ++t) {
                 float obs[S];
                 real_env_obs<ENV, S>(st, obs);
-                const int act = wave_q_argmax<S, A>(q_onl, obs, wscr, Hq, RP, cfg.q_act, cfg.q_prelu, lane);
+                const int act = wave_q_argmax<S, A, PR, QACT>(q_onl, q_w2, HqP, obs, wscr, Hq, cfg.q_prelu, lane, tanh_tab);
                 double rew; int done;
                 real_env_step<ENV>(st, act, rew, done);
                 ep_reward = ep_reward + (float)rew;
@@ -214,12 +370,13 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
             }
             if (lane == 0) ret[te] = (double)ep_reward;
         }
-        if (lane == 0) ctrl[4 + wave] = __int_as_float(my_steps);
+        if (lane == 0) ctrl[8 + wave] = __int_as_float(my_steps);
         n_test_ep += cfg.test_episodes;
         __syncthreads();
-        for (int w = 0; w < NW; ++w) test_steps += __float_as_int(ctrl[4 + w]);
+        for (int w = 0; w < NW; ++w) test_steps += __float_as_int(ctrl[8 + w]);
     };
 
+    PT_DECL;
     for (int episode = 0; episode < cfg.train_episodes; ++episode) {
         // DDQN.update_parameters_per_episode (DDQN.py:112-117)
         if (episode == 0) eps_g = cfg.eps_init;
@@ -227,7 +384,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
         const bool learning = episode >= cfg.init_episodes;
 
         // env.reset(): VirtualEnv.reset -> real-env reset state as fp32 (virtual_env.py:35-41)
-        {
+        if (wave == ENV_WAVE) {
             double st0[4];
             if (tape) {
                 if (episode >= a.tapes.train_reset_stride) { status = -5; for (int i = 0; i < 4; ++i) st0[i] = 0.0; }
@@ -240,21 +397,21 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
         }
 
         int ep_len = 0;
+        spec_valid = false;                               // a reset state has no precomputed candidates
         for (int t = 0; t < cfg.max_steps; ++t) {
-            const int64_t size_after = rb_size + 1 < a.rb_cap ? rb_size + 1 : a.rb_cap;
-            const int64_t new_pos = rb_ptr;
+            const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;     // ReplayBuffer.size after this add
+            const int new_pos = train_steps % rb_cap;                                       // ReplayBuffer.ptr before this add
             // ================= phase A =================
-            float row[16];
+            float row[RS];
             int my_idx = -1;
-            const int b = tid & (MAX_B - 1), pass = tid >> 8;
+            PT_MARK(9);
             if (wave == ENV_WAVE) {
                 // ---- select_train_action (DDQN.py:97-104) ----
                 double u;
                 if (tape) {
-                    if (n_eps >= a.tapes.eps_uniform_stride) { status = -2; u = 1.0; }
-                    else u = a.tapes.eps_uniform[chain * a.tapes.eps_uniform_stride + n_eps];
-                } else u = u64_to_unit(rng_u64(key, STREAM_EPS, (uint64_t)n_eps));
-                ++n_eps;
+                    if (train_steps >= a.tapes.eps_uniform_stride) { status = -2; u = 1.0; }
+                    else u = a.tapes.eps_uniform[chain * a.tapes.eps_uniform_stride + train_steps];
+                } else u = u64_to_unit(rng_u64(key, STREAM_EPS, (uint64_t)train_steps));
                 int action, explored = 0;
                 if (u < eps_g) {
                     explored = 1;
@@ -264,36 +421,28 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     } else action = (int)u64_to_below(rng_u64(key, STREAM_ACTION, (uint64_t)n_act), (uint32_t)A);
                     ++n_act;
                 } else {
-                    action = wave_q_argmax<S, A>(q_onl, state, wscr, Hq, RP, cfg.q_act, cfg.q_prelu, lane);
+                    action = wave_q_argmax<S, A, PR, QACT>(q_onl, q_w2, HqP, state, wscr, Hq, cfg.q_prelu, lane, tanh_tab);
                 }
-                // ---- EnvWrapper.step -> VirtualEnv.step: x = [onehot(action), state] ----
-                float x[K];
+                PT_MARK(0);   // (env wave) act
+                // ---- EnvWrapper.step -> VirtualEnv.step (envs/env_wrapper.py:16-47, envs/virtual_env.py:43-54) ----
+                float next_state[S], reward, done;
+                if (spec_valid) {
+                    // evaluated for every action during the previous step's forward interval
 #pragma unroll
-                for (int k = 0; k < A; ++k) x[k] = (k == action) ? 1.0f : 0.0f;
+                    for (int i = 0; i < S; ++i) next_state[i] = cand[action * 16 + i];
+                    reward = cand[action * 16 + S]; done = cand[action * 16 + S + 1];
+                } else {
+                    const float acc = se_eval(se_hw, state, action);
 #pragma unroll
-                for (int i = 0; i < S; ++i) x[A + i] = state[i];
-                for (int uu = lane; uu < 3 * Hse; uu += 64) {
-                    const int net = uu / Hse, j = uu - net * Hse;
-                    const float *w = se_w0T + net * K * Hse + j;
-                    float z = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) z = fma32(x[k], w[k * Hse], z);
-                    z = z + se_b0[uu];
-                    se_h[uu] = act_fwd(cfg.se_act, cfg.se_prelu, z);
+                    for (int i = 0; i < S; ++i) next_state[i] = __shfl(acc, i);
+                    reward = __shfl(acc, S); done = __shfl(acc, S + 1);
                 }
-                wave_sync();
-                float acc = 0.0f;
-                if (lane < S + 2) {
-                    const int net = lane < S ? 0 : (lane == S ? 1 : 2);
-                    const float *h = se_h + net * Hse, *w = se_wout + lane * Hse;
-                    for (int j = 0; j < Hse; ++j) acc = fma32(h[j], w[j], acc);
-                    acc = acc + se_bout[lane];
-                }
-                wave_sync();
-                float next_state[S];
+                if (lane < S) {
+                    float v = next_state[0];
 #pragma unroll
-                for (int i = 0; i < S; ++i) next_state[i] = __shfl(acc, i);
-                const float reward = __shfl(acc, S), done = __shfl(acc, S + 1);
+                    for (int i = 1; i < S; ++i) v = (lane == i) ? next_state[i] : v;
+                    cur_state[lane] = v;
+                }
                 // ---- ReplayBuffer.add (utils.py:24-32) ----
                 {
                     float val = done;
@@ -304,23 +453,23 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     }
                     if (lane == S) val = (float)action;
                     if (lane == 2 * S + 1) val = reward;
-                    if (lane < 2 * S + 3) { rb[new_pos * RS + lane] = val; newrow[lane] = val; }
+                    if (lane < 2 * S + 3) { rb[(int64_t)new_pos * RS + lane] = val; newrow[lane] = val; }
                 }
                 if (lane == 0) {
                     ctrl[t & 1] = done;
-                    if (a.out.trace_action && n_trace < a.out.trace_cap) {
-                        const int64_t k = chain * a.out.trace_cap + n_trace;
+                    if (a.out.trace_action && train_steps < a.out.trace_cap) {
+                        const int64_t k = chain * a.out.trace_cap + train_steps;
                         a.out.trace_action[k] = action | (explored << 16);
                         for (int i = 0; i < S; ++i) { a.out.trace_state[k * S + i] = state[i]; a.out.trace_next_state[k * S + i] = next_state[i]; }
                         a.out.trace_reward_done[k * 2] = reward; a.out.trace_reward_done[k * 2 + 1] = done;
                     }
                 }
-                ++n_trace;
 #pragma unroll
                 for (int i = 0; i < S; ++i) state[i] = next_state[i];
-            } else if (learning && pass < 3 && b < B) {
+                PT_MARK(1);   // (env wave) SE step + append
+            } else if (learning && fwd_active) {
                 // ---- ReplayBuffer.sample (utils.py:34-45): prefetch this step's minibatch row ----
-                const int64_t n = learn_it * B + b;
+                const int64_t n = (int64_t)learn_it * B + fwd_b;
                 if (tape) {
                     if (n >= a.tapes.replay_idx_stride) { status = -4; my_idx = 0; }
                     else my_idx = a.tapes.replay_idx[chain * a.tapes.replay_idx_stride + n];
@@ -329,52 +478,84 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 if (my_idx != new_pos) {
                     const float4 *src = reinterpret_cast<const float4 *>(rb + (int64_t)my_idx * RS);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        if (v * 4 < RS) { float4 f = src[v]; row[v * 4] = f.x; row[v * 4 + 1] = f.y; row[v * 4 + 2] = f.z; row[v * 4 + 3] = f.w; }
+                    for (int v = 0; v < RS / 4; ++v) { float4 f = src[v]; row[v * 4] = f.x; row[v * 4 + 1] = f.y; row[v * 4 + 2] = f.z; row[v * 4 + 3] = f.w; }
                 }
             }
-            rb_ptr = rb_ptr + 1 == a.rb_cap ? 0 : rb_ptr + 1;
-            rb_size = size_after;
             ++ep_len; ++train_steps;
             __syncthreads();                                   // B1
+            PT_MARK(2);       // (other waves) phase A incl. wait for the env wave
             const float done_now = ctrl[t & 1];
 
             if (learning) {
                 // ================= learn: DDQN.learn (DDQN.py:60-94) =================
-                if (pass < 3 && b < B) {
-                    if (my_idx == (int)new_pos) {
+                if (fwd_active) {
+                    if (my_idx == new_pos) {
 #pragma unroll
-                        for (int v = 0; v < 16; ++v) if (v < RS) row[v] = newrow[v];
+                        for (int v = 0; v < RS; ++v) row[v] = newrow[v];
                     }
                     float x[S];
 #pragma unroll
-                    for (int i = 0; i < S; ++i) x[i] = pass == 0 ? row[i] : row[S + 1 + i];
-                    const float *W = pass == 2 ? q_tgt : q_onl;
+                    for (int i = 0; i < S; ++i) x[i] = fwd_pass == 0 ? row[i] : row[S + 1 + i];
+                    const float *W = fwd_pass == 2 ? q_tgt : q_onl;
                     float q[A];
 #pragma unroll
                     for (int aa = 0; aa < A; ++aa) q[aa] = 0.0f;
-                    for (int j = 0; j < Hq; ++j) {
-                        const float *rec = W + j * RP;
-                        float z = 0.0f;
+                    // two hidden units per iteration: independent dependency chains + packed fp32 math on the
+                    // interleaved pair record; the output accumulators stay sequential in j (canonical order)
+                    constexpr int PR4 = PR / 4;
+                    const float4 *W4 = reinterpret_cast<const float4 *>(W);
+                    const int npairs = (Hq + 1) >> 1;
+                    float4 nxt[PR4];
 #pragma unroll
-                        for (int i = 0; i < S; ++i) z = fma32(x[i], rec[i], z);
-                        z = z + rec[S];
-                        const float h = act_fwd(cfg.q_act, cfg.q_prelu, z);
+                    for (int v = 0; v < PR4; ++v) nxt[v] = W4[v];
+                    float *hrow = hB + fwd_b * HP;
+                    for (int jp = 0; jp < npairs; ++jp) {
+                        float rec[PR];
 #pragma unroll
-                        for (int aa = 0; aa < A; ++aa) q[aa] = fma32(h, rec[S + 1 + aa], q[aa]);
-                        if (pass == 0) hB[b * HP + j] = h;
+                        for (int v = 0; v < PR4; ++v) { rec[4 * v] = nxt[v].x; rec[4 * v + 1] = nxt[v].y; rec[4 * v + 2] = nxt[v].z; rec[4 * v + 3] = nxt[v].w; }
+                        const int jn = jp + 1 < npairs ? jp + 1 : jp;       // software prefetch of the next pair record
+#pragma unroll
+                        for (int v = 0; v < PR4; ++v) nxt[v] = W4[jn * PR4 + v];
+                        v2f z = {0.0f, 0.0f};
+#pragma unroll
+                        for (int i = 0; i < S; ++i) z = fma2((v2f){x[i], x[i]}, (v2f){rec[2 * i], rec[2 * i + 1]}, z);
+                        z = z + (v2f){rec[2 * S], rec[2 * S + 1]};
+                        ActPipe<QACT> a0, a1;
+                        a0.issue(tanh_tab, z.x);
+                        a1.issue(tanh_tab, z.y);
+                        const float h0 = a0.finish(cfg.q_prelu);
+                        const float h1 = a1.finish(cfg.q_prelu);
+                        const bool two = 2 * jp + 1 < Hq;                   // odd Hq: the last record holds one unit
+#pragma unroll
+                        for (int aa = 0; aa < A; ++aa) {
+                            q[aa] = fma32(h0, rec[2 * S + 2 + 2 * aa], q[aa]);
+                            if (two) q[aa] = fma32(h1, rec[2 * S + 2 + 2 * aa + 1], q[aa]);
+                        }
+                        if (fwd_pass == 0) { hrow[2 * jp] = h0; if (two) hrow[2 * jp + 1] = h1; }
                     }
 #pragma unroll
-                    for (int aa = 0; aa < A; ++aa) qres[(pass * MAX_B + b) * A + aa] = q[aa] + W[Hq * RP + aa];
-                    if (pass == 0) {
+                    for (int aa = 0; aa < A; ++aa) qres[(fwd_pass * MAX_B + fwd_b) * A + aa] = q[aa] + W[npairs * PR + aa];
+                    if (fwd_pass == 0) {
 #pragma unroll
-                        for (int i = 0; i < S; ++i) sB[b * S + i] = row[i];
-                        rda[b * 4 + 0] = row[2 * S + 1]; rda[b * 4 + 1] = row[2 * S + 2]; rda[b * 4 + 2] = row[S];
+                        for (int i = 0; i < S; ++i) sB[fwd_b * S + i] = row[i];
+                        rda[fwd_b * 4 + 0] = row[2 * S + 1]; rda[fwd_b * 4 + 1] = row[2 * S + 2]; rda[fwd_b * 4 + 2] = row[S];
+                    }
+                } else if (wave >= first_spec && done_now <= 0.5f) {
+                    // ---- speculative SE step of the NEXT env step for every action (this wave's share) ----
+                    float st[S];
+#pragma unroll
+                    for (int i = 0; i < S; ++i) st[i] = cur_state[i];
+                    for (int act = wave - first_spec; act < A; act += n_spec) {
+                        const float acc = se_eval(se_hw, st, act);
+                        if (lane < S + 2) cand[act * 16 + lane] = acc;
                     }
                 }
                 __syncthreads();                               // B2
+                PT_MARK(3);
                 if (tid < B) {
                     // TD target and dLoss/dQ(s,a) per sample (DDQN.py:82-86; mse_loss backward = 2/B * diff)
+                    const int b = tid;
+                    const float g32 = (float)cfg.gamma, norm = (float)(2.0 / (double)B);
                     const float r = rda[b * 4], d = rda[b * 4 + 1];
                     const int ab = (int)rda[b * 4 + 2];
                     int am = 0;
@@ -385,29 +566,46 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     const float t2 = 1.0f - d;
                     const float y = r + t1 * t2;
                     const float diff = qres[(0 * MAX_B + b) * A + ab] - y;
-                    dqB[b] = norm * diff;
+                    dqB[2 * b] = norm * diff;
+                    dqB[2 * b + 1] = rda[b * 4 + 2];
+                }
+                if (tid == NT - 1) {
+                    // Adam bias corrections of this step (torch.optim.Adam: step_size = lr/(1-beta1^t), sqrt(1-beta2^t))
+                    b1pow *= cfg.adam_beta1;
+                    b2pow *= cfg.adam_beta2;
+                    ctrl[3] = (float)(-(cfg.lr / (1.0 - b1pow)));
+                    ctrl[4] = (float)__builtin_sqrt(1.0 - b2pow);
                 }
                 __syncthreads();                               // B3
+                PT_MARK(4);
                 // ---- batch gradient in micro-chunks: wave c reduces samples [c*chunk, (c+1)*chunk) ----
                 if (wave < a.n_chunks) {
                     const int b0 = wave * a.chunk, b1 = (b0 + a.chunk < B) ? b0 + a.chunk : B;
                     float *pc = part + wave * P;
                     for (int j = lane; j < ((Hq + 63) & ~63); j += 64) {
                         const bool jv = j < Hq;
-                        float gW1[S], gW2[A], gb2[A], gb1 = 0.0f;
+                        float gW1[S], gW2[A], gb2[A], w2j[A], gb1 = 0.0f;
 #pragma unroll
                         for (int i = 0; i < S; ++i) gW1[i] = 0.0f;
 #pragma unroll
-                        for (int aa = 0; aa < A; ++aa) { gW2[aa] = 0.0f; gb2[aa] = 0.0f; }
+                        for (int aa = 0; aa < A; ++aa) { gW2[aa] = 0.0f; gb2[aa] = 0.0f; w2j[aa] = jv ? q_onl[(j >> 1) * PR + 2 * S + 2 + 2 * aa + (j & 1)] : 0.0f; }
+                        const float *hcol = hB + (jv ? j : 0);
+#pragma unroll 4
                         for (int bb = b0; bb < b1; ++bb) {
-                            const float h = jv ? hB[bb * HP + j] : 0.0f;
-                            const float dq = dqB[bb];
-                            const int ab = (int)rda[bb * 4 + 2];
-                            // dL/dz through the output layer and the activation (only row a_b of dQ is non-zero)
-                            const float da = dq * (jv ? q_onl[j * RP + S + 1 + ab] : 0.0f);
-                            const float dz = act_bwd(cfg.q_act, cfg.q_prelu, h, da);
+                            const float h = hcol[bb * HP];
+                            const float2 da2 = *reinterpret_cast<const float2 *>(dqB + 2 * bb);
+                            const float dq = da2.x;
+                            const int ab = (int)da2.y;
+                            float sv[S];
 #pragma unroll
-                            for (int i = 0; i < S; ++i) gW1[i] = fma32(dz, sB[bb * S + i], gW1[i]);
+                            for (int i = 0; i < S; ++i) sv[i] = sB[bb * S + i];
+                            // dL/dz through the output layer and the activation (only row a_b of dQ is non-zero)
+                            float w2 = w2j[0];
+#pragma unroll
+                            for (int aa = 1; aa < A; ++aa) w2 = (ab == aa) ? w2j[aa] : w2;
+                            const float dz = act_bwd_t<QACT>(cfg.q_prelu, h, dq * w2);
+#pragma unroll
+                            for (int i = 0; i < S; ++i) gW1[i] = fma32(dz, sv[i], gW1[i]);
                             gb1 = gb1 + dz;
 #pragma unroll
                             for (int aa = 0; aa < A; ++aa)
@@ -427,19 +625,22 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     }
                 }
                 __syncthreads();                               // B4
+                PT_MARK(5);
                 // ---- torch.optim.Adam single-tensor step + Polyak (DDQN.py:88-93), one thread per parameter ----
-                b1pow *= cfg.adam_beta1;
-                b2pow *= cfg.adam_beta2;
                 {
-                    const double bc1 = 1.0 - b1pow, bc2 = 1.0 - b2pow;
-                    const float neg_step = (float)(-(cfg.lr / bc1));
-                    const float bc2_sqrt = (float)__builtin_sqrt(bc2);
+                    const float neg_step = ctrl[3], bc2_sqrt = ctrl[4];
+                    const float w1 = (float)(1.0 - cfg.adam_beta1), w2 = (float)(1.0 - cfg.adam_beta2), beta2 = (float)cfg.adam_beta2;
+                    const float adam_eps = (float)cfg.adam_eps, tau = (float)cfg.tau, omt = (float)(1.0 - cfg.tau);
 #pragma unroll
                     for (int k = 0; k < PPT; ++k) {
                         const int p = tid + k * NT;
                         if (p < P) {
-                            float g = part[p];
-                            for (int c = 1; c < a.n_chunks; ++c) g = g + part[c * P + p];
+                            float pv[NW];
+#pragma unroll
+                            for (int c = 0; c < NW; ++c) pv[c] = c < a.n_chunks ? part[c * P + p] : 0.0f;
+                            float g = pv[0];
+#pragma unroll
+                            for (int c = 1; c < NW; ++c) if (c < a.n_chunks) g = g + pv[c];
                             p_m[k] = fma32(w1, g - p_m[k], p_m[k]);
                             p_v[k] = p_v[k] * beta2;
                             p_v[k] = fma32(w2 * g, g, p_v[k]);
@@ -448,12 +649,15 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                             p_tgt[k] = tau * p_onl[k] + omt * p_tgt[k];
                             q_onl[my_off[k]] = p_onl[k];
                             q_tgt[my_off[k]] = p_tgt[k];
+                            if (my_w2[k] >= 0) q_w2[my_w2[k]] = p_onl[k];
                         }
                     }
                 }
                 ++learn_it;
                 __syncthreads();                               // B5
+                PT_MARK(6);
             }
+            spec_valid = learning && n_spec > 0;
             if (done_now > 0.5f) break;                        // base_agent.py:128
         }
         ++episodes_run;
@@ -461,25 +665,26 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
         __syncthreads();
 
         // ---- per-episode test on the real env (base_agent.py:134-136) ----
+        PT_MARK(9);
         test_phase();
+        PT_MARK(7);
         int brk = 0;
         if (tid == 0) {
             double sm = 0.0;
             for (int i = 0; i < cfg.test_episodes; ++i) sm += ret[i];
             const double tm = sm / (double)cfg.test_episodes;
-            meter[n_meter] = tm;
+            meter[episode] = tm;
             if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
             // early out on the real env (base_agent.py:49-62,141-148; AverageMeter._mean utils.py:103-105)
             if (learning) {
-                int lo = n_meter + 1 - cfg.early_out_num; if (lo < 0) lo = 0;
+                int lo = episode + 1 - cfg.early_out_num; if (lo < 0) lo = 0;
                 double s2 = 0.0;
-                for (int i = lo; i <= n_meter; ++i) s2 += meter[i];
-                const double avg = s2 / ((double)(n_meter + 1 - lo) + 1e-9);
+                for (int i = lo; i <= episode; ++i) s2 += meter[i];
+                const double avg = s2 / ((double)(episode + 1 - lo) + 1e-9);
                 if (avg >= cfg.solved_reward) brk = 1;
             }
             ctrl[2] = (float)brk;
         }
-        ++n_meter;
         __syncthreads();
         brk = ctrl[2] > 0.5f;
         __syncthreads();
@@ -488,6 +693,10 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 
     // ---- final test (GTN_worker.py:199) and score = statistics.mean(reward_list_test) ----
     test_phase();
+#ifdef LENV_PHASE_TIMING
+    if (tid == 0) PT_FLUSH(0, 10);
+    if (tid == ENV_WAVE * 64) { if (chain == 0) { g_phase_cycles[10] = pt_acc[0]; g_phase_cycles[11] = pt_acc[1]; } }
+#endif
     if (tid == 0) {
         double sm = 0.0;
         for (int i = 0; i < cfg.test_episodes; ++i) sm += ret[i];
@@ -540,7 +749,7 @@ static int inner_layout(const lenv_ddqn_cfg *cfg, InnerArgs &a)
     a.se_net_size[0] = (int)mlp_params(S + A, Hse, 1, S);
     a.se_net_size[1] = a.se_net_size[2] = (int)mlp_params(S + A, Hse, 1, 1);
     a.P_se = a.se_net_size[0] + a.se_net_size[1] + a.se_net_size[2];
-    if (a.P_q > PPT * NT) return LENV_ERR_UNSUPPORTED;
+    if (a.P_q > MAX_PPT * NT) return LENV_ERR_UNSUPPORTED;
     a.RP = (S + 1 + A + 3) & ~3;
     a.HP = Hq | 1;
     a.chunk = cfg->grad_chunk > 0 ? cfg->grad_chunk : (B + NW - 1) / NW;
@@ -549,16 +758,18 @@ static int inner_layout(const lenv_ddqn_cfg *cfg, InnerArgs &a)
     const int K = S + A, HqPad = (Hq + 63) & ~63;
     int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
-    a.o_se_w0T = take(3 * K * Hse); a.o_se_b0 = take(3 * Hse); a.o_se_wout = take((S + 2) * Hse); a.o_se_bout = take(S + 2);
-    a.o_se_h = take(3 * Hse);
-    a.o_q_onl = take(Hq * a.RP + A); a.o_q_tgt = take(Hq * a.RP + A);
+    a.o_se_w0T = take(3 * K * Hse); a.o_se_b0 = take(3 * Hse); a.o_se_wout = take((S + 2) * ((Hse + 3) & ~3)); a.o_se_bout = take(S + 2);
+    a.o_se_h = take(2 * 3 * ((Hse + 3) & ~3));
+    a.o_q_onl = take(((Hq + 1) / 2) * 2 * a.RP + A); a.o_q_tgt = take(((Hq + 1) / 2) * 2 * a.RP + A); a.o_q_w2 = take(A * ((Hq + 3) & ~3));
     a.o_wscr = take(NW * HqPad);
     a.o_hB = take(B * a.HP);
-    a.o_sB = take(B * S); a.o_rda = take(B * 4); a.o_dqB = take(B);
+    a.o_sB = take(B * S); a.o_rda = take(B * 4); a.o_dqB = take(2 * B);
     a.o_qres = take(3 * MAX_B * A);
     a.o_part = take(a.n_chunks * a.P_q);
-    a.o_newrow = take(16); a.o_ctrl = take(4 + NW);
+    a.o_newrow = take(16); a.o_ctrl = take(8 + NW);
     a.o_ret = take(2 * cfg->test_episodes + 2);
+    a.o_tanh = take(LENV_TANH_N * 4);
+    a.o_cand = take(16 * A); a.o_cur_state = take(16);
     a.lds_floats = o;
     if ((size_t)o * sizeof(float) > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     return LENV_OK;
@@ -574,6 +785,13 @@ static int inner_check(const lenv_ddqn_cfg *cfg)
         return LENV_ERR_UNSUPPORTED;
     return LENV_OK;
 }
+
+#ifdef LENV_PHASE_TIMING
+extern "C" int lenv_debug_phase_cycles(unsigned long long *host_out)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_phase_cycles), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;
+}
+#endif
 
 extern "C" int64_t lenv_ddqn_se_lds_bytes(const lenv_ddqn_cfg *cfg)
 {
@@ -624,8 +842,19 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
     const size_t lds_bytes = (size_t)a.lds_floats * sizeof(float);
 
     void (*kern)(const InnerArgs) = nullptr;
-    if (cfg->env_id == LENV_ENV_CARTPOLE) kern = ddqn_se_inner_kernel<LENV_ENV_CARTPOLE, 4, 2>;
-    else kern = ddqn_se_inner_kernel<LENV_ENV_ACROBOT, 6, 3>;
+#define LENV_PICK2(ENVID, SS, AA, PP)                                                                              \
+    switch (cfg->q_act) {                                                                                          \
+    case LENV_ACT_RELU: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_RELU, PP>; break;                      \
+    case LENV_ACT_LEAKYRELU: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_LEAKYRELU, PP>; break;            \
+    case LENV_ACT_TANH: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_TANH, PP>; break;                      \
+    case LENV_ACT_PRELU: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_PRELU, PP>; break;                    \
+    default: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_IDENTITY, PP>; break;                             \
+    }
+#define LENV_PICK(ENVID, SS, AA) if (a.P_q <= NT) { LENV_PICK2(ENVID, SS, AA, 1) } else { LENV_PICK2(ENVID, SS, AA, 2) }
+    if (cfg->env_id == LENV_ENV_CARTPOLE) { LENV_PICK(LENV_ENV_CARTPOLE, 4, 2) }
+    else { LENV_PICK(LENV_ENV_ACROBOT, 6, 3) }
+#undef LENV_PICK2
+#undef LENV_PICK
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;
     if (out->status) {

@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "../../include/lenv_hip.h"
+#include "lenv_tanh_table.h"
 
 #define LENV_WAVE 64
 
@@ -18,29 +19,24 @@ namespace lenv {
 __device__ __forceinline__ float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma64(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-// tanh(x) = em1/(em1+2), em1 = expm1(2|x|) = 2^k*(r*Q(r)) + (2^k-1); |r| <= ln2/2, Q Taylor to r^7.
-__device__ __forceinline__ float det_tanhf(float x)
+// Canonical tanh (same sequence as the oracle's orc_tanhf): tanh(x) = copysign(min(t*p_i(t-c_i), 1), x),
+// t = min(|x|, TMAX), i = trunc(32 t), p_i = cubic of lenv_tanh_table.h (g(t) = tanh(t)/t).  `tab` may point to the
+// global copy below or to a copy staged in LDS (one 16-byte gather per evaluation).
+static __device__ const float lenv_tanh_table[LENV_TANH_N * 4] = LENV_TANH_TABLE_INIT;
+
+__device__ __forceinline__ float det_tanhf(const float *tab, float x)
 {
-    float ax = __builtin_fabsf(x);
-    ax = ax > 10.0f ? 10.0f : ax;
-    float y = ax + ax;
-    float kf = __builtin_rintf(y * 1.44269504088896341f);
-    float r = fma32(-kf, 0.693145751953125f, y);
-    r = fma32(-kf, 1.42860682030941723212e-6f, r);
-    float q = 2.48015873015873e-5f;
-    q = fma32(q, r, 1.98412698412698e-4f);
-    q = fma32(q, r, 1.38888888888889e-3f);
-    q = fma32(q, r, 8.33333333333333e-3f);
-    q = fma32(q, r, 4.16666666666667e-2f);
-    q = fma32(q, r, 1.66666666666667e-1f);
-    q = fma32(q, r, 0.5f);
-    q = fma32(q, r, 1.0f);
-    float p = r * q;
-    int k = (int)kf;
-    float s = __int_as_float((k + 127) << 23);
-    float em1 = fma32(s, p, s - 1.0f);
-    float t = em1 / (em1 + 2.0f);
-    return __builtin_copysignf(t, x);
+    const float ax = __builtin_fabsf(x);
+    const float t = ax < LENV_TANH_TMAX ? ax : LENV_TANH_TMAX;
+    const float t32 = t * 32.0f;
+    const int idx = (int)t32;
+    const float u = fma32(__builtin_amdgcn_fractf(t32), 0.03125f, -0.015625f);   // = t - (idx+0.5)/32, exact
+    const float4 k = *reinterpret_cast<const float4 *>(tab + 4 * idx);
+    float p = fma32(k.w, u, k.z);
+    p = fma32(p, u, k.y);
+    p = fma32(p, u, k.x);
+    const float r = __builtin_fminf(t * p, 1.0f);
+    return __builtin_copysignf(r, x);
 }
 
 __device__ __forceinline__ double det_ksin(double x)
@@ -120,7 +116,7 @@ __device__ __forceinline__ float act_fwd(int act, float prelu, float z)
     switch (act) {
     case LENV_ACT_RELU: return z > 0.0f ? z : 0.0f;
     case LENV_ACT_LEAKYRELU: return z > 0.0f ? z : z * 0.01f;
-    case LENV_ACT_TANH: return det_tanhf(z);
+    case LENV_ACT_TANH: return det_tanhf(lenv_tanh_table, z);
     case LENV_ACT_PRELU: return z > 0.0f ? z : prelu * z;
     default: return z;
     }

@@ -23,7 +23,8 @@
  *     `linear` order for K <= 128, verified bitwise);
  *   - batch-gradient sums are accumulated in micro-chunks of `grad_chunk`
  *     samples (sequential fmaf inside a chunk, chunk partials added in order);
- *   - tanh / sin / cos are the polynomial routines in this file (no libm);
+ *   - tanh is the table-driven piecewise cubic of lenv_tanh_table.h, sin / cos are the polynomial routines in
+ *     lenv_oracle.c (no libm);
  *   - element-wise update formulas follow torch 2.10's CPU kernels op by op
  *     (lerp = fma, addcmul = fma, addcdiv = plain, tanh' = dh*fma(-h,h,1)).
  */

@@ -123,7 +123,7 @@ def _inner_cfg(orc, cfgd, **over):
 def test_inner_loop_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
     g = golden(name)
     cfgd = json.loads(str(g["config_json"]))
-    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=13, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=17, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
     n = g["tr_action"].size
     otapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
     o = orc.ddqn_se_chain(ocfg, g["theta"], g["agent_init"], tapes=otapes, trace_cap=n + 8)
@@ -169,7 +169,7 @@ def test_inner_loop_counter_mode_vs_oracle(eng, orc, golden, env_name, chains, e
         cfgd["envs"][env_name] = dict(cfgd["envs"]["CartPole-v0"], solved_reward=-100.0, hidden_size=64)
         cfgd["agents"]["ddqn"].update(hidden_size=112, activation_fn="leakyrelu")
     cfgd["agents"]["ddqn"]["batch_size"] = batch
-    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0 if batch != 199 else 13, rng_mode=0, train_episodes=episodes, max_steps=max_steps)
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, train_episodes=episodes, max_steps=max_steps)
     if ocfg.grad_chunk == 0:
         from learning_environments_amd.config import pick_grad_chunk
         ocfg.grad_chunk = cfg.grad_chunk = pick_grad_chunk(cfg)
@@ -205,7 +205,7 @@ def test_inner_loop_early_out(eng, orc, golden):
     # solved_reward low enough that the real-env early-out (base_agent.py:141-148) fires after init_episodes
     g = golden("g8_calc_score_cartpole_a")
     cfgd = json.loads(str(g["config_json"]))
-    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=13, rng_mode=0, train_episodes=6, max_steps=20, solved_reward=5.0, early_out_num=2)
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=17, rng_mode=0, train_episodes=6, max_steps=20, solved_reward=5.0, early_out_num=2)
     key = orc.chain_key(1, 0, 0, 0)
     il = eng.InnerLoop(cfg, 1)
     il.run(dev(g["theta"]), None, None, None, dev(g["agent_init"][None]), rng_keys=dev(np.array([key], np.uint64).view(np.int64)))
