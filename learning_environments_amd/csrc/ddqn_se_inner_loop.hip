@@ -500,22 +500,22 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     float q[A];
 #pragma unroll
                     for (int aa = 0; aa < A; ++aa) q[aa] = 0.0f;
-                    // two hidden units per iteration: independent dependency chains + packed fp32 math on the
-                    // interleaved pair record; the output accumulators stay sequential in j (canonical order)
+                    // Two hidden units per iteration (pair record, packed fp32 math): independent dependency chains; the
+                    // output accumulators stay sequential in j (canonical order).  The loop is unrolled x2 with ping-pong
+                    // record buffers so the next record is in flight while the current one is consumed.
                     constexpr int PR4 = PR / 4;
                     const float4 *W4 = reinterpret_cast<const float4 *>(W);
                     const int npairs = (Hq + 1) >> 1;
-                    float4 nxt[PR4];
-#pragma unroll
-                    for (int v = 0; v < PR4; ++v) nxt[v] = W4[v];
+                    const int nfull = Hq >> 1;                      // pairs holding two units
                     float *hrow = hB + fwd_b * HP;
-                    for (int jp = 0; jp < npairs; ++jp) {
+                    auto load_rec = [&](int jp, float4 (&r)[PR4]) {
+#pragma unroll
+                        for (int v = 0; v < PR4; ++v) r[v] = W4[jp * PR4 + v];
+                    };
+                    auto pair_step = [&](const float4 (&r)[PR4], int jp, bool two) {
                         float rec[PR];
 #pragma unroll
-                        for (int v = 0; v < PR4; ++v) { rec[4 * v] = nxt[v].x; rec[4 * v + 1] = nxt[v].y; rec[4 * v + 2] = nxt[v].z; rec[4 * v + 3] = nxt[v].w; }
-                        const int jn = jp + 1 < npairs ? jp + 1 : jp;       // software prefetch of the next pair record
-#pragma unroll
-                        for (int v = 0; v < PR4; ++v) nxt[v] = W4[jn * PR4 + v];
+                        for (int v = 0; v < PR4; ++v) { rec[4 * v] = r[v].x; rec[4 * v + 1] = r[v].y; rec[4 * v + 2] = r[v].z; rec[4 * v + 3] = r[v].w; }
                         v2f z = {0.0f, 0.0f};
 #pragma unroll
                         for (int i = 0; i < S; ++i) z = fma2((v2f){x[i], x[i]}, (v2f){rec[2 * i], rec[2 * i + 1]}, z);
@@ -525,14 +525,28 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         a1.issue(tanh_tab, z.y);
                         const float h0 = a0.finish(cfg.q_prelu);
                         const float h1 = a1.finish(cfg.q_prelu);
-                        const bool two = 2 * jp + 1 < Hq;                   // odd Hq: the last record holds one unit
 #pragma unroll
                         for (int aa = 0; aa < A; ++aa) {
                             q[aa] = fma32(h0, rec[2 * S + 2 + 2 * aa], q[aa]);
                             if (two) q[aa] = fma32(h1, rec[2 * S + 2 + 2 * aa + 1], q[aa]);
                         }
                         if (fwd_pass == 0) { hrow[2 * jp] = h0; if (two) hrow[2 * jp + 1] = h1; }
+                    };
+                    float4 ra[PR4], rb4[PR4];
+                    load_rec(0, ra);
+                    int jp = 0;
+                    for (; jp + 2 <= nfull; jp += 2) {
+                        load_rec(jp + 1, rb4);
+                        pair_step(ra, jp, true);
+                        load_rec(jp + 2 < npairs ? jp + 2 : jp + 1, ra);
+                        pair_step(rb4, jp + 1, true);
                     }
+                    if (jp < nfull) {                               // one full pair left
+                        pair_step(ra, jp, true);
+                        ++jp;
+                        if (jp < npairs) load_rec(jp, ra);
+                    }
+                    if (jp < npairs) pair_step(ra, jp, false);      // odd Hq: the last record holds one unit
 #pragma unroll
                     for (int aa = 0; aa < A; ++aa) qres[(fwd_pass * MAX_B + fwd_b) * A + aa] = q[aa] + W[npairs * PR + aa];
                     if (fwd_pass == 0) {
@@ -590,26 +604,36 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 #pragma unroll
                         for (int aa = 0; aa < A; ++aa) { gW2[aa] = 0.0f; gb2[aa] = 0.0f; w2j[aa] = jv ? q_onl[(j >> 1) * PR + 2 * S + 2 + 2 * aa + (j & 1)] : 0.0f; }
                         const float *hcol = hB + (jv ? j : 0);
-#pragma unroll 4
-                        for (int bb = b0; bb < b1; ++bb) {
-                            const float h = hcol[bb * HP];
-                            const float2 da2 = *reinterpret_cast<const float2 *>(dqB + 2 * bb);
-                            const float dq = da2.x;
-                            const int ab = (int)da2.y;
-                            float sv[S];
+                        for (int bq = b0; bq < b1; bq += 4) {
+                            // issue every LDS read of up to four samples first, then accumulate them in order
+                            float hv[4], dqv[4], av[4], sv[4][S];
 #pragma unroll
-                            for (int i = 0; i < S; ++i) sv[i] = sB[bb * S + i];
-                            // dL/dz through the output layer and the activation (only row a_b of dQ is non-zero)
-                            float w2 = w2j[0];
+                            for (int u = 0; u < 4; ++u) {
+                                const int bb = bq + u < b1 ? bq + u : b1 - 1;
+                                hv[u] = hcol[bb * HP];
+                                const float2 da2 = *reinterpret_cast<const float2 *>(dqB + 2 * bb);
+                                dqv[u] = da2.x; av[u] = da2.y;
 #pragma unroll
-                            for (int aa = 1; aa < A; ++aa) w2 = (ab == aa) ? w2j[aa] : w2;
-                            const float dz = act_bwd_t<QACT>(cfg.q_prelu, h, dq * w2);
+                                for (int i = 0; i < S; ++i) sv[u][i] = sB[bb * S + i];
+                            }
 #pragma unroll
-                            for (int i = 0; i < S; ++i) gW1[i] = fma32(dz, sv[i], gW1[i]);
-                            gb1 = gb1 + dz;
+                            for (int u = 0; u < 4; ++u) {
+                                if (bq + u < b1) {
+                                    const float h = hv[u], dq = dqv[u];
+                                    const int ab = (int)av[u];
+                                    // dL/dz through the output layer and the activation (only row a_b of dQ is non-zero)
+                                    float w2 = w2j[0];
 #pragma unroll
-                            for (int aa = 0; aa < A; ++aa)
-                                if (ab == aa) { gW2[aa] = fma32(dq, h, gW2[aa]); gb2[aa] = gb2[aa] + dq; }
+                                    for (int aa = 1; aa < A; ++aa) w2 = (ab == aa) ? w2j[aa] : w2;
+                                    const float dz = act_bwd_t<QACT>(cfg.q_prelu, h, dq * w2);
+#pragma unroll
+                                    for (int i = 0; i < S; ++i) gW1[i] = fma32(dz, sv[u][i], gW1[i]);
+                                    gb1 = gb1 + dz;
+#pragma unroll
+                                    for (int aa = 0; aa < A; ++aa)
+                                        if (ab == aa) { gW2[aa] = fma32(dq, h, gW2[aa]); gb2[aa] = gb2[aa] + dq; }
+                                }
+                            }
                         }
                         if (jv) {
 #pragma unroll
