@@ -63,6 +63,22 @@ def algorithmic_bytes(master, stats):
     return b, train_steps, learn_steps, test_steps
 
 
+def measured_traffic():
+    """HBM bytes per fused-kernel launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/rNN_summary.json, written by tools/summarize_profiles.py: 2*FETCH_SIZE + WRITE_SIZE, KB -> bytes, with the
+    gfx950 read-side correction of MI355X_MICROARCH.md).  PMC counters cannot be read from inside the run, hence the file."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
+        try:
+            d = json.load(open(f))
+            if "hbm_traffic_bytes_per_launch" in d:
+                best = (d["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT))
+        except Exception:
+            pass
+    return best
+
+
 def cpu_baseline(master, cfgd):
     """The oracle (CPU port of the same path, oracle/lenv_oracle.c) timed on this box's host cores on a bounded sample
     of the same workload: `pop_s` workers (3 chains each, same theta/eps/agent-init recipe), one thread per core."""
@@ -169,6 +185,10 @@ def main():
                          "note": "latency/issue-bound small-MLP chains: weights+activations live in LDS, only the replay "
                                  "buffer touches HBM/L2 (see DESIGN.md)"},
         }
+        tr = measured_traffic()
+        if tr is not None:
+            line["roofline"]["traffic"] = tr[0]
+            line["roofline"]["traffic_source"] = tr[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(master, cfgd)
         print(json.dumps(line))
