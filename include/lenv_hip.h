@@ -138,6 +138,43 @@ int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg /*HOST*/, const float *thet
                             const lenv_inner_out *out /*HOST struct of device ptrs*/, void *stream);
 
 /*
+ * Config 4: fused inner loop for tabular Q-learning on a potential-shaped RewardEnv over a grid MDP
+ * (agents/QL.py:13-106, envs/reward_env.py:61-133, envs/gridworld.py:38-110), one wave per chain.
+ * The MDP is given as transition tables next_state/reward/done [n_states, n_actions] (device pointers, shared by all
+ * chains); theta = flat reward_net parameters (PReLU slope excluded), perturbed per chain as theta + sign*eps[worker].
+ * shaped_override [n_states*n_actions] (optional) replaces the reward-net evaluation by a given shaped-reward table.
+ */
+typedef struct {
+    int32_t n_states, n_actions, start_state, max_steps;
+    int32_t rn_hidden, rn_layers, rn_act;
+    float rn_prelu;
+    int32_t reward_env_type;            /* 0,1,2,5,6 */
+    int32_t train_episodes, test_episodes, init_episodes, early_out_num, batch_size;
+    int32_t rng_mode;
+    double solved_reward, alpha, gamma, eps_init, eps_min, eps_decay;
+} lenv_ql_cfg;
+
+typedef struct {
+    double *score;              /* [chains] */
+    int64_t *stats;             /* [chains,4] episodes_run, train_steps, learn_steps, test_steps */
+    int32_t *status;            /* [chains] */
+    double *episode_test_mean;  /* [chains,train_episodes] */
+    int32_t *episode_len;       /* [chains,train_episodes] */
+    double *final_returns;      /* [chains,test_episodes] */
+    double *q_table;            /* [chains,n_states*n_actions] final fp64 Q-table */
+    float *shaped;              /* [chains,n_states*n_actions] shaped reward of every (s,a) */
+    int64_t trace_cap;
+    int32_t *trace_action;      /* [chains,trace_cap] action | explored<<16 */
+    int32_t *trace_state;       /* [chains,trace_cap,2] state, next_state */
+    float *trace_reward_done;   /* [chains,trace_cap,2] */
+} lenv_ql_out;
+
+int lenv_ql_rn_inner_loop(const lenv_ql_cfg *cfg /*HOST*/, const float *theta, const float *eps, const int32_t *worker,
+                          const float *sign, const float *shaped_override, const int32_t *next_state, const double *reward,
+                          const uint8_t *done, const uint64_t *rng_keys, const lenv_tapes *tapes /*HOST, may be NULL*/,
+                          int64_t chains, const lenv_ql_out *out /*HOST struct of device ptrs*/, void *stream);
+
+/*
  * Real-environment reset/step for n independent instances (replaces gym==0.17.3 CartPole-v0 / Acrobot-v1
  * reset()/step() + gym.wrappers.TimeLimit behind EnvWrapper.reset/step, envs/env_wrapper.py:49-85).
  * state [n,4] float64 (gym's internal state), elapsed [n] TimeLimit counters, obs [n,S] fp32 observations.

@@ -50,9 +50,25 @@ class InnerOut(C.Structure):
                 ("trace_state", C.c_void_p), ("trace_next_state", C.c_void_p), ("trace_reward_done", C.c_void_p)]
 
 
+class QlCfg(C.Structure):
+    _fields_ = [("n_states", C.c_int32), ("n_actions", C.c_int32), ("start_state", C.c_int32), ("max_steps", C.c_int32),
+                ("rn_hidden", C.c_int32), ("rn_layers", C.c_int32), ("rn_act", C.c_int32), ("rn_prelu", C.c_float),
+                ("reward_env_type", C.c_int32), ("train_episodes", C.c_int32), ("test_episodes", C.c_int32),
+                ("init_episodes", C.c_int32), ("early_out_num", C.c_int32), ("batch_size", C.c_int32), ("rng_mode", C.c_int32),
+                ("solved_reward", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double), ("eps_init", C.c_double),
+                ("eps_min", C.c_double), ("eps_decay", C.c_double)]
+
+
+class QlOut(C.Structure):
+    _fields_ = [("score", C.c_void_p), ("stats", C.c_void_p), ("status", C.c_void_p), ("episode_test_mean", C.c_void_p),
+                ("episode_len", C.c_void_p), ("final_returns", C.c_void_p), ("q_table", C.c_void_p), ("shaped", C.c_void_p),
+                ("trace_cap", C.c_int64), ("trace_action", C.c_void_p), ("trace_state", C.c_void_p),
+                ("trace_reward_done", C.c_void_p)]
+
+
 EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv_se_step_population",
            "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_lds_bytes", "lenv_ddqn_se_inner_loop",
-           "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step"]
+           "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop"]
 
 
 def build(force=False):
@@ -98,6 +114,9 @@ def lib():
         L.lenv_real_env_reset.argtypes = [C.c_int32, vp, vp, C.c_int64, vp, vp, vp, vp]
         L.lenv_real_env_step.restype = C.c_int
         L.lenv_real_env_step.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
+        L.lenv_ql_rn_inner_loop.restype = C.c_int
+        L.lenv_ql_rn_inner_loop.argtypes = [C.POINTER(QlCfg), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(Tapes), C.c_int64,
+                                            C.POINTER(QlOut), vp]
         L.lenv_nes_worker_best.restype = C.c_int
         L.lenv_nes_worker_best.argtypes = [vp, C.c_int64, C.c_int32, vp, vp]
         L.lenv_nes_rank_update.restype = C.c_int

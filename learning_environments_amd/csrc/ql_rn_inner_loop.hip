@@ -1,0 +1,220 @@
+// ql_rn_inner_loop.hip -- fused NES inner loop for config 4: tabular Q-learning on a potential-shaped RewardEnv over a
+// grid MDP, one wave64 per chain.
+//
+// Replaces, for `chains` (theta +/- eps) perturbations of the reward network at once, the reference's
+//   GTN_Worker.calc_score                       agents/GTN_worker.py:187-221
+//     QL() / select_train_action / learn        agents/QL.py:13-106 (python-float64 Q-table, argmax on the fp32 cast row)
+//     BaseAgent.train / test                    agents/base_agent.py:64-227
+//     EnvWrapper.step -> RewardEnv.step         envs/env_wrapper.py:49-70, envs/reward_env.py:61-133
+//     GridworldEnv.step + TimeLimit             envs/gridworld.py:38-110 (given as transition tables)
+//
+// The reward network only ever sees one-hot states, so phi(s) for all N states and the shaped reward of every (s,a) are
+// evaluated ONCE per chain (lane = state, coalesced reads of theta/eps) and kept in LDS; the training itself is a
+// strictly sequential scalar walk (<= train_episodes*max_steps steps) executed by lane 0 on the LDS-resident fp64 Q-table.
+// Integer/fp64 work is exact by construction; phi uses the canonical sequential-fmaf order of oracle/lenv_oracle.h.
+#include "lenv_device.cuh"
+
+namespace lenv {
+
+struct QlArgs {
+    lenv_ql_cfg cfg;
+    const float *theta, *eps; const int32_t *worker; const float *sign;
+    const float *shaped_override;
+    const int32_t *next_state; const double *reward; const uint8_t *done;
+    const uint64_t *rng_keys;
+    lenv_tapes tapes;
+    lenv_ql_out out;
+    int64_t P;
+};
+
+__device__ __forceinline__ int ql_argmax_f32(const double *row, int n)
+{
+    int best = 0;
+    float bv = (float)row[0];
+    for (int i = 1; i < n; ++i) { const float v = (float)row[i]; if (v > bv) { bv = v; best = i; } }
+    return best;
+}
+
+__global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const lenv_ql_cfg &cfg = a.cfg;
+    const int lane = threadIdx.x;
+    const int64_t chain = blockIdx.x;
+    const int N = cfg.n_states, A = cfg.n_actions, H = cfg.rn_hidden;
+    double *q = reinterpret_cast<double *>(lds_raw);                 // [N*A] fp64 Q-table
+    double *meter = q + N * A;                                       // [train_episodes]
+    double *rets = meter + cfg.train_episodes;                       // [test_episodes]
+    float *phi = reinterpret_cast<float *>(rets + cfg.test_episodes);    // [N]
+    float *shaped = phi + N;                                         // [N*A]
+
+    // ---- phi(s) = reward_net(one_hot(s)), W = theta + sign*eps[worker] (reward_env.py:74-76, GTN_worker.py:165-175) ----
+    const int t = cfg.reward_env_type;
+    if (t != 0 && !a.shaped_override) {
+        const float sg = a.eps ? a.sign[chain] : 0.0f;
+        const float *th = a.theta, *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P : nullptr;
+        auto W = [&](int64_t i) { return e ? fma32(sg, e[i], th[i]) : th[i]; };
+        const int64_t off_b0 = (int64_t)H * N, off_wo = off_b0 + H, off_bo = off_wo + H;
+        for (int s = lane; s < N; s += 64) {
+            float acc = 0.0f;
+            for (int j = 0; j < H; ++j) {
+                const float z = W((int64_t)j * N + s) + W(off_b0 + j);   // one-hot input: the fmaf chain collapses to W0[j][s]
+                const float h = act_fwd(cfg.rn_act, cfg.rn_prelu, z);
+                acc = fma32(h, W(off_wo + j), acc);
+            }
+            phi[s] = acc + W(off_bo);
+        }
+    } else {
+        for (int s = lane; s < N; s += 64) phi[s] = 0.0f;
+    }
+    for (int i = lane; i < N * A; i += 64) q[i] = 0.0;                // q_table = [[0]*A for _ in range(N)]  QL.py:25
+    __syncthreads();
+    // ---- RewardEnv._calc_reward for every (s,a) (reward_env.py:81-110), fp32 left to right ----
+    {
+        const float g32 = (float)cfg.gamma;
+        for (int i = lane; i < N * A; i += 64) {
+            float v;
+            if (a.shaped_override) v = a.shaped_override[i];
+            else {
+                const int s = i / A, s2 = a.next_state[i];
+                const float r32 = (float)a.reward[i];
+                switch (t) {
+                case 0: v = r32; break;
+                case 1: v = g32 * phi[s2] - phi[s]; break;
+                case 2: v = (r32 + g32 * phi[s2]) - phi[s]; break;
+                case 5: v = phi[s2]; break;
+                default: v = r32 + phi[s2]; break;
+                }
+            }
+            shaped[i] = v;
+            if (a.out.shaped) a.out.shaped[chain * N * A + i] = v;
+        }
+    }
+    __syncthreads();
+    if (lane != 0) return;
+
+    // ---- the sequential part: lane 0 ----
+    const uint64_t key = a.rng_keys ? a.rng_keys[chain] : 0;
+    const bool tape = cfg.rng_mode == LENV_RNG_TAPE;
+    int status = 0, episodes_run = 0;
+    int64_t n_eps = 0, n_act = 0, train_steps = 0, test_steps = 0;
+    double eps_g = cfg.eps_init;
+
+    auto test_phase = [&]() {
+        for (int te = 0; te < cfg.test_episodes; ++te) {
+            int s = cfg.start_state;
+            float ep_reward = 0.0f;                                    // fp32 tensor accumulation, base_agent.py:212
+            for (int st = 0; st < cfg.max_steps; ++st) {
+                const int ac = ql_argmax_f32(q + s * A, A);
+                const int dn = a.done[s * A + ac];
+                ep_reward = ep_reward + (float)a.reward[s * A + ac];
+                s = a.next_state[s * A + ac];
+                ++test_steps;
+                if (dn) break;
+            }
+            rets[te] = (double)ep_reward;
+        }
+    };
+    auto mean_rets = [&]() { double sm = 0.0; for (int i = 0; i < cfg.test_episodes; ++i) sm += rets[i]; return sm / (double)cfg.test_episodes; };
+
+    for (int episode = 0; episode < cfg.train_episodes; ++episode) {
+        if (episode == 0) eps_g = cfg.eps_init;                       // QL.py:101-106
+        else { eps_g *= cfg.eps_decay; if (eps_g < cfg.eps_min) eps_g = cfg.eps_min; }
+        int s = cfg.start_state, ep_len = 0;
+        for (int st = 0; st < cfg.max_steps; ++st) {
+            double u;
+            if (tape) { if (n_eps >= a.tapes.eps_uniform_stride) { status = -2; u = 1.0; } else u = a.tapes.eps_uniform[chain * a.tapes.eps_uniform_stride + n_eps]; }
+            else u = u64_to_unit(rng_u64(key, STREAM_EPS, (uint64_t)n_eps));
+            ++n_eps;
+            int ac, explored = 0;
+            if (u < eps_g) {
+                explored = 1;
+                if (tape) { if (n_act >= a.tapes.rand_action_stride) { status = -3; ac = 0; } else ac = a.tapes.rand_action[chain * a.tapes.rand_action_stride + n_act]; }
+                else ac = (int)u64_to_below(rng_u64(key, STREAM_ACTION, (uint64_t)n_act), (uint32_t)A);
+                ++n_act;
+            } else ac = ql_argmax_f32(q + s * A, A);
+            const int s2 = a.next_state[s * A + ac];
+            int dn = a.done[s * A + ac];
+            if (st + 1 >= cfg.max_steps) dn = 1;                       // gym.wrappers.TimeLimit
+            const double r = (double)shaped[s * A + ac];
+            for (int k = 0; k < cfg.batch_size; ++k) {                 // QL.learn (QL.py:44-73)
+                double mx = q[s2 * A];
+                for (int i = 1; i < A; ++i) if (q[s2 * A + i] > mx) mx = q[s2 * A + i];
+                const double delta = r + cfg.gamma * mx * (dn ? 0.0 : 1.0) - q[s * A + ac];
+                q[s * A + ac] += cfg.alpha * delta;
+            }
+            if (a.out.trace_action && train_steps < a.out.trace_cap) {
+                const int64_t k = chain * a.out.trace_cap + train_steps;
+                a.out.trace_action[k] = ac | (explored << 16);
+                a.out.trace_state[k * 2] = s; a.out.trace_state[k * 2 + 1] = s2;
+                a.out.trace_reward_done[k * 2] = (float)r; a.out.trace_reward_done[k * 2 + 1] = dn ? 1.0f : 0.0f;
+            }
+            s = s2;
+            ++ep_len; ++train_steps;
+            if (dn) break;
+        }
+        ++episodes_run;
+        if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
+        test_phase();
+        const double tm = mean_rets();
+        meter[episode] = tm;
+        if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
+        if (episode >= cfg.init_episodes) {                           // base_agent.py:141-148, utils.py:103-105
+            int lo = episode + 1 - cfg.early_out_num; if (lo < 0) lo = 0;
+            double sm = 0.0;
+            for (int i = lo; i <= episode; ++i) sm += meter[i];
+            if (sm / ((double)(episode + 1 - lo) + 1e-9) >= cfg.solved_reward) break;
+        }
+    }
+    test_phase();
+    a.out.score[chain] = mean_rets();
+    if (a.out.final_returns) for (int i = 0; i < cfg.test_episodes; ++i) a.out.final_returns[chain * cfg.test_episodes + i] = rets[i];
+    if (a.out.stats) {
+        a.out.stats[chain * 4 + 0] = episodes_run; a.out.stats[chain * 4 + 1] = train_steps;
+        a.out.stats[chain * 4 + 2] = train_steps; a.out.stats[chain * 4 + 3] = test_steps;
+    }
+    const double nan = __builtin_nan("");
+    for (int e = episodes_run; e < cfg.train_episodes; ++e) {
+        if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + e] = nan;
+        if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = 0;
+    }
+    if (a.out.q_table) for (int i = 0; i < N * A; ++i) a.out.q_table[chain * N * A + i] = q[i];
+    if (a.out.status) a.out.status[chain] = status;
+}
+
+}  // namespace lenv
+
+using namespace lenv;
+
+extern "C" int lenv_ql_rn_inner_loop(const lenv_ql_cfg *cfg, const float *theta, const float *eps, const int32_t *worker,
+                                     const float *sign, const float *shaped_override, const int32_t *next_state,
+                                     const double *reward, const uint8_t *done, const uint64_t *rng_keys,
+                                     const lenv_tapes *tapes, int64_t chains, const lenv_ql_out *out, void *stream)
+{
+    if (!cfg || !next_state || !reward || !done || !out || !out->score || chains < 0) return LENV_ERR_INVALID;
+    if (!theta && !shaped_override) return LENV_ERR_INVALID;
+    if (eps && (!worker || !sign)) return LENV_ERR_INVALID;
+    if (cfg->rng_mode == LENV_RNG_TAPE && !tapes) return LENV_ERR_INVALID;
+    if (cfg->rng_mode == LENV_RNG_COUNTER && !rng_keys) return LENV_ERR_INVALID;
+    if (chains == 0) return LENV_OK;
+    const int t = cfg->reward_env_type;
+    if (!(t == 0 || t == 1 || t == 2 || t == 5 || t == 6)) return LENV_ERR_UNSUPPORTED;   // info-vector types: next round
+    if (cfg->rn_layers != 1 && t != 0 && !shaped_override) return LENV_ERR_UNSUPPORTED;
+    if (cfg->n_states < 1 || cfg->n_actions < 1 || cfg->n_actions > 16 || cfg->test_episodes < 1 || cfg->train_episodes < 0 ||
+        cfg->max_steps < 1 || cfg->batch_size < 1)
+        return LENV_ERR_UNSUPPORTED;
+    QlArgs a;
+    a.cfg = *cfg;
+    a.theta = theta; a.eps = eps; a.worker = worker; a.sign = sign; a.shaped_override = shaped_override;
+    a.next_state = next_state; a.reward = reward; a.done = done; a.rng_keys = rng_keys;
+    if (tapes) a.tapes = *tapes; else a.tapes = lenv_tapes{};
+    a.out = *out;
+    a.P = (int64_t)cfg->n_states * cfg->rn_hidden + 2 * (int64_t)cfg->rn_hidden + 1;
+    const size_t NA = (size_t)cfg->n_states * cfg->n_actions;
+    const size_t lds_bytes = sizeof(double) * (NA + cfg->train_episodes + cfg->test_episodes) + sizeof(float) * (cfg->n_states + NA) + 16;
+    if (lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ql_rn_inner_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return LENV_ERR_LAUNCH;
+    hipLaunchKernelGGL(ql_rn_inner_kernel, dim3((unsigned)chains), dim3(64), lds_bytes, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}

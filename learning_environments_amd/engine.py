@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import DdqnCfg, InnerOut, MlpDesc, Tapes
+from ._lib import DdqnCfg, InnerOut, MlpDesc, QlCfg, QlOut, Tapes
 
 
 def require_device():
@@ -142,6 +142,57 @@ class InnerLoop(object):
                                                 _ptr(agent_init), _ptr(rng_keys), C.byref(t) if t is not None else None,
                                                 self.chains, _ptr(self.workspace), self.ws_bytes, C.byref(self.out), _stream())
         _lib.check(rc, "lenv_ddqn_se_inner_loop")
+        return self.score
+
+
+class QlInnerLoop(object):
+    """Owns the outputs of lenv_ql_rn_inner_loop for a fixed (cfg, chains, grid MDP)."""
+
+    def __init__(self, cfg, chains, tables, want_episode_stats=True, trace_cap=0):
+        self.dev = require_device()
+        self.cfg, self.chains = cfg, int(chains)
+        N, A, E, T = cfg.n_states, cfg.n_actions, cfg.train_episodes, cfg.test_episodes
+        self.next_state = torch.from_numpy(tables["next_state"].astype("int32")).contiguous().to(self.dev)
+        self.reward = torch.from_numpy(tables["reward"].astype("float64")).contiguous().to(self.dev)
+        self.done = torch.from_numpy(tables["done"].astype("uint8")).contiguous().to(self.dev)
+        self.p_theta = N * cfg.rn_hidden + 2 * cfg.rn_hidden + 1
+        self.score = torch.zeros(self.chains, dtype=torch.float64, device=self.dev)
+        self.stats = torch.zeros((self.chains, 4), dtype=torch.int64, device=self.dev)
+        self.status = torch.zeros(self.chains, dtype=torch.int32, device=self.dev)
+        self.episode_test_mean = self.episode_len = self.final_returns = self.q_table = self.shaped = None
+        if want_episode_stats:
+            self.episode_test_mean = torch.zeros((self.chains, max(E, 1)), dtype=torch.float64, device=self.dev)
+            self.episode_len = torch.zeros((self.chains, max(E, 1)), dtype=torch.int32, device=self.dev)
+            self.final_returns = torch.zeros((self.chains, T), dtype=torch.float64, device=self.dev)
+            self.q_table = torch.zeros((self.chains, N * A), dtype=torch.float64, device=self.dev)
+            self.shaped = torch.zeros((self.chains, N * A), dtype=torch.float32, device=self.dev)
+        self.trace_cap = int(trace_cap)
+        self.trace = None
+        if trace_cap:
+            self.trace = dict(action=torch.zeros((self.chains, trace_cap), dtype=torch.int32, device=self.dev),
+                              state=torch.zeros((self.chains, trace_cap, 2), dtype=torch.int32, device=self.dev),
+                              reward_done=torch.zeros((self.chains, trace_cap, 2), dtype=torch.float32, device=self.dev))
+        tr = self.trace or {}
+        self.out = QlOut(_ptr(self.score), _ptr(self.stats), _ptr(self.status), _ptr(self.episode_test_mean),
+                         _ptr(self.episode_len), _ptr(self.final_returns), _ptr(self.q_table), _ptr(self.shaped),
+                         self.trace_cap, _ptr(tr.get("action")), _ptr(tr.get("state")), _ptr(tr.get("reward_done")))
+
+    def run(self, theta, eps, worker, sign, rng_keys=None, tapes=None, shaped_override=None):
+        _chk(theta, torch.float32, "theta"); _chk(eps, torch.float32, "eps"); _chk(worker, torch.int32, "worker")
+        _chk(sign, torch.float32, "sign"); _chk(shaped_override, torch.float32, "shaped_override")
+        if theta is not None and theta.numel() != self.p_theta and self.cfg.reward_env_type != 0:
+            raise ValueError("theta must hold %d reward-net parameters" % self.p_theta)
+        t = None
+        if tapes is not None:
+            t = Tapes(_ptr(tapes["eps_uniform"]), tapes["eps_uniform"].shape[1], _ptr(tapes["rand_action"]),
+                      tapes["rand_action"].shape[1], None, 0, None, 0, None, 0)
+        if rng_keys is not None:
+            _chk(rng_keys, torch.int64, "rng_keys")
+        rc = _lib.lib().lenv_ql_rn_inner_loop(C.byref(self.cfg), _ptr(theta), _ptr(eps), _ptr(worker), _ptr(sign),
+                                              _ptr(shaped_override), _ptr(self.next_state), _ptr(self.reward), _ptr(self.done),
+                                              _ptr(rng_keys), C.byref(t) if t is not None else None, self.chains,
+                                              C.byref(self.out), _stream())
+        _lib.check(rc, "lenv_ql_rn_inner_loop")
         return self.score
 
 

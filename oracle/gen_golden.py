@@ -436,8 +436,153 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
          reward_list_test=np.array(reward_list_test, np.float64), score=np.array(score))
 
 
+# ------------------------------------------------------------------------------------------------
+# G10: gridworld transition tables for every layout (envs/gridworld.py, pure reference code)
+# ------------------------------------------------------------------------------------------------
+def gen_g10():
+    import envs.gridworld as gw
+    out = {}
+    names = ["EmptyRoom22", "EmptyRoom23", "EmptyRoom33", "WallRoom", "HoleRoom", "HoleRoomLarge", "HoleRoomLargeShifted", "Cliff"]
+    for name in names:
+        env = getattr(gw, name)()
+        m, n = len(env.grid), len(env.grid[0])
+        N = m * n
+        nxt = np.zeros((N, 4), np.int32); rew = np.zeros((N, 4), np.float64); dn = np.zeros((N, 4), np.uint8)
+        for s in range(N):
+            for a in range(4):
+                env.state = env._obs_to_state(s)
+                if env.grid[env.state[0]][env.state[1]] == '#':
+                    continue          # wall cells are unreachable
+                obs, r, d, _ = env.step(a)
+                nxt[s, a], rew[s, a], dn[s, a] = obs, r, d
+        out[name + "_next"] = nxt; out[name + "_reward"] = rew; out[name + "_done"] = dn
+        out[name + "_start"] = np.array(env.reset())
+        out[name + "_walls"] = np.array([env.grid[s // n][s % n] == '#' for s in range(N)])
+    save("g10_gridworld_tables", names=np.array(names), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# G2: RewardEnv._calc_reward on Cliff for the info-free types (envs/reward_env.py:67-133)
+# ------------------------------------------------------------------------------------------------
+def gen_g2():
+    from envs.env_factory import EnvFactory
+    out = {}
+    types = [0, 1, 2, 5, 6]
+    for t in types:
+        for act, layers in (("prelu", 1), ("tanh", 2)):
+            cfg = load_cfg("default_config_gridworld_reward_env.yaml")
+            cfg["envs"]["Cliff"]["reward_env_type"] = t
+            cfg["envs"]["Cliff"]["activation_fn"] = act
+            cfg["envs"]["Cliff"]["hidden_layer"] = layers
+            seed_all(200 + t)
+            with quiet():
+                renv = EnvFactory(cfg).generate_reward_env()
+            renv.set_agent_params(same_action_num=1, gamma=0.8)
+            theta = pack_linear_params(renv.state_dict(), "env.reward_net.") if t != 0 else np.zeros(1, np.float32)
+            if t == 0:
+                theta = pack_linear_params(renv.state_dict(), "env.reward_net.")
+            vals = np.zeros((48, 4), np.float64)
+            with torch.no_grad():
+                for s in range(48):
+                    for a in range(4):
+                        renv.env.real_env.reset()
+                        renv.env.real_env.env.state = renv.env.real_env.env._obs_to_state(s)
+                        renv.env.state = s
+                        _, r, _, _ = renv.env.step(a)
+                        vals[s, a] = r
+            key = "t%d_%s%d_" % (t, act, layers)
+            out[key + "theta"] = theta
+            out[key + "shaped"] = vals
+    save("g2_reward_env_cliff", types=np.array(types), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# G9: full GTN_Worker.calc_score on the Cliff RewardEnv with QL (cfg 4) + tapes + per-step trace
+# ------------------------------------------------------------------------------------------------
+def gen_g9(name, seed, eps_over=None):
+    import json
+    import statistics
+    import agents.GTN_worker as gw
+    from agents.GTN import GTN_Worker
+    import gym.spaces as gspaces
+    cfg = load_cfg("default_config_gridworld_reward_env.yaml")
+    cfg["agents"]["ql"]["print_rate"] = int(1e9)
+    if eps_over is not None:
+        cfg["agents"]["ql"]["eps_init"] = eps_over
+        cfg["agents"]["ql"]["eps_min"] = eps_over
+    rec = Recorder()
+    orig_random = random.random
+    orig_sample = gspaces.Discrete.sample
+
+    def rec_random():
+        v = orig_random()
+        if rec.active:
+            rec.eps_uniform.append(v)
+        return v
+
+    def rec_sample(self):
+        v = orig_sample(self)
+        if rec.active:
+            rec.rand_action.append(v)
+        return v
+
+    with quiet():
+        w = GTN_Worker(id=0, bohb_id=0)
+        seed_all(seed)
+        w.config = cfg
+        w.late_init(cfg)
+        w.timeout = 1e9
+        env = w.synthetic_env_orig
+        theta = pack_linear_params(env.state_dict(), "env.reward_net.")
+        orig_step = env.step
+
+        def rec_step(action, state=None):
+            s_before = int(env.env.state)
+            ns, r, d = orig_step(action=action, state=state)
+            rec.steps.append(dict(state=s_before, action=int(action.item()), next_state=int(ns.item()), reward=float(r.item()),
+                                  done=float(d.item()), n_rand=len(rec.rand_action)))
+            return ns, r, d
+
+        env.step = rec_step
+        random.random = rec_random
+        gspaces.Discrete.sample = rec_sample
+        try:
+            rec.active = True
+            agent = gw.select_agent(config=w.config, agent_name=w.agent_name)
+            real_env = w.env_factory.generate_real_env()
+            reward_list_train, episode_length_train, _ = agent.train(env=env, test_env=real_env, time_remaining=1e9)
+            reward_list_test, _, _ = agent.test(env=real_env, time_remaining=1e9)
+            rec.active = False
+        finally:
+            random.random = orig_random
+            gspaces.Discrete.sample = orig_sample
+    explored = np.zeros(len(rec.steps), np.int32)
+    prev = 0
+    for k, st in enumerate(rec.steps):
+        explored[k] = 1 if st["n_rand"] > prev else 0
+        prev = st["n_rand"]
+    # the reference's own shaped-reward table for this theta (what RewardEnv.step returned for every (s,a))
+    shaped = np.zeros((48, 4), np.float32)
+    env.step = orig_step
+    with torch.no_grad():
+        for s_ in range(48):
+            for a_ in range(4):
+                env.env.real_env.reset()
+                env.env.real_env.env.state = env.env.real_env.env._obs_to_state(s_)
+                env.env.state = s_
+                shaped[s_, a_] = env.env.step(a_)[1]
+    save(name, config_json=np.array(json.dumps(cfg)), theta=theta, shaped_ref=shaped,
+         tape_eps_uniform=np.array(rec.eps_uniform, np.float64), tape_rand_action=np.array(rec.rand_action, np.int32),
+         tr_state=np.array([s["state"] for s in rec.steps], np.int32), tr_action=np.array([s["action"] for s in rec.steps], np.int32),
+         tr_explored=explored, tr_next_state=np.array([s["next_state"] for s in rec.steps], np.int32),
+         tr_reward=np.array([s["reward"] for s in rec.steps], np.float32), tr_done=np.array([s["done"] for s in rec.steps], np.float32),
+         q_table=np.array(agent.q_table, np.float64), reward_list_train=np.array(reward_list_train, np.float64),
+         episode_length_train=np.array(episode_length_train, np.int32), reward_list_test=np.array(reward_list_test, np.float64),
+         score=np.array(statistics.mean(reward_list_test)))
+
+
 def main():
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8", "g9", "g10"]
     os.makedirs(OUT, exist_ok=True)
     if "g1" in which:
         gen_g1()
@@ -449,6 +594,13 @@ def main():
         gen_g6()
     if "g7" in which:
         gen_g7()
+    if "g2" in which:
+        gen_g2()
+    if "g9" in which:
+        gen_g9("g9_calc_score_cliff_a", seed=900)
+        gen_g9("g9_calc_score_cliff_b", seed=901, eps_over=0.2)
+    if "g10" in which:
+        gen_g10()
     if "g8" in which:
         gen_g8("g8_calc_score_cartpole_a", train_episodes=3, done_bias_shift=0.0, seed=800)
         gen_g8("g8_calc_score_cartpole_b", train_episodes=4, done_bias_shift=0.45, seed=801, max_steps=60)

@@ -743,6 +743,159 @@ int orc_ddqn_se_population(const orc_ddqn_cfg *cfg, const float *theta, const fl
 }
 
 /* ------------------------------------------------------------------------------------------
+ * config 4: QL on a RewardEnv over a grid MDP
+ * ---------------------------------------------------------------------------------------- */
+/* phi(s) = reward_net(one_hot(s)) (reward_env.py:74-76) and the shaped reward of every (s,a):
+ * type 0: r; 1: g*phi(s') - phi(s); 2: r + g*phi(s') - phi(s); 5: phi(s'); 6: r + phi(s')  (reward_env.py:81-110),
+ * evaluated left to right in fp32 exactly like the torch expression, result `.item()`. */
+int orc_rn_shaped_rewards(const orc_ql_cfg *cfg, const float *rn_params, const int32_t *next_state, const double *reward,
+                          float *phi_out, float *shaped)
+{
+    const int N = cfg->n_states, A = cfg->n_actions;
+    if (N > ORC_MAX_WIDTH || cfg->rn_hidden > ORC_MAX_WIDTH || cfg->rn_layers > ORC_MAX_LAYERS || cfg->rn_layers < 1) return -1;
+    const int t = cfg->reward_env_type;
+    if (!(t == 0 || t == 1 || t == 2 || t == 5 || t == 6)) return -1;
+    orc_mlp_desc rd = { N, cfg->rn_hidden, cfg->rn_layers, 1, cfg->rn_act, cfg->rn_prelu };
+    float *phi = malloc(sizeof(float) * N);
+    float *x = calloc(N, sizeof(float));
+    float (*z)[ORC_MAX_WIDTH] = malloc(sizeof(float) * ORC_MAX_LAYERS * ORC_MAX_WIDTH);
+    float (*a)[ORC_MAX_WIDTH] = malloc(sizeof(float) * ORC_MAX_LAYERS * ORC_MAX_WIDTH);
+    for (int s = 0; s < N; ++s) {
+        if (t == 0) { phi[s] = 0.0f; continue; }     /* type 0 builds a dummy 1-input net that is never evaluated */
+        x[s] = 1.0f;
+        mlp_forward_one(&rd, rn_params, x, &phi[s], z, a);
+        x[s] = 0.0f;
+    }
+    const float g32 = (float)cfg->gamma;
+    for (int s = 0; s < N; ++s)
+        for (int ac = 0; ac < A; ++ac) {
+            const int s2 = next_state[s * A + ac];
+            const float r32 = (float)reward[s * A + ac];
+            float v;
+            switch (t) {
+            case 0: v = r32; break;
+            case 1: v = g32 * phi[s2] - phi[s]; break;
+            case 2: v = (r32 + g32 * phi[s2]) - phi[s]; break;
+            case 5: v = phi[s2]; break;
+            default: v = r32 + phi[s2]; break;
+            }
+            shaped[s * A + ac] = v;
+        }
+    if (phi_out) memcpy(phi_out, phi, sizeof(float) * N);
+    free(phi); free(x); free(z); free(a);
+    return 0;
+}
+
+static int ql_argmax_f32(const double *row, int n)
+{
+    /* torch.argmax(torch.tensor(row)) (QL.py:93-94,98-99): the fp64 row is cast to fp32 first; first maximum wins */
+    int best = 0;
+    float bv = (float)row[0];
+    for (int i = 1; i < n; ++i) { float v = (float)row[i]; if (v > bv) { bv = v; best = i; } }
+    return best;
+}
+
+int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *shaped_override, const int32_t *next_state,
+                    const double *reward, const uint8_t *done_tab, uint64_t rng_key, const orc_tapes *tapes, double *episode_test_mean,
+                    int32_t *episode_len, double *final_test_returns, double *q_table_out, orc_ql_trace *trace,
+                    orc_chain_result *res)
+{
+    const int N = cfg->n_states, A = cfg->n_actions;
+    if (cfg->rng_mode == ORC_RNG_TAPE && !tapes) return -1;
+    float *shaped = malloc(sizeof(float) * N * A);
+    if (shaped_override) memcpy(shaped, shaped_override, sizeof(float) * N * A);   /* parity tests: the reference's own table */
+    else if (orc_rn_shaped_rewards(cfg, rn_params, next_state, reward, NULL, shaped)) { free(shaped); return -1; }
+    double *q = calloc((size_t)N * A, sizeof(double));       /* q_table = [[0]*A for _ in range(N)]  QL.py:25 */
+    double *meter = malloc(sizeof(double) * (cfg->train_episodes > 0 ? cfg->train_episodes : 1));
+    double *rets = malloc(sizeof(double) * (cfg->test_episodes > 0 ? cfg->test_episodes : 1));
+    int64_t n_eps = 0, n_act = 0, train_steps = 0, learn_steps = 0, test_steps = 0;
+    int err = 0, episodes_run = 0, n_meter = 0;
+    double eps = cfg->eps_init;
+    if (trace) trace->n = 0;
+
+#define QL_TEST_PHASE()                                                                                       \
+    for (int te = 0; te < cfg->test_episodes; ++te) {                                                         \
+        int s = cfg->start_state;                                                                             \
+        float ep_reward = 0.0f;                                                                               \
+        for (int t = 0; t < cfg->max_steps; ++t) {                                                            \
+            int ac = ql_argmax_f32(q + (size_t)s * A, A);                                                     \
+            int dn = done_tab[s * A + ac];                                                                    \
+            ep_reward = ep_reward + (float)reward[s * A + ac];                                                \
+            s = next_state[s * A + ac];                                                                       \
+            ++test_steps;                                                                                     \
+            if (dn) break;                                                                                    \
+        }                                                                                                     \
+        rets[te] = (double)ep_reward;                                                                         \
+    }
+
+    for (int episode = 0; episode < cfg->train_episodes; ++episode) {
+        if (episode == 0) eps = cfg->eps_init;                                  /* QL.py:101-106 */
+        else { eps *= cfg->eps_decay; if (eps < cfg->eps_min) eps = cfg->eps_min; }
+        int s = cfg->start_state, ep_len = 0;                                   /* RewardEnv.reset -> real_env.reset() */
+        for (int t = 0; t < cfg->max_steps; ++t) {
+            double u;
+            if (cfg->rng_mode == ORC_RNG_TAPE) { if (n_eps >= tapes->n_eps_uniform) { err = -2; u = 1.0; } else u = tapes->eps_uniform[n_eps]; }
+            else u = u64_to_unit(orc_rng_u64(rng_key, STREAM_EPS, (uint64_t)n_eps));
+            ++n_eps;
+            int ac, explored = 0;
+            if (u < eps) {
+                explored = 1;
+                if (cfg->rng_mode == ORC_RNG_TAPE) { if (n_act >= tapes->n_rand_action) { err = -3; ac = 0; } else ac = tapes->rand_action[n_act]; }
+                else ac = (int)u64_to_below(orc_rng_u64(rng_key, STREAM_ACTION, (uint64_t)n_act), (uint32_t)A);
+                ++n_act;
+            } else ac = ql_argmax_f32(q + (size_t)s * A, A);
+            /* RewardEnv.step (reward_env.py:61-66) + TimeLimit */
+            const int s2 = next_state[s * A + ac];
+            int dn = done_tab[s * A + ac];
+            if (t + 1 >= cfg->max_steps) dn = 1;
+            const double r = (double)shaped[s * A + ac];
+            /* QL.learn (QL.py:44-73): batch_size draws of the single stored transition */
+            for (int k = 0; k < cfg->batch_size; ++k) {
+                double mx = q[(size_t)s2 * A];
+                for (int i = 1; i < A; ++i) if (q[(size_t)s2 * A + i] > mx) mx = q[(size_t)s2 * A + i];
+                const double delta = r + cfg->gamma * mx * (dn ? 0.0 : 1.0) - q[(size_t)s * A + ac];
+                q[(size_t)s * A + ac] += cfg->alpha * delta;
+            }
+            ++learn_steps;
+            if (trace && trace->n < trace->cap) {
+                int64_t k = trace->n++;
+                trace->action[k] = ac | (explored << 16); trace->state[k] = s; trace->next_state[k] = s2;
+                trace->reward[k] = (float)r; trace->done[k] = dn ? 1.0f : 0.0f;
+            }
+            s = s2;
+            ++ep_len; ++train_steps;
+            if (dn) break;
+        }
+        ++episodes_run;
+        if (episode_len) episode_len[episode] = ep_len;
+        QL_TEST_PHASE()
+        double tm = mean_seq(rets, cfg->test_episodes);
+        meter[n_meter++] = tm;
+        if (episode_test_mean) episode_test_mean[episode] = tm;
+        if (episode >= cfg->init_episodes) {
+            int lo = n_meter - cfg->early_out_num; if (lo < 0) lo = 0;
+            double sm = 0.0;
+            for (int i = lo; i < n_meter; ++i) sm += meter[i];
+            if (sm / ((double)(n_meter - lo) + 1e-9) >= cfg->solved_reward) break;
+        }
+    }
+    for (int e = episodes_run; e < cfg->train_episodes; ++e) {
+        if (episode_test_mean) episode_test_mean[e] = NAN;
+        if (episode_len) episode_len[e] = 0;
+    }
+    QL_TEST_PHASE()
+#undef QL_TEST_PHASE
+    if (final_test_returns) memcpy(final_test_returns, rets, sizeof(double) * cfg->test_episodes);
+    if (q_table_out) memcpy(q_table_out, q, sizeof(double) * N * A);
+    if (res) {
+        res->score = mean_seq(rets, cfg->test_episodes);
+        res->episodes_run = episodes_run; res->train_steps = train_steps; res->learn_steps = learn_steps; res->test_steps = test_steps;
+    }
+    free(shaped); free(q); free(meter); free(rets);
+    return err;
+}
+
+/* ------------------------------------------------------------------------------------------
  * NES worker / master math
  * ---------------------------------------------------------------------------------------- */
 /* GTN_worker.py:234-254 (num_grad_evals == 1, so 'mean' and 'minmax' coincide) */

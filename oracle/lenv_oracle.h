@@ -148,6 +148,36 @@ int orc_ddqn_se_population(const orc_ddqn_cfg *cfg, const float *theta, const fl
                            int64_t worker_offset, int threads, double *chain_scores /*[3*pop]*/,
                            orc_chain_result *results /*[3*pop] or NULL*/);
 
+/* ---- config 4: tabular Q-learning on a potential-shaped RewardEnv over a grid MDP ----
+ * agents/QL.py:13-105, envs/reward_env.py:29-149, envs/gridworld.py:24-124 (MDP given as transition tables) */
+typedef struct {
+    int32_t n_states, n_actions, start_state, max_steps;
+    int32_t rn_hidden, rn_layers, rn_act;
+    float rn_prelu;
+    int32_t reward_env_type;            /* 0,1,2,5,6 (types with an info vector are not part of the grid path) */
+    int32_t train_episodes, test_episodes, init_episodes, early_out_num, batch_size;
+    int32_t rng_mode;
+    double solved_reward, alpha, gamma, eps_init, eps_min, eps_decay;
+} orc_ql_cfg;
+
+typedef struct {
+    int64_t cap, n;
+    int32_t *action;      /* action | explored<<16 */
+    int32_t *state;       /* state before the step */
+    int32_t *next_state;
+    float *reward;        /* shaped reward returned by the RewardEnv */
+    float *done;
+} orc_ql_trace;
+
+/* RewardEnv._calc_reward (reward_env.py:67-133) for every (s,a) of the grid MDP -> shaped[n_states*n_actions] */
+int orc_rn_shaped_rewards(const orc_ql_cfg *cfg, const float *rn_params, const int32_t *next_state, const double *reward,
+                          float *phi /*[n_states] or NULL*/, float *shaped);
+/* GTN_Worker.calc_score with QL on a RewardEnv (GTN_worker.py:187-221) */
+int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *shaped_override /*[N*A] or NULL*/,
+                    const int32_t *next_state, const double *reward, const uint8_t *done, uint64_t rng_key, const orc_tapes *tapes, double *episode_test_mean,
+                    int32_t *episode_len, double *final_test_returns, double *q_table_out, orc_ql_trace *trace,
+                    orc_chain_result *res);
+
 /* ---- NES master/worker math ---- */
 /* GTN_worker.py:234-254: mirrored sampling pick; out[p] = {score_best, sign} */
 void orc_worker_best(const double *score_add, const double *score_sub, int64_t pop, int mirrored, double *score_best, float *sign);

@@ -47,6 +47,20 @@ class Trace(C.Structure):
                 ("reward", C.POINTER(C.c_float)), ("done", C.POINTER(C.c_float)), ("loss", C.POINTER(C.c_float))]
 
 
+class QlCfg(C.Structure):
+    _fields_ = [("n_states", C.c_int32), ("n_actions", C.c_int32), ("start_state", C.c_int32), ("max_steps", C.c_int32),
+                ("rn_hidden", C.c_int32), ("rn_layers", C.c_int32), ("rn_act", C.c_int32), ("rn_prelu", C.c_float),
+                ("reward_env_type", C.c_int32), ("train_episodes", C.c_int32), ("test_episodes", C.c_int32),
+                ("init_episodes", C.c_int32), ("early_out_num", C.c_int32), ("batch_size", C.c_int32), ("rng_mode", C.c_int32),
+                ("solved_reward", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double), ("eps_init", C.c_double),
+                ("eps_min", C.c_double), ("eps_decay", C.c_double)]
+
+
+class QlTrace(C.Structure):
+    _fields_ = [("cap", C.c_int64), ("n", C.c_int64), ("action", C.POINTER(C.c_int32)), ("state", C.POINTER(C.c_int32)),
+                ("next_state", C.POINTER(C.c_int32)), ("reward", C.POINTER(C.c_float)), ("done", C.POINTER(C.c_float))]
+
+
 class ChainResult(C.Structure):
     _fields_ = [("score", C.c_double), ("episodes_run", C.c_int32), ("train_steps", C.c_int64),
                 ("learn_steps", C.c_int64), ("test_steps", C.c_int64)]
@@ -292,3 +306,68 @@ def ddqn_cfg_from_config(config, grad_chunk=13, rng_mode=0, **overrides):
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg
+
+
+def ql_cfg_from_config(config, tables, rng_mode=0, **overrides):
+    """Reference YAML dict (QL agent + reward env on a gridworld) -> oracle config.  Fields read at agents/QL.py:13-27,
+    agents/base_agent.py:9-26, envs/reward_env.py:8-27."""
+    env_name = config["env_name"]
+    e = config["envs"][env_name]
+    a = config["agents"]["ql"]
+    assert a["same_action_num"] == 1
+    cfg = QlCfg(n_states=tables["n_states"], n_actions=tables["n_actions"], start_state=tables["start_state"],
+                max_steps=int(e["max_steps"]), rn_hidden=int(e["hidden_size"]), rn_layers=int(e["hidden_layer"]),
+                rn_act=ACT[e["activation_fn"]], rn_prelu=0.25, reward_env_type=int(e["reward_env_type"]),
+                train_episodes=int(a["train_episodes"]), test_episodes=int(a["test_episodes"]),
+                init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]), batch_size=int(a["batch_size"]),
+                rng_mode=rng_mode, solved_reward=float(e["solved_reward"]), alpha=float(a["alpha"]), gamma=float(a["gamma"]),
+                eps_init=float(a["eps_init"]), eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]))
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def rn_shaped_rewards(cfg, rn_params, tables):
+    rn_params = _f32(rn_params)
+    nxt = np.ascontiguousarray(tables["next_state"], np.int32)
+    rew = np.ascontiguousarray(tables["reward"], np.float64)
+    N, A = nxt.shape
+    phi = np.empty(N, np.float32)
+    shaped = np.empty((N, A), np.float32)
+    rc = lib().orc_rn_shaped_rewards(C.byref(cfg), _p(rn_params, C.c_float), _p(nxt, C.c_int32), _p(rew, C.c_double),
+                                     _p(phi, C.c_float), _p(shaped, C.c_float))
+    assert rc == 0
+    return phi, shaped
+
+
+def ql_rn_chain(cfg, rn_params, tables, rng_key=0, tapes=None, trace_cap=0, shaped_override=None):
+    rn_params = _f32(rn_params)
+    nxt = np.ascontiguousarray(tables["next_state"], np.int32)
+    rew = np.ascontiguousarray(tables["reward"], np.float64)
+    dn = np.ascontiguousarray(tables["done"], np.uint8)
+    N, A = nxt.shape
+    E, T = cfg.train_episodes, cfg.test_episodes
+    ep_mean = np.full(max(E, 1), np.nan)
+    ep_len = np.zeros(max(E, 1), np.int32)
+    final = np.zeros(max(T, 1))
+    q = np.zeros((N, A))
+    res = ChainResult()
+    tr, arrs = None, None
+    if trace_cap:
+        arrs = dict(action=np.zeros(trace_cap, np.int32), state=np.zeros(trace_cap, np.int32),
+                    next_state=np.zeros(trace_cap, np.int32), reward=np.zeros(trace_cap, np.float32),
+                    done=np.zeros(trace_cap, np.float32))
+        tr = QlTrace(trace_cap, 0, _p(arrs["action"], C.c_int32), _p(arrs["state"], C.c_int32),
+                     _p(arrs["next_state"], C.c_int32), _p(arrs["reward"], C.c_float), _p(arrs["done"], C.c_float))
+    so = _f32(shaped_override) if shaped_override is not None else None
+    rc = lib().orc_ql_rn_chain(C.byref(cfg), _p(rn_params, C.c_float), _p(so, C.c_float) if so is not None else None,
+                               _p(nxt, C.c_int32), _p(rew, C.c_double),
+                               _p(dn, C.c_uint8), C.c_uint64(rng_key), C.byref(tapes) if tapes is not None else None,
+                               _p(ep_mean, C.c_double), _p(ep_len, C.c_int32), _p(final, C.c_double), _p(q, C.c_double),
+                               C.byref(tr) if tr is not None else None, C.byref(res))
+    out = dict(rc=rc, score=res.score, episodes_run=res.episodes_run, train_steps=res.train_steps,
+               learn_steps=res.learn_steps, test_steps=res.test_steps, episode_test_mean=ep_mean[:E],
+               episode_len=ep_len[:E], final_test_returns=final[:T], q_table=q)
+    if tr is not None:
+        out["trace"] = {k: v[:tr.n] for k, v in arrs.items()}
+    return out

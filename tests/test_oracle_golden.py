@@ -159,3 +159,67 @@ def test_g8_calc_score_trace(golden, name):
     np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(out["final_test_returns"], g["reward_list_test"], rtol=0, atol=1e-4)
     assert abs(out["score"] - float(g["score"])) <= 1e-4
+
+
+def test_g10_gridworld_tables(golden):
+    """The package's table compiler (envs/gridworld.py) against tables produced by stepping the reference's classes."""
+    from learning_environments_amd.envs.gridworld import transition_tables
+    g = golden("g10_gridworld_tables")
+    for name in [str(n) for n in g["names"]]:
+        t = transition_tables(name)
+        ok = ~g[name + "_walls"]
+        assert t["start_state"] == int(g[name + "_start"])
+        assert np.array_equal(t["next_state"][ok], g[name + "_next"][ok]), name
+        assert np.array_equal(t["reward"][ok], g[name + "_reward"][ok]), name
+        assert np.array_equal(t["done"][ok], g[name + "_done"][ok]), name
+
+
+def _ql_cfg(cfgd, rng_mode=1, **over):
+    from learning_environments_amd.envs.gridworld import transition_tables
+    tables = transition_tables(cfgd["env_name"])
+    return orc.ql_cfg_from_config(cfgd, tables, rng_mode=rng_mode, **over), tables
+
+
+def test_g2_reward_env_shaping(golden):
+    import json
+    g = golden("g2_reward_env_cliff")
+    cfgd = json.loads(str(golden("g9_calc_score_cliff_a")["config_json"]))
+    for t in [int(v) for v in g["types"]]:
+        for act, layers in (("prelu", 1), ("tanh", 2)):
+            cfg, tables = _ql_cfg(cfgd, reward_env_type=t, rn_act=orc.ACT[act], rn_layers=layers)
+            key = "t%d_%s%d_" % (t, act, layers)
+            _, shaped = orc.rn_shaped_rewards(cfg, g[key + "theta"], tables)
+            if t == 0:
+                assert np.array_equal(shaped.astype(np.float64), g[key + "shaped"])
+            else:
+                np.testing.assert_allclose(shaped, g[key + "shaped"], rtol=2e-6, atol=2e-6, err_msg=key)
+
+
+@pytest.mark.parametrize("name", ["g9_calc_score_cliff_a", "g9_calc_score_cliff_b"])
+def test_g9_calc_score_cliff(golden, name):
+    """cfg 4: integer-state path.  Trajectories, Q-table argmax decisions, episode lengths and returns are EXACT."""
+    import json
+    g = golden(name)
+    cfg, tables = _ql_cfg(json.loads(str(g["config_json"])))
+    tapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], np.zeros(0, np.int32), np.zeros((0, 4)), np.zeros((0, 4)))
+    n = g["tr_action"].size
+    # phi's 32-term output dot product runs through torch's batch-1 gemv, whose summation order is MKL-defined; a 1-ulp
+    # difference in a shaped reward can flip an argmax between two near-tied Q entries.  The integer path is therefore
+    # pinned with the reference's own shaped-reward table as input (phi itself is pinned by G2 at 2e-6).
+    _, shaped = orc.rn_shaped_rewards(cfg, g["theta"], tables)
+    np.testing.assert_allclose(shaped, g["shaped_ref"], rtol=2e-6, atol=2e-6)
+    out = orc.ql_rn_chain(cfg, g["theta"], tables, tapes=tapes, trace_cap=n + 4, shaped_override=g["shaped_ref"])
+    assert out["rc"] == 0
+    tr = out["trace"]
+    assert tr["action"].size == n
+    assert np.array_equal(tr["action"] & 0xFFFF, g["tr_action"])
+    assert np.array_equal(tr["action"] >> 16, g["tr_explored"])
+    assert np.array_equal(tr["state"], g["tr_state"])
+    assert np.array_equal(tr["next_state"], g["tr_next_state"])
+    assert np.array_equal(tr["done"], g["tr_done"])
+    assert np.array_equal(tr["reward"], g["tr_reward"])
+    assert np.array_equal(out["q_table"], g["q_table"])          # fp64 Q-table: bit-exact
+    assert np.array_equal(out["episode_len"][:g["episode_length_train"].size], g["episode_length_train"])
+    assert np.array_equal(out["episode_test_mean"][:g["reward_list_train"].size], g["reward_list_train"])
+    assert np.array_equal(out["final_test_returns"], g["reward_list_test"])
+    assert out["score"] == float(g["score"])
