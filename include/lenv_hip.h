@@ -175,6 +175,15 @@ int lenv_ql_rn_inner_loop(const lenv_ql_cfg *cfg /*HOST*/, const float *theta, c
                           int64_t chains, const lenv_ql_out *out /*HOST struct of device ptrs*/, void *stream);
 
 /*
+ * RewardEnv shaping for a population of perturbed reward networks on a grid MDP (envs/reward_env.py:67-133): phi_out
+ * [chains,n_states] (optional) = reward_net(one_hot(s)), shaped_out [chains,n_states*n_actions] = what RewardEnv.step
+ * returns as reward for (s,a).  Only n_states/n_actions/rn_* /reward_env_type/gamma of cfg are read.
+ */
+int lenv_rn_shape_population(const lenv_ql_cfg *cfg /*HOST*/, const float *theta, const float *eps, const int32_t *worker,
+                             const float *sign, int64_t chains, const int32_t *next_state, const double *reward,
+                             float *phi_out, float *shaped_out, void *stream);
+
+/*
  * Real-environment reset/step for n independent instances (replaces gym==0.17.3 CartPole-v0 / Acrobot-v1
  * reset()/step() + gym.wrappers.TimeLimit behind EnvWrapper.reset/step, envs/env_wrapper.py:49-85).
  * state [n,4] float64 (gym's internal state), elapsed [n] TimeLimit counters, obs [n,S] fp32 observations.

@@ -68,7 +68,7 @@ class QlOut(C.Structure):
 
 EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv_se_step_population",
            "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_lds_bytes", "lenv_ddqn_se_inner_loop",
-           "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop"]
+           "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population"]
 
 
 def build(force=False):
@@ -117,6 +117,8 @@ def lib():
         L.lenv_ql_rn_inner_loop.restype = C.c_int
         L.lenv_ql_rn_inner_loop.argtypes = [C.POINTER(QlCfg), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(Tapes), C.c_int64,
                                             C.POINTER(QlOut), vp]
+        L.lenv_rn_shape_population.restype = C.c_int
+        L.lenv_rn_shape_population.argtypes = [C.POINTER(QlCfg), vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
         L.lenv_nes_worker_best.restype = C.c_int
         L.lenv_nes_worker_best.argtypes = [vp, C.c_int64, C.c_int32, vp, vp]
         L.lenv_nes_rank_update.restype = C.c_int

@@ -22,11 +22,11 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from ..config import ddqn_cfg_from_config
 from ..envs.env_factory import EnvFactory
 from ..utils import calc_abs_param_sum
 from .GTN_base import GTN_Base
-from .nes_common import chain_keys, fresh_agent_init, linear_init_bounds, rank_table, shard_bounds
+from .nes_common import chain_keys, fresh_agent_init, rank_table, shard_bounds
+from .tasks import select_task
 
 __all__ = ["GTN_Master", "rank_table"]
 
@@ -62,8 +62,8 @@ class GTN_Master(GTN_Base):
             raise NotImplementedError('Unknown parameter for grad_eval_type: ' + str(self.grad_eval_type))
         if self.num_grad_evals != 1:
             raise NotImplementedError("num_grad_evals != 1")
-        if self.agent_name.lower() != "ddqn":
-            raise NotImplementedError("inner agent '%s': only DDQN has a fused kernel so far" % self.agent_name)
+        if self.agent_name.lower() not in ("ddqn", "ql"):
+            raise NotImplementedError("inner agent '%s' has no fused kernel yet" % self.agent_name)
 
         self.time_elapsed_list = [None] * self.num_workers
         self.score_list = [None] * self.num_workers
@@ -96,10 +96,10 @@ class GTN_Master(GTN_Base):
         self.w_lo, self.w_hi, self.w_per = shard_bounds(self.num_workers, self.rank, self.world)
         self.n_local = self.w_hi - self.w_lo
 
-        self.cfg = ddqn_cfg_from_config(config) if engine.name == "hip" else engine.cfg_from_config(config)
-        S, A, Hq = self.cfg.state_dim, self.cfg.num_actions, self.cfg.q_hidden
-        self.agent_bounds = torch.from_numpy(linear_init_bounds([(S, Hq), (Hq, A)])).to(dev)
-        self.inner = engine.make_inner(self.cfg, 3 * self.n_local) if self.n_local > 0 else None
+        self.task = select_task(config, engine, self.synthetic_env_orig)
+        self.cfg = self.task.cfg
+        self.agent_bounds = self.task.agent_bounds
+        self.inner = self.task.make_inner(3 * self.n_local) if self.n_local > 0 else None
         lw = np.arange(self.w_lo, self.w_hi)
         self.chain_worker = torch.from_numpy(np.repeat(lw, 3).astype(np.int32)).to(dev)
         self.chain_sign = torch.tensor([0.0, 1.0, -1.0] * self.n_local, dtype=torch.float32, device=dev)
@@ -136,14 +136,15 @@ class GTN_Master(GTN_Base):
         g.manual_seed((self.seed * 1000003 + it) % (2 ** 63 - 1))
         # GTN_Worker.get_random_noise (agents/GTN_worker.py:156-163): N(0,1) * noise_std, full population on every rank
         self.eps = torch.randn((pop, self.p_theta), generator=g, device=dev, dtype=torch.float32) * self.noise_std
-        agent_init = fresh_agent_init(self.agent_bounds, 3 * pop, g, dev)
+        agent_init = fresh_agent_init(self.agent_bounds, 3 * pop, g, dev) if self.task.needs_agent_init() else None
         local = torch.zeros((self.w_per, 4), dtype=torch.float64, device=dev)
         if self.n_local > 0:
             lw = np.arange(self.w_lo, self.w_hi)
             keys = chain_keys(self.seed, it, np.repeat(lw, 3), np.tile(np.arange(3), self.n_local))
             keys_t = torch.from_numpy(keys.view(np.int64)).to(dev)
-            chain_scores = self.engine.inner_scores(self.inner, self.theta, self.eps, self.chain_worker, self.chain_sign,
-                                                    agent_init[3 * self.w_lo:3 * self.w_hi].contiguous(), keys_t)
+            local_init = agent_init[3 * self.w_lo:3 * self.w_hi].contiguous() if agent_init is not None else None
+            chain_scores = self.task.scores(self.inner, self.theta, self.eps, self.chain_worker, self.chain_sign, keys_t,
+                                            local_init)
             local[:self.n_local] = self.engine.worker_best(chain_scores, self.n_local, self.mirrored_sampling)
         if self.world > 1:
             gathered = torch.empty((self.world * self.w_per, 4), dtype=torch.float64, device=dev)

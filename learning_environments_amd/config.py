@@ -50,3 +50,28 @@ def pick_grad_chunk(cfg):
             return chunk
         chunk += 1
     raise NotImplementedError("DDQN/SE shapes do not fit the fused kernel's LDS budget")
+
+
+def ql_cfg_from_config(config, tables, rng_mode=_lib.RNG_COUNTER, **overrides):
+    """QL agent + RewardEnv on a gridworld.  Fields read at reference agents/QL.py:13-27, agents/base_agent.py:9-26,
+    envs/reward_env.py:8-27, envs/env_factory.py:45-59."""
+    env_name = config["env_name"]
+    e = config["envs"][env_name]
+    a = config["agents"]["ql"]
+    if a["same_action_num"] != 1:
+        raise NotImplementedError("same_action_num != 1")
+
+    def val(v):
+        return float(v[1]) if isinstance(v, list) else v
+
+    cfg = _lib.QlCfg(n_states=tables["n_states"], n_actions=tables["n_actions"], start_state=tables["start_state"],
+                     max_steps=int(val(e["max_steps"])), rn_hidden=int(val(e["hidden_size"])), rn_layers=int(val(e["hidden_layer"])),
+                     rn_act=_lib.ACT[e["activation_fn"]], rn_prelu=0.25, reward_env_type=int(val(e["reward_env_type"])),
+                     train_episodes=int(a["train_episodes"]), test_episodes=int(a["test_episodes"]),
+                     init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]),
+                     batch_size=int(a["batch_size"]), rng_mode=int(rng_mode), solved_reward=float(val(e["solved_reward"])),
+                     alpha=float(a["alpha"]), gamma=float(a["gamma"]), eps_init=float(a["eps_init"]),
+                     eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]))
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return cfg

@@ -25,6 +25,27 @@ def cartpole_syn_env_ddqn(num_workers=64, max_iterations=200):
     })
 
 
+def cliff_reward_env_ql(num_workers=128, max_iterations=50):
+    """BASELINE config 4: Cliff gridworld RewardEnv (potential shaped, type 2) + tabular QL (values = the published
+    hyper-parameters of default_config_gridworld_reward_env.yaml: gtn :5-26, ql :28-43, Cliff :126-133)."""
+    return copy.deepcopy({
+        "env_name": "Cliff", "device": "cuda", "render_env": False,
+        "agents": {
+            "gtn": {"mode": "multi", "max_iterations": max_iterations, "num_threads_per_worker": 1,
+                    "num_workers": num_workers, "noise_std": 0.1, "step_size": 0.5, "nes_step_size": False,
+                    "mirrored_sampling": True, "num_grad_evals": 1, "grad_eval_type": "mean", "weight_decay": 0.0,
+                    "time_mult": 3, "time_max": 300, "time_sleep_master": 0.2, "time_sleep_worker": 2,
+                    "score_transform_type": 3, "quit_when_solved": True, "synthetic_env_type": 1, "unsolved_weight": 100,
+                    "agent_name": "QL"},
+            "ql": {"train_episodes": 100, "test_episodes": 1, "init_episodes": 0, "batch_size": 1, "alpha": 1.0, "gamma": 0.8,
+                   "eps_init": 0.01, "eps_min": 0.01, "eps_decay": 0.0, "rb_size": 1, "same_action_num": 1, "beta": 0.005,
+                   "print_rate": 100, "early_out_num": 10, "early_out_virtual_diff": 0.02},
+        },
+        "envs": {"Cliff": {"solved_reward": -20.0, "max_steps": 50, "activation_fn": "prelu", "hidden_size": 32,
+                           "hidden_layer": 1, "info_dim": 0, "reward_env_type": 2}},
+    })
+
+
 def fixed_work(config, train_episodes):
     """BASELINE.md §3 fixed-work variant: early-out disabled (solved_reward=+1e9) and a fixed number of train episodes,
     so both the GPU path and the CPU baseline do identical, data-independent amounts of work."""

@@ -35,24 +35,19 @@ __device__ __forceinline__ int ql_argmax_f32(const double *row, int n)
     return best;
 }
 
-__global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
+// phi(s) = reward_net(one_hot(s)) for all states with W = theta + sign*eps[worker] (reward_env.py:74-76,
+// GTN_worker.py:165-175), then RewardEnv._calc_reward for every (s,a) (reward_env.py:81-110) in fp32, left to right.
+// One wave; phi/shaped are LDS (or global) arrays of the calling wave.  Ends with a barrier.
+__device__ __forceinline__ void rn_phi_and_shaped(const lenv_ql_cfg &cfg, const float *theta, const float *eps_all,
+                                                  const int32_t *worker, const float *sign, const float *shaped_override,
+                                                  const int32_t *next_state, const double *reward, int64_t P, int64_t chain,
+                                                  int lane, float *phi, float *shaped, float *shaped_out, float *phi_out)
 {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    const lenv_ql_cfg &cfg = a.cfg;
-    const int lane = threadIdx.x;
-    const int64_t chain = blockIdx.x;
     const int N = cfg.n_states, A = cfg.n_actions, H = cfg.rn_hidden;
-    double *q = reinterpret_cast<double *>(lds_raw);                 // [N*A] fp64 Q-table
-    double *meter = q + N * A;                                       // [train_episodes]
-    double *rets = meter + cfg.train_episodes;                       // [test_episodes]
-    float *phi = reinterpret_cast<float *>(rets + cfg.test_episodes);    // [N]
-    float *shaped = phi + N;                                         // [N*A]
-
-    // ---- phi(s) = reward_net(one_hot(s)), W = theta + sign*eps[worker] (reward_env.py:74-76, GTN_worker.py:165-175) ----
     const int t = cfg.reward_env_type;
-    if (t != 0 && !a.shaped_override) {
-        const float sg = a.eps ? a.sign[chain] : 0.0f;
-        const float *th = a.theta, *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P : nullptr;
+    if (t != 0 && !shaped_override) {
+        const float sg = eps_all ? sign[chain] : 0.0f;
+        const float *th = theta, *e = eps_all ? eps_all + (int64_t)worker[chain] * P : nullptr;
         auto W = [&](int64_t i) { return e ? fma32(sg, e[i], th[i]) : th[i]; };
         const int64_t off_b0 = (int64_t)H * N, off_wo = off_b0 + H, off_bo = off_wo + H;
         for (int s = lane; s < N; s += 64) {
@@ -67,29 +62,55 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
     } else {
         for (int s = lane; s < N; s += 64) phi[s] = 0.0f;
     }
-    for (int i = lane; i < N * A; i += 64) q[i] = 0.0;                // q_table = [[0]*A for _ in range(N)]  QL.py:25
     __syncthreads();
-    // ---- RewardEnv._calc_reward for every (s,a) (reward_env.py:81-110), fp32 left to right ----
-    {
-        const float g32 = (float)cfg.gamma;
-        for (int i = lane; i < N * A; i += 64) {
-            float v;
-            if (a.shaped_override) v = a.shaped_override[i];
-            else {
-                const int s = i / A, s2 = a.next_state[i];
-                const float r32 = (float)a.reward[i];
-                switch (t) {
-                case 0: v = r32; break;
-                case 1: v = g32 * phi[s2] - phi[s]; break;
-                case 2: v = (r32 + g32 * phi[s2]) - phi[s]; break;
-                case 5: v = phi[s2]; break;
-                default: v = r32 + phi[s2]; break;
-                }
+    const float g32 = (float)cfg.gamma;
+    for (int i = lane; i < N * A; i += 64) {
+        float v;
+        if (shaped_override) v = shaped_override[i];
+        else {
+            const int s = i / A, s2 = next_state[i];
+            const float r32 = (float)reward[i];
+            switch (t) {
+            case 0: v = r32; break;
+            case 1: v = g32 * phi[s2] - phi[s]; break;
+            case 2: v = (r32 + g32 * phi[s2]) - phi[s]; break;
+            case 5: v = phi[s2]; break;
+            default: v = r32 + phi[s2]; break;
             }
-            shaped[i] = v;
-            if (a.out.shaped) a.out.shaped[chain * N * A + i] = v;
         }
+        shaped[i] = v;
+        if (shaped_out) shaped_out[i] = v;
     }
+    if (phi_out) for (int s = lane; s < N; s += 64) phi_out[s] = phi[s];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void rn_shape_kernel(const QlArgs a, float *phi_out, float *shaped_out)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int N = a.cfg.n_states, A = a.cfg.n_actions;
+    float *phi = reinterpret_cast<float *>(lds_raw), *shaped = phi + N;
+    const int64_t chain = blockIdx.x;
+    rn_phi_and_shaped(a.cfg, a.theta, a.eps, a.worker, a.sign, nullptr, a.next_state, a.reward, a.P, chain, threadIdx.x, phi,
+                      shaped, shaped_out + chain * N * A, phi_out ? phi_out + chain * N : nullptr);
+}
+
+__global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const lenv_ql_cfg &cfg = a.cfg;
+    const int lane = threadIdx.x;
+    const int64_t chain = blockIdx.x;
+    const int N = cfg.n_states, A = cfg.n_actions;
+    double *q = reinterpret_cast<double *>(lds_raw);                 // [N*A] fp64 Q-table
+    double *meter = q + N * A;                                       // [train_episodes]
+    double *rets = meter + cfg.train_episodes;                       // [test_episodes]
+    float *phi = reinterpret_cast<float *>(rets + cfg.test_episodes);    // [N]
+    float *shaped = phi + N;                                         // [N*A]
+
+    rn_phi_and_shaped(cfg, a.theta, a.eps, a.worker, a.sign, a.shaped_override, a.next_state, a.reward, a.P, chain, lane,
+                      phi, shaped, a.out.shaped ? a.out.shaped + chain * N * A : nullptr, nullptr);
+    for (int i = lane; i < N * A; i += 64) q[i] = 0.0;                // q_table = [[0]*A for _ in range(N)]  QL.py:25
     __syncthreads();
     if (lane != 0) return;
 
@@ -216,5 +237,32 @@ extern "C" int lenv_ql_rn_inner_loop(const lenv_ql_cfg *cfg, const float *theta,
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ql_rn_inner_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;
     hipLaunchKernelGGL(ql_rn_inner_kernel, dim3((unsigned)chains), dim3(64), lds_bytes, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}
+
+
+// RewardEnv shaping for a population (the `rn_shape_population` entry of SURVEY.md §8(b)): phi_out [chains,N] (optional),
+// shaped_out [chains,N*A].
+extern "C" int lenv_rn_shape_population(const lenv_ql_cfg *cfg, const float *theta, const float *eps, const int32_t *worker,
+                                        const float *sign, int64_t chains, const int32_t *next_state, const double *reward,
+                                        float *phi_out, float *shaped_out, void *stream)
+{
+    if (!cfg || !theta || !next_state || !reward || !shaped_out || chains < 0) return LENV_ERR_INVALID;
+    if (eps && (!worker || !sign)) return LENV_ERR_INVALID;
+    if (chains == 0) return LENV_OK;
+    const int t = cfg->reward_env_type;
+    if (!(t == 0 || t == 1 || t == 2 || t == 5 || t == 6)) return LENV_ERR_UNSUPPORTED;
+    if (cfg->rn_layers != 1 && t != 0) return LENV_ERR_UNSUPPORTED;
+    QlArgs a;
+    a.cfg = *cfg;
+    a.theta = theta; a.eps = eps; a.worker = worker; a.sign = sign; a.shaped_override = nullptr;
+    a.next_state = next_state; a.reward = reward; a.done = nullptr; a.rng_keys = nullptr;
+    a.tapes = lenv_tapes{}; a.out = lenv_ql_out{};
+    a.P = (int64_t)cfg->n_states * cfg->rn_hidden + 2 * (int64_t)cfg->rn_hidden + 1;
+    const size_t lds_bytes = sizeof(float) * ((size_t)cfg->n_states * (1 + cfg->n_actions)) + 16;
+    if (lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rn_shape_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return LENV_ERR_LAUNCH;
+    hipLaunchKernelGGL(rn_shape_kernel, dim3((unsigned)chains), dim3(64), lds_bytes, static_cast<hipStream_t>(stream), a, phi_out, shaped_out);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }

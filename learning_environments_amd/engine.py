@@ -196,6 +196,18 @@ class QlInnerLoop(object):
         return self.score
 
 
+def rn_shape_population(cfg, theta, eps, worker, sign, next_state, reward, chains=1):
+    """(phi [chains,N], shaped [chains,N,A]) of a population of perturbed reward networks on a grid MDP."""
+    dev = require_device()
+    N, A = cfg.n_states, cfg.n_actions
+    phi = torch.empty((chains, N), dtype=torch.float32, device=dev)
+    shaped = torch.empty((chains, N, A), dtype=torch.float32, device=dev)
+    rc = _lib.lib().lenv_rn_shape_population(C.byref(cfg), _ptr(theta), _ptr(eps), _ptr(worker), _ptr(sign), chains,
+                                             _ptr(next_state), _ptr(reward), _ptr(phi), _ptr(shaped), _stream())
+    _lib.check(rc, "lenv_rn_shape_population")
+    return phi, shaped
+
+
 def nes_worker_best(chain_scores, pop, mirrored=True):
     dev = require_device()
     _chk(chain_scores, torch.float64, "chain_scores")
@@ -229,6 +241,12 @@ class HipNesEngine(object):
 
     def make_inner(self, cfg, chains, **kw):
         return InnerLoop(cfg, chains, **kw)
+
+    def make_inner_ql(self, cfg, chains, tables, **kw):
+        return QlInnerLoop(cfg, chains, tables, **kw)
+
+    def inner_scores_ql(self, inner, theta, eps, worker, sign, rng_keys):
+        return inner.run(theta, eps, worker, sign, rng_keys=rng_keys)
 
     def inner_scores(self, inner, theta, eps, worker, sign, agent_init, rng_keys):
         return inner.run(theta, eps, worker, sign, agent_init, rng_keys=rng_keys)

@@ -1,6 +1,9 @@
 """EnvFactory (reference envs/env_factory.py:10-93): builds real / virtual envs from the YAML config dict."""
 from .env_wrapper import EnvWrapper
+from .grid_env import GridEnv
+from .gridworld import LAYOUTS
 from .real_env import DeviceRealEnv
+from .reward_env import RewardEnv
 from .virtual_env import VirtualEnv
 
 
@@ -26,7 +29,10 @@ class EnvFactory:
         return EnvWrapper(env=env)
 
     def generate_reward_env(self, print_str=''):
-        raise NotImplementedError("RewardEnv (synthetic_env_type 1) is the next row of the scope table (DESIGN.md)")
+        kwargs = self._get_default_parameters(virtual_env=True)
+        real_env = self._generate_real_env_with_kwargs(kwargs=kwargs, env_name=self.env_name)
+        reward_env = RewardEnv(real_env=real_env, kwargs=kwargs)
+        return EnvWrapper(env=reward_env)
 
     def _get_default_parameters(self, virtual_env):
         kwargs = {"env_name": self.env_name, "device": self.device}
@@ -44,7 +50,7 @@ class EnvFactory:
         return kwargs
 
     def _generate_real_env_with_kwargs(self, kwargs, env_name):
-        env = DeviceRealEnv(env_name)
+        env = GridEnv(env_name) if env_name in LAYOUTS else DeviceRealEnv(env_name)
         for key, value in kwargs.items():
             setattr(env, key, value)
         env._max_episode_steps = int(kwargs["max_steps"])

@@ -1,0 +1,195 @@
+"""GPU tests of the drop-in Python surface (EnvFactory / EnvWrapper / VirtualEnv / RewardEnv / GTN_Master / GTN_Worker):
+the same calls a user of the reference makes, checked against the reference's golden vectors and the oracle."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load_theta(envw, flat):
+    sd = envw.state_dict()
+    off, new = 0, {}
+    for k, v in sd.items():
+        prelu = k.endswith("weight") and (k[:-6] + "bias") not in sd
+        if prelu:
+            new[k] = v
+        else:
+            new[k] = torch.from_numpy(flat[off:off + v.numel()].reshape(tuple(v.shape)).copy())
+            off += v.numel()
+    assert off == flat.size
+    envw.load_state_dict(new)
+
+
+def test_envwrapper_step_virtual_env_matches_reference(golden):
+    from learning_environments_amd.configs import cartpole_syn_env_ddqn
+    from learning_environments_amd.envs.env_factory import EnvFactory
+    g = golden("g1_virtual_env_step")
+    venv = EnvFactory(cartpole_syn_env_ddqn()).generate_virtual_env()
+    _load_theta(venv, g["c00_theta"])
+    for i in range(g["c00_state"].shape[0]):
+        venv.env.state = torch.from_numpy(g["c00_state"][i].copy())
+        ns, r, d = venv.step(torch.tensor([float(g["c00_action"][i])]))
+        assert ns.device.type == "cpu" and ns.dtype == torch.float32 and tuple(ns.shape) == (4,) and tuple(r.shape) == (1,)
+        np.testing.assert_allclose(ns.numpy(), g["c00_next_state"][i], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(r.numpy(), g["c00_reward"][i:i + 1], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(d.numpy(), g["c00_done"][i:i + 1], rtol=2e-6, atol=2e-6)
+    # internal state advanced like the reference's VirtualEnv (virtual_env.py:52)
+    ns2, _, _ = venv.step(torch.tensor([1.0]))
+    assert tuple(ns2.shape) == (4,)
+    # batched states (histogram experiment, env_wrapper.py:33-40)
+    ns, r, d = venv.step(torch.from_numpy(g["c00_action"].astype(np.float32)), state=torch.from_numpy(g["c00_state"].copy()))
+    np.testing.assert_allclose(ns.numpy(), g["c00_next_state"], rtol=2e-6, atol=2e-6)
+    assert tuple(r.shape) == (12, 1)
+    # reset draws a real-env reset state
+    s0 = venv.reset()
+    assert tuple(s0.shape) == (4,) and float(s0.abs().max()) <= 0.05
+
+
+def test_real_env_step_matches_oracle():
+    from learning_environments_amd.configs import cartpole_syn_env_ddqn
+    from learning_environments_amd.envs.env_factory import EnvFactory
+    from oracle import oracle as orc
+    import ctypes as C
+    real = EnvFactory(cartpole_syn_env_ddqn()).generate_real_env()
+    s = real.reset().numpy().astype(np.float64)
+    st = (C.c_double * 4)(*real.env._alloc()["state"].cpu().tolist())
+    rew, dn = C.c_double(), C.c_int()
+    total = 0
+    for t in range(200):
+        a = t % 2
+        ns, r, d = real.step(torch.tensor([float(a)]))
+        orc.lib().orc_cartpole_step(st, a, C.byref(rew), C.byref(dn))
+        assert np.array_equal(ns.numpy(), np.array(list(st), np.float64).astype(np.float32))
+        assert float(r) == rew.value
+        total += 1
+        if float(d) > 0.5:
+            assert dn.value == 1 or total == 200
+            break
+    assert total < 200
+
+
+def test_reward_env_step_matches_reference(golden):
+    from learning_environments_amd.configs import cliff_reward_env_ql
+    from learning_environments_amd.envs.env_factory import EnvFactory
+    g = golden("g9_calc_score_cliff_a")
+    renv = EnvFactory(cliff_reward_env_ql()).generate_reward_env()
+    _load_theta(renv, g["theta"])
+    renv.set_agent_params(same_action_num=1, gamma=0.8)
+    table = renv.env.shaped_table().numpy()
+    np.testing.assert_allclose(table, g["shaped_ref"], rtol=2e-6, atol=2e-6)
+    # replay the reference's first training episode through EnvWrapper.step
+    renv.reset()
+    for k in range(int(g["episode_length_train"][0])):
+        ns, r, d = renv.step(torch.tensor([float(g["tr_action"][k])]))
+        assert int(ns.item()) == int(g["tr_next_state"][k]) and float(d) == float(g["tr_done"][k])
+        assert abs(float(r) - float(g["tr_reward"][k])) <= 2e-6
+
+
+def _master_pair(cfg, tmp_path, monkeypatch, hip_only=False):
+    from _oracle_engine import OracleNesEngine
+    from learning_environments_amd.agents.GTN import GTN_Master
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    hip = GTN_Master(cfg, bohb_id=0, seed=5)
+    return hip
+
+
+def test_gtn_master_run_ddqn_se_matches_oracle_engine(tmp_path, monkeypatch):
+    """Full NES generations through GTN_Master.run() on the GPU; theta after the update and every fitness equal a
+    CPU-oracle evaluation of the same population (same noise, same keys)."""
+    from learning_environments_amd.agents.nes_common import chain_keys
+    from learning_environments_amd.configs import cartpole_syn_env_ddqn, fixed_work
+    from oracle import oracle as orc
+    cfg = fixed_work(cartpole_syn_env_ddqn(num_workers=3, max_iterations=2), 2)
+    cfg["envs"]["CartPole-v0"]["max_steps"] = 15
+    cfg["agents"]["ddqn"]["test_episodes"] = 3
+    m = _master_pair(cfg, tmp_path, monkeypatch)
+    theta0 = m.theta.cpu().numpy().copy()
+    mean_score, mean_list, model_name = m.run()
+    assert len(mean_list) == 2 and isinstance(model_name, str) and len(m.score_list) == 3
+    # re-evaluate the LAST generation with the oracle from the theta it started from
+    it = 1
+    m2 = _master_pair(cfg, tmp_path, monkeypatch)
+    m2.step(0)
+    theta1 = m2.theta.cpu().numpy().copy()
+    gathered = m2.evaluate_population(it).cpu().numpy()
+    eps = m2.eps.cpu().numpy()
+    g = torch.Generator(device=m2.engine.device)
+    g.manual_seed((m2.seed * 1000003 + it) % (2 ** 63 - 1))
+    _ = torch.randn((3, m2.p_theta), generator=g, device=m2.engine.device)
+    from learning_environments_amd.agents.nes_common import fresh_agent_init
+    init = fresh_agent_init(m2.agent_bounds, 9, g, m2.engine.device).cpu().numpy()
+    ocfg = orc.ddqn_cfg_from_config(cfg, grad_chunk=m2.cfg.grad_chunk)
+    scores = orc.ddqn_se_population(ocfg, theta1, eps, init, seed=m2.seed, generation=it, threads=4)
+    best, sign = orc.worker_best(scores[1::3], scores[2::3], True)
+    assert np.array_equal(gathered[:, 0], best) and np.array_equal(gathered[:, 1], scores[0::3])
+    assert np.array_equal(gathered[:, 2], sign.astype(np.float64))
+    m2._transform_and_update(torch.from_numpy(gathered).cuda())
+    w = orc.score_transform(3, gathered[:, 0], gathered[:, 1])
+    assert np.array_equal(m2.theta.cpu().numpy(), orc.update_env(theta1, eps, sign, w, cfg["agents"]["gtn"]["step_size"]))
+    assert np.array_equal(m2.theta.cpu().numpy(), m.theta.cpu().numpy())      # run() == step(0); step(1)
+    assert not np.array_equal(theta0, theta1)
+    # the module parameters alias the flat theta: state_dict() shows the updated weights (checkpoint contract)
+    sd = m.synthetic_env_orig.state_dict()
+    assert np.array_equal(sd["env.state_net.0.weight"].cpu().numpy().reshape(-1), m.theta.cpu().numpy()[:83 * 6])
+
+
+def test_gtn_master_run_ql_cliff(tmp_path, monkeypatch):
+    from learning_environments_amd.configs import cliff_reward_env_ql
+    from learning_environments_amd.envs.gridworld import transition_tables
+    from oracle import oracle as orc
+    cfg = cliff_reward_env_ql(num_workers=6, max_iterations=2)
+    cfg["agents"]["gtn"]["quit_when_solved"] = False
+    m = _master_pair(cfg, tmp_path, monkeypatch)
+    theta0 = m.theta.cpu().numpy().copy()
+    gathered = m.evaluate_population(0).cpu().numpy()
+    eps = m.eps.cpu().numpy()
+    tables = transition_tables("Cliff")
+    ocfg = orc.ql_cfg_from_config(cfg, tables)
+    for p in range(6):
+        sc = []
+        for kind, sg in enumerate((0.0, 1.0, -1.0)):
+            w = (np.float32(sg) * eps[p] + theta0).astype(np.float32)
+            sc.append(orc.ql_rn_chain(ocfg, w, tables, rng_key=orc.chain_key(m.seed, 0, p, kind))["score"])
+        assert gathered[p, 1] == sc[0] and gathered[p, 0] == max(sc[1], sc[2])
+        assert gathered[p, 2] == (-1.0 if sc[2] > sc[1] else 1.0)
+    mean_score, mean_list, _ = m.run()
+    assert len(mean_list) == 2 and -102.0 <= mean_score <= -12.0
+    # RN models are saved whenever the mean improves (GTN_master.py:127-129)
+    saved = torch.load(os.path.join(m.model_dir, os.path.basename(m.model_name)), weights_only=False)
+    assert set(saved.keys()) == {"model", "config"} and "env.reward_net.1.weight" in saved["model"]
+
+
+def test_gtn_worker_file_protocol(tmp_path, monkeypatch):
+    """A GTN_Worker of this package served through the reference's sync-file protocol (GTN_base.py:19-29)."""
+    from learning_environments_amd.agents.GTN import GTN_Worker
+    from learning_environments_amd.configs import cartpole_syn_env_ddqn, fixed_work
+    from learning_environments_amd.envs.env_factory import EnvFactory
+    monkeypatch.chdir(tmp_path)
+    cfg = fixed_work(cartpole_syn_env_ddqn(num_workers=1, max_iterations=1), 2)
+    cfg["envs"]["CartPole-v0"]["max_steps"] = 10
+    cfg["agents"]["gtn"]["time_sleep_worker"] = 0.01
+    w = GTN_Worker(id=0, bohb_id=7, seed=3)
+    venv = EnvFactory(cfg).generate_virtual_env()
+    data = {"timeout": 600.0, "quit_flag": True, "config": cfg,
+            "synthetic_env_orig": {k: v.cpu() for k, v in venv.state_dict().items()}}
+    torch.save(data, w.get_input_file_name(0))
+    torch.save({}, w.get_input_check_file_name(0))
+    w.run()
+    res = torch.load(w.get_result_file_name(0), weights_only=False)
+    assert os.path.isfile(w.get_result_check_file_name(0)) and not os.path.isfile(w.get_input_file_name(0))
+    assert set(res.keys()) == {"eps", "synthetic_env", "time_elapsed", "score", "score_orig"}
+    assert set(res["eps"].keys()) == set(data["synthetic_env_orig"].keys())
+    assert 1.0 <= res["score"] <= 10.0 and 1.0 <= res["score_orig"] <= 10.0
+    # eps has the configured scale and the returned env is theta +/- eps (mirrored sampling)
+    e = res["eps"]["env.state_net.0.weight"]
+    assert 0.5 * cfg["agents"]["gtn"]["noise_std"] < float(e.std()) < 2 * cfg["agents"]["gtn"]["noise_std"]
+    d = res["synthetic_env"]["env.state_net.0.weight"] - data["synthetic_env_orig"]["env.state_net.0.weight"]
+    assert torch.allclose(d, e, atol=1e-6)
