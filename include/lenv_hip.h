@@ -62,6 +62,8 @@ typedef struct {
     int32_t early_out_num;
     int32_t grad_chunk;   /* samples per gradient micro-chunk; 0 = ceil(batch/16) */
     int32_t rng_mode;
+    int32_t agent_kind;   /* 0 = DDQN (agents/DDQN.py), 1 = DuelingDDQN (agents/DuelingDDQN.py) */
+    int32_t feature_dim;  /* DuelingDDQN: width of the feature vector / of the two head hidden layers */
     double solved_reward;
     double gamma, lr, tau;
     double eps_init, eps_min, eps_decay;
@@ -193,6 +195,19 @@ int lenv_real_env_reset(int32_t env_id, const uint64_t *keys, const int64_t *epi
                         float *obs, int32_t *elapsed, void *stream);
 int lenv_real_env_step(int32_t env_id, int32_t max_steps, int64_t n, const int32_t *action, double *state,
                        int32_t *elapsed, float *obs, float *reward, float *done, void *stream);
+
+/*
+ * Fused inner loop for DuelingDDQN agents on a synthetic environment (cfg.agent_kind == 1; agents/DuelingDDQN.py:59-110,
+ * models/actor_critic.py:94-122; BASELINE config 3).  Same contract and outputs as lenv_ddqn_se_inner_loop; the agent's
+ * parameters / Adam state / activations live in the workspace (lenv_dueling_se_workspace_bytes), agent_init is
+ * [chains, lenv_dueling_num_params(cfg)] in state-dict order feature_stream | value_stream | advantage_stream.
+ */
+size_t lenv_dueling_se_workspace_bytes(const lenv_ddqn_cfg *cfg /*HOST*/, int64_t chains);
+int64_t lenv_dueling_num_params(const lenv_ddqn_cfg *cfg /*HOST*/);
+int lenv_dueling_se_inner_loop(const lenv_ddqn_cfg *cfg /*HOST*/, const float *theta, const float *eps,
+                               const int32_t *worker, const float *sign, const float *agent_init,
+                               const uint64_t *rng_keys, const lenv_tapes *tapes /*HOST, may be NULL*/, int64_t chains,
+                               void *workspace, size_t workspace_bytes, const lenv_inner_out *out /*HOST*/, void *stream);
 
 /* Counter-RNG key of a chain (same function as the oracle's): kind 0 = theta, 1 = theta+eps, 2 = theta-eps. HOST. */
 uint64_t lenv_chain_key(uint64_t seed, uint64_t generation, uint64_t worker, uint64_t kind);

@@ -30,6 +30,7 @@ class DdqnCfg(C.Structure):
                 ("batch_size", C.c_int32), ("rb_size", C.c_int32),
                 ("train_episodes", C.c_int32), ("test_episodes", C.c_int32), ("init_episodes", C.c_int32),
                 ("early_out_num", C.c_int32), ("grad_chunk", C.c_int32), ("rng_mode", C.c_int32),
+                ("agent_kind", C.c_int32), ("feature_dim", C.c_int32),
                 ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
                 ("eps_init", C.c_double), ("eps_min", C.c_double), ("eps_decay", C.c_double),
                 ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
@@ -68,7 +69,8 @@ class QlOut(C.Structure):
 
 EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv_se_step_population",
            "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_lds_bytes", "lenv_ddqn_se_inner_loop",
-           "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population"]
+           "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population", "lenv_dueling_se_workspace_bytes",
+           "lenv_dueling_num_params", "lenv_dueling_se_inner_loop"]
 
 
 def build(force=False):
@@ -117,6 +119,12 @@ def lib():
         L.lenv_ql_rn_inner_loop.restype = C.c_int
         L.lenv_ql_rn_inner_loop.argtypes = [C.POINTER(QlCfg), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(Tapes), C.c_int64,
                                             C.POINTER(QlOut), vp]
+        L.lenv_dueling_se_workspace_bytes.restype = C.c_size_t
+        L.lenv_dueling_se_workspace_bytes.argtypes = [C.POINTER(DdqnCfg), C.c_int64]
+        L.lenv_dueling_num_params.restype = C.c_int64
+        L.lenv_dueling_num_params.argtypes = [C.POINTER(DdqnCfg)]
+        L.lenv_dueling_se_inner_loop.restype = C.c_int
+        L.lenv_dueling_se_inner_loop.argtypes = L.lenv_ddqn_se_inner_loop.argtypes
         L.lenv_rn_shape_population.restype = C.c_int
         L.lenv_rn_shape_population.argtypes = [C.POINTER(QlCfg), vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
         L.lenv_nes_worker_best.restype = C.c_int

@@ -802,6 +802,7 @@ static int inner_layout(const lenv_ddqn_cfg *cfg, InnerArgs &a)
 static int inner_check(const lenv_ddqn_cfg *cfg)
 {
     const int S = cfg->state_dim, A = cfg->num_actions, Hq = cfg->q_hidden, Hse = cfg->se_hidden, B = cfg->batch_size;
+    if (cfg->agent_kind != 0) return LENV_ERR_INVALID;                             // DuelingDDQN: lenv_dueling_se_inner_loop
     if (cfg->q_layers != 1 || cfg->se_layers != 1) return LENV_ERR_UNSUPPORTED;   // hidden_layer > 1: next round
     if (B < 1 || B > MAX_B || Hq < 1 || Hse < 1 || cfg->test_episodes < 1 || cfg->train_episodes < 0 || cfg->max_steps < 1)
         return LENV_ERR_UNSUPPORTED;

@@ -1,0 +1,610 @@
+// dueling_se_inner_loop.hip -- fused NES inner loop for DuelingDDQN agents on a synthetic environment (BASELINE config 3:
+// Acrobot-v1 SE + DuelingDDQN), one 512-thread workgroup per chain.
+//
+// Replaces GTN_Worker.calc_score (agents/GTN_worker.py:187-221) with
+//   DuelingDDQN.learn / select_*_action        agents/DuelingDDQN.py:59-110
+//   Critic_DuelingDQN                          models/actor_critic.py:94-122  (q = V + (Adv - Adv.mean()), GLOBAL mean)
+//   BaseAgent.train / test, ReplayBuffer       agents/base_agent.py:64-227, utils.py:9-72
+//   EnvWrapper.step -> VirtualEnv.step         envs/env_wrapper.py:16-47, envs/virtual_env.py:43-54
+//
+// Unlike the DDQN kernel, the agent (67 460 parameters at the config-3 shapes, x5 with target/Adam/grad) does not fit
+// LDS: parameters, Adam state and minibatch activations live in a per-chain arena in HBM (L2/MALL-resident while the
+// chain runs) and every layer is a workgroup-cooperative, LDS-tiled GEMM  C[i][j] = sum_r P[i][r]*Q[j][r]  whose
+// reduction index r runs in ascending order inside one thread (32 accumulators per thread, K-blocked through LDS) --
+// i.e. the canonical sequential fmaf chain of oracle/lenv_oracle.h, so results are bit-identical to the oracle.
+// The same routine serves forward (r = input feature), input-gradient (r = output unit) and weight-gradient (r = sample)
+// products by changing strides.  This is the configuration where HBM traffic is real: ~5 MB of weight/Adam streaming
+// per learn step and chain.
+#include "lenv_device.cuh"
+
+namespace lenv {
+
+constexpr int DNT = 512;          // threads per chain (8 waves)
+constexpr int GT_I = 128, GT_J = 128, GT_RB = 64, GT_LD = 132;   // GEMM tile: 128x128 outputs, 64-deep stages, padded LDS rows
+constexpr int D_MAXL = 2;         // feature-stream hidden layers supported
+constexpr int D_MAXW = 128;       // max layer width (hidden_size / feature_dim)
+
+struct DuelArgs {
+    lenv_ddqn_cfg cfg;
+    const float *theta, *eps; const int32_t *worker; const float *sign;
+    const float *agent_init; const uint64_t *rng_keys;
+    lenv_tapes tapes;
+    float *arena; int64_t arena_stride;       // per-chain arena (floats)
+    lenv_inner_out out;
+    int64_t rb_cap; int RS;
+    int P, P_se, se_net_size[3];
+    // parameter offsets inside one parameter vector
+    int oWf[D_MAXL + 1], obf[D_MAXL + 1];     // feature stream: hidden layers 0..L-1, then the output Linear (index L)
+    int oWv1, obv1, oWv2, obv2, oWa1, oba1, oWa2, oba2;
+    // arena offsets (floats)
+    int64_t a_online, a_target, a_m, a_v, a_grad, a_replay, a_xs, a_xs2, a_act[D_MAXL], a_feat, a_v1, a_a1,
+        a_t[4], a_dbuf[5], a_meter;
+};
+
+// ---- workgroup-cooperative GEMM: C[i][j] = epi(i, j, sum_{r<R} P[i*sPi + r*sPr] * Q[j*sQj + r*sQr]), r ascending -------
+template <class Epi>
+__device__ __forceinline__ void wg_gemm(const float *P, int sPi, int sPr, const float *Q, int sQj, int sQr, int I, int J, int R,
+                                        float *Ps, float *Qs, Epi epi)
+{
+    const int tid = threadIdx.x;
+    const int ti = tid & 31, tj = tid >> 5;              // 32 x 16 thread grid, 4 x 8 outputs each
+    float acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = 0.0f;
+    const bool active = 4 * ti < I && 8 * tj < J;
+    for (int r0 = 0; r0 < R; r0 += GT_RB) {
+        const int rb = R - r0 < GT_RB ? R - r0 : GT_RB;
+        __syncthreads();                                   // previous stage fully consumed
+        // stage P -> Ps[r][i], Q -> Qs[r][j] (zero padded); the unit-stride index runs fastest across threads
+        if (sPr == 1) { for (int e = tid; e < GT_I * rb; e += DNT) { int i = e / rb, r = e - i * rb; Ps[r * GT_LD + i] = i < I ? P[(int64_t)i * sPi + (r0 + r)] : 0.0f; } }
+        else { for (int e = tid; e < GT_I * rb; e += DNT) { int r = e >> 7, i = e & 127; Ps[r * GT_LD + i] = i < I ? P[(int64_t)i * sPi + (int64_t)(r0 + r) * sPr] : 0.0f; } }
+        if (sQr == 1) { for (int e = tid; e < GT_J * rb; e += DNT) { int j = e / rb, r = e - j * rb; Qs[r * GT_LD + j] = j < J ? Q[(int64_t)j * sQj + (r0 + r)] : 0.0f; } }
+        else { for (int e = tid; e < GT_J * rb; e += DNT) { int r = e >> 7, j = e & 127; Qs[r * GT_LD + j] = j < J ? Q[(int64_t)j * sQj + (int64_t)(r0 + r) * sQr] : 0.0f; } }
+        __syncthreads();
+        if (active) {
+            for (int r = 0; r < rb; ++r) {
+                const float4 p4 = *reinterpret_cast<const float4 *>(Ps + r * GT_LD + 4 * ti);
+                const float4 q0 = *reinterpret_cast<const float4 *>(Qs + r * GT_LD + 8 * tj);
+                const float4 q1 = *reinterpret_cast<const float4 *>(Qs + r * GT_LD + 8 * tj + 4);
+                const float pv[4] = { p4.x, p4.y, p4.z, p4.w };
+                const float qv[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) acc[a][b] = fma32(pv[a], qv[b], acc[a][b]);
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int i = 4 * ti + a, j = 8 * tj + b;
+                if (i < I && j < J) epi(i, j, acc[a][b]);
+            }
+    }
+}
+
+__global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
+{
+    extern __shared__ __align__(16) float lds[];
+    const lenv_ddqn_cfg &cfg = a.cfg;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t chain = blockIdx.x;
+    const int S = cfg.state_dim, A = cfg.num_actions, K = S + A, H = cfg.q_hidden, F = cfg.feature_dim, L = cfg.q_layers;
+    const int B = cfg.batch_size, Hse = cfg.se_hidden, RS = a.RS, P = a.P, T = cfg.test_episodes;
+    const int act_id = cfg.q_act;
+    const float prelu = cfg.q_prelu;
+
+    // ---- LDS carve-up ----
+    float *Ps = lds, *Qs = Ps + GT_RB * GT_LD;
+    float *se_w0T = Qs + GT_RB * GT_LD;                  // [3][K][Hse]
+    float *se_b0 = se_w0T + 3 * K * Hse;                  // [3][Hse]
+    float *se_wout = se_b0 + 3 * Hse;                     // [S+2][Hse]
+    float *se_bout = se_wout + (S + 2) * Hse;             // [S+2] (padded to 16)
+    float *se_h = se_bout + 16;                           // [3][Hse]
+    float *qv = se_h + 3 * Hse;                           // [3][B][A]   q(s), q_online(s'), q_target(s')
+    float *Vb = qv + 3 * B * A;                           // [B]
+    float *Advb = Vb + B;                                 // [B][A]
+    float *dq = Advb + B * A;                             // [B]
+    float *dAdv = dq + B;                                 // [B][A]
+    float *misc = dAdv + B * A;                           // [64] control words
+    double *dstate = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(misc + 64) + 7) & ~(uintptr_t)7);   // [T][4] real-env states (tests)
+    double *ret = dstate + 4 * T;                         // [T]
+    float *ep_rew = reinterpret_cast<float *>(ret + T);   // [T]
+    int *alive = reinterpret_cast<int *>(ep_rew + T);     // [T]
+    float *state = reinterpret_cast<float *>(alive + T);  // [8] current SE state
+    float *newrow = state + 8;                            // [16]
+    volatile float *ctrl = misc;
+    volatile int *ictrl = reinterpret_cast<volatile int *>(misc + 32);
+
+    float *arena = a.arena + chain * a.arena_stride;
+    float *online = arena + a.a_online, *target = arena + a.a_target, *adam_m = arena + a.a_m, *adam_v = arena + a.a_v;
+    float *grad = arena + a.a_grad, *rb = arena + a.a_replay, *xs = arena + a.a_xs, *xs2 = arena + a.a_xs2;
+    float *feat_s = arena + a.a_feat, *v1_s = arena + a.a_v1, *a1_s = arena + a.a_a1;
+    double *meter = reinterpret_cast<double *>(arena + a.a_meter);
+
+    // ---- stage the perturbed SE (GTN_worker.py:165-175) ----
+    {
+        const float sg = a.eps ? a.sign[chain] : 0.0f;
+        const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P_se : nullptr;
+        for (int i = tid; i < a.P_se; i += DNT) {
+            const float w = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
+            int net = 0, r = i;
+            if (r >= a.se_net_size[0]) { r -= a.se_net_size[0]; net = 1; if (r >= a.se_net_size[1]) { r -= a.se_net_size[1]; net = 2; } }
+            const int orow = net == 0 ? 0 : (net == 1 ? S : S + 1);
+            if (r < Hse * K) { int j = r / K, k = r - j * K; se_w0T[(net * K + k) * Hse + j] = w; }
+            else if ((r -= Hse * K) < Hse) se_b0[net * Hse + r] = w;
+            else {
+                r -= Hse;
+                const int n_out = net == 0 ? S : 1;
+                if (r < n_out * Hse) { int o = r / Hse, j = r - o * Hse; se_wout[(orow + o) * Hse + j] = w; }
+                else se_bout[orow + (r - n_out * Hse)] = w;
+            }
+        }
+    }
+    // ---- fresh agent: online = target = agent_init, Adam state 0 (DuelingDDQN.py:31-36) ----
+    for (int p = tid; p < P; p += DNT) {
+        const float w = a.agent_init[chain * P + p];
+        online[p] = w; target[p] = w; adam_m[p] = 0.0f; adam_v[p] = 0.0f;
+    }
+    if (tid < 64) misc[tid] = 0.0f;
+    __syncthreads();
+
+    const uint64_t key = a.rng_keys ? a.rng_keys[chain] : 0;
+    const bool tape = cfg.rng_mode == LENV_RNG_TAPE;
+    const int env_id = cfg.env_id;
+    const double reset_lim = env_id == LENV_ENV_CARTPOLE ? 0.05 : 0.1;
+    int status = 0;
+    int train_steps = 0, n_act = 0, learn_it = 0, n_test_ep = 0, test_steps = 0, episodes_run = 0;
+    double eps_g = cfg.eps_init, b1pow = 1.0, b2pow = 1.0;
+    const int rb_cap = (int)a.rb_cap;
+
+    auto obs_of = [&](const double *st, float *obs) {
+        if (env_id == LENV_ENV_CARTPOLE) { for (int i = 0; i < 4; ++i) obs[i] = (float)st[i]; }
+        else {
+            obs[0] = (float)det_cos(st[0]); obs[1] = (float)det_sin(st[0]); obs[2] = (float)det_cos(st[1]); obs[3] = (float)det_sin(st[1]);
+            obs[4] = (float)st[2]; obs[5] = (float)st[3];
+        }
+    };
+
+    // ---- Critic_DuelingDQN forward of I rows X[I][S] with parameters `par` (actor_critic.py:117-122) -------------------
+    // Intermediate activations go to the given buffers (stored ones are kept for the backward pass).
+    // Results: Vb[I], Advb[I][A] and q_out[I][A] in LDS.  global_mean: mean over all I*A advantages (learn) or per row.
+    auto forward = [&](const float *par, const float *X, int I, float *const *hid, float *featb, float *v1b, float *a1b,
+                       float *q_out, bool global_mean) {
+        const float *in = X;
+        int n_in = S;
+        for (int l = 0; l < L; ++l) {
+            const float *W = par + a.oWf[l], *bb = par + a.obf[l];
+            float *o = hid[l];
+            wg_gemm(in, n_in, 1, W, n_in, 1, I, H, n_in, Ps, Qs,
+                    [&](int i, int j, float acc) { o[i * H + j] = act_fwd(act_id, prelu, acc + bb[j]); });
+            __syncthreads();
+            in = o; n_in = H;
+        }
+        {   // feature_stream's last Linear: no activation (build_nn_from_config ends with a Linear)
+            const float *W = par + a.oWf[L], *bb = par + a.obf[L];
+            wg_gemm(in, n_in, 1, W, n_in, 1, I, F, n_in, Ps, Qs, [&](int i, int j, float acc) { featb[i * F + j] = acc + bb[j]; });
+            __syncthreads();
+        }
+        {
+            const float *W = par + a.oWv1, *bb = par + a.obv1;
+            wg_gemm(featb, F, 1, W, F, 1, I, F, F, Ps, Qs, [&](int i, int j, float acc) { v1b[i * F + j] = act_fwd(act_id, prelu, acc + bb[j]); });
+            const float *W2 = par + a.oWa1, *bb2 = par + a.oba1;
+            wg_gemm(featb, F, 1, W2, F, 1, I, F, F, Ps, Qs, [&](int i, int j, float acc) { a1b[i * F + j] = act_fwd(act_id, prelu, acc + bb2[j]); });
+            __syncthreads();
+        }
+        {
+            const float *W = par + a.oWv2, *bb = par + a.obv2;
+            wg_gemm(v1b, F, 1, W, F, 1, I, 1, F, Ps, Qs, [&](int i, int j, float acc) { Vb[i] = acc + bb[0]; });
+            const float *W2 = par + a.oWa2, *bb2 = par + a.oba2;
+            wg_gemm(a1b, F, 1, W2, F, 1, I, A, F, Ps, Qs, [&](int i, int j, float acc) { Advb[i * A + j] = acc + bb2[j]; });
+            __syncthreads();
+        }
+        if (global_mean) {
+            if (tid == 0) {
+                float sum = 0.0f;
+                for (int e = 0; e < I * A; ++e) sum = sum + Advb[e];
+                ctrl[8] = sum / (float)(I * A);
+            }
+            __syncthreads();
+            const float mean = ctrl[8];
+            for (int e = tid; e < I * A; e += DNT) q_out[e] = Vb[e / A] + (Advb[e] - mean);
+        } else {
+            for (int i = tid; i < I; i += DNT) {
+                float sum = 0.0f;
+                for (int aa = 0; aa < A; ++aa) sum = sum + Advb[i * A + aa];
+                const float mean = sum / (float)A;
+                for (int aa = 0; aa < A; ++aa) q_out[i * A + aa] = Vb[i] + (Advb[i * A + aa] - mean);
+            }
+        }
+        __syncthreads();
+    };
+
+    float *hid_s[D_MAXL], *hid_t[D_MAXL];
+    for (int l = 0; l < D_MAXL; ++l) { hid_s[l] = arena + a.a_act[l]; hid_t[l] = arena + a.a_t[l]; }
+    float *feat_t = arena + a.a_t[2], *v1_t = arena + a.a_t[3], *a1_t = arena + a.a_dbuf[0];   // temporaries of non-stored passes
+
+    // ---- real-env test phase: the T episodes advance in lock-step as one batch (weights are streamed once per step) ----
+    auto test_phase = [&]() {
+        if (tid < T) {
+            double st[4];
+            const int64_t row = (int64_t)n_test_ep + tid;
+            if (tape) {
+                if (row >= a.tapes.test_reset_stride) { status = -5; for (int i = 0; i < 4; ++i) st[i] = 0.0; }
+                else for (int i = 0; i < 4; ++i) st[i] = a.tapes.test_reset[(chain * a.tapes.test_reset_stride + row) * 4 + i];
+            } else {
+                for (int i = 0; i < 4; ++i) st[i] = -reset_lim + (2 * reset_lim) * u64_to_unit(rng_u64(key, STREAM_TEST_RESET, (uint64_t)(row * 4 + i)));
+            }
+            for (int i = 0; i < 4; ++i) dstate[tid * 4 + i] = st[i];
+            ep_rew[tid] = 0.0f; alive[tid] = 1;
+        }
+        if (tid == 0) ictrl[0] = 0;
+        __syncthreads();
+        float *xt = xs2;                                   // [T][S] observation batch (xs2 is free outside learn)
+        for (int t = 0; t < cfg.max_steps; ++t) {
+            if (tid < T) { float obs[8]; obs_of(dstate + tid * 4, obs); for (int i = 0; i < S; ++i) xt[tid * S + i] = obs[i]; }
+            __syncthreads();
+            forward(online, xt, T, hid_t, feat_t, v1_t, a1_t, qv, false);
+            if (tid < T && alive[tid]) {
+                int am = 0; float best = qv[tid * A];
+                for (int aa = 1; aa < A; ++aa) { const float v = qv[tid * A + aa]; if (v > best) { best = v; am = aa; } }
+                double st[4] = { dstate[tid * 4], dstate[tid * 4 + 1], dstate[tid * 4 + 2], dstate[tid * 4 + 3] };
+                double rew; int dn;
+                if (env_id == LENV_ENV_CARTPOLE) cartpole_step(st, am, rew, dn); else acrobot_step(st, am, rew, dn);
+                for (int i = 0; i < 4; ++i) dstate[tid * 4 + i] = st[i];
+                ep_rew[tid] = ep_rew[tid] + (float)rew;
+                atomicAdd(const_cast<int *>(&ictrl[0]), 1);
+                if (dn) alive[tid] = 0;
+            }
+            __syncthreads();
+            int any = 0;
+            for (int e = 0; e < T; ++e) any |= alive[e];
+            if (!any) break;
+        }
+        if (tid < T) ret[tid] = (double)ep_rew[tid];
+        n_test_ep += T;
+        __syncthreads();
+        test_steps += ictrl[0];
+        __syncthreads();
+    };
+
+    for (int episode = 0; episode < cfg.train_episodes; ++episode) {
+        if (episode == 0) eps_g = cfg.eps_init;            // DuelingDDQN.update_parameters_per_episode (:112-117)
+        else { eps_g *= cfg.eps_decay; if (eps_g < cfg.eps_min) eps_g = cfg.eps_min; }
+        const bool learning = episode >= cfg.init_episodes;
+        if (tid == 0) {                                    // env.reset(): VirtualEnv.reset (virtual_env.py:35-41)
+            double st0[4];
+            if (tape) {
+                if (episode >= a.tapes.train_reset_stride) { status = -5; for (int i = 0; i < 4; ++i) st0[i] = 0.0; }
+                else for (int i = 0; i < 4; ++i) st0[i] = a.tapes.train_reset[(chain * a.tapes.train_reset_stride + episode) * 4 + i];
+            } else {
+                for (int i = 0; i < 4; ++i) st0[i] = -reset_lim + (2 * reset_lim) * u64_to_unit(rng_u64(key, STREAM_TRAIN_RESET, (uint64_t)(episode * 4 + i)));
+            }
+            float obs[8];
+            obs_of(st0, obs);
+            for (int i = 0; i < S; ++i) state[i] = obs[i];
+        }
+        __syncthreads();
+        int ep_len = 0;
+        for (int t = 0; t < cfg.max_steps; ++t) {
+            const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
+            const int new_pos = train_steps % rb_cap;
+            // ---- select_train_action (DuelingDDQN.py:96-103) ----
+            if (tid == 0) {
+                double u;
+                if (tape) { if (train_steps >= a.tapes.eps_uniform_stride) { status = -2; u = 1.0; } else u = a.tapes.eps_uniform[chain * a.tapes.eps_uniform_stride + train_steps]; }
+                else u = u64_to_unit(rng_u64(key, STREAM_EPS, (uint64_t)train_steps));
+                int explored = u < eps_g, action = -1;
+                if (explored) {
+                    if (tape) { if (n_act >= a.tapes.rand_action_stride) { status = -3; action = 0; } else action = a.tapes.rand_action[chain * a.tapes.rand_action_stride + n_act]; }
+                    else action = (int)u64_to_below(rng_u64(key, STREAM_ACTION, (uint64_t)n_act), (uint32_t)A);
+                }
+                ictrl[1] = explored; ictrl[2] = action;
+            }
+            __syncthreads();
+            const int explored = ictrl[1];
+            if (explored) ++n_act;
+            if (!explored) {
+                for (int i = tid; i < S; i += DNT) xs2[i] = state[i];
+                __syncthreads();
+                forward(online, xs2, 1, hid_t, feat_t, v1_t, a1_t, qv, false);
+                if (tid == 0) {
+                    int am = 0; float best = qv[0];
+                    for (int aa = 1; aa < A; ++aa) if (qv[aa] > best) { best = qv[aa]; am = aa; }
+                    ictrl[2] = am;
+                }
+                __syncthreads();
+            }
+            const int action = ictrl[2];
+            // ---- EnvWrapper.step -> VirtualEnv.step: x = [onehot(action), state] ----
+            for (int uu = tid; uu < 3 * Hse; uu += DNT) {
+                const int net = uu / Hse, j = uu - net * Hse;
+                const float *w = se_w0T + net * K * Hse + j;
+                float z = 0.0f;
+                for (int k = 0; k < K; ++k) z = fma32(k < A ? (k == action ? 1.0f : 0.0f) : state[k - A], w[k * Hse], z);
+                z = z + se_b0[uu];
+                se_h[uu] = act_fwd(cfg.se_act, cfg.se_prelu, z);
+            }
+            __syncthreads();
+            if (tid < S + 2) {
+                const int net = tid < S ? 0 : (tid == S ? 1 : 2);
+                const float *h = se_h + net * Hse, *w = se_wout + tid * Hse;
+                float acc = 0.0f;
+                for (int j = 0; j < Hse; ++j) acc = fma32(h[j], w[j], acc);
+                acc = acc + se_bout[tid];
+                // ReplayBuffer.add (utils.py:24-32): row = [s, a, s', r, done]
+                if (tid < S) newrow[S + 1 + tid] = acc; else newrow[2 * S + 1 + (tid - S)] = acc;
+            }
+            if (tid >= 64 && tid < 64 + S) newrow[tid - 64] = state[tid - 64];
+            if (tid == 128) newrow[S] = (float)action;
+            __syncthreads();
+            if (tid < 2 * S + 3) rb[(int64_t)new_pos * RS + tid] = newrow[tid];
+            if (tid == 0 && a.out.trace_action && train_steps < a.out.trace_cap) {
+                const int64_t k = chain * a.out.trace_cap + train_steps;
+                a.out.trace_action[k] = action | (explored << 16);
+                for (int i = 0; i < S; ++i) { a.out.trace_state[k * S + i] = newrow[i]; a.out.trace_next_state[k * S + i] = newrow[S + 1 + i]; }
+                a.out.trace_reward_done[k * 2] = newrow[2 * S + 1]; a.out.trace_reward_done[k * 2 + 1] = newrow[2 * S + 2];
+            }
+            const float done_now = newrow[2 * S + 2];
+            __syncthreads();
+            if (tid < S) state[tid] = newrow[S + 1 + tid];
+            ++ep_len; ++train_steps;
+            __syncthreads();
+
+            if (learning) {
+                // ================= DuelingDDQN.learn (DuelingDDQN.py:59-94) =================
+                // ReplayBuffer.sample: gather rows; keep a, r, done in LDS (dAdv/dq reuse below), states to xs / xs2
+                for (int b = tid; b < B; b += DNT) {
+                    const int64_t n = (int64_t)learn_it * B + b;
+                    int idx;
+                    if (tape) {
+                        if (n >= a.tapes.replay_idx_stride) { status = -4; idx = 0; } else idx = a.tapes.replay_idx[chain * a.tapes.replay_idx_stride + n];
+                        if (idx < 0 || idx >= size_after) { status = -6; idx = 0; }
+                    } else idx = (int)u64_to_below(rng_u64(key, STREAM_REPLAY, (uint64_t)n), (uint32_t)size_after);
+                    const float *row = rb + (int64_t)idx * RS;
+                    for (int i = 0; i < S; ++i) { xs[b * S + i] = row[i]; xs2[b * S + i] = row[S + 1 + i]; }
+                    dAdv[b * A + 0] = row[S];               // stash (a, r, done) in dAdv/dq until the TD step
+                    dAdv[b * A + 1] = row[2 * S + 1];
+                    dq[b] = row[2 * S + 2];
+                }
+                __syncthreads();
+                forward(online, xs2, B, hid_t, feat_t, v1_t, a1_t, qv + B * A, true);        // next_q_values (online)
+                forward(target, xs2, B, hid_t, feat_t, v1_t, a1_t, qv + 2 * B * A, true);    // next_q_values_target
+                forward(online, xs, B, hid_s, feat_s, v1_s, a1_s, qv, true);                  // q_values, activations kept
+                // TD error (DuelingDDQN.py:80-85) and the gradient of the loss w.r.t. V / Adv
+                if (tid == 0) {
+                    const float g32 = (float)cfg.gamma, norm = (float)(2.0 / (double)B);
+                    float s_dq = 0.0f;
+                    for (int b = 0; b < B; ++b) {
+                        const int ab = (int)dAdv[b * A + 0];
+                        const float r = dAdv[b * A + 1], d = dq[b];
+                        int am = 0; float best = qv[(B + b) * A];
+                        for (int aa = 1; aa < A; ++aa) { const float v = qv[(B + b) * A + aa]; if (v > best) { best = v; am = aa; } }
+                        const float t1 = g32 * qv[(2 * B + b) * A + am];
+                        const float t2 = 1.0f - d;
+                        const float y = r + t1 * t2;
+                        const float g = norm * (qv[b * A + ab] - y);
+                        dq[b] = g;
+                        Vb[b] = (float)ab;                  // keep the action index
+                        s_dq = s_dq + g;
+                    }
+                    ctrl[9] = (-s_dq) / (float)(B * A);     // backward of `- advantages.mean()`
+                    b1pow *= cfg.adam_beta1; b2pow *= cfg.adam_beta2;
+                    ctrl[10] = (float)(-(cfg.lr / (1.0 - b1pow)));
+                    ctrl[11] = (float)__builtin_sqrt(1.0 - b2pow);
+                }
+                __syncthreads();
+                {
+                    const float mean_grad = ctrl[9];
+                    for (int e = tid; e < B * A; e += DNT) { const int b = e / A, aa = e - b * A; dAdv[e] = (aa == (int)Vb[b] ? dq[b] : 0.0f) + mean_grad; }
+                }
+                __syncthreads();
+                float *d_a1 = arena + a.a_dbuf[0], *d_v1 = arena + a.a_dbuf[1], *d_feat = arena + a.a_dbuf[2];
+                float *dh[2] = { arena + a.a_dbuf[3], arena + a.a_dbuf[4] };
+                // ---- heads, output layers: dW = dOut^T . hidden (reduction over the batch), db = column sums ----
+                wg_gemm(dAdv, 1, A, a1_s, 1, F, A, F, B, Ps, Qs, [&](int i, int j, float acc) { grad[a.oWa2 + i * F + j] = acc; });
+                wg_gemm(dq, 1, 1, v1_s, 1, F, 1, F, B, Ps, Qs, [&](int i, int j, float acc) { grad[a.oWv2 + j] = acc; });
+                if (tid < A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dAdv[b * A + tid]; grad[a.oba2 + tid] = s; }
+                if (tid == A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dq[b]; grad[a.obv2] = s; }
+                // d hidden of the heads: act'(h) * sum_o dOut[o] * W2[o][k]  (reduction over the few outputs)
+                for (int e = tid; e < B * F; e += DNT) {
+                    const int b = e / F, k = e - b * F;
+                    float acc = 0.0f;
+                    for (int aa = 0; aa < A; ++aa) acc = fma32(dAdv[b * A + aa], online[a.oWa2 + aa * F + k], acc);
+                    d_a1[e] = act_bwd(act_id, prelu, a1_s[e], acc);
+                    d_v1[e] = act_bwd(act_id, prelu, v1_s[e], fma32(dq[b], online[a.oWv2 + k], 0.0f));
+                }
+                __syncthreads();
+                // heads, hidden layers: dW1 = dHid^T . feat, db1; dfeat = d_v1 . Wv1 + d_a1 . Wa1
+                wg_gemm(d_a1, 1, F, feat_s, 1, F, F, F, B, Ps, Qs, [&](int i, int j, float acc) { grad[a.oWa1 + i * F + j] = acc; });
+                wg_gemm(d_v1, 1, F, feat_s, 1, F, F, F, B, Ps, Qs, [&](int i, int j, float acc) { grad[a.oWv1 + i * F + j] = acc; });
+                if (tid < F) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + d_a1[b * F + tid]; grad[a.oba1 + tid] = s; }
+                else if (tid >= 128 && tid < 128 + F) { const int k = tid - 128; float s = 0.0f; for (int b = 0; b < B; ++b) s = s + d_v1[b * F + k]; grad[a.obv1 + k] = s; }
+                wg_gemm(d_v1, F, 1, online + a.oWv1, 1, F, B, F, F, Ps, Qs, [&](int i, int j, float acc) { d_feat[i * F + j] = acc; });
+                __syncthreads();
+                wg_gemm(d_a1, F, 1, online + a.oWa1, 1, F, B, F, F, Ps, Qs, [&](int i, int j, float acc) { d_feat[i * F + j] = d_feat[i * F + j] + acc; });
+                __syncthreads();
+                // ---- feature stream: output Linear (no activation), then the hidden layers downwards ----
+                const float *dcur = d_feat;                // dL/d(output of layer l+1)'s pre-activation
+                int n_out = F;
+                for (int l = L; l >= 0; --l) {
+                    const int n_in = l == 0 ? S : H;
+                    const float *inp = l == 0 ? xs : hid_s[l - 1];
+                    const float *dc = dcur;
+                    wg_gemm(dc, 1, n_out, inp, 1, n_in, n_out, n_in, B, Ps, Qs, [&](int i, int j, float acc) { grad[a.oWf[l] + i * n_in + j] = acc; });
+                    for (int k = tid; k < n_out; k += DNT) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dc[b * n_out + k]; grad[a.obf[l] + k] = s; }
+                    if (l > 0) {
+                        float *dn = dh[l & 1];
+                        const float *hprev = hid_s[l - 1];
+                        wg_gemm(dc, n_out, 1, online + a.oWf[l], 1, n_in, B, n_in, n_out, Ps, Qs,
+                                [&](int i, int j, float acc) { dn[i * n_in + j] = act_bwd(act_id, prelu, hprev[i * n_in + j], acc); });
+                        dcur = dn; n_out = n_in;
+                    }
+                    __syncthreads();
+                }
+                // ---- torch.optim.Adam + Polyak (DuelingDDQN.py:87-93) ----
+                {
+                    const float neg_step = ctrl[10], bc2_sqrt = ctrl[11];
+                    const float w1 = (float)(1.0 - cfg.adam_beta1), w2 = (float)(1.0 - cfg.adam_beta2), beta2 = (float)cfg.adam_beta2;
+                    const float adam_eps = (float)cfg.adam_eps, tau = (float)cfg.tau, omt = (float)(1.0 - cfg.tau);
+                    for (int p = tid; p < P; p += DNT) {
+                        const float g = grad[p];
+                        const float m = fma32(w1, g - adam_m[p], adam_m[p]);
+                        float v = adam_v[p] * beta2;
+                        v = fma32(w2 * g, g, v);
+                        const float denom = __builtin_sqrtf(v) / bc2_sqrt + adam_eps;
+                        const float pn = online[p] + (neg_step * m) / denom;
+                        adam_m[p] = m; adam_v[p] = v; online[p] = pn;
+                        target[p] = tau * pn + omt * target[p];
+                    }
+                }
+                ++learn_it;
+                __syncthreads();
+            }
+            if (done_now > 0.5f) break;
+        }
+        ++episodes_run;
+        if (tid == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
+        __syncthreads();
+        test_phase();
+        if (tid == 0) {
+            double sm = 0.0;
+            for (int i = 0; i < T; ++i) sm += ret[i];
+            const double tm = sm / (double)T;
+            meter[episode] = tm;
+            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
+            int brk = 0;
+            if (learning) {
+                int lo = episode + 1 - cfg.early_out_num; if (lo < 0) lo = 0;
+                double s2 = 0.0;
+                for (int i = lo; i <= episode; ++i) s2 += meter[i];
+                if (s2 / ((double)(episode + 1 - lo) + 1e-9) >= cfg.solved_reward) brk = 1;
+            }
+            ictrl[3] = brk;
+        }
+        __syncthreads();
+        const int brk = ictrl[3];
+        __syncthreads();
+        if (brk) break;
+    }
+    test_phase();
+    if (tid == 0) {
+        double sm = 0.0;
+        for (int i = 0; i < T; ++i) sm += ret[i];
+        a.out.score[chain] = sm / (double)T;
+        if (a.out.final_returns) for (int i = 0; i < T; ++i) a.out.final_returns[chain * T + i] = ret[i];
+        if (a.out.stats) {
+            a.out.stats[chain * 4 + 0] = episodes_run; a.out.stats[chain * 4 + 1] = train_steps;
+            a.out.stats[chain * 4 + 2] = learn_it; a.out.stats[chain * 4 + 3] = test_steps;
+        }
+        const double nan = __builtin_nan("");
+        for (int e = episodes_run; e < cfg.train_episodes; ++e) {
+            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + e] = nan;
+            if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = 0;
+        }
+    }
+    if (a.out.final_online) for (int p = tid; p < P; p += DNT) a.out.final_online[chain * P + p] = online[p];
+    if (a.out.status && status != 0) atomicMin(&a.out.status[chain], status);
+    (void)lane; (void)wave;
+}
+
+}  // namespace lenv
+
+using namespace lenv;
+
+static int64_t d_mlp_params(int in, int H, int L, int out) { return (int64_t)in * H + H + (int64_t)(L - 1) * ((int64_t)H * H + H) + (int64_t)H * out + out; }
+
+static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_bytes)
+{
+    const int S = cfg->state_dim, A = cfg->num_actions, H = cfg->q_hidden, F = cfg->feature_dim, L = cfg->q_layers, B = cfg->batch_size;
+    const int Hse = cfg->se_hidden, T = cfg->test_episodes, K = S + A;
+    if (cfg->agent_kind != 1) return LENV_ERR_INVALID;
+    if (cfg->grad_chunk != 0 && cfg->grad_chunk < B) return LENV_ERR_UNSUPPORTED;   // batch gradient = one sequential chunk here
+    if (L < 1 || L > D_MAXL || H < 1 || H > D_MAXW || F < 1 || F > D_MAXW || B < 1 || B > GT_I || T < 1 || T > GT_I || cfg->se_layers != 1)
+        return LENV_ERR_UNSUPPORTED;
+    if (!((cfg->env_id == LENV_ENV_CARTPOLE && S == 4 && A == 2) || (cfg->env_id == LENV_ENV_ACROBOT && S == 6 && A == 3)))
+        return LENV_ERR_UNSUPPORTED;
+    int o = 0, n_in = S;
+    for (int l = 0; l < L; ++l) { a.oWf[l] = o; o += H * n_in; a.obf[l] = o; o += H; n_in = H; }
+    a.oWf[L] = o; o += F * H; a.obf[L] = o; o += F;
+    a.oWv1 = o; o += F * F; a.obv1 = o; o += F; a.oWv2 = o; o += F; a.obv2 = o; o += 1;
+    a.oWa1 = o; o += F * F; a.oba1 = o; o += F; a.oWa2 = o; o += A * F; a.oba2 = o; o += A;
+    a.P = o;
+    a.se_net_size[0] = (int)d_mlp_params(K, Hse, 1, S);
+    a.se_net_size[1] = a.se_net_size[2] = (int)d_mlp_params(K, Hse, 1, 1);
+    a.P_se = a.se_net_size[0] + a.se_net_size[1] + a.se_net_size[2];
+    a.RS = (2 * S + 3 + 3) & ~3;
+    int64_t cap = (int64_t)cfg->train_episodes * cfg->max_steps;
+    if (cap > cfg->rb_size) cap = cfg->rb_size;
+    a.rb_cap = cap < 1 ? 1 : cap;
+    const int W = H > F ? H : F;
+    int64_t off = 0;
+    auto take = [&](int64_t n) { int64_t r = off; off += (n + 3) & ~(int64_t)3; return r; };
+    a.a_online = take(a.P); a.a_target = take(a.P); a.a_m = take(a.P); a.a_v = take(a.P); a.a_grad = take(a.P);
+    a.a_replay = take(a.rb_cap * a.RS);
+    a.a_xs = take((int64_t)GT_I * S); a.a_xs2 = take((int64_t)GT_I * S);
+    for (int l = 0; l < D_MAXL; ++l) a.a_act[l] = take((int64_t)B * H);
+    a.a_feat = take((int64_t)B * F); a.a_v1 = take((int64_t)B * F); a.a_a1 = take((int64_t)B * F);
+    for (int l = 0; l < 4; ++l) a.a_t[l] = take((int64_t)GT_I * W);
+    for (int l = 0; l < 5; ++l) a.a_dbuf[l] = take((int64_t)GT_I * W);
+    a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
+    a.arena_stride = (off + 63) & ~(int64_t)63;
+    const size_t lds_floats = 2 * (size_t)GT_RB * GT_LD + 3 * K * Hse + 3 * Hse + (S + 2) * Hse + 16 + 3 * Hse + 3 * (size_t)B * A + B +
+                              (size_t)B * A + B + (size_t)B * A + 64 + 2 * (4 * (size_t)T + T) + 2 * T + 8 + 16 + 16;
+    *lds_bytes = lds_floats * sizeof(float);
+    if (*lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
+    return LENV_OK;
+}
+
+extern "C" size_t lenv_dueling_se_workspace_bytes(const lenv_ddqn_cfg *cfg, int64_t chains)
+{
+    if (!cfg || chains < 0) return 0;
+    DuelArgs a;
+    size_t lds;
+    if (dueling_layout(cfg, a, &lds) != LENV_OK) return 0;
+    return (size_t)chains * a.arena_stride * sizeof(float) + 256;
+}
+
+extern "C" int64_t lenv_dueling_num_params(const lenv_ddqn_cfg *cfg)
+{
+    if (!cfg) return LENV_ERR_INVALID;
+    DuelArgs a;
+    size_t lds;
+    const int rc = dueling_layout(cfg, a, &lds);
+    return rc != LENV_OK ? rc : a.P;
+}
+
+extern "C" int lenv_dueling_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *theta, const float *eps, const int32_t *worker,
+                                          const float *sign, const float *agent_init, const uint64_t *rng_keys,
+                                          const lenv_tapes *tapes, int64_t chains, void *workspace, size_t workspace_bytes,
+                                          const lenv_inner_out *out, void *stream)
+{
+    if (!cfg || !theta || !agent_init || !out || !out->score || !workspace || chains < 0) return LENV_ERR_INVALID;
+    if (eps && (!worker || !sign)) return LENV_ERR_INVALID;
+    if (cfg->rng_mode == LENV_RNG_TAPE && !tapes) return LENV_ERR_INVALID;
+    if (cfg->rng_mode == LENV_RNG_COUNTER && !rng_keys) return LENV_ERR_INVALID;
+    if (chains == 0) return LENV_OK;
+    DuelArgs a;
+    size_t lds_bytes;
+    const int rc = dueling_layout(cfg, a, &lds_bytes);
+    if (rc != LENV_OK) return rc;
+    if (workspace_bytes < (size_t)chains * a.arena_stride * sizeof(float)) return LENV_ERR_WORKSPACE;
+    a.cfg = *cfg;
+    a.theta = theta; a.eps = eps; a.worker = worker; a.sign = sign; a.agent_init = agent_init; a.rng_keys = rng_keys;
+    if (tapes) a.tapes = *tapes; else a.tapes = lenv_tapes{};
+    a.arena = static_cast<float *>(workspace);
+    a.out = *out;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dueling_se_inner_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return LENV_ERR_LAUNCH;
+    if (out->status) {
+        e = hipMemsetAsync(out->status, 0, sizeof(int32_t) * chains, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return LENV_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(dueling_se_inner_kernel, dim3((unsigned)chains), dim3(DNT), lds_bytes, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}

@@ -95,11 +95,19 @@ class InnerLoop(object):
         self.dev = require_device()
         self.cfg, self.chains = cfg, int(chains)
         L = _lib.lib()
-        self.ws_bytes = int(L.lenv_ddqn_se_workspace_bytes(C.byref(cfg), self.chains))
-        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
         E, T, S = cfg.train_episodes, cfg.test_episodes, cfg.state_dim
-        qd = mlp_desc(S, cfg.q_hidden, cfg.q_layers, cfg.num_actions, cfg.q_act)
-        self.p_agent = mlp_num_params(qd)
+        self.dueling = cfg.agent_kind == 1
+        if self.dueling:
+            self.p_agent = int(L.lenv_dueling_num_params(C.byref(cfg)))
+            _lib.check(min(self.p_agent, 0), "lenv_dueling_num_params")
+            self.ws_bytes = int(L.lenv_dueling_se_workspace_bytes(C.byref(cfg), self.chains))
+            self._fn = L.lenv_dueling_se_inner_loop
+        else:
+            self.ws_bytes = int(L.lenv_ddqn_se_workspace_bytes(C.byref(cfg), self.chains))
+            qd = mlp_desc(S, cfg.q_hidden, cfg.q_layers, cfg.num_actions, cfg.q_act)
+            self.p_agent = mlp_num_params(qd)
+            self._fn = L.lenv_ddqn_se_inner_loop
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
         self.score = torch.zeros(self.chains, dtype=torch.float64, device=self.dev)
         self.stats = torch.zeros((self.chains, 4), dtype=torch.int64, device=self.dev)
         self.status = torch.zeros(self.chains, dtype=torch.int32, device=self.dev)
@@ -138,10 +146,10 @@ class InnerLoop(object):
                       _ptr(tapes["test_reset"]), tapes["test_reset"].shape[1])
         if rng_keys is not None:
             _chk(rng_keys, torch.int64, "rng_keys")
-        rc = _lib.lib().lenv_ddqn_se_inner_loop(C.byref(self.cfg), _ptr(theta), _ptr(eps), _ptr(worker), _ptr(sign),
-                                                _ptr(agent_init), _ptr(rng_keys), C.byref(t) if t is not None else None,
-                                                self.chains, _ptr(self.workspace), self.ws_bytes, C.byref(self.out), _stream())
-        _lib.check(rc, "lenv_ddqn_se_inner_loop")
+        rc = self._fn(C.byref(self.cfg), _ptr(theta), _ptr(eps), _ptr(worker), _ptr(sign), _ptr(agent_init), _ptr(rng_keys),
+                      C.byref(t) if t is not None else None, self.chains, _ptr(self.workspace), self.ws_bytes,
+                      C.byref(self.out), _stream())
+        _lib.check(rc, "lenv_dueling_se_inner_loop" if self.dueling else "lenv_ddqn_se_inner_loop")
         return self.score
 
 

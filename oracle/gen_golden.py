@@ -312,14 +312,18 @@ class Recorder(object):
 
 
 def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml="default_config_cartpole_syn_env.yaml",
-           env_name="CartPole-v0", env_cls="CartPoleEnv"):
+           env_name="CartPole-v0", env_cls="CartPoleEnv", agent_key="ddqn", agent_over=None, env_over=None):
     import agents.GTN_worker as gw
     from agents.GTN import GTN_Worker
     import gym.envs as genvs
     import gym.spaces as gspaces
     cfg = load_cfg(env_yaml)
-    cfg["agents"]["ddqn"]["train_episodes"] = train_episodes
-    cfg["agents"]["ddqn"]["print_rate"] = int(1e9)
+    cfg["agents"][agent_key]["train_episodes"] = train_episodes
+    cfg["agents"][agent_key]["print_rate"] = int(1e9)
+    cfg["agents"][agent_key].update(agent_over or {})
+    cfg["envs"][env_name].update(env_over or {})
+    cfg["agents"]["gtn"]["agent_name"] = {"ddqn": "DDQN", "duelingddqn": "DuelingDDQN"}[agent_key]
+    cfg["agents"]["gtn"]["synthetic_env_type"] = 0
     if max_steps:
         cfg["envs"][env_name]["max_steps"] = max_steps
     rec = Recorder()
@@ -358,7 +362,8 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
     def wrapped_select_agent(config, agent_name):
         agent = orig_select_agent(config=config, agent_name=agent_name)
         holder["agent"] = agent
-        holder["init"] = pack_linear_params(agent.model.state_dict(), "net.")
+        holder["init"] = pack_linear_params(agent.model.state_dict(), "net.") if hasattr(agent.model, "net") \
+            else _pack_dueling(agent.model.state_dict())
         orig_learn = agent.learn
 
         def learn(replay_buffer, env, episode):
@@ -410,7 +415,7 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
     score = statistics.mean(reward_list_test)
     train_reset = np.array([s for (i, s) in rec.resets if i == train_reset_id])
     test_reset = np.array([s for (i, s) in rec.resets if i != train_reset_id])
-    a = cfg["agents"]["ddqn"]
+    a = cfg["agents"][agent_key]
     B = a["batch_size"]
     n = len(rec.steps)
     explored = np.zeros(n, np.int32)
@@ -581,6 +586,70 @@ def gen_g9(name, seed, eps_over=None):
          score=np.array(statistics.mean(reward_list_test)))
 
 
+# ------------------------------------------------------------------------------------------------
+# G3d / G4d: Critic_DuelingDQN forward (global advantage mean) and DuelingDDQN.learn steps
+# ------------------------------------------------------------------------------------------------
+def _pack_dueling(sd, prefix=""):
+    return np.concatenate([pack_linear_params(sd, prefix + "feature_stream."), pack_linear_params(sd, prefix + "value_stream."),
+                           pack_linear_params(sd, prefix + "advantage_stream.")])
+
+
+def gen_g4d():
+    from agents.DuelingDDQN import DuelingDDQN
+    from envs.env_factory import EnvFactory
+    from utils import ReplayBuffer
+    out = {}
+    variants = [("default_config_acrobot.yaml", {"hidden_size": 24, "feature_dim": 16, "batch_size": 32}, 3),
+                ("default_config_acrobot.yaml", {"hidden_size": 20, "feature_dim": 12, "batch_size": 16, "hidden_layer": 1,
+                                                 "activation_fn": "tanh"}, 3),
+                ("default_config_cartpole_syn_env.yaml", {"hidden_size": 16, "feature_dim": 16, "batch_size": 24}, 2)]
+    for vi, (yml, over, nsteps) in enumerate(variants):
+        cfg = load_cfg(yml)
+        cfg["agents"]["duelingddqn"].update(over)
+        seed_all(450 + vi)
+        with quiet():
+            fac = EnvFactory(cfg)
+            real_env = fac.generate_real_env()
+            agent = DuelingDDQN(env=real_env, config=cfg)
+        S, A = real_env.get_state_dim(), real_env.get_action_dim()
+        a = cfg["agents"]["duelingddqn"]
+        B = a["batch_size"]
+        rb = ReplayBuffer(state_dim=S, action_dim=1, device="cpu", max_size=300)
+        for i in range(200):
+            rb.add(torch.randn(S) * 0.5, torch.tensor([float(np.random.randint(A))]), torch.randn(S) * 0.5,
+                   torch.randn(1) * 0.3 - 0.5, torch.randn(1) * 0.2)
+        with torch.no_grad():
+            for p in agent.model_target.parameters():
+                p.add_(torch.randn_like(p) * 0.05)
+        pre = "v%d_" % vi
+        out[pre + "meta"] = np.array([S, A, a["hidden_size"], a["hidden_layer"], a["feature_dim"],
+                                      ["identity", "relu", "leakyrelu", "tanh", "prelu"].index(a["activation_fn"]), B, nsteps], np.int64)
+        out[pre + "hparams"] = np.array([a["gamma"], a["lr"], a["tau"]], np.float64)
+        out[pre + "online0"] = _pack_dueling(agent.model.state_dict())
+        out[pre + "target0"] = _pack_dueling(agent.model_target.state_dict())
+        x = torch.randn(9, S)
+        with torch.no_grad():
+            out[pre + "fwd_x"] = x.numpy()
+            out[pre + "fwd_q"] = agent.model(x).numpy()
+            out[pre + "fwd_q_single"] = torch.stack([agent.model(x[i]) for i in range(4)]).numpy()
+        rows_all, onl, tgt, losses = [], [], [], []
+        for step in range(nsteps):
+            idx = np.random.randint(0, rb.size, size=B)
+            rb.sample = lambda batch_size, _idx=idx: rb._sample_idx(_idx)
+            rows = np.concatenate([rb.state[idx].numpy(), rb.action[idx].numpy(), rb.next_state[idx].numpy(),
+                                   rb.reward[idx].numpy(), rb.done[idx].numpy()], axis=1)
+            loss = agent.learn(rb, real_env, episode=50)
+            rows_all.append(rows); losses.append(float(loss.item()))
+            onl.append(_pack_dueling(agent.model.state_dict()))
+            tgt.append(_pack_dueling(agent.model_target.state_dict()))
+        out[pre + "rows"] = np.stack(rows_all).astype(np.float32)
+        out[pre + "loss"] = np.array(losses, np.float64)
+        out[pre + "online"] = np.stack(onl)
+        out[pre + "target"] = np.stack(tgt)
+    out["n_variants"] = np.array(len(variants))
+    save("g4d_dueling_learn", **out)
+
+
 def main():
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8", "g9", "g10"]
     os.makedirs(OUT, exist_ok=True)
@@ -594,6 +663,13 @@ def main():
         gen_g6()
     if "g7" in which:
         gen_g7()
+    if "g4d" in which:
+        gen_g4d()
+    if "g8d" in which:
+        gen_g8("g8d_calc_score_acrobot_dueling", train_episodes=4, done_bias_shift=0.0, seed=810, max_steps=25,
+               env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="duelingddqn",
+               agent_over={"hidden_size": 24, "feature_dim": 16, "batch_size": 32, "init_episodes": 1, "test_episodes": 3},
+               env_over={"hidden_size": 32, "solved_reward": 0.5})
     if "g2" in which:
         gen_g2()
     if "g9" in which:

@@ -467,6 +467,221 @@ float orc_ddqn_learn(const orc_ddqn_cfg *cfg, float *online, float *target, floa
 }
 
 /* ------------------------------------------------------------------------------------------
+ * DuelingDDQN (agents/DuelingDDQN.py:59-110, models/actor_critic.py:94-122)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { orc_mlp_desc feat, val, adv; int64_t p_feat, p_val, p_adv, P; } dueling_layout;
+
+static void dueling_layout_of(const orc_ddqn_cfg *cfg, dueling_layout *L)
+{
+    const int F = cfg->feature_dim;
+    L->feat = (orc_mlp_desc){ cfg->state_dim, cfg->q_hidden, cfg->q_layers, F, cfg->q_act, cfg->q_prelu };
+    /* heads_config: hidden_layer = 1, hidden_size = feature_dim (actor_critic.py:103-105) */
+    L->val = (orc_mlp_desc){ F, F, 1, 1, cfg->q_act, cfg->q_prelu };
+    L->adv = (orc_mlp_desc){ F, F, 1, cfg->num_actions, cfg->q_act, cfg->q_prelu };
+    L->p_feat = orc_mlp_num_params(&L->feat);
+    L->p_val = orc_mlp_num_params(&L->val);
+    L->p_adv = orc_mlp_num_params(&L->adv);
+    L->P = L->p_feat + L->p_val + L->p_adv;
+}
+
+int64_t orc_dueling_num_params(const orc_ddqn_cfg *cfg)
+{
+    dueling_layout L;
+    dueling_layout_of(cfg, &L);
+    return L.P;
+}
+
+/* per-sample scratch of one dueling forward */
+typedef struct {
+    float zf[ORC_MAX_LAYERS][ORC_MAX_WIDTH], af[ORC_MAX_LAYERS][ORC_MAX_WIDTH];
+    float zv[1][ORC_MAX_WIDTH], av[1][ORC_MAX_WIDTH], za[1][ORC_MAX_WIDTH], aa[1][ORC_MAX_WIDTH];
+    float feat[ORC_MAX_WIDTH], V, adv[64];
+} dueling_act;
+
+static void dueling_forward_one(const dueling_layout *L, const float *p, const float *x, dueling_act *s)
+{
+    mlp_forward_one(&L->feat, p, x, s->feat, s->zf, s->af);                       /* no activation after the last Linear */
+    mlp_forward_one(&L->val, p + L->p_feat, s->feat, &s->V, s->zv, s->av);
+    mlp_forward_one(&L->adv, p + L->p_feat + L->p_val, s->feat, s->adv, s->za, s->aa);
+}
+
+/* q = values + (advantages - advantages.mean()); the mean runs over every element of the [B,A] tensor
+ * (actor_critic.py:121), summed sequentially in row-major order here */
+int orc_dueling_forward(const orc_ddqn_cfg *cfg, const float *params, const float *x, int64_t B, float *q)
+{
+    dueling_layout L;
+    dueling_layout_of(cfg, &L);
+    if (cfg->feature_dim > ORC_MAX_WIDTH || cfg->q_hidden > ORC_MAX_WIDTH || cfg->num_actions > 64 || cfg->q_layers > ORC_MAX_LAYERS) return -1;
+    const int A = cfg->num_actions;
+    dueling_act *s = malloc(sizeof(dueling_act));
+    float *V = malloc(sizeof(float) * B), *adv = malloc(sizeof(float) * B * A);
+    float sum = 0.0f;
+    for (int64_t b = 0; b < B; ++b) {
+        dueling_forward_one(&L, params, x + b * cfg->state_dim, s);
+        V[b] = s->V;
+        for (int a = 0; a < A; ++a) { adv[b * A + a] = s->adv[a]; sum = sum + s->adv[a]; }
+    }
+    const float mean = sum / (float)(B * A);
+    for (int64_t b = 0; b < B; ++b)
+        for (int a = 0; a < A; ++a) q[b * A + a] = V[b] + (adv[b * A + a] - mean);
+    free(s); free(V); free(adv);
+    return 0;
+}
+
+/* backward of one MLP for one sample: accumulates parameter gradients into g (same layout as p), returns dL/dx */
+static void mlp_backward_one(const orc_mlp_desc *d, const float *p, const float *x, float z[][ORC_MAX_WIDTH],
+                             float a[][ORC_MAX_WIDTH], const float *dout, float *g, float *dx)
+{
+    const int H = d->hidden, L = d->layers, O = d->out_dim;
+    int64_t offW[ORC_MAX_LAYERS + 1], offb[ORC_MAX_LAYERS + 1];
+    {
+        int64_t o = 0; int n_in = d->in_dim;
+        for (int l = 0; l < L; ++l) { offW[l] = o; o += (int64_t)H * n_in; offb[l] = o; o += H; n_in = H; }
+        offW[L] = o; o += (int64_t)O * H; offb[L] = o;
+    }
+    float da[ORC_MAX_WIDTH], dz[ORC_MAX_WIDTH], dprev[ORC_MAX_WIDTH];
+    for (int o = 0; o < O; ++o) {
+        float *gW = g + offW[L] + (int64_t)o * H;
+        for (int j = 0; j < H; ++j) gW[j] = fmaf(dout[o], a[L - 1][j], gW[j]);
+        g[offb[L] + o] = g[offb[L] + o] + dout[o];
+    }
+    for (int j = 0; j < H; ++j) {
+        float acc = 0.0f;
+        for (int o = 0; o < O; ++o) acc = fmaf(dout[o], p[offW[L] + (int64_t)o * H + j], acc);
+        da[j] = acc;
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        const int n_in = l == 0 ? d->in_dim : H;
+        const float *inp = l == 0 ? x : a[l - 1];
+        for (int j = 0; j < H; ++j) dz[j] = act_bwd(d->act, d->prelu, z[l][j], a[l][j], da[j]);
+        float *gW = g + offW[l], *gb = g + offb[l];
+        for (int j = 0; j < H; ++j) {
+            for (int i = 0; i < n_in; ++i) gW[(int64_t)j * n_in + i] = fmaf(dz[j], inp[i], gW[(int64_t)j * n_in + i]);
+            gb[j] = gb[j] + dz[j];
+        }
+        if (l > 0 || dx) {
+            const float *W = p + offW[l];
+            for (int i = 0; i < n_in; ++i) {
+                float acc = 0.0f;
+                for (int j = 0; j < H; ++j) acc = fmaf(dz[j], W[(int64_t)j * n_in + i], acc);
+                dprev[i] = acc;
+            }
+            if (l > 0) memcpy(da, dprev, sizeof(float) * n_in);
+            else memcpy(dx, dprev, sizeof(float) * n_in);
+        }
+    }
+}
+
+/* One DuelingDDQN.learn step (DuelingDDQN.py:59-94): forward of the three batches with the GLOBAL advantage mean,
+ * loss = mse_loss(expected.detach(), q_value), backward through the mean, Adam, Polyak. */
+float orc_dueling_learn(const orc_ddqn_cfg *cfg, float *online, float *target, float *adam_m, float *adam_v,
+                        double *b1pow, double *b2pow, const float *rows, int64_t row_stride)
+{
+    dueling_layout L;
+    dueling_layout_of(cfg, &L);
+    const int S = cfg->state_dim, A = cfg->num_actions, B = cfg->batch_size, F = cfg->feature_dim;
+    const int64_t P = L.P;
+    const int chunk = cfg->grad_chunk > 0 ? cfg->grad_chunk : B;
+    dueling_act *acts = malloc(sizeof(dueling_act) * (size_t)B);      /* online(s) activations of every sample */
+    float *s_in = malloc(sizeof(float) * (size_t)B * S), *s2_in = malloc(sizeof(float) * (size_t)B * S);
+    float *q = malloc(sizeof(float) * (size_t)B * A), *qn = malloc(sizeof(float) * (size_t)B * A), *qt = malloc(sizeof(float) * (size_t)B * A);
+    float *dq = malloc(sizeof(float) * (size_t)B);
+    float *grad = calloc(P, sizeof(float)), *gch = malloc(sizeof(float) * P);
+    for (int b = 0; b < B; ++b) {
+        memcpy(s_in + (size_t)b * S, rows + (int64_t)b * row_stride, sizeof(float) * S);
+        memcpy(s2_in + (size_t)b * S, rows + (int64_t)b * row_stride + S + 1, sizeof(float) * S);
+    }
+    /* q_values = model(states) keeping the activations */
+    {
+        float sum = 0.0f;
+        for (int b = 0; b < B; ++b) {
+            dueling_forward_one(&L, online, s_in + (size_t)b * S, &acts[b]);
+            for (int a = 0; a < A; ++a) sum = sum + acts[b].adv[a];
+        }
+        const float mean = sum / (float)(B * A);
+        for (int b = 0; b < B; ++b)
+            for (int a = 0; a < A; ++a) q[b * A + a] = acts[b].V + (acts[b].adv[a] - mean);
+    }
+    orc_dueling_forward(cfg, online, s2_in, B, qn);
+    orc_dueling_forward(cfg, target, s2_in, B, qt);
+    const float g32 = (float)cfg->gamma, norm = (float)(2.0 / (double)B);
+    float loss_acc = 0.0f, S_dq = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        const float *row = rows + (int64_t)b * row_stride;
+        const int act = (int)row[S];
+        const float r = row[2 * S + 1], d = row[2 * S + 2];
+        const int am = argmax_first(qn + b * A, A);
+        const float t1 = g32 * qt[b * A + am];
+        const float t2 = 1.0f - d;
+        const float yv = r + t1 * t2;
+        const float diff = q[b * A + act] - yv;
+        loss_acc = fmaf(diff, diff, loss_acc);
+        dq[b] = norm * diff;
+        S_dq = S_dq + dq[b];                       /* sum of dL/dQ over the whole [B,A] tensor (one non-zero per row) */
+    }
+    const float mean_grad = (-S_dq) / (float)(B * A);   /* backward of `- advantages.mean()` */
+    int first_chunk = 1;
+    float dadv[64], dfeat_v[ORC_MAX_WIDTH], dfeat_a[ORC_MAX_WIDTH], dfeat[ORC_MAX_WIDTH];
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int b1 = b0 + chunk < B ? b0 + chunk : B;
+        memset(gch, 0, sizeof(float) * P);
+        for (int b = b0; b < b1; ++b) {
+            const int act = (int)rows[(int64_t)b * row_stride + S];
+            for (int a = 0; a < A; ++a) dadv[a] = (a == act ? dq[b] : 0.0f) + mean_grad;
+            const float dV = dq[b];
+            mlp_backward_one(&L.val, online + L.p_feat, acts[b].feat, acts[b].zv, acts[b].av, &dV, gch + L.p_feat, dfeat_v);
+            mlp_backward_one(&L.adv, online + L.p_feat + L.p_val, acts[b].feat, acts[b].za, acts[b].aa, dadv,
+                             gch + L.p_feat + L.p_val, dfeat_a);
+            for (int i = 0; i < F; ++i) dfeat[i] = dfeat_v[i] + dfeat_a[i];
+            mlp_backward_one(&L.feat, online, s_in + (size_t)b * S, acts[b].zf, acts[b].af, dfeat, gch, NULL);
+        }
+        if (first_chunk) { memcpy(grad, gch, sizeof(float) * P); first_chunk = 0; }
+        else for (int64_t i = 0; i < P; ++i) grad[i] = grad[i] + gch[i];
+    }
+    *b1pow *= cfg->adam_beta1;
+    *b2pow *= cfg->adam_beta2;
+    const double bc1 = 1.0 - *b1pow, bc2 = 1.0 - *b2pow;
+    const float neg_step = (float)(-(cfg->lr / bc1));
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - cfg->adam_beta1), w2 = (float)(1.0 - cfg->adam_beta2);
+    const float beta2 = (float)cfg->adam_beta2, eps = (float)cfg->adam_eps;
+    const float tau = (float)cfg->tau, omt = (float)(1.0 - cfg->tau);
+    for (int64_t i = 0; i < P; ++i) {
+        const float g = grad[i];
+        const float m = fmaf(w1, g - adam_m[i], adam_m[i]);
+        float v = adam_v[i] * beta2;
+        v = fmaf(w2 * g, g, v);
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        const float pnew = online[i] + (neg_step * m) / denom;
+        adam_m[i] = m; adam_v[i] = v; online[i] = pnew;
+        target[i] = tau * pnew + omt * target[i];
+    }
+    free(acts); free(s_in); free(s2_in); free(q); free(qn); free(qt); free(dq); free(grad); free(gch);
+    return loss_acc / (float)B;
+}
+
+/* agent dispatch used by the chain: greedy action and learn step of the configured inner agent */
+static int64_t agent_num_params(const orc_ddqn_cfg *cfg)
+{
+    if (cfg->agent_kind == 1) return orc_dueling_num_params(cfg);
+    orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu };
+    return orc_mlp_num_params(&qd);
+}
+
+static int agent_greedy_action(const orc_ddqn_cfg *cfg, const float *params, const float *obs,
+                               float (*z)[ORC_MAX_WIDTH], float (*a)[ORC_MAX_WIDTH])
+{
+    float q[ORC_MAX_WIDTH];
+    if (cfg->agent_kind == 1) {
+        orc_dueling_forward(cfg, params, obs, 1, q);       /* single state: the mean is over its A advantages */
+    } else {
+        orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu };
+        mlp_forward_one(&qd, params, obs, q, z, a);
+    }
+    return argmax_first(q, cfg->num_actions);
+}
+
+/* ------------------------------------------------------------------------------------------
  * One chain: GTN_Worker.calc_score (GTN_worker.py:187-221) =
  *   select_agent -> DDQN (fresh agent, agent_init weights) ; BaseAgent.train(env=SE, test_env=real)
  *   (base_agent.py:64-153) ; BaseAgent.test(real) (base_agent.py:155-227) ; statistics.mean.
@@ -541,15 +756,15 @@ static void real_env_obs(int env_id, const double st[4], float *obs)
 static void run_test_phase(const orc_ddqn_cfg *cfg, const orc_mlp_desc *qd, const float *online, rng_state *rng,
                            double *returns, int64_t *test_steps, float (*z)[ORC_MAX_WIDTH], float (*a)[ORC_MAX_WIDTH])
 {
-    float obs[8], q[ORC_MAX_WIDTH];
+    float obs[8];
+    (void)qd;
     for (int te = 0; te < cfg->test_episodes; ++te) {
         double st[4];
         draw_reset(rng, 0, rng->n_test_ep++, st);
         float ep_reward = 0.0f;   /* fp32 tensor accumulation, base_agent.py:212 */
         for (int t = 0; t < cfg->max_steps; ++t) {
             real_env_obs(cfg->env_id, st, obs);
-            mlp_forward_one(qd, online, obs, q, z, a);
-            int act = argmax_first(q, cfg->num_actions);
+            int act = agent_greedy_action(cfg, online, obs, z, a);
             double rew; int done;
             if (cfg->env_id == ORC_ENV_CARTPOLE) orc_cartpole_step(st, act, &rew, &done);
             else orc_acrobot_step(st, act, &rew, &done);
@@ -582,7 +797,7 @@ int orc_ddqn_se_chain(const orc_ddqn_cfg *cfg, const float *se_params, const flo
     if (cfg->env_id == ORC_ENV_ACROBOT && S != 6) return -1;
     if (cfg->q_hidden > ORC_MAX_WIDTH || cfg->se_hidden > ORC_MAX_WIDTH || S + A > 64) return -1;
     if (cfg->rng_mode == ORC_RNG_TAPE && !tapes) return -1;
-    const int64_t P = orc_mlp_num_params(&qd);
+    const int64_t P = agent_num_params(cfg);
     const int64_t ps = orc_mlp_num_params(&sn), pr = orc_mlp_num_params(&rn);
     const int64_t row_stride = 2 * S + 3;
     int64_t cap = (int64_t)cfg->train_episodes * cfg->max_steps;
@@ -622,7 +837,7 @@ int orc_ddqn_se_chain(const orc_ddqn_cfg *cfg, const float *se_params, const flo
             int act, explored = 0;
             double u = draw_eps_uniform(&rng);
             if (u < eps) { act = draw_rand_action(&rng); explored = 1; }
-            else { mlp_forward_one(&qd, online, state, q, z, a); act = argmax_first(q, A); }
+            else act = agent_greedy_action(cfg, online, state, z, a);
             /* EnvWrapper.step -> VirtualEnv.step */
             for (int i = 0; i < A; ++i) x[i] = (i == act) ? 1.0f : 0.0f;
             for (int i = 0; i < S; ++i) x[A + i] = state[i];
@@ -646,7 +861,8 @@ int orc_ddqn_se_chain(const orc_ddqn_cfg *cfg, const float *se_params, const flo
                     memcpy(batch + (int64_t)b * row_stride, rb + (int64_t)idx * row_stride, sizeof(float) * row_stride);
                 }
                 ++learn_it;
-                loss = orc_ddqn_learn(cfg, online, target, am, av, learn_it, &b1pow, &b2pow, batch, row_stride);
+                loss = cfg->agent_kind == 1 ? orc_dueling_learn(cfg, online, target, am, av, &b1pow, &b2pow, batch, row_stride)
+                                            : orc_ddqn_learn(cfg, online, target, am, av, learn_it, &b1pow, &b2pow, batch, row_stride);
             }
             if (trace && trace->n < trace->cap) {
                 int64_t k = trace->n++;
@@ -731,8 +947,7 @@ int orc_ddqn_se_population(const orc_ddqn_cfg *cfg, const float *theta, const fl
                            const float *agent_init, uint64_t seed, uint64_t generation, int64_t worker_offset,
                            int threads, double *chain_scores, orc_chain_result *results)
 {
-    orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu };
-    pop_job j = { cfg, theta, eps, agent_init, pop, p_theta, orc_mlp_num_params(&qd), worker_offset, seed, generation,
+    pop_job j = { cfg, theta, eps, agent_init, pop, p_theta, agent_num_params(cfg), worker_offset, seed, generation,
                   chain_scores, results, 0, PTHREAD_MUTEX_INITIALIZER, 0 };
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;

@@ -62,6 +62,8 @@ typedef struct {
     int32_t early_out_num;
     int32_t grad_chunk;
     int32_t rng_mode;
+    int32_t agent_kind;   /* 0 = DDQN (agents/DDQN.py), 1 = DuelingDDQN (agents/DuelingDDQN.py) */
+    int32_t feature_dim;  /* DuelingDDQN: width of the feature vector / of the two head hidden layers */
     double solved_reward;
     double gamma, lr, tau;
     double eps_init, eps_min, eps_decay;
@@ -135,6 +137,14 @@ int orc_qnet_td_forward(const orc_mlp_desc *q, const float *online, const float 
 float orc_ddqn_learn(const orc_ddqn_cfg *cfg, float *online, float *target, float *adam_m, float *adam_v,
                      int64_t step /*1-based*/, double *b1pow, double *b2pow,
                      const float *rows, int64_t row_stride);
+
+/* ---- DuelingDDQN (agents/DuelingDDQN.py:59-110, models/actor_critic.py:94-122) ----
+ * parameters: feature MLP (S -> H x layers -> F) | value MLP (F -> F -> 1) | advantage MLP (F -> F -> A), flat in
+ * state-dict order.  q = V + (Adv - mean(Adv over ALL batch x action elements)) (actor_critic.py:121). */
+int64_t orc_dueling_num_params(const orc_ddqn_cfg *cfg);
+int orc_dueling_forward(const orc_ddqn_cfg *cfg, const float *params, const float *x, int64_t B, float *q /*[B,A]*/);
+float orc_dueling_learn(const orc_ddqn_cfg *cfg, float *online, float *target, float *adam_m, float *adam_v,
+                        double *b1pow, double *b2pow, const float *rows, int64_t row_stride);
 
 /* ---- one chain = GTN_Worker.calc_score (GTN_worker.py:187-221) ---- */
 int orc_ddqn_se_chain(const orc_ddqn_cfg *cfg, const float *se_params /*perturbed, [P_theta]*/,

@@ -28,6 +28,7 @@ class DdqnCfg(C.Structure):
                 ("batch_size", C.c_int32), ("rb_size", C.c_int32),
                 ("train_episodes", C.c_int32), ("test_episodes", C.c_int32), ("init_episodes", C.c_int32),
                 ("early_out_num", C.c_int32), ("grad_chunk", C.c_int32), ("rng_mode", C.c_int32),
+                ("agent_kind", C.c_int32), ("feature_dim", C.c_int32),
                 ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
                 ("eps_init", C.c_double), ("eps_min", C.c_double), ("eps_decay", C.c_double),
                 ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
@@ -290,9 +291,12 @@ def ddqn_cfg_from_config(config, grad_chunk=13, rng_mode=0, **overrides):
     agents/DDQN.py:15-38, agents/base_agent.py:9-26, envs/env_factory.py:45-59."""
     env_name = config["env_name"]
     e = config["envs"][env_name]
-    a = config["agents"]["ddqn"]
+    agent_key = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "ddqn"
+    a = config["agents"][agent_key]
     S, A = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3)}[env_name]
     assert a["same_action_num"] == 1, "same_action_num != 1 not supported by the oracle yet"
+    overrides.setdefault("agent_kind", 1 if agent_key == "duelingddqn" else 0)
+    overrides.setdefault("feature_dim", int(a.get("feature_dim", 0)))
     cfg = DdqnCfg(env_id=ENV[env_name], state_dim=S, num_actions=A, max_steps=int(e["max_steps"]),
                   se_hidden=int(e["hidden_size"]), se_layers=int(e["hidden_layer"]), se_act=ACT[e["activation_fn"]],
                   se_prelu=0.25, q_hidden=int(a["hidden_size"]), q_layers=int(a["hidden_layer"]),
@@ -371,3 +375,26 @@ def ql_rn_chain(cfg, rn_params, tables, rng_key=0, tapes=None, trace_cap=0, shap
     if tr is not None:
         out["trace"] = {k: v[:tr.n] for k, v in arrs.items()}
     return out
+
+
+def dueling_num_params(cfg):
+    lib().orc_dueling_num_params.restype = C.c_int64
+    return int(lib().orc_dueling_num_params(C.byref(cfg)))
+
+
+def dueling_forward(cfg, params, x):
+    params, x = _f32(params), _f32(x).reshape(-1, cfg.state_dim)
+    q = np.empty((x.shape[0], cfg.num_actions), np.float32)
+    rc = lib().orc_dueling_forward(C.byref(cfg), _p(params, C.c_float), _p(x, C.c_float), C.c_int64(x.shape[0]), _p(q, C.c_float))
+    assert rc == 0
+    return q
+
+
+def dueling_learn(cfg, online, target, m, v, b1pow, b2pow, rows):
+    online, target, m, v = [_f32(t).copy() for t in (online, target, m, v)]
+    rows = _f32(rows)
+    b1, b2 = C.c_double(b1pow), C.c_double(b2pow)
+    lib().orc_dueling_learn.restype = C.c_float
+    loss = lib().orc_dueling_learn(C.byref(cfg), _p(online, C.c_float), _p(target, C.c_float), _p(m, C.c_float),
+                                   _p(v, C.c_float), C.byref(b1), C.byref(b2), _p(rows, C.c_float), C.c_int64(rows.shape[1]))
+    return float(loss), online, target, m, v, b1.value, b2.value

@@ -344,3 +344,77 @@ def test_ql_rn_counter_mode_population_vs_oracle(eng, orc, golden, env_name, rty
         assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
         assert float(il.score[c]) == o["score"]
         assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 3: DuelingDDQN on a synthetic environment (LDS-tiled GEMM kernel, parameters in the HBM arena)
+# ---------------------------------------------------------------------------------------------------------------
+def test_dueling_tape_mode_vs_reference_and_oracle(eng, orc, golden):
+    g = golden("g8d_calc_score_acrobot_dueling")
+    cfgd = json.loads(str(g["config_json"]))
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
+    assert cfg.agent_kind == 1
+    n = g["tr_action"].size
+    otapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    o = orc.ddqn_se_chain(ocfg, g["theta"], g["agent_init"], tapes=otapes, trace_cap=n + 8)
+    chains = 2
+    tapes = dict(eps_uniform=dev(np.tile(g["tape_eps_uniform"], (chains, 1))),
+                 rand_action=dev(np.tile(g["tape_rand_action"], (chains, 1))),
+                 replay_idx=dev(np.tile(g["tape_replay_idx"].reshape(1, -1), (chains, 1))),
+                 train_reset=dev(np.tile(g["tape_train_reset"][None], (chains, 1, 1))),
+                 test_reset=dev(np.tile(g["tape_test_reset"][None], (chains, 1, 1))))
+    il = eng.InnerLoop(cfg, chains, trace_cap=n + 8)
+    assert il.p_agent == g["agent_init"].size
+    il.run(dev(g["theta"]), None, None, None, dev(np.tile(g["agent_init"], (chains, 1))), tapes=tapes)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        act = il.trace["action"][c, :n].cpu().numpy()
+        assert np.array_equal(act & 0xFFFF, o["trace"]["action"]) and np.array_equal(act >> 16, o["trace"]["explored"])
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"])
+        assert np.array_equal(il.trace["reward_done"][c, :n, 0].cpu().numpy(), o["trace"]["reward"])
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(il.final_returns[c].cpu().numpy(), o["final_test_returns"])
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        # the reference's own run
+        assert np.array_equal(act & 0xFFFF, g["tr_action"])
+        np.testing.assert_allclose(il.trace["next_state"][c, :n].cpu().numpy(), g["tr_next_state"], rtol=1e-5, atol=1e-5)
+        assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4
+
+
+@pytest.mark.parametrize("env_name,layers,hidden,feat,batch,act", [("Acrobot-v1", 2, 128, 128, 128, "relu"), ("CartPole-v0", 1, 40, 24, 50, "tanh"),
+                                                                   ("Acrobot-v1", 2, 33, 17, 77, "leakyrelu")])
+def test_dueling_counter_mode_vs_oracle(eng, orc, golden, env_name, layers, hidden, feat, batch, act):
+    g = golden("g8d_calc_score_acrobot_dueling")
+    cfgd = json.loads(str(g["config_json"]))
+    cfgd["env_name"] = env_name
+    cfgd["envs"][env_name] = dict(cfgd["envs"]["Acrobot-v1"], hidden_size=48)
+    cfgd["agents"]["duelingddqn"].update(hidden_size=hidden, hidden_layer=layers, feature_dim=feat, batch_size=batch, activation_fn=act,
+                                         test_episodes=4)
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, train_episodes=3, max_steps=12)
+    S, A = ocfg.state_dim, ocfg.num_actions
+    rng = np.random.RandomState(8)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, ocfg.se_hidden, 1, "leakyrelu"))
+    P_q = orc.dueling_num_params(ocfg)
+    chains = 3
+    theta = (rng.randn(P_se) * 0.15).astype(np.float32)
+    eps = (rng.randn(1, P_se) * 0.05).astype(np.float32)
+    agent_init = (rng.uniform(-0.15, 0.15, (chains, P_q))).astype(np.float32)
+    worker = np.zeros(chains, np.int32)
+    sign = np.array([0.0, 1.0, -1.0], np.float32)
+    keys = np.array([orc.chain_key(9, 2, 0, c) for c in range(chains)], np.uint64)
+    il = eng.InnerLoop(cfg, chains, trace_cap=40, want_final_online=True)
+    assert il.p_agent == P_q
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        w = (np.float32(sign[c]) * eps[0] + theta).astype(np.float32)
+        o = orc.ddqn_se_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]), trace_cap=40)
+        n = o["trace"]["action"].size
+        assert np.array_equal(il.trace["action"][c, :n].cpu().numpy() & 0xFFFF, o["trace"]["action"]), c
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"]), c
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]

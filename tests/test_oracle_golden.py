@@ -223,3 +223,55 @@ def test_g9_calc_score_cliff(golden, name):
     assert np.array_equal(out["episode_test_mean"][:g["reward_list_train"].size], g["reward_list_train"])
     assert np.array_equal(out["final_test_returns"], g["reward_list_test"])
     assert out["score"] == float(g["score"])
+
+
+def _dueling_cfg(meta, hp, grad_chunk):
+    S, A, H, L, F, act, B, _ = [int(v) for v in meta]
+    return orc.DdqnCfg(env_id=0 if S == 4 else 1, state_dim=S, num_actions=A, max_steps=200, se_hidden=8, se_layers=1, se_act=2,
+                       se_prelu=0.25, q_hidden=H, q_layers=L, q_act=act, q_prelu=0.25, batch_size=B, rb_size=1000,
+                       train_episodes=1, test_episodes=1, init_episodes=0, early_out_num=1, grad_chunk=grad_chunk, rng_mode=0,
+                       agent_kind=1, feature_dim=F, solved_reward=1e9, gamma=float(hp[0]), lr=float(hp[1]), tau=float(hp[2]),
+                       eps_init=1.0, eps_min=0.1, eps_decay=0.9, adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8)
+
+
+@pytest.mark.parametrize("grad_chunk", [0, 7])
+def test_g4d_dueling_forward_and_learn(golden, grad_chunk):
+    g = golden("g4d_dueling_learn")
+    for vi in range(int(g["n_variants"])):
+        pre = "v%d_" % vi
+        cfg = _dueling_cfg(g[pre + "meta"], g[pre + "hparams"], grad_chunk)
+        assert orc.dueling_num_params(cfg) == g[pre + "online0"].size
+        # forward: global advantage mean over batch x actions (actor_critic.py:121) and the per-state mean for single inputs
+        np.testing.assert_allclose(orc.dueling_forward(cfg, g[pre + "online0"], g[pre + "fwd_x"]), g[pre + "fwd_q"], rtol=2e-6, atol=2e-6)
+        for i in range(4):
+            np.testing.assert_allclose(orc.dueling_forward(cfg, g[pre + "online0"], g[pre + "fwd_x"][i:i + 1])[0],
+                                       g[pre + "fwd_q_single"][i], rtol=2e-6, atol=2e-6)
+        online, target = g[pre + "online0"].copy(), g[pre + "target0"].copy()
+        m, v = np.zeros_like(online), np.zeros_like(online)
+        b1p, b2p = 1.0, 1.0
+        for step in range(int(g[pre + "meta"][7])):
+            loss, online, target, m, v, b1p, b2p = orc.dueling_learn(cfg, online, target, m, v, b1p, b2p, g[pre + "rows"][step])
+            assert abs(loss - g[pre + "loss"][step]) <= 3e-6 * max(1.0, abs(g[pre + "loss"][step])), (pre, step)
+            np.testing.assert_allclose(online, g[pre + "online"][step], rtol=0, atol=2e-5, err_msg=pre + "online%d" % step)
+            np.testing.assert_allclose(target, g[pre + "target"][step], rtol=0, atol=2e-5, err_msg=pre + "target%d" % step)
+
+
+def test_g8d_calc_score_acrobot_dueling(golden):
+    import json
+    g = golden("g8d_calc_score_acrobot_dueling")
+    cfgd = json.loads(str(g["config_json"]))
+    cfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
+    assert cfg.agent_kind == 1 and cfg.feature_dim == 16
+    tapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    n = g["tr_action"].size
+    out = orc.ddqn_se_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 10)
+    assert out["rc"] == 0
+    tr = out["trace"]
+    assert tr["action"].size == n
+    assert np.array_equal(tr["action"], g["tr_action"])
+    np.testing.assert_allclose(tr["next_state"], g["tr_next_state"], rtol=1e-5, atol=1e-5)
+    losses = tr["loss"][~np.isnan(tr["loss"])]
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-3, atol=1e-6)
+    assert np.array_equal(out["episode_len"], g["episode_length_train"])
+    np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=1e-4)
+    assert abs(out["score"] - float(g["score"])) <= 1e-4
