@@ -50,8 +50,8 @@ class GTN_Worker(GTN_Base):
         self.unsolved_weight = gtn_config["unsolved_weight"]
         if gtn_config["mode"] == 'single':
             self.time_sleep_worker /= 10
-        if self.agent_name.lower() != "ddqn":
-            raise NotImplementedError("inner agent '%s': only DDQN has a fused kernel so far" % self.agent_name)
+        if self.agent_name.lower() not in ("ddqn", "duelingddqn"):
+            raise NotImplementedError("GTN_Worker: inner agent '%s' (use GTN_Master for QL)" % self.agent_name)
         if self.engine is None:
             from ..engine import HipNesEngine
             self.engine = HipNesEngine()
@@ -68,8 +68,8 @@ class GTN_Worker(GTN_Base):
         self.synthetic_env = generate_synthetic_env_fn(print_str='GTN_Worker' + str(id) + ': ')
         self.eps = generate_synthetic_env_fn('GTN_Worker' + str(id) + ': ')
         self.cfg = ddqn_cfg_from_config(config)
-        S, A, Hq = self.cfg.state_dim, self.cfg.num_actions, self.cfg.q_hidden
-        self._bounds = torch.from_numpy(linear_init_bounds([(S, Hq), (Hq, A)])).to(self.engine.device)
+        from ..config import agent_layer_dims
+        self._bounds = torch.from_numpy(linear_init_bounds(agent_layer_dims(self.cfg))).to(self.engine.device)
         self._inner = {}
 
     # ---- noise handling: reference :156-185, same loops over nn.Linear modules ----

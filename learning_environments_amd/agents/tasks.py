@@ -3,12 +3,13 @@
 The reference dispatches through select_agent (agents/agent_utils.py:15-66) + EnvFactory; here each supported
 combination owns one fused kernel:
     DDQN on a VirtualEnv (synthetic_env_type 0)   -> lenv_ddqn_se_inner_loop   (BASELINE configs 1-2, Acrobot-DDQN)
+    DuelingDDQN on a VirtualEnv                   -> lenv_dueling_se_inner_loop (BASELINE config 3)
     QL   on a RewardEnv over a gridworld (type 1) -> lenv_ql_rn_inner_loop     (BASELINE config 4)
 Anything else raises NotImplementedError, like the reference does for unknown agents."""
 import numpy as np
 import torch
 
-from ..config import ddqn_cfg_from_config, ql_cfg_from_config
+from ..config import agent_layer_dims, ddqn_cfg_from_config, ql_cfg_from_config
 from .nes_common import chain_keys, fresh_agent_init, linear_init_bounds
 
 
@@ -18,8 +19,9 @@ class DdqnSeTask(object):
     def __init__(self, config, engine):
         self.engine = engine
         self.cfg = ddqn_cfg_from_config(config) if engine.name == "hip" else engine.cfg_from_config(config)
-        S, A, Hq = self.cfg.state_dim, self.cfg.num_actions, self.cfg.q_hidden
-        self.agent_bounds = torch.from_numpy(linear_init_bounds([(S, Hq), (Hq, A)])).to(engine.device)
+        dims = agent_layer_dims(self.cfg) if engine.name == "hip" else [(self.cfg.state_dim, self.cfg.q_hidden),
+                                                                         (self.cfg.q_hidden, self.cfg.num_actions)]
+        self.agent_bounds = torch.from_numpy(linear_init_bounds(dims)).to(engine.device)
 
     def make_inner(self, chains):
         return self.engine.make_inner(self.cfg, chains)
@@ -53,7 +55,7 @@ class QlRnTask(object):
 def select_task(config, engine, synthetic_env):
     agent_name = config["agents"]["gtn"]["agent_name"].lower()
     env_type = config["agents"]["gtn"]["synthetic_env_type"]
-    if agent_name == "ddqn" and env_type == 0:
+    if agent_name in ("ddqn", "duelingddqn") and env_type == 0:
         return DdqnSeTask(config, engine)
     if agent_name == "ql" and env_type == 1:
         real = synthetic_env.env.real_env

@@ -13,7 +13,11 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
     if env_name not in ENV_DIMS:
         raise NotImplementedError("real env '%s' has no device implementation yet" % env_name)
     e = config["envs"][env_name]
-    a = config["agents"]["ddqn"]
+    agent_key = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "ddqn"
+    if agent_key not in ("ddqn", "duelingddqn"):
+        raise NotImplementedError("ddqn_cfg_from_config: agent '%s'" % agent_key)
+    a = config["agents"][agent_key]
+    dueling = agent_key == "duelingddqn"
     S, A = ENV_DIMS[env_name]
     if a["same_action_num"] != 1:
         raise NotImplementedError("same_action_num != 1")
@@ -28,15 +32,27 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
                        q_prelu=0.25, batch_size=int(a["batch_size"]), rb_size=int(a["rb_size"]),
                        train_episodes=int(a["train_episodes"]), test_episodes=int(a["test_episodes"]),
                        init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]),
-                       grad_chunk=int(grad_chunk), rng_mode=int(rng_mode), solved_reward=float(val(e["solved_reward"])),
+                       grad_chunk=int(grad_chunk), rng_mode=int(rng_mode), agent_kind=1 if dueling else 0,
+                       feature_dim=int(a.get("feature_dim", 0)) if dueling else 0,
+                       solved_reward=float(val(e["solved_reward"])),
                        gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), eps_init=float(a["eps_init"]),
                        eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]),
                        adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8)
     for k, v in overrides.items():
         setattr(cfg, k, v)
-    if cfg.grad_chunk == 0:
-        cfg.grad_chunk = pick_grad_chunk(cfg)
+    if cfg.grad_chunk == 0 and cfg.agent_kind == 0:
+        cfg.grad_chunk = pick_grad_chunk(cfg)          # DuelingDDQN: one sequential chunk (grad_chunk stays 0)
     return cfg
+
+
+def agent_layer_dims(cfg):
+    """[(fan_in, fan_out), ...] of the agent's nn.Linear layers in flat state-dict order (for fresh-agent initialisation)."""
+    S, A, H, L = cfg.state_dim, cfg.num_actions, cfg.q_hidden, cfg.q_layers
+    if cfg.agent_kind == 1:
+        F = cfg.feature_dim
+        feat = [(S, H)] + [(H, H)] * (L - 1) + [(H, F)]
+        return feat + [(F, F), (F, 1)] + [(F, F), (F, A)]
+    return [(S, H)] + [(H, H)] * (L - 1) + [(H, A)]
 
 
 def pick_grad_chunk(cfg):

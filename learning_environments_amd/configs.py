@@ -25,6 +25,28 @@ def cartpole_syn_env_ddqn(num_workers=64, max_iterations=200):
     })
 
 
+def acrobot_syn_env_duelingddqn(num_workers=256, max_iterations=50):
+    """BASELINE config 3: Acrobot-v1 SE + DuelingDDQN (values = the published hyper-parameters of default_config_acrobot.yaml:
+    gtn :5-26 with agent_name DuelingDDQN, duelingddqn :61-80, env :131-139)."""
+    return copy.deepcopy({
+        "env_name": "Acrobot-v1", "device": "cuda", "render_env": False,
+        "agents": {
+            "gtn": {"mode": "multi", "max_iterations": max_iterations, "num_threads_per_worker": 1,
+                    "num_workers": num_workers, "noise_std": 0.05, "step_size": 1.0, "nes_step_size": False,
+                    "mirrored_sampling": True, "num_grad_evals": 1, "grad_eval_type": "mean", "weight_decay": 0.0,
+                    "time_mult": 3, "time_max": 300, "time_sleep_master": 0.2, "time_sleep_worker": 2,
+                    "score_transform_type": 7, "quit_when_solved": True, "synthetic_env_type": 0,
+                    "unsolved_weight": 10000, "agent_name": "DuelingDDQN"},
+            "duelingddqn": {"train_episodes": 1000, "test_episodes": 10, "init_episodes": 10, "batch_size": 128, "gamma": 0.99,
+                            "lr": 1e-3, "tau": 0.01, "eps_init": 1.0, "eps_min": 0.01, "eps_decay": 0.9, "rb_size": 100000,
+                            "same_action_num": 1, "activation_fn": "relu", "hidden_size": 128, "hidden_layer": 2,
+                            "feature_dim": 128, "print_rate": 1, "early_out_num": 10, "early_out_virtual_diff": 0.01},
+        },
+        "envs": {"Acrobot-v1": {"solved_reward": -100.0, "max_steps": 500, "activation_fn": "leakyrelu", "hidden_size": 128,
+                                "hidden_layer": 1, "info_dim": 0, "reward_env_type": 0}},
+    })
+
+
 def cliff_reward_env_ql(num_workers=128, max_iterations=50):
     """BASELINE config 4: Cliff gridworld RewardEnv (potential shaped, type 2) + tabular QL (values = the published
     hyper-parameters of default_config_gridworld_reward_env.yaml: gtn :5-26, ql :28-43, Cliff :126-133)."""
@@ -50,6 +72,6 @@ def fixed_work(config, train_episodes):
     """BASELINE.md §3 fixed-work variant: early-out disabled (solved_reward=+1e9) and a fixed number of train episodes,
     so both the GPU path and the CPU baseline do identical, data-independent amounts of work."""
     cfg = copy.deepcopy(config)
-    cfg["agents"]["ddqn"]["train_episodes"] = train_episodes
+    cfg["agents"][cfg["agents"]["gtn"]["agent_name"].lower()]["train_episodes"] = train_episodes
     cfg["envs"][cfg["env_name"]]["solved_reward"] = 1e9
     return cfg

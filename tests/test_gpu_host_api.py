@@ -193,3 +193,30 @@ def test_gtn_worker_file_protocol(tmp_path, monkeypatch):
     assert 0.5 * cfg["agents"]["gtn"]["noise_std"] < float(e.std()) < 2 * cfg["agents"]["gtn"]["noise_std"]
     d = res["synthetic_env"]["env.state_net.0.weight"] - data["synthetic_env_orig"]["env.state_net.0.weight"]
     assert torch.allclose(d, e, atol=1e-6)
+
+
+def test_gtn_master_acrobot_dueling_generation(tmp_path, monkeypatch):
+    """BASELINE config 3 shapes (Acrobot SE 9-128-{6,1,1}, DuelingDDQN 6-128-128-128 / 128-128-{1,3}, B=128) through
+    GTN_Master on a tiny step budget; the fitness triples equal an oracle evaluation of the same population."""
+    from learning_environments_amd.agents.nes_common import fresh_agent_init
+    from learning_environments_amd.configs import acrobot_syn_env_duelingddqn, fixed_work
+    from oracle import oracle as orc
+    cfg = fixed_work(acrobot_syn_env_duelingddqn(num_workers=2, max_iterations=1), 2)
+    cfg["envs"]["Acrobot-v1"]["max_steps"] = 10
+    cfg["agents"]["duelingddqn"].update(init_episodes=1, test_episodes=2)
+    m = _master_pair(cfg, tmp_path, monkeypatch)
+    assert m.cfg.agent_kind == 1 and m.inner.p_agent == 67460 and m.p_theta == 4872
+    theta0 = m.theta.cpu().numpy().copy()
+    gathered = m.evaluate_population(0).cpu().numpy()
+    eps = m.eps.cpu().numpy()
+    g = torch.Generator(device=m.engine.device)
+    g.manual_seed((m.seed * 1000003 + 0) % (2 ** 63 - 1))
+    _ = torch.randn((2, m.p_theta), generator=g, device=m.engine.device)
+    init = fresh_agent_init(m.agent_bounds, 6, g, m.engine.device).cpu().numpy()
+    ocfg = orc.ddqn_cfg_from_config(cfg, grad_chunk=0)
+    scores = orc.ddqn_se_population(ocfg, theta0, eps, init, seed=m.seed, generation=0, threads=6)
+    best, sign = orc.worker_best(scores[1::3], scores[2::3], True)
+    assert np.array_equal(gathered[:, 0], best) and np.array_equal(gathered[:, 1], scores[0::3])
+    assert np.array_equal(gathered[:, 2], sign.astype(np.float64))
+    mean_score, mean_list, _ = m.run()
+    assert len(mean_list) == 1 and -10.0 <= mean_score <= 0.0
