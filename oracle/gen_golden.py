@@ -650,8 +650,201 @@ def gen_g4d():
     save("g4d_dueling_learn", **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# config 5: TD3 on the HalfCheetah stand-in RewardEnv.  G4t: TD3.learn steps; G8t: full calc_score with tapes
+# ------------------------------------------------------------------------------------------------
+def _pack_td3(agent, target=False):
+    if target:
+        nets = (agent.actor_target, agent.critic_target_1, agent.critic_target_2)
+    else:
+        nets = (agent.actor, agent.critic_1, agent.critic_2)
+    return np.concatenate([pack_linear_params(n.state_dict(), "net.") for n in nets])
+
+
+def _td3_cfg(over=None, env_over=None):
+    cfg = load_cfg("default_config_halfcheetah_reward_env.yaml")
+    cfg["agents"]["td3"].update(over or {})
+    cfg["agents"]["td3"]["print_rate"] = int(1e9)
+    cfg["envs"]["HalfCheetah-v3"].update(env_over or {})
+    return cfg
+
+
+def gen_g4t():
+    from agents.TD3 import TD3
+    from envs.env_factory import EnvFactory
+    from utils import ReplayBuffer
+    out = {}
+    variants = [({"hidden_size": 24, "batch_size": 16, "policy_delay": 1}, 3), ({"hidden_size": 20, "batch_size": 12, "policy_delay": 2,
+                                                                                 "hidden_layer": 1, "activation_fn": "tanh"}, 4)]
+    for vi, (over, nsteps) in enumerate(variants):
+        cfg = _td3_cfg(over)
+        seed_all(470 + vi)
+        with quiet():
+            fac = EnvFactory(cfg)
+            real_env = fac.generate_real_env()
+            agent = TD3(env=real_env, max_action=real_env.get_max_action(), config=cfg)
+        a = cfg["agents"]["td3"]
+        B, S, A = a["batch_size"], 17, 6
+        rb = ReplayBuffer(state_dim=S, action_dim=A, device="cpu", max_size=300)
+        for i in range(120):
+            rb.add(torch.randn(S) * 0.5, torch.rand(A) * 2 - 1, torch.randn(S) * 0.5, torch.randn(1) * 0.3, torch.zeros(1) + (i % 17 == 0))
+        with torch.no_grad():
+            for net in (agent.actor_target, agent.critic_target_1, agent.critic_target_2):
+                for p in net.parameters():
+                    p.add_(torch.randn_like(p) * 0.03)
+        pre = "v%d_" % vi
+        out[pre + "meta"] = np.array([a["hidden_size"], a["hidden_layer"], ["identity", "relu", "leakyrelu", "tanh", "prelu"].index(a["activation_fn"]),
+                                      B, a["policy_delay"], nsteps], np.int64)
+        out[pre + "hparams"] = np.array([a["gamma"], a["lr"], a["tau"], a["policy_std"], a["policy_std_clip"]], np.float64)
+        out[pre + "params0"] = _pack_td3(agent)
+        out[pre + "targets0"] = _pack_td3(agent, True)
+        x = torch.randn(5, S); act = torch.rand(5, A) * 2 - 1
+        with torch.no_grad():
+            out[pre + "fwd_s"] = x.numpy(); out[pre + "fwd_a"] = act.numpy()
+            out[pre + "fwd_actor"] = agent.actor(x).numpy()
+            out[pre + "fwd_critic1"] = agent.critic_1(x, act).numpy().reshape(-1)
+        rows_all, noises, pars, tars = [], [], [], []
+        orig_randn_like = torch.randn_like
+        for step in range(nsteps):
+            idx = np.random.randint(0, rb.size, size=B)
+            rb.sample = lambda batch_size, _idx=idx: rb._sample_idx(_idx)
+            rows = np.concatenate([rb.state[idx].numpy(), rb.action[idx].numpy(), rb.next_state[idx].numpy(),
+                                   rb.reward[idx].numpy(), rb.done[idx].numpy()], axis=1)
+            holder = {}
+
+            def rec_randn_like(t, *a_, **k_):
+                v = orig_randn_like(t, *a_, **k_)
+                holder["n"] = v.numpy().copy()
+                return v
+            torch.randn_like = rec_randn_like
+            try:
+                agent.learn(rb, real_env, episode=50)
+            finally:
+                torch.randn_like = orig_randn_like
+            rows_all.append(rows); noises.append(holder["n"])
+            pars.append(_pack_td3(agent)); tars.append(_pack_td3(agent, True))
+        out[pre + "rows"] = np.stack(rows_all).astype(np.float32)
+        out[pre + "policy_noise"] = np.stack(noises).astype(np.float32)
+        out[pre + "params"] = np.stack(pars)
+        out[pre + "targets"] = np.stack(tars)
+    out["n_variants"] = np.array(len(variants))
+    save("g4t_td3_learn", **out)
+
+
+def gen_g8t(name, seed):
+    import json
+    import statistics
+    import agents.GTN_worker as gw
+    from agents.GTN import GTN_Worker
+    import gym.envs as genvs
+    import gym.spaces as gspaces
+    cfg = _td3_cfg({"train_episodes": 4, "init_episodes": 2, "batch_size": 16, "hidden_size": 24, "test_episodes": 2},
+                   {"max_steps": 7, "hidden_size": 20})
+    rec = dict(rand=[], act_noise=[], test_noise=[], policy_noise=[], replay=[], resets=[], steps=[], purpose=None, active=False)
+    orig_randn, orig_randn_like, orig_randint = torch.randn, torch.randn_like, np.random.randint
+    orig_box_sample, orig_reset = gspaces.Box.sample, genvs.CheetahStandinEnv.reset
+
+    def rec_randn(*a, **k):
+        v = orig_randn(*a, **k)
+        if rec["active"] and rec["purpose"] in ("act_noise", "test_noise"):
+            rec[rec["purpose"]].append(v.numpy().copy())
+        return v
+
+    def rec_randn_like(t, *a, **k):
+        v = orig_randn_like(t, *a, **k)
+        if rec["active"] and rec["purpose"] == "learn":
+            rec["policy_noise"].append(v.numpy().copy())
+        return v
+
+    def rec_randint(*a, **k):
+        v = orig_randint(*a, **k)
+        if rec["active"]:
+            rec["replay"].append(np.asarray(v).copy())
+        return v
+
+    def rec_box_sample(self):
+        v = orig_box_sample(self)
+        if rec["active"]:
+            rec["rand"].append(np.asarray(v).copy())
+        return v
+
+    def rec_reset(self):
+        obs = orig_reset(self)
+        if rec["active"]:
+            rec["resets"].append((id(self), np.array(self.state, np.float64).copy()))
+        return obs
+
+    orig_select_agent = gw.select_agent
+    holder = {}
+
+    def wrapped_select_agent(config, agent_name):
+        agent = orig_select_agent(config=config, agent_name=agent_name)
+        holder["init"] = _pack_td3(agent)
+
+        def wrap(fn, purpose):
+            def inner(*a, **k):
+                prev = rec["purpose"]
+                rec["purpose"] = purpose
+                try:
+                    return fn(*a, **k)
+                finally:
+                    rec["purpose"] = prev
+            return inner
+        agent.select_train_action = wrap(agent.select_train_action, "act_noise")
+        agent.select_test_action = wrap(agent.select_test_action, "test_noise")
+        agent.learn = wrap(agent.learn, "learn")
+        return agent
+
+    with quiet():
+        w = GTN_Worker(id=0, bohb_id=0)
+        seed_all(seed)
+        w.config = cfg
+        w.late_init(cfg)
+        w.timeout = 1e9
+        env = w.synthetic_env_orig
+        theta = pack_linear_params(env.state_dict(), "env.reward_net.")
+        orig_step = env.step
+
+        def rec_step(action, state=None):
+            s_before = np.asarray(env.env.state, np.float64).astype(np.float32)
+            ns, r, d = orig_step(action=action, state=state)
+            rec["steps"].append(dict(state=s_before, action=action.detach().numpy().astype(np.float32).copy(), next_state=ns.detach().numpy().copy(),
+                                     reward=float(r.item()), done=float(d.item())))
+            return ns, r, d
+        env.step = rec_step
+        torch.randn, torch.randn_like, np.random.randint = rec_randn, rec_randn_like, rec_randint
+        gspaces.Box.sample, genvs.CheetahStandinEnv.reset = rec_box_sample, rec_reset
+        gw.select_agent = wrapped_select_agent
+        train_reset_id = id(env.env.real_env.unwrapped)
+        try:
+            rec["active"] = True
+            agent = gw.select_agent(config=w.config, agent_name=w.agent_name)
+            real_env = w.env_factory.generate_real_env()
+            reward_list_train, episode_length_train, _ = agent.train(env=env, test_env=real_env, time_remaining=1e9)
+            reward_list_test, _, _ = agent.test(env=real_env, time_remaining=1e9)
+            rec["active"] = False
+        finally:
+            torch.randn, torch.randn_like, np.random.randint = orig_randn, orig_randn_like, orig_randint
+            gspaces.Box.sample, genvs.CheetahStandinEnv.reset = orig_box_sample, orig_reset
+            gw.select_agent = orig_select_agent
+    B = cfg["agents"]["td3"]["batch_size"]
+    save(name, config_json=np.array(json.dumps(cfg)), theta=theta, agent_init=holder["init"],
+         tape_rand_action=np.stack(rec["rand"][1::2]).astype(np.float32),          # get_random_action samples twice, returns the 2nd
+         tape_act_noise=np.stack(rec["act_noise"]).astype(np.float32), tape_test_noise=np.stack(rec["test_noise"]).astype(np.float32),
+         tape_policy_noise=np.stack(rec["policy_noise"]).astype(np.float32).reshape(-1, 6),
+         tape_replay_idx=np.stack(rec["replay"]).astype(np.int32),
+         tape_train_reset=np.array([s for (i, s) in rec["resets"] if i == train_reset_id]),
+         tape_test_reset=np.array([s for (i, s) in rec["resets"] if i != train_reset_id]),
+         tr_state=np.stack([s["state"] for s in rec["steps"]]), tr_action=np.stack([s["action"] for s in rec["steps"]]),
+         tr_next_state=np.stack([s["next_state"] for s in rec["steps"]]).astype(np.float32),
+         tr_reward=np.array([s["reward"] for s in rec["steps"]], np.float32),
+         reward_list_train=np.array(reward_list_train, np.float64), episode_length_train=np.array(episode_length_train, np.int32),
+         reward_list_test=np.array(reward_list_test, np.float64), score=np.array(statistics.mean(reward_list_test)),
+         final_params=_pack_td3(agent))
+
+
 def main():
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10"]
     os.makedirs(OUT, exist_ok=True)
     if "g1" in which:
         gen_g1()
@@ -663,6 +856,10 @@ def main():
         gen_g6()
     if "g7" in which:
         gen_g7()
+    if "g4t" in which:
+        gen_g4t()
+    if "g8t" in which:
+        gen_g8t("g8t_calc_score_cheetah_td3", seed=830)
     if "g4d" in which:
         gen_g4d()
     if "g8d" in which:

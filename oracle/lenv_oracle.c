@@ -1110,6 +1110,8 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
     return err;
 }
 
+#include "lenv_oracle_td3.inc"
+
 /* ------------------------------------------------------------------------------------------
  * NES worker / master math
  * ---------------------------------------------------------------------------------------- */

@@ -188,6 +188,55 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
                     int32_t *episode_len, double *final_test_returns, double *q_table_out, orc_ql_trace *trace,
                     orc_chain_result *res);
 
+/* ---- config 5: TD3 on a continuous-state RewardEnv (agents/TD3.py:13-135, envs/reward_env.py:61-133) ----
+ * real env: the documented HalfCheetah-v3 stand-in (tools/gen_cheetah_standin.py). */
+enum { ORC_ENV_CHEETAH_STANDIN = 2 };
+typedef struct {
+    int32_t env_id, state_dim, action_dim, max_steps;
+    int32_t rn_hidden, rn_layers, rn_act;
+    float rn_prelu;
+    int32_t reward_env_type;                 /* 0,1,2,5,6 */
+    int32_t hidden, layers, act;             /* actor / critic MLPs (models/actor_critic.py:11-19,64-71) */
+    float prelu;
+    int32_t batch_size, rb_size, train_episodes, test_episodes, init_episodes, early_out_num, policy_delay, rng_mode;
+    double solved_reward, gamma, lr, tau, action_std, policy_std, policy_std_clip, max_action;
+    double adam_beta1, adam_beta2, adam_eps;
+} orc_td3_cfg;
+
+typedef struct {
+    const float *rand_action;  int64_t n_rand_action;   /* rows of A: Box.sample() returned by get_random_action  env_wrapper.py:87-90 */
+    const float *act_noise;    int64_t n_act_noise;     /* rows of A: torch.randn(action_dim) in select_train_action  TD3.py:123 */
+    const float *test_noise;   int64_t n_test_noise;    /* rows of A: torch.randn(action_dim) in select_test_action   TD3.py:128 */
+    const float *policy_noise; int64_t n_policy_noise;  /* rows of B*A: torch.randn_like(actions) in learn            TD3.py:75 */
+    const int32_t *replay_idx; int64_t n_replay_idx;    /* rows of B */
+    const double *train_reset; int64_t n_train_reset;   /* rows of S */
+    const double *test_reset;  int64_t n_test_reset;    /* rows of S */
+} orc_td3_tapes;
+
+typedef struct {
+    int64_t cap, n;
+    float *action;      /* [cap,A] action passed to env.step */
+    float *state;       /* [cap,S] */
+    float *next_state;  /* [cap,S] */
+    float *reward;      /* [cap] shaped reward */
+} orc_td3_trace;
+
+double orc_log(double x);
+double orc_normal(uint64_t key, uint32_t stream, uint64_t n);      /* Box-Muller on two counter draws */
+void orc_cheetah_step(double x[17], const float a[6], double *reward);
+int64_t orc_td3_actor_params(const orc_td3_cfg *cfg);
+int64_t orc_td3_critic_params(const orc_td3_cfg *cfg);
+/* actor forward: tanh(net(s)) * max_action; critic forward: net(cat(s,a)) */
+int orc_td3_actor_forward(const orc_td3_cfg *cfg, const float *actor, const float *s, int64_t B, float *out);
+int orc_td3_critic_forward(const orc_td3_cfg *cfg, const float *critic, const float *s, const float *a, int64_t B, float *out);
+/* one TD3.learn step; params = [actor | critic1 | critic2], targets/m/v same layout; pows: {b1c,b2c,b1a,b2a} */
+int orc_td3_learn(const orc_td3_cfg *cfg, float *params, float *targets, float *adam_m, float *adam_v, double pows[4],
+                  int64_t total_it /*1-based*/, const float *rows, int64_t row_stride, const float *policy_noise /*[B,A] N(0,1)*/,
+                  float *losses /*[2] critic, actor (optional)*/);
+int orc_td3_rn_chain(const orc_td3_cfg *cfg, const float *rn_params, const float *agent_init /*[actor|critic1|critic2]*/,
+                     uint64_t rng_key, const orc_td3_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
+                     double *final_test_returns, orc_td3_trace *trace, orc_chain_result *res);
+
 /* ---- NES master/worker math ---- */
 /* GTN_worker.py:234-254: mirrored sampling pick; out[p] = {score_best, sign} */
 void orc_worker_best(const double *score_add, const double *score_sub, int64_t pop, int mirrored, double *score_best, float *sign);

@@ -62,6 +62,33 @@ class QlTrace(C.Structure):
                 ("next_state", C.POINTER(C.c_int32)), ("reward", C.POINTER(C.c_float)), ("done", C.POINTER(C.c_float))]
 
 
+class Td3Cfg(C.Structure):
+    _fields_ = [("env_id", C.c_int32), ("state_dim", C.c_int32), ("action_dim", C.c_int32), ("max_steps", C.c_int32),
+                ("rn_hidden", C.c_int32), ("rn_layers", C.c_int32), ("rn_act", C.c_int32), ("rn_prelu", C.c_float),
+                ("reward_env_type", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("act", C.c_int32),
+                ("prelu", C.c_float), ("batch_size", C.c_int32), ("rb_size", C.c_int32), ("train_episodes", C.c_int32),
+                ("test_episodes", C.c_int32), ("init_episodes", C.c_int32), ("early_out_num", C.c_int32),
+                ("policy_delay", C.c_int32), ("rng_mode", C.c_int32),
+                ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
+                ("action_std", C.c_double), ("policy_std", C.c_double), ("policy_std_clip", C.c_double),
+                ("max_action", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
+
+
+class Td3Tapes(C.Structure):
+    _fields_ = [("rand_action", C.POINTER(C.c_float)), ("n_rand_action", C.c_int64),
+                ("act_noise", C.POINTER(C.c_float)), ("n_act_noise", C.c_int64),
+                ("test_noise", C.POINTER(C.c_float)), ("n_test_noise", C.c_int64),
+                ("policy_noise", C.POINTER(C.c_float)), ("n_policy_noise", C.c_int64),
+                ("replay_idx", C.POINTER(C.c_int32)), ("n_replay_idx", C.c_int64),
+                ("train_reset", C.POINTER(C.c_double)), ("n_train_reset", C.c_int64),
+                ("test_reset", C.POINTER(C.c_double)), ("n_test_reset", C.c_int64)]
+
+
+class Td3Trace(C.Structure):
+    _fields_ = [("cap", C.c_int64), ("n", C.c_int64), ("action", C.POINTER(C.c_float)), ("state", C.POINTER(C.c_float)),
+                ("next_state", C.POINTER(C.c_float)), ("reward", C.POINTER(C.c_float))]
+
+
 class ChainResult(C.Structure):
     _fields_ = [("score", C.c_double), ("episodes_run", C.c_int32), ("train_steps", C.c_int64),
                 ("learn_steps", C.c_int64), ("test_steps", C.c_int64)]
@@ -398,3 +425,94 @@ def dueling_learn(cfg, online, target, m, v, b1pow, b2pow, rows):
     loss = lib().orc_dueling_learn(C.byref(cfg), _p(online, C.c_float), _p(target, C.c_float), _p(m, C.c_float),
                                    _p(v, C.c_float), C.byref(b1), C.byref(b2), _p(rows, C.c_float), C.c_int64(rows.shape[1]))
     return float(loss), online, target, m, v, b1.value, b2.value
+
+
+def td3_cfg_from_config(config, rng_mode=0, **overrides):
+    """Reference YAML dict (TD3 agent + reward env on the HalfCheetah stand-in) -> oracle config; fields read at
+    agents/TD3.py:13-29, agents/base_agent.py:9-26, envs/reward_env.py:8-27."""
+    env_name = config["env_name"]
+    assert env_name == "HalfCheetah-v3"
+    e = config["envs"][env_name]
+    a = config["agents"]["td3"]
+    assert a["same_action_num"] == 1
+    cfg = Td3Cfg(env_id=2, state_dim=17, action_dim=6, max_steps=int(e["max_steps"]), rn_hidden=int(e["hidden_size"]),
+                 rn_layers=int(e["hidden_layer"]), rn_act=ACT[e["activation_fn"]], rn_prelu=0.25,
+                 reward_env_type=int(e["reward_env_type"]), hidden=int(a["hidden_size"]), layers=int(a["hidden_layer"]),
+                 act=ACT[a["activation_fn"]], prelu=0.25, batch_size=int(a["batch_size"]), rb_size=int(a["rb_size"]),
+                 train_episodes=int(a["train_episodes"]), test_episodes=int(a["test_episodes"]),
+                 init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]),
+                 policy_delay=int(a["policy_delay"]), rng_mode=rng_mode, solved_reward=float(e["solved_reward"]),
+                 gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), action_std=float(a["action_std"]),
+                 policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=1.0,
+                 adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8)
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def td3_param_counts(cfg):
+    L = lib()
+    L.orc_td3_actor_params.restype = C.c_int64
+    L.orc_td3_critic_params.restype = C.c_int64
+    return int(L.orc_td3_actor_params(C.byref(cfg))), int(L.orc_td3_critic_params(C.byref(cfg)))
+
+
+def td3_actor_forward(cfg, actor, s):
+    actor, s = _f32(actor), _f32(s).reshape(-1, cfg.state_dim)
+    out = np.empty((s.shape[0], cfg.action_dim), np.float32)
+    lib().orc_td3_actor_forward(C.byref(cfg), _p(actor, C.c_float), _p(s, C.c_float), C.c_int64(s.shape[0]), _p(out, C.c_float))
+    return out
+
+
+def td3_critic_forward(cfg, critic, s, a):
+    critic, s, a = _f32(critic), _f32(s).reshape(-1, cfg.state_dim), _f32(a).reshape(-1, cfg.action_dim)
+    out = np.empty(s.shape[0], np.float32)
+    lib().orc_td3_critic_forward(C.byref(cfg), _p(critic, C.c_float), _p(s, C.c_float), _p(a, C.c_float), C.c_int64(s.shape[0]),
+                                 _p(out, C.c_float))
+    return out
+
+
+def td3_learn(cfg, params, targets, m, v, pows, total_it, rows, policy_noise):
+    params, targets, m, v = [_f32(t).copy() for t in (params, targets, m, v)]
+    rows, policy_noise = _f32(rows), _f32(policy_noise)
+    pw = (C.c_double * 4)(*pows)
+    losses = (C.c_float * 2)(float("nan"), float("nan"))
+    rc = lib().orc_td3_learn(C.byref(cfg), _p(params, C.c_float), _p(targets, C.c_float), _p(m, C.c_float), _p(v, C.c_float),
+                             pw, C.c_int64(total_it), _p(rows, C.c_float), C.c_int64(rows.shape[1]), _p(policy_noise, C.c_float), losses)
+    assert rc == 0
+    return params, targets, m, v, list(pw), (losses[0], losses[1])
+
+
+def make_td3_tapes(rand_action, act_noise, test_noise, policy_noise, replay_idx, train_reset, test_reset, A=6, S=17):
+    keep = [np.ascontiguousarray(rand_action, np.float32).reshape(-1, A), np.ascontiguousarray(act_noise, np.float32).reshape(-1, A),
+            np.ascontiguousarray(test_noise, np.float32).reshape(-1, A), np.ascontiguousarray(policy_noise, np.float32).reshape(-1, A),
+            np.ascontiguousarray(replay_idx, np.int32).reshape(-1), np.ascontiguousarray(train_reset, np.float64).reshape(-1, S),
+            np.ascontiguousarray(test_reset, np.float64).reshape(-1, S)]
+    t = Td3Tapes(_p(keep[0], C.c_float), keep[0].shape[0], _p(keep[1], C.c_float), keep[1].shape[0],
+                 _p(keep[2], C.c_float), keep[2].shape[0], _p(keep[3], C.c_float), keep[3].shape[0],
+                 _p(keep[4], C.c_int32), keep[4].size, _p(keep[5], C.c_double), keep[5].shape[0], _p(keep[6], C.c_double), keep[6].shape[0])
+    t._keep = keep
+    return t
+
+
+def td3_rn_chain(cfg, rn_params, agent_init, rng_key=0, tapes=None, trace_cap=0):
+    rn_params, agent_init = _f32(rn_params), _f32(agent_init)
+    E, T, S, A = cfg.train_episodes, cfg.test_episodes, cfg.state_dim, cfg.action_dim
+    ep_mean = np.full(max(E, 1), np.nan)
+    ep_len = np.zeros(max(E, 1), np.int32)
+    final = np.zeros(max(T, 1))
+    res = ChainResult()
+    tr, arrs = None, None
+    if trace_cap:
+        arrs = dict(action=np.zeros((trace_cap, A), np.float32), state=np.zeros((trace_cap, S), np.float32),
+                    next_state=np.zeros((trace_cap, S), np.float32), reward=np.zeros(trace_cap, np.float32))
+        tr = Td3Trace(trace_cap, 0, _p(arrs["action"], C.c_float), _p(arrs["state"], C.c_float), _p(arrs["next_state"], C.c_float),
+                      _p(arrs["reward"], C.c_float))
+    rc = lib().orc_td3_rn_chain(C.byref(cfg), _p(rn_params, C.c_float), _p(agent_init, C.c_float), C.c_uint64(rng_key),
+                                C.byref(tapes) if tapes is not None else None, _p(ep_mean, C.c_double), _p(ep_len, C.c_int32),
+                                _p(final, C.c_double), C.byref(tr) if tr is not None else None, C.byref(res))
+    out = dict(rc=rc, score=res.score, episodes_run=res.episodes_run, train_steps=res.train_steps, learn_steps=res.learn_steps,
+               test_steps=res.test_steps, episode_test_mean=ep_mean[:E], episode_len=ep_len[:E], final_test_returns=final[:T])
+    if tr is not None:
+        out["trace"] = {k: v[:tr.n] for k, v in arrs.items()}
+    return out

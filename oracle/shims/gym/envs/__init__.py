@@ -195,10 +195,59 @@ class AcrobotEnv(Env):
         return None
 
 
+class CheetahStandinEnv(Env):
+    """HalfCheetah-v3 STAND-IN (tools/gen_cheetah_standin.py): MuJoCo is unavailable, so config 5 runs -- on the reference side
+    too -- on this fixed 17-obs / 6-action saturated linear system.  Plain python float arithmetic, left to right."""
+
+    def __init__(self):
+        import json
+        import os
+        d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "cheetah_standin.json")))
+        self.A = [float.fromhex(v) for v in d["A"]]
+        self.B = [float.fromhex(v) for v in d["B"]]
+        self.c = [float.fromhex(v) for v in d["c"]]
+        high = np.full(17, np.inf, dtype=np.float32)
+        self.observation_space = spaces.Box(-high, high, dtype=np.float32)
+        self.action_space = spaces.Box(low=-1.0, high=1.0, shape=(6,), dtype=np.float32)
+        self.state = None
+        self.seed()
+
+    def seed(self, seed=None):
+        self.np_random, seed = seeding.np_random(seed)
+        return [seed]
+
+    def reset(self):
+        self.state = self.np_random.uniform(low=-0.1, high=0.1, size=(17,))
+        return np.array(self.state)
+
+    def step(self, action):
+        x = [float(v) for v in self.state]
+        a = [float(v) for v in np.asarray(action).reshape(-1)]
+        nx = []
+        for i in range(17):
+            acc = self.c[i]
+            for j in range(17):
+                acc = acc + self.A[i * 17 + j] * x[j]
+            for k in range(6):
+                acc = acc + self.B[i * 6 + k] * a[k]
+            nx.append(min(max(acc, -10.0), 10.0))
+        ctrl = 0.0
+        for k in range(6):
+            ctrl = ctrl + a[k] * a[k]
+        reward = nx[8] - 0.1 * ctrl
+        self.state = np.array(nx)
+        info = {"x_position": nx[0], "x_velocity": nx[8], "reward_run": nx[8], "reward_ctrl": -0.1 * ctrl}
+        return np.array(nx), reward, False, info
+
+    def render(self, mode='human'):
+        return None
+
+
 _REGISTRY = {
     'CartPole-v0': (CartPoleEnv, EnvSpec('CartPole-v0', 200, 195.0)),
     'CartPole-v1': (CartPoleEnv, EnvSpec('CartPole-v1', 500, 475.0)),
     'Acrobot-v1': (AcrobotEnv, EnvSpec('Acrobot-v1', 500, -100.0)),
+    'HalfCheetah-v3': (CheetahStandinEnv, EnvSpec('HalfCheetah-v3', 1000, 4800.0)),
 }
 
 

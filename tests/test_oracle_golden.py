@@ -275,3 +275,70 @@ def test_g8d_calc_score_acrobot_dueling(golden):
     assert np.array_equal(out["episode_len"], g["episode_length_train"])
     np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=1e-4)
     assert abs(out["score"] - float(g["score"])) <= 1e-4
+
+
+def _td3_cfg(meta, hp):
+    H, L, act, B, delay, _ = [int(v) for v in meta]
+    return orc.Td3Cfg(env_id=2, state_dim=17, action_dim=6, max_steps=10, rn_hidden=8, rn_layers=1, rn_act=4, rn_prelu=0.25,
+                      reward_env_type=2, hidden=H, layers=L, act=act, prelu=0.25, batch_size=B, rb_size=1000, train_episodes=1,
+                      test_episodes=1, init_episodes=0, early_out_num=1, policy_delay=delay, rng_mode=0, solved_reward=1e9,
+                      gamma=float(hp[0]), lr=float(hp[1]), tau=float(hp[2]), action_std=0.05, policy_std=float(hp[3]),
+                      policy_std_clip=float(hp[4]), max_action=1.0, adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8)
+
+
+def test_g4t_td3_forward_and_learn(golden):
+    g = golden("g4t_td3_learn")
+    for vi in range(int(g["n_variants"])):
+        pre = "v%d_" % vi
+        cfg = _td3_cfg(g[pre + "meta"], g[pre + "hparams"])
+        Pa, Pc = orc.td3_param_counts(cfg)
+        assert Pa + 2 * Pc == g[pre + "params0"].size
+        p0 = g[pre + "params0"]
+        np.testing.assert_allclose(orc.td3_actor_forward(cfg, p0[:Pa], g[pre + "fwd_s"]), g[pre + "fwd_actor"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(orc.td3_critic_forward(cfg, p0[Pa:Pa + Pc], g[pre + "fwd_s"], g[pre + "fwd_a"]), g[pre + "fwd_critic1"],
+                                   rtol=2e-6, atol=2e-6)
+        params, targets = p0.copy(), g[pre + "targets0"].copy()
+        m, v = np.zeros_like(params), np.zeros_like(params)
+        pows = [1.0, 1.0, 1.0, 1.0]
+        for step in range(int(g[pre + "meta"][5])):
+            params, targets, m, v, pows, _ = orc.td3_learn(cfg, params, targets, m, v, pows, step + 1, g[pre + "rows"][step],
+                                                           g[pre + "policy_noise"][step])
+            # lr = 3e-3: Adam moves a weight by lr*g/(|g|+1e-8) on its first steps, so a weight whose gradient is ~1e-8 is
+            # sensitive to rounding-level differences in g; a wrong sign or a missing term would show as >= 3e-3
+            np.testing.assert_allclose(params, g[pre + "params"][step], rtol=0, atol=1.5e-4, err_msg=pre + "params%d" % step)
+            np.testing.assert_allclose(targets, g[pre + "targets"][step], rtol=0, atol=1.5e-4, err_msg=pre + "targets%d" % step)
+            assert np.mean(np.abs(params - g[pre + "params"][step]) > 3e-6) < 0.01
+
+
+def test_cheetah_standin_matches_shim_run(golden):
+    """The stand-in dynamics inside the oracle reproduce, bit for bit, the next states / raw rewards of the shim env the
+    reference ran on (plain float64 arithmetic, same order)."""
+    import ctypes as C
+    g = golden("g8t_calc_score_cheetah_td3")
+    L = orc.lib()
+    x = (C.c_double * 17)(*g["tape_train_reset"][0])
+    rew = C.c_double()
+    for k in range(7):                       # first training episode
+        a = (C.c_float * 6)(*g["tr_action"][k])
+        L.orc_cheetah_step(x, a, C.byref(rew))
+        assert np.array_equal(np.array(list(x)).astype(np.float32), g["tr_next_state"][k])
+
+
+def test_g8t_calc_score_cheetah_td3(golden):
+    import json
+    g = golden("g8t_calc_score_cheetah_td3")
+    cfg = orc.td3_cfg_from_config(json.loads(str(g["config_json"])), rng_mode=1)
+    tapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
+                               g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    n = g["tr_reward"].size
+    out = orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 4)
+    assert out["rc"] == 0
+    tr = out["trace"]
+    assert tr["reward"].size == n
+    np.testing.assert_allclose(tr["action"], g["tr_action"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(tr["next_state"], g["tr_next_state"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(tr["reward"], g["tr_reward"], rtol=0, atol=5e-5)
+    assert np.array_equal(out["episode_len"], g["episode_length_train"])
+    np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(out["final_test_returns"], g["reward_list_test"], rtol=0, atol=2e-3)
+    assert abs(out["score"] - float(g["score"])) <= 2e-3
