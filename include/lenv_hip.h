@@ -38,7 +38,7 @@ enum {
 };
 
 enum { LENV_ACT_IDENTITY = 0, LENV_ACT_RELU = 1, LENV_ACT_LEAKYRELU = 2, LENV_ACT_TANH = 3, LENV_ACT_PRELU = 4 };
-enum { LENV_ENV_CARTPOLE = 0, LENV_ENV_ACROBOT = 1 };
+enum { LENV_ENV_CARTPOLE = 0, LENV_ENV_ACROBOT = 1, LENV_ENV_CHEETAH_STANDIN = 2 };
 enum { LENV_RNG_COUNTER = 0, LENV_RNG_TAPE = 1 };
 
 /* models/model_utils.py:4-39 */
@@ -208,6 +208,57 @@ int lenv_dueling_se_inner_loop(const lenv_ddqn_cfg *cfg /*HOST*/, const float *t
                                const int32_t *worker, const float *sign, const float *agent_init,
                                const uint64_t *rng_keys, const lenv_tapes *tapes /*HOST, may be NULL*/, int64_t chains,
                                void *workspace, size_t workspace_bytes, const lenv_inner_out *out /*HOST*/, void *stream);
+
+/*
+ * Config 5: fused inner loop for a TD3 agent on a RewardEnv over a continuous-state real env (agents/TD3.py:63-135,
+ * envs/reward_env.py:61-133).  Real env = the documented HalfCheetah-v3 STAND-IN (17 obs / 6 actions, see
+ * tools/gen_cheetah_standin.py; MuJoCo is unavailable).  theta = flat reward_net parameters (17 -> H -> 1, PReLU slope
+ * excluded); agent_init [chains, P] = actor | critic_1 | critic_2 in state-dict order (lenv_td3_num_params).
+ */
+typedef struct {
+    int32_t env_id, state_dim, action_dim, max_steps;
+    int32_t rn_hidden, rn_layers, rn_act;
+    float rn_prelu;
+    int32_t reward_env_type;                 /* 0,1,2,5,6 */
+    int32_t hidden, layers, act;             /* actor / critic MLPs (models/actor_critic.py:11-19,64-71) */
+    float prelu;
+    int32_t batch_size, rb_size, train_episodes, test_episodes, init_episodes, early_out_num, policy_delay, rng_mode;
+    double solved_reward, gamma, lr, tau, action_std, policy_std, policy_std_clip, max_action;
+    double adam_beta1, adam_beta2, adam_eps;
+} lenv_td3_cfg;
+
+/* RNG tapes (parity mode); per-chain rows, strides in ROWS (rows of A floats / B ints / S doubles as noted) */
+typedef struct {
+    const float *rand_action;  int64_t rand_action_stride;    /* rows of A: env.get_random_action()      env_wrapper.py:87-90 */
+    const float *act_noise;    int64_t act_noise_stride;      /* rows of A: randn in select_train_action TD3.py:123 */
+    const float *test_noise;   int64_t test_noise_stride;     /* rows of A: randn in select_test_action  TD3.py:128 */
+    const float *policy_noise; int64_t policy_noise_stride;   /* rows of A: randn_like(actions) in learn TD3.py:75 */
+    const int32_t *replay_idx; int64_t replay_idx_stride;     /* elements */
+    const double *train_reset; int64_t train_reset_stride;    /* rows of S */
+    const double *test_reset;  int64_t test_reset_stride;     /* rows of S */
+} lenv_td3_tapes;
+
+typedef struct {
+    double *score;              /* [chains] */
+    int64_t *stats;             /* [chains,4] episodes_run, train_steps, learn_steps, test_steps */
+    int32_t *status;            /* [chains] */
+    double *episode_test_mean;  /* [chains,train_episodes] */
+    int32_t *episode_len;       /* [chains,train_episodes] */
+    double *final_returns;      /* [chains,test_episodes] */
+    float *final_params;        /* [chains,P] */
+    int64_t trace_cap;
+    float *trace_action;        /* [chains,trace_cap,A] */
+    float *trace_state;         /* [chains,trace_cap,S] */
+    float *trace_next_state;    /* [chains,trace_cap,S] */
+    float *trace_reward;        /* [chains,trace_cap] shaped reward */
+} lenv_td3_out;
+
+size_t lenv_td3_rn_workspace_bytes(const lenv_td3_cfg *cfg /*HOST*/, int64_t chains);
+int64_t lenv_td3_num_params(const lenv_td3_cfg *cfg /*HOST*/, int64_t *actor_params /*HOST out*/, int64_t *critic_params /*HOST out*/);
+int lenv_td3_rn_inner_loop(const lenv_td3_cfg *cfg /*HOST*/, const float *theta, const float *eps, const int32_t *worker,
+                           const float *sign, const float *agent_init, const uint64_t *rng_keys,
+                           const lenv_td3_tapes *tapes /*HOST, may be NULL*/, int64_t chains, void *workspace,
+                           size_t workspace_bytes, const lenv_td3_out *out /*HOST*/, void *stream);
 
 /* Counter-RNG key of a chain (same function as the oracle's): kind 0 = theta, 1 = theta+eps, 2 = theta-eps. HOST. */
 uint64_t lenv_chain_key(uint64_t seed, uint64_t generation, uint64_t worker, uint64_t kind);

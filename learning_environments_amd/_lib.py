@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "liblenv_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 ACT = {"identity": 0, "relu": 1, "leakyrelu": 2, "tanh": 3, "prelu": 4}
-ENV = {"CartPole-v0": 0, "Acrobot-v1": 1}
+ENV = {"CartPole-v0": 0, "Acrobot-v1": 1, "HalfCheetah-v3": 2}
 RNG_COUNTER, RNG_TAPE = 0, 1
 
 ERRORS = {-1: ValueError, -2: NotImplementedError, -3: ValueError, -4: RuntimeError, -5: RuntimeError}
@@ -67,10 +67,36 @@ class QlOut(C.Structure):
                 ("trace_reward_done", C.c_void_p)]
 
 
+class Td3Cfg(C.Structure):
+    _fields_ = [("env_id", C.c_int32), ("state_dim", C.c_int32), ("action_dim", C.c_int32), ("max_steps", C.c_int32),
+                ("rn_hidden", C.c_int32), ("rn_layers", C.c_int32), ("rn_act", C.c_int32), ("rn_prelu", C.c_float),
+                ("reward_env_type", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("act", C.c_int32),
+                ("prelu", C.c_float), ("batch_size", C.c_int32), ("rb_size", C.c_int32), ("train_episodes", C.c_int32),
+                ("test_episodes", C.c_int32), ("init_episodes", C.c_int32), ("early_out_num", C.c_int32),
+                ("policy_delay", C.c_int32), ("rng_mode", C.c_int32),
+                ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
+                ("action_std", C.c_double), ("policy_std", C.c_double), ("policy_std_clip", C.c_double),
+                ("max_action", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
+
+
+class Td3Tapes(C.Structure):
+    _fields_ = [("rand_action", C.c_void_p), ("rand_action_stride", C.c_int64), ("act_noise", C.c_void_p), ("act_noise_stride", C.c_int64),
+                ("test_noise", C.c_void_p), ("test_noise_stride", C.c_int64), ("policy_noise", C.c_void_p), ("policy_noise_stride", C.c_int64),
+                ("replay_idx", C.c_void_p), ("replay_idx_stride", C.c_int64), ("train_reset", C.c_void_p), ("train_reset_stride", C.c_int64),
+                ("test_reset", C.c_void_p), ("test_reset_stride", C.c_int64)]
+
+
+class Td3Out(C.Structure):
+    _fields_ = [("score", C.c_void_p), ("stats", C.c_void_p), ("status", C.c_void_p), ("episode_test_mean", C.c_void_p),
+                ("episode_len", C.c_void_p), ("final_returns", C.c_void_p), ("final_params", C.c_void_p), ("trace_cap", C.c_int64),
+                ("trace_action", C.c_void_p), ("trace_state", C.c_void_p), ("trace_next_state", C.c_void_p), ("trace_reward", C.c_void_p)]
+
+
 EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv_se_step_population",
            "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_lds_bytes", "lenv_ddqn_se_inner_loop",
            "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population", "lenv_dueling_se_workspace_bytes",
-           "lenv_dueling_num_params", "lenv_dueling_se_inner_loop"]
+           "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
+           "lenv_td3_rn_inner_loop"]
 
 
 def build(force=False):
@@ -125,6 +151,13 @@ def lib():
         L.lenv_dueling_num_params.argtypes = [C.POINTER(DdqnCfg)]
         L.lenv_dueling_se_inner_loop.restype = C.c_int
         L.lenv_dueling_se_inner_loop.argtypes = L.lenv_ddqn_se_inner_loop.argtypes
+        L.lenv_td3_rn_workspace_bytes.restype = C.c_size_t
+        L.lenv_td3_rn_workspace_bytes.argtypes = [C.POINTER(Td3Cfg), C.c_int64]
+        L.lenv_td3_num_params.restype = C.c_int64
+        L.lenv_td3_num_params.argtypes = [C.POINTER(Td3Cfg), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.lenv_td3_rn_inner_loop.restype = C.c_int
+        L.lenv_td3_rn_inner_loop.argtypes = [C.POINTER(Td3Cfg), vp, vp, vp, vp, vp, vp, C.POINTER(Td3Tapes), C.c_int64, vp, C.c_size_t,
+                                             C.POINTER(Td3Out), vp]
         L.lenv_rn_shape_population.restype = C.c_int
         L.lenv_rn_shape_population.argtypes = [C.POINTER(QlCfg), vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
         L.lenv_nes_worker_best.restype = C.c_int

@@ -11,6 +11,7 @@
 
 #include "../../include/lenv_hip.h"
 #include "lenv_tanh_table.h"
+#include "lenv_cheetah_standin.h"
 
 #define LENV_WAVE 64
 
@@ -109,7 +110,54 @@ __host__ __device__ __forceinline__ uint64_t rng_u64(uint64_t key, uint32_t stre
 __device__ __forceinline__ double u64_to_unit(uint64_t u) { return (double)(u >> 11) * (1.0 / 9007199254740992.0); }
 __device__ __forceinline__ uint32_t u64_to_below(uint64_t u, uint32_t n) { return (uint32_t)(((u >> 32) * (uint64_t)n) >> 32); }
 
-enum { STREAM_EPS = 0, STREAM_ACTION = 1, STREAM_REPLAY = 2, STREAM_TRAIN_RESET = 3, STREAM_TEST_RESET = 4 };
+enum { STREAM_EPS = 0, STREAM_ACTION = 1, STREAM_REPLAY = 2, STREAM_TRAIN_RESET = 3, STREAM_TEST_RESET = 4,
+       STREAM_TD3_RAND_ACTION = 5, STREAM_TD3_ACT_NOISE = 6, STREAM_TD3_TEST_NOISE = 7, STREAM_TD3_POLICY_NOISE = 8 };
+
+// natural log, same sequence as the oracle's orc_log (fdlibm scheme, fma Horner); used by the counter-mode Box-Muller
+__device__ __forceinline__ double det_log(double x)
+{
+    unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    int e = (int)((u >> 52) & 0x7ff) - 1023;
+    u = (u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = __longlong_as_double((long long)u);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    double p = 1.479819860511658591e-01;
+    p = fma64(p, z, 1.531383769920937332e-01);
+    p = fma64(p, z, 1.818357216161805012e-01);
+    p = fma64(p, z, 2.222219843214978396e-01);
+    p = fma64(p, z, 2.857142874366239149e-01);
+    p = fma64(p, z, 3.999999999940941908e-01);
+    p = fma64(p, z, 6.666666666666735130e-01);
+    const double R = z * p;
+    const double hfsq = 0.5 * f * f;
+    const double de = (double)e;
+    return de * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + de * 1.90821492927058770002e-10)) - f);
+}
+
+// N(0,1) = sqrt(-2 ln u1) * cos(2 pi u2) on counter draws 2n, 2n+1 (oracle: orc_normal)
+__device__ __forceinline__ double det_normal(uint64_t key, uint32_t stream, uint64_t n)
+{
+    const double u1 = (double)((rng_u64(key, stream, 2 * n) >> 11) + 1) * (1.0 / 9007199254740992.0);
+    const double u2 = u64_to_unit(rng_u64(key, stream, 2 * n + 1));
+    return __builtin_sqrt(-2.0 * det_log(u1)) * det_cos(6.283185307179586 * u2);
+}
+
+// HalfCheetah-v3 STAND-IN constants (tools/gen_cheetah_standin.py; a build decision, not reference behaviour)
+static __device__ const double lenv_cheetah_A[17 * 17] = LENV_CHEETAH_A_INIT;
+static __device__ const double lenv_cheetah_B[17 * 6] = LENV_CHEETAH_B_INIT;
+static __device__ const double lenv_cheetah_c[17] = LENV_CHEETAH_C_INIT;
+
+// row i of x' = clip(c + A x + B a, -10, 10), accumulated left to right without FMA (oracle: orc_cheetah_step)
+__device__ __forceinline__ double cheetah_row(int i, const double *x, const float *a)
+{
+    double acc = lenv_cheetah_c[i];
+    for (int j = 0; j < 17; ++j) acc = acc + lenv_cheetah_A[i * 17 + j] * x[j];
+    for (int k = 0; k < 6; ++k) acc = acc + lenv_cheetah_B[i * 6 + k] * (double)a[k];
+    return acc < -10.0 ? -10.0 : (acc > 10.0 ? 10.0 : acc);
+}
 
 __device__ __forceinline__ float act_fwd(int act, float prelu, float z)
 {

@@ -1,0 +1,562 @@
+// td3_rn_inner_loop.hip -- fused NES inner loop for config 5: a TD3 agent trained on a RewardEnv (learned potential shaping
+// around a continuous-state real env), one 512-thread workgroup per chain.
+//
+// Replaces GTN_Worker.calc_score (agents/GTN_worker.py:187-221) with
+//   TD3.learn / select_train_action / select_test_action   agents/TD3.py:63-135
+//   Actor_TD3, Critic_Q                                      models/actor_critic.py:11-19,64-71
+//   BaseAgent.train / test, ReplayBuffer                     agents/base_agent.py:64-227, utils.py:9-72
+//   EnvWrapper.step (real branch) -> RewardEnv.step          envs/env_wrapper.py:49-70, envs/reward_env.py:61-133
+//   real env: the documented HalfCheetah-v3 STAND-IN (tools/gen_cheetah_standin.py; MuJoCo cannot exist on either box)
+//
+// Same structure as the DuelingDDQN kernel: actor + twin critics + their targets + Adam state (59 016 parameters x5 at the
+// config-5 shapes) live in a per-chain HBM arena; every layer product is the canonical-order workgroup GEMM of
+// lenv_gemm.cuh (batch 192 = two row blocks); the reward network (17-128-1) is staged in LDS and evaluated once per env
+// step (phi(s') of step t is phi(s) of step t+1).  Gaussian noises come from RNG tapes (parity mode) or from the
+// counter RNG through a Box-Muller with deterministic log / cos (production mode).
+#include "lenv_gemm.cuh"
+
+namespace lenv {
+
+constexpr int T3_MAXL = 2;     // hidden layers of actor / critic
+constexpr int T3_MAXW = 128;
+constexpr int T3_S = 17, T3_A = 6, T3_SA = 23;
+
+struct MlpOff { int in, H, L, out; int oW[T3_MAXL + 1], ob[T3_MAXL + 1]; int P; };
+
+struct Td3Args {
+    lenv_td3_cfg cfg;
+    const float *theta, *eps; const int32_t *worker; const float *sign;
+    const float *agent_init; const uint64_t *rng_keys;
+    lenv_td3_tapes tapes;
+    float *arena; int64_t arena_stride;
+    lenv_td3_out out;
+    int64_t rb_cap; int RS;
+    MlpOff actor, critic;
+    int P, P_rn;
+    int64_t a_params, a_targets, a_m, a_v, a_grad, a_replay, a_xc, a_xn, a_xa, a_hc1[T3_MAXL], a_hc2[T3_MAXL], a_ha[T3_MAXL],
+        a_ht[T3_MAXL], a_d[2], a_dx, a_act, a_th, a_dz, a_meter;
+};
+
+__global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
+{
+    extern __shared__ __align__(16) float lds[];
+    const lenv_td3_cfg &cfg = a.cfg;
+    const int tid = threadIdx.x;
+    const int64_t chain = blockIdx.x;
+    constexpr int S = T3_S, A = T3_A, SA = T3_SA;
+    const int H = cfg.hidden, L = cfg.layers, B = cfg.batch_size, T = cfg.test_episodes, Hrn = cfg.rn_hidden, RS = a.RS, P = a.P;
+    const int Pa = a.actor.P, Pc = a.critic.P;
+    const int act_id = cfg.act;
+    const float prelu = cfg.prelu, ma = (float)cfg.max_action;
+
+    // ---- LDS carve-up ----
+    float *Ps = lds, *Qs = Ps + GT_RB * GT_LD;
+    float *rn_w = Qs + GT_RB * GT_LD;                     // reward net: W0 [Hrn][S] | b0 [Hrn] | Wout [Hrn] | bout
+    float *rn_h = rn_w + ((a.P_rn + 3) & ~3);             // [Hrn]
+    float *q1 = rn_h + ((Hrn + 3) & ~3);                  // [B]
+    float *q2 = q1 + B, *tq1 = q2 + B, *tq2 = tq1 + B, *rr = tq2 + B, *dd = rr + B, *dq1 = dd + B, *dq2 = dq1 + B;
+    float *misc = dq2 + B;                                // [64]
+    double *xs_d = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(misc + 64) + 7) & ~(uintptr_t)7);   // [17] train env state
+    double *xt_d = xs_d + 20;                             // [T][17] test env states
+    double *ret = xt_d + 17 * T;                          // [T]
+    float *ep_rew = reinterpret_cast<float *>(ret + T);   // [T]
+    float *state = ep_rew + T;                            // [20] current observation (fp32)
+    float *action = state + 20;                           // [8]
+    float *newrow = action + 8;                           // [48]
+    volatile float *ctrl = misc;
+    volatile int *ictrl = reinterpret_cast<volatile int *>(misc + 32);
+
+    float *arena = a.arena + chain * a.arena_stride;
+    float *params = arena + a.a_params, *targets = arena + a.a_targets, *adam_m = arena + a.a_m, *adam_v = arena + a.a_v;
+    float *grad = arena + a.a_grad, *rb = arena + a.a_replay;
+    float *xc = arena + a.a_xc, *xn = arena + a.a_xn, *xa = arena + a.a_xa;      // [B][SA] critic inputs
+    float *dxb = arena + a.a_dx, *actb = arena + a.a_act, *thb = arena + a.a_th, *dzb = arena + a.a_dz;
+    float *hc1[T3_MAXL], *hc2[T3_MAXL], *ha[T3_MAXL], *ht[T3_MAXL], *dbuf[2] = { arena + a.a_d[0], arena + a.a_d[1] };
+    for (int l = 0; l < T3_MAXL; ++l) { hc1[l] = arena + a.a_hc1[l]; hc2[l] = arena + a.a_hc2[l]; ha[l] = arena + a.a_ha[l]; ht[l] = arena + a.a_ht[l]; }
+    double *meter = reinterpret_cast<double *>(arena + a.a_meter);
+
+    // ---- stage the perturbed reward network (GTN_worker.py:165-175) and the fresh agent (TD3.py:31-39) ----
+    {
+        const float sg = a.eps ? a.sign[chain] : 0.0f;
+        const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P_rn : nullptr;
+        if (cfg.reward_env_type != 0)
+            for (int i = tid; i < a.P_rn; i += DNT) rn_w[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
+    }
+    for (int p = tid; p < P; p += DNT) {
+        const float w = a.agent_init[chain * P + p];
+        params[p] = w; targets[p] = w; adam_m[p] = 0.0f; adam_v[p] = 0.0f;
+    }
+    if (tid < 64) misc[tid] = 0.0f;
+    __syncthreads();
+
+    const uint64_t key = a.rng_keys ? a.rng_keys[chain] : 0;
+    const bool tape = cfg.rng_mode == LENV_RNG_TAPE;
+    const int rtype = cfg.reward_env_type;
+    int status = 0;
+    int64_t n_rand = 0, n_actn = 0, n_testn = 0, n_test_ep = 0, learn_it = 0;
+    int train_steps = 0, test_steps = 0, episodes_run = 0;
+    double pows[4] = { 1.0, 1.0, 1.0, 1.0 };
+    const int rb_cap = (int)a.rb_cap;
+
+    // ---- generic MLP forward over I rows (row stride ldx); hidden activations to hid[l][I][H] -------------------------
+    // final_tanh: out = tanh(net)*max_action (Actor_TD3.forward) with tanh values to th_out; else out = net (Critic_Q).
+    auto mlp_forward = [&](const float *par, const MlpOff &mo, const float *X, int ldx, int I, float *const *hid, float *out,
+                           int ldo, int ocol, bool final_tanh, float *th_out) {
+        for (int i0 = 0; i0 < I; i0 += GT_I) {
+            const int ib = I - i0 < GT_I ? I - i0 : GT_I;
+            const float *in = X + (int64_t)i0 * ldx;
+            int n_in = mo.in, ldin = ldx;
+            for (int l = 0; l < mo.L; ++l) {
+                const float *W = par + mo.oW[l], *bb = par + mo.ob[l];
+                float *o = hid[l] + (int64_t)i0 * mo.H;
+                wg_gemm(in, ldin, 1, W, n_in, 1, ib, mo.H, n_in, Ps, Qs,
+                        [&](int i, int j, float acc) { o[i * mo.H + j] = act_fwd(act_id, prelu, acc + bb[j]); });
+                __syncthreads();
+                in = o; n_in = mo.H; ldin = mo.H;
+            }
+            const float *W = par + mo.oW[mo.L], *bb = par + mo.ob[mo.L];
+            wg_gemm(in, ldin, 1, W, n_in, 1, ib, mo.out, n_in, Ps, Qs, [&](int i, int j, float acc) {
+                const float v = acc + bb[j];
+                if (final_tanh) {
+                    const float t = det_tanhf(lenv_tanh_table, v);
+                    if (th_out) th_out[(i0 + i) * mo.out + j] = t;
+                    out[(int64_t)(i0 + i) * ldo + ocol + j] = t * ma;
+                } else out[(int64_t)(i0 + i) * ldo + ocol + j] = v;
+            });
+            __syncthreads();
+        }
+    };
+
+    // ---- generic MLP backward: dOut [I][out] -> parameter gradients gpar (may be null) and input gradient dX (may be null)
+    auto mlp_backward = [&](const float *par, const MlpOff &mo, const float *X, int ldx, int I, float *const *hid, const float *dOut,
+                            float *gpar, float *dX) {
+        const int Hh = mo.H, O = mo.out;
+        if (gpar) {
+            wg_gemm(dOut, 1, O, hid[mo.L - 1], 1, Hh, O, Hh, I, Ps, Qs, [&](int i, int j, float acc) { gpar[mo.oW[mo.L] + i * Hh + j] = acc; });
+            if (tid < O) { float s = 0.0f; for (int b = 0; b < I; ++b) s = s + dOut[b * O + tid]; gpar[mo.ob[mo.L] + tid] = s; }
+        }
+        float *dcur = dbuf[0];
+        for (int i0 = 0; i0 < I; i0 += GT_I) {
+            const int ib = I - i0 < GT_I ? I - i0 : GT_I;
+            const float *hl = hid[mo.L - 1] + (int64_t)i0 * Hh;
+            float *dc = dcur + (int64_t)i0 * Hh;
+            wg_gemm(dOut + (int64_t)i0 * O, O, 1, par + mo.oW[mo.L], 1, Hh, ib, Hh, O, Ps, Qs,
+                    [&](int i, int j, float acc) { dc[i * Hh + j] = act_bwd(act_id, prelu, hl[i * Hh + j], acc); });
+        }
+        __syncthreads();
+        for (int l = mo.L - 1; l >= 0; --l) {
+            const int n_in = l == 0 ? mo.in : Hh;
+            const float *inp = l == 0 ? X : hid[l - 1];
+            const int ldin = l == 0 ? ldx : Hh;
+            const float *dc = dcur;
+            if (gpar) {
+                wg_gemm(dc, 1, Hh, inp, 1, ldin, Hh, n_in, I, Ps, Qs, [&](int i, int j, float acc) { gpar[mo.oW[l] + i * n_in + j] = acc; });
+                for (int k = tid; k < Hh; k += DNT) { float s = 0.0f; for (int b = 0; b < I; ++b) s = s + dc[b * Hh + k]; gpar[mo.ob[l] + k] = s; }
+            }
+            if (l > 0) {
+                float *dn = dbuf[(mo.L - l) & 1];
+                for (int i0 = 0; i0 < I; i0 += GT_I) {
+                    const int ib = I - i0 < GT_I ? I - i0 : GT_I;
+                    const float *hp = hid[l - 1] + (int64_t)i0 * Hh;
+                    float *dnb = dn + (int64_t)i0 * Hh;
+                    wg_gemm(dc + (int64_t)i0 * Hh, Hh, 1, par + mo.oW[l], 1, n_in, ib, n_in, Hh, Ps, Qs,
+                            [&](int i, int j, float acc) { dnb[i * n_in + j] = act_bwd(act_id, prelu, hp[i * n_in + j], acc); });
+                }
+                dcur = dn;
+            } else if (dX) {
+                for (int i0 = 0; i0 < I; i0 += GT_I) {
+                    const int ib = I - i0 < GT_I ? I - i0 : GT_I;
+                    float *dxo = dX + (int64_t)i0 * n_in;
+                    wg_gemm(dc + (int64_t)i0 * Hh, Hh, 1, par + mo.oW[0], 1, n_in, ib, n_in, Hh, Ps, Qs,
+                            [&](int i, int j, float acc) { dxo[i * n_in + j] = acc; });
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    // torch.optim.Adam single-tensor step on params[p0, p0+n) (pows index pi), thread 0 publishes the bias corrections
+    auto adam = [&](int p0, int n, int pi) {
+        if (tid == 0) {
+            pows[pi] *= cfg.adam_beta1; pows[pi + 1] *= cfg.adam_beta2;
+            ctrl[10] = (float)(-(cfg.lr / (1.0 - pows[pi])));
+            ctrl[11] = (float)__builtin_sqrt(1.0 - pows[pi + 1]);
+        }
+        __syncthreads();
+        const float neg_step = ctrl[10], bc2_sqrt = ctrl[11];
+        const float w1 = (float)(1.0 - cfg.adam_beta1), w2 = (float)(1.0 - cfg.adam_beta2), beta2 = (float)cfg.adam_beta2, aeps = (float)cfg.adam_eps;
+        for (int p = p0 + tid; p < p0 + n; p += DNT) {
+            const float g = grad[p];
+            const float m = fma32(w1, g - adam_m[p], adam_m[p]);
+            float v = adam_v[p] * beta2;
+            v = fma32(w2 * g, g, v);
+            const float denom = __builtin_sqrtf(v) / bc2_sqrt + aeps;
+            params[p] = params[p] + (neg_step * m) / denom;
+            adam_m[p] = m; adam_v[p] = v;
+        }
+        __syncthreads();
+    };
+
+    // phi(obs) = reward_net(obs) for the observation in `obs` (LDS/global, S floats) -> ctrl[slot]
+    auto rn_eval = [&](const float *obs, int slot) {
+        if (rtype == 0) { if (tid == 0) ctrl[slot] = 0.0f; __syncthreads(); return; }
+        const float *W0 = rn_w, *b0 = rn_w + Hrn * S, *Wo = b0 + Hrn, *bo = Wo + Hrn;
+        for (int j = tid; j < Hrn; j += DNT) {
+            float z = 0.0f;
+            for (int k = 0; k < S; ++k) z = fma32(obs[k], W0[j * S + k], z);
+            rn_h[j] = act_fwd(cfg.rn_act, cfg.rn_prelu, z + b0[j]);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float acc = 0.0f;
+            for (int j = 0; j < Hrn; ++j) acc = fma32(rn_h[j], Wo[j], acc);
+            ctrl[slot] = acc + bo[0];
+        }
+        __syncthreads();
+    };
+
+    // ---- real-env test phase: T episodes in lock-step (the stand-in never terminates: every episode runs max_steps) ----
+    auto test_phase = [&]() {
+        for (int e = tid; e < T * S; e += DNT) {
+            const int te = e / S, i = e - te * S;
+            const int64_t row = n_test_ep + te;
+            double v;
+            if (tape) { if (row >= a.tapes.test_reset_stride) { status = -5; v = 0.0; } else v = a.tapes.test_reset[(chain * a.tapes.test_reset_stride + row) * S + i]; }
+            else v = -0.1 + 0.2 * u64_to_unit(rng_u64(key, STREAM_TEST_RESET, (uint64_t)(row * S + i)));
+            xt_d[e] = v;
+        }
+        if (tid < T) ep_rew[tid] = 0.0f;
+        __syncthreads();
+        float *xt = xn;                                    // [T][S] fp32 observations (xn is free outside learn)
+        float *at = xa;                                    // [T][A] actions
+        for (int t = 0; t < cfg.max_steps; ++t) {
+            for (int e = tid; e < T * S; e += DNT) xt[e] = (float)xt_d[e];
+            __syncthreads();
+            mlp_forward(params, a.actor, xt, S, T, ht, at, A, 0, true, nullptr);
+            // select_test_action (TD3.py:126-129): (actor(s) + randn(A)*action_std*max_action).clamp(-max, max)
+            for (int e = tid; e < T * A; e += DNT) {
+                const int te = e / A, k = e - te * A;
+                const int64_t n = (n_testn + (int64_t)te * cfg.max_steps + t) * A + k;
+                float zn;
+                if (tape) { if (n >= a.tapes.test_noise_stride * A) { status = -7; zn = 0.0f; } else zn = a.tapes.test_noise[chain * a.tapes.test_noise_stride * A + n]; }
+                else zn = (float)det_normal(key, STREAM_TD3_TEST_NOISE, (uint64_t)n);
+                const float v = at[e] + (zn * (float)cfg.action_std) * ma;
+                at[e] = v < -ma ? -ma : (v > ma ? ma : v);
+            }
+            __syncthreads();
+            double nx = 0.0;
+            if (tid < T * S) { const int te = tid / S, i = tid - te * S; nx = cheetah_row(i, xt_d + te * S, at + te * A); }
+            __syncthreads();
+            if (tid < T * S) xt_d[tid] = nx;
+            __syncthreads();
+            if (tid < T) {
+                double ctrlc = 0.0;
+                for (int k = 0; k < A; ++k) ctrlc = ctrlc + (double)at[tid * A + k] * (double)at[tid * A + k];
+                const double rew = xt_d[tid * S + 8] - 0.1 * ctrlc;
+                ep_rew[tid] = ep_rew[tid] + (float)rew;
+            }
+            __syncthreads();
+        }
+        if (tid < T) ret[tid] = (double)ep_rew[tid];
+        n_test_ep += T;
+        n_testn += (int64_t)T * cfg.max_steps;
+        test_steps += T * cfg.max_steps;
+        __syncthreads();
+    };
+
+    const float g32 = (float)cfg.gamma;
+    for (int episode = 0; episode < cfg.train_episodes; ++episode) {
+        const bool learning = episode >= cfg.init_episodes;
+        // env.reset(): RewardEnv.reset -> real_env.reset() (reward_env.py:141-143)
+        for (int i = tid; i < S; i += DNT) {
+            double v;
+            if (tape) { if (episode >= a.tapes.train_reset_stride) { status = -5; v = 0.0; } else v = a.tapes.train_reset[(chain * a.tapes.train_reset_stride + episode) * S + i]; }
+            else v = -0.1 + 0.2 * u64_to_unit(rng_u64(key, STREAM_TRAIN_RESET, (uint64_t)((int64_t)episode * S + i)));
+            xs_d[i] = v;
+            state[i] = (float)v;
+        }
+        __syncthreads();
+        rn_eval(state, 12);                                // phi(s) of the reset state
+        int ep_len = 0;
+        for (int t = 0; t < cfg.max_steps; ++t) {
+            const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
+            const int new_pos = train_steps % rb_cap;
+            // ---- select_train_action (TD3.py:118-124) ----
+            if (!learning) {
+                if (tid < A) {
+                    float v;
+                    if (tape) { if (n_rand >= a.tapes.rand_action_stride) { status = -3; v = 0.0f; } else v = a.tapes.rand_action[(chain * a.tapes.rand_action_stride + n_rand) * A + tid]; }
+                    else v = (float)(-1.0 + 2.0 * u64_to_unit(rng_u64(key, STREAM_TD3_RAND_ACTION, (uint64_t)(n_rand * A + tid))));
+                    action[tid] = v;
+                }
+                ++n_rand;
+                __syncthreads();
+            } else {
+                mlp_forward(params, a.actor, state, S, 1, ht, action, A, 0, true, nullptr);
+                if (tid < A) {
+                    float zn;
+                    if (tape) { if (n_actn >= a.tapes.act_noise_stride) { status = -7; zn = 0.0f; } else zn = a.tapes.act_noise[(chain * a.tapes.act_noise_stride + n_actn) * A + tid]; }
+                    else zn = (float)det_normal(key, STREAM_TD3_ACT_NOISE, (uint64_t)(n_actn * A + tid));
+                    const float v = action[tid] + (zn * (float)cfg.action_std) * ma;
+                    action[tid] = v < -ma ? -ma : (v > ma ? ma : v);
+                }
+                ++n_actn;
+                __syncthreads();
+            }
+            // ---- EnvWrapper.step -> RewardEnv.step -> real_env.step + TimeLimit ----
+            double nx = 0.0;
+            if (tid < S) nx = cheetah_row(tid, xs_d, action);
+            if (tid == 64) {
+                double ctrlc = 0.0;
+                for (int k = 0; k < A; ++k) ctrlc = ctrlc + (double)action[k] * (double)action[k];
+                xs_d[18] = ctrlc;
+            }
+            __syncthreads();
+            if (tid < S) { xs_d[tid] = nx; newrow[tid] = state[tid]; newrow[S + A + tid] = (float)nx; }
+            if (tid >= 64 && tid < 64 + A) newrow[S + tid - 64] = action[tid - 64];
+            __syncthreads();
+            rn_eval(newrow + S + A, 13);                   // phi(s')
+            if (tid == 0) {
+                const double rew = xs_d[8] - 0.1 * xs_d[18];
+                const float r32 = (float)rew, phi_s = ctrl[12], phi_s2 = ctrl[13];
+                float shaped;                              // RewardEnv._calc_reward (reward_env.py:81-110)
+                switch (rtype) {
+                case 0: shaped = r32; break;
+                case 1: shaped = g32 * phi_s2 - phi_s; break;
+                case 2: shaped = (r32 + g32 * phi_s2) - phi_s; break;
+                case 5: shaped = phi_s2; break;
+                default: shaped = r32 + phi_s2; break;
+                }
+                const int dn = t + 1 >= cfg.max_steps;
+                newrow[2 * S + A] = shaped; newrow[2 * S + A + 1] = dn ? 1.0f : 0.0f;
+                ctrl[12] = phi_s2;
+            }
+            __syncthreads();
+            if (tid < 2 * S + A + 2) rb[(int64_t)new_pos * RS + tid] = newrow[tid];
+            if (a.out.trace_reward && train_steps < a.out.trace_cap) {
+                const int64_t k = chain * a.out.trace_cap + train_steps;
+                if (tid < S) { a.out.trace_state[k * S + tid] = newrow[tid]; a.out.trace_next_state[k * S + tid] = newrow[S + A + tid]; }
+                if (tid < A) a.out.trace_action[k * A + tid] = newrow[S + tid];
+                if (tid == 0) a.out.trace_reward[k] = newrow[2 * S + A];
+            }
+            const float done_now = newrow[2 * S + A + 1];
+            __syncthreads();
+            if (tid < S) state[tid] = newrow[S + A + tid];
+            ++ep_len; ++train_steps;
+            __syncthreads();
+
+            if (learning) {
+                // ================= TD3.learn (TD3.py:63-116) =================
+                for (int b = tid; b < B; b += DNT) {
+                    const int64_t n = learn_it * B + b;
+                    int idx;
+                    if (tape) {
+                        if (n >= a.tapes.replay_idx_stride) { status = -4; idx = 0; } else idx = a.tapes.replay_idx[chain * a.tapes.replay_idx_stride + n];
+                        if (idx < 0 || idx >= size_after) { status = -6; idx = 0; }
+                    } else idx = (int)u64_to_below(rng_u64(key, STREAM_REPLAY, (uint64_t)n), (uint32_t)size_after);
+                    const float *row = rb + (int64_t)idx * RS;
+                    for (int i = 0; i < SA; ++i) xc[b * SA + i] = row[i];                  // [s, a]
+                    for (int i = 0; i < S; ++i) xn[b * SA + i] = row[S + A + i];           // s' (action part filled below)
+                    rr[b] = row[2 * S + A]; dd[b] = row[2 * S + A + 1];
+                }
+                __syncthreads();
+                // next_actions = (actor_target(s') + clamp(randn*policy_std)).clamp(-max, max)
+                mlp_forward(targets, a.actor, xn, SA, B, ht, xn, SA, S, true, nullptr);
+                for (int e = tid; e < B * A; e += DNT) {
+                    const int b = e / A, k = e - b * A;
+                    const int64_t n = (learn_it * B + b) * A + k;
+                    float zn;
+                    if (tape) { if (n >= a.tapes.policy_noise_stride * A) { status = -8; zn = 0.0f; } else zn = a.tapes.policy_noise[chain * a.tapes.policy_noise_stride * A + n]; }
+                    else zn = (float)det_normal(key, STREAM_TD3_POLICY_NOISE, (uint64_t)n);
+                    float nz = zn * (float)cfg.policy_std;
+                    const float clipv = (float)cfg.policy_std_clip;
+                    nz = nz < -clipv ? -clipv : (nz > clipv ? clipv : nz);
+                    const float v = xn[b * SA + S + k] + nz;
+                    xn[b * SA + S + k] = v < -ma ? -ma : (v > ma ? ma : v);
+                }
+                __syncthreads();
+                mlp_forward(targets + Pa, a.critic, xn, SA, B, ht, tq1, 1, 0, false, nullptr);
+                mlp_forward(targets + Pa + Pc, a.critic, xn, SA, B, ht, tq2, 1, 0, false, nullptr);
+                mlp_forward(params + Pa, a.critic, xc, SA, B, hc1, q1, 1, 0, false, nullptr);
+                mlp_forward(params + Pa + Pc, a.critic, xc, SA, B, hc2, q2, 1, 0, false, nullptr);
+                {
+                    const float norm = (float)(2.0 / (double)B);
+                    for (int b = tid; b < B; b += DNT) {
+                        const float tq = tq1[b] < tq2[b] ? tq1[b] : tq2[b];
+                        const float y = rr[b] + ((1.0f - dd[b]) * g32) * tq;       // rewards + (1 - dones) * gamma * target_Q
+                        dq1[b] = norm * (q1[b] - y);
+                        dq2[b] = norm * (q2[b] - y);
+                    }
+                }
+                __syncthreads();
+                mlp_backward(params + Pa, a.critic, xc, SA, B, hc1, dq1, grad + Pa, nullptr);
+                mlp_backward(params + Pa + Pc, a.critic, xc, SA, B, hc2, dq2, grad + Pa + Pc, nullptr);
+                adam(Pa, 2 * Pc, 0);                       // critic_optimizer: critic_1 then critic_2 parameters
+                ++learn_it;
+                if (learn_it % cfg.policy_delay == 0) {
+                    // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1
+                    for (int e = tid; e < B * S; e += DNT) { const int b = e / S, i = e - b * S; xa[b * SA + i] = xc[b * SA + i]; }
+                    __syncthreads();
+                    mlp_forward(params, a.actor, xc, SA, B, ha, xa, SA, S, true, thb);
+                    mlp_forward(params + Pa, a.critic, xa, SA, B, hc1, q1, 1, 0, false, nullptr);
+                    const float dqa = -(1.0f / (float)B);
+                    for (int b = tid; b < B; b += DNT) dq1[b] = dqa;
+                    __syncthreads();
+                    mlp_backward(params + Pa, a.critic, xa, SA, B, hc1, dq1, nullptr, dxb);
+                    for (int e = tid; e < B * A; e += DNT) {
+                        const int b = e / A, k = e - b * A;
+                        const float th = thb[e];
+                        dzb[e] = (dxb[b * SA + S + k] * ma) * fma32(-th, th, 1.0f);   // d(tanh(z)*max_action)
+                    }
+                    __syncthreads();
+                    mlp_backward(params, a.actor, xc, SA, B, ha, dzb, grad, nullptr);
+                    adam(0, Pa, 2);
+                    const float tau = (float)cfg.tau, omt = (float)(1.0 - cfg.tau);
+                    for (int p = tid; p < P; p += DNT) targets[p] = tau * params[p] + omt * targets[p];
+                    __syncthreads();
+                }
+            }
+            if (done_now > 0.5f) break;
+        }
+        ++episodes_run;
+        if (tid == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
+        __syncthreads();
+        test_phase();
+        if (tid == 0) {
+            double sm = 0.0;
+            for (int i = 0; i < T; ++i) sm += ret[i];
+            const double tm = sm / (double)T;
+            meter[episode] = tm;
+            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
+            int brk = 0;
+            if (learning) {
+                int lo = episode + 1 - cfg.early_out_num; if (lo < 0) lo = 0;
+                double s2 = 0.0;
+                for (int i = lo; i <= episode; ++i) s2 += meter[i];
+                if (s2 / ((double)(episode + 1 - lo) + 1e-9) >= cfg.solved_reward) brk = 1;
+            }
+            ictrl[3] = brk;
+        }
+        __syncthreads();
+        const int brk = ictrl[3];
+        __syncthreads();
+        if (brk) break;
+    }
+    test_phase();
+    if (tid == 0) {
+        double sm = 0.0;
+        for (int i = 0; i < T; ++i) sm += ret[i];
+        a.out.score[chain] = sm / (double)T;
+        if (a.out.final_returns) for (int i = 0; i < T; ++i) a.out.final_returns[chain * T + i] = ret[i];
+        if (a.out.stats) {
+            a.out.stats[chain * 4 + 0] = episodes_run; a.out.stats[chain * 4 + 1] = train_steps;
+            a.out.stats[chain * 4 + 2] = learn_it; a.out.stats[chain * 4 + 3] = test_steps;
+        }
+        const double nan = __builtin_nan("");
+        for (int e = episodes_run; e < cfg.train_episodes; ++e) {
+            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + e] = nan;
+            if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = 0;
+        }
+    }
+    if (a.out.final_params) for (int p = tid; p < P; p += DNT) a.out.final_params[chain * P + p] = params[p];
+    if (a.out.status && status != 0) atomicMin(&a.out.status[chain], status);
+}
+
+}  // namespace lenv
+
+using namespace lenv;
+
+static void mlp_off(MlpOff &m, int in, int H, int L, int out)
+{
+    m.in = in; m.H = H; m.L = L; m.out = out;
+    int o = 0, n_in = in;
+    for (int l = 0; l < L; ++l) { m.oW[l] = o; o += H * n_in; m.ob[l] = o; o += H; n_in = H; }
+    m.oW[L] = o; o += out * H; m.ob[L] = o; o += out;
+    m.P = o;
+}
+
+static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
+{
+    const int H = cfg->hidden, L = cfg->layers, B = cfg->batch_size, T = cfg->test_episodes, Hrn = cfg->rn_hidden;
+    if (cfg->env_id != LENV_ENV_CHEETAH_STANDIN || cfg->state_dim != T3_S || cfg->action_dim != T3_A) return LENV_ERR_UNSUPPORTED;
+    const int t = cfg->reward_env_type;
+    if (!(t == 0 || t == 1 || t == 2 || t == 5 || t == 6)) return LENV_ERR_UNSUPPORTED;      // info-vector types: next
+    if (L < 1 || L > T3_MAXL || H < 1 || H > T3_MAXW || B < 1 || B > 2 * GT_I || T < 1 || T * T3_S > DNT || cfg->rn_layers != 1 || Hrn < 1 ||
+        cfg->policy_delay < 1 || cfg->max_steps < 1 || cfg->train_episodes < 0)
+        return LENV_ERR_UNSUPPORTED;
+    mlp_off(a.actor, T3_S, H, L, T3_A);
+    mlp_off(a.critic, T3_SA, H, L, 1);
+    a.P = a.actor.P + 2 * a.critic.P;
+    a.P_rn = T3_S * Hrn + Hrn + Hrn + 1;
+    a.RS = (2 * T3_S + T3_A + 2 + 3) & ~3;
+    int64_t cap = (int64_t)cfg->train_episodes * cfg->max_steps;
+    if (cap > cfg->rb_size) cap = cfg->rb_size;
+    a.rb_cap = cap < 1 ? 1 : cap;
+    const int RB = B > T ? B : T;                               // rows of the batch buffers
+    int64_t off = 0;
+    auto take = [&](int64_t n) { int64_t r = off; off += (n + 3) & ~(int64_t)3; return r; };
+    a.a_params = take(a.P); a.a_targets = take(a.P); a.a_m = take(a.P); a.a_v = take(a.P); a.a_grad = take(a.P);
+    a.a_replay = take(a.rb_cap * a.RS);
+    a.a_xc = take((int64_t)RB * T3_SA); a.a_xn = take((int64_t)RB * T3_SA); a.a_xa = take((int64_t)RB * T3_SA);
+    for (int l = 0; l < T3_MAXL; ++l) { a.a_hc1[l] = take((int64_t)RB * H); a.a_hc2[l] = take((int64_t)RB * H); a.a_ha[l] = take((int64_t)RB * H); a.a_ht[l] = take((int64_t)RB * H); }
+    a.a_d[0] = take((int64_t)RB * H); a.a_d[1] = take((int64_t)RB * H);
+    a.a_dx = take((int64_t)RB * T3_SA); a.a_act = take((int64_t)RB * T3_A); a.a_th = take((int64_t)RB * T3_A); a.a_dz = take((int64_t)RB * T3_A);
+    a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
+    a.arena_stride = (off + 63) & ~(int64_t)63;
+    const size_t lds_floats = 2 * (size_t)GT_RB * GT_LD + ((a.P_rn + 3) & ~3) + ((Hrn + 3) & ~3) + 8 * (size_t)B + 64 + 2 + 2 * (20 + 17 * (size_t)T + T) + T + 20 + 8 + 48 + 16;
+    *lds_bytes = lds_floats * sizeof(float);
+    if (*lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
+    return LENV_OK;
+}
+
+extern "C" size_t lenv_td3_rn_workspace_bytes(const lenv_td3_cfg *cfg, int64_t chains)
+{
+    if (!cfg || chains < 0) return 0;
+    Td3Args a;
+    size_t lds;
+    if (td3_layout(cfg, a, &lds) != LENV_OK) return 0;
+    return (size_t)chains * a.arena_stride * sizeof(float) + 256;
+}
+
+extern "C" int64_t lenv_td3_num_params(const lenv_td3_cfg *cfg, int64_t *actor_params, int64_t *critic_params)
+{
+    if (!cfg) return LENV_ERR_INVALID;
+    Td3Args a;
+    size_t lds;
+    const int rc = td3_layout(cfg, a, &lds);
+    if (rc != LENV_OK) return rc;
+    if (actor_params) *actor_params = a.actor.P;
+    if (critic_params) *critic_params = a.critic.P;
+    return a.P;
+}
+
+extern "C" int lenv_td3_rn_inner_loop(const lenv_td3_cfg *cfg, const float *theta, const float *eps, const int32_t *worker,
+                                      const float *sign, const float *agent_init, const uint64_t *rng_keys,
+                                      const lenv_td3_tapes *tapes, int64_t chains, void *workspace, size_t workspace_bytes,
+                                      const lenv_td3_out *out, void *stream)
+{
+    if (!cfg || !agent_init || !out || !out->score || !workspace || chains < 0) return LENV_ERR_INVALID;
+    if (!theta && cfg->reward_env_type != 0) return LENV_ERR_INVALID;
+    if (eps && (!worker || !sign)) return LENV_ERR_INVALID;
+    if (cfg->rng_mode == LENV_RNG_TAPE && !tapes) return LENV_ERR_INVALID;
+    if (cfg->rng_mode == LENV_RNG_COUNTER && !rng_keys) return LENV_ERR_INVALID;
+    if (chains == 0) return LENV_OK;
+    Td3Args a;
+    size_t lds_bytes;
+    const int rc = td3_layout(cfg, a, &lds_bytes);
+    if (rc != LENV_OK) return rc;
+    if (workspace_bytes < (size_t)chains * a.arena_stride * sizeof(float)) return LENV_ERR_WORKSPACE;
+    a.cfg = *cfg;
+    a.theta = theta; a.eps = eps; a.worker = worker; a.sign = sign; a.agent_init = agent_init; a.rng_keys = rng_keys;
+    if (tapes) a.tapes = *tapes; else a.tapes = lenv_td3_tapes{};
+    a.arena = static_cast<float *>(workspace);
+    a.out = *out;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(td3_rn_inner_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return LENV_ERR_LAUNCH;
+    if (out->status) {
+        e = hipMemsetAsync(out->status, 0, sizeof(int32_t) * chains, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return LENV_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(td3_rn_inner_kernel, dim3((unsigned)chains), dim3(DNT), lds_bytes, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}

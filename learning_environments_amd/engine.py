@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import DdqnCfg, InnerOut, MlpDesc, QlCfg, QlOut, Tapes
+from ._lib import DdqnCfg, InnerOut, MlpDesc, QlCfg, QlOut, Tapes, Td3Cfg, Td3Out, Td3Tapes
 
 
 def require_device():
@@ -201,6 +201,63 @@ class QlInnerLoop(object):
                                               _ptr(rng_keys), C.byref(t) if t is not None else None, self.chains,
                                               C.byref(self.out), _stream())
         _lib.check(rc, "lenv_ql_rn_inner_loop")
+        return self.score
+
+
+class Td3InnerLoop(object):
+    """Owns the workspace/outputs of lenv_td3_rn_inner_loop for a fixed (cfg, chains)."""
+
+    def __init__(self, cfg, chains, want_episode_stats=True, want_final_params=False, trace_cap=0):
+        self.dev = require_device()
+        self.cfg, self.chains = cfg, int(chains)
+        L = _lib.lib()
+        pa, pc = C.c_int64(), C.c_int64()
+        self.p_agent = int(L.lenv_td3_num_params(C.byref(cfg), C.byref(pa), C.byref(pc)))
+        _lib.check(min(self.p_agent, 0), "lenv_td3_num_params")
+        self.p_actor, self.p_critic = pa.value, pc.value
+        self.p_theta = cfg.state_dim * cfg.rn_hidden + 2 * cfg.rn_hidden + 1
+        self.ws_bytes = int(L.lenv_td3_rn_workspace_bytes(C.byref(cfg), self.chains))
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
+        E, T, S, A = cfg.train_episodes, cfg.test_episodes, cfg.state_dim, cfg.action_dim
+        self.score = torch.zeros(self.chains, dtype=torch.float64, device=self.dev)
+        self.stats = torch.zeros((self.chains, 4), dtype=torch.int64, device=self.dev)
+        self.status = torch.zeros(self.chains, dtype=torch.int32, device=self.dev)
+        self.episode_test_mean = self.episode_len = self.final_returns = self.final_params = None
+        if want_episode_stats:
+            self.episode_test_mean = torch.zeros((self.chains, max(E, 1)), dtype=torch.float64, device=self.dev)
+            self.episode_len = torch.zeros((self.chains, max(E, 1)), dtype=torch.int32, device=self.dev)
+            self.final_returns = torch.zeros((self.chains, T), dtype=torch.float64, device=self.dev)
+        if want_final_params:
+            self.final_params = torch.zeros((self.chains, self.p_agent), dtype=torch.float32, device=self.dev)
+        self.trace_cap = int(trace_cap)
+        self.trace = None
+        if trace_cap:
+            self.trace = dict(action=torch.zeros((self.chains, trace_cap, A), dtype=torch.float32, device=self.dev),
+                              state=torch.zeros((self.chains, trace_cap, S), dtype=torch.float32, device=self.dev),
+                              next_state=torch.zeros((self.chains, trace_cap, S), dtype=torch.float32, device=self.dev),
+                              reward=torch.zeros((self.chains, trace_cap), dtype=torch.float32, device=self.dev))
+        tr = self.trace or {}
+        self.out = Td3Out(_ptr(self.score), _ptr(self.stats), _ptr(self.status), _ptr(self.episode_test_mean), _ptr(self.episode_len),
+                          _ptr(self.final_returns), _ptr(self.final_params), self.trace_cap, _ptr(tr.get("action")),
+                          _ptr(tr.get("state")), _ptr(tr.get("next_state")), _ptr(tr.get("reward")))
+
+    def run(self, theta, eps, worker, sign, agent_init, rng_keys=None, tapes=None):
+        _chk(theta, torch.float32, "theta"); _chk(eps, torch.float32, "eps"); _chk(worker, torch.int32, "worker")
+        _chk(sign, torch.float32, "sign"); _chk(agent_init, torch.float32, "agent_init")
+        if agent_init.shape != (self.chains, self.p_agent):
+            raise ValueError("agent_init must be [chains, %d]" % self.p_agent)
+        t = None
+        if tapes is not None:
+            t = Td3Tapes(_ptr(tapes["rand_action"]), tapes["rand_action"].shape[1], _ptr(tapes["act_noise"]), tapes["act_noise"].shape[1],
+                         _ptr(tapes["test_noise"]), tapes["test_noise"].shape[1], _ptr(tapes["policy_noise"]), tapes["policy_noise"].shape[1],
+                         _ptr(tapes["replay_idx"]), tapes["replay_idx"].shape[1], _ptr(tapes["train_reset"]), tapes["train_reset"].shape[1],
+                         _ptr(tapes["test_reset"]), tapes["test_reset"].shape[1])
+        if rng_keys is not None:
+            _chk(rng_keys, torch.int64, "rng_keys")
+        rc = _lib.lib().lenv_td3_rn_inner_loop(C.byref(self.cfg), _ptr(theta), _ptr(eps), _ptr(worker), _ptr(sign), _ptr(agent_init),
+                                               _ptr(rng_keys), C.byref(t) if t is not None else None, self.chains,
+                                               _ptr(self.workspace), self.ws_bytes, C.byref(self.out), _stream())
+        _lib.check(rc, "lenv_td3_rn_inner_loop")
         return self.score
 
 
