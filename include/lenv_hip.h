@@ -260,6 +260,19 @@ int lenv_td3_rn_inner_loop(const lenv_td3_cfg *cfg /*HOST*/, const float *theta,
                            const lenv_td3_tapes *tapes /*HOST, may be NULL*/, int64_t chains, void *workspace,
                            size_t workspace_bytes, const lenv_td3_out *out /*HOST*/, void *stream);
 
+/*
+ * Batched forward of one MLP in the flat layout above: y [rows,out] = net(x [rows,in]) (models/model_utils.py:31-39;
+ * behind Critic_DQN / Actor_TD3.net / Critic_Q / reward_net calls of the one-step API).
+ */
+int lenv_mlp_forward(const lenv_mlp_desc *d /*HOST*/, const float *params, const float *x, int64_t rows, float *y, void *stream);
+
+/* HalfCheetah-v3 STAND-IN reset / step for n instances (state [n,17] float64, action [n,6], obs [n,17]); same contract as
+ * lenv_real_env_reset / lenv_real_env_step. */
+int lenv_cheetah_standin_reset(const uint64_t *keys, const int64_t *episode, int64_t n, double *state, float *obs,
+                               int32_t *elapsed, void *stream);
+int lenv_cheetah_standin_step(int32_t max_steps, int64_t n, const float *action, double *state, int32_t *elapsed,
+                              float *obs, float *reward, float *done, void *stream);
+
 /* Counter-RNG key of a chain (same function as the oracle's): kind 0 = theta, 1 = theta+eps, 2 = theta-eps. HOST. */
 uint64_t lenv_chain_key(uint64_t seed, uint64_t generation, uint64_t worker, uint64_t kind);
 

@@ -96,7 +96,7 @@ EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv
            "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_lds_bytes", "lenv_ddqn_se_inner_loop",
            "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population", "lenv_dueling_se_workspace_bytes",
            "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
-           "lenv_td3_rn_inner_loop"]
+           "lenv_td3_rn_inner_loop", "lenv_mlp_forward", "lenv_cheetah_standin_reset", "lenv_cheetah_standin_step"]
 
 
 def build(force=False):
@@ -158,6 +158,12 @@ def lib():
         L.lenv_td3_rn_inner_loop.restype = C.c_int
         L.lenv_td3_rn_inner_loop.argtypes = [C.POINTER(Td3Cfg), vp, vp, vp, vp, vp, vp, C.POINTER(Td3Tapes), C.c_int64, vp, C.c_size_t,
                                              C.POINTER(Td3Out), vp]
+        L.lenv_mlp_forward.restype = C.c_int
+        L.lenv_mlp_forward.argtypes = [C.POINTER(MlpDesc), vp, vp, C.c_int64, vp, vp]
+        L.lenv_cheetah_standin_reset.restype = C.c_int
+        L.lenv_cheetah_standin_reset.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp]
+        L.lenv_cheetah_standin_step.restype = C.c_int
+        L.lenv_cheetah_standin_step.argtypes = [C.c_int32, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
         L.lenv_rn_shape_population.restype = C.c_int
         L.lenv_rn_shape_population.argtypes = [C.POINTER(QlCfg), vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
         L.lenv_nes_worker_best.restype = C.c_int

@@ -62,7 +62,7 @@ class GTN_Master(GTN_Base):
             raise NotImplementedError('Unknown parameter for grad_eval_type: ' + str(self.grad_eval_type))
         if self.num_grad_evals != 1:
             raise NotImplementedError("num_grad_evals != 1")
-        if self.agent_name.lower() not in ("ddqn", "duelingddqn", "ql"):
+        if self.agent_name.lower() not in ("ddqn", "duelingddqn", "ql", "td3"):
             raise NotImplementedError("inner agent '%s' has no fused kernel yet" % self.agent_name)
 
         self.time_elapsed_list = [None] * self.num_workers

@@ -5,11 +5,12 @@ combination owns one fused kernel:
     DDQN on a VirtualEnv (synthetic_env_type 0)   -> lenv_ddqn_se_inner_loop   (BASELINE configs 1-2, Acrobot-DDQN)
     DuelingDDQN on a VirtualEnv                   -> lenv_dueling_se_inner_loop (BASELINE config 3)
     QL   on a RewardEnv over a gridworld (type 1) -> lenv_ql_rn_inner_loop     (BASELINE config 4)
+    TD3  on a RewardEnv over the HalfCheetah stand-in -> lenv_td3_rn_inner_loop (BASELINE config 5)
 Anything else raises NotImplementedError, like the reference does for unknown agents."""
 import numpy as np
 import torch
 
-from ..config import agent_layer_dims, ddqn_cfg_from_config, ql_cfg_from_config
+from ..config import agent_layer_dims, ddqn_cfg_from_config, ql_cfg_from_config, td3_cfg_from_config, td3_layer_dims
 from .nes_common import chain_keys, fresh_agent_init, linear_init_bounds
 
 
@@ -52,6 +53,24 @@ class QlRnTask(object):
         return False          # a fresh QL agent is an all-zero table (QL.py:25)
 
 
+class Td3RnTask(object):
+    name = "td3_rn"
+
+    def __init__(self, config, engine):
+        self.engine = engine
+        self.cfg = td3_cfg_from_config(config)
+        self.agent_bounds = torch.from_numpy(linear_init_bounds(td3_layer_dims(self.cfg))).to(engine.device)
+
+    def make_inner(self, chains):
+        return self.engine.make_inner_td3(self.cfg, chains, want_episode_stats=False)
+
+    def scores(self, inner, theta, eps, chain_worker, chain_sign, keys_t, agent_init):
+        return self.engine.inner_scores_td3(inner, theta, eps, chain_worker, chain_sign, agent_init, keys_t)
+
+    def needs_agent_init(self):
+        return True
+
+
 def select_task(config, engine, synthetic_env):
     agent_name = config["agents"]["gtn"]["agent_name"].lower()
     env_type = config["agents"]["gtn"]["synthetic_env_type"]
@@ -62,4 +81,6 @@ def select_task(config, engine, synthetic_env):
         if not hasattr(real, "tables"):
             raise NotImplementedError("QL needs a discrete (gridworld) real env")
         return QlRnTask(config, engine, real.tables)
+    if agent_name == "td3" and env_type == 1:
+        return Td3RnTask(config, engine)
     raise NotImplementedError("inner agent '%s' on synthetic_env_type %s has no fused kernel yet" % (agent_name, env_type))

@@ -3,7 +3,7 @@ import ctypes as C
 
 from . import _lib
 
-ENV_DIMS = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3)}
+ENV_DIMS = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3), "HalfCheetah-v3": (17, 6)}
 
 
 def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **overrides):
@@ -91,3 +91,39 @@ def ql_cfg_from_config(config, tables, rng_mode=_lib.RNG_COUNTER, **overrides):
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg
+
+
+def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
+    """TD3 agent + RewardEnv on the HalfCheetah stand-in.  Fields read at reference agents/TD3.py:13-29,
+    agents/base_agent.py:9-26, envs/reward_env.py:8-27, envs/env_wrapper.py:106-110 (max_action)."""
+    env_name = config["env_name"]
+    if env_name != "HalfCheetah-v3":
+        raise NotImplementedError("TD3 fused kernel: real env '%s'" % env_name)
+    e = config["envs"][env_name]
+    a = config["agents"]["td3"]
+    if a["same_action_num"] != 1:
+        raise NotImplementedError("same_action_num != 1")
+
+    def val(v):
+        return float(v[1]) if isinstance(v, list) else v
+
+    cfg = _lib.Td3Cfg(env_id=_lib.ENV[env_name], state_dim=17, action_dim=6, max_steps=int(val(e["max_steps"])),
+                      rn_hidden=int(val(e["hidden_size"])), rn_layers=int(val(e["hidden_layer"])), rn_act=_lib.ACT[e["activation_fn"]],
+                      rn_prelu=0.25, reward_env_type=int(val(e["reward_env_type"])), hidden=int(a["hidden_size"]),
+                      layers=int(a["hidden_layer"]), act=_lib.ACT[a["activation_fn"]], prelu=0.25, batch_size=int(a["batch_size"]),
+                      rb_size=int(a["rb_size"]), train_episodes=int(a["train_episodes"]), test_episodes=int(a["test_episodes"]),
+                      init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]),
+                      policy_delay=int(a["policy_delay"]), rng_mode=int(rng_mode), solved_reward=float(val(e["solved_reward"])),
+                      gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), action_std=float(a["action_std"]),
+                      policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=1.0,
+                      adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8)
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def td3_layer_dims(cfg):
+    H, L = cfg.hidden, cfg.layers
+    actor = [(cfg.state_dim, H)] + [(H, H)] * (L - 1) + [(H, cfg.action_dim)]
+    critic = [(cfg.state_dim + cfg.action_dim, H)] + [(H, H)] * (L - 1) + [(H, 1)]
+    return actor + critic + critic

@@ -68,6 +68,29 @@ def cliff_reward_env_ql(num_workers=128, max_iterations=50):
     })
 
 
+def halfcheetah_reward_env_td3(num_workers=64, max_iterations=50):
+    """BASELINE config 5: HalfCheetah-v3 RewardEnv (potential shaped, type 2) + TD3 (values = the published hyper-parameters of
+    default_config_halfcheetah_reward_env.yaml: td3 :31-50, env :53-60; gtn as in the gridworld RN config).  The real env is
+    the documented stand-in (tools/gen_cheetah_standin.py) on BOTH sides: MuJoCo cannot be installed."""
+    return copy.deepcopy({
+        "env_name": "HalfCheetah-v3", "device": "cuda", "render_env": False,
+        "agents": {
+            "gtn": {"mode": "multi", "max_iterations": max_iterations, "num_threads_per_worker": 1,
+                    "num_workers": num_workers, "noise_std": 0.1, "step_size": 0.5, "nes_step_size": False,
+                    "mirrored_sampling": True, "num_grad_evals": 1, "grad_eval_type": "mean", "weight_decay": 0.0,
+                    "time_mult": 3, "time_max": 3600, "time_sleep_master": 0.2, "time_sleep_worker": 2,
+                    "score_transform_type": 3, "quit_when_solved": True, "synthetic_env_type": 1, "unsolved_weight": 100,
+                    "agent_name": "TD3"},
+            "td3": {"train_episodes": 100, "test_episodes": 1, "init_episodes": 20, "batch_size": 192, "gamma": 0.98, "lr": 0.003,
+                    "tau": 0.01, "policy_delay": 1, "rb_size": 1000000, "same_action_num": 1, "activation_fn": "relu",
+                    "hidden_size": 128, "hidden_layer": 2, "action_std": 0.05, "policy_std": 0.2, "policy_std_clip": 0.5,
+                    "print_rate": 5, "early_out_num": 5, "early_out_virtual_diff": 0.02},
+        },
+        "envs": {"HalfCheetah-v3": {"solved_reward": 3000.0, "max_steps": 1000, "activation_fn": "prelu", "hidden_size": 128,
+                                    "hidden_layer": 1, "info_dim": 4, "reward_env_type": 2}},
+    })
+
+
 def fixed_work(config, train_episodes):
     """BASELINE.md §3 fixed-work variant: early-out disabled (solved_reward=+1e9) and a fixed number of train episodes,
     so both the GPU path and the CPU baseline do identical, data-independent amounts of work."""

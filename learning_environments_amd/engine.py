@@ -41,6 +41,17 @@ def mlp_num_params(d):
     return int(_lib.lib().lenv_mlp_num_params(C.byref(d)))
 
 
+def mlp_forward(d, params, x):
+    """y [rows,out] = MLP(x [rows,in]) with the flat parameter vector `params` (device tensors)."""
+    dev = require_device()
+    _chk(params, torch.float32, "params"); _chk(x, torch.float32, "x")
+    rows = x.shape[0]
+    y = torch.empty((rows, d.out_dim), dtype=torch.float32, device=dev)
+    rc = _lib.lib().lenv_mlp_forward(C.byref(d), _ptr(params), _ptr(x), rows, _ptr(y), _stream())
+    _lib.check(rc, "lenv_mlp_forward")
+    return y
+
+
 def se_descs(S, A, hidden, layers, act, prelu=0.25):
     return (mlp_desc(S + A, hidden, layers, S, act, prelu), mlp_desc(S + A, hidden, layers, 1, act, prelu),
             mlp_desc(S + A, hidden, layers, 1, act, prelu))
@@ -306,6 +317,12 @@ class HipNesEngine(object):
 
     def make_inner(self, cfg, chains, **kw):
         return InnerLoop(cfg, chains, **kw)
+
+    def make_inner_td3(self, cfg, chains, **kw):
+        return Td3InnerLoop(cfg, chains, **kw)
+
+    def inner_scores_td3(self, inner, theta, eps, worker, sign, agent_init, rng_keys):
+        return inner.run(theta, eps, worker, sign, agent_init, rng_keys=rng_keys)
 
     def make_inner_ql(self, cfg, chains, tables, **kw):
         return QlInnerLoop(cfg, chains, tables, **kw)

@@ -15,6 +15,8 @@ _SPECS = {
     "CartPole-v0": dict(S=4, A=2, max_steps=200,
                         high=[4.8, np.finfo(np.float32).max, 24 * 2 * math.pi / 360, np.finfo(np.float32).max]),
     "Acrobot-v1": dict(S=6, A=3, max_steps=500, high=[1.0, 1.0, 1.0, 1.0, 4 * math.pi, 9 * math.pi]),
+    # HalfCheetah-v3 is served by the documented STAND-IN (tools/gen_cheetah_standin.py): MuJoCo cannot be installed
+    "HalfCheetah-v3": dict(S=17, A=6, max_steps=1000, high=[np.inf] * 17, continuous=True),
 }
 
 
@@ -28,7 +30,10 @@ class DeviceRealEnv(object):
         self.env_name = env_name
         self.env_id = _lib.ENV[env_name]
         self.observation_space = Box(-np.asarray(spec["high"]), np.asarray(spec["high"]))
-        self.action_space = Discrete(spec["A"])
+        self.continuous = bool(spec.get("continuous", False))
+        self.action_space = Box(-np.ones(spec["A"]), np.ones(spec["A"])) if self.continuous else Discrete(spec["A"])
+        self._A = spec["A"]
+        self._SD = 17 if self.continuous else 4          # float64 state words
         self._max_episode_steps = spec["max_steps"]
         self._S = spec["S"]
         self._seed = int(seed)
@@ -38,9 +43,10 @@ class DeviceRealEnv(object):
     def _alloc(self):
         if self._dev is None:
             dev = require_device()
-            self._dev = dict(state=torch.zeros(4, dtype=torch.float64, device=dev), elapsed=torch.zeros(1, dtype=torch.int32, device=dev),
+            self._dev = dict(state=torch.zeros(self._SD, dtype=torch.float64, device=dev), elapsed=torch.zeros(1, dtype=torch.int32, device=dev),
                              obs=torch.zeros(self._S, dtype=torch.float32, device=dev), reward=torch.zeros(1, device=dev),
-                             done=torch.zeros(1, device=dev), action=torch.zeros(1, dtype=torch.int32, device=dev),
+                             done=torch.zeros(1, device=dev),
+                             action=torch.zeros(self._A if self.continuous else 1, dtype=torch.float32 if self.continuous else torch.int32, device=dev),
                              key=torch.zeros(1, dtype=torch.int64, device=dev), episode=torch.zeros(1, dtype=torch.int64, device=dev))
         return self._dev
 
@@ -55,16 +61,25 @@ class DeviceRealEnv(object):
         d["key"].fill_(np.array([key], np.uint64).view(np.int64)[0].item())
         d["episode"].fill_(self._episode)
         self._episode += 1
-        rc = _lib.lib().lenv_real_env_reset(self.env_id, _ptr(d["key"]), _ptr(d["episode"]), 1, _ptr(d["state"]), _ptr(d["obs"]),
-                                            _ptr(d["elapsed"]), _stream())
+        if self.continuous:
+            rc = _lib.lib().lenv_cheetah_standin_reset(_ptr(d["key"]), _ptr(d["episode"]), 1, _ptr(d["state"]), _ptr(d["obs"]),
+                                                       _ptr(d["elapsed"]), _stream())
+        else:
+            rc = _lib.lib().lenv_real_env_reset(self.env_id, _ptr(d["key"]), _ptr(d["episode"]), 1, _ptr(d["state"]), _ptr(d["obs"]),
+                                                _ptr(d["elapsed"]), _stream())
         _lib.check(rc, "lenv_real_env_reset")
         return d["obs"].cpu().numpy()
 
     def step(self, action):
         d = self._alloc()
-        d["action"].fill_(int(action))
-        rc = _lib.lib().lenv_real_env_step(self.env_id, int(self._max_episode_steps), 1, _ptr(d["action"]), _ptr(d["state"]),
-                                           _ptr(d["elapsed"]), _ptr(d["obs"]), _ptr(d["reward"]), _ptr(d["done"]), _stream())
+        if self.continuous:
+            d["action"].copy_(torch.as_tensor(np.asarray(action, np.float32).reshape(-1)))
+            rc = _lib.lib().lenv_cheetah_standin_step(int(self._max_episode_steps), 1, _ptr(d["action"]), _ptr(d["state"]),
+                                                      _ptr(d["elapsed"]), _ptr(d["obs"]), _ptr(d["reward"]), _ptr(d["done"]), _stream())
+        else:
+            d["action"].fill_(int(action))
+            rc = _lib.lib().lenv_real_env_step(self.env_id, int(self._max_episode_steps), 1, _ptr(d["action"]), _ptr(d["state"]),
+                                               _ptr(d["elapsed"]), _ptr(d["obs"]), _ptr(d["reward"]), _ptr(d["done"]), _stream())
         _lib.check(rc, "lenv_real_env_step")
         return d["obs"].cpu().numpy(), float(d["reward"].item()), bool(d["done"].item() > 0.5), {}
 

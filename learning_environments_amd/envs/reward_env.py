@@ -6,6 +6,7 @@ Same constructor kwargs, attributes and state-dict keys (`reward_net.0.weight`, 
 `step` reads the shaped reward of (state, action) from a table that `lenv_rn_shape_population` evaluates on the device
 whenever the parameters change.  Reward types that need the real env's info vector (3,4,7,8,101,102) and
 continuous-state real envs are the next row of the scope table and raise NotImplementedError."""
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -97,9 +98,31 @@ class RewardEnv(nn.Module):
                                       % self.reward_env_type)
         state = self.state
         next_state, reward, done, info = self.real_env.step(action)
-        reward_res = self.shaped_table()[int(state), int(action)].item()
+        if isinstance(self.real_env, GridEnv):
+            reward_res = self.shaped_table()[int(state), int(action)].item()
+        else:
+            reward_res = self._shape_continuous(state, next_state, reward)
         self.state = next_state
         return next_state, reward_res, done, {}
+
+    def _shape_continuous(self, state, next_state, reward):
+        """reward_env.py:77-110 for vector states: phi(s), phi(s') through lenv_mlp_forward, combined in fp32 left to right."""
+        from ..models.model_utils import mlp_desc
+        t = self.reward_env_type
+        r32 = torch.tensor(reward, dtype=torch.float32)
+        if t == 0:
+            return r32.item()
+        dev = engine.require_device()
+        x = torch.from_numpy(np.stack([np.asarray(state, np.float32), np.asarray(next_state, np.float32)])).to(dev)
+        phi = engine.mlp_forward(mlp_desc(self.reward_net, self.activation_fn), self.flat_params(), x).cpu().reshape(-1)
+        g = torch.tensor(self.gamma, dtype=torch.float32)
+        if t == 1:
+            return (g * phi[1] - phi[0]).item()
+        if t == 2:
+            return ((r32 + g * phi[1]) - phi[0]).item()
+        if t == 5:
+            return phi[1].item()
+        return (r32 + phi[1]).item()
 
     def seed(self, seed):
         return self.real_env.seed(seed)
