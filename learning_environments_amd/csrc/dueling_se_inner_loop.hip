@@ -39,6 +39,16 @@ struct DuelArgs {
         a_t[4], a_dbuf[5], a_meter;
 };
 
+// Diagnostic build only (-DLENV_PHASE_TIMING): per-phase shader-clock totals of chain 0, never in the shipped library.
+#ifdef LENV_PHASE_TIMING
+__device__ unsigned long long g_duel_phase_cycles[16];
+#define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PT_MARK(i) do { unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
+#else
+#define PT_DECL
+#define PT_MARK(i)
+#endif
+
 __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
 {
     extern __shared__ __align__(16) float lds[];
@@ -110,6 +120,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     const int env_id = cfg.env_id;
     const double reset_lim = env_id == LENV_ENV_CARTPOLE ? 0.05 : 0.1;
     int status = 0;
+    PT_DECL;
     int train_steps = 0, n_act = 0, learn_it = 0, n_test_ep = 0, test_steps = 0, episodes_run = 0;
     double eps_g = cfg.eps_init, b1pow = 1.0, b2pow = 1.0;
     const int rb_cap = (int)a.rb_cap;
@@ -132,28 +143,27 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
         for (int l = 0; l < L; ++l) {
             const float *W = par + a.oWf[l], *bb = par + a.obf[l];
             float *o = hid[l];
-            wg_gemm(in, n_in, 1, W, n_in, 1, I, H, n_in, Ps, Qs,
-                    [&](int i, int j, float acc) { o[i * H + j] = act_fwd(act_id, prelu, acc + bb[j]); });
+            wg_gemm(in, n_in, 1, W, n_in, 1, I, H, n_in, Ps, Qs, epi_bias_act(o, H, bb, act_id, prelu));
             __syncthreads();
             in = o; n_in = H;
         }
         {   // feature_stream's last Linear: no activation (build_nn_from_config ends with a Linear)
             const float *W = par + a.oWf[L], *bb = par + a.obf[L];
-            wg_gemm(in, n_in, 1, W, n_in, 1, I, F, n_in, Ps, Qs, [&](int i, int j, float acc) { featb[i * F + j] = acc + bb[j]; });
+            wg_gemm(in, n_in, 1, W, n_in, 1, I, F, n_in, Ps, Qs, epi_bias(featb, F, 0, bb));
             __syncthreads();
         }
         {
             const float *W = par + a.oWv1, *bb = par + a.obv1;
-            wg_gemm(featb, F, 1, W, F, 1, I, F, F, Ps, Qs, [&](int i, int j, float acc) { v1b[i * F + j] = act_fwd(act_id, prelu, acc + bb[j]); });
+            wg_gemm(featb, F, 1, W, F, 1, I, F, F, Ps, Qs, epi_bias_act(v1b, F, bb, act_id, prelu));
             const float *W2 = par + a.oWa1, *bb2 = par + a.oba1;
-            wg_gemm(featb, F, 1, W2, F, 1, I, F, F, Ps, Qs, [&](int i, int j, float acc) { a1b[i * F + j] = act_fwd(act_id, prelu, acc + bb2[j]); });
+            wg_gemm(featb, F, 1, W2, F, 1, I, F, F, Ps, Qs, epi_bias_act(a1b, F, bb2, act_id, prelu));
             __syncthreads();
         }
         {
             const float *W = par + a.oWv2, *bb = par + a.obv2;
-            wg_gemm(v1b, F, 1, W, F, 1, I, 1, F, Ps, Qs, [&](int i, int j, float acc) { Vb[i] = acc + bb[0]; });
+            wg_gemm(v1b, F, 1, W, F, 1, I, 1, F, Ps, Qs, epi_bias(Vb, 1, 0, bb));
             const float *W2 = par + a.oWa2, *bb2 = par + a.oba2;
-            wg_gemm(a1b, F, 1, W2, F, 1, I, A, F, Ps, Qs, [&](int i, int j, float acc) { Advb[i * A + j] = acc + bb2[j]; });
+            wg_gemm(a1b, F, 1, W2, F, 1, I, A, F, Ps, Qs, epi_bias(Advb, A, 0, bb2));
             __syncthreads();
         }
         if (global_mean) {
@@ -243,6 +253,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
         __syncthreads();
         int ep_len = 0;
         for (int t = 0; t < cfg.max_steps; ++t) {
+            PT_MARK(9);
             const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
             const int new_pos = train_steps % rb_cap;
             // ---- select_train_action (DuelingDDQN.py:96-103) ----
@@ -272,6 +283,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 __syncthreads();
             }
             const int action = ictrl[2];
+            PT_MARK(0);
             // ---- EnvWrapper.step -> VirtualEnv.step: x = [onehot(action), state] ----
             for (int uu = tid; uu < 3 * Hse; uu += DNT) {
                 const int net = uu / Hse, j = uu - net * Hse;
@@ -306,6 +318,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
             if (tid < S) state[tid] = newrow[S + 1 + tid];
             ++ep_len; ++train_steps;
             __syncthreads();
+            PT_MARK(1);
 
             if (learning) {
                 // ================= DuelingDDQN.learn (DuelingDDQN.py:59-94) =================
@@ -324,9 +337,11 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                     dq[b] = row[2 * S + 2];
                 }
                 __syncthreads();
+                PT_MARK(2);
                 forward(online, xs2, B, hid_t, feat_t, v1_t, a1_t, qv + B * A, true);        // next_q_values (online)
                 forward(target, xs2, B, hid_t, feat_t, v1_t, a1_t, qv + 2 * B * A, true);    // next_q_values_target
                 forward(online, xs, B, hid_s, feat_s, v1_s, a1_s, qv, true);                  // q_values, activations kept
+                PT_MARK(3);
                 // TD error (DuelingDDQN.py:80-85) and the gradient of the loss w.r.t. V / Adv
                 if (tid == 0) {
                     const float g32 = (float)cfg.gamma, norm = (float)(2.0 / (double)B);
@@ -355,31 +370,46 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                     for (int e = tid; e < B * A; e += DNT) { const int b = e / A, aa = e - b * A; dAdv[e] = (aa == (int)Vb[b] ? dq[b] : 0.0f) + mean_grad; }
                 }
                 __syncthreads();
+                PT_MARK(4);
                 float *d_a1 = arena + a.a_dbuf[0], *d_v1 = arena + a.a_dbuf[1], *d_feat = arena + a.a_dbuf[2];
                 float *dh[2] = { arena + a.a_dbuf[3], arena + a.a_dbuf[4] };
                 // ---- heads, output layers: dW = dOut^T . hidden (reduction over the batch), db = column sums ----
-                wg_gemm(dAdv, 1, A, a1_s, 1, F, A, F, B, Ps, Qs, [&](int i, int j, float acc) { grad[a.oWa2 + i * F + j] = acc; });
-                wg_gemm(dq, 1, 1, v1_s, 1, F, 1, F, B, Ps, Qs, [&](int i, int j, float acc) { grad[a.oWv2 + j] = acc; });
+                wg_gemm(dAdv, 1, A, a1_s, 1, F, A, F, B, Ps, Qs, epi_store(grad + a.oWa2, F));
+                wg_gemm(dq, 1, 1, v1_s, 1, F, 1, F, B, Ps, Qs, epi_store(grad + a.oWv2, F));
                 if (tid < A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dAdv[b * A + tid]; grad[a.oba2 + tid] = s; }
                 if (tid == A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dq[b]; grad[a.obv2] = s; }
                 // d hidden of the heads: act'(h) * sum_o dOut[o] * W2[o][k]  (reduction over the few outputs)
-                for (int e = tid; e < B * F; e += DNT) {
-                    const int b = e / F, k = e - b * F;
-                    float acc = 0.0f;
-                    for (int aa = 0; aa < A; ++aa) acc = fma32(dAdv[b * A + aa], online[a.oWa2 + aa * F + k], acc);
-                    d_a1[e] = act_bwd(act_id, prelu, a1_s[e], acc);
-                    d_v1[e] = act_bwd(act_id, prelu, v1_s[e], fma32(dq[b], online[a.oWv2 + k], 0.0f));
+                for (int e0 = tid; e0 < B * F; e0 += 4 * DNT) {
+                    float ra[4], rv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = e0 + u * DNT;
+                        ra[u] = rv[u] = 0.0f;
+                        if (e < B * F) {
+                            const int b = e / F, k = e - b * F;
+                            float acc = 0.0f;
+                            for (int aa = 0; aa < A; ++aa) acc = fma32(dAdv[b * A + aa], online[a.oWa2 + aa * F + k], acc);
+                            ra[u] = act_bwd(act_id, prelu, a1_s[e], acc);
+                            rv[u] = act_bwd(act_id, prelu, v1_s[e], fma32(dq[b], online[a.oWv2 + k], 0.0f));
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = e0 + u * DNT;
+                        if (e < B * F) { d_a1[e] = ra[u]; d_v1[e] = rv[u]; }
+                    }
                 }
                 __syncthreads();
                 // heads, hidden layers: dW1 = dHid^T . feat, db1; dfeat = d_v1 . Wv1 + d_a1 . Wa1
-                wg_gemm(d_a1, 1, F, feat_s, 1, F, F, F, B, Ps, Qs, [&](int i, int j, float acc) { grad[a.oWa1 + i * F + j] = acc; });
-                wg_gemm(d_v1, 1, F, feat_s, 1, F, F, F, B, Ps, Qs, [&](int i, int j, float acc) { grad[a.oWv1 + i * F + j] = acc; });
-                if (tid < F) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + d_a1[b * F + tid]; grad[a.oba1 + tid] = s; }
-                else if (tid >= 128 && tid < 128 + F) { const int k = tid - 128; float s = 0.0f; for (int b = 0; b < B; ++b) s = s + d_v1[b * F + k]; grad[a.obv1 + k] = s; }
-                wg_gemm(d_v1, F, 1, online + a.oWv1, 1, F, B, F, F, Ps, Qs, [&](int i, int j, float acc) { d_feat[i * F + j] = acc; });
+                wg_gemm(d_a1, 1, F, feat_s, 1, F, F, F, B, Ps, Qs, epi_store(grad + a.oWa1, F));
+                wg_gemm(d_v1, 1, F, feat_s, 1, F, F, F, B, Ps, Qs, epi_store(grad + a.oWv1, F));
+                wg_colsum(d_a1, B, F, grad + a.oba1);
+                wg_colsum(d_v1, B, F, grad + a.obv1);
+                wg_gemm(d_v1, F, 1, online + a.oWv1, 1, F, B, F, F, Ps, Qs, epi_store(d_feat, F));
                 __syncthreads();
-                wg_gemm(d_a1, F, 1, online + a.oWa1, 1, F, B, F, F, Ps, Qs, [&](int i, int j, float acc) { d_feat[i * F + j] = d_feat[i * F + j] + acc; });
+                wg_gemm(d_a1, F, 1, online + a.oWa1, 1, F, B, F, F, Ps, Qs, epi_accum(d_feat, F));
                 __syncthreads();
+                PT_MARK(5);
                 // ---- feature stream: output Linear (no activation), then the hidden layers downwards ----
                 const float *dcur = d_feat;                // dL/d(output of layer l+1)'s pre-activation
                 int n_out = F;
@@ -387,42 +417,37 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                     const int n_in = l == 0 ? S : H;
                     const float *inp = l == 0 ? xs : hid_s[l - 1];
                     const float *dc = dcur;
-                    wg_gemm(dc, 1, n_out, inp, 1, n_in, n_out, n_in, B, Ps, Qs, [&](int i, int j, float acc) { grad[a.oWf[l] + i * n_in + j] = acc; });
-                    for (int k = tid; k < n_out; k += DNT) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dc[b * n_out + k]; grad[a.obf[l] + k] = s; }
+                    wg_gemm(dc, 1, n_out, inp, 1, n_in, n_out, n_in, B, Ps, Qs, epi_store(grad + a.oWf[l], n_in));
+                    wg_colsum(dc, B, n_out, grad + a.obf[l]);
                     if (l > 0) {
                         float *dn = dh[l & 1];
                         const float *hprev = hid_s[l - 1];
-                        wg_gemm(dc, n_out, 1, online + a.oWf[l], 1, n_in, B, n_in, n_out, Ps, Qs,
-                                [&](int i, int j, float acc) { dn[i * n_in + j] = act_bwd(act_id, prelu, hprev[i * n_in + j], acc); });
+                        wg_gemm(dc, n_out, 1, online + a.oWf[l], 1, n_in, B, n_in, n_out, Ps, Qs, epi_act_bwd(dn, n_in, hprev, n_in, act_id, prelu));
                         dcur = dn; n_out = n_in;
                     }
                     __syncthreads();
                 }
+                PT_MARK(6);
                 // ---- torch.optim.Adam + Polyak (DuelingDDQN.py:87-93) ----
                 {
                     const float neg_step = ctrl[10], bc2_sqrt = ctrl[11];
                     const float w1 = (float)(1.0 - cfg.adam_beta1), w2 = (float)(1.0 - cfg.adam_beta2), beta2 = (float)cfg.adam_beta2;
                     const float adam_eps = (float)cfg.adam_eps, tau = (float)cfg.tau, omt = (float)(1.0 - cfg.tau);
-                    for (int p = tid; p < P; p += DNT) {
-                        const float g = grad[p];
-                        const float m = fma32(w1, g - adam_m[p], adam_m[p]);
-                        float v = adam_v[p] * beta2;
-                        v = fma32(w2 * g, g, v);
-                        const float denom = __builtin_sqrtf(v) / bc2_sqrt + adam_eps;
-                        const float pn = online[p] + (neg_step * m) / denom;
-                        adam_m[p] = m; adam_v[p] = v; online[p] = pn;
-                        target[p] = tau * pn + omt * target[p];
-                    }
+                    const AdamConsts ac{ neg_step, bc2_sqrt, w1, w2, beta2, adam_eps };
+                    wg_adam(online, adam_m, adam_v, grad, 0, P, ac, target, tau, omt);
                 }
                 ++learn_it;
                 __syncthreads();
+                PT_MARK(7);
             }
             if (done_now > 0.5f) break;
         }
         ++episodes_run;
         if (tid == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
         __syncthreads();
+        PT_MARK(9);
         test_phase();
+        PT_MARK(8);
         if (tid == 0) {
             double sm = 0.0;
             for (int i = 0; i < T; ++i) sm += ret[i];
@@ -443,7 +468,12 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
         __syncthreads();
         if (brk) break;
     }
+    PT_MARK(9);
     test_phase();
+    PT_MARK(8);
+#ifdef LENV_PHASE_TIMING
+    if (tid == 0 && chain == 0) for (int pi = 0; pi < 10; ++pi) g_duel_phase_cycles[pi] = pt_acc[pi];
+#endif
     if (tid == 0) {
         double sm = 0.0;
         for (int i = 0; i < T; ++i) sm += ret[i];
@@ -559,3 +589,10 @@ extern "C" int lenv_dueling_se_inner_loop(const lenv_ddqn_cfg *cfg, const float 
     hipLaunchKernelGGL(dueling_se_inner_kernel, dim3((unsigned)chains), dim3(DNT), lds_bytes, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }
+
+#ifdef LENV_PHASE_TIMING
+extern "C" int lenv_debug_duel_phase_cycles(unsigned long long *host_out)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_duel_phase_cycles), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;
+}
+#endif

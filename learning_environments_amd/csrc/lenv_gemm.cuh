@@ -1,11 +1,21 @@
-// lenv_gemm.cuh -- workgroup-cooperative, LDS-tiled GEMM with a canonical (ascending, single-thread) reduction order.
+// lenv_gemm.cuh -- workgroup-cooperative, LDS-tiled fp32 GEMM on the f32-input matrix cores with the canonical
+// (k-ascending fmaf chain) reduction order.
 //
 //   C[i][j] = epi(i, j, sum_{r<R} P[i*sPi + r*sPr] * Q[j*sQj + r*sQr])       I, J <= 128, any R
 //
-// 512 threads, 4x8 outputs per thread, the reduction staged through LDS 64 deep (Ps/Qs: GT_RB*GT_LD floats each).  Every
-// output is accumulated by ONE thread with r ascending, i.e. the sequential fmaf chain of oracle/lenv_oracle.h, whatever
-// the strides -- the same routine serves forward (r = input feature), input-gradient (r = output unit) and
-// weight-gradient (r = sample) products of the big-net agents (DuelingDDQN, TD3).
+// 512 threads (8 waves).  The reduction is staged through LDS 64 deep (Ps/Qs: GT_RB*GT_LD floats each, r-major); the
+// output is cut into 32x32 tiles, wave w owns tiles w and w+8, and each tile is accumulated with
+// v_mfma_f32_32x32x2_f32.  That instruction is bit-for-bit D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) (one rounding per
+// product, k ascending), so every output is exactly the sequential fmaf chain of oracle/lenv_oracle.h starting from 0,
+// whatever the strides -- the same routine serves the forward (r = input feature), input-gradient (r = output unit) and
+// weight-gradient (r = sample) products of the big-net agents (DuelingDDQN, TD3).  An odd last k is added with one
+// scalar fmaf per output (a zero-padded k would turn a -0 accumulator into +0).
+// Why MFMA when the peak rate equals v_pk_fma_f32's: a 4x8 register tile needs 24.6 KB of LDS reads per k for the
+// workgroup (LDS-bound at 2.7x the FMA time, measured); the MFMA operands are one dword per lane (3 KB per k).
+// ONE out-of-line instance (descriptor-driven epilogue) is shared by all call sites.  The routine is instruction-issue
+// bound around the MFMAs (2 waves per SIMD), so every descriptor field is made wave-uniform (readfirstlane -> SGPRs,
+// scalar branches), global operands use 32-bit offsets off a scalar base, and the per-output switches are hoisted out
+// of the register loops.  Operands that live in LDS (a few small vectors) take a generic-pointer path (GEMM_GENERIC_*).
 #pragma once
 
 #include "lenv_device.cuh"
@@ -15,50 +25,397 @@ namespace lenv {
 constexpr int DNT = 512;          // threads per chain (8 waves)
 constexpr int GT_I = 128, GT_J = 128, GT_RB = 64, GT_LD = 132;   // 128x128 outputs, 64-deep stages, padded LDS rows
 
-// ---- workgroup-cooperative GEMM: C[i][j] = epi(i, j, sum_{r<R} P[i*sPi + r*sPr] * Q[j*sQj + r*sQr]), r ascending -------
-template <class Epi>
-__device__ __forceinline__ void wg_gemm(const float *P, int sPi, int sPr, const float *Q, int sQj, int sQr, int I, int J, int R,
-                                        float *Ps, float *Qs, Epi epi)
+enum { EPI_STORE = 0,       // out = acc
+       EPI_BIAS_ACT = 1,    // out = act(acc + bias[j])
+       EPI_BIAS = 2,        // out = acc + bias[j]
+       EPI_ACT_BWD = 3,     // out = act'(aux[i][j]) * acc      (aux = the layer's activation)
+       EPI_ACCUM = 4,       // out = out + acc
+       EPI_BIAS_TANH = 5 }; // t = tanh(acc + bias[j]); out2 = t (optional); out = t * scale
+
+enum { GEMM_GENERIC_P = 1, GEMM_GENERIC_OUT = 2 };   // the P operand / the output may live in LDS (generic pointers)
+
+struct GemmEpi {
+    int kind;
+    float *out; int ldo, ocol;          // out[i*ldo + ocol + j]
+    const float *bias;                  // global
+    const float *aux; int ldaux;        // EPI_ACT_BWD, global
+    float *out2; int ldo2;              // EPI_BIAS_TANH, global
+    int act; float prelu, scale;
+    int flags;
+};
+
+struct GemmOp {
+    const float *P; int sPi, sPr;
+    const float *Q; int sQj, sQr;       // Q is always global
+    int I, J, R;
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(3))) float lfloat;
+
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ float unif(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+template <class T> __device__ __forceinline__ T *uni_ptr(T *p)
 {
-    const int tid = threadIdx.x;
-    const int ti = tid & 31, tj = tid >> 5;              // 32 x 16 thread grid, 4 x 8 outputs each
-    float acc[4][8];
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = (uint32_t)uni((int)(uint32_t)v), hi = (uint32_t)uni((int)(uint32_t)(v >> 32));
+    return reinterpret_cast<T *>(((uint64_t)hi << 32) | lo);
+}
+
+// memory views: global (scalar base + 32-bit offset) or generic
+template <bool G> struct MemView;
+template <> struct MemView<true> {
+    const gfloat *p;
+    __device__ __forceinline__ explicit MemView(const float *q) : p((const gfloat *)q) {}
+    __device__ __forceinline__ float ld(int idx) const { return p[(uint32_t)idx]; }
+    __device__ __forceinline__ f32x4 ld4(int idx) const { return *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(p + (uint32_t)idx); }
+    __device__ __forceinline__ void st(int idx, float v) const { const_cast<gfloat *>(p)[(uint32_t)idx] = v; }
+};
+template <> struct MemView<false> {
+    const float *p;
+    __device__ __forceinline__ explicit MemView(const float *q) : p(q) {}
+    __device__ __forceinline__ float ld(int idx) const { return p[idx]; }
+    __device__ __forceinline__ f32x4 ld4(int idx) const { return *reinterpret_cast<const f32x4 *>(p + idx); }
+    __device__ __forceinline__ void st(int idx, float v) const { const_cast<float *>(p)[idx] = v; }
+};
+
+__device__ __forceinline__ int pow2_shift(int n) { return n <= 1 ? 0 : 32 - __builtin_clz(n - 1); }   // ceil(log2 n)
+
+// Copy src[i*sI + (r0+r)*sR], i < nI, r < rb, into dst[r*GT_LD + i] (all scalars wave-uniform).  A thread's global reads
+// are issued before its LDS writes (staging is latency bound).  Rows i >= nI are not needed: they only feed outputs that
+// the epilogue drops.
+template <bool G>
+__device__ __forceinline__ void stage_operand(const float *src_, int sI, int sR, int nI, int r0, int rb, int R, lfloat *dst, int tid, int lane, int wave)
+{
+    const MemView<G> src(src_);
+    const bool al16 = (reinterpret_cast<uintptr_t>(src_) & 15) == 0;
+    if (G && sR == 1 && al16 && (sI & 3) == 0 && (R & 3) == 0) {
+        // row-major along r: float4 = 4 consecutive r of one row; a wave instruction covers 16 rows x 64 B
+        f32x4 v[4];
+        const int i = (lane >> 2) | (wave << 4);
+        const int base = i * sI + r0 + 4 * (lane & 3);
+        const bool rowok = i < nI;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int k = 0; k < 4; ++k) v[k] = (rowok && 16 * k + 4 * (lane & 3) < rb) ? src.ld4(base + 16 * k) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        lfloat *d = dst + (4 * (lane & 3)) * GT_LD + i;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = 0.0f;
-    const bool active = 4 * ti < I && 8 * tj < J;
-    for (int r0 = 0; r0 < R; r0 += GT_RB) {
-        const int rb = R - r0 < GT_RB ? R - r0 : GT_RB;
-        __syncthreads();                                   // previous stage fully consumed
-        // stage P -> Ps[r][i], Q -> Qs[r][j] (zero padded); the unit-stride index runs fastest across threads
-        if (sPr == 1) { for (int e = tid; e < GT_I * rb; e += DNT) { int i = e / rb, r = e - i * rb; Ps[r * GT_LD + i] = i < I ? P[(int64_t)i * sPi + (r0 + r)] : 0.0f; } }
-        else { for (int e = tid; e < GT_I * rb; e += DNT) { int r = e >> 7, i = e & 127; Ps[r * GT_LD + i] = i < I ? P[(int64_t)i * sPi + (int64_t)(r0 + r) * sPr] : 0.0f; } }
-        if (sQr == 1) { for (int e = tid; e < GT_J * rb; e += DNT) { int j = e / rb, r = e - j * rb; Qs[r * GT_LD + j] = j < J ? Q[(int64_t)j * sQj + (r0 + r)] : 0.0f; } }
-        else { for (int e = tid; e < GT_J * rb; e += DNT) { int r = e >> 7, j = e & 127; Qs[r * GT_LD + j] = j < J ? Q[(int64_t)j * sQj + (int64_t)(r0 + r) * sQr] : 0.0f; } }
-        __syncthreads();
-        if (active) {
-            for (int r = 0; r < rb; ++r) {
-                const float4 p4 = *reinterpret_cast<const float4 *>(Ps + r * GT_LD + 4 * ti);
-                const float4 q0 = *reinterpret_cast<const float4 *>(Qs + r * GT_LD + 8 * tj);
-                const float4 q1 = *reinterpret_cast<const float4 *>(Qs + r * GT_LD + 8 * tj + 4);
-                const float pv[4] = { p4.x, p4.y, p4.z, p4.w };
-                const float qv[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+        for (int k = 0; k < 4; ++k)
+            if (rowok && 16 * k + 4 * (lane & 3) < rb) {
+                d[(16 * k) * GT_LD] = v[k].x; d[(16 * k + 1) * GT_LD] = v[k].y; d[(16 * k + 2) * GT_LD] = v[k].z; d[(16 * k + 3) * GT_LD] = v[k].w;
+            }
+    } else if (G && sI == 1 && al16 && (sR & 3) == 0) {
+        // contiguous along i: float4 = 4 consecutive i of one r; a wave instruction covers 2 r x 512 B
+        f32x4 v[4];
+        const int iq = lane & 31, rl = (lane >> 5) | (wave << 1);
+        const int base = (r0 + rl) * sR + 4 * iq;
+        const bool colok = 4 * iq < nI;
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+        for (int k = 0; k < 4; ++k) v[k] = (colok && rl + 16 * k < rb) ? src.ld4(base + 16 * k * sR) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        lfloat *d = dst + rl * GT_LD + 4 * iq;
 #pragma unroll
-                    for (int b = 0; b < 8; ++b) acc[a][b] = fma32(pv[a], qv[b], acc[a][b]);
+        for (int k = 0; k < 4; ++k)
+            if (colok && rl + 16 * k < rb) {
+                *reinterpret_cast<__attribute__((address_space(3))) f32x4 *>(d + 16 * k * GT_LD) = v[k];
+            }
+    } else if (sR == 1 || (sI != 1 && sR < sI)) {
+        // small / unaligned operands, r fastest across lanes: e -> (i = e >> sh, r = e & mask)
+        const int sh = pow2_shift(rb), mask = (1 << sh) - 1, total = nI << sh;
+        for (int e0 = tid; e0 < total; e0 += 4 * DNT) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * DNT, i = e >> sh, r = e & mask;
+                v[u] = (e < total && r < rb) ? src.ld(i * sI + (r0 + r) * sR) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * DNT, i = e >> sh, r = e & mask;
+                if (e < total && r < rb) dst[r * GT_LD + i] = v[u];
+            }
+        }
+    } else {
+        // i fastest across lanes: e -> (r = e >> sh, i = e & mask)
+        const int sh = pow2_shift(nI), mask = (1 << sh) - 1, total = rb << sh;
+        for (int e0 = tid; e0 < total; e0 += 4 * DNT) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * DNT, r = e >> sh, i = e & mask;
+                v[u] = (e < total && i < nI) ? src.ld(i * sI + (r0 + r) * sR) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * DNT, r = e >> sh, i = e & mask;
+                if (e < total && i < nI) dst[r * GT_LD + i] = v[u];
             }
         }
     }
-    if (active) {
+}
+
+__device__ __forceinline__ void act_fwd16(int act, float prelu, float (&z)[16])
+{
+    switch (act) {                                         // uniform: one arm runs
+    case LENV_ACT_RELU:
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int v = 0; v < 16; ++v) z[v] = z[v] > 0.0f ? z[v] : 0.0f;
+        break;
+    case LENV_ACT_LEAKYRELU:
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int i = 4 * ti + a, j = 8 * tj + b;
-                if (i < I && j < J) epi(i, j, acc[a][b]);
+        for (int v = 0; v < 16; ++v) z[v] = z[v] > 0.0f ? z[v] : z[v] * 0.01f;
+        break;
+    case LENV_ACT_TANH:
+#pragma unroll
+        for (int v = 0; v < 16; ++v) z[v] = det_tanhf(lenv_tanh_table, z[v]);
+        break;
+    case LENV_ACT_PRELU:
+#pragma unroll
+        for (int v = 0; v < 16; ++v) z[v] = z[v] > 0.0f ? z[v] : prelu * z[v];
+        break;
+    default: break;
+    }
+}
+
+// res = act'(a) * g  (see act_bwd)
+__device__ __forceinline__ void act_bwd16(int act, float prelu, const float (&a)[16], float (&g)[16])
+{
+    switch (act) {
+    case LENV_ACT_RELU:
+#pragma unroll
+        for (int v = 0; v < 16; ++v) g[v] = a[v] > 0.0f ? g[v] : 0.0f;
+        break;
+    case LENV_ACT_LEAKYRELU:
+#pragma unroll
+        for (int v = 0; v < 16; ++v) g[v] = a[v] > 0.0f ? g[v] : g[v] * 0.01f;
+        break;
+    case LENV_ACT_TANH:
+#pragma unroll
+        for (int v = 0; v < 16; ++v) g[v] = g[v] * fma32(-a[v], a[v], 1.0f);
+        break;
+    case LENV_ACT_PRELU:
+#pragma unroll
+        for (int v = 0; v < 16; ++v) g[v] = a[v] > 0.0f ? g[v] : prelu * g[v];
+        break;
+    default: break;
+    }
+}
+
+// Epilogue of one 32x32 tile.  MFMA D layout: lane l holds column j = l % 32 and, in register v, row
+// 8*(v/4) + 4*(l/32) + v%4.  Every global read (bias / aux / old value) is issued before the first store; a store
+// instruction writes two 128-B row pieces.  `ep` fields are wave-uniform.
+template <bool G>
+__device__ __forceinline__ void tile_epilogue(const f32x16 acc, int i0, int j0, int I, int J, const GemmEpi &ep, int lane)
+{
+    const int j = j0 + (lane & 31), ib = i0 + 4 * (lane >> 5);
+    const bool full = i0 + 32 <= I && j0 + 32 <= J;        // uniform: no per-element predicates
+    const bool jok = full || j < J;
+    const int kind = ep.kind;
+    const MemView<G> out(ep.out + ep.ocol);
+    const int ldo = ep.ldo;
+    float x[16], res[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) res[v] = acc[v];
+    if (kind == EPI_ACT_BWD) {
+        const MemView<true> aux(ep.aux);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { const int i = ib + 8 * (v >> 2) + (v & 3); x[v] = (full || (jok && i < I)) ? aux.ld(i * ep.ldaux + j) : 0.0f; }
+        act_bwd16(ep.act, ep.prelu, x, res);
+    } else if (kind == EPI_ACCUM) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { const int i = ib + 8 * (v >> 2) + (v & 3); x[v] = (full || (jok && i < I)) ? out.ld(i * ldo + j) : 0.0f; }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) res[v] = x[v] + res[v];
+    } else if (kind != EPI_STORE) {
+        const MemView<true> bias(ep.bias);
+        const float bv = jok ? bias.ld(j) : 0.0f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) res[v] = res[v] + bv;
+        if (kind == EPI_BIAS_ACT) act_fwd16(ep.act, ep.prelu, res);
+        else if (kind == EPI_BIAS_TANH) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) res[v] = det_tanhf(lenv_tanh_table, res[v]);
+            if (ep.out2) {
+                const MemView<true> o2(ep.out2);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) { const int i = ib + 8 * (v >> 2) + (v & 3); if (full || (jok && i < I)) o2.st(i * ep.ldo2 + j, res[v]); }
             }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) res[v] = res[v] * ep.scale;
+        }
+    }
+    if (full) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) out.st((ib + 8 * (v >> 2) + (v & 3)) * ldo + j, res[v]);
+    } else if (jok) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { const int i = ib + 8 * (v >> 2) + (v & 3); if (i < I) out.st(i * ldo + j, res[v]); }
+    }
+}
+
+__device__ __noinline__ void wg_gemm_run(const GemmOp op_, const GemmEpi ep_, float *Ps_, float *Qs_)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    // descriptors arrive in VGPRs: make every field wave-uniform
+    GemmOp op; GemmEpi ep;
+    op.P = uni_ptr(op_.P); op.sPi = uni(op_.sPi); op.sPr = uni(op_.sPr); op.Q = uni_ptr(op_.Q); op.sQj = uni(op_.sQj); op.sQr = uni(op_.sQr);
+    op.I = uni(op_.I); op.J = uni(op_.J); op.R = uni(op_.R);
+    ep.kind = uni(ep_.kind); ep.out = uni_ptr(ep_.out); ep.ldo = uni(ep_.ldo); ep.ocol = uni(ep_.ocol); ep.bias = uni_ptr(ep_.bias);
+    ep.aux = uni_ptr(ep_.aux); ep.ldaux = uni(ep_.ldaux); ep.out2 = uni_ptr(ep_.out2); ep.ldo2 = uni(ep_.ldo2); ep.act = uni(ep_.act);
+    ep.prelu = unif(ep_.prelu); ep.scale = unif(ep_.scale); ep.flags = uni(ep_.flags);
+    lfloat *Ps = (lfloat *)uni_ptr(Ps_), *Qs = (lfloat *)uni_ptr(Qs_);
+    const int I = op.I, J = op.J, R = op.R;
+    const int nbi = (I + 31) >> 5, nbj = (J + 31) >> 5, ntile = nbi * nbj;      // <= 16 tiles of 32x32
+    const bool has0 = wave < ntile, has1 = wave + 8 < ntile;
+    const int bi0 = wave % nbi, bj0 = wave / nbi, bi1 = (wave + 8) % nbi, bj1 = (wave + 8) / nbi;
+    // A operand: lane l supplies P[row l%32][k = l/32]; B operand: Q[col l%32][k = l/32]; both one LDS dword, r-major rows
+    const int koff = (lane >> 5) * GT_LD + (lane & 31);
+    const lfloat *pa0 = Ps + koff + 32 * bi0, *pb0 = Qs + koff + 32 * bj0;
+    const lfloat *pa1 = Ps + koff + 32 * bi1, *pb1 = Qs + koff + 32 * bj1;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { acc0[v] = 0.0f; acc1[v] = 0.0f; }
+    for (int r0 = 0; r0 < R; r0 += GT_RB) {
+        const int rb = R - r0 < GT_RB ? R - r0 : GT_RB;
+        __syncthreads();                                   // previous stage fully consumed
+#ifndef LENV_DIAG_SKIP_STAGE
+        if (ep.flags & GEMM_GENERIC_P) stage_operand<false>(op.P, op.sPi, op.sPr, I, r0, rb, R, Ps, tid, lane, wave);
+        else stage_operand<true>(op.P, op.sPi, op.sPr, I, r0, rb, R, Ps, tid, lane, wave);
+        stage_operand<true>(op.Q, op.sQj, op.sQr, J, r0, rb, R, Qs, tid, lane, wave);
+#endif
+        __syncthreads();
+#ifndef LENV_DIAG_SKIP_COMPUTE
+        const int rb2 = rb & ~1;
+        if (has1) {
+            if (rb == GT_RB) {
+#pragma unroll 8
+                for (int r = 0; r < GT_RB; r += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0[r * GT_LD], pb0[r * GT_LD], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa1[r * GT_LD], pb1[r * GT_LD], acc1, 0, 0, 0);
+                }
+            } else {
+                for (int r = 0; r < rb2; r += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0[r * GT_LD], pb0[r * GT_LD], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa1[r * GT_LD], pb1[r * GT_LD], acc1, 0, 0, 0);
+                }
+            }
+        } else if (has0) {
+            if (rb == GT_RB) {
+#pragma unroll 8
+                for (int r = 0; r < GT_RB; r += 2) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0[r * GT_LD], pb0[r * GT_LD], acc0, 0, 0, 0);
+            } else {
+                for (int r = 0; r < rb2; r += 2) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0[r * GT_LD], pb0[r * GT_LD], acc0, 0, 0, 0);
+            }
+        }
+        if (rb & 1) {                                      // odd last k: one scalar fmaf per output
+            const lfloat *prow = Ps + rb2 * GT_LD + 4 * (lane >> 5), *qrow = Qs + rb2 * GT_LD + (lane & 31);
+            if (has0) {
+                const float q = qrow[32 * bj0];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc0[v] = fma32(prow[32 * bi0 + 8 * (v >> 2) + (v & 3)], q, acc0[v]);
+            }
+            if (has1) {
+                const float q = qrow[32 * bj1];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc1[v] = fma32(prow[32 * bi1 + 8 * (v >> 2) + (v & 3)], q, acc1[v]);
+            }
+        }
+#endif
+    }
+#ifdef LENV_DIAG_SKIP_EPI
+    if (R > 0) return;
+#endif
+    if (ep.flags & GEMM_GENERIC_OUT) {
+        if (has0) tile_epilogue<false>(acc0, 32 * bi0, 32 * bj0, I, J, ep, lane);
+        if (has1) tile_epilogue<false>(acc1, 32 * bi1, 32 * bj1, I, J, ep, lane);
+    } else {
+        if (has0) tile_epilogue<true>(acc0, 32 * bi0, 32 * bj0, I, J, ep, lane);
+        if (has1) tile_epilogue<true>(acc1, 32 * bi1, 32 * bj1, I, J, ep, lane);
+    }
+}
+
+__device__ __forceinline__ GemmEpi epi_store(float *out, int ldo, int ocol = 0) { GemmEpi e{}; e.kind = EPI_STORE; e.out = out; e.ldo = ldo; e.ocol = ocol; return e; }
+__device__ __forceinline__ GemmEpi epi_accum(float *out, int ldo) { GemmEpi e{}; e.kind = EPI_ACCUM; e.out = out; e.ldo = ldo; return e; }
+__device__ __forceinline__ GemmEpi epi_bias(float *out, int ldo, int ocol, const float *bias) { GemmEpi e{}; e.kind = EPI_BIAS; e.out = out; e.ldo = ldo; e.ocol = ocol; e.bias = bias; return e; }
+__device__ __forceinline__ GemmEpi epi_bias_act(float *out, int ldo, const float *bias, int act, float prelu) { GemmEpi e{}; e.kind = EPI_BIAS_ACT; e.out = out; e.ldo = ldo; e.bias = bias; e.act = act; e.prelu = prelu; return e; }
+__device__ __forceinline__ GemmEpi epi_act_bwd(float *out, int ldo, const float *aux, int ldaux, int act, float prelu) { GemmEpi e{}; e.kind = EPI_ACT_BWD; e.out = out; e.ldo = ldo; e.aux = aux; e.ldaux = ldaux; e.act = act; e.prelu = prelu; return e; }
+__device__ __forceinline__ GemmEpi epi_bias_tanh(float *out, int ldo, int ocol, const float *bias, float scale, float *out2, int ldo2) { GemmEpi e{}; e.kind = EPI_BIAS_TANH; e.out = out; e.ldo = ldo; e.ocol = ocol; e.bias = bias; e.scale = scale; e.out2 = out2; e.ldo2 = ldo2; return e; }
+
+__device__ __forceinline__ void wg_gemm(const float *P, int sPi, int sPr, const float *Q, int sQj, int sQr, int I, int J, int R,
+                                        float *Ps, float *Qs, const GemmEpi &ep)
+{
+    GemmOp op{ P, sPi, sPr, Q, sQj, sQr, I, J, R };
+    GemmEpi e = ep;
+#ifdef __HIP_DEVICE_COMPILE__
+    if (__builtin_amdgcn_is_shared(P)) e.flags |= GEMM_GENERIC_P;
+    if (__builtin_amdgcn_is_shared(ep.out)) e.flags |= GEMM_GENERIC_OUT;
+#endif
+    wg_gemm_run(op, e, Ps, Qs);
+}
+
+
+// ---- elementwise passes over a chain's HBM arena: 4 elements per thread with all reads issued before the first write
+// (the arrays may alias as far as the compiler knows; one element at a time costs one HBM round trip each) ----
+
+struct AdamConsts { float neg_step, bc2_sqrt, w1, w2, beta2, eps; };
+
+// torch.optim.Adam single-tensor step on [p0, p0+n) (+ optional Polyak update of `target` with the new parameter)
+__device__ __forceinline__ void wg_adam(float *params, float *adam_m, float *adam_v, const float *grad, int p0, int n, const AdamConsts c,
+                                        float *target, float tau, float omt)
+{
+    const int end = p0 + n;
+    for (int q = p0 + (int)threadIdx.x; q < end; q += 4 * DNT) {
+        float g[4], m[4], v[4], w[4], t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = q + u * DNT;
+            const bool ok = p < end;
+            g[u] = ok ? grad[p] : 0.0f; m[u] = ok ? adam_m[p] : 0.0f; v[u] = ok ? adam_v[p] : 0.0f; w[u] = ok ? params[p] : 0.0f;
+            t[u] = (ok && target) ? target[p] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            m[u] = fma32(c.w1, g[u] - m[u], m[u]);
+            v[u] = fma32(c.w2 * g[u], g[u], v[u] * c.beta2);
+            const float denom = __builtin_sqrtf(v[u]) / c.bc2_sqrt + c.eps;
+            w[u] = w[u] + (c.neg_step * m[u]) / denom;
+            t[u] = tau * w[u] + omt * t[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = q + u * DNT;
+            if (p < end) { adam_m[p] = m[u]; adam_v[p] = v[u]; params[p] = w[u]; if (target) target[p] = t[u]; }
+        }
+    }
+}
+
+// target = tau * params + (1 - tau) * target on [0, n)
+__device__ __forceinline__ void wg_polyak(const float *params, float *target, int n, float tau, float omt)
+{
+    for (int q = (int)threadIdx.x; q < n; q += 8 * DNT) {
+        float w[8], t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int p = q + u * DNT; const bool ok = p < n; w[u] = ok ? params[p] : 0.0f; t[u] = ok ? target[p] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int p = q + u * DNT; if (p < n) target[p] = tau * w[u] + omt * t[u]; }
+    }
+}
+
+// out[k] = sum_b d[b*n + k] (b ascending), k < n: the bias gradient of a Linear layer
+__device__ __forceinline__ void wg_colsum(const float *d, int rows, int n, float *out)
+{
+    for (int k = (int)threadIdx.x; k < n; k += DNT) {
+        float s = 0.0f;
+        int b = 0;
+        for (; b + 8 <= rows; b += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = d[(int64_t)(b + u) * n + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = s + x[u];
+        }
+        for (; b < rows; ++b) s = s + d[(int64_t)b * n + k];
+        out[k] = s;
     }
 }
 

@@ -109,20 +109,16 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             for (int l = 0; l < mo.L; ++l) {
                 const float *W = par + mo.oW[l], *bb = par + mo.ob[l];
                 float *o = hid[l] + (int64_t)i0 * mo.H;
-                wg_gemm(in, ldin, 1, W, n_in, 1, ib, mo.H, n_in, Ps, Qs,
-                        [&](int i, int j, float acc) { o[i * mo.H + j] = act_fwd(act_id, prelu, acc + bb[j]); });
+                wg_gemm(in, ldin, 1, W, n_in, 1, ib, mo.H, n_in, Ps, Qs, epi_bias_act(o, mo.H, bb, act_id, prelu));
                 __syncthreads();
                 in = o; n_in = mo.H; ldin = mo.H;
             }
             const float *W = par + mo.oW[mo.L], *bb = par + mo.ob[mo.L];
-            wg_gemm(in, ldin, 1, W, n_in, 1, ib, mo.out, n_in, Ps, Qs, [&](int i, int j, float acc) {
-                const float v = acc + bb[j];
-                if (final_tanh) {
-                    const float t = det_tanhf(lenv_tanh_table, v);
-                    if (th_out) th_out[(i0 + i) * mo.out + j] = t;
-                    out[(int64_t)(i0 + i) * ldo + ocol + j] = t * ma;
-                } else out[(int64_t)(i0 + i) * ldo + ocol + j] = v;
-            });
+            if (final_tanh)
+                wg_gemm(in, ldin, 1, W, n_in, 1, ib, mo.out, n_in, Ps, Qs,
+                        epi_bias_tanh(out + (int64_t)i0 * ldo, ldo, ocol, bb, ma, th_out ? th_out + (int64_t)i0 * mo.out : nullptr, mo.out));
+            else
+                wg_gemm(in, ldin, 1, W, n_in, 1, ib, mo.out, n_in, Ps, Qs, epi_bias(out + (int64_t)i0 * ldo, ldo, ocol, bb));
             __syncthreads();
         }
     };
@@ -132,7 +128,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                             float *gpar, float *dX) {
         const int Hh = mo.H, O = mo.out;
         if (gpar) {
-            wg_gemm(dOut, 1, O, hid[mo.L - 1], 1, Hh, O, Hh, I, Ps, Qs, [&](int i, int j, float acc) { gpar[mo.oW[mo.L] + i * Hh + j] = acc; });
+            wg_gemm(dOut, 1, O, hid[mo.L - 1], 1, Hh, O, Hh, I, Ps, Qs, epi_store(gpar + mo.oW[mo.L], Hh));
             if (tid < O) { float s = 0.0f; for (int b = 0; b < I; ++b) s = s + dOut[b * O + tid]; gpar[mo.ob[mo.L] + tid] = s; }
         }
         float *dcur = dbuf[0];
@@ -140,8 +136,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             const int ib = I - i0 < GT_I ? I - i0 : GT_I;
             const float *hl = hid[mo.L - 1] + (int64_t)i0 * Hh;
             float *dc = dcur + (int64_t)i0 * Hh;
-            wg_gemm(dOut + (int64_t)i0 * O, O, 1, par + mo.oW[mo.L], 1, Hh, ib, Hh, O, Ps, Qs,
-                    [&](int i, int j, float acc) { dc[i * Hh + j] = act_bwd(act_id, prelu, hl[i * Hh + j], acc); });
+            wg_gemm(dOut + (int64_t)i0 * O, O, 1, par + mo.oW[mo.L], 1, Hh, ib, Hh, O, Ps, Qs, epi_act_bwd(dc, Hh, hl, Hh, act_id, prelu));
         }
         __syncthreads();
         for (int l = mo.L - 1; l >= 0; --l) {
@@ -150,8 +145,8 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             const int ldin = l == 0 ? ldx : Hh;
             const float *dc = dcur;
             if (gpar) {
-                wg_gemm(dc, 1, Hh, inp, 1, ldin, Hh, n_in, I, Ps, Qs, [&](int i, int j, float acc) { gpar[mo.oW[l] + i * n_in + j] = acc; });
-                for (int k = tid; k < Hh; k += DNT) { float s = 0.0f; for (int b = 0; b < I; ++b) s = s + dc[b * Hh + k]; gpar[mo.ob[l] + k] = s; }
+                wg_gemm(dc, 1, Hh, inp, 1, ldin, Hh, n_in, I, Ps, Qs, epi_store(gpar + mo.oW[l], n_in));
+                wg_colsum(dc, I, Hh, gpar + mo.ob[l]);
             }
             if (l > 0) {
                 float *dn = dbuf[(mo.L - l) & 1];
@@ -159,16 +154,14 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     const int ib = I - i0 < GT_I ? I - i0 : GT_I;
                     const float *hp = hid[l - 1] + (int64_t)i0 * Hh;
                     float *dnb = dn + (int64_t)i0 * Hh;
-                    wg_gemm(dc + (int64_t)i0 * Hh, Hh, 1, par + mo.oW[l], 1, n_in, ib, n_in, Hh, Ps, Qs,
-                            [&](int i, int j, float acc) { dnb[i * n_in + j] = act_bwd(act_id, prelu, hp[i * n_in + j], acc); });
+                    wg_gemm(dc + (int64_t)i0 * Hh, Hh, 1, par + mo.oW[l], 1, n_in, ib, n_in, Hh, Ps, Qs, epi_act_bwd(dnb, n_in, hp, n_in, act_id, prelu));
                 }
                 dcur = dn;
             } else if (dX) {
                 for (int i0 = 0; i0 < I; i0 += GT_I) {
                     const int ib = I - i0 < GT_I ? I - i0 : GT_I;
                     float *dxo = dX + (int64_t)i0 * n_in;
-                    wg_gemm(dc + (int64_t)i0 * Hh, Hh, 1, par + mo.oW[0], 1, n_in, ib, n_in, Hh, Ps, Qs,
-                            [&](int i, int j, float acc) { dxo[i * n_in + j] = acc; });
+                    wg_gemm(dc + (int64_t)i0 * Hh, Hh, 1, par + mo.oW[0], 1, n_in, ib, n_in, Hh, Ps, Qs, epi_store(dxo, n_in));
                 }
             }
             __syncthreads();
@@ -185,15 +178,8 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         __syncthreads();
         const float neg_step = ctrl[10], bc2_sqrt = ctrl[11];
         const float w1 = (float)(1.0 - cfg.adam_beta1), w2 = (float)(1.0 - cfg.adam_beta2), beta2 = (float)cfg.adam_beta2, aeps = (float)cfg.adam_eps;
-        for (int p = p0 + tid; p < p0 + n; p += DNT) {
-            const float g = grad[p];
-            const float m = fma32(w1, g - adam_m[p], adam_m[p]);
-            float v = adam_v[p] * beta2;
-            v = fma32(w2 * g, g, v);
-            const float denom = __builtin_sqrtf(v) / bc2_sqrt + aeps;
-            params[p] = params[p] + (neg_step * m) / denom;
-            adam_m[p] = m; adam_v[p] = v;
-        }
+        const AdamConsts ac{ neg_step, bc2_sqrt, w1, w2, beta2, aeps };
+        wg_adam(params, adam_m, adam_v, grad, p0, n, ac, nullptr, 0.0f, 0.0f);
         __syncthreads();
     };
 
@@ -412,7 +398,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     mlp_backward(params, a.actor, xc, SA, B, ha, dzb, grad, nullptr);
                     adam(0, Pa, 2);
                     const float tau = (float)cfg.tau, omt = (float)(1.0 - cfg.tau);
-                    for (int p = tid; p < P; p += DNT) targets[p] = tau * params[p] + omt * targets[p];
+                    wg_polyak(params, targets, P, tau, omt);
                     __syncthreads();
                 }
             }

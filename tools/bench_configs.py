@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Throughput of the fused kernels at the FULL shapes of BASELINE configs 2-5 on a reduced episode budget (extra
+information for DESIGN.md; bench.py's contract line is config 2 only).  Prints one JSON object per config."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.makedirs("/tmp/lenv_bench", exist_ok=True)
+os.chdir("/tmp/lenv_bench")
+
+from learning_environments_amd.agents.GTN import GTN_Master  # noqa: E402
+from learning_environments_amd import configs  # noqa: E402
+
+
+def run(name, cfg, gens=2):
+    torch.manual_seed(0)
+    m = GTN_Master(cfg, bohb_id=0, seed=7)
+    m.step(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(1, 1 + gens):
+        m.step(it)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / gens
+    st = m.inner.stats.cpu().numpy()
+    out = dict(config=name, pop=cfg["agents"]["gtn"]["num_workers"], chains=int(st.shape[0]), s_per_generation=dt,
+               evals_per_s=cfg["agents"]["gtn"]["num_workers"] / dt, train_steps=int(st[:, 1].sum()), learn_steps=int(st[:, 2].sum()),
+               test_steps=int(st[:, 3].sum()), us_per_learn_step_per_chain=1e6 * dt / max(1.0, st[:, 2].mean()))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["2", "3", "4", "5"]
+    if "2" in which:
+        run("cfg2 CartPole SE + DDQN pop 64 (20 episodes)", configs.fixed_work(configs.cartpole_syn_env_ddqn(64), 20))
+    if "4" in which:
+        c = configs.cliff_reward_env_ql(128)
+        c["agents"]["gtn"]["quit_when_solved"] = False
+        run("cfg4 Cliff RN + QL pop 128 (100 episodes, early-out on)", c)
+    if "3" in which:
+        c = configs.fixed_work(configs.acrobot_syn_env_duelingddqn(32), 3)
+        c["agents"]["duelingddqn"]["init_episodes"] = 1
+        c["envs"]["Acrobot-v1"]["max_steps"] = 100
+        run("cfg3 Acrobot SE + DuelingDDQN pop 32 (3 episodes x 100 steps)", c, gens=1)
+    if "5" in which:
+        c = configs.fixed_work(configs.halfcheetah_reward_env_td3(32), 3)
+        c["agents"]["td3"]["init_episodes"] = 1
+        c["envs"]["HalfCheetah-v3"]["max_steps"] = 100
+        run("cfg5 HalfCheetah-standin RN + TD3 pop 32 (3 episodes x 100 steps)", c, gens=1)
