@@ -67,11 +67,12 @@ template <class T> __device__ __forceinline__ T *uni_ptr(T *p)
 // memory views: global (scalar base + 32-bit offset) or generic
 template <bool G> struct MemView;
 template <> struct MemView<true> {
-    const gfloat *p;
-    __device__ __forceinline__ explicit MemView(const float *q) : p((const gfloat *)q) {}
-    __device__ __forceinline__ float ld(int idx) const { return p[(uint32_t)idx]; }
-    __device__ __forceinline__ f32x4 ld4(int idx) const { return *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(p + (uint32_t)idx); }
-    __device__ __forceinline__ void st(int idx, float v) const { const_cast<gfloat *>(p)[(uint32_t)idx] = v; }
+    typedef __attribute__((address_space(1))) char gchar;
+    const gchar *p;                                        // uniform base; 32-bit byte offsets -> `global_* v, v, s[..]` forms
+    __device__ __forceinline__ explicit MemView(const float *q) : p((const gchar *)q) {}
+    __device__ __forceinline__ float ld(int idx) const { return *reinterpret_cast<const gfloat *>(p + (uint32_t)(idx << 2)); }
+    __device__ __forceinline__ f32x4 ld4(int idx) const { return *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(p + (uint32_t)(idx << 2)); }
+    __device__ __forceinline__ void st(int idx, float v) const { *reinterpret_cast<gfloat *>(const_cast<gchar *>(p) + (uint32_t)(idx << 2)) = v; }
 };
 template <> struct MemView<false> {
     const float *p;
@@ -204,11 +205,10 @@ __device__ __forceinline__ void act_bwd16(int act, float prelu, const float (&a)
 // Epilogue of one 32x32 tile.  MFMA D layout: lane l holds column j = l % 32 and, in register v, row
 // 8*(v/4) + 4*(l/32) + v%4.  Every global read (bias / aux / old value) is issued before the first store; a store
 // instruction writes two 128-B row pieces.  `ep` fields are wave-uniform.
-template <bool G>
+template <bool G, bool full>
 __device__ __forceinline__ void tile_epilogue(const f32x16 acc, int i0, int j0, int I, int J, const GemmEpi &ep, int lane)
 {
     const int j = j0 + (lane & 31), ib = i0 + 4 * (lane >> 5);
-    const bool full = i0 + 32 <= I && j0 + 32 <= J;        // uniform: no per-element predicates
     const bool jok = full || j < J;
     const int kind = ep.kind;
     const MemView<G> out(ep.out + ep.ocol);
@@ -219,11 +219,11 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 acc, int i0, int j0, 
     if (kind == EPI_ACT_BWD) {
         const MemView<true> aux(ep.aux);
 #pragma unroll
-        for (int v = 0; v < 16; ++v) { const int i = ib + 8 * (v >> 2) + (v & 3); x[v] = (full || (jok && i < I)) ? aux.ld(i * ep.ldaux + j) : 0.0f; }
+        for (int v = 0; v < 16; ++v) { const int i = ib + 8 * (v >> 2) + (v & 3); x[v] = (full || (jok && i < I)) ? aux.ld(ib * ep.ldaux + j + (8 * (v >> 2) + (v & 3)) * ep.ldaux) : 0.0f; }
         act_bwd16(ep.act, ep.prelu, x, res);
     } else if (kind == EPI_ACCUM) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) { const int i = ib + 8 * (v >> 2) + (v & 3); x[v] = (full || (jok && i < I)) ? out.ld(i * ldo + j) : 0.0f; }
+        for (int v = 0; v < 16; ++v) { const int i = ib + 8 * (v >> 2) + (v & 3); x[v] = (full || (jok && i < I)) ? out.ld(ib * ldo + j + (8 * (v >> 2) + (v & 3)) * ldo) : 0.0f; }
 #pragma unroll
         for (int v = 0; v < 16; ++v) res[v] = x[v] + res[v];
     } else if (kind != EPI_STORE) {
@@ -238,7 +238,7 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 acc, int i0, int j0, 
             if (ep.out2) {
                 const MemView<true> o2(ep.out2);
 #pragma unroll
-                for (int v = 0; v < 16; ++v) { const int i = ib + 8 * (v >> 2) + (v & 3); if (full || (jok && i < I)) o2.st(i * ep.ldo2 + j, res[v]); }
+                for (int v = 0; v < 16; ++v) { const int i = ib + 8 * (v >> 2) + (v & 3); if (full || (jok && i < I)) o2.st(ib * ep.ldo2 + j + (8 * (v >> 2) + (v & 3)) * ep.ldo2, res[v]); }
             }
 #pragma unroll
             for (int v = 0; v < 16; ++v) res[v] = res[v] * ep.scale;
@@ -246,10 +246,10 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 acc, int i0, int j0, 
     }
     if (full) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) out.st((ib + 8 * (v >> 2) + (v & 3)) * ldo + j, res[v]);
+        for (int v = 0; v < 16; ++v) out.st(ib * ldo + j + (8 * (v >> 2) + (v & 3)) * ldo, res[v]);
     } else if (jok) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) { const int i = ib + 8 * (v >> 2) + (v & 3); if (i < I) out.st(i * ldo + j, res[v]); }
+        for (int v = 0; v < 16; ++v) { const int i = ib + 8 * (v >> 2) + (v & 3); if (i < I) out.st(ib * ldo + j + (8 * (v >> 2) + (v & 3)) * ldo, res[v]); }
     }
 }
 
@@ -267,7 +267,8 @@ __device__ __noinline__ void wg_gemm_run(const GemmOp op_, const GemmEpi ep_, fl
     const int I = op.I, J = op.J, R = op.R;
     const int nbi = (I + 31) >> 5, nbj = (J + 31) >> 5, ntile = nbi * nbj;      // <= 16 tiles of 32x32
     const bool has0 = wave < ntile, has1 = wave + 8 < ntile;
-    const int bi0 = wave % nbi, bj0 = wave / nbi, bi1 = (wave + 8) % nbi, bj1 = (wave + 8) / nbi;
+    const int inv = nbi == 1 ? 256 : (nbi == 2 ? 128 : (nbi == 3 ? 86 : 64));     // t / nbi == (t * inv) >> 8 for t < 16
+    const int bj0 = (wave * inv) >> 8, bi0 = wave - bj0 * nbi, bj1 = ((wave + 8) * inv) >> 8, bi1 = wave + 8 - bj1 * nbi;
     // A operand: lane l supplies P[row l%32][k = l/32]; B operand: Q[col l%32][k = l/32]; both one LDS dword, r-major rows
     const int koff = (lane >> 5) * GT_LD + (lane & 31);
     const lfloat *pa0 = Ps + koff + 32 * bi0, *pb0 = Qs + koff + 32 * bj0;
@@ -326,11 +327,17 @@ __device__ __noinline__ void wg_gemm_run(const GemmOp op_, const GemmEpi ep_, fl
     if (R > 0) return;
 #endif
     if (ep.flags & GEMM_GENERIC_OUT) {
-        if (has0) tile_epilogue<false>(acc0, 32 * bi0, 32 * bj0, I, J, ep, lane);
-        if (has1) tile_epilogue<false>(acc1, 32 * bi1, 32 * bj1, I, J, ep, lane);
+        if (has0) tile_epilogue<false, false>(acc0, 32 * bi0, 32 * bj0, I, J, ep, lane);
+        if (has1) tile_epilogue<false, false>(acc1, 32 * bi1, 32 * bj1, I, J, ep, lane);
     } else {
-        if (has0) tile_epilogue<true>(acc0, 32 * bi0, 32 * bj0, I, J, ep, lane);
-        if (has1) tile_epilogue<true>(acc1, 32 * bi1, 32 * bj1, I, J, ep, lane);
+        if (has0) {
+            if (32 * bi0 + 32 <= I && 32 * bj0 + 32 <= J) tile_epilogue<true, true>(acc0, 32 * bi0, 32 * bj0, I, J, ep, lane);
+            else tile_epilogue<true, false>(acc0, 32 * bi0, 32 * bj0, I, J, ep, lane);
+        }
+        if (has1) {
+            if (32 * bi1 + 32 <= I && 32 * bj1 + 32 <= J) tile_epilogue<true, true>(acc1, 32 * bi1, 32 * bj1, I, J, ep, lane);
+            else tile_epilogue<true, false>(acc1, 32 * bi1, 32 * bj1, I, J, ep, lane);
+        }
     }
 }
 
