@@ -497,3 +497,55 @@ def test_td3_counter_mode_vs_oracle(eng, orc, golden, hidden, layers, batch, act
         assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
         assert float(il.score[c]) == o["score"]
         assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
+def test_inner_loop_full_size_properties(eng, orc):
+    """BASELINE configs[1] at full size (pop 64 = 192 chains, B=199, 200-step episodes, the bench's 20 train episodes):
+    size-independent properties of the fused kernel + a spot check of whole chains against the oracle.
+      * determinism: two launches are bit-identical;
+      * chains are independent: permuting the chain order permutes every output;
+      * antithetic symmetry: (sign=+1, eps) == (sign=-1, -eps) bit for bit (GTN_worker.py:165-198)."""
+    from learning_environments_amd import configs
+    from learning_environments_amd.config import ddqn_cfg_from_config
+    cfgd = configs.fixed_work(configs.cartpole_syn_env_ddqn(64), 20)
+    cfg = ddqn_cfg_from_config(cfgd)
+    ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=cfg.grad_chunk, rng_mode=0)
+    S, A, pop = cfg.state_dim, cfg.num_actions, 64
+    chains = 3 * pop
+    rng = np.random.RandomState(11)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, cfg.se_hidden, 1, "leakyrelu"))
+    P_q = orc.mlp_num_params(orc.mlp_desc(S, cfg.q_hidden, 1, A, "tanh"))
+    theta = (rng.randn(P_se) * 0.15).astype(np.float32)
+    eps = (rng.randn(pop, P_se) * 0.0124).astype(np.float32)
+    agent_init = rng.uniform(-0.4, 0.4, (chains, P_q)).astype(np.float32)
+    worker = np.repeat(np.arange(pop), 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), pop)
+    keys = np.array([orc.chain_key(1234, 5, int(worker[c]), c % 3) for c in range(chains)], np.uint64)
+
+    def run(theta_, eps_, worker_, sign_, init_, keys_):
+        il = eng.InnerLoop(cfg, chains)
+        il.run(dev(theta_), dev(eps_), dev(worker_), dev(sign_), dev(init_), rng_keys=dev(keys_.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return (il.score.cpu().numpy().copy(), il.stats.cpu().numpy().copy(), il.episode_test_mean.cpu().numpy().copy(),
+                il.final_returns.cpu().numpy().copy())
+
+    base = run(theta, eps, worker, sign, agent_init, keys)
+    assert base[1][:, 2].min() > 0                                     # every chain trained
+    again = run(theta, eps, worker, sign, agent_init, keys)
+    for a, b in zip(base, again):
+        assert np.array_equal(a, b, equal_nan=True)
+    perm = rng.permutation(chains)
+    permuted = run(theta, eps, worker[perm], sign[perm], agent_init[perm], keys[perm])
+    for a, b in zip(base, permuted):
+        assert np.array_equal(a[perm], b, equal_nan=True)
+    flipped = run(theta, -eps, worker, -sign, agent_init, keys)          # sign 0 stays 0, +1 <-> -1 with eps negated
+    for a, b in zip(base, flipped):
+        assert np.array_equal(a, b, equal_nan=True)
+    for c in (1, 95):                                                   # whole chains against the oracle at full size
+        w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+        o = orc.ddqn_se_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]))
+        assert float(base[0][c]) == o["score"]
+        assert base[1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(base[2][c], o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(base[3][c], o["final_test_returns"])
