@@ -219,7 +219,8 @@ typedef struct {
     int32_t env_id, state_dim, action_dim, max_steps;
     int32_t rn_hidden, rn_layers, rn_act;
     float rn_prelu;
-    int32_t reward_env_type;                 /* 0,1,2,5,6 */
+    int32_t reward_env_type;                 /* 0-8, 101, 102 (envs/reward_env.py:29-59) */
+    int32_t info_dim;                        /* length of the real env's info vector (4 for the stand-in; used by types 3,4,7,8,101,102) */
     int32_t hidden, layers, act;             /* actor / critic MLPs (models/actor_critic.py:11-19,64-71) */
     float prelu;
     int32_t batch_size, rb_size, train_episodes, test_episodes, init_episodes, early_out_num, policy_delay, rng_mode;
@@ -265,6 +266,20 @@ int lenv_td3_rn_inner_loop(const lenv_td3_cfg *cfg /*HOST*/, const float *theta,
  * behind Critic_DQN / Actor_TD3.net / Critic_Q / reward_net calls of the one-step API).
  */
 int lenv_mlp_forward(const lenv_mlp_desc *d /*HOST*/, const float *params, const float *x, int64_t rows, float *y, void *stream);
+
+/*
+ * RewardEnv on a vector-state real env, one-step API (envs/reward_env.py:29-133).
+ * lenv_rn_num_params: parameters of build_reward_net for a reward type -- MLP on state_dim (types 1,2,5,6) or
+ * state_dim+info_dim (3,4,7,8) inputs, Linear(info_dim,1,bias=False) for 101/102, 0 for type 0; LENV_ERR_UNSUPPORTED for an
+ * unknown type (the reference raises NotImplementedError).  HOST.
+ * lenv_rn_shape_rows: RewardEnv._calc_reward for `rows` transitions: s, s2 [rows,state_dim], info [rows,info_dim] (the
+ * real env's info values in dict order, fp32; may be NULL for the types that do not read it -- otherwise a missing info
+ * is LENV_ERR_INVALID, the reference's ValueError), r [rows] the real reward rounded to fp32; out [rows] fp32.
+ */
+int64_t lenv_rn_num_params(int32_t type, int32_t state_dim, int32_t info_dim, int32_t hidden, int32_t layers);
+int lenv_rn_shape_rows(int32_t type, const lenv_mlp_desc *rn /*HOST, types 1-8*/, int32_t state_dim, int32_t info_dim, double gamma,
+                       const float *theta, const float *s, const float *s2, const float *info, const float *r, int64_t rows,
+                       float *out, void *stream);
 
 /* HalfCheetah-v3 STAND-IN reset / step for n instances (state [n,17] float64, action [n,6], obs [n,17]); same contract as
  * lenv_real_env_reset / lenv_real_env_step. */

@@ -70,7 +70,7 @@ class QlOut(C.Structure):
 class Td3Cfg(C.Structure):
     _fields_ = [("env_id", C.c_int32), ("state_dim", C.c_int32), ("action_dim", C.c_int32), ("max_steps", C.c_int32),
                 ("rn_hidden", C.c_int32), ("rn_layers", C.c_int32), ("rn_act", C.c_int32), ("rn_prelu", C.c_float),
-                ("reward_env_type", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("act", C.c_int32),
+                ("reward_env_type", C.c_int32), ("info_dim", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("act", C.c_int32),
                 ("prelu", C.c_float), ("batch_size", C.c_int32), ("rb_size", C.c_int32), ("train_episodes", C.c_int32),
                 ("test_episodes", C.c_int32), ("init_episodes", C.c_int32), ("early_out_num", C.c_int32),
                 ("policy_delay", C.c_int32), ("rng_mode", C.c_int32),
@@ -96,7 +96,8 @@ EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv
            "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_lds_bytes", "lenv_ddqn_se_inner_loop",
            "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population", "lenv_dueling_se_workspace_bytes",
            "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
-           "lenv_td3_rn_inner_loop", "lenv_mlp_forward", "lenv_cheetah_standin_reset", "lenv_cheetah_standin_step"]
+           "lenv_td3_rn_inner_loop", "lenv_mlp_forward", "lenv_cheetah_standin_reset", "lenv_cheetah_standin_step",
+           "lenv_rn_num_params", "lenv_rn_shape_rows"]
 
 
 def build(force=False):
@@ -158,6 +159,10 @@ def lib():
         L.lenv_td3_rn_inner_loop.restype = C.c_int
         L.lenv_td3_rn_inner_loop.argtypes = [C.POINTER(Td3Cfg), vp, vp, vp, vp, vp, vp, C.POINTER(Td3Tapes), C.c_int64, vp, C.c_size_t,
                                              C.POINTER(Td3Out), vp]
+        L.lenv_rn_num_params.restype = C.c_int64
+        L.lenv_rn_num_params.argtypes = [C.c_int32] * 5
+        L.lenv_rn_shape_rows.restype = C.c_int
+        L.lenv_rn_shape_rows.argtypes = [C.c_int32, C.POINTER(MlpDesc), C.c_int32, C.c_int32, C.c_double, vp, vp, vp, vp, vp, C.c_int64, vp, vp]
         L.lenv_mlp_forward.restype = C.c_int
         L.lenv_mlp_forward.argtypes = [C.POINTER(MlpDesc), vp, vp, C.c_int64, vp, vp]
         L.lenv_cheetah_standin_reset.restype = C.c_int

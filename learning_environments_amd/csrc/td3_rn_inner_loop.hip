@@ -62,7 +62,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     float *ep_rew = reinterpret_cast<float *>(ret + T);   // [T]
     float *state = ep_rew + T;                            // [20] current observation (fp32)
     float *action = state + 20;                           // [8]
-    float *newrow = action + 8;                           // [48]
+    float *newrow = action + 8;                           // [56] replay row [s | a | s' | r | done] + scratch + info[4] at 2S+A+4
     volatile float *ctrl = misc;
     volatile int *ictrl = reinterpret_cast<volatile int *>(misc + 32);
 
@@ -79,8 +79,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     {
         const float sg = a.eps ? a.sign[chain] : 0.0f;
         const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P_rn : nullptr;
-        if (cfg.reward_env_type != 0)
-            for (int i = tid; i < a.P_rn; i += DNT) rn_w[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
+        for (int i = tid; i < a.P_rn; i += DNT) rn_w[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
     }
     for (int p = tid; p < P; p += DNT) {
         const float w = a.agent_init[chain * P + p];
@@ -183,13 +182,26 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         __syncthreads();
     };
 
-    // phi(obs) = reward_net(obs) for the observation in `obs` (LDS/global, S floats) -> ctrl[slot]
-    auto rn_eval = [&](const float *obs, int slot) {
+    // phi = reward_net(obs [| info]) for the observation in `obs` (LDS, S floats) -> ctrl[slot].  Types 3,4,7,8 append the
+    // real env's info vector to the input (reward_env.py:98-101); 101/102 are Linear(info_dim, 1, bias=False) of it.
+    const bool rn_info_in = rtype == 3 || rtype == 4 || rtype == 7 || rtype == 8;
+    const int Drn = rn_info_in ? S + cfg.info_dim : S;
+    auto rn_eval = [&](const float *obs, const float *info, int slot) {
         if (rtype == 0) { if (tid == 0) ctrl[slot] = 0.0f; __syncthreads(); return; }
-        const float *W0 = rn_w, *b0 = rn_w + Hrn * S, *Wo = b0 + Hrn, *bo = Wo + Hrn;
+        if (rtype > 100) {
+            if (tid == 0) {
+                float acc = 0.0f;
+                for (int k = 0; k < cfg.info_dim; ++k) acc = fma32(info[k], rn_w[k], acc);
+                ctrl[slot] = acc;
+            }
+            __syncthreads();
+            return;
+        }
+        const float *W0 = rn_w, *b0 = rn_w + Hrn * Drn, *Wo = b0 + Hrn, *bo = Wo + Hrn;
         for (int j = tid; j < Hrn; j += DNT) {
             float z = 0.0f;
-            for (int k = 0; k < S; ++k) z = fma32(obs[k], W0[j * S + k], z);
+            for (int k = 0; k < S; ++k) z = fma32(obs[k], W0[j * Drn + k], z);
+            if (rn_info_in) for (int k = 0; k < cfg.info_dim; ++k) z = fma32(info[k], W0[j * Drn + S + k], z);
             rn_h[j] = act_fwd(cfg.rn_act, cfg.rn_prelu, z + b0[j]);
         }
         __syncthreads();
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             state[i] = (float)v;
         }
         __syncthreads();
-        rn_eval(state, 12);                                // phi(s) of the reset state
+        if (rtype == 1 || rtype == 2) rn_eval(state, nullptr, 12);   // phi(s) of the reset state (carried from step to step)
         int ep_len = 0;
         for (int t = 0; t < cfg.max_steps; ++t) {
             const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
@@ -301,17 +313,23 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             if (tid < S) { xs_d[tid] = nx; newrow[tid] = state[tid]; newrow[S + A + tid] = (float)nx; }
             if (tid >= 64 && tid < 64 + A) newrow[S + tid - 64] = action[tid - 64];
             __syncthreads();
-            rn_eval(newrow + S + A, 13);                   // phi(s')
+            float *info = newrow + 2 * S + A + 4;          // [4] info vector of this step (fp32, as torch.tensor(list(info.values())))
+            if (tid == 0 && rtype >= 3) {
+                info[0] = (float)xs_d[0]; info[1] = (float)xs_d[8]; info[2] = (float)xs_d[8]; info[3] = (float)(-0.1 * xs_d[18]);
+            }
+            __syncthreads();
+            if (rtype == 3 || rtype == 4) rn_eval(newrow, info, 12);                 // phi([s | info]): not cacheable, info is this step's
+            rn_eval(newrow + S + A, info, 13);             // phi(s') / phi([s' | info]) / w . info
             if (tid == 0) {
                 const double rew = xs_d[8] - 0.1 * xs_d[18];
                 const float r32 = (float)rew, phi_s = ctrl[12], phi_s2 = ctrl[13];
-                float shaped;                              // RewardEnv._calc_reward (reward_env.py:81-110)
+                float shaped;                              // RewardEnv._calc_reward (reward_env.py:81-131)
                 switch (rtype) {
                 case 0: shaped = r32; break;
-                case 1: shaped = g32 * phi_s2 - phi_s; break;
-                case 2: shaped = (r32 + g32 * phi_s2) - phi_s; break;
-                case 5: shaped = phi_s2; break;
-                default: shaped = r32 + phi_s2; break;
+                case 1: case 3: shaped = g32 * phi_s2 - phi_s; break;
+                case 2: case 4: shaped = (r32 + g32 * phi_s2) - phi_s; break;
+                case 5: case 7: case 101: shaped = phi_s2; break;
+                default: shaped = r32 + phi_s2; break;     // 6, 8, 102
                 }
                 const int dn = t + 1 >= cfg.max_steps;
                 newrow[2 * S + A] = shaped; newrow[2 * S + A + 1] = dn ? 1.0f : 0.0f;
@@ -466,14 +484,16 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
     const int H = cfg->hidden, L = cfg->layers, B = cfg->batch_size, T = cfg->test_episodes, Hrn = cfg->rn_hidden;
     if (cfg->env_id != LENV_ENV_CHEETAH_STANDIN || cfg->state_dim != T3_S || cfg->action_dim != T3_A) return LENV_ERR_UNSUPPORTED;
     const int t = cfg->reward_env_type;
-    if (!(t == 0 || t == 1 || t == 2 || t == 5 || t == 6)) return LENV_ERR_UNSUPPORTED;      // info-vector types: next
+    if (!((t >= 0 && t <= 8) || t == 101 || t == 102)) return LENV_ERR_UNSUPPORTED;          // reward_env.py:49,58 NotImplementedError
+    const bool uses_info = t == 3 || t == 4 || t == 7 || t == 8 || t > 100;
+    if (uses_info && cfg->info_dim != 4) return LENV_ERR_INVALID;                              // the stand-in's info vector has 4 entries
     if (L < 1 || L > T3_MAXL || H < 1 || H > T3_MAXW || B < 1 || B > 2 * GT_I || T < 1 || T * T3_S > DNT || cfg->rn_layers != 1 || Hrn < 1 ||
         cfg->policy_delay < 1 || cfg->max_steps < 1 || cfg->train_episodes < 0)
         return LENV_ERR_UNSUPPORTED;
     mlp_off(a.actor, T3_S, H, L, T3_A);
     mlp_off(a.critic, T3_SA, H, L, 1);
     a.P = a.actor.P + 2 * a.critic.P;
-    a.P_rn = T3_S * Hrn + Hrn + Hrn + 1;
+    a.P_rn = (int)lenv_rn_num_params(t, T3_S, cfg->info_dim, Hrn, 1);
     a.RS = (2 * T3_S + T3_A + 2 + 3) & ~3;
     int64_t cap = (int64_t)cfg->train_episodes * cfg->max_steps;
     if (cap > cfg->rb_size) cap = cfg->rb_size;
@@ -489,7 +509,7 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
     a.a_dx = take((int64_t)RB * T3_SA); a.a_act = take((int64_t)RB * T3_A); a.a_th = take((int64_t)RB * T3_A); a.a_dz = take((int64_t)RB * T3_A);
     a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
     a.arena_stride = (off + 63) & ~(int64_t)63;
-    const size_t lds_floats = 2 * (size_t)GT_RB * GT_LD + ((a.P_rn + 3) & ~3) + ((Hrn + 3) & ~3) + 8 * (size_t)B + 64 + 2 + 2 * (20 + 17 * (size_t)T + T) + T + 20 + 8 + 48 + 16;
+    const size_t lds_floats = 2 * (size_t)GT_RB * GT_LD + ((a.P_rn + 3) & ~3) + ((Hrn + 3) & ~3) + 8 * (size_t)B + 64 + 2 + 2 * (20 + 17 * (size_t)T + T) + T + 20 + 8 + 56 + 16;
     *lds_bytes = lds_floats * sizeof(float);
     if (*lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     return LENV_OK;

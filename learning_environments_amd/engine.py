@@ -52,6 +52,29 @@ def mlp_forward(d, params, x):
     return y
 
 
+def rn_num_params(rtype, state_dim, info_dim, hidden, layers):
+    """Parameter count of RewardEnv.build_reward_net for a reward type (reference envs/reward_env.py:29-59)."""
+    n = _lib.lib().lenv_rn_num_params(int(rtype), int(state_dim), int(info_dim), int(hidden), int(layers))
+    _lib.check(int(n) if n < 0 else 0, "lenv_rn_num_params")
+    return int(n)
+
+
+def rn_shape_rows(rtype, rn_desc, state_dim, info_dim, gamma, theta, s, s2, info, r):
+    """RewardEnv._calc_reward (reference envs/reward_env.py:68-133) for rows of a vector-state real env; device tensors.
+    `info` may be None for the types that do not read it; for the others a missing info raises ValueError like the
+    reference."""
+    dev = require_device()
+    for t, n in ((s, "s"), (s2, "s2"), (r, "r")):
+        _chk(t, torch.float32, n)
+    rows = s.shape[0]
+    out = torch.empty(rows, dtype=torch.float32, device=dev)
+    rc = _lib.lib().lenv_rn_shape_rows(int(rtype), C.byref(rn_desc) if rn_desc is not None else None, int(state_dim), int(info_dim),
+                                       float(gamma), _ptr(theta) if theta is not None else None, _ptr(s), _ptr(s2),
+                                       _ptr(info) if info is not None else None, _ptr(r), rows, _ptr(out), _stream())
+    _lib.check(rc, "lenv_rn_shape_rows")
+    return out
+
+
 def se_descs(S, A, hidden, layers, act, prelu=0.25):
     return (mlp_desc(S + A, hidden, layers, S, act, prelu), mlp_desc(S + A, hidden, layers, 1, act, prelu),
             mlp_desc(S + A, hidden, layers, 1, act, prelu))

@@ -81,7 +81,16 @@ class DeviceRealEnv(object):
             rc = _lib.lib().lenv_real_env_step(self.env_id, int(self._max_episode_steps), 1, _ptr(d["action"]), _ptr(d["state"]),
                                                _ptr(d["elapsed"]), _ptr(d["obs"]), _ptr(d["reward"]), _ptr(d["done"]), _stream())
         _lib.check(rc, "lenv_real_env_step")
-        return d["obs"].cpu().numpy(), float(d["reward"].item()), bool(d["done"].item() > 0.5), {}
+        info = {}
+        if self.continuous:
+            # info dict of the stand-in (same keys/order as HalfCheetah-v3: x_position, x_velocity, reward_run, reward_ctrl);
+            # consumed by the RewardEnv types 3,4,7,8,101,102 (reward_env.py:95-131)
+            st = d["state"].cpu().numpy().reshape(-1)
+            ctrl = 0.0
+            for v in np.asarray(action, np.float32).reshape(-1):
+                ctrl = ctrl + float(v) * float(v)
+            info = {"x_position": float(st[0]), "x_velocity": float(st[8]), "reward_run": float(st[8]), "reward_ctrl": -0.1 * ctrl}
+        return d["obs"].cpu().numpy(), float(d["reward"].item()), bool(d["done"].item() > 0.5), info
 
     def render(self, mode='human'):
         return None

@@ -4,8 +4,9 @@ envs/reward_env.py:7-149), MI355X edition.
 Same constructor kwargs, attributes and state-dict keys (`reward_net.0.weight`, `reward_net.1.weight` (PReLU slope),
 `reward_net.2.weight`, ...).  For discrete-state real envs (gridworlds) the network only ever sees one-hot states, so
 `step` reads the shaped reward of (state, action) from a table that `lenv_rn_shape_population` evaluates on the device
-whenever the parameters change.  Reward types that need the real env's info vector (3,4,7,8,101,102) and
-continuous-state real envs are the next row of the scope table and raise NotImplementedError."""
+whenever the parameters change; the info-vector reward types (3,4,7,8,101,102) raise ValueError there exactly like the
+reference, because gridworlds return an empty info dict (reward_env.py:95-96).  For vector-state real envs (the
+HalfCheetah stand-in) all 11 types go through `lenv_rn_shape_rows`."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -93,36 +94,33 @@ class RewardEnv(nn.Module):
         return self._table
 
     def step(self, action):
-        if self.reward_env_type in (3, 4, 7, 8, 101, 102):
-            raise NotImplementedError("reward_env_type %d needs the real env's info vector: next row of the scope table"
-                                      % self.reward_env_type)
         state = self.state
         next_state, reward, done, info = self.real_env.step(action)
-        if isinstance(self.real_env, GridEnv):
-            reward_res = self.shaped_table()[int(state), int(action)].item()
-        else:
-            reward_res = self._shape_continuous(state, next_state, reward)
+        reward_res = self._calc_reward(state=state, next_state=next_state, reward=reward, info=info, action=action)
         self.state = next_state
         return next_state, reward_res, done, {}
 
-    def _shape_continuous(self, state, next_state, reward):
-        """reward_env.py:77-110 for vector states: phi(s), phi(s') through lenv_mlp_forward, combined in fp32 left to right."""
-        from ..models.model_utils import mlp_desc
+    def _calc_reward(self, state, next_state, reward, info, action=None):
+        """reference envs/reward_env.py:68-133."""
+        if 'TimeLimit.truncated' in info:
+            info.pop('TimeLimit.truncated')
         t = self.reward_env_type
-        r32 = torch.tensor(reward, dtype=torch.float32)
+        if t in (3, 4, 7, 8, 101, 102) and not info:
+            raise ValueError('No info dict provided by environment')
+        if isinstance(self.real_env, GridEnv):
+            return self.shaped_table()[int(state), int(action)].item()
+        from ..models.model_utils import mlp_desc
+        dev = engine.require_device()
+        r32 = torch.tensor([reward], dtype=torch.float32, device=dev)
         if t == 0:
             return r32.item()
-        dev = engine.require_device()
-        x = torch.from_numpy(np.stack([np.asarray(state, np.float32), np.asarray(next_state, np.float32)])).to(dev)
-        phi = engine.mlp_forward(mlp_desc(self.reward_net, self.activation_fn), self.flat_params(), x).cpu().reshape(-1)
-        g = torch.tensor(self.gamma, dtype=torch.float32)
-        if t == 1:
-            return (g * phi[1] - phi[0]).item()
-        if t == 2:
-            return ((r32 + g * phi[1]) - phi[0]).item()
-        if t == 5:
-            return phi[1].item()
-        return (r32 + phi[1]).item()
+        s = torch.from_numpy(np.asarray(state, np.float32).reshape(1, -1)).to(dev)
+        s2 = torch.from_numpy(np.asarray(next_state, np.float32).reshape(1, -1)).to(dev)
+        inf = torch.tensor([list(info.values())], dtype=torch.float32, device=dev) if info else None
+        desc = mlp_desc(self.reward_net, self.activation_fn) if t < 100 else None
+        out = engine.rn_shape_rows(t, desc, self.state_dim, self.info_dim if inf is not None else 0, self.gamma, self.flat_params(),
+                                   s, s2, inf, r32)
+        return out.item()
 
     def seed(self, seed):
         return self.real_env.seed(seed)

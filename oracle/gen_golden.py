@@ -501,6 +501,46 @@ def gen_g2():
     save("g2_reward_env_cliff", types=np.array(types), **out)
 
 
+
+# ------------------------------------------------------------------------------------------------
+# G2F: RewardEnv.step on the vector-state stand-in, all 11 reward types incl. the info-vector ones
+# ------------------------------------------------------------------------------------------------
+def gen_g2f():
+    import json
+    from envs.env_factory import EnvFactory
+    out = {}
+    types = [0, 1, 2, 3, 4, 5, 6, 7, 8, 101, 102]
+    n_steps = 6
+    for t in types:
+        cfg = _td3_cfg(env_over={"reward_env_type": t, "hidden_size": 24, "max_steps": n_steps})
+        seed_all(2600 + t)
+        with quiet():
+            renv = EnvFactory(cfg).generate_reward_env()
+        renv.set_agent_params(same_action_num=1, gamma=0.98)
+        sd = renv.state_dict()
+        if t in (101, 102):
+            theta = sd["env.reward_net.weight"].numpy().reshape(-1).astype(np.float32)
+        else:
+            theta = pack_linear_params(sd, "env.reward_net.")
+        rng = np.random.RandomState(77 + t)
+        s0 = renv.reset().numpy().astype(np.float64)          # fp32 view of the env's fp64 state
+        s0_exact = np.array(renv.env.real_env.env.state, np.float64)
+        acts = rng.uniform(-1, 1, (n_steps, 6)).astype(np.float32)
+        ns, rs, ds = [], [], []
+        with torch.no_grad():
+            for k in range(n_steps):
+                n_, r_, d_ = renv.step(torch.from_numpy(acts[k].copy()))
+                ns.append(n_.numpy().copy()); rs.append(float(r_)); ds.append(float(d_))
+        key = "t%d_" % t
+        out[key + "theta"] = theta
+        out[key + "reset_state"] = s0_exact
+        out[key + "actions"] = acts
+        out[key + "next_states"] = np.array(ns, np.float32)
+        out[key + "shaped"] = np.array(rs, np.float64)
+        out[key + "done"] = np.array(ds, np.float32)
+        out[key + "sd_keys"] = np.array(list(sd.keys()))
+    save("g2f_reward_env_cheetah_info", types=np.array(types), hidden=24, gamma=0.98, config_json=json.dumps(_td3_cfg(env_over={"hidden_size": 24, "max_steps": n_steps})), **out)
+
 # ------------------------------------------------------------------------------------------------
 # G9: full GTN_Worker.calc_score on the Cliff RewardEnv with QL (cfg 4) + tapes + per-step trace
 # ------------------------------------------------------------------------------------------------
@@ -844,7 +884,7 @@ def gen_g8t(name, seed):
 
 
 def main():
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f"]
     os.makedirs(OUT, exist_ok=True)
     if "g1" in which:
         gen_g1()
@@ -869,6 +909,8 @@ def main():
                env_over={"hidden_size": 32, "solved_reward": 0.5})
     if "g2" in which:
         gen_g2()
+    if "g2f" in which:
+        gen_g2f()
     if "g9" in which:
         gen_g9("g9_calc_score_cliff_a", seed=900)
         gen_g9("g9_calc_score_cliff_b", seed=901, eps_over=0.2)

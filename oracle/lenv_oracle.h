@@ -195,7 +195,8 @@ typedef struct {
     int32_t env_id, state_dim, action_dim, max_steps;
     int32_t rn_hidden, rn_layers, rn_act;
     float rn_prelu;
-    int32_t reward_env_type;                 /* 0,1,2,5,6 */
+    int32_t reward_env_type;                 /* 0-8, 101, 102 (reward_env.py:29-59) */
+    int32_t info_dim;                        /* length of the real env's info vector (4 for the stand-in) */
     int32_t hidden, layers, act;             /* actor / critic MLPs (models/actor_critic.py:11-19,64-71) */
     float prelu;
     int32_t batch_size, rb_size, train_episodes, test_episodes, init_episodes, early_out_num, policy_delay, rng_mode;
@@ -233,6 +234,14 @@ int orc_td3_critic_forward(const orc_td3_cfg *cfg, const float *critic, const fl
 int orc_td3_learn(const orc_td3_cfg *cfg, float *params, float *targets, float *adam_m, float *adam_v, double pows[4],
                   int64_t total_it /*1-based*/, const float *rows, int64_t row_stride, const float *policy_noise /*[B,A] N(0,1)*/,
                   float *losses /*[2] critic, actor (optional)*/);
+/* number of reward-net parameters for a RewardEnv type (reward_env.py:29-59): MLP on S (types 1,2,5,6) or S+info_dim
+ * (3,4,7,8) inputs, Linear(info_dim,1,bias=False) for 101/102, 0 for type 0 (its dummy net is never evaluated) */
+int64_t orc_rn_num_params(int type, int S, int info_dim, int hidden, int layers);
+/* RewardEnv._calc_reward (reward_env.py:68-133) for n rows of a vector-state env: s,s2 [n,S], info [n,info_dim], r [n]
+ * (the real reward already rounded to fp32); fp32, left to right.  Returns -1 for unknown types. */
+int orc_rn_shape_rows(int type, int S, int info_dim, int hidden, int layers, int act, float prelu, double gamma,
+                      const float *rn_params, const float *s, const float *s2, const float *info, const float *r, int64_t n,
+                      float *out);
 int orc_td3_rn_chain(const orc_td3_cfg *cfg, const float *rn_params, const float *agent_init /*[actor|critic1|critic2]*/,
                      uint64_t rng_key, const orc_td3_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
                      double *final_test_returns, orc_td3_trace *trace, orc_chain_result *res);

@@ -65,7 +65,7 @@ class QlTrace(C.Structure):
 class Td3Cfg(C.Structure):
     _fields_ = [("env_id", C.c_int32), ("state_dim", C.c_int32), ("action_dim", C.c_int32), ("max_steps", C.c_int32),
                 ("rn_hidden", C.c_int32), ("rn_layers", C.c_int32), ("rn_act", C.c_int32), ("rn_prelu", C.c_float),
-                ("reward_env_type", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("act", C.c_int32),
+                ("reward_env_type", C.c_int32), ("info_dim", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("act", C.c_int32),
                 ("prelu", C.c_float), ("batch_size", C.c_int32), ("rb_size", C.c_int32), ("train_episodes", C.c_int32),
                 ("test_episodes", C.c_int32), ("init_episodes", C.c_int32), ("early_out_num", C.c_int32),
                 ("policy_delay", C.c_int32), ("rng_mode", C.c_int32),
@@ -437,8 +437,8 @@ def td3_cfg_from_config(config, rng_mode=0, **overrides):
     assert a["same_action_num"] == 1
     cfg = Td3Cfg(env_id=2, state_dim=17, action_dim=6, max_steps=int(e["max_steps"]), rn_hidden=int(e["hidden_size"]),
                  rn_layers=int(e["hidden_layer"]), rn_act=ACT[e["activation_fn"]], rn_prelu=0.25,
-                 reward_env_type=int(e["reward_env_type"]), hidden=int(a["hidden_size"]), layers=int(a["hidden_layer"]),
-                 act=ACT[a["activation_fn"]], prelu=0.25, batch_size=int(a["batch_size"]), rb_size=int(a["rb_size"]),
+                 reward_env_type=int(e["reward_env_type"]), info_dim=int(e.get("info_dim", 0)), hidden=int(a["hidden_size"]),
+                 layers=int(a["hidden_layer"]), act=ACT[a["activation_fn"]], prelu=0.25, batch_size=int(a["batch_size"]), rb_size=int(a["rb_size"]),
                  train_episodes=int(a["train_episodes"]), test_episodes=int(a["test_episodes"]),
                  init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]),
                  policy_delay=int(a["policy_delay"]), rng_mode=rng_mode, solved_reward=float(e["solved_reward"]),
@@ -515,4 +515,24 @@ def td3_rn_chain(cfg, rn_params, agent_init, rng_key=0, tapes=None, trace_cap=0)
                test_steps=res.test_steps, episode_test_mean=ep_mean[:E], episode_len=ep_len[:E], final_test_returns=final[:T])
     if tr is not None:
         out["trace"] = {k: v[:tr.n] for k, v in arrs.items()}
+    return out
+
+
+def rn_num_params(rtype, S, info_dim, hidden, layers):
+    lib().orc_rn_num_params.restype = C.c_int64
+    return int(lib().orc_rn_num_params(int(rtype), int(S), int(info_dim), int(hidden), int(layers)))
+
+
+def rn_shape_rows(rtype, S, info_dim, hidden, layers, act, prelu, gamma, rn_params, s, s2, info, r):
+    """RewardEnv._calc_reward (reward_env.py:68-133) for rows of a vector-state env; all 11 reward types."""
+    s, s2, r = _f32(s).reshape(-1, S), _f32(s2).reshape(-1, S), _f32(r).reshape(-1)
+    n = s.shape[0]
+    info = _f32(info).reshape(n, info_dim) if info is not None and info_dim > 0 else None
+    rn_params = _f32(rn_params if rn_params is not None and len(rn_params) else np.zeros(1, np.float32))
+    out = np.zeros(n, np.float32)
+    rc = lib().orc_rn_shape_rows(int(rtype), int(S), int(info_dim), int(hidden), int(layers), int(ACT[act]) if isinstance(act, str) else int(act),
+                                 C.c_float(prelu), C.c_double(gamma), _p(rn_params, C.c_float), _p(s, C.c_float), _p(s2, C.c_float),
+                                 _p(info, C.c_float) if info is not None else None, _p(r, C.c_float), C.c_int64(n), _p(out, C.c_float))
+    if rc != 0:
+        raise ValueError("orc_rn_shape_rows rc=%d" % rc)
     return out

@@ -465,7 +465,10 @@ def test_td3_tape_mode_vs_reference_and_oracle(eng, orc, golden):
         assert abs(float(il.score[c]) - float(g["score"])) <= 2e-3
 
 
-@pytest.mark.parametrize("hidden,layers,batch,act,delay,rtype", [(128, 2, 192, "relu", 1, 2), (40, 1, 50, "tanh", 2, 1), (33, 2, 130, "leakyrelu", 3, 6)])
+@pytest.mark.parametrize("hidden,layers,batch,act,delay,rtype", [(128, 2, 192, "relu", 1, 2), (40, 1, 50, "tanh", 2, 1), (33, 2, 130, "leakyrelu", 3, 6),
+                                                                 (24, 1, 32, "relu", 1, 3), (24, 1, 32, "relu", 1, 4), (24, 1, 32, "relu", 2, 7),
+                                                                 (24, 1, 32, "tanh", 1, 8), (24, 1, 32, "relu", 1, 101), (24, 1, 32, "relu", 1, 102),
+                                                                 (24, 1, 32, "relu", 1, 0), (24, 1, 32, "relu", 1, 5)])
 def test_td3_counter_mode_vs_oracle(eng, orc, golden, hidden, layers, batch, act, delay, rtype):
     g = golden("g8t_calc_score_cheetah_td3")
     cfgd = json.loads(str(g["config_json"]))
@@ -474,7 +477,8 @@ def test_td3_counter_mode_vs_oracle(eng, orc, golden, hidden, layers, batch, act
     cfgd["envs"]["HalfCheetah-v3"].update(max_steps=6, hidden_size=128 if hidden == 128 else 24, reward_env_type=rtype)
     ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
     Pa, Pc = orc.td3_param_counts(ocfg)
-    P_rn = 17 * ocfg.rn_hidden + 2 * ocfg.rn_hidden + 1
+    P_rn = max(1, orc.rn_num_params(rtype, 17, 4, ocfg.rn_hidden, 1))
+    assert ocfg.info_dim == 4
     rng = np.random.RandomState(11)
     chains = 3
     theta = (rng.randn(P_rn) * 0.2).astype(np.float32)
@@ -497,6 +501,30 @@ def test_td3_counter_mode_vs_oracle(eng, orc, golden, hidden, layers, batch, act
         assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
         assert float(il.score[c]) == o["score"]
         assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
+@pytest.mark.parametrize("rtype", [0, 1, 2, 3, 4, 5, 6, 7, 8, 101, 102])
+def test_rn_shape_rows_vs_oracle(eng, orc, rtype):
+    """RewardEnv._calc_reward for rows of a vector-state env, every reward type: bit-exact against the oracle."""
+    rng = np.random.RandomState(rtype)
+    S, nI, H, n = 17, 4, 37, 33
+    P = max(1, orc.rn_num_params(rtype, S, nI, H, 1))
+    theta = (rng.randn(P) * 0.3).astype(np.float32)
+    s, s2 = rng.randn(n, S).astype(np.float32), rng.randn(n, S).astype(np.float32)
+    info, r = rng.randn(n, nI).astype(np.float32), rng.randn(n).astype(np.float32)
+    for act in ("prelu", "tanh"):
+        desc = eng.mlp_desc(S + nI if rtype in (3, 4, 7, 8) else S, H, 1, 1, act, 0.25) if 1 <= rtype <= 8 else None
+        got = eng.rn_shape_rows(rtype, desc, S, nI, 0.98, dev(theta), dev(s), dev(s2), dev(info), dev(r)).cpu().numpy()
+        want = orc.rn_shape_rows(rtype, S, nI, H, 1, act, 0.25, 0.98, theta, s, s2, info, r)
+        assert np.array_equal(got, want), (rtype, act)
+    if rtype in (3, 4, 7, 8, 101, 102):
+        with pytest.raises(ValueError):                       # reward_env.py:96: 'No info dict provided by environment'
+            eng.rn_shape_rows(rtype, desc, S, 0, 0.98, dev(theta), dev(s), dev(s2), None, dev(r))
+
+
+def test_rn_unknown_type_raises(eng):
+    with pytest.raises(NotImplementedError):                  # reward_env.py:49,58
+        eng.rn_num_params(9, 17, 4, 8, 1)
 
 
 def test_inner_loop_full_size_properties(eng, orc):

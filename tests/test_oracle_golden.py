@@ -342,3 +342,44 @@ def test_g8t_calc_score_cheetah_td3(golden):
     np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=2e-3)
     np.testing.assert_allclose(out["final_test_returns"], g["reward_list_test"], rtol=0, atol=2e-3)
     assert abs(out["score"] - float(g["score"])) <= 2e-3
+
+
+def _standin_rollout(g, t):
+    """Replay the fixture's episode on the oracle's stand-in env: fp32 states, info vectors and raw fp32 rewards."""
+    import ctypes as C
+    L = orc.lib()
+    pre = "t%d_" % t
+    x = (C.c_double * 17)(*g[pre + "reset_state"])
+    rew = C.c_double()
+    s, s2, info, r = [], [], [], []
+    for k in range(g[pre + "actions"].shape[0]):
+        a = g[pre + "actions"][k]
+        s.append(np.array(list(x)).astype(np.float32))
+        L.orc_cheetah_step(x, (C.c_float * 6)(*a), C.byref(rew))
+        xa = np.array(list(x))
+        ctrl = 0.0
+        for v in a:
+            ctrl = ctrl + float(v) * float(v)
+        s2.append(xa.astype(np.float32))
+        info.append(np.array([xa[0], xa[8], xa[8], -0.1 * ctrl]).astype(np.float32))
+        r.append(np.float32(rew.value))
+    return np.array(s), np.array(s2), np.array(info), np.array(r)
+
+
+def test_g2f_reward_env_vector_state_all_types(golden):
+    """RewardEnv._calc_reward on a vector-state env for all 11 reward types (reward_env.py:29-133), incl. the types that
+    feed the real env's info vector to the network (3,4,7,8) and the linear info baselines (101,102)."""
+    g = golden("g2f_reward_env_cheetah_info")
+    H = int(g["hidden"])
+    for t in g["types"]:
+        t = int(t)
+        pre = "t%d_" % t
+        s, s2, info, r = _standin_rollout(g, t)
+        assert np.array_equal(s2, g[pre + "next_states"])
+        n_par = orc.rn_num_params(t, 17, 4, H, 1)
+        if t != 0:
+            assert n_par == g[pre + "theta"].size
+        shaped = orc.rn_shape_rows(t, 17, 4, H, 1, "prelu", 0.25, float(g["gamma"]), g[pre + "theta"], s, s2, info, r)
+        np.testing.assert_allclose(shaped, g[pre + "shaped"], rtol=0, atol=3e-6, err_msg="type %d" % t)
+    with pytest.raises(ValueError):
+        orc.rn_shape_rows(9, 17, 4, H, 1, "prelu", 0.25, 0.98, np.zeros(4), s, s2, info, r)
