@@ -24,8 +24,8 @@ class DdqnSeTask(object):
                                                                          (self.cfg.q_hidden, self.cfg.num_actions)]
         self.agent_bounds = torch.from_numpy(linear_init_bounds(dims)).to(engine.device)
 
-    def make_inner(self, chains):
-        return self.engine.make_inner(self.cfg, chains)
+    def make_inner(self, chains, want_episode_stats=True):
+        return self.engine.make_inner(self.cfg, chains, want_episode_stats=want_episode_stats)
 
     def scores(self, inner, theta, eps, chain_worker, chain_sign, keys_t, agent_init):
         return self.engine.inner_scores(inner, theta, eps, chain_worker, chain_sign, agent_init, keys_t)
@@ -43,8 +43,8 @@ class QlRnTask(object):
         self.cfg = ql_cfg_from_config(config, tables)
         self.agent_bounds = None
 
-    def make_inner(self, chains):
-        return self.engine.make_inner_ql(self.cfg, chains, self.tables, want_episode_stats=False)
+    def make_inner(self, chains, want_episode_stats=False):
+        return self.engine.make_inner_ql(self.cfg, chains, self.tables, want_episode_stats=want_episode_stats)
 
     def scores(self, inner, theta, eps, chain_worker, chain_sign, keys_t, agent_init):
         return self.engine.inner_scores_ql(inner, theta, eps, chain_worker, chain_sign, keys_t)
@@ -61,8 +61,8 @@ class Td3RnTask(object):
         self.cfg = td3_cfg_from_config(config)
         self.agent_bounds = torch.from_numpy(linear_init_bounds(td3_layer_dims(self.cfg))).to(engine.device)
 
-    def make_inner(self, chains):
-        return self.engine.make_inner_td3(self.cfg, chains, want_episode_stats=False)
+    def make_inner(self, chains, want_episode_stats=False):
+        return self.engine.make_inner_td3(self.cfg, chains, want_episode_stats=want_episode_stats)
 
     def scores(self, inner, theta, eps, chain_worker, chain_sign, keys_t, agent_init):
         return self.engine.inner_scores_td3(inner, theta, eps, chain_worker, chain_sign, agent_init, keys_t)

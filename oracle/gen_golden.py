@@ -541,6 +541,39 @@ def gen_g2f():
         out[key + "sd_keys"] = np.array(list(sd.keys()))
     save("g2f_reward_env_cheetah_info", types=np.array(types), hidden=24, gamma=0.98, config_json=json.dumps(_td3_cfg(env_over={"hidden_size": 24, "max_steps": n_steps})), **out)
 
+
+# ------------------------------------------------------------------------------------------------
+# CKPT: a reference-format checkpoint {'model': state_dict, 'config': dict} (GTN_master.py:133-139) + step outputs
+# ------------------------------------------------------------------------------------------------
+def gen_ckpt():
+    from envs.env_factory import EnvFactory
+    cfg = load_cfg("default_config_cartpole_syn_env.yaml")
+    cfg["agents"]["ddqn"].update(train_episodes=3, test_episodes=3, init_episodes=1, print_rate=int(1e9))
+    cfg["envs"]["CartPole-v0"]["max_steps"] = 30
+    seed_all(4100)
+    with quiet():
+        venv = EnvFactory(cfg).generate_virtual_env()
+    with torch.no_grad():
+        venv.env.done_net[-1].bias.fill_(-5.0)
+    path = os.path.join(OUT, "ckpt_cartpole_se_reference.pt")
+    torch.save({'model': venv.state_dict(), 'config': cfg}, path)           # exactly GTN_Master.save_model's payload
+    # what the reference computes with the re-loaded checkpoint (experiments/syn_env_evaluate_cartpole_vary_hp_2.py:12-23)
+    sd = torch.load(path)
+    with quiet():
+        v2 = EnvFactory(sd['config']).generate_virtual_env()
+    v2.load_state_dict(sd['model'])
+    rng = np.random.RandomState(9)
+    states = rng.uniform(-0.5, 0.5, (8, 4)).astype(np.float32)
+    actions = rng.randint(0, 2, 8)
+    ns, rs, ds = [], [], []
+    with torch.no_grad():
+        for k in range(8):
+            n_, r_, d_ = v2.step(action=torch.tensor([float(actions[k])]), state=torch.from_numpy(states[k]))
+            ns.append(n_.numpy().copy()); rs.append(float(r_)); ds.append(float(d_))
+    save("ckpt_cartpole_se_reference_steps", states=states, actions=actions.astype(np.int32), next_states=np.array(ns, np.float32),
+         rewards=np.array(rs, np.float32), dones=np.array(ds, np.float32), theta=se_theta(v2))
+    print("wrote", path, os.path.getsize(path))
+
 # ------------------------------------------------------------------------------------------------
 # G9: full GTN_Worker.calc_score on the Cliff RewardEnv with QL (cfg 4) + tapes + per-step trace
 # ------------------------------------------------------------------------------------------------
@@ -884,7 +917,7 @@ def gen_g8t(name, seed):
 
 
 def main():
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt"]
     os.makedirs(OUT, exist_ok=True)
     if "g1" in which:
         gen_g1()
@@ -911,6 +944,8 @@ def main():
         gen_g2()
     if "g2f" in which:
         gen_g2f()
+    if "ckpt" in which:
+        gen_ckpt()
     if "g9" in which:
         gen_g9("g9_calc_score_cliff_a", seed=900)
         gen_g9("g9_calc_score_cliff_b", seed=901, eps_over=0.2)

@@ -196,3 +196,17 @@ def test_master_rejects_unknown_options(tmp_path, monkeypatch):
     cfg["agents"]["gtn"]["agent_name"] = "PPO"
     with pytest.raises(NotImplementedError):
         GTN_Master(cfg, engine=OracleNesEngine())
+
+
+def test_reference_checkpoint_fixture_is_plain_payload():
+    """The committed reference-format checkpoint ({'model','config'}, GTN_master.py:133-139) loads under torch's safe
+    loader and carries the state-dict layout SURVEY.md §8(b) lists."""
+    import os
+    import torch
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt_cartpole_se_reference.pt")
+    d = torch.load(path, map_location="cpu", weights_only=True)
+    assert sorted(d.keys()) == ["config", "model"]
+    keys = list(d["model"].keys())
+    assert keys[:4] == ["env.state_net.0.weight", "env.state_net.0.bias", "env.state_net.2.weight", "env.state_net.2.bias"]
+    assert tuple(d["model"]["env.state_net.0.weight"].shape) == (83, 6) and tuple(d["model"]["env.done_net.2.bias"].shape) == (1,)
+    assert d["config"]["env_name"] == "CartPole-v0"
