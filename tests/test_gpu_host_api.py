@@ -379,3 +379,20 @@ def test_reference_checkpoint_round_trip_and_evaluation(golden, tmp_path):
         assert ours[k].dtype == ref["model"][k].dtype and torch.equal(ours[k], ref["model"][k]), k
     with pytest.raises(NotImplementedError):
         train_test_agents(venv, real_env, config, agents_num=1, agent_name="DDQN_vary")
+
+
+def test_experiment_wrapper_compute(tmp_path, monkeypatch):
+    """the BOHB-facing compute() runs GTN_Master and returns the reference's payload; failures map to
+    loss = +Inf (experiments/GTNC_evaluate_cartpole.py:36-73)."""
+    from learning_environments_amd.configs import cliff_reward_env_ql
+    from learning_environments_amd.experiments.GTNC_evaluate import ExperimentWrapper
+    monkeypatch.chdir(tmp_path)
+    cfg = cliff_reward_env_ql(num_workers=4, max_iterations=2)
+    cfg["agents"]["gtn"]["quit_when_solved"] = False
+    ew = ExperimentWrapper(cfg)
+    assert ew.get_bohb_parameters()["eta"] == 2
+    res = ew.compute(working_dir=str(tmp_path), bohb_id=7, config_id=(0, 0, 0), cso={}, budget=1)
+    assert res["loss"] == 2 and res["info"]["error"] == ""
+    bad = dict(cfg, agents=dict(cfg["agents"], gtn=dict(cfg["agents"]["gtn"], agent_name="sarsa")))
+    res = ExperimentWrapper(bad).compute(working_dir=str(tmp_path), bohb_id=8, config_id=(0, 0, 1), cso={}, budget=1)
+    assert res["loss"] == float("inf") and "NotImplementedError" in res["info"]["error"]
