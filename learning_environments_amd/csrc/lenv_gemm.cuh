@@ -253,7 +253,10 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 acc, int i0, int j0, 
     }
 }
 
-__device__ __noinline__ void wg_gemm_run(const GemmOp op_, const GemmEpi ep_, float *Ps_, float *Qs_)
+#ifndef LENV_GEMM_CALL
+#define LENV_GEMM_CALL __noinline__
+#endif
+__device__ LENV_GEMM_CALL void wg_gemm_run(const GemmOp op_, const GemmEpi ep_, float *Ps_, float *Qs_)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     // descriptors arrive in VGPRs: make every field wave-uniform

@@ -917,7 +917,7 @@ def gen_g8t(name, seed):
 
 
 def main():
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w"]
     os.makedirs(OUT, exist_ok=True)
     if "g1" in which:
         gen_g1()
@@ -954,6 +954,10 @@ def main():
     if "g8" in which:
         gen_g8("g8_calc_score_cartpole_a", train_episodes=3, done_bias_shift=0.0, seed=800)
         gen_g8("g8_calc_score_cartpole_b", train_episodes=4, done_bias_shift=0.45, seed=801, max_steps=60)
+    if "g8w" in which:
+        # replay ring wraps (ReplayBuffer.add, utils.py:24-32): capacity 37 rows, ~90 env steps
+        gen_g8("g8w_calc_score_cartpole_ringwrap", train_episodes=3, done_bias_shift=0.0, seed=802, max_steps=30,
+               agent_over={"rb_size": 37, "batch_size": 24})
 
 
 if __name__ == "__main__":

@@ -119,7 +119,7 @@ def _inner_cfg(orc, cfgd, **over):
     return o, c
 
 
-@pytest.mark.parametrize("name", ["g8_calc_score_cartpole_a", "g8_calc_score_cartpole_b"])
+@pytest.mark.parametrize("name", ["g8_calc_score_cartpole_a", "g8_calc_score_cartpole_b", "g8w_calc_score_cartpole_ringwrap"])
 def test_inner_loop_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
     g = golden(name)
     cfgd = json.loads(str(g["config_json"]))
@@ -159,9 +159,10 @@ def test_inner_loop_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
         assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4   # north_star: returns within 1e-4 of the reference
 
 
-@pytest.mark.parametrize("env_name,chains,episodes,max_steps,batch", [("CartPole-v0", 9, 4, 40, 199), ("CartPole-v0", 6, 3, 25, 64),
-                                                                     ("Acrobot-v1", 6, 3, 30, 149)])
-def test_inner_loop_counter_mode_vs_oracle(eng, orc, golden, env_name, chains, episodes, max_steps, batch):
+@pytest.mark.parametrize("env_name,chains,episodes,max_steps,batch,rb", [("CartPole-v0", 9, 4, 40, 199, None), ("CartPole-v0", 6, 3, 25, 64, None),
+                                                                        ("Acrobot-v1", 6, 3, 30, 149, None),
+                                                                        ("CartPole-v0", 3, 4, 40, 48, 53)])   # replay ring wraps
+def test_inner_loop_counter_mode_vs_oracle(eng, orc, golden, env_name, chains, episodes, max_steps, batch, rb):
     g = golden("g8_calc_score_cartpole_a")
     cfgd = json.loads(str(g["config_json"]))
     if env_name == "Acrobot-v1":
@@ -169,6 +170,8 @@ def test_inner_loop_counter_mode_vs_oracle(eng, orc, golden, env_name, chains, e
         cfgd["envs"][env_name] = dict(cfgd["envs"]["CartPole-v0"], solved_reward=-100.0, hidden_size=64)
         cfgd["agents"]["ddqn"].update(hidden_size=112, activation_fn="leakyrelu")
     cfgd["agents"]["ddqn"]["batch_size"] = batch
+    if rb:
+        cfgd["agents"]["ddqn"]["rb_size"] = rb
     ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, train_episodes=episodes, max_steps=max_steps)
     if ocfg.grad_chunk == 0:
         from learning_environments_amd.config import pick_grad_chunk
@@ -384,7 +387,8 @@ def test_dueling_tape_mode_vs_reference_and_oracle(eng, orc, golden):
 
 
 @pytest.mark.parametrize("env_name,layers,hidden,feat,batch,act", [("Acrobot-v1", 2, 128, 128, 128, "relu"), ("CartPole-v0", 1, 40, 24, 50, "tanh"),
-                                                                   ("Acrobot-v1", 2, 33, 17, 77, "leakyrelu")])
+                                                                   ("Acrobot-v1", 2, 33, 17, 77, "leakyrelu"),
+                                                                   ("CartPole-v0", 1, 24, 16, 20, "relu")])      # rb_size 23: ring wraps
 def test_dueling_counter_mode_vs_oracle(eng, orc, golden, env_name, layers, hidden, feat, batch, act):
     g = golden("g8d_calc_score_acrobot_dueling")
     cfgd = json.loads(str(g["config_json"]))
@@ -392,6 +396,8 @@ def test_dueling_counter_mode_vs_oracle(eng, orc, golden, env_name, layers, hidd
     cfgd["envs"][env_name] = dict(cfgd["envs"]["Acrobot-v1"], hidden_size=48)
     cfgd["agents"]["duelingddqn"].update(hidden_size=hidden, hidden_layer=layers, feature_dim=feat, batch_size=batch, activation_fn=act,
                                          test_episodes=4)
+    if batch == 20:
+        cfgd["agents"]["duelingddqn"]["rb_size"] = 23
     ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, train_episodes=3, max_steps=12)
     S, A = ocfg.state_dim, ocfg.num_actions
     rng = np.random.RandomState(8)
@@ -475,6 +481,8 @@ def test_td3_counter_mode_vs_oracle(eng, orc, golden, hidden, layers, batch, act
     cfgd["agents"]["td3"].update(hidden_size=hidden, hidden_layer=layers, batch_size=batch, activation_fn=act, policy_delay=delay,
                                  train_episodes=3, init_episodes=1, test_episodes=3)
     cfgd["envs"]["HalfCheetah-v3"].update(max_steps=6, hidden_size=128 if hidden == 128 else 24, reward_env_type=rtype)
+    if rtype == 5:
+        cfgd["agents"]["td3"]["rb_size"] = 11                   # 18 env steps: the replay ring wraps
     ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
     Pa, Pc = orc.td3_param_counts(ocfg)
     P_rn = max(1, orc.rn_num_params(rtype, 17, 4, ocfg.rn_hidden, 1))

@@ -133,7 +133,7 @@ def test_g7_master(golden):
     assert np.array_equal(th2, g["theta2"])
 
 
-@pytest.mark.parametrize("name", ["g8_calc_score_cartpole_a", "g8_calc_score_cartpole_b"])
+@pytest.mark.parametrize("name", ["g8_calc_score_cartpole_a", "g8_calc_score_cartpole_b", "g8w_calc_score_cartpole_ringwrap"])
 def test_g8_calc_score_trace(golden, name):
     import json
     g = golden(name)
