@@ -585,3 +585,44 @@ def test_inner_loop_full_size_properties(eng, orc):
         assert base[1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
         assert np.array_equal(base[2][c], o["episode_test_mean"], equal_nan=True)
         assert np.array_equal(base[3][c], o["final_test_returns"])
+
+
+def test_dueling_and_td3_early_out(eng, orc, golden):
+    """BaseAgent.train's early-out (base_agent.py:141-148: mean of the last early_out_num real-env test means >= solved_reward,
+    only once learning has started) in the big-net kernels: fewer episodes than train_episodes, same as the oracle."""
+    # DuelingDDQN on an Acrobot SE: returns are >= -max_steps, so solved_reward = -1000 fires at the first learning episode
+    g = golden("g8d_calc_score_acrobot_dueling")
+    cfgd = json.loads(str(g["config_json"]))
+    cfgd["agents"]["duelingddqn"].update(hidden_size=24, feature_dim=16, batch_size=16, test_episodes=2, init_episodes=2, early_out_num=2)
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, train_episodes=6, max_steps=10, solved_reward=-1000.0)
+    rng = np.random.RandomState(3)
+    S, A = ocfg.state_dim, ocfg.num_actions
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, ocfg.se_hidden, 1, "leakyrelu"))
+    theta = (rng.randn(P_se) * 0.15).astype(np.float32)
+    init = rng.uniform(-0.15, 0.15, (1, orc.dueling_num_params(ocfg))).astype(np.float32)
+    key = orc.chain_key(4, 0, 0, 0)
+    il = eng.InnerLoop(cfg, 1)
+    il.run(dev(theta), None, None, None, dev(init), rng_keys=dev(np.array([key], np.uint64).view(np.int64)))
+    torch.cuda.synchronize()
+    o = orc.ddqn_se_chain(ocfg, theta, init[0], rng_key=key)
+    assert o["episodes_run"] == 3                       # 2 init episodes + the first learning episode
+    assert il.stats[0].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+    assert np.array_equal(il.episode_test_mean[0].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+    assert float(il.score[0]) == o["score"]
+    # TD3 on the stand-in RewardEnv
+    g = golden("g8t_calc_score_cheetah_td3")
+    cfgd = json.loads(str(g["config_json"]))
+    cfgd["agents"]["td3"].update(hidden_size=24, hidden_layer=1, batch_size=16, train_episodes=6, init_episodes=2, test_episodes=2, early_out_num=2)
+    cfgd["envs"]["HalfCheetah-v3"].update(max_steps=5, hidden_size=24, solved_reward=-1e6)
+    ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
+    Pa, Pc = orc.td3_param_counts(ocfg)
+    theta = (rng.randn(orc.rn_num_params(ocfg.reward_env_type, 17, 4, 24, 1)) * 0.2).astype(np.float32)
+    init = rng.uniform(-0.2, 0.2, (1, Pa + 2 * Pc)).astype(np.float32)
+    il = eng.Td3InnerLoop(cfg, 1)
+    il.run(dev(theta), None, None, None, dev(init), rng_keys=dev(np.array([key], np.uint64).view(np.int64)))
+    torch.cuda.synchronize()
+    o = orc.td3_rn_chain(ocfg, theta, init[0], rng_key=key)
+    assert o["episodes_run"] == 3
+    assert il.stats[0].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+    assert np.array_equal(il.episode_test_mean[0].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+    assert float(il.score[0]) == o["score"]
