@@ -21,6 +21,7 @@ namespace lenv {
 
 constexpr int D_MAXL = 2;         // feature-stream hidden layers supported
 constexpr int D_MAXW = 128;       // max layer width (hidden_size / feature_dim)
+constexpr int D_MAXI = 128;       // max rows of one product (batch size / test episodes)
 
 struct DuelArgs {
     lenv_ddqn_cfg cfg;
@@ -61,16 +62,18 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     const float prelu = cfg.q_prelu;
 
     // ---- LDS carve-up ----
-    float *Ps = lds, *Qs = Ps + GT_RB * GT_LD;
-    float *se_w0T = Qs + GT_RB * GT_LD;                  // [3][K][Hse]
+    float *Ps = lds, *Qs = Ps + GemmShape<D_MAXI>::PS_FLOATS;
+    GemmCmd *cmds = reinterpret_cast<GemmCmd *>(Qs + GemmShape<D_MAXI>::QS_FLOATS);   // [GEMM_QUEUE_MAX] command queue
+    float *se_w0T = reinterpret_cast<float *>(cmds + GEMM_QUEUE_MAX);   // [3][K][Hse]
     float *se_b0 = se_w0T + 3 * K * Hse;                  // [3][Hse]
     float *se_wout = se_b0 + 3 * Hse;                     // [S+2][Hse]
     float *se_bout = se_wout + (S + 2) * Hse;             // [S+2] (padded to 16)
     float *se_h = se_bout + 16;                           // [3][Hse]
     float *qv = se_h + 3 * Hse;                           // [3][B][A]   q(s), q_online(s'), q_target(s')
-    float *Vb = qv + 3 * B * A;                           // [B]
-    float *Advb = Vb + B;                                 // [B][A]
-    float *dq = Advb + B * A;                             // [B]
+    const int RBH = B > T ? B : T;
+    float *Vb = qv + 3 * B * A;                           // [3][RBH]  value-head outputs of the three passes (slot 0 reused as scratch)
+    float *Advb = Vb + 3 * RBH;                           // [3][RBH][A] advantage-head outputs (RBH = max(B, T) rows per slot)
+    float *dq = Advb + 3 * RBH * A;                       // [B]
     float *dAdv = dq + B;                                 // [B][A]
     float *misc = dAdv + B * A;                           // [64] control words
     double *dstate = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(misc + 64) + 7) & ~(uintptr_t)7);   // [T][4] real-env states (tests)
@@ -134,56 +137,50 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     };
 
     // ---- Critic_DuelingDQN forward of I rows X[I][S] with parameters `par` (actor_critic.py:117-122) -------------------
-    // Intermediate activations go to the given buffers (stored ones are kept for the backward pass).
-    // Results: Vb[I], Advb[I][A] and q_out[I][A] in LDS.  global_mean: mean over all I*A advantages (learn) or per row.
-    auto forward = [&](const float *par, const float *X, int I, float *const *hid, float *featb, float *v1b, float *a1b,
-                       float *q_out, bool global_mean) {
+    // queue_forward queues the six layer products (intermediate activations to the given buffers; stored ones are kept for
+    // the backward pass), head outputs to slot `slot` of Vb / Advb; after gq.run, finish_q combines them into q_out[I][A]
+    // (LDS).  global_mean: mean over all I*A advantages (learn, the reference's batch quirk) or per row.
+    GemmQueue gq(cmds);
+    auto queue_forward = [&](const float *par, const float *X, int I, float *const *hid, float *featb, float *v1b, float *a1b, int slot) {
         const float *in = X;
         int n_in = S;
         for (int l = 0; l < L; ++l) {
-            const float *W = par + a.oWf[l], *bb = par + a.obf[l];
-            float *o = hid[l];
-            wg_gemm(in, n_in, 1, W, n_in, 1, I, H, n_in, Ps, Qs, epi_bias_act(o, H, bb, act_id, prelu));
-            __syncthreads();
-            in = o; n_in = H;
+            gq.gemm(in, n_in, 1, par + a.oWf[l], n_in, 1, I, H, n_in, epi_bias_act(hid[l], H, par + a.obf[l], act_id, prelu));
+            in = hid[l]; n_in = H;
         }
-        {   // feature_stream's last Linear: no activation (build_nn_from_config ends with a Linear)
-            const float *W = par + a.oWf[L], *bb = par + a.obf[L];
-            wg_gemm(in, n_in, 1, W, n_in, 1, I, F, n_in, Ps, Qs, epi_bias(featb, F, 0, bb));
-            __syncthreads();
-        }
-        {
-            const float *W = par + a.oWv1, *bb = par + a.obv1;
-            wg_gemm(featb, F, 1, W, F, 1, I, F, F, Ps, Qs, epi_bias_act(v1b, F, bb, act_id, prelu));
-            const float *W2 = par + a.oWa1, *bb2 = par + a.oba1;
-            wg_gemm(featb, F, 1, W2, F, 1, I, F, F, Ps, Qs, epi_bias_act(a1b, F, bb2, act_id, prelu));
-            __syncthreads();
-        }
-        {
-            const float *W = par + a.oWv2, *bb = par + a.obv2;
-            wg_gemm(v1b, F, 1, W, F, 1, I, 1, F, Ps, Qs, epi_bias(Vb, 1, 0, bb));
-            const float *W2 = par + a.oWa2, *bb2 = par + a.oba2;
-            wg_gemm(a1b, F, 1, W2, F, 1, I, A, F, Ps, Qs, epi_bias(Advb, A, 0, bb2));
-            __syncthreads();
-        }
+        // feature_stream's last Linear: no activation (build_nn_from_config ends with a Linear)
+        gq.gemm(in, n_in, 1, par + a.oWf[L], n_in, 1, I, F, n_in, epi_bias(featb, F, 0, par + a.obf[L]));
+        gq.gemm(featb, F, 1, par + a.oWv1, F, 1, I, F, F, epi_bias_act(v1b, F, par + a.obv1, act_id, prelu));
+        gq.gemm(featb, F, 1, par + a.oWa1, F, 1, I, F, F, epi_bias_act(a1b, F, par + a.oba1, act_id, prelu));
+        gq.gemm(v1b, F, 1, par + a.oWv2, F, 1, I, 1, F, epi_bias(Vb + slot * RBH, 1, 0, par + a.obv2));
+        gq.gemm(a1b, F, 1, par + a.oWa2, F, 1, I, A, F, epi_bias(Advb + slot * RBH * A, A, 0, par + a.oba2));
+    };
+    auto finish_q = [&](int slot, int I, float *q_out, bool global_mean) {
+        const float *Vs = Vb + slot * RBH, *As = Advb + slot * RBH * A;
         if (global_mean) {
             if (tid == 0) {
                 float sum = 0.0f;
-                for (int e = 0; e < I * A; ++e) sum = sum + Advb[e];
+                for (int e = 0; e < I * A; ++e) sum = sum + As[e];
                 ctrl[8] = sum / (float)(I * A);
             }
             __syncthreads();
             const float mean = ctrl[8];
-            for (int e = tid; e < I * A; e += DNT) q_out[e] = Vb[e / A] + (Advb[e] - mean);
+            for (int e = tid; e < I * A; e += DNT) q_out[e] = Vs[e / A] + (As[e] - mean);
         } else {
             for (int i = tid; i < I; i += DNT) {
                 float sum = 0.0f;
-                for (int aa = 0; aa < A; ++aa) sum = sum + Advb[i * A + aa];
+                for (int aa = 0; aa < A; ++aa) sum = sum + As[i * A + aa];
                 const float mean = sum / (float)A;
-                for (int aa = 0; aa < A; ++aa) q_out[i * A + aa] = Vb[i] + (Advb[i * A + aa] - mean);
+                for (int aa = 0; aa < A; ++aa) q_out[i * A + aa] = Vs[i] + (As[i * A + aa] - mean);
             }
         }
         __syncthreads();
+    };
+    auto forward = [&](const float *par, const float *X, int I, float *const *hid, float *featb, float *v1b, float *a1b,
+                       float *q_out, bool global_mean) {
+        queue_forward(par, X, I, hid, featb, v1b, a1b, 0);
+        gq.run<D_MAXI>(Ps, Qs);
+        finish_q(0, I, q_out, global_mean);
     };
 
     float *hid_s[D_MAXL], *hid_t[D_MAXL];
@@ -338,9 +335,13 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 }
                 __syncthreads();
                 PT_MARK(2);
-                forward(online, xs2, B, hid_t, feat_t, v1_t, a1_t, qv + B * A, true);        // next_q_values (online)
-                forward(target, xs2, B, hid_t, feat_t, v1_t, a1_t, qv + 2 * B * A, true);    // next_q_values_target
-                forward(online, xs, B, hid_s, feat_s, v1_s, a1_s, qv, true);                  // q_values, activations kept
+                queue_forward(online, xs2, B, hid_t, feat_t, v1_t, a1_t, 1);                 // next_q_values (online)
+                queue_forward(target, xs2, B, hid_t, feat_t, v1_t, a1_t, 2);                 // next_q_values_target
+                queue_forward(online, xs, B, hid_s, feat_s, v1_s, a1_s, 0);                  // q_values, activations kept
+                gq.run<D_MAXI>(Ps, Qs);                                                       // 18 products, one call
+                finish_q(1, B, qv + B * A, true);
+                finish_q(2, B, qv + 2 * B * A, true);
+                finish_q(0, B, qv, true);
                 PT_MARK(3);
                 // TD error (DuelingDDQN.py:80-85) and the gradient of the loss w.r.t. V / Adv
                 if (tid == 0) {
@@ -373,12 +374,10 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 PT_MARK(4);
                 float *d_a1 = arena + a.a_dbuf[0], *d_v1 = arena + a.a_dbuf[1], *d_feat = arena + a.a_dbuf[2];
                 float *dh[2] = { arena + a.a_dbuf[3], arena + a.a_dbuf[4] };
-                // ---- heads, output layers: dW = dOut^T . hidden (reduction over the batch), db = column sums ----
-                wg_gemm(dAdv, 1, A, a1_s, 1, F, A, F, B, Ps, Qs, epi_store(grad + a.oWa2, F));
-                wg_gemm(dq, 1, 1, v1_s, 1, F, 1, F, B, Ps, Qs, epi_store(grad + a.oWv2, F));
+                // ---- heads, output layers: db = column sums; d hidden of the heads = act'(h) * sum_o dOut[o] * W2[o][k]
+                // (reduction over the few outputs).  Everything GEMM-shaped of the backward pass is queued below.
                 if (tid < A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dAdv[b * A + tid]; grad[a.oba2 + tid] = s; }
                 if (tid == A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dq[b]; grad[a.obv2] = s; }
-                // d hidden of the heads: act'(h) * sum_o dOut[o] * W2[o][k]  (reduction over the few outputs)
                 for (int e0 = tid; e0 < B * F; e0 += 4 * DNT) {
                     float ra[4], rv[4];
 #pragma unroll
@@ -399,34 +398,33 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                         if (e < B * F) { d_a1[e] = ra[u]; d_v1[e] = rv[u]; }
                     }
                 }
-                __syncthreads();
-                // heads, hidden layers: dW1 = dHid^T . feat, db1; dfeat = d_v1 . Wv1 + d_a1 . Wa1
-                wg_gemm(d_a1, 1, F, feat_s, 1, F, F, F, B, Ps, Qs, epi_store(grad + a.oWa1, F));
-                wg_gemm(d_v1, 1, F, feat_s, 1, F, F, F, B, Ps, Qs, epi_store(grad + a.oWv1, F));
-                wg_colsum(d_a1, B, F, grad + a.oba1);
-                wg_colsum(d_v1, B, F, grad + a.obv1);
-                wg_gemm(d_v1, F, 1, online + a.oWv1, 1, F, B, F, F, Ps, Qs, epi_store(d_feat, F));
-                __syncthreads();
-                wg_gemm(d_a1, F, 1, online + a.oWa1, 1, F, B, F, F, Ps, Qs, epi_accum(d_feat, F));
-                __syncthreads();
                 PT_MARK(5);
-                // ---- feature stream: output Linear (no activation), then the hidden layers downwards ----
-                const float *dcur = d_feat;                // dL/d(output of layer l+1)'s pre-activation
-                int n_out = F;
-                for (int l = L; l >= 0; --l) {
-                    const int n_in = l == 0 ? S : H;
-                    const float *inp = l == 0 ? xs : hid_s[l - 1];
-                    const float *dc = dcur;
-                    wg_gemm(dc, 1, n_out, inp, 1, n_in, n_out, n_in, B, Ps, Qs, epi_store(grad + a.oWf[l], n_in));
-                    wg_colsum(dc, B, n_out, grad + a.obf[l]);
-                    if (l > 0) {
-                        float *dn = dh[l & 1];
-                        const float *hprev = hid_s[l - 1];
-                        wg_gemm(dc, n_out, 1, online + a.oWf[l], 1, n_in, B, n_in, n_out, Ps, Qs, epi_act_bwd(dn, n_in, hprev, n_in, act_id, prelu));
-                        dcur = dn; n_out = n_in;
+                // heads: dW2 = dOut^T . hidden (reduction over the batch); dW1 = dHid^T . feat, db1; dfeat = d_v1 . Wv1 + d_a1 . Wa1
+                gq.gemm(dAdv, 1, A, a1_s, 1, F, A, F, B, epi_store(grad + a.oWa2, F));
+                gq.gemm(dq, 1, 1, v1_s, 1, F, 1, F, B, epi_store(grad + a.oWv2, F));
+                gq.gemm(d_a1, 1, F, feat_s, 1, F, F, F, B, epi_store(grad + a.oWa1, F));
+                gq.gemm(d_v1, 1, F, feat_s, 1, F, F, F, B, epi_store(grad + a.oWv1, F));
+                gq.colsum(d_a1, B, F, F, grad + a.oba1);
+                gq.colsum(d_v1, B, F, F, grad + a.obv1);
+                gq.gemm(d_v1, F, 1, online + a.oWv1, 1, F, B, F, F, epi_store(d_feat, F));
+                gq.gemm(d_a1, F, 1, online + a.oWa1, 1, F, B, F, F, epi_accum(d_feat, F));
+                // feature stream: output Linear (no activation), then the hidden layers downwards
+                {
+                    const float *dcur = d_feat;            // dL/d(output of layer l+1)'s pre-activation
+                    int n_out = F;
+                    for (int l = L; l >= 0; --l) {
+                        const int n_in = l == 0 ? S : H;
+                        const float *inp = l == 0 ? xs : hid_s[l - 1];
+                        gq.gemm(dcur, 1, n_out, inp, 1, n_in, n_out, n_in, B, epi_store(grad + a.oWf[l], n_in));
+                        gq.colsum(dcur, B, n_out, n_out, grad + a.obf[l]);
+                        if (l > 0) {
+                            float *dn = dh[l & 1];
+                            gq.gemm(dcur, n_out, 1, online + a.oWf[l], 1, n_in, B, n_in, n_out, epi_act_bwd(dn, n_in, hid_s[l - 1], n_in, act_id, prelu));
+                            dcur = dn; n_out = n_in;
+                        }
                     }
-                    __syncthreads();
                 }
+                gq.run<D_MAXI>(Ps, Qs);
                 PT_MARK(6);
                 // ---- torch.optim.Adam + Polyak (DuelingDDQN.py:87-93) ----
                 {
@@ -535,8 +533,9 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     for (int l = 0; l < 5; ++l) a.a_dbuf[l] = take((int64_t)GT_I * W);
     a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
     a.arena_stride = (off + 63) & ~(int64_t)63;
-    const size_t lds_floats = 2 * (size_t)GT_RB * GT_LD + 3 * K * Hse + 3 * Hse + (S + 2) * Hse + 16 + 3 * Hse + 3 * (size_t)B * A + B +
-                              (size_t)B * A + B + (size_t)B * A + 64 + 2 * (4 * (size_t)T + T) + 2 * T + 8 + 16 + 16;
+    const size_t lds_floats = GemmShape<D_MAXI>::PS_FLOATS + GemmShape<D_MAXI>::QS_FLOATS + GEMM_QUEUE_MAX * sizeof(GemmCmd) / sizeof(float) +
+                              3 * K * Hse + 3 * Hse + (S + 2) * Hse + 16 + 3 * Hse + 3 * (size_t)B * A + 3 * (size_t)(B > T ? B : T) * (1 + A) +
+                              B + (size_t)B * A + 64 + 2 * (4 * (size_t)T + T) + 2 * T + 8 + 16 + 16;
     *lds_bytes = lds_floats * sizeof(float);
     if (*lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     return LENV_OK;

@@ -1,10 +1,10 @@
 // lenv_gemm.cuh -- workgroup-cooperative, LDS-tiled fp32 GEMM on the f32-input matrix cores with the canonical
 // (k-ascending fmaf chain) reduction order.
 //
-//   C[i][j] = epi(i, j, sum_{r<R} P[i*sPi + r*sPr] * Q[j*sQj + r*sQr])       I, J <= 128, any R
+//   C[i][j] = epi(i, j, sum_{r<R} P[i*sPi + r*sPr] * Q[j*sQj + r*sQr])       I <= MAXI (128 or 256), J <= 128, any R
 //
-// 512 threads (8 waves).  The reduction is staged through LDS 64 deep (Ps/Qs: GT_RB*GT_LD floats each, r-major); the
-// output is cut into 32x32 tiles, wave w owns tiles w and w+8, and each tile is accumulated with
+// 512 threads (8 waves).  The reduction is staged through LDS 64 deep (Ps/Qs, r-major rows); the
+// output is cut into 32x32 tiles, wave w owns tiles w, w+8, ... and each tile is accumulated with
 // v_mfma_f32_32x32x2_f32.  That instruction is bit-for-bit D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) (one rounding per
 // product, k ascending), so every output is exactly the sequential fmaf chain of oracle/lenv_oracle.h starting from 0,
 // whatever the strides -- the same routine serves the forward (r = input feature), input-gradient (r = output unit) and
@@ -12,7 +12,7 @@
 // scalar fmaf per output (a zero-padded k would turn a -0 accumulator into +0).
 // Why MFMA when the peak rate equals v_pk_fma_f32's: a 4x8 register tile needs 24.6 KB of LDS reads per k for the
 // workgroup (LDS-bound at 2.7x the FMA time, measured); the MFMA operands are one dword per lane (3 KB per k).
-// ONE out-of-line instance (descriptor-driven epilogue) is shared by all call sites.  The routine is instruction-issue
+// ONE instance (descriptor-driven epilogue) serves every product of a kernel (see 'GEMM programs').  The routine is instruction-issue
 // bound around the MFMAs (2 waves per SIMD), so every descriptor field is made wave-uniform (readfirstlane -> SGPRs,
 // scalar branches), global operands use 32-bit offsets off a scalar base, and the per-output switches are hoisted out
 // of the register loops.  Operands that live in LDS (a few small vectors) take a generic-pointer path (GEMM_GENERIC_*).
@@ -84,42 +84,44 @@ template <> struct MemView<false> {
 
 __device__ __forceinline__ int pow2_shift(int n) { return n <= 1 ? 0 : 32 - __builtin_clz(n - 1); }   // ceil(log2 n)
 
-// Copy src[i*sI + (r0+r)*sR], i < nI, r < rb, into dst[r*GT_LD + i] (all scalars wave-uniform).  A thread's global reads
+// Copy src[i*sI + (r0+r)*sR], i < nI, r < rb, into dst[r*ld + i] (all scalars wave-uniform).  A thread's global reads
 // are issued before its LDS writes (staging is latency bound).  Rows i >= nI are not needed: they only feed outputs that
 // the epilogue drops.
 template <bool G>
-__device__ __forceinline__ void stage_operand(const float *src_, int sI, int sR, int nI, int r0, int rb, int R, lfloat *dst, int tid, int lane, int wave)
+__device__ __forceinline__ void stage_operand(const float *src_, int sI, int sR, int nI, int r0, int rb, int R, lfloat *dst, int ld, int tid, int lane, int wave)
 {
     const MemView<G> src(src_);
     const bool al16 = (reinterpret_cast<uintptr_t>(src_) & 15) == 0;
     if (G && sR == 1 && al16 && (sI & 3) == 0 && (R & 3) == 0) {
         // row-major along r: float4 = 4 consecutive r of one row; a wave instruction covers 16 rows x 64 B
-        f32x4 v[4];
-        const int i = (lane >> 2) | (wave << 4);
-        const int base = i * sI + r0 + 4 * (lane & 3);
-        const bool rowok = i < nI;
+        for (int ib = 0; ib < nI; ib += 128) {
+            f32x4 v[4];
+            const int i = ib + ((lane >> 2) | (wave << 4));
+            const int base = i * sI + r0 + 4 * (lane & 3);
+            const bool rowok = i < nI;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (rowok && 16 * k + 4 * (lane & 3) < rb) ? src.ld4(base + 16 * k) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        lfloat *d = dst + (4 * (lane & 3)) * GT_LD + i;
+            for (int k = 0; k < 4; ++k) v[k] = (rowok && 16 * k + 4 * (lane & 3) < rb) ? src.ld4(base + 16 * k) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            lfloat *d = dst + (4 * (lane & 3)) * ld + i;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (rowok && 16 * k + 4 * (lane & 3) < rb) {
-                d[(16 * k) * GT_LD] = v[k].x; d[(16 * k + 1) * GT_LD] = v[k].y; d[(16 * k + 2) * GT_LD] = v[k].z; d[(16 * k + 3) * GT_LD] = v[k].w;
-            }
+            for (int k = 0; k < 4; ++k)
+                if (rowok && 16 * k + 4 * (lane & 3) < rb) {
+                    d[(16 * k) * ld] = v[k].x; d[(16 * k + 1) * ld] = v[k].y; d[(16 * k + 2) * ld] = v[k].z; d[(16 * k + 3) * ld] = v[k].w;
+                }
+        }
     } else if (G && sI == 1 && al16 && (sR & 3) == 0) {
         // contiguous along i: float4 = 4 consecutive i of one r; a wave instruction covers 2 r x 512 B
-        f32x4 v[4];
-        const int iq = lane & 31, rl = (lane >> 5) | (wave << 1);
-        const int base = (r0 + rl) * sR + 4 * iq;
-        const bool colok = 4 * iq < nI;
+        for (int ib = 0; ib < nI; ib += 128) {
+            f32x4 v[4];
+            const int i4 = ib + 4 * (lane & 31), rl = (lane >> 5) | (wave << 1);
+            const int base = (r0 + rl) * sR + i4;
+            const bool colok = i4 < nI;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (colok && rl + 16 * k < rb) ? src.ld4(base + 16 * k * sR) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        lfloat *d = dst + rl * GT_LD + 4 * iq;
+            for (int k = 0; k < 4; ++k) v[k] = (colok && rl + 16 * k < rb) ? src.ld4(base + 16 * k * sR) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            lfloat *d = dst + rl * ld + i4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (colok && rl + 16 * k < rb) {
-                *reinterpret_cast<__attribute__((address_space(3))) f32x4 *>(d + 16 * k * GT_LD) = v[k];
-            }
+            for (int k = 0; k < 4; ++k)
+                if (colok && rl + 16 * k < rb) *reinterpret_cast<__attribute__((address_space(3))) f32x4 *>(d + 16 * k * ld) = v[k];
+        }
     } else if (sR == 1 || (sI != 1 && sR < sI)) {
         // small / unaligned operands, r fastest across lanes: e -> (i = e >> sh, r = e & mask)
         const int sh = pow2_shift(rb), mask = (1 << sh) - 1, total = nI << sh;
@@ -133,7 +135,7 @@ __device__ __forceinline__ void stage_operand(const float *src_, int sI, int sR,
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = e0 + u * DNT, i = e >> sh, r = e & mask;
-                if (e < total && r < rb) dst[r * GT_LD + i] = v[u];
+                if (e < total && r < rb) dst[r * ld + i] = v[u];
             }
         }
     } else {
@@ -149,7 +151,7 @@ __device__ __forceinline__ void stage_operand(const float *src_, int sI, int sR,
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = e0 + u * DNT, r = e >> sh, i = e & mask;
-                if (e < total && i < nI) dst[r * GT_LD + i] = v[u];
+                if (e < total && i < nI) dst[r * ld + i] = v[u];
             }
         }
     }
@@ -253,96 +255,191 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 acc, int i0, int j0, 
     }
 }
 
-#ifndef LENV_GEMM_CALL
-#define LENV_GEMM_CALL __noinline__
-#endif
-__device__ LENV_GEMM_CALL void wg_gemm_run(const GemmOp op_, const GemmEpi ep_, float *Ps_, float *Qs_)
+// ---- GEMM programs -------------------------------------------------------------------------------------------------
+// A kernel queues the products of a phase (a forward pass, a backward chain) as commands in LDS and runs the queue with
+// ONE out-of-line call: the GEMM body is instantiated once per kernel and inlined at a single site, so no per-product
+// argument marshalling / callee-save traffic (measured 5-7 k cycles per product when every product was a call).
+// Commands run in order, a workgroup barrier after each (the epilogue's global writes are visible to the next staging).
+
+enum { CMD_GEMM = 0, CMD_COLSUM = 1 };
+
+struct GemmCmd {                                           // 32 dwords, lives in LDS
+    int kind;                                              // CMD_GEMM | CMD_COLSUM (out[j] = sum_i P[i*sPi + j], i < I, j < J)
+    int sPi, sPr, sQj, sQr, I, J, R;
+    const float *P, *Q;
+    int ekind, ldo, ocol, ldaux, ldo2, act, flags;
+    float prelu, scale;
+    float *out, *out2;
+    const float *bias, *aux;
+    int pad_;
+};
+
+template <int MAXI> struct GemmShape {
+    static constexpr int LDP = MAXI + 4;                   // Ps row stride (floats): r-major rows of MAXI operand rows
+    static constexpr int NTW = MAXI / 64;                  // 32x32 tiles per wave: (MAXI/32)*4 tiles over 8 waves
+    static constexpr int PS_FLOATS = GT_RB * LDP, QS_FLOATS = GT_RB * GT_LD;
+};
+
+template <int MAXI>
+__device__ __forceinline__ void gemm_body(const GemmOp &op, const GemmEpi &ep, lfloat *Ps, lfloat *Qs, int tid, int lane, int wave)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
-    // descriptors arrive in VGPRs: make every field wave-uniform
-    GemmOp op; GemmEpi ep;
-    op.P = uni_ptr(op_.P); op.sPi = uni(op_.sPi); op.sPr = uni(op_.sPr); op.Q = uni_ptr(op_.Q); op.sQj = uni(op_.sQj); op.sQr = uni(op_.sQr);
-    op.I = uni(op_.I); op.J = uni(op_.J); op.R = uni(op_.R);
-    ep.kind = uni(ep_.kind); ep.out = uni_ptr(ep_.out); ep.ldo = uni(ep_.ldo); ep.ocol = uni(ep_.ocol); ep.bias = uni_ptr(ep_.bias);
-    ep.aux = uni_ptr(ep_.aux); ep.ldaux = uni(ep_.ldaux); ep.out2 = uni_ptr(ep_.out2); ep.ldo2 = uni(ep_.ldo2); ep.act = uni(ep_.act);
-    ep.prelu = unif(ep_.prelu); ep.scale = unif(ep_.scale); ep.flags = uni(ep_.flags);
-    lfloat *Ps = (lfloat *)uni_ptr(Ps_), *Qs = (lfloat *)uni_ptr(Qs_);
+    constexpr int LDP = GemmShape<MAXI>::LDP, NTW = GemmShape<MAXI>::NTW;
     const int I = op.I, J = op.J, R = op.R;
-    const int nbi = (I + 31) >> 5, nbj = (J + 31) >> 5, ntile = nbi * nbj;      // <= 16 tiles of 32x32
-    const bool has0 = wave < ntile, has1 = wave + 8 < ntile;
-    const int inv = nbi == 1 ? 256 : (nbi == 2 ? 128 : (nbi == 3 ? 86 : 64));     // t / nbi == (t * inv) >> 8 for t < 16
-    const int bj0 = (wave * inv) >> 8, bi0 = wave - bj0 * nbi, bj1 = ((wave + 8) * inv) >> 8, bi1 = wave + 8 - bj1 * nbi;
+    const int nbi = (I + 31) >> 5, nbj = (J + 31) >> 5, ntile = nbi * nbj;      // <= 8*NTW tiles of 32x32
+    // t / nbi == (t * inv) >> 10 for t < 32, nbi <= 8
+    const int inv = nbi == 1 ? 1024 : (nbi == 2 ? 512 : (nbi == 3 ? 342 : (nbi == 4 ? 256 : (nbi == 5 ? 205 : (nbi == 6 ? 171 : (nbi == 7 ? 147 : 128))))));
+    bool has[NTW];
+    int bi[NTW], bj[NTW];
+    const lfloat *pa[NTW], *pb[NTW];
+    f32x16 acc[NTW];
     // A operand: lane l supplies P[row l%32][k = l/32]; B operand: Q[col l%32][k = l/32]; both one LDS dword, r-major rows
-    const int koff = (lane >> 5) * GT_LD + (lane & 31);
-    const lfloat *pa0 = Ps + koff + 32 * bi0, *pb0 = Qs + koff + 32 * bj0;
-    const lfloat *pa1 = Ps + koff + 32 * bi1, *pb1 = Qs + koff + 32 * bj1;
-    f32x16 acc0, acc1;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) { acc0[v] = 0.0f; acc1[v] = 0.0f; }
+    for (int m = 0; m < NTW; ++m) {
+        const int t = wave + 8 * m;
+        has[m] = t < ntile;
+        bj[m] = (t * inv) >> 10; bi[m] = t - bj[m] * nbi;
+        pa[m] = Ps + (lane >> 5) * LDP + (lane & 31) + 32 * bi[m];
+        pb[m] = Qs + (lane >> 5) * GT_LD + (lane & 31) + 32 * bj[m];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[m][v] = 0.0f;
+    }
     for (int r0 = 0; r0 < R; r0 += GT_RB) {
         const int rb = R - r0 < GT_RB ? R - r0 : GT_RB;
-        __syncthreads();                                   // previous stage fully consumed
+        if (r0 > 0) __syncthreads();                       // previous stage fully consumed (the queue barriers cover r0 == 0)
 #ifndef LENV_DIAG_SKIP_STAGE
-        if (ep.flags & GEMM_GENERIC_P) stage_operand<false>(op.P, op.sPi, op.sPr, I, r0, rb, R, Ps, tid, lane, wave);
-        else stage_operand<true>(op.P, op.sPi, op.sPr, I, r0, rb, R, Ps, tid, lane, wave);
-        stage_operand<true>(op.Q, op.sQj, op.sQr, J, r0, rb, R, Qs, tid, lane, wave);
+        if (ep.flags & GEMM_GENERIC_P) stage_operand<false>(op.P, op.sPi, op.sPr, I, r0, rb, R, Ps, LDP, tid, lane, wave);
+        else stage_operand<true>(op.P, op.sPi, op.sPr, I, r0, rb, R, Ps, LDP, tid, lane, wave);
+        stage_operand<true>(op.Q, op.sQj, op.sQr, J, r0, rb, R, Qs, GT_LD, tid, lane, wave);
 #endif
         __syncthreads();
 #ifndef LENV_DIAG_SKIP_COMPUTE
         const int rb2 = rb & ~1;
-        if (has1) {
+        if (has[NTW - 1]) {                                // every tile slot of this wave is live: the common full-size case
             if (rb == GT_RB) {
-#pragma unroll 8
-                for (int r = 0; r < GT_RB; r += 2) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0[r * GT_LD], pb0[r * GT_LD], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa1[r * GT_LD], pb1[r * GT_LD], acc1, 0, 0, 0);
-                }
+#pragma unroll (16 / (NTW * NTW))
+                for (int r = 0; r < GT_RB; r += 2)
+#pragma unroll
+                    for (int m = 0; m < NTW; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[m][r * LDP], pb[m][r * GT_LD], acc[m], 0, 0, 0);
             } else {
-                for (int r = 0; r < rb2; r += 2) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0[r * GT_LD], pb0[r * GT_LD], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa1[r * GT_LD], pb1[r * GT_LD], acc1, 0, 0, 0);
-                }
+                for (int r = 0; r < rb2; r += 2)
+#pragma unroll
+                    for (int m = 0; m < NTW; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[m][r * LDP], pb[m][r * GT_LD], acc[m], 0, 0, 0);
             }
-        } else if (has0) {
-            if (rb == GT_RB) {
+        } else {
+#pragma unroll
+            for (int m = 0; m < NTW - 1; ++m)
+                if (has[m]) {
+                    if (rb == GT_RB) {
 #pragma unroll 8
-                for (int r = 0; r < GT_RB; r += 2) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0[r * GT_LD], pb0[r * GT_LD], acc0, 0, 0, 0);
-            } else {
-                for (int r = 0; r < rb2; r += 2) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0[r * GT_LD], pb0[r * GT_LD], acc0, 0, 0, 0);
-            }
+                        for (int r = 0; r < GT_RB; r += 2) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[m][r * LDP], pb[m][r * GT_LD], acc[m], 0, 0, 0);
+                    } else {
+                        for (int r = 0; r < rb2; r += 2) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[m][r * LDP], pb[m][r * GT_LD], acc[m], 0, 0, 0);
+                    }
+                }
         }
         if (rb & 1) {                                      // odd last k: one scalar fmaf per output
-            const lfloat *prow = Ps + rb2 * GT_LD + 4 * (lane >> 5), *qrow = Qs + rb2 * GT_LD + (lane & 31);
-            if (has0) {
-                const float q = qrow[32 * bj0];
+            const lfloat *prow = Ps + rb2 * LDP + 4 * (lane >> 5), *qrow = Qs + rb2 * GT_LD + (lane & 31);
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc0[v] = fma32(prow[32 * bi0 + 8 * (v >> 2) + (v & 3)], q, acc0[v]);
-            }
-            if (has1) {
-                const float q = qrow[32 * bj1];
+            for (int m = 0; m < NTW; ++m)
+                if (has[m]) {
+                    const float q = qrow[32 * bj[m]];
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc1[v] = fma32(prow[32 * bi1 + 8 * (v >> 2) + (v & 3)], q, acc1[v]);
-            }
+                    for (int v = 0; v < 16; ++v) acc[m][v] = fma32(prow[32 * bi[m] + 8 * (v >> 2) + (v & 3)], q, acc[m][v]);
+                }
         }
 #endif
     }
 #ifdef LENV_DIAG_SKIP_EPI
     if (R > 0) return;
 #endif
-    if (ep.flags & GEMM_GENERIC_OUT) {
-        if (has0) tile_epilogue<false, false>(acc0, 32 * bi0, 32 * bj0, I, J, ep, lane);
-        if (has1) tile_epilogue<false, false>(acc1, 32 * bi1, 32 * bj1, I, J, ep, lane);
-    } else {
-        if (has0) {
-            if (32 * bi0 + 32 <= I && 32 * bj0 + 32 <= J) tile_epilogue<true, true>(acc0, 32 * bi0, 32 * bj0, I, J, ep, lane);
-            else tile_epilogue<true, false>(acc0, 32 * bi0, 32 * bj0, I, J, ep, lane);
-        }
-        if (has1) {
-            if (32 * bi1 + 32 <= I && 32 * bj1 + 32 <= J) tile_epilogue<true, true>(acc1, 32 * bi1, 32 * bj1, I, J, ep, lane);
-            else tile_epilogue<true, false>(acc1, 32 * bi1, 32 * bj1, I, J, ep, lane);
-        }
+#pragma unroll
+    for (int m = 0; m < NTW; ++m) {
+        if (!has[m]) continue;
+        if (ep.flags & GEMM_GENERIC_OUT) tile_epilogue<false, false>(acc[m], 32 * bi[m], 32 * bj[m], I, J, ep, lane);
+        else if (32 * bi[m] + 32 <= I && 32 * bj[m] + 32 <= J) tile_epilogue<true, true>(acc[m], 32 * bi[m], 32 * bj[m], I, J, ep, lane);
+        else tile_epilogue<true, false>(acc[m], 32 * bi[m], 32 * bj[m], I, J, ep, lane);
     }
 }
+
+// out[j] = sum_i d[i*ld + j] (i ascending), j < n: the bias gradient of a Linear layer
+__device__ __forceinline__ void wg_colsum(const float *d, int rows, int ld, int n, float *out)
+{
+    for (int k = (int)threadIdx.x; k < n; k += DNT) {
+        float s = 0.0f;
+        int b = 0;
+        for (; b + 8 <= rows; b += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = d[(int64_t)(b + u) * ld + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = s + x[u];
+        }
+        for (; b < rows; ++b) s = s + d[(int64_t)b * ld + k];
+        out[k] = s;
+    }
+}
+
+template <int MAXI>
+__device__ __noinline__ void gemm_run_queue(const GemmCmd *cmds_, int n_, float *Ps_, float *Qs_)
+{
+    typedef __attribute__((address_space(3))) const GemmCmd LCmd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int n = uni(n_);
+    LCmd *cmds = (LCmd *)uni_ptr(cmds_);
+    lfloat *Ps = (lfloat *)uni_ptr(Ps_), *Qs = (lfloat *)uni_ptr(Qs_);
+    for (int k = 0; k < n; ++k) {
+        LCmd &c = cmds[k];
+        GemmOp op; GemmEpi ep;
+        const int kind = uni(c.kind);
+        op.P = uni_ptr(c.P); op.sPi = uni(c.sPi); op.sPr = uni(c.sPr); op.Q = uni_ptr(c.Q); op.sQj = uni(c.sQj); op.sQr = uni(c.sQr);
+        op.I = uni(c.I); op.J = uni(c.J); op.R = uni(c.R);
+        ep.kind = uni(c.ekind); ep.out = uni_ptr(c.out); ep.ldo = uni(c.ldo); ep.ocol = uni(c.ocol); ep.bias = uni_ptr(c.bias);
+        ep.aux = uni_ptr(c.aux); ep.ldaux = uni(c.ldaux); ep.out2 = uni_ptr(c.out2); ep.ldo2 = uni(c.ldo2); ep.act = uni(c.act);
+        ep.prelu = unif(c.prelu); ep.scale = unif(c.scale); ep.flags = uni(c.flags);
+        if (kind == CMD_COLSUM) wg_colsum(op.P, op.I, op.sPi, op.J, ep.out);
+        else gemm_body<MAXI>(op, ep, Ps, Qs, tid, lane, wave);
+        __syncthreads();
+    }
+}
+
+// Per-thread handle of the command queue (the count is uniform; thread 0 writes the records).
+struct GemmQueue {
+    GemmCmd *cmds;
+    int n;
+    __device__ __forceinline__ explicit GemmQueue(GemmCmd *c) : cmds(c), n(0) {}
+    __device__ __forceinline__ void gemm(const float *P, int sPi, int sPr, const float *Q, int sQj, int sQr, int I, int J, int R, const GemmEpi &ep)
+    {
+        if (threadIdx.x == 0) {
+            GemmCmd &c = cmds[n];                          // written field by field straight into LDS
+            int flags = ep.flags;
+#ifdef __HIP_DEVICE_COMPILE__
+            if (__builtin_amdgcn_is_shared(P)) flags |= GEMM_GENERIC_P;
+            if (__builtin_amdgcn_is_shared(ep.out)) flags |= GEMM_GENERIC_OUT;
+#endif
+            c.kind = CMD_GEMM; c.sPi = sPi; c.sPr = sPr; c.sQj = sQj; c.sQr = sQr; c.I = I; c.J = J; c.R = R; c.P = P; c.Q = Q;
+            c.ekind = ep.kind; c.ldo = ep.ldo; c.ocol = ep.ocol; c.ldaux = ep.ldaux; c.ldo2 = ep.ldo2; c.act = ep.act; c.flags = flags;
+            c.prelu = ep.prelu; c.scale = ep.scale; c.out = ep.out; c.out2 = ep.out2; c.bias = ep.bias; c.aux = ep.aux;
+        }
+        ++n;
+    }
+    // out[j] = sum_{i<rows} d[i*ld + j], j < cols
+    __device__ __forceinline__ void colsum(const float *d, int rows, int ld, int cols, float *out)
+    {
+        if (threadIdx.x == 0) {
+            GemmCmd &c = cmds[n];
+            c.kind = CMD_COLSUM; c.P = d; c.I = rows; c.sPi = ld; c.J = cols; c.out = out;
+        }
+        ++n;
+    }
+    template <int MAXI> __device__ __forceinline__ void run(float *Ps, float *Qs)
+    {
+        __syncthreads();                                   // records written; every earlier global write of the workgroup visible
+        gemm_run_queue<MAXI>(cmds, n, Ps, Qs);
+        n = 0;
+    }
+};
+
+constexpr int GEMM_QUEUE_MAX = 24;                         // commands per queue run (LDS: 24 x 128 B)
 
 __device__ __forceinline__ GemmEpi epi_store(float *out, int ldo, int ocol = 0) { GemmEpi e{}; e.kind = EPI_STORE; e.out = out; e.ldo = ldo; e.ocol = ocol; return e; }
 __device__ __forceinline__ GemmEpi epi_accum(float *out, int ldo) { GemmEpi e{}; e.kind = EPI_ACCUM; e.out = out; e.ldo = ldo; return e; }
@@ -350,18 +447,6 @@ __device__ __forceinline__ GemmEpi epi_bias(float *out, int ldo, int ocol, const
 __device__ __forceinline__ GemmEpi epi_bias_act(float *out, int ldo, const float *bias, int act, float prelu) { GemmEpi e{}; e.kind = EPI_BIAS_ACT; e.out = out; e.ldo = ldo; e.bias = bias; e.act = act; e.prelu = prelu; return e; }
 __device__ __forceinline__ GemmEpi epi_act_bwd(float *out, int ldo, const float *aux, int ldaux, int act, float prelu) { GemmEpi e{}; e.kind = EPI_ACT_BWD; e.out = out; e.ldo = ldo; e.aux = aux; e.ldaux = ldaux; e.act = act; e.prelu = prelu; return e; }
 __device__ __forceinline__ GemmEpi epi_bias_tanh(float *out, int ldo, int ocol, const float *bias, float scale, float *out2, int ldo2) { GemmEpi e{}; e.kind = EPI_BIAS_TANH; e.out = out; e.ldo = ldo; e.ocol = ocol; e.bias = bias; e.scale = scale; e.out2 = out2; e.ldo2 = ldo2; return e; }
-
-__device__ __forceinline__ void wg_gemm(const float *P, int sPi, int sPr, const float *Q, int sQj, int sQr, int I, int J, int R,
-                                        float *Ps, float *Qs, const GemmEpi &ep)
-{
-    GemmOp op{ P, sPi, sPr, Q, sQj, sQr, I, J, R };
-    GemmEpi e = ep;
-#ifdef __HIP_DEVICE_COMPILE__
-    if (__builtin_amdgcn_is_shared(P)) e.flags |= GEMM_GENERIC_P;
-    if (__builtin_amdgcn_is_shared(ep.out)) e.flags |= GEMM_GENERIC_OUT;
-#endif
-    wg_gemm_run(op, e, Ps, Qs);
-}
 
 
 // ---- elementwise passes over a chain's HBM arena: 4 elements per thread with all reads issued before the first write
@@ -408,24 +493,6 @@ __device__ __forceinline__ void wg_polyak(const float *params, float *target, in
         for (int u = 0; u < 8; ++u) { const int p = q + u * DNT; const bool ok = p < n; w[u] = ok ? params[p] : 0.0f; t[u] = ok ? target[p] : 0.0f; }
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int p = q + u * DNT; if (p < n) target[p] = tau * w[u] + omt * t[u]; }
-    }
-}
-
-// out[k] = sum_b d[b*n + k] (b ascending), k < n: the bias gradient of a Linear layer
-__device__ __forceinline__ void wg_colsum(const float *d, int rows, int n, float *out)
-{
-    for (int k = (int)threadIdx.x; k < n; k += DNT) {
-        float s = 0.0f;
-        int b = 0;
-        for (; b + 8 <= rows; b += 8) {
-            float x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = d[(int64_t)(b + u) * n + k];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s = s + x[u];
-        }
-        for (; b < rows; ++b) s = s + d[(int64_t)b * n + k];
-        out[k] = s;
     }
 }
 

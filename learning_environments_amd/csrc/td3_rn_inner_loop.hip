@@ -19,6 +19,7 @@ namespace lenv {
 
 constexpr int T3_MAXL = 2;     // hidden layers of actor / critic
 constexpr int T3_MAXW = 128;
+constexpr int T3_MAXI = 256;   // max rows of one product (batch size)
 constexpr int T3_S = 17, T3_A = 6, T3_SA = 23;
 
 struct MlpOff { int in, H, L, out; int oW[T3_MAXL + 1], ob[T3_MAXL + 1]; int P; };
@@ -50,8 +51,9 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     const float prelu = cfg.prelu, ma = (float)cfg.max_action;
 
     // ---- LDS carve-up ----
-    float *Ps = lds, *Qs = Ps + GT_RB * GT_LD;
-    float *rn_w = Qs + GT_RB * GT_LD;                     // reward net: W0 [Hrn][S] | b0 [Hrn] | Wout [Hrn] | bout
+    float *Ps = lds, *Qs = Ps + GemmShape<T3_MAXI>::PS_FLOATS;
+    GemmCmd *cmds = reinterpret_cast<GemmCmd *>(Qs + GemmShape<T3_MAXI>::QS_FLOATS);   // [GEMM_QUEUE_MAX] command queue
+    float *rn_w = reinterpret_cast<float *>(cmds + GEMM_QUEUE_MAX);   // reward net: W0 [Hrn][S] | b0 [Hrn] | Wout [Hrn] | bout
     float *rn_h = rn_w + ((a.P_rn + 3) & ~3);             // [Hrn]
     float *q1 = rn_h + ((Hrn + 3) & ~3);                  // [B]
     float *q2 = q1 + B, *tq1 = q2 + B, *tq2 = tq1 + B, *rr = tq2 + B, *dd = rr + B, *dq1 = dd + B, *dq2 = dq1 + B;
@@ -97,73 +99,49 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     double pows[4] = { 1.0, 1.0, 1.0, 1.0 };
     const int rb_cap = (int)a.rb_cap;
 
-    // ---- generic MLP forward over I rows (row stride ldx); hidden activations to hid[l][I][H] -------------------------
-    // final_tanh: out = tanh(net)*max_action (Actor_TD3.forward) with tanh values to th_out; else out = net (Critic_Q).
+    // ---- generic MLP forward over I <= 256 rows (row stride ldx); hidden activations to hid[l][I][H].  The layer products
+    // are QUEUED (gq); the caller runs the queue.  final_tanh: out = tanh(net)*max_action (Actor_TD3.forward) with tanh
+    // values to th_out; else out = net (Critic_Q).
+    GemmQueue gq(cmds);
     auto mlp_forward = [&](const float *par, const MlpOff &mo, const float *X, int ldx, int I, float *const *hid, float *out,
                            int ldo, int ocol, bool final_tanh, float *th_out) {
-        for (int i0 = 0; i0 < I; i0 += GT_I) {
-            const int ib = I - i0 < GT_I ? I - i0 : GT_I;
-            const float *in = X + (int64_t)i0 * ldx;
-            int n_in = mo.in, ldin = ldx;
-            for (int l = 0; l < mo.L; ++l) {
-                const float *W = par + mo.oW[l], *bb = par + mo.ob[l];
-                float *o = hid[l] + (int64_t)i0 * mo.H;
-                wg_gemm(in, ldin, 1, W, n_in, 1, ib, mo.H, n_in, Ps, Qs, epi_bias_act(o, mo.H, bb, act_id, prelu));
-                __syncthreads();
-                in = o; n_in = mo.H; ldin = mo.H;
-            }
-            const float *W = par + mo.oW[mo.L], *bb = par + mo.ob[mo.L];
-            if (final_tanh)
-                wg_gemm(in, ldin, 1, W, n_in, 1, ib, mo.out, n_in, Ps, Qs,
-                        epi_bias_tanh(out + (int64_t)i0 * ldo, ldo, ocol, bb, ma, th_out ? th_out + (int64_t)i0 * mo.out : nullptr, mo.out));
-            else
-                wg_gemm(in, ldin, 1, W, n_in, 1, ib, mo.out, n_in, Ps, Qs, epi_bias(out + (int64_t)i0 * ldo, ldo, ocol, bb));
-            __syncthreads();
+        const float *in = X;
+        int n_in = mo.in, ldin = ldx;
+        for (int l = 0; l < mo.L; ++l) {
+            gq.gemm(in, ldin, 1, par + mo.oW[l], n_in, 1, I, mo.H, n_in, epi_bias_act(hid[l], mo.H, par + mo.ob[l], act_id, prelu));
+            in = hid[l]; n_in = mo.H; ldin = mo.H;
         }
+        const float *W = par + mo.oW[mo.L], *bb = par + mo.ob[mo.L];
+        if (final_tanh) gq.gemm(in, ldin, 1, W, n_in, 1, I, mo.out, n_in, epi_bias_tanh(out, ldo, ocol, bb, ma, th_out, mo.out));
+        else gq.gemm(in, ldin, 1, W, n_in, 1, I, mo.out, n_in, epi_bias(out, ldo, ocol, bb));
     };
 
-    // ---- generic MLP backward: dOut [I][out] -> parameter gradients gpar (may be null) and input gradient dX (may be null)
+    // ---- generic MLP backward: dOut [I][out] -> parameter gradients gpar (may be null) and input gradient dX (may be null);
+    // queued like the forward.  The output-layer bias gradient (a handful of columns of an LDS vector) is done in place.
     auto mlp_backward = [&](const float *par, const MlpOff &mo, const float *X, int ldx, int I, float *const *hid, const float *dOut,
                             float *gpar, float *dX) {
         const int Hh = mo.H, O = mo.out;
         if (gpar) {
-            wg_gemm(dOut, 1, O, hid[mo.L - 1], 1, Hh, O, Hh, I, Ps, Qs, epi_store(gpar + mo.oW[mo.L], Hh));
-            if (tid < O) { float s = 0.0f; for (int b = 0; b < I; ++b) s = s + dOut[b * O + tid]; gpar[mo.ob[mo.L] + tid] = s; }
+            gq.gemm(dOut, 1, O, hid[mo.L - 1], 1, Hh, O, Hh, I, epi_store(gpar + mo.oW[mo.L], Hh));
+            gq.colsum(dOut, I, O, O, gpar + mo.ob[mo.L]);
         }
         float *dcur = dbuf[0];
-        for (int i0 = 0; i0 < I; i0 += GT_I) {
-            const int ib = I - i0 < GT_I ? I - i0 : GT_I;
-            const float *hl = hid[mo.L - 1] + (int64_t)i0 * Hh;
-            float *dc = dcur + (int64_t)i0 * Hh;
-            wg_gemm(dOut + (int64_t)i0 * O, O, 1, par + mo.oW[mo.L], 1, Hh, ib, Hh, O, Ps, Qs, epi_act_bwd(dc, Hh, hl, Hh, act_id, prelu));
-        }
-        __syncthreads();
+        gq.gemm(dOut, O, 1, par + mo.oW[mo.L], 1, Hh, I, Hh, O, epi_act_bwd(dcur, Hh, hid[mo.L - 1], Hh, act_id, prelu));
         for (int l = mo.L - 1; l >= 0; --l) {
             const int n_in = l == 0 ? mo.in : Hh;
             const float *inp = l == 0 ? X : hid[l - 1];
             const int ldin = l == 0 ? ldx : Hh;
-            const float *dc = dcur;
             if (gpar) {
-                wg_gemm(dc, 1, Hh, inp, 1, ldin, Hh, n_in, I, Ps, Qs, epi_store(gpar + mo.oW[l], n_in));
-                wg_colsum(dc, I, Hh, gpar + mo.ob[l]);
+                gq.gemm(dcur, 1, Hh, inp, 1, ldin, Hh, n_in, I, epi_store(gpar + mo.oW[l], n_in));
+                gq.colsum(dcur, I, Hh, Hh, gpar + mo.ob[l]);
             }
             if (l > 0) {
                 float *dn = dbuf[(mo.L - l) & 1];
-                for (int i0 = 0; i0 < I; i0 += GT_I) {
-                    const int ib = I - i0 < GT_I ? I - i0 : GT_I;
-                    const float *hp = hid[l - 1] + (int64_t)i0 * Hh;
-                    float *dnb = dn + (int64_t)i0 * Hh;
-                    wg_gemm(dc + (int64_t)i0 * Hh, Hh, 1, par + mo.oW[l], 1, n_in, ib, n_in, Hh, Ps, Qs, epi_act_bwd(dnb, n_in, hp, n_in, act_id, prelu));
-                }
+                gq.gemm(dcur, Hh, 1, par + mo.oW[l], 1, n_in, I, n_in, Hh, epi_act_bwd(dn, n_in, hid[l - 1], n_in, act_id, prelu));
                 dcur = dn;
             } else if (dX) {
-                for (int i0 = 0; i0 < I; i0 += GT_I) {
-                    const int ib = I - i0 < GT_I ? I - i0 : GT_I;
-                    float *dxo = dX + (int64_t)i0 * n_in;
-                    wg_gemm(dc + (int64_t)i0 * Hh, Hh, 1, par + mo.oW[0], 1, n_in, ib, n_in, Hh, Ps, Qs, epi_store(dxo, n_in));
-                }
+                gq.gemm(dcur, Hh, 1, par + mo.oW[0], 1, n_in, I, n_in, Hh, epi_store(dX, n_in));
             }
-            __syncthreads();
         }
     };
 
@@ -231,6 +209,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             for (int e = tid; e < T * S; e += DNT) xt[e] = (float)xt_d[e];
             __syncthreads();
             mlp_forward(params, a.actor, xt, S, T, ht, at, A, 0, true, nullptr);
+            gq.run<T3_MAXI>(Ps, Qs);
             // select_test_action (TD3.py:126-129): (actor(s) + randn(A)*action_std*max_action).clamp(-max, max)
             for (int e = tid; e < T * A; e += DNT) {
                 const int te = e / A, k = e - te * A;
@@ -291,6 +270,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 __syncthreads();
             } else {
                 mlp_forward(params, a.actor, state, S, 1, ht, action, A, 0, true, nullptr);
+                gq.run<T3_MAXI>(Ps, Qs);
                 if (tid < A) {
                     float zn;
                     if (tape) { if (n_actn >= a.tapes.act_noise_stride) { status = -7; zn = 0.0f; } else zn = a.tapes.act_noise[(chain * a.tapes.act_noise_stride + n_actn) * A + tid]; }
@@ -366,6 +346,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 __syncthreads();
                 // next_actions = (actor_target(s') + clamp(randn*policy_std)).clamp(-max, max)
                 mlp_forward(targets, a.actor, xn, SA, B, ht, xn, SA, S, true, nullptr);
+                gq.run<T3_MAXI>(Ps, Qs);
                 for (int e = tid; e < B * A; e += DNT) {
                     const int b = e / A, k = e - b * A;
                     const int64_t n = (learn_it * B + b) * A + k;
@@ -383,6 +364,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 mlp_forward(targets + Pa + Pc, a.critic, xn, SA, B, ht, tq2, 1, 0, false, nullptr);
                 mlp_forward(params + Pa, a.critic, xc, SA, B, hc1, q1, 1, 0, false, nullptr);
                 mlp_forward(params + Pa + Pc, a.critic, xc, SA, B, hc2, q2, 1, 0, false, nullptr);
+                gq.run<T3_MAXI>(Ps, Qs);                   // 4 critic forwards, one call
                 {
                     const float norm = (float)(2.0 / (double)B);
                     for (int b = tid; b < B; b += DNT) {
@@ -395,6 +377,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 __syncthreads();
                 mlp_backward(params + Pa, a.critic, xc, SA, B, hc1, dq1, grad + Pa, nullptr);
                 mlp_backward(params + Pa + Pc, a.critic, xc, SA, B, hc2, dq2, grad + Pa + Pc, nullptr);
+                gq.run<T3_MAXI>(Ps, Qs);
                 adam(Pa, 2 * Pc, 0);                       // critic_optimizer: critic_1 then critic_2 parameters
                 ++learn_it;
                 if (learn_it % cfg.policy_delay == 0) {
@@ -403,10 +386,12 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     __syncthreads();
                     mlp_forward(params, a.actor, xc, SA, B, ha, xa, SA, S, true, thb);
                     mlp_forward(params + Pa, a.critic, xa, SA, B, hc1, q1, 1, 0, false, nullptr);
+                    gq.run<T3_MAXI>(Ps, Qs);
                     const float dqa = -(1.0f / (float)B);
                     for (int b = tid; b < B; b += DNT) dq1[b] = dqa;
                     __syncthreads();
                     mlp_backward(params + Pa, a.critic, xa, SA, B, hc1, dq1, nullptr, dxb);
+                    gq.run<T3_MAXI>(Ps, Qs);
                     for (int e = tid; e < B * A; e += DNT) {
                         const int b = e / A, k = e - b * A;
                         const float th = thb[e];
@@ -414,6 +399,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     }
                     __syncthreads();
                     mlp_backward(params, a.actor, xc, SA, B, ha, dzb, grad, nullptr);
+                    gq.run<T3_MAXI>(Ps, Qs);
                     adam(0, Pa, 2);
                     const float tau = (float)cfg.tau, omt = (float)(1.0 - cfg.tau);
                     wg_polyak(params, targets, P, tau, omt);
@@ -487,7 +473,7 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
     if (!((t >= 0 && t <= 8) || t == 101 || t == 102)) return LENV_ERR_UNSUPPORTED;          // reward_env.py:49,58 NotImplementedError
     const bool uses_info = t == 3 || t == 4 || t == 7 || t == 8 || t > 100;
     if (uses_info && cfg->info_dim != 4) return LENV_ERR_INVALID;                              // the stand-in's info vector has 4 entries
-    if (L < 1 || L > T3_MAXL || H < 1 || H > T3_MAXW || B < 1 || B > 2 * GT_I || T < 1 || T * T3_S > DNT || cfg->rn_layers != 1 || Hrn < 1 ||
+    if (L < 1 || L > T3_MAXL || H < 1 || H > T3_MAXW || B < 1 || B > T3_MAXI || T < 1 || T * T3_S > DNT || cfg->rn_layers != 1 || Hrn < 1 ||
         cfg->policy_delay < 1 || cfg->max_steps < 1 || cfg->train_episodes < 0)
         return LENV_ERR_UNSUPPORTED;
     mlp_off(a.actor, T3_S, H, L, T3_A);
@@ -509,7 +495,7 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
     a.a_dx = take((int64_t)RB * T3_SA); a.a_act = take((int64_t)RB * T3_A); a.a_th = take((int64_t)RB * T3_A); a.a_dz = take((int64_t)RB * T3_A);
     a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
     a.arena_stride = (off + 63) & ~(int64_t)63;
-    const size_t lds_floats = 2 * (size_t)GT_RB * GT_LD + ((a.P_rn + 3) & ~3) + ((Hrn + 3) & ~3) + 8 * (size_t)B + 64 + 2 + 2 * (20 + 17 * (size_t)T + T) + T + 20 + 8 + 56 + 16;
+    const size_t lds_floats = GemmShape<T3_MAXI>::PS_FLOATS + GemmShape<T3_MAXI>::QS_FLOATS + GEMM_QUEUE_MAX * sizeof(GemmCmd) / sizeof(float) + ((a.P_rn + 3) & ~3) + ((Hrn + 3) & ~3) + 8 * (size_t)B + 64 + 2 + 2 * (20 + 17 * (size_t)T + T) + T + 20 + 8 + 56 + 16;
     *lds_bytes = lds_floats * sizeof(float);
     if (*lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     return LENV_OK;
