@@ -9,15 +9,16 @@ using namespace lenv;
 __global__ __launch_bounds__(DNT) void gemm_k(float *arena, int64_t stride, int I, int J, int R, int reps, int mode, unsigned long long *cyc)
 {
     extern __shared__ __align__(16) float lds[];
-    float *Ps = lds, *Qs = lds + GT_RB * GT_LD;
+    float *Ps = lds, *Qs = lds + GemmShape<128>::PS_FLOATS;
+    GemmQueue gq(reinterpret_cast<GemmCmd *>(Qs + GemmShape<128>::QS_FLOATS));
     float *base = arena + blockIdx.x * stride;
     float *X = base, *W = base + 128 * 128, *bias = W + 128 * 128, *Y = bias + 128, *Y2 = Y + 128 * 128;
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int r = 0; r < reps; ++r) {
-        if (mode == 0) wg_gemm(X, R, 1, W, R, 1, I, J, R, Ps, Qs, epi_bias_act(Y, J, bias, LENV_ACT_RELU, 0.0f));
-        else if (mode == 1) wg_gemm(Y, 1, J, X, 1, R, J, R, I, Ps, Qs, epi_store(Y2, R));                      // dW = dY^T X
-        else wg_gemm(Y, J, 1, W, 1, R, I, R, J, Ps, Qs, epi_act_bwd(Y2, R, X, R, LENV_ACT_RELU, 0.0f));        // dX = dY W
-        __syncthreads();
+        if (mode == 0) gq.gemm(X, R, 1, W, R, 1, I, J, R, epi_bias_act(Y, J, bias, LENV_ACT_RELU, 0.0f));
+        else if (mode == 1) gq.gemm(Y, 1, J, X, 1, R, J, R, I, epi_store(Y2, R));                      // dW = dY^T X
+        else gq.gemm(Y, J, 1, W, 1, R, I, R, J, epi_act_bwd(Y2, R, X, R, LENV_ACT_RELU, 0.0f));        // dX = dY W
+        if ((r & 7) == 7 || r == reps - 1) gq.run<128>(Ps, Qs);                                       // queues of 8 products
     }
     if (threadIdx.x == 0) cyc[blockIdx.x] = __builtin_readcyclecounter() - t0;
 }
@@ -32,7 +33,7 @@ int main()
     std::vector<float> h(stride * chains);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)rand() / RAND_MAX - 0.5f;
     hipMemcpy(arena, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice);
-    const size_t ldsb = 2 * GT_RB * GT_LD * sizeof(float);
+    const size_t ldsb = (GemmShape<128>::PS_FLOATS + GemmShape<128>::QS_FLOATS) * sizeof(float) + GEMM_QUEUE_MAX * sizeof(GemmCmd);
     hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     const int shapes[][3] = { {128, 128, 128}, {128, 128, 6}, {10, 128, 128}, {1, 128, 128}, {128, 3, 128} };
     for (auto &sh : shapes)
