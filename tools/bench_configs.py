@@ -17,7 +17,7 @@ from learning_environments_amd.agents.GTN import GTN_Master  # noqa: E402
 from learning_environments_amd import configs  # noqa: E402
 
 
-def run(name, cfg, gens=2):
+def run(name, cfg, gens=2, extra=None):
     torch.manual_seed(0)
     m = GTN_Master(cfg, bohb_id=0, seed=7)
     m.step(0)
@@ -31,7 +31,37 @@ def run(name, cfg, gens=2):
     out = dict(config=name, pop=cfg["agents"]["gtn"]["num_workers"], chains=int(st.shape[0]), s_per_generation=dt,
                evals_per_s=cfg["agents"]["gtn"]["num_workers"] / dt, train_steps=int(st[:, 1].sum()), learn_steps=int(st[:, 2].sum()),
                test_steps=int(st[:, 3].sum()), us_per_learn_step_per_chain=1e6 * dt / max(1.0, st[:, 2].mean()))
+    out.update(extra(cfg, st, dt) if extra else {})
     print(json.dumps(out))
+
+
+HBM_PEAK_GBPS, MFMA_F32_PEAK_TFLOPS = 8000.0, 157.3       # MI355X_MICROARCH.md
+
+
+def dueling_model(cfg, st, dt):
+    """SURVEY.md 8(d) algorithmic bytes and the fp32 FLOPs of the layer products for config 3."""
+    a, e = cfg["agents"]["duelingddqn"], cfg["envs"]["Acrobot-v1"]
+    S, A, H, F, L, B = 6, 3, a["hidden_size"], a["feature_dim"], a["hidden_layer"], a["batch_size"]
+    P = S * H + H + (L - 1) * (H * H + H) + H * F + F + 2 * (F * F + F) + F + 1 + A * F + A
+    f = 2 * (S * H + (L - 1) * H * H + H * F + 2 * F * F + F * (1 + A))                      # FLOPs of one forward row
+    learn, train, test = float(st[:, 2].sum()), float(st[:, 1].sum()), float(st[:, 3].sum())
+    nbytes = 4 * (learn * (B * (2 * S + 3) + 8 * P) + train * ((2 * S + 3) + (A + S) + (S + 2)) + test * (P + 2 * S + 2))
+    flops = learn * 5 * B * f + (train + test) * f
+    return dict(algorithmic_GBps=nbytes / dt / 1e9, hbm_frac=nbytes / dt / 1e9 / HBM_PEAK_GBPS, fp32_TFLOPs=flops / dt / 1e12,
+                mfma_f32_frac=flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, busy_cus=int(st.shape[0]))
+
+
+def td3_model(cfg, st, dt):
+    a = cfg["agents"]["td3"]
+    S, A, H, B = 17, 6, a["hidden_size"], a["batch_size"]
+    Pa = S * H + H + H * H + H + H * A + A
+    Pc = (S + A) * H + H + H * H + H + H + 1
+    fa, fc = 2 * (S * H + H * H + H * A), 2 * ((S + A) * H + H * H + H)
+    learn, train, test = float(st[:, 2].sum()), float(st[:, 1].sum()), float(st[:, 3].sum())
+    nbytes = 4 * (learn * (B * (2 * S + A + 2) + 8 * (Pa + 2 * Pc)) + train * (2 * S + A + 2) + test * (Pa + 2 * S + 2))
+    flops = learn * B * (4 * fa + 10 * fc) + (train + test) * fa
+    return dict(algorithmic_GBps=nbytes / dt / 1e9, hbm_frac=nbytes / dt / 1e9 / HBM_PEAK_GBPS, fp32_TFLOPs=flops / dt / 1e12,
+                mfma_f32_frac=flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, busy_cus=int(st.shape[0]))
 
 
 if __name__ == "__main__":
@@ -46,9 +76,9 @@ if __name__ == "__main__":
         c = configs.fixed_work(configs.acrobot_syn_env_duelingddqn(32), 3)
         c["agents"]["duelingddqn"]["init_episodes"] = 1
         c["envs"]["Acrobot-v1"]["max_steps"] = 100
-        run("cfg3 Acrobot SE + DuelingDDQN pop 32 (3 episodes x 100 steps)", c, gens=1)
+        run("cfg3 Acrobot SE + DuelingDDQN pop 32 (3 episodes x 100 steps)", c, gens=1, extra=dueling_model)
     if "5" in which:
         c = configs.fixed_work(configs.halfcheetah_reward_env_td3(32), 3)
         c["agents"]["td3"]["init_episodes"] = 1
         c["envs"]["HalfCheetah-v3"]["max_steps"] = 100
-        run("cfg5 HalfCheetah-standin RN + TD3 pop 32 (3 episodes x 100 steps)", c, gens=1)
+        run("cfg5 HalfCheetah-standin RN + TD3 pop 32 (3 episodes x 100 steps)", c, gens=1, extra=td3_model)

@@ -38,6 +38,17 @@ if "FETCH_SIZE_KB_per_launch" in out and "WRITE_SIZE_KB_per_launch" in out:
     # streaming reads -> double the read side (upper bound for this kernel's 16-byte row gathers); WRITE_SIZE is exact.
     out["hbm_traffic_bytes_per_launch"] = (2.0 * out["FETCH_SIZE_KB_per_launch"] + out["WRITE_SIZE_KB_per_launch"]) * 1024.0
     out["traffic_note"] = "2*FETCH_SIZE + WRITE_SIZE (KB->bytes), per fused-kernel launch, gfx950 read-side correction applied"
+# the other configurations (tools/bench_configs.py under rocprofv3 --kernel-trace --stats)
+for f in glob.glob(os.path.join(R, "gpurun_out/prof_configs/*/*kernel_stats.csv")):
+    rows = list(csv.reader(open(f)))
+    with open(os.path.join(R, "profiles", tag + "_configs_kernel_stats.csv"), "w") as o:
+        w = csv.writer(o)
+        for r in rows:
+            r[0] = r[0][:96]
+            w.writerow(r)
+cfgs = os.path.join(R, "gpurun_out", "bench_configs.jsonl")
+if os.path.exists(cfgs):
+    out["configs"] = [json.loads(l) for l in open(cfgs) if l.startswith("{")]
 bench = os.path.join(R, "gpurun_out", "bench.json")
 if os.path.exists(bench):
     try:
