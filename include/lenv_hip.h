@@ -296,6 +296,11 @@ uint64_t lenv_chain_key(uint64_t seed, uint64_t generation, uint64_t worker, uin
  * laid out [pop,3] = (orig, add, sub): result[p] = {score_best, score_orig, sign, 0} (double).
  */
 int lenv_nes_worker_best(const double *chain_scores, int64_t pop, int32_t mirrored, double *result, void *stream);
+/* the same for num_grad_evals = G evaluations per direction (agents/GTN_worker.py:90-104,234-242): chain_scores [pop,1+2G] =
+ * (orig, add_1..add_G, sub_1..sub_G); grad_eval_type 0 = 'mean' (statistics.mean: the exactly rounded mean), 1 = 'minmax'
+ * (min of both lists, as the reference computes it); anything else LENV_ERR_UNSUPPORTED. */
+int lenv_nes_worker_best_multi(const double *chain_scores, int64_t pop, int32_t num_grad_evals, int32_t mirrored,
+                               int32_t grad_eval_type, double *result, void *stream);
 
 /*
  * GTN_Master.score_transform + update_env (agents/GTN_master.py:197-298) on device.

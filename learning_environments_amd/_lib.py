@@ -97,7 +97,7 @@ EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv
            "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population", "lenv_dueling_se_workspace_bytes",
            "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
            "lenv_td3_rn_inner_loop", "lenv_mlp_forward", "lenv_cheetah_standin_reset", "lenv_cheetah_standin_step",
-           "lenv_rn_num_params", "lenv_rn_shape_rows"]
+           "lenv_rn_num_params", "lenv_rn_shape_rows", "lenv_nes_worker_best_multi"]
 
 
 def build(force=False):
@@ -171,6 +171,8 @@ def lib():
         L.lenv_cheetah_standin_step.argtypes = [C.c_int32, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
         L.lenv_rn_shape_population.restype = C.c_int
         L.lenv_rn_shape_population.argtypes = [C.POINTER(QlCfg), vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
+        L.lenv_nes_worker_best_multi.restype = C.c_int
+        L.lenv_nes_worker_best_multi.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp, vp]
         L.lenv_nes_worker_best.restype = C.c_int
         L.lenv_nes_worker_best.argtypes = [vp, C.c_int64, C.c_int32, vp, vp]
         L.lenv_nes_rank_update.restype = C.c_int

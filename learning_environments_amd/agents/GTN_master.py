@@ -60,8 +60,9 @@ class GTN_Master(GTN_Base):
             raise ValueError("Unknown rank transform type: " + str(self.score_transform_type))
         if self.grad_eval_type not in ('mean', 'minmax'):
             raise NotImplementedError('Unknown parameter for grad_eval_type: ' + str(self.grad_eval_type))
-        if self.num_grad_evals != 1:
-            raise NotImplementedError("num_grad_evals != 1")
+        if int(self.num_grad_evals) < 1:
+            raise ValueError("num_grad_evals must be >= 1")
+        self.cpw = 1 + 2 * int(self.num_grad_evals)       # chains per worker: orig, G x (+eps), G x (-eps)  (GTN_worker.py:84-104)
         if self.agent_name.lower() not in ("ddqn", "duelingddqn", "ql", "td3"):
             raise NotImplementedError("inner agent '%s' has no fused kernel yet" % self.agent_name)
 
@@ -99,10 +100,11 @@ class GTN_Master(GTN_Base):
         self.task = select_task(config, engine, self.synthetic_env_orig)
         self.cfg = self.task.cfg
         self.agent_bounds = self.task.agent_bounds
-        self.inner = self.task.make_inner(3 * self.n_local) if self.n_local > 0 else None
+        G = int(self.num_grad_evals)
+        self.inner = self.task.make_inner(self.cpw * self.n_local) if self.n_local > 0 else None
         lw = np.arange(self.w_lo, self.w_hi)
-        self.chain_worker = torch.from_numpy(np.repeat(lw, 3).astype(np.int32)).to(dev)
-        self.chain_sign = torch.tensor([0.0, 1.0, -1.0] * self.n_local, dtype=torch.float32, device=dev)
+        self.chain_worker = torch.from_numpy(np.repeat(lw, self.cpw).astype(np.int32)).to(dev)
+        self.chain_sign = torch.tensor(([0.0] + [1.0] * G + [-1.0] * G) * self.n_local, dtype=torch.float32, device=dev)
         self.rank_table = torch.from_numpy(rank_table(self.score_transform_type, self.num_workers)).to(dev)
         self.eps = None
 
@@ -136,16 +138,18 @@ class GTN_Master(GTN_Base):
         g.manual_seed((self.seed * 1000003 + it) % (2 ** 63 - 1))
         # GTN_Worker.get_random_noise (agents/GTN_worker.py:156-163): N(0,1) * noise_std, full population on every rank
         self.eps = torch.randn((pop, self.p_theta), generator=g, device=dev, dtype=torch.float32) * self.noise_std
-        agent_init = fresh_agent_init(self.agent_bounds, 3 * pop, g, dev) if self.task.needs_agent_init() else None
+        cpw = self.cpw
+        agent_init = fresh_agent_init(self.agent_bounds, cpw * pop, g, dev) if self.task.needs_agent_init() else None
         local = torch.zeros((self.w_per, 4), dtype=torch.float64, device=dev)
         if self.n_local > 0:
             lw = np.arange(self.w_lo, self.w_hi)
-            keys = chain_keys(self.seed, it, np.repeat(lw, 3), np.tile(np.arange(3), self.n_local))
+            keys = chain_keys(self.seed, it, np.repeat(lw, cpw), np.tile(np.arange(cpw), self.n_local))
             keys_t = torch.from_numpy(keys.view(np.int64)).to(dev)
-            local_init = agent_init[3 * self.w_lo:3 * self.w_hi].contiguous() if agent_init is not None else None
+            local_init = agent_init[cpw * self.w_lo:cpw * self.w_hi].contiguous() if agent_init is not None else None
             chain_scores = self.task.scores(self.inner, self.theta, self.eps, self.chain_worker, self.chain_sign, keys_t,
                                             local_init)
-            local[:self.n_local] = self.engine.worker_best(chain_scores, self.n_local, self.mirrored_sampling)
+            local[:self.n_local] = self.engine.worker_best(chain_scores, self.n_local, self.mirrored_sampling,
+                                                           int(self.num_grad_evals), self.grad_eval_type)
         if self.world > 1:
             gathered = torch.empty((self.world * self.w_per, 4), dtype=torch.float64, device=dev)
             dist.all_gather_into_tensor(gathered, local)      # the ONE collective of a generation (RCCL over xGMI)

@@ -121,7 +121,7 @@ class GTN_Worker(GTN_Base):
         g = torch.Generator(device=dev)
         g.manual_seed((self.seed * 1000003 + self.generation * 7919 + self.test_counter) % (2 ** 63 - 1))
         agent_init = fresh_agent_init(self._bounds, n, g, dev)
-        keys = chain_keys(self.seed, self.generation * 1000 + self.test_counter, np.full(n, self.id), np.arange(n) % 4)
+        keys = chain_keys(self.seed, self.generation * 1000 + self.test_counter, np.full(n, self.id), np.arange(n))
         self.test_counter += 1
         scores = self.engine.inner_scores(inner, zero, eps, worker, sign, agent_init,
                                           torch.from_numpy(keys.view(np.int64)).to(dev))
@@ -162,9 +162,11 @@ class GTN_Worker(GTN_Base):
         self.get_random_noise()
         th = self._flat(self.synthetic_env_orig)
         e = self._flat(self.eps)
-        score_orig, score_add, score_sub = self._run_chains([th, th + e, th - e])
+        G = int(self.num_grad_evals)                       # reference :90-104: G evaluations of +eps, then G of -eps
+        scores = self._run_chains([th] + [th + e] * G + [th - e] * G)
+        score_orig, score_add, score_sub = scores[0], scores[1:1 + G], scores[1 + G:]
         self.subtract_noise_from_synthetic_env()          # state the reference is in before calc_best_score
-        score_best = self.calc_best_score(score_add=[score_add], score_sub=[score_sub])
+        score_best = self.calc_best_score(score_add=score_add, score_sub=score_sub)
         return score_best, score_orig
 
     # ---- file transport, reference :76-154 ----

@@ -27,6 +27,37 @@ __global__ void worker_best_kernel(const double *chain_scores, int64_t pop, int 
     result[p * 4] = best; result[p * 4 + 1] = orig; result[p * 4 + 2] = sign; result[p * 4 + 3] = 0.0;
 }
 
+// statistics.mean of python floats = the correctly rounded exact mean; same double-double accumulation as the oracle's
+__device__ __forceinline__ double exact_mean(const double *x, int n)
+{
+    double hi = 0.0, lo = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double s = hi + x[i], bb = s - hi, err = (hi - (s - bb)) + (x[i] - bb);
+        hi = s; lo = lo + err;
+    }
+    const double s = hi + lo, e = lo - (s - hi);
+    const double q = s / (double)n, r = __builtin_fma(-q, (double)n, s) + e;
+    return q + r / (double)n;
+}
+
+// num_grad_evals = G evaluations per direction: chain_scores [pop, 1+2G] = (orig, add_1..add_G, sub_1..sub_G);
+// grad_eval_type 0 'mean', 1 'minmax' (the reference takes min() of BOTH lists, GTN_worker.py:238-240)
+__global__ void worker_best_multi_kernel(const double *chain_scores, int64_t pop, int G, int mirrored, int type, double *result)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= pop) return;
+    const double *row = chain_scores + p * (1 + 2 * G);
+    double add, sub;
+    if (type == 0) { add = exact_mean(row + 1, G); sub = exact_mean(row + 1 + G, G); }
+    else {
+        add = row[1]; sub = row[1 + G];
+        for (int i = 1; i < G; ++i) { if (row[1 + i] < add) add = row[1 + i]; if (row[1 + G + i] < sub) sub = row[1 + G + i]; }
+    }
+    double best = add, sign = 1.0;
+    if (mirrored) { best = add > sub ? add : sub; sign = sub > add ? -1.0 : 1.0; }
+    result[p * 4] = best; result[p * 4 + 1] = row[0]; result[p * 4 + 2] = sign; result[p * 4 + 3] = 0.0;
+}
+
 constexpr int RT_NT = 1024;
 
 // single workgroup: weights_out[i] = score_transform(scores)[i]
@@ -134,6 +165,17 @@ extern "C" int lenv_nes_worker_best(const double *chain_scores, int64_t pop, int
     if (pop == 0) return LENV_OK;
     hipLaunchKernelGGL(worker_best_kernel, dim3((unsigned)((pop + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        chain_scores, pop, mirrored, result);
+    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}
+
+extern "C" int lenv_nes_worker_best_multi(const double *chain_scores, int64_t pop, int32_t num_grad_evals, int32_t mirrored,
+                                          int32_t grad_eval_type, double *result, void *stream)
+{
+    if (!chain_scores || !result || pop < 0 || num_grad_evals < 1) return LENV_ERR_INVALID;
+    if (grad_eval_type != 0 && grad_eval_type != 1) return LENV_ERR_UNSUPPORTED;       // GTN_worker.py:242 NotImplementedError
+    if (pop == 0) return LENV_OK;
+    hipLaunchKernelGGL(worker_best_multi_kernel, dim3((unsigned)((pop + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       chain_scores, pop, num_grad_evals, mirrored, grad_eval_type, result);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }
 

@@ -307,12 +307,19 @@ def rn_shape_population(cfg, theta, eps, worker, sign, next_state, reward, chain
     return phi, shaped
 
 
-def nes_worker_best(chain_scores, pop, mirrored=True):
+GRAD_EVAL_TYPES = {"mean": 0, "minmax": 1}
+
+
+def nes_worker_best(chain_scores, pop, mirrored=True, num_grad_evals=1, grad_eval_type="mean"):
+    """GTN_Worker.calc_best_score for `pop` workers; chain_scores [pop, 1+2G] = (orig, add_1..G, sub_1..G)."""
     dev = require_device()
     _chk(chain_scores, torch.float64, "chain_scores")
+    if grad_eval_type not in GRAD_EVAL_TYPES:
+        raise NotImplementedError('Unknown parameter for grad_eval_type: ' + str(grad_eval_type))
     result = torch.empty((pop, 4), dtype=torch.float64, device=dev)
-    rc = _lib.lib().lenv_nes_worker_best(_ptr(chain_scores), pop, 1 if mirrored else 0, _ptr(result), _stream())
-    _lib.check(rc, "lenv_nes_worker_best")
+    rc = _lib.lib().lenv_nes_worker_best_multi(_ptr(chain_scores), pop, int(num_grad_evals), 1 if mirrored else 0,
+                                               GRAD_EVAL_TYPES[grad_eval_type], _ptr(result), _stream())
+    _lib.check(rc, "lenv_nes_worker_best_multi")
     return result
 
 
@@ -361,8 +368,8 @@ class HipNesEngine(object):
         if int(st.min()) != 0:
             raise _lib.LenvError("inner loop reported status %s" % st.tolist())
 
-    def worker_best(self, chain_scores, pop, mirrored):
-        return nes_worker_best(chain_scores, pop, mirrored)
+    def worker_best(self, chain_scores, pop, mirrored, num_grad_evals=1, grad_eval_type="mean"):
+        return nes_worker_best(chain_scores, pop, mirrored, num_grad_evals, grad_eval_type)
 
     def rank_update(self, score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size, weight_decay):
         return nes_rank_update(score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size, weight_decay)

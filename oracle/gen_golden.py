@@ -243,6 +243,40 @@ def gen_g6():
          env_after=np.stack([c[4] for c in cases]))
 
 
+
+def gen_g6m():
+    """calc_best_score with num_grad_evals = 3 score lists, 'mean' (statistics.mean) and 'minmax', mirrored or not."""
+    from agents.GTN import GTN_Worker
+    cfg = load_cfg("default_config_cartpole_syn_env.yaml")
+    rng = np.random.RandomState(61)
+    n = 40
+    add = rng.uniform(5, 200, (n, 3)) / rng.choice([1.0, 3.0, 7.0, 10.0], (n, 1))
+    sub = rng.uniform(5, 200, (n, 3)) / rng.choice([1.0, 3.0, 7.0, 10.0], (n, 1))
+    add[0] = sub[0]                                    # a tie: +eps is kept
+    add[1] = [0.1, 0.2, 0.3]; sub[1] = [0.3, 0.2, 0.1]   # equal exact means, different float sums
+    out = {}
+    with quiet():
+        w = GTN_Worker(id=0, bohb_id=0)
+        seed_all(601)
+        w.config = cfg
+        w.late_init(cfg)
+        w.get_random_noise()
+        eps = se_theta(w.eps)
+        for gtype in ("mean", "minmax"):
+            for mirrored in (True, False):
+                w.grad_eval_type = gtype
+                w.mirrored_sampling = mirrored
+                best, sign = [], []
+                for i in range(n):
+                    w.eps.load_state_dict(_sd_from_flat(w.eps, eps))
+                    b = w.calc_best_score(score_sub=[float(v) for v in sub[i]], score_add=[float(v) for v in add[i]])
+                    best.append(b)
+                    sign.append(-1.0 if np.array_equal(se_theta(w.eps), -eps) else 1.0)
+                out["best_%s_%d" % (gtype, mirrored)] = np.array(best)
+                out["sign_%s_%d" % (gtype, mirrored)] = np.array(sign, np.float32)
+    save("g6m_worker_best_multi", score_add=add, score_sub=sub, **out)
+
+
 def _sd_from_flat(envw, flat):
     sd = copy.deepcopy(envw.state_dict())
     off = 0
@@ -917,7 +951,7 @@ def gen_g8t(name, seed):
 
 
 def main():
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m"]
     os.makedirs(OUT, exist_ok=True)
     if "g1" in which:
         gen_g1()
@@ -927,6 +961,8 @@ def main():
         gen_g4()
     if "g6" in which:
         gen_g6()
+    if "g6m" in which:
+        gen_g6m()
     if "g7" in which:
         gen_g7()
     if "g4t" in which:

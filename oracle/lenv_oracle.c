@@ -1129,6 +1129,39 @@ void orc_worker_best(const double *score_add, const double *score_sub, int64_t p
     }
 }
 
+/* statistics.mean of python floats is the correctly rounded exact mean; this double-double accumulation (TwoSum per term,
+ * one renormalisation, one correction step of the division) reproduces it for the handful of scores a worker averages. */
+static double exact_mean(const double *x, int n)
+{
+    double hi = 0.0, lo = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double s = hi + x[i], bb = s - hi, err = (hi - (s - bb)) + (x[i] - bb);
+        hi = s; lo = lo + err;
+    }
+    const double s = hi + lo, e = lo - (s - hi);
+    const double q = s / (double)n, r = fma(-q, (double)n, s) + e;
+    return q + r / (double)n;
+}
+
+/* GTN_worker.py:234-254 with num_grad_evals = G score lists per direction: grad_eval_type 0 = 'mean' (statistics.mean),
+ * 1 = 'minmax' (min of BOTH lists, as the reference does) */
+int orc_worker_best_multi(const double *score_add /*[pop,G]*/, const double *score_sub /*[pop,G]*/, int64_t pop, int G, int mirrored,
+                          int grad_eval_type, double *score_best, float *sign)
+{
+    if (G < 1 || (grad_eval_type != 0 && grad_eval_type != 1)) return -1;
+    for (int64_t p = 0; p < pop; ++p) {
+        double a, b;
+        if (grad_eval_type == 0) { a = exact_mean(score_add + p * G, G); b = exact_mean(score_sub + p * G, G); }
+        else {
+            a = score_add[p * G]; b = score_sub[p * G];
+            for (int i = 1; i < G; ++i) { if (score_add[p * G + i] < a) a = score_add[p * G + i]; if (score_sub[p * G + i] < b) b = score_sub[p * G + i]; }
+        }
+        if (mirrored) { score_best[p] = a > b ? a : b; sign[p] = b > a ? -1.0f : 1.0f; }
+        else { score_best[p] = a; sign[p] = 1.0f; }
+    }
+    return 0;
+}
+
 /* rank helpers with a documented stable order (np.argsort's tie order is implementation-defined,
  * SURVEY.md Appendix A #14): among equal scores the lower index comes first. */
 static void argsort_stable(const double *v, int64_t n, int descending, int64_t *idx)

@@ -249,6 +249,9 @@ int orc_td3_rn_chain(const orc_td3_cfg *cfg, const float *rn_params, const float
 /* ---- NES master/worker math ---- */
 /* GTN_worker.py:234-254: mirrored sampling pick; out[p] = {score_best, sign} */
 void orc_worker_best(const double *score_add, const double *score_sub, int64_t pop, int mirrored, double *score_best, float *sign);
+/* the same with num_grad_evals = G evaluations per direction (score lists [pop,G]); grad_eval_type 0 'mean', 1 'minmax' */
+int orc_worker_best_multi(const double *score_add, const double *score_sub, int64_t pop, int G, int mirrored, int grad_eval_type,
+                          double *score_best, float *sign);
 /* GTN_master.py:197-265; ties broken by lower index first (documented stable order) */
 int orc_score_transform(int type, const double *scores, const double *scores_orig, int64_t n, double *out);
 /* GTN_master.py:267-298: theta <- theta*(1-wd); theta += ss*w_i*sign_i*eps_i sequentially over i */

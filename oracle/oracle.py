@@ -536,3 +536,15 @@ def rn_shape_rows(rtype, S, info_dim, hidden, layers, act, prelu, gamma, rn_para
     if rc != 0:
         raise ValueError("orc_rn_shape_rows rc=%d" % rc)
     return out
+
+
+def worker_best_multi(score_add, score_sub, mirrored=True, grad_eval_type="mean"):
+    """GTN_Worker.calc_best_score for num_grad_evals = G: score_add / score_sub [pop,G] -> (score_best [pop], sign [pop])."""
+    a, b = np.ascontiguousarray(score_add, np.float64), np.ascontiguousarray(score_sub, np.float64)
+    pop, G = a.shape
+    best, sign = np.zeros(pop), np.zeros(pop, np.float32)
+    rc = lib().orc_worker_best_multi(_p(a, C.c_double), _p(b, C.c_double), C.c_int64(pop), C.c_int(G), C.c_int(1 if mirrored else 0),
+                                     C.c_int({"mean": 0, "minmax": 1}[grad_eval_type]), _p(best, C.c_double), _p(sign, C.c_float))
+    if rc != 0:
+        raise ValueError("orc_worker_best_multi rc=%d" % rc)
+    return best, sign

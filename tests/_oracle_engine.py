@@ -39,9 +39,10 @@ class OracleNesEngine(object):
             inner.stats[c] = torch.tensor([r["episodes_run"], r["train_steps"], r["learn_steps"], r["test_steps"]])
         return torch.from_numpy(out)
 
-    def worker_best(self, chain_scores, pop, mirrored):
-        cs = chain_scores.numpy().reshape(pop, 3)
-        best, sign = orc.worker_best(cs[:, 1], cs[:, 2], mirrored)
+    def worker_best(self, chain_scores, pop, mirrored, num_grad_evals=1, grad_eval_type="mean"):
+        G = num_grad_evals
+        cs = chain_scores.numpy().reshape(pop, 1 + 2 * G)
+        best, sign = orc.worker_best_multi(cs[:, 1:1 + G], cs[:, 1 + G:], mirrored, grad_eval_type)
         return torch.from_numpy(np.stack([best, cs[:, 0], sign.astype(np.float64), np.zeros(pop)], axis=1))
 
     def rank_update(self, score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size, weight_decay):

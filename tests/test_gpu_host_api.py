@@ -396,3 +396,30 @@ def test_experiment_wrapper_compute(tmp_path, monkeypatch):
     bad = dict(cfg, agents=dict(cfg["agents"], gtn=dict(cfg["agents"]["gtn"], agent_name="sarsa")))
     res = ExperimentWrapper(bad).compute(working_dir=str(tmp_path), bohb_id=8, config_id=(0, 0, 1), cso={}, budget=1)
     assert res["loss"] == float("inf") and "NotImplementedError" in res["info"]["error"]
+
+
+def test_gtn_master_num_grad_evals(tmp_path, monkeypatch):
+    """num_grad_evals = 2, grad_eval_type 'minmax' (GTN_worker.py:84-104,234-242): 1 + 2*2 chains per worker in one launch,
+    per-worker (score_best, score_orig, sign) equal to the oracle's chains + calc_best_score."""
+    from learning_environments_amd.configs import cliff_reward_env_ql
+    from learning_environments_amd.envs.gridworld import transition_tables
+    from oracle import oracle as orc
+    cfg = cliff_reward_env_ql(num_workers=5, max_iterations=1)
+    cfg["agents"]["gtn"].update(quit_when_solved=False, num_grad_evals=2, grad_eval_type="minmax")
+    cfg["agents"]["ql"]["eps_init"] = cfg["agents"]["ql"]["eps_min"] = 0.3      # make the evaluations of one direction differ
+    m = _master_pair(cfg, tmp_path, monkeypatch)
+    assert m.cpw == 5
+    theta0 = m.theta.cpu().numpy().copy()
+    gathered = m.evaluate_population(0).cpu().numpy()
+    eps = m.eps.cpu().numpy()
+    tables = transition_tables("Cliff")
+    ocfg = orc.ql_cfg_from_config(cfg, tables)
+    for p in range(5):
+        sc = []
+        for kind, sg in enumerate((0.0, 1.0, 1.0, -1.0, -1.0)):
+            w = (np.float32(sg) * eps[p] + theta0).astype(np.float32)
+            sc.append(orc.ql_rn_chain(ocfg, w, tables, rng_key=orc.chain_key(m.seed, 0, p, kind))["score"])
+        best, sign = orc.worker_best_multi(np.array([sc[1:3]]), np.array([sc[3:5]]), True, "minmax")
+        assert gathered[p, 1] == sc[0] and gathered[p, 0] == best[0] and gathered[p, 2] == sign[0]
+    mean_score, mean_list, _ = m.run()
+    assert len(mean_list) == 1

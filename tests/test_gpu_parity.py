@@ -626,3 +626,20 @@ def test_dueling_and_td3_early_out(eng, orc, golden):
     assert il.stats[0].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
     assert np.array_equal(il.episode_test_mean[0].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
     assert float(il.score[0]) == o["score"]
+
+
+def test_nes_worker_best_multi(eng, orc, golden):
+    """num_grad_evals = 3: device calc_best_score == the reference's (fixture G6M) for 'mean' / 'minmax', mirrored or not."""
+    g = golden("g6m_worker_best_multi")
+    add, sub = g["score_add"], g["score_sub"]
+    pop = add.shape[0]
+    orig = np.arange(pop, dtype=np.float64)
+    cs = np.concatenate([orig[:, None], add, sub], axis=1)
+    for gt in ("mean", "minmax"):
+        for m in (True, False):
+            res = eng.nes_worker_best(dev(cs.reshape(-1)), pop, m, 3, gt).cpu().numpy()
+            assert np.array_equal(res[:, 0], g["best_%s_%d" % (gt, int(m))]), (gt, m)
+            assert np.array_equal(res[:, 1], orig)
+            assert np.array_equal(res[:, 2].astype(np.float32), g["sign_%s_%d" % (gt, int(m))]), (gt, m)
+    with pytest.raises(NotImplementedError):
+        eng.nes_worker_best(dev(cs.reshape(-1)), pop, True, 3, "median")

@@ -383,3 +383,18 @@ def test_g2f_reward_env_vector_state_all_types(golden):
         np.testing.assert_allclose(shaped, g[pre + "shaped"], rtol=0, atol=3e-6, err_msg="type %d" % t)
     with pytest.raises(ValueError):
         orc.rn_shape_rows(9, 17, 4, H, 1, "prelu", 0.25, 0.98, np.zeros(4), s, s2, info, r)
+
+
+def test_g6m_worker_best_multi(golden):
+    """calc_best_score with num_grad_evals = 3 (GTN_worker.py:234-254): statistics.mean (exactly rounded) / min of both lists,
+    mirrored or not -- best scores and eps signs equal to the reference's."""
+    g = golden("g6m_worker_best_multi")
+    for gt in ("mean", "minmax"):
+        for m in (1, 0):
+            best, sign = orc.worker_best_multi(g["score_add"], g["score_sub"], bool(m), gt)
+            assert np.array_equal(best, g["best_%s_%d" % (gt, m)]), (gt, m)
+            assert np.array_equal(sign, g["sign_%s_%d" % (gt, m)]), (gt, m)
+    # G = 1 degenerates to the single-evaluation rule
+    b1, s1 = orc.worker_best_multi(g["score_add"][:, :1], g["score_sub"][:, :1], True, "mean")
+    b0, s0 = orc.worker_best(g["score_add"][:, 0], g["score_sub"][:, 0], True)
+    assert np.array_equal(b1, b0) and np.array_equal(s1, s0)

@@ -22,7 +22,7 @@ extra = dict(a.split("=") for a in sys.argv[1:])
 for k, v in extra.items():
     setattr(master.cfg, k, int(v))
 if extra:
-    master.inner = master.engine.make_inner(master.cfg, 3 * master.n_local)
+    master.inner = master.engine.make_inner(master.cfg, master.cpw * master.n_local)
 master.step(0)
 torch.cuda.synchronize()
 import time
