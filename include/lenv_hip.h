@@ -140,8 +140,8 @@ int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg /*HOST*/, const float *thet
                             const lenv_inner_out *out /*HOST struct of device ptrs*/, void *stream);
 
 /*
- * Config 4: fused inner loop for tabular Q-learning on a potential-shaped RewardEnv over a grid MDP
- * (agents/QL.py:13-106, envs/reward_env.py:61-133, envs/gridworld.py:38-110), one wave per chain.
+ * Config 4: fused inner loop for the tabular agents (Q-learning, SARSA, and their count-based variants) on a potential-shaped
+ * RewardEnv over a grid MDP (agents/QL.py:13-106, agents/SARSA.py:12-91, envs/reward_env.py:61-133, envs/gridworld.py:38-110), one wave per chain.
  * The MDP is given as transition tables next_state/reward/done [n_states, n_actions] (device pointers, shared by all
  * chains); theta = flat reward_net parameters (PReLU slope excluded), perturbed per chain as theta + sign*eps[worker].
  * shaped_override [n_states*n_actions] (optional) replaces the reward-net evaluation by a given shaped-reward table.
@@ -153,7 +153,10 @@ typedef struct {
     int32_t reward_env_type;            /* 0,1,2,5,6 */
     int32_t train_episodes, test_episodes, init_episodes, early_out_num, batch_size;
     int32_t rng_mode;
-    double solved_reward, alpha, gamma, eps_init, eps_min, eps_decay;
+    int32_t agent_kind;                 /* 0 QL (agents/QL.py:37-75), 1 SARSA (agents/SARSA.py:36-60: bootstrap on a freshly drawn
+                                           eps-greedy next action) */
+    int32_t count_based;                /* ql_cb / sarsa_cb (agents/agent_utils.py:57-64): reward += beta / (sqrt(n(s,a)) + 1e-9) */
+    double solved_reward, alpha, gamma, eps_init, eps_min, eps_decay, beta;
 } lenv_ql_cfg;
 
 typedef struct {

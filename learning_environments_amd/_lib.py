@@ -56,8 +56,9 @@ class QlCfg(C.Structure):
                 ("rn_hidden", C.c_int32), ("rn_layers", C.c_int32), ("rn_act", C.c_int32), ("rn_prelu", C.c_float),
                 ("reward_env_type", C.c_int32), ("train_episodes", C.c_int32), ("test_episodes", C.c_int32),
                 ("init_episodes", C.c_int32), ("early_out_num", C.c_int32), ("batch_size", C.c_int32), ("rng_mode", C.c_int32),
+                ("agent_kind", C.c_int32), ("count_based", C.c_int32),
                 ("solved_reward", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double), ("eps_init", C.c_double),
-                ("eps_min", C.c_double), ("eps_decay", C.c_double)]
+                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double)]
 
 
 class QlOut(C.Structure):

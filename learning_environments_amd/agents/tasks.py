@@ -4,13 +4,13 @@ The reference dispatches through select_agent (agents/agent_utils.py:15-66) + En
 combination owns one fused kernel:
     DDQN on a VirtualEnv (synthetic_env_type 0)   -> lenv_ddqn_se_inner_loop   (BASELINE configs 1-2, Acrobot-DDQN)
     DuelingDDQN on a VirtualEnv                   -> lenv_dueling_se_inner_loop (BASELINE config 3)
-    QL   on a RewardEnv over a gridworld (type 1) -> lenv_ql_rn_inner_loop     (BASELINE config 4)
+    QL / QL_cb / SARSA / SARSA_cb on a RewardEnv over a gridworld (type 1) -> lenv_ql_rn_inner_loop (BASELINE config 4)
     TD3  on a RewardEnv over the HalfCheetah stand-in -> lenv_td3_rn_inner_loop (BASELINE config 5)
 Anything else raises NotImplementedError, like the reference does for unknown agents."""
 import numpy as np
 import torch
 
-from ..config import agent_layer_dims, ddqn_cfg_from_config, ql_cfg_from_config, td3_cfg_from_config, td3_layer_dims
+from ..config import TABULAR_AGENTS, agent_layer_dims, ddqn_cfg_from_config, ql_cfg_from_config, td3_cfg_from_config, td3_layer_dims
 from .nes_common import chain_keys, fresh_agent_init, linear_init_bounds
 
 
@@ -76,7 +76,7 @@ def select_task(config, engine, synthetic_env):
     env_type = config["agents"]["gtn"]["synthetic_env_type"]
     if agent_name in ("ddqn", "duelingddqn") and env_type == 0:
         return DdqnSeTask(config, engine)
-    if agent_name == "ql" and env_type == 1:
+    if agent_name in TABULAR_AGENTS and env_type == 1:
         real = synthetic_env.env.real_env
         if not hasattr(real, "tables"):
             raise NotImplementedError("QL needs a discrete (gridworld) real env")

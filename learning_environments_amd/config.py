@@ -68,19 +68,28 @@ def pick_grad_chunk(cfg):
     raise NotImplementedError("DDQN/SE shapes do not fit the fused kernel's LDS budget")
 
 
+TABULAR_AGENTS = ("ql", "ql_cb", "sarsa", "sarsa_cb")     # agents/agent_utils.py:57-64
+
+
 def ql_cfg_from_config(config, tables, rng_mode=_lib.RNG_COUNTER, **overrides):
     """QL agent + RewardEnv on a gridworld.  Fields read at reference agents/QL.py:13-27, agents/base_agent.py:9-26,
     envs/reward_env.py:8-27, envs/env_factory.py:45-59."""
     env_name = config["env_name"]
     e = config["envs"][env_name]
-    a = config["agents"]["ql"]
+    name = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "ql"
+    if name not in TABULAR_AGENTS:
+        raise NotImplementedError("ql_cfg_from_config: agent '%s'" % name)
+    a = config["agents"]["sarsa" if name.startswith("sarsa") else "ql"]      # SARSA reads its own section (SARSA.py:14-18)
     if a["same_action_num"] != 1:
         raise NotImplementedError("same_action_num != 1")
+    if int(a["rb_size"]) != 1:
+        raise NotImplementedError("tabular agents with rb_size != 1 (the reference configs keep the single latest transition)")
 
     def val(v):
         return float(v[1]) if isinstance(v, list) else v
 
-    cfg = _lib.QlCfg(n_states=tables["n_states"], n_actions=tables["n_actions"], start_state=tables["start_state"],
+    cfg = _lib.QlCfg(agent_kind=1 if name.startswith("sarsa") else 0, count_based=1 if name.endswith("_cb") else 0,
+                     beta=float(a.get("beta", 0.0)), n_states=tables["n_states"], n_actions=tables["n_actions"], start_state=tables["start_state"],
                      max_steps=int(val(e["max_steps"])), rn_hidden=int(val(e["hidden_size"])), rn_layers=int(val(e["hidden_layer"])),
                      rn_act=_lib.ACT[e["activation_fn"]], rn_prelu=0.25, reward_env_type=int(val(e["reward_env_type"])),
                      train_episodes=int(a["train_episodes"]), test_episodes=int(a["test_episodes"]),

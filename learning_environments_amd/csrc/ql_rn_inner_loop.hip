@@ -107,10 +107,11 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
     double *rets = meter + cfg.train_episodes;                       // [test_episodes]
     float *phi = reinterpret_cast<float *>(rets + cfg.test_episodes);    // [N]
     float *shaped = phi + N;                                         // [N*A]
+    int *visits = reinterpret_cast<int *>(shaped + N * A);           // [N*A] visitation counts n(s,a) (count-based agents)
 
     rn_phi_and_shaped(cfg, a.theta, a.eps, a.worker, a.sign, a.shaped_override, a.next_state, a.reward, a.P, chain, lane,
                       phi, shaped, a.out.shaped ? a.out.shaped + chain * N * A : nullptr, nullptr);
-    for (int i = lane; i < N * A; i += 64) q[i] = 0.0;                // q_table = [[0]*A for _ in range(N)]  QL.py:25
+    for (int i = lane; i < N * A; i += 64) { q[i] = 0.0; if (cfg.count_based) visits[i] = 0; }   // QL.py:25,31
     __syncthreads();
     if (lane != 0) return;
 
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
     const uint64_t key = a.rng_keys ? a.rng_keys[chain] : 0;
     const bool tape = cfg.rng_mode == LENV_RNG_TAPE;
     int status = 0, episodes_run = 0;
-    int64_t n_eps = 0, n_act = 0, train_steps = 0, test_steps = 0;
+    int64_t n_eps = 0, n_act = 0, train_steps = 0, learn_steps = 0, test_steps = 0;
     double eps_g = cfg.eps_init;
 
     auto test_phase = [&]() {
@@ -158,11 +159,35 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
             int dn = a.done[s * A + ac];
             if (st + 1 >= cfg.max_steps) dn = 1;                       // gym.wrappers.TimeLimit
             const double r = (double)shaped[s * A + ac];
-            for (int k = 0; k < cfg.batch_size; ++k) {                 // QL.learn (QL.py:44-73)
-                double mx = q[s2 * A];
-                for (int i = 1; i < A; ++i) if (q[s2 * A + i] > mx) mx = q[s2 * A + i];
-                const double delta = r + cfg.gamma * mx * (dn ? 0.0 : 1.0) - q[s * A + ac];
-                q[s * A + ac] += cfg.alpha * delta;
+            // QL.learn (QL.py:37-75) / SARSA.learn (SARSA.py:36-60), only once episode >= init_episodes (base_agent.py:127-128)
+            if (episode >= cfg.init_episodes) {
+                for (int k = 0; k < cfg.batch_size; ++k) {
+                    double boot;
+                    if (cfg.agent_kind == 1) {                         // next_action = select_train_action(next_state)
+                        double u2;
+                        if (tape) { if (n_eps >= a.tapes.eps_uniform_stride) { status = -2; u2 = 1.0; } else u2 = a.tapes.eps_uniform[chain * a.tapes.eps_uniform_stride + n_eps]; }
+                        else u2 = u64_to_unit(rng_u64(key, STREAM_EPS, (uint64_t)n_eps));
+                        ++n_eps;
+                        int a2;
+                        if (u2 < eps_g) {
+                            if (tape) { if (n_act >= a.tapes.rand_action_stride) { status = -3; a2 = 0; } else a2 = a.tapes.rand_action[chain * a.tapes.rand_action_stride + n_act]; }
+                            else a2 = (int)u64_to_below(rng_u64(key, STREAM_ACTION, (uint64_t)n_act), (uint32_t)A);
+                            ++n_act;
+                        } else a2 = ql_argmax_f32(q + s2 * A, A);
+                        boot = q[s2 * A + a2];
+                    } else {
+                        boot = q[s2 * A];
+                        for (int i = 1; i < A; ++i) if (q[s2 * A + i] > boot) boot = q[s2 * A + i];
+                    }
+                    double rr = r;
+                    if (cfg.count_based) {                             // QL.py:52-55
+                        visits[s * A + ac] += 1;
+                        rr += cfg.beta / (__builtin_sqrt((double)visits[s * A + ac]) + 1e-9);
+                    }
+                    const double delta = rr + cfg.gamma * boot * (dn ? 0.0 : 1.0) - q[s * A + ac];
+                    q[s * A + ac] += cfg.alpha * delta;
+                }
+                ++learn_steps;
             }
             if (a.out.trace_action && train_steps < a.out.trace_cap) {
                 const int64_t k = chain * a.out.trace_cap + train_steps;
@@ -192,7 +217,7 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
     if (a.out.final_returns) for (int i = 0; i < cfg.test_episodes; ++i) a.out.final_returns[chain * cfg.test_episodes + i] = rets[i];
     if (a.out.stats) {
         a.out.stats[chain * 4 + 0] = episodes_run; a.out.stats[chain * 4 + 1] = train_steps;
-        a.out.stats[chain * 4 + 2] = train_steps; a.out.stats[chain * 4 + 3] = test_steps;
+        a.out.stats[chain * 4 + 2] = learn_steps; a.out.stats[chain * 4 + 3] = test_steps;
     }
     const double nan = __builtin_nan("");
     for (int e = episodes_run; e < cfg.train_episodes; ++e) {
@@ -232,7 +257,7 @@ extern "C" int lenv_ql_rn_inner_loop(const lenv_ql_cfg *cfg, const float *theta,
     a.out = *out;
     a.P = (int64_t)cfg->n_states * cfg->rn_hidden + 2 * (int64_t)cfg->rn_hidden + 1;
     const size_t NA = (size_t)cfg->n_states * cfg->n_actions;
-    const size_t lds_bytes = sizeof(double) * (NA + cfg->train_episodes + cfg->test_episodes) + sizeof(float) * (cfg->n_states + NA) + 16;
+    const size_t lds_bytes = sizeof(double) * (NA + cfg->train_episodes + cfg->test_episodes) + sizeof(float) * (cfg->n_states + NA) + sizeof(int) * NA + 16;
     if (lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ql_rn_inner_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;

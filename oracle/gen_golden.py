@@ -611,17 +611,20 @@ def gen_ckpt():
 # ------------------------------------------------------------------------------------------------
 # G9: full GTN_Worker.calc_score on the Cliff RewardEnv with QL (cfg 4) + tapes + per-step trace
 # ------------------------------------------------------------------------------------------------
-def gen_g9(name, seed, eps_over=None):
+def gen_g9(name, seed, eps_over=None, agent_name="QL", agent_over=None):
     import json
     import statistics
     import agents.GTN_worker as gw
     from agents.GTN import GTN_Worker
     import gym.spaces as gspaces
     cfg = load_cfg("default_config_gridworld_reward_env.yaml")
-    cfg["agents"]["ql"]["print_rate"] = int(1e9)
+    sec = "sarsa" if agent_name.lower().startswith("sarsa") else "ql"
+    cfg["agents"]["gtn"]["agent_name"] = agent_name
+    cfg["agents"][sec]["print_rate"] = int(1e9)
+    cfg["agents"][sec].update(agent_over or {})
     if eps_over is not None:
-        cfg["agents"]["ql"]["eps_init"] = eps_over
-        cfg["agents"]["ql"]["eps_min"] = eps_over
+        cfg["agents"][sec]["eps_init"] = eps_over
+        cfg["agents"][sec]["eps_min"] = eps_over
     rec = Recorder()
     orig_random = random.random
     orig_sample = gspaces.Discrete.sample
@@ -951,7 +954,7 @@ def gen_g8t(name, seed):
 
 
 def main():
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x"]
     os.makedirs(OUT, exist_ok=True)
     if "g1" in which:
         gen_g1()
@@ -985,6 +988,12 @@ def main():
     if "g9" in which:
         gen_g9("g9_calc_score_cliff_a", seed=900)
         gen_g9("g9_calc_score_cliff_b", seed=901, eps_over=0.2)
+    if "g9x" in which:
+        # the other tabular agents of select_agent (agent_utils.py:57-64) and the init_episodes gate of BaseAgent.train
+        gen_g9("g9s_calc_score_cliff_sarsa", seed=902, agent_name="SARSA")
+        gen_g9("g9c_calc_score_cliff_ql_cb", seed=903, agent_name="QL_cb", agent_over={"beta": 0.3}, eps_over=0.05)
+        gen_g9("g9sc_calc_score_cliff_sarsa_cb", seed=904, agent_name="SARSA_cb", agent_over={"beta": 0.3})
+        gen_g9("g9i_calc_score_cliff_ql_init2", seed=905, eps_over=0.2, agent_over={"init_episodes": 2, "train_episodes": 12})
     if "g10" in which:
         gen_g10()
     if "g8" in which:

@@ -1021,6 +1021,7 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
     if (shaped_override) memcpy(shaped, shaped_override, sizeof(float) * N * A);   /* parity tests: the reference's own table */
     else if (orc_rn_shaped_rewards(cfg, rn_params, next_state, reward, NULL, shaped)) { free(shaped); return -1; }
     double *q = calloc((size_t)N * A, sizeof(double));       /* q_table = [[0]*A for _ in range(N)]  QL.py:25 */
+    int64_t *visits = calloc((size_t)N * A, sizeof(int64_t)); /* visitation_table n(s,a)  QL.py:31 */
     double *meter = malloc(sizeof(double) * (cfg->train_episodes > 0 ? cfg->train_episodes : 1));
     double *rets = malloc(sizeof(double) * (cfg->test_episodes > 0 ? cfg->test_episodes : 1));
     int64_t n_eps = 0, n_act = 0, train_steps = 0, learn_steps = 0, test_steps = 0;
@@ -1064,14 +1065,37 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
             int dn = done_tab[s * A + ac];
             if (t + 1 >= cfg->max_steps) dn = 1;
             const double r = (double)shaped[s * A + ac];
-            /* QL.learn (QL.py:44-73): batch_size draws of the single stored transition */
-            for (int k = 0; k < cfg->batch_size; ++k) {
-                double mx = q[(size_t)s2 * A];
-                for (int i = 1; i < A; ++i) if (q[(size_t)s2 * A + i] > mx) mx = q[(size_t)s2 * A + i];
-                const double delta = r + cfg->gamma * mx * (dn ? 0.0 : 1.0) - q[(size_t)s * A + ac];
-                q[(size_t)s * A + ac] += cfg->alpha * delta;
+            /* QL.learn (QL.py:37-75) / SARSA.learn (SARSA.py:36-60): batch_size draws of the single stored transition,
+             * only once episode >= init_episodes (base_agent.py:127-128) */
+            if (episode >= cfg->init_episodes) {
+                for (int k = 0; k < cfg->batch_size; ++k) {
+                    double boot;
+                    if (cfg->agent_kind == 1) {                                     /* next_action = select_train_action(next_state) */
+                        double u2;
+                        if (cfg->rng_mode == ORC_RNG_TAPE) { if (n_eps >= tapes->n_eps_uniform) { err = -2; u2 = 1.0; } else u2 = tapes->eps_uniform[n_eps]; }
+                        else u2 = u64_to_unit(orc_rng_u64(rng_key, STREAM_EPS, (uint64_t)n_eps));
+                        ++n_eps;
+                        int a2;
+                        if (u2 < eps) {
+                            if (cfg->rng_mode == ORC_RNG_TAPE) { if (n_act >= tapes->n_rand_action) { err = -3; a2 = 0; } else a2 = tapes->rand_action[n_act]; }
+                            else a2 = (int)u64_to_below(orc_rng_u64(rng_key, STREAM_ACTION, (uint64_t)n_act), (uint32_t)A);
+                            ++n_act;
+                        } else a2 = ql_argmax_f32(q + (size_t)s2 * A, A);
+                        boot = q[(size_t)s2 * A + a2];
+                    } else {
+                        boot = q[(size_t)s2 * A];
+                        for (int i = 1; i < A; ++i) if (q[(size_t)s2 * A + i] > boot) boot = q[(size_t)s2 * A + i];
+                    }
+                    double rr = r;
+                    if (cfg->count_based) {                                         /* QL.py:52-55 */
+                        visits[(size_t)s * A + ac] += 1;
+                        rr += cfg->beta / (sqrt((double)visits[(size_t)s * A + ac]) + 1e-9);
+                    }
+                    const double delta = rr + cfg->gamma * boot * (dn ? 0.0 : 1.0) - q[(size_t)s * A + ac];
+                    q[(size_t)s * A + ac] += cfg->alpha * delta;
+                }
+                ++learn_steps;
             }
-            ++learn_steps;
             if (trace && trace->n < trace->cap) {
                 int64_t k = trace->n++;
                 trace->action[k] = ac | (explored << 16); trace->state[k] = s; trace->next_state[k] = s2;
@@ -1106,7 +1130,7 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
         res->score = mean_seq(rets, cfg->test_episodes);
         res->episodes_run = episodes_run; res->train_steps = train_steps; res->learn_steps = learn_steps; res->test_steps = test_steps;
     }
-    free(shaped); free(q); free(meter); free(rets);
+    free(shaped); free(q); free(visits); free(meter); free(rets);
     return err;
 }
 

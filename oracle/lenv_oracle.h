@@ -167,7 +167,9 @@ typedef struct {
     int32_t reward_env_type;            /* 0,1,2,5,6 (types with an info vector are not part of the grid path) */
     int32_t train_episodes, test_episodes, init_episodes, early_out_num, batch_size;
     int32_t rng_mode;
-    double solved_reward, alpha, gamma, eps_init, eps_min, eps_decay;
+    int32_t agent_kind;                 /* 0 QL (agents/QL.py), 1 SARSA (agents/SARSA.py) */
+    int32_t count_based;                /* ql_cb / sarsa_cb (agent_utils.py:57-64): reward += beta / (sqrt(n(s,a)) + 1e-9) */
+    double solved_reward, alpha, gamma, eps_init, eps_min, eps_decay, beta;
 } orc_ql_cfg;
 
 typedef struct {

@@ -53,8 +53,9 @@ class QlCfg(C.Structure):
                 ("rn_hidden", C.c_int32), ("rn_layers", C.c_int32), ("rn_act", C.c_int32), ("rn_prelu", C.c_float),
                 ("reward_env_type", C.c_int32), ("train_episodes", C.c_int32), ("test_episodes", C.c_int32),
                 ("init_episodes", C.c_int32), ("early_out_num", C.c_int32), ("batch_size", C.c_int32), ("rng_mode", C.c_int32),
+                ("agent_kind", C.c_int32), ("count_based", C.c_int32),
                 ("solved_reward", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double), ("eps_init", C.c_double),
-                ("eps_min", C.c_double), ("eps_decay", C.c_double)]
+                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double)]
 
 
 class QlTrace(C.Structure):
@@ -344,9 +345,13 @@ def ql_cfg_from_config(config, tables, rng_mode=0, **overrides):
     agents/base_agent.py:9-26, envs/reward_env.py:8-27."""
     env_name = config["env_name"]
     e = config["envs"][env_name]
-    a = config["agents"]["ql"]
+    name = config["agents"].get("gtn", {}).get("agent_name", "ql").lower()
+    if name not in ("ql", "ql_cb", "sarsa", "sarsa_cb"):
+        name = "ql"
+    a = config["agents"]["sarsa" if name.startswith("sarsa") else "ql"]
     assert a["same_action_num"] == 1
-    cfg = QlCfg(n_states=tables["n_states"], n_actions=tables["n_actions"], start_state=tables["start_state"],
+    cfg = QlCfg(agent_kind=1 if name.startswith("sarsa") else 0, count_based=1 if name.endswith("_cb") else 0,
+                beta=float(a.get("beta", 0.0)), n_states=tables["n_states"], n_actions=tables["n_actions"], start_state=tables["start_state"],
                 max_steps=int(e["max_steps"]), rn_hidden=int(e["hidden_size"]), rn_layers=int(e["hidden_layer"]),
                 rn_act=ACT[e["activation_fn"]], rn_prelu=0.25, reward_env_type=int(e["reward_env_type"]),
                 train_episodes=int(a["train_episodes"]), test_episodes=int(a["test_episodes"]),
