@@ -22,7 +22,12 @@
 
 namespace lenv {
 
-constexpr int DNT = 512;          // threads per chain (8 waves)
+#ifndef LENV_DNT
+#define LENV_DNT 512
+#endif
+constexpr int DNT = LENV_DNT;     // threads per chain (8 or 16 waves)
+constexpr int DNW = DNT / 64;     // waves per chain
+constexpr int SKQ = 2048 / DNT;   // float4 pieces per thread and 128-row block of a 64-deep stage
 constexpr int GT_I = 128, GT_J = 128, GT_RB = 64, GT_LD = 132;   // 128x128 outputs, 64-deep stages, padded LDS rows
 
 enum { EPI_STORE = 0,       // out = acc
@@ -95,32 +100,40 @@ __device__ __forceinline__ void stage_operand(const float *src_, int sI, int sR,
     if (G && sR == 1 && al16 && (sI & 3) == 0 && (R & 3) == 0) {
         // row-major along r: float4 = 4 consecutive r of one row; a wave instruction covers 16 rows x 64 B
         for (int ib = 0; ib < nI; ib += 128) {
-            f32x4 v[4];
-            const int i = ib + ((lane >> 2) | (wave << 4));
-            const int base = i * sI + r0 + 4 * (lane & 3);
+            f32x4 v[SKQ];
+            // unit u = tid + k*DNT of the 2048 float4 pieces: lane bits 0-1 and bits 9-10 of u -> the r quad, the rest -> the row
+            const int i = ib + ((lane >> 2) | ((wave & 7) << 4));
             const bool rowok = i < nI;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (rowok && 16 * k + 4 * (lane & 3) < rb) ? src.ld4(base + 16 * k) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            lfloat *d = dst + (4 * (lane & 3)) * ld + i;
+            for (int k = 0; k < SKQ; ++k) {
+                const int q = (lane & 3) | ((((wave >> 3) + (DNW >> 3) * k) & 3) << 2);
+                v[k] = (rowok && 4 * q < rb) ? src.ld4(i * sI + r0 + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (rowok && 16 * k + 4 * (lane & 3) < rb) {
-                    d[(16 * k) * ld] = v[k].x; d[(16 * k + 1) * ld] = v[k].y; d[(16 * k + 2) * ld] = v[k].z; d[(16 * k + 3) * ld] = v[k].w;
+            for (int k = 0; k < SKQ; ++k) {
+                const int q = (lane & 3) | ((((wave >> 3) + (DNW >> 3) * k) & 3) << 2);
+                if (rowok && 4 * q < rb) {
+                    lfloat *d = dst + (4 * q) * ld + i;
+                    d[0] = v[k].x; d[ld] = v[k].y; d[2 * ld] = v[k].z; d[3 * ld] = v[k].w;
                 }
+            }
         }
     } else if (G && sI == 1 && al16 && (sR & 3) == 0) {
         // contiguous along i: float4 = 4 consecutive i of one r; a wave instruction covers 2 r x 512 B
         for (int ib = 0; ib < nI; ib += 128) {
-            f32x4 v[4];
-            const int i4 = ib + 4 * (lane & 31), rl = (lane >> 5) | (wave << 1);
-            const int base = (r0 + rl) * sR + i4;
+            f32x4 v[SKQ];
+            const int i4 = ib + 4 * (lane & 31);
             const bool colok = i4 < nI;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (colok && rl + 16 * k < rb) ? src.ld4(base + 16 * k * sR) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            lfloat *d = dst + rl * ld + i4;
+            for (int k = 0; k < SKQ; ++k) {
+                const int r = (lane >> 5) | (wave << 1) | (k * 2 * DNW);
+                v[k] = (colok && r < rb) ? src.ld4((r0 + r) * sR + i4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (colok && rl + 16 * k < rb) *reinterpret_cast<__attribute__((address_space(3))) f32x4 *>(d + 16 * k * ld) = v[k];
+            for (int k = 0; k < SKQ; ++k) {
+                const int r = (lane >> 5) | (wave << 1) | (k * 2 * DNW);
+                if (colok && r < rb) *reinterpret_cast<__attribute__((address_space(3))) f32x4 *>(dst + r * ld + i4) = v[k];
+            }
         }
     } else if (sR == 1 || (sI != 1 && sR < sI)) {
         // small / unaligned operands, r fastest across lanes: e -> (i = e >> sh, r = e & mask)
@@ -276,7 +289,7 @@ struct GemmCmd {                                           // 32 dwords, lives i
 
 template <int MAXI> struct GemmShape {
     static constexpr int LDP = MAXI + 4;                   // Ps row stride (floats): r-major rows of MAXI operand rows
-    static constexpr int NTW = MAXI / 64;                  // 32x32 tiles per wave: (MAXI/32)*4 tiles over 8 waves
+    static constexpr int NTW = (MAXI / 32) * 4 / DNW;      // 32x32 tiles per wave
     static constexpr int PS_FLOATS = GT_RB * LDP, QS_FLOATS = GT_RB * GT_LD;
 };
 
@@ -295,7 +308,7 @@ __device__ __forceinline__ void gemm_body(const GemmOp &op, const GemmEpi &ep, l
     // A operand: lane l supplies P[row l%32][k = l/32]; B operand: Q[col l%32][k = l/32]; both one LDS dword, r-major rows
 #pragma unroll
     for (int m = 0; m < NTW; ++m) {
-        const int t = wave + 8 * m;
+        const int t = wave + DNW * m;
         has[m] = t < ntile;
         bj[m] = (t * inv) >> 10; bi[m] = t - bj[m] * nbi;
         pa[m] = Ps + (lane >> 5) * LDP + (lane & 31) + 32 * bi[m];
@@ -316,7 +329,7 @@ __device__ __forceinline__ void gemm_body(const GemmOp &op, const GemmEpi &ep, l
         const int rb2 = rb & ~1;
         if (has[NTW - 1]) {                                // every tile slot of this wave is live: the common full-size case
             if (rb == GT_RB) {
-#pragma unroll (16 / (NTW * NTW))
+#pragma unroll (NTW >= 4 ? 1 : 8 / NTW)
                 for (int r = 0; r < GT_RB; r += 2)
 #pragma unroll
                     for (int m = 0; m < NTW; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[m][r * LDP], pb[m][r * GT_LD], acc[m], 0, 0, 0);
