@@ -647,3 +647,44 @@ def test_nes_worker_best_multi(eng, orc, golden):
             assert np.array_equal(res[:, 2].astype(np.float32), g["sign_%s_%d" % (gt, int(m))]), (gt, m)
     with pytest.raises(NotImplementedError):
         eng.nes_worker_best(dev(cs.reshape(-1)), pop, True, 3, "median")
+
+
+def test_ql_full_size_population_vs_oracle_and_properties(eng, orc):
+    """BASELINE configs[3] at full size (Cliff RewardEnv + QL, pop 128 = 384 chains, 100 episodes): EVERY chain against the
+    oracle (integer path: fp64 Q-tables bit-exact), plus determinism and chain-order independence."""
+    from learning_environments_amd import configs
+    from learning_environments_amd.config import ql_cfg_from_config
+    from learning_environments_amd.envs.gridworld import transition_tables
+    cfgd = configs.cliff_reward_env_ql(128)
+    tables = transition_tables("Cliff")
+    cfg = ql_cfg_from_config(cfgd, tables)
+    ocfg = orc.ql_cfg_from_config(cfgd, tables)
+    N, pop = tables["n_states"], 128
+    chains = 3 * pop
+    P = N * cfg.rn_hidden + 2 * cfg.rn_hidden + 1
+    rng = np.random.RandomState(17)
+    theta = (rng.randn(P) * 0.3).astype(np.float32)
+    eps = (rng.randn(pop, P) * 0.1).astype(np.float32)
+    worker = np.repeat(np.arange(pop), 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), pop)
+    keys = np.array([orc.chain_key(9, 4, int(worker[c]), c % 3) for c in range(chains)], np.uint64)
+
+    def run(worker_, sign_, keys_):
+        il = eng.QlInnerLoop(cfg, chains, tables)
+        il.run(dev(theta), dev(eps), dev(worker_), dev(sign_), rng_keys=dev(keys_.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return il.score.cpu().numpy().copy(), il.q_table.cpu().numpy().copy(), il.stats.cpu().numpy().copy()
+
+    base = run(worker, sign, keys)
+    again = run(worker, sign, keys)
+    perm = rng.permutation(chains)
+    permuted = run(worker[perm], sign[perm], keys[perm])
+    for a, b, c in zip(base, again, permuted):
+        assert np.array_equal(a, b) and np.array_equal(a[perm], c)
+    for c in range(chains):
+        w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+        o = orc.ql_rn_chain(ocfg, w, tables, rng_key=int(keys[c]))
+        assert np.array_equal(base[1][c].reshape(N, 4), o["q_table"]), c
+        assert float(base[0][c]) == o["score"]
+        assert base[2][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
