@@ -344,22 +344,23 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 finish_q(0, B, qv, true);
                 PT_MARK(3);
                 // TD error (DuelingDDQN.py:80-85) and the gradient of the loss w.r.t. V / Adv
-                if (tid == 0) {
+                if (tid < B) {                              // one thread per sample
+                    const int b = tid;
                     const float g32 = (float)cfg.gamma, norm = (float)(2.0 / (double)B);
-                    float s_dq = 0.0f;
-                    for (int b = 0; b < B; ++b) {
-                        const int ab = (int)dAdv[b * A + 0];
-                        const float r = dAdv[b * A + 1], d = dq[b];
-                        int am = 0; float best = qv[(B + b) * A];
-                        for (int aa = 1; aa < A; ++aa) { const float v = qv[(B + b) * A + aa]; if (v > best) { best = v; am = aa; } }
-                        const float t1 = g32 * qv[(2 * B + b) * A + am];
-                        const float t2 = 1.0f - d;
-                        const float y = r + t1 * t2;
-                        const float g = norm * (qv[b * A + ab] - y);
-                        dq[b] = g;
-                        Vb[b] = (float)ab;                  // keep the action index
-                        s_dq = s_dq + g;
-                    }
+                    const int ab = (int)dAdv[b * A + 0];
+                    const float r = dAdv[b * A + 1], d = dq[b];
+                    int am = 0; float best = qv[(B + b) * A];
+                    for (int aa = 1; aa < A; ++aa) { const float v = qv[(B + b) * A + aa]; if (v > best) { best = v; am = aa; } }
+                    const float t1 = g32 * qv[(2 * B + b) * A + am];
+                    const float t2 = 1.0f - d;
+                    const float y = r + t1 * t2;
+                    dq[b] = norm * (qv[b * A + ab] - y);
+                    Vb[b] = (float)ab;                      // keep the action index
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    float s_dq = 0.0f;                      // sequential in b (canonical order of the sum)
+                    for (int b = 0; b < B; ++b) s_dq = s_dq + dq[b];
                     ctrl[9] = (-s_dq) / (float)(B * A);     // backward of `- advantages.mean()`
                     b1pow *= cfg.adam_beta1; b2pow *= cfg.adam_beta2;
                     ctrl[10] = (float)(-(cfg.lr / (1.0 - b1pow)));
