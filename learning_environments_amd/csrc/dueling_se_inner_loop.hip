@@ -379,24 +379,33 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 // (reduction over the few outputs).  Everything GEMM-shaped of the backward pass is queued below.
                 if (tid < A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dAdv[b * A + tid]; grad[a.oba2 + tid] = s; }
                 if (tid == A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dq[b]; grad[a.obv2] = s; }
-                for (int e0 = tid; e0 < B * F; e0 += 4 * DNT) {
-                    float ra[4], rv[4];
+                {
+                    // thread = (column k, row group): the head weights of column k are loop invariants, a1/v1 reads are coalesced
+                    // along k and 8 rows are in flight per thread (A <= 3 for the supported envs)
+                    const int k = tid & 127, rg = tid >> 7, nrg = DNT >> 7;
+                    if (k < F) {
+                        float wa[3] = { 0.0f, 0.0f, 0.0f };
+                        for (int aa = 0; aa < A; ++aa) wa[aa] = online[a.oWa2 + aa * F + k];
+                        const float wv = online[a.oWv2 + k];
+                        for (int b0 = rg; b0 < B; b0 += 8 * nrg) {
+                            float ha[8], hv[8];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int e = e0 + u * DNT;
-                        ra[u] = rv[u] = 0.0f;
-                        if (e < B * F) {
-                            const int b = e / F, k = e - b * F;
-                            float acc = 0.0f;
-                            for (int aa = 0; aa < A; ++aa) acc = fma32(dAdv[b * A + aa], online[a.oWa2 + aa * F + k], acc);
-                            ra[u] = act_bwd(act_id, prelu, a1_s[e], acc);
-                            rv[u] = act_bwd(act_id, prelu, v1_s[e], fma32(dq[b], online[a.oWv2 + k], 0.0f));
+                            for (int u = 0; u < 8; ++u) {
+                                const int b = b0 + u * nrg;
+                                ha[u] = b < B ? a1_s[b * F + k] : 0.0f;
+                                hv[u] = b < B ? v1_s[b * F + k] : 0.0f;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const int b = b0 + u * nrg;
+                                if (b < B) {
+                                    float acc = 0.0f;
+                                    for (int aa = 0; aa < A; ++aa) acc = fma32(dAdv[b * A + aa], wa[aa], acc);
+                                    d_a1[b * F + k] = act_bwd(act_id, prelu, ha[u], acc);
+                                    d_v1[b * F + k] = act_bwd(act_id, prelu, hv[u], fma32(dq[b], wv, 0.0f));
+                                }
+                            }
                         }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int e = e0 + u * DNT;
-                        if (e < B * F) { d_a1[e] = ra[u]; d_v1[e] = rv[u]; }
                     }
                 }
                 PT_MARK(5);
