@@ -95,6 +95,8 @@ __global__ __launch_bounds__(64) void rn_shape_kernel(const QlArgs a, float *phi
                       shaped, shaped_out + chain * N * A, phi_out ? phi_out + chain * N : nullptr);
 }
 
+// KIND: 0 QL, 1 SARSA; CB: count-based exploration bonus (compile-time so that the plain-QL walk carries none of their code)
+template <int KIND, bool CB>
 __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
 
     rn_phi_and_shaped(cfg, a.theta, a.eps, a.worker, a.sign, a.shaped_override, a.next_state, a.reward, a.P, chain, lane,
                       phi, shaped, a.out.shaped ? a.out.shaped + chain * N * A : nullptr, nullptr);
-    for (int i = lane; i < N * A; i += 64) { q[i] = 0.0; if (cfg.count_based) visits[i] = 0; }   // QL.py:25,31
+    for (int i = lane; i < N * A; i += 64) { q[i] = 0.0; if (CB) visits[i] = 0; }   // QL.py:25,31
     __syncthreads();
     if (lane != 0) return;
 
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
             if (episode >= cfg.init_episodes) {
                 for (int k = 0; k < cfg.batch_size; ++k) {
                     double boot;
-                    if (cfg.agent_kind == 1) {                         // next_action = select_train_action(next_state)
+                    if (KIND == 1) {                                   // next_action = select_train_action(next_state)
                         double u2;
                         if (tape) { if (n_eps >= a.tapes.eps_uniform_stride) { status = -2; u2 = 1.0; } else u2 = a.tapes.eps_uniform[chain * a.tapes.eps_uniform_stride + n_eps]; }
                         else u2 = u64_to_unit(rng_u64(key, STREAM_EPS, (uint64_t)n_eps));
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
                         for (int i = 1; i < A; ++i) if (q[s2 * A + i] > boot) boot = q[s2 * A + i];
                     }
                     double rr = r;
-                    if (cfg.count_based) {                             // QL.py:52-55
+                    if (CB) {                                          // QL.py:52-55
                         visits[s * A + ac] += 1;
                         rr += cfg.beta / (__builtin_sqrt((double)visits[s * A + ac]) + 1e-9);
                     }
@@ -259,9 +261,12 @@ extern "C" int lenv_ql_rn_inner_loop(const lenv_ql_cfg *cfg, const float *theta,
     const size_t NA = (size_t)cfg->n_states * cfg->n_actions;
     const size_t lds_bytes = sizeof(double) * (NA + cfg->train_episodes + cfg->test_episodes) + sizeof(float) * (cfg->n_states + NA) + sizeof(int) * NA + 16;
     if (lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ql_rn_inner_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (cfg->agent_kind != 0 && cfg->agent_kind != 1) return LENV_ERR_UNSUPPORTED;
+    void (*kern)(const QlArgs) = cfg->agent_kind == 1 ? (cfg->count_based ? ql_rn_inner_kernel<1, true> : ql_rn_inner_kernel<1, false>)
+                                                      : (cfg->count_based ? ql_rn_inner_kernel<0, true> : ql_rn_inner_kernel<0, false>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;
-    hipLaunchKernelGGL(ql_rn_inner_kernel, dim3((unsigned)chains), dim3(64), lds_bytes, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)chains), dim3(64), lds_bytes, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }
 
