@@ -38,6 +38,16 @@ struct Td3Args {
         a_ht[T3_MAXL], a_d[2], a_dx, a_act, a_th, a_dz, a_meter;
 };
 
+// Diagnostic build only (-DLENV_PHASE_TIMING): per-phase shader-clock totals of chain 0, never in the shipped library.
+#ifdef LENV_PHASE_TIMING
+__device__ unsigned long long g_td3_phase_cycles[16];
+#define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PT_MARK(i) do { unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
+#else
+#define PT_DECL
+#define PT_MARK(i)
+#endif
+
 __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
 {
     extern __shared__ __align__(16) float lds[];
@@ -94,6 +104,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     const bool tape = cfg.rng_mode == LENV_RNG_TAPE;
     const int rtype = cfg.reward_env_type;
     int status = 0;
+    PT_DECL;
     int64_t n_rand = 0, n_actn = 0, n_testn = 0, n_test_ep = 0, learn_it = 0;
     int train_steps = 0, test_steps = 0, episodes_run = 0;
     double pows[4] = { 1.0, 1.0, 1.0, 1.0 };
@@ -329,6 +340,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             ++ep_len; ++train_steps;
             __syncthreads();
 
+            PT_MARK(0);                                   // act + env step + reward net + append
             if (learning) {
                 // ================= TD3.learn (TD3.py:63-116) =================
                 for (int b = tid; b < B; b += DNT) {
@@ -344,6 +356,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     rr[b] = row[2 * S + A]; dd[b] = row[2 * S + A + 1];
                 }
                 __syncthreads();
+                PT_MARK(1);                               // replay gather
                 // next_actions = (actor_target(s') + clamp(randn*policy_std)).clamp(-max, max)
                 mlp_forward(targets, a.actor, xn, SA, B, ht, xn, SA, S, true, nullptr);
                 gq.run<T3_MAXI>(Ps, Qs);
@@ -360,11 +373,13 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     xn[b * SA + S + k] = v < -ma ? -ma : (v > ma ? ma : v);
                 }
                 __syncthreads();
+                PT_MARK(2);                               // actor_target forward + smoothing noise
                 mlp_forward(targets + Pa, a.critic, xn, SA, B, ht, tq1, 1, 0, false, nullptr);
                 mlp_forward(targets + Pa + Pc, a.critic, xn, SA, B, ht, tq2, 1, 0, false, nullptr);
                 mlp_forward(params + Pa, a.critic, xc, SA, B, hc1, q1, 1, 0, false, nullptr);
                 mlp_forward(params + Pa + Pc, a.critic, xc, SA, B, hc2, q2, 1, 0, false, nullptr);
                 gq.run<T3_MAXI>(Ps, Qs);                   // 4 critic forwards, one call
+                PT_MARK(3);
                 {
                     const float norm = (float)(2.0 / (double)B);
                     for (int b = tid; b < B; b += DNT) {
@@ -375,10 +390,13 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     }
                 }
                 __syncthreads();
+                PT_MARK(4);                               // TD error
                 mlp_backward(params + Pa, a.critic, xc, SA, B, hc1, dq1, grad + Pa, nullptr);
                 mlp_backward(params + Pa + Pc, a.critic, xc, SA, B, hc2, dq2, grad + Pa + Pc, nullptr);
                 gq.run<T3_MAXI>(Ps, Qs);
+                PT_MARK(5);                               // critics backward
                 adam(Pa, 2 * Pc, 0);                       // critic_optimizer: critic_1 then critic_2 parameters
+                PT_MARK(6);
                 ++learn_it;
                 if (learn_it % cfg.policy_delay == 0) {
                     // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1
@@ -400,10 +418,12 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     __syncthreads();
                     mlp_backward(params, a.actor, xc, SA, B, ha, dzb, grad, nullptr);
                     gq.run<T3_MAXI>(Ps, Qs);
+                    PT_MARK(7);                           // policy update: forwards + backwards
                     adam(0, Pa, 2);
                     const float tau = (float)cfg.tau, omt = (float)(1.0 - cfg.tau);
                     wg_polyak(params, targets, P, tau, omt);
                     __syncthreads();
+                    PT_MARK(8);                           // actor adam + polyak
                 }
             }
             if (done_now > 0.5f) break;
@@ -411,7 +431,9 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         ++episodes_run;
         if (tid == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
         __syncthreads();
+        PT_MARK(10);
         test_phase();
+        PT_MARK(9);
         if (tid == 0) {
             double sm = 0.0;
             for (int i = 0; i < T; ++i) sm += ret[i];
@@ -432,7 +454,12 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         __syncthreads();
         if (brk) break;
     }
+    PT_MARK(10);
     test_phase();
+    PT_MARK(9);
+#ifdef LENV_PHASE_TIMING
+    if (tid == 0 && chain == 0) for (int pi = 0; pi < 12; ++pi) g_td3_phase_cycles[pi] = pt_acc[pi];
+#endif
     if (tid == 0) {
         double sm = 0.0;
         for (int i = 0; i < T; ++i) sm += ret[i];
@@ -552,3 +579,11 @@ extern "C" int lenv_td3_rn_inner_loop(const lenv_td3_cfg *cfg, const float *thet
     hipLaunchKernelGGL(td3_rn_inner_kernel, dim3((unsigned)chains), dim3(DNT), lds_bytes, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }
+
+#ifdef LENV_PHASE_TIMING
+namespace lenv { __global__ void td3_phase_dummy() {} }
+extern "C" int lenv_debug_td3_phase_cycles(unsigned long long *host_out)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_td3_phase_cycles), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;
+}
+#endif

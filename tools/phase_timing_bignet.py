@@ -38,3 +38,21 @@ tot = sum(buf[i] for i in range(10))
 print("generation wall %.1f ms; stats %s; total %.1f Mcycles" % (dt * 1e3, m.inner.stats[0].tolist(), tot / 1e6))
 for i, n in enumerate(names):
     print("%-22s %12d cycles  %5.1f%%" % (n, buf[i], 100.0 * buf[i] / max(1, tot)))
+
+# ---- config 5: TD3 kernel ----
+c = configs.fixed_work(configs.halfcheetah_reward_env_td3(32), 3)
+c["agents"]["td3"]["init_episodes"] = 1
+c["envs"]["HalfCheetah-v3"]["max_steps"] = 100
+m = GTN_Master(c, bohb_id=0, seed=7)
+m.step(0)
+torch.cuda.synchronize()
+t0 = time.time(); m.step(1); torch.cuda.synchronize(); dt = time.time() - t0
+buf = (C.c_ulonglong * 16)()
+_lib.lib().lenv_debug_td3_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
+assert _lib.lib().lenv_debug_td3_phase_cycles(buf) == 0
+names = ["act+env step+append", "replay gather", "actor_t fwd+noise", "4 critic fwds", "TD error", "critics backward", "critic adam",
+         "policy fwd/bwd", "actor adam+polyak", "tests", "other"]
+tot = sum(buf[i] for i in range(11))
+print("TD3 generation wall %.1f ms; stats %s; total %.1f Mcycles" % (dt * 1e3, m.inner.stats[0].tolist(), tot / 1e6))
+for i, n in enumerate(names):
+    print("%-22s %12d cycles  %5.1f%%" % (n, buf[i], 100.0 * buf[i] / max(1, tot)))
