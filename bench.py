@@ -6,15 +6,23 @@
 
 A "step" is one NES generation of GTN_Master: noise draw, ONE fused-kernel launch evaluating this rank's share of the
 population (3 inner loops per worker: train DDQN on the perturbed CartPole SE with per-episode real-env tests + final
-test), mirrored-sampling pick, one all-gather of the fitness triples, rank transform + theta update.
+test), mirrored-sampling pick, one all-gather of the fitness records, rank transform + theta update.
 Workload = BASELINE configs[1] ("CartPole-v0 SE, DDQN inner agent, NES pop=64 on 1xMI355X") in the fixed-work form of
 BASELINE.md §3: theta = torch default Linear init under seed 0 with done-net output bias -10, early-out disabled,
-train_episodes=20.  Weak scaling: every GPU evaluates 64 workers (global population 64*N).
-Prints ONE JSON line (rank 0).
+train_episodes=20.
+
+Multi-GPU: one process per GPU over RCCL.  Under torchrun the RANK/LOCAL_RANK/WORLD_SIZE environment is used as is; a
+bare `python bench.py --gpus N` (N > 1, no WORLD_SIZE) starts the N ranks itself as CHILD processes -- the launcher parent
+never touches the GPU, nothing re-execs.  With N > 1 two population layouts are timed back to back, K steps each:
+    weak   : 64 workers per GPU (global population 64*N)      -> `value`, "scaling": "weak"
+    strong : global population 64 (64/N workers per GPU)       -> `strong.value`   (BASELINE's "pop=64 at 1/2/4/8 GPU")
+At N = 1 the two coincide.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,26 +32,94 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-POP_PER_GPU = 64
+POP = 64                    # BASELINE metric: pop = 64
 TRAIN_EPISODES = 20
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: vector fp32 (256 CU x 4 SIMD x 16 lanes x 2 (fma) x 2 (packed) x 2.4 GHz)
+PLUMBING_ENV = "LENV_BENCH_PLUMBING_ENGINE"   # tests only: "module:Class" of a stand-in engine -> CPU/gloo, tiny workload
 
 
-def build_master(world):
-    from learning_environments_amd.agents.GTN import GTN_Master
+# ----------------------------------------------------------------------------------------------------------------------
+# launcher: python bench.py --gpus N without a torchrun environment
+# ----------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """Start n ranks of this script as child processes (one per GPU) and wait for them.  The parent only counts devices
+    (torch.cuda.device_count() does not initialise HIP on this image) and never creates a context."""
+    if not os.environ.get(PLUMBING_ENV):
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (n, have))
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+            if p.returncode != 0:
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# workload
+# ----------------------------------------------------------------------------------------------------------------------
+def bench_config(num_workers, plumbing=False):
     from learning_environments_amd.configs import cartpole_syn_env_ddqn, fixed_work
-    cfg = fixed_work(cartpole_syn_env_ddqn(num_workers=POP_PER_GPU * world), TRAIN_EPISODES)
+    cfg = fixed_work(cartpole_syn_env_ddqn(num_workers=num_workers), 2 if plumbing else TRAIN_EPISODES)
+    if plumbing:       # tests/test_bench_launcher.py: seconds on the CPU oracle, never reported as a measurement
+        cfg["envs"]["CartPole-v0"]["max_steps"] = 10
+        cfg["agents"]["ddqn"].update(test_episodes=2, batch_size=16)
+    return cfg
+
+
+def build_master(num_workers, engine=None, plumbing=False):
+    from learning_environments_amd.agents.GTN import GTN_Master
+    cfg = bench_config(num_workers, plumbing)
     torch.manual_seed(0)                      # theta: torch default Linear init under seed 0 (BASELINE.md §3)
     cwd = os.getcwd()
-    os.makedirs("/tmp/lenv_bench", exist_ok=True)
-    os.chdir("/tmp/lenv_bench")               # GTN_Base creates ./results/GTN_sync relative to cwd
+    work = os.path.join("/tmp", "lenv_bench_%d" % os.getpid())
+    os.makedirs(work, exist_ok=True)
+    os.chdir(work)                            # GTN_Base creates ./results/GTN_sync relative to cwd
     try:
-        master = GTN_Master(cfg, bohb_id=0, seed=1234)
+        master = GTN_Master(cfg, bohb_id=0, seed=1234, engine=engine)
     finally:
         os.chdir(cwd)
     with torch.no_grad():
         master.synthetic_env_orig.env.done_net[-1].bias.fill_(-10.0)   # SE never terminates: fixed work per episode
     return master, cfg
+
+
+def host_theta(cfgd):
+    """The bench's theta built on the host (same recipe as build_master) for the CPU baseline, before the GPU is touched."""
+    from learning_environments_amd.envs.env_factory import EnvFactory
+    from learning_environments_amd.models.model_utils import linear_params
+    torch.manual_seed(0)
+    env = EnvFactory(cfgd).generate_virtual_env()
+    with torch.no_grad():
+        env.env.done_net[-1].bias.fill_(-10.0)
+    return env, torch.cat([p.detach().reshape(-1) for p in linear_params(env)]).numpy().astype(np.float32)
 
 
 def algorithmic_bytes(master, stats):
@@ -63,60 +139,225 @@ def algorithmic_bytes(master, stats):
     return b, train_steps, learn_steps, test_steps
 
 
-def measured_traffic():
-    """HBM bytes per fused-kernel launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/rNN_summary.json, written by tools/summarize_profiles.py: 2*FETCH_SIZE + WRITE_SIZE, KB -> bytes, with the
-    gfx950 read-side correction of MI355X_MICROARCH.md).  PMC counters cannot be read from inside the run, hence the file."""
+def algorithmic_flops(master, train_steps, learn_steps, test_steps):
+    """fp32 FLOPs the path needs (2 per multiply-add, activations not counted): SE step 3 nets, batch-1 Q forward per
+    env step, and per learn step 3 minibatch forwards + the backward (2x one forward) + ~12 per parameter for Adam/Polyak."""
+    c = master.cfg
+    S, A, B, Hq, Hse = c.state_dim, c.num_actions, c.batch_size, c.q_hidden, c.se_hidden
+    q_fwd = 2 * (S * Hq + Hq * A)
+    se = 2 * (3 * (S + A) * Hse + (S + 2) * Hse)
+    return train_steps * (se + q_fwd) + learn_steps * (5 * B * q_fwd + 12 * master.inner.p_agent) + test_steps * q_fwd
+
+
+def profile_summary():
+    """Numbers that cannot be read from inside the run (PMC counters, launch counts) come from the committed rocprofv3
+    passes of this same command: profiles/rNN_summary.json (tools/summarize_profiles.py)."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
         try:
             d = json.load(open(f))
             if "hbm_traffic_bytes_per_launch" in d:
-                best = (d["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT))
+                best = (d, os.path.relpath(f, ROOT))
         except Exception:
             pass
     return best
 
 
-def cpu_baseline(master, cfgd):
-    """The oracle (CPU port of the same path, oracle/lenv_oracle.c) timed on this box's host cores on a bounded sample
-    of the same workload: `pop_s` workers (3 chains each, same theta/eps/agent-init recipe), one thread per core."""
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the only place bench.py touches oracle/)
+# ----------------------------------------------------------------------------------------------------------------------
+def available_cores():
+    """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota (v2 cpu.max / v1 cfs_quota)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(p)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota)))
+    return n, quota
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfgd, theta, grad_chunk, file_io=True):
+    """The oracle (CPU port of the same path, oracle/lenv_oracle.c) timed on this box's host cores on a bounded sample of
+    the same workload.  Leg (i) "threads": one chain per available core, all at once, inside one process.  Leg (ii)
+    "file_io" (SURVEY.md §8(d)(ii)): the reference's deployment shape -- one single-threaded worker process per core
+    talking to a master through the sync-file protocol with the reference's 'single'-mode sleeps."""
     from oracle import oracle as orc
-    cores = os.cpu_count() or 1
-    threads = min(cores, 256)
-    pop_s = max(2, min(64, threads // 3 if threads >= 6 else 2))
-    ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=master.cfg.grad_chunk, rng_mode=0)
-    theta = master.theta.detach().cpu().numpy()
-    eps = (np.random.RandomState(1).randn(pop_s, theta.size) * cfgd["agents"]["gtn"]["noise_std"]).astype(np.float32)
-    bounds = master.agent_bounds.cpu().numpy()
-    init = ((np.random.RandomState(2).rand(3 * pop_s, bounds.size).astype(np.float32) * 2 - 1) * bounds).astype(np.float32)
-    t0 = time.time()
-    orc.ddqn_se_population(ocfg, theta, eps, init, seed=1234, generation=0, threads=threads)
-    dt = time.time() - t0
-    return {"value": pop_s / dt, "unit": "worker-evaluations/s", "cores": threads, "kind": "port",
-            "sample": "%d workers (=%d chains) of the same fixed-work CartPole-SE/DDQN workload, %d threads, %.1f s wall"
-                      % (pop_s, 3 * pop_s, threads, dt)}
+    cores, quota = available_cores()
+    model = cpu_model()
+    noise_std = cfgd["agents"]["gtn"]["noise_std"]
+    ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=grad_chunk, rng_mode=0)
+    from oracle.file_worker import agent_bounds
+    bounds = agent_bounds(ocfg)
+
+    def population(pop_s, threads):
+        eps = (np.random.RandomState(1).randn(pop_s, theta.size) * noise_std).astype(np.float32)
+        init = ((np.random.RandomState(2).rand(3 * pop_s, bounds.size).astype(np.float32) * 2 - 1) * bounds).astype(np.float32)
+        t0 = time.time()
+        orc.ddqn_se_population(ocfg, theta, eps, init, seed=1234, generation=0, threads=threads)
+        return time.time() - t0
+
+    # single-thread calibration: one worker-evaluation = 3 chains on one core
+    t1 = population(1, 1)
+    # all cores: as many whole workers as there are cores/3 (>= 2 workers), one chain per thread
+    pop_s = max(2, min(POP, cores // 3))
+    threads = min(cores, 3 * pop_s)
+    dt = population(pop_s, threads)
+    out = {"value": pop_s / dt, "unit": "worker-evaluations/s", "cores": threads, "kind": "port",
+           "cpu_model": model, "affinity_cores": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": quota,
+           "single_core_value": 1.0 / t1, "parallel_speedup": (pop_s / dt) * t1,
+           "sample": "%d workers (=%d chains) of the same fixed-work CartPole-SE/DDQN workload on %d threads (one chain per "
+                     "thread), %.1f s wall; single-thread calibration: 1 worker (3 chains) in %.1f s" % (pop_s, 3 * pop_s, threads, dt, t1)}
+    if file_io:
+        out["file_io"] = cpu_baseline_file_io(cfgd, theta, cores, deadline_s=max(60.0, 8.0 * t1))
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def cpu_baseline_file_io(cfgd, theta, cores, deadline_s):
+    """One generation of a file-transport GTN_Master driving W oracle workers (oracle/file_worker.py), W = min(cores, 32)
+    (each worker process imports torch for the .pt files: 32 bounds the memory).  evals/s = W / wall of the generation."""
+    import copy
+    import tempfile
+    from learning_environments_amd.agents.GTN import GTN_Master
+    from oracle.engine_standin import OracleNesEngine       # CPU-side master of the CPU baseline (oracle infrastructure)
+    W = max(1, min(cores, 32))
+    cfg = copy.deepcopy(cfgd)
+    cfg["device"] = "cpu"
+    cfg["agents"]["gtn"].update(num_workers=W, max_iterations=1, mode="single")
+    work = tempfile.mkdtemp(prefix="lenv_fileio_")
+    cwd = os.getcwd()
+    os.chdir(work)
+    procs = []
+    try:
+        torch.manual_seed(0)
+        master = GTN_Master(cfg, bohb_id=-1, engine=OracleNesEngine(), transport="file")
+        with torch.no_grad():
+            master.theta.copy_(torch.from_numpy(theta))
+        env = dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        for i in range(W):
+            procs.append(subprocess.Popen([sys.executable, "-m", "oracle.file_worker", str(i), "--max-generations", "1"],
+                                          env=env, cwd=work, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+        time.sleep(min(20.0, 2.0 + 0.25 * W))     # let the workers import torch and start polling (not part of the sample)
+        t0 = time.time()
+        master.write_worker_inputs(0)
+        deadline = t0 + deadline_s
+        while time.time() < deadline:
+            if all(os.path.isfile(master.get_result_check_file_name(i)) for i in range(W)):
+                break
+            time.sleep(master.time_sleep_master)
+        else:
+            return {"value": None, "cores": W, "note": "file-IO leg did not finish within %.0f s; not reported" % deadline_s}
+        master.read_worker_results()
+        dt = time.time() - t0
+        return {"value": W / dt, "unit": "worker-evaluations/s", "cores": W, "kind": "port",
+                "sample": "1 generation: file-transport GTN_Master + %d single-threaded oracle worker processes through "
+                          "results/GTN_sync (reference protocol, 'single'-mode sleeps 0.02 s master / 0.2 s worker), %.1f s "
+                          "wall, mean worker time %.1f s" % (W, dt, float(np.mean(master.time_elapsed_list)))}
+    finally:
+        os.chdir(cwd)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        import shutil
+        shutil.rmtree(work, ignore_errors=True)
 
+
+# ----------------------------------------------------------------------------------------------------------------------
+# one rank
+# ----------------------------------------------------------------------------------------------------------------------
+def timed_generations(master, steps, warmup, barrier, world, use_events):
+    """W untimed + K timed generations, barrier + synchronize on both sides, MAX over ranks.  Returns (seconds, kernel_ms)."""
+    it = 0
+    for _ in range(warmup):
+        master.step(it)
+        it += 1
+    barrier()
+    ev = []
+    orig_inner = master.engine.inner_scores
+
+    def timed_inner(*a, **k):
+        # HIP events on the stream the fused kernel is enqueued on (= torch's current stream, see engine._stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_inner(*a, **k)
+        e1.record()
+        ev.append((e0, e1))
+        return out
+
+    if use_events:
+        master.engine.inner_scores = timed_inner
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        master.step(it)
+        it += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    master.engine.inner_scores = orig_inner
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=master.engine.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+    return dt, kernel_ms
+
+
+def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (MI355X); the product path has no CPU fallback")
-    # LENV_BENCH_BACKEND=gloo is a plumbing check only (several ranks sharing one GPU on a 1-GPU box); the product path is RCCL
-    backend = os.environ.get("LENV_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
+    plumbing = os.environ.get(PLUMBING_ENV)
+    engine = None
+    if plumbing:
+        import importlib
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        mod, cls = plumbing.split(":")
+        engine = getattr(importlib.import_module(mod), cls)()
+        backend = "gloo"
+    else:
+        backend = os.environ.get("LENV_BENCH_BACKEND", "nccl")   # gloo: several ranks sharing one GPU (plumbing check only)
+
+    # ---- CPU baseline first (rank 0, N = 1), so that the GPU section below is one contiguous busy interval ----
+    cpu = None
+    if not args.no_cpu_baseline and world == 1 and not plumbing:
+        from learning_environments_amd.config import ddqn_cfg_from_config
+        cfgd = bench_config(POP)
+        _, theta_host = host_theta(cfgd)
+        cpu_grad_chunk = ddqn_cfg_from_config(cfgd).grad_chunk      # host-side query of the library, no device call
+        cpu = cpu_baseline(cfgd, theta_host, grad_chunk=cpu_grad_chunk, file_io=not args.no_file_io)
+
+    if not plumbing:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (MI355X); the product path has no CPU fallback")
+        if backend != "nccl":
+            local_rank = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -124,85 +365,106 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    if args.gpus != world and rank == 0 and world > 1:
+    if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-
-    master, cfgd = build_master(world)
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
-        torch.cuda.synchronize()
+        if not plumbing:
+            torch.cuda.synchronize()
 
-    it = 0
-    for _ in range(args.warmup):
-        master.step(it)
-        it += 1
-    barrier()
-    # HIP events around every fused-kernel launch (same stream the kernel is enqueued on = torch's current stream)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    orig_inner = master.engine.inner_scores
-    slot = {"i": 0}
-
-    def timed_inner(*a, **k):
-        e0, e1 = ev[slot["i"]]
-        e0.record()
-        out = orig_inner(*a, **k)
-        e1.record()
-        slot["i"] += 1
-        return out
-
-    master.engine.inner_scores = timed_inner
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        master.step(it)
-        it += 1
-    barrier()
-    dt = time.perf_counter() - t0
-    master.engine.inner_scores = orig_inner
-
+    use_events = not plumbing
+    # weak: 64 workers per GPU.  (grad_chunk of the CPU baseline == the kernel's, asserted below)
+    master, cfgd = build_master(POP * world, engine, bool(plumbing))
+    if cpu is not None:
+        assert master.cfg.grad_chunk == cpu_grad_chunk      # CPU baseline and kernel use the same canonical summation order
+    t_start = time.perf_counter()
+    dt, kernel_ms = timed_generations(master, args.steps, args.warmup, barrier, world, use_events)
+    strong = None
     if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        smaster, _ = build_master(POP, engine, bool(plumbing))
+        sdt, skernel_ms = timed_generations(smaster, args.steps, args.warmup, barrier, world, use_events)
+        strong = {"value": POP * args.steps / sdt, "unit": "worker-evaluations/s", "global_pop": POP,
+                  "workers_per_gpu": smaster.w_per,
+                  "ms_per_step": sdt / args.steps * 1e3, "kernel_ms": skernel_ms,
+                  "note": "one workgroup per chain: a chain's %d serial learn steps bound the generation, so fewer chains per "
+                          "GPU do not shorten it once every chain already has its own CU" % (TRAIN_EPISODES * 200)}
+    gpu_section_s = time.perf_counter() - t_start
 
     if rank == 0:
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         stats = master.inner.stats.cpu().numpy()
-        bytes_launch, train_steps, learn_steps, test_steps = algorithmic_bytes(master, stats)
-        achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
-        total_evals = POP_PER_GPU * world * args.steps
+        total_evals = POP * world * args.steps
         line = {
             "metric": "NES worker-evaluations/sec (full inner-loop train+eval) at pop=64 per GPU",
             "value": total_evals / dt, "unit": "worker-evaluations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: CartPole-v0 SE (6-83-{4,1,1} leakyrelu) + DDQN (4-57-2 tanh, B=199), "
-                                   "NES pop=64 per GPU, fixed-work: train_episodes=%d x 200 steps, 10 real-env test episodes "
-                                   "per train episode + final test, early-out off" % TRAIN_EPISODES,
-                       "pop_per_gpu": POP_PER_GPU, "global_pop": POP_PER_GPU * world, "chains_per_gpu": 3 * POP_PER_GPU,
-                       "train_episodes": TRAIN_EPISODES, "parallelism": "population-sharded x%d, 1 all-gather/generation" % world,
-                       "env_steps_per_s": (train_steps + test_steps) * world / (dt / args.steps),
-                       "kernel_launches_per_generation": 1 + 3},
-            "roofline": {"bound": "hbm", "kernel": "ddqn_se_inner_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": kernel_ms,
-                         "note": "latency/issue-bound small-MLP chains: weights+activations live in LDS, only the replay "
-                                 "buffer touches HBM/L2 (see DESIGN.md)"},
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not plumbing else "PLUMBING TEST (CPU stand-in engine, tiny workload) -- not a measurement",
+            "timed_region_s": dt, "gpu_section_s": gpu_section_s,
+            "ranks": {"world_size": world, "backend": ("rccl" if backend == "nccl" else backend),
+                      "launcher": "bench.py child processes" if os.environ.get("LENV_BENCH_SPAWNED") else ("torchrun/env" if world > 1 else "single process")},
+            "weak": {"value": total_evals / dt, "global_pop": POP * world, "workers_per_gpu": POP, "ms_per_step": dt / args.steps * 1e3},
+            "strong": strong if strong is not None else {"value": total_evals / dt, "global_pop": POP, "workers_per_gpu": POP,
+                                                         "ms_per_step": dt / args.steps * 1e3, "note": "N=1: identical to weak"},
         }
-        tr = measured_traffic()
-        if tr is not None:
-            line["roofline"]["traffic"] = tr[0]
-            line["roofline"]["traffic_source"] = tr[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(master, cfgd)
-        print(json.dumps(line))
+        if not plumbing:
+            bytes_launch, train_steps, learn_steps, test_steps = algorithmic_bytes(master, stats)
+            flops_launch = algorithmic_flops(master, train_steps, learn_steps, test_steps)
+            achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
+            tflops = flops_launch / (kernel_ms * 1e-3) / 1e12
+            chains = stats.shape[0]
+            line["config"] = {
+                "workload": "BASELINE configs[1]: CartPole-v0 SE (6-83-{4,1,1} leakyrelu) + DDQN (4-57-2 tanh, B=199), "
+                            "NES pop=64 per GPU, fixed-work: train_episodes=%d x 200 steps, 10 real-env test episodes "
+                            "per train episode + final test, early-out off" % TRAIN_EPISODES,
+                "pop_per_gpu": POP, "global_pop": POP * world, "chains_per_gpu": 3 * POP, "train_episodes": TRAIN_EPISODES,
+                "parallelism": "population-sharded x%d, 1 all-gather/generation" % world,
+                "env_steps_per_s": (train_steps + test_steps) * world / (dt / args.steps),
+                "us_per_learn_step_per_chain": kernel_ms * 1e3 / (learn_steps / chains) if learn_steps else None,
+                "kernel_launches_per_generation": None}
+            line["roofline"] = {"bound": "hbm", "kernel": "ddqn_se_inner_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                                "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": kernel_ms,
+                                "note": "latency/issue-bound small-MLP chains: weights+activations live in LDS, only the replay "
+                                        "buffer touches HBM/L2 (see DESIGN.md); the binding resource is VALU issue, see roofline_valu"}
+            busy = min(chains, 256)
+            line["roofline_valu"] = {"bound": "valu issue (fp32 vector)", "kernel": "ddqn_se_inner_kernel", "achieved": tflops,
+                                     "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VALU_PEAK_TFLOPS,
+                                     "algorithmic_flops_per_launch": flops_launch, "busy_cus": busy,
+                                     "frac_of_busy_cus": tflops / (FP32_VALU_PEAK_TFLOPS * busy / 256.0)}
+            ps = profile_summary()
+            if ps is not None:
+                d, src = ps
+                line["roofline"]["traffic"] = d["hbm_traffic_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                if "launches_per_generation" in d:
+                    line["config"]["kernel_launches_per_generation"] = d["launches_per_generation"]
+                    line["config"]["kernel_launches_source"] = src + " (rocprofv3 --kernel-trace: all dispatches / fused-kernel dispatches)"
+        else:
+            line["config"] = {"workload": "plumbing self-test of the multi-rank path"}
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line), flush=True)
 
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-file-io", action="store_true", help="skip the file-IO worker-mode leg of the CPU baseline")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        os.environ["LENV_BENCH_SPAWNED"] = "1"
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    run_rank(args)
 
 
 if __name__ == "__main__":

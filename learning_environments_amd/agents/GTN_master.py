@@ -11,7 +11,12 @@ Same constructor, attributes (`score_list`, `score_orig_list`, `score_transform_
     redundantly on bit-identical inputs, so theta never needs a broadcast (replaces write_worker_inputs, :147-176);
   * noise eps is one [num_workers, P] tensor drawn from a (seed, generation)-keyed device generator that every rank
     reproduces (agents/GTN_worker.py:156-163 drew it per worker from a time-seeded global RNG);
-  * wall-clock time-outs (calc_worker_timeout, :141-145) have no counterpart: chains run to their step budgets.
+  * wall-clock time-outs (calc_worker_timeout, :141-145) have no counterpart on the fused path: chains run to their step
+    budgets.
+
+`transport="file"` (or config["agents"]["gtn"]["transport"] == "file") is the compatibility mode: the master then drives
+file-based GTN_Worker processes -- this package's or the reference's -- through the sync directory exactly like
+reference :147-195 (`write_worker_inputs` / `read_worker_results`), and only the rank transform + theta update run here.
 """
 import os
 import random
@@ -24,6 +29,7 @@ import torch.distributed as dist
 
 from ..config import TABULAR_AGENTS
 from ..envs.env_factory import EnvFactory
+from ..models.model_utils import linear_params
 from ..utils import calc_abs_param_sum
 from .GTN_base import GTN_Base
 from .nes_common import chain_keys, fresh_agent_init, rank_table, shard_bounds
@@ -33,7 +39,7 @@ __all__ = ["GTN_Master", "rank_table"]
 
 
 class GTN_Master(GTN_Base):
-    def __init__(self, config, bohb_id=-1, bohb_working_dir=None, engine=None, seed=0, verbose=False):
+    def __init__(self, config, bohb_id=-1, bohb_working_dir=None, engine=None, seed=0, verbose=False, transport=None):
         super().__init__(bohb_id)
         self.config = config
         self.device = config["device"]
@@ -54,6 +60,14 @@ class GTN_Master(GTN_Base):
         self.quit_when_solved = gtn_config["quit_when_solved"]
         self.synthetic_env_type = gtn_config["synthetic_env_type"]
         self.unsolved_weight = gtn_config["unsolved_weight"]
+        self.time_mult = gtn_config.get("time_mult", 3)
+        self.time_max = gtn_config.get("time_max", 600)
+        self.time_sleep_master = gtn_config.get("time_sleep_master", 0.2)
+        if gtn_config.get("mode") == 'single':       # reference :37-39
+            self.time_sleep_master /= 10
+        self.transport = transport or gtn_config.get("transport", "fused")
+        if self.transport not in ("fused", "file"):
+            raise ValueError("Unknown transport: " + str(self.transport))
         self.seed = int(seed)
         self.verbose = verbose
 
@@ -98,9 +112,16 @@ class GTN_Master(GTN_Base):
         self.w_lo, self.w_hi, self.w_per = shard_bounds(self.num_workers, self.rank, self.world)
         self.n_local = self.w_hi - self.w_lo
 
-        self.task = select_task(config, engine, self.synthetic_env_orig)
-        self.cfg = self.task.cfg
-        self.agent_bounds = self.task.agent_bounds
+        if self.transport == "file":
+            if self.world > 1:
+                raise ValueError('transport="file" is single-process: the workers are the parallelism')
+            self.w_lo, self.w_hi, self.w_per, self.n_local = 0, 0, self.num_workers, 0      # nothing is evaluated in-process
+            self.task = self.cfg = self.agent_bounds = None
+            self._eps_scratch = generate_synthetic_env_fn(print_str='GTN_Master: ')      # decodes the workers' eps state dicts
+        else:
+            self.task = select_task(config, engine, self.synthetic_env_orig)
+            self.cfg = self.task.cfg
+            self.agent_bounds = self.task.agent_bounds
         G = int(self.num_grad_evals)
         self.inner = self.task.make_inner(self.cpw * self.n_local) if self.n_local > 0 else None
         lw = np.arange(self.w_lo, self.w_hi)
@@ -108,6 +129,7 @@ class GTN_Master(GTN_Base):
         self.chain_sign = torch.tensor(([0.0] + [1.0] * G + [-1.0] * G) * self.n_local, dtype=torch.float32, device=dev)
         self.rank_table = torch.from_numpy(rank_table(self.score_transform_type, self.num_workers)).to(dev)
         self.eps = None
+        self._gathered = None
 
         if bohb_working_dir:
             self.model_dir = str(os.path.join(bohb_working_dir, 'GTN_models_' + self.env_name))
@@ -117,6 +139,17 @@ class GTN_Master(GTN_Base):
             self.env_name + '_' + ''.join(random.choices(string.ascii_uppercase + string.digits, k=6)) + '.pt')
         self.best_score = -float('Inf')
         os.makedirs(self.model_dir, exist_ok=True)
+        self._sync_replicas()
+
+    def _sync_replicas(self):
+        """theta is replicated, never exchanged per generation -- so it must START identical: rank 0's initial theta and
+        model name are broadcast ONCE here (every later update is computed redundantly from bit-identical inputs)."""
+        if self.world <= 1:
+            return
+        dist.broadcast(self.theta, src=0)
+        name = [self.model_name]
+        dist.broadcast_object_list(name, src=0)
+        self.model_name = name[0]
 
     def _flat_theta(self, dev):
         env = self.synthetic_env_orig.env
@@ -151,6 +184,9 @@ class GTN_Master(GTN_Base):
                                             local_init)
             local[:self.n_local] = self.engine.worker_best(chain_scores, self.n_local, self.mirrored_sampling,
                                                            int(self.num_grad_evals), self.grad_eval_type)
+            # column 3 carries this rank's worst chain status through the all-gather: every rank sees every rank's
+            # failure in the one host read-back of the generation and raises together (no second sync, no hang)
+            local[:self.n_local, 3] = self.inner.status.min().to(torch.float64)
         if self.world > 1:
             gathered = torch.empty((self.world * self.w_per, 4), dtype=torch.float64, device=dev)
             dist.all_gather_into_tensor(gathered, local)      # the ONE collective of a generation (RCCL over xGMI)
@@ -161,11 +197,15 @@ class GTN_Master(GTN_Base):
 
     def step(self, it):
         """One NES generation (the body of the reference's run() loop, :84-106).  Returns (mean_score_orig, solved)."""
+        if self.transport == "file":
+            return self._step_file(it)
         t1 = time.time()
         gathered = self.evaluate_population(it)
+        self._gathered = gathered
         host = gathered.cpu().numpy()               # the generation's only host sync
-        if self.inner is not None and hasattr(self.engine, "check_status"):
-            self.engine.check_status(self.inner)
+        if host[:, 3].min() != 0:
+            raise RuntimeError("inner loop reported status %d on worker(s) %s (tape underrun / invalid replay index)"
+                               % (int(host[:, 3].min()), np.nonzero(host[:, 3])[0].tolist()))
         self.score_list = host[:, 0].tolist()
         self.score_orig_list = host[:, 1].tolist()
         self.time_elapsed_list = [time.time() - t1] * self.num_workers
@@ -212,9 +252,10 @@ class GTN_Master(GTN_Base):
 
     def score_transform(self, gathered=None):
         """reference :197-265.  Weights are computed on device together with update_env; this method keeps the
-        reference's name and fills `score_transform_list`."""
+        reference's name and fills `score_transform_list`.  Without an argument it ranks the last evaluated generation
+        (INCLUDING the mirrored-sampling sign of every worker)."""
         if gathered is None:
-            gathered = self._gathered_from_lists()
+            gathered = self._last_gathered()
         self._weights = self.engine.rank_update(self.score_transform_type, gathered, self.rank_table, None, None, 0.0,
                                                 False, 0.0)
         self.score_transform_list = self._weights.cpu().tolist()
@@ -223,25 +264,97 @@ class GTN_Master(GTN_Base):
         """reference :267-298: theta <- theta*(1-wd); theta += (ss*w_i) * eps_i in worker order (eps_i sign-flipped when
         mirrored sampling picked -eps)."""
         if gathered is None:
-            gathered = self._gathered_from_lists()
+            gathered = self._last_gathered()
         self.engine.rank_update(self.score_transform_type, gathered, self.rank_table, self.theta, self.eps,
                                 self.step_size, self.nes_step_size, self.weight_decay)
+        self._theta_changed()
 
     def _transform_and_update(self, gathered):
         """score_transform + update_env in one device call (one ranking pass)."""
         self._weights = self.engine.rank_update(self.score_transform_type, gathered, self.rank_table, self.theta, self.eps,
                                                 self.step_size, self.nes_step_size, self.weight_decay)
         self.score_transform_list = None     # materialised lazily (needs a host copy)
+        self._theta_changed()
+
+    def _theta_changed(self):
+        """The kernels write theta through a raw pointer, which bumps no torch version counter: tell the env wrapper so
+        caches derived from the parameters (RewardEnv's shaped-reward table) are rebuilt."""
+        env = self.synthetic_env_orig.env
+        if hasattr(env, "params_changed"):
+            env.params_changed()
 
     def get_score_transform_list(self):
         if self.score_transform_list is None:
             self.score_transform_list = self._weights.cpu().tolist()
         return self.score_transform_list
 
-    def _gathered_from_lists(self):
+    def _last_gathered(self):
+        """(score_best, score_orig, sign, status) of the generation whose eps is in self.eps.  If the caller edited
+        `score_list` / `score_orig_list` (the reference's public attributes) the edited scores are used, the signs stay."""
+        if self._gathered is None:
+            raise RuntimeError("no generation evaluated yet: pass `gathered` or run step()/read_worker_results() first")
+        g = self._gathered.clone()
+        g[:, 0] = torch.tensor(self.score_list, dtype=torch.float64, device=g.device)
+        g[:, 1] = torch.tensor(self.score_orig_list, dtype=torch.float64, device=g.device)
+        return g
+
+    def gathered_from_lists(self, sign_list):
+        """Explicit form for callers that bring their own lists: sign_list[i] = -1 where worker i's -eps won."""
+        g = np.zeros((self.num_workers, 4))
+        g[:, 0], g[:, 1], g[:, 2] = self.score_list, self.score_orig_list, sign_list
+        return torch.from_numpy(g).to(self.engine.device)
+
+    # ---- file transport (compatibility mode), reference :141-195 ----
+    def calc_worker_timeout(self):
+        if self.time_elapsed_list[0] is None:
+            return self.time_max
+        return float(np.mean(self.time_elapsed_list)) * self.time_mult
+
+    def write_worker_inputs(self, it):
+        timeout = self.calc_worker_timeout()
+        state = {k: v.detach().cpu() for k, v in self.synthetic_env_orig.state_dict().items()}
+        for id in range(self.num_workers):
+            file_name = self.get_input_file_name(id=id)
+            while os.path.isfile(file_name):          # the worker deletes it to acknowledge the previous input
+                time.sleep(self.time_sleep_master)
+            time.sleep(self.time_sleep_master)
+            quit_flag = (it == self.max_iterations - 1) if self.bohb_id < 0 else False
+            torch.save({'timeout': timeout, 'quit_flag': quit_flag, 'config': self.config, 'synthetic_env_orig': state}, file_name)
+            torch.save({}, self.get_input_check_file_name(id=id))
+
+    def read_worker_results(self):
+        dev = self.engine.device
+        self.eps = torch.empty((self.num_workers, self.p_theta), dtype=torch.float32, device=dev)
+        for id in range(self.num_workers):
+            file_name = self.get_result_file_name(id)
+            check_file_name = self.get_result_check_file_name(id)
+            while not os.path.isfile(check_file_name):
+                time.sleep(self.time_sleep_master)
+            data = torch.load(file_name)
+            self.time_elapsed_list[id] = data['time_elapsed']
+            self.score_list[id] = data['score']
+            self.score_orig_list[id] = data['score_orig']
+            # the worker's eps already carries the mirrored-sampling sign (GTN_worker.py:180-185 invert_eps)
+            self._eps_scratch.load_state_dict(data['eps'])
+            self.eps[id] = torch.cat([p.detach().reshape(-1) for p in linear_params(self._eps_scratch)]).to(dev)
+            os.remove(check_file_name)
+            os.remove(file_name)
         g = np.zeros((self.num_workers, 4))
         g[:, 0], g[:, 1], g[:, 2] = self.score_list, self.score_orig_list, 1.0
-        return torch.from_numpy(g).to(self.engine.device)
+        self._gathered = torch.from_numpy(g).to(dev)
+
+    def _step_file(self, it):
+        t1 = time.time()
+        self.write_worker_inputs(it)
+        self.read_worker_results()
+        mean_score = np.mean(self.score_orig_list)
+        solved_flag = self.save_good_model(mean_score)
+        if solved_flag and self.quit_when_solved:
+            return mean_score, True
+        self._transform_and_update(self._gathered)
+        if self.verbose:
+            self.print_statistics(it=it, time_elapsed=time.time() - t1)
+        return mean_score, False
 
     def print_statistics(self, it, time_elapsed):
         print('--------------')

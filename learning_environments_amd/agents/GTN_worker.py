@@ -2,7 +2,9 @@
 
 Kept for API/transport compatibility: same constructor, `late_init`, noise methods, `calc_score`,
 `calc_best_score`, and the file protocol of `run()` (read `<bohb_id>_<id>_input.pt`, write `..._result.pt`), so it can
-serve a reference GTN_Master.  The three inner loops of an evaluation (theta, theta+eps, theta-eps) run as ONE launch
+serve a reference GTN_Master (or this package's GTN_Master in transport="file" mode).  Every (inner agent, synthetic env)
+combination of agents/tasks.py is supported: DDQN / DuelingDDQN on a VirtualEnv, QL / SARSA (+count-based) on a gridworld
+RewardEnv, TD3 on the HalfCheetah stand-in RewardEnv.  The three inner loops of an evaluation (theta, theta+eps, theta-eps) run as ONE launch
 of the fused kernel (3 chains) instead of three sequential python training runs.  The in-process GTN_Master of this
 package does not use worker objects at all.
 """
@@ -14,11 +16,11 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..config import ddqn_cfg_from_config
 from ..envs.env_factory import EnvFactory
 from ..models.model_utils import linear_params
 from .GTN_base import GTN_Base
-from .nes_common import chain_keys, fresh_agent_init, linear_init_bounds
+from .nes_common import chain_keys, fresh_agent_init
+from .tasks import select_task
 
 
 class GTN_Worker(GTN_Base):
@@ -33,8 +35,7 @@ class GTN_Worker(GTN_Base):
         self.timeout = None
         self.engine = engine
         self.generation = 0
-        for file in [self.get_input_file_name(self.id), self.get_input_check_file_name(self.id),
-                     self.get_result_file_name(self.id), self.get_result_check_file_name(self.id)]:
+        for file in self.worker_files(self.id):
             if os.path.isfile(file):
                 os.remove(file)
 
@@ -50,8 +51,6 @@ class GTN_Worker(GTN_Base):
         self.unsolved_weight = gtn_config["unsolved_weight"]
         if gtn_config["mode"] == 'single':
             self.time_sleep_worker /= 10
-        if self.agent_name.lower() not in ("ddqn", "duelingddqn"):
-            raise NotImplementedError("GTN_Worker: inner agent '%s' (use GTN_Master for QL)" % self.agent_name)
         if self.engine is None:
             from ..engine import HipNesEngine
             self.engine = HipNesEngine()
@@ -67,9 +66,10 @@ class GTN_Worker(GTN_Base):
         self.synthetic_env_orig = generate_synthetic_env_fn(print_str='GTN_Base: ')
         self.synthetic_env = generate_synthetic_env_fn(print_str='GTN_Worker' + str(id) + ': ')
         self.eps = generate_synthetic_env_fn('GTN_Worker' + str(id) + ': ')
-        self.cfg = ddqn_cfg_from_config(config)
-        from ..config import agent_layer_dims
-        self._bounds = torch.from_numpy(linear_init_bounds(agent_layer_dims(self.cfg))).to(self.engine.device)
+        # inner agent x synthetic-env type -> fused kernel (agents/agent_utils.py:15-66 select_agent + EnvFactory)
+        self.task = select_task(config, self.engine, self.synthetic_env_orig)
+        self.cfg = self.task.cfg
+        self._bounds = self.task.agent_bounds
         self._inner = {}
 
     # ---- noise handling: reference :156-185, same loops over nn.Linear modules ----
@@ -111,7 +111,7 @@ class GTN_Worker(GTN_Base):
         n = len(thetas)
         dev = self.engine.device
         if n not in self._inner:
-            self._inner[n] = self.engine.make_inner(self.cfg, n)
+            self._inner[n] = self.task.make_inner(n, want_episode_stats=False)
         inner = self._inner[n]
         # express chain c as theta0 + 1*(theta_c - theta0)?  No: exactness matters -> run with eps rows = theta_c, theta = 0
         zero = torch.zeros_like(thetas[0])
@@ -120,20 +120,20 @@ class GTN_Worker(GTN_Base):
         sign = torch.ones(n, dtype=torch.float32, device=dev)
         g = torch.Generator(device=dev)
         g.manual_seed((self.seed * 1000003 + self.generation * 7919 + self.test_counter) % (2 ** 63 - 1))
-        agent_init = fresh_agent_init(self._bounds, n, g, dev)
+        agent_init = fresh_agent_init(self._bounds, n, g, dev) if self.task.needs_agent_init() else None
         keys = chain_keys(self.seed, self.generation * 1000 + self.test_counter, np.full(n, self.id), np.arange(n))
         self.test_counter += 1
-        scores = self.engine.inner_scores(inner, zero, eps, worker, sign, agent_init,
-                                          torch.from_numpy(keys.view(np.int64)).to(dev))
+        scores = self.task.scores(inner, zero, eps, worker, sign, torch.from_numpy(keys.view(np.int64)).to(dev), agent_init)
         out = scores.cpu().tolist()
         if hasattr(self.engine, "check_status"):
             self.engine.check_status(inner)
         return out
 
     def calc_score(self, env, time_remaining=1e9):
-        """reference :187-221: fresh agent, train on `env` with per-episode real-env tests, final test, mean return."""
-        if not env.is_virtual_env():
-            raise NotImplementedError("calc_score on a RewardEnv: next row of the scope table")
+        """reference :187-221: fresh agent, train on `env` (VirtualEnv :199-209 or RewardEnv :211-221) with per-episode
+        real-env tests, final test on the real env, mean test return."""
+        if env.is_virtual_env() != (self.synthetic_env_type == 0):
+            raise ValueError("calc_score: env kind does not match synthetic_env_type %s" % self.synthetic_env_type)
         return self._run_chains([self._flat(env)])[0]
 
     def calc_best_score(self, score_sub, score_add):

@@ -513,6 +513,9 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     const int S = cfg->state_dim, A = cfg->num_actions, H = cfg->q_hidden, F = cfg->feature_dim, L = cfg->q_layers, B = cfg->batch_size;
     const int Hse = cfg->se_hidden, T = cfg->test_episodes, K = S + A;
     if (cfg->agent_kind != 1) return LENV_ERR_INVALID;
+    // the agent's shared nn.PReLU slope is a TRAINED parameter in the reference (model.parameters() -> Adam); a fixed slope
+    // would diverge silently, so agent-net PReLU is refused (SE / reward nets keep theirs: the reference never updates those)
+    if (cfg->q_act == LENV_ACT_PRELU) return LENV_ERR_UNSUPPORTED;
     if (cfg->grad_chunk != 0 && cfg->grad_chunk < B) return LENV_ERR_UNSUPPORTED;   // batch gradient = one sequential chunk here
     if (L < 1 || L > D_MAXL || H < 1 || H > D_MAXW || F < 1 || F > D_MAXW || B < 1 || B > GT_I || T < 1 || T > GT_I || cfg->se_layers != 1)
         return LENV_ERR_UNSUPPORTED;

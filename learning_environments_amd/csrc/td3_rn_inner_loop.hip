@@ -498,6 +498,7 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
     if (cfg->env_id != LENV_ENV_CHEETAH_STANDIN || cfg->state_dim != T3_S || cfg->action_dim != T3_A) return LENV_ERR_UNSUPPORTED;
     const int t = cfg->reward_env_type;
     if (!((t >= 0 && t <= 8) || t == 101 || t == 102)) return LENV_ERR_UNSUPPORTED;          // reward_env.py:49,58 NotImplementedError
+    if (cfg->act == LENV_ACT_PRELU) return LENV_ERR_UNSUPPORTED;   // trained PReLU slope of the agent nets: not a parameter here yet
     const bool uses_info = t == 3 || t == 4 || t == 7 || t == 8 || t > 100;
     if (uses_info && cfg->info_dim != 4) return LENV_ERR_INVALID;                              // the stand-in's info vector has 4 entries
     if (L < 1 || L > T3_MAXL || H < 1 || H > T3_MAXW || B < 1 || B > T3_MAXI || T < 1 || T * T3_S > DNT || cfg->rn_layers != 1 || Hrn < 1 ||

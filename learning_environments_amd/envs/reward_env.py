@@ -69,6 +69,11 @@ class RewardEnv(nn.Module):
         self._table_key = None
         return super()._apply(fn, *a, **k)
 
+    def params_changed(self):
+        """Called by whoever writes the flat parameter buffer behind torch's back (GTN_Master after lenv_nes_rank_update,
+        in-place ops on flat_params()): such writes bump no Parameter._version, so the shaped-reward table is dropped."""
+        self._table_key = None
+
     def ql_cfg(self):
         if not isinstance(self.real_env, GridEnv):
             raise NotImplementedError("RewardEnv over a continuous-state real env: next row of the scope table")
