@@ -35,13 +35,16 @@ constexpr int MAX_PPT = 2;        // Q-net parameters owned per thread (P_agent 
 
 // Diagnostic build only (-DLENV_PHASE_TIMING): per-phase shader-clock totals of chain 0, never in the shipped library.
 #ifdef LENV_PHASE_TIMING
-__device__ unsigned long long g_phase_cycles[16];
-#define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+__device__ unsigned long long g_phase_cycles[40];
+#define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_own[4] = {0, 0, 0, 0}
 #define PT_MARK(i) do { unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
+// own-work stamp: time since the last PT_MARK at which THIS wave reached the coming barrier (no reset)
+#define PT_OWN(i) do { pt_own[i] += __builtin_readcyclecounter() - pt_last; } while (0)
 #define PT_FLUSH(first, n) do { if (chain == 0) for (int pi = 0; pi < (n); ++pi) g_phase_cycles[(first) + pi] = pt_acc[pi]; } while (0)
 #else
 #define PT_DECL
 #define PT_MARK(i)
+#define PT_OWN(i)
 #define PT_FLUSH(first, n)
 #endif
 
@@ -53,7 +56,13 @@ struct InnerArgs {
     float *replay; double *meter; int64_t rb_cap; int row_stride;
     lenv_inner_out out;
     int P_q, P_se, se_net_size[3];
-    int RP, HP, chunk, n_chunks;
+    int RP, HP, chunk, n_chunks, n_chunks4, tanh16;
+    // fp32 constants of the learn step, converted ONCE on the host exactly as the kernel used to ((float) of the double
+    // expression): keeps ten double-precision config fields (20 SGPRs) and their conversions out of the step loop
+    float f_gamma, f_norm, f_w1, f_w2, f_beta2, f_adam_eps, f_tau, f_omt;
+    // torch.optim.Adam bias corrections per learn step t = 1, 2, ...: {-(lr / (1 - beta1^t)), sqrt(1 - beta2^t)} as fp32,
+    // computed in double on the host with the same operation sequence the kernel's thread NT-1 used to run every step
+    const float2 *adam_sched;
     // LDS offsets (floats)
     int o_se_w0T, o_se_b0, o_se_wout, o_se_bout, o_se_h, o_q_onl, o_q_tgt, o_q_w2, o_wscr, o_hB, o_sB, o_rda,
         o_dqB, o_qres, o_part, o_newrow, o_ctrl, o_ret, o_tanh, o_cand, o_cur_state, lds_floats;
@@ -67,9 +76,13 @@ __device__ __forceinline__ void wave_sync()
 }
 
 // Q-net parameters live in LDS as PAIR records: hidden units (2q, 2q+1) share one record of PR = 2*RP floats
-//   [W1[2q][0], W1[2q+1][0], ..., W1[2q][S-1], W1[2q+1][S-1] | b1[2q], b1[2q+1] | W2[0][2q], W2[0][2q+1], ... ]
-// so one thread can evaluate two hidden units per iteration with packed fp32 math on adjacent register pairs; the
-// output biases b2 follow the last record.  Canonical parameter index p -> LDS offset:
+//   [W1[2q][0], W1[2q+1][0], ..., W1[2q][S-1], W1[2q+1][S-1] | b1[2q], b1[2q+1] | pad to 16 B || W2[0..A-1][2q] | W2[0..A-1][2q+1] | pad ]
+// so one thread can evaluate two hidden units per iteration with packed fp32 math on adjacent register pairs (layer 1:
+// the two units of the pair; output layer: the actions of one unit).  The layer-1 part [0, OW2) and the output part
+// [OW2, PR) are separate 16-byte-aligned pieces: the forward loop reads them at different times (software pipeline).
+// The output biases b2 follow the last record.  Canonical parameter index p -> LDS offset:
+template <int S> constexpr int rec_ow2() { return (2 * S + 2 + 3) & ~3; }
+template <int S, int A> constexpr int rec_pr() { return rec_ow2<S>() + ((2 * A + 3) & ~3); }
 template <int S, int A>
 __device__ __forceinline__ int packed_off(int p, int Hq, int PR)
 {
@@ -79,7 +92,7 @@ __device__ __forceinline__ int packed_off(int p, int Hq, int PR)
     p -= nW1;
     if (p < Hq) return (p >> 1) * PR + 2 * S + (p & 1);
     p -= Hq;
-    if (p < A * Hq) { int aa = p / Hq; int j = p - aa * Hq; return (j >> 1) * PR + 2 * S + 2 + 2 * aa + (j & 1); }
+    if (p < A * Hq) { int aa = p / Hq; int j = p - aa * Hq; return (j >> 1) * PR + rec_ow2<S>() + (j & 1) * A + aa; }
     p -= A * Hq;
     return npairs * PR + p;
 }
@@ -87,12 +100,13 @@ __device__ __forceinline__ int packed_off(int p, int Hq, int PR)
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
+// tanh_tab = LDS byte address of the workgroup's image of the canonical tanh table, tl = its addressing (lenv_device.cuh)
 template <int ACT>
-__device__ __forceinline__ float act_fwd_t(const float *tanh_tab, float prelu, float z)
+__device__ __forceinline__ float act_fwd_t(uint32_t tanh_tab, const TanhLds &tl, float prelu, float z)
 {
     if constexpr (ACT == LENV_ACT_RELU) return z > 0.0f ? z : 0.0f;
     else if constexpr (ACT == LENV_ACT_LEAKYRELU) return z > 0.0f ? z : z * 0.01f;
-    else if constexpr (ACT == LENV_ACT_TANH) return det_tanhf(tanh_tab, z);
+    else if constexpr (ACT == LENV_ACT_TANH) return det_tanhf_lds(tanh_tab, tl, z);
     else if constexpr (ACT == LENV_ACT_PRELU) return z > 0.0f ? z : prelu * z;
     else return z;
 }
@@ -107,34 +121,25 @@ __device__ __forceinline__ float act_bwd_t(float prelu, float a, float g)
     else return g;
 }
 
-// Two-stage activation so that the table gather of the canonical tanh can be issued one iteration ahead of its use.
+// Two-stage activation so that the table gather of the canonical tanh (lenv_device.cuh, v3) can be issued ahead of its
+// use.
 template <int ACT>
 struct ActPipe {
-    float z, t, u;
+    float z, d;
     float4 k;
-    __device__ __forceinline__ void issue(const float *tanh_tab, float zz)
+    __device__ __forceinline__ void issue(uint32_t tanh_tab, const TanhLds &tl, float zz)
     {
         z = zz;
         if constexpr (ACT == LENV_ACT_TANH) {
-            const float ax = __builtin_fabsf(zz);
-            t = ax < LENV_TANH_TMAX ? ax : LENV_TANH_TMAX;
-            const float t32 = t * 32.0f;
-            const int idx = (int)t32;
-            u = fma32(__builtin_amdgcn_fractf(t32), 0.03125f, -0.015625f);
-            k = *reinterpret_cast<const float4 *>(tanh_tab + 4 * idx);
+            const TanhArg a = det_tanh_arg(zz);
+            d = a.d;
+            k = det_tanh_lds_gather(tanh_tab, det_tanh_lds_off(a, tl));
         }
     }
     __device__ __forceinline__ float finish(float prelu) const
     {
-        if constexpr (ACT == LENV_ACT_TANH) {
-            float p = fma32(k.w, u, k.z);
-            p = fma32(p, u, k.y);
-            p = fma32(p, u, k.x);
-            const float r = __builtin_fminf(t * p, 1.0f);
-            return __builtin_copysignf(r, z);
-        } else {
-            return act_fwd_t<ACT>(nullptr, prelu, z);
-        }
+        if constexpr (ACT == LENV_ACT_TANH) return det_tanh_poly(k, d, z);
+        else return act_fwd_t<ACT>(0u, TanhLds{}, prelu, z);
     }
 };
 
@@ -167,7 +172,7 @@ __device__ __forceinline__ float seq_dot_lds(const float *h, const float *w, int
 // one wave, lane = hidden unit.  Returns argmax_a Q(obs) (first maximum), identical in every lane.
 template <int S, int A, int PR, int QACT>
 __device__ __forceinline__ int wave_q_argmax(const float *W, const float *W2rows, int HqP, const float (&obs)[S], float *scratch,
-                                             int Hq, float prelu, int lane, const float *tanh_tab)
+                                             int Hq, float prelu, int lane, uint32_t tanh_tab, const TanhLds &tl)
 {
     for (int j = lane; j < Hq; j += 64) {
         const float *rec = W + (j >> 1) * PR + (j & 1);
@@ -175,7 +180,7 @@ __device__ __forceinline__ int wave_q_argmax(const float *W, const float *W2rows
 #pragma unroll
         for (int i = 0; i < S; ++i) z = fma32(obs[i], rec[2 * i], z);
         z = z + rec[2 * S];
-        scratch[j] = act_fwd_t<QACT>(tanh_tab, prelu, z);
+        scratch[j] = act_fwd_t<QACT>(tanh_tab, tl, prelu, z);
     }
     wave_sync();
     float q = 0.0f;
@@ -219,9 +224,10 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t chain = blockIdx.x;
     constexpr int K = S + A;
-    constexpr int RP = (S + 1 + A + 3) & ~3;
-    constexpr int PR = 2 * RP;                        // floats per pair record
+    constexpr int OW2 = rec_ow2<S>();                 // offset of the output-layer part inside a pair record
+    constexpr int PR = rec_pr<S, A>();                // floats per pair record
     constexpr int RS = (2 * S + 3 + 3) & ~3;          // replay row stride (floats)
+    constexpr int SP = (S + 3) & ~3;                  // minibatch-state row stride in LDS (16-byte rows)
     const int Hq = cfg.q_hidden, Hse = cfg.se_hidden, B = cfg.batch_size, HP = a.HP, P = a.P_q;
     const int HqP = (Hq + 3) & ~3, HseP = (Hse + 3) & ~3;
 
@@ -232,10 +238,13 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     float *cand = lds + a.o_cand, *cur_state = lds + a.o_cur_state;
     float *hB = lds + a.o_hB, *sB = lds + a.o_sB, *rda = lds + a.o_rda, *dqB = lds + a.o_dqB;
     float *qres = lds + a.o_qres, *part = lds + a.o_part, *newrow = lds + a.o_newrow;
-    volatile float *ctrl = lds + a.o_ctrl;   // [0..1] done (double buffered by step parity), [2] break, [3] Adam -step, [4] sqrt(bc2), [8..] wave step counts
+    float *ctrl = lds + a.o_ctrl;            // [0..1] done (double buffered by step parity), [2] break, [8..] wave step counts (every use is barrier-separated)
     double *ret = reinterpret_cast<double *>(lds + a.o_ret);   // [test_episodes] returns
-    float *tanh_tab = lds + a.o_tanh;                  // LDS copy of the canonical tanh table (4.7 KB)
-    for (int i = tid; i < LENV_TANH_N * 4; i += NT) tanh_tab[i] = lenv_tanh_table[i];
+    // LDS image of the canonical tanh table at the START of the workgroup's LDS (its base folds into the DS immediate
+    // offset): 16 bank-private copies (32 KB, conflict-free gathers) when the shapes leave room, one copy (2 KB) otherwise
+    det_tanh_lds_stage(lds, a.tanh16 != 0, tid, NT);
+    const uint32_t tanh_tab = lds_addr_of(lds);        // LDS byte address of the image (0: the dynamic LDS starts there)
+    const TanhLds tl = TanhLds::make(a.tanh16 != 0, lane);
 
     // ---------------- stage the perturbed SE: W = theta + sign*eps[worker]  (GTN_worker.py:165-175) ----------------
     {
@@ -260,6 +269,12 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     // thread tid owns parameters tid and tid+NT (master copy, target, Adam m/v in registers)
     float p_onl[PPT], p_tgt[PPT], p_m[PPT], p_v[PPT];
     int my_off[PPT], my_w2[PPT];
+    {
+        // pad slots and the missing unit of an odd last pair are read (and masked) by the forward loop: keep them finite
+        const int rec_floats = ((Hq + 1) >> 1) * PR + A;
+        for (int i = tid; i < rec_floats; i += NT) { q_onl[i] = 0.0f; q_tgt[i] = 0.0f; }
+        __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int p = tid + k * NT;
@@ -277,6 +292,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
         }
     }
     if (tid < 8 + NW) ctrl[tid] = 0.0f;
+    for (int i = tid; i < a.n_chunks4 * P; i += NT) part[i] = 0.0f;  // padding chunk slots stay +0 (see the Adam phase)
     __syncthreads();
 
     const uint64_t key = a.rng_keys ? a.rng_keys[chain] : 0;
@@ -285,7 +301,6 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     // counters (all uniform): one eps-uniform draw and one replay append per train step
     int train_steps = 0, n_act = 0, learn_it = 0, n_test_ep = 0, test_steps = 0;
     double eps_g = cfg.eps_init;
-    double b1pow = 1.0, b2pow = 1.0;                   // maintained by thread 0 only
     float *rb = a.replay + chain * a.rb_cap * RS;
     const int rb_cap = (int)a.rb_cap;
     double *meter = a.meter + chain * cfg.train_episodes;
@@ -324,7 +339,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 #pragma unroll
                 for (int k = 0; k < K; ++k) z = fma32(x[k], w[k * Hse], z);
                 z = z + se_b0[uu];
-                hbuf[net * HseP + j] = act_fwd_t<SEACT>(tanh_tab, cfg.se_prelu, z);
+                hbuf[net * HseP + j] = act_fwd_t<SEACT>(tanh_tab, tl, cfg.se_prelu, z);
             }
         };
         switch (cfg.se_act) {
@@ -361,7 +376,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
             for (int t = 0; t < cfg.max_steps; ++t) {
                 float obs[S];
                 real_env_obs<ENV, S>(st, obs);
-                const int act = wave_q_argmax<S, A, PR, QACT>(q_onl, q_w2, HqP, obs, wscr, Hq, cfg.q_prelu, lane, tanh_tab);
+                const int act = wave_q_argmax<S, A, PR, QACT>(q_onl, q_w2, HqP, obs, wscr, Hq, cfg.q_prelu, lane, tanh_tab, tl);
                 double rew; int done;
                 real_env_step<ENV>(st, act, rew, done);
                 ep_reward = ep_reward + (float)rew;
@@ -374,6 +389,47 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
         n_test_ep += cfg.test_episodes;
         __syncthreads();
         for (int w = 0; w < NW; ++w) test_steps += __float_as_int(ctrl[8 + w]);
+    };
+
+    // ReplayBuffer.sample (utils.py:34-45) for forward item (fwd_b): draw the index of learn step `lit` and start loading the
+    // row.  Issued one step AHEAD (right after the TD error, so the HBM/L2 latency hides behind the gradient and Adam
+    // phases); a row equal to the slot the env wave is about to write is patched from LDS at use time.
+    float4 rowv[RS / 4];                                // kept as whole vectors: nothing touches them until the forward
+    int my_idx = -1, pf_status = 0;
+    bool pf_valid = false;
+    auto fetch_row = [&](int lit, int size_after, int new_pos) {
+        const int64_t n = (int64_t)lit * B + fwd_b;
+        pf_status = 0;
+        if (tape) {
+            if (n >= a.tapes.replay_idx_stride) { pf_status = -4; my_idx = 0; }
+            else my_idx = a.tapes.replay_idx[chain * a.tapes.replay_idx_stride + n];
+            if (my_idx < 0 || my_idx >= size_after) { if (!pf_status) pf_status = -6; my_idx = 0; }
+        } else my_idx = (int)rng_replay_below(key, (uint64_t)n, (uint32_t)size_after);
+        if (my_idx != new_pos) {
+            const float4 *src = reinterpret_cast<const float4 *>(rb + (int64_t)my_idx * RS);
+#pragma unroll
+            for (int v = 0; v < RS / 4; ++v) rowv[v] = src[v];
+        }
+    };
+    // the env wave draws the exploration decision of the NEXT step while the other waves run the minibatch forwards
+    int nx_action = 0, nx_explored = 0;
+    bool nx_valid = false;
+    auto draw_action = [&](int step_no) {
+        // ---- select_train_action, random branch (DDQN.py:97-101): u = random.random(); u < eps -> random action ----
+        double u;
+        if (tape) {
+            if (step_no >= a.tapes.eps_uniform_stride) { status = -2; u = 1.0; }
+            else u = a.tapes.eps_uniform[chain * a.tapes.eps_uniform_stride + step_no];
+        } else u = u64_to_unit(rng_u64(key, STREAM_EPS, (uint64_t)step_no));
+        nx_explored = 0; nx_action = 0;
+        if (u < eps_g) {
+            nx_explored = 1;
+            if (tape) {
+                if (n_act >= a.tapes.rand_action_stride) { status = -3; nx_action = 0; }
+                else nx_action = a.tapes.rand_action[chain * a.tapes.rand_action_stride + n_act];
+            } else nx_action = (int)u64_to_below(rng_u64(key, STREAM_ACTION, (uint64_t)n_act), (uint32_t)A);
+            ++n_act;
+        }
     };
 
     PT_DECL;
@@ -402,27 +458,15 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
             const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;     // ReplayBuffer.size after this add
             const int new_pos = train_steps % rb_cap;                                       // ReplayBuffer.ptr before this add
             // ================= phase A =================
-            float row[RS];
-            int my_idx = -1;
             PT_MARK(9);
             if (wave == ENV_WAVE) {
                 // ---- select_train_action (DDQN.py:97-104) ----
-                double u;
-                if (tape) {
-                    if (train_steps >= a.tapes.eps_uniform_stride) { status = -2; u = 1.0; }
-                    else u = a.tapes.eps_uniform[chain * a.tapes.eps_uniform_stride + train_steps];
-                } else u = u64_to_unit(rng_u64(key, STREAM_EPS, (uint64_t)train_steps));
-                int action, explored = 0;
-                if (u < eps_g) {
-                    explored = 1;
-                    if (tape) {
-                        if (n_act >= a.tapes.rand_action_stride) { status = -3; action = 0; }
-                        else action = a.tapes.rand_action[chain * a.tapes.rand_action_stride + n_act];
-                    } else action = (int)u64_to_below(rng_u64(key, STREAM_ACTION, (uint64_t)n_act), (uint32_t)A);
-                    ++n_act;
-                } else {
-                    action = wave_q_argmax<S, A, PR, QACT>(q_onl, q_w2, HqP, state, wscr, Hq, cfg.q_prelu, lane, tanh_tab);
-                }
+                if (!nx_valid) draw_action(train_steps);
+                nx_valid = false;
+                int action = nx_action;
+                const int explored = nx_explored;
+                if (!explored)
+                    action = wave_q_argmax<S, A, PR, QACT>(q_onl, q_w2, HqP, state, wscr, Hq, cfg.q_prelu, lane, tanh_tab, tl);
                 PT_MARK(0);   // (env wave) act
                 // ---- EnvWrapper.step -> VirtualEnv.step (envs/env_wrapper.py:16-47, envs/virtual_env.py:43-54) ----
                 float next_state[S], reward, done;
@@ -468,18 +512,9 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 for (int i = 0; i < S; ++i) state[i] = next_state[i];
                 PT_MARK(1);   // (env wave) SE step + append
             } else if (learning && fwd_active) {
-                // ---- ReplayBuffer.sample (utils.py:34-45): prefetch this step's minibatch row ----
-                const int64_t n = (int64_t)learn_it * B + fwd_b;
-                if (tape) {
-                    if (n >= a.tapes.replay_idx_stride) { status = -4; my_idx = 0; }
-                    else my_idx = a.tapes.replay_idx[chain * a.tapes.replay_idx_stride + n];
-                    if (my_idx < 0 || my_idx >= size_after) { status = -6; my_idx = 0; }
-                } else my_idx = (int)u64_to_below(rng_u64(key, STREAM_REPLAY, (uint64_t)n), (uint32_t)size_after);
-                if (my_idx != new_pos) {
-                    const float4 *src = reinterpret_cast<const float4 *>(rb + (int64_t)my_idx * RS);
-#pragma unroll
-                    for (int v = 0; v < RS / 4; ++v) { float4 f = src[v]; row[v * 4] = f.x; row[v * 4 + 1] = f.y; row[v * 4 + 2] = f.z; row[v * 4 + 3] = f.w; }
-                }
+                if (!pf_valid) fetch_row(learn_it, size_after, new_pos);     // first learn step: nothing was prefetched
+                pf_valid = false;
+                if (pf_status) status = pf_status;
             }
             ++ep_len; ++train_steps;
             __syncthreads();                                   // B1
@@ -489,9 +524,13 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
             if (learning) {
                 // ================= learn: DDQN.learn (DDQN.py:60-94) =================
                 if (fwd_active) {
+                    float row[RS];
                     if (my_idx == new_pos) {
 #pragma unroll
                         for (int v = 0; v < RS; ++v) row[v] = newrow[v];
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < RS / 4; ++v) { row[v * 4] = rowv[v].x; row[v * 4 + 1] = rowv[v].y; row[v * 4 + 2] = rowv[v].z; row[v * 4 + 3] = rowv[v].w; }
                     }
                     float x[S];
 #pragma unroll
@@ -500,58 +539,99 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     float q[A];
 #pragma unroll
                     for (int aa = 0; aa < A; ++aa) q[aa] = 0.0f;
-                    // Two hidden units per iteration (pair record, packed fp32 math): independent dependency chains; the
-                    // output accumulators stay sequential in j (canonical order).  The loop is unrolled x2 with ping-pong
-                    // record buffers so the next record is in flight while the current one is consumed.
-                    constexpr int PR4 = PR / 4;
+                    // Two hidden units per iteration (pair record, packed fp32 math); the output accumulators stay sequential in
+                    // j (canonical order).  SOFTWARE PIPELINE, one pair of skew: while the tanh-table gathers of pair jp are in
+                    // flight the thread already runs layer 1 of pair jp+1 and issues ITS gathers, then finishes pair jp
+                    // (polynomial, output accumulation, h store).  With 3 waves per SIMD the LDS latency of a gather (~100+
+                    // cycles) is otherwise exposed once per pair.
+                    constexpr int N1 = OW2 / 4, N2 = (PR - OW2) / 4, PR4 = PR / 4;
                     const float4 *W4 = reinterpret_cast<const float4 *>(W);
                     const int npairs = (Hq + 1) >> 1;
-                    const int nfull = Hq >> 1;                      // pairs holding two units
                     float *hrow = hB + fwd_b * HP;
-                    auto load_rec = [&](int jp, float4 (&r)[PR4]) {
+                    float4 r1[N1], r2[N2];
+                    auto load1 = [&](int jp) {
 #pragma unroll
-                        for (int v = 0; v < PR4; ++v) r[v] = W4[jp * PR4 + v];
+                        for (int v = 0; v < N1; ++v) r1[v] = W4[jp * PR4 + v];
                     };
-                    auto pair_step = [&](const float4 (&r)[PR4], int jp, bool two) {
-                        float rec[PR];
+                    auto load2 = [&](int jp) {
 #pragma unroll
-                        for (int v = 0; v < PR4; ++v) { rec[4 * v] = r[v].x; rec[4 * v + 1] = r[v].y; rec[4 * v + 2] = r[v].z; rec[4 * v + 3] = r[v].w; }
+                        for (int v = 0; v < N2; ++v) r2[v] = W4[jp * PR4 + N1 + v];
+                    };
+                    auto layer1 = [&]() -> v2f {
+                        float rec[OW2];
+#pragma unroll
+                        for (int v = 0; v < N1; ++v) { rec[4 * v] = r1[v].x; rec[4 * v + 1] = r1[v].y; rec[4 * v + 2] = r1[v].z; rec[4 * v + 3] = r1[v].w; }
                         v2f z = {0.0f, 0.0f};
 #pragma unroll
                         for (int i = 0; i < S; ++i) z = fma2((v2f){x[i], x[i]}, (v2f){rec[2 * i], rec[2 * i + 1]}, z);
-                        z = z + (v2f){rec[2 * S], rec[2 * S + 1]};
-                        ActPipe<QACT> a0, a1;
-                        a0.issue(tanh_tab, z.x);
-                        a1.issue(tanh_tab, z.y);
+                        return z + (v2f){rec[2 * S], rec[2 * S + 1]};
+                    };
+                    // finish pair jp (its activations were issued one stage earlier) with the output part in r2
+                    auto finish = [&](const ActPipe<QACT> &a0, const ActPipe<QACT> &a1, int jp, bool two) {
+                        float w2[PR - OW2];
+#pragma unroll
+                        for (int v = 0; v < N2; ++v) { w2[4 * v] = r2[v].x; w2[4 * v + 1] = r2[v].y; w2[4 * v + 2] = r2[v].z; w2[4 * v + 3] = r2[v].w; }
                         const float h0 = a0.finish(cfg.q_prelu);
                         const float h1 = a1.finish(cfg.q_prelu);
+                        // output layer: unit 2jp then unit 2jp+1, packed over actions
+                        if constexpr (A == 2) {
+                            v2f qq = {q[0], q[1]};
+                            qq = fma2((v2f){h0, h0}, (v2f){w2[0], w2[1]}, qq);
+                            if (two) qq = fma2((v2f){h1, h1}, (v2f){w2[2], w2[3]}, qq);
+                            q[0] = qq.x; q[1] = qq.y;
+                        } else {
 #pragma unroll
-                        for (int aa = 0; aa < A; ++aa) {
-                            q[aa] = fma32(h0, rec[2 * S + 2 + 2 * aa], q[aa]);
-                            if (two) q[aa] = fma32(h1, rec[2 * S + 2 + 2 * aa + 1], q[aa]);
+                            for (int aa = 0; aa < A; ++aa) q[aa] = fma32(h0, w2[aa], q[aa]);
+                            if (two) {
+#pragma unroll
+                                for (int aa = 0; aa < A; ++aa) q[aa] = fma32(h1, w2[A + aa], q[aa]);
+                            }
                         }
-                        if (fwd_pass == 0) { hrow[2 * jp] = h0; if (two) hrow[2 * jp + 1] = h1; }
+                        if (fwd_pass == 0) {                       // HP is even: 8-byte aligned pair store
+                            if (two) *reinterpret_cast<float2 *>(hrow + 2 * jp) = make_float2(h0, h1);
+                            else hrow[2 * jp] = h0;
+                        }
                     };
-                    float4 ra[PR4], rb4[PR4];
-                    load_rec(0, ra);
+                    // one pipeline stage: start pair jp+1 into (n0, n1), finish pair jp from (c0, c1).  FULL = steady state
+                    // (pair jp+2 exists, pair jp has both units): no conditions, so the stage is straight-line code and the
+                    // compiler can count outstanding LDS reads instead of draining them
+                    auto stage = [&](ActPipe<QACT> &c0, ActPipe<QACT> &c1, ActPipe<QACT> &n0, ActPipe<QACT> &n1, int jp, auto full_tag) {
+                        constexpr bool FULL = decltype(full_tag)::value;
+                        if (FULL || jp + 1 < npairs) {
+                            const v2f z = layer1();                 // r1 holds pair jp+1
+                            n0.issue(tanh_tab, tl, z.x);
+                            n1.issue(tanh_tab, tl, z.y);
+                            if (FULL || jp + 2 < npairs) load1(jp + 2);
+                        }
+                        finish(c0, c1, jp, FULL || 2 * jp + 1 < Hq);   // r2 holds pair jp
+                        if (FULL || jp + 1 < npairs) load2(jp + 1);
+                    };
+                    using T = std::true_type;
+                    using F = std::false_type;
+                    ActPipe<QACT> pa0, pa1, pb0, pb1;
+                    load1(0);
+                    {
+                        const v2f z = layer1();
+                        pa0.issue(tanh_tab, tl, z.x);
+                        pa1.issue(tanh_tab, tl, z.y);
+                    }
+                    if (npairs > 1) load1(1);
+                    load2(0);
                     int jp = 0;
-                    for (; jp + 2 <= nfull; jp += 2) {
-                        load_rec(jp + 1, rb4);
-                        pair_step(ra, jp, true);
-                        load_rec(jp + 2 < npairs ? jp + 2 : jp + 1, ra);
-                        pair_step(rb4, jp + 1, true);
+                    for (; jp + 4 <= npairs; jp += 2) {             // jp+3 < npairs: both stages are steady-state
+                        stage(pa0, pa1, pb0, pb1, jp, T{});
+                        stage(pb0, pb1, pa0, pa1, jp + 1, T{});
                     }
-                    if (jp < nfull) {                               // one full pair left
-                        pair_step(ra, jp, true);
-                        ++jp;
-                        if (jp < npairs) load_rec(jp, ra);
+                    for (; jp + 2 <= npairs; jp += 2) {             // at most one more double stage, with the tail conditions
+                        stage(pa0, pa1, pb0, pb1, jp, F{});
+                        stage(pb0, pb1, pa0, pa1, jp + 1, F{});
                     }
-                    if (jp < npairs) pair_step(ra, jp, false);      // odd Hq: the last record holds one unit
+                    if (jp < npairs) finish(pa0, pa1, jp, 2 * jp + 1 < Hq);
 #pragma unroll
                     for (int aa = 0; aa < A; ++aa) qres[(fwd_pass * MAX_B + fwd_b) * A + aa] = q[aa] + W[npairs * PR + aa];
                     if (fwd_pass == 0) {
 #pragma unroll
-                        for (int i = 0; i < S; ++i) sB[fwd_b * S + i] = row[i];
+                        for (int i = 0; i < S; ++i) sB[fwd_b * SP + i] = row[i];
                         rda[fwd_b * 4 + 0] = row[2 * S + 1]; rda[fwd_b * 4 + 1] = row[2 * S + 2]; rda[fwd_b * 4 + 2] = row[S];
                     }
                 } else if (wave >= first_spec && done_now <= 0.5f) {
@@ -564,12 +644,17 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         if (lane < S + 2) cand[act * 16 + lane] = acc;
                     }
                 }
+                if (wave == ENV_WAVE && !fwd_active && done_now <= 0.5f && t + 1 < cfg.max_steps) {
+                    draw_action(train_steps);                  // train_steps already counts this step: index of the next one
+                    nx_valid = true;
+                }
+                PT_OWN(0);
                 __syncthreads();                               // B2
                 PT_MARK(3);
                 if (tid < B) {
                     // TD target and dLoss/dQ(s,a) per sample (DDQN.py:82-86; mse_loss backward = 2/B * diff)
                     const int b = tid;
-                    const float g32 = (float)cfg.gamma, norm = (float)(2.0 / (double)B);
+                    const float g32 = a.f_gamma, norm = a.f_norm;
                     const float r = rda[b * 4], d = rda[b * 4 + 1];
                     const int ab = (int)rda[b * 4 + 2];
                     int am = 0;
@@ -580,19 +665,26 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     const float t2 = 1.0f - d;
                     const float y = r + t1 * t2;
                     const float diff = qres[(0 * MAX_B + b) * A + ab] - y;
-                    dqB[2 * b] = norm * diff;
-                    dqB[2 * b + 1] = rda[b * 4 + 2];
+                    const float dq = norm * diff;
+                    // dL/dQ(s_b, .) as a row: only entry a_b is non-zero (DDQN.py:84 gather) -- the backward pass multiplies
+                    // by these masks instead of branching on the action
+                    float4 dm;
+                    dm.x = ab == 0 ? dq : 0.0f; dm.y = ab == 1 ? dq : 0.0f; dm.z = ab == 2 ? dq : 0.0f; dm.w = 0.0f;
+                    *reinterpret_cast<float4 *>(dqB + 4 * b) = dm;
                 }
-                if (tid == NT - 1) {
-                    // Adam bias corrections of this step (torch.optim.Adam: step_size = lr/(1-beta1^t), sqrt(1-beta2^t))
-                    b1pow *= cfg.adam_beta1;
-                    b2pow *= cfg.adam_beta2;
-                    ctrl[3] = (float)(-(cfg.lr / (1.0 - b1pow)));
-                    ctrl[4] = (float)__builtin_sqrt(1.0 - b2pow);
-                }
+                PT_OWN(1);
                 __syncthreads();                               // B3
                 PT_MARK(4);
+                if (fwd_active) {
+                    // next step: ReplayBuffer.size = min(train_steps + 1, cap), write slot = train_steps % cap
+                    const int nsz = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
+                    fetch_row(learn_it + 1, nsz, train_steps % rb_cap);
+                    pf_valid = true;
+                }
                 // ---- batch gradient in micro-chunks: wave c reduces samples [c*chunk, (c+1)*chunk) ----
+                // lane = hidden unit j.  Per sample (canonical order, oracle orc_ddqn_learn): da = dq*W2[a_b][j] (as a sum over
+                // the action masks, exactly one term non-zero), dz = act'(h)*da, gW1[j][:] += dz*s, gb1[j] += dz,
+                // gW2[a][j] += dqm[a]*h, gb2[a] += dqm[a] -- adding an exact zero leaves the other actions' sums untouched.
                 if (wave < a.n_chunks) {
                     const int b0 = wave * a.chunk, b1 = (b0 + a.chunk < B) ? b0 + a.chunk : B;
                     float *pc = part + wave * P;
@@ -602,36 +694,52 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 #pragma unroll
                         for (int i = 0; i < S; ++i) gW1[i] = 0.0f;
 #pragma unroll
-                        for (int aa = 0; aa < A; ++aa) { gW2[aa] = 0.0f; gb2[aa] = 0.0f; w2j[aa] = jv ? q_onl[(j >> 1) * PR + 2 * S + 2 + 2 * aa + (j & 1)] : 0.0f; }
+                        for (int aa = 0; aa < A; ++aa) { gW2[aa] = 0.0f; gb2[aa] = 0.0f; w2j[aa] = jv ? q_onl[(j >> 1) * PR + OW2 + (j & 1) * A + aa] : 0.0f; }
                         const float *hcol = hB + (jv ? j : 0);
                         for (int bq = b0; bq < b1; bq += 4) {
                             // issue every LDS read of up to four samples first, then accumulate them in order
-                            float hv[4], dqv[4], av[4], sv[4][S];
+                            float hv[4], sv[4][SP];
+                            float4 dmv[4];
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
                                 const int bb = bq + u < b1 ? bq + u : b1 - 1;
                                 hv[u] = hcol[bb * HP];
-                                const float2 da2 = *reinterpret_cast<const float2 *>(dqB + 2 * bb);
-                                dqv[u] = da2.x; av[u] = da2.y;
+                                dmv[u] = *reinterpret_cast<const float4 *>(dqB + 4 * bb);
 #pragma unroll
-                                for (int i = 0; i < S; ++i) sv[u][i] = sB[bb * S + i];
+                                for (int v = 0; v < SP / 4; ++v) {
+                                    const float4 f = *reinterpret_cast<const float4 *>(sB + bb * SP + 4 * v);
+                                    sv[u][4 * v] = f.x; sv[u][4 * v + 1] = f.y; sv[u][4 * v + 2] = f.z; sv[u][4 * v + 3] = f.w;
+                                }
                             }
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
                                 if (bq + u < b1) {
-                                    const float h = hv[u], dq = dqv[u];
-                                    const int ab = (int)av[u];
-                                    // dL/dz through the output layer and the activation (only row a_b of dQ is non-zero)
-                                    float w2 = w2j[0];
+                                    const float h = hv[u];
+                                    const float dm[3] = {dmv[u].x, dmv[u].y, dmv[u].z};
+                                    float da = dm[0] * w2j[0];
 #pragma unroll
-                                    for (int aa = 1; aa < A; ++aa) w2 = (ab == aa) ? w2j[aa] : w2;
-                                    const float dz = act_bwd_t<QACT>(cfg.q_prelu, h, dq * w2);
+                                    for (int aa = 1; aa < A; ++aa) da = fma32(dm[aa], w2j[aa], da);
+                                    const float dz = act_bwd_t<QACT>(cfg.q_prelu, h, da);
+                                    if constexpr ((S & 1) == 0) {
 #pragma unroll
-                                    for (int i = 0; i < S; ++i) gW1[i] = fma32(dz, sv[u][i], gW1[i]);
+                                        for (int i = 0; i < S; i += 2) {
+                                            const v2f g = fma2((v2f){dz, dz}, (v2f){sv[u][i], sv[u][i + 1]}, (v2f){gW1[i], gW1[i + 1]});
+                                            gW1[i] = g.x; gW1[i + 1] = g.y;
+                                        }
+                                    } else {
+#pragma unroll
+                                        for (int i = 0; i < S; ++i) gW1[i] = fma32(dz, sv[u][i], gW1[i]);
+                                    }
                                     gb1 = gb1 + dz;
+                                    if constexpr (A == 2) {
+                                        const v2f g2 = fma2((v2f){dm[0], dm[1]}, (v2f){h, h}, (v2f){gW2[0], gW2[1]});
+                                        gW2[0] = g2.x; gW2[1] = g2.y;
+                                        const v2f gb = (v2f){gb2[0], gb2[1]} + (v2f){dm[0], dm[1]};
+                                        gb2[0] = gb.x; gb2[1] = gb.y;
+                                    } else {
 #pragma unroll
-                                    for (int aa = 0; aa < A; ++aa)
-                                        if (ab == aa) { gW2[aa] = fma32(dq, h, gW2[aa]); gb2[aa] = gb2[aa] + dq; }
+                                        for (int aa = 0; aa < A; ++aa) { gW2[aa] = fma32(dm[aa], h, gW2[aa]); gb2[aa] = gb2[aa] + dm[aa]; }
+                                    }
                                 }
                             }
                         }
@@ -648,23 +756,36 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         }
                     }
                 }
+                PT_OWN(2);
                 __syncthreads();                               // B4
                 PT_MARK(5);
                 // ---- torch.optim.Adam single-tensor step + Polyak (DDQN.py:88-93), one thread per parameter ----
                 {
-                    const float neg_step = ctrl[3], bc2_sqrt = ctrl[4];
-                    const float w1 = (float)(1.0 - cfg.adam_beta1), w2 = (float)(1.0 - cfg.adam_beta2), beta2 = (float)cfg.adam_beta2;
-                    const float adam_eps = (float)cfg.adam_eps, tau = (float)cfg.tau, omt = (float)(1.0 - cfg.tau);
+                    // Adam bias corrections of this step (torch.optim.Adam: step_size = lr/(1-beta1^t), sqrt(1-beta2^t))
+                    const float2 sched = a.adam_sched[learn_it];
+                    const float neg_step = sched.x, bc2_sqrt = sched.y;
+                    const float w1 = a.f_w1, w2 = a.f_w2, beta2 = a.f_beta2;
+                    const float adam_eps = a.f_adam_eps, tau = a.f_tau, omt = a.f_omt;
 #pragma unroll
                     for (int k = 0; k < PPT; ++k) {
                         const int p = tid + k * NT;
                         if (p < P) {
-                            float pv[NW];
+                            // chunk partials in order; the slots n_chunks .. n_chunks4-1 (n_chunks rounded up to 4) hold +0 for
+                            // the whole run, and g + 0 == g, so whole groups of four are summed without per-slot conditions
+                            float g;
+                            {
+                                float pv[4];
 #pragma unroll
-                            for (int c = 0; c < NW; ++c) pv[c] = c < a.n_chunks ? part[c * P + p] : 0.0f;
-                            float g = pv[0];
+                                for (int c = 0; c < 4; ++c) pv[c] = part[c * P + p];
+                                g = pv[0]; g = g + pv[1]; g = g + pv[2]; g = g + pv[3];
+                            }
+                            for (int c0 = 4; c0 < a.n_chunks4; c0 += 4) {          // uniform trip count, four slots per round
+                                float pv[4];
 #pragma unroll
-                            for (int c = 1; c < NW; ++c) if (c < a.n_chunks) g = g + pv[c];
+                                for (int c = 0; c < 4; ++c) pv[c] = part[(c0 + c) * P + p];
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) g = g + pv[c];
+                            }
                             p_m[k] = fma32(w1, g - p_m[k], p_m[k]);
                             p_v[k] = p_v[k] * beta2;
                             p_v[k] = fma32(w2 * g, g, p_v[k]);
@@ -678,6 +799,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     }
                 }
                 ++learn_it;
+                PT_OWN(3);
                 __syncthreads();                               // B5
                 PT_MARK(6);
             }
@@ -720,6 +842,10 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 #ifdef LENV_PHASE_TIMING
     if (tid == 0) PT_FLUSH(0, 10);
     if (tid == ENV_WAVE * 64) { if (chain == 0) { g_phase_cycles[10] = pt_acc[0]; g_phase_cycles[11] = pt_acc[1]; } }
+    if (chain == 0 && lane == 0) {       // own-work stamps (forward, TD, gradient, Adam) of waves 0, 4, 8, 9, 10, 11
+        const int slot = wave == 0 ? 0 : (wave == 4 ? 1 : (wave == 8 ? 2 : (wave == 9 ? 3 : (wave == 10 ? 4 : (wave == 11 ? 5 : -1)))));
+        if (slot >= 0) for (int pi = 0; pi < 4; ++pi) g_phase_cycles[12 + 4 * slot + pi] = pt_own[pi];
+    }
 #endif
     if (tid == 0) {
         double sm = 0.0;
@@ -765,6 +891,38 @@ static int64_t inner_rb_cap(const lenv_ddqn_cfg *cfg)
 
 static int inner_row_stride(const lenv_ddqn_cfg *cfg) { return (2 * cfg->state_dim + 3 + 3) & ~3; }
 
+// Adam bias-correction schedule (see InnerArgs::adam_sched), cached per (device, lr, beta1, beta2, length): the bench and
+// the NES loop launch the same configuration every generation, so this is computed and uploaded once.
+#include <mutex>
+#include <vector>
+namespace {
+struct SchedEntry { int dev; double lr, b1, b2; int64_t n; float2 *dptr; };
+std::mutex g_sched_mu;
+std::vector<SchedEntry> g_sched;
+}
+static const float2 *adam_schedule(const lenv_ddqn_cfg *cfg, int64_t n)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_sched_mu);
+    for (const SchedEntry &e : g_sched)
+        if (e.dev == dev && e.lr == cfg->lr && e.b1 == cfg->adam_beta1 && e.b2 == cfg->adam_beta2 && e.n >= n) return e.dptr;
+    std::vector<float2> h((size_t)n);
+    double b1pow = 1.0, b2pow = 1.0;
+    for (int64_t t = 0; t < n; ++t) {
+        b1pow *= cfg->adam_beta1;
+        b2pow *= cfg->adam_beta2;
+        h[(size_t)t].x = (float)(-(cfg->lr / (1.0 - b1pow)));
+        h[(size_t)t].y = (float)__builtin_sqrt(1.0 - b2pow);
+    }
+    float2 *d = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&d), sizeof(float2) * (size_t)n) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    if (g_sched.size() >= 16) { (void)hipFree(g_sched.front().dptr); g_sched.erase(g_sched.begin()); }
+    g_sched.push_back(SchedEntry{dev, cfg->lr, cfg->adam_beta1, cfg->adam_beta2, n, d});
+    return d;
+}
+
 // LDS carve-up of one chain's workgroup; returns LENV_ERR_UNSUPPORTED when the shapes do not fit 160 KiB
 static int inner_layout(const lenv_ddqn_cfg *cfg, InnerArgs &a)
 {
@@ -774,29 +932,36 @@ static int inner_layout(const lenv_ddqn_cfg *cfg, InnerArgs &a)
     a.se_net_size[1] = a.se_net_size[2] = (int)mlp_params(S + A, Hse, 1, 1);
     a.P_se = a.se_net_size[0] + a.se_net_size[1] + a.se_net_size[2];
     if (a.P_q > MAX_PPT * NT) return LENV_ERR_UNSUPPORTED;
-    a.RP = (S + 1 + A + 3) & ~3;
-    a.HP = Hq | 1;
+    a.RP = 0;
+    a.HP = (Hq + 1) & ~1;                       // even (8-byte pair stores of h) ...
+    if (((a.HP >> 1) & 1) == 0) a.HP += 2;      // ... with HP/2 odd: lanes = samples write pairs without bank conflicts
     a.chunk = cfg->grad_chunk > 0 ? cfg->grad_chunk : (B + NW - 1) / NW;
     a.n_chunks = (B + a.chunk - 1) / a.chunk;
     if (a.n_chunks > NW) return LENV_ERR_UNSUPPORTED;
+    a.n_chunks4 = (a.n_chunks + 3) & ~3;
     const int K = S + A, HqPad = (Hq + 63) & ~63;
-    int o = 0;
-    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
-    a.o_se_w0T = take(3 * K * Hse); a.o_se_b0 = take(3 * Hse); a.o_se_wout = take((S + 2) * ((Hse + 3) & ~3)); a.o_se_bout = take(S + 2);
-    a.o_se_h = take(2 * 3 * ((Hse + 3) & ~3));
-    a.o_q_onl = take(((Hq + 1) / 2) * 2 * a.RP + A); a.o_q_tgt = take(((Hq + 1) / 2) * 2 * a.RP + A); a.o_q_w2 = take(A * ((Hq + 3) & ~3));
-    a.o_wscr = take(NW * HqPad);
-    a.o_hB = take(B * a.HP);
-    a.o_sB = take(B * S); a.o_rda = take(B * 4); a.o_dqB = take(2 * B);
-    a.o_qres = take(3 * MAX_B * A);
-    a.o_part = take(a.n_chunks * a.P_q);
-    a.o_newrow = take(16); a.o_ctrl = take(8 + NW);
-    a.o_ret = take(2 * cfg->test_episodes + 2);
-    a.o_tanh = take(LENV_TANH_N * 4);
-    a.o_cand = take(16 * A); a.o_cur_state = take(16);
-    a.lds_floats = o;
-    if ((size_t)o * sizeof(float) > 160 * 1024) return LENV_ERR_UNSUPPORTED;
-    return LENV_OK;
+    // the tanh image is carved first (offset 0, see det_tanh_lds_off): 16 bank-private copies when they fit, else one
+    for (int sixteen = 1; sixteen >= 0; --sixteen) {
+        int o = 0;
+        auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+        a.tanh16 = sixteen;
+        a.o_tanh = take(sixteen ? LENV_TANH16_FLOATS : LENV_TANH1_FLOATS);
+        a.o_se_w0T = take(3 * K * Hse); a.o_se_b0 = take(3 * Hse); a.o_se_wout = take((S + 2) * ((Hse + 3) & ~3)); a.o_se_bout = take(S + 2);
+        a.o_se_h = take(2 * 3 * ((Hse + 3) & ~3));
+        const int PRh = ((2 * S + 2 + 3) & ~3) + ((2 * A + 3) & ~3);      // floats per pair record (rec_pr<S, A>())
+        a.o_q_onl = take(((Hq + 1) / 2) * PRh + A); a.o_q_tgt = take(((Hq + 1) / 2) * PRh + A); a.o_q_w2 = take(A * ((Hq + 3) & ~3));
+        a.o_wscr = take(NW * HqPad);
+        a.o_hB = take(B * a.HP);
+        a.o_sB = take(B * ((S + 3) & ~3)); a.o_rda = take(B * 4); a.o_dqB = take(4 * B);
+        a.o_qres = take(3 * MAX_B * A);
+        a.o_part = take(a.n_chunks4 * a.P_q);
+        a.o_newrow = take(16); a.o_ctrl = take(8 + NW);
+        a.o_ret = take(2 * cfg->test_episodes + 2);
+        a.o_cand = take(16 * A); a.o_cur_state = take(16);
+        a.lds_floats = o;
+        if ((size_t)o * sizeof(float) <= 160 * 1024) return LENV_OK;
+    }
+    return LENV_ERR_UNSUPPORTED;
 }
 
 static int inner_check(const lenv_ddqn_cfg *cfg)
@@ -817,7 +982,7 @@ static int inner_check(const lenv_ddqn_cfg *cfg)
 #ifdef LENV_PHASE_TIMING
 extern "C" int lenv_debug_phase_cycles(unsigned long long *host_out)
 {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_phase_cycles), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_phase_cycles), sizeof(unsigned long long) * 40) == hipSuccess ? 0 : -4;
 }
 #endif
 
@@ -868,6 +1033,11 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
     const int lrc = inner_layout(cfg, a);
     if (lrc != LENV_OK) return lrc;
     const size_t lds_bytes = (size_t)a.lds_floats * sizeof(float);
+    a.f_gamma = (float)cfg->gamma; a.f_norm = (float)(2.0 / (double)cfg->batch_size);
+    a.f_w1 = (float)(1.0 - cfg->adam_beta1); a.f_w2 = (float)(1.0 - cfg->adam_beta2); a.f_beta2 = (float)cfg->adam_beta2;
+    a.f_adam_eps = (float)cfg->adam_eps; a.f_tau = (float)cfg->tau; a.f_omt = (float)(1.0 - cfg->tau);
+    a.adam_sched = adam_schedule(cfg, (int64_t)cfg->train_episodes * cfg->max_steps + 1);
+    if (!a.adam_sched) return LENV_ERR_LAUNCH;
 
     void (*kern)(const InnerArgs) = nullptr;
 #define LENV_PICK2(ENVID, SS, AA, PP)                                                                              \

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                     if (tape) {
                         if (n >= a.tapes.replay_idx_stride) { status = -4; idx = 0; } else idx = a.tapes.replay_idx[chain * a.tapes.replay_idx_stride + n];
                         if (idx < 0 || idx >= size_after) { status = -6; idx = 0; }
-                    } else idx = (int)u64_to_below(rng_u64(key, STREAM_REPLAY, (uint64_t)n), (uint32_t)size_after);
+                    } else idx = (int)rng_replay_below(key, (uint64_t)n, (uint32_t)size_after);
                     const float *row = rb + (int64_t)idx * RS;
                     for (int i = 0; i < S; ++i) { xs[b * S + i] = row[i]; xs2[b * S + i] = row[S + 1 + i]; }
                     dAdv[b * A + 0] = row[S];               // stash (a, r, done) in dAdv/dq until the TD step

@@ -20,24 +20,82 @@ namespace lenv {
 __device__ __forceinline__ float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma64(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-// Canonical tanh (same sequence as the oracle's orc_tanhf): tanh(x) = copysign(min(t*p_i(t-c_i), 1), x),
-// t = min(|x|, TMAX), i = trunc(32 t), p_i = cubic of lenv_tanh_table.h (g(t) = tanh(t)/t).  `tab` may point to the
-// global copy below or to a copy staged in LDS (one 16-byte gather per evaluation).
+// Canonical tanh v3 (same sequence as the oracle's orc_tanhf): t = min(|x|, TMAX), w = t + 1, i = (bits(w) >> SHIFT) - IDX0,
+// d = w - float(bits(w) with the low SHIFT bits cleared), tanh(x) = copysign(((c3 d + c2) d + c1) d + c0, x) with the cubic
+// (c0..c3)_i of lenv_tanh_table.h.  10 VALU instructions + one 16-byte gather.
+// Table images: `tab` = one copy, entry i at tab[4 i] (the global copy below, or a plain LDS copy); `tab16` = SIXTEEN
+// interleaved copies in LDS, 128 slots of 256 B: slot s = (bits(w) >> SHIFT) & 127 (= (IDX0 + i) & 127, a rotation of the
+// entry index -- no subtraction on the address path), copy c at byte 16 c of the slot.  A lane that reads copy
+// (lane & 15) owns bank quad (lane & 15) of the 64 LDS banks, and the 16 lanes a ds_read_b128 services per cycle
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ... -- MI355X_MICROARCH.md, LDS) have distinct (lane & 15): every gather is
+// conflict-free.  Address = ((bits(w) >> 10) & 0x7f00) | 16 (lane & 15): v_lshrrev + v_and_or, the image base rides in the
+// DS instruction's immediate offset.
 static __device__ const float lenv_tanh_table[LENV_TANH_N * 4] = LENV_TANH_TABLE_INIT;
+constexpr int LENV_TANH16_FLOATS = 128 * 64, LENV_TANH1_FLOATS = 128 * 4;
+static_assert(LENV_TANH_N <= 128 && LENV_TANH_SHIFT == 18, "tab16 addressing assumes <= 128 slots and an 18-bit shift");
 
-__device__ __forceinline__ float det_tanhf(const float *tab, float x)
+struct TanhArg { float d; int idx; uint32_t bits; };
+__device__ __forceinline__ TanhArg det_tanh_arg(float x)
 {
     const float ax = __builtin_fabsf(x);
     const float t = ax < LENV_TANH_TMAX ? ax : LENV_TANH_TMAX;
-    const float t32 = t * 32.0f;
-    const int idx = (int)t32;
-    const float u = fma32(__builtin_amdgcn_fractf(t32), 0.03125f, -0.015625f);   // = t - (idx+0.5)/32, exact
-    const float4 k = *reinterpret_cast<const float4 *>(tab + 4 * idx);
-    float p = fma32(k.w, u, k.z);
-    p = fma32(p, u, k.y);
-    p = fma32(p, u, k.x);
-    const float r = __builtin_fminf(t * p, 1.0f);
-    return __builtin_copysignf(r, x);
+    const float w = t + 1.0f;
+    const uint32_t b = __float_as_uint(w);
+    TanhArg r;
+    r.bits = b;
+    r.d = w - __uint_as_float(b & ~((1u << LENV_TANH_SHIFT) - 1u));
+    r.idx = (int)(b >> LENV_TANH_SHIFT) - LENV_TANH_IDX0;
+    return r;
+}
+__device__ __forceinline__ float det_tanh_poly(const float4 k, float d, float x)
+{
+    float p = fma32(k.w, d, k.z);
+    p = fma32(p, d, k.y);
+    p = fma32(p, d, k.x);
+    return __builtin_copysignf(p, x);
+}
+__device__ __forceinline__ float det_tanhf(const float *tab, float x)
+{
+    const TanhArg a = det_tanh_arg(x);
+    return det_tanh_poly(*reinterpret_cast<const float4 *>(tab + 4 * a.idx), a.d, x);
+}
+// Addressing of an LDS image with 16 copies (slot stride 256 B) or, when LDS is short, ONE copy (slot stride 16 B, gathers
+// then conflict like any random 16-byte access).  All three fields are wave-uniform except lane_off.
+struct TanhLds {
+    uint32_t shift, mask, lane_off;
+    __device__ __forceinline__ static TanhLds make(bool sixteen, int lane)
+    {
+        TanhLds t;
+        t.shift = sixteen ? 10u : 14u; t.mask = sixteen ? 0x7f00u : 0x7f0u; t.lane_off = sixteen ? 16u * (uint32_t)(lane & 15) : 0u;
+        return t;
+    }
+};
+// byte offset of this lane's coefficients inside the image
+__device__ __forceinline__ uint32_t det_tanh_lds_off(const TanhArg &a, const TanhLds &t) { return ((a.bits >> t.shift) & t.mask) | t.lane_off; }
+// 16-byte gather at LDS byte address `img_addr + off`.  The address is formed as an INTEGER in the LDS address space: with
+// the image at LDS address 0 the whole computation is v_lshrrev + v_and_or and the DS instruction needs no base add.
+__device__ __forceinline__ float4 det_tanh_lds_gather(uint32_t img_addr, uint32_t off)
+{
+    typedef __attribute__((address_space(3))) const float4 lds_f4;
+    return *reinterpret_cast<lds_f4 *>(static_cast<uintptr_t>(img_addr + off));
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const float *p)
+{
+    return (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const float *)p);
+}
+__device__ __forceinline__ float det_tanhf_lds(uint32_t img_addr, const TanhLds &t, float x)
+{
+    const TanhArg a = det_tanh_arg(x);
+    return det_tanh_poly(det_tanh_lds_gather(img_addr, det_tanh_lds_off(a, t)), a.d, x);
+}
+// fill the LDS image (all threads of the workgroup; caller synchronises)
+__device__ __forceinline__ void det_tanh_lds_stage(float *img, bool sixteen, int tid, int nthreads)
+{
+    const int per_slot = sixteen ? 64 : 4, sh = sixteen ? 6 : 2;
+    for (int e = tid; e < 128 * per_slot; e += nthreads) {
+        const int i = ((e >> sh) - LENV_TANH_IDX0) & 127;         // slot -> entry
+        img[e] = i < LENV_TANH_N ? lenv_tanh_table[4 * i + (e & 3)] : 0.0f;
+    }
 }
 
 __device__ __forceinline__ double det_ksin(double x)
@@ -105,6 +163,19 @@ __host__ __device__ __forceinline__ uint64_t rng_u64(uint64_t key, uint32_t stre
 {
     uint64_t x = key + 0x9e3779b97f4a7c15ULL * (((uint64_t)stream << 56) ^ n);
     return mix64(mix64(x) ^ key);
+}
+
+// ReplayBuffer.sample index draw n of a chain (utils.py:35 np.random.randint(0, size)): one 32-bit murmur3 finaliser over
+// (n, key) -- this draw runs once per minibatch sample per learn step, where the 64-bit double mix above cost ~350 cycles
+// of quarter-rate integer multiplies per wave; the mapping to [0, size) is the multiply-high of u64_to_below.
+__host__ __device__ __forceinline__ uint32_t rng_replay_below(uint64_t key, uint64_t n, uint32_t size)
+{
+    uint32_t h = (uint32_t)n * 0x9e3779b1u + (uint32_t)key;
+    h ^= (uint32_t)(key >> 32);
+    h ^= h >> 16; h *= 0x85ebca6bu;
+    h ^= h >> 13; h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return (uint32_t)(((uint64_t)h * (uint64_t)size) >> 32);
 }
 
 __device__ __forceinline__ double u64_to_unit(uint64_t u) { return (double)(u >> 11) * (1.0 / 9007199254740992.0); }

@@ -103,6 +103,7 @@ typedef struct {
 
 /* ---- deterministic math ---- */
 float orc_tanhf(float x);
+int64_t orc_tanhf_scan(uint32_t lo_bits, uint32_t hi_bits, float slack, float *max_out);
 double orc_sin(double x);
 double orc_cos(double x);
 
@@ -110,6 +111,7 @@ double orc_cos(double x);
 uint64_t orc_mix64(uint64_t x);
 uint64_t orc_chain_key(uint64_t seed, uint64_t generation, uint64_t worker, uint64_t kind);
 uint64_t orc_rng_u64(uint64_t key, uint32_t stream, uint64_t n);
+uint32_t orc_rng_replay_below(uint64_t key, uint64_t n, uint32_t size);
 
 /* ---- MLP ---- */
 int64_t orc_mlp_num_params(const orc_mlp_desc *d);

@@ -113,6 +113,8 @@ def lib():
         _lib = C.CDLL(_LIB_PATH)
         _lib.orc_tanhf.restype = C.c_float
         _lib.orc_tanhf.argtypes = [C.c_float]
+        _lib.orc_tanhf_scan.restype = C.c_int64
+        _lib.orc_tanhf_scan.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.POINTER(C.c_float)]
         _lib.orc_sin.restype = C.c_double
         _lib.orc_sin.argtypes = [C.c_double]
         _lib.orc_cos.restype = C.c_double
@@ -152,6 +154,15 @@ def tanhf(x):
     for i in range(flat_in.size):
         flat_out[i] = L.orc_tanhf(float(flat_in[i]))
     return out
+
+
+def tanhf_scan(lo, hi, slack=0.0):
+    """(number of violations, max result) of orc_tanhf over every float in [lo, hi] (lo, hi >= 0)."""
+    lo_b = int(np.array([lo], np.float32).view(np.uint32)[0])
+    hi_b = int(np.array([hi], np.float32).view(np.uint32)[0])
+    mx = C.c_float(0.0)
+    bad = lib().orc_tanhf_scan(lo_b, hi_b, C.c_float(slack), C.byref(mx))
+    return int(bad), float(mx.value)
 
 
 def mlp_forward(d, params, x, want_hidden=False):

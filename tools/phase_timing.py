@@ -10,15 +10,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "learning_environments_amd", "csrc")
 OUT = "/tmp/liblenv_hip_timing.so"
-srcs = ["lenv_api.hip", "se_step.hip", "qnet_td.hip", "ddqn_se_inner_loop.hip", "nes_update.hip", "real_env.hip"]
+srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-                       "-fPIC", "-shared", "-DLENV_PHASE_TIMING", "-o", OUT] + [os.path.join(CSRC, s) for s in srcs])
+                       "-fPIC", "-shared", "-DLENV_PHASE_TIMING", "-o", OUT] + [a for a in sys.argv[1:] if a.startswith("-")]
+                      + [os.path.join(CSRC, s) for s in srcs])
 from learning_environments_amd import _lib
 _lib.LIB_PATH = OUT
 import torch
 import bench
-master, cfgd = bench.build_master(1)
-extra = dict(a.split("=") for a in sys.argv[1:])
+master, cfgd = bench.build_master(bench.POP)
+extra = dict(a.split("=") for a in sys.argv[1:] if not a.startswith("-"))
 for k, v in extra.items():
     setattr(master.cfg, k, int(v))
 if extra:
@@ -27,7 +28,7 @@ master.step(0)
 torch.cuda.synchronize()
 import time
 t0 = time.time(); master.step(1); torch.cuda.synchronize(); dt = time.time() - t0
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 40)()
 _lib.lib().lenv_debug_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
 assert _lib.lib().lenv_debug_phase_cycles(buf) == 0
 names = ["(unused)", "(unused)", "phaseA+wait(B1)", "forward(B2)", "td-error(B3)", "grad-reduce(B4)", "adam(B5)", "test", "-", "loop-overhead",
@@ -37,3 +38,8 @@ print("generation wall %.1f ms; stats %s" % (dt * 1e3, master.inner.stats[0].tol
 for i, n in enumerate(names):
     if buf[i]:
         print("%-22s %12d cycles  %5.1f%%" % (n, buf[i], 100.0 * buf[i] / tot))
+print("own-work cycles before each barrier (forward | TD | gradient | Adam), per learn step:")
+steps = max(1, int(master.inner.stats[0][2]))
+for slot, w in enumerate((0, 4, 8, 9, 10, 11)):
+    print("  wave %2d: " % w + " | ".join("%7.0f" % (buf[12 + 4 * slot + i] / steps) for i in range(4)))
+print("phase totals per learn step: " + ", ".join("%s %.0f" % (names[i], buf[i] / steps) for i in (2, 3, 4, 5, 6)))

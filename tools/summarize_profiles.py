@@ -8,7 +8,7 @@ import os
 import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 os.makedirs(os.path.join(R, "profiles"), exist_ok=True)
 out = {}
 for f in glob.glob(os.path.join(R, "gpurun_out/prof/*/*kernel_stats.csv")):
@@ -18,10 +18,15 @@ for f in glob.glob(os.path.join(R, "gpurun_out/prof/*/*kernel_stats.csv")):
         for r in rows:
             r[0] = r[0][:96]
             w.writerow(r)
+    total_calls = 0
     for r in rows[1:]:
+        total_calls += int(r[1])
         if "ddqn_se_inner" in r[0]:
             out["inner_kernel_calls"] = int(r[1])
             out["inner_kernel_avg_ms"] = float(r[3]) / 1e6
+    if out.get("inner_kernel_calls"):
+        # every dispatch rocprofv3 saw (kernels, fills, device copies) per generation, start-up launches included
+        out["launches_per_generation"] = total_calls / out["inner_kernel_calls"]
     print("".join(",".join(r[:5]) + "\n" for r in rows[:6]))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = []
