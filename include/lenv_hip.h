@@ -83,7 +83,7 @@ typedef struct {
 typedef struct {
     double *score;              /* [chains] statistics.mean(final test returns)   GTN_worker.py:209 */
     int64_t *stats;             /* [chains,4] episodes_run, train_steps, learn_steps, test_steps */
-    int32_t *status;            /* [chains] 0 ok, <0 tape underrun / internal error */
+    int32_t *status;            /* [chains] 0 ok, <0 internal error: -2..-5 tape underrun (eps / action / replay / reset), -6 replay index out of range, -7 unexpected LDS placement */
     double *episode_test_mean;  /* [chains,train_episodes]  reward_list_train (NaN past early-out) */
     int32_t *episode_len;       /* [chains,train_episodes] */
     double *final_returns;      /* [chains,test_episodes] */

@@ -121,25 +121,31 @@ __device__ __forceinline__ float act_bwd_t(float prelu, float a, float g)
     else return g;
 }
 
-// Two-stage activation so that the table gather of the canonical tanh (lenv_device.cuh, v3) can be issued ahead of its
-// use.
+// Two-stage activation of a hidden-unit PAIR, so that the table gathers of the canonical tanh (lenv_device.cuh, v3) can
+// be issued ahead of their use.  The pair form keeps the two-at-a-time steps (|z|+1, w - trunc(w)) on packed fp32
+// instructions; everything is the same operation sequence as det_tanhf, element by element.
 template <int ACT>
-struct ActPipe {
-    float z, d;
-    float4 k;
-    __device__ __forceinline__ void issue(uint32_t tanh_tab, const TanhLds &tl, float zz)
+struct ActPipe2 {
+    v2f z, d;
+    float4 k0, k1;
+    __device__ __forceinline__ void issue(uint32_t tanh_tab, const TanhLds &tl, v2f zz)
     {
         z = zz;
         if constexpr (ACT == LENV_ACT_TANH) {
-            const TanhArg a = det_tanh_arg(zz);
-            d = a.d;
-            k = det_tanh_lds_gather(tanh_tab, det_tanh_lds_off(a, tl));
+            const float a0 = __builtin_fabsf(zz.x), a1 = __builtin_fabsf(zz.y);
+            const v2f t = {a0 < LENV_TANH_TMAX ? a0 : LENV_TANH_TMAX, a1 < LENV_TANH_TMAX ? a1 : LENV_TANH_TMAX};
+            const v2f w = t + (v2f){1.0f, 1.0f};
+            const uint32_t b0 = __float_as_uint(w.x), b1 = __float_as_uint(w.y);
+            constexpr uint32_t keep = ~((1u << LENV_TANH_SHIFT) - 1u);
+            d = w - (v2f){__uint_as_float(b0 & keep), __uint_as_float(b1 & keep)};
+            k0 = det_tanh_lds_gather(tanh_tab, ((b0 >> tl.shift) & tl.mask) | tl.lane_off);
+            k1 = det_tanh_lds_gather(tanh_tab, ((b1 >> tl.shift) & tl.mask) | tl.lane_off);
         }
     }
-    __device__ __forceinline__ float finish(float prelu) const
+    __device__ __forceinline__ v2f finish(float prelu) const
     {
-        if constexpr (ACT == LENV_ACT_TANH) return det_tanh_poly(k, d, z);
-        else return act_fwd_t<ACT>(0u, TanhLds{}, prelu, z);
+        if constexpr (ACT == LENV_ACT_TANH) return (v2f){det_tanh_poly(k0, d.x, z.x), det_tanh_poly(k1, d.y, z.y)};
+        else return (v2f){act_fwd_t<ACT>(0u, TanhLds{}, prelu, z.x), act_fwd_t<ACT>(0u, TanhLds{}, prelu, z.y)};
     }
 };
 
@@ -243,7 +249,10 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     // LDS image of the canonical tanh table at the START of the workgroup's LDS (its base folds into the DS immediate
     // offset): 16 bank-private copies (32 KB, conflict-free gathers) when the shapes leave room, one copy (2 KB) otherwise
     det_tanh_lds_stage(lds, a.tanh16 != 0, tid, NT);
-    const uint32_t tanh_tab = lds_addr_of(lds);        // LDS byte address of the image (0: the dynamic LDS starts there)
+    // LDS byte address of the image: the literal 0 (this kernel has no static LDS, so its dynamic LDS starts at address
+    // 0; a literal lets the gather address be the bare v_and_or result).  Verified below, never assumed silently.
+    constexpr uint32_t tanh_tab = 0u;
+    if (lds_addr_of(lds) != 0u) { if (tid == 0 && a.out.status) a.out.status[blockIdx.x] = -7; return; }
     const TanhLds tl = TanhLds::make(a.tanh16 != 0, lane);
 
     // ---------------- stage the perturbed SE: W = theta + sign*eps[worker]  (GTN_worker.py:165-175) ----------------
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     const bool tape = cfg.rng_mode == LENV_RNG_TAPE;
     int status = 0;
     // counters (all uniform): one eps-uniform draw and one replay append per train step
-    int train_steps = 0, n_act = 0, learn_it = 0, n_test_ep = 0, test_steps = 0;
+    int train_steps = 0, n_act = 0, learn_it = 0, n_test_ep = 0, test_steps = 0, wr_pos = 0;
     double eps_g = cfg.eps_init;
     float *rb = a.replay + chain * a.rb_cap * RS;
     const int rb_cap = (int)a.rb_cap;
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
         spec_valid = false;                               // a reset state has no precomputed candidates
         for (int t = 0; t < cfg.max_steps; ++t) {
             const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;     // ReplayBuffer.size after this add
-            const int new_pos = train_steps % rb_cap;                                       // ReplayBuffer.ptr before this add
+            const int new_pos = wr_pos;                                                     // ReplayBuffer.ptr before this add (== train_steps % rb_cap)
             // ================= phase A =================
             PT_MARK(9);
             if (wave == ENV_WAVE) {
@@ -517,6 +526,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 if (pf_status) status = pf_status;
             }
             ++ep_len; ++train_steps;
+            wr_pos = wr_pos + 1 == rb_cap ? 0 : wr_pos + 1;    // ReplayBuffer.ptr = (ptr + 1) % max_size, without the division
             __syncthreads();                                   // B1
             PT_MARK(2);       // (other waves) phase A incl. wait for the env wave
             const float done_now = ctrl[t & 1];
@@ -567,12 +577,12 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         return z + (v2f){rec[2 * S], rec[2 * S + 1]};
                     };
                     // finish pair jp (its activations were issued one stage earlier) with the output part in r2
-                    auto finish = [&](const ActPipe<QACT> &a0, const ActPipe<QACT> &a1, int jp, bool two) {
+                    auto finish = [&](const ActPipe2<QACT> &ap, int jp, bool two) {
                         float w2[PR - OW2];
 #pragma unroll
                         for (int v = 0; v < N2; ++v) { w2[4 * v] = r2[v].x; w2[4 * v + 1] = r2[v].y; w2[4 * v + 2] = r2[v].z; w2[4 * v + 3] = r2[v].w; }
-                        const float h0 = a0.finish(cfg.q_prelu);
-                        const float h1 = a1.finish(cfg.q_prelu);
+                        const v2f hh = ap.finish(cfg.q_prelu);
+                        const float h0 = hh.x, h1 = hh.y;
                         // output layer: unit 2jp then unit 2jp+1, packed over actions
                         if constexpr (A == 2) {
                             v2f qq = {q[0], q[1]};
@@ -588,45 +598,39 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                             }
                         }
                         if (fwd_pass == 0) {                       // HP is even: 8-byte aligned pair store
-                            if (two) *reinterpret_cast<float2 *>(hrow + 2 * jp) = make_float2(h0, h1);
+                            if (two) *reinterpret_cast<v2f *>(hrow + 2 * jp) = hh;
                             else hrow[2 * jp] = h0;
                         }
                     };
-                    // one pipeline stage: start pair jp+1 into (n0, n1), finish pair jp from (c0, c1).  FULL = steady state
+                    // one pipeline stage: start pair jp+1 into `nxt`, finish pair jp from `cur`.  FULL = steady state
                     // (pair jp+2 exists, pair jp has both units): no conditions, so the stage is straight-line code and the
                     // compiler can count outstanding LDS reads instead of draining them
-                    auto stage = [&](ActPipe<QACT> &c0, ActPipe<QACT> &c1, ActPipe<QACT> &n0, ActPipe<QACT> &n1, int jp, auto full_tag) {
+                    auto stage = [&](ActPipe2<QACT> &cur, ActPipe2<QACT> &nxt, int jp, auto full_tag) {
                         constexpr bool FULL = decltype(full_tag)::value;
                         if (FULL || jp + 1 < npairs) {
-                            const v2f z = layer1();                 // r1 holds pair jp+1
-                            n0.issue(tanh_tab, tl, z.x);
-                            n1.issue(tanh_tab, tl, z.y);
+                            nxt.issue(tanh_tab, tl, layer1());      // r1 holds pair jp+1
                             if (FULL || jp + 2 < npairs) load1(jp + 2);
                         }
-                        finish(c0, c1, jp, FULL || 2 * jp + 1 < Hq);   // r2 holds pair jp
+                        finish(cur, jp, FULL || 2 * jp + 1 < Hq);   // r2 holds pair jp
                         if (FULL || jp + 1 < npairs) load2(jp + 1);
                     };
                     using T = std::true_type;
                     using F = std::false_type;
-                    ActPipe<QACT> pa0, pa1, pb0, pb1;
+                    ActPipe2<QACT> pa, pb;
                     load1(0);
-                    {
-                        const v2f z = layer1();
-                        pa0.issue(tanh_tab, tl, z.x);
-                        pa1.issue(tanh_tab, tl, z.y);
-                    }
+                    pa.issue(tanh_tab, tl, layer1());
                     if (npairs > 1) load1(1);
                     load2(0);
                     int jp = 0;
                     for (; jp + 4 <= npairs; jp += 2) {             // jp+3 < npairs: both stages are steady-state
-                        stage(pa0, pa1, pb0, pb1, jp, T{});
-                        stage(pb0, pb1, pa0, pa1, jp + 1, T{});
+                        stage(pa, pb, jp, T{});
+                        stage(pb, pa, jp + 1, T{});
                     }
                     for (; jp + 2 <= npairs; jp += 2) {             // at most one more double stage, with the tail conditions
-                        stage(pa0, pa1, pb0, pb1, jp, F{});
-                        stage(pb0, pb1, pa0, pa1, jp + 1, F{});
+                        stage(pa, pb, jp, F{});
+                        stage(pb, pa, jp + 1, F{});
                     }
-                    if (jp < npairs) finish(pa0, pa1, jp, 2 * jp + 1 < Hq);
+                    if (jp < npairs) finish(pa, jp, 2 * jp + 1 < Hq);
 #pragma unroll
                     for (int aa = 0; aa < A; ++aa) qres[(fwd_pass * MAX_B + fwd_b) * A + aa] = q[aa] + W[npairs * PR + aa];
                     if (fwd_pass == 0) {
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 if (fwd_active) {
                     // next step: ReplayBuffer.size = min(train_steps + 1, cap), write slot = train_steps % cap
                     const int nsz = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
-                    fetch_row(learn_it + 1, nsz, train_steps % rb_cap);
+                    fetch_row(learn_it + 1, nsz, wr_pos);
                     pf_valid = true;
                 }
                 // ---- batch gradient in micro-chunks: wave c reduces samples [c*chunk, (c+1)*chunk) ----
@@ -695,53 +699,63 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         for (int i = 0; i < S; ++i) gW1[i] = 0.0f;
 #pragma unroll
                         for (int aa = 0; aa < A; ++aa) { gW2[aa] = 0.0f; gb2[aa] = 0.0f; w2j[aa] = jv ? q_onl[(j >> 1) * PR + OW2 + (j & 1) * A + aa] : 0.0f; }
-                        const float *hcol = hB + (jv ? j : 0);
-                        for (int bq = b0; bq < b1; bq += 4) {
-                            // issue every LDS read of up to four samples first, then accumulate them in order
+                        // one sample: everything in canonical order (oracle orc_ddqn_learn)
+                        auto accumulate = [&](float h, const float4 dm4, const float (&sv)[SP]) {
+                            const float dm[3] = {dm4.x, dm4.y, dm4.z};
+                            float da = dm[0] * w2j[0];
+#pragma unroll
+                            for (int aa = 1; aa < A; ++aa) da = fma32(dm[aa], w2j[aa], da);
+                            const float dz = act_bwd_t<QACT>(cfg.q_prelu, h, da);
+                            if constexpr ((S & 1) == 0) {
+#pragma unroll
+                                for (int i = 0; i < S; i += 2) {
+                                    const v2f g = fma2((v2f){dz, dz}, (v2f){sv[i], sv[i + 1]}, (v2f){gW1[i], gW1[i + 1]});
+                                    gW1[i] = g.x; gW1[i + 1] = g.y;
+                                }
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < S; ++i) gW1[i] = fma32(dz, sv[i], gW1[i]);
+                            }
+                            gb1 = gb1 + dz;
+                            if constexpr (A == 2) {
+                                const v2f g2 = fma2((v2f){dm[0], dm[1]}, (v2f){h, h}, (v2f){gW2[0], gW2[1]});
+                                gW2[0] = g2.x; gW2[1] = g2.y;
+                                const v2f gb = (v2f){gb2[0], gb2[1]} + (v2f){dm[0], dm[1]};
+                                gb2[0] = gb.x; gb2[1] = gb.y;
+                            } else {
+#pragma unroll
+                                for (int aa = 0; aa < A; ++aa) { gW2[aa] = fma32(dm[aa], h, gW2[aa]); gb2[aa] = gb2[aa] + dm[aa]; }
+                            }
+                        };
+                        auto load_s = [&](const float *sp, float (&sv)[SP]) {
+#pragma unroll
+                            for (int v = 0; v < SP / 4; ++v) {
+                                const float4 f = *reinterpret_cast<const float4 *>(sp + 4 * v);
+                                sv[4 * v] = f.x; sv[4 * v + 1] = f.y; sv[4 * v + 2] = f.z; sv[4 * v + 3] = f.w;
+                            }
+                        };
+                        // running pointers (one add per round each): h column of this lane, dq rows and state rows of the chunk
+                        const float *hp = hB + (jv ? j : 0) + b0 * HP, *dqp = dqB + 4 * b0, *sp = sB + SP * b0;
+                        int bq = b0;
+                        for (; bq + 4 <= b1; bq += 4, hp += 4 * HP, dqp += 16, sp += 4 * SP) {
+                            // whole groups of four samples: every LDS read is issued before the first use
                             float hv[4], sv[4][SP];
                             float4 dmv[4];
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
-                                const int bb = bq + u < b1 ? bq + u : b1 - 1;
-                                hv[u] = hcol[bb * HP];
-                                dmv[u] = *reinterpret_cast<const float4 *>(dqB + 4 * bb);
-#pragma unroll
-                                for (int v = 0; v < SP / 4; ++v) {
-                                    const float4 f = *reinterpret_cast<const float4 *>(sB + bb * SP + 4 * v);
-                                    sv[u][4 * v] = f.x; sv[u][4 * v + 1] = f.y; sv[u][4 * v + 2] = f.z; sv[u][4 * v + 3] = f.w;
-                                }
+                                hv[u] = hp[u * HP];
+                                dmv[u] = *reinterpret_cast<const float4 *>(dqp + 4 * u);
+                                load_s(sp + SP * u, sv[u]);
                             }
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                if (bq + u < b1) {
-                                    const float h = hv[u];
-                                    const float dm[3] = {dmv[u].x, dmv[u].y, dmv[u].z};
-                                    float da = dm[0] * w2j[0];
-#pragma unroll
-                                    for (int aa = 1; aa < A; ++aa) da = fma32(dm[aa], w2j[aa], da);
-                                    const float dz = act_bwd_t<QACT>(cfg.q_prelu, h, da);
-                                    if constexpr ((S & 1) == 0) {
-#pragma unroll
-                                        for (int i = 0; i < S; i += 2) {
-                                            const v2f g = fma2((v2f){dz, dz}, (v2f){sv[u][i], sv[u][i + 1]}, (v2f){gW1[i], gW1[i + 1]});
-                                            gW1[i] = g.x; gW1[i + 1] = g.y;
-                                        }
-                                    } else {
-#pragma unroll
-                                        for (int i = 0; i < S; ++i) gW1[i] = fma32(dz, sv[u][i], gW1[i]);
-                                    }
-                                    gb1 = gb1 + dz;
-                                    if constexpr (A == 2) {
-                                        const v2f g2 = fma2((v2f){dm[0], dm[1]}, (v2f){h, h}, (v2f){gW2[0], gW2[1]});
-                                        gW2[0] = g2.x; gW2[1] = g2.y;
-                                        const v2f gb = (v2f){gb2[0], gb2[1]} + (v2f){dm[0], dm[1]};
-                                        gb2[0] = gb.x; gb2[1] = gb.y;
-                                    } else {
-#pragma unroll
-                                        for (int aa = 0; aa < A; ++aa) { gW2[aa] = fma32(dm[aa], h, gW2[aa]); gb2[aa] = gb2[aa] + dm[aa]; }
-                                    }
-                                }
-                            }
+                            for (int u = 0; u < 4; ++u) accumulate(hv[u], dmv[u], sv[u]);
+                        }
+                        for (; bq < b1; ++bq, hp += HP, dqp += 4, sp += SP) {       // chunk tail
+                            float sv[SP];
+                            const float h = hp[0];
+                            const float4 dm4 = *reinterpret_cast<const float4 *>(dqp);
+                            load_s(sp, sv);
+                            accumulate(h, dm4, sv);
                         }
                         if (jv) {
 #pragma unroll

@@ -76,8 +76,10 @@ __device__ __forceinline__ uint32_t det_tanh_lds_off(const TanhArg &a, const Tan
 // the image at LDS address 0 the whole computation is v_lshrrev + v_and_or and the DS instruction needs no base add.
 __device__ __forceinline__ float4 det_tanh_lds_gather(uint32_t img_addr, uint32_t off)
 {
-    typedef __attribute__((address_space(3))) const float4 lds_f4;
-    return *reinterpret_cast<lds_f4 *>(static_cast<uintptr_t>(img_addr + off));
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const f4v lds_f4;
+    const f4v v = *reinterpret_cast<lds_f4 *>(static_cast<uintptr_t>(img_addr + off));
+    return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const float *p)
 {
