@@ -68,6 +68,21 @@ struct InnerArgs {
         o_dqB, o_qres, o_part, o_newrow, o_ctrl, o_ret, o_tanh, o_cand, o_cur_state, lds_floats;
 };
 
+// Workgroup-internal flag in LDS: the env wave publishes "phase A of step `tag` is done" while the other waves are already
+// in the minibatch forward; only waves that need its results poll.  LDS operations of one wave execute in order, so every
+// LDS write the env wave issued before the flag store is visible to a wave that has read the new flag value.
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ void lds_flag_store(float *p, int tag)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    *(volatile lds_int *)((lds_int *)p) = tag;
+}
+__device__ __forceinline__ void lds_flag_wait(const float *p, int tag)
+{
+    while (*(volatile lds_int *)((lds_int *)const_cast<float *>(p)) != tag) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -342,12 +357,16 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
         auto se_hidden = [&](auto act_tag) {
             constexpr int SEACT = decltype(act_tag)::value;
             for (int uu = lane; uu < 3 * Hse; uu += 64) {
-                const int net = uu / Hse, j = uu - net * Hse;
-                const float *w = se_w0T + net * K * Hse + j;
+                const int net = (uu >= Hse ? 1 : 0) + (uu >= 2 * Hse ? 1 : 0), j = uu - net * Hse;   // no division
+                const float *w = se_w0T + net * (K * Hse) + j;
+                float wv[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) { wv[k] = *w; w += Hse; }      // every weight read in flight before the chain
+                const float bias = se_b0[uu];
                 float z = 0.0f;
 #pragma unroll
-                for (int k = 0; k < K; ++k) z = fma32(x[k], w[k * Hse], z);
-                z = z + se_b0[uu];
+                for (int k = 0; k < K; ++k) z = fma32(x[k], wv[k], z);
+                z = z + bias;
                 hbuf[net * HseP + j] = act_fwd_t<SEACT>(tanh_tab, tl, cfg.se_prelu, z);
             }
         };
@@ -467,6 +486,11 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
             const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;     // ReplayBuffer.size after this add
             const int new_pos = wr_pos;                                                     // ReplayBuffer.ptr before this add (== train_steps % rb_cap)
             // ================= phase A =================
+            // In a learning episode there is NO barrier after phase A: the other waves go straight from the previous step's
+            // Adam barrier into this step's minibatch forward (their rows were prefetched, the weights are final) while the env
+            // wave acts, steps the SE and appends; it then publishes step_tag in ctrl[5].  Only a wave that sampled the very
+            // row being appended, and the speculation wave (needs the new state), wait for that flag.
+            const int step_tag = train_steps + 1;
             PT_MARK(9);
             if (wave == ENV_WAVE) {
                 // ---- select_train_action (DDQN.py:97-104) ----
@@ -519,17 +543,18 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 }
 #pragma unroll
                 for (int i = 0; i < S; ++i) state[i] = next_state[i];
+                if (learning && lane == 0) lds_flag_store(ctrl + 5, step_tag);
                 PT_MARK(1);   // (env wave) SE step + append
             } else if (learning && fwd_active) {
                 if (!pf_valid) fetch_row(learn_it, size_after, new_pos);     // first learn step: nothing was prefetched
                 pf_valid = false;
                 if (pf_status) status = pf_status;
+                if (__builtin_amdgcn_ballot_w64(my_idx == new_pos) != 0) lds_flag_wait(ctrl + 5, step_tag);   // needs newrow
             }
             ++ep_len; ++train_steps;
             wr_pos = wr_pos + 1 == rb_cap ? 0 : wr_pos + 1;    // ReplayBuffer.ptr = (ptr + 1) % max_size, without the division
-            __syncthreads();                                   // B1
-            PT_MARK(2);       // (other waves) phase A incl. wait for the env wave
-            const float done_now = ctrl[t & 1];
+            if (!learning) __syncthreads();                    // B1 (init episodes only: nothing else to overlap with)
+            PT_MARK(2);
 
             if (learning) {
                 // ================= learn: DDQN.learn (DDQN.py:60-94) =================
@@ -638,7 +663,9 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         for (int i = 0; i < S; ++i) sB[fwd_b * SP + i] = row[i];
                         rda[fwd_b * 4 + 0] = row[2 * S + 1]; rda[fwd_b * 4 + 1] = row[2 * S + 2]; rda[fwd_b * 4 + 2] = row[S];
                     }
-                } else if (wave >= first_spec && done_now <= 0.5f) {
+                } else if (wave >= first_spec) {
+                    if (wave != ENV_WAVE) lds_flag_wait(ctrl + 5, step_tag);       // cur_state / done of this step
+                  if (ctrl[t & 1] <= 0.5f) {
                     // ---- speculative SE step of the NEXT env step for every action (this wave's share) ----
                     float st[S];
 #pragma unroll
@@ -647,10 +674,11 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         const float acc = se_eval(se_hw, st, act);
                         if (lane < S + 2) cand[act * 16 + lane] = acc;
                     }
-                }
-                if (wave == ENV_WAVE && !fwd_active && done_now <= 0.5f && t + 1 < cfg.max_steps) {
-                    draw_action(train_steps);                  // train_steps already counts this step: index of the next one
-                    nx_valid = true;
+                    if (wave == ENV_WAVE && t + 1 < cfg.max_steps) {
+                        draw_action(train_steps);              // train_steps already counts this step: index of the next one
+                        nx_valid = true;
+                    }
+                  }
                 }
                 PT_OWN(0);
                 __syncthreads();                               // B2
@@ -818,7 +846,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 PT_MARK(6);
             }
             spec_valid = learning && n_spec > 0;
-            if (done_now > 0.5f) break;                        // base_agent.py:128
+            if (ctrl[t & 1] > 0.5f) break;                     // base_agent.py:128 (slot written in this step's phase A, behind B1/B2)
         }
         ++episodes_run;
         if (tid == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;

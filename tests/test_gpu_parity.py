@@ -472,7 +472,7 @@ def test_td3_tape_mode_vs_reference_and_oracle(eng, orc, golden):
         # against the reference's own run (continuous control: tolerances of tests/test_oracle_golden.py)
         np.testing.assert_allclose(il.trace["action"][c, :n].cpu().numpy(), g["tr_action"], rtol=0, atol=2e-5)
         np.testing.assert_allclose(il.trace["reward"][c, :n].cpu().numpy(), g["tr_reward"], rtol=0, atol=5e-5)
-        assert abs(float(il.score[c]) - float(g["score"])) <= 2e-3
+        assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4        # north_star bar (measured 2.4e-7)
 
 
 @pytest.mark.parametrize("hidden,layers,batch,act,delay,rtype", [(128, 2, 192, "relu", 1, 2), (40, 1, 50, "tanh", 2, 1), (33, 2, 130, "leakyrelu", 3, 6),
@@ -585,6 +585,126 @@ def test_inner_loop_full_size_properties(eng, orc):
     for c in (1, 95):                                                   # whole chains against the oracle at full size
         w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
         o = orc.ddqn_se_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]))
+        assert float(base[0][c]) == o["score"]
+        assert base[1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(base[2][c], o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(base[3][c], o["final_test_returns"])
+
+
+def _oracle_chains_parallel(fn, jobs):
+    """Run the (GIL-releasing) oracle on several whole chains at once."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        return list(ex.map(lambda j: fn(*j), jobs))
+
+
+@pytest.mark.timeout(900)
+def test_dueling_full_size_properties(eng, orc):
+    """BASELINE configs[2] at its real shapes -- Acrobot SE 9-128-{6,1,1}, DuelingDDQN 6-128-128-128 / 128-128-{1,3}
+    (67 460 parameters), B = 128, 500-step episodes, 10 real-env test episodes -- on 96 chains (32 workers = one 8-GPU rank's
+    share of pop 256): one full-length 500-step exploration episode + one full-length 500-step learning episode.
+      * determinism, chain independence (permutation), antithetic symmetry -- bit for bit;
+      * two whole chains against the oracle: score, counters, per-episode test means, final returns -- bit for bit."""
+    from learning_environments_amd import configs
+    from learning_environments_amd.config import ddqn_cfg_from_config
+    cfgd = configs.fixed_work(configs.acrobot_syn_env_duelingddqn(32), 2)
+    cfgd["agents"]["duelingddqn"]["init_episodes"] = 1
+    cfg = ddqn_cfg_from_config(cfgd)
+    ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=0)
+    assert (cfg.q_hidden, cfg.q_layers, cfg.feature_dim, cfg.batch_size, cfg.max_steps, cfg.se_hidden) == (128, 2, 128, 128, 500, 128)
+    S, A, pop = cfg.state_dim, cfg.num_actions, 32
+    chains = 3 * pop
+    rng = np.random.RandomState(21)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, cfg.se_hidden, 1, "leakyrelu"))
+    P_q = orc.dueling_num_params(ocfg)
+    assert P_q == 67460
+    theta = (rng.randn(P_se) * 0.1).astype(np.float32)
+    theta[-1] = -10.0                                   # done-net output bias: the SE never terminates -> full-length episodes
+    eps = (rng.randn(pop, P_se) * 0.05).astype(np.float32)
+    agent_init = rng.uniform(-0.08, 0.08, (chains, P_q)).astype(np.float32)
+    worker = np.repeat(np.arange(pop), 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), pop)
+    keys = np.array([orc.chain_key(77, 3, int(worker[c]), c % 3) for c in range(chains)], np.uint64)
+
+    def run(theta_, eps_, worker_, sign_, init_, keys_):
+        il = eng.InnerLoop(cfg, chains)
+        il.run(dev(theta_), dev(eps_), dev(worker_), dev(sign_), dev(init_), rng_keys=dev(keys_.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return (il.score.cpu().numpy().copy(), il.stats.cpu().numpy().copy(), il.episode_test_mean.cpu().numpy().copy(),
+                il.final_returns.cpu().numpy().copy())
+
+    base = run(theta, eps, worker, sign, agent_init, keys)
+    assert (base[1][:, 1] == 1000).all() and (base[1][:, 2] == 500).all()      # 2 x 500 env steps, 500 learn steps per chain
+    again = run(theta, eps, worker, sign, agent_init, keys)
+    for a, b in zip(base, again):
+        assert np.array_equal(a, b, equal_nan=True)
+    perm = rng.permutation(chains)
+    permuted = run(theta, eps, worker[perm], sign[perm], agent_init[perm], keys[perm])
+    for a, b in zip(base, permuted):
+        assert np.array_equal(a[perm], b, equal_nan=True)
+    flipped = run(theta, -eps, worker, -sign, agent_init, keys)
+    for a, b in zip(base, flipped):
+        assert np.array_equal(a, b, equal_nan=True)
+    picks = (4, 95)
+    outs = _oracle_chains_parallel(
+        lambda c: orc.ddqn_se_chain(ocfg, (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32), agent_init[c], rng_key=int(keys[c])),
+        [(c,) for c in picks])
+    for c, o in zip(picks, outs):
+        assert float(base[0][c]) == o["score"]
+        assert base[1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(base[2][c], o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(base[3][c], o["final_test_returns"])
+
+
+@pytest.mark.timeout(1200)
+def test_td3_full_size_properties(eng, orc):
+    """BASELINE configs[4] at its real shapes -- RewardEnv 17-128-1 (type 2) on the HalfCheetah stand-in, TD3 actor
+    17-128-128-6 + twin critics 23-128-128-1 (59 016 parameters), B = 192, 1000-step episodes -- on 96 chains: one full-length
+    1000-step random-action episode + one full-length 1000-step learning episode.  Same properties as the cfg-3 test."""
+    from learning_environments_amd import configs
+    cfgd = configs.fixed_work(configs.halfcheetah_reward_env_td3(32), 2)
+    cfgd["agents"]["td3"]["init_episodes"] = 1
+    ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
+    assert (cfg.hidden, cfg.layers, cfg.batch_size, cfg.max_steps, cfg.rn_hidden) == (128, 2, 192, 1000, 128)
+    Pa, Pc = orc.td3_param_counts(ocfg)
+    assert Pa + 2 * Pc == 59016
+    P_rn = orc.rn_num_params(2, 17, 4, ocfg.rn_hidden, 1)
+    pop = 32
+    chains = 3 * pop
+    rng = np.random.RandomState(31)
+    theta = (rng.randn(P_rn) * 0.2).astype(np.float32)
+    eps = (rng.randn(pop, P_rn) * 0.1).astype(np.float32)
+    agent_init = rng.uniform(-0.08, 0.08, (chains, Pa + 2 * Pc)).astype(np.float32)
+    worker = np.repeat(np.arange(pop), 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), pop)
+    keys = np.array([orc.chain_key(78, 1, int(worker[c]), c % 3) for c in range(chains)], np.uint64)
+
+    def run(theta_, eps_, worker_, sign_, init_, keys_):
+        il = eng.Td3InnerLoop(cfg, chains)
+        il.run(dev(theta_), dev(eps_), dev(worker_), dev(sign_), dev(init_), rng_keys=dev(keys_.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return (il.score.cpu().numpy().copy(), il.stats.cpu().numpy().copy(), il.episode_test_mean.cpu().numpy().copy(),
+                il.final_returns.cpu().numpy().copy())
+
+    base = run(theta, eps, worker, sign, agent_init, keys)
+    assert (base[1][:, 1] == 2000).all() and (base[1][:, 2] == 1000).all()
+    again = run(theta, eps, worker, sign, agent_init, keys)
+    for a, b in zip(base, again):
+        assert np.array_equal(a, b, equal_nan=True)
+    perm = rng.permutation(chains)
+    permuted = run(theta, eps, worker[perm], sign[perm], agent_init[perm], keys[perm])
+    for a, b in zip(base, permuted):
+        assert np.array_equal(a[perm], b, equal_nan=True)
+    flipped = run(theta, -eps, worker, -sign, agent_init, keys)
+    for a, b in zip(base, flipped):
+        assert np.array_equal(a, b, equal_nan=True)
+    picks = (7, 92)
+    outs = _oracle_chains_parallel(
+        lambda c: orc.td3_rn_chain(ocfg, (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32), agent_init[c], rng_key=int(keys[c])),
+        [(c,) for c in picks])
+    for c, o in zip(picks, outs):
         assert float(base[0][c]) == o["score"]
         assert base[1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
         assert np.array_equal(base[2][c], o["episode_test_mean"], equal_nan=True)

@@ -349,9 +349,10 @@ def test_g8t_calc_score_cheetah_td3(golden):
     np.testing.assert_allclose(tr["next_state"], g["tr_next_state"], rtol=0, atol=5e-5)
     np.testing.assert_allclose(tr["reward"], g["tr_reward"], rtol=0, atol=5e-5)
     assert np.array_equal(out["episode_len"], g["episode_length_train"])
-    np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=2e-3)
-    np.testing.assert_allclose(out["final_test_returns"], g["reward_list_test"], rtol=0, atol=2e-3)
-    assert abs(out["score"] - float(g["score"])) <= 2e-3
+    # north_star: returns within 1e-4 of the reference (measured here: 2.4e-7 on the score)
+    np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out["final_test_returns"], g["reward_list_test"], rtol=0, atol=1e-4)
+    assert abs(out["score"] - float(g["score"])) <= 1e-4
 
 
 def _standin_rollout(g, t):
