@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LENV_ABI_VERSION 1
+#define LENV_ABI_VERSION 2
 
 enum {
     LENV_OK = 0,
@@ -68,6 +68,12 @@ typedef struct {
     double gamma, lr, tau;
     double eps_init, eps_min, eps_decay;
     double adam_beta1, adam_beta2, adam_eps;
+    /* Deterministic stand-in for the wall-clock time-out of BaseAgent.train/test (agents/base_agent.py:30-47,90-97,177-184):
+     * "elapsed" = env steps (train + test) this chain has taken.  <= 0: no budget.  At the start of a training episode with
+     * elapsed > step_budget the per-episode reward list is padded with its minimum so far (-1e9 if empty) and training
+     * stops; the final test gets the remainder and pads its returns the same way (so a chain that timed out in training
+     * scores -1e9, as the reference does).  Supported by lenv_ddqn_se_inner_loop; the other kernels return UNSUPPORTED. */
+    int64_t step_budget;
 } lenv_ddqn_cfg;
 
 /* RNG tapes (parity mode).  Per-chain rows: element [c*stride + n]; all DEVICE pointers. */

@@ -33,7 +33,8 @@ class DdqnCfg(C.Structure):
                 ("agent_kind", C.c_int32), ("feature_dim", C.c_int32),
                 ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
                 ("eps_init", C.c_double), ("eps_min", C.c_double), ("eps_decay", C.c_double),
-                ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
+                ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
+                ("step_budget", C.c_int64)]
 
 
 class Tapes(C.Structure):
@@ -179,7 +180,7 @@ def lib():
         L.lenv_nes_rank_update.restype = C.c_int
         L.lenv_nes_rank_update.argtypes = [C.c_int32, vp, vp, C.c_int64, vp, vp, C.c_int64, C.c_double, C.c_int32,
                                            C.c_double, vp, vp]
-        if L.lenv_abi_version() != 1:
+        if L.lenv_abi_version() != 2:
             raise LenvError("liblenv_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -37,7 +37,8 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
                        solved_reward=float(val(e["solved_reward"])),
                        gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), eps_init=float(a["eps_init"]),
                        eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]),
-                       adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8)
+                       adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
+                       step_budget=int(a.get("step_budget", 0)))      # env-step stand-in for time_remaining (base_agent.py:30-47)
     for k, v in overrides.items():
         setattr(cfg, k, v)
     if cfg.grad_chunk == 0 and cfg.agent_kind == 0:

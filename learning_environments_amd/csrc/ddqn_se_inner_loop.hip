@@ -261,6 +261,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     float *qres = lds + a.o_qres, *part = lds + a.o_part, *newrow = lds + a.o_newrow;
     float *ctrl = lds + a.o_ctrl;            // [0..1] done (double buffered by step parity), [2] break, [8..] wave step counts (every use is barrier-separated)
     double *ret = reinterpret_cast<double *>(lds + a.o_ret);   // [test_episodes] returns
+    int *tlen = reinterpret_cast<int *>(lds + a.o_ret + 2 * cfg.test_episodes);   // [test_episodes] lengths of the last test phase
     // LDS image of the canonical tanh table at the START of the workgroup's LDS (its base folds into the DS immediate
     // offset): 16 bank-private copies (32 KB, conflict-free gathers) when the shapes leave room, one copy (2 KB) otherwise
     det_tanh_lds_stage(lds, a.tanh16 != 0, tid, NT);
@@ -401,6 +402,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     st[i] = -reset_lim + (2 * reset_lim) * u64_to_unit(rng_u64(key, STREAM_TEST_RESET, (uint64_t)(row * 4 + i)));
             }
             float ep_reward = 0.0f;
+            int ep_steps = 0;
             for (int t = 0; t < cfg.max_steps; ++t) {
                 float obs[S];
                 real_env_obs<ENV, S>(st, obs);
@@ -408,10 +410,10 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 double rew; int done;
                 real_env_step<ENV>(st, act, rew, done);
                 ep_reward = ep_reward + (float)rew;
-                ++my_steps;
+                ++my_steps; ++ep_steps;
                 if (done) break;
             }
-            if (lane == 0) ret[te] = (double)ep_reward;
+            if (lane == 0) { ret[te] = (double)ep_reward; tlen[te] = ep_steps; }
         }
         if (lane == 0) ctrl[8 + wave] = __int_as_float(my_steps);
         n_test_ep += cfg.test_episodes;
@@ -460,8 +462,12 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
         }
     };
 
+    // Deterministic time-out (lenv_ddqn_cfg::step_budget, base_agent.py:30-47): elapsed = env steps taken so far
+    const bool budgeted = cfg.step_budget > 0;
+    int timed_out_at = -1;
     PT_DECL;
     for (int episode = 0; episode < cfg.train_episodes; ++episode) {
+        if (budgeted && (int64_t)train_steps + test_steps > cfg.step_budget) { timed_out_at = episode; break; }   // uniform
         // DDQN.update_parameters_per_episode (DDQN.py:112-117)
         if (episode == 0) eps_g = cfg.eps_init;
         else { eps_g *= cfg.eps_decay; if (eps_g < cfg.eps_min) eps_g = cfg.eps_min; }
@@ -880,7 +886,28 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     }
 
     // ---- final test (GTN_worker.py:199) and score = statistics.mean(reward_list_test) ----
+    const int64_t remaining = cfg.step_budget - ((int64_t)train_steps + test_steps);     // time_remaining - elapsed
+    const int test_before = test_steps;
     test_phase();
+    if (budgeted) {
+        // BaseAgent.test under the time-out: episode e starts only while the earlier episodes of this test used <= remaining
+        // steps; the rest of the list is padded with the minimum so far (-1e9 if empty).  Episodes are independent, so the
+        // list rolled out above is cut here.
+        if (tid == 0) {
+            int64_t used = 0;
+            int stop = cfg.test_episodes;
+            for (int te = 0; te < cfg.test_episodes; ++te) {
+                if (used > remaining) { stop = te; break; }
+                used += tlen[te];
+            }
+            double mn = -1e9;
+            if (stop > 0) { mn = ret[0]; for (int i = 1; i < stop; ++i) if (ret[i] < mn) mn = ret[i]; }
+            for (int te = stop; te < cfg.test_episodes; ++te) ret[te] = mn;
+            ctrl[6] = __int_as_float((int)used);
+        }
+        __syncthreads();
+        test_steps = test_before + __float_as_int(ctrl[6]);
+    }
 #ifdef LENV_PHASE_TIMING
     if (tid == 0) PT_FLUSH(0, 10);
     if (tid == ENV_WAVE * 64) { if (chain == 0) { g_phase_cycles[10] = pt_acc[0]; g_phase_cycles[11] = pt_acc[1]; } }
@@ -898,10 +925,21 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
             a.out.stats[chain * 4 + 0] = episodes_run; a.out.stats[chain * 4 + 1] = train_steps;
             a.out.stats[chain * 4 + 2] = learn_it; a.out.stats[chain * 4 + 3] = test_steps;
         }
-        const double nan = __builtin_nan("");
+        // episodes that never ran: NaN / 0, or -- after a time-out -- time_is_up's padding (base_agent.py:33-44): rewards
+        // with the minimum so far (-1e9 if none), lengths with the maximum so far (1e9 if none)
+        double pad_r = __builtin_nan("");
+        int pad_l = 0;
+        if (timed_out_at >= 0) {
+            pad_r = -1e9; pad_l = 1000000000;
+            if (episodes_run > 0) { pad_r = meter[0]; for (int i = 1; i < episodes_run; ++i) if (meter[i] < pad_r) pad_r = meter[i]; }
+            if (episodes_run > 0 && a.out.episode_len) {
+                pad_l = a.out.episode_len[chain * cfg.train_episodes];
+                for (int i = 1; i < episodes_run; ++i) { const int l = a.out.episode_len[chain * cfg.train_episodes + i]; if (l > pad_l) pad_l = l; }
+            }
+        }
         for (int e = episodes_run; e < cfg.train_episodes; ++e) {
-            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + e] = nan;
-            if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = 0;
+            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + e] = pad_r;
+            if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = pad_l;
         }
     }
     if (a.out.final_online) {
@@ -998,7 +1036,7 @@ static int inner_layout(const lenv_ddqn_cfg *cfg, InnerArgs &a)
         a.o_qres = take(3 * MAX_B * A);
         a.o_part = take(a.n_chunks4 * a.P_q);
         a.o_newrow = take(16); a.o_ctrl = take(8 + NW);
-        a.o_ret = take(2 * cfg->test_episodes + 2);
+        a.o_ret = take(3 * cfg->test_episodes + 2);
         a.o_cand = take(16 * A); a.o_cur_state = take(16);
         a.lds_floats = o;
         if ((size_t)o * sizeof(float) <= 160 * 1024) return LENV_OK;

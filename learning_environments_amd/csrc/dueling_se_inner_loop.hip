@@ -516,6 +516,7 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     // the agent's shared nn.PReLU slope is a TRAINED parameter in the reference (model.parameters() -> Adam); a fixed slope
     // would diverge silently, so agent-net PReLU is refused (SE / reward nets keep theirs: the reference never updates those)
     if (cfg->q_act == LENV_ACT_PRELU) return LENV_ERR_UNSUPPORTED;
+    if (cfg->step_budget > 0) return LENV_ERR_UNSUPPORTED;                           // the env-step time-out lives in the DDQN kernel only
     if (cfg->grad_chunk != 0 && cfg->grad_chunk < B) return LENV_ERR_UNSUPPORTED;   // batch gradient = one sequential chunk here
     if (L < 1 || L > D_MAXL || H < 1 || H > D_MAXW || F < 1 || F > D_MAXW || B < 1 || B > GT_I || T < 1 || T > GT_I || cfg->se_layers != 1)
         return LENV_ERR_UNSUPPORTED;

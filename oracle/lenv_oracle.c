@@ -816,6 +816,38 @@ static void run_test_phase(const orc_ddqn_cfg *cfg, const orc_mlp_desc *qd, cons
     }
 }
 
+/* BaseAgent.test under a time-out (base_agent.py:177-184 + time_is_up :30-47) with the env-step budget standing in for
+ * wall-clock: episode e starts only while the steps of this test's earlier episodes do not exceed `remaining`; from the
+ * first episode that may not start, the returns are padded with the minimum so far (-1e9 if there is none).  The episodes
+ * are independent, so all of them are rolled out and the list is cut afterwards; *test_steps counts the ones that ran. */
+static void run_test_phase_budget(const orc_ddqn_cfg *cfg, const orc_mlp_desc *qd, const float *online, rng_state *rng,
+                                  double *returns, int64_t *test_steps, float (*z)[ORC_MAX_WIDTH], float (*a)[ORC_MAX_WIDTH],
+                                  int64_t remaining)
+{
+    int64_t used = 0;
+    int stop = cfg->test_episodes;
+    int64_t *len = malloc(sizeof(int64_t) * (cfg->test_episodes > 0 ? cfg->test_episodes : 1));
+    for (int te = 0; te < cfg->test_episodes; ++te) {
+        int64_t steps = 0;
+        double r1;
+        /* one episode at a time through the ordinary phase code (test_episodes = 1 view) */
+        orc_ddqn_cfg one = *cfg; one.test_episodes = 1;
+        run_test_phase(&one, qd, online, rng, &r1, &steps, z, a);
+        returns[te] = r1; len[te] = steps;
+    }
+    for (int te = 0; te < cfg->test_episodes; ++te) {
+        if (used > remaining) { stop = te; break; }
+        used += len[te];
+    }
+    for (int te = stop; te < cfg->test_episodes; ++te) {
+        double mn = -1e9;
+        if (stop > 0) { mn = returns[0]; for (int i = 1; i < stop; ++i) if (returns[i] < mn) mn = returns[i]; }
+        returns[te] = mn;
+    }
+    *test_steps += used;
+    free(len);
+}
+
 static double mean_seq(const double *v, int n)
 {
     double s = 0.0;
@@ -861,7 +893,11 @@ int orc_ddqn_se_chain(const orc_ddqn_cfg *cfg, const float *se_params, const flo
     int n_meter = 0, episodes_run = 0;
     if (trace) trace->n = 0;
 
+    const int budgeted = cfg->step_budget > 0;
+    int timed_out_at = -1;
     for (int episode = 0; episode < cfg->train_episodes; ++episode) {
+        /* time_is_up (base_agent.py:90-97): elapsed = env steps taken so far (train + test) */
+        if (budgeted && train_steps + test_steps > cfg->step_budget) { timed_out_at = episode; break; }
         /* DDQN.update_parameters_per_episode (DDQN.py:112-117) */
         if (episode == 0) eps = cfg->eps_init;
         else { eps *= cfg->eps_decay; if (eps < cfg->eps_min) eps = cfg->eps_min; }
@@ -930,12 +966,25 @@ int orc_ddqn_se_chain(const orc_ddqn_cfg *cfg, const float *se_params, const flo
             if (avg >= cfg->solved_reward) break;
         }
     }
-    for (int e = episodes_run; e < cfg->train_episodes; ++e) {
-        if (episode_test_mean) episode_test_mean[e] = NAN;
-        if (episode_len) episode_len[e] = 0;
+    if (timed_out_at >= 0) {
+        /* time_is_up padding (base_agent.py:33-44): rewards with the minimum so far (-1e9 if none), lengths with the maximum
+         * so far (1e9 if none) */
+        double mn = -1e9; int mx = 1000000000;
+        if (n_meter > 0) { mn = meter[0]; for (int i = 1; i < n_meter; ++i) if (meter[i] < mn) mn = meter[i]; }
+        if (episodes_run > 0 && episode_len) { mx = episode_len[0]; for (int i = 1; i < episodes_run; ++i) if (episode_len[i] > mx) mx = episode_len[i]; }
+        for (int e = episodes_run; e < cfg->train_episodes; ++e) {
+            if (episode_test_mean) episode_test_mean[e] = mn;
+            if (episode_len) episode_len[e] = mx;
+        }
+    } else {
+        for (int e = episodes_run; e < cfg->train_episodes; ++e) {
+            if (episode_test_mean) episode_test_mean[e] = NAN;
+            if (episode_len) episode_len[e] = 0;
+        }
     }
-    /* final test (GTN_worker.py:199) */
-    run_test_phase(cfg, &qd, online, &rng, test_returns, &test_steps, z, a);
+    /* final test (GTN_worker.py:199) with the time that is left (GTN_worker.py:199 time_remaining - elapsed) */
+    if (budgeted) run_test_phase_budget(cfg, &qd, online, &rng, test_returns, &test_steps, z, a, cfg->step_budget - (train_steps + test_steps));
+    else run_test_phase(cfg, &qd, online, &rng, test_returns, &test_steps, z, a);
     if (final_test_returns) memcpy(final_test_returns, test_returns, sizeof(double) * cfg->test_episodes);
     if (res) {
         res->score = mean_seq(test_returns, cfg->test_episodes);

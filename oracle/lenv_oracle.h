@@ -68,6 +68,7 @@ typedef struct {
     double gamma, lr, tau;
     double eps_init, eps_min, eps_decay;
     double adam_beta1, adam_beta2, adam_eps;
+    int64_t step_budget;   /* see include/lenv_hip.h: env-step budget standing in for time_remaining (base_agent.py:30-47) */
 } orc_ddqn_cfg;
 
 /* RNG tapes (parity mode): values the reference drew, in per-stream order. */

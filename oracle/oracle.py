@@ -31,7 +31,8 @@ class DdqnCfg(C.Structure):
                 ("agent_kind", C.c_int32), ("feature_dim", C.c_int32),
                 ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
                 ("eps_init", C.c_double), ("eps_min", C.c_double), ("eps_decay", C.c_double),
-                ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
+                ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
+                ("step_budget", C.c_int64)]
 
 
 class Tapes(C.Structure):
@@ -345,7 +346,8 @@ def ddqn_cfg_from_config(config, grad_chunk=13, rng_mode=0, **overrides):
                   early_out_num=int(a["early_out_num"]), grad_chunk=grad_chunk, rng_mode=rng_mode,
                   solved_reward=float(e["solved_reward"]), gamma=float(a["gamma"]), lr=float(a["lr"]),
                   tau=float(a["tau"]), eps_init=float(a["eps_init"]), eps_min=float(a["eps_min"]),
-                  eps_decay=float(a["eps_decay"]), adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8)
+                  eps_decay=float(a["eps_decay"]), adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
+                  step_budget=int(a.get("step_budget", 0)))
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg

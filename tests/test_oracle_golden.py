@@ -409,3 +409,41 @@ def test_g6m_worker_best_multi(golden):
     b1, s1 = orc.worker_best_multi(g["score_add"][:, :1], g["score_sub"][:, :1], True, "mean")
     b0, s0 = orc.worker_best(g["score_add"][:, 0], g["score_sub"][:, 0], True)
     assert np.array_equal(b1, b0) and np.array_equal(s1, s0)
+
+
+def test_step_budget_semantics():
+    """lenv_ddqn_cfg::step_budget, the env-step stand-in for BaseAgent's wall-clock time-out (base_agent.py:30-47,90-97,
+    177-184): no budget == huge budget; a budget of one step stops after the first episode, pads the reward list with that
+    episode's value and makes the final test return -1e9 (the reference pads an empty list with -1e9); more budget never
+    runs fewer episodes."""
+    from learning_environments_amd import configs
+    cfgd = configs.fixed_work(configs.cartpole_syn_env_ddqn(2), 5)
+    cfgd["envs"]["CartPole-v0"]["max_steps"] = 14
+    cfgd["agents"]["ddqn"].update(test_episodes=4, batch_size=24, hidden_size=20)
+    rng = np.random.RandomState(3)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(4, 2, 83, 1, "leakyrelu"))
+    theta = (rng.randn(P_se) * 0.15).astype(np.float32)
+    theta[-1] = -10.0
+    init = rng.uniform(-0.4, 0.4, orc.mlp_num_params(orc.mlp_desc(4, 20, 1, 2, "tanh"))).astype(np.float32)
+
+    def run(budget):
+        cfgd["agents"]["ddqn"]["step_budget"] = budget
+        return orc.ddqn_se_chain(orc.ddqn_cfg_from_config(cfgd, grad_chunk=2, rng_mode=0), theta, init, rng_key=99)
+
+    free, huge, one = run(0), run(10 ** 9), run(1)
+    for k in ("score", "episodes_run", "train_steps", "learn_steps", "test_steps"):
+        assert free[k] == huge[k]
+    assert np.array_equal(free["episode_test_mean"], huge["episode_test_mean"])
+    assert one["episodes_run"] == 1 and one["score"] == -1e9 and np.all(one["final_test_returns"] == -1e9)
+    assert np.all(one["episode_test_mean"] == one["episode_test_mean"][0])
+    assert one["episode_test_mean"][0] == free["episode_test_mean"][0]
+    assert np.all(one["episode_len"] == one["episode_len"][0])
+    runs = [run(b)["episodes_run"] for b in (1, 30, 60, 90, 120, 200, 400)]
+    assert runs == sorted(runs) and runs[-1] == 5
+    # a budget that ends inside the final test: returns padded with the minimum of the episodes that did run
+    total = free["train_steps"] + free["test_steps"]
+    cut = run(total - 20)
+    assert cut["episodes_run"] == 5 and cut["test_steps"] < free["test_steps"]
+    r = cut["final_test_returns"]
+    k = int(np.argmax(r != free["final_test_returns"])) if np.any(r != free["final_test_returns"]) else len(r)
+    assert 0 < k < len(r) and np.all(r[k:] == r[:k].min()) and np.array_equal(r[:k], free["final_test_returns"][:k])
