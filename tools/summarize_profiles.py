@@ -11,7 +11,13 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 os.makedirs(os.path.join(R, "profiles"), exist_ok=True)
 out = {}
-for f in glob.glob(os.path.join(R, "gpurun_out/prof/*/*kernel_stats.csv")):
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: keep only the most recent match."""
+    files = sorted(glob.glob(os.path.join(R, pattern)), key=os.path.getmtime)
+    return files[-1:]
+
+
+for f in newest("gpurun_out/prof/*/*kernel_stats.csv"):
     rows = list(csv.reader(open(f)))
     with open(os.path.join(R, "profiles", tag + "_bench_kernel_stats.csv"), "w") as o:
         w = csv.writer(o)
@@ -30,7 +36,7 @@ for f in glob.glob(os.path.join(R, "gpurun_out/prof/*/*kernel_stats.csv")):
     print("".join(",".join(r[:5]) + "\n" for r in rows[:6]))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = []
-    for f in glob.glob(os.path.join(R, "gpurun_out/pmc_%s/*/*counter_collection.csv" % c)):
+    for f in newest("gpurun_out/pmc_%s/*/*counter_collection.csv" % c):
         per_dispatch = collections.defaultdict(float)
         for r in csv.DictReader(open(f)):
             if "ddqn_se_inner" in r["Kernel_Name"] and r["Counter_Name"] == c:
@@ -44,7 +50,7 @@ if "FETCH_SIZE_KB_per_launch" in out and "WRITE_SIZE_KB_per_launch" in out:
     out["hbm_traffic_bytes_per_launch"] = (2.0 * out["FETCH_SIZE_KB_per_launch"] + out["WRITE_SIZE_KB_per_launch"]) * 1024.0
     out["traffic_note"] = "2*FETCH_SIZE + WRITE_SIZE (KB->bytes), per fused-kernel launch, gfx950 read-side correction applied"
 # the other configurations (tools/bench_configs.py under rocprofv3 --kernel-trace --stats)
-for f in glob.glob(os.path.join(R, "gpurun_out/prof_configs/*/*kernel_stats.csv")):
+for f in newest("gpurun_out/prof_configs/*/*kernel_stats.csv"):
     rows = list(csv.reader(open(f)))
     with open(os.path.join(R, "profiles", tag + "_configs_kernel_stats.csv"), "w") as o:
         w = csv.writer(o)
