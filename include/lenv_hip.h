@@ -312,6 +312,21 @@ int lenv_nes_worker_best_multi(const double *chain_scores, int64_t pop, int32_t 
                                int32_t grad_eval_type, double *result, void *stream);
 
 /*
+ * One NES generation's stochastic inputs in a single launch, all from the counter RNG (reproduced by every rank and by the
+ * CPU oracle): eps [pop, p_theta] = N(0,1) * noise_std (GTN_Worker.get_random_noise, agents/GTN_worker.py:156-163);
+ * agent_init [chains, p_agent] = U(-bound_i, bound_i) (the nn.Linear default init of the fresh agent every calc_score builds,
+ * agents/agent_utils.py:15-66); rng_keys [chains] = lenv_chain_key(seed, generation, worker_lo + c / chains_per_worker,
+ * c % chains_per_worker).  Any of the three outputs may be NULL.
+ */
+int lenv_nes_draw(uint64_t seed, uint64_t generation, int64_t pop, int64_t p_theta, float noise_std, float *eps,
+                  int64_t chains, int32_t chains_per_worker, int64_t worker_lo, int64_t p_agent, const float *bounds,
+                  float *agent_init, uint64_t *rng_keys, void *stream);
+
+/* result[w][3] = min(status[0..n)) for w < pop: this rank's worst chain status rides in the fitness records through the
+ * all-gather (replaces the second host read-back of a generation). */
+int lenv_nes_status_fold(const int32_t *status, int64_t n, double *result, int64_t pop, void *stream);
+
+/*
  * GTN_Master.score_transform + update_env (agents/GTN_master.py:197-298) on device.
  * gathered [pop,4] as produced by lenv_nes_worker_best (after the all-gather); rank_table [pop] doubles =
  * weight by rank for the rank-only transforms 1,2,3 (host-computed with the reference's numpy formulas);

@@ -99,7 +99,7 @@ EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv
            "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population", "lenv_dueling_se_workspace_bytes",
            "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
            "lenv_td3_rn_inner_loop", "lenv_mlp_forward", "lenv_cheetah_standin_reset", "lenv_cheetah_standin_step",
-           "lenv_rn_num_params", "lenv_rn_shape_rows", "lenv_nes_worker_best_multi"]
+           "lenv_rn_num_params", "lenv_rn_shape_rows", "lenv_nes_worker_best_multi", "lenv_nes_draw", "lenv_nes_status_fold"]
 
 
 def build(force=False):
@@ -180,6 +180,11 @@ def lib():
         L.lenv_nes_rank_update.restype = C.c_int
         L.lenv_nes_rank_update.argtypes = [C.c_int32, vp, vp, C.c_int64, vp, vp, C.c_int64, C.c_double, C.c_int32,
                                            C.c_double, vp, vp]
+        L.lenv_nes_draw.restype = C.c_int
+        L.lenv_nes_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_float, vp, C.c_int64, C.c_int32, C.c_int64,
+                                    C.c_int64, vp, vp, vp, vp]
+        L.lenv_nes_status_fold.restype = C.c_int
+        L.lenv_nes_status_fold.argtypes = [vp, C.c_int64, vp, C.c_int64, vp]
         if L.lenv_abi_version() != 2:
             raise LenvError("liblenv_hip.so ABI version mismatch")
         _lib = L

@@ -9,8 +9,9 @@ Same constructor, attributes (`score_list`, `score_orig_list`, `score_transform_
     split in contiguous blocks; the only exchange is ONE all-gather of [score_best, score_orig, sign] per worker
     (replaces write_worker_result/read_worker_results, :178-195); every rank then runs score_transform + update_env
     redundantly on bit-identical inputs, so theta never needs a broadcast (replaces write_worker_inputs, :147-176);
-  * noise eps is one [num_workers, P] tensor drawn from a (seed, generation)-keyed device generator that every rank
-    reproduces (agents/GTN_worker.py:156-163 drew it per worker from a time-seeded global RNG);
+  * noise eps is one [num_workers, P] tensor drawn by ONE kernel (lenv_nes_draw: noise + fresh agents + chain keys) from
+    a (seed, generation)-keyed counter RNG that every rank -- and the CPU oracle -- reproduces bit for bit
+    (agents/GTN_worker.py:156-163 drew it per worker from a time-seeded global RNG);
   * wall-clock time-outs (calc_worker_timeout, :141-145) have no counterpart on the fused path: chains run to their step
     budgets.
 
@@ -32,7 +33,7 @@ from ..envs.env_factory import EnvFactory
 from ..models.model_utils import linear_params
 from ..utils import calc_abs_param_sum
 from .GTN_base import GTN_Base
-from .nes_common import chain_keys, fresh_agent_init, rank_table, shard_bounds
+from .nes_common import rank_table, shard_bounds
 from .tasks import select_task
 
 __all__ = ["GTN_Master", "rank_table"]
@@ -130,6 +131,7 @@ class GTN_Master(GTN_Base):
         self.rank_table = torch.from_numpy(rank_table(self.score_transform_type, self.num_workers)).to(dev)
         self.eps = None
         self._gathered = None
+        self._local = None
 
         if bohb_working_dir:
             self.model_dir = str(os.path.join(bohb_working_dir, 'GTN_models_' + self.env_name))
@@ -168,25 +170,23 @@ class GTN_Master(GTN_Base):
         = (score_best, score_orig, sign, 0) in worker order, identical on every rank."""
         dev = self.engine.device
         pop = self.num_workers
-        g = torch.Generator(device=dev)
-        g.manual_seed((self.seed * 1000003 + it) % (2 ** 63 - 1))
-        # GTN_Worker.get_random_noise (agents/GTN_worker.py:156-163): N(0,1) * noise_std, full population on every rank
-        self.eps = torch.randn((pop, self.p_theta), generator=g, device=dev, dtype=torch.float32) * self.noise_std
         cpw = self.cpw
-        agent_init = fresh_agent_init(self.agent_bounds, cpw * pop, g, dev) if self.task.needs_agent_init() else None
-        local = torch.zeros((self.w_per, 4), dtype=torch.float64, device=dev)
+        # ONE launch draws the generation's stochastic inputs from the (seed, generation)-keyed counter RNG: the noise of the
+        # WHOLE population (every rank needs every eps row for the redundant theta update), and the fresh agents + chain
+        # keys of this rank's chains.  GTN_Worker.get_random_noise (agents/GTN_worker.py:156-163): N(0,1) * noise_std.
+        bounds = self.agent_bounds if self.task.needs_agent_init() else None
+        self.eps, local_init, keys_t = self.engine.draw(self.seed, it, pop, self.p_theta, self.noise_std, cpw * self.n_local, cpw,
+                                                        self.w_lo, bounds)
+        local = torch.zeros((self.w_per, 4), dtype=torch.float64, device=dev) if self._local is None else self._local.zero_()
+        self._local = local
         if self.n_local > 0:
-            lw = np.arange(self.w_lo, self.w_hi)
-            keys = chain_keys(self.seed, it, np.repeat(lw, cpw), np.tile(np.arange(cpw), self.n_local))
-            keys_t = torch.from_numpy(keys.view(np.int64)).to(dev)
-            local_init = agent_init[cpw * self.w_lo:cpw * self.w_hi].contiguous() if agent_init is not None else None
             chain_scores = self.task.scores(self.inner, self.theta, self.eps, self.chain_worker, self.chain_sign, keys_t,
                                             local_init)
-            local[:self.n_local] = self.engine.worker_best(chain_scores, self.n_local, self.mirrored_sampling,
-                                                           int(self.num_grad_evals), self.grad_eval_type)
+            self.engine.worker_best(chain_scores, self.n_local, self.mirrored_sampling, int(self.num_grad_evals),
+                                    self.grad_eval_type, out=local[:self.n_local])
             # column 3 carries this rank's worst chain status through the all-gather: every rank sees every rank's
             # failure in the one host read-back of the generation and raises together (no second sync, no hang)
-            local[:self.n_local, 3] = self.inner.status.min().to(torch.float64)
+            self.engine.status_fold(self.inner, local[:self.n_local])
         if self.world > 1:
             gathered = torch.empty((self.world * self.w_per, 4), dtype=torch.float64, device=dev)
             dist.all_gather_into_tensor(gathered, local)      # the ONE collective of a generation (RCCL over xGMI)

@@ -155,9 +155,75 @@ __global__ void update_env_kernel(float *theta, const float *eps, const double *
     theta[i] = t;
 }
 
+// One generation's stochastic inputs in ONE launch (replaces torch.randn * noise_std, torch.rand -> agent init, the host
+// computation + upload of the chain keys): element e of the flat index space
+//   [0, pop*P)                      eps[w][i]        = (float)N(0,1) * noise_std   GTN_Worker.get_random_noise (GTN_worker.py:156-163)
+//   [.., + chains*p_agent)          agent_init[c][i] = (2u - 1) * bound[i]        nn.Linear default init of a fresh agent
+//   [.., + chains)                  rng_keys[c]      = lenv_chain_key(seed, generation, worker(c), kind(c))
+// all from the counter RNG (same functions as the oracle's orc_nes_draw), so every rank regenerates identical tensors and
+// the CPU oracle can reproduce a whole generation bit for bit.
+constexpr uint32_t STREAM_NES_EPS = 9, STREAM_AGENT_INIT = 10;
+constexpr uint64_t NES_EPS_DOMAIN = 0x6e65735f657073ULL;      // "nes_eps": separates the noise keys from the chain keys
+
+__device__ __host__ __forceinline__ uint64_t chain_key_dev(uint64_t seed, uint64_t generation, uint64_t worker, uint64_t kind)
+{
+    uint64_t k = mix64(seed + 0x9e3779b97f4a7c15ULL);
+    k = mix64(k ^ (generation + 0x9e3779b97f4a7c15ULL * 2));
+    k = mix64(k ^ (worker * 4 + kind + 0x9e3779b97f4a7c15ULL * 3));
+    return k;
+}
+
+__global__ void nes_draw_kernel(uint64_t seed, uint64_t generation, int64_t pop, int64_t P, float noise_std, float *eps,
+                                int64_t chains, int64_t cpw, int64_t worker_lo, int64_t p_agent, const float *bounds, float *agent_init,
+                                uint64_t *rng_keys)
+{
+    const int64_t n_eps = eps ? pop * P : 0, n_init = agent_init ? chains * p_agent : 0, n_keys = rng_keys ? chains : 0;
+    const int64_t total = n_eps + n_init + n_keys;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < n_eps) {
+            const int64_t w = e / P, i = e - w * P;
+            const uint64_t key = chain_key_dev(seed ^ NES_EPS_DOMAIN, generation, (uint64_t)w, 0);
+            eps[e] = (float)det_normal(key, STREAM_NES_EPS, (uint64_t)i) * noise_std;
+        } else if (e < n_eps + n_init) {
+            const int64_t q = e - n_eps, c = q / p_agent, i = q - c * p_agent;
+            const uint64_t key = chain_key_dev(seed, generation, (uint64_t)(worker_lo + c / cpw), (uint64_t)(c % cpw));
+            const float u = (float)u64_to_unit(rng_u64(key, STREAM_AGENT_INIT, (uint64_t)i));
+            agent_init[q] = (u * 2.0f - 1.0f) * bounds[i];
+        } else {
+            const int64_t c = e - n_eps - n_init;
+            rng_keys[c] = chain_key_dev(seed, generation, (uint64_t)(worker_lo + c / cpw), (uint64_t)(c % cpw));
+        }
+    }
+}
+
+// column 3 of the per-worker records = this rank's worst chain status (min over `n` int32), so a failure travels through the
+// fitness all-gather (one thread; n is a few hundred)
+__global__ void status_fold_kernel(const int32_t *status, int64_t n, double *result, int64_t pop)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int32_t m = 0;
+        for (int64_t i = 0; i < n; ++i) m = status[i] < m ? status[i] : m;
+        for (int64_t w = 0; w < pop; ++w) result[w * 4 + 3] = (double)m;
+    }
+}
+
 }  // namespace lenv
 
 using namespace lenv;
+
+extern "C" int lenv_nes_draw(uint64_t seed, uint64_t generation, int64_t pop, int64_t p_theta, float noise_std, float *eps,
+                             int64_t chains, int32_t chains_per_worker, int64_t worker_lo, int64_t p_agent, const float *bounds,
+                             float *agent_init, uint64_t *rng_keys, void *stream)
+{
+    if (pop < 0 || chains < 0 || chains_per_worker < 1 || (eps && p_theta < 1)) return LENV_ERR_INVALID;
+    if (agent_init && (!bounds || p_agent < 1)) return LENV_ERR_INVALID;
+    const int64_t total = (eps ? pop * p_theta : 0) + (agent_init ? chains * p_agent : 0) + (rng_keys ? chains : 0);
+    if (total == 0) return LENV_OK;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(nes_draw_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), seed, generation, pop, p_theta,
+                       noise_std, eps, chains, (int64_t)chains_per_worker, worker_lo, p_agent, bounds, agent_init, rng_keys);
+    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}
 
 extern "C" int lenv_nes_worker_best(const double *chain_scores, int64_t pop, int32_t mirrored, double *result, void *stream)
 {
@@ -176,6 +242,14 @@ extern "C" int lenv_nes_worker_best_multi(const double *chain_scores, int64_t po
     if (pop == 0) return LENV_OK;
     hipLaunchKernelGGL(worker_best_multi_kernel, dim3((unsigned)((pop + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        chain_scores, pop, num_grad_evals, mirrored, grad_eval_type, result);
+    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}
+
+extern "C" int lenv_nes_status_fold(const int32_t *status, int64_t n, double *result, int64_t pop, void *stream)
+{
+    if (!status || !result || n < 0 || pop < 0) return LENV_ERR_INVALID;
+    if (pop == 0) return LENV_OK;
+    hipLaunchKernelGGL(status_fold_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), status, n, result, pop);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }
 

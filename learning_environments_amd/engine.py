@@ -310,17 +310,36 @@ def rn_shape_population(cfg, theta, eps, worker, sign, next_state, reward, chain
 GRAD_EVAL_TYPES = {"mean": 0, "minmax": 1}
 
 
-def nes_worker_best(chain_scores, pop, mirrored=True, num_grad_evals=1, grad_eval_type="mean"):
+def nes_worker_best(chain_scores, pop, mirrored=True, num_grad_evals=1, grad_eval_type="mean", out=None):
     """GTN_Worker.calc_best_score for `pop` workers; chain_scores [pop, 1+2G] = (orig, add_1..G, sub_1..G)."""
     dev = require_device()
     _chk(chain_scores, torch.float64, "chain_scores")
     if grad_eval_type not in GRAD_EVAL_TYPES:
         raise NotImplementedError('Unknown parameter for grad_eval_type: ' + str(grad_eval_type))
-    result = torch.empty((pop, 4), dtype=torch.float64, device=dev)
+    result = out if out is not None else torch.empty((pop, 4), dtype=torch.float64, device=dev)
+    _chk(result, torch.float64, "out")
     rc = _lib.lib().lenv_nes_worker_best_multi(_ptr(chain_scores), pop, int(num_grad_evals), 1 if mirrored else 0,
                                                GRAD_EVAL_TYPES[grad_eval_type], _ptr(result), _stream())
     _lib.check(rc, "lenv_nes_worker_best_multi")
     return result
+
+
+def nes_draw(seed, generation, pop, p_theta, noise_std, chains, chains_per_worker, worker_lo, bounds, want_keys=True):
+    """(eps [pop,p_theta], agent_init [chains,p_agent] or None, rng_keys int64 [chains]) of one generation, one launch."""
+    dev = require_device()
+    eps = torch.empty((pop, p_theta), dtype=torch.float32, device=dev)
+    init = torch.empty((chains, bounds.numel()), dtype=torch.float32, device=dev) if bounds is not None and chains > 0 else None
+    keys = torch.empty(chains, dtype=torch.int64, device=dev) if want_keys and chains > 0 else None
+    rc = _lib.lib().lenv_nes_draw(int(seed) & (2 ** 64 - 1), int(generation), pop, p_theta, float(noise_std), _ptr(eps), chains,
+                                  int(chains_per_worker), int(worker_lo), bounds.numel() if bounds is not None else 0,
+                                  _ptr(bounds), _ptr(init), _ptr(keys), _stream())
+    _lib.check(rc, "lenv_nes_draw")
+    return eps, init, keys
+
+
+def nes_status_fold(status, result):
+    rc = _lib.lib().lenv_nes_status_fold(_ptr(status), status.numel(), _ptr(result), result.shape[0], _stream())
+    _lib.check(rc, "lenv_nes_status_fold")
 
 
 def nes_rank_update(score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size=False, weight_decay=0.0):
@@ -368,8 +387,14 @@ class HipNesEngine(object):
         if int(st.min()) != 0:
             raise _lib.LenvError("inner loop reported status %s" % st.tolist())
 
-    def worker_best(self, chain_scores, pop, mirrored, num_grad_evals=1, grad_eval_type="mean"):
-        return nes_worker_best(chain_scores, pop, mirrored, num_grad_evals, grad_eval_type)
+    def worker_best(self, chain_scores, pop, mirrored, num_grad_evals=1, grad_eval_type="mean", out=None):
+        return nes_worker_best(chain_scores, pop, mirrored, num_grad_evals, grad_eval_type, out=out)
+
+    def draw(self, seed, generation, pop, p_theta, noise_std, chains, chains_per_worker, worker_lo, bounds):
+        return nes_draw(seed, generation, pop, p_theta, noise_std, chains, chains_per_worker, worker_lo, bounds)
+
+    def status_fold(self, inner, result):
+        nes_status_fold(inner.status, result)
 
     def rank_update(self, score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size, weight_decay):
         return nes_rank_update(score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size, weight_decay)

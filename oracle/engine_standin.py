@@ -40,11 +40,24 @@ class OracleNesEngine(object):
             inner.stats[c] = torch.tensor([r["episodes_run"], r["train_steps"], r["learn_steps"], r["test_steps"]])
         return torch.from_numpy(out)
 
-    def worker_best(self, chain_scores, pop, mirrored, num_grad_evals=1, grad_eval_type="mean"):
+    def draw(self, seed, generation, pop, p_theta, noise_std, chains, chains_per_worker, worker_lo, bounds):
+        eps, init, keys = orc.nes_draw(seed, generation, pop, p_theta, noise_std, chains, chains_per_worker, worker_lo,
+                                       bounds.numpy() if bounds is not None else None)
+        return (torch.from_numpy(eps), torch.from_numpy(init) if init is not None else None,
+                torch.from_numpy(keys.view(np.int64)) if chains > 0 else None)
+
+    def status_fold(self, inner, result):
+        result[:, 3] = float(inner.status.min())
+
+    def worker_best(self, chain_scores, pop, mirrored, num_grad_evals=1, grad_eval_type="mean", out=None):
         G = num_grad_evals
         cs = chain_scores.numpy().reshape(pop, 1 + 2 * G)
         best, sign = orc.worker_best_multi(cs[:, 1:1 + G], cs[:, 1 + G:], mirrored, grad_eval_type)
-        return torch.from_numpy(np.stack([best, cs[:, 0], sign.astype(np.float64), np.zeros(pop)], axis=1))
+        res = torch.from_numpy(np.stack([best, cs[:, 0], sign.astype(np.float64), np.zeros(pop)], axis=1))
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
 
     def rank_update(self, score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size, weight_decay):
         g = gathered.numpy()

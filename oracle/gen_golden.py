@@ -841,15 +841,15 @@ def gen_g4t():
     save("g4t_td3_learn", **out)
 
 
-def gen_g8t(name, seed):
+def gen_g8t(name, seed, agent_over=None, env_over=None):
     import json
     import statistics
     import agents.GTN_worker as gw
     from agents.GTN import GTN_Worker
     import gym.envs as genvs
     import gym.spaces as gspaces
-    cfg = _td3_cfg({"train_episodes": 4, "init_episodes": 2, "batch_size": 16, "hidden_size": 24, "test_episodes": 2},
-                   {"max_steps": 7, "hidden_size": 20})
+    cfg = _td3_cfg(agent_over or {"train_episodes": 4, "init_episodes": 2, "batch_size": 16, "hidden_size": 24, "test_episodes": 2},
+                   env_over or {"max_steps": 7, "hidden_size": 20})
     rec = dict(rand=[], act_noise=[], test_noise=[], policy_noise=[], replay=[], resets=[], steps=[], purpose=None, active=False)
     orig_randn, orig_randn_like, orig_randint = torch.randn, torch.randn_like, np.random.randint
     orig_box_sample, orig_reset = gspaces.Box.sample, genvs.CheetahStandinEnv.reset
@@ -972,8 +972,19 @@ def main():
         gen_g4t()
     if "g8t" in which:
         gen_g8t("g8t_calc_score_cheetah_td3", seed=830)
+    if "g8tf" in which:
+        # BASELINE configs[4] at its REAL network shapes (actor 17-128-128-6, critics 23-128-128-1, B 192, RN 17-128-1)
+        gen_g8t("g8tf_calc_score_cheetah_td3_fullshape", seed=831,
+                agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 192, "hidden_size": 128, "hidden_layer": 2, "test_episodes": 1},
+                env_over={"max_steps": 12, "hidden_size": 128})
     if "g4d" in which:
         gen_g4d()
+    if "g8df" in which:
+        # BASELINE configs[2] at its REAL network shapes (feature 6-128-128-128, heads 128-128-{1,3}, B 128, SE hidden 128)
+        gen_g8("g8df_calc_score_acrobot_dueling_fullshape", train_episodes=3, done_bias_shift=0.0, seed=811, max_steps=20,
+               env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="duelingddqn",
+               agent_over={"hidden_size": 128, "hidden_layer": 2, "feature_dim": 128, "batch_size": 128, "init_episodes": 1, "test_episodes": 2},
+               env_over={"hidden_size": 128, "solved_reward": 0.5})
     if "g8d" in which:
         gen_g8("g8d_calc_score_acrobot_dueling", train_episodes=4, done_bias_shift=0.0, seed=810, max_steps=25,
                env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="duelingddqn",

@@ -1255,6 +1255,29 @@ static double exact_mean(const double *x, int n)
     return q + r / (double)n;
 }
 
+/* One generation's stochastic inputs from the counter RNG -- the CPU twin of lenv_nes_draw (csrc/nes_update.hip): eps [pop,P]
+ * = (float)N(0,1) * noise_std (GTN_Worker.get_random_noise, GTN_worker.py:156-163), agent_init [chains,p_agent] =
+ * (2u-1)*bound (nn.Linear default init of a fresh agent), rng_keys [chains].  Any output may be NULL. */
+void orc_nes_draw(uint64_t seed, uint64_t generation, int64_t pop, int64_t P, float noise_std, float *eps, int64_t chains,
+                  int64_t cpw, int64_t worker_lo, int64_t p_agent, const float *bounds, float *agent_init, uint64_t *rng_keys)
+{
+    const uint64_t eps_domain = 0x6e65735f657073ULL;
+    if (eps)
+        for (int64_t w = 0; w < pop; ++w) {
+            const uint64_t key = orc_chain_key(seed ^ eps_domain, generation, (uint64_t)w, 0);
+            for (int64_t i = 0; i < P; ++i) eps[w * P + i] = (float)orc_normal(key, 9, (uint64_t)i) * noise_std;
+        }
+    for (int64_t c = 0; c < chains; ++c) {
+        const uint64_t key = orc_chain_key(seed, generation, (uint64_t)(worker_lo + c / cpw), (uint64_t)(c % cpw));
+        if (rng_keys) rng_keys[c] = key;
+        if (agent_init)
+            for (int64_t i = 0; i < p_agent; ++i) {
+                const float u = (float)u64_to_unit(orc_rng_u64(key, 10, (uint64_t)i));
+                agent_init[c * p_agent + i] = (u * 2.0f - 1.0f) * bounds[i];
+            }
+    }
+}
+
 /* GTN_worker.py:234-254 with num_grad_evals = G score lists per direction: grad_eval_type 0 = 'mean' (statistics.mean),
  * 1 = 'minmax' (min of BOTH lists, as the reference does) */
 int orc_worker_best_multi(const double *score_add /*[pop,G]*/, const double *score_sub /*[pop,G]*/, int64_t pop, int G, int mirrored,

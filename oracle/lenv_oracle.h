@@ -113,6 +113,8 @@ uint64_t orc_mix64(uint64_t x);
 uint64_t orc_chain_key(uint64_t seed, uint64_t generation, uint64_t worker, uint64_t kind);
 uint64_t orc_rng_u64(uint64_t key, uint32_t stream, uint64_t n);
 uint32_t orc_rng_replay_below(uint64_t key, uint64_t n, uint32_t size);
+void orc_nes_draw(uint64_t seed, uint64_t generation, int64_t pop, int64_t P, float noise_std, float *eps, int64_t chains,
+                  int64_t cpw, int64_t worker_lo, int64_t p_agent, const float *bounds, float *agent_init, uint64_t *rng_keys);
 
 /* ---- MLP ---- */
 int64_t orc_mlp_num_params(const orc_mlp_desc *d);

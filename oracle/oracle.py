@@ -294,6 +294,21 @@ def chain_key(seed, generation, worker, kind):
     return int(lib().orc_chain_key(seed, generation, worker, kind))
 
 
+def nes_draw(seed, generation, pop, p_theta, noise_std, chains, cpw, worker_lo, bounds):
+    """(eps, agent_init or None, rng_keys uint64) of one generation: the CPU twin of lenv_nes_draw."""
+    eps = np.empty((pop, p_theta), np.float32)
+    init = np.empty((chains, bounds.size), np.float32) if bounds is not None and chains > 0 else None
+    keys = np.empty(chains, np.uint64)
+    b = _f32(bounds) if bounds is not None else None
+    L = lib()
+    L.orc_nes_draw.restype = None
+    L.orc_nes_draw(C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint64(int(generation)), C.c_int64(pop), C.c_int64(p_theta),
+                   C.c_float(noise_std), _p(eps, C.c_float), C.c_int64(chains), C.c_int64(cpw), C.c_int64(worker_lo),
+                   C.c_int64(bounds.size if bounds is not None else 0), _p(b, C.c_float) if b is not None else None,
+                   _p(init, C.c_float) if init is not None else None, keys.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return eps, init, keys
+
+
 def worker_best(score_add, score_sub, mirrored=True):
     a = np.ascontiguousarray(score_add, np.float64)
     s = np.ascontiguousarray(score_sub, np.float64)

@@ -356,8 +356,9 @@ def test_ql_rn_counter_mode_population_vs_oracle(eng, orc, golden, env_name, rty
 # ---------------------------------------------------------------------------------------------------------------
 # config 3: DuelingDDQN on a synthetic environment (LDS-tiled GEMM kernel, parameters in the HBM arena)
 # ---------------------------------------------------------------------------------------------------------------
-def test_dueling_tape_mode_vs_reference_and_oracle(eng, orc, golden):
-    g = golden("g8d_calc_score_acrobot_dueling")
+@pytest.mark.parametrize("name", ["g8d_calc_score_acrobot_dueling", "g8df_calc_score_acrobot_dueling_fullshape"])
+def test_dueling_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
+    g = golden(name)
     cfgd = json.loads(str(g["config_json"]))
     ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
     assert cfg.agent_kind == 1
@@ -442,8 +443,9 @@ def _td3_cfgs(orc, cfgd, rng_mode, **over):
     return o, c
 
 
-def test_td3_tape_mode_vs_reference_and_oracle(eng, orc, golden):
-    g = golden("g8t_calc_score_cheetah_td3")
+@pytest.mark.parametrize("name", ["g8t_calc_score_cheetah_td3", "g8tf_calc_score_cheetah_td3_fullshape"])
+def test_td3_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
+    g = golden(name)
     ocfg, cfg = _td3_cfgs(orc, json.loads(str(g["config_json"])), 1)
     n = g["tr_reward"].size
     otapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
@@ -792,6 +794,24 @@ def test_dueling_and_td3_early_out(eng, orc, golden):
     assert il.stats[0].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
     assert np.array_equal(il.episode_test_mean[0].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
     assert float(il.score[0]) == o["score"]
+
+
+def test_nes_draw_vs_oracle(eng, orc):
+    """lenv_nes_draw (noise + fresh agents + chain keys of a generation, one launch) against its CPU twin: bit-exact, for a
+    rank that owns workers [2, 5) of a population of 7 with 5 chains per worker."""
+    from learning_environments_amd.agents.nes_common import chain_keys
+    pop, P, cpw, w_lo, n_local = 7, 2247, 5, 2, 3
+    bounds = np.linspace(0.1, 0.5, 401).astype(np.float32)
+    eps, init, keys = eng.nes_draw(99, 4, pop, P, 0.0124, cpw * n_local, cpw, w_lo, dev(bounds))
+    oeps, oinit, okeys = orc.nes_draw(99, 4, pop, P, 0.0124, cpw * n_local, cpw, w_lo, bounds)
+    assert np.array_equal(eps.cpu().numpy(), oeps) and np.array_equal(init.cpu().numpy(), oinit)
+    assert np.array_equal(keys.cpu().numpy().view(np.uint64), okeys)
+    workers = np.repeat(np.arange(w_lo, w_lo + n_local), cpw)
+    assert np.array_equal(okeys, chain_keys(99, 4, workers, np.tile(np.arange(cpw), n_local)))
+    assert np.all(np.abs(oinit) <= bounds[None, :])
+    # another generation / seed gives other numbers; QL-style call without agents
+    e2, i2, k2 = eng.nes_draw(99, 5, pop, P, 0.0124, cpw * n_local, cpw, w_lo, None)
+    assert i2 is None and not np.array_equal(e2.cpu().numpy(), oeps)
 
 
 def test_nes_worker_best_multi(eng, orc, golden):

@@ -266,12 +266,13 @@ def test_g4d_dueling_forward_and_learn(golden, grad_chunk):
             np.testing.assert_allclose(target, g[pre + "target"][step], rtol=0, atol=2e-5, err_msg=pre + "target%d" % step)
 
 
-def test_g8d_calc_score_acrobot_dueling(golden):
+@pytest.mark.parametrize("name", ["g8d_calc_score_acrobot_dueling", "g8df_calc_score_acrobot_dueling_fullshape"])
+def test_g8d_calc_score_acrobot_dueling(golden, name):
     import json
-    g = golden("g8d_calc_score_acrobot_dueling")
+    g = golden(name)
     cfgd = json.loads(str(g["config_json"]))
     cfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
-    assert cfg.agent_kind == 1 and cfg.feature_dim == 16
+    assert cfg.agent_kind == 1 and cfg.feature_dim == (128 if name.endswith("fullshape") else 16)
     tapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
     n = g["tr_action"].size
     out = orc.ddqn_se_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 10)
@@ -334,9 +335,11 @@ def test_cheetah_standin_matches_shim_run(golden):
         assert np.array_equal(np.array(list(x)).astype(np.float32), g["tr_next_state"][k])
 
 
-def test_g8t_calc_score_cheetah_td3(golden):
+@pytest.mark.parametrize("name", ["g8t_calc_score_cheetah_td3", "g8tf_calc_score_cheetah_td3_fullshape"])
+def test_g8t_calc_score_cheetah_td3(golden, name):
+    """The *_fullshape fixture is BASELINE configs[4] at its real network shapes (128x2 actor/critics, B 192, RN hidden 128)."""
     import json
-    g = golden("g8t_calc_score_cheetah_td3")
+    g = golden(name)
     cfg = orc.td3_cfg_from_config(json.loads(str(g["config_json"])), rng_mode=1)
     tapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
                                g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
@@ -447,3 +450,20 @@ def test_step_budget_semantics():
     r = cut["final_test_returns"]
     k = int(np.argmax(r != free["final_test_returns"])) if np.any(r != free["final_test_returns"]) else len(r)
     assert 0 < k < len(r) and np.all(r[k:] == r[:k].min()) and np.array_equal(r[:k], free["final_test_returns"][:k])
+
+
+def test_nes_draw_statistics():
+    """The counter-RNG noise of a generation (CPU twin of lenv_nes_draw): N(0,1)*noise_std moments, independent rows, agent
+    inits inside the nn.Linear default bounds."""
+    pop, P = 64, 2247
+    bounds = np.full(401, 0.5, np.float32)
+    eps, init, keys = orc.nes_draw(1234, 0, pop, P, 0.0124, 3 * pop, 3, 0, bounds)
+    z = eps.astype(np.float64) / 0.0124
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01
+    assert abs(np.mean(z ** 3)) < 0.05 and abs(np.mean(z ** 4) - 3.0) < 0.1
+    c = np.corrcoef(z[:8])
+    assert np.max(np.abs(c - np.eye(8))) < 0.1
+    assert init.shape == (192, 401) and np.all(np.abs(init) <= 0.5) and abs(init.mean()) < 0.01
+    assert abs(init.std() - 0.5 / np.sqrt(3.0)) < 0.01 and len(set(keys.tolist())) == 192
+    e2, _, _ = orc.nes_draw(1234, 1, pop, P, 0.0124, 0, 3, 0, None)
+    assert not np.array_equal(e2, eps)
