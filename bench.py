@@ -220,15 +220,14 @@ def cpu_baseline(cfgd, theta, grad_chunk, file_io=True):
 
     # single-thread calibration: one worker-evaluation = 3 chains on one core
     t1 = population(1, 1)
-    # all cores: as many whole workers as there are cores/3 (>= 2 workers), one chain per thread
-    pop_s = max(2, min(POP, cores // 3))
+    # all cores: ceil(cores/3) whole workers (>= 2), the chains are handed to `threads` worker threads
+    pop_s = max(2, min(POP, (cores + 2) // 3))       # enough whole workers to keep every core busy
     threads = min(cores, 3 * pop_s)
     dt = population(pop_s, threads)
     out = {"value": pop_s / dt, "unit": "worker-evaluations/s", "cores": threads, "kind": "port",
            "cpu_model": model, "affinity_cores": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": quota,
            "single_core_value": 1.0 / t1, "parallel_speedup": (pop_s / dt) * t1,
-           "sample": "%d workers (=%d chains) of the same fixed-work CartPole-SE/DDQN workload on %d threads (one chain per "
-                     "thread), %.1f s wall; single-thread calibration: 1 worker (3 chains) in %.1f s" % (pop_s, 3 * pop_s, threads, dt, t1)}
+           "sample": "%d workers (=%d chains) of the same fixed-work CartPole-SE/DDQN workload on %d threads, %.1f s wall; single-thread calibration: 1 worker (3 chains) in %.1f s" % (pop_s, 3 * pop_s, threads, dt, t1)}
     if file_io:
         out["file_io"] = cpu_baseline_file_io(cfgd, theta, cores, deadline_s=max(60.0, 8.0 * t1))
     return out
