@@ -53,7 +53,7 @@ def _free_port():
 def launch_ranks(n, argv):
     """Start n ranks of this script as child processes (one per GPU) and wait for them.  The parent only counts devices
     (torch.cuda.device_count() does not initialise HIP on this image) and never creates a context."""
-    if not os.environ.get(PLUMBING_ENV):
+    if not os.environ.get(PLUMBING_ENV) and os.environ.get("LENV_BENCH_BACKEND", "nccl") == "nccl":
         have = torch.cuda.device_count()
         if have < n:
             raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (n, have))

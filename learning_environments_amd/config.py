@@ -28,7 +28,9 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
     cfg = _lib.DdqnCfg(env_id=_lib.ENV[env_name], state_dim=S, num_actions=A, max_steps=int(val(e["max_steps"])),
                        se_hidden=int(val(e["hidden_size"])), se_layers=int(val(e["hidden_layer"])),
                        se_act=_lib.ACT[e["activation_fn"]], se_prelu=0.25,
-                       q_hidden=int(a["hidden_size"]), q_layers=int(a["hidden_layer"]), q_act=_lib.ACT[a["activation_fn"]],
+                       # build_nn_from_config (models/model_utils.py:33-37) adds `hidden_layer - 1` extra blocks: 0 builds the same
+                       # network as 1 (the *_vary agents sample hidden_layer in {L-1, L, L+1})
+                       q_hidden=int(a["hidden_size"]), q_layers=max(1, int(a["hidden_layer"])), q_act=_lib.ACT[a["activation_fn"]],
                        q_prelu=0.25, batch_size=int(a["batch_size"]), rb_size=int(a["rb_size"]),
                        train_episodes=int(a["train_episodes"]), test_episodes=int(a["test_episodes"]),
                        init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]),

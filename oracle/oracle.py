@@ -354,7 +354,7 @@ def ddqn_cfg_from_config(config, grad_chunk=13, rng_mode=0, **overrides):
     overrides.setdefault("feature_dim", int(a.get("feature_dim", 0)))
     cfg = DdqnCfg(env_id=ENV[env_name], state_dim=S, num_actions=A, max_steps=int(e["max_steps"]),
                   se_hidden=int(e["hidden_size"]), se_layers=int(e["hidden_layer"]), se_act=ACT[e["activation_fn"]],
-                  se_prelu=0.25, q_hidden=int(a["hidden_size"]), q_layers=int(a["hidden_layer"]),
+                  se_prelu=0.25, q_hidden=int(a["hidden_size"]), q_layers=max(1, int(a["hidden_layer"])),   # hidden_layer 0 == 1 (model_utils.py:33)
                   q_act=ACT[a["activation_fn"]], q_prelu=0.25, batch_size=int(a["batch_size"]),
                   rb_size=int(a["rb_size"]), train_episodes=int(a["train_episodes"]),
                   test_episodes=int(a["test_episodes"]), init_episodes=int(a["init_episodes"]),

@@ -210,3 +210,17 @@ def test_reference_checkpoint_fixture_is_plain_payload():
     assert keys[:4] == ["env.state_net.0.weight", "env.state_net.0.bias", "env.state_net.2.weight", "env.state_net.2.bias"]
     assert tuple(d["model"]["env.state_net.0.weight"].shape) == (83, 6) and tuple(d["model"]["env.done_net.2.bias"].shape) == (1,)
     assert d["config"]["env_name"] == "CartPole-v0"
+
+
+def test_hidden_layer_zero_builds_the_one_hidden_layer_net():
+    """build_nn_from_config adds `hidden_layer - 1` extra blocks (reference models/model_utils.py:33-37), so hidden_layer 0 --
+    which the *_vary agents sample (DDQN_vary.py:44-46: hidden_layer in {L-1, L, L+1}) -- is the same network as 1."""
+    from learning_environments_amd.config import ddqn_cfg_from_config
+    from learning_environments_amd.configs import cartpole_syn_env_ddqn
+    from learning_environments_amd.models.model_utils import build_nn_from_config
+    n0 = build_nn_from_config(4, 2, {"hidden_size": 8, "hidden_layer": 0, "activation_fn": "tanh"})
+    n1 = build_nn_from_config(4, 2, {"hidden_size": 8, "hidden_layer": 1, "activation_fn": "tanh"})
+    assert [type(m) for m in n0] == [type(m) for m in n1] and list(n0.state_dict().keys()) == list(n1.state_dict().keys())
+    cfgd = cartpole_syn_env_ddqn(2)
+    cfgd["agents"]["ddqn"]["hidden_layer"] = 0
+    assert ddqn_cfg_from_config(cfgd).q_layers == 1

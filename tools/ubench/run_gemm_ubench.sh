@@ -1,0 +1,7 @@
+#!/bin/bash
+# Diagnostic: cycles per GEMM product, current lenv_gemm.cuh vs the committed one (tools/ubench/_old, scratch copy)
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math"
+/opt/rocm/bin/hipcc $F tools/ubench/gemm_ubench.hip -o /tmp/gemm_ub_new 2>/dev/null && echo "== new" && /tmp/gemm_ub_new
+if [ -d tools/ubench/_old ]; then (cd tools/ubench/_old && /opt/rocm/bin/hipcc $F tools/ubench/gemm_ubench.hip -o /tmp/gemm_ub_old 2>/dev/null) && echo "== old" && /tmp/gemm_ub_old; fi
