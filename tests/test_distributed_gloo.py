@@ -22,7 +22,7 @@ def _small_config(num_workers):
     return cfg
 
 
-def _run(rank, world, port, tmp, q):
+def _run(rank, world, port, tmp, q, seed_per_rank=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.chdir(tmp)
@@ -31,21 +31,25 @@ def _run(rank, world, port, tmp, q):
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     from _oracle_engine import OracleNesEngine
     from learning_environments_amd.agents.GTN import GTN_Master
-    torch.manual_seed(0)
+    # a launcher that seeds every rank differently must not matter: rank 0's theta / model name are broadcast at construction
+    torch.manual_seed(1000 * rank if seed_per_rank else 0)
+    import random
+    random.seed(rank if seed_per_rank else 0)
     m = GTN_Master(_small_config(5), bohb_id=0, engine=OracleNesEngine(), seed=11)
     with torch.no_grad():
         m.synthetic_env_orig.env.done_net[-1].bias.fill_(-10.0)
     mean_score, mean_list, _ = m.run()
-    q.put((rank, m.theta.numpy().copy(), list(m.score_list), list(m.score_orig_list), float(mean_score), (m.w_lo, m.w_hi)))
+    q.put((rank, m.theta.numpy().copy(), list(m.score_list), list(m.score_orig_list), float(mean_score), (m.w_lo, m.w_hi),
+           os.path.basename(m.model_name)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _launch(world, tmp_path, port):
+def _launch(world, tmp_path, port, seed_per_rank=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_run, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, str(tmp_path), q, seed_per_rank)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get(timeout=120) for _ in range(world)]
@@ -68,6 +72,16 @@ def test_two_rank_run_matches_single_rank(tmp_path):
         assert np.array_equal(r[1], single[1])
         assert r[2] == single[2] and r[3] == single[3] and r[4] == single[4]
     assert not np.array_equal(single[1], np.zeros_like(single[1]))
+
+
+@pytest.mark.timeout(400)
+def test_ranks_seeded_differently_still_agree(tmp_path):
+    """theta is replicated and never exchanged per generation, so it must start identical.  Ranks that build
+    their initial theta under different torch / random seeds end with bit-identical theta, fitness lists and model name."""
+    (tmp_path / "w").mkdir()
+    double = _launch(2, tmp_path / "w", 29613, seed_per_rank=True)
+    assert np.array_equal(double[0][1], double[1][1]) and double[0][2] == double[1][2] and double[0][3] == double[1][3]
+    assert double[0][6] == double[1][6]
 
 
 def _run_hip(rank, world, port, tmp, q):

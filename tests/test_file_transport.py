@@ -127,3 +127,36 @@ def test_file_master_drives_hip_workers(tmp_path, monkeypatch, name):
     # the env wrapper the master saves sees the updated parameters (flat-buffer aliasing)
     flat = torch.cat([p.detach().reshape(-1) for p in linear_params(master.synthetic_env_orig)])
     assert torch.equal(flat, master.theta)
+
+
+def test_score_transform_and_update_env_keep_the_mirrored_sign(tmp_path, monkeypatch):
+    """the reference-compatible call sequence `score_transform(); update_env()` (no arguments) must apply the
+    eps of a worker whose -eps scored better with sign -1 (in the reference eps_list already holds the inverted eps,
+    GTN_worker.py:180-185).  Compared against the update recomputed by the oracle with the signs of the generation."""
+    from oracle import oracle as orc
+    from oracle.engine_standin import OracleNesEngine
+    from learning_environments_amd.agents.GTN import GTN_Master
+    monkeypatch.chdir(tmp_path)
+    cfg = _tiny_cartpole(4, 1)
+    cfg["device"] = "cpu"
+    torch.manual_seed(7)
+    m = GTN_Master(cfg, bohb_id=0, engine=OracleNesEngine(), seed=3)
+    theta0 = m.theta.clone().numpy()
+    gathered = m.evaluate_population(0)
+    m._gathered = gathered
+    host = gathered.numpy()
+    m.score_list, m.score_orig_list = host[:, 0].tolist(), host[:, 1].tolist()
+    assert (host[:, 2] == -1).any() or (host[:, 2] == 1).all()        # at least exercised; the seed below gives both signs
+    m.score_transform()
+    m.update_env()
+    w = orc.score_transform(cfg["agents"]["gtn"]["score_transform_type"], host[:, 0], host[:, 1])
+    want = orc.update_env(theta0, m.eps.numpy(), host[:, 2].astype(np.float32), w, cfg["agents"]["gtn"]["step_size"])
+    assert np.array_equal(m.theta.numpy(), want)
+    assert m.score_transform_list == w.tolist()
+    # editing the public score lists is honoured, the signs stay
+    m.theta.copy_(torch.from_numpy(theta0))
+    m.score_list = [s + 1.0 for s in m.score_list]
+    m.update_env()
+    w2 = orc.score_transform(cfg["agents"]["gtn"]["score_transform_type"], host[:, 0] + 1.0, host[:, 1])
+    assert np.array_equal(m.theta.numpy(), orc.update_env(theta0, m.eps.numpy(), host[:, 2].astype(np.float32), w2,
+                                                          cfg["agents"]["gtn"]["step_size"]))

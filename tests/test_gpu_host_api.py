@@ -158,6 +158,20 @@ def test_gtn_master_run_ql_cliff(tmp_path, monkeypatch):
             sc.append(orc.ql_rn_chain(ocfg, w, tables, rng_key=orc.chain_key(m.seed, 0, p, kind))["score"])
         assert gathered[p, 1] == sc[0] and gathered[p, 0] == max(sc[1], sc[2])
         assert gathered[p, 2] == (-1.0 if sc[2] > sc[1] else 1.0)
+    # the shaped-reward table of the wrapper must follow theta although the kernels update it through a raw
+    # pointer (no torch version bump): one env step before and after an update sees different shaped rewards
+    renv = m.synthetic_env_orig
+    renv.set_agent_params(same_action_num=1, gamma=cfg["agents"]["ql"]["gamma"])
+    table_before = renv.env.shaped_table().clone()
+    m._gathered = torch.from_numpy(gathered).cuda()
+    m.score_list, m.score_orig_list = gathered[:, 0].tolist(), gathered[:, 1].tolist()
+    m.update_env()
+    table_after = renv.env.shaped_table()
+    assert not torch.equal(table_before, table_after)
+    _, want = __import__("learning_environments_amd.engine", fromlist=["x"]).rn_shape_population(
+        renv.env.ql_cfg(), m.theta, None, None, None,
+        torch.from_numpy(tables["next_state"]).contiguous().cuda(), torch.from_numpy(tables["reward"]).contiguous().cuda(), 1)
+    assert torch.equal(table_after, want[0].cpu())
     mean_score, mean_list, _ = m.run()
     assert len(mean_list) == 2 and -102.0 <= mean_score <= -12.0
     # RN models are saved whenever the mean improves (GTN_master.py:127-129)
