@@ -72,7 +72,7 @@ typedef struct {
      * "elapsed" = env steps (train + test) this chain has taken.  <= 0: no budget.  At the start of a training episode with
      * elapsed > step_budget the per-episode reward list is padded with its minimum so far (-1e9 if empty) and training
      * stops; the final test gets the remainder and pads its returns the same way (so a chain that timed out in training
-     * scores -1e9, as the reference does).  Supported by lenv_ddqn_se_inner_loop; the other kernels return UNSUPPORTED. */
+     * scores -1e9, as the reference does).  All four fused inner loops implement it. */
     int64_t step_budget;
 } lenv_ddqn_cfg;
 
@@ -163,6 +163,7 @@ typedef struct {
                                            eps-greedy next action) */
     int32_t count_based;                /* ql_cb / sarsa_cb (agents/agent_utils.py:57-64): reward += beta / (sqrt(n(s,a)) + 1e-9) */
     double solved_reward, alpha, gamma, eps_init, eps_min, eps_decay, beta;
+    int64_t step_budget;                /* env-step stand-in for time_remaining, see lenv_ddqn_cfg::step_budget */
 } lenv_ql_cfg;
 
 typedef struct {
@@ -235,6 +236,7 @@ typedef struct {
     int32_t batch_size, rb_size, train_episodes, test_episodes, init_episodes, early_out_num, policy_delay, rng_mode;
     double solved_reward, gamma, lr, tau, action_std, policy_std, policy_std_clip, max_action;
     double adam_beta1, adam_beta2, adam_eps;
+    int64_t step_budget;                     /* env-step stand-in for time_remaining, see lenv_ddqn_cfg::step_budget */
 } lenv_td3_cfg;
 
 /* RNG tapes (parity mode); per-chain rows, strides in ROWS (rows of A floats / B ints / S doubles as noted) */

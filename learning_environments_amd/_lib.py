@@ -59,7 +59,7 @@ class QlCfg(C.Structure):
                 ("init_episodes", C.c_int32), ("early_out_num", C.c_int32), ("batch_size", C.c_int32), ("rng_mode", C.c_int32),
                 ("agent_kind", C.c_int32), ("count_based", C.c_int32),
                 ("solved_reward", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double), ("eps_init", C.c_double),
-                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double)]
+                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double), ("step_budget", C.c_int64)]
 
 
 class QlOut(C.Structure):
@@ -78,7 +78,8 @@ class Td3Cfg(C.Structure):
                 ("policy_delay", C.c_int32), ("rng_mode", C.c_int32),
                 ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
                 ("action_std", C.c_double), ("policy_std", C.c_double), ("policy_std_clip", C.c_double),
-                ("max_action", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
+                ("max_action", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
+                ("step_budget", C.c_int64)]
 
 
 class Td3Tapes(C.Structure):

@@ -8,7 +8,8 @@ ENV_DIMS = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3), "HalfCheetah-v3": (17, 
 
 def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **overrides):
     """Fields read at reference agents/DDQN.py:15-38, agents/base_agent.py:9-26, envs/env_factory.py:45-59.
-    grad_chunk=0 picks the smallest micro-chunk (>= ceil(batch/16)) whose LDS footprint fits one CU."""
+    grad_chunk=0 picks the smallest micro-chunk (>= ceil(batch/16)) whose LDS footprint fits one CU; it stays 0 (one
+    sequential batch gradient) for DuelingDDQN and for DDQN nets that only the GEMM-tiled kernel takes."""
     env_name = config["env_name"]
     if env_name not in ENV_DIMS:
         raise NotImplementedError("real env '%s' has no device implementation yet" % env_name)
@@ -68,7 +69,12 @@ def pick_grad_chunk(cfg):
         if L.lenv_ddqn_se_lds_bytes(C.byref(probe)) > 0:
             return chunk
         chunk += 1
-    raise NotImplementedError("DDQN/SE shapes do not fit the fused kernel's LDS budget")
+    # Critic_DQN shapes the register-resident kernel does not take (hidden_layer >= 2, wide layers): the GEMM-tiled kernel
+    # trains them with one sequential batch gradient (grad_chunk 0) -- engine.InnerLoop routes on the same probe
+    probe.grad_chunk = 0
+    if L.lenv_dueling_num_params(C.byref(probe)) > 0:
+        return 0
+    raise NotImplementedError("DDQN/SE shapes fit neither fused kernel")
 
 
 TABULAR_AGENTS = ("ql", "ql_cb", "sarsa", "sarsa_cb")     # agents/agent_utils.py:57-64
@@ -99,7 +105,7 @@ def ql_cfg_from_config(config, tables, rng_mode=_lib.RNG_COUNTER, **overrides):
                      init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]),
                      batch_size=int(a["batch_size"]), rng_mode=int(rng_mode), solved_reward=float(val(e["solved_reward"])),
                      alpha=float(a["alpha"]), gamma=float(a["gamma"]), eps_init=float(a["eps_init"]),
-                     eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]))
+                     eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]), step_budget=int(a.get("step_budget", 0)))
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg
@@ -129,7 +135,7 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
                       policy_delay=int(a["policy_delay"]), rng_mode=int(rng_mode), solved_reward=float(val(e["solved_reward"])),
                       gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), action_std=float(a["action_std"]),
                       policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=1.0,
-                      adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8)
+                      adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, step_budget=int(a.get("step_budget", 0)))
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg

@@ -56,7 +56,11 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     const lenv_ddqn_cfg &cfg = a.cfg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t chain = blockIdx.x;
-    const int S = cfg.state_dim, A = cfg.num_actions, K = S + A, H = cfg.q_hidden, F = cfg.feature_dim, L = cfg.q_layers;
+    // agent_kind 1 = DuelingDDQN (Critic_DuelingDQN); agent_kind 0 = DDQN whose Critic_DQN (models/actor_critic.py:84-91:
+    // build_nn_from_config(S -> A) with `hidden_layer` hidden layers) does not fit the register-resident small kernel
+    // (hidden_layer >= 2, wide layers): the "feature stream" IS the Q-net then (output width A, no heads, no advantage mean).
+    const bool plain = cfg.agent_kind == 0;
+    const int S = cfg.state_dim, A = cfg.num_actions, K = S + A, H = cfg.q_hidden, F = plain ? A : cfg.feature_dim, L = cfg.q_layers;
     const int B = cfg.batch_size, Hse = cfg.se_hidden, RS = a.RS, P = a.P, T = cfg.test_episodes;
     const int act_id = cfg.q_act;
     const float prelu = cfg.q_prelu;
@@ -69,9 +73,9 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     float *se_wout = se_b0 + 3 * Hse;                     // [S+2][Hse]
     float *se_bout = se_wout + (S + 2) * Hse;             // [S+2] (padded to 16)
     float *se_h = se_bout + 16;                           // [3][Hse]
-    float *qv = se_h + 3 * Hse;                           // [3][B][A]   q(s), q_online(s'), q_target(s')
     const int RBH = B > T ? B : T;
-    float *Vb = qv + 3 * B * A;                           // [3][RBH]  value-head outputs of the three passes (slot 0 reused as scratch)
+    float *qv = se_h + 3 * Hse;                           // [3][B][A]   q(s), q_online(s'), q_target(s'); [T][A] in the test phase
+    float *Vb = qv + 3 * RBH * A;                           // [3][RBH]  value-head outputs of the three passes (slot 0 reused as scratch)
     float *Advb = Vb + 3 * RBH;                           // [3][RBH][A] advantage-head outputs (RBH = max(B, T) rows per slot)
     float *dq = Advb + 3 * RBH * A;                       // [B]
     float *dAdv = dq + B;                                 // [B][A]
@@ -82,6 +86,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     int *alive = reinterpret_cast<int *>(ep_rew + T);     // [T]
     float *state = reinterpret_cast<float *>(alive + T);  // [8] current SE state
     float *newrow = state + 8;                            // [16]
+    int *tlen = reinterpret_cast<int *>(newrow + 16);     // [T] lengths of the episodes of the last test phase (time-out cut)
     volatile float *ctrl = misc;
     volatile int *ictrl = reinterpret_cast<volatile int *>(misc + 32);
 
@@ -149,6 +154,10 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
             in = hid[l]; n_in = H;
         }
         // feature_stream's last Linear: no activation (build_nn_from_config ends with a Linear)
+        if (plain) {                                       // Critic_DQN: that Linear's output is Q(s, .) -> slot `slot` of Advb
+            gq.gemm(in, n_in, 1, par + a.oWf[L], n_in, 1, I, A, n_in, epi_bias(Advb + slot * RBH * A, A, 0, par + a.obf[L]));
+            return;
+        }
         gq.gemm(in, n_in, 1, par + a.oWf[L], n_in, 1, I, F, n_in, epi_bias(featb, F, 0, par + a.obf[L]));
         gq.gemm(featb, F, 1, par + a.oWv1, F, 1, I, F, F, epi_bias_act(v1b, F, par + a.obv1, act_id, prelu));
         gq.gemm(featb, F, 1, par + a.oWa1, F, 1, I, F, F, epi_bias_act(a1b, F, par + a.oba1, act_id, prelu));
@@ -156,6 +165,12 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
         gq.gemm(a1b, F, 1, par + a.oWa2, F, 1, I, A, F, epi_bias(Advb + slot * RBH * A, A, 0, par + a.oba2));
     };
     auto finish_q = [&](int slot, int I, float *q_out, bool global_mean) {
+        if (plain) {                                       // Q itself sits in the "advantage" slot (sized for max(B, T) rows)
+            const float *src = Advb + slot * RBH * A;
+            for (int e = tid; e < I * A; e += DNT) q_out[e] = src[e];
+            __syncthreads();
+            return;
+        }
         const float *Vs = Vb + slot * RBH, *As = Advb + slot * RBH * A;
         if (global_mean) {
             if (tid == 0) {
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 for (int i = 0; i < 4; ++i) st[i] = -reset_lim + (2 * reset_lim) * u64_to_unit(rng_u64(key, STREAM_TEST_RESET, (uint64_t)(row * 4 + i)));
             }
             for (int i = 0; i < 4; ++i) dstate[tid * 4 + i] = st[i];
-            ep_rew[tid] = 0.0f; alive[tid] = 1;
+            ep_rew[tid] = 0.0f; alive[tid] = 1; tlen[tid] = 0;
         }
         if (tid == 0) ictrl[0] = 0;
         __syncthreads();
@@ -216,6 +231,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 if (env_id == LENV_ENV_CARTPOLE) cartpole_step(st, am, rew, dn); else acrobot_step(st, am, rew, dn);
                 for (int i = 0; i < 4; ++i) dstate[tid * 4 + i] = st[i];
                 ep_rew[tid] = ep_rew[tid] + (float)rew;
+                tlen[tid] = tlen[tid] + 1;
                 atomicAdd(const_cast<int *>(&ictrl[0]), 1);
                 if (dn) alive[tid] = 0;
             }
@@ -231,7 +247,11 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
         __syncthreads();
     };
 
+    // Deterministic time-out (lenv_ddqn_cfg::step_budget, base_agent.py:30-47): elapsed = env steps taken so far
+    const bool budgeted = cfg.step_budget > 0;
+    int timed_out_at = -1;
     for (int episode = 0; episode < cfg.train_episodes; ++episode) {
+        if (budgeted && (int64_t)train_steps + test_steps > cfg.step_budget) { timed_out_at = episode; break; }   // uniform
         if (episode == 0) eps_g = cfg.eps_init;            // DuelingDDQN.update_parameters_per_episode (:112-117)
         else { eps_g *= cfg.eps_decay; if (eps_g < cfg.eps_min) eps_g = cfg.eps_min; }
         const bool learning = episode >= cfg.init_episodes;
@@ -361,7 +381,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 if (tid == 0) {
                     float s_dq = 0.0f;                      // sequential in b (canonical order of the sum)
                     for (int b = 0; b < B; ++b) s_dq = s_dq + dq[b];
-                    ctrl[9] = (-s_dq) / (float)(B * A);     // backward of `- advantages.mean()`
+                    ctrl[9] = plain ? 0.0f : (-s_dq) / (float)(B * A);     // backward of `- advantages.mean()` (dueling only)
                     b1pow *= cfg.adam_beta1; b2pow *= cfg.adam_beta2;
                     ctrl[10] = (float)(-(cfg.lr / (1.0 - b1pow)));
                     ctrl[11] = (float)__builtin_sqrt(1.0 - b2pow);
@@ -369,7 +389,12 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 __syncthreads();
                 {
                     const float mean_grad = ctrl[9];
-                    for (int e = tid; e < B * A; e += DNT) { const int b = e / A, aa = e - b * A; dAdv[e] = (aa == (int)Vb[b] ? dq[b] : 0.0f) + mean_grad; }
+                    // dueling: dL/dAdv; plain DQN: dL/dQ (only entry a_b of a row is non-zero, no mean term)
+                    for (int e = tid; e < B * A; e += DNT) {
+                        const int b = e / A, aa = e - b * A;
+                        const float g = aa == (int)Vb[b] ? dq[b] : 0.0f;
+                        dAdv[e] = plain ? g : g + mean_grad;
+                    }
                 }
                 __syncthreads();
                 PT_MARK(4);
@@ -377,9 +402,9 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 float *dh[2] = { arena + a.a_dbuf[3], arena + a.a_dbuf[4] };
                 // ---- heads, output layers: db = column sums; d hidden of the heads = act'(h) * sum_o dOut[o] * W2[o][k]
                 // (reduction over the few outputs).  Everything GEMM-shaped of the backward pass is queued below.
-                if (tid < A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dAdv[b * A + tid]; grad[a.oba2 + tid] = s; }
-                if (tid == A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dq[b]; grad[a.obv2] = s; }
-                {
+                if (!plain && tid < A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dAdv[b * A + tid]; grad[a.oba2 + tid] = s; }
+                if (!plain && tid == A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dq[b]; grad[a.obv2] = s; }
+                if (!plain) {
                     // thread = (column k, row group): the head weights of column k are loop invariants, a1/v1 reads are coalesced
                     // along k and 8 rows are in flight per thread (A <= 3 for the supported envs)
                     const int k = tid & 127, rg = tid >> 7, nrg = DNT >> 7;
@@ -409,18 +434,21 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                     }
                 }
                 PT_MARK(5);
-                // heads: dW2 = dOut^T . hidden (reduction over the batch); dW1 = dHid^T . feat, db1; dfeat = d_v1 . Wv1 + d_a1 . Wa1
-                gq.gemm(dAdv, 1, A, a1_s, 1, F, A, F, B, epi_store(grad + a.oWa2, F));
-                gq.gemm(dq, 1, 1, v1_s, 1, F, 1, F, B, epi_store(grad + a.oWv2, F));
-                gq.gemm(d_a1, 1, F, feat_s, 1, F, F, F, B, epi_store(grad + a.oWa1, F));
-                gq.gemm(d_v1, 1, F, feat_s, 1, F, F, F, B, epi_store(grad + a.oWv1, F));
-                gq.colsum(d_a1, B, F, F, grad + a.oba1);
-                gq.colsum(d_v1, B, F, F, grad + a.obv1);
-                gq.gemm(d_v1, F, 1, online + a.oWv1, 1, F, B, F, F, epi_store(d_feat, F));
-                gq.gemm(d_a1, F, 1, online + a.oWa1, 1, F, B, F, F, epi_accum(d_feat, F));
-                // feature stream: output Linear (no activation), then the hidden layers downwards
+                if (!plain) {
+                    // heads: dW2 = dOut^T . hidden (reduction over the batch); dW1 = dHid^T . feat, db1; dfeat = d_v1 . Wv1 + d_a1 . Wa1
+                    gq.gemm(dAdv, 1, A, a1_s, 1, F, A, F, B, epi_store(grad + a.oWa2, F));
+                    gq.gemm(dq, 1, 1, v1_s, 1, F, 1, F, B, epi_store(grad + a.oWv2, F));
+                    gq.gemm(d_a1, 1, F, feat_s, 1, F, F, F, B, epi_store(grad + a.oWa1, F));
+                    gq.gemm(d_v1, 1, F, feat_s, 1, F, F, F, B, epi_store(grad + a.oWv1, F));
+                    gq.colsum(d_a1, B, F, F, grad + a.oba1);
+                    gq.colsum(d_v1, B, F, F, grad + a.obv1);
+                    gq.gemm(d_v1, F, 1, online + a.oWv1, 1, F, B, F, F, epi_store(d_feat, F));
+                    gq.gemm(d_a1, F, 1, online + a.oWa1, 1, F, B, F, F, epi_accum(d_feat, F));
+                }
+                // feature stream: output Linear (no activation), then the hidden layers downwards.  Plain DQN: the stream's
+                // output is Q itself, so its output gradient is the masked dq rows (dAdv, LDS) -- DDQN.py:82-94
                 {
-                    const float *dcur = d_feat;            // dL/d(output of layer l+1)'s pre-activation
+                    const float *dcur = plain ? dAdv : d_feat;            // dL/d(output of layer l+1)'s pre-activation
                     int n_out = F;
                     for (int l = L; l >= 0; --l) {
                         const int n_in = l == 0 ? S : H;
@@ -477,7 +505,28 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
         if (brk) break;
     }
     PT_MARK(9);
+    const int64_t remaining = cfg.step_budget - ((int64_t)train_steps + test_steps);     // time_remaining - elapsed
+    const int test_before = test_steps;
     test_phase();
+    if (budgeted) {
+        // BaseAgent.test under the time-out (base_agent.py:177-184): episode e starts only while the earlier episodes of this
+        // test used <= remaining steps; the rest is padded with the minimum so far (-1e9 if empty).  Episodes are independent,
+        // so the list rolled out above is cut here.
+        if (tid == 0) {
+            int64_t used = 0;
+            int stop = T;
+            for (int te = 0; te < T; ++te) {
+                if (used > remaining) { stop = te; break; }
+                used += tlen[te];
+            }
+            double mn = -1e9;
+            if (stop > 0) { mn = ret[0]; for (int i = 1; i < stop; ++i) if (ret[i] < mn) mn = ret[i]; }
+            for (int te = stop; te < T; ++te) ret[te] = mn;
+            ictrl[4] = (int)used;
+        }
+        __syncthreads();
+        test_steps = test_before + ictrl[4];
+    }
     PT_MARK(8);
 #ifdef LENV_PHASE_TIMING
     if (tid == 0 && chain == 0) for (int pi = 0; pi < 10; ++pi) g_duel_phase_cycles[pi] = pt_acc[pi];
@@ -491,10 +540,20 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
             a.out.stats[chain * 4 + 0] = episodes_run; a.out.stats[chain * 4 + 1] = train_steps;
             a.out.stats[chain * 4 + 2] = learn_it; a.out.stats[chain * 4 + 3] = test_steps;
         }
-        const double nan = __builtin_nan("");
+        // episodes that never ran: NaN / 0, or -- after a time-out -- time_is_up's padding (base_agent.py:33-44)
+        double pad_r = __builtin_nan("");
+        int pad_l = 0;
+        if (timed_out_at >= 0) {
+            pad_r = -1e9; pad_l = 1000000000;
+            if (episodes_run > 0) { pad_r = meter[0]; for (int i = 1; i < episodes_run; ++i) if (meter[i] < pad_r) pad_r = meter[i]; }
+            if (episodes_run > 0 && a.out.episode_len) {
+                pad_l = a.out.episode_len[chain * cfg.train_episodes];
+                for (int i = 1; i < episodes_run; ++i) { const int l = a.out.episode_len[chain * cfg.train_episodes + i]; if (l > pad_l) pad_l = l; }
+            }
+        }
         for (int e = episodes_run; e < cfg.train_episodes; ++e) {
-            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + e] = nan;
-            if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = 0;
+            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + e] = pad_r;
+            if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = pad_l;
         }
     }
     if (a.out.final_online) for (int p = tid; p < P; p += DNT) a.out.final_online[chain * P + p] = online[p];
@@ -510,13 +569,13 @@ static int64_t d_mlp_params(int in, int H, int L, int out) { return (int64_t)in 
 
 static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_bytes)
 {
-    const int S = cfg->state_dim, A = cfg->num_actions, H = cfg->q_hidden, F = cfg->feature_dim, L = cfg->q_layers, B = cfg->batch_size;
+    const bool plain = cfg->agent_kind == 0;               // DDQN with a multi-layer / wide Critic_DQN (see the kernel)
+    const int S = cfg->state_dim, A = cfg->num_actions, H = cfg->q_hidden, F = plain ? A : cfg->feature_dim, L = cfg->q_layers, B = cfg->batch_size;
     const int Hse = cfg->se_hidden, T = cfg->test_episodes, K = S + A;
-    if (cfg->agent_kind != 1) return LENV_ERR_INVALID;
+    if (cfg->agent_kind != 1 && cfg->agent_kind != 0) return LENV_ERR_INVALID;
     // the agent's shared nn.PReLU slope is a TRAINED parameter in the reference (model.parameters() -> Adam); a fixed slope
     // would diverge silently, so agent-net PReLU is refused (SE / reward nets keep theirs: the reference never updates those)
     if (cfg->q_act == LENV_ACT_PRELU) return LENV_ERR_UNSUPPORTED;
-    if (cfg->step_budget > 0) return LENV_ERR_UNSUPPORTED;                           // the env-step time-out lives in the DDQN kernel only
     if (cfg->grad_chunk != 0 && cfg->grad_chunk < B) return LENV_ERR_UNSUPPORTED;   // batch gradient = one sequential chunk here
     if (L < 1 || L > D_MAXL || H < 1 || H > D_MAXW || F < 1 || F > D_MAXW || B < 1 || B > GT_I || T < 1 || T > GT_I || cfg->se_layers != 1)
         return LENV_ERR_UNSUPPORTED;
@@ -525,8 +584,11 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     int o = 0, n_in = S;
     for (int l = 0; l < L; ++l) { a.oWf[l] = o; o += H * n_in; a.obf[l] = o; o += H; n_in = H; }
     a.oWf[L] = o; o += F * H; a.obf[L] = o; o += F;
-    a.oWv1 = o; o += F * F; a.obv1 = o; o += F; a.oWv2 = o; o += F; a.obv2 = o; o += 1;
-    a.oWa1 = o; o += F * F; a.oba1 = o; o += F; a.oWa2 = o; o += A * F; a.oba2 = o; o += A;
+    if (plain) { a.oWv1 = a.obv1 = a.oWv2 = a.obv2 = a.oWa1 = a.oba1 = a.oWa2 = a.oba2 = o; }       // no heads
+    else {
+        a.oWv1 = o; o += F * F; a.obv1 = o; o += F; a.oWv2 = o; o += F; a.obv2 = o; o += 1;
+        a.oWa1 = o; o += F * F; a.oba1 = o; o += F; a.oWa2 = o; o += A * F; a.oba2 = o; o += A;
+    }
     a.P = o;
     a.se_net_size[0] = (int)d_mlp_params(K, Hse, 1, S);
     a.se_net_size[1] = a.se_net_size[2] = (int)d_mlp_params(K, Hse, 1, 1);
@@ -548,8 +610,8 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
     a.arena_stride = (off + 63) & ~(int64_t)63;
     const size_t lds_floats = GemmShape<D_MAXI>::PS_FLOATS + GemmShape<D_MAXI>::QS_FLOATS + GEMM_QUEUE_MAX * sizeof(GemmCmd) / sizeof(float) +
-                              3 * K * Hse + 3 * Hse + (S + 2) * Hse + 16 + 3 * Hse + 3 * (size_t)B * A + 3 * (size_t)(B > T ? B : T) * (1 + A) +
-                              B + (size_t)B * A + 64 + 2 * (4 * (size_t)T + T) + 2 * T + 8 + 16 + 16;
+                              3 * K * Hse + 3 * Hse + (S + 2) * Hse + 16 + 3 * Hse + 3 * (size_t)(B > T ? B : T) * A + 3 * (size_t)(B > T ? B : T) * (1 + A) +
+                              B + (size_t)B * A + 64 + 2 * (4 * (size_t)T + T) + 2 * T + 8 + 16 + 16 + (size_t)T;
     *lds_bytes = lds_floats * sizeof(float);
     if (*lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     return LENV_OK;

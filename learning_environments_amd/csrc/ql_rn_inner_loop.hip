@@ -124,8 +124,17 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
     int64_t n_eps = 0, n_act = 0, train_steps = 0, learn_steps = 0, test_steps = 0;
     double eps_g = cfg.eps_init;
 
-    auto test_phase = [&]() {
+    // BaseAgent.test; with `budgeted` the time_is_up check of base_agent.py:177-184 runs before every episode against the
+    // env steps this test has used (`remaining` = budget left when the test starts) and pads like base_agent.py:33-36
+    auto test_phase = [&](bool budgeted = false, int64_t remaining = 0) {
+        int64_t used = 0;
         for (int te = 0; te < cfg.test_episodes; ++te) {
+            if (budgeted && used > remaining) {
+                double mn = -1e9;
+                if (te > 0) { mn = rets[0]; for (int i = 1; i < te; ++i) if (rets[i] < mn) mn = rets[i]; }
+                for (int i = te; i < cfg.test_episodes; ++i) rets[i] = mn;
+                break;
+            }
             int s = cfg.start_state;
             float ep_reward = 0.0f;                                    // fp32 tensor accumulation, base_agent.py:212
             for (int st = 0; st < cfg.max_steps; ++st) {
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
                 const int dn = a.done[s * A + ac];
                 ep_reward = ep_reward + (float)a.reward[s * A + ac];
                 s = a.next_state[s * A + ac];
-                ++test_steps;
+                ++test_steps; ++used;
                 if (dn) break;
             }
             rets[te] = (double)ep_reward;
@@ -141,7 +150,10 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
     };
     auto mean_rets = [&]() { double sm = 0.0; for (int i = 0; i < cfg.test_episodes; ++i) sm += rets[i]; return sm / (double)cfg.test_episodes; };
 
+    int timed_out_at = -1;
     for (int episode = 0; episode < cfg.train_episodes; ++episode) {
+        // deterministic time-out (lenv_ql_cfg::step_budget, base_agent.py:30-47,90-97): elapsed = env steps taken so far
+        if (cfg.step_budget > 0 && train_steps + test_steps > cfg.step_budget) { timed_out_at = episode; break; }
         if (episode == 0) eps_g = cfg.eps_init;                       // QL.py:101-106
         else { eps_g *= cfg.eps_decay; if (eps_g < cfg.eps_min) eps_g = cfg.eps_min; }
         int s = cfg.start_state, ep_len = 0;
@@ -214,17 +226,26 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
             if (sm / ((double)(episode + 1 - lo) + 1e-9) >= cfg.solved_reward) break;
         }
     }
-    test_phase();
+    test_phase(cfg.step_budget > 0, cfg.step_budget - (train_steps + test_steps));
     a.out.score[chain] = mean_rets();
     if (a.out.final_returns) for (int i = 0; i < cfg.test_episodes; ++i) a.out.final_returns[chain * cfg.test_episodes + i] = rets[i];
     if (a.out.stats) {
         a.out.stats[chain * 4 + 0] = episodes_run; a.out.stats[chain * 4 + 1] = train_steps;
         a.out.stats[chain * 4 + 2] = learn_steps; a.out.stats[chain * 4 + 3] = test_steps;
     }
-    const double nan = __builtin_nan("");
+    double pad_r = __builtin_nan("");
+    int pad_l = 0;
+    if (timed_out_at >= 0) {                                          // time_is_up's padding, base_agent.py:33-44
+        pad_r = -1e9; pad_l = 1000000000;
+        if (episodes_run > 0) { pad_r = meter[0]; for (int i = 1; i < episodes_run; ++i) if (meter[i] < pad_r) pad_r = meter[i]; }
+        if (episodes_run > 0 && a.out.episode_len) {
+            pad_l = a.out.episode_len[chain * cfg.train_episodes];
+            for (int i = 1; i < episodes_run; ++i) { const int l = a.out.episode_len[chain * cfg.train_episodes + i]; if (l > pad_l) pad_l = l; }
+        }
+    }
     for (int e = episodes_run; e < cfg.train_episodes; ++e) {
-        if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + e] = nan;
-        if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = 0;
+        if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + e] = pad_r;
+        if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = pad_l;
     }
     if (a.out.q_table) for (int i = 0; i < N * A; ++i) a.out.q_table[chain * N * A + i] = q[i];
     if (a.out.status) a.out.status[chain] = status;

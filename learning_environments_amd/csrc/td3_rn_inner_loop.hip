@@ -253,7 +253,11 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     };
 
     const float g32 = (float)cfg.gamma;
+    // Deterministic time-out (lenv_td3_cfg::step_budget, base_agent.py:30-47): elapsed = env steps taken so far
+    const bool budgeted = cfg.step_budget > 0;
+    int timed_out_at = -1;
     for (int episode = 0; episode < cfg.train_episodes; ++episode) {
+        if (budgeted && (int64_t)train_steps + test_steps > cfg.step_budget) { timed_out_at = episode; break; }   // uniform
         const bool learning = episode >= cfg.init_episodes;
         // env.reset(): RewardEnv.reset -> real_env.reset() (reward_env.py:141-143)
         for (int i = tid; i < S; i += DNT) {
@@ -455,7 +459,26 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         if (brk) break;
     }
     PT_MARK(10);
+    const int64_t remaining = cfg.step_budget - ((int64_t)train_steps + test_steps);     // time_remaining - elapsed
+    const int test_before = test_steps;
     test_phase();
+    if (budgeted) {
+        // BaseAgent.test under the time-out (base_agent.py:177-184): every stand-in episode lasts max_steps; episode e starts only
+        // while the earlier ones used <= remaining steps, the rest is padded with the minimum so far (-1e9 if empty)
+        int64_t used = 0;
+        int stop = T;
+        for (int te = 0; te < T; ++te) {
+            if (used > remaining) { stop = te; break; }
+            used += cfg.max_steps;
+        }
+        if (tid == 0) {
+            double mn = -1e9;
+            if (stop > 0) { mn = ret[0]; for (int i = 1; i < stop; ++i) if (ret[i] < mn) mn = ret[i]; }
+            for (int te = stop; te < T; ++te) ret[te] = mn;
+        }
+        test_steps = test_before + (int)used;
+        __syncthreads();
+    }
     PT_MARK(9);
 #ifdef LENV_PHASE_TIMING
     if (tid == 0 && chain == 0) for (int pi = 0; pi < 12; ++pi) g_td3_phase_cycles[pi] = pt_acc[pi];
@@ -469,10 +492,20 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             a.out.stats[chain * 4 + 0] = episodes_run; a.out.stats[chain * 4 + 1] = train_steps;
             a.out.stats[chain * 4 + 2] = learn_it; a.out.stats[chain * 4 + 3] = test_steps;
         }
-        const double nan = __builtin_nan("");
+        // episodes that never ran: NaN / 0, or -- after a time-out -- time_is_up's padding (base_agent.py:33-44)
+        double pad_r = __builtin_nan("");
+        int pad_l = 0;
+        if (timed_out_at >= 0) {
+            pad_r = -1e9; pad_l = 1000000000;
+            if (episodes_run > 0) { pad_r = meter[0]; for (int i = 1; i < episodes_run; ++i) if (meter[i] < pad_r) pad_r = meter[i]; }
+            if (episodes_run > 0 && a.out.episode_len) {
+                pad_l = a.out.episode_len[chain * cfg.train_episodes];
+                for (int i = 1; i < episodes_run; ++i) { const int l = a.out.episode_len[chain * cfg.train_episodes + i]; if (l > pad_l) pad_l = l; }
+            }
+        }
         for (int e = episodes_run; e < cfg.train_episodes; ++e) {
-            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + e] = nan;
-            if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = 0;
+            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + e] = pad_r;
+            if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = pad_l;
         }
     }
     if (a.out.final_params) for (int p = tid; p < P; p += DNT) a.out.final_params[chain * P + p] = params[p];

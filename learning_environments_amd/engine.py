@@ -130,7 +130,10 @@ class InnerLoop(object):
         self.cfg, self.chains = cfg, int(chains)
         L = _lib.lib()
         E, T, S = cfg.train_episodes, cfg.test_episodes, cfg.state_dim
-        self.dueling = cfg.agent_kind == 1
+        # DuelingDDQN, and DDQN whose Critic_DQN the register-resident kernel refuses (hidden_layer >= 2 / wide layers),
+        # run in the GEMM-tiled kernel; `dueling` keeps its name from the first of the two
+        self.dueling = cfg.agent_kind == 1 or (cfg.agent_kind == 0 and L.lenv_ddqn_se_lds_bytes(C.byref(cfg)) <= 0
+                                               and L.lenv_dueling_num_params(C.byref(cfg)) > 0)
         if self.dueling:
             self.p_agent = int(L.lenv_dueling_num_params(C.byref(cfg)))
             _lib.check(min(self.p_agent, 0), "lenv_dueling_num_params")

@@ -848,6 +848,35 @@ static void run_test_phase_budget(const orc_ddqn_cfg *cfg, const orc_mlp_desc *q
     free(len);
 }
 
+/* time_is_up for a finished test phase (base_agent.py:177-184 + :30-47) with per-episode lengths: episode e may start only
+ * while the earlier episodes used <= remaining steps; later returns are padded with the minimum so far (-1e9 if none).
+ * Returns the steps of the episodes that ran. */
+static int64_t budget_cut_test(double *returns, const int64_t *len, int T, int64_t remaining)
+{
+    int64_t used = 0;
+    int stop = T;
+    for (int te = 0; te < T; ++te) {
+        if (used > remaining) { stop = te; break; }
+        used += len[te];
+    }
+    double mn = -1e9;
+    if (stop > 0) { mn = returns[0]; for (int i = 1; i < stop; ++i) if (returns[i] < mn) mn = returns[i]; }
+    for (int te = stop; te < T; ++te) returns[te] = mn;
+    return used;
+}
+
+/* time_is_up padding of the per-episode lists after a training time-out (base_agent.py:33-44) */
+static void budget_pad_train(double *episode_test_mean, int32_t *episode_len, const double *meter, int n_meter, int episodes_run, int train_episodes)
+{
+    double mn = -1e9; int mx = 1000000000;
+    if (n_meter > 0) { mn = meter[0]; for (int i = 1; i < n_meter; ++i) if (meter[i] < mn) mn = meter[i]; }
+    if (episodes_run > 0 && episode_len) { mx = episode_len[0]; for (int i = 1; i < episodes_run; ++i) if (episode_len[i] > mx) mx = episode_len[i]; }
+    for (int e = episodes_run; e < train_episodes; ++e) {
+        if (episode_test_mean) episode_test_mean[e] = mn;
+        if (episode_len) episode_len[e] = mx;
+    }
+}
+
 static double mean_seq(const double *v, int n)
 {
     double s = 0.0;
@@ -966,21 +995,10 @@ int orc_ddqn_se_chain(const orc_ddqn_cfg *cfg, const float *se_params, const flo
             if (avg >= cfg->solved_reward) break;
         }
     }
-    if (timed_out_at >= 0) {
-        /* time_is_up padding (base_agent.py:33-44): rewards with the minimum so far (-1e9 if none), lengths with the maximum
-         * so far (1e9 if none) */
-        double mn = -1e9; int mx = 1000000000;
-        if (n_meter > 0) { mn = meter[0]; for (int i = 1; i < n_meter; ++i) if (meter[i] < mn) mn = meter[i]; }
-        if (episodes_run > 0 && episode_len) { mx = episode_len[0]; for (int i = 1; i < episodes_run; ++i) if (episode_len[i] > mx) mx = episode_len[i]; }
-        for (int e = episodes_run; e < cfg->train_episodes; ++e) {
-            if (episode_test_mean) episode_test_mean[e] = mn;
-            if (episode_len) episode_len[e] = mx;
-        }
-    } else {
-        for (int e = episodes_run; e < cfg->train_episodes; ++e) {
-            if (episode_test_mean) episode_test_mean[e] = NAN;
-            if (episode_len) episode_len[e] = 0;
-        }
+    if (timed_out_at >= 0) budget_pad_train(episode_test_mean, episode_len, meter, n_meter, episodes_run, cfg->train_episodes);
+    else for (int e = episodes_run; e < cfg->train_episodes; ++e) {
+        if (episode_test_mean) episode_test_mean[e] = NAN;
+        if (episode_len) episode_len[e] = 0;
     }
     /* final test (GTN_worker.py:199) with the time that is left (GTN_worker.py:199 time_remaining - elapsed) */
     if (budgeted) run_test_phase_budget(cfg, &qd, online, &rng, test_returns, &test_steps, z, a, cfg->step_budget - (train_steps + test_steps));
@@ -1112,8 +1130,9 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
     int64_t *visits = calloc((size_t)N * A, sizeof(int64_t)); /* visitation_table n(s,a)  QL.py:31 */
     double *meter = malloc(sizeof(double) * (cfg->train_episodes > 0 ? cfg->train_episodes : 1));
     double *rets = malloc(sizeof(double) * (cfg->test_episodes > 0 ? cfg->test_episodes : 1));
+    int64_t *tlens = malloc(sizeof(int64_t) * (cfg->test_episodes > 0 ? cfg->test_episodes : 1));
     int64_t n_eps = 0, n_act = 0, train_steps = 0, learn_steps = 0, test_steps = 0;
-    int err = 0, episodes_run = 0, n_meter = 0;
+    int err = 0, episodes_run = 0, n_meter = 0, timed_out = 0;
     double eps = cfg->eps_init;
     if (trace) trace->n = 0;
 
@@ -1121,18 +1140,20 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
     for (int te = 0; te < cfg->test_episodes; ++te) {                                                         \
         int s = cfg->start_state;                                                                             \
         float ep_reward = 0.0f;                                                                               \
+        tlens[te] = 0;                                                                                        \
         for (int t = 0; t < cfg->max_steps; ++t) {                                                            \
             int ac = ql_argmax_f32(q + (size_t)s * A, A);                                                     \
             int dn = done_tab[s * A + ac];                                                                    \
             ep_reward = ep_reward + (float)reward[s * A + ac];                                                \
             s = next_state[s * A + ac];                                                                       \
-            ++test_steps;                                                                                     \
+            ++test_steps; ++tlens[te];                                                                        \
             if (dn) break;                                                                                    \
         }                                                                                                     \
         rets[te] = (double)ep_reward;                                                                         \
     }
 
     for (int episode = 0; episode < cfg->train_episodes; ++episode) {
+        if (cfg->step_budget > 0 && train_steps + test_steps > cfg->step_budget) { timed_out = 1; break; }   /* time_is_up */
         if (episode == 0) eps = cfg->eps_init;                                  /* QL.py:101-106 */
         else { eps *= cfg->eps_decay; if (eps < cfg->eps_min) eps = cfg->eps_min; }
         int s = cfg->start_state, ep_len = 0;                                   /* RewardEnv.reset -> real_env.reset() */
@@ -1206,11 +1227,16 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
             if (sm / ((double)(n_meter - lo) + 1e-9) >= cfg->solved_reward) break;
         }
     }
-    for (int e = episodes_run; e < cfg->train_episodes; ++e) {
+    if (timed_out) budget_pad_train(episode_test_mean, episode_len, meter, n_meter, episodes_run, cfg->train_episodes);
+    else for (int e = episodes_run; e < cfg->train_episodes; ++e) {
         if (episode_test_mean) episode_test_mean[e] = NAN;
         if (episode_len) episode_len[e] = 0;
     }
-    QL_TEST_PHASE()
+    {
+        const int64_t remaining = cfg->step_budget - (train_steps + test_steps), before = test_steps;
+        QL_TEST_PHASE()
+        if (cfg->step_budget > 0) test_steps = before + budget_cut_test(rets, tlens, cfg->test_episodes, remaining);
+    }
 #undef QL_TEST_PHASE
     if (final_test_returns) memcpy(final_test_returns, rets, sizeof(double) * cfg->test_episodes);
     if (q_table_out) memcpy(q_table_out, q, sizeof(double) * N * A);
@@ -1218,7 +1244,7 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
         res->score = mean_seq(rets, cfg->test_episodes);
         res->episodes_run = episodes_run; res->train_steps = train_steps; res->learn_steps = learn_steps; res->test_steps = test_steps;
     }
-    free(shaped); free(q); free(visits); free(meter); free(rets);
+    free(shaped); free(q); free(visits); free(meter); free(rets); free(tlens);
     return err;
 }
 

@@ -175,6 +175,7 @@ typedef struct {
     int32_t agent_kind;                 /* 0 QL (agents/QL.py), 1 SARSA (agents/SARSA.py) */
     int32_t count_based;                /* ql_cb / sarsa_cb (agent_utils.py:57-64): reward += beta / (sqrt(n(s,a)) + 1e-9) */
     double solved_reward, alpha, gamma, eps_init, eps_min, eps_decay, beta;
+    int64_t step_budget;
 } orc_ql_cfg;
 
 typedef struct {
@@ -209,6 +210,7 @@ typedef struct {
     int32_t batch_size, rb_size, train_episodes, test_episodes, init_episodes, early_out_num, policy_delay, rng_mode;
     double solved_reward, gamma, lr, tau, action_std, policy_std, policy_std_clip, max_action;
     double adam_beta1, adam_beta2, adam_eps;
+    int64_t step_budget;
 } orc_td3_cfg;
 
 typedef struct {

@@ -56,7 +56,7 @@ class QlCfg(C.Structure):
                 ("init_episodes", C.c_int32), ("early_out_num", C.c_int32), ("batch_size", C.c_int32), ("rng_mode", C.c_int32),
                 ("agent_kind", C.c_int32), ("count_based", C.c_int32),
                 ("solved_reward", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double), ("eps_init", C.c_double),
-                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double)]
+                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double), ("step_budget", C.c_int64)]
 
 
 class QlTrace(C.Structure):
@@ -73,7 +73,8 @@ class Td3Cfg(C.Structure):
                 ("policy_delay", C.c_int32), ("rng_mode", C.c_int32),
                 ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
                 ("action_std", C.c_double), ("policy_std", C.c_double), ("policy_std_clip", C.c_double),
-                ("max_action", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
+                ("max_action", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
+                ("step_budget", C.c_int64)]
 
 
 class Td3Tapes(C.Structure):
@@ -385,7 +386,8 @@ def ql_cfg_from_config(config, tables, rng_mode=0, **overrides):
                 train_episodes=int(a["train_episodes"]), test_episodes=int(a["test_episodes"]),
                 init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]), batch_size=int(a["batch_size"]),
                 rng_mode=rng_mode, solved_reward=float(e["solved_reward"]), alpha=float(a["alpha"]), gamma=float(a["gamma"]),
-                eps_init=float(a["eps_init"]), eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]))
+                eps_init=float(a["eps_init"]), eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]),
+                step_budget=int(a.get("step_budget", 0)))
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg
@@ -477,7 +479,7 @@ def td3_cfg_from_config(config, rng_mode=0, **overrides):
                  policy_delay=int(a["policy_delay"]), rng_mode=rng_mode, solved_reward=float(e["solved_reward"]),
                  gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), action_std=float(a["action_std"]),
                  policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=1.0,
-                 adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8)
+                 adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, step_budget=int(a.get("step_budget", 0)))
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg

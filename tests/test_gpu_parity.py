@@ -755,6 +755,71 @@ def test_inner_loop_step_budget_vs_oracle(eng, orc, budget):
         assert timed_out == 0
 
 
+@pytest.mark.parametrize("budget", [1, 60, 200, 10 ** 6])
+def test_step_budget_other_kernels_vs_oracle(eng, orc, golden, budget):
+    """The env-step time-out in the DuelingDDQN, TD3 and QL kernels: counters, padded per-episode lists, cut final test and
+    score bit-exact against the oracle, for a budget that stops training at once, in the middle, inside the final test, never."""
+    from learning_environments_amd import configs
+    from learning_environments_amd.envs.gridworld import transition_tables
+    rng = np.random.RandomState(5)
+    key = orc.chain_key(6, 0, 0, 0)
+    kt = dev(np.array([key], np.uint64).view(np.int64))
+    # DuelingDDQN on an Acrobot SE
+    g = golden("g8d_calc_score_acrobot_dueling")
+    cfgd = json.loads(str(g["config_json"]))
+    cfgd["agents"]["duelingddqn"].update(hidden_size=24, feature_dim=16, batch_size=16, test_episodes=3, init_episodes=1, step_budget=budget)
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, train_episodes=4, max_steps=9)
+    S, A = ocfg.state_dim, ocfg.num_actions
+    theta = (rng.randn(sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, ocfg.se_hidden, 1, "leakyrelu"))) * 0.15).astype(np.float32)
+    init = rng.uniform(-0.15, 0.15, (1, orc.dueling_num_params(ocfg))).astype(np.float32)
+    il = eng.InnerLoop(cfg, 1)
+    il.run(dev(theta), None, None, None, dev(init), rng_keys=kt)
+    torch.cuda.synchronize()
+    o = orc.ddqn_se_chain(ocfg, theta, init[0], rng_key=key)
+    assert il.stats[0].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+    assert np.array_equal(il.episode_test_mean[0].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+    assert np.array_equal(il.episode_len[0].cpu().numpy(), o["episode_len"])
+    assert np.array_equal(il.final_returns[0].cpu().numpy(), o["final_test_returns"]) and float(il.score[0]) == o["score"]
+    if budget == 1:
+        assert o["episodes_run"] == 1 and o["score"] == -1e9
+    # TD3 on the stand-in RewardEnv
+    g = golden("g8t_calc_score_cheetah_td3")
+    cfgd = json.loads(str(g["config_json"]))
+    cfgd["agents"]["td3"].update(hidden_size=24, hidden_layer=1, batch_size=16, train_episodes=4, init_episodes=1, test_episodes=3, step_budget=budget)
+    cfgd["envs"]["HalfCheetah-v3"].update(max_steps=6, hidden_size=24)
+    ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
+    assert cfg.step_budget == budget
+    Pa, Pc = orc.td3_param_counts(ocfg)
+    theta = (rng.randn(orc.rn_num_params(ocfg.reward_env_type, 17, 4, 24, 1)) * 0.2).astype(np.float32)
+    init = rng.uniform(-0.2, 0.2, (1, Pa + 2 * Pc)).astype(np.float32)
+    il = eng.Td3InnerLoop(cfg, 1)
+    il.run(dev(theta), None, None, None, dev(init), rng_keys=kt)
+    torch.cuda.synchronize()
+    o = orc.td3_rn_chain(ocfg, theta, init[0], rng_key=key)
+    assert il.stats[0].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+    assert np.array_equal(il.episode_test_mean[0].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+    assert np.array_equal(il.episode_len[0].cpu().numpy(), o["episode_len"])
+    assert np.array_equal(il.final_returns[0].cpu().numpy(), o["final_test_returns"]) and float(il.score[0]) == o["score"]
+    # QL on the Cliff RewardEnv
+    cfgd = configs.cliff_reward_env_ql(num_workers=1)
+    cfgd["agents"]["ql"].update(train_episodes=8, test_episodes=3, step_budget=budget)
+    cfgd["envs"]["Cliff"]["solved_reward"] = 1e9
+    tables = transition_tables("Cliff")
+    from learning_environments_amd.config import ql_cfg_from_config
+    cfg = ql_cfg_from_config(cfgd, tables)
+    ocfg = orc.ql_cfg_from_config(cfgd, tables)
+    assert cfg.step_budget == budget and ocfg.step_budget == budget
+    theta = (rng.randn(48 * 32 + 32 + 32 + 1) * 0.3).astype(np.float32)
+    il = eng.QlInnerLoop(cfg, 1, tables)
+    il.run(dev(theta), None, None, None, rng_keys=kt)
+    torch.cuda.synchronize()
+    o = orc.ql_rn_chain(ocfg, theta, tables, rng_key=key)
+    assert il.stats[0].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+    assert np.array_equal(il.episode_test_mean[0].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+    assert np.array_equal(il.episode_len[0].cpu().numpy(), o["episode_len"])
+    assert np.array_equal(il.final_returns[0].cpu().numpy(), o["final_test_returns"]) and float(il.score[0]) == o["score"]
+
+
 def test_dueling_and_td3_early_out(eng, orc, golden):
     """BaseAgent.train's early-out (base_agent.py:141-148: mean of the last early_out_num real-env test means >= solved_reward,
     only once learning has started) in the big-net kernels: fewer episodes than train_episodes, same as the oracle."""
