@@ -211,6 +211,10 @@ int lenv_real_env_step(int32_t env_id, int32_t max_steps, int64_t n, const int32
  * models/actor_critic.py:94-122; BASELINE config 3).  Same contract and outputs as lenv_ddqn_se_inner_loop; the agent's
  * parameters / Adam state / activations live in the workspace (lenv_dueling_se_workspace_bytes), agent_init is
  * [chains, lenv_dueling_num_params(cfg)] in state-dict order feature_stream | value_stream | advantage_stream.
+ * cfg.agent_kind == 0 selects the plain-DQN mode: a DDQN (agents/DDQN.py:60-94) whose Critic_DQN (models/actor_critic.py:
+ * 84-91) has q_layers 1-2 hidden layers of up to 128 units -- the shapes lenv_ddqn_se_inner_loop refuses, e.g. the
+ * 6-128-128-3 net of default_config_acrobot.yaml; cfg.feature_dim is ignored, cfg.grad_chunk must be 0 (one sequential
+ * batch gradient), agent_init is [chains, lenv_dueling_num_params(cfg)] in the Critic_DQN state-dict order.
  */
 size_t lenv_dueling_se_workspace_bytes(const lenv_ddqn_cfg *cfg /*HOST*/, int64_t chains);
 int64_t lenv_dueling_num_params(const lenv_ddqn_cfg *cfg /*HOST*/);

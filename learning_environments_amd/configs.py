@@ -47,6 +47,18 @@ def acrobot_syn_env_duelingddqn(num_workers=256, max_iterations=50):
     })
 
 
+def acrobot_syn_env_ddqn(num_workers=256, max_iterations=50):
+    """Acrobot-v1 SE + the DDQN section of default_config_acrobot.yaml (:30-48: Critic_DQN 6-128-128-3, relu, batch 128,
+    init_episodes 1).  Its two-hidden-layer Q-net runs in the GEMM-tiled kernel's plain-DQN mode."""
+    cfg = acrobot_syn_env_duelingddqn(num_workers, max_iterations)
+    cfg["agents"]["gtn"]["agent_name"] = "DDQN"
+    d = cfg["agents"].pop("duelingddqn")
+    d.pop("feature_dim")
+    d.update(init_episodes=1, print_rate=10)
+    cfg["agents"]["ddqn"] = d
+    return cfg
+
+
 def cliff_reward_env_ql(num_workers=128, max_iterations=50):
     """BASELINE config 4: Cliff gridworld RewardEnv (potential shaped, type 2) + tabular QL (values = the published
     hyper-parameters of default_config_gridworld_reward_env.yaml: gtn :5-26, ql :28-43, Cliff :126-133)."""

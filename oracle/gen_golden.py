@@ -985,6 +985,12 @@ def main():
                env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="duelingddqn",
                agent_over={"hidden_size": 128, "hidden_layer": 2, "feature_dim": 128, "batch_size": 128, "init_episodes": 1, "test_episodes": 2},
                env_over={"hidden_size": 128, "solved_reward": 0.5})
+    if "g8l2" in which:
+        # the DDQN of default_config_acrobot.yaml (Critic_DQN 6-128-128-3, relu, B 128) on a synthetic Acrobot: the
+        # multi-layer Q-net that only the GEMM-tiled kernel takes
+        gen_g8("g8l2_calc_score_acrobot_ddqn_2layer", train_episodes=3, done_bias_shift=0.0, seed=812, max_steps=20,
+               env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="ddqn",
+               agent_over={"init_episodes": 1, "test_episodes": 2}, env_over={"hidden_size": 128, "solved_reward": 0.5})
     if "g8d" in which:
         gen_g8("g8d_calc_score_acrobot_dueling", train_episodes=4, done_bias_shift=0.0, seed=810, max_steps=25,
                env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="duelingddqn",

@@ -232,6 +232,28 @@ def test_gtn_master_acrobot_dueling_generation(tmp_path, monkeypatch):
     assert len(mean_list) == 1 and -10.0 <= mean_score <= 0.0
 
 
+def test_gtn_master_acrobot_ddqn_two_layer_generation(tmp_path, monkeypatch):
+    """default_config_acrobot.yaml's DDQN (Critic_DQN 6-128-128-3, B 128) through GTN_Master: the config builder keeps
+    grad_chunk 0, InnerLoop routes to the GEMM-tiled kernel, and the fitness triples equal an oracle evaluation."""
+    from learning_environments_amd.configs import acrobot_syn_env_ddqn, fixed_work
+    from oracle import oracle as orc
+    cfg = fixed_work(acrobot_syn_env_ddqn(num_workers=2, max_iterations=1), 2)
+    cfg["envs"]["Acrobot-v1"]["max_steps"] = 10
+    cfg["agents"]["ddqn"].update(test_episodes=2)
+    m = _master_pair(cfg, tmp_path, monkeypatch)
+    assert m.cfg.agent_kind == 0 and m.cfg.grad_chunk == 0 and m.inner.dueling and m.inner.p_agent == 17795
+    theta0 = m.theta.cpu().numpy().copy()
+    gathered = m.evaluate_population(0).cpu().numpy()
+    eps = m.eps.cpu().numpy()
+    oeps, init, okeys = orc.nes_draw(m.seed, 0, 2, m.p_theta, cfg["agents"]["gtn"]["noise_std"], 6, 3, 0, m.agent_bounds.cpu().numpy())
+    assert np.array_equal(eps, oeps)
+    ocfg = orc.ddqn_cfg_from_config(cfg, grad_chunk=0)
+    scores = orc.ddqn_se_population(ocfg, theta0, eps, init, seed=m.seed, generation=0, threads=6)
+    best, sign = orc.worker_best(scores[1::3], scores[2::3], True)
+    assert np.array_equal(gathered[:, 0], best) and np.array_equal(gathered[:, 1], scores[0::3])
+    assert np.array_equal(gathered[:, 2], sign.astype(np.float64))
+
+
 def test_reward_env_cheetah_standin_step_matches_reference(golden):
     """EnvWrapper.step on the continuous-state RewardEnv: next states bit-equal to the shim run of the reference, shaped
     rewards within the fixture tolerance."""

@@ -119,11 +119,13 @@ def _inner_cfg(orc, cfgd, **over):
     return o, c
 
 
-@pytest.mark.parametrize("name", ["g8_calc_score_cartpole_a", "g8_calc_score_cartpole_b", "g8w_calc_score_cartpole_ringwrap"])
-def test_inner_loop_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
+@pytest.mark.parametrize("name,chunk", [("g8_calc_score_cartpole_a", 17), ("g8_calc_score_cartpole_b", 17),
+                                        ("g8w_calc_score_cartpole_ringwrap", 17),
+                                        ("g8l2_calc_score_acrobot_ddqn_2layer", 0)])   # Critic_DQN 6-128-128-3 -> GEMM-tiled kernel
+def test_inner_loop_tape_mode_vs_reference_and_oracle(eng, orc, golden, name, chunk):
     g = golden(name)
     cfgd = json.loads(str(g["config_json"]))
-    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=17, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=chunk, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
     n = g["tr_action"].size
     otapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
     o = orc.ddqn_se_chain(ocfg, g["theta"], g["agent_init"], tapes=otapes, trace_cap=n + 8)
@@ -223,7 +225,7 @@ def test_inner_loop_early_out(eng, orc, golden):
 def test_unsupported_shapes_raise(eng, orc, golden):
     g = golden("g8_calc_score_cartpole_a")
     cfgd = json.loads(str(g["config_json"]))
-    _, cfg = _inner_cfg(orc, cfgd, q_layers=2)
+    _, cfg = _inner_cfg(orc, cfgd, se_layers=2)            # neither fused kernel takes a two-hidden-layer SE
     with pytest.raises(NotImplementedError):
         il = eng.InnerLoop(cfg, 1)
         il.run(dev(g["theta"]), None, None, None, dev(np.zeros((1, il.p_agent), np.float32)), rng_keys=dev(np.zeros(1, np.int64)))
@@ -427,6 +429,53 @@ def test_dueling_counter_mode_vs_oracle(eng, orc, golden, env_name, layers, hidd
         assert np.array_equal(il.trace["action"][c, :n].cpu().numpy() & 0xFFFF, o["trace"]["action"]), c
         assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"]), c
         assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
+@pytest.mark.parametrize("env_name,layers,hidden,batch,act,T", [("Acrobot-v1", 2, 128, 128, "relu", 3), ("CartPole-v0", 2, 64, 64, "tanh", 4),
+                                                                 ("CartPole-v0", 2, 33, 50, "leakyrelu", 70),      # test rows > batch rows
+                                                                 ("Acrobot-v1", 2, 40, 20, "relu", 2)])           # rb_size 23: ring wraps
+def test_ddqn_multilayer_counter_mode_vs_oracle(eng, orc, golden, env_name, layers, hidden, batch, act, T):
+    """DDQN whose Critic_DQN has hidden_layer >= 2 (default_config_acrobot.yaml: 6-128-128-3) runs in the GEMM-tiled kernel's
+    plain-DQN mode: bit-exact against the oracle's DDQN with one sequential batch gradient."""
+    from learning_environments_amd.config import ddqn_cfg_from_config
+    g = golden("g8l2_calc_score_acrobot_ddqn_2layer")
+    cfgd = json.loads(str(g["config_json"]))
+    cfgd["env_name"] = env_name
+    cfgd["envs"][env_name] = dict(cfgd["envs"]["Acrobot-v1"], hidden_size=48)
+    cfgd["agents"]["ddqn"].update(hidden_size=hidden, hidden_layer=layers, batch_size=batch, activation_fn=act, test_episodes=T)
+    if batch == 20:
+        cfgd["agents"]["ddqn"]["rb_size"] = 23
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, train_episodes=3, max_steps=12)
+    assert cfg.agent_kind == 0 and cfg.q_layers == layers
+    # the package's own cfg builder keeps grad_chunk 0 for these shapes (pick_grad_chunk's second probe)
+    assert ddqn_cfg_from_config(cfgd, train_episodes=3, max_steps=12).grad_chunk == 0
+    S, A = ocfg.state_dim, ocfg.num_actions
+    rng = np.random.RandomState(18)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, ocfg.se_hidden, 1, "leakyrelu"))
+    P_q = orc.mlp_num_params(orc.mlp_desc(S, hidden, layers, A, act))
+    chains = 3
+    theta = (rng.randn(P_se) * 0.15).astype(np.float32)
+    eps = (rng.randn(1, P_se) * 0.05).astype(np.float32)
+    agent_init = (rng.uniform(-0.15, 0.15, (chains, P_q))).astype(np.float32)
+    worker = np.zeros(chains, np.int32)
+    sign = np.array([0.0, 1.0, -1.0], np.float32)
+    keys = np.array([orc.chain_key(19, 2, 0, c) for c in range(chains)], np.uint64)
+    il = eng.InnerLoop(cfg, chains, trace_cap=40, want_final_online=True)
+    assert il.dueling and il.p_agent == P_q
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        w = (np.float32(sign[c]) * eps[0] + theta).astype(np.float32)
+        o = orc.ddqn_se_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]), trace_cap=40)
+        n = o["trace"]["action"].size
+        assert o["learn_steps"] > 0
+        assert np.array_equal(il.trace["action"][c, :n].cpu().numpy() & 0xFFFF, o["trace"]["action"]), c
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"]), c
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
+        assert np.array_equal(il.final_returns[c].cpu().numpy(), o["final_test_returns"]), c
         assert float(il.score[c]) == o["score"]
         assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
 

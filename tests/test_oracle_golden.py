@@ -140,12 +140,14 @@ def test_g7_master(golden):
     assert np.array_equal(th2, g["theta2"])
 
 
-@pytest.mark.parametrize("name", ["g8_calc_score_cartpole_a", "g8_calc_score_cartpole_b", "g8w_calc_score_cartpole_ringwrap"])
-def test_g8_calc_score_trace(golden, name):
+@pytest.mark.parametrize("name,chunk", [("g8_calc_score_cartpole_a", 13), ("g8_calc_score_cartpole_b", 13),
+                                        ("g8w_calc_score_cartpole_ringwrap", 13),
+                                        ("g8l2_calc_score_acrobot_ddqn_2layer", 0)])   # Critic_DQN 6-128-128-3: batch gradient
+def test_g8_calc_score_trace(golden, name, chunk):
     import json
     g = golden(name)
     cfgd = json.loads(str(g["config_json"]))
-    cfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=13, rng_mode=1, train_episodes=int(g["train_episodes"]),
+    cfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=chunk, rng_mode=1, train_episodes=int(g["train_episodes"]),
                                    max_steps=int(g["max_steps"]))
     tapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"],
                            g["tape_test_reset"])
