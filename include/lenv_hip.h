@@ -89,7 +89,7 @@ typedef struct {
 typedef struct {
     double *score;              /* [chains] statistics.mean(final test returns)   GTN_worker.py:209 */
     int64_t *stats;             /* [chains,4] episodes_run, train_steps, learn_steps, test_steps */
-    int32_t *status;            /* [chains] 0 ok, <0 internal error: -2..-5 tape underrun (eps / action / replay / reset), -6 replay index out of range, -7 unexpected LDS placement */
+    int32_t *status;            /* [chains] 0 ok, <0 internal error: -2..-5 tape underrun (eps / action / replay / reset), -6 replay index out of range, -7 unexpected LDS placement, -8 per-chain hyper-parameter outside cfg's maxima */
     double *episode_test_mean;  /* [chains,train_episodes]  reward_list_train (NaN past early-out) */
     int32_t *episode_len;       /* [chains,train_episodes] */
     double *final_returns;      /* [chains,test_episodes] */
@@ -216,12 +216,36 @@ int lenv_real_env_step(int32_t env_id, int32_t max_steps, int64_t n, const int32
  * 6-128-128-3 net of default_config_acrobot.yaml; cfg.feature_dim is ignored, cfg.grad_chunk must be 0 (one sequential
  * batch gradient), agent_init is [chains, lenv_dueling_num_params(cfg)] in the Critic_DQN state-dict order.
  */
+/*
+ * Per-chain hyper-parameters of the *_vary agents (agents/DDQN_vary.py:26-59, agents/DuelingDDQN_vary.py:24-69: every agent
+ * the worker builds draws its own lr / batch_size / hidden_size / hidden_layer).  Device arrays [chains]; with them the
+ * cfg carries the MAXIMA (batch_size, q_hidden, q_layers: workspace, LDS and the row stride of agent_init / final_online
+ * are sized from cfg) and chain c runs with the c-th entries -- its agent_init row holds lenv_dueling_num_params at ITS
+ * shapes, the rest of the row is ignored.  q_layers = max(1, hidden_layer) as in lenv_ddqn_cfg.  A chain whose values
+ * exceed cfg's reports status -8.
+ */
+typedef struct lenv_chain_hp {
+    const double *lr;
+    const int32_t *batch_size, *q_hidden, *q_layers;
+} lenv_chain_hp;
+
 size_t lenv_dueling_se_workspace_bytes(const lenv_ddqn_cfg *cfg /*HOST*/, int64_t chains);
 int64_t lenv_dueling_num_params(const lenv_ddqn_cfg *cfg /*HOST*/);
 int lenv_dueling_se_inner_loop(const lenv_ddqn_cfg *cfg /*HOST*/, const float *theta, const float *eps,
                                const int32_t *worker, const float *sign, const float *agent_init,
                                const uint64_t *rng_keys, const lenv_tapes *tapes /*HOST, may be NULL*/, int64_t chains,
                                void *workspace, size_t workspace_bytes, const lenv_inner_out *out /*HOST*/, void *stream);
+/* Fresh agents (nn.Linear default init, the draw of lenv_nes_draw) for chains with their own shapes: row c of agent_init
+ * [chains, lenv_dueling_num_params(cfg)] gets the parameters of a (hp->q_hidden[c], hp->q_layers[c]) network, keyed by
+ * rng_keys[c].  hp == NULL: every chain has cfg's shapes (== lenv_nes_draw's agent_init for the same keys). */
+int lenv_dueling_agent_init_hp(const lenv_ddqn_cfg *cfg /*HOST*/, const lenv_chain_hp *hp /*HOST struct of device arrays*/,
+                               const uint64_t *rng_keys, int64_t chains, float *agent_init, void *stream);
+/* the same with per-chain hyper-parameters (hp == NULL: identical to lenv_dueling_se_inner_loop) */
+int lenv_dueling_se_inner_loop_hp(const lenv_ddqn_cfg *cfg /*HOST*/, const lenv_chain_hp *hp /*HOST struct of device arrays*/,
+                                  const float *theta, const float *eps, const int32_t *worker, const float *sign,
+                                  const float *agent_init, const uint64_t *rng_keys, const lenv_tapes *tapes /*HOST*/,
+                                  int64_t chains, void *workspace, size_t workspace_bytes, const lenv_inner_out *out /*HOST*/,
+                                  void *stream);
 
 /*
  * Config 5: fused inner loop for a TD3 agent on a RewardEnv over a continuous-state real env (agents/TD3.py:63-135,
@@ -304,6 +328,8 @@ int lenv_cheetah_standin_step(int32_t max_steps, int64_t n, const float *action,
                               float *obs, float *reward, float *done, void *stream);
 
 /* Counter-RNG key of a chain (same function as the oracle's): kind 0 = theta, 1 = theta+eps, 2 = theta-eps. HOST. */
+/* one uniform in [0,1) of a chain's counter RNG (HOST function, no device work): unit(rng(key, stream, index)) */
+double lenv_rng_unit(uint64_t key, uint32_t stream, uint64_t index);
 uint64_t lenv_chain_key(uint64_t seed, uint64_t generation, uint64_t worker, uint64_t kind);
 
 /*

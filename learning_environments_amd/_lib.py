@@ -52,6 +52,10 @@ class InnerOut(C.Structure):
                 ("trace_state", C.c_void_p), ("trace_next_state", C.c_void_p), ("trace_reward_done", C.c_void_p)]
 
 
+class ChainHp(C.Structure):                  # include/lenv_hip.h: lenv_chain_hp (device arrays [chains])
+    _fields_ = [("lr", C.c_void_p), ("batch_size", C.c_void_p), ("q_hidden", C.c_void_p), ("q_layers", C.c_void_p)]
+
+
 class QlCfg(C.Structure):
     _fields_ = [("n_states", C.c_int32), ("n_actions", C.c_int32), ("start_state", C.c_int32), ("max_steps", C.c_int32),
                 ("rn_hidden", C.c_int32), ("rn_layers", C.c_int32), ("rn_act", C.c_int32), ("rn_prelu", C.c_float),
@@ -98,7 +102,7 @@ class Td3Out(C.Structure):
 EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv_se_step_population",
            "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_lds_bytes", "lenv_ddqn_se_inner_loop",
            "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population", "lenv_dueling_se_workspace_bytes",
-           "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
+           "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_dueling_se_inner_loop_hp", "lenv_dueling_agent_init_hp", "lenv_rng_unit", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
            "lenv_td3_rn_inner_loop", "lenv_mlp_forward", "lenv_cheetah_standin_reset", "lenv_cheetah_standin_step",
            "lenv_rn_num_params", "lenv_rn_shape_rows", "lenv_nes_worker_best_multi", "lenv_nes_draw", "lenv_nes_status_fold"]
 
@@ -155,6 +159,12 @@ def lib():
         L.lenv_dueling_num_params.argtypes = [C.POINTER(DdqnCfg)]
         L.lenv_dueling_se_inner_loop.restype = C.c_int
         L.lenv_dueling_se_inner_loop.argtypes = L.lenv_ddqn_se_inner_loop.argtypes
+        L.lenv_dueling_se_inner_loop_hp.restype = C.c_int
+        L.lenv_dueling_se_inner_loop_hp.argtypes = [L.lenv_ddqn_se_inner_loop.argtypes[0], C.POINTER(ChainHp)] + list(L.lenv_ddqn_se_inner_loop.argtypes[1:])
+        L.lenv_dueling_agent_init_hp.restype = C.c_int
+        L.lenv_dueling_agent_init_hp.argtypes = [C.POINTER(DdqnCfg), C.POINTER(ChainHp), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.lenv_rng_unit.restype = C.c_double
+        L.lenv_rng_unit.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
         L.lenv_td3_rn_workspace_bytes.restype = C.c_size_t
         L.lenv_td3_rn_workspace_bytes.argtypes = [C.POINTER(Td3Cfg), C.c_int64]
         L.lenv_td3_num_params.restype = C.c_int64

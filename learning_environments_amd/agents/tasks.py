@@ -4,6 +4,7 @@ The reference dispatches through select_agent (agents/agent_utils.py:15-66) + En
 combination owns one fused kernel:
     DDQN on a VirtualEnv (synthetic_env_type 0)   -> lenv_ddqn_se_inner_loop   (BASELINE configs 1-2, Acrobot-DDQN)
     DuelingDDQN on a VirtualEnv                   -> lenv_dueling_se_inner_loop (BASELINE config 3)
+    DDQN_vary / DuelingDDQN_vary on a VirtualEnv  -> lenv_dueling_se_inner_loop_hp (per-chain lr / batch / width / depth)
     QL / QL_cb / SARSA / SARSA_cb on a RewardEnv over a gridworld (type 1) -> lenv_ql_rn_inner_loop (BASELINE config 4)
     TD3  on a RewardEnv over the HalfCheetah stand-in -> lenv_td3_rn_inner_loop (BASELINE config 5)
 Anything else raises NotImplementedError, like the reference does for unknown agents."""
@@ -32,6 +33,50 @@ class DdqnSeTask(object):
 
     def needs_agent_init(self):
         return True
+
+
+class DdqnVaryTask(object):
+    """DDQN_vary / DuelingDDQN_vary on a VirtualEnv (agents/DDQN_vary.py, agents/DuelingDDQN_vary.py): every chain draws its
+    own lr / batch_size / hidden_size / hidden_layer (agents/vary.py) and the whole heterogeneous population still runs as ONE
+    launch of the GEMM-tiled kernel (per-chain hyper-parameter arrays, workspace sized for the largest draw)."""
+    name = "ddqn_vary_se"
+
+    def __init__(self, config, engine):
+        import copy
+        from . import vary
+        if engine.name != "hip":
+            raise NotImplementedError("the *_vary agents need the HIP engine")
+        self.engine = engine
+        self.agent_key = config["agents"]["gtn"]["agent_name"].lower()[:-5]
+        self.base = config["agents"][self.agent_key]
+        bd = vary.hp_bounds(self.base)
+        big = copy.deepcopy(config)
+        big["agents"][self.agent_key].update(batch_size=bd["batch_size"][1], hidden_size=bd["hidden_size"][1],
+                                             hidden_layer=bd["hidden_layer"][1])
+        self.cfg = ddqn_cfg_from_config(big)              # the maxima: workspace / LDS / row strides
+        self.cfg.grad_chunk = 0                           # one sequential batch gradient (GEMM-tiled kernel)
+        self.agent_bounds = None
+        self.last_hp = None
+
+    def make_inner(self, chains, want_episode_stats=True):
+        return self.engine.make_inner(self.cfg, chains, want_episode_stats=want_episode_stats, vary=True)
+
+    def draw_hp(self, keys):
+        from . import vary
+        return [vary.vary_hyperparameters(self.base, vary.chain_units(k)) for k in keys]
+
+    def scores(self, inner, theta, eps, chain_worker, chain_sign, keys_t, agent_init):
+        # the draws are a host function of the chain keys (ConfigSpace's role in the reference); reading the keys back
+        # waits only for the generation's draw kernel
+        keys = keys_t.cpu().numpy().view(np.uint64)
+        hp = self.last_hp = self.draw_hp(keys)
+        inner.set_hp([h["lr"] for h in hp], [h["batch_size"] for h in hp], [h["hidden_size"] for h in hp],
+                     [h["hidden_layer"] for h in hp])
+        inner.draw_agent_init(keys_t)
+        return self.engine.inner_scores(inner, theta, eps, chain_worker, chain_sign, None, keys_t)
+
+    def needs_agent_init(self):
+        return False          # drawn inside scores(), once the chains' shapes are known
 
 
 class QlRnTask(object):
@@ -76,6 +121,9 @@ def select_task(config, engine, synthetic_env):
     env_type = config["agents"]["gtn"]["synthetic_env_type"]
     if agent_name in ("ddqn", "duelingddqn") and env_type == 0:
         return DdqnSeTask(config, engine)
+    if agent_name in ("ddqn_vary", "duelingddqn_vary") and env_type == 0:
+        # vary_hp False: the agent IS its base agent (DDQN_vary.py:16-21)
+        return DdqnVaryTask(config, engine) if config["agents"][agent_name]["vary_hp"] else DdqnSeTask(config, engine)
     if agent_name in TABULAR_AGENTS and env_type == 1:
         real = synthetic_env.env.real_env
         if not hasattr(real, "tables"):

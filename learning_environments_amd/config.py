@@ -15,6 +15,8 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
         raise NotImplementedError("real env '%s' has no device implementation yet" % env_name)
     e = config["envs"][env_name]
     agent_key = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "ddqn"
+    if agent_key.endswith("_vary"):                  # DDQN_vary / DuelingDDQN_vary read the base agent's section (DDQN_vary.py:14)
+        agent_key = agent_key[:-5]
     if agent_key not in ("ddqn", "duelingddqn"):
         raise NotImplementedError("ddqn_cfg_from_config: agent '%s'" % agent_key)
     a = config["agents"][agent_key]

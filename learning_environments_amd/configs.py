@@ -103,10 +103,21 @@ def halfcheetah_reward_env_td3(num_workers=64, max_iterations=50):
     })
 
 
+def with_vary(config, vary_hp=True):
+    """The same experiment with the *_vary agent of the family (default_config_acrobot.yaml:26 ships `agent_name: DDQN_vary`;
+    the `<agent>_vary: {vary_hp: ...}` section is :27-28 there)."""
+    cfg = copy.deepcopy(config)
+    base = cfg["agents"]["gtn"]["agent_name"]
+    cfg["agents"]["gtn"]["agent_name"] = base + "_vary"
+    cfg["agents"][base.lower() + "_vary"] = {"vary_hp": bool(vary_hp)}
+    return cfg
+
+
 def fixed_work(config, train_episodes):
     """BASELINE.md §3 fixed-work variant: early-out disabled (solved_reward=+1e9) and a fixed number of train episodes,
     so both the GPU path and the CPU baseline do identical, data-independent amounts of work."""
     cfg = copy.deepcopy(config)
-    cfg["agents"][cfg["agents"]["gtn"]["agent_name"].lower()]["train_episodes"] = train_episodes
+    key = cfg["agents"]["gtn"]["agent_name"].lower()
+    cfg["agents"][key[:-5] if key.endswith("_vary") else key]["train_episodes"] = train_episodes
     cfg["envs"][cfg["env_name"]]["solved_reward"] = 1e9
     return cfg

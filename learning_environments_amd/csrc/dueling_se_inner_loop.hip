@@ -19,9 +19,11 @@
 
 namespace lenv {
 
-constexpr int D_MAXL = 2;         // feature-stream hidden layers supported
-constexpr int D_MAXW = 128;       // max layer width (hidden_size / feature_dim)
-constexpr int D_MAXI = 128;       // max rows of one product (batch size / test episodes)
+constexpr int D_MAXL = 3;         // feature-stream hidden layers supported (the *_vary agents draw hidden_layer + 1)
+constexpr int D_MAXW = 128;       // max feature_dim (head width) and test episodes
+constexpr int D_MAXH = 512;       // max hidden_size  (outputs wider than 128 run as several 128-column blocks)
+constexpr int D_MAXB = 640;       // max batch size   (more than 128 rows run as several 128-row blocks)
+constexpr int D_MAXI = 128;       // rows of one product block
 
 struct DuelArgs {
     lenv_ddqn_cfg cfg;
@@ -31,14 +33,36 @@ struct DuelArgs {
     float *arena; int64_t arena_stride;       // per-chain arena (floats)
     lenv_inner_out out;
     int64_t rb_cap; int RS;
-    int P, P_se, se_net_size[3];
-    // parameter offsets inside one parameter vector
+    int P, P_se, se_net_size[3];              // P: parameters at cfg's (maximal) shapes = row stride of agent_init / final_online
+    // per-chain hyper-parameters (device arrays [chains], all or none): the *_vary agents (agents/DDQN_vary.py:26-59)
+    const double *hp_lr; const int32_t *hp_batch, *hp_hidden, *hp_layers;
+    // arena offsets (floats), sized for cfg's (maximal) shapes
+    int64_t a_online, a_target, a_m, a_v, a_grad, a_replay, a_xs, a_xs2, a_act[D_MAXL], a_feat, a_v1, a_a1,
+        a_t[6], a_dbuf[5], a_meter;
+};
+
+// parameter offsets inside one parameter vector (state-dict order)
+struct DuelOffsets {
     int oWf[D_MAXL + 1], obf[D_MAXL + 1];     // feature stream: hidden layers 0..L-1, then the output Linear (index L)
     int oWv1, obv1, oWv2, obv2, oWa1, oba1, oWa2, oba2;
-    // arena offsets (floats)
-    int64_t a_online, a_target, a_m, a_v, a_grad, a_replay, a_xs, a_xs2, a_act[D_MAXL], a_feat, a_v1, a_a1,
-        a_t[4], a_dbuf[5], a_meter;
+    int P;
 };
+
+__host__ __device__ inline DuelOffsets duel_param_offsets(int S, int A, int H, int F, int L, bool plain)
+{
+    DuelOffsets d;
+    int o = 0, n_in = S;
+    for (int l = 0; l <= D_MAXL; ++l) d.oWf[l] = d.obf[l] = 0;
+    for (int l = 0; l < L; ++l) { d.oWf[l] = o; o += H * n_in; d.obf[l] = o; o += H; n_in = H; }
+    d.oWf[L] = o; o += F * H; d.obf[L] = o; o += F;
+    if (plain) { d.oWv1 = d.obv1 = d.oWv2 = d.obv2 = d.oWa1 = d.oba1 = d.oWa2 = d.oba2 = o; }       // no heads
+    else {
+        d.oWv1 = o; o += F * F; d.obv1 = o; o += F; d.oWv2 = o; o += F; d.obv2 = o; o += 1;
+        d.oWa1 = o; o += F * F; d.oba1 = o; o += F; d.oWa2 = o; o += A * F; d.oba2 = o; o += A;
+    }
+    d.P = o;
+    return d;
+}
 
 // Diagnostic build only (-DLENV_PHASE_TIMING): per-phase shader-clock totals of chain 0, never in the shipped library.
 #ifdef LENV_PHASE_TIMING
@@ -60,8 +84,18 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     // build_nn_from_config(S -> A) with `hidden_layer` hidden layers) does not fit the register-resident small kernel
     // (hidden_layer >= 2, wide layers): the "feature stream" IS the Q-net then (output width A, no heads, no advantage mean).
     const bool plain = cfg.agent_kind == 0;
-    const int S = cfg.state_dim, A = cfg.num_actions, K = S + A, H = cfg.q_hidden, F = plain ? A : cfg.feature_dim, L = cfg.q_layers;
-    const int B = cfg.batch_size, Hse = cfg.se_hidden, RS = a.RS, P = a.P, T = cfg.test_episodes;
+    const int S = cfg.state_dim, A = cfg.num_actions, K = S + A, F = plain ? A : cfg.feature_dim;
+    // the chain's own lr / batch_size / hidden_size / hidden_layer when the launch carries per-chain arrays, else cfg's
+    const bool vary = a.hp_batch != nullptr;
+    const int H = vary ? a.hp_hidden[chain] : cfg.q_hidden, L = vary ? a.hp_layers[chain] : cfg.q_layers;
+    const int B = vary ? a.hp_batch[chain] : cfg.batch_size;
+    const double lr = vary ? a.hp_lr[chain] : cfg.lr;
+    if (vary && (H < 1 || H > cfg.q_hidden || L < 1 || L > cfg.q_layers || B < 1 || B > cfg.batch_size)) {   // uniform per chain
+        if (tid == 0) { if (a.out.status) a.out.status[chain] = -8; a.out.score[chain] = 0.0; }
+        return;
+    }
+    const DuelOffsets po = duel_param_offsets(S, A, H, F, L, plain);
+    const int Hse = cfg.se_hidden, RS = a.RS, P = po.P, T = cfg.test_episodes;
     const int act_id = cfg.q_act;
     const float prelu = cfg.q_prelu;
 
@@ -73,13 +107,13 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     float *se_wout = se_b0 + 3 * Hse;                     // [S+2][Hse]
     float *se_bout = se_wout + (S + 2) * Hse;             // [S+2] (padded to 16)
     float *se_h = se_bout + 16;                           // [3][Hse]
-    const int RBH = B > T ? B : T;
+    const int RBH = cfg.batch_size > T ? cfg.batch_size : T;      // LDS is carved for cfg's (maximal) batch
     float *qv = se_h + 3 * Hse;                           // [3][B][A]   q(s), q_online(s'), q_target(s'); [T][A] in the test phase
     float *Vb = qv + 3 * RBH * A;                           // [3][RBH]  value-head outputs of the three passes (slot 0 reused as scratch)
     float *Advb = Vb + 3 * RBH;                           // [3][RBH][A] advantage-head outputs (RBH = max(B, T) rows per slot)
     float *dq = Advb + 3 * RBH * A;                       // [B]
-    float *dAdv = dq + B;                                 // [B][A]
-    float *misc = dAdv + B * A;                           // [64] control words
+    float *dAdv = dq + cfg.batch_size;                    // [B][A]
+    float *misc = dAdv + cfg.batch_size * A;                           // [64] control words
     double *dstate = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(misc + 64) + 7) & ~(uintptr_t)7);   // [T][4] real-env states (tests)
     double *ret = dstate + 4 * T;                         // [T]
     float *ep_rew = reinterpret_cast<float *>(ret + T);   // [T]
@@ -117,7 +151,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     }
     // ---- fresh agent: online = target = agent_init, Adam state 0 (DuelingDDQN.py:31-36) ----
     for (int p = tid; p < P; p += DNT) {
-        const float w = a.agent_init[chain * P + p];
+        const float w = a.agent_init[chain * a.P + p];
         online[p] = w; target[p] = w; adam_m[p] = 0.0f; adam_v[p] = 0.0f;
     }
     if (tid < 64) misc[tid] = 0.0f;
@@ -150,19 +184,19 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
         const float *in = X;
         int n_in = S;
         for (int l = 0; l < L; ++l) {
-            gq.gemm(in, n_in, 1, par + a.oWf[l], n_in, 1, I, H, n_in, epi_bias_act(hid[l], H, par + a.obf[l], act_id, prelu));
+            gq.gemm(in, n_in, 1, par + po.oWf[l], n_in, 1, I, H, n_in, epi_bias_act(hid[l], H, par + po.obf[l], act_id, prelu));
             in = hid[l]; n_in = H;
         }
         // feature_stream's last Linear: no activation (build_nn_from_config ends with a Linear)
         if (plain) {                                       // Critic_DQN: that Linear's output is Q(s, .) -> slot `slot` of Advb
-            gq.gemm(in, n_in, 1, par + a.oWf[L], n_in, 1, I, A, n_in, epi_bias(Advb + slot * RBH * A, A, 0, par + a.obf[L]));
+            gq.gemm(in, n_in, 1, par + po.oWf[L], n_in, 1, I, A, n_in, epi_bias(Advb + slot * RBH * A, A, 0, par + po.obf[L]));
             return;
         }
-        gq.gemm(in, n_in, 1, par + a.oWf[L], n_in, 1, I, F, n_in, epi_bias(featb, F, 0, par + a.obf[L]));
-        gq.gemm(featb, F, 1, par + a.oWv1, F, 1, I, F, F, epi_bias_act(v1b, F, par + a.obv1, act_id, prelu));
-        gq.gemm(featb, F, 1, par + a.oWa1, F, 1, I, F, F, epi_bias_act(a1b, F, par + a.oba1, act_id, prelu));
-        gq.gemm(v1b, F, 1, par + a.oWv2, F, 1, I, 1, F, epi_bias(Vb + slot * RBH, 1, 0, par + a.obv2));
-        gq.gemm(a1b, F, 1, par + a.oWa2, F, 1, I, A, F, epi_bias(Advb + slot * RBH * A, A, 0, par + a.oba2));
+        gq.gemm(in, n_in, 1, par + po.oWf[L], n_in, 1, I, F, n_in, epi_bias(featb, F, 0, par + po.obf[L]));
+        gq.gemm(featb, F, 1, par + po.oWv1, F, 1, I, F, F, epi_bias_act(v1b, F, par + po.obv1, act_id, prelu));
+        gq.gemm(featb, F, 1, par + po.oWa1, F, 1, I, F, F, epi_bias_act(a1b, F, par + po.oba1, act_id, prelu));
+        gq.gemm(v1b, F, 1, par + po.oWv2, F, 1, I, 1, F, epi_bias(Vb + slot * RBH, 1, 0, par + po.obv2));
+        gq.gemm(a1b, F, 1, par + po.oWa2, F, 1, I, A, F, epi_bias(Advb + slot * RBH * A, A, 0, par + po.oba2));
     };
     auto finish_q = [&](int slot, int I, float *q_out, bool global_mean) {
         if (plain) {                                       // Q itself sits in the "advantage" slot (sized for max(B, T) rows)
@@ -200,7 +234,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
 
     float *hid_s[D_MAXL], *hid_t[D_MAXL];
     for (int l = 0; l < D_MAXL; ++l) { hid_s[l] = arena + a.a_act[l]; hid_t[l] = arena + a.a_t[l]; }
-    float *feat_t = arena + a.a_t[2], *v1_t = arena + a.a_t[3], *a1_t = arena + a.a_dbuf[0];   // temporaries of non-stored passes
+    float *feat_t = arena + a.a_t[3], *v1_t = arena + a.a_t[4], *a1_t = arena + a.a_t[5];   // temporaries of non-stored passes
 
     // ---- real-env test phase: the T episodes advance in lock-step as one batch (weights are streamed once per step) ----
     auto test_phase = [&]() {
@@ -364,8 +398,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 finish_q(0, B, qv, true);
                 PT_MARK(3);
                 // TD error (DuelingDDQN.py:80-85) and the gradient of the loss w.r.t. V / Adv
-                if (tid < B) {                              // one thread per sample
-                    const int b = tid;
+                for (int b = tid; b < B; b += DNT) {        // one thread per sample
                     const float g32 = (float)cfg.gamma, norm = (float)(2.0 / (double)B);
                     const int ab = (int)dAdv[b * A + 0];
                     const float r = dAdv[b * A + 1], d = dq[b];
@@ -383,7 +416,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                     for (int b = 0; b < B; ++b) s_dq = s_dq + dq[b];
                     ctrl[9] = plain ? 0.0f : (-s_dq) / (float)(B * A);     // backward of `- advantages.mean()` (dueling only)
                     b1pow *= cfg.adam_beta1; b2pow *= cfg.adam_beta2;
-                    ctrl[10] = (float)(-(cfg.lr / (1.0 - b1pow)));
+                    ctrl[10] = (float)(-(lr / (1.0 - b1pow)));
                     ctrl[11] = (float)__builtin_sqrt(1.0 - b2pow);
                 }
                 __syncthreads();
@@ -402,16 +435,16 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 float *dh[2] = { arena + a.a_dbuf[3], arena + a.a_dbuf[4] };
                 // ---- heads, output layers: db = column sums; d hidden of the heads = act'(h) * sum_o dOut[o] * W2[o][k]
                 // (reduction over the few outputs).  Everything GEMM-shaped of the backward pass is queued below.
-                if (!plain && tid < A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dAdv[b * A + tid]; grad[a.oba2 + tid] = s; }
-                if (!plain && tid == A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dq[b]; grad[a.obv2] = s; }
+                if (!plain && tid < A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dAdv[b * A + tid]; grad[po.oba2 + tid] = s; }
+                if (!plain && tid == A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dq[b]; grad[po.obv2] = s; }
                 if (!plain) {
                     // thread = (column k, row group): the head weights of column k are loop invariants, a1/v1 reads are coalesced
                     // along k and 8 rows are in flight per thread (A <= 3 for the supported envs)
                     const int k = tid & 127, rg = tid >> 7, nrg = DNT >> 7;
                     if (k < F) {
                         float wa[3] = { 0.0f, 0.0f, 0.0f };
-                        for (int aa = 0; aa < A; ++aa) wa[aa] = online[a.oWa2 + aa * F + k];
-                        const float wv = online[a.oWv2 + k];
+                        for (int aa = 0; aa < A; ++aa) wa[aa] = online[po.oWa2 + aa * F + k];
+                        const float wv = online[po.oWv2 + k];
                         for (int b0 = rg; b0 < B; b0 += 8 * nrg) {
                             float ha[8], hv[8];
 #pragma unroll
@@ -436,14 +469,14 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 PT_MARK(5);
                 if (!plain) {
                     // heads: dW2 = dOut^T . hidden (reduction over the batch); dW1 = dHid^T . feat, db1; dfeat = d_v1 . Wv1 + d_a1 . Wa1
-                    gq.gemm(dAdv, 1, A, a1_s, 1, F, A, F, B, epi_store(grad + a.oWa2, F));
-                    gq.gemm(dq, 1, 1, v1_s, 1, F, 1, F, B, epi_store(grad + a.oWv2, F));
-                    gq.gemm(d_a1, 1, F, feat_s, 1, F, F, F, B, epi_store(grad + a.oWa1, F));
-                    gq.gemm(d_v1, 1, F, feat_s, 1, F, F, F, B, epi_store(grad + a.oWv1, F));
-                    gq.colsum(d_a1, B, F, F, grad + a.oba1);
-                    gq.colsum(d_v1, B, F, F, grad + a.obv1);
-                    gq.gemm(d_v1, F, 1, online + a.oWv1, 1, F, B, F, F, epi_store(d_feat, F));
-                    gq.gemm(d_a1, F, 1, online + a.oWa1, 1, F, B, F, F, epi_accum(d_feat, F));
+                    gq.gemm(dAdv, 1, A, a1_s, 1, F, A, F, B, epi_store(grad + po.oWa2, F));
+                    gq.gemm(dq, 1, 1, v1_s, 1, F, 1, F, B, epi_store(grad + po.oWv2, F));
+                    gq.gemm(d_a1, 1, F, feat_s, 1, F, F, F, B, epi_store(grad + po.oWa1, F));
+                    gq.gemm(d_v1, 1, F, feat_s, 1, F, F, F, B, epi_store(grad + po.oWv1, F));
+                    gq.colsum(d_a1, B, F, F, grad + po.oba1);
+                    gq.colsum(d_v1, B, F, F, grad + po.obv1);
+                    gq.gemm(d_v1, F, 1, online + po.oWv1, 1, F, B, F, F, epi_store(d_feat, F));
+                    gq.gemm(d_a1, F, 1, online + po.oWa1, 1, F, B, F, F, epi_accum(d_feat, F));
                 }
                 // feature stream: output Linear (no activation), then the hidden layers downwards.  Plain DQN: the stream's
                 // output is Q itself, so its output gradient is the masked dq rows (dAdv, LDS) -- DDQN.py:82-94
@@ -453,11 +486,11 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                     for (int l = L; l >= 0; --l) {
                         const int n_in = l == 0 ? S : H;
                         const float *inp = l == 0 ? xs : hid_s[l - 1];
-                        gq.gemm(dcur, 1, n_out, inp, 1, n_in, n_out, n_in, B, epi_store(grad + a.oWf[l], n_in));
-                        gq.colsum(dcur, B, n_out, n_out, grad + a.obf[l]);
+                        gq.gemm(dcur, 1, n_out, inp, 1, n_in, n_out, n_in, B, epi_store(grad + po.oWf[l], n_in));
+                        gq.colsum(dcur, B, n_out, n_out, grad + po.obf[l]);
                         if (l > 0) {
                             float *dn = dh[l & 1];
-                            gq.gemm(dcur, n_out, 1, online + a.oWf[l], 1, n_in, B, n_in, n_out, epi_act_bwd(dn, n_in, hid_s[l - 1], n_in, act_id, prelu));
+                            gq.gemm(dcur, n_out, 1, online + po.oWf[l], 1, n_in, B, n_in, n_out, epi_act_bwd(dn, n_in, hid_s[l - 1], n_in, act_id, prelu));
                             dcur = dn; n_out = n_in;
                         }
                     }
@@ -556,7 +589,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
             if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = pad_l;
         }
     }
-    if (a.out.final_online) for (int p = tid; p < P; p += DNT) a.out.final_online[chain * P + p] = online[p];
+    if (a.out.final_online) for (int p = tid; p < P; p += DNT) a.out.final_online[chain * a.P + p] = online[p];
     if (a.out.status && status != 0) atomicMin(&a.out.status[chain], status);
     (void)lane; (void)wave;
 }
@@ -564,6 +597,29 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
 }  // namespace lenv
 
 using namespace lenv;
+
+// Fresh agents for chains with their own network shapes: nn.Linear's default init U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for
+// weight and bias (the bounds agents/nes_common.py:linear_init_bounds tabulates for ONE shape), drawn like lenv_nes_draw:
+// agent_init[c][i] = (2u - 1) * bound(i), u = unit(rng(key_c, STREAM_AGENT_INIT, i)).
+__global__ void dueling_agent_init_kernel(lenv_ddqn_cfg cfg, const int32_t *hp_hidden, const int32_t *hp_layers, const uint64_t *rng_keys,
+                                          int64_t chains, int64_t row_stride, float *agent_init)
+{
+    const int64_t c = blockIdx.y;
+    if (c >= chains) return;
+    const bool plain = cfg.agent_kind == 0;
+    const int S = cfg.state_dim, A = cfg.num_actions, F = plain ? A : cfg.feature_dim;
+    const int H = hp_hidden ? hp_hidden[c] : cfg.q_hidden, L = hp_layers ? hp_layers[c] : cfg.q_layers;
+    if (H < 1 || H > cfg.q_hidden || L < 1 || L > cfg.q_layers) return;        // the inner loop reports status -8 for this chain
+    const DuelOffsets po = duel_param_offsets(S, A, H, F, L, plain);
+    const uint64_t key = rng_keys[c];
+    // (float)(1/sqrt(fan_in)) in double like the host table (both IEEE-exact)
+    const float bS = (float)(1.0 / __builtin_sqrt((double)S)), bH = (float)(1.0 / __builtin_sqrt((double)H)), bF = (float)(1.0 / __builtin_sqrt((double)F));
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < po.P; i += gridDim.x * blockDim.x) {
+        const float bound = i < po.oWf[1] ? bS : (i < (plain ? po.P : po.oWv1) ? bH : bF);
+        const float u = (float)u64_to_unit(rng_u64(key, STREAM_AGENT_INIT, (uint64_t)i));
+        agent_init[c * row_stride + i] = (u * 2.0f - 1.0f) * bound;
+    }
+}
 
 static int64_t d_mlp_params(int in, int H, int L, int out) { return (int64_t)in * H + H + (int64_t)(L - 1) * ((int64_t)H * H + H) + (int64_t)H * out + out; }
 
@@ -577,19 +633,11 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     // would diverge silently, so agent-net PReLU is refused (SE / reward nets keep theirs: the reference never updates those)
     if (cfg->q_act == LENV_ACT_PRELU) return LENV_ERR_UNSUPPORTED;
     if (cfg->grad_chunk != 0 && cfg->grad_chunk < B) return LENV_ERR_UNSUPPORTED;   // batch gradient = one sequential chunk here
-    if (L < 1 || L > D_MAXL || H < 1 || H > D_MAXW || F < 1 || F > D_MAXW || B < 1 || B > GT_I || T < 1 || T > GT_I || cfg->se_layers != 1)
+    if (L < 1 || L > D_MAXL || H < 1 || H > D_MAXH || F < 1 || F > D_MAXW || B < 1 || B > D_MAXB || T < 1 || T > D_MAXW || cfg->se_layers != 1)
         return LENV_ERR_UNSUPPORTED;
     if (!((cfg->env_id == LENV_ENV_CARTPOLE && S == 4 && A == 2) || (cfg->env_id == LENV_ENV_ACROBOT && S == 6 && A == 3)))
         return LENV_ERR_UNSUPPORTED;
-    int o = 0, n_in = S;
-    for (int l = 0; l < L; ++l) { a.oWf[l] = o; o += H * n_in; a.obf[l] = o; o += H; n_in = H; }
-    a.oWf[L] = o; o += F * H; a.obf[L] = o; o += F;
-    if (plain) { a.oWv1 = a.obv1 = a.oWv2 = a.obv2 = a.oWa1 = a.oba1 = a.oWa2 = a.oba2 = o; }       // no heads
-    else {
-        a.oWv1 = o; o += F * F; a.obv1 = o; o += F; a.oWv2 = o; o += F; a.obv2 = o; o += 1;
-        a.oWa1 = o; o += F * F; a.oba1 = o; o += F; a.oWa2 = o; o += A * F; a.oba2 = o; o += A;
-    }
-    a.P = o;
+    a.P = duel_param_offsets(S, A, H, F, L, plain).P;
     a.se_net_size[0] = (int)d_mlp_params(K, Hse, 1, S);
     a.se_net_size[1] = a.se_net_size[2] = (int)d_mlp_params(K, Hse, 1, 1);
     a.P_se = a.se_net_size[0] + a.se_net_size[1] + a.se_net_size[2];
@@ -602,11 +650,12 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     auto take = [&](int64_t n) { int64_t r = off; off += (n + 3) & ~(int64_t)3; return r; };
     a.a_online = take(a.P); a.a_target = take(a.P); a.a_m = take(a.P); a.a_v = take(a.P); a.a_grad = take(a.P);
     a.a_replay = take(a.rb_cap * a.RS);
-    a.a_xs = take((int64_t)GT_I * S); a.a_xs2 = take((int64_t)GT_I * S);
-    for (int l = 0; l < D_MAXL; ++l) a.a_act[l] = take((int64_t)B * H);
+    const int64_t rows = B > T ? B : T;                    // minibatch rows / lock-step test episodes
+    a.a_xs = take(rows * S); a.a_xs2 = take(rows * S);
+    for (int l = 0; l < D_MAXL; ++l) a.a_act[l] = take(l < L ? (int64_t)B * H : 0);
     a.a_feat = take((int64_t)B * F); a.a_v1 = take((int64_t)B * F); a.a_a1 = take((int64_t)B * F);
-    for (int l = 0; l < 4; ++l) a.a_t[l] = take((int64_t)GT_I * W);
-    for (int l = 0; l < 5; ++l) a.a_dbuf[l] = take((int64_t)GT_I * W);
+    for (int l = 0; l < 6; ++l) a.a_t[l] = take(l < L || l >= 3 ? rows * W : 0);
+    for (int l = 0; l < 5; ++l) a.a_dbuf[l] = take(rows * W);
     a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
     a.arena_stride = (off + 63) & ~(int64_t)63;
     const size_t lds_floats = GemmShape<D_MAXI>::PS_FLOATS + GemmShape<D_MAXI>::QS_FLOATS + GEMM_QUEUE_MAX * sizeof(GemmCmd) / sizeof(float) +
@@ -640,7 +689,17 @@ extern "C" int lenv_dueling_se_inner_loop(const lenv_ddqn_cfg *cfg, const float 
                                           const lenv_tapes *tapes, int64_t chains, void *workspace, size_t workspace_bytes,
                                           const lenv_inner_out *out, void *stream)
 {
+    return lenv_dueling_se_inner_loop_hp(cfg, nullptr, theta, eps, worker, sign, agent_init, rng_keys, tapes, chains, workspace,
+                                         workspace_bytes, out, stream);
+}
+
+extern "C" int lenv_dueling_se_inner_loop_hp(const lenv_ddqn_cfg *cfg, const lenv_chain_hp *hp, const float *theta, const float *eps,
+                                             const int32_t *worker, const float *sign, const float *agent_init, const uint64_t *rng_keys,
+                                             const lenv_tapes *tapes, int64_t chains, void *workspace, size_t workspace_bytes,
+                                             const lenv_inner_out *out, void *stream)
+{
     if (!cfg || !theta || !agent_init || !out || !out->score || !workspace || chains < 0) return LENV_ERR_INVALID;
+    if (hp && (!hp->lr || !hp->batch_size || !hp->q_hidden || !hp->q_layers)) return LENV_ERR_INVALID;
     if (eps && (!worker || !sign)) return LENV_ERR_INVALID;
     if (cfg->rng_mode == LENV_RNG_TAPE && !tapes) return LENV_ERR_INVALID;
     if (cfg->rng_mode == LENV_RNG_COUNTER && !rng_keys) return LENV_ERR_INVALID;
@@ -655,6 +714,8 @@ extern "C" int lenv_dueling_se_inner_loop(const lenv_ddqn_cfg *cfg, const float 
     if (tapes) a.tapes = *tapes; else a.tapes = lenv_tapes{};
     a.arena = static_cast<float *>(workspace);
     a.out = *out;
+    a.hp_lr = hp ? hp->lr : nullptr; a.hp_batch = hp ? hp->batch_size : nullptr;
+    a.hp_hidden = hp ? hp->q_hidden : nullptr; a.hp_layers = hp ? hp->q_layers : nullptr;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dueling_se_inner_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;
     if (out->status) {
@@ -662,6 +723,21 @@ extern "C" int lenv_dueling_se_inner_loop(const lenv_ddqn_cfg *cfg, const float 
         if (e != hipSuccess) return LENV_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(dueling_se_inner_kernel, dim3((unsigned)chains), dim3(DNT), lds_bytes, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}
+
+extern "C" int lenv_dueling_agent_init_hp(const lenv_ddqn_cfg *cfg, const lenv_chain_hp *hp, const uint64_t *rng_keys, int64_t chains,
+                                          float *agent_init, void *stream)
+{
+    if (!cfg || !rng_keys || !agent_init || chains < 0) return LENV_ERR_INVALID;
+    if (hp && (!hp->q_hidden || !hp->q_layers)) return LENV_ERR_INVALID;
+    if (chains == 0) return LENV_OK;
+    DuelArgs a;
+    size_t lds_bytes;
+    const int rc = dueling_layout(cfg, a, &lds_bytes);
+    if (rc != LENV_OK) return rc;
+    hipLaunchKernelGGL(dueling_agent_init_kernel, dim3(64, (unsigned)chains), dim3(256), 0, static_cast<hipStream_t>(stream), *cfg,
+                       hp ? hp->q_hidden : nullptr, hp ? hp->q_layers : nullptr, rng_keys, chains, (int64_t)a.P, agent_init);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }
 

@@ -17,6 +17,12 @@ extern "C" const char *lenv_error_string(int code)
 }
 
 // same key schedule as the oracle's orc_chain_key
+// one uniform in [0, 1) of a chain's counter RNG (host): the *_vary hyper-parameter draws (STREAM_VARY_HP) are made on the host
+extern "C" double lenv_rng_unit(uint64_t key, uint32_t stream, uint64_t index)
+{
+    return (double)(lenv::rng_u64(key, stream, index) >> 11) * (1.0 / 9007199254740992.0);
+}
+
 extern "C" uint64_t lenv_chain_key(uint64_t seed, uint64_t generation, uint64_t worker, uint64_t kind)
 {
     uint64_t k = lenv::mix64(seed + 0x9e3779b97f4a7c15ULL);

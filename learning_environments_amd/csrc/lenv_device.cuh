@@ -184,7 +184,9 @@ __device__ __forceinline__ double u64_to_unit(uint64_t u) { return (double)(u >>
 __device__ __forceinline__ uint32_t u64_to_below(uint64_t u, uint32_t n) { return (uint32_t)(((u >> 32) * (uint64_t)n) >> 32); }
 
 enum { STREAM_EPS = 0, STREAM_ACTION = 1, STREAM_REPLAY = 2, STREAM_TRAIN_RESET = 3, STREAM_TEST_RESET = 4,
-       STREAM_TD3_RAND_ACTION = 5, STREAM_TD3_ACT_NOISE = 6, STREAM_TD3_TEST_NOISE = 7, STREAM_TD3_POLICY_NOISE = 8 };
+       STREAM_TD3_RAND_ACTION = 5, STREAM_TD3_ACT_NOISE = 6, STREAM_TD3_TEST_NOISE = 7, STREAM_TD3_POLICY_NOISE = 8,
+       STREAM_NES_EPS = 9, STREAM_AGENT_INIT = 10,
+       STREAM_VARY_HP = 11 };   // host side only (agents/vary.py): the four hyper-parameter draws of a *_vary agent
 
 // natural log, same sequence as the oracle's orc_log (fdlibm scheme, fma Horner); used by the counter-mode Box-Muller
 __device__ __forceinline__ double det_log(double x)

@@ -1,7 +1,8 @@
 // lenv_gemm.cuh -- workgroup-cooperative, LDS-tiled fp32 GEMM on the f32-input matrix cores with the canonical
 // (k-ascending fmaf chain) reduction order.
 //
-//   C[i][j] = epi(i, j, sum_{r<R} P[i*sPi + r*sPr] * Q[j*sQj + r*sQr])       I <= MAXI (128 or 256), J <= 128, any R
+//   C[i][j] = epi(i, j, sum_{r<R} P[i*sPi + r*sPr] * Q[j*sQj + r*sQr])       one block: I <= MAXI (128 or 256), J <= 128, any R;
+//                                                                           larger outputs run block by block (gemm_run_queue)
 //
 // 512 threads (8 waves).  The reduction is staged through LDS 64 deep (Ps/Qs, r-major rows); the
 // output is cut into 32x32 tiles, wave w owns tiles w, w+8, ... and each tile is accumulated with
@@ -410,7 +411,25 @@ __device__ __noinline__ void gemm_run_queue(const GemmCmd *cmds_, int n_, float 
         ep.aux = uni_ptr(c.aux); ep.ldaux = uni(c.ldaux); ep.out2 = uni_ptr(c.out2); ep.ldo2 = uni(c.ldo2); ep.act = uni(c.act);
         ep.prelu = unif(c.prelu); ep.scale = unif(c.scale); ep.flags = uni(c.flags);
         if (kind == CMD_COLSUM) wg_colsum(op.P, op.I, op.sPi, op.J, ep.out);
-        else gemm_body<MAXI>(op, ep, Ps, Qs, tid, lane, wave);
+        else if (op.I <= MAXI && op.J <= GT_J) gemm_body<MAXI>(op, ep, Ps, Qs, tid, lane, wave);
+        else {
+            // outputs larger than one MAXI x 128 block (the *_vary agents: batch / width up to 3x the configured size):
+            // block by block, each with the whole reduction -- every output is still its own k-ascending chain
+            const int I = op.I, J = op.J;
+            const float *P0 = op.P, *Q0 = op.Q, *bias0 = ep.bias, *aux0 = ep.aux;
+            float *out0 = ep.out, *out20 = ep.out2;
+            for (int j0 = 0; j0 < J; j0 += GT_J)
+                for (int i0 = 0; i0 < I; i0 += MAXI) {
+                    if (i0 | j0) __syncthreads();
+                    op.P = P0 + (int64_t)i0 * op.sPi; op.Q = Q0 + (int64_t)j0 * op.sQj;
+                    op.I = I - i0 < MAXI ? I - i0 : MAXI; op.J = J - j0 < GT_J ? J - j0 : GT_J;
+                    ep.out = out0 + (int64_t)i0 * ep.ldo + j0;
+                    ep.bias = bias0 ? bias0 + j0 : nullptr;
+                    ep.aux = aux0 ? aux0 + (int64_t)i0 * ep.ldaux + j0 : nullptr;
+                    ep.out2 = out20 ? out20 + (int64_t)i0 * ep.ldo2 + j0 : nullptr;
+                    gemm_body<MAXI>(op, ep, Ps, Qs, tid, lane, wave);
+                }
+        }
         __syncthreads();
     }
 }

@@ -162,7 +162,6 @@ __global__ void update_env_kernel(float *theta, const float *eps, const double *
 //   [.., + chains)                  rng_keys[c]      = lenv_chain_key(seed, generation, worker(c), kind(c))
 // all from the counter RNG (same functions as the oracle's orc_nes_draw), so every rank regenerates identical tensors and
 // the CPU oracle can reproduce a whole generation bit for bit.
-constexpr uint32_t STREAM_NES_EPS = 9, STREAM_AGENT_INIT = 10;
 constexpr uint64_t NES_EPS_DOMAIN = 0x6e65735f657073ULL;      // "nes_eps": separates the noise keys from the chain keys
 
 __device__ __host__ __forceinline__ uint64_t chain_key_dev(uint64_t seed, uint64_t generation, uint64_t worker, uint64_t kind)

@@ -125,20 +125,32 @@ def chain_key(seed, generation, worker, kind):
 class InnerLoop(object):
     """Owns the workspace/outputs of lenv_ddqn_se_inner_loop for a fixed (cfg, chains)."""
 
-    def __init__(self, cfg, chains, want_episode_stats=True, want_final_online=False, trace_cap=0):
+    def __init__(self, cfg, chains, want_episode_stats=True, want_final_online=False, trace_cap=0, vary=False):
+        """vary=True: the *_vary agents -- cfg carries the MAXIMAL batch_size / q_hidden / q_layers, every chain runs with its
+        own lr / batch_size / hidden_size / hidden_layer (set_hp) in the GEMM-tiled kernel (lenv_dueling_se_inner_loop_hp)."""
         self.dev = require_device()
         self.cfg, self.chains = cfg, int(chains)
         L = _lib.lib()
         E, T, S = cfg.train_episodes, cfg.test_episodes, cfg.state_dim
+        self.vary = bool(vary)
+        self.hp = self.hp_struct = self.agent_init = None
         # DuelingDDQN, and DDQN whose Critic_DQN the register-resident kernel refuses (hidden_layer >= 2 / wide layers),
         # run in the GEMM-tiled kernel; `dueling` keeps its name from the first of the two
-        self.dueling = cfg.agent_kind == 1 or (cfg.agent_kind == 0 and L.lenv_ddqn_se_lds_bytes(C.byref(cfg)) <= 0
-                                               and L.lenv_dueling_num_params(C.byref(cfg)) > 0)
+        self.dueling = self.vary or cfg.agent_kind == 1 or (cfg.agent_kind == 0 and L.lenv_ddqn_se_lds_bytes(C.byref(cfg)) <= 0
+                                                            and L.lenv_dueling_num_params(C.byref(cfg)) > 0)
         if self.dueling:
             self.p_agent = int(L.lenv_dueling_num_params(C.byref(cfg)))
             _lib.check(min(self.p_agent, 0), "lenv_dueling_num_params")
             self.ws_bytes = int(L.lenv_dueling_se_workspace_bytes(C.byref(cfg), self.chains))
             self._fn = L.lenv_dueling_se_inner_loop
+            if self.vary:
+                self.hp = dict(lr=torch.zeros(self.chains, dtype=torch.float64, device=self.dev),
+                               batch_size=torch.zeros(self.chains, dtype=torch.int32, device=self.dev),
+                               q_hidden=torch.zeros(self.chains, dtype=torch.int32, device=self.dev),
+                               q_layers=torch.zeros(self.chains, dtype=torch.int32, device=self.dev))
+                self.hp_struct = _lib.ChainHp(_ptr(self.hp["lr"]), _ptr(self.hp["batch_size"]), _ptr(self.hp["q_hidden"]),
+                                              _ptr(self.hp["q_layers"]))
+                self.agent_init = torch.zeros((self.chains, self.p_agent), dtype=torch.float32, device=self.dev)
         else:
             self.ws_bytes = int(L.lenv_ddqn_se_workspace_bytes(C.byref(cfg), self.chains))
             qd = mlp_desc(S, cfg.q_hidden, cfg.q_layers, cfg.num_actions, cfg.q_act)
@@ -168,8 +180,44 @@ class InnerLoop(object):
                             _ptr(tr.get("action")), _ptr(tr.get("state")), _ptr(tr.get("next_state")),
                             _ptr(tr.get("reward_done")))
 
+    def set_hp(self, lr, batch_size, hidden_size, hidden_layer):
+        """The chains' own hyper-parameters (host sequences of length `chains`; hidden_layer as the config writes it: the
+        network has max(1, hidden_layer) hidden layers, models/model_utils.py:33-37)."""
+        if not self.vary:
+            raise ValueError("InnerLoop was built without vary=True")
+        n = self.chains
+        if not (len(lr) == len(batch_size) == len(hidden_size) == len(hidden_layer) == n):
+            raise ValueError("set_hp: need %d values per hyper-parameter" % n)
+        layers = [max(1, int(v)) for v in hidden_layer]
+        c = self.cfg
+        if max(batch_size) > c.batch_size or max(hidden_size) > c.q_hidden or max(layers) > c.q_layers or min(batch_size) < 1 \
+                or min(hidden_size) < 1:
+            raise ValueError("set_hp: a chain's hyper-parameters exceed the maxima the InnerLoop was sized for")
+        self.hp["lr"].copy_(torch.tensor([float(v) for v in lr], dtype=torch.float64))
+        self.hp["batch_size"].copy_(torch.tensor([int(v) for v in batch_size], dtype=torch.int32))
+        self.hp["q_hidden"].copy_(torch.tensor([int(v) for v in hidden_size], dtype=torch.int32))
+        self.hp["q_layers"].copy_(torch.tensor(layers, dtype=torch.int32))
+
+    def chain_num_params(self, hidden_size, hidden_layer):
+        """Parameter count of one chain's agent at its own shapes (the used prefix of its agent_init / final_online row)."""
+        probe = _lib.DdqnCfg.from_buffer_copy(self.cfg)
+        probe.q_hidden, probe.q_layers = int(hidden_size), max(1, int(hidden_layer))
+        n = int(_lib.lib().lenv_dueling_num_params(C.byref(probe)))
+        _lib.check(min(n, 0), "lenv_dueling_num_params")
+        return n
+
+    def draw_agent_init(self, rng_keys):
+        """Fresh agents at every chain's own shapes into self.agent_init (nn.Linear default init, keyed by the chain keys)."""
+        _chk(rng_keys, torch.int64, "rng_keys")
+        rc = _lib.lib().lenv_dueling_agent_init_hp(C.byref(self.cfg), C.byref(self.hp_struct), _ptr(rng_keys), self.chains,
+                                                   _ptr(self.agent_init), _stream())
+        _lib.check(rc, "lenv_dueling_agent_init_hp")
+        return self.agent_init
+
     def run(self, theta, eps, worker, sign, agent_init, rng_keys=None, tapes=None):
         """Enqueue one fused inner loop for all chains on the current stream (asynchronous)."""
+        if agent_init is None and self.vary:
+            agent_init = self.agent_init
         _chk(theta, torch.float32, "theta"); _chk(eps, torch.float32, "eps"); _chk(worker, torch.int32, "worker")
         _chk(sign, torch.float32, "sign"); _chk(agent_init, torch.float32, "agent_init")
         if agent_init.shape != (self.chains, self.p_agent):
@@ -183,9 +231,12 @@ class InnerLoop(object):
                       _ptr(tapes["test_reset"]), tapes["test_reset"].shape[1])
         if rng_keys is not None:
             _chk(rng_keys, torch.int64, "rng_keys")
-        rc = self._fn(C.byref(self.cfg), _ptr(theta), _ptr(eps), _ptr(worker), _ptr(sign), _ptr(agent_init), _ptr(rng_keys),
-                      C.byref(t) if t is not None else None, self.chains, _ptr(self.workspace), self.ws_bytes,
-                      C.byref(self.out), _stream())
+        args = (_ptr(theta), _ptr(eps), _ptr(worker), _ptr(sign), _ptr(agent_init), _ptr(rng_keys),
+                C.byref(t) if t is not None else None, self.chains, _ptr(self.workspace), self.ws_bytes, C.byref(self.out), _stream())
+        if self.vary:
+            rc = _lib.lib().lenv_dueling_se_inner_loop_hp(C.byref(self.cfg), C.byref(self.hp_struct), *args)
+        else:
+            rc = self._fn(C.byref(self.cfg), *args)
         _lib.check(rc, "lenv_dueling_se_inner_loop" if self.dueling else "lenv_ddqn_se_inner_loop")
         return self.score
 

@@ -346,7 +346,7 @@ class Recorder(object):
 
 
 def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml="default_config_cartpole_syn_env.yaml",
-           env_name="CartPole-v0", env_cls="CartPoleEnv", agent_key="ddqn", agent_over=None, env_over=None):
+           env_name="CartPole-v0", env_cls="CartPoleEnv", agent_key="ddqn", agent_over=None, env_over=None, vary_seed=None):
     import agents.GTN_worker as gw
     from agents.GTN import GTN_Worker
     import gym.envs as genvs
@@ -357,6 +357,13 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
     cfg["agents"][agent_key].update(agent_over or {})
     cfg["envs"][env_name].update(env_over or {})
     cfg["agents"]["gtn"]["agent_name"] = {"ddqn": "DDQN", "duelingddqn": "DuelingDDQN"}[agent_key]
+    if vary_seed is not None:
+        # the *_vary agent of the same family (agents/DDQN_vary.py, DuelingDDQN_vary.py): its ConfigSpace draw comes from
+        # the stand-in under oracle/shims (seeded here); the sampled values are recorded in the fixture
+        import ConfigSpace
+        ConfigSpace.RANDOM.seed(vary_seed)
+        cfg["agents"]["gtn"]["agent_name"] += "_vary"
+        cfg["agents"][agent_key + "_vary"] = {"vary_hp": True}
     cfg["agents"]["gtn"]["synthetic_env_type"] = 0
     if max_steps:
         cfg["envs"][env_name]["max_steps"] = max_steps
@@ -396,6 +403,8 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
     def wrapped_select_agent(config, agent_name):
         agent = orig_select_agent(config=config, agent_name=agent_name)
         holder["agent"] = agent
+        holder["hp"] = {k: agent.full_config["agents"][agent_key][k] for k in ("lr", "batch_size", "hidden_size", "hidden_layer")} \
+            if hasattr(agent, "full_config") else {}
         holder["init"] = pack_linear_params(agent.model.state_dict(), "net.") if hasattr(agent.model, "net") \
             else _pack_dueling(agent.model.state_dict())
         orig_learn = agent.learn
@@ -450,7 +459,7 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
     train_reset = np.array([s for (i, s) in rec.resets if i == train_reset_id])
     test_reset = np.array([s for (i, s) in rec.resets if i != train_reset_id])
     a = cfg["agents"][agent_key]
-    B = a["batch_size"]
+    B = holder["hp"].get("batch_size", a["batch_size"])
     n = len(rec.steps)
     explored = np.zeros(n, np.int32)
     prev = 0
@@ -458,7 +467,7 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
         explored[k] = 1 if st["n_rand"] > prev else 0
         prev = st["n_rand"]
     import json
-    save(name, config_json=np.array(json.dumps(cfg)),
+    save(name, config_json=np.array(json.dumps(cfg)), hp_json=np.array(json.dumps(holder["hp"])),
          theta=theta, agent_init=holder["init"],
          train_episodes=np.array(train_episodes), max_steps=np.array(cfg["envs"][env_name]["max_steps"]),
          tape_eps_uniform=np.array(rec.eps_uniform, np.float64), tape_rand_action=np.array(rec.rand_action, np.int32),
@@ -991,6 +1000,17 @@ def main():
         gen_g8("g8l2_calc_score_acrobot_ddqn_2layer", train_episodes=3, done_bias_shift=0.0, seed=812, max_steps=20,
                env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="ddqn",
                agent_over={"init_episodes": 1, "test_episodes": 2}, env_over={"hidden_size": 128, "solved_reward": 0.5})
+    if "g8v" in which:
+        # DDQN_vary / DuelingDDQN_vary (agents/DDQN_vary.py:26-59): the agent draws lr / batch_size / hidden_size / hidden_layer
+        # and trains with them; the fixture records the draw and the run
+        gen_g8("g8v_calc_score_cartpole_ddqn_vary", train_episodes=3, done_bias_shift=0.0, seed=820, max_steps=25, vary_seed=14,
+               agent_over={"init_episodes": 1, "test_episodes": 2})            # draws batch 204, width 129, 2 hidden layers
+        gen_g8("g8v2_calc_score_cartpole_ddqn_vary_wide", train_episodes=3, done_bias_shift=0.0, seed=822, max_steps=15, vary_seed=4,
+               agent_over={"init_episodes": 1, "test_episodes": 2})            # draws batch 555, width 161, 1 hidden layer
+        gen_g8("g8vd_calc_score_acrobot_dueling_vary", train_episodes=3, done_bias_shift=0.0, seed=821, max_steps=12, vary_seed=8,      # batch 145, width 108, 3 layers
+               env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="duelingddqn",
+               agent_over={"hidden_size": 48, "feature_dim": 32, "batch_size": 64, "init_episodes": 1, "test_episodes": 2},
+               env_over={"hidden_size": 32, "solved_reward": 0.5})
     if "g8d" in which:
         gen_g8("g8d_calc_score_acrobot_dueling", train_episodes=4, done_bias_shift=0.0, seed=810, max_steps=25,
                env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="duelingddqn",

@@ -348,6 +348,8 @@ def ddqn_cfg_from_config(config, grad_chunk=13, rng_mode=0, **overrides):
     env_name = config["env_name"]
     e = config["envs"][env_name]
     agent_key = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "ddqn"
+    if agent_key.endswith("_vary"):                  # the *_vary agents read their base agent's section (DDQN_vary.py:14)
+        agent_key = agent_key[:-5]
     a = config["agents"][agent_key]
     S, A = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3)}[env_name]
     assert a["same_action_num"] == 1, "same_action_num != 1 not supported by the oracle yet"
@@ -583,3 +585,65 @@ def worker_best_multi(score_add, score_sub, mirrored=True, grad_eval_type="mean"
     if rc != 0:
         raise ValueError("orc_worker_best_multi rc=%d" % rc)
     return best, sign
+
+
+# ------------------------------------------------------------------------------------------------
+# *_vary agents (agents/DDQN_vary.py:26-59, DuelingDDQN_vary.py:24-69, TD3_vary.py:24-58): hyper-parameter draws
+# ------------------------------------------------------------------------------------------------
+STREAM_AGENT_INIT, STREAM_VARY_HP = 10, 11
+
+
+def rng_unit(key, stream, index):
+    L = lib()
+    L.orc_rng_u64.restype = C.c_uint64
+    L.orc_rng_u64.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
+    return float(L.orc_rng_u64(int(key), int(stream), int(index)) >> 11) * (1.0 / 9007199254740992.0)
+
+
+def vary_hyperparameters(section, units):
+    """ConfigSpace 0.4.13's draw of the four varied hyper-parameters from four uniforms given in name order
+    (batch_size, hidden_layer, hidden_size, lr), restated with numpy like the library computes it."""
+    def flt(u, lo, hi, log):
+        a, b = (np.log(lo), np.log(hi)) if log else (lo, hi)
+        v = u * (b - a) + a
+        v = np.exp(v) if log else v
+        return float(np.clip(v, lo, hi))
+
+    def integer(u, lo, hi, log):
+        return int(np.clip(np.rint(flt(u, lo - 0.49999, hi + 0.49999, log)), lo, hi))
+
+    lr, b, h, l = section["lr"], section["batch_size"], section["hidden_size"], section["hidden_layer"]
+    ub, ul, uh, ulr = units
+    return {"lr": flt(ulr, lr / 3, lr * 3, True), "batch_size": integer(ub, int(b / 3), int(b * 3), True),
+            "hidden_size": integer(uh, int(h / 3), int(h * 3), True), "hidden_layer": integer(ul, l - 1, l + 1, False)}
+
+
+def hp_overrides(hp):
+    """ddqn_cfg_from_config overrides for one drawn set of hyper-parameters."""
+    return dict(lr=float(hp["lr"]), batch_size=int(hp["batch_size"]), q_hidden=int(hp["hidden_size"]),
+                q_layers=max(1, int(hp["hidden_layer"])))
+
+
+def vary_chain_hp(section, key):
+    return vary_hyperparameters(section, [rng_unit(key, STREAM_VARY_HP, i) for i in range(4)])
+
+
+def rng_u64_array(key, stream, n):
+    """orc_rng_u64(key, stream, i) for i < n, vectorised (uint64 wrap-around arithmetic)."""
+    def mix(x):
+        x = x ^ (x >> np.uint64(30)); x = x * np.uint64(0xbf58476d1ce4e5b9)
+        x = x ^ (x >> np.uint64(27)); x = x * np.uint64(0x94d049bb133111eb)
+        return x ^ (x >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        k = np.uint64(key)
+        idx = np.arange(n, dtype=np.uint64)
+        x = k + np.uint64(0x9e3779b97f4a7c15) * ((np.uint64(stream) << np.uint64(56)) ^ idx)
+        return mix(mix(x) ^ k)
+
+
+def agent_init_from_key(key, layer_dims):
+    """Fresh agent of an MLP stack given as [(fan_in, fan_out), ...] in state-dict order: nn.Linear's default init
+    U(-1/sqrt(fan_in), 1/sqrt(fan_in)), u = unit(rng(key, STREAM_AGENT_INIT, i)) as in orc_nes_draw."""
+    bounds = np.concatenate([np.full(fi * fo + fo, 1.0 / np.sqrt(float(fi)), np.float32) for fi, fo in layer_dims])
+    u = ((rng_u64_array(key, STREAM_AGENT_INIT, bounds.size) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)).astype(np.float32)
+    return (u * np.float32(2.0) - np.float32(1.0)) * bounds

@@ -254,6 +254,52 @@ def test_gtn_master_acrobot_ddqn_two_layer_generation(tmp_path, monkeypatch):
     assert np.array_equal(gathered[:, 2], sign.astype(np.float64))
 
 
+def test_gtn_master_ddqn_vary_generation(tmp_path, monkeypatch):
+    """`agent_name: DDQN_vary` (what default_config_acrobot.yaml:26 ships) through GTN_Master: every chain draws its own
+    hyper-parameters, the population runs as one launch, the fitness records equal an oracle evaluation chain by chain;
+    vary_hp False is the base agent (DDQN_vary.py:16-21)."""
+    from learning_environments_amd.agents import tasks
+    from learning_environments_amd.config import agent_layer_dims
+    from learning_environments_amd.configs import cartpole_syn_env_ddqn, fixed_work, with_vary
+    from learning_environments_amd import _lib
+    from oracle import oracle as orc
+    base = fixed_work(cartpole_syn_env_ddqn(num_workers=2, max_iterations=1), 2)
+    base["envs"]["CartPole-v0"]["max_steps"] = 10
+    base["agents"]["ddqn"].update(test_episodes=2, init_episodes=1)
+    cfg = with_vary(base)
+    m = _master_pair(cfg, tmp_path, monkeypatch)
+    assert isinstance(m.task, tasks.DdqnVaryTask) and m.inner.vary and m.cfg.batch_size == 597 and m.cfg.q_hidden == 171
+    theta0 = m.theta.cpu().numpy().copy()
+    gathered = m.evaluate_population(0).cpu().numpy()
+    eps = m.eps.cpu().numpy()
+    hps = m.task.last_hp
+    assert len(hps) == 6 and len({h["batch_size"] for h in hps}) > 1
+    scores = []
+    for c in range(6):
+        key = orc.chain_key(m.seed, 0, c // 3, c % 3)
+        oh = orc.vary_chain_hp(cfg["agents"]["ddqn"], key)       # numpy's exp/log vs libm's: lr may differ in the last bit
+        assert all(hps[c][n] == oh[n] for n in ("batch_size", "hidden_size", "hidden_layer")) and abs(hps[c]["lr"] / oh["lr"] - 1) < 1e-14
+        ocfg = orc.ddqn_cfg_from_config(cfg, grad_chunk=0, **orc.hp_overrides(hps[c]))
+        pc = _lib.DdqnCfg()
+        for f, _ in _lib.DdqnCfg._fields_:
+            setattr(pc, f, getattr(ocfg, f))
+        init = orc.agent_init_from_key(key, agent_layer_dims(pc))
+        sg = np.float32([0.0, 1.0, -1.0][c % 3])
+        w = (sg * eps[c // 3] + theta0).astype(np.float32)
+        scores.append(orc.ddqn_se_chain(ocfg, w, init, rng_key=key)["score"])
+    scores = np.array(scores)
+    best, sign = orc.worker_best(scores[1::3], scores[2::3], True)
+    assert np.array_equal(gathered[:, 0], best) and np.array_equal(gathered[:, 1], scores[0::3])
+    assert np.array_equal(gathered[:, 2], sign.astype(np.float64))
+    mean_score, mean_list, _ = m.run()
+    assert len(mean_list) == 1
+    # vary_hp False: the plain DDQN task, same kernel and numbers as agent_name DDQN
+    m0 = _master_pair(with_vary(base, vary_hp=False), tmp_path, monkeypatch)
+    m1 = _master_pair(base, tmp_path, monkeypatch)
+    assert isinstance(m0.task, tasks.DdqnSeTask) and not m0.inner.vary
+    assert torch.equal(m0.evaluate_population(0), m1.evaluate_population(0))
+
+
 def test_reward_env_cheetah_standin_step_matches_reference(golden):
     """EnvWrapper.step on the continuous-state RewardEnv: next states bit-equal to the shim run of the reference, shaped
     rewards within the fixture tolerance."""

@@ -481,6 +481,126 @@ def test_ddqn_multilayer_counter_mode_vs_oracle(eng, orc, golden, env_name, laye
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# *_vary agents: per-chain lr / batch_size / hidden_size / hidden_layer in ONE launch (lenv_dueling_se_inner_loop_hp)
+# ---------------------------------------------------------------------------------------------------------------
+def _vary_max_cfg(orc, cfgd, agent_key, **over):
+    from learning_environments_amd.agents import vary
+    bd = vary.hp_bounds(cfgd["agents"][agent_key])
+    return _inner_cfg(orc, cfgd, grad_chunk=0, batch_size=bd["batch_size"][1], q_hidden=bd["hidden_size"][1],
+                      q_layers=max(1, bd["hidden_layer"][1]), **over)[1]
+
+
+@pytest.mark.parametrize("name", ["g8v_calc_score_cartpole_ddqn_vary", "g8v2_calc_score_cartpole_ddqn_vary_wide",
+                                  "g8vd_calc_score_acrobot_dueling_vary"])
+def test_vary_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
+    """The reference's DDQN_vary / DuelingDDQN_vary runs (hyper-parameters drawn through the ConfigSpace stand-in, recorded in
+    the fixture) replayed in a launch sized for the LARGEST possible draw: chain 0 carries the recorded draw, chain 1 the
+    family's base hyper-parameters.  Products with more than 128 rows / columns run block by block."""
+    g = golden(name)
+    cfgd, hp = json.loads(str(g["config_json"])), json.loads(str(g["hp_json"]))
+    agent_key = cfgd["agents"]["gtn"]["agent_name"].lower()[:-5]
+    base = cfgd["agents"][agent_key]
+    common = dict(rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
+    ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, **common, **orc.hp_overrides(hp))
+    cfg = _vary_max_cfg(orc, cfgd, agent_key, **common)
+    assert cfg.batch_size >= 3 * base["batch_size"] - 2 and cfg.q_layers == base["hidden_layer"] + 1
+    n = g["tr_action"].size
+    otapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    o = orc.ddqn_se_chain(ocfg, g["theta"], g["agent_init"], tapes=otapes, trace_cap=n + 8)
+    chains = 2
+    il = eng.InnerLoop(cfg, chains, trace_cap=n + 8, vary=True, want_final_online=True)
+    il.set_hp([hp["lr"]] * 2, [hp["batch_size"]] * 2, [hp["hidden_size"]] * 2, [hp["hidden_layer"]] * 2)
+    p_c = il.chain_num_params(hp["hidden_size"], hp["hidden_layer"])
+    assert p_c == g["agent_init"].size and p_c <= il.p_agent
+    init = np.full((chains, il.p_agent), np.nan, np.float32)            # the unused tail of a row is never read
+    init[:, :p_c] = g["agent_init"]
+    tapes = dict(eps_uniform=dev(np.tile(g["tape_eps_uniform"], (chains, 1))),
+                 rand_action=dev(np.tile(g["tape_rand_action"], (chains, 1))),
+                 replay_idx=dev(np.tile(g["tape_replay_idx"].reshape(1, -1), (chains, 1))),
+                 train_reset=dev(np.tile(g["tape_train_reset"][None], (chains, 1, 1))),
+                 test_reset=dev(np.tile(g["tape_test_reset"][None], (chains, 1, 1))))
+    il.run(dev(g["theta"]), None, None, None, dev(init), tapes=tapes)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        act = il.trace["action"][c, :n].cpu().numpy()
+        assert np.array_equal(act & 0xFFFF, o["trace"]["action"]) and np.array_equal(act >> 16, o["trace"]["explored"])
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"])
+        assert np.array_equal(il.trace["reward_done"][c, :n, 0].cpu().numpy(), o["trace"]["reward"])
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(il.final_returns[c].cpu().numpy(), o["final_test_returns"])
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(act & 0xFFFF, g["tr_action"])
+        np.testing.assert_allclose(il.trace["next_state"][c, :n].cpu().numpy(), g["tr_next_state"], rtol=1e-5, atol=1e-5)
+        assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4
+    # a chain whose draw exceeds the maxima the launch was sized for reports status -8 and leaves the others alone
+    il.hp["q_hidden"][1] = cfg.q_hidden + 1
+    il.run(dev(g["theta"]), None, None, None, dev(init), tapes=tapes)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0, -8] and float(il.score[0]) == o["score"]
+
+
+@pytest.mark.parametrize("family", ["ddqn", "duelingddqn"])
+def test_vary_counter_mode_heterogeneous_population_vs_oracle(eng, orc, golden, family):
+    """Six chains with six different (lr, batch, width, depth) draws in one launch: each equals the oracle chain run with
+    that chain's hyper-parameters and the same fresh agent (lenv_dueling_agent_init_hp == nn.Linear default init per shape)."""
+    from learning_environments_amd.agents import vary
+    from learning_environments_amd.config import agent_layer_dims
+    g = golden("g8v_calc_score_cartpole_ddqn_vary" if family == "ddqn" else "g8vd_calc_score_acrobot_dueling_vary")
+    cfgd = json.loads(str(g["config_json"]))
+    cfgd["agents"][family].update(test_episodes=3)
+    common = dict(rng_mode=0, train_episodes=3, max_steps=10)
+    cfg = _vary_max_cfg(orc, cfgd, family, **common)
+    S, A = cfg.state_dim, cfg.num_actions
+    chains = 6
+    keys = np.array([orc.chain_key(21, 4, c // 3, c % 3) for c in range(chains)], np.uint64)
+    hps = [vary.vary_hyperparameters(cfgd["agents"][family], vary.chain_units(int(k))) for k in keys]
+    for k, h in zip(keys, hps):                            # the package's draw == the oracle's restatement, key by key
+        o = orc.vary_chain_hp(cfgd["agents"][family], int(k))
+        assert all(h[n] == o[n] for n in ("batch_size", "hidden_size", "hidden_layer")) and abs(h["lr"] / o["lr"] - 1) < 1e-14
+    assert len({(h["batch_size"], h["hidden_size"]) for h in hps}) == chains
+    rng = np.random.RandomState(31)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, cfg.se_hidden, 1, "leakyrelu"))
+    theta = (rng.randn(P_se) * 0.15).astype(np.float32)
+    eps = (rng.randn(2, P_se) * 0.05).astype(np.float32)
+    worker = np.repeat(np.arange(2), 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), 2)
+    il = eng.InnerLoop(cfg, chains, trace_cap=30, vary=True)
+    il.set_hp([h["lr"] for h in hps], [h["batch_size"] for h in hps], [h["hidden_size"] for h in hps], [h["hidden_layer"] for h in hps])
+    keys_t = dev(keys.view(np.int64))
+    init = il.draw_agent_init(keys_t).cpu().numpy()
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), None, rng_keys=keys_t)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        h = hps[c]
+        ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, **common, **orc.hp_overrides(h))
+        pc = _lib_cfg_copy(ocfg)
+        dims = agent_layer_dims(pc)
+        oinit = orc.agent_init_from_key(int(keys[c]), dims)
+        assert oinit.size == il.chain_num_params(h["hidden_size"], h["hidden_layer"])
+        assert np.array_equal(init[c, :oinit.size], oinit), c
+        w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+        o = orc.ddqn_se_chain(ocfg, w, oinit, rng_key=int(keys[c]), trace_cap=30)
+        n = o["trace"]["action"].size
+        assert o["learn_steps"] > 0
+        assert np.array_equal(il.trace["action"][c, :n].cpu().numpy() & 0xFFFF, o["trace"]["action"]), (c, h)
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"]), (c, h)
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), (c, h)
+        assert float(il.score[c]) == o["score"], (c, h)
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
+def _lib_cfg_copy(ocfg):
+    from learning_environments_amd import _lib
+    c = _lib.DdqnCfg()
+    for f, _ in _lib.DdqnCfg._fields_:
+        setattr(c, f, getattr(ocfg, f))
+    return c
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # config 5: TD3 on a continuous-state RewardEnv (HalfCheetah stand-in)
 # ---------------------------------------------------------------------------------------------------------------
 def _td3_cfgs(orc, cfgd, rng_mode, **over):

@@ -170,6 +170,61 @@ def test_g8_calc_score_trace(golden, name, chunk):
     assert abs(out["score"] - float(g["score"])) <= 1e-4
 
 
+@pytest.mark.parametrize("name", ["g8v_calc_score_cartpole_ddqn_vary", "g8v2_calc_score_cartpole_ddqn_vary_wide",
+                                  "g8vd_calc_score_acrobot_dueling_vary"])
+def test_g8v_vary_agents_replay_of_the_recorded_draw(golden, name):
+    """DDQN_vary / DuelingDDQN_vary (agents/DDQN_vary.py:26-59): the reference run drew its hyper-parameters through the
+    ConfigSpace stand-in; the oracle replays the run with the recorded draw (lr, batch 204/555/145, width 129/161/108,
+    2/1/3 hidden layers) and the recorded tapes."""
+    import json
+    g = golden(name)
+    cfgd, hp = json.loads(str(g["config_json"])), json.loads(str(g["hp_json"]))
+    assert cfgd["agents"]["gtn"]["agent_name"].endswith("_vary")
+    cfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=1, train_episodes=int(g["train_episodes"]),
+                                   max_steps=int(g["max_steps"]), **orc.hp_overrides(hp))
+    tapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"],
+                           g["tape_test_reset"])
+    n = g["tr_action"].size
+    out = orc.ddqn_se_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 10)
+    assert out["rc"] == 0
+    tr = out["trace"]
+    assert np.array_equal(tr["action"], g["tr_action"]) and np.array_equal(tr["explored"], g["tr_explored"])
+    np.testing.assert_allclose(tr["next_state"], g["tr_next_state"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(tr["reward"], g["tr_reward"], rtol=1e-5, atol=1e-5)
+    losses = tr["loss"][~np.isnan(tr["loss"])]
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-3, atol=1e-6)
+    assert np.array_equal(out["episode_len"], g["episode_length_train"])
+    np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=1e-4)
+    assert abs(out["score"] - float(g["score"])) <= 1e-4
+
+
+def test_vary_hyperparameter_draw():
+    """The package's sampler (agents/vary.py) against the oracle's numpy restatement of ConfigSpace 0.4.13 on the same
+    uniforms, the reference's bounds, and the log-uniform shape of the draw."""
+    from learning_environments_amd.agents import vary
+    sec = dict(lr=1e-3, batch_size=199, hidden_size=57, hidden_layer=1)
+    rs = np.random.RandomState(4)
+    draws = []
+    for _ in range(4000):
+        u = rs.rand(4)
+        d = vary.vary_hyperparameters(sec, u)
+        o = orc.vary_hyperparameters(sec, u)
+        assert d["batch_size"] == o["batch_size"] and d["hidden_size"] == o["hidden_size"] and d["hidden_layer"] == o["hidden_layer"]
+        assert abs(d["lr"] - o["lr"]) <= 1e-15
+        draws.append(d)
+    b = np.array([d["batch_size"] for d in draws]); h = np.array([d["hidden_size"] for d in draws])
+    l = np.array([d["hidden_layer"] for d in draws]); lr = np.array([d["lr"] for d in draws])
+    assert b.min() >= 66 and b.max() <= 597 and h.min() >= 19 and h.max() <= 171 and set(l.tolist()) == {0, 1, 2}
+    assert lr.min() >= 1e-3 / 3 and lr.max() <= 3e-3
+    # log-uniform: the median sits at the geometric centre, a third of the integer draws per layer count
+    assert abs(np.median(np.log(lr)) - np.log(1e-3)) < 0.08 and abs(np.median(np.log(b)) - 0.5 * (np.log(65.5) + np.log(597.5))) < 0.08
+    assert np.all(np.abs(np.bincount(l) / l.size - 1 / 3) < 0.03)
+    # edge of the range: u -> 0 / 1 hit the bounds exactly
+    lo = vary.vary_hyperparameters(sec, [0.0, 0.0, 0.0, 0.0]); hi = vary.vary_hyperparameters(sec, [1.0 - 2 ** -53] * 4)
+    assert (lo["batch_size"], lo["hidden_size"], lo["hidden_layer"]) == (66, 19, 0)
+    assert (hi["batch_size"], hi["hidden_size"], hi["hidden_layer"]) == (597, 171, 2)
+
+
 def test_g10_gridworld_tables(golden):
     """The package's table compiler (envs/gridworld.py) against tables produced by stepping the reference's classes."""
     from learning_environments_amd.envs.gridworld import transition_tables
