@@ -299,6 +299,15 @@ int lenv_td3_rn_inner_loop(const lenv_td3_cfg *cfg /*HOST*/, const float *theta,
                            const float *sign, const float *agent_init, const uint64_t *rng_keys,
                            const lenv_td3_tapes *tapes /*HOST, may be NULL*/, int64_t chains, void *workspace,
                            size_t workspace_bytes, const lenv_td3_out *out /*HOST*/, void *stream);
+/* TD3_vary (agents/TD3_vary.py:24-58): per-chain lr / batch_size / hidden_size / hidden_layer through the lenv_chain_hp arrays: q_hidden ->
+ * cfg.hidden, q_layers -> cfg.layers; cfg carries the maxima, agent_init rows hold actor | critic_1 | critic_2 at the chain's
+ * own shapes (row stride lenv_td3_num_params(cfg)).  hp == NULL: identical to lenv_td3_rn_inner_loop. */
+int lenv_td3_rn_inner_loop_hp(const lenv_td3_cfg *cfg /*HOST*/, const lenv_chain_hp *hp /*HOST struct of device arrays*/,
+                              const float *theta, const float *eps, const int32_t *worker, const float *sign,
+                              const float *agent_init, const uint64_t *rng_keys, const lenv_td3_tapes *tapes /*HOST*/,
+                              int64_t chains, void *workspace, size_t workspace_bytes, const lenv_td3_out *out /*HOST*/, void *stream);
+int lenv_td3_agent_init_hp(const lenv_td3_cfg *cfg /*HOST*/, const lenv_chain_hp *hp, const uint64_t *rng_keys, int64_t chains,
+                           float *agent_init, void *stream);
 
 /*
  * Batched forward of one MLP in the flat layout above: y [rows,out] = net(x [rows,in]) (models/model_utils.py:31-39;

@@ -102,7 +102,7 @@ class Td3Out(C.Structure):
 EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv_se_step_population",
            "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_lds_bytes", "lenv_ddqn_se_inner_loop",
            "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population", "lenv_dueling_se_workspace_bytes",
-           "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_dueling_se_inner_loop_hp", "lenv_dueling_agent_init_hp", "lenv_rng_unit", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
+           "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_dueling_se_inner_loop_hp", "lenv_dueling_agent_init_hp", "lenv_rng_unit", "lenv_td3_rn_inner_loop_hp", "lenv_td3_agent_init_hp", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
            "lenv_td3_rn_inner_loop", "lenv_mlp_forward", "lenv_cheetah_standin_reset", "lenv_cheetah_standin_step",
            "lenv_rn_num_params", "lenv_rn_shape_rows", "lenv_nes_worker_best_multi", "lenv_nes_draw", "lenv_nes_status_fold"]
 
@@ -172,6 +172,10 @@ def lib():
         L.lenv_td3_rn_inner_loop.restype = C.c_int
         L.lenv_td3_rn_inner_loop.argtypes = [C.POINTER(Td3Cfg), vp, vp, vp, vp, vp, vp, C.POINTER(Td3Tapes), C.c_int64, vp, C.c_size_t,
                                              C.POINTER(Td3Out), vp]
+        L.lenv_td3_rn_inner_loop_hp.restype = C.c_int
+        L.lenv_td3_rn_inner_loop_hp.argtypes = [C.POINTER(Td3Cfg), C.POINTER(ChainHp)] + list(L.lenv_td3_rn_inner_loop.argtypes[1:])
+        L.lenv_td3_agent_init_hp.restype = C.c_int
+        L.lenv_td3_agent_init_hp.argtypes = [C.POINTER(Td3Cfg), C.POINTER(ChainHp), vp, C.c_int64, vp, vp]
         L.lenv_rn_num_params.restype = C.c_int64
         L.lenv_rn_num_params.argtypes = [C.c_int32] * 5
         L.lenv_rn_shape_rows.restype = C.c_int

@@ -5,6 +5,7 @@ combination owns one fused kernel:
     DDQN on a VirtualEnv (synthetic_env_type 0)   -> lenv_ddqn_se_inner_loop   (BASELINE configs 1-2, Acrobot-DDQN)
     DuelingDDQN on a VirtualEnv                   -> lenv_dueling_se_inner_loop (BASELINE config 3)
     DDQN_vary / DuelingDDQN_vary on a VirtualEnv  -> lenv_dueling_se_inner_loop_hp (per-chain lr / batch / width / depth)
+    TD3_vary on a RewardEnv over the stand-in     -> lenv_td3_rn_inner_loop_hp
     QL / QL_cb / SARSA / SARSA_cb on a RewardEnv over a gridworld (type 1) -> lenv_ql_rn_inner_loop (BASELINE config 4)
     TD3  on a RewardEnv over the HalfCheetah stand-in -> lenv_td3_rn_inner_loop (BASELINE config 5)
 Anything else raises NotImplementedError, like the reference does for unknown agents."""
@@ -116,6 +117,44 @@ class Td3RnTask(object):
         return True
 
 
+class Td3VaryTask(object):
+    """TD3_vary on the stand-in RewardEnv (agents/TD3_vary.py:24-58): per-chain lr / batch_size / hidden_size / hidden_layer in
+    one launch of the TD3 kernel (lenv_td3_rn_inner_loop_hp), like DdqnVaryTask."""
+    name = "td3_vary_rn"
+
+    def __init__(self, config, engine):
+        import copy
+        from . import vary
+        if engine.name != "hip":
+            raise NotImplementedError("the *_vary agents need the HIP engine")
+        self.engine = engine
+        self.base = config["agents"]["td3"]
+        bd = vary.hp_bounds(self.base)
+        big = copy.deepcopy(config)
+        big["agents"]["td3"].update(batch_size=bd["batch_size"][1], hidden_size=bd["hidden_size"][1], hidden_layer=bd["hidden_layer"][1])
+        self.cfg = td3_cfg_from_config(big)
+        self.agent_bounds = None
+        self.last_hp = None
+
+    def make_inner(self, chains, want_episode_stats=False):
+        return self.engine.make_inner_td3(self.cfg, chains, want_episode_stats=want_episode_stats, vary=True)
+
+    def draw_hp(self, keys):
+        from . import vary
+        return [vary.vary_hyperparameters(self.base, vary.chain_units(k)) for k in keys]
+
+    def scores(self, inner, theta, eps, chain_worker, chain_sign, keys_t, agent_init):
+        keys = keys_t.cpu().numpy().view(np.uint64)
+        hp = self.last_hp = self.draw_hp(keys)
+        inner.set_hp([h["lr"] for h in hp], [h["batch_size"] for h in hp], [h["hidden_size"] for h in hp],
+                     [h["hidden_layer"] for h in hp])
+        inner.draw_agent_init(keys_t)
+        return self.engine.inner_scores_td3(inner, theta, eps, chain_worker, chain_sign, None, keys_t)
+
+    def needs_agent_init(self):
+        return False
+
+
 def select_task(config, engine, synthetic_env):
     agent_name = config["agents"]["gtn"]["agent_name"].lower()
     env_type = config["agents"]["gtn"]["synthetic_env_type"]
@@ -131,4 +170,6 @@ def select_task(config, engine, synthetic_env):
         return QlRnTask(config, engine, real.tables)
     if agent_name == "td3" and env_type == 1:
         return Td3RnTask(config, engine)
+    if agent_name == "td3_vary" and env_type == 1:
+        return Td3VaryTask(config, engine) if config["agents"]["td3_vary"]["vary_hp"] else Td3RnTask(config, engine)
     raise NotImplementedError("inner agent '%s' on synthetic_env_type %s has no fused kernel yet" % (agent_name, env_type))

@@ -131,7 +131,7 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
                       rn_hidden=int(val(e["hidden_size"])), rn_layers=int(val(e["hidden_layer"])), rn_act=_lib.ACT[e["activation_fn"]],
                       rn_prelu=0.25, reward_env_type=int(val(e["reward_env_type"])), info_dim=int(val(e.get("info_dim", 0))),
                       hidden=int(a["hidden_size"]),
-                      layers=int(a["hidden_layer"]), act=_lib.ACT[a["activation_fn"]], prelu=0.25, batch_size=int(a["batch_size"]),
+                      layers=max(1, int(a["hidden_layer"])), act=_lib.ACT[a["activation_fn"]], prelu=0.25, batch_size=int(a["batch_size"]),
                       rb_size=int(a["rb_size"]), train_episodes=int(a["train_episodes"]), test_episodes=int(a["test_episodes"]),
                       init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]),
                       policy_delay=int(a["policy_delay"]), rng_mode=int(rng_mode), solved_reward=float(val(e["solved_reward"])),

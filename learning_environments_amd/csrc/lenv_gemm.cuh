@@ -471,7 +471,7 @@ struct GemmQueue {
     }
 };
 
-constexpr int GEMM_QUEUE_MAX = 24;                         // commands per queue run (LDS: 24 x 128 B)
+constexpr int GEMM_QUEUE_MAX = 32;                         // commands per queue run (LDS: 32 x 128 B)
 
 __device__ __forceinline__ GemmEpi epi_store(float *out, int ldo, int ocol = 0) { GemmEpi e{}; e.kind = EPI_STORE; e.out = out; e.ldo = ldo; e.ocol = ocol; return e; }
 __device__ __forceinline__ GemmEpi epi_accum(float *out, int ldo) { GemmEpi e{}; e.kind = EPI_ACCUM; e.out = out; e.ldo = ldo; return e; }

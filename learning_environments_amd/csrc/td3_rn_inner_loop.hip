@@ -17,12 +17,23 @@
 
 namespace lenv {
 
-constexpr int T3_MAXL = 2;     // hidden layers of actor / critic
-constexpr int T3_MAXW = 128;
-constexpr int T3_MAXI = 256;   // max rows of one product (batch size)
+constexpr int T3_MAXL = 3;     // hidden layers of actor / critic (TD3_vary draws hidden_layer + 1)
+constexpr int T3_MAXW = 512;   // max hidden_size (outputs wider than 128 run as several 128-column blocks)
+constexpr int T3_MAXB = 640;   // max batch size  (more than 256 rows run as several row blocks)
+constexpr int T3_MAXI = 256;   // rows of one product block
 constexpr int T3_S = 17, T3_A = 6, T3_SA = 23;
 
 struct MlpOff { int in, H, L, out; int oW[T3_MAXL + 1], ob[T3_MAXL + 1]; int P; };
+
+__host__ __device__ inline void mlp_off(MlpOff &m, int in, int H, int L, int out)
+{
+    m.in = in; m.H = H; m.L = L; m.out = out;
+    int o = 0, n_in = in;
+    for (int l = 0; l <= T3_MAXL; ++l) m.oW[l] = m.ob[l] = 0;
+    for (int l = 0; l < L; ++l) { m.oW[l] = o; o += H * n_in; m.ob[l] = o; o += H; n_in = H; }
+    m.oW[L] = o; o += out * H; m.ob[L] = o; o += out;
+    m.P = o;
+}
 
 struct Td3Args {
     lenv_td3_cfg cfg;
@@ -32,8 +43,10 @@ struct Td3Args {
     float *arena; int64_t arena_stride;
     lenv_td3_out out;
     int64_t rb_cap; int RS;
-    MlpOff actor, critic;
-    int P, P_rn;
+    MlpOff actor, critic;                     // at cfg's (maximal) shapes
+    int P, P_rn;                              // P = row stride of agent_init / final_params
+    // per-chain hyper-parameters (device arrays [chains], all or none): TD3_vary (agents/TD3_vary.py:24-58)
+    const double *hp_lr; const int32_t *hp_batch, *hp_hidden, *hp_layers;
     int64_t a_params, a_targets, a_m, a_v, a_grad, a_replay, a_xc, a_xn, a_xa, a_hc1[T3_MAXL], a_hc2[T3_MAXL], a_ha[T3_MAXL],
         a_ht[T3_MAXL], a_d[2], a_dx, a_act, a_th, a_dz, a_meter;
 };
@@ -55,8 +68,19 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     const int tid = threadIdx.x;
     const int64_t chain = blockIdx.x;
     constexpr int S = T3_S, A = T3_A, SA = T3_SA;
-    const int H = cfg.hidden, L = cfg.layers, B = cfg.batch_size, T = cfg.test_episodes, Hrn = cfg.rn_hidden, RS = a.RS, P = a.P;
-    const int Pa = a.actor.P, Pc = a.critic.P;
+    const bool vary = a.hp_batch != nullptr;
+    const int H = vary ? a.hp_hidden[chain] : cfg.hidden, L = vary ? a.hp_layers[chain] : cfg.layers;
+    const int B = vary ? a.hp_batch[chain] : cfg.batch_size, Bm = cfg.batch_size;      // LDS is carved for cfg's (maximal) batch
+    const double lr = vary ? a.hp_lr[chain] : cfg.lr;
+    const int T = cfg.test_episodes, Hrn = cfg.rn_hidden, RS = a.RS;
+    if (vary && (H < 1 || H > cfg.hidden || L < 1 || L > cfg.layers || B < 1 || B > cfg.batch_size)) {   // uniform per chain
+        if (tid == 0) { if (a.out.status) a.out.status[chain] = -8; a.out.score[chain] = 0.0; }
+        return;
+    }
+    MlpOff mo_actor, mo_critic;
+    mlp_off(mo_actor, S, H, L, A);
+    mlp_off(mo_critic, SA, H, L, 1);
+    const int Pa = mo_actor.P, Pc = mo_critic.P, P = Pa + 2 * Pc;
     const int act_id = cfg.act;
     const float prelu = cfg.prelu, ma = (float)cfg.max_action;
 
@@ -66,8 +90,8 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     float *rn_w = reinterpret_cast<float *>(cmds + GEMM_QUEUE_MAX);   // reward net: W0 [Hrn][S] | b0 [Hrn] | Wout [Hrn] | bout
     float *rn_h = rn_w + ((a.P_rn + 3) & ~3);             // [Hrn]
     float *q1 = rn_h + ((Hrn + 3) & ~3);                  // [B]
-    float *q2 = q1 + B, *tq1 = q2 + B, *tq2 = tq1 + B, *rr = tq2 + B, *dd = rr + B, *dq1 = dd + B, *dq2 = dq1 + B;
-    float *misc = dq2 + B;                                // [64]
+    float *q2 = q1 + Bm, *tq1 = q2 + Bm, *tq2 = tq1 + Bm, *rr = tq2 + Bm, *dd = rr + Bm, *dq1 = dd + Bm, *dq2 = dq1 + Bm;
+    float *misc = dq2 + Bm;                                // [64]
     double *xs_d = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(misc + 64) + 7) & ~(uintptr_t)7);   // [17] train env state
     double *xt_d = xs_d + 20;                             // [T][17] test env states
     double *ret = xt_d + 17 * T;                          // [T]
@@ -94,7 +118,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         for (int i = tid; i < a.P_rn; i += DNT) rn_w[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
     }
     for (int p = tid; p < P; p += DNT) {
-        const float w = a.agent_init[chain * P + p];
+        const float w = a.agent_init[chain * a.P + p];
         params[p] = w; targets[p] = w; adam_m[p] = 0.0f; adam_v[p] = 0.0f;
     }
     if (tid < 64) misc[tid] = 0.0f;
@@ -160,7 +184,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     auto adam = [&](int p0, int n, int pi) {
         if (tid == 0) {
             pows[pi] *= cfg.adam_beta1; pows[pi + 1] *= cfg.adam_beta2;
-            ctrl[10] = (float)(-(cfg.lr / (1.0 - pows[pi])));
+            ctrl[10] = (float)(-(lr / (1.0 - pows[pi])));
             ctrl[11] = (float)__builtin_sqrt(1.0 - pows[pi + 1]);
         }
         __syncthreads();
@@ -219,7 +243,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         for (int t = 0; t < cfg.max_steps; ++t) {
             for (int e = tid; e < T * S; e += DNT) xt[e] = (float)xt_d[e];
             __syncthreads();
-            mlp_forward(params, a.actor, xt, S, T, ht, at, A, 0, true, nullptr);
+            mlp_forward(params, mo_actor, xt, S, T, ht, at, A, 0, true, nullptr);
             gq.run<T3_MAXI>(Ps, Qs);
             // select_test_action (TD3.py:126-129): (actor(s) + randn(A)*action_std*max_action).clamp(-max, max)
             for (int e = tid; e < T * A; e += DNT) {
@@ -284,7 +308,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 ++n_rand;
                 __syncthreads();
             } else {
-                mlp_forward(params, a.actor, state, S, 1, ht, action, A, 0, true, nullptr);
+                mlp_forward(params, mo_actor, state, S, 1, ht, action, A, 0, true, nullptr);
                 gq.run<T3_MAXI>(Ps, Qs);
                 if (tid < A) {
                     float zn;
@@ -362,7 +386,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 __syncthreads();
                 PT_MARK(1);                               // replay gather
                 // next_actions = (actor_target(s') + clamp(randn*policy_std)).clamp(-max, max)
-                mlp_forward(targets, a.actor, xn, SA, B, ht, xn, SA, S, true, nullptr);
+                mlp_forward(targets, mo_actor, xn, SA, B, ht, xn, SA, S, true, nullptr);
                 gq.run<T3_MAXI>(Ps, Qs);
                 for (int e = tid; e < B * A; e += DNT) {
                     const int b = e / A, k = e - b * A;
@@ -378,10 +402,10 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 }
                 __syncthreads();
                 PT_MARK(2);                               // actor_target forward + smoothing noise
-                mlp_forward(targets + Pa, a.critic, xn, SA, B, ht, tq1, 1, 0, false, nullptr);
-                mlp_forward(targets + Pa + Pc, a.critic, xn, SA, B, ht, tq2, 1, 0, false, nullptr);
-                mlp_forward(params + Pa, a.critic, xc, SA, B, hc1, q1, 1, 0, false, nullptr);
-                mlp_forward(params + Pa + Pc, a.critic, xc, SA, B, hc2, q2, 1, 0, false, nullptr);
+                mlp_forward(targets + Pa, mo_critic, xn, SA, B, ht, tq1, 1, 0, false, nullptr);
+                mlp_forward(targets + Pa + Pc, mo_critic, xn, SA, B, ht, tq2, 1, 0, false, nullptr);
+                mlp_forward(params + Pa, mo_critic, xc, SA, B, hc1, q1, 1, 0, false, nullptr);
+                mlp_forward(params + Pa + Pc, mo_critic, xc, SA, B, hc2, q2, 1, 0, false, nullptr);
                 gq.run<T3_MAXI>(Ps, Qs);                   // 4 critic forwards, one call
                 PT_MARK(3);
                 {
@@ -395,8 +419,8 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 }
                 __syncthreads();
                 PT_MARK(4);                               // TD error
-                mlp_backward(params + Pa, a.critic, xc, SA, B, hc1, dq1, grad + Pa, nullptr);
-                mlp_backward(params + Pa + Pc, a.critic, xc, SA, B, hc2, dq2, grad + Pa + Pc, nullptr);
+                mlp_backward(params + Pa, mo_critic, xc, SA, B, hc1, dq1, grad + Pa, nullptr);
+                mlp_backward(params + Pa + Pc, mo_critic, xc, SA, B, hc2, dq2, grad + Pa + Pc, nullptr);
                 gq.run<T3_MAXI>(Ps, Qs);
                 PT_MARK(5);                               // critics backward
                 adam(Pa, 2 * Pc, 0);                       // critic_optimizer: critic_1 then critic_2 parameters
@@ -406,13 +430,13 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1
                     for (int e = tid; e < B * S; e += DNT) { const int b = e / S, i = e - b * S; xa[b * SA + i] = xc[b * SA + i]; }
                     __syncthreads();
-                    mlp_forward(params, a.actor, xc, SA, B, ha, xa, SA, S, true, thb);
-                    mlp_forward(params + Pa, a.critic, xa, SA, B, hc1, q1, 1, 0, false, nullptr);
+                    mlp_forward(params, mo_actor, xc, SA, B, ha, xa, SA, S, true, thb);
+                    mlp_forward(params + Pa, mo_critic, xa, SA, B, hc1, q1, 1, 0, false, nullptr);
                     gq.run<T3_MAXI>(Ps, Qs);
                     const float dqa = -(1.0f / (float)B);
                     for (int b = tid; b < B; b += DNT) dq1[b] = dqa;
                     __syncthreads();
-                    mlp_backward(params + Pa, a.critic, xa, SA, B, hc1, dq1, nullptr, dxb);
+                    mlp_backward(params + Pa, mo_critic, xa, SA, B, hc1, dq1, nullptr, dxb);
                     gq.run<T3_MAXI>(Ps, Qs);
                     for (int e = tid; e < B * A; e += DNT) {
                         const int b = e / A, k = e - b * A;
@@ -420,7 +444,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                         dzb[e] = (dxb[b * SA + S + k] * ma) * fma32(-th, th, 1.0f);   // d(tanh(z)*max_action)
                     }
                     __syncthreads();
-                    mlp_backward(params, a.actor, xc, SA, B, ha, dzb, grad, nullptr);
+                    mlp_backward(params, mo_actor, xc, SA, B, ha, dzb, grad, nullptr);
                     gq.run<T3_MAXI>(Ps, Qs);
                     PT_MARK(7);                           // policy update: forwards + backwards
                     adam(0, Pa, 2);
@@ -508,22 +532,38 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = pad_l;
         }
     }
-    if (a.out.final_params) for (int p = tid; p < P; p += DNT) a.out.final_params[chain * P + p] = params[p];
+    if (a.out.final_params) for (int p = tid; p < P; p += DNT) a.out.final_params[chain * a.P + p] = params[p];
     if (a.out.status && status != 0) atomicMin(&a.out.status[chain], status);
+}
+
+// Fresh TD3 agents (actor | critic_1 | critic_2, TD3.py:31-39) for chains with their own network shapes: nn.Linear's default
+// init, drawn like lenv_nes_draw (see dueling_agent_init_kernel)
+__global__ void td3_agent_init_kernel(lenv_td3_cfg cfg, const int32_t *hp_hidden, const int32_t *hp_layers, const uint64_t *rng_keys,
+                                      int64_t chains, int64_t row_stride, float *agent_init)
+{
+    const int64_t c = blockIdx.y;
+    if (c >= chains) return;
+    const int H = hp_hidden ? hp_hidden[c] : cfg.hidden, L = hp_layers ? hp_layers[c] : cfg.layers;
+    if (H < 1 || H > cfg.hidden || L < 1 || L > cfg.layers) return;            // the inner loop reports status -8 for this chain
+    MlpOff ma, mc;
+    mlp_off(ma, T3_S, H, L, T3_A);
+    mlp_off(mc, T3_SA, H, L, 1);
+    const int P = ma.P + 2 * mc.P;
+    const uint64_t key = rng_keys[c];
+    const float bS = (float)(1.0 / __builtin_sqrt((double)T3_S)), bSA = (float)(1.0 / __builtin_sqrt((double)T3_SA)),
+                bH = (float)(1.0 / __builtin_sqrt((double)H));
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
+        float bound;
+        if (i < ma.P) bound = i < ma.oW[1] ? bS : bH;
+        else { const int j = (i - ma.P) % mc.P; bound = j < mc.oW[1] ? bSA : bH; }
+        const float u = (float)u64_to_unit(rng_u64(key, STREAM_AGENT_INIT, (uint64_t)i));
+        agent_init[c * row_stride + i] = (u * 2.0f - 1.0f) * bound;
+    }
 }
 
 }  // namespace lenv
 
 using namespace lenv;
-
-static void mlp_off(MlpOff &m, int in, int H, int L, int out)
-{
-    m.in = in; m.H = H; m.L = L; m.out = out;
-    int o = 0, n_in = in;
-    for (int l = 0; l < L; ++l) { m.oW[l] = o; o += H * n_in; m.ob[l] = o; o += H; n_in = H; }
-    m.oW[L] = o; o += out * H; m.ob[L] = o; o += out;
-    m.P = o;
-}
 
 static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
 {
@@ -534,7 +574,7 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
     if (cfg->act == LENV_ACT_PRELU) return LENV_ERR_UNSUPPORTED;   // trained PReLU slope of the agent nets: not a parameter here yet
     const bool uses_info = t == 3 || t == 4 || t == 7 || t == 8 || t > 100;
     if (uses_info && cfg->info_dim != 4) return LENV_ERR_INVALID;                              // the stand-in's info vector has 4 entries
-    if (L < 1 || L > T3_MAXL || H < 1 || H > T3_MAXW || B < 1 || B > T3_MAXI || T < 1 || T * T3_S > DNT || cfg->rn_layers != 1 || Hrn < 1 ||
+    if (L < 1 || L > T3_MAXL || H < 1 || H > T3_MAXW || B < 1 || B > T3_MAXB || T < 1 || T * T3_S > DNT || cfg->rn_layers != 1 || Hrn < 1 ||
         cfg->policy_delay < 1 || cfg->max_steps < 1 || cfg->train_episodes < 0)
         return LENV_ERR_UNSUPPORTED;
     mlp_off(a.actor, T3_S, H, L, T3_A);
@@ -588,6 +628,31 @@ extern "C" int lenv_td3_rn_inner_loop(const lenv_td3_cfg *cfg, const float *thet
                                       const lenv_td3_tapes *tapes, int64_t chains, void *workspace, size_t workspace_bytes,
                                       const lenv_td3_out *out, void *stream)
 {
+    return lenv_td3_rn_inner_loop_hp(cfg, nullptr, theta, eps, worker, sign, agent_init, rng_keys, tapes, chains, workspace,
+                                     workspace_bytes, out, stream);
+}
+
+extern "C" int lenv_td3_agent_init_hp(const lenv_td3_cfg *cfg, const lenv_chain_hp *hp, const uint64_t *rng_keys, int64_t chains,
+                                      float *agent_init, void *stream)
+{
+    if (!cfg || !rng_keys || !agent_init || chains < 0) return LENV_ERR_INVALID;
+    if (hp && (!hp->q_hidden || !hp->q_layers)) return LENV_ERR_INVALID;
+    if (chains == 0) return LENV_OK;
+    Td3Args a;
+    size_t lds_bytes;
+    const int rc = td3_layout(cfg, a, &lds_bytes);
+    if (rc != LENV_OK) return rc;
+    hipLaunchKernelGGL(td3_agent_init_kernel, dim3(64, (unsigned)chains), dim3(256), 0, static_cast<hipStream_t>(stream), *cfg,
+                       hp ? hp->q_hidden : nullptr, hp ? hp->q_layers : nullptr, rng_keys, chains, (int64_t)a.P, agent_init);
+    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}
+
+extern "C" int lenv_td3_rn_inner_loop_hp(const lenv_td3_cfg *cfg, const lenv_chain_hp *hp, const float *theta, const float *eps,
+                                         const int32_t *worker, const float *sign, const float *agent_init, const uint64_t *rng_keys,
+                                         const lenv_td3_tapes *tapes, int64_t chains, void *workspace, size_t workspace_bytes,
+                                         const lenv_td3_out *out, void *stream)
+{
+    if (hp && (!hp->lr || !hp->batch_size || !hp->q_hidden || !hp->q_layers)) return LENV_ERR_INVALID;
     if (!cfg || !agent_init || !out || !out->score || !workspace || chains < 0) return LENV_ERR_INVALID;
     if (!theta && cfg->reward_env_type != 0) return LENV_ERR_INVALID;
     if (eps && (!worker || !sign)) return LENV_ERR_INVALID;
@@ -604,6 +669,8 @@ extern "C" int lenv_td3_rn_inner_loop(const lenv_td3_cfg *cfg, const float *thet
     if (tapes) a.tapes = *tapes; else a.tapes = lenv_td3_tapes{};
     a.arena = static_cast<float *>(workspace);
     a.out = *out;
+    a.hp_lr = hp ? hp->lr : nullptr; a.hp_batch = hp ? hp->batch_size : nullptr;
+    a.hp_hidden = hp ? hp->q_hidden : nullptr; a.hp_layers = hp ? hp->q_layers : nullptr;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(td3_rn_inner_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;
     if (out->status) {

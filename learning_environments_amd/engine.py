@@ -122,6 +122,31 @@ def chain_key(seed, generation, worker, kind):
     return int(_lib.lib().lenv_chain_key(seed, generation, worker, kind))
 
 
+def _alloc_chain_hp(obj):
+    """Device arrays of include/lenv_hip.h's lenv_chain_hp for obj.chains chains + the struct that points at them."""
+    dev, n = obj.dev, obj.chains
+    obj.hp = dict(lr=torch.zeros(n, dtype=torch.float64, device=dev), batch_size=torch.zeros(n, dtype=torch.int32, device=dev),
+                  q_hidden=torch.zeros(n, dtype=torch.int32, device=dev), q_layers=torch.zeros(n, dtype=torch.int32, device=dev))
+    obj.hp_struct = _lib.ChainHp(_ptr(obj.hp["lr"]), _ptr(obj.hp["batch_size"]), _ptr(obj.hp["q_hidden"]), _ptr(obj.hp["q_layers"]))
+    obj.agent_init = torch.zeros((n, obj.p_agent), dtype=torch.float32, device=dev)
+
+
+def _set_chain_hp(obj, lr, batch_size, hidden_size, hidden_layer, max_batch, max_hidden, max_layers):
+    if not obj.vary:
+        raise ValueError("the inner loop was built without vary=True")
+    n = obj.chains
+    if not (len(lr) == len(batch_size) == len(hidden_size) == len(hidden_layer) == n):
+        raise ValueError("set_hp: need %d values per hyper-parameter" % n)
+    layers = [max(1, int(v)) for v in hidden_layer]
+    if max(batch_size) > max_batch or max(hidden_size) > max_hidden or max(layers) > max_layers or min(batch_size) < 1 \
+            or min(hidden_size) < 1:
+        raise ValueError("set_hp: a chain's hyper-parameters exceed the maxima the inner loop was sized for")
+    obj.hp["lr"].copy_(torch.tensor([float(v) for v in lr], dtype=torch.float64))
+    obj.hp["batch_size"].copy_(torch.tensor([int(v) for v in batch_size], dtype=torch.int32))
+    obj.hp["q_hidden"].copy_(torch.tensor([int(v) for v in hidden_size], dtype=torch.int32))
+    obj.hp["q_layers"].copy_(torch.tensor(layers, dtype=torch.int32))
+
+
 class InnerLoop(object):
     """Owns the workspace/outputs of lenv_ddqn_se_inner_loop for a fixed (cfg, chains)."""
 
@@ -144,13 +169,7 @@ class InnerLoop(object):
             self.ws_bytes = int(L.lenv_dueling_se_workspace_bytes(C.byref(cfg), self.chains))
             self._fn = L.lenv_dueling_se_inner_loop
             if self.vary:
-                self.hp = dict(lr=torch.zeros(self.chains, dtype=torch.float64, device=self.dev),
-                               batch_size=torch.zeros(self.chains, dtype=torch.int32, device=self.dev),
-                               q_hidden=torch.zeros(self.chains, dtype=torch.int32, device=self.dev),
-                               q_layers=torch.zeros(self.chains, dtype=torch.int32, device=self.dev))
-                self.hp_struct = _lib.ChainHp(_ptr(self.hp["lr"]), _ptr(self.hp["batch_size"]), _ptr(self.hp["q_hidden"]),
-                                              _ptr(self.hp["q_layers"]))
-                self.agent_init = torch.zeros((self.chains, self.p_agent), dtype=torch.float32, device=self.dev)
+                _alloc_chain_hp(self)
         else:
             self.ws_bytes = int(L.lenv_ddqn_se_workspace_bytes(C.byref(cfg), self.chains))
             qd = mlp_desc(S, cfg.q_hidden, cfg.q_layers, cfg.num_actions, cfg.q_act)
@@ -183,20 +202,7 @@ class InnerLoop(object):
     def set_hp(self, lr, batch_size, hidden_size, hidden_layer):
         """The chains' own hyper-parameters (host sequences of length `chains`; hidden_layer as the config writes it: the
         network has max(1, hidden_layer) hidden layers, models/model_utils.py:33-37)."""
-        if not self.vary:
-            raise ValueError("InnerLoop was built without vary=True")
-        n = self.chains
-        if not (len(lr) == len(batch_size) == len(hidden_size) == len(hidden_layer) == n):
-            raise ValueError("set_hp: need %d values per hyper-parameter" % n)
-        layers = [max(1, int(v)) for v in hidden_layer]
-        c = self.cfg
-        if max(batch_size) > c.batch_size or max(hidden_size) > c.q_hidden or max(layers) > c.q_layers or min(batch_size) < 1 \
-                or min(hidden_size) < 1:
-            raise ValueError("set_hp: a chain's hyper-parameters exceed the maxima the InnerLoop was sized for")
-        self.hp["lr"].copy_(torch.tensor([float(v) for v in lr], dtype=torch.float64))
-        self.hp["batch_size"].copy_(torch.tensor([int(v) for v in batch_size], dtype=torch.int32))
-        self.hp["q_hidden"].copy_(torch.tensor([int(v) for v in hidden_size], dtype=torch.int32))
-        self.hp["q_layers"].copy_(torch.tensor(layers, dtype=torch.int32))
+        _set_chain_hp(self, lr, batch_size, hidden_size, hidden_layer, self.cfg.batch_size, self.cfg.q_hidden, self.cfg.q_layers)
 
     def chain_num_params(self, hidden_size, hidden_layer):
         """Parameter count of one chain's agent at its own shapes (the used prefix of its agent_init / final_online row)."""
@@ -295,13 +301,19 @@ class QlInnerLoop(object):
 class Td3InnerLoop(object):
     """Owns the workspace/outputs of lenv_td3_rn_inner_loop for a fixed (cfg, chains)."""
 
-    def __init__(self, cfg, chains, want_episode_stats=True, want_final_params=False, trace_cap=0):
+    def __init__(self, cfg, chains, want_episode_stats=True, want_final_params=False, trace_cap=0, vary=False):
+        """vary=True: TD3_vary -- cfg carries the maximal batch_size / hidden / layers, every chain runs with its own
+        hyper-parameters (set_hp) through lenv_td3_rn_inner_loop_hp."""
         self.dev = require_device()
         self.cfg, self.chains = cfg, int(chains)
+        self.vary = bool(vary)
+        self.hp = self.hp_struct = self.agent_init = None
         L = _lib.lib()
         pa, pc = C.c_int64(), C.c_int64()
         self.p_agent = int(L.lenv_td3_num_params(C.byref(cfg), C.byref(pa), C.byref(pc)))
         _lib.check(min(self.p_agent, 0), "lenv_td3_num_params")
+        if self.vary:
+            _alloc_chain_hp(self)
         self.p_actor, self.p_critic = pa.value, pc.value
         self.p_theta = cfg.state_dim * cfg.rn_hidden + 2 * cfg.rn_hidden + 1
         self.ws_bytes = int(L.lenv_td3_rn_workspace_bytes(C.byref(cfg), self.chains))
@@ -329,7 +341,27 @@ class Td3InnerLoop(object):
                           _ptr(self.final_returns), _ptr(self.final_params), self.trace_cap, _ptr(tr.get("action")),
                           _ptr(tr.get("state")), _ptr(tr.get("next_state")), _ptr(tr.get("reward")))
 
+    def set_hp(self, lr, batch_size, hidden_size, hidden_layer):
+        _set_chain_hp(self, lr, batch_size, hidden_size, hidden_layer, self.cfg.batch_size, self.cfg.hidden, self.cfg.layers)
+
+    def chain_num_params(self, hidden_size, hidden_layer):
+        probe = _lib.Td3Cfg.from_buffer_copy(self.cfg)
+        probe.hidden, probe.layers = int(hidden_size), max(1, int(hidden_layer))
+        n = int(_lib.lib().lenv_td3_num_params(C.byref(probe), None, None))
+        _lib.check(min(n, 0), "lenv_td3_num_params")
+        return n
+
+    def draw_agent_init(self, rng_keys):
+        """Fresh actor | critic_1 | critic_2 at every chain's own shapes into self.agent_init."""
+        _chk(rng_keys, torch.int64, "rng_keys")
+        rc = _lib.lib().lenv_td3_agent_init_hp(C.byref(self.cfg), C.byref(self.hp_struct), _ptr(rng_keys), self.chains,
+                                               _ptr(self.agent_init), _stream())
+        _lib.check(rc, "lenv_td3_agent_init_hp")
+        return self.agent_init
+
     def run(self, theta, eps, worker, sign, agent_init, rng_keys=None, tapes=None):
+        if agent_init is None and self.vary:
+            agent_init = self.agent_init
         _chk(theta, torch.float32, "theta"); _chk(eps, torch.float32, "eps"); _chk(worker, torch.int32, "worker")
         _chk(sign, torch.float32, "sign"); _chk(agent_init, torch.float32, "agent_init")
         if agent_init.shape != (self.chains, self.p_agent):
@@ -342,9 +374,12 @@ class Td3InnerLoop(object):
                          _ptr(tapes["test_reset"]), tapes["test_reset"].shape[1])
         if rng_keys is not None:
             _chk(rng_keys, torch.int64, "rng_keys")
-        rc = _lib.lib().lenv_td3_rn_inner_loop(C.byref(self.cfg), _ptr(theta), _ptr(eps), _ptr(worker), _ptr(sign), _ptr(agent_init),
-                                               _ptr(rng_keys), C.byref(t) if t is not None else None, self.chains,
-                                               _ptr(self.workspace), self.ws_bytes, C.byref(self.out), _stream())
+        args = (_ptr(theta), _ptr(eps), _ptr(worker), _ptr(sign), _ptr(agent_init), _ptr(rng_keys),
+                C.byref(t) if t is not None else None, self.chains, _ptr(self.workspace), self.ws_bytes, C.byref(self.out), _stream())
+        if self.vary:
+            rc = _lib.lib().lenv_td3_rn_inner_loop_hp(C.byref(self.cfg), C.byref(self.hp_struct), *args)
+        else:
+            rc = _lib.lib().lenv_td3_rn_inner_loop(C.byref(self.cfg), *args)
         _lib.check(rc, "lenv_td3_rn_inner_loop")
         return self.score
 

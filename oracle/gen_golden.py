@@ -850,7 +850,7 @@ def gen_g4t():
     save("g4t_td3_learn", **out)
 
 
-def gen_g8t(name, seed, agent_over=None, env_over=None):
+def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None):
     import json
     import statistics
     import agents.GTN_worker as gw
@@ -859,6 +859,20 @@ def gen_g8t(name, seed, agent_over=None, env_over=None):
     import gym.spaces as gspaces
     cfg = _td3_cfg(agent_over or {"train_episodes": 4, "init_episodes": 2, "batch_size": 16, "hidden_size": 24, "test_episodes": 2},
                    env_over or {"max_steps": 7, "hidden_size": 20})
+    drawn = {}
+    if vary_seed is not None:
+        # TD3_vary (agents/TD3_vary.py:24-58): the draw of the ConfigSpace stand-in is recorded in the fixture
+        import ConfigSpace
+        ConfigSpace.RANDOM.seed(vary_seed)
+        cfg["agents"]["gtn"]["agent_name"] = "TD3_vary"
+        cfg["agents"]["td3_vary"] = {"vary_hp": True}
+        orig_sample = ConfigSpace.ConfigurationSpace.sample_configuration
+
+        def rec_sample(self):
+            d = orig_sample(self)
+            drawn.update(d)
+            return d
+        ConfigSpace.ConfigurationSpace.sample_configuration = rec_sample
     rec = dict(rand=[], act_noise=[], test_noise=[], policy_noise=[], replay=[], resets=[], steps=[], purpose=None, active=False)
     orig_randn, orig_randn_like, orig_randint = torch.randn, torch.randn_like, np.random.randint
     orig_box_sample, orig_reset = gspaces.Box.sample, genvs.CheetahStandinEnv.reset
@@ -946,8 +960,9 @@ def gen_g8t(name, seed, agent_over=None, env_over=None):
             torch.randn, torch.randn_like, np.random.randint = orig_randn, orig_randn_like, orig_randint
             gspaces.Box.sample, genvs.CheetahStandinEnv.reset = orig_box_sample, orig_reset
             gw.select_agent = orig_select_agent
-    B = cfg["agents"]["td3"]["batch_size"]
-    save(name, config_json=np.array(json.dumps(cfg)), theta=theta, agent_init=holder["init"],
+    if vary_seed is not None:
+        ConfigSpace.ConfigurationSpace.sample_configuration = orig_sample
+    save(name, config_json=np.array(json.dumps(cfg)), hp_json=np.array(json.dumps(drawn)), theta=theta, agent_init=holder["init"],
          tape_rand_action=np.stack(rec["rand"][1::2]).astype(np.float32),          # get_random_action samples twice, returns the 2nd
          tape_act_noise=np.stack(rec["act_noise"]).astype(np.float32), tape_test_noise=np.stack(rec["test_noise"]).astype(np.float32),
          tape_policy_noise=np.stack(rec["policy_noise"]).astype(np.float32).reshape(-1, 6),
@@ -981,6 +996,10 @@ def main():
         gen_g4t()
     if "g8t" in which:
         gen_g8t("g8t_calc_score_cheetah_td3", seed=830)
+    if "g8tv" in which:
+        gen_g8t("g8tv_calc_score_cheetah_td3_vary", seed=832, vary_seed=8,
+                agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 64, "hidden_size": 48, "hidden_layer": 2, "test_episodes": 1},
+                env_over={"max_steps": 10, "hidden_size": 24})          # draws batch 145, width 108, 3 hidden layers
     if "g8tf" in which:
         # BASELINE configs[4] at its REAL network shapes (actor 17-128-128-6, critics 23-128-128-1, B 192, RN 17-128-1)
         gen_g8t("g8tf_calc_score_cheetah_td3_fullshape", seed=831,

@@ -366,6 +366,41 @@ def test_gtn_master_td3_cheetah_generation(tmp_path, monkeypatch):
     assert len(mean_list) == 1 and np.isfinite(mean_score)
 
 
+def test_gtn_master_td3_vary_generation(tmp_path, monkeypatch):
+    """`agent_name: TD3_vary` through GTN_Master (agents/TD3_vary.py): per-chain draws, one launch, oracle-equal fitness."""
+    from learning_environments_amd import _lib
+    from learning_environments_amd.agents import tasks
+    from learning_environments_amd.config import td3_layer_dims
+    from learning_environments_amd.configs import fixed_work, halfcheetah_reward_env_td3, with_vary
+    from oracle import oracle as orc
+    cfg = fixed_work(halfcheetah_reward_env_td3(num_workers=2, max_iterations=1), 2)
+    cfg["envs"]["HalfCheetah-v3"]["max_steps"] = 5
+    cfg["agents"]["td3"].update(init_episodes=1, batch_size=32, hidden_size=40)
+    cfg = with_vary(cfg)
+    m = _master_pair(cfg, tmp_path, monkeypatch)
+    assert isinstance(m.task, tasks.Td3VaryTask) and m.inner.vary and m.cfg.batch_size == 96 and m.cfg.hidden == 120 and m.cfg.layers == 3
+    theta0 = m.theta.cpu().numpy().copy()
+    gathered = m.evaluate_population(0).cpu().numpy()
+    eps = m.eps.cpu().numpy()
+    hps = m.task.last_hp
+    for p in range(2):
+        sc = []
+        for kind, sg in enumerate((0.0, 1.0, -1.0)):
+            h = hps[3 * p + kind]
+            key = orc.chain_key(m.seed, 0, p, kind)
+            ocfg = orc.td3_cfg_from_config(cfg, lr=float(h["lr"]), batch_size=int(h["batch_size"]), hidden=int(h["hidden_size"]),
+                                           layers=max(1, int(h["hidden_layer"])))
+            pc = _lib.Td3Cfg()
+            for f, _ in _lib.Td3Cfg._fields_:
+                setattr(pc, f, getattr(ocfg, f))
+            init = orc.agent_init_from_key(key, td3_layer_dims(pc))
+            w = (np.float32(sg) * eps[p] + theta0).astype(np.float32)
+            sc.append(orc.td3_rn_chain(ocfg, w, init, rng_key=key)["score"])
+        assert gathered[p, 1] == sc[0] and gathered[p, 0] == max(sc[1], sc[2])
+    mean_score, mean_list, _ = m.run()
+    assert len(mean_list) == 1 and np.isfinite(mean_score)
+
+
 def test_reward_env_all_types_on_vector_state_env(golden):
     """EnvWrapper.step on the RewardEnv over the stand-in for all 11 reward types (reward_env.py:29-133), incl. the
     info-vector types: next states bit-equal to the reference run, shaped rewards within 5e-6, state-dict keys equal."""

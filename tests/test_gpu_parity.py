@@ -646,6 +646,79 @@ def test_td3_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
         assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4        # north_star bar (measured 2.4e-7)
 
 
+def test_td3_vary_tape_and_counter_mode_vs_oracle(eng, orc, golden):
+    """TD3_vary: (a) the reference run of fixture G8TV (batch 145, width 108, 3 hidden layers, its own lr) replayed in a launch
+    sized for the largest possible draw; (b) three chains with their own counter-RNG draws, each equal to the oracle chain
+    with that chain's hyper-parameters and fresh agent."""
+    from learning_environments_amd.agents import vary
+    from learning_environments_amd.config import td3_layer_dims
+    g = golden("g8tv_calc_score_cheetah_td3_vary")
+    cfgd, hp = json.loads(str(g["config_json"])), json.loads(str(g["hp_json"]))
+    base = cfgd["agents"]["td3"]
+    bd = vary.hp_bounds(base)
+    mx = dict(batch_size=bd["batch_size"][1], hidden=bd["hidden_size"][1], layers=bd["hidden_layer"][1])
+    ocfg, _ = _td3_cfgs(orc, cfgd, 1, lr=float(hp["lr"]), batch_size=int(hp["batch_size"]), hidden=int(hp["hidden_size"]),
+                        layers=max(1, int(hp["hidden_layer"])))
+    _, cfg = _td3_cfgs(orc, cfgd, 1, **mx)
+    n = g["tr_reward"].size
+    otapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
+                                g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    o = orc.td3_rn_chain(ocfg, g["theta"], g["agent_init"], tapes=otapes, trace_cap=n + 4)
+    chains = 2
+    rep = lambda a: dev(np.tile(np.ascontiguousarray(a)[None], (chains,) + (1,) * np.ndim(a)))
+    tapes = dict(rand_action=rep(g["tape_rand_action"]), act_noise=rep(g["tape_act_noise"]), test_noise=rep(g["tape_test_noise"]),
+                 policy_noise=rep(g["tape_policy_noise"]), replay_idx=rep(g["tape_replay_idx"].reshape(-1)),
+                 train_reset=rep(g["tape_train_reset"]), test_reset=rep(g["tape_test_reset"]))
+    il = eng.Td3InnerLoop(cfg, chains, trace_cap=n + 4, vary=True)
+    il.set_hp([hp["lr"]] * 2, [hp["batch_size"]] * 2, [hp["hidden_size"]] * 2, [hp["hidden_layer"]] * 2)
+    p_c = il.chain_num_params(hp["hidden_size"], hp["hidden_layer"])
+    assert p_c == g["agent_init"].size and p_c < il.p_agent
+    init = np.full((chains, il.p_agent), np.nan, np.float32)
+    init[:, :p_c] = g["agent_init"]
+    il.run(dev(g["theta"]), None, None, None, dev(init), tapes=tapes)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        assert np.array_equal(il.trace["action"][c, :n].cpu().numpy(), o["trace"]["action"])
+        assert np.array_equal(il.trace["reward"][c, :n].cpu().numpy(), o["trace"]["reward"])
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        np.testing.assert_allclose(il.trace["action"][c, :n].cpu().numpy(), g["tr_action"], rtol=0, atol=2e-5)
+        assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4
+    # (b) counter mode, heterogeneous chains
+    chains = 3
+    _, cfg = _td3_cfgs(orc, cfgd, 0, **mx)
+    keys = np.array([orc.chain_key(23, 1, 0, c) for c in range(chains)], np.uint64)
+    hps = [vary.vary_hyperparameters(base, vary.chain_units(int(k))) for k in keys]
+    assert len({h["batch_size"] for h in hps}) == chains
+    rng = np.random.RandomState(41)
+    theta = (rng.randn(g["theta"].size) * 0.2).astype(np.float32)
+    eps = (rng.randn(1, theta.size) * 0.05).astype(np.float32)
+    worker, sign = np.zeros(chains, np.int32), np.array([0.0, 1.0, -1.0], np.float32)
+    il = eng.Td3InnerLoop(cfg, chains, trace_cap=40, vary=True, want_episode_stats=True)
+    il.set_hp([h["lr"] for h in hps], [h["batch_size"] for h in hps], [h["hidden_size"] for h in hps], [h["hidden_layer"] for h in hps])
+    keys_t = dev(keys.view(np.int64))
+    init = il.draw_agent_init(keys_t).cpu().numpy()
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), None, rng_keys=keys_t)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        h = hps[c]
+        oc, pc = _td3_cfgs(orc, cfgd, 0, lr=float(h["lr"]), batch_size=int(h["batch_size"]), hidden=int(h["hidden_size"]),
+                           layers=max(1, int(h["hidden_layer"])))
+        oinit = orc.agent_init_from_key(int(keys[c]), td3_layer_dims(pc))
+        assert np.array_equal(init[c, :oinit.size], oinit), c
+        w = (np.float32(sign[c]) * eps[0] + theta).astype(np.float32)
+        oo = orc.td3_rn_chain(oc, w, oinit, rng_key=int(keys[c]), trace_cap=40)
+        m = oo["trace"]["reward"].size
+        assert oo["learn_steps"] > 0
+        assert np.array_equal(il.trace["action"][c, :m].cpu().numpy(), oo["trace"]["action"]), (c, h)
+        assert np.array_equal(il.trace["reward"][c, :m].cpu().numpy(), oo["trace"]["reward"]), (c, h)
+        assert float(il.score[c]) == oo["score"], (c, h)
+        assert il.stats[c].cpu().tolist() == [oo["episodes_run"], oo["train_steps"], oo["learn_steps"], oo["test_steps"]]
+
+
 @pytest.mark.parametrize("hidden,layers,batch,act,delay,rtype", [(128, 2, 192, "relu", 1, 2), (40, 1, 50, "tanh", 2, 1), (33, 2, 130, "leakyrelu", 3, 6),
                                                                  (24, 1, 32, "relu", 1, 3), (24, 1, 32, "relu", 1, 4), (24, 1, 32, "relu", 2, 7),
                                                                  (24, 1, 32, "tanh", 1, 8), (24, 1, 32, "relu", 1, 101), (24, 1, 32, "relu", 1, 102),

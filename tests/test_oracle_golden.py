@@ -415,6 +415,25 @@ def test_g8t_calc_score_cheetah_td3(golden, name):
     assert abs(out["score"] - float(g["score"])) <= 1e-4
 
 
+def test_g8tv_td3_vary_replay_of_the_recorded_draw(golden):
+    """TD3_vary (agents/TD3_vary.py:24-58): the reference run drew batch 145 / width 108 / 3 hidden layers / its own lr
+    through the ConfigSpace stand-in; the oracle replays it with the recorded draw."""
+    import json
+    g = golden("g8tv_calc_score_cheetah_td3_vary")
+    hp = json.loads(str(g["hp_json"]))
+    cfg = orc.td3_cfg_from_config(json.loads(str(g["config_json"])), rng_mode=1, lr=float(hp["lr"]), batch_size=int(hp["batch_size"]),
+                                  hidden=int(hp["hidden_size"]), layers=max(1, int(hp["hidden_layer"])))
+    tapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
+                               g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    n = g["tr_reward"].size
+    out = orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 4)
+    assert out["rc"] == 0 and out["trace"]["reward"].size == n
+    np.testing.assert_allclose(out["trace"]["action"], g["tr_action"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["trace"]["reward"], g["tr_reward"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=1e-4)
+    assert abs(out["score"] - float(g["score"])) <= 1e-4
+
+
 def _standin_rollout(g, t):
     """Replay the fixture's episode on the oracle's stand-in env: fp32 states, info vectors and raw fp32 rewards."""
     import ctypes as C
