@@ -486,46 +486,93 @@ __device__ __forceinline__ GemmEpi epi_bias_tanh(float *out, int ldo, int ocol, 
 
 struct AdamConsts { float neg_step, bc2_sqrt, w1, w2, beta2, eps; };
 
-// torch.optim.Adam single-tensor step on [p0, p0+n) (+ optional Polyak update of `target` with the new parameter)
+// one element of torch.optim.Adam's single-tensor step (+ Polyak update of the target value t with the new parameter)
+__device__ __forceinline__ void adam_elem(float g, float &m, float &v, float &w, float &t, const AdamConsts c, float tau, float omt)
+{
+    m = fma32(c.w1, g - m, m);
+    v = fma32(c.w2 * g, g, v * c.beta2);
+    const float denom = __builtin_sqrtf(v) / c.bc2_sqrt + c.eps;
+    w = w + (c.neg_step * m) / denom;
+    t = tau * w + omt * t;
+}
+
+// torch.optim.Adam single-tensor step on [p0, p0+n) (+ optional Polyak update of `target` with the new parameter).
+// The body moves float4 pieces (the arena arrays are 16-byte aligned; 2 pieces x 5 arrays in flight per thread: the pass
+// is bound by the latency of one workgroup's loads, not by arithmetic); a misaligned head and the tail go element-wise.
 __device__ __forceinline__ void wg_adam(float *params, float *adam_m, float *adam_v, const float *grad, int p0, int n, const AdamConsts c,
                                         float *target, float tau, float omt)
 {
+    typedef __attribute__((address_space(1))) f32x4 gf4;
     const int end = p0 + n;
-    for (int q = p0 + (int)threadIdx.x; q < end; q += 4 * DNT) {
-        float g[4], m[4], v[4], w[4], t[4];
+    const int b0 = (p0 + 3) & ~3, b1 = end & ~3;           // float4 body [b0, b1)
+    const int tid = (int)threadIdx.x;
+    if (b1 > b0) {
+        const int npieces = (b1 - b0) >> 2;
+        for (int q0 = tid; q0 < npieces; q0 += 2 * DNT) {
+            f32x4 g[2], m[2], v[2], w[2], t[2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int p = q + u * DNT;
-            const bool ok = p < end;
-            g[u] = ok ? grad[p] : 0.0f; m[u] = ok ? adam_m[p] : 0.0f; v[u] = ok ? adam_v[p] : 0.0f; w[u] = ok ? params[p] : 0.0f;
-            t[u] = (ok && target) ? target[p] : 0.0f;
-        }
+            for (int u = 0; u < 2; ++u) {
+                const int q = q0 + u * DNT;
+                const bool ok = q < npieces;
+                const int p = b0 + 4 * (ok ? q : q0);
+                g[u] = *((const gf4 *)(grad + p)); m[u] = *((const gf4 *)(adam_m + p));
+                v[u] = *((const gf4 *)(adam_v + p)); w[u] = *((const gf4 *)(params + p));
+                t[u] = target ? *((const gf4 *)(target + p)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            m[u] = fma32(c.w1, g[u] - m[u], m[u]);
-            v[u] = fma32(c.w2 * g[u], g[u], v[u] * c.beta2);
-            const float denom = __builtin_sqrtf(v[u]) / c.bc2_sqrt + c.eps;
-            w[u] = w[u] + (c.neg_step * m[u]) / denom;
-            t[u] = tau * w[u] + omt * t[u];
-        }
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int p = q + u * DNT;
-            if (p < end) { adam_m[p] = m[u]; adam_v[p] = v[u]; params[p] = w[u]; if (target) target[p] = t[u]; }
+                for (int k = 0; k < 4; ++k) {
+                    float mm = m[u][k], vv = v[u][k], ww = w[u][k], tt = t[u][k];
+                    adam_elem(g[u][k], mm, vv, ww, tt, c, tau, omt);
+                    m[u][k] = mm; v[u][k] = vv; w[u][k] = ww; t[u][k] = tt;
+                }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = q0 + u * DNT;
+                if (q < npieces) {
+                    const int p = b0 + 4 * q;
+                    *((gf4 *)(adam_m + p)) = m[u]; *((gf4 *)(adam_v + p)) = v[u];
+                    *((gf4 *)(params + p)) = w[u];
+                    if (target) *((gf4 *)(target + p)) = t[u];
+                }
+            }
         }
+    }
+    // element-wise: [p0, min(b0, end)) and [max(b1, b0), end)  (at most 3 + 3 elements, or everything when n < 4)
+    const int head_end = b0 < end ? b0 : end, tail_start = b1 > b0 ? b1 : head_end;
+    const int nhead = head_end - p0, nrest = nhead + (end - tail_start);
+    if (tid < nrest) {
+        const int p = tid < nhead ? p0 + tid : tail_start + (tid - nhead);
+        float m = adam_m[p], v = adam_v[p], w = params[p], t = target ? target[p] : 0.0f;
+        adam_elem(grad[p], m, v, w, t, c, tau, omt);
+        adam_m[p] = m; adam_v[p] = v; params[p] = w;
+        if (target) target[p] = t;
     }
 }
 
 // target = tau * params + (1 - tau) * target on [0, n)
 __device__ __forceinline__ void wg_polyak(const float *params, float *target, int n, float tau, float omt)
 {
-    for (int q = (int)threadIdx.x; q < n; q += 8 * DNT) {
-        float w[8], t[8];
+    typedef __attribute__((address_space(1))) f32x4 gf4;
+    const int n4 = n >> 2, tid = (int)threadIdx.x;
+    for (int q0 = tid; q0 < n4; q0 += 4 * DNT) {
+        f32x4 w[4], t[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int p = q + u * DNT; const bool ok = p < n; w[u] = ok ? params[p] : 0.0f; t[u] = ok ? target[p] : 0.0f; }
+        for (int u = 0; u < 4; ++u) { const int q = q0 + u * DNT; const int p = 4 * (q < n4 ? q : q0); w[u] = *((const gf4 *)(params + p)); t[u] = *((const gf4 *)(target + p)); }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int p = q + u * DNT; if (p < n) target[p] = tau * w[u] + omt * t[u]; }
+        for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u * DNT;
+            if (q < n4) {
+                f32x4 r;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r[k] = tau * w[u][k] + omt * t[u][k];
+                *((gf4 *)(target + 4 * q)) = r;
+            }
+        }
     }
+    const int p = 4 * n4 + tid;
+    if (p < n) target[p] = tau * params[p] + omt * target[p];
 }
 
 }  // namespace lenv
