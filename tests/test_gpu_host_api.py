@@ -366,6 +366,28 @@ def test_gtn_master_td3_cheetah_generation(tmp_path, monkeypatch):
     assert len(mean_list) == 1 and np.isfinite(mean_score)
 
 
+def test_gtn_master_acrobot_ddqn_vary_as_shipped(tmp_path, monkeypatch):
+    """default_config_acrobot.yaml as the reference ships it (`agent_name: DDQN_vary`, ddqn 128 / 2 layers / batch 128): the
+    launch is sized for batch 384, width 384, 3 hidden layers; one short generation runs and every chain's draw is inside
+    the reference's ranges."""
+    from learning_environments_amd.agents import tasks
+    from learning_environments_amd.configs import acrobot_syn_env_ddqn, fixed_work, with_vary
+    cfg = with_vary(fixed_work(acrobot_syn_env_ddqn(num_workers=3, max_iterations=1), 2))
+    cfg["envs"]["Acrobot-v1"]["max_steps"] = 8
+    cfg["agents"]["ddqn"].update(test_episodes=2)
+    m = _master_pair(cfg, tmp_path, monkeypatch)
+    assert isinstance(m.task, tasks.DdqnVaryTask)
+    assert (m.cfg.batch_size, m.cfg.q_hidden, m.cfg.q_layers, m.cfg.agent_kind) == (384, 384, 3, 0) and m.inner.p_agent == 299523
+    mean_score, mean_list, _ = m.run()
+    assert len(mean_list) == 1 and -8.0 <= mean_score <= 0.0
+    assert m.inner.status.cpu().tolist() == [0] * 9
+    for h in m.task.last_hp:
+        assert 42 <= h["batch_size"] <= 384 and 42 <= h["hidden_size"] <= 384 and 1 <= h["hidden_layer"] <= 3
+        assert 1e-3 / 3 <= h["lr"] <= 3e-3
+    st = m.inner.stats.cpu().numpy()
+    assert (st[:, 2] > 0).all()                              # every chain learned
+
+
 def test_gtn_master_td3_vary_generation(tmp_path, monkeypatch):
     """`agent_name: TD3_vary` through GTN_Master (agents/TD3_vary.py): per-chain draws, one launch, oracle-equal fitness."""
     from learning_environments_amd import _lib
