@@ -298,6 +298,7 @@ template <int MAXI>
 __device__ __forceinline__ void gemm_body(const GemmOp &op, const GemmEpi &ep, lfloat *Ps, lfloat *Qs, int tid, int lane, int wave)
 {
     constexpr int LDP = GemmShape<MAXI>::LDP, NTW = GemmShape<MAXI>::NTW;
+    constexpr int UNROLL_R = NTW >= 4 ? 1 : 8 / NTW;         // k-steps unrolled in the full-stage MFMA loop
     const int I = op.I, J = op.J, R = op.R;
     const int nbi = (I + 31) >> 5, nbj = (J + 31) >> 5, ntile = nbi * nbj;      // <= 8*NTW tiles of 32x32
     // t / nbi == (t * inv) >> 10 for t < 32, nbi <= 8
@@ -330,7 +331,7 @@ __device__ __forceinline__ void gemm_body(const GemmOp &op, const GemmEpi &ep, l
         const int rb2 = rb & ~1;
         if (has[NTW - 1]) {                                // every tile slot of this wave is live: the common full-size case
             if (rb == GT_RB) {
-#pragma unroll (NTW >= 4 ? 1 : 8 / NTW)
+#pragma unroll UNROLL_R
                 for (int r = 0; r < GT_RB; r += 2)
 #pragma unroll
                     for (int m = 0; m < NTW; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[m][r * LDP], pb[m][r * GT_LD], acc[m], 0, 0, 0);

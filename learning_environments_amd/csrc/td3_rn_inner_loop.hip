@@ -106,7 +106,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     float *params = arena + a.a_params, *targets = arena + a.a_targets, *adam_m = arena + a.a_m, *adam_v = arena + a.a_v;
     float *grad = arena + a.a_grad, *rb = arena + a.a_replay;
     float *xc = arena + a.a_xc, *xn = arena + a.a_xn, *xa = arena + a.a_xa;      // [B][SA] critic inputs
-    float *dxb = arena + a.a_dx, *actb = arena + a.a_act, *thb = arena + a.a_th, *dzb = arena + a.a_dz;
+    float *dxb = arena + a.a_dx, *thb = arena + a.a_th, *dzb = arena + a.a_dz;
     float *hc1[T3_MAXL], *hc2[T3_MAXL], *ha[T3_MAXL], *ht[T3_MAXL], *dbuf[2] = { arena + a.a_d[0], arena + a.a_d[1] };
     for (int l = 0; l < T3_MAXL; ++l) { hc1[l] = arena + a.a_hc1[l]; hc2[l] = arena + a.a_hc2[l]; ha[l] = arena + a.a_ha[l]; ht[l] = arena + a.a_ht[l]; }
     double *meter = reinterpret_cast<double *>(arena + a.a_meter);

@@ -17,6 +17,31 @@ class _Inner(object):
         self.status = torch.zeros(chains, dtype=torch.int32)
 
 
+class _VaryInner(_Inner):
+    """Stand-in of engine.InnerLoop(vary=True): per-chain hyper-parameters, fresh agents drawn per chain shape."""
+    vary = True
+
+    def __init__(self, cfg, chains):
+        super().__init__(cfg, chains)
+        self.hp = None
+        self.keys = None
+
+    def set_hp(self, lr, batch_size, hidden_size, hidden_layer):
+        self.hp = [dict(lr=float(a), batch_size=int(b), hidden_size=int(c), hidden_layer=int(d))
+                   for a, b, c, d in zip(lr, batch_size, hidden_size, hidden_layer)]
+
+    def draw_agent_init(self, rng_keys):
+        self.keys = rng_keys.numpy().view(np.uint64).copy()
+
+
+def _oracle_cfg(cfg):
+    """the package's DdqnCfg (ctypes) -> the oracle's (same field names)"""
+    o = orc.DdqnCfg()
+    for f, _ in orc.DdqnCfg._fields_:
+        setattr(o, f, getattr(cfg, f))
+    return o
+
+
 class OracleNesEngine(object):
     name = "oracle"
 
@@ -26,8 +51,8 @@ class OracleNesEngine(object):
     def cfg_from_config(self, config):
         return orc.ddqn_cfg_from_config(config, grad_chunk=17)
 
-    def make_inner(self, cfg, chains, **kw):
-        return _Inner(cfg, chains)
+    def make_inner(self, cfg, chains, vary=False, **kw):
+        return _VaryInner(cfg, chains) if vary else _Inner(cfg, chains)
 
     def inner_scores(self, inner, theta, eps, worker, sign, agent_init, rng_keys):
         th, ep = theta.numpy(), eps.numpy()
@@ -35,6 +60,20 @@ class OracleNesEngine(object):
         out = np.zeros(inner.chains)
         for c in range(inner.chains):
             w = (np.float32(sign[c].item()) * ep[int(worker[c])] + th).astype(np.float32)
+            if getattr(inner, "vary", False):
+                # the chain's own shapes: cfg carries the maxima, the draw replaces them (agents/vary.py)
+                h = inner.hp[c]
+                ocfg = _oracle_cfg(inner.cfg)
+                for k, v in orc.hp_overrides(h).items():
+                    setattr(ocfg, k, v)
+                S, A, H, L, F = ocfg.state_dim, ocfg.num_actions, ocfg.q_hidden, ocfg.q_layers, ocfg.feature_dim
+                dims = [(S, H)] + [(H, H)] * (L - 1)
+                dims += [(H, F), (F, F), (F, 1), (F, F), (F, A)] if ocfg.agent_kind == 1 else [(H, A)]
+                init = orc.agent_init_from_key(int(inner.keys[c]), dims)
+                r = orc.ddqn_se_chain(ocfg, w, init, rng_key=int(keys[c]))
+                out[c] = r["score"]
+                inner.stats[c] = torch.tensor([r["episodes_run"], r["train_steps"], r["learn_steps"], r["test_steps"]])
+                continue
             r = orc.ddqn_se_chain(inner.cfg, w, agent_init[c].numpy(), rng_key=int(keys[c]))
             out[c] = r["score"]
             inner.stats[c] = torch.tensor([r["episodes_run"], r["train_steps"], r["learn_steps"], r["test_steps"]])

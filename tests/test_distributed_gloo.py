@@ -22,7 +22,15 @@ def _small_config(num_workers):
     return cfg
 
 
-def _run(rank, world, port, tmp, q, seed_per_rank=False):
+def _vary_config(num_workers):
+    from learning_environments_amd.configs import with_vary
+    cfg = with_vary(_small_config(num_workers))
+    cfg["agents"]["ddqn"].update(batch_size=24, hidden_size=16, init_episodes=1)
+    cfg["agents"]["gtn"]["max_iterations"] = 1
+    return cfg
+
+
+def _run(rank, world, port, tmp, q, seed_per_rank=False, vary=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.chdir(tmp)
@@ -35,7 +43,7 @@ def _run(rank, world, port, tmp, q, seed_per_rank=False):
     torch.manual_seed(1000 * rank if seed_per_rank else 0)
     import random
     random.seed(rank if seed_per_rank else 0)
-    m = GTN_Master(_small_config(5), bohb_id=0, engine=OracleNesEngine(), seed=11)
+    m = GTN_Master(_vary_config(4) if vary else _small_config(5), bohb_id=0, engine=OracleNesEngine(), seed=11)
     with torch.no_grad():
         m.synthetic_env_orig.env.done_net[-1].bias.fill_(-10.0)
     mean_score, mean_list, _ = m.run()
@@ -46,10 +54,10 @@ def _run(rank, world, port, tmp, q, seed_per_rank=False):
         dist.destroy_process_group()
 
 
-def _launch(world, tmp_path, port, seed_per_rank=False):
+def _launch(world, tmp_path, port, seed_per_rank=False, vary=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_run, args=(r, world, port, str(tmp_path), q, seed_per_rank)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, str(tmp_path), q, seed_per_rank, vary)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get(timeout=120) for _ in range(world)]
@@ -75,6 +83,25 @@ def test_two_rank_run_matches_single_rank(tmp_path):
 
 
 @pytest.mark.timeout(400)
+def test_vary_agents_two_ranks_match_single_rank(tmp_path):
+    """DDQN_vary through GTN_Master on CPU tensors (oracle-backed engine): every chain's hyper-parameter draw and fresh agent
+    are functions of its (seed, generation, worker, kind) key, so the sharded run equals the single-rank run bit for bit."""
+    (tmp_path / "v1").mkdir(); (tmp_path / "v2").mkdir()
+    one = _launch(1, tmp_path / "v1", 29671, vary=True)[0]
+    two = _launch(2, tmp_path / "v2", 29672, vary=True)
+    for r in two:
+        assert np.array_equal(r[1], one[1])                    # theta after the generation
+        assert r[2] == one[2] and r[3] == one[3]               # score lists
+    assert two[0][5] != two[1][5]                              # different shards
+    # the draws really differ between chains (otherwise this would be the plain-agent test again)
+    sys.path.insert(0, ROOT)
+    from learning_environments_amd.agents import vary
+    from oracle import oracle as orc
+    hps = {tuple(sorted(vary.vary_hyperparameters(_vary_config(4)["agents"]["ddqn"], vary.chain_units(orc.chain_key(11, 0, w, k))).items()))
+           for w in range(4) for k in range(3)}
+    assert len(hps) == 12
+
+
 def test_ranks_seeded_differently_still_agree(tmp_path):
     """theta is replicated and never exchanged per generation, so it must start identical.  Ranks that build
     their initial theta under different torch / random seeds end with bit-identical theta, fitness lists and model name."""
