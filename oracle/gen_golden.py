@@ -346,7 +346,8 @@ class Recorder(object):
 
 
 def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml="default_config_cartpole_syn_env.yaml",
-           env_name="CartPole-v0", env_cls="CartPoleEnv", agent_key="ddqn", agent_over=None, env_over=None, vary_seed=None):
+           env_name="CartPole-v0", env_cls="CartPoleEnv", agent_key="ddqn", agent_over=None, env_over=None, vary_seed=None,
+           icm_over=None):
     import agents.GTN_worker as gw
     from agents.GTN import GTN_Worker
     import gym.envs as genvs
@@ -357,6 +358,10 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
     cfg["agents"][agent_key].update(agent_over or {})
     cfg["envs"][env_name].update(env_over or {})
     cfg["agents"]["gtn"]["agent_name"] = {"ddqn": "DDQN", "duelingddqn": "DuelingDDQN"}[agent_key]
+    if icm_over is not None:
+        # the agent with its Intrinsic Curiosity Module (select_agent: "ddqn_icm" -> DDQN(icm=True), agents/DDQN.py:40-58,74-76)
+        cfg["agents"]["gtn"]["agent_name"] += "_icm"
+        cfg["agents"]["icm"].update(icm_over)
     if vary_seed is not None:
         # the *_vary agent of the same family (agents/DDQN_vary.py, DuelingDDQN_vary.py): its ConfigSpace draw comes from
         # the stand-in under oracle/shims (seeded here); the sampled values are recorded in the fixture
@@ -407,6 +412,10 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
             if hasattr(agent, "full_config") else {}
         holder["init"] = pack_linear_params(agent.model.state_dict(), "net.") if hasattr(agent.model, "net") \
             else _pack_dueling(agent.model.state_dict())
+        if getattr(agent, "icm", None):
+            # ICMModel parameters in state-dict order (features, inverse, forward_pre, residual blocks 1-4, forward_post)
+            holder["icm_init"] = np.concatenate([v.detach().cpu().numpy().astype(np.float32).reshape(-1)
+                                                 for v in agent.icm.model.state_dict().values()])
         orig_learn = agent.learn
 
         def learn(replay_buffer, env, episode):
@@ -467,7 +476,12 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
         explored[k] = 1 if st["n_rand"] > prev else 0
         prev = st["n_rand"]
     import json
-    save(name, config_json=np.array(json.dumps(cfg)), hp_json=np.array(json.dumps(holder["hp"])),
+    extra = {}
+    if "icm_init" in holder:
+        extra["icm_init"] = holder["icm_init"]
+        extra["icm_final"] = np.concatenate([v.detach().cpu().numpy().astype(np.float32).reshape(-1)
+                                             for v in holder["agent"].icm.model.state_dict().values()])
+    save(name, config_json=np.array(json.dumps(cfg)), hp_json=np.array(json.dumps(holder["hp"])), **extra,
          theta=theta, agent_init=holder["init"],
          train_episodes=np.array(train_episodes), max_steps=np.array(cfg["envs"][env_name]["max_steps"]),
          tape_eps_uniform=np.array(rec.eps_uniform, np.float64), tape_rand_action=np.array(rec.rand_action, np.int32),
@@ -1019,6 +1033,16 @@ def main():
         gen_g8("g8l2_calc_score_acrobot_ddqn_2layer", train_episodes=3, done_bias_shift=0.0, seed=812, max_steps=20,
                env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="ddqn",
                agent_over={"init_episodes": 1, "test_episodes": 2}, env_over={"hidden_size": 128, "solved_reward": 0.5})
+    if "g8i" in which:
+        # DDQN / DuelingDDQN with the ICM baseline inside learn() (models/icm_baseline.py): CartPole = BCE inverse loss on one
+        # action logit, Acrobot = cross-entropy over three
+        gen_g8("g8i_calc_score_cartpole_ddqn_icm", train_episodes=3, done_bias_shift=0.0, seed=840, max_steps=12,
+               agent_over={"init_episodes": 1, "test_episodes": 2, "batch_size": 24, "hidden_size": 32},
+               icm_over={"feature_dim": 16, "hidden_size": 24})
+        gen_g8("g8ia_calc_score_acrobot_dueling_icm", train_episodes=3, done_bias_shift=0.0, seed=841, max_steps=10,
+               env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="duelingddqn",
+               agent_over={"hidden_size": 24, "feature_dim": 16, "batch_size": 20, "init_episodes": 1, "test_episodes": 2},
+               env_over={"hidden_size": 32, "solved_reward": 0.5}, icm_over={"feature_dim": 12, "hidden_size": 20})
     if "g8v" in which:
         # DDQN_vary / DuelingDDQN_vary (agents/DDQN_vary.py:26-59): the agent draws lr / batch_size / hidden_size / hidden_layer
         # and trains with them; the fixture records the draw and the run

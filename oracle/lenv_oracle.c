@@ -884,11 +884,39 @@ static double mean_seq(const double *v, int n)
     return s / (double)n;
 }
 
+#include "lenv_oracle_icm.inc"
+
+int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const float *agent_init, const float *icm_init, uint64_t rng_key,
+                          const orc_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
+                          double *final_test_returns, orc_trace *trace, orc_chain_result *res, float *icm_final);
+
 int orc_ddqn_se_chain(const orc_ddqn_cfg *cfg, const float *se_params, const float *agent_init, uint64_t rng_key,
                       const orc_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
                       double *final_test_returns, orc_trace *trace, orc_chain_result *res)
 {
+    if (cfg->icm_enabled) return -1;               /* an ICM agent needs its own fresh ICM parameters: orc_ddqn_se_chain_icm */
+    return orc_ddqn_se_chain_icm(cfg, se_params, agent_init, NULL, rng_key, tapes, episode_test_mean, episode_len, final_test_returns,
+                                 trace, res, NULL);
+}
+
+/* icm_init: [orc_icm_num_params] fresh ICMModel parameters in state-dict order when cfg->icm_enabled, else NULL;
+ * icm_final (may be NULL): the ICM parameters after the last learn step */
+int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const float *agent_init, const float *icm_init, uint64_t rng_key,
+                          const orc_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
+                          double *final_test_returns, orc_trace *trace, orc_chain_result *res, float *icm_final)
+{
     const int S = cfg->state_dim, A = cfg->num_actions, B = cfg->batch_size;
+    if (cfg->icm_enabled && !icm_init) return -1;
+    icm_net icm;
+    icm_hp ihp = { cfg->icm_lr, cfg->icm_beta, cfg->icm_eta, cfg->adam_beta1, cfg->adam_beta2, cfg->adam_eps };
+    float *icm_p = NULL, *icm_m = NULL, *icm_v = NULL, *r_intr = NULL;
+    double icm_pows[2] = { 1.0, 1.0 };
+    if (cfg->icm_enabled) {
+        icm_build(&icm, S, A, cfg->icm_feature_dim, cfg->icm_hidden);
+        icm_p = malloc(sizeof(float) * icm.P); icm_m = calloc(icm.P, sizeof(float)); icm_v = calloc(icm.P, sizeof(float));
+        r_intr = malloc(sizeof(float) * B);
+        memcpy(icm_p, icm_init, sizeof(float) * icm.P);
+    }
     orc_mlp_desc qd = { S, cfg->q_hidden, cfg->q_layers, A, cfg->q_act, cfg->q_prelu };
     orc_mlp_desc sn = { S + A, cfg->se_hidden, cfg->se_layers, S, cfg->se_act, cfg->se_prelu };
     orc_mlp_desc rn = sn, dn = sn;
@@ -965,6 +993,10 @@ int orc_ddqn_se_chain(const orc_ddqn_cfg *cfg, const float *se_params, const flo
                     memcpy(batch + (int64_t)b * row_stride, rb + (int64_t)idx * row_stride, sizeof(float) * row_stride);
                 }
                 ++learn_it;
+                if (cfg->icm_enabled) {          /* DDQN.py:74-76 / DuelingDDQN.py: icm.train, then rewards += intrinsic rewards */
+                    icm_train_and_reward(&icm, &ihp, icm_p, icm_m, icm_v, icm_pows, batch, row_stride, B, r_intr);
+                    for (int b = 0; b < B; ++b) batch[(int64_t)b * row_stride + 2 * S + 1] = batch[(int64_t)b * row_stride + 2 * S + 1] + r_intr[b];
+                }
                 loss = cfg->agent_kind == 1 ? orc_dueling_learn(cfg, online, target, am, av, &b1pow, &b2pow, batch, row_stride)
                                             : orc_ddqn_learn(cfg, online, target, am, av, learn_it, &b1pow, &b2pow, batch, row_stride);
             }
@@ -1009,6 +1041,8 @@ int orc_ddqn_se_chain(const orc_ddqn_cfg *cfg, const float *se_params, const flo
         res->episodes_run = episodes_run; res->train_steps = train_steps;
         res->learn_steps = learn_it; res->test_steps = test_steps;
     }
+    if (cfg->icm_enabled && icm_final) memcpy(icm_final, icm_p, sizeof(float) * icm.P);
+    free(icm_p); free(icm_m); free(icm_v); free(r_intr);
     free(online); free(target); free(am); free(av); free(rb); free(batch); free(z); free(a); free(test_returns); free(meter);
     return rng.err;
 }

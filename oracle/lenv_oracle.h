@@ -69,6 +69,9 @@ typedef struct {
     double eps_init, eps_min, eps_decay;
     double adam_beta1, adam_beta2, adam_eps;
     int64_t step_budget;   /* see include/lenv_hip.h: env-step budget standing in for time_remaining (base_agent.py:30-47) */
+    /* Intrinsic Curiosity Module inside learn() (agents/DDQN.py:40-58,74-76; models/icm_baseline.py): config section `icm` */
+    int32_t icm_enabled, icm_feature_dim, icm_hidden, icm_pad_;
+    double icm_lr, icm_beta, icm_eta;
 } orc_ddqn_cfg;
 
 /* RNG tapes (parity mode): values the reference drew, in per-stream order. */

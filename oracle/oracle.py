@@ -32,7 +32,9 @@ class DdqnCfg(C.Structure):
                 ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
                 ("eps_init", C.c_double), ("eps_min", C.c_double), ("eps_decay", C.c_double),
                 ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
-                ("step_budget", C.c_int64)]
+                ("step_budget", C.c_int64),
+                ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("icm_pad_", C.c_int32),
+                ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double)]
 
 
 class Tapes(C.Structure):
@@ -244,7 +246,15 @@ def make_tapes(eps_uniform, rand_action, replay_idx, train_reset, test_reset):
     return t
 
 
-def ddqn_se_chain(cfg, se_params, agent_init, rng_key=0, tapes=None, trace_cap=0):
+def icm_num_params(cfg):
+    L = lib()
+    L.orc_icm_num_params.restype = C.c_int64
+    return int(L.orc_icm_num_params(cfg.state_dim, cfg.num_actions, cfg.icm_feature_dim, cfg.icm_hidden))
+
+
+def ddqn_se_chain(cfg, se_params, agent_init, rng_key=0, tapes=None, trace_cap=0, icm_init=None):
+    """icm_init: fresh ICMModel parameters (state-dict order) for an agent with cfg.icm_enabled; the result then carries
+    "icm_final" (the ICM parameters after the last learn step)."""
     se_params, agent_init = _f32(se_params), _f32(agent_init)
     E, T, S = cfg.train_episodes, cfg.test_episodes, cfg.state_dim
     ep_mean = np.full(max(E, 1), np.nan)
@@ -261,16 +271,28 @@ def ddqn_se_chain(cfg, se_params, agent_init, rng_key=0, tapes=None, trace_cap=0
         tr = Trace(trace_cap, 0, _p(arrs["episode"], C.c_int32), _p(arrs["action"], C.c_int32),
                    _p(arrs["explored"], C.c_int32), _p(arrs["state"], C.c_float), _p(arrs["next_state"], C.c_float),
                    _p(arrs["reward"], C.c_float), _p(arrs["done"], C.c_float), _p(arrs["loss"], C.c_float))
-    rc = lib().orc_ddqn_se_chain(C.byref(cfg), _p(se_params, C.c_float), _p(agent_init, C.c_float), C.c_uint64(rng_key),
-                                 C.byref(tapes) if tapes is not None else None, _p(ep_mean, C.c_double),
-                                 _p(ep_len, C.c_int32), _p(final, C.c_double), C.byref(tr) if tr is not None else None,
-                                 C.byref(res))
+    icm_final = None
+    if icm_init is not None:
+        icm_init = _f32(icm_init)
+        assert icm_init.size == icm_num_params(cfg), (icm_init.size, icm_num_params(cfg))
+        icm_final = np.zeros_like(icm_init)
+        rc = lib().orc_ddqn_se_chain_icm(C.byref(cfg), _p(se_params, C.c_float), _p(agent_init, C.c_float), _p(icm_init, C.c_float),
+                                         C.c_uint64(rng_key), C.byref(tapes) if tapes is not None else None, _p(ep_mean, C.c_double),
+                                         _p(ep_len, C.c_int32), _p(final, C.c_double), C.byref(tr) if tr is not None else None,
+                                         C.byref(res), _p(icm_final, C.c_float))
+    else:
+        rc = lib().orc_ddqn_se_chain(C.byref(cfg), _p(se_params, C.c_float), _p(agent_init, C.c_float), C.c_uint64(rng_key),
+                                     C.byref(tapes) if tapes is not None else None, _p(ep_mean, C.c_double),
+                                     _p(ep_len, C.c_int32), _p(final, C.c_double), C.byref(tr) if tr is not None else None,
+                                     C.byref(res))
     out = dict(rc=rc, score=res.score, episodes_run=res.episodes_run, train_steps=res.train_steps,
                learn_steps=res.learn_steps, test_steps=res.test_steps, episode_test_mean=ep_mean[:E],
                episode_len=ep_len[:E], final_test_returns=final[:T])
     if tr is not None:
         n = tr.n
         out["trace"] = {k: v[:n] for k, v in arrs.items()}
+    if icm_final is not None:
+        out["icm_final"] = icm_final
     return out
 
 
@@ -350,6 +372,16 @@ def ddqn_cfg_from_config(config, grad_chunk=13, rng_mode=0, **overrides):
     agent_key = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "ddqn"
     if agent_key.endswith("_vary"):                  # the *_vary agents read their base agent's section (DDQN_vary.py:14)
         agent_key = agent_key[:-5]
+    icm = agent_key.endswith("_icm")                 # select_agent: ddqn_icm / duelingddqn_icm = the agent with icm=True
+    if icm:
+        agent_key = agent_key[:-4]
+        ic = config["agents"]["icm"]                 # DDQN.py:43-49
+        overrides.setdefault("icm_enabled", 1)
+        overrides.setdefault("icm_feature_dim", int(ic["feature_dim"]))
+        overrides.setdefault("icm_hidden", int(ic["hidden_size"]))
+        overrides.setdefault("icm_lr", float(ic["lr"]))
+        overrides.setdefault("icm_beta", float(ic["beta"]))
+        overrides.setdefault("icm_eta", float(ic["eta"]))
     a = config["agents"][agent_key]
     S, A = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3)}[env_name]
     assert a["same_action_num"] == 1, "same_action_num != 1 not supported by the oracle yet"

@@ -198,6 +198,34 @@ def test_g8v_vary_agents_replay_of_the_recorded_draw(golden, name):
     assert abs(out["score"] - float(g["score"])) <= 1e-4
 
 
+@pytest.mark.parametrize("name", ["g8i_calc_score_cartpole_ddqn_icm", "g8ia_calc_score_acrobot_dueling_icm"])
+def test_g8i_agents_with_icm(golden, name):
+    """DDQN / DuelingDDQN with the Intrinsic Curiosity Module inside learn() (agents/DDQN.py:74-76, models/icm_baseline.py):
+    the reference's run (select_agent "ddqn_icm" / "duelingddqn_icm") replayed by the oracle -- same actions, DDQN losses
+    (which see the intrinsic rewards), and the ICM parameters after every update of the run within 2e-7 (they move 2e-3).
+    CartPole exercises the BCE inverse loss on one logit, Acrobot the cross-entropy over three."""
+    import json
+    g = golden(name)
+    cfgd = json.loads(str(g["config_json"]))
+    cfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
+    assert cfg.icm_enabled == 1 and orc.icm_num_params(cfg) == g["icm_init"].size
+    tapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    n = g["tr_action"].size
+    out = orc.ddqn_se_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 10, icm_init=g["icm_init"])
+    assert out["rc"] == 0
+    tr = out["trace"]
+    assert np.array_equal(tr["action"], g["tr_action"]) and np.array_equal(tr["explored"], g["tr_explored"])
+    np.testing.assert_allclose(tr["next_state"], g["tr_next_state"], rtol=1e-5, atol=1e-5)
+    losses = tr["loss"][~np.isnan(tr["loss"])]
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-4, atol=1e-7)
+    assert np.abs(g["icm_final"] - g["icm_init"]).max() > 1e-3                 # the module really trained
+    np.testing.assert_allclose(out["icm_final"], g["icm_final"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=1e-4)
+    assert abs(out["score"] - float(g["score"])) <= 1e-4
+    # without fresh ICM parameters an ICM config is refused
+    assert orc.ddqn_se_chain(cfg, g["theta"], g["agent_init"], tapes=tapes)["rc"] != 0
+
+
 def test_vary_hyperparameter_draw():
     """The package's sampler (agents/vary.py) against the oracle's numpy restatement of ConfigSpace 0.4.13 on the same
     uniforms, the reference's bounds, and the log-uniform shape of the draw."""
