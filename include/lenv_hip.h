@@ -74,6 +74,12 @@ typedef struct {
      * stops; the final test gets the remainder and pads its returns the same way (so a chain that timed out in training
      * scores -1e9, as the reference does).  All four fused inner loops implement it. */
     int64_t step_budget;
+    /* Intrinsic Curiosity Module inside learn() (select_agent "ddqn_icm" / "duelingddqn_icm": agents/DDQN.py:40-58,74-76,
+     * models/icm_baseline.py:8-172; config section `icm`).  icm_enabled != 0: every learn step first trains the ICM on the
+     * minibatch (one Adam step with icm_lr) and adds eta * mean_f (features(s') - forward(s, a))^2 to the minibatch rewards.
+     * Only lenv_dueling_se_inner_loop_icm takes such a cfg (GEMM-tiled kernel; fresh ICM parameters per chain). */
+    int32_t icm_enabled, icm_feature_dim, icm_hidden, icm_pad_;
+    double icm_lr, icm_beta, icm_eta;
 } lenv_ddqn_cfg;
 
 /* RNG tapes (parity mode).  Per-chain rows: element [c*stride + n]; all DEVICE pointers. */
@@ -240,6 +246,19 @@ int lenv_dueling_se_inner_loop(const lenv_ddqn_cfg *cfg /*HOST*/, const float *t
  * rng_keys[c].  hp == NULL: every chain has cfg's shapes (== lenv_nes_draw's agent_init for the same keys). */
 int lenv_dueling_agent_init_hp(const lenv_ddqn_cfg *cfg /*HOST*/, const lenv_chain_hp *hp /*HOST struct of device arrays*/,
                                const uint64_t *rng_keys, int64_t chains, float *agent_init, void *stream);
+/* ICM agents: icm_init [chains, lenv_icm_num_params(cfg)] = fresh ICMModel parameters per chain in state-dict order
+ * (features_model, inverse_model, forward_pre_model, residual_block1..4 {fc1, fc2}, forward_post_model); icm_final (may be
+ * NULL) receives them after the last learn step.  cfg->icm_enabled == 0: identical to lenv_dueling_se_inner_loop_hp. */
+typedef struct lenv_icm_io {
+    const float *icm_init;
+    float *icm_final;
+} lenv_icm_io;
+int64_t lenv_icm_num_params(const lenv_ddqn_cfg *cfg /*HOST*/);
+int lenv_dueling_se_inner_loop_icm(const lenv_ddqn_cfg *cfg /*HOST*/, const lenv_chain_hp *hp /*HOST, may be NULL*/,
+                                   const lenv_icm_io *icm /*HOST struct of device arrays*/, const float *theta, const float *eps,
+                                   const int32_t *worker, const float *sign, const float *agent_init, const uint64_t *rng_keys,
+                                   const lenv_tapes *tapes /*HOST*/, int64_t chains, void *workspace, size_t workspace_bytes,
+                                   const lenv_inner_out *out /*HOST*/, void *stream);
 /* the same with per-chain hyper-parameters (hp == NULL: identical to lenv_dueling_se_inner_loop) */
 int lenv_dueling_se_inner_loop_hp(const lenv_ddqn_cfg *cfg /*HOST*/, const lenv_chain_hp *hp /*HOST struct of device arrays*/,
                                   const float *theta, const float *eps, const int32_t *worker, const float *sign,
@@ -337,6 +356,11 @@ int lenv_cheetah_standin_step(int32_t max_steps, int64_t n, const float *action,
                               float *obs, float *reward, float *done, void *stream);
 
 /* Counter-RNG key of a chain (same function as the oracle's): kind 0 = theta, 1 = theta+eps, 2 = theta-eps. HOST. */
+/* out[c][i] = (2u - 1) * bounds[i], u = unit(rng(rng_keys[c], rng_stream, i)), i < p: freshly initialised parameter vectors
+ * (nn.Linear default init with bounds[i] = 1/sqrt(fan_in)) keyed by the chains' counter-RNG keys.  rng_stream 10 reproduces
+ * lenv_nes_draw's agent_init; ICM modules (lenv_dueling_se_inner_loop_icm) are drawn from stream 12. */
+int lenv_chain_uniform_init(const uint64_t *rng_keys, int64_t chains, uint32_t rng_stream, int64_t p, const float *bounds, float *out,
+                            void *stream);
 /* one uniform in [0,1) of a chain's counter RNG (HOST function, no device work): unit(rng(key, stream, index)) */
 double lenv_rng_unit(uint64_t key, uint32_t stream, uint64_t index);
 uint64_t lenv_chain_key(uint64_t seed, uint64_t generation, uint64_t worker, uint64_t kind);

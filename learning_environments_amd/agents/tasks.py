@@ -12,7 +12,8 @@ Anything else raises NotImplementedError, like the reference does for unknown ag
 import numpy as np
 import torch
 
-from ..config import TABULAR_AGENTS, agent_layer_dims, ddqn_cfg_from_config, ql_cfg_from_config, td3_cfg_from_config, td3_layer_dims
+from ..config import (TABULAR_AGENTS, agent_layer_dims, ddqn_cfg_from_config, icm_layer_dims, ql_cfg_from_config, td3_cfg_from_config,
+                      td3_layer_dims)
 from .nes_common import chain_keys, fresh_agent_init, linear_init_bounds
 
 
@@ -25,11 +26,18 @@ class DdqnSeTask(object):
         dims = agent_layer_dims(self.cfg) if engine.name == "hip" else [(self.cfg.state_dim, self.cfg.q_hidden),
                                                                          (self.cfg.q_hidden, self.cfg.num_actions)]
         self.agent_bounds = torch.from_numpy(linear_init_bounds(dims)).to(engine.device)
+        # "ddqn_icm" / "duelingddqn_icm": the agent carries an Intrinsic Curiosity Module (agents/DDQN.py:40-58); every chain
+        # gets a fresh one (nn.Linear default init), drawn from its own counter-RNG stream
+        self.icm_bounds = None
+        if engine.name == "hip" and self.cfg.icm_enabled:
+            self.icm_bounds = torch.from_numpy(linear_init_bounds(icm_layer_dims(self.cfg))).to(engine.device)
 
     def make_inner(self, chains, want_episode_stats=True):
         return self.engine.make_inner(self.cfg, chains, want_episode_stats=want_episode_stats)
 
     def scores(self, inner, theta, eps, chain_worker, chain_sign, keys_t, agent_init):
+        if self.icm_bounds is not None:
+            inner.draw_icm_init(keys_t, self.icm_bounds)
         return self.engine.inner_scores(inner, theta, eps, chain_worker, chain_sign, agent_init, keys_t)
 
     def needs_agent_init(self):
@@ -156,7 +164,7 @@ class Td3VaryTask(object):
 def select_task(config, engine, synthetic_env):
     agent_name = config["agents"]["gtn"]["agent_name"].lower()
     env_type = config["agents"]["gtn"]["synthetic_env_type"]
-    if agent_name in ("ddqn", "duelingddqn") and env_type == 0:
+    if agent_name in ("ddqn", "duelingddqn", "ddqn_icm", "duelingddqn_icm") and env_type == 0:
         return DdqnSeTask(config, engine)
     if agent_name in ("ddqn_vary", "duelingddqn_vary") and env_type == 0:
         # vary_hp False: the agent IS its base agent (DDQN_vary.py:16-21)

@@ -17,6 +17,9 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
     agent_key = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "ddqn"
     if agent_key.endswith("_vary"):                  # DDQN_vary / DuelingDDQN_vary read the base agent's section (DDQN_vary.py:14)
         agent_key = agent_key[:-5]
+    icm = agent_key.endswith("_icm")                 # select_agent: "ddqn_icm" / "duelingddqn_icm" = the agent with icm=True
+    if icm:
+        agent_key = agent_key[:-4]
     if agent_key not in ("ddqn", "duelingddqn"):
         raise NotImplementedError("ddqn_cfg_from_config: agent '%s'" % agent_key)
     a = config["agents"][agent_key]
@@ -44,11 +47,24 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
                        eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]),
                        adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
                        step_budget=int(a.get("step_budget", 0)))      # env-step stand-in for time_remaining (base_agent.py:30-47)
+    if icm:                                          # config section `icm` (agents/DDQN.py:43-49)
+        ic = config["agents"]["icm"]
+        cfg.icm_enabled, cfg.icm_feature_dim, cfg.icm_hidden = 1, int(ic["feature_dim"]), int(ic["hidden_size"])
+        cfg.icm_lr, cfg.icm_beta, cfg.icm_eta = float(ic["lr"]), float(ic["beta"]), float(ic["eta"])
     for k, v in overrides.items():
         setattr(cfg, k, v)
-    if cfg.grad_chunk == 0 and cfg.agent_kind == 0:
-        cfg.grad_chunk = pick_grad_chunk(cfg)          # DuelingDDQN: one sequential chunk (grad_chunk stays 0)
+    if cfg.grad_chunk == 0 and cfg.agent_kind == 0 and not cfg.icm_enabled:
+        cfg.grad_chunk = pick_grad_chunk(cfg)          # DuelingDDQN / ICM agents: one sequential chunk (grad_chunk stays 0)
     return cfg
+
+
+def icm_layer_dims(cfg):
+    """[(fan_in, fan_out), ...] of ICMModel's nn.Linear layers in state-dict order (models/icm_baseline.py:42-78)."""
+    S, A, F, H = cfg.state_dim, cfg.num_actions, cfg.icm_feature_dim, cfg.icm_hidden
+    Ai = 1 if A == 2 else A
+    C = F + Ai
+    return ([(S, H), (H, H), (H, F)] + [(2 * F, H), (H, H), (H, Ai)] + [(C, H), (H, H), (H, F)] + [(C, F), (C, F)] * 4
+            + [(F, H), (H, F)])
 
 
 def agent_layer_dims(cfg):

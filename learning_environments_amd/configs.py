@@ -113,11 +113,23 @@ def with_vary(config, vary_hp=True):
     return cfg
 
 
+def with_icm(config, lr=1e-4, beta=0.2, eta=0.5, feature_dim=32, hidden_size=128):
+    """The same experiment with the agent's Intrinsic Curiosity Module switched on (select_agent "<agent>_icm"; the `icm`
+    section's defaults are default_config_cartpole_syn_env.yaml:48-53)."""
+    cfg = copy.deepcopy(config)
+    cfg["agents"]["gtn"]["agent_name"] += "_icm"
+    cfg["agents"]["icm"] = {"lr": lr, "beta": beta, "eta": eta, "feature_dim": feature_dim, "hidden_size": hidden_size}
+    return cfg
+
+
 def fixed_work(config, train_episodes):
     """BASELINE.md §3 fixed-work variant: early-out disabled (solved_reward=+1e9) and a fixed number of train episodes,
     so both the GPU path and the CPU baseline do identical, data-independent amounts of work."""
     cfg = copy.deepcopy(config)
     key = cfg["agents"]["gtn"]["agent_name"].lower()
-    cfg["agents"][key[:-5] if key.endswith("_vary") else key]["train_episodes"] = train_episodes
+    for suffix in ("_vary", "_icm"):
+        if key.endswith(suffix):
+            key = key[:-len(suffix)]
+    cfg["agents"][key]["train_episodes"] = train_episodes
     cfg["envs"][cfg["env_name"]]["solved_reward"] = 1e9
     return cfg

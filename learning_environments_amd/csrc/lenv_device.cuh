@@ -186,7 +186,8 @@ __device__ __forceinline__ uint32_t u64_to_below(uint64_t u, uint32_t n) { retur
 enum { STREAM_EPS = 0, STREAM_ACTION = 1, STREAM_REPLAY = 2, STREAM_TRAIN_RESET = 3, STREAM_TEST_RESET = 4,
        STREAM_TD3_RAND_ACTION = 5, STREAM_TD3_ACT_NOISE = 6, STREAM_TD3_TEST_NOISE = 7, STREAM_TD3_POLICY_NOISE = 8,
        STREAM_NES_EPS = 9, STREAM_AGENT_INIT = 10,
-       STREAM_VARY_HP = 11 };   // host side only (agents/vary.py): the four hyper-parameter draws of a *_vary agent
+       STREAM_VARY_HP = 11,     // host side only (agents/vary.py): the four hyper-parameter draws of a *_vary agent
+       STREAM_ICM_INIT = 12 };  // fresh ICMModel parameters of an ICM agent (lenv_chain_uniform_init)
 
 // natural log, same sequence as the oracle's orc_log (fdlibm scheme, fma Horner); used by the counter-mode Box-Muller
 __device__ __forceinline__ double det_log(double x)
@@ -210,6 +211,24 @@ __device__ __forceinline__ double det_log(double x)
     const double hfsq = 0.5 * f * f;
     const double de = (double)e;
     return de * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + de * 1.90821492927058770002e-10)) - f);
+}
+
+// deterministic expf (oracle: orc_expf, the same sequence): 2^n * p(r), n = rint(x*log2e), r = x - n*ln2 (two constants),
+// p = degree-6 Horner in fmaf.  Used for the softmax of the ICM inverse model (arguments <= 0).
+__device__ __forceinline__ float det_expf(float x)
+{
+    if (x < -87.0f) return 0.0f;
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = fma32(-n, 0.693145751953125f, x);
+    r = fma32(-n, 1.42860682030941723212e-6f, r);
+    float p = 1.0f / 720.0f;
+    p = fma32(p, r, 1.0f / 120.0f);
+    p = fma32(p, r, 1.0f / 24.0f);
+    p = fma32(p, r, 1.0f / 6.0f);
+    p = fma32(p, r, 0.5f);
+    p = fma32(p, r, 1.0f);
+    p = fma32(p, r, 1.0f);
+    return __builtin_ldexpf(p, (int)n);
 }
 
 // N(0,1) = sqrt(-2 ln u1) * cos(2 pi u2) on counter draws 2n, 2n+1 (oracle: orc_normal)

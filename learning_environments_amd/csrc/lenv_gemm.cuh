@@ -36,7 +36,8 @@ enum { EPI_STORE = 0,       // out = acc
        EPI_BIAS = 2,        // out = acc + bias[j]
        EPI_ACT_BWD = 3,     // out = act'(aux[i][j]) * acc      (aux = the layer's activation)
        EPI_ACCUM = 4,       // out = out + acc
-       EPI_BIAS_TANH = 5 }; // t = tanh(acc + bias[j]); out2 = t (optional); out = t * scale
+       EPI_BIAS_TANH = 5,   // t = tanh(acc + bias[j]); out2 = t (optional); out = t * scale
+       EPI_BIAS_ADD = 6 };  // out = aux[i][j] + (acc + bias[j])     (residual connection)
 
 enum { GEMM_GENERIC_P = 1, GEMM_GENERIC_OUT = 2 };   // the P operand / the output may live in LDS (generic pointers)
 
@@ -44,7 +45,7 @@ struct GemmEpi {
     int kind;
     float *out; int ldo, ocol;          // out[i*ldo + ocol + j]
     const float *bias;                  // global
-    const float *aux; int ldaux;        // EPI_ACT_BWD, global
+    const float *aux; int ldaux;        // EPI_ACT_BWD / EPI_BIAS_ADD, global
     float *out2; int ldo2;              // EPI_BIAS_TANH, global
     int act; float prelu, scale;
     int flags;
@@ -248,7 +249,13 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 acc, int i0, int j0, 
 #pragma unroll
         for (int v = 0; v < 16; ++v) res[v] = res[v] + bv;
         if (kind == EPI_BIAS_ACT) act_fwd16(ep.act, ep.prelu, res);
-        else if (kind == EPI_BIAS_TANH) {
+        else if (kind == EPI_BIAS_ADD) {
+            const MemView<true> aux(ep.aux);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { const int i = ib + 8 * (v >> 2) + (v & 3); x[v] = (full || (jok && i < I)) ? aux.ld(ib * ep.ldaux + j + (8 * (v >> 2) + (v & 3)) * ep.ldaux) : 0.0f; }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) res[v] = x[v] + res[v];
+        } else if (kind == EPI_BIAS_TANH) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) res[v] = det_tanhf(lenv_tanh_table, res[v]);
             if (ep.out2) {
@@ -479,6 +486,8 @@ __device__ __forceinline__ GemmEpi epi_accum(float *out, int ldo) { GemmEpi e{};
 __device__ __forceinline__ GemmEpi epi_bias(float *out, int ldo, int ocol, const float *bias) { GemmEpi e{}; e.kind = EPI_BIAS; e.out = out; e.ldo = ldo; e.ocol = ocol; e.bias = bias; return e; }
 __device__ __forceinline__ GemmEpi epi_bias_act(float *out, int ldo, const float *bias, int act, float prelu) { GemmEpi e{}; e.kind = EPI_BIAS_ACT; e.out = out; e.ldo = ldo; e.bias = bias; e.act = act; e.prelu = prelu; return e; }
 __device__ __forceinline__ GemmEpi epi_act_bwd(float *out, int ldo, const float *aux, int ldaux, int act, float prelu) { GemmEpi e{}; e.kind = EPI_ACT_BWD; e.out = out; e.ldo = ldo; e.aux = aux; e.ldaux = ldaux; e.act = act; e.prelu = prelu; return e; }
+__device__ __forceinline__ GemmEpi epi_bias_add(float *out, int ldo, const float *bias, const float *aux, int ldaux) { GemmEpi e{}; e.kind = EPI_BIAS_ADD; e.out = out; e.ldo = ldo; e.bias = bias; e.aux = aux; e.ldaux = ldaux; return e; }
+__device__ __forceinline__ GemmEpi epi_bias_act_ld(float *out, int ldo, const float *bias, int act) { return epi_bias_act(out, ldo, bias, act, 0.25f); }
 __device__ __forceinline__ GemmEpi epi_bias_tanh(float *out, int ldo, int ocol, const float *bias, float scale, float *out2, int ldo2) { GemmEpi e{}; e.kind = EPI_BIAS_TANH; e.out = out; e.ldo = ldo; e.ocol = ocol; e.bias = bias; e.scale = scale; e.out2 = out2; e.ldo2 = ldo2; return e; }
 
 

@@ -195,6 +195,18 @@ __global__ void nes_draw_kernel(uint64_t seed, uint64_t generation, int64_t pop,
     }
 }
 
+// out[c][i] = (2u - 1) * bounds[i], u = unit(rng(keys[c], rng_stream, i)): fresh nn.Linear-initialised parameter vectors
+// keyed by the chains' counter-RNG keys (the agent_init draw of nes_draw_kernel for any stream: ICM modules use their own)
+__global__ void chain_uniform_init_kernel(const uint64_t *keys, int64_t chains, uint32_t rng_stream, int64_t P, const float *bounds, float *out)
+{
+    const int64_t total = chains * P;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = e / P, i = e - c * P;
+        const float u = (float)u64_to_unit(rng_u64(keys[c], rng_stream, (uint64_t)i));
+        out[e] = (u * 2.0f - 1.0f) * bounds[i];
+    }
+}
+
 // column 3 of the per-worker records = this rank's worst chain status (min over `n` int32), so a failure travels through the
 // fitness all-gather (one thread; n is a few hundred)
 __global__ void status_fold_kernel(const int32_t *status, int64_t n, double *result, int64_t pop)
@@ -221,6 +233,17 @@ extern "C" int lenv_nes_draw(uint64_t seed, uint64_t generation, int64_t pop, in
     const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(nes_draw_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), seed, generation, pop, p_theta,
                        noise_std, eps, chains, (int64_t)chains_per_worker, worker_lo, p_agent, bounds, agent_init, rng_keys);
+    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}
+
+extern "C" int lenv_chain_uniform_init(const uint64_t *rng_keys, int64_t chains, uint32_t rng_stream, int64_t p, const float *bounds, float *out,
+                                       void *stream)
+{
+    if (!rng_keys || !bounds || !out || chains < 0 || p < 1) return LENV_ERR_INVALID;
+    if (chains == 0) return LENV_OK;
+    const int64_t total = chains * p;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(chain_uniform_init_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), rng_keys, chains, rng_stream, p, bounds, out);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }
 

@@ -161,8 +161,10 @@ class InnerLoop(object):
         self.hp = self.hp_struct = self.agent_init = None
         # DuelingDDQN, and DDQN whose Critic_DQN the register-resident kernel refuses (hidden_layer >= 2 / wide layers),
         # run in the GEMM-tiled kernel; `dueling` keeps its name from the first of the two
-        self.dueling = self.vary or cfg.agent_kind == 1 or (cfg.agent_kind == 0 and L.lenv_ddqn_se_lds_bytes(C.byref(cfg)) <= 0
-                                                            and L.lenv_dueling_num_params(C.byref(cfg)) > 0)
+        self.icm = bool(cfg.icm_enabled)               # ICM agents (ddqn_icm / duelingddqn_icm): GEMM-tiled kernel only
+        self.icm_init = self.icm_final = self.icm_io = None
+        self.dueling = self.vary or self.icm or cfg.agent_kind == 1 or (cfg.agent_kind == 0 and L.lenv_ddqn_se_lds_bytes(C.byref(cfg)) <= 0
+                                                                        and L.lenv_dueling_num_params(C.byref(cfg)) > 0)
         if self.dueling:
             self.p_agent = int(L.lenv_dueling_num_params(C.byref(cfg)))
             _lib.check(min(self.p_agent, 0), "lenv_dueling_num_params")
@@ -170,6 +172,12 @@ class InnerLoop(object):
             self._fn = L.lenv_dueling_se_inner_loop
             if self.vary:
                 _alloc_chain_hp(self)
+            if self.icm:
+                self.p_icm = int(L.lenv_icm_num_params(C.byref(cfg)))
+                _lib.check(min(self.p_icm, 0), "lenv_icm_num_params")
+                self.icm_init = torch.zeros((self.chains, self.p_icm), dtype=torch.float32, device=self.dev)
+                self.icm_final = torch.zeros((self.chains, self.p_icm), dtype=torch.float32, device=self.dev)
+                self.icm_io = _lib.IcmIo(_ptr(self.icm_init), _ptr(self.icm_final))
         else:
             self.ws_bytes = int(L.lenv_ddqn_se_workspace_bytes(C.byref(cfg), self.chains))
             qd = mlp_desc(S, cfg.q_hidden, cfg.q_layers, cfg.num_actions, cfg.q_act)
@@ -212,6 +220,14 @@ class InnerLoop(object):
         _lib.check(min(n, 0), "lenv_dueling_num_params")
         return n
 
+    def draw_icm_init(self, rng_keys, bounds):
+        """Fresh ICMModel parameters per chain into self.icm_init (nn.Linear default init with `bounds` [p_icm], counter-RNG
+        stream 12 of every chain key)."""
+        _chk(rng_keys, torch.int64, "rng_keys"); _chk(bounds, torch.float32, "bounds")
+        rc = _lib.lib().lenv_chain_uniform_init(_ptr(rng_keys), self.chains, 12, self.p_icm, _ptr(bounds), _ptr(self.icm_init), _stream())
+        _lib.check(rc, "lenv_chain_uniform_init")
+        return self.icm_init
+
     def draw_agent_init(self, rng_keys):
         """Fresh agents at every chain's own shapes into self.agent_init (nn.Linear default init, keyed by the chain keys)."""
         _chk(rng_keys, torch.int64, "rng_keys")
@@ -239,7 +255,9 @@ class InnerLoop(object):
             _chk(rng_keys, torch.int64, "rng_keys")
         args = (_ptr(theta), _ptr(eps), _ptr(worker), _ptr(sign), _ptr(agent_init), _ptr(rng_keys),
                 C.byref(t) if t is not None else None, self.chains, _ptr(self.workspace), self.ws_bytes, C.byref(self.out), _stream())
-        if self.vary:
+        if self.icm:
+            rc = _lib.lib().lenv_dueling_se_inner_loop_icm(C.byref(self.cfg), None, C.byref(self.icm_io), *args)
+        elif self.vary:
             rc = _lib.lib().lenv_dueling_se_inner_loop_hp(C.byref(self.cfg), C.byref(self.hp_struct), *args)
         else:
             rc = self._fn(C.byref(self.cfg), *args)

@@ -673,9 +673,21 @@ def rng_u64_array(key, stream, n):
         return mix(mix(x) ^ k)
 
 
-def agent_init_from_key(key, layer_dims):
+STREAM_ICM_INIT = 12
+
+
+def icm_layer_dims(cfg):
+    """ICMModel's nn.Linear layers in state-dict order (models/icm_baseline.py:42-78)."""
+    S, A, F, H = cfg.state_dim, cfg.num_actions, cfg.icm_feature_dim, cfg.icm_hidden
+    Ai = 1 if A == 2 else A
+    C = F + Ai
+    return ([(S, H), (H, H), (H, F)] + [(2 * F, H), (H, H), (H, Ai)] + [(C, H), (H, H), (H, F)] + [(C, F), (C, F)] * 4
+            + [(F, H), (H, F)])
+
+
+def agent_init_from_key(key, layer_dims, stream=STREAM_AGENT_INIT):
     """Fresh agent of an MLP stack given as [(fan_in, fan_out), ...] in state-dict order: nn.Linear's default init
-    U(-1/sqrt(fan_in), 1/sqrt(fan_in)), u = unit(rng(key, STREAM_AGENT_INIT, i)) as in orc_nes_draw."""
+    U(-1/sqrt(fan_in), 1/sqrt(fan_in)), u = unit(rng(key, stream, i)) as in orc_nes_draw (stream 12: ICM modules)."""
     bounds = np.concatenate([np.full(fi * fo + fo, 1.0 / np.sqrt(float(fi)), np.float32) for fi, fo in layer_dims])
-    u = ((rng_u64_array(key, STREAM_AGENT_INIT, bounds.size) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)).astype(np.float32)
+    u = ((rng_u64_array(key, stream, bounds.size) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)).astype(np.float32)
     return (u * np.float32(2.0) - np.float32(1.0)) * bounds

@@ -388,6 +388,36 @@ def test_gtn_master_acrobot_ddqn_vary_as_shipped(tmp_path, monkeypatch):
     assert (st[:, 2] > 0).all()                              # every chain learned
 
 
+def test_gtn_master_ddqn_icm_generation(tmp_path, monkeypatch):
+    """`agent_name: DDQN_icm` through GTN_Master: every chain gets a fresh ICM (counter-RNG stream 12), trains it inside
+    learn() and sees the intrinsic rewards; fitness records equal an oracle evaluation."""
+    from learning_environments_amd import _lib
+    from learning_environments_amd.configs import cartpole_syn_env_ddqn, fixed_work, with_icm
+    from oracle import oracle as orc
+    cfg = fixed_work(with_icm(cartpole_syn_env_ddqn(num_workers=2, max_iterations=1), feature_dim=16, hidden_size=24), 2)
+    cfg["envs"]["CartPole-v0"]["max_steps"] = 10
+    cfg["agents"]["ddqn"].update(test_episodes=2, init_episodes=1, batch_size=24)
+    m = _master_pair(cfg, tmp_path, monkeypatch)
+    assert m.cfg.icm_enabled == 1 and m.cfg.grad_chunk == 0 and m.inner.icm and m.inner.p_icm == 7081
+    theta0 = m.theta.cpu().numpy().copy()
+    gathered = m.evaluate_population(0).cpu().numpy()
+    eps = m.eps.cpu().numpy()
+    oeps, init, okeys = orc.nes_draw(m.seed, 0, 2, m.p_theta, cfg["agents"]["gtn"]["noise_std"], 6, 3, 0, m.agent_bounds.cpu().numpy())
+    assert np.array_equal(eps, oeps)
+    ocfg = orc.ddqn_cfg_from_config(cfg, grad_chunk=0)
+    scores = []
+    for c in range(6):
+        key = orc.chain_key(m.seed, 0, c // 3, c % 3)
+        icm_init = orc.agent_init_from_key(key, orc.icm_layer_dims(ocfg), stream=orc.STREAM_ICM_INIT)
+        w = (np.float32([0.0, 1.0, -1.0][c % 3]) * eps[c // 3] + theta0).astype(np.float32)
+        scores.append(orc.ddqn_se_chain(ocfg, w, init[c], rng_key=key, icm_init=icm_init)["score"])
+    scores = np.array(scores)
+    best, sign = orc.worker_best(scores[1::3], scores[2::3], True)
+    assert np.array_equal(gathered[:, 0], best) and np.array_equal(gathered[:, 1], scores[0::3])
+    mean_score, mean_list, _ = m.run()
+    assert len(mean_list) == 1
+
+
 def test_gtn_master_td3_vary_generation(tmp_path, monkeypatch):
     """`agent_name: TD3_vary` through GTN_Master (agents/TD3_vary.py): per-chain draws, one launch, oracle-equal fitness."""
     from learning_environments_amd import _lib

@@ -481,6 +481,87 @@ def test_ddqn_multilayer_counter_mode_vs_oracle(eng, orc, golden, env_name, laye
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# ICM agents: the Intrinsic Curiosity Module trained inside learn() (lenv_dueling_se_inner_loop_icm)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["g8i_calc_score_cartpole_ddqn_icm", "g8ia_calc_score_acrobot_dueling_icm"])
+def test_icm_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
+    """select_agent "ddqn_icm" / "duelingddqn_icm": the reference's run replayed on the GPU -- bit-exact against the oracle
+    (trace, returns AND the ICM parameters after the last update), actions / score equal to the reference's own run."""
+    g = golden(name)
+    cfgd = json.loads(str(g["config_json"]))
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
+    assert cfg.icm_enabled == 1
+    n = g["tr_action"].size
+    otapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    o = orc.ddqn_se_chain(ocfg, g["theta"], g["agent_init"], tapes=otapes, trace_cap=n + 8, icm_init=g["icm_init"])
+    chains = 2
+    tapes = dict(eps_uniform=dev(np.tile(g["tape_eps_uniform"], (chains, 1))),
+                 rand_action=dev(np.tile(g["tape_rand_action"], (chains, 1))),
+                 replay_idx=dev(np.tile(g["tape_replay_idx"].reshape(1, -1), (chains, 1))),
+                 train_reset=dev(np.tile(g["tape_train_reset"][None], (chains, 1, 1))),
+                 test_reset=dev(np.tile(g["tape_test_reset"][None], (chains, 1, 1))))
+    il = eng.InnerLoop(cfg, chains, trace_cap=n + 8)
+    assert il.icm and il.dueling and il.p_icm == g["icm_init"].size and il.p_agent == g["agent_init"].size
+    il.icm_init.copy_(dev(np.tile(g["icm_init"], (chains, 1))))
+    il.run(dev(g["theta"]), None, None, None, dev(np.tile(g["agent_init"], (chains, 1))), tapes=tapes)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        act = il.trace["action"][c, :n].cpu().numpy()
+        assert np.array_equal(act & 0xFFFF, o["trace"]["action"]) and np.array_equal(act >> 16, o["trace"]["explored"])
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"])
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(il.final_returns[c].cpu().numpy(), o["final_test_returns"])
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(il.icm_final[c].cpu().numpy(), o["icm_final"])           # every ICM update, bit for bit
+        assert np.array_equal(act & 0xFFFF, g["tr_action"])
+        np.testing.assert_allclose(il.icm_final[c].cpu().numpy(), g["icm_final"], rtol=0, atol=2e-7)
+        assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4
+
+
+@pytest.mark.parametrize("family,env_name,batch,fdim,hid", [("ddqn", "CartPole-v0", 40, 32, 128), ("duelingddqn", "Acrobot-v1", 33, 20, 48)])
+def test_icm_counter_mode_vs_oracle(eng, orc, golden, family, env_name, batch, fdim, hid):
+    """ICM agents in counter mode at the shipped ICM shapes (feature_dim 32, hidden 128) and at odd ones: fresh ICM parameters
+    from the chains' counter RNG (stream 12), three chains, everything bit-exact against the oracle."""
+    from learning_environments_amd.agents.nes_common import linear_init_bounds
+    from learning_environments_amd.config import icm_layer_dims
+    g = golden("g8i_calc_score_cartpole_ddqn_icm" if family == "ddqn" else "g8ia_calc_score_acrobot_dueling_icm")
+    cfgd = json.loads(str(g["config_json"]))
+    cfgd["agents"][family].update(batch_size=batch, test_episodes=3)
+    cfgd["agents"]["icm"].update(feature_dim=fdim, hidden_size=hid)
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, train_episodes=3, max_steps=9)
+    S, A = cfg.state_dim, cfg.num_actions
+    chains = 3
+    rng = np.random.RandomState(51)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, ocfg.se_hidden, 1, "leakyrelu"))
+    theta = (rng.randn(P_se) * 0.15).astype(np.float32)
+    eps = (rng.randn(1, P_se) * 0.05).astype(np.float32)
+    worker, sign = np.zeros(chains, np.int32), np.array([0.0, 1.0, -1.0], np.float32)
+    keys = np.array([orc.chain_key(29, 3, 0, c) for c in range(chains)], np.uint64)
+    il = eng.InnerLoop(cfg, chains, trace_cap=30)
+    agent_init = (rng.uniform(-0.2, 0.2, (chains, il.p_agent))).astype(np.float32)
+    keys_t = dev(keys.view(np.int64))
+    bounds = torch.from_numpy(linear_init_bounds(icm_layer_dims(cfg))).cuda()
+    icm_init = il.draw_icm_init(keys_t, bounds).cpu().numpy()
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=keys_t)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        oinit = orc.agent_init_from_key(int(keys[c]), orc.icm_layer_dims(ocfg), stream=orc.STREAM_ICM_INIT)
+        assert np.array_equal(icm_init[c], oinit), c
+        w = (np.float32(sign[c]) * eps[0] + theta).astype(np.float32)
+        o = orc.ddqn_se_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]), trace_cap=30, icm_init=oinit)
+        m = o["trace"]["action"].size
+        assert o["learn_steps"] > 0
+        assert np.array_equal(il.trace["action"][c, :m].cpu().numpy() & 0xFFFF, o["trace"]["action"]), c
+        assert np.array_equal(il.icm_final[c].cpu().numpy(), o["icm_final"]), c
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # *_vary agents: per-chain lr / batch_size / hidden_size / hidden_layer in ONE launch (lenv_dueling_se_inner_loop_hp)
 # ---------------------------------------------------------------------------------------------------------------
 def _vary_max_cfg(orc, cfgd, agent_key, **over):
