@@ -248,7 +248,8 @@ int lenv_dueling_agent_init_hp(const lenv_ddqn_cfg *cfg /*HOST*/, const lenv_cha
                                const uint64_t *rng_keys, int64_t chains, float *agent_init, void *stream);
 /* ICM agents: icm_init [chains, lenv_icm_num_params(cfg)] = fresh ICMModel parameters per chain in state-dict order
  * (features_model, inverse_model, forward_pre_model, residual_block1..4 {fc1, fc2}, forward_post_model); icm_final (may be
- * NULL) receives them after the last learn step.  cfg->icm_enabled == 0: identical to lenv_dueling_se_inner_loop_hp. */
+ * NULL) receives them after the last learn step.  hp != NULL: the *_icm_vary agents (per-chain hyper-parameters of the agent;
+ * the ICM keeps cfg's shapes and learning rate).  cfg->icm_enabled == 0: identical to lenv_dueling_se_inner_loop_hp. */
 typedef struct lenv_icm_io {
     const float *icm_init;
     float *icm_final;

@@ -55,6 +55,8 @@ class DdqnVaryTask(object):
         from . import vary
         self.engine = engine              # HipNesEngine, or the test suite's oracle-backed stand-in (CPU tensors)
         self.agent_key = config["agents"]["gtn"]["agent_name"].lower()[:-5]
+        if self.agent_key.endswith("_icm"):               # "ddqn_icm_vary": DDQN_vary(icm=True), agents/agent_utils.py:43-44
+            self.agent_key = self.agent_key[:-4]
         self.base = config["agents"][self.agent_key]
         bd = vary.hp_bounds(self.base)
         big = copy.deepcopy(config)
@@ -64,6 +66,9 @@ class DdqnVaryTask(object):
         self.cfg.grad_chunk = 0                           # one sequential batch gradient (GEMM-tiled kernel)
         self.agent_bounds = None
         self.last_hp = None
+        self.icm_bounds = None
+        if engine.name == "hip" and self.cfg.icm_enabled:
+            self.icm_bounds = torch.from_numpy(linear_init_bounds(icm_layer_dims(self.cfg))).to(engine.device)
 
     def make_inner(self, chains, want_episode_stats=True):
         return self.engine.make_inner(self.cfg, chains, want_episode_stats=want_episode_stats, vary=True)
@@ -80,6 +85,8 @@ class DdqnVaryTask(object):
         inner.set_hp([h["lr"] for h in hp], [h["batch_size"] for h in hp], [h["hidden_size"] for h in hp],
                      [h["hidden_layer"] for h in hp])
         inner.draw_agent_init(keys_t)
+        if self.icm_bounds is not None:
+            inner.draw_icm_init(keys_t, self.icm_bounds)
         return self.engine.inner_scores(inner, theta, eps, chain_worker, chain_sign, None, keys_t)
 
     def needs_agent_init(self):
@@ -166,9 +173,11 @@ def select_task(config, engine, synthetic_env):
     env_type = config["agents"]["gtn"]["synthetic_env_type"]
     if agent_name in ("ddqn", "duelingddqn", "ddqn_icm", "duelingddqn_icm") and env_type == 0:
         return DdqnSeTask(config, engine)
-    if agent_name in ("ddqn_vary", "duelingddqn_vary") and env_type == 0:
-        # vary_hp False: the agent IS its base agent (DDQN_vary.py:16-21)
-        return DdqnVaryTask(config, engine) if config["agents"][agent_name]["vary_hp"] else DdqnSeTask(config, engine)
+    if agent_name in ("ddqn_vary", "duelingddqn_vary", "ddqn_icm_vary", "duelingddqn_icm_vary") and env_type == 0:
+        # vary_hp False: the agent IS its base agent (DDQN_vary.py:16-21); the *_icm_vary names read the same `<agent>_vary`
+        # section (DDQN_vary.py:16) and switch the ICM on
+        section = agent_name.replace("_icm", "")
+        return DdqnVaryTask(config, engine) if config["agents"][section]["vary_hp"] else DdqnSeTask(config, engine)
     if agent_name in TABULAR_AGENTS and env_type == 1:
         real = synthetic_env.env.real_env
         if not hasattr(real, "tables"):

@@ -109,7 +109,7 @@ def with_vary(config, vary_hp=True):
     cfg = copy.deepcopy(config)
     base = cfg["agents"]["gtn"]["agent_name"]
     cfg["agents"]["gtn"]["agent_name"] = base + "_vary"
-    cfg["agents"][base.lower() + "_vary"] = {"vary_hp": bool(vary_hp)}
+    cfg["agents"][base.lower().replace("_icm", "") + "_vary"] = {"vary_hp": bool(vary_hp)}     # DDQN_vary(icm=True) reads `ddqn_vary` too
     return cfg
 
 

@@ -896,7 +896,6 @@ extern "C" int lenv_dueling_se_inner_loop_icm(const lenv_ddqn_cfg *cfg, const le
 {
     if (!cfg || !theta || !agent_init || !out || !out->score || !workspace || chains < 0) return LENV_ERR_INVALID;
     if (cfg->icm_enabled && (!icm || !icm->icm_init)) return LENV_ERR_INVALID;
-    if (cfg->icm_enabled && hp) return LENV_ERR_UNSUPPORTED;           // ddqn_icm_vary: per-chain shapes and an ICM together are not built
     if (hp && (!hp->lr || !hp->batch_size || !hp->q_hidden || !hp->q_layers)) return LENV_ERR_INVALID;
     if (eps && (!worker || !sign)) return LENV_ERR_INVALID;
     if (cfg->rng_mode == LENV_RNG_TAPE && !tapes) return LENV_ERR_INVALID;

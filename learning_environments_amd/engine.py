@@ -256,7 +256,8 @@ class InnerLoop(object):
         args = (_ptr(theta), _ptr(eps), _ptr(worker), _ptr(sign), _ptr(agent_init), _ptr(rng_keys),
                 C.byref(t) if t is not None else None, self.chains, _ptr(self.workspace), self.ws_bytes, C.byref(self.out), _stream())
         if self.icm:
-            rc = _lib.lib().lenv_dueling_se_inner_loop_icm(C.byref(self.cfg), None, C.byref(self.icm_io), *args)
+            rc = _lib.lib().lenv_dueling_se_inner_loop_icm(C.byref(self.cfg), C.byref(self.hp_struct) if self.vary else None,
+                                                           C.byref(self.icm_io), *args)
         elif self.vary:
             rc = _lib.lib().lenv_dueling_se_inner_loop_hp(C.byref(self.cfg), C.byref(self.hp_struct), *args)
         else:
