@@ -285,6 +285,10 @@ typedef struct {
     double solved_reward, gamma, lr, tau, action_std, policy_std, policy_std_clip, max_action;
     double adam_beta1, adam_beta2, adam_eps;
     int64_t step_budget;                     /* env-step stand-in for time_remaining, see lenv_ddqn_cfg::step_budget */
+    /* TD3(icm=True), select_agent "td3_icm" (agents/TD3.py:44-60,68-70): as lenv_ddqn_cfg's icm_* fields; continuous actions,
+     * so the action vector is the ICM's input and its inverse loss is an MSE.  Only lenv_td3_rn_inner_loop_icm takes it. */
+    int32_t icm_enabled, icm_feature_dim, icm_hidden, icm_pad_;
+    double icm_lr, icm_beta, icm_eta;
 } lenv_td3_cfg;
 
 /* RNG tapes (parity mode); per-chain rows, strides in ROWS (rows of A floats / B ints / S doubles as noted) */
@@ -326,6 +330,14 @@ int lenv_td3_rn_inner_loop_hp(const lenv_td3_cfg *cfg /*HOST*/, const lenv_chain
                               const float *theta, const float *eps, const int32_t *worker, const float *sign,
                               const float *agent_init, const uint64_t *rng_keys, const lenv_td3_tapes *tapes /*HOST*/,
                               int64_t chains, void *workspace, size_t workspace_bytes, const lenv_td3_out *out /*HOST*/, void *stream);
+/* TD3 with an ICM: icm as in lenv_dueling_se_inner_loop_icm (icm_init rows of lenv_td3_icm_num_params(cfg) floats);
+ * hp may be NULL (td3_icm) or the per-chain hyper-parameters (td3_icm_vary) */
+int64_t lenv_td3_icm_num_params(const lenv_td3_cfg *cfg /*HOST*/);
+int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg /*HOST*/, const lenv_chain_hp *hp /*HOST, may be NULL*/,
+                               const lenv_icm_io *icm /*HOST struct of device arrays*/, const float *theta, const float *eps,
+                               const int32_t *worker, const float *sign, const float *agent_init, const uint64_t *rng_keys,
+                               const lenv_td3_tapes *tapes /*HOST*/, int64_t chains, void *workspace, size_t workspace_bytes,
+                               const lenv_td3_out *out /*HOST*/, void *stream);
 int lenv_td3_agent_init_hp(const lenv_td3_cfg *cfg /*HOST*/, const lenv_chain_hp *hp, const uint64_t *rng_keys, int64_t chains,
                            float *agent_init, void *stream);
 

@@ -89,7 +89,9 @@ class Td3Cfg(C.Structure):
                 ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
                 ("action_std", C.c_double), ("policy_std", C.c_double), ("policy_std_clip", C.c_double),
                 ("max_action", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
-                ("step_budget", C.c_int64)]
+                ("step_budget", C.c_int64),
+                ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("icm_pad_", C.c_int32),
+                ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double)]
 
 
 class Td3Tapes(C.Structure):
@@ -108,7 +110,7 @@ class Td3Out(C.Structure):
 EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv_se_step_population",
            "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_lds_bytes", "lenv_ddqn_se_inner_loop",
            "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population", "lenv_dueling_se_workspace_bytes",
-           "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_dueling_se_inner_loop_hp", "lenv_dueling_agent_init_hp", "lenv_rng_unit", "lenv_td3_rn_inner_loop_hp", "lenv_td3_agent_init_hp", "lenv_icm_num_params", "lenv_dueling_se_inner_loop_icm", "lenv_chain_uniform_init", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
+           "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_dueling_se_inner_loop_hp", "lenv_dueling_agent_init_hp", "lenv_rng_unit", "lenv_td3_rn_inner_loop_hp", "lenv_td3_agent_init_hp", "lenv_icm_num_params", "lenv_dueling_se_inner_loop_icm", "lenv_chain_uniform_init", "lenv_td3_icm_num_params", "lenv_td3_rn_inner_loop_icm", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
            "lenv_td3_rn_inner_loop", "lenv_mlp_forward", "lenv_cheetah_standin_reset", "lenv_cheetah_standin_step",
            "lenv_rn_num_params", "lenv_rn_shape_rows", "lenv_nes_worker_best_multi", "lenv_nes_draw", "lenv_nes_status_fold"]
 
@@ -186,6 +188,10 @@ def lib():
                                              C.POINTER(Td3Out), vp]
         L.lenv_td3_rn_inner_loop_hp.restype = C.c_int
         L.lenv_td3_rn_inner_loop_hp.argtypes = [C.POINTER(Td3Cfg), C.POINTER(ChainHp)] + list(L.lenv_td3_rn_inner_loop.argtypes[1:])
+        L.lenv_td3_icm_num_params.restype = C.c_int64
+        L.lenv_td3_icm_num_params.argtypes = [C.POINTER(Td3Cfg)]
+        L.lenv_td3_rn_inner_loop_icm.restype = C.c_int
+        L.lenv_td3_rn_inner_loop_icm.argtypes = [C.POINTER(Td3Cfg), C.POINTER(ChainHp), C.POINTER(IcmIo)] + list(L.lenv_td3_rn_inner_loop.argtypes[1:])
         L.lenv_td3_agent_init_hp.restype = C.c_int
         L.lenv_td3_agent_init_hp.argtypes = [C.POINTER(Td3Cfg), C.POINTER(ChainHp), vp, C.c_int64, vp, vp]
         L.lenv_rn_num_params.restype = C.c_int64

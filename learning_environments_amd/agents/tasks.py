@@ -119,11 +119,16 @@ class Td3RnTask(object):
         self.engine = engine
         self.cfg = td3_cfg_from_config(config)
         self.agent_bounds = torch.from_numpy(linear_init_bounds(td3_layer_dims(self.cfg))).to(engine.device)
+        self.icm_bounds = None                    # "td3_icm": TD3(icm=True), a fresh ICM per chain
+        if self.cfg.icm_enabled:
+            self.icm_bounds = torch.from_numpy(linear_init_bounds(icm_layer_dims(self.cfg))).to(engine.device)
 
     def make_inner(self, chains, want_episode_stats=False):
         return self.engine.make_inner_td3(self.cfg, chains, want_episode_stats=want_episode_stats)
 
     def scores(self, inner, theta, eps, chain_worker, chain_sign, keys_t, agent_init):
+        if self.icm_bounds is not None:
+            inner.draw_icm_init(keys_t, self.icm_bounds)
         return self.engine.inner_scores_td3(inner, theta, eps, chain_worker, chain_sign, agent_init, keys_t)
 
     def needs_agent_init(self):
@@ -148,6 +153,9 @@ class Td3VaryTask(object):
         self.cfg = td3_cfg_from_config(big)
         self.agent_bounds = None
         self.last_hp = None
+        self.icm_bounds = None
+        if self.cfg.icm_enabled:
+            self.icm_bounds = torch.from_numpy(linear_init_bounds(icm_layer_dims(self.cfg))).to(engine.device)
 
     def make_inner(self, chains, want_episode_stats=False):
         return self.engine.make_inner_td3(self.cfg, chains, want_episode_stats=want_episode_stats, vary=True)
@@ -162,6 +170,8 @@ class Td3VaryTask(object):
         inner.set_hp([h["lr"] for h in hp], [h["batch_size"] for h in hp], [h["hidden_size"] for h in hp],
                      [h["hidden_layer"] for h in hp])
         inner.draw_agent_init(keys_t)
+        if self.icm_bounds is not None:
+            inner.draw_icm_init(keys_t, self.icm_bounds)
         return self.engine.inner_scores_td3(inner, theta, eps, chain_worker, chain_sign, None, keys_t)
 
     def needs_agent_init(self):
@@ -183,8 +193,8 @@ def select_task(config, engine, synthetic_env):
         if not hasattr(real, "tables"):
             raise NotImplementedError("QL needs a discrete (gridworld) real env")
         return QlRnTask(config, engine, real.tables)
-    if agent_name == "td3" and env_type == 1:
+    if agent_name in ("td3", "td3_icm") and env_type == 1:
         return Td3RnTask(config, engine)
-    if agent_name == "td3_vary" and env_type == 1:
+    if agent_name in ("td3_vary", "td3_icm_vary") and env_type == 1:
         return Td3VaryTask(config, engine) if config["agents"]["td3_vary"]["vary_hp"] else Td3RnTask(config, engine)
     raise NotImplementedError("inner agent '%s' on synthetic_env_type %s has no fused kernel yet" % (agent_name, env_type))

@@ -60,8 +60,10 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
 
 def icm_layer_dims(cfg):
     """[(fan_in, fan_out), ...] of ICMModel's nn.Linear layers in state-dict order (models/icm_baseline.py:42-78)."""
-    S, A, F, H = cfg.state_dim, cfg.num_actions, cfg.icm_feature_dim, cfg.icm_hidden
-    Ai = 1 if A == 2 else A
+    S, F, H = cfg.state_dim, cfg.icm_feature_dim, cfg.icm_hidden
+    discrete = hasattr(cfg, "num_actions")           # a TD3 cfg has action_dim: continuous actions, the vector itself is the input
+    A = cfg.num_actions if discrete else cfg.action_dim
+    Ai = 1 if (discrete and A == 2) else A
     C = F + Ai
     return ([(S, H), (H, H), (H, F)] + [(2 * F, H), (H, H), (H, Ai)] + [(C, H), (H, H), (H, F)] + [(C, F), (C, F)] * 4
             + [(F, H), (H, F)])
@@ -154,6 +156,11 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
                       gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), action_std=float(a["action_std"]),
                       policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=1.0,
                       adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, step_budget=int(a.get("step_budget", 0)))
+    name = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "td3"
+    if name.replace("_vary", "").endswith("_icm"):   # select_agent "td3_icm" / "td3_icm_vary": TD3(icm=True), agents/TD3.py:44-60
+        ic = config["agents"]["icm"]
+        cfg.icm_enabled, cfg.icm_feature_dim, cfg.icm_hidden = 1, int(ic["feature_dim"]), int(ic["hidden_size"])
+        cfg.icm_lr, cfg.icm_beta, cfg.icm_eta = float(ic["lr"]), float(ic["beta"]), float(ic["eta"])
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg

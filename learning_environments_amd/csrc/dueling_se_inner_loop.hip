@@ -16,6 +16,7 @@
 // products by changing strides.  This is the configuration where HBM traffic is real: ~5 MB of weight/Adam streaming
 // per learn step and chain.
 #include "lenv_gemm.cuh"
+#include "lenv_icm.cuh"
 
 namespace lenv {
 
@@ -24,31 +25,6 @@ constexpr int D_MAXW = 128;       // max feature_dim (head width) and test episo
 constexpr int D_MAXH = 512;       // max hidden_size  (outputs wider than 128 run as several 128-column blocks)
 constexpr int D_MAXB = 640;       // max batch size   (more than 128 rows run as several 128-row blocks)
 constexpr int D_MAXI = 128;       // rows of one product block
-
-// ---- Intrinsic Curiosity Module (models/icm_baseline.py:8-172; oracle/lenv_oracle_icm.inc is the canonical restatement) ----
-struct IcmLin { int in, out, oW, ob; };
-struct IcmNet { int S, A, Ai, F, H, C, P; IcmLin feat[3], inv[3], pre[3], res[4][2], post[2]; };
-
-__host__ __device__ inline void icm_lin_set(IcmLin &L, int in, int out, int &o) { L.in = in; L.out = out; L.oW = o; o += in * out; L.ob = o; o += out; }
-
-// ICMModel.__init__ in state-dict order: features S-H-H-F, inverse 2F-H-H-Ai, forward_pre (F+Ai)-H-H-F, four residual blocks
-// {fc1, fc2: (F+Ai)-F}, forward_post F-H-F; Ai = 1 for a two-action discrete env (icm_baseline.py:39-40)
-__host__ __device__ inline void icm_build(IcmNet &n, int S, int A, int F, int H)
-{
-    int o = 0;
-    n.S = S; n.A = A; n.Ai = A == 2 ? 1 : A; n.F = F; n.H = H; n.C = F + n.Ai;
-    icm_lin_set(n.feat[0], S, H, o); icm_lin_set(n.feat[1], H, H, o); icm_lin_set(n.feat[2], H, F, o);
-    icm_lin_set(n.inv[0], 2 * F, H, o); icm_lin_set(n.inv[1], H, H, o); icm_lin_set(n.inv[2], H, n.Ai, o);
-    icm_lin_set(n.pre[0], n.C, H, o); icm_lin_set(n.pre[1], H, H, o); icm_lin_set(n.pre[2], H, F, o);
-    for (int k = 0; k < 4; ++k) { icm_lin_set(n.res[k][0], n.C, F, o); icm_lin_set(n.res[k][1], n.C, F, o); }
-    icm_lin_set(n.post[0], F, H, o); icm_lin_set(n.post[1], H, F, o);
-    n.P = o;
-}
-
-// per-chain ICM buffers in the arena
-enum { IB_P, IB_M, IB_V, IB_G, IB_X2, IB_ACT, IB_FH0, IB_FH1, IB_FE, IB_IIN, IB_IH0, IB_IH1, IB_IZ, IB_PIN, IB_PH0, IB_PH1,
-       IB_XC0, IB_XC1, IB_XC2, IB_XC3, IB_XC4, IB_HC0, IB_HC1, IB_HC2, IB_HC3, IB_QH, IB_PRED,
-       IB_DPRED, IB_DZ, IB_DQH, IB_DX, IB_DH, IB_DPH1, IB_DPH0, IB_DFE, IB_DIH1, IB_DIH0, IB_DIIN, IB_DFH1, IB_DFH0, IB_COUNT };
 
 struct DuelArgs {
     lenv_ddqn_cfg cfg;
@@ -187,7 +163,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     IcmNet icm;
     double icm_pows[2] = { 1.0, 1.0 };
     if constexpr (ICM) {
-        icm_build(icm, S, A, cfg.icm_feature_dim, cfg.icm_hidden);
+        icm_build(icm, S, A, cfg.icm_feature_dim, cfg.icm_hidden, /*discrete=*/true);
         float *ip = arena + a.a_icm[IB_P], *im = arena + a.a_icm[IB_M], *iv = arena + a.a_icm[IB_V];
         for (int p = tid; p < icm.P; p += DNT) { ip[p] = a.icm_init[chain * a.P_icm + p]; im[p] = 0.0f; iv[p] = 0.0f; }
     }
@@ -269,125 +245,16 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
         finish_q(0, I, q_out, global_mean);
     };
 
-    // ---- ICM.train + compute_intrinsic_rewards on the gathered minibatch (agents/DDQN.py:74-76); arithmetic and order of
-    // oracle/lenv_oracle_icm.inc: every Linear is a queued product, features_model runs once on the stacked rows [s; s'] ----
+    // ---- ICM.train + compute_intrinsic_rewards on the gathered minibatch (agents/DDQN.py:74-76): lenv_icm.cuh ----
     auto icm_step = [&]() {
         if constexpr (ICM) {
-            const int F = icm.F, Hi = icm.H, Ai = icm.Ai, C = icm.C;
-            auto buf = [&](int i) { return arena + a.a_icm[i]; };
-            float *ip = buf(IB_P), *ig = buf(IB_G), *X2 = buf(IB_X2), *actin = buf(IB_ACT);
-            float *fh0 = buf(IB_FH0), *fh1 = buf(IB_FH1), *fe = buf(IB_FE), *iin = buf(IB_IIN), *ih0 = buf(IB_IH0), *ih1 = buf(IB_IH1), *iz = buf(IB_IZ);
-            float *pin = buf(IB_PIN), *ph0 = buf(IB_PH0), *ph1 = buf(IB_PH1), *qh = buf(IB_QH), *pred = buf(IB_PRED);
-            float *xc[5], *hc[4];
-            for (int k = 0; k < 5; ++k) xc[k] = buf(IB_XC0 + k);
-            for (int k = 0; k < 4; ++k) hc[k] = buf(IB_HC0 + k);
-            constexpr int LK = LENV_ACT_LEAKYRELU, RL = LENV_ACT_RELU;
-            auto lin = [&](const IcmLin &L, const float *X, int ldx, int rows, float *Y, int ldy, int act) {
-                if (act >= 0) gq.gemm(X, ldx, 1, ip + L.oW, L.in, 1, rows, L.out, L.in, epi_bias_act(Y, ldy, ip + L.ob, act, 0.25f));
-                else gq.gemm(X, ldx, 1, ip + L.oW, L.in, 1, rows, L.out, L.in, epi_bias(Y, ldy, 0, ip + L.ob));
-            };
-            // stacked states, action inputs (one logit target for two actions, else one-hot: icm_baseline.py:39-40,134-136) and
-            // the action columns of every concatenated buffer
-            for (int e = tid; e < B * S; e += DNT) { X2[e] = xs[e]; X2[B * S + e] = xs2[e]; }
-            for (int e = tid; e < B * Ai; e += DNT) {
-                const int b = e / Ai, i = e - b * Ai;
-                const float av = Ai == 1 ? dAdv[b * A] : ((int)dAdv[b * A] == i ? 1.0f : 0.0f);
-                actin[e] = av;
-                pin[b * C + F + i] = av;
-                for (int k = 0; k < 5; ++k) xc[k][b * C + F + i] = av;
-                for (int k = 0; k < 4; ++k) hc[k][b * C + F + i] = av;
-            }
-            __syncthreads();
-            auto icm_forward = [&]() {                                  // ICMModel.forward (icm_baseline.py:80-102)
-                lin(icm.feat[0], X2, S, 2 * B, fh0, Hi, LK); lin(icm.feat[1], fh0, Hi, 2 * B, fh1, Hi, LK); lin(icm.feat[2], fh1, Hi, 2 * B, fe, F, -1);
-                gq.run<D_MAXI>(Ps, Qs);
-                for (int e = tid; e < B * F; e += DNT) {
-                    const int b = e / F, f = e - b * F;
-                    const float vs = fe[e], vn = fe[B * F + e];
-                    iin[b * 2 * F + f] = vs; iin[b * 2 * F + F + f] = vn; pin[b * C + f] = vs;
-                }
-                __syncthreads();
-                lin(icm.inv[0], iin, 2 * F, B, ih0, Hi, RL); lin(icm.inv[1], ih0, Hi, B, ih1, Hi, RL); lin(icm.inv[2], ih1, Hi, B, iz, Ai, -1);
-                lin(icm.pre[0], pin, C, B, ph0, Hi, LK); lin(icm.pre[1], ph0, Hi, B, ph1, Hi, LK); lin(icm.pre[2], ph1, Hi, B, xc[0], C, -1);
-                for (int k = 0; k < 4; ++k) {
-                    lin(icm.res[k][0], xc[k], C, B, hc[k], C, LK);
-                    const IcmLin &L2 = icm.res[k][1];                   // x_{k+1} = x_k + fc2([fc1([x_k | a]) | a])
-                    gq.gemm(hc[k], C, 1, ip + L2.oW, L2.in, 1, B, L2.out, L2.in, epi_bias_add(xc[k + 1], C, ip + L2.ob, xc[k], C));
-                }
-                lin(icm.post[0], xc[4], C, B, qh, Hi, LK); lin(icm.post[1], qh, Hi, B, pred, F, -1);
-                gq.run<D_MAXI>(Ps, Qs);
-            };
-            icm_forward();
-            // ---- loss gradients: beta * mse(forward, features(s')) and (1 - beta) * BCEWithLogits | CrossEntropy(inverse, action) ----
-            float *dpred = buf(IB_DPRED), *dz = buf(IB_DZ), *dqh = buf(IB_DQH), *dx = buf(IB_DX), *dh = buf(IB_DH), *dph1 = buf(IB_DPH1);
-            float *dph0 = buf(IB_DPH0), *dfe = buf(IB_DFE), *dih1 = buf(IB_DIH1), *dih0 = buf(IB_DIH0), *diin = buf(IB_DIIN), *dfh1 = buf(IB_DFH1), *dfh0 = buf(IB_DFH0);
-            const float c_mse = (float)(cfg.icm_beta * 2.0 / ((double)B * F)), c_act = (float)((1.0 - cfg.icm_beta) / (double)B);
-            for (int e = tid; e < B * F; e += DNT) dpred[e] = c_mse * (pred[e] - fe[B * F + e]);
-            for (int b = tid; b < B; b += DNT) {
-                if (Ai == 1) {
-                    const float sg = fma32(0.5f, det_tanhf(lenv_tanh_table, 0.5f * iz[b]), 0.5f);
-                    dz[b] = c_act * (sg - actin[b]);
-                } else {
-                    float mx = iz[b * A];
-                    for (int i = 1; i < A; ++i) if (iz[b * A + i] > mx) mx = iz[b * A + i];
-                    float ex[4], sm = 0.0f;                           // A <= 3 for the supported envs
-                    for (int i = 0; i < A; ++i) { ex[i] = det_expf(iz[b * A + i] - mx); sm = sm + ex[i]; }
-                    for (int i = 0; i < A; ++i) dz[b * A + i] = c_act * (ex[i] / sm - actin[b * A + i]);
-                }
-            }
-            __syncthreads();
-            // ---- backward: per Linear dW = dY^T X (reduction over the rows), db = column sums, dX = dY W ----
-            auto bw_w = [&](const IcmLin &L, const float *dY, int ldd, const float *X, int ldx, int rows) {
-                gq.gemm(dY, 1, ldd, X, 1, ldx, L.out, L.in, rows, epi_store(ig + L.oW, L.in));
-                gq.colsum(dY, rows, ldd, L.out, ig + L.ob);
-            };
-            auto bw_x = [&](const IcmLin &L, const float *dY, int ldd, int rows, int ncols, const GemmEpi &ep) {
-                gq.gemm(dY, ldd, 1, ip + L.oW, 1, L.in, rows, ncols, L.out, ep);
-            };
-            bw_w(icm.post[1], dpred, F, qh, Hi, B); bw_x(icm.post[1], dpred, F, B, Hi, epi_act_bwd(dqh, Hi, qh, Hi, LK, 0.25f));
-            bw_w(icm.post[0], dqh, Hi, xc[4], C, B); bw_x(icm.post[0], dqh, Hi, B, F, epi_store(dx, F));
-            for (int k = 3; k >= 0; --k) {
-                bw_w(icm.res[k][1], dx, F, hc[k], C, B); bw_x(icm.res[k][1], dx, F, B, F, epi_act_bwd(dh, F, hc[k], C, LK, 0.25f));
-                bw_w(icm.res[k][0], dh, F, xc[k], C, B); bw_x(icm.res[k][0], dh, F, B, F, epi_accum(dx, F));
-            }
-            gq.run<D_MAXI>(Ps, Qs);
-            bw_w(icm.pre[2], dx, F, ph1, Hi, B); bw_x(icm.pre[2], dx, F, B, Hi, epi_act_bwd(dph1, Hi, ph1, Hi, LK, 0.25f));
-            bw_w(icm.pre[1], dph1, Hi, ph0, Hi, B); bw_x(icm.pre[1], dph1, Hi, B, Hi, epi_act_bwd(dph0, Hi, ph0, Hi, LK, 0.25f));
-            bw_w(icm.pre[0], dph0, Hi, pin, C, B); bw_x(icm.pre[0], dph0, Hi, B, F, epi_store(dfe, F));
-            bw_w(icm.inv[2], dz, Ai, ih1, Hi, B); bw_x(icm.inv[2], dz, Ai, B, Hi, epi_act_bwd(dih1, Hi, ih1, Hi, RL, 0.25f));
-            bw_w(icm.inv[1], dih1, Hi, ih0, Hi, B); bw_x(icm.inv[1], dih1, Hi, B, Hi, epi_act_bwd(dih0, Hi, ih0, Hi, RL, 0.25f));
-            bw_w(icm.inv[0], dih0, Hi, iin, 2 * F, B); bw_x(icm.inv[0], dih0, Hi, B, 2 * F, epi_store(diin, 2 * F));
-            gq.run<D_MAXI>(Ps, Qs);
-            for (int e = tid; e < B * F; e += DNT) {                    // gradient at features([s; s'])
-                const int b = e / F, f = e - b * F;
-                dfe[e] = dfe[e] + diin[b * 2 * F + f];                 // features(s): forward_pre + inverse
-                dfe[B * F + e] = diin[b * 2 * F + F + f] - dpred[e];   // features(s'): inverse + mse target
-            }
-            __syncthreads();
-            bw_w(icm.feat[2], dfe, F, fh1, Hi, 2 * B); bw_x(icm.feat[2], dfe, F, 2 * B, Hi, epi_act_bwd(dfh1, Hi, fh1, Hi, LK, 0.25f));
-            bw_w(icm.feat[1], dfh1, Hi, fh0, Hi, 2 * B); bw_x(icm.feat[1], dfh1, Hi, 2 * B, Hi, epi_act_bwd(dfh0, Hi, fh0, Hi, LK, 0.25f));
-            bw_w(icm.feat[0], dfh0, Hi, X2, S, 2 * B);
-            gq.run<D_MAXI>(Ps, Qs);
-            // ---- torch.optim.Adam over all ICM parameters (lr = icm.lr), then the intrinsic rewards of the UPDATED model ----
-            if (tid == 0) {
-                icm_pows[0] *= cfg.adam_beta1; icm_pows[1] *= cfg.adam_beta2;
-                ctrl[12] = (float)(-(cfg.icm_lr / (1.0 - icm_pows[0])));
-                ctrl[13] = (float)__builtin_sqrt(1.0 - icm_pows[1]);
-            }
-            __syncthreads();
-            {
-                const AdamConsts ac{ ctrl[12], ctrl[13], (float)(1.0 - cfg.adam_beta1), (float)(1.0 - cfg.adam_beta2), (float)cfg.adam_beta2, (float)cfg.adam_eps };
-                wg_adam(ip, buf(IB_M), buf(IB_V), ig, 0, icm.P, ac, nullptr, 0.0f, 0.0f);
-            }
-            __syncthreads();
-            icm_forward();
-            const float eta = (float)cfg.icm_eta;
-            for (int b = tid; b < B; b += DNT) {                        // rewards += eta * mean_f (features(s') - forward)^2
-                float sm = 0.0f;
-                for (int f = 0; f < F; ++f) { const float d = fe[(B + b) * F + f] - pred[b * F + f]; sm = fma32(d, d, sm); }
-                dAdv[b * A + 1] = dAdv[b * A + 1] + eta * (sm / (float)F);
-            }
-            __syncthreads();
+            IcmStep st{ gq, Ps, Qs, arena, a.a_icm, ctrl, 12, icm, icm_pows, cfg.icm_lr, cfg.icm_beta, cfg.icm_eta, cfg.adam_beta1, cfg.adam_beta2,
+                        cfg.adam_eps, B, xs, S, xs2, S, /*continuous=*/false };
+            const int Ai = icm.Ai;
+            // action inputs: the index itself for two actions (one BCE logit), else its one-hot (icm_baseline.py:39-40,134-136);
+            // the sampled (a, r, done) sit in dAdv / dq until the TD step
+            icm_train_and_reward<D_MAXI>(st, [&](int b, int i) { return Ai == 1 ? dAdv[b * A] : ((int)dAdv[b * A] == i ? 1.0f : 0.0f); },
+                                         [&](int b, float r) { dAdv[b * A + 1] = dAdv[b * A + 1] + r; });
         }
     };
 
@@ -826,12 +693,10 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
         const int Fi = cfg->icm_feature_dim, Hi = cfg->icm_hidden;
         if (Fi < 1 || Fi > D_MAXW || Hi < 1 || Hi > D_MAXW) return LENV_ERR_UNSUPPORTED;
         IcmNet n;
-        icm_build(n, S, A, Fi, Hi);
+        icm_build(n, S, A, Fi, Hi, /*discrete=*/true);
         a.P_icm = n.P;
-        const int64_t b = B, b2 = 2 * (int64_t)B;
-        const int64_t sz[IB_COUNT] = { n.P, n.P, n.P, n.P, b2 * S, b * n.Ai, b2 * Hi, b2 * Hi, b2 * Fi, b * 2 * Fi, b * Hi, b * Hi, b * n.Ai, b * n.C, b * Hi, b * Hi,
-                                       b * n.C, b * n.C, b * n.C, b * n.C, b * n.C, b * n.C, b * n.C, b * n.C, b * n.C, b * Hi, b * Fi,
-                                       b * Fi, b * n.Ai, b * Hi, b * Fi, b * Fi, b * Hi, b * Hi, b2 * Fi, b * Hi, b * Hi, b * 2 * Fi, b2 * Hi, b2 * Hi };
+        int64_t sz[IB_COUNT];
+        icm_buffer_sizes(n, B, sz);
         for (int i = 0; i < IB_COUNT; ++i) a.a_icm[i] = take(sz[i]);
     }
     a.arena_stride = (off + 63) & ~(int64_t)63;

@@ -14,6 +14,7 @@
 // step (phi(s') of step t is phi(s) of step t+1).  Gaussian noises come from RNG tapes (parity mode) or from the
 // counter RNG through a Box-Muller with deterministic log / cos (production mode).
 #include "lenv_gemm.cuh"
+#include "lenv_icm.cuh"
 
 namespace lenv {
 
@@ -47,6 +48,9 @@ struct Td3Args {
     int P, P_rn;                              // P = row stride of agent_init / final_params
     // per-chain hyper-parameters (device arrays [chains], all or none): TD3_vary (agents/TD3_vary.py:24-58)
     const double *hp_lr; const int32_t *hp_batch, *hp_hidden, *hp_layers;
+    // TD3(icm=True) (agents/TD3.py:44-60,68-70): fresh ICM parameters per chain, optional final parameters, arena offsets
+    const float *icm_init; float *icm_final; int P_icm;
+    int64_t a_icm[IB_COUNT];
     int64_t a_params, a_targets, a_m, a_v, a_grad, a_replay, a_xc, a_xn, a_xa, a_hc1[T3_MAXL], a_hc2[T3_MAXL], a_ha[T3_MAXL],
         a_ht[T3_MAXL], a_d[2], a_dx, a_act, a_th, a_dz, a_meter;
 };
@@ -61,6 +65,7 @@ __device__ unsigned long long g_td3_phase_cycles[16];
 #define PT_MARK(i)
 #endif
 
+template <bool ICM>
 __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
 {
     extern __shared__ __align__(16) float lds[];
@@ -120,6 +125,14 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     for (int p = tid; p < P; p += DNT) {
         const float w = a.agent_init[chain * a.P + p];
         params[p] = w; targets[p] = w; adam_m[p] = 0.0f; adam_v[p] = 0.0f;
+    }
+    // fresh ICM (continuous actions: the action vector is the model input, MSE inverse loss -- icm_baseline.py:121-122)
+    IcmNet icm;
+    double icm_pows[2] = { 1.0, 1.0 };
+    if constexpr (ICM) {
+        icm_build(icm, S, A, cfg.icm_feature_dim, cfg.icm_hidden, /*discrete=*/false);
+        float *ip = arena + a.a_icm[IB_P], *im = arena + a.a_icm[IB_M], *iv = arena + a.a_icm[IB_V];
+        for (int p = tid; p < icm.P; p += DNT) { ip[p] = a.icm_init[chain * a.P_icm + p]; im[p] = 0.0f; iv[p] = 0.0f; }
     }
     if (tid < 64) misc[tid] = 0.0f;
     __syncthreads();
@@ -384,6 +397,11 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     rr[b] = row[2 * S + A]; dd[b] = row[2 * S + A + 1];
                 }
                 __syncthreads();
+                if constexpr (ICM) {                     // TD3.py:68-70: icm.train, then rewards += intrinsic rewards
+                    IcmStep st{ gq, Ps, Qs, arena, a.a_icm, ctrl, 20, icm, icm_pows, cfg.icm_lr, cfg.icm_beta, cfg.icm_eta, cfg.adam_beta1,
+                                cfg.adam_beta2, cfg.adam_eps, B, xc, SA, xn, SA, /*continuous=*/true };
+                    icm_train_and_reward<T3_MAXI>(st, [&](int b, int i) { return xc[b * SA + S + i]; }, [&](int b, float r) { rr[b] = rr[b] + r; });
+                }
                 PT_MARK(1);                               // replay gather
                 // next_actions = (actor_target(s') + clamp(randn*policy_std)).clamp(-max, max)
                 mlp_forward(targets, mo_actor, xn, SA, B, ht, xn, SA, S, true, nullptr);
@@ -533,6 +551,9 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         }
     }
     if (a.out.final_params) for (int p = tid; p < P; p += DNT) a.out.final_params[chain * a.P + p] = params[p];
+    if constexpr (ICM) {
+        if (a.icm_final) for (int p = tid; p < icm.P; p += DNT) a.icm_final[chain * a.P_icm + p] = arena[a.a_icm[IB_P] + p];
+    }
     if (a.out.status && status != 0) atomicMin(&a.out.status[chain], status);
 }
 
@@ -595,6 +616,17 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
     a.a_d[0] = take((int64_t)RB * H); a.a_d[1] = take((int64_t)RB * H);
     a.a_dx = take((int64_t)RB * T3_SA); a.a_act = take((int64_t)RB * T3_A); a.a_th = take((int64_t)RB * T3_A); a.a_dz = take((int64_t)RB * T3_A);
     a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
+    a.P_icm = 0;
+    for (int i = 0; i < IB_COUNT; ++i) a.a_icm[i] = 0;
+    if (cfg->icm_enabled) {
+        if (cfg->icm_feature_dim < 1 || cfg->icm_feature_dim > 128 || cfg->icm_hidden < 1 || cfg->icm_hidden > 128) return LENV_ERR_UNSUPPORTED;
+        IcmNet n;
+        icm_build(n, T3_S, T3_A, cfg->icm_feature_dim, cfg->icm_hidden, /*discrete=*/false);
+        a.P_icm = n.P;
+        int64_t sz[IB_COUNT];
+        icm_buffer_sizes(n, B, sz);
+        for (int i = 0; i < IB_COUNT; ++i) a.a_icm[i] = take(sz[i]);
+    }
     a.arena_stride = (off + 63) & ~(int64_t)63;
     const size_t lds_floats = GemmShape<T3_MAXI>::PS_FLOATS + GemmShape<T3_MAXI>::QS_FLOATS + GEMM_QUEUE_MAX * sizeof(GemmCmd) / sizeof(float) + ((a.P_rn + 3) & ~3) + ((Hrn + 3) & ~3) + 8 * (size_t)B + 64 + 2 + 2 * (20 + 17 * (size_t)T + T) + T + 20 + 8 + 56 + 16;
     *lds_bytes = lds_floats * sizeof(float);
@@ -647,12 +679,32 @@ extern "C" int lenv_td3_agent_init_hp(const lenv_td3_cfg *cfg, const lenv_chain_
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }
 
+extern "C" int64_t lenv_td3_icm_num_params(const lenv_td3_cfg *cfg)
+{
+    if (!cfg || !cfg->icm_enabled) return LENV_ERR_INVALID;
+    Td3Args a;
+    size_t lds;
+    const int rc = td3_layout(cfg, a, &lds);
+    return rc != LENV_OK ? rc : a.P_icm;
+}
+
 extern "C" int lenv_td3_rn_inner_loop_hp(const lenv_td3_cfg *cfg, const lenv_chain_hp *hp, const float *theta, const float *eps,
                                          const int32_t *worker, const float *sign, const float *agent_init, const uint64_t *rng_keys,
                                          const lenv_td3_tapes *tapes, int64_t chains, void *workspace, size_t workspace_bytes,
                                          const lenv_td3_out *out, void *stream)
 {
+    if (cfg && cfg->icm_enabled) return LENV_ERR_INVALID;              // TD3(icm=True) needs lenv_td3_rn_inner_loop_icm
+    return lenv_td3_rn_inner_loop_icm(cfg, hp, nullptr, theta, eps, worker, sign, agent_init, rng_keys, tapes, chains, workspace,
+                                      workspace_bytes, out, stream);
+}
+
+extern "C" int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg, const lenv_chain_hp *hp, const lenv_icm_io *icm, const float *theta,
+                                          const float *eps, const int32_t *worker, const float *sign, const float *agent_init,
+                                          const uint64_t *rng_keys, const lenv_td3_tapes *tapes, int64_t chains, void *workspace,
+                                          size_t workspace_bytes, const lenv_td3_out *out, void *stream)
+{
     if (hp && (!hp->lr || !hp->batch_size || !hp->q_hidden || !hp->q_layers)) return LENV_ERR_INVALID;
+    if (cfg && cfg->icm_enabled && (!icm || !icm->icm_init)) return LENV_ERR_INVALID;
     if (!cfg || !agent_init || !out || !out->score || !workspace || chains < 0) return LENV_ERR_INVALID;
     if (!theta && cfg->reward_env_type != 0) return LENV_ERR_INVALID;
     if (eps && (!worker || !sign)) return LENV_ERR_INVALID;
@@ -671,13 +723,16 @@ extern "C" int lenv_td3_rn_inner_loop_hp(const lenv_td3_cfg *cfg, const lenv_cha
     a.out = *out;
     a.hp_lr = hp ? hp->lr : nullptr; a.hp_batch = hp ? hp->batch_size : nullptr;
     a.hp_hidden = hp ? hp->q_hidden : nullptr; a.hp_layers = hp ? hp->q_layers : nullptr;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(td3_rn_inner_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    a.icm_init = cfg->icm_enabled ? icm->icm_init : nullptr; a.icm_final = cfg->icm_enabled ? icm->icm_final : nullptr;
+    const void *kfn = cfg->icm_enabled ? reinterpret_cast<const void *>(td3_rn_inner_kernel<true>) : reinterpret_cast<const void *>(td3_rn_inner_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;
     if (out->status) {
         e = hipMemsetAsync(out->status, 0, sizeof(int32_t) * chains, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return LENV_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(td3_rn_inner_kernel, dim3((unsigned)chains), dim3(DNT), lds_bytes, static_cast<hipStream_t>(stream), a);
+    if (cfg->icm_enabled) hipLaunchKernelGGL(td3_rn_inner_kernel<true>, dim3((unsigned)chains), dim3(DNT), lds_bytes, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(td3_rn_inner_kernel<false>, dim3((unsigned)chains), dim3(DNT), lds_bytes, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }
 

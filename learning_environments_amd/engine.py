@@ -147,6 +147,15 @@ def _set_chain_hp(obj, lr, batch_size, hidden_size, hidden_layer, max_batch, max
     obj.hp["q_layers"].copy_(torch.tensor(layers, dtype=torch.int32))
 
 
+def _draw_icm_init(obj, rng_keys, bounds):
+    """Fresh ICMModel parameters per chain into obj.icm_init (nn.Linear default init with `bounds` [p_icm], counter-RNG stream
+    12 of every chain key)."""
+    _chk(rng_keys, torch.int64, "rng_keys"); _chk(bounds, torch.float32, "bounds")
+    rc = _lib.lib().lenv_chain_uniform_init(_ptr(rng_keys), obj.chains, 12, obj.p_icm, _ptr(bounds), _ptr(obj.icm_init), _stream())
+    _lib.check(rc, "lenv_chain_uniform_init")
+    return obj.icm_init
+
+
 class InnerLoop(object):
     """Owns the workspace/outputs of lenv_ddqn_se_inner_loop for a fixed (cfg, chains)."""
 
@@ -221,12 +230,7 @@ class InnerLoop(object):
         return n
 
     def draw_icm_init(self, rng_keys, bounds):
-        """Fresh ICMModel parameters per chain into self.icm_init (nn.Linear default init with `bounds` [p_icm], counter-RNG
-        stream 12 of every chain key)."""
-        _chk(rng_keys, torch.int64, "rng_keys"); _chk(bounds, torch.float32, "bounds")
-        rc = _lib.lib().lenv_chain_uniform_init(_ptr(rng_keys), self.chains, 12, self.p_icm, _ptr(bounds), _ptr(self.icm_init), _stream())
-        _lib.check(rc, "lenv_chain_uniform_init")
-        return self.icm_init
+        return _draw_icm_init(self, rng_keys, bounds)
 
     def draw_agent_init(self, rng_keys):
         """Fresh agents at every chain's own shapes into self.agent_init (nn.Linear default init, keyed by the chain keys)."""
@@ -333,6 +337,14 @@ class Td3InnerLoop(object):
         _lib.check(min(self.p_agent, 0), "lenv_td3_num_params")
         if self.vary:
             _alloc_chain_hp(self)
+        self.icm = bool(cfg.icm_enabled)               # TD3(icm=True): select_agent "td3_icm" / "td3_icm_vary"
+        self.icm_init = self.icm_final = self.icm_io = None
+        if self.icm:
+            self.p_icm = int(L.lenv_td3_icm_num_params(C.byref(cfg)))
+            _lib.check(min(self.p_icm, 0), "lenv_td3_icm_num_params")
+            self.icm_init = torch.zeros((self.chains, self.p_icm), dtype=torch.float32, device=self.dev)
+            self.icm_final = torch.zeros((self.chains, self.p_icm), dtype=torch.float32, device=self.dev)
+            self.icm_io = _lib.IcmIo(_ptr(self.icm_init), _ptr(self.icm_final))
         self.p_actor, self.p_critic = pa.value, pc.value
         self.p_theta = cfg.state_dim * cfg.rn_hidden + 2 * cfg.rn_hidden + 1
         self.ws_bytes = int(L.lenv_td3_rn_workspace_bytes(C.byref(cfg), self.chains))
@@ -370,6 +382,9 @@ class Td3InnerLoop(object):
         _lib.check(min(n, 0), "lenv_td3_num_params")
         return n
 
+    def draw_icm_init(self, rng_keys, bounds):
+        return _draw_icm_init(self, rng_keys, bounds)
+
     def draw_agent_init(self, rng_keys):
         """Fresh actor | critic_1 | critic_2 at every chain's own shapes into self.agent_init."""
         _chk(rng_keys, torch.int64, "rng_keys")
@@ -395,7 +410,10 @@ class Td3InnerLoop(object):
             _chk(rng_keys, torch.int64, "rng_keys")
         args = (_ptr(theta), _ptr(eps), _ptr(worker), _ptr(sign), _ptr(agent_init), _ptr(rng_keys),
                 C.byref(t) if t is not None else None, self.chains, _ptr(self.workspace), self.ws_bytes, C.byref(self.out), _stream())
-        if self.vary:
+        if self.icm:
+            rc = _lib.lib().lenv_td3_rn_inner_loop_icm(C.byref(self.cfg), C.byref(self.hp_struct) if self.vary else None,
+                                                       C.byref(self.icm_io), *args)
+        elif self.vary:
             rc = _lib.lib().lenv_td3_rn_inner_loop_hp(C.byref(self.cfg), C.byref(self.hp_struct), *args)
         else:
             rc = _lib.lib().lenv_td3_rn_inner_loop(C.byref(self.cfg), *args)

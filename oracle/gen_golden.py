@@ -864,7 +864,7 @@ def gen_g4t():
     save("g4t_td3_learn", **out)
 
 
-def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None):
+def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over=None):
     import json
     import statistics
     import agents.GTN_worker as gw
@@ -874,6 +874,9 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None):
     cfg = _td3_cfg(agent_over or {"train_episodes": 4, "init_episodes": 2, "batch_size": 16, "hidden_size": 24, "test_episodes": 2},
                    env_over or {"max_steps": 7, "hidden_size": 20})
     drawn = {}
+    if icm_over is not None:                      # select_agent "td3_icm": TD3(icm=True), agents/TD3.py:44-60,68-70
+        cfg["agents"]["gtn"]["agent_name"] = "td3_icm"
+        cfg["agents"].setdefault("icm", {"lr": 1e-4, "beta": 0.2, "eta": 0.5, "feature_dim": 32, "hidden_size": 128}).update(icm_over)
     if vary_seed is not None:
         # TD3_vary (agents/TD3_vary.py:24-58): the draw of the ConfigSpace stand-in is recorded in the fixture
         import ConfigSpace
@@ -927,6 +930,10 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None):
     def wrapped_select_agent(config, agent_name):
         agent = orig_select_agent(config=config, agent_name=agent_name)
         holder["init"] = _pack_td3(agent)
+        holder["agent"] = agent
+        if getattr(agent, "icm", None):
+            holder["icm_init"] = np.concatenate([v.detach().cpu().numpy().astype(np.float32).reshape(-1)
+                                                 for v in agent.icm.model.state_dict().values()])
 
         def wrap(fn, purpose):
             def inner(*a, **k):
@@ -976,7 +983,12 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None):
             gw.select_agent = orig_select_agent
     if vary_seed is not None:
         ConfigSpace.ConfigurationSpace.sample_configuration = orig_sample
-    save(name, config_json=np.array(json.dumps(cfg)), hp_json=np.array(json.dumps(drawn)), theta=theta, agent_init=holder["init"],
+    extra = {}
+    if "icm_init" in holder:
+        extra["icm_init"] = holder["icm_init"]
+        extra["icm_final"] = np.concatenate([v.detach().cpu().numpy().astype(np.float32).reshape(-1)
+                                             for v in holder["agent"].icm.model.state_dict().values()])
+    save(name, config_json=np.array(json.dumps(cfg)), hp_json=np.array(json.dumps(drawn)), theta=theta, agent_init=holder["init"], **extra,
          tape_rand_action=np.stack(rec["rand"][1::2]).astype(np.float32),          # get_random_action samples twice, returns the 2nd
          tape_act_noise=np.stack(rec["act_noise"]).astype(np.float32), tape_test_noise=np.stack(rec["test_noise"]).astype(np.float32),
          tape_policy_noise=np.stack(rec["policy_noise"]).astype(np.float32).reshape(-1, 6),
@@ -1014,6 +1026,10 @@ def main():
         gen_g8t("g8tv_calc_score_cheetah_td3_vary", seed=832, vary_seed=8,
                 agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 64, "hidden_size": 48, "hidden_layer": 2, "test_episodes": 1},
                 env_over={"max_steps": 10, "hidden_size": 24})          # draws batch 145, width 108, 3 hidden layers
+    if "g8ti" in which:
+        gen_g8t("g8ti_calc_score_cheetah_td3_icm", seed=833,
+                agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 16, "hidden_size": 24, "test_episodes": 1},
+                env_over={"max_steps": 8, "hidden_size": 20}, icm_over={"feature_dim": 12, "hidden_size": 20})
     if "g8tf" in which:
         # BASELINE configs[4] at its REAL network shapes (actor 17-128-128-6, critics 23-128-128-1, B 192, RN 17-128-1)
         gen_g8t("g8tf_calc_score_cheetah_td3_fullshape", seed=831,

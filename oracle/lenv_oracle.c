@@ -912,7 +912,7 @@ int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const
     float *icm_p = NULL, *icm_m = NULL, *icm_v = NULL, *r_intr = NULL;
     double icm_pows[2] = { 1.0, 1.0 };
     if (cfg->icm_enabled) {
-        icm_build(&icm, S, A, cfg->icm_feature_dim, cfg->icm_hidden);
+        icm_build(&icm, S, A, cfg->icm_feature_dim, cfg->icm_hidden, 1);
         icm_p = malloc(sizeof(float) * icm.P); icm_m = calloc(icm.P, sizeof(float)); icm_v = calloc(icm.P, sizeof(float));
         r_intr = malloc(sizeof(float) * B);
         memcpy(icm_p, icm_init, sizeof(float) * icm.P);
@@ -960,7 +960,7 @@ int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const
         else { eps *= cfg->eps_decay; if (eps < cfg->eps_min) eps = cfg->eps_min; }
 
         double st0[4];
-        float state[64], next_state[64], x[64], q[ORC_MAX_WIDTH];
+        float state[64], next_state[64], x[64];
         draw_reset(&rng, 1, rng.n_train_ep++, st0);
         real_env_obs(cfg->env_id, st0, state);   /* VirtualEnv.reset -> fp32 real-env reset state (virtual_env.py:35-41) */
         int ep_len = 0;
@@ -994,7 +994,7 @@ int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const
                 }
                 ++learn_it;
                 if (cfg->icm_enabled) {          /* DDQN.py:74-76 / DuelingDDQN.py: icm.train, then rewards += intrinsic rewards */
-                    icm_train_and_reward(&icm, &ihp, icm_p, icm_m, icm_v, icm_pows, batch, row_stride, B, r_intr);
+                    icm_train_and_reward(&icm, &ihp, icm_p, icm_m, icm_v, icm_pows, batch, row_stride, S + 1, 1, B, r_intr);
                     for (int b = 0; b < B; ++b) batch[(int64_t)b * row_stride + 2 * S + 1] = batch[(int64_t)b * row_stride + 2 * S + 1] + r_intr[b];
                 }
                 loss = cfg->agent_kind == 1 ? orc_dueling_learn(cfg, online, target, am, av, &b1pow, &b2pow, batch, row_stride)

@@ -214,6 +214,9 @@ typedef struct {
     double solved_reward, gamma, lr, tau, action_std, policy_std, policy_std_clip, max_action;
     double adam_beta1, adam_beta2, adam_eps;
     int64_t step_budget;
+    /* TD3(icm=True), select_agent "td3_icm" (agents/TD3.py:44-60,68-70): config section `icm` */
+    int32_t icm_enabled, icm_feature_dim, icm_hidden, icm_pad_;
+    double icm_lr, icm_beta, icm_eta;
 } orc_td3_cfg;
 
 typedef struct {

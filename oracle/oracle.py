@@ -76,7 +76,9 @@ class Td3Cfg(C.Structure):
                 ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
                 ("action_std", C.c_double), ("policy_std", C.c_double), ("policy_std_clip", C.c_double),
                 ("max_action", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
-                ("step_budget", C.c_int64)]
+                ("step_budget", C.c_int64),
+                ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("icm_pad_", C.c_int32),
+                ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double)]
 
 
 class Td3Tapes(C.Structure):
@@ -514,6 +516,11 @@ def td3_cfg_from_config(config, rng_mode=0, **overrides):
                  gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), action_std=float(a["action_std"]),
                  policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=1.0,
                  adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, step_budget=int(a.get("step_budget", 0)))
+    name = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "td3"
+    if name.replace("_vary", "").endswith("_icm"):   # select_agent "td3_icm": TD3(icm=True), agents/TD3.py:44-60
+        ic = config["agents"]["icm"]
+        cfg.icm_enabled, cfg.icm_feature_dim, cfg.icm_hidden = 1, int(ic["feature_dim"]), int(ic["hidden_size"])
+        cfg.icm_lr, cfg.icm_beta, cfg.icm_eta = float(ic["lr"]), float(ic["beta"]), float(ic["eta"])
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg
@@ -564,7 +571,13 @@ def make_td3_tapes(rand_action, act_noise, test_noise, policy_noise, replay_idx,
     return t
 
 
-def td3_rn_chain(cfg, rn_params, agent_init, rng_key=0, tapes=None, trace_cap=0):
+def td3_icm_num_params(cfg):
+    L = lib()
+    L.orc_icm_num_params_continuous.restype = C.c_int64
+    return int(L.orc_icm_num_params_continuous(cfg.state_dim, cfg.action_dim, cfg.icm_feature_dim, cfg.icm_hidden))
+
+
+def td3_rn_chain(cfg, rn_params, agent_init, rng_key=0, tapes=None, trace_cap=0, icm_init=None):
     rn_params, agent_init = _f32(rn_params), _f32(agent_init)
     E, T, S, A = cfg.train_episodes, cfg.test_episodes, cfg.state_dim, cfg.action_dim
     ep_mean = np.full(max(E, 1), np.nan)
@@ -577,13 +590,25 @@ def td3_rn_chain(cfg, rn_params, agent_init, rng_key=0, tapes=None, trace_cap=0)
                     next_state=np.zeros((trace_cap, S), np.float32), reward=np.zeros(trace_cap, np.float32))
         tr = Td3Trace(trace_cap, 0, _p(arrs["action"], C.c_float), _p(arrs["state"], C.c_float), _p(arrs["next_state"], C.c_float),
                       _p(arrs["reward"], C.c_float))
-    rc = lib().orc_td3_rn_chain(C.byref(cfg), _p(rn_params, C.c_float), _p(agent_init, C.c_float), C.c_uint64(rng_key),
-                                C.byref(tapes) if tapes is not None else None, _p(ep_mean, C.c_double), _p(ep_len, C.c_int32),
-                                _p(final, C.c_double), C.byref(tr) if tr is not None else None, C.byref(res))
+    icm_final = None
+    if icm_init is not None:
+        icm_init = _f32(icm_init)
+        assert icm_init.size == td3_icm_num_params(cfg), (icm_init.size, td3_icm_num_params(cfg))
+        icm_final = np.zeros_like(icm_init)
+        rc = lib().orc_td3_rn_chain_icm(C.byref(cfg), _p(rn_params, C.c_float), _p(agent_init, C.c_float), _p(icm_init, C.c_float),
+                                        C.c_uint64(rng_key), C.byref(tapes) if tapes is not None else None, _p(ep_mean, C.c_double),
+                                        _p(ep_len, C.c_int32), _p(final, C.c_double), C.byref(tr) if tr is not None else None,
+                                        C.byref(res), _p(icm_final, C.c_float))
+    else:
+        rc = lib().orc_td3_rn_chain(C.byref(cfg), _p(rn_params, C.c_float), _p(agent_init, C.c_float), C.c_uint64(rng_key),
+                                    C.byref(tapes) if tapes is not None else None, _p(ep_mean, C.c_double), _p(ep_len, C.c_int32),
+                                    _p(final, C.c_double), C.byref(tr) if tr is not None else None, C.byref(res))
     out = dict(rc=rc, score=res.score, episodes_run=res.episodes_run, train_steps=res.train_steps, learn_steps=res.learn_steps,
                test_steps=res.test_steps, episode_test_mean=ep_mean[:E], episode_len=ep_len[:E], final_test_returns=final[:T])
     if tr is not None:
         out["trace"] = {k: v[:tr.n] for k, v in arrs.items()}
+    if icm_final is not None:
+        out["icm_final"] = icm_final
     return out
 
 
@@ -677,9 +702,10 @@ STREAM_ICM_INIT = 12
 
 
 def icm_layer_dims(cfg):
-    """ICMModel's nn.Linear layers in state-dict order (models/icm_baseline.py:42-78)."""
-    S, A, F, H = cfg.state_dim, cfg.num_actions, cfg.icm_feature_dim, cfg.icm_hidden
-    Ai = 1 if A == 2 else A
+    """ICMModel's nn.Linear layers in state-dict order (models/icm_baseline.py:42-78); a TD3 cfg = continuous actions."""
+    S, F, H = cfg.state_dim, cfg.icm_feature_dim, cfg.icm_hidden
+    A = cfg.num_actions if hasattr(cfg, "num_actions") else cfg.action_dim
+    Ai = 1 if (A == 2 and hasattr(cfg, "num_actions")) else A
     C = F + Ai
     return ([(S, H), (H, H), (H, F)] + [(2 * F, H), (H, H), (H, Ai)] + [(C, H), (H, H), (H, F)] + [(C, F), (C, F)] * 4
             + [(F, H), (H, F)])

@@ -462,6 +462,26 @@ def test_g8tv_td3_vary_replay_of_the_recorded_draw(golden):
     assert abs(out["score"] - float(g["score"])) <= 1e-4
 
 
+def test_g8ti_td3_with_icm(golden):
+    """select_agent "td3_icm" = TD3(icm=True) (agents/TD3.py:44-60,68-70): continuous actions, so the ICM's inverse loss is an
+    MSE on the action vector.  Reference run replayed by the oracle; ICM parameters after the run within 2e-7."""
+    import json
+    g = golden("g8ti_calc_score_cheetah_td3_icm")
+    cfg = orc.td3_cfg_from_config(json.loads(str(g["config_json"])), rng_mode=1)
+    assert cfg.icm_enabled == 1 and orc.td3_icm_num_params(cfg) == g["icm_init"].size
+    tapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
+                               g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    n = g["tr_reward"].size
+    out = orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 4, icm_init=g["icm_init"])
+    assert out["rc"] == 0
+    np.testing.assert_allclose(out["trace"]["action"], g["tr_action"], rtol=0, atol=2e-5)
+    assert np.abs(g["icm_final"] - g["icm_init"]).max() > 1e-3
+    np.testing.assert_allclose(out["icm_final"], g["icm_final"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=1e-4)
+    assert abs(out["score"] - float(g["score"])) <= 1e-4
+    assert orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], tapes=tapes)["rc"] != 0
+
+
 def _standin_rollout(g, t):
     """Replay the fixture's episode on the oracle's stand-in env: fp32 states, info vectors and raw fp32 rewards."""
     import ctypes as C
