@@ -77,6 +77,18 @@ if __name__ == "__main__":
         c["agents"]["duelingddqn"]["init_episodes"] = 1
         c["envs"]["Acrobot-v1"]["max_steps"] = 100
         run("cfg3 Acrobot SE + DuelingDDQN pop 32 (3 episodes x 100 steps)", c, gens=1, extra=dueling_model)
+    if "3full" in which:
+        # the same workload with every CU busy (85 workers = 255 chains on 256 CUs): what the kernel delivers per chip rather
+        # than per BASELINE's 8-GPU shard of 32 workers
+        c = configs.fixed_work(configs.acrobot_syn_env_duelingddqn(85), 3)
+        c["agents"]["duelingddqn"]["init_episodes"] = 1
+        c["envs"]["Acrobot-v1"]["max_steps"] = 100
+        run("cfg3 Acrobot SE + DuelingDDQN pop 85 = 255 chains (3 episodes x 100 steps)", c, gens=1, extra=dueling_model)
+    if "5full" in which:
+        c = configs.fixed_work(configs.halfcheetah_reward_env_td3(85), 3)
+        c["agents"]["td3"]["init_episodes"] = 1
+        c["envs"]["HalfCheetah-v3"]["max_steps"] = 100
+        run("cfg5 HalfCheetah-standin RN + TD3 pop 85 = 255 chains (3 episodes x 100 steps)", c, gens=1, extra=td3_model)
     if "5" in which:
         c = configs.fixed_work(configs.halfcheetah_reward_env_td3(32), 3)
         c["agents"]["td3"]["init_episodes"] = 1
