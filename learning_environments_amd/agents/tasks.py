@@ -23,8 +23,7 @@ class DdqnSeTask(object):
     def __init__(self, config, engine):
         self.engine = engine
         self.cfg = ddqn_cfg_from_config(config) if engine.name == "hip" else engine.cfg_from_config(config)
-        dims = agent_layer_dims(self.cfg) if engine.name == "hip" else [(self.cfg.state_dim, self.cfg.q_hidden),
-                                                                         (self.cfg.q_hidden, self.cfg.num_actions)]
+        dims = agent_layer_dims(self.cfg)
         self.agent_bounds = torch.from_numpy(linear_init_bounds(dims)).to(engine.device)
         # "ddqn_icm" / "duelingddqn_icm": the agent carries an Intrinsic Curiosity Module (agents/DDQN.py:40-58); every chain
         # gets a fresh one (nn.Linear default init), drawn from its own counter-RNG stream

@@ -49,7 +49,10 @@ class OracleNesEngine(object):
         self.device = torch.device("cpu")
 
     def cfg_from_config(self, config):
-        return orc.ddqn_cfg_from_config(config, grad_chunk=17)
+        cfg = orc.ddqn_cfg_from_config(config, grad_chunk=17)
+        if cfg.icm_enabled or cfg.agent_kind == 1 or cfg.q_layers > 1:
+            cfg.grad_chunk = 0                       # what the GEMM-tiled kernel computes: one sequential batch gradient
+        return cfg
 
     def make_inner(self, cfg, chains, vary=False, **kw):
         return _VaryInner(cfg, chains) if vary else _Inner(cfg, chains)
@@ -70,11 +73,19 @@ class OracleNesEngine(object):
                 dims = [(S, H)] + [(H, H)] * (L - 1)
                 dims += [(H, F), (F, F), (F, 1), (F, F), (F, A)] if ocfg.agent_kind == 1 else [(H, A)]
                 init = orc.agent_init_from_key(int(inner.keys[c]), dims)
-                r = orc.ddqn_se_chain(ocfg, w, init, rng_key=int(keys[c]))
+                icm_init = orc.agent_init_from_key(int(keys[c]), orc.icm_layer_dims(ocfg), stream=orc.STREAM_ICM_INIT) if ocfg.icm_enabled else None
+                r = orc.ddqn_se_chain(ocfg, w, init, rng_key=int(keys[c]), icm_init=icm_init)
+                if r["rc"] != 0:
+                    raise RuntimeError("oracle chain failed: rc %d" % r["rc"])
                 out[c] = r["score"]
                 inner.stats[c] = torch.tensor([r["episodes_run"], r["train_steps"], r["learn_steps"], r["test_steps"]])
                 continue
-            r = orc.ddqn_se_chain(inner.cfg, w, agent_init[c].numpy(), rng_key=int(keys[c]))
+            # ICM agents: a fresh ICM per chain from the chain's counter RNG (stream 12), as tasks.DdqnSeTask draws it on the GPU
+            icm_init = orc.agent_init_from_key(int(keys[c]), orc.icm_layer_dims(inner.cfg), stream=orc.STREAM_ICM_INIT) \
+                if inner.cfg.icm_enabled else None
+            r = orc.ddqn_se_chain(inner.cfg, w, agent_init[c].numpy(), rng_key=int(keys[c]), icm_init=icm_init)
+            if r["rc"] != 0:
+                raise RuntimeError("oracle chain failed: rc %d" % r["rc"])
             out[c] = r["score"]
             inner.stats[c] = torch.tensor([r["episodes_run"], r["train_steps"], r["learn_steps"], r["test_steps"]])
         return torch.from_numpy(out)

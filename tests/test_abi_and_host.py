@@ -3,6 +3,7 @@ GPU), argument validation that needs no device, and the host-side mirror of the 
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -224,3 +225,42 @@ def test_hidden_layer_zero_builds_the_one_hidden_layer_net():
     cfgd = cartpole_syn_env_ddqn(2)
     cfgd["agents"]["ddqn"]["hidden_layer"] = 0
     assert ddqn_cfg_from_config(cfgd).q_layers == 1
+
+
+def test_master_host_logic_for_icm_and_multilayer_agents_on_the_oracle_engine(tmp_path, monkeypatch):
+    """GTN_Master + select_task on CPU tensors (oracle-backed engine, no GPU): `DDQN_icm` and a two-hidden-layer DDQN go through
+    the same host path as on the GPU -- config parsing, task choice, per-chain keys, fresh agents / ICMs from the counter RNG --
+    and the fitness records equal a direct oracle evaluation."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _oracle_engine import OracleNesEngine
+    from learning_environments_amd.agents.GTN import GTN_Master
+    from learning_environments_amd.configs import cartpole_syn_env_ddqn, fixed_work, with_icm
+    from oracle import oracle as orc
+    monkeypatch.chdir(tmp_path)
+    base = fixed_work(cartpole_syn_env_ddqn(num_workers=2, max_iterations=1), 2)
+    base["envs"]["CartPole-v0"]["max_steps"] = 8
+    base["agents"]["ddqn"].update(test_episodes=2, init_episodes=1, batch_size=12, hidden_size=10)
+    deep = fixed_work(cartpole_syn_env_ddqn(num_workers=2, max_iterations=1), 2)
+    deep["envs"]["CartPole-v0"]["max_steps"] = 8
+    deep["agents"]["ddqn"].update(test_episodes=2, init_episodes=1, batch_size=12, hidden_size=10, hidden_layer=2)
+    for cfg in (with_icm(base, feature_dim=6, hidden_size=8), deep):
+        torch.manual_seed(0)
+        m = GTN_Master(cfg, bohb_id=0, engine=OracleNesEngine(), seed=4)
+        assert m.cfg.grad_chunk == 0
+        theta0 = m.theta.numpy().copy()
+        gathered = m.evaluate_population(0).numpy()
+        eps = m.eps.numpy()
+        oeps, init, okeys = orc.nes_draw(m.seed, 0, 2, m.p_theta, cfg["agents"]["gtn"]["noise_std"], 6, 3, 0, m.agent_bounds.numpy())
+        assert np.array_equal(eps, oeps)
+        ocfg = orc.ddqn_cfg_from_config(cfg, grad_chunk=0)
+        scores = []
+        for c in range(6):
+            key = orc.chain_key(m.seed, 0, c // 3, c % 3)
+            icm_init = orc.agent_init_from_key(key, orc.icm_layer_dims(ocfg), stream=orc.STREAM_ICM_INIT) if ocfg.icm_enabled else None
+            w = (np.float32([0.0, 1.0, -1.0][c % 3]) * eps[c // 3] + theta0).astype(np.float32)
+            scores.append(orc.ddqn_se_chain(ocfg, w, init[c], rng_key=key, icm_init=icm_init)["score"])
+        scores = np.array(scores)
+        best, sign = orc.worker_best(scores[1::3], scores[2::3], True)
+        assert np.array_equal(gathered[:, 0], best) and np.array_equal(gathered[:, 1], scores[0::3])
