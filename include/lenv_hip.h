@@ -45,6 +45,10 @@ enum { LENV_RNG_COUNTER = 0, LENV_RNG_TAPE = 1 };
 typedef struct {
     int32_t in_dim, hidden, layers, out_dim, act;
     float prelu;
+    /* `use_layer_norm` of models/model_utils.py:22-37: ONE shared nn.LayerNorm(hidden) (eps 1e-5) after every hidden Linear but
+     * the first, before the activation; its weight and bias [hidden] follow the second Linear in the flat vector
+     * (Module.parameters() order).  Honoured by lenv_mlp_num_params / lenv_mlp_forward; the fused loops take plain MLPs only. */
+    int32_t use_layer_norm;
 } lenv_mlp_desc;
 
 /* agents/DDQN.py:15-38, agents/base_agent.py:9-26, envs/env_factory.py:45-59 */

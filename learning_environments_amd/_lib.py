@@ -20,7 +20,7 @@ class LenvError(RuntimeError):
 
 class MlpDesc(C.Structure):
     _fields_ = [("in_dim", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("out_dim", C.c_int32),
-                ("act", C.c_int32), ("prelu", C.c_float)]
+                ("act", C.c_int32), ("prelu", C.c_float), ("use_layer_norm", C.c_int32)]
 
 
 class DdqnCfg(C.Structure):

@@ -20,15 +20,30 @@ __global__ __launch_bounds__(MF_NT) void mlp_forward_kernel(lenv_mlp_desc d, con
     const float *p = params;
     int n_in = d.in_dim;
     float *in = a0, *out = a1;
+    const float *ln_w = nullptr, *ln_b = nullptr;
     for (int l = 0; l < d.layers; ++l) {
         const float *Wl = p, *bl = p + (int64_t)d.hidden * n_in;
+        const bool ln = d.use_layer_norm && l >= 1;        // model_utils.py:33-36: norm after every hidden Linear but the first
         for (int j = tid; j < d.hidden; j += MF_NT) {
             float acc = 0.0f;
             for (int k = 0; k < n_in; ++k) acc = fma32(in[k], Wl[(int64_t)j * n_in + k], acc);
-            out[j] = act_fwd(d.act, d.prelu, acc + bl[j]);
+            out[j] = ln ? acc + bl[j] : act_fwd(d.act, d.prelu, acc + bl[j]);
         }
         __syncthreads();
         p += (int64_t)d.hidden * n_in + d.hidden;
+        if (ln) {
+            // nn.LayerNorm(hidden), eps 1e-5, biased variance; sums in index order (every thread the same values), then
+            // y = fma((z - mean) * rstd, w, b) and the activation -- oracle: mlp_forward_one
+            if (l == 1) { ln_w = p; ln_b = p + d.hidden; p += 2 * d.hidden; }
+            float sm = 0.0f, sv = 0.0f;
+            for (int j = 0; j < d.hidden; ++j) sm = sm + out[j];
+            const float mean = sm / (float)d.hidden;
+            for (int j = 0; j < d.hidden; ++j) { const float dj = out[j] - mean; sv = fma32(dj, dj, sv); }
+            const float rstd = 1.0f / __builtin_sqrtf(sv / (float)d.hidden + 1e-5f);
+            __syncthreads();
+            for (int j = tid; j < d.hidden; j += MF_NT) out[j] = act_fwd(d.act, d.prelu, fma32((out[j] - mean) * rstd, ln_w[j], ln_b[j]));
+            __syncthreads();
+        }
         n_in = d.hidden;
         float *t = in; in = out; out = t;
     }

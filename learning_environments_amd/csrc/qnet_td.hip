@@ -88,6 +88,7 @@ extern "C" int lenv_qnet_td_forward(const lenv_mlp_desc *q, const float *online,
 {
     if (!q || !online || !target || !replay || !idx || !q_sa || !y || chains < 0 || batch < 1 || replay_cap < 1) return LENV_ERR_INVALID;
     if (chains == 0) return LENV_OK;
+    if (q->use_layer_norm) return LENV_ERR_UNSUPPORTED;
     if (q->layers != 1 || q->in_dim > TD_MAX_IN || q->out_dim > TD_MAX_OUT || q->in_dim < 1 || q->out_dim < 1) return LENV_ERR_UNSUPPORTED;
     if (row_stride < 2 * q->in_dim + 3) return LENV_ERR_INVALID;
     TdArgs a;

@@ -82,7 +82,7 @@ extern "C" int64_t lenv_rn_num_params(int32_t type, int32_t state_dim, int32_t i
     if (type == 0) return 0;
     if (type > 100) return info_dim;
     const int in = (type == 3 || type == 4 || type == 7 || type == 8) ? state_dim + info_dim : state_dim;
-    lenv_mlp_desc d = { in, hidden, layers, 1, 0, 0.0f };
+    lenv_mlp_desc d = { in, hidden, layers, 1, 0, 0.0f, 0 };
     return lenv_mlp_num_params(&d);
 }
 

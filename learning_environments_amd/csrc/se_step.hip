@@ -93,7 +93,8 @@ extern "C" int64_t lenv_mlp_num_params(const lenv_mlp_desc *d)
 {
     if (!d || d->layers < 1) return -1;
     const int64_t H = d->hidden;
-    return (int64_t)d->in_dim * H + H + (int64_t)(d->layers - 1) * (H * H + H) + H * d->out_dim + d->out_dim;
+    return (int64_t)d->in_dim * H + H + (int64_t)(d->layers - 1) * (H * H + H) + H * d->out_dim + d->out_dim
+           + ((d->use_layer_norm && d->layers >= 2) ? 2 * H : 0);      // the shared nn.LayerNorm's weight + bias
 }
 
 extern "C" int lenv_se_step_population(const lenv_mlp_desc *sn, const lenv_mlp_desc *rn, const lenv_mlp_desc *dn,
@@ -104,6 +105,7 @@ extern "C" int lenv_se_step_population(const lenv_mlp_desc *sn, const lenv_mlp_d
     if (!sn || !rn || !dn || !theta || !state || !action || !next_state || !reward || !done) return LENV_ERR_INVALID;
     if (eps && (!worker || !sign)) return LENV_ERR_INVALID;
     if (chains < 0 || n_per_chain < 1) return LENV_ERR_INVALID;
+    if (sn->use_layer_norm || rn->use_layer_norm || dn->use_layer_norm) return LENV_ERR_UNSUPPORTED;   // env nets never carry one
     if (chains == 0) return LENV_OK;
     // the three nets share input, width and depth (envs/virtual_env.py:23-31)
     if (sn->in_dim != rn->in_dim || sn->in_dim != dn->in_dim || sn->hidden != rn->hidden || sn->hidden != dn->hidden ||

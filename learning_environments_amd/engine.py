@@ -32,9 +32,9 @@ def _chk(t, dtype, name):
     return t
 
 
-def mlp_desc(in_dim, hidden, layers, out_dim, act, prelu=0.25):
+def mlp_desc(in_dim, hidden, layers, out_dim, act, prelu=0.25, use_layer_norm=False):
     return MlpDesc(int(in_dim), int(hidden), int(layers), int(out_dim), _lib.ACT[act] if isinstance(act, str) else int(act),
-                   float(prelu))
+                   float(prelu), 1 if use_layer_norm else 0)
 
 
 def mlp_num_params(d):

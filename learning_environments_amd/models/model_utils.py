@@ -20,12 +20,13 @@ def build_nn_from_config(input_dim, output_dim, nn_config):
     activation_fn = nn_config['activation_fn']
     if activation_fn not in _ACTS:
         raise NotImplementedError('Unknown activation function: ' + str(activation_fn))
-    if nn_config.get("use_layer_norm", False):
-        raise NotImplementedError("use_layer_norm is not supported by the MI355X kernels")
+    # `use_layer_norm` (reference :22-29): ONE shared nn.LayerNorm after every hidden Linear but the first; lenv_mlp_forward
+    # applies it (one-step API); the fused inner loops take plain MLPs only and their config builders say so
+    norm = nn.LayerNorm(hidden_size) if nn_config.get("use_layer_norm", False) else nn.Identity()
     act_fn = _ACTS[activation_fn]()
     modules = [nn.Linear(input_dim, hidden_size), act_fn]
     for _ in range(hidden_layer - 1):
-        modules += [nn.Linear(hidden_size, hidden_size), nn.Identity(), act_fn]
+        modules += [nn.Linear(hidden_size, hidden_size), norm, act_fn]
     modules.append(nn.Linear(hidden_size, output_dim))
     return nn.Sequential(*modules)
 
@@ -38,15 +39,15 @@ def mlp_desc(net, activation_fn):
         if isinstance(m, nn.PReLU):
             prelu = float(m.weight.detach().reshape(-1)[0])
     return _lib.MlpDesc(linears[0].in_features, linears[0].out_features, len(linears) - 1, linears[-1].out_features,
-                        _lib.ACT[activation_fn], prelu)
+                        _lib.ACT[activation_fn], prelu, 1 if any(isinstance(m, nn.LayerNorm) for m in net) else 0)
 
 
 def linear_params(module):
     """nn.Linear weights and biases in modules() order (the order GTN_worker.py:156-175 / GTN_master.py:281-296
     iterate in, == state-dict order); shared activation modules are skipped."""
     out = []
-    for m in module.modules():
-        if isinstance(m, nn.Linear):
+    for m in module.modules():                      # modules() yields a shared module once, at its first position
+        if isinstance(m, (nn.Linear, nn.LayerNorm)):
             out.append(m.weight)
             if m.bias is not None:
                 out.append(m.bias)

@@ -499,6 +499,32 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
 
 
 # ------------------------------------------------------------------------------------------------
+# G1LN: build_nn_from_config with use_layer_norm (models/model_utils.py:22-37): forward of the reference's module
+# ------------------------------------------------------------------------------------------------
+def gen_g1ln():
+    from models.model_utils import build_nn_from_config
+    out = {}
+    cases = [(5, 3, 24, 2, "relu"), (7, 2, 33, 3, "tanh"), (4, 4, 16, 1, "leakyrelu"), (6, 1, 40, 3, "leakyrelu")]
+    for ci, (din, dout, H, L, act) in enumerate(cases):
+        seed_all(1200 + ci)
+        net = build_nn_from_config(din, dout, {"hidden_size": H, "hidden_layer": L, "activation_fn": act, "use_layer_norm": True})
+        with torch.no_grad():
+            for m in net.modules():
+                if isinstance(m, torch.nn.LayerNorm):          # the default weight 1 / bias 0 would hide a swapped or missing affine
+                    m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+        x = torch.randn(9, din) * 1.3
+        with torch.no_grad():
+            y = net(x)
+        pre = "c%d_" % ci
+        out[pre + "meta"] = np.array([din, dout, H, L, ["identity", "relu", "leakyrelu", "tanh", "prelu"].index(act)], np.int64)
+        out[pre + "params"] = np.concatenate([p.detach().numpy().astype(np.float32).reshape(-1) for p in net.parameters()])
+        out[pre + "keys"] = np.array(list(net.state_dict().keys()))
+        out[pre + "x"] = x.numpy(); out[pre + "y"] = y.numpy()
+    out["n_cases"] = np.array(len(cases))
+    save("g1ln_mlp_layer_norm", **out)
+
+
+# ------------------------------------------------------------------------------------------------
 # G10: gridworld transition tables for every layout (envs/gridworld.py, pure reference code)
 # ------------------------------------------------------------------------------------------------
 def gen_g10():
@@ -1008,6 +1034,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if "g1" in which:
         gen_g1()
+    if "g1ln" in which:
+        gen_g1ln()
     if "g3" in which:
         gen_g3()
     if "g4" in which:

@@ -185,7 +185,8 @@ static inline uint32_t u64_to_below(uint64_t u, uint32_t n) { return (uint32_t)(
 int64_t orc_mlp_num_params(const orc_mlp_desc *d)
 {
     int64_t H = d->hidden;
-    return (int64_t)d->in_dim * H + H + (int64_t)(d->layers - 1) * (H * H + H) + H * d->out_dim + d->out_dim;
+    return (int64_t)d->in_dim * H + H + (int64_t)(d->layers - 1) * (H * H + H) + H * d->out_dim + d->out_dim
+           + ((d->use_layer_norm && d->layers >= 2) ? 2 * H : 0);
 }
 
 static inline float act_fwd(int act, float prelu, float z)
@@ -232,10 +233,21 @@ static void mlp_forward_one(const orc_mlp_desc *d, const float *p, const float *
     const int H = d->hidden, L = d->layers;
     const float *in = x;
     int n_in = d->in_dim;
+    const float *ln_w = NULL, *ln_b = NULL;
     for (int l = 0; l < L; ++l) {
         const float *W = p; p += (int64_t)H * n_in;
         const float *b = p; p += H;
         linear_fwd(W, b, H, n_in, in, z[l]);
+        if (d->use_layer_norm && l >= 1) {
+            /* nn.LayerNorm(hidden), eps 1e-5, biased variance: sequential sums, y = fma((z - mean) * rstd, w, b) */
+            if (l == 1) { ln_w = p; ln_b = p + H; p += 2 * H; }
+            float sm = 0.0f, sv = 0.0f;
+            for (int j = 0; j < H; ++j) sm = sm + z[l][j];
+            const float mean = sm / (float)H;
+            for (int j = 0; j < H; ++j) { const float dj = z[l][j] - mean; sv = fmaf(dj, dj, sv); }
+            const float rstd = 1.0f / sqrtf(sv / (float)H + 1e-5f);
+            for (int j = 0; j < H; ++j) z[l][j] = fmaf((z[l][j] - mean) * rstd, ln_w[j], ln_b[j]);
+        }
         for (int j = 0; j < H; ++j) a[l][j] = act_fwd(d->act, d->prelu, z[l][j]);
         in = a[l];
         n_in = H;
@@ -404,7 +416,7 @@ int orc_qnet_td_forward(const orc_mlp_desc *q, const float *online, const float 
 float orc_ddqn_learn(const orc_ddqn_cfg *cfg, float *online, float *target, float *adam_m, float *adam_v,
                      int64_t step, double *b1pow, double *b2pow, const float *rows, int64_t row_stride)
 {
-    orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu };
+    orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu, 0 };
     const int S = cfg->state_dim, H = cfg->q_hidden, L = cfg->q_layers, A = cfg->num_actions, B = cfg->batch_size;
     const int64_t P = orc_mlp_num_params(&qd);
     const int chunk = cfg->grad_chunk > 0 ? cfg->grad_chunk : B;
@@ -513,10 +525,10 @@ typedef struct { orc_mlp_desc feat, val, adv; int64_t p_feat, p_val, p_adv, P; }
 static void dueling_layout_of(const orc_ddqn_cfg *cfg, dueling_layout *L)
 {
     const int F = cfg->feature_dim;
-    L->feat = (orc_mlp_desc){ cfg->state_dim, cfg->q_hidden, cfg->q_layers, F, cfg->q_act, cfg->q_prelu };
+    L->feat = (orc_mlp_desc){ cfg->state_dim, cfg->q_hidden, cfg->q_layers, F, cfg->q_act, cfg->q_prelu, 0 };
     /* heads_config: hidden_layer = 1, hidden_size = feature_dim (actor_critic.py:103-105) */
-    L->val = (orc_mlp_desc){ F, F, 1, 1, cfg->q_act, cfg->q_prelu };
-    L->adv = (orc_mlp_desc){ F, F, 1, cfg->num_actions, cfg->q_act, cfg->q_prelu };
+    L->val = (orc_mlp_desc){ F, F, 1, 1, cfg->q_act, cfg->q_prelu, 0 };
+    L->adv = (orc_mlp_desc){ F, F, 1, cfg->num_actions, cfg->q_act, cfg->q_prelu, 0 };
     L->p_feat = orc_mlp_num_params(&L->feat);
     L->p_val = orc_mlp_num_params(&L->val);
     L->p_adv = orc_mlp_num_params(&L->adv);
@@ -703,7 +715,7 @@ float orc_dueling_learn(const orc_ddqn_cfg *cfg, float *online, float *target, f
 static int64_t agent_num_params(const orc_ddqn_cfg *cfg)
 {
     if (cfg->agent_kind == 1) return orc_dueling_num_params(cfg);
-    orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu };
+    orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu, 0 };
     return orc_mlp_num_params(&qd);
 }
 
@@ -714,7 +726,7 @@ static int agent_greedy_action(const orc_ddqn_cfg *cfg, const float *params, con
     if (cfg->agent_kind == 1) {
         orc_dueling_forward(cfg, params, obs, 1, q);       /* single state: the mean is over its A advantages */
     } else {
-        orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu };
+        orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu, 0 };
         mlp_forward_one(&qd, params, obs, q, z, a);
     }
     return argmax_first(q, cfg->num_actions);
@@ -917,8 +929,8 @@ int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const
         r_intr = malloc(sizeof(float) * B);
         memcpy(icm_p, icm_init, sizeof(float) * icm.P);
     }
-    orc_mlp_desc qd = { S, cfg->q_hidden, cfg->q_layers, A, cfg->q_act, cfg->q_prelu };
-    orc_mlp_desc sn = { S + A, cfg->se_hidden, cfg->se_layers, S, cfg->se_act, cfg->se_prelu };
+    orc_mlp_desc qd = { S, cfg->q_hidden, cfg->q_layers, A, cfg->q_act, cfg->q_prelu, 0 };
+    orc_mlp_desc sn = { S + A, cfg->se_hidden, cfg->se_layers, S, cfg->se_act, cfg->se_prelu, 0 };
     orc_mlp_desc rn = sn, dn = sn;
     rn.out_dim = 1; dn.out_dim = 1;
     if (cfg->env_id == ORC_ENV_CARTPOLE && S != 4) return -1;
@@ -1110,7 +1122,7 @@ int orc_rn_shaped_rewards(const orc_ql_cfg *cfg, const float *rn_params, const i
     if (N > ORC_MAX_WIDTH || cfg->rn_hidden > ORC_MAX_WIDTH || cfg->rn_layers > ORC_MAX_LAYERS || cfg->rn_layers < 1) return -1;
     const int t = cfg->reward_env_type;
     if (!(t == 0 || t == 1 || t == 2 || t == 5 || t == 6)) return -1;
-    orc_mlp_desc rd = { N, cfg->rn_hidden, cfg->rn_layers, 1, cfg->rn_act, cfg->rn_prelu };
+    orc_mlp_desc rd = { N, cfg->rn_hidden, cfg->rn_layers, 1, cfg->rn_act, cfg->rn_prelu, 0 };
     float *phi = malloc(sizeof(float) * N);
     float *x = calloc(N, sizeof(float));
     float (*z)[ORC_MAX_WIDTH] = malloc(sizeof(float) * ORC_MAX_LAYERS * ORC_MAX_WIDTH);

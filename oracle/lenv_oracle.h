@@ -45,6 +45,10 @@ enum { ORC_RNG_COUNTER = 0, ORC_RNG_TAPE = 1 };
 typedef struct {
     int32_t in_dim, hidden, layers, out_dim, act;
     float prelu; /* single shared PReLU slope (init 0.25, never perturbed) */
+    /* model_utils.py:22-37 `use_layer_norm`: ONE shared nn.LayerNorm(hidden) after every hidden Linear but the first (before the
+     * activation); its weight/bias [hidden] sit right after the second Linear in the flat vector (Module.parameters() order).
+     * Only orc_mlp_forward / orc_mlp_num_params read it. */
+    int32_t use_layer_norm;
 } orc_mlp_desc;
 
 /* Inner-loop configuration: agents/DDQN.py:15-38 + agents/base_agent.py:9-26 + env config. */

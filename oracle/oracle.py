@@ -18,7 +18,7 @@ ENV = {"CartPole-v0": 0, "Acrobot-v1": 1}
 
 class MlpDesc(C.Structure):
     _fields_ = [("in_dim", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("out_dim", C.c_int32),
-                ("act", C.c_int32), ("prelu", C.c_float)]
+                ("act", C.c_int32), ("prelu", C.c_float), ("use_layer_norm", C.c_int32)]
 
 
 class DdqnCfg(C.Structure):
@@ -144,8 +144,8 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def mlp_desc(in_dim, hidden, layers, out_dim, act, prelu=0.25):
-    return MlpDesc(in_dim, hidden, layers, out_dim, ACT[act] if isinstance(act, str) else act, prelu)
+def mlp_desc(in_dim, hidden, layers, out_dim, act, prelu=0.25, use_layer_norm=False):
+    return MlpDesc(in_dim, hidden, layers, out_dim, ACT[act] if isinstance(act, str) else act, prelu, 1 if use_layer_norm else 0)
 
 
 def mlp_num_params(d):
