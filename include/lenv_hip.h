@@ -84,6 +84,11 @@ typedef struct {
      * Only lenv_dueling_se_inner_loop_icm takes such a cfg (GEMM-tiled kernel; fresh ICM parameters per chain). */
     int32_t icm_enabled, icm_feature_dim, icm_hidden, icm_pad_;
     double icm_lr, icm_beta, icm_eta;
+    /* gtn.synthetic_env_type: 0 = the agent trains on the VirtualEnv (theta = the three SE nets); 1 = on a RewardEnv over the
+     * REAL env (envs/reward_env.py:61-133, default_config_cartpole_reward_env.yaml): real transitions, reward through the
+     * reward network theta (state_dim -> se_hidden -> 1, se_act; a 1-input dummy for type 0), reward_env_type 0, 1, 2, 5 or 6
+     * (the real CartPole / Acrobot step carries no info vector).  GEMM-tiled kernel only (lenv_dueling_se_inner_loop*). */
+    int32_t synthetic_env_type, reward_env_type;
 } lenv_ddqn_cfg;
 
 /* RNG tapes (parity mode).  Per-chain rows: element [c*stride + n]; all DEVICE pointers. */

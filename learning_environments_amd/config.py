@@ -51,9 +51,12 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
         ic = config["agents"]["icm"]
         cfg.icm_enabled, cfg.icm_feature_dim, cfg.icm_hidden = 1, int(ic["feature_dim"]), int(ic["hidden_size"])
         cfg.icm_lr, cfg.icm_beta, cfg.icm_eta = float(ic["lr"]), float(ic["beta"]), float(ic["eta"])
+    if "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 0)) == 1:
+        # RewardEnv over the real env (default_config_cartpole_reward_env.yaml): the `envs` section describes the reward network
+        cfg.synthetic_env_type, cfg.reward_env_type = 1, int(val(e["reward_env_type"]))
     for k, v in overrides.items():
         setattr(cfg, k, v)
-    if cfg.grad_chunk == 0 and cfg.agent_kind == 0 and not cfg.icm_enabled:
+    if cfg.grad_chunk == 0 and cfg.agent_kind == 0 and not cfg.icm_enabled and not cfg.synthetic_env_type:
         cfg.grad_chunk = pick_grad_chunk(cfg)          # DuelingDDQN / ICM agents: one sequential chunk (grad_chunk stays 0)
     return cfg
 

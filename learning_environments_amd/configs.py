@@ -59,6 +59,29 @@ def acrobot_syn_env_ddqn(num_workers=256, max_iterations=50):
     return cfg
 
 
+def cartpole_reward_env_ddqn(num_workers=16, max_iterations=50):
+    """CartPole-v0 RewardEnv (potential-shaped, type 2, PReLU reward net 4-64-1) + DDQN 4-64-2: the published values of
+    default_config_cartpole_reward_env.yaml (gtn :5-26, ddqn :28-46, env :49-56).  synthetic_env_type 1: the agents train on the
+    REAL CartPole with the learned reward."""
+    return copy.deepcopy({
+        "env_name": "CartPole-v0", "device": "cuda", "render_env": False,
+        "agents": {
+            "gtn": {"mode": "multi", "max_iterations": max_iterations, "num_threads_per_worker": 1,
+                    "num_workers": num_workers, "noise_std": 0.1, "step_size": 0.5, "nes_step_size": False,
+                    "mirrored_sampling": True, "num_grad_evals": 1, "grad_eval_type": "mean", "weight_decay": 0.0,
+                    "time_mult": 3, "time_max": 3600, "time_sleep_master": 0.2, "time_sleep_worker": 2,
+                    "score_transform_type": 3, "quit_when_solved": True, "synthetic_env_type": 1,
+                    "unsolved_weight": 100, "agent_name": "DDQN"},
+            "ddqn": {"train_episodes": 100, "test_episodes": 1, "init_episodes": 1, "batch_size": 192, "gamma": 0.99,
+                     "lr": 0.003, "tau": 0.01, "eps_init": 0.8, "eps_min": 0.03, "eps_decay": 0.95, "rb_size": 1000000,
+                     "same_action_num": 1, "activation_fn": "leakyrelu", "hidden_size": 64, "hidden_layer": 1,
+                     "print_rate": 10, "early_out_num": 10, "early_out_virtual_diff": 0.02},
+        },
+        "envs": {"CartPole-v0": {"solved_reward": 195.0, "max_steps": 200, "activation_fn": "prelu", "hidden_size": 64,
+                                 "hidden_layer": 1, "info_dim": 0, "reward_env_type": 2}},
+    })
+
+
 def cliff_reward_env_ql(num_workers=128, max_iterations=50):
     """BASELINE config 4: Cliff gridworld RewardEnv (potential shaped, type 2) + tabular QL (values = the published
     hyper-parameters of default_config_gridworld_reward_env.yaml: gtn :5-26, ql :28-43, Cliff :126-133)."""

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     float *state = reinterpret_cast<float *>(alive + T);  // [8] current SE state
     float *newrow = state + 8;                            // [16]
     int *tlen = reinterpret_cast<int *>(newrow + 16);     // [T] lengths of the episodes of the last test phase (time-out cut)
+    double *tstate = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(tlen + T) + 7) & ~(uintptr_t)7);   // [4] RewardEnv: the real training env's state
     volatile float *ctrl = misc;
     volatile int *ictrl = reinterpret_cast<volatile int *>(misc + 32);
 
@@ -135,8 +136,18 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     float *feat_s = arena + a.a_feat, *v1_s = arena + a.a_v1, *a1_s = arena + a.a_a1;
     double *meter = reinterpret_cast<double *>(arena + a.a_meter);
 
+    // gtn.synthetic_env_type 1: the agent trains on a RewardEnv over the REAL env (envs/reward_env.py:61-133): the transition is
+    // the real one, the reward goes through the perturbed reward network (state_dim -> se_hidden -> 1; reward types 0,1,2,5,6)
+    const bool reward_env = cfg.synthetic_env_type == 1;
+    const int rtype = cfg.reward_env_type;
+    const int Drn = rtype == 0 ? 1 : S;                   // RewardEnv.build_reward_net: a 1-input dummy net for type 0
+    float *rn_w = se_w0T, *rn_h = se_h;                   // RewardEnv: flat reward-net parameters / its hidden layer (LDS)
     // ---- stage the perturbed SE (GTN_worker.py:165-175) ----
-    {
+    if (reward_env) {
+        const float sg = a.eps ? a.sign[chain] : 0.0f;
+        const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P_se : nullptr;
+        for (int i = tid; i < a.P_se; i += DNT) rn_w[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
+    } else {
         const float sg = a.eps ? a.sign[chain] : 0.0f;
         const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P_se : nullptr;
         for (int i = tid; i < a.P_se; i += DNT) {
@@ -326,6 +337,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
             float obs[8];
             obs_of(st0, obs);
             for (int i = 0; i < S; ++i) state[i] = obs[i];
+            if (reward_env) { for (int i = 0; i < 4; ++i) tstate[i] = st0[i]; ictrl[5] = 0; }   // RewardEnv.reset: real env state; no phi(s) yet
         }
         __syncthreads();
         int ep_len = 0;
@@ -361,6 +373,56 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
             }
             const int action = ictrl[2];
             PT_MARK(0);
+            if (reward_env) {
+                // ---- EnvWrapper.step -> RewardEnv.step (reward_env.py:61-66): real transition (TimeLimit: done at max_steps),
+                // reward = _calc_reward(state, next_state, reward) -- oracle: rn_shape_one ----
+                auto rn_phi = [&](const float *obs, int slot) {       // phi = reward_net(obs) -> ctrl[slot]
+                    const float *W0 = rn_w, *b0 = rn_w + Hse * Drn, *Wo = b0 + Hse, *bo = Wo + Hse;
+                    for (int j = tid; j < Hse; j += DNT) {
+                        float z = 0.0f;
+                        for (int k = 0; k < Drn; ++k) z = fma32(obs[k], W0[j * Drn + k], z);
+                        rn_h[j] = act_fwd(cfg.se_act, cfg.se_prelu, z + b0[j]);
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        float acc = 0.0f;
+                        for (int j = 0; j < Hse; ++j) acc = fma32(rn_h[j], Wo[j], acc);
+                        ctrl[slot] = acc + bo[0];
+                    }
+                    __syncthreads();
+                };
+                if (tid == 0) {
+                    double st[4] = { tstate[0], tstate[1], tstate[2], tstate[3] };
+                    double rew; int dn;
+                    if (env_id == LENV_ENV_CARTPOLE) cartpole_step(st, action, rew, dn); else acrobot_step(st, action, rew, dn);
+                    if (t + 1 >= cfg.max_steps) dn = 1;
+                    for (int i = 0; i < 4; ++i) tstate[i] = st[i];
+                    float obs[8];
+                    obs_of(st, obs);
+                    for (int i = 0; i < S; ++i) newrow[S + 1 + i] = obs[i];
+                    ctrl[16] = (float)rew; newrow[2 * S + 2] = dn ? 1.0f : 0.0f;
+                }
+                if (tid >= 64 && tid < 64 + S) newrow[tid - 64] = state[tid - 64];
+                if (tid == 128) newrow[S] = (float)action;
+                __syncthreads();
+                if (rtype != 0) {
+                    if ((rtype == 1 || rtype == 2) && ictrl[5] == 0) rn_phi(state, 14);      // phi(s): carried over after the first step
+                    rn_phi(newrow + S + 1, 15);
+                }
+                if (tid == 0) {
+                    const float g32 = (float)cfg.gamma, r32 = ctrl[16], phi_s = ctrl[14], phi_s2 = ctrl[15];
+                    float shaped;
+                    switch (rtype) {
+                    case 0: shaped = r32; break;
+                    case 1: shaped = g32 * phi_s2 - phi_s; break;
+                    case 2: shaped = (r32 + g32 * phi_s2) - phi_s; break;
+                    case 5: shaped = phi_s2; break;
+                    default: shaped = r32 + phi_s2; break;             // 6
+                    }
+                    newrow[2 * S + 1] = shaped;
+                    ctrl[14] = phi_s2; ictrl[5] = 1;
+                }
+            } else {
             // ---- EnvWrapper.step -> VirtualEnv.step: x = [onehot(action), state] ----
             for (int uu = tid; uu < 3 * Hse; uu += DNT) {
                 const int net = uu / Hse, j = uu - net * Hse;
@@ -382,6 +444,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
             }
             if (tid >= 64 && tid < 64 + S) newrow[tid - 64] = state[tid - 64];
             if (tid == 128) newrow[S] = (float)action;
+            }
             __syncthreads();
             if (tid < 2 * S + 3) rb[(int64_t)new_pos * RS + tid] = newrow[tid];
             if (tid == 0 && a.out.trace_action && train_steps < a.out.trace_cap) {
@@ -671,6 +734,13 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     a.se_net_size[0] = (int)d_mlp_params(K, Hse, 1, S);
     a.se_net_size[1] = a.se_net_size[2] = (int)d_mlp_params(K, Hse, 1, 1);
     a.P_se = a.se_net_size[0] + a.se_net_size[1] + a.se_net_size[2];
+    if (cfg->synthetic_env_type == 1) {
+        // RewardEnv over the real env: theta = the reward network (reward_env.py:29-46; a 1-input dummy for type 0); the real
+        // CartPole / Acrobot step has no info vector, so the info types (3, 4, 7, 8, 101, 102) cannot be evaluated
+        const int t = cfg->reward_env_type;
+        if (!(t == 0 || t == 1 || t == 2 || t == 5 || t == 6)) return LENV_ERR_UNSUPPORTED;
+        a.P_se = (int)d_mlp_params(t == 0 ? 1 : S, Hse, 1, 1);
+    } else if (cfg->synthetic_env_type != 0) return LENV_ERR_INVALID;
     a.RS = (2 * S + 3 + 3) & ~3;
     int64_t cap = (int64_t)cfg->train_episodes * cfg->max_steps;
     if (cap > cfg->rb_size) cap = cfg->rb_size;
@@ -702,7 +772,7 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     a.arena_stride = (off + 63) & ~(int64_t)63;
     const size_t lds_floats = GemmShape<D_MAXI>::PS_FLOATS + GemmShape<D_MAXI>::QS_FLOATS + GEMM_QUEUE_MAX * sizeof(GemmCmd) / sizeof(float) +
                               3 * K * Hse + 3 * Hse + (S + 2) * Hse + 16 + 3 * Hse + 3 * (size_t)(B > T ? B : T) * A + 3 * (size_t)(B > T ? B : T) * (1 + A) +
-                              B + (size_t)B * A + 64 + 2 * (4 * (size_t)T + T) + 2 * T + 8 + 16 + 16 + (size_t)T;
+                              B + (size_t)B * A + 64 + 2 * (4 * (size_t)T + T) + 2 * T + 8 + 16 + 16 + (size_t)T + 10;
     *lds_bytes = lds_floats * sizeof(float);
     if (*lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     return LENV_OK;

@@ -347,7 +347,7 @@ class Recorder(object):
 
 def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml="default_config_cartpole_syn_env.yaml",
            env_name="CartPole-v0", env_cls="CartPoleEnv", agent_key="ddqn", agent_over=None, env_over=None, vary_seed=None,
-           icm_over=None):
+           icm_over=None, reward_env_type=None):
     import agents.GTN_worker as gw
     from agents.GTN import GTN_Worker
     import gym.envs as genvs
@@ -370,6 +370,10 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
         cfg["agents"]["gtn"]["agent_name"] += "_vary"
         cfg["agents"][agent_key + "_vary"] = {"vary_hp": True}
     cfg["agents"]["gtn"]["synthetic_env_type"] = 0
+    if reward_env_type is not None:
+        # the agent trains on a RewardEnv over the real env (envs/reward_env.py) instead of a VirtualEnv
+        cfg["agents"]["gtn"]["synthetic_env_type"] = 1
+        cfg["envs"][env_name]["reward_env_type"] = reward_env_type
     if max_steps:
         cfg["envs"][env_name]["max_steps"] = max_steps
     rec = Recorder()
@@ -435,13 +439,15 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
         if done_bias_shift:
             with torch.no_grad():
                 w.synthetic_env_orig.env.done_net[-1].bias.add_(done_bias_shift)
-        theta = se_theta(w.synthetic_env_orig)
+        theta = se_theta(w.synthetic_env_orig) if reward_env_type is None \
+            else pack_linear_params(w.synthetic_env_orig.state_dict(), "env.reward_net.")
         env = w.synthetic_env_orig
         orig_step = env.step
 
         def rec_step(action, state=None):
-            s_before = env.env.state.detach().numpy().copy()
-            ns, r, d = orig_step(action=action, state=state)
+            s_before = env.env.state.detach().numpy().copy() if reward_env_type is None \
+                else np.asarray(env.env.state, np.float32).copy()
+            ns, r, d = orig_step(action=action, state=state) if reward_env_type is None else orig_step(action=action)
             rec.steps.append(dict(state=s_before, action=int(action.item()), next_state=ns.detach().numpy().copy(),
                                   reward=float(r.item()), done=float(d.item()), n_rand=len(rec.rand_action)))
             return ns, r, d
@@ -450,7 +456,7 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
         random.random, np.random.randint = rec_random, rec_randint
         cls.reset, gspaces.Discrete.sample = rec_reset, rec_sample
         gw.select_agent = wrapped_select_agent
-        train_reset_id = id(env.env.reset_env.env.unwrapped)
+        train_reset_id = id(env.env.reset_env.env.unwrapped) if reward_env_type is None else id(env.env.real_env.unwrapped)
         try:
             rec.active = True
             # replicate calc_score but keep the per-episode lists (GTN_worker.py:187-209)
@@ -1077,6 +1083,15 @@ def main():
         gen_g8("g8l2_calc_score_acrobot_ddqn_2layer", train_episodes=3, done_bias_shift=0.0, seed=812, max_steps=20,
                env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="ddqn",
                agent_over={"init_episodes": 1, "test_episodes": 2}, env_over={"hidden_size": 128, "solved_reward": 0.5})
+    if "g8r" in which:
+        # default_config_cartpole_reward_env.yaml's experiment: DDQN on a RewardEnv over the real CartPole (potential-shaped,
+        # type 2, PReLU reward net 4-64-1) -- the env transition is the real one, the reward goes through the network
+        gen_g8("g8r_calc_score_cartpole_ddqn_reward_env", train_episodes=4, done_bias_shift=0.0, seed=850, max_steps=40,
+               env_yaml="default_config_cartpole_reward_env.yaml", reward_env_type=2,
+               agent_over={"init_episodes": 1, "test_episodes": 2, "batch_size": 32})
+        gen_g8("g8r6_calc_score_cartpole_ddqn_reward_env_t6", train_episodes=3, done_bias_shift=0.0, seed=851, max_steps=30,
+               env_yaml="default_config_cartpole_reward_env.yaml", reward_env_type=6,
+               agent_over={"init_episodes": 1, "test_episodes": 2, "batch_size": 24}, env_over={"activation_fn": "tanh", "hidden_size": 24})
     if "g8i" in which:
         # DDQN / DuelingDDQN with the ICM baseline inside learn() (models/icm_baseline.py): CartPole = BCE inverse loss on one
         # action logit, Acrobot = cross-entropy over three

@@ -898,6 +898,11 @@ static double mean_seq(const double *v, int n)
 
 #include "lenv_oracle_icm.inc"
 
+/* RewardEnv._calc_reward for one transition (defined with the TD3 / RewardEnv code in lenv_oracle_td3.inc) */
+static float rn_shape_one(int t, int S, int info_dim, const orc_mlp_desc *rd, const float *rn_params, float g32, const float *state,
+                          const float *next_state, const float *info, float r32, float *phi_s_cache, int have_cache,
+                          float (*z)[ORC_MAX_WIDTH], float (*a)[ORC_MAX_WIDTH]);
+
 int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const float *agent_init, const float *icm_init, uint64_t rng_key,
                           const orc_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
                           double *final_test_returns, orc_trace *trace, orc_chain_result *res, float *icm_final);
@@ -937,6 +942,12 @@ int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const
     if (cfg->env_id == ORC_ENV_ACROBOT && S != 6) return -1;
     if (cfg->q_hidden > ORC_MAX_WIDTH || cfg->se_hidden > ORC_MAX_WIDTH || S + A > 64) return -1;
     if (cfg->rng_mode == ORC_RNG_TAPE && !tapes) return -1;
+    const int reward_env = cfg->synthetic_env_type == 1;
+    const int rtype = cfg->reward_env_type;
+    if (reward_env && !(rtype == 0 || rtype == 1 || rtype == 2 || rtype == 5 || rtype == 6)) return -1;   /* info types: no info vector here */
+    /* RewardEnv.build_reward_net (reward_env.py:29-46): an MLP on the state (a 1-input dummy for type 0) */
+    orc_mlp_desc rd = { rtype == 0 ? 1 : S, cfg->se_hidden, cfg->se_layers, 1, cfg->se_act, cfg->se_prelu, 0 };
+    const float g32 = (float)cfg->gamma;
     const int64_t P = agent_num_params(cfg);
     const int64_t ps = orc_mlp_num_params(&sn), pr = orc_mlp_num_params(&rn);
     const int64_t row_stride = 2 * S + 3;
@@ -974,7 +985,9 @@ int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const
         double st0[4];
         float state[64], next_state[64], x[64];
         draw_reset(&rng, 1, rng.n_train_ep++, st0);
-        real_env_obs(cfg->env_id, st0, state);   /* VirtualEnv.reset -> fp32 real-env reset state (virtual_env.py:35-41) */
+        real_env_obs(cfg->env_id, st0, state);   /* VirtualEnv.reset / RewardEnv.reset -> fp32 real-env reset state (virtual_env.py:35-41) */
+        float phi_cache = 0.0f;                  /* RewardEnv: phi(s) of the state the env is in */
+        int have_phi = 0;
         int ep_len = 0;
         for (int t = 0; t < cfg->max_steps; ++t) {
             /* select_train_action (DDQN.py:97-104) */
@@ -986,9 +999,22 @@ int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const
             for (int i = 0; i < A; ++i) x[i] = (i == act) ? 1.0f : 0.0f;
             for (int i = 0; i < S; ++i) x[A + i] = state[i];
             float reward, done;
+            if (reward_env) {
+                /* RewardEnv.step (reward_env.py:61-66): the real env's transition (TimeLimit: done at max_steps), the reward
+                 * through _calc_reward with the perturbed reward network (se_params) */
+                double rew; int dn_i;
+                if (cfg->env_id == ORC_ENV_CARTPOLE) orc_cartpole_step(st0, act, &rew, &dn_i);
+                else orc_acrobot_step(st0, act, &rew, &dn_i);
+                if (t + 1 >= cfg->max_steps) dn_i = 1;
+                real_env_obs(cfg->env_id, st0, next_state);
+                reward = rn_shape_one(rtype, S, 0, &rd, se_params, g32, state, next_state, NULL, (float)rew, &phi_cache, have_phi, z, a);
+                have_phi = 1;
+                done = dn_i ? 1.0f : 0.0f;
+            } else {
             mlp_forward_one(&sn, se_params, x, next_state, z, a);
             mlp_forward_one(&rn, se_params + ps, x, &reward, z, a);
             mlp_forward_one(&dn, se_params + ps + pr, x, &done, z, a);
+            }
             /* ReplayBuffer.add (utils.py:24-32) */
             float *row = rb + rb_ptr * row_stride;
             memcpy(row, state, sizeof(float) * S);

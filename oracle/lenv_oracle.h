@@ -76,6 +76,10 @@ typedef struct {
     /* Intrinsic Curiosity Module inside learn() (agents/DDQN.py:40-58,74-76; models/icm_baseline.py): config section `icm` */
     int32_t icm_enabled, icm_feature_dim, icm_hidden, icm_pad_;
     double icm_lr, icm_beta, icm_eta;
+    /* gtn.synthetic_env_type 1: the agent trains on a RewardEnv over the REAL env (envs/reward_env.py:61-133) instead of the
+     * VirtualEnv; se_hidden / se_layers / se_act then describe the reward network (state_dim -> 1), theta holds its parameters;
+     * reward_env_type 0, 1, 2, 5, 6 (the real CartPole / Acrobot step returns no info vector) */
+    int32_t synthetic_env_type, reward_env_type;
 } orc_ddqn_cfg;
 
 /* RNG tapes (parity mode): values the reference drew, in per-stream order. */

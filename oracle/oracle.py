@@ -34,7 +34,8 @@ class DdqnCfg(C.Structure):
                 ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
                 ("step_budget", C.c_int64),
                 ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("icm_pad_", C.c_int32),
-                ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double)]
+                ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
+                ("synthetic_env_type", C.c_int32), ("reward_env_type", C.c_int32)]
 
 
 class Tapes(C.Structure):
@@ -400,6 +401,9 @@ def ddqn_cfg_from_config(config, grad_chunk=13, rng_mode=0, **overrides):
                   tau=float(a["tau"]), eps_init=float(a["eps_init"]), eps_min=float(a["eps_min"]),
                   eps_decay=float(a["eps_decay"]), adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
                   step_budget=int(a.get("step_budget", 0)))
+    if "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 0)) == 1:
+        # the agent trains on a RewardEnv over the real env; the `envs` section describes the reward network (env_factory.py:45-59)
+        cfg.synthetic_env_type, cfg.reward_env_type = 1, int(e["reward_env_type"])
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg

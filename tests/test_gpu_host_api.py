@@ -439,6 +439,35 @@ def test_gtn_master_ddqn_icm_generation(tmp_path, monkeypatch):
     assert len(mean_list) == 1
 
 
+def test_gtn_master_cartpole_reward_env_ddqn(tmp_path, monkeypatch):
+    """default_config_cartpole_reward_env.yaml's experiment through GTN_Master: theta is the reward network (RewardEnv wrapper,
+    state-dict keys of the reference), the agents train on the real CartPole with shaped rewards inside the fused kernel; the
+    fitness records equal an oracle evaluation, and a short NES run updates theta."""
+    from learning_environments_amd.configs import cartpole_reward_env_ddqn, fixed_work
+    from oracle import oracle as orc
+    cfg = fixed_work(cartpole_reward_env_ddqn(num_workers=3, max_iterations=2), 3)
+    cfg["envs"]["CartPole-v0"]["max_steps"] = 25
+    cfg["agents"]["ddqn"].update(batch_size=32, test_episodes=2)
+    m = _master_pair(cfg, tmp_path, monkeypatch)
+    assert m.cfg.synthetic_env_type == 1 and m.cfg.reward_env_type == 2 and m.inner.dueling and m.p_theta == 4 * 64 + 64 + 64 + 1
+    assert "env.reward_net.0.weight" in m.synthetic_env_orig.state_dict() and not m.synthetic_env_orig.is_virtual_env()
+    theta0 = m.theta.cpu().numpy().copy()
+    gathered = m.evaluate_population(0).cpu().numpy()
+    eps = m.eps.cpu().numpy()
+    oeps, init, okeys = orc.nes_draw(m.seed, 0, 3, m.p_theta, cfg["agents"]["gtn"]["noise_std"], 9, 3, 0, m.agent_bounds.cpu().numpy())
+    assert np.array_equal(eps, oeps)
+    ocfg = orc.ddqn_cfg_from_config(cfg, grad_chunk=0)
+    scores = []
+    for c in range(9):
+        w = (np.float32([0.0, 1.0, -1.0][c % 3]) * eps[c // 3] + theta0).astype(np.float32)
+        scores.append(orc.ddqn_se_chain(ocfg, w, init[c], rng_key=orc.chain_key(m.seed, 0, c // 3, c % 3))["score"])
+    scores = np.array(scores)
+    best, sign = orc.worker_best(scores[1::3], scores[2::3], True)
+    assert np.array_equal(gathered[:, 0], best) and np.array_equal(gathered[:, 1], scores[0::3])
+    mean_score, mean_list, _ = m.run()
+    assert len(mean_list) == 2 and not np.array_equal(m.theta.cpu().numpy(), theta0)
+
+
 def test_gtn_master_td3_vary_generation(tmp_path, monkeypatch):
     """`agent_name: TD3_vary` through GTN_Master (agents/TD3_vary.py): per-chain draws, one launch, oracle-equal fitness."""
     from learning_environments_amd import _lib

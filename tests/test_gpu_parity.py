@@ -481,6 +481,85 @@ def test_ddqn_multilayer_counter_mode_vs_oracle(eng, orc, golden, env_name, laye
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# synthetic_env_type 1 with a DDQN-family agent: RewardEnv over the real CartPole / Acrobot
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["g8r_calc_score_cartpole_ddqn_reward_env", "g8r6_calc_score_cartpole_ddqn_reward_env_t6"])
+def test_ddqn_reward_env_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
+    g = golden(name)
+    cfgd = json.loads(str(g["config_json"]))
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
+    assert cfg.synthetic_env_type == 1
+    n = g["tr_action"].size
+    otapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    o = orc.ddqn_se_chain(ocfg, g["theta"], g["agent_init"], tapes=otapes, trace_cap=n + 8)
+    chains = 2
+    tapes = dict(eps_uniform=dev(np.tile(g["tape_eps_uniform"], (chains, 1))),
+                 rand_action=dev(np.tile(g["tape_rand_action"], (chains, 1))),
+                 replay_idx=dev(np.tile(g["tape_replay_idx"].reshape(1, -1), (chains, 1))),
+                 train_reset=dev(np.tile(g["tape_train_reset"][None], (chains, 1, 1))),
+                 test_reset=dev(np.tile(g["tape_test_reset"][None], (chains, 1, 1))))
+    il = eng.InnerLoop(cfg, chains, trace_cap=n + 8)
+    assert il.dueling and il.p_agent == g["agent_init"].size
+    il.run(dev(g["theta"]), None, None, None, dev(np.tile(g["agent_init"], (chains, 1))), tapes=tapes)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        act = il.trace["action"][c, :n].cpu().numpy()
+        assert np.array_equal(act & 0xFFFF, o["trace"]["action"]) and np.array_equal(act >> 16, o["trace"]["explored"])
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"])
+        assert np.array_equal(il.trace["reward_done"][c, :n, 0].cpu().numpy(), o["trace"]["reward"])
+        assert np.array_equal(il.trace["reward_done"][c, :n, 1].cpu().numpy(), o["trace"]["done"])
+        assert np.array_equal(il.episode_len[c].cpu().numpy(), o["episode_len"])
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(act & 0xFFFF, g["tr_action"]) and np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), g["tr_next_state"])
+        np.testing.assert_allclose(il.trace["reward_done"][c, :n, 0].cpu().numpy(), g["tr_reward"], rtol=0, atol=1e-6)
+        assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4
+
+
+@pytest.mark.parametrize("env_name,family,rtype,act", [("CartPole-v0", "ddqn", 2, "prelu"), ("Acrobot-v1", "duelingddqn", 1, "leakyrelu"),
+                                                       ("CartPole-v0", "ddqn", 5, "tanh"), ("Acrobot-v1", "ddqn", 0, "relu"),
+                                                       ("CartPole-v0", "duelingddqn", 6, "relu")])
+def test_ddqn_reward_env_counter_mode_vs_oracle(eng, orc, golden, env_name, family, rtype, act):
+    """All info-free reward types, both real envs, both agent families, perturbed reward networks: bit-exact against the oracle."""
+    g = golden("g8r_calc_score_cartpole_ddqn_reward_env" if family == "ddqn" else "g8ia_calc_score_acrobot_dueling_icm")
+    cfgd = json.loads(str(g["config_json"]))
+    cfgd["agents"]["gtn"].update(agent_name="DDQN" if family == "ddqn" else "DuelingDDQN", synthetic_env_type=1)
+    cfgd["env_name"] = env_name
+    base_env = dict(list(cfgd["envs"].values())[0])
+    base_env.update(hidden_size=40, hidden_layer=1, activation_fn=act, reward_env_type=rtype, info_dim=0, max_steps=14,
+                    solved_reward=1e9)
+    cfgd["envs"] = {env_name: base_env}
+    cfgd["agents"][family].update(batch_size=20, test_episodes=3, init_episodes=1, hidden_size=24)
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, train_episodes=3)
+    S = cfg.state_dim
+    P_rn = orc.mlp_num_params(orc.mlp_desc(1 if rtype == 0 else S, 40, 1, 1, act))
+    chains = 3
+    rng = np.random.RandomState(81)
+    theta = (rng.randn(P_rn) * 0.3).astype(np.float32)
+    eps = (rng.randn(1, P_rn) * 0.1).astype(np.float32)
+    worker, sign = np.zeros(chains, np.int32), np.array([0.0, 1.0, -1.0], np.float32)
+    keys = np.array([orc.chain_key(41, 5, 0, c) for c in range(chains)], np.uint64)
+    il = eng.InnerLoop(cfg, chains, trace_cap=50)
+    agent_init = (rng.uniform(-0.3, 0.3, (chains, il.p_agent))).astype(np.float32)
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        w = (np.float32(sign[c]) * eps[0] + theta).astype(np.float32)
+        o = orc.ddqn_se_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]), trace_cap=50)
+        m = o["trace"]["action"].size
+        assert o["rc"] == 0 and o["learn_steps"] > 0
+        assert np.array_equal(il.trace["action"][c, :m].cpu().numpy() & 0xFFFF, o["trace"]["action"]), c
+        assert np.array_equal(il.trace["next_state"][c, :m].cpu().numpy(), o["trace"]["next_state"]), c
+        assert np.array_equal(il.trace["reward_done"][c, :m, 0].cpu().numpy(), o["trace"]["reward"]), c
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # ICM agents: the Intrinsic Curiosity Module trained inside learn() (lenv_dueling_se_inner_loop_icm)
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["g8i_calc_score_cartpole_ddqn_icm", "g8ia_calc_score_acrobot_dueling_icm"])

@@ -249,6 +249,30 @@ def test_g1ln_mlp_with_layer_norm(golden):
     assert mlp_desc(build_nn_from_config(4, 2, {"hidden_size": 8, "hidden_layer": 2, "activation_fn": "relu"}), "relu").use_layer_norm == 0
 
 
+@pytest.mark.parametrize("name", ["g8r_calc_score_cartpole_ddqn_reward_env", "g8r6_calc_score_cartpole_ddqn_reward_env_t6"])
+def test_g8r_ddqn_on_a_reward_env(golden, name):
+    """default_config_cartpole_reward_env.yaml's experiment (synthetic_env_type 1): DDQN trains on a RewardEnv over the real
+    CartPole -- real transitions, reward through the reward network (type 2 with a PReLU net / type 6 with tanh)."""
+    import json
+    g = golden(name)
+    cfgd = json.loads(str(g["config_json"]))
+    cfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
+    assert cfg.synthetic_env_type == 1 and cfg.reward_env_type in (2, 6)
+    tapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    n = g["tr_action"].size
+    out = orc.ddqn_se_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 10)
+    assert out["rc"] == 0
+    tr = out["trace"]
+    assert tr["action"].size == n and np.array_equal(tr["action"], g["tr_action"]) and np.array_equal(tr["done"], g["tr_done"])
+    assert np.array_equal(tr["next_state"], g["tr_next_state"])                      # the real env's fp64 step, cast once
+    np.testing.assert_allclose(tr["reward"], g["tr_reward"], rtol=0, atol=1e-6)      # shaped rewards
+    losses = tr["loss"][~np.isnan(tr["loss"])]
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-4, atol=1e-7)
+    assert np.array_equal(out["episode_len"], g["episode_length_train"])
+    np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=1e-4)
+    assert abs(out["score"] - float(g["score"])) <= 1e-4
+
+
 def test_vary_hyperparameter_draw():
     """The package's sampler (agents/vary.py) against the oracle's numpy restatement of ConfigSpace 0.4.13 on the same
     uniforms, the reference's bounds, and the log-uniform shape of the draw."""
