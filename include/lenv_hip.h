@@ -298,6 +298,11 @@ typedef struct {
      * so the action vector is the ICM's input and its inverse loss is an MSE.  Only lenv_td3_rn_inner_loop_icm takes it. */
     int32_t icm_enabled, icm_feature_dim, icm_hidden, icm_pad_;
     double icm_lr, icm_beta, icm_eta;
+    /* virtual_env != 0 (gtn.synthetic_env_type 0, default_config_halfcheetah.yaml): the agent trains on a VirtualEnv
+     * (envs/virtual_env.py:43-54) instead of the RewardEnv: theta = state_net | reward_net | done_net, each
+     * (action_dim + state_dim) -> rn_hidden x rn_layers (1-3) -> {state_dim, 1, 1} with rn_act; the learned done flag (> 0.5)
+     * ends a training episode.  Tests run on the real (stand-in) env as before. */
+    int32_t virtual_env, virtual_pad_;
 } lenv_td3_cfg;
 
 /* RNG tapes (parity mode); per-chain rows, strides in ROWS (rows of A floats / B ints / S doubles as noted) */

@@ -159,6 +159,8 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
                       gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), action_std=float(a["action_std"]),
                       policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=1.0,
                       adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, step_budget=int(a.get("step_budget", 0)))
+    if "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 1)) == 0:
+        cfg.virtual_env = 1                           # VirtualEnv (default_config_halfcheetah.yaml): `envs` describes the three SE nets
     name = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "td3"
     if name.replace("_vary", "").endswith("_icm"):   # select_agent "td3_icm" / "td3_icm_vary": TD3(icm=True), agents/TD3.py:44-60
         ic = config["agents"]["icm"]

@@ -126,6 +126,29 @@ def halfcheetah_reward_env_td3(num_workers=64, max_iterations=50):
     })
 
 
+def halfcheetah_syn_env_td3(num_workers=128, max_iterations=100):
+    """HalfCheetah-v3 (stand-in) VirtualEnv + TD3: the published values of default_config_halfcheetah.yaml (gtn :6-27 with
+    synthetic_env_type 0, td3 :29-48, env :79-86: three SE nets 23-128-128-128-{17,1,1}, relu).  The yaml's agent_name is
+    td3_vary: wrap with with_vary()."""
+    return copy.deepcopy({
+        "env_name": "HalfCheetah-v3", "device": "cuda", "render_env": False,
+        "agents": {
+            "gtn": {"mode": "multi", "max_iterations": max_iterations, "num_threads_per_worker": 1,
+                    "num_workers": num_workers, "noise_std": 0.1, "step_size": 1.0, "nes_step_size": False,
+                    "mirrored_sampling": True, "num_grad_evals": 1, "grad_eval_type": "mean", "weight_decay": 0.0,
+                    "time_mult": 3, "time_max": 360000, "time_sleep_master": 0.2, "time_sleep_worker": 2,
+                    "score_transform_type": 7, "quit_when_solved": True, "synthetic_env_type": 0,
+                    "unsolved_weight": 1, "agent_name": "td3"},
+            "td3": {"train_episodes": 1000, "test_episodes": 10, "init_episodes": 20, "batch_size": 256, "gamma": 0.99,
+                    "lr": 3e-4, "tau": 0.005, "policy_delay": 2, "rb_size": 1000000, "same_action_num": 1,
+                    "activation_fn": "relu", "hidden_size": 128, "hidden_layer": 2, "action_std": 0.1, "policy_std": 0.2,
+                    "policy_std_clip": 0.5, "print_rate": 10, "early_out_num": 50, "early_out_virtual_diff": 0.02},
+        },
+        "envs": {"HalfCheetah-v3": {"solved_reward": 3000.0, "max_steps": 1000, "activation_fn": "relu", "hidden_size": 128,
+                                    "hidden_layer": 3, "info_dim": 4, "reward_env_type": 0}},
+    })
+
+
 def with_vary(config, vary_hp=True):
     """The same experiment with the *_vary agent of the family (default_config_acrobot.yaml:26 ships `agent_name: DDQN_vary`;
     the `<agent>_vary: {vary_hp: ...}` section is :27-28 there)."""

@@ -20,7 +20,7 @@ namespace lenv {
 
 constexpr int T3_MAXL = 3;     // hidden layers of actor / critic (TD3_vary draws hidden_layer + 1)
 constexpr int T3_MAXW = 512;   // max hidden_size (outputs wider than 128 run as several 128-column blocks)
-constexpr int T3_MAXB = 640;   // max batch size  (more than 256 rows run as several row blocks)
+constexpr int T3_MAXB = 768;   // max batch size  (more than 256 rows run as several row blocks; 768 = 3 x the shipped 256)
 constexpr int T3_MAXI = 256;   // rows of one product block
 constexpr int T3_S = 17, T3_A = 6, T3_SA = 23;
 
@@ -45,7 +45,9 @@ struct Td3Args {
     lenv_td3_out out;
     int64_t rb_cap; int RS;
     MlpOff actor, critic;                     // at cfg's (maximal) shapes
-    int P, P_rn;                              // P = row stride of agent_init / final_params
+    int P, P_rn;                              // P = row stride of agent_init / final_params; P_rn = parameters of theta
+    int P_rn_lds;                             // floats of theta staged in LDS (RewardEnv); a VirtualEnv's three nets live in the arena
+    int64_t a_se, a_xse, a_nse;               // VirtualEnv: perturbed SE parameters, its input cat(action, state), its outputs [S + 2]
     // per-chain hyper-parameters (device arrays [chains], all or none): TD3_vary (agents/TD3_vary.py:24-58)
     const double *hp_lr; const int32_t *hp_batch, *hp_hidden, *hp_layers;
     // TD3(icm=True) (agents/TD3.py:44-60,68-70): fresh ICM parameters per chain, optional final parameters, arena offsets
@@ -85,6 +87,10 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     MlpOff mo_actor, mo_critic;
     mlp_off(mo_actor, S, H, L, A);
     mlp_off(mo_critic, SA, H, L, 1);
+    MlpOff mo_se[3];                                      // VirtualEnv: state_net | reward_net | done_net on cat(action, state)
+    mlp_off(mo_se[0], SA, cfg.rn_hidden, cfg.rn_layers, S);
+    mlp_off(mo_se[1], SA, cfg.rn_hidden, cfg.rn_layers, 1);
+    mlp_off(mo_se[2], SA, cfg.rn_hidden, cfg.rn_layers, 1);
     const int Pa = mo_actor.P, Pc = mo_critic.P, P = Pa + 2 * Pc;
     const int act_id = cfg.act;
     const float prelu = cfg.prelu, ma = (float)cfg.max_action;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     float *Ps = lds, *Qs = Ps + GemmShape<T3_MAXI>::PS_FLOATS;
     GemmCmd *cmds = reinterpret_cast<GemmCmd *>(Qs + GemmShape<T3_MAXI>::QS_FLOATS);   // [GEMM_QUEUE_MAX] command queue
     float *rn_w = reinterpret_cast<float *>(cmds + GEMM_QUEUE_MAX);   // reward net: W0 [Hrn][S] | b0 [Hrn] | Wout [Hrn] | bout
-    float *rn_h = rn_w + ((a.P_rn + 3) & ~3);             // [Hrn]
+    float *rn_h = rn_w + ((a.P_rn_lds + 3) & ~3);         // [Hrn]
     float *q1 = rn_h + ((Hrn + 3) & ~3);                  // [B]
     float *q2 = q1 + Bm, *tq1 = q2 + Bm, *tq2 = tq1 + Bm, *rr = tq2 + Bm, *dd = rr + Bm, *dq1 = dd + Bm, *dq2 = dq1 + Bm;
     float *misc = dq2 + Bm;                                // [64]
@@ -120,7 +126,8 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     {
         const float sg = a.eps ? a.sign[chain] : 0.0f;
         const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P_rn : nullptr;
-        for (int i = tid; i < a.P_rn; i += DNT) rn_w[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
+        float *dst = cfg.virtual_env ? arena + a.a_se : rn_w;      // VirtualEnv: three nets, too large for LDS -> arena
+        for (int i = tid; i < a.P_rn; i += DNT) dst[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
     }
     for (int p = tid; p < P; p += DNT) {
         const float w = a.agent_init[chain * a.P + p];
@@ -152,11 +159,12 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     // values to th_out; else out = net (Critic_Q).
     GemmQueue gq(cmds);
     auto mlp_forward = [&](const float *par, const MlpOff &mo, const float *X, int ldx, int I, float *const *hid, float *out,
-                           int ldo, int ocol, bool final_tanh, float *th_out) {
+                           int ldo, int ocol, bool final_tanh, float *th_out, int act = -1, float pr = 0.25f) {
+        if (act < 0) { act = act_id; pr = prelu; }                // default: the agent's activation
         const float *in = X;
         int n_in = mo.in, ldin = ldx;
         for (int l = 0; l < mo.L; ++l) {
-            gq.gemm(in, ldin, 1, par + mo.oW[l], n_in, 1, I, mo.H, n_in, epi_bias_act(hid[l], mo.H, par + mo.ob[l], act_id, prelu));
+            gq.gemm(in, ldin, 1, par + mo.oW[l], n_in, 1, I, mo.H, n_in, epi_bias_act(hid[l], mo.H, par + mo.ob[l], act, pr));
             in = hid[l]; n_in = mo.H; ldin = mo.H;
         }
         const float *W = par + mo.oW[mo.L], *bb = par + mo.ob[mo.L];
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             state[i] = (float)v;
         }
         __syncthreads();
-        if (rtype == 1 || rtype == 2) rn_eval(state, nullptr, 12);   // phi(s) of the reset state (carried from step to step)
+        if (!cfg.virtual_env && (rtype == 1 || rtype == 2)) rn_eval(state, nullptr, 12);   // phi(s) of the reset state (carried from step to step)
         int ep_len = 0;
         for (int t = 0; t < cfg.max_steps; ++t) {
             const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
@@ -333,6 +341,23 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 ++n_actn;
                 __syncthreads();
             }
+            if (cfg.virtual_env) {
+                // ---- EnvWrapper.step -> VirtualEnv.step (virtual_env.py:43-54): the three SE nets on cat(action, state) as queued
+                // single-row products; reward / done see the pre-transition state; the learned done flag ends the episode ----
+                float *xse = arena + a.a_xse, *nse = arena + a.a_nse;
+                const float *sep = arena + a.a_se;
+                if (tid < A) xse[tid] = action[tid];
+                if (tid >= 64 && tid < 64 + S) xse[A + tid - 64] = state[tid - 64];
+                if (tid >= 128 && tid < 128 + S) newrow[tid - 128] = state[tid - 128];
+                if (tid >= 192 && tid < 192 + A) newrow[S + tid - 192] = action[tid - 192];
+                __syncthreads();
+                mlp_forward(sep, mo_se[0], xse, SA, 1, ht, nse, S + 2, 0, false, nullptr, cfg.rn_act, cfg.rn_prelu);
+                mlp_forward(sep + mo_se[0].P, mo_se[1], xse, SA, 1, ht, nse, S + 2, S, false, nullptr, cfg.rn_act, cfg.rn_prelu);
+                mlp_forward(sep + mo_se[0].P + mo_se[1].P, mo_se[2], xse, SA, 1, ht, nse, S + 2, S + 1, false, nullptr, cfg.rn_act, cfg.rn_prelu);
+                gq.run<T3_MAXI>(Ps, Qs);
+                if (tid < S) newrow[S + A + tid] = nse[tid];
+                if (tid == 64) { newrow[2 * S + A] = nse[S]; newrow[2 * S + A + 1] = nse[S + 1]; }
+            } else {
             // ---- EnvWrapper.step -> RewardEnv.step -> real_env.step + TimeLimit ----
             double nx = 0.0;
             if (tid < S) nx = cheetah_row(tid, xs_d, action);
@@ -366,6 +391,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 const int dn = t + 1 >= cfg.max_steps;
                 newrow[2 * S + A] = shaped; newrow[2 * S + A + 1] = dn ? 1.0f : 0.0f;
                 ctrl[12] = phi_s2;
+            }
             }
             __syncthreads();
             if (tid < 2 * S + A + 2) rb[(int64_t)new_pos * RS + tid] = newrow[tid];
@@ -595,13 +621,20 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
     if (cfg->act == LENV_ACT_PRELU) return LENV_ERR_UNSUPPORTED;   // trained PReLU slope of the agent nets: not a parameter here yet
     const bool uses_info = t == 3 || t == 4 || t == 7 || t == 8 || t > 100;
     if (uses_info && cfg->info_dim != 4) return LENV_ERR_INVALID;                              // the stand-in's info vector has 4 entries
-    if (L < 1 || L > T3_MAXL || H < 1 || H > T3_MAXW || B < 1 || B > T3_MAXB || T < 1 || T * T3_S > DNT || cfg->rn_layers != 1 || Hrn < 1 ||
+    if (L < 1 || L > T3_MAXL || H < 1 || H > T3_MAXW || B < 1 || B > T3_MAXB || T < 1 || T * T3_S > DNT || (cfg->virtual_env ? (cfg->rn_layers < 1 || cfg->rn_layers > T3_MAXL || Hrn > T3_MAXW) : cfg->rn_layers != 1) || Hrn < 1 ||
         cfg->policy_delay < 1 || cfg->max_steps < 1 || cfg->train_episodes < 0)
         return LENV_ERR_UNSUPPORTED;
     mlp_off(a.actor, T3_S, H, L, T3_A);
     mlp_off(a.critic, T3_SA, H, L, 1);
     a.P = a.actor.P + 2 * a.critic.P;
     a.P_rn = (int)lenv_rn_num_params(t, T3_S, cfg->info_dim, Hrn, 1);
+    a.P_rn_lds = a.P_rn;
+    if (cfg->virtual_env) {
+        MlpOff m;
+        mlp_off(m, T3_SA, Hrn, cfg->rn_layers, T3_S); a.P_rn = m.P;
+        mlp_off(m, T3_SA, Hrn, cfg->rn_layers, 1); a.P_rn += 2 * m.P;
+        a.P_rn_lds = 0;
+    }
     a.RS = (2 * T3_S + T3_A + 2 + 3) & ~3;
     int64_t cap = (int64_t)cfg->train_episodes * cfg->max_steps;
     if (cap > cfg->rb_size) cap = cfg->rb_size;
@@ -616,6 +649,11 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
     a.a_d[0] = take((int64_t)RB * H); a.a_d[1] = take((int64_t)RB * H);
     a.a_dx = take((int64_t)RB * T3_SA); a.a_act = take((int64_t)RB * T3_A); a.a_th = take((int64_t)RB * T3_A); a.a_dz = take((int64_t)RB * T3_A);
     a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
+    a.a_se = a.a_xse = a.a_nse = 0;
+    if (cfg->virtual_env) {
+        if ((int64_t)RB * H < Hrn) return LENV_ERR_UNSUPPORTED;          // the SE's hidden rows reuse the agent's temporaries
+        a.a_se = take(a.P_rn); a.a_xse = take(T3_SA); a.a_nse = take(T3_S + 2);
+    }
     a.P_icm = 0;
     for (int i = 0; i < IB_COUNT; ++i) a.a_icm[i] = 0;
     if (cfg->icm_enabled) {
@@ -628,7 +666,7 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
         for (int i = 0; i < IB_COUNT; ++i) a.a_icm[i] = take(sz[i]);
     }
     a.arena_stride = (off + 63) & ~(int64_t)63;
-    const size_t lds_floats = GemmShape<T3_MAXI>::PS_FLOATS + GemmShape<T3_MAXI>::QS_FLOATS + GEMM_QUEUE_MAX * sizeof(GemmCmd) / sizeof(float) + ((a.P_rn + 3) & ~3) + ((Hrn + 3) & ~3) + 8 * (size_t)B + 64 + 2 + 2 * (20 + 17 * (size_t)T + T) + T + 20 + 8 + 56 + 16;
+    const size_t lds_floats = GemmShape<T3_MAXI>::PS_FLOATS + GemmShape<T3_MAXI>::QS_FLOATS + GEMM_QUEUE_MAX * sizeof(GemmCmd) / sizeof(float) + ((a.P_rn_lds + 3) & ~3) + ((Hrn + 3) & ~3) + 8 * (size_t)B + 64 + 2 + 2 * (20 + 17 * (size_t)T + T) + T + 20 + 8 + 56 + 16;
     *lds_bytes = lds_floats * sizeof(float);
     if (*lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     return LENV_OK;

@@ -896,7 +896,7 @@ def gen_g4t():
     save("g4t_td3_learn", **out)
 
 
-def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over=None):
+def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over=None, virtual=False):
     import json
     import statistics
     import agents.GTN_worker as gw
@@ -906,6 +906,8 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over
     cfg = _td3_cfg(agent_over or {"train_episodes": 4, "init_episodes": 2, "batch_size": 16, "hidden_size": 24, "test_episodes": 2},
                    env_over or {"max_steps": 7, "hidden_size": 20})
     drawn = {}
+    if virtual:                                   # default_config_halfcheetah.yaml: TD3 on a VirtualEnv (synthetic_env_type 0)
+        cfg["agents"]["gtn"]["synthetic_env_type"] = 0
     if icm_over is not None:                      # select_agent "td3_icm": TD3(icm=True), agents/TD3.py:44-60,68-70
         cfg["agents"]["gtn"]["agent_name"] = "td3_icm"
         cfg["agents"].setdefault("icm", {"lr": 1e-4, "beta": 0.2, "eta": 0.5, "feature_dim": 32, "hidden_size": 128}).update(icm_over)
@@ -988,11 +990,12 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over
         w.late_init(cfg)
         w.timeout = 1e9
         env = w.synthetic_env_orig
-        theta = pack_linear_params(env.state_dict(), "env.reward_net.")
+        theta = se_theta(env) if virtual else pack_linear_params(env.state_dict(), "env.reward_net.")
         orig_step = env.step
 
         def rec_step(action, state=None):
-            s_before = np.asarray(env.env.state, np.float64).astype(np.float32)
+            s_before = env.env.state.detach().numpy().astype(np.float32).copy() if virtual \
+                else np.asarray(env.env.state, np.float64).astype(np.float32)
             ns, r, d = orig_step(action=action, state=state)
             rec["steps"].append(dict(state=s_before, action=action.detach().numpy().astype(np.float32).copy(), next_state=ns.detach().numpy().copy(),
                                      reward=float(r.item()), done=float(d.item())))
@@ -1001,7 +1004,7 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over
         torch.randn, torch.randn_like, np.random.randint = rec_randn, rec_randn_like, rec_randint
         gspaces.Box.sample, genvs.CheetahStandinEnv.reset = rec_box_sample, rec_reset
         gw.select_agent = wrapped_select_agent
-        train_reset_id = id(env.env.real_env.unwrapped)
+        train_reset_id = id(env.env.reset_env.env.unwrapped) if virtual else id(env.env.real_env.unwrapped)
         try:
             rec["active"] = True
             agent = gw.select_agent(config=w.config, agent_name=w.agent_name)
@@ -1060,6 +1063,12 @@ def main():
         gen_g8t("g8tv_calc_score_cheetah_td3_vary", seed=832, vary_seed=8,
                 agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 64, "hidden_size": 48, "hidden_layer": 2, "test_episodes": 1},
                 env_over={"max_steps": 10, "hidden_size": 24})          # draws batch 145, width 108, 3 hidden layers
+    if "g8ts" in which:
+        # default_config_halfcheetah.yaml's combination: TD3 on a VirtualEnv (three SE nets on cat(action, state), two hidden
+        # layers here), tested on the real (stand-in) env
+        gen_g8t("g8ts_calc_score_cheetah_td3_virtual_env", seed=834, virtual=True,
+                agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 16, "hidden_size": 24, "test_episodes": 1},
+                env_over={"max_steps": 8, "hidden_size": 20, "hidden_layer": 2, "activation_fn": "leakyrelu", "reward_env_type": 0})
     if "g8ti" in which:
         gen_g8t("g8ti_calc_score_cheetah_td3_icm", seed=833,
                 agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 16, "hidden_size": 24, "test_episodes": 1},

@@ -225,6 +225,10 @@ typedef struct {
     /* TD3(icm=True), select_agent "td3_icm" (agents/TD3.py:44-60,68-70): config section `icm` */
     int32_t icm_enabled, icm_feature_dim, icm_hidden, icm_pad_;
     double icm_lr, icm_beta, icm_eta;
+    /* virtual_env != 0 (gtn.synthetic_env_type 0, default_config_halfcheetah.yaml): the agent trains on a VirtualEnv
+     * (envs/virtual_env.py:43-54) instead of the RewardEnv -- rn_params then holds state_net | reward_net | done_net, each
+     * (action_dim + state_dim) -> rn_hidden x rn_layers -> {state_dim, 1, 1} with rn_act; the episode ends on done > 0.5 */
+    int32_t virtual_env, virtual_pad_;
 } orc_td3_cfg;
 
 typedef struct {

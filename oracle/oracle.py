@@ -79,7 +79,8 @@ class Td3Cfg(C.Structure):
                 ("max_action", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
                 ("step_budget", C.c_int64),
                 ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("icm_pad_", C.c_int32),
-                ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double)]
+                ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
+                ("virtual_env", C.c_int32), ("virtual_pad_", C.c_int32)]
 
 
 class Td3Tapes(C.Structure):
@@ -520,6 +521,8 @@ def td3_cfg_from_config(config, rng_mode=0, **overrides):
                  gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), action_std=float(a["action_std"]),
                  policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=1.0,
                  adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, step_budget=int(a.get("step_budget", 0)))
+    if "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 1)) == 0:
+        cfg.virtual_env = 1                           # the agent trains on a VirtualEnv: the `envs` section describes the three SE nets
     name = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "td3"
     if name.replace("_vary", "").endswith("_icm"):   # select_agent "td3_icm": TD3(icm=True), agents/TD3.py:44-60
         ic = config["agents"]["icm"]

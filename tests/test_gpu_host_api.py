@@ -468,6 +468,38 @@ def test_gtn_master_cartpole_reward_env_ddqn(tmp_path, monkeypatch):
     assert len(mean_list) == 2 and not np.array_equal(m.theta.cpu().numpy(), theta0)
 
 
+def test_gtn_master_halfcheetah_virtual_env_td3_vary_as_shipped(tmp_path, monkeypatch):
+    """default_config_halfcheetah.yaml as shipped (agent td3_vary, synthetic_env_type 0, SE 23-128-128-128-{17,1,1}, TD3 batch 256 /
+    128 x 2) on the HalfCheetah stand-in: theta is the VirtualEnv (state-dict keys of the reference), the launch is sized for
+    batch 768 / width 384 / 3 layers, a short generation runs, and the plain-td3 form of the same config equals the oracle."""
+    from learning_environments_amd.agents import tasks
+    from learning_environments_amd.configs import fixed_work, halfcheetah_syn_env_td3, with_vary
+    from oracle import oracle as orc
+    base = fixed_work(halfcheetah_syn_env_td3(num_workers=2, max_iterations=1), 2)
+    base["envs"]["HalfCheetah-v3"]["max_steps"] = 6
+    base["agents"]["td3"].update(init_episodes=1, test_episodes=1)
+    m = _master_pair(with_vary(base), tmp_path, monkeypatch)
+    assert isinstance(m.task, tasks.Td3VaryTask) and m.cfg.virtual_env == 1
+    assert (m.cfg.batch_size, m.cfg.hidden, m.cfg.layers, m.cfg.rn_layers) == (768, 384, 3, 3)
+    assert m.synthetic_env_orig.is_virtual_env() and "env.state_net.0.weight" in m.synthetic_env_orig.state_dict()
+    mean_score, mean_list, _ = m.run()
+    assert len(mean_list) == 1 and np.isfinite(mean_score) and m.inner.status.cpu().tolist() == [0] * 6
+    # plain td3 on the same VirtualEnv: oracle-equal fitness
+    base["agents"]["td3"].update(batch_size=32)
+    m = _master_pair(base, tmp_path, monkeypatch)
+    theta0 = m.theta.cpu().numpy().copy()
+    gathered = m.evaluate_population(0).cpu().numpy()
+    eps = m.eps.cpu().numpy()
+    oeps, init, okeys = orc.nes_draw(m.seed, 0, 2, m.p_theta, base["agents"]["gtn"]["noise_std"], 6, 3, 0, m.agent_bounds.cpu().numpy())
+    ocfg = orc.td3_cfg_from_config(base)
+    for p in range(2):
+        sc = []
+        for kind, sg in enumerate((0.0, 1.0, -1.0)):
+            w = (np.float32(sg) * eps[p] + theta0).astype(np.float32)
+            sc.append(orc.td3_rn_chain(ocfg, w, init[3 * p + kind], rng_key=orc.chain_key(m.seed, 0, p, kind))["score"])
+        assert gathered[p, 1] == sc[0] and gathered[p, 0] == max(sc[1], sc[2])
+
+
 def test_gtn_master_td3_vary_generation(tmp_path, monkeypatch):
     """`agent_name: TD3_vary` through GTN_Master (agents/TD3_vary.py): per-chain draws, one launch, oracle-equal fitness."""
     from learning_environments_amd import _lib

@@ -684,6 +684,67 @@ def test_icm_vary_counter_mode_vs_oracle(eng, orc, golden):
         assert float(il.score[c]) == o["score"], (c, hps[c])
 
 
+def test_td3_virtual_env_tape_and_counter_mode_vs_oracle(eng, orc, golden):
+    """TD3 on a VirtualEnv (default_config_halfcheetah.yaml: synthetic_env_type 0): (a) the reference run G8TS, (b) counter mode
+    with perturbed three-hidden-layer SEs of width 128 (the shipped SE shape); bit-exact against the oracle."""
+    g = golden("g8ts_calc_score_cheetah_td3_virtual_env")
+    cfgd = json.loads(str(g["config_json"]))
+    ocfg, cfg = _td3_cfgs(orc, cfgd, 1)
+    assert cfg.virtual_env == 1
+    n = g["tr_reward"].size
+    otapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
+                                g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    o = orc.td3_rn_chain(ocfg, g["theta"], g["agent_init"], tapes=otapes, trace_cap=n + 4)
+    chains = 2
+    rep = lambda a: dev(np.tile(np.ascontiguousarray(a)[None], (chains,) + (1,) * np.ndim(a)))
+    tapes = dict(rand_action=rep(g["tape_rand_action"]), act_noise=rep(g["tape_act_noise"]), test_noise=rep(g["tape_test_noise"]),
+                 policy_noise=rep(g["tape_policy_noise"]), replay_idx=rep(g["tape_replay_idx"].reshape(-1)),
+                 train_reset=rep(g["tape_train_reset"]), test_reset=rep(g["tape_test_reset"]))
+    il = eng.Td3InnerLoop(cfg, chains, trace_cap=n + 4, want_episode_stats=True)
+    il.run(dev(g["theta"]), None, None, None, dev(np.tile(g["agent_init"], (chains, 1))), tapes=tapes)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        assert np.array_equal(il.trace["action"][c, :n].cpu().numpy(), o["trace"]["action"])
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"])
+        assert np.array_equal(il.trace["reward"][c, :n].cpu().numpy(), o["trace"]["reward"])
+        assert np.array_equal(il.episode_len[c].cpu().numpy(), o["episode_len"])
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        np.testing.assert_allclose(il.trace["next_state"][c, :n].cpu().numpy(), g["tr_next_state"], rtol=0, atol=2e-6)
+        assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4
+    # (b) the shipped SE shape: three hidden layers of 128, relu; a done head biased so that episodes end early
+    cfgd["envs"]["HalfCheetah-v3"].update(hidden_size=128, hidden_layer=3, activation_fn="relu", max_steps=12)
+    cfgd["agents"]["td3"].update(batch_size=24)
+    ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
+    chains = 3
+    keys = np.array([orc.chain_key(43, 1, 0, c) for c in range(chains)], np.uint64)
+    rng = np.random.RandomState(91)
+    d_s = orc.mlp_desc(23, 128, 3, 17, "relu"); d_1 = orc.mlp_desc(23, 128, 3, 1, "relu")
+    P = orc.mlp_num_params(d_s) + 2 * orc.mlp_num_params(d_1)
+    theta = (rng.randn(P) * 0.08).astype(np.float32)
+    theta[-1] = 0.45                                       # done_net output bias: the learned done flag hovers around 0.5
+    eps = (rng.randn(1, P) * 0.02).astype(np.float32)
+    worker, sign = np.zeros(chains, np.int32), np.array([0.0, 1.0, -1.0], np.float32)
+    il = eng.Td3InnerLoop(cfg, chains, trace_cap=40, want_episode_stats=True)
+    agent_init = (rng.uniform(-0.2, 0.2, (chains, il.p_agent))).astype(np.float32)
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    lens = []
+    for c in range(chains):
+        w = (np.float32(sign[c]) * eps[0] + theta).astype(np.float32)
+        oo = orc.td3_rn_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]), trace_cap=40)
+        m = oo["trace"]["reward"].size
+        assert oo["rc"] == 0 and oo["learn_steps"] > 0
+        assert np.array_equal(il.trace["action"][c, :m].cpu().numpy(), oo["trace"]["action"]), c
+        assert np.array_equal(il.trace["next_state"][c, :m].cpu().numpy(), oo["trace"]["next_state"]), c
+        assert np.array_equal(il.episode_len[c].cpu().numpy(), oo["episode_len"]), c
+        assert float(il.score[c]) == oo["score"], c
+        lens += oo["episode_len"].tolist()
+    assert min(lens) < 12 or max(lens) == 12               # (informational) the learned done flag may cut episodes short
+
+
 def test_td3_icm_tape_and_counter_mode_vs_oracle(eng, orc, golden):
     """TD3(icm=True): (a) the reference run G8TI replayed -- bit-exact against the oracle incl. the ICM parameters, reference
     within tolerance; (b) counter mode at the shipped ICM shapes (32 / 128) with fresh ICMs from the chains' RNG."""

@@ -529,6 +529,25 @@ def test_g8ti_td3_with_icm(golden):
     assert orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], tapes=tapes)["rc"] != 0
 
 
+def test_g8ts_td3_on_a_virtual_env(golden):
+    """default_config_halfcheetah.yaml's combination (synthetic_env_type 0): TD3 trains on a VirtualEnv -- three SE nets with two
+    hidden layers on cat(action, state) -- and is tested on the real (stand-in) env."""
+    import json
+    g = golden("g8ts_calc_score_cheetah_td3_virtual_env")
+    cfg = orc.td3_cfg_from_config(json.loads(str(g["config_json"])), rng_mode=1)
+    assert cfg.virtual_env == 1 and cfg.rn_layers == 2
+    tapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
+                               g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    n = g["tr_reward"].size
+    out = orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 4)
+    assert out["rc"] == 0 and out["trace"]["reward"].size == n
+    np.testing.assert_allclose(out["trace"]["action"], g["tr_action"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["trace"]["next_state"], g["tr_next_state"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["trace"]["reward"], g["tr_reward"], rtol=0, atol=2e-6)
+    assert np.array_equal(out["episode_len"], g["episode_length_train"])
+    assert abs(out["score"] - float(g["score"])) <= 1e-4
+
+
 def _standin_rollout(g, t):
     """Replay the fixture's episode on the oracle's stand-in env: fp32 states, info vectors and raw fp32 rewards."""
     import ctypes as C
