@@ -38,7 +38,7 @@ enum {
 };
 
 enum { LENV_ACT_IDENTITY = 0, LENV_ACT_RELU = 1, LENV_ACT_LEAKYRELU = 2, LENV_ACT_TANH = 3, LENV_ACT_PRELU = 4 };
-enum { LENV_ENV_CARTPOLE = 0, LENV_ENV_ACROBOT = 1, LENV_ENV_CHEETAH_STANDIN = 2 };
+enum { LENV_ENV_CARTPOLE = 0, LENV_ENV_ACROBOT = 1, LENV_ENV_CHEETAH_STANDIN = 2, LENV_ENV_MOUNTAINCAR = 3 };
 enum { LENV_RNG_COUNTER = 0, LENV_RNG_TAPE = 1 };
 
 /* models/model_utils.py:4-39 */

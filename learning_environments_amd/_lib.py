@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "liblenv_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 ACT = {"identity": 0, "relu": 1, "leakyrelu": 2, "tanh": 3, "prelu": 4}
-ENV = {"CartPole-v0": 0, "Acrobot-v1": 1, "HalfCheetah-v3": 2}
+ENV = {"CartPole-v0": 0, "Acrobot-v1": 1, "HalfCheetah-v3": 2, "MountainCar-v0": 3}
 RNG_COUNTER, RNG_TAPE = 0, 1
 
 ERRORS = {-1: ValueError, -2: NotImplementedError, -3: ValueError, -4: RuntimeError, -5: RuntimeError}

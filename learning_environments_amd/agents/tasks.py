@@ -187,7 +187,7 @@ def select_task(config, engine, synthetic_env):
         # section (DDQN_vary.py:16) and switch the ICM on
         section = agent_name.replace("_icm", "")
         return DdqnVaryTask(config, engine) if config["agents"][section]["vary_hp"] else DdqnSeTask(config, engine)
-    if agent_name in ("ddqn", "duelingddqn", "ddqn_icm", "duelingddqn_icm") and env_type == 1 and config["env_name"] in ("CartPole-v0", "Acrobot-v1"):
+    if agent_name in ("ddqn", "duelingddqn", "ddqn_icm", "duelingddqn_icm") and env_type == 1 and config["env_name"] in ("CartPole-v0", "Acrobot-v1", "MountainCar-v0"):
         return DdqnSeTask(config, engine)         # RewardEnv over the real env (default_config_cartpole_reward_env.yaml): same kernel
     if agent_name in TABULAR_AGENTS and env_type == 1:
         real = synthetic_env.env.real_env

@@ -59,6 +59,23 @@ def acrobot_syn_env_ddqn(num_workers=256, max_iterations=50):
     return cfg
 
 
+def mountaincar_syn_env_ddqn(num_workers=16, max_iterations=50):
+    """MountainCar-v0 SE (2+1 -> 128 -> 2/1/1, leakyrelu) + DDQN 2-256-256-3: the published values of
+    default_config_mountaincar.yaml (gtn :5-26, ddqn :30-48, env :52-59).  100 random init episodes fill the replay buffer; the
+    two-hidden-layer Q-net runs in the GEMM-tiled kernel's plain-DQN mode."""
+    cfg = acrobot_syn_env_ddqn(num_workers, max_iterations)
+    cfg["env_name"] = "MountainCar-v0"
+    cfg["agents"]["gtn"].update(noise_std=0.05, step_size=1.0, time_max=300, score_transform_type=7, unsolved_weight=10000,
+                                agent_name="DDQN")
+    cfg["agents"]["ddqn"].update(train_episodes=1000, test_episodes=10, init_episodes=100, batch_size=128, gamma=0.99, lr=1e-3,
+                                 tau=0.01, eps_init=1.0, eps_min=0.01, eps_decay=0.99, rb_size=100000, same_action_num=1,
+                                 activation_fn="relu", hidden_size=256, hidden_layer=2, print_rate=10, early_out_num=10,
+                                 early_out_virtual_diff=0.01)
+    cfg["envs"] = {"MountainCar-v0": {"solved_reward": -110.0, "max_steps": 200, "activation_fn": "leakyrelu", "hidden_size": 128,
+                                      "hidden_layer": 1, "info_dim": 0, "reward_env_type": 0}}
+    return cfg
+
+
 def cartpole_reward_env_ddqn(num_workers=16, max_iterations=50):
     """CartPole-v0 RewardEnv (potential-shaped, type 2, PReLU reward net 4-64-1) + DDQN 4-64-2: the published values of
     default_config_cartpole_reward_env.yaml (gtn :5-26, ddqn :28-46, env :49-56).  synthetic_env_type 1: the agents train on the

@@ -184,20 +184,13 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     const uint64_t key = a.rng_keys ? a.rng_keys[chain] : 0;
     const bool tape = cfg.rng_mode == LENV_RNG_TAPE;
     const int env_id = cfg.env_id;
-    const double reset_lim = env_id == LENV_ENV_CARTPOLE ? 0.05 : 0.1;
     int status = 0;
     PT_DECL;
     int train_steps = 0, n_act = 0, learn_it = 0, n_test_ep = 0, test_steps = 0, episodes_run = 0;
     double eps_g = cfg.eps_init, b1pow = 1.0, b2pow = 1.0;
     const int rb_cap = (int)a.rb_cap;
 
-    auto obs_of = [&](const double *st, float *obs) {
-        if (env_id == LENV_ENV_CARTPOLE) { for (int i = 0; i < 4; ++i) obs[i] = (float)st[i]; }
-        else {
-            obs[0] = (float)det_cos(st[0]); obs[1] = (float)det_sin(st[0]); obs[2] = (float)det_cos(st[1]); obs[3] = (float)det_sin(st[1]);
-            obs[4] = (float)st[2]; obs[5] = (float)st[3];
-        }
-    };
+    auto obs_of = [&](const double *st, float *obs) { real_env_obs(env_id, st, obs); };
 
     // ---- Critic_DuelingDQN forward of I rows X[I][S] with parameters `par` (actor_critic.py:117-122) -------------------
     // queue_forward queues the six layer products (intermediate activations to the given buffers; stored ones are kept for
@@ -282,7 +275,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 if (row >= a.tapes.test_reset_stride) { status = -5; for (int i = 0; i < 4; ++i) st[i] = 0.0; }
                 else for (int i = 0; i < 4; ++i) st[i] = a.tapes.test_reset[(chain * a.tapes.test_reset_stride + row) * 4 + i];
             } else {
-                for (int i = 0; i < 4; ++i) st[i] = -reset_lim + (2 * reset_lim) * u64_to_unit(rng_u64(key, STREAM_TEST_RESET, (uint64_t)(row * 4 + i)));
+                real_env_reset_draw(env_id, key, STREAM_TEST_RESET, row, st);
             }
             for (int i = 0; i < 4; ++i) dstate[tid * 4 + i] = st[i];
             ep_rew[tid] = 0.0f; alive[tid] = 1; tlen[tid] = 0;
@@ -299,7 +292,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 for (int aa = 1; aa < A; ++aa) { const float v = qv[tid * A + aa]; if (v > best) { best = v; am = aa; } }
                 double st[4] = { dstate[tid * 4], dstate[tid * 4 + 1], dstate[tid * 4 + 2], dstate[tid * 4 + 3] };
                 double rew; int dn;
-                if (env_id == LENV_ENV_CARTPOLE) cartpole_step(st, am, rew, dn); else acrobot_step(st, am, rew, dn);
+                real_env_step(env_id, st, am, rew, dn);
                 for (int i = 0; i < 4; ++i) dstate[tid * 4 + i] = st[i];
                 ep_rew[tid] = ep_rew[tid] + (float)rew;
                 tlen[tid] = tlen[tid] + 1;
@@ -332,7 +325,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 if (episode >= a.tapes.train_reset_stride) { status = -5; for (int i = 0; i < 4; ++i) st0[i] = 0.0; }
                 else for (int i = 0; i < 4; ++i) st0[i] = a.tapes.train_reset[(chain * a.tapes.train_reset_stride + episode) * 4 + i];
             } else {
-                for (int i = 0; i < 4; ++i) st0[i] = -reset_lim + (2 * reset_lim) * u64_to_unit(rng_u64(key, STREAM_TRAIN_RESET, (uint64_t)(episode * 4 + i)));
+                real_env_reset_draw(env_id, key, STREAM_TRAIN_RESET, episode, st0);
             }
             float obs[8];
             obs_of(st0, obs);
@@ -394,7 +387,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 if (tid == 0) {
                     double st[4] = { tstate[0], tstate[1], tstate[2], tstate[3] };
                     double rew; int dn;
-                    if (env_id == LENV_ENV_CARTPOLE) cartpole_step(st, action, rew, dn); else acrobot_step(st, action, rew, dn);
+                    real_env_step(env_id, st, action, rew, dn);
                     if (t + 1 >= cfg.max_steps) dn = 1;
                     for (int i = 0; i < 4; ++i) tstate[i] = st[i];
                     float obs[8];
@@ -728,7 +721,8 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     if (cfg->grad_chunk != 0 && cfg->grad_chunk < B) return LENV_ERR_UNSUPPORTED;   // batch gradient = one sequential chunk here
     if (L < 1 || L > D_MAXL || H < 1 || H > D_MAXH || F < 1 || F > D_MAXW || B < 1 || B > D_MAXB || T < 1 || T > D_MAXW || cfg->se_layers != 1)
         return LENV_ERR_UNSUPPORTED;
-    if (!((cfg->env_id == LENV_ENV_CARTPOLE && S == 4 && A == 2) || (cfg->env_id == LENV_ENV_ACROBOT && S == 6 && A == 3)))
+    if (!((cfg->env_id == LENV_ENV_CARTPOLE && S == 4 && A == 2) || (cfg->env_id == LENV_ENV_ACROBOT && S == 6 && A == 3) ||
+          (cfg->env_id == LENV_ENV_MOUNTAINCAR && S == 2 && A == 3)))
         return LENV_ERR_UNSUPPORTED;
     a.P = duel_param_offsets(S, A, H, F, L, plain).P;
     a.se_net_size[0] = (int)d_mlp_params(K, Hse, 1, S);

@@ -301,6 +301,21 @@ __device__ __forceinline__ void cartpole_step(double st[4], int action, double &
     reward = 1.0;
 }
 
+// gym==0.17.3 MountainCar-v0 (classic_control/mountain_car.py; third party, restated; oracle: orc_mountaincar_step):
+// state = (position, velocity)
+__device__ __forceinline__ void mountaincar_step(double st[4], int action, double &reward, int &done)
+{
+    double position = st[0], velocity = st[1];
+    velocity = velocity + ((double)(action - 1) * 0.001 + det_cos(3 * position) * (-0.0025));
+    velocity = velocity < -0.07 ? -0.07 : (velocity > 0.07 ? 0.07 : velocity);
+    position = position + velocity;
+    position = position < -1.2 ? -1.2 : (position > 0.6 ? 0.6 : position);
+    if (position == -1.2 && velocity < 0) velocity = 0;
+    done = (position >= 0.5 && velocity >= 0) ? 1 : 0;
+    reward = -1.0;
+    st[0] = position; st[1] = velocity;
+}
+
 __device__ __forceinline__ void acrobot_dsdt(const double s[5], double out[5])
 {
     const double m1 = 1., m2 = 1., l1 = 1., lc1 = .5, lc2 = .5, I1 = 1., I2 = 1., g = 9.8, pi = 3.141592653589793;
@@ -343,6 +358,38 @@ __device__ __forceinline__ void acrobot_step(double st[4], int action, double &r
     int terminal = (-det_cos(st[0]) - det_cos(st[1] + st[0]) > 1.) ? 1 : 0;
     done = terminal;
     reward = terminal ? 0. : -1.;
+}
+
+// ---- the discrete-action real envs behind one interface (env_id: include/lenv_hip.h) ----
+__device__ __forceinline__ void real_env_step(int env_id, double st[4], int action, double &reward, int &done)
+{
+    if (env_id == LENV_ENV_CARTPOLE) cartpole_step(st, action, reward, done);
+    else if (env_id == LENV_ENV_MOUNTAINCAR) mountaincar_step(st, action, reward, done);
+    else acrobot_step(st, action, reward, done);
+}
+
+// fp32 observation of the fp64 state (CartPole: the state; Acrobot: cos/sin of the angles + velocities; MountainCar: the state)
+__device__ __forceinline__ void real_env_obs(int env_id, const double st[4], float *obs)
+{
+    if (env_id == LENV_ENV_CARTPOLE) { for (int i = 0; i < 4; ++i) obs[i] = (float)st[i]; }
+    else if (env_id == LENV_ENV_MOUNTAINCAR) { obs[0] = (float)st[0]; obs[1] = (float)st[1]; }
+    else {
+        obs[0] = (float)det_cos(st[0]); obs[1] = (float)det_sin(st[0]); obs[2] = (float)det_cos(st[1]); obs[3] = (float)det_sin(st[1]);
+        obs[4] = (float)st[2]; obs[5] = (float)st[3];
+    }
+}
+
+// reset state from the counter RNG: CartPole U(-0.05, 0.05)^4, Acrobot U(-0.1, 0.1)^4, MountainCar (U(-0.6, -0.4), 0); draws
+// rng(key, stream, 4 * episode + i) -- oracle: draw_reset
+__device__ __forceinline__ void real_env_reset_draw(int env_id, uint64_t key, uint32_t stream, int64_t episode, double st[4])
+{
+    if (env_id == LENV_ENV_MOUNTAINCAR) {
+        st[0] = -0.6 + 0.2 * u64_to_unit(rng_u64(key, stream, (uint64_t)(episode * 4)));
+        st[1] = st[2] = st[3] = 0.0;
+        return;
+    }
+    const double lim = env_id == LENV_ENV_CARTPOLE ? 0.05 : 0.1;
+    for (int i = 0; i < 4; ++i) st[i] = -lim + (2 * lim) * u64_to_unit(rng_u64(key, stream, (uint64_t)(episode * 4 + i)));
 }
 
 }  // namespace lenv

@@ -14,20 +14,12 @@ __global__ void real_env_reset_kernel(int env_id, const uint64_t *keys, const in
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double lim = env_id == LENV_ENV_CARTPOLE ? 0.05 : 0.1;
     double st[4];
-    for (int k = 0; k < 4; ++k) {
-        st[k] = -lim + (2 * lim) * u64_to_unit(rng_u64(keys[i], STREAM_TEST_RESET, (uint64_t)(episode[i] * 4 + k)));
-        state[i * 4 + k] = st[k];
-    }
+    real_env_reset_draw(env_id, keys[i], STREAM_TEST_RESET, episode[i], st);
+    for (int k = 0; k < 4; ++k) state[i * 4 + k] = st[k];
     elapsed[i] = 0;
-    if (env_id == LENV_ENV_CARTPOLE) {
-        for (int k = 0; k < 4; ++k) obs[i * 4 + k] = (float)st[k];
-    } else {
-        obs[i * 6 + 0] = (float)det_cos(st[0]); obs[i * 6 + 1] = (float)det_sin(st[0]);
-        obs[i * 6 + 2] = (float)det_cos(st[1]); obs[i * 6 + 3] = (float)det_sin(st[1]);
-        obs[i * 6 + 4] = (float)st[2]; obs[i * 6 + 5] = (float)st[3];
-    }
+    const int S = env_id == LENV_ENV_CARTPOLE ? 4 : (env_id == LENV_ENV_MOUNTAINCAR ? 2 : 6);
+    real_env_obs(env_id, st, obs + i * S);
 }
 
 __global__ void real_env_step_kernel(int env_id, int max_steps, int64_t n, const int32_t *action, double *state, int32_t *elapsed,
@@ -37,19 +29,13 @@ __global__ void real_env_step_kernel(int env_id, int max_steps, int64_t n, const
     if (i >= n) return;
     double st[4] = { state[i * 4], state[i * 4 + 1], state[i * 4 + 2], state[i * 4 + 3] };
     double rew; int dn;
-    if (env_id == LENV_ENV_CARTPOLE) cartpole_step(st, action[i], rew, dn);
-    else acrobot_step(st, action[i], rew, dn);
+    real_env_step(env_id, st, action[i], rew, dn);
     for (int k = 0; k < 4; ++k) state[i * 4 + k] = st[k];
     const int el = elapsed[i] + 1;
     elapsed[i] = el;
     if (el >= max_steps) dn = 1;                       // gym.wrappers.TimeLimit
-    if (env_id == LENV_ENV_CARTPOLE) {
-        for (int k = 0; k < 4; ++k) obs[i * 4 + k] = (float)st[k];
-    } else {
-        obs[i * 6 + 0] = (float)det_cos(st[0]); obs[i * 6 + 1] = (float)det_sin(st[0]);
-        obs[i * 6 + 2] = (float)det_cos(st[1]); obs[i * 6 + 3] = (float)det_sin(st[1]);
-        obs[i * 6 + 4] = (float)st[2]; obs[i * 6 + 5] = (float)st[3];
-    }
+    const int S = env_id == LENV_ENV_CARTPOLE ? 4 : (env_id == LENV_ENV_MOUNTAINCAR ? 2 : 6);
+    real_env_obs(env_id, st, obs + i * S);
     reward[i] = (float)rew;
     done[i] = dn ? 1.0f : 0.0f;
 }
@@ -62,7 +48,7 @@ extern "C" int lenv_real_env_reset(int32_t env_id, const uint64_t *keys, const i
                                    int32_t *elapsed, void *stream)
 {
     if (!keys || !episode || !state || !obs || !elapsed || n < 0) return LENV_ERR_INVALID;
-    if (env_id != LENV_ENV_CARTPOLE && env_id != LENV_ENV_ACROBOT) return LENV_ERR_UNSUPPORTED;
+    if (env_id != LENV_ENV_CARTPOLE && env_id != LENV_ENV_ACROBOT && env_id != LENV_ENV_MOUNTAINCAR) return LENV_ERR_UNSUPPORTED;
     if (n == 0) return LENV_OK;
     hipLaunchKernelGGL(real_env_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        (int)env_id, keys, episode, n, state, obs, elapsed);
@@ -73,7 +59,7 @@ extern "C" int lenv_real_env_step(int32_t env_id, int32_t max_steps, int64_t n, 
                                   float *obs, float *reward, float *done, void *stream)
 {
     if (!action || !state || !elapsed || !obs || !reward || !done || n < 0) return LENV_ERR_INVALID;
-    if (env_id != LENV_ENV_CARTPOLE && env_id != LENV_ENV_ACROBOT) return LENV_ERR_UNSUPPORTED;
+    if (env_id != LENV_ENV_CARTPOLE && env_id != LENV_ENV_ACROBOT && env_id != LENV_ENV_MOUNTAINCAR) return LENV_ERR_UNSUPPORTED;
     if (n == 0) return LENV_OK;
     hipLaunchKernelGGL(real_env_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        (int)env_id, (int)max_steps, n, action, state, elapsed, obs, reward, done);

@@ -1,4 +1,4 @@
-"""Device-resident real environments (CartPole-v0 / Acrobot-v1 of gym==0.17.3, third party; dynamics restated in
+"""Device-resident real environments (CartPole-v0 / Acrobot-v1 / MountainCar-v0 of gym==0.17.3, third party; dynamics restated in
 csrc/lenv_device.cuh and UNPINNED -- see DESIGN.md).  One instance = one environment whose float64 state lives in HBM
 and is stepped by lenv_real_env_step; the fused inner loop uses the same device functions for its scoring rollouts."""
 import ctypes as C
@@ -15,6 +15,7 @@ _SPECS = {
     "CartPole-v0": dict(S=4, A=2, max_steps=200,
                         high=[4.8, np.finfo(np.float32).max, 24 * 2 * math.pi / 360, np.finfo(np.float32).max]),
     "Acrobot-v1": dict(S=6, A=3, max_steps=500, high=[1.0, 1.0, 1.0, 1.0, 4 * math.pi, 9 * math.pi]),
+    "MountainCar-v0": dict(S=2, A=3, max_steps=200, low=[-1.2, -0.07], high=[0.6, 0.07]),
     # HalfCheetah-v3 is served by the documented STAND-IN (tools/gen_cheetah_standin.py): MuJoCo cannot be installed
     "HalfCheetah-v3": dict(S=17, A=6, max_steps=1000, high=[np.inf] * 17, continuous=True),
 }
@@ -29,7 +30,7 @@ class DeviceRealEnv(object):
         spec = _SPECS[env_name]
         self.env_name = env_name
         self.env_id = _lib.ENV[env_name]
-        self.observation_space = Box(-np.asarray(spec["high"]), np.asarray(spec["high"]))
+        self.observation_space = Box(np.asarray(spec["low"]) if "low" in spec else -np.asarray(spec["high"]), np.asarray(spec["high"]))
         self.continuous = bool(spec.get("continuous", False))
         self.action_space = Box(-np.ones(spec["A"]), np.ones(spec["A"])) if self.continuous else Discrete(spec["A"])
         self._A = spec["A"]

@@ -471,8 +471,11 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
             gw.select_agent = orig_select_agent
     import statistics
     score = statistics.mean(reward_list_test)
-    train_reset = np.array([s for (i, s) in rec.resets if i == train_reset_id])
-    test_reset = np.array([s for (i, s) in rec.resets if i != train_reset_id])
+    def pad4(rows):                       # the reset tapes carry four doubles per episode (MountainCar's state has two)
+        rows = np.array(rows, np.float64).reshape(len(rows), -1)
+        return np.concatenate([rows, np.zeros((rows.shape[0], 4 - rows.shape[1]))], axis=1) if rows.shape[1] < 4 else rows
+    train_reset = pad4([s for (i, s) in rec.resets if i == train_reset_id])
+    test_reset = pad4([s for (i, s) in rec.resets if i != train_reset_id])
     a = cfg["agents"][agent_key]
     B = holder["hp"].get("batch_size", a["batch_size"])
     n = len(rec.steps)
@@ -1092,6 +1095,16 @@ def main():
         gen_g8("g8l2_calc_score_acrobot_ddqn_2layer", train_episodes=3, done_bias_shift=0.0, seed=812, max_steps=20,
                env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="ddqn",
                agent_over={"init_episodes": 1, "test_episodes": 2}, env_over={"hidden_size": 128, "solved_reward": 0.5})
+    if "g8m" in which:
+        # default_config_mountaincar.yaml's pair: MountainCar-v0 SE + DDQN with two hidden layers (GEMM-tiled kernel, plain-DQN mode)
+        gen_g8("g8m_calc_score_mountaincar_ddqn", train_episodes=3, done_bias_shift=0.0, seed=860, max_steps=25,
+               env_yaml="default_config_mountaincar.yaml", env_name="MountainCar-v0", env_cls="MountainCarEnv",
+               agent_over={"hidden_size": 48, "batch_size": 32, "init_episodes": 1, "test_episodes": 2},
+               env_over={"hidden_size": 32, "solved_reward": 0.5})
+        gen_g8("g8mr_calc_score_mountaincar_ddqn_reward_env", train_episodes=3, done_bias_shift=0.0, seed=861, max_steps=25,
+               env_yaml="default_config_mountaincar.yaml", env_name="MountainCar-v0", env_cls="MountainCarEnv", reward_env_type=2,
+               agent_over={"hidden_size": 40, "batch_size": 24, "init_episodes": 1, "test_episodes": 2},
+               env_over={"hidden_size": 24, "solved_reward": 0.5, "info_dim": 0})
     if "g8r" in which:
         # default_config_cartpole_reward_env.yaml's experiment: DDQN on a RewardEnv over the real CartPole (potential-shaped,
         # type 2, PReLU reward net 4-64-1) -- the env transition is the real one, the reward goes through the network

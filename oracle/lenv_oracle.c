@@ -321,6 +321,28 @@ void orc_cartpole_step(double st[4], int action, double *reward, int *done)
     *reward = 1.0; /* first step past the threshold still pays 1.0; the loop stops on done */
 }
 
+/* gym==0.17.3 MountainCar-v0 (classic_control/mountain_car.py; third party, restated): state = (position, velocity) */
+void orc_mountaincar_step(double st[4], int action, double *reward, int *done)
+{
+    double position = st[0], velocity = st[1];
+    velocity = velocity + ((double)(action - 1) * 0.001 + orc_cos(3 * position) * (-0.0025));
+    velocity = velocity < -0.07 ? -0.07 : (velocity > 0.07 ? 0.07 : velocity);
+    position = position + velocity;
+    position = position < -1.2 ? -1.2 : (position > 0.6 ? 0.6 : position);
+    if (position == -1.2 && velocity < 0) velocity = 0;
+    *done = (position >= 0.5 && velocity >= 0) ? 1 : 0;
+    *reward = -1.0;
+    st[0] = position; st[1] = velocity;
+}
+
+void orc_acrobot_step(double st[4], int action, double *reward, int *done);
+static void real_env_step(int env_id, double st[4], int action, double *reward, int *done)
+{
+    if (env_id == ORC_ENV_CARTPOLE) orc_cartpole_step(st, action, reward, done);
+    else if (env_id == ORC_ENV_MOUNTAINCAR) orc_mountaincar_step(st, action, reward, done);
+    else orc_acrobot_step(st, action, reward, done);
+}
+
 static void acrobot_dsdt(const double s[5], double out[5])
 {
     const double m1 = 1., m2 = 1., l1 = 1., lc1 = .5, lc2 = .5, I1 = 1., I2 = 1., g = 9.8, pi = 3.141592653589793;
@@ -779,6 +801,12 @@ static int draw_replay_idx(rng_state *r, int64_t learn_it, int b, int64_t size)
 static void draw_reset(rng_state *r, int train, int64_t ep, double st[4])
 {
     const double lim = r->cfg->env_id == ORC_ENV_CARTPOLE ? 0.05 : 0.1;
+    if (r->cfg->rng_mode != ORC_RNG_TAPE && r->cfg->env_id == ORC_ENV_MOUNTAINCAR) {
+        /* mountain_car.py reset: position ~ U(-0.6, -0.4), velocity 0 */
+        st[0] = -0.6 + 0.2 * u64_to_unit(orc_rng_u64(r->key, train ? STREAM_TRAIN_RESET : STREAM_TEST_RESET, (uint64_t)(ep * 4)));
+        st[1] = st[2] = st[3] = 0.0;
+        return;
+    }
     if (r->cfg->rng_mode == ORC_RNG_TAPE) {
         const double *tp = train ? r->tapes->train_reset : r->tapes->test_reset;
         int64_t nrows = train ? r->tapes->n_train_reset : r->tapes->n_test_reset;
@@ -796,6 +824,8 @@ static void real_env_obs(int env_id, const double st[4], float *obs)
 {
     if (env_id == ORC_ENV_CARTPOLE) {
         for (int i = 0; i < 4; ++i) obs[i] = (float)st[i];
+    } else if (env_id == ORC_ENV_MOUNTAINCAR) {
+        obs[0] = (float)st[0]; obs[1] = (float)st[1];
     } else {
         double o[6];
         orc_acrobot_obs(st, o);
@@ -817,8 +847,7 @@ static void run_test_phase(const orc_ddqn_cfg *cfg, const orc_mlp_desc *qd, cons
             real_env_obs(cfg->env_id, st, obs);
             int act = agent_greedy_action(cfg, online, obs, z, a);
             double rew; int done;
-            if (cfg->env_id == ORC_ENV_CARTPOLE) orc_cartpole_step(st, act, &rew, &done);
-            else orc_acrobot_step(st, act, &rew, &done);
+            real_env_step(cfg->env_id, st, act, &rew, &done);
             /* TimeLimit: elapsed >= max_steps -> done (the loop bound does the same) */
             ep_reward = ep_reward + (float)rew;
             ++*test_steps;
@@ -940,6 +969,7 @@ int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const
     rn.out_dim = 1; dn.out_dim = 1;
     if (cfg->env_id == ORC_ENV_CARTPOLE && S != 4) return -1;
     if (cfg->env_id == ORC_ENV_ACROBOT && S != 6) return -1;
+    if (cfg->env_id == ORC_ENV_MOUNTAINCAR && (S != 2 || A != 3)) return -1;
     if (cfg->q_hidden > ORC_MAX_WIDTH || cfg->se_hidden > ORC_MAX_WIDTH || S + A > 64) return -1;
     if (cfg->rng_mode == ORC_RNG_TAPE && !tapes) return -1;
     const int reward_env = cfg->synthetic_env_type == 1;
@@ -1003,8 +1033,7 @@ int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const
                 /* RewardEnv.step (reward_env.py:61-66): the real env's transition (TimeLimit: done at max_steps), the reward
                  * through _calc_reward with the perturbed reward network (se_params) */
                 double rew; int dn_i;
-                if (cfg->env_id == ORC_ENV_CARTPOLE) orc_cartpole_step(st0, act, &rew, &dn_i);
-                else orc_acrobot_step(st0, act, &rew, &dn_i);
+                real_env_step(cfg->env_id, st0, act, &rew, &dn_i);
                 if (t + 1 >= cfg->max_steps) dn_i = 1;
                 real_env_obs(cfg->env_id, st0, next_state);
                 reward = rn_shape_one(rtype, S, 0, &rd, se_params, g32, state, next_state, NULL, (float)rew, &phi_cache, have_phi, z, a);

@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 enum { ORC_ACT_IDENTITY = 0, ORC_ACT_RELU = 1, ORC_ACT_LEAKYRELU = 2, ORC_ACT_TANH = 3, ORC_ACT_PRELU = 4 };
-enum { ORC_ENV_CARTPOLE = 0, ORC_ENV_ACROBOT = 1 };
+enum { ORC_ENV_CARTPOLE = 0, ORC_ENV_ACROBOT = 1, ORC_ENV_MOUNTAINCAR = 3 };   /* 2 = the HalfCheetah stand-in (TD3) */
 enum { ORC_RNG_COUNTER = 0, ORC_RNG_TAPE = 1 };
 
 /* models/model_utils.py:4-39 -- Linear(in,H) act [Linear(H,H) act]x(L-1) Linear(H,out) */

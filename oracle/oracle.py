@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liblenv_oracle.so")
 
 ACT = {"identity": 0, "relu": 1, "leakyrelu": 2, "tanh": 3, "prelu": 4}
-ENV = {"CartPole-v0": 0, "Acrobot-v1": 1}
+ENV = {"CartPole-v0": 0, "Acrobot-v1": 1, "MountainCar-v0": 3}
 
 
 class MlpDesc(C.Structure):
@@ -387,7 +387,7 @@ def ddqn_cfg_from_config(config, grad_chunk=13, rng_mode=0, **overrides):
         overrides.setdefault("icm_beta", float(ic["beta"]))
         overrides.setdefault("icm_eta", float(ic["eta"]))
     a = config["agents"][agent_key]
-    S, A = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3)}[env_name]
+    S, A = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3), "MountainCar-v0": (2, 3)}[env_name]
     assert a["same_action_num"] == 1, "same_action_num != 1 not supported by the oracle yet"
     overrides.setdefault("agent_kind", 1 if agent_key == "duelingddqn" else 0)
     overrides.setdefault("feature_dim", int(a.get("feature_dim", 0)))

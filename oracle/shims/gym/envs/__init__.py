@@ -195,6 +195,49 @@ class AcrobotEnv(Env):
         return None
 
 
+class MountainCarEnv(Env):
+    """gym/envs/classic_control/mountain_car.py @0.17.3 (restated from memory like the other classic-control envs)"""
+
+    def __init__(self, goal_velocity=0):
+        self.min_position = -1.2
+        self.max_position = 0.6
+        self.max_speed = 0.07
+        self.goal_position = 0.5
+        self.goal_velocity = goal_velocity
+        self.force = 0.001
+        self.gravity = 0.0025
+        self.low = np.array([self.min_position, -self.max_speed], dtype=np.float32)
+        self.high = np.array([self.max_position, self.max_speed], dtype=np.float32)
+        self.viewer = None
+        self.action_space = spaces.Discrete(3)
+        self.observation_space = spaces.Box(self.low, self.high, dtype=np.float32)
+        self.seed()
+
+    def seed(self, seed=None):
+        self.np_random, seed = seeding.np_random(seed)
+        return [seed]
+
+    def step(self, action):
+        position, velocity = self.state
+        velocity += (action - 1) * self.force + math.cos(3 * position) * (-self.gravity)
+        velocity = np.clip(velocity, -self.max_speed, self.max_speed)
+        position += velocity
+        position = np.clip(position, self.min_position, self.max_position)
+        if (position == self.min_position and velocity < 0):
+            velocity = 0
+        done = bool(position >= self.goal_position and velocity >= self.goal_velocity)
+        reward = -1.0
+        self.state = (position, velocity)
+        return np.array(self.state), reward, done, {}
+
+    def reset(self):
+        self.state = np.array([self.np_random.uniform(low=-0.6, high=-0.4), 0])
+        return np.array(self.state)
+
+    def render(self, mode='human'):
+        return None
+
+
 class CheetahStandinEnv(Env):
     """HalfCheetah-v3 STAND-IN (tools/gen_cheetah_standin.py): MuJoCo is unavailable, so config 5 runs -- on the reference side
     too -- on this fixed 17-obs / 6-action saturated linear system.  Plain python float arithmetic, left to right."""
@@ -247,6 +290,7 @@ _REGISTRY = {
     'CartPole-v0': (CartPoleEnv, EnvSpec('CartPole-v0', 200, 195.0)),
     'CartPole-v1': (CartPoleEnv, EnvSpec('CartPole-v1', 500, 475.0)),
     'Acrobot-v1': (AcrobotEnv, EnvSpec('Acrobot-v1', 500, -100.0)),
+    'MountainCar-v0': (MountainCarEnv, EnvSpec('MountainCar-v0', 200, -110.0)),
     'HalfCheetah-v3': (CheetahStandinEnv, EnvSpec('HalfCheetah-v3', 1000, 4800.0)),
 }
 

@@ -75,6 +75,31 @@ def test_real_env_step_matches_oracle():
     assert total < 200
 
 
+def test_real_env_mountaincar_step_matches_oracle():
+    """MountainCar-v0 through EnvWrapper.reset/step on the device against the oracle's step: swing to the flag (bang-bang on the
+    velocity sign), bit-exact observations, -1 rewards, done at the flag."""
+    from learning_environments_amd.configs import mountaincar_syn_env_ddqn
+    from learning_environments_amd.envs.env_factory import EnvFactory
+    from oracle import oracle as orc
+    import ctypes as C
+    real = EnvFactory(mountaincar_syn_env_ddqn()).generate_real_env()
+    assert real.get_state_dim() == 2 and real.get_action_dim() == 3
+    s = real.reset()
+    assert tuple(s.shape) == (2,) and -0.6 <= float(s[0]) <= -0.4 and float(s[1]) == 0.0
+    st = (C.c_double * 4)(*real.env._alloc()["state"].cpu().tolist())
+    rew, dn = C.c_double(), C.c_int()
+    for t in range(200):
+        a = 2 if st[1] >= 0 else 0
+        ns, r, d = real.step(torch.tensor([float(a)]))
+        orc.lib().orc_mountaincar_step(st, a, C.byref(rew), C.byref(dn))
+        assert np.array_equal(ns.numpy(), np.array([st[0], st[1]], np.float64).astype(np.float32))
+        assert float(r) == rew.value == -1.0
+        if float(d) > 0.5:
+            assert dn.value == 1 and st[0] >= 0.5
+            break
+    assert 60 < t < 199
+
+
 def test_reward_env_step_matches_reference(golden):
     from learning_environments_amd.configs import cliff_reward_env_ql
     from learning_environments_amd.envs.env_factory import EnvFactory

@@ -121,7 +121,8 @@ def _inner_cfg(orc, cfgd, **over):
 
 @pytest.mark.parametrize("name,chunk", [("g8_calc_score_cartpole_a", 17), ("g8_calc_score_cartpole_b", 17),
                                         ("g8w_calc_score_cartpole_ringwrap", 17),
-                                        ("g8l2_calc_score_acrobot_ddqn_2layer", 0)])   # Critic_DQN 6-128-128-3 -> GEMM-tiled kernel
+                                        ("g8l2_calc_score_acrobot_ddqn_2layer", 0),    # Critic_DQN 6-128-128-3 -> GEMM-tiled kernel
+                                        ("g8m_calc_score_mountaincar_ddqn", 0)])       # MountainCar-v0 SE + DDQN 2-48-48-3
 def test_inner_loop_tape_mode_vs_reference_and_oracle(eng, orc, golden, name, chunk):
     g = golden(name)
     cfgd = json.loads(str(g["config_json"]))
@@ -435,7 +436,8 @@ def test_dueling_counter_mode_vs_oracle(eng, orc, golden, env_name, layers, hidd
 
 @pytest.mark.parametrize("env_name,layers,hidden,batch,act,T", [("Acrobot-v1", 2, 128, 128, "relu", 3), ("CartPole-v0", 2, 64, 64, "tanh", 4),
                                                                  ("CartPole-v0", 2, 33, 50, "leakyrelu", 70),      # test rows > batch rows
-                                                                 ("Acrobot-v1", 2, 40, 20, "relu", 2)])           # rb_size 23: ring wraps
+                                                                 ("Acrobot-v1", 2, 40, 20, "relu", 2),            # rb_size 23: ring wraps
+                                                                 ("MountainCar-v0", 2, 256, 128, "relu", 3)])     # default_config_mountaincar.yaml's Q-net
 def test_ddqn_multilayer_counter_mode_vs_oracle(eng, orc, golden, env_name, layers, hidden, batch, act, T):
     """DDQN whose Critic_DQN has hidden_layer >= 2 (default_config_acrobot.yaml: 6-128-128-3) runs in the GEMM-tiled kernel's
     plain-DQN mode: bit-exact against the oracle's DDQN with one sequential batch gradient."""
@@ -483,7 +485,8 @@ def test_ddqn_multilayer_counter_mode_vs_oracle(eng, orc, golden, env_name, laye
 # ---------------------------------------------------------------------------------------------------------------
 # synthetic_env_type 1 with a DDQN-family agent: RewardEnv over the real CartPole / Acrobot
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["g8r_calc_score_cartpole_ddqn_reward_env", "g8r6_calc_score_cartpole_ddqn_reward_env_t6"])
+@pytest.mark.parametrize("name", ["g8r_calc_score_cartpole_ddqn_reward_env", "g8r6_calc_score_cartpole_ddqn_reward_env_t6",
+                                  "g8mr_calc_score_mountaincar_ddqn_reward_env"])
 def test_ddqn_reward_env_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
     g = golden(name)
     cfgd = json.loads(str(g["config_json"]))
@@ -520,7 +523,8 @@ def test_ddqn_reward_env_tape_mode_vs_reference_and_oracle(eng, orc, golden, nam
 
 @pytest.mark.parametrize("env_name,family,rtype,act", [("CartPole-v0", "ddqn", 2, "prelu"), ("Acrobot-v1", "duelingddqn", 1, "leakyrelu"),
                                                        ("CartPole-v0", "ddqn", 5, "tanh"), ("Acrobot-v1", "ddqn", 0, "relu"),
-                                                       ("CartPole-v0", "duelingddqn", 6, "relu")])
+                                                       ("CartPole-v0", "duelingddqn", 6, "relu"), ("MountainCar-v0", "ddqn", 1, "leakyrelu"),
+                                                       ("MountainCar-v0", "duelingddqn", 2, "tanh")])
 def test_ddqn_reward_env_counter_mode_vs_oracle(eng, orc, golden, env_name, family, rtype, act):
     """All info-free reward types, both real envs, both agent families, perturbed reward networks: bit-exact against the oracle."""
     g = golden("g8r_calc_score_cartpole_ddqn_reward_env" if family == "ddqn" else "g8ia_calc_score_acrobot_dueling_icm")

@@ -142,7 +142,8 @@ def test_g7_master(golden):
 
 @pytest.mark.parametrize("name,chunk", [("g8_calc_score_cartpole_a", 13), ("g8_calc_score_cartpole_b", 13),
                                         ("g8w_calc_score_cartpole_ringwrap", 13),
-                                        ("g8l2_calc_score_acrobot_ddqn_2layer", 0)])   # Critic_DQN 6-128-128-3: batch gradient
+                                        ("g8l2_calc_score_acrobot_ddqn_2layer", 0),    # Critic_DQN 6-128-128-3: batch gradient
+                                        ("g8m_calc_score_mountaincar_ddqn", 0)])       # default_config_mountaincar.yaml's pair
 def test_g8_calc_score_trace(golden, name, chunk):
     import json
     g = golden(name)
@@ -226,6 +227,35 @@ def test_g8i_agents_with_icm(golden, name):
     assert orc.ddqn_se_chain(cfg, g["theta"], g["agent_init"], tapes=tapes)["rc"] != 0
 
 
+def test_mountaincar_step_physics():
+    """gym==0.17.3 classic_control/mountain_car.py (third party, absent from the reference tree; restated): the oracle's step
+    against a line-by-line float64 restatement over an episode that reaches the flag, the left wall, and the velocity clip."""
+    import ctypes as C
+    import math
+    st = (C.c_double * 4)(-0.5, 0.0, 0.0, 0.0)
+    rew, dn = C.c_double(), C.c_int()
+    pos, vel = -0.5, 0.0
+    hit_wall = reached = False
+    for t in range(400):
+        a = 0 if t < 60 else (2 if vel >= 0 else 0)          # first run into the left wall, then swing up to the flag
+        orc.lib().orc_mountaincar_step(st, a, C.byref(rew), C.byref(dn))
+        vel += (a - 1) * 0.001 + math.cos(3 * pos) * (-0.0025)
+        vel = min(max(vel, -0.07), 0.07)
+        pos += vel
+        pos = min(max(pos, -1.2), 0.6)
+        if pos == -1.2 and vel < 0:
+            vel = 0.0
+            hit_wall = True
+        assert abs(st[0] - pos) <= 1e-13 and abs(st[1] - vel) <= 1e-14 and rew.value == -1.0
+        # keep the two in lock-step so the comparison stays one step deep (orc_cos is a restated cos, not libm's)
+        pos, vel = st[0], st[1]
+        assert dn.value == int(pos >= 0.5 and vel >= 0)
+        if dn.value:
+            reached = True
+            break
+    assert hit_wall and reached and t < 399
+
+
 def test_g1ln_mlp_with_layer_norm(golden):
     """build_nn_from_config with `use_layer_norm` (models/model_utils.py:22-37): ONE shared nn.LayerNorm after every hidden
     Linear but the first.  The oracle's forward against the reference module's (random LayerNorm affine), the package's
@@ -249,7 +279,8 @@ def test_g1ln_mlp_with_layer_norm(golden):
     assert mlp_desc(build_nn_from_config(4, 2, {"hidden_size": 8, "hidden_layer": 2, "activation_fn": "relu"}), "relu").use_layer_norm == 0
 
 
-@pytest.mark.parametrize("name", ["g8r_calc_score_cartpole_ddqn_reward_env", "g8r6_calc_score_cartpole_ddqn_reward_env_t6"])
+@pytest.mark.parametrize("name", ["g8r_calc_score_cartpole_ddqn_reward_env", "g8r6_calc_score_cartpole_ddqn_reward_env_t6",
+                                  "g8mr_calc_score_mountaincar_ddqn_reward_env"])
 def test_g8r_ddqn_on_a_reward_env(golden, name):
     """default_config_cartpole_reward_env.yaml's experiment (synthetic_env_type 1): DDQN trains on a RewardEnv over the real
     CartPole -- real transitions, reward through the reward network (type 2 with a PReLU net / type 6 with tanh)."""
