@@ -35,7 +35,7 @@ constexpr int MAX_PPT = 2;        // Q-net parameters owned per thread (P_agent 
 
 // Diagnostic build only (-DLENV_PHASE_TIMING): per-phase shader-clock totals of chain 0, never in the shipped library.
 #ifdef LENV_PHASE_TIMING
-__device__ unsigned long long g_phase_cycles[40];
+__device__ unsigned long long g_phase_cycles[64];
 #define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_own[4] = {0, 0, 0, 0}
 #define PT_MARK(i) do { unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
 // own-work stamp: time since the last PT_MARK at which THIS wave reached the coming barrier (no reset)
@@ -911,9 +911,8 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 #ifdef LENV_PHASE_TIMING
     if (tid == 0) PT_FLUSH(0, 10);
     if (tid == ENV_WAVE * 64) { if (chain == 0) { g_phase_cycles[10] = pt_acc[0]; g_phase_cycles[11] = pt_acc[1]; } }
-    if (chain == 0 && lane == 0) {       // own-work stamps (forward, TD, gradient, Adam) of waves 0, 4, 8, 9, 10, 11
-        const int slot = wave == 0 ? 0 : (wave == 4 ? 1 : (wave == 8 ? 2 : (wave == 9 ? 3 : (wave == 10 ? 4 : (wave == 11 ? 5 : -1)))));
-        if (slot >= 0) for (int pi = 0; pi < 4; ++pi) g_phase_cycles[12 + 4 * slot + pi] = pt_own[pi];
+    if (chain == 0 && lane == 0) {       // own-work stamps (forward, TD, gradient, Adam) of every wave
+        for (int pi = 0; pi < 4; ++pi) g_phase_cycles[12 + 4 * wave + pi] = pt_own[pi];
     }
 #endif
     if (tid == 0) {
@@ -1064,7 +1063,7 @@ static int inner_check(const lenv_ddqn_cfg *cfg)
 #ifdef LENV_PHASE_TIMING
 extern "C" int lenv_debug_phase_cycles(unsigned long long *host_out)
 {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_phase_cycles), sizeof(unsigned long long) * 40) == hipSuccess ? 0 : -4;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_phase_cycles), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -4;
 }
 #endif
 

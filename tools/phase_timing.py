@@ -28,7 +28,7 @@ master.step(0)
 torch.cuda.synchronize()
 import time
 t0 = time.time(); master.step(1); torch.cuda.synchronize(); dt = time.time() - t0
-buf = (C.c_ulonglong * 40)()
+buf = (C.c_ulonglong * 64)()
 _lib.lib().lenv_debug_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
 assert _lib.lib().lenv_debug_phase_cycles(buf) == 0
 names = ["(unused)", "(unused)", "phaseA+wait(B1)", "forward(B2)", "td-error(B3)", "grad-reduce(B4)", "adam(B5)", "test", "-", "loop-overhead",
@@ -40,6 +40,6 @@ for i, n in enumerate(names):
         print("%-22s %12d cycles  %5.1f%%" % (n, buf[i], 100.0 * buf[i] / tot))
 print("own-work cycles before each barrier (forward | TD | gradient | Adam), per learn step:")
 steps = max(1, int(master.inner.stats[0][2]))
-for slot, w in enumerate((0, 4, 8, 9, 10, 11)):
+for slot, w in enumerate(range(12)):
     print("  wave %2d: " % w + " | ".join("%7.0f" % (buf[12 + 4 * slot + i] / steps) for i in range(4)))
 print("phase totals per learn step: " + ", ".join("%s %.0f" % (names[i], buf[i] / steps) for i in (2, 3, 4, 5, 6)))
