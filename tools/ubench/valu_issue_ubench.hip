@@ -39,7 +39,7 @@ __global__ void k(float *out, unsigned long long *cyc, int iters, const float *w
             asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(wA) : "s"(p2));
             body(wB);
         }
-    } else
+    } else if (MODE < 9)
     for (int it = 0; it < iters; ++it) {
         if (MODE == 0) {        // 8 independent v_fma_f32 x 2
 #pragma unroll
@@ -89,6 +89,33 @@ __global__ void k(float *out, unsigned long long *cyc, int iters, const float *w
             a4 = fmaf(a4, w[12], c); a5 = fmaf(a5, w[13], c); a6 = fmaf(a6, w[14], c); a7 = fmaf(a7, w[15], c);
         }
     }
+    if (MODE == 10 || MODE == 11) {   // a LONG straight-line body (256 instructions per iteration): instruction-fetch bound?
+        for (int it = 0; it < iters / 16; ++it) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                if (MODE == 10)     // 8-byte VOP3 encodings
+                    asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                                 "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+                else                // 4-byte VOP2 encodings
+                    asm volatile("v_fmac_f32_e32 %0, %8, %9\n v_fmac_f32_e32 %1, %8, %9\n v_fmac_f32_e32 %2, %8, %9\n v_fmac_f32_e32 %3, %8, %9\n"
+                                 "v_fmac_f32_e32 %4, %8, %9\n v_fmac_f32_e32 %5, %8, %9\n v_fmac_f32_e32 %6, %8, %9\n v_fmac_f32_e32 %7, %8, %9\n"
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            }
+        }
+    }
+    if (MODE == 9) {            // back-to-back v_mfma_f32_32x32x2_f32 (64 shader cycles each on one SIMD): calibrates ticks per cycle
+        typedef float v16 __attribute__((ext_vector_type(16)));
+        v16 acc0 = {0}, acc1 = {0};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, a1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a0, acc1, 0, 0, 0);
+            }
+        }
+        a2 += acc0[0] + acc1[3];
+    }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     out[threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
@@ -131,5 +158,8 @@ int main()
     run<6>("s_load x16 + 16 fma", out, cyc, 16);
     run<7>("s_load x16 + inv/29", out, cyc, 16);
     run<8>("s_load x16 prefetched", out, cyc, 16);
+    run<9>("v_mfma_f32_32x32x2_f32", out, cyc, 16);
+    run<10>("256 indep v_fma_f32 (VOP3)", out, cyc, 16);
+    run<11>("256 indep v_fmac_f32 (VOP2)", out, cyc, 16);
     return 0;
 }
