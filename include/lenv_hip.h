@@ -38,7 +38,7 @@ enum {
 };
 
 enum { LENV_ACT_IDENTITY = 0, LENV_ACT_RELU = 1, LENV_ACT_LEAKYRELU = 2, LENV_ACT_TANH = 3, LENV_ACT_PRELU = 4 };
-enum { LENV_ENV_CARTPOLE = 0, LENV_ENV_ACROBOT = 1, LENV_ENV_CHEETAH_STANDIN = 2, LENV_ENV_MOUNTAINCAR = 3 };
+enum { LENV_ENV_CARTPOLE = 0, LENV_ENV_ACROBOT = 1, LENV_ENV_CHEETAH_STANDIN = 2, LENV_ENV_MOUNTAINCAR = 3, LENV_ENV_PENDULUM = 4 };
 enum { LENV_RNG_COUNTER = 0, LENV_RNG_TAPE = 1 };
 
 /* models/model_utils.py:4-39 */
@@ -381,6 +381,14 @@ int lenv_cheetah_standin_reset(const uint64_t *keys, const int64_t *episode, int
                                int32_t *elapsed, void *stream);
 int lenv_cheetah_standin_step(int32_t max_steps, int64_t n, const float *action, double *state, int32_t *elapsed,
                               float *obs, float *reward, float *done, void *stream);
+
+/* The continuous real envs of the TD3 path by id (LENV_ENV_CHEETAH_STANDIN: state [n,17], action [n,6], obs [n,17];
+ * LENV_ENV_PENDULUM = gym 0.17.3 Pendulum-v0: state [n,2] = (theta, theta_dot), action [n,1], obs [n,3]); replaces
+ * gym.make(...).reset / .step + TimeLimit behind EnvWrapper (envs/env_wrapper.py:58-75).  Other ids: LENV_ERR_UNSUPPORTED. */
+int lenv_cont_env_reset(int32_t env_id, const uint64_t *keys, const int64_t *episode, int64_t n, double *state, float *obs,
+                        int32_t *elapsed, void *stream);
+int lenv_cont_env_step(int32_t env_id, int32_t max_steps, int64_t n, const float *action, double *state, int32_t *elapsed,
+                       float *obs, float *reward, float *done, void *stream);
 
 /* Counter-RNG key of a chain (same function as the oracle's): kind 0 = theta, 1 = theta+eps, 2 = theta-eps. HOST. */
 /* out[c][i] = (2u - 1) * bounds[i], u = unit(rng(rng_keys[c], rng_stream, i)), i < p: freshly initialised parameter vectors

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "liblenv_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 ACT = {"identity": 0, "relu": 1, "leakyrelu": 2, "tanh": 3, "prelu": 4}
-ENV = {"CartPole-v0": 0, "Acrobot-v1": 1, "HalfCheetah-v3": 2, "MountainCar-v0": 3}
+ENV = {"CartPole-v0": 0, "Acrobot-v1": 1, "HalfCheetah-v3": 2, "MountainCar-v0": 3, "Pendulum-v0": 4}
 RNG_COUNTER, RNG_TAPE = 0, 1
 
 ERRORS = {-1: ValueError, -2: NotImplementedError, -3: ValueError, -4: RuntimeError, -5: RuntimeError}
@@ -113,7 +113,7 @@ EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv
            "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_lds_bytes", "lenv_ddqn_se_inner_loop",
            "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population", "lenv_dueling_se_workspace_bytes",
            "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_dueling_se_inner_loop_hp", "lenv_dueling_agent_init_hp", "lenv_rng_unit", "lenv_td3_rn_inner_loop_hp", "lenv_td3_agent_init_hp", "lenv_icm_num_params", "lenv_dueling_se_inner_loop_icm", "lenv_chain_uniform_init", "lenv_td3_icm_num_params", "lenv_td3_rn_inner_loop_icm", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
-           "lenv_td3_rn_inner_loop", "lenv_mlp_forward", "lenv_cheetah_standin_reset", "lenv_cheetah_standin_step",
+           "lenv_td3_rn_inner_loop", "lenv_mlp_forward", "lenv_cheetah_standin_reset", "lenv_cheetah_standin_step", "lenv_cont_env_reset", "lenv_cont_env_step",
            "lenv_rn_num_params", "lenv_rn_shape_rows", "lenv_nes_worker_best_multi", "lenv_nes_draw", "lenv_nes_status_fold"]
 
 
@@ -206,6 +206,10 @@ def lib():
         L.lenv_cheetah_standin_reset.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp]
         L.lenv_cheetah_standin_step.restype = C.c_int
         L.lenv_cheetah_standin_step.argtypes = [C.c_int32, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
+        L.lenv_cont_env_reset.restype = C.c_int
+        L.lenv_cont_env_reset.argtypes = [C.c_int32, vp, vp, C.c_int64, vp, vp, vp, vp]
+        L.lenv_cont_env_step.restype = C.c_int
+        L.lenv_cont_env_step.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
         L.lenv_rn_shape_population.restype = C.c_int
         L.lenv_rn_shape_population.argtypes = [C.POINTER(QlCfg), vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
         L.lenv_nes_worker_best_multi.restype = C.c_int

@@ -3,7 +3,9 @@ import ctypes as C
 
 from . import _lib
 
-ENV_DIMS = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3), "HalfCheetah-v3": (17, 6), "MountainCar-v0": (2, 3)}
+ENV_DIMS = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3), "HalfCheetah-v3": (17, 6), "MountainCar-v0": (2, 3), "Pendulum-v0": (3, 1)}
+# continuous real envs of the TD3 path: EnvWrapper.get_max_action (envs/env_wrapper.py:106-110)
+TD3_MAX_ACTION = {"HalfCheetah-v3": 1.0, "Pendulum-v0": 2.0}
 
 
 def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **overrides):
@@ -135,11 +137,12 @@ def ql_cfg_from_config(config, tables, rng_mode=_lib.RNG_COUNTER, **overrides):
 
 
 def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
-    """TD3 agent + RewardEnv on the HalfCheetah stand-in.  Fields read at reference agents/TD3.py:13-29,
+    """TD3 agent + RewardEnv / VirtualEnv on the HalfCheetah stand-in or Pendulum-v0.  Fields read at reference agents/TD3.py:13-29,
     agents/base_agent.py:9-26, envs/reward_env.py:8-27, envs/env_wrapper.py:106-110 (max_action)."""
     env_name = config["env_name"]
-    if env_name != "HalfCheetah-v3":
+    if env_name not in TD3_MAX_ACTION:
         raise NotImplementedError("TD3 fused kernel: real env '%s'" % env_name)
+    S, A = ENV_DIMS[env_name]
     e = config["envs"][env_name]
     a = config["agents"]["td3"]
     if a["same_action_num"] != 1:
@@ -148,7 +151,7 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
     def val(v):
         return float(v[1]) if isinstance(v, list) else v
 
-    cfg = _lib.Td3Cfg(env_id=_lib.ENV[env_name], state_dim=17, action_dim=6, max_steps=int(val(e["max_steps"])),
+    cfg = _lib.Td3Cfg(env_id=_lib.ENV[env_name], state_dim=S, action_dim=A, max_steps=int(val(e["max_steps"])),
                       rn_hidden=int(val(e["hidden_size"])), rn_layers=int(val(e["hidden_layer"])), rn_act=_lib.ACT[e["activation_fn"]],
                       rn_prelu=0.25, reward_env_type=int(val(e["reward_env_type"])), info_dim=int(val(e.get("info_dim", 0))),
                       hidden=int(a["hidden_size"]),
@@ -157,7 +160,7 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
                       init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]),
                       policy_delay=int(a["policy_delay"]), rng_mode=int(rng_mode), solved_reward=float(val(e["solved_reward"])),
                       gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), action_std=float(a["action_std"]),
-                      policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=1.0,
+                      policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=TD3_MAX_ACTION[env_name],
                       adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, step_budget=int(a.get("step_budget", 0)))
     if "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 1)) == 0:
         cfg.virtual_env = 1                           # VirtualEnv (default_config_halfcheetah.yaml): `envs` describes the three SE nets

@@ -166,6 +166,18 @@ def halfcheetah_syn_env_td3(num_workers=128, max_iterations=100):
     })
 
 
+def pendulum_syn_env_td3(num_workers=16, max_iterations=50):
+    """Pendulum-v0 VirtualEnv (three SE nets 4-32-32-{3,1,1}, leakyrelu) + TD3 (max_action 2): the published values of
+    default_config_pendulum.yaml (gtn :5-26, td3 :29-48, env :78-85).  The yaml's agent_name is td3_vary: wrap with with_vary()."""
+    cfg = halfcheetah_syn_env_td3(num_workers, max_iterations)
+    cfg["env_name"] = "Pendulum-v0"
+    cfg["agents"]["gtn"].update(time_max=600, quit_when_solved=False)
+    cfg["agents"]["td3"].update(train_episodes=70, lr=1e-3, tau=0.02, print_rate=1, early_out_num=5, early_out_virtual_diff=0.1)
+    cfg["envs"] = {"Pendulum-v0": {"solved_reward": -300.0, "max_steps": 200, "activation_fn": "leakyrelu", "hidden_size": 32,
+                                   "hidden_layer": 2, "info_dim": 0, "reward_env_type": 2}}
+    return cfg
+
+
 def with_vary(config, vary_hp=True):
     """The same experiment with the *_vary agent of the family (default_config_acrobot.yaml:26 ships `agent_name: DDQN_vary`;
     the `<agent>_vary: {vary_hp: ...}` section is :27-28 there)."""

@@ -253,6 +253,60 @@ __device__ __forceinline__ double cheetah_row(int i, const double *x, const floa
     return acc < -10.0 ? -10.0 : (acc > 10.0 ? 10.0 : acc);
 }
 
+// ---- the continuous real envs behind the TD3 path (oracle: td3_env_* in lenv_oracle_td3.inc) ----
+// S / A = observation / action dims, SD = fp64 words of the env's own state (= width of the reset tapes), INFO = entries of
+// the step's info dict.  reset_word: word i of the reset state of episode `row`; step_word: word i of the next state;
+// obs: fp32 observation i of a state; the reward is split into the part that sees the OLD state (reward_pre, computed
+// before the state is overwritten in place) and the part that sees the new one (reward_post).
+template <int ENV> struct ContEnv;
+template <> struct ContEnv<LENV_ENV_CHEETAH_STANDIN> {
+    static constexpr int S = 17, A = 6, SD = 17, INFO = 4;
+    static __device__ __forceinline__ double reset_word(uint64_t key, uint32_t stream, int64_t row, int i)
+    {
+        return -0.1 + 0.2 * u64_to_unit(rng_u64(key, stream, (uint64_t)(row * 17 + i)));
+    }
+    static __device__ __forceinline__ double step_word(int i, const double *x, const float *a) { return cheetah_row(i, x, a); }
+    static __device__ __forceinline__ float obs(int i, const double *x) { return (float)x[i]; }
+    static __device__ __forceinline__ double reward_pre(const double *, const float *a)      // control cost sum a^2
+    {
+        double ctrl = 0.0;
+        for (int k = 0; k < 6; ++k) ctrl = ctrl + (double)a[k] * (double)a[k];
+        return ctrl;
+    }
+    static __device__ __forceinline__ double reward_post(const double *x_new, double pre) { return x_new[8] - 0.1 * pre; }
+};
+// gym==0.17.3 Pendulum-v0 (classic_control/pendulum.py; third party, restated; oracle: orc_pendulum_step): state = (theta,
+// theta_dot); the torque arrives as fp32 and its square in the cost is an fp32 square
+template <> struct ContEnv<LENV_ENV_PENDULUM> {
+    static constexpr int S = 3, A = 1, SD = 2, INFO = 0;
+    static __device__ __forceinline__ double reset_word(uint64_t key, uint32_t stream, int64_t row, int i)
+    {
+        const double pi = 3.141592653589793, u = u64_to_unit(rng_u64(key, stream, (uint64_t)(row * 2 + i)));
+        return i == 0 ? -pi + (2 * pi) * u : -1.0 + 2.0 * u;
+    }
+    static __device__ __forceinline__ float torque(const float *a) { return a[0] < -2.0f ? -2.0f : (a[0] > 2.0f ? 2.0f : a[0]); }
+    static __device__ __forceinline__ double step_word(int i, const double *x, const float *a)
+    {
+        const double g = 10.0, m = 1.0, l = 1.0, dt = 0.05, pi = 3.141592653589793;
+        const double u = (double)torque(a);
+        double newthdot = x[1] + (-3 * g / (2 * l) * det_sin(x[0] + pi) + 3. / (m * (l * l)) * u) * dt;
+        if (i == 0) return x[0] + newthdot * dt;
+        return newthdot < -8.0 ? -8.0 : (newthdot > 8.0 ? 8.0 : newthdot);
+    }
+    static __device__ __forceinline__ float obs(int i, const double *x) { return i == 0 ? (float)det_cos(x[0]) : (i == 1 ? (float)det_sin(x[0]) : (float)x[1]); }
+    static __device__ __forceinline__ double reward_pre(const double *x, const float *a)
+    {
+        const double pi = 3.141592653589793;
+        const float u32 = torque(a);
+        const double usq = (double)(u32 * u32);
+        double an = fmod(x[0] + pi, 2 * pi);               // python float %: the result takes the divisor's sign
+        if (an != 0.0 && an < 0.0) an += 2 * pi;
+        an = an - pi;
+        return -(an * an + .1 * (x[1] * x[1]) + .001 * usq);
+    }
+    static __device__ __forceinline__ double reward_post(const double *, double pre) { return pre; }
+};
+
 __device__ __forceinline__ float act_fwd(int act, float prelu, float z)
 {
     switch (act) {

@@ -85,9 +85,73 @@ __global__ void cheetah_step_kernel(int max_steps, int64_t n, const float *actio
     }
 }
 
+// one env instance per workgroup of 64 threads, any ContEnv
+template <int ENV>
+__global__ void cont_env_reset_kernel(const uint64_t *keys, const int64_t *episode, int64_t n, double *state, float *obs, int32_t *elapsed)
+{
+    using E = ContEnv<ENV>;
+    __shared__ double st[E::SD];
+    const int64_t i = blockIdx.x;
+    const int k = threadIdx.x;
+    if (k < E::SD) { st[k] = E::reset_word(keys[i], STREAM_TEST_RESET, episode[i], k); state[i * E::SD + k] = st[k]; }
+    __syncthreads();
+    if (k < E::S) obs[i * E::S + k] = E::obs(k, st);
+    if (k == 0) elapsed[i] = 0;
+}
+
+template <int ENV>
+__global__ void cont_env_step_kernel(int max_steps, int64_t n, const float *action, double *state, int32_t *elapsed, float *obs,
+                                     float *reward, float *done)
+{
+    using E = ContEnv<ENV>;
+    __shared__ double nx[E::SD];
+    const int64_t i = blockIdx.x;
+    const int k = threadIdx.x;
+    double pre = 0.0;
+    if (k < E::SD) nx[k] = E::step_word(k, state + i * E::SD, action + i * E::A);
+    if (k == 0) pre = E::reward_pre(state + i * E::SD, action + i * E::A);
+    __syncthreads();
+    if (k < E::SD) state[i * E::SD + k] = nx[k];
+    if (k < E::S) obs[i * E::S + k] = E::obs(k, nx);
+    if (k == 0) {
+        reward[i] = (float)E::reward_post(nx, pre);
+        const int el = elapsed[i] + 1;
+        elapsed[i] = el;
+        done[i] = el >= max_steps ? 1.0f : 0.0f;
+    }
+}
+
 }  // namespace lenv
 
 using namespace lenv;
+
+extern "C" int lenv_cont_env_reset(int32_t env_id, const uint64_t *keys, const int64_t *episode, int64_t n, double *state, float *obs,
+                                   int32_t *elapsed, void *stream)
+{
+    if (!keys || !episode || !state || !obs || !elapsed || n < 0) return LENV_ERR_INVALID;
+    if (env_id != LENV_ENV_CHEETAH_STANDIN && env_id != LENV_ENV_PENDULUM) return LENV_ERR_UNSUPPORTED;
+    if (n == 0) return LENV_OK;
+    if (env_id == LENV_ENV_PENDULUM)
+        hipLaunchKernelGGL(cont_env_reset_kernel<LENV_ENV_PENDULUM>, dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream), keys, episode, n, state, obs, elapsed);
+    else
+        hipLaunchKernelGGL(cont_env_reset_kernel<LENV_ENV_CHEETAH_STANDIN>, dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream), keys, episode, n, state, obs, elapsed);
+    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}
+
+extern "C" int lenv_cont_env_step(int32_t env_id, int32_t max_steps, int64_t n, const float *action, double *state, int32_t *elapsed,
+                                  float *obs, float *reward, float *done, void *stream)
+{
+    if (!action || !state || !elapsed || !obs || !reward || !done || n < 0) return LENV_ERR_INVALID;
+    if (env_id != LENV_ENV_CHEETAH_STANDIN && env_id != LENV_ENV_PENDULUM) return LENV_ERR_UNSUPPORTED;
+    if (n == 0) return LENV_OK;
+    if (env_id == LENV_ENV_PENDULUM)
+        hipLaunchKernelGGL(cont_env_step_kernel<LENV_ENV_PENDULUM>, dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream), (int)max_steps, n,
+                           action, state, elapsed, obs, reward, done);
+    else
+        hipLaunchKernelGGL(cont_env_step_kernel<LENV_ENV_CHEETAH_STANDIN>, dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream), (int)max_steps, n,
+                           action, state, elapsed, obs, reward, done);
+    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}
 
 extern "C" int lenv_mlp_forward(const lenv_mlp_desc *d, const float *params, const float *x, int64_t rows, float *y, void *stream)
 {

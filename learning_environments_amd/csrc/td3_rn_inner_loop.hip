@@ -22,7 +22,7 @@ constexpr int T3_MAXL = 3;     // hidden layers of actor / critic (TD3_vary draw
 constexpr int T3_MAXW = 512;   // max hidden_size (outputs wider than 128 run as several 128-column blocks)
 constexpr int T3_MAXB = 768;   // max batch size  (more than 256 rows run as several row blocks; 768 = 3 x the shipped 256)
 constexpr int T3_MAXI = 256;   // rows of one product block
-constexpr int T3_S = 17, T3_A = 6, T3_SA = 23;
+// observation / action dims come from the env (ContEnv<ENV> in lenv_device.cuh): the stand-in 17 / 6, Pendulum-v0 3 / 1
 
 struct MlpOff { int in, H, L, out; int oW[T3_MAXL + 1], ob[T3_MAXL + 1]; int P; };
 
@@ -67,14 +67,15 @@ __device__ unsigned long long g_td3_phase_cycles[16];
 #define PT_MARK(i)
 #endif
 
-template <bool ICM>
+template <bool ICM, int ENV>
 __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
 {
+    using EnvT = ContEnv<ENV>;
     extern __shared__ __align__(16) float lds[];
     const lenv_td3_cfg &cfg = a.cfg;
     const int tid = threadIdx.x;
     const int64_t chain = blockIdx.x;
-    constexpr int S = T3_S, A = T3_A, SA = T3_SA;
+    constexpr int S = EnvT::S, A = EnvT::A, SA = S + A, SD = EnvT::SD;   // observation / action dims, fp64 words of the env's own state
     const bool vary = a.hp_batch != nullptr;
     const int H = vary ? a.hp_hidden[chain] : cfg.hidden, L = vary ? a.hp_layers[chain] : cfg.layers;
     const int B = vary ? a.hp_batch[chain] : cfg.batch_size, Bm = cfg.batch_size;      // LDS is carved for cfg's (maximal) batch
@@ -249,12 +250,12 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
 
     // ---- real-env test phase: T episodes in lock-step (the stand-in never terminates: every episode runs max_steps) ----
     auto test_phase = [&]() {
-        for (int e = tid; e < T * S; e += DNT) {
-            const int te = e / S, i = e - te * S;
+        for (int e = tid; e < T * SD; e += DNT) {
+            const int te = e / SD, i = e - te * SD;
             const int64_t row = n_test_ep + te;
             double v;
-            if (tape) { if (row >= a.tapes.test_reset_stride) { status = -5; v = 0.0; } else v = a.tapes.test_reset[(chain * a.tapes.test_reset_stride + row) * S + i]; }
-            else v = -0.1 + 0.2 * u64_to_unit(rng_u64(key, STREAM_TEST_RESET, (uint64_t)(row * S + i)));
+            if (tape) { if (row >= a.tapes.test_reset_stride) { status = -5; v = 0.0; } else v = a.tapes.test_reset[(chain * a.tapes.test_reset_stride + row) * SD + i]; }
+            else v = EnvT::reset_word(key, STREAM_TEST_RESET, row, i);
             xt_d[e] = v;
         }
         if (tid < T) ep_rew[tid] = 0.0f;
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         float *xt = xn;                                    // [T][S] fp32 observations (xn is free outside learn)
         float *at = xa;                                    // [T][A] actions
         for (int t = 0; t < cfg.max_steps; ++t) {
-            for (int e = tid; e < T * S; e += DNT) xt[e] = (float)xt_d[e];
+            for (int e = tid; e < T * S; e += DNT) { const int te = e / S; xt[e] = EnvT::obs(e - te * S, xt_d + te * SD); }
             __syncthreads();
             mlp_forward(params, mo_actor, xt, S, T, ht, at, A, 0, true, nullptr);
             gq.run<T3_MAXI>(Ps, Qs);
@@ -277,15 +278,14 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 at[e] = v < -ma ? -ma : (v > ma ? ma : v);
             }
             __syncthreads();
-            double nx = 0.0;
-            if (tid < T * S) { const int te = tid / S, i = tid - te * S; nx = cheetah_row(i, xt_d + te * S, at + te * A); }
+            double nx = 0.0, pre = 0.0;
+            if (tid < T * SD) { const int te = tid / SD, i = tid - te * SD; nx = EnvT::step_word(i, xt_d + te * SD, at + te * A); }
+            if (tid < T) pre = EnvT::reward_pre(xt_d + tid * SD, at + tid * A);     // the part of the reward that sees the OLD state
             __syncthreads();
-            if (tid < T * S) xt_d[tid] = nx;
+            if (tid < T * SD) xt_d[tid] = nx;
             __syncthreads();
             if (tid < T) {
-                double ctrlc = 0.0;
-                for (int k = 0; k < A; ++k) ctrlc = ctrlc + (double)at[tid * A + k] * (double)at[tid * A + k];
-                const double rew = xt_d[tid * S + 8] - 0.1 * ctrlc;
+                const double rew = EnvT::reward_post(xt_d + tid * SD, pre);
                 ep_rew[tid] = ep_rew[tid] + (float)rew;
             }
             __syncthreads();
@@ -305,13 +305,14 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         if (budgeted && (int64_t)train_steps + test_steps > cfg.step_budget) { timed_out_at = episode; break; }   // uniform
         const bool learning = episode >= cfg.init_episodes;
         // env.reset(): RewardEnv.reset -> real_env.reset() (reward_env.py:141-143)
-        for (int i = tid; i < S; i += DNT) {
+        for (int i = tid; i < SD; i += DNT) {
             double v;
-            if (tape) { if (episode >= a.tapes.train_reset_stride) { status = -5; v = 0.0; } else v = a.tapes.train_reset[(chain * a.tapes.train_reset_stride + episode) * S + i]; }
-            else v = -0.1 + 0.2 * u64_to_unit(rng_u64(key, STREAM_TRAIN_RESET, (uint64_t)((int64_t)episode * S + i)));
+            if (tape) { if (episode >= a.tapes.train_reset_stride) { status = -5; v = 0.0; } else v = a.tapes.train_reset[(chain * a.tapes.train_reset_stride + episode) * SD + i]; }
+            else v = EnvT::reset_word(key, STREAM_TRAIN_RESET, (int64_t)episode, i);
             xs_d[i] = v;
-            state[i] = (float)v;
         }
+        __syncthreads();
+        if (tid < S) state[tid] = EnvT::obs(tid, xs_d);
         __syncthreads();
         if (!cfg.virtual_env && (rtype == 1 || rtype == 2)) rn_eval(state, nullptr, 12);   // phi(s) of the reset state (carried from step to step)
         int ep_len = 0;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 if (tid < A) {
                     float v;
                     if (tape) { if (n_rand >= a.tapes.rand_action_stride) { status = -3; v = 0.0f; } else v = a.tapes.rand_action[(chain * a.tapes.rand_action_stride + n_rand) * A + tid]; }
-                    else v = (float)(-1.0 + 2.0 * u64_to_unit(rng_u64(key, STREAM_TD3_RAND_ACTION, (uint64_t)(n_rand * A + tid))));
+                    else v = (float)(-(double)ma + (2.0 * (double)ma) * u64_to_unit(rng_u64(key, STREAM_TD3_RAND_ACTION, (uint64_t)(n_rand * A + tid))));   // action_space.sample()
                     action[tid] = v;
                 }
                 ++n_rand;
@@ -359,26 +360,27 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 if (tid == 64) { newrow[2 * S + A] = nse[S]; newrow[2 * S + A + 1] = nse[S + 1]; }
             } else {
             // ---- EnvWrapper.step -> RewardEnv.step -> real_env.step + TimeLimit ----
-            double nx = 0.0;
-            if (tid < S) nx = cheetah_row(tid, xs_d, action);
-            if (tid == 64) {
-                double ctrlc = 0.0;
-                for (int k = 0; k < A; ++k) ctrlc = ctrlc + (double)action[k] * (double)action[k];
-                xs_d[18] = ctrlc;
-            }
+            double nx = 0.0, pre = 0.0;
+            if (tid < SD) nx = EnvT::step_word(tid, xs_d, action);
+            if (tid == 64) pre = EnvT::reward_pre(xs_d, action);                  // the part of the reward that sees the OLD state
             __syncthreads();
-            if (tid < S) { xs_d[tid] = nx; newrow[tid] = state[tid]; newrow[S + A + tid] = (float)nx; }
+            if (tid < SD) xs_d[tid] = nx;
+            if (tid == 64) xs_d[18] = pre;
+            if (tid < S) newrow[tid] = state[tid];
             if (tid >= 64 && tid < 64 + A) newrow[S + tid - 64] = action[tid - 64];
             __syncthreads();
+            if (tid < S) newrow[S + A + tid] = EnvT::obs(tid, xs_d);
             float *info = newrow + 2 * S + A + 4;          // [4] info vector of this step (fp32, as torch.tensor(list(info.values())))
-            if (tid == 0 && rtype >= 3) {
-                info[0] = (float)xs_d[0]; info[1] = (float)xs_d[8]; info[2] = (float)xs_d[8]; info[3] = (float)(-0.1 * xs_d[18]);
+            if constexpr (EnvT::INFO == 4) {
+                if (tid == 64 && rtype >= 3) {
+                    info[0] = (float)xs_d[0]; info[1] = (float)xs_d[8]; info[2] = (float)xs_d[8]; info[3] = (float)(-0.1 * xs_d[18]);
+                }
             }
             __syncthreads();
             if (rtype == 3 || rtype == 4) rn_eval(newrow, info, 12);                 // phi([s | info]): not cacheable, info is this step's
             rn_eval(newrow + S + A, info, 13);             // phi(s') / phi([s' | info]) / w . info
             if (tid == 0) {
-                const double rew = xs_d[8] - 0.1 * xs_d[18];
+                const double rew = EnvT::reward_post(xs_d, xs_d[18]);
                 const float r32 = (float)rew, phi_s = ctrl[12], phi_s2 = ctrl[13];
                 float shaped;                              // RewardEnv._calc_reward (reward_env.py:81-131)
                 switch (rtype) {
@@ -593,6 +595,7 @@ __global__ void td3_agent_init_kernel(lenv_td3_cfg cfg, const int32_t *hp_hidden
     const int H = hp_hidden ? hp_hidden[c] : cfg.hidden, L = hp_layers ? hp_layers[c] : cfg.layers;
     if (H < 1 || H > cfg.hidden || L < 1 || L > cfg.layers) return;            // the inner loop reports status -8 for this chain
     MlpOff ma, mc;
+    const int T3_S = cfg.state_dim, T3_A = cfg.action_dim, T3_SA = T3_S + T3_A;
     mlp_off(ma, T3_S, H, L, T3_A);
     mlp_off(mc, T3_SA, H, L, 1);
     const int P = ma.P + 2 * mc.P;
@@ -615,12 +618,15 @@ using namespace lenv;
 static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
 {
     const int H = cfg->hidden, L = cfg->layers, B = cfg->batch_size, T = cfg->test_episodes, Hrn = cfg->rn_hidden;
-    if (cfg->env_id != LENV_ENV_CHEETAH_STANDIN || cfg->state_dim != T3_S || cfg->action_dim != T3_A) return LENV_ERR_UNSUPPORTED;
+    const int T3_S = cfg->state_dim, T3_A = cfg->action_dim, T3_SA = T3_S + T3_A;
+    if (!((cfg->env_id == LENV_ENV_CHEETAH_STANDIN && T3_S == 17 && T3_A == 6) || (cfg->env_id == LENV_ENV_PENDULUM && T3_S == 3 && T3_A == 1)))
+        return LENV_ERR_UNSUPPORTED;
     const int t = cfg->reward_env_type;
     if (!((t >= 0 && t <= 8) || t == 101 || t == 102)) return LENV_ERR_UNSUPPORTED;          // reward_env.py:49,58 NotImplementedError
     if (cfg->act == LENV_ACT_PRELU) return LENV_ERR_UNSUPPORTED;   // trained PReLU slope of the agent nets: not a parameter here yet
     const bool uses_info = t == 3 || t == 4 || t == 7 || t == 8 || t > 100;
     if (uses_info && cfg->info_dim != 4) return LENV_ERR_INVALID;                              // the stand-in's info vector has 4 entries
+    if (uses_info && cfg->env_id != LENV_ENV_CHEETAH_STANDIN) return LENV_ERR_INVALID;         // Pendulum's step returns an empty info dict
     if (L < 1 || L > T3_MAXL || H < 1 || H > T3_MAXW || B < 1 || B > T3_MAXB || T < 1 || T * T3_S > DNT || (cfg->virtual_env ? (cfg->rn_layers < 1 || cfg->rn_layers > T3_MAXL || Hrn > T3_MAXW) : cfg->rn_layers != 1) || Hrn < 1 ||
         cfg->policy_delay < 1 || cfg->max_steps < 1 || cfg->train_episodes < 0)
         return LENV_ERR_UNSUPPORTED;
@@ -762,15 +768,16 @@ extern "C" int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg, const lenv_ch
     a.hp_lr = hp ? hp->lr : nullptr; a.hp_batch = hp ? hp->batch_size : nullptr;
     a.hp_hidden = hp ? hp->q_hidden : nullptr; a.hp_layers = hp ? hp->q_layers : nullptr;
     a.icm_init = cfg->icm_enabled ? icm->icm_init : nullptr; a.icm_final = cfg->icm_enabled ? icm->icm_final : nullptr;
-    const void *kfn = cfg->icm_enabled ? reinterpret_cast<const void *>(td3_rn_inner_kernel<true>) : reinterpret_cast<const void *>(td3_rn_inner_kernel<false>);
-    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    void (*kern)(const Td3Args) = nullptr;
+    if (cfg->env_id == LENV_ENV_PENDULUM) kern = cfg->icm_enabled ? td3_rn_inner_kernel<true, LENV_ENV_PENDULUM> : td3_rn_inner_kernel<false, LENV_ENV_PENDULUM>;
+    else kern = cfg->icm_enabled ? td3_rn_inner_kernel<true, LENV_ENV_CHEETAH_STANDIN> : td3_rn_inner_kernel<false, LENV_ENV_CHEETAH_STANDIN>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;
     if (out->status) {
         e = hipMemsetAsync(out->status, 0, sizeof(int32_t) * chains, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return LENV_ERR_LAUNCH;
     }
-    if (cfg->icm_enabled) hipLaunchKernelGGL(td3_rn_inner_kernel<true>, dim3((unsigned)chains), dim3(DNT), lds_bytes, static_cast<hipStream_t>(stream), a);
-    else hipLaunchKernelGGL(td3_rn_inner_kernel<false>, dim3((unsigned)chains), dim3(DNT), lds_bytes, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)chains), dim3(DNT), lds_bytes, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }
 

@@ -17,7 +17,8 @@ _SPECS = {
     "Acrobot-v1": dict(S=6, A=3, max_steps=500, high=[1.0, 1.0, 1.0, 1.0, 4 * math.pi, 9 * math.pi]),
     "MountainCar-v0": dict(S=2, A=3, max_steps=200, low=[-1.2, -0.07], high=[0.6, 0.07]),
     # HalfCheetah-v3 is served by the documented STAND-IN (tools/gen_cheetah_standin.py): MuJoCo cannot be installed
-    "HalfCheetah-v3": dict(S=17, A=6, max_steps=1000, high=[np.inf] * 17, continuous=True),
+    "HalfCheetah-v3": dict(S=17, A=6, SD=17, max_steps=1000, high=[np.inf] * 17, continuous=True, max_action=1.0),
+    "Pendulum-v0": dict(S=3, A=1, SD=2, max_steps=200, high=[1.0, 1.0, 8.0], continuous=True, max_action=2.0),
 }
 
 
@@ -32,9 +33,9 @@ class DeviceRealEnv(object):
         self.env_id = _lib.ENV[env_name]
         self.observation_space = Box(np.asarray(spec["low"]) if "low" in spec else -np.asarray(spec["high"]), np.asarray(spec["high"]))
         self.continuous = bool(spec.get("continuous", False))
-        self.action_space = Box(-np.ones(spec["A"]), np.ones(spec["A"])) if self.continuous else Discrete(spec["A"])
+        self.action_space = Box(-np.ones(spec["A"]) * spec["max_action"], np.ones(spec["A"]) * spec["max_action"]) if self.continuous else Discrete(spec["A"])
         self._A = spec["A"]
-        self._SD = 17 if self.continuous else 4          # float64 state words
+        self._SD = spec["SD"] if self.continuous else 4  # float64 state words
         self._max_episode_steps = spec["max_steps"]
         self._S = spec["S"]
         self._seed = int(seed)
@@ -63,8 +64,8 @@ class DeviceRealEnv(object):
         d["episode"].fill_(self._episode)
         self._episode += 1
         if self.continuous:
-            rc = _lib.lib().lenv_cheetah_standin_reset(_ptr(d["key"]), _ptr(d["episode"]), 1, _ptr(d["state"]), _ptr(d["obs"]),
-                                                       _ptr(d["elapsed"]), _stream())
+            rc = _lib.lib().lenv_cont_env_reset(self.env_id, _ptr(d["key"]), _ptr(d["episode"]), 1, _ptr(d["state"]), _ptr(d["obs"]),
+                                                _ptr(d["elapsed"]), _stream())
         else:
             rc = _lib.lib().lenv_real_env_reset(self.env_id, _ptr(d["key"]), _ptr(d["episode"]), 1, _ptr(d["state"]), _ptr(d["obs"]),
                                                 _ptr(d["elapsed"]), _stream())
@@ -75,15 +76,15 @@ class DeviceRealEnv(object):
         d = self._alloc()
         if self.continuous:
             d["action"].copy_(torch.as_tensor(np.asarray(action, np.float32).reshape(-1)))
-            rc = _lib.lib().lenv_cheetah_standin_step(int(self._max_episode_steps), 1, _ptr(d["action"]), _ptr(d["state"]),
-                                                      _ptr(d["elapsed"]), _ptr(d["obs"]), _ptr(d["reward"]), _ptr(d["done"]), _stream())
+            rc = _lib.lib().lenv_cont_env_step(self.env_id, int(self._max_episode_steps), 1, _ptr(d["action"]), _ptr(d["state"]),
+                                               _ptr(d["elapsed"]), _ptr(d["obs"]), _ptr(d["reward"]), _ptr(d["done"]), _stream())
         else:
             d["action"].fill_(int(action))
             rc = _lib.lib().lenv_real_env_step(self.env_id, int(self._max_episode_steps), 1, _ptr(d["action"]), _ptr(d["state"]),
                                                _ptr(d["elapsed"]), _ptr(d["obs"]), _ptr(d["reward"]), _ptr(d["done"]), _stream())
         _lib.check(rc, "lenv_real_env_step")
         info = {}
-        if self.continuous:
+        if self.env_name == "HalfCheetah-v3":
             # info dict of the stand-in (same keys/order as HalfCheetah-v3: x_position, x_velocity, reward_run, reward_ctrl);
             # consumed by the RewardEnv types 3,4,7,8,101,102 (reward_env.py:95-131)
             st = d["state"].cpu().numpy().reshape(-1)

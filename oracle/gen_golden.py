@@ -829,11 +829,11 @@ def _pack_td3(agent, target=False):
     return np.concatenate([pack_linear_params(n.state_dict(), "net.") for n in nets])
 
 
-def _td3_cfg(over=None, env_over=None):
-    cfg = load_cfg("default_config_halfcheetah_reward_env.yaml")
+def _td3_cfg(over=None, env_over=None, cfg_yaml="default_config_halfcheetah_reward_env.yaml", env_name="HalfCheetah-v3"):
+    cfg = load_cfg(cfg_yaml)
     cfg["agents"]["td3"].update(over or {})
     cfg["agents"]["td3"]["print_rate"] = int(1e9)
-    cfg["envs"]["HalfCheetah-v3"].update(env_over or {})
+    cfg["envs"][env_name].update(env_over or {})
     return cfg
 
 
@@ -899,7 +899,8 @@ def gen_g4t():
     save("g4t_td3_learn", **out)
 
 
-def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over=None, virtual=False):
+def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over=None, virtual=False,
+            cfg_yaml="default_config_halfcheetah_reward_env.yaml", env_name="HalfCheetah-v3", env_cls="CheetahStandinEnv"):
     import json
     import statistics
     import agents.GTN_worker as gw
@@ -907,7 +908,7 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over
     import gym.envs as genvs
     import gym.spaces as gspaces
     cfg = _td3_cfg(agent_over or {"train_episodes": 4, "init_episodes": 2, "batch_size": 16, "hidden_size": 24, "test_episodes": 2},
-                   env_over or {"max_steps": 7, "hidden_size": 20})
+                   env_over or {"max_steps": 7, "hidden_size": 20}, cfg_yaml=cfg_yaml, env_name=env_name)
     drawn = {}
     if virtual:                                   # default_config_halfcheetah.yaml: TD3 on a VirtualEnv (synthetic_env_type 0)
         cfg["agents"]["gtn"]["synthetic_env_type"] = 0
@@ -929,7 +930,8 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over
         ConfigSpace.ConfigurationSpace.sample_configuration = rec_sample
     rec = dict(rand=[], act_noise=[], test_noise=[], policy_noise=[], replay=[], resets=[], steps=[], purpose=None, active=False)
     orig_randn, orig_randn_like, orig_randint = torch.randn, torch.randn_like, np.random.randint
-    orig_box_sample, orig_reset = gspaces.Box.sample, genvs.CheetahStandinEnv.reset
+    env_class = getattr(genvs, env_cls)
+    orig_box_sample, orig_reset = gspaces.Box.sample, env_class.reset
 
     def rec_randn(*a, **k):
         v = orig_randn(*a, **k)
@@ -1005,7 +1007,7 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over
             return ns, r, d
         env.step = rec_step
         torch.randn, torch.randn_like, np.random.randint = rec_randn, rec_randn_like, rec_randint
-        gspaces.Box.sample, genvs.CheetahStandinEnv.reset = rec_box_sample, rec_reset
+        gspaces.Box.sample, env_class.reset = rec_box_sample, rec_reset
         gw.select_agent = wrapped_select_agent
         train_reset_id = id(env.env.reset_env.env.unwrapped) if virtual else id(env.env.real_env.unwrapped)
         try:
@@ -1017,7 +1019,7 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over
             rec["active"] = False
         finally:
             torch.randn, torch.randn_like, np.random.randint = orig_randn, orig_randn_like, orig_randint
-            gspaces.Box.sample, genvs.CheetahStandinEnv.reset = orig_box_sample, orig_reset
+            gspaces.Box.sample, env_class.reset = orig_box_sample, orig_reset
             gw.select_agent = orig_select_agent
     if vary_seed is not None:
         ConfigSpace.ConfigurationSpace.sample_configuration = orig_sample
@@ -1029,7 +1031,7 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over
     save(name, config_json=np.array(json.dumps(cfg)), hp_json=np.array(json.dumps(drawn)), theta=theta, agent_init=holder["init"], **extra,
          tape_rand_action=np.stack(rec["rand"][1::2]).astype(np.float32),          # get_random_action samples twice, returns the 2nd
          tape_act_noise=np.stack(rec["act_noise"]).astype(np.float32), tape_test_noise=np.stack(rec["test_noise"]).astype(np.float32),
-         tape_policy_noise=np.stack(rec["policy_noise"]).astype(np.float32).reshape(-1, 6),
+         tape_policy_noise=np.stack(rec["policy_noise"]).astype(np.float32).reshape(-1, np.stack(rec["rand"]).shape[-1]),
          tape_replay_idx=np.stack(rec["replay"]).astype(np.int32),
          tape_train_reset=np.array([s for (i, s) in rec["resets"] if i == train_reset_id]),
          tape_test_reset=np.array([s for (i, s) in rec["resets"] if i != train_reset_id]),
@@ -1072,6 +1074,17 @@ def main():
         gen_g8t("g8ts_calc_score_cheetah_td3_virtual_env", seed=834, virtual=True,
                 agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 16, "hidden_size": 24, "test_episodes": 1},
                 env_over={"max_steps": 8, "hidden_size": 20, "hidden_layer": 2, "activation_fn": "leakyrelu", "reward_env_type": 0})
+    if "g8p" in which:
+        # default_config_pendulum.yaml's combination: TD3 on a VirtualEnv of Pendulum-v0 (3 obs, 1 action, max_action 2), tested on
+        # the real Pendulum; and default_config_pendulum_reward_env.yaml's: TD3 on a RewardEnv (type 2) over the real Pendulum
+        gen_g8t("g8p_calc_score_pendulum_td3_virtual_env", seed=870, virtual=True, cfg_yaml="default_config_pendulum_reward_env.yaml",
+                env_name="Pendulum-v0", env_cls="PendulumEnv",
+                agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 16, "hidden_size": 24, "test_episodes": 2},
+                env_over={"max_steps": 9, "hidden_size": 20, "hidden_layer": 2, "activation_fn": "leakyrelu", "reward_env_type": 0})
+        gen_g8t("g8pr_calc_score_pendulum_td3_reward_env", seed=871, cfg_yaml="default_config_pendulum_reward_env.yaml",
+                env_name="Pendulum-v0", env_cls="PendulumEnv",
+                agent_over={"train_episodes": 4, "init_episodes": 2, "batch_size": 16, "hidden_size": 24, "test_episodes": 2},
+                env_over={"max_steps": 8, "hidden_size": 20, "hidden_layer": 1, "activation_fn": "prelu", "reward_env_type": 2})
     if "g8ti" in which:
         gen_g8t("g8ti_calc_score_cheetah_td3_icm", seed=833,
                 agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 16, "hidden_size": 24, "test_episodes": 1},

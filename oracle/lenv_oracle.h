@@ -209,7 +209,7 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
 
 /* ---- config 5: TD3 on a continuous-state RewardEnv (agents/TD3.py:13-135, envs/reward_env.py:61-133) ----
  * real env: the documented HalfCheetah-v3 stand-in (tools/gen_cheetah_standin.py). */
-enum { ORC_ENV_CHEETAH_STANDIN = 2 };
+enum { ORC_ENV_CHEETAH_STANDIN = 2, ORC_ENV_PENDULUM = 4 };
 typedef struct {
     int32_t env_id, state_dim, action_dim, max_steps;
     int32_t rn_hidden, rn_layers, rn_act;

@@ -507,11 +507,11 @@ def td3_cfg_from_config(config, rng_mode=0, **overrides):
     """Reference YAML dict (TD3 agent + reward env on the HalfCheetah stand-in) -> oracle config; fields read at
     agents/TD3.py:13-29, agents/base_agent.py:9-26, envs/reward_env.py:8-27."""
     env_name = config["env_name"]
-    assert env_name == "HalfCheetah-v3"
+    env_id, S, A, max_action = TD3_ENVS[env_name]
     e = config["envs"][env_name]
     a = config["agents"]["td3"]
     assert a["same_action_num"] == 1
-    cfg = Td3Cfg(env_id=2, state_dim=17, action_dim=6, max_steps=int(e["max_steps"]), rn_hidden=int(e["hidden_size"]),
+    cfg = Td3Cfg(env_id=env_id, state_dim=S, action_dim=A, max_steps=int(e["max_steps"]), rn_hidden=int(e["hidden_size"]),
                  rn_layers=int(e["hidden_layer"]), rn_act=ACT[e["activation_fn"]], rn_prelu=0.25,
                  reward_env_type=int(e["reward_env_type"]), info_dim=int(e.get("info_dim", 0)), hidden=int(a["hidden_size"]),
                  layers=int(a["hidden_layer"]), act=ACT[a["activation_fn"]], prelu=0.25, batch_size=int(a["batch_size"]), rb_size=int(a["rb_size"]),
@@ -519,7 +519,7 @@ def td3_cfg_from_config(config, rng_mode=0, **overrides):
                  init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]),
                  policy_delay=int(a["policy_delay"]), rng_mode=rng_mode, solved_reward=float(e["solved_reward"]),
                  gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), action_std=float(a["action_std"]),
-                 policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=1.0,
+                 policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=max_action,
                  adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, step_budget=int(a.get("step_budget", 0)))
     if "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 1)) == 0:
         cfg.virtual_env = 1                           # the agent trains on a VirtualEnv: the `envs` section describes the three SE nets
@@ -531,6 +531,11 @@ def td3_cfg_from_config(config, rng_mode=0, **overrides):
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg
+
+
+# continuous real envs of the TD3 path: env id, observation dim, action dim, EnvWrapper.get_max_action (env_wrapper.py:106-110)
+TD3_ENVS = {"HalfCheetah-v3": (2, 17, 6, 1.0), "Pendulum-v0": (4, 3, 1, 2.0)}
+TD3_STATE_WORDS = {2: 17, 4: 2}          # fp64 words of the env's own state (= width of the reset tapes)
 
 
 def td3_param_counts(cfg):

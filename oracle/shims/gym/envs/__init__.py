@@ -286,12 +286,68 @@ class CheetahStandinEnv(Env):
         return None
 
 
+class PendulumEnv(Env):
+    """gym==0.17.3 classic_control/pendulum.py (Pendulum-v0), restated; third party, not under /root/reference.  The torque
+    arrives as a float32 array (EnvWrapper.step: action.cpu().detach().numpy()); with the numpy of the reference's era
+    (value-based casting) `u ** 2` is a float32 square and every other product promotes u to float64 -- written out
+    explicitly here so the arithmetic does not depend on the installed numpy."""
+
+    def __init__(self, g=10.0):
+        self.max_speed = 8
+        self.max_torque = 2.
+        self.dt = .05
+        self.g = g
+        self.m = 1.
+        self.l = 1.
+        high = np.array([1., 1., self.max_speed], dtype=np.float32)
+        self.action_space = spaces.Box(low=-self.max_torque, high=self.max_torque, shape=(1,), dtype=np.float32)
+        self.observation_space = spaces.Box(low=-high, high=high, dtype=np.float32)
+        self.state = None
+        self.seed()
+
+    def seed(self, seed=None):
+        self.np_random, seed = seeding.np_random(seed)
+        return [seed]
+
+    def step(self, u):
+        th, thdot = float(self.state[0]), float(self.state[1])
+        g, m, l, dt = self.g, self.m, self.l, self.dt
+        u32 = np.float32(np.clip(np.asarray(u, np.float32), np.float32(-self.max_torque), np.float32(self.max_torque)).reshape(-1)[0])
+        ud = float(u32)
+        self.last_u = ud
+        usq = float(np.float32(u32 * u32))
+        costs = _angle_normalize(th) ** 2 + .1 * thdot ** 2 + .001 * usq
+        newthdot = thdot + (-3 * g / (2 * l) * math.sin(th + math.pi) + 3. / (m * l ** 2) * ud) * dt
+        newth = th + newthdot * dt
+        newthdot = min(max(newthdot, -float(self.max_speed)), float(self.max_speed))
+        self.state = np.array([newth, newthdot])
+        return self._get_obs(), -costs, False, {}
+
+    def reset(self):
+        high = np.array([np.pi, 1])
+        self.state = self.np_random.uniform(low=-high, high=high)
+        self.last_u = None
+        return self._get_obs()
+
+    def _get_obs(self):
+        theta, thetadot = float(self.state[0]), float(self.state[1])
+        return np.array([math.cos(theta), math.sin(theta), thetadot])
+
+    def render(self, mode='human'):
+        return None
+
+
+def _angle_normalize(x):
+    return (((x + math.pi) % (2 * math.pi)) - math.pi)
+
+
 _REGISTRY = {
     'CartPole-v0': (CartPoleEnv, EnvSpec('CartPole-v0', 200, 195.0)),
     'CartPole-v1': (CartPoleEnv, EnvSpec('CartPole-v1', 500, 475.0)),
     'Acrobot-v1': (AcrobotEnv, EnvSpec('Acrobot-v1', 500, -100.0)),
     'MountainCar-v0': (MountainCarEnv, EnvSpec('MountainCar-v0', 200, -110.0)),
     'HalfCheetah-v3': (CheetahStandinEnv, EnvSpec('HalfCheetah-v3', 1000, 4800.0)),
+    'Pendulum-v0': (PendulumEnv, EnvSpec('Pendulum-v0', 200, None)),
 }
 
 

@@ -1,6 +1,7 @@
 """GPU tests of the drop-in Python surface (EnvFactory / EnvWrapper / VirtualEnv / RewardEnv / GTN_Master / GTN_Worker):
 the same calls a user of the reference makes, checked against the reference's golden vectors and the oracle."""
 import json
+import math
 import os
 import sys
 
@@ -98,6 +99,33 @@ def test_real_env_mountaincar_step_matches_oracle():
             assert dn.value == 1 and st[0] >= 0.5
             break
     assert 60 < t < 199
+
+
+def test_real_env_pendulum_step_matches_oracle():
+    """Pendulum-v0 through EnvWrapper.reset/step on the device against the oracle's step: pumped up to the speed clip, bit-exact
+    observations and rewards, TimeLimit after 200 steps, max_action 2 and a Box(-2, 2) action space."""
+    from learning_environments_amd.configs import pendulum_syn_env_td3
+    from learning_environments_amd.envs.env_factory import EnvFactory
+    from oracle import oracle as orc
+    import ctypes as C
+    real = EnvFactory(pendulum_syn_env_td3()).generate_real_env()
+    assert (real.get_state_dim(), real.get_action_dim(), real.get_max_action()) == (3, 1, 2)
+    assert float(real.env.action_space.high[0]) == 2.0 and not real.has_discrete_action_space()
+    s = real.reset()
+    st = (C.c_double * 2)(*real.env._alloc()["state"].cpu().tolist())
+    assert -math.pi <= st[0] <= math.pi and -1 <= st[1] <= 1
+    assert abs(float(s[0]) - math.cos(st[0])) <= 1e-6 and float(s[2]) == np.float32(st[1])
+    rew = C.c_double()
+    for t in range(200):
+        a = np.float32(2.5 if st[1] >= 0 else -2.5)
+        ns, r, d = real.step(torch.tensor([float(a)]))
+        orc.lib().orc_pendulum_step(st, (C.c_float * 1)(a), C.byref(rew))
+        dev_state = real.env._alloc()["state"].cpu().tolist()
+        assert dev_state == [st[0], st[1]]
+        assert abs(float(ns[0]) - math.cos(st[0])) <= 1e-6 and abs(float(ns[1]) - math.sin(st[0])) <= 1e-6 and float(ns[2]) == np.float32(st[1])
+        assert float(r) == np.float32(rew.value)
+        assert float(d) == (1.0 if t == 199 else 0.0)
+    assert abs(st[1]) == 8.0 or abs(st[0]) > 2 * math.pi
 
 
 def test_reward_env_step_matches_reference(golden):

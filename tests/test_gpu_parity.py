@@ -1089,6 +1089,98 @@ def test_td3_counter_mode_vs_oracle(eng, orc, golden, hidden, layers, batch, act
         assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Pendulum-v0 behind the TD3 path (default_config_pendulum.yaml / default_config_pendulum_reward_env.yaml)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["g8p_calc_score_pendulum_td3_virtual_env", "g8pr_calc_score_pendulum_td3_reward_env"])
+def test_td3_pendulum_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
+    g = golden(name)
+    ocfg, cfg = _td3_cfgs(orc, json.loads(str(g["config_json"])), 1)
+    assert (cfg.env_id, cfg.state_dim, cfg.action_dim, cfg.max_action) == (4, 3, 1, 2.0)
+    n = g["tr_reward"].size
+    otapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
+                                g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"], A=1, S=2)
+    o = orc.td3_rn_chain(ocfg, g["theta"], g["agent_init"], tapes=otapes, trace_cap=n + 4)
+    assert o["rc"] == 0
+    chains = 2
+    rep = lambda a: dev(np.tile(np.ascontiguousarray(a)[None], (chains,) + (1,) * np.ndim(a)))
+    tapes = dict(rand_action=rep(g["tape_rand_action"]), act_noise=rep(g["tape_act_noise"]), test_noise=rep(g["tape_test_noise"]),
+                 policy_noise=rep(g["tape_policy_noise"]), replay_idx=rep(g["tape_replay_idx"].reshape(-1)),
+                 train_reset=rep(g["tape_train_reset"]), test_reset=rep(g["tape_test_reset"]))
+    il = eng.Td3InnerLoop(cfg, chains, trace_cap=n + 4, want_episode_stats=True)
+    assert il.p_agent == g["agent_init"].size
+    il.run(dev(g["theta"]), None, None, None, dev(np.tile(g["agent_init"], (chains, 1))), tapes=tapes)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        assert np.array_equal(il.trace["action"][c, :n].cpu().numpy(), o["trace"]["action"])
+        assert np.array_equal(il.trace["state"][c, :n].cpu().numpy(), o["trace"]["state"])
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"])
+        assert np.array_equal(il.trace["reward"][c, :n].cpu().numpy(), o["trace"]["reward"])
+        assert np.array_equal(il.episode_len[c].cpu().numpy(), o["episode_len"])
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(il.final_returns[c].cpu().numpy(), o["final_test_returns"])
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        # against the reference's own run
+        np.testing.assert_allclose(il.trace["action"][c, :n].cpu().numpy(), g["tr_action"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(il.trace["next_state"][c, :n].cpu().numpy(), g["tr_next_state"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(il.trace["reward"][c, :n].cpu().numpy(), g["tr_reward"], rtol=0, atol=5e-5)
+        assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4
+
+
+@pytest.mark.parametrize("virtual,rtype,rn_layers,act,hidden,layers,batch", [(False, 2, 1, "prelu", 128, 2, 256), (False, 1, 1, "tanh", 24, 1, 20),
+                                                                             (False, 0, 1, "relu", 24, 1, 20), (False, 6, 1, "relu", 33, 2, 40),
+                                                                             (True, 0, 2, "leakyrelu", 128, 2, 256), (True, 0, 1, "tanh", 24, 1, 20)])
+def test_td3_pendulum_counter_mode_vs_oracle(eng, orc, golden, virtual, rtype, rn_layers, act, hidden, layers, batch):
+    """Pendulum-v0, RewardEnv types without an info vector and the VirtualEnv (the shipped 4-32-32-x SE shape among them),
+    perturbed synthetic envs, full-length 200-step episodes in the first case: bit-exact against the oracle."""
+    g = golden("g8pr_calc_score_pendulum_td3_reward_env")
+    cfgd = json.loads(str(g["config_json"]))
+    cfgd["agents"]["gtn"]["synthetic_env_type"] = 0 if virtual else 1
+    long_run = hidden == 128 and not virtual
+    cfgd["agents"]["td3"].update(hidden_size=hidden, hidden_layer=layers, batch_size=batch, train_episodes=3, init_episodes=1, test_episodes=3,
+                                 early_out_num=50)
+    cfgd["envs"]["Pendulum-v0"].update(max_steps=200 if long_run else 12, hidden_size=32, hidden_layer=rn_layers, activation_fn=act,
+                                       reward_env_type=rtype, solved_reward=1e9)
+    ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
+    Pa, Pc = orc.td3_param_counts(ocfg)
+    if virtual:
+        P_rn = orc.mlp_num_params(orc.mlp_desc(4, 32, rn_layers, 3, act)) + 2 * orc.mlp_num_params(orc.mlp_desc(4, 32, rn_layers, 1, act))
+    else:
+        P_rn = max(1, orc.rn_num_params(rtype, 3, 0, 32, 1))
+    rng = np.random.RandomState(13 + rtype)
+    chains = 3
+    theta = (rng.randn(P_rn) * 0.2).astype(np.float32)
+    eps = (rng.randn(1, P_rn) * 0.1).astype(np.float32)
+    agent_init = rng.uniform(-0.2, 0.2, (chains, Pa + 2 * Pc)).astype(np.float32)
+    worker, sign = np.zeros(chains, np.int32), np.array([0.0, 1.0, -1.0], np.float32)
+    keys = np.array([orc.chain_key(23, 6, 0, c) for c in range(chains)], np.uint64)
+    cap = 3 * (200 if long_run else 12)
+    il = eng.Td3InnerLoop(cfg, chains, trace_cap=cap, want_episode_stats=True)
+    assert (il.p_actor, il.p_critic) == (Pa, Pc)
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains if not long_run else 2):
+        w = (np.float32(sign[c]) * eps[0] + theta).astype(np.float32)
+        o = orc.td3_rn_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]), trace_cap=cap)
+        n = o["trace"]["reward"].size
+        assert o["rc"] == 0 and o["learn_steps"] > 0
+        assert np.array_equal(il.trace["action"][c, :n].cpu().numpy(), o["trace"]["action"]), c
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"]), c
+        assert np.array_equal(il.trace["reward"][c, :n].cpu().numpy(), o["trace"]["reward"]), c
+        assert np.array_equal(il.episode_len[c].cpu().numpy(), o["episode_len"]), c
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+    # reward types that need the step's info vector do not exist on Pendulum
+    if not virtual and rtype == 0:
+        cfg.reward_env_type, cfg.info_dim = 3, 4
+        with pytest.raises(Exception):
+            eng.Td3InnerLoop(cfg, chains)
+
+
 @pytest.mark.parametrize("rtype", [0, 1, 2, 3, 4, 5, 6, 7, 8, 101, 102])
 def test_rn_shape_rows_vs_oracle(eng, orc, rtype):
     """RewardEnv._calc_reward for rows of a vector-state env, every reward type: bit-exact against the oracle."""

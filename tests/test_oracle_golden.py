@@ -579,6 +579,63 @@ def test_g8ts_td3_on_a_virtual_env(golden):
     assert abs(out["score"] - float(g["score"])) <= 1e-4
 
 
+@pytest.mark.parametrize("name", ["g8p_calc_score_pendulum_td3_virtual_env", "g8pr_calc_score_pendulum_td3_reward_env"])
+def test_g8p_td3_on_pendulum(golden, name):
+    """default_config_pendulum.yaml / default_config_pendulum_reward_env.yaml's env: TD3 (max_action 2) on a VirtualEnv of
+    Pendulum-v0 and on a RewardEnv (type 2) over the real Pendulum; the reference's runs replayed by the oracle.  The real
+    env's transitions (RewardEnv mode) are bit-exact, the rest within the TD3 tolerances."""
+    import json
+    g = golden(name)
+    cfg = orc.td3_cfg_from_config(json.loads(str(g["config_json"])), rng_mode=1)
+    assert (cfg.env_id, cfg.state_dim, cfg.action_dim, cfg.max_action) == (4, 3, 1, 2.0)
+    tapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
+                               g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"], A=1, S=orc.TD3_STATE_WORDS[4])
+    n = g["tr_reward"].size
+    out = orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 4)
+    assert out["rc"] == 0 and out["trace"]["reward"].size == n
+    np.testing.assert_allclose(out["trace"]["action"], g["tr_action"], rtol=0, atol=2e-5)
+    if cfg.virtual_env:
+        np.testing.assert_allclose(out["trace"]["next_state"], g["tr_next_state"], rtol=0, atol=2e-6)
+    else:
+        assert np.array_equal(out["trace"]["next_state"], g["tr_next_state"])        # the real env's fp64 step, cast once
+        assert np.abs(g["tr_action"]).max() > 1.0                                    # random actions span [-2, 2]
+    np.testing.assert_allclose(out["trace"]["reward"], g["tr_reward"], rtol=0, atol=2e-6)
+    m = g["episode_length_train"].size
+    assert np.array_equal(out["episode_len"][:m], g["episode_length_train"]) and out["episodes_run"] == m   # early-out like the reference
+    np.testing.assert_allclose(out["episode_test_mean"][:m], g["reward_list_train"], rtol=0, atol=1e-4)
+    assert abs(out["score"] - float(g["score"])) <= 1e-4
+    # reward types that read the step's info dict do not exist on Pendulum (its info dict is empty)
+    cfg.reward_env_type, cfg.info_dim = 3, 4
+    if not cfg.virtual_env:
+        assert orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], tapes=tapes)["rc"] != 0
+
+
+def test_pendulum_step_physics():
+    """gym==0.17.3 classic_control/pendulum.py (third party, restated): the oracle's step against a line-by-line float64
+    restatement -- swing with saturated torques (clipped to +-2), the speed clip at 8, angle_normalize across several turns."""
+    import ctypes as C
+    import math
+    st = (C.c_double * 2)(3.0, 0.5)
+    rew = C.c_double()
+    th, thdot = 3.0, 0.5
+    clipped_speed = wrapped = False
+    for t in range(300):
+        a = np.float32((3.0 if thdot >= 0 else -3.0) if t < 200 else -0.7 * (1 + t % 3))     # pump energy in, then small torques
+        orc.lib().orc_pendulum_step(st, (C.c_float * 1)(a), C.byref(rew))
+        u = np.float32(min(max(a, np.float32(-2.0)), np.float32(2.0)))
+        an = ((th + math.pi) % (2 * math.pi)) - math.pi
+        costs = an ** 2 + .1 * thdot ** 2 + .001 * float(np.float32(u * u))
+        nthdot = thdot + (-3 * 10.0 / 2 * math.sin(th + math.pi) + 3. * float(u)) * .05
+        nth = th + nthdot * .05
+        if abs(nthdot) > 8:
+            clipped_speed = True
+        nthdot = min(max(nthdot, -8.0), 8.0)
+        wrapped = wrapped or abs(nth) > 2 * math.pi
+        assert abs(st[0] - nth) <= 1e-12 and abs(st[1] - nthdot) <= 1e-12 and abs(rew.value + costs) <= 1e-12
+        th, thdot = st[0], st[1]                                   # lock-step (orc_sin is a restated sine, not libm's)
+    assert clipped_speed and wrapped
+
+
 def _standin_rollout(g, t):
     """Replay the fixture's episode on the oracle's stand-in env: fp32 states, info vectors and raw fp32 rewards."""
     import ctypes as C
