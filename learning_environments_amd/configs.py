@@ -178,6 +178,17 @@ def pendulum_syn_env_td3(num_workers=16, max_iterations=50):
     return cfg
 
 
+def pendulum_reward_env_td3(num_workers=16, max_iterations=20):
+    """Pendulum-v0 RewardEnv (potential-shaped, type 2, PReLU reward net 3-128-128-1) + TD3: the published values of
+    default_config_pendulum_reward_env.yaml (gtn :5-26, td3 :28-47, env :50-57)."""
+    cfg = pendulum_syn_env_td3(num_workers, max_iterations)
+    cfg["agents"]["gtn"].update(synthetic_env_type=1, noise_std=0.01, step_size=0.5, score_transform_type=3)
+    cfg["agents"]["td3"].update(batch_size=192, gamma=0.98, lr=0.003, tau=0.03, policy_delay=1, activation_fn="leakyrelu",
+                                action_std=0.05, policy_std=0.1, policy_std_clip=0.25, print_rate=5, early_out_virtual_diff=0.04)
+    cfg["envs"]["Pendulum-v0"].update(activation_fn="prelu", hidden_size=128, hidden_layer=2, reward_env_type=2)
+    return cfg
+
+
 def with_vary(config, vary_hp=True):
     """The same experiment with the *_vary agent of the family (default_config_acrobot.yaml:26 ships `agent_name: DDQN_vary`;
     the `<agent>_vary: {vary_hp: ...}` section is :27-28 there)."""

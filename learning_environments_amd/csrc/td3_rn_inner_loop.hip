@@ -101,7 +101,8 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     GemmCmd *cmds = reinterpret_cast<GemmCmd *>(Qs + GemmShape<T3_MAXI>::QS_FLOATS);   // [GEMM_QUEUE_MAX] command queue
     float *rn_w = reinterpret_cast<float *>(cmds + GEMM_QUEUE_MAX);   // reward net: W0 [Hrn][S] | b0 [Hrn] | Wout [Hrn] | bout
     float *rn_h = rn_w + ((a.P_rn_lds + 3) & ~3);         // [Hrn]
-    float *q1 = rn_h + ((Hrn + 3) & ~3);                  // [B]
+    float *rn_h2 = rn_h + ((Hrn + 3) & ~3);               // [Hrn] second hidden row of a reward net with more than one hidden layer
+    float *q1 = rn_h2 + ((Hrn + 3) & ~3);                 // [B]
     float *q2 = q1 + Bm, *tq1 = q2 + Bm, *tq2 = tq1 + Bm, *rr = tq2 + Bm, *dd = rr + Bm, *dq1 = dd + Bm, *dq2 = dq1 + Bm;
     float *misc = dq2 + Bm;                                // [64]
     double *xs_d = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(misc + 64) + 7) & ~(uintptr_t)7);   // [17] train env state
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     {
         const float sg = a.eps ? a.sign[chain] : 0.0f;
         const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P_rn : nullptr;
-        float *dst = cfg.virtual_env ? arena + a.a_se : rn_w;      // VirtualEnv: three nets, too large for LDS -> arena
+        // VirtualEnv (three nets) and reward nets with several hidden layers are too large for LDS -> arena
+        float *dst = (cfg.virtual_env || cfg.rn_layers > 1) ? arena + a.a_se : rn_w;
         for (int i = tid; i < a.P_rn; i += DNT) dst[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
     }
     for (int p = tid; p < P; p += DNT) {
@@ -232,7 +234,10 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             __syncthreads();
             return;
         }
-        const float *W0 = rn_w, *b0 = rn_w + Hrn * Drn, *Wo = b0 + Hrn, *bo = Wo + Hrn;
+        // build_nn_from_config (model_utils.py:16-29): Linear(D, H) | [Linear(H, H)] x (layers - 1) | Linear(H, 1), flat in
+        // Module.parameters() order; one hidden layer lives in LDS, deeper nets in the arena
+        const float *rnp = cfg.rn_layers > 1 ? arena + a.a_se : rn_w;
+        const float *W0 = rnp, *b0 = rnp + Hrn * Drn;
         for (int j = tid; j < Hrn; j += DNT) {
             float z = 0.0f;
             for (int k = 0; k < S; ++k) z = fma32(obs[k], W0[j * Drn + k], z);
@@ -240,9 +245,23 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             rn_h[j] = act_fwd(cfg.rn_act, cfg.rn_prelu, z + b0[j]);
         }
         __syncthreads();
+        const float *hp = rn_h, *Wl = b0 + Hrn;
+        float *hn = rn_h2;
+        for (int l = 1; l < cfg.rn_layers; ++l) {
+            const float *bl = Wl + Hrn * Hrn;
+            for (int j = tid; j < Hrn; j += DNT) {
+                float z = 0.0f;
+                for (int k = 0; k < Hrn; ++k) z = fma32(hp[k], Wl[j * Hrn + k], z);
+                hn[j] = act_fwd(cfg.rn_act, cfg.rn_prelu, z + bl[j]);
+            }
+            __syncthreads();
+            const float *t2 = hp; hp = hn; hn = const_cast<float *>(t2);
+            Wl = bl + Hrn;
+        }
+        const float *Wo = Wl, *bo = Wo + Hrn;
         if (tid == 0) {
             float acc = 0.0f;
-            for (int j = 0; j < Hrn; ++j) acc = fma32(rn_h[j], Wo[j], acc);
+            for (int j = 0; j < Hrn; ++j) acc = fma32(hp[j], Wo[j], acc);
             ctrl[slot] = acc + bo[0];
         }
         __syncthreads();
@@ -627,14 +646,14 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
     const bool uses_info = t == 3 || t == 4 || t == 7 || t == 8 || t > 100;
     if (uses_info && cfg->info_dim != 4) return LENV_ERR_INVALID;                              // the stand-in's info vector has 4 entries
     if (uses_info && cfg->env_id != LENV_ENV_CHEETAH_STANDIN) return LENV_ERR_INVALID;         // Pendulum's step returns an empty info dict
-    if (L < 1 || L > T3_MAXL || H < 1 || H > T3_MAXW || B < 1 || B > T3_MAXB || T < 1 || T * T3_S > DNT || (cfg->virtual_env ? (cfg->rn_layers < 1 || cfg->rn_layers > T3_MAXL || Hrn > T3_MAXW) : cfg->rn_layers != 1) || Hrn < 1 ||
+    if (L < 1 || L > T3_MAXL || H < 1 || H > T3_MAXW || B < 1 || B > T3_MAXB || T < 1 || T * T3_S > DNT || cfg->rn_layers < 1 || cfg->rn_layers > T3_MAXL || Hrn > T3_MAXW || Hrn < 1 ||
         cfg->policy_delay < 1 || cfg->max_steps < 1 || cfg->train_episodes < 0)
         return LENV_ERR_UNSUPPORTED;
     mlp_off(a.actor, T3_S, H, L, T3_A);
     mlp_off(a.critic, T3_SA, H, L, 1);
     a.P = a.actor.P + 2 * a.critic.P;
-    a.P_rn = (int)lenv_rn_num_params(t, T3_S, cfg->info_dim, Hrn, 1);
-    a.P_rn_lds = a.P_rn;
+    a.P_rn = (int)lenv_rn_num_params(t, T3_S, cfg->info_dim, Hrn, cfg->rn_layers);
+    a.P_rn_lds = cfg->rn_layers > 1 ? 0 : a.P_rn;             // deeper reward nets are staged in the arena
     if (cfg->virtual_env) {
         MlpOff m;
         mlp_off(m, T3_SA, Hrn, cfg->rn_layers, T3_S); a.P_rn = m.P;
@@ -659,7 +678,7 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
     if (cfg->virtual_env) {
         if ((int64_t)RB * H < Hrn) return LENV_ERR_UNSUPPORTED;          // the SE's hidden rows reuse the agent's temporaries
         a.a_se = take(a.P_rn); a.a_xse = take(T3_SA); a.a_nse = take(T3_S + 2);
-    }
+    } else if (cfg->rn_layers > 1) a.a_se = take(a.P_rn);
     a.P_icm = 0;
     for (int i = 0; i < IB_COUNT; ++i) a.a_icm[i] = 0;
     if (cfg->icm_enabled) {
@@ -672,7 +691,7 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
         for (int i = 0; i < IB_COUNT; ++i) a.a_icm[i] = take(sz[i]);
     }
     a.arena_stride = (off + 63) & ~(int64_t)63;
-    const size_t lds_floats = GemmShape<T3_MAXI>::PS_FLOATS + GemmShape<T3_MAXI>::QS_FLOATS + GEMM_QUEUE_MAX * sizeof(GemmCmd) / sizeof(float) + ((a.P_rn_lds + 3) & ~3) + ((Hrn + 3) & ~3) + 8 * (size_t)B + 64 + 2 + 2 * (20 + 17 * (size_t)T + T) + T + 20 + 8 + 56 + 16;
+    const size_t lds_floats = GemmShape<T3_MAXI>::PS_FLOATS + GemmShape<T3_MAXI>::QS_FLOATS + GEMM_QUEUE_MAX * sizeof(GemmCmd) / sizeof(float) + ((a.P_rn_lds + 3) & ~3) + 2 * ((Hrn + 3) & ~3) + 8 * (size_t)B + 64 + 2 + 2 * (20 + 17 * (size_t)T + T) + T + 20 + 8 + 56 + 16;
     *lds_bytes = lds_floats * sizeof(float);
     if (*lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     return LENV_OK;

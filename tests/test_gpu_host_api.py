@@ -553,6 +553,41 @@ def test_gtn_master_halfcheetah_virtual_env_td3_vary_as_shipped(tmp_path, monkey
         assert gathered[p, 1] == sc[0] and gathered[p, 0] == max(sc[1], sc[2])
 
 
+def test_gtn_master_pendulum_configs_as_shipped(tmp_path, monkeypatch):
+    """default_config_pendulum.yaml (td3_vary on a VirtualEnv 4-32-32-{3,1,1}) and default_config_pendulum_reward_env.yaml (td3 on
+    a RewardEnv with a two-hidden-layer PReLU reward net) through GTN_Master: the synthetic envs carry the reference's state-dict
+    keys, a short generation runs, and the plain-td3 fitness values equal the oracle's."""
+    from learning_environments_amd.agents import tasks
+    from learning_environments_amd.configs import fixed_work, pendulum_reward_env_td3, pendulum_syn_env_td3, with_vary
+    from oracle import oracle as orc
+    base = fixed_work(pendulum_syn_env_td3(num_workers=2, max_iterations=1), 2)
+    base["envs"]["Pendulum-v0"]["max_steps"] = 8
+    base["agents"]["td3"].update(init_episodes=1, test_episodes=2)
+    m = _master_pair(with_vary(base), tmp_path, monkeypatch)
+    assert isinstance(m.task, tasks.Td3VaryTask) and m.cfg.virtual_env == 1 and (m.cfg.state_dim, m.cfg.action_dim, m.cfg.max_action) == (3, 1, 2.0)
+    assert m.synthetic_env_orig.is_virtual_env() and tuple(m.synthetic_env_orig.state_dict()["env.state_net.0.weight"].shape) == (32, 4)
+    mean_score, mean_list, _ = m.run()
+    assert len(mean_list) == 1 and np.isfinite(mean_score) and m.inner.status.cpu().tolist() == [0] * 6
+    for cfg in (base, fixed_work(pendulum_reward_env_td3(num_workers=2, max_iterations=1), 2)):
+        cfg["envs"]["Pendulum-v0"]["max_steps"] = 8
+        cfg["agents"]["td3"].update(init_episodes=1, test_episodes=2, batch_size=32)
+        m = _master_pair(cfg, tmp_path, monkeypatch)
+        if cfg["agents"]["gtn"]["synthetic_env_type"] == 1:
+            assert m.p_theta == (3 * 128 + 128) + (128 * 128 + 128) + (128 + 1) and m.cfg.rn_layers == 2
+        theta0 = m.theta.cpu().numpy().copy()
+        gathered = m.evaluate_population(0).cpu().numpy()
+        eps = m.eps.cpu().numpy()
+        oeps, init, okeys = orc.nes_draw(m.seed, 0, 2, m.p_theta, cfg["agents"]["gtn"]["noise_std"], 6, 3, 0, m.agent_bounds.cpu().numpy())
+        assert np.array_equal(eps, oeps)
+        ocfg = orc.td3_cfg_from_config(cfg)
+        for p in range(2):
+            sc = []
+            for kind, sg in enumerate((0.0, 1.0, -1.0)):
+                w = (np.float32(sg) * eps[p] + theta0).astype(np.float32)
+                sc.append(orc.td3_rn_chain(ocfg, w, init[3 * p + kind], rng_key=orc.chain_key(m.seed, 0, p, kind))["score"])
+            assert gathered[p, 1] == sc[0] and gathered[p, 0] == max(sc[1], sc[2])
+
+
 def test_gtn_master_td3_vary_generation(tmp_path, monkeypatch):
     """`agent_name: TD3_vary` through GTN_Master (agents/TD3_vary.py): per-chain draws, one launch, oracle-equal fitness."""
     from learning_environments_amd import _lib

@@ -1130,6 +1130,7 @@ def test_td3_pendulum_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
 
 
 @pytest.mark.parametrize("virtual,rtype,rn_layers,act,hidden,layers,batch", [(False, 2, 1, "prelu", 128, 2, 256), (False, 1, 1, "tanh", 24, 1, 20),
+                                                                             (False, 2, 2, "prelu", 24, 1, 20), (False, 5, 3, "leakyrelu", 24, 2, 20),
                                                                              (False, 0, 1, "relu", 24, 1, 20), (False, 6, 1, "relu", 33, 2, 40),
                                                                              (True, 0, 2, "leakyrelu", 128, 2, 256), (True, 0, 1, "tanh", 24, 1, 20)])
 def test_td3_pendulum_counter_mode_vs_oracle(eng, orc, golden, virtual, rtype, rn_layers, act, hidden, layers, batch):
@@ -1148,7 +1149,7 @@ def test_td3_pendulum_counter_mode_vs_oracle(eng, orc, golden, virtual, rtype, r
     if virtual:
         P_rn = orc.mlp_num_params(orc.mlp_desc(4, 32, rn_layers, 3, act)) + 2 * orc.mlp_num_params(orc.mlp_desc(4, 32, rn_layers, 1, act))
     else:
-        P_rn = max(1, orc.rn_num_params(rtype, 3, 0, 32, 1))
+        P_rn = max(1, orc.rn_num_params(rtype, 3, 0, 32, rn_layers))
     rng = np.random.RandomState(13 + rtype)
     chains = 3
     theta = (rng.randn(P_rn) * 0.2).astype(np.float32)
