@@ -38,7 +38,7 @@ enum {
 };
 
 enum { LENV_ACT_IDENTITY = 0, LENV_ACT_RELU = 1, LENV_ACT_LEAKYRELU = 2, LENV_ACT_TANH = 3, LENV_ACT_PRELU = 4 };
-enum { LENV_ENV_CARTPOLE = 0, LENV_ENV_ACROBOT = 1, LENV_ENV_CHEETAH_STANDIN = 2, LENV_ENV_MOUNTAINCAR = 3, LENV_ENV_PENDULUM = 4 };
+enum { LENV_ENV_CARTPOLE = 0, LENV_ENV_ACROBOT = 1, LENV_ENV_CHEETAH_STANDIN = 2, LENV_ENV_MOUNTAINCAR = 3, LENV_ENV_PENDULUM = 4, LENV_ENV_CMC = 5 };
 enum { LENV_RNG_COUNTER = 0, LENV_RNG_TAPE = 1 };
 
 /* models/model_utils.py:4-39 */
@@ -302,7 +302,10 @@ typedef struct {
      * (envs/virtual_env.py:43-54) instead of the RewardEnv: theta = state_net | reward_net | done_net, each
      * (action_dim + state_dim) -> rn_hidden x rn_layers (1-3) -> {state_dim, 1, 1} with rn_act; the learned done flag (> 0.5)
      * ends a training episode.  Tests run on the real (stand-in) env as before. */
-    int32_t virtual_env, virtual_pad_;
+    int32_t virtual_env;
+    /* same_action_num (agents/base_agent.py:20,104,194; envs/env_wrapper.py:24,57): env steps per chosen action -- the rewards of
+     * the repeats are summed, a real env's repeats stop at done; 0 and 1 both mean 1 (MountainCarContinuous configs ship 2) */
+    int32_t same_action_num;
 } lenv_td3_cfg;
 
 /* RNG tapes (parity mode); per-chain rows, strides in ROWS (rows of A floats / B ints / S doubles as noted) */
@@ -383,7 +386,8 @@ int lenv_cheetah_standin_step(int32_t max_steps, int64_t n, const float *action,
                               float *obs, float *reward, float *done, void *stream);
 
 /* The continuous real envs of the TD3 path by id (LENV_ENV_CHEETAH_STANDIN: state [n,17], action [n,6], obs [n,17];
- * LENV_ENV_PENDULUM = gym 0.17.3 Pendulum-v0: state [n,2] = (theta, theta_dot), action [n,1], obs [n,3]); replaces
+ * LENV_ENV_PENDULUM = gym 0.17.3 Pendulum-v0: state [n,2] = (theta, theta_dot), action [n,1], obs [n,3]; LENV_ENV_CMC =
+ * MountainCarContinuous-v0: state [n,2] = (position, velocity), action [n,1], obs [n,2], done at the flag); replaces
  * gym.make(...).reset / .step + TimeLimit behind EnvWrapper (envs/env_wrapper.py:58-75).  Other ids: LENV_ERR_UNSUPPORTED. */
 int lenv_cont_env_reset(int32_t env_id, const uint64_t *keys, const int64_t *episode, int64_t n, double *state, float *obs,
                         int32_t *elapsed, void *stream);

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "liblenv_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 ACT = {"identity": 0, "relu": 1, "leakyrelu": 2, "tanh": 3, "prelu": 4}
-ENV = {"CartPole-v0": 0, "Acrobot-v1": 1, "HalfCheetah-v3": 2, "MountainCar-v0": 3, "Pendulum-v0": 4}
+ENV = {"CartPole-v0": 0, "Acrobot-v1": 1, "HalfCheetah-v3": 2, "MountainCar-v0": 3, "Pendulum-v0": 4, "MountainCarContinuous-v0": 5}
 RNG_COUNTER, RNG_TAPE = 0, 1
 
 ERRORS = {-1: ValueError, -2: NotImplementedError, -3: ValueError, -4: RuntimeError, -5: RuntimeError}
@@ -93,7 +93,7 @@ class Td3Cfg(C.Structure):
                 ("step_budget", C.c_int64),
                 ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("icm_pad_", C.c_int32),
                 ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
-                ("virtual_env", C.c_int32), ("virtual_pad_", C.c_int32)]
+                ("virtual_env", C.c_int32), ("same_action_num", C.c_int32)]
 
 
 class Td3Tapes(C.Structure):

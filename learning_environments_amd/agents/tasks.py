@@ -177,6 +177,9 @@ class Td3VaryTask(object):
         return False
 
 
+TD3_ENVS = ("HalfCheetah-v3", "Pendulum-v0", "MountainCarContinuous-v0")       # continuous real envs of the TD3 kernel
+
+
 def select_task(config, engine, synthetic_env):
     agent_name = config["agents"]["gtn"]["agent_name"].lower()
     env_type = config["agents"]["gtn"]["synthetic_env_type"]
@@ -194,9 +197,9 @@ def select_task(config, engine, synthetic_env):
         if not hasattr(real, "tables"):
             raise NotImplementedError("QL needs a discrete (gridworld) real env")
         return QlRnTask(config, engine, real.tables)
-    # TD3 on the HalfCheetah stand-in / Pendulum-v0: RewardEnv (type 1, BASELINE config 5) or VirtualEnv (type 0, default_config_halfcheetah.yaml)
-    if agent_name in ("td3", "td3_icm") and env_type in (0, 1) and config["env_name"] in ("HalfCheetah-v3", "Pendulum-v0"):
+    # TD3 on the HalfCheetah stand-in / Pendulum-v0 / MountainCarContinuous-v0: RewardEnv (type 1, BASELINE config 5) or VirtualEnv (type 0, default_config_halfcheetah.yaml)
+    if agent_name in ("td3", "td3_icm") and env_type in (0, 1) and config["env_name"] in TD3_ENVS:
         return Td3RnTask(config, engine)
-    if agent_name in ("td3_vary", "td3_icm_vary") and env_type in (0, 1) and config["env_name"] in ("HalfCheetah-v3", "Pendulum-v0"):
+    if agent_name in ("td3_vary", "td3_icm_vary") and env_type in (0, 1) and config["env_name"] in TD3_ENVS:
         return Td3VaryTask(config, engine) if config["agents"]["td3_vary"]["vary_hp"] else Td3RnTask(config, engine)
     raise NotImplementedError("inner agent '%s' on synthetic_env_type %s has no fused kernel yet" % (agent_name, env_type))

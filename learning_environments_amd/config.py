@@ -3,9 +3,9 @@ import ctypes as C
 
 from . import _lib
 
-ENV_DIMS = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3), "HalfCheetah-v3": (17, 6), "MountainCar-v0": (2, 3), "Pendulum-v0": (3, 1)}
+ENV_DIMS = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3), "HalfCheetah-v3": (17, 6), "MountainCar-v0": (2, 3), "Pendulum-v0": (3, 1), "MountainCarContinuous-v0": (2, 1)}
 # continuous real envs of the TD3 path: EnvWrapper.get_max_action (envs/env_wrapper.py:106-110)
-TD3_MAX_ACTION = {"HalfCheetah-v3": 1.0, "Pendulum-v0": 2.0}
+TD3_MAX_ACTION = {"HalfCheetah-v3": 1.0, "Pendulum-v0": 2.0, "MountainCarContinuous-v0": 1.0}
 
 
 def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **overrides):
@@ -145,8 +145,6 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
     S, A = ENV_DIMS[env_name]
     e = config["envs"][env_name]
     a = config["agents"]["td3"]
-    if a["same_action_num"] != 1:
-        raise NotImplementedError("same_action_num != 1")
 
     def val(v):
         return float(v[1]) if isinstance(v, list) else v
@@ -164,6 +162,7 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
                       adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, step_budget=int(a.get("step_budget", 0)))
     if "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 1)) == 0:
         cfg.virtual_env = 1                           # VirtualEnv (default_config_halfcheetah.yaml): `envs` describes the three SE nets
+    cfg.same_action_num = int(a["same_action_num"])   # env steps per chosen action (the MountainCarContinuous configs ship 2)
     name = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "td3"
     if name.replace("_vary", "").endswith("_icm"):   # select_agent "td3_icm" / "td3_icm_vary": TD3(icm=True), agents/TD3.py:44-60
         ic = config["agents"]["icm"]

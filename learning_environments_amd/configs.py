@@ -189,6 +189,31 @@ def pendulum_reward_env_td3(num_workers=16, max_iterations=20):
     return cfg
 
 
+def cmc_syn_env_td3(num_workers=128, max_iterations=20):
+    """MountainCarContinuous-v0 VirtualEnv (three SE nets 3-96-96-{2,1,1}, leakyrelu) + TD3 with same_action_num 2: the published
+    values of default_config_cmc.yaml (gtn :5-26, td3 :28-47, env :78-85)."""
+    cfg = halfcheetah_syn_env_td3(num_workers, max_iterations)
+    cfg["env_name"] = "MountainCarContinuous-v0"
+    cfg["agents"]["gtn"].update(num_threads_per_worker=2, time_max=1500, quit_when_solved=False)
+    cfg["agents"]["td3"].update(train_episodes=500, test_episodes=1, init_episodes=50, same_action_num=2, early_out_num=5,
+                                early_out_virtual_diff=0.1)
+    cfg["envs"] = {"MountainCarContinuous-v0": {"solved_reward": 90.0, "max_steps": 999, "activation_fn": "leakyrelu", "hidden_size": 96,
+                                                "hidden_layer": 2, "info_dim": 0, "reward_env_type": 0}}
+    return cfg
+
+
+def cmc_reward_env_td3(num_workers=16, max_iterations=50):
+    """MountainCarContinuous-v0 RewardEnv (potential-shaped, type 2, tanh reward net 2-128-1) + TD3 with same_action_num 2: the
+    published values of default_config_cmc_reward_env.yaml (gtn :5-26, td3 :28-47, env :50-57)."""
+    cfg = cmc_syn_env_td3(num_workers, max_iterations)
+    cfg["agents"]["gtn"].update(num_threads_per_worker=1, step_size=0.5, time_max=3600, score_transform_type=3, synthetic_env_type=1,
+                                unsolved_weight=100)
+    cfg["agents"]["td3"].update(train_episodes=100, batch_size=192, lr=0.003, tau=0.01, policy_delay=1, activation_fn="leakyrelu",
+                                action_std=0.05, print_rate=5, early_out_virtual_diff=0.02)
+    cfg["envs"]["MountainCarContinuous-v0"].update(activation_fn="tanh", hidden_size=128, hidden_layer=1, reward_env_type=2)
+    return cfg
+
+
 def with_vary(config, vary_hp=True):
     """The same experiment with the *_vary agent of the family (default_config_acrobot.yaml:26 ships `agent_name: DDQN_vary`;
     the `<agent>_vary: {vary_hp: ...}` section is :27-28 there)."""

@@ -261,6 +261,8 @@ __device__ __forceinline__ double cheetah_row(int i, const double *x, const floa
 template <int ENV> struct ContEnv;
 template <> struct ContEnv<LENV_ENV_CHEETAH_STANDIN> {
     static constexpr int S = 17, A = 6, SD = 17, INFO = 4;
+    static constexpr bool TERMINATES = false;              // episodes end only through TimeLimit
+    static __device__ __forceinline__ bool done(const double *) { return false; }
     static __device__ __forceinline__ double reset_word(uint64_t key, uint32_t stream, int64_t row, int i)
     {
         return -0.1 + 0.2 * u64_to_unit(rng_u64(key, stream, (uint64_t)(row * 17 + i)));
@@ -279,6 +281,8 @@ template <> struct ContEnv<LENV_ENV_CHEETAH_STANDIN> {
 // theta_dot); the torque arrives as fp32 and its square in the cost is an fp32 square
 template <> struct ContEnv<LENV_ENV_PENDULUM> {
     static constexpr int S = 3, A = 1, SD = 2, INFO = 0;
+    static constexpr bool TERMINATES = false;
+    static __device__ __forceinline__ bool done(const double *) { return false; }
     static __device__ __forceinline__ double reset_word(uint64_t key, uint32_t stream, int64_t row, int i)
     {
         const double pi = 3.141592653589793, u = u64_to_unit(rng_u64(key, stream, (uint64_t)(row * 2 + i)));
@@ -305,6 +309,35 @@ template <> struct ContEnv<LENV_ENV_PENDULUM> {
         return -(an * an + .1 * (x[1] * x[1]) + .001 * usq);
     }
     static __device__ __forceinline__ double reward_post(const double *, double pre) { return pre; }
+};
+
+// gym==0.17.3 MountainCarContinuous-v0 (classic_control/continuous_mountain_car.py; third party, restated; oracle: orc_cmc_step):
+// state = (position, velocity); force = the fp32 action clipped to [-1, 1], the action cost uses the unclipped action; the episode
+// ends at the flag (position >= 0.45 while moving right) with a bonus of 100
+template <> struct ContEnv<LENV_ENV_CMC> {
+    static constexpr int S = 2, A = 1, SD = 2, INFO = 0;
+    static constexpr bool TERMINATES = true;
+    static __device__ __forceinline__ double reset_word(uint64_t key, uint32_t stream, int64_t row, int i)
+    {
+        return i == 0 ? -0.6 + 0.2 * u64_to_unit(rng_u64(key, stream, (uint64_t)(row * 2))) : 0.0;
+    }
+    static __device__ __forceinline__ double step_word(int i, const double *x, const float *a)
+    {
+        double position = x[0], velocity = x[1];
+        const float f32 = a[0] < -1.0f ? -1.0f : (a[0] > 1.0f ? 1.0f : a[0]);
+        velocity = velocity + ((double)f32 * 0.0015 - 0.0025 * det_cos(3 * position));
+        if (velocity > 0.07) velocity = 0.07;
+        if (velocity < -0.07) velocity = -0.07;
+        position = position + velocity;
+        if (position > 0.6) position = 0.6;
+        if (position < -1.2) position = -1.2;
+        if (position == -1.2 && velocity < 0) velocity = 0;
+        return i == 0 ? position : velocity;
+    }
+    static __device__ __forceinline__ float obs(int i, const double *x) { return (float)x[i]; }
+    static __device__ __forceinline__ bool done(const double *x) { return x[0] >= 0.45 && x[1] >= 0.0; }
+    static __device__ __forceinline__ double reward_pre(const double *, const float *a) { return ((double)a[0] * (double)a[0]) * 0.1; }
+    static __device__ __forceinline__ double reward_post(const double *x_new, double pre) { return (done(x_new) ? 100.0 : 0.0) - pre; }
 };
 
 __device__ __forceinline__ float act_fwd(int act, float prelu, float z)

@@ -117,7 +117,7 @@ __global__ void cont_env_step_kernel(int max_steps, int64_t n, const float *acti
         reward[i] = (float)E::reward_post(nx, pre);
         const int el = elapsed[i] + 1;
         elapsed[i] = el;
-        done[i] = el >= max_steps ? 1.0f : 0.0f;
+        done[i] = (E::done(nx) || el >= max_steps) ? 1.0f : 0.0f;
     }
 }
 
@@ -129,10 +129,12 @@ extern "C" int lenv_cont_env_reset(int32_t env_id, const uint64_t *keys, const i
                                    int32_t *elapsed, void *stream)
 {
     if (!keys || !episode || !state || !obs || !elapsed || n < 0) return LENV_ERR_INVALID;
-    if (env_id != LENV_ENV_CHEETAH_STANDIN && env_id != LENV_ENV_PENDULUM) return LENV_ERR_UNSUPPORTED;
+    if (env_id != LENV_ENV_CHEETAH_STANDIN && env_id != LENV_ENV_PENDULUM && env_id != LENV_ENV_CMC) return LENV_ERR_UNSUPPORTED;
     if (n == 0) return LENV_OK;
     if (env_id == LENV_ENV_PENDULUM)
         hipLaunchKernelGGL(cont_env_reset_kernel<LENV_ENV_PENDULUM>, dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream), keys, episode, n, state, obs, elapsed);
+    else if (env_id == LENV_ENV_CMC)
+        hipLaunchKernelGGL(cont_env_reset_kernel<LENV_ENV_CMC>, dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream), keys, episode, n, state, obs, elapsed);
     else
         hipLaunchKernelGGL(cont_env_reset_kernel<LENV_ENV_CHEETAH_STANDIN>, dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream), keys, episode, n, state, obs, elapsed);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
@@ -142,10 +144,13 @@ extern "C" int lenv_cont_env_step(int32_t env_id, int32_t max_steps, int64_t n, 
                                   float *obs, float *reward, float *done, void *stream)
 {
     if (!action || !state || !elapsed || !obs || !reward || !done || n < 0) return LENV_ERR_INVALID;
-    if (env_id != LENV_ENV_CHEETAH_STANDIN && env_id != LENV_ENV_PENDULUM) return LENV_ERR_UNSUPPORTED;
+    if (env_id != LENV_ENV_CHEETAH_STANDIN && env_id != LENV_ENV_PENDULUM && env_id != LENV_ENV_CMC) return LENV_ERR_UNSUPPORTED;
     if (n == 0) return LENV_OK;
     if (env_id == LENV_ENV_PENDULUM)
         hipLaunchKernelGGL(cont_env_step_kernel<LENV_ENV_PENDULUM>, dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream), (int)max_steps, n,
+                           action, state, elapsed, obs, reward, done);
+    else if (env_id == LENV_ENV_CMC)
+        hipLaunchKernelGGL(cont_env_step_kernel<LENV_ENV_CMC>, dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream), (int)max_steps, n,
                            action, state, elapsed, obs, reward, done);
     else
         hipLaunchKernelGGL(cont_env_step_kernel<LENV_ENV_CHEETAH_STANDIN>, dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream), (int)max_steps, n,

@@ -109,7 +109,9 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     double *xt_d = xs_d + 20;                             // [T][17] test env states
     double *ret = xt_d + 17 * T;                          // [T]
     float *ep_rew = reinterpret_cast<float *>(ret + T);   // [T]
-    float *state = ep_rew + T;                            // [20] current observation (fp32)
+    int *tlen = reinterpret_cast<int *>(ep_rew + T);      // [T] env steps of each test episode
+    int *tflag = tlen + T;                                // [T] test episode still running
+    float *state = reinterpret_cast<float *>(tflag + T);  // [20] current observation (fp32)
     float *action = state + 20;                           // [8]
     float *newrow = action + 8;                           // [56] replay row [s | a | s' | r | done] + scratch + info[4] at 2S+A+4
     volatile float *ctrl = misc;
@@ -267,52 +269,83 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         __syncthreads();
     };
 
-    // ---- real-env test phase: T episodes in lock-step (the stand-in never terminates: every episode runs max_steps) ----
+    // ---- real-env test phase (BaseAgent.test, base_agent.py:155-227): T episodes in lock-step.  Every chosen action is applied
+    // same_action_num times (EnvWrapper.step, env_wrapper.py:56-61: python-float reward sum, the repeats stop at done); an episode
+    // ends at the env's own done flag or after max_steps env steps (TimeLimit).  Thread te < Tg owns episode g0 + te's
+    // bookkeeping.  With a noise TAPE and an env that can terminate the reference's draws are consumed episode by episode, so
+    // the episodes run one after the other there (Tg = 1); everywhere else the noise of (episode, agent step) has a fixed index.
+    const int k_rep = cfg.same_action_num > 1 ? cfg.same_action_num : 1;
     auto test_phase = [&]() {
-        for (int e = tid; e < T * SD; e += DNT) {
-            const int te = e / SD, i = e - te * SD;
-            const int64_t row = n_test_ep + te;
-            double v;
-            if (tape) { if (row >= a.tapes.test_reset_stride) { status = -5; v = 0.0; } else v = a.tapes.test_reset[(chain * a.tapes.test_reset_stride + row) * SD + i]; }
-            else v = EnvT::reset_word(key, STREAM_TEST_RESET, row, i);
-            xt_d[e] = v;
-        }
-        if (tid < T) ep_rew[tid] = 0.0f;
-        __syncthreads();
-        float *xt = xn;                                    // [T][S] fp32 observations (xn is free outside learn)
-        float *at = xa;                                    // [T][A] actions
-        for (int t = 0; t < cfg.max_steps; ++t) {
-            for (int e = tid; e < T * S; e += DNT) { const int te = e / S; xt[e] = EnvT::obs(e - te * S, xt_d + te * SD); }
-            __syncthreads();
-            mlp_forward(params, mo_actor, xt, S, T, ht, at, A, 0, true, nullptr);
-            gq.run<T3_MAXI>(Ps, Qs);
-            // select_test_action (TD3.py:126-129): (actor(s) + randn(A)*action_std*max_action).clamp(-max, max)
-            for (int e = tid; e < T * A; e += DNT) {
-                const int te = e / A, k = e - te * A;
-                const int64_t n = (n_testn + (int64_t)te * cfg.max_steps + t) * A + k;
-                float zn;
-                if (tape) { if (n >= a.tapes.test_noise_stride * A) { status = -7; zn = 0.0f; } else zn = a.tapes.test_noise[chain * a.tapes.test_noise_stride * A + n]; }
-                else zn = (float)det_normal(key, STREAM_TD3_TEST_NOISE, (uint64_t)n);
-                const float v = at[e] + (zn * (float)cfg.action_std) * ma;
-                at[e] = v < -ma ? -ma : (v > ma ? ma : v);
+        const int nag = (cfg.max_steps + k_rep - 1) / k_rep;               // agent steps of a full-length episode
+        const bool serial = tape && EnvT::TERMINATES;
+        const int Tg = serial ? 1 : T;
+        const int64_t nstride = tape ? nag : cfg.max_steps;                // noise index stride between episodes
+        int64_t noise_used = 0;
+        float *xt = xn;                                    // [Tg][S] fp32 observations (xn is free outside learn)
+        float *at = xa;                                    // [Tg][A] actions
+        for (int g0 = 0; g0 < T; g0 += Tg) {
+            for (int e = tid; e < Tg * SD; e += DNT) {
+                const int te = e / SD, i = e - te * SD;
+                const int64_t row = n_test_ep + g0 + te;
+                double v;
+                if (tape) { if (row >= a.tapes.test_reset_stride) { status = -5; v = 0.0; } else v = a.tapes.test_reset[(chain * a.tapes.test_reset_stride + row) * SD + i]; }
+                else v = EnvT::reset_word(key, STREAM_TEST_RESET, row, i);
+                xt_d[e] = v;
             }
+            if (tid < Tg) { ep_rew[g0 + tid] = 0.0f; tflag[tid] = 1; }
             __syncthreads();
-            double nx = 0.0, pre = 0.0;
-            if (tid < T * SD) { const int te = tid / SD, i = tid - te * SD; nx = EnvT::step_word(i, xt_d + te * SD, at + te * A); }
-            if (tid < T) pre = EnvT::reward_pre(xt_d + tid * SD, at + tid * A);     // the part of the reward that sees the OLD state
-            __syncthreads();
-            if (tid < T * SD) xt_d[tid] = nx;
-            __syncthreads();
-            if (tid < T) {
-                const double rew = EnvT::reward_post(xt_d + tid * SD, pre);
-                ep_rew[tid] = ep_rew[tid] + (float)rew;
+            int my_el = 0;
+            bool my_alive = tid < Tg;
+            int ai = 0;
+            for (; ai < nag; ++ai) {
+                for (int e = tid; e < Tg * S; e += DNT) { const int te = e / S; xt[e] = EnvT::obs(e - te * S, xt_d + te * SD); }
+                __syncthreads();
+                mlp_forward(params, mo_actor, xt, S, Tg, ht, at, A, 0, true, nullptr);
+                gq.run<T3_MAXI>(Ps, Qs);
+                // select_test_action (TD3.py:126-129): (actor(s) + randn(A)*action_std*max_action).clamp(-max, max)
+                for (int e = tid; e < Tg * A; e += DNT) {
+                    const int te = e / A, k = e - te * A;
+                    const int64_t n = (serial ? n_testn + noise_used + ai : n_testn + (int64_t)(g0 + te) * nstride + ai) * A + k;
+                    float zn;
+                    if (tape) { if (n >= a.tapes.test_noise_stride * A) { status = -7; zn = 0.0f; } else zn = a.tapes.test_noise[chain * a.tapes.test_noise_stride * A + n]; }
+                    else zn = (float)det_normal(key, STREAM_TD3_TEST_NOISE, (uint64_t)n);
+                    const float v = at[e] + (zn * (float)cfg.action_std) * ma;
+                    at[e] = v < -ma ? -ma : (v > ma ? ma : v);
+                }
+                __syncthreads();
+                double rsum = 0.0;
+                const bool started = my_alive;
+                for (int r_ = 0; r_ < k_rep; ++r_) {
+                    double nx = 0.0, pre = 0.0;
+                    const int wte = tid / SD;
+                    const bool wstep = tid < Tg * SD && tflag[wte] != 0;
+                    if (wstep) nx = EnvT::step_word(tid - wte * SD, xt_d + wte * SD, at + wte * A);
+                    if (my_alive) pre = EnvT::reward_pre(xt_d + tid * SD, at + tid * A);     // the part of the reward that sees the OLD state
+                    __syncthreads();
+                    if (wstep) xt_d[tid] = nx;
+                    __syncthreads();
+                    if (my_alive) {
+                        rsum = rsum + EnvT::reward_post(xt_d + tid * SD, pre);
+                        ++my_el;
+                        if (EnvT::done(xt_d + tid * SD) || my_el >= cfg.max_steps) { my_alive = false; tflag[tid] = 0; }
+                    }
+                    __syncthreads();
+                }
+                if (started) ep_rew[g0 + tid] = ep_rew[g0 + tid] + (float)rsum;
+                if (tid == 0) { int c = 0; for (int te = 0; te < Tg; ++te) c += tflag[te]; ictrl[4] = c; }
+                __syncthreads();
+                const int alive = ictrl[4];
+                __syncthreads();
+                if (alive == 0) { ++ai; break; }
             }
+            if (tid < Tg) tlen[g0 + tid] = my_el;
+            noise_used += ai;
             __syncthreads();
         }
         if (tid < T) ret[tid] = (double)ep_rew[tid];
         n_test_ep += T;
-        n_testn += (int64_t)T * cfg.max_steps;
-        test_steps += T * cfg.max_steps;
+        n_testn += serial ? noise_used : (int64_t)T * nstride;
+        for (int te = 0; te < T; ++te) test_steps += tlen[te];
         __syncthreads();
     };
 
@@ -334,8 +367,8 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         if (tid < S) state[tid] = EnvT::obs(tid, xs_d);
         __syncthreads();
         if (!cfg.virtual_env && (rtype == 1 || rtype == 2)) rn_eval(state, nullptr, 12);   // phi(s) of the reset state (carried from step to step)
-        int ep_len = 0;
-        for (int t = 0; t < cfg.max_steps; ++t) {
+        int ep_len = 0, env_steps = 0;
+        for (int t = 0; t < cfg.max_steps; t += k_rep) {         // base_agent.py:104 range(0, max_steps, same_action_num)
             const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
             const int new_pos = train_steps % rb_cap;
             // ---- select_train_action (TD3.py:118-124) ----
@@ -364,6 +397,8 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             if (cfg.virtual_env) {
                 // ---- EnvWrapper.step -> VirtualEnv.step (virtual_env.py:43-54): the three SE nets on cat(action, state) as queued
                 // single-row products; reward / done see the pre-transition state; the learned done flag ends the episode ----
+                // EnvWrapper.step repeats the SE step same_action_num times whatever the done flag says and sums the fp32 rewards
+                // (env_wrapper.py:24-29)
                 float *xse = arena + a.a_xse, *nse = arena + a.a_nse;
                 const float *sep = arena + a.a_se;
                 if (tid < A) xse[tid] = action[tid];
@@ -371,23 +406,31 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 if (tid >= 128 && tid < 128 + S) newrow[tid - 128] = state[tid - 128];
                 if (tid >= 192 && tid < 192 + A) newrow[S + tid - 192] = action[tid - 192];
                 __syncthreads();
-                mlp_forward(sep, mo_se[0], xse, SA, 1, ht, nse, S + 2, 0, false, nullptr, cfg.rn_act, cfg.rn_prelu);
-                mlp_forward(sep + mo_se[0].P, mo_se[1], xse, SA, 1, ht, nse, S + 2, S, false, nullptr, cfg.rn_act, cfg.rn_prelu);
-                mlp_forward(sep + mo_se[0].P + mo_se[1].P, mo_se[2], xse, SA, 1, ht, nse, S + 2, S + 1, false, nullptr, cfg.rn_act, cfg.rn_prelu);
-                gq.run<T3_MAXI>(Ps, Qs);
-                if (tid < S) newrow[S + A + tid] = nse[tid];
-                if (tid == 64) { newrow[2 * S + A] = nse[S]; newrow[2 * S + A + 1] = nse[S + 1]; }
+                for (int r_ = 0; r_ < k_rep; ++r_) {
+                    mlp_forward(sep, mo_se[0], xse, SA, 1, ht, nse, S + 2, 0, false, nullptr, cfg.rn_act, cfg.rn_prelu);
+                    mlp_forward(sep + mo_se[0].P, mo_se[1], xse, SA, 1, ht, nse, S + 2, S, false, nullptr, cfg.rn_act, cfg.rn_prelu);
+                    mlp_forward(sep + mo_se[0].P + mo_se[1].P, mo_se[2], xse, SA, 1, ht, nse, S + 2, S + 1, false, nullptr, cfg.rn_act, cfg.rn_prelu);
+                    gq.run<T3_MAXI>(Ps, Qs);
+                    if (tid < S) { newrow[S + A + tid] = nse[tid]; xse[A + tid] = nse[tid]; }
+                    if (tid == 64) { newrow[2 * S + A] = r_ == 0 ? nse[S] : newrow[2 * S + A] + nse[S]; newrow[2 * S + A + 1] = nse[S + 1]; }
+                    if (r_ + 1 < k_rep) __syncthreads();
+                }
             } else {
-            // ---- EnvWrapper.step -> RewardEnv.step -> real_env.step + TimeLimit ----
+            // ---- EnvWrapper.step -> RewardEnv.step -> real_env.step + TimeLimit, same_action_num times or until done; the shaped
+            // rewards of the repeats are summed as python floats (env_wrapper.py:56-61); `state` follows the repeats ----
+            if (tid < S) newrow[tid] = state[tid];
+            if (tid >= 64 && tid < 64 + A) newrow[S + tid - 64] = action[tid - 64];
+            double rsum = 0.0;
+            for (int r_ = 0; r_ < k_rep; ++r_) {
             double nx = 0.0, pre = 0.0;
             if (tid < SD) nx = EnvT::step_word(tid, xs_d, action);
             if (tid == 64) pre = EnvT::reward_pre(xs_d, action);                  // the part of the reward that sees the OLD state
             __syncthreads();
             if (tid < SD) xs_d[tid] = nx;
             if (tid == 64) xs_d[18] = pre;
-            if (tid < S) newrow[tid] = state[tid];
-            if (tid >= 64 && tid < 64 + A) newrow[S + tid - 64] = action[tid - 64];
             __syncthreads();
+            ++env_steps;
+            const bool dn = EnvT::done(xs_d) || env_steps >= cfg.max_steps;      // the env's own flag or TimeLimit (uniform)
             if (tid < S) newrow[S + A + tid] = EnvT::obs(tid, xs_d);
             float *info = newrow + 2 * S + A + 4;          // [4] info vector of this step (fp32, as torch.tensor(list(info.values())))
             if constexpr (EnvT::INFO == 4) {
@@ -396,7 +439,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 }
             }
             __syncthreads();
-            if (rtype == 3 || rtype == 4) rn_eval(newrow, info, 12);                 // phi([s | info]): not cacheable, info is this step's
+            if (rtype == 3 || rtype == 4) rn_eval(state, info, 12);                  // phi([s | info]): not cacheable, info is this step's
             rn_eval(newrow + S + A, info, 13);             // phi(s') / phi([s' | info]) / w . info
             if (tid == 0) {
                 const double rew = EnvT::reward_post(xs_d, xs_d[18]);
@@ -409,9 +452,14 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 case 5: case 7: case 101: shaped = phi_s2; break;
                 default: shaped = r32 + phi_s2; break;     // 6, 8, 102
                 }
-                const int dn = t + 1 >= cfg.max_steps;
-                newrow[2 * S + A] = shaped; newrow[2 * S + A + 1] = dn ? 1.0f : 0.0f;
+                rsum = rsum + (double)shaped;
+                newrow[2 * S + A] = (float)rsum; newrow[2 * S + A + 1] = dn ? 1.0f : 0.0f;
                 ctrl[12] = phi_s2;
+            }
+            __syncthreads();
+            if (tid < S) state[tid] = newrow[S + A + tid];                           // RewardEnv.state = next_state
+            if (dn) break;
+            if (r_ + 1 < k_rep) __syncthreads();
             }
             }
             __syncthreads();
@@ -425,7 +473,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             const float done_now = newrow[2 * S + A + 1];
             __syncthreads();
             if (tid < S) state[tid] = newrow[S + A + tid];
-            ++ep_len; ++train_steps;
+            ep_len += k_rep; ++train_steps;                  // base_agent.py:122: episode_length += same_action_num
             __syncthreads();
 
             PT_MARK(0);                                   // act + env step + reward net + append
@@ -552,13 +600,13 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     const int test_before = test_steps;
     test_phase();
     if (budgeted) {
-        // BaseAgent.test under the time-out (base_agent.py:177-184): every stand-in episode lasts max_steps; episode e starts only
+        // BaseAgent.test under the time-out (base_agent.py:177-184): episode e (tlen[e] env steps) starts only
         // while the earlier ones used <= remaining steps, the rest is padded with the minimum so far (-1e9 if empty)
         int64_t used = 0;
         int stop = T;
         for (int te = 0; te < T; ++te) {
             if (used > remaining) { stop = te; break; }
-            used += cfg.max_steps;
+            used += tlen[te];
         }
         if (tid == 0) {
             double mn = -1e9;
@@ -638,8 +686,10 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
 {
     const int H = cfg->hidden, L = cfg->layers, B = cfg->batch_size, T = cfg->test_episodes, Hrn = cfg->rn_hidden;
     const int T3_S = cfg->state_dim, T3_A = cfg->action_dim, T3_SA = T3_S + T3_A;
-    if (!((cfg->env_id == LENV_ENV_CHEETAH_STANDIN && T3_S == 17 && T3_A == 6) || (cfg->env_id == LENV_ENV_PENDULUM && T3_S == 3 && T3_A == 1)))
+    if (!((cfg->env_id == LENV_ENV_CHEETAH_STANDIN && T3_S == 17 && T3_A == 6) || (cfg->env_id == LENV_ENV_PENDULUM && T3_S == 3 && T3_A == 1) ||
+          (cfg->env_id == LENV_ENV_CMC && T3_S == 2 && T3_A == 1)))
         return LENV_ERR_UNSUPPORTED;
+    if (cfg->same_action_num < 0 || cfg->same_action_num > 64) return LENV_ERR_UNSUPPORTED;
     const int t = cfg->reward_env_type;
     if (!((t >= 0 && t <= 8) || t == 101 || t == 102)) return LENV_ERR_UNSUPPORTED;          // reward_env.py:49,58 NotImplementedError
     if (cfg->act == LENV_ACT_PRELU) return LENV_ERR_UNSUPPORTED;   // trained PReLU slope of the agent nets: not a parameter here yet
@@ -691,7 +741,7 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
         for (int i = 0; i < IB_COUNT; ++i) a.a_icm[i] = take(sz[i]);
     }
     a.arena_stride = (off + 63) & ~(int64_t)63;
-    const size_t lds_floats = GemmShape<T3_MAXI>::PS_FLOATS + GemmShape<T3_MAXI>::QS_FLOATS + GEMM_QUEUE_MAX * sizeof(GemmCmd) / sizeof(float) + ((a.P_rn_lds + 3) & ~3) + 2 * ((Hrn + 3) & ~3) + 8 * (size_t)B + 64 + 2 + 2 * (20 + 17 * (size_t)T + T) + T + 20 + 8 + 56 + 16;
+    const size_t lds_floats = GemmShape<T3_MAXI>::PS_FLOATS + GemmShape<T3_MAXI>::QS_FLOATS + GEMM_QUEUE_MAX * sizeof(GemmCmd) / sizeof(float) + ((a.P_rn_lds + 3) & ~3) + 2 * ((Hrn + 3) & ~3) + 8 * (size_t)B + 64 + 2 + 2 * (20 + 17 * (size_t)T + T) + 3 * (size_t)T + 20 + 8 + 56 + 16;
     *lds_bytes = lds_floats * sizeof(float);
     if (*lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     return LENV_OK;
@@ -789,6 +839,7 @@ extern "C" int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg, const lenv_ch
     a.icm_init = cfg->icm_enabled ? icm->icm_init : nullptr; a.icm_final = cfg->icm_enabled ? icm->icm_final : nullptr;
     void (*kern)(const Td3Args) = nullptr;
     if (cfg->env_id == LENV_ENV_PENDULUM) kern = cfg->icm_enabled ? td3_rn_inner_kernel<true, LENV_ENV_PENDULUM> : td3_rn_inner_kernel<false, LENV_ENV_PENDULUM>;
+    else if (cfg->env_id == LENV_ENV_CMC) kern = cfg->icm_enabled ? td3_rn_inner_kernel<true, LENV_ENV_CMC> : td3_rn_inner_kernel<false, LENV_ENV_CMC>;
     else kern = cfg->icm_enabled ? td3_rn_inner_kernel<true, LENV_ENV_CHEETAH_STANDIN> : td3_rn_inner_kernel<false, LENV_ENV_CHEETAH_STANDIN>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;

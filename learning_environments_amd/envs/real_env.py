@@ -19,6 +19,7 @@ _SPECS = {
     # HalfCheetah-v3 is served by the documented STAND-IN (tools/gen_cheetah_standin.py): MuJoCo cannot be installed
     "HalfCheetah-v3": dict(S=17, A=6, SD=17, max_steps=1000, high=[np.inf] * 17, continuous=True, max_action=1.0),
     "Pendulum-v0": dict(S=3, A=1, SD=2, max_steps=200, high=[1.0, 1.0, 8.0], continuous=True, max_action=2.0),
+    "MountainCarContinuous-v0": dict(S=2, A=1, SD=2, max_steps=999, low=[-1.2, -0.07], high=[0.6, 0.07], continuous=True, max_action=1.0),
 }
 
 

@@ -1085,6 +1085,18 @@ def main():
                 env_name="Pendulum-v0", env_cls="PendulumEnv",
                 agent_over={"train_episodes": 4, "init_episodes": 2, "batch_size": 16, "hidden_size": 24, "test_episodes": 2},
                 env_over={"max_steps": 8, "hidden_size": 20, "hidden_layer": 1, "activation_fn": "prelu", "reward_env_type": 2})
+    if "g8c" in which:
+        # default_config_cmc.yaml's combination: TD3 on a VirtualEnv of MountainCarContinuous-v0 (2 obs, 1 action), tested on the real
+        # env; and default_config_cmc_reward_env.yaml's: TD3 on a RewardEnv (type 2, tanh) over the real env, whose episodes end at
+        # the flag
+        gen_g8t("g8c_calc_score_cmc_td3_virtual_env", seed=880, virtual=True, cfg_yaml="default_config_cmc_reward_env.yaml",
+                env_name="MountainCarContinuous-v0", env_cls="Continuous_MountainCarEnv",
+                agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 16, "hidden_size": 24, "test_episodes": 2},
+                env_over={"max_steps": 9, "hidden_size": 20, "hidden_layer": 2, "activation_fn": "leakyrelu", "reward_env_type": 0})
+        gen_g8t("g8cr_calc_score_cmc_td3_reward_env", seed=881, cfg_yaml="default_config_cmc_reward_env.yaml",
+                env_name="MountainCarContinuous-v0", env_cls="Continuous_MountainCarEnv",
+                agent_over={"train_episodes": 4, "init_episodes": 2, "batch_size": 16, "hidden_size": 24, "test_episodes": 2},
+                env_over={"max_steps": 8, "hidden_size": 20, "hidden_layer": 1, "activation_fn": "tanh", "reward_env_type": 2})
     if "g8ti" in which:
         gen_g8t("g8ti_calc_score_cheetah_td3_icm", seed=833,
                 agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 16, "hidden_size": 24, "test_episodes": 1},

@@ -209,7 +209,7 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
 
 /* ---- config 5: TD3 on a continuous-state RewardEnv (agents/TD3.py:13-135, envs/reward_env.py:61-133) ----
  * real env: the documented HalfCheetah-v3 stand-in (tools/gen_cheetah_standin.py). */
-enum { ORC_ENV_CHEETAH_STANDIN = 2, ORC_ENV_PENDULUM = 4 };
+enum { ORC_ENV_CHEETAH_STANDIN = 2, ORC_ENV_PENDULUM = 4, ORC_ENV_CMC = 5 };
 typedef struct {
     int32_t env_id, state_dim, action_dim, max_steps;
     int32_t rn_hidden, rn_layers, rn_act;
@@ -228,7 +228,9 @@ typedef struct {
     /* virtual_env != 0 (gtn.synthetic_env_type 0, default_config_halfcheetah.yaml): the agent trains on a VirtualEnv
      * (envs/virtual_env.py:43-54) instead of the RewardEnv -- rn_params then holds state_net | reward_net | done_net, each
      * (action_dim + state_dim) -> rn_hidden x rn_layers -> {state_dim, 1, 1} with rn_act; the episode ends on done > 0.5 */
-    int32_t virtual_env, virtual_pad_;
+    int32_t virtual_env;
+    /* same_action_num (base_agent.py:20, env_wrapper.py:24,57): env steps per chosen action; 0 and 1 both mean 1 */
+    int32_t same_action_num;
 } orc_td3_cfg;
 
 typedef struct {

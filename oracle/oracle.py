@@ -80,7 +80,7 @@ class Td3Cfg(C.Structure):
                 ("step_budget", C.c_int64),
                 ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("icm_pad_", C.c_int32),
                 ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
-                ("virtual_env", C.c_int32), ("virtual_pad_", C.c_int32)]
+                ("virtual_env", C.c_int32), ("same_action_num", C.c_int32)]
 
 
 class Td3Tapes(C.Structure):
@@ -510,7 +510,6 @@ def td3_cfg_from_config(config, rng_mode=0, **overrides):
     env_id, S, A, max_action = TD3_ENVS[env_name]
     e = config["envs"][env_name]
     a = config["agents"]["td3"]
-    assert a["same_action_num"] == 1
     cfg = Td3Cfg(env_id=env_id, state_dim=S, action_dim=A, max_steps=int(e["max_steps"]), rn_hidden=int(e["hidden_size"]),
                  rn_layers=int(e["hidden_layer"]), rn_act=ACT[e["activation_fn"]], rn_prelu=0.25,
                  reward_env_type=int(e["reward_env_type"]), info_dim=int(e.get("info_dim", 0)), hidden=int(a["hidden_size"]),
@@ -523,6 +522,7 @@ def td3_cfg_from_config(config, rng_mode=0, **overrides):
                  adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, step_budget=int(a.get("step_budget", 0)))
     if "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 1)) == 0:
         cfg.virtual_env = 1                           # the agent trains on a VirtualEnv: the `envs` section describes the three SE nets
+    cfg.same_action_num = int(a["same_action_num"])
     name = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "td3"
     if name.replace("_vary", "").endswith("_icm"):   # select_agent "td3_icm": TD3(icm=True), agents/TD3.py:44-60
         ic = config["agents"]["icm"]
@@ -534,8 +534,8 @@ def td3_cfg_from_config(config, rng_mode=0, **overrides):
 
 
 # continuous real envs of the TD3 path: env id, observation dim, action dim, EnvWrapper.get_max_action (env_wrapper.py:106-110)
-TD3_ENVS = {"HalfCheetah-v3": (2, 17, 6, 1.0), "Pendulum-v0": (4, 3, 1, 2.0)}
-TD3_STATE_WORDS = {2: 17, 4: 2}          # fp64 words of the env's own state (= width of the reset tapes)
+TD3_ENVS = {"HalfCheetah-v3": (2, 17, 6, 1.0), "Pendulum-v0": (4, 3, 1, 2.0), "MountainCarContinuous-v0": (5, 2, 1, 1.0)}
+TD3_STATE_WORDS = {2: 17, 4: 2, 5: 2}          # fp64 words of the env's own state (= width of the reset tapes)
 
 
 def td3_param_counts(cfg):

@@ -337,6 +337,59 @@ class PendulumEnv(Env):
         return None
 
 
+class Continuous_MountainCarEnv(Env):
+    """gym==0.17.3 classic_control/continuous_mountain_car.py (MountainCarContinuous-v0), restated; third party, not under
+    /root/reference.  The action arrives as a float32 array; with the numpy of the reference's era `force * power` promotes the
+    float32 force to float64 -- written out explicitly here so the arithmetic does not depend on the installed numpy."""
+
+    def __init__(self, goal_velocity=0):
+        self.min_action = -1.0
+        self.max_action = 1.0
+        self.min_position = -1.2
+        self.max_position = 0.6
+        self.max_speed = 0.07
+        self.goal_position = 0.45
+        self.goal_velocity = goal_velocity
+        self.power = 0.0015
+        self.low_state = np.array([self.min_position, -self.max_speed], dtype=np.float32)
+        self.high_state = np.array([self.max_position, self.max_speed], dtype=np.float32)
+        self.action_space = spaces.Box(low=self.min_action, high=self.max_action, shape=(1,), dtype=np.float32)
+        self.observation_space = spaces.Box(low=self.low_state, high=self.high_state, dtype=np.float32)
+        self.state = None
+        self.seed()
+
+    def seed(self, seed=None):
+        self.np_random, seed = seeding.np_random(seed)
+        return [seed]
+
+    def step(self, action):
+        position = float(self.state[0])
+        velocity = float(self.state[1])
+        a0 = float(np.asarray(action, np.float32).reshape(-1)[0])
+        force = min(max(a0, self.min_action), self.max_action)
+        velocity += force * self.power - 0.0025 * math.cos(3 * position)
+        if (velocity > self.max_speed): velocity = self.max_speed
+        if (velocity < -self.max_speed): velocity = -self.max_speed
+        position += velocity
+        if (position > self.max_position): position = self.max_position
+        if (position < self.min_position): position = self.min_position
+        if (position == self.min_position and velocity < 0): velocity = 0
+        done = bool(position >= self.goal_position and velocity >= self.goal_velocity)
+        reward = 0
+        if done:
+            reward = 100.0
+        reward -= math.pow(a0, 2) * 0.1
+        self.state = np.array([position, velocity])
+        return self.state, reward, done, {}
+
+    def reset(self):
+        self.state = np.array([self.np_random.uniform(low=-0.6, high=-0.4), 0])
+        return np.array(self.state)
+
+    def render(self, mode='human'):
+        return None
+
+
 def _angle_normalize(x):
     return (((x + math.pi) % (2 * math.pi)) - math.pi)
 
@@ -348,6 +401,7 @@ _REGISTRY = {
     'MountainCar-v0': (MountainCarEnv, EnvSpec('MountainCar-v0', 200, -110.0)),
     'HalfCheetah-v3': (CheetahStandinEnv, EnvSpec('HalfCheetah-v3', 1000, 4800.0)),
     'Pendulum-v0': (PendulumEnv, EnvSpec('Pendulum-v0', 200, None)),
+    'MountainCarContinuous-v0': (Continuous_MountainCarEnv, EnvSpec('MountainCarContinuous-v0', 999, 90.0)),
 }
 
 

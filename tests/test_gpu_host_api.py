@@ -588,6 +588,65 @@ def test_gtn_master_pendulum_configs_as_shipped(tmp_path, monkeypatch):
             assert gathered[p, 1] == sc[0] and gathered[p, 0] == max(sc[1], sc[2])
 
 
+def test_real_env_cmc_step_matches_oracle():
+    """MountainCarContinuous-v0 through EnvWrapper.reset/step on the device against the oracle's step, with same_action_num 2
+    (EnvWrapper.step repeats the action and sums the rewards, env_wrapper.py:56-61): swing up to the flag, done there, +100."""
+    from learning_environments_amd.configs import cmc_syn_env_td3
+    from learning_environments_amd.envs.env_factory import EnvFactory
+    from oracle import oracle as orc
+    import ctypes as C
+    real = EnvFactory(cmc_syn_env_td3()).generate_real_env()
+    assert (real.get_state_dim(), real.get_action_dim(), real.get_max_action()) == (2, 1, 1) and not real.has_discrete_action_space()
+    real.set_agent_params(same_action_num=2, gamma=0.99)
+    s = real.reset()
+    st = (C.c_double * 2)(*real.env._alloc()["state"].cpu().tolist())
+    assert -0.6 <= st[0] <= -0.4 and st[1] == 0.0 and float(s[0]) == np.float32(st[0])
+    rew, dn = C.c_double(), C.c_int()
+    reached = False
+    for t in range(400):
+        a = np.float32(1.0 if st[1] >= 0 else -1.0)
+        ns, r, d = real.step(torch.tensor([float(a)]))
+        rsum = 0.0
+        for _ in range(2):
+            orc.lib().orc_cmc_step(st, (C.c_float * 1)(a), C.byref(rew), C.byref(dn))
+            rsum = rsum + float(np.float32(rew.value))        # the one-step device API hands rewards back as fp32
+            if dn.value:
+                break
+        assert np.array_equal(ns.numpy(), np.array([st[0], st[1]]).astype(np.float32)) and float(r) == np.float32(rsum)
+        assert float(d) == float(dn.value)
+        if dn.value:
+            reached = float(r) > 99.0
+            break
+    assert reached and t < 300
+
+
+def test_gtn_master_cmc_configs_as_shipped(tmp_path, monkeypatch):
+    """default_config_cmc.yaml (td3, VirtualEnv 3-96-96-{2,1,1}) and default_config_cmc_reward_env.yaml (td3, tanh reward net), both
+    with same_action_num 2, through GTN_Master: fitness values equal to the oracle's."""
+    from learning_environments_amd.configs import cmc_reward_env_td3, cmc_syn_env_td3, fixed_work
+    from oracle import oracle as orc
+    for make in (cmc_syn_env_td3, cmc_reward_env_td3):
+        cfg = fixed_work(make(num_workers=2, max_iterations=1), 2)
+        cfg["envs"]["MountainCarContinuous-v0"]["max_steps"] = 9
+        cfg["agents"]["td3"].update(init_episodes=1, test_episodes=2, batch_size=32)
+        m = _master_pair(cfg, tmp_path, monkeypatch)
+        assert m.cfg.same_action_num == 2 and (m.cfg.state_dim, m.cfg.action_dim) == (2, 1)
+        theta0 = m.theta.cpu().numpy().copy()
+        gathered = m.evaluate_population(0).cpu().numpy()
+        eps = m.eps.cpu().numpy()
+        oeps, init, okeys = orc.nes_draw(m.seed, 0, 2, m.p_theta, cfg["agents"]["gtn"]["noise_std"], 6, 3, 0, m.agent_bounds.cpu().numpy())
+        assert np.array_equal(eps, oeps)
+        ocfg = orc.td3_cfg_from_config(cfg)
+        for p in range(2):
+            sc = []
+            for kind, sg in enumerate((0.0, 1.0, -1.0)):
+                w = (np.float32(sg) * eps[p] + theta0).astype(np.float32)
+                sc.append(orc.td3_rn_chain(ocfg, w, init[3 * p + kind], rng_key=orc.chain_key(m.seed, 0, p, kind))["score"])
+            assert gathered[p, 1] == sc[0] and gathered[p, 0] == max(sc[1], sc[2])
+        mean_score, mean_list, _ = m.run()
+        assert len(mean_list) == 1 and np.isfinite(mean_score)
+
+
 def test_gtn_master_td3_vary_generation(tmp_path, monkeypatch):
     """`agent_name: TD3_vary` through GTN_Master (agents/TD3_vary.py): per-chain draws, one launch, oracle-equal fitness."""
     from learning_environments_amd import _lib

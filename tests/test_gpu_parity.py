@@ -1182,6 +1182,106 @@ def test_td3_pendulum_counter_mode_vs_oracle(eng, orc, golden, virtual, rtype, r
             eng.Td3InnerLoop(cfg, chains)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# MountainCarContinuous-v0 behind the TD3 path (default_config_cmc.yaml / default_config_cmc_reward_env.yaml), same_action_num
+# ---------------------------------------------------------------------------------------------------------------
+def _td3_compare(il, o, c, n, with_state=True):
+    assert np.array_equal(il.trace["action"][c, :n].cpu().numpy(), o["trace"]["action"]), c
+    if with_state:
+        assert np.array_equal(il.trace["state"][c, :n].cpu().numpy(), o["trace"]["state"]), c
+    assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"]), c
+    assert np.array_equal(il.trace["reward"][c, :n].cpu().numpy(), o["trace"]["reward"]), c
+    assert np.array_equal(il.episode_len[c].cpu().numpy(), o["episode_len"]), c
+    assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
+    assert np.array_equal(il.final_returns[c].cpu().numpy(), o["final_test_returns"]), c
+    assert float(il.score[c]) == o["score"], c
+    assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]], c
+
+
+@pytest.mark.parametrize("name,near_flag", [("g8c_calc_score_cmc_td3_virtual_env", False), ("g8cr_calc_score_cmc_td3_reward_env", False),
+                                            ("g8c_calc_score_cmc_td3_virtual_env", True), ("g8cr_calc_score_cmc_td3_reward_env", True)])
+def test_td3_cmc_tape_mode_vs_reference_and_oracle(eng, orc, golden, name, near_flag):
+    """The reference's runs (same_action_num 2) replayed; and the same tapes with every episode reset next to the flag, so that
+    training episodes (RewardEnv mode) and test episodes end at the env's own done flag after a step or two -- with the +100."""
+    g = golden(name)
+    ocfg, cfg = _td3_cfgs(orc, json.loads(str(g["config_json"])), 1)
+    assert (cfg.env_id, cfg.state_dim, cfg.action_dim, cfg.same_action_num) == (5, 2, 1, 2)
+    n = g["tr_reward"].size
+    train_reset, test_reset = g["tape_train_reset"].copy(), g["tape_test_reset"].copy()
+    if near_flag:
+        train_reset[:] = np.array([0.40, 0.045]) + np.arange(train_reset.shape[0])[:, None] * np.array([0.004, 0.0])
+        test_reset[:] = np.array([0.36, 0.05]) + np.arange(test_reset.shape[0])[:, None] * np.array([0.011, 0.001])
+    replay_idx = g["tape_replay_idx"] % 2 if near_flag else g["tape_replay_idx"]     # short episodes: keep the recorded indices inside the buffer
+    otapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
+                                replay_idx, train_reset, test_reset, A=1, S=2)
+    o = orc.td3_rn_chain(ocfg, g["theta"], g["agent_init"], tapes=otapes, trace_cap=n + 4)
+    assert o["rc"] == 0
+    chains = 2
+    rep = lambda a: dev(np.tile(np.ascontiguousarray(a)[None], (chains,) + (1,) * np.ndim(a)))
+    tapes = dict(rand_action=rep(g["tape_rand_action"]), act_noise=rep(g["tape_act_noise"]), test_noise=rep(g["tape_test_noise"]),
+                 policy_noise=rep(g["tape_policy_noise"]), replay_idx=rep(replay_idx.reshape(-1)),
+                 train_reset=rep(train_reset), test_reset=rep(test_reset))
+    il = eng.Td3InnerLoop(cfg, chains, trace_cap=n + 4, want_episode_stats=True)
+    il.run(dev(g["theta"]), None, None, None, dev(np.tile(g["agent_init"], (chains, 1))), tapes=tapes)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    m = o["trace"]["reward"].size
+    for c in range(chains):
+        _td3_compare(il, o, c, m)
+        if not near_flag:
+            np.testing.assert_allclose(il.trace["action"][c, :n].cpu().numpy(), g["tr_action"], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(il.trace["next_state"][c, :n].cpu().numpy(), g["tr_next_state"], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(il.trace["reward"][c, :n].cpu().numpy(), g["tr_reward"], rtol=0, atol=5e-5)
+            assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4
+    if near_flag:
+        assert o["final_test_returns"].max() > 90.0                        # test episodes reached the flag
+        if not cfg.virtual_env:
+            assert o["trace"]["reward"].max() > 50.0 and o["episode_len"].min() < cfg.max_steps      # so did training episodes on the real env
+
+
+@pytest.mark.parametrize("env_name,virtual,k,rtype", [("MountainCarContinuous-v0", False, 2, 2), ("MountainCarContinuous-v0", True, 2, 0),
+                                                      ("MountainCarContinuous-v0", False, 1, 6), ("MountainCarContinuous-v0", False, 3, 1),
+                                                      ("Pendulum-v0", False, 2, 2), ("Pendulum-v0", True, 3, 0), ("HalfCheetah-v3", False, 2, 4),
+                                                      ("HalfCheetah-v3", True, 2, 0)])
+def test_td3_same_action_num_counter_mode_vs_oracle(eng, orc, golden, env_name, virtual, k, rtype):
+    """same_action_num 1..3 on all three continuous envs, RewardEnv and VirtualEnv: bit-exact against the oracle; max_steps odd, so
+    the last action of an episode is cut short by TimeLimit on the real env."""
+    fx = {"MountainCarContinuous-v0": "g8cr_calc_score_cmc_td3_reward_env", "Pendulum-v0": "g8pr_calc_score_pendulum_td3_reward_env",
+          "HalfCheetah-v3": "g8t_calc_score_cheetah_td3"}[env_name]
+    cfgd = json.loads(str(golden(fx)["config_json"]))
+    cfgd["agents"]["gtn"]["synthetic_env_type"] = 0 if virtual else 1
+    cfgd["agents"]["td3"].update(hidden_size=24, hidden_layer=1, batch_size=20, train_episodes=3, init_episodes=1, test_episodes=3,
+                                 same_action_num=k, early_out_num=50)
+    cfgd["envs"][env_name].update(max_steps=11, hidden_size=24, hidden_layer=1, activation_fn="relu", reward_env_type=rtype, solved_reward=1e9,
+                                  info_dim=4 if env_name == "HalfCheetah-v3" else 0)
+    ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
+    assert cfg.same_action_num == k
+    S, A = cfg.state_dim, cfg.action_dim
+    Pa, Pc = orc.td3_param_counts(ocfg)
+    if virtual:
+        P_rn = orc.mlp_num_params(orc.mlp_desc(S + A, 24, 1, S, "relu")) + 2 * orc.mlp_num_params(orc.mlp_desc(S + A, 24, 1, 1, "relu"))
+    else:
+        P_rn = max(1, orc.rn_num_params(rtype, S, ocfg.info_dim, 24, 1))
+    rng = np.random.RandomState(29 + k)
+    chains = 3
+    theta = (rng.randn(P_rn) * 0.2).astype(np.float32)
+    eps = (rng.randn(1, P_rn) * 0.1).astype(np.float32)
+    agent_init = rng.uniform(-0.2, 0.2, (chains, Pa + 2 * Pc)).astype(np.float32)
+    worker, sign = np.zeros(chains, np.int32), np.array([0.0, 1.0, -1.0], np.float32)
+    keys = np.array([orc.chain_key(27, 8, 0, c) for c in range(chains)], np.uint64)
+    il = eng.Td3InnerLoop(cfg, chains, trace_cap=40, want_episode_stats=True)
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        w = (np.float32(sign[c]) * eps[0] + theta).astype(np.float32)
+        o = orc.td3_rn_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]), trace_cap=40)
+        assert o["rc"] == 0 and o["learn_steps"] > 0
+        _td3_compare(il, o, c, o["trace"]["reward"].size)
+        if not virtual:
+            assert o["episode_len"].tolist() == [k * ((11 + k - 1) // k)] * 3 and o["test_steps"] == 4 * 3 * 11
+
+
 @pytest.mark.parametrize("rtype", [0, 1, 2, 3, 4, 5, 6, 7, 8, 101, 102])
 def test_rn_shape_rows_vs_oracle(eng, orc, rtype):
     """RewardEnv._calc_reward for rows of a vector-state env, every reward type: bit-exact against the oracle."""

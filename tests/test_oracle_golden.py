@@ -610,6 +610,63 @@ def test_g8p_td3_on_pendulum(golden, name):
         assert orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], tapes=tapes)["rc"] != 0
 
 
+@pytest.mark.parametrize("name", ["g8c_calc_score_cmc_td3_virtual_env", "g8cr_calc_score_cmc_td3_reward_env"])
+def test_g8c_td3_on_mountaincar_continuous(golden, name):
+    """default_config_cmc.yaml / default_config_cmc_reward_env.yaml's env with their same_action_num = 2: TD3 on a VirtualEnv of
+    MountainCarContinuous-v0 and on a RewardEnv (type 2, tanh) over the real env.  Every chosen action is applied twice
+    (EnvWrapper.step, env_wrapper.py:24-29,56-61), episode lengths count env steps (base_agent.py:122)."""
+    import json
+    g = golden(name)
+    cfg = orc.td3_cfg_from_config(json.loads(str(g["config_json"])), rng_mode=1)
+    assert (cfg.env_id, cfg.state_dim, cfg.action_dim, cfg.max_action, cfg.same_action_num) == (5, 2, 1, 1.0, 2)
+    tapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
+                               g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"], A=1, S=2)
+    n = g["tr_reward"].size
+    out = orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 4)
+    assert out["rc"] == 0 and out["trace"]["reward"].size == n
+    np.testing.assert_allclose(out["trace"]["action"], g["tr_action"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["trace"]["next_state"], g["tr_next_state"], rtol=0, atol=2e-6 if cfg.virtual_env else 1e-9)
+    np.testing.assert_allclose(out["trace"]["reward"], g["tr_reward"], rtol=0, atol=2e-6)
+    assert np.array_equal(out["episode_len"], g["episode_length_train"]) and int(g["episode_length_train"][0]) == 2 * ((cfg.max_steps + 1) // 2)
+    np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=1e-4)
+    assert abs(out["score"] - float(g["score"])) <= 1e-4
+    # one env step per action again: a different run (twice as many actions per episode)
+    cfg.same_action_num, cfg.rng_mode = 1, 0
+    out1 = orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], rng_key=5)
+    assert out1["rc"] == 0 and out1["train_steps"] > out["train_steps"]
+
+
+def test_mountaincar_continuous_step_physics():
+    """gym==0.17.3 classic_control/continuous_mountain_car.py (third party, restated): the oracle's step against a line-by-line
+    float64 restatement -- left wall, speed clip, the flag with its +100, the action cost on the UNclipped action."""
+    import ctypes as C
+    import math
+    st = (C.c_double * 2)(-0.5, 0.0)
+    rew, dn = C.c_double(), C.c_int()
+    pos, vel = -0.5, 0.0
+    hit_wall = reached = False
+    for t in range(600):
+        a = np.float32(-1.5 if t < 80 else (1.25 if vel >= 0 else -1.25))      # into the left wall first, then swing up; |a| > 1 is clipped
+        orc.lib().orc_cmc_step(st, (C.c_float * 1)(a), C.byref(rew), C.byref(dn))
+        force = min(max(float(a), -1.0), 1.0)
+        vel += force * 0.0015 - 0.0025 * math.cos(3 * pos)
+        vel = min(max(vel, -0.07), 0.07)
+        pos += vel
+        pos = min(max(pos, -1.2), 0.6)
+        if pos == -1.2 and vel < 0:
+            vel = 0.0
+            hit_wall = True
+        done = pos >= 0.45 and vel >= 0
+        r = (100.0 if done else 0) - math.pow(float(a), 2) * 0.1
+        assert abs(st[0] - pos) <= 1e-13 and abs(st[1] - vel) <= 1e-14 and abs(rew.value - r) <= 1e-12 and dn.value == int(done)
+        pos, vel = st[0], st[1]
+        if done:
+            reached = True
+            assert rew.value > 99.0
+            break
+    assert hit_wall and reached
+
+
 def test_pendulum_step_physics():
     """gym==0.17.3 classic_control/pendulum.py (third party, restated): the oracle's step against a line-by-line float64
     restatement -- swing with saturated torques (clipped to +-2), the speed clip at 8, angle_normalize across several turns."""
