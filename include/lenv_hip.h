@@ -312,11 +312,12 @@ typedef struct {
 typedef struct {
     const float *rand_action;  int64_t rand_action_stride;    /* rows of A: env.get_random_action()      env_wrapper.py:87-90 */
     const float *act_noise;    int64_t act_noise_stride;      /* rows of A: randn in select_train_action TD3.py:123 */
-    const float *test_noise;   int64_t test_noise_stride;     /* rows of A: randn in select_test_action  TD3.py:128 */
+    const float *test_noise;   int64_t test_noise_stride;     /* rows of A: randn in select_test_action  TD3.py:128, one row per
+                                                                 * chosen action in the reference's order (episode by episode) */
     const float *policy_noise; int64_t policy_noise_stride;   /* rows of A: randn_like(actions) in learn TD3.py:75 */
     const int32_t *replay_idx; int64_t replay_idx_stride;     /* elements */
-    const double *train_reset; int64_t train_reset_stride;    /* rows of S */
-    const double *test_reset;  int64_t test_reset_stride;     /* rows of S */
+    const double *train_reset; int64_t train_reset_stride;    /* rows of the env's own state: 17 (stand-in), 2 (Pendulum: theta, */
+    const double *test_reset;  int64_t test_reset_stride;     /* theta_dot; MountainCarContinuous: position, velocity) */
 } lenv_td3_tapes;
 
 typedef struct {
