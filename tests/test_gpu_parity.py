@@ -810,6 +810,57 @@ def test_td3_icm_tape_and_counter_mode_vs_oracle(eng, orc, golden):
         assert float(il.score[c]) == oo["score"], c
 
 
+@pytest.mark.parametrize("env_name,fx", [("Pendulum-v0", "g8pr_calc_score_pendulum_td3_reward_env"),
+                                         ("MountainCarContinuous-v0", "g8cr_calc_score_cmc_td3_reward_env")])
+def test_td3_icm_vary_on_the_other_continuous_envs_vs_oracle(eng, orc, golden, env_name, fx):
+    """td3_icm (one-dimensional actions: the inverse model predicts a single torque / force) and per-chain hyper-parameters on
+    Pendulum-v0 and MountainCarContinuous-v0 (same_action_num 2 there): bit-exact against the oracle, ICM parameters included."""
+    from learning_environments_amd.config import icm_layer_dims
+    from learning_environments_amd.agents.nes_common import linear_init_bounds
+    cfgd = json.loads(str(golden(fx)["config_json"]))
+    cfgd["agents"]["gtn"]["agent_name"] = "td3_icm"
+    cfgd["agents"]["icm"] = {"lr": 1e-3, "beta": 0.2, "eta": 0.5, "feature_dim": 24, "hidden_size": 40}
+    cfgd["agents"]["td3"].update(hidden_size=48, hidden_layer=2, batch_size=40, train_episodes=3, init_episodes=1, test_episodes=2, early_out_num=50)
+    cfgd["envs"][env_name].update(max_steps=10, hidden_size=24, hidden_layer=1, reward_env_type=2, solved_reward=1e9)
+    ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
+    assert cfg.icm_enabled == 1
+    chains = 3
+    keys = np.array([orc.chain_key(39, 2, 0, c) for c in range(chains)], np.uint64)
+    rng = np.random.RandomState(73)
+    P_rn = orc.rn_num_params(2, cfg.state_dim, 0, 24, 1)
+    theta = (rng.randn(P_rn) * 0.2).astype(np.float32)
+    eps = (rng.randn(1, P_rn) * 0.05).astype(np.float32)
+    worker, sign = np.zeros(chains, np.int32), np.array([0.0, 1.0, -1.0], np.float32)
+    # chains 1 and 2 carry their own (smaller) hyper-parameters: the *_vary form of the launch
+    hps = [dict(lr=cfg.lr, batch_size=40, hidden_size=48, hidden_layer=2), dict(lr=2e-3, batch_size=17, hidden_size=20, hidden_layer=1),
+           dict(lr=5e-4, batch_size=33, hidden_size=31, hidden_layer=2)]
+    il = eng.Td3InnerLoop(cfg, chains, trace_cap=40, vary=True)
+    il.set_hp([h["lr"] for h in hps], [h["batch_size"] for h in hps], [h["hidden_size"] for h in hps], [h["hidden_layer"] for h in hps])
+    keys_t = dev(keys.view(np.int64))
+    init = il.draw_agent_init(keys_t).cpu().numpy()
+    icm_init = il.draw_icm_init(keys_t, torch.from_numpy(linear_init_bounds(icm_layer_dims(cfg))).cuda()).cpu().numpy()
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), None, rng_keys=keys_t)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    from learning_environments_amd.config import td3_layer_dims
+    for c in range(chains):
+        h = hps[c]
+        oc, pc = _td3_cfgs(orc, cfgd, 0, lr=float(h["lr"]), batch_size=int(h["batch_size"]), hidden=int(h["hidden_size"]),
+                           layers=max(1, int(h["hidden_layer"])))
+        oinit = orc.agent_init_from_key(int(keys[c]), td3_layer_dims(pc))
+        assert np.array_equal(init[c, :oinit.size], oinit), c
+        oicm = orc.agent_init_from_key(int(keys[c]), orc.icm_layer_dims(oc), stream=orc.STREAM_ICM_INIT)
+        assert np.array_equal(icm_init[c], oicm), c
+        w = (np.float32(sign[c]) * eps[0] + theta).astype(np.float32)
+        oo = orc.td3_rn_chain(oc, w, oinit, rng_key=int(keys[c]), trace_cap=40, icm_init=oicm)
+        m = oo["trace"]["reward"].size
+        assert oo["rc"] == 0 and oo["learn_steps"] > 0
+        assert np.array_equal(il.trace["action"][c, :m].cpu().numpy(), oo["trace"]["action"]), c
+        assert np.array_equal(il.trace["reward"][c, :m].cpu().numpy(), oo["trace"]["reward"]), c
+        assert np.array_equal(il.icm_final[c].cpu().numpy(), oo["icm_final"]), c
+        assert float(il.score[c]) == oo["score"], c
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # *_vary agents: per-chain lr / batch_size / hidden_size / hidden_layer in ONE launch (lenv_dueling_se_inner_loop_hp)
 # ---------------------------------------------------------------------------------------------------------------
