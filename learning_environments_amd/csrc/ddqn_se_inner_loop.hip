@@ -48,6 +48,61 @@ __device__ unsigned long long g_phase_cycles[64];
 #define PT_FLUSH(first, n)
 #endif
 
+// LDS carve-up and derived sizes of one (S, A, Hq, Hse, B, T, grad_chunk) shape.  constexpr so that the kernel instantiated for the
+// published CartPole configuration (SHAPE 1 below) gets every offset, trip count and tail condition as a literal, while every
+// other shape reads the same struct from the kernel arguments.
+struct InnerLayout {
+    int P_q, P_se, se_net_size[3];
+    int HP, chunk, n_chunks, n_chunks4, tanh16;
+    int o_se_w0T, o_se_b0, o_se_wout, o_se_bout, o_se_h, o_q_onl, o_q_tgt, o_q_w2, o_wscr, o_hB, o_sB, o_rda,
+        o_dqB, o_qres, o_part, o_newrow, o_ctrl, o_ret, o_tanh, o_cand, o_cur_state, lds_floats;
+    int rc;                                           // LENV_OK or the reason the shape does not fit
+};
+constexpr int layout_mlp_params(int in, int H, int out) { return in * H + H + H * out + out; }
+constexpr InnerLayout make_inner_layout(int S, int A, int Hq, int Hse, int B, int T, int grad_chunk, int nt, int nw, int max_ppt, int max_b)
+{
+    InnerLayout a{};
+    a.P_q = layout_mlp_params(S, Hq, A);
+    a.se_net_size[0] = layout_mlp_params(S + A, Hse, S);
+    a.se_net_size[1] = a.se_net_size[2] = layout_mlp_params(S + A, Hse, 1);
+    a.P_se = a.se_net_size[0] + a.se_net_size[1] + a.se_net_size[2];
+    a.rc = LENV_ERR_UNSUPPORTED;
+    if (a.P_q > max_ppt * nt) return a;
+    a.HP = (Hq + 1) & ~1;                       // even (8-byte pair stores of h) ...
+    if (((a.HP >> 1) & 1) == 0) a.HP += 2;      // ... with HP/2 odd: lanes = samples write pairs without bank conflicts
+    a.chunk = grad_chunk > 0 ? grad_chunk : (B + nw - 1) / nw;
+    a.n_chunks = (B + a.chunk - 1) / a.chunk;
+    if (a.n_chunks > nw) return a;
+    a.n_chunks4 = (a.n_chunks + 3) & ~3;
+    const int K = S + A, HqPad = (Hq + 63) & ~63;
+    // the tanh image is carved first (offset 0, see det_tanh_lds_off): 16 bank-private copies when they fit, else one
+    for (int sixteen = 1; sixteen >= 0; --sixteen) {
+        int o = 0;
+#define LENV_TAKE(n) ([&]() { int r_ = o; o += ((n) + 3) & ~3; return r_; }())
+        a.tanh16 = sixteen;
+        a.o_tanh = LENV_TAKE(sixteen ? LENV_TANH16_FLOATS : LENV_TANH1_FLOATS);
+        a.o_se_w0T = LENV_TAKE(3 * K * Hse); a.o_se_b0 = LENV_TAKE(3 * Hse); a.o_se_wout = LENV_TAKE((S + 2) * ((Hse + 3) & ~3)); a.o_se_bout = LENV_TAKE(S + 2);
+        a.o_se_h = LENV_TAKE(2 * 3 * ((Hse + 3) & ~3));
+        const int PRh = ((2 * S + 2 + 3) & ~3) + ((2 * A + 3) & ~3);      // floats per pair record (rec_pr<S, A>())
+        a.o_q_onl = LENV_TAKE(((Hq + 1) / 2) * PRh + A); a.o_q_tgt = LENV_TAKE(((Hq + 1) / 2) * PRh + A); a.o_q_w2 = LENV_TAKE(A * ((Hq + 3) & ~3));
+        a.o_wscr = LENV_TAKE(nw * HqPad);
+        a.o_hB = LENV_TAKE(B * a.HP);
+        a.o_sB = LENV_TAKE(B * ((S + 3) & ~3)); a.o_rda = LENV_TAKE(B * 4); a.o_dqB = LENV_TAKE(4 * B);
+        a.o_qres = LENV_TAKE(3 * max_b * A);
+        a.o_part = LENV_TAKE(a.n_chunks4 * a.P_q);
+        a.o_newrow = LENV_TAKE(16); a.o_ctrl = LENV_TAKE(8 + nw);
+        a.o_ret = LENV_TAKE(3 * T + 2);
+        a.o_cand = LENV_TAKE(16 * A); a.o_cur_state = LENV_TAKE(16);
+#undef LENV_TAKE
+        a.lds_floats = o;
+        if ((long long)o * 4 <= 160 * 1024) { a.rc = LENV_OK; return a; }
+    }
+    return a;
+}
+// the published CartPole configuration (default_config_cartpole_syn_env.yaml: Critic_DQN 4-57-2 tanh, batch 199, SE hidden 83,
+// 10 test episodes; grad_chunk 17 = ceil(199 / 12)): BASELINE configs[1]
+constexpr int FIX_HQ = 57, FIX_HSE = 83, FIX_B = 199, FIX_T = 10, FIX_CHUNK = 17, FIX_MAX_STEPS = 200;
+
 struct InnerArgs {
     lenv_ddqn_cfg cfg;
     const float *theta, *eps; const int32_t *worker; const float *sign;
@@ -55,17 +110,13 @@ struct InnerArgs {
     lenv_tapes tapes; int has_tapes;
     float *replay; double *meter; int64_t rb_cap; int row_stride;
     lenv_inner_out out;
-    int P_q, P_se, se_net_size[3];
-    int RP, HP, chunk, n_chunks, n_chunks4, tanh16;
+    InnerLayout L;
     // fp32 constants of the learn step, converted ONCE on the host exactly as the kernel used to ((float) of the double
     // expression): keeps ten double-precision config fields (20 SGPRs) and their conversions out of the step loop
     float f_gamma, f_norm, f_w1, f_w2, f_beta2, f_adam_eps, f_tau, f_omt;
     // torch.optim.Adam bias corrections per learn step t = 1, 2, ...: {-(lr / (1 - beta1^t)), sqrt(1 - beta2^t)} as fp32,
     // computed in double on the host with the same operation sequence the kernel's thread NT-1 used to run every step
     const float2 *adam_sched;
-    // LDS offsets (floats)
-    int o_se_w0T, o_se_b0, o_se_wout, o_se_bout, o_se_h, o_q_onl, o_q_tgt, o_q_w2, o_wscr, o_hB, o_sB, o_rda,
-        o_dqB, o_qres, o_part, o_newrow, o_ctrl, o_ret, o_tanh, o_cand, o_cur_state, lds_floats;
 };
 
 // Workgroup-internal flag in LDS: the env wave publishes "phase A of step `tag` is done" while the other waves are already
@@ -237,11 +288,18 @@ __device__ __forceinline__ void real_env_obs(const double (&st)[4], float (&obs)
     }
 }
 
-template <int ENV, int S, int A, int QACT, int PPT>
+// SHAPE 1 = the published CartPole configuration (FIX_* above): network widths, batch size, chunking and the whole LDS layout are
+// literals, which frees the scalar registers that otherwise carry them (the generic build spills ~350 SGPR values to VGPR lanes
+// and reloads ~100 of them per learn step with v_readlane, a VALU slot each) and removes the tail code of the pair loops.
+template <int ENV, int S, int A, int QACT, int PPT, int SHAPE = 0>
 __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 {
     extern __shared__ __align__(16) float lds[];
     const lenv_ddqn_cfg &cfg = a.cfg;
+    constexpr bool FIXED = SHAPE == 1;
+    constexpr InnerLayout LC = make_inner_layout(S, A, FIX_HQ, FIX_HSE, FIX_B, FIX_T, FIX_CHUNK, NT, NW, MAX_PPT, MAX_B);
+    static_assert(!FIXED || LC.rc == LENV_OK, "the fixed shape must fit");
+#define LV(f) (FIXED ? LC.f : a.L.f)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t chain = blockIdx.x;
     constexpr int K = S + A;
@@ -249,36 +307,41 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     constexpr int PR = rec_pr<S, A>();                // floats per pair record
     constexpr int RS = (2 * S + 3 + 3) & ~3;          // replay row stride (floats)
     constexpr int SP = (S + 3) & ~3;                  // minibatch-state row stride in LDS (16-byte rows)
-    const int Hq = cfg.q_hidden, Hse = cfg.se_hidden, B = cfg.batch_size, HP = a.HP, P = a.P_q;
+    // Literal in the SHAPE 1 build: SE width, batch size, test episodes, parameter count, chunking and every LDS offset.  The Q-net
+    // width stays a run-time value outside the minibatch forward: as a literal it makes the compiler keep more per-lane state
+    // live and spill ~70 VGPRs to scratch inside the forward and gradient loops (measured: 11.4 us per learn step instead of 8.8).
+    const int Hq = cfg.q_hidden, Hse = FIXED ? FIX_HSE : cfg.se_hidden, B = FIXED ? FIX_B : cfg.batch_size;
+    const int HP = a.L.HP, P = LV(P_q), T_EP = FIXED ? FIX_T : cfg.test_episodes, MAX_STEPS = FIXED ? FIX_MAX_STEPS : cfg.max_steps;
     const int HqP = (Hq + 3) & ~3, HseP = (Hse + 3) & ~3;
 
-    float *se_w0T = lds + a.o_se_w0T, *se_b0 = lds + a.o_se_b0, *se_wout = lds + a.o_se_wout, *se_bout = lds + a.o_se_bout;
-    float *se_h = lds + a.o_se_h, *q_onl = lds + a.o_q_onl, *q_tgt = lds + a.o_q_tgt, *q_w2 = lds + a.o_q_w2;
-    float *wscr = lds + a.o_wscr + wave * ((Hq + 63) & ~63);
+    float *se_w0T = lds + LV(o_se_w0T), *se_b0 = lds + LV(o_se_b0), *se_wout = lds + LV(o_se_wout), *se_bout = lds + LV(o_se_bout);
+    float *se_h = lds + LV(o_se_h), *q_onl = lds + LV(o_q_onl), *q_tgt = lds + LV(o_q_tgt), *q_w2 = lds + LV(o_q_w2);
+    float *wscr = lds + LV(o_wscr) + wave * ((Hq + 63) & ~63);
     float *se_hw = se_h + (wave & 1) * 3 * HseP;      // per-wave SE hidden scratch (waves NW-2 / NW-1)
-    float *cand = lds + a.o_cand, *cur_state = lds + a.o_cur_state;
-    float *hB = lds + a.o_hB, *sB = lds + a.o_sB, *rda = lds + a.o_rda, *dqB = lds + a.o_dqB;
-    float *qres = lds + a.o_qres, *part = lds + a.o_part, *newrow = lds + a.o_newrow;
-    float *ctrl = lds + a.o_ctrl;            // [0..1] done (double buffered by step parity), [2] break, [8..] wave step counts (every use is barrier-separated)
-    double *ret = reinterpret_cast<double *>(lds + a.o_ret);   // [test_episodes] returns
-    int *tlen = reinterpret_cast<int *>(lds + a.o_ret + 2 * cfg.test_episodes);   // [test_episodes] lengths of the last test phase
+    float *cand = lds + LV(o_cand), *cur_state = lds + LV(o_cur_state);
+    float *hB = lds + LV(o_hB), *sB = lds + LV(o_sB), *rda = lds + LV(o_rda), *dqB = lds + LV(o_dqB);
+    float *qres = lds + LV(o_qres), *part = lds + LV(o_part), *newrow = lds + LV(o_newrow);
+    float *ctrl = lds + LV(o_ctrl);            // [0..1] done (double buffered by step parity), [2] break, [8..] wave step counts (every use is barrier-separated)
+    double *ret = reinterpret_cast<double *>(lds + LV(o_ret));   // [test_episodes] returns
+    int *tlen = reinterpret_cast<int *>(lds + LV(o_ret) + 2 * T_EP);   // [test_episodes] lengths of the last test phase
     // LDS image of the canonical tanh table at the START of the workgroup's LDS (its base folds into the DS immediate
     // offset): 16 bank-private copies (32 KB, conflict-free gathers) when the shapes leave room, one copy (2 KB) otherwise
-    det_tanh_lds_stage(lds, a.tanh16 != 0, tid, NT);
+    det_tanh_lds_stage(lds, LV(tanh16) != 0, tid, NT);
     // LDS byte address of the image: the literal 0 (this kernel has no static LDS, so its dynamic LDS starts at address
     // 0; a literal lets the gather address be the bare v_and_or result).  Verified below, never assumed silently.
     constexpr uint32_t tanh_tab = 0u;
     if (lds_addr_of(lds) != 0u) { if (tid == 0 && a.out.status) a.out.status[blockIdx.x] = -7; return; }
-    const TanhLds tl = TanhLds::make(a.tanh16 != 0, lane);
+    const TanhLds tl = TanhLds::make(LV(tanh16) != 0, lane);
 
     // ---------------- stage the perturbed SE: W = theta + sign*eps[worker]  (GTN_worker.py:165-175) ----------------
     {
         const float sg = a.eps ? a.sign[chain] : 0.0f;
-        const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P_se : nullptr;
-        for (int i = tid; i < a.P_se; i += NT) {
+        const int P_se = LV(P_se), sn0 = LV(se_net_size[0]), sn1 = LV(se_net_size[1]);
+        const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * P_se : nullptr;
+        for (int i = tid; i < P_se; i += NT) {
             float w = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
             int net = 0, r = i;
-            if (r >= a.se_net_size[0]) { r -= a.se_net_size[0]; net = 1; if (r >= a.se_net_size[1]) { r -= a.se_net_size[1]; net = 2; } }
+            if (r >= sn0) { r -= sn0; net = 1; if (r >= sn1) { r -= sn1; net = 2; } }
             const int orow = net == 0 ? 0 : (net == 1 ? S : S + 1);
             if (r < Hse * K) { int j = r / K, k = r - j * K; se_w0T[(net * K + k) * Hse + j] = w; }
             else if ((r -= Hse * K) < Hse) se_b0[net * Hse + r] = w;
@@ -317,11 +380,12 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
         }
     }
     if (tid < 8 + NW) ctrl[tid] = 0.0f;
-    for (int i = tid; i < a.n_chunks4 * P; i += NT) part[i] = 0.0f;  // padding chunk slots stay +0 (see the Adam phase)
+    for (int i = tid; i < LV(n_chunks4) * P; i += NT) part[i] = 0.0f;  // padding chunk slots stay +0 (see the Adam phase)
     __syncthreads();
 
     const uint64_t key = a.rng_keys ? a.rng_keys[chain] : 0;
-    const bool tape = cfg.rng_mode == LENV_RNG_TAPE;
+    // the shape-specialised build serves production launches only: counter RNG, no step trace (tests with tapes / traces take the generic one)
+    const bool tape = !FIXED && cfg.rng_mode == LENV_RNG_TAPE;
     int status = 0;
     // counters (all uniform): one eps-uniform draw and one replay append per train step
     int train_steps = 0, n_act = 0, learn_it = 0, n_test_ep = 0, test_steps = 0, wr_pos = 0;
@@ -371,7 +435,8 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 hbuf[net * HseP + j] = act_fwd_t<SEACT>(tanh_tab, tl, cfg.se_prelu, z);
             }
         };
-        switch (cfg.se_act) {
+        if constexpr (FIXED) se_hidden(std::integral_constant<int, LENV_ACT_LEAKYRELU>{});      // the published SE: leakyrelu
+        else switch (cfg.se_act) {
         case LENV_ACT_RELU: se_hidden(std::integral_constant<int, LENV_ACT_RELU>{}); break;
         case LENV_ACT_LEAKYRELU: se_hidden(std::integral_constant<int, LENV_ACT_LEAKYRELU>{}); break;
         case LENV_ACT_TANH: se_hidden(std::integral_constant<int, LENV_ACT_TANH>{}); break;
@@ -391,7 +456,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     // one real-env test phase (BaseAgent.test + DDQN.select_test_action): wave w plays test episodes w, w+NW, ...
     auto test_phase = [&]() {
         int my_steps = 0;
-        for (int te = wave; te < cfg.test_episodes; te += NW) {
+        for (int te = wave; te < T_EP; te += NW) {
             double st[4];
             const int64_t row = (int64_t)n_test_ep + te;
             if (tape) {
@@ -403,7 +468,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
             }
             float ep_reward = 0.0f;
             int ep_steps = 0;
-            for (int t = 0; t < cfg.max_steps; ++t) {
+            for (int t = 0; t < MAX_STEPS; ++t) {
                 float obs[S];
                 real_env_obs<ENV, S>(st, obs);
                 const int act = wave_q_argmax<S, A, PR, QACT>(q_onl, q_w2, HqP, obs, wscr, Hq, cfg.q_prelu, lane, tanh_tab, tl);
@@ -416,7 +481,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
             if (lane == 0) { ret[te] = (double)ep_reward; tlen[te] = ep_steps; }
         }
         if (lane == 0) ctrl[8 + wave] = __int_as_float(my_steps);
-        n_test_ep += cfg.test_episodes;
+        n_test_ep += T_EP;
         __syncthreads();
         for (int w = 0; w < NW; ++w) test_steps += __float_as_int(ctrl[8 + w]);
     };
@@ -488,7 +553,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 
         int ep_len = 0;
         spec_valid = false;                               // a reset state has no precomputed candidates
-        for (int t = 0; t < cfg.max_steps; ++t) {
+        for (int t = 0; t < MAX_STEPS; ++t) {
             const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;     // ReplayBuffer.size after this add
             const int new_pos = wr_pos;                                                     // ReplayBuffer.ptr before this add (== train_steps % rb_cap)
             // ================= phase A =================
@@ -540,7 +605,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 }
                 if (lane == 0) {
                     ctrl[t & 1] = done;
-                    if (a.out.trace_action && train_steps < a.out.trace_cap) {
+                    if (!FIXED && a.out.trace_action && train_steps < a.out.trace_cap) {
                         const int64_t k = chain * a.out.trace_cap + train_steps;
                         a.out.trace_action[k] = action | (explored << 16);
                         for (int i = 0; i < S; ++i) { a.out.trace_state[k * S + i] = state[i]; a.out.trace_next_state[k * S + i] = next_state[i]; }
@@ -587,7 +652,8 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     // cycles) is otherwise exposed once per pair.
                     constexpr int N1 = OW2 / 4, N2 = (PR - OW2) / 4, PR4 = PR / 4;
                     const float4 *W4 = reinterpret_cast<const float4 *>(W);
-                    const int npairs = (Hq + 1) >> 1;
+                    const int Hqf = FIXED ? FIX_HQ : Hq;                            // literal only here: pair count and tail of this loop
+                    const int npairs = (Hqf + 1) >> 1;
                     float *hrow = hB + fwd_b * HP;
                     float4 r1[N1], r2[N2];
                     auto load1 = [&](int jp) {
@@ -642,7 +708,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                             nxt.issue(tanh_tab, tl, layer1());      // r1 holds pair jp+1
                             if (FULL || jp + 2 < npairs) load1(jp + 2);
                         }
-                        finish(cur, jp, FULL || 2 * jp + 1 < Hq);   // r2 holds pair jp
+                        finish(cur, jp, FULL || 2 * jp + 1 < Hqf);  // r2 holds pair jp
                         if (FULL || jp + 1 < npairs) load2(jp + 1);
                     };
                     using T = std::true_type;
@@ -653,6 +719,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     if (npairs > 1) load1(1);
                     load2(0);
                     int jp = 0;
+#pragma unroll 1
                     for (; jp + 4 <= npairs; jp += 2) {             // jp+3 < npairs: both stages are steady-state
                         stage(pa, pb, jp, T{});
                         stage(pb, pa, jp + 1, T{});
@@ -661,7 +728,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         stage(pa, pb, jp, F{});
                         stage(pb, pa, jp + 1, F{});
                     }
-                    if (jp < npairs) finish(pa, jp, 2 * jp + 1 < Hq);
+                    if (jp < npairs) finish(pa, jp, 2 * jp + 1 < Hqf);
 #pragma unroll
                     for (int aa = 0; aa < A; ++aa) qres[(fwd_pass * MAX_B + fwd_b) * A + aa] = q[aa] + W[npairs * PR + aa];
                     if (fwd_pass == 0) {
@@ -680,7 +747,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         const float acc = se_eval(se_hw, st, act);
                         if (lane < S + 2) cand[act * 16 + lane] = acc;
                     }
-                    if (wave == ENV_WAVE && t + 1 < cfg.max_steps) {
+                    if (wave == ENV_WAVE && t + 1 < MAX_STEPS) {
                         draw_action(train_steps);              // train_steps already counts this step: index of the next one
                         nx_valid = true;
                     }
@@ -723,8 +790,8 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 // lane = hidden unit j.  Per sample (canonical order, oracle orc_ddqn_learn): da = dq*W2[a_b][j] (as a sum over
                 // the action masks, exactly one term non-zero), dz = act'(h)*da, gW1[j][:] += dz*s, gb1[j] += dz,
                 // gW2[a][j] += dqm[a]*h, gb2[a] += dqm[a] -- adding an exact zero leaves the other actions' sums untouched.
-                if (wave < a.n_chunks) {
-                    const int b0 = wave * a.chunk, b1 = (b0 + a.chunk < B) ? b0 + a.chunk : B;
+                if (wave < LV(n_chunks)) {
+                    const int b0 = wave * LV(chunk), b1 = (b0 + LV(chunk) < B) ? b0 + LV(chunk) : B;
                     float *pc = part + wave * P;
                     for (int j = lane; j < ((Hq + 63) & ~63); j += 64) {
                         const bool jv = j < Hq;
@@ -771,6 +838,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         // running pointers (one add per round each): h column of this lane, dq rows and state rows of the chunk
                         const float *hp = hB + (jv ? j : 0) + b0 * HP, *dqp = dqB + 4 * b0, *sp = sB + SP * b0;
                         int bq = b0;
+#pragma unroll 1
                         for (; bq + 4 <= b1; bq += 4, hp += 4 * HP, dqp += 16, sp += 4 * SP) {
                             // whole groups of four samples: every LDS read is issued before the first use
                             float hv[4], sv[4][SP];
@@ -827,7 +895,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                                 for (int c = 0; c < 4; ++c) pv[c] = part[c * P + p];
                                 g = pv[0]; g = g + pv[1]; g = g + pv[2]; g = g + pv[3];
                             }
-                            for (int c0 = 4; c0 < a.n_chunks4; c0 += 4) {          // uniform trip count, four slots per round
+                            for (int c0 = 4; c0 < LV(n_chunks4); c0 += 4) {          // uniform trip count, four slots per round
                                 float pv[4];
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) pv[c] = part[(c0 + c) * P + p];
@@ -865,8 +933,8 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
         int brk = 0;
         if (tid == 0) {
             double sm = 0.0;
-            for (int i = 0; i < cfg.test_episodes; ++i) sm += ret[i];
-            const double tm = sm / (double)cfg.test_episodes;
+            for (int i = 0; i < T_EP; ++i) sm += ret[i];
+            const double tm = sm / (double)T_EP;
             meter[episode] = tm;
             if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
             // early out on the real env (base_agent.py:49-62,141-148; AverageMeter._mean utils.py:103-105)
@@ -895,14 +963,14 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
         // list rolled out above is cut here.
         if (tid == 0) {
             int64_t used = 0;
-            int stop = cfg.test_episodes;
-            for (int te = 0; te < cfg.test_episodes; ++te) {
+            int stop = T_EP;
+            for (int te = 0; te < T_EP; ++te) {
                 if (used > remaining) { stop = te; break; }
                 used += tlen[te];
             }
             double mn = -1e9;
             if (stop > 0) { mn = ret[0]; for (int i = 1; i < stop; ++i) if (ret[i] < mn) mn = ret[i]; }
-            for (int te = stop; te < cfg.test_episodes; ++te) ret[te] = mn;
+            for (int te = stop; te < T_EP; ++te) ret[te] = mn;
             ctrl[6] = __int_as_float((int)used);
         }
         __syncthreads();
@@ -917,9 +985,9 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 #endif
     if (tid == 0) {
         double sm = 0.0;
-        for (int i = 0; i < cfg.test_episodes; ++i) sm += ret[i];
-        a.out.score[chain] = sm / (double)cfg.test_episodes;
-        if (a.out.final_returns) for (int i = 0; i < cfg.test_episodes; ++i) a.out.final_returns[chain * cfg.test_episodes + i] = ret[i];
+        for (int i = 0; i < T_EP; ++i) sm += ret[i];
+        a.out.score[chain] = sm / (double)T_EP;
+        if (a.out.final_returns) for (int i = 0; i < T_EP; ++i) a.out.final_returns[chain * T_EP + i] = ret[i];
         if (a.out.stats) {
             a.out.stats[chain * 4 + 0] = episodes_run; a.out.stats[chain * 4 + 1] = train_steps;
             a.out.stats[chain * 4 + 2] = learn_it; a.out.stats[chain * 4 + 3] = test_steps;
@@ -951,6 +1019,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
         if (status != 0) atomicMin(&a.out.status[chain], status);
     }
 }
+#undef LV
 
 }  // namespace lenv
 
@@ -1005,42 +1074,26 @@ static const float2 *adam_schedule(const lenv_ddqn_cfg *cfg, int64_t n)
 // LDS carve-up of one chain's workgroup; returns LENV_ERR_UNSUPPORTED when the shapes do not fit 160 KiB
 static int inner_layout(const lenv_ddqn_cfg *cfg, InnerArgs &a)
 {
-    const int S = cfg->state_dim, A = cfg->num_actions, Hq = cfg->q_hidden, Hse = cfg->se_hidden, B = cfg->batch_size;
-    a.P_q = (int)mlp_params(S, Hq, 1, A);
-    a.se_net_size[0] = (int)mlp_params(S + A, Hse, 1, S);
-    a.se_net_size[1] = a.se_net_size[2] = (int)mlp_params(S + A, Hse, 1, 1);
-    a.P_se = a.se_net_size[0] + a.se_net_size[1] + a.se_net_size[2];
-    if (a.P_q > MAX_PPT * NT) return LENV_ERR_UNSUPPORTED;
-    a.RP = 0;
-    a.HP = (Hq + 1) & ~1;                       // even (8-byte pair stores of h) ...
-    if (((a.HP >> 1) & 1) == 0) a.HP += 2;      // ... with HP/2 odd: lanes = samples write pairs without bank conflicts
-    a.chunk = cfg->grad_chunk > 0 ? cfg->grad_chunk : (B + NW - 1) / NW;
-    a.n_chunks = (B + a.chunk - 1) / a.chunk;
-    if (a.n_chunks > NW) return LENV_ERR_UNSUPPORTED;
-    a.n_chunks4 = (a.n_chunks + 3) & ~3;
-    const int K = S + A, HqPad = (Hq + 63) & ~63;
-    // the tanh image is carved first (offset 0, see det_tanh_lds_off): 16 bank-private copies when they fit, else one
-    for (int sixteen = 1; sixteen >= 0; --sixteen) {
-        int o = 0;
-        auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
-        a.tanh16 = sixteen;
-        a.o_tanh = take(sixteen ? LENV_TANH16_FLOATS : LENV_TANH1_FLOATS);
-        a.o_se_w0T = take(3 * K * Hse); a.o_se_b0 = take(3 * Hse); a.o_se_wout = take((S + 2) * ((Hse + 3) & ~3)); a.o_se_bout = take(S + 2);
-        a.o_se_h = take(2 * 3 * ((Hse + 3) & ~3));
-        const int PRh = ((2 * S + 2 + 3) & ~3) + ((2 * A + 3) & ~3);      // floats per pair record (rec_pr<S, A>())
-        a.o_q_onl = take(((Hq + 1) / 2) * PRh + A); a.o_q_tgt = take(((Hq + 1) / 2) * PRh + A); a.o_q_w2 = take(A * ((Hq + 3) & ~3));
-        a.o_wscr = take(NW * HqPad);
-        a.o_hB = take(B * a.HP);
-        a.o_sB = take(B * ((S + 3) & ~3)); a.o_rda = take(B * 4); a.o_dqB = take(4 * B);
-        a.o_qres = take(3 * MAX_B * A);
-        a.o_part = take(a.n_chunks4 * a.P_q);
-        a.o_newrow = take(16); a.o_ctrl = take(8 + NW);
-        a.o_ret = take(3 * cfg->test_episodes + 2);
-        a.o_cand = take(16 * A); a.o_cur_state = take(16);
-        a.lds_floats = o;
-        if ((size_t)o * sizeof(float) <= 160 * 1024) return LENV_OK;
-    }
-    return LENV_ERR_UNSUPPORTED;
+    a.L = make_inner_layout(cfg->state_dim, cfg->num_actions, cfg->q_hidden, cfg->se_hidden, cfg->batch_size, cfg->test_episodes,
+                            cfg->grad_chunk, NT, NW, MAX_PPT, MAX_B);
+    return a.L.rc;
+}
+
+// diagnostic switch: LENV_NO_FIXED_SHAPE=1 in the environment runs the published shape through the generic instantiation (A/B timing)
+static bool cfg_disables_fixed_shape()
+{
+    static const bool off = [] { const char *e = getenv("LENV_NO_FIXED_SHAPE"); return e && e[0] == '1'; }();
+    return off;
+}
+
+// the shape the SHAPE 1 instantiation was compiled for
+static bool is_published_cartpole_shape(const lenv_ddqn_cfg *cfg, const InnerLayout &L)
+{
+    constexpr InnerLayout LC = make_inner_layout(4, 2, FIX_HQ, FIX_HSE, FIX_B, FIX_T, FIX_CHUNK, NT, NW, MAX_PPT, MAX_B);
+    return cfg->env_id == LENV_ENV_CARTPOLE && cfg->q_act == LENV_ACT_TANH && cfg->q_hidden == FIX_HQ && cfg->se_hidden == FIX_HSE &&
+           cfg->batch_size == FIX_B && cfg->test_episodes == FIX_T && cfg->max_steps == FIX_MAX_STEPS && cfg->se_act == LENV_ACT_LEAKYRELU &&
+           L.chunk == FIX_CHUNK && L.lds_floats == LC.lds_floats &&
+           L.tanh16 == LC.tanh16 && L.P_q <= NT;
 }
 
 static int inner_check(const lenv_ddqn_cfg *cfg)
@@ -1075,7 +1128,7 @@ extern "C" int64_t lenv_ddqn_se_lds_bytes(const lenv_ddqn_cfg *cfg)
     InnerArgs a;
     rc = inner_layout(cfg, a);
     if (rc != LENV_OK) return rc;
-    return (int64_t)a.lds_floats * (int64_t)sizeof(float);
+    return (int64_t)a.L.lds_floats * (int64_t)sizeof(float);
 }
 
 extern "C" size_t lenv_ddqn_se_workspace_bytes(const lenv_ddqn_cfg *cfg, int64_t chains)
@@ -1113,7 +1166,7 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
     a.out = *out;
     const int lrc = inner_layout(cfg, a);
     if (lrc != LENV_OK) return lrc;
-    const size_t lds_bytes = (size_t)a.lds_floats * sizeof(float);
+    const size_t lds_bytes = (size_t)a.L.lds_floats * sizeof(float);
     a.f_gamma = (float)cfg->gamma; a.f_norm = (float)(2.0 / (double)cfg->batch_size);
     a.f_w1 = (float)(1.0 - cfg->adam_beta1); a.f_w2 = (float)(1.0 - cfg->adam_beta2); a.f_beta2 = (float)cfg->adam_beta2;
     a.f_adam_eps = (float)cfg->adam_eps; a.f_tau = (float)cfg->tau; a.f_omt = (float)(1.0 - cfg->tau);
@@ -1129,11 +1182,13 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
     case LENV_ACT_PRELU: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_PRELU, PP>; break;                    \
     default: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_IDENTITY, PP>; break;                             \
     }
-#define LENV_PICK(ENVID, SS, AA) if (a.P_q <= NT) { LENV_PICK2(ENVID, SS, AA, 1) } else { LENV_PICK2(ENVID, SS, AA, 2) }
+#define LENV_PICK(ENVID, SS, AA) if (a.L.P_q <= NT) { LENV_PICK2(ENVID, SS, AA, 1) } else { LENV_PICK2(ENVID, SS, AA, 2) }
     if (cfg->env_id == LENV_ENV_CARTPOLE) { LENV_PICK(LENV_ENV_CARTPOLE, 4, 2) }
     else { LENV_PICK(LENV_ENV_ACROBOT, 6, 3) }
 #undef LENV_PICK2
 #undef LENV_PICK
+    if (is_published_cartpole_shape(cfg, a.L) && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action && !cfg_disables_fixed_shape())
+        kern = ddqn_se_inner_kernel<LENV_ENV_CARTPOLE, 4, 2, LENV_ACT_TANH, 1, 1>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;
     if (out->status) {
