@@ -1418,6 +1418,47 @@ def test_inner_loop_full_size_properties(eng, orc):
         assert np.array_equal(base[3][c], o["final_test_returns"])
 
 
+@pytest.mark.parametrize("budget", [0, 9000])
+def test_inner_loop_specialised_vs_generic_instantiation(eng, orc, budget):
+    """The published CartPole shape in its production form (early-out on, as default_config_cartpole_syn_env.yaml ships it; with and
+    without a step budget): the shape-specialised instantiation (no trace) and the generic one (a launch that asks for a trace)
+    must agree on every output of every chain, and one chain is checked against the oracle."""
+    from learning_environments_amd import configs
+    from learning_environments_amd.config import ddqn_cfg_from_config
+    cfgd = configs.cartpole_syn_env_ddqn(8)
+    cfgd["agents"]["ddqn"].update(train_episodes=30)
+    if budget:
+        cfgd["agents"]["ddqn"]["step_budget"] = budget
+    cfg = ddqn_cfg_from_config(cfgd)
+    ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=cfg.grad_chunk, rng_mode=0)
+    assert (cfg.q_hidden, cfg.se_hidden, cfg.batch_size, cfg.test_episodes, cfg.max_steps, cfg.grad_chunk) == (57, 83, 199, 10, 200, 17)
+    S, A, pop = cfg.state_dim, cfg.num_actions, 8
+    chains = 3 * pop
+    rng = np.random.RandomState(17)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, cfg.se_hidden, 1, "leakyrelu"))
+    P_q = orc.mlp_num_params(orc.mlp_desc(S, cfg.q_hidden, 1, A, "tanh"))
+    theta = (rng.randn(P_se) * 0.15).astype(np.float32)
+    eps = (rng.randn(pop, P_se) * 0.02).astype(np.float32)
+    agent_init = rng.uniform(-0.4, 0.4, (chains, P_q)).astype(np.float32)
+    worker = np.repeat(np.arange(pop), 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), pop)
+    keys = np.array([orc.chain_key(77, 3, int(worker[c]), c % 3) for c in range(chains)], np.uint64)
+    outs = []
+    for trace_cap in (0, 2):
+        il = eng.InnerLoop(cfg, chains, trace_cap=trace_cap, want_final_online=True)
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        outs.append([t.cpu().numpy().copy() for t in (il.score, il.stats, il.episode_test_mean, il.episode_len, il.final_returns, il.final_online)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+    c = 4
+    w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+    o = orc.ddqn_se_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]))
+    assert float(outs[0][0][c]) == o["score"] and outs[0][1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+    assert np.array_equal(outs[0][2][c], o["episode_test_mean"], equal_nan=True) and np.array_equal(outs[0][4][c], o["final_test_returns"])
+
+
 def _oracle_chains_parallel(fn, jobs):
     """Run the (GIL-releasing) oracle on several whole chains at once."""
     from concurrent.futures import ThreadPoolExecutor
