@@ -1418,6 +1418,49 @@ def test_inner_loop_full_size_properties(eng, orc):
         assert np.array_equal(base[3][c], o["final_test_returns"])
 
 
+@pytest.mark.parametrize("env_name,hq,hse,batch,act", [("Acrobot-v1", 112, 64, 149, "leakyrelu"), ("CartPole-v0", 33, 40, 64, "relu"),
+                                                      ("CartPole-v0", 57, 83, 199, "tanh")])
+def test_inner_loop_with_and_without_trace_agree(eng, orc, golden, env_name, hq, hse, batch, act):
+    """A launch without a step trace and the same launch asking for one must agree on every output, chain for chain, for shapes
+    other than the published one too (the third case has the published widths but 40-step episodes and 4 test episodes, so it
+    does NOT take the shape-specialised instantiation).  A production-mode instantiation without the tape / trace plumbing but
+    with the run-time layout was measured for these shapes and brought nothing (9.30 vs 9.30 us per learn step), so it does not exist."""
+    cfgd = json.loads(str(golden("g8_calc_score_cartpole_a")["config_json"]))
+    if env_name == "Acrobot-v1":
+        cfgd["env_name"] = env_name
+        cfgd["envs"][env_name] = dict(cfgd["envs"]["CartPole-v0"], solved_reward=-100.0)
+    cfgd["envs"][env_name]["hidden_size"] = hse
+    cfgd["agents"]["ddqn"].update(hidden_size=hq, batch_size=batch, activation_fn=act, test_episodes=4)
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, train_episodes=5, max_steps=40)
+    from learning_environments_amd.config import pick_grad_chunk
+    ocfg.grad_chunk = cfg.grad_chunk = pick_grad_chunk(cfg)
+    S, A = ocfg.state_dim, ocfg.num_actions
+    rng = np.random.RandomState(31)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, hse, 1, "leakyrelu"))
+    P_q = orc.mlp_num_params(orc.mlp_desc(S, hq, 1, A, act))
+    chains, pop = 9, 3
+    theta = (rng.randn(P_se) * 0.15).astype(np.float32)
+    eps = (rng.randn(pop, P_se) * 0.05).astype(np.float32)
+    agent_init = (rng.uniform(-0.4, 0.4, (chains, P_q))).astype(np.float32)
+    worker = np.repeat(np.arange(pop), 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), pop)
+    keys = np.array([orc.chain_key(9, 3, int(worker[c]), c % 3) for c in range(chains)], np.uint64)
+    outs = []
+    for trace_cap in (0, 2):
+        il = eng.InnerLoop(cfg, chains, trace_cap=trace_cap, want_final_online=True)
+        assert not il.dueling
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        outs.append([t.cpu().numpy().copy() for t in (il.score, il.stats, il.episode_test_mean, il.episode_len, il.final_returns, il.final_online)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+    c = 5
+    w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+    o = orc.ddqn_se_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]))
+    assert float(outs[0][0][c]) == o["score"] and outs[0][1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
 @pytest.mark.parametrize("budget", [0, 9000])
 def test_inner_loop_specialised_vs_generic_instantiation(eng, orc, budget):
     """The published CartPole shape in its production form (early-out on, as default_config_cartpole_syn_env.yaml ships it; with and
