@@ -99,9 +99,17 @@ constexpr InnerLayout make_inner_layout(int S, int A, int Hq, int Hse, int B, in
     }
     return a;
 }
-// the published CartPole configuration (default_config_cartpole_syn_env.yaml: Critic_DQN 4-57-2 tanh, batch 199, SE hidden 83,
-// 10 test episodes; grad_chunk 17 = ceil(199 / 12)): BASELINE configs[1]
-constexpr int FIX_HQ = 57, FIX_HSE = 83, FIX_B = 199, FIX_T = 10, FIX_CHUNK = 17, FIX_MAX_STEPS = 200;
+// The published one-hidden-layer DDQN configurations of the reference, each with its own shape-specialised instantiation (SHAPE
+// template parameter of the kernel): env, S, A, Q-net width / activation, batch, SE width / activation, test episodes, max_steps.
+// chunk is the package's pick_grad_chunk value for the shape (the launch must carry the same one).
+struct ShapeSpec { int env, S, A, Hq, q_act, B, Hse, se_act, T, max_steps, chunk; };
+constexpr ShapeSpec kShapes[] = {
+    { -1, 4, 2, 1, 0, 1, 1, 0, 1, 1, 1 },                                                                            // 0: generic (unused entry)
+    { LENV_ENV_CARTPOLE, 4, 2, 57, LENV_ACT_TANH, 199, 83, LENV_ACT_LEAKYRELU, 10, 200, 17 },    // 1: default_config_cartpole_syn_env.yaml = BASELINE configs[1]
+    { LENV_ENV_CARTPOLE, 4, 2, 64, LENV_ACT_RELU, 32, 128, LENV_ACT_LEAKYRELU, 1, 200, 3 },      // 2: default_config_cartpole.yaml
+    { LENV_ENV_ACROBOT, 6, 3, 112, LENV_ACT_LEAKYRELU, 149, 167, LENV_ACT_PRELU, 10, 500, 38 },  // 3: default_config_acrobot_syn_env.yaml
+};
+constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 
 struct InnerArgs {
     lenv_ddqn_cfg cfg;
@@ -288,7 +296,7 @@ __device__ __forceinline__ void real_env_obs(const double (&st)[4], float (&obs)
     }
 }
 
-// SHAPE 1 = the published CartPole configuration (FIX_* above): network widths, batch size, chunking and the whole LDS layout are
+// SHAPE > 0 = a published configuration (kShapes above; 1 = BASELINE configs[1]): network widths, batch size, chunking and the whole LDS layout are
 // literals, which frees the scalar registers that otherwise carry them (the generic build spills ~350 SGPR values to VGPR lanes
 // and reloads ~100 of them per learn step with v_readlane, a VALU slot each) and removes the tail code of the pair loops.
 template <int ENV, int S, int A, int QACT, int PPT, int SHAPE = 0>
@@ -296,7 +304,10 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 {
     extern __shared__ __align__(16) float lds[];
     const lenv_ddqn_cfg &cfg = a.cfg;
-    constexpr bool FIXED = SHAPE == 1;
+    constexpr bool FIXED = SHAPE != 0;
+    constexpr ShapeSpec SPEC = kShapes[SHAPE];
+    constexpr int FIX_HQ = SPEC.Hq, FIX_HSE = SPEC.Hse, FIX_B = SPEC.B, FIX_T = SPEC.T, FIX_CHUNK = SPEC.chunk, FIX_MAX_STEPS = SPEC.max_steps;
+    static_assert(!FIXED || (SPEC.env == ENV && SPEC.S == S && SPEC.A == A && SPEC.q_act == QACT), "shape table entry vs instantiation");
     constexpr InnerLayout LC = make_inner_layout(S, A, FIX_HQ, FIX_HSE, FIX_B, FIX_T, FIX_CHUNK, NT, NW, MAX_PPT, MAX_B);
     static_assert(!FIXED || LC.rc == LENV_OK, "the fixed shape must fit");
 #define LV(f) (FIXED ? LC.f : a.L.f)
@@ -435,7 +446,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 hbuf[net * HseP + j] = act_fwd_t<SEACT>(tanh_tab, tl, cfg.se_prelu, z);
             }
         };
-        if constexpr (FIXED) se_hidden(std::integral_constant<int, LENV_ACT_LEAKYRELU>{});      // the published SE: leakyrelu
+        if constexpr (FIXED) se_hidden(std::integral_constant<int, SPEC.se_act>{});             // the published SE's activation
         else switch (cfg.se_act) {
         case LENV_ACT_RELU: se_hidden(std::integral_constant<int, LENV_ACT_RELU>{}); break;
         case LENV_ACT_LEAKYRELU: se_hidden(std::integral_constant<int, LENV_ACT_LEAKYRELU>{}); break;
@@ -1086,14 +1097,22 @@ static bool cfg_disables_fixed_shape()
     return off;
 }
 
-// the shape the SHAPE 1 instantiation was compiled for
-static bool is_published_cartpole_shape(const lenv_ddqn_cfg *cfg, const InnerLayout &L)
+// index into kShapes of the published shape this launch has exactly (0 = none: generic instantiation)
+template <int I> static bool shape_matches(const lenv_ddqn_cfg *cfg, const InnerLayout &L)
 {
-    constexpr InnerLayout LC = make_inner_layout(4, 2, FIX_HQ, FIX_HSE, FIX_B, FIX_T, FIX_CHUNK, NT, NW, MAX_PPT, MAX_B);
-    return cfg->env_id == LENV_ENV_CARTPOLE && cfg->q_act == LENV_ACT_TANH && cfg->q_hidden == FIX_HQ && cfg->se_hidden == FIX_HSE &&
-           cfg->batch_size == FIX_B && cfg->test_episodes == FIX_T && cfg->max_steps == FIX_MAX_STEPS && cfg->se_act == LENV_ACT_LEAKYRELU &&
-           L.chunk == FIX_CHUNK && L.lds_floats == LC.lds_floats &&
-           L.tanh16 == LC.tanh16 && L.P_q <= NT;
+    constexpr ShapeSpec sp = kShapes[I];
+    constexpr InnerLayout LC = make_inner_layout(sp.S, sp.A, sp.Hq, sp.Hse, sp.B, sp.T, sp.chunk, NT, NW, MAX_PPT, MAX_B);
+    return cfg->env_id == sp.env && cfg->q_act == sp.q_act && cfg->q_hidden == sp.Hq && cfg->se_hidden == sp.Hse && cfg->batch_size == sp.B &&
+           cfg->test_episodes == sp.T && cfg->max_steps == sp.max_steps && cfg->se_act == sp.se_act && L.chunk == sp.chunk &&
+           L.lds_floats == LC.lds_floats && L.tanh16 == LC.tanh16 && L.P_q <= NT;
+}
+static int published_shape(const lenv_ddqn_cfg *cfg, const InnerLayout &L)
+{
+    static_assert(kNumShapes == 4, "extend the dispatch below together with kShapes");
+    if (shape_matches<1>(cfg, L)) return 1;
+    if (shape_matches<2>(cfg, L)) return 2;
+    if (shape_matches<3>(cfg, L)) return 3;
+    return 0;
 }
 
 static int inner_check(const lenv_ddqn_cfg *cfg)
@@ -1187,8 +1206,14 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
     else { LENV_PICK(LENV_ENV_ACROBOT, 6, 3) }
 #undef LENV_PICK2
 #undef LENV_PICK
-    if (is_published_cartpole_shape(cfg, a.L) && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action && !cfg_disables_fixed_shape())
-        kern = ddqn_se_inner_kernel<LENV_ENV_CARTPOLE, 4, 2, LENV_ACT_TANH, 1, 1>;
+    if (cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action && !cfg_disables_fixed_shape()) {
+        switch (published_shape(cfg, a.L)) {
+        case 1: kern = ddqn_se_inner_kernel<LENV_ENV_CARTPOLE, 4, 2, LENV_ACT_TANH, 1, 1>; break;
+        case 2: kern = ddqn_se_inner_kernel<LENV_ENV_CARTPOLE, 4, 2, LENV_ACT_RELU, 1, 2>; break;
+        case 3: kern = ddqn_se_inner_kernel<LENV_ENV_ACROBOT, 6, 3, LENV_ACT_LEAKYRELU, 2, 3>; break;
+        default: break;
+        }
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;
     if (out->status) {

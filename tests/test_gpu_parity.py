@@ -1461,6 +1461,57 @@ def test_inner_loop_with_and_without_trace_agree(eng, orc, golden, env_name, hq,
     assert float(outs[0][0][c]) == o["score"] and outs[0][1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
 
 
+@pytest.mark.parametrize("which", ["cartpole", "acrobot_syn_env"])
+def test_inner_loop_other_published_shapes_specialised_vs_generic(eng, orc, which):
+    """default_config_cartpole.yaml (Critic_DQN 4-64-2 relu, batch 32, SE hidden 128, one test episode) and
+    default_config_acrobot_syn_env.yaml (6-112-3 leakyrelu, batch 149, SE hidden 167 prelu, 500-step episodes) have their own
+    shape-specialised instantiations: outputs equal to the generic build's (a launch asking for a trace) and to the oracle's."""
+    from learning_environments_amd import configs
+    from learning_environments_amd.config import ddqn_cfg_from_config
+    cfgd = configs.cartpole_syn_env_ddqn(4)
+    if which == "cartpole":
+        cfgd["envs"]["CartPole-v0"].update(hidden_size=128)
+        cfgd["agents"]["ddqn"].update(hidden_size=64, batch_size=32, activation_fn="relu", test_episodes=1, train_episodes=12, init_episodes=1)
+        expect = (64, 128, 32, 1, 200)
+    else:
+        cfgd["env_name"] = "Acrobot-v1"
+        cfgd["envs"] = {"Acrobot-v1": {"solved_reward": -100.0, "max_steps": 500, "activation_fn": "prelu", "hidden_size": 167, "hidden_layer": 1,
+                                       "info_dim": 0, "reward_env_type": 0}}
+        cfgd["agents"]["ddqn"].update(hidden_size=112, batch_size=149, activation_fn="leakyrelu", test_episodes=10, train_episodes=3, init_episodes=1)
+        expect = (112, 167, 149, 10, 500)
+    cfg = ddqn_cfg_from_config(cfgd)
+    ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=cfg.grad_chunk, rng_mode=0)
+    assert (cfg.q_hidden, cfg.se_hidden, cfg.batch_size, cfg.test_episodes, cfg.max_steps) == expect
+    S, A, pop = cfg.state_dim, cfg.num_actions, 4
+    chains = 3 * pop
+    rng = np.random.RandomState(19)
+    se_act = "leakyrelu" if which == "cartpole" else "prelu"
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, cfg.se_hidden, 1, se_act))
+    P_q = orc.mlp_num_params(orc.mlp_desc(S, cfg.q_hidden, 1, A, cfgd["agents"]["ddqn"]["activation_fn"]))
+    theta = (rng.randn(P_se) * 0.15).astype(np.float32)
+    eps = (rng.randn(pop, P_se) * 0.02).astype(np.float32)
+    agent_init = rng.uniform(-0.3, 0.3, (chains, P_q)).astype(np.float32)
+    worker = np.repeat(np.arange(pop), 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), pop)
+    keys = np.array([orc.chain_key(79, 4, int(worker[c]), c % 3) for c in range(chains)], np.uint64)
+    outs = []
+    for trace_cap in (0, 2):
+        il = eng.InnerLoop(cfg, chains, trace_cap=trace_cap, want_final_online=True)
+        assert not il.dueling
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        outs.append([t.cpu().numpy().copy() for t in (il.score, il.stats, il.episode_test_mean, il.episode_len, il.final_returns, il.final_online)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+    c = 7
+    w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+    o = orc.ddqn_se_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]))
+    assert o["learn_steps"] > 0
+    assert float(outs[0][0][c]) == o["score"] and outs[0][1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+    assert np.array_equal(outs[0][2][c], o["episode_test_mean"], equal_nan=True) and np.array_equal(outs[0][4][c], o["final_test_returns"])
+
+
 @pytest.mark.parametrize("budget", [0, 9000])
 def test_inner_loop_specialised_vs_generic_instantiation(eng, orc, budget):
     """The published CartPole shape in its production form (early-out on, as default_config_cartpole_syn_env.yaml ships it; with and
