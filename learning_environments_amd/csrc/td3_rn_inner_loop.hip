@@ -67,21 +67,34 @@ __device__ unsigned long long g_td3_phase_cycles[16];
 #define PT_MARK(i)
 #endif
 
-template <bool ICM, int ENV>
+// SHAPE 1 = the published HalfCheetah RewardEnv + TD3 configuration (default_config_halfcheetah_reward_env.yaml = BASELINE
+// configs[4]: actor 17-128-128-6 / twin critics 23-128-128-1 relu, batch 192, policy_delay 1, reward net 17-128-1 prelu of type 2,
+// one test episode) in production form (counter RNG, no step trace, no per-chain hyper-parameters, no ICM): dimensions and mode
+// switches are literals (see the DuelingDDQN kernel for what that buys).
+struct Td3Shape { int H, L, B, T, Hrn, rn_layers, rn_act, rtype, act, policy_delay; };
+constexpr Td3Shape kTd3Shape = { 128, 2, 192, 1, 128, 1, LENV_ACT_PRELU, 2, LENV_ACT_RELU, 1 };
+
+template <bool ICM, int ENV, int SHAPE = 0>
 __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
 {
     using EnvT = ContEnv<ENV>;
+    constexpr bool FIXED = SHAPE == 1;
+    static_assert(!FIXED || (!ICM && ENV == LENV_ENV_CHEETAH_STANDIN), "the specialised instantiation: stand-in env, no ICM");
     extern __shared__ __align__(16) float lds[];
     const lenv_td3_cfg &cfg = a.cfg;
     const int tid = threadIdx.x;
     const int64_t chain = blockIdx.x;
     constexpr int S = EnvT::S, A = EnvT::A, SA = S + A, SD = EnvT::SD;   // observation / action dims, fp64 words of the env's own state
-    const bool vary = a.hp_batch != nullptr;
-    const int H = vary ? a.hp_hidden[chain] : cfg.hidden, L = vary ? a.hp_layers[chain] : cfg.layers;
-    const int B = vary ? a.hp_batch[chain] : cfg.batch_size, Bm = cfg.batch_size;      // LDS is carved for cfg's (maximal) batch
+    const bool vary = FIXED ? false : a.hp_batch != nullptr;
+    const int H = FIXED ? kTd3Shape.H : (vary ? a.hp_hidden[chain] : cfg.hidden), L = FIXED ? kTd3Shape.L : (vary ? a.hp_layers[chain] : cfg.layers);
+    const int Bm = FIXED ? kTd3Shape.B : cfg.batch_size;                               // LDS is carved for cfg's (maximal) batch
+    const int B = FIXED ? kTd3Shape.B : (vary ? a.hp_batch[chain] : cfg.batch_size);
     const double lr = vary ? a.hp_lr[chain] : cfg.lr;
-    const int T = cfg.test_episodes, Hrn = cfg.rn_hidden, RS = a.RS;
-    if (vary && (H < 1 || H > cfg.hidden || L < 1 || L > cfg.layers || B < 1 || B > cfg.batch_size)) {   // uniform per chain
+    const int T = FIXED ? kTd3Shape.T : cfg.test_episodes, Hrn = FIXED ? kTd3Shape.Hrn : cfg.rn_hidden, RS = a.RS;
+    const int rn_layers = FIXED ? kTd3Shape.rn_layers : cfg.rn_layers, rn_act = FIXED ? kTd3Shape.rn_act : cfg.rn_act;
+    const bool virtual_env = FIXED ? false : cfg.virtual_env != 0;
+    const int info_dim = cfg.info_dim, policy_delay = FIXED ? kTd3Shape.policy_delay : cfg.policy_delay;
+    if (vary && (H < 1 || H > cfg.hidden || L < 1 || L > cfg.layers || B < 1 || B > Bm)) {   // uniform per chain
         if (tid == 0) { if (a.out.status) a.out.status[chain] = -8; a.out.score[chain] = 0.0; }
         return;
     }
@@ -89,11 +102,11 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     mlp_off(mo_actor, S, H, L, A);
     mlp_off(mo_critic, SA, H, L, 1);
     MlpOff mo_se[3];                                      // VirtualEnv: state_net | reward_net | done_net on cat(action, state)
-    mlp_off(mo_se[0], SA, cfg.rn_hidden, cfg.rn_layers, S);
-    mlp_off(mo_se[1], SA, cfg.rn_hidden, cfg.rn_layers, 1);
-    mlp_off(mo_se[2], SA, cfg.rn_hidden, cfg.rn_layers, 1);
+    mlp_off(mo_se[0], SA, Hrn, rn_layers, S);
+    mlp_off(mo_se[1], SA, Hrn, rn_layers, 1);
+    mlp_off(mo_se[2], SA, Hrn, rn_layers, 1);
     const int Pa = mo_actor.P, Pc = mo_critic.P, P = Pa + 2 * Pc;
-    const int act_id = cfg.act;
+    const int act_id = FIXED ? kTd3Shape.act : cfg.act;
     const float prelu = cfg.prelu, ma = (float)cfg.max_action;
 
     // ---- LDS carve-up ----
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         const float sg = a.eps ? a.sign[chain] : 0.0f;
         const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P_rn : nullptr;
         // VirtualEnv (three nets) and reward nets with several hidden layers are too large for LDS -> arena
-        float *dst = (cfg.virtual_env || cfg.rn_layers > 1) ? arena + a.a_se : rn_w;
+        float *dst = (virtual_env || rn_layers > 1) ? arena + a.a_se : rn_w;
         for (int i = tid; i < a.P_rn; i += DNT) dst[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
     }
     for (int p = tid; p < P; p += DNT) {
@@ -150,8 +163,8 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     __syncthreads();
 
     const uint64_t key = a.rng_keys ? a.rng_keys[chain] : 0;
-    const bool tape = cfg.rng_mode == LENV_RNG_TAPE;
-    const int rtype = cfg.reward_env_type;
+    const bool tape = FIXED ? false : cfg.rng_mode == LENV_RNG_TAPE;
+    const int rtype = FIXED ? kTd3Shape.rtype : cfg.reward_env_type;
     int status = 0;
     PT_DECL;
     int64_t n_rand = 0, n_actn = 0, n_testn = 0, n_test_ep = 0, learn_it = 0;
@@ -224,13 +237,13 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     // phi = reward_net(obs [| info]) for the observation in `obs` (LDS, S floats) -> ctrl[slot].  Types 3,4,7,8 append the
     // real env's info vector to the input (reward_env.py:98-101); 101/102 are Linear(info_dim, 1, bias=False) of it.
     const bool rn_info_in = rtype == 3 || rtype == 4 || rtype == 7 || rtype == 8;
-    const int Drn = rn_info_in ? S + cfg.info_dim : S;
+    const int Drn = rn_info_in ? S + info_dim : S;
     auto rn_eval = [&](const float *obs, const float *info, int slot) {
         if (rtype == 0) { if (tid == 0) ctrl[slot] = 0.0f; __syncthreads(); return; }
         if (rtype > 100) {
             if (tid == 0) {
                 float acc = 0.0f;
-                for (int k = 0; k < cfg.info_dim; ++k) acc = fma32(info[k], rn_w[k], acc);
+                for (int k = 0; k < info_dim; ++k) acc = fma32(info[k], rn_w[k], acc);
                 ctrl[slot] = acc;
             }
             __syncthreads();
@@ -238,23 +251,23 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         }
         // build_nn_from_config (model_utils.py:16-29): Linear(D, H) | [Linear(H, H)] x (layers - 1) | Linear(H, 1), flat in
         // Module.parameters() order; one hidden layer lives in LDS, deeper nets in the arena
-        const float *rnp = cfg.rn_layers > 1 ? arena + a.a_se : rn_w;
+        const float *rnp = rn_layers > 1 ? arena + a.a_se : rn_w;
         const float *W0 = rnp, *b0 = rnp + Hrn * Drn;
         for (int j = tid; j < Hrn; j += DNT) {
             float z = 0.0f;
             for (int k = 0; k < S; ++k) z = fma32(obs[k], W0[j * Drn + k], z);
-            if (rn_info_in) for (int k = 0; k < cfg.info_dim; ++k) z = fma32(info[k], W0[j * Drn + S + k], z);
-            rn_h[j] = act_fwd(cfg.rn_act, cfg.rn_prelu, z + b0[j]);
+            if (rn_info_in) for (int k = 0; k < info_dim; ++k) z = fma32(info[k], W0[j * Drn + S + k], z);
+            rn_h[j] = act_fwd(rn_act, cfg.rn_prelu, z + b0[j]);
         }
         __syncthreads();
         const float *hp = rn_h, *Wl = b0 + Hrn;
         float *hn = rn_h2;
-        for (int l = 1; l < cfg.rn_layers; ++l) {
+        for (int l = 1; l < rn_layers; ++l) {
             const float *bl = Wl + Hrn * Hrn;
             for (int j = tid; j < Hrn; j += DNT) {
                 float z = 0.0f;
                 for (int k = 0; k < Hrn; ++k) z = fma32(hp[k], Wl[j * Hrn + k], z);
-                hn[j] = act_fwd(cfg.rn_act, cfg.rn_prelu, z + bl[j]);
+                hn[j] = act_fwd(rn_act, cfg.rn_prelu, z + bl[j]);
             }
             __syncthreads();
             const float *t2 = hp; hp = hn; hn = const_cast<float *>(t2);
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     // ends at the env's own done flag or after max_steps env steps (TimeLimit).  Thread te < Tg owns episode g0 + te's
     // bookkeeping.  With a noise TAPE and an env that can terminate the reference's draws are consumed episode by episode, so
     // the episodes run one after the other there (Tg = 1); everywhere else the noise of (episode, agent step) has a fixed index.
-    const int k_rep = cfg.same_action_num > 1 ? cfg.same_action_num : 1;
+    const int k_rep = FIXED ? 1 : (cfg.same_action_num > 1 ? cfg.same_action_num : 1);
     auto test_phase = [&]() {
         const int nag = (cfg.max_steps + k_rep - 1) / k_rep;               // agent steps of a full-length episode
         const bool serial = tape && EnvT::TERMINATES;
@@ -366,7 +379,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         __syncthreads();
         if (tid < S) state[tid] = EnvT::obs(tid, xs_d);
         __syncthreads();
-        if (!cfg.virtual_env && (rtype == 1 || rtype == 2)) rn_eval(state, nullptr, 12);   // phi(s) of the reset state (carried from step to step)
+        if (!virtual_env && (rtype == 1 || rtype == 2)) rn_eval(state, nullptr, 12);   // phi(s) of the reset state (carried from step to step)
         int ep_len = 0, env_steps = 0;
         for (int t = 0; t < cfg.max_steps; t += k_rep) {         // base_agent.py:104 range(0, max_steps, same_action_num)
             const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
@@ -394,7 +407,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 ++n_actn;
                 __syncthreads();
             }
-            if (cfg.virtual_env) {
+            if (virtual_env) {
                 // ---- EnvWrapper.step -> VirtualEnv.step (virtual_env.py:43-54): the three SE nets on cat(action, state) as queued
                 // single-row products; reward / done see the pre-transition state; the learned done flag ends the episode ----
                 // EnvWrapper.step repeats the SE step same_action_num times whatever the done flag says and sums the fp32 rewards
@@ -407,9 +420,9 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 if (tid >= 192 && tid < 192 + A) newrow[S + tid - 192] = action[tid - 192];
                 __syncthreads();
                 for (int r_ = 0; r_ < k_rep; ++r_) {
-                    mlp_forward(sep, mo_se[0], xse, SA, 1, ht, nse, S + 2, 0, false, nullptr, cfg.rn_act, cfg.rn_prelu);
-                    mlp_forward(sep + mo_se[0].P, mo_se[1], xse, SA, 1, ht, nse, S + 2, S, false, nullptr, cfg.rn_act, cfg.rn_prelu);
-                    mlp_forward(sep + mo_se[0].P + mo_se[1].P, mo_se[2], xse, SA, 1, ht, nse, S + 2, S + 1, false, nullptr, cfg.rn_act, cfg.rn_prelu);
+                    mlp_forward(sep, mo_se[0], xse, SA, 1, ht, nse, S + 2, 0, false, nullptr, rn_act, cfg.rn_prelu);
+                    mlp_forward(sep + mo_se[0].P, mo_se[1], xse, SA, 1, ht, nse, S + 2, S, false, nullptr, rn_act, cfg.rn_prelu);
+                    mlp_forward(sep + mo_se[0].P + mo_se[1].P, mo_se[2], xse, SA, 1, ht, nse, S + 2, S + 1, false, nullptr, rn_act, cfg.rn_prelu);
                     gq.run<T3_MAXI>(Ps, Qs);
                     if (tid < S) { newrow[S + A + tid] = nse[tid]; xse[A + tid] = nse[tid]; }
                     if (tid == 64) { newrow[2 * S + A] = r_ == 0 ? nse[S] : newrow[2 * S + A] + nse[S]; newrow[2 * S + A + 1] = nse[S + 1]; }
@@ -464,7 +477,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             }
             __syncthreads();
             if (tid < 2 * S + A + 2) rb[(int64_t)new_pos * RS + tid] = newrow[tid];
-            if (a.out.trace_reward && train_steps < a.out.trace_cap) {
+            if (!FIXED && a.out.trace_reward && train_steps < a.out.trace_cap) {
                 const int64_t k = chain * a.out.trace_cap + train_steps;
                 if (tid < S) { a.out.trace_state[k * S + tid] = newrow[tid]; a.out.trace_next_state[k * S + tid] = newrow[S + A + tid]; }
                 if (tid < A) a.out.trace_action[k * A + tid] = newrow[S + tid];
@@ -539,7 +552,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 adam(Pa, 2 * Pc, 0);                       // critic_optimizer: critic_1 then critic_2 parameters
                 PT_MARK(6);
                 ++learn_it;
-                if (learn_it % cfg.policy_delay == 0) {
+                if (learn_it % policy_delay == 0) {
                     // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1
                     for (int e = tid; e < B * S; e += DNT) { const int b = e / S, i = e - b * S; xa[b * SA + i] = xc[b * SA + i]; }
                     __syncthreads();
@@ -841,6 +854,16 @@ extern "C" int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg, const lenv_ch
     if (cfg->env_id == LENV_ENV_PENDULUM) kern = cfg->icm_enabled ? td3_rn_inner_kernel<true, LENV_ENV_PENDULUM> : td3_rn_inner_kernel<false, LENV_ENV_PENDULUM>;
     else if (cfg->env_id == LENV_ENV_CMC) kern = cfg->icm_enabled ? td3_rn_inner_kernel<true, LENV_ENV_CMC> : td3_rn_inner_kernel<false, LENV_ENV_CMC>;
     else kern = cfg->icm_enabled ? td3_rn_inner_kernel<true, LENV_ENV_CHEETAH_STANDIN> : td3_rn_inner_kernel<false, LENV_ENV_CHEETAH_STANDIN>;
+    {
+        // the published HalfCheetah RewardEnv + TD3 shape in production form takes the shape-specialised instantiation
+        static const bool off = [] { const char *e_ = getenv("LENV_NO_FIXED_SHAPE"); return e_ && e_[0] == '1'; }();
+        constexpr Td3Shape sp = kTd3Shape;
+        if (!off && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_reward && cfg->env_id == LENV_ENV_CHEETAH_STANDIN &&
+            !cfg->virtual_env && cfg->same_action_num <= 1 && cfg->hidden == sp.H && cfg->layers == sp.L && cfg->batch_size == sp.B &&
+            cfg->test_episodes == sp.T && cfg->rn_hidden == sp.Hrn && cfg->rn_layers == sp.rn_layers && cfg->rn_act == sp.rn_act &&
+            cfg->reward_env_type == sp.rtype && cfg->act == sp.act && cfg->policy_delay == sp.policy_delay)
+            kern = td3_rn_inner_kernel<false, LENV_ENV_CHEETAH_STANDIN, 1>;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;
     if (out->status) {

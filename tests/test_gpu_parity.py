@@ -1646,8 +1646,8 @@ def test_td3_full_size_properties(eng, orc):
     sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), pop)
     keys = np.array([orc.chain_key(78, 1, int(worker[c]), c % 3) for c in range(chains)], np.uint64)
 
-    def run(theta_, eps_, worker_, sign_, init_, keys_):
-        il = eng.Td3InnerLoop(cfg, chains)
+    def run(theta_, eps_, worker_, sign_, init_, keys_, trace_cap=0):
+        il = eng.Td3InnerLoop(cfg, chains, trace_cap=trace_cap)
         il.run(dev(theta_), dev(eps_), dev(worker_), dev(sign_), dev(init_), rng_keys=dev(keys_.view(np.int64)))
         torch.cuda.synchronize()
         assert il.status.cpu().tolist() == [0] * chains
@@ -1665,6 +1665,10 @@ def test_td3_full_size_properties(eng, orc):
         assert np.array_equal(a[perm], b, equal_nan=True)
     flipped = run(theta, -eps, worker, -sign, agent_init, keys)
     for a, b in zip(base, flipped):
+        assert np.array_equal(a, b, equal_nan=True)
+    # this shape takes the shape-specialised instantiation; a launch that asks for a step trace takes the generic one
+    generic = run(theta, eps, worker, sign, agent_init, keys, trace_cap=2)
+    for a, b in zip(base, generic):
         assert np.array_equal(a, b, equal_nan=True)
     picks = (7, 92)
     outs = _oracle_chains_parallel(
