@@ -26,6 +26,27 @@ constexpr int D_MAXH = 512;       // max hidden_size  (outputs wider than 128 ru
 constexpr int D_MAXB = 640;       // max batch size   (more than 128 rows run as several 128-row blocks)
 constexpr int D_MAXI = 128;       // rows of one product block
 
+// Arena offsets (floats) of everything whose size follows from the network / batch shapes; the replay buffer, the episode meter and
+// the ICM buffers depend on run-time sizes and are carved after these.  constexpr: literal in the SHAPE 1 instantiation.
+struct DuelArena { int64_t a_online, a_target, a_m, a_v, a_grad, a_xs, a_xs2, a_act[D_MAXL], a_feat, a_v1, a_a1, a_t[6], a_dbuf[5], end; };
+constexpr DuelArena duel_arena(int S, int H, int F, int L, int B, int T, int64_t P)
+{
+    DuelArena a{};
+    int64_t off = 0;
+#define LENV_TAKE64(n) ([&]() { int64_t r_ = off; off += ((int64_t)(n) + 3) & ~(int64_t)3; return r_; }())
+    a.a_online = LENV_TAKE64(P); a.a_target = LENV_TAKE64(P); a.a_m = LENV_TAKE64(P); a.a_v = LENV_TAKE64(P); a.a_grad = LENV_TAKE64(P);
+    const int64_t rows = B > T ? B : T;                    // minibatch rows / lock-step test episodes
+    const int W = H > F ? H : F;
+    a.a_xs = LENV_TAKE64(rows * S); a.a_xs2 = LENV_TAKE64(rows * S);
+    for (int l = 0; l < D_MAXL; ++l) a.a_act[l] = LENV_TAKE64(l < L ? (int64_t)B * H : 0);
+    a.a_feat = LENV_TAKE64((int64_t)B * F); a.a_v1 = LENV_TAKE64((int64_t)B * F); a.a_a1 = LENV_TAKE64((int64_t)B * F);
+    for (int l = 0; l < 6; ++l) a.a_t[l] = LENV_TAKE64(l < L || l >= 3 ? rows * W : 0);
+    for (int l = 0; l < 5; ++l) a.a_dbuf[l] = LENV_TAKE64(rows * W);
+#undef LENV_TAKE64
+    a.end = off;
+    return a;
+}
+
 struct DuelArgs {
     lenv_ddqn_cfg cfg;
     const float *theta, *eps; const int32_t *worker; const float *sign;
@@ -38,8 +59,8 @@ struct DuelArgs {
     // per-chain hyper-parameters (device arrays [chains], all or none): the *_vary agents (agents/DDQN_vary.py:26-59)
     const double *hp_lr; const int32_t *hp_batch, *hp_hidden, *hp_layers;
     // arena offsets (floats), sized for cfg's (maximal) shapes
-    int64_t a_online, a_target, a_m, a_v, a_grad, a_replay, a_xs, a_xs2, a_act[D_MAXL], a_feat, a_v1, a_a1,
-        a_t[6], a_dbuf[5], a_meter;
+    DuelArena A;                              // shape-determined part (see duel_arena)
+    int64_t a_replay, a_meter;                // run-time sized: carved after A.end
     // ICM agents (cfg.icm_enabled): fresh parameters per chain, optional final parameters, arena offsets of the ICM buffers
     const float *icm_init; float *icm_final; int P_icm;
     int64_t a_icm[IB_COUNT];
@@ -52,9 +73,9 @@ struct DuelOffsets {
     int P;
 };
 
-__host__ __device__ inline DuelOffsets duel_param_offsets(int S, int A, int H, int F, int L, bool plain)
+__host__ __device__ constexpr DuelOffsets duel_param_offsets(int S, int A, int H, int F, int L, bool plain)
 {
-    DuelOffsets d;
+    DuelOffsets d{};
     int o = 0, n_in = S;
     for (int l = 0; l <= D_MAXL; ++l) d.oWf[l] = d.obf[l] = 0;
     for (int l = 0; l < L; ++l) { d.oWf[l] = o; o += H * n_in; d.obf[l] = o; o += H; n_in = H; }
@@ -142,9 +163,12 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     volatile int *ictrl = reinterpret_cast<volatile int *>(misc + 32);
 
     float *arena = a.arena + chain * a.arena_stride;
-    float *online = arena + a.a_online, *target = arena + a.a_target, *adam_m = arena + a.a_m, *adam_v = arena + a.a_v;
-    float *grad = arena + a.a_grad, *rb = arena + a.a_replay, *xs = arena + a.a_xs, *xs2 = arena + a.a_xs2;
-    float *feat_s = arena + a.a_feat, *v1_s = arena + a.a_v1, *a1_s = arena + a.a_a1;
+    constexpr DuelArena AC = duel_arena(kDuelShape.S, kDuelShape.H, kDuelShape.F, kDuelShape.L, kDuelShape.B, kDuelShape.T,
+                                        duel_param_offsets(kDuelShape.S, kDuelShape.A, kDuelShape.H, kDuelShape.F, kDuelShape.L, false).P);
+#define AV(f) (FIXED ? AC.f : a.A.f)
+    float *online = arena + AV(a_online), *target = arena + AV(a_target), *adam_m = arena + AV(a_m), *adam_v = arena + AV(a_v);
+    float *grad = arena + AV(a_grad), *rb = arena + a.a_replay, *xs = arena + AV(a_xs), *xs2 = arena + AV(a_xs2);
+    float *feat_s = arena + AV(a_feat), *v1_s = arena + AV(a_v1), *a1_s = arena + AV(a_a1);
     double *meter = reinterpret_cast<double *>(arena + a.a_meter);
 
     // gtn.synthetic_env_type 1: the agent trains on a RewardEnv over the REAL env (envs/reward_env.py:61-133): the transition is
@@ -274,8 +298,8 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     };
 
     float *hid_s[D_MAXL], *hid_t[D_MAXL];
-    for (int l = 0; l < D_MAXL; ++l) { hid_s[l] = arena + a.a_act[l]; hid_t[l] = arena + a.a_t[l]; }
-    float *feat_t = arena + a.a_t[3], *v1_t = arena + a.a_t[4], *a1_t = arena + a.a_t[5];   // temporaries of non-stored passes
+    for (int l = 0; l < D_MAXL; ++l) { hid_s[l] = arena + AV(a_act[l]); hid_t[l] = arena + AV(a_t[l]); }
+    float *feat_t = arena + AV(a_t[3]), *v1_t = arena + AV(a_t[4]), *a1_t = arena + AV(a_t[5]);   // temporaries of non-stored passes
 
     // ---- real-env test phase: the T episodes advance in lock-step as one batch (weights are streamed once per step) ----
     auto test_phase = [&]() {
@@ -525,8 +549,8 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 }
                 __syncthreads();
                 PT_MARK(4);
-                float *d_a1 = arena + a.a_dbuf[0], *d_v1 = arena + a.a_dbuf[1], *d_feat = arena + a.a_dbuf[2];
-                float *dh[2] = { arena + a.a_dbuf[3], arena + a.a_dbuf[4] };
+                float *d_a1 = arena + AV(a_dbuf[0]), *d_v1 = arena + AV(a_dbuf[1]), *d_feat = arena + AV(a_dbuf[2]);
+                float *dh[2] = { arena + AV(a_dbuf[3]), arena + AV(a_dbuf[4]) };
                 // ---- heads, output layers: db = column sums; d hidden of the heads = act'(h) * sum_o dOut[o] * W2[o][k]
                 // (reduction over the few outputs).  Everything GEMM-shaped of the backward pass is queued below.
                 if (!plain && tid < A) { float s = 0.0f; for (int b = 0; b < B; ++b) s = s + dAdv[b * A + tid]; grad[po.oba2 + tid] = s; }
@@ -750,17 +774,10 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     int64_t cap = (int64_t)cfg->train_episodes * cfg->max_steps;
     if (cap > cfg->rb_size) cap = cfg->rb_size;
     a.rb_cap = cap < 1 ? 1 : cap;
-    const int W = H > F ? H : F;
-    int64_t off = 0;
+    a.A = duel_arena(S, H, F, L, B, T, a.P);
+    int64_t off = a.A.end;
     auto take = [&](int64_t n) { int64_t r = off; off += (n + 3) & ~(int64_t)3; return r; };
-    a.a_online = take(a.P); a.a_target = take(a.P); a.a_m = take(a.P); a.a_v = take(a.P); a.a_grad = take(a.P);
     a.a_replay = take(a.rb_cap * a.RS);
-    const int64_t rows = B > T ? B : T;                    // minibatch rows / lock-step test episodes
-    a.a_xs = take(rows * S); a.a_xs2 = take(rows * S);
-    for (int l = 0; l < D_MAXL; ++l) a.a_act[l] = take(l < L ? (int64_t)B * H : 0);
-    a.a_feat = take((int64_t)B * F); a.a_v1 = take((int64_t)B * F); a.a_a1 = take((int64_t)B * F);
-    for (int l = 0; l < 6; ++l) a.a_t[l] = take(l < L || l >= 3 ? rows * W : 0);
-    for (int l = 0; l < 5; ++l) a.a_dbuf[l] = take(rows * W);
     a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
     a.P_icm = 0;
     for (int i = 0; i < IB_COUNT; ++i) a.a_icm[i] = 0;
