@@ -103,8 +103,12 @@ __device__ unsigned long long g_duel_phase_cycles[16];
 // configs[2]: Critic_DuelingDQN 6-128-128 / feature 128 / 3 actions, relu, batch 128; SE hidden 128 leakyrelu; 10 test episodes) in
 // production form (counter RNG, no step trace, no per-chain hyper-parameters, no ICM): its dimensions are literals, which removes
 // a third of the scalar-register reloads and folds the orchestration arithmetic (646 -> 578 us per learn step, tools/ubench/ab_duel.sh).
-struct DuelShape { int S, A, F, H, L, B, Hse, T, q_act, se_act; };
-constexpr DuelShape kDuelShape = { 6, 3, 128, 128, 2, 128, 128, 10, LENV_ACT_RELU, LENV_ACT_LEAKYRELU };
+struct DuelShape { int env, kind, S, A, F, H, L, B, Hse, T, q_act, se_act; };        // kind 1 = DuelingDDQN, 0 = DDQN (plain mode: F = A)
+constexpr DuelShape kDuelShapes[] = {
+    { -1, 1, 4, 2, 1, 1, 1, 1, 1, 1, 0, 0 },                                                                          // 0: generic (unused entry)
+    { LENV_ENV_ACROBOT, 1, 6, 3, 128, 128, 2, 128, 128, 10, LENV_ACT_RELU, LENV_ACT_LEAKYRELU },        // 1: default_config_acrobot.yaml duelingddqn = BASELINE configs[2]
+    { LENV_ENV_MOUNTAINCAR, 0, 2, 3, 3, 256, 2, 128, 128, 10, LENV_ACT_RELU, LENV_ACT_LEAKYRELU },      // 2: default_config_mountaincar.yaml (DDQN 2-256-256-3)
+};
 
 template <bool ICM, int SHAPE = 0>
 __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
@@ -113,12 +117,13 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     const lenv_ddqn_cfg &cfg = a.cfg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t chain = blockIdx.x;
-    constexpr bool FIXED = SHAPE == 1;
-    static_assert(!(FIXED && ICM), "the specialised instantiation has no ICM");
+    constexpr bool FIXED = SHAPE != 0;
+    constexpr DuelShape kDuelShape = kDuelShapes[SHAPE];
+    static_assert(!(FIXED && ICM), "the specialised instantiations have no ICM");
     // agent_kind 1 = DuelingDDQN (Critic_DuelingDQN); agent_kind 0 = DDQN whose Critic_DQN (models/actor_critic.py:84-91:
     // build_nn_from_config(S -> A) with `hidden_layer` hidden layers) does not fit the register-resident small kernel
     // (hidden_layer >= 2, wide layers): the "feature stream" IS the Q-net then (output width A, no heads, no advantage mean).
-    const bool plain = FIXED ? false : cfg.agent_kind == 0;
+    const bool plain = FIXED ? kDuelShape.kind == 0 : cfg.agent_kind == 0;
     const int S = FIXED ? kDuelShape.S : cfg.state_dim, A = FIXED ? kDuelShape.A : cfg.num_actions, K = S + A;
     const int F = FIXED ? kDuelShape.F : (plain ? A : cfg.feature_dim);
     const int CFG_B = FIXED ? kDuelShape.B : cfg.batch_size;                     // the launch's (maximal) batch: LDS is carved for it
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
 
     float *arena = a.arena + chain * a.arena_stride;
     constexpr DuelArena AC = duel_arena(kDuelShape.S, kDuelShape.H, kDuelShape.F, kDuelShape.L, kDuelShape.B, kDuelShape.T,
-                                        duel_param_offsets(kDuelShape.S, kDuelShape.A, kDuelShape.H, kDuelShape.F, kDuelShape.L, false).P);
+                                        duel_param_offsets(kDuelShape.S, kDuelShape.A, kDuelShape.H, kDuelShape.F, kDuelShape.L, kDuelShape.kind == 0).P);
 #define AV(f) (FIXED ? AC.f : a.A.f)
     float *online = arena + AV(a_online), *target = arena + AV(a_target), *adam_m = arena + AV(a_m), *adam_v = arena + AV(a_v);
     float *grad = arena + AV(a_grad), *rb = arena + a.a_replay, *xs = arena + AV(a_xs), *xs2 = arena + AV(a_xs2);
@@ -875,12 +880,15 @@ extern "C" int lenv_dueling_se_inner_loop_icm(const lenv_ddqn_cfg *cfg, const le
     {
         // the published Acrobot DuelingDDQN shape in production form takes the shape-specialised instantiation
         static const bool off = [] { const char *e_ = getenv("LENV_NO_FIXED_SHAPE"); return e_ && e_[0] == '1'; }();
-        constexpr DuelShape sp = kDuelShape;
-        if (!off && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action && cfg->agent_kind == 1 &&
-            cfg->synthetic_env_type == 0 && cfg->env_id == LENV_ENV_ACROBOT && cfg->state_dim == sp.S && cfg->num_actions == sp.A &&
-            cfg->feature_dim == sp.F && cfg->q_hidden == sp.H && cfg->q_layers == sp.L && cfg->batch_size == sp.B && cfg->se_hidden == sp.Hse &&
-            cfg->test_episodes == sp.T && cfg->q_act == sp.q_act && cfg->se_act == sp.se_act)
-            kern = dueling_se_inner_kernel<false, 1>;
+        auto matches = [&](const DuelShape &sp) {
+            return cfg->agent_kind == sp.kind && cfg->env_id == sp.env && cfg->state_dim == sp.S && cfg->num_actions == sp.A &&
+                   (sp.kind == 0 || cfg->feature_dim == sp.F) && cfg->q_hidden == sp.H && cfg->q_layers == sp.L && cfg->batch_size == sp.B &&
+                   cfg->se_hidden == sp.Hse && cfg->test_episodes == sp.T && cfg->q_act == sp.q_act && cfg->se_act == sp.se_act;
+        };
+        if (!off && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action && cfg->synthetic_env_type == 0) {
+            if (matches(kDuelShapes[1])) kern = dueling_se_inner_kernel<false, 1>;
+            else if (matches(kDuelShapes[2])) kern = dueling_se_inner_kernel<false, 2>;
+        }
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;

@@ -1461,7 +1461,7 @@ def test_inner_loop_with_and_without_trace_agree(eng, orc, golden, env_name, hq,
     assert float(outs[0][0][c]) == o["score"] and outs[0][1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
 
 
-@pytest.mark.parametrize("which", ["cartpole", "acrobot_syn_env"])
+@pytest.mark.parametrize("which", ["cartpole", "acrobot_syn_env", "mountaincar"])
 def test_inner_loop_other_published_shapes_specialised_vs_generic(eng, orc, which):
     """default_config_cartpole.yaml (Critic_DQN 4-64-2 relu, batch 32, SE hidden 128, one test episode) and
     default_config_acrobot_syn_env.yaml (6-112-3 leakyrelu, batch 149, SE hidden 167 prelu, 500-step episodes) have their own
@@ -1473,6 +1473,11 @@ def test_inner_loop_other_published_shapes_specialised_vs_generic(eng, orc, whic
         cfgd["envs"]["CartPole-v0"].update(hidden_size=128)
         cfgd["agents"]["ddqn"].update(hidden_size=64, batch_size=32, activation_fn="relu", test_episodes=1, train_episodes=12, init_episodes=1)
         expect = (64, 128, 32, 1, 200)
+    elif which == "mountaincar":                           # default_config_mountaincar.yaml: DDQN 2-256-256-3 in the GEMM-tiled kernel
+        cfgd = configs.mountaincar_syn_env_ddqn(4)
+        cfgd["agents"]["ddqn"].update(train_episodes=3, init_episodes=1)
+        cfgd["envs"]["MountainCar-v0"]["max_steps"] = 60
+        expect = (256, 128, 128, 10, 60)
     else:
         cfgd["env_name"] = "Acrobot-v1"
         cfgd["envs"] = {"Acrobot-v1": {"solved_reward": -100.0, "max_steps": 500, "activation_fn": "prelu", "hidden_size": 167, "hidden_layer": 1,
@@ -1485,9 +1490,9 @@ def test_inner_loop_other_published_shapes_specialised_vs_generic(eng, orc, whic
     S, A, pop = cfg.state_dim, cfg.num_actions, 4
     chains = 3 * pop
     rng = np.random.RandomState(19)
-    se_act = "leakyrelu" if which == "cartpole" else "prelu"
+    se_act = "prelu" if which == "acrobot_syn_env" else "leakyrelu"
     P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, cfg.se_hidden, 1, se_act))
-    P_q = orc.mlp_num_params(orc.mlp_desc(S, cfg.q_hidden, 1, A, cfgd["agents"]["ddqn"]["activation_fn"]))
+    P_q = orc.mlp_num_params(orc.mlp_desc(S, cfg.q_hidden, cfg.q_layers, A, cfgd["agents"]["ddqn"]["activation_fn"]))
     theta = (rng.randn(P_se) * 0.15).astype(np.float32)
     eps = (rng.randn(pop, P_se) * 0.02).astype(np.float32)
     agent_init = rng.uniform(-0.3, 0.3, (chains, P_q)).astype(np.float32)
@@ -1497,7 +1502,7 @@ def test_inner_loop_other_published_shapes_specialised_vs_generic(eng, orc, whic
     outs = []
     for trace_cap in (0, 2):
         il = eng.InnerLoop(cfg, chains, trace_cap=trace_cap, want_final_online=True)
-        assert not il.dueling
+        assert il.dueling == (which == "mountaincar")
         il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
         torch.cuda.synchronize()
         assert il.status.cpu().tolist() == [0] * chains
