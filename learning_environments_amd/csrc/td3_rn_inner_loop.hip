@@ -71,15 +71,22 @@ __device__ unsigned long long g_td3_phase_cycles[16];
 // configs[4]: actor 17-128-128-6 / twin critics 23-128-128-1 relu, batch 192, policy_delay 1, reward net 17-128-1 prelu of type 2,
 // one test episode) in production form (counter RNG, no step trace, no per-chain hyper-parameters, no ICM): dimensions and mode
 // switches are literals (see the DuelingDDQN kernel for what that buys).
-struct Td3Shape { int H, L, B, T, Hrn, rn_layers, rn_act, rtype, act, policy_delay; };
-constexpr Td3Shape kTd3Shape = { 128, 2, 192, 1, 128, 1, LENV_ACT_PRELU, 2, LENV_ACT_RELU, 1 };
+struct Td3Shape { int env, H, L, B, T, Hrn, rn_layers, rn_act, rtype, act, policy_delay, virtual_env, k_rep; };
+constexpr Td3Shape kTd3Shapes[] = {
+    { -1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 0, 1 },                                                                                          // 0: generic (unused entry)
+    { LENV_ENV_CHEETAH_STANDIN, 128, 2, 192, 1, 128, 1, LENV_ACT_PRELU, 2, LENV_ACT_RELU, 1, 0, 1 },      // 1: default_config_halfcheetah_reward_env.yaml = BASELINE configs[4]
+    { LENV_ENV_PENDULUM, 128, 2, 192, 10, 128, 2, LENV_ACT_PRELU, 2, LENV_ACT_LEAKYRELU, 1, 0, 1 },       // 2: default_config_pendulum_reward_env.yaml
+    { LENV_ENV_CMC, 128, 2, 256, 1, 96, 2, LENV_ACT_LEAKYRELU, 0, LENV_ACT_RELU, 2, 1, 2 },               // 3: default_config_cmc.yaml (VirtualEnv, same_action_num 2)
+    { LENV_ENV_CMC, 128, 2, 192, 1, 128, 1, LENV_ACT_TANH, 2, LENV_ACT_LEAKYRELU, 1, 0, 2 },              // 4: default_config_cmc_reward_env.yaml
+};
 
 template <bool ICM, int ENV, int SHAPE = 0>
 __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
 {
     using EnvT = ContEnv<ENV>;
-    constexpr bool FIXED = SHAPE == 1;
-    static_assert(!FIXED || (!ICM && ENV == LENV_ENV_CHEETAH_STANDIN), "the specialised instantiation: stand-in env, no ICM");
+    constexpr bool FIXED = SHAPE != 0;
+    constexpr Td3Shape kTd3Shape = kTd3Shapes[SHAPE];
+    static_assert(!FIXED || (!ICM && ENV == kTd3Shape.env), "the specialised instantiations: their own env, no ICM");
     extern __shared__ __align__(16) float lds[];
     const lenv_td3_cfg &cfg = a.cfg;
     const int tid = threadIdx.x;
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     const double lr = vary ? a.hp_lr[chain] : cfg.lr;
     const int T = FIXED ? kTd3Shape.T : cfg.test_episodes, Hrn = FIXED ? kTd3Shape.Hrn : cfg.rn_hidden, RS = a.RS;
     const int rn_layers = FIXED ? kTd3Shape.rn_layers : cfg.rn_layers, rn_act = FIXED ? kTd3Shape.rn_act : cfg.rn_act;
-    const bool virtual_env = FIXED ? false : cfg.virtual_env != 0;
+    const bool virtual_env = FIXED ? kTd3Shape.virtual_env != 0 : cfg.virtual_env != 0;
     const int info_dim = cfg.info_dim, policy_delay = FIXED ? kTd3Shape.policy_delay : cfg.policy_delay;
     if (vary && (H < 1 || H > cfg.hidden || L < 1 || L > cfg.layers || B < 1 || B > Bm)) {   // uniform per chain
         if (tid == 0) { if (a.out.status) a.out.status[chain] = -8; a.out.score[chain] = 0.0; }
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     // ends at the env's own done flag or after max_steps env steps (TimeLimit).  Thread te < Tg owns episode g0 + te's
     // bookkeeping.  With a noise TAPE and an env that can terminate the reference's draws are consumed episode by episode, so
     // the episodes run one after the other there (Tg = 1); everywhere else the noise of (episode, agent step) has a fixed index.
-    const int k_rep = FIXED ? 1 : (cfg.same_action_num > 1 ? cfg.same_action_num : 1);
+    const int k_rep = FIXED ? kTd3Shape.k_rep : (cfg.same_action_num > 1 ? cfg.same_action_num : 1);
     auto test_phase = [&]() {
         const int nag = (cfg.max_steps + k_rep - 1) / k_rep;               // agent steps of a full-length episode
         const bool serial = tape && EnvT::TERMINATES;
@@ -857,12 +864,18 @@ extern "C" int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg, const lenv_ch
     {
         // the published HalfCheetah RewardEnv + TD3 shape in production form takes the shape-specialised instantiation
         static const bool off = [] { const char *e_ = getenv("LENV_NO_FIXED_SHAPE"); return e_ && e_[0] == '1'; }();
-        constexpr Td3Shape sp = kTd3Shape;
-        if (!off && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_reward && cfg->env_id == LENV_ENV_CHEETAH_STANDIN &&
-            !cfg->virtual_env && cfg->same_action_num <= 1 && cfg->hidden == sp.H && cfg->layers == sp.L && cfg->batch_size == sp.B &&
-            cfg->test_episodes == sp.T && cfg->rn_hidden == sp.Hrn && cfg->rn_layers == sp.rn_layers && cfg->rn_act == sp.rn_act &&
-            cfg->reward_env_type == sp.rtype && cfg->act == sp.act && cfg->policy_delay == sp.policy_delay)
-            kern = td3_rn_inner_kernel<false, LENV_ENV_CHEETAH_STANDIN, 1>;
+        auto matches = [&](const Td3Shape &sp) {
+            return cfg->env_id == sp.env && (cfg->virtual_env != 0) == (sp.virtual_env != 0) && (cfg->same_action_num > 1 ? cfg->same_action_num : 1) == sp.k_rep &&
+                   cfg->hidden == sp.H && cfg->layers == sp.L && cfg->batch_size == sp.B && cfg->test_episodes == sp.T && cfg->rn_hidden == sp.Hrn &&
+                   cfg->rn_layers == sp.rn_layers && cfg->rn_act == sp.rn_act && cfg->reward_env_type == sp.rtype && cfg->act == sp.act &&
+                   cfg->policy_delay == sp.policy_delay;
+        };
+        if (!off && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_reward) {
+            if (matches(kTd3Shapes[1])) kern = td3_rn_inner_kernel<false, LENV_ENV_CHEETAH_STANDIN, 1>;
+            else if (matches(kTd3Shapes[2])) kern = td3_rn_inner_kernel<false, LENV_ENV_PENDULUM, 2>;
+            else if (matches(kTd3Shapes[3])) kern = td3_rn_inner_kernel<false, LENV_ENV_CMC, 3>;
+            else if (matches(kTd3Shapes[4])) kern = td3_rn_inner_kernel<false, LENV_ENV_CMC, 4>;
+        }
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;
