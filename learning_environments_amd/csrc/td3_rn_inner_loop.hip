@@ -197,6 +197,35 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         else gq.gemm(in, ldin, 1, W, n_in, 1, I, mo.out, n_in, epi_bias(out, ldo, ocol, bb));
     };
 
+    // ---- the actor on ONE row (the training step's action, a single test episode): thread j owns output j of a layer and runs
+    // the same k-ascending fmaf chain the MFMA product runs (then + bias, activation; tanh * max_action at the end), so the
+    // result is bit-identical to mlp_forward(..., I = 1, ...) at a fraction of a queued product's fixed cost ----
+    auto actor_row1 = [&](const float *par, const float *x, float *out) {
+        const float *in = x;
+        int n_in = S;
+        for (int l = 0; l <= L; ++l) {
+            const bool last = l == L;
+            const int n_out = last ? A : H;
+            const float *W = par + mo_actor.oW[l], *bb = par + mo_actor.ob[l];
+            float *h = last ? out : ht[l];
+            for (int j = tid; j < n_out; j += DNT) {
+                const float *w = W + (int64_t)j * n_in;
+                float z = 0.0f;
+                if ((n_in & 3) == 0) {
+                    for (int k = 0; k < n_in; k += 4) {
+                        const float4 wv = *reinterpret_cast<const float4 *>(w + k);
+                        const float4 xv = *reinterpret_cast<const float4 *>(in + k);
+                        z = fma32(xv.x, wv.x, z); z = fma32(xv.y, wv.y, z); z = fma32(xv.z, wv.z, z); z = fma32(xv.w, wv.w, z);
+                    }
+                } else for (int k = 0; k < n_in; ++k) z = fma32(in[k], w[k], z);
+                z = z + bb[j];
+                h[j] = last ? det_tanhf(lenv_tanh_table, z) * ma : act_fwd(act_id, prelu, z);
+            }
+            __syncthreads();
+            in = h; n_in = H;
+        }
+    };
+
     // ---- generic MLP backward: dOut [I][out] -> parameter gradients gpar (may be null) and input gradient dX (may be null);
     // queued like the forward.  The output-layer bias gradient (a handful of columns of an LDS vector) is done in place.
     auto mlp_backward = [&](const float *par, const MlpOff &mo, const float *X, int ldx, int I, float *const *hid, const float *dOut,
@@ -320,8 +349,11 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             for (; ai < nag; ++ai) {
                 for (int e = tid; e < Tg * S; e += DNT) { const int te = e / S; xt[e] = EnvT::obs(e - te * S, xt_d + te * SD); }
                 __syncthreads();
-                mlp_forward(params, mo_actor, xt, S, Tg, ht, at, A, 0, true, nullptr);
-                gq.run<T3_MAXI>(Ps, Qs);
+                if (Tg == 1) actor_row1(params, xt, at);
+                else {
+                    mlp_forward(params, mo_actor, xt, S, Tg, ht, at, A, 0, true, nullptr);
+                    gq.run<T3_MAXI>(Ps, Qs);
+                }
                 // select_test_action (TD3.py:126-129): (actor(s) + randn(A)*action_std*max_action).clamp(-max, max)
                 for (int e = tid; e < Tg * A; e += DNT) {
                     const int te = e / A, k = e - te * A;
@@ -402,8 +434,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 ++n_rand;
                 __syncthreads();
             } else {
-                mlp_forward(params, mo_actor, state, S, 1, ht, action, A, 0, true, nullptr);
-                gq.run<T3_MAXI>(Ps, Qs);
+                actor_row1(params, state, action);
                 if (tid < A) {
                     float zn;
                     if (tape) { if (n_actn >= a.tapes.act_noise_stride) { status = -7; zn = 0.0f; } else zn = a.tapes.act_noise[(chain * a.tapes.act_noise_stride + n_actn) * A + tid]; }
