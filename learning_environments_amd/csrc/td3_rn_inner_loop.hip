@@ -200,14 +200,14 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     // ---- the actor on ONE row (the training step's action, a single test episode): thread j owns output j of a layer and runs
     // the same k-ascending fmaf chain the MFMA product runs (then + bias, activation; tanh * max_action at the end), so the
     // result is bit-identical to mlp_forward(..., I = 1, ...) at a fraction of a queued product's fixed cost ----
-    auto actor_row1 = [&](const float *par, const float *x, float *out) {
+    auto mlp_row1 = [&](const float *par, const MlpOff &mo, const float *x, float *out, int ocol, bool final_tanh, int act, float pr) {
         const float *in = x;
-        int n_in = S;
-        for (int l = 0; l <= L; ++l) {
-            const bool last = l == L;
-            const int n_out = last ? A : H;
-            const float *W = par + mo_actor.oW[l], *bb = par + mo_actor.ob[l];
-            float *h = last ? out : ht[l];
+        int n_in = mo.in;
+        for (int l = 0; l <= mo.L; ++l) {
+            const bool last = l == mo.L;
+            const int n_out = last ? mo.out : mo.H;
+            const float *W = par + mo.oW[l], *bb = par + mo.ob[l];
+            float *h = last ? out + ocol : ht[l];
             for (int j = tid; j < n_out; j += DNT) {
                 const float *w = W + (int64_t)j * n_in;
                 float z = 0.0f;
@@ -219,12 +219,13 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     }
                 } else for (int k = 0; k < n_in; ++k) z = fma32(in[k], w[k], z);
                 z = z + bb[j];
-                h[j] = last ? det_tanhf(lenv_tanh_table, z) * ma : act_fwd(act_id, prelu, z);
+                h[j] = last ? (final_tanh ? det_tanhf(lenv_tanh_table, z) * ma : z) : act_fwd(act, pr, z);
             }
             __syncthreads();
-            in = h; n_in = H;
+            in = h; n_in = mo.H;
         }
     };
+    auto actor_row1 = [&](const float *par, const float *x, float *out) { mlp_row1(par, mo_actor, x, out, 0, true, act_id, prelu); };
 
     // ---- generic MLP backward: dOut [I][out] -> parameter gradients gpar (may be null) and input gradient dX (may be null);
     // queued like the forward.  The output-layer bias gradient (a handful of columns of an LDS vector) is done in place.
@@ -458,10 +459,9 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 if (tid >= 192 && tid < 192 + A) newrow[S + tid - 192] = action[tid - 192];
                 __syncthreads();
                 for (int r_ = 0; r_ < k_rep; ++r_) {
-                    mlp_forward(sep, mo_se[0], xse, SA, 1, ht, nse, S + 2, 0, false, nullptr, rn_act, cfg.rn_prelu);
-                    mlp_forward(sep + mo_se[0].P, mo_se[1], xse, SA, 1, ht, nse, S + 2, S, false, nullptr, rn_act, cfg.rn_prelu);
-                    mlp_forward(sep + mo_se[0].P + mo_se[1].P, mo_se[2], xse, SA, 1, ht, nse, S + 2, S + 1, false, nullptr, rn_act, cfg.rn_prelu);
-                    gq.run<T3_MAXI>(Ps, Qs);
+                    mlp_row1(sep, mo_se[0], xse, nse, 0, false, rn_act, cfg.rn_prelu);
+                    mlp_row1(sep + mo_se[0].P, mo_se[1], xse, nse, S, false, rn_act, cfg.rn_prelu);
+                    mlp_row1(sep + mo_se[0].P + mo_se[1].P, mo_se[2], xse, nse, S + 1, false, rn_act, cfg.rn_prelu);
                     if (tid < S) { newrow[S + A + tid] = nse[tid]; xse[A + tid] = nse[tid]; }
                     if (tid == 64) { newrow[2 * S + A] = r_ == 0 ? nse[S] : newrow[2 * S + A] + nse[S]; newrow[2 * S + A + 1] = nse[S + 1]; }
                     if (r_ + 1 < k_rep) __syncthreads();
