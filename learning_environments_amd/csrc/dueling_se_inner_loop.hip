@@ -178,7 +178,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
 
     // gtn.synthetic_env_type 1: the agent trains on a RewardEnv over the REAL env (envs/reward_env.py:61-133): the transition is
     // the real one, the reward goes through the perturbed reward network (state_dim -> se_hidden -> 1; reward types 0,1,2,5,6)
-    const bool reward_env = cfg.synthetic_env_type == 1;
+    const bool reward_env = FIXED ? false : cfg.synthetic_env_type == 1;      // the specialised shapes are VirtualEnv configurations
     const int rtype = cfg.reward_env_type;
     const int Drn = rtype == 0 ? 1 : S;                   // RewardEnv.build_reward_net: a 1-input dummy net for type 0
     float *rn_w = se_w0T, *rn_h = se_h;                   // RewardEnv: flat reward-net parameters / its hidden layer (LDS)
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
 
     const uint64_t key = a.rng_keys ? a.rng_keys[chain] : 0;
     const bool tape = FIXED ? false : cfg.rng_mode == LENV_RNG_TAPE;
-    const int env_id = cfg.env_id;
+    const int env_id = FIXED ? kDuelShape.env : cfg.env_id;
     int status = 0;
     PT_DECL;
     int train_steps = 0, n_act = 0, learn_it = 0, n_test_ep = 0, test_steps = 0, episodes_run = 0;
