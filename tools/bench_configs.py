@@ -68,6 +68,9 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["2", "3", "4", "5"]
     if "2" in which:
         run("cfg2 CartPole SE + DDQN pop 64 (20 episodes)", configs.fixed_work(configs.cartpole_syn_env_ddqn(64), 20))
+    if "2full" in which:
+        # every CU busy: 85 workers = 255 chains on 256 CUs (BASELINE's metric is quoted at pop 64 = 192 chains)
+        run("cfg2 CartPole SE + DDQN pop 85 = 255 chains (20 episodes)", configs.fixed_work(configs.cartpole_syn_env_ddqn(85), 20))
     if "4" in which:
         c = configs.cliff_reward_env_ql(128)
         c["agents"]["gtn"]["quit_when_solved"] = False

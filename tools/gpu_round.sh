@@ -16,6 +16,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- py
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_$c.log 2>&1
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_configs -- python3 $R/tools/bench_configs.py 2 3 4 5 3full 5full > $R/gpurun_out/bench_configs.jsonl 2> $R/gpurun_out/prof_configs.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_configs -- python3 $R/tools/bench_configs.py 2 2full 3 4 5 3full 5full > $R/gpurun_out/bench_configs.jsonl 2> $R/gpurun_out/prof_configs.log
 cd $R
 python3 tools/summarize_profiles.py $TAG
