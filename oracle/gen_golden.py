@@ -1044,7 +1044,12 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over
 
 
 def main():
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x"]
+    # no arguments (or "all"): every fixture under tests/golden is regenerated (the full-shape runs g8df / g8tf take minutes each)
+    ALL = ["g1", "g1ln", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x",
+           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8df", "g8l2", "g8m", "g8r", "g8i", "g8v"]
+    which = sys.argv[1:] or ALL
+    if "all" in which:
+        which = ALL
     os.makedirs(OUT, exist_ok=True)
     if "g1" in which:
         gen_g1()
