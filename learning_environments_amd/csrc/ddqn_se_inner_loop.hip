@@ -1036,11 +1036,6 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 
 using namespace lenv;
 
-static inline int64_t mlp_params(int in, int H, int L, int out)
-{
-    return (int64_t)in * H + H + (int64_t)(L - 1) * ((int64_t)H * H + H) + (int64_t)H * out + out;
-}
-
 static int64_t inner_rb_cap(const lenv_ddqn_cfg *cfg)
 {
     int64_t cap = (int64_t)cfg->train_episodes * cfg->max_steps;
