@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LENV_ABI_VERSION 2
+#define LENV_ABI_VERSION 3
 
 enum {
     LENV_OK = 0,
@@ -149,7 +149,8 @@ int lenv_qnet_td_forward(const lenv_mlp_desc *qnet /*HOST*/, const float *online
  * chains, one workgroup per chain: fresh DDQN agent (agent_init [chains,P_agent]), BaseAgent.train on the
  * perturbed SE with per-episode real-env tests and early-out (agents/base_agent.py:64-153), final
  * BaseAgent.test (agents/base_agent.py:155-227).  rng_keys [chains] (counter mode) / tapes (tape mode).
- * The replay buffers live in `workspace` (lenv_ddqn_se_workspace_bytes).
+ * The replay buffers, the per-episode meter and the Adam bias-correction table (8 B per possible learn step, filled by a
+ * prologue kernel on `stream`) live in `workspace` (lenv_ddqn_se_workspace_bytes): the entry allocates nothing.
  */
 size_t lenv_ddqn_se_workspace_bytes(const lenv_ddqn_cfg *cfg /*HOST*/, int64_t chains);
 /* LDS bytes one chain needs for this cfg (incl. grad_chunk), or a negative LENV_ERR_* when unsupported / > 160 KiB */
@@ -427,6 +428,13 @@ int lenv_nes_draw(uint64_t seed, uint64_t generation, int64_t pop, int64_t p_the
                   int64_t chains, int32_t chains_per_worker, int64_t worker_lo, int64_t p_agent, const float *bounds,
                   float *agent_init, uint64_t *rng_keys, void *stream);
 
+/* The same with the generation read from device memory (generation_dev[0]) when the kernel runs: a captured generation
+ * (HIP graph) is replayed for generation after generation without touching its kernel arguments; lenv_nes_rank_update_keep
+ * advances the counter. */
+int lenv_nes_draw_dev(uint64_t seed, const int64_t *generation_dev, int64_t pop, int64_t p_theta, float noise_std, float *eps,
+                      int64_t chains, int32_t chains_per_worker, int64_t worker_lo, int64_t p_agent, const float *bounds,
+                      float *agent_init, uint64_t *rng_keys, void *stream);
+
 /* result[w][3] = min(status[0..n)) for w < pop: this rank's worst chain status rides in the fitness records through the
  * all-gather (replaces the second host read-back of a generation). */
 int lenv_nes_status_fold(const int32_t *status, int64_t n, double *result, int64_t pop, void *stream);
@@ -441,6 +449,14 @@ int lenv_nes_status_fold(const int32_t *status, int64_t n, double *result, int64
 int lenv_nes_rank_update(int32_t score_transform_type, const double *gathered, const double *rank_table, int64_t pop,
                          float *theta, const float *eps, int64_t p_theta, double step_size, int32_t nes_step_size,
                          double weight_decay, double *weights_out, void *stream);
+
+/* lenv_nes_rank_update for a generation that runs as ONE captured graph (draw -> fused inner loop -> worker_best -> status_fold
+ * -> rank update) with the host read-back behind it: theta_prev [P] (may be NULL) receives theta as it was before the update --
+ * what GTN_Master.save_good_model saves and what stays when the run quits on "solved" (agents/GTN_master.py:95-101,118-131:
+ * the reference decides both BEFORE update_env) -- and generation_dev[0] (may be NULL) is incremented for the next replay. */
+int lenv_nes_rank_update_keep(int32_t score_transform_type, const double *gathered, const double *rank_table, int64_t pop,
+                              float *theta, const float *eps, int64_t p_theta, double step_size, int32_t nes_step_size,
+                              double weight_decay, double *weights_out, float *theta_prev, int64_t *generation_dev, void *stream);
 
 #ifdef __cplusplus
 }

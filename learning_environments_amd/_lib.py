@@ -114,7 +114,7 @@ EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv
            "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population", "lenv_dueling_se_workspace_bytes",
            "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_dueling_se_inner_loop_hp", "lenv_dueling_agent_init_hp", "lenv_rng_unit", "lenv_td3_rn_inner_loop_hp", "lenv_td3_agent_init_hp", "lenv_icm_num_params", "lenv_dueling_se_inner_loop_icm", "lenv_chain_uniform_init", "lenv_td3_icm_num_params", "lenv_td3_rn_inner_loop_icm", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
            "lenv_td3_rn_inner_loop", "lenv_mlp_forward", "lenv_cheetah_standin_reset", "lenv_cheetah_standin_step", "lenv_cont_env_reset", "lenv_cont_env_step",
-           "lenv_rn_num_params", "lenv_rn_shape_rows", "lenv_nes_worker_best_multi", "lenv_nes_draw", "lenv_nes_status_fold"]
+           "lenv_rn_num_params", "lenv_rn_shape_rows", "lenv_nes_worker_best_multi", "lenv_nes_draw", "lenv_nes_status_fold", "lenv_nes_draw_dev", "lenv_nes_rank_update_keep"]
 
 
 def build(force=False):
@@ -224,7 +224,13 @@ def lib():
                                     C.c_int64, vp, vp, vp, vp]
         L.lenv_nes_status_fold.restype = C.c_int
         L.lenv_nes_status_fold.argtypes = [vp, C.c_int64, vp, C.c_int64, vp]
-        if L.lenv_abi_version() != 2:
+        L.lenv_nes_draw_dev.restype = C.c_int
+        L.lenv_nes_draw_dev.argtypes = [C.c_uint64, vp, C.c_int64, C.c_int64, C.c_float, vp, C.c_int64, C.c_int32, C.c_int64,
+                                        C.c_int64, vp, vp, vp, vp]
+        L.lenv_nes_rank_update_keep.restype = C.c_int
+        L.lenv_nes_rank_update_keep.argtypes = [C.c_int32, vp, vp, C.c_int64, vp, vp, C.c_int64, C.c_double, C.c_int32,
+                                                C.c_double, vp, vp, vp, vp]
+        if L.lenv_abi_version() != 3:
             raise LenvError("liblenv_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -40,7 +40,7 @@ __all__ = ["GTN_Master", "rank_table"]
 
 
 class GTN_Master(GTN_Base):
-    def __init__(self, config, bohb_id=-1, bohb_working_dir=None, engine=None, seed=0, verbose=False, transport=None):
+    def __init__(self, config, bohb_id=-1, bohb_working_dir=None, engine=None, seed=0, verbose=False, transport=None, graph=None):
         super().__init__(bohb_id)
         self.config = config
         self.device = config["device"]
@@ -132,6 +132,16 @@ class GTN_Master(GTN_Base):
         self.eps = None
         self._gathered = None
         self._local = None
+        # One HIP graph per generation (draw -> fused inner loop -> worker_best -> status_fold -> score_transform + update_env):
+        # single-process runs on the HIP engine whose task needs no host work between the kernels (the *_vary tasks draw their
+        # hyper-parameters on the host).  graph=False keeps the eager launches.
+        capable = (self.transport == "fused" and self.world == 1 and self.n_local > 0 and getattr(engine, "graph_capable", False)
+                   and not hasattr(self.task, "draw_hp"))
+        if graph and not capable:
+            raise ValueError("graph=True needs the fused transport on the HIP engine, one process, and a task without host-side draws")
+        self.use_graph = capable if graph is None else bool(graph)
+        self._graph = self._graph_gathered = self._gen_t = self._theta_prev = None
+        self._gen_next = None
 
         if bohb_working_dir:
             self.model_dir = str(os.path.join(bohb_working_dir, 'GTN_models_' + self.env_name))
@@ -177,8 +187,10 @@ class GTN_Master(GTN_Base):
         bounds = self.agent_bounds if self.task.needs_agent_init() else None
         self.eps, local_init, keys_t = self.engine.draw(self.seed, it, pop, self.p_theta, self.noise_std, cpw * self.n_local, cpw,
                                                         self.w_lo, bounds)
-        local = torch.zeros((self.w_per, 4), dtype=torch.float64, device=dev) if self._local is None else self._local.zero_()
-        self._local = local
+        # rows [n_local, w_per) are padding of an uneven split: zero from the allocation on, never written
+        if self._local is None:
+            self._local = torch.zeros((self.w_per, 4), dtype=torch.float64, device=dev)
+        local = self._local
         if self.n_local > 0:
             chain_scores = self.task.scores(self.inner, self.theta, self.eps, self.chain_worker, self.chain_sign, keys_t,
                                             local_init)
@@ -199,6 +211,8 @@ class GTN_Master(GTN_Base):
         """One NES generation (the body of the reference's run() loop, :84-106).  Returns (mean_score_orig, solved)."""
         if self.transport == "file":
             return self._step_file(it)
+        if self.use_graph:
+            return self._step_graph(it)
         t1 = time.time()
         gathered = self.evaluate_population(it)
         self._gathered = gathered
@@ -218,6 +232,60 @@ class GTN_Master(GTN_Base):
             self.print_statistics(it=it, time_elapsed=time.time() - t1)
         return mean_score, False
 
+    def _capture_generation(self):
+        """Capture one whole generation on a side stream.  Every tensor the kernels touch is allocated inside the capture (the
+        graph's private pool) or owned by self, so replays need no argument updates: the generation number lives on the device
+        (lenv_nes_draw_dev reads it, lenv_nes_rank_update_keep advances it)."""
+        dev = self.engine.device
+        self._gen_t = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._theta_prev = torch.empty_like(self.theta)
+        self._local = torch.zeros((self.w_per, 4), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(g, stream=side):
+            gathered = self.evaluate_population(self._gen_t)
+            self._weights = self.engine.rank_update(self.score_transform_type, gathered, self.rank_table, self.theta, self.eps,
+                                                    self.step_size, self.nes_step_size, self.weight_decay,
+                                                    theta_prev=self._theta_prev, generation=self._gen_t)
+        self._graph, self._graph_gathered, self._gen_next = g, gathered, 0
+
+    def _step_graph(self, it):
+        """step() as one graph replay + the generation's single host read-back.  The reference decides save_good_model and
+        quit_when_solved BEFORE update_env (agents/GTN_master.py:95-101); here the update has already run when the scores reach the
+        host, so the pre-update theta the graph kept (theta_prev) is swapped back in for the save / the early return."""
+        t1 = time.time()
+        if self._graph is None:
+            self._capture_generation()
+        if self._gen_next != it:
+            self._gen_t.fill_(int(it))
+        self._graph.replay()
+        self._gen_next = it + 1
+        gathered = self._gathered = self._graph_gathered
+        host = gathered.cpu().numpy()               # the generation's only host sync
+        if host[:, 3].min() != 0:
+            raise RuntimeError("inner loop reported status %d on worker(s) %s (tape underrun / invalid replay index)"
+                               % (int(host[:, 3].min()), np.nonzero(host[:, 3])[0].tolist()))
+        self.score_list = host[:, 0].tolist()
+        self.score_orig_list = host[:, 1].tolist()
+        self.time_elapsed_list = [time.time() - t1] * self.num_workers
+        mean_score = np.mean(self.score_orig_list)
+        save, solved = self._save_decision(mean_score)
+        if save:
+            updated = self.theta.clone()
+            self.theta.copy_(self._theta_prev)
+            self._theta_changed()
+            self.save_good_model(mean_score)
+            if solved and self.quit_when_solved:
+                return mean_score, True             # theta stays as it was before this generation's update, like the reference
+            self.theta.copy_(updated)
+        self.score_transform_list = None
+        self._theta_changed()
+        if self.verbose and self.rank == 0:
+            self.print_statistics(it=it, time_elapsed=time.time() - t1)
+        return mean_score, False
+
     def run(self):
         mean_score_orig_list = []
         for it in range(self.max_iterations):
@@ -229,18 +297,20 @@ class GTN_Master(GTN_Base):
             return np.mean(self.score_orig_list), mean_score_orig_list, self.model_name
         return 1e9, mean_score_orig_list, self.model_name
 
-    def save_good_model(self, mean_score):
-        # reference :118-131
+    def _save_decision(self, mean_score):
+        """(save the model?, counts as solved?) -- the two conditions of reference :118-131."""
+        better = mean_score > self.best_score
         if self.synthetic_env_orig.is_virtual_env():
-            if mean_score > self.real_env.get_solved_reward() and mean_score > self.best_score:
-                self.save_model()
-                self.best_score = mean_score
-                return True
-        else:
-            if mean_score > self.best_score:
-                self.save_model()
-                self.best_score = mean_score
-        return False
+            hit = bool(better and mean_score > self.real_env.get_solved_reward())
+            return hit, hit
+        return bool(better), False
+
+    def save_good_model(self, mean_score):
+        save, solved = self._save_decision(mean_score)
+        if save:
+            self.save_model()
+            self.best_score = mean_score
+        return solved
 
     def save_model(self):
         # reference :133-139 -- {'model': state_dict, 'config': config}

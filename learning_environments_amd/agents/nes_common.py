@@ -20,7 +20,8 @@ def chain_keys(seed, generation, workers, kinds):
     with np.errstate(over="ignore"):
         k = _mix64(np.full(len(workers), seed, np.uint64) + _G)
         k = _mix64(k ^ (np.uint64(generation) + _G * np.uint64(2)))
-        k = _mix64(k ^ (np.asarray(workers, np.uint64) * np.uint64(4) + np.asarray(kinds, np.uint64) + _G * np.uint64(3)))
+        k = _mix64(k ^ (np.asarray(workers, np.uint64) + _G * np.uint64(3)))
+        k = _mix64(k ^ (np.asarray(kinds, np.uint64) + _G * np.uint64(4)))
     return k
 
 

@@ -1045,37 +1045,39 @@ static int64_t inner_rb_cap(const lenv_ddqn_cfg *cfg)
 
 static int inner_row_stride(const lenv_ddqn_cfg *cfg) { return (2 * cfg->state_dim + 3 + 3) & ~3; }
 
-// Adam bias-correction schedule (see InnerArgs::adam_sched), cached per (device, lr, beta1, beta2, length): the bench and
-// the NES loop launch the same configuration every generation, so this is computed and uploaded once.
-#include <mutex>
-#include <vector>
-namespace {
-struct SchedEntry { int dev; double lr, b1, b2; int64_t n; float2 *dptr; };
-std::mutex g_sched_mu;
-std::vector<SchedEntry> g_sched;
-}
-static const float2 *adam_schedule(const lenv_ddqn_cfg *cfg, int64_t n)
+// Adam bias-correction schedule (see InnerArgs::adam_sched): entry t = { -(lr / (1 - beta1^(t+1))), sqrt(1 - beta2^(t+1)) } with the
+// powers as the running double products torch keeps (oracle: ddqn_learn).  The table lives in the CALLER's workspace and is
+// filled on the caller's stream by this prologue kernel (include/lenv_hip.h: an entry never allocates, never synchronises and
+// keeps no global state -- the launch is graph-capturable on its first call).  Two lanes carry the two serial product chains
+// 256 entries at a time; the conversions (IEEE double divide / sqrt) run one entry per thread.
+__global__ __launch_bounds__(256) void adam_schedule_kernel(double lr, double beta1, double beta2, int64_t n, float2 *sched, int32_t *status, int64_t chains)
 {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(g_sched_mu);
-    for (const SchedEntry &e : g_sched)
-        if (e.dev == dev && e.lr == cfg->lr && e.b1 == cfg->adam_beta1 && e.b2 == cfg->adam_beta2 && e.n >= n) return e.dptr;
-    std::vector<float2> h((size_t)n);
-    double b1pow = 1.0, b2pow = 1.0;
-    for (int64_t t = 0; t < n; ++t) {
-        b1pow *= cfg->adam_beta1;
-        b2pow *= cfg->adam_beta2;
-        h[(size_t)t].x = (float)(-(cfg->lr / (1.0 - b1pow)));
-        h[(size_t)t].y = (float)__builtin_sqrt(1.0 - b2pow);
+    if (status) for (int64_t c = threadIdx.x; c < chains; c += 256) status[c] = 0;      // the chains' status words start at 0 (ok)
+    __shared__ double pw[2][256];
+    __shared__ double carry[2];
+    const int tid = threadIdx.x;
+    if (tid < 2) carry[tid] = 1.0;
+    __syncthreads();
+    for (int64_t t0 = 0; t0 < n; t0 += 256) {
+        if (tid == 0 || tid == 64) {
+            const int c = tid >> 6;
+            const double beta = c ? beta2 : beta1;
+            double p = carry[c];
+            const int m = n - t0 < 256 ? (int)(n - t0) : 256;
+            for (int i = 0; i < m; ++i) { p *= beta; pw[c][i] = p; }
+            carry[c] = p;
+        }
+        __syncthreads();
+        if (t0 + tid < n) {
+            float2 e;
+            e.x = (float)(-(lr / (1.0 - pw[0][tid])));
+            e.y = (float)__builtin_sqrt(1.0 - pw[1][tid]);
+            sched[t0 + tid] = e;
+        }
+        __syncthreads();
     }
-    float2 *d = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&d), sizeof(float2) * (size_t)n) != hipSuccess) return nullptr;
-    if (hipMemcpy(d, h.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
-    if (g_sched.size() >= 16) { (void)hipFree(g_sched.front().dptr); g_sched.erase(g_sched.begin()); }
-    g_sched.push_back(SchedEntry{dev, cfg->lr, cfg->adam_beta1, cfg->adam_beta2, n, d});
-    return d;
 }
+static int64_t adam_schedule_len(const lenv_ddqn_cfg *cfg) { return (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 0) * cfg->max_steps + 1; }
 
 // LDS carve-up of one chain's workgroup; returns LENV_ERR_UNSUPPORTED when the shapes do not fit 160 KiB
 static int inner_layout(const lenv_ddqn_cfg *cfg, InnerArgs &a)
@@ -1150,7 +1152,8 @@ extern "C" size_t lenv_ddqn_se_workspace_bytes(const lenv_ddqn_cfg *cfg, int64_t
     if (!cfg || chains < 0) return 0;
     size_t replay = (size_t)chains * inner_rb_cap(cfg) * inner_row_stride(cfg) * sizeof(float);
     size_t meter = (size_t)chains * (cfg->train_episodes > 0 ? cfg->train_episodes : 1) * sizeof(double);
-    return ((replay + 255) & ~(size_t)255) + meter + 256;
+    size_t sched = (size_t)adam_schedule_len(cfg) * sizeof(float2);
+    return ((replay + 255) & ~(size_t)255) + ((meter + 255) & ~(size_t)255) + sched + 256;
 }
 
 extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *theta, const float *eps,
@@ -1184,8 +1187,9 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
     a.f_gamma = (float)cfg->gamma; a.f_norm = (float)(2.0 / (double)cfg->batch_size);
     a.f_w1 = (float)(1.0 - cfg->adam_beta1); a.f_w2 = (float)(1.0 - cfg->adam_beta2); a.f_beta2 = (float)cfg->adam_beta2;
     a.f_adam_eps = (float)cfg->adam_eps; a.f_tau = (float)cfg->tau; a.f_omt = (float)(1.0 - cfg->tau);
-    a.adam_sched = adam_schedule(cfg, (int64_t)cfg->train_episodes * cfg->max_steps + 1);
-    if (!a.adam_sched) return LENV_ERR_LAUNCH;
+    const size_t meter_bytes = ((size_t)chains * (cfg->train_episodes > 0 ? cfg->train_episodes : 1) * sizeof(double) + 255) & ~(size_t)255;
+    float2 *sched = reinterpret_cast<float2 *>(static_cast<char *>(workspace) + replay_bytes + meter_bytes);
+    a.adam_sched = sched;
 
     void (*kern)(const InnerArgs) = nullptr;
 #define LENV_PICK2(ENVID, SS, AA, PP)                                                                              \
@@ -1211,10 +1215,8 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;
-    if (out->status) {
-        e = hipMemsetAsync(out->status, 0, sizeof(int32_t) * chains, static_cast<hipStream_t>(stream));
-        if (e != hipSuccess) return LENV_ERR_LAUNCH;
-    }
+    hipLaunchKernelGGL(adam_schedule_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), cfg->lr, cfg->adam_beta1, cfg->adam_beta2,
+                       adam_schedule_len(cfg), sched, out->status, chains);
     hipLaunchKernelGGL(kern, dim3((unsigned)chains), dim3(NT), lds_bytes, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }

@@ -27,6 +27,7 @@ extern "C" uint64_t lenv_chain_key(uint64_t seed, uint64_t generation, uint64_t 
 {
     uint64_t k = lenv::mix64(seed + 0x9e3779b97f4a7c15ULL);
     k = lenv::mix64(k ^ (generation + 0x9e3779b97f4a7c15ULL * 2));
-    k = lenv::mix64(k ^ (worker * 4 + kind + 0x9e3779b97f4a7c15ULL * 3));
+    k = lenv::mix64(k ^ (worker + 0x9e3779b97f4a7c15ULL * 3));
+    k = lenv::mix64(k ^ (kind + 0x9e3779b97f4a7c15ULL * 4));     // own round: (worker, kind) never collides with (worker + 1, kind - 4)
     return k;
 }

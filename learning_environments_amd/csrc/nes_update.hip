@@ -142,10 +142,12 @@ __global__ __launch_bounds__(RT_NT) void score_transform_kernel(int type, const 
 }
 
 __global__ void update_env_kernel(float *theta, const float *eps, const double *gathered, const double *weights, int64_t pop,
-                                  int64_t P, double ss, float decay)
+                                  int64_t P, double ss, float decay, float *theta_prev, int64_t *generation)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && generation) generation[0] += 1;                 // captured generations: the next replay draws generation + 1
     if (i >= P) return;
+    if (theta_prev) theta_prev[i] = theta[i];                     // the master saves / keeps the pre-update theta (GTN_master.py:95-101)
     float t = theta[i] * decay;                                   // weight decay, GTN_master.py:281-286
     for (int64_t w = 0; w < pop; ++w) {
         const float c = (float)(ss * weights[w]);                 // (ss * score_transform) * eps
@@ -168,14 +170,16 @@ __device__ __host__ __forceinline__ uint64_t chain_key_dev(uint64_t seed, uint64
 {
     uint64_t k = mix64(seed + 0x9e3779b97f4a7c15ULL);
     k = mix64(k ^ (generation + 0x9e3779b97f4a7c15ULL * 2));
-    k = mix64(k ^ (worker * 4 + kind + 0x9e3779b97f4a7c15ULL * 3));
+    k = mix64(k ^ (worker + 0x9e3779b97f4a7c15ULL * 3));
+    k = mix64(k ^ (kind + 0x9e3779b97f4a7c15ULL * 4));
     return k;
 }
 
-__global__ void nes_draw_kernel(uint64_t seed, uint64_t generation, int64_t pop, int64_t P, float noise_std, float *eps,
+__global__ void nes_draw_kernel(uint64_t seed, uint64_t generation, const int64_t *generation_dev, int64_t pop, int64_t P, float noise_std, float *eps,
                                 int64_t chains, int64_t cpw, int64_t worker_lo, int64_t p_agent, const float *bounds, float *agent_init,
                                 uint64_t *rng_keys)
 {
+    if (generation_dev) generation = (uint64_t)generation_dev[0];      // device-resident counter (graph replays)
     const int64_t n_eps = eps ? pop * P : 0, n_init = agent_init ? chains * p_agent : 0, n_keys = rng_keys ? chains : 0;
     const int64_t total = n_eps + n_init + n_keys;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -222,18 +226,35 @@ __global__ void status_fold_kernel(const int32_t *status, int64_t n, double *res
 
 using namespace lenv;
 
-extern "C" int lenv_nes_draw(uint64_t seed, uint64_t generation, int64_t pop, int64_t p_theta, float noise_std, float *eps,
-                             int64_t chains, int32_t chains_per_worker, int64_t worker_lo, int64_t p_agent, const float *bounds,
-                             float *agent_init, uint64_t *rng_keys, void *stream)
+static int nes_draw_launch(uint64_t seed, uint64_t generation, const int64_t *generation_dev, int64_t pop, int64_t p_theta, float noise_std, float *eps,
+                           int64_t chains, int32_t chains_per_worker, int64_t worker_lo, int64_t p_agent, const float *bounds,
+                           float *agent_init, uint64_t *rng_keys, void *stream)
 {
     if (pop < 0 || chains < 0 || chains_per_worker < 1 || (eps && p_theta < 1)) return LENV_ERR_INVALID;
     if (agent_init && (!bounds || p_agent < 1)) return LENV_ERR_INVALID;
     const int64_t total = (eps ? pop * p_theta : 0) + (agent_init ? chains * p_agent : 0) + (rng_keys ? chains : 0);
     if (total == 0) return LENV_OK;
     const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(nes_draw_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), seed, generation, pop, p_theta,
+    hipLaunchKernelGGL(nes_draw_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), seed, generation, generation_dev, pop, p_theta,
                        noise_std, eps, chains, (int64_t)chains_per_worker, worker_lo, p_agent, bounds, agent_init, rng_keys);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}
+
+extern "C" int lenv_nes_draw(uint64_t seed, uint64_t generation, int64_t pop, int64_t p_theta, float noise_std, float *eps,
+                             int64_t chains, int32_t chains_per_worker, int64_t worker_lo, int64_t p_agent, const float *bounds,
+                             float *agent_init, uint64_t *rng_keys, void *stream)
+{
+    return nes_draw_launch(seed, generation, nullptr, pop, p_theta, noise_std, eps, chains, chains_per_worker, worker_lo, p_agent, bounds, agent_init,
+                           rng_keys, stream);
+}
+
+extern "C" int lenv_nes_draw_dev(uint64_t seed, const int64_t *generation_dev, int64_t pop, int64_t p_theta, float noise_std, float *eps,
+                                 int64_t chains, int32_t chains_per_worker, int64_t worker_lo, int64_t p_agent, const float *bounds,
+                                 float *agent_init, uint64_t *rng_keys, void *stream)
+{
+    if (!generation_dev) return LENV_ERR_INVALID;
+    return nes_draw_launch(seed, 0, generation_dev, pop, p_theta, noise_std, eps, chains, chains_per_worker, worker_lo, p_agent, bounds, agent_init,
+                           rng_keys, stream);
 }
 
 extern "C" int lenv_chain_uniform_init(const uint64_t *rng_keys, int64_t chains, uint32_t rng_stream, int64_t p, const float *bounds, float *out,
@@ -275,9 +296,9 @@ extern "C" int lenv_nes_status_fold(const int32_t *status, int64_t n, double *re
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }
 
-extern "C" int lenv_nes_rank_update(int32_t type, const double *gathered, const double *rank_table, int64_t pop, float *theta,
-                                    const float *eps, int64_t p_theta, double step_size, int32_t nes_step_size,
-                                    double weight_decay, double *weights_out, void *stream)
+static int rank_update_launch(int32_t type, const double *gathered, const double *rank_table, int64_t pop, float *theta,
+                              const float *eps, int64_t p_theta, double step_size, int32_t nes_step_size,
+                              double weight_decay, double *weights_out, float *theta_prev, int64_t *generation_dev, void *stream)
 {
     if (!gathered || !weights_out || pop < 1) return LENV_ERR_INVALID;
     if (type < 0 || type > 7) return LENV_ERR_INVALID;            // ValueError("Unknown rank transform type") GTN_master.py:263
@@ -291,8 +312,25 @@ extern "C" int lenv_nes_rank_update(int32_t type, const double *gathered, const 
         if (nes_step_size) ss = ss / (double)pop;
         const float decay = (float)(1.0 - weight_decay);
         hipLaunchKernelGGL(update_env_kernel, dim3((unsigned)((p_theta + 255) / 256)), dim3(256), 0, st, theta, eps, gathered,
-                           weights_out, pop, p_theta, ss, decay);
+                           weights_out, pop, p_theta, ss, decay, theta_prev, generation_dev);
         if (hipGetLastError() != hipSuccess) return LENV_ERR_LAUNCH;
     }
     return LENV_OK;
+}
+
+extern "C" int lenv_nes_rank_update(int32_t type, const double *gathered, const double *rank_table, int64_t pop, float *theta,
+                                    const float *eps, int64_t p_theta, double step_size, int32_t nes_step_size,
+                                    double weight_decay, double *weights_out, void *stream)
+{
+    return rank_update_launch(type, gathered, rank_table, pop, theta, eps, p_theta, step_size, nes_step_size, weight_decay, weights_out, nullptr,
+                              nullptr, stream);
+}
+
+extern "C" int lenv_nes_rank_update_keep(int32_t type, const double *gathered, const double *rank_table, int64_t pop, float *theta,
+                                         const float *eps, int64_t p_theta, double step_size, int32_t nes_step_size,
+                                         double weight_decay, double *weights_out, float *theta_prev, int64_t *generation_dev, void *stream)
+{
+    if (!theta) return LENV_ERR_INVALID;
+    return rank_update_launch(type, gathered, rank_table, pop, theta, eps, p_theta, step_size, nes_step_size, weight_decay, weights_out, theta_prev,
+                              generation_dev, stream);
 }

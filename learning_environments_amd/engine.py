@@ -451,14 +451,18 @@ def nes_worker_best(chain_scores, pop, mirrored=True, num_grad_evals=1, grad_eva
 
 
 def nes_draw(seed, generation, pop, p_theta, noise_std, chains, chains_per_worker, worker_lo, bounds, want_keys=True):
-    """(eps [pop,p_theta], agent_init [chains,p_agent] or None, rng_keys int64 [chains]) of one generation, one launch."""
+    """(eps [pop,p_theta], agent_init [chains,p_agent] or None, rng_keys int64 [chains]) of one generation, one launch.
+    `generation` may be a device int64 tensor [1] (captured generations: read when the kernel runs)."""
     dev = require_device()
     eps = torch.empty((pop, p_theta), dtype=torch.float32, device=dev)
     init = torch.empty((chains, bounds.numel()), dtype=torch.float32, device=dev) if bounds is not None and chains > 0 else None
     keys = torch.empty(chains, dtype=torch.int64, device=dev) if want_keys and chains > 0 else None
-    rc = _lib.lib().lenv_nes_draw(int(seed) & (2 ** 64 - 1), int(generation), pop, p_theta, float(noise_std), _ptr(eps), chains,
-                                  int(chains_per_worker), int(worker_lo), bounds.numel() if bounds is not None else 0,
-                                  _ptr(bounds), _ptr(init), _ptr(keys), _stream())
+    tail = (pop, p_theta, float(noise_std), _ptr(eps), chains, int(chains_per_worker), int(worker_lo),
+            bounds.numel() if bounds is not None else 0, _ptr(bounds), _ptr(init), _ptr(keys), _stream())
+    if torch.is_tensor(generation):
+        rc = _lib.lib().lenv_nes_draw_dev(int(seed) & (2 ** 64 - 1), _ptr(_chk(generation, torch.int64, "generation")), *tail)
+    else:
+        rc = _lib.lib().lenv_nes_draw(int(seed) & (2 ** 64 - 1), int(generation), *tail)
     _lib.check(rc, "lenv_nes_draw")
     return eps, init, keys
 
@@ -468,16 +472,22 @@ def nes_status_fold(status, result):
     _lib.check(rc, "lenv_nes_status_fold")
 
 
-def nes_rank_update(score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size=False, weight_decay=0.0):
-    """In-place theta update; returns the score_transform weights [pop] (float64)."""
+def nes_rank_update(score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size=False, weight_decay=0.0,
+                    theta_prev=None, generation=None):
+    """In-place theta update; returns the score_transform weights [pop] (float64).  theta_prev / generation (device tensors):
+    the captured-generation form, lenv_nes_rank_update_keep (theta_prev <- theta before the update, generation[0] += 1)."""
     dev = require_device()
     _chk(gathered, torch.float64, "gathered"); _chk(rank_table, torch.float64, "rank_table")
     _chk(theta, torch.float32, "theta"); _chk(eps, torch.float32, "eps")
     pop = gathered.shape[0]
     weights = torch.empty(pop, dtype=torch.float64, device=dev)
-    rc = _lib.lib().lenv_nes_rank_update(int(score_transform_type), _ptr(gathered), _ptr(rank_table), pop, _ptr(theta),
-                                         _ptr(eps), theta.numel() if theta is not None else 0, float(step_size),
-                                         1 if nes_step_size else 0, float(weight_decay), _ptr(weights), _stream())
+    head = (int(score_transform_type), _ptr(gathered), _ptr(rank_table), pop, _ptr(theta), _ptr(eps),
+            theta.numel() if theta is not None else 0, float(step_size), 1 if nes_step_size else 0, float(weight_decay), _ptr(weights))
+    if theta_prev is not None or generation is not None:
+        rc = _lib.lib().lenv_nes_rank_update_keep(*head, _ptr(_chk(theta_prev, torch.float32, "theta_prev")),
+                                                  _ptr(_chk(generation, torch.int64, "generation")), _stream())
+    else:
+        rc = _lib.lib().lenv_nes_rank_update(*head, _stream())
     _lib.check(rc, "lenv_nes_rank_update")
     return weights
 
@@ -522,5 +532,9 @@ class HipNesEngine(object):
     def status_fold(self, inner, result):
         nes_status_fold(inner.status, result)
 
-    def rank_update(self, score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size, weight_decay):
-        return nes_rank_update(score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size, weight_decay)
+    def rank_update(self, score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size, weight_decay,
+                    theta_prev=None, generation=None):
+        return nes_rank_update(score_transform_type, gathered, rank_table, theta, eps, step_size, nes_step_size, weight_decay,
+                               theta_prev=theta_prev, generation=generation)
+
+    graph_capable = True            # every call above only enqueues on the current stream: a generation can be captured

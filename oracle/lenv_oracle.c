@@ -152,7 +152,8 @@ uint64_t orc_chain_key(uint64_t seed, uint64_t generation, uint64_t worker, uint
 {
     uint64_t k = orc_mix64(seed + 0x9e3779b97f4a7c15ULL);
     k = orc_mix64(k ^ (generation + 0x9e3779b97f4a7c15ULL * 2));
-    k = orc_mix64(k ^ (worker * 4 + kind + 0x9e3779b97f4a7c15ULL * 3));
+    k = orc_mix64(k ^ (worker + 0x9e3779b97f4a7c15ULL * 3));
+    k = orc_mix64(k ^ (kind + 0x9e3779b97f4a7c15ULL * 4));     /* own round: distinct for every (worker, kind) */
     return k;
 }
 

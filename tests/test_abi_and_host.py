@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "liblenv_hip.so does not export " + name
     assert set(_lib.EXPORTS) <= declared
-    assert L.lenv_abi_version() == 2
+    assert L.lenv_abi_version() == 3
     assert L.lenv_error_string(-2) == b"unsupported shape or option"
 
 
@@ -50,12 +50,21 @@ def test_host_only_entry_points():
 def test_chain_keys_vectorised_matches_abi():
     from learning_environments_amd import _lib
     from learning_environments_amd.agents.nes_common import chain_keys, shard_bounds
+    from oracle import oracle as orc
     L = _lib.lib()
     w = np.repeat(np.arange(5, 9), 3)
     k = np.tile(np.arange(3), 4)
     got = chain_keys(1234, 17, w, k)
     for i in range(12):
         assert int(got[i]) == L.lenv_chain_key(1234, 17, int(w[i]), int(k[i]))
+    # every (worker, kind) of a generation has its own key, also with num_grad_evals 2 and 3 (5 / 7 chains per worker):
+    # the old key mixed worker*4 + kind, so (w, 4 + j) collided with (w + 1, j)
+    for g in (1, 2, 3):
+        cpw = 1 + 2 * g
+        ws, ks = np.repeat(np.arange(64), cpw), np.tile(np.arange(cpw), 64)
+        keys = chain_keys(7, 3, ws, ks)
+        assert len(set(keys.tolist())) == 64 * cpw
+        assert int(keys[cpw + 1]) == L.lenv_chain_key(7, 3, 1, 1) == orc.chain_key(7, 3, 1, 1)
     # sharding: contiguous blocks cover the population exactly once
     for pop, world in ((64, 8), (64, 1), (10, 4), (3, 8)):
         seen = []

@@ -839,3 +839,78 @@ def test_gtn_master_sarsa_cb_generation(tmp_path, monkeypatch):
             w = (np.float32(sg) * eps[p] + theta0).astype(np.float32)
             sc.append(orc.ql_rn_chain(ocfg, w, tables, rng_key=orc.chain_key(m.seed, 0, p, kind))["score"])
         assert gathered[p, 1] == sc[0] and gathered[p, 0] == max(sc[1], sc[2])
+
+
+def test_ddqn_inner_loop_captured_on_first_call():
+    """include/lenv_hip.h's contract (never allocate, never synchronise, graph-capturable): the FIRST call of
+    lenv_ddqn_se_inner_loop for a configuration is captured into a HIP graph on a non-default stream under the strictest capture
+    mode, and two replays reproduce an eager launch bit for bit (the Adam bias-correction table is rebuilt by a prologue kernel
+    into the caller's workspace on every launch)."""
+    from learning_environments_amd import engine
+    from learning_environments_amd.config import ddqn_cfg_from_config
+    from learning_environments_amd.configs import cartpole_syn_env_ddqn, fixed_work
+    cfgd = fixed_work(cartpole_syn_env_ddqn(num_workers=2), 3)
+    cfgd["envs"]["CartPole-v0"]["max_steps"] = 25
+    cfgd["agents"]["ddqn"]["lr"] = 1.2345e-3                 # a learning rate no other test used: nothing can be cached
+    cfg = ddqn_cfg_from_config(cfgd)
+    chains = 6
+    bounds = torch.full((401,), 0.4, device="cuda")
+    eps, init, keys = engine.nes_draw(77, 0, 2, 2247, 0.0124, chains, 3, 0, bounds)
+    theta = (torch.randn(2247, generator=torch.Generator().manual_seed(3)) * 0.1).cuda()
+    worker = torch.arange(2, dtype=torch.int32).repeat_interleave(3).cuda()
+    sign = torch.tensor([0.0, 1.0, -1.0] * 2, device="cuda")
+    torch.cuda.synchronize()
+    il = engine.InnerLoop(cfg, chains, want_final_online=True)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=side, capture_error_mode="global"):
+        il.run(theta, eps, worker, sign, init, rng_keys=keys)
+    outs = []
+    for _ in range(2):
+        il.score.fill_(-1.0); il.final_online.zero_(); il.status.fill_(7)
+        g.replay()
+        torch.cuda.synchronize()
+        outs.append((il.score.cpu().clone(), il.final_online.cpu().clone(), il.stats.cpu().clone()))
+        assert il.status.cpu().tolist() == [0] * chains
+    il2 = engine.InnerLoop(cfg, chains, want_final_online=True)
+    il2.run(theta, eps, worker, sign, init, rng_keys=keys)
+    torch.cuda.synchronize()
+    for sc, fo, st in outs:
+        assert torch.equal(sc, il2.score.cpu()) and torch.equal(fo, il2.final_online.cpu()) and torch.equal(st, il2.stats.cpu())
+    assert int(il2.stats[:, 2].min()) > 0                     # learn steps happened (the table was read)
+
+
+@pytest.mark.parametrize("which", ["ddqn", "ql"])
+def test_gtn_master_graph_generation_equals_eager(which, tmp_path, monkeypatch):
+    """A generation replayed as ONE captured graph (draw -> fused -> worker_best -> status_fold -> score_transform + update_env,
+    generation counter on the device) gives the same fitness lists and the same theta as the eager launches, generation after
+    generation, including the save-before-update semantics of reference GTN_master.py:95-101."""
+    from learning_environments_amd.agents.GTN import GTN_Master
+    from learning_environments_amd.configs import cartpole_syn_env_ddqn, cliff_reward_env_ql, fixed_work
+    monkeypatch.chdir(tmp_path)
+    if which == "ddqn":
+        cfg = fixed_work(cartpole_syn_env_ddqn(num_workers=4, max_iterations=3), 2)
+        cfg["envs"]["CartPole-v0"]["max_steps"] = 12
+        cfg["agents"]["ddqn"]["test_episodes"] = 2
+    else:
+        cfg = cliff_reward_env_ql(num_workers=6, max_iterations=3)
+        cfg["agents"]["gtn"]["quit_when_solved"] = False
+    torch.manual_seed(0)
+    a = GTN_Master(cfg, bohb_id=0, seed=9, graph=True)
+    torch.manual_seed(0)
+    b = GTN_Master(cfg, bohb_id=1, seed=9, graph=False)
+    assert a.use_graph and not b.use_graph and torch.equal(a.theta, b.theta)
+    for it in range(3):
+        ra, rb = a.step(it), b.step(it)
+        assert ra == rb
+        assert a.score_list == b.score_list and a.score_orig_list == b.score_orig_list
+        assert torch.equal(a.theta, b.theta), it
+        assert a.get_score_transform_list() == b.get_score_transform_list()
+    # a generation out of sequence (the device counter is reset) and the explicit reference-style calls still work
+    ra, rb = a.step(7), b.step(7)
+    assert ra == rb and torch.equal(a.theta, b.theta)
+    if which == "ql":             # RN runs save whenever the mean improves: the file holds the PRE-update theta on both paths
+        sa = torch.load(os.path.join(a.model_dir, os.path.basename(a.model_name)), weights_only=False)["model"]
+        sb = torch.load(os.path.join(b.model_dir, os.path.basename(b.model_name)), weights_only=False)["model"]
+        assert all(torch.equal(sa[k], sb[k]) for k in sa)
