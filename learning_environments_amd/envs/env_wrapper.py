@@ -34,22 +34,24 @@ class EnvWrapper(nn.Module):
             if self.has_discrete_state_space():
                 next_state = from_one_hot_encoding(next_state)
             return next_state, reward, done
-        else:
-            action = action.cpu().detach().numpy()
-            if self.has_discrete_action_space():
-                action = action.astype(int)[0]
-            reward_sum = 0
-            for _ in range(self.same_action_num):
-                state, reward, done, _info = self.env.step(action)
-                reward_sum += reward
-                if done:
-                    break
-            next_state_torch = torch.tensor(state, device="cpu", dtype=torch.float32)
-            reward_torch = torch.tensor(reward_sum, device="cpu", dtype=torch.float32)
-            done_torch = torch.tensor(done, device="cpu", dtype=torch.float32)
-            if next_state_torch.dim() == 0:
-                next_state_torch = next_state_torch.unsqueeze(0)
-            return next_state_torch, reward_torch, done_torch
+        return self._step_real(action)
+
+    def _step_real(self, action):
+        """Real / reward env (reference :48-70): numpy action (an int for discrete spaces), the action repeated `same_action_num`
+        times with summed rewards until the env reports done; 0-dim reward / done tensors, scalar states become 1-element
+        vectors."""
+        act = action.detach().cpu().numpy()
+        if self.has_discrete_action_space():
+            act = int(act.astype(int)[0])
+        total, obs, done = 0, None, False
+        for _ in range(self.same_action_num):
+            obs, reward, done, _ = self.env.step(act)
+            total += reward
+            if done:
+                break
+        as_f32 = lambda v: torch.tensor(v, device="cpu", dtype=torch.float32)
+        obs_t = as_f32(obs)
+        return (obs_t.unsqueeze(0) if obs_t.dim() == 0 else obs_t), as_f32(total), as_f32(done)
 
     def step_population(self, actions, states, eps=None, worker=None, sign=None):
         """Batched fast path: chain c steps the SE with weights theta + sign[c]*eps[worker[c]].
@@ -59,16 +61,16 @@ class EnvWrapper(nn.Module):
         return engine.se_step_population(self.env.descs(), self.env.flat_params(), eps, worker, sign, states, actions)
 
     def reset(self):
-        state = self.env.reset()
-        if type(state) == np.ndarray:
-            state_torch = torch.from_numpy(state).float().cpu()
-        elif torch.is_tensor(state):
-            state_torch = state.cpu()
-        else:
-            state_torch = torch.tensor([state], device="cpu", dtype=torch.float32)
-        if self.has_discrete_state_space() and self.is_virtual_env():
-            return from_one_hot_encoding(state_torch)
-        return state_torch
+        """CPU fp32 state of a fresh episode; a virtual env over a discrete observation space hands back the index."""
+        first = self.env.reset()
+        if torch.is_tensor(first):
+            out = first.cpu()
+        elif isinstance(first, np.ndarray):
+            out = torch.from_numpy(first).float().cpu()
+        else:                                          # a gridworld's integer state
+            out = torch.tensor([first], device="cpu", dtype=torch.float32)
+        discrete_virtual = self.is_virtual_env() and self.has_discrete_state_space()
+        return from_one_hot_encoding(out) if discrete_virtual else out
 
     def get_random_action(self):
         space = self.env.action_space
@@ -115,10 +117,11 @@ class EnvWrapper(nn.Module):
         return self.env.solved_reward < 1e9
 
     def seed(self, seed):
-        if not self.is_virtual_env():
-            return self.env.seed(seed)
-        print("Setting manuel seed not yet implemented, performance may decrease")
-        return 0
+        """Real envs forward the seed; a virtual env has no RNG of its own to seed (its resets come from `reset_env`)."""
+        if self.is_virtual_env():
+            print("EnvWrapper.seed: a virtual env is not seeded (its reset states come from the real env)")
+            return 0
+        return self.env.seed(seed)
 
     def is_virtual_env(self):
         return isinstance(self.env, VirtualEnv)

@@ -36,31 +36,33 @@ def calc_abs_param_sum(model):
 
 
 class AverageMeter:
-    """reference utils.py:75-105 (host-side bookkeeping; the device kernels implement `_mean` themselves)."""
+    """Running record of per-episode values with windowed means -- the behaviour of reference utils.py:75-105 (host-side
+    bookkeeping; the device kernels implement the window mean themselves).  Parity-critical detail: a window mean divides by
+    `len(window) + 1e-9`, so an empty window gives 0.0 and early-out comparisons see the slightly shrunk mean."""
 
     def __init__(self, print_str):
-        self.print_str = print_str
-        self.vals = []
-        self.it = 0
+        self.print_str, self.vals, self.it = print_str, [], 0
+
+    def _window(self, size, skip):
+        """The `size` values that precede the newest `skip` ones (fewer at the start of a run)."""
+        end = max(len(self.vals) - skip, 0)
+        return self.vals[max(end - size, 0):end]
+
+    def _mean(self, num, ignore_last):
+        win = self._window(num, ignore_last)
+        return sum(win) / (len(win) + 1e-9)
 
     def update(self, val, print_rate=10):
-        if torch.is_tensor(val):
-            val = val.item()
-        self.vals.append(val)
+        self.vals.append(val.item() if torch.is_tensor(val) else val)
         self.it += 1
         if self.it % print_rate == 0:
-            mean_val = self._mean(num=print_rate, ignore_last=0)
-            print(self.print_str + "{:15.6f} {:>25} {}".format(mean_val, "Total updates: ", self.it))
+            print(self.print_str + "{:15.6f} {:>25} {}".format(self._mean(print_rate, 0), "Total updates: ", self.it))
 
     def get_mean(self, num=10):
-        return self._mean(num, ignore_last=0)
+        return self._mean(num, 0)
 
     def get_mean_last(self, num=10):
-        return self._mean(num, ignore_last=num)
+        return self._mean(num, num)
 
     def get_raw_data(self):
         return self.vals
-
-    def _mean(self, num, ignore_last):
-        vals = self.vals[max(len(self.vals) - num - ignore_last, 0): max(len(self.vals) - ignore_last, 0)]
-        return sum(vals) / (len(vals) + 1e-9)
