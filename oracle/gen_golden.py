@@ -1043,10 +1043,65 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over
          final_params=_pack_td3(agent))
 
 
+# ------------------------------------------------------------------------------------------------
+# G11: the sync-file transport written by the REFERENCE, both directions (agents/GTN_master.py:147-195,267-298,
+# agents/GTN_worker.py:76-154): the payload files themselves are the fixture (tensors + plain dicts: data), next to the
+# values the reference's master computes from the workers' results.
+# ------------------------------------------------------------------------------------------------
+def gen_g11():
+    import shutil
+    from agents.GTN import GTN_Master, GTN_Worker
+    cfg = load_cfg("default_config_cartpole_syn_env.yaml")
+    n = 2
+    cfg["agents"]["gtn"].update(num_workers=n, max_iterations=1, mode="single", time_sleep_master=0.02, time_sleep_worker=0.02,
+                                quit_when_solved=False)
+    cfg["agents"]["ddqn"].update(train_episodes=2, test_episodes=2, init_episodes=1, print_rate=int(1e9), batch_size=16)
+    cfg["envs"]["CartPole-v0"]["max_steps"] = 12
+    # a deterministic clock (0.25 s per reading) and no sleeping: `time_elapsed` / `timeout` are part of the payloads, and the
+    # fixtures must regenerate byte for byte; everything here runs sequentially, so nothing ever has to wait for a file
+    import time as _time
+    real_time, real_sleep, ticks = _time.time, _time.sleep, [0]
+
+    def fake_time():
+        ticks[0] += 1
+        return 1.7e9 + 0.25 * ticks[0]
+    _time.time, _time.sleep = fake_time, (lambda s: None)
+    try:
+        _gen_g11_body(cfg, n, GTN_Master, GTN_Worker, shutil)
+    finally:
+        _time.time, _time.sleep = real_time, real_sleep
+
+
+def _gen_g11_body(cfg, n, GTN_Master, GTN_Worker, shutil):
+    with quiet():
+        seed_all(1100)
+        m = GTN_Master(cfg, bohb_id=-1)                      # bohb_id < 0: quit_flag on the last iteration (:163-166)
+        m.clean_working_dir()
+        workers = [GTN_Worker(id=i, bohb_id=-1) for i in range(n)]        # the constructor deletes the worker's stale sync files
+        theta0 = se_theta(m.synthetic_env_orig)
+        m.write_worker_inputs(0)
+        for i in range(n):
+            shutil.copyfile(m.get_input_file_name(i), os.path.join(OUT, "g11_ref_master_input_w%d.pt" % i))
+        for i, w in enumerate(workers):
+            seed_all(1101 + i)
+            w.run()                                          # read input -> 3 calc_score -> calc_best_score -> write result -> quit
+            shutil.copyfile(w.get_result_file_name(i), os.path.join(OUT, "g11_ref_worker_result_w%d.pt" % i))
+        m.read_worker_results()
+        eps = np.stack([se_theta(e) for e in m.eps_list])
+        m.score_transform()
+        weights = np.array(m.score_transform_list, np.float64)
+        m.update_env()
+        theta1 = se_theta(m.synthetic_env_orig)
+    save("g11_file_transport", theta0=theta0, theta1=theta1, eps=eps, weights=weights, score=np.array(m.score_list, np.float64),
+         score_orig=np.array(m.score_orig_list, np.float64), time_elapsed=np.array(m.time_elapsed_list, np.float64),
+         timeout=np.array(float(m.time_max)), step_size=np.array(cfg["agents"]["gtn"]["step_size"]),
+         score_transform_type=np.array(cfg["agents"]["gtn"]["score_transform_type"]))
+
+
 def main():
     # no arguments (or "all"): every fixture under tests/golden is regenerated (the full-shape runs g8df / g8tf take minutes each)
     ALL = ["g1", "g1ln", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x",
-           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8df", "g8l2", "g8m", "g8r", "g8i", "g8v"]
+           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8df", "g8l2", "g8m", "g8r", "g8i", "g8v", "g11"]
     which = sys.argv[1:] or ALL
     if "all" in which:
         which = ALL
@@ -1063,6 +1118,8 @@ def main():
         gen_g6()
     if "g6m" in which:
         gen_g6m()
+    if "g11" in which:
+        gen_g11()
     if "g7" in which:
         gen_g7()
     if "g4t" in which:

@@ -160,3 +160,114 @@ def test_score_transform_and_update_env_keep_the_mirrored_sign(tmp_path, monkeyp
     w2 = orc.score_transform(cfg["agents"]["gtn"]["score_transform_type"], host[:, 0] + 1.0, host[:, 1])
     assert np.array_equal(m.theta.numpy(), orc.update_env(theta0, m.eps.numpy(), host[:, 2].astype(np.float32), w2,
                                                           cfg["agents"]["gtn"]["step_size"]))
+
+
+# ---- G11: the payload files the REFERENCE wrote (oracle/gen_golden.py gen_g11; reference agents/GTN_master.py:147-176 write_worker_inputs,
+# agents/GTN_worker.py:139-154 write_worker_result) meet this package's worker and master ----
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _flat(envw):
+    from learning_environments_amd.models.model_utils import linear_params
+    return torch.cat([p.detach().reshape(-1) for p in linear_params(envw)]).cpu().numpy()
+
+
+def _place(src, dst, check):
+    import shutil
+    shutil.copyfile(os.path.join(GOLDEN, src), dst)
+    torch.save({}, check)
+
+
+def _g11():
+    return np.load(os.path.join(GOLDEN, "g11_file_transport.npz"))
+
+
+def _sd_signature(sd):
+    return [(k, tuple(v.shape), v.dtype) for k, v in sd.items()]
+
+
+def _check_worker_reads_reference_input(engine, tmp_path, monkeypatch):
+    from learning_environments_amd.agents.GTN import GTN_Worker
+    monkeypatch.chdir(tmp_path)
+    g = _g11()
+    ref_in = torch.load(os.path.join(GOLDEN, "g11_ref_master_input_w1.pt"))
+    w = GTN_Worker(1, bohb_id=-1, engine=engine, seed=4)
+    _place("g11_ref_master_input_w1.pt", w.get_input_file_name(1), w.get_input_check_file_name(1))
+    w.time_sleep_worker = 0.0
+    w.read_worker_input()
+    assert w.timeout == float(g["timeout"]) == ref_in["timeout"] and w.quit_flag is True and w.config == ref_in["config"]
+    assert np.array_equal(_flat(w.synthetic_env_orig), g["theta0"]) and np.array_equal(_flat(w.synthetic_env), g["theta0"])
+    assert not os.path.exists(w.get_input_file_name(1)) and not os.path.exists(w.get_input_check_file_name(1))
+    # ... and answers with a result payload of the reference's shape: same keys, same state-dict keys / shapes / dtypes
+    best, orig = w.evaluate()
+    w.write_worker_result(score=best, score_orig=orig, time_elapsed=0.5)
+    mine = torch.load(w.get_result_file_name(1))
+    ref_out = torch.load(os.path.join(GOLDEN, "g11_ref_worker_result_w1.pt"))
+    assert list(mine.keys()) == list(ref_out.keys())
+    for k in ("eps", "synthetic_env"):
+        assert _sd_signature(mine[k]) == _sd_signature(ref_out[k])
+    assert all(type(mine[k]) is type(ref_out[k]) for k in ("time_elapsed", "score", "score_orig"))
+    assert os.path.isfile(w.get_result_check_file_name(1))
+    # the eps it reports is the one its synthetic_env carries: synthetic_env = theta0 + eps (mirrored pick folded in)
+    assert np.array_equal(_flat_sd(mine["synthetic_env"]), (torch.from_numpy(g["theta0"]) + torch.from_numpy(_flat_sd(mine["eps"]))).numpy())
+
+
+def _flat_sd(sd):
+    return np.concatenate([v.reshape(-1).numpy() for k, v in sd.items() if (k[:-6] + "bias") in sd or k.endswith("bias")])
+
+
+def _check_master_reads_reference_results(engine, device, tmp_path, monkeypatch):
+    from learning_environments_amd.agents.GTN import GTN_Master
+    monkeypatch.chdir(tmp_path)
+    g = _g11()
+    cfg = copy.deepcopy(torch.load(os.path.join(GOLDEN, "g11_ref_master_input_w0.pt"))["config"])
+    cfg["device"] = device
+    cfg["agents"]["gtn"]["time_sleep_master"] = 0.0
+    m = GTN_Master(cfg, bohb_id=-1, engine=engine, transport="file")
+    m.clean_working_dir()
+    m.theta.copy_(torch.from_numpy(g["theta0"]).to(m.theta.device))
+    # (a) what this master writes for its workers has the reference master's format ...
+    m.write_worker_inputs(0)
+    mine = torch.load(m.get_input_file_name(0))
+    ref_in = torch.load(os.path.join(GOLDEN, "g11_ref_master_input_w0.pt"))
+    assert list(mine.keys()) == list(ref_in.keys()) and mine["quit_flag"] is True and mine["timeout"] == ref_in["timeout"]
+    assert _sd_signature(mine["synthetic_env_orig"]) == _sd_signature(ref_in["synthetic_env_orig"])
+    assert all(torch.equal(mine["synthetic_env_orig"][k], ref_in["synthetic_env_orig"][k]) for k in ref_in["synthetic_env_orig"])
+    m.clean_working_dir()
+    # (b) ... and from the reference WORKERS' result payloads it reproduces the reference master's lists and its theta after
+    # score_transform + update_env bit for bit
+    for i in range(2):
+        _place("g11_ref_worker_result_w%d.pt" % i, m.get_result_file_name(i), m.get_result_check_file_name(i))
+    m.read_worker_results()
+    assert m.score_list == g["score"].tolist() and m.score_orig_list == g["score_orig"].tolist()
+    assert m.time_elapsed_list == g["time_elapsed"].tolist()
+    assert np.array_equal(m.eps.cpu().numpy(), g["eps"])
+    assert os.listdir(m.sync_dir) == []
+    m.score_transform()
+    assert m.score_transform_list == g["weights"].tolist()
+    m.update_env()
+    assert np.array_equal(m.theta.cpu().numpy(), g["theta1"])
+    assert np.array_equal(_flat(m.synthetic_env_orig), g["theta1"])
+    assert m.calc_worker_timeout() == float(np.mean(g["time_elapsed"])) * cfg["agents"]["gtn"]["time_mult"]
+
+
+def test_master_reads_reference_worker_results_cpu(tmp_path, monkeypatch):
+    from oracle.engine_standin import OracleNesEngine
+    _check_master_reads_reference_results(OracleNesEngine(), "cpu", tmp_path, monkeypatch)
+
+
+def test_worker_reads_reference_master_input_cpu(tmp_path, monkeypatch):
+    from oracle.engine_standin import OracleNesEngine
+    _check_worker_reads_reference_input(OracleNesEngine(), tmp_path, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_master_reads_reference_worker_results_hip(tmp_path, monkeypatch):
+    from learning_environments_amd.engine import HipNesEngine
+    _check_master_reads_reference_results(HipNesEngine(), "cuda", tmp_path, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_worker_reads_reference_master_input_hip(tmp_path, monkeypatch):
+    from learning_environments_amd.engine import HipNesEngine
+    _check_worker_reads_reference_input(HipNesEngine(), tmp_path, monkeypatch)
