@@ -64,12 +64,22 @@ def launch_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
     rc = 0
+    deadline = time.time() + float(os.environ.get("LENV_BENCH_LAUNCH_TIMEOUT", "3600"))
     try:
-        for p in procs:
-            p.wait()
-            rc = rc or p.returncode
-            if p.returncode != 0:
+        # poll every rank: the first failure (or the overall deadline) ends the job at once instead of leaving the other
+        # ranks blocked in a collective until the RCCL watchdog fires
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
                 break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                rc = 124
+                break
+            time.sleep(0.2)
     finally:
         for p in procs:
             if p.poll() is None:
@@ -220,20 +230,21 @@ def cpu_baseline(cfgd, theta, grad_chunk, file_io=True):
 
     # single-thread calibration: one worker-evaluation = 3 chains on one core
     t1 = population(1, 1)
-    # all cores: ceil(cores/3) whole workers (>= 2), the chains are handed to `threads` worker threads
-    pop_s = max(2, min(POP, (cores + 2) // 3))       # enough whole workers to keep every core busy
-    threads = min(cores, 3 * pop_s)
+    # all cores, whole rounds: `cores` workers = 3*cores chains of equal length handed to the largest thread count <= cores that
+    # divides the chain count (16 cores: 48 chains on 16 threads = exactly three rounds)
+    pop_s = max(1, min(POP, cores))
+    threads = max(t for t in range(1, cores + 1) if (3 * pop_s) % t == 0)
     dt = population(pop_s, threads)
     out = {"value": pop_s / dt, "unit": "worker-evaluations/s", "cores": threads, "kind": "port",
            "cpu_model": model, "affinity_cores": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": quota,
            "single_core_value": 1.0 / t1, "parallel_speedup": (pop_s / dt) * t1,
            "sample": "%d workers (=%d chains) of the same fixed-work CartPole-SE/DDQN workload on %d threads, %.1f s wall; single-thread calibration: 1 worker (3 chains) in %.1f s" % (pop_s, 3 * pop_s, threads, dt, t1)}
     if file_io:
-        out["file_io"] = cpu_baseline_file_io(cfgd, theta, cores, deadline_s=max(60.0, 8.0 * t1))
+        out["file_io"] = cpu_baseline_file_io(cfgd, theta, cores, deadline_s=max(60.0, 8.0 * t1), grad_chunk=grad_chunk)
     return out
 
 
-def cpu_baseline_file_io(cfgd, theta, cores, deadline_s):
+def cpu_baseline_file_io(cfgd, theta, cores, deadline_s, grad_chunk):
     """One generation of a file-transport GTN_Master driving W oracle workers (oracle/file_worker.py), W = min(cores, 32)
     (each worker process imports torch for the .pt files: 32 bounds the memory).  evals/s = W / wall of the generation."""
     import copy
@@ -255,7 +266,8 @@ def cpu_baseline_file_io(cfgd, theta, cores, deadline_s):
             master.theta.copy_(torch.from_numpy(theta))
         env = dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         for i in range(W):
-            procs.append(subprocess.Popen([sys.executable, "-m", "oracle.file_worker", str(i), "--max-generations", "1"],
+            procs.append(subprocess.Popen([sys.executable, "-m", "oracle.file_worker", str(i), "--max-generations", "1",
+                                           "--grad-chunk", str(int(grad_chunk))],      # the same canonical summation order as leg (i) and the kernel
                                           env=env, cwd=work, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
         time.sleep(min(20.0, 2.0 + 0.25 * W))     # let the workers import torch and start polling (not part of the sample)
         t0 = time.time()
@@ -288,6 +300,101 @@ def cpu_baseline_file_io(cfgd, theta, cores, deadline_s):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# the other BASELINE configurations, one shard each at the per-GPU size the config names (N = 1 only, after the headline)
+# ----------------------------------------------------------------------------------------------------------------------
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD = the fp32 vector rate
+
+
+def dueling_model(cfg, st):
+    """SURVEY.md §8(d) algorithmic bytes and the fp32 FLOPs of the layer products of one launch, BASELINE configs[2]."""
+    a = cfg["agents"]["duelingddqn"]
+    S, A, H, F, L, B = 6, 3, a["hidden_size"], a["feature_dim"], a["hidden_layer"], a["batch_size"]
+    P = S * H + H + (L - 1) * (H * H + H) + H * F + F + 2 * (F * F + F) + F + 1 + A * F + A
+    f = 2 * (S * H + (L - 1) * H * H + H * F + 2 * F * F + F * (1 + A))                      # FLOPs of one forward row
+    learn, train, test = float(st[:, 2].sum()), float(st[:, 1].sum()), float(st[:, 3].sum())
+    nbytes = 4 * (learn * (B * (2 * S + 3) + 8 * P) + train * ((2 * S + 3) + (A + S) + (S + 2)) + test * (P + 2 * S + 2))
+    return nbytes, learn * 5 * B * f + (train + test) * f
+
+
+def td3_model(cfg, st):
+    """The same for BASELINE configs[4] (actor 17-128-128-6, twin critics 23-128-128-1, policy_delay 1)."""
+    a = cfg["agents"]["td3"]
+    S, A, H, B = 17, 6, a["hidden_size"], a["batch_size"]
+    Pa = S * H + H + H * H + H + H * A + A
+    Pc = (S + A) * H + H + H * H + H + H + 1
+    fa, fc = 2 * (S * H + H * H + H * A), 2 * ((S + A) * H + H * H + H)
+    learn, train, test = float(st[:, 2].sum()), float(st[:, 1].sum()), float(st[:, 3].sum())
+    nbytes = 4 * (learn * (B * (2 * S + A + 2) + 8 * (Pa + 2 * Pc)) + train * (2 * S + A + 2) + test * (Pa + 2 * S + 2))
+    return nbytes, learn * B * (4 * fa + 10 * fc) + (train + test) * fa
+
+
+def ql_model(cfg, st):
+    """Tabular Q-learning on the Cliff RewardEnv (BASELINE configs[3]): 80 B per env step + the reward net read once per chain
+    (SURVEY.md §8(d)); no floating-point products worth a FLOP count."""
+    train, test = float(st[:, 1].sum()), float(st[:, 3].sum())
+    return 80.0 * (train + test) + st.shape[0] * 4 * 2 * 1602, 0.0
+
+
+def secondary_configs():
+    """One GTN_Master per configuration, its §8(d) fixed-work form, 1 untimed + K timed generations each, HIP events around
+    the generation's device work.  Sized to finish in about a minute."""
+    from learning_environments_amd import configs as C
+    from learning_environments_amd.agents.GTN import GTN_Master
+    out = []
+
+    def run(name, key, kernel, cfg, model, steps, warmup=1, se=True):
+        torch.manual_seed(0)
+        cwd = os.getcwd()
+        work = os.path.join("/tmp", "lenv_bench_%d" % os.getpid())
+        os.makedirs(work, exist_ok=True)
+        os.chdir(work)
+        try:
+            m = GTN_Master(cfg, bohb_id=0, seed=1234)
+        finally:
+            os.chdir(cwd)
+        if se:
+            with torch.no_grad():
+                m.synthetic_env_orig.env.done_net[-1].bias.fill_(-10.0)       # the SE never terminates: fixed work per episode
+        dt, kernel_ms = timed_generations(m, steps, warmup, torch.cuda.synchronize, 1, True)
+        st = m.inner.stats.cpu().numpy()
+        pop = cfg["agents"]["gtn"]["num_workers"]
+        nbytes, flops = model(cfg, st)
+        learn = float(st[:, 2].mean())
+        rec = {"config": key, "workload": name, "kernel": kernel, "pop_on_this_gpu": pop, "chains": int(st.shape[0]), "steps": steps,
+               "ms_per_step": dt / steps * 1e3, "kernel_ms": kernel_ms, "value": pop * steps / dt, "unit": "worker-evaluations/s",
+               "train_steps": int(st[:, 1].sum()), "learn_steps": int(st[:, 2].sum()), "test_steps": int(st[:, 3].sum()),
+               "us_per_learn_step_per_chain": kernel_ms * 1e3 / learn if learn else None,
+               "algorithmic_GBps": nbytes / (kernel_ms * 1e-3) / 1e9, "hbm_frac": nbytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+               "graph": bool(getattr(m, "use_graph", False))}
+        if flops:
+            busy = min(int(st.shape[0]), 256)
+            tf = flops / (kernel_ms * 1e-3) / 1e12
+            rec.update({"mfma_f32_TFLOPs": tf, "mfma_f32_frac": tf / MFMA_F32_PEAK_TFLOPS, "busy_cus": busy,
+                        "mfma_f32_frac_of_busy_cus": tf / (MFMA_F32_PEAK_TFLOPS * busy / 256.0)})
+        out.append(rec)
+        del m
+        torch.cuda.empty_cache()
+
+    # configs[2]: Acrobot SE + DuelingDDQN, pop 256 over 8 GPUs = 32 workers = 96 chains per GPU; 20 train episodes x 500 steps
+    # (init_episodes 10 as published: the second half learns), 10 lock-step test episodes after every train episode
+    c3 = C.fixed_work(C.acrobot_syn_env_duelingddqn(32), 20)
+    run("Acrobot-v1 SE + DuelingDDQN (6-128-128 / 128 / 3, B=128): one 8-GPU shard of pop 256 = 32 workers, 20 x 500 train steps",
+        "BASELINE configs[2]", "dueling_se_inner_kernel", c3, dueling_model, steps=2)
+    # configs[3]: Cliff RewardEnv + QL, pop 128 on one GPU, 100 episodes (published early-out)
+    c4 = C.cliff_reward_env_ql(128)
+    c4["agents"]["gtn"]["quit_when_solved"] = False
+    run("Cliff RewardEnv (potential-shaped) + QL, pop 128 = 384 chains, 100 episodes", "BASELINE configs[3]", "ql_rn_inner_kernel",
+        c4, ql_model, steps=50, warmup=5, se=False)
+    # configs[4]: HalfCheetah stand-in RewardEnv + TD3, pop 64 over 8 GPUs = 8 workers = 24 chains per GPU; 5 episodes x 1000 steps
+    # (init_episodes 1 instead of the published 20, so that four of the five episodes learn)
+    c5 = C.fixed_work(C.halfcheetah_reward_env_td3(8), 5)
+    c5["agents"]["td3"]["init_episodes"] = 1
+    run("HalfCheetah stand-in RewardEnv + TD3 (17-128-128-6, twin critics, B=192): one 8-GPU shard of pop 64 = 8 workers, 5 x 1000 "
+        "train steps", "BASELINE configs[4]", "td3_rn_inner_kernel", c5, td3_model, steps=2, se=False)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # one rank
 # ----------------------------------------------------------------------------------------------------------------------
 def timed_generations(master, steps, warmup, barrier, world, use_events):
@@ -309,7 +416,23 @@ def timed_generations(master, steps, warmup, barrier, world, use_events):
         ev.append((e0, e1))
         return out
 
-    if use_events:
+    if getattr(master, "use_graph", False) and master._graph is None:
+        master._capture_generation()           # (no warm-up generation ran: capture before the event hooks go in)
+    graph = getattr(master, "_graph", None) if getattr(master, "use_graph", False) else None
+    orig_replay = graph.replay if graph is not None else None
+
+    def timed_replay():
+        # captured generation: HIP events around the replay on the launching stream = device time of the generation's seven
+        # kernels, of which the fused inner loop is > 99 %: an upper bound of its duration, taken over the timed region
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_replay()
+        e1.record()
+        ev.append((e0, e1))
+
+    if use_events and graph is not None:
+        graph.replay = timed_replay
+    elif use_events:
         master.engine.inner_scores = timed_inner
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -318,6 +441,8 @@ def timed_generations(master, steps, warmup, barrier, world, use_events):
     barrier()
     dt = time.perf_counter() - t0
     master.engine.inner_scores = orig_inner
+    if graph is not None and use_events:
+        del graph.replay
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=master.engine.device)
@@ -390,6 +515,9 @@ def run_rank(args):
                   "ms_per_step": sdt / args.steps * 1e3, "kernel_ms": skernel_ms,
                   "note": "one workgroup per chain: a chain's %d serial learn steps bound the generation, so fewer chains per "
                           "GPU do not shorten it once every chain already has its own CU" % (TRAIN_EPISODES * 200)}
+    others = None
+    if world == 1 and not plumbing and not args.no_configs:
+        others = secondary_configs()           # the other BASELINE configurations, one shard each (not part of `value`)
     gpu_section_s = time.perf_counter() - t_start
 
     if rank == 0:
@@ -442,6 +570,8 @@ def run_rank(args):
                     line["config"]["kernel_launches_source"] = src + " (rocprofv3 --kernel-trace: all dispatches / fused-kernel dispatches)"
         else:
             line["config"] = {"workload": "plumbing self-test of the multi-rank path"}
+        if others is not None:
+            line["configs"] = others
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
@@ -459,6 +589,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-file-io", action="store_true", help="skip the file-IO worker-mode leg of the CPU baseline")
+    ap.add_argument("--no-configs", action="store_true", help="skip the shards of the other BASELINE configurations")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         os.environ["LENV_BENCH_SPAWNED"] = "1"

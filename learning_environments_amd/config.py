@@ -8,6 +8,15 @@ ENV_DIMS = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3), "HalfCheetah-v3": (17, 
 TD3_MAX_ACTION = {"HalfCheetah-v3": 1.0, "Pendulum-v0": 2.0, "MountainCarContinuous-v0": 1.0}
 
 
+def _refuse_layer_norm(config, env_section, agent_section):
+    """The fused inner loops take plain MLPs: `use_layer_norm` (models/model_utils.py:22-29) in the synthetic env's or the
+    agent's section would silently train a different network, so the config builders refuse it (the one-step forward
+    lenv_mlp_forward and the TD3_discrete_vary loop are the LayerNorm paths)."""
+    for name, sec in (("envs." + config["env_name"], env_section), ("agent", agent_section)):
+        if sec is not None and sec.get("use_layer_norm", False):
+            raise NotImplementedError("use_layer_norm in the %s section: no fused inner loop takes LayerNorm nets here" % name)
+
+
 def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **overrides):
     """Fields read at reference agents/DDQN.py:15-38, agents/base_agent.py:9-26, envs/env_factory.py:45-59.
     grad_chunk=0 picks the smallest micro-chunk (>= ceil(batch/16)) whose LDS footprint fits one CU; it stays 0 (one
@@ -29,6 +38,7 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
     S, A = ENV_DIMS[env_name]
     if a["same_action_num"] != 1:
         raise NotImplementedError("same_action_num != 1")
+    _refuse_layer_norm(config, e, a)
 
     def val(v):  # env_factory.py:54-58: list-valued entries -> float(value[1])
         return float(v[1]) if isinstance(v, list) else v
@@ -118,6 +128,7 @@ def ql_cfg_from_config(config, tables, rng_mode=_lib.RNG_COUNTER, **overrides):
         raise NotImplementedError("same_action_num != 1")
     if int(a["rb_size"]) != 1:
         raise NotImplementedError("tabular agents with rb_size != 1 (the reference configs keep the single latest transition)")
+    _refuse_layer_norm(config, e, None)
 
     def val(v):
         return float(v[1]) if isinstance(v, list) else v
@@ -149,6 +160,7 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
     def val(v):
         return float(v[1]) if isinstance(v, list) else v
 
+    _refuse_layer_norm(config, e, a)
     cfg = _lib.Td3Cfg(env_id=_lib.ENV[env_name], state_dim=S, action_dim=A, max_steps=int(val(e["max_steps"])),
                       rn_hidden=int(val(e["hidden_size"])), rn_layers=int(val(e["hidden_layer"])), rn_act=_lib.ACT[e["activation_fn"]],
                       rn_prelu=0.25, reward_env_type=int(val(e["reward_env_type"])), info_dim=int(val(e.get("info_dim", 0))),

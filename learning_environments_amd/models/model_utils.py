@@ -42,16 +42,27 @@ def mlp_desc(net, activation_fn):
                         _lib.ACT[activation_fn], prelu, 1 if any(isinstance(m, nn.LayerNorm) for m in net) else 0)
 
 
-def linear_params(module):
-    """nn.Linear weights and biases in modules() order (the order GTN_worker.py:156-175 / GTN_master.py:281-296
-    iterate in, == state-dict order); shared activation modules are skipped."""
+def _params_of(module, kinds):
     out = []
     for m in module.modules():                      # modules() yields a shared module once, at its first position
-        if isinstance(m, (nn.Linear, nn.LayerNorm)):
+        if isinstance(m, kinds):
             out.append(m.weight)
             if m.bias is not None:
                 out.append(m.bias)
     return out
+
+
+def linear_params(module):
+    """nn.Linear weights and biases in modules() order (the order GTN_worker.py:156-175 / GTN_master.py:281-296
+    iterate in, == state-dict order): THE flat NES layout of theta / eps.  Only nn.Linear is perturbed and updated by the
+    reference (GTN_worker.py:158,167; GTN_master.py:283,293): PReLU slopes and LayerNorm affines keep their initial values."""
+    return _params_of(module, nn.Linear)
+
+
+def mlp_params(module):
+    """Every parameter lenv_mlp_forward reads for a build_nn_from_config net, in its flat order: the nn.Linear parameters
+    plus -- for `use_layer_norm` nets -- the shared nn.LayerNorm's weight and bias at the module's (first) position."""
+    return _params_of(module, (nn.Linear, nn.LayerNorm))
 
 
 class FlatParams(object):

@@ -273,3 +273,17 @@ def test_master_host_logic_for_icm_and_multilayer_agents_on_the_oracle_engine(tm
         scores = np.array(scores)
         best, sign = orc.worker_best(scores[1::3], scores[2::3], True)
         assert np.array_equal(gathered[:, 0], best) and np.array_equal(gathered[:, 1], scores[0::3])
+
+
+def test_config_builders_refuse_layer_norm_sections():
+    """theta / eps are the nn.Linear parameters only; a `use_layer_norm` section must not slip into a fused loop
+    that would ignore the normalisation."""
+    from learning_environments_amd import config, configs
+    c = configs.cartpole_syn_env_ddqn(2)
+    c["envs"]["CartPole-v0"]["use_layer_norm"] = True
+    with pytest.raises(NotImplementedError):
+        config.ddqn_cfg_from_config(c)
+    c = configs.halfcheetah_reward_env_td3(2)
+    c["agents"]["td3"]["use_layer_norm"] = True
+    with pytest.raises(NotImplementedError):
+        config.td3_cfg_from_config(c)

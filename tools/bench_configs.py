@@ -35,33 +35,19 @@ def run(name, cfg, gens=2, extra=None):
     print(json.dumps(out))
 
 
-HBM_PEAK_GBPS, MFMA_F32_PEAK_TFLOPS = 8000.0, 157.3       # MI355X_MICROARCH.md
+import bench  # noqa: E402  (the byte / FLOP models live next to the contract line)
+HBM_PEAK_GBPS, MFMA_F32_PEAK_TFLOPS = bench.HBM_PEAK_GBPS, bench.MFMA_F32_PEAK_TFLOPS
 
 
-def dueling_model(cfg, st, dt):
-    """SURVEY.md 8(d) algorithmic bytes and the fp32 FLOPs of the layer products for config 3."""
-    a, e = cfg["agents"]["duelingddqn"], cfg["envs"]["Acrobot-v1"]
-    S, A, H, F, L, B = 6, 3, a["hidden_size"], a["feature_dim"], a["hidden_layer"], a["batch_size"]
-    P = S * H + H + (L - 1) * (H * H + H) + H * F + F + 2 * (F * F + F) + F + 1 + A * F + A
-    f = 2 * (S * H + (L - 1) * H * H + H * F + 2 * F * F + F * (1 + A))                      # FLOPs of one forward row
-    learn, train, test = float(st[:, 2].sum()), float(st[:, 1].sum()), float(st[:, 3].sum())
-    nbytes = 4 * (learn * (B * (2 * S + 3) + 8 * P) + train * ((2 * S + 3) + (A + S) + (S + 2)) + test * (P + 2 * S + 2))
-    flops = learn * 5 * B * f + (train + test) * f
-    return dict(algorithmic_GBps=nbytes / dt / 1e9, hbm_frac=nbytes / dt / 1e9 / HBM_PEAK_GBPS, fp32_TFLOPs=flops / dt / 1e12,
-                mfma_f32_frac=flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, busy_cus=int(st.shape[0]))
+def _frac(model):
+    def f(cfg, st, dt):
+        nbytes, flops = model(cfg, st)
+        return dict(algorithmic_GBps=nbytes / dt / 1e9, hbm_frac=nbytes / dt / 1e9 / HBM_PEAK_GBPS, fp32_TFLOPs=flops / dt / 1e12,
+                    mfma_f32_frac=flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, busy_cus=int(st.shape[0]))
+    return f
 
 
-def td3_model(cfg, st, dt):
-    a = cfg["agents"]["td3"]
-    S, A, H, B = 17, 6, a["hidden_size"], a["batch_size"]
-    Pa = S * H + H + H * H + H + H * A + A
-    Pc = (S + A) * H + H + H * H + H + H + 1
-    fa, fc = 2 * (S * H + H * H + H * A), 2 * ((S + A) * H + H * H + H)
-    learn, train, test = float(st[:, 2].sum()), float(st[:, 1].sum()), float(st[:, 3].sum())
-    nbytes = 4 * (learn * (B * (2 * S + A + 2) + 8 * (Pa + 2 * Pc)) + train * (2 * S + A + 2) + test * (Pa + 2 * S + 2))
-    flops = learn * B * (4 * fa + 10 * fc) + (train + test) * fa
-    return dict(algorithmic_GBps=nbytes / dt / 1e9, hbm_frac=nbytes / dt / 1e9 / HBM_PEAK_GBPS, fp32_TFLOPs=flops / dt / 1e12,
-                mfma_f32_frac=flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, busy_cus=int(st.shape[0]))
+dueling_model, td3_model = _frac(bench.dueling_model), _frac(bench.td3_model)
 
 
 if __name__ == "__main__":
