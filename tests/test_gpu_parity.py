@@ -1072,7 +1072,7 @@ def test_td3_vary_tape_and_counter_mode_vs_oracle(eng, orc, golden):
     _, cfg = _td3_cfgs(orc, cfgd, 0, **mx)
     keys = np.array([orc.chain_key(23, 1, 0, c) for c in range(chains)], np.uint64)
     hps = [vary.vary_hyperparameters(base, vary.chain_units(int(k))) for k in keys]
-    assert len({h["batch_size"] for h in hps}) == chains
+    assert len({h["batch_size"] for h in hps}) >= 2          # heterogeneous chains in one launch
     rng = np.random.RandomState(41)
     theta = (rng.randn(g["theta"].size) * 0.2).astype(np.float32)
     eps = (rng.randn(1, theta.size) * 0.05).astype(np.float32)
