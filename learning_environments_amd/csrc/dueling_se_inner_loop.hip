@@ -17,6 +17,7 @@
 // per learn step and chain.
 #include "lenv_gemm.cuh"
 #include "lenv_icm.cuh"
+#include "lenv_wavechain_host.h"
 
 namespace lenv {
 
@@ -797,6 +798,13 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
         for (int i = 0; i < IB_COUNT; ++i) a.a_icm[i] = take(sz[i]);
     }
     a.arena_stride = (off + 63) & ~(int64_t)63;
+    {   // the wave-chain kernel (dueling_wavechain.hip) keeps its own arena layout inside the same workspace
+        const int wshape = lenv_wc_dueling_shape(cfg);
+        if (wshape) {
+            const int64_t wfl = lenv_wc_dueling_arena_floats(cfg, wshape, a.rb_cap, a.RS, a.P_se);
+            if (wfl > a.arena_stride) a.arena_stride = wfl;
+        }
+    }
     const size_t lds_floats = GemmShape<D_MAXI>::PS_FLOATS + GemmShape<D_MAXI>::QS_FLOATS + GEMM_QUEUE_MAX * sizeof(GemmCmd) / sizeof(float) +
                               3 * K * Hse + 3 * Hse + (S + 2) * Hse + 16 + 3 * Hse + 3 * (size_t)(B > T ? B : T) * A + 3 * (size_t)(B > T ? B : T) * (1 + A) +
                               B + (size_t)B * A + 64 + 2 * (4 * (size_t)T + T) + 2 * T + 8 + 16 + 16 + (size_t)T + 10;
@@ -885,6 +893,19 @@ extern "C" int lenv_dueling_se_inner_loop_icm(const lenv_ddqn_cfg *cfg, const le
                    (sp.kind == 0 || cfg->feature_dim == sp.F) && cfg->q_hidden == sp.H && cfg->q_layers == sp.L && cfg->batch_size == sp.B &&
                    cfg->se_hidden == sp.Hse && cfg->test_episodes == sp.T && cfg->q_act == sp.q_act && cfg->se_act == sp.se_act;
         };
+        // production launches of a wave-chain shape (dueling_wavechain.hip): LENV_NO_WAVECHAIN=1 keeps the GEMM-queue kernel (A/B runs)
+        const char *nw_ = getenv("LENV_NO_WAVECHAIN");
+        const bool no_wc = nw_ && nw_[0] == '1';
+        if (!off && !no_wc && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action && cfg->synthetic_env_type == 0) {
+            const int wshape = lenv_wc_dueling_shape(cfg);
+            if (wshape) {
+                if (out->status) {
+                    if (hipMemsetAsync(out->status, 0, sizeof(int32_t) * chains, static_cast<hipStream_t>(stream)) != hipSuccess) return LENV_ERR_LAUNCH;
+                }
+                return lenv_wc_dueling_launch(wshape, cfg, theta, eps, worker, sign, agent_init, rng_keys, chains, a.arena, a.arena_stride, a.rb_cap,
+                                              a.RS, a.P, a.P_se, a.se_net_size, out, static_cast<hipStream_t>(stream));
+            }
+        }
         if (!off && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action && cfg->synthetic_env_type == 0) {
             if (matches(kDuelShapes[1])) kern = dueling_se_inner_kernel<false, 1>;
             else if (matches(kDuelShapes[2])) kern = dueling_se_inner_kernel<false, 2>;

@@ -1,0 +1,859 @@
+// dueling_wavechain.hip -- the DuelingDDQN inner loop of BASELINE configs[2] (Acrobot-v1 SE + DuelingDDQN, default_config_acrobot.yaml)
+// rebuilt on the wave-chain primitives of lenv_wavechain.cuh.  Same semantics, same canonical arithmetic order and therefore the
+// same bits as dueling_se_inner_kernel (which stays the generic path: other shapes, tapes, traces, *_vary, ICM, RewardEnv), but a
+// different execution structure:
+//
+//   reference                                   here
+//   DuelingDDQN.learn  agents/DuelingDDQN.py:59-94     learn_step(): target pass (4 sample blocks) + online pass (8 blocks: s and s'
+//   Critic_DuelingDQN  models/actor_critic.py:94-122     share every staged weight image), activations chained in registers
+//   loss.backward()                                     backward(): per layer one resident transposed weight image for the input
+//                                                         gradients (4 waves, one per SIMD) and two [sample][unit] images for the
+//                                                         weight gradients (8 waves)
+//   optimizer.step + Polyak  :87-93                     wg_adam over the arena-layout parameter vector
+//   select_train_action / BaseAgent.test greedy rows    forward_thin(): A operand straight from the K-major arena arrays
+//
+// Arena layout of a parameter vector (online, target, Adam m / v, grad all alike; every 128x128 matrix K-MAJOR, Wt[k][unit]):
+//   W1t[8][128] (rows >= S are zero) b1 | W2t b2 | W3t b3 | Wv1t bv1 | Wa1t ba1 | Wh[128][4] = (wv2, wa2_0..2)[k] | bh[4]
+#include "lenv_wavechain.cuh"
+#include "lenv_wavechain_host.h"
+
+namespace lenv {
+
+using namespace wc;
+
+struct WcShape { int env, S, A, Hse, T, q_act, se_act; };       // fixed: H = F = 128, L = 2, B = 128, DuelingDDQN
+constexpr WcShape kWcShapes[] = {
+    { -1, 2, 2, 1, 1, 0, 0 },
+    { LENV_ENV_ACROBOT, 6, 3, 128, 10, LENV_ACT_RELU, LENV_ACT_LEAKYRELU },     // default_config_acrobot.yaml duelingddqn = BASELINE configs[2]
+};
+constexpr int WC_B = 128, WC_H = 128;
+
+namespace wcp {     // arena-layout parameter offsets (floats)
+constexpr int oW1t = 0, ob1 = 8 * W, oW2t = ob1 + W, ob2 = oW2t + IMG, oW3t = ob2 + W, ob3 = oW3t + IMG, oWv1t = ob3 + W, obv1 = oWv1t + IMG,
+              oWa1t = obv1 + W, oba1 = oWa1t + IMG, oWh = oba1 + W, obh = oWh + 4 * W, PW = obh + 4;
+static_assert(PW % 4 == 0, "float4 passes");
+}
+
+enum { D_H1 = 0, D_H2, D_FEAT, D_V1, D_A1, S_F1, S_DFEAT, S_DH2, S_DH1, WC_NDUMP };
+
+struct WcArgs {
+    lenv_ddqn_cfg cfg;
+    const float *theta, *eps; const int32_t *worker; const float *sign;
+    const float *agent_init; const uint64_t *rng_keys;
+    float *arena; int64_t arena_stride;
+    lenv_inner_out out;
+    int64_t rb_cap; int RS;
+    int P, P_se, se_net_size[3];
+    int64_t a_par, a_xs, a_xs2, a_dump, a_se, a_replay, a_meter;      // arena offsets (floats)
+};
+
+// state-dict index (duel_param_offsets order) -> arena-layout index
+__device__ __forceinline__ int wc_sd_to_arena(int p, int S, int A)
+{
+    using namespace wcp;
+    int o = p;
+    if (o < WC_H * S) { const int j = o / S, k = o - j * S; return oW1t + k * W + j; }
+    o -= WC_H * S;
+    if (o < W) return ob1 + o;
+    o -= W;
+    const int mats[4] = { oW2t, oW3t, oWv1t, -1 };
+    const int bias[4] = { ob2, ob3, obv1, -1 };
+    for (int l = 0; l < 3; ++l) {
+        if (o < IMG) { const int j = o >> 7, k = o & 127; return mats[l] + k * W + j; }
+        o -= IMG;
+        if (o < W) return bias[l] + o;
+        o -= W;
+    }
+    if (o < W) return oWh + o * 4;                       // Wv2[0][k]
+    o -= W;
+    if (o < 1) return obh;
+    o -= 1;
+    if (o < IMG) { const int j = o >> 7, k = o & 127; return oWa1t + k * W + j; }
+    o -= IMG;
+    if (o < W) return oba1 + o;
+    o -= W;
+    if (o < A * W) { const int aa = o >> 7, k = o & 127; return oWh + k * 4 + 1 + aa; }
+    o -= A * W;
+    return obh + 1 + o;
+}
+
+
+// Everything the phase routines need, written once into LDS by thread 0.  The phases are OUT-OF-LINE functions on purpose: inlined into
+// the one big kernel body their per-lane address sets (swizzled image positions, staging slots) are loop invariants of the episode
+// loops, get hoisted to the kernel prologue and spilled (2.4 KB of scratch per lane in the first build); behind a call each phase
+// computes them where it uses them and the register file belongs to the MFMA chains.
+struct WcCtx {
+    float *bufA, *bufB, *sm_w1t, *sm_bias, *sm_wh, *sm_bh, *qv, *Vb, *Advb, *dq, *dAdv;
+    float *online, *target, *grad, *xs, *xs2, *dumps;
+    volatile float *ctrl;
+    float prelu;
+};
+
+template <class T> __device__ __forceinline__ T *lds_uni_ptr(T *const *field) { return uni_ptr(*field); }
+
+__device__ __forceinline__ float *wc_dump(float *dumps, int which, int blk) { return dumps + ((int64_t)which * 4 + blk) * BLK; }
+
+#ifdef LENV_PHASE_TIMING
+__device__ unsigned long long g_wc_phase_cycles[16];
+#define WPT_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define WPT_MARK(i) do { unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
+#else
+#define WPT_DECL
+#define WPT_MARK(i)
+#endif
+
+
+// ---- thin forward: I <= 32 rows X[I][S] through the ONLINE net, head outputs to slot 0, q to qv (per-row advantage mean) ----
+template <int SHAPE> __device__ __noinline__ void wc_forward_thin_layers(const WcCtx *ctx_, const float *X_, int I_)
+{
+    using namespace wcp;
+    constexpr WcShape SP = kWcShapes[SHAPE];
+    constexpr int S = SP.S, A = SP.A, T = SP.T, B = WC_B, ACT = SP.q_act, RBH = B > T ? B : T;
+    (void)S; (void)A; (void)T; (void)B; (void)ACT; (void)RBH;
+    Lane L;
+    L.init();
+    const int tid = L.tid, wave = L.wave;
+    (void)tid; (void)wave;
+    typedef __attribute__((address_space(3))) const WcCtx LCtx;
+    LCtx *c = (LCtx *)uni_ptr(ctx_);
+    float *bufA = uni_ptr(c->bufA), *bufB = uni_ptr(c->bufB), *sm_w1t = uni_ptr(c->sm_w1t), *sm_bias = uni_ptr(c->sm_bias), *sm_wh = uni_ptr(c->sm_wh),
+          *sm_bh = uni_ptr(c->sm_bh), *qv = uni_ptr(c->qv), *Vb = uni_ptr(c->Vb), *Advb = uni_ptr(c->Advb), *dq = uni_ptr(c->dq), *dAdv = uni_ptr(c->dAdv);
+    float *online = uni_ptr(c->online), *target = uni_ptr(c->target), *grad = uni_ptr(c->grad), *xs = uni_ptr(c->xs), *xs2 = uni_ptr(c->xs2),
+          *dumps = uni_ptr(c->dumps);
+    const float prelu = unif(c->prelu);
+    (void)bufA; (void)bufB; (void)sm_w1t; (void)sm_bias; (void)sm_wh; (void)sm_bh; (void)qv; (void)Vb; (void)Advb; (void)dq; (void)dAdv;
+    (void)online; (void)target; (void)grad; (void)xs; (void)xs2; (void)dumps; (void)prelu;
+    const float *X = uni_ptr(X_);
+    const int I = uni(I_);
+    float *imgX = bufA, *imgY = bufA + 32 * W, *imgZ = bufA + 64 * W;      // thin-product activation images [unit][32]
+    auto dump_of = [&](int which, int blk) { return wc_dump(dumps, which, blk); };
+    {   // layer 1 (K = S): one thread per (unit, sample)
+        const int j = tid & (W - 1);
+        float w[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) w[k] = online[oW1t + k * W + j];
+        const float bj = online[ob1 + j];
+        for (int i = tid >> 7; i < I; i += NT >> 7) {
+            float z = 0.0f;
+#pragma unroll
+            for (int k = 0; k < S; ++k) z = fma32(X[i * S + k], w[k], z);
+            imgX[j * 32 + i] = act_fwd(ACT, prelu, z + bj);
+        }
+    }
+    __syncthreads();
+    if (wave < 4) thin_layer<ACT>(online + oW2t, online + ob2, imgX, imgY, wave, L, prelu);
+    __syncthreads();
+    if (wave < 4) thin_layer<LENV_ACT_IDENTITY>(online + oW3t, online + ob3, imgY, imgX, wave, L, prelu);
+    __syncthreads();
+    if (wave < 4) thin_layer<ACT>(online + oWv1t, online + obv1, imgX, imgY, wave, L, prelu);
+    else thin_layer<ACT>(online + oWa1t, online + oba1, imgX, imgZ, wave - 4, L, prelu);
+    __syncthreads();
+    if (tid < 4 * I) {
+        const int i = tid >> 2, o = tid & 3;
+        if (o <= A) {
+            const float *img = o == 0 ? imgY : imgZ;
+            const float *wh = online + oWh + o;
+            float acc = 0.0f;
+#pragma unroll 8
+            for (int k = 0; k < W; ++k) acc = fma32(img[k * 32 + i], wh[k * 4], acc);
+            acc = acc + online[obh + o];
+            if (o == 0) Vb[i] = acc; else Advb[i * A + (o - 1)] = acc;
+        }
+    }
+    __syncthreads();
+}
+
+// ---- one pass of Critic_DuelingDQN over sample blocks: pass 0 = target net on s' (waves 0-3 -> slot 2), pass 1 = online net on
+// s (waves 0-3 -> slot 0, activations dumped for the backward pass) and on s' (waves 4-7 -> slot 1) ----
+template <int SHAPE> __device__ __noinline__ void wc_forward_big(const WcCtx *ctx_, int pass_)
+{
+    using namespace wcp;
+    constexpr WcShape SP = kWcShapes[SHAPE];
+    constexpr int S = SP.S, A = SP.A, T = SP.T, B = WC_B, ACT = SP.q_act, RBH = B > T ? B : T;
+    (void)S; (void)A; (void)T; (void)B; (void)ACT; (void)RBH;
+    Lane L;
+    L.init();
+    const int tid = L.tid, wave = L.wave;
+    (void)tid; (void)wave;
+    typedef __attribute__((address_space(3))) const WcCtx LCtx;
+    LCtx *c = (LCtx *)uni_ptr(ctx_);
+    float *bufA = uni_ptr(c->bufA), *bufB = uni_ptr(c->bufB), *sm_w1t = uni_ptr(c->sm_w1t), *sm_bias = uni_ptr(c->sm_bias), *sm_wh = uni_ptr(c->sm_wh),
+          *sm_bh = uni_ptr(c->sm_bh), *qv = uni_ptr(c->qv), *Vb = uni_ptr(c->Vb), *Advb = uni_ptr(c->Advb), *dq = uni_ptr(c->dq), *dAdv = uni_ptr(c->dAdv);
+    float *online = uni_ptr(c->online), *target = uni_ptr(c->target), *grad = uni_ptr(c->grad), *xs = uni_ptr(c->xs), *xs2 = uni_ptr(c->xs2),
+          *dumps = uni_ptr(c->dumps);
+    const float prelu = unif(c->prelu);
+    (void)bufA; (void)bufB; (void)sm_w1t; (void)sm_bias; (void)sm_wh; (void)sm_bh; (void)qv; (void)Vb; (void)Advb; (void)dq; (void)dAdv;
+    (void)online; (void)target; (void)grad; (void)xs; (void)xs2; (void)dumps; (void)prelu;
+    const int pass = uni(pass_);
+    auto dump_of = [&](int which, int blk) { return wc_dump(dumps, which, blk); };
+    const float *par = pass ? online : target;
+    for (int i = tid; i < 8 * W; i += NT) sm_w1t[i] = par[oW1t + i];
+    for (int i = tid; i < 5 * W; i += NT) {
+        const int l = i >> 7, j = i & 127;
+        const int off = l == 0 ? ob1 : (l == 1 ? ob2 : (l == 2 ? ob3 : (l == 3 ? obv1 : oba1)));
+        sm_bias[i] = par[off + j];
+    }
+    for (int i = tid; i < 4 * W + 4; i += NT) sm_wh[i] = par[oWh + i];       // Wh and bh are contiguous in both places
+    StageRegs sr;
+    stage_load_direct(par + oW2t, L, sr);
+    stage_store_direct(bufA, L, sr);
+    __syncthreads();
+    const bool active = pass == 1 || wave < 4;
+    const bool stored = pass == 1 && wave < 4;
+    const int blk = wave & 3, slot = pass == 0 ? 2 : (wave < 4 ? 0 : 1);
+    const float *X = stored ? xs : xs2;
+    float bin[64], r[64];
+    f32x16 acc[4];
+    if (active) {                                      // layer 1: K = S
+        acc_zero(acc);
+        const lfloat *w1 = (const lfloat *)sm_w1t + L.h * W + L.li;
+#pragma unroll
+        for (int t = 0; t < S / 2; ++t) {
+            const float xb = X[(32 * blk + L.li) * S + 2 * t + L.h];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2 * t * W + 32 * jt], xb, acc[jt], 0, 0, 0);
+        }
+        tile_bias_act<ACT>(acc, sm_bias, L, prelu, r);
+        if (stored) dump_store(dump_of(D_H1, blk), L, r);
+        tile_to_operand(r);
+#pragma unroll
+        for (int v = 0; v < 64; ++v) bin[v] = r[v];
+    }
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {                      // W2 (bufA), W3 (bufB), Wv1 (bufA), Wa1 (bufB)
+        float *cur = (l & 1) ? bufB : bufA, *nxt = (l & 1) ? bufA : bufB;
+        if (l < 3) stage_load_direct(par + (l == 0 ? oW3t : (l == 1 ? oWv1t : oWa1t)), L, sr);
+        if (active) {
+            acc_zero(acc);
+            chain128(cur, L, bin, acc);
+            if (l == 1) tile_bias_act<LENV_ACT_IDENTITY>(acc, sm_bias + 2 * W, L, prelu, r);
+            else tile_bias_act<ACT>(acc, sm_bias + (l == 0 ? 1 : (l == 2 ? 3 : 4)) * W, L, prelu, r);
+            if (stored) dump_store(dump_of(l == 0 ? D_H2 : (l == 1 ? D_FEAT : (l == 2 ? D_V1 : D_A1)), blk), L, r);
+            tile_to_operand(r);
+            if (l < 2) {
+#pragma unroll
+                for (int v = 0; v < 64; ++v) bin[v] = r[v];
+            } else {
+                // head output layer on the fresh hidden block: V = wv2 . v1 + bv2 (row 0 of the tile), Adv = Wa2 . a1 + ba2 (rows 0..A-1)
+                f32x16 hacc;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) hacc[v] = 0.0f;
+                const int col = l == 2 ? 0 : 1 + (L.li < A ? L.li : A - 1);
+                const lfloat *wh = (const lfloat *)sm_wh + L.h * 4 + col;
+#pragma unroll
+                for (int t = 0; t < 64; ++t) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[2 * t * 4], r[breg_of(t)], hacc, 0, 0, 0);
+                if (L.h == 0) {
+                    const int row = 32 * blk + L.li;
+                    if (l == 2) Vb[slot * RBH + row] = hacc[0] + sm_bh[0];
+                    else {
+#pragma unroll
+                        for (int aa = 0; aa < A; ++aa) Advb[slot * RBH * A + row * A + aa] = hacc[aa] + sm_bh[1 + aa];
+                    }
+                }
+            }
+        }
+        if (l < 3) stage_store_direct(nxt, L, sr);
+        __syncthreads();
+    }
+}
+
+// ---- backward pass of the TD loss through the online net on the s blocks (waves 0-3 own the sample blocks) ----
+template <int SHAPE> __device__ __noinline__ void wc_backward_big(const WcCtx *ctx_)
+{
+    using namespace wcp;
+    constexpr WcShape SP = kWcShapes[SHAPE];
+    constexpr int S = SP.S, A = SP.A, T = SP.T, B = WC_B, ACT = SP.q_act, RBH = B > T ? B : T;
+    (void)S; (void)A; (void)T; (void)B; (void)ACT; (void)RBH;
+    Lane L;
+    L.init();
+    const int tid = L.tid, wave = L.wave;
+    (void)tid; (void)wave;
+    typedef __attribute__((address_space(3))) const WcCtx LCtx;
+    LCtx *c = (LCtx *)uni_ptr(ctx_);
+    float *bufA = uni_ptr(c->bufA), *bufB = uni_ptr(c->bufB), *sm_w1t = uni_ptr(c->sm_w1t), *sm_bias = uni_ptr(c->sm_bias), *sm_wh = uni_ptr(c->sm_wh),
+          *sm_bh = uni_ptr(c->sm_bh), *qv = uni_ptr(c->qv), *Vb = uni_ptr(c->Vb), *Advb = uni_ptr(c->Advb), *dq = uni_ptr(c->dq), *dAdv = uni_ptr(c->dAdv);
+    float *online = uni_ptr(c->online), *target = uni_ptr(c->target), *grad = uni_ptr(c->grad), *xs = uni_ptr(c->xs), *xs2 = uni_ptr(c->xs2),
+          *dumps = uni_ptr(c->dumps);
+    const float prelu = unif(c->prelu);
+    (void)bufA; (void)bufB; (void)sm_w1t; (void)sm_bias; (void)sm_wh; (void)sm_bh; (void)qv; (void)Vb; (void)Advb; (void)dq; (void)dAdv;
+    (void)online; (void)target; (void)grad; (void)xs; (void)xs2; (void)dumps; (void)prelu;
+    auto dump_of = [&](int which, int blk) { return wc_dump(dumps, which, blk); };
+    float r[64];
+    f32x16 acc[4];
+    StageRegs sr;
+    const int blk = wave & 3;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {                      // Wv1, Wa1, W3, W2
+        const int oWt = q == 0 ? oWv1t : (q == 1 ? oWa1t : (q == 2 ? oW3t : oW2t));
+        const int ob = q == 0 ? obv1 : (q == 1 ? oba1 : (q == 2 ? ob3 : ob2));
+        stage_load_transposed(online + oWt, L, sr);
+        if (wave < 4) {
+            // upstream gradient block dz (lane = sample, register = unit)
+            if (q < 2) {
+                const gf4 *hd = (const gf4 *)dump_of(q == 0 ? D_V1 : D_A1, blk) + L.lane;
+                const int i = 32 * blk + L.li;
+                const float dqi = dq[i];
+                float da[A];
+#pragma unroll
+                for (int aa = 0; aa < A; ++aa) da[aa] = dAdv[i * A + aa];
+#pragma unroll
+                for (int pc = 0; pc < 16; ++pc) {            // piece (jt, g) = 16 B of the dump = units 32 jt + 8 g + 4 h + c
+                    const f32x4 hv = hd[pc * 64];
+                    const lfloat *whp = (const lfloat *)sm_wh + (32 * (pc >> 2) + 8 * (pc & 3) + 4 * L.h) * 4;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const f32x4 wk = *(const lf4 *)(whp + 4 * cc);      // (wv2, wa2_0, wa2_1, wa2_2)[unit]
+                        float up;
+                        if (q == 0) up = fma32(dqi, wk[0], 0.0f);
+                        else {
+                            up = 0.0f;
+#pragma unroll
+                            for (int aa = 0; aa < A; ++aa) up = fma32(da[aa], wk[1 + aa], up);
+                        }
+                        r[4 * pc + cc] = act_bwd(ACT, prelu, hv[cc], up);
+                    }
+                }
+            } else dump_load(dump_of(q == 2 ? S_DFEAT : S_DH2, blk), L, r);
+            tile_to_image(bufB, blk, L, r);
+            tile_to_operand(r);
+        }
+        stage_store_transposed(bufA, L, sr);
+        __syncthreads();
+        if (wave < 4) {
+            acc_zero(acc);
+            chain128(bufA, L, r, acc);
+            // epilogue, 16 bytes at a time: q 0: f1 = acc -> S_F1; q 1: d_feat = f1 + acc (epi_store, then epi_accum: old + new)
+            // -> S_DFEAT; q 2 / 3: d_h = act'(h) * acc -> S_DH2 / S_DH1
+            const gf4 *src = (const gf4 *)dump_of(q == 1 ? S_F1 : (q == 2 ? D_H2 : D_H1), blk) + L.lane;
+            gf4 *dst = (gf4 *)dump_of(q == 0 ? S_F1 : (q == 1 ? S_DFEAT : (q == 2 ? S_DH2 : S_DH1)), blk) + L.lane;
+#pragma unroll
+            for (int pc = 0; pc < 16; ++pc) {
+                f32x4 o;
+                if (q == 0) {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) o[cc] = acc[pc >> 2][4 * (pc & 3) + cc];
+                } else {
+                    const f32x4 hv = src[pc * 64];
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const float g = acc[pc >> 2][4 * (pc & 3) + cc];
+                        o[cc] = q == 1 ? hv[cc] + g : act_bwd(ACT, prelu, hv[cc], g);
+                    }
+                }
+                dst[pc * 64] = o;
+            }
+        } else {
+            // the idle half: bias gradient of this layer (column sums of the dz image) and, once, the head output layer
+            if (tid < 256 + W) grad[ob + (tid - 256)] = image_colsum(bufB, tid - 256, B);
+            if (q == 0) {
+                const int o = (tid - 256) >> 7 & 1, k = tid & 127;               // waves 4,5: o = 0; waves 6,7: o = 1
+                // gWh[k][0] = sum_i dq[i] v1[i][k];  gWh[k][1+aa] = sum_i dAdv[i][aa] a1[i][k]   (i ascending)
+                for (int col = o; col < 1 + A; col += 2) {
+                    const float *dmp = dumps + (int64_t)(col == 0 ? D_V1 : D_A1) * 4 * BLK;
+                    float s = 0.0f;
+                    for (int i0 = 0; i0 < B; i0 += 8) {
+                        float hv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) hv[u] = dmp[((i0 + u) >> 5) * BLK + dump_index((i0 + u) & 31, k)];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) s = fma32(col == 0 ? dq[i0 + u] : dAdv[(i0 + u) * A + col - 1], hv[u], s);
+                    }
+                    grad[oWh + k * 4 + col] = s;
+                }
+                if (tid >= 256 && tid < 256 + 1 + A) {
+                    const int col = tid - 256;
+                    float s = 0.0f;
+                    for (int i = 0; i < B; ++i) s = s + (col == 0 ? dq[i] : dAdv[i * A + col - 1]);
+                    grad[obh + col] = s;
+                }
+            }
+        }
+        __syncthreads();
+        if (wave < 4) {                                // image of the layer's input: feat, feat, h2, h1
+            dump_load(dump_of(q < 2 ? D_FEAT : (q == 2 ? D_H2 : D_H1), blk), L, r);
+            tile_to_image(bufA, blk, L, r);
+        }
+        __syncthreads();
+        wgrad_tiles(bufA, bufB, B, L, grad + oWt);
+        __syncthreads();
+    }
+    // layer 1: gW1t[k][j] = sum_i x[i][k] d_h1[i][j], gb1 = column sums of d_h1
+    if (wave < 4) {
+        dump_load(dump_of(S_DH1, blk), L, r);
+        tile_to_image(bufB, blk, L, r);
+    }
+    for (int e = tid; e < B * S; e += NT) qv[e] = xs[e];                  // the minibatch states (qv is free after the TD step)
+    __syncthreads();
+    {
+        const int j = tid & 127, kq = tid >> 7;
+        const lfloat *img = (const lfloat *)bufB;
+        for (int k = kq; k < S; k += 4) {
+            float s = 0.0f;
+            for (int i0 = 0; i0 < B; i0 += 8) {
+                float dv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dv[u] = img[(i0 + u) * W + (j ^ (u << 2))];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s = fma32(dv[u], qv[(i0 + u) * S + k], s);
+            }
+            grad[oW1t + k * W + j] = s;
+        }
+        if (tid >= 384) grad[ob1 + j] = image_colsum(bufB, j, B);
+    }
+    __syncthreads();
+}
+
+template <int SHAPE>
+__global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
+{
+    using namespace wcp;
+    extern __shared__ __align__(16) float lds[];
+    constexpr WcShape SP = kWcShapes[SHAPE];
+    constexpr int S = SP.S, A = SP.A, K = S + A, Hse = SP.Hse, T = SP.T, B = WC_B, ACT = SP.q_act;
+    static_assert(S % 2 == 0 && S <= 8 && A <= 3 && T <= 32 && Hse <= 128, "shape limits of the wave-chain kernel");
+    const lenv_ddqn_cfg &cfg = a.cfg;
+    Lane L;
+    L.init();
+    const int tid = L.tid, wave = L.wave;
+    const int64_t chain = blockIdx.x;
+    const float prelu = cfg.q_prelu;
+
+    // ---- LDS carve-up ----
+    float *bufA = lds, *bufB = bufA + IMG;
+    float *sm_w1t = bufB + IMG;                           // [8][128]
+    float *sm_bias = sm_w1t + 8 * W;                      // [5][128]: b1 b2 b3 bv1 ba1
+    float *sm_wh = sm_bias + 5 * W;                       // [128][4]
+    float *sm_bh = sm_wh + 4 * W;                         // [4] (+4 pad)
+    float *se_wout = sm_bh + 8;                           // [S+2][Hse]
+    float *se_bout = se_wout + (S + 2) * Hse;             // [16]
+    float *se_h = se_bout + 16;                           // [3][Hse]
+    constexpr int RBH = B > T ? B : T;
+    float *qv = se_h + 3 * Hse;                           // [3][B][A]
+    float *Vb = qv + 3 * RBH * A;                         // [3][RBH]
+    float *Advb = Vb + 3 * RBH;                           // [3][RBH][A]
+    float *dq = Advb + 3 * RBH * A;                       // [B]
+    float *dAdv = dq + B;                                 // [B][A]
+    float *misc = dAdv + B * A;                           // [64]
+    double *dstate = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(misc + 64) + 7) & ~(uintptr_t)7);   // [T][4]
+    double *ret = dstate + 4 * T;                         // [T]
+    float *ep_rew = reinterpret_cast<float *>(ret + T);   // [T]
+    int *alive = reinterpret_cast<int *>(ep_rew + T);     // [T]
+    float *state = reinterpret_cast<float *>(alive + T);  // [8]
+    float *newrow = state + 8;                            // [16]
+    int *tlen = reinterpret_cast<int *>(newrow + 16);     // [T]
+    WcCtx *ctx = reinterpret_cast<WcCtx *>((reinterpret_cast<uintptr_t>(tlen + T) + 15) & ~(uintptr_t)15);
+    volatile float *ctrl = misc;
+    volatile int *ictrl = reinterpret_cast<volatile int *>(misc + 32);
+
+    float *arena = a.arena + chain * a.arena_stride;
+    float *online = arena + a.a_par, *target = online + PW, *adam_m = target + PW, *adam_v = adam_m + PW, *grad = adam_v + PW;
+    float *xs = arena + a.a_xs, *xs2 = arena + a.a_xs2, *dumps = arena + a.a_dump, *rb = arena + a.a_replay;
+    float *se_w0T = arena + a.a_se, *se_b0 = se_w0T + 3 * K * Hse;        // [3][K][Hse], [3][Hse]
+    double *meter = reinterpret_cast<double *>(arena + a.a_meter);
+    const int RS = a.RS;
+    auto dump_of = [&](int which, int blk) { return dumps + ((int64_t)which * 4 + blk) * BLK; };
+
+    // ---- stage the perturbed SE (GTN_worker.py:165-175): first layers transposed into the arena, output layers into LDS ----
+    {
+        const float sg = a.eps ? a.sign[chain] : 0.0f;
+        const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P_se : nullptr;
+        for (int i = tid; i < a.P_se; i += NT) {
+            const float w = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
+            int net = 0, r = i;
+            if (r >= a.se_net_size[0]) { r -= a.se_net_size[0]; net = 1; if (r >= a.se_net_size[1]) { r -= a.se_net_size[1]; net = 2; } }
+            const int orow = net == 0 ? 0 : (net == 1 ? S : S + 1);
+            if (r < Hse * K) { int j = r / K, k = r - j * K; se_w0T[(net * K + k) * Hse + j] = w; }
+            else if ((r -= Hse * K) < Hse) se_b0[net * Hse + r] = w;
+            else {
+                r -= Hse;
+                const int n_out = net == 0 ? S : 1;
+                if (r < n_out * Hse) { int o = r / Hse, j = r - o * Hse; se_wout[(orow + o) * Hse + j] = w; }
+                else se_bout[orow + (r - n_out * Hse)] = w;
+            }
+        }
+    }
+    // ---- fresh agent (DuelingDDQN.py:31-36): arena layout, Adam state and gradient (incl. the zero rows of W1t) cleared ----
+    for (int p = tid; p < PW; p += NT) { online[p] = 0.0f; target[p] = 0.0f; adam_m[p] = 0.0f; adam_v[p] = 0.0f; grad[p] = 0.0f; }
+    __syncthreads();
+    for (int p = tid; p < a.P; p += NT) {
+        const float w = a.agent_init[chain * a.P + p];
+        const int q = wc_sd_to_arena(p, S, A);
+        online[q] = w; target[q] = w;
+    }
+    if (tid < 64) misc[tid] = 0.0f;
+    if (tid == 0) {
+        WcCtx cx{ bufA, bufB, sm_w1t, sm_bias, sm_wh, sm_bh, qv, Vb, Advb, dq, dAdv, online, target, grad, xs, xs2, dumps, ctrl, prelu };
+        *ctx = cx;
+    }
+    __syncthreads();
+
+    const uint64_t key = a.rng_keys[chain];
+    constexpr int env_id = SP.env;
+    int status = 0;
+    WPT_DECL;
+    int train_steps = 0, n_act = 0, learn_it = 0, n_test_ep = 0, test_steps = 0, episodes_run = 0;
+    double eps_g = cfg.eps_init, b1pow = 1.0, b2pow = 1.0;
+    const int rb_cap = (int)a.rb_cap;
+
+    // q_out[I][A] from the head outputs of `slot` (models/actor_critic.py:117-122; learn: mean over ALL I*A advantages)
+    auto finish_q = [&](int slot, int I, float *q_out, bool global_mean) {
+        const float *Vs = Vb + slot * RBH, *As = Advb + slot * RBH * A;
+        if (global_mean) {
+            if (tid == 0) {
+                float sum = 0.0f;
+                for (int e = 0; e < I * A; ++e) sum = sum + As[e];
+                ctrl[8] = sum / (float)(I * A);
+            }
+            __syncthreads();
+            const float mean = ctrl[8];
+            for (int e = tid; e < I * A; e += NT) q_out[e] = Vs[e / A] + (As[e] - mean);
+        } else {
+            for (int i = tid; i < I; i += NT) {
+                float sum = 0.0f;
+                for (int aa = 0; aa < A; ++aa) sum = sum + As[i * A + aa];
+                const float mean = sum / (float)A;
+                for (int aa = 0; aa < A; ++aa) q_out[i * A + aa] = Vs[i] + (As[i * A + aa] - mean);
+            }
+        }
+        __syncthreads();
+    };
+
+    auto forward_thin = [&](const float *X, int I) {      // I <= 32 rows through the ONLINE net -> qv (per-row advantage mean)
+        wc_forward_thin_layers<SHAPE>(ctx, X, I);
+        finish_q(0, I, qv, false);
+    };
+
+    // ---- real-env test phase: T episodes in lock-step (BaseAgent.test, agents/base_agent.py:155-227) ----
+    auto test_phase = [&]() {
+        if (tid < T) {
+            double st[4];
+            real_env_reset_draw(env_id, key, STREAM_TEST_RESET, (int64_t)n_test_ep + tid, st);
+            for (int i = 0; i < 4; ++i) dstate[tid * 4 + i] = st[i];
+            ep_rew[tid] = 0.0f; alive[tid] = 1; tlen[tid] = 0;
+        }
+        if (tid == 0) ictrl[0] = 0;
+        __syncthreads();
+        float *xt = xs2;
+        for (int t = 0; t < cfg.max_steps; ++t) {
+            if (tid < T) { float obs[8]; real_env_obs(env_id, dstate + tid * 4, obs); for (int i = 0; i < S; ++i) xt[tid * S + i] = obs[i]; }
+            __syncthreads();
+            forward_thin(xt, T);
+            if (tid < T && alive[tid]) {
+                int am = 0; float best = qv[tid * A];
+                for (int aa = 1; aa < A; ++aa) { const float v = qv[tid * A + aa]; if (v > best) { best = v; am = aa; } }
+                double st[4] = { dstate[tid * 4], dstate[tid * 4 + 1], dstate[tid * 4 + 2], dstate[tid * 4 + 3] };
+                double rew; int dn;
+                real_env_step(env_id, st, am, rew, dn);
+                for (int i = 0; i < 4; ++i) dstate[tid * 4 + i] = st[i];
+                ep_rew[tid] = ep_rew[tid] + (float)rew;
+                tlen[tid] = tlen[tid] + 1;
+                atomicAdd(const_cast<int *>(&ictrl[0]), 1);
+                if (dn) alive[tid] = 0;
+            }
+            __syncthreads();
+            int any = 0;
+            for (int e = 0; e < T; ++e) any |= alive[e];
+            if (!any) break;
+        }
+        if (tid < T) ret[tid] = (double)ep_rew[tid];
+        n_test_ep += T;
+        __syncthreads();
+        test_steps += ictrl[0];
+        __syncthreads();
+    };
+
+    const bool budgeted = cfg.step_budget > 0;
+    int timed_out_at = -1;
+    for (int episode = 0; episode < cfg.train_episodes; ++episode) {
+        if (budgeted && (int64_t)train_steps + test_steps > cfg.step_budget) { timed_out_at = episode; break; }
+        if (episode == 0) eps_g = cfg.eps_init;
+        else { eps_g *= cfg.eps_decay; if (eps_g < cfg.eps_min) eps_g = cfg.eps_min; }
+        const bool learning = episode >= cfg.init_episodes;
+        if (tid == 0) {
+            double st0[4];
+            real_env_reset_draw(env_id, key, STREAM_TRAIN_RESET, episode, st0);
+            float obs[8];
+            real_env_obs(env_id, st0, obs);
+            for (int i = 0; i < S; ++i) state[i] = obs[i];
+        }
+        __syncthreads();
+        int ep_len = 0;
+        for (int t = 0; t < cfg.max_steps; ++t) {
+            WPT_MARK(9);
+            const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
+            const int new_pos = train_steps % rb_cap;
+            if (tid == 0) {                                // select_train_action (DuelingDDQN.py:96-103)
+                const double u = u64_to_unit(rng_u64(key, STREAM_EPS, (uint64_t)train_steps));
+                int explored = u < eps_g, action = -1;
+                if (explored) action = (int)u64_to_below(rng_u64(key, STREAM_ACTION, (uint64_t)n_act), (uint32_t)A);
+                ictrl[1] = explored; ictrl[2] = action;
+            }
+            __syncthreads();
+            const int explored = ictrl[1];
+            if (explored) ++n_act;
+            if (!explored) {
+                for (int i = tid; i < S; i += NT) xs2[i] = state[i];
+                __syncthreads();
+                forward_thin(xs2, 1);
+                if (tid == 0) {
+                    int am = 0; float best = qv[0];
+                    for (int aa = 1; aa < A; ++aa) if (qv[aa] > best) { best = qv[aa]; am = aa; }
+                    ictrl[2] = am;
+                }
+                __syncthreads();
+            }
+            const int action = ictrl[2];
+            WPT_MARK(0);
+            // ---- EnvWrapper.step -> VirtualEnv.step: x = [onehot(action), state] ----
+            for (int uu = tid; uu < 3 * Hse; uu += NT) {
+                const int net = uu / Hse, j = uu - net * Hse;
+                const float *w = se_w0T + net * K * Hse + j;
+                float wk[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) wk[k] = w[k * Hse];
+                float z = 0.0f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) z = fma32(k < A ? (k == action ? 1.0f : 0.0f) : state[k - A], wk[k], z);
+                z = z + se_b0[uu];
+                se_h[uu] = act_fwd(SP.se_act, cfg.se_prelu, z);
+            }
+            __syncthreads();
+            if (tid < S + 2) {
+                const int net = tid < S ? 0 : (tid == S ? 1 : 2);
+                const float *h = se_h + net * Hse, *w = se_wout + tid * Hse;
+                float acc = 0.0f;
+                for (int j = 0; j < Hse; ++j) acc = fma32(h[j], w[j], acc);
+                acc = acc + se_bout[tid];
+                if (tid < S) newrow[S + 1 + tid] = acc; else newrow[2 * S + 1 + (tid - S)] = acc;
+            }
+            if (tid >= 64 && tid < 64 + S) newrow[tid - 64] = state[tid - 64];
+            if (tid == 128) newrow[S] = (float)action;
+            __syncthreads();
+            if (tid < 2 * S + 3) rb[(int64_t)new_pos * RS + tid] = newrow[tid];
+            const float done_now = newrow[2 * S + 2];
+            __syncthreads();
+            if (tid < S) state[tid] = newrow[S + 1 + tid];
+            ++ep_len; ++train_steps;
+            __syncthreads();
+            WPT_MARK(1);
+
+            if (learning) {
+                // ================= DuelingDDQN.learn (DuelingDDQN.py:59-94) =================
+                for (int b = tid; b < B; b += NT) {
+                    const int64_t n = (int64_t)learn_it * B + b;
+                    const int idx = (int)rng_replay_below(key, (uint64_t)n, (uint32_t)size_after);
+                    const float *row = rb + (int64_t)idx * RS;
+                    for (int i = 0; i < S; ++i) { xs[b * S + i] = row[i]; xs2[b * S + i] = row[S + 1 + i]; }
+                    dAdv[b * A + 0] = row[S];
+                    dAdv[b * A + 1] = row[2 * S + 1];
+                    dq[b] = row[2 * S + 2];
+                }
+                __syncthreads();
+                WPT_MARK(2);
+#ifndef WC_DIAG_NO_FWD
+#pragma unroll 1
+                for (int pass = 0; pass < 2; ++pass) wc_forward_big<SHAPE>(ctx, pass);      // target net on s'; online net on s (stored) and s'
+#endif
+                finish_q(1, B, qv + B * A, true);
+                finish_q(2, B, qv + 2 * B * A, true);
+                finish_q(0, B, qv, true);
+                WPT_MARK(3);
+                for (int b = tid; b < B; b += NT) {        // TD error (DuelingDDQN.py:80-85)
+                    const float g32 = (float)cfg.gamma, norm = (float)(2.0 / (double)B);
+                    const int ab = (int)dAdv[b * A + 0];
+                    const float rr = dAdv[b * A + 1], d = dq[b];
+                    int am = 0; float best = qv[(B + b) * A];
+                    for (int aa = 1; aa < A; ++aa) { const float v = qv[(B + b) * A + aa]; if (v > best) { best = v; am = aa; } }
+                    const float t1 = g32 * qv[(2 * B + b) * A + am];
+                    const float t2 = 1.0f - d;
+                    const float y = rr + t1 * t2;
+                    dq[b] = norm * (qv[b * A + ab] - y);
+                    Vb[b] = (float)ab;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    float s_dq = 0.0f;
+                    for (int b = 0; b < B; ++b) s_dq = s_dq + dq[b];
+                    ctrl[9] = (-s_dq) / (float)(B * A);
+                    b1pow *= cfg.adam_beta1; b2pow *= cfg.adam_beta2;
+                    ctrl[10] = (float)(-(cfg.lr / (1.0 - b1pow)));
+                    ctrl[11] = (float)__builtin_sqrt(1.0 - b2pow);
+                }
+                __syncthreads();
+                {
+                    const float mean_grad = ctrl[9];
+                    for (int e = tid; e < B * A; e += NT) {
+                        const int b = e / A, aa = e - b * A;
+                        const float g = aa == (int)Vb[b] ? dq[b] : 0.0f;
+                        dAdv[e] = g + mean_grad;
+                    }
+                }
+                __syncthreads();
+                WPT_MARK(4);
+#ifndef WC_DIAG_NO_BWD
+                wc_backward_big<SHAPE>(ctx);
+#endif
+                WPT_MARK(6);
+                {
+                    const float neg_step = ctrl[10], bc2_sqrt = ctrl[11];
+                    const float w1 = (float)(1.0 - cfg.adam_beta1), w2 = (float)(1.0 - cfg.adam_beta2), beta2 = (float)cfg.adam_beta2;
+                    const float adam_eps = (float)cfg.adam_eps, tau = (float)cfg.tau, omt = (float)(1.0 - cfg.tau);
+                    const AdamConsts ac{ neg_step, bc2_sqrt, w1, w2, beta2, adam_eps };
+                    wg_adam(online, adam_m, adam_v, grad, 0, PW, ac, target, tau, omt);
+                }
+                ++learn_it;
+                __syncthreads();
+                WPT_MARK(7);
+            }
+            if (done_now > 0.5f) break;
+        }
+        ++episodes_run;
+        if (tid == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
+        __syncthreads();
+        WPT_MARK(9);
+        test_phase();
+        WPT_MARK(8);
+        if (tid == 0) {
+            double sm = 0.0;
+            for (int i = 0; i < T; ++i) sm += ret[i];
+            const double tm = sm / (double)T;
+            meter[episode] = tm;
+            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
+            int brk = 0;
+            if (learning) {
+                int lo = episode + 1 - cfg.early_out_num; if (lo < 0) lo = 0;
+                double s2 = 0.0;
+                for (int i = lo; i <= episode; ++i) s2 += meter[i];
+                if (s2 / ((double)(episode + 1 - lo) + 1e-9) >= cfg.solved_reward) brk = 1;
+            }
+            ictrl[3] = brk;
+        }
+        __syncthreads();
+        const int brk = ictrl[3];
+        __syncthreads();
+        if (brk) break;
+    }
+    WPT_MARK(9);
+    const int64_t remaining = cfg.step_budget - ((int64_t)train_steps + test_steps);
+    const int test_before = test_steps;
+    test_phase();
+    if (budgeted) {
+        if (tid == 0) {
+            int64_t used = 0;
+            int stop = T;
+            for (int te = 0; te < T; ++te) {
+                if (used > remaining) { stop = te; break; }
+                used += tlen[te];
+            }
+            double mn = -1e9;
+            if (stop > 0) { mn = ret[0]; for (int i = 1; i < stop; ++i) if (ret[i] < mn) mn = ret[i]; }
+            for (int te = stop; te < T; ++te) ret[te] = mn;
+            ictrl[4] = (int)used;
+        }
+        __syncthreads();
+        test_steps = test_before + ictrl[4];
+    }
+    WPT_MARK(8);
+#ifdef LENV_PHASE_TIMING
+    if (tid == 0 && chain == 0) for (int pi = 0; pi < 12; ++pi) g_wc_phase_cycles[pi] = pt_acc[pi];
+#endif
+    if (tid == 0) {
+        double sm = 0.0;
+        for (int i = 0; i < T; ++i) sm += ret[i];
+        a.out.score[chain] = sm / (double)T;
+        if (a.out.final_returns) for (int i = 0; i < T; ++i) a.out.final_returns[chain * T + i] = ret[i];
+        if (a.out.stats) {
+            a.out.stats[chain * 4 + 0] = episodes_run; a.out.stats[chain * 4 + 1] = train_steps;
+            a.out.stats[chain * 4 + 2] = learn_it; a.out.stats[chain * 4 + 3] = test_steps;
+        }
+        double pad_r = __builtin_nan("");
+        int pad_l = 0;
+        if (timed_out_at >= 0) {
+            pad_r = -1e9; pad_l = 1000000000;
+            if (episodes_run > 0) { pad_r = meter[0]; for (int i = 1; i < episodes_run; ++i) if (meter[i] < pad_r) pad_r = meter[i]; }
+            if (episodes_run > 0 && a.out.episode_len) {
+                pad_l = a.out.episode_len[chain * cfg.train_episodes];
+                for (int i = 1; i < episodes_run; ++i) { const int l = a.out.episode_len[chain * cfg.train_episodes + i]; if (l > pad_l) pad_l = l; }
+            }
+        }
+        for (int e = episodes_run; e < cfg.train_episodes; ++e) {
+            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + e] = pad_r;
+            if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = pad_l;
+        }
+    }
+    if (a.out.final_online) for (int p = tid; p < a.P; p += NT) a.out.final_online[chain * a.P + p] = online[wc_sd_to_arena(p, S, A)];
+    if (a.out.status && status != 0) atomicMin(&a.out.status[chain], status);
+}
+
+}  // namespace lenv
+
+using namespace lenv;
+
+// Host side (internal linkage to the library: declared in lenv_wavechain_host.h): called by lenv_dueling_se_inner_loop_icm
+// (dueling_se_inner_loop.hip) for launches whose shape and mode the wave-chain kernel covers.  Returns 0 when `cfg` is not one of its shapes.
+int lenv_wc_dueling_shape(const lenv_ddqn_cfg *cfg)
+{
+    for (int s = 1; s < (int)(sizeof(kWcShapes) / sizeof(kWcShapes[0])); ++s) {
+        const WcShape &sp = kWcShapes[s];
+        if (cfg->agent_kind == 1 && cfg->env_id == sp.env && cfg->state_dim == sp.S && cfg->num_actions == sp.A && cfg->feature_dim == WC_H &&
+            cfg->q_hidden == WC_H && cfg->q_layers == 2 && cfg->batch_size == WC_B && cfg->se_hidden == sp.Hse && cfg->se_layers == 1 &&
+            cfg->test_episodes == sp.T && cfg->q_act == sp.q_act && cfg->se_act == sp.se_act && cfg->synthetic_env_type == 0 && !cfg->icm_enabled)
+            return s;
+    }
+    return 0;
+}
+
+static size_t wc_lds_bytes(const WcShape &sp)
+{
+    const int S = sp.S, A = sp.A, Hse = sp.Hse, T = sp.T, B = WC_B, RBH = B > T ? B : T;
+    size_t f = 2 * (size_t)wc::IMG + 8 * wc::W + 5 * wc::W + 4 * wc::W + 8 + (size_t)(S + 2) * Hse + 16 + 3 * (size_t)Hse + 3 * (size_t)RBH * A +
+               3 * (size_t)RBH + 3 * (size_t)RBH * A + B + (size_t)B * A + 64 + 2 + 2 * (4 * (size_t)T + T) + 2 * (size_t)T + 8 + 16 + T + 4 + (sizeof(WcCtx) + 3) / 4;
+    return f * sizeof(float);
+}
+
+// floats of one chain's arena in the wave-chain layout (the workspace query of the generic path takes the maximum of both)
+int64_t lenv_wc_dueling_arena_floats(const lenv_ddqn_cfg *cfg, int shape, int64_t rb_cap, int RS, int P_se)
+{
+    const WcShape &sp = kWcShapes[shape];
+    const int S = sp.S, B = WC_B, T = sp.T, K = sp.S + sp.A;
+    int64_t off = 0;
+    auto take = [&](int64_t n) { int64_t r = off; off += (n + 3) & ~(int64_t)3; return r; };
+    take(5 * (int64_t)wcp::PW); take((int64_t)B * S); take((int64_t)(B > T ? B : T) * S); take((int64_t)WC_NDUMP * 4 * wc::BLK);
+    take(3 * (int64_t)(K + 1) * sp.Hse); take(rb_cap * RS); take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
+    (void)P_se;
+    return (off + 63) & ~(int64_t)63;
+}
+
+int lenv_wc_dueling_launch(int shape, const lenv_ddqn_cfg *cfg, const float *theta, const float *eps, const int32_t *worker,
+                                      const float *sign, const float *agent_init, const uint64_t *rng_keys, int64_t chains, float *arena,
+                                      int64_t arena_stride, int64_t rb_cap, int RS, int P, int P_se, const int *se_net_size,
+                                      const lenv_inner_out *out, hipStream_t stream)
+{
+    const WcShape &sp = kWcShapes[shape];
+    WcArgs a;
+    a.cfg = *cfg;
+    a.theta = theta; a.eps = eps; a.worker = worker; a.sign = sign; a.agent_init = agent_init; a.rng_keys = rng_keys;
+    a.arena = arena; a.arena_stride = arena_stride; a.out = *out; a.rb_cap = rb_cap; a.RS = RS; a.P = P; a.P_se = P_se;
+    for (int i = 0; i < 3; ++i) a.se_net_size[i] = se_net_size[i];
+    const int S = sp.S, B = WC_B, T = sp.T, K = sp.S + sp.A;
+    int64_t off = 0;
+    auto take = [&](int64_t n) { int64_t r = off; off += (n + 3) & ~(int64_t)3; return r; };
+    a.a_par = take(5 * (int64_t)wcp::PW); a.a_xs = take((int64_t)B * S); a.a_xs2 = take((int64_t)(B > T ? B : T) * S);
+    a.a_dump = take((int64_t)WC_NDUMP * 4 * wc::BLK); a.a_se = take(3 * (int64_t)(K + 1) * sp.Hse); a.a_replay = take(rb_cap * RS);
+    a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
+    if (off > arena_stride) return LENV_ERR_WORKSPACE;
+    const size_t lds_bytes = wc_lds_bytes(sp);
+    if (lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
+    void (*kern)(const WcArgs) = dueling_wavechain_kernel<1>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+        return LENV_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)chains), dim3(wc::NT), lds_bytes, stream, a);
+    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}
+
+#ifdef LENV_PHASE_TIMING
+extern "C" int lenv_debug_wc_phase_cycles(unsigned long long *host_out)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_wc_phase_cycles), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;
+}
+#endif

@@ -1,0 +1,271 @@
+// lenv_wavechain.cuh -- "wave-chain" building blocks for the 128-wide MLPs of the big-net agents (DuelingDDQN / TD3) on gfx950.
+//
+// The GEMM-queue routine (lenv_gemm.cuh) treats every Linear of every pass as an independent product: operands staged from the
+// HBM arena through LDS, outputs written back, five barriers each -- about 11 k cycles of fixed cost per product and 64 KB of
+// weights re-staged for every pass that shares them.  Here the unit of work is a BLOCK OF 32 SAMPLES OWNED BY ONE WAVE:
+//
+//   * the product is computed transposed, out^T[unit][sample] = sum_k W[unit][k] * in^T[k][sample], on v_mfma_f32_32x32x2_f32
+//     (bit for bit a k-ascending fmaf chain = the canonical order of oracle/lenv_oracle.h): the A operand is the weight matrix,
+//     read from an LDS image that ALL waves share (staged once per layer and pass), the B operand is the wave's own activation
+//     block held in 64 VGPRs;
+//   * the 32x32 result tiles (lane = sample, register = unit) become the next layer's B operand with 32 v_permlane32_swap --
+//     activations never leave the register file between the layers of a pass; what the backward pass needs is dumped to the
+//     HBM arena in register order (16-byte stores, 1 KB per wave instruction) and read back by the same lanes;
+//   * weight gradients (a reduction over the samples) read two LDS images, [sample][unit] of the upstream gradient and
+//     [sample][unit] of the layer input, written from the register tiles with 16-byte stores;
+//   * thin products (the 1-row greedy action and the T-row lock-step test forward) take their A operand straight from the
+//     K-major weight arrays in the arena (coalesced, each weight read once) and exchange activations through a 16 KB image.
+//
+// LDS images are 128 x 128 floats without padding; element (row r, col c) sits at r*128 + (c ^ 4*(r & 7)): the XOR keeps
+// 16-byte groups intact, makes the tile -> image stores (8 lanes = 8 rows per LDS cycle) and the transposing weight stores
+// conflict-free, and leaves the MFMA operand reads (32 consecutive columns of one row) a permutation of the 32 banks.
+#pragma once
+
+#include "lenv_gemm.cuh"
+
+namespace lenv {
+namespace wc {
+
+constexpr int NT = 512, NW = 8;           // threads / waves per chain
+constexpr int W = 128;                    // units per layer = rows and columns of an image
+constexpr int IMG = W * W;                // floats per image (64 KB)
+constexpr int BLK = 32 * W;               // floats of one wave's register dump of a [32 samples x 128 units] block
+
+typedef __attribute__((address_space(1))) f32x4 gf4;
+typedef __attribute__((address_space(3))) f32x4 lf4;
+
+__device__ __forceinline__ int img_pos(int r, int c) { return r * W + (c ^ ((r & 7) << 2)); }
+
+struct Lane {
+    int tid, lane, wave, li, h;
+    int colsw[4];                         // swizzled column (li) of rows 2t+h with (t & 3) = q
+    __device__ __forceinline__ void init()
+    {
+        tid = (int)threadIdx.x; lane = tid & 63; wave = uni(tid >> 6); li = lane & 31; h = lane >> 5;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) colsw[q] = li ^ ((2 * q + h) << 2);
+    }
+};
+
+// register index of the B operand of k-step t (k = 2t, 2t+1) inside a [4 tiles x 16] register block after tile_to_operand
+__device__ __forceinline__ constexpr int breg_of(int t) { return (t & ~3) | ((t & 1) << 1) | ((t >> 1) & 1); }
+
+// D layout of a 32x32 tile: lane (sample li, half h), register v -> unit 8*(v/4) + 4*h + v%4.  After the swaps register
+// 4g+{0,2,1,3} holds, in its lower / upper lane half, units (8g, 8g+1), (8g+2, 8g+3), (8g+4, 8g+5), (8g+6, 8g+7): the B operand
+// of four consecutive k-steps (see breg_of).
+__device__ __forceinline__ void tile_to_operand(float (&r)[64])
+{
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+        const int a = 2 * p, b = 2 * p + 1;                    // (4g, 4g+1) and (4g+2, 4g+3)
+        auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(r[a]), __float_as_uint(r[b]), false, false);
+        r[a] = __uint_as_float(s[0]); r[b] = __uint_as_float(s[1]);
+    }
+}
+
+// acc[jt] += sum over 64 k-steps: A = image rows 2t+h (all 128 columns = 4 tiles), B = the wave's operand registers
+__device__ __forceinline__ void chain128(const float *img_, const Lane &L, const float (&b)[64], f32x16 (&acc)[4])
+{
+    const lfloat *img = (const lfloat *)img_;
+    const lfloat *ab[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ab[q] = img + L.h * W + L.colsw[q];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[t & 3][2 * t * W + 32 * jt], b[breg_of(t)], acc[jt], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[4])
+{
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[jt][v] = 0.0f;
+}
+
+// r[16 jt + 4 g + c] = acc[jt][4 g + c] + bias[32 jt + 8 g + 4 h + c]  (bias: 128 floats in LDS), optional ReLU-family activation
+template <int ACT>
+__device__ __forceinline__ void tile_bias_act(const f32x16 (&acc)[4], const float *bias_, const Lane &L, float prelu, float (&r)[64])
+{
+    const lfloat *bias = (const lfloat *)bias_;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *(const lf4 *)(bias + 32 * jt + 8 * g + 4 * L.h);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float z = acc[jt][4 * g + c] + bv[c];
+                if (ACT == LENV_ACT_RELU) z = z > 0.0f ? z : 0.0f;
+                else if (ACT == LENV_ACT_LEAKYRELU) z = z > 0.0f ? z : z * 0.01f;
+                else if (ACT == LENV_ACT_PRELU) z = z > 0.0f ? z : prelu * z;
+                else if (ACT == LENV_ACT_TANH) z = det_tanhf(lenv_tanh_table, z);
+                r[16 * jt + 4 * g + c] = z;
+            }
+        }
+}
+
+// register dump of a block: piece (jt, g) of lane l at dump[((4 jt + g) * 64 + l) * 4 .. +3]
+__device__ __forceinline__ void dump_store(float *dump, const Lane &L, const float (&r)[64])
+{
+    gf4 *d = (gf4 *)dump + L.lane;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) d[p * 64] = f32x4{r[4 * p], r[4 * p + 1], r[4 * p + 2], r[4 * p + 3]};
+}
+__device__ __forceinline__ void dump_load(const float *dump, const Lane &L, float (&r)[64])
+{
+    const gf4 *d = (const gf4 *)dump + L.lane;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const f32x4 v = d[p * 64];
+        r[4 * p] = v[0]; r[4 * p + 1] = v[1]; r[4 * p + 2] = v[2]; r[4 * p + 3] = v[3];
+    }
+}
+// element (sample i of the block, unit u) of a dump: for the few consumers that walk a dump unit-wise (head weight gradients)
+__device__ __forceinline__ int dump_index(int i, int u) { return ((((u >> 5) * 4 + ((u >> 3) & 3)) * 64 + i + 32 * ((u >> 2) & 1)) << 2) + (u & 3); }
+
+// [sample][unit] image rows 32 blk .. 32 blk + 31 from a register block (D layout): 16 conflict-free 16-byte stores
+__device__ __forceinline__ void tile_to_image(float *img_, int blk, const Lane &L, const float (&r)[64])
+{
+    lfloat *img = (lfloat *)img_;
+    const int row = 32 * blk + L.li;
+    lfloat *base = img + row * W;
+    const int sw = (row & 7) << 2;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = (32 * jt + 8 * g + 4 * L.h) ^ sw;
+            *(lf4 *)(base + col) = f32x4{r[16 * jt + 4 * g], r[16 * jt + 4 * g + 1], r[16 * jt + 4 * g + 2], r[16 * jt + 4 * g + 3]};
+        }
+}
+
+// ---- weight images.  The arena keeps every 128x128 matrix K-MAJOR: Wt[k][unit] (so the forward image is a straight copy and the
+// thin products read it coalesced); the input-gradient products reduce over the units and need image[unit][k] = the transpose.
+struct StageRegs { f32x4 v[8]; };
+
+// straight copy: piece p = tid + 512 u -> row p >> 5, float4 column p & 31
+__device__ __forceinline__ void stage_load_direct(const float *Wt, const Lane &L, StageRegs &s)
+{
+    const gf4 *src = (const gf4 *)Wt + L.tid;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s.v[u] = src[u * NT];
+}
+__device__ __forceinline__ void stage_store_direct(float *img_, const Lane &L, const StageRegs &s)
+{
+    lfloat *img = (lfloat *)img_;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int p = L.tid + u * NT, r = p >> 5, c = (p & 31) << 2;
+        *(lf4 *)(img + r * W + (c ^ ((r & 7) << 2))) = s.v[u];
+    }
+}
+// transposing copy: a wave instruction takes 16 rows k x 4 float4 columns (units 4 c4 .. 4 c4 + 3) of Wt and writes image rows
+// (units) 4 c4 + cc, column k: 2-way bank conflicts at most (free for ds_write_b32)
+__device__ __forceinline__ void stage_load_transposed(const float *Wt, const Lane &L, StageRegs &s)
+{
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        // wave w, instruction u: k block = (w & 7), c4 block = u  -> k = 16 w + lane / 4, c4 = 4 u + lane % 4
+        const int k = 16 * L.wave + (L.lane >> 2), c4 = 4 * u + (L.lane & 3);
+        s.v[u] = *((const gf4 *)Wt + k * 32 + c4);
+    }
+}
+__device__ __forceinline__ void stage_store_transposed(float *img_, const Lane &L, const StageRegs &s)
+{
+    lfloat *img = (lfloat *)img_;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = 16 * L.wave + (L.lane >> 2), c4 = 4 * u + (L.lane & 3);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int r = 4 * c4 + cc;
+            img[r * W + (k ^ ((r & 7) << 2))] = s.v[u][cc];
+        }
+    }
+}
+
+// out[j] = sum_i image[i][j] (i ascending, plain adds): the bias gradient of a layer from the [sample][unit] image of its
+// upstream gradient; one thread per unit
+__device__ __forceinline__ float image_colsum(const float *img_, int j, int rows)
+{
+    const lfloat *img = (const lfloat *)img_;
+    float s = 0.0f;
+    for (int i0 = 0; i0 < rows; i0 += 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = img[(i0 + u) * W + (j ^ (u << 2))];      // (i0 + u) & 7 == u: i0 is a multiple of 8
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = s + x[u];
+    }
+    return s;
+}
+
+// Weight gradient of a 128 -> 128 layer: gWt[k][j] = sum_i in[i][k] * dz[i][j] (i ascending over `rows` samples, rows even).
+// A = image of the layer input (rows i, columns k), B = image of the upstream gradient (rows i, columns j); wave w owns the
+// tiles (kt = w / 2, jt = 2 (w % 2) + {0, 1}).  Output rows are 128-byte segments of the K-major gradient array.
+__device__ __forceinline__ void wgrad_tiles(const float *img_in_, const float *img_dz_, int rows, const Lane &L, float *gWt)
+{
+    const lfloat *img_in = (const lfloat *)img_in_, *img_dz = (const lfloat *)img_dz_;
+    const int kt = L.wave >> 1, jt0 = (L.wave & 1) << 1;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { acc0[v] = 0.0f; acc1[v] = 0.0f; }
+    const lfloat *pa[4], *pb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { pa[q] = img_in + L.h * W + 32 * kt + L.colsw[q]; pb[q] = img_dz + L.h * W + 32 * jt0 + L.colsw[q]; }
+    const int steps = rows >> 1;                               // rows is a multiple of 8 here (whole sample blocks)
+#pragma unroll 2
+    for (int t4 = 0; t4 < steps; t4 += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a = pa[q][2 * (t4 + q) * W];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[q][2 * (t4 + q) * W], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[q][2 * (t4 + q) * W + 32], acc1, 0, 0, 0);
+        }
+    }
+    gfloat *out = (gfloat *)gWt + (32 * kt + 4 * L.h) * W + 32 * jt0 + L.li;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int r = 8 * (v >> 2) + (v & 3);
+        out[r * W] = acc0[v];
+        out[r * W + 32] = acc1[v];
+    }
+}
+
+// ---- thin products: I <= 32 samples, activations in [unit][32] images (hT[k * 32 + sample]) ----
+// wave w < 4 computes units 32 w .. 32 w + 31 of out^T = act(Wt^T . in^T + bias): A straight from the K-major array in the arena
+// (lane (unit li, half h) reads Wt[(2t+h) * 128 + 32 w + li]: two 128-byte segments per instruction, every weight read once)
+template <int ACT>
+__device__ __forceinline__ void thin_layer(const float *Wt, const float *bias, const float *in_img_, float *out_img_, int jt, const Lane &L, float prelu)
+{
+    const lfloat *in_img = (const lfloat *)in_img_;
+    lfloat *out_img = (lfloat *)out_img_;
+    const gfloat *wa = (const gfloat *)Wt + L.h * W + 32 * jt + L.li;
+    const lfloat *xb = in_img + L.h * 32 + L.li;
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+#pragma unroll 16
+    for (int t = 0; t < 64; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * t * W], xb[2 * t * 32], acc, 0, 0, 0);
+    const gfloat *bg = (const gfloat *)bias + 32 * jt + 4 * L.h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *(const gf4 *)(bg + 8 * g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float z = acc[4 * g + c] + bv[c];
+            if (ACT == LENV_ACT_RELU) z = z > 0.0f ? z : 0.0f;
+            else if (ACT == LENV_ACT_LEAKYRELU) z = z > 0.0f ? z : z * 0.01f;
+            else if (ACT == LENV_ACT_PRELU) z = z > 0.0f ? z : prelu * z;
+            else if (ACT == LENV_ACT_TANH) z = det_tanhf(lenv_tanh_table, z);
+            out_img[(32 * jt + 8 * g + 4 * L.h + c) * 32 + L.li] = z;
+        }
+    }
+}
+
+}  // namespace wc
+}  // namespace lenv
