@@ -34,7 +34,9 @@ constexpr int oW1t = 0, ob1 = 8 * W, oW2t = ob1 + W, ob2 = oW2t + IMG, oW3t = ob
 static_assert(PW % 4 == 0, "float4 passes");
 }
 
-enum { D_H1 = 0, D_H2, D_FEAT, D_V1, D_A1, S_F1, S_DFEAT, S_DH2, S_DH1, WC_NDUMP };
+enum { D_H1 = 0, D_H2, D_FEAT, D_V1, D_A1, S_F1, S_DFEAT, S_DH2, S_DH1,
+       R_V1, R_A1,          // v1 / a1 once more as plain [sample][unit] arrays: the head weight gradients walk them unit-wise
+       WC_NDUMP };
 
 struct WcArgs {
     lenv_ddqn_cfg cfg;
@@ -84,9 +86,10 @@ __device__ __forceinline__ int wc_sd_to_arena(int p, int S, int A)
 // computes them where it uses them and the register file belongs to the MFMA chains.
 struct WcCtx {
     float *bufA, *bufB, *sm_w1t, *sm_bias, *sm_wh, *sm_bh, *qv, *Vb, *Advb, *dq, *dAdv;
-    float *online, *target, *grad, *xs, *xs2, *dumps;
+    float *online, *target, *grad, *xs, *xs2, *dumps, *adam_m, *adam_v;
     volatile float *ctrl;
     float prelu;
+    float w1, w2, beta2, adam_eps, tau, omt;            // Adam / Polyak constants (torch single-tensor Adam, DuelingDDQN.py:87-93)
 };
 
 template <class T> __device__ __forceinline__ T *lds_uni_ptr(T *const *field) { return uni_ptr(*field); }
@@ -94,12 +97,18 @@ template <class T> __device__ __forceinline__ T *lds_uni_ptr(T *const *field) { 
 __device__ __forceinline__ float *wc_dump(float *dumps, int which, int blk) { return dumps + ((int64_t)which * 4 + blk) * BLK; }
 
 #ifdef LENV_PHASE_TIMING
-__device__ unsigned long long g_wc_phase_cycles[16];
+__device__ unsigned long long g_wc_phase_cycles[64];      // [0,16): kernel phases; [16,64): sub-phases inside the out-of-line routines (chain 0)
+#define WSUB_DECL unsigned long long sp_last = __builtin_readcyclecounter()
+#define WSUB_MARK(i) do { unsigned long long sp_now = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) g_wc_phase_cycles[i] += sp_now - sp_last; sp_last = sp_now; } while (0)
+#define WSUB_MARK4(i) do { unsigned long long sp_now = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 256) g_wc_phase_cycles[i] += sp_now - sp_last; sp_last = sp_now; } while (0)
 #define WPT_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define WPT_MARK(i) do { unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
 #else
 #define WPT_DECL
 #define WPT_MARK(i)
+#define WSUB_DECL
+#define WSUB_MARK(i)
+#define WSUB_MARK4(i)
 #endif
 
 
@@ -119,15 +128,29 @@ template <int SHAPE> __device__ __noinline__ void wc_forward_thin_layers(const W
     float *bufA = uni_ptr(c->bufA), *bufB = uni_ptr(c->bufB), *sm_w1t = uni_ptr(c->sm_w1t), *sm_bias = uni_ptr(c->sm_bias), *sm_wh = uni_ptr(c->sm_wh),
           *sm_bh = uni_ptr(c->sm_bh), *qv = uni_ptr(c->qv), *Vb = uni_ptr(c->Vb), *Advb = uni_ptr(c->Advb), *dq = uni_ptr(c->dq), *dAdv = uni_ptr(c->dAdv);
     float *online = uni_ptr(c->online), *target = uni_ptr(c->target), *grad = uni_ptr(c->grad), *xs = uni_ptr(c->xs), *xs2 = uni_ptr(c->xs2),
-          *dumps = uni_ptr(c->dumps);
+          *dumps = uni_ptr(c->dumps), *adam_m = uni_ptr(c->adam_m), *adam_v = uni_ptr(c->adam_v);
     const float prelu = unif(c->prelu);
+    (void)adam_m; (void)adam_v;
     (void)bufA; (void)bufB; (void)sm_w1t; (void)sm_bias; (void)sm_wh; (void)sm_bh; (void)qv; (void)Vb; (void)Advb; (void)dq; (void)dAdv;
     (void)online; (void)target; (void)grad; (void)xs; (void)xs2; (void)dumps; (void)prelu;
+    // LDS arrays through address-space-3 pointers: a generic pointer makes every access a FLAT instruction, which the hardware
+    // completes out of order with respect to both counters -- each one then waits for every global load in flight
+    lfloat *qv_l = (lfloat *)qv, *Vb_l = (lfloat *)Vb, *Advb_l = (lfloat *)Advb, *dq_l = (lfloat *)dq, *dAdv_l = (lfloat *)dAdv, *sm_wh_l = (lfloat *)sm_wh,
+           *sm_bh_l = (lfloat *)sm_bh;
+    (void)qv_l; (void)Vb_l; (void)Advb_l; (void)dq_l; (void)dAdv_l; (void)sm_wh_l; (void)sm_bh_l;
     const float *X = uni_ptr(X_);
     const int I = uni(I_);
-    float *imgX = bufA, *imgY = bufA + 32 * W, *imgZ = bufA + 64 * W;      // thin-product activation images [unit][32]
+    float *imgX = bufA;                                  // thin-product activation images [unit][16 or 32] live in bufA
     auto dump_of = [&](int which, int blk) { return wc_dump(dumps, which, blk); };
-    {   // layer 1 (K = S): one thread per (unit, sample)
+    WSUB_DECL;
+    constexpr int IW = T <= 16 ? 16 : 32;               // samples per image row (the 16x16x4 tiles take up to 16)
+    float *imgY = bufA + IW * W, *imgZ = bufA + 2 * IW * W;
+    float a2[32], a3[32], av[32], aa[32];                // this wave's weight tiles of the four 128x128 layers
+    if constexpr (IW == 16) {
+        thin_load16(online + oW2t, wave, L, a2); thin_load16(online + oW3t, wave, L, a3);
+        thin_load16(online + oWv1t, wave, L, av); thin_load16(online + oWa1t, wave, L, aa);
+    }
+    {   // layer 1 (K = S): one thread per (unit, sample); the head output layer's weights go to LDS alongside
         const int j = tid & (W - 1);
         float w[S];
 #pragma unroll
@@ -137,30 +160,46 @@ template <int SHAPE> __device__ __noinline__ void wc_forward_thin_layers(const W
             float z = 0.0f;
 #pragma unroll
             for (int k = 0; k < S; ++k) z = fma32(X[i * S + k], w[k], z);
-            imgX[j * 32 + i] = act_fwd(ACT, prelu, z + bj);
+            ((lfloat *)imgX)[j * IW + i] = act_fwd(ACT, prelu, z + bj);
         }
+        for (int e = tid; e < 4 * W + 4; e += NT) sm_wh_l[e] = online[oWh + e];
     }
     __syncthreads();
-    if (wave < 4) thin_layer<ACT>(online + oW2t, online + ob2, imgX, imgY, wave, L, prelu);
+    WSUB_MARK(24);
+    if constexpr (IW == 16) {
+        thin_layer16<ACT, 1>(a2, online + ob2, imgY, a2, nullptr, nullptr, imgX, wave, L, prelu);
+        __syncthreads();
+        WSUB_MARK(25);
+        thin_layer16<LENV_ACT_IDENTITY, 1>(a3, online + ob3, imgX, a3, nullptr, nullptr, imgY, wave, L, prelu);
+        __syncthreads();
+        WSUB_MARK(26);
+        thin_layer16<ACT, 2>(av, online + obv1, imgY, aa, online + oba1, imgZ, imgX, wave, L, prelu);
+    } else {
+        if (wave < 4) thin_layer<ACT>(online + oW2t, online + ob2, imgX, imgY, wave, L, prelu);
+        __syncthreads();
+        WSUB_MARK(25);
+        if (wave < 4) thin_layer<LENV_ACT_IDENTITY>(online + oW3t, online + ob3, imgY, imgX, wave, L, prelu);
+        __syncthreads();
+        WSUB_MARK(26);
+        if (wave < 4) thin_layer<ACT>(online + oWv1t, online + obv1, imgX, imgY, wave, L, prelu);
+        else thin_layer<ACT>(online + oWa1t, online + oba1, imgX, imgZ, wave - 4, L, prelu);
+    }
     __syncthreads();
-    if (wave < 4) thin_layer<LENV_ACT_IDENTITY>(online + oW3t, online + ob3, imgY, imgX, wave, L, prelu);
-    __syncthreads();
-    if (wave < 4) thin_layer<ACT>(online + oWv1t, online + obv1, imgX, imgY, wave, L, prelu);
-    else thin_layer<ACT>(online + oWa1t, online + oba1, imgX, imgZ, wave - 4, L, prelu);
-    __syncthreads();
+    WSUB_MARK(27);
     if (tid < 4 * I) {
         const int i = tid >> 2, o = tid & 3;
         if (o <= A) {
-            const float *img = o == 0 ? imgY : imgZ;
-            const float *wh = online + oWh + o;
+            const lfloat *img = (const lfloat *)(o == 0 ? imgY : imgZ) + i;
+            const lfloat *wh = (const lfloat *)sm_wh + o;
             float acc = 0.0f;
-#pragma unroll 8
-            for (int k = 0; k < W; ++k) acc = fma32(img[k * 32 + i], wh[k * 4], acc);
-            acc = acc + online[obh + o];
-            if (o == 0) Vb[i] = acc; else Advb[i * A + (o - 1)] = acc;
+#pragma unroll 16
+            for (int k = 0; k < W; ++k) acc = fma32(img[k * IW], wh[k * 4], acc);
+            acc = acc + sm_bh_l[o];
+            if (o == 0) Vb_l[i] = acc; else Advb_l[i * A + (o - 1)] = acc;
         }
     }
     __syncthreads();
+    WSUB_MARK(28);
 }
 
 // ---- one pass of Critic_DuelingDQN over sample blocks: pass 0 = target net on s' (waves 0-3 -> slot 2), pass 1 = online net on
@@ -180,24 +219,32 @@ template <int SHAPE> __device__ __noinline__ void wc_forward_big(const WcCtx *ct
     float *bufA = uni_ptr(c->bufA), *bufB = uni_ptr(c->bufB), *sm_w1t = uni_ptr(c->sm_w1t), *sm_bias = uni_ptr(c->sm_bias), *sm_wh = uni_ptr(c->sm_wh),
           *sm_bh = uni_ptr(c->sm_bh), *qv = uni_ptr(c->qv), *Vb = uni_ptr(c->Vb), *Advb = uni_ptr(c->Advb), *dq = uni_ptr(c->dq), *dAdv = uni_ptr(c->dAdv);
     float *online = uni_ptr(c->online), *target = uni_ptr(c->target), *grad = uni_ptr(c->grad), *xs = uni_ptr(c->xs), *xs2 = uni_ptr(c->xs2),
-          *dumps = uni_ptr(c->dumps);
+          *dumps = uni_ptr(c->dumps), *adam_m = uni_ptr(c->adam_m), *adam_v = uni_ptr(c->adam_v);
     const float prelu = unif(c->prelu);
+    (void)adam_m; (void)adam_v;
     (void)bufA; (void)bufB; (void)sm_w1t; (void)sm_bias; (void)sm_wh; (void)sm_bh; (void)qv; (void)Vb; (void)Advb; (void)dq; (void)dAdv;
     (void)online; (void)target; (void)grad; (void)xs; (void)xs2; (void)dumps; (void)prelu;
+    // LDS arrays through address-space-3 pointers: a generic pointer makes every access a FLAT instruction, which the hardware
+    // completes out of order with respect to both counters -- each one then waits for every global load in flight
+    lfloat *qv_l = (lfloat *)qv, *Vb_l = (lfloat *)Vb, *Advb_l = (lfloat *)Advb, *dq_l = (lfloat *)dq, *dAdv_l = (lfloat *)dAdv, *sm_wh_l = (lfloat *)sm_wh,
+           *sm_bh_l = (lfloat *)sm_bh;
+    (void)qv_l; (void)Vb_l; (void)Advb_l; (void)dq_l; (void)dAdv_l; (void)sm_wh_l; (void)sm_bh_l;
     const int pass = uni(pass_);
     auto dump_of = [&](int which, int blk) { return wc_dump(dumps, which, blk); };
     const float *par = pass ? online : target;
-    for (int i = tid; i < 8 * W; i += NT) sm_w1t[i] = par[oW1t + i];
+    for (int i = tid; i < 8 * W; i += NT) ((lfloat *)sm_w1t)[i] = par[oW1t + i];
     for (int i = tid; i < 5 * W; i += NT) {
         const int l = i >> 7, j = i & 127;
         const int off = l == 0 ? ob1 : (l == 1 ? ob2 : (l == 2 ? ob3 : (l == 3 ? obv1 : oba1)));
-        sm_bias[i] = par[off + j];
+        ((lfloat *)sm_bias)[i] = par[off + j];
     }
-    for (int i = tid; i < 4 * W + 4; i += NT) sm_wh[i] = par[oWh + i];       // Wh and bh are contiguous in both places
+    for (int i = tid; i < 4 * W + 4; i += NT) sm_wh_l[i] = par[oWh + i];       // Wh and bh are contiguous in both places
     StageRegs sr;
+    WSUB_DECL;
     stage_load_direct(par + oW2t, L, sr);
     stage_store_direct(bufA, L, sr);
     __syncthreads();
+    WSUB_MARK(32);
     const bool active = pass == 1 || wave < 4;
     const bool stored = pass == 1 && wave < 4;
     const int blk = wave & 3, slot = pass == 0 ? 2 : (wave < 4 ? 0 : 1);
@@ -229,6 +276,12 @@ template <int SHAPE> __device__ __noinline__ void wc_forward_big(const WcCtx *ct
             if (l == 1) tile_bias_act<LENV_ACT_IDENTITY>(acc, sm_bias + 2 * W, L, prelu, r);
             else tile_bias_act<ACT>(acc, sm_bias + (l == 0 ? 1 : (l == 2 ? 3 : 4)) * W, L, prelu, r);
             if (stored) dump_store(dump_of(l == 0 ? D_H2 : (l == 1 ? D_FEAT : (l == 2 ? D_V1 : D_A1)), blk), L, r);
+            if (stored && l >= 2) {                     // row-major copy for the head output layer's weight gradient
+                gfloat *rm = (gfloat *)dump_of(l == 2 ? R_V1 : R_A1, 0) + (32 * blk + L.li) * W + 4 * L.h;
+#pragma unroll
+                for (int pc = 0; pc < 16; ++pc)
+                    *(gf4 *)(rm + 32 * (pc >> 2) + 8 * (pc & 3)) = f32x4{r[4 * pc], r[4 * pc + 1], r[4 * pc + 2], r[4 * pc + 3]};
+            }
             tile_to_operand(r);
             if (l < 2) {
 #pragma unroll
@@ -244,16 +297,17 @@ template <int SHAPE> __device__ __noinline__ void wc_forward_big(const WcCtx *ct
                 for (int t = 0; t < 64; ++t) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[2 * t * 4], r[breg_of(t)], hacc, 0, 0, 0);
                 if (L.h == 0) {
                     const int row = 32 * blk + L.li;
-                    if (l == 2) Vb[slot * RBH + row] = hacc[0] + sm_bh[0];
+                    if (l == 2) Vb_l[slot * RBH + row] = hacc[0] + sm_bh_l[0];
                     else {
 #pragma unroll
-                        for (int aa = 0; aa < A; ++aa) Advb[slot * RBH * A + row * A + aa] = hacc[aa] + sm_bh[1 + aa];
+                        for (int aa = 0; aa < A; ++aa) Advb_l[slot * RBH * A + row * A + aa] = hacc[aa] + sm_bh_l[1 + aa];
                     }
                 }
             }
         }
         if (l < 3) stage_store_direct(nxt, L, sr);
         __syncthreads();
+        WSUB_MARK(33 + l);
     }
 }
 
@@ -273,29 +327,61 @@ template <int SHAPE> __device__ __noinline__ void wc_backward_big(const WcCtx *c
     float *bufA = uni_ptr(c->bufA), *bufB = uni_ptr(c->bufB), *sm_w1t = uni_ptr(c->sm_w1t), *sm_bias = uni_ptr(c->sm_bias), *sm_wh = uni_ptr(c->sm_wh),
           *sm_bh = uni_ptr(c->sm_bh), *qv = uni_ptr(c->qv), *Vb = uni_ptr(c->Vb), *Advb = uni_ptr(c->Advb), *dq = uni_ptr(c->dq), *dAdv = uni_ptr(c->dAdv);
     float *online = uni_ptr(c->online), *target = uni_ptr(c->target), *grad = uni_ptr(c->grad), *xs = uni_ptr(c->xs), *xs2 = uni_ptr(c->xs2),
-          *dumps = uni_ptr(c->dumps);
+          *dumps = uni_ptr(c->dumps), *adam_m = uni_ptr(c->adam_m), *adam_v = uni_ptr(c->adam_v);
     const float prelu = unif(c->prelu);
+    (void)adam_m; (void)adam_v;
     (void)bufA; (void)bufB; (void)sm_w1t; (void)sm_bias; (void)sm_wh; (void)sm_bh; (void)qv; (void)Vb; (void)Advb; (void)dq; (void)dAdv;
     (void)online; (void)target; (void)grad; (void)xs; (void)xs2; (void)dumps; (void)prelu;
+    // LDS arrays through address-space-3 pointers: a generic pointer makes every access a FLAT instruction, which the hardware
+    // completes out of order with respect to both counters -- each one then waits for every global load in flight
+    lfloat *qv_l = (lfloat *)qv, *Vb_l = (lfloat *)Vb, *Advb_l = (lfloat *)Advb, *dq_l = (lfloat *)dq, *dAdv_l = (lfloat *)dAdv, *sm_wh_l = (lfloat *)sm_wh,
+           *sm_bh_l = (lfloat *)sm_bh;
+    (void)qv_l; (void)Vb_l; (void)Advb_l; (void)dq_l; (void)dAdv_l; (void)sm_wh_l; (void)sm_bh_l;
     auto dump_of = [&](int which, int blk) { return wc_dump(dumps, which, blk); };
     float r[64];
     f32x16 acc[4];
     StageRegs sr;
     const int blk = wave & 3;
+    // torch.optim.Adam + the Polyak update run INSIDE the backward pass: the first half of layer q-1's matrix is updated by the
+    // idle half of the workgroup while waves 0-3 run layer q's input-gradient chain (an element-wise pass bound by HBM / L2
+    // latency next to a product bound by the matrix pipe), the rest at the end; element-wise, so the schedule changes no bit
+    // (ctrl[10], ctrl[11]: this step's bias corrections)
+    volatile float *ctrl = uni_ptr(c->ctrl);
+    const AdamConsts ac{ ctrl[10], ctrl[11], unif(c->w1), unif(c->w2), unif(c->beta2), unif(c->adam_eps) };
+    const float tau = unif(c->tau), omt = unif(c->omt);
+    WSUB_DECL;
+    {   // head output layer, one element of gWh per thread (i ascending): gWh[k][0] = sum_i dq[i] v1[i][k], gWh[k][1+aa] = sum_i
+        // dAdv[i][aa] a1[i][k], from the row-major copies of v1 / a1 (coalesced along k)
+        const int k = tid & 127, col = tid >> 7;
+        if (col <= A) {
+            const gfloat *rm = (const gfloat *)dump_of(col == 0 ? R_V1 : R_A1, 0) + k;
+            float s = 0.0f;
+            for (int i0 = 0; i0 < B; i0 += 64) {
+                float hv[64];                          // 64 row reads in flight, then the ordered chain
+#pragma unroll
+                for (int u = 0; u < 64; ++u) hv[u] = rm[(i0 + u) * W];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) s = fma32(col == 0 ? dq_l[i0 + u] : dAdv_l[(i0 + u) * A + col - 1], hv[u], s);
+            }
+            grad[oWh + k * 4 + col] = s;
+        }
+    }
+    WSUB_MARK(22);
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {                      // Wv1, Wa1, W3, W2
         const int oWt = q == 0 ? oWv1t : (q == 1 ? oWa1t : (q == 2 ? oW3t : oW2t));
         const int ob = q == 0 ? obv1 : (q == 1 ? oba1 : (q == 2 ? ob3 : ob2));
+        L.refresh();
         stage_load_transposed(online + oWt, L, sr);
         if (wave < 4) {
             // upstream gradient block dz (lane = sample, register = unit)
             if (q < 2) {
                 const gf4 *hd = (const gf4 *)dump_of(q == 0 ? D_V1 : D_A1, blk) + L.lane;
                 const int i = 32 * blk + L.li;
-                const float dqi = dq[i];
+                const float dqi = dq_l[i];
                 float da[A];
 #pragma unroll
-                for (int aa = 0; aa < A; ++aa) da[aa] = dAdv[i * A + aa];
+                for (int aa = 0; aa < A; ++aa) da[aa] = dAdv_l[i * A + aa];
 #pragma unroll
                 for (int pc = 0; pc < 16; ++pc) {            // piece (jt, g) = 16 B of the dump = units 32 jt + 8 g + 4 h + c
                     const f32x4 hv = hd[pc * 64];
@@ -319,70 +405,76 @@ template <int SHAPE> __device__ __noinline__ void wc_backward_big(const WcCtx *c
         }
         stage_store_transposed(bufA, L, sr);
         __syncthreads();
+        WSUB_MARK(16);
+        L.refresh();
         if (wave < 4) {
+            // the epilogue's operand (f1, h2 or h1 dump) is requested before the chain: its latency hides behind the 256 MFMAs
+            const gf4 *src = (const gf4 *)dump_of(q == 1 ? S_F1 : (q == 2 ? D_H2 : D_H1), blk) + L.lane;
+            f32x4 hv[16];
+#pragma unroll
+            for (int pc = 0; pc < 16; ++pc) hv[pc] = src[pc * 64];      // (q 0 reads and ignores the h1 dump: no conditional array)
             acc_zero(acc);
             chain128(bufA, L, r, acc);
+            WSUB_MARK(40);
             // epilogue, 16 bytes at a time: q 0: f1 = acc -> S_F1; q 1: d_feat = f1 + acc (epi_store, then epi_accum: old + new)
             // -> S_DFEAT; q 2 / 3: d_h = act'(h) * acc -> S_DH2 / S_DH1
-            const gf4 *src = (const gf4 *)dump_of(q == 1 ? S_F1 : (q == 2 ? D_H2 : D_H1), blk) + L.lane;
             gf4 *dst = (gf4 *)dump_of(q == 0 ? S_F1 : (q == 1 ? S_DFEAT : (q == 2 ? S_DH2 : S_DH1)), blk) + L.lane;
 #pragma unroll
             for (int pc = 0; pc < 16; ++pc) {
                 f32x4 o;
-                if (q == 0) {
 #pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) o[cc] = acc[pc >> 2][4 * (pc & 3) + cc];
-                } else {
-                    const f32x4 hv = src[pc * 64];
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        const float g = acc[pc >> 2][4 * (pc & 3) + cc];
-                        o[cc] = q == 1 ? hv[cc] + g : act_bwd(ACT, prelu, hv[cc], g);
-                    }
+                for (int cc = 0; cc < 4; ++cc) {
+                    const float g = acc[pc >> 2][4 * (pc & 3) + cc];
+                    o[cc] = q == 0 ? g : (q == 1 ? hv[pc][cc] + g : act_bwd(ACT, prelu, hv[pc][cc], g));
                 }
                 dst[pc * 64] = o;
             }
+            WSUB_MARK(41);
         } else {
-            // the idle half: bias gradient of this layer (column sums of the dz image) and, once, the head output layer
+            // the idle half: bias gradient of this layer (column sums of the dz image), half of the previous layer's optimizer step
+            // (raised priority: next to an MFMA-paced wave on the same SIMD an un-prioritised VALU / memory wave only gets the
+            // left-over issue slots and ran 4-5x slower than alone; the chain needs one issue slot per 64 cycles)
+            __builtin_amdgcn_s_setprio(3);
             if (tid < 256 + W) grad[ob + (tid - 256)] = image_colsum(bufB, tid - 256, B);
+            WSUB_MARK4(44);
             if (q == 0) {
-                const int o = (tid - 256) >> 7 & 1, k = tid & 127;               // waves 4,5: o = 0; waves 6,7: o = 1
-                // gWh[k][0] = sum_i dq[i] v1[i][k];  gWh[k][1+aa] = sum_i dAdv[i][aa] a1[i][k]   (i ascending)
-                for (int col = o; col < 1 + A; col += 2) {
-                    const float *dmp = dumps + (int64_t)(col == 0 ? D_V1 : D_A1) * 4 * BLK;
-                    float s = 0.0f;
-                    for (int i0 = 0; i0 < B; i0 += 8) {
-                        float hv[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) hv[u] = dmp[((i0 + u) >> 5) * BLK + dump_index((i0 + u) & 31, k)];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) s = fma32(col == 0 ? dq[i0 + u] : dAdv[(i0 + u) * A + col - 1], hv[u], s);
-                    }
-                    grad[oWh + k * 4 + col] = s;
-                }
                 if (tid >= 256 && tid < 256 + 1 + A) {
                     const int col = tid - 256;
                     float s = 0.0f;
-                    for (int i = 0; i < B; ++i) s = s + (col == 0 ? dq[i] : dAdv[i * A + col - 1]);
+                    for (int i = 0; i < B; ++i) s = s + (col == 0 ? dq_l[i] : dAdv_l[i * A + col - 1]);
                     grad[obh + col] = s;
                 }
             }
+            WSUB_MARK4(45);
+            if (q >= 1) {                                  // first half of layer q-1's matrix: its gradient is complete, the chain hides the pass
+                const int oPrev = q == 1 ? oWv1t : (q == 2 ? oWa1t : oW3t);
+                wg_adam_t(online, adam_m, adam_v, grad, oPrev, IMG / 2, ac, target, tau, omt, tid - 256, 256);
+            }
+            WSUB_MARK4(46);
+            __builtin_amdgcn_s_setprio(0);
+            WSUB_MARK4(46);
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
+        WSUB_MARK(17);
+        L.refresh();
         if (wave < 4) {                                // image of the layer's input: feat, feat, h2, h1
             dump_load(dump_of(q < 2 ? D_FEAT : (q == 2 ? D_H2 : D_H1), blk), L, r);
             tile_to_image(bufA, blk, L, r);
         }
         __syncthreads();
+        WSUB_MARK(18);
+        L.refresh();
         wgrad_tiles(bufA, bufB, B, L, grad + oWt);
         __syncthreads();
+        WSUB_MARK(19);
     }
     // layer 1: gW1t[k][j] = sum_i x[i][k] d_h1[i][j], gb1 = column sums of d_h1
     if (wave < 4) {
         dump_load(dump_of(S_DH1, blk), L, r);
         tile_to_image(bufB, blk, L, r);
     }
-    for (int e = tid; e < B * S; e += NT) qv[e] = xs[e];                  // the minibatch states (qv is free after the TD step)
+    for (int e = tid; e < B * S; e += NT) qv_l[e] = xs[e];                  // the minibatch states (qv is free after the TD step)
     __syncthreads();
     {
         const int j = tid & 127, kq = tid >> 7;
@@ -394,13 +486,21 @@ template <int SHAPE> __device__ __noinline__ void wc_backward_big(const WcCtx *c
 #pragma unroll
                 for (int u = 0; u < 8; ++u) dv[u] = img[(i0 + u) * W + (j ^ (u << 2))];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) s = fma32(dv[u], qv[(i0 + u) * S + k], s);
+                for (int u = 0; u < 8; ++u) s = fma32(dv[u], qv_l[(i0 + u) * S + k], s);
             }
             grad[oW1t + k * W + j] = s;
         }
         if (tid >= 384) grad[ob1 + j] = image_colsum(bufB, j, B);
     }
     __syncthreads();
+    WSUB_MARK(20);
+    // what is left of the optimizer step
+    wg_adam_t(online, adam_m, adam_v, grad, oW1t, ob2 + W - oW1t, ac, target, tau, omt, tid, NT);                 // W1t b1 W2t b2
+    wg_adam_t(online, adam_m, adam_v, grad, oW3t + IMG / 2, IMG / 2 + W, ac, target, tau, omt, tid, NT);          // second halves + biases
+    wg_adam_t(online, adam_m, adam_v, grad, oWv1t + IMG / 2, IMG / 2 + W, ac, target, tau, omt, tid, NT);
+    wg_adam_t(online, adam_m, adam_v, grad, oWa1t + IMG / 2, PW - (oWa1t + IMG / 2), ac, target, tau, omt, tid, NT);   // ... ba1 Wh bh
+    __syncthreads();
+    WSUB_MARK(21);
 }
 
 template <int SHAPE>
@@ -482,7 +582,9 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     }
     if (tid < 64) misc[tid] = 0.0f;
     if (tid == 0) {
-        WcCtx cx{ bufA, bufB, sm_w1t, sm_bias, sm_wh, sm_bh, qv, Vb, Advb, dq, dAdv, online, target, grad, xs, xs2, dumps, ctrl, prelu };
+        WcCtx cx{ bufA, bufB, sm_w1t, sm_bias, sm_wh, sm_bh, qv, Vb, Advb, dq, dAdv, online, target, grad, xs, xs2, dumps, adam_m, adam_v, ctrl, prelu,
+                  (float)(1.0 - cfg.adam_beta1), (float)(1.0 - cfg.adam_beta2), (float)cfg.adam_beta2, (float)cfg.adam_eps, (float)cfg.tau,
+                  (float)(1.0 - cfg.tau) };
         *ctx = cx;
     }
     __syncthreads();
@@ -694,14 +796,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                 wc_backward_big<SHAPE>(ctx);
 #endif
                 WPT_MARK(6);
-                {
-                    const float neg_step = ctrl[10], bc2_sqrt = ctrl[11];
-                    const float w1 = (float)(1.0 - cfg.adam_beta1), w2 = (float)(1.0 - cfg.adam_beta2), beta2 = (float)cfg.adam_beta2;
-                    const float adam_eps = (float)cfg.adam_eps, tau = (float)cfg.tau, omt = (float)(1.0 - cfg.tau);
-                    const AdamConsts ac{ neg_step, bc2_sqrt, w1, w2, beta2, adam_eps };
-                    wg_adam(online, adam_m, adam_v, grad, 0, PW, ac, target, tau, omt);
-                }
-                ++learn_it;
+                ++learn_it;                                // (optimizer step + Polyak update: inside wc_backward_big)
                 __syncthreads();
                 WPT_MARK(7);
             }
@@ -854,6 +949,6 @@ int lenv_wc_dueling_launch(int shape, const lenv_ddqn_cfg *cfg, const float *the
 #ifdef LENV_PHASE_TIMING
 extern "C" int lenv_debug_wc_phase_cycles(unsigned long long *host_out)
 {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_wc_phase_cycles), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_wc_phase_cycles), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -4;
 }
 #endif

@@ -509,20 +509,19 @@ __device__ __forceinline__ void adam_elem(float g, float &m, float &v, float &w,
 // torch.optim.Adam single-tensor step on [p0, p0+n) (+ optional Polyak update of `target` with the new parameter).
 // The body moves float4 pieces (the arena arrays are 16-byte aligned; 2 pieces x 5 arrays in flight per thread: the pass
 // is bound by the latency of one workgroup's loads, not by arithmetic); a misaligned head and the tail go element-wise.
-__device__ __forceinline__ void wg_adam(float *params, float *adam_m, float *adam_v, const float *grad, int p0, int n, const AdamConsts c,
-                                        float *target, float tau, float omt)
+__device__ __forceinline__ void wg_adam_t(float *params, float *adam_m, float *adam_v, const float *grad, int p0, int n, const AdamConsts c,
+                                          float *target, float tau, float omt, int tid, int nthreads)
 {
     typedef __attribute__((address_space(1))) f32x4 gf4;
     const int end = p0 + n;
     const int b0 = (p0 + 3) & ~3, b1 = end & ~3;           // float4 body [b0, b1)
-    const int tid = (int)threadIdx.x;
     if (b1 > b0) {
         const int npieces = (b1 - b0) >> 2;
-        for (int q0 = tid; q0 < npieces; q0 += 2 * DNT) {
+        for (int q0 = tid; q0 < npieces; q0 += 2 * nthreads) {
             f32x4 g[2], m[2], v[2], w[2], t[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int q = q0 + u * DNT;
+                const int q = q0 + u * nthreads;
                 const bool ok = q < npieces;
                 const int p = b0 + 4 * (ok ? q : q0);
                 g[u] = *((const gf4 *)(grad + p)); m[u] = *((const gf4 *)(adam_m + p));
@@ -539,7 +538,7 @@ __device__ __forceinline__ void wg_adam(float *params, float *adam_m, float *ada
                 }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int q = q0 + u * DNT;
+                const int q = q0 + u * nthreads;
                 if (q < npieces) {
                     const int p = b0 + 4 * q;
                     *((gf4 *)(adam_m + p)) = m[u]; *((gf4 *)(adam_v + p)) = v[u];
@@ -559,6 +558,12 @@ __device__ __forceinline__ void wg_adam(float *params, float *adam_m, float *ada
         adam_m[p] = m; adam_v[p] = v; params[p] = w;
         if (target) target[p] = t;
     }
+}
+
+__device__ __forceinline__ void wg_adam(float *params, float *adam_m, float *adam_v, const float *grad, int p0, int n, const AdamConsts c,
+                                        float *target, float tau, float omt)
+{
+    wg_adam_t(params, adam_m, adam_v, grad, p0, n, c, target, tau, omt, (int)threadIdx.x, DNT);
 }
 
 // target = tau * params + (1 - tau) * target on [0, n)

@@ -45,6 +45,16 @@ struct Lane {
 #pragma unroll
         for (int q = 0; q < 4; ++q) colsw[q] = li ^ ((2 * q + h) << 2);
     }
+    // Make the lane coordinates opaque to the optimiser at this point.  Every per-lane address of a phase (swizzled image slots,
+    // staging pieces, tile rows) is a function of them and of compile-time constants; without the cut LLVM treats the whole set as
+    // loop invariants of the enclosing layer loop, hoists it in front of the loop and spills it (100+ registers), where
+    // recomputing an address costs one or two VALU instructions next to its use.
+    __device__ __forceinline__ void refresh()
+    {
+        asm volatile("" : "+v"(tid), "+v"(lane), "+v"(li), "+v"(h));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) colsw[q] = li ^ ((2 * q + h) << 2);
+    }
 };
 
 // register index of the B operand of k-step t (k = 2t, 2t+1) inside a [4 tiles x 16] register block after tile_to_operand
@@ -194,12 +204,12 @@ __device__ __forceinline__ float image_colsum(const float *img_, int j, int rows
 {
     const lfloat *img = (const lfloat *)img_;
     float s = 0.0f;
-    for (int i0 = 0; i0 < rows; i0 += 8) {
-        float x[8];
+    for (int i0 = 0; i0 < rows; i0 += 32) {                // rows is a multiple of 32: 32 reads in flight, then the ordered adds
+        float x[32];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = img[(i0 + u) * W + (j ^ (u << 2))];      // (i0 + u) & 7 == u: i0 is a multiple of 8
+        for (int u = 0; u < 32; ++u) x[u] = img[(i0 + u) * W + (j ^ ((u & 7) << 2))];      // (i0 + u) & 7 == u & 7
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s = s + x[u];
+        for (int u = 0; u < 32; ++u) s = s + x[u];
     }
     return s;
 }
@@ -236,6 +246,59 @@ __device__ __forceinline__ void wgrad_tiles(const float *img_in_, const float *i
     }
 }
 
+// The same with torch.optim.Adam's step + the Polyak update of the target net applied to the tile right away (element-wise:
+// adam_elem is the routine wg_adam uses): the four state arrays of the tile are loaded BEFORE the MFMA loop, so their latency
+// hides behind it, and the gradient never makes the round trip through the arena.
+__device__ __forceinline__ void wgrad_tiles_adam(const float *img_in_, const float *img_dz_, int rows, const Lane &L, float *Wt, float *Mt, float *Vt,
+                                                 float *Tt, const AdamConsts c, float tau, float omt)
+{
+    const lfloat *img_in = (const lfloat *)img_in_, *img_dz = (const lfloat *)img_dz_;
+    const int kt = L.wave >> 1, jt0 = (L.wave & 1) << 1;
+    // uniform (SGPR) array bases + ONE 32-bit per-lane offset: the 128 element addresses of a lane differ by compile-time constants
+    const MemView<true> pw(Wt), pm(Mt), pv(Vt), pt(Tt);
+    const int off = (32 * kt + 4 * L.h) * W + 32 * jt0 + L.li;
+    // tile 0's state is loaded before the MFMA loop (latency hidden behind it), tile 1's while tile 0 is being updated
+    float w0[16], m0[16], v0[16], t0[16], w1[16], m1[16], v1[16], t1[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int o = off + (8 * (e >> 2) + (e & 3)) * W;
+        w0[e] = pw.ld(o); m0[e] = pm.ld(o); v0[e] = pv.ld(o); t0[e] = pt.ld(o);
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int x = 0; x < 16; ++x) { acc0[x] = 0.0f; acc1[x] = 0.0f; }
+    const lfloat *pa[4], *pb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { pa[q] = img_in + L.h * W + 32 * kt + L.colsw[q]; pb[q] = img_dz + L.h * W + 32 * jt0 + L.colsw[q]; }
+    const int steps = rows >> 1;
+#pragma unroll 2
+    for (int t4 = 0; t4 < steps; t4 += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a = pa[q][2 * (t4 + q) * W];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[q][2 * (t4 + q) * W], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[q][2 * (t4 + q) * W + 32], acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int o = off + (8 * (e >> 2) + (e & 3)) * W + 32;
+        w1[e] = pw.ld(o); m1[e] = pm.ld(o); v1[e] = pv.ld(o); t1[e] = pt.ld(o);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int o = off + (8 * (e >> 2) + (e & 3)) * W;
+        adam_elem(acc0[e], m0[e], v0[e], w0[e], t0[e], c, tau, omt);
+        pm.st(o, m0[e]); pv.st(o, v0[e]); pw.st(o, w0[e]); pt.st(o, t0[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int o = off + (8 * (e >> 2) + (e & 3)) * W + 32;
+        adam_elem(acc1[e], m1[e], v1[e], w1[e], t1[e], c, tau, omt);
+        pm.st(o, m1[e]); pv.st(o, v1[e]); pw.st(o, w1[e]); pt.st(o, t1[e]);
+    }
+}
+
 // ---- thin products: I <= 32 samples, activations in [unit][32] images (hT[k * 32 + sample]) ----
 // wave w < 4 computes units 32 w .. 32 w + 31 of out^T = act(Wt^T . in^T + bias): A straight from the K-major array in the arena
 // (lane (unit li, half h) reads Wt[(2t+h) * 128 + 32 w + li]: two 128-byte segments per instruction, every weight read once)
@@ -263,6 +326,48 @@ __device__ __forceinline__ void thin_layer(const float *Wt, const float *bias, c
             else if (ACT == LENV_ACT_PRELU) z = z > 0.0f ? z : prelu * z;
             else if (ACT == LENV_ACT_TANH) z = det_tanhf(lenv_tanh_table, z);
             out_img[(32 * jt + 8 * g + 4 * L.h + c) * 32 + L.li] = z;
+        }
+    }
+}
+
+// The same for I <= 16 samples on v_mfma_f32_16x16x4_f32 (also a k-ascending fmaf chain, four k per instruction; 32 cycles per
+// instruction instead of 64 for a tile that wastes no sample columns): activations in [unit][16] images, wave w computes units
+// 16 w .. 16 w + 15.  NOUT = 2: two layers that share the input (the value and advantage streams), interleaved accumulators.
+// A operand of unit tile ut for all 32 k-steps: 32 registers, loaded long before the product needs them (the weights do not depend
+// on the activations: a thin forward issues the loads of ALL its layers up front and runs the chains back to back)
+__device__ __forceinline__ void thin_load16(const float *Wt, int ut, const Lane &L, float (&a)[32])
+{
+    const gfloat *wa = (const gfloat *)Wt + (L.lane >> 4) * W + 16 * ut + (L.lane & 15);
+#pragma unroll
+    for (int t = 0; t < 32; ++t) a[t] = wa[4 * t * W];
+}
+template <int ACT, int NOUT>
+__device__ __forceinline__ void thin_layer16(const float (&a0)[32], const float *bias0, float *out0_, const float (&a1)[32], const float *bias1, float *out1_,
+                                             const float *in_img_, int ut, const Lane &L, float prelu)
+{
+    const lfloat *in_img = (const lfloat *)in_img_;
+    const int l16 = L.lane & 15, q = L.lane >> 4;
+    const lfloat *xb = in_img + q * 16 + l16;
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const float x = xb[4 * t * 16];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], x, acc0, 0, 0, 0);
+        if (NOUT == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], x, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        const f32x4 acc = o == 0 ? acc0 : acc1;
+        const f32x4 bv = *(const gf4 *)((const gfloat *)(o == 0 ? bias0 : bias1) + 16 * ut + 4 * q);
+        lfloat *out = (lfloat *)(o == 0 ? out0_ : out1_) + (16 * ut + 4 * q) * 16 + l16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float z = acc[c] + bv[c];
+            if (ACT == LENV_ACT_RELU) z = z > 0.0f ? z : 0.0f;
+            else if (ACT == LENV_ACT_LEAKYRELU) z = z > 0.0f ? z : z * 0.01f;
+            else if (ACT == LENV_ACT_PRELU) z = z > 0.0f ? z : prelu * z;
+            else if (ACT == LENV_ACT_TANH) z = det_tanhf(lenv_tanh_table, z);
+            out[c * 16] = z;
         }
     }
 }
