@@ -34,6 +34,17 @@ constexpr int BLK = 32 * W;               // floats of one wave's register dump 
 typedef __attribute__((address_space(1))) f32x4 gf4;
 typedef __attribute__((address_space(3))) f32x4 lf4;
 
+// Workgroup barrier for hand-offs through LDS only.  __syncthreads() also drains the wave's global loads AND stores (s_waitcnt
+// vmcnt(0)): behind a burst of dump stores that is several thousand cycles of write-acknowledge latency which nothing in the next
+// phase depends on.  Use it only where every datum the next phase reads from another wave went through LDS; global data written
+// before it must pass a later __syncthreads() before another wave reads it.
+__device__ __forceinline__ void barrier_lds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ int img_pos(int r, int c) { return r * W + (c ^ ((r & 7) << 2)); }
 
 struct Lane {
@@ -237,6 +248,38 @@ __device__ __forceinline__ void wgrad_tiles(const float *img_in_, const float *i
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[q][2 * (t4 + q) * W + 32], acc1, 0, 0, 0);
         }
     }
+    gfloat *out = (gfloat *)gWt + (32 * kt + 4 * L.h) * W + 32 * jt0 + L.li;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int r = 8 * (v >> 2) + (v & 3);
+        out[r * W] = acc0[v];
+        out[r * W + 32] = acc1[v];
+    }
+}
+
+// Weight gradient over more samples than one image holds (batch 192 = two half-batches of 96 rows): the accumulators live across the
+// calls, the reduction stays one i-ascending chain.
+__device__ __forceinline__ void wgrad_accum(const float *img_in_, const float *img_dz_, int rows, const Lane &L, f32x16 &acc0, f32x16 &acc1)
+{
+    const lfloat *img_in = (const lfloat *)img_in_, *img_dz = (const lfloat *)img_dz_;
+    const int kt = L.wave >> 1, jt0 = (L.wave & 1) << 1;
+    const lfloat *pa[4], *pb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { pa[q] = img_in + L.h * W + 32 * kt + L.colsw[q]; pb[q] = img_dz + L.h * W + 32 * jt0 + L.colsw[q]; }
+    const int steps = rows >> 1;
+#pragma unroll 2
+    for (int t4 = 0; t4 < steps; t4 += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a = pa[q][2 * (t4 + q) * W];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[q][2 * (t4 + q) * W], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[q][2 * (t4 + q) * W + 32], acc1, 0, 0, 0);
+        }
+    }
+}
+__device__ __forceinline__ void wgrad_store(const Lane &L, float *gWt, const f32x16 &acc0, const f32x16 &acc1)
+{
+    const int kt = L.wave >> 1, jt0 = (L.wave & 1) << 1;
     gfloat *out = (gfloat *)gWt + (32 * kt + 4 * L.h) * W + 32 * jt0 + L.li;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {

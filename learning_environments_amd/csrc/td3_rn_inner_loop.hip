@@ -15,6 +15,7 @@
 // counter RNG through a Box-Muller with deterministic log / cos (production mode).
 #include "lenv_gemm.cuh"
 #include "lenv_icm.cuh"
+#include "lenv_wavechain_host.h"
 
 namespace lenv {
 
@@ -792,6 +793,10 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
         for (int i = 0; i < IB_COUNT; ++i) a.a_icm[i] = take(sz[i]);
     }
     a.arena_stride = (off + 63) & ~(int64_t)63;
+    if (lenv_wc_td3_shape(cfg)) {                             // the wave-chain kernel (td3_wavechain.hip) keeps its own arena layout
+        const int64_t wfl = lenv_wc_td3_arena_floats(cfg, a.rb_cap, a.RS);
+        if (wfl > a.arena_stride) a.arena_stride = wfl;
+    }
     const size_t lds_floats = GemmShape<T3_MAXI>::PS_FLOATS + GemmShape<T3_MAXI>::QS_FLOATS + GEMM_QUEUE_MAX * sizeof(GemmCmd) / sizeof(float) + ((a.P_rn_lds + 3) & ~3) + 2 * ((Hrn + 3) & ~3) + 8 * (size_t)B + 64 + 2 + 2 * (20 + 17 * (size_t)T + T) + 3 * (size_t)T + 20 + 8 + 56 + 16;
     *lds_bytes = lds_floats * sizeof(float);
     if (*lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
@@ -901,6 +906,13 @@ extern "C" int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg, const lenv_ch
                    cfg->rn_layers == sp.rn_layers && cfg->rn_act == sp.rn_act && cfg->reward_env_type == sp.rtype && cfg->act == sp.act &&
                    cfg->policy_delay == sp.policy_delay;
         };
+        // production launches of the cfg-5 shape: the wave-chain kernel (LENV_NO_WAVECHAIN=1 keeps the GEMM-queue kernel for A/B runs)
+        const char *nw_ = getenv("LENV_NO_WAVECHAIN");
+        if (!off && !(nw_ && nw_[0] == '1') && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_reward && lenv_wc_td3_shape(cfg)) {
+            if (out->status && hipMemsetAsync(out->status, 0, sizeof(int32_t) * chains, static_cast<hipStream_t>(stream)) != hipSuccess) return LENV_ERR_LAUNCH;
+            return lenv_wc_td3_launch(cfg, theta, eps, worker, sign, agent_init, rng_keys, chains, a.arena, a.arena_stride, a.rb_cap, a.RS, a.P, a.actor.P,
+                                      a.critic.P, a.P_rn, out, static_cast<hipStream_t>(stream));
+        }
         if (!off && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_reward) {
             if (matches(kTd3Shapes[1])) kern = td3_rn_inner_kernel<false, LENV_ENV_CHEETAH_STANDIN, 1>;
             else if (matches(kTd3Shapes[2])) kern = td3_rn_inner_kernel<false, LENV_ENV_PENDULUM, 2>;

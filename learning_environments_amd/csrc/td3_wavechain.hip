@@ -1,0 +1,863 @@
+// td3_wavechain.hip -- the TD3 inner loop of BASELINE configs[4] (HalfCheetah stand-in RewardEnv + TD3, default_config_halfcheetah_
+// reward_env.yaml: actor 17-128-128-6, twin critics 23-128-128-1, relu, batch 192, policy_delay 1, one test episode) on the
+// wave-chain primitives of lenv_wavechain.cuh.  Same semantics and the same canonical arithmetic order -- hence the same bits -- as
+// td3_rn_inner_kernel (which stays the generic path: other shapes / envs, tapes, traces, TD3_vary, ICM, VirtualEnv), different
+// execution structure: a wave owns a block of 32 minibatch samples (6 blocks) through a whole network pass.
+//
+//   reference                                          here
+//   TD3.learn  agents/TD3.py:63-116                     t3_forward x7 (actor_target, 2 target critics, 2 critics; actor, critic_1)
+//   Actor_TD3 / Critic_Q  models/actor_critic.py:11-19,64-71   + t3_backward x3 (critic_1, critic_2; critic_1 for d/da and the actor)
+//   critic_optimizer / actor_optimizer.step, Polyak     wg_adam / wg_polyak over the arena-layout parameter vectors
+//   select_train_action / select_test_action (1 row)    actor_row1: per-thread k-ascending chains, coalesced K-major weights
+//
+// Arena layout of ONE network (actor, critic_1, critic_2 alike; every matrix K-MAJOR):
+//   W1t[24][128] (rows >= in_dim zero) b1[128] | W2t[128][128] b2[128] | Wo[128][8] (columns >= out_dim zero) bo[8]
+#include "lenv_wavechain.cuh"
+#include "lenv_wavechain_host.h"
+
+namespace lenv {
+
+using namespace wc;
+
+namespace t3p {
+constexpr int R1 = 24;                                                    // rows of W1t
+constexpr int oW1t = 0, ob1 = R1 * W, oW2t = ob1 + W, ob2 = oW2t + IMG, oWo = ob2 + W, obo = oWo + 8 * W, PN = obo + 8;
+static_assert(PN % 4 == 0, "float4 passes");
+}
+constexpr int T3W_B = 192, T3W_NB = T3W_B / 32;                           // minibatch rows, sample blocks
+
+// dumps: [T3W_NB] blocks of BLK floats each (register order), or [192][128] row-major copies (same size)
+enum { TD_C1_H1 = 0, TD_C1_H2, TD_C2_H1, TD_C2_H2, TD_A_H1, TD_A_H2, TR_C1_H2, TR_C2_H2, TR_A_H2, TS_DZ2, TR_DZ2, TR_DH1, T3W_NDUMP };
+
+struct T3wArgs {
+    lenv_td3_cfg cfg;
+    const float *theta, *eps; const int32_t *worker; const float *sign;
+    const float *agent_init; const uint64_t *rng_keys;
+    float *arena; int64_t arena_stride;
+    lenv_td3_out out;
+    int64_t rb_cap; int RS;
+    int P, Pa, Pc, P_rn;
+    int64_t a_par, a_xc, a_xn, a_xa, a_th, a_dump, a_replay, a_meter;
+};
+
+struct T3wCtx {
+    float *bufA, *bufB, *sm_b, *sm_wo, *sm_bo, *qvec, *dzl;
+    float *params, *targets, *grad, *dumps;
+    float prelu, ma;
+};
+
+// state-dict index inside ONE net (mlp_off order: W0 [128 x in] b0 W1 [128 x 128] b1 Wout [out x 128] bout) -> arena-layout index
+__device__ __forceinline__ int t3w_sd_to_arena(int p, int in, int out)
+{
+    using namespace t3p;
+    int o = p;
+    if (o < W * in) { const int j = o / in, k = o - j * in; return oW1t + k * W + j; }
+    o -= W * in;
+    if (o < W) return ob1 + o;
+    o -= W;
+    if (o < IMG) { const int j = o >> 7, k = o & 127; return oW2t + k * W + j; }
+    o -= IMG;
+    if (o < W) return ob2 + o;
+    o -= W;
+    if (o < out * W) { const int c = o >> 7, k = o & 127; return oWo + k * 8 + c; }
+    o -= out * W;
+    return obo + o;
+}
+
+#ifdef LENV_PHASE_TIMING
+__device__ unsigned long long g_t3w_phase_cycles[48];
+#define TSUB_DECL unsigned long long sp_last = __builtin_readcyclecounter()
+#define TSUB_MARK(i) do { unsigned long long sp_now = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) g_t3w_phase_cycles[i] += sp_now - sp_last; sp_last = sp_now; } while (0)
+#define TPT_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define TPT_MARK(i) do { unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
+#else
+#define TPT_DECL
+#define TPT_MARK(i)
+#define TSUB_DECL
+#define TSUB_MARK(i)
+#endif
+
+#define T3W_CTX_PROLOGUE                                                                                                                   \
+    using namespace t3p;                                                                                                                   \
+    Lane L;                                                                                                                                \
+    L.init();                                                                                                                              \
+    const int tid = L.tid, wave = L.wave;                                                                                                  \
+    (void)tid; (void)wave;                                                                                                                 \
+    typedef __attribute__((address_space(3))) const T3wCtx LCtx;                                                                           \
+    LCtx *c = (LCtx *)uni_ptr(ctx_);                                                                                                       \
+    float *bufA = uni_ptr(c->bufA), *bufB = uni_ptr(c->bufB);                                                                              \
+    lfloat *sm_b = (lfloat *)uni_ptr(c->sm_b), *sm_wo = (lfloat *)uni_ptr(c->sm_wo), *sm_bo = (lfloat *)uni_ptr(c->sm_bo);                 \
+    float *dumps = uni_ptr(c->dumps);                                                                                                      \
+    const float prelu = unif(c->prelu), ma = unif(c->ma);                                                                                  \
+    (void)bufA; (void)bufB; (void)sm_b; (void)sm_wo; (void)sm_bo; (void)dumps; (void)prelu; (void)ma;                                      \
+    auto dump_of = [&](int which, int blk) { return dumps + ((int64_t)which * T3W_NB + blk) * BLK; };                                      \
+    (void)dump_of
+
+// [32 samples x 128 units] register block -> rows 32 blk .. of a plain [sample][unit] array (16-byte stores)
+__device__ __forceinline__ void block_to_rowmajor(float *rm_, int blk, const Lane &L, const float (&r)[64])
+{
+    gfloat *rm = (gfloat *)rm_ + (32 * blk + L.li) * W + 4 * L.h;
+#pragma unroll
+    for (int pc = 0; pc < 16; ++pc) *(gf4 *)(rm + 32 * (pc >> 2) + 8 * (pc & 3)) = f32x4{r[4 * pc], r[4 * pc + 1], r[4 * pc + 2], r[4 * pc + 3]};
+}
+
+// ---- one network pass over the 192 minibatch rows X[i][ldx] (waves 0-5 own the sample blocks) ----------------------------------
+// mode 0 (Critic_Q): q_out[i] = net(x)      mode 1 (Actor_TD3): Y[i][ocol + c] = tanh(net(x)) * max_action, th_out[i][c] = tanh
+template <int ACT, int IN, int OUT>
+__device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, const float *X_, int ldx_, int mode_, float *q_out_,
+                                         float *Y_, int ldy_, int ocol_, float *th_out_, int d_h1_, int d_h2_, int r_h2_)
+{
+    T3W_CTX_PROLOGUE;
+    const float *par = uni_ptr(par_), *X = uni_ptr(X_);
+    float *Y = uni_ptr(Y_), *th_out = uni_ptr(th_out_);
+    lfloat *q_out = (lfloat *)uni_ptr(q_out_);
+    constexpr int in = IN, out = OUT;
+    const int ldx = uni(ldx_), mode = uni(mode_), ldy = uni(ldy_), ocol = uni(ocol_);
+    const int d_h1 = uni(d_h1_), d_h2 = uni(d_h2_), r_h2 = uni(r_h2_);
+    for (int i = tid; i < 2 * W; i += NT) sm_b[i] = par[(i < W ? ob1 : ob2 - W) + i];
+    for (int i = tid; i < 8 * W + 8; i += NT) sm_wo[i] = par[oWo + i];                  // Wo and bo are contiguous in both places
+    StageRegs sr;
+    TSUB_DECL;
+    // layer 1's operands (A straight from the K-major array, B from the minibatch rows) are requested first: their latency hides
+    // behind the staging of the W2 image
+    float xb[in >> 1], wa[in >> 1][4];
+    {
+        const int row0 = 32 * (wave < T3W_NB ? wave : 0) + L.li;
+        const gfloat *w1 = (const gfloat *)par + oW1t + L.h * W + L.li;
+        const gfloat *xr = (const gfloat *)X + row0 * ldx + L.h;
+#pragma unroll
+        for (int t = 0; t < (in >> 1); ++t) {
+            xb[t] = xr[2 * t];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) wa[t][jt] = w1[2 * t * W + 32 * jt];
+        }
+    }
+    stage_load_direct(par + oW2t, L, sr);
+    stage_store_direct(bufA, L, sr);
+    barrier_lds();                                         // image + small vectors: LDS only (the layer-1 operand loads stay in flight)
+    TSUB_MARK(16);
+    if (wave < T3W_NB) {
+        const int blk = wave, row = 32 * blk + L.li;
+        float r[64];
+        f32x16 acc[4];
+        acc_zero(acc);
+        {   // layer 1 (K = in, 17 or 23); an odd last k is one fmaf per output
+#pragma unroll
+            for (int t = 0; t < (in >> 1); ++t)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t][jt], xb[t], acc[jt], 0, 0, 0);
+            if (in & 1) {
+                const float xl = ((const gfloat *)X)[row * ldx + in - 1];
+                const gfloat *wl = (const gfloat *)par + oW1t + (in - 1) * W + 4 * L.h;
+#pragma unroll
+                for (int pc = 0; pc < 16; ++pc) {
+                    const f32x4 wv = *(const gf4 *)(wl + 32 * (pc >> 2) + 8 * (pc & 3));
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) acc[pc >> 2][4 * (pc & 3) + cc] = fma32(xl, wv[cc], acc[pc >> 2][4 * (pc & 3) + cc]);
+                }
+            }
+        }
+        tile_bias_act<ACT>(acc, (const float *)sm_b, L, prelu, r);
+        if (d_h1 >= 0) dump_store(dump_of(d_h1, blk), L, r);
+        tile_to_operand(r);
+        TSUB_MARK(17);
+        acc_zero(acc);
+        chain128(bufA, L, r, acc);
+        TSUB_MARK(18);
+        tile_bias_act<ACT>(acc, (const float *)(sm_b + W), L, prelu, r);
+        if (r_h2 >= 0) block_to_rowmajor(dump_of(r_h2, 0), blk, L, r);     // h2 is kept as a plain [sample][unit] array only
+        tile_to_operand(r);
+        // output layer: rows 0 .. out-1 of one 32x32 tile (row c of lane half h = 4 h + register)
+        f32x16 hacc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) hacc[v] = 0.0f;
+        const lfloat *wo = sm_wo + L.h * 8 + (L.li < out ? L.li : out - 1);
+#pragma unroll
+        for (int t = 0; t < 64; ++t) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wo[2 * t * 8], r[breg_of(t)], hacc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int cidx = 4 * L.h + v;
+            if (cidx < out) {
+                const float z = hacc[v] + sm_bo[cidx];
+                if (mode == 0) q_out[row] = z;
+                else {
+                    const float th = det_tanhf(lenv_tanh_table, z);
+                    if (th_out) th_out[row * out + cidx] = th;
+                    Y[row * ldy + ocol + cidx] = th * ma;
+                }
+            }
+        }
+        TSUB_MARK(19);
+    }
+    __syncthreads();
+    TSUB_MARK(20);
+}
+
+// ---- backward of one network from dOut[i][out] (LDS): parameter gradients to gpar (may be null) and, for the policy step, the
+// action part of the input gradient turned into the actor's output gradient dz (LDS) right away ----
+template <int ACT, int IN, int OUT>
+__device__ __noinline__ void t3w_backward(const T3wCtx *ctx_, const float *par_, float *gpar_, const float *X_, int ldx_,
+                                          const float *dOut_, int d_h1_, int d_h2_, int r_h2_, int dx_col_, int dx_n_, const float *th_, float *dz_out_)
+{
+    T3W_CTX_PROLOGUE;
+    const float *par = uni_ptr(par_), *X = uni_ptr(X_), *th = uni_ptr(th_);
+    float *gpar = uni_ptr(gpar_);
+    const lfloat *dOut = (const lfloat *)uni_ptr(dOut_);
+    lfloat *dz_out = (lfloat *)uni_ptr(dz_out_);
+    constexpr int in = IN, out = OUT;
+    const int ldx = uni(ldx_), d_h1 = uni(d_h1_), d_h2 = uni(d_h2_), r_h2 = uni(r_h2_), dx_col = uni(dx_col_), dx_n = uni(dx_n_);
+    constexpr int B = T3W_B;
+    for (int i = tid; i < 8 * W + 8; i += NT) sm_wo[i] = par[oWo + i];
+    StageRegs sr;
+    TSUB_DECL;
+    stage_load_transposed(par + oW2t, L, sr);
+    if (gpar) {
+        // output layer: gWo[k][c] = sum_i dOut[i][c] h2[i][k] (i ascending) from the row-major copy of h2; gbo[c] = sum_i dOut[i][c]
+        const gfloat *rm = (const gfloat *)dump_of(r_h2, 0);
+        for (int e = tid; e < W * out; e += NT) {
+            const int k = e & 127, cidx = e >> 7;
+            float s = 0.0f;
+            for (int i0 = 0; i0 < B; i0 += 64) {
+                float hv[64];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) hv[u] = rm[(i0 + u) * W + k];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) s = fma32(dOut[(i0 + u) * out + cidx], hv[u], s);
+            }
+            gpar[oWo + k * 8 + cidx] = s;
+        }
+        if (tid >= NT - 64 && tid < NT - 64 + out) {
+            const int cidx = tid - (NT - 64);
+            float s = 0.0f;
+            for (int i = 0; i < B; ++i) s = s + dOut[i * out + cidx];
+            gpar[obo + cidx] = s;
+        }
+    }
+    __syncthreads();                                       // sm_wo staged
+    TSUB_MARK(24);
+    float r[64];
+    f32x16 acc[4];
+    if (wave < T3W_NB) {
+        // dz2 = act'(h2) * (sum_c dOut[i][c] Wo[c][unit], c ascending from 0)
+        const int blk = wave, row = 32 * blk + L.li;
+        const gfloat *hd = (const gfloat *)dump_of(d_h2, 0) + row * W + 4 * L.h;        // d_h2: the row-major copy of h2
+        float dO[out];
+#pragma unroll
+        for (int cc = 0; cc < out; ++cc) dO[cc] = dOut[row * out + cc];
+#pragma unroll
+        for (int pc = 0; pc < 16; ++pc) {
+            const f32x4 hv = *(const gf4 *)(hd + 32 * (pc >> 2) + 8 * (pc & 3));
+            const lfloat *wp = sm_wo + (32 * (pc >> 2) + 8 * (pc & 3) + 4 * L.h) * 8;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                float wv[8];
+                const f32x4 w0 = *(const lf4 *)(wp + 8 * cc);
+                wv[0] = w0[0]; wv[1] = w0[1]; wv[2] = w0[2]; wv[3] = w0[3];
+                if (out > 4) { const f32x4 w1 = *(const lf4 *)(wp + 8 * cc + 4); wv[4] = w1[0]; wv[5] = w1[1]; wv[6] = w1[2]; wv[7] = w1[3]; }
+                float up = 0.0f;
+#pragma unroll
+                for (int o = 0; o < out; ++o) up = fma32(dO[o], wv[o], up);
+                r[4 * pc + cc] = act_bwd(ACT, prelu, hv[cc], up);
+            }
+        }
+        block_to_rowmajor(dump_of(TR_DZ2, 0), blk, L, r);
+        tile_to_operand(r);
+    }
+    stage_store_transposed(bufA, L, sr);
+    barrier_lds();                                         // the chain reads the image only; the dz2 copy in the arena is read two phases on
+    TSUB_MARK(25);
+    L.refresh();
+    if (wave < T3W_NB) {
+        const int blk = wave, row = 32 * blk + L.li;
+        const gf4 *src = (const gf4 *)dump_of(d_h1, blk) + L.lane;
+        f32x4 hv[16];
+#pragma unroll
+        for (int pc = 0; pc < 16; ++pc) hv[pc] = src[pc * 64];
+        acc_zero(acc);
+        chain128(bufA, L, r, acc);
+#pragma unroll
+        for (int pc = 0; pc < 16; ++pc)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) r[4 * pc + cc] = act_bwd(ACT, prelu, hv[pc][cc], acc[pc >> 2][4 * (pc & 3) + cc]);
+        if (gpar) block_to_rowmajor(dump_of(TR_DH1, 0), blk, L, r);
+        if (dx_n > 0) {
+            // dX[i][dx_col + c] = sum_u dh1[i][u] W1[u][dx_col + c] (u ascending), c < dx_n, then dz = (dX * max_action) * (1 - th^2)
+            tile_to_operand(r);
+            f32x16 hacc;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) hacc[v] = 0.0f;
+            const gfloat *w1 = (const gfloat *)par + oW1t + (dx_col + (L.li < dx_n ? L.li : dx_n - 1)) * W + L.h;
+#pragma unroll 16
+            for (int t = 0; t < 64; ++t) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2 * t], r[breg_of(t)], hacc, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int cidx = 4 * L.h + v;
+                if (cidx < dx_n) {
+                    const float t_ = th[row * dx_n + cidx];
+                    dz_out[row * dx_n + cidx] = (hacc[v] * ma) * fma32(-t_, t_, 1.0f);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    TSUB_MARK(26);
+    if (!gpar) return;
+    // gW2t[k][j] = sum_i h1[i][k] dz2[i][j] over the 192 samples: two half-batches of 96 rows through the two images
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { acc0[v] = 0.0f; acc1[v] = 0.0f; }
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        L.refresh();
+        {   // dz2 rows 96 half .. + 95: straight copy of the row-major array into the swizzled image (bufB)
+            const gf4 *src = (const gf4 *)dump_of(TR_DZ2, 0) + half * 96 * 32 + tid;
+            lfloat *img = (lfloat *)bufB;
+            f32x4 v[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) v[u] = src[u * NT];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int p = tid + u * NT, rr_ = p >> 5, cc_ = (p & 31) << 2;
+                *(lf4 *)(img + rr_ * W + (cc_ ^ ((rr_ & 7) << 2))) = v[u];
+            }
+        }
+        if (wave < 3) {                                    // h1 blocks 3 half .. + 2 from the register dumps -> bufA
+            dump_load(dump_of(d_h1, 3 * half + wave), L, r);
+            tile_to_image(bufA, wave, L, r);
+        }
+        barrier_lds();
+        L.refresh();
+        wgrad_accum(bufA, bufB, 96, L, acc0, acc1);
+        barrier_lds();
+    }
+    wgrad_store(L, gpar + oW2t, acc0, acc1);
+    TSUB_MARK(27);
+    // layer 1: gW1t[k][j] = sum_i x[i][k] dh1[i][j] (k < in) on the matrix cores too: A = the minibatch inputs straight from the arena
+    // (lane = input column k, clamped), B = an image of dh1 built from its row-major copy, again in two half-batches; waves 0-3 own
+    // one 32-unit column tile each, waves 4-5 walk the same images for gb1[j] = sum_i dh1[i][j], waves 6-7 an image of dz2 for gb2
+    f32x16 accw;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) accw[v] = 0.0f;
+    float sb = 0.0f;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        L.refresh();
+        {   // half-batch images of dh1 (bufB) and dz2 (bufA) from their row-major copies
+            const gf4 *src = (const gf4 *)dump_of(TR_DH1, 0) + half * 96 * 32 + tid, *src2 = (const gf4 *)dump_of(TR_DZ2, 0) + half * 96 * 32 + tid;
+            lfloat *img = (lfloat *)bufB, *img2 = (lfloat *)bufA;
+            f32x4 v[6], v2[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) { v[u] = src[u * NT]; v2[u] = src2[u * NT]; }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int p = tid + u * NT, rr_ = p >> 5, cc_ = (p & 31) << 2;
+                *(lf4 *)(img + rr_ * W + (cc_ ^ ((rr_ & 7) << 2))) = v[u];
+                *(lf4 *)(img2 + rr_ * W + (cc_ ^ ((rr_ & 7) << 2))) = v2[u];
+            }
+        }
+        barrier_lds();
+        L.refresh();
+        if (wave < 4) {
+            const lfloat *img = (const lfloat *)bufB;
+            const lfloat *pb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pb[q] = img + L.h * W + 32 * wave + L.colsw[q];
+            const gfloat *xa_ = (const gfloat *)X + (96 * half + L.h) * ldx + (L.li < in ? L.li : in - 1);
+#pragma unroll 2
+            for (int t4 = 0; t4 < 48; t4 += 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) accw = __builtin_amdgcn_mfma_f32_32x32x2f32(xa_[2 * (t4 + q) * ldx], pb[q][2 * (t4 + q) * W], accw, 0, 0, 0);
+            }
+        } else {                                       // waves 4,5: gb1 from the dh1 image; waves 6,7: gb2 from the dz2 image
+            const lfloat *img = (const lfloat *)(wave < 6 ? bufB : bufA);
+            const int j = tid & 127;
+            for (int i0 = 0; i0 < 96; i0 += 32) {
+                float x[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) x[u] = img[(i0 + u) * W + (j ^ ((u & 7) << 2))];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) sb = sb + x[u];
+            }
+        }
+        barrier_lds();
+    }
+    if (wave < 4) {
+        gfloat *out = (gfloat *)gpar + oW1t + (4 * L.h) * W + 32 * wave + L.li;      // rows k = 8 (v / 4) + 4 h + v % 4 of the K-major gradient
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int k = 8 * (v >> 2) + 4 * L.h + (v & 3);
+            if (k < in) out[(8 * (v >> 2) + (v & 3)) * W] = accw[v];
+        }
+    } else gpar[(wave < 6 ? ob1 : ob2) + (tid & 127)] = sb;
+    __syncthreads();
+    TSUB_MARK(28);
+}
+
+template <int SHAPE>
+__global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
+{
+    using namespace t3p;
+    using EnvT = ContEnv<LENV_ENV_CHEETAH_STANDIN>;
+    extern __shared__ __align__(16) float lds[];
+    constexpr int S = EnvT::S, A = EnvT::A, SA = S + A, SD = EnvT::SD, B = T3W_B, Hrn = 128, ACT = LENV_ACT_RELU, T = 1;
+    const lenv_td3_cfg &cfg = a.cfg;
+    const int tid = threadIdx.x;
+    const int64_t chain = blockIdx.x;
+    const float prelu = cfg.prelu, ma = (float)cfg.max_action;
+    const int RS = a.RS, rn_act = cfg.rn_act, rtype = cfg.reward_env_type;
+
+    // ---- LDS carve-up ----
+    float *bufA = lds, *bufB = bufA + IMG;
+    float *sm_b = bufB + IMG;                             // [2][128] b1 b2
+    float *sm_wo = sm_b + 2 * W;                          // [128][8]
+    float *sm_bo = sm_wo + 8 * W;                         // [8]
+    float *rn_w = sm_bo + 8;                              // reward net: W0 [Hrn][S] | b0 [Hrn] | Wout [Hrn] | bout
+    float *rn_h = rn_w + ((a.P_rn + 3) & ~3);             // [Hrn]
+    float *dq1 = rn_h + Hrn;                              // [B]
+    float *q1 = dq1 + B;                                  // [B] ... six vectors; from q1 on they double as dz [B][A] in the policy step
+    float *q2 = q1 + B, *tq1 = q2 + B, *tq2 = tq1 + B, *rr = tq2 + B, *dd = rr + B;
+    float *dq2 = dd + B;                                  // [B]
+    float *h_row = dq2 + B;                               // [2][128] hidden rows of the one-row actor
+    float *misc = h_row + 2 * W;                          // [64]
+    double *xs_d = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(misc + 64) + 7) & ~(uintptr_t)7);   // [20] train env state
+    double *xt_d = xs_d + 20;                             // [T][17]
+    double *ret = xt_d + 17 * T;                          // [T]
+    float *ep_rew = reinterpret_cast<float *>(ret + T);   // [T]
+    int *tlen = reinterpret_cast<int *>(ep_rew + T);      // [T]
+    float *state = reinterpret_cast<float *>(tlen + T + 1);   // [20]
+    float *action = state + 20;                           // [8]
+    float *newrow = action + 8;                           // [56]
+    T3wCtx *ctx = reinterpret_cast<T3wCtx *>((reinterpret_cast<uintptr_t>(newrow + 56) + 15) & ~(uintptr_t)15);
+    volatile float *ctrl = misc;
+    volatile int *ictrl = reinterpret_cast<volatile int *>(misc + 32);
+    float *dzl = q1;
+
+    float *arena = a.arena + chain * a.arena_stride;
+    float *params = arena + a.a_par, *targets = params + 3 * PN, *adam_m = targets + 3 * PN, *adam_v = adam_m + 3 * PN, *grad = adam_v + 3 * PN;
+    float *rb = arena + a.a_replay, *xc = arena + a.a_xc, *xn = arena + a.a_xn, *xa = arena + a.a_xa, *thb = arena + a.a_th, *dumps = arena + a.a_dump;
+    double *meter = reinterpret_cast<double *>(arena + a.a_meter);
+
+    // ---- stage the perturbed reward network (GTN_worker.py:165-175) and the fresh agent (TD3.py:31-39) ----
+    {
+        const float sg = a.eps ? a.sign[chain] : 0.0f;
+        const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P_rn : nullptr;
+        for (int i = tid; i < a.P_rn; i += NT) rn_w[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
+    }
+    for (int p = tid; p < 3 * PN; p += NT) { params[p] = 0.0f; targets[p] = 0.0f; adam_m[p] = 0.0f; adam_v[p] = 0.0f; grad[p] = 0.0f; }
+    __syncthreads();
+    for (int p = tid; p < a.P; p += NT) {
+        const float w = a.agent_init[chain * a.P + p];
+        int q;
+        if (p < a.Pa) q = t3w_sd_to_arena(p, S, A);
+        else { const int n = (p - a.Pa) / a.Pc; q = (1 + n) * PN + t3w_sd_to_arena(p - a.Pa - n * a.Pc, SA, 1); }
+        params[q] = w; targets[q] = w;
+    }
+    if (tid < 64) misc[tid] = 0.0f;
+    if (tid == 0) { T3wCtx cx{ bufA, bufB, sm_b, sm_wo, sm_bo, q1, dzl, params, targets, grad, dumps, prelu, ma }; *ctx = cx; }
+    __syncthreads();
+
+    const uint64_t key = a.rng_keys[chain];
+    int status = 0;
+    TPT_DECL;
+    int64_t n_rand = 0, n_actn = 0, n_testn = 0, n_test_ep = 0, learn_it = 0;
+    int train_steps = 0, test_steps = 0, episodes_run = 0;
+    double pows[4] = { 1.0, 1.0, 1.0, 1.0 };
+    const int rb_cap = (int)a.rb_cap;
+    const float g32 = (float)cfg.gamma;
+
+    // ---- the actor on ONE row (TD3.select_train_action / select_test_action): thread j owns unit j, k-ascending fmaf chains over the
+    // K-major arrays (coalesced across the threads) ----
+    auto actor_row1 = [&](const float *x, float *out) {
+        const float *par = params;
+        if (tid < W) {
+            float w[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k) w[k] = par[oW1t + k * W + tid];
+            float z = 0.0f;
+#pragma unroll
+            for (int k = 0; k < S; ++k) z = fma32(x[k], w[k], z);
+            h_row[tid] = act_fwd(ACT, prelu, z + par[ob1 + tid]);
+        }
+        __syncthreads();
+        if (tid < W) {
+            float z = 0.0f;
+            for (int k0 = 0; k0 < W; k0 += 64) {           // 64 coalesced weight reads in flight, then the ordered chain
+                float w[64];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) w[u] = par[oW2t + (k0 + u) * W + tid];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) z = fma32(h_row[k0 + u], w[u], z);
+            }
+            h_row[W + tid] = act_fwd(ACT, prelu, z + par[ob2 + tid]);
+        }
+        __syncthreads();
+        if (tid < A) {
+            float z = 0.0f;
+            for (int k0 = 0; k0 < W; k0 += 64) {
+                float w[64];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) w[u] = par[oWo + (k0 + u) * 8 + tid];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) z = fma32(h_row[W + k0 + u], w[u], z);
+            }
+            out[tid] = det_tanhf(lenv_tanh_table, z + par[obo + tid]) * ma;
+        }
+        __syncthreads();
+    };
+
+    auto adam = [&](int p0, int n, int pi) {
+        if (tid == 0) {
+            pows[pi] *= cfg.adam_beta1; pows[pi + 1] *= cfg.adam_beta2;
+            ctrl[10] = (float)(-(cfg.lr / (1.0 - pows[pi])));
+            ctrl[11] = (float)__builtin_sqrt(1.0 - pows[pi + 1]);
+        }
+        __syncthreads();
+        const float neg_step = ctrl[10], bc2_sqrt = ctrl[11];
+        const float w1 = (float)(1.0 - cfg.adam_beta1), w2 = (float)(1.0 - cfg.adam_beta2), beta2 = (float)cfg.adam_beta2, aeps = (float)cfg.adam_eps;
+        const AdamConsts ac{ neg_step, bc2_sqrt, w1, w2, beta2, aeps };
+        // the Polyak update of the same parameters rides in the pass (TD3.py:104-116 runs it after both optimizer steps; policy_delay
+        // is 1 here and nothing between the critic step and the soft update reads a target net: element for element the same
+        // tau * w + (1 - tau) * t on the same operands)
+        wg_adam(params, adam_m, adam_v, grad, p0, n, ac, targets, (float)cfg.tau, (float)(1.0 - cfg.tau));
+        __syncthreads();
+    };
+
+    // phi = reward_net(obs) -> ctrl[slot]   (one hidden layer, types 1 / 2 / 5 / 6: no info inputs on this path)
+    auto rn_eval = [&](const float *obs, int slot) {
+        if (rtype == 0) { if (tid == 0) ctrl[slot] = 0.0f; __syncthreads(); return; }
+        const float *W0 = rn_w, *b0 = rn_w + Hrn * S;
+        for (int j = tid; j < Hrn; j += NT) {
+            float z = 0.0f;
+            for (int k = 0; k < S; ++k) z = fma32(obs[k], W0[j * S + k], z);
+            rn_h[j] = act_fwd(rn_act, cfg.rn_prelu, z + b0[j]);
+        }
+        __syncthreads();
+        const float *Wo = b0 + Hrn, *bo = Wo + Hrn;
+        if (tid == 0) {
+            float acc = 0.0f;
+            for (int j = 0; j < Hrn; ++j) acc = fma32(rn_h[j], Wo[j], acc);
+            ctrl[slot] = acc + bo[0];
+        }
+        __syncthreads();
+    };
+
+    // ---- real-env test phase (BaseAgent.test): ONE episode, actions from the one-row actor + exploration noise (TD3.py:126-129) ----
+    auto test_phase = [&]() {
+        const int64_t nstride = cfg.max_steps;
+        for (int e = tid; e < SD; e += NT) xt_d[e] = EnvT::reset_word(key, STREAM_TEST_RESET, n_test_ep, e);
+        if (tid == 0) ep_rew[0] = 0.0f;
+        __syncthreads();
+        int my_el = 0;
+        float *xt = state + 0;                             // not used by the training loop while a test runs? -- no: keep `state`; use newrow as scratch
+        xt = newrow;                                       // [S] observation
+        float *at = newrow + 24;                           // [A] action
+        for (int ai = 0; ai < cfg.max_steps; ++ai) {
+            if (tid < S) xt[tid] = EnvT::obs(tid, xt_d);
+            __syncthreads();
+            actor_row1(xt, at);
+            if (tid < A) {
+                const int64_t n = (n_testn + ai) * A + tid;
+                const float zn = (float)det_normal(key, STREAM_TD3_TEST_NOISE, (uint64_t)n);
+                const float v = at[tid] + (zn * (float)cfg.action_std) * ma;
+                at[tid] = v < -ma ? -ma : (v > ma ? ma : v);
+            }
+            __syncthreads();
+            double nx = 0.0, pre = 0.0;
+            if (tid < SD) nx = EnvT::step_word(tid, xt_d, at);
+            if (tid == 0) pre = EnvT::reward_pre(xt_d, at);
+            __syncthreads();
+            if (tid < SD) xt_d[tid] = nx;
+            __syncthreads();
+            if (tid == 0) ep_rew[0] = ep_rew[0] + (float)(0.0 + EnvT::reward_post(xt_d, pre));
+            ++my_el;
+            __syncthreads();
+        }
+        if (tid == 0) { ret[0] = (double)ep_rew[0]; tlen[0] = my_el; }
+        n_test_ep += 1;
+        n_testn += nstride;
+        test_steps += my_el;
+        __syncthreads();
+    };
+
+    const bool budgeted = cfg.step_budget > 0;
+    int timed_out_at = -1;
+    for (int episode = 0; episode < cfg.train_episodes; ++episode) {
+        if (budgeted && (int64_t)train_steps + test_steps > cfg.step_budget) { timed_out_at = episode; break; }
+        const bool learning = episode >= cfg.init_episodes;
+        for (int i = tid; i < SD; i += NT) xs_d[i] = EnvT::reset_word(key, STREAM_TRAIN_RESET, (int64_t)episode, i);
+        __syncthreads();
+        if (tid < S) state[tid] = EnvT::obs(tid, xs_d);
+        __syncthreads();
+        if (rtype == 1 || rtype == 2) rn_eval(state, 12);
+        int ep_len = 0, env_steps = 0;
+        for (int t = 0; t < cfg.max_steps; ++t) {
+            const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
+            const int new_pos = train_steps % rb_cap;
+            if (!learning) {
+                if (tid < A) action[tid] = (float)(-(double)ma + (2.0 * (double)ma) * u64_to_unit(rng_u64(key, STREAM_TD3_RAND_ACTION, (uint64_t)(n_rand * A + tid))));
+                ++n_rand;
+                __syncthreads();
+            } else {
+                actor_row1(state, action);
+                if (tid < A) {
+                    const float zn = (float)det_normal(key, STREAM_TD3_ACT_NOISE, (uint64_t)(n_actn * A + tid));
+                    const float v = action[tid] + (zn * (float)cfg.action_std) * ma;
+                    action[tid] = v < -ma ? -ma : (v > ma ? ma : v);
+                }
+                ++n_actn;
+                __syncthreads();
+            }
+            // ---- EnvWrapper.step -> RewardEnv.step -> real_env.step + TimeLimit ----
+            if (tid < S) newrow[tid] = state[tid];
+            if (tid >= 64 && tid < 64 + A) newrow[S + tid - 64] = action[tid - 64];
+            {
+                double nx = 0.0, pre = 0.0;
+                if (tid < SD) nx = EnvT::step_word(tid, xs_d, action);
+                if (tid == 64) pre = EnvT::reward_pre(xs_d, action);
+                __syncthreads();
+                if (tid < SD) xs_d[tid] = nx;
+                if (tid == 64) xs_d[18] = pre;
+                __syncthreads();
+                ++env_steps;
+                const bool dn = EnvT::done(xs_d) || env_steps >= cfg.max_steps;
+                if (tid < S) newrow[S + A + tid] = EnvT::obs(tid, xs_d);
+                __syncthreads();
+                rn_eval(newrow + S + A, 13);
+                if (tid == 0) {
+                    const double rew = EnvT::reward_post(xs_d, xs_d[18]);
+                    const float r32 = (float)rew, phi_s = ctrl[12], phi_s2 = ctrl[13];
+                    float shaped;
+                    switch (rtype) {
+                    case 0: shaped = r32; break;
+                    case 1: shaped = g32 * phi_s2 - phi_s; break;
+                    case 2: shaped = (r32 + g32 * phi_s2) - phi_s; break;
+                    case 5: shaped = phi_s2; break;
+                    default: shaped = r32 + phi_s2; break;
+                    }
+                    newrow[2 * S + A] = (float)(0.0 + (double)shaped); newrow[2 * S + A + 1] = dn ? 1.0f : 0.0f;
+                    ctrl[12] = phi_s2;
+                }
+                __syncthreads();
+                if (tid < S) state[tid] = newrow[S + A + tid];
+            }
+            __syncthreads();
+            if (tid < 2 * S + A + 2) rb[(int64_t)new_pos * RS + tid] = newrow[tid];
+            const float done_now = newrow[2 * S + A + 1];
+            __syncthreads();
+            if (tid < S) state[tid] = newrow[S + A + tid];
+            ep_len += 1; ++train_steps;
+            __syncthreads();
+            TPT_MARK(0);
+            if (learning) {
+                // ================= TD3.learn (TD3.py:63-116) =================
+#pragma unroll 4
+                for (int e = tid; e < B * (2 * S + A + 2); e += NT) {      // ReplayBuffer.sample: one (sample, row element) pair per thread
+                    const int b = e / (2 * S + A + 2), i = e - b * (2 * S + A + 2);
+                    const int64_t n = learn_it * B + b;
+                    const int idx = (int)rng_replay_below(key, (uint64_t)n, (uint32_t)size_after);
+                    const float v = rb[(int64_t)idx * RS + i];
+                    if (i < SA) xc[b * SA + i] = v;                           // [s, a]
+                    else if (i < SA + S) xn[b * SA + (i - SA)] = v;           // s' (the action part is filled by actor_target)
+                    else if (i == SA + S) rr[b] = v;
+                    else dd[b] = v;
+                }
+                __syncthreads();
+                TPT_MARK(1);
+                // next_actions = (actor_target(s') + clamp(randn * policy_std)).clamp(-max, max)
+                t3w_forward<ACT, S, A>(ctx, targets, xn, SA, 1, nullptr, xn, SA, S, nullptr, -1, -1, -1);
+                for (int e = tid; e < B * A; e += NT) {
+                    const int b = e / A, k = e - b * A;
+                    const int64_t n = (learn_it * B + b) * A + k;
+                    const float zn = (float)det_normal(key, STREAM_TD3_POLICY_NOISE, (uint64_t)n);
+                    float nz = zn * (float)cfg.policy_std;
+                    const float clipv = (float)cfg.policy_std_clip;
+                    nz = nz < -clipv ? -clipv : (nz > clipv ? clipv : nz);
+                    const float v = xn[b * SA + S + k] + nz;
+                    xn[b * SA + S + k] = v < -ma ? -ma : (v > ma ? ma : v);
+                }
+                __syncthreads();
+                TPT_MARK(2);
+                t3w_forward<ACT, SA, 1>(ctx, targets + PN, xn, SA, 0, tq1, nullptr, 0, 0, nullptr, -1, -1, -1);
+                t3w_forward<ACT, SA, 1>(ctx, targets + 2 * PN, xn, SA, 0, tq2, nullptr, 0, 0, nullptr, -1, -1, -1);
+                t3w_forward<ACT, SA, 1>(ctx, params + PN, xc, SA, 0, q1, nullptr, 0, 0, nullptr, TD_C1_H1, TD_C1_H2, TR_C1_H2);
+                t3w_forward<ACT, SA, 1>(ctx, params + 2 * PN, xc, SA, 0, q2, nullptr, 0, 0, nullptr, TD_C2_H1, TD_C2_H2, TR_C2_H2);
+                TPT_MARK(3);
+                {
+                    const float norm = (float)(2.0 / (double)B);
+                    for (int b = tid; b < B; b += NT) {
+                        const float tq = tq1[b] < tq2[b] ? tq1[b] : tq2[b];
+                        const float y = rr[b] + ((1.0f - dd[b]) * g32) * tq;
+                        dq1[b] = norm * (q1[b] - y);
+                        dq2[b] = norm * (q2[b] - y);
+                    }
+                }
+                __syncthreads();
+                TPT_MARK(4);
+                t3w_backward<ACT, SA, 1>(ctx, params + PN, grad + PN, xc, SA, dq1, TD_C1_H1, TR_C1_H2, TR_C1_H2, 0, 0, nullptr, nullptr);
+                t3w_backward<ACT, SA, 1>(ctx, params + 2 * PN, grad + 2 * PN, xc, SA, dq2, TD_C2_H1, TR_C2_H2, TR_C2_H2, 0, 0, nullptr, nullptr);
+                TPT_MARK(5);
+                adam(PN, 2 * PN, 0);                       // critic_optimizer
+                TPT_MARK(6);
+                ++learn_it;
+                {
+                    // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1 (policy_delay 1)
+                    for (int e = tid; e < B * S; e += NT) { const int b = e / S, i = e - b * S; xa[b * SA + i] = xc[b * SA + i]; }
+                    __syncthreads();
+                    t3w_forward<ACT, S, A>(ctx, params, xc, SA, 1, nullptr, xa, SA, S, thb, TD_A_H1, TD_A_H2, TR_A_H2);
+                    t3w_forward<ACT, SA, 1>(ctx, params + PN, xa, SA, 0, dq2, nullptr, 0, 0, nullptr, TD_C1_H1, -1, TR_C1_H2);
+                    const float dqa = -(1.0f / (float)B);
+                    for (int b = tid; b < B; b += NT) dq1[b] = dqa;
+                    __syncthreads();
+                    t3w_backward<ACT, SA, 1>(ctx, params + PN, nullptr, xa, SA, dq1, TD_C1_H1, TR_C1_H2, -1, S, A, thb, dzl);
+                    t3w_backward<ACT, S, A>(ctx, params, grad, xc, SA, dzl, TD_A_H1, TR_A_H2, TR_A_H2, 0, 0, nullptr, nullptr);
+                    TPT_MARK(7);
+                    adam(0, PN, 2);
+                    TPT_MARK(8);
+                }
+            }
+            if (done_now > 0.5f) break;
+        }
+        ++episodes_run;
+        if (tid == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
+        __syncthreads();
+        TPT_MARK(10);
+        test_phase();
+        TPT_MARK(9);
+        if (tid == 0) {
+            const double tm = ret[0] / (double)T;
+            meter[episode] = tm;
+            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
+            int brk = 0;
+            if (learning) {
+                int lo = episode + 1 - cfg.early_out_num; if (lo < 0) lo = 0;
+                double s2 = 0.0;
+                for (int i = lo; i <= episode; ++i) s2 += meter[i];
+                if (s2 / ((double)(episode + 1 - lo) + 1e-9) >= cfg.solved_reward) brk = 1;
+            }
+            ictrl[3] = brk;
+        }
+        __syncthreads();
+        const int brk = ictrl[3];
+        __syncthreads();
+        if (brk) break;
+    }
+    TPT_MARK(10);
+    const int64_t remaining = cfg.step_budget - ((int64_t)train_steps + test_steps);
+    const int test_before = test_steps;
+    test_phase();
+    if (budgeted) {
+        int64_t used = 0;
+        int stop = T;
+        for (int te = 0; te < T; ++te) {
+            if (used > remaining) { stop = te; break; }
+            used += tlen[te];
+        }
+        if (tid == 0) {
+            double mn = -1e9;
+            if (stop > 0) { mn = ret[0]; for (int i = 1; i < stop; ++i) if (ret[i] < mn) mn = ret[i]; }
+            for (int te = stop; te < T; ++te) ret[te] = mn;
+        }
+        test_steps = test_before + (int)used;
+        __syncthreads();
+    }
+    TPT_MARK(9);
+#ifdef LENV_PHASE_TIMING
+    if (tid == 0 && chain == 0) for (int pi = 0; pi < 12; ++pi) g_t3w_phase_cycles[pi] = pt_acc[pi];
+#endif
+    if (tid == 0) {
+        double sm = 0.0;
+        for (int i = 0; i < T; ++i) sm += ret[i];
+        a.out.score[chain] = sm / (double)T;
+        if (a.out.final_returns) for (int i = 0; i < T; ++i) a.out.final_returns[chain * T + i] = ret[i];
+        if (a.out.stats) {
+            a.out.stats[chain * 4 + 0] = episodes_run; a.out.stats[chain * 4 + 1] = train_steps;
+            a.out.stats[chain * 4 + 2] = learn_it; a.out.stats[chain * 4 + 3] = test_steps;
+        }
+        double pad_r = __builtin_nan("");
+        int pad_l = 0;
+        if (timed_out_at >= 0) {
+            pad_r = -1e9; pad_l = 1000000000;
+            if (episodes_run > 0) { pad_r = meter[0]; for (int i = 1; i < episodes_run; ++i) if (meter[i] < pad_r) pad_r = meter[i]; }
+            if (episodes_run > 0 && a.out.episode_len) {
+                pad_l = a.out.episode_len[chain * cfg.train_episodes];
+                for (int i = 1; i < episodes_run; ++i) { const int l = a.out.episode_len[chain * cfg.train_episodes + i]; if (l > pad_l) pad_l = l; }
+            }
+        }
+        for (int e = episodes_run; e < cfg.train_episodes; ++e) {
+            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + e] = pad_r;
+            if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = pad_l;
+        }
+    }
+    if (a.out.final_params) {
+        for (int p = tid; p < a.P; p += NT) {
+            int q;
+            if (p < a.Pa) q = t3w_sd_to_arena(p, S, A);
+            else { const int n = (p - a.Pa) / a.Pc; q = (1 + n) * PN + t3w_sd_to_arena(p - a.Pa - n * a.Pc, SA, 1); }
+            a.out.final_params[chain * a.P + p] = params[q];
+        }
+    }
+    if (a.out.status && status != 0) atomicMin(&a.out.status[chain], status);
+}
+
+}  // namespace lenv
+
+using namespace lenv;
+
+// the published cfg-5 shape in production form (checked by the caller: counter RNG, no trace, no hp, no ICM)
+int lenv_wc_td3_shape(const lenv_td3_cfg *cfg)
+{
+    if (cfg->env_id == LENV_ENV_CHEETAH_STANDIN && cfg->state_dim == 17 && cfg->action_dim == 6 && cfg->hidden == 128 && cfg->layers == 2 &&
+        cfg->batch_size == T3W_B && cfg->test_episodes == 1 && cfg->rn_hidden == 128 && cfg->rn_layers == 1 && !cfg->virtual_env &&
+        (cfg->same_action_num <= 1) && cfg->act == LENV_ACT_RELU && cfg->policy_delay == 1 && !cfg->icm_enabled &&
+        (cfg->reward_env_type == 0 || cfg->reward_env_type == 1 || cfg->reward_env_type == 2 || cfg->reward_env_type == 5 || cfg->reward_env_type == 6))
+        return 1;
+    return 0;
+}
+
+static void t3w_offsets(const lenv_td3_cfg *cfg, int64_t rb_cap, int RS, T3wArgs &a, int64_t *total)
+{
+    const int SA = 23, B = T3W_B;
+    int64_t off = 0;
+    auto take = [&](int64_t n) { int64_t r = off; off += (n + 3) & ~(int64_t)3; return r; };
+    a.a_par = take(5 * 3 * (int64_t)t3p::PN); a.a_xc = take((int64_t)B * SA); a.a_xn = take((int64_t)B * SA); a.a_xa = take((int64_t)B * SA);
+    a.a_th = take((int64_t)B * 6); a.a_dump = take((int64_t)T3W_NDUMP * T3W_NB * wc::BLK); a.a_replay = take(rb_cap * RS);
+    a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
+    *total = (off + 63) & ~(int64_t)63;
+}
+
+int64_t lenv_wc_td3_arena_floats(const lenv_td3_cfg *cfg, int64_t rb_cap, int RS)
+{
+    T3wArgs a;
+    int64_t total;
+    t3w_offsets(cfg, rb_cap, RS, a, &total);
+    return total;
+}
+
+int lenv_wc_td3_launch(const lenv_td3_cfg *cfg, const float *theta, const float *eps, const int32_t *worker, const float *sign, const float *agent_init,
+                       const uint64_t *rng_keys, int64_t chains, float *arena, int64_t arena_stride, int64_t rb_cap, int RS, int P, int Pa, int Pc, int P_rn,
+                       const lenv_td3_out *out, hipStream_t stream)
+{
+    T3wArgs a;
+    a.cfg = *cfg;
+    a.theta = theta; a.eps = eps; a.worker = worker; a.sign = sign; a.agent_init = agent_init; a.rng_keys = rng_keys;
+    a.arena = arena; a.arena_stride = arena_stride; a.out = *out; a.rb_cap = rb_cap; a.RS = RS; a.P = P; a.Pa = Pa; a.Pc = Pc; a.P_rn = P_rn;
+    int64_t total;
+    t3w_offsets(cfg, rb_cap, RS, a, &total);
+    if (total > arena_stride) return LENV_ERR_WORKSPACE;
+    const int B = T3W_B, T = 1;
+    const size_t lds_floats = 2 * (size_t)wc::IMG + 2 * wc::W + 8 * wc::W + 8 + ((P_rn + 3) & ~3) + 128 + 8 * (size_t)B + 2 * wc::W + 64 + 2 + 2 * (20 + 17 * T + T) + 2 * T + 1 +
+                              20 + 8 + 56 + 4 + (sizeof(T3wCtx) + 3) / 4;
+    const size_t lds_bytes = lds_floats * sizeof(float);
+    if (lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
+    void (*kern)(const T3wArgs) = td3_wavechain_kernel<1>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return LENV_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)chains), dim3(wc::NT), lds_bytes, stream, a);
+    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
+}
+
+#ifdef LENV_PHASE_TIMING
+extern "C" int lenv_debug_t3w_phase_cycles(unsigned long long *host_out)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_t3w_phase_cycles), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : -4;
+}
+#endif
