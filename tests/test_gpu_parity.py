@@ -1954,3 +1954,77 @@ def test_ql_full_size_population_vs_oracle_and_properties(eng, orc):
         assert np.array_equal(base[1][c].reshape(N, 4), o["q_table"]), c
         assert float(base[0][c]) == o["score"]
         assert base[2][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
+def _wavechain_pair(run):
+    """(production launch = wave-chain kernel, launch with a step trace = GEMM-queue kernel) of the same inputs."""
+    return run(0), run(2)
+
+
+def test_wavechain_dueling_kernel_equals_gemm_queue_kernel(eng):
+    """dueling_wavechain.hip (BASELINE configs[2]'s shape, production launches) against dueling_se_inner_kernel on the same inputs:
+    scores, counters, per-episode test means AND all 67 460 online parameters after 80 learn steps, bit for bit.  (The full-size
+    property test above adds the oracle.)"""
+    from learning_environments_amd import configs
+    from learning_environments_amd.agents.nes_common import chain_keys
+    from learning_environments_amd.config import ddqn_cfg_from_config
+    cfgd = configs.fixed_work(configs.acrobot_syn_env_duelingddqn(2), 3)
+    cfgd["agents"]["duelingddqn"]["init_episodes"] = 1
+    cfgd["envs"]["Acrobot-v1"]["max_steps"] = 40
+    cfg = ddqn_cfg_from_config(cfgd)
+    chains = 6
+    rng = np.random.RandomState(5)
+    P_se = 3 * (9 * 128 + 128) + (6 + 1 + 1) * 128 + 8
+    theta = (rng.randn(P_se) * 0.1).astype(np.float32)
+    theta[-1] = -10.0
+    eps = (rng.randn(2, P_se) * 0.05).astype(np.float32)
+    worker = (np.arange(chains) // 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), 2)
+    keys = chain_keys(77, 3, worker, np.arange(chains) % 3)
+    init = rng.uniform(-0.08, 0.08, (chains, 67460)).astype(np.float32)
+
+    def run(trace_cap):
+        il = eng.InnerLoop(cfg, chains, trace_cap=trace_cap, want_final_online=True)
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return [t.cpu().numpy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_online)]
+
+    a, b = _wavechain_pair(run)
+    assert a[1][:, 2].min() == 80
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert not np.array_equal(a[4], init)
+
+
+def test_wavechain_td3_kernel_equals_gemm_queue_kernel(eng, orc):
+    """td3_wavechain.hip (BASELINE configs[4]'s shape) against td3_rn_inner_kernel: scores, counters, test means and all 59 016
+    parameters (actor | critic_1 | critic_2) after 120 learn steps, bit for bit."""
+    from learning_environments_amd import configs
+    from learning_environments_amd.agents.nes_common import chain_keys
+    cfgd = configs.fixed_work(configs.halfcheetah_reward_env_td3(2), 3)
+    cfgd["agents"]["td3"]["init_episodes"] = 1
+    cfgd["envs"]["HalfCheetah-v3"]["max_steps"] = 60
+    _, cfg = _td3_cfgs(orc, cfgd, 0)
+    chains = 6
+    rng = np.random.RandomState(7)
+    P_rn = 17 * 128 + 128 + 128 + 1
+    theta = (rng.randn(P_rn) * 0.2).astype(np.float32)
+    eps = (rng.randn(2, P_rn) * 0.1).astype(np.float32)
+    worker = (np.arange(chains) // 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), 2)
+    keys = chain_keys(78, 1, worker, np.arange(chains) % 3)
+    init = rng.uniform(-0.08, 0.08, (chains, 59016)).astype(np.float32)
+
+    def run(trace_cap):
+        il = eng.Td3InnerLoop(cfg, chains, trace_cap=trace_cap, want_final_params=True, want_episode_stats=True)
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return [t.cpu().numpy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_params)]
+
+    a, b = _wavechain_pair(run)
+    assert a[1][:, 2].min() == 120
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert not np.array_equal(a[4], init)
