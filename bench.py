@@ -335,14 +335,17 @@ def ql_model(cfg, st):
     return 80.0 * (train + test) + st.shape[0] * 4 * 2 * 1602, 0.0
 
 
-def secondary_configs():
+def secondary_configs(only=None):
     """One GTN_Master per configuration, its §8(d) fixed-work form, 1 untimed + K timed generations each, HIP events around
-    the generation's device work.  Sized to finish in about a minute."""
+    the generation's device work.  Sized to finish in about a minute.  only = 2 / 3 / 4: just that BASELINE configs[] entry (the
+    rocprofv3 passes profile one configuration per run)."""
     from learning_environments_amd import configs as C
     from learning_environments_amd.agents.GTN import GTN_Master
     out = []
 
     def run(name, key, kernel, cfg, model, steps, warmup=1, se=True):
+        if only is not None and key != "BASELINE configs[%d]" % only:
+            return
         torch.manual_seed(0)
         cwd = os.getcwd()
         work = os.path.join("/tmp", "lenv_bench_%d" % os.getpid())
@@ -379,7 +382,7 @@ def secondary_configs():
     # (init_episodes 10 as published: the second half learns), 10 lock-step test episodes after every train episode
     c3 = C.fixed_work(C.acrobot_syn_env_duelingddqn(32), 20)
     run("Acrobot-v1 SE + DuelingDDQN (6-128-128 / 128 / 3, B=128): one 8-GPU shard of pop 256 = 32 workers, 20 x 500 train steps",
-        "BASELINE configs[2]", "dueling_se_inner_kernel", c3, dueling_model, steps=2)
+        "BASELINE configs[2]", "dueling_wavechain_kernel", c3, dueling_model, steps=2)
     # configs[3]: Cliff RewardEnv + QL, pop 128 on one GPU, 100 episodes (published early-out)
     c4 = C.cliff_reward_env_ql(128)
     c4["agents"]["gtn"]["quit_when_solved"] = False
@@ -390,7 +393,7 @@ def secondary_configs():
     c5 = C.fixed_work(C.halfcheetah_reward_env_td3(8), 5)
     c5["agents"]["td3"]["init_episodes"] = 1
     run("HalfCheetah stand-in RewardEnv + TD3 (17-128-128-6, twin critics, B=192): one 8-GPU shard of pop 64 = 8 workers, 5 x 1000 "
-        "train steps", "BASELINE configs[4]", "td3_rn_inner_kernel", c5, td3_model, steps=2, se=False)
+        "train steps", "BASELINE configs[4]", "td3_wavechain_kernel", c5, td3_model, steps=2, se=False)
     return out
 
 
@@ -590,7 +593,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-file-io", action="store_true", help="skip the file-IO worker-mode leg of the CPU baseline")
     ap.add_argument("--no-configs", action="store_true", help="skip the shards of the other BASELINE configurations")
+    ap.add_argument("--only-config", type=int, default=None, choices=(2, 3, 4),
+                    help="run only the shard of BASELINE configs[N] (profiling aid; prints its record alone)")
     args = ap.parse_args()
+    if args.only_config is not None:
+        # profiling aid: one shard of one of the other BASELINE configurations, nothing else
+        torch.cuda.set_device(0)
+        print(json.dumps(secondary_configs(only=args.only_config)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         os.environ["LENV_BENCH_SPAWNED"] = "1"
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
