@@ -118,6 +118,9 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     const lenv_ddqn_cfg &cfg = a.cfg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t chain = blockIdx.x;
+    // the chain's status word starts at 0 (ok); written here rather than by a memset node in front of the launch (a captured
+    // generation replayed under rocprofv3 did not run the memset)
+    if (threadIdx.x == 0 && a.out.status) a.out.status[chain] = 0;
     constexpr bool FIXED = SHAPE != 0;
     constexpr DuelShape kDuelShape = kDuelShapes[SHAPE];
     static_assert(!(FIXED && ICM), "the specialised instantiations have no ICM");
@@ -899,9 +902,6 @@ extern "C" int lenv_dueling_se_inner_loop_icm(const lenv_ddqn_cfg *cfg, const le
         if (!off && !no_wc && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action && cfg->synthetic_env_type == 0) {
             const int wshape = lenv_wc_dueling_shape(cfg);
             if (wshape) {
-                if (out->status) {
-                    if (hipMemsetAsync(out->status, 0, sizeof(int32_t) * chains, static_cast<hipStream_t>(stream)) != hipSuccess) return LENV_ERR_LAUNCH;
-                }
                 return lenv_wc_dueling_launch(wshape, cfg, theta, eps, worker, sign, agent_init, rng_keys, chains, a.arena, a.arena_stride, a.rb_cap,
                                               a.RS, a.P, a.P_se, a.se_net_size, out, static_cast<hipStream_t>(stream));
             }
@@ -913,10 +913,6 @@ extern "C" int lenv_dueling_se_inner_loop_icm(const lenv_ddqn_cfg *cfg, const le
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;
-    if (out->status) {
-        e = hipMemsetAsync(out->status, 0, sizeof(int32_t) * chains, static_cast<hipStream_t>(stream));
-        if (e != hipSuccess) return LENV_ERR_LAUNCH;
-    }
     hipLaunchKernelGGL(kern, dim3((unsigned)chains), dim3(DNT), lds_bytes, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }

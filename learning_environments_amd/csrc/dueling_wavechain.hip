@@ -516,6 +516,9 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     L.init();
     const int tid = L.tid, wave = L.wave;
     const int64_t chain = blockIdx.x;
+    // the chain's status word starts at 0 (ok); written here rather than by a memset node in front of the launch (a captured
+    // generation replayed under rocprofv3 did not run the memset)
+    if (threadIdx.x == 0 && a.out.status) a.out.status[chain] = 0;
     const float prelu = cfg.q_prelu;
 
     // ---- LDS carve-up ----

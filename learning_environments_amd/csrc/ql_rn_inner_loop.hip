@@ -41,11 +41,39 @@ __device__ __forceinline__ int ql_argmax_f32(const double *row, int n)
 __device__ __forceinline__ void rn_phi_and_shaped(const lenv_ql_cfg &cfg, const float *theta, const float *eps_all,
                                                   const int32_t *worker, const float *sign, const float *shaped_override,
                                                   const int32_t *next_state, const double *reward, int64_t P, int64_t chain,
-                                                  int lane, float *phi, float *shaped, float *shaped_out, float *phi_out)
+                                                  int lane, float *phi, float *shaped, float *shaped_out, float *phi_out, float *hbuf)
 {
     const int N = cfg.n_states, A = cfg.n_actions, H = cfg.rn_hidden;
     const int t = cfg.reward_env_type;
-    if (t != 0 && !shaped_override) {
+    if (t != 0 && !shaped_override && cfg.rn_layers > 1) {
+        // reward nets with several hidden layers (default_config_gridworld_reward_env.yaml: HoleRoomLarge ships hidden_layer 2;
+        // build_nn_from_config, models/model_utils.py:16-29): Linear(N, H) | [Linear(H, H)] x (layers - 1) | Linear(H, 1), one
+        // shared activation.  Lane = state; the hidden rows of a lane live in LDS (hbuf [2][H][64], lane-minor: conflict-free);
+        // every dot product is the k-ascending fmaf chain from 0 with the bias added last (oracle: mlp_forward_one)
+        const float sg = eps_all ? sign[chain] : 0.0f;
+        const float *th = theta, *e = eps_all ? eps_all + (int64_t)worker[chain] * P : nullptr;
+        auto Wp = [&](int64_t i) { return e ? fma32(sg, e[i], th[i]) : th[i]; };
+        float *h0 = hbuf + lane, *h1 = hbuf + (int64_t)H * 64 + lane;
+        for (int s0 = 0; s0 < N; s0 += 64) {
+            const int s = s0 + lane < N ? s0 + lane : N - 1;                      // idle lanes redo the last state (uniform loops)
+            const int64_t off_b0 = (int64_t)H * N;
+            for (int j = 0; j < H; ++j) h0[j * 64] = act_fwd(cfg.rn_act, cfg.rn_prelu, Wp((int64_t)j * N + s) + Wp(off_b0 + j));
+            float *hin = h0, *hout = h1;
+            int64_t off = off_b0 + H;
+            for (int l = 1; l < cfg.rn_layers; ++l) {
+                for (int j = 0; j < H; ++j) {
+                    float z = 0.0f;
+                    for (int k = 0; k < H; ++k) z = fma32(hin[k * 64], Wp(off + (int64_t)j * H + k), z);
+                    hout[j * 64] = act_fwd(cfg.rn_act, cfg.rn_prelu, z + Wp(off + (int64_t)H * H + j));
+                }
+                off += (int64_t)H * H + H;
+                float *tmp = hin; hin = hout; hout = tmp;
+            }
+            float acc = 0.0f;
+            for (int j = 0; j < H; ++j) acc = fma32(hin[j * 64], Wp(off + j), acc);
+            if (s0 + lane < N) phi[s] = acc + Wp(off + H);
+        }
+    } else if (t != 0 && !shaped_override) {
         const float sg = eps_all ? sign[chain] : 0.0f;
         const float *th = theta, *e = eps_all ? eps_all + (int64_t)worker[chain] * P : nullptr;
         auto W = [&](int64_t i) { return e ? fma32(sg, e[i], th[i]) : th[i]; };
@@ -92,7 +120,7 @@ __global__ __launch_bounds__(64) void rn_shape_kernel(const QlArgs a, float *phi
     float *phi = reinterpret_cast<float *>(lds_raw), *shaped = phi + N;
     const int64_t chain = blockIdx.x;
     rn_phi_and_shaped(a.cfg, a.theta, a.eps, a.worker, a.sign, nullptr, a.next_state, a.reward, a.P, chain, threadIdx.x, phi,
-                      shaped, shaped_out + chain * N * A, phi_out ? phi_out + chain * N : nullptr);
+                      shaped, shaped_out + chain * N * A, phi_out ? phi_out + chain * N : nullptr, shaped + N * A);
 }
 
 // KIND: 0 QL, 1 SARSA; CB: count-based exploration bonus (compile-time so that the plain-QL walk carries none of their code)
@@ -110,9 +138,10 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
     float *phi = reinterpret_cast<float *>(rets + cfg.test_episodes);    // [N]
     float *shaped = phi + N;                                         // [N*A]
     int *visits = reinterpret_cast<int *>(shaped + N * A);           // [N*A] visitation counts n(s,a) (count-based agents)
+    float *hbuf = reinterpret_cast<float *>(visits + N * A);         // [2][H][64] hidden rows of a multi-layer reward net (rn_layers > 1 only)
 
     rn_phi_and_shaped(cfg, a.theta, a.eps, a.worker, a.sign, a.shaped_override, a.next_state, a.reward, a.P, chain, lane,
-                      phi, shaped, a.out.shaped ? a.out.shaped + chain * N * A : nullptr, nullptr);
+                      phi, shaped, a.out.shaped ? a.out.shaped + chain * N * A : nullptr, nullptr, hbuf);
     for (int i = lane; i < N * A; i += 64) { q[i] = 0.0; if (CB) visits[i] = 0; }   // QL.py:25,31
     __syncthreads();
     if (lane != 0) return;
@@ -255,6 +284,13 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
 
 using namespace lenv;
 
+// parameters of the grid reward net (models/model_utils.py:16-29 on one-hot states): Linear(N, H) | (layers - 1) x Linear(H, H) | Linear(H, 1)
+static int64_t ql_rn_params(const lenv_ql_cfg *cfg)
+{
+    const int64_t H = cfg->rn_hidden;
+    return (int64_t)cfg->n_states * H + H + (int64_t)(cfg->rn_layers - 1) * (H * H + H) + H + 1;
+}
+
 extern "C" int lenv_ql_rn_inner_loop(const lenv_ql_cfg *cfg, const float *theta, const float *eps, const int32_t *worker,
                                      const float *sign, const float *shaped_override, const int32_t *next_state,
                                      const double *reward, const uint8_t *done, const uint64_t *rng_keys,
@@ -268,7 +304,7 @@ extern "C" int lenv_ql_rn_inner_loop(const lenv_ql_cfg *cfg, const float *theta,
     if (chains == 0) return LENV_OK;
     const int t = cfg->reward_env_type;
     if (!(t == 0 || t == 1 || t == 2 || t == 5 || t == 6)) return LENV_ERR_UNSUPPORTED;   // info-vector types: next round
-    if (cfg->rn_layers != 1 && t != 0 && !shaped_override) return LENV_ERR_UNSUPPORTED;
+    if (cfg->rn_layers < 1 || cfg->rn_layers > 4) return LENV_ERR_UNSUPPORTED;
     if (cfg->n_states < 1 || cfg->n_actions < 1 || cfg->n_actions > 16 || cfg->test_episodes < 1 || cfg->train_episodes < 0 ||
         cfg->max_steps < 1 || cfg->batch_size < 1)
         return LENV_ERR_UNSUPPORTED;
@@ -278,9 +314,10 @@ extern "C" int lenv_ql_rn_inner_loop(const lenv_ql_cfg *cfg, const float *theta,
     a.next_state = next_state; a.reward = reward; a.done = done; a.rng_keys = rng_keys;
     if (tapes) a.tapes = *tapes; else a.tapes = lenv_tapes{};
     a.out = *out;
-    a.P = (int64_t)cfg->n_states * cfg->rn_hidden + 2 * (int64_t)cfg->rn_hidden + 1;
+    a.P = ql_rn_params(cfg);
     const size_t NA = (size_t)cfg->n_states * cfg->n_actions;
-    const size_t lds_bytes = sizeof(double) * (NA + cfg->train_episodes + cfg->test_episodes) + sizeof(float) * (cfg->n_states + NA) + sizeof(int) * NA + 16;
+    const size_t lds_bytes = sizeof(double) * (NA + cfg->train_episodes + cfg->test_episodes) + sizeof(float) * (cfg->n_states + NA) + sizeof(int) * NA + 16 +
+                             (cfg->rn_layers > 1 ? sizeof(float) * 2 * 64 * (size_t)cfg->rn_hidden : 0);
     if (lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     if (cfg->agent_kind != 0 && cfg->agent_kind != 1) return LENV_ERR_UNSUPPORTED;
     void (*kern)(const QlArgs) = cfg->agent_kind == 1 ? (cfg->count_based ? ql_rn_inner_kernel<1, true> : ql_rn_inner_kernel<1, false>)
@@ -303,14 +340,14 @@ extern "C" int lenv_rn_shape_population(const lenv_ql_cfg *cfg, const float *the
     if (chains == 0) return LENV_OK;
     const int t = cfg->reward_env_type;
     if (!(t == 0 || t == 1 || t == 2 || t == 5 || t == 6)) return LENV_ERR_UNSUPPORTED;
-    if (cfg->rn_layers != 1 && t != 0) return LENV_ERR_UNSUPPORTED;
+    if (cfg->rn_layers < 1 || cfg->rn_layers > 4) return LENV_ERR_UNSUPPORTED;
     QlArgs a;
     a.cfg = *cfg;
     a.theta = theta; a.eps = eps; a.worker = worker; a.sign = sign; a.shaped_override = nullptr;
     a.next_state = next_state; a.reward = reward; a.done = nullptr; a.rng_keys = nullptr;
     a.tapes = lenv_tapes{}; a.out = lenv_ql_out{};
-    a.P = (int64_t)cfg->n_states * cfg->rn_hidden + 2 * (int64_t)cfg->rn_hidden + 1;
-    const size_t lds_bytes = sizeof(float) * ((size_t)cfg->n_states * (1 + cfg->n_actions)) + 16;
+    a.P = ql_rn_params(cfg);
+    const size_t lds_bytes = sizeof(float) * ((size_t)cfg->n_states * (1 + cfg->n_actions)) + 16 + (cfg->rn_layers > 1 ? sizeof(float) * 2 * 64 * (size_t)cfg->rn_hidden : 0);
     if (lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rn_shape_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;

@@ -92,6 +92,9 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     const lenv_td3_cfg &cfg = a.cfg;
     const int tid = threadIdx.x;
     const int64_t chain = blockIdx.x;
+    // the chain's status word starts at 0 (ok); written here rather than by a memset node in front of the launch (a captured
+    // generation replayed under rocprofv3 did not run the memset)
+    if (threadIdx.x == 0 && a.out.status) a.out.status[chain] = 0;
     constexpr int S = EnvT::S, A = EnvT::A, SA = S + A, SD = EnvT::SD;   // observation / action dims, fp64 words of the env's own state
     const bool vary = FIXED ? false : a.hp_batch != nullptr;
     const int H = FIXED ? kTd3Shape.H : (vary ? a.hp_hidden[chain] : cfg.hidden), L = FIXED ? kTd3Shape.L : (vary ? a.hp_layers[chain] : cfg.layers);
@@ -909,7 +912,6 @@ extern "C" int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg, const lenv_ch
         // production launches of the cfg-5 shape: the wave-chain kernel (LENV_NO_WAVECHAIN=1 keeps the GEMM-queue kernel for A/B runs)
         const char *nw_ = getenv("LENV_NO_WAVECHAIN");
         if (!off && !(nw_ && nw_[0] == '1') && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_reward && lenv_wc_td3_shape(cfg)) {
-            if (out->status && hipMemsetAsync(out->status, 0, sizeof(int32_t) * chains, static_cast<hipStream_t>(stream)) != hipSuccess) return LENV_ERR_LAUNCH;
             return lenv_wc_td3_launch(cfg, theta, eps, worker, sign, agent_init, rng_keys, chains, a.arena, a.arena_stride, a.rb_cap, a.RS, a.P, a.actor.P,
                                       a.critic.P, a.P_rn, out, static_cast<hipStream_t>(stream));
         }
@@ -922,10 +924,6 @@ extern "C" int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg, const lenv_ch
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;
-    if (out->status) {
-        e = hipMemsetAsync(out->status, 0, sizeof(int32_t) * chains, static_cast<hipStream_t>(stream));
-        if (e != hipSuccess) return LENV_ERR_LAUNCH;
-    }
     hipLaunchKernelGGL(kern, dim3((unsigned)chains), dim3(DNT), lds_bytes, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }

@@ -403,6 +403,9 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     const lenv_td3_cfg &cfg = a.cfg;
     const int tid = threadIdx.x;
     const int64_t chain = blockIdx.x;
+    // the chain's status word starts at 0 (ok); written here rather than by a memset node in front of the launch (a captured
+    // generation replayed under rocprofv3 did not run the memset)
+    if (threadIdx.x == 0 && a.out.status) a.out.status[chain] = 0;
     const float prelu = cfg.prelu, ma = (float)cfg.max_action;
     const int RS = a.RS, rn_act = cfg.rn_act, rtype = cfg.reward_env_type;
 

@@ -280,7 +280,8 @@ class QlInnerLoop(object):
         self.next_state = torch.from_numpy(tables["next_state"].astype("int32")).contiguous().to(self.dev)
         self.reward = torch.from_numpy(tables["reward"].astype("float64")).contiguous().to(self.dev)
         self.done = torch.from_numpy(tables["done"].astype("uint8")).contiguous().to(self.dev)
-        self.p_theta = N * cfg.rn_hidden + 2 * cfg.rn_hidden + 1
+        H = cfg.rn_hidden            # Linear(N, H) | (layers - 1) x Linear(H, H) | Linear(H, 1)
+        self.p_theta = N * H + H + (max(1, cfg.rn_layers) - 1) * (H * H + H) + H + 1
         self.score = torch.zeros(self.chains, dtype=torch.float64, device=self.dev)
         self.stats = torch.zeros((self.chains, 4), dtype=torch.int64, device=self.dev)
         self.status = torch.zeros(self.chains, dtype=torch.int32, device=self.dev)

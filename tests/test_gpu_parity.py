@@ -356,6 +356,43 @@ def test_ql_rn_counter_mode_population_vs_oracle(eng, orc, golden, env_name, rty
         assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
 
 
+@pytest.mark.parametrize("layers", [2, 3])
+def test_ql_rn_multi_layer_reward_net_vs_oracle(eng, orc, golden, layers):
+    """Grid reward nets with more than one hidden layer (default_config_gridworld_reward_env.yaml:108-115 ships HoleRoomLarge with
+    hidden_layer 2): the shaped-reward table of every perturbation and whole QL chains, bit for bit against the oracle."""
+    g = golden("g9_calc_score_cliff_a")
+    cfgd = json.loads(str(g["config_json"]))
+    cfgd["env_name"] = "HoleRoomLarge"
+    cfgd["envs"]["HoleRoomLarge"] = dict(cfgd["envs"]["Cliff"], reward_env_type=2, hidden_layer=layers, hidden_size=32, max_steps=30)
+    cfgd["agents"]["ql"].update(eps_init=0.3, eps_min=0.05, eps_decay=0.9, alpha=0.7, train_episodes=20)
+    ocfg, cfg, tables = _ql_cfgs(orc, cfgd, 0)
+    assert cfg.rn_layers == layers
+    N, H = tables["n_states"], ocfg.rn_hidden
+    P = N * H + H + (layers - 1) * (H * H + H) + H + 1
+    rng = np.random.RandomState(13)
+    pop = 2
+    theta = (rng.randn(P) * 0.3).astype(np.float32)
+    eps = (rng.randn(pop, P) * 0.1).astype(np.float32)
+    worker = np.repeat(np.arange(pop), 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), pop)
+    keys = np.array([orc.chain_key(15, 1, int(worker[c]), c % 3) for c in range(3 * pop)], np.uint64)
+    il = eng.QlInnerLoop(cfg, 3 * pop, tables)
+    assert il.p_theta == P
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), rng_keys=dev(keys.view(np.int64)))
+    phi, shaped = eng.rn_shape_population(cfg, dev(theta), dev(eps), dev(worker), dev(sign), dev(tables["next_state"].astype(np.int32)),
+                                          dev(tables["reward"].astype(np.float64)), 3 * pop)
+    torch.cuda.synchronize()
+    A = tables["n_actions"]
+    for c in range(3 * pop):
+        w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+        ophi, oshaped = orc.rn_shaped_rewards(ocfg, w, tables)
+        assert np.array_equal(phi[c].cpu().numpy(), ophi) and np.array_equal(shaped[c].cpu().numpy().reshape(N, A), oshaped)
+        o = orc.ql_rn_chain(ocfg, w, tables, rng_key=int(keys[c]))
+        assert np.array_equal(il.q_table[c].cpu().numpy().reshape(N, A), o["q_table"]), c
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # config 3: DuelingDDQN on a synthetic environment (LDS-tiled GEMM kernel, parameters in the HBM arena)
 # ---------------------------------------------------------------------------------------------------------------

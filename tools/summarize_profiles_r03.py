@@ -57,10 +57,23 @@ def traffic(prefix, kernel_sub):
             "note": "2*FETCH_SIZE + WRITE_SIZE (KB -> bytes) per launch, gfx950 read-side correction"}
 
 
+def steady_state_dispatches(pattern, kernel_sub):
+    """Dispatches (kernels, fills, device copies) between the last two launches of the fused kernel in the kernel trace: one
+    steady-state generation, start-up launches excluded."""
+    for f in newest(pattern):
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+        idx = [i for i, r in enumerate(rows) if kernel_sub in r["Kernel_Name"]]
+        if len(idx) >= 2:
+            return idx[-1] - idx[-2], [rows[i]["Kernel_Name"][:48] for i in range(idx[-2] + 1, idx[-1] + 1)]
+    return None, None
+
+
 head = copy_stats("gpurun_out/prof/*/*kernel_stats.csv", tag + "_bench_kernel_stats.csv", "ddqn_se_inner")
 if head:
     out["inner_kernel_calls"], out["inner_kernel_avg_ms"] = head["calls"], head["avg_ms"]
-    out["launches_per_generation"] = head["dispatches_per_generation"]
+    n, names = steady_state_dispatches("gpurun_out/prof/*/*kernel_trace.csv", "ddqn_se_inner")
+    out["launches_per_generation"] = n if n is not None else head["dispatches_per_generation"]
+    out["launches_of_a_generation"] = names
 t = traffic("gpurun_out/pmc_", "ddqn_se_inner")
 if t:
     out.update({k: v for k, v in t.items() if k != "note"})
