@@ -62,6 +62,7 @@ struct DuelArgs {
     // arena offsets (floats), sized for cfg's (maximal) shapes
     DuelArena A;                              // shape-determined part (see duel_arena)
     int64_t a_replay, a_meter;                // run-time sized: carved after A.end
+    int64_t a_se_mid;                         // SEs with several hidden layers: [3][se_layers - 1][Hse*Hse + Hse] perturbed weights | biases
     // ICM agents (cfg.icm_enabled): fresh parameters per chain, optional final parameters, arena offsets of the ICM buffers
     const float *icm_init; float *icm_final; int P_icm;
     int64_t a_icm[IB_COUNT];
@@ -153,8 +154,10 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     float *se_wout = se_b0 + 3 * Hse;                     // [S+2][Hse]
     float *se_bout = se_wout + (S + 2) * Hse;             // [S+2] (padded to 16)
     float *se_h = se_bout + 16;                           // [3][Hse]
+    const int seL = FIXED ? 1 : cfg.se_layers;              // hidden layers of the SE's three nets (virtual_env.py:16-33)
+    float *se_h2 = se_h + 3 * Hse;                        // [3][Hse] second hidden row (se_layers > 1 only)
     const int RBH = CFG_B > T ? CFG_B : T;                  // LDS is carved for cfg's (maximal) batch
-    float *qv = se_h + 3 * Hse;                           // [3][B][A]   q(s), q_online(s'), q_target(s'); [T][A] in the test phase
+    float *qv = se_h2 + (seL > 1 ? 3 * Hse : 0);                           // [3][B][A]   q(s), q_online(s'), q_target(s'); [T][A] in the test phase
     float *Vb = qv + 3 * RBH * A;                           // [3][RBH]  value-head outputs of the three passes (slot 0 reused as scratch)
     float *Advb = Vb + 3 * RBH;                           // [3][RBH][A] advantage-head outputs (RBH = max(B, T) rows per slot)
     float *dq = Advb + 3 * RBH * A;                       // [B]
@@ -199,10 +202,12 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
             int net = 0, r = i;
             if (r >= a.se_net_size[0]) { r -= a.se_net_size[0]; net = 1; if (r >= a.se_net_size[1]) { r -= a.se_net_size[1]; net = 2; } }
             const int orow = net == 0 ? 0 : (net == 1 ? S : S + 1);
+            const int mid = (seL - 1) * (Hse * Hse + Hse);        // hidden-to-hidden layers of this net (state-dict order: W_l | b_l)
             if (r < Hse * K) { int j = r / K, k = r - j * K; se_w0T[(net * K + k) * Hse + j] = w; }
             else if ((r -= Hse * K) < Hse) se_b0[net * Hse + r] = w;
+            else if ((r -= Hse) < mid) arena[a.a_se_mid + (int64_t)net * mid + r] = w;
             else {
-                r -= Hse;
+                r -= mid;
                 const int n_out = net == 0 ? S : 1;
                 if (r < n_out * Hse) { int o = r / Hse, j = r - o * Hse; se_wout[(orow + o) * Hse + j] = w; }
                 else se_bout[orow + (r - n_out * Hse)] = w;
@@ -470,9 +475,24 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 se_h[uu] = act_fwd(se_act_id, cfg.se_prelu, z);
             }
             __syncthreads();
+            const float *se_hl = se_h;                     // the last hidden row of the three nets
+            for (int l = 1; l < seL; ++l) {                // further hidden layers (build_nn_from_config): k-ascending chains over the arena copy
+                const float *hin = (l & 1) ? se_h : se_h2;
+                float *hout = (l & 1) ? se_h2 : se_h;
+                for (int uu = tid; uu < 3 * Hse; uu += DNT) {
+                    const int net = uu / Hse, j = uu - net * Hse;
+                    const float *wm = arena + a.a_se_mid + ((int64_t)net * (seL - 1) + (l - 1)) * (Hse * Hse + Hse);
+                    const float *w = wm + (int64_t)j * Hse, *hi = hin + net * Hse;
+                    float z = 0.0f;
+                    for (int k = 0; k < Hse; ++k) z = fma32(hi[k], w[k], z);
+                    hout[uu] = act_fwd(se_act_id, cfg.se_prelu, z + wm[Hse * Hse + j]);
+                }
+                __syncthreads();
+                se_hl = hout;
+            }
             if (tid < S + 2) {
                 const int net = tid < S ? 0 : (tid == S ? 1 : 2);
-                const float *h = se_h + net * Hse, *w = se_wout + tid * Hse;
+                const float *h = se_hl + net * Hse, *w = se_wout + tid * Hse;
                 float acc = 0.0f;
                 for (int j = 0; j < Hse; ++j) acc = fma32(h[j], w[j], acc);
                 acc = acc + se_bout[tid];
@@ -763,14 +783,15 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     // would diverge silently, so agent-net PReLU is refused (SE / reward nets keep theirs: the reference never updates those)
     if (cfg->q_act == LENV_ACT_PRELU) return LENV_ERR_UNSUPPORTED;
     if (cfg->grad_chunk != 0 && cfg->grad_chunk < B) return LENV_ERR_UNSUPPORTED;   // batch gradient = one sequential chunk here
-    if (L < 1 || L > D_MAXL || H < 1 || H > D_MAXH || F < 1 || F > D_MAXW || B < 1 || B > D_MAXB || T < 1 || T > D_MAXW || cfg->se_layers != 1)
+    if (L < 1 || L > D_MAXL || H < 1 || H > D_MAXH || F < 1 || F > D_MAXW || B < 1 || B > D_MAXB || T < 1 || T > D_MAXW || cfg->se_layers < 1 || cfg->se_layers > D_MAXL)
         return LENV_ERR_UNSUPPORTED;
+    if (cfg->synthetic_env_type == 1 && cfg->se_layers != 1) return LENV_ERR_UNSUPPORTED;    // the reward net over a real env: one hidden layer here
     if (!((cfg->env_id == LENV_ENV_CARTPOLE && S == 4 && A == 2) || (cfg->env_id == LENV_ENV_ACROBOT && S == 6 && A == 3) ||
           (cfg->env_id == LENV_ENV_MOUNTAINCAR && S == 2 && A == 3)))
         return LENV_ERR_UNSUPPORTED;
     a.P = duel_param_offsets(S, A, H, F, L, plain).P;
-    a.se_net_size[0] = (int)d_mlp_params(K, Hse, 1, S);
-    a.se_net_size[1] = a.se_net_size[2] = (int)d_mlp_params(K, Hse, 1, 1);
+    a.se_net_size[0] = (int)d_mlp_params(K, Hse, cfg->se_layers, S);
+    a.se_net_size[1] = a.se_net_size[2] = (int)d_mlp_params(K, Hse, cfg->se_layers, 1);
     a.P_se = a.se_net_size[0] + a.se_net_size[1] + a.se_net_size[2];
     if (cfg->synthetic_env_type == 1) {
         // RewardEnv over the real env: theta = the reward network (reward_env.py:29-46; a 1-input dummy for type 0); the real
@@ -788,6 +809,7 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     auto take = [&](int64_t n) { int64_t r = off; off += (n + 3) & ~(int64_t)3; return r; };
     a.a_replay = take(a.rb_cap * a.RS);
     a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
+    a.a_se_mid = take(cfg->se_layers > 1 ? 3 * (int64_t)(cfg->se_layers - 1) * ((int64_t)Hse * Hse + Hse) : 0);
     a.P_icm = 0;
     for (int i = 0; i < IB_COUNT; ++i) a.a_icm[i] = 0;
     if (cfg->icm_enabled) {
@@ -809,7 +831,7 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
         }
     }
     const size_t lds_floats = GemmShape<D_MAXI>::PS_FLOATS + GemmShape<D_MAXI>::QS_FLOATS + GEMM_QUEUE_MAX * sizeof(GemmCmd) / sizeof(float) +
-                              3 * K * Hse + 3 * Hse + (S + 2) * Hse + 16 + 3 * Hse + 3 * (size_t)(B > T ? B : T) * A + 3 * (size_t)(B > T ? B : T) * (1 + A) +
+                              3 * K * Hse + 3 * Hse + (S + 2) * Hse + 16 + 3 * Hse + (cfg->se_layers > 1 ? 3 * Hse : 0) + 3 * (size_t)(B > T ? B : T) * A + 3 * (size_t)(B > T ? B : T) * (1 + A) +
                               B + (size_t)B * A + 64 + 2 * (4 * (size_t)T + T) + 2 * T + 8 + 16 + 16 + (size_t)T + 10;
     *lds_bytes = lds_floats * sizeof(float);
     if (*lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;

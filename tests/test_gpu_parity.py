@@ -226,10 +226,40 @@ def test_inner_loop_early_out(eng, orc, golden):
 def test_unsupported_shapes_raise(eng, orc, golden):
     g = golden("g8_calc_score_cartpole_a")
     cfgd = json.loads(str(g["config_json"]))
-    _, cfg = _inner_cfg(orc, cfgd, se_layers=2)            # neither fused kernel takes a two-hidden-layer SE
+    _, cfg = _inner_cfg(orc, cfgd, se_layers=4)            # no fused kernel takes an SE with four hidden layers
     with pytest.raises(NotImplementedError):
         il = eng.InnerLoop(cfg, 1)
         il.run(dev(g["theta"]), None, None, None, dev(np.zeros((1, il.p_agent), np.float32)), rng_keys=dev(np.zeros(1, np.int64)))
+
+
+@pytest.mark.parametrize("se_layers", [2, 3])
+def test_inner_loop_multi_layer_se_vs_oracle(eng, orc, golden, se_layers):
+    """Synthetic envs whose three nets have more than one hidden layer (envs/virtual_env.py:16-33 builds them with
+    build_nn_from_config and the env section's hidden_layer): DDQN chains run in the GEMM-queue kernel's plain-DQN mode with the
+    hidden-to-hidden SE layers in the arena; whole chains bit for bit against the oracle (counter mode)."""
+    g = golden("g8_calc_score_cartpole_a")
+    cfgd = json.loads(str(g["config_json"]))
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, se_layers=se_layers, se_hidden=24, train_episodes=4, max_steps=15, test_episodes=3)
+    S, A = cfg.state_dim, cfg.num_actions
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, 24, se_layers, "leakyrelu"))
+    rng = np.random.RandomState(17)
+    chains = 3
+    theta = (rng.randn(P_se) * 0.3).astype(np.float32)
+    eps = (rng.randn(1, P_se) * 0.05).astype(np.float32)
+    worker, sign = np.zeros(chains, np.int32), np.array([0.0, 1.0, -1.0], np.float32)
+    keys = np.array([orc.chain_key(31, 2, 0, c) for c in range(chains)], np.uint64)
+    il = eng.InnerLoop(cfg, chains)
+    assert il.dueling                                        # the register-resident DDQN kernel keeps to one SE hidden layer
+    init = rng.uniform(-0.4, 0.4, (chains, il.p_agent)).astype(np.float32)
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(init), rng_keys=dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        w = (np.float32(sign[c]) * eps[0] + theta).astype(np.float32)
+        o = orc.ddqn_se_chain(ocfg, w, init[c], rng_key=int(keys[c]))
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
 
 
 def test_nes_worker_best_and_rank_update(eng, orc, golden):
