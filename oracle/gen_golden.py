@@ -1044,6 +1044,290 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over
 
 
 # ------------------------------------------------------------------------------------------------
+# G4TD / G8TD: TD3_discrete_vary (agents/TD3_discrete_vary.py) -- learn calls on a fixed buffer, and whole calc_score runs on
+# a CartPole / Acrobot VirtualEnv through GTN_Worker.  The Gumbel(0,1) draws of F.gumbel_softmax are recorded where torch
+# makes them (Tensor.exponential_, then -log as torch computes it) next to the Gaussian noises, replay indices and resets.
+# ------------------------------------------------------------------------------------------------
+def _params_flat(net):
+    """Module.parameters() order (the shared LayerNorm appears once, behind the second Linear)."""
+    return np.concatenate([p.detach().cpu().numpy().astype(np.float32).reshape(-1) for p in net.parameters()])
+
+
+def _pack_td3d(agent, target=False):
+    nets = (agent.actor_target, agent.critic_target_1, agent.critic_target_2) if target else (agent.actor, agent.critic_1, agent.critic_2)
+    return np.concatenate([_params_flat(n) for n in nets])
+
+
+def _td3d_cfg(cfg_yaml, env_name, over=None, env_over=None):
+    cfg = load_cfg(cfg_yaml)
+    cfg["agents"]["td3_discrete_vary"].update(over or {})
+    cfg["agents"]["td3_discrete_vary"]["print_rate"] = int(1e9)
+    cfg["envs"][env_name].update(env_over or {})
+    cfg["agents"]["gtn"]["agent_name"] = "TD3_discrete_vary"
+    cfg["agents"]["gtn"]["synthetic_env_type"] = 0
+    return cfg
+
+
+class _GumbelTap(object):
+    """Records every Tensor.exponential_() result as the Gumbel draw torch derives from it (-log(e))."""
+    def __init__(self):
+        self.orig = torch.Tensor.exponential_
+        self.sink = None
+
+    def __enter__(self):
+        tap = self
+
+        def rec_exponential(t, *a, **k):
+            v = tap.orig(t, *a, **k)
+            if tap.sink is not None:
+                tap.sink.append((-(v.clone().log())).numpy().copy())
+            return v
+        torch.Tensor.exponential_ = rec_exponential
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.exponential_ = self.orig
+
+
+def gen_g4td():
+    from agents.TD3_discrete_vary import TD3_discrete_vary
+    from envs.env_factory import EnvFactory
+    from utils import ReplayBuffer
+    out = {}
+    variants = [("default_config_cartpole_syn_env.yaml", "CartPole-v0", {"hidden_size": 24, "batch_size": 16, "policy_delay": 1, "hidden_layer": 2,
+                                                                        "use_layer_norm": True, "gumbel_softmax_hard": False}, 4),
+                ("default_config_acrobot_syn_env.yaml", "Acrobot-v1", {"hidden_size": 20, "batch_size": 12, "policy_delay": 2, "hidden_layer": 3,
+                                                                      "use_layer_norm": True, "activation_fn": "tanh", "gumbel_softmax_hard": True}, 4),
+                ("default_config_cartpole_syn_env.yaml", "CartPole-v0", {"hidden_size": 18, "batch_size": 10, "policy_delay": 1, "hidden_layer": 2,
+                                                                        "activation_fn": "leakyrelu", "gumbel_softmax_temp": 0.7}, 3)]
+    for vi, (yaml_name, env_name, over, nsteps) in enumerate(variants):
+        over = dict(over, vary_hp=False)
+        cfg = _td3d_cfg(yaml_name, env_name, over)
+        seed_all(1470 + vi)
+        with quiet():
+            fac = EnvFactory(cfg)
+            real_env = fac.generate_real_env()
+            agent = TD3_discrete_vary(env=real_env, min_action=real_env.get_min_action(), max_action=real_env.get_max_action(), config=cfg)
+        a = cfg["agents"]["td3_discrete_vary"]
+        B, S, A = a["batch_size"], real_env.get_state_dim(), real_env.get_action_dim()
+        rb = ReplayBuffer(state_dim=S, action_dim=A, device="cpu", max_size=300)
+        for i in range(120):
+            rb.add(torch.randn(S) * 0.5, torch.softmax(torch.randn(A) * 2, 0) + torch.randn(A) * 0.1, torch.randn(S) * 0.5, torch.randn(1) * 0.3,
+                   torch.zeros(1) + (i % 17 == 0))
+        with torch.no_grad():
+            for net in (agent.actor_target, agent.critic_target_1, agent.critic_target_2):
+                for p in net.parameters():
+                    p.add_(torch.randn_like(p) * 0.03)
+            for net in (agent.actor, agent.critic_1, agent.critic_2, agent.actor_target, agent.critic_target_1, agent.critic_target_2):
+                for m in net.modules():
+                    if isinstance(m, torch.nn.LayerNorm):      # default 1 / 0 would hide a swapped or missing affine
+                        m.weight.uniform_(0.6, 1.4); m.bias.uniform_(-0.2, 0.2)
+        agent.total_it = 3 * vi                                  # a temperature off the schedule's first entry
+        pre = "v%d_" % vi
+        out[pre + "meta"] = np.array([S, A, a["hidden_size"], a["hidden_layer"], ["identity", "relu", "leakyrelu", "tanh", "prelu"].index(a["activation_fn"]),
+                                      B, a["policy_delay"], nsteps, int(bool(a.get("use_layer_norm", False))), int(bool(a["gumbel_softmax_hard"])),
+                                      agent.total_it], np.int64)
+        out[pre + "hparams"] = np.array([a["gamma"], a["lr"], a["tau"], a["policy_std"], a["policy_std_clip"], float(real_env.get_max_action()),
+                                         a["gumbel_softmax_temp"]], np.float64)
+        out[pre + "params0"] = _pack_td3d(agent)
+        out[pre + "targets0"] = _pack_td3d(agent, True)
+        # forward of the actor with recorded Gumbel draws
+        x = torch.randn(5, S)
+        sink = []
+        with _GumbelTap() as tap, torch.no_grad():
+            tap.sink = sink
+            out[pre + "fwd_actor"] = agent.actor(x, 0.8).numpy()
+        out[pre + "fwd_s"] = x.numpy(); out[pre + "fwd_gumbel"] = sink[0]
+        rows_all, noises, gts, gas, pars, tars = [], [], [], [], [], []
+        orig_randn_like = torch.randn_like
+        for step in range(nsteps):
+            idx = np.random.randint(0, rb.size, size=B)
+            rb.sample = lambda batch_size, _idx=idx: rb._sample_idx(_idx)
+            rows = np.concatenate([rb.state[idx].numpy(), rb.action[idx].numpy(), rb.next_state[idx].numpy(),
+                                   rb.reward[idx].numpy(), rb.done[idx].numpy()], axis=1)
+            holder = {}
+
+            def rec_randn_like(t, *a_, **k_):
+                v = orig_randn_like(t, *a_, **k_)
+                holder["n"] = v.numpy().copy()
+                return v
+            torch.randn_like = rec_randn_like
+            sink = []
+            try:
+                with _GumbelTap() as tap:
+                    tap.sink = sink
+                    agent.learn(rb, real_env, episode=50)
+            finally:
+                torch.randn_like = orig_randn_like
+            rows_all.append(rows); noises.append(holder["n"]); gts.append(sink[0])
+            gas.append(sink[1] if len(sink) > 1 else np.zeros_like(sink[0]))
+            pars.append(_pack_td3d(agent)); tars.append(_pack_td3d(agent, True))
+        out[pre + "rows"] = np.stack(rows_all).astype(np.float32)
+        out[pre + "policy_noise"] = np.stack(noises).astype(np.float32)
+        out[pre + "gumbel_target"] = np.stack(gts).astype(np.float32)
+        out[pre + "gumbel_actor"] = np.stack(gas).astype(np.float32)
+        out[pre + "params"] = np.stack(pars)
+        out[pre + "targets"] = np.stack(tars)
+    out["n_variants"] = np.array(len(variants))
+    save("g4td_td3_discrete_learn", **out)
+
+
+def gen_g8td(name, seed, cfg_yaml="default_config_cartpole_syn_env.yaml", env_name="CartPole-v0", env_cls="CartPoleEnv", agent_over=None,
+             env_over=None, done_bias_shift=0.0, vary_seed=None):
+    import json
+    import statistics
+    import agents.GTN_worker as gw
+    from agents.GTN import GTN_Worker
+    import gym.envs as genvs
+    import gym.spaces as gspaces
+    over = dict(train_episodes=4, init_episodes=2, batch_size=16, hidden_size=24, hidden_layer=2, test_episodes=2, vary_hp=False)
+    over.update(agent_over or {})
+    cfg = _td3d_cfg(cfg_yaml, env_name, over, env_over or {"max_steps": 7, "hidden_size": 20})
+    drawn = {}
+    if vary_seed is not None:
+        import ConfigSpace
+        ConfigSpace.RANDOM.seed(vary_seed)
+        cfg["agents"]["td3_discrete_vary"]["vary_hp"] = True
+        orig_cs_sample = ConfigSpace.ConfigurationSpace.sample_configuration
+
+        def rec_cs_sample(self):
+            d = orig_cs_sample(self)
+            drawn.update(d)
+            return d
+        ConfigSpace.ConfigurationSpace.sample_configuration = rec_cs_sample
+    rec = dict(rand=[], act_noise=[], test_noise=[], policy_noise=[], replay=[], resets=[], steps=[], gumbel_act=[], gumbel_test=[],
+               gumbel_learn=[], learn_calls=[], purpose=None, active=False)
+    orig_randn, orig_randn_like, orig_randint = torch.randn, torch.randn_like, np.random.randint
+    env_class = getattr(genvs, env_cls)
+    orig_disc_sample, orig_reset = gspaces.Discrete.sample, env_class.reset
+
+    def rec_randn(*a, **k):
+        v = orig_randn(*a, **k)
+        if rec["active"] and rec["purpose"] in ("act_noise", "test_noise"):
+            rec[rec["purpose"]].append(v.numpy().copy())
+        return v
+
+    def rec_randn_like(t, *a, **k):
+        v = orig_randn_like(t, *a, **k)
+        if rec["active"] and rec["purpose"] == "learn":
+            rec["policy_noise"].append(v.numpy().copy())
+        return v
+
+    def rec_randint(*a, **k):
+        v = orig_randint(*a, **k)
+        if rec["active"]:
+            rec["replay"].append(np.asarray(v).copy())
+        return v
+
+    def rec_disc_sample(self):
+        v = orig_disc_sample(self)
+        if rec["active"]:
+            rec["rand"].append(int(v))
+        return v
+
+    def rec_reset(self):
+        obs = orig_reset(self)
+        if rec["active"]:
+            rec["resets"].append((id(self), np.array(self.state, np.float64).copy()))
+        return obs
+
+    orig_select_agent = gw.select_agent
+    holder = {}
+    tap = _GumbelTap()
+
+    def wrapped_select_agent(config, agent_name):
+        agent = orig_select_agent(config=config, agent_name=agent_name)
+        holder["init"] = _pack_td3d(agent)
+        holder["agent"] = agent
+
+        def wrap(fn, purpose, sink_name):
+            def inner(*a, **k):
+                prev, prev_sink = rec["purpose"], tap.sink
+                rec["purpose"] = purpose
+                tap.sink = rec[sink_name]
+                n0 = len(rec[sink_name])
+                try:
+                    return fn(*a, **k)
+                finally:
+                    rec["purpose"], tap.sink = prev, prev_sink
+                    if purpose == "learn":
+                        rec["learn_calls"].append(len(rec[sink_name]) - n0)       # 1 = critics only, 2 = policy update too
+            return inner
+        agent.select_train_action = wrap(agent.select_train_action, "act_noise", "gumbel_act")
+        agent.select_test_action = wrap(agent.select_test_action, "test_noise", "gumbel_test")
+        agent.learn = wrap(agent.learn, "learn", "gumbel_learn")
+        return agent
+
+    with quiet():
+        w = GTN_Worker(id=0, bohb_id=0)
+        seed_all(seed)
+        w.config = cfg
+        w.late_init(cfg)
+        w.timeout = 1e9
+        env = w.synthetic_env_orig
+        if done_bias_shift:
+            with torch.no_grad():
+                env.env.done_net[-1].bias.add_(done_bias_shift)
+        theta = se_theta(env)
+        orig_step = env.step
+
+        def rec_step(action, state=None):
+            s_before = env.env.state.detach().numpy().astype(np.float32).copy()
+            ns, r, d = orig_step(action=action, state=state)
+            rec["steps"].append(dict(state=s_before, action=int(action.item()), next_state=ns.detach().numpy().copy(),
+                                     reward=float(r.item()), done=float(d.item())))
+            return ns, r, d
+        env.step = rec_step
+        torch.randn, torch.randn_like, np.random.randint = rec_randn, rec_randn_like, rec_randint
+        gspaces.Discrete.sample, env_class.reset = rec_disc_sample, rec_reset
+        gw.select_agent = wrapped_select_agent
+        train_reset_id = id(env.env.reset_env.env.unwrapped)
+        try:
+            with tap:
+                rec["active"] = True
+                agent = gw.select_agent(config=w.config, agent_name=w.agent_name)
+                real_env = w.env_factory.generate_real_env()
+                reward_list_train, episode_length_train, rbuf = agent.train(env=env, test_env=real_env, time_remaining=1e9)
+                reward_list_test, _, _ = agent.test(env=real_env, time_remaining=1e9)
+                rec["active"] = False
+        finally:
+            torch.randn, torch.randn_like, np.random.randint = orig_randn, orig_randn_like, orig_randint
+            gspaces.Discrete.sample, env_class.reset = orig_disc_sample, orig_reset
+            gw.select_agent = orig_select_agent
+            if vary_seed is not None:
+                ConfigSpace.ConfigurationSpace.sample_configuration = orig_cs_sample
+    A = real_env.get_action_dim()
+    # the learn calls' Gumbel draws: the first of a call belongs to actor_target(next_states), the second (policy updates) to actor(states)
+    gt, ga, i = [], [], 0
+    for n in rec["learn_calls"]:
+        gt.append(rec["gumbel_learn"][i])
+        if n > 1:
+            ga.append(rec["gumbel_learn"][i + 1])
+        i += n
+
+    def pad4(rows):
+        rows = np.array(rows, np.float64).reshape(len(rows), -1)
+        return np.concatenate([rows, np.zeros((rows.shape[0], 4 - rows.shape[1]))], axis=1) if rows.shape[1] < 4 else rows
+
+    def rows_of(lst):
+        return np.concatenate([np.asarray(v, np.float32).reshape(-1, A) for v in lst]) if lst else np.zeros((0, A), np.float32)
+    save(name, config_json=np.array(json.dumps(cfg)), hp_json=np.array(json.dumps(drawn)), theta=theta, agent_init=holder["init"],
+         tape_rand_action=np.array(rec["rand"], np.int32), tape_act_noise=rows_of(rec["act_noise"]), tape_test_noise=rows_of(rec["test_noise"]),
+         tape_policy_noise=rows_of(rec["policy_noise"]), tape_gumbel_act=rows_of(rec["gumbel_act"]), tape_gumbel_test=rows_of(rec["gumbel_test"]),
+         tape_gumbel_target=rows_of(gt), tape_gumbel_actor=rows_of(ga),
+         tape_replay_idx=(np.concatenate([np.asarray(v, np.int32).reshape(-1) for v in rec["replay"]]) if rec["replay"] else np.zeros(0, np.int32)),
+         tape_train_reset=pad4([s for (i_, s) in rec["resets"] if i_ == train_reset_id]),
+         tape_test_reset=pad4([s for (i_, s) in rec["resets"] if i_ != train_reset_id]),
+         tr_state=np.stack([s["state"] for s in rec["steps"]]), tr_action=np.array([s["action"] for s in rec["steps"]], np.int32),
+         tr_next_state=np.stack([s["next_state"] for s in rec["steps"]]).astype(np.float32),
+         tr_reward=np.array([s["reward"] for s in rec["steps"]], np.float32), tr_done=np.array([s["done"] for s in rec["steps"]], np.float32),
+         rb_action=rbuf.action[:rbuf.size].numpy().astype(np.float32),
+         reward_list_train=np.array(reward_list_train, np.float64), episode_length_train=np.array(episode_length_train, np.int32),
+         reward_list_test=np.array(reward_list_test, np.float64), score=np.array(statistics.mean(reward_list_test)),
+         final_params=_pack_td3d(agent))
+
+
+# ------------------------------------------------------------------------------------------------
 # G11: the sync-file transport written by the REFERENCE, both directions (agents/GTN_master.py:147-195,267-298,
 # agents/GTN_worker.py:76-154): the payload files themselves are the fixture (tensors + plain dicts: data), next to the
 # values the reference's master computes from the workers' results.
@@ -1101,7 +1385,7 @@ def _gen_g11_body(cfg, n, GTN_Master, GTN_Worker, shutil):
 def main():
     # no arguments (or "all"): every fixture under tests/golden is regenerated (the full-shape runs g8df / g8tf take minutes each)
     ALL = ["g1", "g1ln", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x",
-           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8df", "g8l2", "g8m", "g8r", "g8i", "g8v", "g11"]
+           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8df", "g8l2", "g8m", "g8r", "g8i", "g8v", "g11", "g4td", "g8td"]
     which = sys.argv[1:] or ALL
     if "all" in which:
         which = ALL
@@ -1126,6 +1410,19 @@ def main():
         gen_g4t()
     if "g8t" in which:
         gen_g8t("g8t_calc_score_cheetah_td3", seed=830)
+    if "g4td" in which:
+        gen_g4td()
+    if "g8td" in which:
+        # TD3_discrete_vary (agents/TD3_discrete_vary.py) through GTN_Worker on a VirtualEnv: CartPole (A = 2) plain, Acrobot (A = 3)
+        # with the shared LayerNorm and the hard (straight-through) Gumbel softmax, CartPole with three hidden layers + LayerNorm
+        gen_g8td("g8td_calc_score_cartpole_td3_discrete", seed=1830, agent_over={"train_episodes": 3, "init_episodes": 1, "test_episodes": 3},
+                 env_over={"max_steps": 30, "hidden_size": 20})
+        gen_g8td("g8tdl_calc_score_acrobot_td3_discrete_layer_norm", seed=1831, cfg_yaml="default_config_acrobot_syn_env.yaml", env_name="Acrobot-v1",
+                 env_cls="AcrobotEnv", agent_over={"use_layer_norm": True, "gumbel_softmax_hard": True, "policy_delay": 2, "activation_fn": "tanh"},
+                 env_over={"max_steps": 9, "hidden_size": 16}, done_bias_shift=-0.3)
+        gen_g8td("g8td3_calc_score_cartpole_td3_discrete_3_layers", seed=1832, agent_over={"use_layer_norm": True, "hidden_layer": 3, "hidden_size": 20,
+                                                                                         "policy_delay": 1, "batch_size": 12}, done_bias_shift=-0.3)
+        gen_g8td("g8tdv_calc_score_cartpole_td3_discrete_vary", seed=1833, vary_seed=11, agent_over={"use_layer_norm": True}, done_bias_shift=-0.3)
     if "g8tv" in which:
         gen_g8t("g8tv_calc_score_cheetah_td3_vary", seed=832, vary_seed=8,
                 agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 64, "hidden_size": 48, "hidden_layer": 2, "test_episodes": 1},

@@ -227,9 +227,10 @@ static inline void linear_fwd(const float *W, const float *b, int n_out, int n_i
 #define ORC_MAX_WIDTH 1024
 #define ORC_MAX_LAYERS 4
 
-/* single-sample forward keeping pre-activations z[l] and activations a[l] (l = 0..L-1) */
-static void mlp_forward_one(const orc_mlp_desc *d, const float *p, const float *x, float *y,
-                            float z[][ORC_MAX_WIDTH], float a[][ORC_MAX_WIDTH])
+/* single-sample forward keeping pre-activations z[l] (after the LayerNorm where there is one) and activations a[l]
+ * (l = 0..L-1); xh / rstd (optional): the normalised rows and 1/sqrt(var + eps) of the LayerNorm positions, for the backward */
+static void mlp_forward_one_ex(const orc_mlp_desc *d, const float *p, const float *x, float *y,
+                               float z[][ORC_MAX_WIDTH], float a[][ORC_MAX_WIDTH], float xh[][ORC_MAX_WIDTH], float *rstd_out)
 {
     const int H = d->hidden, L = d->layers;
     const float *in = x;
@@ -247,13 +248,24 @@ static void mlp_forward_one(const orc_mlp_desc *d, const float *p, const float *
             const float mean = sm / (float)H;
             for (int j = 0; j < H; ++j) { const float dj = z[l][j] - mean; sv = fmaf(dj, dj, sv); }
             const float rstd = 1.0f / sqrtf(sv / (float)H + 1e-5f);
-            for (int j = 0; j < H; ++j) z[l][j] = fmaf((z[l][j] - mean) * rstd, ln_w[j], ln_b[j]);
+            if (rstd_out) rstd_out[l] = rstd;
+            for (int j = 0; j < H; ++j) {
+                const float xn = (z[l][j] - mean) * rstd;
+                if (xh) xh[l][j] = xn;
+                z[l][j] = fmaf(xn, ln_w[j], ln_b[j]);
+            }
         }
         for (int j = 0; j < H; ++j) a[l][j] = act_fwd(d->act, d->prelu, z[l][j]);
         in = a[l];
         n_in = H;
     }
     linear_fwd(p, p + (int64_t)d->out_dim * H, d->out_dim, H, in, y);
+}
+
+static void mlp_forward_one(const orc_mlp_desc *d, const float *p, const float *x, float *y,
+                            float z[][ORC_MAX_WIDTH], float a[][ORC_MAX_WIDTH])
+{
+    mlp_forward_one_ex(d, p, x, y, z, a, NULL, NULL);
 }
 
 int orc_mlp_forward(const orc_mlp_desc *d, const float *params, const float *x, int64_t B, float *y, float *hidden_out)
@@ -603,14 +615,19 @@ int orc_dueling_forward(const orc_ddqn_cfg *cfg, const float *params, const floa
 }
 
 /* backward of one MLP for one sample: accumulates parameter gradients into g (same layout as p), returns dL/dx */
-static void mlp_backward_one(const orc_mlp_desc *d, const float *p, const float *x, float z[][ORC_MAX_WIDTH],
-                             float a[][ORC_MAX_WIDTH], const float *dout, float *g, float *dx)
+static void mlp_backward_one_ex(const orc_mlp_desc *d, const float *p, const float *x, float z[][ORC_MAX_WIDTH],
+                                float a[][ORC_MAX_WIDTH], float xh[][ORC_MAX_WIDTH], const float *rstd, const float *dout,
+                                float *g, float *gln, float *dx)
 {
     const int H = d->hidden, L = d->layers, O = d->out_dim;
-    int64_t offW[ORC_MAX_LAYERS + 1], offb[ORC_MAX_LAYERS + 1];
+    const int ln = d->use_layer_norm && L >= 2;
+    int64_t offW[ORC_MAX_LAYERS + 1], offb[ORC_MAX_LAYERS + 1], off_ln = 0;
     {
         int64_t o = 0; int n_in = d->in_dim;
-        for (int l = 0; l < L; ++l) { offW[l] = o; o += (int64_t)H * n_in; offb[l] = o; o += H; n_in = H; }
+        for (int l = 0; l < L; ++l) {
+            offW[l] = o; o += (int64_t)H * n_in; offb[l] = o; o += H; n_in = H;
+            if (ln && l == 1) { off_ln = o; o += 2 * H; }         /* the shared nn.LayerNorm sits behind the second Linear */
+        }
         offW[L] = o; o += (int64_t)O * H; offb[L] = o;
     }
     float da[ORC_MAX_WIDTH], dz[ORC_MAX_WIDTH], dprev[ORC_MAX_WIDTH];
@@ -628,6 +645,23 @@ static void mlp_backward_one(const orc_mlp_desc *d, const float *p, const float 
         const int n_in = l == 0 ? d->in_dim : H;
         const float *inp = l == 0 ? x : a[l - 1];
         for (int j = 0; j < H; ++j) dz[j] = act_bwd(d->act, d->prelu, z[l][j], a[l][j], da[j]);
+        if (ln && l >= 1) {
+            /* LayerNorm backward.  dz = grad of the LayerNorm output; its weight / bias gradients accumulate per POSITION
+             * (gln [(L-1)][2][H], position l - 1; the caller adds the positions up, last layer first); the input gradient
+             * is rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)) with sequential sums */
+            float *gw = gln + (int64_t)(l - 1) * 2 * H, *gb = gw + H;
+            const float *w = p + off_ln;
+            float s1 = 0.0f, s2 = 0.0f;
+            for (int j = 0; j < H; ++j) {
+                gw[j] = fmaf(dz[j], xh[l][j], gw[j]);
+                gb[j] = gb[j] + dz[j];
+                dz[j] = dz[j] * w[j];
+            }
+            for (int j = 0; j < H; ++j) s1 = s1 + dz[j];
+            for (int j = 0; j < H; ++j) s2 = fmaf(dz[j], xh[l][j], s2);
+            const float m1 = s1 / (float)H, m2 = s2 / (float)H;
+            for (int j = 0; j < H; ++j) dz[j] = fmaf(-xh[l][j], m2, dz[j] - m1) * rstd[l];
+        }
         float *gW = g + offW[l], *gb = g + offb[l];
         for (int j = 0; j < H; ++j) {
             for (int i = 0; i < n_in; ++i) gW[(int64_t)j * n_in + i] = fmaf(dz[j], inp[i], gW[(int64_t)j * n_in + i]);
@@ -644,6 +678,25 @@ static void mlp_backward_one(const orc_mlp_desc *d, const float *p, const float 
             else memcpy(dx, dprev, sizeof(float) * n_in);
         }
     }
+}
+
+/* fold the per-position LayerNorm gradients of mlp_backward_one_ex into the flat gradient: position L-1 first, then down */
+static void mlp_fold_ln_grads(const orc_mlp_desc *d, const float *gln, float *g)
+{
+    const int H = d->hidden, L = d->layers;
+    if (!(d->use_layer_norm && L >= 2)) return;
+    float *gl = g + (int64_t)d->in_dim * H + H + (int64_t)H * H + H;
+    for (int j = 0; j < 2 * H; ++j) {
+        float acc = gln[(int64_t)(L - 2) * 2 * H + j];
+        for (int pos = L - 3; pos >= 0; --pos) acc = acc + gln[(int64_t)pos * 2 * H + j];
+        gl[j] = acc;
+    }
+}
+
+static void mlp_backward_one(const orc_mlp_desc *d, const float *p, const float *x, float z[][ORC_MAX_WIDTH],
+                             float a[][ORC_MAX_WIDTH], const float *dout, float *g, float *dx)
+{
+    mlp_backward_one_ex(d, p, x, z, a, NULL, NULL, dout, g, NULL, dx);      /* plain MLPs only (use_layer_norm == 0) */
 }
 
 /* One DuelingDDQN.learn step (DuelingDDQN.py:59-94): forward of the three batches with the GLOBAL advantage mean,
@@ -1351,6 +1404,7 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
 }
 
 #include "lenv_oracle_td3.inc"
+#include "lenv_oracle_td3d.inc"
 
 /* ------------------------------------------------------------------------------------------
  * NES worker / master math

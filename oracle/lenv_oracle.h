@@ -275,6 +275,51 @@ int orc_td3_rn_chain(const orc_td3_cfg *cfg, const float *rn_params, const float
                      uint64_t rng_key, const orc_td3_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
                      double *final_test_returns, orc_td3_trace *trace, orc_chain_result *res);
 
+/* ---- TD3_discrete_vary on a VirtualEnv over a discrete-action real env (agents/TD3_discrete_vary.py:62-117,159-171,
+ * models/actor_critic.py:22-35, agents/base_agent.py:64-227 with discretize_action) ---- */
+typedef struct {
+    int32_t env_id, state_dim, action_dim, max_steps;       /* CartPole-v0 4 / 2, Acrobot-v1 6 / 3, MountainCar-v0 2 / 3 */
+    int32_t se_hidden, se_layers, se_act;                    /* the VirtualEnv's three nets on cat(one_hot(argmax action), state) */
+    float se_prelu;
+    int32_t hidden, layers, act;                             /* actor state->action_dim and critics (state+action_dim)->1 */
+    float prelu;
+    int32_t use_layer_norm;                                  /* model_utils.py:22-37: one shared LayerNorm behind hidden Linear 2..L */
+    int32_t gumbel_hard;                                     /* actor_critic.py:31,35 */
+    int32_t batch_size, rb_size, train_episodes, test_episodes, init_episodes, early_out_num, policy_delay, rng_mode;
+    double solved_reward, gamma, lr, tau, action_std, policy_std, policy_std_clip, max_action;
+    double gumbel_temp;                                      /* annealed over the first 2000 learn calls to gumbel_temp / 20 (:59-60,64-68) */
+    double adam_beta1, adam_beta2, adam_eps;
+    int64_t step_budget;
+} orc_td3d_cfg;
+
+typedef struct {
+    const int32_t *rand_action; int64_t n_rand_action;     /* Discrete.sample() of the init episodes (env_wrapper.py:87-92) */
+    const float *act_noise;     int64_t n_act_noise;       /* rows of A: torch.randn(action_dim) in select_train_action :167 */
+    const float *test_noise;    int64_t n_test_noise;      /* rows of A: the same in select_test_action :171 */
+    const float *policy_noise;  int64_t n_policy_noise;    /* rows of A, B per learn call: randn_like(actions) :76 */
+    const float *gumbel_act;    int64_t n_gumbel_act;      /* rows of A: the Gumbel(0,1) draw of F.gumbel_softmax in select_train_action */
+    const float *gumbel_test;   int64_t n_gumbel_test;     /* rows of A: ... in select_test_action */
+    const float *gumbel_target; int64_t n_gumbel_target;   /* rows of A, B per learn call: actor_target(next_states) :77 */
+    const float *gumbel_actor;  int64_t n_gumbel_actor;    /* rows of A, B per policy update: actor(states) :101 */
+    const int32_t *replay_idx;  int64_t n_replay_idx;      /* elements, B per learn call */
+    const double *train_reset;  int64_t n_train_reset;     /* rows of 4: the reset env's state */
+    const double *test_reset;   int64_t n_test_reset;
+} orc_td3d_tapes;
+
+int64_t orc_td3d_actor_params(const orc_td3d_cfg *cfg);
+int64_t orc_td3d_critic_params(const orc_td3d_cfg *cfg);
+float orc_td3d_temperature(const orc_td3d_cfg *cfg, int64_t learn_calls_so_far);      /* np.linspace(t, t/20, 2000)[min(n, 1999)] as fp32 */
+float orc_gumbel(uint64_t key, uint32_t stream, uint64_t n);                           /* counter mode: -log(-log(u)) */
+/* Actor_TD3_discrete.forward on B rows: gumbel_softmax(net(s) * max_action, tau, hard) with the given Gumbel draws [B,A] */
+int orc_td3d_actor_forward(const orc_td3d_cfg *cfg, const float *actor, const float *s, const float *gumbel, float tau, int64_t B, float *out);
+/* one TD3_discrete_vary.learn call; params = [actor | critic_1 | critic_2]; total_it = calls so far INCLUDING this one */
+int orc_td3d_learn(const orc_td3d_cfg *cfg, float *params, float *targets, float *adam_m, float *adam_v, double pows[4],
+                   int64_t total_it, const float *rows, int64_t row_stride, const float *policy_noise /*[B,A]*/,
+                   const float *gumbel_target /*[B,A]*/, const float *gumbel_actor /*[B,A], read on policy updates*/);
+int orc_td3d_chain(const orc_td3d_cfg *cfg, const float *se_params, const float *agent_init, uint64_t rng_key,
+                   const orc_td3d_tapes *tapes, double *episode_test_mean, int32_t *episode_len, double *final_test_returns,
+                   orc_td3_trace *trace, orc_chain_result *res, float *final_params);
+
 /* ---- NES master/worker math ---- */
 /* GTN_worker.py:234-254: mirrored sampling pick; out[p] = {score_best, sign} */
 void orc_worker_best(const double *score_add, const double *score_sub, int64_t pop, int mirrored, double *score_best, float *sign);

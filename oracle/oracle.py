@@ -93,6 +93,34 @@ class Td3Tapes(C.Structure):
                 ("test_reset", C.POINTER(C.c_double)), ("n_test_reset", C.c_int64)]
 
 
+class Td3dCfg(C.Structure):
+    """orc_td3d_cfg: TD3_discrete_vary on a VirtualEnv over a discrete-action real env."""
+    _fields_ = [("env_id", C.c_int32), ("state_dim", C.c_int32), ("action_dim", C.c_int32), ("max_steps", C.c_int32),
+                ("se_hidden", C.c_int32), ("se_layers", C.c_int32), ("se_act", C.c_int32), ("se_prelu", C.c_float),
+                ("hidden", C.c_int32), ("layers", C.c_int32), ("act", C.c_int32), ("prelu", C.c_float),
+                ("use_layer_norm", C.c_int32), ("gumbel_hard", C.c_int32),
+                ("batch_size", C.c_int32), ("rb_size", C.c_int32), ("train_episodes", C.c_int32), ("test_episodes", C.c_int32),
+                ("init_episodes", C.c_int32), ("early_out_num", C.c_int32), ("policy_delay", C.c_int32), ("rng_mode", C.c_int32),
+                ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
+                ("action_std", C.c_double), ("policy_std", C.c_double), ("policy_std_clip", C.c_double), ("max_action", C.c_double),
+                ("gumbel_temp", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
+                ("step_budget", C.c_int64)]
+
+
+class Td3dTapes(C.Structure):
+    _fields_ = [("rand_action", C.POINTER(C.c_int32)), ("n_rand_action", C.c_int64),
+                ("act_noise", C.POINTER(C.c_float)), ("n_act_noise", C.c_int64),
+                ("test_noise", C.POINTER(C.c_float)), ("n_test_noise", C.c_int64),
+                ("policy_noise", C.POINTER(C.c_float)), ("n_policy_noise", C.c_int64),
+                ("gumbel_act", C.POINTER(C.c_float)), ("n_gumbel_act", C.c_int64),
+                ("gumbel_test", C.POINTER(C.c_float)), ("n_gumbel_test", C.c_int64),
+                ("gumbel_target", C.POINTER(C.c_float)), ("n_gumbel_target", C.c_int64),
+                ("gumbel_actor", C.POINTER(C.c_float)), ("n_gumbel_actor", C.c_int64),
+                ("replay_idx", C.POINTER(C.c_int32)), ("n_replay_idx", C.c_int64),
+                ("train_reset", C.POINTER(C.c_double)), ("n_train_reset", C.c_int64),
+                ("test_reset", C.POINTER(C.c_double)), ("n_test_reset", C.c_int64)]
+
+
 class Td3Trace(C.Structure):
     _fields_ = [("cap", C.c_int64), ("n", C.c_int64), ("action", C.POINTER(C.c_float)), ("state", C.POINTER(C.c_float)),
                 ("next_state", C.POINTER(C.c_float)), ("reward", C.POINTER(C.c_float))]
@@ -621,6 +649,127 @@ def td3_rn_chain(cfg, rn_params, agent_init, rng_key=0, tapes=None, trace_cap=0,
         out["trace"] = {k: v[:tr.n] for k, v in arrs.items()}
     if icm_final is not None:
         out["icm_final"] = icm_final
+    return out
+
+
+# ---- TD3_discrete_vary (oracle/lenv_oracle_td3d.inc) ----
+TD3D_TAPE_KEYS = ("rand_action", "act_noise", "test_noise", "policy_noise", "gumbel_act", "gumbel_test", "gumbel_target", "gumbel_actor",
+                  "replay_idx", "train_reset", "test_reset")
+
+
+TD3D_ENVS = {"CartPole-v0": (0, 4, 2), "Acrobot-v1": (1, 6, 3), "MountainCar-v0": (3, 2, 3)}      # env id, observation dim, actions
+
+
+def td3d_cfg_from_config(config, rng_mode=0, hp=None, **overrides):
+    """Reference YAML dict (TD3_discrete_vary on a VirtualEnv) -> oracle config; fields read at agents/TD3_discrete_vary.py:30-42,
+    models/actor_critic.py:27-31, models/model_utils.py:5-29, agents/base_agent.py:9-26, envs/env_wrapper.py:106-110 (max_action 1).
+    hp: the recorded draw of vary_hyperparameters (lr / batch_size / hidden_size / hidden_layer), if any."""
+    env_name = config["env_name"]
+    env_id, S, A = TD3D_ENVS[env_name]
+    e = config["envs"][env_name]
+    a = dict(config["agents"]["td3_discrete_vary"])
+    a.update(hp or {})
+
+    def val(v):
+        return float(v[1]) if isinstance(v, list) else v
+    cfg = Td3dCfg(env_id=env_id, state_dim=S, action_dim=A, max_steps=int(val(e["max_steps"])), se_hidden=int(val(e["hidden_size"])),
+                  se_layers=int(val(e["hidden_layer"])), se_act=ACT[e["activation_fn"]], se_prelu=0.25, hidden=int(a["hidden_size"]),
+                  layers=max(1, int(a["hidden_layer"])), act=ACT[a["activation_fn"]], prelu=0.25,
+                  use_layer_norm=int(bool(a.get("use_layer_norm", False))), gumbel_hard=int(bool(a["gumbel_softmax_hard"])),
+                  batch_size=int(a["batch_size"]), rb_size=int(a["rb_size"]), train_episodes=int(a["train_episodes"]),
+                  test_episodes=int(a["test_episodes"]), init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]),
+                  policy_delay=int(a["policy_delay"]), rng_mode=rng_mode, solved_reward=float(val(e["solved_reward"])),
+                  gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), action_std=float(a["action_std"]),
+                  policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=1.0,
+                  gumbel_temp=float(a["gumbel_softmax_temp"]), adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
+                  step_budget=int(a.get("step_budget", 0)))
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def td3d_num_params(cfg):
+    L = lib()
+    L.orc_td3d_actor_params.restype = C.c_int64
+    L.orc_td3d_critic_params.restype = C.c_int64
+    pa, pc = int(L.orc_td3d_actor_params(C.byref(cfg))), int(L.orc_td3d_critic_params(C.byref(cfg)))
+    return pa + 2 * pc, pa, pc
+
+
+def td3d_temperature(cfg, n):
+    lib().orc_td3d_temperature.restype = C.c_float
+    return float(lib().orc_td3d_temperature(C.byref(cfg), C.c_int64(n)))
+
+
+def gumbel(key, stream, n):
+    lib().orc_gumbel.restype = C.c_float
+    return float(lib().orc_gumbel(C.c_uint64(key), C.c_uint32(stream), C.c_uint64(n)))
+
+
+def td3d_actor_forward(cfg, actor, s, gumbels, tau):
+    actor, s, gumbels = _f32(actor), _f32(s).reshape(-1, cfg.state_dim), _f32(gumbels).reshape(-1, cfg.action_dim)
+    out = np.zeros((s.shape[0], cfg.action_dim), np.float32)
+    rc = lib().orc_td3d_actor_forward(C.byref(cfg), _p(actor, C.c_float), _p(s, C.c_float), _p(gumbels, C.c_float), C.c_float(tau),
+                                      C.c_int64(s.shape[0]), _p(out, C.c_float))
+    assert rc == 0
+    return out
+
+
+def td3d_learn(cfg, params, targets, m, v, pows, total_it, rows, policy_noise, gumbel_target, gumbel_actor):
+    params, targets, m, v = [_f32(t).copy() for t in (params, targets, m, v)]
+    rows, policy_noise, gumbel_target, gumbel_actor = _f32(rows), _f32(policy_noise), _f32(gumbel_target), _f32(gumbel_actor)
+    pw = (C.c_double * 4)(*pows)
+    rc = lib().orc_td3d_learn(C.byref(cfg), _p(params, C.c_float), _p(targets, C.c_float), _p(m, C.c_float), _p(v, C.c_float), pw,
+                              C.c_int64(total_it), _p(rows, C.c_float), C.c_int64(rows.shape[1]), _p(policy_noise, C.c_float),
+                              _p(gumbel_target, C.c_float), _p(gumbel_actor, C.c_float))
+    assert rc == 0
+    return params, targets, m, v, list(pw)
+
+
+def make_td3d_tapes(A, **t):
+    """Keyword arrays named as in TD3D_TAPE_KEYS (missing ones: empty)."""
+    def arr(name, dtype, cols):
+        a = np.ascontiguousarray(t.get(name, np.zeros((0, cols) if cols else 0)), dtype)
+        return a.reshape(-1, cols) if cols else a.reshape(-1)
+    keep = dict(rand_action=arr("rand_action", np.int32, 0), act_noise=arr("act_noise", np.float32, A), test_noise=arr("test_noise", np.float32, A),
+                policy_noise=arr("policy_noise", np.float32, A), gumbel_act=arr("gumbel_act", np.float32, A),
+                gumbel_test=arr("gumbel_test", np.float32, A), gumbel_target=arr("gumbel_target", np.float32, A),
+                gumbel_actor=arr("gumbel_actor", np.float32, A), replay_idx=arr("replay_idx", np.int32, 0),
+                train_reset=arr("train_reset", np.float64, 4), test_reset=arr("test_reset", np.float64, 4))
+    ct = dict(rand_action=C.c_int32, replay_idx=C.c_int32, train_reset=C.c_double, test_reset=C.c_double)
+    args = []
+    for k in TD3D_TAPE_KEYS:
+        a = keep[k]
+        args += [_p(a, ct.get(k, C.c_float)), a.shape[0]]
+    tp = Td3dTapes(*args)
+    tp._keep = keep
+    return tp
+
+
+def td3d_chain(cfg, se_params, agent_init, rng_key=0, tapes=None, trace_cap=0):
+    se_params, agent_init = _f32(se_params), _f32(agent_init)
+    E, T, S, A = cfg.train_episodes, cfg.test_episodes, cfg.state_dim, cfg.action_dim
+    P = td3d_num_params(cfg)[0]
+    assert agent_init.size == P, (agent_init.size, P)
+    ep_mean = np.full(max(E, 1), np.nan)
+    ep_len = np.zeros(max(E, 1), np.int32)
+    final = np.zeros(max(T, 1))
+    final_params = np.zeros(P, np.float32)
+    res = ChainResult()
+    tr, arrs = None, None
+    if trace_cap:
+        arrs = dict(action=np.zeros((trace_cap, A), np.float32), state=np.zeros((trace_cap, S), np.float32),
+                    next_state=np.zeros((trace_cap, S), np.float32), reward=np.zeros(trace_cap, np.float32))
+        tr = Td3Trace(trace_cap, 0, _p(arrs["action"], C.c_float), _p(arrs["state"], C.c_float), _p(arrs["next_state"], C.c_float),
+                      _p(arrs["reward"], C.c_float))
+    rc = lib().orc_td3d_chain(C.byref(cfg), _p(se_params, C.c_float), _p(agent_init, C.c_float), C.c_uint64(rng_key),
+                              C.byref(tapes) if tapes is not None else None, _p(ep_mean, C.c_double), _p(ep_len, C.c_int32),
+                              _p(final, C.c_double), C.byref(tr) if tr is not None else None, C.byref(res), _p(final_params, C.c_float))
+    out = dict(rc=rc, score=res.score, episodes_run=res.episodes_run, train_steps=res.train_steps, learn_steps=res.learn_steps,
+               test_steps=res.test_steps, episode_test_mean=ep_mean[:E], episode_len=ep_len[:E], final_test_returns=final[:T],
+               final_params=final_params)
+    if tr is not None:
+        out["trace"] = {k: v[:tr.n] for k, v in arrs.items()}
     return out
 
 

@@ -1,0 +1,104 @@
+"""TD3_discrete_vary (agents/TD3_discrete_vary.py: TD3 on a discrete action space through a Gumbel-softmax actor, optionally with the
+shared LayerNorm of models/model_utils.py:22-37).
+
+CPU part: the oracle (oracle/lenv_oracle_td3d.inc) against runs of the REFERENCE (fixtures G4TD: learn calls on a fixed buffer;
+G8TD*: whole GTN_Worker.calc_score runs on a CartPole / Acrobot VirtualEnv with every random draw recorded).
+GPU part: the fused HIP kernel against the oracle, bit for bit, in tape and counter mode."""
+import json
+
+import numpy as np
+import pytest
+
+CHAIN_FIXTURES = ["g8td_calc_score_cartpole_td3_discrete", "g8tdl_calc_score_acrobot_td3_discrete_layer_norm",
+                  "g8td3_calc_score_cartpole_td3_discrete_3_layers", "g8tdv_calc_score_cartpole_td3_discrete_vary"]
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _learn_cfg(orc, g, pre):
+    S, A, H, L, act, B, pd, nsteps, ln, hard, it0 = [int(x) for x in g[pre + "meta"]]
+    gamma, lr, tau, pstd, pclip, ma, temp = [float(x) for x in g[pre + "hparams"]]
+    cfg = orc.Td3dCfg(env_id={4: 0, 6: 1}[S], state_dim=S, action_dim=A, max_steps=5, se_hidden=8, se_layers=1, se_act=1, se_prelu=0.25,
+                      hidden=H, layers=L, act=act, prelu=0.25, use_layer_norm=ln, gumbel_hard=hard, batch_size=B, rb_size=100,
+                      train_episodes=1, test_episodes=1, init_episodes=0, early_out_num=1, policy_delay=pd, rng_mode=1, solved_reward=1e9,
+                      gamma=gamma, lr=lr, tau=tau, action_std=0.1, policy_std=pstd, policy_std_clip=pclip, max_action=ma, gumbel_temp=temp,
+                      adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, step_budget=0)
+    return cfg, nsteps, it0
+
+
+def test_temperature_schedule_is_numpy_linspace(orc):
+    for temp in (1.0, 0.7, 2.5):
+        cfg = orc.Td3dCfg(gumbel_temp=temp)
+        steps = np.linspace(temp, temp / 20, 2000)              # TD3_discrete_vary.py:59
+        got = np.array([orc.td3d_temperature(cfg, i) for i in range(2000)], np.float32)
+        assert np.array_equal(got, steps.astype(np.float32))
+        assert orc.td3d_temperature(cfg, 123456) == np.float32(steps[-1])
+
+
+def test_learn_calls_vs_reference(orc, golden):
+    """Actor_TD3_discrete forward and TD3_discrete_vary.learn: LayerNorm (one and two positions sharing one module), soft and hard
+    Gumbel softmax, policy_delay 1 and 2, a temperature off the schedule's first entry."""
+    g = golden("g4td_td3_discrete_learn")
+    for vi in range(int(g["n_variants"])):
+        pre = "v%d_" % vi
+        cfg, nsteps, it0 = _learn_cfg(orc, g, pre)
+        P, Pa, Pc = orc.td3d_num_params(cfg)
+        assert P == g[pre + "params0"].size
+        y = orc.td3d_actor_forward(cfg, g[pre + "params0"][:Pa], g[pre + "fwd_s"], g[pre + "fwd_gumbel"], 0.8)
+        np.testing.assert_allclose(y, g[pre + "fwd_actor"], rtol=0, atol=5e-7)
+        p, t = g[pre + "params0"].copy(), g[pre + "targets0"].copy()
+        m, v, pows = np.zeros_like(p), np.zeros_like(p), [1.0] * 4
+        for st in range(nsteps):
+            p, t, m, v, pows = orc.td3d_learn(cfg, p, t, m, v, pows, it0 + st + 1, g[pre + "rows"][st], g[pre + "policy_noise"][st],
+                                              g[pre + "gumbel_target"][st], g[pre + "gumbel_actor"][st])
+            np.testing.assert_allclose(p, g[pre + "params"][st], rtol=0, atol=2e-6)      # measured 7e-7
+            np.testing.assert_allclose(t, g[pre + "targets"][st], rtol=0, atol=5e-7)
+        assert np.abs(p[:Pa] - g[pre + "params0"][:Pa]).max() > 1e-3                    # the actor did train
+
+
+def chain_inputs(orc, g, rng_mode=1, **over):
+    cfgd = json.loads(str(g["config_json"]))
+    hp = json.loads(str(g["hp_json"]))
+    cfg = orc.td3d_cfg_from_config(cfgd, rng_mode=rng_mode, hp=hp, **over)
+    tapes = {k: g["tape_" + k] for k in orc.TD3D_TAPE_KEYS}
+    return cfg, tapes
+
+
+@pytest.mark.parametrize("name", CHAIN_FIXTURES)
+def test_calc_score_vs_reference(orc, golden, name):
+    g = golden(name)
+    cfg, tapes = chain_inputs(orc, g)
+    assert orc.td3d_num_params(cfg)[0] == g["agent_init"].size
+    n = g["tr_reward"].size
+    r = orc.td3d_chain(cfg, g["theta"], g["agent_init"], tapes=orc.make_td3d_tapes(cfg.action_dim, **tapes), trace_cap=n + 4)
+    assert r["rc"] == 0
+    assert r["train_steps"] == n and len(r["trace"]["reward"]) == n
+    E = g["reward_list_train"].size                              # the reference's lists stop at the early-out
+    assert r["episodes_run"] == E
+    assert np.array_equal(r["episode_len"][:E], g["episode_length_train"])
+    np.testing.assert_allclose(r["episode_test_mean"][:E], g["reward_list_train"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(r["final_test_returns"], g["reward_list_test"], rtol=0, atol=1e-9)
+    assert abs(r["score"] - float(g["score"])) <= 1e-4           # north_star bar
+    # the action vectors the replay buffer holds (Gumbel softmax + Gaussian noise), the env's view of them, the SE's answers
+    np.testing.assert_allclose(r["trace"]["action"], g["rb_action"][:n], rtol=0, atol=2e-6)
+    assert np.array_equal(r["trace"]["action"].argmax(1), g["tr_action"])
+    np.testing.assert_allclose(r["trace"]["next_state"], g["tr_next_state"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(r["trace"]["reward"], g["tr_reward"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(r["final_params"], g["final_params"], rtol=0, atol=2e-5)     # measured <= 2.1e-6
+
+
+def test_counter_mode_runs_and_is_deterministic(orc, golden):
+    g = golden(CHAIN_FIXTURES[1])
+    cfg, _ = chain_inputs(orc, g, rng_mode=0)
+    a = orc.td3d_chain(cfg, g["theta"], g["agent_init"], rng_key=77)
+    b = orc.td3d_chain(cfg, g["theta"], g["agent_init"], rng_key=77)
+    c = orc.td3d_chain(cfg, g["theta"], g["agent_init"], rng_key=78)
+    assert a["rc"] == 0 and np.array_equal(a["final_params"], b["final_params"]) and a["score"] == b["score"]
+    assert not np.array_equal(a["final_params"], c["final_params"])
+    # the Gumbel draw: -log(-log(u)) is finite and has the Gumbel(0,1) mean (Euler-Mascheroni) / variance (pi^2 / 6)
+    gs = np.array([orc.gumbel(5, 13, i) for i in range(20000)])
+    assert np.isfinite(gs).all() and abs(gs.mean() - 0.5772) < 0.03 and abs(gs.var() - np.pi ** 2 / 6) < 0.08
