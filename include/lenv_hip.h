@@ -361,6 +361,59 @@ int lenv_td3_agent_init_hp(const lenv_td3_cfg *cfg /*HOST*/, const lenv_chain_hp
                            float *agent_init, void *stream);
 
 /*
+ * TD3_discrete_vary: fused inner loop for TD3 on a DISCRETE action space through a Gumbel-softmax actor, trained on a VirtualEnv and
+ * tested on the real env (agents/TD3_discrete_vary.py:16-117,159-177; models/actor_critic.py:22-35 Actor_TD3_discrete;
+ * agents/base_agent.py:64-227 with discretize_action: the replay buffer keeps the action VECTOR, the env gets its argmax;
+ * envs/env_wrapper.py:16-47 one-hot of that index in front of the three SE nets, envs/virtual_env.py:43-54).
+ * use_layer_norm (models/model_utils.py:22-37): ONE nn.LayerNorm(hidden) shared by the hidden Linear layers 2..L of a net, in front
+ * of the activation.  Flat parameters of a net in Module.parameters() order: W0 b0 [W1 b1 [LNw LNb] W2 b2 ...] Wout bout;
+ * agent_init / final_params rows = actor | critic_1 | critic_2.  theta = state_net | reward_net | done_net as in lenv_ddqn_cfg.
+ */
+typedef struct {
+    int32_t env_id, state_dim, action_dim, max_steps;   /* LENV_ENV_CARTPOLE 4 / 2, LENV_ENV_ACROBOT 6 / 3, LENV_ENV_MOUNTAINCAR 2 / 3 */
+    int32_t se_hidden, se_layers, se_act;
+    float se_prelu;
+    int32_t hidden, layers, act;                         /* actor S -> A and critics (S + A) -> 1 (models/model_utils.py:4-39) */
+    float prelu;
+    int32_t use_layer_norm;
+    int32_t gumbel_hard;                                 /* gumbel_softmax_hard: straight-through one-hot forward (actor_critic.py:31,35) */
+    int32_t batch_size, rb_size, train_episodes, test_episodes, init_episodes, early_out_num, policy_delay, rng_mode;
+    double solved_reward, gamma, lr, tau, action_std, policy_std, policy_std_clip, max_action;
+    double gumbel_temp;                                  /* gumbel_softmax_temp, annealed to 1/20 of it over the first 2000 learn calls (:59-68) */
+    double adam_beta1, adam_beta2, adam_eps;
+    int64_t step_budget;                                 /* env-step stand-in for time_remaining, see lenv_ddqn_cfg::step_budget */
+} lenv_td3d_cfg;
+
+/* RNG tapes (parity mode); per-chain rows, strides in ROWS (rows of A floats / one int / four doubles as noted) */
+typedef struct {
+    const int32_t *rand_action; int64_t rand_action_stride;    /* Discrete.sample() of the init episodes (env_wrapper.py:87-92) */
+    const float *act_noise;     int64_t act_noise_stride;      /* rows of A: randn(action_dim) in select_train_action :167 */
+    const float *test_noise;    int64_t test_noise_stride;     /* rows of A: the same in select_test_action :171 */
+    const float *policy_noise;  int64_t policy_noise_stride;   /* rows of A, B per learn call: randn_like(actions) :76 */
+    const float *gumbel_act;    int64_t gumbel_act_stride;     /* rows of A: Gumbel(0,1) draws of F.gumbel_softmax in select_train_action */
+    const float *gumbel_test;   int64_t gumbel_test_stride;    /* rows of A: ... in select_test_action */
+    const float *gumbel_target; int64_t gumbel_target_stride;  /* rows of A, B per learn call: actor_target(next_states) :77 */
+    const float *gumbel_actor;  int64_t gumbel_actor_stride;   /* rows of A, B per policy update: actor(states) :101 */
+    const int32_t *replay_idx;  int64_t replay_idx_stride;     /* elements, B per learn call */
+    const double *train_reset;  int64_t train_reset_stride;    /* rows of 4: the reset env's own state */
+    const double *test_reset;   int64_t test_reset_stride;
+} lenv_td3d_tapes;
+
+size_t lenv_td3d_workspace_bytes(const lenv_td3d_cfg *cfg /*HOST*/, int64_t chains);
+int64_t lenv_td3d_num_params(const lenv_td3d_cfg *cfg /*HOST*/, int64_t *actor_params /*HOST out*/, int64_t *critic_params /*HOST out*/);
+int64_t lenv_td3d_se_num_params(const lenv_td3d_cfg *cfg /*HOST*/);
+/* hp (may be NULL): per-chain lr / batch_size / hidden_size / hidden_layer of vary_hyperparameters (:119-157); cfg carries the
+ * maxima, agent_init rows hold the nets at the chain's own shapes (row stride lenv_td3d_num_params(cfg)).  out: lenv_td3_out
+ * (trace_action rows hold the action vectors the replay buffer got). */
+int lenv_td3d_inner_loop(const lenv_td3d_cfg *cfg /*HOST*/, const lenv_chain_hp *hp /*HOST struct of device arrays, may be NULL*/,
+                         const float *theta, const float *eps, const int32_t *worker, const float *sign, const float *agent_init,
+                         const uint64_t *rng_keys, const lenv_td3d_tapes *tapes /*HOST, may be NULL*/, int64_t chains, void *workspace,
+                         size_t workspace_bytes, const lenv_td3_out *out /*HOST*/, void *stream);
+/* fresh agents: nn.Linear default init from the chain key's counter stream, LayerNorm weight 1 / bias 0 */
+int lenv_td3d_agent_init(const lenv_td3d_cfg *cfg /*HOST*/, const lenv_chain_hp *hp /*may be NULL*/, const uint64_t *rng_keys,
+                         int64_t chains, float *agent_init, void *stream);
+
+/*
  * Batched forward of one MLP in the flat layout above: y [rows,out] = net(x [rows,in]) (models/model_utils.py:31-39;
  * behind Critic_DQN / Actor_TD3.net / Critic_Q / reward_net calls of the one-step API).
  */

@@ -103,6 +103,28 @@ class Td3Tapes(C.Structure):
                 ("test_reset", C.c_void_p), ("test_reset_stride", C.c_int64)]
 
 
+class Td3dCfg(C.Structure):
+    """lenv_td3d_cfg (include/lenv_hip.h): TD3_discrete_vary on a VirtualEnv over a discrete-action real env."""
+    _fields_ = [("env_id", C.c_int32), ("state_dim", C.c_int32), ("action_dim", C.c_int32), ("max_steps", C.c_int32),
+                ("se_hidden", C.c_int32), ("se_layers", C.c_int32), ("se_act", C.c_int32), ("se_prelu", C.c_float),
+                ("hidden", C.c_int32), ("layers", C.c_int32), ("act", C.c_int32), ("prelu", C.c_float),
+                ("use_layer_norm", C.c_int32), ("gumbel_hard", C.c_int32),
+                ("batch_size", C.c_int32), ("rb_size", C.c_int32), ("train_episodes", C.c_int32), ("test_episodes", C.c_int32),
+                ("init_episodes", C.c_int32), ("early_out_num", C.c_int32), ("policy_delay", C.c_int32), ("rng_mode", C.c_int32),
+                ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
+                ("action_std", C.c_double), ("policy_std", C.c_double), ("policy_std_clip", C.c_double), ("max_action", C.c_double),
+                ("gumbel_temp", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
+                ("step_budget", C.c_int64)]
+
+
+TD3D_TAPE_KEYS = ("rand_action", "act_noise", "test_noise", "policy_noise", "gumbel_act", "gumbel_test", "gumbel_target", "gumbel_actor",
+                  "replay_idx", "train_reset", "test_reset")
+
+
+class Td3dTapes(C.Structure):
+    _fields_ = [f for k in TD3D_TAPE_KEYS for f in ((k, C.c_void_p), (k + "_stride", C.c_int64))]
+
+
 class Td3Out(C.Structure):
     _fields_ = [("score", C.c_void_p), ("stats", C.c_void_p), ("status", C.c_void_p), ("episode_test_mean", C.c_void_p),
                 ("episode_len", C.c_void_p), ("final_returns", C.c_void_p), ("final_params", C.c_void_p), ("trace_cap", C.c_int64),
@@ -114,7 +136,8 @@ EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv
            "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population", "lenv_dueling_se_workspace_bytes",
            "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_dueling_se_inner_loop_hp", "lenv_dueling_agent_init_hp", "lenv_rng_unit", "lenv_td3_rn_inner_loop_hp", "lenv_td3_agent_init_hp", "lenv_icm_num_params", "lenv_dueling_se_inner_loop_icm", "lenv_chain_uniform_init", "lenv_td3_icm_num_params", "lenv_td3_rn_inner_loop_icm", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
            "lenv_td3_rn_inner_loop", "lenv_mlp_forward", "lenv_cheetah_standin_reset", "lenv_cheetah_standin_step", "lenv_cont_env_reset", "lenv_cont_env_step",
-           "lenv_rn_num_params", "lenv_rn_shape_rows", "lenv_nes_worker_best_multi", "lenv_nes_draw", "lenv_nes_status_fold", "lenv_nes_draw_dev", "lenv_nes_rank_update_keep"]
+           "lenv_rn_num_params", "lenv_rn_shape_rows", "lenv_nes_worker_best_multi", "lenv_nes_draw", "lenv_nes_status_fold", "lenv_nes_draw_dev", "lenv_nes_rank_update_keep",
+           "lenv_td3d_workspace_bytes", "lenv_td3d_num_params", "lenv_td3d_se_num_params", "lenv_td3d_inner_loop", "lenv_td3d_agent_init"]
 
 
 def build(force=False):
@@ -230,6 +253,17 @@ def lib():
         L.lenv_nes_rank_update_keep.restype = C.c_int
         L.lenv_nes_rank_update_keep.argtypes = [C.c_int32, vp, vp, C.c_int64, vp, vp, C.c_int64, C.c_double, C.c_int32,
                                                 C.c_double, vp, vp, vp, vp]
+        L.lenv_td3d_workspace_bytes.restype = C.c_size_t
+        L.lenv_td3d_workspace_bytes.argtypes = [C.POINTER(Td3dCfg), C.c_int64]
+        L.lenv_td3d_num_params.restype = C.c_int64
+        L.lenv_td3d_num_params.argtypes = [C.POINTER(Td3dCfg), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.lenv_td3d_se_num_params.restype = C.c_int64
+        L.lenv_td3d_se_num_params.argtypes = [C.POINTER(Td3dCfg)]
+        L.lenv_td3d_inner_loop.restype = C.c_int
+        L.lenv_td3d_inner_loop.argtypes = [C.POINTER(Td3dCfg), C.POINTER(ChainHp), vp, vp, vp, vp, vp, vp, C.POINTER(Td3dTapes), C.c_int64, vp,
+                                           C.c_size_t, C.POINTER(Td3Out), vp]
+        L.lenv_td3d_agent_init.restype = C.c_int
+        L.lenv_td3d_agent_init.argtypes = [C.POINTER(Td3dCfg), C.POINTER(ChainHp), vp, C.c_int64, vp, vp]
         if L.lenv_abi_version() != 3:
             raise LenvError("liblenv_hip.so ABI version mismatch")
         _lib = L

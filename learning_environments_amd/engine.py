@@ -422,6 +422,92 @@ class Td3InnerLoop(object):
         return self.score
 
 
+class Td3DiscreteInnerLoop(object):
+    """Owns the workspace/outputs of lenv_td3d_inner_loop (TD3_discrete_vary on a VirtualEnv) for a fixed (cfg, chains).
+    vary=True: cfg carries the maximal batch_size / hidden / layers, every chain runs with its own draw (set_hp)."""
+
+    def __init__(self, cfg, chains, want_episode_stats=True, want_final_params=False, trace_cap=0, vary=False):
+        self.dev = require_device()
+        self.cfg, self.chains = cfg, int(chains)
+        self.vary = bool(vary)
+        self.hp = self.hp_struct = self.agent_init = None
+        L = _lib.lib()
+        pa, pc = C.c_int64(), C.c_int64()
+        self.p_agent = int(L.lenv_td3d_num_params(C.byref(cfg), C.byref(pa), C.byref(pc)))
+        _lib.check(min(self.p_agent, 0), "lenv_td3d_num_params")
+        self.p_actor, self.p_critic = pa.value, pc.value
+        self.p_theta = int(L.lenv_td3d_se_num_params(C.byref(cfg)))
+        if self.vary:
+            _alloc_chain_hp(self)
+        else:
+            self.agent_init = torch.zeros((self.chains, self.p_agent), dtype=torch.float32, device=self.dev)
+        self.ws_bytes = int(L.lenv_td3d_workspace_bytes(C.byref(cfg), self.chains))
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
+        E, T, S, A = cfg.train_episodes, cfg.test_episodes, cfg.state_dim, cfg.action_dim
+        self.score = torch.zeros(self.chains, dtype=torch.float64, device=self.dev)
+        self.stats = torch.zeros((self.chains, 4), dtype=torch.int64, device=self.dev)
+        self.status = torch.zeros(self.chains, dtype=torch.int32, device=self.dev)
+        self.episode_test_mean = self.episode_len = self.final_returns = self.final_params = None
+        if want_episode_stats:
+            self.episode_test_mean = torch.zeros((self.chains, max(E, 1)), dtype=torch.float64, device=self.dev)
+            self.episode_len = torch.zeros((self.chains, max(E, 1)), dtype=torch.int32, device=self.dev)
+            self.final_returns = torch.zeros((self.chains, T), dtype=torch.float64, device=self.dev)
+        if want_final_params:
+            self.final_params = torch.zeros((self.chains, self.p_agent), dtype=torch.float32, device=self.dev)
+        self.trace_cap = int(trace_cap)
+        self.trace = None
+        if trace_cap:
+            self.trace = dict(action=torch.zeros((self.chains, trace_cap, A), dtype=torch.float32, device=self.dev),
+                              state=torch.zeros((self.chains, trace_cap, S), dtype=torch.float32, device=self.dev),
+                              next_state=torch.zeros((self.chains, trace_cap, S), dtype=torch.float32, device=self.dev),
+                              reward=torch.zeros((self.chains, trace_cap), dtype=torch.float32, device=self.dev))
+        tr = self.trace or {}
+        self.out = Td3Out(_ptr(self.score), _ptr(self.stats), _ptr(self.status), _ptr(self.episode_test_mean), _ptr(self.episode_len),
+                          _ptr(self.final_returns), _ptr(self.final_params), self.trace_cap, _ptr(tr.get("action")),
+                          _ptr(tr.get("state")), _ptr(tr.get("next_state")), _ptr(tr.get("reward")))
+
+    def set_hp(self, lr, batch_size, hidden_size, hidden_layer):
+        _set_chain_hp(self, lr, batch_size, hidden_size, hidden_layer, self.cfg.batch_size, self.cfg.hidden, self.cfg.layers)
+
+    def chain_num_params(self, hidden_size, hidden_layer):
+        probe = _lib.Td3dCfg.from_buffer_copy(self.cfg)
+        probe.hidden, probe.layers = int(hidden_size), max(1, int(hidden_layer))
+        n = int(_lib.lib().lenv_td3d_num_params(C.byref(probe), None, None))
+        _lib.check(min(n, 0), "lenv_td3d_num_params")
+        return n
+
+    def draw_agent_init(self, rng_keys):
+        """Fresh actor | critic_1 | critic_2 (nn.Linear default init, LayerNorm 1 / 0) at every chain's own shapes."""
+        _chk(rng_keys, torch.int64, "rng_keys")
+        rc = _lib.lib().lenv_td3d_agent_init(C.byref(self.cfg), C.byref(self.hp_struct) if self.vary else None, _ptr(rng_keys), self.chains,
+                                             _ptr(self.agent_init), _stream())
+        _lib.check(rc, "lenv_td3d_agent_init")
+        return self.agent_init
+
+    def run(self, theta, eps, worker, sign, agent_init=None, rng_keys=None, tapes=None):
+        if agent_init is None:
+            agent_init = self.agent_init
+        _chk(theta, torch.float32, "theta"); _chk(eps, torch.float32, "eps"); _chk(worker, torch.int32, "worker")
+        _chk(sign, torch.float32, "sign"); _chk(agent_init, torch.float32, "agent_init")
+        if agent_init.shape != (self.chains, self.p_agent):
+            raise ValueError("agent_init must be [chains, %d]" % self.p_agent)
+        if theta.numel() != self.p_theta:
+            raise ValueError("theta must hold %d SE parameters" % self.p_theta)
+        t = None
+        if tapes is not None:
+            vals = []
+            for k in _lib.TD3D_TAPE_KEYS:
+                vals += [_ptr(tapes[k]), tapes[k].shape[1]]
+            t = _lib.Td3dTapes(*vals)
+        if rng_keys is not None:
+            _chk(rng_keys, torch.int64, "rng_keys")
+        rc = _lib.lib().lenv_td3d_inner_loop(C.byref(self.cfg), C.byref(self.hp_struct) if self.vary else None, _ptr(theta), _ptr(eps),
+                                             _ptr(worker), _ptr(sign), _ptr(agent_init), _ptr(rng_keys), C.byref(t) if t is not None else None,
+                                             self.chains, _ptr(self.workspace), self.ws_bytes, C.byref(self.out), _stream())
+        _lib.check(rc, "lenv_td3d_inner_loop")
+        return self.score
+
+
 def rn_shape_population(cfg, theta, eps, worker, sign, next_state, reward, chains=1):
     """(phi [chains,N], shaped [chains,N,A]) of a population of perturbed reward networks on a grid MDP."""
     dev = require_device()

@@ -102,3 +102,119 @@ def test_counter_mode_runs_and_is_deterministic(orc, golden):
     # the Gumbel draw: -log(-log(u)) is finite and has the Gumbel(0,1) mean (Euler-Mascheroni) / variance (pi^2 / 6)
     gs = np.array([orc.gumbel(5, 13, i) for i in range(20000)])
     assert np.isfinite(gs).all() and abs(gs.mean() - 0.5772) < 0.03 and abs(gs.var() - np.pi ** 2 / 6) < 0.08
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU part: the fused kernel (lenv_td3d_inner_loop) against the oracle, bit for bit
+# ------------------------------------------------------------------------------------------------------------------
+def _dev(a, dtype=None):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _hip_cfg(ocfg):
+    from learning_environments_amd import _lib
+    c = _lib.Td3dCfg()
+    for f, _ in _lib.Td3dCfg._fields_:
+        setattr(c, f, getattr(ocfg, f))
+    return c
+
+
+def _assert_chain_equals_oracle(il, c, o, n):
+    assert np.array_equal(il.trace["action"][c, :n].cpu().numpy(), o["trace"]["action"][:n])
+    assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"][:n])
+    assert np.array_equal(il.trace["reward"][c, :n].cpu().numpy(), o["trace"]["reward"][:n])
+    assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+    assert np.array_equal(il.episode_len[c].cpu().numpy(), o["episode_len"])
+    assert np.array_equal(il.final_returns[c].cpu().numpy(), o["final_test_returns"])
+    assert float(il.score[c]) == o["score"]
+    assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CHAIN_FIXTURES)
+def test_hip_tape_mode_vs_reference_and_oracle(orc, golden, name):
+    """The reference's own run replayed from its recorded draws: HIP == oracle bit for bit, and both within the fixture tolerances
+    of the reference.  The *_vary fixture runs in a launch sized for the largest possible draw."""
+    import torch
+    from learning_environments_amd import engine
+    engine.require_device()
+    g = golden(name)
+    ocfg, tapes = chain_inputs(orc, g)
+    hp = json.loads(str(g["hp_json"]))
+    n = g["tr_reward"].size
+    o = orc.td3d_chain(ocfg, g["theta"], g["agent_init"], tapes=orc.make_td3d_tapes(ocfg.action_dim, **tapes), trace_cap=n + 4)
+    assert o["rc"] == 0
+    chains = 2
+    cfg = _hip_cfg(ocfg)
+    if hp:                                                  # launch sized for the maxima of the draw
+        cfg.batch_size, cfg.hidden, cfg.layers = 3 * ocfg.batch_size, 3 * ocfg.hidden, min(3, ocfg.layers + 2)
+    il = engine.Td3DiscreteInnerLoop(cfg, chains, trace_cap=n + 4, want_final_params=True, vary=bool(hp))
+    if hp:
+        il.set_hp([hp["lr"]] * chains, [hp["batch_size"]] * chains, [hp["hidden_size"]] * chains, [hp["hidden_layer"]] * chains)
+        assert il.chain_num_params(hp["hidden_size"], hp["hidden_layer"]) == g["agent_init"].size
+    else:
+        assert il.p_agent == g["agent_init"].size
+    init = np.zeros((chains, il.p_agent), np.float32)
+    init[:, :g["agent_init"].size] = g["agent_init"]
+    rep = lambda a: _dev(np.tile(np.ascontiguousarray(a)[None], (chains,) + (1,) * np.ndim(a)))
+    dt = {k: rep(tapes[k]) for k in orc.TD3D_TAPE_KEYS}
+    il.run(_dev(g["theta"]), None, None, None, _dev(init), tapes=dt)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    P = g["agent_init"].size
+    for c in range(chains):
+        _assert_chain_equals_oracle(il, c, o, n)
+        assert np.array_equal(il.final_params[c, :P].cpu().numpy(), o["final_params"])
+        np.testing.assert_allclose(il.trace["action"][c, :n].cpu().numpy(), g["rb_action"][:n], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(il.final_params[c, :P].cpu().numpy(), g["final_params"], rtol=0, atol=2e-5)
+        assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4        # north_star bar
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,over", [
+    (CHAIN_FIXTURES[0], dict()),
+    (CHAIN_FIXTURES[0], dict(use_layer_norm=1, layers=3, hidden=33, batch_size=21, policy_delay=2, test_episodes=4)),
+    (CHAIN_FIXTURES[1], dict()),
+    (CHAIN_FIXTURES[1], dict(gumbel_hard=0, layers=1, act=1, batch_size=130, hidden=40, init_episodes=1)),
+    (CHAIN_FIXTURES[2], dict(act=2, gumbel_hard=1, gumbel_temp=0.5, step_budget=60)),
+])
+def test_hip_counter_mode_vs_oracle(orc, golden, name, over):
+    """Production RNG: every chain's draws come from its key (Gumbel = -log(-log(u)), Box-Muller Gaussians, replay indices,
+    resets); three chains with different keys, each equal to the oracle chain with that key."""
+    import torch
+    from learning_environments_amd import engine
+    engine.require_device()
+    g = golden(name)
+    ocfg, _ = chain_inputs(orc, g, rng_mode=0, **over)
+    P = orc.td3d_num_params(ocfg)[0]
+    cfg = _hip_cfg(ocfg)
+    chains = 3
+    keys = np.array([11, 2 ** 62 + 5, 123456789], np.uint64)
+    il = engine.Td3DiscreteInnerLoop(cfg, chains, trace_cap=512, want_final_params=True)
+    assert il.p_agent == P
+    kt = _dev(keys.view(np.int64))
+    init = il.draw_agent_init(kt)
+    rng = np.random.RandomState(3)
+    theta = g["theta"]
+    eps = (rng.randn(2, theta.size) * 0.05).astype(np.float32)
+    worker, sign = np.array([0, 1, 1], np.int32), np.array([1.0, -1.0, 0.0], np.float32)
+    il.run(_dev(theta), _dev(eps), _dev(worker), _dev(sign), None, rng_keys=kt)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    init_h = init.cpu().numpy()
+    if ocfg.use_layer_norm and ocfg.layers >= 2:            # LayerNorm weight 1 / bias 0 inside every net
+        H, S = ocfg.hidden, ocfg.state_dim
+        o0 = S * H + H + H * H + H
+        assert np.array_equal(init_h[:, o0:o0 + H], np.ones((chains, H), np.float32)) and not init_h[:, o0 + H:o0 + 2 * H].any()
+    for c in range(chains):
+        se = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)     # sign in {1, -1, 0}: the kernel's fma is exact
+        o = orc.td3d_chain(ocfg, se, init_h[c], rng_key=int(keys[c]), trace_cap=512)
+        assert o["rc"] == 0
+        n = min(o["train_steps"], 512)
+        _assert_chain_equals_oracle(il, c, o, n)
+        assert np.array_equal(il.final_params[c].cpu().numpy(), o["final_params"])
+    assert len({float(s) for s in il.score.cpu()}) >= 1
