@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LENV_ABI_VERSION 3
+#define LENV_ABI_VERSION 4
 
 enum {
     LENV_OK = 0,
@@ -324,7 +324,7 @@ typedef struct {
 typedef struct {
     double *score;              /* [chains] */
     int64_t *stats;             /* [chains,4] episodes_run, train_steps, learn_steps, test_steps */
-    int32_t *status;            /* [chains] */
+    int32_t *status;            /* [chains] 0 ok; -3..-8 as lenv_inner_out::status (-7, -8 here also: noise / policy-noise tape underrun); -9 Gumbel tape underrun (lenv_td3d_inner_loop) */
     double *episode_test_mean;  /* [chains,train_episodes] */
     int32_t *episode_len;       /* [chains,train_episodes] */
     double *final_returns;      /* [chains,test_episodes] */

@@ -264,7 +264,7 @@ def lib():
                                            C.c_size_t, C.POINTER(Td3Out), vp]
         L.lenv_td3d_agent_init.restype = C.c_int
         L.lenv_td3d_agent_init.argtypes = [C.POINTER(Td3dCfg), C.POINTER(ChainHp), vp, C.c_int64, vp, vp]
-        if L.lenv_abi_version() != 3:
+        if L.lenv_abi_version() != 4:
             raise LenvError("liblenv_hip.so ABI version mismatch")
         _lib = L
     return _lib

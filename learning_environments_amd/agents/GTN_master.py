@@ -79,7 +79,7 @@ class GTN_Master(GTN_Base):
         if int(self.num_grad_evals) < 1:
             raise ValueError("num_grad_evals must be >= 1")
         self.cpw = 1 + 2 * int(self.num_grad_evals)       # chains per worker: orig, G x (+eps), G x (-eps)  (GTN_worker.py:84-104)
-        if self.agent_name.lower() not in ("ddqn", "duelingddqn", "td3", "ddqn_vary", "duelingddqn_vary", "td3_vary", "ddqn_icm", "duelingddqn_icm", "ddqn_icm_vary", "duelingddqn_icm_vary", "td3_icm", "td3_icm_vary") + TABULAR_AGENTS:
+        if self.agent_name.lower() not in ("ddqn", "duelingddqn", "td3", "ddqn_vary", "duelingddqn_vary", "td3_vary", "ddqn_icm", "duelingddqn_icm", "ddqn_icm_vary", "duelingddqn_icm_vary", "td3_icm", "td3_icm_vary", "td3_discrete_vary") + TABULAR_AGENTS:
             raise NotImplementedError("inner agent '%s' has no fused kernel yet" % self.agent_name)
 
         self.time_elapsed_list = [None] * self.num_workers

@@ -8,12 +8,13 @@ combination owns one fused kernel:
     TD3_vary on a RewardEnv over the stand-in     -> lenv_td3_rn_inner_loop_hp
     QL / QL_cb / SARSA / SARSA_cb on a RewardEnv over a gridworld (type 1) -> lenv_ql_rn_inner_loop (BASELINE config 4)
     TD3  on a RewardEnv over the HalfCheetah stand-in -> lenv_td3_rn_inner_loop (BASELINE config 5)
+    TD3_discrete_vary on a VirtualEnv (CartPole / Acrobot / MountainCar) -> lenv_td3d_inner_loop
 Anything else raises NotImplementedError, like the reference does for unknown agents."""
 import numpy as np
 import torch
 
-from ..config import (TABULAR_AGENTS, agent_layer_dims, ddqn_cfg_from_config, icm_layer_dims, ql_cfg_from_config, td3_cfg_from_config,
-                      td3_layer_dims)
+from ..config import (TABULAR_AGENTS, TD3_DISCRETE_ENVS, agent_layer_dims, ddqn_cfg_from_config, icm_layer_dims, ql_cfg_from_config,
+                      td3_cfg_from_config, td3_layer_dims, td3d_cfg_from_config)
 from .nes_common import chain_keys, fresh_agent_init, linear_init_bounds
 
 
@@ -177,6 +178,51 @@ class Td3VaryTask(object):
         return False
 
 
+class Td3DiscreteTask(object):
+    """TD3_discrete_vary on a VirtualEnv (agents/TD3_discrete_vary.py): one launch of lenv_td3d_inner_loop per generation.  With
+    vary_hp (:21-26,119-157) every chain draws its own lr / batch_size / hidden_size / hidden_layer (agents/vary.py) and the launch is
+    sized for the largest possible draw, like Td3VaryTask.  The fresh agents (nn.Linear default init, LayerNorm 1 / 0) are drawn on
+    the device from the chain keys."""
+    name = "td3_discrete_se"
+
+    def __init__(self, config, engine):
+        import copy
+        from . import vary
+        if engine.name != "hip":
+            raise NotImplementedError("TD3_discrete_vary needs the HIP engine")
+        self.engine = engine
+        self.base = config["agents"]["td3_discrete_vary"]
+        self.vary = bool(self.base["vary_hp"])
+        big = config
+        if self.vary:
+            bd = vary.hp_bounds(self.base)
+            big = copy.deepcopy(config)
+            big["agents"]["td3_discrete_vary"].update(batch_size=bd["batch_size"][1], hidden_size=bd["hidden_size"][1],
+                                                      hidden_layer=bd["hidden_layer"][1])
+        self.cfg = td3d_cfg_from_config(big)
+        self.agent_bounds = None
+        self.last_hp = None
+
+    def make_inner(self, chains, want_episode_stats=False):
+        return self.engine.make_inner_td3d(self.cfg, chains, want_episode_stats=want_episode_stats, vary=self.vary)
+
+    def draw_hp(self, keys):
+        from . import vary
+        return [vary.vary_hyperparameters(self.base, vary.chain_units(k)) for k in keys]
+
+    def scores(self, inner, theta, eps, chain_worker, chain_sign, keys_t, agent_init):
+        if self.vary:
+            keys = keys_t.cpu().numpy().view(np.uint64)
+            hp = self.last_hp = self.draw_hp(keys)
+            inner.set_hp([h["lr"] for h in hp], [h["batch_size"] for h in hp], [h["hidden_size"] for h in hp],
+                         [h["hidden_layer"] for h in hp])
+        inner.draw_agent_init(keys_t)
+        return self.engine.inner_scores_td3(inner, theta, eps, chain_worker, chain_sign, None, keys_t)
+
+    def needs_agent_init(self):
+        return False          # drawn inside scores() (the LayerNorm parameters are not uniform draws)
+
+
 TD3_ENVS = ("HalfCheetah-v3", "Pendulum-v0", "MountainCarContinuous-v0")       # continuous real envs of the TD3 kernel
 
 
@@ -202,4 +248,6 @@ def select_task(config, engine, synthetic_env):
         return Td3RnTask(config, engine)
     if agent_name in ("td3_vary", "td3_icm_vary") and env_type in (0, 1) and config["env_name"] in TD3_ENVS:
         return Td3VaryTask(config, engine) if config["agents"]["td3_vary"]["vary_hp"] else Td3RnTask(config, engine)
+    if agent_name == "td3_discrete_vary" and env_type == 0 and config["env_name"] in TD3_DISCRETE_ENVS:
+        return Td3DiscreteTask(config, engine)
     raise NotImplementedError("inner agent '%s' on synthetic_env_type %s has no fused kernel yet" % (agent_name, env_type))

@@ -11,7 +11,7 @@ TD3_MAX_ACTION = {"HalfCheetah-v3": 1.0, "Pendulum-v0": 2.0, "MountainCarContinu
 def _refuse_layer_norm(config, env_section, agent_section):
     """The fused inner loops take plain MLPs: `use_layer_norm` (models/model_utils.py:22-29) in the synthetic env's or the
     agent's section would silently train a different network, so the config builders refuse it (the one-step forward
-    lenv_mlp_forward and the TD3_discrete_vary loop are the LayerNorm paths)."""
+    lenv_mlp_forward and the TD3_discrete_vary agent nets are the LayerNorm paths)."""
     for name, sec in (("envs." + config["env_name"], env_section), ("agent", agent_section)):
         if sec is not None and sec.get("use_layer_norm", False):
             raise NotImplementedError("use_layer_norm in the %s section: no fused inner loop takes LayerNorm nets here" % name)
@@ -180,6 +180,44 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
         ic = config["agents"]["icm"]
         cfg.icm_enabled, cfg.icm_feature_dim, cfg.icm_hidden = 1, int(ic["feature_dim"]), int(ic["hidden_size"])
         cfg.icm_lr, cfg.icm_beta, cfg.icm_eta = float(ic["lr"]), float(ic["beta"]), float(ic["eta"])
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+TD3_DISCRETE_ENVS = ("CartPole-v0", "Acrobot-v1", "MountainCar-v0")      # discrete-action real envs of the TD3_discrete_vary kernel
+
+
+def td3d_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
+    """TD3_discrete_vary + VirtualEnv on CartPole-v0 / Acrobot-v1 / MountainCar-v0.  Fields read at reference
+    agents/TD3_discrete_vary.py:30-42, models/actor_critic.py:27-31 (gumbel_softmax_temp / _hard), models/model_utils.py:5-29
+    (use_layer_norm), agents/base_agent.py:9-26, envs/env_wrapper.py:106-110 (max_action 1 for these envs)."""
+    env_name = config["env_name"]
+    if env_name not in TD3_DISCRETE_ENVS:
+        raise NotImplementedError("TD3_discrete_vary fused kernel: real env '%s'" % env_name)
+    if int(config["agents"]["gtn"].get("synthetic_env_type", 0)) != 0:
+        raise NotImplementedError("TD3_discrete_vary trains on a VirtualEnv here (synthetic_env_type 0)")
+    S, A = ENV_DIMS[env_name]
+    e = config["envs"][env_name]
+    a = config["agents"]["td3_discrete_vary"]
+    if a["same_action_num"] != 1:
+        raise NotImplementedError("same_action_num != 1")
+    _refuse_layer_norm(config, e, None)               # the SE nets stay plain MLPs; the AGENT's LayerNorm is what this kernel adds
+
+    def val(v):
+        return float(v[1]) if isinstance(v, list) else v
+
+    cfg = _lib.Td3dCfg(env_id=_lib.ENV[env_name], state_dim=S, action_dim=A, max_steps=int(val(e["max_steps"])),
+                       se_hidden=int(val(e["hidden_size"])), se_layers=int(val(e["hidden_layer"])), se_act=_lib.ACT[e["activation_fn"]],
+                       se_prelu=0.25, hidden=int(a["hidden_size"]), layers=max(1, int(a["hidden_layer"])), act=_lib.ACT[a["activation_fn"]],
+                       prelu=0.25, use_layer_norm=1 if a.get("use_layer_norm", False) else 0,
+                       gumbel_hard=1 if a["gumbel_softmax_hard"] else 0, batch_size=int(a["batch_size"]), rb_size=int(a["rb_size"]),
+                       train_episodes=int(a["train_episodes"]), test_episodes=int(a["test_episodes"]), init_episodes=int(a["init_episodes"]),
+                       early_out_num=int(a["early_out_num"]), policy_delay=int(a["policy_delay"]), rng_mode=int(rng_mode),
+                       solved_reward=float(val(e["solved_reward"])), gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]),
+                       action_std=float(a["action_std"]), policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]),
+                       max_action=1.0, gumbel_temp=float(a["gumbel_softmax_temp"]), adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
+                       step_budget=int(a.get("step_budget", 0)))
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg

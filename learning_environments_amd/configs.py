@@ -214,6 +214,37 @@ def cmc_reward_env_td3(num_workers=16, max_iterations=50):
     return cfg
 
 
+def _td3_discrete_section(**over):
+    """The `td3_discrete_vary` section both syn-env YAMLs ship (default_config_cartpole_syn_env.yaml:79-102 =
+    default_config_acrobot_syn_env.yaml:58-81): actor S-510-510-A / critics (S+A)-510-510-1, tanh, hard Gumbel softmax."""
+    d = {"train_episodes": 1000, "test_episodes": 10, "init_episodes": 1, "batch_size": 122, "gamma": 0.9989, "lr": 0.0017496,
+         "tau": 0.0724303, "policy_delay": 1, "rb_size": 1000000, "same_action_num": 1, "activation_fn": "tanh", "hidden_size": 510,
+         "hidden_layer": 2, "action_std": 0.037275, "policy_std": 0.2225286, "policy_std_clip": 0.5, "print_rate": 1, "early_out_num": 1,
+         "early_out_virtual_diff": 0.01, "gumbel_softmax_temp": 2.3076235, "gumbel_softmax_hard": True, "vary_hp": False}
+    d.update(over)
+    return d
+
+
+def cartpole_syn_env_td3_discrete(num_workers=16, max_iterations=50, **agent_over):
+    """CartPole-v0 SE + TD3_discrete_vary (select_agent "td3_discrete_vary"): the GTN / env sections of
+    default_config_cartpole_syn_env.yaml with its td3_discrete_vary agent section; agent_over e.g. use_layer_norm=True
+    (default_config_cartpole.yaml:106-130 `td3_discrete_vary_layer_norm`) or vary_hp=True."""
+    cfg = cartpole_syn_env_ddqn(num_workers, max_iterations)
+    cfg["agents"]["gtn"]["agent_name"] = "TD3_discrete_vary"
+    cfg["agents"].pop("ddqn")
+    cfg["agents"]["td3_discrete_vary"] = _td3_discrete_section(**agent_over)
+    return cfg
+
+
+def acrobot_syn_env_td3_discrete(num_workers=16, max_iterations=50, **agent_over):
+    """Acrobot-v1 SE + TD3_discrete_vary (default_config_acrobot_syn_env.yaml:58-81)."""
+    cfg = acrobot_syn_env_duelingddqn(num_workers, max_iterations)
+    cfg["agents"]["gtn"]["agent_name"] = "TD3_discrete_vary"
+    cfg["agents"].pop("duelingddqn")
+    cfg["agents"]["td3_discrete_vary"] = _td3_discrete_section(**agent_over)
+    return cfg
+
+
 def with_vary(config, vary_hp=True):
     """The same experiment with the *_vary agent of the family (default_config_acrobot.yaml:26 ships `agent_name: DDQN_vary`;
     the `<agent>_vary: {vary_hp: ...}` section is :27-28 there)."""
@@ -239,7 +270,7 @@ def fixed_work(config, train_episodes):
     cfg = copy.deepcopy(config)
     key = cfg["agents"]["gtn"]["agent_name"].lower()
     for suffix in ("_vary", "_icm"):
-        if key.endswith(suffix):
+        if key.endswith(suffix) and key != "td3_discrete_vary":       # TD3_discrete_vary reads its own section
             key = key[:-len(suffix)]
     cfg["agents"][key]["train_episodes"] = train_episodes
     cfg["envs"][cfg["env_name"]]["solved_reward"] = 1e9

@@ -593,6 +593,9 @@ class HipNesEngine(object):
     def make_inner_td3(self, cfg, chains, **kw):
         return Td3InnerLoop(cfg, chains, **kw)
 
+    def make_inner_td3d(self, cfg, chains, **kw):
+        return Td3DiscreteInnerLoop(cfg, chains, **kw)
+
     def inner_scores_td3(self, inner, theta, eps, worker, sign, agent_init, rng_keys):
         return inner.run(theta, eps, worker, sign, agent_init, rng_keys=rng_keys)
 

@@ -218,3 +218,80 @@ def test_hip_counter_mode_vs_oracle(orc, golden, name, over):
         _assert_chain_equals_oracle(il, c, o, n)
         assert np.array_equal(il.final_params[c].cpu().numpy(), o["final_params"])
     assert len({float(s) for s in il.score.cpu()}) >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["plain", "layer_norm_vary"])
+def test_gtn_master_td3_discrete_generation(variant, tmp_path, monkeypatch):
+    """`agent_name: TD3_discrete_vary` through GTN_Master: one launch per generation, every fitness equal to the oracle chain with
+    that chain's key, fresh agent and (vary_hp) hyper-parameter draw; then a full run()."""
+    import torch
+    from learning_environments_amd.agents import tasks
+    from learning_environments_amd.agents.GTN import GTN_Master
+    from learning_environments_amd.configs import cartpole_syn_env_td3_discrete, fixed_work
+    from oracle import oracle as orc
+    over = dict(hidden_size=40, batch_size=24, test_episodes=3)
+    if variant != "plain":
+        over.update(use_layer_norm=True, vary_hp=True, gumbel_softmax_hard=False, policy_delay=2)
+    cfg = fixed_work(cartpole_syn_env_td3_discrete(num_workers=2, max_iterations=1, **over), 3)
+    cfg["envs"]["CartPole-v0"]["max_steps"] = 12
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    m = GTN_Master(cfg, bohb_id=0, seed=5)
+    assert isinstance(m.task, tasks.Td3DiscreteTask) and m.inner.vary == (variant != "plain")
+    if variant != "plain":
+        assert m.cfg.batch_size == 72 and m.cfg.hidden == 120 and m.cfg.layers == 3 and m.cfg.use_layer_norm == 1
+    theta0 = m.theta.cpu().numpy().copy()
+    gathered = m.evaluate_population(0).cpu().numpy()
+    eps = m.eps.cpu().numpy()
+    inits = m.inner.agent_init.cpu().numpy()
+    hps = m.task.last_hp
+    for p in range(2):
+        sc = []
+        for kind, sg in enumerate((0.0, 1.0, -1.0)):
+            c = 3 * p + kind
+            key = orc.chain_key(m.seed, 0, p, kind)
+            ocfg = orc.td3d_cfg_from_config(cfg, hp=hps[c] if hps else None)
+            P = orc.td3d_num_params(ocfg)[0]
+            w = (np.float32(sg) * eps[p] + theta0).astype(np.float32)
+            r = orc.td3d_chain(ocfg, w, inits[c, :P], rng_key=key)
+            assert r["rc"] == 0 and r["learn_steps"] > 0
+            sc.append(r["score"])
+        assert gathered[p, 1] == sc[0] and gathered[p, 0] == max(sc[1], sc[2])
+    mean_score, mean_list, _ = m.run()
+    assert len(mean_list) == 1 and np.isfinite(mean_score)
+
+
+@pytest.mark.gpu
+def test_shipped_shape_runs_and_matches_oracle(orc):
+    """The td3_discrete_vary section as the syn-env YAMLs ship it (510-wide tanh nets, batch 122, hard Gumbel softmax, temperature
+    2.31) on an Acrobot SE, shortened to a few episodes: two chains, bit-equal to the oracle."""
+    import torch
+    from learning_environments_amd import engine
+    from learning_environments_amd.config import td3d_cfg_from_config
+    from learning_environments_amd.configs import acrobot_syn_env_td3_discrete, fixed_work
+    engine.require_device()
+    cfgd = fixed_work(acrobot_syn_env_td3_discrete(num_workers=2, train_episodes=3, test_episodes=2), 3)
+    cfgd["envs"]["Acrobot-v1"]["max_steps"] = 20
+    cfg = td3d_cfg_from_config(cfgd)
+    ocfg = orc.td3d_cfg_from_config(cfgd)
+    for f, _ in type(cfg)._fields_:
+        assert getattr(cfg, f) == getattr(ocfg, f), f
+    chains = 2
+    il = engine.Td3DiscreteInnerLoop(cfg, chains, want_final_params=True)
+    keys = np.array([901, 902], np.uint64)
+    kt = _dev(keys.view(np.int64))
+    init = il.draw_agent_init(kt).cpu().numpy()
+    # nn.Linear default init: |w| <= 1 / sqrt(fan_in) per layer of the actor
+    S, H = 6, 510
+    assert np.abs(init[:, :S * H]).max() <= 1 / np.sqrt(S) and np.abs(init[:, S * H + H:S * H + H + H * H]).max() <= 1 / np.sqrt(H)
+    rng = np.random.RandomState(1)
+    theta = (rng.randn(il.p_theta) * 0.1).astype(np.float32)
+    il.run(_dev(theta), None, None, None, None, rng_keys=kt)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0, 0]
+    for c in range(chains):
+        o = orc.td3d_chain(ocfg, theta, init[c], rng_key=int(keys[c]))
+        assert o["rc"] == 0 and o["learn_steps"] == 40
+        assert float(il.score[c]) == o["score"]
+        assert np.array_equal(il.final_params[c].cpu().numpy(), o["final_params"])
