@@ -51,7 +51,7 @@ dueling_model, td3_model = _frac(bench.dueling_model), _frac(bench.td3_model)
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["2", "3", "4", "5"]
+    which = sys.argv[1:] or ["2", "3", "4", "5", "td3d"]
     if "2" in which:
         run("cfg2 CartPole SE + DDQN pop 64 (20 episodes)", configs.fixed_work(configs.cartpole_syn_env_ddqn(64), 20))
     if "2full" in which:
@@ -78,6 +78,14 @@ if __name__ == "__main__":
         c["agents"]["td3"]["init_episodes"] = 1
         c["envs"]["HalfCheetah-v3"]["max_steps"] = 100
         run("cfg5 HalfCheetah-standin RN + TD3 pop 85 = 255 chains (3 episodes x 100 steps)", c, gens=1, extra=td3_model)
+    if "td3d" in which:
+        # TD3_discrete_vary as the syn-env YAMLs ship it (510-wide tanh nets, batch 122, hard Gumbel softmax) on an Acrobot SE
+        c = configs.fixed_work(configs.acrobot_syn_env_td3_discrete(32), 3)
+        c["envs"]["Acrobot-v1"]["max_steps"] = 100
+        run("TD3_discrete_vary on an Acrobot SE, pop 32 (3 episodes x 100 steps, shipped 510-wide nets)", c, gens=1)
+        c = configs.fixed_work(configs.cartpole_syn_env_td3_discrete(32, hidden_size=128, batch_size=128, use_layer_norm=True, activation_fn="relu"), 3)
+        c["envs"]["CartPole-v0"]["max_steps"] = 100
+        run("TD3_discrete_vary + LayerNorm on a CartPole SE, pop 32 (128-wide relu nets, batch 128)", c, gens=1)
     if "5" in which:
         c = configs.fixed_work(configs.halfcheetah_reward_env_td3(32), 3)
         c["agents"]["td3"]["init_episodes"] = 1
