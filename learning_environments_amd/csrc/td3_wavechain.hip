@@ -27,7 +27,7 @@ static_assert(PN % 4 == 0, "float4 passes");
 constexpr int T3W_B = 192, T3W_NB = T3W_B / 32;                           // minibatch rows, sample blocks
 
 // dumps: [T3W_NB] blocks of BLK floats each (register order), or [192][128] row-major copies (same size)
-enum { TD_C1_H1 = 0, TD_C1_H2, TD_C2_H1, TD_C2_H2, TD_A_H1, TD_A_H2, TR_C1_H2, TR_C2_H2, TR_A_H2, TS_DZ2, TR_DZ2, TR_DH1, T3W_NDUMP };
+enum { TD_C1_H1 = 0, TD_C1_H2, TD_C2_H1, TD_C2_H2, TD_A_H1, TD_A_H2, TR_C1_H2, TR_C2_H2, TR_A_H2, TS_DZ2, TR_DZ2, TR_DH1, TR_DZ2B, TR_DH1B, T3W_NDUMP };
 
 struct T3wArgs {
     lenv_td3_cfg cfg;
@@ -37,13 +37,16 @@ struct T3wArgs {
     lenv_td3_out out;
     int64_t rb_cap; int RS;
     int P, Pa, Pc, P_rn;
-    int64_t a_par, a_xc, a_xn, a_xa, a_th, a_dump, a_replay, a_meter;
+    int64_t a_par, a_xc, a_xn, a_xa, a_th, a_dump, a_replay, a_meter, a_gx, a_bar;
+    int G;                                   // workgroups per chain (team): 1, 2, 3 or 6
+    int64_t chains;
 };
 
 struct T3wCtx {
-    float *bufA, *bufB, *sm_b, *sm_wo, *sm_bo, *qvec, *dzl;
+    float *bufA, *bufB, *sm_b, *sm_wo, *sm_bo, *qvec, *dzl, *sm_b2, *sm_wo2;
     float *params, *targets, *grad, *dumps;
     float prelu, ma;
+    int g, G;                                // this workgroup's place in its chain's team
 };
 
 // state-dict index inside ONE net (mlp_off order: W0 [128 x in] b0 W1 [128 x 128] b1 Wout [out x 128] bout) -> arena-layout index
@@ -89,9 +92,12 @@ __device__ unsigned long long g_t3w_phase_cycles[48];
     lfloat *sm_b = (lfloat *)uni_ptr(c->sm_b), *sm_wo = (lfloat *)uni_ptr(c->sm_wo), *sm_bo = (lfloat *)uni_ptr(c->sm_bo);                 \
     float *dumps = uni_ptr(c->dumps);                                                                                                      \
     const float prelu = unif(c->prelu), ma = unif(c->ma);                                                                                  \
+    const int tg = uni(c->g), TG = uni(c->G);                                                                                              \
+    /* slot s of an n-slot phase (sample blocks: 6, tile / vector waves: 8) runs on wave s of the team's workgroup s * G / n */          \
+    auto mine = [&](int s_, int n_) { return TG == 1 || (s_ * TG) / n_ == tg; };                                                          \
     (void)bufA; (void)bufB; (void)sm_b; (void)sm_wo; (void)sm_bo; (void)dumps; (void)prelu; (void)ma;                                      \
     auto dump_of = [&](int which, int blk) { return dumps + ((int64_t)which * T3W_NB + blk) * BLK; };                                      \
-    (void)dump_of
+    (void)dump_of; (void)mine
 
 // [32 samples x 128 units] register block -> rows 32 blk .. of a plain [sample][unit] array (16-byte stores)
 __device__ __forceinline__ void block_to_rowmajor(float *rm_, int blk, const Lane &L, const float (&r)[64])
@@ -103,26 +109,47 @@ __device__ __forceinline__ void block_to_rowmajor(float *rm_, int blk, const Lan
 
 // ---- one network pass over the 192 minibatch rows X[i][ldx] (waves 0-5 own the sample blocks) ----------------------------------
 // mode 0 (Critic_Q): q_out[i] = net(x)      mode 1 (Actor_TD3): Y[i][ocol + c] = tanh(net(x)) * max_action, th_out[i][c] = tanh
+// A team member owns at most three of the six blocks, so a SECOND, independent critic pass (par2 != null: its own parameters, inputs,
+// outputs and dumps; image in bufB, small vectors in the second LDS set) runs next to the first one on the waves four places on.
 template <int ACT, int IN, int OUT>
 __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, const float *X_, int ldx_, int mode_, float *q_out_,
-                                         float *Y_, int ldy_, int ocol_, float *th_out_, int d_h1_, int d_h2_, int r_h2_)
+                                         float *Y_, int ldy_, int ocol_, float *th_out_, int d_h1_, int d_h2_, int r_h2_,
+                                         const float *par2_ = nullptr, const float *X2_ = nullptr, float *q_out2_ = nullptr, int d_h1_2_ = -1, int r_h2_2_ = -1)
 {
     T3W_CTX_PROLOGUE;
-    const float *par = uni_ptr(par_), *X = uni_ptr(X_);
+    const bool dual = uni_ptr(par2_) != nullptr;
+    // this wave's job: (pass 0, block = wave) or, in a dual call, (pass 1, block = wave + 4 mod 8)
+    const int wave2 = (wave + 4) & 7;
+    const bool act0 = wave < T3W_NB && mine(wave, T3W_NB);
+    const bool act1 = dual && !act0 && wave2 < T3W_NB && mine(wave2, T3W_NB);
+    const bool active = act0 || act1;
+    const int blk = act1 ? wave2 : (act0 ? wave : 0);
+    const float *par = uni_ptr(act1 ? par2_ : par_), *X = uni_ptr(act1 ? X2_ : X_);
     float *Y = uni_ptr(Y_), *th_out = uni_ptr(th_out_);
-    lfloat *q_out = (lfloat *)uni_ptr(q_out_);
+    lfloat *q_out = (lfloat *)uni_ptr(act1 ? q_out2_ : q_out_);
     constexpr int in = IN, out = OUT;
     const int ldx = uni(ldx_), mode = uni(mode_), ldy = uni(ldy_), ocol = uni(ocol_);
-    const int d_h1 = uni(d_h1_), d_h2 = uni(d_h2_), r_h2 = uni(r_h2_);
-    for (int i = tid; i < 2 * W; i += NT) sm_b[i] = par[(i < W ? ob1 : ob2 - W) + i];
-    for (int i = tid; i < 8 * W + 8; i += NT) sm_wo[i] = par[oWo + i];                  // Wo and bo are contiguous in both places
+    const int d_h1 = uni(act1 ? d_h1_2_ : d_h1_), r_h2 = uni(act1 ? r_h2_2_ : r_h2_);
+    lfloat *sm_b2 = (lfloat *)uni_ptr(c->sm_b2), *sm_wo2 = (lfloat *)uni_ptr(c->sm_wo2);
+    {
+        const float *p0 = uni_ptr(par_);
+        for (int i = tid; i < 2 * W; i += NT) sm_b[i] = p0[(i < W ? ob1 : ob2 - W) + i];
+        for (int i = tid; i < 8 * W + 8; i += NT) sm_wo[i] = p0[oWo + i];                // Wo and bo are contiguous in both places
+        if (dual) {
+            const float *p1 = uni_ptr(par2_);
+            for (int i = tid; i < 2 * W; i += NT) sm_b2[i] = p1[(i < W ? ob1 : ob2 - W) + i];
+            for (int i = tid; i < 8 * W + 8; i += NT) sm_wo2[i] = p1[oWo + i];
+        }
+    }
+    const lfloat *smb = act1 ? sm_b2 : sm_b, *smwo = act1 ? sm_wo2 : sm_wo, *smbo = smwo + 8 * W;
+    const float *img = act1 ? bufB : bufA;
     StageRegs sr;
     TSUB_DECL;
     // layer 1's operands (A straight from the K-major array, B from the minibatch rows) are requested first: their latency hides
     // behind the staging of the W2 image
     float xb[in >> 1], wa[in >> 1][4];
     {
-        const int row0 = 32 * (wave < T3W_NB ? wave : 0) + L.li;
+        const int row0 = 32 * blk + L.li;
         const gfloat *w1 = (const gfloat *)par + oW1t + L.h * W + L.li;
         const gfloat *xr = (const gfloat *)X + row0 * ldx + L.h;
 #pragma unroll
@@ -132,12 +159,16 @@ __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, 
             for (int jt = 0; jt < 4; ++jt) wa[t][jt] = w1[2 * t * W + 32 * jt];
         }
     }
-    stage_load_direct(par + oW2t, L, sr);
+    stage_load_direct(uni_ptr(par_) + oW2t, L, sr);
     stage_store_direct(bufA, L, sr);
-    barrier_lds();                                         // image + small vectors: LDS only (the layer-1 operand loads stay in flight)
+    if (dual) {
+        stage_load_direct(uni_ptr(par2_) + oW2t, L, sr);
+        stage_store_direct(bufB, L, sr);
+    }
+    barrier_lds();                                         // images + small vectors: LDS only (the layer-1 operand loads stay in flight)
     TSUB_MARK(16);
-    if (wave < T3W_NB) {
-        const int blk = wave, row = 32 * blk + L.li;
+    if (active) {
+        const int row = 32 * blk + L.li;
         float r[64];
         f32x16 acc[4];
         acc_zero(acc);
@@ -157,28 +188,28 @@ __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, 
                 }
             }
         }
-        tile_bias_act<ACT>(acc, (const float *)sm_b, L, prelu, r);
+        tile_bias_act<ACT>(acc, (const float *)smb, L, prelu, r);
         if (d_h1 >= 0) dump_store(dump_of(d_h1, blk), L, r);
         tile_to_operand(r);
         TSUB_MARK(17);
         acc_zero(acc);
-        chain128(bufA, L, r, acc);
+        chain128(img, L, r, acc);
         TSUB_MARK(18);
-        tile_bias_act<ACT>(acc, (const float *)(sm_b + W), L, prelu, r);
+        tile_bias_act<ACT>(acc, (const float *)(smb + W), L, prelu, r);
         if (r_h2 >= 0) block_to_rowmajor(dump_of(r_h2, 0), blk, L, r);     // h2 is kept as a plain [sample][unit] array only
         tile_to_operand(r);
         // output layer: rows 0 .. out-1 of one 32x32 tile (row c of lane half h = 4 h + register)
         f32x16 hacc;
 #pragma unroll
         for (int v = 0; v < 16; ++v) hacc[v] = 0.0f;
-        const lfloat *wo = sm_wo + L.h * 8 + (L.li < out ? L.li : out - 1);
+        const lfloat *wo = smwo + L.h * 8 + (L.li < out ? L.li : out - 1);
 #pragma unroll
         for (int t = 0; t < 64; ++t) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wo[2 * t * 8], r[breg_of(t)], hacc, 0, 0, 0);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int cidx = 4 * L.h + v;
             if (cidx < out) {
-                const float z = hacc[v] + sm_bo[cidx];
+                const float z = hacc[v] + smbo[cidx];
                 if (mode == 0) q_out[row] = z;
                 else {
                     const float th = det_tanhf(lenv_tanh_table, z);
@@ -193,53 +224,45 @@ __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, 
     TSUB_MARK(20);
 }
 
-// ---- backward of one network from dOut[i][out] (LDS): parameter gradients to gpar (may be null) and, for the policy step, the
-// action part of the input gradient turned into the actor's output gradient dz (LDS) right away ----
+// ---- backward of one network, first half: the per-sample chain from dOut[i][out] (LDS; the rows of this workgroup's blocks) back to
+// dz2 and dh1 (row-major copies r_dz2 / r_dh1 in the arena for the weight gradients) and, for the policy step, the action part of the
+// input gradient turned into the actor's output gradient dz (LDS) right away ----
 template <int ACT, int IN, int OUT>
-__device__ __noinline__ void t3w_backward(const T3wCtx *ctx_, const float *par_, float *gpar_, const float *X_, int ldx_,
-                                          const float *dOut_, int d_h1_, int d_h2_, int r_h2_, int dx_col_, int dx_n_, const float *th_, float *dz_out_)
+__device__ __noinline__ void t3w_backward_chain(const T3wCtx *ctx_, const float *par_, const float *dOut_, int d_h1_, int d_h2_, int r_dz2_, int r_dh1_,
+                                                int dx_col_, int dx_n_, const float *th_, float *dz_out_,
+                                                const float *par2_ = nullptr, const float *dOut2_ = nullptr, int d_h1_2_ = -1, int d_h2_2_ = -1,
+                                                int r_dz2_2_ = -1, int r_dh1_2_ = -1)
 {
     T3W_CTX_PROLOGUE;
-    const float *par = uni_ptr(par_), *X = uni_ptr(X_), *th = uni_ptr(th_);
-    float *gpar = uni_ptr(gpar_);
-    const lfloat *dOut = (const lfloat *)uni_ptr(dOut_);
+    // a second, independent network's chain (par2 != null) runs on the waves four places on, as in t3w_forward
+    const bool dual = uni_ptr(par2_) != nullptr;
+    const int wave2 = (wave + 4) & 7;
+    const bool act0 = wave < T3W_NB && mine(wave, T3W_NB);
+    const bool act1 = dual && !act0 && wave2 < T3W_NB && mine(wave2, T3W_NB);
+    const bool own = act0 || act1;
+    const int blk = act1 ? wave2 : (act0 ? wave : 0);
+    const float *par = uni_ptr(act1 ? par2_ : par_), *th = uni_ptr(th_);
+    const lfloat *dOut = (const lfloat *)uni_ptr(act1 ? dOut2_ : dOut_);
     lfloat *dz_out = (lfloat *)uni_ptr(dz_out_);
-    constexpr int in = IN, out = OUT;
-    const int ldx = uni(ldx_), d_h1 = uni(d_h1_), d_h2 = uni(d_h2_), r_h2 = uni(r_h2_), dx_col = uni(dx_col_), dx_n = uni(dx_n_);
-    constexpr int B = T3W_B;
-    for (int i = tid; i < 8 * W + 8; i += NT) sm_wo[i] = par[oWo + i];
-    StageRegs sr;
+    constexpr int out = OUT;
+    const int d_h1 = uni(act1 ? d_h1_2_ : d_h1_), d_h2 = uni(act1 ? d_h2_2_ : d_h2_), r_dz2 = uni(act1 ? r_dz2_2_ : r_dz2_),
+              r_dh1 = uni(act1 ? r_dh1_2_ : r_dh1_), dx_col = uni(dx_col_), dx_n = uni(dx_n_);
+    lfloat *sm_wo2 = (lfloat *)uni_ptr(c->sm_wo2);
+    for (int i = tid; i < 8 * W + 8; i += NT) sm_wo[i] = uni_ptr(par_)[oWo + i];
+    if (dual) for (int i = tid; i < 8 * W + 8; i += NT) sm_wo2[i] = uni_ptr(par2_)[oWo + i];
+    const lfloat *smwo = act1 ? sm_wo2 : sm_wo;
+    const float *img = act1 ? bufB : bufA;
+    StageRegs sr, sr2;
     TSUB_DECL;
-    stage_load_transposed(par + oW2t, L, sr);
-    if (gpar) {
-        // output layer: gWo[k][c] = sum_i dOut[i][c] h2[i][k] (i ascending) from the row-major copy of h2; gbo[c] = sum_i dOut[i][c]
-        const gfloat *rm = (const gfloat *)dump_of(r_h2, 0);
-        for (int e = tid; e < W * out; e += NT) {
-            const int k = e & 127, cidx = e >> 7;
-            float s = 0.0f;
-            for (int i0 = 0; i0 < B; i0 += 64) {
-                float hv[64];
-#pragma unroll
-                for (int u = 0; u < 64; ++u) hv[u] = rm[(i0 + u) * W + k];
-#pragma unroll
-                for (int u = 0; u < 64; ++u) s = fma32(dOut[(i0 + u) * out + cidx], hv[u], s);
-            }
-            gpar[oWo + k * 8 + cidx] = s;
-        }
-        if (tid >= NT - 64 && tid < NT - 64 + out) {
-            const int cidx = tid - (NT - 64);
-            float s = 0.0f;
-            for (int i = 0; i < B; ++i) s = s + dOut[i * out + cidx];
-            gpar[obo + cidx] = s;
-        }
-    }
+    stage_load_transposed(uni_ptr(par_) + oW2t, L, sr);
+    if (dual) stage_load_transposed(uni_ptr(par2_) + oW2t, L, sr2);
     __syncthreads();                                       // sm_wo staged
     TSUB_MARK(24);
     float r[64];
     f32x16 acc[4];
-    if (wave < T3W_NB) {
+    if (own) {
         // dz2 = act'(h2) * (sum_c dOut[i][c] Wo[c][unit], c ascending from 0)
-        const int blk = wave, row = 32 * blk + L.li;
+        const int row = 32 * blk + L.li;
         const gfloat *hd = (const gfloat *)dump_of(d_h2, 0) + row * W + 4 * L.h;        // d_h2: the row-major copy of h2
         float dO[out];
 #pragma unroll
@@ -247,7 +270,7 @@ __device__ __noinline__ void t3w_backward(const T3wCtx *ctx_, const float *par_,
 #pragma unroll
         for (int pc = 0; pc < 16; ++pc) {
             const f32x4 hv = *(const gf4 *)(hd + 32 * (pc >> 2) + 8 * (pc & 3));
-            const lfloat *wp = sm_wo + (32 * (pc >> 2) + 8 * (pc & 3) + 4 * L.h) * 8;
+            const lfloat *wp = smwo + (32 * (pc >> 2) + 8 * (pc & 3) + 4 * L.h) * 8;
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
                 float wv[8];
@@ -260,26 +283,27 @@ __device__ __noinline__ void t3w_backward(const T3wCtx *ctx_, const float *par_,
                 r[4 * pc + cc] = act_bwd(ACT, prelu, hv[cc], up);
             }
         }
-        block_to_rowmajor(dump_of(TR_DZ2, 0), blk, L, r);
+        block_to_rowmajor(dump_of(r_dz2, 0), blk, L, r);
         tile_to_operand(r);
     }
     stage_store_transposed(bufA, L, sr);
-    barrier_lds();                                         // the chain reads the image only; the dz2 copy in the arena is read two phases on
+    if (dual) stage_store_transposed(bufB, L, sr2);
+    barrier_lds();                                         // the chain reads the image only; the dz2 copy in the arena is read by the weight gradients
     TSUB_MARK(25);
     L.refresh();
-    if (wave < T3W_NB) {
-        const int blk = wave, row = 32 * blk + L.li;
+    if (own) {
+        const int row = 32 * blk + L.li;
         const gf4 *src = (const gf4 *)dump_of(d_h1, blk) + L.lane;
         f32x4 hv[16];
 #pragma unroll
         for (int pc = 0; pc < 16; ++pc) hv[pc] = src[pc * 64];
         acc_zero(acc);
-        chain128(bufA, L, r, acc);
+        chain128(img, L, r, acc);
 #pragma unroll
         for (int pc = 0; pc < 16; ++pc)
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) r[4 * pc + cc] = act_bwd(ACT, prelu, hv[pc][cc], acc[pc >> 2][4 * (pc & 3) + cc]);
-        if (gpar) block_to_rowmajor(dump_of(TR_DH1, 0), blk, L, r);
+        if (r_dh1 >= 0) block_to_rowmajor(dump_of(r_dh1, 0), blk, L, r);
         if (dx_n > 0) {
             // dX[i][dx_col + c] = sum_u dh1[i][u] W1[u][dx_col + c] (u ascending), c < dx_n, then dz = (dX * max_action) * (1 - th^2)
             tile_to_operand(r);
@@ -301,7 +325,53 @@ __device__ __noinline__ void t3w_backward(const T3wCtx *ctx_, const float *par_,
     }
     __syncthreads();
     TSUB_MARK(26);
-    if (!gpar) return;
+}
+
+// ---- backward of one network, second half: the parameter gradients from the row-major copies of ALL 192 samples (dOut in LDS, h2 /
+// dz2 / dh1 in the arena, the h1 register dumps).  The work is cut by wave -- output-layer gradients (VALU), two W2 tiles per wave,
+// one W1 column tile or one bias vector per wave -- and wave w's share runs in the team's workgroup w * G / 8 ----
+template <int ACT, int IN, int OUT>
+__device__ __noinline__ void t3w_backward_wgrad(const T3wCtx *ctx_, float *gpar_, const float *X_, int ldx_, const float *dOut_, int d_h1_, int r_h2_,
+                                                int r_dz2_, int r_dh1_, int slot0_, int slots_)
+{
+    T3W_CTX_PROLOGUE;
+    // the team deals `slots` wave slots (8 per network of this phase: the two critics' gradients run side by side in different
+    // members); a member without a slot of this network skips the call, image staging included
+    const int slot0 = uni(slot0_), slots = uni(slots_);
+    if (TG > 1 && ((slot0 + NW - 1) * TG) / slots < tg) return;
+    if (TG > 1 && (slot0 * TG) / slots > tg) return;
+    const float *X = uni_ptr(X_);
+    float *gpar = uni_ptr(gpar_);
+    const lfloat *dOut = (const lfloat *)uni_ptr(dOut_);
+    constexpr int in = IN, out = OUT;
+    const int ldx = uni(ldx_), d_h1 = uni(d_h1_), r_h2 = uni(r_h2_), r_dz2 = uni(r_dz2_), r_dh1 = uni(r_dh1_);
+    constexpr int B = T3W_B;
+    const bool my_wave = mine(slot0 + wave, slots);
+    TSUB_DECL;
+    if (my_wave) {
+        // output layer: gWo[k][c] = sum_i dOut[i][c] h2[i][k] (i ascending) from the row-major copy of h2; gbo[c] = sum_i dOut[i][c]
+        const gfloat *rm = (const gfloat *)dump_of(r_h2, 0);
+        for (int e = tid; e < W * out; e += NT) {
+            const int k = e & 127, cidx = e >> 7;
+            float s = 0.0f;
+            for (int i0 = 0; i0 < B; i0 += 64) {
+                float hv[64];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) hv[u] = rm[(i0 + u) * W + k];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) s = fma32(dOut[(i0 + u) * out + cidx], hv[u], s);
+            }
+            gpar[oWo + k * 8 + cidx] = s;
+        }
+        if (tid >= NT - 64 && tid < NT - 64 + out) {
+            const int cidx = tid - (NT - 64);
+            float s = 0.0f;
+            for (int i = 0; i < B; ++i) s = s + dOut[i * out + cidx];
+            gpar[obo + cidx] = s;
+        }
+    }
+    TSUB_MARK(24);
+    float r[64];
     // gW2t[k][j] = sum_i h1[i][k] dz2[i][j] over the 192 samples: two half-batches of 96 rows through the two images
     f32x16 acc0, acc1;
 #pragma unroll
@@ -310,7 +380,7 @@ __device__ __noinline__ void t3w_backward(const T3wCtx *ctx_, const float *par_,
     for (int half = 0; half < 2; ++half) {
         L.refresh();
         {   // dz2 rows 96 half .. + 95: straight copy of the row-major array into the swizzled image (bufB)
-            const gf4 *src = (const gf4 *)dump_of(TR_DZ2, 0) + half * 96 * 32 + tid;
+            const gf4 *src = (const gf4 *)dump_of(r_dz2, 0) + half * 96 * 32 + tid;
             lfloat *img = (lfloat *)bufB;
             f32x4 v[6];
 #pragma unroll
@@ -327,10 +397,10 @@ __device__ __noinline__ void t3w_backward(const T3wCtx *ctx_, const float *par_,
         }
         barrier_lds();
         L.refresh();
-        wgrad_accum(bufA, bufB, 96, L, acc0, acc1);
+        if (my_wave) wgrad_accum(bufA, bufB, 96, L, acc0, acc1);
         barrier_lds();
     }
-    wgrad_store(L, gpar + oW2t, acc0, acc1);
+    if (my_wave) wgrad_store(L, gpar + oW2t, acc0, acc1);
     TSUB_MARK(27);
     // layer 1: gW1t[k][j] = sum_i x[i][k] dh1[i][j] (k < in) on the matrix cores too: A = the minibatch inputs straight from the arena
     // (lane = input column k, clamped), B = an image of dh1 built from its row-major copy, again in two half-batches; waves 0-3 own
@@ -343,7 +413,7 @@ __device__ __noinline__ void t3w_backward(const T3wCtx *ctx_, const float *par_,
     for (int half = 0; half < 2; ++half) {
         L.refresh();
         {   // half-batch images of dh1 (bufB) and dz2 (bufA) from their row-major copies
-            const gf4 *src = (const gf4 *)dump_of(TR_DH1, 0) + half * 96 * 32 + tid, *src2 = (const gf4 *)dump_of(TR_DZ2, 0) + half * 96 * 32 + tid;
+            const gf4 *src = (const gf4 *)dump_of(r_dh1, 0) + half * 96 * 32 + tid, *src2 = (const gf4 *)dump_of(r_dz2, 0) + half * 96 * 32 + tid;
             lfloat *img = (lfloat *)bufB, *img2 = (lfloat *)bufA;
             f32x4 v[6], v2[6];
 #pragma unroll
@@ -357,7 +427,8 @@ __device__ __noinline__ void t3w_backward(const T3wCtx *ctx_, const float *par_,
         }
         barrier_lds();
         L.refresh();
-        if (wave < 4) {
+        if (!my_wave) { /* another workgroup of the team runs this wave's tile / vector */ }
+        else if (wave < 4) {
             const lfloat *img = (const lfloat *)bufB;
             const lfloat *pb[4];
 #pragma unroll
@@ -381,12 +452,13 @@ __device__ __noinline__ void t3w_backward(const T3wCtx *ctx_, const float *par_,
         }
         barrier_lds();
     }
-    if (wave < 4) {
-        gfloat *out = (gfloat *)gpar + oW1t + (4 * L.h) * W + 32 * wave + L.li;      // rows k = 8 (v / 4) + 4 h + v % 4 of the K-major gradient
+    if (!my_wave) { }
+    else if (wave < 4) {
+        gfloat *out_ = (gfloat *)gpar + oW1t + (4 * L.h) * W + 32 * wave + L.li;      // rows k = 8 (v / 4) + 4 h + v % 4 of the K-major gradient
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int k = 8 * (v >> 2) + 4 * L.h + (v & 3);
-            if (k < in) out[(8 * (v >> 2) + (v & 3)) * W] = accw[v];
+            if (k < in) out_[(8 * (v >> 2) + (v & 3)) * W] = accw[v];
         }
     } else gpar[(wave < 6 ? ob1 : ob2) + (tid & 127)] = sb;
     __syncthreads();
@@ -402,10 +474,17 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     constexpr int S = EnvT::S, A = EnvT::A, SA = S + A, SD = EnvT::SD, B = T3W_B, Hrn = 128, ACT = LENV_ACT_RELU, T = 1;
     const lenv_td3_cfg &cfg = a.cfg;
     const int tid = threadIdx.x;
-    const int64_t chain = blockIdx.x;
+    // A chain is run by a TEAM of G workgroups (G = 1: the plain one-workgroup-per-chain launch).  Workgroups are dealt to the eight
+    // XCDs round-robin by index, so the members of a team sit at indices that agree mod 8 and share one L2: block x + 8 k is member
+    // k % G of the chain 8 (k / G) + x.
+    const int G = a.G;
+    const int xcd_ = blockIdx.x & 7, slot_ = blockIdx.x >> 3;
+    const int g = G == 1 ? 0 : slot_ % G;
+    const int64_t chain = G == 1 ? (int64_t)blockIdx.x : (int64_t)8 * (slot_ / G) + xcd_;
+    if (chain >= a.chains) return;
     // the chain's status word starts at 0 (ok); written here rather than by a memset node in front of the launch (a captured
     // generation replayed under rocprofv3 did not run the memset)
-    if (threadIdx.x == 0 && a.out.status) a.out.status[chain] = 0;
+    if (threadIdx.x == 0 && g == 0 && a.out.status) a.out.status[chain] = 0;
     const float prelu = cfg.prelu, ma = (float)cfg.max_action;
     const int RS = a.RS, rn_act = cfg.rn_act, rtype = cfg.reward_env_type;
 
@@ -414,7 +493,9 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     float *sm_b = bufB + IMG;                             // [2][128] b1 b2
     float *sm_wo = sm_b + 2 * W;                          // [128][8]
     float *sm_bo = sm_wo + 8 * W;                         // [8]
-    float *rn_w = sm_bo + 8;                              // reward net: W0 [Hrn][S] | b0 [Hrn] | Wout [Hrn] | bout
+    float *sm_b2 = sm_bo + 8;                             // [2][128], [128][8] + [8]: the second pass of a dual call
+    float *sm_wo2 = sm_b2 + 2 * W;
+    float *rn_w = sm_wo2 + 8 * W + 8;                     // reward net: W0 [Hrn][S] | b0 [Hrn] | Wout [Hrn] | bout
     float *rn_h = rn_w + ((a.P_rn + 3) & ~3);             // [Hrn]
     float *dq1 = rn_h + Hrn;                              // [B]
     float *q1 = dq1 + B;                                  // [B] ... six vectors; from q1 on they double as dz [B][A] in the policy step
@@ -439,6 +520,8 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     float *params = arena + a.a_par, *targets = params + 3 * PN, *adam_m = targets + 3 * PN, *adam_v = adam_m + 3 * PN, *grad = adam_v + 3 * PN;
     float *rb = arena + a.a_replay, *xc = arena + a.a_xc, *xn = arena + a.a_xn, *xa = arena + a.a_xa, *thb = arena + a.a_th, *dumps = arena + a.a_dump;
     double *meter = reinterpret_cast<double *>(arena + a.a_meter);
+    float *gdq = arena + a.a_gx, *gdz = gdq + 2 * B;       // team exchange: dq1 | dq2 [B] each, dz [B][A]
+    unsigned *team_bar = reinterpret_cast<unsigned *>(arena + a.a_bar);
 
     // ---- stage the perturbed reward network (GTN_worker.py:165-175) and the fresh agent (TD3.py:31-39) ----
     {
@@ -446,21 +529,51 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P_rn : nullptr;
         for (int i = tid; i < a.P_rn; i += NT) rn_w[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
     }
-    for (int p = tid; p < 3 * PN; p += NT) { params[p] = 0.0f; targets[p] = 0.0f; adam_m[p] = 0.0f; adam_v[p] = 0.0f; grad[p] = 0.0f; }
-    __syncthreads();
-    for (int p = tid; p < a.P; p += NT) {
-        const float w = a.agent_init[chain * a.P + p];
-        int q;
-        if (p < a.Pa) q = t3w_sd_to_arena(p, S, A);
-        else { const int n = (p - a.Pa) / a.Pc; q = (1 + n) * PN + t3w_sd_to_arena(p - a.Pa - n * a.Pc, SA, 1); }
-        params[q] = w; targets[q] = w;
+    if (g == 0) {                                          // the arena is shared by the team: its first member fills it
+        for (int p = tid; p < 3 * PN; p += NT) { params[p] = 0.0f; targets[p] = 0.0f; adam_m[p] = 0.0f; adam_v[p] = 0.0f; grad[p] = 0.0f; }
+        __syncthreads();
+        for (int p = tid; p < a.P; p += NT) {
+            const float w = a.agent_init[chain * a.P + p];
+            int q;
+            if (p < a.Pa) q = t3w_sd_to_arena(p, S, A);
+            else { const int n = (p - a.Pa) / a.Pc; q = (1 + n) * PN + t3w_sd_to_arena(p - a.Pa - n * a.Pc, SA, 1); }
+            params[q] = w; targets[q] = w;
+        }
     }
     if (tid < 64) misc[tid] = 0.0f;
-    if (tid == 0) { T3wCtx cx{ bufA, bufB, sm_b, sm_wo, sm_bo, q1, dzl, params, targets, grad, dumps, prelu, ma }; *ctx = cx; }
+    if (tid == 0) { T3wCtx cx{ bufA, bufB, sm_b, sm_wo, sm_bo, q1, dzl, sm_b2, sm_wo2, params, targets, grad, dumps, prelu, ma, g, G }; *ctx = cx; }
     __syncthreads();
 
     const uint64_t key = a.rng_keys[chain];
     int status = 0;
+    // ---- team barrier (G > 1): every member has finished its share of a phase and its arena writes are visible to the others.
+    // One monotonically increasing counter per chain (zeroed by t3w_team_reset_kernel in front of the launch); thread 0 releases,
+    // arrives, waits for the epoch's count and acquires (agent scope: the members may sit on different XCDs).  A member that waits
+    // longer than a few seconds gives up for good (status -10) instead of hanging the device: the launch is only valid when all G x
+    // chains workgroups are resident at once, which the host checks against the CU count.
+    unsigned team_epoch = 0;
+    bool team_dead = false;
+    auto team_barrier = [&]() {
+        if (G == 1) return;
+        __syncthreads();
+        ++team_epoch;
+        if (tid == 0 && !team_dead) {
+            __threadfence();
+            atomicAdd(team_bar, 1u);
+            const unsigned target = team_epoch * (unsigned)G;
+            long spins = 0;
+            while (__hip_atomic_load(team_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > 8000000L) { ictrl[5] = 1; break; }
+            }
+            __threadfence();
+        }
+        __syncthreads();
+        if (ictrl[5]) { team_dead = true; status = -10; }
+    };
+    // sample block of row b -> does it belong to this member (blocks are dealt like the waves that own them)
+    auto my_row = [&](int b) { return G == 1 || ((b >> 5) * G) / T3W_NB == g; };
+    team_barrier();                                        // the arena is initialised
     TPT_DECL;
     int64_t n_rand = 0, n_actn = 0, n_testn = 0, n_test_ep = 0, learn_it = 0;
     int train_steps = 0, test_steps = 0, episodes_run = 0;
@@ -521,7 +634,10 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         // the Polyak update of the same parameters rides in the pass (TD3.py:104-116 runs it after both optimizer steps; policy_delay
         // is 1 here and nothing between the critic step and the soft update reads a target net: element for element the same
         // tau * w + (1 - tau) * t on the same operands)
-        wg_adam(params, adam_m, adam_v, grad, p0, n, ac, targets, (float)cfg.tau, (float)(1.0 - cfg.tau));
+        // a team cuts the range into G pieces of whole float4s
+        const int piece = G == 1 ? n : (((n + G - 1) / G + 3) & ~3);
+        const int lo = p0 + piece * g, hi = lo + piece < p0 + n ? lo + piece : p0 + n;
+        if (hi > lo) wg_adam(params, adam_m, adam_v, grad, lo, hi - lo, ac, targets, (float)cfg.tau, (float)(1.0 - cfg.tau));
         __syncthreads();
     };
 
@@ -670,6 +786,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 t3w_forward<ACT, S, A>(ctx, targets, xn, SA, 1, nullptr, xn, SA, S, nullptr, -1, -1, -1);
                 for (int e = tid; e < B * A; e += NT) {
                     const int b = e / A, k = e - b * A;
+                    if (!my_row(b)) continue;
                     const int64_t n = (learn_it * B + b) * A + k;
                     const float zn = (float)det_normal(key, STREAM_TD3_POLICY_NOISE, (uint64_t)n);
                     float nz = zn * (float)cfg.policy_std;
@@ -680,26 +797,50 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 }
                 __syncthreads();
                 TPT_MARK(2);
-                t3w_forward<ACT, SA, 1>(ctx, targets + PN, xn, SA, 0, tq1, nullptr, 0, 0, nullptr, -1, -1, -1);
-                t3w_forward<ACT, SA, 1>(ctx, targets + 2 * PN, xn, SA, 0, tq2, nullptr, 0, 0, nullptr, -1, -1, -1);
-                t3w_forward<ACT, SA, 1>(ctx, params + PN, xc, SA, 0, q1, nullptr, 0, 0, nullptr, TD_C1_H1, TD_C1_H2, TR_C1_H2);
-                t3w_forward<ACT, SA, 1>(ctx, params + 2 * PN, xc, SA, 0, q2, nullptr, 0, 0, nullptr, TD_C2_H1, TD_C2_H2, TR_C2_H2);
+                if (G > 1) {                               // twin critics side by side (a member owns at most three blocks)
+                    t3w_forward<ACT, SA, 1>(ctx, targets + PN, xn, SA, 0, tq1, nullptr, 0, 0, nullptr, -1, -1, -1, targets + 2 * PN, xn, tq2, -1, -1);
+                    t3w_forward<ACT, SA, 1>(ctx, params + PN, xc, SA, 0, q1, nullptr, 0, 0, nullptr, TD_C1_H1, TD_C1_H2, TR_C1_H2, params + 2 * PN, xc, q2,
+                                            TD_C2_H1, TR_C2_H2);
+                } else {
+                    t3w_forward<ACT, SA, 1>(ctx, targets + PN, xn, SA, 0, tq1, nullptr, 0, 0, nullptr, -1, -1, -1);
+                    t3w_forward<ACT, SA, 1>(ctx, targets + 2 * PN, xn, SA, 0, tq2, nullptr, 0, 0, nullptr, -1, -1, -1);
+                    t3w_forward<ACT, SA, 1>(ctx, params + PN, xc, SA, 0, q1, nullptr, 0, 0, nullptr, TD_C1_H1, TD_C1_H2, TR_C1_H2);
+                    t3w_forward<ACT, SA, 1>(ctx, params + 2 * PN, xc, SA, 0, q2, nullptr, 0, 0, nullptr, TD_C2_H1, TD_C2_H2, TR_C2_H2);
+                }
                 TPT_MARK(3);
                 {
                     const float norm = (float)(2.0 / (double)B);
                     for (int b = tid; b < B; b += NT) {
+                        if (!my_row(b)) continue;
                         const float tq = tq1[b] < tq2[b] ? tq1[b] : tq2[b];
                         const float y = rr[b] + ((1.0f - dd[b]) * g32) * tq;
                         dq1[b] = norm * (q1[b] - y);
                         dq2[b] = norm * (q2[b] - y);
+                        if (G > 1) { gdq[b] = dq1[b]; gdq[B + b] = dq2[b]; }      // the weight gradients need every row's value
                     }
                 }
                 __syncthreads();
                 TPT_MARK(4);
-                t3w_backward<ACT, SA, 1>(ctx, params + PN, grad + PN, xc, SA, dq1, TD_C1_H1, TR_C1_H2, TR_C1_H2, 0, 0, nullptr, nullptr);
-                t3w_backward<ACT, SA, 1>(ctx, params + 2 * PN, grad + 2 * PN, xc, SA, dq2, TD_C2_H1, TR_C2_H2, TR_C2_H2, 0, 0, nullptr, nullptr);
+                // per-sample halves of the two critic backwards (this member's blocks), then -- once the whole team is there -- the
+                // parameter gradients, cut by wave over the team
+                if (G > 1)
+                    t3w_backward_chain<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1, 0, 0, nullptr, nullptr,
+                                                   params + 2 * PN, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B);
+                else {
+                    t3w_backward_chain<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1, 0, 0, nullptr, nullptr);
+                    t3w_backward_chain<ACT, SA, 1>(ctx, params + 2 * PN, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
+                }
+                team_barrier();
+                if (G > 1) {
+                    for (int b = tid; b < B; b += NT) { dq1[b] = gdq[b]; dq2[b] = gdq[B + b]; }
+                    __syncthreads();
+                }
+                t3w_backward_wgrad<ACT, SA, 1>(ctx, grad + PN, xc, SA, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1, 0, 2 * NW);
+                t3w_backward_wgrad<ACT, SA, 1>(ctx, grad + 2 * PN, xc, SA, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B, NW, 2 * NW);
                 TPT_MARK(5);
+                team_barrier();
                 adam(PN, 2 * PN, 0);                       // critic_optimizer
+                team_barrier();
                 TPT_MARK(6);
                 ++learn_it;
                 {
@@ -711,17 +852,28 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                     const float dqa = -(1.0f / (float)B);
                     for (int b = tid; b < B; b += NT) dq1[b] = dqa;
                     __syncthreads();
-                    t3w_backward<ACT, SA, 1>(ctx, params + PN, nullptr, xa, SA, dq1, TD_C1_H1, TR_C1_H2, -1, S, A, thb, dzl);
-                    t3w_backward<ACT, S, A>(ctx, params, grad, xc, SA, dzl, TD_A_H1, TR_A_H2, TR_A_H2, 0, 0, nullptr, nullptr);
+                    t3w_backward_chain<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, -1, S, A, thb, dzl);
+                    if (G > 1) {
+                        for (int e = tid; e < B * A; e += NT) if (my_row(e / A)) gdz[e] = dzl[e];
+                    }
+                    t3w_backward_chain<ACT, S, A>(ctx, params, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
+                    team_barrier();
+                    if (G > 1) {
+                        for (int e = tid; e < B * A; e += NT) dzl[e] = gdz[e];
+                        __syncthreads();
+                    }
+                    t3w_backward_wgrad<ACT, S, A>(ctx, grad, xc, SA, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, NW);
                     TPT_MARK(7);
+                    team_barrier();
                     adam(0, PN, 2);
+                    team_barrier();
                     TPT_MARK(8);
                 }
             }
             if (done_now > 0.5f) break;
         }
         ++episodes_run;
-        if (tid == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
+        if (tid == 0 && g == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
         __syncthreads();
         TPT_MARK(10);
         test_phase();
@@ -729,7 +881,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         if (tid == 0) {
             const double tm = ret[0] / (double)T;
             meter[episode] = tm;
-            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
+            if (g == 0 && a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
             int brk = 0;
             if (learning) {
                 int lo = episode + 1 - cfg.early_out_num; if (lo < 0) lo = 0;
@@ -767,7 +919,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
 #ifdef LENV_PHASE_TIMING
     if (tid == 0 && chain == 0) for (int pi = 0; pi < 12; ++pi) g_t3w_phase_cycles[pi] = pt_acc[pi];
 #endif
-    if (tid == 0) {
+    if (tid == 0 && g == 0) {
         double sm = 0.0;
         for (int i = 0; i < T; ++i) sm += ret[i];
         a.out.score[chain] = sm / (double)T;
@@ -791,7 +943,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
             if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = pad_l;
         }
     }
-    if (a.out.final_params) {
+    if (a.out.final_params && g == 0) {
         for (int p = tid; p < a.P; p += NT) {
             int q;
             if (p < a.Pa) q = t3w_sd_to_arena(p, S, A);
@@ -825,7 +977,36 @@ static void t3w_offsets(const lenv_td3_cfg *cfg, int64_t rb_cap, int RS, T3wArgs
     a.a_par = take(5 * 3 * (int64_t)t3p::PN); a.a_xc = take((int64_t)B * SA); a.a_xn = take((int64_t)B * SA); a.a_xa = take((int64_t)B * SA);
     a.a_th = take((int64_t)B * 6); a.a_dump = take((int64_t)T3W_NDUMP * T3W_NB * wc::BLK); a.a_replay = take(rb_cap * RS);
     a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
+    a.a_gx = take(2 * (int64_t)B + (int64_t)B * 6);             // team exchange: dq1 | dq2 | dz
+    a.a_bar = take(16);                                          // team barrier counter (one cache line of its own would be 32 floats; the slot is padded below)
     *total = (off + 63) & ~(int64_t)63;
+}
+
+namespace lenv {
+// the team barrier counters start at 0: a kernel rather than a memset node (see the status word in the fused kernels)
+__global__ void t3w_team_reset_kernel(float *arena, int64_t arena_stride, int64_t a_bar, int64_t chains)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < chains) *reinterpret_cast<unsigned *>(arena + c * arena_stride + a_bar) = 0u;
+}
+}
+
+// Workgroups per chain.  A team only works when every workgroup of the launch is resident at the same time (its members wait for each
+// other): 8 * ceil(chains / 8) * G workgroups of one per CU must fit the device.  192 minibatch rows = 6 sample blocks: G = 6, 3, 2 or 1;
+// LENV_TD3_TEAM=<G> overrides the choice (1 = the plain launch), still subject to the residency check.
+static int t3w_pick_team(int64_t chains)
+{
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return n;
+    }();
+    const char *e = getenv("LENV_TD3_TEAM");
+    const int want = e ? atoi(e) : 6;
+    const int64_t padded = 8 * ((chains + 7) / 8);
+    for (int G : { 6, 3, 2 })
+        if (G <= want && padded * G <= cus) return G;
+    return 1;
 }
 
 int64_t lenv_wc_td3_arena_floats(const lenv_td3_cfg *cfg, int64_t rb_cap, int RS)
@@ -848,13 +1029,20 @@ int lenv_wc_td3_launch(const lenv_td3_cfg *cfg, const float *theta, const float 
     t3w_offsets(cfg, rb_cap, RS, a, &total);
     if (total > arena_stride) return LENV_ERR_WORKSPACE;
     const int B = T3W_B, T = 1;
-    const size_t lds_floats = 2 * (size_t)wc::IMG + 2 * wc::W + 8 * wc::W + 8 + ((P_rn + 3) & ~3) + 128 + 8 * (size_t)B + 2 * wc::W + 64 + 2 + 2 * (20 + 17 * T + T) + 2 * T + 1 +
+    const size_t lds_floats = 2 * (size_t)wc::IMG + 2 * (2 * wc::W + 8 * wc::W + 8) + ((P_rn + 3) & ~3) + 128 + 8 * (size_t)B + 2 * wc::W + 64 + 2 + 2 * (20 + 17 * T + T) + 2 * T + 1 +
                               20 + 8 + 56 + 4 + (sizeof(T3wCtx) + 3) / 4;
     const size_t lds_bytes = lds_floats * sizeof(float);
     if (lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     void (*kern)(const T3wArgs) = td3_wavechain_kernel<1>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return LENV_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3((unsigned)chains), dim3(wc::NT), lds_bytes, stream, a);
+    a.chains = chains;
+    a.G = t3w_pick_team(chains);
+    unsigned grid = (unsigned)chains;
+    if (a.G > 1) {
+        grid = (unsigned)(8 * ((chains + 7) / 8) * a.G);
+        hipLaunchKernelGGL(t3w_team_reset_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, stream, arena, arena_stride, a.a_bar, chains);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(wc::NT), lds_bytes, stream, a);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }
 

@@ -2095,3 +2095,39 @@ def test_wavechain_td3_kernel_equals_gemm_queue_kernel(eng, orc):
     for x, y in zip(a, b):
         assert np.array_equal(x, y, equal_nan=True)
     assert not np.array_equal(a[4], init)
+
+@pytest.mark.parametrize("chains", [5, 11])
+def test_wavechain_td3_team_sizes_agree(eng, orc, chains, monkeypatch):
+    """A chain run by a team of G = 2, 3, 6 workgroups (sample blocks and gradient tiles dealt over the team, six agent-scope
+    barriers per learn step) gives the same bits as the one-workgroup launch (G = 1) and as the GEMM-queue kernel: scores, counters,
+    test means and all 59 016 parameters."""
+    from learning_environments_amd import configs
+    from learning_environments_amd.agents.nes_common import chain_keys
+    cfgd = configs.fixed_work(configs.halfcheetah_reward_env_td3(2), 3)
+    cfgd["agents"]["td3"]["init_episodes"] = 1
+    cfgd["envs"]["HalfCheetah-v3"]["max_steps"] = 30
+    _, cfg = _td3_cfgs(orc, cfgd, 0)
+    rng = np.random.RandomState(70 + chains)
+    P_rn = 17 * 128 + 128 + 128 + 1
+    theta = (rng.randn(P_rn) * 0.2).astype(np.float32)
+    eps = (rng.randn(4, P_rn) * 0.1).astype(np.float32)
+    worker = (np.arange(chains) // 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), 4)[:chains].copy()
+    keys = chain_keys(79, 2, worker, np.arange(chains) % 3)
+    init = rng.uniform(-0.08, 0.08, (chains, 59016)).astype(np.float32)
+
+    def run(trace_cap):
+        il = eng.Td3InnerLoop(cfg, chains, trace_cap=trace_cap, want_final_params=True, want_episode_stats=True)
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return [t.cpu().numpy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_params)]
+
+    ref = run(2)                                            # GEMM-queue kernel
+    assert ref[1][:, 2].min() == 60
+    for G in (1, 2, 3, 6):
+        monkeypatch.setenv("LENV_TD3_TEAM", str(G))
+        out = run(0)
+        for x, y in zip(out, ref):
+            assert np.array_equal(x, y, equal_nan=True), G
+

@@ -23,7 +23,7 @@ os.chdir("/tmp/lenv_bench")
 from learning_environments_amd.agents.GTN import GTN_Master
 from learning_environments_amd import configs
 
-c = configs.fixed_work(configs.halfcheetah_reward_env_td3(32), 3)
+c = configs.fixed_work(configs.halfcheetah_reward_env_td3(int(os.environ.get("LENV_TIMING_POP", "32"))), 3)
 c["agents"]["td3"]["init_episodes"] = 1
 c["envs"]["HalfCheetah-v3"]["max_steps"] = 100
 m = GTN_Master(c, bohb_id=0, seed=7, graph=False)
