@@ -110,7 +110,7 @@ __device__ __forceinline__ void block_to_rowmajor(float *rm_, int blk, const Lan
 // ---- one network pass over the 192 minibatch rows X[i][ldx] (waves 0-5 own the sample blocks) ----------------------------------
 // mode 0 (Critic_Q): q_out[i] = net(x)      mode 1 (Actor_TD3): Y[i][ocol + c] = tanh(net(x)) * max_action, th_out[i][c] = tanh
 // A team member owns at most three of the six blocks, so a SECOND, independent critic pass (par2 != null: its own parameters, inputs,
-// outputs and dumps; image in bufB, small vectors in the second LDS set) runs next to the first one on the waves four places on.
+// outputs and dumps; image in bufB, small vectors in the second LDS set) runs next to the first one on the waves behind the member's blocks.
 template <int ACT, int IN, int OUT>
 __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, const float *X_, int ldx_, int mode_, float *q_out_,
                                          float *Y_, int ldy_, int ocol_, float *th_out_, int d_h1_, int d_h2_, int r_h2_,
@@ -118,8 +118,9 @@ __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, 
 {
     T3W_CTX_PROLOGUE;
     const bool dual = uni_ptr(par2_) != nullptr;
-    // this wave's job: (pass 0, block = wave) or, in a dual call, (pass 1, block = wave + 4 mod 8)
-    const int wave2 = (wave + 4) & 7;
+    // this wave's job: (pass 0, block = wave) or, in a dual call, (pass 1, block = wave - 6 / G mod 8: the member's blocks are
+    // consecutive, so pass 1 sits on the waves right behind them -- other SIMDs than the blocks' own waves)
+    const int wave2 = (wave - T3W_NB / TG) & 7;
     const bool act0 = wave < T3W_NB && mine(wave, T3W_NB);
     const bool act1 = dual && !act0 && wave2 < T3W_NB && mine(wave2, T3W_NB);
     const bool active = act0 || act1;
@@ -234,9 +235,9 @@ __device__ __noinline__ void t3w_backward_chain(const T3wCtx *ctx_, const float 
                                                 int r_dz2_2_ = -1, int r_dh1_2_ = -1)
 {
     T3W_CTX_PROLOGUE;
-    // a second, independent network's chain (par2 != null) runs on the waves four places on, as in t3w_forward
+    // a second, independent network's chain (par2 != null) runs on the waves behind the member's own blocks, as in t3w_forward
     const bool dual = uni_ptr(par2_) != nullptr;
-    const int wave2 = (wave + 4) & 7;
+    const int wave2 = (wave - T3W_NB / TG) & 7;
     const bool act0 = wave < T3W_NB && mine(wave, T3W_NB);
     const bool act1 = dual && !act0 && wave2 < T3W_NB && mine(wave2, T3W_NB);
     const bool own = act0 || act1;
@@ -325,6 +326,243 @@ __device__ __noinline__ void t3w_backward_chain(const T3wCtx *ctx_, const float 
     }
     __syncthreads();
     TSUB_MARK(26);
+}
+
+// ---- split passes: a team member that owns only one or two sample blocks (G = 6 / G = 3) runs each block on FOUR waves -- wave
+// 4 q + jt computes output tile jt (32 units) of its quad's block for every layer and the quad exchanges the operand registers through
+// LDS (bufB: two quads x two stages x 16 KB; the image of the pass is in bufA), so a layer costs one tile's 64 MFMAs per SIMD instead
+// of four.  Same products, same k-ascending chains: the bits do not change.  Single passes only (a dual call needs bufB).
+__device__ __forceinline__ void tile16_to_operand(float (&r)[16])
+{
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        auto s_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(r[2 * p]), __float_as_uint(r[2 * p + 1]), false, false);
+        r[2 * p] = __uint_as_float(s_[0]); r[2 * p + 1] = __uint_as_float(s_[1]);
+    }
+}
+__device__ __forceinline__ void xch_put(float *xch_, int jt, int lane, const float (&r)[16])
+{
+    lfloat *x = (lfloat *)xch_ + (16 * jt) * 64 + lane;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) x[v * 64] = r[v];
+}
+__device__ __forceinline__ void xch_get(const float *xch_, int lane, float (&r)[64])
+{
+    const lfloat *x = (const lfloat *)xch_ + lane;
+#pragma unroll
+    for (int v = 0; v < 64; ++v) r[v] = x[v * 64];
+}
+// one 32-unit tile of a 128 -> 128 layer: acc += sum over 64 k-steps, A = image rows 2t+h, columns of tile jt
+__device__ __forceinline__ void chain_tile(const float *img_, int jt, const Lane &L, const float (&b)[64], f32x16 &acc)
+{
+    const lfloat *img = (const lfloat *)img_;
+    const lfloat *ab[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ab[q] = img + L.h * W + 32 * jt + L.colsw[q];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[t & 3][2 * t * W], b[breg_of(t)], acc, 0, 0, 0);
+}
+
+template <int ACT, int IN, int OUT>
+__device__ __noinline__ void t3w_forward_split(const T3wCtx *ctx_, const float *par_, const float *X_, int ldx_, int mode_, float *q_out_,
+                                               float *Y_, int ldy_, int ocol_, float *th_out_, int d_h1_, int r_h2_)
+{
+    T3W_CTX_PROLOGUE;
+    const float *par = uni_ptr(par_), *X = uni_ptr(X_);
+    float *Y = uni_ptr(Y_), *th_out = uni_ptr(th_out_);
+    lfloat *q_out = (lfloat *)uni_ptr(q_out_);
+    constexpr int in = IN, out = OUT;
+    const int ldx = uni(ldx_), mode = uni(mode_), ldy = uni(ldy_), ocol = uni(ocol_), d_h1 = uni(d_h1_), r_h2 = uni(r_h2_);
+    const int nb = T3W_NB / TG, quad = wave >> 2, jt = wave & 3;
+    const bool active = quad < nb;
+    const int blk = tg * nb + (active ? quad : 0), row = 32 * blk + L.li;
+    float *xch0 = bufB + quad * 4096, *xch1 = bufB + 8192 + quad * 4096;
+    for (int i = tid; i < 2 * W; i += NT) sm_b[i] = par[(i < W ? ob1 : ob2 - W) + i];
+    for (int i = tid; i < 8 * W + 8; i += NT) sm_wo[i] = par[oWo + i];
+    StageRegs sr;
+    float xb[in >> 1], wa[in >> 1];
+    {
+        const gfloat *w1 = (const gfloat *)par + oW1t + L.h * W + 32 * jt + L.li;
+        const gfloat *xr = (const gfloat *)X + row * ldx + L.h;
+#pragma unroll
+        for (int t = 0; t < (in >> 1); ++t) { xb[t] = xr[2 * t]; wa[t] = w1[2 * t * W]; }
+    }
+    stage_load_direct(par + oW2t, L, sr);
+    stage_store_direct(bufA, L, sr);
+    barrier_lds();
+    float r16[16], rf[64];
+    f32x16 acc;
+    if (active) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < (in >> 1); ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t], xb[t], acc, 0, 0, 0);
+        if (in & 1) {
+            const float xl = ((const gfloat *)X)[row * ldx + in - 1];
+            const gfloat *wl = (const gfloat *)par + oW1t + (in - 1) * W + 32 * jt + 4 * L.h;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 wv = *(const gf4 *)(wl + 8 * g4);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) acc[4 * g4 + cc] = fma32(xl, wv[cc], acc[4 * g4 + cc]);
+            }
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 bv = *(const lf4 *)(sm_b + 32 * jt + 8 * g4 + 4 * L.h);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) r16[4 * g4 + cc] = act_fwd(ACT, prelu, acc[4 * g4 + cc] + bv[cc]);
+        }
+        if (d_h1 >= 0) {
+            gf4 *d = (gf4 *)dump_of(d_h1, blk) + L.lane;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) d[(4 * jt + g4) * 64] = f32x4{r16[4 * g4], r16[4 * g4 + 1], r16[4 * g4 + 2], r16[4 * g4 + 3]};
+        }
+        tile16_to_operand(r16);
+        xch_put(xch0, jt, L.lane, r16);
+    }
+    barrier_lds();
+    if (active) {
+        xch_get(xch0, L.lane, rf);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+        chain_tile(bufA, jt, L, rf, acc);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 bv = *(const lf4 *)(sm_b + W + 32 * jt + 8 * g4 + 4 * L.h);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) r16[4 * g4 + cc] = act_fwd(ACT, prelu, acc[4 * g4 + cc] + bv[cc]);
+        }
+        if (r_h2 >= 0) {
+            gfloat *rm = (gfloat *)dump_of(r_h2, 0) + row * W + 32 * jt + 4 * L.h;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) *(gf4 *)(rm + 8 * g4) = f32x4{r16[4 * g4], r16[4 * g4 + 1], r16[4 * g4 + 2], r16[4 * g4 + 3]};
+        }
+        tile16_to_operand(r16);
+        xch_put(xch1, jt, L.lane, r16);
+    }
+    barrier_lds();
+    if (active && jt == 0) {
+        xch_get(xch1, L.lane, rf);
+        f32x16 hacc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) hacc[v] = 0.0f;
+        const lfloat *wo = sm_wo + L.h * 8 + (L.li < out ? L.li : out - 1);
+#pragma unroll
+        for (int t = 0; t < 64; ++t) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wo[2 * t * 8], rf[breg_of(t)], hacc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int cidx = 4 * L.h + v;
+            if (cidx < out) {
+                const float z = hacc[v] + sm_bo[cidx];
+                if (mode == 0) q_out[row] = z;
+                else {
+                    const float th = det_tanhf(lenv_tanh_table, z);
+                    if (th_out) th_out[row * out + cidx] = th;
+                    Y[row * ldy + ocol + cidx] = th * ma;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int ACT, int IN, int OUT>
+__device__ __noinline__ void t3w_backward_chain_split(const T3wCtx *ctx_, const float *par_, const float *dOut_, int d_h1_, int d_h2_, int r_dz2_,
+                                                      int r_dh1_, int dx_col_, int dx_n_, const float *th_, float *dz_out_)
+{
+    T3W_CTX_PROLOGUE;
+    const float *par = uni_ptr(par_), *th = uni_ptr(th_);
+    const lfloat *dOut = (const lfloat *)uni_ptr(dOut_);
+    lfloat *dz_out = (lfloat *)uni_ptr(dz_out_);
+    constexpr int out = OUT;
+    const int d_h1 = uni(d_h1_), d_h2 = uni(d_h2_), r_dz2 = uni(r_dz2_), r_dh1 = uni(r_dh1_), dx_col = uni(dx_col_), dx_n = uni(dx_n_);
+    const int nb = T3W_NB / TG, quad = wave >> 2, jt = wave & 3;
+    const bool active = quad < nb;
+    const int blk = tg * nb + (active ? quad : 0), row = 32 * blk + L.li;
+    float *xch0 = bufB + quad * 4096, *xch1 = bufB + 8192 + quad * 4096;
+    for (int i = tid; i < 8 * W + 8; i += NT) sm_wo[i] = par[oWo + i];
+    StageRegs sr;
+    stage_load_transposed(par + oW2t, L, sr);
+    __syncthreads();                                       // sm_wo staged
+    float r16[16], rf[64];
+    f32x16 acc;
+    if (active) {
+        // dz2 = act'(h2) * (sum_c dOut[i][c] Wo[c][unit], c ascending from 0), the 32 units of tile jt
+        const gfloat *hd = (const gfloat *)dump_of(d_h2, 0) + row * W + 32 * jt + 4 * L.h;
+        float dO[out];
+#pragma unroll
+        for (int cc = 0; cc < out; ++cc) dO[cc] = dOut[row * out + cc];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 hv = *(const gf4 *)(hd + 8 * g4);
+            const lfloat *wp = sm_wo + (32 * jt + 8 * g4 + 4 * L.h) * 8;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                float wv[8];
+                const f32x4 w0 = *(const lf4 *)(wp + 8 * cc);
+                wv[0] = w0[0]; wv[1] = w0[1]; wv[2] = w0[2]; wv[3] = w0[3];
+                if (out > 4) { const f32x4 w1 = *(const lf4 *)(wp + 8 * cc + 4); wv[4] = w1[0]; wv[5] = w1[1]; wv[6] = w1[2]; wv[7] = w1[3]; }
+                float up = 0.0f;
+#pragma unroll
+                for (int o = 0; o < out; ++o) up = fma32(dO[o], wv[o], up);
+                r16[4 * g4 + cc] = act_bwd(ACT, prelu, hv[cc], up);
+            }
+        }
+        {
+            gfloat *rm = (gfloat *)dump_of(r_dz2, 0) + row * W + 32 * jt + 4 * L.h;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) *(gf4 *)(rm + 8 * g4) = f32x4{r16[4 * g4], r16[4 * g4 + 1], r16[4 * g4 + 2], r16[4 * g4 + 3]};
+        }
+        tile16_to_operand(r16);
+        xch_put(xch0, jt, L.lane, r16);
+    }
+    stage_store_transposed(bufA, L, sr);
+    barrier_lds();
+    L.refresh();
+    if (active) {
+        const gf4 *src = (const gf4 *)dump_of(d_h1, blk) + L.lane;
+        f32x4 hv[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) hv[g4] = src[(4 * jt + g4) * 64];
+        xch_get(xch0, L.lane, rf);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+        chain_tile(bufA, jt, L, rf, acc);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) r16[4 * g4 + cc] = act_bwd(ACT, prelu, hv[g4][cc], acc[4 * g4 + cc]);
+        if (r_dh1 >= 0) {
+            gfloat *rm = (gfloat *)dump_of(r_dh1, 0) + row * W + 32 * jt + 4 * L.h;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) *(gf4 *)(rm + 8 * g4) = f32x4{r16[4 * g4], r16[4 * g4 + 1], r16[4 * g4 + 2], r16[4 * g4 + 3]};
+        }
+        if (dx_n > 0) {
+            tile16_to_operand(r16);
+            xch_put(xch1, jt, L.lane, r16);
+        }
+    }
+    barrier_lds();
+    if (active && jt == 0 && dx_n > 0) {
+        // dX[i][dx_col + c] = sum_u dh1[i][u] W1[u][dx_col + c] (u ascending), c < dx_n, then dz = (dX * max_action) * (1 - th^2)
+        xch_get(xch1, L.lane, rf);
+        f32x16 hacc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) hacc[v] = 0.0f;
+        const gfloat *w1 = (const gfloat *)par + oW1t + (dx_col + (L.li < dx_n ? L.li : dx_n - 1)) * W + L.h;
+#pragma unroll 16
+        for (int t = 0; t < 64; ++t) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2 * t], rf[breg_of(t)], hacc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int cidx = 4 * L.h + v;
+            if (cidx < dx_n) {
+                const float t_ = th[row * dx_n + cidx];
+                dz_out[row * dx_n + cidx] = (hacc[v] * ma) * fma32(-t_, t_, 1.0f);
+            }
+        }
+    }
+    __syncthreads();
 }
 
 // ---- backward of one network, second half: the parameter gradients from the row-major copies of ALL 192 samples (dOut in LDS, h2 /
@@ -558,15 +796,17 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         __syncthreads();
         ++team_epoch;
         if (tid == 0 && !team_dead) {
-            __threadfence();
-            atomicAdd(team_bar, 1u);
+            // release (every wave's stores have been acknowledged at the __syncthreads above; this makes them visible at agent scope),
+            // arrive, wait for the epoch's count, acquire
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(team_bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned target = team_epoch * (unsigned)G;
             long spins = 0;
             while (__hip_atomic_load(team_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
                 if (++spins > 8000000L) { ictrl[5] = 1; break; }
             }
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
         if (ictrl[5]) { team_dead = true; status = -10; }
@@ -783,7 +1023,8 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 __syncthreads();
                 TPT_MARK(1);
                 // next_actions = (actor_target(s') + clamp(randn * policy_std)).clamp(-max, max)
-                t3w_forward<ACT, S, A>(ctx, targets, xn, SA, 1, nullptr, xn, SA, S, nullptr, -1, -1, -1);
+                if (G >= 3) t3w_forward_split<ACT, S, A>(ctx, targets, xn, SA, 1, nullptr, xn, SA, S, nullptr, -1, -1);
+                else t3w_forward<ACT, S, A>(ctx, targets, xn, SA, 1, nullptr, xn, SA, S, nullptr, -1, -1, -1);
                 for (int e = tid; e < B * A; e += NT) {
                     const int b = e / A, k = e - b * A;
                     if (!my_row(b)) continue;
@@ -847,16 +1088,23 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                     // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1 (policy_delay 1)
                     for (int e = tid; e < B * S; e += NT) { const int b = e / S, i = e - b * S; xa[b * SA + i] = xc[b * SA + i]; }
                     __syncthreads();
-                    t3w_forward<ACT, S, A>(ctx, params, xc, SA, 1, nullptr, xa, SA, S, thb, TD_A_H1, TD_A_H2, TR_A_H2);
-                    t3w_forward<ACT, SA, 1>(ctx, params + PN, xa, SA, 0, dq2, nullptr, 0, 0, nullptr, TD_C1_H1, -1, TR_C1_H2);
+                    if (G >= 3) {
+                        t3w_forward_split<ACT, S, A>(ctx, params, xc, SA, 1, nullptr, xa, SA, S, thb, TD_A_H1, TR_A_H2);
+                        t3w_forward_split<ACT, SA, 1>(ctx, params + PN, xa, SA, 0, dq2, nullptr, 0, 0, nullptr, TD_C1_H1, TR_C1_H2);
+                    } else {
+                        t3w_forward<ACT, S, A>(ctx, params, xc, SA, 1, nullptr, xa, SA, S, thb, TD_A_H1, TD_A_H2, TR_A_H2);
+                        t3w_forward<ACT, SA, 1>(ctx, params + PN, xa, SA, 0, dq2, nullptr, 0, 0, nullptr, TD_C1_H1, -1, TR_C1_H2);
+                    }
                     const float dqa = -(1.0f / (float)B);
                     for (int b = tid; b < B; b += NT) dq1[b] = dqa;
                     __syncthreads();
-                    t3w_backward_chain<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, -1, S, A, thb, dzl);
+                    if (G >= 3) t3w_backward_chain_split<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, -1, S, A, thb, dzl);
+                    else t3w_backward_chain<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, -1, S, A, thb, dzl);
                     if (G > 1) {
                         for (int e = tid; e < B * A; e += NT) if (my_row(e / A)) gdz[e] = dzl[e];
                     }
-                    t3w_backward_chain<ACT, S, A>(ctx, params, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
+                    if (G >= 3) t3w_backward_chain_split<ACT, S, A>(ctx, params, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
+                    else t3w_backward_chain<ACT, S, A>(ctx, params, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
                     team_barrier();
                     if (G > 1) {
                         for (int e = tid; e < B * A; e += NT) dzl[e] = gdz[e];
