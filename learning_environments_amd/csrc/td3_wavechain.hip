@@ -1009,9 +1009,11 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
             TPT_MARK(0);
             if (learning) {
                 // ================= TD3.learn (TD3.py:63-116) =================
+                // ReplayBuffer.sample: one (sample, row element) pair per thread; a team member gathers the rows of its own blocks
+                const int gb0 = G == 1 ? 0 : 32 * (T3W_NB / G) * g, gbn = G == 1 ? B : 32 * (T3W_NB / G);
 #pragma unroll 4
-                for (int e = tid; e < B * (2 * S + A + 2); e += NT) {      // ReplayBuffer.sample: one (sample, row element) pair per thread
-                    const int b = e / (2 * S + A + 2), i = e - b * (2 * S + A + 2);
+                for (int e = tid; e < gbn * (2 * S + A + 2); e += NT) {
+                    const int b = gb0 + e / (2 * S + A + 2), i = e - (b - gb0) * (2 * S + A + 2);
                     const int64_t n = learn_it * B + b;
                     const int idx = (int)rng_replay_below(key, (uint64_t)n, (uint32_t)size_after);
                     const float v = rb[(int64_t)idx * RS + i];
@@ -1038,7 +1040,12 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 }
                 __syncthreads();
                 TPT_MARK(2);
-                if (G > 1) {                               // twin critics side by side (a member owns at most three blocks)
+                if (G >= 3) {                              // one or two blocks per member: every block on four waves, pass after pass
+                    t3w_forward_split<ACT, SA, 1>(ctx, targets + PN, xn, SA, 0, tq1, nullptr, 0, 0, nullptr, -1, -1);
+                    t3w_forward_split<ACT, SA, 1>(ctx, targets + 2 * PN, xn, SA, 0, tq2, nullptr, 0, 0, nullptr, -1, -1);
+                    t3w_forward_split<ACT, SA, 1>(ctx, params + PN, xc, SA, 0, q1, nullptr, 0, 0, nullptr, TD_C1_H1, TR_C1_H2);
+                    t3w_forward_split<ACT, SA, 1>(ctx, params + 2 * PN, xc, SA, 0, q2, nullptr, 0, 0, nullptr, TD_C2_H1, TR_C2_H2);
+                } else if (G == 2) {                       // three blocks per member: twin critics side by side on six waves
                     t3w_forward<ACT, SA, 1>(ctx, targets + PN, xn, SA, 0, tq1, nullptr, 0, 0, nullptr, -1, -1, -1, targets + 2 * PN, xn, tq2, -1, -1);
                     t3w_forward<ACT, SA, 1>(ctx, params + PN, xc, SA, 0, q1, nullptr, 0, 0, nullptr, TD_C1_H1, TD_C1_H2, TR_C1_H2, params + 2 * PN, xc, q2,
                                             TD_C2_H1, TR_C2_H2);
@@ -1064,7 +1071,10 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 TPT_MARK(4);
                 // per-sample halves of the two critic backwards (this member's blocks), then -- once the whole team is there -- the
                 // parameter gradients, cut by wave over the team
-                if (G > 1)
+                if (G >= 3) {
+                    t3w_backward_chain_split<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1, 0, 0, nullptr, nullptr);
+                    t3w_backward_chain_split<ACT, SA, 1>(ctx, params + 2 * PN, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
+                } else if (G == 2)
                     t3w_backward_chain<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1, 0, 0, nullptr, nullptr,
                                                    params + 2 * PN, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B);
                 else {
@@ -1086,7 +1096,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 ++learn_it;
                 {
                     // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1 (policy_delay 1)
-                    for (int e = tid; e < B * S; e += NT) { const int b = e / S, i = e - b * S; xa[b * SA + i] = xc[b * SA + i]; }
+                    for (int e = tid; e < gbn * S; e += NT) { const int b = gb0 + e / S, i = e - (b - gb0) * S; xa[b * SA + i] = xc[b * SA + i]; }
                     __syncthreads();
                     if (G >= 3) {
                         t3w_forward_split<ACT, S, A>(ctx, params, xc, SA, 1, nullptr, xa, SA, S, thb, TD_A_H1, TR_A_H2);
