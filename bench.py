@@ -371,6 +371,12 @@ def secondary_configs(only=None):
                "graph": bool(getattr(m, "use_graph", False))}
         if flops:
             busy = min(int(st.shape[0]), 256)
+            if kernel == "td3_wavechain_kernel":           # a chain is run by a team of workgroups when the whole launch stays resident
+                import ctypes
+                from learning_environments_amd import _lib
+                team = int(_lib.lib().lenv_td3_rn_team_size(ctypes.byref(m.cfg), int(st.shape[0])))
+                rec["workgroups_per_chain"] = team
+                busy = min(busy * max(team, 1), 256)
             tf = flops / (kernel_ms * 1e-3) / 1e12
             rec.update({"mfma_f32_TFLOPs": tf, "mfma_f32_frac": tf / MFMA_F32_PEAK_TFLOPS, "busy_cus": busy,
                         "mfma_f32_frac_of_busy_cus": tf / (MFMA_F32_PEAK_TFLOPS * busy / 256.0)})

@@ -357,6 +357,10 @@ int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg /*HOST*/, const lenv_chai
                                const int32_t *worker, const float *sign, const float *agent_init, const uint64_t *rng_keys,
                                const lenv_td3_tapes *tapes /*HOST*/, int64_t chains, void *workspace, size_t workspace_bytes,
                                const lenv_td3_out *out /*HOST*/, void *stream);
+/* Workgroups per chain a production launch (counter RNG, no trace, no hp, no ICM) of this cfg will use: the wave-chain kernel of the
+ * published HalfCheetah RewardEnv + TD3 shape runs a chain on a TEAM of 6, 3 or 2 workgroups when 8 * ceil(chains / 8) * G of them
+ * are resident at once (one per CU); every other launch: 1.  LENV_TD3_TEAM=<G> caps it.  Same bits for every G. */
+int lenv_td3_rn_team_size(const lenv_td3_cfg *cfg /*HOST*/, int64_t chains);
 int lenv_td3_agent_init_hp(const lenv_td3_cfg *cfg /*HOST*/, const lenv_chain_hp *hp, const uint64_t *rng_keys, int64_t chains,
                            float *agent_init, void *stream);
 

@@ -815,6 +815,14 @@ extern "C" size_t lenv_td3_rn_workspace_bytes(const lenv_td3_cfg *cfg, int64_t c
     return (size_t)chains * a.arena_stride * sizeof(float) + 256;
 }
 
+extern "C" int lenv_td3_rn_team_size(const lenv_td3_cfg *cfg, int64_t chains)
+{
+    if (!cfg || chains < 1) return LENV_ERR_INVALID;
+    const char *nw_ = getenv("LENV_NO_WAVECHAIN"), *nf_ = getenv("LENV_NO_FIXED_SHAPE");
+    if ((nw_ && nw_[0] == '1') || (nf_ && nf_[0] == '1') || cfg->icm_enabled || cfg->rng_mode != LENV_RNG_COUNTER || !lenv_wc_td3_shape(cfg)) return 1;
+    return lenv_wc_td3_team(chains);
+}
+
 extern "C" int64_t lenv_td3_num_params(const lenv_td3_cfg *cfg, int64_t *actor_params, int64_t *critic_params)
 {
     if (!cfg) return LENV_ERR_INVALID;

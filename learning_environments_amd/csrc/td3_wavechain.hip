@@ -1267,6 +1267,8 @@ static int t3w_pick_team(int64_t chains)
     return 1;
 }
 
+int lenv_wc_td3_team(int64_t chains) { return t3w_pick_team(chains); }
+
 int64_t lenv_wc_td3_arena_floats(const lenv_td3_cfg *cfg, int64_t rb_cap, int RS)
 {
     T3wArgs a;
