@@ -164,6 +164,39 @@ __device__ __forceinline__ void tile_to_image(float *img_, int blk, const Lane &
         }
 }
 
+// ---- split passes (a block of 32 samples on FOUR waves, wave jt = output tile jt of every layer; the quad exchanges the operand
+// registers through a 16 KB LDS buffer: 64 k-step registers x 64 lanes) ----
+__device__ __forceinline__ void tile16_to_operand(float (&r)[16])
+{
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        auto s_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(r[2 * p]), __float_as_uint(r[2 * p + 1]), false, false);
+        r[2 * p] = __uint_as_float(s_[0]); r[2 * p + 1] = __uint_as_float(s_[1]);
+    }
+}
+__device__ __forceinline__ void xch_put(float *xch_, int jt, int lane, const float (&r)[16])
+{
+    lfloat *x = (lfloat *)xch_ + (16 * jt) * 64 + lane;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) x[v * 64] = r[v];
+}
+__device__ __forceinline__ void xch_get(const float *xch_, int lane, float (&r)[64])
+{
+    const lfloat *x = (const lfloat *)xch_ + lane;
+#pragma unroll
+    for (int v = 0; v < 64; ++v) r[v] = x[v * 64];
+}
+// one 32-unit tile of a 128 -> 128 layer: acc += sum over 64 k-steps, A = image rows 2t+h, columns of tile jt
+__device__ __forceinline__ void chain_tile(const float *img_, int jt, const Lane &L, const float (&b)[64], f32x16 &acc)
+{
+    const lfloat *img = (const lfloat *)img_;
+    const lfloat *ab[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ab[q] = img + L.h * W + 32 * jt + L.colsw[q];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[t & 3][2 * t * W], b[breg_of(t)], acc, 0, 0, 0);
+}
+
 // ---- weight images.  The arena keeps every 128x128 matrix K-MAJOR: Wt[k][unit] (so the forward image is a straight copy and the
 // thin products read it coalesced); the input-gradient products reduce over the units and need image[unit][k] = the transpose.
 struct StageRegs { f32x4 v[8]; };

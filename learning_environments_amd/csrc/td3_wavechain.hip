@@ -332,37 +332,6 @@ __device__ __noinline__ void t3w_backward_chain(const T3wCtx *ctx_, const float 
 // 4 q + jt computes output tile jt (32 units) of its quad's block for every layer and the quad exchanges the operand registers through
 // LDS (bufB: two quads x two stages x 16 KB; the image of the pass is in bufA), so a layer costs one tile's 64 MFMAs per SIMD instead
 // of four.  Same products, same k-ascending chains: the bits do not change.  Single passes only (a dual call needs bufB).
-__device__ __forceinline__ void tile16_to_operand(float (&r)[16])
-{
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        auto s_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(r[2 * p]), __float_as_uint(r[2 * p + 1]), false, false);
-        r[2 * p] = __uint_as_float(s_[0]); r[2 * p + 1] = __uint_as_float(s_[1]);
-    }
-}
-__device__ __forceinline__ void xch_put(float *xch_, int jt, int lane, const float (&r)[16])
-{
-    lfloat *x = (lfloat *)xch_ + (16 * jt) * 64 + lane;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) x[v * 64] = r[v];
-}
-__device__ __forceinline__ void xch_get(const float *xch_, int lane, float (&r)[64])
-{
-    const lfloat *x = (const lfloat *)xch_ + lane;
-#pragma unroll
-    for (int v = 0; v < 64; ++v) r[v] = x[v * 64];
-}
-// one 32-unit tile of a 128 -> 128 layer: acc += sum over 64 k-steps, A = image rows 2t+h, columns of tile jt
-__device__ __forceinline__ void chain_tile(const float *img_, int jt, const Lane &L, const float (&b)[64], f32x16 &acc)
-{
-    const lfloat *img = (const lfloat *)img_;
-    const lfloat *ab[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ab[q] = img + L.h * W + 32 * jt + L.colsw[q];
-#pragma unroll
-    for (int t = 0; t < 64; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[t & 3][2 * t * W], b[breg_of(t)], acc, 0, 0, 0);
-}
-
 template <int ACT, int IN, int OUT>
 __device__ __noinline__ void t3w_forward_split(const T3wCtx *ctx_, const float *par_, const float *X_, int ldx_, int mode_, float *q_out_,
                                                float *Y_, int ldy_, int ocol_, float *th_out_, int d_h1_, int r_h2_)
