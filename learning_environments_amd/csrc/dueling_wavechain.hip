@@ -47,6 +47,9 @@ struct WcArgs {
     int64_t rb_cap; int RS;
     int P, P_se, se_net_size[3];
     int64_t a_par, a_xs, a_xs2, a_dump, a_se, a_replay, a_meter;      // arena offsets (floats)
+    int64_t a_gx, a_bar, a_xtm;                                       // team exchange (V | Adv of the three passes), barrier word, per-member scratch rows
+    int G;                                                            // workgroups per chain: 1 or 2
+    int64_t chains;
 };
 
 // state-dict index (duel_param_offsets order) -> arena-layout index
@@ -90,6 +93,8 @@ struct WcCtx {
     volatile float *ctrl;
     float prelu;
     float w1, w2, beta2, adam_eps, tau, omt;            // Adam / Polyak constants (torch single-tensor Adam, DuelingDDQN.py:87-93)
+    int g, G;                                           // this workgroup's place in its chain's team
+    float *gva;                                         // team exchange: Vb [3][B] | Advb [3][B][A] (arena)
 };
 
 template <class T> __device__ __forceinline__ T *lds_uni_ptr(T *const *field) { return uni_ptr(*field); }
@@ -503,6 +508,357 @@ template <int SHAPE> __device__ __noinline__ void wc_backward_big(const WcCtx *c
     WSUB_MARK(21);
 }
 
+// =====================================================================================================================================
+// A chain on a TEAM of two workgroups (BASELINE configs[2]'s shard is 96 chains on 256 CUs).  Member g owns the sample blocks 2g, 2g+1
+// of the 128-row minibatch and runs each of them on FOUR waves (wave 4q + jt = output tile jt of block 2g + q; the quad exchanges
+// operand registers through bufB, see lenv_wavechain.cuh); the per-parameter work (weight gradients: reductions over all samples)
+// is dealt by layer: member 0 takes the two stream layers and the head, member 1 the feature layers.  Same products, same chains,
+// same bits as the one-workgroup kernel.
+// =====================================================================================================================================
+#define WCT_PROLOGUE                                                                                                                       \
+    using namespace wcp;                                                                                                                   \
+    constexpr WcShape SP = kWcShapes[SHAPE];                                                                                               \
+    constexpr int S = SP.S, A = SP.A, T = SP.T, B = WC_B, ACT = SP.q_act, RBH = B > T ? B : T;                                             \
+    (void)S; (void)A; (void)T; (void)B; (void)ACT; (void)RBH;                                                                              \
+    Lane L;                                                                                                                                \
+    L.init();                                                                                                                              \
+    const int tid = L.tid, wave = L.wave;                                                                                                  \
+    (void)tid; (void)wave;                                                                                                                 \
+    typedef __attribute__((address_space(3))) const WcCtx LCtx;                                                                            \
+    LCtx *c = (LCtx *)uni_ptr(ctx_);                                                                                                       \
+    float *bufA = uni_ptr(c->bufA), *bufB = uni_ptr(c->bufB);                                                                              \
+    lfloat *sm_w1t = (lfloat *)uni_ptr(c->sm_w1t), *sm_bias = (lfloat *)uni_ptr(c->sm_bias), *sm_wh = (lfloat *)uni_ptr(c->sm_wh),         \
+           *sm_bh = (lfloat *)uni_ptr(c->sm_bh), *Vb_l = (lfloat *)uni_ptr(c->Vb), *Advb_l = (lfloat *)uni_ptr(c->Advb),                   \
+           *dq_l = (lfloat *)uni_ptr(c->dq), *dAdv_l = (lfloat *)uni_ptr(c->dAdv), *qv_l = (lfloat *)uni_ptr(c->qv);                       \
+    float *online = uni_ptr(c->online), *target = uni_ptr(c->target), *grad = uni_ptr(c->grad), *xs = uni_ptr(c->xs), *xs2 = uni_ptr(c->xs2), \
+          *dumps = uni_ptr(c->dumps), *adam_m = uni_ptr(c->adam_m), *adam_v = uni_ptr(c->adam_v), *gva = uni_ptr(c->gva);                  \
+    const float prelu = unif(c->prelu);                                                                                                    \
+    const int tg = uni(c->g);                                                                                                              \
+    (void)bufA; (void)bufB; (void)sm_w1t; (void)sm_bias; (void)sm_wh; (void)sm_bh; (void)Vb_l; (void)Advb_l; (void)dq_l; (void)dAdv_l;     \
+    (void)qv_l; (void)online; (void)target; (void)grad; (void)xs; (void)xs2; (void)dumps; (void)adam_m; (void)adam_v; (void)gva;           \
+    (void)prelu; (void)tg;                                                                                                                 \
+    auto dump_of = [&](int which, int blk) { return wc_dump(dumps, which, blk); };                                                         \
+    (void)dump_of
+
+// one piece (16 bytes per lane) of a register-order dump: tile jt, group g4
+__device__ __forceinline__ void piece_store(float *dump, int jt, int lane, const float (&r)[16])
+{
+    gf4 *d = (gf4 *)dump + lane;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) d[(4 * jt + g4) * 64] = f32x4{r[4 * g4], r[4 * g4 + 1], r[4 * g4 + 2], r[4 * g4 + 3]};
+}
+__device__ __forceinline__ void piece_load(const float *dump, int jt, int lane, f32x4 (&v)[4])
+{
+    const gf4 *d = (const gf4 *)dump + lane;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) v[g4] = d[(4 * jt + g4) * 64];
+}
+
+// ---- team forward: pass 0 = target net on s' (slot 2), pass 1 = online net on s (slot 0, activations dumped) and on s' (slot 1):
+// the two inputs of pass 1 share every staged image (two jobs per wave).  The head outputs of this member's rows go to LDS and to
+// the team's exchange arrays ----
+template <int SHAPE> __device__ __noinline__ void wct_forward(const WcCtx *ctx_, int pass_)
+{
+    WCT_PROLOGUE;
+    const int pass = uni(pass_);
+    const float *par = pass ? online : target;
+    const int nj = pass ? 2 : 1;
+    const int quad = wave >> 2, jt = wave & 3, blk = 2 * tg + quad, row = 32 * blk + L.li;
+    for (int i = tid; i < 8 * W; i += NT) sm_w1t[i] = par[oW1t + i];
+    for (int i = tid; i < 5 * W; i += NT) {
+        const int l = i >> 7, j = i & 127;
+        const int off = l == 0 ? ob1 : (l == 1 ? ob2 : (l == 2 ? ob3 : (l == 3 ? obv1 : oba1)));
+        sm_bias[i] = par[off + j];
+    }
+    for (int i = tid; i < 4 * W + 4; i += NT) sm_wh[i] = par[oWh + i];
+    StageRegs sr;
+    stage_load_direct(par + oW2t, L, sr);
+    stage_store_direct(bufA, L, sr);
+    __syncthreads();
+    float r16[2][16], rf[2][64];
+    f32x16 acc;
+    // exchange slots: [quad][job] x 16 KB = all of bufB
+    auto xch = [&](int job) { return bufB + (quad * 2 + job) * 4096; };
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j < nj) {                                   // layer 1: K = S
+            const float *X = pass == 0 ? xs2 : (j == 0 ? xs : xs2);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+            const lfloat *w1 = sm_w1t + L.h * W + 32 * jt + L.li;
+#pragma unroll
+            for (int t = 0; t < S / 2; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2 * t * W], X[row * S + 2 * t + L.h], acc, 0, 0, 0);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 bv = *(const lf4 *)(sm_bias + 32 * jt + 8 * g4 + 4 * L.h);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) r16[j][4 * g4 + cc] = act_fwd(ACT, prelu, acc[4 * g4 + cc] + bv[cc]);
+            }
+            if (pass == 1 && j == 0) piece_store(dump_of(D_H1, blk), jt, L.lane, r16[j]);
+            tile16_to_operand(r16[j]);
+            xch_put(xch(j), jt, L.lane, r16[j]);
+        }
+    }
+    barrier_lds();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) if (j < nj) xch_get(xch(j), L.lane, rf[j]);
+    barrier_lds();
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {                      // W2, W3, Wv1, Wa1 (image of layer l in bufA)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j < nj) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+                chain_tile(bufA, jt, L, rf[j], acc);
+                const lfloat *bb = sm_bias + (l + 1) * W + 32 * jt + 4 * L.h;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 bv = *(const lf4 *)(bb + 8 * g4);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const float z = acc[4 * g4 + cc] + bv[cc];
+                        r16[j][4 * g4 + cc] = l == 1 ? z : act_fwd(ACT, prelu, z);
+                    }
+                }
+                if (pass == 1 && j == 0) {
+                    piece_store(dump_of(l == 0 ? D_H2 : (l == 1 ? D_FEAT : (l == 2 ? D_V1 : D_A1)), blk), jt, L.lane, r16[j]);
+                    if (l >= 2) {                       // row-major copy for the head output layer's weight gradient
+                        gfloat *rm = (gfloat *)dump_of(l == 2 ? R_V1 : R_A1, 0) + row * W + 32 * jt + 4 * L.h;
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) *(gf4 *)(rm + 8 * g4) = f32x4{r16[j][4 * g4], r16[j][4 * g4 + 1], r16[j][4 * g4 + 2], r16[j][4 * g4 + 3]};
+                    }
+                }
+                tile16_to_operand(r16[j]);
+            }
+        }
+        if (l < 2) {                                    // h2 / feat: the next layer's operand
+#pragma unroll
+            for (int j = 0; j < 2; ++j) if (j < nj) xch_put(xch(j), jt, L.lane, r16[j]);
+            barrier_lds();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) if (j < nj) xch_get(xch(j), L.lane, rf[j]);
+            stage_load_direct(par + (l == 0 ? oW3t : oWv1t), L, sr);
+            stage_store_direct(bufA, L, sr);
+            barrier_lds();
+        } else {
+            // v1 (l = 2) / a1 (l = 3) go through the exchange to ONE wave per (quad, job) for the head output layer: V = wv2 . v1 + bv2
+            // (row 0 of the tile), Adv = Wa2 . a1 + ba2 (rows 0..A-1); after l = 2 the Wa1 image replaces Wv1 (both read feat)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) if (j < nj) xch_put(xch(j), jt, L.lane, r16[j]);
+            if (l == 2) { stage_load_direct(par + oWa1t, L, sr); }
+            barrier_lds();
+            if (jt == (l == 2 ? 0 : 1)) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (j < nj) {
+                        float rh[64];
+                        xch_get(xch(j), L.lane, rh);
+                        f32x16 hacc;
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) hacc[v] = 0.0f;
+                        const int col = l == 2 ? 0 : 1 + (L.li < A ? L.li : A - 1);
+                        const lfloat *wh = sm_wh + L.h * 4 + col;
+#pragma unroll
+                        for (int t = 0; t < 64; ++t) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[2 * t * 4], rh[breg_of(t)], hacc, 0, 0, 0);
+                        if (L.h == 0) {
+                            const int slot = pass == 0 ? 2 : j;
+                            if (l == 2) {
+                                const float v = hacc[0] + sm_bh[0];
+                                Vb_l[slot * RBH + row] = v;
+                                gva[slot * B + row] = v;
+                            } else {
+#pragma unroll
+                                for (int aa = 0; aa < A; ++aa) {
+                                    const float v = hacc[aa] + sm_bh[1 + aa];
+                                    Advb_l[slot * RBH * A + row * A + aa] = v;
+                                    gva[3 * B + (slot * B + row) * A + aa] = v;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (l == 2) stage_store_direct(bufA, L, sr);      // every wave finished the Wv1 image before the barrier above
+            barrier_lds();
+        }
+    }
+    __syncthreads();
+}
+
+// ---- team backward, per-sample half: the input-gradient chain of this member's blocks through Wv1, Wa1 (-> d_feat), W3 (-> d_h2), W2
+// (-> d_h1); the gradients go to the register-order dumps S_DFEAT / S_DH2 / S_DH1 the weight-gradient phase reads ----
+template <int SHAPE> __device__ __noinline__ void wct_backward_chain(const WcCtx *ctx_)
+{
+    WCT_PROLOGUE;
+    const int quad = wave >> 2, jt = wave & 3, blk = 2 * tg + quad, row = 32 * blk + L.li;
+    float *xch = bufB + quad * 4096;
+    for (int i = tid; i < 4 * W + 4; i += NT) sm_wh[i] = online[oWh + i];
+    StageRegs sr;
+    stage_load_transposed(online + oWv1t, L, sr);
+    __syncthreads();
+    float r16[16], f1[16], rf[64];
+    f32x16 acc;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {                      // Wv1, Wa1, W3, W2
+        if (q < 2) {
+            // upstream gradient tile dz (lane = sample, register = unit) from the stream's hidden activations and the head gradient
+            f32x4 hv[4];
+            piece_load(dump_of(q == 0 ? D_V1 : D_A1, blk), jt, L.lane, hv);
+            const float dqi = dq_l[row];
+            float da[A];
+#pragma unroll
+            for (int aa = 0; aa < A; ++aa) da[aa] = dAdv_l[row * A + aa];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const lfloat *whp = sm_wh + (32 * jt + 8 * g4 + 4 * L.h) * 4;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const f32x4 wk = *(const lf4 *)(whp + 4 * cc);      // (wv2, wa2_0, wa2_1, wa2_2)[unit]
+                    float up;
+                    if (q == 0) up = fma32(dqi, wk[0], 0.0f);
+                    else {
+                        up = 0.0f;
+#pragma unroll
+                        for (int aa = 0; aa < A; ++aa) up = fma32(da[aa], wk[1 + aa], up);
+                    }
+                    r16[4 * g4 + cc] = act_bwd(ACT, prelu, hv[g4][cc], up);
+                }
+            }
+        }
+        // (q >= 2: r16 holds the previous layer's input gradient tile)
+        tile16_to_operand(r16);
+        xch_put(xch, jt, L.lane, r16);
+        stage_store_transposed(bufA, L, sr);
+        barrier_lds();
+        xch_get(xch, L.lane, rf);
+        f32x4 hv[4];
+        if (q >= 2) piece_load(dump_of(q == 2 ? D_H2 : D_H1, blk), jt, L.lane, hv);
+        if (q < 3) stage_load_transposed(online + (q == 0 ? oWa1t : (q == 1 ? oW3t : oW2t)), L, sr);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+        chain_tile(bufA, jt, L, rf, acc);
+        // epilogue: q 0: f1 = acc; q 1: d_feat = f1 + acc -> S_DFEAT; q 2 / 3: d_h = act'(h) * acc -> S_DH2 / S_DH1
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const float gq = acc[4 * g4 + cc];
+                if (q == 0) f1[4 * g4 + cc] = gq;
+                else if (q == 1) r16[4 * g4 + cc] = f1[4 * g4 + cc] + gq;
+                else r16[4 * g4 + cc] = act_bwd(ACT, prelu, hv[g4][cc], gq);
+            }
+        if (q >= 1) piece_store(dump_of(q == 1 ? S_DFEAT : (q == 2 ? S_DH2 : S_DH1), blk), jt, L.lane, r16);
+        barrier_lds();                                     // every wave is through with the image and the exchange slot
+    }
+    __syncthreads();
+}
+
+// ---- team backward, per-parameter half for layer q (0 Wv1, 1 Wa1, 2 W3, 3 W2): the [sample][unit] images of the upstream gradient
+// (bufB, waves 0-3) and of the layer input (bufA, waves 4-7) of ALL four blocks from the dumps, the 16 gradient tiles, the bias ----
+template <int SHAPE> __device__ __noinline__ void wct_wgrad_layer(const WcCtx *ctx_, int q_)
+{
+    WCT_PROLOGUE;
+    const int q = uni(q_);
+    const int oWt = q == 0 ? oWv1t : (q == 1 ? oWa1t : (q == 2 ? oW3t : oW2t));
+    const int ob = q == 0 ? obv1 : (q == 1 ? oba1 : (q == 2 ? ob3 : ob2));
+    float r[64];
+    if (q < 2) for (int i = tid; i < 4 * W + 4; i += NT) sm_wh[i] = online[oWh + i];
+    __syncthreads();
+    if (wave < 4) {
+        const int blk = wave;
+        if (q < 2) {
+            const gf4 *hd = (const gf4 *)dump_of(q == 0 ? D_V1 : D_A1, blk) + L.lane;
+            const int i = 32 * blk + L.li;
+            const float dqi = dq_l[i];
+            float da[A];
+#pragma unroll
+            for (int aa = 0; aa < A; ++aa) da[aa] = dAdv_l[i * A + aa];
+#pragma unroll
+            for (int pc = 0; pc < 16; ++pc) {
+                const f32x4 hv = hd[pc * 64];
+                const lfloat *whp = sm_wh + (32 * (pc >> 2) + 8 * (pc & 3) + 4 * L.h) * 4;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const f32x4 wk = *(const lf4 *)(whp + 4 * cc);
+                    float up;
+                    if (q == 0) up = fma32(dqi, wk[0], 0.0f);
+                    else {
+                        up = 0.0f;
+#pragma unroll
+                        for (int aa = 0; aa < A; ++aa) up = fma32(da[aa], wk[1 + aa], up);
+                    }
+                    r[4 * pc + cc] = act_bwd(ACT, prelu, hv[cc], up);
+                }
+            }
+        } else dump_load(dump_of(q == 2 ? S_DFEAT : S_DH2, blk), L, r);
+        tile_to_image(bufB, blk, L, r);
+    } else {
+        const int blk = wave - 4;
+        dump_load(dump_of(q < 2 ? D_FEAT : (q == 2 ? D_H2 : D_H1), blk), L, r);
+        tile_to_image(bufA, blk, L, r);
+    }
+    __syncthreads();
+    L.refresh();
+    wgrad_tiles(bufA, bufB, B, L, grad + oWt);
+    if (tid < W) grad[ob + tid] = image_colsum(bufB, tid, B);
+    __syncthreads();
+}
+
+// head output layer (gWh, gbh) from the row-major copies of v1 / a1 -- member 0; layer 1 (gW1t, gb1) from the S_DH1 dumps -- member 1
+template <int SHAPE> __device__ __noinline__ void wct_wgrad_ends(const WcCtx *ctx_, int which_)
+{
+    WCT_PROLOGUE;
+    const int which = uni(which_);
+    if (which == 0) {
+        const int k = tid & 127, col = tid >> 7;
+        if (col <= A) {
+            const gfloat *rm = (const gfloat *)dump_of(col == 0 ? R_V1 : R_A1, 0) + k;
+            float s_ = 0.0f;
+            for (int i0 = 0; i0 < B; i0 += 64) {
+                float hv[64];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) hv[u] = rm[(i0 + u) * W];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) s_ = fma32(col == 0 ? dq_l[i0 + u] : dAdv_l[(i0 + u) * A + col - 1], hv[u], s_);
+            }
+            grad[oWh + k * 4 + col] = s_;
+        }
+        if (tid >= 256 && tid < 256 + 1 + A) {
+            const int col2 = tid - 256;
+            float s_ = 0.0f;
+            for (int i = 0; i < B; ++i) s_ = s_ + (col2 == 0 ? dq_l[i] : dAdv_l[i * A + col2 - 1]);
+            grad[obh + col2] = s_;
+        }
+        __syncthreads();
+        return;
+    }
+    float r[64];
+    if (wave < 4) {
+        dump_load(dump_of(S_DH1, wave), L, r);
+        tile_to_image(bufB, wave, L, r);
+    }
+    for (int e = tid; e < B * S; e += NT) qv_l[e] = xs[e];                  // the minibatch states (qv is free after the TD step)
+    __syncthreads();
+    {
+        const int j = tid & 127, kq = tid >> 7;
+        const lfloat *img = (const lfloat *)bufB;
+        for (int k = kq; k < S; k += 4) {
+            float s_ = 0.0f;
+            for (int i0 = 0; i0 < B; i0 += 8) {
+                float dv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dv[u] = img[(i0 + u) * W + (j ^ (u << 2))];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s_ = fma32(dv[u], qv_l[(i0 + u) * S + k], s_);
+            }
+            grad[oW1t + k * W + j] = s_;
+        }
+        if (tid >= 384) grad[ob1 + j] = image_colsum(bufB, j, B);
+    }
+    __syncthreads();
+}
+
 template <int SHAPE>
 __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
 {
@@ -515,10 +871,14 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     Lane L;
     L.init();
     const int tid = L.tid, wave = L.wave;
-    const int64_t chain = blockIdx.x;
+    // a chain on a team of G workgroups (1 or 2): block x + 8 k is member k % G of chain 8 (k / G) + x, so the members share an XCD
+    const int G = a.G;
+    const int g = G == 1 ? 0 : (int)((blockIdx.x >> 3) % G);
+    const int64_t chain = G == 1 ? (int64_t)blockIdx.x : (int64_t)8 * ((blockIdx.x >> 3) / G) + (blockIdx.x & 7);
+    if (chain >= a.chains) return;
     // the chain's status word starts at 0 (ok); written here rather than by a memset node in front of the launch (a captured
     // generation replayed under rocprofv3 did not run the memset)
-    if (threadIdx.x == 0 && a.out.status) a.out.status[chain] = 0;
+    if (threadIdx.x == 0 && g == 0 && a.out.status) a.out.status[chain] = 0;
     const float prelu = cfg.q_prelu;
 
     // ---- LDS carve-up ----
@@ -553,6 +913,9 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     float *xs = arena + a.a_xs, *xs2 = arena + a.a_xs2, *dumps = arena + a.a_dump, *rb = arena + a.a_replay;
     float *se_w0T = arena + a.a_se, *se_b0 = se_w0T + 3 * K * Hse;        // [3][K][Hse], [3][Hse]
     double *meter = reinterpret_cast<double *>(arena + a.a_meter);
+    float *gva = arena + a.a_gx;                                              // team exchange: Vb [3][B] | Advb [3][B][A]
+    unsigned *team_bar = reinterpret_cast<unsigned *>(arena + a.a_bar);
+    float *xscr = G == 1 ? xs2 : arena + a.a_xtm + (int64_t)g * RBH * S;      // rows of the one-row / lock-step forwards: a member's own in a team
     const int RS = a.RS;
     auto dump_of = [&](int which, int blk) { return dumps + ((int64_t)which * 4 + blk) * BLK; };
 
@@ -576,18 +939,20 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
         }
     }
     // ---- fresh agent (DuelingDDQN.py:31-36): arena layout, Adam state and gradient (incl. the zero rows of W1t) cleared ----
-    for (int p = tid; p < PW; p += NT) { online[p] = 0.0f; target[p] = 0.0f; adam_m[p] = 0.0f; adam_v[p] = 0.0f; grad[p] = 0.0f; }
-    __syncthreads();
-    for (int p = tid; p < a.P; p += NT) {
-        const float w = a.agent_init[chain * a.P + p];
-        const int q = wc_sd_to_arena(p, S, A);
-        online[q] = w; target[q] = w;
+    if (g == 0) {                                          // the arena is shared by the team: its first member fills it
+        for (int p = tid; p < PW; p += NT) { online[p] = 0.0f; target[p] = 0.0f; adam_m[p] = 0.0f; adam_v[p] = 0.0f; grad[p] = 0.0f; }
+        __syncthreads();
+        for (int p = tid; p < a.P; p += NT) {
+            const float w = a.agent_init[chain * a.P + p];
+            const int q = wc_sd_to_arena(p, S, A);
+            online[q] = w; target[q] = w;
+        }
     }
     if (tid < 64) misc[tid] = 0.0f;
     if (tid == 0) {
         WcCtx cx{ bufA, bufB, sm_w1t, sm_bias, sm_wh, sm_bh, qv, Vb, Advb, dq, dAdv, online, target, grad, xs, xs2, dumps, adam_m, adam_v, ctrl, prelu,
                   (float)(1.0 - cfg.adam_beta1), (float)(1.0 - cfg.adam_beta2), (float)cfg.adam_beta2, (float)cfg.adam_eps, (float)cfg.tau,
-                  (float)(1.0 - cfg.tau) };
+                  (float)(1.0 - cfg.tau), g, G, gva };
         *ctx = cx;
     }
     __syncthreads();
@@ -599,6 +964,30 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     int train_steps = 0, n_act = 0, learn_it = 0, n_test_ep = 0, test_steps = 0, episodes_run = 0;
     double eps_g = cfg.eps_init, b1pow = 1.0, b2pow = 1.0;
     const int rb_cap = (int)a.rb_cap;
+    // ---- team barrier (G = 2): as in td3_wavechain.hip -- one monotonically increasing counter per chain, zeroed by a kernel in front
+    // of the launch; thread 0 releases, arrives, waits for the epoch's count, acquires (agent scope).  A member that waits for
+    // seconds gives up for good (status -10) instead of hanging the device.
+    unsigned team_epoch = 0;
+    bool team_dead = false;
+    auto team_barrier = [&]() {
+        if (G == 1) return;
+        __syncthreads();
+        ++team_epoch;
+        if (tid == 0 && !team_dead) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(team_bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target_ = team_epoch * (unsigned)G;
+            long spins = 0;
+            while (__hip_atomic_load(team_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target_) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > 8000000L) { ictrl[5] = 1; break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (ictrl[5]) { team_dead = true; status = -10; }
+    };
+    team_barrier();                                        // the arena is initialised
 
     // q_out[I][A] from the head outputs of `slot` (models/actor_critic.py:117-122; learn: mean over ALL I*A advantages)
     auto finish_q = [&](int slot, int I, float *q_out, bool global_mean) {
@@ -638,7 +1027,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
         }
         if (tid == 0) ictrl[0] = 0;
         __syncthreads();
-        float *xt = xs2;
+        float *xt = xscr;
         for (int t = 0; t < cfg.max_steps; ++t) {
             if (tid < T) { float obs[8]; real_env_obs(env_id, dstate + tid * 4, obs); for (int i = 0; i < S; ++i) xt[tid * S + i] = obs[i]; }
             __syncthreads();
@@ -697,9 +1086,9 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
             const int explored = ictrl[1];
             if (explored) ++n_act;
             if (!explored) {
-                for (int i = tid; i < S; i += NT) xs2[i] = state[i];
+                for (int i = tid; i < S; i += NT) xscr[i] = state[i];
                 __syncthreads();
-                forward_thin(xs2, 1);
+                forward_thin(xscr, 1);
                 if (tid == 0) {
                     int am = 0; float best = qv[0];
                     for (int aa = 1; aa < A; ++aa) if (qv[aa] > best) { best = qv[aa]; am = aa; }
@@ -756,8 +1145,17 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                 __syncthreads();
                 WPT_MARK(2);
 #ifndef WC_DIAG_NO_FWD
+                if (G == 2) {
 #pragma unroll 1
-                for (int pass = 0; pass < 2; ++pass) wc_forward_big<SHAPE>(ctx, pass);      // target net on s'; online net on s (stored) and s'
+                    for (int pass = 0; pass < 2; ++pass) wct_forward<SHAPE>(ctx, pass);
+                    team_barrier();                        // every row's V / Adv is in the exchange arrays
+                    for (int e = tid; e < 3 * B; e += NT) Vb[(e / B) * RBH + (e % B)] = gva[e];
+                    for (int e = tid; e < 3 * B * A; e += NT) Advb[(e / (B * A)) * RBH * A + (e % (B * A))] = gva[3 * B + e];
+                    __syncthreads();
+                } else {
+#pragma unroll 1
+                    for (int pass = 0; pass < 2; ++pass) wc_forward_big<SHAPE>(ctx, pass);  // target net on s'; online net on s (stored) and s'
+                }
 #endif
                 finish_q(1, B, qv + B * A, true);
                 finish_q(2, B, qv + 2 * B * A, true);
@@ -796,7 +1194,21 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                 __syncthreads();
                 WPT_MARK(4);
 #ifndef WC_DIAG_NO_BWD
-                wc_backward_big<SHAPE>(ctx);
+                if (G == 2) {
+                    wct_backward_chain<SHAPE>(ctx);
+                    team_barrier();                        // all four blocks' gradient dumps are there
+                    if (g == 0) { wct_wgrad_ends<SHAPE>(ctx, 0); wct_wgrad_layer<SHAPE>(ctx, 0); wct_wgrad_layer<SHAPE>(ctx, 1); }
+                    else { wct_wgrad_layer<SHAPE>(ctx, 2); wct_wgrad_layer<SHAPE>(ctx, 3); wct_wgrad_ends<SHAPE>(ctx, 1); }
+                    team_barrier();
+                    {   // torch.optim.Adam + Polyak, half of the parameter vector per member (ctrl[10], ctrl[11]: this step's bias corrections)
+                        const AdamConsts ac{ ctrl[10], ctrl[11], (float)(1.0 - cfg.adam_beta1), (float)(1.0 - cfg.adam_beta2), (float)cfg.adam_beta2,
+                                             (float)cfg.adam_eps };
+                        const int half = ((PW / 2) + 3) & ~3;
+                        const int lo = g == 0 ? 0 : half, n = g == 0 ? half : PW - half;
+                        wg_adam_t(online, adam_m, adam_v, grad, lo, n, ac, target, (float)cfg.tau, (float)(1.0 - cfg.tau), tid, NT);
+                    }
+                    team_barrier();
+                } else wc_backward_big<SHAPE>(ctx);
 #endif
                 WPT_MARK(6);
                 ++learn_it;                                // (optimizer step + Polyak update: inside wc_backward_big)
@@ -806,7 +1218,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
             if (done_now > 0.5f) break;
         }
         ++episodes_run;
-        if (tid == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
+        if (tid == 0 && g == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
         __syncthreads();
         WPT_MARK(9);
         test_phase();
@@ -816,7 +1228,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
             for (int i = 0; i < T; ++i) sm += ret[i];
             const double tm = sm / (double)T;
             meter[episode] = tm;
-            if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
+            if (g == 0 && a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
             int brk = 0;
             if (learning) {
                 int lo = episode + 1 - cfg.early_out_num; if (lo < 0) lo = 0;
@@ -855,7 +1267,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
 #ifdef LENV_PHASE_TIMING
     if (tid == 0 && chain == 0) for (int pi = 0; pi < 12; ++pi) g_wc_phase_cycles[pi] = pt_acc[pi];
 #endif
-    if (tid == 0) {
+    if (tid == 0 && g == 0) {
         double sm = 0.0;
         for (int i = 0; i < T; ++i) sm += ret[i];
         a.out.score[chain] = sm / (double)T;
@@ -879,7 +1291,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
             if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = pad_l;
         }
     }
-    if (a.out.final_online) for (int p = tid; p < a.P; p += NT) a.out.final_online[chain * a.P + p] = online[wc_sd_to_arena(p, S, A)];
+    if (a.out.final_online && g == 0) for (int p = tid; p < a.P; p += NT) a.out.final_online[chain * a.P + p] = online[wc_sd_to_arena(p, S, A)];
     if (a.out.status && status != 0) atomicMin(&a.out.status[chain], status);
 }
 
@@ -918,8 +1330,31 @@ int64_t lenv_wc_dueling_arena_floats(const lenv_ddqn_cfg *cfg, int shape, int64_
     auto take = [&](int64_t n) { int64_t r = off; off += (n + 3) & ~(int64_t)3; return r; };
     take(5 * (int64_t)wcp::PW); take((int64_t)B * S); take((int64_t)(B > T ? B : T) * S); take((int64_t)WC_NDUMP * 4 * wc::BLK);
     take(3 * (int64_t)(K + 1) * sp.Hse); take(rb_cap * RS); take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
+    take(3 * (int64_t)B * (1 + sp.A)); take(16); take(2 * (int64_t)(B > T ? B : T) * S);      // team exchange, barrier word, per-member scratch rows
     (void)P_se;
     return (off + 63) & ~(int64_t)63;
+}
+
+namespace lenv {
+__global__ void wct_team_reset_kernel(float *arena, int64_t arena_stride, int64_t a_bar, int64_t chains)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < chains) *reinterpret_cast<unsigned *>(arena + c * arena_stride + a_bar) = 0u;
+}
+}
+
+// Workgroups per chain: 2 when all 8 * ceil(chains / 8) * 2 workgroups (one per CU) are resident at once -- the members wait for
+// each other --, else 1.  LENV_DUELING_TEAM=1 forces one workgroup per chain.
+int lenv_wc_dueling_team(int64_t chains)
+{
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return n;
+    }();
+    const char *e = getenv("LENV_DUELING_TEAM");
+    const int want = e ? atoi(e) : 2;
+    return (want >= 2 && 8 * ((chains + 7) / 8) * 2 <= cus) ? 2 : 1;
 }
 
 int lenv_wc_dueling_launch(int shape, const lenv_ddqn_cfg *cfg, const float *theta, const float *eps, const int32_t *worker,
@@ -939,13 +1374,21 @@ int lenv_wc_dueling_launch(int shape, const lenv_ddqn_cfg *cfg, const float *the
     a.a_par = take(5 * (int64_t)wcp::PW); a.a_xs = take((int64_t)B * S); a.a_xs2 = take((int64_t)(B > T ? B : T) * S);
     a.a_dump = take((int64_t)WC_NDUMP * 4 * wc::BLK); a.a_se = take(3 * (int64_t)(K + 1) * sp.Hse); a.a_replay = take(rb_cap * RS);
     a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
+    a.a_gx = take(3 * (int64_t)B * (1 + sp.A)); a.a_bar = take(16); a.a_xtm = take(2 * (int64_t)(B > T ? B : T) * S);
     if (off > arena_stride) return LENV_ERR_WORKSPACE;
     const size_t lds_bytes = wc_lds_bytes(sp);
     if (lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     void (*kern)(const WcArgs) = dueling_wavechain_kernel<1>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
         return LENV_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3((unsigned)chains), dim3(wc::NT), lds_bytes, stream, a);
+    a.chains = chains;
+    a.G = lenv_wc_dueling_team(chains);
+    unsigned grid = (unsigned)chains;
+    if (a.G > 1) {
+        grid = (unsigned)(8 * ((chains + 7) / 8) * a.G);
+        hipLaunchKernelGGL(wct_team_reset_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, stream, arena, arena_stride, a.a_bar, chains);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(wc::NT), lds_bytes, stream, a);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }
 

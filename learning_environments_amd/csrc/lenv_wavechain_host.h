@@ -10,6 +10,7 @@
 int lenv_wc_dueling_shape(const lenv_ddqn_cfg *cfg);
 // floats of one chain's arena in the wave-chain layout
 int64_t lenv_wc_dueling_arena_floats(const lenv_ddqn_cfg *cfg, int shape, int64_t rb_cap, int RS, int P_se);
+int lenv_wc_dueling_team(int64_t chains);                 // workgroups per chain the launch will use (1 or 2)
 int lenv_wc_dueling_launch(int shape, const lenv_ddqn_cfg *cfg, const float *theta, const float *eps, const int32_t *worker, const float *sign,
                            const float *agent_init, const uint64_t *rng_keys, int64_t chains, float *arena, int64_t arena_stride, int64_t rb_cap,
                            int RS, int P, int P_se, const int *se_net_size, const lenv_inner_out *out, hipStream_t stream);

@@ -2064,6 +2064,43 @@ def test_wavechain_dueling_kernel_equals_gemm_queue_kernel(eng):
     assert not np.array_equal(a[4], init)
 
 
+@pytest.mark.parametrize("chains", [5, 10])
+def test_wavechain_dueling_team_agrees(eng, chains, monkeypatch):
+    """The DuelingDDQN wave-chain kernel with a chain on a team of two workgroups (blocks on four waves each, weight gradients dealt by
+    layer, four agent-scope barriers per learn step) against the one-workgroup launch and the GEMM-queue kernel: same bits."""
+    from learning_environments_amd import configs
+    from learning_environments_amd.agents.nes_common import chain_keys
+    from learning_environments_amd.config import ddqn_cfg_from_config
+    cfgd = configs.fixed_work(configs.acrobot_syn_env_duelingddqn(2), 3)
+    cfgd["agents"]["duelingddqn"]["init_episodes"] = 1
+    cfgd["envs"]["Acrobot-v1"]["max_steps"] = 30
+    cfg = ddqn_cfg_from_config(cfgd)
+    rng = np.random.RandomState(50 + chains)
+    P_se = 3 * (9 * 128 + 128) + (6 + 1 + 1) * 128 + 8
+    theta = (rng.randn(P_se) * 0.1).astype(np.float32)
+    theta[-1] = -10.0
+    eps = (rng.randn(4, P_se) * 0.05).astype(np.float32)
+    worker = (np.arange(chains) // 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), 4)[:chains].copy()
+    keys = chain_keys(76, 4, worker, np.arange(chains) % 3)
+    init = rng.uniform(-0.08, 0.08, (chains, 67460)).astype(np.float32)
+
+    def run(trace_cap):
+        il = eng.InnerLoop(cfg, chains, trace_cap=trace_cap, want_final_online=True)
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return [t.cpu().numpy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_online)]
+
+    ref = run(2)                                            # GEMM-queue kernel
+    assert ref[1][:, 2].min() == 60
+    for G in (1, 2):
+        monkeypatch.setenv("LENV_DUELING_TEAM", str(G))
+        out = run(0)
+        for x, y in zip(out, ref):
+            assert np.array_equal(x, y, equal_nan=True), G
+
+
 def test_wavechain_td3_kernel_equals_gemm_queue_kernel(eng, orc):
     """td3_wavechain.hip (BASELINE configs[4]'s shape) against td3_rn_inner_kernel: scores, counters, test means and all 59 016
     parameters (actor | critic_1 | critic_2) after 120 learn steps, bit for bit."""

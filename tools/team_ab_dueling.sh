@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B of the DuelingDDQN wave-chain kernel's team size at BASELINE configs[2]'s shard (96 chains): LENV_DUELING_TEAM = 1, 2
+for G in 1 2; do
+  LENV_DUELING_TEAM=$G timeout 300 python bench.py --only-config 2 2>/dev/null | tail -1 > /tmp/dteam_$G.json
+  python - $G <<'PY'
+import json, sys
+G = sys.argv[1]
+d = json.loads(open('/tmp/dteam_%s.json' % G).read())
+c = d[0] if isinstance(d, list) else d.get("configs", [d])[0]
+print("G", G, "ms_per_step", c.get("ms_per_step"), "kernel_ms", c.get("kernel_ms"), "us/learn", c.get("us_per_learn_step_per_chain"))
+PY
+done
