@@ -371,10 +371,11 @@ def secondary_configs(only=None):
                "graph": bool(getattr(m, "use_graph", False))}
         if flops:
             busy = min(int(st.shape[0]), 256)
-            if kernel == "td3_wavechain_kernel":           # a chain is run by a team of workgroups when the whole launch stays resident
+            if kernel in ("td3_wavechain_kernel", "dueling_wavechain_kernel"):    # a chain is run by a team of workgroups when the whole launch stays resident
                 import ctypes
                 from learning_environments_amd import _lib
-                team = int(_lib.lib().lenv_td3_rn_team_size(ctypes.byref(m.cfg), int(st.shape[0])))
+                fn = _lib.lib().lenv_td3_rn_team_size if kernel == "td3_wavechain_kernel" else _lib.lib().lenv_dueling_team_size
+                team = int(fn(ctypes.byref(m.cfg), int(st.shape[0])))
                 rec["workgroups_per_chain"] = team
                 busy = min(busy * max(team, 1), 256)
             tf = flops / (kernel_ms * 1e-3) / 1e12

@@ -251,6 +251,10 @@ int lenv_dueling_se_inner_loop(const lenv_ddqn_cfg *cfg /*HOST*/, const float *t
                                const int32_t *worker, const float *sign, const float *agent_init,
                                const uint64_t *rng_keys, const lenv_tapes *tapes /*HOST, may be NULL*/, int64_t chains,
                                void *workspace, size_t workspace_bytes, const lenv_inner_out *out /*HOST*/, void *stream);
+/* Workgroups per chain a production launch (counter RNG, no trace, no hp, no ICM) of this cfg will use: the wave-chain kernel of the
+ * published Acrobot SE + DuelingDDQN shape runs a chain on a TEAM of 2 workgroups when 8 * ceil(chains / 8) * 2 of them are resident at
+ * once (one per CU); every other launch: 1.  LENV_DUELING_TEAM=1 forces 1.  Same bits either way. */
+int lenv_dueling_team_size(const lenv_ddqn_cfg *cfg /*HOST*/, int64_t chains);
 /* Fresh agents (nn.Linear default init, the draw of lenv_nes_draw) for chains with their own shapes: row c of agent_init
  * [chains, lenv_dueling_num_params(cfg)] gets the parameters of a (hp->q_hidden[c], hp->q_layers[c]) network, keyed by
  * rng_keys[c].  hp == NULL: every chain has cfg's shapes (== lenv_nes_draw's agent_init for the same keys). */

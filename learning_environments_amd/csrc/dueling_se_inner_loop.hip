@@ -847,6 +847,16 @@ extern "C" size_t lenv_dueling_se_workspace_bytes(const lenv_ddqn_cfg *cfg, int6
     return (size_t)chains * a.arena_stride * sizeof(float) + 256;
 }
 
+extern "C" int lenv_dueling_team_size(const lenv_ddqn_cfg *cfg, int64_t chains)
+{
+    if (!cfg || chains < 1) return LENV_ERR_INVALID;
+    const char *nw_ = getenv("LENV_NO_WAVECHAIN"), *nf_ = getenv("LENV_NO_FIXED_SHAPE");
+    if ((nw_ && nw_[0] == '1') || (nf_ && nf_[0] == '1') || cfg->icm_enabled || cfg->rng_mode != LENV_RNG_COUNTER || cfg->synthetic_env_type != 0 ||
+        !lenv_wc_dueling_shape(cfg))
+        return 1;
+    return lenv_wc_dueling_team(chains);
+}
+
 extern "C" int64_t lenv_dueling_num_params(const lenv_ddqn_cfg *cfg)
 {
     if (!cfg) return LENV_ERR_INVALID;

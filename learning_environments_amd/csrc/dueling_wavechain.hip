@@ -572,9 +572,11 @@ template <int SHAPE> __device__ __noinline__ void wct_forward(const WcCtx *ctx_,
     }
     for (int i = tid; i < 4 * W + 4; i += NT) sm_wh[i] = par[oWh + i];
     StageRegs sr;
+    WSUB_DECL;
     stage_load_direct(par + oW2t, L, sr);
     stage_store_direct(bufA, L, sr);
     __syncthreads();
+    WSUB_MARK(48);
     float r16[2][16], rf[2][64];
     f32x16 acc;
     // exchange slots: [quad][job] x 16 KB = all of bufB
@@ -603,6 +605,7 @@ template <int SHAPE> __device__ __noinline__ void wct_forward(const WcCtx *ctx_,
 #pragma unroll
     for (int j = 0; j < 2; ++j) if (j < nj) xch_get(xch(j), L.lane, rf[j]);
     barrier_lds();
+    WSUB_MARK(49);
 #pragma unroll 1
     for (int l = 0; l < 4; ++l) {                      // W2, W3, Wv1, Wa1 (image of layer l in bufA)
 #pragma unroll
@@ -632,6 +635,7 @@ template <int SHAPE> __device__ __noinline__ void wct_forward(const WcCtx *ctx_,
                 tile16_to_operand(r16[j]);
             }
         }
+        WSUB_MARK(50);
         if (l < 2) {                                    // h2 / feat: the next layer's operand
 #pragma unroll
             for (int j = 0; j < 2; ++j) if (j < nj) xch_put(xch(j), jt, L.lane, r16[j]);
@@ -641,49 +645,54 @@ template <int SHAPE> __device__ __noinline__ void wct_forward(const WcCtx *ctx_,
             stage_load_direct(par + (l == 0 ? oW3t : oWv1t), L, sr);
             stage_store_direct(bufA, L, sr);
             barrier_lds();
-        } else {
-            // v1 (l = 2) / a1 (l = 3) go through the exchange to ONE wave per (quad, job) for the head output layer: V = wv2 . v1 + bv2
-            // (row 0 of the tile), Adv = Wa2 . a1 + ba2 (rows 0..A-1); after l = 2 the Wa1 image replaces Wv1 (both read feat)
+        } else if (l == 2) {
+            // v1 waits in the exchange slots (bufB) for the head output layer; the Wa1 image replaces Wv1 (both layers read feat)
 #pragma unroll
             for (int j = 0; j < 2; ++j) if (j < nj) xch_put(xch(j), jt, L.lane, r16[j]);
-            if (l == 2) { stage_load_direct(par + oWa1t, L, sr); }
+            barrier_lds();                                 // every wave is through with the Wv1 image
+            stage_load_direct(par + oWa1t, L, sr);
+            stage_store_direct(bufA, L, sr);
             barrier_lds();
-            if (jt == (l == 2 ? 0 : 1)) {
+        } else {
+            // a1 goes to exchange slots in bufA (the last image is used up), then the 2 quads x nj jobs x {V, Adv} head output layers
+            // run one per wave: V = wv2 . v1 + bv2 (row 0 of the tile), Adv = Wa2 . a1 + ba2 (rows 0..A-1)
+            barrier_lds();                                 // every wave is through with the Wa1 image
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (j < nj) {
-                        float rh[64];
-                        xch_get(xch(j), L.lane, rh);
-                        f32x16 hacc;
+            for (int j = 0; j < 2; ++j) if (j < nj) xch_put(bufA + (quad * 2 + j) * 4096, jt, L.lane, r16[j]);
+            barrier_lds();
+            // task = wave: pass 1 (nj = 2): head = wave & 1, job = (wave >> 1) & 1, quad = wave >> 2; pass 0: head = wave & 1, quad = wave >> 1 (waves 0-3)
+            const int hd = wave & 1, tj = nj == 2 ? (wave >> 1) & 1 : 0, tq = nj == 2 ? wave >> 2 : wave >> 1;
+            if (nj == 2 || wave < 4) {
+                float rh[64];
+                xch_get((hd == 0 ? bufB : bufA) + (tq * 2 + tj) * 4096, L.lane, rh);
+                f32x16 hacc;
 #pragma unroll
-                        for (int v = 0; v < 16; ++v) hacc[v] = 0.0f;
-                        const int col = l == 2 ? 0 : 1 + (L.li < A ? L.li : A - 1);
-                        const lfloat *wh = sm_wh + L.h * 4 + col;
+                for (int v = 0; v < 16; ++v) hacc[v] = 0.0f;
+                const int col = hd == 0 ? 0 : 1 + (L.li < A ? L.li : A - 1);
+                const lfloat *wh = sm_wh + L.h * 4 + col;
 #pragma unroll
-                        for (int t = 0; t < 64; ++t) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[2 * t * 4], rh[breg_of(t)], hacc, 0, 0, 0);
-                        if (L.h == 0) {
-                            const int slot = pass == 0 ? 2 : j;
-                            if (l == 2) {
-                                const float v = hacc[0] + sm_bh[0];
-                                Vb_l[slot * RBH + row] = v;
-                                gva[slot * B + row] = v;
-                            } else {
+                for (int t = 0; t < 64; ++t) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[2 * t * 4], rh[breg_of(t)], hacc, 0, 0, 0);
+                if (L.h == 0) {
+                    const int slot = pass == 0 ? 2 : tj, hrow = 32 * (2 * tg + tq) + L.li;
+                    if (hd == 0) {
+                        const float v = hacc[0] + sm_bh[0];
+                        Vb_l[slot * RBH + hrow] = v;
+                        gva[slot * B + hrow] = v;
+                    } else {
 #pragma unroll
-                                for (int aa = 0; aa < A; ++aa) {
-                                    const float v = hacc[aa] + sm_bh[1 + aa];
-                                    Advb_l[slot * RBH * A + row * A + aa] = v;
-                                    gva[3 * B + (slot * B + row) * A + aa] = v;
-                                }
-                            }
+                        for (int aa = 0; aa < A; ++aa) {
+                            const float v = hacc[aa] + sm_bh[1 + aa];
+                            Advb_l[slot * RBH * A + hrow * A + aa] = v;
+                            gva[3 * B + (slot * B + hrow) * A + aa] = v;
                         }
                     }
                 }
             }
-            if (l == 2) stage_store_direct(bufA, L, sr);      // every wave finished the Wv1 image before the barrier above
-            barrier_lds();
         }
+        WSUB_MARK(51);
     }
     __syncthreads();
+    WSUB_MARK(52);
 }
 
 // ---- team backward, per-sample half: the input-gradient chain of this member's blocks through Wv1, Wa1 (-> d_feat), W3 (-> d_h2), W2
@@ -695,8 +704,10 @@ template <int SHAPE> __device__ __noinline__ void wct_backward_chain(const WcCtx
     float *xch = bufB + quad * 4096;
     for (int i = tid; i < 4 * W + 4; i += NT) sm_wh[i] = online[oWh + i];
     StageRegs sr;
+    WSUB_DECL;
     stage_load_transposed(online + oWv1t, L, sr);
     __syncthreads();
+    WSUB_MARK(53);
     float r16[16], f1[16], rf[64];
     f32x16 acc;
 #pragma unroll 1
@@ -731,6 +742,7 @@ template <int SHAPE> __device__ __noinline__ void wct_backward_chain(const WcCtx
         xch_put(xch, jt, L.lane, r16);
         stage_store_transposed(bufA, L, sr);
         barrier_lds();
+        WSUB_MARK(54);
         xch_get(xch, L.lane, rf);
         f32x4 hv[4];
         if (q >= 2) piece_load(dump_of(q == 2 ? D_H2 : D_H1, blk), jt, L.lane, hv);
@@ -750,8 +762,10 @@ template <int SHAPE> __device__ __noinline__ void wct_backward_chain(const WcCtx
             }
         if (q >= 1) piece_store(dump_of(q == 1 ? S_DFEAT : (q == 2 ? S_DH2 : S_DH1), blk), jt, L.lane, r16);
         barrier_lds();                                     // every wave is through with the image and the exchange slot
+        WSUB_MARK(55);
     }
     __syncthreads();
+    WSUB_MARK(56);
 }
 
 // ---- team backward, per-parameter half for layer q (0 Wv1, 1 Wa1, 2 W3, 3 W2): the [sample][unit] images of the upstream gradient
@@ -763,6 +777,7 @@ template <int SHAPE> __device__ __noinline__ void wct_wgrad_layer(const WcCtx *c
     const int oWt = q == 0 ? oWv1t : (q == 1 ? oWa1t : (q == 2 ? oW3t : oW2t));
     const int ob = q == 0 ? obv1 : (q == 1 ? oba1 : (q == 2 ? ob3 : ob2));
     float r[64];
+    WSUB_DECL;
     if (q < 2) for (int i = tid; i < 4 * W + 4; i += NT) sm_wh[i] = online[oWh + i];
     __syncthreads();
     if (wave < 4) {
@@ -799,10 +814,13 @@ template <int SHAPE> __device__ __noinline__ void wct_wgrad_layer(const WcCtx *c
         tile_to_image(bufA, blk, L, r);
     }
     __syncthreads();
+    WSUB_MARK(57);
     L.refresh();
     wgrad_tiles(bufA, bufB, B, L, grad + oWt);
+    WSUB_MARK(58);
     if (tid < W) grad[ob + tid] = image_colsum(bufB, tid, B);
     __syncthreads();
+    WSUB_MARK(59);
 }
 
 // head output layer (gWh, gbh) from the row-major copies of v1 / a1 -- member 0; layer 1 (gW1t, gb1) from the S_DH1 dumps -- member 1

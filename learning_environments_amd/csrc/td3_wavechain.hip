@@ -69,10 +69,23 @@ __device__ __forceinline__ int t3w_sd_to_arena(int p, int in, int out)
 
 #ifdef LENV_PHASE_TIMING
 __device__ unsigned long long g_t3w_phase_cycles[48];
+// sub-phase marks inside the out-of-line routines: their own switch (-DLENV_PHASE_TIMING_SUB; together with the kernel-level marks the
+// build of this file trips a backend assertion of the ROCm 7.2 compiler)
+#ifdef LENV_PHASE_TIMING_SUB
 #define TSUB_DECL unsigned long long sp_last = __builtin_readcyclecounter()
 #define TSUB_MARK(i) do { unsigned long long sp_now = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) g_t3w_phase_cycles[i] += sp_now - sp_last; sp_last = sp_now; } while (0)
+#else
+#define TSUB_DECL
+#define TSUB_MARK(i)
+#endif
 #define TPT_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define TPT_MARK(i) do { unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
+#ifdef LENV_PHASE_TIMING_SUB
+#undef TPT_DECL
+#undef TPT_MARK
+#define TPT_DECL
+#define TPT_MARK(i)
+#endif
 #else
 #define TPT_DECL
 #define TPT_MARK(i)
@@ -114,10 +127,10 @@ __device__ __forceinline__ void block_to_rowmajor(float *rm_, int blk, const Lan
 template <int ACT, int IN, int OUT>
 __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, const float *X_, int ldx_, int mode_, float *q_out_,
                                          float *Y_, int ldy_, int ocol_, float *th_out_, int d_h1_, int d_h2_, int r_h2_,
-                                         const float *par2_ = nullptr, const float *X2_ = nullptr, float *q_out2_ = nullptr, int d_h1_2_ = -1, int r_h2_2_ = -1)
+                                         const float *par2_ = nullptr, const float *X2_ = nullptr, float *q_out2_ = nullptr, int d_h1_2_ = -2, int r_h2_2_ = -1)
 {
     T3W_CTX_PROLOGUE;
-    const bool dual = uni_ptr(par2_) != nullptr;
+    const bool dual = uni(d_h1_2_) != -2;                  // (a flag rather than a null test of the generic pointer)
     // this wave's job: (pass 0, block = wave) or, in a dual call, (pass 1, block = wave - 6 / G mod 8: the member's blocks are
     // consecutive, so pass 1 sits on the waves right behind them -- other SIMDs than the blocks' own waves)
     const int wave2 = (wave - T3W_NB / TG) & 7;
@@ -231,12 +244,12 @@ __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, 
 template <int ACT, int IN, int OUT>
 __device__ __noinline__ void t3w_backward_chain(const T3wCtx *ctx_, const float *par_, const float *dOut_, int d_h1_, int d_h2_, int r_dz2_, int r_dh1_,
                                                 int dx_col_, int dx_n_, const float *th_, float *dz_out_,
-                                                const float *par2_ = nullptr, const float *dOut2_ = nullptr, int d_h1_2_ = -1, int d_h2_2_ = -1,
+                                                const float *par2_ = nullptr, const float *dOut2_ = nullptr, int d_h1_2_ = -2, int d_h2_2_ = -1,
                                                 int r_dz2_2_ = -1, int r_dh1_2_ = -1)
 {
     T3W_CTX_PROLOGUE;
-    // a second, independent network's chain (par2 != null) runs on the waves behind the member's own blocks, as in t3w_forward
-    const bool dual = uni_ptr(par2_) != nullptr;
+    // a second, independent network's chain (d_h1_2 given) runs on the waves behind the member's own blocks, as in t3w_forward
+    const bool dual = uni(d_h1_2_) != -2;
     const int wave2 = (wave - T3W_NB / TG) & 7;
     const bool act0 = wave < T3W_NB && mine(wave, T3W_NB);
     const bool act1 = dual && !act0 && wave2 < T3W_NB && mine(wave2, T3W_NB);
@@ -1143,7 +1156,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         __syncthreads();
     }
     TPT_MARK(9);
-#ifdef LENV_PHASE_TIMING
+#if defined(LENV_PHASE_TIMING) && !defined(LENV_PHASE_TIMING_SUB)
     if (tid == 0 && chain == 0) for (int pi = 0; pi < 12; ++pi) g_t3w_phase_cycles[pi] = pt_acc[pi];
 #endif
     if (tid == 0 && g == 0) {

@@ -52,6 +52,9 @@ for i, n in enumerate(names):
 sub = {16: "bwd (a) dz + W^T image", 17: "bwd (b) input-grad chain | colsum/head grads", 18: "bwd (c) input image", 19: "bwd (d) weight-grad tiles",
        22: "bwd head output-layer weight grads", 20: "bwd layer 1", 21: "bwd adam tail (layers 1, 2, heads)", 24: "thin L1", 25: "thin L2", 26: "thin L3", 27: "thin L4 (v1 | a1)", 28: "thin heads", 32: "fwd smalls + W2 image",
        40: "  (b) wave 0: chain", 41: "  (b) wave 0: epilogue", 44: "  (b) wave 4: colsum", 45: "  (b) wave 4: head grads", 46: "  (b) wave 4: adam, half of layer q-1", 33: "fwd L1+L2", 34: "fwd L3", 35: "fwd L4v + V", 36: "fwd L4a + Adv"}
+sub.update({48: "team fwd: smalls + W2 image", 49: "team fwd: L1 + exchange", 50: "team fwd: layer tiles (4 layers)", 51: "team fwd: exchange / staging / heads",
+            52: "team fwd: final barrier", 53: "team bwd chain: first image load", 54: "team bwd chain: dz + image store + barrier", 55: "team bwd chain: chain + epilogue",
+            56: "team bwd chain: final barrier", 57: "team wgrad layer: images", 58: "team wgrad layer: tiles", 59: "team wgrad layer: colsum + barrier"})
 nthin = st[3] / 10.0 + buf[0] * 0  # lock-step test forwards; greedy forwards are counted on top
 for i, n in sub.items():
     div = 2 * st[2] if i < 24 or i >= 32 else 1      # the sub-phase counters accumulate over both generations
