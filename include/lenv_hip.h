@@ -89,6 +89,10 @@ typedef struct {
      * reward network theta (state_dim -> se_hidden -> 1, se_act; a 1-input dummy for type 0), reward_env_type 0, 1, 2, 5 or 6
      * (the real CartPole / Acrobot step carries no info vector).  GEMM-tiled kernel only (lenv_dueling_se_inner_loop*). */
     int32_t synthetic_env_type, reward_env_type;
+    /* same_action_num (agents/base_agent.py:20,104,194; envs/env_wrapper.py:24-29,56-61): env steps per chosen action -- a VirtualEnv
+     * repeats the step whatever the done flag says and sums the fp32 rewards, a real env's repeats stop at done (python-float sum);
+     * 0 and 1 both mean 1.  Values > 1: GEMM-tiled kernel only (lenv_dueling_se_inner_loop*, plain-DQN mode for DDQN). */
+    int32_t same_action_num, pad2_;
 } lenv_ddqn_cfg;
 
 /* RNG tapes (parity mode).  Per-chain rows: element [c*stride + n]; all DEVICE pointers. */
@@ -180,6 +184,8 @@ typedef struct {
     int32_t count_based;                /* ql_cb / sarsa_cb (agents/agent_utils.py:57-64): reward += beta / (sqrt(n(s,a)) + 1e-9) */
     double solved_reward, alpha, gamma, eps_init, eps_min, eps_decay, beta;
     int64_t step_budget;                /* env-step stand-in for time_remaining, see lenv_ddqn_cfg::step_budget */
+    int32_t same_action_num, pad2_;     /* env steps per chosen action (base_agent.py:104,194; env_wrapper.py:56-61: stop at done, python-float
+                                           reward sum); 0 and 1 both mean 1 */
 } lenv_ql_cfg;
 
 typedef struct {

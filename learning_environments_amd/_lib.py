@@ -37,7 +37,8 @@ class DdqnCfg(C.Structure):
                 ("step_budget", C.c_int64),
                 ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("icm_pad_", C.c_int32),
                 ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
-                ("synthetic_env_type", C.c_int32), ("reward_env_type", C.c_int32)]
+                ("synthetic_env_type", C.c_int32), ("reward_env_type", C.c_int32),
+                ("same_action_num", C.c_int32), ("pad2_", C.c_int32)]
 
 
 class Tapes(C.Structure):
@@ -70,7 +71,7 @@ class QlCfg(C.Structure):
                 ("init_episodes", C.c_int32), ("early_out_num", C.c_int32), ("batch_size", C.c_int32), ("rng_mode", C.c_int32),
                 ("agent_kind", C.c_int32), ("count_based", C.c_int32),
                 ("solved_reward", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double), ("eps_init", C.c_double),
-                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double), ("step_budget", C.c_int64)]
+                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double), ("step_budget", C.c_int64), ("same_action_num", C.c_int32), ("pad2_", C.c_int32)]
 
 
 class QlOut(C.Structure):

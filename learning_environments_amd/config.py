@@ -36,8 +36,6 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
     a = config["agents"][agent_key]
     dueling = agent_key == "duelingddqn"
     S, A = ENV_DIMS[env_name]
-    if a["same_action_num"] != 1:
-        raise NotImplementedError("same_action_num != 1")
     _refuse_layer_norm(config, e, a)
 
     def val(v):  # env_factory.py:54-58: list-valued entries -> float(value[1])
@@ -59,6 +57,7 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
                        eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]),
                        adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
                        step_budget=int(a.get("step_budget", 0)))      # env-step stand-in for time_remaining (base_agent.py:30-47)
+    cfg.same_action_num = int(a["same_action_num"])    # env steps per chosen action (base_agent.py:104,194); > 1: GEMM-tiled kernel
     if icm:                                          # config section `icm` (agents/DDQN.py:43-49)
         ic = config["agents"]["icm"]
         cfg.icm_enabled, cfg.icm_feature_dim, cfg.icm_hidden = 1, int(ic["feature_dim"]), int(ic["hidden_size"])
@@ -124,8 +123,6 @@ def ql_cfg_from_config(config, tables, rng_mode=_lib.RNG_COUNTER, **overrides):
     if name not in TABULAR_AGENTS:
         raise NotImplementedError("ql_cfg_from_config: agent '%s'" % name)
     a = config["agents"]["sarsa" if name.startswith("sarsa") else "ql"]      # SARSA reads its own section (SARSA.py:14-18)
-    if a["same_action_num"] != 1:
-        raise NotImplementedError("same_action_num != 1")
     if int(a["rb_size"]) != 1:
         raise NotImplementedError("tabular agents with rb_size != 1 (the reference configs keep the single latest transition)")
     _refuse_layer_norm(config, e, None)
@@ -142,6 +139,7 @@ def ql_cfg_from_config(config, tables, rng_mode=_lib.RNG_COUNTER, **overrides):
                      batch_size=int(a["batch_size"]), rng_mode=int(rng_mode), solved_reward=float(val(e["solved_reward"])),
                      alpha=float(a["alpha"]), gamma=float(a["gamma"]), eps_init=float(a["eps_init"]),
                      eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]), step_budget=int(a.get("step_budget", 0)))
+    cfg.same_action_num = int(a["same_action_num"])
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     // gtn.synthetic_env_type 1: the agent trains on a RewardEnv over the REAL env (envs/reward_env.py:61-133): the transition is
     // the real one, the reward goes through the perturbed reward network (state_dim -> se_hidden -> 1; reward types 0,1,2,5,6)
     const bool reward_env = FIXED ? false : cfg.synthetic_env_type == 1;      // the specialised shapes are VirtualEnv configurations
+    const int k_rep = FIXED ? 1 : (cfg.same_action_num > 1 ? cfg.same_action_num : 1);   // env steps per chosen action (same_action_num)
     const int rtype = cfg.reward_env_type;
     const int Drn = rtype == 0 ? 1 : S;                   // RewardEnv.build_reward_net: a 1-input dummy net for type 0
     float *rn_w = se_w0T, *rn_h = se_h;                   // RewardEnv: flat reward-net parameters / its hidden layer (LDS)
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
         if (tid == 0) ictrl[0] = 0;
         __syncthreads();
         float *xt = xs2;                                   // [T][S] observation batch (xs2 is free outside learn)
-        for (int t = 0; t < cfg.max_steps; ++t) {
+        for (int t = 0; t < cfg.max_steps; t += k_rep) {   // base_agent.py:194 range(0, max_steps, same_action_num)
             if (tid < T) { float obs[8]; obs_of(dstate + tid * 4, obs); for (int i = 0; i < S; ++i) xt[tid * S + i] = obs[i]; }
             __syncthreads();
             forward(online, xt, T, hid_t, feat_t, v1_t, a1_t, qv, false);
@@ -340,13 +341,22 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 int am = 0; float best = qv[tid * A];
                 for (int aa = 1; aa < A; ++aa) { const float v = qv[tid * A + aa]; if (v > best) { best = v; am = aa; } }
                 double st[4] = { dstate[tid * 4], dstate[tid * 4 + 1], dstate[tid * 4 + 2], dstate[tid * 4 + 3] };
-                double rew; int dn;
-                real_env_step(env_id, st, am, rew, dn);
+                // EnvWrapper.step on the real env (env_wrapper.py:56-61): the action same_action_num times or until done (TimeLimit:
+                // done after max_steps env steps), python-float reward sum
+                double rsum = 0.0;
+                int nstep = 0;
+                for (int r_ = 0; r_ < k_rep; ++r_) {
+                    double rew; int dn;
+                    real_env_step(env_id, st, am, rew, dn);
+                    rsum = rsum + rew;
+                    ++nstep;
+                    if (tlen[tid] + nstep >= cfg.max_steps) dn = 1;
+                    if (dn) { alive[tid] = 0; break; }
+                }
                 for (int i = 0; i < 4; ++i) dstate[tid * 4 + i] = st[i];
-                ep_rew[tid] = ep_rew[tid] + (float)rew;
-                tlen[tid] = tlen[tid] + 1;
-                atomicAdd(const_cast<int *>(&ictrl[0]), 1);
-                if (dn) alive[tid] = 0;
+                ep_rew[tid] = ep_rew[tid] + (float)rsum;
+                tlen[tid] = tlen[tid] + nstep;
+                atomicAdd(const_cast<int *>(&ictrl[0]), nstep);
             }
             __syncthreads();
             int any = 0;
@@ -382,8 +392,8 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
             if (reward_env) { for (int i = 0; i < 4; ++i) tstate[i] = st0[i]; ictrl[5] = 0; }   // RewardEnv.reset: real env state; no phi(s) yet
         }
         __syncthreads();
-        int ep_len = 0;
-        for (int t = 0; t < cfg.max_steps; ++t) {
+        int ep_len = 0, env_steps = 0;
+        for (int t = 0; t < cfg.max_steps; t += k_rep) {         // base_agent.py:104 range(0, max_steps, same_action_num)
             PT_MARK(9);
             const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
             const int new_pos = train_steps % rb_cap;
@@ -433,39 +443,55 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                     }
                     __syncthreads();
                 };
-                if (tid == 0) {
-                    double st[4] = { tstate[0], tstate[1], tstate[2], tstate[3] };
-                    double rew; int dn;
-                    real_env_step(env_id, st, action, rew, dn);
-                    if (t + 1 >= cfg.max_steps) dn = 1;
-                    for (int i = 0; i < 4; ++i) tstate[i] = st[i];
-                    float obs[8];
-                    obs_of(st, obs);
-                    for (int i = 0; i < S; ++i) newrow[S + 1 + i] = obs[i];
-                    ctrl[16] = (float)rew; newrow[2 * S + 2] = dn ? 1.0f : 0.0f;
-                }
                 if (tid >= 64 && tid < 64 + S) newrow[tid - 64] = state[tid - 64];
                 if (tid == 128) newrow[S] = (float)action;
-                __syncthreads();
-                if (rtype != 0) {
-                    if ((rtype == 1 || rtype == 2) && ictrl[5] == 0) rn_phi(state, 14);      // phi(s): carried over after the first step
-                    rn_phi(newrow + S + 1, 15);
-                }
-                if (tid == 0) {
-                    const float g32 = (float)cfg.gamma, r32 = ctrl[16], phi_s = ctrl[14], phi_s2 = ctrl[15];
-                    float shaped;
-                    switch (rtype) {
-                    case 0: shaped = r32; break;
-                    case 1: shaped = g32 * phi_s2 - phi_s; break;
-                    case 2: shaped = (r32 + g32 * phi_s2) - phi_s; break;
-                    case 5: shaped = phi_s2; break;
-                    default: shaped = r32 + phi_s2; break;             // 6
+                // EnvWrapper.step (env_wrapper.py:56-61): the action same_action_num times or until done, python-float sum of the
+                // shaped rewards (thread 0 keeps it)
+                double rsum = 0.0;
+                for (int r_ = 0; r_ < k_rep; ++r_) {
+                    ++env_steps;
+                    if (tid == 0) {
+                        double st[4] = { tstate[0], tstate[1], tstate[2], tstate[3] };
+                        double rew; int dn;
+                        real_env_step(env_id, st, action, rew, dn);
+                        if (env_steps >= cfg.max_steps) dn = 1;
+                        for (int i = 0; i < 4; ++i) tstate[i] = st[i];
+                        float obs[8];
+                        obs_of(st, obs);
+                        for (int i = 0; i < S; ++i) newrow[S + 1 + i] = obs[i];
+                        ctrl[16] = (float)rew; newrow[2 * S + 2] = dn ? 1.0f : 0.0f;
                     }
-                    newrow[2 * S + 1] = shaped;
-                    ctrl[14] = phi_s2; ictrl[5] = 1;
+                    __syncthreads();
+                    if (rtype != 0) {
+                        if ((rtype == 1 || rtype == 2) && ictrl[5] == 0) rn_phi(state, 14);      // phi(s): carried over after the first step
+                        rn_phi(newrow + S + 1, 15);
+                    }
+                    if (tid == 0) {
+                        const float g32 = (float)cfg.gamma, r32 = ctrl[16], phi_s = ctrl[14], phi_s2 = ctrl[15];
+                        float shaped;
+                        switch (rtype) {
+                        case 0: shaped = r32; break;
+                        case 1: shaped = g32 * phi_s2 - phi_s; break;
+                        case 2: shaped = (r32 + g32 * phi_s2) - phi_s; break;
+                        case 5: shaped = phi_s2; break;
+                        default: shaped = r32 + phi_s2; break;             // 6
+                        }
+                        rsum = rsum + (double)shaped;
+                        newrow[2 * S + 1] = (float)rsum;
+                        ctrl[14] = phi_s2; ictrl[5] = 1;
+                    }
+                    if (r_ + 1 < k_rep) {
+                        __syncthreads();
+                        if (newrow[2 * S + 2] > 0.5f) break;                          // uniform: the repeats stop at done
+                        __syncthreads();
+                    }
                 }
             } else {
-            // ---- EnvWrapper.step -> VirtualEnv.step: x = [onehot(action), state] ----
+            // ---- EnvWrapper.step -> VirtualEnv.step: x = [onehot(action), state]; same_action_num SE steps whatever the done flag says,
+            // fp32 reward sum (env_wrapper.py:24-29) ----
+            if (tid >= 64 && tid < 64 + S) newrow[tid - 64] = state[tid - 64];
+            if (tid == 128) newrow[S] = (float)action;
+            for (int r_ = 0; r_ < k_rep; ++r_) {
             for (int uu = tid; uu < 3 * Hse; uu += DNT) {
                 const int net = uu / Hse, j = uu - net * Hse;
                 const float *w = se_w0T + net * K * Hse + j;
@@ -497,10 +523,16 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 for (int j = 0; j < Hse; ++j) acc = fma32(h[j], w[j], acc);
                 acc = acc + se_bout[tid];
                 // ReplayBuffer.add (utils.py:24-32): row = [s, a, s', r, done]
-                if (tid < S) newrow[S + 1 + tid] = acc; else newrow[2 * S + 1 + (tid - S)] = acc;
+                if (tid < S) newrow[S + 1 + tid] = acc;
+                else if (tid == S) newrow[2 * S + 1] = r_ == 0 ? acc : newrow[2 * S + 1] + acc;
+                else newrow[2 * S + 2] = acc;
             }
-            if (tid >= 64 && tid < 64 + S) newrow[tid - 64] = state[tid - 64];
-            if (tid == 128) newrow[S] = (float)action;
+            if (r_ + 1 < k_rep) {                              // the next repeat starts from the state the SE just produced
+                __syncthreads();
+                if (tid < S) state[tid] = newrow[S + 1 + tid];
+                __syncthreads();
+            }
+            }
             }
             __syncthreads();
             if (tid < 2 * S + 3) rb[(int64_t)new_pos * RS + tid] = newrow[tid];
@@ -513,7 +545,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
             const float done_now = newrow[2 * S + 2];
             __syncthreads();
             if (tid < S) state[tid] = newrow[S + 1 + tid];
-            ++ep_len; ++train_steps;
+            ep_len += k_rep; ++train_steps;                  // base_agent.py:122: episode_length += same_action_num
             __syncthreads();
             PT_MARK(1);
 
@@ -786,6 +818,7 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     if (L < 1 || L > D_MAXL || H < 1 || H > D_MAXH || F < 1 || F > D_MAXW || B < 1 || B > D_MAXB || T < 1 || T > D_MAXW || cfg->se_layers < 1 || cfg->se_layers > D_MAXL)
         return LENV_ERR_UNSUPPORTED;
     if (cfg->synthetic_env_type == 1 && cfg->se_layers != 1) return LENV_ERR_UNSUPPORTED;    // the reward net over a real env: one hidden layer here
+    if (cfg->same_action_num < 0 || cfg->same_action_num > 64) return LENV_ERR_UNSUPPORTED;
     if (!((cfg->env_id == LENV_ENV_CARTPOLE && S == 4 && A == 2) || (cfg->env_id == LENV_ENV_ACROBOT && S == 6 && A == 3) ||
           (cfg->env_id == LENV_ENV_MOUNTAINCAR && S == 2 && A == 3)))
         return LENV_ERR_UNSUPPORTED;
@@ -852,7 +885,7 @@ extern "C" int lenv_dueling_team_size(const lenv_ddqn_cfg *cfg, int64_t chains)
     if (!cfg || chains < 1) return LENV_ERR_INVALID;
     const char *nw_ = getenv("LENV_NO_WAVECHAIN"), *nf_ = getenv("LENV_NO_FIXED_SHAPE");
     if ((nw_ && nw_[0] == '1') || (nf_ && nf_[0] == '1') || cfg->icm_enabled || cfg->rng_mode != LENV_RNG_COUNTER || cfg->synthetic_env_type != 0 ||
-        !lenv_wc_dueling_shape(cfg))
+        cfg->same_action_num > 1 || !lenv_wc_dueling_shape(cfg))
         return 1;
     return lenv_wc_dueling_team(chains);
 }
@@ -926,12 +959,13 @@ extern "C" int lenv_dueling_se_inner_loop_icm(const lenv_ddqn_cfg *cfg, const le
         auto matches = [&](const DuelShape &sp) {
             return cfg->agent_kind == sp.kind && cfg->env_id == sp.env && cfg->state_dim == sp.S && cfg->num_actions == sp.A &&
                    (sp.kind == 0 || cfg->feature_dim == sp.F) && cfg->q_hidden == sp.H && cfg->q_layers == sp.L && cfg->batch_size == sp.B &&
-                   cfg->se_hidden == sp.Hse && cfg->test_episodes == sp.T && cfg->q_act == sp.q_act && cfg->se_act == sp.se_act;
+                   cfg->se_hidden == sp.Hse && cfg->test_episodes == sp.T && cfg->q_act == sp.q_act && cfg->se_act == sp.se_act && cfg->same_action_num <= 1;
         };
         // production launches of a wave-chain shape (dueling_wavechain.hip): LENV_NO_WAVECHAIN=1 keeps the GEMM-queue kernel (A/B runs)
         const char *nw_ = getenv("LENV_NO_WAVECHAIN");
         const bool no_wc = nw_ && nw_[0] == '1';
-        if (!off && !no_wc && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action && cfg->synthetic_env_type == 0) {
+        if (!off && !no_wc && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action && cfg->synthetic_env_type == 0 &&
+            cfg->same_action_num <= 1) {
             const int wshape = lenv_wc_dueling_shape(cfg);
             if (wshape) {
                 return lenv_wc_dueling_launch(wshape, cfg, theta, eps, worker, sign, agent_init, rng_keys, chains, a.arena, a.arena_stride, a.rb_cap,

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
     int status = 0, episodes_run = 0;
     int64_t n_eps = 0, n_act = 0, train_steps = 0, learn_steps = 0, test_steps = 0;
     double eps_g = cfg.eps_init;
+    const int k_rep = cfg.same_action_num > 1 ? cfg.same_action_num : 1;   // env steps per chosen action
 
     // BaseAgent.test; with `budgeted` the time_is_up check of base_agent.py:177-184 runs before every episode against the
     // env steps this test has used (`remaining` = budget left when the test starts) and pads like base_agent.py:33-36
@@ -166,13 +167,19 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
             }
             int s = cfg.start_state;
             float ep_reward = 0.0f;                                    // fp32 tensor accumulation, base_agent.py:212
-            for (int st = 0; st < cfg.max_steps; ++st) {
+            int dn = 0, el = 0;
+            for (int st = 0; st < cfg.max_steps && !dn; st += k_rep) {     // base_agent.py:194 range(0, max_steps, same_action_num)
                 const int ac = ql_argmax_f32(q + s * A, A);
-                const int dn = a.done[s * A + ac];
-                ep_reward = ep_reward + (float)a.reward[s * A + ac];
-                s = a.next_state[s * A + ac];
-                ++test_steps; ++used;
-                if (dn) break;
+                double rsum = 0.0;                                     // EnvWrapper.step: python-float sum, the repeats stop at done
+                for (int r_ = 0; r_ < k_rep; ++r_) {
+                    dn = a.done[s * A + ac];
+                    rsum = rsum + a.reward[s * A + ac];
+                    s = a.next_state[s * A + ac];
+                    ++test_steps; ++used; ++el;
+                    if (el >= cfg.max_steps) dn = 1;
+                    if (dn) break;
+                }
+                ep_reward = ep_reward + (float)rsum;
             }
             rets[te] = (double)ep_reward;
         }
@@ -185,8 +192,8 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
         if (cfg.step_budget > 0 && train_steps + test_steps > cfg.step_budget) { timed_out_at = episode; break; }
         if (episode == 0) eps_g = cfg.eps_init;                       // QL.py:101-106
         else { eps_g *= cfg.eps_decay; if (eps_g < cfg.eps_min) eps_g = cfg.eps_min; }
-        int s = cfg.start_state, ep_len = 0;
-        for (int st = 0; st < cfg.max_steps; ++st) {
+        int s = cfg.start_state, ep_len = 0, env_steps = 0;
+        for (int st = 0; st < cfg.max_steps; st += k_rep) {            // base_agent.py:104 range(0, max_steps, same_action_num)
             double u;
             if (tape) { if (n_eps >= a.tapes.eps_uniform_stride) { status = -2; u = 1.0; } else u = a.tapes.eps_uniform[chain * a.tapes.eps_uniform_stride + n_eps]; }
             else u = u64_to_unit(rng_u64(key, STREAM_EPS, (uint64_t)n_eps));
@@ -198,10 +205,20 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
                 else ac = (int)u64_to_below(rng_u64(key, STREAM_ACTION, (uint64_t)n_act), (uint32_t)A);
                 ++n_act;
             } else ac = ql_argmax_f32(q + s * A, A);
-            const int s2 = a.next_state[s * A + ac];
-            int dn = a.done[s * A + ac];
-            if (st + 1 >= cfg.max_steps) dn = 1;                       // gym.wrappers.TimeLimit
-            const double r = (double)shaped[s * A + ac];
+            // EnvWrapper.step (env_wrapper.py:56-61): the action same_action_num times or until done (gym.wrappers.TimeLimit: done after
+            // max_steps env steps), the shaped rewards summed as python floats and stored as one fp32 value
+            int s2 = s, dn = 0;
+            double rsum = 0.0;
+            for (int r_ = 0; r_ < k_rep; ++r_) {
+                const int sc = s2;
+                dn = a.done[sc * A + ac];
+                ++env_steps;
+                if (env_steps >= cfg.max_steps) dn = 1;
+                rsum = rsum + (double)shaped[sc * A + ac];
+                s2 = a.next_state[sc * A + ac];
+                if (dn) break;
+            }
+            const double r = (double)(float)rsum;
             // QL.learn (QL.py:37-75) / SARSA.learn (SARSA.py:36-60), only once episode >= init_episodes (base_agent.py:127-128)
             if (episode >= cfg.init_episodes) {
                 for (int k = 0; k < cfg.batch_size; ++k) {
@@ -239,7 +256,7 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
                 a.out.trace_reward_done[k * 2] = (float)r; a.out.trace_reward_done[k * 2 + 1] = dn ? 1.0f : 0.0f;
             }
             s = s2;
-            ++ep_len; ++train_steps;
+            ep_len += k_rep; ++train_steps;
             if (dn) break;
         }
         ++episodes_run;

@@ -1385,7 +1385,7 @@ def _gen_g11_body(cfg, n, GTN_Master, GTN_Worker, shutil):
 def main():
     # no arguments (or "all"): every fixture under tests/golden is regenerated (the full-shape runs g8df / g8tf take minutes each)
     ALL = ["g1", "g1ln", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x",
-           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8df", "g8l2", "g8m", "g8r", "g8i", "g8v", "g11", "g4td", "g8td"]
+           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8df", "g8l2", "g8m", "g8r", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k"]
     which = sys.argv[1:] or ALL
     if "all" in which:
         which = ALL
@@ -1498,6 +1498,19 @@ def main():
         gen_g8("g8r6_calc_score_cartpole_ddqn_reward_env_t6", train_episodes=3, done_bias_shift=0.0, seed=851, max_steps=30,
                env_yaml="default_config_cartpole_reward_env.yaml", reward_env_type=6,
                agent_over={"init_episodes": 1, "test_episodes": 2, "batch_size": 24}, env_over={"activation_fn": "tanh", "hidden_size": 24})
+    if "g8k" in which:
+        # same_action_num > 1 outside the TD3 family (agents/base_agent.py:104,194; envs/env_wrapper.py:24-29,56-61; no shipped DDQN
+        # config sets it): DDQN on a CartPole VirtualEnv with 2 steps per action (odd max_steps: the last action of an episode gets
+        # one env step in the real test env), DuelingDDQN on an Acrobot VirtualEnv with 3, DDQN on the CartPole RewardEnv with 2
+        gen_g8("g8k_calc_score_cartpole_ddqn_same_action_2", train_episodes=4, done_bias_shift=-0.3, seed=860, max_steps=25,
+               agent_over={"init_episodes": 1, "test_episodes": 3, "batch_size": 24, "same_action_num": 2})
+        gen_g8("g8kd_calc_score_acrobot_duelingddqn_same_action_3", train_episodes=3, done_bias_shift=-0.3, seed=861, max_steps=20,
+               env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="duelingddqn",
+               agent_over={"init_episodes": 1, "test_episodes": 2, "batch_size": 16, "hidden_size": 24, "feature_dim": 20, "same_action_num": 3},
+               env_over={"hidden_size": 20, "solved_reward": 0.5})
+        gen_g8("g8kr_calc_score_cartpole_ddqn_reward_env_same_action_2", train_episodes=4, done_bias_shift=0.0, seed=862, max_steps=31,
+               env_yaml="default_config_cartpole_reward_env.yaml", reward_env_type=2,
+               agent_over={"init_episodes": 1, "test_episodes": 2, "batch_size": 32, "same_action_num": 2})
     if "g8i" in which:
         # DDQN / DuelingDDQN with the ICM baseline inside learn() (models/icm_baseline.py): CartPole = BCE inverse loss on one
         # action logit, Acrobot = cross-entropy over three
@@ -1539,6 +1552,11 @@ def main():
         gen_g9("g9c_calc_score_cliff_ql_cb", seed=903, agent_name="QL_cb", agent_over={"beta": 0.3}, eps_over=0.05)
         gen_g9("g9sc_calc_score_cliff_sarsa_cb", seed=904, agent_name="SARSA_cb", agent_over={"beta": 0.3})
         gen_g9("g9i_calc_score_cliff_ql_init2", seed=905, eps_over=0.2, agent_over={"init_episodes": 2, "train_episodes": 12})
+    if "g9k" in which:
+        # same_action_num > 1 for the tabular agents (no shipped gridworld config sets it): every chosen action is applied twice /
+        # three times, the repeats stop at the cliff / goal / TimeLimit, the shaped rewards are summed
+        gen_g9("g9k_calc_score_cliff_ql_same_action_2", seed=906, eps_over=0.15, agent_over={"same_action_num": 2})
+        gen_g9("g9ks_calc_score_cliff_sarsa_same_action_3", seed=907, agent_name="SARSA", eps_over=0.1, agent_over={"same_action_num": 3})
     if "g10" in which:
         gen_g10()
     if "g8" in which:

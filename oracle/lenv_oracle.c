@@ -897,15 +897,23 @@ static void run_test_phase(const orc_ddqn_cfg *cfg, const orc_mlp_desc *qd, cons
         double st[4];
         draw_reset(rng, 0, rng->n_test_ep++, st);
         float ep_reward = 0.0f;   /* fp32 tensor accumulation, base_agent.py:212 */
-        for (int t = 0; t < cfg->max_steps; ++t) {
+        const int k_rep = cfg->same_action_num > 1 ? cfg->same_action_num : 1;
+        int env_steps = 0, done = 0;
+        for (int t = 0; t < cfg->max_steps && !done; t += k_rep) {       /* base_agent.py:194 range(0, max_steps, same_action_num) */
             real_env_obs(cfg->env_id, st, obs);
             int act = agent_greedy_action(cfg, online, obs, z, a);
-            double rew; int done;
-            real_env_step(cfg->env_id, st, act, &rew, &done);
-            /* TimeLimit: elapsed >= max_steps -> done (the loop bound does the same) */
-            ep_reward = ep_reward + (float)rew;
-            ++*test_steps;
-            if (done) break;
+            /* EnvWrapper.step on a real env (env_wrapper.py:56-61): reward_sum = 0; += reward; break on done (TimeLimit: elapsed >=
+             * max_steps -> done) */
+            double rsum = 0.0;
+            for (int r_ = 0; r_ < k_rep; ++r_) {
+                double rew;
+                real_env_step(cfg->env_id, st, act, &rew, &done);
+                rsum = rsum + rew;
+                ++*test_steps; ++env_steps;
+                if (env_steps >= cfg->max_steps) done = 1;
+                if (done) break;
+            }
+            ep_reward = ep_reward + (float)rsum;
         }
         returns[te] = (double)ep_reward;
     }
@@ -1072,31 +1080,50 @@ int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const
         real_env_obs(cfg->env_id, st0, state);   /* VirtualEnv.reset / RewardEnv.reset -> fp32 real-env reset state (virtual_env.py:35-41) */
         float phi_cache = 0.0f;                  /* RewardEnv: phi(s) of the state the env is in */
         int have_phi = 0;
-        int ep_len = 0;
-        for (int t = 0; t < cfg->max_steps; ++t) {
+        int ep_len = 0, env_steps = 0;
+        const int k_rep = cfg->same_action_num > 1 ? cfg->same_action_num : 1;
+        for (int t = 0; t < cfg->max_steps; t += k_rep) {                       /* base_agent.py:104 range(0, max_steps, same_action_num) */
             /* select_train_action (DDQN.py:97-104) */
             int act, explored = 0;
             double u = draw_eps_uniform(&rng);
             if (u < eps) { act = draw_rand_action(&rng); explored = 1; }
             else act = agent_greedy_action(cfg, online, state, z, a);
-            /* EnvWrapper.step -> VirtualEnv.step */
-            for (int i = 0; i < A; ++i) x[i] = (i == act) ? 1.0f : 0.0f;
-            for (int i = 0; i < S; ++i) x[A + i] = state[i];
-            float reward, done;
+            /* EnvWrapper.step: same_action_num env steps with the one action */
+            float reward = 0.0f, done = 0.0f, cur[64];
+            memcpy(cur, state, sizeof(float) * S);
             if (reward_env) {
-                /* RewardEnv.step (reward_env.py:61-66): the real env's transition (TimeLimit: done at max_steps), the reward
-                 * through _calc_reward with the perturbed reward network (se_params) */
-                double rew; int dn_i;
-                real_env_step(cfg->env_id, st0, act, &rew, &dn_i);
-                if (t + 1 >= cfg->max_steps) dn_i = 1;
-                real_env_obs(cfg->env_id, st0, next_state);
-                reward = rn_shape_one(rtype, S, 0, &rd, se_params, g32, state, next_state, NULL, (float)rew, &phi_cache, have_phi, z, a);
-                have_phi = 1;
+                /* real branch (env_wrapper.py:56-61) over RewardEnv.step (reward_env.py:61-66): the real env's transition (TimeLimit:
+                 * done at max_steps), the reward through _calc_reward with the perturbed reward network (se_params); the repeats stop
+                 * at done, the shaped rewards are summed as python floats */
+                double rsum = 0.0;
+                int dn_i = 0;
+                for (int r_ = 0; r_ < k_rep; ++r_) {
+                    double rew;
+                    real_env_step(cfg->env_id, st0, act, &rew, &dn_i);
+                    ++env_steps;
+                    if (env_steps >= cfg->max_steps) dn_i = 1;
+                    real_env_obs(cfg->env_id, st0, next_state);
+                    const float sh = rn_shape_one(rtype, S, 0, &rd, se_params, g32, cur, next_state, NULL, (float)rew, &phi_cache, have_phi, z, a);
+                    have_phi = 1;
+                    rsum = rsum + (double)sh;
+                    memcpy(cur, next_state, sizeof(float) * S);
+                    if (dn_i) break;
+                }
+                reward = (float)rsum;
                 done = dn_i ? 1.0f : 0.0f;
             } else {
-            mlp_forward_one(&sn, se_params, x, next_state, z, a);
-            mlp_forward_one(&rn, se_params + ps, x, &reward, z, a);
-            mlp_forward_one(&dn, se_params + ps + pr, x, &done, z, a);
+                /* virtual branch (env_wrapper.py:17-29) over VirtualEnv.step: every repeat runs whatever the done flag says, the fp32
+                 * rewards are added up, the last state / done flag are returned */
+                for (int r_ = 0; r_ < k_rep; ++r_) {
+                    float r1;
+                    for (int i = 0; i < A; ++i) x[i] = (i == act) ? 1.0f : 0.0f;
+                    for (int i = 0; i < S; ++i) x[A + i] = cur[i];
+                    mlp_forward_one(&sn, se_params, x, next_state, z, a);
+                    mlp_forward_one(&rn, se_params + ps, x, &r1, z, a);
+                    mlp_forward_one(&dn, se_params + ps + pr, x, &done, z, a);
+                    reward = r_ == 0 ? r1 : reward + r1;
+                    memcpy(cur, next_state, sizeof(float) * S);
+                }
             }
             /* ReplayBuffer.add (utils.py:24-32) */
             float *row = rb + rb_ptr * row_stride;
@@ -1129,7 +1156,7 @@ int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const
                 trace->reward[k] = reward; trace->done[k] = done; trace->loss[k] = loss;
             }
             memcpy(state, next_state, sizeof(float) * S);
-            ++ep_len; ++train_steps;
+            ep_len += k_rep; ++train_steps;                                         /* base_agent.py:122 episode_length += same_action_num */
             if (done > 0.5f) break;
         }
         ++episodes_run;
@@ -1289,6 +1316,7 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
     int64_t n_eps = 0, n_act = 0, train_steps = 0, learn_steps = 0, test_steps = 0;
     int err = 0, episodes_run = 0, n_meter = 0, timed_out = 0;
     double eps = cfg->eps_init;
+    const int k_rep = cfg->same_action_num > 1 ? cfg->same_action_num : 1;
     if (trace) trace->n = 0;
 
 #define QL_TEST_PHASE()                                                                                       \
@@ -1296,13 +1324,19 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
         int s = cfg->start_state;                                                                             \
         float ep_reward = 0.0f;                                                                               \
         tlens[te] = 0;                                                                                        \
-        for (int t = 0; t < cfg->max_steps; ++t) {                                                            \
+        int dn = 0;                                                                                           \
+        for (int t = 0; t < cfg->max_steps && !dn; t += k_rep) {                                              \
             int ac = ql_argmax_f32(q + (size_t)s * A, A);                                                     \
-            int dn = done_tab[s * A + ac];                                                                    \
-            ep_reward = ep_reward + (float)reward[s * A + ac];                                                \
-            s = next_state[s * A + ac];                                                                       \
-            ++test_steps; ++tlens[te];                                                                        \
-            if (dn) break;                                                                                    \
+            double rsum_ = 0.0;                               /* EnvWrapper.step: python-float sum, stop at done */ \
+            for (int r_ = 0; r_ < k_rep; ++r_) {                                                              \
+                dn = done_tab[s * A + ac];                                                                    \
+                rsum_ = rsum_ + reward[s * A + ac];                                                           \
+                s = next_state[s * A + ac];                                                                   \
+                ++test_steps; ++tlens[te];                                                                    \
+                if (tlens[te] >= cfg->max_steps) dn = 1;                                                      \
+                if (dn) break;                                                                                \
+            }                                                                                                 \
+            ep_reward = ep_reward + (float)rsum_;                                                             \
         }                                                                                                     \
         rets[te] = (double)ep_reward;                                                                         \
     }
@@ -1311,8 +1345,8 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
         if (cfg->step_budget > 0 && train_steps + test_steps > cfg->step_budget) { timed_out = 1; break; }   /* time_is_up */
         if (episode == 0) eps = cfg->eps_init;                                  /* QL.py:101-106 */
         else { eps *= cfg->eps_decay; if (eps < cfg->eps_min) eps = cfg->eps_min; }
-        int s = cfg->start_state, ep_len = 0;                                   /* RewardEnv.reset -> real_env.reset() */
-        for (int t = 0; t < cfg->max_steps; ++t) {
+        int s = cfg->start_state, ep_len = 0, env_steps = 0;                    /* RewardEnv.reset -> real_env.reset() */
+        for (int t = 0; t < cfg->max_steps; t += k_rep) {                       /* base_agent.py:104 range(0, max_steps, same_action_num) */
             double u;
             if (cfg->rng_mode == ORC_RNG_TAPE) { if (n_eps >= tapes->n_eps_uniform) { err = -2; u = 1.0; } else u = tapes->eps_uniform[n_eps]; }
             else u = u64_to_unit(orc_rng_u64(rng_key, STREAM_EPS, (uint64_t)n_eps));
@@ -1324,11 +1358,20 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
                 else ac = (int)u64_to_below(orc_rng_u64(rng_key, STREAM_ACTION, (uint64_t)n_act), (uint32_t)A);
                 ++n_act;
             } else ac = ql_argmax_f32(q + (size_t)s * A, A);
-            /* RewardEnv.step (reward_env.py:61-66) + TimeLimit */
-            const int s2 = next_state[s * A + ac];
-            int dn = done_tab[s * A + ac];
-            if (t + 1 >= cfg->max_steps) dn = 1;
-            const double r = (double)shaped[s * A + ac];
+            /* EnvWrapper.step (env_wrapper.py:56-61) over RewardEnv.step (reward_env.py:61-66) + TimeLimit: the action same_action_num
+             * times or until done, the shaped rewards (python floats from .item()) summed and stored as one fp32 value */
+            int s2 = s, dn = 0;
+            double rsum = 0.0;
+            for (int r_ = 0; r_ < k_rep; ++r_) {
+                const int sc = s2;
+                dn = done_tab[sc * A + ac];
+                ++env_steps;
+                if (env_steps >= cfg->max_steps) dn = 1;
+                rsum = rsum + (double)shaped[sc * A + ac];
+                s2 = next_state[sc * A + ac];
+                if (dn) break;
+            }
+            const double r = (double)(float)rsum;
             /* QL.learn (QL.py:37-75) / SARSA.learn (SARSA.py:36-60): batch_size draws of the single stored transition,
              * only once episode >= init_episodes (base_agent.py:127-128) */
             if (episode >= cfg->init_episodes) {
@@ -1366,7 +1409,7 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
                 trace->reward[k] = (float)r; trace->done[k] = dn ? 1.0f : 0.0f;
             }
             s = s2;
-            ++ep_len; ++train_steps;
+            ep_len += k_rep; ++train_steps;
             if (dn) break;
         }
         ++episodes_run;

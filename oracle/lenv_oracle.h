@@ -80,6 +80,8 @@ typedef struct {
      * VirtualEnv; se_hidden / se_layers / se_act then describe the reward network (state_dim -> 1), theta holds its parameters;
      * reward_env_type 0, 1, 2, 5, 6 (the real CartPole / Acrobot step returns no info vector) */
     int32_t synthetic_env_type, reward_env_type;
+    /* same_action_num (base_agent.py:20,104,194; env_wrapper.py:24-29,56-61): env steps per chosen action; 0 and 1 both mean 1 */
+    int32_t same_action_num, pad2_;
 } orc_ddqn_cfg;
 
 /* RNG tapes (parity mode): values the reference drew, in per-stream order. */
@@ -187,6 +189,7 @@ typedef struct {
     int32_t count_based;                /* ql_cb / sarsa_cb (agent_utils.py:57-64): reward += beta / (sqrt(n(s,a)) + 1e-9) */
     double solved_reward, alpha, gamma, eps_init, eps_min, eps_decay, beta;
     int64_t step_budget;
+    int32_t same_action_num, pad2_;     /* env steps per chosen action; 0 and 1 both mean 1 */
 } orc_ql_cfg;
 
 typedef struct {

@@ -35,7 +35,8 @@ class DdqnCfg(C.Structure):
                 ("step_budget", C.c_int64),
                 ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("icm_pad_", C.c_int32),
                 ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
-                ("synthetic_env_type", C.c_int32), ("reward_env_type", C.c_int32)]
+                ("synthetic_env_type", C.c_int32), ("reward_env_type", C.c_int32),
+                ("same_action_num", C.c_int32), ("pad2_", C.c_int32)]
 
 
 class Tapes(C.Structure):
@@ -59,7 +60,7 @@ class QlCfg(C.Structure):
                 ("init_episodes", C.c_int32), ("early_out_num", C.c_int32), ("batch_size", C.c_int32), ("rng_mode", C.c_int32),
                 ("agent_kind", C.c_int32), ("count_based", C.c_int32),
                 ("solved_reward", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double), ("eps_init", C.c_double),
-                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double), ("step_budget", C.c_int64)]
+                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double), ("step_budget", C.c_int64), ("same_action_num", C.c_int32), ("pad2_", C.c_int32)]
 
 
 class QlTrace(C.Structure):
@@ -416,7 +417,7 @@ def ddqn_cfg_from_config(config, grad_chunk=13, rng_mode=0, **overrides):
         overrides.setdefault("icm_eta", float(ic["eta"]))
     a = config["agents"][agent_key]
     S, A = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3), "MountainCar-v0": (2, 3)}[env_name]
-    assert a["same_action_num"] == 1, "same_action_num != 1 not supported by the oracle yet"
+    overrides.setdefault("same_action_num", int(a["same_action_num"]))
     overrides.setdefault("agent_kind", 1 if agent_key == "duelingddqn" else 0)
     overrides.setdefault("feature_dim", int(a.get("feature_dim", 0)))
     cfg = DdqnCfg(env_id=ENV[env_name], state_dim=S, num_actions=A, max_steps=int(e["max_steps"]),
@@ -447,7 +448,6 @@ def ql_cfg_from_config(config, tables, rng_mode=0, **overrides):
     if name not in ("ql", "ql_cb", "sarsa", "sarsa_cb"):
         name = "ql"
     a = config["agents"]["sarsa" if name.startswith("sarsa") else "ql"]
-    assert a["same_action_num"] == 1
     cfg = QlCfg(agent_kind=1 if name.startswith("sarsa") else 0, count_based=1 if name.endswith("_cb") else 0,
                 beta=float(a.get("beta", 0.0)), n_states=tables["n_states"], n_actions=tables["n_actions"], start_state=tables["start_state"],
                 max_steps=int(e["max_steps"]), rn_hidden=int(e["hidden_size"]), rn_layers=int(e["hidden_layer"]),
@@ -457,6 +457,7 @@ def ql_cfg_from_config(config, tables, rng_mode=0, **overrides):
                 rng_mode=rng_mode, solved_reward=float(e["solved_reward"]), alpha=float(a["alpha"]), gamma=float(a["gamma"]),
                 eps_init=float(a["eps_init"]), eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]),
                 step_budget=int(a.get("step_budget", 0)))
+    cfg.same_action_num = int(a["same_action_num"])
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg

@@ -313,7 +313,8 @@ def _ql_cfgs(orc, cfgd, rng_mode, **over):
 
 
 @pytest.mark.parametrize("name", ["g9_calc_score_cliff_a", "g9_calc_score_cliff_b", "g9s_calc_score_cliff_sarsa", "g9c_calc_score_cliff_ql_cb",
-                                  "g9sc_calc_score_cliff_sarsa_cb", "g9i_calc_score_cliff_ql_init2"])
+                                  "g9sc_calc_score_cliff_sarsa_cb", "g9i_calc_score_cliff_ql_init2",
+                                  "g9k_calc_score_cliff_ql_same_action_2", "g9ks_calc_score_cliff_sarsa_same_action_3"])     # same_action_num 2 / 3
 def test_ql_rn_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
     """The tabular agents of select_agent (QL, SARSA, count-based variants; init_episodes gate) against the reference's runs."""
     g = golden(name)
@@ -586,6 +587,64 @@ def test_ddqn_reward_env_tape_mode_vs_reference_and_oracle(eng, orc, golden, nam
         assert np.array_equal(act & 0xFFFF, g["tr_action"]) and np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), g["tr_next_state"])
         np.testing.assert_allclose(il.trace["reward_done"][c, :n, 0].cpu().numpy(), g["tr_reward"], rtol=0, atol=1e-6)
         assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4
+
+
+@pytest.mark.parametrize("name,k", [("g8k_calc_score_cartpole_ddqn_same_action_2", 2), ("g8kd_calc_score_acrobot_duelingddqn_same_action_3", 3),
+                                    ("g8kr_calc_score_cartpole_ddqn_reward_env_same_action_2", 2)])
+def test_ddqn_same_action_num_vs_reference_and_oracle(eng, orc, golden, name, k):
+    """same_action_num > 1 in the DDQN family (GEMM-tiled kernel; the register-resident kernel and the wave-chain kernel refuse it and
+    the engine routes): the reference's runs replayed (tape mode) and three counter-mode chains, bit-equal to the oracle."""
+    g = golden(name)
+    cfgd = json.loads(str(g["config_json"]))
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
+    assert cfg.same_action_num == k
+    n = g["tr_action"].size
+    otapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    o = orc.ddqn_se_chain(ocfg, g["theta"], g["agent_init"], tapes=otapes, trace_cap=n + 8)
+    assert o["rc"] == 0
+    chains = 2
+    tapes = dict(eps_uniform=dev(np.tile(g["tape_eps_uniform"], (chains, 1))),
+                 rand_action=dev(np.tile(g["tape_rand_action"], (chains, 1))),
+                 replay_idx=dev(np.tile(g["tape_replay_idx"].reshape(1, -1), (chains, 1))),
+                 train_reset=dev(np.tile(g["tape_train_reset"][None], (chains, 1, 1))),
+                 test_reset=dev(np.tile(g["tape_test_reset"][None], (chains, 1, 1))))
+    il = eng.InnerLoop(cfg, chains, trace_cap=n + 8)
+    assert il.dueling and il.p_agent == g["agent_init"].size
+    il.run(dev(g["theta"]), None, None, None, dev(np.tile(g["agent_init"], (chains, 1))), tapes=tapes)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        act = il.trace["action"][c, :n].cpu().numpy()
+        assert np.array_equal(act & 0xFFFF, o["trace"]["action"]) and np.array_equal(act & 0xFFFF, g["tr_action"])
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"])
+        assert np.array_equal(il.trace["reward_done"][c, :n, 0].cpu().numpy(), o["trace"]["reward"])
+        assert np.array_equal(il.trace["reward_done"][c, :n, 1].cpu().numpy(), o["trace"]["done"])
+        assert np.array_equal(il.episode_len[c].cpu().numpy(), o["episode_len"]) and np.array_equal(o["episode_len"], g["episode_length_train"])
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(il.final_returns[c].cpu().numpy(), o["final_test_returns"])
+        assert float(il.score[c]) == o["score"] and abs(float(il.score[c]) - float(g["score"])) <= 1e-4
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        np.testing.assert_allclose(il.trace["reward_done"][c, :n, 0].cpu().numpy(), g["tr_reward"], rtol=0, atol=2e-6)
+    # production RNG, perturbed theta, a step budget that cuts the run short
+    ocfg2, cfg2 = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
+    keys = np.array([5, 6, 2 ** 61 + 7], np.uint64)
+    rng = np.random.RandomState(9)
+    eps = (rng.randn(1, g["theta"].size) * 0.03).astype(np.float32)
+    sign = np.array([0.0, 1.0, -1.0], np.float32)
+    init = np.tile(g["agent_init"], (3, 1))
+    il2 = eng.InnerLoop(cfg2, 3, trace_cap=64)
+    il2.run(dev(g["theta"]), dev(eps), dev(np.zeros(3, np.int32)), dev(sign), dev(init), rng_keys=dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il2.status.cpu().tolist() == [0, 0, 0]
+    for c in range(3):
+        w = (np.float32(sign[c]) * eps[0] + g["theta"]).astype(np.float32)
+        o2 = orc.ddqn_se_chain(ocfg2, w, init[c], rng_key=int(keys[c]), trace_cap=64)
+        m = min(o2["trace"]["action"].size, 64)
+        assert np.array_equal(il2.trace["action"][c, :m].cpu().numpy() & 0xFFFF, o2["trace"]["action"][:m])
+        assert np.array_equal(il2.trace["reward_done"][c, :m, 0].cpu().numpy(), o2["trace"]["reward"][:m])
+        assert np.array_equal(il2.episode_len[c].cpu().numpy(), o2["episode_len"])
+        assert float(il2.score[c]) == o2["score"]
+        assert il2.stats[c].cpu().tolist() == [o2["episodes_run"], o2["train_steps"], o2["learn_steps"], o2["test_steps"]]
 
 
 @pytest.mark.parametrize("env_name,family,rtype,act", [("CartPole-v0", "ddqn", 2, "prelu"), ("Acrobot-v1", "duelingddqn", 1, "leakyrelu"),

@@ -306,6 +306,35 @@ def test_g8r_ddqn_on_a_reward_env(golden, name):
     assert abs(out["score"] - float(g["score"])) <= 1e-4
 
 
+@pytest.mark.parametrize("name,k", [("g8k_calc_score_cartpole_ddqn_same_action_2", 2), ("g8kd_calc_score_acrobot_duelingddqn_same_action_3", 3),
+                                    ("g8kr_calc_score_cartpole_ddqn_reward_env_same_action_2", 2)])
+def test_g8k_same_action_num(golden, name, k):
+    """same_action_num > 1 in the DDQN family (agents/base_agent.py:104,122,194; envs/env_wrapper.py:24-29 virtual: every repeat runs,
+    fp32 reward sum; :56-61 real: the repeats stop at done, python-float sum): reference runs on a CartPole / Acrobot VirtualEnv and
+    on the CartPole RewardEnv replayed from their recorded draws."""
+    import json
+    g = golden(name)
+    cfgd = json.loads(str(g["config_json"]))
+    cfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
+    assert cfg.same_action_num == k
+    tapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
+    n = g["tr_action"].size
+    out = orc.ddqn_se_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 10)
+    assert out["rc"] == 0
+    tr = out["trace"]
+    assert tr["action"].size == n and np.array_equal(tr["action"], g["tr_action"])
+    np.testing.assert_allclose(tr["next_state"], g["tr_next_state"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(tr["reward"], g["tr_reward"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(tr["done"], g["tr_done"], rtol=0, atol=2e-6)
+    losses = tr["loss"][~np.isnan(tr["loss"])]
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-4, atol=1e-7)
+    assert np.array_equal(out["episode_len"], g["episode_length_train"])             # episode_length += same_action_num per agent step
+    assert out["episode_len"].max() > g["tr_action"].size / len(out["episode_len"])  # ... so it exceeds the number of agent steps
+    np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out["final_test_returns"], g["reward_list_test"], rtol=0, atol=1e-4)
+    assert abs(out["score"] - float(g["score"])) <= 1e-4
+
+
 def test_vary_hyperparameter_draw():
     """The package's sampler (agents/vary.py) against the oracle's numpy restatement of ConfigSpace 0.4.13 on the same
     uniforms, the reference's bounds, and the log-uniform shape of the draw."""
@@ -368,7 +397,8 @@ def test_g2_reward_env_shaping(golden):
 
 
 @pytest.mark.parametrize("name", ["g9_calc_score_cliff_a", "g9_calc_score_cliff_b", "g9s_calc_score_cliff_sarsa", "g9c_calc_score_cliff_ql_cb",
-                                  "g9sc_calc_score_cliff_sarsa_cb", "g9i_calc_score_cliff_ql_init2"])
+                                  "g9sc_calc_score_cliff_sarsa_cb", "g9i_calc_score_cliff_ql_init2",
+                                  "g9k_calc_score_cliff_ql_same_action_2", "g9ks_calc_score_cliff_sarsa_same_action_3"])     # same_action_num 2 / 3
 def test_g9_calc_score_cliff(golden, name):
     """cfg 4: integer-state path.  Trajectories, Q-table argmax decisions, episode lengths and returns are EXACT -- for QL and
     for the other tabular agents of select_agent (SARSA, count-based QL / SARSA) and with init_episodes > 0."""
