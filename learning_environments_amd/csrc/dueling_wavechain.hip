@@ -146,7 +146,6 @@ template <int SHAPE> __device__ __noinline__ void wc_forward_thin_layers(const W
     const float *X = uni_ptr(X_);
     const int I = uni(I_);
     float *imgX = bufA;                                  // thin-product activation images [unit][16 or 32] live in bufA
-    auto dump_of = [&](int which, int blk) { return wc_dump(dumps, which, blk); };
     WSUB_DECL;
     constexpr int IW = T <= 16 ? 16 : 32;               // samples per image row (the 16x16x4 tiles take up to 16)
     float *imgY = bufA + IW * W, *imgZ = bufA + 2 * IW * W;
@@ -883,12 +882,12 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     using namespace wcp;
     extern __shared__ __align__(16) float lds[];
     constexpr WcShape SP = kWcShapes[SHAPE];
-    constexpr int S = SP.S, A = SP.A, K = S + A, Hse = SP.Hse, T = SP.T, B = WC_B, ACT = SP.q_act;
+    constexpr int S = SP.S, A = SP.A, K = S + A, Hse = SP.Hse, T = SP.T, B = WC_B;
     static_assert(S % 2 == 0 && S <= 8 && A <= 3 && T <= 32 && Hse <= 128, "shape limits of the wave-chain kernel");
     const lenv_ddqn_cfg &cfg = a.cfg;
     Lane L;
     L.init();
-    const int tid = L.tid, wave = L.wave;
+    const int tid = L.tid;
     // a chain on a team of G workgroups (1 or 2): block x + 8 k is member k % G of chain 8 (k / G) + x, so the members share an XCD
     const int G = a.G;
     const int g = G == 1 ? 0 : (int)((blockIdx.x >> 3) % G);
@@ -935,7 +934,6 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     unsigned *team_bar = reinterpret_cast<unsigned *>(arena + a.a_bar);
     float *xscr = G == 1 ? xs2 : arena + a.a_xtm + (int64_t)g * RBH * S;      // rows of the one-row / lock-step forwards: a member's own in a team
     const int RS = a.RS;
-    auto dump_of = [&](int which, int blk) { return dumps + ((int64_t)which * 4 + blk) * BLK; };
 
     // ---- stage the perturbed SE (GTN_worker.py:165-175): first layers transposed into the arena, output layers into LDS ----
     {

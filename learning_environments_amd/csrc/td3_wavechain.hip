@@ -144,6 +144,7 @@ __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, 
     constexpr int in = IN, out = OUT;
     const int ldx = uni(ldx_), mode = uni(mode_), ldy = uni(ldy_), ocol = uni(ocol_);
     const int d_h1 = uni(act1 ? d_h1_2_ : d_h1_), r_h2 = uni(act1 ? r_h2_2_ : r_h2_);
+    (void)d_h2_;
     lfloat *sm_b2 = (lfloat *)uni_ptr(c->sm_b2), *sm_wo2 = (lfloat *)uni_ptr(c->sm_wo2);
     {
         const float *p0 = uni_ptr(par_);
