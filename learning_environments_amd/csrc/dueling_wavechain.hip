@@ -984,13 +984,15 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     // of the launch; thread 0 releases, arrives, waits for the epoch's count, acquires (agent scope).  A member that waits for
     // seconds gives up for good (status -10) instead of hanging the device.
     unsigned team_epoch = 0;
-    bool team_dead = false;
+    bool team_dead = false, team_same_xcd = false;
     auto team_barrier = [&]() {
         if (G == 1) return;
         __syncthreads();
         ++team_epoch;
         if (tid == 0 && !team_dead) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // members on one XCD share its L2 (td3_wavechain.hip): no L2 write-back on release, only this CU's L1 dropped on acquire
+            if (team_same_xcd) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __hip_atomic_fetch_add(team_bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned target_ = team_epoch * (unsigned)G;
             long spins = 0;
@@ -998,12 +1000,21 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > 8000000L) { ictrl[5] = 1; break; }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (team_same_xcd) asm volatile("buffer_inv sc1" ::: "memory");
+            else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
         if (ictrl[5]) { team_dead = true; status = -10; }
     };
-    team_barrier();                                        // the arena is initialised
+    if (G > 1 && tid == 0) reinterpret_cast<unsigned *>(gva)[g] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
+    team_barrier();                                        // the arena is initialised, every member's XCD id is posted
+    if (G > 1) {
+        bool same = true;
+        const unsigned x0 = reinterpret_cast<unsigned *>(gva)[0];
+        for (int m = 1; m < G; ++m) same = same && reinterpret_cast<unsigned *>(gva)[m] == x0;
+        team_barrier();                                    // everybody has read the ids before the exchange rows are reused
+        team_same_xcd = same;
+    }
 
     // q_out[I][A] from the head outputs of `slot` (models/actor_critic.py:117-122; learn: mean over ALL I*A advantages)
     auto finish_q = [&](int slot, int I, float *q_out, bool global_mean) {

@@ -773,15 +773,20 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     // longer than a few seconds gives up for good (status -10) instead of hanging the device: the launch is only valid when all G x
     // chains workgroups are resident at once, which the host checks against the CU count.
     unsigned team_epoch = 0;
-    bool team_dead = false;
+    bool team_dead = false, team_same_xcd = false;
+    unsigned long long bar_cycles = 0;
     auto team_barrier = [&]() {
         if (G == 1) return;
+        const unsigned long long bt0 = __builtin_readcyclecounter();
         __syncthreads();
         ++team_epoch;
         if (tid == 0 && !team_dead) {
             // release (every wave's stores have been acknowledged at the __syncthreads above; this makes them visible at agent scope),
-            // arrive, wait for the epoch's count, acquire
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // arrive, wait for the epoch's count, acquire.  When all members sit on ONE XCD (checked once, below) they share its L2:
+            // the stores are there already (the vector L1 writes through), so the release needs no L2 write-back and the acquire
+            // only has to drop this CU's L1 lines.
+            if (team_same_xcd) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __hip_atomic_fetch_add(team_bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned target = team_epoch * (unsigned)G;
             long spins = 0;
@@ -789,14 +794,25 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > 8000000L) { ictrl[5] = 1; break; }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (team_same_xcd) asm volatile("buffer_inv sc1" ::: "memory");
+            else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
         if (ictrl[5]) { team_dead = true; status = -10; }
+        bar_cycles += __builtin_readcyclecounter() - bt0;
     };
     // sample block of row b -> does it belong to this member (blocks are dealt like the waves that own them)
     auto my_row = [&](int b) { return G == 1 || ((b >> 5) * G) / T3W_NB == g; };
-    team_barrier();                                        // the arena is initialised
+    if (G > 1 && tid == 0) reinterpret_cast<unsigned *>(gdz)[g] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
+    team_barrier();                                        // the arena is initialised, every member's XCD id is posted
+    if (G > 1) {
+        // are all members on one XCD (the block-to-XCD round robin the index mapping above counts on)?  The same answer in every member.
+        bool same = true;
+        const unsigned x0 = reinterpret_cast<unsigned *>(gdz)[0];
+        for (int m = 1; m < G; ++m) same = same && reinterpret_cast<unsigned *>(gdz)[m] == x0;
+        team_barrier();                                    // everybody has read the ids before the exchange rows are reused
+        team_same_xcd = same;
+    }
     TPT_DECL;
     int64_t n_rand = 0, n_actn = 0, n_testn = 0, n_test_ep = 0, learn_it = 0;
     int train_steps = 0, test_steps = 0, episodes_run = 0;
@@ -1158,7 +1174,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     }
     TPT_MARK(9);
 #if defined(LENV_PHASE_TIMING) && !defined(LENV_PHASE_TIMING_SUB)
-    if (tid == 0 && chain == 0) for (int pi = 0; pi < 12; ++pi) g_t3w_phase_cycles[pi] = pt_acc[pi];
+    if (tid == 0 && chain == 0) { for (int pi = 0; pi < 12; ++pi) g_t3w_phase_cycles[pi] = pt_acc[pi]; g_t3w_phase_cycles[11] = bar_cycles; }
 #endif
     if (tid == 0 && g == 0) {
         double sm = 0.0;

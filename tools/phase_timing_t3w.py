@@ -37,6 +37,7 @@ names = ["act+env step+append", "replay gather", "actor_t fwd+noise", "4 critic 
          "policy fwd/bwd", "actor adam+polyak", "tests", "other"]
 st = m.inner.stats[0].tolist()
 tot = sum(buf[i] for i in range(11))
+print("team barriers: %d cycles total, %.0f per learn step" % (buf[11], buf[11] / max(1, st[2])))
 print("TD3 generation wall %.1f ms; stats %s; total %.1f Mcycles" % (dt * 1e3, st, tot / 1e6))
 for i, n in enumerate(names):
     per = buf[i] / max(1, st[2]) if 1 <= i <= 8 else (buf[i] / max(1, st[1]) if i == 0 else buf[i] / max(1, st[3]))
