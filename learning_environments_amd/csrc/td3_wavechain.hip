@@ -630,20 +630,29 @@ __device__ __noinline__ void t3w_backward_wgrad(const T3wCtx *ctx_, float *gpar_
 #pragma unroll
     for (int v = 0; v < 16; ++v) accw[v] = 0.0f;
     float sb = 0.0f;
+    bool need_dh1 = false, need_dz2 = false;               // uniform per workgroup
+    for (int w_ = 0; w_ < NW; ++w_) if (mine(slot0 + w_, slots)) { if (w_ < 6) need_dh1 = true; else need_dz2 = true; }
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         L.refresh();
-        {   // half-batch images of dh1 (bufB) and dz2 (bufA) from their row-major copies
+        {   // half-batch images of dh1 (bufB: waves 0-5 read it) and dz2 (bufA: waves 6-7) from their row-major copies; a team member
+            // stages only what its waves of this phase read
             const gf4 *src = (const gf4 *)dump_of(r_dh1, 0) + half * 96 * 32 + tid, *src2 = (const gf4 *)dump_of(r_dz2, 0) + half * 96 * 32 + tid;
             lfloat *img = (lfloat *)bufB, *img2 = (lfloat *)bufA;
             f32x4 v[6], v2[6];
+            if (need_dh1) {
 #pragma unroll
-            for (int u = 0; u < 6; ++u) { v[u] = src[u * NT]; v2[u] = src2[u * NT]; }
+                for (int u = 0; u < 6; ++u) v[u] = src[u * NT];
+            }
+            if (need_dz2) {
+#pragma unroll
+                for (int u = 0; u < 6; ++u) v2[u] = src2[u * NT];
+            }
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
                 const int p = tid + u * NT, rr_ = p >> 5, cc_ = (p & 31) << 2;
-                *(lf4 *)(img + rr_ * W + (cc_ ^ ((rr_ & 7) << 2))) = v[u];
-                *(lf4 *)(img2 + rr_ * W + (cc_ ^ ((rr_ & 7) << 2))) = v2[u];
+                if (need_dh1) *(lf4 *)(img + rr_ * W + (cc_ ^ ((rr_ & 7) << 2))) = v[u];
+                if (need_dz2) *(lf4 *)(img2 + rr_ * W + (cc_ ^ ((rr_ & 7) << 2))) = v2[u];
             }
         }
         barrier_lds();
@@ -801,6 +810,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         if (ictrl[5]) { team_dead = true; status = -10; }
         bar_cycles += __builtin_readcyclecounter() - bt0;
     };
+    (void)bar_cycles;
     // sample block of row b -> does it belong to this member (blocks are dealt like the waves that own them)
     auto my_row = [&](int b) { return G == 1 || ((b >> 5) * G) / T3W_NB == g; };
     if (G > 1 && tid == 0) reinterpret_cast<unsigned *>(gdz)[g] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
