@@ -167,19 +167,30 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
             }
             int s = cfg.start_state;
             float ep_reward = 0.0f;                                    // fp32 tensor accumulation, base_agent.py:212
-            int dn = 0, el = 0;
-            for (int st = 0; st < cfg.max_steps && !dn; st += k_rep) {     // base_agent.py:194 range(0, max_steps, same_action_num)
-                const int ac = ql_argmax_f32(q + s * A, A);
-                double rsum = 0.0;                                     // EnvWrapper.step: python-float sum, the repeats stop at done
-                for (int r_ = 0; r_ < k_rep; ++r_) {
-                    dn = a.done[s * A + ac];
-                    rsum = rsum + a.reward[s * A + ac];
+            if (k_rep == 1) {
+                for (int st = 0; st < cfg.max_steps; ++st) {
+                    const int ac = ql_argmax_f32(q + s * A, A);
+                    const int dn = a.done[s * A + ac];
+                    ep_reward = ep_reward + (float)a.reward[s * A + ac];
                     s = a.next_state[s * A + ac];
-                    ++test_steps; ++used; ++el;
-                    if (el >= cfg.max_steps) dn = 1;
+                    ++test_steps; ++used;
                     if (dn) break;
                 }
-                ep_reward = ep_reward + (float)rsum;
+            } else {
+                int dn = 0, el = 0;
+                for (int st = 0; st < cfg.max_steps && !dn; st += k_rep) {     // base_agent.py:194 range(0, max_steps, same_action_num)
+                    const int ac = ql_argmax_f32(q + s * A, A);
+                    double rsum = 0.0;                                 // EnvWrapper.step: python-float sum, the repeats stop at done
+                    for (int r_ = 0; r_ < k_rep; ++r_) {
+                        dn = a.done[s * A + ac];
+                        rsum = rsum + a.reward[s * A + ac];
+                        s = a.next_state[s * A + ac];
+                        ++test_steps; ++used; ++el;
+                        if (el >= cfg.max_steps) dn = 1;
+                        if (dn) break;
+                    }
+                    ep_reward = ep_reward + (float)rsum;
+                }
             }
             rets[te] = (double)ep_reward;
         }
@@ -207,18 +218,27 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
             } else ac = ql_argmax_f32(q + s * A, A);
             // EnvWrapper.step (env_wrapper.py:56-61): the action same_action_num times or until done (gym.wrappers.TimeLimit: done after
             // max_steps env steps), the shaped rewards summed as python floats and stored as one fp32 value
-            int s2 = s, dn = 0;
-            double rsum = 0.0;
-            for (int r_ = 0; r_ < k_rep; ++r_) {
-                const int sc = s2;
-                dn = a.done[sc * A + ac];
-                ++env_steps;
-                if (env_steps >= cfg.max_steps) dn = 1;
-                rsum = rsum + (double)shaped[sc * A + ac];
-                s2 = a.next_state[sc * A + ac];
-                if (dn) break;
+            int s2, dn;
+            double r;
+            if (k_rep == 1) {                                          // (the shipped configurations: kept free of the repeat bookkeeping)
+                s2 = a.next_state[s * A + ac];
+                dn = a.done[s * A + ac];
+                if (st + 1 >= cfg.max_steps) dn = 1;
+                r = (double)shaped[s * A + ac];
+            } else {
+                s2 = s; dn = 0;
+                double rsum = 0.0;
+                for (int r_ = 0; r_ < k_rep; ++r_) {
+                    const int sc = s2;
+                    dn = a.done[sc * A + ac];
+                    ++env_steps;
+                    if (env_steps >= cfg.max_steps) dn = 1;
+                    rsum = rsum + (double)shaped[sc * A + ac];
+                    s2 = a.next_state[sc * A + ac];
+                    if (dn) break;
+                }
+                r = (double)(float)rsum;
             }
-            const double r = (double)(float)rsum;
             // QL.learn (QL.py:37-75) / SARSA.learn (SARSA.py:36-60), only once episode >= init_episodes (base_agent.py:127-128)
             if (episode >= cfg.init_episodes) {
                 for (int k = 0; k < cfg.batch_size; ++k) {
