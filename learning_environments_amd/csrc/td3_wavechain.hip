@@ -131,20 +131,23 @@ __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, 
 {
     T3W_CTX_PROLOGUE;
     const bool dual = uni(d_h1_2_) != -2;                  // (a flag rather than a null test of the generic pointer)
-    // this wave's job: (pass 0, block = wave) or, in a dual call, (pass 1, block = wave - 6 / G mod 8: the member's blocks are
-    // consecutive, so pass 1 sits on the waves right behind them -- other SIMDs than the blocks' own waves)
-    const int wave2 = (wave - T3W_NB / TG) & 7;
-    const bool act0 = wave < T3W_NB && mine(wave, T3W_NB);
-    const bool act1 = dual && !act0 && wave2 < T3W_NB && mine(wave2, T3W_NB);
-    const bool active = act0 || act1;
-    const int blk = act1 ? wave2 : (act0 ? wave : 0);
-    const float *par = uni_ptr(act1 ? par2_ : par_), *X = uni_ptr(act1 ? X2_ : X_);
+    (void)d_h2_;
+    // This wave's jobs (pass, block).  Team member: (pass 0, block = wave) or, in a dual call, (pass 1, block = wave - 6 / G mod 8: the
+    // member's blocks are consecutive, so pass 1 sits on the waves right behind them -- other SIMDs than the blocks' own waves).
+    // One workgroup per chain: a single pass puts block w on wave w; a dual pass has 12 jobs (pass j / 6, block j % 6) for 8 waves:
+    // wave w runs job w and, for w < 4, job w + 8 afterwards -- three jobs on every SIMD instead of four for two passes in a row.
+    int njobs = 0, jp0 = 0, jb0 = 0, jp1 = 0, jb1 = 0;
+    if (TG > 1) {
+        const int wave2 = (wave - T3W_NB / TG) & 7;
+        if (wave < T3W_NB && mine(wave, T3W_NB)) { jp0 = 0; jb0 = wave; njobs = 1; }
+        else if (dual && wave2 < T3W_NB && mine(wave2, T3W_NB)) { jp0 = 1; jb0 = wave2; njobs = 1; }
+    } else if (dual) {
+        jp0 = wave / T3W_NB; jb0 = wave % T3W_NB; njobs = 1;
+        if (wave < 4) { jp1 = (wave + 8) / T3W_NB; jb1 = (wave + 8) % T3W_NB; njobs = 2; }
+    } else if (wave < T3W_NB) { jb0 = wave; njobs = 1; }
     float *Y = uni_ptr(Y_), *th_out = uni_ptr(th_out_);
-    lfloat *q_out = (lfloat *)uni_ptr(act1 ? q_out2_ : q_out_);
     constexpr int in = IN, out = OUT;
     const int ldx = uni(ldx_), mode = uni(mode_), ldy = uni(ldy_), ocol = uni(ocol_);
-    const int d_h1 = uni(act1 ? d_h1_2_ : d_h1_), r_h2 = uni(act1 ? r_h2_2_ : r_h2_);
-    (void)d_h2_;
     lfloat *sm_b2 = (lfloat *)uni_ptr(c->sm_b2), *sm_wo2 = (lfloat *)uni_ptr(c->sm_wo2);
     {
         const float *p0 = uni_ptr(par_);
@@ -156,15 +159,14 @@ __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, 
             for (int i = tid; i < 8 * W + 8; i += NT) sm_wo2[i] = p1[oWo + i];
         }
     }
-    const lfloat *smb = act1 ? sm_b2 : sm_b, *smwo = act1 ? sm_wo2 : sm_wo, *smbo = smwo + 8 * W;
-    const float *img = act1 ? bufB : bufA;
     StageRegs sr;
     TSUB_DECL;
-    // layer 1's operands (A straight from the K-major array, B from the minibatch rows) are requested first: their latency hides
-    // behind the staging of the W2 image
+    // the first job's layer-1 operands (A straight from the K-major array, B from the minibatch rows) are requested first: their
+    // latency hides behind the staging of the W2 image(s)
     float xb[in >> 1], wa[in >> 1][4];
-    {
-        const int row0 = 32 * blk + L.li;
+    auto l1_operands = [&](int jpass, int jblk) {
+        const float *par = uni_ptr(jpass ? par2_ : par_), *X = uni_ptr(jpass ? X2_ : X_);
+        const int row0 = 32 * jblk + L.li;
         const gfloat *w1 = (const gfloat *)par + oW1t + L.h * W + L.li;
         const gfloat *xr = (const gfloat *)X + row0 * ldx + L.h;
 #pragma unroll
@@ -173,7 +175,8 @@ __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, 
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) wa[t][jt] = w1[2 * t * W + 32 * jt];
         }
-    }
+    };
+    l1_operands(jp0, jb0);
     stage_load_direct(uni_ptr(par_) + oW2t, L, sr);
     stage_store_direct(bufA, L, sr);
     if (dual) {
@@ -182,7 +185,13 @@ __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, 
     }
     barrier_lds();                                         // images + small vectors: LDS only (the layer-1 operand loads stay in flight)
     TSUB_MARK(16);
-    if (active) {
+    auto run_job = [&](int jpass, int blk) {
+        const bool p1 = jpass != 0;
+        const float *par = uni_ptr(p1 ? par2_ : par_), *X = uni_ptr(p1 ? X2_ : X_);
+        lfloat *q_out = (lfloat *)uni_ptr(p1 ? q_out2_ : q_out_);
+        const int d_h1 = uni(p1 ? d_h1_2_ : d_h1_), r_h2 = uni(p1 ? r_h2_2_ : r_h2_);
+        const lfloat *smb = p1 ? sm_b2 : sm_b, *smwo = p1 ? sm_wo2 : sm_wo, *smbo = smwo + 8 * W;
+        const float *img = p1 ? bufB : bufA;
         const int row = 32 * blk + L.li;
         float r[64];
         f32x16 acc[4];
@@ -234,7 +243,9 @@ __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, 
             }
         }
         TSUB_MARK(19);
-    }
+    };
+    if (njobs >= 1) run_job(jp0, jb0);
+    if (njobs >= 2) { L.refresh(); l1_operands(jp1, jb1); run_job(jp1, jb1); }
     __syncthreads();
     TSUB_MARK(20);
 }
@@ -249,34 +260,39 @@ __device__ __noinline__ void t3w_backward_chain(const T3wCtx *ctx_, const float 
                                                 int r_dz2_2_ = -1, int r_dh1_2_ = -1)
 {
     T3W_CTX_PROLOGUE;
-    // a second, independent network's chain (d_h1_2 given) runs on the waves behind the member's own blocks, as in t3w_forward
+    // a second, independent network's chain (d_h1_2 given) runs next to the first one: jobs as in t3w_forward
     const bool dual = uni(d_h1_2_) != -2;
-    const int wave2 = (wave - T3W_NB / TG) & 7;
-    const bool act0 = wave < T3W_NB && mine(wave, T3W_NB);
-    const bool act1 = dual && !act0 && wave2 < T3W_NB && mine(wave2, T3W_NB);
-    const bool own = act0 || act1;
-    const int blk = act1 ? wave2 : (act0 ? wave : 0);
-    const float *par = uni_ptr(act1 ? par2_ : par_), *th = uni_ptr(th_);
-    const lfloat *dOut = (const lfloat *)uni_ptr(act1 ? dOut2_ : dOut_);
+    int njobs = 0, jp0 = 0, jb0 = 0, jp1 = 0, jb1 = 0;
+    if (TG > 1) {
+        const int wave2 = (wave - T3W_NB / TG) & 7;
+        if (wave < T3W_NB && mine(wave, T3W_NB)) { jp0 = 0; jb0 = wave; njobs = 1; }
+        else if (dual && wave2 < T3W_NB && mine(wave2, T3W_NB)) { jp0 = 1; jb0 = wave2; njobs = 1; }
+    } else if (dual) {
+        jp0 = wave / T3W_NB; jb0 = wave % T3W_NB; njobs = 1;
+        if (wave < 4) { jp1 = (wave + 8) / T3W_NB; jb1 = (wave + 8) % T3W_NB; njobs = 2; }
+    } else if (wave < T3W_NB) { jb0 = wave; njobs = 1; }
+    const float *th = uni_ptr(th_);
     lfloat *dz_out = (lfloat *)uni_ptr(dz_out_);
     constexpr int out = OUT;
-    const int d_h1 = uni(act1 ? d_h1_2_ : d_h1_), d_h2 = uni(act1 ? d_h2_2_ : d_h2_), r_dz2 = uni(act1 ? r_dz2_2_ : r_dz2_),
-              r_dh1 = uni(act1 ? r_dh1_2_ : r_dh1_), dx_col = uni(dx_col_), dx_n = uni(dx_n_);
+    const int dx_col = uni(dx_col_), dx_n = uni(dx_n_);
     lfloat *sm_wo2 = (lfloat *)uni_ptr(c->sm_wo2);
     for (int i = tid; i < 8 * W + 8; i += NT) sm_wo[i] = uni_ptr(par_)[oWo + i];
     if (dual) for (int i = tid; i < 8 * W + 8; i += NT) sm_wo2[i] = uni_ptr(par2_)[oWo + i];
-    const lfloat *smwo = act1 ? sm_wo2 : sm_wo;
-    const float *img = act1 ? bufB : bufA;
     StageRegs sr, sr2;
     TSUB_DECL;
     stage_load_transposed(uni_ptr(par_) + oW2t, L, sr);
     if (dual) stage_load_transposed(uni_ptr(par2_) + oW2t, L, sr2);
     __syncthreads();                                       // sm_wo staged
     TSUB_MARK(24);
+    // dz2 = act'(h2) * (sum_c dOut[i][c] Wo[c][unit], c ascending from 0) of every job of this wave: to the row-major copy the weight
+    // gradients read, and -- as the chain's B operand -- kept in registers (first job) or re-read from that copy (second job)
     float r[64];
     f32x16 acc[4];
-    if (own) {
-        // dz2 = act'(h2) * (sum_c dOut[i][c] Wo[c][unit], c ascending from 0)
+    auto dz2_block = [&](int jpass, int blk) {
+        const bool p1 = jpass != 0;
+        const lfloat *dOut = (const lfloat *)uni_ptr(p1 ? dOut2_ : dOut_);
+        const lfloat *smwo = p1 ? sm_wo2 : sm_wo;
+        const int d_h2 = uni(p1 ? d_h2_2_ : d_h2_), r_dz2 = uni(p1 ? r_dz2_2_ : r_dz2_);
         const int row = 32 * blk + L.li;
         const gfloat *hd = (const gfloat *)dump_of(d_h2, 0) + row * W + 4 * L.h;        // d_h2: the row-major copy of h2
         float dO[out];
@@ -300,13 +316,18 @@ __device__ __noinline__ void t3w_backward_chain(const T3wCtx *ctx_, const float 
         }
         block_to_rowmajor(dump_of(r_dz2, 0), blk, L, r);
         tile_to_operand(r);
-    }
+    };
+    if (njobs > 0) dz2_block(jp0, jb0);
     stage_store_transposed(bufA, L, sr);
     if (dual) stage_store_transposed(bufB, L, sr2);
     barrier_lds();                                         // the chain reads the image only; the dz2 copy in the arena is read by the weight gradients
     TSUB_MARK(25);
     L.refresh();
-    if (own) {
+    auto run_job = [&](int jpass, int blk) {
+        const bool p1 = jpass != 0;
+        const float *par = uni_ptr(p1 ? par2_ : par_);
+        const int d_h1 = uni(p1 ? d_h1_2_ : d_h1_), r_dh1 = uni(p1 ? r_dh1_2_ : r_dh1_);
+        const float *img = p1 ? bufB : bufA;
         const int row = 32 * blk + L.li;
         const gf4 *src = (const gf4 *)dump_of(d_h1, blk) + L.lane;
         f32x4 hv[16];
@@ -337,7 +358,9 @@ __device__ __noinline__ void t3w_backward_chain(const T3wCtx *ctx_, const float 
                 }
             }
         }
-    }
+    };
+    if (njobs >= 1) run_job(jp0, jb0);
+    if (njobs >= 2) { L.refresh(); dz2_block(jp1, jb1); run_job(jp1, jb1); }
     __syncthreads();
     TSUB_MARK(26);
 }
@@ -1054,15 +1077,12 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                     t3w_forward_split<ACT, SA, 1>(ctx, targets + 2 * PN, xn, SA, 0, tq2, nullptr, 0, 0, nullptr, -1, -1);
                     t3w_forward_split<ACT, SA, 1>(ctx, params + PN, xc, SA, 0, q1, nullptr, 0, 0, nullptr, TD_C1_H1, TR_C1_H2);
                     t3w_forward_split<ACT, SA, 1>(ctx, params + 2 * PN, xc, SA, 0, q2, nullptr, 0, 0, nullptr, TD_C2_H1, TR_C2_H2);
-                } else if (G == 2) {                       // three blocks per member: twin critics side by side on six waves
+                } else {
+                    // three blocks per member (G = 2): twin critics side by side on six waves; one workgroup per chain: the twelve
+                    // block-passes of the twin critics on eight waves, three per SIMD
                     t3w_forward<ACT, SA, 1>(ctx, targets + PN, xn, SA, 0, tq1, nullptr, 0, 0, nullptr, -1, -1, -1, targets + 2 * PN, xn, tq2, -1, -1);
                     t3w_forward<ACT, SA, 1>(ctx, params + PN, xc, SA, 0, q1, nullptr, 0, 0, nullptr, TD_C1_H1, TD_C1_H2, TR_C1_H2, params + 2 * PN, xc, q2,
                                             TD_C2_H1, TR_C2_H2);
-                } else {
-                    t3w_forward<ACT, SA, 1>(ctx, targets + PN, xn, SA, 0, tq1, nullptr, 0, 0, nullptr, -1, -1, -1);
-                    t3w_forward<ACT, SA, 1>(ctx, targets + 2 * PN, xn, SA, 0, tq2, nullptr, 0, 0, nullptr, -1, -1, -1);
-                    t3w_forward<ACT, SA, 1>(ctx, params + PN, xc, SA, 0, q1, nullptr, 0, 0, nullptr, TD_C1_H1, TD_C1_H2, TR_C1_H2);
-                    t3w_forward<ACT, SA, 1>(ctx, params + 2 * PN, xc, SA, 0, q2, nullptr, 0, 0, nullptr, TD_C2_H1, TD_C2_H2, TR_C2_H2);
                 }
                 TPT_MARK(3);
                 {
@@ -1083,13 +1103,9 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 if (G >= 3) {
                     t3w_backward_chain_split<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1, 0, 0, nullptr, nullptr);
                     t3w_backward_chain_split<ACT, SA, 1>(ctx, params + 2 * PN, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
-                } else if (G == 2)
+                } else                                     // G = 2 and one workgroup per chain: the twin critics' chains side by side
                     t3w_backward_chain<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1, 0, 0, nullptr, nullptr,
                                                    params + 2 * PN, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B);
-                else {
-                    t3w_backward_chain<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1, 0, 0, nullptr, nullptr);
-                    t3w_backward_chain<ACT, SA, 1>(ctx, params + 2 * PN, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
-                }
                 team_barrier();
                 if (G > 1) {
                     for (int b = tid; b < B; b += NT) { dq1[b] = gdq[b]; dq2[b] = gdq[B + b]; }
