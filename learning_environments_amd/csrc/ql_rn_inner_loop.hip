@@ -139,14 +139,20 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
     float *shaped = phi + N;                                         // [N*A]
     int *visits = reinterpret_cast<int *>(shaped + N * A);           // [N*A] visitation counts n(s,a) (count-based agents)
     float *hbuf = reinterpret_cast<float *>(visits + N * A);         // [2][H][64] hidden rows of a multi-layer reward net (rn_layers > 1 only)
+    // this episode's exploration draws, filled by all 64 lanes before lane 0 walks the episode (counter mode): the draws are a
+    // function of (key, stream, index) only, and two 64-bit mixes per draw are a third of a step of the one-lane walk
+    const int draw_cap = cfg.max_steps * (KIND == 1 ? 1 + cfg.batch_size : 1);
+    double *u_buf = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(hbuf + (cfg.rn_layers > 1 ? 2 * 64 * cfg.rn_hidden : 0)) + 7) & ~(uintptr_t)7);   // [draw_cap]
+    int *a_buf = reinterpret_cast<int *>(u_buf + draw_cap);          // [draw_cap]
+    volatile int *xctl = a_buf + draw_cap;                           // [8] walker -> wave: stop flags, draw counters
 
     rn_phi_and_shaped(cfg, a.theta, a.eps, a.worker, a.sign, a.shaped_override, a.next_state, a.reward, a.P, chain, lane,
                       phi, shaped, a.out.shaped ? a.out.shaped + chain * N * A : nullptr, nullptr, hbuf);
     for (int i = lane; i < N * A; i += 64) { q[i] = 0.0; if (CB) visits[i] = 0; }   // QL.py:25,31
     __syncthreads();
-    if (lane != 0) return;
+    const bool walker = lane == 0;
 
-    // ---- the sequential part: lane 0 ----
+    // ---- the sequential part: lane 0 (the other lanes only refill the draw buffers between episodes) ----
     const uint64_t key = a.rng_keys ? a.rng_keys[chain] : 0;
     const bool tape = cfg.rng_mode == LENV_RNG_TAPE;
     int status = 0, episodes_run = 0;
@@ -198,22 +204,37 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
     auto mean_rets = [&]() { double sm = 0.0; for (int i = 0; i < cfg.test_episodes; ++i) sm += rets[i]; return sm / (double)cfg.test_episodes; };
 
     int timed_out_at = -1;
+    int64_t eps0 = 0, act0 = 0;                                       // draw indices the buffers start at
     for (int episode = 0; episode < cfg.train_episodes; ++episode) {
         // deterministic time-out (lenv_ql_cfg::step_budget, base_agent.py:30-47,90-97): elapsed = env steps taken so far
-        if (cfg.step_budget > 0 && train_steps + test_steps > cfg.step_budget) { timed_out_at = episode; break; }
+        if (walker) {
+            xctl[0] = (cfg.step_budget > 0 && train_steps + test_steps > cfg.step_budget) ? 1 : 0;
+            xctl[1] = (int)(n_eps & 0xffffffff); xctl[2] = (int)(n_eps >> 32); xctl[3] = (int)(n_act & 0xffffffff); xctl[4] = (int)(n_act >> 32);
+        }
+        __syncthreads();
+        if (xctl[0]) { timed_out_at = episode; break; }
+        eps0 = (int64_t)(((uint64_t)(uint32_t)xctl[2] << 32) | (uint32_t)xctl[1]);
+        act0 = (int64_t)(((uint64_t)(uint32_t)xctl[4] << 32) | (uint32_t)xctl[3]);
+        if (!tape) for (int i = lane; i < draw_cap; i += 64) {
+            u_buf[i] = u64_to_unit(rng_u64(key, STREAM_EPS, (uint64_t)(eps0 + i)));
+            a_buf[i] = (int)u64_to_below(rng_u64(key, STREAM_ACTION, (uint64_t)(act0 + i)), (uint32_t)A);
+        }
+        __syncthreads();
+        int solved_brk = 0;
+        if (walker) {
         if (episode == 0) eps_g = cfg.eps_init;                       // QL.py:101-106
         else { eps_g *= cfg.eps_decay; if (eps_g < cfg.eps_min) eps_g = cfg.eps_min; }
         int s = cfg.start_state, ep_len = 0, env_steps = 0;
         for (int st = 0; st < cfg.max_steps; st += k_rep) {            // base_agent.py:104 range(0, max_steps, same_action_num)
             double u;
             if (tape) { if (n_eps >= a.tapes.eps_uniform_stride) { status = -2; u = 1.0; } else u = a.tapes.eps_uniform[chain * a.tapes.eps_uniform_stride + n_eps]; }
-            else u = u64_to_unit(rng_u64(key, STREAM_EPS, (uint64_t)n_eps));
+            else u = n_eps - eps0 < draw_cap ? u_buf[n_eps - eps0] : u64_to_unit(rng_u64(key, STREAM_EPS, (uint64_t)n_eps));
             ++n_eps;
             int ac, explored = 0;
             if (u < eps_g) {
                 explored = 1;
                 if (tape) { if (n_act >= a.tapes.rand_action_stride) { status = -3; ac = 0; } else ac = a.tapes.rand_action[chain * a.tapes.rand_action_stride + n_act]; }
-                else ac = (int)u64_to_below(rng_u64(key, STREAM_ACTION, (uint64_t)n_act), (uint32_t)A);
+                else ac = n_act - act0 < draw_cap ? a_buf[n_act - act0] : (int)u64_to_below(rng_u64(key, STREAM_ACTION, (uint64_t)n_act), (uint32_t)A);
                 ++n_act;
             } else ac = ql_argmax_f32(q + s * A, A);
             // EnvWrapper.step (env_wrapper.py:56-61): the action same_action_num times or until done (gym.wrappers.TimeLimit: done after
@@ -246,12 +267,12 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
                     if (KIND == 1) {                                   // next_action = select_train_action(next_state)
                         double u2;
                         if (tape) { if (n_eps >= a.tapes.eps_uniform_stride) { status = -2; u2 = 1.0; } else u2 = a.tapes.eps_uniform[chain * a.tapes.eps_uniform_stride + n_eps]; }
-                        else u2 = u64_to_unit(rng_u64(key, STREAM_EPS, (uint64_t)n_eps));
+                        else u2 = n_eps - eps0 < draw_cap ? u_buf[n_eps - eps0] : u64_to_unit(rng_u64(key, STREAM_EPS, (uint64_t)n_eps));
                         ++n_eps;
                         int a2;
                         if (u2 < eps_g) {
                             if (tape) { if (n_act >= a.tapes.rand_action_stride) { status = -3; a2 = 0; } else a2 = a.tapes.rand_action[chain * a.tapes.rand_action_stride + n_act]; }
-                            else a2 = (int)u64_to_below(rng_u64(key, STREAM_ACTION, (uint64_t)n_act), (uint32_t)A);
+                            else a2 = n_act - act0 < draw_cap ? a_buf[n_act - act0] : (int)u64_to_below(rng_u64(key, STREAM_ACTION, (uint64_t)n_act), (uint32_t)A);
                             ++n_act;
                         } else a2 = ql_argmax_f32(q + s2 * A, A);
                         boot = q[s2 * A + a2];
@@ -289,9 +310,14 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
             int lo = episode + 1 - cfg.early_out_num; if (lo < 0) lo = 0;
             double sm = 0.0;
             for (int i = lo; i <= episode; ++i) sm += meter[i];
-            if (sm / ((double)(episode + 1 - lo) + 1e-9) >= cfg.solved_reward) break;
+            if (sm / ((double)(episode + 1 - lo) + 1e-9) >= cfg.solved_reward) solved_brk = 1;
         }
+        xctl[5] = solved_brk;
+        }
+        __syncthreads();
+        if (xctl[5]) break;
     }
+    if (!walker) return;
     test_phase(cfg.step_budget > 0, cfg.step_budget - (train_steps + test_steps));
     a.out.score[chain] = mean_rets();
     if (a.out.final_returns) for (int i = 0; i < cfg.test_episodes; ++i) a.out.final_returns[chain * cfg.test_episodes + i] = rets[i];
@@ -354,7 +380,8 @@ extern "C" int lenv_ql_rn_inner_loop(const lenv_ql_cfg *cfg, const float *theta,
     a.P = ql_rn_params(cfg);
     const size_t NA = (size_t)cfg->n_states * cfg->n_actions;
     const size_t lds_bytes = sizeof(double) * (NA + cfg->train_episodes + cfg->test_episodes) + sizeof(float) * (cfg->n_states + NA) + sizeof(int) * NA + 16 +
-                             (cfg->rn_layers > 1 ? sizeof(float) * 2 * 64 * (size_t)cfg->rn_hidden : 0);
+                             (cfg->rn_layers > 1 ? sizeof(float) * 2 * 64 * (size_t)cfg->rn_hidden : 0) +
+                             8 + (sizeof(double) + sizeof(int)) * (size_t)cfg->max_steps * (cfg->agent_kind == 1 ? 1 + (size_t)cfg->batch_size : 1) + 64;
     if (lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     if (cfg->agent_kind != 0 && cfg->agent_kind != 1) return LENV_ERR_UNSUPPORTED;
     void (*kern)(const QlArgs) = cfg->agent_kind == 1 ? (cfg->count_based ? ql_rn_inner_kernel<1, true> : ql_rn_inner_kernel<1, false>)
