@@ -176,7 +176,20 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
             }
             int s = cfg.start_state;
             float ep_reward = 0.0f;                                    // fp32 tensor accumulation, base_agent.py:212
-            if (k_rep == 1) {
+            if (k_rep == 1 && A == 4) {
+                // the state's transition rows are requested together with its Q row: one memory round trip per step, not two
+                for (int st = 0; st < cfg.max_steps; ++st) {
+                    const int4 nx = *reinterpret_cast<const int4 *>(a.next_state + s * 4);
+                    const uchar4 dv = *reinterpret_cast<const uchar4 *>(a.done + s * 4);
+                    const double r0 = a.reward[s * 4], r1 = a.reward[s * 4 + 1], r2 = a.reward[s * 4 + 2], r3 = a.reward[s * 4 + 3];
+                    const int ac = ql_argmax_f32(q + s * 4, 4);
+                    const int dn = ac == 0 ? dv.x : (ac == 1 ? dv.y : (ac == 2 ? dv.z : dv.w));
+                    ep_reward = ep_reward + (float)(ac == 0 ? r0 : (ac == 1 ? r1 : (ac == 2 ? r2 : r3)));
+                    s = ac == 0 ? nx.x : (ac == 1 ? nx.y : (ac == 2 ? nx.z : nx.w));
+                    ++test_steps; ++used;
+                    if (dn) break;
+                }
+            } else if (k_rep == 1) {
                 for (int st = 0; st < cfg.max_steps; ++st) {
                     const int ac = ql_argmax_f32(q + s * A, A);
                     const int dn = a.done[s * A + ac];
