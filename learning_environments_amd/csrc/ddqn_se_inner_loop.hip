@@ -767,30 +767,6 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 PT_OWN(0);
                 __syncthreads();                               // B2
                 PT_MARK(3);
-                if (tid < B) {
-                    // TD target and dLoss/dQ(s,a) per sample (DDQN.py:82-86; mse_loss backward = 2/B * diff)
-                    const int b = tid;
-                    const float g32 = a.f_gamma, norm = a.f_norm;
-                    const float r = rda[b * 4], d = rda[b * 4 + 1];
-                    const int ab = (int)rda[b * 4 + 2];
-                    int am = 0;
-                    float best = qres[(1 * MAX_B + b) * A];
-#pragma unroll
-                    for (int aa = 1; aa < A; ++aa) { float v = qres[(1 * MAX_B + b) * A + aa]; if (v > best) { best = v; am = aa; } }
-                    const float t1 = g32 * qres[(2 * MAX_B + b) * A + am];
-                    const float t2 = 1.0f - d;
-                    const float y = r + t1 * t2;
-                    const float diff = qres[(0 * MAX_B + b) * A + ab] - y;
-                    const float dq = norm * diff;
-                    // dL/dQ(s_b, .) as a row: only entry a_b is non-zero (DDQN.py:84 gather) -- the backward pass multiplies
-                    // by these masks instead of branching on the action
-                    float4 dm;
-                    dm.x = ab == 0 ? dq : 0.0f; dm.y = ab == 1 ? dq : 0.0f; dm.z = ab == 2 ? dq : 0.0f; dm.w = 0.0f;
-                    *reinterpret_cast<float4 *>(dqB + 4 * b) = dm;
-                }
-                PT_OWN(1);
-                __syncthreads();                               // B3
-                PT_MARK(4);
                 if (fwd_active) {
                     // next step: ReplayBuffer.size = min(train_steps + 1, cap), write slot = train_steps % cap
                     const int nsz = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
@@ -804,6 +780,29 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 if (wave < LV(n_chunks)) {
                     const int b0 = wave * LV(chunk), b1 = (b0 + LV(chunk) < B) ? b0 + LV(chunk) : B;
                     float *pc = part + wave * P;
+                    // TD target and dLoss/dQ(s,a) of the chunk's own samples (DDQN.py:82-86; mse_loss backward = 2/B * diff), one
+                    // lane per sample: nobody else reads these rows, so the chunk goes on behind a wave-level fence -- no
+                    // workgroup barrier between the TD error and the gradient
+                    for (int b = b0 + lane; b < b1; b += 64) {
+                        const float g32 = a.f_gamma, norm = a.f_norm;
+                        const float r = rda[b * 4], d = rda[b * 4 + 1];
+                        const int ab = (int)rda[b * 4 + 2];
+                        int am = 0;
+                        float best = qres[(1 * MAX_B + b) * A];
+#pragma unroll
+                        for (int aa = 1; aa < A; ++aa) { float v = qres[(1 * MAX_B + b) * A + aa]; if (v > best) { best = v; am = aa; } }
+                        const float t1 = g32 * qres[(2 * MAX_B + b) * A + am];
+                        const float t2 = 1.0f - d;
+                        const float y = r + t1 * t2;
+                        const float diff = qres[(0 * MAX_B + b) * A + ab] - y;
+                        const float dq = norm * diff;
+                        // dL/dQ(s_b, .) as a row: only entry a_b is non-zero (DDQN.py:84 gather) -- the backward pass multiplies
+                        // by these masks instead of branching on the action
+                        float4 dm;
+                        dm.x = ab == 0 ? dq : 0.0f; dm.y = ab == 1 ? dq : 0.0f; dm.z = ab == 2 ? dq : 0.0f; dm.w = 0.0f;
+                        *reinterpret_cast<float4 *>(dqB + 4 * b) = dm;
+                    }
+                    wave_sync();
                     for (int j = lane; j < ((Hq + 63) & ~63); j += 64) {
                         const bool jv = j < Hq;
                         float gW1[S], gW2[A], gb2[A], w2j[A], gb1 = 0.0f;
