@@ -54,8 +54,9 @@ __device__ unsigned long long g_phase_cycles[64];
 struct InnerLayout {
     int P_q, P_se, se_net_size[3];
     int HP, chunk, n_chunks, n_chunks4, tanh16;
+    int split_L, split_D;                             // forward items beyond the first nw-4 waves and the parts each is cut into (0 = no split)
     int o_se_w0T, o_se_b0, o_se_wout, o_se_bout, o_se_h, o_q_onl, o_q_tgt, o_q_w2, o_wscr, o_hB, o_sB, o_rda,
-        o_dqB, o_qres, o_part, o_newrow, o_ctrl, o_ret, o_tanh, o_cand, o_cur_state, lds_floats;
+        o_dqB, o_qres, o_part, o_newrow, o_ctrl, o_ret, o_tanh, o_cand, o_cur_state, o_hX, lds_floats;
     int rc;                                           // LENV_OK or the reason the shape does not fit
 };
 constexpr int layout_mlp_params(int in, int H, int out) { return in * H + H + H * out + out; }
@@ -75,8 +76,17 @@ constexpr InnerLayout make_inner_layout(int S, int A, int Hq, int Hse, int B, in
     if (a.n_chunks > nw) return a;
     a.n_chunks4 = (a.n_chunks + 3) & ~3;
     const int K = S + A, HqPad = (Hq + 63) & ~63;
-    // the tanh image is carved first (offset 0, see det_tanh_lds_off): 16 bank-private copies when they fit, else one
-    for (int sixteen = 1; sixteen >= 0; --sixteen) {
+    // Items of the third forward wave of SIMDs 0 / 1 (see the kernel's "split" path): L of them, each cut into D parts over the
+    // hidden-unit pairs so that the four third waves share their activations; the parts' h rows go through o_hX
+    const int L_all = 3 * B - (nw - 4) * 64;
+    const int split_D = (L_all > 0 && L_all <= 128 && (Hq + 1) / 2 >= 8) ? (L_all <= 64 ? 4 : (L_all <= 85 ? 3 : 2)) : 0;
+    // the tanh image is carved first (offset 0, see det_tanh_lds_off): 16 bank-private copies when they fit, else one;
+    // the split is dropped before the copies are
+    for (int variant = 0; variant < 3; ++variant) {
+        const int sixteen = variant < 2 ? 1 : 0;
+        const int D = variant == 0 ? split_D : 0;
+        if (variant == 1 && split_D == 0) continue;
+        a.split_D = D; a.split_L = D ? L_all : 0;
         int o = 0;
 #define LENV_TAKE(n) ([&]() { int r_ = o; o += ((n) + 3) & ~3; return r_; }())
         a.tanh16 = sixteen;
@@ -93,6 +103,7 @@ constexpr InnerLayout make_inner_layout(int S, int A, int Hq, int Hse, int B, in
         a.o_newrow = LENV_TAKE(16); a.o_ctrl = LENV_TAKE(8 + nw);
         a.o_ret = LENV_TAKE(3 * T + 2);
         a.o_cand = LENV_TAKE(16 * A); a.o_cur_state = LENV_TAKE(16);
+        a.o_hX = LENV_TAKE(a.split_L * a.HP);
 #undef LENV_TAKE
         a.lds_floats = o;
         if ((long long)o * 4 <= 160 * 1024) { a.rc = LENV_OK; return a; }
@@ -195,8 +206,8 @@ __device__ __forceinline__ float act_bwd_t(float prelu, float a, float g)
     else return g;
 }
 
-// Two-stage activation of a hidden-unit PAIR, so that the table gathers of the canonical tanh (lenv_device.cuh, v3) can
-// be issued ahead of their use.  The pair form keeps the two-at-a-time steps (|z|+1, w - trunc(w)) on packed fp32
+// Two-stage activation of a hidden-unit PAIR, so that the table gathers of the canonical tanh (lenv_device.cuh, v4) can
+// be issued ahead of their use.  The pair form keeps the two-at-a-time steps (t + 2^19, the grid point, d) on packed fp32
 // instructions; everything is the same operation sequence as det_tanhf, element by element.
 template <int ACT>
 struct ActPipe2 {
@@ -208,12 +219,10 @@ struct ActPipe2 {
         if constexpr (ACT == LENV_ACT_TANH) {
             const float a0 = __builtin_fabsf(zz.x), a1 = __builtin_fabsf(zz.y);
             const v2f t = {a0 < LENV_TANH_TMAX ? a0 : LENV_TANH_TMAX, a1 < LENV_TANH_TMAX ? a1 : LENV_TANH_TMAX};
-            const v2f w = t + (v2f){1.0f, 1.0f};
-            const uint32_t b0 = __float_as_uint(w.x), b1 = __float_as_uint(w.y);
-            constexpr uint32_t keep = ~((1u << LENV_TANH_SHIFT) - 1u);
-            d = w - (v2f){__uint_as_float(b0 & keep), __uint_as_float(b1 & keep)};
-            k0 = det_tanh_lds_gather(tanh_tab, ((b0 >> tl.shift) & tl.mask) | tl.lane_off);
-            k1 = det_tanh_lds_gather(tanh_tab, ((b1 >> tl.shift) & tl.mask) | tl.lane_off);
+            const v2f u = t + (v2f){LENV_TANH_MAGIC, LENV_TANH_MAGIC};
+            d = t - (u - (v2f){LENV_TANH_MAGIC, LENV_TANH_MAGIC});
+            k0 = det_tanh_lds_gather(tanh_tab, tl.off(__float_as_uint(u.x)));
+            k1 = det_tanh_lds_gather(tanh_tab, tl.off(__float_as_uint(u.y)));
         }
     }
     __device__ __forceinline__ v2f finish(float prelu) const
@@ -411,9 +420,25 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     for (int i = 0; i < S; ++i) state[i] = 0.0f;
 
     // forward work item of this thread: item = pass*B + b (pass-major, dense over the first 3*B threads)
-    const int fwd_pass = tid < B ? 0 : (tid < 2 * B ? 1 : 2);
-    const int fwd_b = tid - fwd_pass * B;
-    const bool fwd_active = tid < 3 * B;
+    //
+    // SPLIT (layout split_D > 0): 3 B items fill waves 0 .. NW-5 and spill L = 3 B - 64 (NW-4) <= 128 items into the third wave of
+    // SIMD 0 (and 1), while the third waves of SIMDs 2 / 3 (speculation, env) have little to do in the forward interval: the
+    // phase would end when SIMDs 0 / 1 have issued three waves' worth of vector work.  So the L spilled items (all of pass 2:
+    // target net on the next states) are cut into D parts over the hidden-unit pairs, and lane u < L D of waves NW-4 .. NW-1
+    // computes the ACTIVATIONS of part u / L of item u % L into an LDS row; the output layer's accumulation -- the one
+    // sequential piece, k ascending over the hidden units -- is then run per item by the thread that owned it, from those rows.
+    // Same operations on the same values in the same order: the bits do not change.
+    const int SPLIT_D = LV(split_D), SPLIT_L = LV(split_L);
+    const bool split = SPLIT_D > 0;
+    constexpr int SPLIT_T0 = (NW - 4) * 64;              // first thread of the four third waves
+    const int split_u = tid - SPLIT_T0;                  // lane number inside them
+    const bool h_lane = split && split_u >= 0 && split_u < SPLIT_L * SPLIT_D;
+    const int split_li = h_lane ? split_u % SPLIT_L : 0, split_part = h_lane ? split_u / SPLIT_L : 0;
+    const bool chain_lane = split && split_u >= 0 && tid < 3 * B;
+    const int fwd_pass = (split && split_u >= 0) ? 2 : (tid < B ? 0 : (tid < 2 * B ? 1 : 2));
+    const int fwd_b = (split && split_u >= 0) ? SPLIT_T0 + split_li - 2 * B : tid - fwd_pass * B;
+    const bool full_item = split ? tid < SPLIT_T0 : tid < 3 * B;   // runs all pairs of its item, output layer included
+    const bool fwd_active = full_item || h_lane;          // samples a replay row
 
     // speculation layout: waves without forward items (at most the last two) evaluate the SE for every action of the
     // NEXT step while the other waves run the minibatch forwards; the env wave then only has to pick a candidate.
@@ -574,6 +599,9 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
             // row being appended, and the speculation wave (needs the new state), wait for that flag.
             const int step_tag = train_steps + 1;
             PT_MARK(9);
+            // split layout: what the four third waves do up to the spilled items' output layers is the critical path of the forward
+            // interval (the SIMDs' arbiters otherwise serve the older waves first and these rows arrive last)
+            if (split && learning && wave >= NW - 4) __builtin_amdgcn_s_setprio(3);
             if (wave == ENV_WAVE) {
                 // ---- select_train_action (DDQN.py:97-104) ----
                 if (!nx_valid) draw_action(train_steps);
@@ -627,11 +655,12 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 for (int i = 0; i < S; ++i) state[i] = next_state[i];
                 if (learning && lane == 0) lds_flag_store(ctrl + 5, step_tag);
                 PT_MARK(1);   // (env wave) SE step + append
-            } else if (learning && fwd_active) {
+            }
+            if (learning && fwd_active) {                          // (the env wave has such lanes in the split layout only)
                 if (!pf_valid) fetch_row(learn_it, size_after, new_pos);     // first learn step: nothing was prefetched
                 pf_valid = false;
                 if (pf_status) status = pf_status;
-                if (__builtin_amdgcn_ballot_w64(my_idx == new_pos) != 0) lds_flag_wait(ctrl + 5, step_tag);   // needs newrow
+                if (wave != ENV_WAVE && __builtin_amdgcn_ballot_w64(my_idx == new_pos) != 0) lds_flag_wait(ctrl + 5, step_tag);   // needs newrow
             }
             ++ep_len; ++train_steps;
             wr_pos = wr_pos + 1 == rb_cap ? 0 : wr_pos + 1;    // ReplayBuffer.ptr = (ptr + 1) % max_size, without the division
@@ -665,7 +694,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     const float4 *W4 = reinterpret_cast<const float4 *>(W);
                     const int Hqf = FIXED ? FIX_HQ : Hq;                            // literal only here: pair count and tail of this loop
                     const int npairs = (Hqf + 1) >> 1;
-                    float *hrow = hB + fwd_b * HP;
+                    float *hrow = full_item ? hB + fwd_b * HP : lds + LV(o_hX) + split_li * HP;
                     float4 r1[N1], r2[N2];
                     auto load1 = [&](int jp) {
 #pragma unroll
@@ -684,8 +713,15 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         for (int i = 0; i < S; ++i) z = fma2((v2f){x[i], x[i]}, (v2f){rec[2 * i], rec[2 * i + 1]}, z);
                         return z + (v2f){rec[2 * S], rec[2 * S + 1]};
                     };
-                    // finish pair jp (its activations were issued one stage earlier) with the output part in r2
-                    auto finish = [&](const ActPipe2<QACT> &ap, int jp, bool two) {
+                    // finish pair jp (its activations were issued one stage earlier) with the output part in r2; an h-only lane
+                    // of the split layout stops at the activations and leaves them in its item's LDS row
+                    auto finish = [&](const ActPipe2<QACT> &ap, int jp, bool two, auto honly_tag) {
+                        if constexpr (decltype(honly_tag)::value) {
+                            const v2f hh = ap.finish(cfg.q_prelu);
+                            if (two) *reinterpret_cast<v2f *>(hrow + 2 * jp) = hh;
+                            else hrow[2 * jp] = hh.x;
+                            return;
+                        }
                         float w2[PR - OW2];
 #pragma unroll
                         for (int v = 0; v < N2; ++v) { w2[4 * v] = r2[v].x; w2[4 * v + 1] = r2[v].y; w2[4 * v + 2] = r2[v].z; w2[4 * v + 3] = r2[v].w; }
@@ -713,41 +749,120 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     // one pipeline stage: start pair jp+1 into `nxt`, finish pair jp from `cur`.  FULL = steady state
                     // (pair jp+2 exists, pair jp has both units): no conditions, so the stage is straight-line code and the
                     // compiler can count outstanding LDS reads instead of draining them
-                    auto stage = [&](ActPipe2<QACT> &cur, ActPipe2<QACT> &nxt, int jp, auto full_tag) {
-                        constexpr bool FULL = decltype(full_tag)::value;
-                        if (FULL || jp + 1 < npairs) {
+                    auto stage = [&](ActPipe2<QACT> &cur, ActPipe2<QACT> &nxt, int jp, int pend, auto full_tag, auto honly_tag) {
+                        constexpr bool FULL = decltype(full_tag)::value, HONLY = decltype(honly_tag)::value;
+                        if (FULL || jp + 1 < pend) {
                             nxt.issue(tanh_tab, tl, layer1());      // r1 holds pair jp+1
-                            if (FULL || jp + 2 < npairs) load1(jp + 2);
+                            if (FULL || jp + 2 < pend) load1(jp + 2);
                         }
-                        finish(cur, jp, FULL || 2 * jp + 1 < Hqf);  // r2 holds pair jp
-                        if (FULL || jp + 1 < npairs) load2(jp + 1);
+                        finish(cur, jp, FULL || 2 * jp + 1 < Hqf, honly_tag);  // r2 holds pair jp
+                        if (!HONLY && (FULL || jp + 1 < pend)) load2(jp + 1);
                     };
                     using T = std::true_type;
                     using F = std::false_type;
                     ActPipe2<QACT> pa, pb;
-                    load1(0);
-                    pa.issue(tanh_tab, tl, layer1());
-                    if (npairs > 1) load1(1);
-                    load2(0);
-                    int jp = 0;
+                    if (full_item) {
+                        load1(0);
+                        pa.issue(tanh_tab, tl, layer1());
+                        if (npairs > 1) load1(1);
+                        load2(0);
+                        int jp = 0;
 #pragma unroll 1
-                    for (; jp + 4 <= npairs; jp += 2) {             // jp+3 < npairs: both stages are steady-state
-                        stage(pa, pb, jp, T{});
-                        stage(pb, pa, jp + 1, T{});
-                    }
-                    for (; jp + 2 <= npairs; jp += 2) {             // at most one more double stage, with the tail conditions
-                        stage(pa, pb, jp, F{});
-                        stage(pb, pa, jp + 1, F{});
-                    }
-                    if (jp < npairs) finish(pa, jp, 2 * jp + 1 < Hqf);
+                        for (; jp + 4 <= npairs; jp += 2) {             // jp+3 < npairs: both stages are steady-state
+                            stage(pa, pb, jp, npairs, T{}, F{});
+                            stage(pb, pa, jp + 1, npairs, T{}, F{});
+                        }
+                        for (; jp + 2 <= npairs; jp += 2) {             // at most one more double stage, with the tail conditions
+                            stage(pa, pb, jp, npairs, F{}, F{});
+                            stage(pb, pa, jp + 1, npairs, F{}, F{});
+                        }
+                        if (jp < npairs) finish(pa, jp, 2 * jp + 1 < Hqf, F{});
 #pragma unroll
-                    for (int aa = 0; aa < A; ++aa) qres[(fwd_pass * MAX_B + fwd_b) * A + aa] = q[aa] + W[npairs * PR + aa];
-                    if (fwd_pass == 0) {
+                        for (int aa = 0; aa < A; ++aa) qres[(fwd_pass * MAX_B + fwd_b) * A + aa] = q[aa] + W[npairs * PR + aa];
+                        if (fwd_pass == 0) {
 #pragma unroll
-                        for (int i = 0; i < S; ++i) sB[fwd_b * SP + i] = row[i];
-                        rda[fwd_b * 4 + 0] = row[2 * S + 1]; rda[fwd_b * 4 + 1] = row[2 * S + 2]; rda[fwd_b * 4 + 2] = row[S];
+                            for (int i = 0; i < S; ++i) sB[fwd_b * SP + i] = row[i];
+                            rda[fwd_b * 4 + 0] = row[2 * S + 1]; rda[fwd_b * 4 + 1] = row[2 * S + 2]; rda[fwd_b * 4 + 2] = row[S];
+                        }
+                    } else {
+                        // split layout, h-only lane: the activations of pairs [p0, p1) of its item
+                        const int sd = SPLIT_D > 0 ? SPLIT_D : 1, p0 = split_part * npairs / sd, p1 = (split_part + 1) * npairs / sd;
+                        load1(p0);
+                        pa.issue(tanh_tab, tl, layer1());
+                        if (p0 + 1 < p1) load1(p0 + 1);
+                        int jp = p0;
+#pragma unroll 1
+                        for (; jp + 2 <= p1; jp += 2) {
+                            stage(pa, pb, jp, p1, F{}, T{});
+                            stage(pb, pa, jp + 1, p1, F{}, T{});
+                        }
+                        if (jp < p1) finish(pa, jp, 2 * jp + 1 < Hqf, T{});
                     }
-                } else if (wave >= first_spec) {
+                }
+                if (split && wave >= NW - 4) {
+                    // split layout: this wave's activation rows are written -- tell the two waves that run the spilled items' output layers
+                    const int k = wave - (NW - 4);
+                    if (lane == 0) lds_flag_store(ctrl + 3 + k + (k >> 1), step_tag);          // ctrl[3], [4], [6], [7]
+                    if (wave >= first_spec) PT_OWN(1);
+                }
+                if (split && wave >= NW - 4 && wave < first_spec) {
+                    lds_flag_wait(ctrl + 3, step_tag); lds_flag_wait(ctrl + 4, step_tag);
+                    lds_flag_wait(ctrl + 6, step_tag); lds_flag_wait(ctrl + 7, step_tag);
+                    PT_OWN(1);
+                    if (chain_lane) {
+                        // output layer of spilled item tid (pass 2, sample tid - 2 B): the canonical chain over all hidden units, h from the rows
+                        constexpr int N1 = OW2 / 4, N2 = (PR - OW2) / 4, PR4 = PR / 4;
+                        const float4 *W4 = reinterpret_cast<const float4 *>(q_tgt);
+                        const int Hqf = FIXED ? FIX_HQ : Hq;
+                        const int npairs = (Hqf + 1) >> 1;
+                        const float *hx = lds + LV(o_hX) + split_u * HP;
+                        float q[A];
+#pragma unroll
+                        for (int aa = 0; aa < A; ++aa) q[aa] = 0.0f;
+                        // blocks of eight pairs: every LDS read of a block is in flight before its first use (one round trip per
+                        // block instead of one per pair -- this chain runs alone on its wave)
+                        constexpr int CB = 8;
+#pragma unroll 1
+                        for (int j0 = 0; j0 < npairs; j0 += CB) {
+                            v2f hv[CB];
+                            float4 wv[CB][N2];
+#pragma unroll
+                            for (int u = 0; u < CB; ++u) {
+                                const int jp = j0 + u < npairs ? j0 + u : npairs - 1;            // (clamped reads, unused)
+                                hv[u] = *reinterpret_cast<const v2f *>(hx + 2 * jp);             // (the odd tail's second word is never used)
+#pragma unroll
+                                for (int v = 0; v < N2; ++v) wv[u][v] = W4[jp * PR4 + N1 + v];
+                            }
+#pragma unroll
+                            for (int u = 0; u < CB; ++u) {
+                                const int jp = j0 + u;
+                                if (jp < npairs) {
+                                    const bool two = 2 * jp + 1 < Hqf;
+                                    float w2[PR - OW2];
+#pragma unroll
+                                    for (int v = 0; v < N2; ++v) { w2[4 * v] = wv[u][v].x; w2[4 * v + 1] = wv[u][v].y; w2[4 * v + 2] = wv[u][v].z; w2[4 * v + 3] = wv[u][v].w; }
+                                    if constexpr (A == 2) {
+                                        v2f qq = {q[0], q[1]};
+                                        qq = fma2((v2f){hv[u].x, hv[u].x}, (v2f){w2[0], w2[1]}, qq);
+                                        if (two) qq = fma2((v2f){hv[u].y, hv[u].y}, (v2f){w2[2], w2[3]}, qq);
+                                        q[0] = qq.x; q[1] = qq.y;
+                                    } else {
+#pragma unroll
+                                        for (int aa = 0; aa < A; ++aa) q[aa] = fma32(hv[u].x, w2[aa], q[aa]);
+                                        if (two) {
+#pragma unroll
+                                            for (int aa = 0; aa < A; ++aa) q[aa] = fma32(hv[u].y, w2[A + aa], q[aa]);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int aa = 0; aa < A; ++aa) qres[(2 * MAX_B + (tid - 2 * B)) * A + aa] = q[aa] + q_tgt[npairs * PR + aa];
+                    }
+                }
+                if (split && wave >= NW - 4) __builtin_amdgcn_s_setprio(0);
+                if (wave >= first_spec) {
                     if (wave != ENV_WAVE) lds_flag_wait(ctrl + 5, step_tag);       // cur_state / done of this step
                   if (ctrl[t & 1] <= 0.5f) {
                     // ---- speculative SE step of the NEXT env step for every action (this wave's share) ----
@@ -785,16 +900,20 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     // workgroup barrier between the TD error and the gradient
                     for (int b = b0 + lane; b < b1; b += 64) {
                         const float g32 = a.f_gamma, norm = a.f_norm;
+                        // every LDS word the sample needs is requested before the first is used: one round trip, not three
+                        // (reward/done/action -> argmax row -> the two selected entries); the selections are register moves
+                        float q0[A], q1[A], q2[A];
+#pragma unroll
+                        for (int aa = 0; aa < A; ++aa) { q0[aa] = qres[(0 * MAX_B + b) * A + aa]; q1[aa] = qres[(1 * MAX_B + b) * A + aa]; q2[aa] = qres[(2 * MAX_B + b) * A + aa]; }
                         const float r = rda[b * 4], d = rda[b * 4 + 1];
                         const int ab = (int)rda[b * 4 + 2];
-                        int am = 0;
-                        float best = qres[(1 * MAX_B + b) * A];
+                        float best = q1[0], qt = q2[0], qa = q0[0];                 // argmax: first maximum, as torch.max
 #pragma unroll
-                        for (int aa = 1; aa < A; ++aa) { float v = qres[(1 * MAX_B + b) * A + aa]; if (v > best) { best = v; am = aa; } }
-                        const float t1 = g32 * qres[(2 * MAX_B + b) * A + am];
+                        for (int aa = 1; aa < A; ++aa) { if (q1[aa] > best) { best = q1[aa]; qt = q2[aa]; } if (ab == aa) qa = q0[aa]; }
+                        const float t1 = g32 * qt;
                         const float t2 = 1.0f - d;
                         const float y = r + t1 * t2;
-                        const float diff = qres[(0 * MAX_B + b) * A + ab] - y;
+                        const float diff = qa - y;
                         const float dq = norm * diff;
                         // dL/dQ(s_b, .) as a row: only entry a_b is non-zero (DDQN.py:84 gather) -- the backward pass multiplies
                         // by these masks instead of branching on the action
@@ -846,7 +965,11 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                             }
                         };
                         // running pointers (one add per round each): h column of this lane, dq rows and state rows of the chunk
-                        const float *hp = hB + (jv ? j : 0) + b0 * HP, *dqp = dqB + 4 * b0, *sp = sB + SP * b0;
+                        // (vzero: a zero the compiler cannot see through -- it keeps the two wave-uniform row pointers in VGPRs, so a
+                        // group's reads differ in their immediate offsets only instead of each getting its own s_add + v_mov)
+                        int vzero;
+                        asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+                        const float *hp = hB + (jv ? j : 0) + b0 * HP, *dqp = dqB + 4 * b0 + vzero, *sp = sB + SP * b0 + vzero;
                         int bq = b0;
 #pragma unroll 1
                         for (; bq + 4 <= b1; bq += 4, hp += 4 * HP, dqp += 16, sp += 4 * SP) {
@@ -1100,7 +1223,7 @@ template <int I> static bool shape_matches(const lenv_ddqn_cfg *cfg, const Inner
     constexpr InnerLayout LC = make_inner_layout(sp.S, sp.A, sp.Hq, sp.Hse, sp.B, sp.T, sp.chunk, NT, NW, MAX_PPT, MAX_B);
     return cfg->env_id == sp.env && cfg->q_act == sp.q_act && cfg->q_hidden == sp.Hq && cfg->se_hidden == sp.Hse && cfg->batch_size == sp.B &&
            cfg->test_episodes == sp.T && cfg->max_steps == sp.max_steps && cfg->se_act == sp.se_act && L.chunk == sp.chunk &&
-           L.lds_floats == LC.lds_floats && L.tanh16 == LC.tanh16 && L.P_q <= NT;
+           L.lds_floats == LC.lds_floats && L.tanh16 == LC.tanh16 && L.split_D == LC.split_D && L.split_L == LC.split_L && L.P_q <= NT;
 }
 static int published_shape(const lenv_ddqn_cfg *cfg, const InnerLayout &L)
 {

@@ -20,14 +20,16 @@
 static inline float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
-/* Canonical tanh (v3): t = min(|x|, TMAX), w = t + 1, b = bits(w), i = (b >> SHIFT) - IDX0 (exponent + top 5 mantissa
- * bits of w: intervals of 1/32 on [0,1), 1/16 on [1,3), 1/8 on [3,7), 1/4 beyond -- 105 entries), d = w - float(b with
- * the low SHIFT bits cleared) (exact), tanh(x) = copysign(((c3 d + c2) d + c1) d + c0, x) with (c0..c3)_i of
- * lenv_tanh_table.h = cubic fit of tanh(w_i - 1 + d) (tools/gen_tanh_table.py; interval 0 pins c0 = 0, c1 = 1, c2 = 0).
- * No exp, no division, no final clamp: 10 VALU instructions + one 16-byte table gather on the GPU, and the table is small
- * enough for 16 bank-private LDS copies (conflict-free gathers).  Replaces torch.tanh (activation_fn 'tanh',
- * models/model_utils.py:15-16); max deviation from the exact tanh is 1.1e-7 absolute (the rounding of t + 1 included);
- * every result lies in [0,1] (tests/test_oracle_golden.py checks all 1.1e9 floats in [0, 16]). */
+/* Canonical tanh (v4): t = min(|x|, TMAX), u = t + 2^19 (one float addition: the ulp of 2^19 is 1/16, so the addition rounds
+ * t to the nearest grid point i/16 and the low mantissa bits of u are i), i = bits(u) - bits(2^19), d = t - (u - 2^19)
+ * (both differences exact, |d| <= 1/32), tanh(x) = copysign(((c3 d + c2) d + c1) d + c0, x) with (c0..c3)_i of
+ * lenv_tanh_table.h = cubic fit of tanh(i/16 + d) (tools/gen_tanh_table.py; entry 0 pins c0 = 0, c1 = 1, c2 = 0).  147 entries.
+ * No exp, no division, no final clamp.  On the GPU a pair of hidden units costs 15 VALU instructions + two 16-byte gathers
+ * (the steps to u, u - 2^19 and d are packed adds, the LDS address is one shift-add of bits(u)); the table is small enough
+ * for 16 bank-private LDS copies (conflict-free gathers).  Replaces torch.tanh (activation_fn 'tanh',
+ * models/model_utils.py:15-16); max deviation from the exact tanh is 6.5e-8 absolute; every result lies in [0,1]
+ * (tests/test_oracle_golden.py checks all 1.1e9 floats in [0, 16]).
+ * (v3, rounds 1-2, indexed a log-spaced table by the exponent / mantissa bits of |x| + 1: 18 instructions per pair.) */
 #include "lenv_tanh_table.h"
 static const float orc_tanh_table[LENV_TANH_N * 4] = LENV_TANH_TABLE_INIT;
 
@@ -35,14 +37,12 @@ float orc_tanhf(float x)
 {
     float ax = fabsf(x);
     float t = ax < LENV_TANH_TMAX ? ax : LENV_TANH_TMAX;
-    float w = t + 1.0f;
-    uint32_t b, bt;
-    float wt;
-    memcpy(&b, &w, 4);
-    bt = b & ~((1u << LENV_TANH_SHIFT) - 1u);
-    memcpy(&wt, &bt, 4);
-    float d = w - wt;
-    const float *k = orc_tanh_table + 4 * ((int)(b >> LENV_TANH_SHIFT) - LENV_TANH_IDX0);
+    float u = t + LENV_TANH_MAGIC;                      /* rounds t to the 1/16 grid (ulp of 2^19): IEEE semantics required --  */
+    float r = u - LENV_TANH_MAGIC;                      /* no -ffast-math / -fassociative-math (oracle/Makefile has neither)  */
+    float d = t - r;                                    /* exact, |d| <= 1/32                                                  */
+    uint32_t b;
+    memcpy(&b, &u, 4);
+    const float *k = orc_tanh_table + 4 * (int)(b - LENV_TANH_MAGIC_BITS);
     float p = fmaf(k[3], d, k[2]);
     p = fmaf(p, d, k[1]);
     p = fmaf(p, d, k[0]);

