@@ -41,7 +41,7 @@ print("generation wall %.1f ms; stats %s" % (dt * 1e3, master.inner.stats[0].tol
 for i, n in enumerate(names):
     if buf[i]:
         print("%-22s %12d cycles  %5.1f%%" % (n, buf[i], 100.0 * buf[i] / tot))
-print("own-work cycles before each barrier (forward | TD | gradient | Adam), per learn step:")
+print("own-work cycles before each barrier (forward | split layout: rows written (waves 10, 11) / all rows seen (8, 9) | gradient | Adam), per learn step:")
 steps = max(1, int(master.inner.stats[0][2]))
 for slot, w in enumerate(range(12)):
     print("  wave %2d: " % w + " | ".join("%7.0f" % (buf[12 + 4 * slot + i] / steps) for i in range(4)))
