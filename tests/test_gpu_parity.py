@@ -1633,6 +1633,52 @@ def test_inner_loop_with_and_without_trace_agree(eng, orc, golden, env_name, hq,
     assert float(outs[0][0][c]) == o["score"] and outs[0][1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
 
 
+@pytest.mark.parametrize("env_name,hq,batch,act,split", [("CartPole-v0", 16, 180, "tanh", (28, 4)), ("CartPole-v0", 33, 213, "relu", (127, 2)),
+                                                         ("CartPole-v0", 24, 200, "leakyrelu", (88, 2)), ("Acrobot-v1", 40, 190, "tanh", (58, 4)),
+                                                         ("CartPole-v0", 57, 199, "relu", (85, 3)), ("CartPole-v0", 10, 199, "tanh", (0, 0))])
+def test_inner_loop_split_forward_layouts(eng, orc, golden, env_name, hq, batch, act, split):
+    """Minibatches of more than 170 samples spill forward items into the third wave of SIMDs 0 / 1; the kernel cuts those items
+    into 2, 3 or 4 parts over the hidden-unit pairs, shares their activations between the four third waves and runs their output
+    layers from LDS rows (split layout).  Every cut (and the fall-back for nets too narrow to cut) must
+    leave the bits alone: whole chains against the oracle."""
+    cfgd = json.loads(str(golden("g8_calc_score_cartpole_a")["config_json"]))
+    if env_name == "Acrobot-v1":
+        cfgd["env_name"] = env_name
+        cfgd["envs"][env_name] = dict(cfgd["envs"]["CartPole-v0"], solved_reward=-100.0)
+    cfgd["envs"][env_name]["hidden_size"] = 64
+    cfgd["agents"]["ddqn"].update(hidden_size=hq, batch_size=batch, activation_fn=act, test_episodes=3)
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, train_episodes=4, max_steps=30)
+    from learning_environments_amd.config import pick_grad_chunk
+    ocfg.grad_chunk = cfg.grad_chunk = pick_grad_chunk(cfg)
+    L = 3 * batch - 512
+    assert split == ((L, 4 if L <= 64 else (3 if L <= 85 else 2)) if (hq + 1) // 2 >= 8 else (0, 0))    # make_inner_layout's rule
+    S, A = ocfg.state_dim, ocfg.num_actions
+    hse = cfgd["envs"][env_name]["hidden_size"]
+    rng = np.random.RandomState(47)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, hse, 1, cfgd["envs"][env_name]["activation_fn"]))
+    P_q = orc.mlp_num_params(orc.mlp_desc(S, hq, 1, A, act))
+    chains = 6
+    theta = (rng.randn(P_se) * 0.15).astype(np.float32)
+    eps = (rng.randn(2, P_se) * 0.05).astype(np.float32)
+    agent_init = (rng.uniform(-0.4, 0.4, (chains, P_q))).astype(np.float32)
+    worker = np.repeat(np.arange(2), 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), 2)
+    keys = np.array([orc.chain_key(11, 5, int(worker[c]), c % 3) for c in range(chains)], np.uint64)
+    il = eng.InnerLoop(cfg, chains)
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in (1, 5):
+        w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+        o = orc.ddqn_se_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]))
+        assert o["learn_steps"] > 10
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(il.episode_len[c].cpu().numpy()[:o["episode_len"].size], o["episode_len"])
+        assert np.array_equal(il.final_returns[c].cpu().numpy(), o["final_test_returns"])
+
+
 @pytest.mark.parametrize("which", ["cartpole", "acrobot_syn_env", "mountaincar"])
 def test_inner_loop_other_published_shapes_specialised_vs_generic(eng, orc, which):
     """default_config_cartpole.yaml (Critic_DQN 4-64-2 relu, batch 32, SE hidden 128, one test episode) and
