@@ -564,7 +564,7 @@ def run_rank(args):
                                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                                 "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": kernel_ms,
                                 "note": "latency/issue-bound small-MLP chains: weights+activations live in LDS, only the replay "
-                                        "buffer touches HBM/L2 (see DESIGN.md); the binding resource is VALU issue, see roofline_valu"}
+                                        "buffer touches HBM/L2 (see DESIGN.md); the binding resources are VALU issue and the LDS pipe together (DESIGN.md section 8, add-work experiment), see roofline_valu"}
             busy = min(chains, 256)
             line["roofline_valu"] = {"bound": "valu issue (fp32 vector)", "kernel": "ddqn_se_inner_kernel", "achieved": tflops,
                                      "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VALU_PEAK_TFLOPS,

@@ -2,7 +2,8 @@
 # One GPU-box round (run via gpurun from the repo root): bench with the CPU baseline, rocprofv3 kernel trace of the headline and of
 # every other BASELINE configuration (one run and one CSV per configuration), the HBM-traffic PMC passes (separate runs, kernel-trace
 # only, as MI355X_MICROARCH.md prescribes) for the three big kernels, and the SQ counter sets.  Outputs: gpurun_out/ -> profiles/.
-# usage: tools/gpu_round_r03.sh [tag]
+# usage: tools/gpu_round_r03.sh [tag]   (before the gpurun call, `rm -rf gpurun_out/pmc* gpurun_out/prof*` in the container: gpurun MERGES
+# the box's files into the local scratch, and counter files of earlier calls would be summarised along with the new ones)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r03}
 mkdir -p $R/gpurun_out
