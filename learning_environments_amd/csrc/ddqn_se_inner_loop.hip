@@ -681,6 +681,13 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     float x[S];
 #pragma unroll
                     for (int i = 0; i < S; ++i) x[i] = fwd_pass == 0 ? row[i] : row[S + 1 + i];
+                    if (full_item && fwd_pass == 0) {
+                        // the sample's state / reward / done / action for the TD error and the backward: stored BEFORE the pair loop, so that
+                        // the row's registers are dead inside it
+#pragma unroll
+                        for (int i = 0; i < S; ++i) sB[fwd_b * SP + i] = row[i];
+                        rda[fwd_b * 4 + 0] = row[2 * S + 1]; rda[fwd_b * 4 + 1] = row[2 * S + 2]; rda[fwd_b * 4 + 2] = row[S];
+                    }
                     const float *W = fwd_pass == 2 ? q_tgt : q_onl;
                     float q[A];
 #pragma unroll
@@ -779,11 +786,6 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         if (jp < npairs) finish(pa, jp, 2 * jp + 1 < Hqf, F{});
 #pragma unroll
                         for (int aa = 0; aa < A; ++aa) qres[(fwd_pass * MAX_B + fwd_b) * A + aa] = q[aa] + W[npairs * PR + aa];
-                        if (fwd_pass == 0) {
-#pragma unroll
-                            for (int i = 0; i < S; ++i) sB[fwd_b * SP + i] = row[i];
-                            rda[fwd_b * 4 + 0] = row[2 * S + 1]; rda[fwd_b * 4 + 1] = row[2 * S + 2]; rda[fwd_b * 4 + 2] = row[S];
-                        }
                     } else {
                         // split layout, h-only lane: the activations of pairs [p0, p1) of its item
                         const int sd = SPLIT_D > 0 ? SPLIT_D : 1, p0 = split_part * npairs / sd, p1 = (split_part + 1) * npairs / sd;
