@@ -159,6 +159,10 @@ int lenv_qnet_td_forward(const lenv_mlp_desc *qnet /*HOST*/, const float *online
 size_t lenv_ddqn_se_workspace_bytes(const lenv_ddqn_cfg *cfg /*HOST*/, int64_t chains);
 /* LDS bytes one chain needs for this cfg (incl. grad_chunk), or a negative LENV_ERR_* when unsupported / > 160 KiB */
 int64_t lenv_ddqn_se_lds_bytes(const lenv_ddqn_cfg *cfg /*HOST*/);
+/* How the minibatch forward of this cfg is laid out (diagnostic, host only): *items = forward items (sample, pass) that spill
+ * beyond the first eight waves of the workgroup, *parts = the number of pieces each of them is cut into over the hidden-unit pairs
+ * (0 = plain layout: nothing spills, too much spills, the net is too narrow to cut, or the shared rows do not fit LDS). */
+int lenv_ddqn_se_forward_split(const lenv_ddqn_cfg *cfg /*HOST*/, int32_t *items, int32_t *parts);
 int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg /*HOST*/, const float *theta, const float *eps,
                             const int32_t *worker, const float *sign, const float *agent_init,
                             const uint64_t *rng_keys, const lenv_tapes *tapes /*HOST struct of device ptrs, may be NULL*/,

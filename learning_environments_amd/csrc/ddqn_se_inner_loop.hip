@@ -1272,6 +1272,18 @@ extern "C" int64_t lenv_ddqn_se_lds_bytes(const lenv_ddqn_cfg *cfg)
     return (int64_t)a.L.lds_floats * (int64_t)sizeof(float);
 }
 
+extern "C" int lenv_ddqn_se_forward_split(const lenv_ddqn_cfg *cfg, int32_t *items, int32_t *parts)
+{
+    if (!cfg || !items || !parts) return LENV_ERR_INVALID;
+    int rc = inner_check(cfg);
+    if (rc != LENV_OK) return rc;
+    InnerArgs a;
+    rc = inner_layout(cfg, a);
+    if (rc != LENV_OK) return rc;
+    *items = a.L.split_L; *parts = a.L.split_D;
+    return LENV_OK;
+}
+
 extern "C" size_t lenv_ddqn_se_workspace_bytes(const lenv_ddqn_cfg *cfg, int64_t chains)
 {
     if (!cfg || chains < 0) return 0;

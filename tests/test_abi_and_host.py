@@ -47,6 +47,30 @@ def test_host_only_entry_points():
     assert L.lenv_nes_rank_update(9, None, None, 4, None, None, 0, 0.1, 0, 0.0, None, None) == -1
 
 
+def test_forward_layout_decisions_of_the_ddqn_kernel():
+    """`lenv_ddqn_se_forward_split` (host only): minibatches of more than 170 samples spill forward items beyond the workgroup's
+    first eight waves; the kernel cuts the spilled items into 4 / 3 / 2 parts (<= 64 / <= 85 / <= 128 items) unless the net has
+    fewer than eight hidden-unit pairs or the shared activation rows do not fit the 160 KiB of LDS next to everything else."""
+    from learning_environments_amd import _lib, configs
+    from learning_environments_amd.config import ddqn_cfg_from_config
+    L = _lib.lib()
+    cfg = ddqn_cfg_from_config(configs.cartpole_syn_env_ddqn(4))            # BASELINE configs[1]: B 199, 4-57-2, SE hidden 83
+    items, parts = C.c_int32(), C.c_int32()
+    assert L.lenv_ddqn_se_forward_split(C.byref(cfg), C.byref(items), C.byref(parts)) == 0 and (items.value, parts.value) == (85, 3)
+    assert L.lenv_ddqn_se_lds_bytes(C.byref(cfg)) <= 160 * 1024
+    expect = {(170, 57): (0, 0), (171, 57): (1, 4), (180, 16): (28, 4), (200, 24): (88, 2), (213, 33): (127, 2),
+              (213, 57): (0, 0),      # the rows of 127 items would not fit: plain layout, still with the 16 tanh-table copies
+              (199, 10): (0, 0),      # five pairs: too narrow to cut
+              (199, 64): (0, 0)}      # does not fit either
+    for (B, H), want in expect.items():
+        c = _lib.DdqnCfg.from_buffer_copy(cfg)
+        c.batch_size, c.q_hidden, c.grad_chunk = B, H, (B + 11) // 12
+        assert L.lenv_ddqn_se_forward_split(C.byref(c), C.byref(items), C.byref(parts)) == 0, (B, H)
+        assert (items.value, parts.value) == want, (B, H, items.value, parts.value)
+        assert 0 < L.lenv_ddqn_se_lds_bytes(C.byref(c)) <= 160 * 1024
+    assert L.lenv_ddqn_se_forward_split(None, C.byref(items), C.byref(parts)) != 0
+
+
 def test_chain_keys_vectorised_matches_abi():
     from learning_environments_amd import _lib
     from learning_environments_amd.agents.nes_common import chain_keys, shard_bounds
