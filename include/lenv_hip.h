@@ -163,6 +163,11 @@ int64_t lenv_ddqn_se_lds_bytes(const lenv_ddqn_cfg *cfg /*HOST*/);
  * beyond the first eight waves of the workgroup, *parts = the number of pieces each of them is cut into over the hidden-unit pairs
  * (0 = plain layout: nothing spills, too much spills, the net is too narrow to cut, or the shared rows do not fit LDS). */
 int lenv_ddqn_se_forward_split(const lenv_ddqn_cfg *cfg /*HOST*/, int32_t *items, int32_t *parts);
+/* Workgroups per chain lenv_ddqn_se_inner_loop would use for a counter-mode launch of `chains` chains on the current device: > 1 when
+ * the launch leaves enough CUs idle for every member of every chain to be resident (shards of a population spread over several
+ * GPUs); the members deal the minibatch by whole gradient micro-chunks and meet once per learn step -- same bits for every team
+ * size.  LENV_DDQN_TEAM=<G> in the environment caps / forces the size (1 = never).  Status -10 = a member gave up waiting. */
+int lenv_ddqn_se_team_size(const lenv_ddqn_cfg *cfg /*HOST*/, int64_t chains);
 int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg /*HOST*/, const float *theta, const float *eps,
                             const int32_t *worker, const float *sign, const float *agent_init,
                             const uint64_t *rng_keys, const lenv_tapes *tapes /*HOST struct of device ptrs, may be NULL*/,

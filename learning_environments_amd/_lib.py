@@ -133,7 +133,7 @@ class Td3Out(C.Structure):
 
 
 EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv_se_step_population",
-           "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_lds_bytes", "lenv_ddqn_se_forward_split", "lenv_ddqn_se_inner_loop",
+           "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_lds_bytes", "lenv_ddqn_se_forward_split", "lenv_ddqn_se_team_size", "lenv_ddqn_se_inner_loop",
            "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population", "lenv_dueling_se_workspace_bytes",
            "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_dueling_se_inner_loop_hp", "lenv_dueling_agent_init_hp", "lenv_rng_unit", "lenv_td3_rn_inner_loop_hp", "lenv_td3_agent_init_hp", "lenv_icm_num_params", "lenv_dueling_se_inner_loop_icm", "lenv_chain_uniform_init", "lenv_td3_icm_num_params", "lenv_td3_rn_inner_loop_icm", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
            "lenv_td3_rn_inner_loop", "lenv_mlp_forward", "lenv_cheetah_standin_reset", "lenv_cheetah_standin_step", "lenv_cont_env_reset", "lenv_cont_env_step",
@@ -180,6 +180,8 @@ def lib():
                                               C.c_size_t, C.POINTER(InnerOut), vp]
         L.lenv_ddqn_se_lds_bytes.restype = C.c_int64
         L.lenv_ddqn_se_lds_bytes.argtypes = [C.POINTER(DdqnCfg)]
+        L.lenv_ddqn_se_team_size.restype = C.c_int
+        L.lenv_ddqn_se_team_size.argtypes = [C.POINTER(DdqnCfg), C.c_int64]
         L.lenv_ddqn_se_forward_split.restype = C.c_int
         L.lenv_ddqn_se_forward_split.argtypes = [C.POINTER(DdqnCfg), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.lenv_real_env_reset.restype = C.c_int

@@ -136,6 +136,12 @@ struct InnerArgs {
     // torch.optim.Adam bias corrections per learn step t = 1, 2, ...: {-(lr / (1 - beta1^t)), sqrt(1 - beta2^t)} as fp32,
     // computed in double on the host with the same operation sequence the kernel's thread NT-1 used to run every step
     const float2 *adam_sched;
+    // TEAM instantiation (a chain on team_G co-resident workgroups, see the kernel): per chain team_stride floats at team_ws --
+    // 16 words (barrier counter, the members' XCD ids, give-up flag), then two copies (learn-step parity) of the chunk partials
+    // [n_chunks4][P_q] as 8-byte {value, learn step + 1} granules
+    float *team_ws;
+    int64_t team_stride, chains;
+    int team_G;
 };
 
 // Workgroup-internal flag in LDS: the env wave publishes "phase A of step `tag` is done" while the other waves are already
@@ -308,7 +314,15 @@ __device__ __forceinline__ void real_env_obs(const double (&st)[4], float (&obs)
 // SHAPE > 0 = a published configuration (kShapes above; 1 = BASELINE configs[1]): network widths, batch size, chunking and the whole LDS layout are
 // literals, which frees the scalar registers that otherwise carry them (the generic build spills ~350 SGPR values to VGPR lanes
 // and reloads ~100 of them per learn step with v_readlane, a VALU slot each) and removes the tail code of the pair loops.
-template <int ENV, int S, int A, int QACT, int PPT, int SHAPE = 0>
+//
+// TEAM = a chain runs on G co-resident workgroups of one XCD (launches that leave most of the GPU idle: the shards of a population
+// spread over several GPUs).  Every member keeps the whole chain state and repeats the cheap serial parts (acting, the SE step, the
+// replay append -- identical rows to the same addresses --, the test episodes); the minibatch is dealt over the members by whole
+// gradient micro-chunks: a member runs the forward items, TD errors and chunk gradients of ITS samples only, leaves its chunk
+// partials in the chain's exchange buffer, the members meet at ONE agent-scope barrier per learn step, read the other members'
+// partials, and each applies the same Adam step to its own copy of the parameters.  The partials are summed in chunk order by
+// every member, so the bits are those of the one-workgroup launch for every G.
+template <int ENV, int S, int A, int QACT, int PPT, int SHAPE = 0, bool TEAM = false>
 __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 {
     extern __shared__ __align__(16) float lds[];
@@ -321,7 +335,18 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     static_assert(!FIXED || LC.rc == LENV_OK, "the fixed shape must fit");
 #define LV(f) (FIXED ? LC.f : a.L.f)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t chain = blockIdx.x;
+    // TEAM: block x + 8 k is member k % G of chain 8 (k / G) + x -- consecutive blocks go to consecutive XCDs, so a chain's members share one
+    int64_t chain_ = blockIdx.x;
+    int g_ = 0, G_ = 1;
+    if constexpr (TEAM) {
+        G_ = a.team_G;
+        const int64_t xb = blockIdx.x, k = xb >> 3;
+        chain_ = 8 * (k / G_) + (xb & 7);
+        g_ = (int)(k % G_);
+        if (chain_ >= a.chains) return;
+    }
+    const int64_t chain = chain_;
+    const int g = g_, G = G_;
     constexpr int K = S + A;
     constexpr int OW2 = rec_ow2<S>();                 // offset of the output-layer part inside a pair record
     constexpr int PR = rec_pr<S, A>();                // floats per pair record
@@ -428,21 +453,30 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     // computes the ACTIVATIONS of part u / L of item u % L into an LDS row; the output layer's accumulation -- the one
     // sequential piece, k ascending over the hidden units -- is then run per item by the thread that owned it, from those rows.
     // Same operations on the same values in the same order: the bits do not change.
-    const int SPLIT_D = LV(split_D), SPLIT_L = LV(split_L);
+    // TEAM: this member's share of the minibatch = whole micro-chunks [mc0, mc1) = samples [mb0, mb0 + Bm)
+    const int mc0 = TEAM ? g * LV(n_chunks) / G : 0, mc1 = TEAM ? (g + 1) * LV(n_chunks) / G : LV(n_chunks);
+    const int mb0 = mc0 * LV(chunk), Bm = (mc1 * LV(chunk) < B ? mc1 * LV(chunk) : B) - mb0;
+    // TEAM: a member of a team of two has 3 Bm = ~300 items = four full waves (one per SIMD) and a fifth, part-filled one that would
+    // make SIMD 0 carry two; those spilled items are cut four ways over waves 4 .. 7, which have nothing else to do in the interval
+    // (the same machinery, one SIMD-round earlier; bigger teams have at most one forward wave per SIMD anyway)
+    const bool tsplit = TEAM && 3 * Bm > 256 && 3 * Bm - 256 <= 64 && 3 * Bm - 256 <= LV(split_L) && 2 * Bm <= 256 && LV(split_D) > 0;
+    const int SPLIT_D = TEAM ? (tsplit ? 4 : 0) : LV(split_D), SPLIT_L = TEAM ? (tsplit ? 3 * Bm - 256 : 0) : LV(split_L);
     const bool split = SPLIT_D > 0;
-    constexpr int SPLIT_T0 = (NW - 4) * 64;              // first thread of the four third waves
+    constexpr int SPLIT_W0 = TEAM ? 4 : NW - 4;          // first of the four waves that share the spilled items' activations
+    constexpr int SPLIT_T0 = SPLIT_W0 * 64;
     const int split_u = tid - SPLIT_T0;                  // lane number inside them
     const bool h_lane = split && split_u >= 0 && split_u < SPLIT_L * SPLIT_D;
     const int split_li = h_lane ? split_u % SPLIT_L : 0, split_part = h_lane ? split_u / SPLIT_L : 0;
-    const bool chain_lane = split && split_u >= 0 && tid < 3 * B;
-    const int fwd_pass = (split && split_u >= 0) ? 2 : (tid < B ? 0 : (tid < 2 * B ? 1 : 2));
-    const int fwd_b = (split && split_u >= 0) ? SPLIT_T0 + split_li - 2 * B : tid - fwd_pass * B;
-    const bool full_item = split ? tid < SPLIT_T0 : tid < 3 * B;   // runs all pairs of its item, output layer included
+    const bool chain_lane = split && split_u >= 0 && tid < 3 * Bm;
+    const bool split_wave = split && wave >= SPLIT_W0 && wave < SPLIT_W0 + 4;
+    const int fwd_pass = (split && split_u >= 0) ? 2 : (tid < Bm ? 0 : (tid < 2 * Bm ? 1 : 2));
+    const int fwd_b = (split && split_u >= 0) ? mb0 + SPLIT_T0 + split_li - 2 * Bm : mb0 + tid - fwd_pass * Bm;
+    const bool full_item = split ? tid < SPLIT_T0 : tid < 3 * Bm;  // runs all pairs of its item, output layer included
     const bool fwd_active = full_item || h_lane;          // samples a replay row
 
     // speculation layout: waves without forward items (at most the last two) evaluate the SE for every action of the
     // NEXT step while the other waves run the minibatch forwards; the env wave then only has to pick a candidate.
-    const int n_fwd_waves = (3 * B + 63) >> 6;
+    const int n_fwd_waves = (3 * Bm + 63) >> 6;
     const int first_spec = n_fwd_waves > NW - 2 ? n_fwd_waves : NW - 2;
     const int n_spec = NW - first_spec;                 // 0, 1 or 2 (uniform)
     bool spec_valid = false;
@@ -566,6 +600,43 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     // Deterministic time-out (lenv_ddqn_cfg::step_budget, base_agent.py:30-47): elapsed = env steps taken so far
     const bool budgeted = cfg.step_budget > 0;
     int timed_out_at = -1;
+    // ---- TEAM barrier (as in td3_wavechain.hip): one monotonically increasing counter per chain, zeroed by a kernel in front of the
+    // launch; thread 0 releases, arrives, waits for the epoch's count, acquires.  Members on one XCD share its L2 (the vector L1
+    // writes through): release = the stores have left the CU, acquire = this CU's L1 lines dropped; otherwise the agent-scope fences.
+    // A member that waits for seconds gives up for good (status -10) instead of hanging the device.
+    unsigned team_epoch = 0;
+    bool team_dead = false, team_same_xcd = false;
+    unsigned *team_bar = TEAM ? reinterpret_cast<unsigned *>(a.team_ws + chain * a.team_stride) : nullptr;
+    auto team_barrier = [&]() {
+        if constexpr (TEAM) {
+            __syncthreads();
+            ++team_epoch;
+            if (tid == 0 && !team_dead) {
+                if (team_same_xcd) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_fetch_add(team_bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned target_ = team_epoch * (unsigned)G;
+                long spins = 0;
+                while (__hip_atomic_load(team_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target_) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > 8000000L) break;
+                }
+                if (team_same_xcd) asm volatile("buffer_inv sc1" ::: "memory");
+                else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (spins > 8000000L) team_bar[15] = 1u;
+            }
+            __syncthreads();
+            if (!team_dead && __hip_atomic_load(team_bar + 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { team_dead = true; status = -10; }
+        }
+    };
+    if constexpr (TEAM) {
+        if (tid == 0) team_bar[1 + g] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;       // HW_REG_XCC_ID[3:0]
+        team_barrier();                                        // every member's XCD id is posted
+        bool same = true;
+        const unsigned x0 = __hip_atomic_load(team_bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int m = 1; m < G; ++m) same = same && __hip_atomic_load(team_bar + 1 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == x0;
+        team_same_xcd = same;
+    }
     PT_DECL;
     for (int episode = 0; episode < cfg.train_episodes; ++episode) {
         if (budgeted && (int64_t)train_steps + test_steps > cfg.step_budget) { timed_out_at = episode; break; }   // uniform
@@ -601,7 +672,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
             PT_MARK(9);
             // split layout: what the four third waves do up to the spilled items' output layers is the critical path of the forward
             // interval (the SIMDs' arbiters otherwise serve the older waves first and these rows arrive last)
-            if (split && learning && wave >= NW - 4) __builtin_amdgcn_s_setprio(3);
+            if (split_wave && learning) __builtin_amdgcn_s_setprio(3);
             if (wave == ENV_WAVE) {
                 // ---- select_train_action (DDQN.py:97-104) ----
                 if (!nx_valid) draw_action(train_steps);
@@ -801,13 +872,13 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         if (jp < p1) finish(pa, jp, 2 * jp + 1 < Hqf, T{});
                     }
                 }
-                if (split && wave >= NW - 4) {
+                if (split_wave) {
                     // split layout: this wave's activation rows are written -- tell the two waves that run the spilled items' output layers
-                    const int k = wave - (NW - 4);
+                    const int k = wave - SPLIT_W0;
                     if (lane == 0) lds_flag_store(ctrl + 3 + k + (k >> 1), step_tag);          // ctrl[3], [4], [6], [7]
                     if (wave >= first_spec) PT_OWN(1);
                 }
-                if (split && wave >= NW - 4 && wave < first_spec) {
+                if (split_wave && wave < first_spec) {
                     lds_flag_wait(ctrl + 3, step_tag); lds_flag_wait(ctrl + 4, step_tag);
                     lds_flag_wait(ctrl + 6, step_tag); lds_flag_wait(ctrl + 7, step_tag);
                     PT_OWN(1);
@@ -860,10 +931,10 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                             }
                         }
 #pragma unroll
-                        for (int aa = 0; aa < A; ++aa) qres[(2 * MAX_B + (tid - 2 * B)) * A + aa] = q[aa] + q_tgt[npairs * PR + aa];
+                        for (int aa = 0; aa < A; ++aa) qres[(2 * MAX_B + (mb0 + tid - 2 * Bm)) * A + aa] = q[aa] + q_tgt[npairs * PR + aa];
                     }
                 }
-                if (split && wave >= NW - 4) __builtin_amdgcn_s_setprio(0);
+                if (split_wave) __builtin_amdgcn_s_setprio(0);
                 if (wave >= first_spec) {
                     if (wave != ENV_WAVE) lds_flag_wait(ctrl + 5, step_tag);       // cur_state / done of this step
                   if (ctrl[t & 1] <= 0.5f) {
@@ -894,9 +965,15 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 // lane = hidden unit j.  Per sample (canonical order, oracle orc_ddqn_learn): da = dq*W2[a_b][j] (as a sum over
                 // the action masks, exactly one term non-zero), dz = act'(h)*da, gW1[j][:] += dz*s, gb1[j] += dz,
                 // gW2[a][j] += dqm[a]*h, gb2[a] += dqm[a] -- adding an exact zero leaves the other actions' sums untouched.
-                if (wave < LV(n_chunks)) {
-                    const int b0 = wave * LV(chunk), b1 = (b0 + LV(chunk) < B) ? b0 + LV(chunk) : B;
-                    float *pc = part + wave * P;
+                if (wave < mc1 - mc0) {
+                    const int cg = mc0 + wave;                         // (TEAM: this member's chunks; else mc0 = 0, mc1 = n_chunks)
+                    const int b0 = cg * LV(chunk), b1 = (b0 + LV(chunk) < B) ? b0 + LV(chunk) : B;
+                    float *pc = part + cg * P;
+                    // TEAM: the chunk's partials also go to the chain's exchange buffer (copy of this learn step's parity) for the other members
+                    // as 8-byte granules {value, learn step + 1}: a granule is stored whole, so a reader that sees this step's tag has this
+                    // step's value -- the hand-off needs no fence and no separate flag
+                    float2 *xg = TEAM ? reinterpret_cast<float2 *>(a.team_ws + chain * a.team_stride + 16) + ((int64_t)(learn_it & 1) * LV(n_chunks4) + cg) * P : nullptr;
+                    const float xtag = __int_as_float(learn_it + 1);
                     // TD target and dLoss/dQ(s,a) of the chunk's own samples (DDQN.py:82-86; mse_loss backward = 2/B * diff), one
                     // lane per sample: nobody else reads these rows, so the chunk goes on behind a wave-level fence -- no
                     // workgroup barrier between the TD error and the gradient
@@ -1000,14 +1077,50 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                             pc[Hq * S + j] = gb1;
 #pragma unroll
                             for (int aa = 0; aa < A; ++aa) pc[Hq * S + Hq + aa * Hq + j] = gW2[aa];
+                            if constexpr (TEAM) {
+#pragma unroll
+                                for (int i = 0; i < S; ++i) xg[j * S + i] = make_float2(gW1[i], xtag);
+                                xg[Hq * S + j] = make_float2(gb1, xtag);
+#pragma unroll
+                                for (int aa = 0; aa < A; ++aa) xg[Hq * S + Hq + aa * Hq + j] = make_float2(gW2[aa], xtag);
+                            }
                         }
                         if (j == 0) {
 #pragma unroll
-                            for (int aa = 0; aa < A; ++aa) pc[Hq * S + Hq + A * Hq + aa] = gb2[aa];
+                            for (int aa = 0; aa < A; ++aa) {
+                                pc[Hq * S + Hq + A * Hq + aa] = gb2[aa];
+                                if constexpr (TEAM) xg[Hq * S + Hq + A * Hq + aa] = make_float2(gb2[aa], xtag);
+                            }
                         }
                     }
                 }
                 PT_OWN(2);
+                if constexpr (TEAM) {
+                    // The other members' chunks, into the LDS rows the Adam phase sums in chunk order: every thread polls ITS granules
+                    // (loads that go to the XCD's L2, which the members share and their stores write through to) until they carry this step's
+                    // tag -- one L2 round trip when the other members are done, and the only synchronisation of the learn step.  A buffer is
+                    // written again two learn steps later; by then every member has consumed it (a member cannot finish step t+1 without
+                    // the partials the others produce AFTER consuming step t's).  Members that do not share an XCD meet at the barrier first.
+                    if (!team_same_xcd) team_barrier();
+                    const unsigned long long *xs_ = reinterpret_cast<const unsigned long long *>(a.team_ws + chain * a.team_stride + 16)
+                                                    + (int64_t)(learn_it & 1) * LV(n_chunks4) * P;
+                    const unsigned want_tag = (unsigned)(learn_it + 1);
+                    const int lo = mc0 * P, hi = mc1 * P, tot = LV(n_chunks) * P;
+                    // (four granules per thread in flight at once instead of one after the other measured SLOWER, 1.09x instead of 1.11-1.17x over
+                    // one workgroup per chain: the reader is usually early, and a batch that fails is re-polled granule by granule anyway)
+                    for (int i = tid; i < tot - (hi - lo); i += NT) {
+                        const int e = i < lo ? i : i + (hi - lo);
+                        unsigned long long v = 0;
+                        long spins = 0;
+                        while (!team_dead) {
+                            v = __hip_atomic_load(xs_ + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((unsigned)(v >> 32) == want_tag) break;
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > 4000000L) { team_bar[15] = 1u; status = -10; break; }
+                        }
+                        part[e] = __uint_as_float((unsigned)v);
+                    }
+                }
                 __syncthreads();                               // B4
                 PT_MARK(5);
                 // ---- torch.optim.Adam single-tensor step + Polyak (DDQN.py:88-93), one thread per parameter ----
@@ -1201,6 +1314,11 @@ __global__ __launch_bounds__(256) void adam_schedule_kernel(double lr, double be
         __syncthreads();
     }
 }
+// TEAM launches: the chains' barrier words (counter, XCD ids, give-up flag) and every granule's tag start at zero
+__global__ __launch_bounds__(256) void ddqn_team_reset_kernel(float *team_ws, int64_t n_floats)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_floats; i += (int64_t)gridDim.x * 256) team_ws[i] = 0.0f;   // tags included
+}
 static int64_t adam_schedule_len(const lenv_ddqn_cfg *cfg) { return (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 0) * cfg->max_steps + 1; }
 
 // LDS carve-up of one chain's workgroup; returns LENV_ERR_UNSUPPORTED when the shapes do not fit 160 KiB
@@ -1284,13 +1402,53 @@ extern "C" int lenv_ddqn_se_forward_split(const lenv_ddqn_cfg *cfg, int32_t *ite
     return LENV_OK;
 }
 
+// floats per chain of the team exchange area: 16 barrier words + two copies (learn-step parity) of the chunk partials as 8-byte
+// {value, tag} granules (0 when the layout is refused)
+static int64_t inner_team_stride(const lenv_ddqn_cfg *cfg)
+{
+    InnerArgs t;
+    if (inner_check(cfg) != LENV_OK || inner_layout(cfg, t) != LENV_OK) return 0;
+    return (16 + 4 * (int64_t)t.L.n_chunks4 * t.L.P_q + 63) & ~(int64_t)63;
+}
+
+// Workgroups per chain of a launch with `chains` chains: G > 1 when the chains leave enough of the GPU idle for every member of every
+// chain to be resident at once (one workgroup per CU; blocks are dealt to the XCDs round-robin, so a team is 8 blocks apart) and the
+// minibatch has at least G micro-chunks to deal.  Launches of fewer than 16 chains keep one workgroup per chain unless
+// LENV_DDQN_TEAM=<G> asks for a team size (1 = never); tape-mode launches and launches with a step trace are never teamed.
+static int ddqn_pick_team(const lenv_ddqn_cfg *cfg, int64_t chains, bool production)
+{
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return n;
+    }();
+    const char *e = getenv("LENV_DDQN_TEAM");
+    const int want = e ? atoi(e) : 0;                  // 0 = automatic
+    if (!production || want == 1 || chains < 1) return 1;
+    if (want == 0 && chains < 16) return 1;
+    InnerArgs t;
+    if (inner_check(cfg) != LENV_OK || inner_layout(cfg, t) != LENV_OK) return 1;
+    const int64_t slots = 8 * ((chains + 7) / 8);
+    int best = 1;
+    for (int G : { 2, 3, 4, 6 })
+        if (slots * G <= cus && G <= t.L.n_chunks && (want == 0 || G <= want)) best = G;
+    return best;
+}
+
+extern "C" int lenv_ddqn_se_team_size(const lenv_ddqn_cfg *cfg, int64_t chains)
+{
+    if (!cfg) return 1;
+    return ddqn_pick_team(cfg, chains, cfg->rng_mode == LENV_RNG_COUNTER);
+}
+
 extern "C" size_t lenv_ddqn_se_workspace_bytes(const lenv_ddqn_cfg *cfg, int64_t chains)
 {
     if (!cfg || chains < 0) return 0;
     size_t replay = (size_t)chains * inner_rb_cap(cfg) * inner_row_stride(cfg) * sizeof(float);
     size_t meter = (size_t)chains * (cfg->train_episodes > 0 ? cfg->train_episodes : 1) * sizeof(double);
-    size_t sched = (size_t)adam_schedule_len(cfg) * sizeof(float2);
-    return ((replay + 255) & ~(size_t)255) + ((meter + 255) & ~(size_t)255) + sched + 256;
+    size_t sched = (((size_t)adam_schedule_len(cfg) * sizeof(float2)) + 255) & ~(size_t)255;
+    size_t team = (size_t)chains * (size_t)inner_team_stride(cfg) * sizeof(float);       // (sized for every launch: the team size is a launch-time choice)
+    return ((replay + 255) & ~(size_t)255) + ((meter + 255) & ~(size_t)255) + sched + team + 256;
 }
 
 extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *theta, const float *eps,
@@ -1327,6 +1485,11 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
     const size_t meter_bytes = ((size_t)chains * (cfg->train_episodes > 0 ? cfg->train_episodes : 1) * sizeof(double) + 255) & ~(size_t)255;
     float2 *sched = reinterpret_cast<float2 *>(static_cast<char *>(workspace) + replay_bytes + meter_bytes);
     a.adam_sched = sched;
+    const size_t sched_bytes = (((size_t)adam_schedule_len(cfg) * sizeof(float2)) + 255) & ~(size_t)255;
+    a.team_ws = reinterpret_cast<float *>(static_cast<char *>(workspace) + replay_bytes + meter_bytes + sched_bytes);
+    a.team_stride = inner_team_stride(cfg);
+    a.chains = chains;
+    a.team_G = ddqn_pick_team(cfg, chains, cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action);
 
     void (*kern)(const InnerArgs) = nullptr;
 #define LENV_PICK2(ENVID, SS, AA, PP)                                                                              \
@@ -1350,10 +1513,28 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
         default: break;
         }
     }
+    unsigned grid = (unsigned)chains;
+    if (a.team_G > 1) {
+        // a chain on a team of workgroups: the generic instantiation with the exchange code, or the published CartPole shape's
+        kern = nullptr;
+#define LENV_PICK2(ENVID, SS, AA, PP)                                                                              \
+        switch (cfg->q_act) {                                                                                      \
+        case LENV_ACT_RELU: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_RELU, PP, 0, true>; break;            \
+        case LENV_ACT_LEAKYRELU: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_LEAKYRELU, PP, 0, true>; break;  \
+        case LENV_ACT_TANH: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_TANH, PP, 0, true>; break;            \
+        default: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_IDENTITY, PP, 0, true>; break;                   \
+        }
+        if (cfg->env_id == LENV_ENV_CARTPOLE) { if (a.L.P_q <= NT) { LENV_PICK2(LENV_ENV_CARTPOLE, 4, 2, 1) } else { LENV_PICK2(LENV_ENV_CARTPOLE, 4, 2, 2) } }
+        else { if (a.L.P_q <= NT) { LENV_PICK2(LENV_ENV_ACROBOT, 6, 3, 1) } else { LENV_PICK2(LENV_ENV_ACROBOT, 6, 3, 2) } }
+#undef LENV_PICK2
+        if (!cfg_disables_fixed_shape() && published_shape(cfg, a.L) == 1) kern = ddqn_se_inner_kernel<LENV_ENV_CARTPOLE, 4, 2, LENV_ACT_TANH, 1, 1, true>;
+        grid = (unsigned)(8 * ((chains + 7) / 8) * a.team_G);
+        hipLaunchKernelGGL(ddqn_team_reset_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream), a.team_ws, chains * a.team_stride);
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return LENV_ERR_LAUNCH;
     hipLaunchKernelGGL(adam_schedule_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), cfg->lr, cfg->adam_beta1, cfg->adam_beta2,
                        adam_schedule_len(cfg), sched, out->status, chains);
-    hipLaunchKernelGGL(kern, dim3((unsigned)chains), dim3(NT), lds_bytes, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds_bytes, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }

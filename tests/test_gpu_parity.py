@@ -1682,6 +1682,72 @@ def test_inner_loop_split_forward_layouts(eng, orc, golden, env_name, hq, batch,
         assert np.array_equal(il.final_returns[c].cpu().numpy(), o["final_test_returns"])
 
 
+@pytest.mark.parametrize("case", ["published", "acrobot", "narrow"])
+def test_ddqn_chain_on_a_team_of_workgroups(eng, orc, golden, case, monkeypatch):
+    """A DDQN chain on G co-resident workgroups (launches that leave most of the GPU idle): the members deal the minibatch by whole
+    gradient micro-chunks, exchange the chunk partials once per learn step and each applies the same Adam step.  Every team size
+    must give the bits of the one-workgroup launch (and of the oracle): the published CartPole shape (its own instantiation), an
+    Acrobot net with three actions, and a narrow net whose chunking leaves only five micro-chunks to deal."""
+    import ctypes as C
+    from learning_environments_amd import _lib
+    from learning_environments_amd.config import pick_grad_chunk
+    cfgd = json.loads(str(golden("g8_calc_score_cartpole_a")["config_json"]))
+    env_name = "CartPole-v0"
+    if case == "published":
+        hq, batch, act, T, max_steps, episodes = 57, 199, "tanh", 10, 200, 3
+    elif case == "acrobot":
+        env_name = "Acrobot-v1"
+        cfgd["env_name"] = env_name
+        cfgd["envs"][env_name] = dict(cfgd["envs"]["CartPole-v0"], solved_reward=-100.0)
+        hq, batch, act, T, max_steps, episodes = 40, 150, "leakyrelu", 3, 40, 5
+    else:
+        hq, batch, act, T, max_steps, episodes = 24, 64, "relu", 4, 50, 5
+    cfgd["envs"][env_name]["hidden_size"] = 83 if case == "published" else 64
+    cfgd["envs"][env_name]["max_steps"] = max_steps
+    cfgd["agents"]["ddqn"].update(hidden_size=hq, batch_size=batch, activation_fn=act, test_episodes=T)
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, train_episodes=episodes, max_steps=max_steps)
+    ocfg.grad_chunk = cfg.grad_chunk = pick_grad_chunk(cfg) if case != "narrow" else 13          # 64 samples in chunks of 13: five chunks
+    S, A = ocfg.state_dim, ocfg.num_actions
+    rng = np.random.RandomState(53)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, cfgd["envs"][env_name]["hidden_size"], 1, cfgd["envs"][env_name]["activation_fn"]))
+    P_q = orc.mlp_num_params(orc.mlp_desc(S, hq, 1, A, act))
+    chains = 11                                           # not a multiple of 8: the grid is rounded up and the extra blocks leave
+    theta = (rng.randn(P_se) * 0.15).astype(np.float32)
+    eps = (rng.randn(4, P_se) * 0.05).astype(np.float32)
+    agent_init = (rng.uniform(-0.4, 0.4, (chains, P_q))).astype(np.float32)
+    worker = (np.arange(chains) % 4).astype(np.int32)
+    sign = np.array([0.0, 1.0, -1.0] * 4, np.float32)[:chains]
+    keys = np.array([orc.chain_key(13, 2, int(worker[c]), c % 3) for c in range(chains)], np.uint64)
+
+    def run(G):
+        monkeypatch.setenv("LENV_DDQN_TEAM", str(G))
+        got = _lib.lib().lenv_ddqn_se_team_size(C.byref(cfg), chains)
+        il = eng.InnerLoop(cfg, chains, want_final_online=True)
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains, (G, il.status.cpu().tolist())
+        return got, [t.cpu().numpy().copy() for t in (il.score, il.stats, il.episode_test_mean, il.episode_len, il.final_returns, il.final_online)]
+
+    g1, base = run(1)
+    assert g1 == 1
+    n_chunks = -(-batch // cfg.grad_chunk)
+    for G in (2, 3, 4, 6):
+        got, outs = run(G)
+        assert got == max(x for x in (1, 2, 3, 4, 6) if x <= G and x <= n_chunks), (G, got, n_chunks)
+        for a, b in zip(base, outs):
+            assert np.array_equal(a, b, equal_nan=True), (case, G)
+    monkeypatch.delenv("LENV_DDQN_TEAM")
+    assert _lib.lib().lenv_ddqn_se_team_size(C.byref(cfg), chains) == 1          # fewer than 16 chains: no team unless asked for
+    assert _lib.lib().lenv_ddqn_se_team_size(C.byref(cfg), 96) == 2 and _lib.lib().lenv_ddqn_se_team_size(C.byref(cfg), 192) == 1
+    for c in (2, 10):
+        w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+        o = orc.ddqn_se_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]))
+        assert o["learn_steps"] > 10
+        assert float(base[0][c]) == o["score"]
+        assert base[1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(base[2][c], o["episode_test_mean"], equal_nan=True)
+
+
 @pytest.mark.parametrize("which", ["cartpole", "acrobot_syn_env", "mountaincar"])
 def test_inner_loop_other_published_shapes_specialised_vs_generic(eng, orc, which):
     """default_config_cartpole.yaml (Critic_DQN 4-64-2 relu, batch 32, SE hidden 128, one test episode) and

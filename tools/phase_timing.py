@@ -21,7 +21,7 @@ from learning_environments_amd import _lib
 _lib.LIB_PATH = OUT
 import torch
 import bench
-master, cfgd = bench.build_master(bench.POP)
+master, cfgd = bench.build_master(int(os.environ.get("LENV_TIMING_POP", bench.POP)))      # e.g. 32 / 16 / 8: the team launches
 extra = dict(a.split("=") for a in sys.argv[1:] if not a.startswith("-"))
 for k, v in extra.items():
     setattr(master.cfg, k, int(v))
