@@ -104,6 +104,16 @@ def bench_config(num_workers, plumbing=False):
     return cfg
 
 
+def team_size(master):
+    """Workgroups per chain the fused DDQN launch of this master uses (1 unless the launch under-fills the GPU)."""
+    try:
+        import ctypes as C
+        from learning_environments_amd import _lib
+        return int(_lib.lib().lenv_ddqn_se_team_size(C.byref(master.cfg), int(master.cpw * master.n_local)))
+    except Exception:
+        return None
+
+
 def build_master(num_workers, engine=None, plumbing=False):
     from learning_environments_amd.agents.GTN import GTN_Master
     cfg = bench_config(num_workers, plumbing)
@@ -523,8 +533,10 @@ def run_rank(args):
         strong = {"value": POP * args.steps / sdt, "unit": "worker-evaluations/s", "global_pop": POP,
                   "workers_per_gpu": smaster.w_per,
                   "ms_per_step": sdt / args.steps * 1e3, "kernel_ms": skernel_ms,
-                  "note": "one workgroup per chain: a chain's %d serial learn steps bound the generation, so fewer chains per "
-                          "GPU do not shorten it once every chain already has its own CU" % (TRAIN_EPISODES * 200)}
+                  "workgroups_per_chain": team_size(smaster),
+                  "note": "a chain's %d serial learn steps bound the generation; launches that under-fill the GPU run every chain on a "
+                          "team of workgroups (DESIGN.md section 5), which shortens a learn step by 10-17 %%, not by the team "
+                          "size" % (TRAIN_EPISODES * 200)}
     others = None
     if world == 1 and not plumbing and not args.no_configs:
         others = secondary_configs()           # the other BASELINE configurations, one shard each (not part of `value`)
