@@ -1748,6 +1748,32 @@ def test_ddqn_chain_on_a_team_of_workgroups(eng, orc, golden, case, monkeypatch)
         assert np.array_equal(base[2][c], o["episode_test_mean"], equal_nan=True)
 
 
+@pytest.mark.parametrize("pop,team", [(32, 2), (8, 6)])
+def test_ddqn_team_full_size_generations_bit_equal(pop, team, monkeypatch):
+    """The strong-scaling shards of BASELINE configs[1] at full length (20 x 200 train steps = 3 800 learn steps per chain, through
+    GTN_Master and its HIP graph): two generations with one workgroup per chain and with the automatic team size must leave the same
+    scores, counters, per-episode test means, final returns and theta, bit for bit."""
+    import ctypes as C
+    import bench
+    from learning_environments_amd import _lib
+    outs = []
+    for mode in ("1", "auto"):
+        if mode == "1":
+            monkeypatch.setenv("LENV_DDQN_TEAM", "1")
+        else:
+            monkeypatch.delenv("LENV_DDQN_TEAM", raising=False)
+        m, _ = bench.build_master(pop)
+        assert _lib.lib().lenv_ddqn_se_team_size(C.byref(m.cfg), 3 * pop) == (1 if mode == "1" else team)
+        m.step(0)
+        m.step(1)
+        torch.cuda.synchronize()
+        assert m.inner.status.cpu().abs().max().item() == 0
+        outs.append([t.cpu().numpy().copy() for t in (m.inner.score, m.inner.stats, m.inner.episode_test_mean, m.inner.final_returns, m.theta)])
+    assert int(outs[0][1][0][2]) == 3800
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 @pytest.mark.parametrize("which", ["cartpole", "acrobot_syn_env", "mountaincar"])
 def test_inner_loop_other_published_shapes_specialised_vs_generic(eng, orc, which):
     """default_config_cartpole.yaml (Critic_DQN 4-64-2 relu, batch 32, SE hidden 128, one test episode) and
