@@ -562,19 +562,28 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     float4 rowv[RS / 4];                                // kept as whole vectors: nothing touches them until the forward
     int my_idx = -1, pf_status = 0;
     bool pf_valid = false;
-    auto fetch_row = [&](int lit, int size_after, int new_pos) {
+    // index draw (status through st) and row load, separately: the prefetch of the next step's row has a third case in between
+    auto draw_row = [&](int lit, int size_after, int &st) -> int {
         const int64_t n = (int64_t)lit * B + fwd_b;
-        pf_status = 0;
+        int idx;
+        st = 0;
         if (tape) {
-            if (n >= a.tapes.replay_idx_stride) { pf_status = -4; my_idx = 0; }
-            else my_idx = a.tapes.replay_idx[chain * a.tapes.replay_idx_stride + n];
-            if (my_idx < 0 || my_idx >= size_after) { if (!pf_status) pf_status = -6; my_idx = 0; }
-        } else my_idx = (int)rng_replay_below(key, (uint64_t)n, (uint32_t)size_after);
+            if (n >= a.tapes.replay_idx_stride) { st = -4; idx = 0; }
+            else idx = a.tapes.replay_idx[chain * a.tapes.replay_idx_stride + n];
+            if (idx < 0 || idx >= size_after) { if (!st) st = -6; idx = 0; }
+        } else idx = (int)rng_replay_below(key, (uint64_t)n, (uint32_t)size_after);
+        return idx;
+    };
+    auto load_row = [&](int new_pos) {
         if (my_idx != new_pos) {
             const float4 *src = reinterpret_cast<const float4 *>(rb + (int64_t)my_idx * RS);
 #pragma unroll
             for (int v = 0; v < RS / 4; ++v) rowv[v] = src[v];
         }
+    };
+    auto fetch_row = [&](int lit, int size_after, int new_pos) {
+        my_idx = draw_row(lit, size_after, pf_status);
+        load_row(new_pos);
     };
     // the env wave draws the exploration decision of the NEXT step while the other waves run the minibatch forwards
     int nx_action = 0, nx_explored = 0;
@@ -871,6 +880,16 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         }
                         if (jp < p1) finish(pa, jp, 2 * jp + 1 < Hqf, T{});
                     }
+                    // The replay row of the NEXT learn step, requested as soon as this thread's forward work is over (its row registers are
+                    // free: the sample's side data went to LDS before the pair loop): the waves that finish their items early wait for the
+                    // interval's barrier anyway, and the draw (four quarter-rate multiplies) no longer opens every wave's gradient interval.
+                    // next step: ReplayBuffer.size = min(train_steps + 1, cap), write slot = train_steps % cap
+                    const int nsz = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
+                    my_idx = draw_row(learn_it + 1, nsz, pf_status);
+                    // (the row the env wave appended in THIS step may still be on its way to memory: that one is taken from its LDS copy
+                    // behind the interval's barrier, below)
+                    if (my_idx != new_pos) load_row(wr_pos);
+                    pf_valid = true;
                 }
                 if (split_wave) {
                     // split layout: this wave's activation rows are written -- tell the two waves that run the spilled items' output layers
@@ -955,11 +974,9 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 PT_OWN(0);
                 __syncthreads();                               // B2
                 PT_MARK(3);
-                if (fwd_active) {
-                    // next step: ReplayBuffer.size = min(train_steps + 1, cap), write slot = train_steps % cap
-                    const int nsz = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
-                    fetch_row(learn_it + 1, nsz, wr_pos);
-                    pf_valid = true;
+                if (fwd_active && my_idx == new_pos) {             // next step samples the row appended in this one: the LDS copy is still there
+#pragma unroll
+                    for (int v = 0; v < RS / 4; ++v) rowv[v] = *reinterpret_cast<const float4 *>(newrow + 4 * v);
                 }
                 // ---- batch gradient in micro-chunks: wave c reduces samples [c*chunk, (c+1)*chunk) ----
                 // lane = hidden unit j.  Per sample (canonical order, oracle orc_ddqn_learn): da = dq*W2[a_b][j] (as a sum over
