@@ -375,7 +375,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     // LDS byte address of the image: the literal 0 (this kernel has no static LDS, so its dynamic LDS starts at address
     // 0; a literal lets the gather address be the bare v_and_or result).  Verified below, never assumed silently.
     constexpr uint32_t tanh_tab = 0u;
-    if (lds_addr_of(lds) != 0u) { if (tid == 0 && a.out.status) a.out.status[blockIdx.x] = -7; return; }
+    if (lds_addr_of(lds) != 0u) { if (tid == 0 && a.out.status) a.out.status[chain] = -7; return; }
     const TanhLds tl = TanhLds::make(LV(tanh16) != 0, lane);
 
     // ---------------- stage the perturbed SE: W = theta + sign*eps[worker]  (GTN_worker.py:165-175) ----------------
