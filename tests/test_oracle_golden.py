@@ -24,6 +24,21 @@ def test_tanh_accuracy():
     assert np.all(np.abs(got) <= 1.0)
 
 
+def test_tanh_matches_the_documented_algorithm():
+    """The canonical tanh (v4) restated in numpy from its description (tools/gen_tanh_table.py: one float addition of 2^19 rounds
+    min(|x|, TMAX) to the 1/16 grid, the table entry is the low mantissa bits of the sum, d = t - (sum - 2^19), three fmaf) gives the
+    oracle's bits, and the committed table is the one the generator fits."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("gen_tanh_table", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gen_tanh_table.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    tab = G.fit()
+    x = np.concatenate([np.linspace(-12, 12, 200001), np.logspace(-30, 1.2, 20000), -np.logspace(-30, 1.2, 20000), [0.0, 9.124999, 9.125, 1e30, -1e30]]).astype(np.float32)
+    assert np.array_equal(G.eval32(tab, x), orc.tanhf(x))
+    assert G.N == 147 and float(G.MAGIC) == 524288.0
+
+
 def test_tanh_range_exhaustive():
     """Every float in [0, 16] (1.1e9 values): result in [0, 1]; across table-interval seams the result never steps down by
     more than 2 ulp(1) (the canonical tanh has no final clamp, so the table itself must guarantee the bound)."""
