@@ -535,7 +535,7 @@ def run_rank(args):
                   "ms_per_step": sdt / args.steps * 1e3, "kernel_ms": skernel_ms,
                   "workgroups_per_chain": team_size(smaster),
                   "note": "a chain's %d serial learn steps bound the generation; launches that under-fill the GPU run every chain on a "
-                          "team of workgroups (DESIGN.md section 5), which shortens a learn step by 10-17 %%, not by the team "
+                          "team of workgroups (DESIGN.md section 5), which shortens a learn step by 7-11 %%, not by the team "
                           "size" % (TRAIN_EPISODES * 200)}
     others = None
     if world == 1 and not plumbing and not args.no_configs:

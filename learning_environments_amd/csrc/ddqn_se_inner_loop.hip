@@ -1133,7 +1133,9 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                             v = __hip_atomic_load(xs_ + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if ((unsigned)(v >> 32) == want_tag) break;
                             __builtin_amdgcn_s_sleep(1);
-                            if (++spins > 4000000L) { team_bar[15] = 1u; status = -10; break; }
+                            // give up after seconds, for good: a thread that gave up never polls again, so a team whose members are not all
+                            // running costs each thread one time-out (all threads at once), not one per learn step
+                            if (++spins > 4000000L) { team_bar[15] = 1u; status = -10; team_dead = true; break; }
                         }
                         part[e] = __uint_as_float((unsigned)v);
                     }
