@@ -10,7 +10,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous
  *     on that stream, never allocate, never synchronise, and are graph-capturable;
  *   - return value: 0 = ok, negative = LENV_ERR_* (no exceptions cross the ABI);
- *   - no internal threads or global mutable state; re-entrant per stream.
+ *   - no internal threads, no global mutable state, no environment variables: everything that steers a launch is in its cfg;
+ *     re-entrant per stream.
  *
  * Flat parameter layout of an MLP (models/model_utils.py:4-39), identical to the reference's
  * state-dict order with PReLU slopes removed: W0[H,in] b0[H] {W_l[H,H] b_l[H]} Wout[out,H] bout[out].
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LENV_ABI_VERSION 4
+#define LENV_ABI_VERSION 5
 
 enum {
     LENV_OK = 0,
@@ -40,6 +41,10 @@ enum {
 enum { LENV_ACT_IDENTITY = 0, LENV_ACT_RELU = 1, LENV_ACT_LEAKYRELU = 2, LENV_ACT_TANH = 3, LENV_ACT_PRELU = 4 };
 enum { LENV_ENV_CARTPOLE = 0, LENV_ENV_ACROBOT = 1, LENV_ENV_CHEETAH_STANDIN = 2, LENV_ENV_MOUNTAINCAR = 3, LENV_ENV_PENDULUM = 4, LENV_ENV_CMC = 5 };
 enum { LENV_RNG_COUNTER = 0, LENV_RNG_TAPE = 1 };
+/* lenv_ddqn_cfg / lenv_td3_cfg `kernel_variant` bits (0 = the fastest kernel that takes the launch; the bits exist for A/B timing and for
+ * the parity tests that hold the kernels against each other -- every variant produces the same bits):
+ * NO_WAVECHAIN keeps the GEMM-queue kernel where a wave-chain kernel exists, GENERIC skips the shape-specialised instantiations. */
+enum { LENV_VARIANT_NO_WAVECHAIN = 1, LENV_VARIANT_GENERIC = 2 };
 
 /* models/model_utils.py:4-39 */
 typedef struct {
@@ -47,7 +52,8 @@ typedef struct {
     float prelu;
     /* `use_layer_norm` of models/model_utils.py:22-37: ONE shared nn.LayerNorm(hidden) (eps 1e-5) after every hidden Linear but
      * the first, before the activation; its weight and bias [hidden] follow the second Linear in the flat vector
-     * (Module.parameters() order).  Honoured by lenv_mlp_num_params / lenv_mlp_forward; the fused loops take plain MLPs only. */
+     * (Module.parameters() order).  Honoured by lenv_mlp_num_params / lenv_mlp_forward; of the fused loops only lenv_td3d_inner_loop
+     * takes LayerNorm nets (its own cfg field), the others take plain MLPs and their config builders refuse the option. */
     int32_t use_layer_norm;
 } lenv_mlp_desc;
 
@@ -92,7 +98,16 @@ typedef struct {
     /* same_action_num (agents/base_agent.py:20,104,194; envs/env_wrapper.py:24-29,56-61): env steps per chosen action -- a VirtualEnv
      * repeats the step whatever the done flag says and sums the fp32 rewards, a real env's repeats stop at done (python-float sum);
      * 0 and 1 both mean 1.  Values > 1: GEMM-tiled kernel only (lenv_dueling_se_inner_loop*, plain-DQN mode for DDQN). */
-    int32_t same_action_num, pad2_;
+    int32_t same_action_num;
+    /* Workgroups per chain (a TEAM: the members split the minibatch / the gradient tiles of a learn step and meet at barriers; same
+     * bits for every size).  0 = automatic: the largest team for which every workgroup of the launch is resident at once on an
+     * otherwise idle device (checked with the occupancy API at launch); 1 = one workgroup per chain; G > 1 = at most G.  A launch
+     * whose members cannot all be resident is never made with a team (the entry falls back to 1).  Team launches need the device to
+     * themselves: a member that waits longer than ~0.25 s for the others (another kernel holds the CUs) gives up, every chain of the
+     * launch reports status -10 within that time, and the caller repeats the launch with team_size 1 (engine.py does). */
+    int32_t team_size;
+    int32_t kernel_variant;   /* LENV_VARIANT_* bits, 0 = fastest */
+    int32_t pad3_;
 } lenv_ddqn_cfg;
 
 /* RNG tapes (parity mode).  Per-chain rows: element [c*stride + n]; all DEVICE pointers. */
@@ -122,6 +137,10 @@ typedef struct {
 } lenv_inner_out;
 
 int lenv_abi_version(void);
+/* sizeof of the ABI structs as the library was compiled (a binding checks its mirror against it): which = 0 lenv_mlp_desc, 1 lenv_ddqn_cfg,
+ * 2 lenv_ql_cfg, 3 lenv_td3_cfg, 4 lenv_td3d_cfg, 5 lenv_tapes, 6 lenv_inner_out, 7 lenv_ql_out, 8 lenv_td3_tapes, 9 lenv_td3_out,
+ * 10 lenv_td3d_tapes, 11 lenv_chain_hp, 12 lenv_icm_io; anything else: LENV_ERR_INVALID.  HOST. */
+int64_t lenv_struct_size(int32_t which);
 const char *lenv_error_string(int code);
 /* number of parameters of an MLP / of the three-net SE */
 int64_t lenv_mlp_num_params(const lenv_mlp_desc *d /*HOST*/);
@@ -166,7 +185,7 @@ int lenv_ddqn_se_forward_split(const lenv_ddqn_cfg *cfg /*HOST*/, int32_t *items
 /* Workgroups per chain lenv_ddqn_se_inner_loop would use for a counter-mode launch of `chains` chains on the current device: > 1 when
  * the launch leaves enough CUs idle for every member of every chain to be resident (shards of a population spread over several
  * GPUs); the members deal the minibatch by whole gradient micro-chunks and meet once per learn step -- same bits for every team
- * size.  LENV_DDQN_TEAM=<G> in the environment caps / forces the size (1 = never).  Status -10 = a member gave up waiting. */
+ * size.  cfg->team_size caps / forces the size (1 = never).  Status -10 = a member gave up waiting (see team_size). */
 int lenv_ddqn_se_team_size(const lenv_ddqn_cfg *cfg /*HOST*/, int64_t chains);
 int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg /*HOST*/, const float *theta, const float *eps,
                             const int32_t *worker, const float *sign, const float *agent_init,
@@ -268,7 +287,7 @@ int lenv_dueling_se_inner_loop(const lenv_ddqn_cfg *cfg /*HOST*/, const float *t
                                void *workspace, size_t workspace_bytes, const lenv_inner_out *out /*HOST*/, void *stream);
 /* Workgroups per chain a production launch (counter RNG, no trace, no hp, no ICM) of this cfg will use: the wave-chain kernel of the
  * published Acrobot SE + DuelingDDQN shape runs a chain on a TEAM of 2 workgroups when 8 * ceil(chains / 8) * 2 of them are resident at
- * once (one per CU); every other launch: 1.  LENV_DUELING_TEAM=1 forces 1.  Same bits either way. */
+ * once (one per CU); every other launch: 1.  cfg->team_size 1 forces 1.  Same bits either way. */
 int lenv_dueling_team_size(const lenv_ddqn_cfg *cfg /*HOST*/, int64_t chains);
 /* Fresh agents (nn.Linear default init, the draw of lenv_nes_draw) for chains with their own shapes: row c of agent_init
  * [chains, lenv_dueling_num_params(cfg)] gets the parameters of a (hp->q_hidden[c], hp->q_layers[c]) network, keyed by
@@ -326,6 +345,8 @@ typedef struct {
     /* same_action_num (agents/base_agent.py:20,104,194; envs/env_wrapper.py:24,57): env steps per chosen action -- the rewards of
      * the repeats are summed, a real env's repeats stop at done; 0 and 1 both mean 1 (MountainCarContinuous configs ship 2) */
     int32_t same_action_num;
+    int32_t team_size;        /* workgroups per chain, as lenv_ddqn_cfg::team_size (0 = automatic, 1 = never a team, G = at most G) */
+    int32_t kernel_variant;   /* LENV_VARIANT_* bits, 0 = fastest */
 } lenv_td3_cfg;
 
 /* RNG tapes (parity mode); per-chain rows, strides in ROWS (rows of A floats / B ints / S doubles as noted) */
@@ -378,7 +399,7 @@ int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg /*HOST*/, const lenv_chai
                                const lenv_td3_out *out /*HOST*/, void *stream);
 /* Workgroups per chain a production launch (counter RNG, no trace, no hp, no ICM) of this cfg will use: the wave-chain kernel of the
  * published HalfCheetah RewardEnv + TD3 shape runs a chain on a TEAM of 6, 3 or 2 workgroups when 8 * ceil(chains / 8) * G of them
- * are resident at once (one per CU); every other launch: 1.  LENV_TD3_TEAM=<G> caps it.  Same bits for every G. */
+ * are resident at once (one per CU); every other launch: 1.  cfg->team_size caps it.  Same bits for every G. */
 int lenv_td3_rn_team_size(const lenv_td3_cfg *cfg /*HOST*/, int64_t chains);
 int lenv_td3_agent_init_hp(const lenv_td3_cfg *cfg /*HOST*/, const lenv_chain_hp *hp, const uint64_t *rng_keys, int64_t chains,
                            float *agent_init, void *stream);
@@ -533,6 +554,13 @@ int lenv_nes_rank_update(int32_t score_transform_type, const double *gathered, c
 int lenv_nes_rank_update_keep(int32_t score_transform_type, const double *gathered, const double *rank_table, int64_t pop,
                               float *theta, const float *eps, int64_t p_theta, double step_size, int32_t nes_step_size,
                               double weight_decay, double *weights_out, float *theta_prev, int64_t *generation_dev, void *stream);
+
+/*
+ * Diagnostic: hold `blocks` compute units for `ticks` of the constant 100 MHz clock (s_memrealtime) on `stream` -- every block
+ * asks for `lds_bytes` of LDS (>= 82 KiB: one block per CU) and spins.  The stand-in for "a foreign kernel occupies part of the
+ * device" in the test of the team launches' give-up path (status -10, lenv_ddqn_cfg::team_size); no product path calls it.
+ */
+int lenv_diag_occupy_cus(int32_t blocks, int32_t lds_bytes, int64_t ticks, void *stream);
 
 #ifdef __cplusplus
 }

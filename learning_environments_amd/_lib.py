@@ -10,6 +10,8 @@ CSRC = os.path.join(_HERE, "csrc")
 ACT = {"identity": 0, "relu": 1, "leakyrelu": 2, "tanh": 3, "prelu": 4}
 ENV = {"CartPole-v0": 0, "Acrobot-v1": 1, "HalfCheetah-v3": 2, "MountainCar-v0": 3, "Pendulum-v0": 4, "MountainCarContinuous-v0": 5}
 RNG_COUNTER, RNG_TAPE = 0, 1
+VARIANT_NO_WAVECHAIN, VARIANT_GENERIC = 1, 2     # lenv_ddqn_cfg / lenv_td3_cfg kernel_variant bits (A/B timing, kernel-vs-kernel parity tests)
+STATUS_TEAM_GAVE_UP = -10                        # a team member waited too long for the others: repeat the launch with team_size 1
 
 ERRORS = {-1: ValueError, -2: NotImplementedError, -3: ValueError, -4: RuntimeError, -5: RuntimeError}
 
@@ -38,7 +40,10 @@ class DdqnCfg(C.Structure):
                 ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("icm_pad_", C.c_int32),
                 ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
                 ("synthetic_env_type", C.c_int32), ("reward_env_type", C.c_int32),
-                ("same_action_num", C.c_int32), ("pad2_", C.c_int32)]
+                ("same_action_num", C.c_int32),
+                ("team_size", C.c_int32),        # workgroups per chain: 0 = automatic, 1 = never a team, G = at most G
+                ("kernel_variant", C.c_int32),   # VARIANT_* bits, 0 = fastest
+                ("pad3_", C.c_int32)]
 
 
 class Tapes(C.Structure):
@@ -94,7 +99,7 @@ class Td3Cfg(C.Structure):
                 ("step_budget", C.c_int64),
                 ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("icm_pad_", C.c_int32),
                 ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
-                ("virtual_env", C.c_int32), ("same_action_num", C.c_int32)]
+                ("virtual_env", C.c_int32), ("same_action_num", C.c_int32), ("team_size", C.c_int32), ("kernel_variant", C.c_int32)]
 
 
 class Td3Tapes(C.Structure):
@@ -132,13 +137,16 @@ class Td3Out(C.Structure):
                 ("trace_action", C.c_void_p), ("trace_state", C.c_void_p), ("trace_next_state", C.c_void_p), ("trace_reward", C.c_void_p)]
 
 
+# lenv_struct_size(which) order (include/lenv_hip.h)
+ABI_STRUCTS = [MlpDesc, DdqnCfg, QlCfg, Td3Cfg, Td3dCfg, Tapes, InnerOut, QlOut, Td3Tapes, Td3Out, Td3dTapes, ChainHp, IcmIo]
+
 EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv_se_step_population",
            "lenv_qnet_td_forward", "lenv_ddqn_se_workspace_bytes", "lenv_ddqn_se_lds_bytes", "lenv_ddqn_se_forward_split", "lenv_ddqn_se_team_size", "lenv_ddqn_se_inner_loop",
            "lenv_chain_key", "lenv_nes_worker_best", "lenv_nes_rank_update", "lenv_real_env_reset", "lenv_real_env_step", "lenv_ql_rn_inner_loop", "lenv_rn_shape_population", "lenv_dueling_se_workspace_bytes",
            "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_dueling_se_inner_loop_hp", "lenv_dueling_agent_init_hp", "lenv_rng_unit", "lenv_td3_rn_inner_loop_hp", "lenv_td3_agent_init_hp", "lenv_icm_num_params", "lenv_dueling_se_inner_loop_icm", "lenv_chain_uniform_init", "lenv_td3_icm_num_params", "lenv_td3_rn_inner_loop_icm", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
            "lenv_td3_rn_inner_loop", "lenv_mlp_forward", "lenv_cheetah_standin_reset", "lenv_cheetah_standin_step", "lenv_cont_env_reset", "lenv_cont_env_step",
            "lenv_rn_num_params", "lenv_rn_shape_rows", "lenv_nes_worker_best_multi", "lenv_nes_draw", "lenv_nes_status_fold", "lenv_nes_draw_dev", "lenv_nes_rank_update_keep",
-           "lenv_td3d_workspace_bytes", "lenv_td3d_num_params", "lenv_td3d_se_num_params", "lenv_td3d_inner_loop", "lenv_td3d_agent_init", "lenv_td3_rn_team_size", "lenv_dueling_team_size"]
+           "lenv_td3d_workspace_bytes", "lenv_td3d_num_params", "lenv_td3d_se_num_params", "lenv_td3d_inner_loop", "lenv_td3d_agent_init", "lenv_td3_rn_team_size", "lenv_dueling_team_size", "lenv_struct_size", "lenv_diag_occupy_cus"]
 
 
 def build(force=False):
@@ -273,8 +281,15 @@ def lib():
                                            C.c_size_t, C.POINTER(Td3Out), vp]
         L.lenv_td3d_agent_init.restype = C.c_int
         L.lenv_td3d_agent_init.argtypes = [C.POINTER(Td3dCfg), C.POINTER(ChainHp), vp, C.c_int64, vp, vp]
-        if L.lenv_abi_version() != 4:
+        if L.lenv_abi_version() != 5:
             raise LenvError("liblenv_hip.so ABI version mismatch")
+        L.lenv_diag_occupy_cus.restype = C.c_int
+        L.lenv_diag_occupy_cus.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp]
+        L.lenv_struct_size.restype = C.c_int64
+        L.lenv_struct_size.argtypes = [C.c_int32]
+        for which, cls in enumerate(ABI_STRUCTS):     # the ctypes mirrors must have the library's layout
+            if L.lenv_struct_size(which) != C.sizeof(cls):
+                raise LenvError("ctypes mirror of %s has %d bytes, the library's struct %d" % (cls.__name__, C.sizeof(cls), L.lenv_struct_size(which)))
         _lib = L
     return _lib
 

@@ -38,6 +38,8 @@ from .tasks import select_task
 
 __all__ = ["GTN_Master", "rank_table"]
 
+TEAM_GAVE_UP = -10          # _lib.STATUS_TEAM_GAVE_UP: chains whose team of workgroups could not assemble
+
 
 class GTN_Master(GTN_Base):
     def __init__(self, config, bohb_id=-1, bohb_working_dir=None, engine=None, seed=0, verbose=False, transport=None, graph=None):
@@ -217,6 +219,12 @@ class GTN_Master(GTN_Base):
         gathered = self.evaluate_population(it)
         self._gathered = gathered
         host = gathered.cpu().numpy()               # the generation's only host sync
+        if host[:, 3].min() == TEAM_GAVE_UP and self._disable_teams():
+            # a team of workgroups could not assemble (a foreign kernel held CUs): the chains are deterministic functions of
+            # (theta, seed, generation), so the generation is simply evaluated again with one workgroup per chain.  Every rank
+            # sees the same gathered statuses and takes this branch together.
+            gathered = self._gathered = self.evaluate_population(it)
+            host = gathered.cpu().numpy()
         if host[:, 3].min() != 0:
             raise RuntimeError("inner loop reported status %d on worker(s) %s (tape underrun / invalid replay index)"
                                % (int(host[:, 3].min()), np.nonzero(host[:, 3])[0].tolist()))
@@ -231,6 +239,16 @@ class GTN_Master(GTN_Base):
         if self.verbose and self.rank == 0:
             self.print_statistics(it=it, time_elapsed=time.time() - t1)
         return mean_score, False
+
+    def _disable_teams(self):
+        """React to status -10 (a team member gave up waiting for the others, include/lenv_hip.h lenv_ddqn_cfg::team_size): from now
+        on every launch of this master uses one workgroup per chain.  False when the launches were not teamed to begin with."""
+        cfg = self.cfg
+        if cfg is None or not hasattr(cfg, "team_size") or cfg.team_size == 1:
+            return False
+        cfg.team_size = 1
+        self.team_fallbacks = getattr(self, "team_fallbacks", 0) + 1
+        return True
 
     def _capture_generation(self):
         """Capture one whole generation on a side stream.  Every tensor the kernels touch is allocated inside the capture (the
@@ -265,6 +283,15 @@ class GTN_Master(GTN_Base):
         gathered = self._gathered = self._graph_gathered
         host = gathered.cpu().numpy()               # the generation's only host sync
         if host[:, 3].min() != 0:
+            # the captured update_env has already run on scores of failed chains: put theta and the device generation counter
+            # back to where the generation started before anything else happens (the eager path never applies such an update)
+            self.theta.copy_(self._theta_prev)
+            self._theta_changed()
+            self._gen_t.fill_(int(it))
+            self._gen_next = it
+            if host[:, 3].min() == TEAM_GAVE_UP and self._disable_teams():
+                self._graph = None                  # re-captured with one workgroup per chain on the next line
+                return self._step_graph(it)
             raise RuntimeError("inner loop reported status %d on worker(s) %s (tape underrun / invalid replay index)"
                                % (int(host[:, 3].min()), np.nonzero(host[:, 3])[0].tolist()))
         self.score_list = host[:, 0].tolist()

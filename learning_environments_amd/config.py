@@ -17,6 +17,14 @@ def _refuse_layer_norm(config, env_section, agent_section):
             raise NotImplementedError("use_layer_norm in the %s section: no fused inner loop takes LayerNorm nets here" % name)
 
 
+def _launch_knobs(cfg, config):
+    """Launch knobs of this implementation (no counterpart in the reference; absent keys = automatic): `team_size` (workgroups per
+    chain: 0 automatic, 1 never a team, G at most G) and `kernel_variant` (_lib.VARIANT_* bits) in the `gtn` section."""
+    gtn = config["agents"].get("gtn", {})
+    cfg.team_size = int(gtn.get("team_size", 0))
+    cfg.kernel_variant = int(gtn.get("kernel_variant", 0))
+
+
 def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **overrides):
     """Fields read at reference agents/DDQN.py:15-38, agents/base_agent.py:9-26, envs/env_factory.py:45-59.
     grad_chunk=0 picks the smallest micro-chunk (>= ceil(batch/16)) whose LDS footprint fits one CU; it stays 0 (one
@@ -58,6 +66,7 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
                        adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
                        step_budget=int(a.get("step_budget", 0)))      # env-step stand-in for time_remaining (base_agent.py:30-47)
     cfg.same_action_num = int(a["same_action_num"])    # env steps per chosen action (base_agent.py:104,194); > 1: GEMM-tiled kernel
+    _launch_knobs(cfg, config)
     if icm:                                          # config section `icm` (agents/DDQN.py:43-49)
         ic = config["agents"]["icm"]
         cfg.icm_enabled, cfg.icm_feature_dim, cfg.icm_hidden = 1, int(ic["feature_dim"]), int(ic["hidden_size"])
@@ -173,6 +182,7 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
     if "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 1)) == 0:
         cfg.virtual_env = 1                           # VirtualEnv (default_config_halfcheetah.yaml): `envs` describes the three SE nets
     cfg.same_action_num = int(a["same_action_num"])   # env steps per chosen action (the MountainCarContinuous configs ship 2)
+    _launch_knobs(cfg, config)
     name = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "td3"
     if name.replace("_vary", "").endswith("_icm"):   # select_agent "td3_icm" / "td3_icm_vary": TD3(icm=True), agents/TD3.py:44-60
         ic = config["agents"]["icm"]

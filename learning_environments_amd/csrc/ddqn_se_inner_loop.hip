@@ -612,12 +612,14 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     // ---- TEAM barrier (as in td3_wavechain.hip): one monotonically increasing counter per chain, zeroed by a kernel in front of the
     // launch; thread 0 releases, arrives, waits for the epoch's count, acquires.  Members on one XCD share its L2 (the vector L1
     // writes through): release = the stores have left the CU, acquire = this CU's L1 lines dropped; otherwise the agent-scope fences.
-    // A member that waits for seconds gives up for good (status -10) instead of hanging the device.
+    // A member that waits longer than LENV_TEAM_GIVEUP_TICKS (0.25 s: a foreign kernel holds CUs) gives up for good (status -10)
+    // instead of hanging the device; the caller repeats the launch with one workgroup per chain.
     unsigned team_epoch = 0;
     bool team_dead = false, team_same_xcd = false;
     unsigned *team_bar = TEAM ? reinterpret_cast<unsigned *>(a.team_ws + chain * a.team_stride) : nullptr;
     auto team_barrier = [&]() {
         if constexpr (TEAM) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's own stores are acknowledged (__syncthreads() is s_barrier without a vmcnt wait)
             __syncthreads();
             ++team_epoch;
             if (tid == 0 && !team_dead) {
@@ -625,14 +627,16 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 __hip_atomic_fetch_add(team_bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned target_ = team_epoch * (unsigned)G;
-                long spins = 0;
+                const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();      // constant 100 MHz
+                unsigned spins = 0;
+                bool gave_up = false;
                 while (__hip_atomic_load(team_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target_) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > 8000000L) break;
+                    if ((++spins & 63u) == 0u && __builtin_amdgcn_s_memrealtime() - w0 > LENV_TEAM_GIVEUP_TICKS) { gave_up = true; break; }
                 }
                 if (team_same_xcd) asm volatile("buffer_inv sc1" ::: "memory");
                 else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                if (spins > 8000000L) team_bar[15] = 1u;
+                if (gave_up) team_bar[15] = 1u;
             }
             __syncthreads();
             if (!team_dead && __hip_atomic_load(team_bar + 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { team_dead = true; status = -10; }
@@ -1128,14 +1132,22 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     for (int i = tid; i < tot - (hi - lo); i += NT) {
                         const int e = i < lo ? i : i + (hi - lo);
                         unsigned long long v = 0;
-                        long spins = 0;
+                        unsigned spins = 0;
+                        unsigned long long w0 = 0;
                         while (!team_dead) {
                             v = __hip_atomic_load(xs_ + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if ((unsigned)(v >> 32) == want_tag) break;
                             __builtin_amdgcn_s_sleep(1);
-                            // give up after seconds, for good: a thread that gave up never polls again, so a team whose members are not all
-                            // running costs each thread one time-out (all threads at once), not one per learn step
-                            if (++spins > 4000000L) { team_bar[15] = 1u; status = -10; team_dead = true; break; }
+                            // give up after LENV_TEAM_GIVEUP_TICKS (or as soon as another member of the chain has), for good: a thread that gave
+                            // up never polls again, so a team whose members are not all running costs each thread one time-out (all threads
+                            // at once), not one per learn step
+                            if ((++spins & 63u) == 0u) {
+                                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                                if (w0 == 0) w0 = now;
+                                if (now - w0 > LENV_TEAM_GIVEUP_TICKS || __hip_atomic_load(team_bar + 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                                    team_bar[15] = 1u; status = -10; team_dead = true; break;
+                                }
+                            }
                         }
                         part[e] = __uint_as_float((unsigned)v);
                     }
@@ -1348,12 +1360,8 @@ static int inner_layout(const lenv_ddqn_cfg *cfg, InnerArgs &a)
     return a.L.rc;
 }
 
-// diagnostic switch: LENV_NO_FIXED_SHAPE=1 in the environment runs the published shape through the generic instantiation (A/B timing)
-static bool cfg_disables_fixed_shape()
-{
-    static const bool off = [] { const char *e = getenv("LENV_NO_FIXED_SHAPE"); return e && e[0] == '1'; }();
-    return off;
-}
+// diagnostic switch: kernel_variant GENERIC runs the published shape through the generic instantiation (A/B timing)
+static bool cfg_disables_fixed_shape(const lenv_ddqn_cfg *cfg) { return (cfg->kernel_variant & LENV_VARIANT_GENERIC) != 0; }
 
 // index into kShapes of the published shape this launch has exactly (0 = none: generic instantiation)
 template <int I> static bool shape_matches(const lenv_ddqn_cfg *cfg, const InnerLayout &L)
@@ -1430,27 +1438,44 @@ static int64_t inner_team_stride(const lenv_ddqn_cfg *cfg)
     return (16 + 4 * (int64_t)t.L.n_chunks4 * t.L.P_q + 63) & ~(int64_t)63;
 }
 
+// the TEAM instantiation that runs this cfg (a chain on a team of workgroups: the generic instantiation with the exchange code, or the
+// published CartPole shape's)
+typedef void (*InnerKern)(const InnerArgs);
+static InnerKern ddqn_team_kernel(const lenv_ddqn_cfg *cfg, const InnerLayout &L)
+{
+    InnerKern kern = nullptr;
+#define LENV_PICK2(ENVID, SS, AA, PP)                                                                              \
+    switch (cfg->q_act) {                                                                                      \
+    case LENV_ACT_RELU: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_RELU, PP, 0, true>; break;            \
+    case LENV_ACT_LEAKYRELU: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_LEAKYRELU, PP, 0, true>; break;  \
+    case LENV_ACT_TANH: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_TANH, PP, 0, true>; break;            \
+    default: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_IDENTITY, PP, 0, true>; break;                   \
+    }
+    if (cfg->env_id == LENV_ENV_CARTPOLE) { if (L.P_q <= NT) { LENV_PICK2(LENV_ENV_CARTPOLE, 4, 2, 1) } else { LENV_PICK2(LENV_ENV_CARTPOLE, 4, 2, 2) } }
+    else { if (L.P_q <= NT) { LENV_PICK2(LENV_ENV_ACROBOT, 6, 3, 1) } else { LENV_PICK2(LENV_ENV_ACROBOT, 6, 3, 2) } }
+#undef LENV_PICK2
+    if (!cfg_disables_fixed_shape(cfg) && published_shape(cfg, L) == 1) kern = ddqn_se_inner_kernel<LENV_ENV_CARTPOLE, 4, 2, LENV_ACT_TANH, 1, 1, true>;
+    return kern;
+}
+
 // Workgroups per chain of a launch with `chains` chains: G > 1 when the chains leave enough of the GPU idle for every member of every
-// chain to be resident at once (one workgroup per CU; blocks are dealt to the XCDs round-robin, so a team is 8 blocks apart) and the
-// minibatch has at least G micro-chunks to deal.  Launches of fewer than 16 chains keep one workgroup per chain unless
-// LENV_DDQN_TEAM=<G> asks for a team size (1 = never); tape-mode launches and launches with a step trace are never teamed.
+// chain to be resident at once (occupancy API x CU count for the TEAM instantiation at this cfg's LDS footprint; blocks are dealt to the
+// XCDs round-robin, so a team is 8 blocks apart) and the minibatch has at least G micro-chunks to deal.  cfg->team_size: 0 = automatic
+// (launches of fewer than 16 chains keep one workgroup per chain), 1 = never, G = at most G (also below 16 chains); tape-mode launches
+// and launches with a step trace are never teamed.
 static int ddqn_pick_team(const lenv_ddqn_cfg *cfg, int64_t chains, bool production)
 {
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        return n;
-    }();
-    const char *e = getenv("LENV_DDQN_TEAM");
-    const int want = e ? atoi(e) : 0;                  // 0 = automatic
+    const int want = cfg->team_size > 0 ? cfg->team_size : 0;      // 0 = automatic
     if (!production || want == 1 || chains < 1) return 1;
     if (want == 0 && chains < 16) return 1;
     InnerArgs t;
     if (inner_check(cfg) != LENV_OK || inner_layout(cfg, t) != LENV_OK) return 1;
+    const void *kern = reinterpret_cast<const void *>(ddqn_team_kernel(cfg, t.L));
+    const size_t lds_bytes = (size_t)t.L.lds_floats * sizeof(float);
     const int64_t slots = 8 * ((chains + 7) / 8);
     int best = 1;
     for (int G : { 2, 3, 4, 6 })
-        if (slots * G <= cus && G <= t.L.n_chunks && (want == 0 || G <= want)) best = G;
+        if (G <= t.L.n_chunks && (want == 0 || G <= want) && lenv_team_grid_resident(kern, NT, lds_bytes, slots * G)) best = G;
     return best;
 }
 
@@ -1466,7 +1491,8 @@ extern "C" size_t lenv_ddqn_se_workspace_bytes(const lenv_ddqn_cfg *cfg, int64_t
     size_t replay = (size_t)chains * inner_rb_cap(cfg) * inner_row_stride(cfg) * sizeof(float);
     size_t meter = (size_t)chains * (cfg->train_episodes > 0 ? cfg->train_episodes : 1) * sizeof(double);
     size_t sched = (((size_t)adam_schedule_len(cfg) * sizeof(float2)) + 255) & ~(size_t)255;
-    size_t team = (size_t)chains * (size_t)inner_team_stride(cfg) * sizeof(float);       // (sized for every launch: the team size is a launch-time choice)
+    // the team exchange area exists only when a launch of this (cfg, chains) can be teamed at all (same predicate as the launch)
+    size_t team = ddqn_pick_team(cfg, chains, cfg->rng_mode == LENV_RNG_COUNTER) > 1 ? (size_t)chains * (size_t)inner_team_stride(cfg) * sizeof(float) : 0;
     return ((replay + 255) & ~(size_t)255) + ((meter + 255) & ~(size_t)255) + sched + team + 256;
 }
 
@@ -1524,7 +1550,7 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
     else { LENV_PICK(LENV_ENV_ACROBOT, 6, 3) }
 #undef LENV_PICK2
 #undef LENV_PICK
-    if (cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action && !cfg_disables_fixed_shape()) {
+    if (cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action && !cfg_disables_fixed_shape(cfg)) {
         switch (published_shape(cfg, a.L)) {
         case 1: kern = ddqn_se_inner_kernel<LENV_ENV_CARTPOLE, 4, 2, LENV_ACT_TANH, 1, 1>; break;
         case 2: kern = ddqn_se_inner_kernel<LENV_ENV_CARTPOLE, 4, 2, LENV_ACT_RELU, 1, 2>; break;
@@ -1534,19 +1560,7 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
     }
     unsigned grid = (unsigned)chains;
     if (a.team_G > 1) {
-        // a chain on a team of workgroups: the generic instantiation with the exchange code, or the published CartPole shape's
-        kern = nullptr;
-#define LENV_PICK2(ENVID, SS, AA, PP)                                                                              \
-        switch (cfg->q_act) {                                                                                      \
-        case LENV_ACT_RELU: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_RELU, PP, 0, true>; break;            \
-        case LENV_ACT_LEAKYRELU: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_LEAKYRELU, PP, 0, true>; break;  \
-        case LENV_ACT_TANH: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_TANH, PP, 0, true>; break;            \
-        default: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_IDENTITY, PP, 0, true>; break;                   \
-        }
-        if (cfg->env_id == LENV_ENV_CARTPOLE) { if (a.L.P_q <= NT) { LENV_PICK2(LENV_ENV_CARTPOLE, 4, 2, 1) } else { LENV_PICK2(LENV_ENV_CARTPOLE, 4, 2, 2) } }
-        else { if (a.L.P_q <= NT) { LENV_PICK2(LENV_ENV_ACROBOT, 6, 3, 1) } else { LENV_PICK2(LENV_ENV_ACROBOT, 6, 3, 2) } }
-#undef LENV_PICK2
-        if (!cfg_disables_fixed_shape() && published_shape(cfg, a.L) == 1) kern = ddqn_se_inner_kernel<LENV_ENV_CARTPOLE, 4, 2, LENV_ACT_TANH, 1, 1, true>;
+        kern = ddqn_team_kernel(cfg, a.L);
         grid = (unsigned)(8 * ((chains + 7) / 8) * a.team_G);
         hipLaunchKernelGGL(ddqn_team_reset_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream), a.team_ws, chains * a.team_stride);
     }

@@ -883,11 +883,10 @@ extern "C" size_t lenv_dueling_se_workspace_bytes(const lenv_ddqn_cfg *cfg, int6
 extern "C" int lenv_dueling_team_size(const lenv_ddqn_cfg *cfg, int64_t chains)
 {
     if (!cfg || chains < 1) return LENV_ERR_INVALID;
-    const char *nw_ = getenv("LENV_NO_WAVECHAIN"), *nf_ = getenv("LENV_NO_FIXED_SHAPE");
-    if ((nw_ && nw_[0] == '1') || (nf_ && nf_[0] == '1') || cfg->icm_enabled || cfg->rng_mode != LENV_RNG_COUNTER || cfg->synthetic_env_type != 0 ||
+    if ((cfg->kernel_variant & (LENV_VARIANT_NO_WAVECHAIN | LENV_VARIANT_GENERIC)) || cfg->icm_enabled || cfg->rng_mode != LENV_RNG_COUNTER || cfg->synthetic_env_type != 0 ||
         cfg->same_action_num > 1 || !lenv_wc_dueling_shape(cfg))
         return 1;
-    return lenv_wc_dueling_team(chains);
+    return lenv_wc_dueling_team(cfg, lenv_wc_dueling_shape(cfg), chains);
 }
 
 extern "C" int64_t lenv_dueling_num_params(const lenv_ddqn_cfg *cfg)
@@ -955,15 +954,14 @@ extern "C" int lenv_dueling_se_inner_loop_icm(const lenv_ddqn_cfg *cfg, const le
     void (*kern)(const DuelArgs) = cfg->icm_enabled ? dueling_se_inner_kernel<true> : dueling_se_inner_kernel<false>;
     {
         // the published Acrobot DuelingDDQN shape in production form takes the shape-specialised instantiation
-        static const bool off = [] { const char *e_ = getenv("LENV_NO_FIXED_SHAPE"); return e_ && e_[0] == '1'; }();
+        const bool off = (cfg->kernel_variant & LENV_VARIANT_GENERIC) != 0;
         auto matches = [&](const DuelShape &sp) {
             return cfg->agent_kind == sp.kind && cfg->env_id == sp.env && cfg->state_dim == sp.S && cfg->num_actions == sp.A &&
                    (sp.kind == 0 || cfg->feature_dim == sp.F) && cfg->q_hidden == sp.H && cfg->q_layers == sp.L && cfg->batch_size == sp.B &&
                    cfg->se_hidden == sp.Hse && cfg->test_episodes == sp.T && cfg->q_act == sp.q_act && cfg->se_act == sp.se_act && cfg->same_action_num <= 1;
         };
-        // production launches of a wave-chain shape (dueling_wavechain.hip): LENV_NO_WAVECHAIN=1 keeps the GEMM-queue kernel (A/B runs)
-        const char *nw_ = getenv("LENV_NO_WAVECHAIN");
-        const bool no_wc = nw_ && nw_[0] == '1';
+        // production launches of a wave-chain shape (dueling_wavechain.hip): kernel_variant NO_WAVECHAIN keeps the GEMM-queue kernel (A/B runs)
+        const bool no_wc = (cfg->kernel_variant & LENV_VARIANT_NO_WAVECHAIN) != 0;
         if (!off && !no_wc && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action && cfg->synthetic_env_type == 0 &&
             cfg->same_action_num <= 1) {
             const int wshape = lenv_wc_dueling_shape(cfg);

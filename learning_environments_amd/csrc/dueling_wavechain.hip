@@ -980,31 +980,13 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     int train_steps = 0, n_act = 0, learn_it = 0, n_test_ep = 0, test_steps = 0, episodes_run = 0;
     double eps_g = cfg.eps_init, b1pow = 1.0, b2pow = 1.0;
     const int rb_cap = (int)a.rb_cap;
-    // ---- team barrier (G = 2): as in td3_wavechain.hip -- one monotonically increasing counter per chain, zeroed by a kernel in front
-    // of the launch; thread 0 releases, arrives, waits for the epoch's count, acquires (agent scope).  A member that waits for
-    // seconds gives up for good (status -10) instead of hanging the device.
-    unsigned team_epoch = 0;
-    bool team_dead = false, team_same_xcd = false;
+    // ---- team barrier (G = 2; wc::team_barrier): the chain's counter and the launch's give-up word are zeroed by wct_team_reset_kernel
+    TeamSync tsync{ team_bar, reinterpret_cast<unsigned *>(a.arena + a.a_bar) + 8, ictrl + 5, 0u, G, false, false };
+    bool team_dead = false;
     auto team_barrier = [&]() {
         if (G == 1) return;
-        __syncthreads();
-        ++team_epoch;
-        if (tid == 0 && !team_dead) {
-            // members on one XCD share its L2 (td3_wavechain.hip): no L2 write-back on release, only this CU's L1 dropped on acquire
-            if (team_same_xcd) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_fetch_add(team_bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target_ = team_epoch * (unsigned)G;
-            long spins = 0;
-            while (__hip_atomic_load(team_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target_) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > 8000000L) { ictrl[5] = 1; break; }
-            }
-            if (team_same_xcd) asm volatile("buffer_inv sc1" ::: "memory");
-            else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        if (ictrl[5]) { team_dead = true; status = -10; }
+        wc::team_barrier(tsync, tid);
+        if (tsync.dead) { team_dead = true; status = -10; }
     };
     if (G > 1 && tid == 0) reinterpret_cast<unsigned *>(gva)[g] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
     team_barrier();                                        // the arena is initialised, every member's XCD id is posted
@@ -1013,7 +995,11 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
         const unsigned x0 = reinterpret_cast<unsigned *>(gva)[0];
         for (int m = 1; m < G; ++m) same = same && reinterpret_cast<unsigned *>(gva)[m] == x0;
         team_barrier();                                    // everybody has read the ids before the exchange rows are reused
-        team_same_xcd = same;
+        tsync.same_xcd = same;
+    }
+    if (team_dead) {                                       // not all members became resident in time: nothing was computed
+        if (a.out.status) atomicMin(&a.out.status[chain], -10);
+        return;
     }
 
     // q_out[I][A] from the head outputs of `slot` (models/actor_critic.py:117-122; learn: mean over ALL I*A advantages)
@@ -1241,10 +1227,12 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                 ++learn_it;                                // (optimizer step + Polyak update: inside wc_backward_big)
                 __syncthreads();
                 WPT_MARK(7);
+                if (team_dead) break;                      // (uniform in the workgroup) the team gave up: leave, status -10
             }
             if (done_now > 0.5f) break;
         }
         ++episodes_run;
+        if (team_dead) break;
         if (tid == 0 && g == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
         __syncthreads();
         WPT_MARK(9);
@@ -1273,7 +1261,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     WPT_MARK(9);
     const int64_t remaining = cfg.step_budget - ((int64_t)train_steps + test_steps);
     const int test_before = test_steps;
-    test_phase();
+    if (!team_dead) test_phase();
     if (budgeted) {
         if (tid == 0) {
             int64_t used = 0;
@@ -1366,22 +1354,17 @@ namespace lenv {
 __global__ void wct_team_reset_kernel(float *arena, int64_t arena_stride, int64_t a_bar, int64_t chains)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < chains) *reinterpret_cast<unsigned *>(arena + c * arena_stride + a_bar) = 0u;
+    if (c < chains) { unsigned *b = reinterpret_cast<unsigned *>(arena + c * arena_stride + a_bar); b[0] = 0u; b[8] = 0u; }
 }
 }
 
-// Workgroups per chain: 2 when all 8 * ceil(chains / 8) * 2 workgroups (one per CU) are resident at once -- the members wait for
-// each other --, else 1.  LENV_DUELING_TEAM=1 forces one workgroup per chain.
-int lenv_wc_dueling_team(int64_t chains)
+// Workgroups per chain: 2 when all 8 * ceil(chains / 8) * 2 workgroups are resident at once (occupancy API: one per CU at this
+// kernel's LDS footprint) -- the members wait for each other --, else 1.  cfg->team_size 1 forces one workgroup per chain.
+int lenv_wc_dueling_team(const lenv_ddqn_cfg *cfg, int shape, int64_t chains)
 {
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        return n;
-    }();
-    const char *e = getenv("LENV_DUELING_TEAM");
-    const int want = e ? atoi(e) : 2;
-    return (want >= 2 && 8 * ((chains + 7) / 8) * 2 <= cus) ? 2 : 1;
+    if (cfg->team_size == 1 || chains < 1 || shape <= 0) return 1;
+    void (*kern)(const WcArgs) = dueling_wavechain_kernel<1>;
+    return lenv_team_grid_resident(reinterpret_cast<const void *>(kern), wc::NT, wc_lds_bytes(kWcShapes[shape]), 8 * ((chains + 7) / 8) * 2) ? 2 : 1;
 }
 
 int lenv_wc_dueling_launch(int shape, const lenv_ddqn_cfg *cfg, const float *theta, const float *eps, const int32_t *worker,
@@ -1409,7 +1392,7 @@ int lenv_wc_dueling_launch(int shape, const lenv_ddqn_cfg *cfg, const float *the
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
         return LENV_ERR_LAUNCH;
     a.chains = chains;
-    a.G = lenv_wc_dueling_team(chains);
+    a.G = lenv_wc_dueling_team(cfg, shape, chains);
     unsigned grid = (unsigned)chains;
     if (a.G > 1) {
         grid = (unsigned)(8 * ((chains + 7) / 8) * a.G);

@@ -14,6 +14,21 @@
 #include "lenv_cheetah_standin.h"
 
 #define LENV_WAVE 64
+// A member of a team of workgroups (a chain on several CUs) that waits this long for the others gives up: ticks of the constant
+// 100 MHz clock (s_memrealtime), 0.25 s.  All team workgroups of a launch are resident at once on an idle device (host-side
+// occupancy check, lenv_team_grid_resident), so only a foreign kernel holding CUs can make a member wait.
+#define LENV_TEAM_GIVEUP_TICKS 25000000ull
+
+// Host side of the team launches: can `grid` workgroups of `kern` (threads per workgroup, dynamic LDS bytes) all be resident at the
+// same time on the current device?  (occupancy API x CU count; false without a device)
+static inline bool lenv_team_grid_resident(const void *kern, int threads, size_t lds_bytes, long long grid)
+{
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds_bytes) != hipSuccess) return false;
+    return grid <= (long long)per_cu * cus;
+}
 
 namespace lenv {
 

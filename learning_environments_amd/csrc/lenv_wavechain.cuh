@@ -45,6 +45,53 @@ __device__ __forceinline__ void barrier_lds()
     asm volatile("" ::: "memory");
 }
 
+// ---- team barrier: a chain that runs on G co-resident workgroups (td3_wavechain.hip, dueling_wavechain.hip).  One monotonically
+// increasing counter per chain (`bar`, zeroed by a reset kernel in front of the launch); every wave waits for the acknowledgement of
+// its own arena stores (__syncthreads() alone is s_barrier without a vmcnt wait on gfx950), then thread 0 releases, arrives, waits
+// for the epoch's count and acquires.  When all members sit on ONE XCD (same_xcd, established once by the kernels) they share its
+// L2 and the vector L1 writes through: the release needs no L2 write-back and the acquire only drops this CU's L1 lines; otherwise
+// the agent-scope fences run.  The launch is only made when all its workgroups fit the device at once (host: lenv_team_grid_resident),
+// but a foreign kernel may hold CUs: a member that waits longer than LENV_TEAM_GIVEUP_TICKS gives up for good and raises the LAUNCH's
+// give-up word (`launch_dead`: one per launch, polled by every waiting member), so the whole launch drains within that time with
+// status -10 and the caller repeats it with one workgroup per chain.  Returns through ts.dead (uniform in the workgroup).
+struct TeamSync {
+    unsigned *bar, *launch_dead;
+    volatile int *lds_flag;               // one LDS word, zero at kernel start
+    unsigned epoch;
+    int G;
+    bool dead, same_xcd;
+};
+__device__ __forceinline__ void team_barrier(TeamSync &ts, int tid)
+{
+    if (ts.G == 1) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++ts.epoch;
+    if (tid == 0 && !ts.dead) {
+        if (ts.same_xcd) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(ts.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = ts.epoch * (unsigned)ts.G;
+        const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();      // constant 100 MHz
+        unsigned spins = 0;
+        while (__hip_atomic_load(ts.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63u) == 0u) {          // every 64th poll: has anybody in the launch given up / is it this member's turn to?
+                if (__hip_atomic_load(ts.launch_dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { *ts.lds_flag = 1; break; }
+                if (__builtin_amdgcn_s_memrealtime() - w0 > LENV_TEAM_GIVEUP_TICKS) {
+                    __hip_atomic_store(ts.launch_dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *ts.lds_flag = 1;
+                    break;
+                }
+            }
+        }
+        if (ts.same_xcd) asm volatile("buffer_inv sc1" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (*ts.lds_flag) ts.dead = true;
+}
+
 __device__ __forceinline__ int img_pos(int r, int c) { return r * W + (c ^ ((r & 7) << 2)); }
 
 struct Lane {

@@ -818,9 +818,8 @@ extern "C" size_t lenv_td3_rn_workspace_bytes(const lenv_td3_cfg *cfg, int64_t c
 extern "C" int lenv_td3_rn_team_size(const lenv_td3_cfg *cfg, int64_t chains)
 {
     if (!cfg || chains < 1) return LENV_ERR_INVALID;
-    const char *nw_ = getenv("LENV_NO_WAVECHAIN"), *nf_ = getenv("LENV_NO_FIXED_SHAPE");
-    if ((nw_ && nw_[0] == '1') || (nf_ && nf_[0] == '1') || cfg->icm_enabled || cfg->rng_mode != LENV_RNG_COUNTER || !lenv_wc_td3_shape(cfg)) return 1;
-    return lenv_wc_td3_team(chains);
+    if ((cfg->kernel_variant & (LENV_VARIANT_NO_WAVECHAIN | LENV_VARIANT_GENERIC)) || cfg->icm_enabled || cfg->rng_mode != LENV_RNG_COUNTER || !lenv_wc_td3_shape(cfg)) return 1;
+    return lenv_wc_td3_team(cfg, chains);
 }
 
 extern "C" int64_t lenv_td3_num_params(const lenv_td3_cfg *cfg, int64_t *actor_params, int64_t *critic_params)
@@ -910,16 +909,15 @@ extern "C" int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg, const lenv_ch
     else kern = cfg->icm_enabled ? td3_rn_inner_kernel<true, LENV_ENV_CHEETAH_STANDIN> : td3_rn_inner_kernel<false, LENV_ENV_CHEETAH_STANDIN>;
     {
         // the published HalfCheetah RewardEnv + TD3 shape in production form takes the shape-specialised instantiation
-        static const bool off = [] { const char *e_ = getenv("LENV_NO_FIXED_SHAPE"); return e_ && e_[0] == '1'; }();
+        const bool off = (cfg->kernel_variant & LENV_VARIANT_GENERIC) != 0;
         auto matches = [&](const Td3Shape &sp) {
             return cfg->env_id == sp.env && (cfg->virtual_env != 0) == (sp.virtual_env != 0) && (cfg->same_action_num > 1 ? cfg->same_action_num : 1) == sp.k_rep &&
                    cfg->hidden == sp.H && cfg->layers == sp.L && cfg->batch_size == sp.B && cfg->test_episodes == sp.T && cfg->rn_hidden == sp.Hrn &&
                    cfg->rn_layers == sp.rn_layers && cfg->rn_act == sp.rn_act && cfg->reward_env_type == sp.rtype && cfg->act == sp.act &&
                    cfg->policy_delay == sp.policy_delay;
         };
-        // production launches of the cfg-5 shape: the wave-chain kernel (LENV_NO_WAVECHAIN=1 keeps the GEMM-queue kernel for A/B runs)
-        const char *nw_ = getenv("LENV_NO_WAVECHAIN");
-        if (!off && !(nw_ && nw_[0] == '1') && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_reward && lenv_wc_td3_shape(cfg)) {
+        // production launches of the cfg-5 shape: the wave-chain kernel (kernel_variant NO_WAVECHAIN keeps the GEMM-queue kernel for A/B runs)
+        if (!off && !(cfg->kernel_variant & LENV_VARIANT_NO_WAVECHAIN) && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_reward && lenv_wc_td3_shape(cfg)) {
             return lenv_wc_td3_launch(cfg, theta, eps, worker, sign, agent_init, rng_keys, chains, a.arena, a.arena_stride, a.rb_cap, a.RS, a.P, a.actor.P,
                                       a.critic.P, a.P_rn, out, static_cast<hipStream_t>(stream));
         }

@@ -386,6 +386,7 @@ __device__ __noinline__ void t3w_forward_split(const T3wCtx *ctx_, const float *
     for (int i = tid; i < 2 * W; i += NT) sm_b[i] = par[(i < W ? ob1 : ob2 - W) + i];
     for (int i = tid; i < 8 * W + 8; i += NT) sm_wo[i] = par[oWo + i];
     StageRegs sr;
+    TSUB_DECL;
     float xb[in >> 1], wa[in >> 1];
     {
         const gfloat *w1 = (const gfloat *)par + oW1t + L.h * W + 32 * jt + L.li;
@@ -396,6 +397,7 @@ __device__ __noinline__ void t3w_forward_split(const T3wCtx *ctx_, const float *
     stage_load_direct(par + oW2t, L, sr);
     stage_store_direct(bufA, L, sr);
     barrier_lds();
+    TSUB_MARK(30);
     float r16[16], rf[64];
     f32x16 acc;
     if (active) {
@@ -428,6 +430,7 @@ __device__ __noinline__ void t3w_forward_split(const T3wCtx *ctx_, const float *
         xch_put(xch0, jt, L.lane, r16);
     }
     barrier_lds();
+    TSUB_MARK(31);
     if (active) {
         xch_get(xch0, L.lane, rf);
 #pragma unroll
@@ -448,6 +451,7 @@ __device__ __noinline__ void t3w_forward_split(const T3wCtx *ctx_, const float *
         xch_put(xch1, jt, L.lane, r16);
     }
     barrier_lds();
+    TSUB_MARK(32);
     if (active && jt == 0) {
         xch_get(xch1, L.lane, rf);
         f32x16 hacc;
@@ -470,7 +474,9 @@ __device__ __noinline__ void t3w_forward_split(const T3wCtx *ctx_, const float *
             }
         }
     }
+    TSUB_MARK(33);
     __syncthreads();
+    TSUB_MARK(34);
 }
 
 template <int ACT, int IN, int OUT>
@@ -489,8 +495,10 @@ __device__ __noinline__ void t3w_backward_chain_split(const T3wCtx *ctx_, const 
     float *xch0 = bufB + quad * 4096, *xch1 = bufB + 8192 + quad * 4096;
     for (int i = tid; i < 8 * W + 8; i += NT) sm_wo[i] = par[oWo + i];
     StageRegs sr;
+    TSUB_DECL;
     stage_load_transposed(par + oW2t, L, sr);
     __syncthreads();                                       // sm_wo staged
+    TSUB_MARK(35);
     float r16[16], rf[64];
     f32x16 acc;
     if (active) {
@@ -525,6 +533,7 @@ __device__ __noinline__ void t3w_backward_chain_split(const T3wCtx *ctx_, const 
     }
     stage_store_transposed(bufA, L, sr);
     barrier_lds();
+    TSUB_MARK(36);
     L.refresh();
     if (active) {
         const gf4 *src = (const gf4 *)dump_of(d_h1, blk) + L.lane;
@@ -550,6 +559,7 @@ __device__ __noinline__ void t3w_backward_chain_split(const T3wCtx *ctx_, const 
         }
     }
     barrier_lds();
+    TSUB_MARK(37);
     if (active && jt == 0 && dx_n > 0) {
         // dX[i][dx_col + c] = sum_u dh1[i][u] W1[u][dx_col + c] (u ascending), c < dx_n, then dz = (dX * max_action) * (1 - th^2)
         xch_get(xch1, L.lane, rf);
@@ -568,7 +578,9 @@ __device__ __noinline__ void t3w_backward_chain_split(const T3wCtx *ctx_, const 
             }
         }
     }
+    TSUB_MARK(38);
     __syncthreads();
+    TSUB_MARK(39);
 }
 
 // ---- backward of one network, second half: the parameter gradients from the row-major copies of ALL 192 samples (dOut in LDS, h2 /
@@ -799,38 +811,16 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
 
     const uint64_t key = a.rng_keys[chain];
     int status = 0;
-    // ---- team barrier (G > 1): every member has finished its share of a phase and its arena writes are visible to the others.
-    // One monotonically increasing counter per chain (zeroed by t3w_team_reset_kernel in front of the launch); thread 0 releases,
-    // arrives, waits for the epoch's count and acquires (agent scope: the members may sit on different XCDs).  A member that waits
-    // longer than a few seconds gives up for good (status -10) instead of hanging the device: the launch is only valid when all G x
-    // chains workgroups are resident at once, which the host checks against the CU count.
-    unsigned team_epoch = 0;
-    bool team_dead = false, team_same_xcd = false;
+    // ---- team barrier (G > 1, wc::team_barrier): every member has finished its share of a phase and its arena writes are visible to the
+    // others.  The chain's counter and the launch's give-up word are zeroed by t3w_team_reset_kernel in front of the launch.
+    TeamSync tsync{ team_bar, reinterpret_cast<unsigned *>(a.arena + a.a_bar) + 8, ictrl + 5, 0u, G, false, false };
+    bool team_dead = false;
     unsigned long long bar_cycles = 0;
     auto team_barrier = [&]() {
         if (G == 1) return;
         const unsigned long long bt0 = __builtin_readcyclecounter();
-        __syncthreads();
-        ++team_epoch;
-        if (tid == 0 && !team_dead) {
-            // release (every wave's stores have been acknowledged at the __syncthreads above; this makes them visible at agent scope),
-            // arrive, wait for the epoch's count, acquire.  When all members sit on ONE XCD (checked once, below) they share its L2:
-            // the stores are there already (the vector L1 writes through), so the release needs no L2 write-back and the acquire
-            // only has to drop this CU's L1 lines.
-            if (team_same_xcd) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_fetch_add(team_bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = team_epoch * (unsigned)G;
-            long spins = 0;
-            while (__hip_atomic_load(team_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > 8000000L) { ictrl[5] = 1; break; }
-            }
-            if (team_same_xcd) asm volatile("buffer_inv sc1" ::: "memory");
-            else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        if (ictrl[5]) { team_dead = true; status = -10; }
+        wc::team_barrier(tsync, tid);
+        if (tsync.dead) { team_dead = true; status = -10; }
         bar_cycles += __builtin_readcyclecounter() - bt0;
     };
     (void)bar_cycles;
@@ -844,7 +834,11 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         const unsigned x0 = reinterpret_cast<unsigned *>(gdz)[0];
         for (int m = 1; m < G; ++m) same = same && reinterpret_cast<unsigned *>(gdz)[m] == x0;
         team_barrier();                                    // everybody has read the ids before the exchange rows are reused
-        team_same_xcd = same;
+        tsync.same_xcd = same;
+    }
+    if (team_dead) {                                       // not all members became resident in time: nothing was computed
+        if (a.out.status) atomicMin(&a.out.status[chain], -10);
+        return;
     }
     TPT_DECL;
     int64_t n_rand = 0, n_actn = 0, n_testn = 0, n_test_ep = 0, learn_it = 0;
@@ -1152,10 +1146,12 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                     team_barrier();
                     TPT_MARK(8);
                 }
+                if (team_dead) break;                      // (uniform in the workgroup) the team gave up: leave, status -10
             }
             if (done_now > 0.5f) break;
         }
         ++episodes_run;
+        if (team_dead) break;
         if (tid == 0 && g == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
         __syncthreads();
         TPT_MARK(10);
@@ -1182,7 +1178,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     TPT_MARK(10);
     const int64_t remaining = cfg.step_budget - ((int64_t)train_steps + test_steps);
     const int test_before = test_steps;
-    test_phase();
+    if (!team_dead) test_phase();
     if (budgeted) {
         int64_t used = 0;
         int stop = T;
@@ -1270,29 +1266,34 @@ namespace lenv {
 __global__ void t3w_team_reset_kernel(float *arena, int64_t arena_stride, int64_t a_bar, int64_t chains)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < chains) *reinterpret_cast<unsigned *>(arena + c * arena_stride + a_bar) = 0u;
+    if (c < chains) { unsigned *b = reinterpret_cast<unsigned *>(arena + c * arena_stride + a_bar); b[0] = 0u; b[8] = 0u; }
 }
+}
+
+static size_t t3w_lds_bytes(int P_rn)
+{
+    const int B = T3W_B, T = 1;
+    const size_t lds_floats = 2 * (size_t)wc::IMG + 2 * (2 * wc::W + 8 * wc::W + 8) + ((P_rn + 3) & ~3) + 128 + 8 * (size_t)B + 2 * wc::W + 64 + 2 + 2 * (20 + 17 * T + T) + 2 * T + 1 +
+                              20 + 8 + 56 + 4 + (sizeof(T3wCtx) + 3) / 4;
+    return lds_floats * sizeof(float);
 }
 
 // Workgroups per chain.  A team only works when every workgroup of the launch is resident at the same time (its members wait for each
-// other): 8 * ceil(chains / 8) * G workgroups of one per CU must fit the device.  192 minibatch rows = 6 sample blocks: G = 6, 3, 2 or 1;
-// LENV_TD3_TEAM=<G> overrides the choice (1 = the plain launch), still subject to the residency check.
-static int t3w_pick_team(int64_t chains)
+// other): 8 * ceil(chains / 8) * G workgroups must fit the device (occupancy API: one per CU at this kernel's LDS footprint).  192
+// minibatch rows = 6 sample blocks: G = 6, 3, 2 or 1; cfg->team_size caps the choice (0 = automatic, 1 = the plain launch).
+static int t3w_pick_team(const lenv_td3_cfg *cfg, int64_t chains)
 {
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        return n;
-    }();
-    const char *e = getenv("LENV_TD3_TEAM");
-    const int want = e ? atoi(e) : 6;
+    const int want = cfg->team_size > 0 ? cfg->team_size : 6;
+    if (want == 1 || chains < 1) return 1;
+    const int P_rn = (int)lenv_rn_num_params(cfg->reward_env_type, cfg->state_dim, cfg->info_dim, cfg->rn_hidden, cfg->rn_layers);
+    void (*kern)(const T3wArgs) = td3_wavechain_kernel<1>;
     const int64_t padded = 8 * ((chains + 7) / 8);
     for (int G : { 6, 3, 2 })
-        if (G <= want && padded * G <= cus) return G;
+        if (G <= want && lenv_team_grid_resident(reinterpret_cast<const void *>(kern), wc::NT, t3w_lds_bytes(P_rn), padded * G)) return G;
     return 1;
 }
 
-int lenv_wc_td3_team(int64_t chains) { return t3w_pick_team(chains); }
+int lenv_wc_td3_team(const lenv_td3_cfg *cfg, int64_t chains) { return t3w_pick_team(cfg, chains); }
 
 int64_t lenv_wc_td3_arena_floats(const lenv_td3_cfg *cfg, int64_t rb_cap, int RS)
 {
@@ -1313,15 +1314,12 @@ int lenv_wc_td3_launch(const lenv_td3_cfg *cfg, const float *theta, const float 
     int64_t total;
     t3w_offsets(cfg, rb_cap, RS, a, &total);
     if (total > arena_stride) return LENV_ERR_WORKSPACE;
-    const int B = T3W_B, T = 1;
-    const size_t lds_floats = 2 * (size_t)wc::IMG + 2 * (2 * wc::W + 8 * wc::W + 8) + ((P_rn + 3) & ~3) + 128 + 8 * (size_t)B + 2 * wc::W + 64 + 2 + 2 * (20 + 17 * T + T) + 2 * T + 1 +
-                              20 + 8 + 56 + 4 + (sizeof(T3wCtx) + 3) / 4;
-    const size_t lds_bytes = lds_floats * sizeof(float);
+    const size_t lds_bytes = t3w_lds_bytes(P_rn);
     if (lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
     void (*kern)(const T3wArgs) = td3_wavechain_kernel<1>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return LENV_ERR_LAUNCH;
     a.chains = chains;
-    a.G = t3w_pick_team(chains);
+    a.G = t3w_pick_team(cfg, chains);
     unsigned grid = (unsigned)chains;
     if (a.G > 1) {
         grid = (unsigned)(8 * ((chains + 7) / 8) * a.G);

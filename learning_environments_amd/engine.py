@@ -613,6 +613,20 @@ class HipNesEngine(object):
         if int(st.min()) != 0:
             raise _lib.LenvError("inner loop reported status %s" % st.tolist())
 
+    def run_checked(self, inner, *args, **kw):
+        """inner.run(...) + host check of the chain statuses (synchronises).  A launch whose teams of workgroups could not assemble
+        (status -10: a foreign kernel held CUs, include/lenv_hip.h lenv_ddqn_cfg::team_size) is repeated once with one workgroup per
+        chain -- the chains are deterministic functions of their inputs -- and the inner loop keeps that setting."""
+        out = inner.run(*args, **kw)
+        st = inner.status.cpu()
+        if int(st.min()) == _lib.STATUS_TEAM_GAVE_UP and hasattr(inner.cfg, "team_size") and inner.cfg.team_size != 1:
+            inner.cfg.team_size = 1
+            out = inner.run(*args, **kw)
+            st = inner.status.cpu()
+        if int(st.min()) != 0:
+            raise _lib.LenvError("inner loop reported status %s" % st.tolist())
+        return out
+
     def worker_best(self, chain_scores, pop, mirrored, num_grad_evals=1, grad_eval_type="mean", out=None):
         return nes_worker_best(chain_scores, pop, mirrored, num_grad_evals, grad_eval_type, out=out)
 

@@ -38,7 +38,7 @@ def _oracle_cfg(cfg):
     """the package's DdqnCfg (ctypes) -> the oracle's (same field names)"""
     o = orc.DdqnCfg()
     for f, _ in orc.DdqnCfg._fields_:
-        setattr(o, f, getattr(cfg, f))
+        setattr(o, f, getattr(cfg, f, 0))      # (the HIP cfg has launch knobs the oracle has no use for, and vice versa padding)
     return o
 
 

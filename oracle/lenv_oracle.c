@@ -994,9 +994,27 @@ static float rn_shape_one(int t, int S, int info_dim, const orc_mlp_desc *rd, co
                           const float *next_state, const float *info, float r32, float *phi_s_cache, int have_cache,
                           float (*z)[ORC_MAX_WIDTH], float (*a)[ORC_MAX_WIDTH]);
 
+static int ddqn_se_chain_impl(const orc_ddqn_cfg *cfg, const float *se_params, const float *agent_init, const float *icm_init, uint64_t rng_key,
+                              const orc_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
+                              double *final_test_returns, orc_trace *trace, orc_chain_result *res, float *icm_final, float *final_online);
+
 int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const float *agent_init, const float *icm_init, uint64_t rng_key,
                           const orc_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
-                          double *final_test_returns, orc_trace *trace, orc_chain_result *res, float *icm_final);
+                          double *final_test_returns, orc_trace *trace, orc_chain_result *res, float *icm_final)
+{
+    return ddqn_se_chain_impl(cfg, se_params, agent_init, icm_init, rng_key, tapes, episode_test_mean, episode_len, final_test_returns, trace, res,
+                              icm_final, NULL);
+}
+
+/* the same, also handing out the trained online net (flat state-dict order, orc_mlp_num_params / orc_dueling_num_params floats) */
+int orc_ddqn_se_chain_params(const orc_ddqn_cfg *cfg, const float *se_params, const float *agent_init, uint64_t rng_key,
+                             const orc_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
+                             double *final_test_returns, orc_trace *trace, orc_chain_result *res, float *final_online)
+{
+    if (cfg->icm_enabled) return -1;
+    return ddqn_se_chain_impl(cfg, se_params, agent_init, NULL, rng_key, tapes, episode_test_mean, episode_len, final_test_returns, trace, res,
+                              NULL, final_online);
+}
 
 int orc_ddqn_se_chain(const orc_ddqn_cfg *cfg, const float *se_params, const float *agent_init, uint64_t rng_key,
                       const orc_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
@@ -1009,9 +1027,9 @@ int orc_ddqn_se_chain(const orc_ddqn_cfg *cfg, const float *se_params, const flo
 
 /* icm_init: [orc_icm_num_params] fresh ICMModel parameters in state-dict order when cfg->icm_enabled, else NULL;
  * icm_final (may be NULL): the ICM parameters after the last learn step */
-int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const float *agent_init, const float *icm_init, uint64_t rng_key,
-                          const orc_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
-                          double *final_test_returns, orc_trace *trace, orc_chain_result *res, float *icm_final)
+static int ddqn_se_chain_impl(const orc_ddqn_cfg *cfg, const float *se_params, const float *agent_init, const float *icm_init, uint64_t rng_key,
+                              const orc_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
+                              double *final_test_returns, orc_trace *trace, orc_chain_result *res, float *icm_final, float *final_online)
 {
     const int S = cfg->state_dim, A = cfg->num_actions, B = cfg->batch_size;
     if (cfg->icm_enabled && !icm_init) return -1;
@@ -1190,6 +1208,7 @@ int orc_ddqn_se_chain_icm(const orc_ddqn_cfg *cfg, const float *se_params, const
         res->learn_steps = learn_it; res->test_steps = test_steps;
     }
     if (cfg->icm_enabled && icm_final) memcpy(icm_final, icm_p, sizeof(float) * icm.P);
+    if (final_online) memcpy(final_online, online, sizeof(float) * P);
     free(icm_p); free(icm_m); free(icm_v); free(r_intr);
     free(online); free(target); free(am); free(av); free(rb); free(batch); free(z); free(a); free(test_returns); free(meter);
     return rng.err;

@@ -169,6 +169,10 @@ int orc_ddqn_se_chain(const orc_ddqn_cfg *cfg, const float *se_params /*perturbe
                       const float *agent_init /*[P_agent]*/, uint64_t rng_key, const orc_tapes *tapes,
                       double *episode_test_mean /*[train_episodes] or NULL*/, int32_t *episode_len /*[train_episodes] or NULL*/,
                       double *final_test_returns /*[test_episodes] or NULL*/, orc_trace *trace, orc_chain_result *res);
+/* the same + the trained online net (flat state-dict order) */
+int orc_ddqn_se_chain_params(const orc_ddqn_cfg *cfg, const float *se_params, const float *agent_init, uint64_t rng_key,
+                             const orc_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
+                             double *final_test_returns, orc_trace *trace, orc_chain_result *res, float *final_online);
 
 /* population driver (multi-threaded over chains; used by the cpu_baseline leg) */
 int orc_ddqn_se_population(const orc_ddqn_cfg *cfg, const float *theta, const float *eps, int64_t pop, int64_t p_theta,
@@ -277,6 +281,10 @@ int orc_rn_shape_rows(int type, int S, int info_dim, int hidden, int layers, int
 int orc_td3_rn_chain(const orc_td3_cfg *cfg, const float *rn_params, const float *agent_init /*[actor|critic1|critic2]*/,
                      uint64_t rng_key, const orc_td3_tapes *tapes, double *episode_test_mean, int32_t *episode_len,
                      double *final_test_returns, orc_td3_trace *trace, orc_chain_result *res);
+/* the same + the trained agent: final_params [actor | critic_1 | critic_2] */
+int orc_td3_rn_chain_params(const orc_td3_cfg *cfg, const float *rn_params, const float *agent_init, uint64_t rng_key,
+                            const orc_td3_tapes *tapes, double *episode_test_mean, int32_t *episode_len, double *final_test_returns,
+                            orc_td3_trace *trace, orc_chain_result *res, float *final_params);
 
 /* ---- TD3_discrete_vary on a VirtualEnv over a discrete-action real env (agents/TD3_discrete_vary.py:62-117,159-171,
  * models/actor_critic.py:22-35, agents/base_agent.py:64-227 with discretize_action) ---- */

@@ -285,9 +285,9 @@ def icm_num_params(cfg):
     return int(L.orc_icm_num_params(cfg.state_dim, cfg.num_actions, cfg.icm_feature_dim, cfg.icm_hidden))
 
 
-def ddqn_se_chain(cfg, se_params, agent_init, rng_key=0, tapes=None, trace_cap=0, icm_init=None):
+def ddqn_se_chain(cfg, se_params, agent_init, rng_key=0, tapes=None, trace_cap=0, icm_init=None, want_final_online=False):
     """icm_init: fresh ICMModel parameters (state-dict order) for an agent with cfg.icm_enabled; the result then carries
-    "icm_final" (the ICM parameters after the last learn step)."""
+    "icm_final" (the ICM parameters after the last learn step).  want_final_online: "final_online" = the trained online net."""
     se_params, agent_init = _f32(se_params), _f32(agent_init)
     E, T, S = cfg.train_episodes, cfg.test_episodes, cfg.state_dim
     ep_mean = np.full(max(E, 1), np.nan)
@@ -313,6 +313,12 @@ def ddqn_se_chain(cfg, se_params, agent_init, rng_key=0, tapes=None, trace_cap=0
                                          C.c_uint64(rng_key), C.byref(tapes) if tapes is not None else None, _p(ep_mean, C.c_double),
                                          _p(ep_len, C.c_int32), _p(final, C.c_double), C.byref(tr) if tr is not None else None,
                                          C.byref(res), _p(icm_final, C.c_float))
+    elif want_final_online:
+        final_online = np.zeros_like(agent_init)
+        rc = lib().orc_ddqn_se_chain_params(C.byref(cfg), _p(se_params, C.c_float), _p(agent_init, C.c_float), C.c_uint64(rng_key),
+                                            C.byref(tapes) if tapes is not None else None, _p(ep_mean, C.c_double),
+                                            _p(ep_len, C.c_int32), _p(final, C.c_double), C.byref(tr) if tr is not None else None,
+                                            C.byref(res), _p(final_online, C.c_float))
     else:
         rc = lib().orc_ddqn_se_chain(C.byref(cfg), _p(se_params, C.c_float), _p(agent_init, C.c_float), C.c_uint64(rng_key),
                                      C.byref(tapes) if tapes is not None else None, _p(ep_mean, C.c_double),
@@ -321,6 +327,8 @@ def ddqn_se_chain(cfg, se_params, agent_init, rng_key=0, tapes=None, trace_cap=0
     out = dict(rc=rc, score=res.score, episodes_run=res.episodes_run, train_steps=res.train_steps,
                learn_steps=res.learn_steps, test_steps=res.test_steps, episode_test_mean=ep_mean[:E],
                episode_len=ep_len[:E], final_test_returns=final[:T])
+    if want_final_online and icm_init is None:
+        out["final_online"] = final_online
     if tr is not None:
         n = tr.n
         out["trace"] = {k: v[:n] for k, v in arrs.items()}
@@ -618,7 +626,7 @@ def td3_icm_num_params(cfg):
     return int(L.orc_icm_num_params_continuous(cfg.state_dim, cfg.action_dim, cfg.icm_feature_dim, cfg.icm_hidden))
 
 
-def td3_rn_chain(cfg, rn_params, agent_init, rng_key=0, tapes=None, trace_cap=0, icm_init=None):
+def td3_rn_chain(cfg, rn_params, agent_init, rng_key=0, tapes=None, trace_cap=0, icm_init=None, want_final_params=False):
     rn_params, agent_init = _f32(rn_params), _f32(agent_init)
     E, T, S, A = cfg.train_episodes, cfg.test_episodes, cfg.state_dim, cfg.action_dim
     ep_mean = np.full(max(E, 1), np.nan)
@@ -640,12 +648,19 @@ def td3_rn_chain(cfg, rn_params, agent_init, rng_key=0, tapes=None, trace_cap=0,
                                         C.c_uint64(rng_key), C.byref(tapes) if tapes is not None else None, _p(ep_mean, C.c_double),
                                         _p(ep_len, C.c_int32), _p(final, C.c_double), C.byref(tr) if tr is not None else None,
                                         C.byref(res), _p(icm_final, C.c_float))
+    elif want_final_params:
+        final_params = np.zeros_like(agent_init)
+        rc = lib().orc_td3_rn_chain_params(C.byref(cfg), _p(rn_params, C.c_float), _p(agent_init, C.c_float), C.c_uint64(rng_key),
+                                           C.byref(tapes) if tapes is not None else None, _p(ep_mean, C.c_double), _p(ep_len, C.c_int32),
+                                           _p(final, C.c_double), C.byref(tr) if tr is not None else None, C.byref(res), _p(final_params, C.c_float))
     else:
         rc = lib().orc_td3_rn_chain(C.byref(cfg), _p(rn_params, C.c_float), _p(agent_init, C.c_float), C.c_uint64(rng_key),
                                     C.byref(tapes) if tapes is not None else None, _p(ep_mean, C.c_double), _p(ep_len, C.c_int32),
                                     _p(final, C.c_double), C.byref(tr) if tr is not None else None, C.byref(res))
     out = dict(rc=rc, score=res.score, episodes_run=res.episodes_run, train_steps=res.train_steps, learn_steps=res.learn_steps,
                test_steps=res.test_steps, episode_test_mean=ep_mean[:E], episode_len=ep_len[:E], final_test_returns=final[:T])
+    if want_final_params and icm_init is None:
+        out["final_params"] = final_params
     if tr is not None:
         out["trace"] = {k: v[:tr.n] for k, v in arrs.items()}
     if icm_final is not None:

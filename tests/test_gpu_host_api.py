@@ -335,7 +335,7 @@ def test_gtn_master_ddqn_vary_generation(tmp_path, monkeypatch):
         ocfg = orc.ddqn_cfg_from_config(cfg, grad_chunk=0, **orc.hp_overrides(hps[c]))
         pc = _lib.DdqnCfg()
         for f, _ in _lib.DdqnCfg._fields_:
-            setattr(pc, f, getattr(ocfg, f))
+            setattr(pc, f, getattr(ocfg, f, 0))
         init = orc.agent_init_from_key(key, agent_layer_dims(pc))
         sg = np.float32([0.0, 1.0, -1.0][c % 3])
         w = (sg * eps[c // 3] + theta0).astype(np.float32)
@@ -673,7 +673,7 @@ def test_gtn_master_td3_vary_generation(tmp_path, monkeypatch):
                                            layers=max(1, int(h["hidden_layer"])))
             pc = _lib.Td3Cfg()
             for f, _ in _lib.Td3Cfg._fields_:
-                setattr(pc, f, getattr(ocfg, f))
+                setattr(pc, f, getattr(ocfg, f, 0))
             init = orc.agent_init_from_key(key, td3_layer_dims(pc))
             w = (np.float32(sg) * eps[p] + theta0).astype(np.float32)
             sc.append(orc.td3_rn_chain(ocfg, w, init, rng_key=key)["score"])

@@ -39,7 +39,7 @@ def dev(a, dtype=None):
 
 def test_native_library_loaded(eng):
     from learning_environments_amd import _lib
-    assert _lib.lib().lenv_abi_version() == 4
+    assert _lib.lib().lenv_abi_version() == 5
     with open("/proc/self/maps") as f:
         assert "liblenv_hip.so" in f.read()
 
@@ -115,7 +115,7 @@ def _inner_cfg(orc, cfgd, **over):
     o = orc.ddqn_cfg_from_config(cfgd, **over)
     c = _lib.DdqnCfg()
     for f, _ in _lib.DdqnCfg._fields_:
-        setattr(c, f, getattr(o, f))
+        setattr(c, f, getattr(o, f, 0))      # (team_size / kernel_variant exist only in the HIP cfg)
     return o, c
 
 
@@ -308,7 +308,7 @@ def _ql_cfgs(orc, cfgd, rng_mode, **over):
     o = orc.ql_cfg_from_config(cfgd, tables, rng_mode=rng_mode, **over)
     c = _lib.QlCfg()
     for f, _ in _lib.QlCfg._fields_:
-        setattr(c, f, getattr(o, f))
+        setattr(c, f, getattr(o, f, 0))      # (team_size / kernel_variant exist only in the HIP cfg)
     return o, c, tables
 
 
@@ -1103,7 +1103,7 @@ def _lib_cfg_copy(ocfg):
     from learning_environments_amd import _lib
     c = _lib.DdqnCfg()
     for f, _ in _lib.DdqnCfg._fields_:
-        setattr(c, f, getattr(ocfg, f))
+        setattr(c, f, getattr(ocfg, f, 0))
     return c
 
 
@@ -1115,7 +1115,7 @@ def _td3_cfgs(orc, cfgd, rng_mode, **over):
     o = orc.td3_cfg_from_config(cfgd, rng_mode=rng_mode, **over)
     c = _lib.Td3Cfg()
     for f, _ in _lib.Td3Cfg._fields_:
-        setattr(c, f, getattr(o, f))
+        setattr(c, f, getattr(o, f, 0))      # (team_size / kernel_variant exist only in the HIP cfg)
     return o, c
 
 
@@ -1683,7 +1683,7 @@ def test_inner_loop_split_forward_layouts(eng, orc, golden, env_name, hq, batch,
 
 
 @pytest.mark.parametrize("case", ["published", "acrobot", "narrow"])
-def test_ddqn_chain_on_a_team_of_workgroups(eng, orc, golden, case, monkeypatch):
+def test_ddqn_chain_on_a_team_of_workgroups(eng, orc, golden, case):
     """A DDQN chain on G co-resident workgroups (launches that leave most of the GPU idle): the members deal the minibatch by whole
     gradient micro-chunks, exchange the chunk partials once per learn step and each applies the same Adam step.  Every team size
     must give the bits of the one-workgroup launch (and of the oracle): the published CartPole shape (its own instantiation), an
@@ -1720,7 +1720,7 @@ def test_ddqn_chain_on_a_team_of_workgroups(eng, orc, golden, case, monkeypatch)
     keys = np.array([orc.chain_key(13, 2, int(worker[c]), c % 3) for c in range(chains)], np.uint64)
 
     def run(G):
-        monkeypatch.setenv("LENV_DDQN_TEAM", str(G))
+        cfg.team_size = G
         got = _lib.lib().lenv_ddqn_se_team_size(C.byref(cfg), chains)
         il = eng.InnerLoop(cfg, chains, want_final_online=True)
         il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
@@ -1736,7 +1736,7 @@ def test_ddqn_chain_on_a_team_of_workgroups(eng, orc, golden, case, monkeypatch)
         assert got == max(x for x in (1, 2, 3, 4, 6) if x <= G and x <= n_chunks), (G, got, n_chunks)
         for a, b in zip(base, outs):
             assert np.array_equal(a, b, equal_nan=True), (case, G)
-    monkeypatch.delenv("LENV_DDQN_TEAM")
+    cfg.team_size = 0
     assert _lib.lib().lenv_ddqn_se_team_size(C.byref(cfg), chains) == 1          # fewer than 16 chains: no team unless asked for
     assert _lib.lib().lenv_ddqn_se_team_size(C.byref(cfg), 96) == 2 and _lib.lib().lenv_ddqn_se_team_size(C.byref(cfg), 192) == 1
     for c in (2, 10):
@@ -1749,7 +1749,7 @@ def test_ddqn_chain_on_a_team_of_workgroups(eng, orc, golden, case, monkeypatch)
 
 
 @pytest.mark.parametrize("pop,team", [(32, 2), (8, 6)])
-def test_ddqn_team_full_size_generations_bit_equal(pop, team, monkeypatch):
+def test_ddqn_team_full_size_generations_bit_equal(pop, team):
     """The strong-scaling shards of BASELINE configs[1] at full length (20 x 200 train steps = 3 800 learn steps per chain, through
     GTN_Master and its HIP graph): two generations with one workgroup per chain and with the automatic team size must leave the same
     scores, counters, per-episode test means, final returns and theta, bit for bit."""
@@ -1758,11 +1758,7 @@ def test_ddqn_team_full_size_generations_bit_equal(pop, team, monkeypatch):
     from learning_environments_amd import _lib
     outs = []
     for mode in ("1", "auto"):
-        if mode == "1":
-            monkeypatch.setenv("LENV_DDQN_TEAM", "1")
-        else:
-            monkeypatch.delenv("LENV_DDQN_TEAM", raising=False)
-        m, _ = bench.build_master(pop)
+        m, _ = bench.build_master(pop, team_size=1 if mode == "1" else 0)
         assert _lib.lib().lenv_ddqn_se_team_size(C.byref(m.cfg), 3 * pop) == (1 if mode == "1" else team)
         m.step(0)
         m.step(1)
@@ -1997,6 +1993,180 @@ def test_td3_full_size_properties(eng, orc):
         assert base[1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
         assert np.array_equal(base[2][c], o["episode_test_mean"], equal_nan=True)
         assert np.array_equal(base[3][c], o["final_test_returns"])
+
+
+@pytest.mark.parametrize("foreign_cus", [128, 200, 244])
+def test_team_launch_next_to_a_foreign_kernel_gives_up_cleanly(eng, orc, foreign_cus):
+    """Team launches assume the device to themselves (members wait for each other).  With a foreign kernel holding 128 / 200 / 244 of
+    the 256 CUs for seconds on another stream, the 144 workgroups of a 24-chain TD3 team launch cannot all be resident.  Either the
+    teams still assemble one after the other as chains finish (clean result), or some cannot (a member waits 0.25 s, gives up, the
+    whole launch drains: status -10, clean refusal) -- in both cases the launch returns within a second, nothing hangs, and
+    engine.run_checked then delivers the bits of the one-workgroup launch (repeating a refused launch with team_size 1) while the
+    foreign kernel is still there."""
+    import ctypes as C
+    import time
+    from learning_environments_amd import _lib, configs
+    from learning_environments_amd.agents.nes_common import chain_keys
+    cfgd = configs.fixed_work(configs.halfcheetah_reward_env_td3(8), 3)
+    cfgd["agents"]["td3"]["init_episodes"] = 1
+    cfgd["envs"]["HalfCheetah-v3"]["max_steps"] = 20
+    _, cfg = _td3_cfgs(orc, cfgd, 0)
+    chains = 24
+    rng = np.random.RandomState(91)
+    P_rn = 17 * 128 + 128 + 128 + 1
+    theta = (rng.randn(P_rn) * 0.2).astype(np.float32)
+    eps = (rng.randn(8, P_rn) * 0.1).astype(np.float32)
+    worker = (np.arange(chains) // 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), 8)
+    keys = chain_keys(80, 3, worker, np.arange(chains) % 3)
+    init = rng.uniform(-0.08, 0.08, (chains, 59016)).astype(np.float32)
+    args = (dev(theta), dev(eps), dev(worker), dev(sign), dev(init))
+    kw = dict(rng_keys=dev(keys.view(np.int64)))
+
+    cfg.team_size = 1
+    il = eng.Td3InnerLoop(cfg, chains, want_final_params=True)
+    il.run(*args, **kw)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    ref = [t.cpu().numpy().copy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_params)]
+
+    cfg.team_size = 0
+    assert _lib.lib().lenv_td3_rn_team_size(C.byref(cfg), chains) == 6
+    il = eng.Td3InnerLoop(cfg, chains, want_final_params=True)      # (allocations first: a hipMalloc would wait for the foreign kernel)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):                          # the foreign kernel: `foreign_cus` CUs for 3 s
+        _lib.check(_lib.lib().lenv_diag_occupy_cus(foreign_cus, 150 * 1024, 3 * 100_000_000, C.c_void_p(side.cuda_stream)), "lenv_diag_occupy_cus")
+    time.sleep(0.05)                                       # let it take its CUs first
+    t0 = time.time()
+    il.run(*args, **kw)
+    torch.cuda.current_stream().synchronize()
+    dt = time.time() - t0
+    st = il.status.cpu().tolist()
+    assert dt < 1.0, dt
+    assert set(st) <= {0, -10}, st                         # clean result, or the team launch gave up; nothing hung
+    assert not side.query()                                # ... while the foreign kernel is still running
+    he = eng.HipNesEngine()
+    he.run_checked(il, *args, **kw)                        # a refused launch is repeated with one workgroup per chain
+    assert cfg.team_size == (1 if min(st) < 0 else 0) and not side.query()
+    out = [t.cpu().numpy().copy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_params)]
+    for a, b in zip(ref, out):
+        assert np.array_equal(a, b, equal_nan=True)
+    side.synchronize()
+
+
+@pytest.mark.timeout(1800)
+def test_td3_bench_launch_vs_oracle_and_one_workgroup(eng, orc):
+    """The launch bench.py times for BASELINE configs[4], exactly as bench.secondary_configs builds it: 8 workers = 24 chains,
+    5 x 1000 train steps with init_episodes 1 (4 000 learn steps per chain: the replay ring holds 5 000 rows, every minibatch index is
+    drawn against a size past B, six-way exchange and 24 000 team barriers), automatic team size = SIX workgroups per chain.
+      * two whole chains against the oracle: score, counters, per-episode test means, final returns, all 59 016 final parameters;
+      * every chain of the team launch against the one-workgroup launch (team_size 1): all outputs, bit for bit."""
+    import ctypes as C
+    from learning_environments_amd import _lib, configs
+    cfgd = configs.fixed_work(configs.halfcheetah_reward_env_td3(8), 5)
+    cfgd["agents"]["td3"]["init_episodes"] = 1
+    ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
+    assert (cfg.hidden, cfg.layers, cfg.batch_size, cfg.max_steps, cfg.train_episodes, cfg.init_episodes) == (128, 2, 192, 1000, 5, 1)
+    Pa, Pc = orc.td3_param_counts(ocfg)
+    P_rn = orc.rn_num_params(2, 17, 4, ocfg.rn_hidden, 1)
+    pop = 8
+    chains = 3 * pop
+    rng = np.random.RandomState(41)
+    theta = (rng.randn(P_rn) * 0.2).astype(np.float32)
+    eps = (rng.randn(pop, P_rn) * 0.1).astype(np.float32)
+    agent_init = rng.uniform(-0.08, 0.08, (chains, Pa + 2 * Pc)).astype(np.float32)
+    worker = np.repeat(np.arange(pop), 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), pop)
+    keys = np.array([orc.chain_key(1234, 1, int(worker[c]), c % 3) for c in range(chains)], np.uint64)
+
+    def run(team_size):
+        cfg.team_size = team_size
+        il = eng.Td3InnerLoop(cfg, chains, want_final_params=True)
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return [t.cpu().numpy().copy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_params)]
+
+    cfg.team_size = 0
+    assert _lib.lib().lenv_td3_rn_team_size(C.byref(cfg), chains) == 6
+    team = run(0)
+    assert (team[1][:, 1] == 5000).all() and (team[1][:, 2] == 4000).all() and (team[1][:, 3] == 6000).all()
+    picks = (5, 22)
+    import threading
+    outs = {}
+    th = threading.Thread(target=lambda: outs.update(o=_oracle_chains_parallel(
+        lambda c: orc.td3_rn_chain(ocfg, (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32), agent_init[c], rng_key=int(keys[c]),
+                                   want_final_params=True),
+        [(c,) for c in picks])))
+    th.start()                                             # the oracle's two chains (minutes of CPU) run while the GPU does the second launch
+    one = run(1)
+    for a, b in zip(team, one):
+        assert np.array_equal(a, b, equal_nan=True)
+    th.join()
+    for c, o in zip(picks, outs["o"]):
+        assert float(team[0][c]) == o["score"]
+        assert team[1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(team[2][c], o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(team[3][c], o["final_test_returns"])
+        assert np.array_equal(team[4][c], o["final_params"])
+
+
+@pytest.mark.timeout(1800)
+def test_dueling_bench_launch_vs_oracle_and_one_workgroup(eng, orc):
+    """The launch bench.py times for BASELINE configs[2]: 32 workers = 96 chains, init_episodes 10 as published, 12 x 500 train steps
+    (two learning episodes = 1 000 learn steps; bench.py runs 20 episodes of the same), automatic team size = two workgroups per chain.
+    Two whole chains against the oracle incl. all 67 460 final parameters; all chains against the one-workgroup launch."""
+    import ctypes as C
+    from learning_environments_amd import _lib, configs
+    from learning_environments_amd.config import ddqn_cfg_from_config
+    cfgd = configs.fixed_work(configs.acrobot_syn_env_duelingddqn(32), 12)
+    assert cfgd["agents"]["duelingddqn"]["init_episodes"] == 10
+    cfg = ddqn_cfg_from_config(cfgd)
+    ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=0)
+    S, A, pop = cfg.state_dim, cfg.num_actions, 32
+    chains = 3 * pop
+    rng = np.random.RandomState(43)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, cfg.se_hidden, 1, "leakyrelu"))
+    P_q = orc.dueling_num_params(ocfg)
+    theta = (rng.randn(P_se) * 0.1).astype(np.float32)
+    theta[-1] = -10.0                                   # done-net output bias: the SE never terminates -> full-length episodes
+    eps = (rng.randn(pop, P_se) * 0.05).astype(np.float32)
+    agent_init = rng.uniform(-0.08, 0.08, (chains, P_q)).astype(np.float32)
+    worker = np.repeat(np.arange(pop), 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), pop)
+    keys = np.array([orc.chain_key(1234, 2, int(worker[c]), c % 3) for c in range(chains)], np.uint64)
+
+    def run(team_size):
+        cfg.team_size = team_size
+        il = eng.InnerLoop(cfg, chains, want_final_online=True)
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return [t.cpu().numpy().copy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_online)]
+
+    cfg.team_size = 0
+    assert _lib.lib().lenv_dueling_team_size(C.byref(cfg), chains) == 2
+    team = run(0)
+    assert (team[1][:, 1] == 6000).all() and (team[1][:, 2] == 1000).all()
+    picks = (9, 94)
+    import threading
+    outs = {}
+    th = threading.Thread(target=lambda: outs.update(o=_oracle_chains_parallel(
+        lambda c: orc.ddqn_se_chain(ocfg, (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32), agent_init[c], rng_key=int(keys[c]),
+                                    want_final_online=True),
+        [(c,) for c in picks])))
+    th.start()
+    one = run(1)
+    for a, b in zip(team, one):
+        assert np.array_equal(a, b, equal_nan=True)
+    th.join()
+    for c, o in zip(picks, outs["o"]):
+        assert float(team[0][c]) == o["score"]
+        assert team[1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(team[2][c], o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(team[3][c], o["final_test_returns"])
+        assert np.array_equal(team[4][c], o["final_online"])
 
 
 @pytest.mark.parametrize("budget", [1, 40, 100, 150, 10 ** 6])
@@ -2265,7 +2435,7 @@ def test_wavechain_dueling_kernel_equals_gemm_queue_kernel(eng):
 
 
 @pytest.mark.parametrize("chains", [5, 10])
-def test_wavechain_dueling_team_agrees(eng, chains, monkeypatch):
+def test_wavechain_dueling_team_agrees(eng, chains):
     """The DuelingDDQN wave-chain kernel with a chain on a team of two workgroups (blocks on four waves each, weight gradients dealt by
     layer, four agent-scope barriers per learn step) against the one-workgroup launch and the GEMM-queue kernel: same bits."""
     from learning_environments_amd import configs
@@ -2295,7 +2465,7 @@ def test_wavechain_dueling_team_agrees(eng, chains, monkeypatch):
     ref = run(2)                                            # GEMM-queue kernel
     assert ref[1][:, 2].min() == 60
     for G in (1, 2):
-        monkeypatch.setenv("LENV_DUELING_TEAM", str(G))
+        cfg.team_size = G
         out = run(0)
         for x, y in zip(out, ref):
             assert np.array_equal(x, y, equal_nan=True), G
@@ -2334,7 +2504,7 @@ def test_wavechain_td3_kernel_equals_gemm_queue_kernel(eng, orc):
     assert not np.array_equal(a[4], init)
 
 @pytest.mark.parametrize("chains", [5, 11])
-def test_wavechain_td3_team_sizes_agree(eng, orc, chains, monkeypatch):
+def test_wavechain_td3_team_sizes_agree(eng, orc, chains):
     """A chain run by a team of G = 2, 3, 6 workgroups (sample blocks and gradient tiles dealt over the team, six agent-scope
     barriers per learn step) gives the same bits as the one-workgroup launch (G = 1) and as the GEMM-queue kernel: scores, counters,
     test means and all 59 016 parameters."""
@@ -2363,7 +2533,7 @@ def test_wavechain_td3_team_sizes_agree(eng, orc, chains, monkeypatch):
     ref = run(2)                                            # GEMM-queue kernel
     assert ref[1][:, 2].min() == 60
     for G in (1, 2, 3, 6):
-        monkeypatch.setenv("LENV_TD3_TEAM", str(G))
+        cfg.team_size = G
         out = run(0)
         for x, y in zip(out, ref):
             assert np.array_equal(x, y, equal_nan=True), G

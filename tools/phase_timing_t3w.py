@@ -12,7 +12,10 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "learning_environments_amd", "csrc")
 OUT = "/tmp/liblenv_hip_timing.so"
 srcs = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+if os.environ.get("LENV_TIMING_LIB"):                    # a diagnostic build made elsewhere (tools/build_variant.sh): just load it
+    OUT = os.path.abspath(os.environ["LENV_TIMING_LIB"])
+else:
+  subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
                        "-fPIC", "-shared", "-DLENV_PHASE_TIMING", "-o", OUT] + [a for a in sys.argv[1:] if a.startswith("-D")] +
                       [os.path.join(CSRC, s) for s in srcs])
 from learning_environments_amd import _lib
@@ -46,8 +49,12 @@ for i, n in enumerate(names):
 
 sub = {16: "fwd smalls + W2 image", 17: "fwd L1", 18: "fwd L2 chain", 19: "fwd epilogue + output layer", 20: "fwd final barrier wait",
        24: "bwd output-layer grads (VALU)", 25: "bwd dz2 + W2^T image", 26: "bwd chain (+dX) | gb2", 27: "bwd W2 weight grads (2 halves)",
-       28: "bwd layer-1 grads (2 halves)"}
+       28: "bwd layer-1 grads (2 halves)",
+       30: "split fwd: smalls + W2 image + barrier", 31: "split fwd: L1 + exchange + barrier", 32: "split fwd: L2 tile chain + exchange + barrier",
+       33: "split fwd: output layer (wave 0)", 34: "split fwd: final barrier",
+       35: "split bwd: Wo + W2^T loads + barrier", 36: "split bwd: dz2 + image store + barrier", 37: "split bwd: tile chain + exchange + barrier",
+       38: "split bwd: dX (wave 0)", 39: "split bwd: final barrier"}
 # the sub-phase counters accumulate over both generations and over all calls of a learn step (7 forwards, 4 backwards)
 for i, n in sub.items():
-    calls = 7 if i < 24 else (4 if i in (25, 26) else 3)
+    calls = 7 if (i < 24 or 30 <= i <= 34) else (4 if (i in (25, 26) or i >= 35) else 3)
     print("%-36s %12d  %9.0f per call" % (n, buf[i], buf[i] / max(1, 2 * st[2] * calls)))

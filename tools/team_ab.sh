@@ -1,7 +1,7 @@
 #!/bin/bash
-# A/B of the TD3 wave-chain kernel's team size at BASELINE configs[4]'s shard (24 chains): LENV_TD3_TEAM = 1, 2, 3, 6
+# A/B of the TD3 wave-chain kernel's team size at BASELINE configs[4]'s shard (24 chains): bench.py --team-size 1, 2, 3, 6
 for G in 1 2 3 6; do
-  LENV_TD3_TEAM=$G timeout 300 python bench.py --only-config 4 2>/dev/null | tail -1 > /tmp/team_$G.json
+  timeout 300 python bench.py --only-config 4 --team-size $G 2>/dev/null | tail -1 > /tmp/team_$G.json
   python - $G <<'PY'
 import json, sys
 G = sys.argv[1]

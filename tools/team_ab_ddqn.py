@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Measure (one GPU) what a DDQN chain on a team of workgroups buys at the chain counts the strong-scaling shards of BASELINE
 configs[1] put on a GPU: pop 64 over 2 / 4 / 8 GPUs = 32 / 16 / 8 workers = 96 / 48 / 24 chains.  For each, the generation time
-with one workgroup per chain (LENV_DDQN_TEAM=1) and with the automatic team size.  usage: tools/team_ab_ddqn.py [steps]"""
+with one workgroup per chain (gtn.team_size 1) and with the automatic team size.  usage: tools/team_ab_ddqn.py [steps]"""
 import ctypes as C
 import json
 import os
@@ -18,11 +18,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 for pop in (64, 32, 16, 8):
     row = {"workers_on_this_gpu": pop, "chains": 3 * pop}
     for mode in ("1", "auto"):
-        if mode == "1":
-            os.environ["LENV_DDQN_TEAM"] = "1"
-        else:
-            os.environ.pop("LENV_DDQN_TEAM", None)
-        master, cfgd = bench.build_master(pop)
+        master, cfgd = bench.build_master(pop, team_size=1 if mode == "1" else 0)
         G = _lib.lib().lenv_ddqn_se_team_size(C.byref(master.cfg), 3 * pop)
         master.step(0)
         torch.cuda.synchronize()

@@ -1,7 +1,7 @@
 #!/bin/bash
-# A/B of the DuelingDDQN wave-chain kernel's team size at BASELINE configs[2]'s shard (96 chains): LENV_DUELING_TEAM = 1, 2
+# A/B of the DuelingDDQN wave-chain kernel's team size at BASELINE configs[2]'s shard (96 chains): bench.py --team-size 1, 2
 for G in 1 2; do
-  LENV_DUELING_TEAM=$G timeout 300 python bench.py --only-config 2 2>/dev/null | tail -1 > /tmp/dteam_$G.json
+  timeout 300 python bench.py --only-config 2 --team-size $G 2>/dev/null | tail -1 > /tmp/dteam_$G.json
   python - $G <<'PY'
 import json, sys
 G = sys.argv[1]
