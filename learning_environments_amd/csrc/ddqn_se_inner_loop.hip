@@ -634,8 +634,9 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     __builtin_amdgcn_s_sleep(1);
                     if ((++spins & 63u) == 0u && __builtin_amdgcn_s_memrealtime() - w0 > LENV_TEAM_GIVEUP_TICKS) { gave_up = true; break; }
                 }
-                if (team_same_xcd) asm volatile("buffer_inv sc1" ::: "memory");
-                else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                // (the invalidate has to be complete before the barrier below releases the other waves: vmcnt counts it)
+                if (team_same_xcd) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+                else { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                 if (gave_up) team_bar[15] = 1u;
             }
             __syncthreads();

@@ -923,7 +923,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     int *tlen = reinterpret_cast<int *>(newrow + 16);     // [T]
     WcCtx *ctx = reinterpret_cast<WcCtx *>((reinterpret_cast<uintptr_t>(tlen + T) + 15) & ~(uintptr_t)15);
     volatile float *ctrl = misc;
-    volatile int *ictrl = reinterpret_cast<volatile int *>(misc + 32);
+    volatile __attribute__((address_space(3))) int *ictrl = (volatile __attribute__((address_space(3))) int *)(misc + 32);      // (explicitly LDS, see td3_wavechain.hip)
 
     float *arena = a.arena + chain * a.arena_stride;
     float *online = arena + a.a_par, *target = online + PW, *adam_m = target + PW, *adam_v = adam_m + PW, *grad = adam_v + PW;
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                 for (int i = 0; i < 4; ++i) dstate[tid * 4 + i] = st[i];
                 ep_rew[tid] = ep_rew[tid] + (float)rew;
                 tlen[tid] = tlen[tid] + 1;
-                atomicAdd(const_cast<int *>(&ictrl[0]), 1);
+                atomicAdd(reinterpret_cast<int *>(misc + 32), 1);      // (= ictrl[0])
                 if (dn) alive[tid] = 0;
             }
             __syncthreads();

@@ -56,7 +56,7 @@ __device__ __forceinline__ void barrier_lds()
 // status -10 and the caller repeats it with one workgroup per chain.  Returns through ts.dead (uniform in the workgroup).
 struct TeamSync {
     unsigned *bar, *launch_dead;
-    volatile int *lds_flag;               // one LDS word, zero at kernel start
+    volatile __attribute__((address_space(3))) int *lds_flag;       // one LDS word, zero at kernel start
     unsigned epoch;
     int G;
     bool dead, same_xcd;
@@ -77,16 +77,18 @@ __device__ __forceinline__ void team_barrier(TeamSync &ts, int tid)
         while (__hip_atomic_load(ts.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 63u) == 0u) {          // every 64th poll: has anybody in the launch given up / is it this member's turn to?
-                if (__hip_atomic_load(ts.launch_dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { *ts.lds_flag = 1; break; }
+                if (__hip_atomic_load(ts.launch_dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { *ts.lds_flag = 1; break; }
                 if (__builtin_amdgcn_s_memrealtime() - w0 > LENV_TEAM_GIVEUP_TICKS) {
-                    __hip_atomic_store(ts.launch_dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ts.launch_dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (system scope: past every XCD's L2)
                     *ts.lds_flag = 1;
                     break;
                 }
             }
         }
-        if (ts.same_xcd) asm volatile("buffer_inv sc1" ::: "memory");
-        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // acquire: drop this CU's L1 lines.  The invalidate must have COMPLETED before the workgroup barrier below lets the other waves
+        // load (a buffer_inv only orders the issuing wave's own later loads; its completion is counted by vmcnt)
+        if (ts.same_xcd) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        else { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     }
     __syncthreads();
     if (*ts.lds_flag) ts.dead = true;

@@ -37,7 +37,7 @@ struct T3wArgs {
     lenv_td3_out out;
     int64_t rb_cap; int RS;
     int P, Pa, Pc, P_rn;
-    int64_t a_par, a_xc, a_xn, a_xa, a_th, a_dump, a_replay, a_meter, a_gx, a_bar;
+    int64_t a_par, a_xc, a_xn, a_xa, a_th, a_dump, a_replay, a_meter, a_gx, a_bar, a_w2u;
     int G;                                   // workgroups per chain (team): 1, 2, 3 or 6
     int64_t chains;
 };
@@ -47,6 +47,10 @@ struct T3wCtx {
     float *params, *targets, *grad, *dumps;
     float prelu, ma;
     int g, G;                                // this workgroup's place in its chain's team
+    // the team path (td3_wavechain_team.cuh): unit-major copies of the three online W2, the LDS control block (Adam's bias corrections of
+    // the step at ctrl[20..23]) and the optimizer constants
+    float *w2u, *ctrl;
+    float w1, w2, beta2, aeps, tau, omt;
 };
 
 // state-dict index inside ONE net (mlp_off order: W0 [128 x in] b0 W1 [128 x 128] b1 Wout [out x 128] bout) -> arena-layout index
@@ -91,6 +95,14 @@ __device__ unsigned long long g_t3w_phase_cycles[48];
 #define TPT_MARK(i)
 #define TSUB_DECL
 #define TSUB_MARK(i)
+#endif
+
+#ifdef LENV_PHASE_TIMING_SUB
+#define KSUB_RESET ksub_last = __builtin_readcyclecounter()
+#define KSUB_MARK(i) do { unsigned long long k_now = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) g_t3w_phase_cycles[i] += k_now - ksub_last; ksub_last = k_now; } while (0)
+#else
+#define KSUB_RESET
+#define KSUB_MARK(i)
 #endif
 
 #define T3W_CTX_PROLOGUE                                                                                                                   \
@@ -365,224 +377,6 @@ __device__ __noinline__ void t3w_backward_chain(const T3wCtx *ctx_, const float 
     TSUB_MARK(26);
 }
 
-// ---- split passes: a team member that owns only one or two sample blocks (G = 6 / G = 3) runs each block on FOUR waves -- wave
-// 4 q + jt computes output tile jt (32 units) of its quad's block for every layer and the quad exchanges the operand registers through
-// LDS (bufB: two quads x two stages x 16 KB; the image of the pass is in bufA), so a layer costs one tile's 64 MFMAs per SIMD instead
-// of four.  Same products, same k-ascending chains: the bits do not change.  Single passes only (a dual call needs bufB).
-template <int ACT, int IN, int OUT>
-__device__ __noinline__ void t3w_forward_split(const T3wCtx *ctx_, const float *par_, const float *X_, int ldx_, int mode_, float *q_out_,
-                                               float *Y_, int ldy_, int ocol_, float *th_out_, int d_h1_, int r_h2_)
-{
-    T3W_CTX_PROLOGUE;
-    const float *par = uni_ptr(par_), *X = uni_ptr(X_);
-    float *Y = uni_ptr(Y_), *th_out = uni_ptr(th_out_);
-    lfloat *q_out = (lfloat *)uni_ptr(q_out_);
-    constexpr int in = IN, out = OUT;
-    const int ldx = uni(ldx_), mode = uni(mode_), ldy = uni(ldy_), ocol = uni(ocol_), d_h1 = uni(d_h1_), r_h2 = uni(r_h2_);
-    const int nb = T3W_NB / TG, quad = wave >> 2, jt = wave & 3;
-    const bool active = quad < nb;
-    const int blk = tg * nb + (active ? quad : 0), row = 32 * blk + L.li;
-    float *xch0 = bufB + quad * 4096, *xch1 = bufB + 8192 + quad * 4096;
-    for (int i = tid; i < 2 * W; i += NT) sm_b[i] = par[(i < W ? ob1 : ob2 - W) + i];
-    for (int i = tid; i < 8 * W + 8; i += NT) sm_wo[i] = par[oWo + i];
-    StageRegs sr;
-    TSUB_DECL;
-    float xb[in >> 1], wa[in >> 1];
-    {
-        const gfloat *w1 = (const gfloat *)par + oW1t + L.h * W + 32 * jt + L.li;
-        const gfloat *xr = (const gfloat *)X + row * ldx + L.h;
-#pragma unroll
-        for (int t = 0; t < (in >> 1); ++t) { xb[t] = xr[2 * t]; wa[t] = w1[2 * t * W]; }
-    }
-    stage_load_direct(par + oW2t, L, sr);
-    stage_store_direct(bufA, L, sr);
-    barrier_lds();
-    TSUB_MARK(30);
-    float r16[16], rf[64];
-    f32x16 acc;
-    if (active) {
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
-#pragma unroll
-        for (int t = 0; t < (in >> 1); ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t], xb[t], acc, 0, 0, 0);
-        if (in & 1) {
-            const float xl = ((const gfloat *)X)[row * ldx + in - 1];
-            const gfloat *wl = (const gfloat *)par + oW1t + (in - 1) * W + 32 * jt + 4 * L.h;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 wv = *(const gf4 *)(wl + 8 * g4);
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) acc[4 * g4 + cc] = fma32(xl, wv[cc], acc[4 * g4 + cc]);
-            }
-        }
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 bv = *(const lf4 *)(sm_b + 32 * jt + 8 * g4 + 4 * L.h);
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) r16[4 * g4 + cc] = act_fwd(ACT, prelu, acc[4 * g4 + cc] + bv[cc]);
-        }
-        if (d_h1 >= 0) {
-            gf4 *d = (gf4 *)dump_of(d_h1, blk) + L.lane;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) d[(4 * jt + g4) * 64] = f32x4{r16[4 * g4], r16[4 * g4 + 1], r16[4 * g4 + 2], r16[4 * g4 + 3]};
-        }
-        tile16_to_operand(r16);
-        xch_put(xch0, jt, L.lane, r16);
-    }
-    barrier_lds();
-    TSUB_MARK(31);
-    if (active) {
-        xch_get(xch0, L.lane, rf);
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
-        chain_tile(bufA, jt, L, rf, acc);
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 bv = *(const lf4 *)(sm_b + W + 32 * jt + 8 * g4 + 4 * L.h);
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) r16[4 * g4 + cc] = act_fwd(ACT, prelu, acc[4 * g4 + cc] + bv[cc]);
-        }
-        if (r_h2 >= 0) {
-            gfloat *rm = (gfloat *)dump_of(r_h2, 0) + row * W + 32 * jt + 4 * L.h;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) *(gf4 *)(rm + 8 * g4) = f32x4{r16[4 * g4], r16[4 * g4 + 1], r16[4 * g4 + 2], r16[4 * g4 + 3]};
-        }
-        tile16_to_operand(r16);
-        xch_put(xch1, jt, L.lane, r16);
-    }
-    barrier_lds();
-    TSUB_MARK(32);
-    if (active && jt == 0) {
-        xch_get(xch1, L.lane, rf);
-        f32x16 hacc;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) hacc[v] = 0.0f;
-        const lfloat *wo = sm_wo + L.h * 8 + (L.li < out ? L.li : out - 1);
-#pragma unroll
-        for (int t = 0; t < 64; ++t) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wo[2 * t * 8], rf[breg_of(t)], hacc, 0, 0, 0);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int cidx = 4 * L.h + v;
-            if (cidx < out) {
-                const float z = hacc[v] + sm_bo[cidx];
-                if (mode == 0) q_out[row] = z;
-                else {
-                    const float th = det_tanhf(lenv_tanh_table, z);
-                    if (th_out) th_out[row * out + cidx] = th;
-                    Y[row * ldy + ocol + cidx] = th * ma;
-                }
-            }
-        }
-    }
-    TSUB_MARK(33);
-    __syncthreads();
-    TSUB_MARK(34);
-}
-
-template <int ACT, int IN, int OUT>
-__device__ __noinline__ void t3w_backward_chain_split(const T3wCtx *ctx_, const float *par_, const float *dOut_, int d_h1_, int d_h2_, int r_dz2_,
-                                                      int r_dh1_, int dx_col_, int dx_n_, const float *th_, float *dz_out_)
-{
-    T3W_CTX_PROLOGUE;
-    const float *par = uni_ptr(par_), *th = uni_ptr(th_);
-    const lfloat *dOut = (const lfloat *)uni_ptr(dOut_);
-    lfloat *dz_out = (lfloat *)uni_ptr(dz_out_);
-    constexpr int out = OUT;
-    const int d_h1 = uni(d_h1_), d_h2 = uni(d_h2_), r_dz2 = uni(r_dz2_), r_dh1 = uni(r_dh1_), dx_col = uni(dx_col_), dx_n = uni(dx_n_);
-    const int nb = T3W_NB / TG, quad = wave >> 2, jt = wave & 3;
-    const bool active = quad < nb;
-    const int blk = tg * nb + (active ? quad : 0), row = 32 * blk + L.li;
-    float *xch0 = bufB + quad * 4096, *xch1 = bufB + 8192 + quad * 4096;
-    for (int i = tid; i < 8 * W + 8; i += NT) sm_wo[i] = par[oWo + i];
-    StageRegs sr;
-    TSUB_DECL;
-    stage_load_transposed(par + oW2t, L, sr);
-    __syncthreads();                                       // sm_wo staged
-    TSUB_MARK(35);
-    float r16[16], rf[64];
-    f32x16 acc;
-    if (active) {
-        // dz2 = act'(h2) * (sum_c dOut[i][c] Wo[c][unit], c ascending from 0), the 32 units of tile jt
-        const gfloat *hd = (const gfloat *)dump_of(d_h2, 0) + row * W + 32 * jt + 4 * L.h;
-        float dO[out];
-#pragma unroll
-        for (int cc = 0; cc < out; ++cc) dO[cc] = dOut[row * out + cc];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 hv = *(const gf4 *)(hd + 8 * g4);
-            const lfloat *wp = sm_wo + (32 * jt + 8 * g4 + 4 * L.h) * 8;
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                float wv[8];
-                const f32x4 w0 = *(const lf4 *)(wp + 8 * cc);
-                wv[0] = w0[0]; wv[1] = w0[1]; wv[2] = w0[2]; wv[3] = w0[3];
-                if (out > 4) { const f32x4 w1 = *(const lf4 *)(wp + 8 * cc + 4); wv[4] = w1[0]; wv[5] = w1[1]; wv[6] = w1[2]; wv[7] = w1[3]; }
-                float up = 0.0f;
-#pragma unroll
-                for (int o = 0; o < out; ++o) up = fma32(dO[o], wv[o], up);
-                r16[4 * g4 + cc] = act_bwd(ACT, prelu, hv[cc], up);
-            }
-        }
-        {
-            gfloat *rm = (gfloat *)dump_of(r_dz2, 0) + row * W + 32 * jt + 4 * L.h;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) *(gf4 *)(rm + 8 * g4) = f32x4{r16[4 * g4], r16[4 * g4 + 1], r16[4 * g4 + 2], r16[4 * g4 + 3]};
-        }
-        tile16_to_operand(r16);
-        xch_put(xch0, jt, L.lane, r16);
-    }
-    stage_store_transposed(bufA, L, sr);
-    barrier_lds();
-    TSUB_MARK(36);
-    L.refresh();
-    if (active) {
-        const gf4 *src = (const gf4 *)dump_of(d_h1, blk) + L.lane;
-        f32x4 hv[4];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) hv[g4] = src[(4 * jt + g4) * 64];
-        xch_get(xch0, L.lane, rf);
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
-        chain_tile(bufA, jt, L, rf, acc);
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) r16[4 * g4 + cc] = act_bwd(ACT, prelu, hv[g4][cc], acc[4 * g4 + cc]);
-        if (r_dh1 >= 0) {
-            gfloat *rm = (gfloat *)dump_of(r_dh1, 0) + row * W + 32 * jt + 4 * L.h;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) *(gf4 *)(rm + 8 * g4) = f32x4{r16[4 * g4], r16[4 * g4 + 1], r16[4 * g4 + 2], r16[4 * g4 + 3]};
-        }
-        if (dx_n > 0) {
-            tile16_to_operand(r16);
-            xch_put(xch1, jt, L.lane, r16);
-        }
-    }
-    barrier_lds();
-    TSUB_MARK(37);
-    if (active && jt == 0 && dx_n > 0) {
-        // dX[i][dx_col + c] = sum_u dh1[i][u] W1[u][dx_col + c] (u ascending), c < dx_n, then dz = (dX * max_action) * (1 - th^2)
-        xch_get(xch1, L.lane, rf);
-        f32x16 hacc;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) hacc[v] = 0.0f;
-        const gfloat *w1 = (const gfloat *)par + oW1t + (dx_col + (L.li < dx_n ? L.li : dx_n - 1)) * W + L.h;
-#pragma unroll 16
-        for (int t = 0; t < 64; ++t) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2 * t], rf[breg_of(t)], hacc, 0, 0, 0);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int cidx = 4 * L.h + v;
-            if (cidx < dx_n) {
-                const float t_ = th[row * dx_n + cidx];
-                dz_out[row * dx_n + cidx] = (hacc[v] * ma) * fma32(-t_, t_, 1.0f);
-            }
-        }
-    }
-    TSUB_MARK(38);
-    __syncthreads();
-    TSUB_MARK(39);
-}
-
 // ---- backward of one network, second half: the parameter gradients from the row-major copies of ALL 192 samples (dOut in LDS, h2 /
 // dz2 / dh1 in the arena, the h1 register dumps).  The work is cut by wave -- output-layer gradients (VALU), two W2 tiles per wave,
 // one W1 column tile or one bias vector per wave -- and wave w's share runs in the team's workgroup w * G / 8 ----
@@ -730,6 +524,10 @@ __device__ __noinline__ void t3w_backward_wgrad(const T3wCtx *ctx_, float *gpar_
     TSUB_MARK(28);
 }
 
+}  // namespace lenv
+#include "td3_wavechain_team.cuh"
+namespace lenv {
+
 template <int SHAPE>
 __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
 {
@@ -768,7 +566,9 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     float *dq2 = dd + B;                                  // [B]
     float *h_row = dq2 + B;                               // [2][128] hidden rows of the one-row actor
     float *misc = h_row + 2 * W;                          // [64]
-    double *xs_d = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(misc + 64) + 7) & ~(uintptr_t)7);   // [20] train env state
+    // (alignment by INDEX arithmetic on the LDS base, which is 16-byte aligned: a round trip through an integer would hide from the compiler
+    // that everything carved out behind it is LDS, and every access to it would become a FLAT instruction that waits for all loads in flight)
+    double *xs_d = reinterpret_cast<double *>(lds + (((int)(misc + 64 - lds) + 1) & ~1));   // [20] train env state
     double *xt_d = xs_d + 20;                             // [T][17]
     double *ret = xt_d + 17 * T;                          // [T]
     float *ep_rew = reinterpret_cast<float *>(ret + T);   // [T]
@@ -776,9 +576,11 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     float *state = reinterpret_cast<float *>(tlen + T + 1);   // [20]
     float *action = state + 20;                           // [8]
     float *newrow = action + 8;                           // [56]
-    T3wCtx *ctx = reinterpret_cast<T3wCtx *>((reinterpret_cast<uintptr_t>(newrow + 56) + 15) & ~(uintptr_t)15);
-    volatile float *ctrl = misc;
-    volatile int *ictrl = reinterpret_cast<volatile int *>(misc + 32);
+    T3wCtx *ctx = reinterpret_cast<T3wCtx *>(lds + (((int)(newrow + 56 - lds) + 3) & ~3));
+    // (explicitly LDS: address-space inference leaves volatile accesses alone, and a volatile generic access is a FLAT instruction with
+    // both cache-bypass bits that waits for every load in flight)
+    volatile __attribute__((address_space(3))) float *ctrl = (volatile __attribute__((address_space(3))) float *)misc;
+    volatile __attribute__((address_space(3))) int *ictrl = (volatile __attribute__((address_space(3))) int *)(misc + 32);
     float *dzl = q1;
 
     float *arena = a.arena + chain * a.arena_stride;
@@ -803,10 +605,41 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
             if (p < a.Pa) q = t3w_sd_to_arena(p, S, A);
             else { const int n = (p - a.Pa) / a.Pc; q = (1 + n) * PN + t3w_sd_to_arena(p - a.Pa - n * a.Pc, SA, 1); }
             params[q] = w; targets[q] = w;
+            if (G >= 3) {                                  // team path: the second layers also in unit-major order (W2u[j][k] = W2[j][k])
+                const int net = q / PN, qi = q - net * PN;
+                if (qi >= oW2t && qi < oW2t + IMG) { const int k = (qi - oW2t) >> 7, j = (qi - oW2t) & 127; arena[a.a_w2u + net * IMG + j * W + k] = w; }
+            }
         }
     }
     if (tid < 64) misc[tid] = 0.0f;
-    if (tid == 0) { T3wCtx cx{ bufA, bufB, sm_b, sm_wo, sm_bo, q1, dzl, sm_b2, sm_wo2, params, targets, grad, dumps, prelu, ma, g, G }; *ctx = cx; }
+    // Team path: the stand-in's dynamics constants (A [17][17], B [17][6], c [17] doubles) in LDS -- the small-vector areas of the image
+    // passes are free there -- instead of 23 scattered 8-byte global loads per state word and env step
+    typedef __attribute__((address_space(3))) double ldouble;
+    ldouble *chA = (ldouble *)sm_b, *chB = chA + 17 * 17, *chC = chB + 17 * 6;
+    if (G >= 3) {
+        for (int i = tid; i < 17 * 17; i += NT) chA[i] = lenv_cheetah_A[i];
+        if (tid < 17 * 6) chB[tid] = lenv_cheetah_B[tid];
+        if (tid < 17) chC[tid] = lenv_cheetah_c[tid];
+    }
+    // word i of x' = clip(c + A x + B a, -10, 10): EnvT::step_word with the constants from LDS (same operations in the same order)
+    auto env_step_word = [&](int i, const double *x_, const float *a_) -> double {
+        if (G < 3) return EnvT::step_word(i, x_, a_);
+        const ldouble *x = (const ldouble *)x_;
+        const lfloat *av = (const lfloat *)a_;
+        double acc = chC[i];
+#pragma unroll
+        for (int j = 0; j < 17; ++j) acc = acc + chA[i * 17 + j] * x[j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc = acc + chB[i * 6 + k] * (double)av[k];
+        return acc < -10.0 ? -10.0 : (acc > 10.0 ? 10.0 : acc);
+    };
+    float *w2u = arena + a.a_w2u;
+    if (tid == 0) {
+        T3wCtx cx{ bufA, bufB, sm_b, sm_wo, sm_bo, q1, dzl, sm_b2, sm_wo2, params, targets, grad, dumps, prelu, ma, g, G, w2u, misc,
+                   (float)(1.0 - cfg.adam_beta1), (float)(1.0 - cfg.adam_beta2), (float)cfg.adam_beta2, (float)cfg.adam_eps, (float)cfg.tau,
+                   (float)(1.0 - cfg.tau) };
+        *ctx = cx;
+    }
     __syncthreads();
 
     const uint64_t key = a.rng_keys[chain];
@@ -827,7 +660,17 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     // sample block of row b -> does it belong to this member (blocks are dealt like the waves that own them)
     auto my_row = [&](int b) { return G == 1 || ((b >> 5) * G) / T3W_NB == g; };
     if (G > 1 && tid == 0) reinterpret_cast<unsigned *>(gdz)[g] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
+#ifdef LENV_DIAG_TEAM_TIMES
+    // diagnostic build: when did this member start / pass the first barrier / leave (ms since the reset kernel), into final_params
+    const unsigned long long dg_t0 = *reinterpret_cast<const unsigned long long *>(a.arena + a.a_bar + 10);
+    auto dg_stamp = [&](int i) { if (tid == 0 && a.out.final_params) a.out.final_params[chain * a.P + 8 * g + i] = (float)((double)(__builtin_amdgcn_s_memrealtime() - dg_t0) * 1e-5); };
+    dg_stamp(0);
+    if (tid == 0 && a.out.final_params) a.out.final_params[chain * a.P + 8 * g + 3] = (float)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u);
+#endif
     team_barrier();                                        // the arena is initialised, every member's XCD id is posted
+#ifdef LENV_DIAG_TEAM_TIMES
+    dg_stamp(1);
+#endif
     if (G > 1) {
         // are all members on one XCD (the block-to-XCD round robin the index mapping above counts on)?  The same answer in every member.
         bool same = true;
@@ -838,6 +681,9 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     }
     if (team_dead) {                                       // not all members became resident in time: nothing was computed
         if (a.out.status) atomicMin(&a.out.status[chain], -10);
+#ifdef LENV_DIAG_TEAM_TIMES
+        dg_stamp(2);
+#endif
         return;
     }
     TPT_DECL;
@@ -849,8 +695,81 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
 
     // ---- the actor on ONE row (TD3.select_train_action / select_test_action): thread j owns unit j, k-ascending fmaf chains over the
     // K-major arrays (coalesced across the threads) ----
-    auto actor_row1 = [&](const float *x, float *out) {
-        const float *par = params;
+    // Team path: between two learn steps a member's big LDS buffers are idle, so the actor's weights live there (W2t [128][128] in bufB,
+    // W1t / b1 / b2 / Wo / bo at the head of bufA): act_lds_load() after every actor update, and the one-row forward of the env and test steps
+    // -- every member repeats it -- reads LDS instead of fetching 73 KB through the L2 three dependent batches deep (21 k -> 6 k
+    // cycles per test step).  Same k-ascending chains.
+    constexpr int aL_b1 = S * W, aL_b2 = aL_b1 + W, aL_wo = aL_b2 + W, aL_bo = aL_wo + 8 * W;
+    auto act_lds_load = [&]() {
+        const gf4 *s2 = (const gf4 *)(params + oW2t);
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = s2[tid + u * NT];
+        const gf4 *s1 = (const gf4 *)(params + oW1t), *sb1 = (const gf4 *)(params + ob1), *sb2 = (const gf4 *)(params + ob2), *so = (const gf4 *)(params + oWo);
+        lf4 *d = (lf4 *)bufA;
+        for (int i = tid; i < S * W / 4; i += NT) d[i] = s1[i];
+        if (tid < W / 4) { d[aL_b1 / 4 + tid] = sb1[tid]; d[aL_b2 / 4 + tid] = sb2[tid]; }
+        for (int i = tid; i < (8 * W + 8) / 4; i += NT) d[aL_wo / 4 + i] = so[i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ((lf4 *)bufB)[tid + u * NT] = v[u];
+        __syncthreads();
+    };
+    // nz_stream != 0: the A standard normals this step's exploration noise needs (det_normal(key, nz_stream, nz_base + c): ~4 k cycles of
+    // fp64 polynomials on six lanes) are drawn by the last wave WHILE the first two run the layers, into nzl[0..A)
+    lfloat *nzl = (lfloat *)(misc + 48);
+    auto actor_row1_lds = [&](const float *x_, float *out_, uint32_t nz_stream, int64_t nz_base) {
+        const lfloat *x = (const lfloat *)x_, *A1 = (const lfloat *)bufA, *A2 = (const lfloat *)bufB;
+        lfloat *hr = (lfloat *)h_row, *out = (lfloat *)out_;
+        if (nz_stream != 0 && tid >= NT - 64 && tid < NT - 64 + A) nzl[tid - (NT - 64)] = (float)det_normal(key, nz_stream, (uint64_t)(nz_base + (tid - (NT - 64))));
+        // (all the LDS reads of a 32-term piece are requested before its fmaf chain starts: written term by term the compiler issues
+        // read, wait, fmaf -- one LDS round trip per term, 15 k cycles per call)
+        if (tid < W) {
+            float w[S], xv[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k) { w[k] = A1[k * W + tid]; xv[k] = x[k]; }
+            float z = 0.0f;
+#pragma unroll
+            for (int k = 0; k < S; ++k) z = fma32(xv[k], w[k], z);
+            hr[tid] = act_fwd(ACT, prelu, z + A1[aL_b1 + tid]);
+        }
+        __syncthreads();
+        if (tid < W) {
+            float z = 0.0f;
+#pragma unroll 1
+            for (int k0 = 0; k0 < W; k0 += 32) {
+                float w[32];
+                f32x4 h4[8];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) w[u] = A2[(k0 + u) * W + tid];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) h4[u] = *(const lf4 *)(hr + k0 + 4 * u);
+#pragma unroll
+                for (int u = 0; u < 32; ++u) z = fma32(h4[u >> 2][u & 3], w[u], z);
+            }
+            hr[W + tid] = act_fwd(ACT, prelu, z + A1[aL_b2 + tid]);
+        }
+        __syncthreads();
+        if (tid < A) {
+            float z = 0.0f;
+#pragma unroll 1
+            for (int k0 = 0; k0 < W; k0 += 32) {
+                float w[32];
+                f32x4 h4[8];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) w[u] = A1[aL_wo + (k0 + u) * 8 + tid];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) h4[u] = *(const lf4 *)(hr + W + k0 + 4 * u);
+#pragma unroll
+                for (int u = 0; u < 32; ++u) z = fma32(h4[u >> 2][u & 3], w[u], z);
+            }
+            out[tid] = det_tanhf(lenv_tanh_table, z + A1[aL_bo + tid]) * ma;
+        }
+        __syncthreads();
+    };
+    auto actor_row1 = [&](const float *x, float *out, uint32_t nz_stream, int64_t nz_base) {
+        if (G >= 3) { actor_row1_lds(x, out, nz_stream, nz_base); return; }
+        if (nz_stream != 0 && tid >= NT - 64 && tid < NT - 64 + A) nzl[tid - (NT - 64)] = (float)det_normal(key, nz_stream, (uint64_t)(nz_base + (tid - (NT - 64))));
+        const gfloat *par = (const gfloat *)params;
         if (tid < W) {
             float w[S];
 #pragma unroll
@@ -919,14 +838,26 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         __syncthreads();
         const float *Wo = b0 + Hrn, *bo = Wo + Hrn;
         if (tid == 0) {
+            // (the reads of a 32-term piece are all requested before its fmaf chain starts; term by term they cost one LDS round trip each)
+            const lfloat *hl = (const lfloat *)rn_h, *wl = (const lfloat *)Wo;
             float acc = 0.0f;
-            for (int j = 0; j < Hrn; ++j) acc = fma32(rn_h[j], Wo[j], acc);
+#pragma unroll 1
+            for (int j0 = 0; j0 < Hrn; j0 += 32) {
+                f32x4 h4[8], w4[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { h4[u] = *(const lf4 *)(hl + j0 + 4 * u); w4[u] = *(const lf4 *)(wl + j0 + 4 * u); }
+#pragma unroll
+                for (int u = 0; u < 32; ++u) acc = fma32(h4[u >> 2][u & 3], w4[u >> 2][u & 3], acc);
+            }
             ctrl[slot] = acc + bo[0];
         }
         __syncthreads();
     };
 
     // ---- real-env test phase (BaseAgent.test): ONE episode, actions from the one-row actor + exploration noise (TD3.py:126-129) ----
+#ifdef LENV_PHASE_TIMING_SUB
+    unsigned long long ksub_last = 0;
+#endif
     auto test_phase = [&]() {
         const int64_t nstride = cfg.max_steps;
         for (int e = tid; e < SD; e += NT) xt_d[e] = EnvT::reset_word(key, STREAM_TEST_RESET, n_test_ep, e);
@@ -937,18 +868,21 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         xt = newrow;                                       // [S] observation
         float *at = newrow + 24;                           // [A] action
         for (int ai = 0; ai < cfg.max_steps; ++ai) {
+            KSUB_RESET;
             if (tid < S) xt[tid] = EnvT::obs(tid, xt_d);
             __syncthreads();
-            actor_row1(xt, at);
+            KSUB_MARK(12);
+            actor_row1(xt, at, STREAM_TD3_TEST_NOISE, (n_testn + ai) * A);
+            KSUB_MARK(13);
             if (tid < A) {
-                const int64_t n = (n_testn + ai) * A + tid;
-                const float zn = (float)det_normal(key, STREAM_TD3_TEST_NOISE, (uint64_t)n);
+                const float zn = nzl[tid];
                 const float v = at[tid] + (zn * (float)cfg.action_std) * ma;
                 at[tid] = v < -ma ? -ma : (v > ma ? ma : v);
             }
             __syncthreads();
+            KSUB_MARK(14);
             double nx = 0.0, pre = 0.0;
-            if (tid < SD) nx = EnvT::step_word(tid, xt_d, at);
+            if (tid < SD) nx = env_step_word(tid, xt_d, at);
             if (tid == 0) pre = EnvT::reward_pre(xt_d, at);
             __syncthreads();
             if (tid < SD) xt_d[tid] = nx;
@@ -956,6 +890,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
             if (tid == 0) ep_rew[0] = ep_rew[0] + (float)(0.0 + EnvT::reward_post(xt_d, pre));
             ++my_el;
             __syncthreads();
+            KSUB_MARK(15);
         }
         if (tid == 0) { ret[0] = (double)ep_rew[0]; tlen[0] = my_el; }
         n_test_ep += 1;
@@ -966,6 +901,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
 
     const bool budgeted = cfg.step_budget > 0;
     int timed_out_at = -1;
+    if (G >= 3) act_lds_load();                            // the fresh actor
     for (int episode = 0; episode < cfg.train_episodes; ++episode) {
         if (budgeted && (int64_t)train_steps + test_steps > cfg.step_budget) { timed_out_at = episode; break; }
         const bool learning = episode >= cfg.init_episodes;
@@ -983,9 +919,9 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 ++n_rand;
                 __syncthreads();
             } else {
-                actor_row1(state, action);
+                actor_row1(state, action, STREAM_TD3_ACT_NOISE, n_actn * A);
                 if (tid < A) {
-                    const float zn = (float)det_normal(key, STREAM_TD3_ACT_NOISE, (uint64_t)(n_actn * A + tid));
+                    const float zn = nzl[tid];
                     const float v = action[tid] + (zn * (float)cfg.action_std) * ma;
                     action[tid] = v < -ma ? -ma : (v > ma ? ma : v);
                 }
@@ -997,7 +933,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
             if (tid >= 64 && tid < 64 + A) newrow[S + tid - 64] = action[tid - 64];
             {
                 double nx = 0.0, pre = 0.0;
-                if (tid < SD) nx = EnvT::step_word(tid, xs_d, action);
+                if (tid < SD) nx = env_step_word(tid, xs_d, action);
                 if (tid == 64) pre = EnvT::reward_pre(xs_d, action);
                 __syncthreads();
                 if (tid < SD) xs_d[tid] = nx;
@@ -1050,9 +986,91 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 }
                 __syncthreads();
                 TPT_MARK(1);
+                if (G >= 3) {
+                    // ================= a member with one or two sample blocks: the team path (td3_wavechain_team.cuh) =================
+                    if (tid == 0) {                        // torch.optim.Adam's bias corrections of this step's two optimizer steps
+                        pows[0] *= cfg.adam_beta1; pows[1] *= cfg.adam_beta2; pows[2] *= cfg.adam_beta1; pows[3] *= cfg.adam_beta2;
+                        ctrl[20] = (float)(-(cfg.lr / (1.0 - pows[0]))); ctrl[21] = (float)__builtin_sqrt(1.0 - pows[1]);      // (12, 13: the reward net's phi values)
+                        ctrl[22] = (float)(-(cfg.lr / (1.0 - pows[2]))); ctrl[23] = (float)__builtin_sqrt(1.0 - pows[3]);
+                    }
+                    // next_actions = (actor_target(s') + clamp(randn * policy_std)).clamp(-max, max) -- and, on the second quad, the policy
+                    // step's actor(states) (TD3.py:97: the actor is not touched by the critic update, so its forward can run here, next to
+                    // the target actor's, instead of alone after the critics' optimizer step)
+                    for (int e = tid; e < gbn * S; e += NT) { const int b = gb0 + e / S, i = e - (b - gb0) * S; xa[b * SA + i] = xc[b * SA + i]; }
+                    t3v_forward<ACT, S, A>(ctx, 2, SA, 1, targets, xn, nullptr, -1, -1, params, xc, nullptr, TD_A_H1, TR_A_H2, xn, nullptr, xa, thb, SA, S);
+                    for (int e = tid; e < gbn * A; e += NT) {
+                        const int b = gb0 + e / A, k = e - (b - gb0) * A;
+                        const int64_t n = (learn_it * B + b) * A + k;
+                        const float zn = (float)det_normal(key, STREAM_TD3_POLICY_NOISE, (uint64_t)n);
+                        float nz = zn * (float)cfg.policy_std;
+                        const float clipv = (float)cfg.policy_std_clip;
+                        nz = nz < -clipv ? -clipv : (nz > clipv ? clipv : nz);
+                        const float v = xn[b * SA + S + k] + nz;
+                        xn[b * SA + S + k] = v < -ma ? -ma : (v > ma ? ma : v);
+                    }
+                    __syncthreads();
+                    TPT_MARK(2);
+                    // the twin target critics side by side on the two quads, then the twin critics
+                    t3v_forward<ACT, SA, 1>(ctx, 2, SA, 0, targets + PN, xn, tq1, -1, -1, targets + 2 * PN, xn, tq2, -1, -1, nullptr, nullptr, nullptr, nullptr, 0, 0);
+                    t3v_forward<ACT, SA, 1>(ctx, 2, SA, 0, params + PN, xc, q1, TD_C1_H1, TR_C1_H2, params + 2 * PN, xc, q2, TD_C2_H1, TR_C2_H2, nullptr, nullptr,
+                                            nullptr, nullptr, 0, 0);
+                    TPT_MARK(3);
+                    {
+                        const float norm = (float)(2.0 / (double)B);
+                        for (int b = gb0 + tid; b < gb0 + gbn; b += NT) {
+                            const float tq = tq1[b] < tq2[b] ? tq1[b] : tq2[b];
+                            const float y = rr[b] + ((1.0f - dd[b]) * g32) * tq;
+                            dq1[b] = norm * (q1[b] - y);
+                            dq2[b] = norm * (q2[b] - y);
+                            gdq[b] = dq1[b]; gdq[B + b] = dq2[b];      // the weight gradients need every row's value
+                        }
+                    }
+                    __syncthreads();
+                    TPT_MARK(4);
+                    // per-sample halves of the two critic backwards, side by side; then -- once the whole team is there -- the parameter
+                    // gradients + the critic optimizer step as wave jobs over the team
+                    t3v_backward<ACT, SA, 1>(ctx, 2, params + PN, w2u + IMG, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1,
+                                             params + 2 * PN, w2u + 2 * IMG, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
+                    team_barrier();
+                    for (int b = tid; b < B; b += NT) { dq1[b] = gdq[b]; dq2[b] = gdq[B + b]; }
+                    __syncthreads();
+                    {
+                        const T3vNet n1{ params + PN, w2u + IMG, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1 };
+                        const T3vNet n2{ params + 2 * PN, w2u + 2 * IMG, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B };
+                        t3v_wgrad<ACT, SA, 1>(ctx, 2, n1, n2, xc, SA, 20);                 // critic_optimizer (+ Polyak of the two critics)
+                    }
+                    TPT_MARK(5);
+                    ++learn_it;
+                    // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1 (policy_delay 1); actor(states) is in
+                    // xa since the start of the step
+                    team_barrier();
+                    TPT_MARK(6);
+                    t3v_forward<ACT, SA, 1>(ctx, 1, SA, 0, params + PN, xa, dq2, TD_C1_H1, TR_C1_H2, params + PN, xa, dq2, -1, -1, nullptr, nullptr, nullptr, nullptr,
+                                            0, 0);
+                    {
+                        const float dqa = -(1.0f / (float)B);
+                        for (int b = tid; b < B; b += NT) dq1[b] = dqa;
+                    }
+                    __syncthreads();
+                    t3v_backward<ACT, SA, 1>(ctx, 1, params + PN, w2u + IMG, dq1, TD_C1_H1, TR_C1_H2, -1, -1,
+                                             params + PN, w2u + IMG, dq1, TD_C1_H1, TR_C1_H2, -1, -1, S, A, thb, dzl);
+                    for (int e = tid; e < gbn * A; e += NT) gdz[gb0 * A + e] = dzl[gb0 * A + e];
+                    t3v_backward<ACT, S, A>(ctx, 1, params, w2u, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B,
+                                            params, w2u, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
+                    team_barrier();
+                    for (int e = tid; e < B * A; e += NT) dzl[e] = gdz[e];
+                    __syncthreads();
+                    {
+                        const T3vNet na{ params, w2u, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B };
+                        t3v_wgrad<ACT, S, A>(ctx, 1, na, na, xc, SA, 22);                  // actor_optimizer (+ Polyak of the actor)
+                    }
+                    TPT_MARK(7);
+                    team_barrier();
+                    act_lds_load();                        // the updated actor, for the next env steps / the test episode
+                    TPT_MARK(8);
+                } else {
                 // next_actions = (actor_target(s') + clamp(randn * policy_std)).clamp(-max, max)
-                if (G >= 3) t3w_forward_split<ACT, S, A>(ctx, targets, xn, SA, 1, nullptr, xn, SA, S, nullptr, -1, -1);
-                else t3w_forward<ACT, S, A>(ctx, targets, xn, SA, 1, nullptr, xn, SA, S, nullptr, -1, -1, -1);
+                t3w_forward<ACT, S, A>(ctx, targets, xn, SA, 1, nullptr, xn, SA, S, nullptr, -1, -1, -1);
                 for (int e = tid; e < B * A; e += NT) {
                     const int b = e / A, k = e - b * A;
                     if (!my_row(b)) continue;
@@ -1066,12 +1084,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 }
                 __syncthreads();
                 TPT_MARK(2);
-                if (G >= 3) {                              // one or two blocks per member: every block on four waves, pass after pass
-                    t3w_forward_split<ACT, SA, 1>(ctx, targets + PN, xn, SA, 0, tq1, nullptr, 0, 0, nullptr, -1, -1);
-                    t3w_forward_split<ACT, SA, 1>(ctx, targets + 2 * PN, xn, SA, 0, tq2, nullptr, 0, 0, nullptr, -1, -1);
-                    t3w_forward_split<ACT, SA, 1>(ctx, params + PN, xc, SA, 0, q1, nullptr, 0, 0, nullptr, TD_C1_H1, TR_C1_H2);
-                    t3w_forward_split<ACT, SA, 1>(ctx, params + 2 * PN, xc, SA, 0, q2, nullptr, 0, 0, nullptr, TD_C2_H1, TR_C2_H2);
-                } else {
+                {
                     // three blocks per member (G = 2): twin critics side by side on six waves; one workgroup per chain: the twelve
                     // block-passes of the twin critics on eight waves, three per SIMD
                     t3w_forward<ACT, SA, 1>(ctx, targets + PN, xn, SA, 0, tq1, nullptr, 0, 0, nullptr, -1, -1, -1, targets + 2 * PN, xn, tq2, -1, -1);
@@ -1094,11 +1107,8 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 TPT_MARK(4);
                 // per-sample halves of the two critic backwards (this member's blocks), then -- once the whole team is there -- the
                 // parameter gradients, cut by wave over the team
-                if (G >= 3) {
-                    t3w_backward_chain_split<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1, 0, 0, nullptr, nullptr);
-                    t3w_backward_chain_split<ACT, SA, 1>(ctx, params + 2 * PN, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
-                } else                                     // G = 2 and one workgroup per chain: the twin critics' chains side by side
-                    t3w_backward_chain<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1, 0, 0, nullptr, nullptr,
+                // G = 2 and one workgroup per chain: the twin critics' chains side by side
+                t3w_backward_chain<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1, 0, 0, nullptr, nullptr,
                                                    params + 2 * PN, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B);
                 team_barrier();
                 if (G > 1) {
@@ -1117,23 +1127,16 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                     // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1 (policy_delay 1)
                     for (int e = tid; e < gbn * S; e += NT) { const int b = gb0 + e / S, i = e - (b - gb0) * S; xa[b * SA + i] = xc[b * SA + i]; }
                     __syncthreads();
-                    if (G >= 3) {
-                        t3w_forward_split<ACT, S, A>(ctx, params, xc, SA, 1, nullptr, xa, SA, S, thb, TD_A_H1, TR_A_H2);
-                        t3w_forward_split<ACT, SA, 1>(ctx, params + PN, xa, SA, 0, dq2, nullptr, 0, 0, nullptr, TD_C1_H1, TR_C1_H2);
-                    } else {
-                        t3w_forward<ACT, S, A>(ctx, params, xc, SA, 1, nullptr, xa, SA, S, thb, TD_A_H1, TD_A_H2, TR_A_H2);
-                        t3w_forward<ACT, SA, 1>(ctx, params + PN, xa, SA, 0, dq2, nullptr, 0, 0, nullptr, TD_C1_H1, -1, TR_C1_H2);
-                    }
+                    t3w_forward<ACT, S, A>(ctx, params, xc, SA, 1, nullptr, xa, SA, S, thb, TD_A_H1, TD_A_H2, TR_A_H2);
+                    t3w_forward<ACT, SA, 1>(ctx, params + PN, xa, SA, 0, dq2, nullptr, 0, 0, nullptr, TD_C1_H1, -1, TR_C1_H2);
                     const float dqa = -(1.0f / (float)B);
                     for (int b = tid; b < B; b += NT) dq1[b] = dqa;
                     __syncthreads();
-                    if (G >= 3) t3w_backward_chain_split<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, -1, S, A, thb, dzl);
-                    else t3w_backward_chain<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, -1, S, A, thb, dzl);
+                    t3w_backward_chain<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, -1, S, A, thb, dzl);
                     if (G > 1) {
                         for (int e = tid; e < B * A; e += NT) if (my_row(e / A)) gdz[e] = dzl[e];
                     }
-                    if (G >= 3) t3w_backward_chain_split<ACT, S, A>(ctx, params, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
-                    else t3w_backward_chain<ACT, S, A>(ctx, params, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
+                    t3w_backward_chain<ACT, S, A>(ctx, params, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
                     team_barrier();
                     if (G > 1) {
                         for (int e = tid; e < B * A; e += NT) dzl[e] = gdz[e];
@@ -1145,6 +1148,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                     adam(0, PN, 2);
                     team_barrier();
                     TPT_MARK(8);
+                }
                 }
                 if (team_dead) break;                      // (uniform in the workgroup) the team gave up: leave, status -10
             }
@@ -1258,6 +1262,7 @@ static void t3w_offsets(const lenv_td3_cfg *cfg, int64_t rb_cap, int RS, T3wArgs
     a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
     a.a_gx = take(2 * (int64_t)B + (int64_t)B * 6);             // team exchange: dq1 | dq2 | dz
     a.a_bar = take(16);                                          // team barrier counter (one cache line of its own would be 32 floats; the slot is padded below)
+    a.a_w2u = take(3 * (int64_t)wc::IMG);                        // team path: unit-major copies W2u[j][k] of the three online second layers
     *total = (off + 63) & ~(int64_t)63;
 }
 
@@ -1267,6 +1272,9 @@ __global__ void t3w_team_reset_kernel(float *arena, int64_t arena_stride, int64_
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < chains) { unsigned *b = reinterpret_cast<unsigned *>(arena + c * arena_stride + a_bar); b[0] = 0u; b[8] = 0u; }
+#ifdef LENV_DIAG_TEAM_TIMES
+    if (c == 0) *reinterpret_cast<unsigned long long *>(arena + a_bar + 10) = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 }
 
@@ -1329,6 +1337,12 @@ int lenv_wc_td3_launch(const lenv_td3_cfg *cfg, const float *theta, const float 
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }
 
+#ifdef LENV_PHASE_TIMING_SUB
+extern "C" int lenv_debug_t3v_jobs(unsigned long long *host_out)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_t3v_jobs), sizeof(unsigned long long) * 20) == hipSuccess ? 0 : -4;
+}
+#endif
 #ifdef LENV_PHASE_TIMING
 extern "C" int lenv_debug_t3w_phase_cycles(unsigned long long *host_out)
 {

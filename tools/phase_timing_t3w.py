@@ -50,11 +50,24 @@ for i, n in enumerate(names):
 sub = {16: "fwd smalls + W2 image", 17: "fwd L1", 18: "fwd L2 chain", 19: "fwd epilogue + output layer", 20: "fwd final barrier wait",
        24: "bwd output-layer grads (VALU)", 25: "bwd dz2 + W2^T image", 26: "bwd chain (+dX) | gb2", 27: "bwd W2 weight grads (2 halves)",
        28: "bwd layer-1 grads (2 halves)",
-       30: "split fwd: smalls + W2 image + barrier", 31: "split fwd: L1 + exchange + barrier", 32: "split fwd: L2 tile chain + exchange + barrier",
-       33: "split fwd: output layer (wave 0)", 34: "split fwd: final barrier",
-       35: "split bwd: Wo + W2^T loads + barrier", 36: "split bwd: dz2 + image store + barrier", 37: "split bwd: tile chain + exchange + barrier",
-       38: "split bwd: dX (wave 0)", 39: "split bwd: final barrier"}
+       30: "team fwd: weights + L1 + exchange + barrier", 31: "team fwd: L2 chain + exchange + barrier", 32: "team fwd: output layer (16x16x4)",
+       33: "team fwd: final barrier", 35: "team bwd: weights + dz2 + exchange + barrier", 36: "team bwd: chain + exchange + barrier",
+       37: "team bwd: dX", 38: "team bwd: final barrier", 40: "team wgrad+adam jobs (wave 0)", 41: "team wgrad: final barrier",
+       42: "  fwd detail: entry -> all weight loads back", 43: "  fwd detail: L1 + epilogue + put", 44: "  fwd detail: get + L2 chain drained", 45: "  fwd detail: epilogue + h2 store + put"}
 # the sub-phase counters accumulate over both generations and over all calls of a learn step (7 forwards, 4 backwards)
 for i, n in sub.items():
-    calls = 7 if (i < 24 or 30 <= i <= 34) else (4 if (i in (25, 26) or i >= 35) else 3)
+    calls = 5 if (30 <= i <= 34 or 42 <= i <= 45) else (3 if 35 <= i <= 39 else (2 if i >= 40 else (7 if i < 24 else (4 if i in (25, 26) else 3))))
     print("%-36s %12d  %9.0f per call" % (n, buf[i], buf[i] / max(1, 2 * st[2] * calls)))
+
+if hasattr(_lib.lib(), "lenv_debug_t3v_jobs"):
+    jb = (C.c_ulonglong * 20)()
+    _lib.lib().lenv_debug_t3v_jobs.argtypes = [C.POINTER(C.c_ulonglong)]
+    if _lib.lib().lenv_debug_t3v_jobs(jb) == 0:
+        for ph, pn in enumerate(("critics", "actor")):
+            for cl, cn in enumerate(("W2 tile job (chain + optimizer epilogue)", "W1 tile job", "bias job", "output-layer job", "  tile chain alone")):
+                sm, ct = jb[(ph * 5 + cl) * 2], jb[(ph * 5 + cl) * 2 + 1]
+                print("wgrad %-8s %-44s %9.0f cycles per job (%d jobs)" % (pn, cn, sm / max(1, ct), ct))
+
+for i, n in ((12, "test step: obs"), (13, "test step: one-row actor"), (14, "test step: action noise (det_normal) + clamp"), (15, "test step: env dynamics + reward")):
+    if buf[i] and not buf[0]:
+        print("%-44s %9.0f cycles per test step" % (n, buf[i] / max(1, 2 * st[3])))
