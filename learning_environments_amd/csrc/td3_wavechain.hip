@@ -699,28 +699,70 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     // W1t / b1 / b2 / Wo / bo at the head of bufA): act_lds_load() after every actor update, and the one-row forward of the env and test steps
     // -- every member repeats it -- reads LDS instead of fetching 73 KB through the L2 three dependent batches deep (21 k -> 6 k
     // cycles per test step).  Same k-ascending chains.
-    constexpr int aL_b1 = S * W, aL_b2 = aL_b1 + W, aL_wo = aL_b2 + W, aL_bo = aL_wo + 8 * W;
+    // LDS layout: W1t [S][128] | b1 | b2 | Wo^T [8][132] | bo at the head of bufA; W2 UNIT-major [128][132] (row = unit, k contiguous, rows
+    // padded to 132 floats: a lane reads four terms per 16-byte LDS instruction) in the last 512 floats of bufA + all of bufB
+#ifdef LENV_PHASE_TIMING_SUB
+    unsigned long long ksub_last = 0;
+#endif
+    constexpr int aL_b1 = S * W, aL_b2 = aL_b1 + W, aL_wo = aL_b2 + W, aL_bo = aL_wo + 8 * 132, aL_w2 = IMG - 512, aLD = 132;
     auto act_lds_load = [&]() {
-        const gf4 *s2 = (const gf4 *)(params + oW2t);
+        const gf4 *s2 = (const gf4 *)w2u;                  // the actor's unit-major copy W2u[j][k] (kept by the optimizer epilogue)
         f32x4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = s2[tid + u * NT];
-        const gf4 *s1 = (const gf4 *)(params + oW1t), *sb1 = (const gf4 *)(params + ob1), *sb2 = (const gf4 *)(params + ob2), *so = (const gf4 *)(params + oWo);
+        const gf4 *s1 = (const gf4 *)(params + oW1t), *sb1 = (const gf4 *)(params + ob1), *sb2 = (const gf4 *)(params + ob2);
         lf4 *d = (lf4 *)bufA;
+        lfloat *df = (lfloat *)bufA;
         for (int i = tid; i < S * W / 4; i += NT) d[i] = s1[i];
         if (tid < W / 4) { d[aL_b1 / 4 + tid] = sb1[tid]; d[aL_b2 / 4 + tid] = sb2[tid]; }
-        for (int i = tid; i < (8 * W + 8) / 4; i += NT) d[aL_wo / 4 + i] = so[i];
+        for (int i = tid; i < 8 * W; i += NT) df[aL_wo + (i & 7) * aLD + (i >> 3)] = ((const gfloat *)params)[oWo + i];      // Wo[k][c] -> [c][k]
+        if (tid < 8) df[aL_bo + tid] = ((const gfloat *)params)[obo + tid];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) ((lf4 *)bufB)[tid + u * NT] = v[u];
+        for (int u = 0; u < 8; ++u) {
+            const int idx = tid + u * NT, j = idx >> 5, k4 = (idx & 31) << 2;
+            *(lf4 *)(df + aL_w2 + j * aLD + k4) = v[u];
+        }
         __syncthreads();
     };
-    // nz_stream != 0: the A standard normals this step's exploration noise needs (det_normal(key, nz_stream, nz_base + c): ~4 k cycles of
-    // fp64 polynomials on six lanes) are drawn by the last wave WHILE the first two run the layers, into nzl[0..A)
-    lfloat *nzl = (lfloat *)(misc + 48);
-    auto actor_row1_lds = [&](const float *x_, float *out_, uint32_t nz_stream, int64_t nz_base) {
-        const lfloat *x = (const lfloat *)x_, *A1 = (const lfloat *)bufA, *A2 = (const lfloat *)bufB;
+    // Exploration noise of the env / test steps: A standard normals per step (det_normal: ~4 k cycles of fp64 polynomials, on six lanes
+    // when drawn step by step).  The team path draws them 64 steps at a time with all 512 threads (one value each) into an LDS batch
+    // behind the dynamics constants: same values, a sixty-fourth of the time on the serial path.
+    lfloat *nzb = (lfloat *)(sm_b + 832);                  // [64][A]
+    uint32_t nz_cur = 0;
+    int64_t nz_step0 = 0;
+    auto step_noise = [&](uint32_t stream, int64_t step) -> float {      // value of lane tid < A; every thread calls (uniform refill)
+        if (G < 3) return tid < A ? (float)det_normal(key, stream, (uint64_t)(step * A + tid)) : 0.0f;
+        if (nz_cur != stream || step < nz_step0 || step >= nz_step0 + 64) {
+            __syncthreads();
+            for (int e = tid; e < 64 * A; e += NT) nzb[e] = (float)det_normal(key, stream, (uint64_t)(step * A + e));
+            nz_cur = stream; nz_step0 = step;
+            __syncthreads();
+        }
+        return tid < A ? nzb[(int)(step - nz_step0) * A + tid] : 0.0f;
+    };
+    // sum_k h[k] * w[k], k = 0..127 ascending in one fmaf chain from 0; both vectors in LDS; the 16-byte reads of the next 32 terms are
+    // in flight while the current 32 are chained (the chain itself is ~8 cycles per term)
+    auto row_chain = [&](const lfloat *wrow, const lfloat *hv) -> float {
+        f32x4 w4[8], h4[8], w4n[8], h4n[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { w4[u] = *(const lf4 *)(wrow + 4 * u); h4[u] = *(const lf4 *)(hv + 4 * u); }
+        float z = 0.0f;
+#pragma unroll
+        for (int k0 = 0; k0 < W; k0 += 32) {
+            if (k0 + 32 < W) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { w4n[u] = *(const lf4 *)(wrow + k0 + 32 + 4 * u); h4n[u] = *(const lf4 *)(hv + k0 + 32 + 4 * u); }
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) z = fma32(h4[u >> 2][u & 3], w4[u >> 2][u & 3], z);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { w4[u] = w4n[u]; h4[u] = h4n[u]; }
+        }
+        return z;
+    };
+    auto actor_row1_lds = [&](const float *x_, float *out_) {
+        const lfloat *x = (const lfloat *)x_, *A1 = (const lfloat *)bufA;
         lfloat *hr = (lfloat *)h_row, *out = (lfloat *)out_;
-        if (nz_stream != 0 && tid >= NT - 64 && tid < NT - 64 + A) nzl[tid - (NT - 64)] = (float)det_normal(key, nz_stream, (uint64_t)(nz_base + (tid - (NT - 64))));
         // (all the LDS reads of a 32-term piece are requested before its fmaf chain starts: written term by term the compiler issues
         // read, wait, fmaf -- one LDS round trip per term, 15 k cycles per call)
         if (tid < W) {
@@ -732,43 +774,26 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
             for (int k = 0; k < S; ++k) z = fma32(xv[k], w[k], z);
             hr[tid] = act_fwd(ACT, prelu, z + A1[aL_b1 + tid]);
         }
+        KSUB_MARK(24);
         __syncthreads();
+        KSUB_MARK(25);
         if (tid < W) {
-            float z = 0.0f;
-#pragma unroll 1
-            for (int k0 = 0; k0 < W; k0 += 32) {
-                float w[32];
-                f32x4 h4[8];
-#pragma unroll
-                for (int u = 0; u < 32; ++u) w[u] = A2[(k0 + u) * W + tid];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) h4[u] = *(const lf4 *)(hr + k0 + 4 * u);
-#pragma unroll
-                for (int u = 0; u < 32; ++u) z = fma32(h4[u >> 2][u & 3], w[u], z);
-            }
-            hr[W + tid] = act_fwd(ACT, prelu, z + A1[aL_b2 + tid]);
+            const lfloat *wrow = A1 + aL_w2 + tid * aLD;
+            hr[W + tid] = act_fwd(ACT, prelu, row_chain(wrow, hr) + A1[aL_b2 + tid]);
         }
+        KSUB_MARK(26);
         __syncthreads();
+        KSUB_MARK(27);
         if (tid < A) {
-            float z = 0.0f;
-#pragma unroll 1
-            for (int k0 = 0; k0 < W; k0 += 32) {
-                float w[32];
-                f32x4 h4[8];
-#pragma unroll
-                for (int u = 0; u < 32; ++u) w[u] = A1[aL_wo + (k0 + u) * 8 + tid];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) h4[u] = *(const lf4 *)(hr + W + k0 + 4 * u);
-#pragma unroll
-                for (int u = 0; u < 32; ++u) z = fma32(h4[u >> 2][u & 3], w[u], z);
-            }
-            out[tid] = det_tanhf(lenv_tanh_table, z + A1[aL_bo + tid]) * ma;
+            const lfloat *wrow = A1 + aL_wo + tid * aLD;
+            out[tid] = det_tanhf(lenv_tanh_table, row_chain(wrow, hr + W) + A1[aL_bo + tid]) * ma;
         }
+        KSUB_MARK(28);
         __syncthreads();
+        KSUB_MARK(29);
     };
-    auto actor_row1 = [&](const float *x, float *out, uint32_t nz_stream, int64_t nz_base) {
-        if (G >= 3) { actor_row1_lds(x, out, nz_stream, nz_base); return; }
-        if (nz_stream != 0 && tid >= NT - 64 && tid < NT - 64 + A) nzl[tid - (NT - 64)] = (float)det_normal(key, nz_stream, (uint64_t)(nz_base + (tid - (NT - 64))));
+    auto actor_row1 = [&](const float *x, float *out) {
+        if (G >= 3) { actor_row1_lds(x, out); return; }
         const gfloat *par = (const gfloat *)params;
         if (tid < W) {
             float w[S];
@@ -855,9 +880,6 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     };
 
     // ---- real-env test phase (BaseAgent.test): ONE episode, actions from the one-row actor + exploration noise (TD3.py:126-129) ----
-#ifdef LENV_PHASE_TIMING_SUB
-    unsigned long long ksub_last = 0;
-#endif
     auto test_phase = [&]() {
         const int64_t nstride = cfg.max_steps;
         for (int e = tid; e < SD; e += NT) xt_d[e] = EnvT::reset_word(key, STREAM_TEST_RESET, n_test_ep, e);
@@ -872,10 +894,10 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
             if (tid < S) xt[tid] = EnvT::obs(tid, xt_d);
             __syncthreads();
             KSUB_MARK(12);
-            actor_row1(xt, at, STREAM_TD3_TEST_NOISE, (n_testn + ai) * A);
+            actor_row1(xt, at);
             KSUB_MARK(13);
+            const float zn = step_noise(STREAM_TD3_TEST_NOISE, n_testn + ai);
             if (tid < A) {
-                const float zn = nzl[tid];
                 const float v = at[tid] + (zn * (float)cfg.action_std) * ma;
                 at[tid] = v < -ma ? -ma : (v > ma ? ma : v);
             }
@@ -919,9 +941,9 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 ++n_rand;
                 __syncthreads();
             } else {
-                actor_row1(state, action, STREAM_TD3_ACT_NOISE, n_actn * A);
+                actor_row1(state, action);
+                const float zn = step_noise(STREAM_TD3_ACT_NOISE, n_actn);
                 if (tid < A) {
-                    const float zn = nzl[tid];
                     const float v = action[tid] + (zn * (float)cfg.action_std) * ma;
                     action[tid] = v < -ma ? -ma : (v > ma ? ma : v);
                 }

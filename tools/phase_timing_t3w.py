@@ -68,6 +68,6 @@ if hasattr(_lib.lib(), "lenv_debug_t3v_jobs"):
                 sm, ct = jb[(ph * 5 + cl) * 2], jb[(ph * 5 + cl) * 2 + 1]
                 print("wgrad %-8s %-44s %9.0f cycles per job (%d jobs)" % (pn, cn, sm / max(1, ct), ct))
 
-for i, n in ((12, "test step: obs"), (13, "test step: one-row actor"), (14, "test step: action noise (det_normal) + clamp"), (15, "test step: env dynamics + reward")):
+for i, n in ((24, "  actor: layer 1 (wave 0)"), (25, "  actor: barrier 1"), (26, "  actor: layer 2"), (27, "  actor: barrier 2"), (28, "  actor: output layer"), (29, "  actor: barrier 3 (incl. the noise wave)"), (12, "test step: obs"), (13, "test step: one-row actor"), (14, "test step: action noise (det_normal) + clamp"), (15, "test step: env dynamics + reward")):
     if buf[i] and not buf[0]:
         print("%-44s %9.0f cycles per test step" % (n, buf[i] / max(1, 2 * st[3])))
