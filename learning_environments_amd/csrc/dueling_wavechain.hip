@@ -914,15 +914,17 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     float *dq = Advb + 3 * RBH * A;                       // [B]
     float *dAdv = dq + B;                                 // [B][A]
     float *misc = dAdv + B * A;                           // [64]
-    double *dstate = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(misc + 64) + 7) & ~(uintptr_t)7);   // [T][4]
+    // (alignment by index arithmetic on the 16-byte aligned LDS base: an integer round trip hides the address space and turns every access
+    // to what is carved out behind it into a FLAT instruction, see td3_wavechain.hip)
+    double *dstate = reinterpret_cast<double *>(lds + (((int)(misc + 64 - lds) + 1) & ~1));   // [T][4]
     double *ret = dstate + 4 * T;                         // [T]
     float *ep_rew = reinterpret_cast<float *>(ret + T);   // [T]
     int *alive = reinterpret_cast<int *>(ep_rew + T);     // [T]
     float *state = reinterpret_cast<float *>(alive + T);  // [8]
     float *newrow = state + 8;                            // [16]
     int *tlen = reinterpret_cast<int *>(newrow + 16);     // [T]
-    WcCtx *ctx = reinterpret_cast<WcCtx *>((reinterpret_cast<uintptr_t>(tlen + T) + 15) & ~(uintptr_t)15);
-    volatile float *ctrl = misc;
+    WcCtx *ctx = reinterpret_cast<WcCtx *>(lds + (((int)(reinterpret_cast<float *>(tlen + T) - lds) + 3) & ~3));
+    volatile __attribute__((address_space(3))) float *ctrl = (volatile __attribute__((address_space(3))) float *)misc;
     volatile __attribute__((address_space(3))) int *ictrl = (volatile __attribute__((address_space(3))) int *)(misc + 32);      // (explicitly LDS, see td3_wavechain.hip)
 
     float *arena = a.arena + chain * a.arena_stride;
@@ -966,7 +968,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     }
     if (tid < 64) misc[tid] = 0.0f;
     if (tid == 0) {
-        WcCtx cx{ bufA, bufB, sm_w1t, sm_bias, sm_wh, sm_bh, qv, Vb, Advb, dq, dAdv, online, target, grad, xs, xs2, dumps, adam_m, adam_v, ctrl, prelu,
+        WcCtx cx{ bufA, bufB, sm_w1t, sm_bias, sm_wh, sm_bh, qv, Vb, Advb, dq, dAdv, online, target, grad, xs, xs2, dumps, adam_m, adam_v, (volatile float *)misc, prelu,
                   (float)(1.0 - cfg.adam_beta1), (float)(1.0 - cfg.adam_beta2), (float)cfg.adam_beta2, (float)cfg.adam_eps, (float)cfg.tau,
                   (float)(1.0 - cfg.tau), g, G, gva };
         *ctx = cx;

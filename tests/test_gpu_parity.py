@@ -2062,12 +2062,17 @@ def test_team_launch_next_to_a_foreign_kernel_gives_up_cleanly(eng, orc, foreign
     torch.cuda.current_stream().synchronize()
     dt = time.time() - t0
     st = il.status.cpu().tolist()
-    assert dt < 1.0, dt
-    assert set(st) <= {0, -10}, st                         # clean result, or the team launch gave up; nothing hung
-    assert not side.query()                                # ... while the foreign kernel is still running
+    # Three outcomes, all clean: the teams assembled next to the foreign kernel (status 0), some could not and the launch drained after
+    # the 0.25 s give-up (status -10) -- both well within a second --, or the hardware dispatcher held the rest of the grid back until the
+    # foreign kernel freed its shader engines (it deals workgroups to the engines in turn and waits for room on the one whose turn it
+    # is: then the launch ends with the foreign kernel).  Never a hang, never a half-finished chain taken for good.
+    assert dt < 3.0 + 1.0, dt
+    assert set(st) <= {0, -10}, st
+    prompt = dt < 1.0
+    assert prompt == (not side.query()), (dt, side.query())
     he = eng.HipNesEngine()
     he.run_checked(il, *args, **kw)                        # a refused launch is repeated with one workgroup per chain
-    assert cfg.team_size == (1 if min(st) < 0 else 0) and not side.query()
+    assert cfg.team_size == (1 if min(st) < 0 else 0)
     out = [t.cpu().numpy().copy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_params)]
     for a, b in zip(ref, out):
         assert np.array_equal(a, b, equal_nan=True)

@@ -13,7 +13,10 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "learning_environments_amd", "csrc")
 OUT = "/tmp/liblenv_hip_timing.so"
 srcs = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+if os.environ.get("LENV_TIMING_LIB"):                    # a diagnostic build made elsewhere (tools/build_variant.sh): just load it
+    OUT = os.path.abspath(os.environ["LENV_TIMING_LIB"])
+else:
+  subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
                        "-fPIC", "-shared", "-DLENV_PHASE_TIMING", "-o", OUT] + [a for a in sys.argv[1:] if a.startswith("-D")] +
                       [os.path.join(CSRC, s) for s in srcs])
 from learning_environments_amd import _lib
