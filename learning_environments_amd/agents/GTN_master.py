@@ -137,13 +137,17 @@ class GTN_Master(GTN_Base):
         # One HIP graph per generation (draw -> fused inner loop -> worker_best -> status_fold -> score_transform + update_env):
         # single-process runs on the HIP engine whose task needs no host work between the kernels (the *_vary tasks draw their
         # hyper-parameters on the host).  graph=False keeps the eager launches.
-        capable = (self.transport == "fused" and self.world == 1 and self.n_local > 0 and getattr(engine, "graph_capable", False)
+        # With world > 1 the generation is TWO graphs around the one collective: (draw -> fused inner loop -> worker_best -> status_fold),
+        # the eager all-gather of the fitness records, (score_transform + update_env) -- the collective itself is not captured, so the
+        # path does not depend on the backend (RCCL, or gloo in the tests).
+        capable = (self.transport == "fused" and self.n_local > 0 and getattr(engine, "graph_capable", False)
                    and not hasattr(self.task, "draw_hp"))
         if graph and not capable:
-            raise ValueError("graph=True needs the fused transport on the HIP engine, one process, and a task without host-side draws")
+            raise ValueError("graph=True needs the fused transport on the HIP engine, local workers, and a task without host-side draws")
         self.use_graph = capable if graph is None else bool(graph)
-        self._graph = self._graph_gathered = self._gen_t = self._theta_prev = None
+        self._graph = self._graph2 = self._graph_gathered = self._gen_t = self._theta_prev = self._gather_buf = None
         self._gen_next = None
+        self.graph_replays = 0                 # graph launches so far (tests: the captured path really ran)
 
         if bohb_working_dir:
             self.model_dir = str(os.path.join(bohb_working_dir, 'GTN_models_' + self.env_name))
@@ -180,6 +184,19 @@ class GTN_Master(GTN_Base):
     def evaluate_population(self, it):
         """One generation's worker evaluations on this rank + the all-gather.  Returns gathered [num_workers,4]
         = (score_best, score_orig, sign, 0) in worker order, identical on every rank."""
+        local = self._evaluate_local(it)
+        return self._gather(local)
+
+    def _gather(self, local, out=None):
+        pop = self.num_workers
+        if self.world > 1:
+            gathered = out if out is not None else torch.empty((self.world * self.w_per, 4), dtype=torch.float64, device=self.engine.device)
+            dist.all_gather_into_tensor(gathered, local)      # the ONE collective of a generation (RCCL over xGMI)
+            return gathered[:pop]                             # (a leading slice of a contiguous tensor: contiguous)
+        return local[:pop]
+
+    def _evaluate_local(self, it):
+        """The device work of a generation on this rank (no collective): returns this rank's [w_per, 4] fitness records."""
         dev = self.engine.device
         pop = self.num_workers
         cpw = self.cpw
@@ -201,13 +218,7 @@ class GTN_Master(GTN_Base):
             # column 3 carries this rank's worst chain status through the all-gather: every rank sees every rank's
             # failure in the one host read-back of the generation and raises together (no second sync, no hang)
             self.engine.status_fold(self.inner, local[:self.n_local])
-        if self.world > 1:
-            gathered = torch.empty((self.world * self.w_per, 4), dtype=torch.float64, device=dev)
-            dist.all_gather_into_tensor(gathered, local)      # the ONE collective of a generation (RCCL over xGMI)
-            gathered = gathered[:pop].contiguous()
-        else:
-            gathered = local[:pop]
-        return gathered
+        return local
 
     def step(self, it):
         """One NES generation (the body of the reference's run() loop, :84-106).  Returns (mean_score_orig, solved)."""
@@ -262,12 +273,26 @@ class GTN_Master(GTN_Base):
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        if self.world == 1:
+            with torch.cuda.graph(g, stream=side):
+                gathered = self.evaluate_population(self._gen_t)
+                self._weights = self.engine.rank_update(self.score_transform_type, gathered, self.rank_table, self.theta, self.eps,
+                                                        self.step_size, self.nes_step_size, self.weight_decay,
+                                                        theta_prev=self._theta_prev, generation=self._gen_t)
+            self._graph, self._graph2, self._graph_gathered, self._gen_next = g, None, gathered, 0
+            return
+        # world > 1: graph 1 = this rank's device work up to its fitness records, graph 2 = the redundant rank update on the gathered
+        # records; the all-gather runs eagerly between the two replays (same memory pool: graph 2 reads the eps graph 1 drew)
+        self._gather_buf = torch.empty((self.world * self.w_per, 4), dtype=torch.float64, device=dev)
         with torch.cuda.graph(g, stream=side):
-            gathered = self.evaluate_population(self._gen_t)
+            self._evaluate_local(self._gen_t)
+        g2 = torch.cuda.CUDAGraph()
+        gathered = self._gather_buf[:self.num_workers]
+        with torch.cuda.graph(g2, stream=side, pool=g.pool()):
             self._weights = self.engine.rank_update(self.score_transform_type, gathered, self.rank_table, self.theta, self.eps,
                                                     self.step_size, self.nes_step_size, self.weight_decay,
                                                     theta_prev=self._theta_prev, generation=self._gen_t)
-        self._graph, self._graph_gathered, self._gen_next = g, gathered, 0
+        self._graph, self._graph2, self._graph_gathered, self._gen_next = g, g2, gathered, 0
 
     def _step_graph(self, it):
         """step() as one graph replay + the generation's single host read-back.  The reference decides save_good_model and
@@ -279,6 +304,11 @@ class GTN_Master(GTN_Base):
         if self._gen_next != it:
             self._gen_t.fill_(int(it))
         self._graph.replay()
+        self.graph_replays += 1
+        if self._graph2 is not None:
+            self._gather(self._local, out=self._gather_buf)      # the generation's one collective, between the two graphs
+            self._graph2.replay()
+            self.graph_replays += 1
         self._gen_next = it + 1
         gathered = self._gathered = self._graph_gathered
         host = gathered.cpu().numpy()               # the generation's only host sync

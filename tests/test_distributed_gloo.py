@@ -111,7 +111,7 @@ def test_ranks_seeded_differently_still_agree(tmp_path):
     assert double[0][6] == double[1][6]
 
 
-def _run_hip(rank, world, port, tmp, q):
+def _run_hip(rank, world, port, tmp, q, graph=None):
     """Same as _run but with the product's HIP engine; both ranks share cuda:0 and talk through gloo (plumbing check of the
     sharded path with the real kernels on a 1-GPU box -- the product path on a multi-GPU node is RCCL, one GPU per rank)."""
     sys.path.insert(0, ROOT)
@@ -121,11 +121,12 @@ def _run_hip(rank, world, port, tmp, q):
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     from learning_environments_amd.agents.GTN import GTN_Master
     torch.manual_seed(0)
-    m = GTN_Master(_small_config(5), bohb_id=0, seed=11)
+    m = GTN_Master(_small_config(5), bohb_id=0, seed=11, graph=graph)
     with torch.no_grad():
         m.synthetic_env_orig.env.done_net[-1].bias.fill_(-10.0)
     mean_score, mean_list, _ = m.run()
-    q.put((rank, m.theta.cpu().numpy().copy(), list(m.score_list), list(m.score_orig_list), float(mean_score), (m.w_lo, m.w_hi)))
+    q.put((rank, m.theta.cpu().numpy().copy(), list(m.score_list), list(m.score_orig_list), float(mean_score), (m.w_lo, m.w_hi),
+           (bool(m.use_graph), int(m.graph_replays), len(mean_list))))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -136,10 +137,10 @@ def _run_hip(rank, world, port, tmp, q):
 def test_two_rank_hip_engine_matches_single_rank(tmp_path):
     ctx = mp.get_context("spawn")
 
-    def launch(world, sub, port):
+    def launch(world, sub, port, graph=None):
         (tmp_path / sub).mkdir()
         q = ctx.Queue()
-        procs = [ctx.Process(target=_run_hip, args=(r, world, port, str(tmp_path / sub), q)) for r in range(world)]
+        procs = [ctx.Process(target=_run_hip, args=(r, world, port, str(tmp_path / sub), q, graph)) for r in range(world)]
         for p in procs:
             p.start()
         out = [q.get(timeout=300) for _ in range(world)]
@@ -150,7 +151,15 @@ def test_two_rank_hip_engine_matches_single_rank(tmp_path):
 
     single = launch(1, "g1", 29621)[0]
     double = launch(2, "g2", 29622)
+    eager = launch(2, "g3", 29623, graph=False)
     assert double[0][5] == (0, 3) and double[1][5] == (3, 5)
+    # the captured paths really ran: one graph per generation in one process, two (around the eager all-gather) with two ranks
+    used, replays, gens = single[6]
+    assert used and replays == gens
     for r in double:
+        assert r[6][0] and r[6][1] == 2 * r[6][2]
+    for r in eager:
+        assert not r[6][0] and r[6][1] == 0
+    for r in double + eager:
         assert np.array_equal(r[1], single[1])
         assert r[2] == single[2] and r[3] == single[3] and r[4] == single[4]
