@@ -387,6 +387,36 @@ def test_ql_rn_counter_mode_population_vs_oracle(eng, orc, golden, env_name, rty
         assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
 
 
+def test_ql_rn_draw_buffers_are_clamped_not_refused(eng, orc, golden):
+    """SARSA with a minibatch draws 1 + batch_size exploration decisions per step; their per-episode LDS buffers (12 B each) are a
+    speed-up only -- the kernel computes draws past the buffer inline -- so a long episode with a large batch (2 000 steps x 65 draws =
+    1.5 MB of buffers, ten times the LDS) must run with clamped buffers, not be refused, and still equal the oracle exactly."""
+    g = golden("g9s_calc_score_cliff_sarsa")
+    cfgd = json.loads(str(g["config_json"]))
+    cfgd["envs"]["Cliff"]["max_steps"] = 2000
+    cfgd["agents"]["sarsa"].update(batch_size=64, eps_init=0.6, eps_min=0.3, eps_decay=0.95, alpha=0.5, train_episodes=6)
+    ocfg, cfg, tables = _ql_cfgs(orc, cfgd, 0)
+    assert cfg.agent_kind == 1 and cfg.max_steps * (1 + cfg.batch_size) * 12 > 160 * 1024
+    N = tables["n_states"]
+    P = N * ocfg.rn_hidden + 2 * ocfg.rn_hidden + 1
+    rng = np.random.RandomState(9)
+    theta = (rng.randn(P) * 0.3).astype(np.float32)
+    eps = (rng.randn(2, P) * 0.1).astype(np.float32)
+    worker = np.repeat(np.arange(2), 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), 2)
+    keys = np.array([orc.chain_key(6, 2, int(worker[c]), c % 3) for c in range(6)], np.uint64)
+    il = eng.QlInnerLoop(cfg, 6, tables)
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), rng_keys=dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * 6
+    for c in range(6):
+        w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+        o = orc.ql_rn_chain(ocfg, w, tables, rng_key=int(keys[c]))
+        assert np.array_equal(il.q_table[c].cpu().numpy().reshape(N, 4), o["q_table"]), c
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
 @pytest.mark.parametrize("layers", [2, 3])
 def test_ql_rn_multi_layer_reward_net_vs_oracle(eng, orc, golden, layers):
     """Grid reward nets with more than one hidden layer (default_config_gridworld_reward_env.yaml:108-115 ships HoleRoomLarge with
