@@ -14,7 +14,6 @@ import time
 
 import numpy as np
 import torch
-import torch.nn as nn
 
 from ..envs.env_factory import EnvFactory
 from ..models.model_utils import linear_params
@@ -72,35 +71,23 @@ class GTN_Worker(GTN_Base):
         self._bounds = self.task.agent_bounds
         self._inner = {}
 
-    # ---- noise handling: reference :156-185, same loops over nn.Linear modules ----
+    # ---- noise handling (reference :156-185) over THE flat NES layout: linear_params() lists the nn.Linear weights and biases of an env
+    # in the order theta / eps are flattened in, so the three envs' lists line up element for element ----
     def get_random_noise(self):
-        for l_virt, l_eps in zip(self.synthetic_env.modules(), self.eps.modules()):
-            if isinstance(l_virt, nn.Linear):
-                l_eps.weight.data.copy_(torch.normal(mean=torch.zeros_like(l_virt.weight), std=torch.ones_like(l_virt.weight)) * self.noise_std)
-                if l_eps.bias is not None:
-                    l_eps.bias.data.copy_(torch.normal(mean=torch.zeros_like(l_virt.bias), std=torch.ones_like(l_virt.bias)) * self.noise_std)
+        for p_eps in linear_params(self.eps):           # one N(0, 1) * noise_std draw per parameter tensor, weights before biases, layer by layer
+            p_eps.data.copy_(torch.normal(mean=torch.zeros_like(p_eps), std=torch.ones_like(p_eps)) * self.noise_std)
 
     def add_noise_to_synthetic_env(self, add=True):
-        for l_orig, l_virt, l_eps in zip(self.synthetic_env_orig.modules(), self.synthetic_env.modules(), self.eps.modules()):
-            if isinstance(l_virt, nn.Linear):
-                if add:
-                    l_virt.weight.data.copy_(l_orig.weight + l_eps.weight)
-                    if l_virt.bias is not None:
-                        l_virt.bias.data.copy_(l_orig.bias + l_eps.bias)
-                else:
-                    l_virt.weight.data.copy_(l_orig.weight - l_eps.weight)
-                    if l_virt.bias is not None:
-                        l_virt.bias.data.copy_(l_orig.bias - l_eps.bias)
+        triples = zip(linear_params(self.synthetic_env_orig), linear_params(self.synthetic_env), linear_params(self.eps))
+        for p_orig, p_virt, p_eps in triples:
+            p_virt.data.copy_(p_orig + p_eps if add else p_orig - p_eps)
 
     def subtract_noise_from_synthetic_env(self):
         self.add_noise_to_synthetic_env(add=False)
 
     def invert_eps(self):
-        for l_eps in self.eps.modules():
-            if isinstance(l_eps, nn.Linear):
-                l_eps.weight.data.neg_()
-                if l_eps.bias is not None:
-                    l_eps.bias.data.neg_()
+        for p_eps in linear_params(self.eps):
+            p_eps.data.neg_()
 
     # ---- scoring ----
     def _flat(self, envw):
