@@ -1,0 +1,37 @@
+#!/bin/bash
+# One GPU-box round (run via gpurun from the repo root): bench with the CPU baseline, rocprofv3 kernel trace of the headline and of
+# every other BASELINE configuration (one run and one CSV per configuration), the HBM-traffic PMC passes (separate runs, kernel-trace
+# only, as MI355X_MICROARCH.md prescribes) for the three big kernels, and the SQ counter sets.  Outputs: gpurun_out/ -> profiles/.
+# usage: tools/gpu_round_r04.sh [tag]   (before the gpurun call, `rm -rf gpurun_out/pmc* gpurun_out/prof*` in the container: gpurun MERGES
+# the box's files into the local scratch, and counter files of earlier calls would be summarised along with the new ones)
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-r04}
+mkdir -p $R/gpurun_out
+cd $R
+python bench.py 2>gpurun_out/bench.err | tail -1 | tee gpurun_out/bench.json | cut -c1-400
+cd /tmp && export TMPDIR=/tmp
+rm -rf $R/gpurun_out/prof $R/gpurun_out/pmc_* $R/gpurun_out/prof_cfg* $R/gpurun_out/pmccfg_*
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-configs > $R/gpurun_out/prof_run.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-configs > $R/gpurun_out/pmc_$c.log 2>&1
+done
+for n in 2 3 4; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg$n -- python3 $R/bench.py --only-config $n > $R/gpurun_out/prof_cfg$n.json 2> $R/gpurun_out/prof_cfg$n.log
+done
+for n in 2 4; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmccfg_${n}_$c -- python3 $R/bench.py --only-config $n > $R/gpurun_out/pmccfg_${n}_$c.log 2>&1
+  done
+done
+for set in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU"; do
+  t=$(echo $set | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_sq_$t -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-configs > $R/gpurun_out/pmc_sq_$t.log 2>&1
+done
+for n in 2 4; do
+  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR"; do
+    t=$(echo $set | cut -d' ' -f1)
+    rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmccfg_${n}_sq_$t -- python3 $R/bench.py --only-config $n > $R/gpurun_out/pmccfg_${n}_sq_$t.log 2>&1
+  done
+done
+cd $R
+python3 tools/summarize_profiles_r04.py $TAG
