@@ -439,7 +439,12 @@ def timed_generations(master, steps, warmup, barrier, world, use_events):
         return out
 
     if getattr(master, "use_graph", False) and master._graph is None:
-        master._capture_generation()           # (no warm-up generation ran: capture before the event hooks go in)
+        try:
+            master._capture_generation()       # (no warm-up generation ran: capture before the event hooks go in)
+        except RuntimeError as e:              # the capture is an optimisation: run eagerly if this stack refuses it
+            master.use_graph, master._graph, master._graph2 = False, None, None
+            master.graph_capture_error = str(e)
+            torch.cuda.synchronize()
     graph = getattr(master, "_graph", None) if getattr(master, "use_graph", False) else None
     orig_replay = graph.replay if graph is not None else None
 
@@ -573,7 +578,12 @@ def run_rank(args):
                 "parallelism": "population-sharded x%d, 1 all-gather/generation" % world,
                 "env_steps_per_s": (train_steps + test_steps) * world / (dt / args.steps),
                 "us_per_learn_step_per_chain": kernel_ms * 1e3 / (learn_steps / chains) if learn_steps else None,
-                "kernel_launches_per_generation": None}
+                "kernel_launches_per_generation": None,
+                # how a generation is launched: one captured graph in one process, two graphs around the eager all-gather with N > 1
+                # ranks, 0 = eager launches (capture refused: the reason is in graph_capture_error)
+                "graphs_per_generation": (0 if not getattr(master, "use_graph", False) else (2 if getattr(master, "_graph2", None) is not None else 1))}
+            if getattr(master, "graph_capture_error", None):
+                line["config"]["graph_capture_error"] = master.graph_capture_error[:300]
             line["roofline"] = {"bound": "hbm", "kernel": "ddqn_se_inner_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                                 "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": kernel_ms,

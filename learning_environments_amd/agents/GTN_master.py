@@ -273,6 +273,8 @@ class GTN_Master(GTN_Base):
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        # with a process group alive its watchdog thread polls events: only THIS thread's calls belong to the capture
+        mode = {"capture_error_mode": "thread_local"} if self.world > 1 else {}
         if self.world == 1:
             with torch.cuda.graph(g, stream=side):
                 gathered = self.evaluate_population(self._gen_t)
@@ -284,11 +286,11 @@ class GTN_Master(GTN_Base):
         # world > 1: graph 1 = this rank's device work up to its fitness records, graph 2 = the redundant rank update on the gathered
         # records; the all-gather runs eagerly between the two replays (same memory pool: graph 2 reads the eps graph 1 drew)
         self._gather_buf = torch.empty((self.world * self.w_per, 4), dtype=torch.float64, device=dev)
-        with torch.cuda.graph(g, stream=side):
+        with torch.cuda.graph(g, stream=side, **mode):
             self._evaluate_local(self._gen_t)
         g2 = torch.cuda.CUDAGraph()
         gathered = self._gather_buf[:self.num_workers]
-        with torch.cuda.graph(g2, stream=side, pool=g.pool()):
+        with torch.cuda.graph(g2, stream=side, pool=g.pool(), **mode):
             self._weights = self.engine.rank_update(self.score_transform_type, gathered, self.rank_table, self.theta, self.eps,
                                                     self.step_size, self.nes_step_size, self.weight_decay,
                                                     theta_prev=self._theta_prev, generation=self._gen_t)
@@ -300,7 +302,16 @@ class GTN_Master(GTN_Base):
         host, so the pre-update theta the graph kept (theta_prev) is swapped back in for the save / the early return."""
         t1 = time.time()
         if self._graph is None:
-            self._capture_generation()
+            try:
+                self._capture_generation()
+            except RuntimeError as e:
+                # the capture is an optimisation: if this stack refuses it (a collective library that polls the device from another
+                # thread, an allocator in an odd state), the generation runs as eager launches -- same kernels, same results.  Every
+                # rank issues exactly one all-gather per generation on either path, so ranks need not agree on it.
+                self.use_graph, self._graph, self._graph2 = False, None, None
+                self.graph_capture_error = str(e)
+                torch.cuda.synchronize()
+                return self.step(it)
         if self._gen_next != it:
             self._gen_t.fill_(int(it))
         self._graph.replay()
