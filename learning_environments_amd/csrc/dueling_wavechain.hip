@@ -95,6 +95,12 @@ struct WcCtx {
     float w1, w2, beta2, adam_eps, tau, omt;            // Adam / Polyak constants (torch single-tensor Adam, DuelingDDQN.py:87-93)
     int g, G;                                           // this workgroup's place in its chain's team
     float *gva;                                         // team exchange: Vb [3][B] | Advb [3][B][A] (arena)
+    double *dstate;                                     // the lock-step test episodes' state (wc_test_steps): [T][4], returns, flags, lengths
+    float *ep_rew;
+    int *alive, *tlen;
+    double *ret;
+    int *test_steps;                                    // out: environment steps of the phase
+    int max_steps;
 };
 
 template <class T> __device__ __forceinline__ T *lds_uni_ptr(T *const *field) { return uni_ptr(*field); }
@@ -204,6 +210,122 @@ template <int SHAPE> __device__ __noinline__ void wc_forward_thin_layers(const W
     }
     __syncthreads();
     WSUB_MARK(28);
+}
+
+// ---- the steps of one test phase (T <= 16 episodes in lock-step, BaseAgent.test agents/base_agent.py:155-227) as ONE routine: the
+// online net does not change during a test phase, so each wave keeps its tiles of the four 128x128 layers in registers (128 VGPRs) for
+// all max_steps forwards instead of fetching 256 KB per forward -- the same chains on the same operands as wc_forward_thin_layers.
+// Lane e < T owns episode e: it writes the observation rows (LDS), picks the greedy action from its row's head outputs and steps the
+// real environment.  Reset draws, returns and the step count included: the call site in the kernel body stays straight-line code (a
+// live-range split copy that the register allocator placed in the divergent reset block in front of the call -- before the block's
+// exec restore -- lost the kernel's zero register in the inactive lanes: rocgdb, first Adam pass after the first test phase).
+template <int SHAPE> __device__ __noinline__ void wc_test_steps(const WcCtx *ctx_, uint32_t key_lo_, uint32_t key_hi_, int first_episode_)
+{
+    using namespace wcp;
+    constexpr WcShape SP = kWcShapes[SHAPE];
+    constexpr int S = SP.S, A = SP.A, T = SP.T, ACT = SP.q_act, env_id = SP.env;
+    static_assert(T <= 16, "one 16-sample tile");
+    Lane L;
+    L.init();
+    const int tid = L.tid, wave = L.wave;
+    typedef __attribute__((address_space(3))) const WcCtx LCtx;
+    LCtx *c = (LCtx *)uni_ptr(ctx_);
+    float *bufA = uni_ptr(c->bufA);
+    lfloat *sm_wh_l = (lfloat *)uni_ptr(c->sm_wh), *sm_bh_l = (lfloat *)uni_ptr(c->sm_bh), *Vb_l = (lfloat *)uni_ptr(c->Vb), *Advb_l = (lfloat *)uni_ptr(c->Advb);
+    const float *online = uni_ptr(c->online);
+    const float prelu = unif(c->prelu);
+    typedef __attribute__((address_space(3))) double ldouble;
+    typedef __attribute__((address_space(3))) int lint;
+    ldouble *dstate = (ldouble *)uni_ptr(c->dstate);
+    lfloat *ep_rew = (lfloat *)uni_ptr(c->ep_rew);
+    lint *alive = (lint *)uni_ptr(c->alive), *tlen = (lint *)uni_ptr(c->tlen);
+    const int max_steps = uni(c->max_steps);
+    ldouble *ret = (ldouble *)uni_ptr(c->ret);
+    const uint64_t key = ((uint64_t)uni((int)key_hi_) << 32) | (uint32_t)uni((int)key_lo_);
+    const int first_episode = uni(first_episode_);
+    if (tid < T) {
+        double st[4];
+        real_env_reset_draw(env_id, key, STREAM_TEST_RESET, (int64_t)first_episode + tid, st);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dstate[tid * 4 + i] = st[i];
+        ep_rew[tid] = 0.0f; alive[tid] = 1; tlen[tid] = 0;
+    }
+    constexpr int IW = 16;
+    float *imgX = bufA, *imgY = bufA + IW * W, *imgZ = bufA + 2 * IW * W;
+    lfloat *Xl = (lfloat *)(bufA + 3 * IW * W);          // observation rows [T][S]
+    float a2[32], a3[32], av[32], aa[32];
+    thin_load16(online + oW2t, wave, L, a2); thin_load16(online + oW3t, wave, L, a3);
+    thin_load16(online + oWv1t, wave, L, av); thin_load16(online + oWa1t, wave, L, aa);
+    const int j = tid & (W - 1);
+    float w[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) w[k] = online[oW1t + k * W + j];
+    const float bj = online[ob1 + j];
+    for (int e = tid; e < 4 * W + 4; e += NT) sm_wh_l[e] = online[oWh + e];
+    auto put_obs = [&]() {
+        double st[4] = { dstate[tid * 4], dstate[tid * 4 + 1], dstate[tid * 4 + 2], dstate[tid * 4 + 3] };
+        float obs[8];
+        real_env_obs(env_id, st, obs);
+#pragma unroll
+        for (int i = 0; i < S; ++i) Xl[tid * S + i] = obs[i];
+    };
+    if (tid < T) put_obs();
+    __syncthreads();
+    for (int t = 0; t < max_steps; ++t) {
+        for (int i = tid >> 7; i < T; i += NT >> 7) {   // layer 1 (K = S): one thread per (unit, sample)
+            float z = 0.0f;
+#pragma unroll
+            for (int k = 0; k < S; ++k) z = fma32(Xl[i * S + k], w[k], z);
+            ((lfloat *)imgX)[j * IW + i] = act_fwd(ACT, prelu, z + bj);
+        }
+        __syncthreads();
+        thin_layer16<ACT, 1>(a2, online + ob2, imgY, a2, nullptr, nullptr, imgX, wave, L, prelu);
+        __syncthreads();
+        thin_layer16<LENV_ACT_IDENTITY, 1>(a3, online + ob3, imgX, a3, nullptr, nullptr, imgY, wave, L, prelu);
+        __syncthreads();
+        thin_layer16<ACT, 2>(av, online + obv1, imgY, aa, online + oba1, imgZ, imgX, wave, L, prelu);
+        __syncthreads();
+        if (tid < 4 * T) {
+            const int i = tid >> 2, o = tid & 3;
+            if (o <= A) {
+                const lfloat *img = (const lfloat *)(o == 0 ? imgY : imgZ) + i;
+                const lfloat *wh = (const lfloat *)sm_wh_l + o;
+                float acc = 0.0f;
+#pragma unroll 16
+                for (int k = 0; k < W; ++k) acc = fma32(img[k * IW], wh[k * 4], acc);
+                acc = acc + sm_bh_l[o];
+                if (o == 0) Vb_l[i] = acc; else Advb_l[i * A + (o - 1)] = acc;
+            }
+        }
+        __syncthreads();
+        if (tid < T && alive[tid]) {                      // q = V + (Adv - mean Adv) (models/actor_critic.py:117-122), greedy action, env.step
+            float sum = 0.0f;
+            for (int b = 0; b < A; ++b) sum = sum + Advb_l[tid * A + b];
+            const float mean = sum / (float)A;
+            int am = 0; float best = Vb_l[tid] + (Advb_l[tid * A] - mean);
+            for (int b = 1; b < A; ++b) { const float v = Vb_l[tid] + (Advb_l[tid * A + b] - mean); if (v > best) { best = v; am = b; } }
+            double st[4] = { dstate[tid * 4], dstate[tid * 4 + 1], dstate[tid * 4 + 2], dstate[tid * 4 + 3] };
+            double rew; int dn;
+            real_env_step(env_id, st, am, rew, dn);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dstate[tid * 4 + i] = st[i];
+            ep_rew[tid] = ep_rew[tid] + (float)rew;
+            tlen[tid] = tlen[tid] + 1;
+            if (dn) alive[tid] = 0;
+            put_obs();
+        }
+        __syncthreads();
+        int any = 0;
+        for (int e = 0; e < T; ++e) any |= alive[e];
+        if (!any) break;
+    }
+    if (tid < T) ret[tid] = (double)ep_rew[tid];
+    if (tid == 0) {
+        int n = 0;
+        for (int e = 0; e < T; ++e) n += tlen[e];
+        *(lint *)uni_ptr(c->test_steps) = n;
+    }
+    __syncthreads();
 }
 
 // ---- one pass of Critic_DuelingDQN over sample blocks: pass 0 = target net on s' (waves 0-3 -> slot 2), pass 1 = online net on
@@ -970,7 +1092,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     if (tid == 0) {
         WcCtx cx{ bufA, bufB, sm_w1t, sm_bias, sm_wh, sm_bh, qv, Vb, Advb, dq, dAdv, online, target, grad, xs, xs2, dumps, adam_m, adam_v, (volatile float *)misc, prelu,
                   (float)(1.0 - cfg.adam_beta1), (float)(1.0 - cfg.adam_beta2), (float)cfg.adam_beta2, (float)cfg.adam_eps, (float)cfg.tau,
-                  (float)(1.0 - cfg.tau), g, G, gva };
+                  (float)(1.0 - cfg.tau), g, G, gva, dstate, ep_rew, alive, tlen, ret, reinterpret_cast<int *>(misc + 32), cfg.max_steps };
         *ctx = cx;
     }
     __syncthreads();
@@ -1034,39 +1156,44 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
 
     // ---- real-env test phase: T episodes in lock-step (BaseAgent.test, agents/base_agent.py:155-227) ----
     auto test_phase = [&]() {
-        if (tid < T) {
-            double st[4];
-            real_env_reset_draw(env_id, key, STREAM_TEST_RESET, (int64_t)n_test_ep + tid, st);
-            for (int i = 0; i < 4; ++i) dstate[tid * 4 + i] = st[i];
-            ep_rew[tid] = 0.0f; alive[tid] = 1; tlen[tid] = 0;
-        }
-        if (tid == 0) ictrl[0] = 0;
-        __syncthreads();
-        float *xt = xscr;
-        for (int t = 0; t < cfg.max_steps; ++t) {
-            if (tid < T) { float obs[8]; real_env_obs(env_id, dstate + tid * 4, obs); for (int i = 0; i < S; ++i) xt[tid * S + i] = obs[i]; }
+        if constexpr (T <= 16) {
             __syncthreads();
-            forward_thin(xt, T);
-            if (tid < T && alive[tid]) {
-                int am = 0; float best = qv[tid * A];
-                for (int aa = 1; aa < A; ++aa) { const float v = qv[tid * A + aa]; if (v > best) { best = v; am = aa; } }
-                double st[4] = { dstate[tid * 4], dstate[tid * 4 + 1], dstate[tid * 4 + 2], dstate[tid * 4 + 3] };
-                double rew; int dn;
-                real_env_step(env_id, st, am, rew, dn);
+            wc_test_steps<SHAPE>(ctx, (uint32_t)key, (uint32_t)(key >> 32), n_test_ep);      // (ends with a barrier; ictrl[0] = steps taken)
+        } else {
+            if (tid < T) {
+                double st[4];
+                real_env_reset_draw(env_id, key, STREAM_TEST_RESET, (int64_t)n_test_ep + tid, st);
                 for (int i = 0; i < 4; ++i) dstate[tid * 4 + i] = st[i];
-                ep_rew[tid] = ep_rew[tid] + (float)rew;
-                tlen[tid] = tlen[tid] + 1;
-                atomicAdd(reinterpret_cast<int *>(misc + 32), 1);      // (= ictrl[0])
-                if (dn) alive[tid] = 0;
+                ep_rew[tid] = 0.0f; alive[tid] = 1; tlen[tid] = 0;
             }
+            if (tid == 0) ictrl[0] = 0;
             __syncthreads();
-            int any = 0;
-            for (int e = 0; e < T; ++e) any |= alive[e];
-            if (!any) break;
+            float *xt = xscr;
+            for (int t = 0; t < cfg.max_steps; ++t) {
+                if (tid < T) { float obs[8]; real_env_obs(env_id, dstate + tid * 4, obs); for (int i = 0; i < S; ++i) xt[tid * S + i] = obs[i]; }
+                __syncthreads();
+                forward_thin(xt, T);
+                if (tid < T && alive[tid]) {
+                    int am = 0; float best = qv[tid * A];
+                    for (int aa = 1; aa < A; ++aa) { const float v = qv[tid * A + aa]; if (v > best) { best = v; am = aa; } }
+                    double st[4] = { dstate[tid * 4], dstate[tid * 4 + 1], dstate[tid * 4 + 2], dstate[tid * 4 + 3] };
+                    double rew; int dn;
+                    real_env_step(env_id, st, am, rew, dn);
+                    for (int i = 0; i < 4; ++i) dstate[tid * 4 + i] = st[i];
+                    ep_rew[tid] = ep_rew[tid] + (float)rew;
+                    tlen[tid] = tlen[tid] + 1;
+                    atomicAdd(reinterpret_cast<int *>(misc + 32), 1);      // (= ictrl[0])
+                    if (dn) alive[tid] = 0;
+                }
+                __syncthreads();
+                int any = 0;
+                for (int e = 0; e < T; ++e) any |= alive[e];
+                if (!any) break;
+            }
+            if (tid < T) ret[tid] = (double)ep_rew[tid];
+            __syncthreads();
         }
-        if (tid < T) ret[tid] = (double)ep_rew[tid];
         n_test_ep += T;
-        __syncthreads();
         test_steps += ictrl[0];
         __syncthreads();
     };

@@ -2098,8 +2098,8 @@ def test_team_launch_next_to_a_foreign_kernel_gives_up_cleanly(eng, orc, foreign
     # is: then the launch ends with the foreign kernel).  Never a hang, never a half-finished chain taken for good.
     assert dt < 3.0 + 1.0, dt
     assert set(st) <= {0, -10}, st
-    prompt = dt < 1.0
-    assert prompt == (not side.query()), (dt, side.query())
+    if dt < 1.0:                                           # (the prompt outcomes really happened NEXT TO the foreign kernel)
+        assert not side.query(), dt
     he = eng.HipNesEngine()
     he.run_checked(il, *args, **kw)                        # a refused launch is repeated with one workgroup per chain
     assert cfg.team_size == (1 if min(st) < 0 else 0)
