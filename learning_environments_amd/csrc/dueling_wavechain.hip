@@ -21,10 +21,15 @@ namespace lenv {
 
 using namespace wc;
 
-struct WcShape { int env, S, A, Hse, T, q_act, se_act; };       // fixed: H = F = 128, L = 2, B = 128, DuelingDDQN
+// fixed: H = F = 128, L = 2, B = 128; kind 1 = DuelingDDQN (Critic_DuelingDQN), kind 0 = DDQN whose Critic_DQN is S-128-128-A (the plain-DQN
+// mode of lenv_dueling_se_inner_loop: models/actor_critic.py:84-91, agents/DDQN.py:60-94): layers 1 and 2, then the A-column output layer
+// where the dueling net has its advantage head -- no feature / stream layers, no value head, no advantage mean.  The arena keeps the
+// dueling layout (the unused matrices stay zero and are skipped by the optimizer pass); plain shapes run on one workgroup per chain.
+struct WcShape { int env, S, A, Hse, T, q_act, se_act, kind; };
 constexpr WcShape kWcShapes[] = {
-    { -1, 2, 2, 1, 1, 0, 0 },
-    { LENV_ENV_ACROBOT, 6, 3, 128, 10, LENV_ACT_RELU, LENV_ACT_LEAKYRELU },     // default_config_acrobot.yaml duelingddqn = BASELINE configs[2]
+    { -1, 2, 2, 1, 1, 0, 0, 1 },
+    { LENV_ENV_ACROBOT, 6, 3, 128, 10, LENV_ACT_RELU, LENV_ACT_LEAKYRELU, 1 },     // default_config_acrobot.yaml duelingddqn = BASELINE configs[2]
+    { LENV_ENV_ACROBOT, 6, 3, 128, 10, LENV_ACT_RELU, LENV_ACT_LEAKYRELU, 0 },     // default_config_acrobot.yaml ddqn (6-128-128-3 relu, B = 128)
 };
 constexpr int WC_B = 128, WC_H = 128;
 
@@ -82,6 +87,24 @@ __device__ __forceinline__ int wc_sd_to_arena(int p, int S, int A)
     return obh + 1 + o;
 }
 
+
+// the same for a Critic_DQN S-128-128-A: net.0.weight [128][S], net.0.bias, net.2.weight [128][128], net.2.bias, net.4.weight [A][128], net.4.bias
+__device__ __forceinline__ int wc_sd_to_arena_plain(int p, int S, int A)
+{
+    using namespace wcp;
+    int o = p;
+    if (o < WC_H * S) { const int j = o / S, k = o - j * S; return oW1t + k * W + j; }
+    o -= WC_H * S;
+    if (o < W) return ob1 + o;
+    o -= W;
+    if (o < IMG) { const int j = o >> 7, k = o & 127; return oW2t + k * W + j; }
+    o -= IMG;
+    if (o < W) return ob2 + o;
+    o -= W;
+    if (o < A * W) { const int aa = o >> 7, k = o & 127; return oWh + k * 4 + 1 + aa; }
+    o -= A * W;
+    return obh + 1 + o;
+}
 
 // Everything the phase routines need, written once into LDS by thread 0.  The phases are OUT-OF-LINE functions on purpose: inlined into
 // the one big kernel body their per-lane address sets (swizzled image positions, staging slots) are loop invariants of the episode
@@ -154,11 +177,16 @@ template <int SHAPE> __device__ __noinline__ void wc_forward_thin_layers(const W
     float *imgX = bufA;                                  // thin-product activation images [unit][16 or 32] live in bufA
     WSUB_DECL;
     constexpr int IW = T <= 16 ? 16 : 32;               // samples per image row (the 16x16x4 tiles take up to 16)
+    constexpr bool PL = SP.kind == 0;                    // plain DQN: layers 1, 2 and the output layer
+    static_assert(!PL || IW == 16, "plain shapes: the 16-sample path");
     float *imgY = bufA + IW * W, *imgZ = bufA + 2 * IW * W;
     float a2[32], a3[32], av[32], aa[32];                // this wave's weight tiles of the four 128x128 layers
     if constexpr (IW == 16) {
-        thin_load16(online + oW2t, wave, L, a2); thin_load16(online + oW3t, wave, L, a3);
-        thin_load16(online + oWv1t, wave, L, av); thin_load16(online + oWa1t, wave, L, aa);
+        thin_load16(online + oW2t, wave, L, a2);
+        if constexpr (!PL) {
+            thin_load16(online + oW3t, wave, L, a3);
+            thin_load16(online + oWv1t, wave, L, av); thin_load16(online + oWa1t, wave, L, aa);
+        }
     }
     {   // layer 1 (K = S): one thread per (unit, sample); the head output layer's weights go to LDS alongside
         const int j = tid & (W - 1);
@@ -176,7 +204,10 @@ template <int SHAPE> __device__ __noinline__ void wc_forward_thin_layers(const W
     }
     __syncthreads();
     WSUB_MARK(24);
-    if constexpr (IW == 16) {
+    if constexpr (PL) {
+        thin_layer16<ACT, 1>(a2, online + ob2, imgY, a2, nullptr, nullptr, imgX, wave, L, prelu);
+        imgZ = imgY;                                     // the output layer reads h2
+    } else if constexpr (IW == 16) {
         thin_layer16<ACT, 1>(a2, online + ob2, imgY, a2, nullptr, nullptr, imgX, wave, L, prelu);
         __syncthreads();
         WSUB_MARK(25);
@@ -198,7 +229,7 @@ template <int SHAPE> __device__ __noinline__ void wc_forward_thin_layers(const W
     WSUB_MARK(27);
     if (tid < 4 * I) {
         const int i = tid >> 2, o = tid & 3;
-        if (o <= A) {
+        if (o <= A && !(PL && o == 0)) {
             const lfloat *img = (const lfloat *)(o == 0 ? imgY : imgZ) + i;
             const lfloat *wh = (const lfloat *)sm_wh + o;
             float acc = 0.0f;
@@ -253,9 +284,13 @@ template <int SHAPE> __device__ __noinline__ void wc_test_steps(const WcCtx *ctx
     constexpr int IW = 16;
     float *imgX = bufA, *imgY = bufA + IW * W, *imgZ = bufA + 2 * IW * W;
     lfloat *Xl = (lfloat *)(bufA + 3 * IW * W);          // observation rows [T][S]
+    constexpr bool PL = SP.kind == 0;                    // plain DQN: layers 1, 2, output layer on h2
     float a2[32], a3[32], av[32], aa[32];
-    thin_load16(online + oW2t, wave, L, a2); thin_load16(online + oW3t, wave, L, a3);
-    thin_load16(online + oWv1t, wave, L, av); thin_load16(online + oWa1t, wave, L, aa);
+    thin_load16(online + oW2t, wave, L, a2);
+    if constexpr (!PL) {
+        thin_load16(online + oW3t, wave, L, a3);
+        thin_load16(online + oWv1t, wave, L, av); thin_load16(online + oWa1t, wave, L, aa);
+    } else imgZ = imgY;
     const int j = tid & (W - 1);
     float w[S];
 #pragma unroll
@@ -281,13 +316,15 @@ template <int SHAPE> __device__ __noinline__ void wc_test_steps(const WcCtx *ctx
         __syncthreads();
         thin_layer16<ACT, 1>(a2, online + ob2, imgY, a2, nullptr, nullptr, imgX, wave, L, prelu);
         __syncthreads();
-        thin_layer16<LENV_ACT_IDENTITY, 1>(a3, online + ob3, imgX, a3, nullptr, nullptr, imgY, wave, L, prelu);
-        __syncthreads();
-        thin_layer16<ACT, 2>(av, online + obv1, imgY, aa, online + oba1, imgZ, imgX, wave, L, prelu);
-        __syncthreads();
+        if constexpr (!PL) {
+            thin_layer16<LENV_ACT_IDENTITY, 1>(a3, online + ob3, imgX, a3, nullptr, nullptr, imgY, wave, L, prelu);
+            __syncthreads();
+            thin_layer16<ACT, 2>(av, online + obv1, imgY, aa, online + oba1, imgZ, imgX, wave, L, prelu);
+            __syncthreads();
+        }
         if (tid < 4 * T) {
             const int i = tid >> 2, o = tid & 3;
-            if (o <= A) {
+            if (o <= A && !(PL && o == 0)) {
                 const lfloat *img = (const lfloat *)(o == 0 ? imgY : imgZ) + i;
                 const lfloat *wh = (const lfloat *)sm_wh_l + o;
                 float acc = 0.0f;
@@ -298,12 +335,18 @@ template <int SHAPE> __device__ __noinline__ void wc_test_steps(const WcCtx *ctx
             }
         }
         __syncthreads();
-        if (tid < T && alive[tid]) {                      // q = V + (Adv - mean Adv) (models/actor_critic.py:117-122), greedy action, env.step
-            float sum = 0.0f;
-            for (int b = 0; b < A; ++b) sum = sum + Advb_l[tid * A + b];
-            const float mean = sum / (float)A;
-            int am = 0; float best = Vb_l[tid] + (Advb_l[tid * A] - mean);
-            for (int b = 1; b < A; ++b) { const float v = Vb_l[tid] + (Advb_l[tid * A + b] - mean); if (v > best) { best = v; am = b; } }
+        if (tid < T && alive[tid]) {                      // q = V + (Adv - mean Adv) (models/actor_critic.py:117-122; plain DQN: q = the output layer), greedy action, env.step
+            int am = 0;
+            if constexpr (PL) {
+                float best = Advb_l[tid * A];
+                for (int b = 1; b < A; ++b) { const float v = Advb_l[tid * A + b]; if (v > best) { best = v; am = b; } }
+            } else {
+                float sum = 0.0f;
+                for (int b = 0; b < A; ++b) sum = sum + Advb_l[tid * A + b];
+                const float mean = sum / (float)A;
+                float best = Vb_l[tid] + (Advb_l[tid * A] - mean);
+                for (int b = 1; b < A; ++b) { const float v = Vb_l[tid] + (Advb_l[tid * A + b] - mean); if (v > best) { best = v; am = b; } }
+            }
             double st[4] = { dstate[tid * 4], dstate[tid * 4 + 1], dstate[tid * 4 + 2], dstate[tid * 4 + 3] };
             double rew; int dn;
             real_env_step(env_id, st, am, rew, dn);
@@ -371,6 +414,8 @@ template <int SHAPE> __device__ __noinline__ void wc_forward_big(const WcCtx *ct
     stage_store_direct(bufA, L, sr);
     __syncthreads();
     WSUB_MARK(32);
+    constexpr bool PL = SP.kind == 0;                    // plain DQN: W2, then the A-column output layer on h2
+    constexpr int NL = PL ? 1 : 4;
     const bool active = pass == 1 || wave < 4;
     const bool stored = pass == 1 && wave < 4;
     const int blk = wave & 3, slot = pass == 0 ? 2 : (wave < 4 ? 0 : 1);
@@ -393,37 +438,38 @@ template <int SHAPE> __device__ __noinline__ void wc_forward_big(const WcCtx *ct
         for (int v = 0; v < 64; ++v) bin[v] = r[v];
     }
 #pragma unroll 1
-    for (int l = 0; l < 4; ++l) {                      // W2 (bufA), W3 (bufB), Wv1 (bufA), Wa1 (bufB)
+    for (int l = 0; l < NL; ++l) {                     // W2 (bufA), W3 (bufB), Wv1 (bufA), Wa1 (bufB)
         float *cur = (l & 1) ? bufB : bufA, *nxt = (l & 1) ? bufA : bufB;
-        if (l < 3) stage_load_direct(par + (l == 0 ? oW3t : (l == 1 ? oWv1t : oWa1t)), L, sr);
+        if (l + 1 < NL) stage_load_direct(par + (l == 0 ? oW3t : (l == 1 ? oWv1t : oWa1t)), L, sr);
         if (active) {
             acc_zero(acc);
             chain128(cur, L, bin, acc);
             if (l == 1) tile_bias_act<LENV_ACT_IDENTITY>(acc, sm_bias + 2 * W, L, prelu, r);
             else tile_bias_act<ACT>(acc, sm_bias + (l == 0 ? 1 : (l == 2 ? 3 : 4)) * W, L, prelu, r);
             if (stored) dump_store(dump_of(l == 0 ? D_H2 : (l == 1 ? D_FEAT : (l == 2 ? D_V1 : D_A1)), blk), L, r);
-            if (stored && l >= 2) {                     // row-major copy for the head output layer's weight gradient
+            if (stored && (l >= 2 || PL)) {             // row-major copy for the head output layer's weight gradient (plain: h2, in R_A1's place)
                 gfloat *rm = (gfloat *)dump_of(l == 2 ? R_V1 : R_A1, 0) + (32 * blk + L.li) * W + 4 * L.h;
 #pragma unroll
                 for (int pc = 0; pc < 16; ++pc)
                     *(gf4 *)(rm + 32 * (pc >> 2) + 8 * (pc & 3)) = f32x4{r[4 * pc], r[4 * pc + 1], r[4 * pc + 2], r[4 * pc + 3]};
             }
             tile_to_operand(r);
-            if (l < 2) {
+            if (l < 2 && !PL) {
 #pragma unroll
                 for (int v = 0; v < 64; ++v) bin[v] = r[v];
             } else {
                 // head output layer on the fresh hidden block: V = wv2 . v1 + bv2 (row 0 of the tile), Adv = Wa2 . a1 + ba2 (rows 0..A-1)
+                // (plain DQN: Q = W3 . h2 + b3 in the advantage columns)
                 f32x16 hacc;
 #pragma unroll
                 for (int v = 0; v < 16; ++v) hacc[v] = 0.0f;
-                const int col = l == 2 ? 0 : 1 + (L.li < A ? L.li : A - 1);
+                const int col = (l == 2 && !PL) ? 0 : 1 + (L.li < A ? L.li : A - 1);
                 const lfloat *wh = (const lfloat *)sm_wh + L.h * 4 + col;
 #pragma unroll
                 for (int t = 0; t < 64; ++t) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[2 * t * 4], r[breg_of(t)], hacc, 0, 0, 0);
                 if (L.h == 0) {
                     const int row = 32 * blk + L.li;
-                    if (l == 2) Vb_l[slot * RBH + row] = hacc[0] + sm_bh_l[0];
+                    if (l == 2 && !PL) Vb_l[slot * RBH + row] = hacc[0] + sm_bh_l[0];
                     else {
 #pragma unroll
                         for (int aa = 0; aa < A; ++aa) Advb_l[slot * RBH * A + row * A + aa] = hacc[aa] + sm_bh_l[1 + aa];
@@ -431,7 +477,7 @@ template <int SHAPE> __device__ __noinline__ void wc_forward_big(const WcCtx *ct
                 }
             }
         }
-        if (l < 3) stage_store_direct(nxt, L, sr);
+        if (l + 1 < NL) stage_store_direct(nxt, L, sr);
         __syncthreads();
         WSUB_MARK(33 + l);
     }
@@ -476,10 +522,12 @@ template <int SHAPE> __device__ __noinline__ void wc_backward_big(const WcCtx *c
     const AdamConsts ac{ ctrl[10], ctrl[11], unif(c->w1), unif(c->w2), unif(c->beta2), unif(c->adam_eps) };
     const float tau = unif(c->tau), omt = unif(c->omt);
     WSUB_DECL;
+    constexpr bool PL = SP.kind == 0;                    // plain DQN: the output layer (advantage columns) on h2, then W2 and layer 1
+    constexpr int NQ = PL ? 1 : 4;
     {   // head output layer, one element of gWh per thread (i ascending): gWh[k][0] = sum_i dq[i] v1[i][k], gWh[k][1+aa] = sum_i
-        // dAdv[i][aa] a1[i][k], from the row-major copies of v1 / a1 (coalesced along k)
+        // dAdv[i][aa] a1[i][k], from the row-major copies of v1 / a1 (coalesced along k); plain DQN: gW3[aa][k] = sum_i dQ[i][aa] h2[i][k]
         const int k = tid & 127, col = tid >> 7;
-        if (col <= A) {
+        if (col <= A && !(PL && col == 0)) {
             const gfloat *rm = (const gfloat *)dump_of(col == 0 ? R_V1 : R_A1, 0) + k;
             float s = 0.0f;
             for (int i0 = 0; i0 < B; i0 += 64) {
@@ -494,15 +542,18 @@ template <int SHAPE> __device__ __noinline__ void wc_backward_big(const WcCtx *c
     }
     WSUB_MARK(22);
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {                      // Wv1, Wa1, W3, W2
+    for (int qi = 0; qi < NQ; ++qi) {                  // Wv1, Wa1, W3, W2
+        // plain DQN: ONE round -- the upstream gradient comes from the output layer (as the advantage stream's does, with h2 in a1's
+        // place), everything behind it is the dueling net's W2 round
+        const int q = PL ? 3 : qi, qu = PL ? 1 : qi;
         const int oWt = q == 0 ? oWv1t : (q == 1 ? oWa1t : (q == 2 ? oW3t : oW2t));
         const int ob = q == 0 ? obv1 : (q == 1 ? oba1 : (q == 2 ? ob3 : ob2));
         L.refresh();
         stage_load_transposed(online + oWt, L, sr);
         if (wave < 4) {
             // upstream gradient block dz (lane = sample, register = unit)
-            if (q < 2) {
-                const gf4 *hd = (const gf4 *)dump_of(q == 0 ? D_V1 : D_A1, blk) + L.lane;
+            if (qu < 2) {
+                const gf4 *hd = (const gf4 *)dump_of(PL ? D_H2 : (qu == 0 ? D_V1 : D_A1), blk) + L.lane;
                 const int i = 32 * blk + L.li;
                 const float dqi = dq_l[i];
                 float da[A];
@@ -516,7 +567,7 @@ template <int SHAPE> __device__ __noinline__ void wc_backward_big(const WcCtx *c
                     for (int cc = 0; cc < 4; ++cc) {
                         const f32x4 wk = *(const lf4 *)(whp + 4 * cc);      // (wv2, wa2_0, wa2_1, wa2_2)[unit]
                         float up;
-                        if (q == 0) up = fma32(dqi, wk[0], 0.0f);
+                        if (qu == 0) up = fma32(dqi, wk[0], 0.0f);
                         else {
                             up = 0.0f;
 #pragma unroll
@@ -563,8 +614,8 @@ template <int SHAPE> __device__ __noinline__ void wc_backward_big(const WcCtx *c
             __builtin_amdgcn_s_setprio(3);
             if (tid < 256 + W) grad[ob + (tid - 256)] = image_colsum(bufB, tid - 256, B);
             WSUB_MARK4(44);
-            if (q == 0) {
-                if (tid >= 256 && tid < 256 + 1 + A) {
+            if (qi == 0) {
+                if (tid >= 256 && tid < 256 + 1 + A && !(PL && tid == 256)) {
                     const int col = tid - 256;
                     float s = 0.0f;
                     for (int i = 0; i < B; ++i) s = s + (col == 0 ? dq_l[i] : dAdv_l[i * A + col - 1]);
@@ -572,7 +623,7 @@ template <int SHAPE> __device__ __noinline__ void wc_backward_big(const WcCtx *c
                 }
             }
             WSUB_MARK4(45);
-            if (q >= 1) {                                  // first half of layer q-1's matrix: its gradient is complete, the chain hides the pass
+            if (!PL && q >= 1) {                           // first half of layer q-1's matrix: its gradient is complete, the chain hides the pass
                 const int oPrev = q == 1 ? oWv1t : (q == 2 ? oWa1t : oW3t);
                 wg_adam_t(online, adam_m, adam_v, grad, oPrev, IMG / 2, ac, target, tau, omt, tid - 256, 256);
             }
@@ -622,9 +673,12 @@ template <int SHAPE> __device__ __noinline__ void wc_backward_big(const WcCtx *c
     WSUB_MARK(20);
     // what is left of the optimizer step
     wg_adam_t(online, adam_m, adam_v, grad, oW1t, ob2 + W - oW1t, ac, target, tau, omt, tid, NT);                 // W1t b1 W2t b2
+    if constexpr (PL) wg_adam_t(online, adam_m, adam_v, grad, oWh, PW - oWh, ac, target, tau, omt, tid, NT);      // the output layer (column 0 of Wh / bh stays zero)
+    else {
     wg_adam_t(online, adam_m, adam_v, grad, oW3t + IMG / 2, IMG / 2 + W, ac, target, tau, omt, tid, NT);          // second halves + biases
     wg_adam_t(online, adam_m, adam_v, grad, oWv1t + IMG / 2, IMG / 2 + W, ac, target, tau, omt, tid, NT);
     wg_adam_t(online, adam_m, adam_v, grad, oWa1t + IMG / 2, PW - (oWa1t + IMG / 2), ac, target, tau, omt, tid, NT);   // ... ba1 Wh bh
+    }
     __syncthreads();
     WSUB_MARK(21);
 }
@@ -1005,6 +1059,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     extern __shared__ __align__(16) float lds[];
     constexpr WcShape SP = kWcShapes[SHAPE];
     constexpr int S = SP.S, A = SP.A, K = S + A, Hse = SP.Hse, T = SP.T, B = WC_B;
+    constexpr bool PL = SP.kind == 0;                    // plain DQN (Critic_DQN S-128-128-A): one workgroup per chain
     static_assert(S % 2 == 0 && S <= 8 && A <= 3 && T <= 32 && Hse <= 128, "shape limits of the wave-chain kernel");
     const lenv_ddqn_cfg &cfg = a.cfg;
     Lane L;
@@ -1084,7 +1139,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
         __syncthreads();
         for (int p = tid; p < a.P; p += NT) {
             const float w = a.agent_init[chain * a.P + p];
-            const int q = wc_sd_to_arena(p, S, A);
+            const int q = PL ? wc_sd_to_arena_plain(p, S, A) : wc_sd_to_arena(p, S, A);
             online[q] = w; target[q] = w;
         }
     }
@@ -1129,6 +1184,9 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     // q_out[I][A] from the head outputs of `slot` (models/actor_critic.py:117-122; learn: mean over ALL I*A advantages)
     auto finish_q = [&](int slot, int I, float *q_out, bool global_mean) {
         const float *Vs = Vb + slot * RBH, *As = Advb + slot * RBH * A;
+        if constexpr (PL) {                                // Critic_DQN: the output layer's rows are the Q values
+            for (int e = tid; e < I * A; e += NT) q_out[e] = As[e];
+        } else
         if (global_mean) {
             if (tid == 0) {
                 float sum = 0.0f;
@@ -1287,9 +1345,11 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                 __syncthreads();
                 WPT_MARK(2);
 #ifndef WC_DIAG_NO_FWD
-                if (G == 2) {
+                if (!PL && G == 2) {
+                    if constexpr (!PL) {
 #pragma unroll 1
                     for (int pass = 0; pass < 2; ++pass) wct_forward<SHAPE>(ctx, pass);
+                    }
                     team_barrier();                        // every row's V / Adv is in the exchange arrays
                     for (int e = tid; e < 3 * B; e += NT) Vb[(e / B) * RBH + (e % B)] = gva[e];
                     for (int e = tid; e < 3 * B * A; e += NT) Advb[(e / (B * A)) * RBH * A + (e % (B * A))] = gva[3 * B + e];
@@ -1319,7 +1379,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                 if (tid == 0) {
                     float s_dq = 0.0f;
                     for (int b = 0; b < B; ++b) s_dq = s_dq + dq[b];
-                    ctrl[9] = (-s_dq) / (float)(B * A);
+                    ctrl[9] = (-s_dq) / (float)(B * A);            // backward of `- advantages.mean()` (dueling only)
                     b1pow *= cfg.adam_beta1; b2pow *= cfg.adam_beta2;
                     ctrl[10] = (float)(-(cfg.lr / (1.0 - b1pow)));
                     ctrl[11] = (float)__builtin_sqrt(1.0 - b2pow);
@@ -1330,17 +1390,19 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                     for (int e = tid; e < B * A; e += NT) {
                         const int b = e / A, aa = e - b * A;
                         const float g = aa == (int)Vb[b] ? dq[b] : 0.0f;
-                        dAdv[e] = g + mean_grad;
+                        dAdv[e] = PL ? g : g + mean_grad;          // (plain DQN: dL/dQ, only entry a_b of a row is non-zero)
                     }
                 }
                 __syncthreads();
                 WPT_MARK(4);
 #ifndef WC_DIAG_NO_BWD
-                if (G == 2) {
+                if (!PL && G == 2) {
+                    if constexpr (!PL) {
                     wct_backward_chain<SHAPE>(ctx);
                     team_barrier();                        // all four blocks' gradient dumps are there
                     if (g == 0) { wct_wgrad_ends<SHAPE>(ctx, 0); wct_wgrad_layer<SHAPE>(ctx, 0); wct_wgrad_layer<SHAPE>(ctx, 1); }
                     else { wct_wgrad_layer<SHAPE>(ctx, 2); wct_wgrad_layer<SHAPE>(ctx, 3); wct_wgrad_ends<SHAPE>(ctx, 1); }
+                    }
                     team_barrier();
                     {   // torch.optim.Adam + Polyak, half of the parameter vector per member (ctrl[10], ctrl[11]: this step's bias corrections)
                         const AdamConsts ac{ ctrl[10], ctrl[11], (float)(1.0 - cfg.adam_beta1), (float)(1.0 - cfg.adam_beta2), (float)cfg.adam_beta2,
@@ -1435,7 +1497,8 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
             if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = pad_l;
         }
     }
-    if (a.out.final_online && g == 0) for (int p = tid; p < a.P; p += NT) a.out.final_online[chain * a.P + p] = online[wc_sd_to_arena(p, S, A)];
+    if (a.out.final_online && g == 0)
+        for (int p = tid; p < a.P; p += NT) a.out.final_online[chain * a.P + p] = online[PL ? wc_sd_to_arena_plain(p, S, A) : wc_sd_to_arena(p, S, A)];
     if (a.out.status && status != 0) atomicMin(&a.out.status[chain], status);
 }
 
@@ -1449,8 +1512,8 @@ int lenv_wc_dueling_shape(const lenv_ddqn_cfg *cfg)
 {
     for (int s = 1; s < (int)(sizeof(kWcShapes) / sizeof(kWcShapes[0])); ++s) {
         const WcShape &sp = kWcShapes[s];
-        if (cfg->agent_kind == 1 && cfg->env_id == sp.env && cfg->state_dim == sp.S && cfg->num_actions == sp.A && cfg->feature_dim == WC_H &&
-            cfg->q_hidden == WC_H && cfg->q_layers == 2 && cfg->batch_size == WC_B && cfg->se_hidden == sp.Hse && cfg->se_layers == 1 &&
+        if (cfg->agent_kind == sp.kind && cfg->env_id == sp.env && cfg->state_dim == sp.S && cfg->num_actions == sp.A &&
+            (sp.kind == 0 || cfg->feature_dim == WC_H) && cfg->q_hidden == WC_H && cfg->q_layers == 2 && cfg->batch_size == WC_B && cfg->se_hidden == sp.Hse && cfg->se_layers == 1 &&
             cfg->test_episodes == sp.T && cfg->q_act == sp.q_act && cfg->se_act == sp.se_act && cfg->synthetic_env_type == 0 && !cfg->icm_enabled)
             return s;
     }
@@ -1491,7 +1554,7 @@ __global__ void wct_team_reset_kernel(float *arena, int64_t arena_stride, int64_
 // kernel's LDS footprint) -- the members wait for each other --, else 1.  cfg->team_size 1 forces one workgroup per chain.
 int lenv_wc_dueling_team(const lenv_ddqn_cfg *cfg, int shape, int64_t chains)
 {
-    if (cfg->team_size == 1 || chains < 1 || shape <= 0) return 1;
+    if (cfg->team_size == 1 || chains < 1 || shape <= 0 || kWcShapes[shape].kind == 0) return 1;
     void (*kern)(const WcArgs) = dueling_wavechain_kernel<1>;
     return lenv_team_grid_resident(reinterpret_cast<const void *>(kern), wc::NT, wc_lds_bytes(kWcShapes[shape]), 8 * ((chains + 7) / 8) * 2) ? 2 : 1;
 }
@@ -1517,7 +1580,7 @@ int lenv_wc_dueling_launch(int shape, const lenv_ddqn_cfg *cfg, const float *the
     if (off > arena_stride) return LENV_ERR_WORKSPACE;
     const size_t lds_bytes = wc_lds_bytes(sp);
     if (lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
-    void (*kern)(const WcArgs) = dueling_wavechain_kernel<1>;
+    void (*kern)(const WcArgs) = shape == 2 ? dueling_wavechain_kernel<2> : dueling_wavechain_kernel<1>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
         return LENV_ERR_LAUNCH;
     a.chains = chains;

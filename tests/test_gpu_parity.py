@@ -2488,6 +2488,57 @@ def test_wavechain_dueling_kernel_equals_gemm_queue_kernel(eng):
     assert not np.array_equal(a[4], init)
 
 
+def test_wavechain_plain_dqn_kernel_equals_gemm_queue_kernel_and_oracle(eng, orc):
+    """The wave-chain kernel's plain-DQN shape -- default_config_acrobot.yaml's ddqn section: Critic_DQN 6-128-128-3 relu, B = 128, on the
+    Acrobot SE (dueling_wavechain.hip, kWcShapes[2]: layers 1 and 2, then the output layer where the dueling net has its advantage head) --
+    in production launches against (i) the GEMM-queue kernel's plain-DQN mode on the same inputs (a launch that asks for a step trace) and
+    (ii) the oracle's DDQN on two whole chains: scores, counters, per-episode test means, final returns AND all 17 795 online parameters
+    after 80 learn steps, bit for bit."""
+    import ctypes as C
+    from learning_environments_amd import _lib, configs
+    from learning_environments_amd.agents.nes_common import chain_keys
+    from learning_environments_amd.config import ddqn_cfg_from_config
+    cfgd = configs.fixed_work(configs.acrobot_syn_env_ddqn(2), 3)
+    cfgd["envs"]["Acrobot-v1"]["max_steps"] = 40
+    cfg = ddqn_cfg_from_config(cfgd)
+    ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=0)
+    assert (cfg.agent_kind, cfg.q_hidden, cfg.q_layers, cfg.batch_size, cfg.init_episodes, cfg.test_episodes) == (0, 128, 2, 128, 1, 10)
+    assert _lib.lib().lenv_dueling_team_size(C.byref(cfg), 6) == 1          # plain shapes: one workgroup per chain
+    chains = 6
+    P_q = 6 * 128 + 128 + 128 * 128 + 128 + 3 * 128 + 3
+    rng = np.random.RandomState(6)
+    P_se = 3 * (9 * 128 + 128) + (6 + 1 + 1) * 128 + 8
+    theta = (rng.randn(P_se) * 0.1).astype(np.float32)
+    theta[-1] = -10.0
+    eps = (rng.randn(2, P_se) * 0.05).astype(np.float32)
+    worker = (np.arange(chains) // 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), 2)
+    keys = chain_keys(78, 3, worker, np.arange(chains) % 3)
+    init = rng.uniform(-0.08, 0.08, (chains, P_q)).astype(np.float32)
+
+    def run(trace_cap):
+        il = eng.InnerLoop(cfg, chains, trace_cap=trace_cap, want_final_online=True)
+        assert il.p_agent == P_q
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return [t.cpu().numpy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_online)]
+
+    a, b = _wavechain_pair(run)
+    assert a[1][:, 2].min() == 80
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert not np.array_equal(a[4], init)
+    for c in (1, 5):
+        w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+        o = orc.ddqn_se_chain(ocfg, w, init[c], rng_key=int(keys[c]), want_final_online=True)
+        assert float(a[0][c]) == o["score"]
+        assert a[1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(a[2][c], o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(a[3][c], o["final_test_returns"])
+        assert np.array_equal(a[4][c], o["final_online"])
+
+
 @pytest.mark.parametrize("chains", [5, 10])
 def test_wavechain_dueling_team_agrees(eng, chains):
     """The DuelingDDQN wave-chain kernel with a chain on a team of two workgroups (blocks on four waves each, weight gradients dealt by

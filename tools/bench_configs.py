@@ -78,6 +78,15 @@ if __name__ == "__main__":
         c["agents"]["td3"]["init_episodes"] = 1
         c["envs"]["HalfCheetah-v3"]["max_steps"] = 100
         run("cfg5 HalfCheetah-standin RN + TD3 pop 85 = 255 chains (3 episodes x 100 steps)", c, gens=1, extra=td3_model)
+    if "acrobot_ddqn" in which:
+        # default_config_acrobot.yaml's ddqn section (Critic_DQN 6-128-128-3, B = 128) on 96 chains: the wave-chain kernel's plain-DQN
+        # shape, then the same launch on the GEMM-queue kernel (gtn.kernel_variant = NO_WAVECHAIN)
+        from learning_environments_amd import _lib
+        for variant, label in ((0, "wave-chain kernel"), (_lib.VARIANT_NO_WAVECHAIN, "GEMM-queue kernel")):
+            c = configs.fixed_work(configs.acrobot_syn_env_ddqn(32), 3)
+            c["envs"]["Acrobot-v1"]["max_steps"] = 100
+            c["agents"]["gtn"]["kernel_variant"] = variant
+            run("Acrobot SE + DDQN 6-128-128-3 pop 32 (3 episodes x 100 steps), " + label, c, gens=2)
     if "td3d" in which:
         # TD3_discrete_vary as the syn-env YAMLs ship it (510-wide tanh nets, batch 122, hard Gumbel softmax) on an Acrobot SE
         c = configs.fixed_work(configs.acrobot_syn_env_td3_discrete(32), 3)
