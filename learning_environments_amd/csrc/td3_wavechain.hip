@@ -26,6 +26,15 @@ static_assert(PN % 4 == 0, "float4 passes");
 }
 constexpr int T3W_B = 192, T3W_NB = T3W_B / 32;                           // minibatch rows, sample blocks
 
+// The published shapes this kernel is instantiated for (hidden 128 x 2, batch 192, policy_delay 1, a RewardEnv with 128-wide reward nets):
+// the real env, the agent's activation, the test episodes per test phase, the reward net's hidden layers.
+struct T3wShape { int env, act, T, rn_layers; };
+constexpr T3wShape kT3wShapes[] = {
+    { -1, 0, 1, 1 },
+    { LENV_ENV_CHEETAH_STANDIN, LENV_ACT_RELU, 1, 1 },        // 1: default_config_halfcheetah_reward_env.yaml = BASELINE configs[4]
+    { LENV_ENV_PENDULUM, LENV_ACT_LEAKYRELU, 10, 2 },         // 2: default_config_pendulum_reward_env.yaml (actor 3-128-128-1, critics 4-128-128-1)
+};
+
 // dumps: [T3W_NB] blocks of BLK floats each (register order), or [192][128] row-major copies (same size)
 enum { TD_C1_H1 = 0, TD_C1_H2, TD_C2_H1, TD_C2_H2, TD_A_H1, TD_A_H2, TR_C1_H2, TR_C2_H2, TR_A_H2, TS_DZ2, TR_DZ2, TR_DH1, TR_DZ2B, TR_DH1B, T3W_NDUMP };
 
@@ -37,7 +46,7 @@ struct T3wArgs {
     lenv_td3_out out;
     int64_t rb_cap; int RS;
     int P, Pa, Pc, P_rn;
-    int64_t a_par, a_xc, a_xn, a_xa, a_th, a_dump, a_replay, a_meter, a_gx, a_bar, a_w2u;
+    int64_t a_par, a_xc, a_xn, a_xa, a_th, a_dump, a_replay, a_meter, a_gx, a_bar, a_w2u, a_rn;
     int G;                                   // workgroups per chain (team): 1, 2, 3 or 6
     int64_t chains;
 };
@@ -51,6 +60,12 @@ struct T3wCtx {
     // the step at ctrl[20..23]) and the optimizer constants
     float *w2u, *ctrl;
     float w1, w2, beta2, aeps, tau, omt;
+    // the lock-step test episodes (t3w_test_steps): env states [T][SD], returns, lengths; exploration noise scale, steps per episode
+    double *xt_d, *ret;
+    float *ep_rew;
+    int *tlen;
+    float action_std;
+    int max_steps;
 };
 
 // state-dict index inside ONE net (mlp_off order: W0 [128 x in] b0 W1 [128 x 128] b1 Wout [out x 128] bout) -> arena-layout index
@@ -528,13 +543,106 @@ __device__ __noinline__ void t3w_backward_wgrad(const T3wCtx *ctx_, float *gpar_
 #include "td3_wavechain_team.cuh"
 namespace lenv {
 
+// ---- the test episodes of one test phase in LOCK-STEP (shapes with T > 1 episodes per phase; BaseAgent.test, base_agent.py:155-227, with
+// TD3.select_test_action TD3.py:126-129): row e < T = episode e.  The actor does not change during a test phase, so each wave keeps its
+// tile of the 128x128 layer in registers for all max_steps forwards (the thin 16-sample product of lenv_wavechain.cuh: k-ascending chains,
+// the bits of the one-row actor); layer 1 and the output layer are per-(unit, row) / per-(row, output) fmaf chains.  The envs of this
+// kernel never terminate: every episode takes max_steps steps; reset rows and noise rows have the fixed indices of td3_rn_inner_kernel's
+// lock-step rollouts.  Uses bufA (the team path reloads its LDS actor afterwards).
+template <int SHAPE> __device__ __noinline__ void t3w_test_steps(const T3wCtx *ctx_, uint32_t key_lo_, uint32_t key_hi_, int first_episode_, int noise_base_)
+{
+    using namespace t3p;
+    constexpr T3wShape SP = kT3wShapes[SHAPE];
+    using EnvT = ContEnv<SP.env>;
+    constexpr int S = EnvT::S, A = EnvT::A, SD = EnvT::SD, ACT = SP.act, T = SP.T, IW = 16, NB = 32;      // NB: steps per noise batch
+    static_assert(T <= 16 && T * SD <= NT && T * A * NB <= 2 * NT, "one 16-sample tile");
+    Lane L;
+    L.init();
+    const int tid = L.tid, wave = L.wave;
+    typedef __attribute__((address_space(3))) const T3wCtx LCtx;
+    typedef __attribute__((address_space(3))) double ldouble;
+    typedef __attribute__((address_space(3))) int lint;
+    LCtx *c = (LCtx *)uni_ptr(ctx_);
+    float *bufA = uni_ptr(c->bufA);
+    const float *par = uni_ptr(c->params);                 // the actor = net 0 of the arena
+    const float prelu = unif(c->prelu), ma = unif(c->ma), astd = unif(c->action_std);
+    ldouble *xt_d = (ldouble *)uni_ptr(c->xt_d), *ret = (ldouble *)uni_ptr(c->ret);
+    lfloat *ep_rew = (lfloat *)uni_ptr(c->ep_rew);
+    lint *tlen = (lint *)uni_ptr(c->tlen);
+    const int max_steps = uni(c->max_steps);
+    const uint64_t key = ((uint64_t)uni((int)key_hi_) << 32) | (uint32_t)uni((int)key_lo_);
+    const int first_episode = uni(first_episode_), noise_base = uni(noise_base_);
+    float *imgX = bufA, *imgY = bufA + IW * W;
+    lfloat *Xl = (lfloat *)(bufA + 2 * IW * W);           // observation rows [T][S]
+    lfloat *at = Xl + 16 * 20;                             // actions [T][A]
+    lfloat *nzb = at + 16 * 8;                             // noise batch [NB][T][A]
+    lfloat *whl = nzb + NB * 16 * 8;                       // output layer [128][8] + bias [8]
+    for (int e = tid; e < T * SD; e += NT) { const int te = e / SD; xt_d[e] = EnvT::reset_word(key, STREAM_TEST_RESET, (int64_t)first_episode + te, e - te * SD); }
+    if (tid < T) ep_rew[tid] = 0.0f;
+    float a2[32];
+    thin_load16(par + oW2t, wave, L, a2);
+    const int j = tid & (W - 1);
+    float w[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) w[k] = ((const gfloat *)par)[oW1t + k * W + j];
+    const float bj = ((const gfloat *)par)[ob1 + j];
+    for (int e = tid; e < 8 * W + 8; e += NT) whl[e] = ((const gfloat *)par)[oWo + e];      // (Wo and bo are contiguous)
+    __syncthreads();
+    if (tid < T * S) { const int te = tid / S; Xl[tid] = EnvT::obs(tid - te * S, (const double *)(xt_d + te * SD)); }
+    __syncthreads();
+    for (int ai = 0; ai < max_steps; ++ai) {
+        if ((ai & (NB - 1)) == 0) {                        // exploration noise of the next NB steps: (episode te, step ai) has row noise_base + te * max_steps + ai
+            for (int e = tid; e < NB * T * A; e += NT) {
+                const int st = e / (T * A), r = e - st * (T * A), te = r / A, k = r - te * A;
+                const int64_t n = ((int64_t)noise_base + (int64_t)te * max_steps + ai + st) * A + k;
+                nzb[e] = (ai + st < max_steps) ? (float)det_normal(key, STREAM_TD3_TEST_NOISE, (uint64_t)n) : 0.0f;
+            }
+        }
+        for (int i = tid >> 7; i < T; i += NT >> 7) {    // layer 1 (K = S): one thread per (unit, row)
+            float z = 0.0f;
+#pragma unroll
+            for (int k = 0; k < S; ++k) z = fma32(Xl[i * S + k], w[k], z);
+            ((lfloat *)imgX)[j * IW + i] = act_fwd(ACT, prelu, z + bj);
+        }
+        __syncthreads();
+        thin_layer16<ACT, 1>(a2, par + ob2, imgY, a2, nullptr, nullptr, imgX, wave, L, prelu);
+        __syncthreads();
+        if (tid < T * A) {                                 // output layer + tanh, exploration noise, clamp
+            const int i = tid / A, o = tid - i * A;
+            const lfloat *img = (const lfloat *)imgY + i;
+            float acc = 0.0f;
+#pragma unroll 16
+            for (int k = 0; k < W; ++k) acc = fma32(img[k * IW], whl[k * 8 + o], acc);
+            const float av = det_tanhf(lenv_tanh_table, acc + whl[8 * W + o]) * ma;
+            const float v = av + (nzb[(ai & (NB - 1)) * T * A + tid] * astd) * ma;
+            at[tid] = v < -ma ? -ma : (v > ma ? ma : v);
+        }
+        __syncthreads();
+        double nx = 0.0, pre = 0.0;
+        const int wte = tid / SD;
+        if (tid < T * SD) nx = EnvT::step_word(tid - wte * SD, (const double *)(xt_d + wte * SD), (const float *)(at + wte * A));
+        if (tid < T) pre = EnvT::reward_pre((const double *)(xt_d + tid * SD), (const float *)(at + tid * A));
+        __syncthreads();
+        if (tid < T * SD) xt_d[tid] = nx;
+        __syncthreads();
+        if (tid < T) ep_rew[tid] = ep_rew[tid] + (float)(0.0 + EnvT::reward_post((const double *)(xt_d + tid * SD), pre));
+        if (tid < T * S) { const int te = tid / S; Xl[tid] = EnvT::obs(tid - te * S, (const double *)(xt_d + te * SD)); }
+        __syncthreads();
+    }
+    if (tid < T) { ret[tid] = (double)ep_rew[tid]; tlen[tid] = max_steps; }
+    __syncthreads();
+}
+
 template <int SHAPE>
 __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
 {
     using namespace t3p;
-    using EnvT = ContEnv<LENV_ENV_CHEETAH_STANDIN>;
+    constexpr T3wShape SP = kT3wShapes[SHAPE];
+    using EnvT = ContEnv<SP.env>;
     extern __shared__ __align__(16) float lds[];
-    constexpr int S = EnvT::S, A = EnvT::A, SA = S + A, SD = EnvT::SD, B = T3W_B, Hrn = 128, ACT = LENV_ACT_RELU, T = 1;
+    constexpr int S = EnvT::S, A = EnvT::A, SA = S + A, SD = EnvT::SD, B = T3W_B, Hrn = 128, ACT = SP.act, T = SP.T, RNL = SP.rn_layers;
+    constexpr bool CHEETAH = SP.env == LENV_ENV_CHEETAH_STANDIN;
+    static_assert(S <= 17 && A <= 6 && SD <= 18 && !EnvT::TERMINATES, "sized for the stand-in; the test episodes run their full length");
     const lenv_td3_cfg &cfg = a.cfg;
     const int tid = threadIdx.x;
     // A chain is run by a TEAM of G workgroups (G = 1: the plain one-workgroup-per-chain launch).  Workgroups are dealt to the eight
@@ -558,8 +666,8 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     float *sm_bo = sm_wo + 8 * W;                         // [8]
     float *sm_b2 = sm_bo + 8;                             // [2][128], [128][8] + [8]: the second pass of a dual call
     float *sm_wo2 = sm_b2 + 2 * W;
-    float *rn_w = sm_wo2 + 8 * W + 8;                     // reward net: W0 [Hrn][S] | b0 [Hrn] | Wout [Hrn] | bout
-    float *rn_h = rn_w + ((a.P_rn + 3) & ~3);             // [Hrn]
+    float *rn_w = sm_wo2 + 8 * W + 8;                     // reward net: W0 [Hrn][S] | b0 [Hrn] | Wout [Hrn] | bout (two hidden layers: in the arena)
+    float *rn_h = rn_w + (RNL == 1 ? ((a.P_rn + 3) & ~3) : Hrn);   // [Hrn] (two hidden layers: rn_w is the second hidden row)
     float *dq1 = rn_h + Hrn;                              // [B]
     float *q1 = dq1 + B;                                  // [B] ... six vectors; from q1 on they double as dz [B][A] in the policy step
     float *q2 = q1 + B, *tq1 = q2 + B, *tq2 = tq1 + B, *rr = tq2 + B, *dd = rr + B;
@@ -569,7 +677,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     // (alignment by INDEX arithmetic on the LDS base, which is 16-byte aligned: a round trip through an integer would hide from the compiler
     // that everything carved out behind it is LDS, and every access to it would become a FLAT instruction that waits for all loads in flight)
     double *xs_d = reinterpret_cast<double *>(lds + (((int)(misc + 64 - lds) + 1) & ~1));   // [20] train env state
-    double *xt_d = xs_d + 20;                             // [T][17]
+    double *xt_d = xs_d + 20;                             // [17] (the test episodes of a phase run one after the other)
     double *ret = xt_d + 17 * T;                          // [T]
     float *ep_rew = reinterpret_cast<float *>(ret + T);   // [T]
     int *tlen = reinterpret_cast<int *>(ep_rew + T);      // [T]
@@ -594,7 +702,8 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     {
         const float sg = a.eps ? a.sign[chain] : 0.0f;
         const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P_rn : nullptr;
-        for (int i = tid; i < a.P_rn; i += NT) rn_w[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
+        if constexpr (RNL == 1) { for (int i = tid; i < a.P_rn; i += NT) rn_w[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i]; }
+        else if (g == 0) { for (int i = tid; i < a.P_rn; i += NT) arena[a.a_rn + i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i]; }
     }
     if (g == 0) {                                          // the arena is shared by the team: its first member fills it
         for (int p = tid; p < 3 * PN; p += NT) { params[p] = 0.0f; targets[p] = 0.0f; adam_m[p] = 0.0f; adam_v[p] = 0.0f; grad[p] = 0.0f; }
@@ -616,14 +725,14 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     // passes are free there -- instead of 23 scattered 8-byte global loads per state word and env step
     typedef __attribute__((address_space(3))) double ldouble;
     ldouble *chA = (ldouble *)sm_b, *chB = chA + 17 * 17, *chC = chB + 17 * 6;
-    if (G >= 3) {
+    if (CHEETAH && G >= 3) {
         for (int i = tid; i < 17 * 17; i += NT) chA[i] = lenv_cheetah_A[i];
         if (tid < 17 * 6) chB[tid] = lenv_cheetah_B[tid];
         if (tid < 17) chC[tid] = lenv_cheetah_c[tid];
     }
     // word i of x' = clip(c + A x + B a, -10, 10): EnvT::step_word with the constants from LDS (same operations in the same order)
     auto env_step_word = [&](int i, const double *x_, const float *a_) -> double {
-        if (G < 3) return EnvT::step_word(i, x_, a_);
+        if (!CHEETAH || G < 3) return EnvT::step_word(i, x_, a_);
         const ldouble *x = (const ldouble *)x_;
         const lfloat *av = (const lfloat *)a_;
         double acc = chC[i];
@@ -637,7 +746,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     if (tid == 0) {
         T3wCtx cx{ bufA, bufB, sm_b, sm_wo, sm_bo, q1, dzl, sm_b2, sm_wo2, params, targets, grad, dumps, prelu, ma, g, G, w2u, misc,
                    (float)(1.0 - cfg.adam_beta1), (float)(1.0 - cfg.adam_beta2), (float)cfg.adam_beta2, (float)cfg.adam_eps, (float)cfg.tau,
-                   (float)(1.0 - cfg.tau) };
+                   (float)(1.0 - cfg.tau), xt_d, ret, ep_rew, tlen, (float)cfg.action_std, cfg.max_steps };
         *ctx = cx;
     }
     __syncthreads();
@@ -854,6 +963,49 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     // phi = reward_net(obs) -> ctrl[slot]   (one hidden layer, types 1 / 2 / 5 / 6: no info inputs on this path)
     auto rn_eval = [&](const float *obs, int slot) {
         if (rtype == 0) { if (tid == 0) ctrl[slot] = 0.0f; __syncthreads(); return; }
+        if constexpr (RNL == 2) {
+            static_assert(RNL != 2 || (Hrn * S) % 4 == 0, "16-byte rows of the second layer");
+            // build_nn_from_config (model_utils.py:16-29): Linear(S, H) | Linear(H, H) | Linear(H, 1) in Module.parameters() order, from the
+            // chain's arena (td3_rn_inner_kernel's deeper reward nets: thread j = unit j, k ascending)
+            const gfloat *rnp = (const gfloat *)(arena + a.a_rn);
+            const gfloat *W0g = rnp, *b0g = rnp + Hrn * S, *W1g = b0g + Hrn, *b1g = W1g + Hrn * Hrn, *Wog = b1g + Hrn, *bog = Wog + Hrn;
+            lfloat *h1 = (lfloat *)rn_h, *h2 = (lfloat *)rn_w;
+            if (tid < Hrn) {
+                float z = 0.0f;
+#pragma unroll
+                for (int k = 0; k < S; ++k) z = fma32(obs[k], W0g[tid * S + k], z);
+                h1[tid] = act_fwd(rn_act, cfg.rn_prelu, z + b0g[tid]);
+            }
+            __syncthreads();
+            if (tid < Hrn) {
+                const gf4 *wr = (const gf4 *)(W1g + tid * Hrn);
+                float z = 0.0f;
+#pragma unroll 1
+                for (int k0 = 0; k0 < Hrn; k0 += 32) {
+                    f32x4 w4[8], h4[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { w4[u] = wr[(k0 >> 2) + u]; h4[u] = *(const lf4 *)(h1 + k0 + 4 * u); }
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) z = fma32(h4[u >> 2][u & 3], w4[u >> 2][u & 3], z);
+                }
+                h2[tid] = act_fwd(rn_act, cfg.rn_prelu, z + b1g[tid]);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float acc = 0.0f;
+#pragma unroll 1
+                for (int j0 = 0; j0 < Hrn; j0 += 32) {
+                    f32x4 h4[8], w4[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { h4[u] = *(const lf4 *)(h2 + j0 + 4 * u); w4[u] = *(const gf4 *)(Wog + j0 + 4 * u); }
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) acc = fma32(h4[u >> 2][u & 3], w4[u >> 2][u & 3], acc);
+                }
+                ctrl[slot] = acc + bog[0];
+            }
+            __syncthreads();
+            return;
+        }
         const float *W0 = rn_w, *b0 = rn_w + Hrn * S;
         for (int j = tid; j < Hrn; j += NT) {
             float z = 0.0f;
@@ -879,45 +1031,55 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         __syncthreads();
     };
 
-    // ---- real-env test phase (BaseAgent.test): ONE episode, actions from the one-row actor + exploration noise (TD3.py:126-129) ----
+    // ---- real-env test phase (BaseAgent.test): T episodes one after the other (the envs of this kernel never terminate: every episode
+    // takes max_steps steps, and the reset row / noise rows of an episode have fixed indices -- td3_rn_inner_kernel's lock-step rollouts
+    // draw the same ones), actions from the one-row actor + exploration noise (TD3.py:126-129) ----
     auto test_phase = [&]() {
         const int64_t nstride = cfg.max_steps;
-        for (int e = tid; e < SD; e += NT) xt_d[e] = EnvT::reset_word(key, STREAM_TEST_RESET, n_test_ep, e);
-        if (tid == 0) ep_rew[0] = 0.0f;
-        __syncthreads();
-        int my_el = 0;
-        float *xt = state + 0;                             // not used by the training loop while a test runs? -- no: keep `state`; use newrow as scratch
-        xt = newrow;                                       // [S] observation
+        float *xt = newrow;                                // [S] observation
         float *at = newrow + 24;                           // [A] action
-        for (int ai = 0; ai < cfg.max_steps; ++ai) {
-            KSUB_RESET;
-            if (tid < S) xt[tid] = EnvT::obs(tid, xt_d);
+        if constexpr (T > 1) {
             __syncthreads();
-            KSUB_MARK(12);
-            actor_row1(xt, at);
-            KSUB_MARK(13);
-            const float zn = step_noise(STREAM_TD3_TEST_NOISE, n_testn + ai);
-            if (tid < A) {
-                const float v = at[tid] + (zn * (float)cfg.action_std) * ma;
-                at[tid] = v < -ma ? -ma : (v > ma ? ma : v);
+            t3w_test_steps<SHAPE>(ctx, (uint32_t)key, (uint32_t)(key >> 32), (int)n_test_ep, (int)n_testn);      // (ends with a barrier)
+            test_steps += T * cfg.max_steps;
+            if (G >= 3) act_lds_load();                    // the routine used bufA
+        } else
+#pragma unroll 1
+        for (int te = 0; te < T; ++te) {
+            for (int e = tid; e < SD; e += NT) xt_d[e] = EnvT::reset_word(key, STREAM_TEST_RESET, n_test_ep + te, e);
+            if (tid == 0) ep_rew[te] = 0.0f;
+            __syncthreads();
+            int my_el = 0;
+            for (int ai = 0; ai < cfg.max_steps; ++ai) {
+                KSUB_RESET;
+                if (tid < S) xt[tid] = EnvT::obs(tid, xt_d);
+                __syncthreads();
+                KSUB_MARK(12);
+                actor_row1(xt, at);
+                KSUB_MARK(13);
+                const float zn = step_noise(STREAM_TD3_TEST_NOISE, n_testn + (int64_t)te * nstride + ai);
+                if (tid < A) {
+                    const float v = at[tid] + (zn * (float)cfg.action_std) * ma;
+                    at[tid] = v < -ma ? -ma : (v > ma ? ma : v);
+                }
+                __syncthreads();
+                KSUB_MARK(14);
+                double nx = 0.0, pre = 0.0;
+                if (tid < SD) nx = env_step_word(tid, xt_d, at);
+                if (tid == 0) pre = EnvT::reward_pre(xt_d, at);
+                __syncthreads();
+                if (tid < SD) xt_d[tid] = nx;
+                __syncthreads();
+                if (tid == 0) ep_rew[te] = ep_rew[te] + (float)(0.0 + EnvT::reward_post(xt_d, pre));
+                ++my_el;
+                __syncthreads();
+                KSUB_MARK(15);
             }
-            __syncthreads();
-            KSUB_MARK(14);
-            double nx = 0.0, pre = 0.0;
-            if (tid < SD) nx = env_step_word(tid, xt_d, at);
-            if (tid == 0) pre = EnvT::reward_pre(xt_d, at);
-            __syncthreads();
-            if (tid < SD) xt_d[tid] = nx;
-            __syncthreads();
-            if (tid == 0) ep_rew[0] = ep_rew[0] + (float)(0.0 + EnvT::reward_post(xt_d, pre));
-            ++my_el;
-            __syncthreads();
-            KSUB_MARK(15);
+            if (tid == 0) { ret[te] = (double)ep_rew[te]; tlen[te] = my_el; }
+            test_steps += my_el;
         }
-        if (tid == 0) { ret[0] = (double)ep_rew[0]; tlen[0] = my_el; }
-        n_test_ep += 1;
-        n_testn += nstride;
-        test_steps += my_el;
+        n_test_ep += T;
+        n_testn += (int64_t)T * nstride;
         __syncthreads();
     };
 
@@ -1059,7 +1221,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                     {
                         const T3vNet n1{ params + PN, w2u + IMG, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1 };
                         const T3vNet n2{ params + 2 * PN, w2u + 2 * IMG, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B };
-                        t3v_wgrad<ACT, SA, 1>(ctx, 2, n1, n2, xc, SA, 20);                 // critic_optimizer (+ Polyak of the two critics)
+                        t3v_wgrad<ACT, SA, 1, SA>(ctx, 2, n1, n2, xc, SA, 20);                 // critic_optimizer (+ Polyak of the two critics)
                     }
                     TPT_MARK(5);
                     ++learn_it;
@@ -1084,7 +1246,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                     __syncthreads();
                     {
                         const T3vNet na{ params, w2u, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B };
-                        t3v_wgrad<ACT, S, A>(ctx, 1, na, na, xc, SA, 22);                  // actor_optimizer (+ Polyak of the actor)
+                        t3v_wgrad<ACT, S, A, SA>(ctx, 1, na, na, xc, SA, 22);                  // actor_optimizer (+ Polyak of the actor)
                     }
                     TPT_MARK(7);
                     team_barrier();
@@ -1184,7 +1346,9 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         test_phase();
         TPT_MARK(9);
         if (tid == 0) {
-            const double tm = ret[0] / (double)T;
+            double sm_ = 0.0;
+            for (int i = 0; i < T; ++i) sm_ += ret[i];
+            const double tm = sm_ / (double)T;
             meter[episode] = tm;
             if (g == 0 && a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
             int brk = 0;
@@ -1266,11 +1430,16 @@ using namespace lenv;
 // the published cfg-5 shape in production form (checked by the caller: counter RNG, no trace, no hp, no ICM)
 int lenv_wc_td3_shape(const lenv_td3_cfg *cfg)
 {
-    if (cfg->env_id == LENV_ENV_CHEETAH_STANDIN && cfg->state_dim == 17 && cfg->action_dim == 6 && cfg->hidden == 128 && cfg->layers == 2 &&
-        cfg->batch_size == T3W_B && cfg->test_episodes == 1 && cfg->rn_hidden == 128 && cfg->rn_layers == 1 && !cfg->virtual_env &&
-        (cfg->same_action_num <= 1) && cfg->act == LENV_ACT_RELU && cfg->policy_delay == 1 && !cfg->icm_enabled &&
-        (cfg->reward_env_type == 0 || cfg->reward_env_type == 1 || cfg->reward_env_type == 2 || cfg->reward_env_type == 5 || cfg->reward_env_type == 6))
+    if (!(cfg->hidden == 128 && cfg->layers == 2 && cfg->batch_size == T3W_B && cfg->rn_hidden == 128 && !cfg->virtual_env && cfg->same_action_num <= 1 &&
+          cfg->policy_delay == 1 && !cfg->icm_enabled &&
+          (cfg->reward_env_type == 0 || cfg->reward_env_type == 1 || cfg->reward_env_type == 2 || cfg->reward_env_type == 5 || cfg->reward_env_type == 6)))
+        return 0;
+    if (cfg->env_id == LENV_ENV_CHEETAH_STANDIN && cfg->state_dim == 17 && cfg->action_dim == 6 && cfg->test_episodes == 1 && cfg->rn_layers == 1 &&
+        cfg->act == LENV_ACT_RELU)
         return 1;
+    if (cfg->env_id == LENV_ENV_PENDULUM && cfg->state_dim == 3 && cfg->action_dim == 1 && cfg->test_episodes == 10 && cfg->rn_layers == 2 &&
+        cfg->act == LENV_ACT_LEAKYRELU)
+        return 2;
     return 0;
 }
 
@@ -1285,6 +1454,7 @@ static void t3w_offsets(const lenv_td3_cfg *cfg, int64_t rb_cap, int RS, T3wArgs
     a.a_gx = take(2 * (int64_t)B + (int64_t)B * 6);             // team exchange: dq1 | dq2 | dz
     a.a_bar = take(16);                                          // team barrier counter (one cache line of its own would be 32 floats; the slot is padded below)
     a.a_w2u = take(3 * (int64_t)wc::IMG);                        // team path: unit-major copies W2u[j][k] of the three online second layers
+    a.a_rn = take(cfg->rn_layers > 1 ? lenv_rn_num_params(cfg->reward_env_type, cfg->state_dim, cfg->info_dim, cfg->rn_hidden, cfg->rn_layers) : 0);   // a deeper reward net
     *total = (off + 63) & ~(int64_t)63;
 }
 
@@ -1300,13 +1470,15 @@ __global__ void t3w_team_reset_kernel(float *arena, int64_t arena_stride, int64_
 }
 }
 
-static size_t t3w_lds_bytes(int P_rn)
+static size_t t3w_lds_bytes(int shape, int P_rn)
 {
-    const int B = T3W_B, T = 1;
-    const size_t lds_floats = 2 * (size_t)wc::IMG + 2 * (2 * wc::W + 8 * wc::W + 8) + ((P_rn + 3) & ~3) + 128 + 8 * (size_t)B + 2 * wc::W + 64 + 2 + 2 * (20 + 17 * T + T) + 2 * T + 1 +
+    const int B = T3W_B, T = kT3wShapes[shape].T;
+    const size_t rn_floats = kT3wShapes[shape].rn_layers == 1 ? (size_t)((P_rn + 3) & ~3) : 128;      // the net itself, or the second hidden row
+    const size_t lds_floats = 2 * (size_t)wc::IMG + 2 * (2 * wc::W + 8 * wc::W + 8) + rn_floats + 128 + 8 * (size_t)B + 2 * wc::W + 64 + 2 + 2 * (20 + 17 * T + T) + 2 * T + 1 +
                               20 + 8 + 56 + 4 + (sizeof(T3wCtx) + 3) / 4;
     return lds_floats * sizeof(float);
 }
+static void (*t3w_kernel(int shape))(const T3wArgs) { return shape == 2 ? td3_wavechain_kernel<2> : td3_wavechain_kernel<1>; }
 
 // Workgroups per chain.  A team only works when every workgroup of the launch is resident at the same time (its members wait for each
 // other): 8 * ceil(chains / 8) * G workgroups must fit the device (occupancy API: one per CU at this kernel's LDS footprint).  192
@@ -1316,10 +1488,12 @@ static int t3w_pick_team(const lenv_td3_cfg *cfg, int64_t chains)
     const int want = cfg->team_size > 0 ? cfg->team_size : 6;
     if (want == 1 || chains < 1) return 1;
     const int P_rn = (int)lenv_rn_num_params(cfg->reward_env_type, cfg->state_dim, cfg->info_dim, cfg->rn_hidden, cfg->rn_layers);
-    void (*kern)(const T3wArgs) = td3_wavechain_kernel<1>;
+    const int shape = lenv_wc_td3_shape(cfg);
+    if (!shape) return 1;
+    void (*kern)(const T3wArgs) = t3w_kernel(shape);
     const int64_t padded = 8 * ((chains + 7) / 8);
     for (int G : { 6, 3, 2 })
-        if (G <= want && lenv_team_grid_resident(reinterpret_cast<const void *>(kern), wc::NT, t3w_lds_bytes(P_rn), padded * G)) return G;
+        if (G <= want && lenv_team_grid_resident(reinterpret_cast<const void *>(kern), wc::NT, t3w_lds_bytes(shape, P_rn), padded * G)) return G;
     return 1;
 }
 
@@ -1344,9 +1518,11 @@ int lenv_wc_td3_launch(const lenv_td3_cfg *cfg, const float *theta, const float 
     int64_t total;
     t3w_offsets(cfg, rb_cap, RS, a, &total);
     if (total > arena_stride) return LENV_ERR_WORKSPACE;
-    const size_t lds_bytes = t3w_lds_bytes(P_rn);
+    const int shape = lenv_wc_td3_shape(cfg);
+    if (!shape) return LENV_ERR_UNSUPPORTED;
+    const size_t lds_bytes = t3w_lds_bytes(shape, P_rn);
     if (lds_bytes > 160 * 1024) return LENV_ERR_UNSUPPORTED;
-    void (*kern)(const T3wArgs) = td3_wavechain_kernel<1>;
+    void (*kern)(const T3wArgs) = t3w_kernel(shape);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return LENV_ERR_LAUNCH;
     a.chains = chains;
     a.G = t3w_pick_team(cfg, chains);

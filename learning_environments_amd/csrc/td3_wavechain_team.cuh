@@ -444,13 +444,13 @@ __device__ unsigned long long g_t3v_jobs[2][5][2];
 #define TJOB_ADD(cls)
 #endif
 
-template <int ACT, int IN, int OUT>
+template <int ACT, int IN, int OUT, int LDX>
 __device__ __noinline__ void t3v_wgrad(const T3wCtx *ctx_, int nnets_, const T3vNet n0_, const T3vNet n1_, const float *X_, int ldx_, int ac_slot_)
 {
     T3W_CTX_PROLOGUE;
     const int nnets = uni(nnets_), ac_slot = uni(ac_slot_);
     (void)ldx_;
-    constexpr int in = IN, out = OUT, B = T3W_B, LDX = 23;       // X = the gathered [s, a] rows (ld = S + A); the actor reads their first S columns
+    constexpr int in = IN, out = OUT, B = T3W_B;                 // X = the gathered [s, a] rows (LDX = S + A); the actor reads their first S columns
     const float *X = uni_ptr(X_);
     const int64_t o_t = 3 * PN, o_m = 6 * PN, o_v = 9 * PN;     // params | targets | adam_m | adam_v (3 nets each)
     volatile lfloat *ctrl = (volatile lfloat *)uni_ptr(c->ctrl);

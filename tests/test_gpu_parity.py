@@ -2608,6 +2608,58 @@ def test_wavechain_td3_kernel_equals_gemm_queue_kernel(eng, orc):
         assert np.array_equal(x, y, equal_nan=True)
     assert not np.array_equal(a[4], init)
 
+def test_wavechain_td3_pendulum_shape_every_team_size(eng, orc):
+    """The TD3 wave-chain kernel's second shape -- default_config_pendulum_reward_env.yaml: Pendulum-v0, actor 3-128-128-1, twin critics
+    4-128-128-1, leakyrelu, batch 192, TEN test episodes per test phase, a reward net with TWO hidden layers (PReLU, potential shaping) --
+    in production launches with G = 1, 2, 3, 6 workgroups per chain against (i) the GEMM-queue kernel on the same inputs and (ii) the
+    oracle on two whole chains: scores, counters, per-episode test means, the ten final returns and all 50 947 parameters, bit for bit."""
+    import ctypes as C
+    from learning_environments_amd import _lib, configs
+    from learning_environments_amd.agents.nes_common import chain_keys
+    cfgd = configs.fixed_work(configs.pendulum_reward_env_td3(2), 3)
+    cfgd["agents"]["td3"]["init_episodes"] = 1
+    cfgd["envs"]["Pendulum-v0"]["max_steps"] = 30
+    ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
+    assert (cfg.state_dim, cfg.action_dim, cfg.hidden, cfg.layers, cfg.batch_size, cfg.test_episodes, cfg.rn_layers, cfg.policy_delay) == (3, 1, 128, 2, 192, 10, 2, 1)
+    chains = 5
+    Pa, Pc = orc.td3_param_counts(ocfg)
+    assert Pa + 2 * Pc == (3 * 128 + 128 + 128 * 128 + 128 + 128 + 1) + 2 * (4 * 128 + 128 + 128 * 128 + 128 + 128 + 1)
+    P_rn = orc.rn_num_params(2, 3, 0, 128, 2)
+    assert P_rn == 3 * 128 + 128 + 128 * 128 + 128 + 128 + 1
+    rng = np.random.RandomState(17)
+    theta = (rng.randn(P_rn) * 0.1).astype(np.float32)
+    eps = (rng.randn(2, P_rn) * 0.05).astype(np.float32)
+    worker = (np.arange(chains) // 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), 2)[:chains].copy()
+    keys = chain_keys(81, 2, worker, np.arange(chains) % 3)
+    init = rng.uniform(-0.08, 0.08, (chains, Pa + 2 * Pc)).astype(np.float32)
+
+    def run(trace_cap):
+        il = eng.Td3InnerLoop(cfg, chains, trace_cap=trace_cap, want_final_params=True, want_episode_stats=True)
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return [t.cpu().numpy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_params)]
+
+    ref = run(2)                                            # GEMM-queue kernel (a launch with a step trace)
+    assert ref[1][:, 2].min() == 60 and ref[3].shape == (chains, 10)
+    assert _lib.lib().lenv_td3_rn_team_size(C.byref(cfg), chains) == 6
+    for G in (1, 2, 3, 6):
+        cfg.team_size = G
+        out = run(0)
+        for x, y in zip(out, ref):
+            assert np.array_equal(x, y, equal_nan=True), G
+    assert not np.array_equal(ref[4], init)
+    for c in (0, 4):
+        w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+        o = orc.td3_rn_chain(ocfg, w, init[c], rng_key=int(keys[c]), want_final_params=True)
+        assert float(ref[0][c]) == o["score"]
+        assert ref[1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(ref[2][c], o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(ref[3][c], o["final_test_returns"])
+        assert np.array_equal(ref[4][c], o["final_params"])
+
+
 @pytest.mark.parametrize("chains", [5, 11])
 def test_wavechain_td3_team_sizes_agree(eng, orc, chains):
     """A chain run by a team of G = 2, 3, 6 workgroups (sample blocks and gradient tiles dealt over the team, six agent-scope

@@ -87,6 +87,18 @@ if __name__ == "__main__":
             c["envs"]["Acrobot-v1"]["max_steps"] = 100
             c["agents"]["gtn"]["kernel_variant"] = variant
             run("Acrobot SE + DDQN 6-128-128-3 pop 32 (3 episodes x 100 steps), " + label, c, gens=2)
+    if "pendulum_td3" in which:
+        # default_config_pendulum_reward_env.yaml (TD3 3-128-128-1 / 4-128-128-1 leakyrelu, B = 192, ten test episodes, reward net with two
+        # hidden layers) at its own population (16 workers = 48 chains) and at 32 workers = 96 chains: the wave-chain kernel's second TD3
+        # shape (teams of 3 / 2), then the same launches on the GEMM-queue kernel
+        from learning_environments_amd import _lib
+        for pop in (16, 32):
+            for variant, label in ((0, "wave-chain kernel"), (_lib.VARIANT_NO_WAVECHAIN, "GEMM-queue kernel")):
+                c = configs.fixed_work(configs.pendulum_reward_env_td3(pop), 3)
+                c["agents"]["td3"]["init_episodes"] = 1
+                c["envs"]["Pendulum-v0"]["max_steps"] = 100
+                c["agents"]["gtn"]["kernel_variant"] = variant
+                run("Pendulum RN + TD3 pop %d (3 episodes x 100 steps), %s" % (pop, label), c, gens=2)
     if "td3d" in which:
         # TD3_discrete_vary as the syn-env YAMLs ship it (510-wide tanh nets, batch 122, hard Gumbel softmax) on an Acrobot SE
         c = configs.fixed_work(configs.acrobot_syn_env_td3_discrete(32), 3)

@@ -1,3 +1,4 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-timeout 600 python tools/bench_configs.py acrobot_ddqn 3 2>&1 | grep "^{"
+timeout 900 python -m pytest tests -m gpu -q -x -k "wavechain_td3" 2>&1 | tail -25
+timeout 600 python tools/bench_configs.py pendulum_td3 2>&1 | grep "^{\|Error\|error" | cut -c1-330
