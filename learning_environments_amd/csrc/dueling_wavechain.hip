@@ -296,6 +296,8 @@ template <int SHAPE> __device__ __noinline__ void wc_test_steps(const WcCtx *ctx
 #pragma unroll
     for (int k = 0; k < S; ++k) w[k] = online[oW1t + k * W + j];
     const float bj = online[ob1 + j];
+    const f32x4 bv2 = thin_bias16(online + ob2, wave, L), bv3 = PL ? bv2 : thin_bias16(online + ob3, wave, L),
+                bvv = PL ? bv2 : thin_bias16(online + obv1, wave, L), bva = PL ? bv2 : thin_bias16(online + oba1, wave, L);
     for (int e = tid; e < 4 * W + 4; e += NT) sm_wh_l[e] = online[oWh + e];
     auto put_obs = [&]() {
         double st[4] = { dstate[tid * 4], dstate[tid * 4 + 1], dstate[tid * 4 + 2], dstate[tid * 4 + 3] };
@@ -314,12 +316,12 @@ template <int SHAPE> __device__ __noinline__ void wc_test_steps(const WcCtx *ctx
             ((lfloat *)imgX)[j * IW + i] = act_fwd(ACT, prelu, z + bj);
         }
         __syncthreads();
-        thin_layer16<ACT, 1>(a2, online + ob2, imgY, a2, nullptr, nullptr, imgX, wave, L, prelu);
+        thin_layer16v<ACT, 1>(a2, bv2, imgY, a2, bv2, nullptr, imgX, wave, L, prelu);
         __syncthreads();
         if constexpr (!PL) {
-            thin_layer16<LENV_ACT_IDENTITY, 1>(a3, online + ob3, imgX, a3, nullptr, nullptr, imgY, wave, L, prelu);
+            thin_layer16v<LENV_ACT_IDENTITY, 1>(a3, bv3, imgX, a3, bv3, nullptr, imgY, wave, L, prelu);
             __syncthreads();
-            thin_layer16<ACT, 2>(av, online + obv1, imgY, aa, online + oba1, imgZ, imgX, wave, L, prelu);
+            thin_layer16v<ACT, 2>(av, bvv, imgY, aa, bva, imgZ, imgX, wave, L, prelu);
             __syncthreads();
         }
         if (tid < 4 * T) {

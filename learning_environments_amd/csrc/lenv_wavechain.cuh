@@ -466,6 +466,38 @@ __device__ __forceinline__ void thin_load16(const float *Wt, int ut, const Lane 
 #pragma unroll
     for (int t = 0; t < 32; ++t) a[t] = wa[4 * t * W];
 }
+// (thin_bias16: the four bias values of this lane's output rows -- a loop over many forwards of the same net loads them once)
+__device__ __forceinline__ f32x4 thin_bias16(const float *bias, int ut, const Lane &L) { return *(const gf4 *)((const gfloat *)bias + 16 * ut + 4 * (L.lane >> 4)); }
+template <int ACT, int NOUT>
+__device__ __forceinline__ void thin_layer16v(const float (&a0)[32], const f32x4 bv0, float *out0_, const float (&a1)[32], const f32x4 bv1, float *out1_,
+                                              const float *in_img_, int ut, const Lane &L, float prelu)
+{
+    const lfloat *in_img = (const lfloat *)in_img_;
+    const int l16 = L.lane & 15, q = L.lane >> 4;
+    const lfloat *xb = in_img + q * 16 + l16;
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const float x = xb[4 * t * 16];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], x, acc0, 0, 0, 0);
+        if (NOUT == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], x, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        const f32x4 acc = o == 0 ? acc0 : acc1;
+        const f32x4 bv = o == 0 ? bv0 : bv1;
+        lfloat *out = (lfloat *)(o == 0 ? out0_ : out1_) + (16 * ut + 4 * q) * 16 + l16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float z = acc[c] + bv[c];
+            if (ACT == LENV_ACT_RELU) z = z > 0.0f ? z : 0.0f;
+            else if (ACT == LENV_ACT_LEAKYRELU) z = z > 0.0f ? z : z * 0.01f;
+            else if (ACT == LENV_ACT_PRELU) z = z > 0.0f ? z : prelu * z;
+            else if (ACT == LENV_ACT_TANH) z = det_tanhf(lenv_tanh_table, z);
+            out[c * 16] = z;
+        }
+    }
+}
 template <int ACT, int NOUT>
 __device__ __forceinline__ void thin_layer16(const float (&a0)[32], const float *bias0, float *out0_, const float (&a1)[32], const float *bias1, float *out1_,
                                              const float *in_img_, int ut, const Lane &L, float prelu)

@@ -555,7 +555,8 @@ template <int SHAPE> __device__ __noinline__ void t3w_test_steps(const T3wCtx *c
     constexpr T3wShape SP = kT3wShapes[SHAPE];
     using EnvT = ContEnv<SP.env>;
     constexpr int S = EnvT::S, A = EnvT::A, SD = EnvT::SD, ACT = SP.act, T = SP.T, IW = 16, NB = 32;      // NB: steps per noise batch
-    static_assert(T <= 16 && T * SD <= NT && T * A * NB <= 2 * NT, "one 16-sample tile");
+    constexpr bool CHEETAH = SP.env == LENV_ENV_CHEETAH_STANDIN;
+    static_assert(T <= 16 && T * SD <= NT, "one 16-sample tile");
     Lane L;
     L.init();
     const int tid = L.tid, wave = L.wave;
@@ -586,7 +587,26 @@ template <int SHAPE> __device__ __noinline__ void t3w_test_steps(const T3wCtx *c
 #pragma unroll
     for (int k = 0; k < S; ++k) w[k] = ((const gfloat *)par)[oW1t + k * W + j];
     const float bj = ((const gfloat *)par)[ob1 + j];
+    const f32x4 bv2 = thin_bias16(par + ob2, wave, L);
     for (int e = tid; e < 8 * W + 8; e += NT) whl[e] = ((const gfloat *)par)[oWo + e];      // (Wo and bo are contiguous)
+    // the stand-in's dynamics constants (A [17][17], B [17][6], c [17] doubles) in LDS instead of 23 scattered 8-byte global loads per word
+    ldouble *chA = (ldouble *)(whl + 8 * W + 8), *chB = chA + 17 * 17, *chC = chB + 17 * 6;
+    if constexpr (CHEETAH) {
+        for (int i = tid; i < 17 * 17; i += NT) chA[i] = lenv_cheetah_A[i];
+        if (tid < 17 * 6) chB[tid] = lenv_cheetah_B[tid];
+        if (tid < 17) chC[tid] = lenv_cheetah_c[tid];
+    }
+    // word i of x' = clip(c + A x + B a, -10, 10): EnvT::step_word with the constants from LDS (same operations in the same order)
+    auto step_word = [&](int i, const ldouble *x, const lfloat *av) -> double {
+        if constexpr (CHEETAH) {
+            double acc = chC[i];
+#pragma unroll
+            for (int jj = 0; jj < 17; ++jj) acc = acc + chA[i * 17 + jj] * x[jj];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc = acc + chB[i * 6 + k] * (double)av[k];
+            return acc < -10.0 ? -10.0 : (acc > 10.0 ? 10.0 : acc);
+        } else return EnvT::step_word(i, (const double *)x, (const float *)av);
+    };
     __syncthreads();
     if (tid < T * S) { const int te = tid / S; Xl[tid] = EnvT::obs(tid - te * S, (const double *)(xt_d + te * SD)); }
     __syncthreads();
@@ -605,7 +625,7 @@ template <int SHAPE> __device__ __noinline__ void t3w_test_steps(const T3wCtx *c
             ((lfloat *)imgX)[j * IW + i] = act_fwd(ACT, prelu, z + bj);
         }
         __syncthreads();
-        thin_layer16<ACT, 1>(a2, par + ob2, imgY, a2, nullptr, nullptr, imgX, wave, L, prelu);
+        thin_layer16v<ACT, 1>(a2, bv2, imgY, a2, bv2, nullptr, imgX, wave, L, prelu);
         __syncthreads();
         if (tid < T * A) {                                 // output layer + tanh, exploration noise, clamp
             const int i = tid / A, o = tid - i * A;
@@ -620,7 +640,7 @@ template <int SHAPE> __device__ __noinline__ void t3w_test_steps(const T3wCtx *c
         __syncthreads();
         double nx = 0.0, pre = 0.0;
         const int wte = tid / SD;
-        if (tid < T * SD) nx = EnvT::step_word(tid - wte * SD, (const double *)(xt_d + wte * SD), (const float *)(at + wte * A));
+        if (tid < T * SD) nx = step_word(tid - wte * SD, xt_d + wte * SD, at + wte * A);
         if (tid < T) pre = EnvT::reward_pre((const double *)(xt_d + tid * SD), (const float *)(at + tid * A));
         __syncthreads();
         if (tid < T * SD) xt_d[tid] = nx;
@@ -1038,7 +1058,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         const int64_t nstride = cfg.max_steps;
         float *xt = newrow;                                // [S] observation
         float *at = newrow + 24;                           // [A] action
-        if constexpr (T > 1) {
+        if constexpr (T > 1) {                              // (measured for the one-episode shape too: 9 % slower there than the LDS-resident one-row actor)
             __syncthreads();
             t3w_test_steps<SHAPE>(ctx, (uint32_t)key, (uint32_t)(key >> 32), (int)n_test_ep, (int)n_testn);      // (ends with a barrier)
             test_steps += T * cfg.max_steps;
