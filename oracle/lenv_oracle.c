@@ -448,10 +448,15 @@ int orc_qnet_td_forward(const orc_mlp_desc *q, const float *online, const float 
 
 /* One DDQN.learn step (DDQN.py:60-94) on an explicit minibatch `rows` [B, row_stride]:
  * MSE TD loss, backward, torch.optim.Adam single-tensor step, Polyak target update. */
+static void mlp_backward_one_ex(const orc_mlp_desc *d, const float *p, const float *x, float z[][ORC_MAX_WIDTH],
+                                float a[][ORC_MAX_WIDTH], float xh[][ORC_MAX_WIDTH], const float *rstd, const float *dout,
+                                float *g, float *gln, float *dx);
+static void mlp_fold_ln_grads(const orc_mlp_desc *d, const float *gln, float *g);
+
 float orc_ddqn_learn(const orc_ddqn_cfg *cfg, float *online, float *target, float *adam_m, float *adam_v,
                      int64_t step, double *b1pow, double *b2pow, const float *rows, int64_t row_stride)
 {
-    orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu, 0 };
+    orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu, cfg->q_layer_norm };
     const int S = cfg->state_dim, H = cfg->q_hidden, L = cfg->q_layers, A = cfg->num_actions, B = cfg->batch_size;
     const int64_t P = orc_mlp_num_params(&qd);
     const int chunk = cfg->grad_chunk > 0 ? cfg->grad_chunk : B;
@@ -465,6 +470,11 @@ float orc_ddqn_learn(const orc_ddqn_cfg *cfg, float *online, float *target, floa
     const float g32 = (float)cfg->gamma;
     const float norm = (float)(2.0 / (double)B);   /* mse_loss backward: 2/numel */
     float loss_acc = 0.0f;
+    /* use_layer_norm with two or more hidden layers: the generic per-sample backward (LayerNorm positions, shared weight / bias) */
+    const int ln = qd.use_layer_norm && L >= 2;
+    float (*xh)[ORC_MAX_WIDTH] = ln ? malloc(sizeof(float) * ORC_MAX_LAYERS * ORC_MAX_WIDTH) : NULL;
+    float rstd[ORC_MAX_LAYERS];
+    float *gln = ln ? malloc(sizeof(float) * (size_t)(L - 1) * 2 * H) : NULL;
 
     /* layer offsets */
     int64_t offW[ORC_MAX_LAYERS + 1], offb[ORC_MAX_LAYERS + 1];
@@ -478,6 +488,7 @@ float orc_ddqn_learn(const orc_ddqn_cfg *cfg, float *online, float *target, floa
     for (int b0 = 0; b0 < B; b0 += chunk) {
         int b1 = b0 + chunk < B ? b0 + chunk : B;
         memset(gch, 0, sizeof(float) * P);
+        if (ln) memset(gln, 0, sizeof(float) * (size_t)(L - 1) * 2 * H);
         for (int b = b0; b < b1; ++b) {
             const float *row = rows + (int64_t)b * row_stride;
             const float *s = row, *s2 = row + S + 1;
@@ -485,7 +496,7 @@ float orc_ddqn_learn(const orc_ddqn_cfg *cfg, float *online, float *target, floa
             float r = row[2 * S + 1], d = row[2 * S + 2];
             mlp_forward_one(&qd, online, s2, qn, z2, a2);
             mlp_forward_one(&qd, target, s2, qt, z2, a2);
-            mlp_forward_one(&qd, online, s, qs, z, a);
+            mlp_forward_one_ex(&qd, online, s, qs, z, a, xh, ln ? rstd : NULL);
             int am = argmax_first(qn, A);
             float t1 = g32 * qt[am];
             float t2 = 1.0f - d;
@@ -493,6 +504,12 @@ float orc_ddqn_learn(const orc_ddqn_cfg *cfg, float *online, float *target, floa
             float diff = qs[act] - yv;
             loss_acc = fmaf(diff, diff, loss_acc);
             float dq = norm * diff;
+            if (ln) {
+                float dout[ORC_MAX_WIDTH];
+                for (int o = 0; o < A; ++o) dout[o] = o == act ? dq : 0.0f;
+                mlp_backward_one_ex(&qd, online, s, z, a, xh, rstd, dout, gch, gln, NULL);
+                continue;
+            }
             /* output layer: only row `act` of dQ is non-zero */
             {
                 float *gW = gch + offW[L] + (int64_t)act * H;
@@ -524,6 +541,7 @@ float orc_ddqn_learn(const orc_ddqn_cfg *cfg, float *online, float *target, floa
                 }
             }
         }
+        if (ln) mlp_fold_ln_grads(&qd, gln, gch);
         if (first_chunk) { memcpy(grad, gch, sizeof(float) * P); first_chunk = 0; }
         else for (int64_t i = 0; i < P; ++i) grad[i] = grad[i] + gch[i];
     }
@@ -548,7 +566,7 @@ float orc_ddqn_learn(const orc_ddqn_cfg *cfg, float *online, float *target, floa
         adam_m[i] = m; adam_v[i] = v; online[i] = p;
         target[i] = tau * p + omt * target[i];                    /* DDQN.py:92-93 */
     }
-    free(z); free(a); free(z2); free(a2); free(grad); free(gch);
+    free(z); free(a); free(z2); free(a2); free(grad); free(gch); free(xh); free(gln);
     return loss_acc / (float)B;
 }
 
@@ -560,7 +578,7 @@ typedef struct { orc_mlp_desc feat, val, adv; int64_t p_feat, p_val, p_adv, P; }
 static void dueling_layout_of(const orc_ddqn_cfg *cfg, dueling_layout *L)
 {
     const int F = cfg->feature_dim;
-    L->feat = (orc_mlp_desc){ cfg->state_dim, cfg->q_hidden, cfg->q_layers, F, cfg->q_act, cfg->q_prelu, 0 };
+    L->feat = (orc_mlp_desc){ cfg->state_dim, cfg->q_hidden, cfg->q_layers, F, cfg->q_act, cfg->q_prelu, cfg->q_layer_norm };
     /* heads_config: hidden_layer = 1, hidden_size = feature_dim (actor_critic.py:103-105) */
     L->val = (orc_mlp_desc){ F, F, 1, 1, cfg->q_act, cfg->q_prelu, 0 };
     L->adv = (orc_mlp_desc){ F, F, 1, cfg->num_actions, cfg->q_act, cfg->q_prelu, 0 };
@@ -580,13 +598,14 @@ int64_t orc_dueling_num_params(const orc_ddqn_cfg *cfg)
 /* per-sample scratch of one dueling forward */
 typedef struct {
     float zf[ORC_MAX_LAYERS][ORC_MAX_WIDTH], af[ORC_MAX_LAYERS][ORC_MAX_WIDTH];
+    float xhf[ORC_MAX_LAYERS][ORC_MAX_WIDTH], rstdf[ORC_MAX_LAYERS];      /* the feature stream's LayerNorm positions (q_layer_norm) */
     float zv[1][ORC_MAX_WIDTH], av[1][ORC_MAX_WIDTH], za[1][ORC_MAX_WIDTH], aa[1][ORC_MAX_WIDTH];
     float feat[ORC_MAX_WIDTH], V, adv[64];
 } dueling_act;
 
 static void dueling_forward_one(const dueling_layout *L, const float *p, const float *x, dueling_act *s)
 {
-    mlp_forward_one(&L->feat, p, x, s->feat, s->zf, s->af);                       /* no activation after the last Linear */
+    mlp_forward_one_ex(&L->feat, p, x, s->feat, s->zf, s->af, s->xhf, s->rstdf);  /* no activation after the last Linear */
     mlp_forward_one(&L->val, p + L->p_feat, s->feat, &s->V, s->zv, s->av);
     mlp_forward_one(&L->adv, p + L->p_feat + L->p_val, s->feat, s->adv, s->za, s->aa);
 }
@@ -749,9 +768,13 @@ float orc_dueling_learn(const orc_ddqn_cfg *cfg, float *online, float *target, f
     const float mean_grad = (-S_dq) / (float)(B * A);   /* backward of `- advantages.mean()` */
     int first_chunk = 1;
     float dadv[64], dfeat_v[ORC_MAX_WIDTH], dfeat_a[ORC_MAX_WIDTH], dfeat[ORC_MAX_WIDTH];
+    const int ln = L.feat.use_layer_norm && L.feat.layers >= 2;
+    const size_t gln_n = ln ? (size_t)(L.feat.layers - 1) * 2 * L.feat.hidden : 0;
+    float *gln = ln ? malloc(sizeof(float) * gln_n) : NULL;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int b1 = b0 + chunk < B ? b0 + chunk : B;
         memset(gch, 0, sizeof(float) * P);
+        if (ln) memset(gln, 0, sizeof(float) * gln_n);
         for (int b = b0; b < b1; ++b) {
             const int act = (int)rows[(int64_t)b * row_stride + S];
             for (int a = 0; a < A; ++a) dadv[a] = (a == act ? dq[b] : 0.0f) + mean_grad;
@@ -760,8 +783,9 @@ float orc_dueling_learn(const orc_ddqn_cfg *cfg, float *online, float *target, f
             mlp_backward_one(&L.adv, online + L.p_feat + L.p_val, acts[b].feat, acts[b].za, acts[b].aa, dadv,
                              gch + L.p_feat + L.p_val, dfeat_a);
             for (int i = 0; i < F; ++i) dfeat[i] = dfeat_v[i] + dfeat_a[i];
-            mlp_backward_one(&L.feat, online, s_in + (size_t)b * S, acts[b].zf, acts[b].af, dfeat, gch, NULL);
+            mlp_backward_one_ex(&L.feat, online, s_in + (size_t)b * S, acts[b].zf, acts[b].af, acts[b].xhf, acts[b].rstdf, dfeat, gch, gln, NULL);
         }
+        if (ln) mlp_fold_ln_grads(&L.feat, gln, gch);
         if (first_chunk) { memcpy(grad, gch, sizeof(float) * P); first_chunk = 0; }
         else for (int64_t i = 0; i < P; ++i) grad[i] = grad[i] + gch[i];
     }
@@ -783,7 +807,7 @@ float orc_dueling_learn(const orc_ddqn_cfg *cfg, float *online, float *target, f
         adam_m[i] = m; adam_v[i] = v; online[i] = pnew;
         target[i] = tau * pnew + omt * target[i];
     }
-    free(acts); free(s_in); free(s2_in); free(q); free(qn); free(qt); free(dq); free(grad); free(gch);
+    free(acts); free(s_in); free(s2_in); free(q); free(qn); free(qt); free(dq); free(grad); free(gch); free(gln);
     return loss_acc / (float)B;
 }
 
@@ -791,7 +815,7 @@ float orc_dueling_learn(const orc_ddqn_cfg *cfg, float *online, float *target, f
 static int64_t agent_num_params(const orc_ddqn_cfg *cfg)
 {
     if (cfg->agent_kind == 1) return orc_dueling_num_params(cfg);
-    orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu, 0 };
+    orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu, cfg->q_layer_norm };
     return orc_mlp_num_params(&qd);
 }
 
@@ -802,7 +826,7 @@ static int agent_greedy_action(const orc_ddqn_cfg *cfg, const float *params, con
     if (cfg->agent_kind == 1) {
         orc_dueling_forward(cfg, params, obs, 1, q);       /* single state: the mean is over its A advantages */
     } else {
-        orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu, 0 };
+        orc_mlp_desc qd = { cfg->state_dim, cfg->q_hidden, cfg->q_layers, cfg->num_actions, cfg->q_act, cfg->q_prelu, cfg->q_layer_norm };
         mlp_forward_one(&qd, params, obs, q, z, a);
     }
     return argmax_first(q, cfg->num_actions);
@@ -1043,7 +1067,7 @@ static int ddqn_se_chain_impl(const orc_ddqn_cfg *cfg, const float *se_params, c
         r_intr = malloc(sizeof(float) * B);
         memcpy(icm_p, icm_init, sizeof(float) * icm.P);
     }
-    orc_mlp_desc qd = { S, cfg->q_hidden, cfg->q_layers, A, cfg->q_act, cfg->q_prelu, 0 };
+    orc_mlp_desc qd = { S, cfg->q_hidden, cfg->q_layers, A, cfg->q_act, cfg->q_prelu, cfg->q_layer_norm };
     orc_mlp_desc sn = { S + A, cfg->se_hidden, cfg->se_layers, S, cfg->se_act, cfg->se_prelu, 0 };
     orc_mlp_desc rn = sn, dn = sn;
     rn.out_dim = 1; dn.out_dim = 1;

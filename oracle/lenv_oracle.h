@@ -81,7 +81,10 @@ typedef struct {
      * reward_env_type 0, 1, 2, 5, 6 (the real CartPole / Acrobot step returns no info vector) */
     int32_t synthetic_env_type, reward_env_type;
     /* same_action_num (base_agent.py:20,104,194; env_wrapper.py:24-29,56-61): env steps per chosen action; 0 and 1 both mean 1 */
-    int32_t same_action_num, pad2_;
+    int32_t same_action_num;
+    /* `use_layer_norm` of the agent's config section (models/model_utils.py:22-37): ONE shared nn.LayerNorm(hidden) behind every hidden
+     * Linear but the first of the Q-net (Critic_DQN) / of the DuelingDDQN's feature stream (the heads have one hidden layer: none there) */
+    int32_t q_layer_norm;
 } orc_ddqn_cfg;
 
 /* RNG tapes (parity mode): values the reference drew, in per-stream order. */
