@@ -107,7 +107,11 @@ typedef struct {
      * launch reports status -10 within that time, and the caller repeats the launch with team_size 1 (engine.py does). */
     int32_t team_size;
     int32_t kernel_variant;   /* LENV_VARIANT_* bits, 0 = fastest */
-    int32_t pad3_;
+    /* `use_layer_norm` of the agent's config section (models/model_utils.py:22-37): ONE shared nn.LayerNorm(hidden) (eps 1e-5) behind every
+     * hidden Linear but the first of the Q-net (agent_kind 0) / of the DuelingDDQN's feature stream (its heads have one hidden layer: none
+     * there); its weight | bias sit behind the second Linear in the parameter vector (Module.parameters() order), fresh agents start them at
+     * 1 | 0.  Nothing to do with one hidden layer.  GEMM-tiled kernel (lenv_dueling_se_inner_loop*); forward and backward in the loop. */
+    int32_t q_layer_norm;
 } lenv_ddqn_cfg;
 
 /* RNG tapes (parity mode).  Per-chain rows: element [c*stride + n]; all DEVICE pointers. */

@@ -43,7 +43,7 @@ class DdqnCfg(C.Structure):
                 ("same_action_num", C.c_int32),
                 ("team_size", C.c_int32),        # workgroups per chain: 0 = automatic, 1 = never a team, G = at most G
                 ("kernel_variant", C.c_int32),   # VARIANT_* bits, 0 = fastest
-                ("pad3_", C.c_int32)]
+                ("q_layer_norm", C.c_int32)]
 
 
 class Tapes(C.Structure):

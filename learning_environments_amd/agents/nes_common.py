@@ -57,6 +57,22 @@ def linear_init_bounds(layer_dims):
     return np.concatenate(parts)
 
 
+def with_layer_norm_block(bounds, ln_slice):
+    """The bounds vector of a net whose shared nn.LayerNorm (weight | bias, 2 H values) sits at `ln_slice` = (offset, H): bound 0 there --
+    the draw leaves zeros, set_layer_norm_init then writes the weight's ones (nn.LayerNorm: weight 1, bias 0)."""
+    if ln_slice is None:
+        return bounds
+    off, H = ln_slice
+    return np.concatenate([bounds[:off], np.zeros(2 * H, np.float32), bounds[off:]])
+
+
+def set_layer_norm_init(agent_init, ln_slice):
+    if ln_slice is not None and agent_init is not None:
+        off, H = ln_slice
+        agent_init[:, off:off + H] = 1.0
+    return agent_init
+
+
 def fresh_agent_init(bounds, chains, generator, device):
     """`chains` freshly initialised agents (reference: select_agent -> DDQN() per calc_score, agents/agent_utils.py:15-66)."""
     u = torch.rand((chains, bounds.numel()), generator=generator, device=device, dtype=torch.float32)

@@ -13,9 +13,9 @@ Anything else raises NotImplementedError, like the reference does for unknown ag
 import numpy as np
 import torch
 
-from ..config import (TABULAR_AGENTS, TD3_DISCRETE_ENVS, agent_layer_dims, ddqn_cfg_from_config, icm_layer_dims, ql_cfg_from_config,
+from ..config import (TABULAR_AGENTS, TD3_DISCRETE_ENVS, agent_layer_dims, agent_layer_norm_slice, ddqn_cfg_from_config, icm_layer_dims, ql_cfg_from_config,
                       td3_cfg_from_config, td3_layer_dims, td3d_cfg_from_config)
-from .nes_common import chain_keys, fresh_agent_init, linear_init_bounds
+from .nes_common import chain_keys, fresh_agent_init, linear_init_bounds, set_layer_norm_init, with_layer_norm_block
 
 
 class DdqnSeTask(object):
@@ -25,7 +25,8 @@ class DdqnSeTask(object):
         self.engine = engine
         self.cfg = ddqn_cfg_from_config(config) if engine.name == "hip" else engine.cfg_from_config(config)
         dims = agent_layer_dims(self.cfg)
-        self.agent_bounds = torch.from_numpy(linear_init_bounds(dims)).to(engine.device)
+        self.ln_slice = agent_layer_norm_slice(self.cfg)      # use_layer_norm: the shared LayerNorm's block in the flat parameter vector
+        self.agent_bounds = torch.from_numpy(with_layer_norm_block(linear_init_bounds(dims), self.ln_slice)).to(engine.device)
         # "ddqn_icm" / "duelingddqn_icm": the agent carries an Intrinsic Curiosity Module (agents/DDQN.py:40-58); every chain
         # gets a fresh one (nn.Linear default init), drawn from its own counter-RNG stream
         self.icm_bounds = None
@@ -38,6 +39,7 @@ class DdqnSeTask(object):
     def scores(self, inner, theta, eps, chain_worker, chain_sign, keys_t, agent_init):
         if self.icm_bounds is not None:
             inner.draw_icm_init(keys_t, self.icm_bounds)
+        set_layer_norm_init(agent_init, self.ln_slice)
         return self.engine.inner_scores(inner, theta, eps, chain_worker, chain_sign, agent_init, keys_t)
 
     def needs_agent_init(self):

@@ -9,9 +9,9 @@ TD3_MAX_ACTION = {"HalfCheetah-v3": 1.0, "Pendulum-v0": 2.0, "MountainCarContinu
 
 
 def _refuse_layer_norm(config, env_section, agent_section):
-    """The fused inner loops take plain MLPs: `use_layer_norm` (models/model_utils.py:22-29) in the synthetic env's or the
-    agent's section would silently train a different network, so the config builders refuse it (the one-step forward
-    lenv_mlp_forward and the TD3_discrete_vary agent nets are the LayerNorm paths)."""
+    """`use_layer_norm` (models/model_utils.py:22-29) where a fused inner loop would silently train a different network is refused:
+    in the synthetic env's section everywhere, in the agent's section of the tabular / continuous-TD3 loops (the DDQN / DuelingDDQN
+    loop takes it through cfg.q_layer_norm, TD3_discrete_vary through its own field, lenv_mlp_forward in the one-step API)."""
     for name, sec in (("envs." + config["env_name"], env_section), ("agent", agent_section)):
         if sec is not None and sec.get("use_layer_norm", False):
             raise NotImplementedError("use_layer_norm in the %s section: no fused inner loop takes LayerNorm nets here" % name)
@@ -44,7 +44,7 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
     a = config["agents"][agent_key]
     dueling = agent_key == "duelingddqn"
     S, A = ENV_DIMS[env_name]
-    _refuse_layer_norm(config, e, a)
+    _refuse_layer_norm(config, e, None)
 
     def val(v):  # env_factory.py:54-58: list-valued entries -> float(value[1])
         return float(v[1]) if isinstance(v, list) else v
@@ -66,6 +66,9 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
                        adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
                        step_budget=int(a.get("step_budget", 0)))      # env-step stand-in for time_remaining (base_agent.py:30-47)
     cfg.same_action_num = int(a["same_action_num"])    # env steps per chosen action (base_agent.py:104,194); > 1: GEMM-tiled kernel
+    # use_layer_norm: ONE shared nn.LayerNorm behind hidden Linear 2..L of the Q-net / the feature stream (model_utils.py:22-37); a net with
+    # one hidden layer has no position for it (and no parameters: the module is created but never registered)
+    cfg.q_layer_norm = 1 if a.get("use_layer_norm", False) else 0
     _launch_knobs(cfg, config)
     if icm:                                          # config section `icm` (agents/DDQN.py:43-49)
         ic = config["agents"]["icm"]
@@ -100,6 +103,15 @@ def agent_layer_dims(cfg):
         feat = [(S, H)] + [(H, H)] * (L - 1) + [(H, F)]
         return feat + [(F, F), (F, 1)] + [(F, F), (F, A)]
     return [(S, H)] + [(H, H)] * (L - 1) + [(H, A)]
+
+
+def agent_layer_norm_slice(cfg):
+    """(offset, H) of the shared LayerNorm's weight | bias block in the agent's flat parameter vector (behind the second Linear:
+    Module.parameters() order), or None."""
+    if not getattr(cfg, "q_layer_norm", 0) or cfg.q_layers < 2:
+        return None
+    S, H = cfg.state_dim, cfg.q_hidden
+    return (S * H + H) + (H * H + H), H
 
 
 def pick_grad_chunk(cfg):

@@ -16,6 +16,7 @@
 // products by changing strides.  This is the configuration where HBM traffic is real: ~5 MB of weight/Adam streaming
 // per learn step and chain.
 #include "lenv_gemm.cuh"
+#include "lenv_ln.cuh"
 #include "lenv_icm.cuh"
 #include "lenv_wavechain_host.h"
 
@@ -29,8 +30,8 @@ constexpr int D_MAXI = 128;       // rows of one product block
 
 // Arena offsets (floats) of everything whose size follows from the network / batch shapes; the replay buffer, the episode meter and
 // the ICM buffers depend on run-time sizes and are carved after these.  constexpr: literal in the SHAPE 1 instantiation.
-struct DuelArena { int64_t a_online, a_target, a_m, a_v, a_grad, a_xs, a_xs2, a_act[D_MAXL], a_feat, a_v1, a_a1, a_t[6], a_dbuf[5], end; };
-constexpr DuelArena duel_arena(int S, int H, int F, int L, int B, int T, int64_t P)
+struct DuelArena { int64_t a_online, a_target, a_m, a_v, a_grad, a_xs, a_xs2, a_act[D_MAXL], a_feat, a_v1, a_a1, a_t[6], a_dbuf[5], a_xh[D_MAXL], a_rstd, end; };
+constexpr DuelArena duel_arena(int S, int H, int F, int L, int B, int T, int64_t P, bool ln = false)
 {
     DuelArena a{};
     int64_t off = 0;
@@ -43,6 +44,9 @@ constexpr DuelArena duel_arena(int S, int H, int F, int L, int B, int T, int64_t
     a.a_feat = LENV_TAKE64((int64_t)B * F); a.a_v1 = LENV_TAKE64((int64_t)B * F); a.a_a1 = LENV_TAKE64((int64_t)B * F);
     for (int l = 0; l < 6; ++l) a.a_t[l] = LENV_TAKE64(l < L || l >= 3 ? rows * W : 0);
     for (int l = 0; l < 5; ++l) a.a_dbuf[l] = LENV_TAKE64(rows * W);
+    // q_layer_norm: the normalised rows and 1 / sqrt(var + eps) of the LayerNorm positions (hidden layers 1 .. L-1) of the online pass over s
+    for (int l = 0; l < D_MAXL; ++l) a.a_xh[l] = LENV_TAKE64(ln && l >= 1 && l < L ? (int64_t)B * H : 0);
+    a.a_rstd = LENV_TAKE64(ln ? (int64_t)D_MAXL * B : 0);
 #undef LENV_TAKE64
     a.end = off;
     return a;
@@ -72,15 +76,19 @@ struct DuelArgs {
 struct DuelOffsets {
     int oWf[D_MAXL + 1], obf[D_MAXL + 1];     // feature stream: hidden layers 0..L-1, then the output Linear (index L)
     int oWv1, obv1, oWv2, obv2, oWa1, oba1, oWa2, oba2;
+    int oLN;                                  // q_layer_norm with L >= 2: weight [H] | bias [H] of the ONE shared nn.LayerNorm, behind the second Linear (Module.parameters() order)
     int P;
 };
 
-__host__ __device__ constexpr DuelOffsets duel_param_offsets(int S, int A, int H, int F, int L, bool plain)
+__host__ __device__ constexpr DuelOffsets duel_param_offsets(int S, int A, int H, int F, int L, bool plain, bool ln = false)
 {
     DuelOffsets d{};
     int o = 0, n_in = S;
     for (int l = 0; l <= D_MAXL; ++l) d.oWf[l] = d.obf[l] = 0;
-    for (int l = 0; l < L; ++l) { d.oWf[l] = o; o += H * n_in; d.obf[l] = o; o += H; n_in = H; }
+    for (int l = 0; l < L; ++l) {
+        d.oWf[l] = o; o += H * n_in; d.obf[l] = o; o += H; n_in = H;
+        if (ln && l == 1) { d.oLN = o; o += 2 * H; }
+    }
     d.oWf[L] = o; o += F * H; d.obf[L] = o; o += F;
     if (plain) { d.oWv1 = d.obv1 = d.oWv2 = d.obv2 = d.oWa1 = d.oba1 = d.oWa2 = d.oba2 = o; }       // no heads
     else {
@@ -141,7 +149,9 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
         if (tid == 0) { if (a.out.status) a.out.status[chain] = -8; a.out.score[chain] = 0.0; }
         return;
     }
-    const DuelOffsets po = duel_param_offsets(S, A, H, F, L, plain);
+    // `use_layer_norm` of the agent's section (model_utils.py:22-37): the shared LayerNorm behind hidden Linear 2..L of the Q-net / the feature stream
+    const bool ln = FIXED ? false : (cfg.q_layer_norm != 0 && L >= 2);
+    const DuelOffsets po = duel_param_offsets(S, A, H, F, L, plain, ln);
     const int Hse = FIXED ? kDuelShape.Hse : cfg.se_hidden, RS = a.RS, P = po.P, T = FIXED ? kDuelShape.T : cfg.test_episodes;
     const int act_id = FIXED ? kDuelShape.q_act : cfg.q_act, se_act_id = FIXED ? kDuelShape.se_act : cfg.se_act;
     const float prelu = cfg.q_prelu;
@@ -247,11 +257,19 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     // the backward pass), head outputs to slot `slot` of Vb / Advb; after gq.run, finish_q combines them into q_out[I][A]
     // (LDS).  global_mean: mean over all I*A advantages (learn, the reference's batch quirk) or per row.
     GemmQueue gq(cmds);
-    auto queue_forward = [&](const float *par, const float *X, int I, float *const *hid, float *featb, float *v1b, float *a1b, int slot) {
+    constexpr int LNBUF = GemmShape<D_MAXI>::PS_FLOATS + GemmShape<D_MAXI>::QS_FLOATS;
+    auto queue_forward = [&](const float *par, const float *X, int I, float *const *hid, float *featb, float *v1b, float *a1b, int slot,
+                             float *const *xhs = nullptr, float *rstds = nullptr) {
         const float *in = X;
         int n_in = S;
         for (int l = 0; l < L; ++l) {
-            gq.gemm(in, n_in, 1, par + po.oWf[l], n_in, 1, I, H, n_in, epi_bias_act(hid[l], H, par + po.obf[l], act_id, prelu));
+            if (ln && l >= 1) {
+                // a LayerNorm position: Linear + bias, the queue runs (everything queued so far, in order), then the row routine
+                // normalises, scales and applies the activation (lenv_ln.cuh); xhs / rstds: kept for the backward pass
+                gq.gemm(in, n_in, 1, par + po.oWf[l], n_in, 1, I, H, n_in, epi_bias(hid[l], H, 0, par + po.obf[l]));
+                gq.run<D_MAXI>(Ps, Qs);
+                ln_rows_forward<LNBUF>(Ps, hid[l], I, H, par + po.oLN, par + po.oLN + H, xhs ? xhs[l] : nullptr, rstds ? rstds + (int64_t)l * CFG_B : nullptr, act_id, prelu);
+            } else gq.gemm(in, n_in, 1, par + po.oWf[l], n_in, 1, I, H, n_in, epi_bias_act(hid[l], H, par + po.obf[l], act_id, prelu));
             in = hid[l]; n_in = H;
         }
         // feature_stream's last Linear: no activation (build_nn_from_config ends with a Linear)
@@ -314,6 +332,8 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
 
     float *hid_s[D_MAXL], *hid_t[D_MAXL];
     for (int l = 0; l < D_MAXL; ++l) { hid_s[l] = arena + AV(a_act[l]); hid_t[l] = arena + AV(a_t[l]); }
+    float *xh_s[D_MAXL], *rstd_s = arena + AV(a_rstd);
+    for (int l = 0; l < D_MAXL; ++l) xh_s[l] = arena + AV(a_xh[l]);
     float *feat_t = arena + AV(a_t[3]), *v1_t = arena + AV(a_t[4]), *a1_t = arena + AV(a_t[5]);   // temporaries of non-stored passes
 
     // ---- real-env test phase: the T episodes advance in lock-step as one batch (weights are streamed once per step) ----
@@ -570,7 +590,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 PT_MARK(2);
                 queue_forward(online, xs2, B, hid_t, feat_t, v1_t, a1_t, 1);                 // next_q_values (online)
                 queue_forward(target, xs2, B, hid_t, feat_t, v1_t, a1_t, 2);                 // next_q_values_target
-                queue_forward(online, xs, B, hid_s, feat_s, v1_s, a1_s, 0);                  // q_values, activations kept
+                queue_forward(online, xs, B, hid_s, feat_s, v1_s, a1_s, 0, xh_s, rstd_s);    // q_values, activations kept
                 gq.run<D_MAXI>(Ps, Qs);                                                       // 18 products, one call
                 finish_q(1, B, qv + B * A, true);
                 finish_q(2, B, qv + 2 * B * A, true);
@@ -670,6 +690,14 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                         if (l > 0) {
                             float *dn = dh[l & 1];
                             gq.gemm(dcur, n_out, 1, online + po.oWf[l], 1, n_in, B, n_in, n_out, epi_act_bwd(dn, n_in, hid_s[l - 1], n_in, act_id, prelu));
+                            if (ln && l - 1 >= 1) {
+                                // dn = gradient of the LayerNorm OUTPUT of hidden layer l-1: run the queue, then the row routine turns it
+                                // into the gradient of the Linear's output and adds this position's share of the shared weight / bias
+                                // gradient (positions from the top down, as the oracle folds them)
+                                gq.run<D_MAXI>(Ps, Qs);
+                                ln_rows_backward<LNBUF, D_MAXH>(Ps, dn, B, H, online + po.oLN, xh_s[l - 1], rstd_s + (int64_t)(l - 1) * CFG_B, grad + po.oLN,
+                                                                grad + po.oLN + H, l - 1 == L - 1);
+                            }
                             dcur = dn; n_out = n_in;
                         }
                     }
@@ -792,11 +820,13 @@ __global__ void dueling_agent_init_kernel(lenv_ddqn_cfg cfg, const int32_t *hp_h
     const int S = cfg.state_dim, A = cfg.num_actions, F = plain ? A : cfg.feature_dim;
     const int H = hp_hidden ? hp_hidden[c] : cfg.q_hidden, L = hp_layers ? hp_layers[c] : cfg.q_layers;
     if (H < 1 || H > cfg.q_hidden || L < 1 || L > cfg.q_layers) return;        // the inner loop reports status -8 for this chain
-    const DuelOffsets po = duel_param_offsets(S, A, H, F, L, plain);
+    const bool ln = cfg.q_layer_norm != 0 && L >= 2;
+    const DuelOffsets po = duel_param_offsets(S, A, H, F, L, plain, ln);
     const uint64_t key = rng_keys[c];
     // (float)(1/sqrt(fan_in)) in double like the host table (both IEEE-exact)
     const float bS = (float)(1.0 / __builtin_sqrt((double)S)), bH = (float)(1.0 / __builtin_sqrt((double)H)), bF = (float)(1.0 / __builtin_sqrt((double)F));
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < po.P; i += gridDim.x * blockDim.x) {
+        if (ln && i >= po.oLN && i < po.oLN + 2 * H) { agent_init[c * row_stride + i] = i < po.oLN + H ? 1.0f : 0.0f; continue; }   // nn.LayerNorm: weight 1, bias 0
         const float bound = i < po.oWf[1] ? bS : (i < (plain ? po.P : po.oWv1) ? bH : bF);
         const float u = (float)u64_to_unit(rng_u64(key, STREAM_AGENT_INIT, (uint64_t)i));
         agent_init[c * row_stride + i] = (u * 2.0f - 1.0f) * bound;
@@ -822,7 +852,8 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     if (!((cfg->env_id == LENV_ENV_CARTPOLE && S == 4 && A == 2) || (cfg->env_id == LENV_ENV_ACROBOT && S == 6 && A == 3) ||
           (cfg->env_id == LENV_ENV_MOUNTAINCAR && S == 2 && A == 3)))
         return LENV_ERR_UNSUPPORTED;
-    a.P = duel_param_offsets(S, A, H, F, L, plain).P;
+    const bool ln = cfg->q_layer_norm != 0 && L >= 2;      // use_layer_norm: one shared LayerNorm behind hidden Linear 2..L (none with one hidden layer)
+    a.P = duel_param_offsets(S, A, H, F, L, plain, ln).P;
     a.se_net_size[0] = (int)d_mlp_params(K, Hse, cfg->se_layers, S);
     a.se_net_size[1] = a.se_net_size[2] = (int)d_mlp_params(K, Hse, cfg->se_layers, 1);
     a.P_se = a.se_net_size[0] + a.se_net_size[1] + a.se_net_size[2];
@@ -837,7 +868,7 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     int64_t cap = (int64_t)cfg->train_episodes * cfg->max_steps;
     if (cap > cfg->rb_size) cap = cfg->rb_size;
     a.rb_cap = cap < 1 ? 1 : cap;
-    a.A = duel_arena(S, H, F, L, B, T, a.P);
+    a.A = duel_arena(S, H, F, L, B, T, a.P, ln);
     int64_t off = a.A.end;
     auto take = [&](int64_t n) { int64_t r = off; off += (n + 3) & ~(int64_t)3; return r; };
     a.a_replay = take(a.rb_cap * a.RS);
@@ -958,7 +989,8 @@ extern "C" int lenv_dueling_se_inner_loop_icm(const lenv_ddqn_cfg *cfg, const le
         auto matches = [&](const DuelShape &sp) {
             return cfg->agent_kind == sp.kind && cfg->env_id == sp.env && cfg->state_dim == sp.S && cfg->num_actions == sp.A &&
                    (sp.kind == 0 || cfg->feature_dim == sp.F) && cfg->q_hidden == sp.H && cfg->q_layers == sp.L && cfg->batch_size == sp.B &&
-                   cfg->se_hidden == sp.Hse && cfg->test_episodes == sp.T && cfg->q_act == sp.q_act && cfg->se_act == sp.se_act && cfg->same_action_num <= 1;
+                   cfg->se_hidden == sp.Hse && cfg->test_episodes == sp.T && cfg->q_act == sp.q_act && cfg->se_act == sp.se_act && cfg->same_action_num <= 1 &&
+                   !cfg->q_layer_norm;
         };
         // production launches of a wave-chain shape (dueling_wavechain.hip): kernel_variant NO_WAVECHAIN keeps the GEMM-queue kernel (A/B runs)
         const bool no_wc = (cfg->kernel_variant & LENV_VARIANT_NO_WAVECHAIN) != 0;

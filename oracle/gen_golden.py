@@ -54,9 +54,12 @@ def seed_all(s):
 def pack_linear_params(state_dict, prefix):
     """Flat fp32 vector of the nn.Linear weights/biases under `prefix`, in state-dict order
     (W0,b0,...,Wout,bout); PReLU slopes (1-element '<idx>.weight') are skipped."""
-    parts = []
+    parts, seen = [], set()
     for k, v in state_dict.items():
         if k.startswith(prefix) and not (k.endswith("weight") and _is_prelu_key(state_dict, k)):
+            if v.data_ptr() in seen:                 # the shared nn.LayerNorm appears once per POSITION in a state dict: Module.parameters() order keeps the first
+                continue
+            seen.add(v.data_ptr())
             parts.append(v.detach().cpu().numpy().astype(np.float32).reshape(-1))
     return np.concatenate(parts)
 
@@ -1385,7 +1388,7 @@ def _gen_g11_body(cfg, n, GTN_Master, GTN_Worker, shutil):
 def main():
     # no arguments (or "all"): every fixture under tests/golden is regenerated (the full-shape runs g8df / g8tf take minutes each)
     ALL = ["g1", "g1ln", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x",
-           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8df", "g8l2", "g8m", "g8r", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k"]
+           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8df", "g8l2", "g8ln", "g8m", "g8r", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k"]
     which = sys.argv[1:] or ALL
     if "all" in which:
         which = ALL
@@ -1479,6 +1482,18 @@ def main():
         gen_g8("g8l2_calc_score_acrobot_ddqn_2layer", train_episodes=3, done_bias_shift=0.0, seed=812, max_steps=20,
                env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="ddqn",
                agent_over={"init_episodes": 1, "test_episodes": 2}, env_over={"hidden_size": 128, "solved_reward": 0.5})
+    if "g8ln" in which:
+        # `use_layer_norm: True` (models/model_utils.py:22-37) in the agent's section: a DDQN whose Critic_DQN has two hidden layers (ONE
+        # shared nn.LayerNorm behind the second Linear) and a DuelingDDQN whose feature stream has three (the same module at two positions)
+        gen_g8("g8ln_calc_score_acrobot_ddqn_layernorm", train_episodes=3, done_bias_shift=0.0, seed=813, max_steps=20,
+               env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="ddqn",
+               agent_over={"hidden_size": 40, "hidden_layer": 2, "batch_size": 32, "init_episodes": 1, "test_episodes": 2, "use_layer_norm": True},
+               env_over={"hidden_size": 32, "solved_reward": 0.5})
+        gen_g8("g8dln_calc_score_acrobot_dueling_layernorm", train_episodes=3, done_bias_shift=0.0, seed=814, max_steps=20,
+               env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="duelingddqn",
+               agent_over={"hidden_size": 24, "hidden_layer": 3, "feature_dim": 16, "batch_size": 32, "init_episodes": 1, "test_episodes": 2,
+                           "use_layer_norm": True},
+               env_over={"hidden_size": 32, "solved_reward": 0.5})
     if "g8m" in which:
         # default_config_mountaincar.yaml's pair: MountainCar-v0 SE + DDQN with two hidden layers (GEMM-tiled kernel, plain-DQN mode)
         gen_g8("g8m_calc_score_mountaincar_ddqn", train_episodes=3, done_bias_shift=0.0, seed=860, max_steps=25,

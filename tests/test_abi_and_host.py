@@ -311,3 +311,13 @@ def test_config_builders_refuse_layer_norm_sections():
     c["agents"]["td3"]["use_layer_norm"] = True
     with pytest.raises(NotImplementedError):
         config.td3_cfg_from_config(c)
+    # the DDQN / DuelingDDQN loop takes the AGENT's LayerNorm (cfg.q_layer_norm); the block of the shared module sits behind the second Linear
+    from learning_environments_amd.agents import nes_common
+    c = configs.acrobot_syn_env_ddqn(2)
+    c["agents"]["ddqn"]["use_layer_norm"] = True
+    cfg = config.ddqn_cfg_from_config(c)
+    assert cfg.q_layer_norm == 1 and config.agent_layer_norm_slice(cfg) == ((6 * 128 + 128) + (128 * 128 + 128), 128)
+    b = nes_common.with_layer_norm_block(nes_common.linear_init_bounds(config.agent_layer_dims(cfg)), config.agent_layer_norm_slice(cfg))
+    assert b.size == 17795 + 256 and not b[17408:17664].any() and b[17407] > 0 and b[17664] > 0
+    c["agents"]["ddqn"]["hidden_layer"] = 1                  # one hidden layer: no position, no parameters
+    assert config.agent_layer_norm_slice(config.ddqn_cfg_from_config(c, grad_chunk=4)) is None

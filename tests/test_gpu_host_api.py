@@ -307,6 +307,35 @@ def test_gtn_master_acrobot_ddqn_two_layer_generation(tmp_path, monkeypatch):
     assert np.array_equal(gathered[:, 2], sign.astype(np.float64))
 
 
+def test_gtn_master_ddqn_layer_norm_generation(tmp_path, monkeypatch):
+    """`use_layer_norm: True` in the ddqn section through GTN_Master: the config builder sets cfg.q_layer_norm, the fresh agents carry the
+    shared LayerNorm's block (weight 1, bias 0) behind the second Linear, the launch trains through it, and the fitness triples equal an
+    oracle evaluation of the same agents."""
+    from learning_environments_amd.configs import acrobot_syn_env_ddqn, fixed_work
+    from oracle import oracle as orc
+    cfg = fixed_work(acrobot_syn_env_ddqn(num_workers=2, max_iterations=1), 2)
+    cfg["envs"]["Acrobot-v1"]["max_steps"] = 10
+    cfg["agents"]["ddqn"].update(test_episodes=2, hidden_size=48, batch_size=8, use_layer_norm=True)
+    m = _master_pair(cfg, tmp_path, monkeypatch)
+    H = 48
+    P = (6 * H + H) + (H * H + H) + 2 * H + (3 * H + 3)
+    assert m.cfg.q_layer_norm == 1 and m.inner.dueling and m.inner.p_agent == P and m.agent_bounds.numel() == P
+    off = (6 * H + H) + (H * H + H)
+    assert m.task.ln_slice == (off, H) and float(m.agent_bounds[off:off + 2 * H].abs().max()) == 0.0
+    theta0 = m.theta.cpu().numpy().copy()
+    gathered = m.evaluate_population(0).cpu().numpy()
+    eps = m.eps.cpu().numpy()
+    oeps, init, okeys = orc.nes_draw(m.seed, 0, 2, m.p_theta, cfg["agents"]["gtn"]["noise_std"], 6, 3, 0, m.agent_bounds.cpu().numpy())
+    assert np.array_equal(eps, oeps) and np.all(init[:, off:off + 2 * H] == 0.0)
+    init[:, off:off + H] = 1.0                               # nn.LayerNorm: weight 1, bias 0 (tasks.set_layer_norm_init)
+    ocfg = orc.ddqn_cfg_from_config(cfg, grad_chunk=0)
+    assert ocfg.q_layer_norm == 1
+    scores = orc.ddqn_se_population(ocfg, theta0, eps, init, seed=m.seed, generation=0, threads=6)
+    best, sign = orc.worker_best(scores[1::3], scores[2::3], True)
+    assert np.array_equal(gathered[:, 0], best) and np.array_equal(gathered[:, 1], scores[0::3])
+    assert np.array_equal(gathered[:, 2], sign.astype(np.float64))
+
+
 def test_gtn_master_ddqn_vary_generation(tmp_path, monkeypatch):
     """`agent_name: DDQN_vary` (what default_config_acrobot.yaml:26 ships) through GTN_Master: every chain draws its own
     hyper-parameters, the population runs as one launch, the fitness records equal an oracle evaluation chain by chain;

@@ -122,6 +122,7 @@ def _inner_cfg(orc, cfgd, **over):
 @pytest.mark.parametrize("name,chunk", [("g8_calc_score_cartpole_a", 17), ("g8_calc_score_cartpole_b", 17),
                                         ("g8w_calc_score_cartpole_ringwrap", 17),
                                         ("g8l2_calc_score_acrobot_ddqn_2layer", 0),    # Critic_DQN 6-128-128-3 -> GEMM-tiled kernel
+                                        ("g8ln_calc_score_acrobot_ddqn_layernorm", 0),  # use_layer_norm: 6-40-40-3 with the LayerNorm behind its second Linear
                                         ("g8m_calc_score_mountaincar_ddqn", 0)])       # MountainCar-v0 SE + DDQN 2-48-48-3
 def test_inner_loop_tape_mode_vs_reference_and_oracle(eng, orc, golden, name, chunk):
     g = golden(name)
@@ -457,7 +458,8 @@ def test_ql_rn_multi_layer_reward_net_vs_oracle(eng, orc, golden, layers):
 # ---------------------------------------------------------------------------------------------------------------
 # config 3: DuelingDDQN on a synthetic environment (LDS-tiled GEMM kernel, parameters in the HBM arena)
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["g8d_calc_score_acrobot_dueling", "g8df_calc_score_acrobot_dueling_fullshape"])
+@pytest.mark.parametrize("name", ["g8d_calc_score_acrobot_dueling", "g8df_calc_score_acrobot_dueling_fullshape",
+                                  "g8dln_calc_score_acrobot_dueling_layernorm"])      # use_layer_norm: feature stream 6-24-24-24-16, ONE LayerNorm at two positions
 def test_dueling_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
     g = golden(name)
     cfgd = json.loads(str(g["config_json"]))
@@ -530,6 +532,62 @@ def test_dueling_counter_mode_vs_oracle(eng, orc, golden, env_name, layers, hidd
         assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
         assert float(il.score[c]) == o["score"]
         assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
+@pytest.mark.parametrize("kind,layers,hidden,feat,batch,act", [("duelingddqn", 2, 48, 24, 40, "relu"), ("duelingddqn", 3, 33, 17, 77, "tanh"),
+                                                                ("ddqn", 2, 64, 0, 50, "leakyrelu"), ("ddqn", 3, 40, 0, 32, "relu"),
+                                                                ("ddqn", 1, 40, 0, 32, "relu")])      # one hidden layer: the flag changes nothing
+def test_layer_norm_in_the_ddqn_loops_vs_oracle(eng, orc, golden, kind, layers, hidden, feat, batch, act):
+    """`use_layer_norm: True` in the agent's section (models/model_utils.py:22-37): the shared LayerNorm behind hidden Linear 2..L of the
+    Q-net / the DuelingDDQN feature stream, forward AND backward inside the fused loop (lenv_ln.cuh row routines between the queued layer
+    products), its weight | bias trained by the same Adam pass.  Counter mode, three chains, against the oracle (which reproduces the
+    reference runs G8LN / G8DLN): step traces, returns, counters and ALL final online parameters incl. the LayerNorm's, bit for bit."""
+    g = golden("g8d_calc_score_acrobot_dueling")
+    cfgd = json.loads(str(g["config_json"]))
+    if kind == "ddqn":
+        cfgd["agents"]["gtn"]["agent_name"] = "DDQN"
+        cfgd["agents"]["ddqn"] = dict(cfgd["agents"]["duelingddqn"])
+        cfgd["agents"]["ddqn"].pop("feature_dim", None)
+    cfgd["agents"][kind].update(hidden_size=hidden, hidden_layer=layers, batch_size=batch, activation_fn=act, test_episodes=3, use_layer_norm=True)
+    if kind == "duelingddqn":
+        cfgd["agents"][kind]["feature_dim"] = feat
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0 if (layers > 1 or kind == "duelingddqn") else 4, rng_mode=0, train_episodes=3, max_steps=14)
+    assert cfg.q_layer_norm == 1 and ocfg.q_layer_norm == 1
+    S, A = ocfg.state_dim, ocfg.num_actions
+    rng = np.random.RandomState(28)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, ocfg.se_hidden, 1, "leakyrelu"))
+    P_q = orc.dueling_num_params(ocfg) if kind == "duelingddqn" else orc.mlp_num_params(orc.mlp_desc(S, hidden, layers, A, act, use_layer_norm=1))
+    plain_P = (S * hidden + hidden) + (layers - 1) * (hidden * hidden + hidden) + (A * hidden + A)
+    if kind == "ddqn":
+        assert P_q == plain_P + (2 * hidden if layers >= 2 else 0)
+    chains = 3
+    theta = (rng.randn(P_se) * 0.15).astype(np.float32)
+    eps = (rng.randn(1, P_se) * 0.05).astype(np.float32)
+    agent_init = (rng.uniform(-0.15, 0.15, (chains, P_q))).astype(np.float32)
+    if layers >= 2:                                        # nn.LayerNorm starts at weight 1 / bias 0; perturbed here so that both matter
+        off = (S * hidden + hidden) + (hidden * hidden + hidden)
+        agent_init[:, off:off + hidden] = 1.0 + 0.1 * rng.randn(chains, hidden).astype(np.float32)
+        agent_init[:, off + hidden:off + 2 * hidden] = 0.05 * rng.randn(chains, hidden).astype(np.float32)
+    worker = np.zeros(chains, np.int32)
+    sign = np.array([0.0, 1.0, -1.0], np.float32)
+    keys = np.array([orc.chain_key(19, 2, 0, c) for c in range(chains)], np.uint64)
+    il = eng.InnerLoop(cfg, chains, trace_cap=48, want_final_online=True)
+    assert il.p_agent == P_q
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        w = (np.float32(sign[c]) * eps[0] + theta).astype(np.float32)
+        o = orc.ddqn_se_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]), trace_cap=48, want_final_online=True)
+        n = o["trace"]["action"].size
+        assert o["learn_steps"] >= 20
+        assert np.array_equal(il.trace["action"][c, :n].cpu().numpy() & 0xFFFF, o["trace"]["action"]), c
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"]), c
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(il.final_online[c].cpu().numpy(), o["final_online"]), c
+        assert not np.array_equal(o["final_online"], agent_init[c])
 
 
 @pytest.mark.parametrize("env_name,layers,hidden,batch,act,T", [("Acrobot-v1", 2, 128, 128, "relu", 3), ("CartPole-v0", 2, 64, 64, "tanh", 4),

@@ -158,6 +158,7 @@ def test_g7_master(golden):
 @pytest.mark.parametrize("name,chunk", [("g8_calc_score_cartpole_a", 13), ("g8_calc_score_cartpole_b", 13),
                                         ("g8w_calc_score_cartpole_ringwrap", 13),
                                         ("g8l2_calc_score_acrobot_ddqn_2layer", 0),    # Critic_DQN 6-128-128-3: batch gradient
+                                        ("g8ln_calc_score_acrobot_ddqn_layernorm", 0),  # use_layer_norm: Critic_DQN 6-40-40-3 with the LayerNorm behind its second Linear
                                         ("g8m_calc_score_mountaincar_ddqn", 0)])       # default_config_mountaincar.yaml's pair
 def test_g8_calc_score_trace(golden, name, chunk):
     import json
@@ -476,13 +477,16 @@ def test_g4d_dueling_forward_and_learn(golden, grad_chunk):
             np.testing.assert_allclose(target, g[pre + "target"][step], rtol=0, atol=2e-5, err_msg=pre + "target%d" % step)
 
 
-@pytest.mark.parametrize("name", ["g8d_calc_score_acrobot_dueling", "g8df_calc_score_acrobot_dueling_fullshape"])
+@pytest.mark.parametrize("name", ["g8d_calc_score_acrobot_dueling", "g8df_calc_score_acrobot_dueling_fullshape",
+                                  "g8dln_calc_score_acrobot_dueling_layernorm"])     # use_layer_norm: feature stream 6-24-24-24-16, ONE LayerNorm at two positions
 def test_g8d_calc_score_acrobot_dueling(golden, name):
     import json
     g = golden(name)
     cfgd = json.loads(str(g["config_json"]))
     cfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
     assert cfg.agent_kind == 1 and cfg.feature_dim == (128 if name.endswith("fullshape") else 16)
+    assert cfg.q_layer_norm == (1 if name.endswith("layernorm") else 0)
+    assert g["agent_init"].size == orc.dueling_num_params(cfg)
     tapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
     n = g["tr_action"].size
     out = orc.ddqn_se_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 10)
