@@ -97,7 +97,7 @@ class Td3Cfg(C.Structure):
                 ("action_std", C.c_double), ("policy_std", C.c_double), ("policy_std_clip", C.c_double),
                 ("max_action", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
                 ("step_budget", C.c_int64),
-                ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("icm_pad_", C.c_int32),
+                ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("use_layer_norm", C.c_int32),
                 ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
                 ("virtual_env", C.c_int32), ("same_action_num", C.c_int32), ("team_size", C.c_int32), ("kernel_variant", C.c_int32)]
 

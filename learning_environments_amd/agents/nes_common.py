@@ -58,18 +58,25 @@ def linear_init_bounds(layer_dims):
 
 
 def with_layer_norm_block(bounds, ln_slice):
-    """The bounds vector of a net whose shared nn.LayerNorm (weight | bias, 2 H values) sits at `ln_slice` = (offset, H): bound 0 there --
-    the draw leaves zeros, set_layer_norm_init then writes the weight's ones (nn.LayerNorm: weight 1, bias 0)."""
-    if ln_slice is None:
+    """The bounds vector of a net whose shared nn.LayerNorm (weight | bias, 2 H values) sits at `ln_slice` = (offset, H) -- or of several
+    nets, `ln_slice` = [(offset, H), ...] ascending, offsets in the FINAL vector: bound 0 there -- the draw leaves zeros,
+    set_layer_norm_init then writes the weight's ones (nn.LayerNorm: weight 1, bias 0)."""
+    if not ln_slice:
         return bounds
-    off, H = ln_slice
-    return np.concatenate([bounds[:off], np.zeros(2 * H, np.float32), bounds[off:]])
+    slices = [ln_slice] if isinstance(ln_slice, tuple) else list(ln_slice)
+    parts, pos, inserted = [], 0, 0
+    for off, H in slices:
+        orig = off - inserted
+        parts += [bounds[pos:orig], np.zeros(2 * H, np.float32)]
+        pos, inserted = orig, inserted + 2 * H
+    parts.append(bounds[pos:])
+    return np.concatenate(parts)
 
 
 def set_layer_norm_init(agent_init, ln_slice):
-    if ln_slice is not None and agent_init is not None:
-        off, H = ln_slice
-        agent_init[:, off:off + H] = 1.0
+    if ln_slice and agent_init is not None:
+        for off, H in ([ln_slice] if isinstance(ln_slice, tuple) else ln_slice):
+            agent_init[:, off:off + H] = 1.0
     return agent_init
 
 

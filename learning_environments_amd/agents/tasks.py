@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from ..config import (TABULAR_AGENTS, TD3_DISCRETE_ENVS, agent_layer_dims, agent_layer_norm_slice, ddqn_cfg_from_config, icm_layer_dims, ql_cfg_from_config,
-                      td3_cfg_from_config, td3_layer_dims, td3d_cfg_from_config)
+                      td3_cfg_from_config, td3_layer_dims, td3_layer_norm_slices, td3d_cfg_from_config)
 from .nes_common import chain_keys, fresh_agent_init, linear_init_bounds, set_layer_norm_init, with_layer_norm_block
 
 
@@ -120,7 +120,8 @@ class Td3RnTask(object):
     def __init__(self, config, engine):
         self.engine = engine
         self.cfg = td3_cfg_from_config(config)
-        self.agent_bounds = torch.from_numpy(linear_init_bounds(td3_layer_dims(self.cfg))).to(engine.device)
+        self.ln_slice = td3_layer_norm_slices(self.cfg)       # use_layer_norm: the three nets' LayerNorm blocks in the flat parameter vector
+        self.agent_bounds = torch.from_numpy(with_layer_norm_block(linear_init_bounds(td3_layer_dims(self.cfg)), self.ln_slice)).to(engine.device)
         self.icm_bounds = None                    # "td3_icm": TD3(icm=True), a fresh ICM per chain
         if self.cfg.icm_enabled:
             self.icm_bounds = torch.from_numpy(linear_init_bounds(icm_layer_dims(self.cfg))).to(engine.device)
@@ -131,6 +132,7 @@ class Td3RnTask(object):
     def scores(self, inner, theta, eps, chain_worker, chain_sign, keys_t, agent_init):
         if self.icm_bounds is not None:
             inner.draw_icm_init(keys_t, self.icm_bounds)
+        set_layer_norm_init(agent_init, self.ln_slice)
         return self.engine.inner_scores_td3(inner, theta, eps, chain_worker, chain_sign, agent_init, keys_t)
 
     def needs_agent_init(self):

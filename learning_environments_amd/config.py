@@ -9,9 +9,9 @@ TD3_MAX_ACTION = {"HalfCheetah-v3": 1.0, "Pendulum-v0": 2.0, "MountainCarContinu
 
 
 def _refuse_layer_norm(config, env_section, agent_section):
-    """`use_layer_norm` (models/model_utils.py:22-29) where a fused inner loop would silently train a different network is refused:
-    in the synthetic env's section everywhere, in the agent's section of the tabular / continuous-TD3 loops (the DDQN / DuelingDDQN
-    loop takes it through cfg.q_layer_norm, TD3_discrete_vary through its own field, lenv_mlp_forward in the one-step API)."""
+    """`use_layer_norm` (models/model_utils.py:22-29) where a fused inner loop would silently train a different network is refused: in
+    the synthetic env's / reward env's section everywhere (the AGENT's LayerNorm is taken: cfg.q_layer_norm in the DDQN / DuelingDDQN
+    loop, cfg.use_layer_norm in the TD3 and TD3_discrete_vary loops; lenv_mlp_forward in the one-step API)."""
     for name, sec in (("envs." + config["env_name"], env_section), ("agent", agent_section)):
         if sec is not None and sec.get("use_layer_norm", False):
             raise NotImplementedError("use_layer_norm in the %s section: no fused inner loop takes LayerNorm nets here" % name)
@@ -179,7 +179,7 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
     def val(v):
         return float(v[1]) if isinstance(v, list) else v
 
-    _refuse_layer_norm(config, e, a)
+    _refuse_layer_norm(config, e, None)
     cfg = _lib.Td3Cfg(env_id=_lib.ENV[env_name], state_dim=S, action_dim=A, max_steps=int(val(e["max_steps"])),
                       rn_hidden=int(val(e["hidden_size"])), rn_layers=int(val(e["hidden_layer"])), rn_act=_lib.ACT[e["activation_fn"]],
                       rn_prelu=0.25, reward_env_type=int(val(e["reward_env_type"])), info_dim=int(val(e.get("info_dim", 0))),
@@ -194,6 +194,8 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
     if "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 1)) == 0:
         cfg.virtual_env = 1                           # VirtualEnv (default_config_halfcheetah.yaml): `envs` describes the three SE nets
     cfg.same_action_num = int(a["same_action_num"])   # env steps per chosen action (the MountainCarContinuous configs ship 2)
+    # use_layer_norm: one shared nn.LayerNorm per net (actor, critic_1, critic_2) behind its hidden Linear 2..L (model_utils.py:22-37)
+    cfg.use_layer_norm = 1 if a.get("use_layer_norm", False) else 0
     _launch_knobs(cfg, config)
     name = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "td3"
     if name.replace("_vary", "").endswith("_icm"):   # select_agent "td3_icm" / "td3_icm_vary": TD3(icm=True), agents/TD3.py:44-60
@@ -241,6 +243,18 @@ def td3d_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg
+
+
+def td3_layer_norm_slices(cfg):
+    """[(offset, H)] of the three LayerNorm blocks (actor, critic_1, critic_2) in TD3's flat parameter vector, or []."""
+    if not getattr(cfg, "use_layer_norm", 0) or cfg.layers < 2:
+        return []
+    H, L, S, A = cfg.hidden, cfg.layers, cfg.state_dim, cfg.action_dim
+
+    def net(n_in, n_out):
+        return (n_in * H + H) + (L - 1) * (H * H + H) + 2 * H + (n_out * H + n_out)
+    pa, pc = net(S, A), net(S + A, 1)
+    return [((S * H + H) + (H * H + H), H), (pa + ((S + A) * H + H) + (H * H + H), H), (pa + pc + ((S + A) * H + H) + (H * H + H), H)]
 
 
 def td3_layer_dims(cfg):

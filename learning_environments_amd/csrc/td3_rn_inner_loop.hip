@@ -14,6 +14,7 @@
 // step (phi(s') of step t is phi(s) of step t+1).  Gaussian noises come from RNG tapes (parity mode) or from the
 // counter RNG through a Box-Muller with deterministic log / cos (production mode).
 #include "lenv_gemm.cuh"
+#include "lenv_ln.cuh"
 #include "lenv_icm.cuh"
 #include "lenv_wavechain_host.h"
 
@@ -25,14 +26,18 @@ constexpr int T3_MAXB = 768;   // max batch size  (more than 256 rows run as sev
 constexpr int T3_MAXI = 256;   // rows of one product block
 // observation / action dims come from the env (ContEnv<ENV> in lenv_device.cuh): the stand-in 17 / 6, Pendulum-v0 3 / 1
 
-struct MlpOff { int in, H, L, out; int oW[T3_MAXL + 1], ob[T3_MAXL + 1]; int P; };
+struct MlpOff { int in, H, L, out; int oW[T3_MAXL + 1], ob[T3_MAXL + 1]; int P; int ln, oLN; };      // ln: the net's shared LayerNorm (weight | bias at oLN, behind the second Linear)
 
-__host__ __device__ inline void mlp_off(MlpOff &m, int in, int H, int L, int out)
+__host__ __device__ inline void mlp_off(MlpOff &m, int in, int H, int L, int out, bool layer_norm = false)
 {
     m.in = in; m.H = H; m.L = L; m.out = out;
+    m.ln = layer_norm && L >= 2 ? 1 : 0; m.oLN = 0;        // use_layer_norm (model_utils.py:22-37): nothing to normalise with one hidden layer
     int o = 0, n_in = in;
     for (int l = 0; l <= T3_MAXL; ++l) m.oW[l] = m.ob[l] = 0;
-    for (int l = 0; l < L; ++l) { m.oW[l] = o; o += H * n_in; m.ob[l] = o; o += H; n_in = H; }
+    for (int l = 0; l < L; ++l) {
+        m.oW[l] = o; o += H * n_in; m.ob[l] = o; o += H; n_in = H;
+        if (m.ln && l == 1) { m.oLN = o; o += 2 * H; }
+    }
     m.oW[L] = o; o += out * H; m.ob[L] = o; o += out;
     m.P = o;
 }
@@ -55,7 +60,7 @@ struct Td3Args {
     const float *icm_init; float *icm_final; int P_icm;
     int64_t a_icm[IB_COUNT];
     int64_t a_params, a_targets, a_m, a_v, a_grad, a_replay, a_xc, a_xn, a_xa, a_hc1[T3_MAXL], a_hc2[T3_MAXL], a_ha[T3_MAXL],
-        a_ht[T3_MAXL], a_d[2], a_dx, a_act, a_th, a_dz, a_meter;
+        a_ht[T3_MAXL], a_d[2], a_dx, a_act, a_th, a_dz, a_meter, a_xh[3][T3_MAXL], a_rstd;      // a_xh / a_rstd: LayerNorm rows of critic_1 / critic_2 / actor passes
 };
 
 // Diagnostic build only (-DLENV_PHASE_TIMING): per-phase shader-clock totals of chain 0, never in the shipped library.
@@ -110,8 +115,9 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         return;
     }
     MlpOff mo_actor, mo_critic;
-    mlp_off(mo_actor, S, H, L, A);
-    mlp_off(mo_critic, SA, H, L, 1);
+    const bool use_ln = FIXED ? false : cfg.use_layer_norm != 0;
+    mlp_off(mo_actor, S, H, L, A, use_ln);
+    mlp_off(mo_critic, SA, H, L, 1, use_ln);
     MlpOff mo_se[3];                                      // VirtualEnv: state_net | reward_net | done_net on cat(action, state)
     mlp_off(mo_se[0], SA, Hrn, rn_layers, S);
     mlp_off(mo_se[1], SA, Hrn, rn_layers, 1);
@@ -148,6 +154,8 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     float *dxb = arena + a.a_dx, *thb = arena + a.a_th, *dzb = arena + a.a_dz;
     float *hc1[T3_MAXL], *hc2[T3_MAXL], *ha[T3_MAXL], *ht[T3_MAXL], *dbuf[2] = { arena + a.a_d[0], arena + a.a_d[1] };
     for (int l = 0; l < T3_MAXL; ++l) { hc1[l] = arena + a.a_hc1[l]; hc2[l] = arena + a.a_hc2[l]; ha[l] = arena + a.a_ha[l]; ht[l] = arena + a.a_ht[l]; }
+    float *xh1[T3_MAXL], *xh2[T3_MAXL], *xha[T3_MAXL], *rstd1 = arena + a.a_rstd, *rstd2 = rstd1 + T3_MAXL * Bm, *rstda = rstd2 + T3_MAXL * Bm;
+    for (int l = 0; l < T3_MAXL; ++l) { xh1[l] = arena + a.a_xh[0][l]; xh2[l] = arena + a.a_xh[1][l]; xha[l] = arena + a.a_xh[2][l]; }
     double *meter = reinterpret_cast<double *>(arena + a.a_meter);
 
     // ---- stage the perturbed reward network (GTN_worker.py:165-175) and the fresh agent (TD3.py:31-39) ----
@@ -187,13 +195,21 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     // are QUEUED (gq); the caller runs the queue.  final_tanh: out = tanh(net)*max_action (Actor_TD3.forward) with tanh
     // values to th_out; else out = net (Critic_Q).
     GemmQueue gq(cmds);
+    constexpr int LNBUF = GemmShape<T3_MAXI>::PS_FLOATS + GemmShape<T3_MAXI>::QS_FLOATS;
     auto mlp_forward = [&](const float *par, const MlpOff &mo, const float *X, int ldx, int I, float *const *hid, float *out,
-                           int ldo, int ocol, bool final_tanh, float *th_out, int act = -1, float pr = 0.25f) {
+                           int ldo, int ocol, bool final_tanh, float *th_out, int act = -1, float pr = 0.25f, float *const *xh = nullptr,
+                           float *rstd = nullptr) {
         if (act < 0) { act = act_id; pr = prelu; }                // default: the agent's activation
         const float *in = X;
         int n_in = mo.in, ldin = ldx;
         for (int l = 0; l < mo.L; ++l) {
-            gq.gemm(in, ldin, 1, par + mo.oW[l], n_in, 1, I, mo.H, n_in, epi_bias_act(hid[l], mo.H, par + mo.ob[l], act, pr));
+            if (mo.ln && l >= 1) {
+                // a LayerNorm position: Linear + bias, the queue runs (everything queued so far, in order), then the row routine normalises,
+                // scales and applies the activation (lenv_ln.cuh); xh / rstd: kept for the backward pass
+                gq.gemm(in, ldin, 1, par + mo.oW[l], n_in, 1, I, mo.H, n_in, epi_bias(hid[l], mo.H, 0, par + mo.ob[l]));
+                gq.run<T3_MAXI>(Ps, Qs);
+                ln_rows_forward<LNBUF>(Ps, hid[l], I, mo.H, par + mo.oLN, par + mo.oLN + mo.H, xh ? xh[l] : nullptr, rstd ? rstd + (int64_t)l * Bm : nullptr, act, pr);
+            } else gq.gemm(in, ldin, 1, par + mo.oW[l], n_in, 1, I, mo.H, n_in, epi_bias_act(hid[l], mo.H, par + mo.ob[l], act, pr));
             in = hid[l]; n_in = mo.H; ldin = mo.H;
         }
         const float *W = par + mo.oW[mo.L], *bb = par + mo.ob[mo.L];
@@ -212,6 +228,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             const int n_out = last ? mo.out : mo.H;
             const float *W = par + mo.oW[l], *bb = par + mo.ob[l];
             float *h = last ? out + ocol : ht[l];
+            const bool lnl = !last && mo.ln && l >= 1;               // a LayerNorm position: reduced by thread 0 (as td3_discrete_inner_loop.hip)
             for (int j = tid; j < n_out; j += DNT) {
                 const float *w = W + (int64_t)j * n_in;
                 float z = 0.0f;
@@ -223,9 +240,23 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     }
                 } else for (int k = 0; k < n_in; ++k) z = fma32(in[k], w[k], z);
                 z = z + bb[j];
-                h[j] = last ? (final_tanh ? det_tanhf(lenv_tanh_table, z) * ma : z) : act_fwd(act, pr, z);
+                h[j] = last ? (final_tanh ? det_tanhf(lenv_tanh_table, z) * ma : z) : (lnl ? z : act_fwd(act, pr, z));
             }
             __syncthreads();
+            if (lnl) {
+                if (tid == 0) {
+                    float sm = 0.0f, sv = 0.0f;
+                    for (int j = 0; j < n_out; ++j) sm = sm + h[j];
+                    const float mean = sm / (float)n_out;
+                    for (int j = 0; j < n_out; ++j) { const float dj = h[j] - mean; sv = fma32(dj, dj, sv); }
+                    ctrl[14] = mean; ctrl[15] = 1.0f / __builtin_sqrtf(sv / (float)n_out + 1e-5f);
+                }
+                __syncthreads();
+                const float mean = ctrl[14], r = ctrl[15];
+                const float *lw = par + mo.oLN, *lb = lw + mo.H;
+                for (int j = tid; j < n_out; j += DNT) h[j] = act_fwd(act, pr, fma32((h[j] - mean) * r, lw[j], lb[j]));
+                __syncthreads();
+            }
             in = h; n_in = mo.H;
         }
     };
@@ -234,14 +265,24 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     // ---- generic MLP backward: dOut [I][out] -> parameter gradients gpar (may be null) and input gradient dX (may be null);
     // queued like the forward.  The output-layer bias gradient (a handful of columns of an LDS vector) is done in place.
     auto mlp_backward = [&](const float *par, const MlpOff &mo, const float *X, int ldx, int I, float *const *hid, const float *dOut,
-                            float *gpar, float *dX) {
+                            float *gpar, float *dX, float *const *xh = nullptr, const float *rstd = nullptr) {
         const int Hh = mo.H, O = mo.out;
+        // a LayerNorm position (hidden layer lp >= 1): d holds the gradient of the LayerNorm OUTPUT; run the queue, then the row routine
+        // turns it into the gradient of the Linear's output and adds the position's share of the shared weight / bias gradient (positions
+        // from the top down, as the oracle folds them; gpar null: the input gradient only)
+        auto ln_pos = [&](float *d, int lp) {
+            if (!(mo.ln && lp >= 1)) return;
+            gq.run<T3_MAXI>(Ps, Qs);
+            ln_rows_backward<LNBUF, T3_MAXW>(Ps, d, I, Hh, par + mo.oLN, xh[lp], rstd + (int64_t)lp * Bm, gpar ? gpar + mo.oLN : nullptr,
+                                             gpar ? gpar + mo.oLN + Hh : nullptr, lp == mo.L - 1);
+        };
         if (gpar) {
             gq.gemm(dOut, 1, O, hid[mo.L - 1], 1, Hh, O, Hh, I, epi_store(gpar + mo.oW[mo.L], Hh));
             gq.colsum(dOut, I, O, O, gpar + mo.ob[mo.L]);
         }
         float *dcur = dbuf[0];
         gq.gemm(dOut, O, 1, par + mo.oW[mo.L], 1, Hh, I, Hh, O, epi_act_bwd(dcur, Hh, hid[mo.L - 1], Hh, act_id, prelu));
+        ln_pos(dcur, mo.L - 1);
         for (int l = mo.L - 1; l >= 0; --l) {
             const int n_in = l == 0 ? mo.in : Hh;
             const float *inp = l == 0 ? X : hid[l - 1];
@@ -253,6 +294,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             if (l > 0) {
                 float *dn = dbuf[(mo.L - l) & 1];
                 gq.gemm(dcur, Hh, 1, par + mo.oW[l], 1, n_in, I, n_in, Hh, epi_act_bwd(dn, n_in, hid[l - 1], n_in, act_id, prelu));
+                ln_pos(dn, l - 1);
                 dcur = dn;
             } else if (dX) {
                 gq.gemm(dcur, Hh, 1, par + mo.oW[0], 1, n_in, I, n_in, Hh, epi_store(dX, n_in));
@@ -572,8 +614,8 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 PT_MARK(2);                               // actor_target forward + smoothing noise
                 mlp_forward(targets + Pa, mo_critic, xn, SA, B, ht, tq1, 1, 0, false, nullptr);
                 mlp_forward(targets + Pa + Pc, mo_critic, xn, SA, B, ht, tq2, 1, 0, false, nullptr);
-                mlp_forward(params + Pa, mo_critic, xc, SA, B, hc1, q1, 1, 0, false, nullptr);
-                mlp_forward(params + Pa + Pc, mo_critic, xc, SA, B, hc2, q2, 1, 0, false, nullptr);
+                mlp_forward(params + Pa, mo_critic, xc, SA, B, hc1, q1, 1, 0, false, nullptr, -1, 0.25f, xh1, rstd1);
+                mlp_forward(params + Pa + Pc, mo_critic, xc, SA, B, hc2, q2, 1, 0, false, nullptr, -1, 0.25f, xh2, rstd2);
                 gq.run<T3_MAXI>(Ps, Qs);                   // 4 critic forwards, one call
                 PT_MARK(3);
                 {
@@ -587,8 +629,8 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 }
                 __syncthreads();
                 PT_MARK(4);                               // TD error
-                mlp_backward(params + Pa, mo_critic, xc, SA, B, hc1, dq1, grad + Pa, nullptr);
-                mlp_backward(params + Pa + Pc, mo_critic, xc, SA, B, hc2, dq2, grad + Pa + Pc, nullptr);
+                mlp_backward(params + Pa, mo_critic, xc, SA, B, hc1, dq1, grad + Pa, nullptr, xh1, rstd1);
+                mlp_backward(params + Pa + Pc, mo_critic, xc, SA, B, hc2, dq2, grad + Pa + Pc, nullptr, xh2, rstd2);
                 gq.run<T3_MAXI>(Ps, Qs);
                 PT_MARK(5);                               // critics backward
                 adam(Pa, 2 * Pc, 0);                       // critic_optimizer: critic_1 then critic_2 parameters
@@ -598,13 +640,13 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1
                     for (int e = tid; e < B * S; e += DNT) { const int b = e / S, i = e - b * S; xa[b * SA + i] = xc[b * SA + i]; }
                     __syncthreads();
-                    mlp_forward(params, mo_actor, xc, SA, B, ha, xa, SA, S, true, thb);
-                    mlp_forward(params + Pa, mo_critic, xa, SA, B, hc1, q1, 1, 0, false, nullptr);
+                    mlp_forward(params, mo_actor, xc, SA, B, ha, xa, SA, S, true, thb, -1, 0.25f, xha, rstda);
+                    mlp_forward(params + Pa, mo_critic, xa, SA, B, hc1, q1, 1, 0, false, nullptr, -1, 0.25f, xh1, rstd1);
                     gq.run<T3_MAXI>(Ps, Qs);
                     const float dqa = -(1.0f / (float)B);
                     for (int b = tid; b < B; b += DNT) dq1[b] = dqa;
                     __syncthreads();
-                    mlp_backward(params + Pa, mo_critic, xa, SA, B, hc1, dq1, nullptr, dxb);
+                    mlp_backward(params + Pa, mo_critic, xa, SA, B, hc1, dq1, nullptr, dxb, xh1, rstd1);
                     gq.run<T3_MAXI>(Ps, Qs);
                     for (int e = tid; e < B * A; e += DNT) {
                         const int b = e / A, k = e - b * A;
@@ -612,7 +654,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                         dzb[e] = (dxb[b * SA + S + k] * ma) * fma32(-th, th, 1.0f);   // d(tanh(z)*max_action)
                     }
                     __syncthreads();
-                    mlp_backward(params, mo_actor, xc, SA, B, ha, dzb, grad, nullptr);
+                    mlp_backward(params, mo_actor, xc, SA, B, ha, dzb, grad, nullptr, xha, rstda);
                     gq.run<T3_MAXI>(Ps, Qs);
                     PT_MARK(7);                           // policy update: forwards + backwards
                     adam(0, Pa, 2);
@@ -718,14 +760,19 @@ __global__ void td3_agent_init_kernel(lenv_td3_cfg cfg, const int32_t *hp_hidden
     if (H < 1 || H > cfg.hidden || L < 1 || L > cfg.layers) return;            // the inner loop reports status -8 for this chain
     MlpOff ma, mc;
     const int T3_S = cfg.state_dim, T3_A = cfg.action_dim, T3_SA = T3_S + T3_A;
-    mlp_off(ma, T3_S, H, L, T3_A);
-    mlp_off(mc, T3_SA, H, L, 1);
+    mlp_off(ma, T3_S, H, L, T3_A, cfg.use_layer_norm != 0);
+    mlp_off(mc, T3_SA, H, L, 1, cfg.use_layer_norm != 0);
     const int P = ma.P + 2 * mc.P;
     const uint64_t key = rng_keys[c];
     const float bS = (float)(1.0 / __builtin_sqrt((double)T3_S)), bSA = (float)(1.0 / __builtin_sqrt((double)T3_SA)),
                 bH = (float)(1.0 / __builtin_sqrt((double)H));
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
         float bound;
+        {   // nn.LayerNorm: weight 1, bias 0
+            const MlpOff &mo = i < ma.P ? ma : mc;
+            const int j = i < ma.P ? i : (i - ma.P) % mc.P;
+            if (mo.ln && j >= mo.oLN && j < mo.oLN + 2 * H) { agent_init[c * row_stride + i] = j < mo.oLN + H ? 1.0f : 0.0f; continue; }
+        }
         if (i < ma.P) bound = i < ma.oW[1] ? bS : bH;
         else { const int j = (i - ma.P) % mc.P; bound = j < mc.oW[1] ? bSA : bH; }
         const float u = (float)u64_to_unit(rng_u64(key, STREAM_AGENT_INIT, (uint64_t)i));
@@ -754,8 +801,8 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
     if (L < 1 || L > T3_MAXL || H < 1 || H > T3_MAXW || B < 1 || B > T3_MAXB || T < 1 || T * T3_S > DNT || cfg->rn_layers < 1 || cfg->rn_layers > T3_MAXL || Hrn > T3_MAXW || Hrn < 1 ||
         cfg->policy_delay < 1 || cfg->max_steps < 1 || cfg->train_episodes < 0)
         return LENV_ERR_UNSUPPORTED;
-    mlp_off(a.actor, T3_S, H, L, T3_A);
-    mlp_off(a.critic, T3_SA, H, L, 1);
+    mlp_off(a.actor, T3_S, H, L, T3_A, cfg->use_layer_norm != 0);
+    mlp_off(a.critic, T3_SA, H, L, 1, cfg->use_layer_norm != 0);
     a.P = a.actor.P + 2 * a.critic.P;
     a.P_rn = (int)lenv_rn_num_params(t, T3_S, cfg->info_dim, Hrn, cfg->rn_layers);
     a.P_rn_lds = cfg->rn_layers > 1 ? 0 : a.P_rn;             // deeper reward nets are staged in the arena
@@ -779,6 +826,11 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
     a.a_d[0] = take((int64_t)RB * H); a.a_d[1] = take((int64_t)RB * H);
     a.a_dx = take((int64_t)RB * T3_SA); a.a_act = take((int64_t)RB * T3_A); a.a_th = take((int64_t)RB * T3_A); a.a_dz = take((int64_t)RB * T3_A);
     a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
+    {   // use_layer_norm: normalised rows / 1 / sqrt(var + eps) of the LayerNorm positions of the passes that are differentiated
+        const bool ln = a.actor.ln != 0;
+        for (int n = 0; n < 3; ++n) for (int l = 0; l < T3_MAXL; ++l) a.a_xh[n][l] = take(ln && l >= 1 && l < L ? (int64_t)RB * H : 0);
+        a.a_rstd = take(ln ? 3 * (int64_t)T3_MAXL * B : 0);
+    }
     a.a_se = a.a_xse = a.a_nse = 0;
     if (cfg->virtual_env) {
         if ((int64_t)RB * H < Hrn) return LENV_ERR_UNSUPPORTED;          // the SE's hidden rows reuse the agent's temporaries
@@ -914,7 +966,7 @@ extern "C" int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg, const lenv_ch
             return cfg->env_id == sp.env && (cfg->virtual_env != 0) == (sp.virtual_env != 0) && (cfg->same_action_num > 1 ? cfg->same_action_num : 1) == sp.k_rep &&
                    cfg->hidden == sp.H && cfg->layers == sp.L && cfg->batch_size == sp.B && cfg->test_episodes == sp.T && cfg->rn_hidden == sp.Hrn &&
                    cfg->rn_layers == sp.rn_layers && cfg->rn_act == sp.rn_act && cfg->reward_env_type == sp.rtype && cfg->act == sp.act &&
-                   cfg->policy_delay == sp.policy_delay;
+                   cfg->policy_delay == sp.policy_delay && !cfg->use_layer_norm;
         };
         // production launches of the cfg-5 shape: the wave-chain kernel (kernel_variant NO_WAVECHAIN keeps the GEMM-queue kernel for A/B runs)
         if (!off && !(cfg->kernel_variant & LENV_VARIANT_NO_WAVECHAIN) && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_reward && lenv_wc_td3_shape(cfg)) {

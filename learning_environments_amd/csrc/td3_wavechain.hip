@@ -1451,7 +1451,7 @@ using namespace lenv;
 int lenv_wc_td3_shape(const lenv_td3_cfg *cfg)
 {
     if (!(cfg->hidden == 128 && cfg->layers == 2 && cfg->batch_size == T3W_B && cfg->rn_hidden == 128 && !cfg->virtual_env && cfg->same_action_num <= 1 &&
-          cfg->policy_delay == 1 && !cfg->icm_enabled &&
+          cfg->policy_delay == 1 && !cfg->icm_enabled && !cfg->use_layer_norm &&
           (cfg->reward_env_type == 0 || cfg->reward_env_type == 1 || cfg->reward_env_type == 2 || cfg->reward_env_type == 5 || cfg->reward_env_type == 6)))
         return 0;
     if (cfg->env_id == LENV_ENV_CHEETAH_STANDIN && cfg->state_dim == 17 && cfg->action_dim == 6 && cfg->test_episodes == 1 && cfg->rn_layers == 1 &&

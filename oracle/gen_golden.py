@@ -1388,7 +1388,7 @@ def _gen_g11_body(cfg, n, GTN_Master, GTN_Worker, shutil):
 def main():
     # no arguments (or "all"): every fixture under tests/golden is regenerated (the full-shape runs g8df / g8tf take minutes each)
     ALL = ["g1", "g1ln", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x",
-           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8df", "g8l2", "g8ln", "g8m", "g8r", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k"]
+           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8tln", "g8df", "g8l2", "g8ln", "g8m", "g8r", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k"]
     which = sys.argv[1:] or ALL
     if "all" in which:
         which = ALL
@@ -1413,6 +1413,14 @@ def main():
         gen_g4t()
     if "g8t" in which:
         gen_g8t("g8t_calc_score_cheetah_td3", seed=830)
+    if "g8tln" in which:
+        # `use_layer_norm: True` in the td3 section (models/model_utils.py:22-37): actor and critics with two / three hidden layers, one
+        # shared nn.LayerNorm per net (at one / two positions)
+        gen_g8t("g8tln_calc_score_cheetah_td3_layernorm", seed=831,
+                agent_over={"train_episodes": 4, "init_episodes": 2, "batch_size": 16, "hidden_size": 24, "test_episodes": 2, "use_layer_norm": True})
+        gen_g8t("g8tln3_calc_score_cheetah_td3_layernorm_3layer", seed=832,
+                agent_over={"train_episodes": 4, "init_episodes": 2, "batch_size": 12, "hidden_size": 20, "hidden_layer": 3, "test_episodes": 2,
+                            "policy_delay": 2, "use_layer_norm": True})
     if "g4td" in which:
         gen_g4td()
     if "g8td" in which:

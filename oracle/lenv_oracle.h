@@ -233,7 +233,10 @@ typedef struct {
     double adam_beta1, adam_beta2, adam_eps;
     int64_t step_budget;
     /* TD3(icm=True), select_agent "td3_icm" (agents/TD3.py:44-60,68-70): config section `icm` */
-    int32_t icm_enabled, icm_feature_dim, icm_hidden, icm_pad_;
+    int32_t icm_enabled, icm_feature_dim, icm_hidden;
+    /* `use_layer_norm` of the td3 section (models/model_utils.py:22-37): ONE shared nn.LayerNorm(hidden) behind every hidden Linear but the
+     * first of the actor and of each critic (three modules, one per net), weight | bias behind the net's second Linear */
+    int32_t use_layer_norm;
     double icm_lr, icm_beta, icm_eta;
     /* virtual_env != 0 (gtn.synthetic_env_type 0, default_config_halfcheetah.yaml): the agent trains on a VirtualEnv
      * (envs/virtual_env.py:43-54) instead of the RewardEnv -- rn_params then holds state_net | reward_net | done_net, each

@@ -79,7 +79,7 @@ class Td3Cfg(C.Structure):
                 ("action_std", C.c_double), ("policy_std", C.c_double), ("policy_std_clip", C.c_double),
                 ("max_action", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
                 ("step_budget", C.c_int64),
-                ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("icm_pad_", C.c_int32),
+                ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("use_layer_norm", C.c_int32),
                 ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
                 ("virtual_env", C.c_int32), ("same_action_num", C.c_int32)]
 
@@ -561,6 +561,7 @@ def td3_cfg_from_config(config, rng_mode=0, **overrides):
     if "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 1)) == 0:
         cfg.virtual_env = 1                           # the agent trains on a VirtualEnv: the `envs` section describes the three SE nets
     cfg.same_action_num = int(a["same_action_num"])
+    cfg.use_layer_norm = 1 if a.get("use_layer_norm", False) else 0      # model_utils.py:22-29
     name = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "td3"
     if name.replace("_vary", "").endswith("_icm"):   # select_agent "td3_icm": TD3(icm=True), agents/TD3.py:44-60
         ic = config["agents"]["icm"]

@@ -308,9 +308,20 @@ def test_config_builders_refuse_layer_norm_sections():
     with pytest.raises(NotImplementedError):
         config.ddqn_cfg_from_config(c)
     c = configs.halfcheetah_reward_env_td3(2)
-    c["agents"]["td3"]["use_layer_norm"] = True
+    c["envs"]["HalfCheetah-v3"]["use_layer_norm"] = True       # the reward net
     with pytest.raises(NotImplementedError):
         config.td3_cfg_from_config(c)
+    # TD3 takes the AGENT's LayerNorm (cfg.use_layer_norm): one block per net (actor, critic_1, critic_2) behind its second Linear
+    c = configs.halfcheetah_reward_env_td3(2)
+    c["agents"]["td3"]["use_layer_norm"] = True
+    tcfg = config.td3_cfg_from_config(c)
+    sl = config.td3_layer_norm_slices(tcfg)
+    pa, pc = (17 * 128 + 128) + (128 * 128 + 128) + 256 + (6 * 128 + 6), (23 * 128 + 128) + (128 * 128 + 128) + 256 + 129
+    assert tcfg.use_layer_norm == 1 and sl == [(17 * 128 + 128 + 128 * 128 + 128, 128), (pa + 23 * 128 + 128 + 128 * 128 + 128, 128),
+                                               (pa + pc + 23 * 128 + 128 + 128 * 128 + 128, 128)]
+    from learning_environments_amd.agents import nes_common as nc
+    tb = nc.with_layer_norm_block(nc.linear_init_bounds(config.td3_layer_dims(tcfg)), sl)
+    assert tb.size == pa + 2 * pc and all(not tb[o:o + 256].any() and tb[o - 1] > 0 and tb[o + 256] > 0 for o, _ in sl)
     # the DDQN / DuelingDDQN loop takes the AGENT's LayerNorm (cfg.q_layer_norm); the block of the shared module sits behind the second Linear
     from learning_environments_amd.agents import nes_common
     c = configs.acrobot_syn_env_ddqn(2)

@@ -469,6 +469,37 @@ def test_gtn_master_td3_cheetah_generation(tmp_path, monkeypatch):
     assert len(mean_list) == 1 and np.isfinite(mean_score)
 
 
+def test_gtn_master_td3_layer_norm_generation(tmp_path, monkeypatch):
+    """`use_layer_norm: True` in the td3 section through GTN_Master: cfg.use_layer_norm, the three nets' LayerNorm blocks (weight 1, bias
+    0) in the fresh agents, and fitness values equal to an oracle evaluation of the same agents."""
+    from learning_environments_amd.configs import fixed_work, halfcheetah_reward_env_td3
+    from oracle import oracle as orc
+    cfg = fixed_work(halfcheetah_reward_env_td3(num_workers=2, max_iterations=1), 2)
+    cfg["envs"]["HalfCheetah-v3"]["max_steps"] = 5
+    cfg["agents"]["td3"].update(init_episodes=1, batch_size=32, hidden_size=40, use_layer_norm=True)
+    m = _master_pair(cfg, tmp_path, monkeypatch)
+    H = 40
+    pa, pc = (17 * H + H) + (H * H + H) + 2 * H + (6 * H + 6), (23 * H + H) + (H * H + H) + 2 * H + (H + 1)
+    assert m.task.name == "td3_rn" and m.cfg.use_layer_norm == 1 and m.inner.p_agent == pa + 2 * pc and m.agent_bounds.numel() == pa + 2 * pc
+    assert [o for o, _ in m.task.ln_slice] == [17 * H + H + H * H + H, pa + 23 * H + H + H * H + H, pa + pc + 23 * H + H + H * H + H]
+    theta0 = m.theta.cpu().numpy().copy()
+    gathered = m.evaluate_population(0).cpu().numpy()
+    eps = m.eps.cpu().numpy()
+    oeps, init, okeys = orc.nes_draw(m.seed, 0, 2, m.p_theta, cfg["agents"]["gtn"]["noise_std"], 6, 3, 0, m.agent_bounds.cpu().numpy())
+    assert np.array_equal(eps, oeps)
+    for off, h in m.task.ln_slice:
+        assert np.all(init[:, off:off + 2 * h] == 0.0)
+        init[:, off:off + h] = 1.0                           # nn.LayerNorm: weight 1, bias 0 (tasks.set_layer_norm_init)
+    ocfg = orc.td3_cfg_from_config(cfg)
+    assert ocfg.use_layer_norm == 1
+    for p in range(2):
+        sc = []
+        for kind, sg in enumerate((0.0, 1.0, -1.0)):
+            w = (np.float32(sg) * eps[p] + theta0).astype(np.float32)
+            sc.append(orc.td3_rn_chain(ocfg, w, init[3 * p + kind], rng_key=orc.chain_key(m.seed, 0, p, kind))["score"])
+        assert gathered[p, 1] == sc[0] and gathered[p, 0] == max(sc[1], sc[2])
+
+
 def test_gtn_master_acrobot_ddqn_vary_as_shipped(tmp_path, monkeypatch):
     """default_config_acrobot.yaml as the reference ships it (`agent_name: DDQN_vary`, ddqn 128 / 2 layers / batch 128): the
     launch is sized for batch 384, width 384, 3 hidden layers; one short generation runs and every chain's draw is inside

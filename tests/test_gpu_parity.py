@@ -1207,7 +1207,8 @@ def _td3_cfgs(orc, cfgd, rng_mode, **over):
     return o, c
 
 
-@pytest.mark.parametrize("name", ["g8t_calc_score_cheetah_td3", "g8tf_calc_score_cheetah_td3_fullshape"])
+@pytest.mark.parametrize("name", ["g8t_calc_score_cheetah_td3", "g8tf_calc_score_cheetah_td3_fullshape",
+                                  "g8tln_calc_score_cheetah_td3_layernorm", "g8tln3_calc_score_cheetah_td3_layernorm_3layer"])   # use_layer_norm in the td3 section
 def test_td3_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
     g = golden(name)
     ocfg, cfg = _td3_cfgs(orc, json.loads(str(g["config_json"])), 1)
@@ -1352,6 +1353,63 @@ def test_td3_counter_mode_vs_oracle(eng, orc, golden, hidden, layers, batch, act
         assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
         assert float(il.score[c]) == o["score"]
         assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
+@pytest.mark.parametrize("hidden,layers,batch,act,delay,env", [(24, 2, 16, "relu", 1, "HalfCheetah-v3"), (40, 3, 33, "tanh", 2, "HalfCheetah-v3"),
+                                                               (128, 2, 192, "leakyrelu", 1, "Pendulum-v0"), (24, 1, 16, "relu", 1, "HalfCheetah-v3")])
+def test_layer_norm_in_the_td3_loop_vs_oracle(eng, orc, golden, hidden, layers, batch, act, delay, env):
+    """`use_layer_norm: True` in the td3 section (models/model_utils.py:22-37): one shared LayerNorm per net (actor, critic_1, critic_2)
+    behind its hidden Linear 2..L -- forward (incl. the one-row actor of the env / test steps), backward and the optimizer step inside
+    td3_rn_inner_kernel (lenv_ln.cuh row routines between the queued products).  Counter mode, three chains, against the oracle (which
+    reproduces the reference runs G8TLN / G8TLN3): step traces, returns, counters and ALL final parameters, bit for bit.  The Pendulum case
+    is default_config_pendulum_reward_env.yaml's shape, which without the flag takes the wave-chain kernel; one hidden layer: no position."""
+    from learning_environments_amd import configs
+    if env == "Pendulum-v0":
+        cfgd = configs.pendulum_reward_env_td3(2)
+        cfgd["agents"]["td3"].update(train_episodes=3, init_episodes=1, test_episodes=10, use_layer_norm=True)
+        cfgd["envs"][env].update(max_steps=8)
+        rtype, S, info = 2, 3, 0
+    else:
+        g = golden("g8t_calc_score_cheetah_td3")
+        cfgd = json.loads(str(g["config_json"]))
+        cfgd["agents"]["td3"].update(hidden_size=hidden, hidden_layer=layers, batch_size=batch, activation_fn=act, policy_delay=delay,
+                                     train_episodes=3, init_episodes=1, test_episodes=3, use_layer_norm=True)
+        cfgd["envs"][env].update(max_steps=8, hidden_size=24, reward_env_type=2)
+        rtype, S, info = 2, 17, 4
+    ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
+    assert cfg.use_layer_norm == 1 and ocfg.use_layer_norm == 1
+    Pa, Pc = orc.td3_param_counts(ocfg)
+    P_rn = orc.rn_num_params(rtype, S, info, ocfg.rn_hidden, ocfg.rn_layers)
+    rng = np.random.RandomState(12)
+    chains = 3
+    theta = (rng.randn(P_rn) * 0.2).astype(np.float32)
+    eps = (rng.randn(1, P_rn) * 0.1).astype(np.float32)
+    agent_init = rng.uniform(-0.2, 0.2, (chains, Pa + 2 * Pc)).astype(np.float32)
+    if layers >= 2:                                        # the three LayerNorm blocks: around weight 1 / bias 0
+        A = ocfg.action_dim
+        for base, n_in in ((0, S), (Pa, S + A), (Pa + Pc, S + A)):
+            off = base + (n_in * hidden + hidden) + (hidden * hidden + hidden)
+            agent_init[:, off:off + hidden] = 1.0 + 0.1 * rng.randn(chains, hidden).astype(np.float32)
+            agent_init[:, off + hidden:off + 2 * hidden] = 0.05 * rng.randn(chains, hidden).astype(np.float32)
+    worker = np.zeros(chains, np.int32)
+    sign = np.array([0.0, 1.0, -1.0], np.float32)
+    keys = np.array([orc.chain_key(23, 4, 0, c) for c in range(chains)], np.uint64)
+    il = eng.Td3InnerLoop(cfg, chains, trace_cap=30, want_final_params=True, want_episode_stats=True)
+    assert (il.p_actor, il.p_critic) == (Pa, Pc)
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        w = (np.float32(sign[c]) * eps[0] + theta).astype(np.float32)
+        o = orc.td3_rn_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]), trace_cap=30, want_final_params=True)
+        n = o["trace"]["reward"].size
+        assert o["learn_steps"] >= 8                       # (the Pendulum case stops early: 8 steps of cost stay above solved_reward)
+        assert np.array_equal(il.trace["action"][c, :n].cpu().numpy(), o["trace"]["action"]), c
+        assert np.array_equal(il.trace["reward"][c, :n].cpu().numpy(), o["trace"]["reward"]), c
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(il.final_params[c].cpu().numpy(), o["final_params"]), c
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -549,12 +549,16 @@ def test_cheetah_standin_matches_shim_run(golden):
         assert np.array_equal(np.array(list(x)).astype(np.float32), g["tr_next_state"][k])
 
 
-@pytest.mark.parametrize("name", ["g8t_calc_score_cheetah_td3", "g8tf_calc_score_cheetah_td3_fullshape"])
+@pytest.mark.parametrize("name", ["g8t_calc_score_cheetah_td3", "g8tf_calc_score_cheetah_td3_fullshape",
+                                  "g8tln_calc_score_cheetah_td3_layernorm", "g8tln3_calc_score_cheetah_td3_layernorm_3layer"])
 def test_g8t_calc_score_cheetah_td3(golden, name):
-    """The *_fullshape fixture is BASELINE configs[4] at its real network shapes (128x2 actor/critics, B 192, RN hidden 128)."""
+    """The *_fullshape fixture is BASELINE configs[4] at its real network shapes (128x2 actor/critics, B 192, RN hidden 128); the
+    *_layernorm ones have `use_layer_norm: True` in the td3 section (one shared nn.LayerNorm per net, at one / two positions)."""
     import json
     g = golden(name)
     cfg = orc.td3_cfg_from_config(json.loads(str(g["config_json"])), rng_mode=1)
+    assert cfg.use_layer_norm == (1 if "layernorm" in name else 0)
+    assert g["agent_init"].size == sum(orc.td3_param_counts(cfg)) + orc.td3_param_counts(cfg)[1]
     tapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
                                g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
     n = g["tr_reward"].size
