@@ -14,6 +14,10 @@ def _refuse_layer_norm(config, env_section, agent_section):
     loop, cfg.use_layer_norm in the TD3 and TD3_discrete_vary loops; lenv_mlp_forward in the one-step API)."""
     for name, sec in (("envs." + config["env_name"], env_section), ("agent", agent_section)):
         if sec is not None and sec.get("use_layer_norm", False):
+            hl = sec.get("hidden_layer", 1)
+            hl = hl[1] if isinstance(hl, list) else hl       # env_factory.py:54-58: list-valued entries -> value[1]
+            if int(hl) < 2:
+                continue                                     # one hidden layer: build_nn_from_config never appends the module -- the same network
             raise NotImplementedError("use_layer_norm in the %s section: no fused inner loop takes LayerNorm nets here" % name)
 
 

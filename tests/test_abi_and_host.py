@@ -305,10 +305,12 @@ def test_config_builders_refuse_layer_norm_sections():
     from learning_environments_amd import config, configs
     c = configs.cartpole_syn_env_ddqn(2)
     c["envs"]["CartPole-v0"]["use_layer_norm"] = True
+    config.ddqn_cfg_from_config(c)                           # one hidden layer: the module is never appended (model_utils.py:33-36) -- the same net
+    c["envs"]["CartPole-v0"]["hidden_layer"] = 2
     with pytest.raises(NotImplementedError):
         config.ddqn_cfg_from_config(c)
     c = configs.halfcheetah_reward_env_td3(2)
-    c["envs"]["HalfCheetah-v3"]["use_layer_norm"] = True       # the reward net
+    c["envs"]["HalfCheetah-v3"].update(use_layer_norm=True, hidden_layer=2)       # the reward net
     with pytest.raises(NotImplementedError):
         config.td3_cfg_from_config(c)
     # TD3 takes the AGENT's LayerNorm (cfg.use_layer_norm): one block per net (actor, critic_1, critic_2) behind its second Linear
