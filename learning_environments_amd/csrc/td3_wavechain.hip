@@ -28,11 +28,13 @@ constexpr int T3W_B = 192, T3W_NB = T3W_B / 32;                           // min
 
 // The published shapes this kernel is instantiated for (hidden 128 x 2, batch 192, policy_delay 1, a RewardEnv with 128-wide reward nets):
 // the real env, the agent's activation, the test episodes per test phase, the reward net's hidden layers.
-struct T3wShape { int env, act, T, rn_layers; };
+// k_rep: same_action_num (env steps per chosen action: the repeats stop at done, their shaped rewards are summed as python floats)
+struct T3wShape { int env, act, T, rn_layers, k_rep; };
 constexpr T3wShape kT3wShapes[] = {
-    { -1, 0, 1, 1 },
-    { LENV_ENV_CHEETAH_STANDIN, LENV_ACT_RELU, 1, 1 },        // 1: default_config_halfcheetah_reward_env.yaml = BASELINE configs[4]
-    { LENV_ENV_PENDULUM, LENV_ACT_LEAKYRELU, 10, 2 },         // 2: default_config_pendulum_reward_env.yaml (actor 3-128-128-1, critics 4-128-128-1)
+    { -1, 0, 1, 1, 1 },
+    { LENV_ENV_CHEETAH_STANDIN, LENV_ACT_RELU, 1, 1, 1 },     // 1: default_config_halfcheetah_reward_env.yaml = BASELINE configs[4]
+    { LENV_ENV_PENDULUM, LENV_ACT_LEAKYRELU, 10, 2, 1 },      // 2: default_config_pendulum_reward_env.yaml (actor 3-128-128-1, critics 4-128-128-1)
+    { LENV_ENV_CMC, LENV_ACT_LEAKYRELU, 1, 1, 2 },            // 3: default_config_cmc_reward_env.yaml (actor 2-128-128-1, critics 3-128-128-1; the episode ends at the flag)
 };
 
 // dumps: [T3W_NB] blocks of BLK floats each (register order), or [192][128] row-major copies (same size)
@@ -662,7 +664,9 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     extern __shared__ __align__(16) float lds[];
     constexpr int S = EnvT::S, A = EnvT::A, SA = S + A, SD = EnvT::SD, B = T3W_B, Hrn = 128, ACT = SP.act, T = SP.T, RNL = SP.rn_layers;
     constexpr bool CHEETAH = SP.env == LENV_ENV_CHEETAH_STANDIN;
-    static_assert(S <= 17 && A <= 6 && SD <= 18 && !EnvT::TERMINATES, "sized for the stand-in; the test episodes run their full length");
+    constexpr int KREP = SP.k_rep;
+    static_assert(S <= 17 && A <= 6 && SD <= 18, "sized for the stand-in");
+    static_assert(!(EnvT::TERMINATES && T > 1) && !(KREP > 1 && T > 1), "the lock-step test routine: full-length episodes, one env step per action");
     const lenv_td3_cfg &cfg = a.cfg;
     const int tid = threadIdx.x;
     // A chain is run by a TEAM of G workgroups (G = 1: the plain one-workgroup-per-chain launch).  Workgroups are dealt to the eight
@@ -1070,7 +1074,9 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
             if (tid == 0) ep_rew[te] = 0.0f;
             __syncthreads();
             int my_el = 0;
-            for (int ai = 0; ai < cfg.max_steps; ++ai) {
+            bool ep_alive = true;                          // (uniform: the episode's state lives in LDS)
+            const int nag = (cfg.max_steps + KREP - 1) / KREP;     // agent steps of a full-length episode
+            for (int ai = 0; ai < nag && ep_alive; ++ai) {
                 KSUB_RESET;
                 if (tid < S) xt[tid] = EnvT::obs(tid, xt_d);
                 __syncthreads();
@@ -1084,15 +1090,23 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 }
                 __syncthreads();
                 KSUB_MARK(14);
-                double nx = 0.0, pre = 0.0;
-                if (tid < SD) nx = env_step_word(tid, xt_d, at);
-                if (tid == 0) pre = EnvT::reward_pre(xt_d, at);
-                __syncthreads();
-                if (tid < SD) xt_d[tid] = nx;
-                __syncthreads();
-                if (tid == 0) ep_rew[te] = ep_rew[te] + (float)(0.0 + EnvT::reward_post(xt_d, pre));
-                ++my_el;
-                __syncthreads();
+                // the action is applied same_action_num times or until the episode ends (the env's own flag / TimeLimit); the rewards of the
+                // repeats are summed as python floats (env_wrapper.py:56-61)
+                double rsum = 0.0;
+#pragma unroll 1
+                for (int r_ = 0; r_ < KREP && ep_alive; ++r_) {
+                    double nx = 0.0, pre = 0.0;
+                    if (tid < SD) nx = env_step_word(tid, xt_d, at);
+                    if (tid == 0) pre = EnvT::reward_pre(xt_d, at);
+                    __syncthreads();
+                    if (tid < SD) xt_d[tid] = nx;
+                    __syncthreads();
+                    if (tid == 0) rsum = rsum + EnvT::reward_post(xt_d, pre);
+                    ++my_el;
+                    if (EnvT::done(xt_d) || my_el >= cfg.max_steps) ep_alive = false;
+                    __syncthreads();
+                }
+                if (tid == 0) ep_rew[te] = ep_rew[te] + (float)rsum;
                 KSUB_MARK(15);
             }
             if (tid == 0) { ret[te] = (double)ep_rew[te]; tlen[te] = my_el; }
@@ -1135,7 +1149,9 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
             // ---- EnvWrapper.step -> RewardEnv.step -> real_env.step + TimeLimit ----
             if (tid < S) newrow[tid] = state[tid];
             if (tid >= 64 && tid < 64 + A) newrow[S + tid - 64] = action[tid - 64];
-            {
+            double rsum = 0.0;                             // (thread 0) python-float sum of the repeats' shaped rewards (env_wrapper.py:56-61)
+#pragma unroll 1
+            for (int r_ = 0; r_ < KREP; ++r_) {
                 double nx = 0.0, pre = 0.0;
                 if (tid < SD) nx = env_step_word(tid, xs_d, action);
                 if (tid == 64) pre = EnvT::reward_pre(xs_d, action);
@@ -1159,18 +1175,21 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                     case 5: shaped = phi_s2; break;
                     default: shaped = r32 + phi_s2; break;
                     }
-                    newrow[2 * S + A] = (float)(0.0 + (double)shaped); newrow[2 * S + A + 1] = dn ? 1.0f : 0.0f;
+                    rsum = rsum + (double)shaped;
+                    newrow[2 * S + A] = (float)rsum; newrow[2 * S + A + 1] = dn ? 1.0f : 0.0f;
                     ctrl[12] = phi_s2;
                 }
                 __syncthreads();
                 if (tid < S) state[tid] = newrow[S + A + tid];
+                if (dn) break;                             // (uniform) the repeats stop at done
+                if (r_ + 1 < KREP) __syncthreads();
             }
             __syncthreads();
             if (tid < 2 * S + A + 2) rb[(int64_t)new_pos * RS + tid] = newrow[tid];
             const float done_now = newrow[2 * S + A + 1];
             __syncthreads();
             if (tid < S) state[tid] = newrow[S + A + tid];
-            ep_len += 1; ++train_steps;
+            ep_len += KREP; ++train_steps;                 // base_agent.py:122: episode_length += same_action_num
             __syncthreads();
             TPT_MARK(0);
             if (learning) {
@@ -1450,16 +1469,20 @@ using namespace lenv;
 // the published cfg-5 shape in production form (checked by the caller: counter RNG, no trace, no hp, no ICM)
 int lenv_wc_td3_shape(const lenv_td3_cfg *cfg)
 {
-    if (!(cfg->hidden == 128 && cfg->layers == 2 && cfg->batch_size == T3W_B && cfg->rn_hidden == 128 && !cfg->virtual_env && cfg->same_action_num <= 1 &&
+    const int k_rep = cfg->same_action_num > 1 ? cfg->same_action_num : 1;
+    if (!(cfg->hidden == 128 && cfg->layers == 2 && cfg->batch_size == T3W_B && cfg->rn_hidden == 128 && !cfg->virtual_env &&
           cfg->policy_delay == 1 && !cfg->icm_enabled && !cfg->use_layer_norm &&
           (cfg->reward_env_type == 0 || cfg->reward_env_type == 1 || cfg->reward_env_type == 2 || cfg->reward_env_type == 5 || cfg->reward_env_type == 6)))
         return 0;
     if (cfg->env_id == LENV_ENV_CHEETAH_STANDIN && cfg->state_dim == 17 && cfg->action_dim == 6 && cfg->test_episodes == 1 && cfg->rn_layers == 1 &&
-        cfg->act == LENV_ACT_RELU)
+        cfg->act == LENV_ACT_RELU && k_rep == 1)
         return 1;
     if (cfg->env_id == LENV_ENV_PENDULUM && cfg->state_dim == 3 && cfg->action_dim == 1 && cfg->test_episodes == 10 && cfg->rn_layers == 2 &&
-        cfg->act == LENV_ACT_LEAKYRELU)
+        cfg->act == LENV_ACT_LEAKYRELU && k_rep == 1)
         return 2;
+    if (cfg->env_id == LENV_ENV_CMC && cfg->state_dim == 2 && cfg->action_dim == 1 && cfg->test_episodes == 1 && cfg->rn_layers == 1 &&
+        cfg->act == LENV_ACT_LEAKYRELU && k_rep == 2)
+        return 3;
     return 0;
 }
 
@@ -1498,7 +1521,7 @@ static size_t t3w_lds_bytes(int shape, int P_rn)
                               20 + 8 + 56 + 4 + (sizeof(T3wCtx) + 3) / 4;
     return lds_floats * sizeof(float);
 }
-static void (*t3w_kernel(int shape))(const T3wArgs) { return shape == 2 ? td3_wavechain_kernel<2> : td3_wavechain_kernel<1>; }
+static void (*t3w_kernel(int shape))(const T3wArgs) { return shape == 3 ? td3_wavechain_kernel<3> : (shape == 2 ? td3_wavechain_kernel<2> : td3_wavechain_kernel<1>); }
 
 // Workgroups per chain.  A team only works when every workgroup of the launch is resident at the same time (its members wait for each
 // other): 8 * ceil(chains / 8) * G workgroups must fit the device (occupancy API: one per CU at this kernel's LDS footprint).  192

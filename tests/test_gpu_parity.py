@@ -2776,6 +2776,58 @@ def test_wavechain_td3_pendulum_shape_every_team_size(eng, orc):
         assert np.array_equal(ref[4][c], o["final_params"])
 
 
+def test_wavechain_td3_cmc_shape_every_team_size(eng, orc):
+    """The TD3 wave-chain kernel's third shape -- default_config_cmc_reward_env.yaml: MountainCarContinuous-v0 (an env that TERMINATES: the
+    episode ends at the flag), actor 2-128-128-1, twin critics 3-128-128-1, leakyrelu, batch 192, one test episode, tanh reward net with one
+    hidden layer, same_action_num 2 (every chosen action applied twice or until done, the shaped rewards summed) -- in production launches
+    with G = 1, 2, 3, 6 workgroups per chain against the GEMM-queue kernel and, on two whole chains, the oracle: all outputs + the 51 331
+    final parameters, bit for bit."""
+    import ctypes as C
+    from learning_environments_amd import _lib, configs
+    from learning_environments_amd.agents.nes_common import chain_keys
+    cfgd = configs.fixed_work(configs.cmc_reward_env_td3(2), 3)
+    cfgd["agents"]["td3"]["init_episodes"] = 1
+    cfgd["envs"]["MountainCarContinuous-v0"]["max_steps"] = 41       # odd: the last action of a full-length episode is applied once
+    ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
+    assert (cfg.state_dim, cfg.action_dim, cfg.hidden, cfg.layers, cfg.batch_size, cfg.test_episodes, cfg.rn_layers, cfg.policy_delay,
+            cfg.same_action_num) == (2, 1, 128, 2, 192, 1, 1, 1, 2)
+    chains = 5
+    Pa, Pc = orc.td3_param_counts(ocfg)
+    assert Pa + 2 * Pc == 51331
+    P_rn = orc.rn_num_params(2, 2, 0, 128, 1)
+    rng = np.random.RandomState(18)
+    theta = (rng.randn(P_rn) * 0.1).astype(np.float32)
+    eps = (rng.randn(2, P_rn) * 0.05).astype(np.float32)
+    worker = (np.arange(chains) // 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), 2)[:chains].copy()
+    keys = chain_keys(82, 2, worker, np.arange(chains) % 3)
+    init = rng.uniform(-0.08, 0.08, (chains, Pa + 2 * Pc)).astype(np.float32)
+
+    def run(trace_cap):
+        il = eng.Td3InnerLoop(cfg, chains, trace_cap=trace_cap, want_final_params=True, want_episode_stats=True)
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return [t.cpu().numpy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_params, il.episode_len)]
+
+    ref = run(2)                                            # GEMM-queue kernel (a launch with a step trace)
+    assert ref[1][:, 2].min() >= 20 and ref[5].max() == 42  # 21 agent steps; episode_length += same_action_num per agent step (base_agent.py:122)
+    assert _lib.lib().lenv_td3_rn_team_size(C.byref(cfg), chains) == 6
+    for G in (1, 2, 3, 6):
+        cfg.team_size = G
+        out = run(0)
+        for x, y in zip(out, ref):
+            assert np.array_equal(x, y, equal_nan=True), G
+    for c in (0, 4):
+        w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+        o = orc.td3_rn_chain(ocfg, w, init[c], rng_key=int(keys[c]), want_final_params=True)
+        assert float(ref[0][c]) == o["score"]
+        assert ref[1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(ref[2][c], o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(ref[3][c], o["final_test_returns"])
+        assert np.array_equal(ref[4][c], o["final_params"])
+
+
 @pytest.mark.parametrize("chains", [5, 11])
 def test_wavechain_td3_team_sizes_agree(eng, orc, chains):
     """A chain run by a team of G = 2, 3, 6 workgroups (sample blocks and gradient tiles dealt over the team, six agent-scope
