@@ -24,7 +24,8 @@ using namespace wc;
 // fixed: H = F = 128, L = 2, B = 128; kind 1 = DuelingDDQN (Critic_DuelingDQN), kind 0 = DDQN whose Critic_DQN is S-128-128-A (the plain-DQN
 // mode of lenv_dueling_se_inner_loop: models/actor_critic.py:84-91, agents/DDQN.py:60-94): layers 1 and 2, then the A-column output layer
 // where the dueling net has its advantage head -- no feature / stream layers, no value head, no advantage mean.  The arena keeps the
-// dueling layout (the unused matrices stay zero and are skipped by the optimizer pass); plain shapes run on one workgroup per chain.
+// dueling layout (the unused matrices stay zero and are skipped by the optimizer pass); teams of two as the dueling shape (the chain
+// round stores d_h2, member 0 takes the output layer's and layer 1's gradients, member 1 W2's).
 struct WcShape { int env, S, A, Hse, T, q_act, se_act, kind; };
 constexpr WcShape kWcShapes[] = {
     { -1, 2, 2, 1, 1, 0, 0, 1 },
@@ -738,6 +739,8 @@ template <int SHAPE> __device__ __noinline__ void wct_forward(const WcCtx *ctx_,
 {
     WCT_PROLOGUE;
     const int pass = uni(pass_);
+    constexpr bool PL = SP.kind == 0;                    // plain DQN: W2, then the A-column output layer on h2 (the advantage head's instructions)
+    constexpr int NL = PL ? 1 : 4;
     const float *par = pass ? online : target;
     const int nj = pass ? 2 : 1;
     const int quad = wave >> 2, jt = wave & 3, blk = 2 * tg + quad, row = 32 * blk + L.li;
@@ -784,7 +787,7 @@ template <int SHAPE> __device__ __noinline__ void wct_forward(const WcCtx *ctx_,
     barrier_lds();
     WSUB_MARK(49);
 #pragma unroll 1
-    for (int l = 0; l < 4; ++l) {                      // W2, W3, Wv1, Wa1 (image of layer l in bufA)
+    for (int l = 0; l < NL; ++l) {                     // W2, W3, Wv1, Wa1 (image of layer l in bufA)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (j < nj) {
@@ -803,7 +806,7 @@ template <int SHAPE> __device__ __noinline__ void wct_forward(const WcCtx *ctx_,
                 }
                 if (pass == 1 && j == 0) {
                     piece_store(dump_of(l == 0 ? D_H2 : (l == 1 ? D_FEAT : (l == 2 ? D_V1 : D_A1)), blk), jt, L.lane, r16[j]);
-                    if (l >= 2) {                       // row-major copy for the head output layer's weight gradient
+                    if (l >= 2 || PL) {                 // row-major copy for the head output layer's weight gradient (plain: h2, in R_A1's place)
                         gfloat *rm = (gfloat *)dump_of(l == 2 ? R_V1 : R_A1, 0) + row * W + 32 * jt + 4 * L.h;
 #pragma unroll
                         for (int g4 = 0; g4 < 4; ++g4) *(gf4 *)(rm + 8 * g4) = f32x4{r16[j][4 * g4], r16[j][4 * g4 + 1], r16[j][4 * g4 + 2], r16[j][4 * g4 + 3]};
@@ -813,7 +816,7 @@ template <int SHAPE> __device__ __noinline__ void wct_forward(const WcCtx *ctx_,
             }
         }
         WSUB_MARK(50);
-        if (l < 2) {                                    // h2 / feat: the next layer's operand
+        if (!PL && l < 2) {                             // h2 / feat: the next layer's operand
 #pragma unroll
             for (int j = 0; j < 2; ++j) if (j < nj) xch_put(xch(j), jt, L.lane, r16[j]);
             barrier_lds();
@@ -822,7 +825,7 @@ template <int SHAPE> __device__ __noinline__ void wct_forward(const WcCtx *ctx_,
             stage_load_direct(par + (l == 0 ? oW3t : oWv1t), L, sr);
             stage_store_direct(bufA, L, sr);
             barrier_lds();
-        } else if (l == 2) {
+        } else if (!PL && l == 2) {
             // v1 waits in the exchange slots (bufB) for the head output layer; the Wa1 image replaces Wv1 (both layers read feat)
 #pragma unroll
             for (int j = 0; j < 2; ++j) if (j < nj) xch_put(xch(j), jt, L.lane, r16[j]);
@@ -839,7 +842,7 @@ template <int SHAPE> __device__ __noinline__ void wct_forward(const WcCtx *ctx_,
             barrier_lds();
             // task = wave: pass 1 (nj = 2): head = wave & 1, job = (wave >> 1) & 1, quad = wave >> 2; pass 0: head = wave & 1, quad = wave >> 1 (waves 0-3)
             const int hd = wave & 1, tj = nj == 2 ? (wave >> 1) & 1 : 0, tq = nj == 2 ? wave >> 2 : wave >> 1;
-            if (nj == 2 || wave < 4) {
+            if ((nj == 2 || wave < 4) && !(PL && hd == 0)) {      // (plain DQN: no value head)
                 float rh[64];
                 xch_get((hd == 0 ? bufB : bufA) + (tq * 2 + tj) * 4096, L.lane, rh);
                 f32x16 hacc;
@@ -878,21 +881,24 @@ template <int SHAPE> __device__ __noinline__ void wct_backward_chain(const WcCtx
 {
     WCT_PROLOGUE;
     const int quad = wave >> 2, jt = wave & 3, blk = 2 * tg + quad, row = 32 * blk + L.li;
+    constexpr bool PL = SP.kind == 0;                    // plain DQN: ONE round -- upstream gradient from the output layer (h2 in a1's place), then the W2 round
+    constexpr int NQ = PL ? 1 : 4;
     float *xch = bufB + quad * 4096;
     for (int i = tid; i < 4 * W + 4; i += NT) sm_wh[i] = online[oWh + i];
     StageRegs sr;
     WSUB_DECL;
-    stage_load_transposed(online + oWv1t, L, sr);
+    stage_load_transposed(online + (PL ? oW2t : oWv1t), L, sr);
     __syncthreads();
     WSUB_MARK(53);
     float r16[16], f1[16], rf[64];
     f32x16 acc;
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {                      // Wv1, Wa1, W3, W2
-        if (q < 2) {
+    for (int qi = 0; qi < NQ; ++qi) {                  // Wv1, Wa1, W3, W2
+        const int q = PL ? 3 : qi, qu = PL ? 1 : qi;
+        if (qu < 2) {
             // upstream gradient tile dz (lane = sample, register = unit) from the stream's hidden activations and the head gradient
             f32x4 hv[4];
-            piece_load(dump_of(q == 0 ? D_V1 : D_A1, blk), jt, L.lane, hv);
+            piece_load(dump_of(PL ? D_H2 : (qu == 0 ? D_V1 : D_A1), blk), jt, L.lane, hv);
             const float dqi = dq_l[row];
             float da[A];
 #pragma unroll
@@ -904,7 +910,7 @@ template <int SHAPE> __device__ __noinline__ void wct_backward_chain(const WcCtx
                 for (int cc = 0; cc < 4; ++cc) {
                     const f32x4 wk = *(const lf4 *)(whp + 4 * cc);      // (wv2, wa2_0, wa2_1, wa2_2)[unit]
                     float up;
-                    if (q == 0) up = fma32(dqi, wk[0], 0.0f);
+                    if (qu == 0) up = fma32(dqi, wk[0], 0.0f);
                     else {
                         up = 0.0f;
 #pragma unroll
@@ -915,6 +921,7 @@ template <int SHAPE> __device__ __noinline__ void wct_backward_chain(const WcCtx
             }
         }
         // (q >= 2: r16 holds the previous layer's input gradient tile)
+        if constexpr (PL) piece_store(dump_of(S_DH2, blk), jt, L.lane, r16);      // plain DQN: this IS d_h2 (the W2 weight gradient reads it)
         tile16_to_operand(r16);
         xch_put(xch, jt, L.lane, r16);
         stage_store_transposed(bufA, L, sr);
@@ -1006,8 +1013,9 @@ template <int SHAPE> __device__ __noinline__ void wct_wgrad_ends(const WcCtx *ct
     WCT_PROLOGUE;
     const int which = uni(which_);
     if (which == 0) {
+        constexpr bool PL = SP.kind == 0;                // plain DQN: the output layer sits in the advantage columns, no value column
         const int k = tid & 127, col = tid >> 7;
-        if (col <= A) {
+        if (col <= A && !(PL && col == 0)) {
             const gfloat *rm = (const gfloat *)dump_of(col == 0 ? R_V1 : R_A1, 0) + k;
             float s_ = 0.0f;
             for (int i0 = 0; i0 < B; i0 += 64) {
@@ -1019,7 +1027,7 @@ template <int SHAPE> __device__ __noinline__ void wct_wgrad_ends(const WcCtx *ct
             }
             grad[oWh + k * 4 + col] = s_;
         }
-        if (tid >= 256 && tid < 256 + 1 + A) {
+        if (tid >= 256 && tid < 256 + 1 + A && !(PL && tid == 256)) {
             const int col2 = tid - 256;
             float s_ = 0.0f;
             for (int i = 0; i < B; ++i) s_ = s_ + (col2 == 0 ? dq_l[i] : dAdv_l[i * A + col2 - 1]);
@@ -1061,7 +1069,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     extern __shared__ __align__(16) float lds[];
     constexpr WcShape SP = kWcShapes[SHAPE];
     constexpr int S = SP.S, A = SP.A, K = S + A, Hse = SP.Hse, T = SP.T, B = WC_B;
-    constexpr bool PL = SP.kind == 0;                    // plain DQN (Critic_DQN S-128-128-A): one workgroup per chain
+    constexpr bool PL = SP.kind == 0;                    // plain DQN (Critic_DQN S-128-128-A)
     static_assert(S % 2 == 0 && S <= 8 && A <= 3 && T <= 32 && Hse <= 128, "shape limits of the wave-chain kernel");
     const lenv_ddqn_cfg &cfg = a.cfg;
     Lane L;
@@ -1347,11 +1355,9 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                 __syncthreads();
                 WPT_MARK(2);
 #ifndef WC_DIAG_NO_FWD
-                if (!PL && G == 2) {
-                    if constexpr (!PL) {
+                if (G == 2) {
 #pragma unroll 1
                     for (int pass = 0; pass < 2; ++pass) wct_forward<SHAPE>(ctx, pass);
-                    }
                     team_barrier();                        // every row's V / Adv is in the exchange arrays
                     for (int e = tid; e < 3 * B; e += NT) Vb[(e / B) * RBH + (e % B)] = gva[e];
                     for (int e = tid; e < 3 * B * A; e += NT) Advb[(e / (B * A)) * RBH * A + (e % (B * A))] = gva[3 * B + e];
@@ -1398,20 +1404,32 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                 __syncthreads();
                 WPT_MARK(4);
 #ifndef WC_DIAG_NO_BWD
-                if (!PL && G == 2) {
-                    if constexpr (!PL) {
+                if (G == 2) {
                     wct_backward_chain<SHAPE>(ctx);
                     team_barrier();                        // all four blocks' gradient dumps are there
-                    if (g == 0) { wct_wgrad_ends<SHAPE>(ctx, 0); wct_wgrad_layer<SHAPE>(ctx, 0); wct_wgrad_layer<SHAPE>(ctx, 1); }
-                    else { wct_wgrad_layer<SHAPE>(ctx, 2); wct_wgrad_layer<SHAPE>(ctx, 3); wct_wgrad_ends<SHAPE>(ctx, 1); }
+                    if constexpr (PL) {                    // plain DQN: the output layer and layer 1 | W2
+                        if (g == 0) { wct_wgrad_ends<SHAPE>(ctx, 0); wct_wgrad_ends<SHAPE>(ctx, 1); }
+                        else wct_wgrad_layer<SHAPE>(ctx, 3);
+                    } else {
+                        if (g == 0) { wct_wgrad_ends<SHAPE>(ctx, 0); wct_wgrad_layer<SHAPE>(ctx, 0); wct_wgrad_layer<SHAPE>(ctx, 1); }
+                        else { wct_wgrad_layer<SHAPE>(ctx, 2); wct_wgrad_layer<SHAPE>(ctx, 3); wct_wgrad_ends<SHAPE>(ctx, 1); }
                     }
                     team_barrier();
                     {   // torch.optim.Adam + Polyak, half of the parameter vector per member (ctrl[10], ctrl[11]: this step's bias corrections)
                         const AdamConsts ac{ ctrl[10], ctrl[11], (float)(1.0 - cfg.adam_beta1), (float)(1.0 - cfg.adam_beta2), (float)cfg.adam_beta2,
                                              (float)cfg.adam_eps };
+                        if constexpr (PL) {                // the used part of the arena layout: W1t b1 W2t b2 | Wh bh (column 0 stays zero)
+                            const int mid = oW2t + IMG / 2;
+                            if (g == 0) wg_adam_t(online, adam_m, adam_v, grad, oW1t, mid - oW1t, ac, target, (float)cfg.tau, (float)(1.0 - cfg.tau), tid, NT);
+                            else {
+                                wg_adam_t(online, adam_m, adam_v, grad, mid, ob2 + W - mid, ac, target, (float)cfg.tau, (float)(1.0 - cfg.tau), tid, NT);
+                                wg_adam_t(online, adam_m, adam_v, grad, oWh, PW - oWh, ac, target, (float)cfg.tau, (float)(1.0 - cfg.tau), tid, NT);
+                            }
+                        } else {
                         const int half = ((PW / 2) + 3) & ~3;
                         const int lo = g == 0 ? 0 : half, n = g == 0 ? half : PW - half;
                         wg_adam_t(online, adam_m, adam_v, grad, lo, n, ac, target, (float)cfg.tau, (float)(1.0 - cfg.tau), tid, NT);
+                        }
                     }
                     team_barrier();
                 } else wc_backward_big<SHAPE>(ctx);
@@ -1557,8 +1575,8 @@ __global__ void wct_team_reset_kernel(float *arena, int64_t arena_stride, int64_
 // kernel's LDS footprint) -- the members wait for each other --, else 1.  cfg->team_size 1 forces one workgroup per chain.
 int lenv_wc_dueling_team(const lenv_ddqn_cfg *cfg, int shape, int64_t chains)
 {
-    if (cfg->team_size == 1 || chains < 1 || shape <= 0 || kWcShapes[shape].kind == 0) return 1;
-    void (*kern)(const WcArgs) = dueling_wavechain_kernel<1>;
+    if (cfg->team_size == 1 || chains < 1 || shape <= 0) return 1;
+    void (*kern)(const WcArgs) = shape == 2 ? dueling_wavechain_kernel<2> : dueling_wavechain_kernel<1>;
     return lenv_team_grid_resident(reinterpret_cast<const void *>(kern), wc::NT, wc_lds_bytes(kWcShapes[shape]), 8 * ((chains + 7) / 8) * 2) ? 2 : 1;
 }
 

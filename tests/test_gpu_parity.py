@@ -2607,7 +2607,7 @@ def test_wavechain_dueling_kernel_equals_gemm_queue_kernel(eng):
 def test_wavechain_plain_dqn_kernel_equals_gemm_queue_kernel_and_oracle(eng, orc):
     """The wave-chain kernel's plain-DQN shape -- default_config_acrobot.yaml's ddqn section: Critic_DQN 6-128-128-3 relu, B = 128, on the
     Acrobot SE (dueling_wavechain.hip, kWcShapes[2]: layers 1 and 2, then the output layer where the dueling net has its advantage head) --
-    in production launches against (i) the GEMM-queue kernel's plain-DQN mode on the same inputs (a launch that asks for a step trace) and
+    in production launches (teams of two workgroups per chain, and one) against (i) the GEMM-queue kernel's plain-DQN mode on the same inputs (a launch that asks for a step trace) and
     (ii) the oracle's DDQN on two whole chains: scores, counters, per-episode test means, final returns AND all 17 795 online parameters
     after 80 learn steps, bit for bit."""
     import ctypes as C
@@ -2619,7 +2619,7 @@ def test_wavechain_plain_dqn_kernel_equals_gemm_queue_kernel_and_oracle(eng, orc
     cfg = ddqn_cfg_from_config(cfgd)
     ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=0)
     assert (cfg.agent_kind, cfg.q_hidden, cfg.q_layers, cfg.batch_size, cfg.init_episodes, cfg.test_episodes) == (0, 128, 2, 128, 1, 10)
-    assert _lib.lib().lenv_dueling_team_size(C.byref(cfg), 6) == 1          # plain shapes: one workgroup per chain
+    assert _lib.lib().lenv_dueling_team_size(C.byref(cfg), 6) == 2          # teams of two, as the dueling shape
     chains = 6
     P_q = 6 * 128 + 128 + 128 * 128 + 128 + 3 * 128 + 3
     rng = np.random.RandomState(6)
@@ -2640,11 +2640,15 @@ def test_wavechain_plain_dqn_kernel_equals_gemm_queue_kernel_and_oracle(eng, orc
         assert il.status.cpu().tolist() == [0] * chains
         return [t.cpu().numpy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_online)]
 
-    a, b = _wavechain_pair(run)
+    a, b = _wavechain_pair(run)                             # (teams of two | the GEMM-queue kernel)
     assert a[1][:, 2].min() == 80
     for x, y in zip(a, b):
         assert np.array_equal(x, y, equal_nan=True)
     assert not np.array_equal(a[4], init)
+    cfg.team_size = 1                                       # one workgroup per chain
+    for x, y in zip(run(0), b):
+        assert np.array_equal(x, y, equal_nan=True)
+    cfg.team_size = 0
     for c in (1, 5):
         w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
         o = orc.ddqn_se_chain(ocfg, w, init[c], rng_key=int(keys[c]), want_final_online=True)
