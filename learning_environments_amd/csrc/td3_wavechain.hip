@@ -551,7 +551,7 @@ namespace lenv {
 // the bits of the one-row actor); layer 1 and the output layer are per-(unit, row) / per-(row, output) fmaf chains.  The envs of this
 // kernel never terminate: every episode takes max_steps steps; reset rows and noise rows have the fixed indices of td3_rn_inner_kernel's
 // lock-step rollouts.  Uses bufA (the team path reloads its LDS actor afterwards).
-template <int SHAPE> __device__ __noinline__ void t3w_test_steps(const T3wCtx *ctx_, uint32_t key_lo_, uint32_t key_hi_, int first_episode_, int noise_base_)
+template <int SHAPE> __device__ __noinline__ void t3w_test_steps(const T3wCtx *ctx_, uint32_t key_lo_, uint32_t key_hi_, int first_episode_, uint32_t noise_lo_, uint32_t noise_hi_)
 {
     using namespace t3p;
     constexpr T3wShape SP = kT3wShapes[SHAPE];
@@ -574,7 +574,8 @@ template <int SHAPE> __device__ __noinline__ void t3w_test_steps(const T3wCtx *c
     lint *tlen = (lint *)uni_ptr(c->tlen);
     const int max_steps = uni(c->max_steps);
     const uint64_t key = ((uint64_t)uni((int)key_hi_) << 32) | (uint32_t)uni((int)key_lo_);
-    const int first_episode = uni(first_episode_), noise_base = uni(noise_base_);
+    const int first_episode = uni(first_episode_);
+    const int64_t noise_base = (int64_t)(((uint64_t)uni((int)noise_hi_) << 32) | (uint32_t)uni((int)noise_lo_));
     float *imgX = bufA, *imgY = bufA + IW * W;
     lfloat *Xl = (lfloat *)(bufA + 2 * IW * W);           // observation rows [T][S]
     lfloat *at = Xl + 16 * 20;                             // actions [T][A]
@@ -616,7 +617,7 @@ template <int SHAPE> __device__ __noinline__ void t3w_test_steps(const T3wCtx *c
         if ((ai & (NB - 1)) == 0) {                        // exploration noise of the next NB steps: (episode te, step ai) has row noise_base + te * max_steps + ai
             for (int e = tid; e < NB * T * A; e += NT) {
                 const int st = e / (T * A), r = e - st * (T * A), te = r / A, k = r - te * A;
-                const int64_t n = ((int64_t)noise_base + (int64_t)te * max_steps + ai + st) * A + k;
+                const int64_t n = (noise_base + (int64_t)te * max_steps + ai + st) * A + k;
                 nzb[e] = (ai + st < max_steps) ? (float)det_normal(key, STREAM_TD3_TEST_NOISE, (uint64_t)n) : 0.0f;
             }
         }
@@ -1064,7 +1065,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         float *at = newrow + 24;                           // [A] action
         if constexpr (T > 1) {                              // (measured for the one-episode shape too: 9 % slower there than the LDS-resident one-row actor)
             __syncthreads();
-            t3w_test_steps<SHAPE>(ctx, (uint32_t)key, (uint32_t)(key >> 32), (int)n_test_ep, (int)n_testn);      // (ends with a barrier)
+            t3w_test_steps<SHAPE>(ctx, (uint32_t)key, (uint32_t)(key >> 32), (int)n_test_ep, (uint32_t)n_testn, (uint32_t)((uint64_t)n_testn >> 32));      // (ends with a barrier)
             test_steps += T * cfg.max_steps;
             if (G >= 3) act_lds_load();                    // the routine used bufA
         } else
