@@ -334,6 +334,16 @@ def test_gtn_master_ddqn_layer_norm_generation(tmp_path, monkeypatch):
     best, sign = orc.worker_best(scores[1::3], scores[2::3], True)
     assert np.array_equal(gathered[:, 0], best) and np.array_equal(gathered[:, 1], scores[0::3])
     assert np.array_equal(gathered[:, 2], sign.astype(np.float64))
+    # the captured generation (the LayerNorm block's fill is one more node of the graph) against the eager one: same theta
+    from learning_environments_amd.agents.GTN import GTN_Master
+    thetas = []
+    for graph in (True, False):
+        torch.manual_seed(0)
+        mm = GTN_Master(cfg, bohb_id=0, seed=5, graph=graph)
+        mm.step(0); mm.step(1)
+        torch.cuda.synchronize()
+        thetas.append(mm.theta.cpu().numpy().copy())
+    assert np.array_equal(thetas[0], thetas[1])
 
 
 def test_gtn_master_ddqn_vary_generation(tmp_path, monkeypatch):
