@@ -2832,6 +2832,59 @@ def test_wavechain_td3_cmc_shape_every_team_size(eng, orc):
         assert np.array_equal(ref[4][c], o["final_params"])
 
 
+def test_wavechain_td3_cmc_episodes_that_end_at_the_flag(eng, orc):
+    """MountainCarContinuous-v0 terminates: with an actor that pushes in the direction of the velocity (hand-built weights: tanh(k v)) the
+    car reaches the flag long before max_steps.  No learn step touches the actor here (init_episodes = train_episodes: random-action
+    training episodes), so every test episode of the wave-chain kernel's one-row test loop ends at the env's own done flag -- in the middle
+    of an action's two repeats or not --, with the +100 of the last step in its return: lengths, returns and scores equal to the GEMM-queue
+    kernel's and the oracle's, bit for bit, for one workgroup per chain and for teams."""
+    from learning_environments_amd import configs
+    from learning_environments_amd.agents.nes_common import chain_keys
+    cfgd = configs.fixed_work(configs.cmc_reward_env_td3(2), 2)
+    cfgd["agents"]["td3"]["init_episodes"] = 2
+    cfgd["envs"]["MountainCarContinuous-v0"]["max_steps"] = 400
+    ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
+    chains = 4
+    Pa, Pc = orc.td3_param_counts(ocfg)
+    P_rn = orc.rn_num_params(2, 2, 0, 128, 1)
+    rng = np.random.RandomState(19)
+    theta = (rng.randn(P_rn) * 0.1).astype(np.float32)
+    eps = (rng.randn(2, P_rn) * 0.05).astype(np.float32)
+    worker = (np.arange(chains) // 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), 2)[:chains].copy()
+    keys = chain_keys(83, 1, worker, np.arange(chains) % 3)
+    init = rng.uniform(-0.01, 0.01, (chains, Pa + 2 * Pc)).astype(np.float32)
+    # actor 2-128-128-1 (leakyrelu): h1_0 = lrelu(c v), h1_1 = lrelu(-c v); h2_0 = h1_0, h2_1 = h1_1; out = K (h2_0 - h2_1) -> tanh(~K c v)
+    H = 128
+    a = np.zeros(Pa, np.float32)
+    W0, b0 = a[:2 * H].reshape(H, 2), a[2 * H:3 * H]
+    W1 = a[3 * H:3 * H + H * H].reshape(H, H)
+    Wo = a[3 * H + H * H + H:3 * H + H * H + H + H]
+    W0[0, 1], W0[1, 1] = 40.0, -40.0
+    W1[0, 0], W1[1, 1] = 1.0, 1.0
+    Wo[0], Wo[1] = 30.0, -30.0
+    init[:, :Pa] = a[None, :] + 0.0 * b0.sum()
+    def run(trace_cap):
+        il = eng.Td3InnerLoop(cfg, chains, trace_cap=trace_cap, want_final_params=True, want_episode_stats=True)
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return [t.cpu().numpy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_params)]
+
+    ref = run(2)                                            # GEMM-queue kernel
+    assert (ref[1][:, 2] == 0).all()                        # no learn step
+    assert ref[0].min() > 50.0                              # every final test episode reached the flag (+100 minus the action costs)
+    assert ref[1][:, 3].max() < 3 * 400                     # ... well before the time limit (three test episodes per chain)
+    for G in (1, 3, 6):
+        cfg.team_size = G
+        out = run(0)
+        for x, y in zip(out, ref):
+            assert np.array_equal(x, y, equal_nan=True), G
+    o = orc.td3_rn_chain(ocfg, (np.float32(sign[1]) * eps[worker[1]] + theta).astype(np.float32), init[1], rng_key=int(keys[1]))
+    assert float(ref[0][1]) == o["score"] and ref[1][1].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+    assert np.array_equal(ref[2][1], o["episode_test_mean"], equal_nan=True)
+
+
 @pytest.mark.parametrize("chains", [5, 11])
 def test_wavechain_td3_team_sizes_agree(eng, orc, chains):
     """A chain run by a team of G = 2, 3, 6 workgroups (sample blocks and gradient tiles dealt over the team, six agent-scope
