@@ -399,6 +399,30 @@ __device__ __forceinline__ void t3v_tile_adam(const f32x16 &acc, T3vTileState &s
 // acc = sum_{i < 192} A[i][ca] * Bm[i][cb], i ascending in ONE chain: lane (li, h) reads rows 2 t + h of the two row-major arrays
 // (pa / pb already point at its row h and column), D k-steps of operands in flight (more in flight did not help: 28 deep the eight waves' outstanding lines
 // overran the 32 KB L1 and the chain got slower)
+#ifdef T3V_DIAG_WIDE
+// timing experiment (results are garbage): the same bytes per k-step, but fetched as ONE 16-byte load per operand every FOUR steps -- a
+// quarter of the vector-memory instructions
+template <int LDA>
+__device__ __forceinline__ f32x16 t3v_wgrad_chain(const gfloat *pa, const gfloat *pb)
+{
+    constexpr int D = 16, NS = T3W_B / 2;
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+    f32x4 ra[D / 4], rb[D / 4];
+    const gf4 *qa = (const gf4 *)((uintptr_t)pa & ~(uintptr_t)15), *qb = (const gf4 *)((uintptr_t)pb & ~(uintptr_t)15);
+#pragma unroll
+    for (int u = 0; u < D / 4; ++u) { ra[u] = qa[u * 2 * LDA / 4 * 4 / 4 + u]; rb[u] = qb[u * 64 + u]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[(t % D) / 4][t & 3], rb[(t % D) / 4][t & 3], acc, 0, 0, 0);
+        if ((t & 3) == 3 && t + D - 3 < NS) { const int u = ((t - 3) % D) / 4; ra[u] = qa[((t + D - 3) / 4) * 8 * ((LDA + 3) / 4)]; rb[u] = qb[((t + D - 3) / 4) * 8 * 32]; }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc;
+}
+#else
 template <int LDA>
 __device__ __forceinline__ f32x16 t3v_wgrad_chain(const gfloat *pa, const gfloat *pb)
 {
@@ -424,6 +448,7 @@ __device__ __forceinline__ f32x16 t3v_wgrad_chain(const gfloat *pa, const gfloat
     }
     return acc;
 }
+#endif
 
 // one parameter of a small vector / matrix: Adam + Polyak in place (4-byte accesses: a few hundred elements per network)
 __device__ __forceinline__ void t3v_adam1(float g, float *w_, float *m_, float *v_, float *t_, int off, const AdamConsts ac, float tau, float omt)
