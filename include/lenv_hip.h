@@ -52,8 +52,10 @@ typedef struct {
     float prelu;
     /* `use_layer_norm` of models/model_utils.py:22-37: ONE shared nn.LayerNorm(hidden) (eps 1e-5) after every hidden Linear but
      * the first, before the activation; its weight and bias [hidden] follow the second Linear in the flat vector
-     * (Module.parameters() order).  Honoured by lenv_mlp_num_params / lenv_mlp_forward; of the fused loops only lenv_td3d_inner_loop
-     * takes LayerNorm nets (its own cfg field), the others take plain MLPs and their config builders refuse the option. */
+     * (Module.parameters() order).  Honoured by lenv_mlp_num_params / lenv_mlp_forward / lenv_se_step_population (the three SE nets of
+     * a VirtualEnv.step).  The fused loops take the AGENT's LayerNorm through their own cfg fields (lenv_ddqn_cfg::q_layer_norm,
+     * lenv_td3_cfg::use_layer_norm, lenv_td3d_cfg::use_layer_norm); the synthetic env's / reward env's nets inside the loops are plain
+     * MLPs (their config builders refuse `use_layer_norm` in the envs section when it would change the network). */
     int32_t use_layer_norm;
 } lenv_mlp_desc;
 

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(SE_NT) void se_step_kernel(const SeArgs a)
     float *x = lds + ((a.P + 3) & ~(int64_t)3);      // [K]
     float *h0 = x + ((K + 3) & ~3);                  // [3][H] ping
     float *h1 = h0 + 3 * H;                          // [3][H] pong
+    float *stat = h1 + 3 * H;                        // [3][2] mean, 1 / sqrt(var + eps) of a LayerNorm position
 
     const float sg = a.eps ? a.sign[chain] : 0.0f;
     const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P : nullptr;
@@ -49,20 +50,48 @@ __global__ __launch_bounds__(SE_NT) void se_step_kernel(const SeArgs a)
         const float *in = x;
         int n_in = K;
         float *hout = h0;
-        int64_t layer_off = 0;
+        // `use_layer_norm` (models/model_utils.py:22-37): ONE shared nn.LayerNorm(hidden) behind every hidden Linear but the first, its
+        // weight | bias behind the second Linear's bias (Module.parameters() order); the three nets come from one config section but
+        // each carries its own flag.  layer_off / ln_off: per net.
+        int64_t layer_off[3] = { 0, 0, 0 }, ln_off[3] = { 0, 0, 0 };
         for (int l = 0; l < L; ++l) {
+            const bool any_ln = l >= 1 && (a.net[0].use_layer_norm || a.net[1].use_layer_norm || a.net[2].use_layer_norm);
             for (int u = tid; u < 3 * H; u += SE_NT) {
                 const int net = u / H, j = u - net * H;
-                const float *w = W + a.net_off[net] + layer_off + (int64_t)j * n_in;
-                const float *b = W + a.net_off[net] + layer_off + (int64_t)H * n_in;
+                const float *w = W + a.net_off[net] + layer_off[net] + (int64_t)j * n_in;
+                const float *b = W + a.net_off[net] + layer_off[net] + (int64_t)H * n_in;
                 const float *xin = (l == 0) ? in : in + net * H;
                 float z = 0.0f;
                 for (int k = 0; k < n_in; ++k) z = fma32(xin[k], w[k], z);
                 z = z + b[j];
-                hout[u] = act_fwd(a.net[net].act, a.net[net].prelu, z);
+                hout[u] = (l >= 1 && a.net[net].use_layer_norm) ? z : act_fwd(a.net[net].act, a.net[net].prelu, z);
             }
             __syncthreads();
-            layer_off += (int64_t)H * n_in + H;
+            for (int net = 0; net < 3; ++net) {
+                layer_off[net] += (int64_t)H * n_in + H;
+                if (l == 1 && a.net[net].use_layer_norm) { ln_off[net] = layer_off[net]; layer_off[net] += 2 * H; }
+            }
+            if (any_ln) {
+                // sequential mean / biased variance per row (one thread per net), then y = fma((z - mean) * rstd, w, b) and the activation
+                // -- the oracle's mlp_forward_one_ex
+                if (tid < 3 && a.net[tid].use_layer_norm) {
+                    const float *zr = hout + tid * H;
+                    float sm = 0.0f, sv = 0.0f;
+                    for (int j = 0; j < H; ++j) sm = sm + zr[j];
+                    const float mean = sm / (float)H;
+                    for (int j = 0; j < H; ++j) { const float dj = zr[j] - mean; sv = fma32(dj, dj, sv); }
+                    stat[2 * tid] = mean; stat[2 * tid + 1] = 1.0f / __builtin_sqrtf(sv / (float)H + 1e-5f);
+                }
+                __syncthreads();
+                for (int u = tid; u < 3 * H; u += SE_NT) {
+                    const int net = u / H, j = u - net * H;
+                    if (a.net[net].use_layer_norm) {
+                        const float *lw = W + a.net_off[net] + ln_off[net], *lb = lw + H;
+                        hout[u] = act_fwd(a.net[net].act, a.net[net].prelu, fma32((hout[u] - stat[2 * net]) * stat[2 * net + 1], lw[j], lb[j]));
+                    }
+                }
+                __syncthreads();
+            }
             in = hout;
             hout = (hout == h0) ? h1 : h0;
             n_in = H;
@@ -72,8 +101,8 @@ __global__ __launch_bounds__(SE_NT) void se_step_kernel(const SeArgs a)
             const int net = tid < a.S ? 0 : (tid == a.S ? 1 : 2);
             const int o = tid < a.S ? tid : 0;
             const int n_out = a.net[net].out_dim;
-            const float *w = W + a.net_off[net] + layer_off + (int64_t)o * H;
-            const float *b = W + a.net_off[net] + layer_off + (int64_t)n_out * H;
+            const float *w = W + a.net_off[net] + layer_off[net] + (int64_t)o * H;
+            const float *b = W + a.net_off[net] + layer_off[net] + (int64_t)n_out * H;
             const float *hin = in + net * H;
             float acc = 0.0f;
             for (int j = 0; j < H; ++j) acc = fma32(hin[j], w[j], acc);
@@ -105,7 +134,6 @@ extern "C" int lenv_se_step_population(const lenv_mlp_desc *sn, const lenv_mlp_d
     if (!sn || !rn || !dn || !theta || !state || !action || !next_state || !reward || !done) return LENV_ERR_INVALID;
     if (eps && (!worker || !sign)) return LENV_ERR_INVALID;
     if (chains < 0 || n_per_chain < 1) return LENV_ERR_INVALID;
-    if (sn->use_layer_norm || rn->use_layer_norm || dn->use_layer_norm) return LENV_ERR_UNSUPPORTED;   // env nets never carry one
     if (chains == 0) return LENV_OK;
     // the three nets share input, width and depth (envs/virtual_env.py:23-31)
     if (sn->in_dim != rn->in_dim || sn->in_dim != dn->in_dim || sn->hidden != rn->hidden || sn->hidden != dn->hidden ||

@@ -74,6 +74,45 @@ def test_se_step_population_golden_and_oracle(eng, orc, golden):
         assert np.array_equal(r.cpu().numpy(), orr) and np.array_equal(d.cpu().numpy(), od), pre
 
 
+@pytest.mark.parametrize("L,H,act", [(2, 24, "relu"), (3, 33, "tanh"), (2, 96, "leakyrelu")])
+def test_se_step_population_layer_norm(eng, orc, L, H, act):
+    """VirtualEnv.step with `use_layer_norm: True` in the env's section (models/model_utils.py:22-37; envs/virtual_env.py:16-33): the three
+    SE nets each carry ONE shared nn.LayerNorm behind their hidden Linear 2..L.  lenv_se_step_population against the oracle bit for bit
+    (perturbed population included) and against torch modules from the package's builder (= the reference's, fixture G1LN) within 2e-6."""
+    import torch as T
+    from learning_environments_amd.models.model_utils import build_nn_from_config
+    S, A = 6, 3
+    T.manual_seed(5)
+    nets = [build_nn_from_config(S + A, o, {"hidden_size": H, "hidden_layer": L, "activation_fn": act, "use_layer_norm": True}) for o in (S, 1, 1)]
+    for n in nets:                                         # LayerNorm starts at 1 / 0: perturb so that both matter
+        for m in n.modules():
+            if isinstance(m, T.nn.LayerNorm):
+                with T.no_grad():
+                    m.weight.add_(0.1 * T.randn_like(m.weight)); m.bias.add_(0.05 * T.randn_like(m.bias))
+    theta = np.concatenate([np.concatenate([p.detach().numpy().reshape(-1) for p in n.parameters()]) for n in nets]).astype(np.float32)
+    descs_h = tuple(eng.mlp_desc(S + A, H, L, o, act, use_layer_norm=True) for o in (S, 1, 1))
+    descs_o = tuple(orc.mlp_desc(S + A, H, L, o, act, use_layer_norm=True) for o in (S, 1, 1))
+    assert theta.size == sum(orc.mlp_num_params(d) for d in descs_o)
+    rng = np.random.RandomState(3)
+    pop = 4
+    eps = (rng.randn(pop, theta.size) * 0.05).astype(np.float32)
+    worker = np.repeat(np.arange(pop), 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), pop)
+    st = rng.randn(3 * pop, S).astype(np.float32)
+    ac = rng.randint(0, A, 3 * pop).astype(np.int32)
+    ns, r, d = eng.se_step_population(descs_h, dev(theta), dev(eps), dev(worker), dev(sign), dev(st), dev(ac))
+    ons, orr, od = orc.se_step_population(descs_o, theta, eps, worker, sign, st, ac)
+    assert np.array_equal(ns.cpu().numpy(), ons) and np.array_equal(r.cpu().numpy(), orr) and np.array_equal(d.cpu().numpy(), od)
+    # the unperturbed chains (sign 0) against torch
+    x = T.from_numpy(np.concatenate([np.eye(A, dtype=np.float32)[ac], st], axis=1))
+    with T.no_grad():
+        ref = [n(x).numpy() for n in nets]
+    rows = np.arange(0, 3 * pop, 3)
+    np.testing.assert_allclose(ons[rows], ref[0][rows], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(orr[rows], ref[1][rows, 0], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(od[rows], ref[2][rows, 0], rtol=2e-6, atol=2e-6)
+
+
 def test_se_step_batched_states(eng, orc, golden):
     # EnvWrapper.step(action, state=batched) (env_wrapper.py:33-40): several states per chain
     g = golden("g1_virtual_env_step")
