@@ -37,7 +37,7 @@ class DdqnCfg(C.Structure):
                 ("eps_init", C.c_double), ("eps_min", C.c_double), ("eps_decay", C.c_double),
                 ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
                 ("step_budget", C.c_int64),
-                ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("icm_pad_", C.c_int32),
+                ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("se_layer_norm", C.c_int32),
                 ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
                 ("synthetic_env_type", C.c_int32), ("reward_env_type", C.c_int32),
                 ("same_action_num", C.c_int32),

@@ -10,8 +10,9 @@ TD3_MAX_ACTION = {"HalfCheetah-v3": 1.0, "Pendulum-v0": 2.0, "MountainCarContinu
 
 def _refuse_layer_norm(config, env_section, agent_section):
     """`use_layer_norm` (models/model_utils.py:22-29) where a fused inner loop would silently train a different network is refused: in
-    the synthetic env's / reward env's section everywhere (the AGENT's LayerNorm is taken: cfg.q_layer_norm in the DDQN / DuelingDDQN
-    loop, cfg.use_layer_norm in the TD3 and TD3_discrete_vary loops; lenv_mlp_forward in the one-step API)."""
+    the synthetic env's / reward env's section of every loop but the DDQN / DuelingDDQN one over a synthetic env (cfg.se_layer_norm); the
+    AGENT's LayerNorm is taken everywhere (cfg.q_layer_norm in the DDQN / DuelingDDQN loop, cfg.use_layer_norm in the TD3 and
+    TD3_discrete_vary loops; lenv_mlp_forward in the one-step API)."""
     for name, sec in (("envs." + config["env_name"], env_section), ("agent", agent_section)):
         if sec is not None and sec.get("use_layer_norm", False):
             hl = sec.get("hidden_layer", 1)
@@ -48,7 +49,9 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
     a = config["agents"][agent_key]
     dueling = agent_key == "duelingddqn"
     S, A = ENV_DIMS[env_name]
-    _refuse_layer_norm(config, e, None)
+    reward_env = "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 0)) == 1
+    if reward_env:
+        _refuse_layer_norm(config, e, None)          # the reward net of this loop has one hidden layer
 
     def val(v):  # env_factory.py:54-58: list-valued entries -> float(value[1])
         return float(v[1]) if isinstance(v, list) else v
@@ -73,6 +76,11 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
     # use_layer_norm: ONE shared nn.LayerNorm behind hidden Linear 2..L of the Q-net / the feature stream (model_utils.py:22-37); a net with
     # one hidden layer has no position for it (and no parameters: the module is created but never registered)
     cfg.q_layer_norm = 1 if a.get("use_layer_norm", False) else 0
+    # the ENV section's use_layer_norm: the synthetic env's three nets normalise behind their hidden Linear 2..L too (virtual_env.py:16-33 builds
+    # them with build_nn_from_config).  NES perturbs and updates nn.Linear modules only (GTN_worker.py:156-175, GTN_master.py:281-296), so the
+    # module keeps its constructor weight 1 / bias 0 on every worker and theta stays the Linear parameters: the kernel normalises without
+    # parameters
+    cfg.se_layer_norm = 1 if (e.get("use_layer_norm", False) and not reward_env) else 0
     _launch_knobs(cfg, config)
     if icm:                                          # config section `icm` (agents/DDQN.py:43-49)
         ic = config["agents"]["icm"]

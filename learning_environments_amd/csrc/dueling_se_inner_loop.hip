@@ -183,6 +183,8 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     double *tstate = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(tlen + T) + 7) & ~(uintptr_t)7);   // [4] RewardEnv: the real training env's state
     volatile float *ctrl = misc;
     volatile int *ictrl = reinterpret_cast<volatile int *>(misc + 32);
+    float *se_ln_stat = misc + 20;                        // [3][2] mean | rstd of the SE nets' LayerNorm rows (cfg.se_layer_norm)
+    const bool se_ln = FIXED ? false : (cfg.se_layer_norm != 0);
 
     float *arena = a.arena + chain * a.arena_stride;
     constexpr DuelArena AC = duel_arena(kDuelShape.S, kDuelShape.H, kDuelShape.F, kDuelShape.L, kDuelShape.B, kDuelShape.T,
@@ -531,9 +533,28 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                     const float *w = wm + (int64_t)j * Hse, *hi = hin + net * Hse;
                     float z = 0.0f;
                     for (int k = 0; k < Hse; ++k) z = fma32(hi[k], w[k], z);
-                    hout[uu] = act_fwd(se_act_id, cfg.se_prelu, z + wm[Hse * Hse + j]);
+                    z = z + wm[Hse * Hse + j];
+                    hout[uu] = se_ln ? z : act_fwd(se_act_id, cfg.se_prelu, z);
                 }
                 __syncthreads();
+                if (se_ln) {
+                    // the SE nets' shared nn.LayerNorm (model_utils.py:22-37): NES perturbs nn.Linear modules only (GTN_worker.py:156-175), so
+                    // its weight / bias are the constructor's 1 / 0 for every worker; sequential row sums as in the oracle's mlp_forward_one_ex
+                    if (tid < 3) {
+                        const float *zr = hout + tid * Hse;
+                        float sm = 0.0f, sv = 0.0f;
+                        for (int jj = 0; jj < Hse; ++jj) sm = sm + zr[jj];
+                        const float mean = sm / (float)Hse;
+                        for (int jj = 0; jj < Hse; ++jj) { const float dj = zr[jj] - mean; sv = fma32(dj, dj, sv); }
+                        se_ln_stat[2 * tid] = mean; se_ln_stat[2 * tid + 1] = 1.0f / __builtin_sqrtf(sv / (float)Hse + 1e-5f);
+                    }
+                    __syncthreads();
+                    for (int uu = tid; uu < 3 * Hse; uu += DNT) {
+                        const int net = uu / Hse;
+                        hout[uu] = act_fwd(se_act_id, cfg.se_prelu, fma32((hout[uu] - se_ln_stat[2 * net]) * se_ln_stat[2 * net + 1], 1.0f, 0.0f));
+                    }
+                    __syncthreads();
+                }
                 se_hl = hout;
             }
             if (tid < S + 2) {

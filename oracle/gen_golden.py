@@ -64,6 +64,19 @@ def pack_linear_params(state_dict, prefix):
     return np.concatenate(parts)
 
 
+def pack_linear_only(state_dict, prefix):
+    """The nn.Linear weights / biases under `prefix` in state-dict order -- THE layout of theta (GTN_worker.py:156-175 perturbs nn.Linear
+    modules only): a LayerNorm's 1-D weight and its bias are left out, as PReLU slopes are."""
+    parts = []
+    for k, v in state_dict.items():
+        if k.startswith(prefix) and k.endswith("weight") and v.dim() == 2:
+            parts.append(v.detach().cpu().numpy().astype(np.float32).reshape(-1))
+            b = state_dict.get(k[:-len("weight")] + "bias")
+            if b is not None:
+                parts.append(b.detach().cpu().numpy().astype(np.float32).reshape(-1))
+    return np.concatenate(parts)
+
+
 def _is_prelu_key(sd, k):
     # a PReLU module has a weight but no bias sibling
     return (k[:-len("weight")] + "bias") not in sd
@@ -213,8 +226,8 @@ def gen_g4():
 # ------------------------------------------------------------------------------------------------
 def se_theta(envw):
     sd = envw.state_dict()
-    return np.concatenate([pack_linear_params(sd, "env.state_net."), pack_linear_params(sd, "env.reward_net."),
-                           pack_linear_params(sd, "env.done_net.")])
+    return np.concatenate([pack_linear_only(sd, "env.state_net."), pack_linear_only(sd, "env.reward_net."),
+                           pack_linear_only(sd, "env.done_net.")])
 
 
 def gen_g6():
@@ -1388,7 +1401,7 @@ def _gen_g11_body(cfg, n, GTN_Master, GTN_Worker, shutil):
 def main():
     # no arguments (or "all"): every fixture under tests/golden is regenerated (the full-shape runs g8df / g8tf take minutes each)
     ALL = ["g1", "g1ln", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x",
-           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8tln", "g8df", "g8l2", "g8ln", "g8m", "g8r", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k"]
+           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8tln", "g8df", "g8l2", "g8ln", "g8seln", "g8m", "g8r", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k"]
     which = sys.argv[1:] or ALL
     if "all" in which:
         which = ALL
@@ -1502,6 +1515,13 @@ def main():
                agent_over={"hidden_size": 24, "hidden_layer": 3, "feature_dim": 16, "batch_size": 32, "init_episodes": 1, "test_episodes": 2,
                            "use_layer_norm": True},
                env_over={"hidden_size": 32, "solved_reward": 0.5})
+    if "g8seln" in which:
+        # `use_layer_norm: True` in the ENV's section with a two-hidden-layer SE: the three SE nets normalise behind their second Linear; NES
+        # never touches the module, theta stays the nn.Linear parameters
+        gen_g8("g8seln_calc_score_acrobot_ddqn_se_layernorm", train_episodes=3, done_bias_shift=0.0, seed=815, max_steps=20,
+               env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="ddqn",
+               agent_over={"hidden_size": 40, "hidden_layer": 2, "batch_size": 32, "init_episodes": 1, "test_episodes": 2},
+               env_over={"hidden_size": 32, "hidden_layer": 2, "solved_reward": 0.5, "use_layer_norm": True})
     if "g8m" in which:
         # default_config_mountaincar.yaml's pair: MountainCar-v0 SE + DDQN with two hidden layers (GEMM-tiled kernel, plain-DQN mode)
         gen_g8("g8m_calc_score_mountaincar_ddqn", train_episodes=3, done_bias_shift=0.0, seed=860, max_steps=25,

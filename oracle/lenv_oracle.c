@@ -262,6 +262,20 @@ static void mlp_forward_one_ex(const orc_mlp_desc *d, const float *p, const floa
     linear_fwd(p, p + (int64_t)d->out_dim * H, d->out_dim, H, in, y);
 }
 
+/* A synthetic env's / reward env's net with `use_layer_norm`: theta holds its nn.Linear parameters only (NES never touches the LayerNorm,
+ * GTN_worker.py:156-175), the module keeps weight 1 / bias 0.  Returns a malloc'ed copy of `p` (layout of `plain`) in the layout of the
+ * same net with use_layer_norm = 1 -- the two vectors behind the second Linear -- or NULL when there is no position (one hidden layer). */
+static float *mlp_with_unit_layer_norm(const orc_mlp_desc *plain, const float *p)
+{
+    if (plain->layers < 2) return NULL;
+    const int64_t H = plain->hidden, head = (int64_t)plain->in_dim * H + H + H * H + H, P = orc_mlp_num_params(plain);
+    float *q = malloc(sizeof(float) * (size_t)(P + 2 * H));
+    memcpy(q, p, sizeof(float) * (size_t)head);
+    for (int64_t j = 0; j < H; ++j) { q[head + j] = 1.0f; q[head + H + j] = 0.0f; }
+    memcpy(q + head + 2 * H, p + head, sizeof(float) * (size_t)(P - head));
+    return q;
+}
+
 static void mlp_forward_one(const orc_mlp_desc *d, const float *p, const float *x, float *y,
                             float z[][ORC_MAX_WIDTH], float a[][ORC_MAX_WIDTH])
 {
@@ -1084,6 +1098,15 @@ static int ddqn_se_chain_impl(const orc_ddqn_cfg *cfg, const float *se_params, c
     const float g32 = (float)cfg->gamma;
     const int64_t P = agent_num_params(cfg);
     const int64_t ps = orc_mlp_num_params(&sn), pr = orc_mlp_num_params(&rn);
+    /* se_layer_norm: the SE nets evaluated with their (never perturbed) LayerNorm, theta keeps the Linear-only layout */
+    orc_mlp_desc sn_e = sn, rn_e = rn, dn_e = dn;
+    const float *se_p[3] = { se_params, se_params + ps, se_params + ps + pr };
+    float *se_own[3] = { NULL, NULL, NULL };
+    if (cfg->se_layer_norm && cfg->se_layers >= 2 && !(cfg->synthetic_env_type == 1)) {
+        sn_e.use_layer_norm = rn_e.use_layer_norm = dn_e.use_layer_norm = 1;
+        se_own[0] = mlp_with_unit_layer_norm(&sn, se_p[0]); se_own[1] = mlp_with_unit_layer_norm(&rn, se_p[1]); se_own[2] = mlp_with_unit_layer_norm(&dn, se_p[2]);
+        for (int i = 0; i < 3; ++i) se_p[i] = se_own[i];
+    }
     const int64_t row_stride = 2 * S + 3;
     int64_t cap = (int64_t)cfg->train_episodes * cfg->max_steps;
     if (cap > cfg->rb_size) cap = cfg->rb_size;
@@ -1160,9 +1183,9 @@ static int ddqn_se_chain_impl(const orc_ddqn_cfg *cfg, const float *se_params, c
                     float r1;
                     for (int i = 0; i < A; ++i) x[i] = (i == act) ? 1.0f : 0.0f;
                     for (int i = 0; i < S; ++i) x[A + i] = cur[i];
-                    mlp_forward_one(&sn, se_params, x, next_state, z, a);
-                    mlp_forward_one(&rn, se_params + ps, x, &r1, z, a);
-                    mlp_forward_one(&dn, se_params + ps + pr, x, &done, z, a);
+                    mlp_forward_one(&sn_e, se_p[0], x, next_state, z, a);
+                    mlp_forward_one(&rn_e, se_p[1], x, &r1, z, a);
+                    mlp_forward_one(&dn_e, se_p[2], x, &done, z, a);
                     reward = r_ == 0 ? r1 : reward + r1;
                     memcpy(cur, next_state, sizeof(float) * S);
                 }
@@ -1235,6 +1258,7 @@ static int ddqn_se_chain_impl(const orc_ddqn_cfg *cfg, const float *se_params, c
     if (final_online) memcpy(final_online, online, sizeof(float) * P);
     free(icm_p); free(icm_m); free(icm_v); free(r_intr);
     free(online); free(target); free(am); free(av); free(rb); free(batch); free(z); free(a); free(test_returns); free(meter);
+    free(se_own[0]); free(se_own[1]); free(se_own[2]);
     return rng.err;
 }
 

@@ -74,7 +74,11 @@ typedef struct {
     double adam_beta1, adam_beta2, adam_eps;
     int64_t step_budget;   /* see include/lenv_hip.h: env-step budget standing in for time_remaining (base_agent.py:30-47) */
     /* Intrinsic Curiosity Module inside learn() (agents/DDQN.py:40-58,74-76; models/icm_baseline.py): config section `icm` */
-    int32_t icm_enabled, icm_feature_dim, icm_hidden, icm_pad_;
+    int32_t icm_enabled, icm_feature_dim, icm_hidden;
+    /* `use_layer_norm` of the env's config section with se_layers >= 2 (models/model_utils.py:22-37): the shared nn.LayerNorm behind hidden
+     * Linear 2..L of each SE net.  NES perturbs and updates nn.Linear parameters only (GTN_worker.py:156-175, GTN_master.py:281-296), so the
+     * module keeps its initial affine (weight 1, bias 0) and theta stays the Linear parameters */
+    int32_t se_layer_norm;
     double icm_lr, icm_beta, icm_eta;
     /* gtn.synthetic_env_type 1: the agent trains on a RewardEnv over the REAL env (envs/reward_env.py:61-133) instead of the
      * VirtualEnv; se_hidden / se_layers / se_act then describe the reward network (state_dim -> 1), theta holds its parameters;

@@ -33,7 +33,7 @@ class DdqnCfg(C.Structure):
                 ("eps_init", C.c_double), ("eps_min", C.c_double), ("eps_decay", C.c_double),
                 ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
                 ("step_budget", C.c_int64),
-                ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("icm_pad_", C.c_int32),
+                ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("se_layer_norm", C.c_int32),
                 ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
                 ("synthetic_env_type", C.c_int32), ("reward_env_type", C.c_int32),
                 ("same_action_num", C.c_int32), ("q_layer_norm", C.c_int32)]
@@ -429,6 +429,7 @@ def ddqn_cfg_from_config(config, grad_chunk=13, rng_mode=0, **overrides):
     overrides.setdefault("agent_kind", 1 if agent_key == "duelingddqn" else 0)
     overrides.setdefault("feature_dim", int(a.get("feature_dim", 0)))
     overrides.setdefault("q_layer_norm", 1 if a.get("use_layer_norm", False) else 0)      # model_utils.py:22-29
+    overrides.setdefault("se_layer_norm", 1 if e.get("use_layer_norm", False) else 0)     # the SE nets' (never perturbed) LayerNorm
     cfg = DdqnCfg(env_id=ENV[env_name], state_dim=S, num_actions=A, max_steps=int(e["max_steps"]),
                   se_hidden=int(e["hidden_size"]), se_layers=int(e["hidden_layer"]), se_act=ACT[e["activation_fn"]],
                   se_prelu=0.25, q_hidden=int(a["hidden_size"]), q_layers=max(1, int(a["hidden_layer"])),   # hidden_layer 0 == 1 (model_utils.py:33)

@@ -307,6 +307,12 @@ def test_config_builders_refuse_layer_norm_sections():
     c["envs"]["CartPole-v0"]["use_layer_norm"] = True
     config.ddqn_cfg_from_config(c)                           # one hidden layer: the module is never appended (model_utils.py:33-36) -- the same net
     c["envs"]["CartPole-v0"]["hidden_layer"] = 2
+    # the DDQN / DuelingDDQN loop over a synthetic env normalises inside its SE step (cfg.se_layer_norm; theta stays the Linear parameters) ...
+    scfg = config.ddqn_cfg_from_config(c)
+    assert scfg.se_layer_norm == 1 and scfg.se_layers == 2 and scfg.q_layer_norm == 0
+    # ... its reward-env mode (one-hidden-layer reward net) does not
+    c = configs.cartpole_reward_env_ddqn(2)
+    c["envs"]["CartPole-v0"].update(use_layer_norm=True, hidden_layer=2)
     with pytest.raises(NotImplementedError):
         config.ddqn_cfg_from_config(c)
     c = configs.halfcheetah_reward_env_td3(2)

@@ -5,6 +5,7 @@ Bar: BIT-EXACT against the oracle (the kernels implement the oracle's canonical 
 work is exact by construction); within the fixture tolerances of tests/test_oracle_golden.py against the
 reference's own numbers (torch's summation order / tanh differ from the canonical order by O(1e-7)).
 """
+import copy
 import json
 
 import numpy as np
@@ -162,6 +163,7 @@ def _inner_cfg(orc, cfgd, **over):
                                         ("g8w_calc_score_cartpole_ringwrap", 17),
                                         ("g8l2_calc_score_acrobot_ddqn_2layer", 0),    # Critic_DQN 6-128-128-3 -> GEMM-tiled kernel
                                         ("g8ln_calc_score_acrobot_ddqn_layernorm", 0),  # use_layer_norm: 6-40-40-3 with the LayerNorm behind its second Linear
+                                        ("g8seln_calc_score_acrobot_ddqn_se_layernorm", 0),  # the ENV's use_layer_norm: SE nets 9-32-32-x with the LayerNorm
                                         ("g8m_calc_score_mountaincar_ddqn", 0)])       # MountainCar-v0 SE + DDQN 2-48-48-3
 def test_inner_loop_tape_mode_vs_reference_and_oracle(eng, orc, golden, name, chunk):
     g = golden(name)
@@ -627,6 +629,58 @@ def test_layer_norm_in_the_ddqn_loops_vs_oracle(eng, orc, golden, kind, layers, 
         assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
         assert np.array_equal(il.final_online[c].cpu().numpy(), o["final_online"]), c
         assert not np.array_equal(o["final_online"], agent_init[c])
+
+
+@pytest.mark.parametrize("kind,se_layers,se_hidden,se_act,q_layers,q_ln", [("ddqn", 2, 32, "leakyrelu", 1, False), ("ddqn", 3, 24, "tanh", 2, True),
+                                                                           ("duelingddqn", 2, 48, "relu", 1, False)])
+def test_layer_norm_in_the_synthetic_env_of_the_ddqn_loops_vs_oracle(eng, orc, golden, kind, se_layers, se_hidden, se_act, q_layers, q_ln):
+    """`use_layer_norm: True` in the ENV's section (virtual_env.py:16-33 builds the three SE nets with build_nn_from_config): the SE step
+    inside the fused loop normalises behind hidden Linear 2..L.  NES perturbs nn.Linear modules only (GTN_worker.py:156-175), so theta is
+    the Linear parameters and the module's weight 1 / bias 0 never move (the oracle reproduces the reference run G8SELN with exactly that).
+    Counter mode, three chains with + / - / 0 perturbation: step traces, returns, counters and final parameters bit for bit."""
+    g = golden("g8d_calc_score_acrobot_dueling")
+    cfgd = json.loads(str(g["config_json"]))
+    if kind == "ddqn":
+        cfgd["agents"]["gtn"]["agent_name"] = "DDQN"
+        cfgd["agents"]["ddqn"] = dict(cfgd["agents"]["duelingddqn"])
+        cfgd["agents"]["ddqn"].pop("feature_dim", None)
+    cfgd["agents"][kind].update(hidden_size=40, hidden_layer=q_layers, batch_size=24, test_episodes=3, use_layer_norm=q_ln)
+    cfgd["envs"]["Acrobot-v1"].update(hidden_size=se_hidden, hidden_layer=se_layers, activation_fn=se_act, use_layer_norm=True)
+    ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, train_episodes=3, max_steps=14)
+    assert cfg.se_layer_norm == 1 and ocfg.se_layer_norm == 1 and cfg.q_layer_norm == int(q_ln)
+    S, A = ocfg.state_dim, ocfg.num_actions
+    rng = np.random.RandomState(61)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, se_hidden, se_layers, se_act))       # Linear parameters only
+    K = S + A
+    assert P_se == 3 * (K * se_hidden + se_hidden + (se_layers - 1) * (se_hidden * se_hidden + se_hidden)) + (S + 2) * (se_hidden + 1)
+    chains = 3
+    theta = (rng.randn(P_se) * 0.2).astype(np.float32)
+    eps = (rng.randn(1, P_se) * 0.05).astype(np.float32)
+    il = eng.InnerLoop(cfg, chains, trace_cap=48, want_final_online=True)
+    agent_init = (rng.uniform(-0.15, 0.15, (chains, il.p_agent))).astype(np.float32)
+    worker = np.zeros(chains, np.int32)
+    sign = np.array([0.0, 1.0, -1.0], np.float32)
+    keys = np.array([orc.chain_key(23, 1, 0, c) for c in range(chains)], np.uint64)
+    il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(agent_init), rng_keys=dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    ocfg_plain = copy.copy(ocfg)
+    for c in range(chains):
+        w = (np.float32(sign[c]) * eps[0] + theta).astype(np.float32)
+        o = orc.ddqn_se_chain(ocfg, w, agent_init[c], rng_key=int(keys[c]), trace_cap=48, want_final_online=True)
+        n = o["trace"]["action"].size
+        assert o["learn_steps"] >= 6
+        assert np.array_equal(il.trace["action"][c, :n].cpu().numpy() & 0xFFFF, o["trace"]["action"]), c
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"]), c
+        assert np.array_equal(il.trace["reward_done"][c, :n, 0].cpu().numpy(), o["trace"]["reward"]), c
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(il.final_online[c].cpu().numpy(), o["final_online"]), c
+    # and the normalisation is what made the difference: the same chain through plain SE nets walks elsewhere
+    ocfg_plain.se_layer_norm = 0
+    o0 = orc.ddqn_se_chain(ocfg_plain, theta, agent_init[0], rng_key=int(keys[0]), trace_cap=48)
+    assert not np.array_equal(o0["trace"]["next_state"][:4], il.trace["next_state"][0, :4].cpu().numpy())
 
 
 @pytest.mark.parametrize("env_name,layers,hidden,batch,act,T", [("Acrobot-v1", 2, 128, 128, "relu", 3), ("CartPole-v0", 2, 64, 64, "tanh", 4),

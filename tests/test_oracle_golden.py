@@ -159,6 +159,7 @@ def test_g7_master(golden):
                                         ("g8w_calc_score_cartpole_ringwrap", 13),
                                         ("g8l2_calc_score_acrobot_ddqn_2layer", 0),    # Critic_DQN 6-128-128-3: batch gradient
                                         ("g8ln_calc_score_acrobot_ddqn_layernorm", 0),  # use_layer_norm: Critic_DQN 6-40-40-3 with the LayerNorm behind its second Linear
+                                        ("g8seln_calc_score_acrobot_ddqn_se_layernorm", 0),  # the ENV's use_layer_norm: SE nets 9-32-32-x normalise behind their second Linear
                                         ("g8m_calc_score_mountaincar_ddqn", 0)])       # default_config_mountaincar.yaml's pair
 def test_g8_calc_score_trace(golden, name, chunk):
     import json
