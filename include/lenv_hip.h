@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LENV_ABI_VERSION 5
+#define LENV_ABI_VERSION 6
 
 enum {
     LENV_OK = 0,
@@ -224,8 +224,9 @@ typedef struct {
     int32_t count_based;                /* ql_cb / sarsa_cb (agents/agent_utils.py:57-64): reward += beta / (sqrt(n(s,a)) + 1e-9) */
     double solved_reward, alpha, gamma, eps_init, eps_min, eps_decay, beta;
     int64_t step_budget;                /* env-step stand-in for time_remaining, see lenv_ddqn_cfg::step_budget */
-    int32_t same_action_num, pad2_;     /* env steps per chosen action (base_agent.py:104,194; env_wrapper.py:56-61: stop at done, python-float
+    int32_t same_action_num;            /* env steps per chosen action (base_agent.py:104,194; env_wrapper.py:56-61: stop at done, python-float
                                            reward sum); 0 and 1 both mean 1 */
+    int32_t rn_layer_norm;              /* the ENV section's `use_layer_norm` with rn_layers >= 2, as lenv_ddqn_cfg::se_layer_norm (ABI 6; was padding) */
 } lenv_ql_cfg;
 
 typedef struct {
@@ -362,6 +363,10 @@ typedef struct {
     int32_t same_action_num;
     int32_t team_size;        /* workgroups per chain, as lenv_ddqn_cfg::team_size (0 = automatic, 1 = never a team, G = at most G) */
     int32_t kernel_variant;   /* LENV_VARIANT_* bits, 0 = fastest */
+    /* ABI 6.  `use_layer_norm` of the ENV's config section with rn_layers >= 2: the reward net (RewardEnv) / the three SE nets (VirtualEnv)
+     * carry the shared nn.LayerNorm behind hidden Linear 2..L.  As lenv_ddqn_cfg::se_layer_norm: NES perturbs nn.Linear modules only, theta / eps
+     * stay the Linear parameters, the kernel normalises with the constructor's weight 1 / bias 0. */
+    int32_t rn_layer_norm;
 } lenv_td3_cfg;
 
 /* RNG tapes (parity mode); per-chain rows, strides in ROWS (rows of A floats / B ints / S doubles as noted) */
@@ -441,6 +446,7 @@ typedef struct {
     double gumbel_temp;                                  /* gumbel_softmax_temp, annealed to 1/20 of it over the first 2000 learn calls (:59-68) */
     double adam_beta1, adam_beta2, adam_eps;
     int64_t step_budget;                                 /* env-step stand-in for time_remaining, see lenv_ddqn_cfg::step_budget */
+    int32_t se_layer_norm;                               /* ABI 6: the ENV section's `use_layer_norm`, as lenv_ddqn_cfg::se_layer_norm */
 } lenv_td3d_cfg;
 
 /* RNG tapes (parity mode); per-chain rows, strides in ROWS (rows of A floats / one int / four doubles as noted) */

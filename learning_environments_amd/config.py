@@ -9,10 +9,10 @@ TD3_MAX_ACTION = {"HalfCheetah-v3": 1.0, "Pendulum-v0": 2.0, "MountainCarContinu
 
 
 def _refuse_layer_norm(config, env_section, agent_section):
-    """`use_layer_norm` (models/model_utils.py:22-29) where a fused inner loop would silently train a different network is refused: in
-    the synthetic env's / reward env's section of every loop but the DDQN / DuelingDDQN one over a synthetic env (cfg.se_layer_norm); the
-    AGENT's LayerNorm is taken everywhere (cfg.q_layer_norm in the DDQN / DuelingDDQN loop, cfg.use_layer_norm in the TD3 and
-    TD3_discrete_vary loops; lenv_mlp_forward in the one-step API)."""
+    """`use_layer_norm` (models/model_utils.py:22-29) where a fused inner loop would silently train a different network is refused: only
+    the reward-env mode of the DDQN loop (one-hidden-layer reward net) is left.  Everywhere else the env nets' LayerNorm is taken
+    (cfg.se_layer_norm / cfg.rn_layer_norm) and so is the AGENT's (cfg.q_layer_norm in the DDQN / DuelingDDQN loop, cfg.use_layer_norm in
+    the TD3 and TD3_discrete_vary loops; lenv_mlp_forward in the one-step API)."""
     for name, sec in (("envs." + config["env_name"], env_section), ("agent", agent_section)):
         if sec is not None and sec.get("use_layer_norm", False):
             hl = sec.get("hidden_layer", 1)
@@ -158,7 +158,6 @@ def ql_cfg_from_config(config, tables, rng_mode=_lib.RNG_COUNTER, **overrides):
     a = config["agents"]["sarsa" if name.startswith("sarsa") else "ql"]      # SARSA reads its own section (SARSA.py:14-18)
     if int(a["rb_size"]) != 1:
         raise NotImplementedError("tabular agents with rb_size != 1 (the reference configs keep the single latest transition)")
-    _refuse_layer_norm(config, e, None)
 
     def val(v):
         return float(v[1]) if isinstance(v, list) else v
@@ -173,6 +172,7 @@ def ql_cfg_from_config(config, tables, rng_mode=_lib.RNG_COUNTER, **overrides):
                      alpha=float(a["alpha"]), gamma=float(a["gamma"]), eps_init=float(a["eps_init"]),
                      eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]), step_budget=int(a.get("step_budget", 0)))
     cfg.same_action_num = int(a["same_action_num"])
+    cfg.rn_layer_norm = 1 if e.get("use_layer_norm", False) else 0     # the reward net's own LayerNorm (never perturbed: see ddqn_cfg_from_config)
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg
@@ -191,7 +191,6 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
     def val(v):
         return float(v[1]) if isinstance(v, list) else v
 
-    _refuse_layer_norm(config, e, None)
     cfg = _lib.Td3Cfg(env_id=_lib.ENV[env_name], state_dim=S, action_dim=A, max_steps=int(val(e["max_steps"])),
                       rn_hidden=int(val(e["hidden_size"])), rn_layers=int(val(e["hidden_layer"])), rn_act=_lib.ACT[e["activation_fn"]],
                       rn_prelu=0.25, reward_env_type=int(val(e["reward_env_type"])), info_dim=int(val(e.get("info_dim", 0))),
@@ -208,6 +207,8 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
     cfg.same_action_num = int(a["same_action_num"])   # env steps per chosen action (the MountainCarContinuous configs ship 2)
     # use_layer_norm: one shared nn.LayerNorm per net (actor, critic_1, critic_2) behind its hidden Linear 2..L (model_utils.py:22-37)
     cfg.use_layer_norm = 1 if a.get("use_layer_norm", False) else 0
+    # the ENV section's use_layer_norm: the reward net / the three SE nets normalise too; theta stays Linear-only (see ddqn_cfg_from_config)
+    cfg.rn_layer_norm = 1 if e.get("use_layer_norm", False) else 0
     _launch_knobs(cfg, config)
     name = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "td3"
     if name.replace("_vary", "").endswith("_icm"):   # select_agent "td3_icm" / "td3_icm_vary": TD3(icm=True), agents/TD3.py:44-60
@@ -236,7 +237,6 @@ def td3d_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
     a = config["agents"]["td3_discrete_vary"]
     if a["same_action_num"] != 1:
         raise NotImplementedError("same_action_num != 1")
-    _refuse_layer_norm(config, e, None)               # the SE nets stay plain MLPs; the AGENT's LayerNorm is what this kernel adds
 
     def val(v):
         return float(v[1]) if isinstance(v, list) else v
@@ -245,6 +245,7 @@ def td3d_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
                        se_hidden=int(val(e["hidden_size"])), se_layers=int(val(e["hidden_layer"])), se_act=_lib.ACT[e["activation_fn"]],
                        se_prelu=0.25, hidden=int(a["hidden_size"]), layers=max(1, int(a["hidden_layer"])), act=_lib.ACT[a["activation_fn"]],
                        prelu=0.25, use_layer_norm=1 if a.get("use_layer_norm", False) else 0,
+                       se_layer_norm=1 if e.get("use_layer_norm", False) else 0,      # the SE nets' own LayerNorm: theta stays Linear-only
                        gumbel_hard=1 if a["gumbel_softmax_hard"] else 0, batch_size=int(a["batch_size"]), rb_size=int(a["rb_size"]),
                        train_episodes=int(a["train_episodes"]), test_episodes=int(a["test_episodes"]), init_episodes=int(a["init_episodes"]),
                        early_out_num=int(a["early_out_num"]), policy_delay=int(a["policy_delay"]), rng_mode=int(rng_mode),

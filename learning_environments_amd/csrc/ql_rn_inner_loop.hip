@@ -65,7 +65,18 @@ __device__ __forceinline__ void rn_phi_and_shaped(const lenv_ql_cfg &cfg, const 
                 for (int j = 0; j < H; ++j) {
                     float z = 0.0f;
                     for (int k = 0; k < H; ++k) z = fma32(hin[k * 64], Wp(off + (int64_t)j * H + k), z);
-                    hout[j * 64] = act_fwd(cfg.rn_act, cfg.rn_prelu, z + Wp(off + (int64_t)H * H + j));
+                    z = z + Wp(off + (int64_t)H * H + j);
+                    hout[j * 64] = cfg.rn_layer_norm ? z : act_fwd(cfg.rn_act, cfg.rn_prelu, z);
+                }
+                if (cfg.rn_layer_norm) {
+                    // the reward net's own LayerNorm (envs section use_layer_norm; model_utils.py:22-37): NES perturbs nn.Linear modules only, so
+                    // weight 1 / bias 0; the lane owns the row: sequential mean / variance as the oracle's mlp_forward_one_ex
+                    float sm = 0.0f, sv = 0.0f;
+                    for (int j = 0; j < H; ++j) sm = sm + hout[j * 64];
+                    const float mean = sm / (float)H;
+                    for (int j = 0; j < H; ++j) { const float dj = hout[j * 64] - mean; sv = fma32(dj, dj, sv); }
+                    const float r = 1.0f / __builtin_sqrtf(sv / (float)H + 1e-5f);
+                    for (int j = 0; j < H; ++j) hout[j * 64] = act_fwd(cfg.rn_act, cfg.rn_prelu, fma32((hout[j * 64] - mean) * r, 1.0f, 0.0f));
                 }
                 off += (int64_t)H * H + H;
                 float *tmp = hin; hin = hout; hout = tmp;

@@ -126,6 +126,9 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
     dmlp_off(mo_se[0], SA, Hse, Lse, S, 0);
     dmlp_off(mo_se[1], SA, Hse, Lse, 1, 0);
     dmlp_off(mo_se[2], SA, Hse, Lse, 1, 0);
+    // cfg.se_layer_norm: the SE nets' own LayerNorm -- never perturbed by NES (nn.Linear modules only, GTN_worker.py:156-175), so no parameters
+    // in theta: ln == 2 marks a position that normalises with the constructor's weight 1 / bias 0
+    if (cfg.se_layer_norm != 0 && Lse >= 2) mo_se[0].ln = mo_se[1].ln = mo_se[2].ln = 2;
     const int Pa = mo_actor.P, Pc = mo_critic.P, P = Pa + 2 * Pc;
     const int act_id = cfg.act;
     const float prelu = cfg.prelu, ma = (float)cfg.max_action;
@@ -256,7 +259,8 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
                 __syncthreads();
                 const float mean = ctrl[14], r = ctrl[15];
                 const float *lw = par + mo.oLN, *lb = lw + mo.H;
-                for (int j = tid; j < n_out; j += DNT) h[j] = act_fwd(act, pr, fma32((h[j] - mean) * r, lw[j], lb[j]));
+                if (mo.ln == 2) { for (int j = tid; j < n_out; j += DNT) h[j] = act_fwd(act, pr, fma32((h[j] - mean) * r, 1.0f, 0.0f)); }
+                else for (int j = tid; j < n_out; j += DNT) h[j] = act_fwd(act, pr, fma32((h[j] - mean) * r, lw[j], lb[j]));
                 __syncthreads();
             }
             in = h; n_in = mo.H;

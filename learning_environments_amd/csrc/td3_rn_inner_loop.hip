@@ -122,6 +122,10 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     mlp_off(mo_se[0], SA, Hrn, rn_layers, S);
     mlp_off(mo_se[1], SA, Hrn, rn_layers, 1);
     mlp_off(mo_se[2], SA, Hrn, rn_layers, 1);
+    // cfg.rn_layer_norm: the env nets' own LayerNorm.  NES perturbs nn.Linear modules only (GTN_worker.py:156-175): no parameters in theta,
+    // the rows are normalised with the constructor's weight 1 / bias 0 (ln == 2: a position without a parameter block)
+    const bool rn_ln = FIXED ? false : (cfg.rn_layer_norm != 0 && rn_layers >= 2);
+    if (rn_ln) mo_se[0].ln = mo_se[1].ln = mo_se[2].ln = 2;
     const int Pa = mo_actor.P, Pc = mo_critic.P, P = Pa + 2 * Pc;
     const int act_id = FIXED ? kTd3Shape.act : cfg.act;
     const float prelu = cfg.prelu, ma = (float)cfg.max_action;
@@ -254,7 +258,8 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 __syncthreads();
                 const float mean = ctrl[14], r = ctrl[15];
                 const float *lw = par + mo.oLN, *lb = lw + mo.H;
-                for (int j = tid; j < n_out; j += DNT) h[j] = act_fwd(act, pr, fma32((h[j] - mean) * r, lw[j], lb[j]));
+                if (mo.ln == 2) { for (int j = tid; j < n_out; j += DNT) h[j] = act_fwd(act, pr, fma32((h[j] - mean) * r, 1.0f, 0.0f)); }
+                else for (int j = tid; j < n_out; j += DNT) h[j] = act_fwd(act, pr, fma32((h[j] - mean) * r, lw[j], lb[j]));
                 __syncthreads();
             }
             in = h; n_in = mo.H;
@@ -350,9 +355,23 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             for (int j = tid; j < Hrn; j += DNT) {
                 float z = 0.0f;
                 for (int k = 0; k < Hrn; ++k) z = fma32(hp[k], Wl[j * Hrn + k], z);
-                hn[j] = act_fwd(rn_act, cfg.rn_prelu, z + bl[j]);
+                z = z + bl[j];
+                hn[j] = rn_ln ? z : act_fwd(rn_act, cfg.rn_prelu, z);
             }
             __syncthreads();
+            if (rn_ln) {                                   // the reward net's LayerNorm row (weight 1 / bias 0), reduced by thread 0 as in mlp_row1
+                if (tid == 0) {
+                    float sm = 0.0f, sv = 0.0f;
+                    for (int j = 0; j < Hrn; ++j) sm = sm + hn[j];
+                    const float mean = sm / (float)Hrn;
+                    for (int j = 0; j < Hrn; ++j) { const float dj = hn[j] - mean; sv = fma32(dj, dj, sv); }
+                    ctrl[14] = mean; ctrl[15] = 1.0f / __builtin_sqrtf(sv / (float)Hrn + 1e-5f);
+                }
+                __syncthreads();
+                const float mean = ctrl[14], r = ctrl[15];
+                for (int j = tid; j < Hrn; j += DNT) hn[j] = act_fwd(rn_act, cfg.rn_prelu, fma32((hn[j] - mean) * r, 1.0f, 0.0f));
+                __syncthreads();
+            }
             const float *t2 = hp; hp = hn; hn = const_cast<float *>(t2);
             Wl = bl + Hrn;
         }
@@ -966,7 +985,7 @@ extern "C" int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg, const lenv_ch
             return cfg->env_id == sp.env && (cfg->virtual_env != 0) == (sp.virtual_env != 0) && (cfg->same_action_num > 1 ? cfg->same_action_num : 1) == sp.k_rep &&
                    cfg->hidden == sp.H && cfg->layers == sp.L && cfg->batch_size == sp.B && cfg->test_episodes == sp.T && cfg->rn_hidden == sp.Hrn &&
                    cfg->rn_layers == sp.rn_layers && cfg->rn_act == sp.rn_act && cfg->reward_env_type == sp.rtype && cfg->act == sp.act &&
-                   cfg->policy_delay == sp.policy_delay && !cfg->use_layer_norm;
+                   cfg->policy_delay == sp.policy_delay && !cfg->use_layer_norm && !(cfg->rn_layer_norm && cfg->rn_layers >= 2);
         };
         // production launches of the cfg-5 shape: the wave-chain kernel (kernel_variant NO_WAVECHAIN keeps the GEMM-queue kernel for A/B runs)
         if (!off && !(cfg->kernel_variant & LENV_VARIANT_NO_WAVECHAIN) && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_reward && lenv_wc_td3_shape(cfg)) {

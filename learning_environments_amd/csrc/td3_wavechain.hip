@@ -1472,7 +1472,7 @@ int lenv_wc_td3_shape(const lenv_td3_cfg *cfg)
 {
     const int k_rep = cfg->same_action_num > 1 ? cfg->same_action_num : 1;
     if (!(cfg->hidden == 128 && cfg->layers == 2 && cfg->batch_size == T3W_B && cfg->rn_hidden == 128 && !cfg->virtual_env &&
-          cfg->policy_delay == 1 && !cfg->icm_enabled && !cfg->use_layer_norm &&
+          cfg->policy_delay == 1 && !cfg->icm_enabled && !cfg->use_layer_norm && !(cfg->rn_layer_norm && cfg->rn_layers >= 2) &&
           (cfg->reward_env_type == 0 || cfg->reward_env_type == 1 || cfg->reward_env_type == 2 || cfg->reward_env_type == 5 || cfg->reward_env_type == 6)))
         return 0;
     if (cfg->env_id == LENV_ENV_CHEETAH_STANDIN && cfg->state_dim == 17 && cfg->action_dim == 6 && cfg->test_episodes == 1 && cfg->rn_layers == 1 &&

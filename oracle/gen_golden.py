@@ -685,7 +685,7 @@ def gen_ckpt():
 # ------------------------------------------------------------------------------------------------
 # G9: full GTN_Worker.calc_score on the Cliff RewardEnv with QL (cfg 4) + tapes + per-step trace
 # ------------------------------------------------------------------------------------------------
-def gen_g9(name, seed, eps_over=None, agent_name="QL", agent_over=None):
+def gen_g9(name, seed, eps_over=None, agent_name="QL", agent_over=None, env_over=None):
     import json
     import statistics
     import agents.GTN_worker as gw
@@ -696,6 +696,7 @@ def gen_g9(name, seed, eps_over=None, agent_name="QL", agent_over=None):
     cfg["agents"]["gtn"]["agent_name"] = agent_name
     cfg["agents"][sec]["print_rate"] = int(1e9)
     cfg["agents"][sec].update(agent_over or {})
+    cfg["envs"][cfg["env_name"]].update(env_over or {})
     if eps_over is not None:
         cfg["agents"][sec]["eps_init"] = eps_over
         cfg["agents"][sec]["eps_min"] = eps_over
@@ -722,7 +723,7 @@ def gen_g9(name, seed, eps_over=None, agent_name="QL", agent_over=None):
         w.late_init(cfg)
         w.timeout = 1e9
         env = w.synthetic_env_orig
-        theta = pack_linear_params(env.state_dict(), "env.reward_net.")
+        theta = pack_linear_only(env.state_dict(), "env.reward_net.")
         orig_step = env.step
 
         def rec_step(action, state=None):
@@ -1011,7 +1012,7 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over
         w.late_init(cfg)
         w.timeout = 1e9
         env = w.synthetic_env_orig
-        theta = se_theta(env) if virtual else pack_linear_params(env.state_dict(), "env.reward_net.")
+        theta = se_theta(env) if virtual else pack_linear_only(env.state_dict(), "env.reward_net.")
         orig_step = env.step
 
         def rec_step(action, state=None):
@@ -1401,7 +1402,7 @@ def _gen_g11_body(cfg, n, GTN_Master, GTN_Worker, shutil):
 def main():
     # no arguments (or "all"): every fixture under tests/golden is regenerated (the full-shape runs g8df / g8tf take minutes each)
     ALL = ["g1", "g1ln", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x",
-           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8tln", "g8df", "g8l2", "g8ln", "g8seln", "g8m", "g8r", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k"]
+           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8tln", "g8df", "g8l2", "g8ln", "g8seln", "g8tseln", "g8tdseln", "g9ln", "g8m", "g8r", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k"]
     which = sys.argv[1:] or ALL
     if "all" in which:
         which = ALL
@@ -1434,6 +1435,24 @@ def main():
         gen_g8t("g8tln3_calc_score_cheetah_td3_layernorm_3layer", seed=832,
                 agent_over={"train_episodes": 4, "init_episodes": 2, "batch_size": 12, "hidden_size": 20, "hidden_layer": 3, "test_episodes": 2,
                             "policy_delay": 2, "use_layer_norm": True})
+    if "g8tseln" in which:
+        # `use_layer_norm: True` in the ENV's section: the two-hidden-layer reward net of a Pendulum RewardEnv (type 2) and the three SE nets
+        # of a HalfCheetah VirtualEnv normalise behind their second Linear; the module is never perturbed, theta = the nn.Linear parameters
+        gen_g8t("g8trnln_calc_score_pendulum_td3_reward_net_layernorm", seed=872, cfg_yaml="default_config_pendulum_reward_env.yaml",
+                env_name="Pendulum-v0", env_cls="PendulumEnv",
+                agent_over={"train_episodes": 4, "init_episodes": 2, "batch_size": 16, "hidden_size": 24, "test_episodes": 2},
+                env_over={"max_steps": 8, "hidden_size": 20, "hidden_layer": 2, "activation_fn": "leakyrelu", "reward_env_type": 2,
+                          "use_layer_norm": True})
+        gen_g8t("g8tseln_calc_score_cheetah_td3_virtual_env_layernorm", seed=835, virtual=True,
+                agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 16, "hidden_size": 24, "test_episodes": 1},
+                env_over={"max_steps": 8, "hidden_size": 20, "hidden_layer": 2, "activation_fn": "tanh", "reward_env_type": 0,
+                          "use_layer_norm": True})
+    if "g8tdseln" in which:
+        gen_g8td("g8tdseln_calc_score_cartpole_td3_discrete_se_layernorm", seed=1834, agent_over={"train_episodes": 3, "init_episodes": 1, "test_episodes": 3},
+                 env_over={"max_steps": 30, "hidden_size": 20, "hidden_layer": 2, "use_layer_norm": True})
+    if "g9ln" in which:
+        gen_g9("g9ln_calc_score_cliff_ql_reward_net_layernorm", seed=908, eps_over=0.2,
+               env_over={"hidden_layer": 2, "hidden_size": 24, "use_layer_norm": True})
     if "g4td" in which:
         gen_g4td()
     if "g8td" in which:

@@ -1326,6 +1326,8 @@ int orc_rn_shaped_rewards(const orc_ql_cfg *cfg, const float *rn_params, const i
     const int t = cfg->reward_env_type;
     if (!(t == 0 || t == 1 || t == 2 || t == 5 || t == 6)) return -1;
     orc_mlp_desc rd = { N, cfg->rn_hidden, cfg->rn_layers, 1, cfg->rn_act, cfg->rn_prelu, 0 };
+    float *rn_own = NULL;               /* the ENV section's use_layer_norm: see mlp_with_unit_layer_norm */
+    if (cfg->rn_layer_norm && cfg->rn_layers >= 2 && t != 0) { rn_own = mlp_with_unit_layer_norm(&rd, rn_params); rd.use_layer_norm = 1; rn_params = rn_own; }
     float *phi = malloc(sizeof(float) * N);
     float *x = calloc(N, sizeof(float));
     float (*z)[ORC_MAX_WIDTH] = malloc(sizeof(float) * ORC_MAX_LAYERS * ORC_MAX_WIDTH);
@@ -1352,7 +1354,7 @@ int orc_rn_shaped_rewards(const orc_ql_cfg *cfg, const float *rn_params, const i
             shaped[s * A + ac] = v;
         }
     if (phi_out) memcpy(phi_out, phi, sizeof(float) * N);
-    free(phi); free(x); free(z); free(a);
+    free(phi); free(x); free(z); free(a); free(rn_own);
     return 0;
 }
 

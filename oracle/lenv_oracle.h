@@ -200,7 +200,8 @@ typedef struct {
     int32_t count_based;                /* ql_cb / sarsa_cb (agent_utils.py:57-64): reward += beta / (sqrt(n(s,a)) + 1e-9) */
     double solved_reward, alpha, gamma, eps_init, eps_min, eps_decay, beta;
     int64_t step_budget;
-    int32_t same_action_num, pad2_;     /* env steps per chosen action; 0 and 1 both mean 1 */
+    int32_t same_action_num;            /* env steps per chosen action; 0 and 1 both mean 1 */
+    int32_t rn_layer_norm;              /* the ENV section's use_layer_norm with rn_layers >= 2: the reward net's (never perturbed) LayerNorm */
 } orc_ql_cfg;
 
 typedef struct {
@@ -248,6 +249,9 @@ typedef struct {
     int32_t virtual_env;
     /* same_action_num (base_agent.py:20, env_wrapper.py:24,57): env steps per chosen action; 0 and 1 both mean 1 */
     int32_t same_action_num;
+    /* the ENV section's use_layer_norm with rn_layers >= 2: the reward net / the three SE nets normalise behind hidden Linear 2..L; NES perturbs
+     * nn.Linear modules only, rn_params stays Linear-only and the module keeps weight 1 / bias 0 */
+    int32_t rn_layer_norm;
 } orc_td3_cfg;
 
 typedef struct {
@@ -311,6 +315,7 @@ typedef struct {
     double gumbel_temp;                                      /* annealed over the first 2000 learn calls to gumbel_temp / 20 (:59-60,64-68) */
     double adam_beta1, adam_beta2, adam_eps;
     int64_t step_budget;
+    int32_t se_layer_norm;                                   /* the ENV section's use_layer_norm, as orc_td3_cfg::rn_layer_norm */
 } orc_td3d_cfg;
 
 typedef struct {

@@ -60,7 +60,7 @@ class QlCfg(C.Structure):
                 ("init_episodes", C.c_int32), ("early_out_num", C.c_int32), ("batch_size", C.c_int32), ("rng_mode", C.c_int32),
                 ("agent_kind", C.c_int32), ("count_based", C.c_int32),
                 ("solved_reward", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double), ("eps_init", C.c_double),
-                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double), ("step_budget", C.c_int64), ("same_action_num", C.c_int32), ("pad2_", C.c_int32)]
+                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double), ("step_budget", C.c_int64), ("same_action_num", C.c_int32), ("rn_layer_norm", C.c_int32)]
 
 
 class QlTrace(C.Structure):
@@ -81,7 +81,7 @@ class Td3Cfg(C.Structure):
                 ("step_budget", C.c_int64),
                 ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("use_layer_norm", C.c_int32),
                 ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
-                ("virtual_env", C.c_int32), ("same_action_num", C.c_int32)]
+                ("virtual_env", C.c_int32), ("same_action_num", C.c_int32), ("rn_layer_norm", C.c_int32)]
 
 
 class Td3Tapes(C.Structure):
@@ -105,7 +105,7 @@ class Td3dCfg(C.Structure):
                 ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
                 ("action_std", C.c_double), ("policy_std", C.c_double), ("policy_std_clip", C.c_double), ("max_action", C.c_double),
                 ("gumbel_temp", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
-                ("step_budget", C.c_int64)]
+                ("step_budget", C.c_int64), ("se_layer_norm", C.c_int32)]
 
 
 class Td3dTapes(C.Structure):
@@ -468,6 +468,7 @@ def ql_cfg_from_config(config, tables, rng_mode=0, **overrides):
                 eps_init=float(a["eps_init"]), eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]),
                 step_budget=int(a.get("step_budget", 0)))
     cfg.same_action_num = int(a["same_action_num"])
+    cfg.rn_layer_norm = 1 if e.get("use_layer_norm", False) else 0     # the reward net's own (never perturbed) LayerNorm
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg
@@ -563,6 +564,7 @@ def td3_cfg_from_config(config, rng_mode=0, **overrides):
         cfg.virtual_env = 1                           # the agent trains on a VirtualEnv: the `envs` section describes the three SE nets
     cfg.same_action_num = int(a["same_action_num"])
     cfg.use_layer_norm = 1 if a.get("use_layer_norm", False) else 0      # model_utils.py:22-29
+    cfg.rn_layer_norm = 1 if e.get("use_layer_norm", False) else 0       # the env nets' own (never perturbed) LayerNorm
     name = config["agents"]["gtn"]["agent_name"].lower() if "gtn" in config["agents"] else "td3"
     if name.replace("_vary", "").endswith("_icm"):   # select_agent "td3_icm": TD3(icm=True), agents/TD3.py:44-60
         ic = config["agents"]["icm"]
@@ -695,6 +697,7 @@ def td3d_cfg_from_config(config, rng_mode=0, hp=None, **overrides):
                   se_layers=int(val(e["hidden_layer"])), se_act=ACT[e["activation_fn"]], se_prelu=0.25, hidden=int(a["hidden_size"]),
                   layers=max(1, int(a["hidden_layer"])), act=ACT[a["activation_fn"]], prelu=0.25,
                   use_layer_norm=int(bool(a.get("use_layer_norm", False))), gumbel_hard=int(bool(a["gumbel_softmax_hard"])),
+                  se_layer_norm=int(bool(e.get("use_layer_norm", False))),
                   batch_size=int(a["batch_size"]), rb_size=int(a["rb_size"]), train_episodes=int(a["train_episodes"]),
                   test_episodes=int(a["test_episodes"]), init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]),
                   policy_delay=int(a["policy_delay"]), rng_mode=rng_mode, solved_reward=float(val(e["solved_reward"])),

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "liblenv_hip.so does not export " + name
     assert set(_lib.EXPORTS) <= declared
-    assert L.lenv_abi_version() == 5
+    assert L.lenv_abi_version() == 6
     assert L.lenv_error_string(-2) == b"unsupported shape or option"
 
 
@@ -315,10 +315,14 @@ def test_config_builders_refuse_layer_norm_sections():
     c["envs"]["CartPole-v0"].update(use_layer_norm=True, hidden_layer=2)
     with pytest.raises(NotImplementedError):
         config.ddqn_cfg_from_config(c)
+    # the TD3 family and the tabular agents take the env nets' LayerNorm as a cfg word as well (ABI 6); theta keeps its Linear-only size
     c = configs.halfcheetah_reward_env_td3(2)
     c["envs"]["HalfCheetah-v3"].update(use_layer_norm=True, hidden_layer=2)       # the reward net
-    with pytest.raises(NotImplementedError):
-        config.td3_cfg_from_config(c)
+    tcfg = config.td3_cfg_from_config(c)
+    assert tcfg.rn_layer_norm == 1 and tcfg.rn_layers == 2 and tcfg.use_layer_norm == 0
+    c = configs.cartpole_syn_env_td3_discrete(2)
+    c["envs"]["CartPole-v0"].update(use_layer_norm=True, hidden_layer=2)
+    assert config.td3d_cfg_from_config(c).se_layer_norm == 1
     # TD3 takes the AGENT's LayerNorm (cfg.use_layer_norm): one block per net (actor, critic_1, critic_2) behind its second Linear
     c = configs.halfcheetah_reward_env_td3(2)
     c["agents"]["td3"]["use_layer_norm"] = True

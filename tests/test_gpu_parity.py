@@ -40,7 +40,7 @@ def dev(a, dtype=None):
 
 def test_native_library_loaded(eng):
     from learning_environments_amd import _lib
-    assert _lib.lib().lenv_abi_version() == 5
+    assert _lib.lib().lenv_abi_version() == 6
     with open("/proc/self/maps") as f:
         assert "liblenv_hip.so" in f.read()
 
@@ -356,7 +356,8 @@ def _ql_cfgs(orc, cfgd, rng_mode, **over):
 
 @pytest.mark.parametrize("name", ["g9_calc_score_cliff_a", "g9_calc_score_cliff_b", "g9s_calc_score_cliff_sarsa", "g9c_calc_score_cliff_ql_cb",
                                   "g9sc_calc_score_cliff_sarsa_cb", "g9i_calc_score_cliff_ql_init2",
-                                  "g9k_calc_score_cliff_ql_same_action_2", "g9ks_calc_score_cliff_sarsa_same_action_3"])     # same_action_num 2 / 3
+                                  "g9k_calc_score_cliff_ql_same_action_2", "g9ks_calc_score_cliff_sarsa_same_action_3",     # same_action_num 2 / 3
+                                  "g9ln_calc_score_cliff_ql_reward_net_layernorm"])     # the ENV section's use_layer_norm: reward net 48-24-24-1 with the LayerNorm
 def test_ql_rn_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
     """The tabular agents of select_agent (QL, SARSA, count-based variants; init_episodes gate) against the reference's runs."""
     g = golden(name)
@@ -459,17 +460,18 @@ def test_ql_rn_draw_buffers_are_clamped_not_refused(eng, orc, golden):
         assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
 
 
-@pytest.mark.parametrize("layers", [2, 3])
-def test_ql_rn_multi_layer_reward_net_vs_oracle(eng, orc, golden, layers):
+@pytest.mark.parametrize("layers,env_ln", [(2, False), (3, False), (2, True), (3, True)])
+def test_ql_rn_multi_layer_reward_net_vs_oracle(eng, orc, golden, layers, env_ln):
     """Grid reward nets with more than one hidden layer (default_config_gridworld_reward_env.yaml:108-115 ships HoleRoomLarge with
-    hidden_layer 2): the shaped-reward table of every perturbation and whole QL chains, bit for bit against the oracle."""
+    hidden_layer 2): the shaped-reward table of every perturbation and whole QL chains, bit for bit against the oracle.  env_ln: with
+    `use_layer_norm` in the env's section (cfg.rn_layer_norm; theta keeps its Linear-only size)."""
     g = golden("g9_calc_score_cliff_a")
     cfgd = json.loads(str(g["config_json"]))
     cfgd["env_name"] = "HoleRoomLarge"
-    cfgd["envs"]["HoleRoomLarge"] = dict(cfgd["envs"]["Cliff"], reward_env_type=2, hidden_layer=layers, hidden_size=32, max_steps=30)
+    cfgd["envs"]["HoleRoomLarge"] = dict(cfgd["envs"]["Cliff"], reward_env_type=2, hidden_layer=layers, hidden_size=32, max_steps=30, use_layer_norm=env_ln)
     cfgd["agents"]["ql"].update(eps_init=0.3, eps_min=0.05, eps_decay=0.9, alpha=0.7, train_episodes=20)
     ocfg, cfg, tables = _ql_cfgs(orc, cfgd, 0)
-    assert cfg.rn_layers == layers
+    assert cfg.rn_layers == layers and cfg.rn_layer_norm == ocfg.rn_layer_norm == int(env_ln)
     N, H = tables["n_states"], ocfg.rn_hidden
     P = N * H + H + (layers - 1) * (H * H + H) + H + 1
     rng = np.random.RandomState(13)
@@ -995,13 +997,15 @@ def test_icm_vary_counter_mode_vs_oracle(eng, orc, golden):
         assert float(il.score[c]) == o["score"], (c, hps[c])
 
 
-def test_td3_virtual_env_tape_and_counter_mode_vs_oracle(eng, orc, golden):
+@pytest.mark.parametrize("name", ["g8ts_calc_score_cheetah_td3_virtual_env", "g8tseln_calc_score_cheetah_td3_virtual_env_layernorm"])
+def test_td3_virtual_env_tape_and_counter_mode_vs_oracle(eng, orc, golden, name):
     """TD3 on a VirtualEnv (default_config_halfcheetah.yaml: synthetic_env_type 0): (a) the reference run G8TS, (b) counter mode
-    with perturbed three-hidden-layer SEs of width 128 (the shipped SE shape); bit-exact against the oracle."""
-    g = golden("g8ts_calc_score_cheetah_td3_virtual_env")
+    with perturbed three-hidden-layer SEs of width 128 (the shipped SE shape); bit-exact against the oracle.  *_layernorm: the same with
+    `use_layer_norm` in the ENV's section (cfg.rn_layer_norm: the SE nets normalise behind hidden Linear 2..L, theta stays Linear-only)."""
+    g = golden(name)
     cfgd = json.loads(str(g["config_json"]))
     ocfg, cfg = _td3_cfgs(orc, cfgd, 1)
-    assert cfg.virtual_env == 1
+    assert cfg.virtual_env == 1 and cfg.rn_layer_norm == ocfg.rn_layer_norm == int(name.endswith("layernorm"))
     n = g["tr_reward"].size
     otapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
                                 g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
@@ -1508,7 +1512,8 @@ def test_layer_norm_in_the_td3_loop_vs_oracle(eng, orc, golden, hidden, layers, 
 # ---------------------------------------------------------------------------------------------------------------
 # Pendulum-v0 behind the TD3 path (default_config_pendulum.yaml / default_config_pendulum_reward_env.yaml)
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["g8p_calc_score_pendulum_td3_virtual_env", "g8pr_calc_score_pendulum_td3_reward_env"])
+@pytest.mark.parametrize("name", ["g8p_calc_score_pendulum_td3_virtual_env", "g8pr_calc_score_pendulum_td3_reward_env",
+                                  "g8trnln_calc_score_pendulum_td3_reward_net_layernorm"])     # the ENV section's use_layer_norm: reward net 3-20-20-1
 def test_td3_pendulum_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
     g = golden(name)
     ocfg, cfg = _td3_cfgs(orc, json.loads(str(g["config_json"])), 1)
@@ -1545,15 +1550,20 @@ def test_td3_pendulum_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
         assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4
 
 
-@pytest.mark.parametrize("virtual,rtype,rn_layers,act,hidden,layers,batch", [(False, 2, 1, "prelu", 128, 2, 256), (False, 1, 1, "tanh", 24, 1, 20),
-                                                                             (False, 2, 2, "prelu", 24, 1, 20), (False, 5, 3, "leakyrelu", 24, 2, 20),
-                                                                             (False, 0, 1, "relu", 24, 1, 20), (False, 6, 1, "relu", 33, 2, 40),
-                                                                             (True, 0, 2, "leakyrelu", 128, 2, 256), (True, 0, 1, "tanh", 24, 1, 20)])
-def test_td3_pendulum_counter_mode_vs_oracle(eng, orc, golden, virtual, rtype, rn_layers, act, hidden, layers, batch):
+@pytest.mark.parametrize("virtual,rtype,rn_layers,act,hidden,layers,batch,env_ln",
+                         [(False, 2, 1, "prelu", 128, 2, 256, False), (False, 1, 1, "tanh", 24, 1, 20, False),
+                          (False, 2, 2, "prelu", 24, 1, 20, False), (False, 5, 3, "leakyrelu", 24, 2, 20, False),
+                          (False, 0, 1, "relu", 24, 1, 20, False), (False, 6, 1, "relu", 33, 2, 40, False),
+                          (True, 0, 2, "leakyrelu", 128, 2, 256, False), (True, 0, 1, "tanh", 24, 1, 20, False),
+                          # `use_layer_norm` in the ENV's section (cfg.rn_layer_norm): reward nets with 2 / 3 hidden layers, the shipped SE shape
+                          (False, 2, 2, "prelu", 24, 1, 20, True), (False, 5, 3, "leakyrelu", 24, 2, 20, True), (True, 0, 2, "leakyrelu", 24, 2, 20, True)])
+def test_td3_pendulum_counter_mode_vs_oracle(eng, orc, golden, virtual, rtype, rn_layers, act, hidden, layers, batch, env_ln):
     """Pendulum-v0, RewardEnv types without an info vector and the VirtualEnv (the shipped 4-32-32-x SE shape among them),
-    perturbed synthetic envs, full-length 200-step episodes in the first case: bit-exact against the oracle."""
+    perturbed synthetic envs, full-length 200-step episodes in the first case: bit-exact against the oracle.  env_ln: the env nets carry
+    the (never perturbed) LayerNorm behind hidden Linear 2..L; theta / eps keep their Linear-only size."""
     g = golden("g8pr_calc_score_pendulum_td3_reward_env")
     cfgd = json.loads(str(g["config_json"]))
+    cfgd["envs"]["Pendulum-v0"]["use_layer_norm"] = env_ln
     cfgd["agents"]["gtn"]["synthetic_env_type"] = 0 if virtual else 1
     long_run = hidden == 128 and not virtual
     cfgd["agents"]["td3"].update(hidden_size=hidden, hidden_layer=layers, batch_size=batch, train_episodes=3, init_episodes=1, test_episodes=3,
@@ -1561,6 +1571,7 @@ def test_td3_pendulum_counter_mode_vs_oracle(eng, orc, golden, virtual, rtype, r
     cfgd["envs"]["Pendulum-v0"].update(max_steps=200 if long_run else 12, hidden_size=32, hidden_layer=rn_layers, activation_fn=act,
                                        reward_env_type=rtype, solved_reward=1e9)
     ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
+    assert cfg.rn_layer_norm == ocfg.rn_layer_norm == int(env_ln)
     Pa, Pc = orc.td3_param_counts(ocfg)
     if virtual:
         P_rn = orc.mlp_num_params(orc.mlp_desc(4, 32, rn_layers, 3, act)) + 2 * orc.mlp_num_params(orc.mlp_desc(4, 32, rn_layers, 1, act))

@@ -415,7 +415,8 @@ def test_g2_reward_env_shaping(golden):
 
 @pytest.mark.parametrize("name", ["g9_calc_score_cliff_a", "g9_calc_score_cliff_b", "g9s_calc_score_cliff_sarsa", "g9c_calc_score_cliff_ql_cb",
                                   "g9sc_calc_score_cliff_sarsa_cb", "g9i_calc_score_cliff_ql_init2",
-                                  "g9k_calc_score_cliff_ql_same_action_2", "g9ks_calc_score_cliff_sarsa_same_action_3"])     # same_action_num 2 / 3
+                                  "g9k_calc_score_cliff_ql_same_action_2", "g9ks_calc_score_cliff_sarsa_same_action_3",     # same_action_num 2 / 3
+                                  "g9ln_calc_score_cliff_ql_reward_net_layernorm"])     # the ENV section's use_layer_norm: two-hidden-layer reward net
 def test_g9_calc_score_cliff(golden, name):
     """cfg 4: integer-state path.  Trajectories, Q-table argmax decisions, episode lengths and returns are EXACT -- for QL and
     for the other tabular agents of select_agent (SARSA, count-based QL / SARSA) and with init_episodes > 0."""
@@ -616,13 +617,15 @@ def test_g8ti_td3_with_icm(golden):
     assert orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], tapes=tapes)["rc"] != 0
 
 
-def test_g8ts_td3_on_a_virtual_env(golden):
+@pytest.mark.parametrize("name", ["g8ts_calc_score_cheetah_td3_virtual_env", "g8tseln_calc_score_cheetah_td3_virtual_env_layernorm"])
+def test_g8ts_td3_on_a_virtual_env(golden, name):
     """default_config_halfcheetah.yaml's combination (synthetic_env_type 0): TD3 trains on a VirtualEnv -- three SE nets with two
-    hidden layers on cat(action, state) -- and is tested on the real (stand-in) env."""
+    hidden layers on cat(action, state) -- and is tested on the real (stand-in) env.  *_layernorm: `use_layer_norm` in the ENV's section
+    (the SE nets' LayerNorm is never perturbed by NES: theta holds the nn.Linear parameters only)."""
     import json
-    g = golden("g8ts_calc_score_cheetah_td3_virtual_env")
+    g = golden(name)
     cfg = orc.td3_cfg_from_config(json.loads(str(g["config_json"])), rng_mode=1)
-    assert cfg.virtual_env == 1 and cfg.rn_layers == 2
+    assert cfg.virtual_env == 1 and cfg.rn_layers == 2 and cfg.rn_layer_norm == int(name.endswith("layernorm"))
     tapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
                                g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
     n = g["tr_reward"].size
@@ -635,7 +638,8 @@ def test_g8ts_td3_on_a_virtual_env(golden):
     assert abs(out["score"] - float(g["score"])) <= 1e-4
 
 
-@pytest.mark.parametrize("name", ["g8p_calc_score_pendulum_td3_virtual_env", "g8pr_calc_score_pendulum_td3_reward_env"])
+@pytest.mark.parametrize("name", ["g8p_calc_score_pendulum_td3_virtual_env", "g8pr_calc_score_pendulum_td3_reward_env",
+                                  "g8trnln_calc_score_pendulum_td3_reward_net_layernorm"])     # the ENV section's use_layer_norm (reward net 3-20-20-1)
 def test_g8p_td3_on_pendulum(golden, name):
     """default_config_pendulum.yaml / default_config_pendulum_reward_env.yaml's env: TD3 (max_action 2) on a VirtualEnv of
     Pendulum-v0 and on a RewardEnv (type 2) over the real Pendulum; the reference's runs replayed by the oracle.  The real

@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 
 CHAIN_FIXTURES = ["g8td_calc_score_cartpole_td3_discrete", "g8tdl_calc_score_acrobot_td3_discrete_layer_norm",
-                  "g8td3_calc_score_cartpole_td3_discrete_3_layers", "g8tdv_calc_score_cartpole_td3_discrete_vary"]
+                  "g8td3_calc_score_cartpole_td3_discrete_3_layers", "g8tdv_calc_score_cartpole_td3_discrete_vary",
+                  "g8tdseln_calc_score_cartpole_td3_discrete_se_layernorm"]       # the ENV section's use_layer_norm (SE nets 6-20-20-x)
 
 
 @pytest.fixture(scope="module")
