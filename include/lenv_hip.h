@@ -55,8 +55,7 @@ typedef struct {
      * (Module.parameters() order).  Honoured by lenv_mlp_num_params / lenv_mlp_forward / lenv_se_step_population (the three SE nets of
      * a VirtualEnv.step).  The fused loops take the AGENT's LayerNorm through their own cfg fields (lenv_ddqn_cfg::q_layer_norm,
      * lenv_td3_cfg::use_layer_norm, lenv_td3d_cfg::use_layer_norm); the synthetic env's nets inside the DDQN /
-     * DuelingDDQN loop: lenv_ddqn_cfg::se_layer_norm; in the other loops they are plain MLPs (their config builders refuse
-     * `use_layer_norm` in the envs section when it would change the network). */
+     * DuelingDDQN loop: lenv_ddqn_cfg::se_layer_norm; the TD3-family and tabular loops: rn_layer_norm / se_layer_norm of their cfgs). */
     int32_t use_layer_norm;
 } lenv_mlp_desc;
 
@@ -93,14 +92,14 @@ typedef struct {
      * Only lenv_dueling_se_inner_loop_icm takes such a cfg (GEMM-tiled kernel; fresh ICM parameters per chain). */
     int32_t icm_enabled, icm_feature_dim, icm_hidden;
     /* `use_layer_norm` of the ENV's config section with se_layers >= 2 (models/model_utils.py:22-37): the shared nn.LayerNorm behind hidden
-     * Linear 2..L of each of the three SE nets.  NES perturbs and updates nn.Linear parameters only (agents/GTN_worker.py:156-175,
+     * Linear 2..L of each of the three SE nets (synthetic_env_type 1: of the reward net).  NES perturbs and updates nn.Linear parameters only (agents/GTN_worker.py:156-175,
      * agents/GTN_master.py:281-296): the module keeps its initial affine (weight 1, bias 0) and theta stays the Linear parameters.
      * GEMM-tiled kernel only (lenv_dueling_se_inner_loop*); nothing to do with one hidden layer. */
     int32_t se_layer_norm;
     double icm_lr, icm_beta, icm_eta;
     /* gtn.synthetic_env_type: 0 = the agent trains on the VirtualEnv (theta = the three SE nets); 1 = on a RewardEnv over the
      * REAL env (envs/reward_env.py:61-133, default_config_cartpole_reward_env.yaml): real transitions, reward through the
-     * reward network theta (state_dim -> se_hidden -> 1, se_act; a 1-input dummy for type 0), reward_env_type 0, 1, 2, 5 or 6
+     * reward network theta (state_dim -> se_hidden x se_layers -> 1, se_act; a 1-input dummy for type 0), reward_env_type 0, 1, 2, 5 or 6
      * (the real CartPole / Acrobot step carries no info vector).  GEMM-tiled kernel only (lenv_dueling_se_inner_loop*). */
     int32_t synthetic_env_type, reward_env_type;
     /* same_action_num (agents/base_agent.py:20,104,194; envs/env_wrapper.py:24-29,56-61): env steps per chosen action -- a VirtualEnv

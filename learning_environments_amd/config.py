@@ -8,20 +8,6 @@ ENV_DIMS = {"CartPole-v0": (4, 2), "Acrobot-v1": (6, 3), "HalfCheetah-v3": (17, 
 TD3_MAX_ACTION = {"HalfCheetah-v3": 1.0, "Pendulum-v0": 2.0, "MountainCarContinuous-v0": 1.0}
 
 
-def _refuse_layer_norm(config, env_section, agent_section):
-    """`use_layer_norm` (models/model_utils.py:22-29) where a fused inner loop would silently train a different network is refused: only
-    the reward-env mode of the DDQN loop (one-hidden-layer reward net) is left.  Everywhere else the env nets' LayerNorm is taken
-    (cfg.se_layer_norm / cfg.rn_layer_norm) and so is the AGENT's (cfg.q_layer_norm in the DDQN / DuelingDDQN loop, cfg.use_layer_norm in
-    the TD3 and TD3_discrete_vary loops; lenv_mlp_forward in the one-step API)."""
-    for name, sec in (("envs." + config["env_name"], env_section), ("agent", agent_section)):
-        if sec is not None and sec.get("use_layer_norm", False):
-            hl = sec.get("hidden_layer", 1)
-            hl = hl[1] if isinstance(hl, list) else hl       # env_factory.py:54-58: list-valued entries -> value[1]
-            if int(hl) < 2:
-                continue                                     # one hidden layer: build_nn_from_config never appends the module -- the same network
-            raise NotImplementedError("use_layer_norm in the %s section: no fused inner loop takes LayerNorm nets here" % name)
-
-
 def _launch_knobs(cfg, config):
     """Launch knobs of this implementation (no counterpart in the reference; absent keys = automatic): `team_size` (workgroups per
     chain: 0 automatic, 1 never a team, G at most G) and `kernel_variant` (_lib.VARIANT_* bits) in the `gtn` section."""
@@ -49,9 +35,6 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
     a = config["agents"][agent_key]
     dueling = agent_key == "duelingddqn"
     S, A = ENV_DIMS[env_name]
-    reward_env = "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 0)) == 1
-    if reward_env:
-        _refuse_layer_norm(config, e, None)          # the reward net of this loop has one hidden layer
 
     def val(v):  # env_factory.py:54-58: list-valued entries -> float(value[1])
         return float(v[1]) if isinstance(v, list) else v
@@ -80,7 +63,7 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
     # them with build_nn_from_config).  NES perturbs and updates nn.Linear modules only (GTN_worker.py:156-175, GTN_master.py:281-296), so the
     # module keeps its constructor weight 1 / bias 0 on every worker and theta stays the Linear parameters: the kernel normalises without
     # parameters
-    cfg.se_layer_norm = 1 if (e.get("use_layer_norm", False) and not reward_env) else 0
+    cfg.se_layer_norm = 1 if e.get("use_layer_norm", False) else 0      # RewardEnv mode: the reward net's
     _launch_knobs(cfg, config)
     if icm:                                          # config section `icm` (agents/DDQN.py:43-49)
         ic = config["agents"]["icm"]

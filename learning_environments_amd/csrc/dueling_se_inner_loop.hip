@@ -206,7 +206,8 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
     if (reward_env) {
         const float sg = a.eps ? a.sign[chain] : 0.0f;
         const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P_se : nullptr;
-        for (int i = tid; i < a.P_se; i += DNT) rn_w[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
+        float *dst = seL > 1 ? arena + a.a_se_mid : rn_w;       // a reward net with several hidden layers does not fit the LDS rows: arena
+        for (int i = tid; i < a.P_se; i += DNT) dst[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
     } else {
         const float sg = a.eps ? a.sign[chain] : 0.0f;
         const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * a.P_se : nullptr;
@@ -450,17 +451,47 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
             if (reward_env) {
                 // ---- EnvWrapper.step -> RewardEnv.step (reward_env.py:61-66): real transition (TimeLimit: done at max_steps),
                 // reward = _calc_reward(state, next_state, reward) -- oracle: rn_shape_one ----
+                // build_nn_from_config (model_utils.py:16-37): Linear(D, H) | [Linear(H, H) (+ the shared LayerNorm)] x (layers - 1) | Linear(H, 1),
+                // flat in Module.parameters() order; the LayerNorm is never perturbed (weight 1 / bias 0, not in theta: cfg.se_layer_norm)
                 auto rn_phi = [&](const float *obs, int slot) {       // phi = reward_net(obs) -> ctrl[slot]
-                    const float *W0 = rn_w, *b0 = rn_w + Hse * Drn, *Wo = b0 + Hse, *bo = Wo + Hse;
+                    const float *rnp = seL > 1 ? arena + a.a_se_mid : rn_w;
+                    const float *W0 = rnp, *b0 = rnp + Hse * Drn;
                     for (int j = tid; j < Hse; j += DNT) {
                         float z = 0.0f;
                         for (int k = 0; k < Drn; ++k) z = fma32(obs[k], W0[j * Drn + k], z);
                         rn_h[j] = act_fwd(se_act_id, cfg.se_prelu, z + b0[j]);
                     }
                     __syncthreads();
+                    const float *hp = rn_h, *Wl = b0 + Hse;
+                    float *hn = se_h2;
+                    for (int l = 1; l < seL; ++l) {
+                        const float *bl = Wl + Hse * Hse;
+                        for (int j = tid; j < Hse; j += DNT) {
+                            float z = 0.0f;
+                            for (int k = 0; k < Hse; ++k) z = fma32(hp[k], Wl[j * Hse + k], z);
+                            z = z + bl[j];
+                            hn[j] = se_ln ? z : act_fwd(se_act_id, cfg.se_prelu, z);
+                        }
+                        __syncthreads();
+                        if (se_ln) {
+                            if (tid == 0) {
+                                float sm = 0.0f, sv = 0.0f;
+                                for (int jj = 0; jj < Hse; ++jj) sm = sm + hn[jj];
+                                const float mean = sm / (float)Hse;
+                                for (int jj = 0; jj < Hse; ++jj) { const float dj = hn[jj] - mean; sv = fma32(dj, dj, sv); }
+                                se_ln_stat[0] = mean; se_ln_stat[1] = 1.0f / __builtin_sqrtf(sv / (float)Hse + 1e-5f);
+                            }
+                            __syncthreads();
+                            for (int j = tid; j < Hse; j += DNT) hn[j] = act_fwd(se_act_id, cfg.se_prelu, fma32((hn[j] - se_ln_stat[0]) * se_ln_stat[1], 1.0f, 0.0f));
+                            __syncthreads();
+                        }
+                        const float *t2 = hp; hp = hn; hn = const_cast<float *>(t2);
+                        Wl = bl + Hse;
+                    }
+                    const float *Wo = Wl, *bo = Wo + Hse;
                     if (tid == 0) {
                         float acc = 0.0f;
-                        for (int j = 0; j < Hse; ++j) acc = fma32(rn_h[j], Wo[j], acc);
+                        for (int j = 0; j < Hse; ++j) acc = fma32(hp[j], Wo[j], acc);
                         ctrl[slot] = acc + bo[0];
                     }
                     __syncthreads();
@@ -868,7 +899,6 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     if (cfg->grad_chunk != 0 && cfg->grad_chunk < B) return LENV_ERR_UNSUPPORTED;   // batch gradient = one sequential chunk here
     if (L < 1 || L > D_MAXL || H < 1 || H > D_MAXH || F < 1 || F > D_MAXW || B < 1 || B > D_MAXB || T < 1 || T > D_MAXW || cfg->se_layers < 1 || cfg->se_layers > D_MAXL)
         return LENV_ERR_UNSUPPORTED;
-    if (cfg->synthetic_env_type == 1 && cfg->se_layers != 1) return LENV_ERR_UNSUPPORTED;    // the reward net over a real env: one hidden layer here
     if (cfg->same_action_num < 0 || cfg->same_action_num > 64) return LENV_ERR_UNSUPPORTED;
     if (!((cfg->env_id == LENV_ENV_CARTPOLE && S == 4 && A == 2) || (cfg->env_id == LENV_ENV_ACROBOT && S == 6 && A == 3) ||
           (cfg->env_id == LENV_ENV_MOUNTAINCAR && S == 2 && A == 3)))
@@ -883,7 +913,7 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
         // CartPole / Acrobot step has no info vector, so the info types (3, 4, 7, 8, 101, 102) cannot be evaluated
         const int t = cfg->reward_env_type;
         if (!(t == 0 || t == 1 || t == 2 || t == 5 || t == 6)) return LENV_ERR_UNSUPPORTED;
-        a.P_se = (int)d_mlp_params(t == 0 ? 1 : S, Hse, 1, 1);
+        a.P_se = (int)d_mlp_params(t == 0 ? 1 : S, Hse, cfg->se_layers, 1);
     } else if (cfg->synthetic_env_type != 0) return LENV_ERR_INVALID;
     a.RS = (2 * S + 3 + 3) & ~3;
     int64_t cap = (int64_t)cfg->train_episodes * cfg->max_steps;
@@ -894,7 +924,8 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     auto take = [&](int64_t n) { int64_t r = off; off += (n + 3) & ~(int64_t)3; return r; };
     a.a_replay = take(a.rb_cap * a.RS);
     a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
-    a.a_se_mid = take(cfg->se_layers > 1 ? 3 * (int64_t)(cfg->se_layers - 1) * ((int64_t)Hse * Hse + Hse) : 0);
+    // several hidden layers: the SEs' hidden-to-hidden blocks, or (RewardEnv mode) the whole reward net
+    a.a_se_mid = take(cfg->se_layers > 1 ? (cfg->synthetic_env_type == 1 ? (int64_t)a.P_se : 3 * (int64_t)(cfg->se_layers - 1) * ((int64_t)Hse * Hse + Hse)) : 0);
     a.P_icm = 0;
     for (int i = 0; i < IB_COUNT; ++i) a.a_icm[i] = 0;
     if (cfg->icm_enabled) {

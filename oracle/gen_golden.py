@@ -456,7 +456,7 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
             with torch.no_grad():
                 w.synthetic_env_orig.env.done_net[-1].bias.add_(done_bias_shift)
         theta = se_theta(w.synthetic_env_orig) if reward_env_type is None \
-            else pack_linear_params(w.synthetic_env_orig.state_dict(), "env.reward_net.")
+            else pack_linear_only(w.synthetic_env_orig.state_dict(), "env.reward_net.")
         env = w.synthetic_env_orig
         orig_step = env.step
 
@@ -1402,7 +1402,7 @@ def _gen_g11_body(cfg, n, GTN_Master, GTN_Worker, shutil):
 def main():
     # no arguments (or "all"): every fixture under tests/golden is regenerated (the full-shape runs g8df / g8tf take minutes each)
     ALL = ["g1", "g1ln", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x",
-           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8tln", "g8df", "g8l2", "g8ln", "g8seln", "g8tseln", "g8tdseln", "g9ln", "g8m", "g8r", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k"]
+           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8tln", "g8df", "g8l2", "g8ln", "g8seln", "g8tseln", "g8tdseln", "g9ln", "g8m", "g8r", "g8rl", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k"]
     which = sys.argv[1:] or ALL
     if "all" in which:
         which = ALL
@@ -1551,6 +1551,15 @@ def main():
                env_yaml="default_config_mountaincar.yaml", env_name="MountainCar-v0", env_cls="MountainCarEnv", reward_env_type=2,
                agent_over={"hidden_size": 40, "batch_size": 24, "init_episodes": 1, "test_episodes": 2},
                env_over={"hidden_size": 24, "solved_reward": 0.5, "info_dim": 0})
+    if "g8rl" in which:
+        # the same RewardEnv mode with a two-hidden-layer reward net (4-24-24-1), plain and with `use_layer_norm` in the env's section
+        gen_g8("g8rl_calc_score_cartpole_ddqn_reward_env_2layer", train_episodes=3, done_bias_shift=0.0, seed=852, max_steps=30,
+               env_yaml="default_config_cartpole_reward_env.yaml", reward_env_type=2,
+               agent_over={"init_episodes": 1, "test_episodes": 2, "batch_size": 24}, env_over={"hidden_size": 24, "hidden_layer": 2})
+        gen_g8("g8rln_calc_score_cartpole_ddqn_reward_env_layernorm", train_episodes=3, done_bias_shift=0.0, seed=853, max_steps=30,
+               env_yaml="default_config_cartpole_reward_env.yaml", reward_env_type=1,
+               agent_over={"init_episodes": 1, "test_episodes": 2, "batch_size": 24},
+               env_over={"hidden_size": 24, "hidden_layer": 2, "activation_fn": "leakyrelu", "use_layer_norm": True})
     if "g8r" in which:
         # default_config_cartpole_reward_env.yaml's experiment: DDQN on a RewardEnv over the real CartPole (potential-shaped,
         # type 2, PReLU reward net 4-64-1) -- the env transition is the real one, the reward goes through the network

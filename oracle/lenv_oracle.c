@@ -1107,6 +1107,10 @@ static int ddqn_se_chain_impl(const orc_ddqn_cfg *cfg, const float *se_params, c
         se_own[0] = mlp_with_unit_layer_norm(&sn, se_p[0]); se_own[1] = mlp_with_unit_layer_norm(&rn, se_p[1]); se_own[2] = mlp_with_unit_layer_norm(&dn, se_p[2]);
         for (int i = 0; i < 3; ++i) se_p[i] = se_own[i];
     }
+    if (cfg->se_layer_norm && cfg->se_layers >= 2 && reward_env && rtype != 0) {      /* the reward net's own LayerNorm, likewise */
+        se_own[0] = mlp_with_unit_layer_norm(&rd, se_params);
+        rd.use_layer_norm = 1; se_params = se_own[0];
+    }
     const int64_t row_stride = 2 * S + 3;
     int64_t cap = (int64_t)cfg->train_episodes * cfg->max_steps;
     if (cap > cfg->rb_size) cap = cfg->rb_size;

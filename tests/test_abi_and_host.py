@@ -299,9 +299,10 @@ def test_master_host_logic_for_icm_and_multilayer_agents_on_the_oracle_engine(tm
         assert np.array_equal(gathered[:, 0], best) and np.array_equal(gathered[:, 1], scores[0::3])
 
 
-def test_config_builders_refuse_layer_norm_sections():
+def test_config_builders_take_layer_norm_sections():
     """theta / eps are the nn.Linear parameters only; a `use_layer_norm` section must not slip into a fused loop
-    that would ignore the normalisation."""
+    that would ignore the normalisation.  Round 4: no builder refuses the flag any more -- the agent's LayerNorm is a parameter block of the
+    agent vector, the env nets' LayerNorm a cfg word (it is never perturbed, theta keeps its layout)."""
     from learning_environments_amd import config, configs
     c = configs.cartpole_syn_env_ddqn(2)
     c["envs"]["CartPole-v0"]["use_layer_norm"] = True
@@ -310,11 +311,11 @@ def test_config_builders_refuse_layer_norm_sections():
     # the DDQN / DuelingDDQN loop over a synthetic env normalises inside its SE step (cfg.se_layer_norm; theta stays the Linear parameters) ...
     scfg = config.ddqn_cfg_from_config(c)
     assert scfg.se_layer_norm == 1 and scfg.se_layers == 2 and scfg.q_layer_norm == 0
-    # ... its reward-env mode (one-hidden-layer reward net) does not
+    # ... and so does its reward-env mode (the reward net's LayerNorm)
     c = configs.cartpole_reward_env_ddqn(2)
     c["envs"]["CartPole-v0"].update(use_layer_norm=True, hidden_layer=2)
-    with pytest.raises(NotImplementedError):
-        config.ddqn_cfg_from_config(c)
+    rcfg = config.ddqn_cfg_from_config(c)
+    assert rcfg.synthetic_env_type == 1 and rcfg.se_layer_norm == 1 and rcfg.se_layers == 2
     # the TD3 family and the tabular agents take the env nets' LayerNorm as a cfg word as well (ABI 6); theta keeps its Linear-only size
     c = configs.halfcheetah_reward_env_td3(2)
     c["envs"]["HalfCheetah-v3"].update(use_layer_norm=True, hidden_layer=2)       # the reward net

@@ -435,8 +435,8 @@ def test_mlp_forward_entry_matches_oracle(golden):
 
 def test_mlp_forward_with_layer_norm_matches_oracle_and_reference(golden):
     """`use_layer_norm` nets (models/model_utils.py:22-37) through lenv_mlp_forward: bit-exact against the oracle, the reference
-    module's outputs within 2e-5; the fused inner loops refuse such descriptors."""
-    from learning_environments_amd import _lib, engine
+    module's outputs within 2e-5 (the one-step SE entry with such nets: test_se_step_population_layer_norm)."""
+    from learning_environments_amd import engine
     from oracle import oracle as orc
     g = golden("g1ln_mlp_layer_norm")
     acts = ["identity", "relu", "leakyrelu", "tanh", "prelu"]
@@ -448,10 +448,6 @@ def test_mlp_forward_with_layer_norm_matches_oracle_and_reference(golden):
         y = engine.mlp_forward(d, torch.from_numpy(g[pre + "params"]).cuda(), torch.from_numpy(g[pre + "x"]).cuda()).cpu().numpy()
         assert np.array_equal(y, orc.mlp_forward(orc.mlp_desc(din, H, L, dout, acts[act], use_layer_norm=True), g[pre + "params"], g[pre + "x"]))
         np.testing.assert_allclose(y, g[pre + "y"], rtol=2e-5, atol=2e-6)
-    d = engine.mlp_desc(6, 8, 1, 4, "relu", use_layer_norm=True)
-    with pytest.raises((NotImplementedError, _lib.LenvError)):
-        engine.se_step_population((d, engine.mlp_desc(6, 8, 1, 1, "relu"), engine.mlp_desc(6, 8, 1, 1, "relu")), torch.zeros(200, device="cuda"),
-                                  None, None, None, torch.zeros((1, 1, 4), device="cuda"), torch.zeros((1, 1), dtype=torch.int32, device="cuda"))
 
 
 def test_gtn_master_td3_cheetah_generation(tmp_path, monkeypatch):

@@ -737,7 +737,9 @@ def test_ddqn_multilayer_counter_mode_vs_oracle(eng, orc, golden, env_name, laye
 # synthetic_env_type 1 with a DDQN-family agent: RewardEnv over the real CartPole / Acrobot
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["g8r_calc_score_cartpole_ddqn_reward_env", "g8r6_calc_score_cartpole_ddqn_reward_env_t6",
-                                  "g8mr_calc_score_mountaincar_ddqn_reward_env"])
+                                  "g8mr_calc_score_mountaincar_ddqn_reward_env",
+                                  "g8rl_calc_score_cartpole_ddqn_reward_env_2layer",        # reward net 4-24-24-1
+                                  "g8rln_calc_score_cartpole_ddqn_reward_env_layernorm"])   # the same with use_layer_norm in the env's section (type 1)
 def test_ddqn_reward_env_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
     g = golden(name)
     cfgd = json.loads(str(g["config_json"]))
@@ -830,24 +832,31 @@ def test_ddqn_same_action_num_vs_reference_and_oracle(eng, orc, golden, name, k)
         assert il2.stats[c].cpu().tolist() == [o2["episodes_run"], o2["train_steps"], o2["learn_steps"], o2["test_steps"]]
 
 
-@pytest.mark.parametrize("env_name,family,rtype,act", [("CartPole-v0", "ddqn", 2, "prelu"), ("Acrobot-v1", "duelingddqn", 1, "leakyrelu"),
-                                                       ("CartPole-v0", "ddqn", 5, "tanh"), ("Acrobot-v1", "ddqn", 0, "relu"),
-                                                       ("CartPole-v0", "duelingddqn", 6, "relu"), ("MountainCar-v0", "ddqn", 1, "leakyrelu"),
-                                                       ("MountainCar-v0", "duelingddqn", 2, "tanh")])
-def test_ddqn_reward_env_counter_mode_vs_oracle(eng, orc, golden, env_name, family, rtype, act):
-    """All info-free reward types, both real envs, both agent families, perturbed reward networks: bit-exact against the oracle."""
+@pytest.mark.parametrize("env_name,family,rtype,act,rn_layers,env_ln",
+                         [("CartPole-v0", "ddqn", 2, "prelu", 1, False), ("Acrobot-v1", "duelingddqn", 1, "leakyrelu", 1, False),
+                          ("CartPole-v0", "ddqn", 5, "tanh", 1, False), ("Acrobot-v1", "ddqn", 0, "relu", 1, False),
+                          ("CartPole-v0", "duelingddqn", 6, "relu", 1, False), ("MountainCar-v0", "ddqn", 1, "leakyrelu", 1, False),
+                          ("MountainCar-v0", "duelingddqn", 2, "tanh", 1, False),
+                          # reward nets with two / three hidden layers (arena-resident), plain and with the env section's use_layer_norm
+                          ("CartPole-v0", "ddqn", 2, "prelu", 2, False), ("Acrobot-v1", "duelingddqn", 1, "leakyrelu", 3, False),
+                          ("CartPole-v0", "ddqn", 6, "tanh", 2, True), ("Acrobot-v1", "duelingddqn", 2, "relu", 3, True),
+                          ("MountainCar-v0", "ddqn", 0, "relu", 2, True)])
+def test_ddqn_reward_env_counter_mode_vs_oracle(eng, orc, golden, env_name, family, rtype, act, rn_layers, env_ln):
+    """All info-free reward types, both real envs, both agent families, perturbed reward networks of one to three hidden layers (with
+    and without their LayerNorm): bit-exact against the oracle."""
     g = golden("g8r_calc_score_cartpole_ddqn_reward_env" if family == "ddqn" else "g8ia_calc_score_acrobot_dueling_icm")
     cfgd = json.loads(str(g["config_json"]))
     cfgd["agents"]["gtn"].update(agent_name="DDQN" if family == "ddqn" else "DuelingDDQN", synthetic_env_type=1)
     cfgd["env_name"] = env_name
     base_env = dict(list(cfgd["envs"].values())[0])
-    base_env.update(hidden_size=40, hidden_layer=1, activation_fn=act, reward_env_type=rtype, info_dim=0, max_steps=14,
-                    solved_reward=1e9)
+    base_env.update(hidden_size=40, hidden_layer=rn_layers, activation_fn=act, reward_env_type=rtype, info_dim=0, max_steps=14,
+                    solved_reward=1e9, use_layer_norm=env_ln)
     cfgd["envs"] = {env_name: base_env}
     cfgd["agents"][family].update(batch_size=20, test_episodes=3, init_episodes=1, hidden_size=24)
     ocfg, cfg = _inner_cfg(orc, cfgd, grad_chunk=0, rng_mode=0, train_episodes=3)
     S = cfg.state_dim
-    P_rn = orc.mlp_num_params(orc.mlp_desc(1 if rtype == 0 else S, 40, 1, 1, act))
+    assert cfg.se_layers == rn_layers and cfg.se_layer_norm == ocfg.se_layer_norm == int(env_ln)
+    P_rn = orc.mlp_num_params(orc.mlp_desc(1 if rtype == 0 else S, 40, rn_layers, 1, act))
     chains = 3
     rng = np.random.RandomState(81)
     theta = (rng.randn(P_rn) * 0.3).astype(np.float32)

@@ -299,7 +299,9 @@ def test_g1ln_mlp_with_layer_norm(golden):
 
 
 @pytest.mark.parametrize("name", ["g8r_calc_score_cartpole_ddqn_reward_env", "g8r6_calc_score_cartpole_ddqn_reward_env_t6",
-                                  "g8mr_calc_score_mountaincar_ddqn_reward_env"])
+                                  "g8mr_calc_score_mountaincar_ddqn_reward_env",
+                                  "g8rl_calc_score_cartpole_ddqn_reward_env_2layer",        # reward net 4-24-24-1
+                                  "g8rln_calc_score_cartpole_ddqn_reward_env_layernorm"])   # the same with use_layer_norm in the env's section (type 1)
 def test_g8r_ddqn_on_a_reward_env(golden, name):
     """default_config_cartpole_reward_env.yaml's experiment (synthetic_env_type 1): DDQN trains on a RewardEnv over the real
     CartPole -- real transitions, reward through the reward network (type 2 with a PReLU net / type 6 with tanh)."""
@@ -307,7 +309,7 @@ def test_g8r_ddqn_on_a_reward_env(golden, name):
     g = golden(name)
     cfgd = json.loads(str(g["config_json"]))
     cfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=1, train_episodes=int(g["train_episodes"]), max_steps=int(g["max_steps"]))
-    assert cfg.synthetic_env_type == 1 and cfg.reward_env_type in (2, 6)
+    assert cfg.synthetic_env_type == 1 and cfg.reward_env_type in (1, 2, 6)
     tapes = orc.make_tapes(g["tape_eps_uniform"], g["tape_rand_action"], g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"])
     n = g["tr_action"].size
     out = orc.ddqn_se_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 10)
