@@ -58,7 +58,7 @@ class EnvWrapper(nn.Module):
         actions int32 [chains], states fp32 [chains,S] (device).  Returns device tensors."""
         if not self.is_virtual_env():
             raise NotImplementedError("step_population is defined for virtual envs")
-        return engine.se_step_population(self.env.descs(), self.env.flat_params(), eps, worker, sign, states, actions)
+        return engine.se_step_population(self.env.descs(), self.env.step_params(), self.env.step_eps(eps), worker, sign, states, actions)
 
     def reset(self):
         """CPU fp32 state of a fresh episode; a virtual env over a discrete observation space hands back the index."""

@@ -123,8 +123,11 @@ class RewardEnv(nn.Module):
         s2 = torch.from_numpy(np.asarray(next_state, np.float32).reshape(1, -1)).to(dev)
         inf = torch.tensor([list(info.values())], dtype=torch.float32, device=dev) if info else None
         desc = mlp_desc(self.reward_net, self.activation_fn) if t < 100 else None
-        out = engine.rn_shape_rows(t, desc, self.state_dim, self.info_dim if inf is not None else 0, self.gamma, self.flat_params(),
-                                   s, s2, inf, r32)
+        theta = self.flat_params()
+        if desc is not None and desc.use_layer_norm:          # the LayerNorm block is not part of theta: lenv_mlp_desc layout for the one-step entry
+            from ..models.model_utils import mlp_params
+            theta = torch.cat([p.detach().reshape(-1).to(theta.device, torch.float32) for p in mlp_params(self.reward_net)])
+        out = engine.rn_shape_rows(t, desc, self.state_dim, self.info_dim if inf is not None else 0, self.gamma, theta, s, s2, inf, r32)
         return out.item()
 
     def seed(self, seed):

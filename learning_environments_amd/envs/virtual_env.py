@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import engine
-from ..models.model_utils import FlatParams, build_nn_from_config, mlp_desc
+from ..models.model_utils import FlatParams, build_nn_from_config, linear_params, mlp_desc, mlp_params
 from ..utils import from_one_hot_encoding, to_one_hot_encoding
 
 
@@ -40,6 +40,31 @@ class VirtualEnv(nn.Module):
             self.to(dev)
             self._flat = FlatParams(self, dev)
         return self._flat.flat
+
+    def step_params(self):
+        """What lenv_se_step_population reads: theta itself, or -- `use_layer_norm` nets -- a copy with each net's LayerNorm weight | bias
+        behind its second Linear (lenv_mlp_desc layout; the module is not part of theta: NES never touches it)."""
+        flat = self.flat_params()
+        nets = (self.state_net, self.reward_net, self.done_net)
+        if not any(isinstance(m, torch.nn.LayerNorm) for net in nets for m in net):
+            return flat
+        return torch.cat([p.detach().reshape(-1).to(flat.device, torch.float32) for net in nets for p in mlp_params(net)])
+
+    def step_eps(self, eps):
+        """eps rows [pop, P_theta] in the layout of step_params(): zero columns where the (never perturbed) LayerNorm blocks sit."""
+        nets = (self.state_net, self.reward_net, self.done_net)
+        if eps is None or not any(isinstance(m, torch.nn.LayerNorm) for net in nets for m in net):
+            return eps
+        cols, off = [], 0
+        lin = set(id(p) for p in linear_params(self))
+        for net in nets:
+            for p in mlp_params(net):
+                if id(p) in lin:
+                    cols.append(torch.arange(off, off + p.numel(), device=eps.device))
+                off += p.numel()
+        wide = torch.zeros((eps.shape[0], off), dtype=eps.dtype, device=eps.device)
+        wide[:, torch.cat(cols)] = eps
+        return wide
 
     def descs(self):
         return (mlp_desc(self.state_net, self.activation_fn), mlp_desc(self.reward_net, self.activation_fn),
@@ -83,7 +108,7 @@ class VirtualEnv(nn.Module):
         a_idx = torch.argmax(action.reshape(-1, self.action_dim), dim=1).to(torch.int32).to(dev)
         s2 = s.reshape(-1, self.state_dim).to(dev, torch.float32).contiguous()
         n = s2.shape[0]
-        ns, r, d = engine.se_step_population(self.descs(), self.flat_params(), None, None, None,
+        ns, r, d = engine.se_step_population(self.descs(), self.step_params(), None, None, None,
                                              s2.unsqueeze(0), a_idx.reshape(1, n).contiguous())
         ns, r, d = ns[0], r[0].unsqueeze(-1), d[0].unsqueeze(-1)
         if not batched:

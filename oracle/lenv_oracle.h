@@ -289,7 +289,7 @@ int orc_td3_learn(const orc_td3_cfg *cfg, float *params, float *targets, float *
 int64_t orc_rn_num_params(int type, int S, int info_dim, int hidden, int layers);
 /* RewardEnv._calc_reward (reward_env.py:68-133) for n rows of a vector-state env: s,s2 [n,S], info [n,info_dim], r [n]
  * (the real reward already rounded to fp32); fp32, left to right.  Returns -1 for unknown types. */
-int orc_rn_shape_rows(int type, int S, int info_dim, int hidden, int layers, int act, float prelu, double gamma,
+int orc_rn_shape_rows(int type, int S, int info_dim, int hidden, int layers, int use_layer_norm, int act, float prelu, double gamma,
                       const float *rn_params, const float *s, const float *s2, const float *info, const float *r, int64_t n,
                       float *out);
 int orc_td3_rn_chain(const orc_td3_cfg *cfg, const float *rn_params, const float *agent_init /*[actor|critic1|critic2]*/,

@@ -800,14 +800,15 @@ def rn_num_params(rtype, S, info_dim, hidden, layers):
     return int(lib().orc_rn_num_params(int(rtype), int(S), int(info_dim), int(hidden), int(layers)))
 
 
-def rn_shape_rows(rtype, S, info_dim, hidden, layers, act, prelu, gamma, rn_params, s, s2, info, r):
+def rn_shape_rows(rtype, S, info_dim, hidden, layers, act, prelu, gamma, rn_params, s, s2, info, r, use_layer_norm=False):
     """RewardEnv._calc_reward (reward_env.py:68-133) for rows of a vector-state env; all 11 reward types."""
     s, s2, r = _f32(s).reshape(-1, S), _f32(s2).reshape(-1, S), _f32(r).reshape(-1)
     n = s.shape[0]
     info = _f32(info).reshape(n, info_dim) if info is not None and info_dim > 0 else None
     rn_params = _f32(rn_params if rn_params is not None and len(rn_params) else np.zeros(1, np.float32))
     out = np.zeros(n, np.float32)
-    rc = lib().orc_rn_shape_rows(int(rtype), int(S), int(info_dim), int(hidden), int(layers), int(ACT[act]) if isinstance(act, str) else int(act),
+    rc = lib().orc_rn_shape_rows(int(rtype), int(S), int(info_dim), int(hidden), int(layers), 1 if use_layer_norm else 0,
+                                 int(ACT[act]) if isinstance(act, str) else int(act),
                                  C.c_float(prelu), C.c_double(gamma), _p(rn_params, C.c_float), _p(s, C.c_float), _p(s2, C.c_float),
                                  _p(info, C.c_float) if info is not None else None, _p(r, C.c_float), C.c_int64(n), _p(out, C.c_float))
     if rc != 0:

@@ -1785,6 +1785,18 @@ def test_rn_shape_rows_vs_oracle(eng, orc, rtype):
     if rtype in (3, 4, 7, 8, 101, 102):
         with pytest.raises(ValueError):                       # reward_env.py:96: 'No info dict provided by environment'
             eng.rn_shape_rows(rtype, desc, S, 0, 0.98, dev(theta), dev(s), dev(s2), None, dev(r))
+    if 1 <= rtype <= 8:
+        # deeper reward nets (default_config_pendulum_reward_env.yaml ships hidden_layer 2) and `use_layer_norm` nets: the LayerNorm's
+        # weight | bias sit behind the second Linear (lenv_mlp_desc layout)
+        D = S + nI if rtype in (3, 4, 7, 8) else S
+        for layers, ln, act in ((2, False, "relu"), (3, False, "leakyrelu"), (2, True, "tanh"), (4, True, "prelu")):
+            d_h, d_o = eng.mlp_desc(D, H, layers, 1, act, 0.25, use_layer_norm=ln), orc.mlp_desc(D, H, layers, 1, act, 0.25, use_layer_norm=ln)
+            Pl = orc.mlp_num_params(d_o)
+            assert Pl == D * H + H + (layers - 1) * (H * H + H) + H + 1 + (2 * H if ln else 0) == eng.mlp_num_params(d_h)
+            th = (rng.randn(Pl) * 0.25).astype(np.float32)
+            got = eng.rn_shape_rows(rtype, d_h, S, nI, 0.98, dev(th), dev(s), dev(s2), dev(info), dev(r)).cpu().numpy()
+            want = orc.rn_shape_rows(rtype, S, nI, H, layers, act, 0.25, 0.98, th, s, s2, info, r, use_layer_norm=ln)
+            assert np.array_equal(got, want), (rtype, layers, ln)
 
 
 def test_rn_unknown_type_raises(eng):
