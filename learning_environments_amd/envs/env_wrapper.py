@@ -58,6 +58,8 @@ class EnvWrapper(nn.Module):
         actions int32 [chains], states fp32 [chains,S] (device).  Returns device tensors."""
         if not self.is_virtual_env():
             raise NotImplementedError("step_population is defined for virtual envs")
+        if not self.has_discrete_action_space():
+            raise NotImplementedError("step_population takes action indices: virtual envs over a discrete action space")
         return engine.se_step_population(self.env.descs(), self.env.step_params(), self.env.step_eps(eps), worker, sign, states, actions)
 
     def reset(self):

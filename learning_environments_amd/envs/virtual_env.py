@@ -105,12 +105,26 @@ class VirtualEnv(nn.Module):
         s = self.state if state is None else state
         dev = engine.require_device()
         batched = action.dim() > 1
-        a_idx = torch.argmax(action.reshape(-1, self.action_dim), dim=1).to(torch.int32).to(dev)
         s2 = s.reshape(-1, self.state_dim).to(dev, torch.float32).contiguous()
         n = s2.shape[0]
-        ns, r, d = engine.se_step_population(self.descs(), self.step_params(), None, None, None,
-                                             s2.unsqueeze(0), a_idx.reshape(1, n).contiguous())
-        ns, r, d = ns[0], r[0].unsqueeze(-1), d[0].unsqueeze(-1)
+        def forward_path(act_rows):
+            # three lenv_mlp_forward launches on cat(action, state) (virtual_env.py:43-54); weights read from HBM: any width / depth
+            x = torch.cat([act_rows.reshape(-1, self.action_dim).to(dev, torch.float32), s2], dim=1).contiguous()
+            self.flat_params()
+            return [engine.mlp_forward(dsc, torch.cat([p.detach().reshape(-1) for p in mlp_params(net)]), x)
+                    for net, dsc in zip((self.state_net, self.reward_net, self.done_net), self.descs())]
+
+        if not hasattr(self.action_space, "n"):
+            # a continuous action space (HalfCheetah / Pendulum / MountainCarContinuous SEs): the action vector goes in as it comes
+            ns, r, d = forward_path(action)
+        else:
+            a_idx = torch.argmax(action.reshape(-1, self.action_dim), dim=1).to(torch.int32).to(dev)
+            try:
+                ns, r, d = engine.se_step_population(self.descs(), self.step_params(), None, None, None,
+                                                     s2.unsqueeze(0), a_idx.reshape(1, n).contiguous())
+                ns, r, d = ns[0], r[0].unsqueeze(-1), d[0].unsqueeze(-1)
+            except NotImplementedError:                    # an SE whose parameters exceed the one-launch kernel's LDS
+                ns, r, d = forward_path(action)
         if not batched:
             ns, r, d = ns[0], r[0], d[0]
         self.state = ns

@@ -53,6 +53,46 @@ def test_envwrapper_step_virtual_env_matches_reference(golden):
     assert tuple(s0.shape) == (4,) and float(s0.abs().max()) <= 0.05
 
 
+def _load_linear_theta(envw, flat):
+    """theta (nn.Linear parameters only, state-dict order) into the mirror's modules; PReLU slopes and LayerNorm affines stay."""
+    sd = envw.state_dict()
+    off, new = 0, {}
+    for k, v in sd.items():
+        if k.endswith("weight") and v.dim() == 2:
+            new[k] = torch.from_numpy(flat[off:off + v.numel()].reshape(tuple(v.shape)).copy()); off += v.numel()
+            b = k[:-6] + "bias"
+            new[b] = torch.from_numpy(flat[off:off + sd[b].numel()].copy()); off += sd[b].numel()
+    for k, v in sd.items():
+        new.setdefault(k, v)
+    assert off == flat.size
+    envw.load_state_dict(new)
+
+
+@pytest.mark.parametrize("name", ["g8ts_calc_score_cheetah_td3_virtual_env", "g8p_calc_score_pendulum_td3_virtual_env",
+                                  "g8tseln_calc_score_cheetah_td3_virtual_env_layernorm"])
+def test_envwrapper_step_continuous_action_virtual_env_matches_reference(golden, name):
+    """EnvWrapper.step -> VirtualEnv.step of an SE over a CONTINUOUS action space (virtual_env.py:43-54: input = cat(action, state), the
+    action vector as it comes): every SE transition of the reference's TD3 runs (HalfCheetah stand-in 23-20-20-x, Pendulum 4-20-20-x, and
+    the HalfCheetah SE with `use_layer_norm`) replayed through the host mirror."""
+    from learning_environments_amd.envs.env_factory import EnvFactory
+    g = golden(name)
+    cfg = json.loads(str(g["config_json"]))
+    cfg["device"] = "cuda"
+    venv = EnvFactory(cfg).generate_virtual_env()
+    assert not venv.has_discrete_action_space()
+    _load_linear_theta(venv, g["theta"])
+    n = min(40, g["tr_reward"].size)
+    for k in range(n):
+        ns, r, d = venv.step(torch.from_numpy(g["tr_action"][k].copy()), state=torch.from_numpy(g["tr_state"][k].copy()))
+        assert tuple(ns.shape) == g["tr_next_state"][k].shape and ns.device.type == "cpu"
+        np.testing.assert_allclose(ns.numpy(), g["tr_next_state"][k], rtol=0, atol=3e-6)
+        assert abs(float(r) - float(g["tr_reward"][k])) <= 3e-6
+    # rows at once
+    ns, r, d = venv.env.step(torch.from_numpy(g["tr_action"][:n].copy()), state=torch.from_numpy(g["tr_state"][:n].copy()))
+    np.testing.assert_allclose(ns.cpu().numpy(), g["tr_next_state"][:n], rtol=0, atol=3e-6)
+    assert tuple(r.shape) == (n, 1) and tuple(d.shape) == (n, 1)
+
+
 def test_host_mirrors_with_layer_norm_env_nets():
     """`use_layer_norm: True` in the env's section with two hidden layers: the one-step entries behind VirtualEnv.step,
     EnvWrapper.step_population and RewardEnv.step read the LayerNorm's weight | bias behind each net's second Linear (lenv_mlp_desc layout)
