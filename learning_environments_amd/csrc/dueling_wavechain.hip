@@ -133,17 +133,23 @@ __device__ __forceinline__ float *wc_dump(float *dumps, int which, int blk) { re
 
 #ifdef LENV_PHASE_TIMING
 __device__ unsigned long long g_wc_phase_cycles[64];      // [0,16): kernel phases; [16,64): sub-phases inside the out-of-line routines (chain 0)
-#define WSUB_DECL unsigned long long sp_last = __builtin_readcyclecounter()
+#define WSUB_DECL unsigned long long sp_last = __builtin_readcyclecounter(), sp8_last = sp_last
 #define WSUB_MARK(i) do { unsigned long long sp_now = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) g_wc_phase_cycles[i] += sp_now - sp_last; sp_last = sp_now; } while (0)
 #define WSUB_MARK4(i) do { unsigned long long sp_now = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 256) g_wc_phase_cycles[i] += sp_now - sp_last; sp_last = sp_now; } while (0)
+#define WSUB_MARK8(i) do { unsigned long long sp_now = __builtin_readcyclecounter(); if (blockIdx.x == 8 && threadIdx.x == 0) g_wc_phase_cycles[i] += sp_now - sp8_last; sp8_last = sp_now; } while (0)   /* member 1 of chain 0 at G = 2 */
 #define WPT_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define WPT_MARK(i) do { unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
+// a team barrier of the learn step with its waiting time: slot i for member 0 of chain 0 (block 0), i - 48 for member 1 (block 8)
+#define WBAR(i) do { const unsigned long long b0_ = __builtin_readcyclecounter(); team_barrier(); const unsigned long long b1_ = __builtin_readcyclecounter(); \
+                     if (threadIdx.x == 0 && blockIdx.x == 0) g_wc_phase_cycles[i] += b1_ - b0_; if (threadIdx.x == 0 && blockIdx.x == 8) g_wc_phase_cycles[(i) - 48] += b1_ - b0_; } while (0)
 #else
+#define WBAR(i) team_barrier()
 #define WPT_DECL
 #define WPT_MARK(i)
 #define WSUB_DECL
 #define WSUB_MARK(i)
 #define WSUB_MARK4(i)
+#define WSUB_MARK8(i)
 #endif
 
 
@@ -1005,6 +1011,7 @@ template <int SHAPE> __device__ __noinline__ void wct_wgrad_layer(const WcCtx *c
     if (tid < W) grad[ob + tid] = image_colsum(bufB, tid, B);
     __syncthreads();
     WSUB_MARK(59);
+    WSUB_MARK8(18);                                        // (member 1: the whole routine)
 }
 
 // head output layer (gWh, gbh) from the row-major copies of v1 / a1 -- member 0; layer 1 (gW1t, gb1) from the S_DH1 dumps -- member 1
@@ -1012,18 +1019,21 @@ template <int SHAPE> __device__ __noinline__ void wct_wgrad_ends(const WcCtx *ct
 {
     WCT_PROLOGUE;
     const int which = uni(which_);
+    WSUB_DECL;
     if (which == 0) {
         constexpr bool PL = SP.kind == 0;                // plain DQN: the output layer sits in the advantage columns, no value column
         const int k = tid & 127, col = tid >> 7;
         if (col <= A && !(PL && col == 0)) {
             const gfloat *rm = (const gfloat *)dump_of(col == 0 ? R_V1 : R_A1, 0) + k;
             float s_ = 0.0f;
-            for (int i0 = 0; i0 < B; i0 += 64) {
-                float hv[64];
+            {   // the whole column in flight at once: one memory round trip (two batches of 64 measured 26 k cycles for this routine)
+                float hv[B];
 #pragma unroll
-                for (int u = 0; u < 64; ++u) hv[u] = rm[(i0 + u) * W];
+                for (int u = 0; u < B; ++u) hv[u] = rm[u * W];
+                const lfloat *up = col == 0 ? dq_l : dAdv_l + (col - 1);
+                const int ups = col == 0 ? 1 : A;
 #pragma unroll
-                for (int u = 0; u < 64; ++u) s_ = fma32(col == 0 ? dq_l[i0 + u] : dAdv_l[(i0 + u) * A + col - 1], hv[u], s_);
+                for (int u = 0; u < B; ++u) s_ = fma32(up[u * ups], hv[u], s_);
             }
             grad[oWh + k * 4 + col] = s_;
         }
@@ -1034,6 +1044,7 @@ template <int SHAPE> __device__ __noinline__ void wct_wgrad_ends(const WcCtx *ct
             grad[obh + col2] = s_;
         }
         __syncthreads();
+        WSUB_MARK(16);
         return;
     }
     float r[64];
@@ -1060,6 +1071,7 @@ template <int SHAPE> __device__ __noinline__ void wct_wgrad_ends(const WcCtx *ct
         if (tid >= 384) grad[ob1 + j] = image_colsum(bufB, j, B);
     }
     __syncthreads();
+    WSUB_MARK8(17);
 }
 
 template <int SHAPE>
@@ -1358,7 +1370,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                 if (G == 2) {
 #pragma unroll 1
                     for (int pass = 0; pass < 2; ++pass) wct_forward<SHAPE>(ctx, pass);
-                    team_barrier();                        // every row's V / Adv is in the exchange arrays
+                    WBAR(60);                              // every row's V / Adv is in the exchange arrays
                     for (int e = tid; e < 3 * B; e += NT) Vb[(e / B) * RBH + (e % B)] = gva[e];
                     for (int e = tid; e < 3 * B * A; e += NT) Advb[(e / (B * A)) * RBH * A + (e % (B * A))] = gva[3 * B + e];
                     __syncthreads();
@@ -1406,7 +1418,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
 #ifndef WC_DIAG_NO_BWD
                 if (G == 2) {
                     wct_backward_chain<SHAPE>(ctx);
-                    team_barrier();                        // all four blocks' gradient dumps are there
+                    WBAR(61);                              // all four blocks' gradient dumps are there
                     if constexpr (PL) {                    // plain DQN: the output layer and layer 1 | W2
                         if (g == 0) { wct_wgrad_ends<SHAPE>(ctx, 0); wct_wgrad_ends<SHAPE>(ctx, 1); }
                         else wct_wgrad_layer<SHAPE>(ctx, 3);
@@ -1414,7 +1426,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                         if (g == 0) { wct_wgrad_ends<SHAPE>(ctx, 0); wct_wgrad_layer<SHAPE>(ctx, 0); wct_wgrad_layer<SHAPE>(ctx, 1); }
                         else { wct_wgrad_layer<SHAPE>(ctx, 2); wct_wgrad_layer<SHAPE>(ctx, 3); wct_wgrad_ends<SHAPE>(ctx, 1); }
                     }
-                    team_barrier();
+                    WBAR(62);
                     {   // torch.optim.Adam + Polyak, half of the parameter vector per member (ctrl[10], ctrl[11]: this step's bias corrections)
                         const AdamConsts ac{ ctrl[10], ctrl[11], (float)(1.0 - cfg.adam_beta1), (float)(1.0 - cfg.adam_beta2), (float)cfg.adam_beta2,
                                              (float)cfg.adam_eps };
@@ -1431,7 +1443,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                         wg_adam_t(online, adam_m, adam_v, grad, lo, n, ac, target, (float)cfg.tau, (float)(1.0 - cfg.tau), tid, NT);
                         }
                     }
-                    team_barrier();
+                    WBAR(63);
                 } else wc_backward_big<SHAPE>(ctx);
 #endif
                 WPT_MARK(6);

@@ -52,12 +52,15 @@ for i, n in enumerate(names):
         per = "  %8.0f per env step" % (buf[i] / max(1, st[1]))
     print("%-22s %12d cycles  %5.1f%%%s" % (n, buf[i], 100.0 * buf[i] / max(1, tot), per))
 
-sub = {16: "bwd (a) dz + W^T image", 17: "bwd (b) input-grad chain | colsum/head grads", 18: "bwd (c) input image", 19: "bwd (d) weight-grad tiles",
+sub = {16: "bwd (a) dz + W^T image | team: head output-layer grads (member 0)", 17: "bwd (b) input-grad chain | colsum/head grads | team: layer-1 grads (member 1)", 18: "bwd (c) input image | team: the two feature-layer gradient routines (member 1)", 19: "bwd (d) weight-grad tiles",
        22: "bwd head output-layer weight grads", 20: "bwd layer 1", 21: "bwd adam tail (layers 1, 2, heads)", 24: "thin L1", 25: "thin L2", 26: "thin L3", 27: "thin L4 (v1 | a1)", 28: "thin heads", 32: "fwd smalls + W2 image",
        40: "  (b) wave 0: chain", 41: "  (b) wave 0: epilogue", 44: "  (b) wave 4: colsum", 45: "  (b) wave 4: head grads", 46: "  (b) wave 4: adam, half of layer q-1", 33: "fwd L1+L2", 34: "fwd L3", 35: "fwd L4v + V", 36: "fwd L4a + Adv"}
 sub.update({48: "team fwd: smalls + W2 image", 49: "team fwd: L1 + exchange", 50: "team fwd: layer tiles (4 layers)", 51: "team fwd: exchange / staging / heads",
             52: "team fwd: final barrier", 53: "team bwd chain: first image load", 54: "team bwd chain: dz + image store + barrier", 55: "team bwd chain: chain + epilogue",
-            56: "team bwd chain: final barrier", 57: "team wgrad layer: images", 58: "team wgrad layer: tiles", 59: "team wgrad layer: colsum + barrier"})
+            56: "team bwd chain: final barrier", 57: "team wgrad layer: images", 58: "team wgrad layer: tiles", 59: "team wgrad layer: colsum + barrier",
+            60: "team barrier behind the forward, member 0 waits", 61: "team barrier behind the chain, member 0 waits", 62: "team barrier behind the weight gradients, member 0 waits",
+            63: "team barrier behind Adam, member 0 waits", 12: "  ... member 1 waits (forward)", 13: "  ... member 1 waits (chain)", 14: "  ... member 1 waits (weight gradients)",
+            15: "  ... member 1 waits (Adam)"})
 nthin = st[3] / 10.0 + buf[0] * 0  # lock-step test forwards; greedy forwards are counted on top
 for i, n in sub.items():
     div = 2 * st[2] if i < 24 or i >= 32 else 1      # the sub-phase counters accumulate over both generations
