@@ -15,6 +15,11 @@
 // Arena layout of a parameter vector (online, target, Adam m / v, grad all alike; every 128x128 matrix K-MAJOR, Wt[k][unit]):
 //   W1t[8][128] (rows >= S are zero) b1 | W2t b2 | W3t b3 | Wv1t bv1 | Wa1t ba1 | Wh[128][4] = (wv2, wa2_0..2)[k] | bh[4]
 #include "lenv_wavechain.cuh"
+// Team launches of the DuelingDDQN shapes run torch's Adam + the Polyak update as the epilogue of the weight-gradient routines (round 4:
+// -1.6 % at the configs[2] shard); -DWCT_NO_FUSED_OPT keeps the separate optimizer pass for A/B timing.  The plain-DQN shape keeps the pass.
+#ifndef WCT_NO_FUSED_OPT
+#define WCT_FUSED_OPT
+#endif
 #include "lenv_wavechain_host.h"
 
 namespace lenv {
@@ -154,7 +159,7 @@ __device__ unsigned long long g_wc_phase_cycles[64];      // [0,16): kernel phas
 
 
 // ---- thin forward: I <= 32 rows X[I][S] through the ONLINE net, head outputs to slot 0, q to qv (per-row advantage mean) ----
-template <int SHAPE> __device__ __noinline__ void wc_forward_thin_layers(const WcCtx *ctx_, const float *X_, int I_)
+template <int SHAPE> static __device__ __noinline__ void wc_forward_thin_layers(const WcCtx *ctx_, const float *X_, int I_)
 {
     using namespace wcp;
     constexpr WcShape SP = kWcShapes[SHAPE];
@@ -257,7 +262,7 @@ template <int SHAPE> __device__ __noinline__ void wc_forward_thin_layers(const W
 // real environment.  Reset draws, returns and the step count included: the call site in the kernel body stays straight-line code (a
 // live-range split copy that the register allocator placed in the divergent reset block in front of the call -- before the block's
 // exec restore -- lost the kernel's zero register in the inactive lanes: rocgdb, first Adam pass after the first test phase).
-template <int SHAPE> __device__ __noinline__ void wc_test_steps(const WcCtx *ctx_, uint32_t key_lo_, uint32_t key_hi_, int first_episode_)
+template <int SHAPE> static __device__ __noinline__ void wc_test_steps(const WcCtx *ctx_, uint32_t key_lo_, uint32_t key_hi_, int first_episode_)
 {
     using namespace wcp;
     constexpr WcShape SP = kWcShapes[SHAPE];
@@ -382,7 +387,7 @@ template <int SHAPE> __device__ __noinline__ void wc_test_steps(const WcCtx *ctx
 
 // ---- one pass of Critic_DuelingDQN over sample blocks: pass 0 = target net on s' (waves 0-3 -> slot 2), pass 1 = online net on
 // s (waves 0-3 -> slot 0, activations dumped for the backward pass) and on s' (waves 4-7 -> slot 1) ----
-template <int SHAPE> __device__ __noinline__ void wc_forward_big(const WcCtx *ctx_, int pass_)
+template <int SHAPE> static __device__ __noinline__ void wc_forward_big(const WcCtx *ctx_, int pass_)
 {
     using namespace wcp;
     constexpr WcShape SP = kWcShapes[SHAPE];
@@ -493,7 +498,7 @@ template <int SHAPE> __device__ __noinline__ void wc_forward_big(const WcCtx *ct
 }
 
 // ---- backward pass of the TD loss through the online net on the s blocks (waves 0-3 own the sample blocks) ----
-template <int SHAPE> __device__ __noinline__ void wc_backward_big(const WcCtx *ctx_)
+template <int SHAPE> static __device__ __noinline__ void wc_backward_big(const WcCtx *ctx_)
 {
     using namespace wcp;
     constexpr WcShape SP = kWcShapes[SHAPE];
@@ -741,7 +746,7 @@ __device__ __forceinline__ void piece_load(const float *dump, int jt, int lane, 
 // ---- team forward: pass 0 = target net on s' (slot 2), pass 1 = online net on s (slot 0, activations dumped) and on s' (slot 1):
 // the two inputs of pass 1 share every staged image (two jobs per wave).  The head outputs of this member's rows go to LDS and to
 // the team's exchange arrays ----
-template <int SHAPE> __device__ __noinline__ void wct_forward(const WcCtx *ctx_, int pass_)
+template <int SHAPE> static __device__ __noinline__ void wct_forward(const WcCtx *ctx_, int pass_)
 {
     WCT_PROLOGUE;
     const int pass = uni(pass_);
@@ -883,7 +888,7 @@ template <int SHAPE> __device__ __noinline__ void wct_forward(const WcCtx *ctx_,
 
 // ---- team backward, per-sample half: the input-gradient chain of this member's blocks through Wv1, Wa1 (-> d_feat), W3 (-> d_h2), W2
 // (-> d_h1); the gradients go to the register-order dumps S_DFEAT / S_DH2 / S_DH1 the weight-gradient phase reads ----
-template <int SHAPE> __device__ __noinline__ void wct_backward_chain(const WcCtx *ctx_)
+template <int SHAPE> static __device__ __noinline__ void wct_backward_chain(const WcCtx *ctx_)
 {
     WCT_PROLOGUE;
     const int quad = wave >> 2, jt = wave & 3, blk = 2 * tg + quad, row = 32 * blk + L.li;
@@ -960,7 +965,7 @@ template <int SHAPE> __device__ __noinline__ void wct_backward_chain(const WcCtx
 
 // ---- team backward, per-parameter half for layer q (0 Wv1, 1 Wa1, 2 W3, 3 W2): the [sample][unit] images of the upstream gradient
 // (bufB, waves 0-3) and of the layer input (bufA, waves 4-7) of ALL four blocks from the dumps, the 16 gradient tiles, the bias ----
-template <int SHAPE> __device__ __noinline__ void wct_wgrad_layer(const WcCtx *ctx_, int q_)
+template <int SHAPE> static __device__ __noinline__ void wct_wgrad_layer(const WcCtx *ctx_, int q_)
 {
     WCT_PROLOGUE;
     const int q = uni(q_);
@@ -1006,6 +1011,35 @@ template <int SHAPE> __device__ __noinline__ void wct_wgrad_layer(const WcCtx *c
     __syncthreads();
     WSUB_MARK(57);
     L.refresh();
+#ifdef WCT_FUSED_OPT
+    if constexpr (SP.kind != 0) {
+        // the optimizer step as the epilogue of the gradient tiles (t3v_tile_adam: the TD3 team path's routine): the two tiles' parameter /
+        // target / Adam state is requested in front of the 128 matrix instructions, the accumulators go through a 4 KB LDS tile per wave
+        // (the images are free by then) so that every arena access is 16 bytes per lane; no gradient round trip, no separate optimizer pass
+        volatile lfloat *ctrl = (volatile lfloat *)uni_ptr(c->ctrl);
+        const AdamConsts ac{ ctrl[10], ctrl[11], unif(c->w1), unif(c->w2), unif(c->beta2), unif(c->adam_eps) };
+        const float tau = unif(c->tau), omt = unif(c->omt);
+        const int kt = wave >> 1, jt0 = (wave & 1) << 1;
+        const int off0 = oWt + (32 * kt) * W + 32 * jt0, off1 = off0 + 32;
+        T3vTileState st0, st1;
+        t3v_tile_state(L, online + off0, adam_m + off0, adam_v + off0, target + off0, 32, st0);
+        t3v_tile_state(L, online + off1, adam_m + off1, adam_v + off1, target + off1, 32, st1);
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { acc0[v] = 0.0f; acc1[v] = 0.0f; }
+        wgrad_accum(bufA, bufB, B, L, acc0, acc1);
+        WSUB_MARK(58);
+        const float sb = tid < W ? image_colsum(bufB, tid, B) : 0.0f;
+        __syncthreads();                                   // every wave is through with the images: their room is the tiles' scratch
+        t3v_tile_adam(acc0, st0, bufA + wave * 1024, nullptr, L, online + off0, adam_m + off0, adam_v + off0, target + off0, 32, nullptr, ac, tau, omt);
+        t3v_tile_adam(acc1, st1, bufA + wave * 1024, nullptr, L, online + off1, adam_m + off1, adam_v + off1, target + off1, 32, nullptr, ac, tau, omt);
+        if (tid < W) t3v_adam1(sb, online, adam_m, adam_v, target, ob + tid, ac, tau, omt);
+        __syncthreads();
+        WSUB_MARK(59);
+        WSUB_MARK8(18);
+        return;
+    }
+#endif
     wgrad_tiles(bufA, bufB, B, L, grad + oWt);
     WSUB_MARK(58);
     if (tid < W) grad[ob + tid] = image_colsum(bufB, tid, B);
@@ -1015,11 +1049,20 @@ template <int SHAPE> __device__ __noinline__ void wct_wgrad_layer(const WcCtx *c
 }
 
 // head output layer (gWh, gbh) from the row-major copies of v1 / a1 -- member 0; layer 1 (gW1t, gb1) from the S_DH1 dumps -- member 1
-template <int SHAPE> __device__ __noinline__ void wct_wgrad_ends(const WcCtx *ctx_, int which_)
+template <int SHAPE> static __device__ __noinline__ void wct_wgrad_ends(const WcCtx *ctx_, int which_)
 {
     WCT_PROLOGUE;
     const int which = uni(which_);
     WSUB_DECL;
+#ifdef WCT_FUSED_OPT
+    volatile lfloat *ctrl = (volatile lfloat *)uni_ptr(c->ctrl);
+    const AdamConsts ac{ ctrl[10], ctrl[11], unif(c->w1), unif(c->w2), unif(c->beta2), unif(c->adam_eps) };
+    const float tau = unif(c->tau), omt = unif(c->omt);
+    constexpr bool FUSED = SP.kind != 0;
+#define WCT_GRAD_OUT(off, val) do { if (FUSED) t3v_adam1((val), online, adam_m, adam_v, target, (off), ac, tau, omt); else grad[(off)] = (val); } while (0)
+#else
+#define WCT_GRAD_OUT(off, val) grad[(off)] = (val)
+#endif
     if (which == 0) {
         constexpr bool PL = SP.kind == 0;                // plain DQN: the output layer sits in the advantage columns, no value column
         const int k = tid & 127, col = tid >> 7;
@@ -1035,13 +1078,13 @@ template <int SHAPE> __device__ __noinline__ void wct_wgrad_ends(const WcCtx *ct
 #pragma unroll
                 for (int u = 0; u < B; ++u) s_ = fma32(up[u * ups], hv[u], s_);
             }
-            grad[oWh + k * 4 + col] = s_;
+            WCT_GRAD_OUT(oWh + k * 4 + col, s_);
         }
         if (tid >= 256 && tid < 256 + 1 + A && !(PL && tid == 256)) {
             const int col2 = tid - 256;
             float s_ = 0.0f;
             for (int i = 0; i < B; ++i) s_ = s_ + (col2 == 0 ? dq_l[i] : dAdv_l[i * A + col2 - 1]);
-            grad[obh + col2] = s_;
+            WCT_GRAD_OUT(obh + col2, s_);
         }
         __syncthreads();
         WSUB_MARK(16);
@@ -1066,9 +1109,9 @@ template <int SHAPE> __device__ __noinline__ void wct_wgrad_ends(const WcCtx *ct
 #pragma unroll
                 for (int u = 0; u < 8; ++u) s_ = fma32(dv[u], qv_l[(i0 + u) * S + k], s_);
             }
-            grad[oW1t + k * W + j] = s_;
+            WCT_GRAD_OUT(oW1t + k * W + j, s_);
         }
-        if (tid >= 384) grad[ob1 + j] = image_colsum(bufB, j, B);
+        if (tid >= 384) { const float sb_ = image_colsum(bufB, j, B); WCT_GRAD_OUT(ob1 + j, sb_); }
     }
     __syncthreads();
     WSUB_MARK8(17);
@@ -1423,9 +1466,20 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                         if (g == 0) { wct_wgrad_ends<SHAPE>(ctx, 0); wct_wgrad_ends<SHAPE>(ctx, 1); }
                         else wct_wgrad_layer<SHAPE>(ctx, 3);
                     } else {
+#ifdef WCT_FUSED_OPT
+                        // (the optimizer step rides on the gradient routines: the head output layer LAST -- the stream layers' upstream
+                        // gradients read its weights as they were)
+                        if (g == 0) { wct_wgrad_layer<SHAPE>(ctx, 0); wct_wgrad_layer<SHAPE>(ctx, 1); wct_wgrad_ends<SHAPE>(ctx, 0); }
+                        else { wct_wgrad_layer<SHAPE>(ctx, 2); wct_wgrad_layer<SHAPE>(ctx, 3); wct_wgrad_ends<SHAPE>(ctx, 1); }
+#else
                         if (g == 0) { wct_wgrad_ends<SHAPE>(ctx, 0); wct_wgrad_layer<SHAPE>(ctx, 0); wct_wgrad_layer<SHAPE>(ctx, 1); }
                         else { wct_wgrad_layer<SHAPE>(ctx, 2); wct_wgrad_layer<SHAPE>(ctx, 3); wct_wgrad_ends<SHAPE>(ctx, 1); }
+#endif
                     }
+#ifdef WCT_FUSED_OPT
+                    if constexpr (PL)
+#endif
+                    {
                     WBAR(62);
                     {   // torch.optim.Adam + Polyak, half of the parameter vector per member (ctrl[10], ctrl[11]: this step's bias corrections)
                         const AdamConsts ac{ ctrl[10], ctrl[11], (float)(1.0 - cfg.adam_beta1), (float)(1.0 - cfg.adam_beta2), (float)cfg.adam_beta2,
@@ -1442,6 +1496,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                         const int lo = g == 0 ? 0 : half, n = g == 0 ? half : PW - half;
                         wg_adam_t(online, adam_m, adam_v, grad, lo, n, ac, target, (float)cfg.tau, (float)(1.0 - cfg.tau), tid, NT);
                         }
+                    }
                     }
                     WBAR(63);
                 } else wc_backward_big<SHAPE>(ctx);

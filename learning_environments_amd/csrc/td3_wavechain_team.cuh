@@ -342,60 +342,6 @@ struct T3vNet {
     int d_h1, r_h2, r_dz2, r_dh1;
 };
 
-// Adam + Polyak on a 32 x 32 tile of a K-major array whose gradient sits in `acc` (D layout: lane = column, register = row
-// 8 (v / 4) + 4 h + v % 4): transposed through the wave's LDS tile so that every arena access is 16 bytes per lane.  Rows >= kmax are
-// left alone (W1t's zero rows).  wu != null: the updated tile also goes to the unit-major copy (element (k, j) at wu[j * W + k]).
-// The tile's state (parameter, target, Adam m / v: 16 float4 per lane) is loaded by t3v_tile_state BEFORE the gradient chain runs.
-struct T3vTileState { f32x4 w[4], m[4], v[4], t[4]; };
-__device__ __forceinline__ void t3v_tile_state(const Lane &L, const float *w_, const float *m_, const float *v_, const float *t_, int kmax, T3vTileState &st)
-{
-    const int kr = L.lane >> 3, j4 = (L.lane & 7) << 2;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int k = kr + 8 * p, off = (k < kmax ? k : 0) * W + j4;       // (rows >= kmax: a harmless in-range load, never written back)
-        st.w[p] = *(const gf4 *)((const gfloat *)w_ + off); st.m[p] = *(const gf4 *)((const gfloat *)m_ + off);
-        st.v[p] = *(const gf4 *)((const gfloat *)v_ + off); st.t[p] = *(const gf4 *)((const gfloat *)t_ + off);
-    }
-}
-__device__ __forceinline__ void t3v_tile_adam(const f32x16 &acc, T3vTileState &st, float *tile_, float *tileT_, const Lane &L, float *w_, float *m_, float *v_, float *t_,
-                                              int kmax, float *wu_, const AdamConsts ac, float tau, float omt)
-{
-    lfloat *tile = (lfloat *)tile_;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) tile[(8 * (v >> 2) + 4 * L.h + (v & 3)) * 32 + L.li] = acc[v];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int kr = L.lane >> 3, j4 = (L.lane & 7) << 2;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int k = kr + 8 * p, off = k * W + j4;
-        const f32x4 g = *(const lf4 *)(tile + k * 32 + j4);
-        if (k < kmax) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float mm = st.m[p][c], v2 = st.v[p][c], ww = st.w[p][c], tt = st.t[p][c];
-                adam_elem(g[c], mm, v2, ww, tt, ac, tau, omt);
-                st.m[p][c] = mm; st.v[p][c] = v2; st.w[p][c] = ww; st.t[p][c] = tt;
-            }
-            *(gf4 *)((gfloat *)m_ + off) = st.m[p]; *(gf4 *)((gfloat *)v_ + off) = st.v[p];
-            *(gf4 *)((gfloat *)w_ + off) = st.w[p]; *(gf4 *)((gfloat *)t_ + off) = st.t[p];
-        }
-    }
-    if (wu_) {
-        lfloat *tt = (lfloat *)tileT_;                     // [j][33]: the updated tile, transposed
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) tt[(j4 + c) * 33 + kr + 8 * p] = st.w[p][c];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int j = kr + 8 * p;                      // (kr, j4) now address (row j, columns k = j4 .. j4 + 3)
-            const f32x4 o = { tt[j * 33 + j4], tt[j * 33 + j4 + 1], tt[j * 33 + j4 + 2], tt[j * 33 + j4 + 3] };
-            *(gf4 *)((gfloat *)wu_ + j * W + j4) = o;
-        }
-    }
-}
-
 // acc = sum_{i < 192} A[i][ca] * Bm[i][cb], i ascending in ONE chain: lane (li, h) reads rows 2 t + h of the two row-major arrays
 // (pa / pb already point at its row h and column), D k-steps of operands in flight (more in flight did not help: 28 deep the eight waves' outstanding lines
 // overran the 32 KB L1 and the chain got slower)
@@ -449,14 +395,6 @@ __device__ __forceinline__ f32x16 t3v_wgrad_chain(const gfloat *pa, const gfloat
     return acc;
 }
 #endif
-
-// one parameter of a small vector / matrix: Adam + Polyak in place (4-byte accesses: a few hundred elements per network)
-__device__ __forceinline__ void t3v_adam1(float g, float *w_, float *m_, float *v_, float *t_, int off, const AdamConsts ac, float tau, float omt)
-{
-    float w = ((gfloat *)w_)[off], m = ((gfloat *)m_)[off], v = ((gfloat *)v_)[off], t = ((gfloat *)t_)[off];
-    adam_elem(g, m, v, w, t, ac, tau, omt);
-    ((gfloat *)m_)[off] = m; ((gfloat *)v_)[off] = v; ((gfloat *)w_)[off] = w; ((gfloat *)t_)[off] = t;
-}
 
 #ifdef LENV_PHASE_TIMING_SUB
 // diagnostic: cycles per job class of the gradient phase -- [phase (critics / actor)][class: W2 tile, W1 tile, bias, output layer, epilogue

@@ -1,3 +1,2 @@
 #!/bin/bash
-LENV_TIMING_POP=8 timeout 900 python3 tools/phase_timing_t3w.py 2>&1 | grep -v " 0          0 per" | tail -30
-LENV_TIMING_POP=8 timeout 900 python3 tools/phase_timing_t3w.py -DLENV_PHASE_TIMING_SUB 2>&1 | grep -v " 0          0 per" | tail -40
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_host_api.py -m gpu -x -q -k "dueling or wavechain or acrobot" 2>&1 | tail -4
