@@ -721,6 +721,12 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     float *rb = arena + a.a_replay, *xc = arena + a.a_xc, *xn = arena + a.a_xn, *xa = arena + a.a_xa, *thb = arena + a.a_th, *dumps = arena + a.a_dump;
     double *meter = reinterpret_cast<double *>(arena + a.a_meter);
     float *gdq = arena + a.a_gx, *gdz = gdq + 2 * B;       // team exchange: dq1 | dq2 [B] each, dz [B][A]
+    // the chain's arena pointers from scalar registers, fresh: the chain index goes through an empty asm so that the compiler cannot share
+    // the result with the long-lived copies above (which it keeps in vector registers and, around calls, in scratch memory)
+    auto arena_fresh = [&]() -> float * { long long ch_ = (long long)chain; asm volatile("" : "+s"(ch_)); return a.arena + ch_ * a.arena_stride; };
+#define TEAM_PTRS float *ar_ = arena_fresh(); float *params = ar_ + a.a_par, *targets = params + 3 * PN, *xc = ar_ + a.a_xc, *xn = ar_ + a.a_xn, \
+                  *xa = ar_ + a.a_xa, *thb = ar_ + a.a_th, *gdq = ar_ + a.a_gx, *gdz = gdq + 2 * B, *w2u = ar_ + a.a_w2u;                    \
+                  (void)params; (void)targets; (void)xc; (void)xn; (void)xa; (void)thb; (void)gdq; (void)gdz; (void)w2u
     unsigned *team_bar = reinterpret_cast<unsigned *>(arena + a.a_bar);
 
     // ---- stage the perturbed reward network (GTN_worker.py:165-175) and the fresh agent (TD3.py:31-39) ----
@@ -781,16 +787,22 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     // ---- team barrier (G > 1, wc::team_barrier): every member has finished its share of a phase and its arena writes are visible to the
     // others.  The chain's counter and the launch's give-up word are zeroed by t3w_team_reset_kernel in front of the launch.
     TeamSync tsync{ team_bar, reinterpret_cast<unsigned *>(a.arena + a.a_bar) + 8, ictrl + 5, 0u, G, false, false };
-    bool team_dead = false;
+    // (no copies of the give-up flag or counters in kernel-lifetime variables: what lives across the calls of the learn step ends up in
+    // scratch memory and costs a round trip at every use; tsync.dead is read where it matters)
+#ifdef LENV_PHASE_TIMING
     unsigned long long bar_cycles = 0;
+#endif
     auto team_barrier = [&]() {
         if (G == 1) return;
+#ifdef LENV_PHASE_TIMING
         const unsigned long long bt0 = __builtin_readcyclecounter();
+#endif
         wc::team_barrier(tsync, tid);
-        if (tsync.dead) { team_dead = true; status = -10; }
+#ifdef LENV_PHASE_TIMING
         bar_cycles += __builtin_readcyclecounter() - bt0;
+#endif
     };
-    (void)bar_cycles;
+#define team_dead (tsync.dead)
     // sample block of row b -> does it belong to this member (blocks are dealt like the waves that own them)
     auto my_row = [&](int b) { return G == 1 || ((b >> 5) * G) / T3W_NB == g; };
     if (G > 1 && tid == 0) reinterpret_cast<unsigned *>(gdz)[g] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
@@ -1220,8 +1232,15 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                     // next_actions = (actor_target(s') + clamp(randn * policy_std)).clamp(-max, max) -- and, on the second quad, the policy
                     // step's actor(states) (TD3.py:97: the actor is not touched by the critic update, so its forward can run here, next to
                     // the target actor's, instead of alone after the critics' optimizer step)
+                    // (the arena pointers are re-derived from scalar registers in front of every call -- TEAM_PTRS: held in the kernel's own
+                    // registers across the calls they were spilled to scratch memory, and every call started with a round trip to fetch them)
+                    {
+                    TEAM_PTRS;
                     for (int e = tid; e < gbn * S; e += NT) { const int b = gb0 + e / S, i = e - (b - gb0) * S; xa[b * SA + i] = xc[b * SA + i]; }
                     t3v_forward<ACT, S, A>(ctx, 2, SA, 1, targets, xn, nullptr, -1, -1, params, xc, nullptr, TD_A_H1, TR_A_H2, xn, nullptr, xa, thb, SA, S);
+                    }
+                    {
+                    TEAM_PTRS;
                     for (int e = tid; e < gbn * A; e += NT) {
                         const int b = gb0 + e / A, k = e - (b - gb0) * A;
                         const int64_t n = (learn_it * B + b) * A + k;
@@ -1236,9 +1255,15 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                     TPT_MARK(2);
                     // the twin target critics side by side on the two quads, then the twin critics
                     t3v_forward<ACT, SA, 1>(ctx, 2, SA, 0, targets + PN, xn, tq1, -1, -1, targets + 2 * PN, xn, tq2, -1, -1, nullptr, nullptr, nullptr, nullptr, 0, 0);
+                    }
+                    {
+                    TEAM_PTRS;
                     t3v_forward<ACT, SA, 1>(ctx, 2, SA, 0, params + PN, xc, q1, TD_C1_H1, TR_C1_H2, params + 2 * PN, xc, q2, TD_C2_H1, TR_C2_H2, nullptr, nullptr,
                                             nullptr, nullptr, 0, 0);
+                    }
                     TPT_MARK(3);
+                    {
+                    TEAM_PTRS;
                     {
                         const float norm = (float)(2.0 / (double)B);
                         for (int b = gb0 + tid; b < gb0 + gbn; b += NT) {
@@ -1255,7 +1280,10 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                     // gradients + the critic optimizer step as wave jobs over the team
                     t3v_backward<ACT, SA, 1>(ctx, 2, params + PN, w2u + IMG, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1,
                                              params + 2 * PN, w2u + 2 * IMG, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
+                    }
                     team_barrier();
+                    {
+                    TEAM_PTRS;
                     for (int b = tid; b < B; b += NT) { dq1[b] = gdq[b]; dq2[b] = gdq[B + b]; }
                     __syncthreads();
                     {
@@ -1263,30 +1291,43 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                         const T3vNet n2{ params + 2 * PN, w2u + 2 * IMG, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B };
                         t3v_wgrad<ACT, SA, 1, SA>(ctx, 2, n1, n2, xc, SA, 20);                 // critic_optimizer (+ Polyak of the two critics)
                     }
+                    }
                     TPT_MARK(5);
                     ++learn_it;
                     // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1 (policy_delay 1); actor(states) is in
                     // xa since the start of the step
                     team_barrier();
                     TPT_MARK(6);
+                    {
+                    TEAM_PTRS;
                     t3v_forward<ACT, SA, 1>(ctx, 1, SA, 0, params + PN, xa, dq2, TD_C1_H1, TR_C1_H2, params + PN, xa, dq2, -1, -1, nullptr, nullptr, nullptr, nullptr,
                                             0, 0);
+                    }
                     {
                         const float dqa = -(1.0f / (float)B);
                         for (int b = tid; b < B; b += NT) dq1[b] = dqa;
                     }
                     __syncthreads();
+                    {
+                    TEAM_PTRS;
                     t3v_backward<ACT, SA, 1>(ctx, 1, params + PN, w2u + IMG, dq1, TD_C1_H1, TR_C1_H2, -1, -1,
                                              params + PN, w2u + IMG, dq1, TD_C1_H1, TR_C1_H2, -1, -1, S, A, thb, dzl);
+                    }
+                    {
+                    TEAM_PTRS;
                     for (int e = tid; e < gbn * A; e += NT) gdz[gb0 * A + e] = dzl[gb0 * A + e];
                     t3v_backward<ACT, S, A>(ctx, 1, params, w2u, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B,
                                             params, w2u, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
+                    }
                     team_barrier();
+                    {
+                    TEAM_PTRS;
                     for (int e = tid; e < B * A; e += NT) dzl[e] = gdz[e];
                     __syncthreads();
                     {
                         const T3vNet na{ params, w2u, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B };
                         t3v_wgrad<ACT, S, A, SA>(ctx, 1, na, na, xc, SA, 22);                  // actor_optimizer (+ Polyak of the actor)
+                    }
                     }
                     TPT_MARK(7);
                     team_barrier();
@@ -1460,7 +1501,8 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
             a.out.final_params[chain * a.P + p] = params[q];
         }
     }
-    if (a.out.status && status != 0) atomicMin(&a.out.status[chain], status);
+    if (a.out.status && (status != 0 || team_dead)) atomicMin(&a.out.status[chain], team_dead ? -10 : status);
+#undef team_dead
 }
 
 }  // namespace lenv
