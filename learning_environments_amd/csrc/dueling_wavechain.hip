@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
     bool team_dead = false;
     auto team_barrier = [&]() {
         if (G == 1) return;
-        wc::team_barrier(tsync, tid);
+        wc::team_barrier<false>(tsync, tid);
         if (tsync.dead) { team_dead = true; status = -10; }
     };
     if (G > 1 && tid == 0) reinterpret_cast<unsigned *>(gva)[g] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]

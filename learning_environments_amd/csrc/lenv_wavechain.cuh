@@ -56,22 +56,30 @@ __device__ __forceinline__ void barrier_lds()
 // status -10 and the caller repeats it with one workgroup per chain.  Returns through ts.dead (uniform in the workgroup).
 struct TeamSync {
     unsigned *bar, *launch_dead;
-    volatile __attribute__((address_space(3))) int *lds_flag;       // one LDS word, zero at kernel start
+    // two LDS words, zero at kernel start: [0] the give-up flag, [1] the barrier epoch of team_barrier<true>.  The TD3 kernel keeps both in
+    // LDS rather than in this record: a kernel-lifetime register of a kernel that calls out-of-line routines can end up in scratch memory,
+    // and there the barrier started with a memory round trip to fetch its own counter (configs[4] shard: 493 -> 481 ms).  The DuelingDDQN
+    // kernel, whose body spills next to nothing, is 2 % FASTER with the counter in `epoch` (measured both ways): team_barrier<false>.
+    volatile __attribute__((address_space(3))) int *lds_flag;
     unsigned epoch;
     int G;
     bool dead, same_xcd;
 };
+__device__ __forceinline__ bool team_is_dead(const TeamSync &ts) { return ts.lds_flag[0] != 0; }
+template <bool LDS_EPOCH>
 __device__ __forceinline__ void team_barrier(TeamSync &ts, int tid)
 {
     if (ts.G == 1) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    ++ts.epoch;
-    if (tid == 0 && !ts.dead) {
+    if (!LDS_EPOCH) ++ts.epoch;
+    if (tid == 0 && (LDS_EPOCH ? ts.lds_flag[0] == 0 : !ts.dead)) {
+        unsigned epoch = ts.epoch;
+        if (LDS_EPOCH) { epoch = (unsigned)(ts.lds_flag[1] + 1); ts.lds_flag[1] = (int)epoch; }
         if (ts.same_xcd) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(ts.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = ts.epoch * (unsigned)ts.G;
+        const unsigned target = epoch * (unsigned)ts.G;
         const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();      // constant 100 MHz
         unsigned spins = 0;
         while (__hip_atomic_load(ts.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -91,7 +99,7 @@ __device__ __forceinline__ void team_barrier(TeamSync &ts, int tid)
         else { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     }
     __syncthreads();
-    if (*ts.lds_flag) ts.dead = true;
+    if (!LDS_EPOCH) { if (*ts.lds_flag) ts.dead = true; }
 }
 
 __device__ __forceinline__ int img_pos(int r, int c) { return r * W + (c ^ ((r & 7) << 2)); }

@@ -797,12 +797,12 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
 #ifdef LENV_PHASE_TIMING
         const unsigned long long bt0 = __builtin_readcyclecounter();
 #endif
-        wc::team_barrier(tsync, tid);
+        wc::team_barrier<true>(tsync, tid);
 #ifdef LENV_PHASE_TIMING
         bar_cycles += __builtin_readcyclecounter() - bt0;
 #endif
     };
-#define team_dead (tsync.dead)
+#define team_dead (wc::team_is_dead(tsync))
     // sample block of row b -> does it belong to this member (blocks are dealt like the waves that own them)
     auto my_row = [&](int b) { return G == 1 || ((b >> 5) * G) / T3W_NB == g; };
     if (G > 1 && tid == 0) reinterpret_cast<unsigned *>(gdz)[g] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
