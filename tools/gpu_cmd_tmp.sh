@@ -1,2 +1,2 @@
 #!/bin/bash
-bash tools/ab_config.sh 2 gpurun_out_lib_v1.so gpurun_out_lib_v2.so 3
+timeout 1500 python3 tools/nes_learning_demo.py 30 2>/dev/null | tee gpurun_out/nes_learning_demo_r04.jsonl | tail -8
