@@ -1,2 +1,2 @@
 #!/bin/bash
-timeout 1500 python3 tools/nes_learning_demo.py 30 2>/dev/null | tee gpurun_out/nes_learning_demo_r04.jsonl | tail -8
+timeout 900 python3 tools/bench_configs.py acrobot_ddqn pendulum_td3 cmc_td3 2>/dev/null | tail -12
