@@ -1,2 +1,5 @@
 #!/bin/bash
-timeout 900 python3 tools/bench_configs.py acrobot_ddqn pendulum_td3 cmc_td3 2>/dev/null | tail -12
+cp learning_environments_amd/liblenv_hip.so /tmp/orig.so; cp gpurun_out_lib_new.so learning_environments_amd/liblenv_hip.so
+timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "wavechain_td3 or td3_bench_launch or td3_team" 2>&1 | tail -3
+cp /tmp/orig.so learning_environments_amd/liblenv_hip.so
+bash tools/ab_config.sh 4 gpurun_out_lib_base.so gpurun_out_lib_new.so 3
