@@ -1404,10 +1404,16 @@ __global__ __launch_bounds__(NT) void dueling_wavechain_kernel(const WcArgs a)
                     const int64_t n = (int64_t)learn_it * B + b;
                     const int idx = (int)rng_replay_below(key, (uint64_t)n, (uint32_t)size_after);
                     const float *row = rb + (int64_t)idx * RS;
-                    for (int i = 0; i < S; ++i) { xs[b * S + i] = row[i]; xs2[b * S + i] = row[S + 1 + i]; }
-                    dAdv[b * A + 0] = row[S];
-                    dAdv[b * A + 1] = row[2 * S + 1];
-                    dq[b] = row[2 * S + 2];
+                    // (the whole row into registers first: written element by element the compiler cannot move a load over the store in
+                    // front of it -- the arrays may alias as far as it knows -- and the gather was 15 dependent memory round trips)
+                    float rv[2 * S + 3];
+#pragma unroll
+                    for (int i = 0; i < 2 * S + 3; ++i) rv[i] = row[i];
+#pragma unroll
+                    for (int i = 0; i < S; ++i) { xs[b * S + i] = rv[i]; xs2[b * S + i] = rv[S + 1 + i]; }
+                    dAdv[b * A + 0] = rv[S];
+                    dAdv[b * A + 1] = rv[2 * S + 1];
+                    dq[b] = rv[2 * S + 2];
                 }
                 __syncthreads();
                 WPT_MARK(2);
