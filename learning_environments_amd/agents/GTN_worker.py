@@ -9,12 +9,12 @@ of the fused kernel (3 chains) instead of three sequential python training runs.
 package does not use worker objects at all.
 """
 import os
-import statistics
 import time
 
 import numpy as np
 import torch
 
+from .. import _lib
 from ..envs.env_factory import EnvFactory
 from ..models.model_utils import linear_params
 from .GTN_base import GTN_Base
@@ -34,37 +34,39 @@ class GTN_Worker(GTN_Base):
         self.timeout = None
         self.engine = engine
         self.generation = 0
+        self.team_fallbacks = 0                # launches repeated with one workgroup per chain (status -10, _run_chains)
         for file in self.worker_files(self.id):
             if os.path.isfile(file):
                 os.remove(file)
+        # (reference :47 -- also what a launcher waits for before the master writes its first input: the line is flushed after the
+        # worker's stale sync files are gone)
+        print("Starting GTN Worker with bohb_id {} and id {}".format(bohb_id, id), flush=True)
+
+    # the gtn section's keys a worker keeps as attributes of the same name (reference agents/GTN_worker.py:49-58)
+    _GTN_KEYS = ("noise_std", "num_grad_evals", "grad_eval_type", "mirrored_sampling", "time_sleep_worker", "agent_name",
+                 "synthetic_env_type", "unsolved_weight")
+    _ENV_BUILDERS = {0: "generate_virtual_env", 1: "generate_reward_env"}      # gtn.synthetic_env_type -> EnvFactory method
 
     def late_init(self, config):
-        gtn_config = config["agents"]["gtn"]
-        self.noise_std = gtn_config["noise_std"]
-        self.num_grad_evals = gtn_config["num_grad_evals"]
-        self.grad_eval_type = gtn_config["grad_eval_type"]
-        self.mirrored_sampling = gtn_config["mirrored_sampling"]
-        self.time_sleep_worker = gtn_config["time_sleep_worker"]
-        self.agent_name = gtn_config["agent_name"]
-        self.synthetic_env_type = gtn_config["synthetic_env_type"]
-        self.unsolved_weight = gtn_config["unsolved_weight"]
-        if gtn_config["mode"] == 'single':
-            self.time_sleep_worker /= 10
+        """Called with the config the master sent (reference :49-74): settings, then three instances of the synthetic env
+        (theta, the perturbed copy, and one whose parameters hold the noise), then the fused-kernel task for the inner agent."""
+        gtn = config["agents"]["gtn"]
+        for key in self._GTN_KEYS:
+            setattr(self, key, gtn[key])
+        if gtn["mode"] == "single":                      # master and workers on one machine poll ten times as often
+            self.time_sleep_worker = self.time_sleep_worker / 10
         if self.engine is None:
             from ..engine import HipNesEngine
             self.engine = HipNesEngine()
-
         self.config = config
         self.env_factory = EnvFactory(config)
-        if self.synthetic_env_type == 0:
-            generate_synthetic_env_fn = self.env_factory.generate_virtual_env
-        elif self.synthetic_env_type == 1:
-            generate_synthetic_env_fn = self.env_factory.generate_reward_env
-        else:
+        builder = self._ENV_BUILDERS.get(self.synthetic_env_type)
+        if builder is None:
             raise NotImplementedError("Unknown synthetic_env_type value: " + str(self.synthetic_env_type))
-        self.synthetic_env_orig = generate_synthetic_env_fn(print_str='GTN_Base: ')
-        self.synthetic_env = generate_synthetic_env_fn(print_str='GTN_Worker' + str(id) + ': ')
-        self.eps = generate_synthetic_env_fn('GTN_Worker' + str(id) + ': ')
+        make_env = getattr(self.env_factory, builder)
+        tag = "GTN_Worker%s: " % self.id
+        self.synthetic_env_orig = make_env(print_str="GTN_Base: ")
+        self.synthetic_env, self.eps = make_env(print_str=tag), make_env(print_str=tag)
         # inner agent x synthetic-env type -> fused kernel (agents/agent_utils.py:15-66 select_agent + EnvFactory)
         self.task = select_task(config, self.engine, self.synthetic_env_orig)
         self.cfg = self.task.cfg
@@ -110,7 +112,16 @@ class GTN_Worker(GTN_Base):
         agent_init = fresh_agent_init(self._bounds, n, g, dev) if self.task.needs_agent_init() else None
         keys = chain_keys(self.seed, self.generation * 1000 + self.test_counter, np.full(n, self.id), np.arange(n))
         self.test_counter += 1
-        scores = self.task.scores(inner, zero, eps, worker, sign, torch.from_numpy(keys.view(np.int64)).to(dev), agent_init)
+        keys_t = torch.from_numpy(keys.view(np.int64)).to(dev)
+        scores = self.task.scores(inner, zero, eps, worker, sign, keys_t, agent_init)
+        # Several worker processes usually share one GPU: a launch whose teams of workgroups could not assemble next to another
+        # worker's kernel reports status -10 (include/lenv_hip.h, lenv_ddqn_cfg::team_size).  The chains are deterministic functions
+        # of these inputs, so the launch is repeated once with one workgroup per chain; the inner loop keeps that setting.
+        status = getattr(inner, "status", None)
+        if status is not None and status.numel() and int(status.min()) == _lib.STATUS_TEAM_GAVE_UP and getattr(inner.cfg, "team_size", 1) != 1:
+            inner.cfg.team_size = 1
+            self.team_fallbacks += 1
+            scores = self.task.scores(inner, zero, eps, worker, sign, keys_t, agent_init)
         out = scores.cpu().tolist()
         if hasattr(self.engine, "check_status"):
             self.engine.check_status(inner)
@@ -124,23 +135,19 @@ class GTN_Worker(GTN_Base):
         return self._run_chains([self._flat(env)])[0]
 
     def calc_best_score(self, score_sub, score_add):
-        # reference :234-254
-        if self.grad_eval_type == 'mean':
-            score_sub = statistics.mean(score_sub)
-            score_add = statistics.mean(score_add)
-        elif self.grad_eval_type == 'minmax':
-            score_sub = min(score_sub)
-            score_add = min(score_add)
+        """reference :234-254 -- the mirrored pick.  The arithmetic (statistics.mean's exactly rounded mean or the minimum of each
+        side, then the comparison) is the engine's worker-best routine, the one the in-process master runs for the whole
+        population (lenv_nes_worker_best_multi); here it gets this one worker's row.  Afterwards, as in the reference, eps points
+        in the direction that scored better and synthetic_env holds theta + eps."""
+        sub, add = [float(v) for v in score_sub], [float(v) for v in score_add]
+        if len(sub) != len(add) or not add:
+            raise ValueError("calc_best_score: need as many -eps as +eps scores, at least one of each")
+        row = torch.tensor([[0.0] + add + sub], dtype=torch.float64, device=self.engine.device)
+        picked = self.engine.worker_best(row, 1, bool(self.mirrored_sampling), len(add), self.grad_eval_type).cpu()
+        score_best, sign = float(picked[0, 0]), float(picked[0, 2])
+        if sign < 0:
+            self.invert_eps()                   # -eps won: eps := -eps; synthetic_env already holds theta - (old eps)
         else:
-            raise NotImplementedError('Unknown parameter for grad_eval_type: ' + str(self.grad_eval_type))
-        if self.mirrored_sampling:
-            score_best = max(score_add, score_sub)
-            if score_sub > score_add:
-                self.invert_eps()
-            else:
-                self.add_noise_to_synthetic_env()
-        else:
-            score_best = score_add
             self.add_noise_to_synthetic_env()
         return score_best
 

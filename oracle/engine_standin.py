@@ -101,6 +101,8 @@ class OracleNesEngine(object):
 
     def worker_best(self, chain_scores, pop, mirrored, num_grad_evals=1, grad_eval_type="mean", out=None):
         G = num_grad_evals
+        if grad_eval_type not in ("mean", "minmax"):
+            raise NotImplementedError('Unknown parameter for grad_eval_type: ' + str(grad_eval_type))
         cs = chain_scores.numpy().reshape(pop, 1 + 2 * G)
         best, sign = orc.worker_best_multi(cs[:, 1:1 + G], cs[:, 1 + G:], mirrored, grad_eval_type)
         res = torch.from_numpy(np.stack([best, cs[:, 0], sign.astype(np.float64), np.zeros(pop)], axis=1))

@@ -25,6 +25,32 @@ def test_library_exports_every_declared_symbol():
     assert L.lenv_error_string(-2) == b"unsupported shape or option"
 
 
+def test_struct_mirrors_documented_in_integration_md_have_the_library_sizes():
+    """Every `class X(C.Structure)` a maintainer can paste from INTEGRATION.md is built here and its ctypes.sizeof compared with
+    lenv_struct_size (include/lenv_hip.h) -- a stub one field short hands the library a struct whose tail is whatever follows it."""
+    from learning_environments_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    L = _lib.lib()
+    L.lenv_struct_size.restype = C.c_int64
+    L.lenv_struct_size.argtypes = [C.c_int32]
+    index = {cls.__name__: i for i, cls in enumerate(_lib.ABI_STRUCTS)}
+    found = []
+    # a class statement and its (possibly multi-line) _fields_ list, up to the closing bracket
+    for m in re.finditer(r"^class (\w+)\(C\.Structure\):[^\n]*\n((?:[ \t]+[^\n]*\n)+)", text, re.M):
+        name, body = m.group(1), m.group(2)
+        ns = {"C": C}
+        exec("class %s(C.Structure):\n%s" % (name, body), ns)
+        assert name in index, "INTEGRATION.md documents a struct the ABI table does not know: " + name
+        assert C.sizeof(ns[name]) == L.lenv_struct_size(index[name]), \
+            "INTEGRATION.md's %s is %d bytes, the library's is %d" % (name, C.sizeof(ns[name]), L.lenv_struct_size(index[name]))
+        assert [f[0] for f in ns[name]._fields_] == [f[0] for f in _lib.ABI_STRUCTS[index[name]]._fields_]
+        found.append(name)
+    assert "MlpDesc" in found
+    # and the package's own mirrors, the same way (what _lib.lib() checks at load)
+    for i, cls in enumerate(_lib.ABI_STRUCTS):
+        assert C.sizeof(cls) == L.lenv_struct_size(i), cls.__name__
+
+
 def test_host_only_entry_points():
     from learning_environments_amd import _lib, config, configs
     from oracle import oracle as orc
@@ -214,7 +240,7 @@ def test_product_path_fails_loudly_without_device():
 
 
 def test_master_rejects_unknown_options(tmp_path, monkeypatch):
-    from _oracle_engine import OracleNesEngine
+    from oracle.engine_standin import OracleNesEngine
     from learning_environments_amd.agents.GTN import GTN_Master
     from learning_environments_amd.configs import cartpole_syn_env_ddqn
     monkeypatch.chdir(tmp_path)
@@ -267,7 +293,7 @@ def test_master_host_logic_for_icm_and_multilayer_agents_on_the_oracle_engine(tm
     import numpy as np
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from _oracle_engine import OracleNesEngine
+    from oracle.engine_standin import OracleNesEngine
     from learning_environments_amd.agents.GTN import GTN_Master
     from learning_environments_amd.configs import cartpole_syn_env_ddqn, fixed_work, with_icm
     from oracle import oracle as orc

@@ -1,5 +1,5 @@
 """world_size-2 gloo test of the N>1 path: population sharding, the single all-gather, redundant rank update.
-The per-chain scorer is the CPU oracle (tests/_oracle_engine.py); on the GPU box the same GTN_Master code drives the
+The per-chain scorer is the CPU oracle (oracle/engine_standin.py); on the GPU box the same GTN_Master code drives the
 HIP engine over RCCL."""
 import os
 import sys
@@ -37,7 +37,7 @@ def _run(rank, world, port, tmp, q, seed_per_rank=False, vary=False):
     torch.set_num_threads(1)
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    from _oracle_engine import OracleNesEngine
+    from oracle.engine_standin import OracleNesEngine
     from learning_environments_amd.agents.GTN import GTN_Master
     # a launcher that seeds every rank differently must not matter: rank 0's theta / model name are broadcast at construction
     torch.manual_seed(1000 * rank if seed_per_rank else 0)

@@ -271,3 +271,97 @@ def test_master_reads_reference_worker_results_hip(tmp_path, monkeypatch):
 def test_worker_reads_reference_master_input_hip(tmp_path, monkeypatch):
     from learning_environments_amd.engine import HipNesEngine
     _check_worker_reads_reference_input(HipNesEngine(), tmp_path, monkeypatch)
+
+
+# ---- worker process entry points (reference experiments/GTN_Worker.py:13-16, experiments/GTN_Worker_single_pc.py:12-30) ----
+def test_worker_cli_argument_plumbing(monkeypatch, capsys):
+    from learning_environments_amd.experiments import GTN_Worker as cli, GTN_Worker_single_pc as cli_n
+    import learning_environments_amd.agents.GTN as gtn
+    made = []
+
+    class FakeWorker(object):
+        def __init__(self, id, bohb_id=-1, seed=None):
+            made.append((bohb_id, id, seed))
+
+        def run(self):
+            made.append("ran")
+    monkeypatch.setattr(gtn, "GTN_Worker", FakeWorker)
+    assert cli.main(["20003", "7"]) == 0
+    assert made == [(20003, 7, None), "ran"]
+    assert capsys.readouterr().out.split() == ["20003", "7"]          # the reference echoes its arguments
+    with pytest.raises(ValueError):
+        cli.main(["0", "-1"])
+    with pytest.raises(SystemExit):
+        cli.main(["0"])                                                # both ids are required, as in the reference
+    a = cli_n.parse_args([])
+    assert (a.num_workers, a.bohb_id) == (16, 0)                       # the reference's single-PC defaults
+    cmd = cli_n.worker_command(3, 5, seed=100)
+    assert cmd[1:] == ["-m", "learning_environments_amd.experiments.GTN_Worker", "3", "5", "--seed", "105"]
+
+
+def _wait_for_lines(stream, needle, count, timeout_s=180):
+    """read `stream` until `count` lines containing `needle` have gone by"""
+    import time
+    seen, t0 = 0, time.time()
+    while seen < count:
+        line = stream.readline()
+        if not line:
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError("workers did not start")
+            time.sleep(0.05)
+            continue
+        seen += needle in line
+    return seen
+
+
+@pytest.mark.timeout(300)
+def test_worker_cli_fails_loudly_without_a_device(tmp_path, monkeypatch):
+    """No CPU fallback behind the command line either: the process reads the master's input and dies on the first use of the engine."""
+    if torch.cuda.is_available():
+        pytest.skip("needs a box WITHOUT a GPU")
+    from oracle.engine_standin import OracleNesEngine
+    from learning_environments_amd.agents.GTN import GTN_Master
+    monkeypatch.chdir(tmp_path)
+    cfg = _tiny_cartpole(1, 1)
+    cfg["device"] = "cpu"
+    master = GTN_Master(cfg, bohb_id=-1, engine=OracleNesEngine(), transport="file")
+    master.clean_working_dir()
+    env = dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    p = subprocess.Popen([sys.executable, "-m", "learning_environments_amd.experiments.GTN_Worker", "-1", "0"], env=env, cwd=str(tmp_path),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        _wait_for_lines(p.stdout, "Starting GTN Worker", 1)
+        master.write_worker_inputs(0)
+        _, err = p.communicate(timeout=120)
+        assert p.returncode != 0
+        assert "needs a HIP device" in err and "no CPU fallback" in err
+    finally:
+        if p.poll() is None:
+            p.kill()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_file_master_drives_worker_processes_started_by_the_single_pc_launcher(tmp_path, monkeypatch):
+    """`python -m learning_environments_amd.experiments.GTN_Worker_single_pc 2`: two HIP worker PROCESSES that share the GPU serve this
+    package's file-transport master for two generations and end on its quit_flag."""
+    from learning_environments_amd.agents.GTN import GTN_Master
+    monkeypatch.chdir(tmp_path)
+    cfg = _tiny_cartpole(2, 2)
+    torch.manual_seed(5)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    launcher = subprocess.Popen([sys.executable, "-m", "learning_environments_amd.experiments.GTN_Worker_single_pc", "2", "--bohb-id", "-1", "--seed", "100"],
+                                env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, text=True)
+    try:
+        _wait_for_lines(launcher.stdout, "Starting GTN Worker", 2)
+        master = GTN_Master(cfg, bohb_id=-1, transport="file")
+        theta0 = master.theta.clone()
+        mean_score, mean_list, _ = master.run()
+        assert launcher.wait(timeout=120) == 0
+        assert len(mean_list) == 2 and np.isfinite(mean_score)
+        assert bool(torch.isfinite(master.theta).all())
+        assert not torch.equal(master.theta, theta0) or all(w == 0 for w in master.get_score_transform_list())
+        assert os.listdir(master.sync_dir) == []
+    finally:
+        if launcher.poll() is None:
+            launcher.terminate()

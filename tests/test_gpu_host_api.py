@@ -255,7 +255,7 @@ def test_reward_env_step_matches_reference(golden):
 
 
 def _master_pair(cfg, tmp_path, monkeypatch, hip_only=False):
-    from _oracle_engine import OracleNesEngine
+    from oracle.engine_standin import OracleNesEngine
     from learning_environments_amd.agents.GTN import GTN_Master
     monkeypatch.chdir(tmp_path)
     torch.manual_seed(0)
