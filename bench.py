@@ -380,7 +380,7 @@ def secondary_configs(only=None, team_size=0):
                "train_steps": int(st[:, 1].sum()), "learn_steps": int(st[:, 2].sum()), "test_steps": int(st[:, 3].sum()),
                "us_per_learn_step_per_chain": kernel_ms * 1e3 / learn if learn else None,
                "algorithmic_GBps": nbytes / (kernel_ms * 1e-3) / 1e9, "hbm_frac": nbytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-               "graph": bool(getattr(m, "use_graph", False))}
+               "graph": bool(getattr(m, "use_graph", False)), "team_fallbacks": int(getattr(m, "team_fallbacks", 0))}
         if flops:
             busy = min(int(st.shape[0]), 256)
             if kernel in ("td3_wavechain_kernel", "dueling_wavechain_kernel"):    # a chain is run by a team of workgroups when the whole launch stays resident
@@ -397,6 +397,27 @@ def secondary_configs(only=None, team_size=0):
         del m
         torch.cuda.empty_cache()
 
+    # configs[1]'s own 8-GPU form: BASELINE's metric is pop 64 at 1/2/4/8 GPUs, so at N = 8 a GPU holds 8 workers = 24 chains, each on a
+    # team of workgroups (automatic team size).  What this box can measure is that shard's generation time; the 8-GPU value it implies is a
+    # PROJECTION (64 workers / this time; the all-gather of 8 x 32 B adds microseconds), reported as such and never as `value`.
+    if only is None or only == 1:
+        from learning_environments_amd import _lib
+        import ctypes
+        m8, _ = build_master(8, team_size=team_size)
+        dt8, k8 = timed_generations(m8, 10, 2, torch.cuda.synchronize, 1, True)
+        st8 = m8.inner.stats.cpu().numpy()
+        out.append({"config": "BASELINE configs[1] strong-scaling shard", "kernel": "ddqn_se_inner_kernel (TEAM)",
+                    "workload": "CartPole-v0 SE + DDQN, pop 64 over 8 GPUs = 8 workers = 24 chains on this GPU, the headline's fixed-work form",
+                    "pop_on_this_gpu": 8, "chains": int(st8.shape[0]), "steps": 10, "ms_per_step": dt8 / 10 * 1e3, "kernel_ms": k8,
+                    "workgroups_per_chain": int(_lib.lib().lenv_ddqn_se_team_size(ctypes.byref(m8.cfg), int(st8.shape[0]))),
+                    "us_per_learn_step_per_chain": k8 * 1e3 / float(st8[:, 2].mean()),
+                    "value": 8 * 10 / dt8, "unit": "worker-evaluations/s (this shard alone)",
+                    "projected_8gpu_value": POP * 10 / dt8,
+                    "projected_8gpu_note": "PROJECTION, not a measurement: 64 workers / this shard's generation time, as if eight GPUs each ran "
+                                           "this shard and exchanged one 8 x 32 B all-gather; the driver's SCALE run is the measurement",
+                    "team_fallbacks": int(getattr(m8, "team_fallbacks", 0)), "graph": bool(getattr(m8, "use_graph", False))})
+        del m8
+        torch.cuda.empty_cache()
     # configs[2]: Acrobot SE + DuelingDDQN, pop 256 over 8 GPUs = 32 workers = 96 chains per GPU; 20 train episodes x 500 steps
     # (init_episodes 10 as published: the second half learns), 10 lock-step test episodes after every train episode
     c3 = C.fixed_work(C.acrobot_syn_env_duelingddqn(32), 20)
@@ -509,7 +530,10 @@ def run_rank(args):
         if backend != "nccl":
             local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    # a launcher (torchrun, or bench.py's own) set the rendezvous variables: there is a process group, also for ONE rank -- a one-rank
+    # RCCL communicator runs the same all-gather path as N ranks.  A bare `python bench.py` has none and says so in `ranks`.
+    grouped = world > 1 or (os.environ.get("WORLD_SIZE") == "1" and "RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if grouped:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -520,7 +544,7 @@ def run_rank(args):
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
     def barrier():
-        if world > 1:
+        if grouped:
             import torch.distributed as dist
             dist.barrier()
         if not plumbing:
@@ -558,7 +582,11 @@ def run_rank(args):
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not plumbing else "PLUMBING TEST (CPU stand-in engine, tiny workload) -- not a measurement",
             "timed_region_s": dt, "gpu_section_s": gpu_section_s,
-            "ranks": {"world_size": world, "backend": ("rccl" if backend == "nccl" else backend),
+            # `backend` names a communicator that EXISTS; collective_ran = the fitness all-gather really executed in the timed generations
+            "ranks": {"world_size": world, "backend": (("rccl" if backend == "nccl" else backend) if grouped else "none"),
+                      "collective_ran": bool(getattr(master, "collectives_run", 0) > 0),
+                      "collectives_per_generation": (1 if getattr(master, "collectives_run", 0) > 0 else 0),
+                      "team_fallbacks": int(getattr(master, "team_fallbacks", 0)),
                       "launcher": "bench.py child processes" if os.environ.get("LENV_BENCH_SPAWNED") else ("torchrun/env" if world > 1 else "single process")},
             "weak": {"value": total_evals / dt, "global_pop": POP * world, "workers_per_gpu": POP, "ms_per_step": dt / args.steps * 1e3},
             "strong": strong if strong is not None else {"value": total_evals / dt, "global_pop": POP, "workers_per_gpu": POP,
@@ -575,7 +603,8 @@ def run_rank(args):
                             "NES pop=64 per GPU, fixed-work: train_episodes=%d x 200 steps, 10 real-env test episodes "
                             "per train episode + final test, early-out off" % TRAIN_EPISODES,
                 "pop_per_gpu": POP, "global_pop": POP * world, "chains_per_gpu": 3 * POP, "train_episodes": TRAIN_EPISODES,
-                "parallelism": "population-sharded x%d, 1 all-gather/generation" % world,
+                "parallelism": ("population-sharded x%d, 1 all-gather/generation" % world) if grouped else
+                               "one process, one GPU: the whole population in one launch, no process group and no collective",
                 "env_steps_per_s": (train_steps + test_steps) * world / (dt / args.steps),
                 "us_per_learn_step_per_chain": kernel_ms * 1e3 / (learn_steps / chains) if learn_steps else None,
                 "kernel_launches_per_generation": None,
@@ -610,7 +639,7 @@ def run_rank(args):
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if grouped:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
@@ -624,7 +653,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-file-io", action="store_true", help="skip the file-IO worker-mode leg of the CPU baseline")
     ap.add_argument("--no-configs", action="store_true", help="skip the shards of the other BASELINE configurations")
-    ap.add_argument("--only-config", type=int, default=None, choices=(2, 3, 4),
+    ap.add_argument("--only-config", type=int, default=None, choices=(1, 2, 3, 4),
                     help="run only the shard of BASELINE configs[N] (profiling aid; prints its record alone)")
     ap.add_argument("--team-size", type=int, default=0,
                     help="with --only-config: workgroups per chain (lenv_*_cfg::team_size; 0 = automatic, the shipped launch)")

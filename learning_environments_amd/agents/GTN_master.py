@@ -112,6 +112,10 @@ class GTN_Master(GTN_Base):
         # distributed layout: worker p lives on rank p // ceil(pop/world)
         self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # a process group -- of ANY size, a one-rank communicator included -- means the generation's fitness records go through the
+        # collective (and the captured generation is the two graphs around it): what a one-GPU box runs is then exactly what N ranks run
+        self.has_group = bool(dist.is_available() and dist.is_initialized())
+        self.collectives_run = 0               # all-gathers issued so far (bench.py reports whether one really ran)
         self.w_lo, self.w_hi, self.w_per = shard_bounds(self.num_workers, self.rank, self.world)
         self.n_local = self.w_hi - self.w_lo
 
@@ -137,7 +141,7 @@ class GTN_Master(GTN_Base):
         # One HIP graph per generation (draw -> fused inner loop -> worker_best -> status_fold -> score_transform + update_env):
         # single-process runs on the HIP engine whose task needs no host work between the kernels (the *_vary tasks draw their
         # hyper-parameters on the host).  graph=False keeps the eager launches.
-        # With world > 1 the generation is TWO graphs around the one collective: (draw -> fused inner loop -> worker_best -> status_fold),
+        # With a process group (any world size) the generation is TWO graphs around the one collective: (draw -> fused inner loop -> worker_best -> status_fold),
         # the eager all-gather of the fitness records, (score_transform + update_env) -- the collective itself is not captured, so the
         # path does not depend on the backend (RCCL, or gloo in the tests).
         capable = (self.transport == "fused" and self.n_local > 0 and getattr(engine, "graph_capable", False)
@@ -189,9 +193,10 @@ class GTN_Master(GTN_Base):
 
     def _gather(self, local, out=None):
         pop = self.num_workers
-        if self.world > 1:
+        if self.has_group:
             gathered = out if out is not None else torch.empty((self.world * self.w_per, 4), dtype=torch.float64, device=self.engine.device)
             dist.all_gather_into_tensor(gathered, local)      # the ONE collective of a generation (RCCL over xGMI)
+            self.collectives_run += 1
             return gathered[:pop]                             # (a leading slice of a contiguous tensor: contiguous)
         return local[:pop]
 
@@ -274,8 +279,8 @@ class GTN_Master(GTN_Base):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         # with a process group alive its watchdog thread polls events: only THIS thread's calls belong to the capture
-        mode = {"capture_error_mode": "thread_local"} if self.world > 1 else {}
-        if self.world == 1:
+        mode = {"capture_error_mode": "thread_local"} if self.has_group else {}
+        if not self.has_group:
             with torch.cuda.graph(g, stream=side):
                 gathered = self.evaluate_population(self._gen_t)
                 self._weights = self.engine.rank_update(self.score_transform_type, gathered, self.rank_table, self.theta, self.eps,
@@ -283,7 +288,7 @@ class GTN_Master(GTN_Base):
                                                         theta_prev=self._theta_prev, generation=self._gen_t)
             self._graph, self._graph2, self._graph_gathered, self._gen_next = g, None, gathered, 0
             return
-        # world > 1: graph 1 = this rank's device work up to its fitness records, graph 2 = the redundant rank update on the gathered
+        # with a process group: graph 1 = this rank's device work up to its fitness records, graph 2 = the redundant rank update on the gathered
         # records; the all-gather runs eagerly between the two replays (same memory pool: graph 2 reads the eps graph 1 drew)
         self._gather_buf = torch.empty((self.world * self.w_per, 4), dtype=torch.float64, device=dev)
         with torch.cuda.graph(g, stream=side, **mode):

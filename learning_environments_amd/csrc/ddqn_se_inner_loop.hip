@@ -624,7 +624,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     // ---- TEAM barrier (as in td3_wavechain.hip): one monotonically increasing counter per chain, zeroed by a kernel in front of the
     // launch; thread 0 releases, arrives, waits for the epoch's count, acquires.  Members on one XCD share its L2 (the vector L1
     // writes through): release = the stores have left the CU, acquire = this CU's L1 lines dropped; otherwise the agent-scope fences.
-    // A member that waits longer than LENV_TEAM_GIVEUP_TICKS (0.25 s: a foreign kernel holds CUs) gives up for good (status -10)
+    // A member that waits longer than LENV_TEAM_GIVEUP_TICKS for the team to assemble (0.25 s: a foreign kernel holds CUs; 5 s once it has) gives up for good (status -10)
     // instead of hanging the device; the caller repeats the launch with one workgroup per chain.
     unsigned team_epoch = 0;
     bool team_dead = false, team_same_xcd = false;
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 bool gave_up = false;
                 while (__hip_atomic_load(team_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target_) {
                     __builtin_amdgcn_s_sleep(1);
-                    if ((++spins & 63u) == 0u && __builtin_amdgcn_s_memrealtime() - w0 > LENV_TEAM_GIVEUP_TICKS) { gave_up = true; break; }
+                    if ((++spins & 63u) == 0u && __builtin_amdgcn_s_memrealtime() - w0 > (team_epoch <= 1u ? LENV_TEAM_GIVEUP_TICKS : LENV_TEAM_GIVEUP_TICKS_RUN)) { gave_up = true; break; }
                 }
                 // (the invalidate has to be complete before the barrier below releases the other waves: vmcnt counts it)
                 if (team_same_xcd) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
@@ -1210,13 +1210,13 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                             v = __hip_atomic_load(xs_ + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if ((unsigned)(v >> 32) == want_tag) break;
                             __builtin_amdgcn_s_sleep(1);
-                            // give up after LENV_TEAM_GIVEUP_TICKS (or as soon as another member of the chain has), for good: a thread that gave
+                            // give up after LENV_TEAM_GIVEUP_TICKS_RUN (the team has assembled by now; or as soon as another member of the chain has), for good: a thread that gave
                             // up never polls again, so a team whose members are not all running costs each thread one time-out (all threads
                             // at once), not one per learn step
                             if ((++spins & 63u) == 0u) {
                                 const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                                 if (w0 == 0) w0 = now;
-                                if (now - w0 > LENV_TEAM_GIVEUP_TICKS || __hip_atomic_load(team_bar + 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                                if (now - w0 > LENV_TEAM_GIVEUP_TICKS_RUN || __hip_atomic_load(team_bar + 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                                     team_bar[15] = 1u; status = -10; team_dead = true; break;
                                 }
                             }
@@ -1563,8 +1563,10 @@ extern "C" size_t lenv_ddqn_se_workspace_bytes(const lenv_ddqn_cfg *cfg, int64_t
     size_t replay = (size_t)chains * inner_rb_cap(cfg) * inner_row_stride(cfg) * sizeof(float);
     size_t meter = (size_t)chains * (cfg->train_episodes > 0 ? cfg->train_episodes : 1) * sizeof(double);
     size_t sched = (((size_t)adam_schedule_len(cfg) * sizeof(float2)) + 255) & ~(size_t)255;
-    // the team exchange area exists only when a launch of this (cfg, chains) can be teamed at all (same predicate as the launch)
-    size_t team = ddqn_pick_team(cfg, chains, cfg->rng_mode == LENV_RNG_COUNTER) > 1 ? (size_t)chains * (size_t)inner_team_stride(cfg) * sizeof(float) : 0;
+    // the team exchange area: present whenever a launch of this many chains COULD be teamed (counter mode, at most half the device's
+    // CUs' worth of chains), whatever cfg->team_size says today -- an inner loop sizes its workspace once and team_size may be changed
+    // on it later (A/B tooling, the -10 fall-back and back) -- and without asking the occupancy API on every query
+    size_t team = (cfg->rng_mode == LENV_RNG_COUNTER && chains >= 1 && chains <= 128) ? (size_t)chains * (size_t)inner_team_stride(cfg) * sizeof(float) : 0;
     return ((replay + 255) & ~(size_t)255) + ((meter + 255) & ~(size_t)255) + sched + team + 256;
 }
 

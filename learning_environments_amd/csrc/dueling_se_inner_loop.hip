@@ -1042,7 +1042,7 @@ extern "C" int lenv_dueling_se_inner_loop_icm(const lenv_ddqn_cfg *cfg, const le
             return cfg->agent_kind == sp.kind && cfg->env_id == sp.env && cfg->state_dim == sp.S && cfg->num_actions == sp.A &&
                    (sp.kind == 0 || cfg->feature_dim == sp.F) && cfg->q_hidden == sp.H && cfg->q_layers == sp.L && cfg->batch_size == sp.B &&
                    cfg->se_hidden == sp.Hse && cfg->test_episodes == sp.T && cfg->q_act == sp.q_act && cfg->se_act == sp.se_act && cfg->same_action_num <= 1 &&
-                   !cfg->q_layer_norm;
+                   !cfg->q_layer_norm && cfg->se_layers == 1;     // (the FIXED builds hard-code a one-hidden-layer SE without LayerNorm)
         };
         // production launches of a wave-chain shape (dueling_wavechain.hip): kernel_variant NO_WAVECHAIN keeps the GEMM-queue kernel (A/B runs)
         const bool no_wc = (cfg->kernel_variant & LENV_VARIANT_NO_WAVECHAIN) != 0;

@@ -18,6 +18,10 @@
 // 100 MHz clock (s_memrealtime), 0.25 s.  All team workgroups of a launch are resident at once on an idle device (host-side
 // occupancy check, lenv_team_grid_resident), so only a foreign kernel holding CUs can make a member wait.
 #define LENV_TEAM_GIVEUP_TICKS 25000000ull
+// ... and once the team HAS assembled (its first barrier passed: every member is resident and stays so), a member is only ever late because
+// its CU is time-sliced or stalled (another process's kernel, a debugger, a profiler): the later barriers and hand-overs wait 5 s before
+// they call the launch off, so that such a stall does not silently turn a run into one-workgroup launches.
+#define LENV_TEAM_GIVEUP_TICKS_RUN 500000000ull
 
 // Host side of the team launches: can `grid` workgroups of `kern` (threads per workgroup, dynamic LDS bytes) all be resident at the
 // same time on the current device?  (occupancy API x CU count; false without a device)

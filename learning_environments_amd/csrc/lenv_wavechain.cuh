@@ -86,7 +86,7 @@ __device__ __forceinline__ void team_barrier(TeamSync &ts, int tid)
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 63u) == 0u) {          // every 64th poll: has anybody in the launch given up / is it this member's turn to?
                 if (__hip_atomic_load(ts.launch_dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { *ts.lds_flag = 1; break; }
-                if (__builtin_amdgcn_s_memrealtime() - w0 > LENV_TEAM_GIVEUP_TICKS) {
+                if (__builtin_amdgcn_s_memrealtime() - w0 > (epoch <= 1u ? LENV_TEAM_GIVEUP_TICKS : LENV_TEAM_GIVEUP_TICKS_RUN)) {     // (epoch 1 = the team assembles)
                     __hip_atomic_store(ts.launch_dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (system scope: past every XCD's L2)
                     *ts.lds_flag = 1;
                     break;

@@ -363,7 +363,7 @@ class Recorder(object):
 
 def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml="default_config_cartpole_syn_env.yaml",
            env_name="CartPole-v0", env_cls="CartPoleEnv", agent_key="ddqn", agent_over=None, env_over=None, vary_seed=None,
-           icm_over=None, reward_env_type=None):
+           icm_over=None, reward_env_type=None, record_q_gap=False, perturb_ulp=False):
     import agents.GTN_worker as gw
     from agents.GTN import GTN_Worker
     import gym.envs as genvs
@@ -427,6 +427,13 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
 
     def wrapped_select_agent(config, agent_name):
         agent = orig_select_agent(config=config, agent_name=agent_name)
+        if perturb_ulp:
+            # the reference against ITSELF: every weight of the fresh agent moved by one unit in the last place.  How fast the two
+            # reference runs drift apart is the yardstick for any other implementation's drift (test_long_horizon_*)
+            with torch.no_grad():
+                for prm in agent.model.parameters():
+                    prm.copy_(torch.from_numpy(np.nextafter(prm.numpy(), np.float32(np.inf))))
+                agent.model_target.load_state_dict(agent.model.state_dict())      # (DDQN.py:36: the target starts as a copy)
         holder["agent"] = agent
         holder["hp"] = {k: agent.full_config["agents"][agent_key][k] for k in ("lr", "batch_size", "hidden_size", "hidden_layer")} \
             if hasattr(agent, "full_config") else {}
@@ -466,6 +473,13 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
             ns, r, d = orig_step(action=action, state=state) if reward_env_type is None else orig_step(action=action)
             rec.steps.append(dict(state=s_before, action=int(action.item()), next_state=ns.detach().numpy().copy(),
                                   reward=float(r.item()), done=float(d.item()), n_rand=len(rec.rand_action)))
+            if record_q_gap:
+                # how decisive was the choice?  Q(s) of the agent as it stood when it chose (learn() runs after the step): best minus second
+                # best.  The long-horizon fixtures carry it so that a test can say WHY a greedy action of a replay differs, when one does.
+                with torch.no_grad():
+                    q = holder["agent"].model(torch.as_tensor(s_before, dtype=torch.float32).reshape(1, -1)).reshape(-1)
+                top = torch.sort(q, descending=True).values
+                rec.steps[-1]["q_gap"] = float((top[0] - top[1]).item())
             return ns, r, d
 
         env.step = rec_step
@@ -502,10 +516,19 @@ def gen_g8(name, train_episodes, done_bias_shift, seed, max_steps=None, env_yaml
         prev = st["n_rand"]
     import json
     extra = {}
+    if record_q_gap:
+        extra["tr_q_gap"] = np.array([s["q_gap"] for s in rec.steps], np.float32)
     if "icm_init" in holder:
         extra["icm_init"] = holder["icm_init"]
         extra["icm_final"] = np.concatenate([v.detach().cpu().numpy().astype(np.float32).reshape(-1)
                                              for v in holder["agent"].icm.model.state_dict().values()])
+    if perturb_ulp:
+        # only what the comparison needs: the perturbed run shares config, theta and tapes' PROVENANCE with the unperturbed fixture
+        save(name, tr_action=np.array([s["action"] for s in rec.steps], np.int32), tr_explored=explored,
+             tr_next_state=np.stack([s["next_state"] for s in rec.steps]).astype(np.float32),
+             losses=np.array(rec.losses, np.float64), reward_list_train=np.array(reward_list_train, np.float64),
+             reward_list_test=np.array(reward_list_test, np.float64), score=np.array(score))
+        return
     save(name, config_json=np.array(json.dumps(cfg)), hp_json=np.array(json.dumps(holder["hp"])), **extra,
          theta=theta, agent_init=holder["init"],
          train_episodes=np.array(train_episodes), max_steps=np.array(cfg["envs"][env_name]["max_steps"]),
@@ -917,7 +940,7 @@ def gen_g4t():
 
 
 def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over=None, virtual=False,
-            cfg_yaml="default_config_halfcheetah_reward_env.yaml", env_name="HalfCheetah-v3", env_cls="CheetahStandinEnv"):
+            cfg_yaml="default_config_halfcheetah_reward_env.yaml", env_name="HalfCheetah-v3", env_cls="CheetahStandinEnv", perturb_ulp=False):
     import json
     import statistics
     import agents.GTN_worker as gw
@@ -985,6 +1008,12 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over
 
     def wrapped_select_agent(config, agent_name):
         agent = orig_select_agent(config=config, agent_name=agent_name)
+        if perturb_ulp:                            # (see gen_g8: the reference against itself, one ulp apart)
+            with torch.no_grad():
+                for net, tgt in ((agent.actor, agent.actor_target), (agent.critic_1, agent.critic_target_1), (agent.critic_2, agent.critic_target_2)):
+                    for prm in net.parameters():
+                        prm.copy_(torch.from_numpy(np.nextafter(prm.numpy(), np.float32(np.inf))))
+                    tgt.load_state_dict(net.state_dict())
         holder["init"] = _pack_td3(agent)
         holder["agent"] = agent
         if getattr(agent, "icm", None):
@@ -1045,6 +1074,11 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over
         extra["icm_init"] = holder["icm_init"]
         extra["icm_final"] = np.concatenate([v.detach().cpu().numpy().astype(np.float32).reshape(-1)
                                              for v in holder["agent"].icm.model.state_dict().values()])
+    if perturb_ulp:
+        save(name, tr_action=np.stack([s["action"] for s in rec["steps"]]), tr_next_state=np.stack([s["next_state"] for s in rec["steps"]]).astype(np.float32),
+             tr_reward=np.array([s["reward"] for s in rec["steps"]], np.float32), reward_list_train=np.array(reward_list_train, np.float64),
+             reward_list_test=np.array(reward_list_test, np.float64), score=np.array(statistics.mean(reward_list_test)), final_params=_pack_td3(agent))
+        return
     save(name, config_json=np.array(json.dumps(cfg)), hp_json=np.array(json.dumps(drawn)), theta=theta, agent_init=holder["init"], **extra,
          tape_rand_action=np.stack(rec["rand"][1::2]).astype(np.float32),          # get_random_action samples twice, returns the 2nd
          tape_act_noise=np.stack(rec["act_noise"]).astype(np.float32), tape_test_noise=np.stack(rec["test_noise"]).astype(np.float32),
@@ -1402,7 +1436,7 @@ def _gen_g11_body(cfg, n, GTN_Master, GTN_Worker, shutil):
 def main():
     # no arguments (or "all"): every fixture under tests/golden is regenerated (the full-shape runs g8df / g8tf take minutes each)
     ALL = ["g1", "g1ln", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x",
-           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8tln", "g8df", "g8l2", "g8ln", "g8seln", "g8tseln", "g8tdseln", "g9ln", "g8m", "g8r", "g8rl", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k"]
+           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8tln", "g8df", "g8l2", "g8ln", "g8seln", "g8tseln", "g8tdseln", "g9ln", "g8m", "g8r", "g8rl", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k", "g8long"]
     which = sys.argv[1:] or ALL
     if "all" in which:
         which = ALL
@@ -1633,6 +1667,34 @@ def main():
     if "g8" in which:
         gen_g8("g8_calc_score_cartpole_a", train_episodes=3, done_bias_shift=0.0, seed=800)
         gen_g8("g8_calc_score_cartpole_b", train_episodes=4, done_bias_shift=0.45, seed=801, max_steps=60)
+    if "g8long" in which:
+        # LONG-HORIZON runs of the reference, one per NN configuration of BASELINE.json: how far does "returns within
+        # 1e-4 of the reference on a fixed seed" hold when thousands of learn steps feed back into the greedy actions?
+        # configs[1] at EXACTLY the workload bench.py times: 20 train episodes x 200 steps on an SE that never terminates (done bias -10),
+        # 3 800 learn steps at B = 199, ten real-env test episodes after every train episode, early-out off (solved_reward 1e9)
+        gen_g8("g8long_cartpole_ddqn_bench_workload", train_episodes=20, done_bias_shift=-10.0, seed=880, env_over={"solved_reward": 1e9},
+               record_q_gap=True)
+        # configs[2] at its real shapes (DuelingDDQN 6-128-128-128 / heads, B 128, SE hidden 128): 3 x 400 steps, 800 learn steps... and
+        # one more episode to pass 1 000
+        gen_g8("g8long_acrobot_dueling_fullshape", train_episodes=4, done_bias_shift=-10.0, seed=881, max_steps=350,
+               env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="duelingddqn",
+               agent_over={"hidden_size": 128, "hidden_layer": 2, "feature_dim": 128, "batch_size": 128, "init_episodes": 1, "test_episodes": 2},
+               env_over={"hidden_size": 128, "solved_reward": 1e9}, record_q_gap=True)
+        # configs[4] at its real shapes (actor 17-128-128-6, critics 23-128-128-1, B 192, RN 17-128-1): 5 x 260 steps, 1 040 learn steps
+        gen_g8t("g8long_cheetah_td3_fullshape", seed=882,
+                agent_over={"train_episodes": 5, "init_episodes": 1, "batch_size": 192, "hidden_size": 128, "hidden_layer": 2, "test_episodes": 1},
+                env_over={"max_steps": 260, "hidden_size": 128, "solved_reward": 1e9})
+        # ... and each of the three once more with EVERY weight of the fresh agent one ulp larger (same seeds, so the same random draws):
+        # the reference's own sensitivity to a rounding-level difference
+        gen_g8("g8long_cartpole_ddqn_bench_workload_ulp", train_episodes=20, done_bias_shift=-10.0, seed=880, env_over={"solved_reward": 1e9},
+               perturb_ulp=True)
+        gen_g8("g8long_acrobot_dueling_fullshape_ulp", train_episodes=4, done_bias_shift=-10.0, seed=881, max_steps=350,
+               env_yaml="default_config_acrobot.yaml", env_name="Acrobot-v1", env_cls="AcrobotEnv", agent_key="duelingddqn",
+               agent_over={"hidden_size": 128, "hidden_layer": 2, "feature_dim": 128, "batch_size": 128, "init_episodes": 1, "test_episodes": 2},
+               env_over={"hidden_size": 128, "solved_reward": 1e9}, perturb_ulp=True)
+        gen_g8t("g8long_cheetah_td3_fullshape_ulp", seed=882,
+                agent_over={"train_episodes": 5, "init_episodes": 1, "batch_size": 192, "hidden_size": 128, "hidden_layer": 2, "test_episodes": 1},
+                env_over={"max_steps": 260, "hidden_size": 128, "solved_reward": 1e9}, perturb_ulp=True)
     if "g8w" in which:
         # replay ring wraps (ReplayBuffer.add, utils.py:24-32): capacity 37 rows, ~90 env steps
         gen_g8("g8w_calc_score_cartpole_ringwrap", train_episodes=3, done_bias_shift=0.0, seed=802, max_steps=30,

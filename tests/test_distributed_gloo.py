@@ -163,3 +163,41 @@ def test_two_rank_hip_engine_matches_single_rank(tmp_path):
     for r in double + eager:
         assert np.array_equal(r[1], single[1])
         assert r[2] == single[2] and r[3] == single[3] and r[4] == single[4]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_one_rank_rccl_group_runs_the_collective_path(tmp_path):
+    """RCCL on the hardware a one-GPU box has: a child process creates a ONE-RANK `nccl` (= RCCL) process group
+    before any other GPU call and runs two GTN_Master generations.  With a group the fitness records go through
+    dist.all_gather_into_tensor (float64 device tensor) and the captured generation is the two graphs around that collective -- the
+    path N ranks run; theta and the score lists must equal, bit for bit, the child that has no process group (one graph, no collective).
+    The eager (graph=False) variant of the grouped run is checked too."""
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = {}
+    for name, group, graph, port in (("plain", 0, 1, 0), ("rccl", 1, 1, 29631), ("rccl_eager", 1, 0, 29632)):
+        work = tmp_path / name
+        work.mkdir()
+        out = str(tmp_path / (name + ".npz"))
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_one_rank_child.py"), "--group", str(group), "--graph", str(graph),
+                            "--port", str(port or 29630), "--out", out, "--workdir", str(work)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        outs[name] = np.load(out)
+    plain, rccl, eager = outs["plain"], outs["rccl"], outs["rccl_eager"]
+    assert int(plain["has_group"]) == 0 and int(plain["collectives"]) == 0 and int(plain["two_graphs"]) == 0
+    gens = len(plain["mean"])
+    assert gens == 2
+    for r in (rccl, eager):
+        assert int(r["has_group"]) == 1 and str(r["backend"]) == "nccl"
+        assert int(r["collectives"]) == gens                      # ONE all-gather per generation, really issued
+        for k in ("theta", "score", "score_orig", "mean"):
+            assert np.array_equal(r[k], plain[k]), k
+    # the captured path: two graphs per generation around the eager collective (unless this stack refused the capture, which the
+    # master survives by running eagerly -- then it must say why)
+    if int(rccl["use_graph"]):
+        assert int(rccl["two_graphs"]) == 1 and int(rccl["replays"]) == 2 * gens
+    else:
+        assert str(rccl["capture_error"]) != ""
+    assert int(eager["use_graph"]) == 0 and int(eager["replays"]) == 0
+    assert int(plain["use_graph"]) == 1 and int(plain["replays"]) == gens

@@ -2784,6 +2784,58 @@ def test_wavechain_plain_dqn_kernel_equals_gemm_queue_kernel_and_oracle(eng, orc
         assert np.array_equal(a[4][c], o["final_online"])
 
 
+@pytest.mark.parametrize("family", ["duelingddqn", "ddqn_mountaincar"])
+def test_published_big_net_shapes_with_a_two_layer_layer_norm_se_take_the_generic_kernel(eng, orc, family):
+    """the shape-specialised GEMM-queue instantiations (kDuelShapes[1] / [2]) hard-code a one-hidden-layer SE without LayerNorm.
+    A production launch of the published Acrobot DuelingDDQN / MountainCar DDQN agent shape on an SE built with `hidden_layer: 2,
+    use_layer_norm: True` fails the wave-chain predicate and must NOT match those instantiations either: its scores, counters, test means
+    and final parameters equal the launch with a step trace (always the generic kernel) and the oracle's chain."""
+    from learning_environments_amd import configs
+    from learning_environments_amd.agents.nes_common import chain_keys
+    from learning_environments_amd.config import ddqn_cfg_from_config
+    if family == "duelingddqn":
+        cfgd = configs.fixed_work(configs.acrobot_syn_env_duelingddqn(2), 2)
+        env, agent = "Acrobot-v1", "duelingddqn"
+    else:
+        cfgd = configs.fixed_work(configs.mountaincar_syn_env_ddqn(2), 2)
+        env, agent = "MountainCar-v0", "ddqn"
+    cfgd["agents"][agent]["init_episodes"] = 1
+    cfgd["envs"][env].update(max_steps=24, hidden_layer=2, use_layer_norm=True)
+    cfg = ddqn_cfg_from_config(cfgd)
+    ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=0)
+    assert (cfg.se_layers, cfg.se_layer_norm) == (2, 1)
+    S, A = cfg.state_dim, cfg.num_actions
+    chains = 3
+    rng = np.random.RandomState(9)
+    P_se = sum(orc.mlp_num_params(d) for d in orc.se_descs(S, A, cfg.se_hidden, 2, {0: "identity", 1: "relu", 2: "leakyrelu", 3: "tanh", 4: "prelu"}[cfg.se_act]))
+    theta = (rng.randn(P_se) * 0.1).astype(np.float32)
+    theta[-1] = -10.0                               # done_net's output bias: the SE never ends an episode
+    eps = (rng.randn(1, P_se) * 0.05).astype(np.float32)
+    worker = np.zeros(chains, np.int32)
+    sign = np.array([0.0, 1.0, -1.0], np.float32)
+    keys = chain_keys(79, 1, worker, np.arange(chains))
+
+    def run(trace_cap, init=None):
+        il = eng.InnerLoop(cfg, chains, trace_cap=trace_cap, want_final_online=True)
+        if init is None:
+            init = rng.uniform(-0.08, 0.08, (chains, il.p_agent)).astype(np.float32)
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return init, [t.cpu().numpy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_online)]
+
+    init, a = run(0)
+    _, b = run(2, init)
+    assert a[1][:, 2].min() >= 20
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+    w = (np.float32(sign[1]) * eps[0] + theta).astype(np.float32)
+    o = orc.ddqn_se_chain(ocfg, w, init[1], rng_key=int(keys[1]), want_final_online=True)
+    assert float(a[0][1]) == o["score"]
+    assert a[1][1].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+    assert np.array_equal(a[4][1], o["final_online"])
+
+
 @pytest.mark.parametrize("chains", [5, 10])
 def test_wavechain_dueling_team_agrees(eng, chains):
     """The DuelingDDQN wave-chain kernel with a chain on a team of two workgroups (blocks on four waves each, weight gradients dealt by

@@ -4,10 +4,10 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 cp learning_environments_amd/liblenv_hip.so /tmp/liblenv_hip_orig.so
+trap 'cp /tmp/liblenv_hip_orig.so learning_environments_amd/liblenv_hip.so' EXIT      # also when the run is interrupted
 for i in $(seq 1 ${3:-3}); do
   for v in $1 $2; do
     cp $v learning_environments_amd/liblenv_hip.so
     python bench.py --no-cpu-baseline --no-configs 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['value'],1), d['ms_per_step'])"
   done
 done
-cp /tmp/liblenv_hip_orig.so learning_environments_amd/liblenv_hip.so
