@@ -68,6 +68,14 @@ struct T3wCtx {
     int *tlen;
     float action_std;
     int max_steps;
+    // the team path's learn step (t3v_learn_step, one out-of-line routine per TD3.learn): the chain's arena and the offsets of its
+    // minibatch / exchange arrays, the replay ring, the chain's RNG key, the TD target's constants, the team's barrier words
+    float *arena;
+    int64_t a_xc, a_xn, a_xa, a_th, a_gx, a_replay;
+    int RS, same_xcd;
+    uint32_t key_lo, key_hi;
+    float gamma, policy_std, policy_clip;
+    unsigned *team_bar, *launch_dead;
 };
 
 // state-dict index inside ONE net (mlp_off order: W0 [128 x in] b0 W1 [128 x 128] b1 Wout [out x 128] bout) -> arena-layout index
@@ -656,6 +664,153 @@ template <int SHAPE> __device__ __noinline__ void t3w_test_steps(const T3wCtx *c
     __syncthreads();
 }
 
+// ---- TD3.learn (agents/TD3.py:63-116) of a team member with one or two sample blocks (G >= 3), as ONE out-of-line routine ----
+// The kernel body used to make these twelve calls itself: everything it keeps across an episode (counters, RNG state, the env's LDS
+// pointers, 64-bit arena pointers) was live across every one of them, and since the phase routines clobber all but eight VGPRs that
+// state went to scratch memory and came back piecemeal after each call.  Here nothing is live across a call except what is re-read
+// from the context record in LDS (two dozen ds_read per call site), and the kernel body has ONE call boundary per learn step.
+// Same operations in the same order as the inline version of rounds 3-4: bit-identical results.
+template <int SHAPE> __device__ __noinline__ void t3v_learn_step(const T3wCtx *ctx_, uint32_t learn_lo_, uint32_t learn_hi_, int size_after_)
+{
+    using namespace t3p;
+    constexpr T3wShape SP = kT3wShapes[SHAPE];
+    using EnvT = ContEnv<SP.env>;
+    constexpr int S = EnvT::S, A = EnvT::A, SA = S + A, B = T3W_B, ACT = SP.act;
+    typedef __attribute__((address_space(3))) const T3wCtx LCtx;
+    typedef __attribute__((address_space(3))) int lint;
+    const int tid = threadIdx.x;
+    const int64_t learn_it = (int64_t)(((uint64_t)uni((int)learn_hi_) << 32) | (uint32_t)uni((int)learn_lo_));
+    const int size_after = uni(size_after_);
+    // everything else comes from the context record, freshly at every use site (`cx()` hides the pointer from the optimiser so that no
+    // value read through it is carried across a call)
+    auto cx = [&]() -> LCtx * { const T3wCtx *p_ = ctx_; asm volatile("" : "+v"(p_)); return (LCtx *)uni_ptr(p_); };
+    struct Ptrs { float *params, *targets, *w2u; gfloat *xc, *xn, *xa, *thb, *gdq, *gdz; lfloat *q1, *q2, *tq1, *tq2, *rr, *dd, *dq1, *dq2, *dzl; };
+    auto ptrs = [&]() -> Ptrs {
+        LCtx *c = cx();
+        gfloat *ar = (gfloat *)uni_ptr(c->arena);      // (explicitly global: through a pointer read from LDS the accesses would be FLAT)
+        Ptrs r;
+        r.params = uni_ptr(c->params); r.targets = uni_ptr(c->targets); r.w2u = uni_ptr(c->w2u);
+        r.xc = ar + c->a_xc; r.xn = ar + c->a_xn; r.xa = ar + c->a_xa; r.thb = ar + c->a_th; r.gdq = ar + c->a_gx; r.gdz = r.gdq + 2 * B;
+        lfloat *qv = (lfloat *)uni_ptr(c->qvec);
+        r.q1 = qv; r.q2 = qv + B; r.tq1 = qv + 2 * B; r.tq2 = qv + 3 * B; r.rr = qv + 4 * B; r.dd = qv + 5 * B; r.dq2 = qv + 6 * B; r.dq1 = qv - B; r.dzl = qv;
+        return r;
+    };
+    auto team_barrier = [&]() {
+        LCtx *c = cx();
+        TeamSync ts{ uni_ptr(c->team_bar), uni_ptr(c->launch_dead), (volatile lint *)((lfloat *)uni_ptr(c->ctrl) + 32) + 5, 0u, uni(c->G), false, uni(c->same_xcd) != 0 };
+        wc::team_barrier<true>(ts, tid);
+    };
+    const int G = uni(cx()->G), g = uni(cx()->g);
+    const int gb0 = 32 * (T3W_NB / G) * g, gbn = 32 * (T3W_NB / G);
+    const uint64_t key = ((uint64_t)uni((int)cx()->key_hi) << 32) | (uint32_t)uni((int)cx()->key_lo);
+    {
+        // ReplayBuffer.sample: one (sample, row element) pair per thread; a team member gathers the rows of its own blocks
+        LCtx *c = cx();
+        const Ptrs P = ptrs();
+        const gfloat *rb = (const gfloat *)(uni_ptr(c->arena) + c->a_replay);
+        const int RS = uni(c->RS);
+#pragma unroll 4
+        for (int e = tid; e < gbn * (2 * S + A + 2); e += NT) {
+            const int b = gb0 + e / (2 * S + A + 2), i = e - (b - gb0) * (2 * S + A + 2);
+            const int64_t n = learn_it * B + b;
+            const int idx = (int)rng_replay_below(key, (uint64_t)n, (uint32_t)size_after);
+            const float v = rb[(int64_t)idx * RS + i];
+            if (i < SA) P.xc[b * SA + i] = v;                           // [s, a]
+            else if (i < SA + S) P.xn[b * SA + (i - SA)] = v;           // s' (the action part is filled by actor_target)
+            else if (i == SA + S) P.rr[b] = v;
+            else P.dd[b] = v;
+        }
+        __syncthreads();
+    }
+    // next_actions = (actor_target(s') + clamp(randn * policy_std)).clamp(-max, max) -- and, on the second quad, the policy step's
+    // actor(states) (TD3.py:97: the actor is not touched by the critic update, so its forward runs here, next to the target actor's)
+    {
+        const Ptrs P = ptrs();
+        for (int e = tid; e < gbn * S; e += NT) { const int b = gb0 + e / S, i = e - (b - gb0) * S; P.xa[b * SA + i] = P.xc[b * SA + i]; }
+        t3v_forward<ACT, S, A>(ctx_, 2, SA, 1, P.targets, (float *)P.xn, nullptr, -1, -1, P.params, (float *)P.xc, nullptr, TD_A_H1, TR_A_H2, (float *)P.xn, nullptr, (float *)P.xa, (float *)P.thb, SA, S);
+    }
+    {
+        LCtx *c = cx();
+        const Ptrs P = ptrs();
+        const float pstd = unif(c->policy_std), clipv = unif(c->policy_clip), ma = unif(c->ma);
+        for (int e = tid; e < gbn * A; e += NT) {
+            const int b = gb0 + e / A, k = e - (b - gb0) * A;
+            const int64_t n = (learn_it * B + b) * A + k;
+            const float zn = (float)det_normal(key, STREAM_TD3_POLICY_NOISE, (uint64_t)n);
+            float nz = zn * pstd;
+            nz = nz < -clipv ? -clipv : (nz > clipv ? clipv : nz);
+            const float v = P.xn[b * SA + S + k] + nz;
+            P.xn[b * SA + S + k] = v < -ma ? -ma : (v > ma ? ma : v);
+        }
+        __syncthreads();
+        // the twin target critics side by side on the two quads, then the twin critics
+        t3v_forward<ACT, SA, 1>(ctx_, 2, SA, 0, P.targets + PN, (float *)P.xn, (float *)P.tq1, -1, -1, P.targets + 2 * PN, (float *)P.xn, (float *)P.tq2, -1, -1, nullptr, nullptr, nullptr, nullptr, 0, 0);
+    }
+    {
+        const Ptrs P = ptrs();
+        t3v_forward<ACT, SA, 1>(ctx_, 2, SA, 0, P.params + PN, (float *)P.xc, (float *)P.q1, TD_C1_H1, TR_C1_H2, P.params + 2 * PN, (float *)P.xc, (float *)P.q2, TD_C2_H1, TR_C2_H2, nullptr, nullptr,
+                                nullptr, nullptr, 0, 0);
+    }
+    {
+        LCtx *c = cx();
+        const Ptrs P = ptrs();
+        const float g32 = unif(c->gamma);
+        const float norm = (float)(2.0 / (double)B);
+        for (int b = gb0 + tid; b < gb0 + gbn; b += NT) {
+            const float tq = P.tq1[b] < P.tq2[b] ? P.tq1[b] : P.tq2[b];
+            const float y = P.rr[b] + ((1.0f - P.dd[b]) * g32) * tq;
+            P.dq1[b] = norm * (P.q1[b] - y);
+            P.dq2[b] = norm * (P.q2[b] - y);
+            P.gdq[b] = P.dq1[b]; P.gdq[B + b] = P.dq2[b];      // the weight gradients need every row's value
+        }
+        __syncthreads();
+        // per-sample halves of the two critic backwards, side by side; then -- once the whole team is there -- the parameter gradients + the
+        // critic optimizer step as wave jobs over the team
+        t3v_backward<ACT, SA, 1>(ctx_, 2, P.params + PN, P.w2u + IMG, (float *)P.dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1,
+                                 P.params + 2 * PN, P.w2u + 2 * IMG, (float *)P.dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
+    }
+    team_barrier();
+    {
+        const Ptrs P = ptrs();
+        for (int b = tid; b < B; b += NT) { P.dq1[b] = P.gdq[b]; P.dq2[b] = P.gdq[B + b]; }
+        __syncthreads();
+        const T3vNet n1{ P.params + PN, P.w2u + IMG, (float *)P.dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1 };
+        const T3vNet n2{ P.params + 2 * PN, P.w2u + 2 * IMG, (float *)P.dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B };
+        t3v_wgrad<ACT, SA, 1, SA>(ctx_, 2, n1, n2, (float *)P.xc, SA, 20);                 // critic_optimizer (+ Polyak of the two critics)
+    }
+    // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1 (policy_delay 1); actor(states) is in xa since the
+    // start of the step
+    team_barrier();
+    {
+        const Ptrs P = ptrs();
+        t3v_forward<ACT, SA, 1>(ctx_, 1, SA, 0, P.params + PN, (float *)P.xa, (float *)P.dq2, TD_C1_H1, TR_C1_H2, P.params + PN, (float *)P.xa, (float *)P.dq2, -1, -1, nullptr, nullptr, nullptr, nullptr,
+                                0, 0);
+    }
+    {
+        const Ptrs P = ptrs();
+        const float dqa = -(1.0f / (float)B);
+        for (int b = tid; b < B; b += NT) P.dq1[b] = dqa;
+        __syncthreads();
+        t3v_backward<ACT, SA, 1>(ctx_, 1, P.params + PN, P.w2u + IMG, (float *)P.dq1, TD_C1_H1, TR_C1_H2, -1, -1,
+                                 P.params + PN, P.w2u + IMG, (float *)P.dq1, TD_C1_H1, TR_C1_H2, -1, -1, S, A, (float *)P.thb, (float *)P.dzl);
+    }
+    {
+        const Ptrs P = ptrs();
+        for (int e = tid; e < gbn * A; e += NT) P.gdz[gb0 * A + e] = P.dzl[gb0 * A + e];
+        t3v_backward<ACT, S, A>(ctx_, 1, P.params, P.w2u, (float *)P.dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B,
+                                P.params, P.w2u, (float *)P.dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
+    }
+    team_barrier();
+    {
+        const Ptrs P = ptrs();
+        for (int e = tid; e < B * A; e += NT) P.dzl[e] = P.gdz[e];
+        __syncthreads();
+        const T3vNet na{ P.params, P.w2u, (float *)P.dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B };
+        t3v_wgrad<ACT, S, A, SA>(ctx_, 1, na, na, (float *)P.xc, SA, 22);                  // actor_optimizer (+ Polyak of the actor)
+    }
+    team_barrier();
+}
+
 template <int SHAPE>
 __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
 {
@@ -777,7 +932,9 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     if (tid == 0) {
         T3wCtx cx{ bufA, bufB, sm_b, sm_wo, sm_bo, q1, dzl, sm_b2, sm_wo2, params, targets, grad, dumps, prelu, ma, g, G, w2u, misc,
                    (float)(1.0 - cfg.adam_beta1), (float)(1.0 - cfg.adam_beta2), (float)cfg.adam_beta2, (float)cfg.adam_eps, (float)cfg.tau,
-                   (float)(1.0 - cfg.tau), xt_d, ret, ep_rew, tlen, (float)cfg.action_std, cfg.max_steps };
+                   (float)(1.0 - cfg.tau), xt_d, ret, ep_rew, tlen, (float)cfg.action_std, cfg.max_steps,
+                   arena, a.a_xc, a.a_xn, a.a_xa, a.a_th, a.a_gx, a.a_replay, a.RS, 0, (uint32_t)a.rng_keys[chain], (uint32_t)(a.rng_keys[chain] >> 32),
+                   (float)cfg.gamma, (float)cfg.policy_std, (float)cfg.policy_std_clip, team_bar, reinterpret_cast<unsigned *>(a.arena + a.a_bar) + 8 };
         *ctx = cx;
     }
     __syncthreads();
@@ -824,6 +981,8 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         for (int m = 1; m < G; ++m) same = same && reinterpret_cast<unsigned *>(gdz)[m] == x0;
         team_barrier();                                    // everybody has read the ids before the exchange rows are reused
         tsync.same_xcd = same;
+        if (tid == 0) ctx->same_xcd = same ? 1 : 0;        // (the learn-step routine builds its barrier record from the context)
+        __syncthreads();
     }
     if (team_dead) {                                       // not all members became resident in time: nothing was computed
         if (a.out.status) atomicMin(&a.out.status[chain], -10);
@@ -1207,7 +1366,21 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
             TPT_MARK(0);
             if (learning) {
                 // ================= TD3.learn (TD3.py:63-116) =================
-                // ReplayBuffer.sample: one (sample, row element) pair per thread; a team member gathers the rows of its own blocks
+                if (G >= 3) {
+                    // ================= a member with one or two sample blocks: the team path (td3_wavechain_team.cuh) =================
+                    if (tid == 0) {                        // torch.optim.Adam's bias corrections of this step's two optimizer steps
+                        pows[0] *= cfg.adam_beta1; pows[1] *= cfg.adam_beta2; pows[2] *= cfg.adam_beta1; pows[3] *= cfg.adam_beta2;
+                        ctrl[20] = (float)(-(cfg.lr / (1.0 - pows[0]))); ctrl[21] = (float)__builtin_sqrt(1.0 - pows[1]);      // (12, 13: the reward net's phi values)
+                        ctrl[22] = (float)(-(cfg.lr / (1.0 - pows[2]))); ctrl[23] = (float)__builtin_sqrt(1.0 - pows[3]);
+                    }
+                    // replay gather, five forward calls, three backward chains, the two optimizer job phases and the four team barriers:
+                    // one out-of-line routine, so that this body has ONE call boundary per learn step (t3v_learn_step)
+                    t3v_learn_step<SHAPE>(ctx, (uint32_t)learn_it, (uint32_t)((uint64_t)learn_it >> 32), size_after);
+                    TPT_MARK(7);
+                    ++learn_it;
+                    act_lds_load();                        // the updated actor, for the next env steps / the test episode
+                    TPT_MARK(8);
+                } else {
                 const int gb0 = G == 1 ? 0 : 32 * (T3W_NB / G) * g, gbn = G == 1 ? B : 32 * (T3W_NB / G);
 #pragma unroll 4
                 for (int e = tid; e < gbn * (2 * S + A + 2); e += NT) {
@@ -1222,118 +1395,6 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 }
                 __syncthreads();
                 TPT_MARK(1);
-                if (G >= 3) {
-                    // ================= a member with one or two sample blocks: the team path (td3_wavechain_team.cuh) =================
-                    if (tid == 0) {                        // torch.optim.Adam's bias corrections of this step's two optimizer steps
-                        pows[0] *= cfg.adam_beta1; pows[1] *= cfg.adam_beta2; pows[2] *= cfg.adam_beta1; pows[3] *= cfg.adam_beta2;
-                        ctrl[20] = (float)(-(cfg.lr / (1.0 - pows[0]))); ctrl[21] = (float)__builtin_sqrt(1.0 - pows[1]);      // (12, 13: the reward net's phi values)
-                        ctrl[22] = (float)(-(cfg.lr / (1.0 - pows[2]))); ctrl[23] = (float)__builtin_sqrt(1.0 - pows[3]);
-                    }
-                    // next_actions = (actor_target(s') + clamp(randn * policy_std)).clamp(-max, max) -- and, on the second quad, the policy
-                    // step's actor(states) (TD3.py:97: the actor is not touched by the critic update, so its forward can run here, next to
-                    // the target actor's, instead of alone after the critics' optimizer step)
-                    // (the arena pointers are re-derived from scalar registers in front of every call -- TEAM_PTRS: held in the kernel's own
-                    // registers across the calls they were spilled to scratch memory, and every call started with a round trip to fetch them)
-                    {
-                    TEAM_PTRS;
-                    for (int e = tid; e < gbn * S; e += NT) { const int b = gb0 + e / S, i = e - (b - gb0) * S; xa[b * SA + i] = xc[b * SA + i]; }
-                    t3v_forward<ACT, S, A>(ctx, 2, SA, 1, targets, xn, nullptr, -1, -1, params, xc, nullptr, TD_A_H1, TR_A_H2, xn, nullptr, xa, thb, SA, S);
-                    }
-                    {
-                    TEAM_PTRS;
-                    for (int e = tid; e < gbn * A; e += NT) {
-                        const int b = gb0 + e / A, k = e - (b - gb0) * A;
-                        const int64_t n = (learn_it * B + b) * A + k;
-                        const float zn = (float)det_normal(key, STREAM_TD3_POLICY_NOISE, (uint64_t)n);
-                        float nz = zn * (float)cfg.policy_std;
-                        const float clipv = (float)cfg.policy_std_clip;
-                        nz = nz < -clipv ? -clipv : (nz > clipv ? clipv : nz);
-                        const float v = xn[b * SA + S + k] + nz;
-                        xn[b * SA + S + k] = v < -ma ? -ma : (v > ma ? ma : v);
-                    }
-                    __syncthreads();
-                    TPT_MARK(2);
-                    // the twin target critics side by side on the two quads, then the twin critics
-                    t3v_forward<ACT, SA, 1>(ctx, 2, SA, 0, targets + PN, xn, tq1, -1, -1, targets + 2 * PN, xn, tq2, -1, -1, nullptr, nullptr, nullptr, nullptr, 0, 0);
-                    }
-                    {
-                    TEAM_PTRS;
-                    t3v_forward<ACT, SA, 1>(ctx, 2, SA, 0, params + PN, xc, q1, TD_C1_H1, TR_C1_H2, params + 2 * PN, xc, q2, TD_C2_H1, TR_C2_H2, nullptr, nullptr,
-                                            nullptr, nullptr, 0, 0);
-                    }
-                    TPT_MARK(3);
-                    {
-                    TEAM_PTRS;
-                    {
-                        const float norm = (float)(2.0 / (double)B);
-                        for (int b = gb0 + tid; b < gb0 + gbn; b += NT) {
-                            const float tq = tq1[b] < tq2[b] ? tq1[b] : tq2[b];
-                            const float y = rr[b] + ((1.0f - dd[b]) * g32) * tq;
-                            dq1[b] = norm * (q1[b] - y);
-                            dq2[b] = norm * (q2[b] - y);
-                            gdq[b] = dq1[b]; gdq[B + b] = dq2[b];      // the weight gradients need every row's value
-                        }
-                    }
-                    __syncthreads();
-                    TPT_MARK(4);
-                    // per-sample halves of the two critic backwards, side by side; then -- once the whole team is there -- the parameter
-                    // gradients + the critic optimizer step as wave jobs over the team
-                    t3v_backward<ACT, SA, 1>(ctx, 2, params + PN, w2u + IMG, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1,
-                                             params + 2 * PN, w2u + 2 * IMG, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
-                    }
-                    team_barrier();
-                    {
-                    TEAM_PTRS;
-                    for (int b = tid; b < B; b += NT) { dq1[b] = gdq[b]; dq2[b] = gdq[B + b]; }
-                    __syncthreads();
-                    {
-                        const T3vNet n1{ params + PN, w2u + IMG, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1 };
-                        const T3vNet n2{ params + 2 * PN, w2u + 2 * IMG, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B };
-                        t3v_wgrad<ACT, SA, 1, SA>(ctx, 2, n1, n2, xc, SA, 20);                 // critic_optimizer (+ Polyak of the two critics)
-                    }
-                    }
-                    TPT_MARK(5);
-                    ++learn_it;
-                    // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1 (policy_delay 1); actor(states) is in
-                    // xa since the start of the step
-                    team_barrier();
-                    TPT_MARK(6);
-                    {
-                    TEAM_PTRS;
-                    t3v_forward<ACT, SA, 1>(ctx, 1, SA, 0, params + PN, xa, dq2, TD_C1_H1, TR_C1_H2, params + PN, xa, dq2, -1, -1, nullptr, nullptr, nullptr, nullptr,
-                                            0, 0);
-                    }
-                    {
-                        const float dqa = -(1.0f / (float)B);
-                        for (int b = tid; b < B; b += NT) dq1[b] = dqa;
-                    }
-                    __syncthreads();
-                    {
-                    TEAM_PTRS;
-                    t3v_backward<ACT, SA, 1>(ctx, 1, params + PN, w2u + IMG, dq1, TD_C1_H1, TR_C1_H2, -1, -1,
-                                             params + PN, w2u + IMG, dq1, TD_C1_H1, TR_C1_H2, -1, -1, S, A, thb, dzl);
-                    }
-                    {
-                    TEAM_PTRS;
-                    for (int e = tid; e < gbn * A; e += NT) gdz[gb0 * A + e] = dzl[gb0 * A + e];
-                    t3v_backward<ACT, S, A>(ctx, 1, params, w2u, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B,
-                                            params, w2u, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
-                    }
-                    team_barrier();
-                    {
-                    TEAM_PTRS;
-                    for (int e = tid; e < B * A; e += NT) dzl[e] = gdz[e];
-                    __syncthreads();
-                    {
-                        const T3vNet na{ params, w2u, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B };
-                        t3v_wgrad<ACT, S, A, SA>(ctx, 1, na, na, xc, SA, 22);                  // actor_optimizer (+ Polyak of the actor)
-                    }
-                    }
-                    TPT_MARK(7);
-                    team_barrier();
-                    act_lds_load();                        // the updated actor, for the next env steps / the test episode
-                    TPT_MARK(8);
-                } else {
                 // next_actions = (actor_target(s') + clamp(randn * policy_std)).clamp(-max, max)
                 t3w_forward<ACT, S, A>(ctx, targets, xn, SA, 1, nullptr, xn, SA, S, nullptr, -1, -1, -1);
                 for (int e = tid; e < B * A; e += NT) {
