@@ -566,7 +566,7 @@ def run_rank(args):
                   "ms_per_step": sdt / args.steps * 1e3, "kernel_ms": skernel_ms,
                   "workgroups_per_chain": team_size(smaster),
                   "note": "a chain's %d serial learn steps bound the generation; launches that under-fill the GPU run every chain on a "
-                          "team of workgroups (DESIGN.md section 5), which shortens a learn step by 7-11 %%, not by the team "
+                          "team of workgroups (DESIGN.md section 5), which shortens a learn step by 6-10 %%, not by the team "
                           "size" % (TRAIN_EPISODES * 200)}
     others = None
     if world == 1 and not plumbing and not args.no_configs:
@@ -617,7 +617,7 @@ def run_rank(args):
                                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                                 "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": kernel_ms,
                                 "note": "latency/issue-bound small-MLP chains: weights+activations live in LDS, only the replay "
-                                        "buffer touches HBM/L2 (see DESIGN.md); the binding resources are VALU issue and the LDS pipe together (DESIGN.md section 8, add-work experiment), see roofline_valu"}
+                                        "buffer touches HBM/L2 (see DESIGN.md); the binding resource is vector-instruction issue (DESIGN.md section 5, docs/notebook_r05.md section 1), see roofline_valu"}
             busy = min(chains, 256)
             line["roofline_valu"] = {"bound": "valu issue (fp32 vector)", "kernel": "ddqn_se_inner_kernel", "achieved": tflops,
                                      "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VALU_PEAK_TFLOPS,

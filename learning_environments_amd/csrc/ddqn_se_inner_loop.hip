@@ -12,7 +12,7 @@
 //        early-out                            agents/base_agent.py:49-62,141-148
 //     final BaseAgent.test, statistics.mean   agents/GTN_worker.py:199-209
 //
-// Design (DESIGN.md "Kernel K-inner"): the whole chain runs inside one launch of 12 waves.  SE weights
+// Design: the whole chain runs inside one launch of 12 waves.  SE weights
 // (theta + sign*eps), the Q-net, its target, and all minibatch activations live in LDS; Adam state and
 // master copies of the Q parameters live in the owning thread's registers; only the replay buffer is in
 // HBM/L2.  Per training step: the last wave acts + steps the SE + appends the transition while the other waves

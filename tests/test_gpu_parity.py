@@ -1910,7 +1910,7 @@ def test_inner_loop_with_and_without_trace_agree(eng, orc, golden, env_name, hq,
 def test_inner_loop_split_forward_layouts(eng, orc, golden, env_name, hq, batch, act, split):
     """Minibatches of more than 170 samples spill forward items into the third wave of SIMDs 0 / 1; the kernel cuts those items
     into 2, 3 or 4 parts over the hidden-unit pairs, shares their activations between the four third waves and runs their output
-    layers from LDS rows (split layout).  Every cut (and the fall-back for nets too narrow to cut) must
+    layers from LDS rows (docs/notebook_r01_r04.md, split layout).  Every cut (and the fall-back for nets too narrow to cut) must
     leave the bits alone: whole chains against the oracle."""
     cfgd = json.loads(str(golden("g8_calc_score_cartpole_a")["config_json"]))
     if env_name == "Acrobot-v1":

@@ -1,8 +1,8 @@
-// Microbenchmark behind DESIGN.md section 9 "next (a)": the minibatch forward's hidden-unit pair loop of the DDQN kernel (4-57-2 tanh net,
+// Microbenchmark behind docs/notebook_r01_r04.md section 9 "next (a)": the minibatch forward's hidden-unit pair loop of the DDQN kernel (4-57-2 tanh net,
 // pair records + 16 bank-private copies of the canonical tanh table in LDS, packed fp32 math, gathers one or two pairs ahead), run by
 //   W waves per workgroup (one workgroup per CU), each lane carrying I items that share every broadcast weight read,
 // for (W, I) = (12, 1) [today's occupancy: 168 VGPRs], (8, 1), (8, 2), (4, 2), (4, 4) [256 / 512 VGPRs].
-// Prints cycles per (64 items x 1 pair) per CU -- the currency of DESIGN.md section 8 -- so that "two items per lane at two waves per SIMD"
+// Prints cycles per (64 items x 1 pair) per CU -- the currency of docs/notebook_r01_r04.md section 8 -- so that "two items per lane at two waves per SIMD"
 // can be priced before the kernel is restructured.  Same instruction mix as the kernel's steady-state stage; results are checksummed only.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -I learning_environments_amd/csrc tools/ubench/fwd_pair_loop.hip -o /tmp/fwd_pair_loop
 #include <hip/hip_runtime.h>
