@@ -587,7 +587,7 @@ def run_rank(args):
                       "collective_ran": bool(getattr(master, "collectives_run", 0) > 0),
                       "collectives_per_generation": (1 if getattr(master, "collectives_run", 0) > 0 else 0),
                       "team_fallbacks": int(getattr(master, "team_fallbacks", 0)),
-                      "launcher": "bench.py child processes" if os.environ.get("LENV_BENCH_SPAWNED") else ("torchrun/env" if world > 1 else "single process")},
+                      "launcher": "bench.py child processes" if os.environ.get("LENV_BENCH_SPAWNED") else ("torchrun/env" if grouped else "single process")},
             "weak": {"value": total_evals / dt, "global_pop": POP * world, "workers_per_gpu": POP, "ms_per_step": dt / args.steps * 1e3},
             "strong": strong if strong is not None else {"value": total_evals / dt, "global_pop": POP, "workers_per_gpu": POP,
                                                          "ms_per_step": dt / args.steps * 1e3, "note": "N=1: identical to weak"},
