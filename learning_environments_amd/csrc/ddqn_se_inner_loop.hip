@@ -1199,20 +1199,29 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                                                     + (int64_t)(learn_it & 1) * LV(n_chunks4) * P;
                     const unsigned want_tag = (unsigned)(learn_it + 1);
                     const int lo = mc0 * P, hi = mc1 * P, tot = LV(n_chunks) * P;
-                    // (four granules per thread in flight at once instead of one after the other measured SLOWER, 1.09x instead of 1.11-1.17x over
-                    // one workgroup per chain: the reader is usually early, and a batch that fails is re-polled granule by granule anyway)
-                    for (int i = tid; i < tot - (hi - lo); i += NT) {
-                        const int e = i < lo ? i : i + (hi - lo);
-                        unsigned long long v = 0;
+                    // Granules are fetched in PAIRS (one 16-byte load: n_chunks4 * P is even and the area is 64-byte aligned, so pair q = granules
+                    // 2q, 2q+1 never straddles the two parity copies): half the dependent L2 round trips of the granule-by-granule loop of
+                    // rounds 3-4, which cost 3.5 k of the 6.9 k cycles of a team member's gradient interval (tools/phase_timing.py, 24 chains).
+                    // A pair may contain one of this member's own granules (written by its own gradient waves a moment ago): it is polled like
+                    // any other and not copied.  (All of a parameter's foreign partials in flight at once -- twelve 8-byte loads per thread --
+                    // was built twice, inline and out of line: the two dozen registers put spill reloads into the forward's pair loop, 26.6 ->
+                    // 32.3 ms per generation at 24 chains.)
+                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                    const int npairs_x = (tot + 1) >> 1;
+                    for (int q = tid; q < npairs_x; q += NT) {
+                        const int e0 = 2 * q, e1 = e0 + 1;
+                        const bool need0 = e0 < lo || e0 >= hi, need1 = e1 < tot && (e1 < lo || e1 >= hi);
+                        if (!need0 && !need1) continue;
+                        u32x4 v = {0u, 0u, 0u, 0u};
                         unsigned spins = 0;
                         unsigned long long w0 = 0;
+                        const u32x4 *src = reinterpret_cast<const u32x4 *>(xs_ + e0);
                         while (!team_dead) {
-                            v = __hip_atomic_load(xs_ + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((unsigned)(v >> 32) == want_tag) break;
+                            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(src) : "memory");
+                            if ((!need0 || v.y == want_tag) && (!need1 || v.w == want_tag)) break;
                             __builtin_amdgcn_s_sleep(1);
-                            // give up after LENV_TEAM_GIVEUP_TICKS_RUN (the team has assembled by now; or as soon as another member of the chain has), for good: a thread that gave
-                            // up never polls again, so a team whose members are not all running costs each thread one time-out (all threads
-                            // at once), not one per learn step
+                            // give up after LENV_TEAM_GIVEUP_TICKS_RUN (the team has assembled by now; or as soon as another member of the chain
+                            // has), for good: a thread that gave up never polls again
                             if ((++spins & 63u) == 0u) {
                                 const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                                 if (w0 == 0) w0 = now;
@@ -1221,7 +1230,8 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                                 }
                             }
                         }
-                        part[e] = __uint_as_float((unsigned)v);
+                        if (need0) part[e0] = __uint_as_float(v.x);
+                        if (need1) part[e1] = __uint_as_float(v.z);
                     }
                 }
                 __syncthreads();                               // B4
