@@ -41,8 +41,8 @@ constexpr int MAX_PPT = 2;        // Q-net parameters owned per thread (P_agent 
 #define LENV_DDQN_PRIO_T1 12
 #define LENV_DDQN_PRIO_T2 22
 #endif
-#ifndef LENV_DDQN_GPRIO
-#define LENV_DDQN_GPRIO 0
+#ifndef LENV_DDQN_TEAM_GRP
+#define LENV_DDQN_TEAM_GRP 4
 #endif
 
 // Diagnostic build only (-DLENV_PHASE_TIMING): per-phase shader-clock totals of chain 0, never in the shipped library.
@@ -1110,52 +1110,23 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
                         const float *hp = hB + (jv ? j : 0) + b0 * HP, *dqp = dqB + 4 * b0 + vzero, *sp = sB + SP * b0 + vzero;
                         int bq = b0;
-#if LENV_DDQN_GPRIO
-                        // same idea in the gradient interval: a wave's priority falls as its chunk runs out
-                        __builtin_amdgcn_s_setprio(2);
-                        const int bq_a = b0 + ((b1 - b0) / 3 & ~3), bq_b = b0 + (2 * (b1 - b0) / 3 & ~3);
+                        // whole groups of GRP samples: every LDS read of a group is issued before the first use.  (A TEAM member's gradient
+                        // wave is alone on its SIMD and its 17-sample loop is a chain of five LDS round trips, 3.4 k cycles; groups of six /
+                        // eight for it -- LENV_DDQN_TEAM_GRP -- were measured SLOWER, 25.9 -> 26.7 / 29.5 ms at 24 chains: the kernel sits at the
+                        // 168-VGPR cap of a 12-wave workgroup and the extra live registers come back as spill reloads in the forward.)
+                        constexpr int GRP = TEAM ? LENV_DDQN_TEAM_GRP : 4;
 #pragma unroll 1
-                        for (; bq + 4 <= bq_a; bq += 4, hp += 4 * HP, dqp += 16, sp += 4 * SP) {
-                            float hv[4], sv[4][SP];
-                            float4 dmv[4];
+                        for (; bq + GRP <= b1; bq += GRP, hp += GRP * HP, dqp += 4 * GRP, sp += GRP * SP) {
+                            float hv[GRP], sv[GRP][SP];
+                            float4 dmv[GRP];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
+                            for (int u = 0; u < GRP; ++u) {
                                 hv[u] = hp[u * HP];
                                 dmv[u] = *reinterpret_cast<const float4 *>(dqp + 4 * u);
                                 load_s(sp + SP * u, sv[u]);
                             }
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) accumulate(hv[u], dmv[u], sv[u]);
-                        }
-                        __builtin_amdgcn_s_setprio(1);
-#pragma unroll 1
-                        for (; bq + 4 <= bq_b; bq += 4, hp += 4 * HP, dqp += 16, sp += 4 * SP) {
-                            float hv[4], sv[4][SP];
-                            float4 dmv[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                hv[u] = hp[u * HP];
-                                dmv[u] = *reinterpret_cast<const float4 *>(dqp + 4 * u);
-                                load_s(sp + SP * u, sv[u]);
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) accumulate(hv[u], dmv[u], sv[u]);
-                        }
-                        __builtin_amdgcn_s_setprio(0);
-#endif
-#pragma unroll 1
-                        for (; bq + 4 <= b1; bq += 4, hp += 4 * HP, dqp += 16, sp += 4 * SP) {
-                            // whole groups of four samples: every LDS read is issued before the first use
-                            float hv[4], sv[4][SP];
-                            float4 dmv[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                hv[u] = hp[u * HP];
-                                dmv[u] = *reinterpret_cast<const float4 *>(dqp + 4 * u);
-                                load_s(sp + SP * u, sv[u]);
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) accumulate(hv[u], dmv[u], sv[u]);
+                            for (int u = 0; u < GRP; ++u) accumulate(hv[u], dmv[u], sv[u]);
                         }
                         for (; bq < b1; ++bq, hp += HP, dqp += 4, sp += SP) {       // chunk tail
                             float sv[SP];
