@@ -43,8 +43,9 @@ enum { LENV_ENV_CARTPOLE = 0, LENV_ENV_ACROBOT = 1, LENV_ENV_CHEETAH_STANDIN = 2
 enum { LENV_RNG_COUNTER = 0, LENV_RNG_TAPE = 1 };
 /* lenv_ddqn_cfg / lenv_td3_cfg `kernel_variant` bits (0 = the fastest kernel that takes the launch; the bits exist for A/B timing and for
  * the parity tests that hold the kernels against each other -- every variant produces the same bits):
- * NO_WAVECHAIN keeps the GEMM-queue kernel where a wave-chain kernel exists, GENERIC skips the shape-specialised instantiations. */
-enum { LENV_VARIANT_NO_WAVECHAIN = 1, LENV_VARIANT_GENERIC = 2 };
+ * NO_WAVECHAIN keeps the GEMM-queue kernel where a wave-chain kernel exists, GENERIC skips the shape-specialised instantiations,
+ * TEAM_NARROW keeps whole forward items per lane in DDQN teams of three and more (default there: every item cut over the idle lanes). */
+enum { LENV_VARIANT_NO_WAVECHAIN = 1, LENV_VARIANT_GENERIC = 2, LENV_VARIANT_TEAM_NARROW = 4 };
 
 /* models/model_utils.py:4-39 */
 typedef struct {

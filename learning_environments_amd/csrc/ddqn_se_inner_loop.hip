@@ -44,6 +44,15 @@ constexpr int MAX_PPT = 2;        // Q-net parameters owned per thread (P_agent 
 #ifndef LENV_DDQN_TEAM_GRP
 #define LENV_DDQN_TEAM_GRP 4
 #endif
+#ifndef LENV_DDQN_WIDE_GRP
+#define LENV_DDQN_WIDE_GRP 4                              // samples per group of a TWIDE gradient wave (all LDS reads of a group in flight)
+#endif
+#ifndef LENV_DDQN_WIDE_NPF
+#define LENV_DDQN_WIDE_NPF 4                              // granule pairs per thread in flight in the TWIDE exchange
+#endif
+#ifndef LENV_DDQN_WIDE_CB
+#define LENV_DDQN_WIDE_CB 10                              // hidden-unit pairs per block of the WIDE output-layer chains (all reads of a block in flight)
+#endif
 
 // Diagnostic build only (-DLENV_PHASE_TIMING): per-phase shader-clock totals of chain 0, never in the shipped library.
 #ifdef LENV_PHASE_TIMING
@@ -334,9 +343,13 @@ __device__ __forceinline__ void real_env_obs(const double (&st)[4], float (&obs)
 // partials in the chain's exchange buffer, the members meet at ONE agent-scope barrier per learn step, read the other members'
 // partials, and each applies the same Adam step to its own copy of the parameters.  The partials are summed in chunk order by
 // every member, so the bits are those of the one-workgroup launch for every G.
-template <int ENV, int S, int A, int QACT, int PPT, int SHAPE = 0, bool TEAM = false>
+// TWIDE = the TEAM instantiation for teams of three and more (every forward item cut over the idle lanes, see `wide` below): a separate
+// instantiation, so that neither carries the other's forward code -- the kernel sits at the 168-VGPR cap of a 12-wave workgroup, and
+// every extra code path showed up as spill reloads in all of them.
+template <int ENV, int S, int A, int QACT, int PPT, int SHAPE = 0, bool TEAM = false, bool TWIDE = false>
 __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 {
+    static_assert(!TWIDE || TEAM, "TWIDE is a TEAM layout");
     extern __shared__ __align__(16) float lds[];
     const lenv_ddqn_cfg &cfg = a.cfg;
     constexpr bool FIXED = SHAPE != 0;
@@ -471,24 +484,45 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     // TEAM: a member of a team of two has 3 Bm = ~300 items = four full waves (one per SIMD) and a fifth, part-filled one that would
     // make SIMD 0 carry two; those spilled items are cut four ways over waves 4 .. 7, which have nothing else to do in the interval
     // (the same machinery, one SIMD-round earlier; bigger teams have at most one forward wave per SIMD anyway)
-    const bool tsplit = TEAM && 3 * Bm > 256 && 3 * Bm - 256 <= 64 && 3 * Bm - 256 <= LV(split_L) && 2 * Bm <= 256 && LV(split_D) > 0;
+    const bool tsplit = TEAM && !TWIDE && 3 * Bm > 256 && 3 * Bm - 256 <= 64 && 3 * Bm - 256 <= LV(split_L) && 2 * Bm <= 256 && LV(split_D) > 0;
+    // TEAM, three and more members (WIDE): a member has at most 204 items -- two to four waves, each ALONE on its SIMD, and an item's 29
+    // pair stages are a chain of dependent LDS round trips (7.3 k cycles per learn step at G = 6, tools/phase_timing.py) while eight waves
+    // idle.  So EVERY item is cut WIDE_D ways over the hidden-unit pairs: lane u < 3 Bm WIDE_D computes the activations of part u / (3 Bm)
+    // of item u % (3 Bm) into an LDS row with a branch-free pipelined loop of the same trip count in every lane (the parts overlap by a
+    // pair or two where the pair count does not divide: identical values to identical words); ONE workgroup barrier; then lane t < 3 Bm
+    // runs item t's output layer -- the sequential piece, k ascending -- from its row.  Rows: pass 0 in the sample's own h row (the backward
+    // needs it there), passes 1 / 2 in h rows of samples this member does not own (3 Bm <= B) or, pass 2, in the split layout's rows.
+    // Same operations on the same values in the same order: the bits do not change.
+    const int WIDE_L = 3 * Bm;
+    const int WIDE_CAP = (NW - 1) * 64;                     // lanes next to the env wave
+    const int WIDE_D = TWIDE ? (6 * WIDE_L <= WIDE_CAP ? 6 : (5 * WIDE_L <= WIDE_CAP ? 5 : (4 * WIDE_L <= WIDE_CAP ? 4 : 3))) : 0;
+    const bool wide = TWIDE;                                // (the host launches TWIDE exactly when ddqn_team_wide_ok() holds for every member)
     const int SPLIT_D = TEAM ? (tsplit ? 4 : 0) : LV(split_D), SPLIT_L = TEAM ? (tsplit ? 3 * Bm - 256 : 0) : LV(split_L);
     const bool split = SPLIT_D > 0;
     constexpr int SPLIT_W0 = TEAM ? 4 : NW - 4;          // first of the four waves that share the spilled items' activations
     constexpr int SPLIT_T0 = SPLIT_W0 * 64;
     const int split_u = tid - SPLIT_T0;                  // lane number inside them
-    const bool h_lane = split && split_u >= 0 && split_u < SPLIT_L * SPLIT_D;
-    const int split_li = h_lane ? split_u % SPLIT_L : 0, split_part = h_lane ? split_u / SPLIT_L : 0;
-    const bool chain_lane = split && split_u >= 0 && tid < 3 * Bm;
-    const bool split_wave = split && wave >= SPLIT_W0 && wave < SPLIT_W0 + 4;
-    const int fwd_pass = (split && split_u >= 0) ? 2 : (tid < Bm ? 0 : (tid < 2 * Bm ? 1 : 2));
-    const int fwd_b = (split && split_u >= 0) ? mb0 + SPLIT_T0 + split_li - 2 * Bm : mb0 + tid - fwd_pass * Bm;
-    const bool full_item = split ? tid < SPLIT_T0 : tid < 3 * Bm;  // runs all pairs of its item, output layer included
+    const bool h_lane = wide ? tid < WIDE_L * WIDE_D : (split && split_u >= 0 && split_u < SPLIT_L * SPLIT_D);
+    const int wide_item = wide && h_lane ? tid % WIDE_L : 0;
+    const int split_li = wide ? wide_item % Bm : (h_lane ? split_u % SPLIT_L : 0), split_part = wide ? (h_lane ? tid / WIDE_L : 0) : (h_lane ? split_u / SPLIT_L : 0);
+    const bool chain_lane = !wide && split && split_u >= 0 && tid < 3 * Bm;
+    const bool split_wave = !wide && split && wave >= SPLIT_W0 && wave < SPLIT_W0 + 4;
+    const int fwd_pass = wide ? wide_item / Bm : ((split && split_u >= 0) ? 2 : (tid < Bm ? 0 : (tid < 2 * Bm ? 1 : 2)));
+    const int fwd_b = wide ? mb0 + split_li : ((split && split_u >= 0) ? mb0 + SPLIT_T0 + split_li - 2 * Bm : mb0 + tid - fwd_pass * Bm);
+    const bool full_item = !wide && (split ? tid < SPLIT_T0 : tid < 3 * Bm);  // runs all pairs of its item, output layer included
     const bool fwd_active = full_item || h_lane;          // samples a replay row
+    // WIDE: the LDS row that holds the activations of (pass, sample index bi inside the member's share)
+    auto wide_row = [&](int pass, int bi) -> float * {
+        if (pass == 0) return hB + (mb0 + bi) * HP;
+        if (pass == 2 && 3 * Bm > B) return lds + LV(o_hX) + bi * HP;
+        int r = mb0 + Bm + (pass == 1 ? bi : Bm + bi);   // the (pass - 1) Bm + bi-th row behind the member's own, wrapping
+        if (r >= B) r -= B;
+        return hB + r * HP;
+    };
 
     // speculation layout: waves without forward items (at most the last two) evaluate the SE for every action of the
     // NEXT step while the other waves run the minibatch forwards; the env wave then only has to pick a candidate.
-    const int n_fwd_waves = (3 * Bm + 63) >> 6;
+    const int n_fwd_waves = ((wide ? WIDE_L * WIDE_D : 3 * Bm) + 63) >> 6;
     const int first_spec = n_fwd_waves > NW - 2 ? n_fwd_waves : NW - 2;
     const int n_spec = NW - first_spec;                 // 0, 1 or 2 (uniform)
     bool spec_valid = false;
@@ -778,7 +812,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     float x[S];
 #pragma unroll
                     for (int i = 0; i < S; ++i) x[i] = fwd_pass == 0 ? row[i] : row[S + 1 + i];
-                    if (full_item && fwd_pass == 0) {
+                    if ((full_item || (wide && split_part == 0)) && fwd_pass == 0) {
                         // the sample's state / reward / done / action for the TD error and the backward: stored BEFORE the pair loop, so that
                         // the row's registers are dead inside it
 #pragma unroll
@@ -798,7 +832,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     const float4 *W4 = reinterpret_cast<const float4 *>(W);
                     const int Hqf = FIXED ? FIX_HQ : Hq;                            // literal only here: pair count and tail of this loop
                     const int npairs = (Hqf + 1) >> 1;
-                    float *hrow = full_item ? hB + fwd_b * HP : lds + LV(o_hX) + split_li * HP;
+                    float *hrow = wide ? wide_row(fwd_pass, split_li) : (full_item ? hB + fwd_b * HP : lds + LV(o_hX) + split_li * HP);
                     float4 r1[N1], r2[N2];
                     auto load1 = [&](int jp) {
 #pragma unroll
@@ -909,6 +943,24 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         if (jp < npairs) finish(pa, jp, 2 * jp + 1 < Hqf, F{});
 #pragma unroll
                         for (int aa = 0; aa < A; ++aa) qres[(fwd_pass * MAX_B + fwd_b) * A + aa] = q[aa] + W[npairs * PR + aa];
+                    } else if (wide) {
+                        // WIDE h-only lane: `len` pairs from p0 on, the same trip count in every lane and no condition in the loop (a pair is
+                        // always stored whole: for an odd width the second word of the last pair is the row's pad word; loads past the last
+                        // record are clamped, the activation issued past the part's end is never finished)
+                        const int len = (npairs + WIDE_D - 1) / WIDE_D, last = npairs - 1;
+                        int jp = split_part * len < npairs - len ? split_part * len : npairs - len;
+                        auto wstage = [&](ActPipe2<QACT> &cur, ActPipe2<QACT> &nxt) {
+                            nxt.issue(tanh_tab, tl, layer1());                                  // r1 holds pair jp + 1 (clamped)
+                            load1(jp + 2 < last ? jp + 2 : last);
+                            *reinterpret_cast<v2f *>(hrow + 2 * jp) = cur.finish(cfg.q_prelu);
+                            ++jp;
+                        };
+                        load1(jp);
+                        pa.issue(tanh_tab, tl, layer1());
+                        load1(jp + 1 < last ? jp + 1 : last);
+#pragma unroll 1
+                        for (int i = 0; i + 2 <= len; i += 2) { wstage(pa, pb); wstage(pb, pa); }
+                        if (len & 1) *reinterpret_cast<v2f *>(hrow + 2 * jp) = pa.finish(cfg.q_prelu);
                     } else {
                         // split layout, h-only lane: the activations of pairs [p0, p1) of its item
                         const int sd = SPLIT_D > 0 ? SPLIT_D : 1, p0 = split_part * npairs / sd, p1 = (split_part + 1) * npairs / sd;
@@ -997,6 +1049,72 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     }
                 }
                 if (split_wave) __builtin_amdgcn_s_setprio(0);
+                if (wide) {
+                    // every wave with h-only lanes counts itself in (LDS atomic behind a release fence: its rows are written); the chain
+                    // waves wait for this step's count.  No workgroup barrier: the env and speculation waves go their own way.
+                    const int n_hw = (WIDE_L * WIDE_D + 63) >> 6;
+                    if (wave < n_hw && lane == 0) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __hip_atomic_fetch_add((lds_int *)(ctrl + 3), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    if (wave < ((WIDE_L + 63) >> 6)) {
+                        const int want_cnt = n_hw * (learn_it + 1);
+                        while (*(volatile lds_int *)((lds_int *)(ctrl + 3)) < want_cnt) __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+                    if (tid < WIDE_L) {
+                        // output layer of item tid = (pass, sample): the canonical chain over all hidden units, h from the item's row, in
+                        // blocks of eight pairs with every LDS read of a block in flight before its first use
+                        constexpr int N1 = OW2 / 4, N2 = (PR - OW2) / 4, PR4 = PR / 4;
+                        const int cpass = tid / Bm, cbi = tid - cpass * Bm;
+                        const float *Wc = cpass == 2 ? q_tgt : q_onl;
+                        const float4 *W4 = reinterpret_cast<const float4 *>(Wc);
+                        const int Hqf = FIXED ? FIX_HQ : Hq;
+                        const int npairs = (Hqf + 1) >> 1;
+                        const float *hx = wide_row(cpass, cbi);
+                        float q[A];
+#pragma unroll
+                        for (int aa = 0; aa < A; ++aa) q[aa] = 0.0f;
+                        constexpr int CB = LENV_DDQN_WIDE_CB;
+#pragma unroll 1
+                        for (int j0 = 0; j0 < npairs; j0 += CB) {
+                            v2f hv[CB];
+                            float4 wv[CB][N2];
+#pragma unroll
+                            for (int u = 0; u < CB; ++u) {
+                                const int jp = j0 + u < npairs ? j0 + u : npairs - 1;            // (clamped reads, unused)
+                                hv[u] = *reinterpret_cast<const v2f *>(hx + 2 * jp);             // (the odd tail's second word is never used)
+#pragma unroll
+                                for (int v = 0; v < N2; ++v) wv[u][v] = W4[jp * PR4 + N1 + v];
+                            }
+#pragma unroll
+                            for (int u = 0; u < CB; ++u) {
+                                const int jp = j0 + u;
+                                if (jp < npairs) {
+                                    const bool two = 2 * jp + 1 < Hqf;
+                                    float w2[PR - OW2];
+#pragma unroll
+                                    for (int v = 0; v < N2; ++v) { w2[4 * v] = wv[u][v].x; w2[4 * v + 1] = wv[u][v].y; w2[4 * v + 2] = wv[u][v].z; w2[4 * v + 3] = wv[u][v].w; }
+                                    if constexpr (A == 2) {
+                                        v2f qq = {q[0], q[1]};
+                                        qq = fma2((v2f){hv[u].x, hv[u].x}, (v2f){w2[0], w2[1]}, qq);
+                                        if (two) qq = fma2((v2f){hv[u].y, hv[u].y}, (v2f){w2[2], w2[3]}, qq);
+                                        q[0] = qq.x; q[1] = qq.y;
+                                    } else {
+#pragma unroll
+                                        for (int aa = 0; aa < A; ++aa) q[aa] = fma32(hv[u].x, w2[aa], q[aa]);
+                                        if (two) {
+#pragma unroll
+                                            for (int aa = 0; aa < A; ++aa) q[aa] = fma32(hv[u].y, w2[A + aa], q[aa]);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int aa = 0; aa < A; ++aa) qres[(cpass * MAX_B + mb0 + cbi) * A + aa] = q[aa] + Wc[npairs * PR + aa];
+                    }
+                }
                 if (wave >= first_spec) {
                     if (wave != ENV_WAVE) lds_flag_wait(ctrl + 5, step_tag);       // cur_state / done of this step
                   if (ctrl[t & 1] <= 0.5f) {
@@ -1114,7 +1232,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         // wave is alone on its SIMD and its 17-sample loop is a chain of five LDS round trips, 3.4 k cycles; groups of six /
                         // eight for it -- LENV_DDQN_TEAM_GRP -- were measured SLOWER, 25.9 -> 26.7 / 29.5 ms at 24 chains: the kernel sits at the
                         // 168-VGPR cap of a 12-wave workgroup and the extra live registers come back as spill reloads in the forward.)
-                        constexpr int GRP = TEAM ? LENV_DDQN_TEAM_GRP : 4;
+                        constexpr int GRP = TWIDE ? LENV_DDQN_WIDE_GRP : (TEAM ? LENV_DDQN_TEAM_GRP : 4);
 #pragma unroll 1
                         for (; bq + GRP <= b1; bq += GRP, hp += GRP * HP, dqp += 4 * GRP, sp += GRP * SP) {
                             float hv[GRP], sv[GRP][SP];
@@ -1179,6 +1297,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     // 32.3 ms per generation at 24 chains.)
                     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                     const int npairs_x = (tot + 1) >> 1;
+                    if constexpr (!TWIDE) {
                     for (int q = tid; q < npairs_x; q += NT) {
                         const int e0 = 2 * q, e1 = e0 + 1;
                         const bool need0 = e0 < lo || e0 >= hi, need1 = e1 < tot && (e1 < lo || e1 >= hi);
@@ -1204,6 +1323,55 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         if (need0) part[e0] = __uint_as_float(v.x);
                         if (need1) part[e1] = __uint_as_float(v.z);
                     }
+                                    } else {
+                    // NPF pairs per thread in flight at once: one in the TEAM instantiation of teams of two (at the 168-VGPR cap more live
+                    // registers come back as spill reloads in its forward), LENV_DDQN_WIDE_NPF in the TWIDE instantiation
+                    constexpr int NPF = TWIDE ? LENV_DDQN_WIDE_NPF : 1;
+                    for (int q0 = tid; q0 < npairs_x; q0 += NT * NPF) {
+                        u32x4 v[NPF];
+                        bool need0[NPF], need1[NPF];
+                        const u32x4 *src[NPF];
+#pragma unroll
+                        for (int u = 0; u < NPF; ++u) {
+                            const int q = q0 + u * NT, e0 = 2 * q, e1 = e0 + 1;
+                            need0[u] = q < npairs_x && (e0 < lo || e0 >= hi);
+                            need1[u] = q < npairs_x && e1 < tot && (e1 < lo || e1 >= hi);
+                            src[u] = reinterpret_cast<const u32x4 *>(xs_ + (q < npairs_x ? e0 : 0));
+                            v[u] = u32x4{0u, 0u, 0u, 0u};
+                        }
+                        unsigned spins = 0;
+                        unsigned long long w0 = 0;
+                        while (!team_dead) {
+#pragma unroll
+                            for (int u = 0; u < NPF; ++u)
+                                if (need0[u] || need1[u]) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(v[u]) : "v"(src[u]) : "memory");
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            bool all_in = true;
+#pragma unroll
+                            for (int u = 0; u < NPF; ++u) {
+                                asm volatile("" : "+v"(v[u]));         // (the loads' results are defined only behind the wait)
+                                all_in = all_in && (!need0[u] || v[u].y == want_tag) && (!need1[u] || v[u].w == want_tag);
+                            }
+                            if (all_in) break;
+                            __builtin_amdgcn_s_sleep(1);
+                            // give up after LENV_TEAM_GIVEUP_TICKS_RUN (the team has assembled by now; or as soon as another member of the chain
+                            // has), for good: a thread that gave up never polls again
+                            if ((++spins & 63u) == 0u) {
+                                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                                if (w0 == 0) w0 = now;
+                                if (now - w0 > LENV_TEAM_GIVEUP_TICKS_RUN || __hip_atomic_load(team_bar + 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                                    team_bar[15] = 1u; status = -10; team_dead = true; break;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < NPF; ++u) {
+                            const int e0 = 2 * (q0 + u * NT);
+                            if (need0[u]) part[e0] = __uint_as_float(v[u].x);
+                            if (need1[u]) part[e0 + 1] = __uint_as_float(v[u].z);
+                        }
+                    }
+                                    }
                 }
                 __syncthreads();                               // B4
                 PT_MARK(5);
@@ -1511,6 +1679,37 @@ static InnerKern ddqn_team_kernel(const lenv_ddqn_cfg *cfg, const InnerLayout &L
     return kern;
 }
 
+// TWIDE launches (teams of three and more): every member's items cut three or four ways must fit the eleven waves next to the env wave,
+// the nets must have at least eight hidden-unit pairs, and the rows of passes 1 / 2 must find room (h rows of samples the member does
+// not own, or the split layout's rows for pass 2).  Bm = the largest share of a member.
+static bool ddqn_team_wide_ok(const lenv_ddqn_cfg *cfg, const InnerLayout &L, int G)
+{
+    if (G < 3 || (cfg->kernel_variant & LENV_VARIANT_TEAM_NARROW)) return false;
+    const int B = cfg->batch_size, per = (L.n_chunks + G - 1) / G;
+    int Bm = per * L.chunk;
+    if (Bm > B) Bm = B;
+    if (((cfg->q_hidden + 1) >> 1) < 8) return false;
+    if (5 * (3 * Bm) > (NW - 1) * 64) return false;         // at least five parts per item (measured: four parts at G = 4 lose to whole items, 27.2 vs 26.2 ms)
+    if (!(3 * Bm <= B || Bm <= L.split_L)) return false;
+    return 2 * Bm <= B - Bm;
+}
+static InnerKern ddqn_team_wide_kernel(const lenv_ddqn_cfg *cfg, const InnerLayout &L)
+{
+    InnerKern kern = nullptr;
+#define LENV_PICK2(ENVID, SS, AA, PP)                                                                                      \
+    switch (cfg->q_act) {                                                                                                  \
+    case LENV_ACT_RELU: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_RELU, PP, 0, true, true>; break;            \
+    case LENV_ACT_LEAKYRELU: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_LEAKYRELU, PP, 0, true, true>; break;  \
+    case LENV_ACT_TANH: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_TANH, PP, 0, true, true>; break;            \
+    default: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_IDENTITY, PP, 0, true, true>; break;                   \
+    }
+    if (cfg->env_id == LENV_ENV_CARTPOLE) { if (L.P_q <= NT) { LENV_PICK2(LENV_ENV_CARTPOLE, 4, 2, 1) } else { LENV_PICK2(LENV_ENV_CARTPOLE, 4, 2, 2) } }
+    else { if (L.P_q <= NT) { LENV_PICK2(LENV_ENV_ACROBOT, 6, 3, 1) } else { LENV_PICK2(LENV_ENV_ACROBOT, 6, 3, 2) } }
+#undef LENV_PICK2
+    if (!cfg_disables_fixed_shape(cfg) && published_shape(cfg, L) == 1) kern = ddqn_se_inner_kernel<LENV_ENV_CARTPOLE, 4, 2, LENV_ACT_TANH, 1, 1, true, true>;
+    return kern;
+}
+
 // Workgroups per chain of a launch with `chains` chains: G > 1 when the chains leave enough of the GPU idle for every member of every
 // chain to be resident at once (occupancy API x CU count for the TEAM instantiation at this cfg's LDS footprint; blocks are dealt to the
 // XCDs round-robin, so a team is 8 blocks apart) and the minibatch has at least G micro-chunks to deal.  cfg->team_size: 0 = automatic
@@ -1523,12 +1722,13 @@ static int ddqn_pick_team(const lenv_ddqn_cfg *cfg, int64_t chains, bool product
     if (want == 0 && chains < 16) return 1;
     InnerArgs t;
     if (inner_check(cfg) != LENV_OK || inner_layout(cfg, t) != LENV_OK) return 1;
-    const void *kern = reinterpret_cast<const void *>(ddqn_team_kernel(cfg, t.L));
     const size_t lds_bytes = (size_t)t.L.lds_floats * sizeof(float);
     const int64_t slots = 8 * ((chains + 7) / 8);
     int best = 1;
-    for (int G : { 2, 3, 4, 6 })
+    for (int G : { 2, 3, 4, 6 }) {
+        const void *kern = reinterpret_cast<const void *>(ddqn_team_wide_ok(cfg, t.L, G) ? ddqn_team_wide_kernel(cfg, t.L) : ddqn_team_kernel(cfg, t.L));
         if (G <= t.L.n_chunks && (want == 0 || G <= want) && lenv_team_grid_resident(kern, NT, lds_bytes, slots * G)) best = G;
+    }
     return best;
 }
 
@@ -1615,7 +1815,7 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
     }
     unsigned grid = (unsigned)chains;
     if (a.team_G > 1) {
-        kern = ddqn_team_kernel(cfg, a.L);
+        kern = ddqn_team_wide_ok(cfg, a.L, a.team_G) ? ddqn_team_wide_kernel(cfg, a.L) : ddqn_team_kernel(cfg, a.L);
         grid = (unsigned)(8 * ((chains + 7) / 8) * a.team_G);
         hipLaunchKernelGGL(ddqn_team_reset_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream), a.team_ws, chains * a.team_stride);
     }
