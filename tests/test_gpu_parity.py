@@ -2028,8 +2028,12 @@ def test_ddqn_team_full_size_generations_bit_equal(pop, team):
     import bench
     from learning_environments_amd import _lib
     outs = []
-    for mode in ("1", "auto"):
+    # "narrow": the automatic team with whole forward items per lane (kernel_variant TEAM_NARROW) -- teams of six otherwise cut every
+    # item over the idle lanes (the TWIDE instantiation, the launch bench.py's strong-scaling shard record times)
+    for mode in ("1", "auto") + (("narrow",) if team >= 5 else ()):
         m, _ = bench.build_master(pop, team_size=1 if mode == "1" else 0)
+        if mode == "narrow":
+            m.cfg.kernel_variant = _lib.VARIANT_TEAM_NARROW
         assert _lib.lib().lenv_ddqn_se_team_size(C.byref(m.cfg), 3 * pop) == (1 if mode == "1" else team)
         m.step(0)
         m.step(1)
@@ -2037,8 +2041,9 @@ def test_ddqn_team_full_size_generations_bit_equal(pop, team):
         assert m.inner.status.cpu().abs().max().item() == 0
         outs.append([t.cpu().numpy().copy() for t in (m.inner.score, m.inner.stats, m.inner.episode_test_mean, m.inner.final_returns, m.theta)])
     assert int(outs[0][1][0][2]) == 3800
-    for a, b in zip(*outs):
-        assert np.array_equal(a, b, equal_nan=True)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b, equal_nan=True)
 
 
 @pytest.mark.parametrize("which", ["cartpole", "acrobot_syn_env", "mountaincar"])
