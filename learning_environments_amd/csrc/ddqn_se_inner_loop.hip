@@ -450,6 +450,12 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
         }
     }
     if (tid < 8 + NW) ctrl[tid] = 0.0f;
+    // GB2_LANE (the published CartPole shape: 57 hidden units in rows of 58 words): the output-bias gradient gb2[a] = sum_b dm_b[a] is the
+    // output-weight gradient of a virtual hidden unit whose activation is 1.0 -- fma(dm, 1.0, acc) and acc + dm round the same sum once.  The
+    // idle lane 57 of every gradient wave plays that unit (the pad word of every h row holds 1.0 from here on; the forward never writes it:
+    // the last pair stores its first word only), and the per-sample packed add that every lane spent on gb2 is gone from the loop.
+    constexpr bool GB2_LANE = SHAPE == 1 && !TWIDE && A == 2 && (FIX_HQ & 1) == 1 && FIX_HQ < 64;
+    if constexpr (GB2_LANE) { for (int b = tid; b < B; b += NT) hB[b * HP + FIX_HQ] = 1.0f; }
     for (int i = tid; i < LV(n_chunks4) * P; i += NT) part[i] = 0.0f;  // padding chunk slots stay +0 (see the Adam phase)
     __syncthreads();
 
@@ -1207,8 +1213,10 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                             if constexpr (A == 2) {
                                 const v2f g2 = fma2((v2f){dm[0], dm[1]}, (v2f){h, h}, (v2f){gW2[0], gW2[1]});
                                 gW2[0] = g2.x; gW2[1] = g2.y;
-                                const v2f gb = (v2f){gb2[0], gb2[1]} + (v2f){dm[0], dm[1]};
-                                gb2[0] = gb.x; gb2[1] = gb.y;
+                                if constexpr (!GB2_LANE) {
+                                    const v2f gb = (v2f){gb2[0], gb2[1]} + (v2f){dm[0], dm[1]};
+                                    gb2[0] = gb.x; gb2[1] = gb.y;
+                                }
                             } else {
 #pragma unroll
                                 for (int aa = 0; aa < A; ++aa) { gW2[aa] = fma32(dm[aa], h, gW2[aa]); gb2[aa] = gb2[aa] + dm[aa]; }
@@ -1226,7 +1234,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         // group's reads differ in their immediate offsets only instead of each getting its own s_add + v_mov)
                         int vzero;
                         asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-                        const float *hp = hB + (jv ? j : 0) + b0 * HP, *dqp = dqB + 4 * b0 + vzero, *sp = sB + SP * b0 + vzero;
+                        const float *hp = hB + ((jv || (GB2_LANE && j == Hq)) ? j : 0) + b0 * HP, *dqp = dqB + 4 * b0 + vzero, *sp = sB + SP * b0 + vzero;
                         int bq = b0;
                         // whole groups of GRP samples: every LDS read of a group is issued before the first use.  (A TEAM member's gradient
                         // wave is alone on its SIMD and its 17-sample loop is a chain of five LDS round trips, 3.4 k cycles; groups of six /
@@ -1267,11 +1275,12 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                                 for (int aa = 0; aa < A; ++aa) xg[Hq * S + Hq + aa * Hq + j] = make_float2(gW2[aa], xtag);
                             }
                         }
-                        if (j == 0) {
+                        if (GB2_LANE ? j == Hq : j == 0) {
 #pragma unroll
                             for (int aa = 0; aa < A; ++aa) {
-                                pc[Hq * S + Hq + A * Hq + aa] = gb2[aa];
-                                if constexpr (TEAM) xg[Hq * S + Hq + A * Hq + aa] = make_float2(gb2[aa], xtag);
+                                const float gbv = GB2_LANE ? gW2[aa] : gb2[aa];
+                                pc[Hq * S + Hq + A * Hq + aa] = gbv;
+                                if constexpr (TEAM) xg[Hq * S + Hq + A * Hq + aa] = make_float2(gbv, xtag);
                             }
                         }
                     }
