@@ -401,3 +401,40 @@ def test_worker_calc_best_score_matches_the_reference_fixture(tmp_path, monkeypa
     bad["agents"]["gtn"]["synthetic_env_type"] = 2
     with pytest.raises(NotImplementedError):
         GTN_Worker(1, bohb_id=-1, engine=OracleNesEngine(), seed=1).late_init(bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_worker_relaunches_a_team_launch_that_could_not_assemble(tmp_path, monkeypatch):
+    """several worker processes share one GPU, and a worker's three-chain TD3 launch picks teams of six.  Next to a foreign
+    kernel that holds most CUs the teams cannot assemble, the launch reports status -10, and GTN_Worker._run_chains repeats it with one
+    workgroup per chain instead of raising: the evaluation's scores equal those of an undisturbed worker with the same seed."""
+    import ctypes as C
+    import time
+    from learning_environments_amd import _lib, configs
+    from learning_environments_amd.agents.GTN import GTN_Worker
+    monkeypatch.chdir(tmp_path)
+    cfg = configs.fixed_work(configs.halfcheetah_reward_env_td3(num_workers=1, max_iterations=1), 2)
+    cfg["agents"]["td3"]["init_episodes"] = 1
+    cfg["envs"]["HalfCheetah-v3"]["max_steps"] = 40
+    cfg["agents"]["gtn"].update(mode="single", time_sleep_worker=0.1)
+
+    def evaluate(disturb):
+        w = GTN_Worker(0, bohb_id=-1, seed=321)
+        w.late_init(cfg)
+        torch.manual_seed(9)                       # the noise draw of get_random_noise
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        if disturb:
+            with torch.cuda.stream(side):          # 248 of 256 CUs for 1.5 s: a few team members start, most cannot
+                _lib.check(_lib.lib().lenv_diag_occupy_cus(248, 150 * 1024, 150_000_000, C.c_void_p(side.cuda_stream)), "lenv_diag_occupy_cus")
+            time.sleep(0.05)
+        out = w.evaluate()
+        side.synchronize()
+        return out, w.team_fallbacks, int(getattr(next(iter(w._inner.values())).cfg, "team_size", -1))
+
+    ref, fb0, ts0 = evaluate(False)
+    got, fb1, ts1 = evaluate(True)
+    assert fb0 == 0 and ts0 == 0
+    assert got == ref                               # (score_best, score_orig): deterministic functions of the seed either way
+    assert fb1 in (0, 1) and ts1 == (1 if fb1 else 0)
