@@ -33,14 +33,6 @@ constexpr int FWD_THREADS = NT - 64;   // threads available for (sample, pass) f
 constexpr int MAX_B = FWD_THREADS / 3; // minibatch samples (3 forward items per sample, one item per thread)
 constexpr int MAX_PPT = 2;        // Q-net parameters owned per thread (P_agent <= MAX_PPT*NT)
 
-// Forward-interval wave priorities (see the pair loop): 0 = none (rounds 2-4), 1 = by remaining work
-#ifndef LENV_DDQN_PRIO
-#define LENV_DDQN_PRIO 0
-#endif
-#ifndef LENV_DDQN_PRIO_T1
-#define LENV_DDQN_PRIO_T1 12
-#define LENV_DDQN_PRIO_T2 22
-#endif
 #ifndef LENV_DDQN_TEAM_GRP
 #define LENV_DDQN_TEAM_GRP 4
 #endif
@@ -911,37 +903,11 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                         if (npairs > 1) load1(1);
                         load2(0);
                         int jp = 0;
-#if LENV_DDQN_PRIO == 0
 #pragma unroll 1
                         for (; jp + 4 <= npairs; jp += 2) {             // jp+3 < npairs: both stages are steady-state
                             stage(pa, pb, jp, npairs, T{}, F{});
                             stage(pb, pa, jp + 1, npairs, T{}, F{});
                         }
-#else
-                        // PRIORITY BY REMAINING WORK: the three waves of a SIMD are served oldest first, so the youngest full-item wave used to
-                        // run the last fifth of its pairs alone -- one wave's chain of LDS round trips instead of three interleaved ones.  A
-                        // wave's priority now falls as its pairs run out (2, 1, 0 by thirds of the pair loop): whoever is behind is served
-                        // first and the waves of a SIMD reach the interval's barrier together.  Timing only: no value changes.
-                        const int jp_a = LENV_DDQN_PRIO_T1 < npairs ? LENV_DDQN_PRIO_T1 : npairs, jp_b = LENV_DDQN_PRIO_T2 < npairs ? LENV_DDQN_PRIO_T2 : npairs;
-                        __builtin_amdgcn_s_setprio(2);
-#pragma unroll 1
-                        for (; jp + 4 <= jp_a; jp += 2) {
-                            stage(pa, pb, jp, npairs, T{}, F{});
-                            stage(pb, pa, jp + 1, npairs, T{}, F{});
-                        }
-                        __builtin_amdgcn_s_setprio(1);
-#pragma unroll 1
-                        for (; jp + 4 <= jp_b; jp += 2) {
-                            stage(pa, pb, jp, npairs, T{}, F{});
-                            stage(pb, pa, jp + 1, npairs, T{}, F{});
-                        }
-                        __builtin_amdgcn_s_setprio(0);
-#pragma unroll 1
-                        for (; jp + 4 <= npairs; jp += 2) {
-                            stage(pa, pb, jp, npairs, T{}, F{});
-                            stage(pb, pa, jp + 1, npairs, T{}, F{});
-                        }
-#endif
                         for (; jp + 2 <= npairs; jp += 2) {             // at most one more double stage, with the tail conditions
                             stage(pa, pb, jp, npairs, F{}, F{});
                             stage(pb, pa, jp + 1, npairs, F{}, F{});

@@ -876,12 +876,6 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     float *rb = arena + a.a_replay, *xc = arena + a.a_xc, *xn = arena + a.a_xn, *xa = arena + a.a_xa, *thb = arena + a.a_th, *dumps = arena + a.a_dump;
     double *meter = reinterpret_cast<double *>(arena + a.a_meter);
     float *gdq = arena + a.a_gx, *gdz = gdq + 2 * B;       // team exchange: dq1 | dq2 [B] each, dz [B][A]
-    // the chain's arena pointers from scalar registers, fresh: the chain index goes through an empty asm so that the compiler cannot share
-    // the result with the long-lived copies above (which it keeps in vector registers and, around calls, in scratch memory)
-    auto arena_fresh = [&]() -> float * { long long ch_ = (long long)chain; asm volatile("" : "+s"(ch_)); return a.arena + ch_ * a.arena_stride; };
-#define TEAM_PTRS float *ar_ = arena_fresh(); float *params = ar_ + a.a_par, *targets = params + 3 * PN, *xc = ar_ + a.a_xc, *xn = ar_ + a.a_xn, \
-                  *xa = ar_ + a.a_xa, *thb = ar_ + a.a_th, *gdq = ar_ + a.a_gx, *gdz = gdq + 2 * B, *w2u = ar_ + a.a_w2u;                    \
-                  (void)params; (void)targets; (void)xc; (void)xn; (void)xa; (void)thb; (void)gdq; (void)gdz; (void)w2u
     unsigned *team_bar = reinterpret_cast<unsigned *>(arena + a.a_bar);
 
     // ---- stage the perturbed reward network (GTN_worker.py:165-175) and the fresh agent (TD3.py:31-39) ----
