@@ -492,8 +492,9 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     // needs it there), passes 1 / 2 in h rows of samples this member does not own (3 Bm <= B) or, pass 2, in the split layout's rows.
     // Same operations on the same values in the same order: the bits do not change.
     const int WIDE_L = 3 * Bm;
-    const int WIDE_CAP = (NW - 1) * 64;                     // lanes next to the env wave
-    const int WIDE_D = TWIDE ? (6 * WIDE_L <= WIDE_CAP ? 6 : (5 * WIDE_L <= WIDE_CAP ? 5 : (4 * WIDE_L <= WIDE_CAP ? 4 : 3))) : 0;
+    // parts per item: six when that fits the eleven waves next to the env wave (teams of six: 102 items, 612 lanes), else three on at most
+    // eight waves (teams of four: 153 items, 459 lanes -- four parts on ten waves contend for the SIMDs and lose to whole items, measured)
+    const int WIDE_D = TWIDE ? (6 * WIDE_L <= (NW - 1) * 64 ? 6 : 3) : 0;
     const bool wide = TWIDE;                                // (the host launches TWIDE exactly when ddqn_team_wide_ok() holds for every member)
     const int SPLIT_D = TEAM ? (tsplit ? 4 : 0) : LV(split_D), SPLIT_L = TEAM ? (tsplit ? 3 * Bm - 256 : 0) : LV(split_L);
     const bool split = SPLIT_D > 0;
@@ -1654,7 +1655,7 @@ static InnerKern ddqn_team_kernel(const lenv_ddqn_cfg *cfg, const InnerLayout &L
     return kern;
 }
 
-// TWIDE launches (teams of three and more): every member's items cut three or four ways must fit the eleven waves next to the env wave,
+// TWIDE launches (teams of four and six at B = 199): every member's items cut six or three ways must fit the waves next to the env wave,
 // the nets must have at least eight hidden-unit pairs, and the rows of passes 1 / 2 must find room (h rows of samples the member does
 // not own, or the split layout's rows for pass 2).  Bm = the largest share of a member.
 static bool ddqn_team_wide_ok(const lenv_ddqn_cfg *cfg, const InnerLayout &L, int G)
@@ -1664,7 +1665,7 @@ static bool ddqn_team_wide_ok(const lenv_ddqn_cfg *cfg, const InnerLayout &L, in
     int Bm = per * L.chunk;
     if (Bm > B) Bm = B;
     if (((cfg->q_hidden + 1) >> 1) < 8) return false;
-    if (5 * (3 * Bm) > (NW - 1) * 64) return false;         // at least five parts per item (measured: four parts at G = 4 lose to whole items, 27.2 vs 26.2 ms)
+    if (6 * (3 * Bm) > (NW - 1) * 64 && 3 * (3 * Bm) > 8 * 64) return false;       // six parts on eleven waves or three parts on eight (see the kernel's WIDE_D)         // at least five parts per item (measured: four parts at G = 4 lose to whole items, 27.2 vs 26.2 ms)
     if (!(3 * Bm <= B || Bm <= L.split_L)) return false;
     return 2 * Bm <= B - Bm;
 }

@@ -2019,7 +2019,7 @@ def test_ddqn_chain_on_a_team_of_workgroups(eng, orc, golden, case):
         assert np.array_equal(base[2][c], o["episode_test_mean"], equal_nan=True)
 
 
-@pytest.mark.parametrize("pop,team", [(32, 2), (8, 6)])
+@pytest.mark.parametrize("pop,team", [(32, 2), (16, 4), (8, 6)])
 def test_ddqn_team_full_size_generations_bit_equal(pop, team):
     """The strong-scaling shards of BASELINE configs[1] at full length (20 x 200 train steps = 3 800 learn steps per chain, through
     GTN_Master and its HIP graph): two generations with one workgroup per chain and with the automatic team size must leave the same
@@ -2028,9 +2028,9 @@ def test_ddqn_team_full_size_generations_bit_equal(pop, team):
     import bench
     from learning_environments_amd import _lib
     outs = []
-    # "narrow": the automatic team with whole forward items per lane (kernel_variant TEAM_NARROW) -- teams of six otherwise cut every
-    # item over the idle lanes (the TWIDE instantiation, the launch bench.py's strong-scaling shard record times)
-    for mode in ("1", "auto") + (("narrow",) if team >= 5 else ()):
+    # "narrow": the automatic team with whole forward items per lane (kernel_variant TEAM_NARROW) -- teams of four and six otherwise cut
+    # every item over the idle lanes (the TWIDE instantiation: three parts / six parts; the launch bench.py's strong-scaling shard record times)
+    for mode in ("1", "auto") + (("narrow",) if team >= 4 else ()):
         m, _ = bench.build_master(pop, team_size=1 if mode == "1" else 0)
         if mode == "narrow":
             m.cfg.kernel_variant = _lib.VARIANT_TEAM_NARROW
