@@ -7,19 +7,20 @@ from .GTN_master import GTN_Master
 from .GTN_worker import GTN_Worker
 
 
+def _run_master(config):
+    master = GTN_Master(config)
+    master.clean_working_dir()
+    return master.run()
+
+
 def run_gtn_on_single_pc(config):
-    gtn = GTN_Master(config)
-    gtn.clean_working_dir()
-    return gtn.run()
+    """reference agents/GTN.py:14-45 forks a master and num_workers worker processes; here the master evaluates the population itself."""
+    return _run_master(config)
 
 
 def run_gtn_on_multiple_pcs(config, id):
-    if id == -1:
-        gtn_master = GTN_Master(config)
-        gtn_master.clean_working_dir()
-        return gtn_master.run()
-    elif id >= 0:
-        gtn_worker = GTN_Worker(id)
-        return gtn_worker.run()
-    else:
+    """reference agents/GTN.py:47-56: id -1 = the master of a file-transport run, id >= 0 = worker `id` (serves until the master's quit_flag)."""
+    id = int(id)
+    if id < -1:
         raise ValueError("Invalid ID")
+    return _run_master(config) if id == -1 else GTN_Worker(id).run()
