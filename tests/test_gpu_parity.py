@@ -2007,6 +2007,14 @@ def test_ddqn_chain_on_a_team_of_workgroups(eng, orc, golden, case):
         assert got == max(x for x in (1, 2, 3, 4, 6) if x <= G and x <= n_chunks), (G, got, n_chunks)
         for a, b in zip(base, outs):
             assert np.array_equal(a, b, equal_nan=True), (case, G)
+    # teams of four / six cut every forward item over the idle lanes where that fits (the TWIDE instantiation); the same launches with whole
+    # items per lane (kernel_variant TEAM_NARROW) must give the same bits
+    cfg.kernel_variant = _lib.VARIANT_TEAM_NARROW
+    for G in (4, 6):
+        _, outs = run(G)
+        for a, b in zip(base, outs):
+            assert np.array_equal(a, b, equal_nan=True), (case, G, "narrow")
+    cfg.kernel_variant = 0
     cfg.team_size = 0
     assert _lib.lib().lenv_ddqn_se_team_size(C.byref(cfg), chains) == 1          # fewer than 16 chains: no team unless asked for
     assert _lib.lib().lenv_ddqn_se_team_size(C.byref(cfg), 96) == 2 and _lib.lib().lenv_ddqn_se_team_size(C.byref(cfg), 192) == 1
