@@ -418,6 +418,19 @@ def secondary_configs(only=None, team_size=0):
                     "team_fallbacks": int(getattr(m8, "team_fallbacks", 0)), "graph": bool(getattr(m8, "use_graph", False))})
         del m8
         torch.cuda.empty_cache()
+        # ... and the shards of the 2- and 4-GPU forms (32 / 16 workers = 96 / 48 chains, teams of 2 / 4), so that the record carries the whole
+        # projected strong-scaling curve of BASELINE's metric -- projections all, from one-GPU measurements of each shard
+        curve = [{"n_gpus": 8, "workers_per_gpu": 8, "chains_per_gpu": 24, "workgroups_per_chain": out[-1]["workgroups_per_chain"],
+                  "ms_per_generation": out[-1]["ms_per_step"], "projected_value": out[-1]["projected_8gpu_value"]}]
+        for n_gpus, workers in ((4, 16), (2, 32)):
+            ms_, _ = build_master(workers, team_size=team_size)
+            dts, _k = timed_generations(ms_, 10, 2, torch.cuda.synchronize, 1, True)
+            curve.append({"n_gpus": n_gpus, "workers_per_gpu": workers, "chains_per_gpu": 3 * workers,
+                          "workgroups_per_chain": int(_lib.lib().lenv_ddqn_se_team_size(ctypes.byref(ms_.cfg), 3 * workers)),
+                          "ms_per_generation": dts / 10 * 1e3, "projected_value": POP * 10 / dts})
+            del ms_
+            torch.cuda.empty_cache()
+        out[-1]["projected_strong_scaling"] = sorted(curve, key=lambda r: r["n_gpus"])
     # configs[2]: Acrobot SE + DuelingDDQN, pop 256 over 8 GPUs = 32 workers = 96 chains per GPU; 20 train episodes x 500 steps
     # (init_episodes 10 as published: the second half learns), 10 lock-step test episodes after every train episode
     c3 = C.fixed_work(C.acrobot_syn_env_duelingddqn(32), 20)
