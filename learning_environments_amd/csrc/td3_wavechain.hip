@@ -24,20 +24,22 @@ constexpr int R1 = 24;                                                    // row
 constexpr int oW1t = 0, ob1 = R1 * W, oW2t = ob1 + W, ob2 = oW2t + IMG, oWo = ob2 + W, obo = oWo + 8 * W, PN = obo + 8;
 static_assert(PN % 4 == 0, "float4 passes");
 }
-constexpr int T3W_B = 192, T3W_NB = T3W_B / 32;                           // minibatch rows, sample blocks
 
-// The published shapes this kernel is instantiated for (hidden 128 x 2, batch 192, policy_delay 1, a RewardEnv with 128-wide reward nets):
-// the real env, the agent's activation, the test episodes per test phase, the reward net's hidden layers.
-// k_rep: same_action_num (env steps per chosen action: the repeats stop at done, their shaped rewards are summed as python floats)
-struct T3wShape { int env, act, T, rn_layers, k_rep; };
+// The published shapes this kernel is instantiated for (hidden 128 x 2):
+// the real env, the agent's activation, the test episodes per test phase, the hidden layers of the reward net / the synthetic env's nets.
+// k_rep: same_action_num (env steps per chosen action; RewardEnv: the repeats stop at done, their shaped rewards are summed as python floats)
+// B: minibatch rows (sample blocks of 32: 6 or 8), policy_delay: TD3.py:101, venv: the training env is a VirtualEnv (synthetic_env_type 0:
+// three nets on cat(action, state), virtual_env.py:43-54) instead of a RewardEnv over the real env, hrn: width of those nets
+struct T3wShape { int env, act, T, rn_layers, k_rep, B, policy_delay, venv, hrn; };
 constexpr T3wShape kT3wShapes[] = {
-    { -1, 0, 1, 1, 1 },
-    { LENV_ENV_CHEETAH_STANDIN, LENV_ACT_RELU, 1, 1, 1 },     // 1: default_config_halfcheetah_reward_env.yaml = BASELINE configs[4]
-    { LENV_ENV_PENDULUM, LENV_ACT_LEAKYRELU, 10, 2, 1 },      // 2: default_config_pendulum_reward_env.yaml (actor 3-128-128-1, critics 4-128-128-1)
-    { LENV_ENV_CMC, LENV_ACT_LEAKYRELU, 1, 1, 2 },            // 3: default_config_cmc_reward_env.yaml (actor 2-128-128-1, critics 3-128-128-1; the episode ends at the flag)
+    { -1, 0, 1, 1, 1, 192, 1, 0, 128 },
+    { LENV_ENV_CHEETAH_STANDIN, LENV_ACT_RELU, 1, 1, 1, 192, 1, 0, 128 },     // 1: default_config_halfcheetah_reward_env.yaml = BASELINE configs[4]
+    { LENV_ENV_PENDULUM, LENV_ACT_LEAKYRELU, 10, 2, 1, 192, 1, 0, 128 },      // 2: default_config_pendulum_reward_env.yaml (actor 3-128-128-1, critics 4-128-128-1)
+    { LENV_ENV_CMC, LENV_ACT_LEAKYRELU, 1, 1, 2, 192, 1, 0, 128 },            // 3: default_config_cmc_reward_env.yaml (actor 2-128-128-1, critics 3-128-128-1; the episode ends at the flag)
+    { LENV_ENV_CMC, LENV_ACT_RELU, 1, 2, 2, 256, 2, 1, 96 },                  // 4: default_config_cmc.yaml (VirtualEnv with three 3-96-96-x nets, batch 256, policy_delay 2)
 };
 
-// dumps: [T3W_NB] blocks of BLK floats each (register order), or [192][128] row-major copies (same size)
+// dumps: [NBK] blocks of BLK floats each (register order), or [B][128] row-major copies (same size); NBK = B / 32 sample blocks
 enum { TD_C1_H1 = 0, TD_C1_H2, TD_C2_H1, TD_C2_H2, TD_A_H1, TD_A_H2, TR_C1_H2, TR_C2_H2, TR_A_H2, TS_DZ2, TR_DZ2, TR_DH1, TR_DZ2B, TR_DH1B, T3W_NDUMP };
 
 struct T3wArgs {
@@ -49,7 +51,7 @@ struct T3wArgs {
     int64_t rb_cap; int RS;
     int P, Pa, Pc, P_rn;
     int64_t a_par, a_xc, a_xn, a_xa, a_th, a_dump, a_replay, a_meter, a_gx, a_bar, a_w2u, a_rn;
-    int G;                                   // workgroups per chain (team): 1, 2, 3 or 6
+    int G;                                   // workgroups per chain (team): 1, 2, 3 or 6 (batch 192); 1, 2, 4 or 8 (batch 256)
     int64_t chains;
 };
 
@@ -143,10 +145,10 @@ __device__ unsigned long long g_t3w_phase_cycles[48];
     float *dumps = uni_ptr(c->dumps);                                                                                                      \
     const float prelu = unif(c->prelu), ma = unif(c->ma);                                                                                  \
     const int tg = uni(c->g), TG = uni(c->G);                                                                                              \
-    /* slot s of an n-slot phase (sample blocks: 6, tile / vector waves: 8) runs on wave s of the team's workgroup s * G / n */          \
+    /* slot s of an n-slot phase (sample blocks: NBK, tile / vector waves: 8) runs on wave s of the team's workgroup s * G / n */          \
     auto mine = [&](int s_, int n_) { return TG == 1 || (s_ * TG) / n_ == tg; };                                                          \
     (void)bufA; (void)bufB; (void)sm_b; (void)sm_wo; (void)sm_bo; (void)dumps; (void)prelu; (void)ma;                                      \
-    auto dump_of = [&](int which, int blk) { return dumps + ((int64_t)which * T3W_NB + blk) * BLK; };                                      \
+    auto dump_of = [&](int which, int blk) { return dumps + ((int64_t)which * NBK + blk) * BLK; };                                          \
     (void)dump_of; (void)mine
 
 // [32 samples x 128 units] register block -> rows 32 blk .. of a plain [sample][unit] array (16-byte stores)
@@ -157,11 +159,11 @@ __device__ __forceinline__ void block_to_rowmajor(float *rm_, int blk, const Lan
     for (int pc = 0; pc < 16; ++pc) *(gf4 *)(rm + 32 * (pc >> 2) + 8 * (pc & 3)) = f32x4{r[4 * pc], r[4 * pc + 1], r[4 * pc + 2], r[4 * pc + 3]};
 }
 
-// ---- one network pass over the 192 minibatch rows X[i][ldx] (waves 0-5 own the sample blocks) ----------------------------------
+// ---- one network pass over the B = 32 NBK minibatch rows X[i][ldx] (waves 0 .. NBK-1 own the sample blocks) ----------------------
 // mode 0 (Critic_Q): q_out[i] = net(x)      mode 1 (Actor_TD3): Y[i][ocol + c] = tanh(net(x)) * max_action, th_out[i][c] = tanh
 // A team member owns at most three of the six blocks, so a SECOND, independent critic pass (par2 != null: its own parameters, inputs,
 // outputs and dumps; image in bufB, small vectors in the second LDS set) runs next to the first one on the waves behind the member's blocks.
-template <int ACT, int IN, int OUT>
+template <int ACT, int IN, int OUT, int NBK>
 __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, const float *X_, int ldx_, int mode_, float *q_out_,
                                          float *Y_, int ldy_, int ocol_, float *th_out_, int d_h1_, int d_h2_, int r_h2_,
                                          const float *par2_ = nullptr, const float *X2_ = nullptr, float *q_out2_ = nullptr, int d_h1_2_ = -2, int r_h2_2_ = -1)
@@ -171,17 +173,18 @@ __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, 
     (void)d_h2_;
     // This wave's jobs (pass, block).  Team member: (pass 0, block = wave) or, in a dual call, (pass 1, block = wave - 6 / G mod 8: the
     // member's blocks are consecutive, so pass 1 sits on the waves right behind them -- other SIMDs than the blocks' own waves).
-    // One workgroup per chain: a single pass puts block w on wave w; a dual pass has 12 jobs (pass j / 6, block j % 6) for 8 waves:
-    // wave w runs job w and, for w < 4, job w + 8 afterwards -- three jobs on every SIMD instead of four for two passes in a row.
+    // One workgroup per chain: a single pass puts block w on wave w; a dual pass has 2 NBK = 12 jobs (pass j / 6, block j % 6) for 8 waves:
+    // wave w runs job w and, for w < 4, job w + 8 afterwards -- three jobs on every SIMD instead of four for two passes in a row
+    // (batch 256: 16 jobs, two per wave).
     int njobs = 0, jp0 = 0, jb0 = 0, jp1 = 0, jb1 = 0;
     if (TG > 1) {
-        const int wave2 = (wave - T3W_NB / TG) & 7;
-        if (wave < T3W_NB && mine(wave, T3W_NB)) { jp0 = 0; jb0 = wave; njobs = 1; }
-        else if (dual && wave2 < T3W_NB && mine(wave2, T3W_NB)) { jp0 = 1; jb0 = wave2; njobs = 1; }
+        const int wave2 = (wave - NBK / TG) & 7;
+        if (wave < NBK && mine(wave, NBK)) { jp0 = 0; jb0 = wave; njobs = 1; }
+        else if (dual && wave2 < NBK && mine(wave2, NBK)) { jp0 = 1; jb0 = wave2; njobs = 1; }
     } else if (dual) {
-        jp0 = wave / T3W_NB; jb0 = wave % T3W_NB; njobs = 1;
-        if (wave < 4) { jp1 = (wave + 8) / T3W_NB; jb1 = (wave + 8) % T3W_NB; njobs = 2; }
-    } else if (wave < T3W_NB) { jb0 = wave; njobs = 1; }
+        jp0 = wave / NBK; jb0 = wave % NBK; njobs = 1;
+        if (wave < 2 * NBK - 8) { jp1 = (wave + 8) / NBK; jb1 = (wave + 8) % NBK; njobs = 2; }
+    } else if (wave < NBK) { jb0 = wave; njobs = 1; }
     float *Y = uni_ptr(Y_), *th_out = uni_ptr(th_out_);
     constexpr int in = IN, out = OUT;
     const int ldx = uni(ldx_), mode = uni(mode_), ldy = uni(ldy_), ocol = uni(ocol_);
@@ -290,7 +293,7 @@ __device__ __noinline__ void t3w_forward(const T3wCtx *ctx_, const float *par_, 
 // ---- backward of one network, first half: the per-sample chain from dOut[i][out] (LDS; the rows of this workgroup's blocks) back to
 // dz2 and dh1 (row-major copies r_dz2 / r_dh1 in the arena for the weight gradients) and, for the policy step, the action part of the
 // input gradient turned into the actor's output gradient dz (LDS) right away ----
-template <int ACT, int IN, int OUT>
+template <int ACT, int IN, int OUT, int NBK>
 __device__ __noinline__ void t3w_backward_chain(const T3wCtx *ctx_, const float *par_, const float *dOut_, int d_h1_, int d_h2_, int r_dz2_, int r_dh1_,
                                                 int dx_col_, int dx_n_, const float *th_, float *dz_out_,
                                                 const float *par2_ = nullptr, const float *dOut2_ = nullptr, int d_h1_2_ = -2, int d_h2_2_ = -1,
@@ -301,13 +304,13 @@ __device__ __noinline__ void t3w_backward_chain(const T3wCtx *ctx_, const float 
     const bool dual = uni(d_h1_2_) != -2;
     int njobs = 0, jp0 = 0, jb0 = 0, jp1 = 0, jb1 = 0;
     if (TG > 1) {
-        const int wave2 = (wave - T3W_NB / TG) & 7;
-        if (wave < T3W_NB && mine(wave, T3W_NB)) { jp0 = 0; jb0 = wave; njobs = 1; }
-        else if (dual && wave2 < T3W_NB && mine(wave2, T3W_NB)) { jp0 = 1; jb0 = wave2; njobs = 1; }
+        const int wave2 = (wave - NBK / TG) & 7;
+        if (wave < NBK && mine(wave, NBK)) { jp0 = 0; jb0 = wave; njobs = 1; }
+        else if (dual && wave2 < NBK && mine(wave2, NBK)) { jp0 = 1; jb0 = wave2; njobs = 1; }
     } else if (dual) {
-        jp0 = wave / T3W_NB; jb0 = wave % T3W_NB; njobs = 1;
-        if (wave < 4) { jp1 = (wave + 8) / T3W_NB; jb1 = (wave + 8) % T3W_NB; njobs = 2; }
-    } else if (wave < T3W_NB) { jb0 = wave; njobs = 1; }
+        jp0 = wave / NBK; jb0 = wave % NBK; njobs = 1;
+        if (wave < 2 * NBK - 8) { jp1 = (wave + 8) / NBK; jb1 = (wave + 8) % NBK; njobs = 2; }
+    } else if (wave < NBK) { jb0 = wave; njobs = 1; }
     const float *th = uni_ptr(th_);
     lfloat *dz_out = (lfloat *)uni_ptr(dz_out_);
     constexpr int out = OUT;
@@ -402,10 +405,10 @@ __device__ __noinline__ void t3w_backward_chain(const T3wCtx *ctx_, const float 
     TSUB_MARK(26);
 }
 
-// ---- backward of one network, second half: the parameter gradients from the row-major copies of ALL 192 samples (dOut in LDS, h2 /
+// ---- backward of one network, second half: the parameter gradients from the row-major copies of ALL B samples (dOut in LDS, h2 /
 // dz2 / dh1 in the arena, the h1 register dumps).  The work is cut by wave -- output-layer gradients (VALU), two W2 tiles per wave,
 // one W1 column tile or one bias vector per wave -- and wave w's share runs in the team's workgroup w * G / 8 ----
-template <int ACT, int IN, int OUT>
+template <int ACT, int IN, int OUT, int NBK>
 __device__ __noinline__ void t3w_backward_wgrad(const T3wCtx *ctx_, float *gpar_, const float *X_, int ldx_, const float *dOut_, int d_h1_, int r_h2_,
                                                 int r_dz2_, int r_dh1_, int slot0_, int slots_)
 {
@@ -420,7 +423,8 @@ __device__ __noinline__ void t3w_backward_wgrad(const T3wCtx *ctx_, float *gpar_
     const lfloat *dOut = (const lfloat *)uni_ptr(dOut_);
     constexpr int in = IN, out = OUT;
     const int ldx = uni(ldx_), d_h1 = uni(d_h1_), r_h2 = uni(r_h2_), r_dz2 = uni(r_dz2_), r_dh1 = uni(r_dh1_);
-    constexpr int B = T3W_B;
+    constexpr int B = 32 * NBK, HB = B / 2, NST = HB * 32 / NT;     // rows, rows of a half-batch, 16-byte pieces per thread of a half-batch image
+    static_assert(HB <= W && HB * 32 % NT == 0, "a half-batch fills at most one image");
     const bool my_wave = mine(slot0 + wave, slots);
     TSUB_DECL;
     if (my_wave) {
@@ -447,32 +451,32 @@ __device__ __noinline__ void t3w_backward_wgrad(const T3wCtx *ctx_, float *gpar_
     }
     TSUB_MARK(24);
     float r[64];
-    // gW2t[k][j] = sum_i h1[i][k] dz2[i][j] over the 192 samples: two half-batches of 96 rows through the two images
+    // gW2t[k][j] = sum_i h1[i][k] dz2[i][j] over the B samples: two half-batches of B / 2 (96 / 128) rows through the two images
     f32x16 acc0, acc1;
 #pragma unroll
     for (int v = 0; v < 16; ++v) { acc0[v] = 0.0f; acc1[v] = 0.0f; }
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         L.refresh();
-        {   // dz2 rows 96 half .. + 95: straight copy of the row-major array into the swizzled image (bufB)
-            const gf4 *src = (const gf4 *)dump_of(r_dz2, 0) + half * 96 * 32 + tid;
+        {   // dz2 rows HB half .. + HB - 1: straight copy of the row-major array into the swizzled image (bufB)
+            const gf4 *src = (const gf4 *)dump_of(r_dz2, 0) + half * HB * 32 + tid;
             lfloat *img = (lfloat *)bufB;
-            f32x4 v[6];
+            f32x4 v[NST];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) v[u] = src[u * NT];
+            for (int u = 0; u < NST; ++u) v[u] = src[u * NT];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
+            for (int u = 0; u < NST; ++u) {
                 const int p = tid + u * NT, rr_ = p >> 5, cc_ = (p & 31) << 2;
                 *(lf4 *)(img + rr_ * W + (cc_ ^ ((rr_ & 7) << 2))) = v[u];
             }
         }
-        if (wave < 3) {                                    // h1 blocks 3 half .. + 2 from the register dumps -> bufA
-            dump_load(dump_of(d_h1, 3 * half + wave), L, r);
+        if (wave < NBK / 2) {                              // h1 blocks (NBK / 2) half .. from the register dumps -> bufA
+            dump_load(dump_of(d_h1, (NBK / 2) * half + wave), L, r);
             tile_to_image(bufA, wave, L, r);
         }
         barrier_lds();
         L.refresh();
-        if (my_wave) wgrad_accum(bufA, bufB, 96, L, acc0, acc1);
+        if (my_wave) wgrad_accum(bufA, bufB, HB, L, acc0, acc1);
         barrier_lds();
     }
     if (my_wave) wgrad_store(L, gpar + oW2t, acc0, acc1);
@@ -491,19 +495,19 @@ __device__ __noinline__ void t3w_backward_wgrad(const T3wCtx *ctx_, float *gpar_
         L.refresh();
         {   // half-batch images of dh1 (bufB: waves 0-5 read it) and dz2 (bufA: waves 6-7) from their row-major copies; a team member
             // stages only what its waves of this phase read
-            const gf4 *src = (const gf4 *)dump_of(r_dh1, 0) + half * 96 * 32 + tid, *src2 = (const gf4 *)dump_of(r_dz2, 0) + half * 96 * 32 + tid;
+            const gf4 *src = (const gf4 *)dump_of(r_dh1, 0) + half * HB * 32 + tid, *src2 = (const gf4 *)dump_of(r_dz2, 0) + half * HB * 32 + tid;
             lfloat *img = (lfloat *)bufB, *img2 = (lfloat *)bufA;
-            f32x4 v[6], v2[6];
+            f32x4 v[NST], v2[NST];
             if (need_dh1) {
 #pragma unroll
-                for (int u = 0; u < 6; ++u) v[u] = src[u * NT];
+                for (int u = 0; u < NST; ++u) v[u] = src[u * NT];
             }
             if (need_dz2) {
 #pragma unroll
-                for (int u = 0; u < 6; ++u) v2[u] = src2[u * NT];
+                for (int u = 0; u < NST; ++u) v2[u] = src2[u * NT];
             }
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
+            for (int u = 0; u < NST; ++u) {
                 const int p = tid + u * NT, rr_ = p >> 5, cc_ = (p & 31) << 2;
                 if (need_dh1) *(lf4 *)(img + rr_ * W + (cc_ ^ ((rr_ & 7) << 2))) = v[u];
                 if (need_dz2) *(lf4 *)(img2 + rr_ * W + (cc_ ^ ((rr_ & 7) << 2))) = v2[u];
@@ -517,16 +521,16 @@ __device__ __noinline__ void t3w_backward_wgrad(const T3wCtx *ctx_, float *gpar_
             const lfloat *pb[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) pb[q] = img + L.h * W + 32 * wave + L.colsw[q];
-            const gfloat *xa_ = (const gfloat *)X + (96 * half + L.h) * ldx + (L.li < in ? L.li : in - 1);
+            const gfloat *xa_ = (const gfloat *)X + (HB * half + L.h) * ldx + (L.li < in ? L.li : in - 1);
 #pragma unroll 2
-            for (int t4 = 0; t4 < 48; t4 += 4) {
+            for (int t4 = 0; t4 < HB / 2; t4 += 4) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) accw = __builtin_amdgcn_mfma_f32_32x32x2f32(xa_[2 * (t4 + q) * ldx], pb[q][2 * (t4 + q) * W], accw, 0, 0, 0);
             }
         } else {                                       // waves 4,5: gb1 from the dh1 image; waves 6,7: gb2 from the dz2 image
             const lfloat *img = (const lfloat *)(wave < 6 ? bufB : bufA);
             const int j = tid & 127;
-            for (int i0 = 0; i0 < 96; i0 += 32) {
+            for (int i0 = 0; i0 < HB; i0 += 32) {
                 float x[32];
 #pragma unroll
                 for (int u = 0; u < 32; ++u) x[u] = img[(i0 + u) * W + (j ^ ((u & 7) << 2))];
@@ -675,11 +679,14 @@ template <int SHAPE> __device__ __noinline__ void t3v_learn_step(const T3wCtx *c
     using namespace t3p;
     constexpr T3wShape SP = kT3wShapes[SHAPE];
     using EnvT = ContEnv<SP.env>;
-    constexpr int S = EnvT::S, A = EnvT::A, SA = S + A, B = T3W_B, ACT = SP.act;
+    constexpr int S = EnvT::S, A = EnvT::A, SA = S + A, B = SP.B, NBK = B / 32, ACT = SP.act, PD = SP.policy_delay;
     typedef __attribute__((address_space(3))) const T3wCtx LCtx;
     typedef __attribute__((address_space(3))) int lint;
     const int tid = threadIdx.x;
     const int64_t learn_it = (int64_t)(((uint64_t)uni((int)learn_hi_) << 32) | (uint32_t)uni((int)learn_lo_));
+    // the delayed policy update (TD3.py:101: total_it % policy_delay == 0, total_it = this step's index + 1): actor step + the soft
+    // updates of all three targets on those steps only (uniform over the team: every member counts the same learn steps)
+    const bool policy_step = PD == 1 || (learn_it + 1) % PD == 0;
     const int size_after = uni(size_after_);
     // everything else comes from the context record, freshly at every use site (`cx()` hides the pointer from the optimiser so that no
     // value read through it is carried across a call)
@@ -701,7 +708,7 @@ template <int SHAPE> __device__ __noinline__ void t3v_learn_step(const T3wCtx *c
         wc::team_barrier<true>(ts, tid);
     };
     const int G = uni(cx()->G), g = uni(cx()->g);
-    const int gb0 = 32 * (T3W_NB / G) * g, gbn = 32 * (T3W_NB / G);
+    const int gb0 = 32 * (NBK / G) * g, gbn = 32 * (NBK / G);
     const uint64_t key = ((uint64_t)uni((int)cx()->key_hi) << 32) | (uint32_t)uni((int)cx()->key_lo);
     {
         // ReplayBuffer.sample: one (sample, row element) pair per thread; a team member gathers the rows of its own blocks
@@ -727,7 +734,7 @@ template <int SHAPE> __device__ __noinline__ void t3v_learn_step(const T3wCtx *c
     {
         const Ptrs P = ptrs();
         for (int e = tid; e < gbn * S; e += NT) { const int b = gb0 + e / S, i = e - (b - gb0) * S; P.xa[b * SA + i] = P.xc[b * SA + i]; }
-        t3v_forward<ACT, S, A>(ctx_, 2, SA, 1, P.targets, (float *)P.xn, nullptr, -1, -1, P.params, (float *)P.xc, nullptr, TD_A_H1, TR_A_H2, (float *)P.xn, nullptr, (float *)P.xa, (float *)P.thb, SA, S);
+        t3v_forward<ACT, S, A, NBK>(ctx_, policy_step ? 2 : 1, SA, 1, P.targets, (float *)P.xn, nullptr, -1, -1, P.params, (float *)P.xc, nullptr, TD_A_H1, TR_A_H2, (float *)P.xn, nullptr, (float *)P.xa, (float *)P.thb, SA, S);
     }
     {
         LCtx *c = cx();
@@ -744,11 +751,11 @@ template <int SHAPE> __device__ __noinline__ void t3v_learn_step(const T3wCtx *c
         }
         __syncthreads();
         // the twin target critics side by side on the two quads, then the twin critics
-        t3v_forward<ACT, SA, 1>(ctx_, 2, SA, 0, P.targets + PN, (float *)P.xn, (float *)P.tq1, -1, -1, P.targets + 2 * PN, (float *)P.xn, (float *)P.tq2, -1, -1, nullptr, nullptr, nullptr, nullptr, 0, 0);
+        t3v_forward<ACT, SA, 1, NBK>(ctx_, 2, SA, 0, P.targets + PN, (float *)P.xn, (float *)P.tq1, -1, -1, P.targets + 2 * PN, (float *)P.xn, (float *)P.tq2, -1, -1, nullptr, nullptr, nullptr, nullptr, 0, 0);
     }
     {
         const Ptrs P = ptrs();
-        t3v_forward<ACT, SA, 1>(ctx_, 2, SA, 0, P.params + PN, (float *)P.xc, (float *)P.q1, TD_C1_H1, TR_C1_H2, P.params + 2 * PN, (float *)P.xc, (float *)P.q2, TD_C2_H1, TR_C2_H2, nullptr, nullptr,
+        t3v_forward<ACT, SA, 1, NBK>(ctx_, 2, SA, 0, P.params + PN, (float *)P.xc, (float *)P.q1, TD_C1_H1, TR_C1_H2, P.params + 2 * PN, (float *)P.xc, (float *)P.q2, TD_C2_H1, TR_C2_H2, nullptr, nullptr,
                                 nullptr, nullptr, 0, 0);
     }
     {
@@ -766,7 +773,7 @@ template <int SHAPE> __device__ __noinline__ void t3v_learn_step(const T3wCtx *c
         __syncthreads();
         // per-sample halves of the two critic backwards, side by side; then -- once the whole team is there -- the parameter gradients + the
         // critic optimizer step as wave jobs over the team
-        t3v_backward<ACT, SA, 1>(ctx_, 2, P.params + PN, P.w2u + IMG, (float *)P.dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1,
+        t3v_backward<ACT, SA, 1, NBK>(ctx_, 2, P.params + PN, P.w2u + IMG, (float *)P.dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1,
                                  P.params + 2 * PN, P.w2u + 2 * IMG, (float *)P.dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
     }
     team_barrier();
@@ -776,14 +783,14 @@ template <int SHAPE> __device__ __noinline__ void t3v_learn_step(const T3wCtx *c
         __syncthreads();
         const T3vNet n1{ P.params + PN, P.w2u + IMG, (float *)P.dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1 };
         const T3vNet n2{ P.params + 2 * PN, P.w2u + 2 * IMG, (float *)P.dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B };
-        t3v_wgrad<ACT, SA, 1, SA>(ctx_, 2, n1, n2, (float *)P.xc, SA, 20);                 // critic_optimizer (+ Polyak of the two critics)
+        t3v_wgrad<ACT, SA, 1, SA, NBK>(ctx_, 2, n1, n2, (float *)P.xc, SA, 20, policy_step ? 1 : 0);      // critic_optimizer (+ Polyak of the two critics)
     }
-    // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1 (policy_delay 1); actor(states) is in xa since the
-    // start of the step
+    // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1; actor(states) is in xa since the start of the step
     team_barrier();
+    if (!policy_step) return;
     {
         const Ptrs P = ptrs();
-        t3v_forward<ACT, SA, 1>(ctx_, 1, SA, 0, P.params + PN, (float *)P.xa, (float *)P.dq2, TD_C1_H1, TR_C1_H2, P.params + PN, (float *)P.xa, (float *)P.dq2, -1, -1, nullptr, nullptr, nullptr, nullptr,
+        t3v_forward<ACT, SA, 1, NBK>(ctx_, 1, SA, 0, P.params + PN, (float *)P.xa, (float *)P.dq2, TD_C1_H1, TR_C1_H2, P.params + PN, (float *)P.xa, (float *)P.dq2, -1, -1, nullptr, nullptr, nullptr, nullptr,
                                 0, 0);
     }
     {
@@ -791,13 +798,13 @@ template <int SHAPE> __device__ __noinline__ void t3v_learn_step(const T3wCtx *c
         const float dqa = -(1.0f / (float)B);
         for (int b = tid; b < B; b += NT) P.dq1[b] = dqa;
         __syncthreads();
-        t3v_backward<ACT, SA, 1>(ctx_, 1, P.params + PN, P.w2u + IMG, (float *)P.dq1, TD_C1_H1, TR_C1_H2, -1, -1,
+        t3v_backward<ACT, SA, 1, NBK>(ctx_, 1, P.params + PN, P.w2u + IMG, (float *)P.dq1, TD_C1_H1, TR_C1_H2, -1, -1,
                                  P.params + PN, P.w2u + IMG, (float *)P.dq1, TD_C1_H1, TR_C1_H2, -1, -1, S, A, (float *)P.thb, (float *)P.dzl);
     }
     {
         const Ptrs P = ptrs();
         for (int e = tid; e < gbn * A; e += NT) P.gdz[gb0 * A + e] = P.dzl[gb0 * A + e];
-        t3v_backward<ACT, S, A>(ctx_, 1, P.params, P.w2u, (float *)P.dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B,
+        t3v_backward<ACT, S, A, NBK>(ctx_, 1, P.params, P.w2u, (float *)P.dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B,
                                 P.params, P.w2u, (float *)P.dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
     }
     team_barrier();
@@ -806,7 +813,7 @@ template <int SHAPE> __device__ __noinline__ void t3v_learn_step(const T3wCtx *c
         for (int e = tid; e < B * A; e += NT) P.dzl[e] = P.gdz[e];
         __syncthreads();
         const T3vNet na{ P.params, P.w2u, (float *)P.dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B };
-        t3v_wgrad<ACT, S, A, SA>(ctx_, 1, na, na, (float *)P.xc, SA, 22);                  // actor_optimizer (+ Polyak of the actor)
+        t3v_wgrad<ACT, S, A, SA, NBK>(ctx_, 1, na, na, (float *)P.xc, SA, 22, 1);          // actor_optimizer (+ Polyak of the actor)
     }
     team_barrier();
 }
@@ -818,7 +825,10 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     constexpr T3wShape SP = kT3wShapes[SHAPE];
     using EnvT = ContEnv<SP.env>;
     extern __shared__ __align__(16) float lds[];
-    constexpr int S = EnvT::S, A = EnvT::A, SA = S + A, SD = EnvT::SD, B = T3W_B, Hrn = 128, ACT = SP.act, T = SP.T, RNL = SP.rn_layers;
+    constexpr int S = EnvT::S, A = EnvT::A, SA = S + A, SD = EnvT::SD, B = SP.B, NBK = B / 32, Hrn = SP.hrn, ACT = SP.act, T = SP.T, RNL = SP.rn_layers;
+    constexpr int PD = SP.policy_delay;
+    constexpr bool VENV = SP.venv != 0;
+    static_assert(!VENV || (RNL == 2 && Hrn % 4 == 0 && Hrn <= 128 && T == 1), "the synthetic env's nets: two hidden layers of at most 128 units, 16-byte rows");
     constexpr bool CHEETAH = SP.env == LENV_ENV_CHEETAH_STANDIN;
     constexpr int KREP = SP.k_rep;
     static_assert(S <= 17 && A <= 6 && SD <= 18, "sized for the stand-in");
@@ -847,7 +857,8 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     float *sm_b2 = sm_bo + 8;                             // [2][128], [128][8] + [8]: the second pass of a dual call
     float *sm_wo2 = sm_b2 + 2 * W;
     float *rn_w = sm_wo2 + 8 * W + 8;                     // reward net: W0 [Hrn][S] | b0 [Hrn] | Wout [Hrn] | bout (two hidden layers: in the arena)
-    float *rn_h = rn_w + (RNL == 1 ? ((a.P_rn + 3) & ~3) : Hrn);   // [Hrn] (two hidden layers: rn_w is the second hidden row)
+    float *rn_h = rn_w + (VENV ? 6 * 128 : (RNL == 1 ? ((a.P_rn + 3) & ~3) : Hrn));   // [Hrn] (two hidden layers: rn_w is the second hidden row; a VirtualEnv:
+                                                          // rn_w = the hidden rows [3 nets][2][128], rn_h = its input row [8] | output row [8])
     float *dq1 = rn_h + Hrn;                              // [B]
     float *q1 = dq1 + B;                                  // [B] ... six vectors; from q1 on they double as dz [B][A] in the policy step
     float *q2 = q1 + B, *tq1 = q2 + B, *tq2 = tq1 + B, *rr = tq2 + B, *dd = rr + B;
@@ -955,7 +966,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     };
 #define team_dead (wc::team_is_dead(tsync))
     // sample block of row b -> does it belong to this member (blocks are dealt like the waves that own them)
-    auto my_row = [&](int b) { return G == 1 || ((b >> 5) * G) / T3W_NB == g; };
+    auto my_row = [&](int b) { return G == 1 || ((b >> 5) * G) / NBK == g; };
     if (G > 1 && tid == 0) reinterpret_cast<unsigned *>(gdz)[g] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
 #ifdef LENV_DIAG_TEAM_TIMES
     // diagnostic build: when did this member start / pass the first barrier / leave (ms since the reset kernel), into final_params
@@ -1130,7 +1141,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         __syncthreads();
     };
 
-    auto adam = [&](int p0, int n, int pi) {
+    auto adam = [&](int p0, int n, int pi, bool polyak) {
         if (tid == 0) {
             pows[pi] *= cfg.adam_beta1; pows[pi + 1] *= cfg.adam_beta2;
             ctrl[10] = (float)(-(cfg.lr / (1.0 - pows[pi])));
@@ -1140,13 +1151,13 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         const float neg_step = ctrl[10], bc2_sqrt = ctrl[11];
         const float w1 = (float)(1.0 - cfg.adam_beta1), w2 = (float)(1.0 - cfg.adam_beta2), beta2 = (float)cfg.adam_beta2, aeps = (float)cfg.adam_eps;
         const AdamConsts ac{ neg_step, bc2_sqrt, w1, w2, beta2, aeps };
-        // the Polyak update of the same parameters rides in the pass (TD3.py:104-116 runs it after both optimizer steps; policy_delay
-        // is 1 here and nothing between the critic step and the soft update reads a target net: element for element the same
-        // tau * w + (1 - tau) * t on the same operands)
+        // the Polyak update of the same parameters rides in the pass (TD3.py:104-116 runs it after both optimizer steps of a policy
+        // step; nothing between the critic step and the soft update reads a target net: element for element the same
+        // tau * w + (1 - tau) * t on the same operands); polyak false: a learn step without the delayed policy update
         // a team cuts the range into G pieces of whole float4s
         const int piece = G == 1 ? n : (((n + G - 1) / G + 3) & ~3);
         const int lo = p0 + piece * g, hi = lo + piece < p0 + n ? lo + piece : p0 + n;
-        if (hi > lo) wg_adam(params, adam_m, adam_v, grad, lo, hi - lo, ac, targets, (float)cfg.tau, (float)(1.0 - cfg.tau));
+        if (hi > lo) wg_adam(params, adam_m, adam_v, grad, lo, hi - lo, ac, polyak ? targets : nullptr, (float)cfg.tau, (float)(1.0 - cfg.tau));
         __syncthreads();
     };
 
@@ -1221,6 +1232,69 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         __syncthreads();
     };
 
+    // ---- EnvWrapper.step -> VirtualEnv.step (virtual_env.py:43-54) of the training loop: the three nets of the synthetic env (state,
+    // reward, done; build_nn_from_config: Linear(S + A, H) | Linear(H, H) | Linear(H, out) each, Module.parameters() order, the perturbed
+    // copy in the chain's arena) on the row cat(action, state).  The nets run side by side on thread groups of 128; thread j owns unit j of
+    // its net's layer and runs td3_rn_inner_kernel's k-ascending chain (then + bias, activation).  EnvWrapper.step repeats the step
+    // same_action_num times whatever the done output says and sums the fp32 rewards (env_wrapper.py:24-29); reward and done see the
+    // pre-transition state.  Leaves the replay row in newrow (the caller's barrier follows).
+    auto venv_step = [&]() {
+        static_assert(!VENV || (SA <= 8 && S + 2 <= 8 && Hrn % 32 == 0), "input / output rows of 8 floats, 32-term pieces");
+        lfloat *xse = (lfloat *)rn_h, *nse = xse + 8, *hrow = (lfloat *)rn_w;
+        constexpr int P_HID = Hrn * SA + Hrn + Hrn * Hrn + Hrn, P_STATE = P_HID + S * Hrn + S, P_ONE = P_HID + Hrn + 1;
+        const int net = tid >> 7, j = tid & 127;
+        const bool unit = net < 3 && j < Hrn;
+        const gfloat *np = (const gfloat *)(arena + a.a_rn) + (net == 0 ? 0 : (net == 1 ? P_STATE : P_STATE + P_ONE));
+        const int n_out = net == 0 ? S : 1, ocol = net == 0 ? 0 : S + net - 1;
+        lfloat *h1 = hrow + (2 * (net < 3 ? net : 0)) * 128, *h2 = h1 + 128;
+        if (tid < A) xse[tid] = action[tid];
+        if (tid >= 64 && tid < 64 + S) xse[A + tid - 64] = state[tid - 64];
+        if (tid >= 128 && tid < 128 + S) newrow[tid - 128] = state[tid - 128];
+        if (tid >= 192 && tid < 192 + A) newrow[S + tid - 192] = action[tid - 192];
+        __syncthreads();
+#pragma unroll 1
+        for (int r_ = 0; r_ < KREP; ++r_) {
+            if (unit) {
+                float z = 0.0f;
+#pragma unroll
+                for (int k = 0; k < SA; ++k) z = fma32(xse[k], np[j * SA + k], z);
+                h1[j] = act_fwd(rn_act, cfg.rn_prelu, z + np[Hrn * SA + j]);
+            }
+            __syncthreads();
+            if (unit) {
+                const gf4 *wr = (const gf4 *)(np + Hrn * SA + Hrn + j * Hrn);
+                float z = 0.0f;
+#pragma unroll 1
+                for (int k0 = 0; k0 < Hrn; k0 += 32) {
+                    f32x4 w4[8], h4[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { w4[u] = wr[(k0 >> 2) + u]; h4[u] = *(const lf4 *)(h1 + k0 + 4 * u); }
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) z = fma32(h4[u >> 2][u & 3], w4[u >> 2][u & 3], z);
+                }
+                h2[j] = act_fwd(rn_act, cfg.rn_prelu, z + np[Hrn * SA + Hrn + Hrn * Hrn + j]);
+            }
+            __syncthreads();
+            if (net < 3 && j < n_out) {
+                const gf4 *wr = (const gf4 *)(np + P_HID + j * Hrn);
+                float z = 0.0f;
+#pragma unroll 1
+                for (int k0 = 0; k0 < Hrn; k0 += 32) {
+                    f32x4 w4[8], h4[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { w4[u] = wr[(k0 >> 2) + u]; h4[u] = *(const lf4 *)(h2 + k0 + 4 * u); }
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) z = fma32(h4[u >> 2][u & 3], w4[u >> 2][u & 3], z);
+                }
+                nse[ocol + j] = z + np[P_HID + n_out * Hrn + j];
+            }
+            __syncthreads();
+            if (tid < S) { newrow[S + A + tid] = nse[tid]; xse[A + tid] = nse[tid]; }
+            if (tid == 64) { newrow[2 * S + A] = r_ == 0 ? nse[S] : newrow[2 * S + A] + nse[S]; newrow[2 * S + A + 1] = nse[S + 1]; }
+            if (r_ + 1 < KREP) __syncthreads();
+        }
+    };
+
     // ---- real-env test phase (BaseAgent.test): T episodes one after the other (the envs of this kernel never terminate: every episode
     // takes max_steps steps, and the reset row / noise rows of an episode have fixed indices -- td3_rn_inner_kernel's lock-step rollouts
     // draw the same ones), actions from the one-row actor + exploration noise (TD3.py:126-129) ----
@@ -1293,9 +1367,9 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
         __syncthreads();
         if (tid < S) state[tid] = EnvT::obs(tid, xs_d);
         __syncthreads();
-        if (rtype == 1 || rtype == 2) rn_eval(state, 12);
+        if (!VENV && (rtype == 1 || rtype == 2)) rn_eval(state, 12);
         int ep_len = 0, env_steps = 0;
-        for (int t = 0; t < cfg.max_steps; ++t) {
+        for (int t = 0; t < cfg.max_steps; t += VENV ? KREP : 1) {      // (base_agent.py:104 range(0, max_steps, same_action_num); a RewardEnv's TimeLimit ends its loop)
             const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
             const int new_pos = train_steps % rb_cap;
             if (!learning) {
@@ -1312,6 +1386,8 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 ++n_actn;
                 __syncthreads();
             }
+            if constexpr (VENV) venv_step();
+            else {
             // ---- EnvWrapper.step -> RewardEnv.step -> real_env.step + TimeLimit ----
             if (tid < S) newrow[tid] = state[tid];
             if (tid >= 64 && tid < 64 + A) newrow[S + tid - 64] = action[tid - 64];
@@ -1350,6 +1426,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 if (dn) break;                             // (uniform) the repeats stop at done
                 if (r_ + 1 < KREP) __syncthreads();
             }
+            }
             __syncthreads();
             if (tid < 2 * S + A + 2) rb[(int64_t)new_pos * RS + tid] = newrow[tid];
             const float done_now = newrow[2 * S + A + 1];
@@ -1363,9 +1440,12 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 if (G >= 3) {
                     // ================= a member with one or two sample blocks: the team path (td3_wavechain_team.cuh) =================
                     if (tid == 0) {                        // torch.optim.Adam's bias corrections of this step's two optimizer steps
-                        pows[0] *= cfg.adam_beta1; pows[1] *= cfg.adam_beta2; pows[2] *= cfg.adam_beta1; pows[3] *= cfg.adam_beta2;
+                        pows[0] *= cfg.adam_beta1; pows[1] *= cfg.adam_beta2;
                         ctrl[20] = (float)(-(cfg.lr / (1.0 - pows[0]))); ctrl[21] = (float)__builtin_sqrt(1.0 - pows[1]);      // (12, 13: the reward net's phi values)
-                        ctrl[22] = (float)(-(cfg.lr / (1.0 - pows[2]))); ctrl[23] = (float)__builtin_sqrt(1.0 - pows[3]);
+                        if (PD == 1 || (learn_it + 1) % PD == 0) {        // the actor's optimizer steps on the delayed policy updates only
+                            pows[2] *= cfg.adam_beta1; pows[3] *= cfg.adam_beta2;
+                            ctrl[22] = (float)(-(cfg.lr / (1.0 - pows[2]))); ctrl[23] = (float)__builtin_sqrt(1.0 - pows[3]);
+                        }
                     }
                     // replay gather, five forward calls, three backward chains, the two optimizer job phases and the four team barriers:
                     // one out-of-line routine, so that this body has ONE call boundary per learn step (t3v_learn_step)
@@ -1375,7 +1455,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                     act_lds_load();                        // the updated actor, for the next env steps / the test episode
                     TPT_MARK(8);
                 } else {
-                const int gb0 = G == 1 ? 0 : 32 * (T3W_NB / G) * g, gbn = G == 1 ? B : 32 * (T3W_NB / G);
+                const int gb0 = G == 1 ? 0 : 32 * (NBK / G) * g, gbn = G == 1 ? B : 32 * (NBK / G);
 #pragma unroll 4
                 for (int e = tid; e < gbn * (2 * S + A + 2); e += NT) {
                     const int b = gb0 + e / (2 * S + A + 2), i = e - (b - gb0) * (2 * S + A + 2);
@@ -1390,7 +1470,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 __syncthreads();
                 TPT_MARK(1);
                 // next_actions = (actor_target(s') + clamp(randn * policy_std)).clamp(-max, max)
-                t3w_forward<ACT, S, A>(ctx, targets, xn, SA, 1, nullptr, xn, SA, S, nullptr, -1, -1, -1);
+                t3w_forward<ACT, S, A, NBK>(ctx, targets, xn, SA, 1, nullptr, xn, SA, S, nullptr, -1, -1, -1);
                 for (int e = tid; e < B * A; e += NT) {
                     const int b = e / A, k = e - b * A;
                     if (!my_row(b)) continue;
@@ -1407,8 +1487,8 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 {
                     // three blocks per member (G = 2): twin critics side by side on six waves; one workgroup per chain: the twelve
                     // block-passes of the twin critics on eight waves, three per SIMD
-                    t3w_forward<ACT, SA, 1>(ctx, targets + PN, xn, SA, 0, tq1, nullptr, 0, 0, nullptr, -1, -1, -1, targets + 2 * PN, xn, tq2, -1, -1);
-                    t3w_forward<ACT, SA, 1>(ctx, params + PN, xc, SA, 0, q1, nullptr, 0, 0, nullptr, TD_C1_H1, TD_C1_H2, TR_C1_H2, params + 2 * PN, xc, q2,
+                    t3w_forward<ACT, SA, 1, NBK>(ctx, targets + PN, xn, SA, 0, tq1, nullptr, 0, 0, nullptr, -1, -1, -1, targets + 2 * PN, xn, tq2, -1, -1);
+                    t3w_forward<ACT, SA, 1, NBK>(ctx, params + PN, xc, SA, 0, q1, nullptr, 0, 0, nullptr, TD_C1_H1, TD_C1_H2, TR_C1_H2, params + 2 * PN, xc, q2,
                                             TD_C2_H1, TR_C2_H2);
                 }
                 TPT_MARK(3);
@@ -1428,44 +1508,45 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
                 // per-sample halves of the two critic backwards (this member's blocks), then -- once the whole team is there -- the
                 // parameter gradients, cut by wave over the team
                 // G = 2 and one workgroup per chain: the twin critics' chains side by side
-                t3w_backward_chain<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1, 0, 0, nullptr, nullptr,
+                t3w_backward_chain<ACT, SA, 1, NBK>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1, 0, 0, nullptr, nullptr,
                                                    params + 2 * PN, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B);
                 team_barrier();
                 if (G > 1) {
                     for (int b = tid; b < B; b += NT) { dq1[b] = gdq[b]; dq2[b] = gdq[B + b]; }
                     __syncthreads();
                 }
-                t3w_backward_wgrad<ACT, SA, 1>(ctx, grad + PN, xc, SA, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1, 0, 2 * NW);
-                t3w_backward_wgrad<ACT, SA, 1>(ctx, grad + 2 * PN, xc, SA, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B, NW, 2 * NW);
+                t3w_backward_wgrad<ACT, SA, 1, NBK>(ctx, grad + PN, xc, SA, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, TR_DH1, 0, 2 * NW);
+                t3w_backward_wgrad<ACT, SA, 1, NBK>(ctx, grad + 2 * PN, xc, SA, dq2, TD_C2_H1, TR_C2_H2, TR_DZ2B, TR_DH1B, NW, 2 * NW);
                 TPT_MARK(5);
                 team_barrier();
-                adam(PN, 2 * PN, 0);                       // critic_optimizer
+                const bool policy_step = PD == 1 || (learn_it + 1) % PD == 0;      // TD3.py:101 (total_it = learn_it + 1)
+                adam(PN, 2 * PN, 0, policy_step);          // critic_optimizer (+ the critics' soft update on a policy step)
                 team_barrier();
                 TPT_MARK(6);
                 ++learn_it;
-                {
-                    // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1 (policy_delay 1)
+                if (policy_step) {
+                    // actor_loss = (-critic_1(states, actor(states))).mean() with the updated critic_1
                     for (int e = tid; e < gbn * S; e += NT) { const int b = gb0 + e / S, i = e - (b - gb0) * S; xa[b * SA + i] = xc[b * SA + i]; }
                     __syncthreads();
-                    t3w_forward<ACT, S, A>(ctx, params, xc, SA, 1, nullptr, xa, SA, S, thb, TD_A_H1, TD_A_H2, TR_A_H2);
-                    t3w_forward<ACT, SA, 1>(ctx, params + PN, xa, SA, 0, dq2, nullptr, 0, 0, nullptr, TD_C1_H1, -1, TR_C1_H2);
+                    t3w_forward<ACT, S, A, NBK>(ctx, params, xc, SA, 1, nullptr, xa, SA, S, thb, TD_A_H1, TD_A_H2, TR_A_H2);
+                    t3w_forward<ACT, SA, 1, NBK>(ctx, params + PN, xa, SA, 0, dq2, nullptr, 0, 0, nullptr, TD_C1_H1, -1, TR_C1_H2);
                     const float dqa = -(1.0f / (float)B);
                     for (int b = tid; b < B; b += NT) dq1[b] = dqa;
                     __syncthreads();
-                    t3w_backward_chain<ACT, SA, 1>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, -1, S, A, thb, dzl);
+                    t3w_backward_chain<ACT, SA, 1, NBK>(ctx, params + PN, dq1, TD_C1_H1, TR_C1_H2, TR_DZ2, -1, S, A, thb, dzl);
                     if (G > 1) {
                         for (int e = tid; e < B * A; e += NT) if (my_row(e / A)) gdz[e] = dzl[e];
                     }
-                    t3w_backward_chain<ACT, S, A>(ctx, params, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
+                    t3w_backward_chain<ACT, S, A, NBK>(ctx, params, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, 0, nullptr, nullptr);
                     team_barrier();
                     if (G > 1) {
                         for (int e = tid; e < B * A; e += NT) dzl[e] = gdz[e];
                         __syncthreads();
                     }
-                    t3w_backward_wgrad<ACT, S, A>(ctx, grad, xc, SA, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, NW);
+                    t3w_backward_wgrad<ACT, S, A, NBK>(ctx, grad, xc, SA, dzl, TD_A_H1, TR_A_H2, TR_DZ2B, TR_DH1B, 0, NW);
                     TPT_MARK(7);
                     team_barrier();
-                    adam(0, PN, 2);
+                    adam(0, PN, 2, true);
                     team_barrier();
                     TPT_MARK(8);
                 }
@@ -1568,7 +1649,12 @@ using namespace lenv;
 int lenv_wc_td3_shape(const lenv_td3_cfg *cfg)
 {
     const int k_rep = cfg->same_action_num > 1 ? cfg->same_action_num : 1;
-    if (!(cfg->hidden == 128 && cfg->layers == 2 && cfg->batch_size == T3W_B && cfg->rn_hidden == 128 && !cfg->virtual_env &&
+    // default_config_cmc.yaml: TD3 on a VirtualEnv (three 3-96-96-x nets), batch 256, delayed policy updates
+    if (cfg->hidden == 128 && cfg->layers == 2 && cfg->batch_size == 256 && cfg->virtual_env && cfg->rn_hidden == 96 && cfg->rn_layers == 2 && cfg->policy_delay == 2 &&
+        !cfg->icm_enabled && !cfg->use_layer_norm && !cfg->rn_layer_norm && cfg->env_id == LENV_ENV_CMC && cfg->state_dim == 2 && cfg->action_dim == 1 &&
+        cfg->test_episodes == 1 && cfg->act == LENV_ACT_RELU && k_rep == 2)
+        return 4;
+    if (!(cfg->hidden == 128 && cfg->layers == 2 && cfg->batch_size == 192 && cfg->rn_hidden == 128 && !cfg->virtual_env &&
           cfg->policy_delay == 1 && !cfg->icm_enabled && !cfg->use_layer_norm && !(cfg->rn_layer_norm && cfg->rn_layers >= 2) &&
           (cfg->reward_env_type == 0 || cfg->reward_env_type == 1 || cfg->reward_env_type == 2 || cfg->reward_env_type == 5 || cfg->reward_env_type == 6)))
         return 0;
@@ -1584,18 +1670,31 @@ int lenv_wc_td3_shape(const lenv_td3_cfg *cfg)
     return 0;
 }
 
+// parameters of the training env's nets that live in the chain's arena: a reward net with several hidden layers, or the three nets of a VirtualEnv
+static int64_t t3w_env_arena_params(const lenv_td3_cfg *cfg)
+{
+    if (cfg->virtual_env) {
+        const int64_t H = cfg->rn_hidden, in = cfg->state_dim + cfg->action_dim;
+        int64_t hid = H * in + H;
+        for (int l = 1; l < cfg->rn_layers; ++l) hid += H * H + H;
+        return 3 * hid + (cfg->state_dim * H + cfg->state_dim) + 2 * (H + 1);
+    }
+    return cfg->rn_layers > 1 ? lenv_rn_num_params(cfg->reward_env_type, cfg->state_dim, cfg->info_dim, cfg->rn_hidden, cfg->rn_layers) : 0;
+}
+
 static void t3w_offsets(const lenv_td3_cfg *cfg, int64_t rb_cap, int RS, T3wArgs &a, int64_t *total)
 {
-    const int SA = 23, B = T3W_B;
+    const int shape = lenv_wc_td3_shape(cfg);
+    const int SA = 23, B = kT3wShapes[shape].B, NBK = B / 32;
     int64_t off = 0;
     auto take = [&](int64_t n) { int64_t r = off; off += (n + 3) & ~(int64_t)3; return r; };
     a.a_par = take(5 * 3 * (int64_t)t3p::PN); a.a_xc = take((int64_t)B * SA); a.a_xn = take((int64_t)B * SA); a.a_xa = take((int64_t)B * SA);
-    a.a_th = take((int64_t)B * 6); a.a_dump = take((int64_t)T3W_NDUMP * T3W_NB * wc::BLK); a.a_replay = take(rb_cap * RS);
+    a.a_th = take((int64_t)B * 6); a.a_dump = take((int64_t)T3W_NDUMP * NBK * wc::BLK); a.a_replay = take(rb_cap * RS);
     a.a_meter = take(2 * (int64_t)(cfg->train_episodes > 0 ? cfg->train_episodes : 1));
     a.a_gx = take(2 * (int64_t)B + (int64_t)B * 6);             // team exchange: dq1 | dq2 | dz
     a.a_bar = take(16);                                          // team barrier counter (one cache line of its own would be 32 floats; the slot is padded below)
     a.a_w2u = take(3 * (int64_t)wc::IMG);                        // team path: unit-major copies W2u[j][k] of the three online second layers
-    a.a_rn = take(cfg->rn_layers > 1 ? lenv_rn_num_params(cfg->reward_env_type, cfg->state_dim, cfg->info_dim, cfg->rn_hidden, cfg->rn_layers) : 0);   // a deeper reward net
+    a.a_rn = take(t3w_env_arena_params(cfg));                   // a deeper reward net / the VirtualEnv's nets
     *total = (off + 63) & ~(int64_t)63;
 }
 
@@ -1613,28 +1712,34 @@ __global__ void t3w_team_reset_kernel(float *arena, int64_t arena_stride, int64_
 
 static size_t t3w_lds_bytes(int shape, int P_rn)
 {
-    const int B = T3W_B, T = kT3wShapes[shape].T;
-    const size_t rn_floats = kT3wShapes[shape].rn_layers == 1 ? (size_t)((P_rn + 3) & ~3) : 128;      // the net itself, or the second hidden row
+    const int B = kT3wShapes[shape].B, T = kT3wShapes[shape].T;
+    // the reward net itself, or its second hidden row, or the hidden rows of a VirtualEnv's three nets
+    const size_t rn_floats = kT3wShapes[shape].venv ? 6 * 128 : (kT3wShapes[shape].rn_layers == 1 ? (size_t)((P_rn + 3) & ~3) : 128);
     const size_t lds_floats = 2 * (size_t)wc::IMG + 2 * (2 * wc::W + 8 * wc::W + 8) + rn_floats + 128 + 8 * (size_t)B + 2 * wc::W + 64 + 2 + 2 * (20 + 17 * T + T) + 2 * T + 1 +
                               20 + 8 + 56 + 4 + (sizeof(T3wCtx) + 3) / 4;
     return lds_floats * sizeof(float);
 }
-static void (*t3w_kernel(int shape))(const T3wArgs) { return shape == 3 ? td3_wavechain_kernel<3> : (shape == 2 ? td3_wavechain_kernel<2> : td3_wavechain_kernel<1>); }
+static void (*t3w_kernel(int shape))(const T3wArgs)
+{
+    return shape == 4 ? td3_wavechain_kernel<4> : (shape == 3 ? td3_wavechain_kernel<3> : (shape == 2 ? td3_wavechain_kernel<2> : td3_wavechain_kernel<1>));
+}
 
 // Workgroups per chain.  A team only works when every workgroup of the launch is resident at the same time (its members wait for each
 // other): 8 * ceil(chains / 8) * G workgroups must fit the device (occupancy API: one per CU at this kernel's LDS footprint).  192
-// minibatch rows = 6 sample blocks: G = 6, 3, 2 or 1; cfg->team_size caps the choice (0 = automatic, 1 = the plain launch).
+// minibatch rows = 6 sample blocks: G = 6, 3, 2 or 1; 256 rows = 8 blocks: G = 8, 4, 2 or 1; cfg->team_size caps the choice (0 =
+// automatic, 1 = the plain launch).
 static int t3w_pick_team(const lenv_td3_cfg *cfg, int64_t chains)
 {
-    const int want = cfg->team_size > 0 ? cfg->team_size : 6;
+    const int want = cfg->team_size > 0 ? cfg->team_size : 8;
     if (want == 1 || chains < 1) return 1;
-    const int P_rn = (int)lenv_rn_num_params(cfg->reward_env_type, cfg->state_dim, cfg->info_dim, cfg->rn_hidden, cfg->rn_layers);
+    const int P_rn = cfg->virtual_env ? 0 : (int)lenv_rn_num_params(cfg->reward_env_type, cfg->state_dim, cfg->info_dim, cfg->rn_hidden, cfg->rn_layers);
     const int shape = lenv_wc_td3_shape(cfg);
     if (!shape) return 1;
     void (*kern)(const T3wArgs) = t3w_kernel(shape);
     const int64_t padded = 8 * ((chains + 7) / 8);
-    for (int G : { 6, 3, 2 })
-        if (G <= want && lenv_team_grid_resident(reinterpret_cast<const void *>(kern), wc::NT, t3w_lds_bytes(shape, P_rn), padded * G)) return G;
+    const int NBK = kT3wShapes[shape].B / 32;
+    for (int G : { 8, 6, 4, 3, 2 })
+        if (NBK % G == 0 && G <= want && lenv_team_grid_resident(reinterpret_cast<const void *>(kern), wc::NT, t3w_lds_bytes(shape, P_rn), padded * G)) return G;
     return 1;
 }
 

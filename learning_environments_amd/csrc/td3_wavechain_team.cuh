@@ -1,5 +1,5 @@
 // td3_wavechain_team.cuh -- the learn step of td3_wavechain_kernel for a chain on a team of G >= 3 workgroups (a member owns one
-// or two of the six 32-sample blocks of the minibatch).  Included by td3_wavechain.hip; same products and the same canonical
+// or two of the six -- batch 256: eight -- 32-sample blocks of the minibatch).  Included by td3_wavechain.hip; same products and the same canonical
 // k-ascending chains as the one-workgroup routines there -- hence the same bits -- but built for a member that has few samples and
 // a whole CU to itself:
 //
@@ -49,7 +49,7 @@ __device__ __forceinline__ f32x4 head16_chain(const float (&a)[32], const float 
 // ---- one or two network passes (quad q runs job q) over this member's sample blocks ----------------------------------------------
 // mode 0 (Critic_Q): q_out[i] = net(x)      mode 1 (Actor_TD3): Y[i][ocol + c] = tanh(net(x)) * max_action, th_out[i][c] = tanh (if given)
 // d_h1 / r_h2 (>= 0): plain [sample][unit] copies of the hidden activations in the dump area (for the backward pass)
-template <int ACT, int IN, int OUT>
+template <int ACT, int IN, int OUT, int NBK>
 __device__ __noinline__ void t3v_forward(const T3wCtx *ctx_, int njobs_, int ldx_, int mode_,
                                          const float *par0_, const float *X0_, float *q_out0_, int d_h1_0_, int r_h2_0_,
                                          const float *par1_, const float *X1_, float *q_out1_, int d_h1_1_, int r_h2_1_,
@@ -65,7 +65,7 @@ __device__ __noinline__ void t3v_forward(const T3wCtx *ctx_, int njobs_, int ldx
     const int d_h1 = uni(q1 ? d_h1_1_ : d_h1_0_), r_h2 = uni(q1 ? r_h2_1_ : r_h2_0_);
     float *Y = uni_ptr(q1 ? Y1_ : Y0_), *th_out = uni_ptr(q1 ? th_out1_ : th_out0_);
     constexpr int in = IN, out = OUT;
-    const int nb = T3W_NB / TG;
+    const int nb = NBK / TG;
     float *xch0 = bufA + quad * 4096, *xch1 = bufA + 8192 + quad * 4096;
     TSUB_DECL;
     // the wave's weights: its 32 columns of W1t and W2t, the two bias slices, the output layer (waves that run a head).  Issue order =
@@ -197,7 +197,7 @@ __device__ __noinline__ void t3v_forward(const T3wCtx *ctx_, int njobs_, int ldx
 // ---- backward of one or two networks, first half: the per-sample chain from dOut[i][out] (LDS) back to dz2 and dh1 (row-major copies
 // r_dz2 / r_dh1 in the arena for the weight gradients; < 0: not needed) and, for the policy step (job 0, dx_n > 0), the action part of the
 // input gradient turned into the actor's output gradient dz (LDS).  w2u: the unit-major copy W2u[j][k] of the net's second layer. ----
-template <int ACT, int IN, int OUT>
+template <int ACT, int IN, int OUT, int NBK>
 __device__ __noinline__ void t3v_backward(const T3wCtx *ctx_, int njobs_,
                                           const float *par0_, const float *w2u0_, const float *dOut0_, int d_h1_0_, int r_h2_0_, int r_dz2_0_, int r_dh1_0_,
                                           const float *par1_, const float *w2u1_, const float *dOut1_, int d_h1_1_, int r_h2_1_, int r_dz2_1_, int r_dh1_1_,
@@ -215,7 +215,7 @@ __device__ __noinline__ void t3v_backward(const T3wCtx *ctx_, int njobs_,
     const float *th = uni_ptr(th_);
     lfloat *dz_out = (lfloat *)uni_ptr(dz_out_);
     constexpr int out = OUT;
-    const int nb = T3W_NB / TG;
+    const int nb = NBK / TG;
     float *xch0 = bufA + quad * 4096, *xch1 = bufA + 8192 + quad * 4096;
     TSUB_DECL;
     // the wave's weights: the output-layer rows of its 16 units, its 32 columns k of W2u (A[k][j] = W2[j][k]) and -- policy step -- the
@@ -342,16 +342,16 @@ struct T3vNet {
     int d_h1, r_h2, r_dz2, r_dh1;
 };
 
-// acc = sum_{i < 192} A[i][ca] * Bm[i][cb], i ascending in ONE chain: lane (li, h) reads rows 2 t + h of the two row-major arrays
+// acc = sum_{i < B} A[i][ca] * Bm[i][cb] (B = 2 NS rows), i ascending in ONE chain: lane (li, h) reads rows 2 t + h of the two row-major arrays
 // (pa / pb already point at its row h and column), D k-steps of operands in flight (more in flight did not help: 28 deep the eight waves' outstanding lines
 // overran the 32 KB L1 and the chain got slower)
 #ifdef T3V_DIAG_WIDE
 // timing experiment (results are garbage): the same bytes per k-step, but fetched as ONE 16-byte load per operand every FOUR steps -- a
 // quarter of the vector-memory instructions
-template <int LDA>
+template <int LDA, int NS>
 __device__ __forceinline__ f32x16 t3v_wgrad_chain(const gfloat *pa, const gfloat *pb)
 {
-    constexpr int D = 16, NS = T3W_B / 2;
+    constexpr int D = 16;
     f32x16 acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
@@ -369,10 +369,10 @@ __device__ __forceinline__ f32x16 t3v_wgrad_chain(const gfloat *pa, const gfloat
     return acc;
 }
 #else
-template <int LDA>
+template <int LDA, int NS>
 __device__ __forceinline__ f32x16 t3v_wgrad_chain(const gfloat *pa, const gfloat *pb)
 {
-    constexpr int D = 14, NS = T3W_B / 2;
+    constexpr int D = 14;
     f32x16 acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
@@ -407,22 +407,25 @@ __device__ unsigned long long g_t3v_jobs[2][5][2];
 #define TJOB_ADD(cls)
 #endif
 
-template <int ACT, int IN, int OUT, int LDX>
-__device__ __noinline__ void t3v_wgrad(const T3wCtx *ctx_, int nnets_, const T3vNet n0_, const T3vNet n1_, const float *X_, int ldx_, int ac_slot_)
+// polyak_ == 0 (a learn step without the delayed policy update, TD3.py:101): the targets stay as they are (tau = 0, 1 - tau = 1: the
+// epilogue's tau * w + (1 - tau) * t returns t)
+template <int ACT, int IN, int OUT, int LDX, int NBK>
+__device__ __noinline__ void t3v_wgrad(const T3wCtx *ctx_, int nnets_, const T3vNet n0_, const T3vNet n1_, const float *X_, int ldx_, int ac_slot_, int polyak_)
 {
     T3W_CTX_PROLOGUE;
     const int nnets = uni(nnets_), ac_slot = uni(ac_slot_);
     (void)ldx_;
-    constexpr int in = IN, out = OUT, B = T3W_B;                 // X = the gathered [s, a] rows (LDX = S + A); the actor reads their first S columns
+    constexpr int in = IN, out = OUT, B = 32 * NBK, CH = B % 48 == 0 ? 48 : 32;      // (CH: rows per batch of loads of the vector jobs) X = the gathered [s, a] rows (LDX = S + A); the actor reads their first S columns
     const float *X = uni_ptr(X_);
     const int64_t o_t = 3 * PN, o_m = 6 * PN, o_v = 9 * PN;     // params | targets | adam_m | adam_v (3 nets each)
     volatile lfloat *ctrl = (volatile lfloat *)uni_ptr(c->ctrl);
     const AdamConsts ac{ ctrl[ac_slot], ctrl[ac_slot + 1], unif(c->w1), unif(c->w2), unif(c->beta2), unif(c->aeps) };
-    const float tau = unif(c->tau), omt = unif(c->omt);
+    const bool polyak = uni(polyak_) != 0;
+    const float tau = polyak ? unif(c->tau) : 0.0f, omt = polyak ? unif(c->omt) : 1.0f;
     float *tile = bufB + wave * 1024, *tileT = bufA + wave * 1056;     // the wave's gradient tile and its transposed copy ([32][33])
     constexpr int NJ = 24 + 2 * out;                       // jobs per net: 16 + 4 matrix-core tiles, 2 + 2 bias halves, 2 per output unit
     // Dealing the jobs.  Matrix-core jobs in the order (net, W2 tiles by (kt, jt), W1 tiles) go to the members in BLOCKS: a member's six or
-    // seven tiles share their operand panels (the four jt tiles of one kt read the same 192 x 32 slice of h1, tiles of one jt the same slice
+    // seven tiles share their operand panels (the four jt tiles of one kt read the same B x 32 slice of h1, tiles of one jt the same slice
     // of dz2), its waves walk them in step, and what one wave has pulled into the CU's L1 the next finds there -- dealt round robin over
     // the team every tile fetched both its panels through the L1's 64-byte port and the phase ran at that port's speed.  The vector jobs
     // are dealt round robin and run on the member's remaining waves.  Wave w of a member runs entries w, w + 8, ... of its list.
@@ -460,11 +463,11 @@ __device__ __noinline__ void t3v_wgrad(const T3wCtx *ctx_, int nnets_, const T3v
             if (w2) {
                 const gfloat *pa = (const gfloat *)dump_of(d_h1, 0) + L.h * W + 32 * kt + L.li;
                 const gfloat *pb = (const gfloat *)dump_of(r_dz2, 0) + L.h * W + 32 * jt + L.li;
-                acc = t3v_wgrad_chain<W>(pa, pb);
+                acc = t3v_wgrad_chain<W, B / 2>(pa, pb);
             } else {
                 const gfloat *pa = (const gfloat *)X + L.h * LDX + (L.li < in ? L.li : in - 1);
                 const gfloat *pb = (const gfloat *)dump_of(r_dh1, 0) + L.h * W + 32 * jt + L.li;
-                acc = t3v_wgrad_chain<LDX>(pa, pb);
+                acc = t3v_wgrad_chain<LDX, B / 2>(pa, pb);
             }
             TJOB_ADD(4);
             t3v_tile_adam(acc, st, tile, tileT, L, par + off, am + off, av + off, tgt + off, w2 ? 32 : in, w2 ? w2u + (32 * jt) * W + 32 * kt : nullptr, ac, tau,
@@ -476,12 +479,12 @@ __device__ __noinline__ void t3v_wgrad(const T3wCtx *ctx_, int nnets_, const T3v
             const gfloat *src = (const gfloat *)dump_of(job < 22 ? r_dh1 : r_dz2, 0) + j;
             float s = 0.0f;
 #pragma unroll 1
-            for (int i0 = 0; i0 < B; i0 += 48) {
-                float x[48];
+            for (int i0 = 0; i0 < B; i0 += CH) {
+                float x[CH];
 #pragma unroll
-                for (int u = 0; u < 48; ++u) x[u] = src[(i0 + u) * W];
+                for (int u = 0; u < CH; ++u) x[u] = src[(i0 + u) * W];
 #pragma unroll
-                for (int u = 0; u < 48; ++u) s = s + x[u];
+                for (int u = 0; u < CH; ++u) s = s + x[u];
             }
             const int off = (job < 22 ? ob1 : ob2) + j;
             t3v_adam1(s, par, am, av, tgt, off, ac, tau, omt);
@@ -493,12 +496,12 @@ __device__ __noinline__ void t3v_wgrad(const T3wCtx *ctx_, int nnets_, const T3v
             const gfloat *src = (const gfloat *)dump_of(r_h2, 0) + k;
             float s = 0.0f, sb = 0.0f;
 #pragma unroll 1
-            for (int i0 = 0; i0 < B; i0 += 48) {
-                float x[48];
+            for (int i0 = 0; i0 < B; i0 += CH) {
+                float x[CH];
 #pragma unroll
-                for (int u = 0; u < 48; ++u) x[u] = src[(i0 + u) * W];
+                for (int u = 0; u < CH; ++u) x[u] = src[(i0 + u) * W];
 #pragma unroll
-                for (int u = 0; u < 48; ++u) {
+                for (int u = 0; u < CH; ++u) {
                     const float d = dOut[(i0 + u) * out + cc];
                     s = fma32(d, x[u], s);
                     sb = sb + d;

@@ -3022,6 +3022,58 @@ def test_wavechain_td3_cmc_shape_every_team_size(eng, orc):
         assert np.array_equal(ref[4][c], o["final_params"])
 
 
+def test_wavechain_td3_cmc_virtual_env_shape_every_team_size(eng, orc):
+    """The TD3 wave-chain kernel's fourth shape -- default_config_cmc.yaml: TD3 (actor 2-128-128-1, twin critics 3-128-128-1, relu) trained
+    on a VirtualEnv (three nets 3-96-96-{2,1,1} on cat(action, state), leakyrelu; the learned done output ends an episode), batch 256 = eight
+    sample blocks, policy_delay 2 (actor step and soft updates every second learn step), same_action_num 2, one real-env test episode -- in
+    production launches with G = 1, 2, 4, 8 workgroups per chain against the GEMM-queue kernel and, on two whole chains, the oracle: all
+    outputs + the 51 331 final parameters, bit for bit."""
+    import ctypes as C
+    from learning_environments_amd import _lib, configs
+    from learning_environments_amd.agents.nes_common import chain_keys
+    cfgd = configs.fixed_work(configs.cmc_syn_env_td3(2), 3)
+    cfgd["agents"]["td3"]["init_episodes"] = 1
+    cfgd["envs"]["MountainCarContinuous-v0"]["max_steps"] = 41       # odd: range(0, 41, 2) = 21 agent steps per training episode
+    ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
+    assert (cfg.state_dim, cfg.action_dim, cfg.hidden, cfg.layers, cfg.batch_size, cfg.test_episodes, cfg.rn_hidden, cfg.rn_layers, cfg.policy_delay,
+            cfg.same_action_num, cfg.virtual_env) == (2, 1, 128, 2, 256, 1, 96, 2, 2, 2, 1)
+    chains = 5
+    Pa, Pc = orc.td3_param_counts(ocfg)
+    assert Pa + 2 * Pc == 51331
+    P_se = orc.mlp_num_params(orc.mlp_desc(3, 96, 2, 2, "leakyrelu")) + 2 * orc.mlp_num_params(orc.mlp_desc(3, 96, 2, 1, "leakyrelu"))
+    rng = np.random.RandomState(28)
+    theta = (rng.randn(P_se) * 0.1).astype(np.float32)
+    eps = (rng.randn(2, P_se) * 0.05).astype(np.float32)
+    worker = (np.arange(chains) // 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), 2)[:chains].copy()
+    keys = chain_keys(84, 2, worker, np.arange(chains) % 3)
+    init = rng.uniform(-0.08, 0.08, (chains, Pa + 2 * Pc)).astype(np.float32)
+
+    def run(trace_cap):
+        il = eng.Td3InnerLoop(cfg, chains, trace_cap=trace_cap, want_final_params=True, want_episode_stats=True)
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return [t.cpu().numpy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_params, il.episode_len)]
+
+    ref = run(2)                                            # GEMM-queue kernel (a launch with a step trace)
+    assert ref[1][:, 2].min() >= 20 and ref[5].max() == 42  # learn steps; episode_length += same_action_num per agent step (base_agent.py:122)
+    assert _lib.lib().lenv_td3_rn_team_size(C.byref(cfg), chains) == 8
+    for G in (1, 2, 4, 8):
+        cfg.team_size = G
+        out = run(0)
+        for x, y in zip(out, ref):
+            assert np.array_equal(x, y, equal_nan=True), G
+    for c in (0, 4):
+        w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+        o = orc.td3_rn_chain(ocfg, w, init[c], rng_key=int(keys[c]), want_final_params=True)
+        assert float(ref[0][c]) == o["score"]
+        assert ref[1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert np.array_equal(ref[2][c], o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(ref[3][c], o["final_test_returns"])
+        assert np.array_equal(ref[4][c], o["final_params"])
+
+
 def test_wavechain_td3_cmc_episodes_that_end_at_the_flag(eng, orc):
     """MountainCarContinuous-v0 terminates: with an actor that pushes in the direction of the velocity (hand-built weights: tanh(k v)) the
     car reaches the flag long before max_steps.  No learn step touches the actor here (init_episodes = train_episodes: random-action

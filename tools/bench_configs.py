@@ -110,6 +110,18 @@ if __name__ == "__main__":
                 c["envs"]["MountainCarContinuous-v0"]["max_steps"] = 200
                 c["agents"]["gtn"]["kernel_variant"] = variant
                 run("MountainCarContinuous RN + TD3 pop %d (3 episodes x 100 agent steps), %s" % (pop, label), c, gens=2)
+    if "cmc_venv_td3" in which:
+        # default_config_cmc.yaml (TD3 2-128-128-1 / 3-128-128-1 relu, B = 256, policy_delay 2, same_action_num 2, trained on a VirtualEnv
+        # of three 3-96-96-x nets) at its own population (128 workers = 384 chains, one workgroup per chain), as one 8-GPU shard (16 workers =
+        # 48 chains, teams of 4) and at 4 workers (teams of 8): the wave-chain kernel's fourth TD3 shape, then the GEMM-queue kernel
+        from learning_environments_amd import _lib
+        for pop in (128, 16, 4):
+            for variant, label in ((0, "wave-chain kernel"), (_lib.VARIANT_NO_WAVECHAIN, "GEMM-queue kernel")):
+                c = configs.fixed_work(configs.cmc_syn_env_td3(pop), 3)
+                c["agents"]["td3"]["init_episodes"] = 1
+                c["envs"]["MountainCarContinuous-v0"]["max_steps"] = 200
+                c["agents"]["gtn"]["kernel_variant"] = variant
+                run("MountainCarContinuous SE + TD3 (B 256, policy_delay 2) pop %d (3 episodes x 100 agent steps), %s" % (pop, label), c, gens=2)
     if "td3d" in which:
         # TD3_discrete_vary as the syn-env YAMLs ship it (510-wide tanh nets, batch 122, hard Gumbel softmax) on an Acrobot SE
         c = configs.fixed_work(configs.acrobot_syn_env_td3_discrete(32), 3)
