@@ -420,9 +420,10 @@ def secondary_configs(only=None, team_size=0):
         torch.cuda.empty_cache()
         # ... and the shards of the 2- and 4-GPU forms (32 / 16 workers = 96 / 48 chains, teams of 2 / 4), so that the record carries the whole
         # projected strong-scaling curve of BASELINE's metric -- projections all, from one-GPU measurements of each shard
+        # (not under `--only-config 1`: that is the run rocprofv3 profiles, and the other shards launch the same kernel instantiations)
         curve = [{"n_gpus": 8, "workers_per_gpu": 8, "chains_per_gpu": 24, "workgroups_per_chain": out[-1]["workgroups_per_chain"],
                   "ms_per_generation": out[-1]["ms_per_step"], "projected_value": out[-1]["projected_8gpu_value"]}]
-        for n_gpus, workers in ((4, 16), (2, 32)):
+        for n_gpus, workers in ((4, 16), (2, 32)) if only is None else ():
             ms_, _ = build_master(workers, team_size=team_size)
             dts, _k = timed_generations(ms_, 10, 2, torch.cuda.synchronize, 1, True)
             curve.append({"n_gpus": n_gpus, "workers_per_gpu": workers, "chains_per_gpu": 3 * workers,

@@ -32,7 +32,7 @@ def copy_stats(pattern, dest, kernel_sub):
         total = sum(int(r[1]) for r in rows[1:])
         for r in rows[1:]:
             if kernel_sub in r[0]:
-                res = {"kernel": r[0][:64], "calls": int(r[1]), "avg_ms": float(r[3]) / 1e6, "min_ms": float(r[6]) / 1e6 if len(r) > 6 else None,
+                res = {"kernel": r[0][:64], "calls": int(r[1]), "avg_ms": float(r[3]) / 1e6, "min_ms": float(r[5]) / 1e6 if len(r) > 6 else None, "max_ms": float(r[6]) / 1e6 if len(r) > 6 else None,
                        "dispatches_per_generation": total / max(1, int(r[1]))}
     return res
 
