@@ -122,6 +122,23 @@ if __name__ == "__main__":
                 c["envs"]["MountainCarContinuous-v0"]["max_steps"] = 200
                 c["agents"]["gtn"]["kernel_variant"] = variant
                 run("MountainCarContinuous SE + TD3 (B 256, policy_delay 2) pop %d (3 episodes x 100 agent steps), %s" % (pop, label), c, gens=2)
+    if "mountaincar_ddqn" in which:
+        # default_config_mountaincar.yaml (DDQN 2-256-256-3 relu, B = 128, ten test episodes, 16 workers = 48 chains): GEMM-queue kernel, no wave-chain shape
+        c = configs.fixed_work(configs.mountaincar_syn_env_ddqn(16), 3)
+        c["agents"]["ddqn"]["init_episodes"] = 1
+        c["envs"]["MountainCar-v0"]["max_steps"] = 100
+        run("MountainCar SE + DDQN 2-256-256-3 pop 16 (3 episodes x 100 steps), GEMM-queue kernel", c, gens=2)
+    if "cartpole_rn_ddqn" in which:
+        # default_config_cartpole_reward_env.yaml (DDQN 4-64-2 leakyrelu, B = 192, trained on the real CartPole with a learned reward, 16 workers)
+        c = configs.fixed_work(configs.cartpole_reward_env_ddqn(16), 6)
+        c["agents"]["gtn"]["quit_when_solved"] = False
+        run("CartPole RewardEnv + DDQN 4-64-2 pop 16 (6 episodes), GEMM-queue kernel", c, gens=2)
+    if "cmc_opt_td3" in which:
+        # default_config_cmc_syn_env_opt.yaml-like: TD3 with ONE 64-wide hidden layer on a VirtualEnv of three 3-128-128-128-x nets, B = 256
+        c = configs.fixed_work(configs.cmc_syn_env_td3(16), 3)
+        c["agents"]["td3"].update(init_episodes=1, hidden_size=64, hidden_layer=1, activation_fn="leakyrelu")
+        c["envs"]["MountainCarContinuous-v0"].update(max_steps=200, hidden_size=128, hidden_layer=3, activation_fn="relu")
+        run("MountainCarContinuous SE 128x3 + TD3 64x1 (B 256) pop 16 (3 episodes x 100 agent steps), GEMM-queue kernel", c, gens=2)
     if "td3d" in which:
         # TD3_discrete_vary as the syn-env YAMLs ship it (510-wide tanh nets, batch 122, hard Gumbel softmax) on an Acrobot SE
         c = configs.fixed_work(configs.acrobot_syn_env_td3_discrete(32), 3)
