@@ -3074,6 +3074,51 @@ def test_wavechain_td3_cmc_virtual_env_shape_every_team_size(eng, orc):
         assert np.array_equal(ref[4][c], o["final_params"])
 
 
+def test_wavechain_td3_cmc_virtual_env_shard_launch(eng, orc):
+    """default_config_cmc.yaml as one 8-GPU shard of its population (16 workers = 48 chains): the automatic launch puts every chain on a team
+    of FOUR workgroups (192 of the 256 CUs).  Longer episodes than the team-size test (3 x 150 env steps = 3 x 75 agent steps, 150 learn steps, 75 delayed policy
+    updates): every chain equal to the one-workgroup launch, one whole chain equal to the oracle incl.
+    all final parameters."""
+    import ctypes as C
+    from learning_environments_amd import _lib, configs
+    from learning_environments_amd.agents.nes_common import chain_keys
+    cfgd = configs.fixed_work(configs.cmc_syn_env_td3(16), 3)
+    cfgd["agents"]["td3"]["init_episodes"] = 1
+    cfgd["envs"]["MountainCarContinuous-v0"]["max_steps"] = 150
+    ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
+    chains = 48
+    Pa, Pc = orc.td3_param_counts(ocfg)
+    P_se = orc.mlp_num_params(orc.mlp_desc(3, 96, 2, 2, "leakyrelu")) + 2 * orc.mlp_num_params(orc.mlp_desc(3, 96, 2, 1, "leakyrelu"))
+    rng = np.random.RandomState(29)
+    theta = (rng.randn(P_se) * 0.1).astype(np.float32)
+    eps = (rng.randn(16, P_se) * 0.05).astype(np.float32)
+    worker = (np.arange(chains) // 3).astype(np.int32)
+    sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), 16)
+    keys = chain_keys(85, 3, worker, np.arange(chains) % 3)
+    init = rng.uniform(-0.08, 0.08, (chains, Pa + 2 * Pc)).astype(np.float32)
+    assert _lib.lib().lenv_td3_rn_team_size(C.byref(cfg), chains) == 4
+
+    def run(team):
+        cfg.team_size = team
+        il = eng.Td3InnerLoop(cfg, chains, want_final_params=True, want_episode_stats=True)
+        il.run(dev(theta), dev(eps), dev(worker), dev(sign), dev(init), rng_keys=dev(keys.view(np.int64)))
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        return [t.cpu().numpy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_params, il.episode_len)]
+
+    auto, one = run(0), run(1)
+    for x, y in zip(auto, one):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert auto[1][:, 2].min() >= 100
+    c = 7
+    w = (np.float32(sign[c]) * eps[worker[c]] + theta).astype(np.float32)
+    o = orc.td3_rn_chain(ocfg, w, init[c], rng_key=int(keys[c]), want_final_params=True)
+    assert float(auto[0][c]) == o["score"]
+    assert auto[1][c].tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+    assert np.array_equal(auto[2][c], o["episode_test_mean"], equal_nan=True)
+    assert np.array_equal(auto[4][c], o["final_params"])
+
+
 def test_wavechain_td3_cmc_episodes_that_end_at_the_flag(eng, orc):
     """MountainCarContinuous-v0 terminates: with an actor that pushes in the direction of the velocity (hand-built weights: tanh(k v)) the
     car reaches the flag long before max_steps.  No learn step touches the actor here (init_episodes = train_episodes: random-action
