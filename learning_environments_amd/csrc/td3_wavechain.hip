@@ -37,6 +37,8 @@ constexpr T3wShape kT3wShapes[] = {
     { LENV_ENV_PENDULUM, LENV_ACT_LEAKYRELU, 10, 2, 1, 192, 1, 0, 128 },      // 2: default_config_pendulum_reward_env.yaml (actor 3-128-128-1, critics 4-128-128-1)
     { LENV_ENV_CMC, LENV_ACT_LEAKYRELU, 1, 1, 2, 192, 1, 0, 128 },            // 3: default_config_cmc_reward_env.yaml (actor 2-128-128-1, critics 3-128-128-1; the episode ends at the flag)
     { LENV_ENV_CMC, LENV_ACT_RELU, 1, 2, 2, 256, 2, 1, 96 },                  // 4: default_config_cmc.yaml (VirtualEnv with three 3-96-96-x nets, batch 256, policy_delay 2)
+    { LENV_ENV_PENDULUM, LENV_ACT_RELU, 10, 2, 1, 256, 2, 1, 32 },            // 5: default_config_pendulum.yaml's td3 section (VirtualEnv 4-32-32-x; agent td3 = td3_vary without vary_hp)
+    { LENV_ENV_CHEETAH_STANDIN, LENV_ACT_RELU, 10, 3, 1, 256, 2, 1, 128 },    // 6: default_config_halfcheetah.yaml's td3 section (VirtualEnv 23-128-128-128-x)
 };
 
 // dumps: [NBK] blocks of BLK floats each (register order), or [B][128] row-major copies (same size); NBK = B / 32 sample blocks
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     constexpr int S = EnvT::S, A = EnvT::A, SA = S + A, SD = EnvT::SD, B = SP.B, NBK = B / 32, Hrn = SP.hrn, ACT = SP.act, T = SP.T, RNL = SP.rn_layers;
     constexpr int PD = SP.policy_delay;
     constexpr bool VENV = SP.venv != 0;
-    static_assert(!VENV || (RNL == 2 && Hrn % 4 == 0 && Hrn <= 128 && T == 1), "the synthetic env's nets: two hidden layers of at most 128 units, 16-byte rows");
+    static_assert(!VENV || ((RNL == 2 || RNL == 3) && Hrn % 32 == 0 && Hrn <= 128), "the synthetic env's nets: two or three hidden layers of at most 128 units");
     constexpr bool CHEETAH = SP.env == LENV_ENV_CHEETAH_STANDIN;
     constexpr int KREP = SP.k_rep;
     static_assert(S <= 17 && A <= 6 && SD <= 18, "sized for the stand-in");
@@ -858,8 +860,8 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     float *sm_wo2 = sm_b2 + 2 * W;
     float *rn_w = sm_wo2 + 8 * W + 8;                     // reward net: W0 [Hrn][S] | b0 [Hrn] | Wout [Hrn] | bout (two hidden layers: in the arena)
     float *rn_h = rn_w + (VENV ? 6 * 128 : (RNL == 1 ? ((a.P_rn + 3) & ~3) : Hrn));   // [Hrn] (two hidden layers: rn_w is the second hidden row; a VirtualEnv:
-                                                          // rn_w = the hidden rows [3 nets][2][128], rn_h = its input row [8] | output row [8])
-    float *dq1 = rn_h + Hrn;                              // [B]
+                                                          // rn_w = the hidden rows [3 nets][2][128], rn_h = its input row [32] | output row [32])
+    float *dq1 = rn_h + (VENV ? 128 : Hrn);               // [B]
     float *q1 = dq1 + B;                                  // [B] ... six vectors; from q1 on they double as dz [B][A] in the policy step
     float *q2 = q1 + B, *tq1 = q2 + B, *tq2 = tq1 + B, *rr = tq2 + B, *dd = rr + B;
     float *dq2 = dd + B;                                  // [B]
@@ -1239,55 +1241,49 @@ __global__ __launch_bounds__(NT) void td3_wavechain_kernel(const T3wArgs a)
     // same_action_num times whatever the done output says and sums the fp32 rewards (env_wrapper.py:24-29); reward and done see the
     // pre-transition state.  Leaves the replay row in newrow (the caller's barrier follows).
     auto venv_step = [&]() {
-        static_assert(!VENV || (SA <= 8 && S + 2 <= 8 && Hrn % 32 == 0), "input / output rows of 8 floats, 32-term pieces");
-        lfloat *xse = (lfloat *)rn_h, *nse = xse + 8, *hrow = (lfloat *)rn_w;
-        constexpr int P_HID = Hrn * SA + Hrn + Hrn * Hrn + Hrn, P_STATE = P_HID + S * Hrn + S, P_ONE = P_HID + Hrn + 1;
+        static_assert(!VENV || (SA <= 32 && S + 2 <= 32 && Hrn % 32 == 0 && Hrn <= 128), "input / output rows of 32 floats, 32-term pieces, rows of 128");
+        lfloat *xse = (lfloat *)rn_h, *nse = xse + 32, *hrow = (lfloat *)rn_w;      // hrow: [3 nets][2][128], a net's hidden layers alternate between its two rows
+        constexpr int P_HID = Hrn * SA + Hrn + (RNL - 1) * (Hrn * Hrn + Hrn), P_STATE = P_HID + S * Hrn + S, P_ONE = P_HID + Hrn + 1;
         const int net = tid >> 7, j = tid & 127;
         const bool unit = net < 3 && j < Hrn;
         const gfloat *np = (const gfloat *)(arena + a.a_rn) + (net == 0 ? 0 : (net == 1 ? P_STATE : P_STATE + P_ONE));
         const int n_out = net == 0 ? S : 1, ocol = net == 0 ? 0 : S + net - 1;
-        lfloat *h1 = hrow + (2 * (net < 3 ? net : 0)) * 128, *h2 = h1 + 128;
+        lfloat *hr = hrow + (2 * (net < 3 ? net : 0)) * 128;
         if (tid < A) xse[tid] = action[tid];
         if (tid >= 64 && tid < 64 + S) xse[A + tid - 64] = state[tid - 64];
         if (tid >= 128 && tid < 128 + S) newrow[tid - 128] = state[tid - 128];
         if (tid >= 192 && tid < 192 + A) newrow[S + tid - 192] = action[tid - 192];
         __syncthreads();
+        // sum_k h[k] * w[k] over a row of Hrn weights (16-byte loads, alignment of the row: 4 bytes) and Hrn LDS activations, k ascending from 0
+        auto row_dot = [&](const gfloat *wrow, const lfloat *hv) -> float {
+            const gf4 *wr = (const gf4 *)wrow;
+            float z = 0.0f;
+#pragma unroll 1
+            for (int k0 = 0; k0 < Hrn; k0 += 32) {
+                f32x4 w4[8], h4[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { w4[u] = wr[(k0 >> 2) + u]; h4[u] = *(const lf4 *)(hv + k0 + 4 * u); }
+#pragma unroll
+                for (int u = 0; u < 32; ++u) z = fma32(h4[u >> 2][u & 3], w4[u >> 2][u & 3], z);
+            }
+            return z;
+        };
 #pragma unroll 1
         for (int r_ = 0; r_ < KREP; ++r_) {
             if (unit) {
                 float z = 0.0f;
 #pragma unroll
                 for (int k = 0; k < SA; ++k) z = fma32(xse[k], np[j * SA + k], z);
-                h1[j] = act_fwd(rn_act, cfg.rn_prelu, z + np[Hrn * SA + j]);
+                hr[j] = act_fwd(rn_act, cfg.rn_prelu, z + np[Hrn * SA + j]);
             }
             __syncthreads();
-            if (unit) {
-                const gf4 *wr = (const gf4 *)(np + Hrn * SA + Hrn + j * Hrn);
-                float z = 0.0f;
-#pragma unroll 1
-                for (int k0 = 0; k0 < Hrn; k0 += 32) {
-                    f32x4 w4[8], h4[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { w4[u] = wr[(k0 >> 2) + u]; h4[u] = *(const lf4 *)(h1 + k0 + 4 * u); }
-#pragma unroll
-                    for (int u = 0; u < 32; ++u) z = fma32(h4[u >> 2][u & 3], w4[u >> 2][u & 3], z);
-                }
-                h2[j] = act_fwd(rn_act, cfg.rn_prelu, z + np[Hrn * SA + Hrn + Hrn * Hrn + j]);
+            for (int l = 1; l < RNL; ++l) {
+                const gfloat *wl = np + Hrn * SA + Hrn + (l - 1) * (Hrn * Hrn + Hrn);
+                if (unit) hr[(l & 1) * 128 + j] = act_fwd(rn_act, cfg.rn_prelu, row_dot(wl + j * Hrn, hr + ((l - 1) & 1) * 128) + wl[Hrn * Hrn + j]);
+                __syncthreads();
             }
-            __syncthreads();
-            if (net < 3 && j < n_out) {
-                const gf4 *wr = (const gf4 *)(np + P_HID + j * Hrn);
-                float z = 0.0f;
-#pragma unroll 1
-                for (int k0 = 0; k0 < Hrn; k0 += 32) {
-                    f32x4 w4[8], h4[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { w4[u] = wr[(k0 >> 2) + u]; h4[u] = *(const lf4 *)(h2 + k0 + 4 * u); }
-#pragma unroll
-                    for (int u = 0; u < 32; ++u) z = fma32(h4[u >> 2][u & 3], w4[u >> 2][u & 3], z);
-                }
-                nse[ocol + j] = z + np[P_HID + n_out * Hrn + j];
-            }
+            if (net < 3 && j < n_out) nse[ocol + j] = row_dot(np + P_HID + j * Hrn, hr + ((RNL - 1) & 1) * 128) + np[P_HID + n_out * Hrn + j];
             __syncthreads();
             if (tid < S) { newrow[S + A + tid] = nse[tid]; xse[A + tid] = nse[tid]; }
             if (tid == 64) { newrow[2 * S + A] = r_ == 0 ? nse[S] : newrow[2 * S + A] + nse[S]; newrow[2 * S + A + 1] = nse[S + 1]; }
@@ -1654,6 +1650,12 @@ int lenv_wc_td3_shape(const lenv_td3_cfg *cfg)
         !cfg->icm_enabled && !cfg->use_layer_norm && !cfg->rn_layer_norm && cfg->env_id == LENV_ENV_CMC && cfg->state_dim == 2 && cfg->action_dim == 1 &&
         cfg->test_episodes == 1 && cfg->act == LENV_ACT_RELU && k_rep == 2)
         return 4;
+    // default_config_pendulum.yaml / default_config_halfcheetah.yaml with a fixed-shape TD3 (their td3 sections: batch 256, policy_delay 2, ten test episodes)
+    if (cfg->hidden == 128 && cfg->layers == 2 && cfg->batch_size == 256 && cfg->virtual_env && cfg->policy_delay == 2 && !cfg->icm_enabled && !cfg->use_layer_norm &&
+        !cfg->rn_layer_norm && cfg->test_episodes == 10 && cfg->act == LENV_ACT_RELU && k_rep == 1) {
+        if (cfg->env_id == LENV_ENV_PENDULUM && cfg->state_dim == 3 && cfg->action_dim == 1 && cfg->rn_hidden == 32 && cfg->rn_layers == 2) return 5;
+        if (cfg->env_id == LENV_ENV_CHEETAH_STANDIN && cfg->state_dim == 17 && cfg->action_dim == 6 && cfg->rn_hidden == 128 && cfg->rn_layers == 3) return 6;
+    }
     if (!(cfg->hidden == 128 && cfg->layers == 2 && cfg->batch_size == 192 && cfg->rn_hidden == 128 && !cfg->virtual_env &&
           cfg->policy_delay == 1 && !cfg->icm_enabled && !cfg->use_layer_norm && !(cfg->rn_layer_norm && cfg->rn_layers >= 2) &&
           (cfg->reward_env_type == 0 || cfg->reward_env_type == 1 || cfg->reward_env_type == 2 || cfg->reward_env_type == 5 || cfg->reward_env_type == 6)))
@@ -1721,7 +1723,14 @@ static size_t t3w_lds_bytes(int shape, int P_rn)
 }
 static void (*t3w_kernel(int shape))(const T3wArgs)
 {
-    return shape == 4 ? td3_wavechain_kernel<4> : (shape == 3 ? td3_wavechain_kernel<3> : (shape == 2 ? td3_wavechain_kernel<2> : td3_wavechain_kernel<1>));
+    switch (shape) {
+    case 6: return td3_wavechain_kernel<6>;
+    case 5: return td3_wavechain_kernel<5>;
+    case 4: return td3_wavechain_kernel<4>;
+    case 3: return td3_wavechain_kernel<3>;
+    case 2: return td3_wavechain_kernel<2>;
+    default: return td3_wavechain_kernel<1>;
+    }
 }
 
 // Workgroups per chain.  A team only works when every workgroup of the launch is resident at the same time (its members wait for each

@@ -3022,25 +3022,34 @@ def test_wavechain_td3_cmc_shape_every_team_size(eng, orc):
         assert np.array_equal(ref[4][c], o["final_params"])
 
 
-def test_wavechain_td3_cmc_virtual_env_shape_every_team_size(eng, orc):
-    """The TD3 wave-chain kernel's fourth shape -- default_config_cmc.yaml: TD3 (actor 2-128-128-1, twin critics 3-128-128-1, relu) trained
-    on a VirtualEnv (three nets 3-96-96-{2,1,1} on cat(action, state), leakyrelu; the learned done output ends an episode), batch 256 = eight
-    sample blocks, policy_delay 2 (actor step and soft updates every second learn step), same_action_num 2, one real-env test episode -- in
-    production launches with G = 1, 2, 4, 8 workgroups per chain against the GEMM-queue kernel and, on two whole chains, the oracle: all
-    outputs + the 51 331 final parameters, bit for bit."""
+@pytest.mark.parametrize("which", ["cmc", "pendulum", "halfcheetah"])
+def test_wavechain_td3_virtual_env_shapes_every_team_size(eng, orc, which):
+    """The TD3 wave-chain kernel's VirtualEnv shapes (batch 256 = eight sample blocks, policy_delay 2: actor step and soft updates every
+    second learn step; the training env is the synthetic env itself -- three nets on cat(action, state), the learned done output ends an
+    episode -- and the test episodes run on the real env):
+      cmc          default_config_cmc.yaml: actor 2-128-128-1 / critics 3-128-128-1 relu, SE nets 3-96-96-x leakyrelu, same_action_num 2, one test episode
+      pendulum     default_config_pendulum.yaml's td3 section: actor 3-128-128-1, SE nets 4-32-32-x leakyrelu, ten lock-step test episodes
+      halfcheetah  default_config_halfcheetah.yaml's td3 section: actor 17-128-128-6 / critics 23-128-128-1, SE nets 23-128-128-128-x relu, ten test episodes
+    in production launches with G = 1, 2, 4, 8 workgroups per chain against the GEMM-queue kernel and, on two whole chains, the oracle: all
+    outputs + all final parameters, bit for bit."""
     import ctypes as C
     from learning_environments_amd import _lib, configs
     from learning_environments_amd.agents.nes_common import chain_keys
-    cfgd = configs.fixed_work(configs.cmc_syn_env_td3(2), 3)
+    make = {"cmc": configs.cmc_syn_env_td3, "pendulum": configs.pendulum_syn_env_td3, "halfcheetah": configs.halfcheetah_syn_env_td3}[which]
+    cfgd = configs.fixed_work(make(2), 3)
+    env_name = cfgd["env_name"]
     cfgd["agents"]["td3"]["init_episodes"] = 1
-    cfgd["envs"]["MountainCarContinuous-v0"]["max_steps"] = 41       # odd: range(0, 41, 2) = 21 agent steps per training episode
+    cfgd["envs"][env_name]["max_steps"] = {"cmc": 41, "pendulum": 33, "halfcheetah": 25}[which]     # cmc, odd: range(0, 41, 2) = 21 agent steps per training episode
     ocfg, cfg = _td3_cfgs(orc, cfgd, 0)
-    assert (cfg.state_dim, cfg.action_dim, cfg.hidden, cfg.layers, cfg.batch_size, cfg.test_episodes, cfg.rn_hidden, cfg.rn_layers, cfg.policy_delay,
-            cfg.same_action_num, cfg.virtual_env) == (2, 1, 128, 2, 256, 1, 96, 2, 2, 2, 1)
+    e = cfgd["envs"][env_name]
+    S, A = cfg.state_dim, cfg.action_dim
+    assert (cfg.hidden, cfg.layers, cfg.batch_size, cfg.policy_delay, cfg.virtual_env) == (128, 2, 256, 2, 1)
+    assert (S, A, cfg.test_episodes, cfg.rn_hidden, cfg.rn_layers, cfg.same_action_num) == \
+        {"cmc": (2, 1, 1, 96, 2, 2), "pendulum": (3, 1, 10, 32, 2, 1), "halfcheetah": (17, 6, 10, 128, 3, 1)}[which]
     chains = 5
     Pa, Pc = orc.td3_param_counts(ocfg)
-    assert Pa + 2 * Pc == 51331
-    P_se = orc.mlp_num_params(orc.mlp_desc(3, 96, 2, 2, "leakyrelu")) + 2 * orc.mlp_num_params(orc.mlp_desc(3, 96, 2, 1, "leakyrelu"))
+    P_se = orc.mlp_num_params(orc.mlp_desc(S + A, e["hidden_size"], e["hidden_layer"], S, e["activation_fn"])) + \
+        2 * orc.mlp_num_params(orc.mlp_desc(S + A, e["hidden_size"], e["hidden_layer"], 1, e["activation_fn"]))
     rng = np.random.RandomState(28)
     theta = (rng.randn(P_se) * 0.1).astype(np.float32)
     eps = (rng.randn(2, P_se) * 0.05).astype(np.float32)
@@ -3057,7 +3066,9 @@ def test_wavechain_td3_cmc_virtual_env_shape_every_team_size(eng, orc):
         return [t.cpu().numpy() for t in (il.score, il.stats, il.episode_test_mean, il.final_returns, il.final_params, il.episode_len)]
 
     ref = run(2)                                            # GEMM-queue kernel (a launch with a step trace)
-    assert ref[1][:, 2].min() >= 20 and ref[5].max() == 42  # learn steps; episode_length += same_action_num per agent step (base_agent.py:122)
+    assert ref[1][:, 2].min() >= 20                         # learn steps
+    if which == "cmc":
+        assert ref[5].max() == 42                           # episode_length += same_action_num per agent step (base_agent.py:122)
     assert _lib.lib().lenv_td3_rn_team_size(C.byref(cfg), chains) == 8
     for G in (1, 2, 4, 8):
         cfg.team_size = G

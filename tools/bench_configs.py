@@ -122,6 +122,17 @@ if __name__ == "__main__":
                 c["envs"]["MountainCarContinuous-v0"]["max_steps"] = 200
                 c["agents"]["gtn"]["kernel_variant"] = variant
                 run("MountainCarContinuous SE + TD3 (B 256, policy_delay 2) pop %d (3 episodes x 100 agent steps), %s" % (pop, label), c, gens=2)
+    if "venv_td3" in which:
+        # the td3 sections of default_config_pendulum.yaml (16 workers) and default_config_halfcheetah.yaml (one 8-GPU shard of its 128 workers)
+        # as fixed-shape agents (`td3_vary` with vary_hp off): wave-chain shapes 5 / 6 (teams of 4), then the GEMM-queue kernel
+        from learning_environments_amd import _lib
+        for make, env_name, label0, steps in ((configs.pendulum_syn_env_td3, "Pendulum-v0", "Pendulum SE 4-32-32-x", 100), (configs.halfcheetah_syn_env_td3, "HalfCheetah-v3", "HalfCheetah-standin SE 23-128-128-128-x", 100)):
+            for variant, label in ((0, "wave-chain kernel"), (_lib.VARIANT_NO_WAVECHAIN, "GEMM-queue kernel")):
+                c = configs.fixed_work(make(16), 3)
+                c["agents"]["td3"]["init_episodes"] = 1
+                c["envs"][env_name]["max_steps"] = steps
+                c["agents"]["gtn"]["kernel_variant"] = variant
+                run("%s + TD3 (B 256, policy_delay 2, ten test episodes) pop 16 (3 episodes x %d steps), %s" % (label0, steps, label), c, gens=2)
     if "mountaincar_ddqn" in which:
         # default_config_mountaincar.yaml (DDQN 2-256-256-3 relu, B = 128, ten test episodes, 16 workers = 48 chains): GEMM-queue kernel, no wave-chain shape
         c = configs.fixed_work(configs.mountaincar_syn_env_ddqn(16), 3)
