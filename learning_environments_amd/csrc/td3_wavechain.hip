@@ -1,14 +1,18 @@
 // td3_wavechain.hip -- the TD3 inner loop of BASELINE configs[4] (HalfCheetah stand-in RewardEnv + TD3, default_config_halfcheetah_
 // reward_env.yaml: actor 17-128-128-6, twin critics 23-128-128-1, relu, batch 192, policy_delay 1, one test episode) on the
 // wave-chain primitives of lenv_wavechain.cuh.  Same semantics and the same canonical arithmetic order -- hence the same bits -- as
-// td3_rn_inner_kernel (which stays the generic path: other shapes / envs, tapes, traces, TD3_vary, ICM, VirtualEnv), different
-// execution structure: a wave owns a block of 32 minibatch samples (6 blocks) through a whole network pass.
+// td3_rn_inner_kernel (which stays the generic path: other shapes / envs, tapes, traces, TD3_vary, ICM), different
+// execution structure: a wave owns a block of 32 minibatch samples (6 blocks; batch 256: 8) through a whole network pass.
+// The shape table (kT3wShapes) lists the six published configurations the kernel is instantiated for: three RewardEnv shapes (batch 192,
+// policy_delay 1) and three VirtualEnv shapes (batch 256, policy_delay 2; venv_step = EnvWrapper.step -> VirtualEnv.step,
+// envs/virtual_env.py:43-54, in the kernel).
 //
 //   reference                                          here
 //   TD3.learn  agents/TD3.py:63-116                     t3_forward x7 (actor_target, 2 target critics, 2 critics; actor, critic_1)
 //   Actor_TD3 / Critic_Q  models/actor_critic.py:11-19,64-71   + t3_backward x3 (critic_1, critic_2; critic_1 for d/da and the actor)
 //   critic_optimizer / actor_optimizer.step, Polyak     wg_adam / wg_polyak over the arena-layout parameter vectors
 //   select_train_action / select_test_action (1 row)    actor_row1: per-thread k-ascending chains, coalesced K-major weights
+//   delayed policy update  agents/TD3.py:101            policy_step: the actor half of the learn step and all soft updates every policy_delay-th step
 //
 // Arena layout of ONE network (actor, critic_1, critic_2 alike; every matrix K-MAJOR):
 //   W1t[24][128] (rows >= in_dim zero) b1[128] | W2t[128][128] b2[128] | Wo[128][8] (columns >= out_dim zero) bo[8]
