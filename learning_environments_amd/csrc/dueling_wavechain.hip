@@ -1021,8 +1021,9 @@ template <int SHAPE> static __device__ __noinline__ void wct_wgrad_layer(const W
         const float tau = unif(c->tau), omt = unif(c->omt);
         const int kt = wave >> 1, jt0 = (wave & 1) << 1;
         const int off0 = oWt + (32 * kt) * W + 32 * jt0, off1 = off0 + 32;
-        T3vTileState st0;
+        T3vTileState st0, st1;
         t3v_tile_state(L, online + off0, adam_m + off0, adam_v + off0, target + off0, 32, st0);
+        t3v_tile_state(L, online + off1, adam_m + off1, adam_v + off1, target + off1, 32, st1);
         f32x16 acc0, acc1;
 #pragma unroll
         for (int v = 0; v < 16; ++v) { acc0[v] = 0.0f; acc1[v] = 0.0f; }
@@ -1031,10 +1032,9 @@ template <int SHAPE> static __device__ __noinline__ void wct_wgrad_layer(const W
         const float sb = tid < W ? image_colsum(bufB, tid, B) : 0.0f;
         __syncthreads();                                   // every wave is through with the images: their room is the tiles' scratch
         t3v_tile_adam(acc0, st0, bufA + wave * 1024, nullptr, L, online + off0, adam_m + off0, adam_v + off0, target + off0, 32, nullptr, ac, tau, omt);
-        // (the second tile's state after the first tile's step, into the same registers: with both states in flight behind the matrix
-        // instructions the routine needs ~190 VGPRs and saves / restores 70 callee-saved registers through scratch memory per call)
-        t3v_tile_state(L, online + off1, adam_m + off1, adam_v + off1, target + off1, 32, st0);
-        t3v_tile_adam(acc1, st0, bufA + wave * 1024, nullptr, L, online + off1, adam_m + off1, adam_v + off1, target + off1, 32, nullptr, ac, tau, omt);
+        // (both tiles' states are in flight behind the matrix instructions: ~190 VGPRs; until the file was built with
+        // -fno-optimize-sibling-calls that meant 70 callee-saved registers through scratch per call and the second state was fetched here)
+        t3v_tile_adam(acc1, st1, bufA + wave * 1024, nullptr, L, online + off1, adam_m + off1, adam_v + off1, target + off1, 32, nullptr, ac, tau, omt);
         if (tid < W) t3v_adam1(sb, online, adam_m, adam_v, target, ob + tid, ac, tau, omt);
         __syncthreads();
         WSUB_MARK(59);

@@ -402,6 +402,19 @@ __device__ __forceinline__ void t3v_tile_adam(const f32x16 &acc, T3vTileState &s
     }
 }
 
+// the same in two halves: the four state words requested before the gradient is computed, the step once it is there (a job whose
+// gradient is a long reduction does not pay the state's memory round trip behind it)
+struct T3vAdam1State { float w, m, v, t; };
+__device__ __forceinline__ T3vAdam1State t3v_adam1_load(const float *w_, const float *m_, const float *v_, const float *t_, int off)
+{
+    return T3vAdam1State{ ((const gfloat *)w_)[off], ((const gfloat *)m_)[off], ((const gfloat *)v_)[off], ((const gfloat *)t_)[off] };
+}
+__device__ __forceinline__ void t3v_adam1_step(float g, T3vAdam1State st, float *w_, float *m_, float *v_, float *t_, int off, const AdamConsts ac, float tau, float omt)
+{
+    adam_elem(g, st.m, st.v, st.w, st.t, ac, tau, omt);
+    ((gfloat *)m_)[off] = st.m; ((gfloat *)v_)[off] = st.v; ((gfloat *)w_)[off] = st.w; ((gfloat *)t_)[off] = st.t;
+}
+
 // one parameter of a small vector / matrix: Adam + Polyak in place (4-byte accesses: a few hundred elements per network)
 __device__ __forceinline__ void t3v_adam1(float g, float *w_, float *m_, float *v_, float *t_, int off, const AdamConsts ac, float tau, float omt)
 {

@@ -477,6 +477,8 @@ __device__ __noinline__ void t3v_wgrad(const T3wCtx *ctx_, int nnets_, const T3v
             // gb1[j] = sum_i dh1[i][j], gb2[j] = sum_i dz2[i][j] (plain adds, i ascending): lane = unit, 64 units per job
             const int j = 64 * (job & 1) + L.lane;
             const gfloat *src = (const gfloat *)dump_of(job < 22 ? r_dh1 : r_dz2, 0) + j;
+            const int off = (job < 22 ? ob1 : ob2) + j;
+            const T3vAdam1State st1 = t3v_adam1_load(par, am, av, tgt, off);      // (in flight behind the column's loads)
             float s = 0.0f;
 #pragma unroll 1
             for (int i0 = 0; i0 < B; i0 += CH) {
@@ -486,14 +488,17 @@ __device__ __noinline__ void t3v_wgrad(const T3wCtx *ctx_, int nnets_, const T3v
 #pragma unroll
                 for (int u = 0; u < CH; ++u) s = s + x[u];
             }
-            const int off = (job < 22 ? ob1 : ob2) + j;
-            t3v_adam1(s, par, am, av, tgt, off, ac, tau, omt);
+            t3v_adam1_step(s, st1, par, am, av, tgt, off, ac, tau, omt);
             TJOB_ADD(2);
         } else {
             // output layer, output unit cc: gWo[k][cc] = sum_i dOut[i][cc] h2[i][k] (i ascending), lane = k, 64 per job; the job of the
             // first half also sums gbo[cc] = sum_i dOut[i][cc] (plain adds) on the way
             const int cc = (job - 24) >> 1, k = 64 * (job & 1) + L.lane;
             const gfloat *src = (const gfloat *)dump_of(r_h2, 0) + k;
+            const T3vAdam1State st1 = t3v_adam1_load(par, am, av, tgt, oWo + k * 8 + cc);
+            const bool bias_lane = (job & 1) == 0 && L.lane == 0;
+            T3vAdam1State stb{};
+            if (bias_lane) stb = t3v_adam1_load(par, am, av, tgt, obo + cc);
             float s = 0.0f, sb = 0.0f;
 #pragma unroll 1
             for (int i0 = 0; i0 < B; i0 += CH) {
@@ -507,8 +512,8 @@ __device__ __noinline__ void t3v_wgrad(const T3wCtx *ctx_, int nnets_, const T3v
                     sb = sb + d;
                 }
             }
-            t3v_adam1(s, par, am, av, tgt, oWo + k * 8 + cc, ac, tau, omt);
-            if ((job & 1) == 0 && L.lane == 0) t3v_adam1(sb, par, am, av, tgt, obo + cc, ac, tau, omt);
+            t3v_adam1_step(s, st1, par, am, av, tgt, oWo + k * 8 + cc, ac, tau, omt);
+            if (bias_lane) t3v_adam1_step(sb, stb, par, am, av, tgt, obo + cc, ac, tau, omt);
             TJOB_ADD(3);
         }
     }
