@@ -1436,7 +1436,7 @@ def _gen_g11_body(cfg, n, GTN_Master, GTN_Worker, shutil):
 def main():
     # no arguments (or "all"): every fixture under tests/golden is regenerated (the full-shape runs g8df / g8tf take minutes each)
     ALL = ["g1", "g1ln", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x",
-           "g8tv", "g8ts", "g8p", "g8c", "g8ti", "g8tf", "g8tln", "g8df", "g8l2", "g8ln", "g8seln", "g8tseln", "g8tdseln", "g9ln", "g8m", "g8r", "g8rl", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k", "g8long"]
+           "g8tv", "g8ts", "g8p", "g8c", "g8cf", "g8ti", "g8tf", "g8tln", "g8df", "g8l2", "g8ln", "g8seln", "g8tseln", "g8tdseln", "g9ln", "g8m", "g8r", "g8rl", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k", "g8long"]
     which = sys.argv[1:] or ALL
     if "all" in which:
         which = ALL
@@ -1533,6 +1533,12 @@ def main():
                 env_name="MountainCarContinuous-v0", env_cls="Continuous_MountainCarEnv",
                 agent_over={"train_episodes": 4, "init_episodes": 2, "batch_size": 16, "hidden_size": 24, "test_episodes": 2},
                 env_over={"max_steps": 8, "hidden_size": 20, "hidden_layer": 1, "activation_fn": "tanh", "reward_env_type": 2})
+    if "g8cf" in which:
+        # default_config_cmc.yaml at its REAL shapes (actor 2-128-128-1, twin critics 3-128-128-1 relu, batch 256, policy_delay 2,
+        # same_action_num 2, SE nets 3-96-96-{2,1,1} leakyrelu): two learning episodes of 15 agent steps = 30 learn steps, 15 policy steps
+        gen_g8t("g8cf_calc_score_cmc_td3_virtual_env_fullshape", seed=883, virtual=True, cfg_yaml="default_config_cmc.yaml",
+                env_name="MountainCarContinuous-v0", env_cls="Continuous_MountainCarEnv",
+                agent_over={"train_episodes": 3, "init_episodes": 1, "test_episodes": 1}, env_over={"max_steps": 30})
     if "g8ti" in which:
         gen_g8t("g8ti_calc_score_cheetah_td3_icm", seed=833,
                 agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 16, "hidden_size": 24, "test_episodes": 1},

@@ -1635,7 +1635,8 @@ def _td3_compare(il, o, c, n, with_state=True):
 
 
 @pytest.mark.parametrize("name,near_flag", [("g8c_calc_score_cmc_td3_virtual_env", False), ("g8cr_calc_score_cmc_td3_reward_env", False),
-                                            ("g8c_calc_score_cmc_td3_virtual_env", True), ("g8cr_calc_score_cmc_td3_reward_env", True)])
+                                            ("g8c_calc_score_cmc_td3_virtual_env", True), ("g8cr_calc_score_cmc_td3_reward_env", True),
+                                            ("g8cf_calc_score_cmc_td3_virtual_env_fullshape", False)])      # default_config_cmc.yaml at its real shapes
 def test_td3_cmc_tape_mode_vs_reference_and_oracle(eng, orc, golden, name, near_flag):
     """The reference's runs (same_action_num 2) replayed; and the same tapes with every episode reset next to the flag, so that
     training episodes (RewardEnv mode) and test episodes end at the env's own done flag after a step or two -- with the +100."""

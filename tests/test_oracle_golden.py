@@ -674,11 +674,14 @@ def test_g8p_td3_on_pendulum(golden, name):
         assert orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], tapes=tapes)["rc"] != 0
 
 
-@pytest.mark.parametrize("name", ["g8c_calc_score_cmc_td3_virtual_env", "g8cr_calc_score_cmc_td3_reward_env"])
+@pytest.mark.parametrize("name", ["g8c_calc_score_cmc_td3_virtual_env", "g8cr_calc_score_cmc_td3_reward_env",
+                                  "g8cf_calc_score_cmc_td3_virtual_env_fullshape"])
 def test_g8c_td3_on_mountaincar_continuous(golden, name):
     """default_config_cmc.yaml / default_config_cmc_reward_env.yaml's env with their same_action_num = 2: TD3 on a VirtualEnv of
     MountainCarContinuous-v0 and on a RewardEnv (type 2, tanh) over the real env.  Every chosen action is applied twice
-    (EnvWrapper.step, env_wrapper.py:24-29,56-61), episode lengths count env steps (base_agent.py:122)."""
+    (EnvWrapper.step, env_wrapper.py:24-29,56-61), episode lengths count env steps (base_agent.py:122).  g8cf: default_config_cmc.yaml
+    itself at its REAL shapes (actor 2-128-128-1, critics 3-128-128-1, batch 256, policy_delay 2, SE nets 3-96-96-x): 30 learn steps,
+    15 delayed policy updates -- the shape the TD3 wave-chain kernel's fourth instantiation runs."""
     import json
     g = golden(name)
     cfg = orc.td3_cfg_from_config(json.loads(str(g["config_json"])), rng_mode=1)
@@ -686,11 +689,17 @@ def test_g8c_td3_on_mountaincar_continuous(golden, name):
     tapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
                                g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"], A=1, S=2)
     n = g["tr_reward"].size
-    out = orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 4)
+    full = name.endswith("fullshape")
+    out = orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 4, want_final_params=full)
     assert out["rc"] == 0 and out["trace"]["reward"].size == n
     np.testing.assert_allclose(out["trace"]["action"], g["tr_action"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(out["trace"]["next_state"], g["tr_next_state"], rtol=0, atol=2e-6 if cfg.virtual_env else 1e-9)
     np.testing.assert_allclose(out["trace"]["reward"], g["tr_reward"], rtol=0, atol=2e-6)
+    if full:
+        assert (cfg.hidden, cfg.layers, cfg.batch_size, cfg.policy_delay, cfg.rn_hidden, cfg.rn_layers, cfg.virtual_env) == (128, 2, 256, 2, 96, 2, 1)
+        assert out["learn_steps"] == 30 and g["agent_init"].size == 51331
+        # all 51 331 parameters after 30 critic steps and 15 actor steps + soft updates (Adam's first steps move every weight by ~lr)
+        np.testing.assert_allclose(out["final_params"], g["final_params"], rtol=0, atol=2e-6)
     assert np.array_equal(out["episode_len"], g["episode_length_train"]) and int(g["episode_length_train"][0]) == 2 * ((cfg.max_steps + 1) // 2)
     np.testing.assert_allclose(out["episode_test_mean"], g["reward_list_train"], rtol=0, atol=1e-4)
     assert abs(out["score"] - float(g["score"])) <= 1e-4
