@@ -950,6 +950,11 @@ def gen_g8t(name, seed, agent_over=None, env_over=None, vary_seed=None, icm_over
     cfg = _td3_cfg(agent_over or {"train_episodes": 4, "init_episodes": 2, "batch_size": 16, "hidden_size": 24, "test_episodes": 2},
                    env_over or {"max_steps": 7, "hidden_size": 20}, cfg_yaml=cfg_yaml, env_name=env_name)
     drawn = {}
+    if vary_seed is None and cfg["agents"]["gtn"]["agent_name"].lower() == "td3_vary":
+        # default_config_pendulum.yaml / default_config_halfcheetah.yaml name td3_vary without shipping its section (TD3_vary.py:16 raises
+        # KeyError there); with vary_hp off the agent IS TD3 on the yaml's td3 section (TD3_vary.py:16-21)
+        cfg["agents"]["gtn"]["agent_name"] = "td3"
+    cfg["device"] = "cpu"                         # (default_config_pendulum.yaml ships cuda:0)
     if virtual:                                   # default_config_halfcheetah.yaml: TD3 on a VirtualEnv (synthetic_env_type 0)
         cfg["agents"]["gtn"]["synthetic_env_type"] = 0
     if icm_over is not None:                      # select_agent "td3_icm": TD3(icm=True), agents/TD3.py:44-60,68-70
@@ -1436,7 +1441,7 @@ def _gen_g11_body(cfg, n, GTN_Master, GTN_Worker, shutil):
 def main():
     # no arguments (or "all"): every fixture under tests/golden is regenerated (the full-shape runs g8df / g8tf take minutes each)
     ALL = ["g1", "g1ln", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x",
-           "g8tv", "g8ts", "g8p", "g8c", "g8cf", "g8ti", "g8tf", "g8tln", "g8df", "g8l2", "g8ln", "g8seln", "g8tseln", "g8tdseln", "g9ln", "g8m", "g8r", "g8rl", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k", "g8long"]
+           "g8tv", "g8ts", "g8p", "g8c", "g8cf", "g8pf", "g8ti", "g8tf", "g8tln", "g8df", "g8l2", "g8ln", "g8seln", "g8tseln", "g8tdseln", "g9ln", "g8m", "g8r", "g8rl", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k", "g8long"]
     which = sys.argv[1:] or ALL
     if "all" in which:
         which = ALL
@@ -1539,6 +1544,13 @@ def main():
         gen_g8t("g8cf_calc_score_cmc_td3_virtual_env_fullshape", seed=883, virtual=True, cfg_yaml="default_config_cmc.yaml",
                 env_name="MountainCarContinuous-v0", env_cls="Continuous_MountainCarEnv",
                 agent_over={"train_episodes": 3, "init_episodes": 1, "test_episodes": 1}, env_over={"max_steps": 30})
+    if "g8pf" in which:
+        # the td3 sections of default_config_pendulum.yaml (SE nets 4-32-32-x) and default_config_halfcheetah.yaml (SE nets
+        # 23-128-128-128-x) at their REAL shapes: batch 256, policy_delay 2, ten test episodes per test phase
+        gen_g8t("g8pf_calc_score_pendulum_td3_virtual_env_fullshape", seed=884, virtual=True, cfg_yaml="default_config_pendulum.yaml",
+                env_name="Pendulum-v0", env_cls="PendulumEnv", agent_over={"train_episodes": 3, "init_episodes": 1}, env_over={"max_steps": 14})
+        gen_g8t("g8hf_calc_score_cheetah_td3_virtual_env_fullshape", seed=885, virtual=True, cfg_yaml="default_config_halfcheetah.yaml",
+                agent_over={"train_episodes": 3, "init_episodes": 1}, env_over={"max_steps": 10})
     if "g8ti" in which:
         gen_g8t("g8ti_calc_score_cheetah_td3_icm", seed=833,
                 agent_over={"train_episodes": 3, "init_episodes": 1, "batch_size": 16, "hidden_size": 24, "test_episodes": 1},

@@ -1518,6 +1518,45 @@ def test_layer_norm_in_the_td3_loop_vs_oracle(eng, orc, golden, hidden, layers, 
         assert np.array_equal(il.final_params[c].cpu().numpy(), o["final_params"]), c
 
 
+@pytest.mark.parametrize("name", ["g8pf_calc_score_pendulum_td3_virtual_env_fullshape", "g8hf_calc_score_cheetah_td3_virtual_env_fullshape"])
+def test_td3_full_shape_virtual_env_tape_mode_vs_reference_and_oracle(eng, orc, golden, name):
+    """Reference runs of the td3 sections of default_config_pendulum.yaml / default_config_halfcheetah.yaml at their real shapes (batch 256,
+    policy_delay 2, VirtualEnv, ten test episodes) replayed in tape mode: bit-equal to the oracle incl. all final parameters, within the
+    fixture tolerances of the reference's own numbers."""
+    g = golden(name)
+    ocfg, cfg = _td3_cfgs(orc, json.loads(str(g["config_json"])), 1)
+    assert (cfg.hidden, cfg.layers, cfg.batch_size, cfg.policy_delay, cfg.virtual_env, cfg.test_episodes) == (128, 2, 256, 2, 1, 10)
+    n = g["tr_reward"].size
+    otapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
+                                g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"], A=cfg.action_dim, S=orc.TD3_STATE_WORDS[cfg.env_id])
+    o = orc.td3_rn_chain(ocfg, g["theta"], g["agent_init"], tapes=otapes, trace_cap=n + 4, want_final_params=True)
+    assert o["rc"] == 0
+    chains = 2
+    rep = lambda a: dev(np.tile(np.ascontiguousarray(a)[None], (chains,) + (1,) * np.ndim(a)))
+    tapes = dict(rand_action=rep(g["tape_rand_action"]), act_noise=rep(g["tape_act_noise"]), test_noise=rep(g["tape_test_noise"]),
+                 policy_noise=rep(g["tape_policy_noise"]), replay_idx=rep(g["tape_replay_idx"].reshape(-1)),
+                 train_reset=rep(g["tape_train_reset"]), test_reset=rep(g["tape_test_reset"]))
+    il = eng.Td3InnerLoop(cfg, chains, trace_cap=n + 4, want_episode_stats=True, want_final_params=True)
+    assert il.p_agent == g["agent_init"].size
+    il.run(dev(g["theta"]), None, None, None, dev(np.tile(g["agent_init"], (chains, 1))), tapes=tapes)
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    for c in range(chains):
+        assert np.array_equal(il.trace["action"][c, :n].cpu().numpy(), o["trace"]["action"])
+        assert np.array_equal(il.trace["next_state"][c, :n].cpu().numpy(), o["trace"]["next_state"])
+        assert np.array_equal(il.trace["reward"][c, :n].cpu().numpy(), o["trace"]["reward"])
+        assert np.array_equal(il.episode_len[c].cpu().numpy(), o["episode_len"])
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True)
+        assert np.array_equal(il.final_returns[c].cpu().numpy(), o["final_test_returns"])
+        assert np.array_equal(il.final_params[c].cpu().numpy(), o["final_params"])
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        np.testing.assert_allclose(il.trace["action"][c, :n].cpu().numpy(), g["tr_action"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(il.trace["next_state"][c, :n].cpu().numpy(), g["tr_next_state"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(il.final_params[c].cpu().numpy(), g["final_params"], rtol=0, atol=2e-6)
+        assert abs(float(il.score[c]) - float(g["score"])) <= 1e-4
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Pendulum-v0 behind the TD3 path (default_config_pendulum.yaml / default_config_pendulum_reward_env.yaml)
 # ---------------------------------------------------------------------------------------------------------------

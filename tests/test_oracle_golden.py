@@ -640,6 +640,33 @@ def test_g8ts_td3_on_a_virtual_env(golden, name):
     assert abs(out["score"] - float(g["score"])) <= 1e-4
 
 
+@pytest.mark.parametrize("name", ["g8pf_calc_score_pendulum_td3_virtual_env_fullshape", "g8hf_calc_score_cheetah_td3_virtual_env_fullshape"])
+def test_g8_full_shape_virtual_env_td3(golden, name):
+    """The td3 sections of default_config_pendulum.yaml (SE nets 4-32-32-x) and default_config_halfcheetah.yaml (SE nets 23-128-128-128-x)
+    at their REAL shapes -- actor / critics 128 x 2, batch 256, policy_delay 2, ten test episodes per test phase: the shapes the TD3
+    wave-chain kernel's instantiations 5 and 6 run.  The reference's runs (agent td3 = td3_vary with vary_hp off) replayed by the oracle:
+    traces, per-episode test means, the ten final returns and ALL final parameters."""
+    import json
+    g = golden(name)
+    cfg = orc.td3_cfg_from_config(json.loads(str(g["config_json"])), rng_mode=1)
+    assert (cfg.hidden, cfg.layers, cfg.batch_size, cfg.policy_delay, cfg.virtual_env, cfg.test_episodes) == (128, 2, 256, 2, 1, 10)
+    assert (cfg.rn_hidden, cfg.rn_layers) == ((32, 2) if cfg.env_id == 4 else (128, 3))
+    tapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
+                               g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"], A=cfg.action_dim, S=orc.TD3_STATE_WORDS[cfg.env_id])
+    n = g["tr_reward"].size
+    out = orc.td3_rn_chain(cfg, g["theta"], g["agent_init"], tapes=tapes, trace_cap=n + 4, want_final_params=True)
+    assert out["rc"] == 0 and out["trace"]["reward"].size == n and out["learn_steps"] >= 14
+    np.testing.assert_allclose(out["trace"]["action"], g["tr_action"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["trace"]["next_state"], g["tr_next_state"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["trace"]["reward"], g["tr_reward"], rtol=0, atol=2e-6)
+    m = g["episode_length_train"].size
+    assert np.array_equal(out["episode_len"][:m], g["episode_length_train"]) and out["episodes_run"] == m      # early-out like the reference
+    np.testing.assert_allclose(out["episode_test_mean"][:m], g["reward_list_train"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out["final_test_returns"], g["reward_list_test"], rtol=0, atol=1e-4)
+    assert abs(out["score"] - float(g["score"])) <= 1e-4
+    np.testing.assert_allclose(out["final_params"], g["final_params"], rtol=0, atol=2e-6)
+
+
 @pytest.mark.parametrize("name", ["g8p_calc_score_pendulum_td3_virtual_env", "g8pr_calc_score_pendulum_td3_reward_env",
                                   "g8trnln_calc_score_pendulum_td3_reward_net_layernorm"])     # the ENV section's use_layer_norm (reward net 3-20-20-1)
 def test_g8p_td3_on_pendulum(golden, name):
