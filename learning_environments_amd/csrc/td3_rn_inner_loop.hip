@@ -54,6 +54,7 @@ struct Td3Args {
     int P, P_rn;                              // P = row stride of agent_init / final_params; P_rn = parameters of theta
     int P_rn_lds;                             // floats of theta staged in LDS (RewardEnv); a VirtualEnv's three nets live in the arena
     int64_t a_se, a_xse, a_nse;               // VirtualEnv: perturbed SE parameters, its input cat(action, state), its outputs [S + 2]
+    int64_t a_seT;                            // ... and a copy with every weight matrix TRANSPOSED ([in][out]: the one-row products read it coalesced)
     // per-chain hyper-parameters (device arrays [chains], all or none): TD3_vary (agents/TD3_vary.py:24-58)
     const double *hp_lr; const int32_t *hp_batch, *hp_hidden, *hp_layers;
     // TD3(icm=True) (agents/TD3.py:44-60,68-70): fresh ICM parameters per chain, optional final parameters, arena offsets
@@ -169,6 +170,24 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         // VirtualEnv (three nets) and reward nets with several hidden layers are too large for LDS -> arena
         float *dst = (virtual_env || rn_layers > 1) ? arena + a.a_se : rn_w;
         for (int i = tid; i < a.P_rn; i += DNT) dst[i] = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
+        if (virtual_env) {
+            // the same three nets once more with every matrix K-major (Wt[k][j] = W[j][k]): thread j of a one-row product then reads
+            // consecutive words with its neighbours instead of a row of its own
+            __syncthreads();
+            float *dT = arena + a.a_seT;
+            int base = 0;
+            for (int n = 0; n < 3; ++n) {
+                const MlpOff &mo = mo_se[n];
+                int n_in = mo.in;
+                for (int l = 0; l <= mo.L; ++l) {
+                    const int n_out = l == mo.L ? mo.out : mo.H;
+                    for (int e2 = tid; e2 < n_out * n_in; e2 += DNT) { const int j = e2 / n_in, k = e2 - j * n_in; dT[base + mo.oW[l] + k * n_out + j] = dst[base + mo.oW[l] + e2]; }
+                    for (int j = tid; j < n_out; j += DNT) dT[base + mo.ob[l] + j] = dst[base + mo.ob[l] + j];
+                    n_in = mo.H;
+                }
+                base += mo.P;
+            }
+        }
     }
     for (int p = tid; p < P; p += DNT) {
         const float w = a.agent_init[chain * a.P + p];
@@ -266,6 +285,48 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         }
     };
     auto actor_row1 = [&](const float *par, const float *x, float *out) { mlp_row1(par, mo_actor, x, out, 0, true, act_id, prelu); };
+    // The three nets of a VirtualEnv (state | reward | done: same input row, same depth and width) side by side: thread group g = tid / 128
+    // runs net g with mlp_row1's chains (its hidden rows in row g of ht[l]) on the TRANSPOSED copy of its matrices -- thread j reads
+    // Wt[k][j], consecutive words across the wave, 32 terms requested before their fmaf run starts; one barrier per layer for all three.
+    // (Row by row -- thread j walking W[j][:] -- every load instruction touches 64 cache lines: the step of a three-layer 128-wide SE cost
+    // 250 k cycles, 42 % of a small-net TD3 generation: tools/phase_timing_td3_generic.py.)  Nets wider than 128, LayerNorm nets (their row
+    // statistics are one thread's job) and arenas without three rows of room take mlp_row1 net by net.
+    const bool se_side_by_side = DNT >= 384 && Hrn <= 128 && !rn_ln && 3 * (int64_t)Hrn <= (int64_t)(Bm > T ? Bm : T) * H;
+    auto se_rows = [&](const float *x, float *out) {
+        if (!se_side_by_side) {
+            const float *sep = arena + a.a_se;
+            mlp_row1(sep, mo_se[0], x, out, 0, false, rn_act, cfg.rn_prelu);
+            mlp_row1(sep + mo_se[0].P, mo_se[1], x, out, S, false, rn_act, cfg.rn_prelu);
+            mlp_row1(sep + mo_se[0].P + mo_se[1].P, mo_se[2], x, out, S + 1, false, rn_act, cfg.rn_prelu);
+            return;
+        }
+        const int g = tid >> 7, j = tid & 127;
+        const MlpOff &mo = mo_se[g < 3 ? g : 0];
+        const gfloat *par = (const gfloat *)(arena + a.a_seT) + (g == 0 ? 0 : (g == 1 ? mo_se[0].P : mo_se[0].P + mo_se[1].P));
+        const int ocol = g == 0 ? 0 : S + g - 1;
+        const gfloat *in = (const gfloat *)x;              // (the SE's input row and the hidden rows: arena)
+        int n_in = mo.in;
+        for (int l = 0; l <= mo.L; ++l) {
+            const bool last = l == mo.L;
+            const int n_out = last ? mo.out : mo.H;
+            float *h = last ? out + ocol : ht[l] + (g < 3 ? g : 0) * mo.H;
+            if (g < 3 && j < n_out) {
+                const gfloat *wt = par + mo.oW[l] + j;
+                float z = 0.0f;
+                for (int k0 = 0; k0 < n_in; k0 += 32) {
+                    float wv[32], xv[32];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) { const int k = k0 + u < n_in ? k0 + u : n_in - 1; wv[u] = wt[k * n_out]; xv[u] = in[k]; }
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) if (k0 + u < n_in) z = fma32(xv[u], wv[u], z);
+                }
+                z = z + par[mo.ob[l] + j];
+                h[j] = last ? z : act_fwd(rn_act, cfg.rn_prelu, z);
+            }
+            __syncthreads();
+            in = (const gfloat *)h; n_in = mo.H;
+        }
+    };
 
     // ---- generic MLP backward: dOut [I][out] -> parameter gradients gpar (may be null) and input gradient dX (may be null);
     // queued like the forward.  The output-layer bias gradient (a handful of columns of an LDS vector) is done in place.
@@ -517,16 +578,13 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 // EnvWrapper.step repeats the SE step same_action_num times whatever the done flag says and sums the fp32 rewards
                 // (env_wrapper.py:24-29)
                 float *xse = arena + a.a_xse, *nse = arena + a.a_nse;
-                const float *sep = arena + a.a_se;
                 if (tid < A) xse[tid] = action[tid];
                 if (tid >= 64 && tid < 64 + S) xse[A + tid - 64] = state[tid - 64];
                 if (tid >= 128 && tid < 128 + S) newrow[tid - 128] = state[tid - 128];
                 if (tid >= 192 && tid < 192 + A) newrow[S + tid - 192] = action[tid - 192];
                 __syncthreads();
                 for (int r_ = 0; r_ < k_rep; ++r_) {
-                    mlp_row1(sep, mo_se[0], xse, nse, 0, false, rn_act, cfg.rn_prelu);
-                    mlp_row1(sep + mo_se[0].P, mo_se[1], xse, nse, S, false, rn_act, cfg.rn_prelu);
-                    mlp_row1(sep + mo_se[0].P + mo_se[1].P, mo_se[2], xse, nse, S + 1, false, rn_act, cfg.rn_prelu);
+                    se_rows(xse, nse);
                     if (tid < S) { newrow[S + A + tid] = nse[tid]; xse[A + tid] = nse[tid]; }
                     if (tid == 64) { newrow[2 * S + A] = r_ == 0 ? nse[S] : newrow[2 * S + A] + nse[S]; newrow[2 * S + A + 1] = nse[S + 1]; }
                     if (r_ + 1 < k_rep) __syncthreads();
@@ -850,10 +908,10 @@ static int td3_layout(const lenv_td3_cfg *cfg, Td3Args &a, size_t *lds_bytes)
         for (int n = 0; n < 3; ++n) for (int l = 0; l < T3_MAXL; ++l) a.a_xh[n][l] = take(ln && l >= 1 && l < L ? (int64_t)RB * H : 0);
         a.a_rstd = take(ln ? 3 * (int64_t)T3_MAXL * B : 0);
     }
-    a.a_se = a.a_xse = a.a_nse = 0;
+    a.a_se = a.a_seT = a.a_xse = a.a_nse = 0;
     if (cfg->virtual_env) {
         if ((int64_t)RB * H < Hrn) return LENV_ERR_UNSUPPORTED;          // the SE's hidden rows reuse the agent's temporaries
-        a.a_se = take(a.P_rn); a.a_xse = take(T3_SA); a.a_nse = take(T3_S + 2);
+        a.a_se = take(a.P_rn); a.a_seT = take(a.P_rn); a.a_xse = take(T3_SA); a.a_nse = take(T3_S + 2);
     } else if (cfg->rn_layers > 1) a.a_se = take(a.P_rn);
     a.P_icm = 0;
     for (int i = 0; i < IB_COUNT; ++i) a.a_icm[i] = 0;
