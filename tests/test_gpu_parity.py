@@ -3095,6 +3095,8 @@ def test_wavechain_td3_virtual_env_shapes_every_team_size(eng, orc, which):
     eps = (rng.randn(2, P_se) * 0.05).astype(np.float32)
     if which == "pendulum":
         theta[-1] = 0.484                                   # done_net's output bias: the learned done flag hovers around 0.5 and ends some episodes early
+    if which == "cmc":
+        theta[-1] = 0.4                                     # ... here for the last chain only (episodes of 2 / 40 / 18 env steps; both repeats of an action run whatever the flag says)
     worker = (np.arange(chains) // 3).astype(np.int32)
     sign = np.tile(np.array([0.0, 1.0, -1.0], np.float32), 2)[:chains].copy()
     keys = chain_keys(84, 2, worker, np.arange(chains) % 3)
@@ -3114,7 +3116,7 @@ def test_wavechain_td3_virtual_env_shapes_every_team_size(eng, orc, which):
     else:
         assert ref[1][:, 2].min() >= 20                     # learn steps
     if which == "cmc":
-        assert ref[5].max() == 42                           # episode_length += same_action_num per agent step (base_agent.py:122)
+        assert ref[5].max() == 42 and ref[5][4].tolist() == [2, 40, 18]      # episode_length += same_action_num per agent step (base_agent.py:122)
     assert _lib.lib().lenv_td3_rn_team_size(C.byref(cfg), chains) == 8
     for G in (1, 2, 4, 8):
         cfg.team_size = G
