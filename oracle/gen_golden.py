@@ -1438,6 +1438,170 @@ def _gen_g11_body(cfg, n, GTN_Master, GTN_Worker, shutil):
          score_transform_type=np.array(cfg["agents"]["gtn"]["score_transform_type"]))
 
 
+# ------------------------------------------------------------------------------------------------
+# G12: the reference's OWN evaluation harness -- experiments/syn_env_evaluate_cartpole_vary_hp_2.py:25-48 train_test_agents
+# (DDQN_vary agents trained with agent.train(env=train_env) -- NO test env: the meter is fed by the training env's episode reward,
+# early-out on the virtual env by early_out_virtual_diff (base_agent.py:49-56,134-148) -- then ONE agent.test on the real env),
+# called the way experiments/syn_env_run_vary_hp.py:32-117 calls it: mode 0 = train on the REAL env, modes 1/2 = on the loaded SE.
+# ------------------------------------------------------------------------------------------------
+def gen_ckpt_b():
+    """A second reference-written checkpoint for G12: the same SE with the reward net's output bias moved to ~1 per step and a done
+    net that ends episodes (a stand-in for a TRAINED CartPole SE, whose episode reward is its length): the virtual early-out then
+    fires after a few evaluations, not at the first one and not never."""
+    from envs.env_factory import EnvFactory
+    cfg = load_cfg("default_config_cartpole.yaml")          # what experiments/GTNC_evaluate_cartpole_vary_hp.py:46 trains its checkpoints from
+    # 40-step episodes; a solved threshold their 10-episode mean can cross (mode 0 trains on the real env: real early-out rule)
+    cfg["envs"]["CartPole-v0"].update(max_steps=40, solved_reward=16.0)
+    seed_all(4200)
+    with quiet():
+        venv = EnvFactory(cfg).generate_virtual_env()
+    with torch.no_grad():
+        venv.env.reward_net[-1].bias.add_(1.0)
+        venv.env.done_net[-1].bias.add_(0.3)
+    path = os.path.join(OUT, "ckpt_cartpole_se_reference_b.pt")
+    torch.save({'model': venv.state_dict(), 'config': cfg}, path)           # exactly GTN_Master.save_model's payload
+    print("wrote", path, os.path.getsize(path))
+
+
+def gen_g12(name, mode, seed, agents_num=2, vary=True, vary_seed=77, ckpt="ckpt_cartpole_se_reference_b.pt"):
+    import json
+    import shutil
+    import tempfile
+    import ConfigSpace
+    import experiments.syn_env_evaluate_cartpole_vary_hp_2 as ev
+    import gym.envs as genvs
+    import gym.spaces as gspaces
+    tmp = tempfile.mkdtemp(prefix="lenv_g12_")
+    shutil.copy(os.path.join(OUT, ckpt), os.path.join(tmp, "model.pt"))
+    with quiet():
+        venv, real_env, config = ev.load_envs_and_config(file_name="model.pt", model_dir=tmp, device="cpu")
+    theta = se_theta(venv)
+    # syn_env_run_vary_hp.py:47-54 (mode 0): train_env = test_env = the real env; :82-91: train_env = the loaded virtual env
+    train_env = real_env if mode == 0 else venv
+    recs, holders = [], []
+    state = {"rec": None, "phase": None}
+    orig_random, orig_randint = random.random, np.random.randint
+    cls = genvs.CartPoleEnv
+    orig_reset, orig_sample = cls.reset, gspaces.Discrete.sample
+
+    def rec_random():
+        v = orig_random()
+        if state["phase"] == "train":
+            state["rec"].eps_uniform.append(v)
+        return v
+
+    def rec_randint(*a, **k):
+        v = orig_randint(*a, **k)
+        if state["phase"] == "train":
+            state["rec"].replay_idx.append(np.asarray(v).copy())
+        return v
+
+    def rec_reset(self):
+        obs = orig_reset(self)
+        if state["phase"] is not None:
+            state["rec"].resets.append((state["phase"], np.array(self.state, np.float64).copy()))
+        return obs
+
+    def rec_sample(self):
+        v = orig_sample(self)
+        if state["phase"] == "train":
+            state["rec"].rand_action.append(v)
+        return v
+
+    orig_step = train_env.step
+
+    def rec_step(action, state_=None):
+        ns, r, d = orig_step(action=action, state=state_) if mode != 0 else orig_step(action=action)
+        if state["phase"] == "train":
+            rec = state["rec"]
+            rec.steps.append(dict(action=int(np.asarray(action.detach().cpu().numpy()).reshape(-1)[0]), next_state=ns.detach().numpy().reshape(-1).copy(),
+                                  reward=float(r.item()), done=float(d.item()), n_rand=len(rec.rand_action)))
+        return ns, r, d
+
+    orig_select_agent = ev.select_agent
+
+    def wrapped_select_agent(config, agent_name):
+        if not vary:
+            # mode 1 of the experiment family with the base hyper-parameters: DDQN_vary with vary_hp off IS DDQN (DDQN_vary.py:16-21).
+            # train_test_agents has just forced vary_hp = True (:30); flip it back before the agent is built
+            config['agents']['ddqn_vary']['vary_hp'] = False
+        agent = orig_select_agent(config=config, agent_name=agent_name)
+        rec = Recorder()
+        state["rec"] = rec
+        recs.append(rec)
+        h = {"agent": agent,
+             "hp": {k: agent.full_config["agents"]["ddqn"][k] for k in ("lr", "batch_size", "hidden_size", "hidden_layer")},
+             "init": pack_linear_params(agent.model.state_dict(), "net.")}
+        holders.append(h)
+        orig_learn, orig_train, orig_test = agent.learn, agent.train, agent.test
+
+        def learn(replay_buffer, env, episode):
+            loss = orig_learn(replay_buffer=replay_buffer, env=env, episode=episode)
+            rec.losses.append(float(loss.item()))
+            return loss
+
+        def train(env, test_env=None, time_remaining=1e9):
+            assert test_env is None                       # the harness calls agent.train(env=train_env) (:40)
+            state["phase"] = "train"
+            out = orig_train(env=env, test_env=test_env, time_remaining=time_remaining)
+            state["phase"] = None
+            h["reward_train"], h["episode_length"] = list(out[0]), list(out[1])
+            return out
+
+        def test(env, time_remaining=1e9):
+            state["phase"] = "test"
+            out = orig_test(env=env, time_remaining=time_remaining)
+            state["phase"] = None
+            return out
+
+        agent.learn, agent.train, agent.test = learn, train, test
+        return agent
+
+    seed_all(seed)
+    ConfigSpace.RANDOM.seed(vary_seed)
+    train_env.step = rec_step
+    random.random, np.random.randint = rec_random, rec_randint
+    cls.reset, gspaces.Discrete.sample = rec_reset, rec_sample
+    ev.select_agent = wrapped_select_agent
+    try:
+        with quiet():
+            reward_list, train_steps_needed, episodes_needed = ev.train_test_agents(train_env=train_env, test_env=real_env, config=config,
+                                                                                   agents_num=agents_num)
+    finally:
+        random.random, np.random.randint = orig_random, orig_randint
+        cls.reset, gspaces.Discrete.sample = orig_reset, orig_sample
+        ev.select_agent = orig_select_agent
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = dict(config_json=np.array(json.dumps(config)), mode=np.array(mode), agents_num=np.array(agents_num), theta=theta,
+               reward_list=np.array(reward_list, np.float64), train_steps_needed=np.array(train_steps_needed, np.int64),
+               episodes_needed=np.array(episodes_needed, np.int64))
+    for i, (rec, h) in enumerate(zip(recs, holders)):
+        pre = "a%d_" % i
+        B = h["hp"]["batch_size"]
+        n = len(rec.steps)
+        explored = np.zeros(n, np.int32)
+        prev = 0
+        for k, st in enumerate(rec.steps):
+            explored[k] = 1 if st["n_rand"] > prev else 0
+            prev = st["n_rand"]
+        out.update({pre + "hp_json": np.array(json.dumps(h["hp"])), pre + "agent_init": h["init"],
+                    pre + "tape_eps_uniform": np.array(rec.eps_uniform, np.float64),
+                    pre + "tape_rand_action": np.array(rec.rand_action, np.int32),
+                    pre + "tape_replay_idx": (np.stack(rec.replay_idx).astype(np.int32) if rec.replay_idx else np.zeros((0, B), np.int32)),
+                    pre + "tape_train_reset": np.array([s_ for (ph, s_) in rec.resets if ph == "train"], np.float64).reshape(-1, 4),
+                    pre + "tape_test_reset": np.array([s_ for (ph, s_) in rec.resets if ph == "test"], np.float64).reshape(-1, 4),
+                    pre + "tr_action": np.array([s_["action"] for s_ in rec.steps], np.int32), pre + "tr_explored": explored,
+                    pre + "tr_next_state": np.stack([s_["next_state"] for s_ in rec.steps]).astype(np.float32),
+                    pre + "tr_reward": np.array([s_["reward"] for s_ in rec.steps], np.float32),
+                    pre + "tr_done": np.array([s_["done"] for s_ in rec.steps], np.float32),
+                    pre + "losses": np.array(rec.losses, np.float64),
+                    pre + "reward_train": np.array(h["reward_train"], np.float64),
+                    pre + "episode_length": np.array(h["episode_length"], np.int32)})
+    save(name, **out)
+    print(name, "episodes", [int(e[0]) for e in episodes_needed], "steps", [int(t[0]) for t in train_steps_needed],
+          "hp", [h["hp"] for h in holders], "reward_test", [np.mean(r) for r in reward_list])
+
+
 def main():
     # no arguments (or "all"): every fixture under tests/golden is regenerated (the full-shape runs g8df / g8tf take minutes each)
     ALL = ["g1", "g1ln", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x",
@@ -1446,6 +1610,12 @@ def main():
     if "all" in which:
         which = ALL
     os.makedirs(OUT, exist_ok=True)
+    if "g12" in which:
+        # (after "ckpt": g12 reads the committed checkpoints)
+        gen_ckpt_b()
+        gen_g12("g12_train_test_agents_cartpole_mode2_vary", mode=2, seed=1201, vary=True)
+        gen_g12("g12_train_test_agents_cartpole_mode1_plain", mode=1, seed=1202, vary=False)
+        gen_g12("g12_train_test_agents_cartpole_mode0_real_env", mode=0, seed=1203, vary=True)
     if "g1" in which:
         gen_g1()
     if "g1ln" in which:

@@ -1018,6 +1018,26 @@ static void budget_pad_train(double *episode_test_mean, int32_t *episode_len, co
     }
 }
 
+/* BaseAgent.env_solved (base_agent.py:49-62) over the reward meter's list (AverageMeter.get_mean / get_mean_last / _mean,
+ * utils.py:94-105: a slice sum over (len + 1e-9)); called for episode >= init_episodes only (base_agent.py:141).
+ * virtual_rule: break_env is a VirtualEnv (train(env, test_env=None) on one) -- relative change of the last `num` entries' mean
+ * against the `num` before them; otherwise the real rule avg >= solved_reward. */
+static int meter_env_solved(const double *meter, int n, int num, int virtual_rule, double solved_reward, double virtual_diff, int episode,
+                            int init_episodes)
+{
+    int lo = n - num; if (lo < 0) lo = 0;
+    double sm = 0.0;
+    for (int i = lo; i < n; ++i) sm += meter[i];
+    const double avg = sm / ((double)(n - lo) + 1e-9);
+    if (!virtual_rule) return avg >= solved_reward;
+    int hi2 = n - num; if (hi2 < 0) hi2 = 0;
+    int lo2 = n - 2 * num; if (lo2 < 0) lo2 = 0;
+    double s2 = 0.0;
+    for (int i = lo2; i < hi2; ++i) s2 += meter[i];
+    const double last = s2 / ((double)(hi2 - lo2) + 1e-9);
+    return fabs(avg - last) / (fabs(last) + 1e-9) < virtual_diff && episode >= init_episodes + num;
+}
+
 static double mean_seq(const double *v, int n)
 {
     double s = 0.0;
@@ -1150,6 +1170,7 @@ static int ddqn_se_chain_impl(const orc_ddqn_cfg *cfg, const float *se_params, c
         float phi_cache = 0.0f;                  /* RewardEnv: phi(s) of the state the env is in */
         int have_phi = 0;
         int ep_len = 0, env_steps = 0;
+        float ep_reward = 0.0f;                  /* base_agent.py:102,121 episode_reward += reward (fp32 tensors) */
         const int k_rep = cfg->same_action_num > 1 ? cfg->same_action_num : 1;
         for (int t = 0; t < cfg->max_steps; t += k_rep) {                       /* base_agent.py:104 range(0, max_steps, same_action_num) */
             /* select_train_action (DDQN.py:97-104) */
@@ -1225,24 +1246,25 @@ static int ddqn_se_chain_impl(const orc_ddqn_cfg *cfg, const float *se_params, c
                 trace->reward[k] = reward; trace->done[k] = done; trace->loss[k] = loss;
             }
             memcpy(state, next_state, sizeof(float) * S);
+            ep_reward = ep_reward + reward;
             ep_len += k_rep; ++train_steps;                                         /* base_agent.py:122 episode_length += same_action_num */
             if (done > 0.5f) break;
         }
         ++episodes_run;
         if (episode_len) episode_len[episode] = ep_len;
-        /* per-episode test on the real env (base_agent.py:134-136) */
-        run_test_phase(cfg, &qd, online, &rng, test_returns, &test_steps, z, a);
-        double tm = mean_seq(test_returns, cfg->test_episodes);
+        double tm;
+        if (cfg->test_mode == 1) tm = (double)ep_reward;      /* train(env, test_env=None): avg_meter_reward.update(episode_reward) (base_agent.py:138) */
+        else {
+            /* per-episode test on the real env (base_agent.py:134-136) */
+            run_test_phase(cfg, &qd, online, &rng, test_returns, &test_steps, z, a);
+            tm = mean_seq(test_returns, cfg->test_episodes);
+        }
         meter[n_meter++] = tm;
         if (episode_test_mean) episode_test_mean[episode] = tm;
-        /* early out on the real env (base_agent.py:49-62,141-148; AverageMeter._mean utils.py:103-105) */
-        if (episode >= cfg->init_episodes) {
-            int lo = n_meter - cfg->early_out_num; if (lo < 0) lo = 0;
-            double sm = 0.0;
-            for (int i = lo; i < n_meter; ++i) sm += meter[i];
-            double avg = sm / ((double)(n_meter - lo) + 1e-9);
-            if (avg >= cfg->solved_reward) break;
-        }
+        /* early out (base_agent.py:49-62,141-148): break_env = the test env (real rule), or without one the training env itself */
+        if (episode >= cfg->init_episodes &&
+            meter_env_solved(meter, n_meter, cfg->early_out_num, cfg->test_mode == 1 && !reward_env, cfg->solved_reward, cfg->early_out_virtual_diff,
+                             episode, cfg->init_episodes)) break;
     }
     if (timed_out_at >= 0) budget_pad_train(episode_test_mean, episode_len, meter, n_meter, episodes_run, cfg->train_episodes);
     else for (int e = episodes_run; e < cfg->train_episodes; ++e) {
@@ -1419,6 +1441,7 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
         if (episode == 0) eps = cfg->eps_init;                                  /* QL.py:101-106 */
         else { eps *= cfg->eps_decay; if (eps < cfg->eps_min) eps = cfg->eps_min; }
         int s = cfg->start_state, ep_len = 0, env_steps = 0;                    /* RewardEnv.reset -> real_env.reset() */
+        float ep_reward = 0.0f;                                                 /* base_agent.py:121 episode_reward += reward (fp32 tensor) */
         for (int t = 0; t < cfg->max_steps; t += k_rep) {                       /* base_agent.py:104 range(0, max_steps, same_action_num) */
             double u;
             if (cfg->rng_mode == ORC_RNG_TAPE) { if (n_eps >= tapes->n_eps_uniform) { err = -2; u = 1.0; } else u = tapes->eps_uniform[n_eps]; }
@@ -1482,21 +1505,22 @@ int orc_ql_rn_chain(const orc_ql_cfg *cfg, const float *rn_params, const float *
                 trace->reward[k] = (float)r; trace->done[k] = dn ? 1.0f : 0.0f;
             }
             s = s2;
+            ep_reward = ep_reward + (float)r;
             ep_len += k_rep; ++train_steps;
             if (dn) break;
         }
         ++episodes_run;
         if (episode_len) episode_len[episode] = ep_len;
-        QL_TEST_PHASE()
-        double tm = mean_seq(rets, cfg->test_episodes);
+        double tm;
+        if (cfg->test_mode == 1) tm = (double)ep_reward;      /* train(env, test_env=None): the RewardEnv's own episode reward (base_agent.py:138) */
+        else {
+            QL_TEST_PHASE()
+            tm = mean_seq(rets, cfg->test_episodes);
+        }
         meter[n_meter++] = tm;
         if (episode_test_mean) episode_test_mean[episode] = tm;
-        if (episode >= cfg->init_episodes) {
-            int lo = n_meter - cfg->early_out_num; if (lo < 0) lo = 0;
-            double sm = 0.0;
-            for (int i = lo; i < n_meter; ++i) sm += meter[i];
-            if (sm / ((double)(n_meter - lo) + 1e-9) >= cfg->solved_reward) break;
-        }
+        if (episode >= cfg->init_episodes &&
+            meter_env_solved(meter, n_meter, cfg->early_out_num, 0, cfg->solved_reward, 0.0, episode, cfg->init_episodes)) break;
     }
     if (timed_out) budget_pad_train(episode_test_mean, episode_len, meter, n_meter, episodes_run, cfg->train_episodes);
     else for (int e = episodes_run; e < cfg->train_episodes; ++e) {

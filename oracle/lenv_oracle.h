@@ -89,6 +89,16 @@ typedef struct {
     /* `use_layer_norm` of the agent's config section (models/model_utils.py:22-37): ONE shared nn.LayerNorm(hidden) behind every hidden
      * Linear but the first of the Q-net (Critic_DQN) / of the DuelingDDQN's feature stream (the heads have one hidden layer: none there) */
     int32_t q_layer_norm;
+    /* test_mode (what BaseAgent.train is called with; base_agent.py:64,134-148):
+     *   0 = train(env, test_env=real): GTN_Worker.calc_score (GTN_worker.py:195-199) -- the meter is fed by the mean of test_episodes real-env
+     *       test episodes after every training episode, early-out = real rule on it (avg >= solved_reward);
+     *   1 = train(env, test_env=None): every downstream evaluation (experiments/syn_env_evaluate_cartpole_vary_hp_2.py:38-41) -- NO per-episode
+     *       tests, the meter is fed by the training env's own episode reward (fp32 sum of the step rewards, base_agent.py:121,138), break_env =
+     *       the training env: a VirtualEnv ends on |avg - avg_last| / (|avg_last| + 1e-9) < early_out_virtual_diff once episode >=
+     *       init_episodes + early_out_num (base_agent.py:49-56, AverageMeter.get_mean_last utils.py:97-98); a RewardEnv / real env on
+     *       avg >= solved_reward.  episode_test_mean[] then carries the training episode rewards (the function's reward_train list). */
+    int32_t test_mode;
+    double early_out_virtual_diff;
 } orc_ddqn_cfg;
 
 /* RNG tapes (parity mode): values the reference drew, in per-stream order. */
@@ -202,6 +212,8 @@ typedef struct {
     int64_t step_budget;
     int32_t same_action_num;            /* env steps per chosen action; 0 and 1 both mean 1 */
     int32_t rn_layer_norm;              /* the ENV section's use_layer_norm with rn_layers >= 2: the reward net's (never perturbed) LayerNorm */
+    int32_t test_mode;                  /* as orc_ddqn_cfg::test_mode */
+    double early_out_virtual_diff;      /* never read: a grid RewardEnv is not a VirtualEnv */
 } orc_ql_cfg;
 
 typedef struct {
@@ -252,6 +264,8 @@ typedef struct {
     /* the ENV section's use_layer_norm with rn_layers >= 2: the reward net / the three SE nets normalise behind hidden Linear 2..L; NES perturbs
      * nn.Linear modules only, rn_params stays Linear-only and the module keeps weight 1 / bias 0 */
     int32_t rn_layer_norm;
+    int32_t test_mode;                  /* as orc_ddqn_cfg::test_mode */
+    double early_out_virtual_diff;
 } orc_td3_cfg;
 
 typedef struct {
@@ -316,6 +330,8 @@ typedef struct {
     double adam_beta1, adam_beta2, adam_eps;
     int64_t step_budget;
     int32_t se_layer_norm;                                   /* the ENV section's use_layer_norm, as orc_td3_cfg::rn_layer_norm */
+    int32_t test_mode;                  /* as orc_ddqn_cfg::test_mode */
+    double early_out_virtual_diff;
 } orc_td3d_cfg;
 
 typedef struct {

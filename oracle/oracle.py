@@ -36,7 +36,7 @@ class DdqnCfg(C.Structure):
                 ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("se_layer_norm", C.c_int32),
                 ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
                 ("synthetic_env_type", C.c_int32), ("reward_env_type", C.c_int32),
-                ("same_action_num", C.c_int32), ("q_layer_norm", C.c_int32)]
+                ("same_action_num", C.c_int32), ("q_layer_norm", C.c_int32), ("test_mode", C.c_int32), ("early_out_virtual_diff", C.c_double)]
 
 
 class Tapes(C.Structure):
@@ -60,7 +60,7 @@ class QlCfg(C.Structure):
                 ("init_episodes", C.c_int32), ("early_out_num", C.c_int32), ("batch_size", C.c_int32), ("rng_mode", C.c_int32),
                 ("agent_kind", C.c_int32), ("count_based", C.c_int32),
                 ("solved_reward", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double), ("eps_init", C.c_double),
-                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double), ("step_budget", C.c_int64), ("same_action_num", C.c_int32), ("rn_layer_norm", C.c_int32)]
+                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double), ("step_budget", C.c_int64), ("same_action_num", C.c_int32), ("rn_layer_norm", C.c_int32), ("test_mode", C.c_int32), ("early_out_virtual_diff", C.c_double)]
 
 
 class QlTrace(C.Structure):
@@ -81,7 +81,7 @@ class Td3Cfg(C.Structure):
                 ("step_budget", C.c_int64),
                 ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("use_layer_norm", C.c_int32),
                 ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
-                ("virtual_env", C.c_int32), ("same_action_num", C.c_int32), ("rn_layer_norm", C.c_int32)]
+                ("virtual_env", C.c_int32), ("same_action_num", C.c_int32), ("rn_layer_norm", C.c_int32), ("test_mode", C.c_int32), ("early_out_virtual_diff", C.c_double)]
 
 
 class Td3Tapes(C.Structure):
@@ -105,7 +105,7 @@ class Td3dCfg(C.Structure):
                 ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
                 ("action_std", C.c_double), ("policy_std", C.c_double), ("policy_std_clip", C.c_double), ("max_action", C.c_double),
                 ("gumbel_temp", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
-                ("step_budget", C.c_int64), ("se_layer_norm", C.c_int32)]
+                ("step_budget", C.c_int64), ("se_layer_norm", C.c_int32), ("test_mode", C.c_int32), ("early_out_virtual_diff", C.c_double)]
 
 
 class Td3dTapes(C.Structure):
@@ -440,7 +440,7 @@ def ddqn_cfg_from_config(config, grad_chunk=13, rng_mode=0, **overrides):
                   solved_reward=float(e["solved_reward"]), gamma=float(a["gamma"]), lr=float(a["lr"]),
                   tau=float(a["tau"]), eps_init=float(a["eps_init"]), eps_min=float(a["eps_min"]),
                   eps_decay=float(a["eps_decay"]), adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
-                  step_budget=int(a.get("step_budget", 0)))
+                  step_budget=int(a.get("step_budget", 0)), early_out_virtual_diff=float(a.get("early_out_virtual_diff", 0.0)))
     if "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 0)) == 1:
         # the agent trains on a RewardEnv over the real env; the `envs` section describes the reward network (env_factory.py:45-59)
         cfg.synthetic_env_type, cfg.reward_env_type = 1, int(e["reward_env_type"])
@@ -559,7 +559,8 @@ def td3_cfg_from_config(config, rng_mode=0, **overrides):
                  policy_delay=int(a["policy_delay"]), rng_mode=rng_mode, solved_reward=float(e["solved_reward"]),
                  gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), action_std=float(a["action_std"]),
                  policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=max_action,
-                 adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, step_budget=int(a.get("step_budget", 0)))
+                 adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, step_budget=int(a.get("step_budget", 0)),
+                 early_out_virtual_diff=float(a.get("early_out_virtual_diff", 0.0)))
     if "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 1)) == 0:
         cfg.virtual_env = 1                           # the agent trains on a VirtualEnv: the `envs` section describes the three SE nets
     cfg.same_action_num = int(a["same_action_num"])
@@ -704,7 +705,7 @@ def td3d_cfg_from_config(config, rng_mode=0, hp=None, **overrides):
                   gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), action_std=float(a["action_std"]),
                   policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=1.0,
                   gumbel_temp=float(a["gumbel_softmax_temp"]), adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
-                  step_budget=int(a.get("step_budget", 0)))
+                  step_budget=int(a.get("step_budget", 0)), early_out_virtual_diff=float(a.get("early_out_virtual_diff", 0.0)))
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg
