@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LENV_ABI_VERSION 6
+#define LENV_ABI_VERSION 7
 
 enum {
     LENV_OK = 0,
@@ -120,6 +120,19 @@ typedef struct {
      * there); its weight | bias sit behind the second Linear in the parameter vector (Module.parameters() order), fresh agents start them at
      * 1 | 0.  Nothing to do with one hidden layer.  GEMM-tiled kernel (lenv_dueling_se_inner_loop*); forward and backward in the loop. */
     int32_t q_layer_norm;
+    /* ABI 7.  test_mode = which BaseAgent.train call the loop is (agents/base_agent.py:64,134-148):
+     *   0 = train(env, test_env=real_env), GTN_Worker.calc_score (agents/GTN_worker.py:195-199): test_episodes real-env test episodes after
+     *       every training episode feed the meter; early-out = the real rule on it (mean of the last early_out_num entries >= solved_reward);
+     *   1 = train(env, test_env=None), what every downstream evaluation calls (experiments/syn_env_evaluate_cartpole_vary_hp_2.py:38-41):
+     *       NO per-episode tests; the meter is fed by the training env's own episode reward (the fp32 sum of the step rewards,
+     *       base_agent.py:121,138); break_env = the training env (:141-146): a VirtualEnv stops on
+     *       |avg - avg_last| / (|avg_last| + 1e-9) < early_out_virtual_diff once episode >= init_episodes + early_out_num
+     *       (base_agent.py:49-56; AverageMeter.get_mean_last, utils.py:97-105), a RewardEnv / the real env (synthetic_env_type 1) on
+     *       avg >= solved_reward.  out->episode_test_mean[] then holds the training episode rewards (the function's reward_train list);
+     *       the final test and the score are unchanged.  Training on the REAL env (experiments/syn_env_run_vary_hp.py:47-54, mode 0) =
+     *       synthetic_env_type 1 with reward_env_type 0 (envs/reward_env.py:80-81: the real reward passes through; theta is not read). */
+    int32_t test_mode;
+    double early_out_virtual_diff;
 } lenv_ddqn_cfg;
 
 /* RNG tapes (parity mode).  Per-chain rows: element [c*stride + n]; all DEVICE pointers. */
@@ -227,6 +240,8 @@ typedef struct {
     int32_t same_action_num;            /* env steps per chosen action (base_agent.py:104,194; env_wrapper.py:56-61: stop at done, python-float
                                            reward sum); 0 and 1 both mean 1 */
     int32_t rn_layer_norm;              /* the ENV section's `use_layer_norm` with rn_layers >= 2, as lenv_ddqn_cfg::se_layer_norm (ABI 6; was padding) */
+    int32_t test_mode;                  /* ABI 7: as lenv_ddqn_cfg::test_mode (1 = BaseAgent.train without a test env) */
+    double early_out_virtual_diff;      /* never read: a grid RewardEnv is not a VirtualEnv (the real rule applies) */
 } lenv_ql_cfg;
 
 typedef struct {
@@ -367,6 +382,8 @@ typedef struct {
      * carry the shared nn.LayerNorm behind hidden Linear 2..L.  As lenv_ddqn_cfg::se_layer_norm: NES perturbs nn.Linear modules only, theta / eps
      * stay the Linear parameters, the kernel normalises with the constructor's weight 1 / bias 0. */
     int32_t rn_layer_norm;
+    int32_t test_mode;                  /* ABI 7: as lenv_ddqn_cfg::test_mode (1 = BaseAgent.train without a test env) */
+    double early_out_virtual_diff;
 } lenv_td3_cfg;
 
 /* RNG tapes (parity mode); per-chain rows, strides in ROWS (rows of A floats / B ints / S doubles as noted) */
@@ -447,6 +464,8 @@ typedef struct {
     double adam_beta1, adam_beta2, adam_eps;
     int64_t step_budget;                                 /* env-step stand-in for time_remaining, see lenv_ddqn_cfg::step_budget */
     int32_t se_layer_norm;                               /* ABI 6: the ENV section's `use_layer_norm`, as lenv_ddqn_cfg::se_layer_norm */
+    int32_t test_mode;                  /* ABI 7: as lenv_ddqn_cfg::test_mode (1 = BaseAgent.train without a test env) */
+    double early_out_virtual_diff;
 } lenv_td3d_cfg;
 
 /* RNG tapes (parity mode); per-chain rows, strides in ROWS (rows of A floats / one int / four doubles as noted) */

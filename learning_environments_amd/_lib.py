@@ -43,7 +43,7 @@ class DdqnCfg(C.Structure):
                 ("same_action_num", C.c_int32),
                 ("team_size", C.c_int32),        # workgroups per chain: 0 = automatic, 1 = never a team, G = at most G
                 ("kernel_variant", C.c_int32),   # VARIANT_* bits, 0 = fastest
-                ("q_layer_norm", C.c_int32)]
+                ("q_layer_norm", C.c_int32), ("test_mode", C.c_int32), ("early_out_virtual_diff", C.c_double)]
 
 
 class Tapes(C.Structure):
@@ -76,7 +76,7 @@ class QlCfg(C.Structure):
                 ("init_episodes", C.c_int32), ("early_out_num", C.c_int32), ("batch_size", C.c_int32), ("rng_mode", C.c_int32),
                 ("agent_kind", C.c_int32), ("count_based", C.c_int32),
                 ("solved_reward", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double), ("eps_init", C.c_double),
-                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double), ("step_budget", C.c_int64), ("same_action_num", C.c_int32), ("rn_layer_norm", C.c_int32)]
+                ("eps_min", C.c_double), ("eps_decay", C.c_double), ("beta", C.c_double), ("step_budget", C.c_int64), ("same_action_num", C.c_int32), ("rn_layer_norm", C.c_int32), ("test_mode", C.c_int32), ("early_out_virtual_diff", C.c_double)]
 
 
 class QlOut(C.Structure):
@@ -99,7 +99,7 @@ class Td3Cfg(C.Structure):
                 ("step_budget", C.c_int64),
                 ("icm_enabled", C.c_int32), ("icm_feature_dim", C.c_int32), ("icm_hidden", C.c_int32), ("use_layer_norm", C.c_int32),
                 ("icm_lr", C.c_double), ("icm_beta", C.c_double), ("icm_eta", C.c_double),
-                ("virtual_env", C.c_int32), ("same_action_num", C.c_int32), ("team_size", C.c_int32), ("kernel_variant", C.c_int32), ("rn_layer_norm", C.c_int32)]
+                ("virtual_env", C.c_int32), ("same_action_num", C.c_int32), ("team_size", C.c_int32), ("kernel_variant", C.c_int32), ("rn_layer_norm", C.c_int32), ("test_mode", C.c_int32), ("early_out_virtual_diff", C.c_double)]
 
 
 class Td3Tapes(C.Structure):
@@ -120,7 +120,7 @@ class Td3dCfg(C.Structure):
                 ("solved_reward", C.c_double), ("gamma", C.c_double), ("lr", C.c_double), ("tau", C.c_double),
                 ("action_std", C.c_double), ("policy_std", C.c_double), ("policy_std_clip", C.c_double), ("max_action", C.c_double),
                 ("gumbel_temp", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
-                ("step_budget", C.c_int64), ("se_layer_norm", C.c_int32)]
+                ("step_budget", C.c_int64), ("se_layer_norm", C.c_int32), ("test_mode", C.c_int32), ("early_out_virtual_diff", C.c_double)]
 
 
 TD3D_TAPE_KEYS = ("rand_action", "act_noise", "test_noise", "policy_noise", "gumbel_act", "gumbel_test", "gumbel_target", "gumbel_actor",
@@ -281,7 +281,7 @@ def lib():
                                            C.c_size_t, C.POINTER(Td3Out), vp]
         L.lenv_td3d_agent_init.restype = C.c_int
         L.lenv_td3d_agent_init.argtypes = [C.POINTER(Td3dCfg), C.POINTER(ChainHp), vp, C.c_int64, vp, vp]
-        if L.lenv_abi_version() != 6:
+        if L.lenv_abi_version() != 7:
             raise LenvError("liblenv_hip.so ABI version mismatch")
         L.lenv_diag_occupy_cus.restype = C.c_int
         L.lenv_diag_occupy_cus.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp]

@@ -21,9 +21,9 @@ from .nes_common import chain_keys, fresh_agent_init, linear_init_bounds, set_la
 class DdqnSeTask(object):
     name = "ddqn_se"
 
-    def __init__(self, config, engine):
+    def __init__(self, config, engine, test_mode=0):
         self.engine = engine
-        self.cfg = ddqn_cfg_from_config(config) if engine.name == "hip" else engine.cfg_from_config(config)
+        self.cfg = ddqn_cfg_from_config(config, test_mode=test_mode) if engine.name == "hip" else engine.cfg_from_config(config)
         dims = agent_layer_dims(self.cfg)
         self.ln_slice = agent_layer_norm_slice(self.cfg)      # use_layer_norm: the shared LayerNorm's block in the flat parameter vector
         self.agent_bounds = torch.from_numpy(with_layer_norm_block(linear_init_bounds(dims), self.ln_slice)).to(engine.device)
@@ -52,7 +52,7 @@ class DdqnVaryTask(object):
     launch of the GEMM-tiled kernel (per-chain hyper-parameter arrays, workspace sized for the largest draw)."""
     name = "ddqn_vary_se"
 
-    def __init__(self, config, engine):
+    def __init__(self, config, engine, test_mode=0):
         import copy
         from . import vary
         self.engine = engine              # HipNesEngine, or the test suite's oracle-backed stand-in (CPU tensors)
@@ -64,10 +64,11 @@ class DdqnVaryTask(object):
         big = copy.deepcopy(config)
         big["agents"][self.agent_key].update(batch_size=bd["batch_size"][1], hidden_size=bd["hidden_size"][1],
                                              hidden_layer=bd["hidden_layer"][1])
-        self.cfg = ddqn_cfg_from_config(big)              # the maxima: workspace / LDS / row strides
+        self.cfg = ddqn_cfg_from_config(big, test_mode=test_mode)      # the maxima: workspace / LDS / row strides
         self.cfg.grad_chunk = 0                           # one sequential batch gradient (GEMM-tiled kernel)
         self.agent_bounds = None
         self.last_hp = None
+        self.fixed_hp = None
         self.icm_bounds = None
         if engine.name == "hip" and self.cfg.icm_enabled:
             self.icm_bounds = torch.from_numpy(linear_init_bounds(icm_layer_dims(self.cfg))).to(engine.device)
@@ -77,6 +78,8 @@ class DdqnVaryTask(object):
 
     def draw_hp(self, keys):
         from . import vary
+        if self.fixed_hp is not None:     # a recorded draw replayed (parity tests against the reference's runs)
+            return list(self.fixed_hp)
         return [vary.vary_hyperparameters(self.base, vary.chain_units(k)) for k in keys]
 
     def scores(self, inner, theta, eps, chain_worker, chain_sign, keys_t, agent_init):
@@ -98,10 +101,10 @@ class DdqnVaryTask(object):
 class QlRnTask(object):
     name = "ql_rn"
 
-    def __init__(self, config, engine, tables):
+    def __init__(self, config, engine, tables, test_mode=0):
         self.engine = engine
         self.tables = tables
-        self.cfg = ql_cfg_from_config(config, tables)
+        self.cfg = ql_cfg_from_config(config, tables, test_mode=test_mode)
         self.agent_bounds = None
 
     def make_inner(self, chains, want_episode_stats=False):
@@ -117,9 +120,9 @@ class QlRnTask(object):
 class Td3RnTask(object):
     name = "td3_rn"
 
-    def __init__(self, config, engine):
+    def __init__(self, config, engine, test_mode=0):
         self.engine = engine
-        self.cfg = td3_cfg_from_config(config)
+        self.cfg = td3_cfg_from_config(config, test_mode=test_mode)
         self.ln_slice = td3_layer_norm_slices(self.cfg)       # use_layer_norm: the three nets' LayerNorm blocks in the flat parameter vector
         self.agent_bounds = torch.from_numpy(with_layer_norm_block(linear_init_bounds(td3_layer_dims(self.cfg)), self.ln_slice)).to(engine.device)
         self.icm_bounds = None                    # "td3_icm": TD3(icm=True), a fresh ICM per chain
@@ -144,7 +147,7 @@ class Td3VaryTask(object):
     one launch of the TD3 kernel (lenv_td3_rn_inner_loop_hp), like DdqnVaryTask."""
     name = "td3_vary_rn"
 
-    def __init__(self, config, engine):
+    def __init__(self, config, engine, test_mode=0):
         import copy
         from . import vary
         if engine.name != "hip":
@@ -154,9 +157,10 @@ class Td3VaryTask(object):
         bd = vary.hp_bounds(self.base)
         big = copy.deepcopy(config)
         big["agents"]["td3"].update(batch_size=bd["batch_size"][1], hidden_size=bd["hidden_size"][1], hidden_layer=bd["hidden_layer"][1])
-        self.cfg = td3_cfg_from_config(big)
+        self.cfg = td3_cfg_from_config(big, test_mode=test_mode)
         self.agent_bounds = None
         self.last_hp = None
+        self.fixed_hp = None
         self.icm_bounds = None
         if self.cfg.icm_enabled:
             self.icm_bounds = torch.from_numpy(linear_init_bounds(icm_layer_dims(self.cfg))).to(engine.device)
@@ -166,6 +170,8 @@ class Td3VaryTask(object):
 
     def draw_hp(self, keys):
         from . import vary
+        if self.fixed_hp is not None:     # a recorded draw replayed (parity tests against the reference's runs)
+            return list(self.fixed_hp)
         return [vary.vary_hyperparameters(self.base, vary.chain_units(k)) for k in keys]
 
     def scores(self, inner, theta, eps, chain_worker, chain_sign, keys_t, agent_init):
@@ -189,7 +195,7 @@ class Td3DiscreteTask(object):
     the device from the chain keys."""
     name = "td3_discrete_se"
 
-    def __init__(self, config, engine):
+    def __init__(self, config, engine, test_mode=0):
         import copy
         from . import vary
         if engine.name != "hip":
@@ -203,15 +209,18 @@ class Td3DiscreteTask(object):
             big = copy.deepcopy(config)
             big["agents"]["td3_discrete_vary"].update(batch_size=bd["batch_size"][1], hidden_size=bd["hidden_size"][1],
                                                       hidden_layer=bd["hidden_layer"][1])
-        self.cfg = td3d_cfg_from_config(big)
+        self.cfg = td3d_cfg_from_config(big, test_mode=test_mode)
         self.agent_bounds = None
         self.last_hp = None
+        self.fixed_hp = None
 
     def make_inner(self, chains, want_episode_stats=False):
         return self.engine.make_inner_td3d(self.cfg, chains, want_episode_stats=want_episode_stats, vary=self.vary)
 
     def draw_hp(self, keys):
         from . import vary
+        if self.fixed_hp is not None:     # a recorded draw replayed (parity tests against the reference's runs)
+            return list(self.fixed_hp)
         return [vary.vary_hyperparameters(self.base, vary.chain_units(k)) for k in keys]
 
     def scores(self, inner, theta, eps, chain_worker, chain_sign, keys_t, agent_init):
@@ -230,28 +239,35 @@ class Td3DiscreteTask(object):
 TD3_ENVS = ("HalfCheetah-v3", "Pendulum-v0", "MountainCarContinuous-v0")       # continuous real envs of the TD3 kernel
 
 
-def select_task(config, engine, synthetic_env):
+def select_task(config, engine, synthetic_env, test_mode=0):
+    """test_mode: lenv_ddqn_cfg::test_mode -- 0 = GTN_Worker.calc_score's train(env, test_env=real_env); 1 = train(env) without a test env
+    (the evaluation harness, experiments/syn_env_evaluate.py)."""
     agent_name = config["agents"]["gtn"]["agent_name"].lower()
     env_type = config["agents"]["gtn"]["synthetic_env_type"]
+    tm = dict(test_mode=int(test_mode))
     if agent_name in ("ddqn", "duelingddqn", "ddqn_icm", "duelingddqn_icm") and env_type == 0:
-        return DdqnSeTask(config, engine)
+        return DdqnSeTask(config, engine, **tm)
     if agent_name in ("ddqn_vary", "duelingddqn_vary", "ddqn_icm_vary", "duelingddqn_icm_vary") and env_type == 0:
         # vary_hp False: the agent IS its base agent (DDQN_vary.py:16-21); the *_icm_vary names read the same `<agent>_vary`
         # section (DDQN_vary.py:16) and switch the ICM on
         section = agent_name.replace("_icm", "")
-        return DdqnVaryTask(config, engine) if config["agents"][section]["vary_hp"] else DdqnSeTask(config, engine)
+        return DdqnVaryTask(config, engine, **tm) if config["agents"][section]["vary_hp"] else DdqnSeTask(config, engine, **tm)
     if agent_name in ("ddqn", "duelingddqn", "ddqn_icm", "duelingddqn_icm") and env_type == 1 and config["env_name"] in ("CartPole-v0", "Acrobot-v1", "MountainCar-v0"):
-        return DdqnSeTask(config, engine)         # RewardEnv over the real env (default_config_cartpole_reward_env.yaml): same kernel
+        return DdqnSeTask(config, engine, **tm)         # RewardEnv over the real env (default_config_cartpole_reward_env.yaml): same kernel
+    if agent_name in ("ddqn_vary", "duelingddqn_vary", "ddqn_icm_vary", "duelingddqn_icm_vary") and env_type == 1 and config["env_name"] in ("CartPole-v0", "Acrobot-v1", "MountainCar-v0"):
+        # the *_vary agents on a RewardEnv / on the real env itself (experiments/syn_env_run_vary_hp.py:47-54, mode 0): same kernel, per-chain shapes
+        section = agent_name.replace("_icm", "")
+        return DdqnVaryTask(config, engine, **tm) if config["agents"][section]["vary_hp"] else DdqnSeTask(config, engine, **tm)
     if agent_name in TABULAR_AGENTS and env_type == 1:
         real = synthetic_env.env.real_env
         if not hasattr(real, "tables"):
             raise NotImplementedError("QL needs a discrete (gridworld) real env")
-        return QlRnTask(config, engine, real.tables)
+        return QlRnTask(config, engine, real.tables, **tm)
     # TD3 on the HalfCheetah stand-in / Pendulum-v0 / MountainCarContinuous-v0: RewardEnv (type 1, BASELINE config 5) or VirtualEnv (type 0, default_config_halfcheetah.yaml)
     if agent_name in ("td3", "td3_icm") and env_type in (0, 1) and config["env_name"] in TD3_ENVS:
-        return Td3RnTask(config, engine)
+        return Td3RnTask(config, engine, **tm)
     if agent_name in ("td3_vary", "td3_icm_vary") and env_type in (0, 1) and config["env_name"] in TD3_ENVS:
-        return Td3VaryTask(config, engine) if config["agents"]["td3_vary"]["vary_hp"] else Td3RnTask(config, engine)
+        return Td3VaryTask(config, engine, **tm) if config["agents"]["td3_vary"]["vary_hp"] else Td3RnTask(config, engine, **tm)
     if agent_name == "td3_discrete_vary" and env_type == 0 and config["env_name"] in TD3_DISCRETE_ENVS:
-        return Td3DiscreteTask(config, engine)
+        return Td3DiscreteTask(config, engine, **tm)
     raise NotImplementedError("inner agent '%s' on synthetic_env_type %s has no fused kernel yet" % (agent_name, env_type))

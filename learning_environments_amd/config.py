@@ -56,6 +56,8 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
                        adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
                        step_budget=int(a.get("step_budget", 0)))      # env-step stand-in for time_remaining (base_agent.py:30-47)
     cfg.same_action_num = int(a["same_action_num"])    # env steps per chosen action (base_agent.py:104,194); > 1: GEMM-tiled kernel
+    # base_agent.py:24: read by env_solved when BaseAgent.train runs WITHOUT a test env (cfg.test_mode 1, the evaluation harness)
+    cfg.early_out_virtual_diff = float(a.get("early_out_virtual_diff", 0.0))
     # use_layer_norm: ONE shared nn.LayerNorm behind hidden Linear 2..L of the Q-net / the feature stream (model_utils.py:22-37); a net with
     # one hidden layer has no position for it (and no parameters: the module is created but never registered)
     cfg.q_layer_norm = 1 if a.get("use_layer_norm", False) else 0
@@ -153,7 +155,8 @@ def ql_cfg_from_config(config, tables, rng_mode=_lib.RNG_COUNTER, **overrides):
                      init_episodes=int(a["init_episodes"]), early_out_num=int(a["early_out_num"]),
                      batch_size=int(a["batch_size"]), rng_mode=int(rng_mode), solved_reward=float(val(e["solved_reward"])),
                      alpha=float(a["alpha"]), gamma=float(a["gamma"]), eps_init=float(a["eps_init"]),
-                     eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]), step_budget=int(a.get("step_budget", 0)))
+                     eps_min=float(a["eps_min"]), eps_decay=float(a["eps_decay"]), step_budget=int(a.get("step_budget", 0)),
+                       early_out_virtual_diff=float(a.get("early_out_virtual_diff", 0.0)))
     cfg.same_action_num = int(a["same_action_num"])
     cfg.rn_layer_norm = 1 if e.get("use_layer_norm", False) else 0     # the reward net's own LayerNorm (never perturbed: see ddqn_cfg_from_config)
     for k, v in overrides.items():
@@ -184,7 +187,8 @@ def td3_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
                       policy_delay=int(a["policy_delay"]), rng_mode=int(rng_mode), solved_reward=float(val(e["solved_reward"])),
                       gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]), action_std=float(a["action_std"]),
                       policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]), max_action=TD3_MAX_ACTION[env_name],
-                      adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, step_budget=int(a.get("step_budget", 0)))
+                      adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, step_budget=int(a.get("step_budget", 0)),
+                       early_out_virtual_diff=float(a.get("early_out_virtual_diff", 0.0)))
     if "gtn" in config["agents"] and int(config["agents"]["gtn"].get("synthetic_env_type", 1)) == 0:
         cfg.virtual_env = 1                           # VirtualEnv (default_config_halfcheetah.yaml): `envs` describes the three SE nets
     cfg.same_action_num = int(a["same_action_num"])   # env steps per chosen action (the MountainCarContinuous configs ship 2)
@@ -235,7 +239,8 @@ def td3d_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, **overrides):
                        solved_reward=float(val(e["solved_reward"])), gamma=float(a["gamma"]), lr=float(a["lr"]), tau=float(a["tau"]),
                        action_std=float(a["action_std"]), policy_std=float(a["policy_std"]), policy_std_clip=float(a["policy_std_clip"]),
                        max_action=1.0, gumbel_temp=float(a["gumbel_softmax_temp"]), adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
-                       step_budget=int(a.get("step_budget", 0)))
+                       step_budget=int(a.get("step_budget", 0)),
+                       early_out_virtual_diff=float(a.get("early_out_virtual_diff", 0.0)))
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg

@@ -1586,6 +1586,7 @@ static int inner_check(const lenv_ddqn_cfg *cfg)
     if (cfg->icm_enabled) return LENV_ERR_UNSUPPORTED;                             // ICM agents: lenv_dueling_se_inner_loop_icm
     if (cfg->synthetic_env_type != 0) return LENV_ERR_UNSUPPORTED;                 // RewardEnv over the real env: GEMM-tiled kernel
     if (cfg->same_action_num > 1) return LENV_ERR_UNSUPPORTED;                     // several env steps per action: GEMM-tiled kernel
+    if (cfg->test_mode != 0) return LENV_ERR_UNSUPPORTED;                          // BaseAgent.train without a test env (the evaluation harness): GEMM-tiled kernel
     // the Q-net's shared nn.PReLU slope is a trained parameter in the reference (DDQN.py:36 Adam over model.parameters());
     // refusing beats silently training with a frozen 0.25
     if (cfg->q_act == LENV_ACT_PRELU) return LENV_ERR_UNSUPPORTED;

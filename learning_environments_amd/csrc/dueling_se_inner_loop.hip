@@ -395,6 +395,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
 
     // Deterministic time-out (lenv_ddqn_cfg::step_budget, base_agent.py:30-47): elapsed = env steps taken so far
     const bool budgeted = cfg.step_budget > 0;
+    const bool no_test_env = FIXED ? false : cfg.test_mode == 1;      // BaseAgent.train(env, test_env=None): lenv_ddqn_cfg::test_mode
     int timed_out_at = -1;
     for (int episode = 0; episode < cfg.train_episodes; ++episode) {
         if (budgeted && (int64_t)train_steps + test_steps > cfg.step_budget) { timed_out_at = episode; break; }   // uniform
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
         }
         __syncthreads();
         int ep_len = 0, env_steps = 0;
+        float tr_reward = 0.0f;                                  // base_agent.py:102,121 episode_reward += reward (fp32 tensors; uniform over the threads)
         for (int t = 0; t < cfg.max_steps; t += k_rep) {         // base_agent.py:104 range(0, max_steps, same_action_num)
             PT_MARK(9);
             const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
@@ -615,6 +617,7 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
                 a.out.trace_reward_done[k * 2] = newrow[2 * S + 1]; a.out.trace_reward_done[k * 2 + 1] = newrow[2 * S + 2];
             }
             const float done_now = newrow[2 * S + 2];
+            tr_reward = tr_reward + newrow[2 * S + 1];
             __syncthreads();
             if (tid < S) state[tid] = newrow[S + 1 + tid];
             ep_len += k_rep; ++train_steps;                  // base_agent.py:122: episode_length += same_action_num
@@ -774,22 +777,21 @@ __global__ __launch_bounds__(DNT) void dueling_se_inner_kernel(const DuelArgs a)
         if (tid == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
         __syncthreads();
         PT_MARK(9);
-        test_phase();
+        if (!no_test_env) test_phase();                    // per-episode test on the real env (base_agent.py:134-136)
         PT_MARK(8);
         if (tid == 0) {
-            double sm = 0.0;
-            for (int i = 0; i < T; ++i) sm += ret[i];
-            const double tm = sm / (double)T;
+            double tm;
+            if (no_test_env) tm = (double)tr_reward;       // train(env, test_env=None): avg_meter_reward.update(episode_reward) (base_agent.py:138)
+            else {
+                double sm = 0.0;
+                for (int i = 0; i < T; ++i) sm += ret[i];
+                tm = sm / (double)T;
+            }
             meter[episode] = tm;
             if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
-            int brk = 0;
-            if (learning) {
-                int lo = episode + 1 - cfg.early_out_num; if (lo < 0) lo = 0;
-                double s2 = 0.0;
-                for (int i = lo; i <= episode; ++i) s2 += meter[i];
-                if (s2 / ((double)(episode + 1 - lo) + 1e-9) >= cfg.solved_reward) brk = 1;
-            }
-            ictrl[3] = brk;
+            // early out (base_agent.py:49-62,141-148): break_env = the test env (real rule) or, without one, the training env itself
+            ictrl[3] = learning && meter_env_solved(meter, episode + 1, cfg.early_out_num, no_test_env && !reward_env, cfg.solved_reward,
+                                                    cfg.early_out_virtual_diff, episode, cfg.init_episodes);
         }
         __syncthreads();
         const int brk = ictrl[3];
@@ -900,6 +902,7 @@ static int dueling_layout(const lenv_ddqn_cfg *cfg, DuelArgs &a, size_t *lds_byt
     if (L < 1 || L > D_MAXL || H < 1 || H > D_MAXH || F < 1 || F > D_MAXW || B < 1 || B > D_MAXB || T < 1 || T > D_MAXW || cfg->se_layers < 1 || cfg->se_layers > D_MAXL)
         return LENV_ERR_UNSUPPORTED;
     if (cfg->same_action_num < 0 || cfg->same_action_num > 64) return LENV_ERR_UNSUPPORTED;
+    if (cfg->test_mode < 0 || cfg->test_mode > 1) return LENV_ERR_INVALID;
     if (!((cfg->env_id == LENV_ENV_CARTPOLE && S == 4 && A == 2) || (cfg->env_id == LENV_ENV_ACROBOT && S == 6 && A == 3) ||
           (cfg->env_id == LENV_ENV_MOUNTAINCAR && S == 2 && A == 3)))
         return LENV_ERR_UNSUPPORTED;
@@ -1042,7 +1045,7 @@ extern "C" int lenv_dueling_se_inner_loop_icm(const lenv_ddqn_cfg *cfg, const le
             return cfg->agent_kind == sp.kind && cfg->env_id == sp.env && cfg->state_dim == sp.S && cfg->num_actions == sp.A &&
                    (sp.kind == 0 || cfg->feature_dim == sp.F) && cfg->q_hidden == sp.H && cfg->q_layers == sp.L && cfg->batch_size == sp.B &&
                    cfg->se_hidden == sp.Hse && cfg->test_episodes == sp.T && cfg->q_act == sp.q_act && cfg->se_act == sp.se_act && cfg->same_action_num <= 1 &&
-                   !cfg->q_layer_norm && cfg->se_layers == 1;     // (the FIXED builds hard-code a one-hidden-layer SE without LayerNorm)
+                   !cfg->q_layer_norm && cfg->se_layers == 1 && cfg->test_mode == 0;     // (the FIXED builds hard-code a one-hidden-layer SE without LayerNorm)
         };
         // production launches of a wave-chain shape (dueling_wavechain.hip): kernel_variant NO_WAVECHAIN keeps the GEMM-queue kernel (A/B runs)
         const bool no_wc = (cfg->kernel_variant & LENV_VARIANT_NO_WAVECHAIN) != 0;

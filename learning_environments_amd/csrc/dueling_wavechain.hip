@@ -1610,7 +1610,7 @@ int lenv_wc_dueling_shape(const lenv_ddqn_cfg *cfg)
         if (cfg->agent_kind == sp.kind && cfg->env_id == sp.env && cfg->state_dim == sp.S && cfg->num_actions == sp.A &&
             (sp.kind == 0 || cfg->feature_dim == WC_H) && cfg->q_hidden == WC_H && cfg->q_layers == 2 && cfg->batch_size == WC_B && cfg->se_hidden == sp.Hse && cfg->se_layers == 1 &&
             cfg->test_episodes == sp.T && cfg->q_act == sp.q_act && cfg->se_act == sp.se_act && cfg->synthetic_env_type == 0 && !cfg->icm_enabled &&
-            !cfg->q_layer_norm)
+            !cfg->q_layer_norm && cfg->test_mode == 0)      // (test_mode 1, the evaluation harness's training call: GEMM-queue kernel)
             return s;
     }
     return 0;

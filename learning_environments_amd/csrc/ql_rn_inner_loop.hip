@@ -255,6 +255,7 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
         if (episode == 0) eps_g = cfg.eps_init;                       // QL.py:101-106
         else { eps_g *= cfg.eps_decay; if (eps_g < cfg.eps_min) eps_g = cfg.eps_min; }
         int s = cfg.start_state, ep_len = 0, env_steps = 0;
+        float tr_reward = 0.0f;                                        // base_agent.py:102,121 episode_reward += reward (fp32 tensor)
         for (int st = 0; st < cfg.max_steps; st += k_rep) {            // base_agent.py:104 range(0, max_steps, same_action_num)
             double u;
             if (tape) { if (n_eps >= a.tapes.eps_uniform_stride) { status = -2; u = 1.0; } else u = a.tapes.eps_uniform[chain * a.tapes.eps_uniform_stride + n_eps]; }
@@ -327,21 +328,21 @@ __global__ __launch_bounds__(64) void ql_rn_inner_kernel(const QlArgs a)
                 a.out.trace_reward_done[k * 2] = (float)r; a.out.trace_reward_done[k * 2 + 1] = dn ? 1.0f : 0.0f;
             }
             s = s2;
+            tr_reward = tr_reward + (float)r;
             ep_len += k_rep; ++train_steps;
             if (dn) break;
         }
         ++episodes_run;
         if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
-        test_phase();
-        const double tm = mean_rets();
+        // lenv_ql_cfg::test_mode 1 = train(env, test_env=None): no per-episode tests, the RewardEnv's own episode reward feeds the meter
+        // (base_agent.py:134-138); a grid RewardEnv is not a VirtualEnv, so the real rule applies either way (:57-60)
+        double tm;
+        if (cfg.test_mode == 1) tm = (double)tr_reward;
+        else { test_phase(); tm = mean_rets(); }
         meter[episode] = tm;
         if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
-        if (episode >= cfg.init_episodes) {                           // base_agent.py:141-148, utils.py:103-105
-            int lo = episode + 1 - cfg.early_out_num; if (lo < 0) lo = 0;
-            double sm = 0.0;
-            for (int i = lo; i <= episode; ++i) sm += meter[i];
-            if (sm / ((double)(episode + 1 - lo) + 1e-9) >= cfg.solved_reward) solved_brk = 1;
-        }
+        if (episode >= cfg.init_episodes)                             // base_agent.py:141-148, utils.py:103-105
+            solved_brk = meter_env_solved(meter, episode + 1, cfg.early_out_num, false, cfg.solved_reward, 0.0, episode, cfg.init_episodes);
         xctl[5] = solved_brk;
         }
         __syncthreads();

@@ -396,6 +396,7 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
     const float g32 = (float)cfg.gamma;
     const bool budgeted = cfg.step_budget > 0;
     int timed_out_at = -1;
+    const bool no_test_env = cfg.test_mode == 1;      // BaseAgent.train(env, test_env=None): lenv_ddqn_cfg::test_mode
     for (int episode = 0; episode < cfg.train_episodes; ++episode) {
         if (budgeted && (int64_t)train_steps + test_steps > cfg.step_budget) { timed_out_at = episode; break; }   // uniform
         const bool learning = episode >= cfg.init_episodes;
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
         }
         __syncthreads();
         int ep_len = 0;
+        float tr_reward = 0.0f;                                  // base_agent.py:102,121 episode_reward += reward (fp32 tensors; uniform over the threads)
         for (int t = 0; t < cfg.max_steps; ++t) {
             const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
             const int new_pos = train_steps % rb_cap;
@@ -456,6 +458,7 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
                 if (tid == 0) a.out.trace_reward[k] = newrow[2 * S + A];
             }
             const float done_now = newrow[2 * S + A + 1];
+            tr_reward = tr_reward + newrow[2 * S + A];
             __syncthreads();
             if (tid < S) state[tid] = newrow[S + A + tid];
             ++ep_len; ++train_steps;
@@ -567,21 +570,20 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
         ++episodes_run;
         if (tid == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
         __syncthreads();
-        test_phase();
+        if (!no_test_env) test_phase();                    // per-episode test on the real env (base_agent.py:134-136)
         if (tid == 0) {
-            double sm = 0.0;
-            for (int i = 0; i < T; ++i) sm += ret[i];
-            const double tm = sm / (double)T;
+            double tm;
+            if (no_test_env) tm = (double)tr_reward;       // train(env, test_env=None): avg_meter_reward.update(episode_reward) (base_agent.py:138)
+            else {
+                double sm = 0.0;
+                for (int i = 0; i < T; ++i) sm += ret[i];
+                tm = sm / (double)T;
+            }
             meter[episode] = tm;
             if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
-            int brk = 0;
-            if (learning) {
-                int lo = episode + 1 - cfg.early_out_num; if (lo < 0) lo = 0;
-                double s2 = 0.0;
-                for (int i = lo; i <= episode; ++i) s2 += meter[i];
-                if (s2 / ((double)(episode + 1 - lo) + 1e-9) >= cfg.solved_reward) brk = 1;
-            }
-            ictrl[3] = brk;
+            // early out (base_agent.py:49-62,141-148): break_env = the test env (real rule) or, without one, the training env itself
+            ictrl[3] = learning && meter_env_solved(meter, episode + 1, cfg.early_out_num, no_test_env && (true), cfg.solved_reward,
+                                                    cfg.early_out_virtual_diff, episode, cfg.init_episodes);
         }
         __syncthreads();
         const int brk = ictrl[3];

@@ -532,6 +532,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
     // Deterministic time-out (lenv_td3_cfg::step_budget, base_agent.py:30-47): elapsed = env steps taken so far
     const bool budgeted = cfg.step_budget > 0;
     int timed_out_at = -1;
+    const bool no_test_env = FIXED ? false : cfg.test_mode == 1;      // BaseAgent.train(env, test_env=None): lenv_ddqn_cfg::test_mode
     for (int episode = 0; episode < cfg.train_episodes; ++episode) {
         if (budgeted && (int64_t)train_steps + test_steps > cfg.step_budget) { timed_out_at = episode; break; }   // uniform
         const bool learning = episode >= cfg.init_episodes;
@@ -547,6 +548,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         __syncthreads();
         if (!virtual_env && (rtype == 1 || rtype == 2)) rn_eval(state, nullptr, 12);   // phi(s) of the reset state (carried from step to step)
         int ep_len = 0, env_steps = 0;
+        float tr_reward = 0.0f;                                  // base_agent.py:102,121 episode_reward += reward (fp32 tensors; uniform over the threads)
         for (int t = 0; t < cfg.max_steps; t += k_rep) {         // base_agent.py:104 range(0, max_steps, same_action_num)
             const int size_after = train_steps + 1 < rb_cap ? train_steps + 1 : rb_cap;
             const int new_pos = train_steps % rb_cap;
@@ -645,6 +647,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 if (tid == 0) a.out.trace_reward[k] = newrow[2 * S + A];
             }
             const float done_now = newrow[2 * S + A + 1];
+            tr_reward = tr_reward + newrow[2 * S + A];
             __syncthreads();
             if (tid < S) state[tid] = newrow[S + A + tid];
             ep_len += k_rep; ++train_steps;                  // base_agent.py:122: episode_length += same_action_num
@@ -747,22 +750,21 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         if (tid == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
         __syncthreads();
         PT_MARK(10);
-        test_phase();
+        if (!no_test_env) test_phase();                    // per-episode test on the real env (base_agent.py:134-136)
         PT_MARK(9);
         if (tid == 0) {
-            double sm = 0.0;
-            for (int i = 0; i < T; ++i) sm += ret[i];
-            const double tm = sm / (double)T;
+            double tm;
+            if (no_test_env) tm = (double)tr_reward;       // train(env, test_env=None): avg_meter_reward.update(episode_reward) (base_agent.py:138)
+            else {
+                double sm = 0.0;
+                for (int i = 0; i < T; ++i) sm += ret[i];
+                tm = sm / (double)T;
+            }
             meter[episode] = tm;
             if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
-            int brk = 0;
-            if (learning) {
-                int lo = episode + 1 - cfg.early_out_num; if (lo < 0) lo = 0;
-                double s2 = 0.0;
-                for (int i = lo; i <= episode; ++i) s2 += meter[i];
-                if (s2 / ((double)(episode + 1 - lo) + 1e-9) >= cfg.solved_reward) brk = 1;
-            }
-            ictrl[3] = brk;
+            // early out (base_agent.py:49-62,141-148): break_env = the test env (real rule) or, without one, the training env itself
+            ictrl[3] = learning && meter_env_solved(meter, episode + 1, cfg.early_out_num, no_test_env && (virtual_env), cfg.solved_reward,
+                                                    cfg.early_out_virtual_diff, episode, cfg.init_episodes);
         }
         __syncthreads();
         const int brk = ictrl[3];
@@ -1043,7 +1045,7 @@ extern "C" int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg, const lenv_ch
             return cfg->env_id == sp.env && (cfg->virtual_env != 0) == (sp.virtual_env != 0) && (cfg->same_action_num > 1 ? cfg->same_action_num : 1) == sp.k_rep &&
                    cfg->hidden == sp.H && cfg->layers == sp.L && cfg->batch_size == sp.B && cfg->test_episodes == sp.T && cfg->rn_hidden == sp.Hrn &&
                    cfg->rn_layers == sp.rn_layers && cfg->rn_act == sp.rn_act && cfg->reward_env_type == sp.rtype && cfg->act == sp.act &&
-                   cfg->policy_delay == sp.policy_delay && !cfg->use_layer_norm && !(cfg->rn_layer_norm && cfg->rn_layers >= 2);
+                   cfg->policy_delay == sp.policy_delay && !cfg->use_layer_norm && !(cfg->rn_layer_norm && cfg->rn_layers >= 2) && cfg->test_mode == 0;
         };
         // production launches of the cfg-5 shape: the wave-chain kernel (kernel_variant NO_WAVECHAIN keeps the GEMM-queue kernel for A/B runs)
         if (!off && !(cfg->kernel_variant & LENV_VARIANT_NO_WAVECHAIN) && !cfg->icm_enabled && !hp && cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_reward && lenv_wc_td3_shape(cfg)) {

@@ -1649,6 +1649,7 @@ using namespace lenv;
 int lenv_wc_td3_shape(const lenv_td3_cfg *cfg)
 {
     const int k_rep = cfg->same_action_num > 1 ? cfg->same_action_num : 1;
+    if (cfg->test_mode != 0) return 0;      // BaseAgent.train without a test env (the evaluation harness's call): GEMM-queue kernel
     // default_config_cmc.yaml: TD3 on a VirtualEnv (three 3-96-96-x nets), batch 256, delayed policy updates
     if (cfg->hidden == 128 && cfg->layers == 2 && cfg->batch_size == 256 && cfg->virtual_env && cfg->rn_hidden == 96 && cfg->rn_layers == 2 && cfg->policy_delay == 2 &&
         !cfg->icm_enabled && !cfg->use_layer_norm && !cfg->rn_layer_norm && cfg->env_id == LENV_ENV_CMC && cfg->state_dim == 2 && cfg->action_dim == 1 &&

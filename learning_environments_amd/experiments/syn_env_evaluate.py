@@ -1,17 +1,23 @@
-"""Trained-SE checkpoint round trip + "train agents on the SE, test on the real env" evaluation.
+"""Trained-SE checkpoint round trip + the reference's evaluation harness.
 
 Mirrors the two functions every downstream experiment of the reference starts from
-(experiments/syn_env_evaluate_cartpole_vary_hp_2.py:12-48, same names / arguments / return shapes):
+(experiments/syn_env_evaluate_cartpole_vary_hp_2.py:12-48 and its siblings *_DuelingDDQN.py, *_TD3_discrete.py, syn_env_evaluate_acrobot_*;
+same names / arguments / return shapes), called the way experiments/syn_env_run_vary_hp.py:32-117 calls them:
 
     load_envs_and_config(file_name, model_dir, device) -> (virtual_env, real_env, config)
         reads a reference-format checkpoint {'model': state_dict, 'config': dict} (agents/GTN_master.py:133-139)
     train_test_agents(train_env, test_env, config, agents_num) -> (reward_list, train_steps_needed, episodes_needed)
-        trains `agents_num` fresh agents on `train_env` (BaseAgent.train) and tests each on the real env (BaseAgent.test)
+        applies the harness's "settings for comparability" (:29-36) to `config` IN PLACE like the reference, then for each of
+        `agents_num` fresh `DDQN_vary` agents (hyper-parameters resampled per agent, agents/DDQN_vary.py:26-59):
+            reward_train, episode_length, _ = agent.train(env=train_env)      # NO test env: base_agent.py:134-148 with test_env=None
+            reward, _, _ = agent.test(env=test_env)
+        `train_env` is the loaded VirtualEnv (modes 1 / 2 of run_vary_hp), a RewardEnv, or the REAL env (mode 0, the paper's baseline).
 
-Here the `agents_num` agents are independent chains of ONE fused-kernel launch (sign = 0: the unperturbed checkpoint
-weights).  The reference's experiment trains `DDQN_vary` (hyper-parameter resampling, agents/DDQN_vary.py:26-59); that
-variant is not built (§8(f).2) -- this harness trains the configured inner agent (`agent_name`, default the config's GTN
-agent) and raises NotImplementedError for `*_vary`."""
+Here the `agents_num` agents are the chains of ONE fused-kernel launch with lenv_ddqn_cfg::test_mode = 1 (include/lenv_hip.h): the meter is
+fed by the training env's own episode reward, training ends on the virtual rule (early_out_virtual_diff) or, on a real / reward env, on the
+real rule; sign = 0 (the unperturbed checkpoint weights).  Pinned by fixtures G12 = the reference's own function run on a reference-written
+checkpoint (tests/test_train_test_agents.py)."""
+import copy
 import os
 
 import numpy as np
@@ -19,8 +25,13 @@ import torch
 
 from ..agents import tasks
 from ..agents.nes_common import chain_keys, fresh_agent_init
-from ..engine import HipNesEngine
+from ..engine import HipNesEngine, rn_num_params
 from ..envs.env_factory import EnvFactory
+from ..envs.reward_env import RewardEnv
+
+# agent_name -> (config section the harness's settings go to, section that carries vary_hp); the sibling scripts differ in these only
+HARNESS_AGENTS = {"ddqn_vary": ("ddqn", "ddqn_vary"), "duelingddqn_vary": ("duelingddqn", "duelingddqn_vary"),
+                  "td3_discrete_vary": ("td3_discrete_vary", "td3_discrete_vary")}
 
 
 def load_envs_and_config(file_name, model_dir, device):
@@ -35,37 +46,120 @@ def load_envs_and_config(file_name, model_dir, device):
     return virtual_env, real_env, config
 
 
-def train_test_agents(train_env, test_env, config, agents_num, agent_name=None, seed=0):
-    """Returns (reward_list, train_steps_needed, episodes_needed) like the reference: reward_list[i] = the i-th agent's
-    list of real-env test returns (BaseAgent.test), train_steps_needed[i] = [sum(episode_length)],
-    episodes_needed[i] = [number of training episodes run]."""
-    name = (agent_name or config["agents"]["gtn"]["agent_name"]).lower()
-    if name.endswith("_vary"):
-        raise NotImplementedError("agent '%s': hyper-parameter-resampling agents are not built (SURVEY.md §8(f).2)" % name)
+def apply_comparability_settings(config, agent_name="DDQN_vary", train_episodes=1000):
+    """The block every harness script opens with (syn_env_evaluate_cartpole_vary_hp_2.py:29-36; 500 train episodes in
+    syn_env_evaluate_acrobot_vary_hp_2_TD3_discrete.py).  Mutates `config` like the reference."""
+    section, vary_section = HARNESS_AGENTS[agent_name.lower()]
+    config['agents'][vary_section]['vary_hp'] = True
+    config['agents'][section]['print_rate'] = 10
+    config['agents'][section]['early_out_num'] = 10
+    config['agents'][section]['train_episodes'] = train_episodes
+    config['agents'][section]['init_episodes'] = 10
+    config['agents'][section]['test_episodes'] = 10
+    config['agents'][section]['early_out_virtual_diff'] = 0.01
+    return config
+
+
+def _task_config(train_env, config, agent_name):
+    """The configuration the fused launch is built from: the caller's config with the harness's agent as the inner agent and the kind
+    of `train_env` as the synthetic env type -- a VirtualEnv (0), a RewardEnv (1), or the real env itself = a RewardEnv of type 0
+    (envs/reward_env.py:80-81: the real reward passes through; its dummy network is never evaluated)."""
+    cfg = copy.deepcopy(config)
+    cfg["agents"]["gtn"] = dict(cfg["agents"].get("gtn", {}), agent_name=agent_name)
+    if train_env.is_virtual_env():
+        cfg["agents"]["gtn"]["synthetic_env_type"] = 0
+        return cfg, train_env.env.flat_params()
+    cfg["agents"]["gtn"]["synthetic_env_type"] = 1
+    if isinstance(train_env.env, RewardEnv):
+        return cfg, train_env.env.flat_params()
+    e = cfg["envs"][cfg["env_name"]]
+    e["reward_env_type"] = 0
+    S = train_env.get_state_dim()
+    n = rn_num_params(0, S, int(e.get("info_dim", 0)), int(e["hidden_size"]), int(e["hidden_layer"]))
+    return cfg, torch.zeros(n, dtype=torch.float32, device=HipNesEngine().device)
+
+
+def train_test_agents(train_env, test_env, config, agents_num, agent_name="DDQN_vary", train_episodes=1000, vary_hp=True, seed=0, replay=None):
+    """Returns (reward_list, train_steps_needed, episodes_needed) like the reference: reward_list[i] = the i-th agent's list of
+    real-env test returns (BaseAgent.test), train_steps_needed[i] = [sum(episode_length)], episodes_needed[i] = [len(reward_train)].
+
+    agent_name / train_episodes select the sibling script (HARNESS_AGENTS); vary_hp=False keeps the base hyper-parameters (the
+    `_vary` agent with vary_hp off IS its base agent, DDQN_vary.py:16-21).  `seed` keys the agents' counter RNG streams (the reference
+    draws from the process-global generators).  replay = dict(hp=[...], agent_init=[...], tapes={name: [per-agent array]}): the
+    recorded draws of a reference run, replayed in tape mode (parity tests); the returned dict `train_test_agents.last` holds the
+    per-agent training lists (reward_train, episode_length) of the last call."""
+    key = agent_name.lower()
+    if key not in HARNESS_AGENTS:
+        raise NotImplementedError("train_test_agents: agent '%s' (the harness scripts train %s)" % (agent_name, sorted(HARNESS_AGENTS)))
     if test_env.is_virtual_env():
         raise ValueError("test_env must be the real environment")
-    cfg = dict(config)
-    cfg["agents"] = dict(config["agents"])
-    cfg["agents"]["gtn"] = dict(config["agents"]["gtn"], agent_name=name)
+    apply_comparability_settings(config, agent_name, train_episodes)
+    section, vary_section = HARNESS_AGENTS[key]
+    if not vary_hp:
+        config['agents'][vary_section]['vary_hp'] = False
+    cfg, theta = _task_config(train_env, config, agent_name)
     engine = HipNesEngine()
-    task = tasks.select_task(cfg, engine, train_env)
+    task = tasks.select_task(cfg, engine, train_env, test_mode=1)
     dev = engine.device
-    theta = train_env.env.flat_params()
     chains = int(agents_num)
+    if replay is not None:
+        task.cfg.rng_mode = 1
+        if hasattr(task, "fixed_hp"):
+            task.fixed_hp = list(replay["hp"])
     inner = task.make_inner(chains, want_episode_stats=True)
-    g = torch.Generator(device=dev)
-    g.manual_seed(int(seed))
-    agent_init = fresh_agent_init(task.agent_bounds, chains, g, dev) if task.needs_agent_init() else None
     keys = chain_keys(int(seed), 0, np.arange(chains), np.zeros(chains, np.int64))
     keys_t = torch.from_numpy(keys.view(np.int64)).to(dev)
     worker = torch.zeros(chains, dtype=torch.int32, device=dev)
     sign = torch.zeros(chains, dtype=torch.float32, device=dev)
     eps = torch.zeros((1, theta.numel()), dtype=torch.float32, device=dev)
-    task.scores(inner, theta, eps, worker, sign, keys_t, agent_init)
+    agent_init = None
+    if task.needs_agent_init():
+        g = torch.Generator(device=dev)
+        g.manual_seed(int(seed))
+        agent_init = fresh_agent_init(task.agent_bounds, chains, g, dev)
+    if replay is None:
+        task.scores(inner, theta, eps, worker, sign, keys_t, agent_init)
+    else:
+        _replay_launch(task, inner, theta, eps, worker, sign, keys_t, agent_init, replay)
     engine.check_status(inner)
     stats = inner.stats.cpu().numpy()
     finals = inner.final_returns.cpu().numpy()
+    ep_mean, ep_len = inner.episode_test_mean.cpu().numpy(), inner.episode_len.cpu().numpy()
     reward_list = [finals[i].tolist() for i in range(chains)]
-    train_steps_needed = [[int(stats[i, 1])] for i in range(chains)]
+    train_steps_needed = [[int(ep_len[i, :int(stats[i, 0])].sum())] for i in range(chains)]
     episodes_needed = [[int(stats[i, 0])] for i in range(chains)]
+    train_test_agents.last = dict(reward_train=[ep_mean[i, :int(stats[i, 0])].tolist() for i in range(chains)],
+                                  episode_length=[ep_len[i, :int(stats[i, 0])].tolist() for i in range(chains)],
+                                  hp=getattr(task, "last_hp", None), inner=inner, task=task)
     return reward_list, train_steps_needed, episodes_needed
+
+
+train_test_agents.last = None
+
+
+def _pad_rows(rows, dtype, width=None):
+    """[chains, max_len(, width)] device tensor of per-agent tapes of different lengths (a chain never reads past its own run)."""
+    rows = [np.asarray(r, dtype).reshape(-1) if width is None else np.asarray(r, dtype).reshape(-1, width) for r in rows]
+    n = max(1, max(r.shape[0] for r in rows))
+    out = np.zeros((len(rows), n) + (() if width is None else (width,)), dtype)
+    for i, r in enumerate(rows):
+        out[i, :r.shape[0]] = r
+    return torch.from_numpy(out).cuda()
+
+
+def _replay_launch(task, inner, theta, eps, worker, sign, keys_t, agent_init, replay):
+    """One tape-mode launch with the recorded hyper-parameters, fresh agents and RNG draws of a reference run."""
+    t = replay["tapes"]
+    tapes = dict(eps_uniform=_pad_rows(t["eps_uniform"], np.float64), rand_action=_pad_rows(t["rand_action"], np.int32),
+                 replay_idx=_pad_rows(t["replay_idx"], np.int32), train_reset=_pad_rows(t["train_reset"], np.float64, 4),
+                 test_reset=_pad_rows(t["test_reset"], np.float64, 4))
+    if getattr(inner, "vary", False):
+        hp = task.last_hp = task.draw_hp(None)
+        inner.set_hp([h["lr"] for h in hp], [h["batch_size"] for h in hp], [h["hidden_size"] for h in hp], [h["hidden_layer"] for h in hp])
+        init = torch.zeros_like(inner.agent_init)
+    else:
+        init = torch.zeros_like(agent_init)
+    for i, a in enumerate(replay["agent_init"]):
+        a = torch.from_numpy(np.ascontiguousarray(a, np.float32))
+        init[i, :a.numel()] = a.to(init.device)
+    inner.run(theta, eps, worker, sign, init, tapes=tapes)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "liblenv_hip.so does not export " + name
     assert set(_lib.EXPORTS) <= declared
-    assert L.lenv_abi_version() == 6
+    assert L.lenv_abi_version() == 7
     assert L.lenv_error_string(-2) == b"unsupported shape or option"
 
 

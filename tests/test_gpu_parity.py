@@ -40,7 +40,7 @@ def dev(a, dtype=None):
 
 def test_native_library_loaded(eng):
     from learning_environments_amd import _lib
-    assert _lib.lib().lenv_abi_version() == 6
+    assert _lib.lib().lenv_abi_version() == 7
     with open("/proc/self/maps") as f:
         assert "liblenv_hip.so" in f.read()
 
