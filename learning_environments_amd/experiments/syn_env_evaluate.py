@@ -25,7 +25,7 @@ import torch
 
 from ..agents import tasks
 from ..agents.nes_common import chain_keys, fresh_agent_init
-from ..engine import HipNesEngine, rn_num_params
+from ..engine import HipNesEngine, mlp_desc, mlp_num_params
 from ..envs.env_factory import EnvFactory
 from ..envs.reward_env import RewardEnv
 
@@ -74,8 +74,8 @@ def _task_config(train_env, config, agent_name):
         return cfg, train_env.env.flat_params()
     e = cfg["envs"][cfg["env_name"]]
     e["reward_env_type"] = 0
-    S = train_env.get_state_dim()
-    n = rn_num_params(0, S, int(e.get("info_dim", 0)), int(e["hidden_size"]), int(e["hidden_layer"]))
+    # RewardEnv.build_reward_net for type 0 (envs/reward_env.py:44-53): a 1-input dummy MLP -- the launch stages it and never evaluates it
+    n = mlp_num_params(mlp_desc(1, int(e["hidden_size"]), int(e["hidden_layer"]), 1, e["activation_fn"]))
     return cfg, torch.zeros(n, dtype=torch.float32, device=HipNesEngine().device)
 
 

@@ -903,15 +903,12 @@ def test_grid_reward_env_info_types_raise_like_reference():
         renv.step(torch.tensor([0]))
 
 
-def test_reference_checkpoint_round_trip_and_evaluation(golden, tmp_path):
+def test_reference_checkpoint_round_trip(golden, tmp_path):
     """a checkpoint WRITTEN BY THE REFERENCE ({'model','config'}, GTN_master.py:133-139) loads through
-    load_envs_and_config; EnvWrapper.step on it reproduces the reference's outputs; train_test_agents trains fresh agents on
-    it in one fused launch and is bit-identical to the oracle's chains; re-saving through our state_dict gives the same file
-    payload."""
+    load_envs_and_config; EnvWrapper.step on it reproduces the reference's outputs; re-saving through our state_dict gives the same file
+    payload.  (train_test_agents on such a checkpoint: tests/test_train_test_agents.py, against the reference's own function.)"""
     import shutil
-    from learning_environments_amd.agents.nes_common import chain_keys, fresh_agent_init
-    from learning_environments_amd.experiments.syn_env_evaluate import load_envs_and_config, train_test_agents
-    from oracle import oracle as orc
+    from learning_environments_amd.experiments.syn_env_evaluate import load_envs_and_config
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     shutil.copy(os.path.join(here, "ckpt_cartpole_se_reference.pt"), tmp_path / "model.pt")
     venv, real_env, config = load_envs_and_config("model.pt", str(tmp_path), "cuda")
@@ -922,30 +919,12 @@ def test_reference_checkpoint_round_trip_and_evaluation(golden, tmp_path):
         ns, r, d = venv.step(action=torch.tensor([float(g["actions"][k])]), state=torch.from_numpy(g["states"][k].copy()))
         np.testing.assert_allclose(ns.numpy().reshape(-1), g["next_states"][k], rtol=0, atol=2e-6)
         assert abs(float(r) - float(g["rewards"][k])) <= 2e-6 and float(d) == float(g["dones"][k])
-    # evaluation: 5 fresh DDQN agents trained on the SE, tested on the real env
-    rewards, steps, episodes = train_test_agents(venv, real_env, config, agents_num=5, seed=3)
-    assert len(rewards) == 5 and all(len(r) == config["agents"]["ddqn"]["test_episodes"] for r in rewards)
-    from learning_environments_amd.agents import tasks
-    from learning_environments_amd.engine import HipNesEngine
-    eng = HipNesEngine()
-    task = tasks.select_task(config, eng, venv)
-    gen = torch.Generator(device=eng.device)
-    gen.manual_seed(3)
-    init = fresh_agent_init(task.agent_bounds, 5, gen, eng.device).cpu().numpy()
-    keys = chain_keys(3, 0, np.arange(5), np.zeros(5, np.int64))
-    ocfg = orc.ddqn_cfg_from_config(config, grad_chunk=task.cfg.grad_chunk, rng_mode=0)
-    for c in range(5):
-        o = orc.ddqn_se_chain(ocfg, g["theta"], init[c], rng_key=int(keys[c]))
-        assert rewards[c] == o["final_test_returns"].tolist()
-        assert steps[c] == [o["train_steps"]] and episodes[c] == [o["episodes_run"]]
     # our state_dict() re-saves to the same payload (same keys, shapes, dtypes and values)
     ref = torch.load(os.path.join(here, "ckpt_cartpole_se_reference.pt"), map_location="cpu")
     ours = {k: v.detach().cpu() for k, v in venv.state_dict().items()}
     assert list(ours.keys()) == list(ref["model"].keys())
     for k in ours:
         assert ours[k].dtype == ref["model"][k].dtype and torch.equal(ours[k], ref["model"][k]), k
-    with pytest.raises(NotImplementedError):
-        train_test_agents(venv, real_env, config, agents_num=1, agent_name="DDQN_vary")
 
 
 def test_experiment_wrapper_compute(tmp_path, monkeypatch):

@@ -199,3 +199,130 @@ def test_product_train_test_agents_refuses_what_the_harness_does_not_train(tmp_p
         train_test_agents(venv, real_env, config, agents_num=1, agent_name="PPO")
     with pytest.raises(ValueError):
         train_test_agents(venv, venv, config, agents_num=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agent_name", ["DuelingDDQN_vary", "td3_discrete_vary"])
+def test_product_train_test_agents_sibling_scripts_vs_oracle(tmp_path, agent_name):
+    """experiments/syn_env_evaluate_cartpole_vary_hp_2_DuelingDDQN.py / _TD3_discrete.py: the same function around another `_vary` agent
+    (their settings go to that agent's section).  Four agents with drawn hyper-parameters in one launch, each bit-identical to the oracle
+    chain with test_mode 1.  (The sections are shrunk first -- the config is the caller's input -- so the CPU oracle finishes in seconds.)"""
+    from learning_environments_amd.agents.nes_common import chain_keys
+    from learning_environments_amd.experiments.syn_env_evaluate import HARNESS_AGENTS, train_test_agents
+    venv, real_env, config = _load_ckpt_b(tmp_path)
+    section = HARNESS_AGENTS[agent_name.lower()][0]
+    config["agents"][section].update(hidden_size=20, batch_size=12)
+    if section == "duelingddqn":
+        config["agents"][section]["feature_dim"] = 16
+    rewards, steps, episodes = train_test_agents(venv, real_env, config, agents_num=4, agent_name=agent_name, train_episodes=60, seed=5)
+    a = config["agents"][section]
+    assert (a["train_episodes"], a["init_episodes"], a["early_out_num"], a["test_episodes"], a["early_out_virtual_diff"]) == (60, 10, 10, 10, 0.01)
+    last = train_test_agents.last
+    inner, hps = last["inner"], last["hp"]
+    assert inner.cfg.test_mode == 1 and len(hps) == 4
+    keys = chain_keys(5, 0, np.arange(4), np.zeros(4, np.int64))
+    theta = venv.env.flat_params().cpu().numpy()
+    inits = inner.agent_init.cpu().numpy()
+    cfgd = json.loads(json.dumps(config))
+    for c in range(4):
+        if section == "duelingddqn":
+            cfgd["agents"]["gtn"]["agent_name"] = "DuelingDDQN"
+            ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=0, test_mode=1, **orc.hp_overrides(hps[c]))
+            o = orc.ddqn_se_chain(ocfg, theta, inits[c][:orc.dueling_num_params(ocfg)], rng_key=int(keys[c]))
+        else:
+            ocfg = orc.td3d_cfg_from_config(cfgd, rng_mode=0, hp=hps[c], test_mode=1)
+            o = orc.td3d_chain(ocfg, theta, inits[c][:orc.td3d_num_params(ocfg)[0]], rng_key=int(keys[c]))
+        assert o["rc"] == 0
+        assert rewards[c] == o["final_test_returns"].tolist()
+        assert steps[c] == [o["train_steps"]] and episodes[c] == [o["episodes_run"]]
+        assert last["reward_train"][c] == o["episode_test_mean"][:o["episodes_run"]].tolist()
+        assert inner.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        assert o["test_steps"] == int(sum(rewards[c]))          # no per-episode tests: only the final test touched the real env
+
+
+def _mirror(ocfg, cls):
+    c = cls()
+    for f, _ in cls._fields_:
+        setattr(c, f, getattr(ocfg, f, 0))      # (team_size / kernel_variant exist only in the HIP cfg)
+    return c
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("virtual", [True, False])
+def test_td3_kernel_test_mode_1_vs_oracle(golden, virtual):
+    """BaseAgent.train without a test env in the TD3 loop (lenv_td3_cfg::test_mode 1): on a VirtualEnv the virtual rule ends training, on a
+    RewardEnv the real rule on the shaped training rewards; no per-episode tests either way.  Bit-exact against the oracle; the chains
+    stop at different episodes."""
+    import torch
+    from learning_environments_amd import _lib, engine
+    engine.require_device()
+    g = golden("g8ts_calc_score_cheetah_td3_virtual_env" if virtual else "g8t_calc_score_cheetah_td3")
+    cfgd = json.loads(str(g["config_json"]))
+    cfgd["agents"]["td3"].update(train_episodes=40, init_episodes=2, early_out_num=3, test_episodes=2, batch_size=16, hidden_size=24,
+                                 early_out_virtual_diff=0.25)
+    cfgd["envs"]["HalfCheetah-v3"].update(max_steps=6, solved_reward=1.0)
+    ocfg = orc.td3_cfg_from_config(cfgd, rng_mode=0, test_mode=1)
+    assert ocfg.virtual_env == int(virtual) and ocfg.early_out_virtual_diff == 0.25
+    cfg = _mirror(ocfg, _lib.Td3Cfg)
+    chains = 6
+    il = engine.Td3InnerLoop(cfg, chains, want_episode_stats=True)
+    rng = np.random.RandomState(5)
+    theta = g["theta"]
+    eps = (rng.randn(chains, theta.size) * 0.05).astype(np.float32)
+    worker, sign = np.arange(chains).astype(np.int32), np.ones(chains, np.float32)
+    agent_init = rng.uniform(-0.2, 0.2, (chains, il.p_agent)).astype(np.float32)
+    keys = np.array([orc.chain_key(77, 0, c, 1) for c in range(chains)], np.uint64)
+    il.run(_dev(theta), _dev(eps), _dev(worker), _dev(sign), _dev(agent_init), rng_keys=_dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    stops = []
+    for c in range(chains):
+        o = orc.td3_rn_chain(ocfg, (eps[c] + theta).astype(np.float32), agent_init[c], rng_key=int(keys[c]))
+        assert o["rc"] == 0
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
+        assert np.array_equal(il.episode_len[c].cpu().numpy(), o["episode_len"]), c
+        assert np.array_equal(il.final_returns[c].cpu().numpy(), o["final_test_returns"]) and float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        stops.append(o["episodes_run"])
+    assert len(set(stops)) > 1 and min(stops) < 40, stops
+
+
+@pytest.mark.gpu
+def test_ql_kernel_test_mode_1_vs_oracle(golden):
+    """QL on the Cliff RewardEnv trained without a test env (lenv_ql_cfg::test_mode 1): the shaped training rewards feed the meter, the real
+    rule ends training, only the final test walks the real grid."""
+    import torch
+    from learning_environments_amd import _lib, engine
+    from learning_environments_amd.envs.gridworld import transition_tables
+    engine.require_device()
+    g = golden("g9_calc_score_cliff_a")
+    cfgd = json.loads(str(g["config_json"]))
+    cfgd["agents"]["ql"].update(eps_init=0.3, eps_min=0.05, eps_decay=0.9, alpha=0.7, train_episodes=60, early_out_num=3)
+    cfgd["envs"]["Cliff"]["solved_reward"] = -40.0
+    tables = transition_tables("Cliff")
+    ocfg = orc.ql_cfg_from_config(cfgd, tables, rng_mode=0, test_mode=1)
+    cfg = _mirror(ocfg, _lib.QlCfg)
+    chains = 8
+    rng = np.random.RandomState(3)
+    theta = g["theta"]
+    eps = (rng.randn(chains, theta.size) * 0.2).astype(np.float32)
+    worker, sign = np.arange(chains).astype(np.int32), np.ones(chains, np.float32)
+    keys = np.array([orc.chain_key(9, 2, c, 1) for c in range(chains)], np.uint64)
+    il = engine.QlInnerLoop(cfg, chains, tables)
+    il.run(_dev(theta), _dev(eps), _dev(worker), _dev(sign), rng_keys=_dev(keys.view(np.int64)))
+    torch.cuda.synchronize()
+    assert il.status.cpu().tolist() == [0] * chains
+    stops = []
+    for c in range(chains):
+        o = orc.ql_rn_chain(ocfg, (eps[c] + theta).astype(np.float32), tables, rng_key=int(keys[c]))
+        assert np.array_equal(il.episode_test_mean[c].cpu().numpy(), o["episode_test_mean"], equal_nan=True), c
+        assert np.array_equal(il.q_table[c].cpu().numpy().reshape(o["q_table"].shape), o["q_table"]), c
+        assert float(il.score[c]) == o["score"]
+        assert il.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+        stops.append(o["episodes_run"])
+    assert len(set(stops)) > 1, stops
