@@ -595,13 +595,6 @@ int lenv_nes_rank_update_keep(int32_t score_transform_type, const double *gather
                               float *theta, const float *eps, int64_t p_theta, double step_size, int32_t nes_step_size,
                               double weight_decay, double *weights_out, float *theta_prev, int64_t *generation_dev, void *stream);
 
-/*
- * Diagnostic: hold `blocks` compute units for `ticks` of the constant 100 MHz clock (s_memrealtime) on `stream` -- every block
- * asks for `lds_bytes` of LDS (>= 82 KiB: one block per CU) and spins.  The stand-in for "a foreign kernel occupies part of the
- * device" in the test of the team launches' give-up path (status -10, lenv_ddqn_cfg::team_size); no product path calls it.
- */
-int lenv_diag_occupy_cus(int32_t blocks, int32_t lds_bytes, int64_t ticks, void *stream);
-
 #ifdef __cplusplus
 }
 #endif

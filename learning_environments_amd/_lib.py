@@ -146,7 +146,7 @@ EXPORTS = ["lenv_abi_version", "lenv_error_string", "lenv_mlp_num_params", "lenv
            "lenv_dueling_num_params", "lenv_dueling_se_inner_loop", "lenv_dueling_se_inner_loop_hp", "lenv_dueling_agent_init_hp", "lenv_rng_unit", "lenv_td3_rn_inner_loop_hp", "lenv_td3_agent_init_hp", "lenv_icm_num_params", "lenv_dueling_se_inner_loop_icm", "lenv_chain_uniform_init", "lenv_td3_icm_num_params", "lenv_td3_rn_inner_loop_icm", "lenv_td3_rn_workspace_bytes", "lenv_td3_num_params",
            "lenv_td3_rn_inner_loop", "lenv_mlp_forward", "lenv_cheetah_standin_reset", "lenv_cheetah_standin_step", "lenv_cont_env_reset", "lenv_cont_env_step",
            "lenv_rn_num_params", "lenv_rn_shape_rows", "lenv_nes_worker_best_multi", "lenv_nes_draw", "lenv_nes_status_fold", "lenv_nes_draw_dev", "lenv_nes_rank_update_keep",
-           "lenv_td3d_workspace_bytes", "lenv_td3d_num_params", "lenv_td3d_se_num_params", "lenv_td3d_inner_loop", "lenv_td3d_agent_init", "lenv_td3_rn_team_size", "lenv_dueling_team_size", "lenv_struct_size", "lenv_diag_occupy_cus"]
+           "lenv_td3d_workspace_bytes", "lenv_td3d_num_params", "lenv_td3d_se_num_params", "lenv_td3d_inner_loop", "lenv_td3d_agent_init", "lenv_td3_rn_team_size", "lenv_dueling_team_size", "lenv_struct_size"]
 
 
 def build(force=False):
@@ -283,8 +283,6 @@ def lib():
         L.lenv_td3d_agent_init.argtypes = [C.POINTER(Td3dCfg), C.POINTER(ChainHp), vp, C.c_int64, vp, vp]
         if L.lenv_abi_version() != 7:
             raise LenvError("liblenv_hip.so ABI version mismatch")
-        L.lenv_diag_occupy_cus.restype = C.c_int
-        L.lenv_diag_occupy_cus.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp]
         L.lenv_struct_size.restype = C.c_int64
         L.lenv_struct_size.argtypes = [C.c_int32]
         for which, cls in enumerate(ABI_STRUCTS):     # the ctypes mirrors must have the library's layout

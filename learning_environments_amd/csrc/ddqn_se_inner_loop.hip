@@ -1692,11 +1692,16 @@ static InnerKern ddqn_team_wide_kernel(const lenv_ddqn_cfg *cfg, const InnerLayo
 // XCDs round-robin, so a team is 8 blocks apart) and the minibatch has at least G micro-chunks to deal.  cfg->team_size: 0 = automatic
 // (launches of fewer than 16 chains keep one workgroup per chain), 1 = never, G = at most G (also below 16 chains); tape-mode launches
 // and launches with a step trace are never teamed.
+// Launches of more chains than this never run on teams (one workgroup per chain already fills half the device): ONE predicate for the team
+// picker and for the size of the exchange area in the workspace (the two had drifted apart)
+constexpr int64_t DDQN_TEAM_MAX_CHAINS = 128;
+
 static int ddqn_pick_team(const lenv_ddqn_cfg *cfg, int64_t chains, bool production)
 {
     const int want = cfg->team_size > 0 ? cfg->team_size : 0;      // 0 = automatic
     if (!production || want == 1 || chains < 1) return 1;
     if (want == 0 && chains < 16) return 1;
+    if (chains > DDQN_TEAM_MAX_CHAINS) return 1;                  // (no exchange area is carved for such launches: lenv_ddqn_se_workspace_bytes)
     InnerArgs t;
     if (inner_check(cfg) != LENV_OK || inner_layout(cfg, t) != LENV_OK) return 1;
     const size_t lds_bytes = (size_t)t.L.lds_floats * sizeof(float);
@@ -1724,7 +1729,7 @@ extern "C" size_t lenv_ddqn_se_workspace_bytes(const lenv_ddqn_cfg *cfg, int64_t
     // the team exchange area: present whenever a launch of this many chains COULD be teamed (counter mode, at most half the device's
     // CUs' worth of chains), whatever cfg->team_size says today -- an inner loop sizes its workspace once and team_size may be changed
     // on it later (A/B tooling, the -10 fall-back and back) -- and without asking the occupancy API on every query
-    size_t team = (cfg->rng_mode == LENV_RNG_COUNTER && chains >= 1 && chains <= 128) ? (size_t)chains * (size_t)inner_team_stride(cfg) * sizeof(float) : 0;
+    size_t team = (cfg->rng_mode == LENV_RNG_COUNTER && chains >= 1 && chains <= DDQN_TEAM_MAX_CHAINS) ? (size_t)chains * (size_t)inner_team_stride(cfg) * sizeof(float) : 0;
     return ((replay + 255) & ~(size_t)255) + ((meter + 255) & ~(size_t)255) + sched + team + 256;
 }
 
@@ -1767,6 +1772,7 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
     a.team_stride = inner_team_stride(cfg);
     a.chains = chains;
     a.team_G = ddqn_pick_team(cfg, chains, cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action);
+    if (a.team_G > 1 && workspace_bytes < replay_bytes + meter_bytes + sched_bytes + (size_t)chains * (size_t)a.team_stride * sizeof(float)) return LENV_ERR_WORKSPACE;
 
     void (*kern)(const InnerArgs) = nullptr;
 #define LENV_PICK2(ENVID, SS, AA, PP)                                                                              \

@@ -51,22 +51,3 @@ extern "C" uint64_t lenv_chain_key(uint64_t seed, uint64_t generation, uint64_t 
     k = lenv::mix64(k ^ (kind + 0x9e3779b97f4a7c15ULL * 4));     // own round: (worker, kind) never collides with (worker + 1, kind - 4)
     return k;
 }
-
-namespace lenv {
-__global__ __launch_bounds__(64) void occupy_cus_kernel(long long ticks)
-{
-    extern __shared__ float occupy_lds[];
-    if (threadIdx.x == 0) occupy_lds[0] = 0.0f;           // (the allocation is what matters)
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(64);
-}
-}
-
-extern "C" int lenv_diag_occupy_cus(int32_t blocks, int32_t lds_bytes, int64_t ticks, void *stream)
-{
-    if (blocks < 1 || lds_bytes < 0 || lds_bytes > 160 * 1024 || ticks < 0) return LENV_ERR_INVALID;
-    void (*kern)(long long) = lenv::occupy_cus_kernel;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return LENV_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), (size_t)lds_bytes, static_cast<hipStream_t>(stream), (long long)ticks);
-    return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
-}

@@ -409,10 +409,10 @@ def test_worker_relaunches_a_team_launch_that_could_not_assemble(tmp_path, monke
     """several worker processes share one GPU, and a worker's three-chain TD3 launch picks teams of six.  Next to a foreign
     kernel that holds most CUs the teams cannot assemble, the launch reports status -10, and GTN_Worker._run_chains repeats it with one
     workgroup per chain instead of raising: the evaluation's scores equal those of an undisturbed worker with the same seed."""
-    import ctypes as C
     import time
-    from learning_environments_amd import _lib, configs
+    from learning_environments_amd import configs
     from learning_environments_amd.agents.GTN import GTN_Worker
+    from tools import diag
     monkeypatch.chdir(tmp_path)
     cfg = configs.fixed_work(configs.halfcheetah_reward_env_td3(num_workers=1, max_iterations=1), 2)
     cfg["agents"]["td3"]["init_episodes"] = 1
@@ -427,7 +427,7 @@ def test_worker_relaunches_a_team_launch_that_could_not_assemble(tmp_path, monke
         torch.cuda.synchronize()
         if disturb:
             with torch.cuda.stream(side):          # 248 of 256 CUs for 1.5 s: a few team members start, most cannot
-                _lib.check(_lib.lib().lenv_diag_occupy_cus(248, 150 * 1024, 150_000_000, C.c_void_p(side.cuda_stream)), "lenv_diag_occupy_cus")
+                diag.occupy_cus(248, 150 * 1024, 150_000_000, side.cuda_stream)      # tools/diag: test aid, not in the product ABI
             time.sleep(0.05)
         out = w.evaluate()
         side.synchronize()

@@ -2333,6 +2333,7 @@ def test_team_launch_next_to_a_foreign_kernel_gives_up_cleanly(eng, orc, foreign
     import time
     from learning_environments_amd import _lib, configs
     from learning_environments_amd.agents.nes_common import chain_keys
+    from tools import diag
     cfgd = configs.fixed_work(configs.halfcheetah_reward_env_td3(8), 3)
     cfgd["agents"]["td3"]["init_episodes"] = 1
     cfgd["envs"]["HalfCheetah-v3"]["max_steps"] = 20
@@ -2367,7 +2368,7 @@ def test_team_launch_next_to_a_foreign_kernel_gives_up_cleanly(eng, orc, foreign
         cand = torch.cuda.Stream()
         torch.cuda.synchronize()
         with torch.cuda.stream(cand):
-            _lib.check(_lib.lib().lenv_diag_occupy_cus(8, 150 * 1024, 20_000_000, C.c_void_p(cand.cuda_stream)), "lenv_diag_occupy_cus")
+            diag.occupy_cus(8, 150 * 1024, 20_000_000, cand.cuda_stream)
         time.sleep(0.02)
         probe.add_(1.0)
         torch.cuda.current_stream().synchronize()
@@ -2379,7 +2380,7 @@ def test_team_launch_next_to_a_foreign_kernel_gives_up_cleanly(eng, orc, foreign
     assert side is not None, "no stream runs concurrently with the current one"
     torch.cuda.synchronize()
     with torch.cuda.stream(side):                          # the foreign kernel: `foreign_cus` CUs for 3 s
-        _lib.check(_lib.lib().lenv_diag_occupy_cus(foreign_cus, 150 * 1024, 3 * 100_000_000, C.c_void_p(side.cuda_stream)), "lenv_diag_occupy_cus")
+        diag.occupy_cus(foreign_cus, 150 * 1024, 3 * 100_000_000, side.cuda_stream)
     time.sleep(0.05)                                       # let it take its CUs first
     t0 = time.time()
     il.run(*args, **kw)

@@ -7,6 +7,7 @@ import numpy as np, torch
 from learning_environments_amd import _lib, configs, engine as eng
 from learning_environments_amd.config import td3_cfg_from_config
 from learning_environments_amd.agents.nes_common import chain_keys
+from tools import diag
 if os.environ.get("LENV_TIMING_LIB"):
     _lib.LIB_PATH = os.path.abspath(os.environ["LENV_TIMING_LIB"])
 L = _lib.lib()
@@ -14,7 +15,7 @@ dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 side = torch.cuda.Stream()
 # 1. plain concurrency: a torch op on the default stream while the foreign kernel runs
 with torch.cuda.stream(side):
-    _lib.check(L.lenv_diag_occupy_cus(128, 150 * 1024, 100_000_000, C.c_void_p(side.cuda_stream)), "occupy")
+    diag.occupy_cus(128, 150 * 1024, 100_000_000, side.cuda_stream)
 t0 = time.time(); x = torch.ones(1 << 20, device="cuda"); y = (x * 2).sum().item(); print("torch op next to the foreign kernel: %.3f s (foreign done: %s)" % (time.time() - t0, side.query()))
 side.synchronize(); print("foreign kernel ended after %.3f s" % (time.time() - t0))
 cfgd = configs.fixed_work(configs.halfcheetah_reward_env_td3(8), 3)
@@ -40,7 +41,7 @@ for occupy in (232,):
     print("team size", L.lenv_td3_rn_team_size(C.byref(cfg), chains))
     if occupy:
         with torch.cuda.stream(side):
-            _lib.check(L.lenv_diag_occupy_cus(occupy, 150 * 1024, 500_000_000, C.c_void_p(side.cuda_stream)), "occupy")
+            diag.occupy_cus(occupy, 150 * 1024, 500_000_000, side.cuda_stream)
         time.sleep(0.05)
     t0 = time.time()
     il.run(*args, **kw)
