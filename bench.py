@@ -380,7 +380,11 @@ def secondary_configs(only=None, team_size=0):
                "train_steps": int(st[:, 1].sum()), "learn_steps": int(st[:, 2].sum()), "test_steps": int(st[:, 3].sum()),
                "us_per_learn_step_per_chain": kernel_ms * 1e3 / learn if learn else None,
                "algorithmic_GBps": nbytes / (kernel_ms * 1e-3) / 1e9, "hbm_frac": nbytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-               "graph": bool(getattr(m, "use_graph", False)), "team_fallbacks": int(getattr(m, "team_fallbacks", 0))}
+               "graph": bool(getattr(m, "use_graph", False)), "team_fallbacks": int(getattr(m, "team_fallbacks", 0)),
+               # which launch path was timed: inside a process group -- also a one-rank one -- a generation is two graphs around
+               # an eager all-gather, in a bare process one graph and no collective; records of the two launch styles are not comparable
+               "graphs_per_generation": (0 if not getattr(m, "use_graph", False) else (2 if getattr(m, "_graph2", None) is not None else 1)),
+               "collective_ran": bool(getattr(m, "collectives_run", 0) > 0)}
         if flops:
             busy = min(int(st.shape[0]), 256)
             if kernel in ("td3_wavechain_kernel", "dueling_wavechain_kernel"):    # a chain is run by a team of workgroups when the whole launch stays resident
@@ -415,7 +419,9 @@ def secondary_configs(only=None, team_size=0):
                     "projected_8gpu_value": POP * 10 / dt8,
                     "projected_8gpu_note": "PROJECTION, not a measurement: 64 workers / this shard's generation time, as if eight GPUs each ran "
                                            "this shard and exchanged one 8 x 32 B all-gather; the driver's SCALE run is the measurement",
-                    "team_fallbacks": int(getattr(m8, "team_fallbacks", 0)), "graph": bool(getattr(m8, "use_graph", False))})
+                    "team_fallbacks": int(getattr(m8, "team_fallbacks", 0)), "graph": bool(getattr(m8, "use_graph", False)),
+                    "graphs_per_generation": (0 if not getattr(m8, "use_graph", False) else (2 if getattr(m8, "_graph2", None) is not None else 1)),
+                    "collective_ran": bool(getattr(m8, "collectives_run", 0) > 0)})
         del m8
         torch.cuda.empty_cache()
         # ... and the shards of the 2- and 4-GPU forms (32 / 16 workers = 96 / 48 chains, teams of 2 / 4), so that the record carries the whole

@@ -18,7 +18,7 @@ from .. import _lib
 from ..envs.env_factory import EnvFactory
 from ..models.model_utils import linear_params
 from .GTN_base import GTN_Base
-from .nes_common import chain_keys, fresh_agent_init
+from .nes_common import chain_keys, fresh_agent_init, host_worker_best
 from .tasks import select_task
 
 
@@ -35,6 +35,10 @@ class GTN_Worker(GTN_Base):
         self.engine = engine
         self.generation = 0
         self.team_fallbacks = 0                # launches repeated with one workgroup per chain (status -10, _run_chains)
+        self._no_teams = False
+        self.task = None
+        self._task_config = None
+        self._inner = {}
         for file in self.worker_files(self.id):
             if os.path.isfile(file):
                 os.remove(file)
@@ -67,11 +71,16 @@ class GTN_Worker(GTN_Base):
         tag = "GTN_Worker%s: " % self.id
         self.synthetic_env_orig = make_env(print_str="GTN_Base: ")
         self.synthetic_env, self.eps = make_env(print_str=tag), make_env(print_str=tag)
-        # inner agent x synthetic-env type -> fused kernel (agents/agent_utils.py:15-66 select_agent + EnvFactory)
-        self.task = select_task(config, self.engine, self.synthetic_env_orig)
+        # inner agent x synthetic-env type -> fused kernel (agents/agent_utils.py:15-66 select_agent + EnvFactory).  read_worker_input calls
+        # late_init every generation (reference :117): the task and its inner loops (workspaces, the team fall-back of _run_chains) are
+        # rebuilt only when the master sent a different config
+        if self.task is None or config != self._task_config:
+            import copy
+            self.task = select_task(config, self.engine, self.synthetic_env_orig)
+            self._task_config = copy.deepcopy(config)
+            self._inner = {}
         self.cfg = self.task.cfg
         self._bounds = self.task.agent_bounds
-        self._inner = {}
 
     # ---- noise handling (reference :156-185) over THE flat NES layout: linear_params() lists the nn.Linear weights and biases of an env
     # in the order theta / eps are flattened in, so the three envs' lists line up element for element ----
@@ -101,6 +110,8 @@ class GTN_Worker(GTN_Base):
         dev = self.engine.device
         if n not in self._inner:
             self._inner[n] = self.task.make_inner(n, want_episode_stats=False)
+            if self._no_teams and hasattr(self._inner[n].cfg, "team_size"):
+                self._inner[n].cfg.team_size = 1           # a team launch of this worker already gave up once: see below
         inner = self._inner[n]
         # express chain c as theta0 + 1*(theta_c - theta0)?  No: exactness matters -> run with eps rows = theta_c, theta = 0
         zero = torch.zeros_like(thetas[0])
@@ -116,10 +127,12 @@ class GTN_Worker(GTN_Base):
         scores = self.task.scores(inner, zero, eps, worker, sign, keys_t, agent_init)
         # Several worker processes usually share one GPU: a launch whose teams of workgroups could not assemble next to another
         # worker's kernel reports status -10 (include/lenv_hip.h, lenv_ddqn_cfg::team_size).  The chains are deterministic functions
-        # of these inputs, so the launch is repeated once with one workgroup per chain; the inner loop keeps that setting.
+        # of these inputs, so the launch is repeated once with one workgroup per chain; this worker's inner loops keep that setting
+        # (self._no_teams: also the ones it builds later).
         status = getattr(inner, "status", None)
         if status is not None and status.numel() and int(status.min()) == _lib.STATUS_TEAM_GAVE_UP and getattr(inner.cfg, "team_size", 1) != 1:
             inner.cfg.team_size = 1
+            self._no_teams = True
             self.team_fallbacks += 1
             scores = self.task.scores(inner, zero, eps, worker, sign, keys_t, agent_init)
         out = scores.cpu().tolist()
@@ -135,16 +148,11 @@ class GTN_Worker(GTN_Base):
         return self._run_chains([self._flat(env)])[0]
 
     def calc_best_score(self, score_sub, score_add):
-        """reference :234-254 -- the mirrored pick.  The arithmetic (statistics.mean's exactly rounded mean or the minimum of each
-        side, then the comparison) is the engine's worker-best routine, the one the in-process master runs for the whole
-        population (lenv_nes_worker_best_multi); here it gets this one worker's row.  Afterwards, as in the reference, eps points
-        in the direction that scored better and synthetic_env holds theta + eps."""
-        sub, add = [float(v) for v in score_sub], [float(v) for v in score_add]
-        if len(sub) != len(add) or not add:
-            raise ValueError("calc_best_score: need as many -eps as +eps scores, at least one of each")
-        row = torch.tensor([[0.0] + add + sub], dtype=torch.float64, device=self.engine.device)
-        picked = self.engine.worker_best(row, 1, bool(self.mirrored_sampling), len(add), self.grad_eval_type).cpu()
-        score_best, sign = float(picked[0, 0]), float(picked[0, 2])
+        """reference :234-254 -- the mirrored pick, on the host (two scalars: statistics.mean's exactly rounded mean or the minimum of
+        each side, then the comparison; nes_common.host_worker_best, the one-worker form of the engine's lenv_nes_worker_best_multi).
+        Afterwards, as in the reference, eps points in the direction that scored better and synthetic_env holds theta + eps."""
+        score_best, sign = host_worker_best([float(v) for v in score_add], [float(v) for v in score_sub], bool(self.mirrored_sampling),
+                                            self.grad_eval_type)
         if sign < 0:
             self.invert_eps()                   # -eps won: eps := -eps; synthetic_env already holds theta - (old eps)
         else:

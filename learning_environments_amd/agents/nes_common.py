@@ -84,3 +84,19 @@ def fresh_agent_init(bounds, chains, generator, device):
     """`chains` freshly initialised agents (reference: select_agent -> DDQN() per calc_score, agents/agent_utils.py:15-66)."""
     u = torch.rand((chains, bounds.numel()), generator=generator, device=device, dtype=torch.float32)
     return (u * 2.0 - 1.0) * bounds
+
+
+def host_worker_best(score_add, score_sub, mirrored, grad_eval_type):
+    """GTN_Worker.calc_best_score's arithmetic for ONE worker on the host (reference agents/GTN_worker.py:234-254): statistics.mean
+    (exactly rounded) or the minimum of each side, then the mirrored pick.  Returns (score_best, sign): sign -1 = the -eps side won.
+    The population form of the same rule is lenv_nes_worker_best_multi (csrc/nes_update.hip); a GPU test holds the two together."""
+    import statistics
+    if grad_eval_type == 'mean':
+        sub, add = statistics.mean(score_sub), statistics.mean(score_add)
+    elif grad_eval_type == 'minmax':
+        sub, add = min(score_sub), min(score_add)
+    else:
+        raise NotImplementedError('Unknown parameter for grad_eval_type: ' + str(grad_eval_type))
+    if mirrored and sub > add:
+        return sub, -1.0
+    return add, 1.0

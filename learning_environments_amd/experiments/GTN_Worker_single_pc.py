@@ -12,6 +12,7 @@ import argparse
 import os
 import subprocess
 import sys
+import time
 
 
 def parse_args(argv):
@@ -40,9 +41,17 @@ def main(argv=None):
     procs = [subprocess.Popen(worker_command(args.bohb_id, i, args.seed), env=env) for i in range(args.num_workers)]
     rc = 0
     try:
-        for p in procs:
-            code = p.wait()
-            rc = rc or code
+        # poll ALL children: a worker that dies while worker 0 still waits for the master's input must end the launcher (and the
+        # remaining workers, in `finally`) with its exit code, not block behind a sequential wait (bench.launch_ranks does the same)
+        live = list(procs)
+        while live and rc == 0:
+            for p in list(live):
+                code = p.poll()
+                if code is not None:
+                    live.remove(p)
+                    rc = rc or code
+            if live and rc == 0:
+                time.sleep(0.2)
     finally:
         for p in procs:                    # a worker that is still running when this process is interrupted: end exactly that child
             if p.poll() is None:

@@ -438,3 +438,19 @@ def test_worker_relaunches_a_team_launch_that_could_not_assemble(tmp_path, monke
     assert fb0 == 0 and ts0 == 0
     assert got == ref                               # (score_best, score_orig): deterministic functions of the seed either way
     assert fb1 in (0, 1) and ts1 == (1 if fb1 else 0)
+
+
+def test_single_pc_launcher_ends_with_the_first_failing_worker(monkeypatch, tmp_path):
+    """the launcher polls all its children -- a worker that exits non-zero while worker 0 is still waiting for the master ends
+    the launcher with that code (and the surviving worker is terminated) instead of blocking behind a sequential wait."""
+    import time
+    from learning_environments_amd.experiments import GTN_Worker_single_pc as cli_n
+    monkeypatch.chdir(tmp_path)
+    marker = tmp_path / "sleeper_started"
+    cmds = {0: [sys.executable, "-c", "import time, pathlib; pathlib.Path(%r).write_text('x'); time.sleep(120)" % str(marker)],
+            1: [sys.executable, "-c", "import sys, time; time.sleep(0.5); sys.exit(7)"]}
+    monkeypatch.setattr(cli_n, "worker_command", lambda bohb_id, id, seed=None: cmds[id])
+    t0 = time.time()
+    rc = cli_n.main(["2", "--bohb-id", "-1"])
+    assert rc == 7 and time.time() - t0 < 30
+    assert marker.exists()                      # worker 0 was running (and has been terminated: main() returned long before its sleep ends)
