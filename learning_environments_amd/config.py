@@ -76,7 +76,7 @@ def ddqn_cfg_from_config(config, rng_mode=_lib.RNG_COUNTER, grad_chunk=0, **over
         cfg.synthetic_env_type, cfg.reward_env_type = 1, int(val(e["reward_env_type"]))
     for k, v in overrides.items():
         setattr(cfg, k, v)
-    if cfg.grad_chunk == 0 and cfg.agent_kind == 0 and not cfg.icm_enabled and not cfg.synthetic_env_type:
+    if cfg.grad_chunk == 0 and cfg.agent_kind == 0 and not cfg.icm_enabled:
         cfg.grad_chunk = pick_grad_chunk(cfg)          # DuelingDDQN / ICM agents: one sequential chunk (grad_chunk stays 0)
     return cfg
 

@@ -338,10 +338,16 @@ __device__ __forceinline__ void real_env_obs(const double (&st)[4], float (&obs)
 // TWIDE = the TEAM instantiation for teams of three and more (every forward item cut over the idle lanes, see `wide` below): a separate
 // instantiation, so that neither carries the other's forward code -- the kernel sits at the 168-VGPR cap of a 12-wave workgroup, and
 // every extra code path showed up as spill reloads in all of them.
-template <int ENV, int S, int A, int QACT, int PPT, int SHAPE = 0, bool TEAM = false, bool TWIDE = false>
+// RENV = the agent trains on a RewardEnv over the REAL env (gtn.synthetic_env_type 1, envs/reward_env.py:61-133; default_config_cartpole_reward_env.yaml)
+// or -- reward_env_type 0 -- on the real env itself (experiments/syn_env_run_vary_hp.py:47-54, mode 0): the env wave steps the real env's physics
+// (fp64 state, TimeLimit at max_steps) and shapes the reward with the perturbed reward network theta (S -> se_hidden -> 1), whose phi(s') it keeps
+// for the next step; there is nothing to speculate on.  Its own instantiations (one workgroup per chain), so that the VirtualEnv builds carry none
+// of it.  Oracle: ddqn_se_chain_impl's reward_env branch.
+template <int ENV, int S, int A, int QACT, int PPT, int SHAPE = 0, bool TEAM = false, bool TWIDE = false, bool RENV = false>
 __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
 {
     static_assert(!TWIDE || TEAM, "TWIDE is a TEAM layout");
+    static_assert(!RENV || (SHAPE == 0 && !TEAM), "RewardEnv / real-env training: generic one-workgroup instantiations only");
     extern __shared__ __align__(16) float lds[];
     const lenv_ddqn_cfg &cfg = a.cfg;
     constexpr bool FIXED = SHAPE != 0;
@@ -396,7 +402,22 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     const TanhLds tl = TanhLds::make(LV(tanh16) != 0, lane);
 
     // ---------------- stage the perturbed SE: W = theta + sign*eps[worker]  (GTN_worker.py:165-175) ----------------
-    {
+    if constexpr (RENV) {
+        // the reward network (RewardEnv.build_reward_net, reward_env.py:29-53: Drn -> Hse -> 1 with Drn = S, or the 1-input dummy of type 0 that
+        // is never evaluated), flat in Module.parameters() order W0 [Hse][Drn] | b0 | Wout [Hse] | bout, into the SE's rows: first layer
+        // transposed (lane = hidden unit reads consecutive words), output row 0
+        const float sg = a.eps ? a.sign[chain] : 0.0f;
+        const int Drn = cfg.reward_env_type == 0 ? 1 : S, P_rn = Drn * Hse + 2 * Hse + 1;
+        const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * P_rn : nullptr;
+        for (int i = tid; i < P_rn; i += NT) {
+            const float w = e ? fma32(sg, e[i], a.theta[i]) : a.theta[i];
+            int r = i;
+            if (r < Hse * Drn) { const int j = r / Drn, k = r - j * Drn; se_w0T[k * Hse + j] = w; }
+            else if ((r -= Hse * Drn) < Hse) se_b0[r] = w;
+            else if ((r -= Hse) < Hse) se_wout[r] = w;
+            else se_bout[0] = w;
+        }
+    } else {
         const float sg = a.eps ? a.sign[chain] : 0.0f;
         const int P_se = LV(P_se), sn0 = LV(se_net_size[0]), sn1 = LV(se_net_size[1]);
         const float *e = a.eps ? a.eps + (int64_t)a.worker[chain] * P_se : nullptr;
@@ -477,7 +498,14 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
     // sequential piece, k ascending over the hidden units -- is then run per item by the thread that owned it, from those rows.
     // Same operations on the same values in the same order: the bits do not change.
     // TEAM: this member's share of the minibatch = whole micro-chunks [mc0, mc1) = samples [mb0, mb0 + Bm)
+#ifdef LENV_DDQN_UNEVEN_MC
+    // EXPERIMENT build only (tools/uneven_team_ab.sh, docs/notebook_r06.md section 1): teams of two dealt UNEVENLY -- member 0 takes chunks
+    // [0, LENV_DDQN_UNEVEN_MC), member 1 the rest -- to time a primary's learn step when a helper workgroup takes a quarter of its minibatch
+    const int mc0 = TEAM ? (G == 2 ? (g ? LENV_DDQN_UNEVEN_MC : 0) : g * LV(n_chunks) / G) : 0;
+    const int mc1 = TEAM ? (G == 2 ? (g ? LV(n_chunks) : LENV_DDQN_UNEVEN_MC) : (g + 1) * LV(n_chunks) / G) : LV(n_chunks);
+#else
     const int mc0 = TEAM ? g * LV(n_chunks) / G : 0, mc1 = TEAM ? (g + 1) * LV(n_chunks) / G : LV(n_chunks);
+#endif
     const int mb0 = mc0 * LV(chunk), Bm = (mc1 * LV(chunk) < B ? mc1 * LV(chunk) : B) - mb0;
     // TEAM: a member of a team of two has 3 Bm = ~300 items = four full waves (one per SIMD) and a fifth, part-filled one that would
     // make SIMD 0 carry two; those spilled items are cut four ways over waves 4 .. 7, which have nothing else to do in the interval
@@ -567,6 +595,46 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
         wave_sync();
         return acc;
     };
+
+    // RENV: phi(ob) of the reward network for ONE wave (lane = hidden unit, the output a sequential fmaf chain), the same value in every lane
+    [[maybe_unused]] auto rn_eval = [&](float *hbuf, const float (&ob)[S]) -> float {
+        auto rn_hidden = [&](auto act_tag) {
+            constexpr int SEACT = decltype(act_tag)::value;
+            for (int j = lane; j < Hse; j += 64) {
+                const float *w = se_w0T + j;
+                float wv[S];
+#pragma unroll
+                for (int k = 0; k < S; ++k) { wv[k] = *w; w += Hse; }
+                const float bias = se_b0[j];
+                float z = 0.0f;
+#pragma unroll
+                for (int k = 0; k < S; ++k) z = fma32(ob[k], wv[k], z);
+                z = z + bias;
+                hbuf[j] = act_fwd_t<SEACT>(tanh_tab, tl, cfg.se_prelu, z);
+            }
+        };
+        switch (cfg.se_act) {
+        case LENV_ACT_RELU: rn_hidden(std::integral_constant<int, LENV_ACT_RELU>{}); break;
+        case LENV_ACT_LEAKYRELU: rn_hidden(std::integral_constant<int, LENV_ACT_LEAKYRELU>{}); break;
+        case LENV_ACT_TANH: rn_hidden(std::integral_constant<int, LENV_ACT_TANH>{}); break;
+        case LENV_ACT_PRELU: rn_hidden(std::integral_constant<int, LENV_ACT_PRELU>{}); break;
+        default: rn_hidden(std::integral_constant<int, LENV_ACT_IDENTITY>{}); break;
+        }
+        wave_sync();
+        float acc = 0.0f;
+        if (lane == 0) acc = seq_dot_lds(hbuf, se_wout, Hse) + se_bout[0];
+        wave_sync();
+        return __shfl(acc, 0);
+    };
+    // RENV: the real training env's own state (fp64, RewardEnv.real_env), the steps of its episode (TimeLimit), phi(s) of the state it is in
+    [[maybe_unused]] double st_d[4] = {0.0, 0.0, 0.0, 0.0};
+    [[maybe_unused]] int env_steps = 0;
+    [[maybe_unused]] float phi_s = 0.0f;
+    [[maybe_unused]] bool have_phi = false;
+    // lenv_ddqn_cfg::test_mode 1 = BaseAgent.train(env, test_env=None) (base_agent.py:134-148): no per-episode tests, the training env's own
+    // episode reward feeds the meter (the env wave sums it); generic instantiations only
+    const bool no_test_env = FIXED ? false : cfg.test_mode == 1;
+    [[maybe_unused]] float tr_reward = 0.0f;
 
     // one real-env test phase (BaseAgent.test + DDQN.select_test_action): wave w plays test episodes w, w+NW, ...
     auto test_phase = [&]() {
@@ -715,6 +783,12 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     st0[i] = -reset_lim + (2 * reset_lim) * u64_to_unit(rng_u64(key, STREAM_TRAIN_RESET, (uint64_t)(episode * 4 + i)));
             }
             real_env_obs<ENV, S>(st0, state);
+            if constexpr (RENV) {                          // RewardEnv.reset -> real_env.reset(): the env's own state; no phi(s) yet
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st_d[i] = st0[i];
+                env_steps = 0; have_phi = false;
+            }
+            if constexpr (!FIXED) tr_reward = 0.0f;
         }
 
         int ep_len = 0;
@@ -743,7 +817,31 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 PT_MARK(0);   // (env wave) act
                 // ---- EnvWrapper.step -> VirtualEnv.step (envs/env_wrapper.py:16-47, envs/virtual_env.py:43-54) ----
                 float next_state[S], reward, done;
-                if (spec_valid) {
+                if constexpr (RENV) {
+                    // ---- EnvWrapper.step -> RewardEnv.step (reward_env.py:61-66): the real transition (TimeLimit: done at max_steps), reward =
+                    // _calc_reward(state, next_state, reward) with the perturbed reward net (:68-133); oracle: rn_shape_one ----
+                    double rew; int dn;
+                    real_env_step<ENV>(st_d, action, rew, dn);
+                    ++env_steps;
+                    if (env_steps >= MAX_STEPS) dn = 1;
+                    real_env_obs<ENV, S>(st_d, next_state);
+                    const int rtype = cfg.reward_env_type;
+                    const float r32 = (float)rew;
+                    float shaped = r32;                                            // type 0: the real reward passes through
+                    if (rtype != 0) {
+                        if ((rtype == 1 || rtype == 2) && !have_phi) phi_s = rn_eval(se_hw, state);      // phi(s): carried over after the first step
+                        const float phi_s2 = rn_eval(se_hw, next_state);
+                        const float g32 = a.f_gamma;
+                        switch (rtype) {
+                        case 1: shaped = g32 * phi_s2 - phi_s; break;
+                        case 2: shaped = (r32 + g32 * phi_s2) - phi_s; break;
+                        case 5: shaped = phi_s2; break;
+                        default: shaped = r32 + phi_s2; break;                    // 6
+                        }
+                        phi_s = phi_s2; have_phi = true;
+                    }
+                    reward = shaped; done = dn ? 1.0f : 0.0f;
+                } else if (spec_valid) {
                     // evaluated for every action during the previous step's forward interval
 #pragma unroll
                     for (int i = 0; i < S; ++i) next_state[i] = cand[action * 16 + i];
@@ -783,6 +881,7 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 }
 #pragma unroll
                 for (int i = 0; i < S; ++i) state[i] = next_state[i];
+                if constexpr (!FIXED) tr_reward = tr_reward + reward;             // base_agent.py:121 episode_reward += reward (fp32 tensors)
                 if (learning && lane == 0) lds_flag_store(ctrl + 5, step_tag);
                 PT_MARK(1);   // (env wave) SE step + append
             }
@@ -1095,9 +1194,11 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                     float st[S];
 #pragma unroll
                     for (int i = 0; i < S; ++i) st[i] = cur_state[i];
+                    if constexpr (!RENV) {
                     for (int act = wave - first_spec; act < A; act += n_spec) {
                         const float acc = se_eval(se_hw, st, act);
                         if (lane < S + 2) cand[act * 16 + lane] = acc;
+                    }
                     }
                     if (wave == ENV_WAVE && t + 1 < MAX_STEPS) {
                         draw_action(train_steps);              // train_steps already counts this step: index of the next one
@@ -1395,32 +1496,33 @@ __global__ __launch_bounds__(NT) void ddqn_se_inner_kernel(const InnerArgs a)
                 __syncthreads();                               // B5
                 PT_MARK(6);
             }
-            spec_valid = learning && n_spec > 0;
+            spec_valid = !RENV && learning && n_spec > 0;
             if (ctrl[t & 1] > 0.5f) break;                     // base_agent.py:128 (slot written in this step's phase A, behind B1/B2)
         }
         ++episodes_run;
         if (tid == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
+        if constexpr (!FIXED) { if (no_test_env && wave == ENV_WAVE && lane == 0) ctrl[8] = tr_reward; }      // (ctrl[8..]: free outside the test phase)
         __syncthreads();
 
-        // ---- per-episode test on the real env (base_agent.py:134-136) ----
+        // ---- per-episode test on the real env (base_agent.py:134-136); none without a test env (test_mode 1) ----
         PT_MARK(9);
-        test_phase();
+        if (!no_test_env) test_phase();
         PT_MARK(7);
         int brk = 0;
         if (tid == 0) {
-            double sm = 0.0;
-            for (int i = 0; i < T_EP; ++i) sm += ret[i];
-            const double tm = sm / (double)T_EP;
+            double tm;
+            if (no_test_env) tm = (double)ctrl[8];       // avg_meter_reward.update(episode_reward) (base_agent.py:138)
+            else {
+                double sm = 0.0;
+                for (int i = 0; i < T_EP; ++i) sm += ret[i];
+                tm = sm / (double)T_EP;
+            }
             meter[episode] = tm;
             if (a.out.episode_test_mean) a.out.episode_test_mean[chain * cfg.train_episodes + episode] = tm;
-            // early out on the real env (base_agent.py:49-62,141-148; AverageMeter._mean utils.py:103-105)
-            if (learning) {
-                int lo = episode + 1 - cfg.early_out_num; if (lo < 0) lo = 0;
-                double s2 = 0.0;
-                for (int i = lo; i <= episode; ++i) s2 += meter[i];
-                const double avg = s2 / ((double)(episode + 1 - lo) + 1e-9);
-                if (avg >= cfg.solved_reward) brk = 1;
-            }
+            // early out (base_agent.py:49-62,141-148; AverageMeter._mean utils.py:103-105): on the real env the test env's rule; without a
+            // test env break_env = the training env -- the virtual rule on a VirtualEnv, the real rule on a RewardEnv / the real env
+            if (learning) brk = meter_env_solved_inl(meter, episode + 1, cfg.early_out_num, no_test_env && !RENV, cfg.solved_reward,
+                                                     cfg.early_out_virtual_diff, episode, cfg.init_episodes);
             ctrl[2] = (float)brk;
         }
         __syncthreads();
@@ -1558,7 +1660,11 @@ static int inner_layout(const lenv_ddqn_cfg *cfg, InnerArgs &a)
 }
 
 // diagnostic switch: kernel_variant GENERIC runs the published shape through the generic instantiation (A/B timing)
-static bool cfg_disables_fixed_shape(const lenv_ddqn_cfg *cfg) { return (cfg->kernel_variant & LENV_VARIANT_GENERIC) != 0; }
+// (the shape-specialised builds are VirtualEnv + calc_score builds: a RewardEnv / real-env launch and test_mode 1 take the generic ones)
+static bool cfg_disables_fixed_shape(const lenv_ddqn_cfg *cfg)
+{
+    return (cfg->kernel_variant & LENV_VARIANT_GENERIC) != 0 || cfg->synthetic_env_type != 0 || cfg->test_mode != 0;
+}
 
 // index into kShapes of the published shape this launch has exactly (0 = none: generic instantiation)
 template <int I> static bool shape_matches(const lenv_ddqn_cfg *cfg, const InnerLayout &L)
@@ -1584,9 +1690,15 @@ static int inner_check(const lenv_ddqn_cfg *cfg)
     if (cfg->agent_kind != 0) return LENV_ERR_INVALID;                             // DuelingDDQN: lenv_dueling_se_inner_loop
     if (cfg->q_layers != 1 || cfg->se_layers != 1) return LENV_ERR_UNSUPPORTED;   // multi-layer Q-nets: GEMM-tiled kernel (plain-DQN mode)
     if (cfg->icm_enabled) return LENV_ERR_UNSUPPORTED;                             // ICM agents: lenv_dueling_se_inner_loop_icm
-    if (cfg->synthetic_env_type != 0) return LENV_ERR_UNSUPPORTED;                 // RewardEnv over the real env: GEMM-tiled kernel
+    if (cfg->synthetic_env_type == 1) {
+        // RewardEnv over the real env / the real env itself (the RENV instantiations): an explicit micro-chunk (grad_chunk 0 = ONE sequential
+        // batch gradient = the GEMM-tiled kernel's order, what a cfg built for that kernel carries), a reward net without LayerNorm, the
+        // reward types the real CartPole / Acrobot step can serve (no info vector)
+        const int t = cfg->reward_env_type;
+        if (cfg->grad_chunk <= 0 || cfg->se_layer_norm || !(t == 0 || t == 1 || t == 2 || t == 5 || t == 6)) return LENV_ERR_UNSUPPORTED;
+    } else if (cfg->synthetic_env_type != 0) return LENV_ERR_INVALID;
     if (cfg->same_action_num > 1) return LENV_ERR_UNSUPPORTED;                     // several env steps per action: GEMM-tiled kernel
-    if (cfg->test_mode != 0) return LENV_ERR_UNSUPPORTED;                          // BaseAgent.train without a test env (the evaluation harness): GEMM-tiled kernel
+    if (cfg->test_mode < 0 || cfg->test_mode > 1) return LENV_ERR_INVALID;         // 1 = BaseAgent.train without a test env (the evaluation harness)
     // the Q-net's shared nn.PReLU slope is a trained parameter in the reference (DDQN.py:36 Adam over model.parameters());
     // refusing beats silently training with a frozen 0.25
     if (cfg->q_act == LENV_ACT_PRELU) return LENV_ERR_UNSUPPORTED;
@@ -1702,6 +1814,7 @@ static int ddqn_pick_team(const lenv_ddqn_cfg *cfg, int64_t chains, bool product
     if (!production || want == 1 || chains < 1) return 1;
     if (want == 0 && chains < 16) return 1;
     if (chains > DDQN_TEAM_MAX_CHAINS) return 1;                  // (no exchange area is carved for such launches: lenv_ddqn_se_workspace_bytes)
+    if (cfg->synthetic_env_type != 0) return 1;                   // RewardEnv / real-env training: one workgroup per chain (no TEAM instantiation)
     InnerArgs t;
     if (inner_check(cfg) != LENV_OK || inner_layout(cfg, t) != LENV_OK) return 1;
     const size_t lds_bytes = (size_t)t.L.lds_floats * sizeof(float);
@@ -1787,6 +1900,19 @@ extern "C" int lenv_ddqn_se_inner_loop(const lenv_ddqn_cfg *cfg, const float *th
     if (cfg->env_id == LENV_ENV_CARTPOLE) { LENV_PICK(LENV_ENV_CARTPOLE, 4, 2) }
     else { LENV_PICK(LENV_ENV_ACROBOT, 6, 3) }
 #undef LENV_PICK2
+    if (cfg->synthetic_env_type == 1) {
+        // the RENV instantiations (RewardEnv over the real env / the real env itself as the training env)
+#define LENV_PICK2(ENVID, SS, AA, PP)                                                                                                   \
+        switch (cfg->q_act) {                                                                                                           \
+        case LENV_ACT_RELU: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_RELU, PP, 0, false, false, true>; break;                \
+        case LENV_ACT_LEAKYRELU: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_LEAKYRELU, PP, 0, false, false, true>; break;      \
+        case LENV_ACT_TANH: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_TANH, PP, 0, false, false, true>; break;                \
+        default: kern = ddqn_se_inner_kernel<ENVID, SS, AA, LENV_ACT_IDENTITY, PP, 0, false, false, true>; break;                       \
+        }
+        if (cfg->env_id == LENV_ENV_CARTPOLE) { LENV_PICK(LENV_ENV_CARTPOLE, 4, 2) }
+        else { LENV_PICK(LENV_ENV_ACROBOT, 6, 3) }
+#undef LENV_PICK2
+    }
 #undef LENV_PICK
     if (cfg->rng_mode == LENV_RNG_COUNTER && !out->trace_action && !cfg_disables_fixed_shape(cfg)) {
         switch (published_shape(cfg, a.L)) {

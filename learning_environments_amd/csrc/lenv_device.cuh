@@ -502,9 +502,8 @@ __device__ __forceinline__ void real_env_reset_draw(int env_id, uint64_t key, ui
 // utils.py:94-105: a slice sum over (len + 1e-9)); the caller checks episode >= init_episodes (base_agent.py:141).  virtual_rule:
 // break_env is a VirtualEnv (train(env, test_env=None) on one, lenv_ddqn_cfg::test_mode 1): the mean of the last `num` entries
 // against the mean of the `num` before them; otherwise the real rule avg >= solved_reward.  Oracle: meter_env_solved (lenv_oracle.c).
-// NOT forceinline: one thread per chain calls it once per training episode.
-[[maybe_unused]] static __device__ __noinline__ int meter_env_solved(const double *meter, int n, int num, bool virtual_rule, double solved_reward, double virtual_diff,
-                                             int episode, int init_episodes)
+__device__ __forceinline__ int meter_env_solved_inl(const double *meter, int n, int num, bool virtual_rule, double solved_reward, double virtual_diff,
+                                                    int episode, int init_episodes)
 {
     int lo = n - num; if (lo < 0) lo = 0;
     double sm = 0.0;
@@ -517,6 +516,12 @@ __device__ __forceinline__ void real_env_reset_draw(int env_id, uint64_t key, ui
     for (int i = lo2; i < hi2; ++i) s2 += meter[i];
     const double last = s2 / ((double)(hi2 - lo2) + 1e-9);
     return __builtin_fabs(avg - last) / (__builtin_fabs(last) + 1e-9) < virtual_diff && episode >= init_episodes + num;
+}
+// the out-of-line form (the GEMM-queue kernels: one thread per chain calls it once per training episode)
+[[maybe_unused]] static __device__ __noinline__ int meter_env_solved(const double *meter, int n, int num, bool virtual_rule, double solved_reward, double virtual_diff,
+                                                                     int episode, int init_episodes)
+{
+    return meter_env_solved_inl(meter, n, num, virtual_rule, solved_reward, virtual_diff, episode, init_episodes);
 }
 
 }  // namespace lenv

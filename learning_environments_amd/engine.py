@@ -172,7 +172,9 @@ class InnerLoop(object):
         # run in the GEMM-tiled kernel; `dueling` keeps its name from the first of the two
         self.icm = bool(cfg.icm_enabled)               # ICM agents (ddqn_icm / duelingddqn_icm): GEMM-tiled kernel only
         self.icm_init = self.icm_final = self.icm_io = None
-        self.dueling = self.vary or self.icm or cfg.synthetic_env_type == 1 or cfg.agent_kind == 1 or (cfg.agent_kind == 0 and L.lenv_ddqn_se_lds_bytes(C.byref(cfg)) <= 0
+        # (a RewardEnv / real-env cfg with an explicit micro-chunk takes the register-resident kernel's RENV instantiations; with grad_chunk 0 --
+        # one sequential batch gradient -- the probe refuses it and the GEMM-tiled kernel runs it)
+        self.dueling = self.vary or self.icm or cfg.agent_kind == 1 or (cfg.agent_kind == 0 and L.lenv_ddqn_se_lds_bytes(C.byref(cfg)) <= 0
                                                                         and L.lenv_dueling_num_params(C.byref(cfg)) > 0)
         if self.dueling:
             self.p_agent = int(L.lenv_dueling_num_params(C.byref(cfg)))

@@ -22,17 +22,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 G12 = ["g12_train_test_agents_cartpole_mode2_vary", "g12_train_test_agents_cartpole_mode1_plain", "g12_train_test_agents_cartpole_mode0_real_env"]
 
 
-def g12_oracle_cfg(g, i, **over):
+def g12_oracle_cfg(g, i, grad_chunk=0, **over):
     """The oracle configuration of agent i of a G12 fixture: the config the reference function left behind (its "settings for
     comparability" :29-36 are in config_json), agent i's recorded draw, test_mode 1; mode 0 = the real env as the training env =
-    a RewardEnv of type 0 (reward_env.py:80-81: the reward passes through)."""
+    a RewardEnv of type 0 (reward_env.py:80-81: the reward passes through).  grad_chunk: the micro-chunk of the batch gradient's canonical
+    order (0 = one piece: the GEMM-tiled kernel; the register-resident kernel's launches carry config.pick_grad_chunk's value)."""
     cfgd, hp = json.loads(str(g["config_json"])), json.loads(str(g["a%d_hp_json" % i]))
     cfgd["agents"]["gtn"]["agent_name"] = "DDQN"
     a = cfgd["agents"]["ddqn"]
     assert (a["train_episodes"], a["init_episodes"], a["early_out_num"], a["test_episodes"], a["early_out_virtual_diff"]) == (1000, 10, 10, 10, 0.01)
     extra = dict(synthetic_env_type=1, reward_env_type=0) if int(g["mode"]) == 0 else {}
     extra.update(over)
-    return orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=1, test_mode=1, **orc.hp_overrides(hp), **extra), cfgd, hp
+    return orc.ddqn_cfg_from_config(cfgd, grad_chunk=grad_chunk, rng_mode=1, test_mode=1, **orc.hp_overrides(hp), **extra), cfgd, hp
 
 
 def g12_tapes(g, i):
@@ -134,13 +135,15 @@ def test_g12_product_train_test_agents_replays_the_reference_run(golden, tmp_pat
     assert (a["train_episodes"], a["init_episodes"], a["early_out_num"], a["test_episodes"], a["early_out_virtual_diff"]) == (1000, 10, 10, 10, 0.01)
     last = train_test_agents.last
     assert last["inner"].cfg.test_mode == 1 and last["inner"].cfg.synthetic_env_type == (1 if mode == 0 else 0)
+    # the base hyper-parameters (one hidden layer of 64) run in the register-resident kernel, the drawn ones (per-chain shapes) in the GEMM-tiled one
+    assert last["inner"].dueling == (mode != 1) and (last["inner"].cfg.grad_chunk > 0) == (mode == 1)
     assert steps == g["train_steps_needed"].tolist() and episodes == g["episodes_needed"].tolist()
     np.testing.assert_allclose(np.array(rewards), g["reward_list"], rtol=0, atol=1e-4)
     for i in range(n_agents):
         pre = "a%d_" % i
         np.testing.assert_allclose(last["reward_train"][i], g[pre + "reward_train"], rtol=0, atol=1e-4)
         assert last["episode_length"][i] == g[pre + "episode_length"].tolist()
-        ocfg, _, _ = g12_oracle_cfg(g, i)
+        ocfg, _, _ = g12_oracle_cfg(g, i, grad_chunk=last["inner"].cfg.grad_chunk)
         o = orc.ddqn_se_chain(ocfg, g["theta"], g[pre + "agent_init"], tapes=orc.make_tapes(*g12_tapes(g, i)))
         assert rewards[i] == o["final_test_returns"].tolist()
         assert last["reward_train"][i] == o["episode_test_mean"][:o["episodes_run"]].tolist()
@@ -148,24 +151,26 @@ def test_g12_product_train_test_agents_replays_the_reference_run(golden, tmp_pat
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [2, 1, 0])
-def test_product_train_test_agents_counter_mode_vs_oracle(tmp_path, mode):
-    """The function as a user calls it (own counter-RNG draws): 5 agents in ONE launch -- drawn hyper-parameters in mode 2 / 0, the base ones
-    in mode 1 -- each bit-identical to the oracle chain run with that agent's key, draw and fresh parameters."""
+@pytest.mark.parametrize("mode,vary", [(2, True), (1, False), (0, True), (0, False)])
+def test_product_train_test_agents_counter_mode_vs_oracle(tmp_path, mode, vary):
+    """The function as a user calls it (own counter-RNG draws): 5 agents in ONE launch -- drawn hyper-parameters (per-chain shapes: the
+    GEMM-tiled kernel) or the base ones (the register-resident kernel: test_mode 1 on the VirtualEnv, and its RENV instantiation for the
+    real env as the training env) -- each bit-identical to the oracle chain run with that agent's key, draw and fresh parameters."""
     import torch
     from learning_environments_amd.agents.nes_common import chain_keys
     from learning_environments_amd.experiments.syn_env_evaluate import train_test_agents
     venv, real_env, config = _load_ckpt_b(tmp_path)
     config["agents"]["ddqn"]["early_out_virtual_diff_unused"] = 0      # (unknown keys are ignored like in the reference)
     train_env = real_env if mode == 0 else venv
-    rewards, steps, episodes = train_test_agents(train_env, real_env, config, agents_num=5, vary_hp=(mode != 1), seed=11)
+    rewards, steps, episodes = train_test_agents(train_env, real_env, config, agents_num=5, vary_hp=vary, seed=11)
     last = train_test_agents.last
     inner = last["inner"]
+    assert inner.dueling == vary and inner.cfg.test_mode == 1 and inner.cfg.synthetic_env_type == (1 if mode == 0 else 0)
     keys = chain_keys(11, 0, np.arange(5), np.zeros(5, np.int64))
     theta = venv.env.flat_params().cpu().numpy()
     cfgd = json.loads(json.dumps(config))
     cfgd["agents"]["gtn"]["agent_name"] = "DDQN"
-    if mode == 1:
+    if not vary:
         from learning_environments_amd.agents.nes_common import fresh_agent_init
         gen = torch.Generator(device="cuda")
         gen.manual_seed(11)
@@ -179,7 +184,7 @@ def test_product_train_test_agents_counter_mode_vs_oracle(tmp_path, mode):
         over = dict(synthetic_env_type=1, reward_env_type=0) if mode == 0 else {}
         if hps[c] is not None:
             over.update(orc.hp_overrides(hps[c]))
-        ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=0, rng_mode=0, test_mode=1, **over)
+        ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=inner.cfg.grad_chunk, rng_mode=0, test_mode=1, **over)
         p_c = orc.mlp_num_params(orc.mlp_desc(4, ocfg.q_hidden, ocfg.q_layers, 2, ocfg.q_act))
         o = orc.ddqn_se_chain(ocfg, theta if mode != 0 else np.zeros(1, np.float32), inits[c][:p_c], rng_key=int(keys[c]))
         assert o["rc"] == 0
