@@ -677,14 +677,16 @@ def test_gtn_master_cartpole_reward_env_ddqn(tmp_path, monkeypatch):
     cfg["envs"]["CartPole-v0"]["max_steps"] = 25
     cfg["agents"]["ddqn"].update(batch_size=32, test_episodes=2)
     m = _master_pair(cfg, tmp_path, monkeypatch)
-    assert m.cfg.synthetic_env_type == 1 and m.cfg.reward_env_type == 2 and m.inner.dueling and m.p_theta == 4 * 64 + 64 + 64 + 1
+    # (round 6: the register-resident kernel's RENV instantiation runs this configuration -- the cfg carries config.pick_grad_chunk's micro-chunk)
+    assert m.cfg.synthetic_env_type == 1 and m.cfg.reward_env_type == 2 and not m.inner.dueling and m.cfg.grad_chunk > 0
+    assert m.p_theta == 4 * 64 + 64 + 64 + 1
     assert "env.reward_net.0.weight" in m.synthetic_env_orig.state_dict() and not m.synthetic_env_orig.is_virtual_env()
     theta0 = m.theta.cpu().numpy().copy()
     gathered = m.evaluate_population(0).cpu().numpy()
     eps = m.eps.cpu().numpy()
     oeps, init, okeys = orc.nes_draw(m.seed, 0, 3, m.p_theta, cfg["agents"]["gtn"]["noise_std"], 9, 3, 0, m.agent_bounds.cpu().numpy())
     assert np.array_equal(eps, oeps)
-    ocfg = orc.ddqn_cfg_from_config(cfg, grad_chunk=0)
+    ocfg = orc.ddqn_cfg_from_config(cfg, grad_chunk=m.cfg.grad_chunk)
     scores = []
     for c in range(9):
         w = (np.float32([0.0, 1.0, -1.0][c % 3]) * eps[c // 3] + theta0).astype(np.float32)

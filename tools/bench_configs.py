@@ -17,9 +17,13 @@ from learning_environments_amd.agents.GTN import GTN_Master  # noqa: E402
 from learning_environments_amd import configs  # noqa: E402
 
 
-def run(name, cfg, gens=2, extra=None):
+def run(name, cfg, gens=2, extra=None, force_gemm=False):
     torch.manual_seed(0)
     m = GTN_Master(cfg, bohb_id=0, seed=7)
+    if force_gemm:       # A/B aid: one sequential batch gradient (grad_chunk 0) = the GEMM-queue kernel instead of the register-resident one
+        m.cfg.grad_chunk = 0
+        m.inner = m.task.make_inner(m.cpw * m.n_local)
+        assert m.inner.dueling
     m.step(0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -141,9 +145,12 @@ if __name__ == "__main__":
         run("MountainCar SE + DDQN 2-256-256-3 pop 16 (3 episodes x 100 steps), GEMM-queue kernel", c, gens=2)
     if "cartpole_rn_ddqn" in which:
         # default_config_cartpole_reward_env.yaml (DDQN 4-64-2 leakyrelu, B = 192, trained on the real CartPole with a learned reward, 16 workers)
-        c = configs.fixed_work(configs.cartpole_reward_env_ddqn(16), 6)
-        c["agents"]["gtn"]["quit_when_solved"] = False
-        run("CartPole RewardEnv + DDQN 4-64-2 pop 16 (6 episodes), GEMM-queue kernel", c, gens=2)
+        # round 6: the register-resident kernel's RENV instantiation (real-env training step + reward net on the env wave), then the GEMM-queue kernel
+        for pop in (16, 64):
+            for force, label in ((False, "register-resident kernel (RENV)"), (True, "GEMM-queue kernel")):
+                c = configs.fixed_work(configs.cartpole_reward_env_ddqn(pop), 6)
+                c["agents"]["gtn"]["quit_when_solved"] = False
+                run("CartPole RewardEnv + DDQN 4-64-2 pop %d (6 episodes), %s" % (pop, label), c, gens=2, force_gemm=force)
     if "cmc_opt_td3" in which:
         # default_config_cmc_syn_env_opt.yaml-like: TD3 with ONE 64-wide hidden layer on a VirtualEnv of three 3-128-128-128-x nets, B = 256
         c = configs.fixed_work(configs.cmc_syn_env_td3(16), 3)
