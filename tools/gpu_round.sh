@@ -10,7 +10,6 @@ mkdir -p $R/gpurun_out
 cd $R
 # the driver's own command line: the bench line and the profiled headline run are THIS command
 DRIVER_ARGS="--gpus 1 --steps 20 --warmup 5"
-python bench.py $DRIVER_ARGS 2>gpurun_out/bench.err | tail -1 | tee gpurun_out/bench.json | cut -c1-400
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof $R/gpurun_out/pmc_* $R/gpurun_out/prof_cfg* $R/gpurun_out/pmccfg_*
 # one-rank RCCL run of the same bench command under a launcher (a communicator exists: ranks.backend rccl, collective_ran true)
@@ -38,4 +37,12 @@ for n in 2 4; do
   done
 done
 cd $R
+# the bench line's roofline.traffic is read from profiles/<tag>_summary.json -- so THIS round's PMC passes are condensed
+# first, the bench line is taken afterwards (it then carries this round's FETCH_SIZE / WRITE_SIZE figure and names the file), and the
+# summary is written once more with the line attached
+rm -f gpurun_out/bench.json
+python3 tools/summarize_profiles.py $TAG > /dev/null
+cp profiles/${TAG}_summary.json gpurun_out/
+python bench.py $DRIVER_ARGS 2>gpurun_out/bench.err | tail -1 | tee gpurun_out/bench.json | cut -c1-400
 python3 tools/summarize_profiles.py $TAG
+cp profiles/${TAG}_* gpurun_out/ 2>/dev/null
