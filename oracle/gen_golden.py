@@ -1463,18 +1463,27 @@ def gen_ckpt_b():
     print("wrote", path, os.path.getsize(path))
 
 
-def gen_g12(name, mode, seed, agents_num=2, vary=True, vary_seed=77, ckpt="ckpt_cartpole_se_reference_b.pt"):
+def gen_g12(name, mode, seed, agents_num=2, vary=True, vary_seed=77, ckpt="ckpt_cartpole_se_reference_b.pt",
+            module="experiments.syn_env_evaluate_cartpole_vary_hp_2", agent_key="ddqn"):
+    """module / agent_key: the sibling script and the config section its agent reads (experiments/syn_env_evaluate_cartpole_vary_hp_2_DuelingDDQN.py:
+    DuelingDDQN_vary, section `duelingddqn`)."""
+    import importlib
     import json
     import shutil
     import tempfile
     import ConfigSpace
-    import experiments.syn_env_evaluate_cartpole_vary_hp_2 as ev
+    ev = importlib.import_module(module)
     import gym.envs as genvs
     import gym.spaces as gspaces
     tmp = tempfile.mkdtemp(prefix="lenv_g12_")
     shutil.copy(os.path.join(OUT, ckpt), os.path.join(tmp, "model.pt"))
-    with quiet():
-        venv, real_env, config = ev.load_envs_and_config(file_name="model.pt", model_dir=tmp, device="cpu")
+    cwd = os.getcwd()
+    os.chdir(os.path.join(REF, "experiments"))      # (the sibling scripts read "../default_config_cartpole.yaml" relative to their own directory; nothing is written there)
+    try:
+        with quiet():
+            venv, real_env, config = ev.load_envs_and_config(file_name="model.pt", model_dir=tmp, device="cpu")
+    finally:
+        os.chdir(cwd)
     theta = se_theta(venv)
     # syn_env_run_vary_hp.py:47-54 (mode 0): train_env = test_env = the real env; :82-91: train_env = the loaded virtual env
     train_env = real_env if mode == 0 else venv
@@ -1524,14 +1533,14 @@ def gen_g12(name, mode, seed, agents_num=2, vary=True, vary_seed=77, ckpt="ckpt_
         if not vary:
             # mode 1 of the experiment family with the base hyper-parameters: DDQN_vary with vary_hp off IS DDQN (DDQN_vary.py:16-21).
             # train_test_agents has just forced vary_hp = True (:30); flip it back before the agent is built
-            config['agents']['ddqn_vary']['vary_hp'] = False
+            config['agents'][agent_key + '_vary']['vary_hp'] = False
         agent = orig_select_agent(config=config, agent_name=agent_name)
         rec = Recorder()
         state["rec"] = rec
         recs.append(rec)
         h = {"agent": agent,
-             "hp": {k: agent.full_config["agents"]["ddqn"][k] for k in ("lr", "batch_size", "hidden_size", "hidden_layer")},
-             "init": pack_linear_params(agent.model.state_dict(), "net.")}
+             "hp": {k: agent.full_config["agents"][agent_key][k] for k in ("lr", "batch_size", "hidden_size", "hidden_layer")},
+             "init": pack_linear_params(agent.model.state_dict(), "net.") if hasattr(agent.model, "net") else _pack_dueling(agent.model.state_dict())}
         holders.append(h)
         orig_learn, orig_train, orig_test = agent.learn, agent.train, agent.test
 
@@ -1616,6 +1625,10 @@ def main():
         gen_g12("g12_train_test_agents_cartpole_mode2_vary", mode=2, seed=1201, vary=True)
         gen_g12("g12_train_test_agents_cartpole_mode1_plain", mode=1, seed=1202, vary=False)
         gen_g12("g12_train_test_agents_cartpole_mode0_real_env", mode=0, seed=1203, vary=True)
+        # the DuelingDDQN sibling script (settings in the `duelingddqn` section, DuelingDDQN_vary agents); vary_seed 1 draws small nets
+        # (batch 105 / width 42 / 3 layers and 58 / 63 / 1) so that the CPU oracle replays the run in seconds
+        gen_g12("g12d_train_test_agents_cartpole_mode2_dueling_vary", mode=2, seed=1204, vary=True, vary_seed=1,
+                module="experiments.syn_env_evaluate_cartpole_vary_hp_2_DuelingDDQN", agent_key="duelingddqn")
     if "g1" in which:
         gen_g1()
     if "g1ln" in which:

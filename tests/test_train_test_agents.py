@@ -20,16 +20,23 @@ from oracle import oracle as orc
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 G12 = ["g12_train_test_agents_cartpole_mode2_vary", "g12_train_test_agents_cartpole_mode1_plain", "g12_train_test_agents_cartpole_mode0_real_env"]
+# the DuelingDDQN sibling script (experiments/syn_env_evaluate_cartpole_vary_hp_2_DuelingDDQN.py: DuelingDDQN_vary, settings in `duelingddqn`)
+G12D = "g12d_train_test_agents_cartpole_mode2_dueling_vary"
 
 
-def g12_oracle_cfg(g, i, grad_chunk=0, **over):
+def g12_agent(name):
+    """(agent_name of the harness, config section, base agent name) of a G12 fixture."""
+    return ("DuelingDDQN_vary", "duelingddqn", "DuelingDDQN") if "dueling" in name else ("DDQN_vary", "ddqn", "DDQN")
+
+
+def g12_oracle_cfg(g, i, grad_chunk=0, dueling=False, **over):
     """The oracle configuration of agent i of a G12 fixture: the config the reference function left behind (its "settings for
     comparability" :29-36 are in config_json), agent i's recorded draw, test_mode 1; mode 0 = the real env as the training env =
     a RewardEnv of type 0 (reward_env.py:80-81: the reward passes through).  grad_chunk: the micro-chunk of the batch gradient's canonical
     order (0 = one piece: the GEMM-tiled kernel; the register-resident kernel's launches carry config.pick_grad_chunk's value)."""
     cfgd, hp = json.loads(str(g["config_json"])), json.loads(str(g["a%d_hp_json" % i]))
-    cfgd["agents"]["gtn"]["agent_name"] = "DDQN"
-    a = cfgd["agents"]["ddqn"]
+    cfgd["agents"]["gtn"]["agent_name"] = "DuelingDDQN" if dueling else "DDQN"
+    a = cfgd["agents"]["duelingddqn" if dueling else "ddqn"]
     assert (a["train_episodes"], a["init_episodes"], a["early_out_num"], a["test_episodes"], a["early_out_virtual_diff"]) == (1000, 10, 10, 10, 0.01)
     extra = dict(synthetic_env_type=1, reward_env_type=0) if int(g["mode"]) == 0 else {}
     extra.update(over)
@@ -41,15 +48,15 @@ def g12_tapes(g, i):
     return [g[pre + "tape_" + k] for k in ("eps_uniform", "rand_action", "replay_idx", "train_reset", "test_reset")]
 
 
-@pytest.mark.parametrize("name", G12)
+@pytest.mark.parametrize("name", G12 + [G12D])
 def test_g12_oracle_reproduces_the_reference_train_test_agents(golden, name):
     g = golden(name)
     n_agents = int(g["agents_num"])
     assert n_agents == 2 and g["reward_list"].shape == (2, 10)
     for i in range(n_agents):
         pre = "a%d_" % i
-        cfg, cfgd, hp = g12_oracle_cfg(g, i)
-        assert cfg.test_mode == 1 and cfg.early_out_virtual_diff == 0.01
+        cfg, cfgd, hp = g12_oracle_cfg(g, i, dueling="dueling" in name)
+        assert cfg.test_mode == 1 and cfg.early_out_virtual_diff == 0.01 and cfg.agent_kind == int("dueling" in name)
         n = g[pre + "tr_action"].size
         out = orc.ddqn_se_chain(cfg, g["theta"], g[pre + "agent_init"], tapes=orc.make_tapes(*g12_tapes(g, i)), trace_cap=n + 10)
         assert out["rc"] == 0
@@ -115,7 +122,7 @@ def _load_ckpt_b(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", G12)
+@pytest.mark.parametrize("name", G12 + [G12D])
 def test_g12_product_train_test_agents_replays_the_reference_run(golden, tmp_path, name):
     """The reference's recorded draws (hyper-parameters, fresh agents, RNG tapes) replayed through the product function: the three returned
     lists equal the reference's (`reward_list` within 1e-4, `train_steps_needed` / `episodes_needed` EXACTLY) and the oracle's bit for bit,
@@ -129,9 +136,10 @@ def test_g12_product_train_test_agents_replays_the_reference_run(golden, tmp_pat
     replay = dict(hp=hps, agent_init=[g["a%d_agent_init" % i] for i in range(n_agents)],
                   tapes={k: [g["a%d_tape_%s" % (i, k)] for i in range(n_agents)] for k in ("eps_uniform", "rand_action", "replay_idx", "train_reset", "test_reset")})
     train_env = real_env if mode == 0 else venv
-    rewards, steps, episodes = train_test_agents(train_env, real_env, config, agents_num=n_agents, vary_hp=(mode != 1), replay=replay)
+    agent_name, section, _ = g12_agent(name)
+    rewards, steps, episodes = train_test_agents(train_env, real_env, config, agents_num=n_agents, agent_name=agent_name, vary_hp=(mode != 1), replay=replay)
     # the settings for comparability were applied to the caller's config in place, like the reference does
-    a = config["agents"]["ddqn"]
+    a = config["agents"][section]
     assert (a["train_episodes"], a["init_episodes"], a["early_out_num"], a["test_episodes"], a["early_out_virtual_diff"]) == (1000, 10, 10, 10, 0.01)
     last = train_test_agents.last
     assert last["inner"].cfg.test_mode == 1 and last["inner"].cfg.synthetic_env_type == (1 if mode == 0 else 0)
@@ -143,7 +151,7 @@ def test_g12_product_train_test_agents_replays_the_reference_run(golden, tmp_pat
         pre = "a%d_" % i
         np.testing.assert_allclose(last["reward_train"][i], g[pre + "reward_train"], rtol=0, atol=1e-4)
         assert last["episode_length"][i] == g[pre + "episode_length"].tolist()
-        ocfg, _, _ = g12_oracle_cfg(g, i, grad_chunk=last["inner"].cfg.grad_chunk)
+        ocfg, _, _ = g12_oracle_cfg(g, i, grad_chunk=last["inner"].cfg.grad_chunk, dueling="dueling" in name)
         o = orc.ddqn_se_chain(ocfg, g["theta"], g[pre + "agent_init"], tapes=orc.make_tapes(*g12_tapes(g, i)))
         assert rewards[i] == o["final_test_returns"].tolist()
         assert last["reward_train"][i] == o["episode_test_mean"][:o["episodes_run"]].tolist()
