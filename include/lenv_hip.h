@@ -45,7 +45,8 @@ enum { LENV_RNG_COUNTER = 0, LENV_RNG_TAPE = 1 };
  * the parity tests that hold the kernels against each other -- every variant produces the same bits):
  * NO_WAVECHAIN keeps the GEMM-queue kernel where a wave-chain kernel exists, GENERIC skips the shape-specialised instantiations,
  * TEAM_NARROW keeps whole forward items per lane in DDQN teams of three and more (default there: every item cut over the idle lanes). */
-enum { LENV_VARIANT_NO_WAVECHAIN = 1, LENV_VARIANT_GENERIC = 2, LENV_VARIANT_TEAM_NARROW = 4 };
+enum { LENV_VARIANT_NO_WAVECHAIN = 1, LENV_VARIANT_GENERIC = 2, LENV_VARIANT_TEAM_NARROW = 4,
+       LENV_VARIANT_NO_DIRECT = 8 };   /* NO_DIRECT: the GEMM-queue kernels keep narrow nets on the product queue too (A/B timing, kernel-vs-kernel tests) */
 
 /* models/model_utils.py:4-39 */
 typedef struct {

@@ -10,7 +10,7 @@ CSRC = os.path.join(_HERE, "csrc")
 ACT = {"identity": 0, "relu": 1, "leakyrelu": 2, "tanh": 3, "prelu": 4}
 ENV = {"CartPole-v0": 0, "Acrobot-v1": 1, "HalfCheetah-v3": 2, "MountainCar-v0": 3, "Pendulum-v0": 4, "MountainCarContinuous-v0": 5}
 RNG_COUNTER, RNG_TAPE = 0, 1
-VARIANT_NO_WAVECHAIN, VARIANT_GENERIC, VARIANT_TEAM_NARROW = 1, 2, 4     # lenv_ddqn_cfg / lenv_td3_cfg kernel_variant bits (A/B timing, kernel-vs-kernel parity tests)
+VARIANT_NO_WAVECHAIN, VARIANT_GENERIC, VARIANT_TEAM_NARROW, VARIANT_NO_DIRECT = 1, 2, 4, 8     # lenv_ddqn_cfg / lenv_td3_cfg kernel_variant bits (A/B timing, kernel-vs-kernel parity tests)
 STATUS_TEAM_GAVE_UP = -10                        # a team member waited too long for the others: repeat the launch with team_size 1
 
 ERRORS = {-1: ValueError, -2: NotImplementedError, -3: ValueError, -4: RuntimeError, -5: RuntimeError}

@@ -14,6 +14,8 @@
 // step (phi(s') of step t is phi(s) of step t+1).  Gaussian noises come from RNG tapes (parity mode) or from the
 // counter RNG through a Box-Muller with deterministic log / cos (production mode).
 #include "lenv_gemm.cuh"
+
+#include <type_traits>
 #include "lenv_ln.cuh"
 #include "lenv_icm.cuh"
 #include "lenv_wavechain_host.h"
@@ -24,6 +26,7 @@ constexpr int T3_MAXL = 3;     // hidden layers of actor / critic (TD3_vary draw
 constexpr int T3_MAXW = 512;   // max hidden_size (outputs wider than 128 run as several 128-column blocks)
 constexpr int T3_MAXB = 768;   // max batch size  (more than 256 rows run as several row blocks; 768 = 3 x the shipped 256)
 constexpr int T3_MAXI = 256;   // rows of one product block
+constexpr int T3_DIRECT_H = 64, T3_DIRECT_B = 256;   // the DIRECT instantiations: one hidden layer of at most 64 units, batch <= 256 (see the kernel)
 // observation / action dims come from the env (ContEnv<ENV> in lenv_device.cuh): the stand-in 17 / 6, Pendulum-v0 3 / 1
 
 struct MlpOff { int in, H, L, out; int oW[T3_MAXL + 1], ob[T3_MAXL + 1]; int P; int ln, oLN; };      // ln: the net's shared LayerNorm (weight | bias at oLN, behind the second Linear)
@@ -67,11 +70,16 @@ struct Td3Args {
 // Diagnostic build only (-DLENV_PHASE_TIMING): per-phase shader-clock totals of chain 0, never in the shipped library.
 #ifdef LENV_PHASE_TIMING
 __device__ unsigned long long g_td3_phase_cycles[16];
+__device__ unsigned long long g_t3d_sub_cycles[16];      // sub-phases of t3_direct_critics (thread 0 of chain 0)
+#define T3D_SUB_DECL unsigned long long sb_last = __builtin_readcyclecounter()
+#define T3D_SUB(i) do { unsigned long long sb_now = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) g_t3d_sub_cycles[i] += sb_now - sb_last; sb_last = sb_now; } while (0)
 #define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PT_MARK(i) do { unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
 #else
 #define PT_DECL
 #define PT_MARK(i)
+#define T3D_SUB_DECL
+#define T3D_SUB(i)
 #endif
 
 // SHAPE 1 = the published HalfCheetah RewardEnv + TD3 configuration (default_config_halfcheetah_reward_env.yaml = BASELINE
@@ -87,9 +95,329 @@ constexpr Td3Shape kTd3Shapes[] = {
     { LENV_ENV_CMC, 128, 2, 192, 1, 128, 1, LENV_ACT_TANH, 2, LENV_ACT_LEAKYRELU, 1, 0, 2 },              // 4: default_config_cmc_reward_env.yaml
 };
 
-template <bool ICM, int ENV, int SHAPE = 0>
+// ---- the DIRECT learn step (see the comment in front of the kernel): out-of-line routines with their own register allocation -- inlined into the
+// kernel body they drowned in its scalar-register spills (3 000 v_readlane in the instantiation, 15-25 k cycles per forward pass) ----
+struct T3DirectCtx {                           // in LDS, written by thread 0 before every learn step, re-read by the routines
+    float *params, *targets, *grad, *xc, *xn;               // the chain's arena
+    float *l_act, *l_x, *l_na, *l_w;                         // LDS work areas: activations [B][H + 1], rows [B][SA], actions [B][A], two staged nets
+    float *rr, *dd, *q1, *q2, *tq1, *tq2, *dq1, *dq2;        // LDS vectors [B]
+    const float *policy_noise; int64_t policy_noise_rows;    // the chain's tape rows (null: counter RNG)
+    uint64_t key;
+    int H, B, act_id, Pa, Pc;
+    float prelu, ma, g32, policy_std, policy_clip;
+};
+
+// one sample through a one-hidden-layer net whose state-dict-order parameters sit in LDS at w (wave-uniform addresses: broadcast reads): outputs
+// to o, the hidden activations (optionally) to the sample's row of the activation matrix.  Units in blocks of eight: a block's weights are
+// requested before its first fmaf.
+// (STORE, not a null test of hrow: the activation matrix starts at LDS address 0, which IS the null pointer of address space 3 in an icmp --
+// sample 0's row was silently skipped)
+template <int ACT, int IN, int OUT, bool STORE>
+__device__ __forceinline__ void t3d_net_fwd(const lfloat *w, int H, float prelu, const float (&xr)[IN], lfloat *hrow, float (&o)[OUT])
+{
+    const lfloat *W0 = w, *b0 = w + H * IN, *Wo = b0 + H, *bo = Wo + OUT * H;
+    float acc[OUT];
+#pragma unroll
+    for (int c = 0; c < OUT; ++c) acc[c] = 0.0f;
+#ifndef T3D_JB
+#define T3D_JB 8
+#endif
+    constexpr int JB = T3D_JB;
+#pragma unroll 1
+    for (int j0 = 0; j0 < H; j0 += JB) {
+        float w0[JB][IN], bv[JB], wo[OUT][JB];
+#pragma unroll
+        for (int u = 0; u < JB; ++u) {
+            const int j = j0 + u < H ? j0 + u : H - 1;            // (clamped reads past the last unit, unused)
+#pragma unroll
+            for (int k = 0; k < IN; ++k) w0[u][k] = W0[j * IN + k];
+            bv[u] = b0[j];
+#pragma unroll
+            for (int c = 0; c < OUT; ++c) wo[c][u] = Wo[c * H + j];
+        }
+#pragma unroll
+        for (int u = 0; u < JB; ++u) {
+            if (j0 + u < H) {
+                float z = 0.0f;
+#pragma unroll
+                for (int k = 0; k < IN; ++k) z = fma32(xr[k], w0[u][k], z);
+                z = z + bv[u];
+                const float hj = act_fwd(ACT, prelu, z);       // (ACT is a template parameter: a run-time switch here cost six scalar branches per unit, 35 k cycles per pass)
+                if constexpr (STORE) hrow[j0 + u] = hj;
+#pragma unroll
+                for (int c = 0; c < OUT; ++c) acc[c] = fma32(hj, wo[c][u], acc[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < OUT; ++c) o[c] = acc[c] + bo[c];
+}
+// sum_{i < B} p[i * sp] * q[i * sq] as ONE i-ascending chain from 0 (both operands in LDS), sixteen pairs in flight
+__device__ __forceinline__ float t3d_batch_dot(const lfloat *pp, int sp, const lfloat *qq, int sq, int B)
+{
+    float acc = 0.0f;
+    int i = 0;
+    for (; i + 16 <= B; i += 16) {
+        float pv[16], qv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { pv[u] = pp[(i + u) * sp]; qv[u] = qq[(i + u) * sq]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = fma32(pv[u], qv[u], acc);
+    }
+    for (; i < B; ++i) acc = fma32(pp[i * sp], qq[i * sq], acc);
+    return acc;
+}
+__device__ __forceinline__ float t3d_batch_sum(const lfloat *pp, int sp, int B)      // plain adds, i ascending (the bias gradients' column sums)
+{
+    float acc = 0.0f;
+    int i = 0;
+    for (; i + 16 <= B; i += 16) {
+        float pv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) pv[u] = pp[(i + u) * sp];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = acc + pv[u];
+    }
+    for (; i < B; ++i) acc = acc + pp[i * sp];
+    return acc;
+}
+__device__ __forceinline__ void t3d_stage(const float *src, int n, lfloat *dst, int tid) { for (int i = tid; i < n; i += DNT) dst[i] = src[i]; }
+
+// TD3.learn up to the critics' gradients (TD3.py:63-95): smoothed target actions, target critics, TD error, both critics' gradients into
+// ctx->grad.  Returns non-zero on a policy-noise tape underrun.  Thread b & 255 owns minibatch sample b; half h = tid >> 8 runs critic h
+// where the two critics can go side by side.
+template <int S, int A, int ACT>
+__device__ __noinline__ int t3_direct_critics(const T3DirectCtx *ctx_, int64_t learn_it_)
+{
+    constexpr int SA = S + A;
+    typedef __attribute__((address_space(3))) const T3DirectCtx LCtx;
+    LCtx *c = (LCtx *)uni_ptr(ctx_);
+    const int tid = threadIdx.x, half = uni(tid >> 8), b = tid & 255;
+    const int H = uni(c->H), B = uni(c->B), Pa = uni(c->Pa), Pc = uni(c->Pc), HP1 = H + 1;
+    const float prelu = unif(c->prelu), ma = unif(c->ma), g32 = unif(c->g32);
+    const int64_t learn_it = learn_it_;
+    lfloat *l_act = (lfloat *)uni_ptr(c->l_act), *l_x = (lfloat *)uni_ptr(c->l_x), *l_na = (lfloat *)uni_ptr(c->l_na), *l_w = (lfloat *)uni_ptr(c->l_w);
+    lfloat *rr = (lfloat *)uni_ptr(c->rr), *dd = (lfloat *)uni_ptr(c->dd), *q1 = (lfloat *)uni_ptr(c->q1), *q2 = (lfloat *)uni_ptr(c->q2);
+    lfloat *tq1 = (lfloat *)uni_ptr(c->tq1), *tq2 = (lfloat *)uni_ptr(c->tq2), *dq1 = (lfloat *)uni_ptr(c->dq1), *dq2 = (lfloat *)uni_ptr(c->dq2);
+    const float *params = uni_ptr(c->params), *targets = uni_ptr(c->targets), *xc = uni_ptr(c->xc), *xn = uni_ptr(c->xn);
+    float *grad = uni_ptr(c->grad);
+    const bool live = b < B;
+    lfloat *myrow = l_act + b * HP1;
+    int bad = 0;
+    T3D_SUB_DECL;
+    // ---- next_actions = (actor_target(s') + clamp(randn * policy_std)).clamp(-max, max)  (TD3.py:72-78) ----
+    t3d_stage(targets, Pa, l_w, tid);
+    __syncthreads();
+    T3D_SUB(0);
+    if (half == 0 && live) {
+        float xr[S], o[A];
+#pragma unroll
+        for (int k = 0; k < S; ++k) xr[k] = xn[b * SA + k];
+        t3d_net_fwd<ACT, S, A, false>(l_w, H, prelu, xr, l_w, o);
+        const float *tape = uni_ptr(c->policy_noise);
+        const float pstd = unif(c->policy_std), clipv = unif(c->policy_clip);
+        const uint64_t key = c->key;
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            const float v0 = det_tanhf(lenv_tanh_table, o[k]) * ma;
+            const int64_t n = (learn_it * B + b) * A + k;
+            float zn;
+            if (tape) { if (n >= c->policy_noise_rows * A) { bad = 1; zn = 0.0f; } else zn = tape[n]; }
+            else zn = (float)det_normal(key, STREAM_TD3_POLICY_NOISE, (uint64_t)n);
+            float nz = zn * pstd;
+            nz = nz < -clipv ? -clipv : (nz > clipv ? clipv : nz);
+            const float v = v0 + nz;
+            l_na[b * A + k] = v < -ma ? -ma : (v > ma ? ma : v);
+        }
+    }
+    __syncthreads();
+    T3D_SUB(1);
+    // ---- the target critics on (s', next_actions): half h runs critic h  (TD3.py:80-82) ----
+    t3d_stage(targets + Pa, 2 * Pc, l_w, tid);
+    __syncthreads();
+    T3D_SUB(2);
+    if (live) {
+        float xr[SA], o[1];
+#pragma unroll
+        for (int k = 0; k < S; ++k) xr[k] = xn[b * SA + k];
+#pragma unroll
+        for (int k = 0; k < A; ++k) xr[S + k] = l_na[b * A + k];
+        t3d_net_fwd<ACT, SA, 1, false>(l_w + half * Pc, H, prelu, xr, l_w, o);
+        (half ? tq2 : tq1)[b] = o[0];
+    }
+    __syncthreads();
+    T3D_SUB(3);
+    // ---- the online critics on (s, a), TD error (TD3.py:84-91): half h runs critic h ----
+    t3d_stage(params + Pa, 2 * Pc, l_w, tid);
+    __syncthreads();
+    T3D_SUB(4);
+    float xcr[SA];
+#pragma unroll
+    for (int k = 0; k < SA; ++k) xcr[k] = live ? xc[b * SA + k] : 0.0f;
+    if (live) {
+        float o[1];
+        t3d_net_fwd<ACT, SA, 1, false>(l_w + half * Pc, H, prelu, xcr, l_w, o);
+        (half ? q2 : q1)[b] = o[0];
+        if (half == 0) {
+#pragma unroll
+            for (int k = 0; k < SA; ++k) l_x[b * SA + k] = xcr[k];
+        }
+    }
+    __syncthreads();
+    T3D_SUB(5);
+    if (live) {
+        const float norm = (float)(2.0 / (double)B);
+        const float tq = tq1[b] < tq2[b] ? tq1[b] : tq2[b];
+        const float y = rr[b] + ((1.0f - dd[b]) * g32) * tq;       // rewards + (1 - dones) * gamma * target_Q
+        if (half == 0) dq1[b] = norm * (q1[b] - y);
+        else dq2[b] = norm * (q2[b] - y);
+    }
+    __syncthreads();
+    T3D_SUB(6);
+    // ---- critic gradients, one critic after the other through the activation matrix (its forward pass once more, into the rows) ----
+    const int oW0 = 0, ob0 = H * SA, oWo = ob0 + H, obo = oWo + H;      // state-dict offsets of a one-hidden-layer critic (mlp_off)
+#pragma unroll 1
+    for (int cc = 0; cc < 2; ++cc) {
+        const lfloat *dqv = cc ? dq2 : dq1;
+        float *gcr = grad + Pa + cc * Pc;
+        const lfloat *Wo = l_w + cc * Pc + oWo;
+        if (half == 0 && live) { float o[1]; t3d_net_fwd<ACT, SA, 1, true>(l_w + cc * Pc, H, prelu, xcr, myrow, o); }
+        __syncthreads();
+        T3D_SUB(8);
+    T3D_SUB(7);
+        // output layer: gWout[j] = sum_i dq[i] h[i][j], gbout = sum_i dq[i]
+        if (tid < H) gcr[oWo + tid] = t3d_batch_dot(dqv, 1, l_act + tid, HP1, B);
+        else if (tid == H) gcr[obo] = t3d_batch_sum(dqv, 1, B);
+        __syncthreads();
+        T3D_SUB(9);
+    T3D_SUB(8);
+        // hidden gradient in place: act'(h) * (dq * Wout[j])   (the queued product's single k-step: fma(dq, W, +0))
+        if (half == 0 && live) {
+            const float dq = dqv[b];
+#pragma unroll 8
+            for (int j = 0; j < H; ++j) myrow[j] = act_bwd(ACT, prelu, myrow[j], fma32(dq, Wo[j], 0.0f));
+        }
+        __syncthreads();
+        T3D_SUB(10);
+    T3D_SUB(9);
+        // first layer: gW0[j][k] = sum_i dz[i][j] x[i][k], gb0[j] = sum_i dz[i][j]
+        for (int pp = tid; pp < H * SA + H; pp += DNT) {
+            if (pp < H * SA) { const int j = pp / SA, k = pp - j * SA; gcr[oW0 + pp] = t3d_batch_dot(l_act + j, HP1, l_x + k, SA, B); }
+            else { const int j = pp - H * SA; gcr[ob0 + j] = t3d_batch_sum(l_act + j, HP1, B); }
+        }
+        __syncthreads();
+        T3D_SUB(11);
+    T3D_SUB(10);
+    }
+    return bad;
+}
+
+// the delayed policy update's gradients (TD3.py:101-110): actor_loss = (-critic_1(states, actor(states))).mean() with the UPDATED critic_1,
+// the actor's gradient into ctx->grad
+template <int S, int A, int ACT>
+__device__ __noinline__ void t3_direct_actor(const T3DirectCtx *ctx_)
+{
+    constexpr int SA = S + A;
+    typedef __attribute__((address_space(3))) const T3DirectCtx LCtx;
+    LCtx *c = (LCtx *)uni_ptr(ctx_);
+    const int tid = threadIdx.x, half = uni(tid >> 8), b = tid & 255;
+    const int H = uni(c->H), B = uni(c->B), Pa = uni(c->Pa), Pc = uni(c->Pc), HP1 = H + 1;
+    const float prelu = unif(c->prelu), ma = unif(c->ma);
+    lfloat *l_act = (lfloat *)uni_ptr(c->l_act), *l_x = (lfloat *)uni_ptr(c->l_x), *l_na = (lfloat *)uni_ptr(c->l_na), *l_w = (lfloat *)uni_ptr(c->l_w);
+    const float *params = uni_ptr(c->params), *xc = uni_ptr(c->xc);
+    float *grad = uni_ptr(c->grad);
+    const bool live = b < B;
+    lfloat *myrow = l_act + b * HP1;
+    const int oW0 = 0, ob0 = H * S, oWo = ob0 + H, obo = oWo + A * H;  // state-dict offsets of the one-hidden-layer actor
+    t3d_stage(params, Pa + Pc, l_w, tid);                              // actor | critic_1 (contiguous in the parameter vector)
+    __syncthreads();
+    float dza[A];
+#pragma unroll
+    for (int k = 0; k < A; ++k) dza[k] = 0.0f;
+    if (half == 0 && live) {
+        float xr[SA], xs[S], o[A], th[A];
+#pragma unroll
+        for (int k = 0; k < S; ++k) { xs[k] = xc[b * SA + k]; xr[k] = xs[k]; }
+        t3d_net_fwd<ACT, S, A, true>(l_w, H, prelu, xs, myrow, o);          // the actor's activations stay in the sample's row
+#pragma unroll
+        for (int k = 0; k < A; ++k) { th[k] = det_tanhf(lenv_tanh_table, o[k]); xr[S + k] = th[k] * ma; }
+        // critic_1 forward on (s, actor(s)) and, unit by unit, its backward down to the action inputs: dq = -1/B per sample,
+        // dz1[j] = act'(h1[j]) * (dq * Wout[j]), dx[k] = sum_j dz1[j] W0[j][S + k]  (j ascending)
+        const float dqa = -(1.0f / (float)B);
+        const lfloat *W0c = l_w + Pa, *b0c = W0c + H * SA, *Woc = b0c + H;
+        float dx[A];
+#pragma unroll
+        for (int k = 0; k < A; ++k) dx[k] = 0.0f;
+#pragma unroll 1
+        for (int j0 = 0; j0 < H; j0 += 8) {
+            float w0[8][SA], bv[8], wo[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u < H ? j0 + u : H - 1;
+#pragma unroll
+                for (int k = 0; k < SA; ++k) w0[u][k] = W0c[j * SA + k];
+                bv[u] = b0c[j]; wo[u] = Woc[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j0 + u < H) {
+                    float z = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < SA; ++k) z = fma32(xr[k], w0[u][k], z);
+                    z = z + bv[u];
+                    const float dz1 = act_bwd(ACT, prelu, act_fwd(ACT, prelu, z), fma32(dqa, wo[u], 0.0f));
+#pragma unroll
+                    for (int k = 0; k < A; ++k) dx[k] = fma32(dz1, w0[u][S + k], dx[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            dza[k] = (dx[k] * ma) * fma32(-th[k], th[k], 1.0f);       // d(tanh(z)*max_action)
+            l_na[b * A + k] = dza[k];
+        }
+#pragma unroll
+        for (int k = 0; k < S; ++k) l_x[b * S + k] = xs[k];
+    }
+    __syncthreads();
+    // actor output layer: gWout[c][j] = sum_i dza[i][c] h[i][j], gbout[c] = sum_i dza[i][c]
+    for (int pp = tid; pp < A * H + A; pp += DNT) {
+        if (pp < A * H) { const int cidx = pp / H, j = pp - cidx * H; grad[oWo + pp] = t3d_batch_dot(l_na + cidx, A, l_act + j, HP1, B); }
+        else { const int cidx = pp - A * H; grad[obo + cidx] = t3d_batch_sum(l_na + cidx, A, B); }
+    }
+    __syncthreads();
+    if (half == 0 && live) {
+        const lfloat *Woa = l_w + oWo;
+#pragma unroll 2
+        for (int j = 0; j < H; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int cidx = 0; cidx < A; ++cidx) acc = fma32(dza[cidx], Woa[cidx * H + j], acc);
+            myrow[j] = act_bwd(ACT, prelu, myrow[j], acc);
+        }
+    }
+    __syncthreads();
+    for (int pp = tid; pp < H * S + H; pp += DNT) {
+        if (pp < H * S) { const int j = pp / S, k = pp - j * S; grad[oW0 + pp] = t3d_batch_dot(l_act + j, HP1, l_x + k, S, B); }
+        else { const int j = pp - H * S; grad[ob0 + j] = t3d_batch_sum(l_act + j, HP1, B); }
+    }
+    __syncthreads();
+}
+
+// DIRECT (round 6) = launches whose agent nets have ONE hidden layer of at most T3_DIRECT_H units, no LayerNorm, no ICM, batch <= T3_DIRECT_B
+// (default_config_cmc_syn_env_opt.yaml's TD3, the narrow draws of td3_vary): TD3.learn without the product queue.  A queued product costs ~18 k
+// cycles whatever its size (staging through LDS, workgroup barriers, a global round trip between products: profiles/r05_generic_shapes.log --
+// 456 us per learn step for a 64-wide TD3).  Here ONE THREAD OWNS ONE MINIBATCH SAMPLE: it runs the sample's forward passes with the nets'
+// weights broadcast from LDS (the hidden activations stay in its registers), forms the TD target and the per-sample output gradients; the batch
+// sums of the parameter gradients then run as one i-ascending chain per parameter over an LDS copy of the activations ([B][H + 1]: the odd row
+// stride keeps writers = samples and readers = units conflict-free).  Every chain is the queued product's own k- / i-ascending fmaf chain from 0
+// with the epilogues' bias / activation / derivative arithmetic, so the bits are those of the GEMM-queue path and of the oracle.  Its own
+// instantiations: as a run-time branch next to the queued learn step the extra live state pushed the Pendulum instantiation into SGPR spills, where
+// the ROCm 7.2 backend emits an illegal VALU compare on the LDS aperture register.
+template <bool ICM, int ENV, int SHAPE = 0, bool DIRECT = false>
 __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
 {
+    static_assert(!DIRECT || (SHAPE == 0 && !ICM && DNT == 512), "the DIRECT instantiations: generic shapes, no ICM, two 256-thread halves");
     using EnvT = ContEnv<ENV>;
     constexpr bool FIXED = SHAPE != 0;
     constexpr Td3Shape kTd3Shape = kTd3Shapes[SHAPE];
@@ -675,6 +1003,54 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     icm_train_and_reward<T3_MAXI>(st, [&](int b, int i) { return xc[b * SA + S + i]; }, [&](int b, float r) { rr[b] = rr[b] + r; });
                 }
                 PT_MARK(1);                               // replay gather
+                if constexpr (DIRECT) {
+                    // ================= TD3.learn, DIRECT (t3_direct_critics / t3_direct_actor above the kernel) =================
+                    // the context record sits behind the work areas in the queue's staging buffers (which the test phases' products overwrite):
+                    // thread 0 writes it at every learn step
+                    T3DirectCtx *dctx = reinterpret_cast<T3DirectCtx *>(Ps + ((B * (H + 1) + B * SA + B * A + 2 * (Pa > Pc ? Pa : Pc) + 3) & ~3));
+                    if (tid == 0) {
+                        T3DirectCtx d;
+                        d.params = params; d.targets = targets; d.grad = grad; d.xc = xc; d.xn = xn;
+                        d.l_act = Ps; d.l_x = d.l_act + B * (H + 1); d.l_na = d.l_x + B * SA; d.l_w = d.l_na + B * A;
+                        d.rr = rr; d.dd = dd; d.q1 = q1; d.q2 = q2; d.tq1 = tq1; d.tq2 = tq2; d.dq1 = dq1; d.dq2 = dq2;
+                        d.policy_noise = tape ? a.tapes.policy_noise + chain * a.tapes.policy_noise_stride * A : nullptr;
+                        d.policy_noise_rows = tape ? a.tapes.policy_noise_stride : 0;
+                        d.H = H; d.B = B; d.act_id = act_id; d.Pa = Pa; d.Pc = Pc;
+                        d.prelu = prelu; d.ma = ma; d.g32 = g32; d.policy_std = (float)cfg.policy_std; d.policy_clip = (float)cfg.policy_std_clip;
+                        d.key = key;
+                        *dctx = d;
+                    }
+                    __syncthreads();
+                    // (the routines carry the activation as a template parameter: one uniform switch per call instead of one per hidden unit)
+                    int dbad = 0;
+                    switch (act_id) {
+                    case LENV_ACT_RELU: dbad = t3_direct_critics<S, A, LENV_ACT_RELU>(dctx, learn_it); break;
+                    case LENV_ACT_LEAKYRELU: dbad = t3_direct_critics<S, A, LENV_ACT_LEAKYRELU>(dctx, learn_it); break;
+                    case LENV_ACT_TANH: dbad = t3_direct_critics<S, A, LENV_ACT_TANH>(dctx, learn_it); break;
+                    case LENV_ACT_PRELU: dbad = t3_direct_critics<S, A, LENV_ACT_PRELU>(dctx, learn_it); break;
+                    default: dbad = t3_direct_critics<S, A, LENV_ACT_IDENTITY>(dctx, learn_it); break;
+                    }
+                    if (dbad) status = -8;
+                    PT_MARK(5);
+                    adam(Pa, 2 * Pc, 0);                       // critic_optimizer: critic_1 then critic_2 parameters
+                    PT_MARK(6);
+                    ++learn_it;
+                    if (learn_it % policy_delay == 0) {
+                        switch (act_id) {
+                        case LENV_ACT_RELU: t3_direct_actor<S, A, LENV_ACT_RELU>(dctx); break;
+                        case LENV_ACT_LEAKYRELU: t3_direct_actor<S, A, LENV_ACT_LEAKYRELU>(dctx); break;
+                        case LENV_ACT_TANH: t3_direct_actor<S, A, LENV_ACT_TANH>(dctx); break;
+                        case LENV_ACT_PRELU: t3_direct_actor<S, A, LENV_ACT_PRELU>(dctx); break;
+                        default: t3_direct_actor<S, A, LENV_ACT_IDENTITY>(dctx); break;
+                        }
+                        PT_MARK(7);                           // policy update: forwards + backwards
+                        adam(0, Pa, 2);
+                        const float tau = (float)cfg.tau, omt = (float)(1.0 - cfg.tau);
+                        wg_polyak(params, targets, P, tau, omt);
+                        __syncthreads();
+                        PT_MARK(8);                           // actor adam + polyak
+                    }
+                } else {
                 // next_actions = (actor_target(s') + clamp(randn*policy_std)).clamp(-max, max)
                 mlp_forward(targets, mo_actor, xn, SA, B, ht, xn, SA, S, true, nullptr);
                 gq.run<T3_MAXI>(Ps, Qs);
@@ -743,6 +1119,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     __syncthreads();
                     PT_MARK(8);                           // actor adam + polyak
                 }
+                }       // (the queued learn step)
             }
             if (done_now > 0.5f) break;
         }
@@ -1035,9 +1412,20 @@ extern "C" int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg, const lenv_ch
     a.hp_hidden = hp ? hp->q_hidden : nullptr; a.hp_layers = hp ? hp->q_layers : nullptr;
     a.icm_init = cfg->icm_enabled ? icm->icm_init : nullptr; a.icm_final = cfg->icm_enabled ? icm->icm_final : nullptr;
     void (*kern)(const Td3Args) = nullptr;
-    if (cfg->env_id == LENV_ENV_PENDULUM) kern = cfg->icm_enabled ? td3_rn_inner_kernel<true, LENV_ENV_PENDULUM> : td3_rn_inner_kernel<false, LENV_ENV_PENDULUM>;
-    else if (cfg->env_id == LENV_ENV_CMC) kern = cfg->icm_enabled ? td3_rn_inner_kernel<true, LENV_ENV_CMC> : td3_rn_inner_kernel<false, LENV_ENV_CMC>;
-    else kern = cfg->icm_enabled ? td3_rn_inner_kernel<true, LENV_ENV_CHEETAH_STANDIN> : td3_rn_inner_kernel<false, LENV_ENV_CHEETAH_STANDIN>;
+    // narrow one-hidden-layer agent nets (every chain's: cfg carries the maxima of a *_vary launch) without LayerNorm / ICM whose activation
+    // matrix fits the idle staging buffers: the DIRECT instantiations (kernel_variant NO_DIRECT keeps the product queue: A/B runs, tests)
+    bool direct = false;
+    {
+        const int S = cfg->state_dim, A = cfg->action_dim, H = cfg->hidden, B = cfg->batch_size;
+        const int64_t Pa_ = (int64_t)S * H + H + (int64_t)A * H + A, Pc_ = (int64_t)(S + A) * H + H + H + 1;      // one hidden layer
+        const int64_t staged = 2 * (Pa_ > Pc_ ? Pa_ : Pc_);                                                          // two nets at a time
+        const int64_t need = (int64_t)B * (H + 1) + (int64_t)B * (S + A) + (int64_t)B * A + staged + 4 + (int64_t)(sizeof(T3DirectCtx) + 3) / 4;   // + the context record
+        direct = !cfg->icm_enabled && !cfg->use_layer_norm && cfg->layers == 1 && H <= T3_DIRECT_H && B <= T3_DIRECT_B && !(cfg->kernel_variant & LENV_VARIANT_NO_DIRECT) &&
+                 need <= (int64_t)(GemmShape<T3_MAXI>::PS_FLOATS + GemmShape<T3_MAXI>::QS_FLOATS);
+    }
+    if (cfg->env_id == LENV_ENV_PENDULUM) kern = cfg->icm_enabled ? td3_rn_inner_kernel<true, LENV_ENV_PENDULUM> : (direct ? td3_rn_inner_kernel<false, LENV_ENV_PENDULUM, 0, true> : td3_rn_inner_kernel<false, LENV_ENV_PENDULUM>);
+    else if (cfg->env_id == LENV_ENV_CMC) kern = cfg->icm_enabled ? td3_rn_inner_kernel<true, LENV_ENV_CMC> : (direct ? td3_rn_inner_kernel<false, LENV_ENV_CMC, 0, true> : td3_rn_inner_kernel<false, LENV_ENV_CMC>);
+    else kern = cfg->icm_enabled ? td3_rn_inner_kernel<true, LENV_ENV_CHEETAH_STANDIN> : (direct ? td3_rn_inner_kernel<false, LENV_ENV_CHEETAH_STANDIN, 0, true> : td3_rn_inner_kernel<false, LENV_ENV_CHEETAH_STANDIN>);
     {
         // the published HalfCheetah RewardEnv + TD3 shape in production form takes the shape-specialised instantiation
         const bool off = (cfg->kernel_variant & LENV_VARIANT_GENERIC) != 0;
@@ -1069,6 +1457,7 @@ extern "C" int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg, const lenv_ch
 namespace lenv { __global__ void td3_phase_dummy() {} }
 extern "C" int lenv_debug_td3_phase_cycles(unsigned long long *host_out)
 {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_td3_phase_cycles), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_td3_phase_cycles), sizeof(unsigned long long) * 16) != hipSuccess) return -4;
+    return hipMemcpyFromSymbol(host_out + 16, HIP_SYMBOL(lenv::g_t3d_sub_cycles), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;      // (callers pass 32 words)
 }
 #endif

@@ -153,10 +153,15 @@ if __name__ == "__main__":
                 run("CartPole RewardEnv + DDQN 4-64-2 pop %d (6 episodes), %s" % (pop, label), c, gens=2, force_gemm=force)
     if "cmc_opt_td3" in which:
         # default_config_cmc_syn_env_opt.yaml-like: TD3 with ONE 64-wide hidden layer on a VirtualEnv of three 3-128-128-128-x nets, B = 256
-        c = configs.fixed_work(configs.cmc_syn_env_td3(16), 3)
-        c["agents"]["td3"].update(init_episodes=1, hidden_size=64, hidden_layer=1, activation_fn="leakyrelu")
-        c["envs"]["MountainCarContinuous-v0"].update(max_steps=200, hidden_size=128, hidden_layer=3, activation_fn="relu")
-        run("MountainCarContinuous SE 128x3 + TD3 64x1 (B 256) pop 16 (3 episodes x 100 agent steps), GEMM-queue kernel", c, gens=2)
+        # round 6: the DIRECT instantiation (narrow nets skip the product queue), then the queued path (gtn.kernel_variant = NO_DIRECT)
+        from learning_environments_amd import _lib
+        for pop in (16, 64):
+            for variant, label in ((0, "GEMM-queue kernel, DIRECT layer products"), (_lib.VARIANT_NO_DIRECT, "GEMM-queue kernel, queued products")):
+                c = configs.fixed_work(configs.cmc_syn_env_td3(pop), 3)
+                c["agents"]["td3"].update(init_episodes=1, hidden_size=64, hidden_layer=1, activation_fn="leakyrelu")
+                c["envs"]["MountainCarContinuous-v0"].update(max_steps=200, hidden_size=128, hidden_layer=3, activation_fn="relu")
+                c["agents"]["gtn"]["kernel_variant"] = variant
+                run("MountainCarContinuous SE 128x3 + TD3 64x1 (B 256) pop %d (3 episodes x 100 agent steps), %s" % (pop, label), c, gens=2)
     if "td3d" in which:
         # TD3_discrete_vary as the syn-env YAMLs ship it (510-wide tanh nets, batch 122, hard Gumbel softmax) on an Acrobot SE
         c = configs.fixed_work(configs.acrobot_syn_env_td3_discrete(32), 3)

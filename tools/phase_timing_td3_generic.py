@@ -27,7 +27,7 @@ def run(label, c):
     m.step(0)
     torch.cuda.synchronize()
     t0 = time.time(); m.step(1); torch.cuda.synchronize(); dt = time.time() - t0
-    buf = (C.c_ulonglong * 16)()
+    buf = (C.c_ulonglong * 32)()
     _lib.lib().lenv_debug_td3_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
     assert _lib.lib().lenv_debug_td3_phase_cycles(buf) == 0
     st = m.inner.stats[0].tolist()
@@ -37,6 +37,13 @@ def run(label, c):
         per = buf[i] / max(1, st[2]) if 1 <= i <= 8 else (buf[i] / max(1, st[1]) if i == 0 else buf[i] / max(1, st[3]))
         print("  %-22s %12d cycles  %5.1f%%  %9.0f per %s" % (n, buf[i], 100.0 * buf[i] / max(1, tot), per,
                                                                "learn step" if 1 <= i <= 8 else ("env step" if i == 0 else "test step")))
+    sub = ["stage actor_t", "actor_t fwd + noise", "stage target critics", "target critics fwd", "stage critics", "critics fwd", "TD error",
+           "-", "recompute fwd into rows (x2)", "output-layer grads (x2)", "in-place dz (x2)", "first-layer grads (x2)"]
+    if any(buf[16 + i] for i in range(16)):
+        print("  t3_direct_critics sub-phases (thread 0 of chain 0), cycles per learn step:")
+        for i, n in enumerate(sub):
+            if buf[16 + i]:
+                print("    %-34s %9.0f" % (n, buf[16 + i] / max(1, st[2])))
 
 
 c = configs.fixed_work(configs.cmc_syn_env_td3(16), 3)
