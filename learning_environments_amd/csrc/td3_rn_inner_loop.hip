@@ -73,6 +73,7 @@ __device__ unsigned long long g_td3_phase_cycles[16];
 __device__ unsigned long long g_t3d_sub_cycles[16];      // sub-phases of t3_direct_critics (thread 0 of chain 0)
 #define T3D_SUB_DECL unsigned long long sb_last = __builtin_readcyclecounter()
 #define T3D_SUB(i) do { unsigned long long sb_now = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) g_t3d_sub_cycles[i] += sb_now - sb_last; sb_last = sb_now; } while (0)
+#define T3D_ENV_SUB(i) do { unsigned long long sb_now = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) g_t3d_sub_cycles[i] += sb_now - pt_last; } while (0)
 #define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PT_MARK(i) do { unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
 #else
@@ -80,6 +81,7 @@ __device__ unsigned long long g_t3d_sub_cycles[16];      // sub-phases of t3_dir
 #define PT_MARK(i)
 #define T3D_SUB_DECL
 #define T3D_SUB(i)
+#define T3D_ENV_SUB(i)
 #endif
 
 // SHAPE 1 = the published HalfCheetah RewardEnv + TD3 configuration (default_config_halfcheetah_reward_env.yaml = BASELINE
@@ -99,7 +101,7 @@ constexpr Td3Shape kTd3Shapes[] = {
 // kernel body they drowned in its scalar-register spills (3 000 v_readlane in the instantiation, 15-25 k cycles per forward pass) ----
 struct T3DirectCtx {                           // in LDS, written by thread 0 before every learn step, re-read by the routines
     float *params, *targets, *grad, *xc, *xn;               // the chain's arena
-    float *l_act, *l_x, *l_na, *l_w;                         // LDS work areas: activations [B][H + 1], rows [B][SA], actions [B][A], two staged nets
+    float *l_act, *l_x, *l_na, *l_w;                         // LDS work areas (t3d_layout): activations [H][257], rows [B][SA], actions [B][A], two staged nets
     float *rr, *dd, *q1, *q2, *tq1, *tq2, *dq1, *dq2;        // LDS vectors [B]
     const float *policy_noise; int64_t policy_noise_rows;    // the chain's tape rows (null: counter RNG)
     uint64_t key;
@@ -107,85 +109,204 @@ struct T3DirectCtx {                           // in LDS, written by thread 0 be
     float prelu, ma, g32, policy_std, policy_clip;
 };
 
-// one sample through a one-hidden-layer net whose state-dict-order parameters sit in LDS at w (wave-uniform addresses: broadcast reads): outputs
-// to o, the hidden activations (optionally) to the sample's row of the activation matrix.  Units in blocks of eight: a block's weights are
-// requested before its first fmaf.
-// (STORE, not a null test of hrow: the activation matrix starts at LDS address 0, which IS the null pointer of address space 3 in an icmp --
-// sample 0's row was silently skipped)
-template <int ACT, int IN, int OUT, bool STORE>
-__device__ __forceinline__ void t3d_net_fwd(const lfloat *w, int H, float prelu, const float (&xr)[IN], lfloat *hrow, float (&o)[OUT])
+// LDS work areas of the DIRECT learn step (floats from the start of the product queue's staging buffers), one definition for host and kernel:
+// the activation matrix is UNIT-MAJOR, [H][T3D_BP] with T3D_BP = 257: sample b writes h[j] at j * 257 + b (lanes = samples: consecutive banks), the
+// reduction for unit j walks its row at consecutive addresses (lanes = units: 257 = 1 mod 32 banks apart) -- every offset inside a block of units /
+// samples is an immediate of the ds instruction, whatever H is.  Staged nets start at multiples of four floats (ds_read_b128 of eight units' weights).
+constexpr int T3D_BP = T3_DIRECT_B + 1;
+struct T3DirectLayout { int x, na, w, w2_actor, w2_critic, ctx, total; };
+__host__ __device__ inline T3DirectLayout t3d_layout(int S, int A, int H, int B)
 {
-    const lfloat *W0 = w, *b0 = w + H * IN, *Wo = b0 + H, *bo = Wo + OUT * H;
-    float acc[OUT];
+    const int SA = S + A, Pa = S * H + H + A * H + A, Pc = SA * H + H + H + 1, PaA = (Pa + 3) & ~3, PcA = (Pc + 3) & ~3;
+    T3DirectLayout l;
+    l.x = H * T3D_BP; l.na = l.x + B * SA; l.w = (l.na + B * A + 3) & ~3;
+    l.w2_actor = PaA; l.w2_critic = PcA;                                   // second staged net: behind the actor / behind a critic
+    l.ctx = l.w + 2 * (PaA > PcA ? PaA : PcA);
+    l.total = l.ctx + (int)((sizeof(T3DirectCtx) + 3) / 4) + 4;
+    return l;
+}
+
+typedef float t3d_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const t3d_f4 t3d_lf4;
+template <int N> __device__ __forceinline__ void t3d_ld4(const lfloat *p, float (&d)[N])     // N floats from a 16-byte aligned LDS address
+{
+    static_assert(N % 4 == 0, "whole float4s");
+    t3d_lf4 *q = (t3d_lf4 *)p;
 #pragma unroll
-    for (int c = 0; c < OUT; ++c) acc[c] = 0.0f;
-#ifndef T3D_JB
-#define T3D_JB 8
-#endif
-    constexpr int JB = T3D_JB;
+    for (int i = 0; i < N / 4; ++i) { const t3d_f4 v = q[i]; d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w; }
+}
+
+// one sample through hidden units [j_lo, j_hi) of a one-hidden-layer net whose state-dict-order parameters sit in LDS at w (wave-uniform
+// addresses: broadcast reads): the output chains continue in acc (j ascending), the hidden activations go (STORE) to the sample's column of the
+// activation matrix.  Units in blocks: a block's weights are requested before its first fmaf.  FAST (H a multiple of eight, w 16-byte aligned,
+// j_lo / j_hi multiples of eight): eight units' weights are 2 IN + 2 + 2 OUT ds_read_b128 and no guard; otherwise clamped scalar reads + a guard
+// per unit (the run-time switch over the activation, six scalar branches per unit, cost 35 k cycles per pass: ACT is a template parameter).
+// (STORE, not a null test of hcol: the activation matrix starts at LDS address 0, which IS the null pointer of address space 3 in an icmp --
+// sample 0's activations were silently skipped)
+template <int ACT, int IN, int OUT, bool STORE, bool NEED_O, bool FAST>
+__device__ __forceinline__ void t3d_net_fwd_range(const lfloat *w, int H, float prelu, const float (&xr)[IN], lfloat *hcol, float (&acc)[OUT], int j_lo, int j_hi)
+{
+    constexpr int JB = IN <= 8 ? 8 : 4, NO = NEED_O ? OUT : 1;
+    const lfloat *W0 = w, *b0 = w + H * IN, *Wo = b0 + H;
 #pragma unroll 1
-    for (int j0 = 0; j0 < H; j0 += JB) {
-        float w0[JB][IN], bv[JB], wo[OUT][JB];
+    for (int j0 = j_lo; j0 < j_hi; j0 += JB) {
+        float w0[JB * IN], bv[JB], wo[NO][JB];
+        if constexpr (FAST) {
+            t3d_ld4<JB * IN>(W0 + j0 * IN, w0);
+            t3d_ld4<JB>(b0 + j0, bv);
+            if constexpr (NEED_O) {
 #pragma unroll
-        for (int u = 0; u < JB; ++u) {
-            const int j = j0 + u < H ? j0 + u : H - 1;            // (clamped reads past the last unit, unused)
+                for (int c = 0; c < OUT; ++c) t3d_ld4<JB>(Wo + c * H + j0, wo[c]);
+            }
+        } else {
 #pragma unroll
-            for (int k = 0; k < IN; ++k) w0[u][k] = W0[j * IN + k];
-            bv[u] = b0[j];
+            for (int u = 0; u < JB; ++u) {
+                const int j = j0 + u < j_hi ? j0 + u : j_hi - 1;      // (clamped reads past the last unit, unused)
 #pragma unroll
-            for (int c = 0; c < OUT; ++c) wo[c][u] = Wo[c * H + j];
+                for (int k = 0; k < IN; ++k) w0[u * IN + k] = W0[j * IN + k];
+                bv[u] = b0[j];
+                if constexpr (NEED_O) {
+#pragma unroll
+                    for (int c = 0; c < OUT; ++c) wo[c][u] = Wo[c * H + j];
+                }
+            }
         }
+        lfloat *hc = hcol + j0 * T3D_BP;
 #pragma unroll
         for (int u = 0; u < JB; ++u) {
-            if (j0 + u < H) {
+            if (FAST || j0 + u < j_hi) {
                 float z = 0.0f;
 #pragma unroll
-                for (int k = 0; k < IN; ++k) z = fma32(xr[k], w0[u][k], z);
+                for (int k = 0; k < IN; ++k) z = fma32(xr[k], w0[u * IN + k], z);
                 z = z + bv[u];
-                const float hj = act_fwd(ACT, prelu, z);       // (ACT is a template parameter: a run-time switch here cost six scalar branches per unit, 35 k cycles per pass)
-                if constexpr (STORE) hrow[j0 + u] = hj;
+                const float hj = act_fwd(ACT, prelu, z);
+                if constexpr (STORE) hc[u * T3D_BP] = hj;
+                if constexpr (NEED_O) {
 #pragma unroll
-                for (int c = 0; c < OUT; ++c) acc[c] = fma32(hj, wo[c][u], acc[c]);
+                    for (int c = 0; c < OUT; ++c) acc[c] = fma32(hj, wo[c][u], acc[c]);
+                }
             }
         }
     }
-#pragma unroll
-    for (int c = 0; c < OUT; ++c) o[c] = acc[c] + bo[c];
 }
-// sum_{i < B} p[i * sp] * q[i * sq] as ONE i-ascending chain from 0 (both operands in LDS), sixteen pairs in flight
-__device__ __forceinline__ float t3d_batch_dot(const lfloat *pp, int sp, const lfloat *qq, int sq, int B)
+template <int ACT, int IN, int OUT, bool STORE, bool NEED_O>
+__device__ __forceinline__ void t3d_net_fwd(const lfloat *w, int H, float prelu, const float (&xr)[IN], lfloat *hcol, float (&o)[OUT], int j_lo, int j_hi)
 {
-    float acc = 0.0f;
-    int i = 0;
-    for (; i + 16 <= B; i += 16) {
-        float pv[16], qv[16];
+    float acc[OUT];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { pv[u] = pp[(i + u) * sp]; qv[u] = qq[(i + u) * sq]; }
+    for (int c = 0; c < OUT; ++c) acc[c] = 0.0f;
+    if ((H & 7) == 0) t3d_net_fwd_range<ACT, IN, OUT, STORE, NEED_O, true>(w, H, prelu, xr, hcol, acc, j_lo, j_hi);
+    else t3d_net_fwd_range<ACT, IN, OUT, STORE, NEED_O, false>(w, H, prelu, xr, hcol, acc, j_lo, j_hi);
+    if constexpr (NEED_O) {
+        const lfloat *bo = w + H * IN + H + OUT * H;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc = fma32(pv[u], qv[u], acc);
+        for (int c = 0; c < OUT; ++c) o[c] = acc[c] + bo[c];
     }
-    for (; i < B; ++i) acc = fma32(pp[i * sp], qq[i * sq], acc);
+}
+// the hidden gradient in place, units [j_lo, j_hi) of one sample's column: h[j] <- act'(h[j]) * sum_c g[c] Wo[c][j]  (c ascending from +0: the
+// queued product's k-chain; one output = its single k-step fma(dq, W, +0))
+template <int ACT, int NC, bool FAST>
+__device__ __forceinline__ void t3d_dz_range(lfloat *hcol, const lfloat *Wo, int H, float prelu, const float (&g)[NC], int j_lo, int j_hi)
+{
+#pragma unroll 1
+    for (int j0 = j_lo; j0 < j_hi; j0 += 8) {
+        float hv[8], wo[NC][8];
+        lfloat *hc = hcol + j0 * T3D_BP;
+        if constexpr (FAST) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) hv[u] = hc[u * T3D_BP];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) t3d_ld4<8>(Wo + c * H + j0, wo[c]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u < j_hi ? j0 + u : j_hi - 1;
+                hv[u] = hcol[j * T3D_BP];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) wo[c][u] = Wo[c * H + j];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (FAST || j0 + u < j_hi) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc = fma32(g[c], wo[c][u], acc);
+                hc[u * T3D_BP] = act_bwd(ACT, prelu, hv[u], acc);
+            }
+        }
+    }
+}
+template <int ACT, int NC>
+__device__ __forceinline__ void t3d_dz(lfloat *hcol, const lfloat *Wo, int H, float prelu, const float (&g)[NC], int j_lo, int j_hi)
+{
+    if ((H & 7) == 0) t3d_dz_range<ACT, NC, true>(hcol, Wo, H, prelu, g, j_lo, j_hi);
+    else t3d_dz_range<ACT, NC, false>(hcol, Wo, H, prelu, g, j_lo, j_hi);
+}
+__device__ __forceinline__ int t3d_split(int H) { return (H & 7) == 0 ? (((H >> 3) + 1) >> 1) << 3 : (H + 1) >> 1; }     // units [0, split) to half 0, the rest to half 1
+
+// sum_{i < B} p[i * SP] * q[i * SQ] as ONE i-ascending chain from 0 (both operands in LDS; strides are literals: immediates), the next eight
+// pairs requested before the current eight are consumed
+template <int SP, int SQ>
+__device__ __forceinline__ float t3d_batch_dot(const lfloat *pp, const lfloat *qq, int B)
+{
+    // two register blocks of eight pairs, refilled alternately (a "next -> current" copy at the end of an iteration made the compiler wait for
+    // the loads it had just issued: 8.5 k cycles per 256-sample chain instead of ~3 k)
+    constexpr int U = 8;
+    float acc = 0.0f;
+    const int nb = B / U;
+    int blk = 0;
+    float pa[U], qa[U], pb[U], qb[U];
+    if (nb > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { pa[u] = pp[u * SP]; qa[u] = qq[u * SQ]; }
+    }
+#pragma unroll 1
+    while (blk + 2 <= nb) {                                    // block blk sits in (pa, qa)
+        const lfloat *p1 = pp + (blk + 1) * U * SP, *q1 = qq + (blk + 1) * U * SQ;
+#pragma unroll
+        for (int u = 0; u < U; ++u) { pb[u] = p1[u * SP]; qb[u] = q1[u * SQ]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = fma32(pa[u], qa[u], acc);
+        if (blk + 2 < nb) {
+            const lfloat *p2 = pp + (blk + 2) * U * SP, *q2 = qq + (blk + 2) * U * SQ;
+#pragma unroll
+            for (int u = 0; u < U; ++u) { pa[u] = p2[u * SP]; qa[u] = q2[u * SQ]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = fma32(pb[u], qb[u], acc);
+        blk += 2;
+    }
+    if (blk < nb) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = fma32(pa[u], qa[u], acc);
+        ++blk;
+    }
+    for (int i = blk * U; i < B; ++i) acc = fma32(pp[i * SP], qq[i * SQ], acc);
     return acc;
 }
-__device__ __forceinline__ float t3d_batch_sum(const lfloat *pp, int sp, int B)      // plain adds, i ascending (the bias gradients' column sums)
+template <int SP>
+__device__ __forceinline__ float t3d_batch_sum(const lfloat *pp, int B)      // plain adds, i ascending (the bias gradients' column sums)
 {
+    constexpr int U = 16;
     float acc = 0.0f;
     int i = 0;
-    for (; i + 16 <= B; i += 16) {
-        float pv[16];
+    for (; i + U <= B; i += U) {
+        float pv[U];
+        const lfloat *p2 = pp + i * SP;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) pv[u] = pp[(i + u) * sp];
+        for (int u = 0; u < U; ++u) pv[u] = p2[u * SP];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc = acc + pv[u];
+        for (int u = 0; u < U; ++u) acc = acc + pv[u];
     }
-    for (; i < B; ++i) acc = acc + pp[i * sp];
+    for (; i < B; ++i) acc = acc + pp[i * SP];
     return acc;
 }
 __device__ __forceinline__ void t3d_stage(const float *src, int n, lfloat *dst, int tid) { for (int i = tid; i < n; i += DNT) dst[i] = src[i]; }
 
 // TD3.learn up to the critics' gradients (TD3.py:63-95): smoothed target actions, target critics, TD error, both critics' gradients into
 // ctx->grad.  Returns non-zero on a policy-noise tape underrun.  Thread b & 255 owns minibatch sample b; half h = tid >> 8 runs critic h
-// where the two critics can go side by side.
+// where the two critics can go side by side, and half of the hidden units where a pass only fills the activation matrix.
 template <int S, int A, int ACT>
 __device__ __noinline__ int t3_direct_critics(const T3DirectCtx *ctx_, int64_t learn_it_)
 {
@@ -193,7 +314,7 @@ __device__ __noinline__ int t3_direct_critics(const T3DirectCtx *ctx_, int64_t l
     typedef __attribute__((address_space(3))) const T3DirectCtx LCtx;
     LCtx *c = (LCtx *)uni_ptr(ctx_);
     const int tid = threadIdx.x, half = uni(tid >> 8), b = tid & 255;
-    const int H = uni(c->H), B = uni(c->B), Pa = uni(c->Pa), Pc = uni(c->Pc), HP1 = H + 1;
+    const int H = uni(c->H), B = uni(c->B), Pa = uni(c->Pa), Pc = uni(c->Pc), PcA = (Pc + 3) & ~3;
     const float prelu = unif(c->prelu), ma = unif(c->ma), g32 = unif(c->g32);
     const int64_t learn_it = learn_it_;
     lfloat *l_act = (lfloat *)uni_ptr(c->l_act), *l_x = (lfloat *)uni_ptr(c->l_x), *l_na = (lfloat *)uni_ptr(c->l_na), *l_w = (lfloat *)uni_ptr(c->l_w);
@@ -202,18 +323,23 @@ __device__ __noinline__ int t3_direct_critics(const T3DirectCtx *ctx_, int64_t l
     const float *params = uni_ptr(c->params), *targets = uni_ptr(c->targets), *xc = uni_ptr(c->xc), *xn = uni_ptr(c->xn);
     float *grad = uni_ptr(c->grad);
     const bool live = b < B;
-    lfloat *myrow = l_act + b * HP1;
+    lfloat *mycol = l_act + b;
+    const int Hs = t3d_split(H), my_lo = half ? Hs : 0, my_hi = half ? H : Hs;
     int bad = 0;
     T3D_SUB_DECL;
+    // the sample's rows (s, a) and s' from the arena, requested before anything else (their round trip hides behind the first staging)
+    float xcr[SA], xnr[S];
+#pragma unroll
+    for (int k = 0; k < SA; ++k) xcr[k] = live ? xc[b * SA + k] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < S; ++k) xnr[k] = live ? xn[b * SA + k] : 0.0f;
     // ---- next_actions = (actor_target(s') + clamp(randn * policy_std)).clamp(-max, max)  (TD3.py:72-78) ----
     t3d_stage(targets, Pa, l_w, tid);
     __syncthreads();
     T3D_SUB(0);
     if (half == 0 && live) {
-        float xr[S], o[A];
-#pragma unroll
-        for (int k = 0; k < S; ++k) xr[k] = xn[b * SA + k];
-        t3d_net_fwd<ACT, S, A, false>(l_w, H, prelu, xr, l_w, o);
+        float o[A];
+        t3d_net_fwd<ACT, S, A, false, true>(l_w, H, prelu, xnr, l_w, o, 0, H);
         const float *tape = uni_ptr(c->policy_noise);
         const float pstd = unif(c->policy_std), clipv = unif(c->policy_clip);
         const uint64_t key = c->key;
@@ -233,34 +359,36 @@ __device__ __noinline__ int t3_direct_critics(const T3DirectCtx *ctx_, int64_t l
     __syncthreads();
     T3D_SUB(1);
     // ---- the target critics on (s', next_actions): half h runs critic h  (TD3.py:80-82) ----
-    t3d_stage(targets + Pa, 2 * Pc, l_w, tid);
+    t3d_stage(targets + Pa, Pc, l_w, tid);
+    t3d_stage(targets + Pa + Pc, Pc, l_w + PcA, tid);
     __syncthreads();
     T3D_SUB(2);
     if (live) {
         float xr[SA], o[1];
 #pragma unroll
-        for (int k = 0; k < S; ++k) xr[k] = xn[b * SA + k];
+        for (int k = 0; k < S; ++k) xr[k] = xnr[k];
 #pragma unroll
         for (int k = 0; k < A; ++k) xr[S + k] = l_na[b * A + k];
-        t3d_net_fwd<ACT, SA, 1, false>(l_w + half * Pc, H, prelu, xr, l_w, o);
+        t3d_net_fwd<ACT, SA, 1, false, true>(l_w + half * PcA, H, prelu, xr, l_w, o, 0, H);
         (half ? tq2 : tq1)[b] = o[0];
     }
     __syncthreads();
     T3D_SUB(3);
-    // ---- the online critics on (s, a), TD error (TD3.py:84-91): half h runs critic h ----
-    t3d_stage(params + Pa, 2 * Pc, l_w, tid);
+    // ---- the online critics on (s, a), TD error (TD3.py:84-91): half h runs critic h; critic_1's activations stay in the matrix ----
+    t3d_stage(params + Pa, Pc, l_w, tid);
+    t3d_stage(params + Pa + Pc, Pc, l_w + PcA, tid);
     __syncthreads();
     T3D_SUB(4);
-    float xcr[SA];
-#pragma unroll
-    for (int k = 0; k < SA; ++k) xcr[k] = live ? xc[b * SA + k] : 0.0f;
     if (live) {
         float o[1];
-        t3d_net_fwd<ACT, SA, 1, false>(l_w + half * Pc, H, prelu, xcr, l_w, o);
-        (half ? q2 : q1)[b] = o[0];
         if (half == 0) {
+            t3d_net_fwd<ACT, SA, 1, true, true>(l_w, H, prelu, xcr, mycol, o, 0, H);
+            q1[b] = o[0];
 #pragma unroll
             for (int k = 0; k < SA; ++k) l_x[b * SA + k] = xcr[k];
+        } else {
+            t3d_net_fwd<ACT, SA, 1, false, true>(l_w + PcA, H, prelu, xcr, l_w, o, 0, H);
+            q2[b] = o[0];
         }
     }
     __syncthreads();
@@ -274,40 +402,35 @@ __device__ __noinline__ int t3_direct_critics(const T3DirectCtx *ctx_, int64_t l
     }
     __syncthreads();
     T3D_SUB(6);
-    // ---- critic gradients, one critic after the other through the activation matrix (its forward pass once more, into the rows) ----
+    // ---- critic gradients, one critic after the other through the activation matrix (critic_2's forward pass once more, into the matrix: the
+    // two halves fill half of the units each) ----
     const int oW0 = 0, ob0 = H * SA, oWo = ob0 + H, obo = oWo + H;      // state-dict offsets of a one-hidden-layer critic (mlp_off)
 #pragma unroll 1
     for (int cc = 0; cc < 2; ++cc) {
         const lfloat *dqv = cc ? dq2 : dq1;
         float *gcr = grad + Pa + cc * Pc;
-        const lfloat *Wo = l_w + cc * Pc + oWo;
-        if (half == 0 && live) { float o[1]; t3d_net_fwd<ACT, SA, 1, true>(l_w + cc * Pc, H, prelu, xcr, myrow, o); }
+        const lfloat *wcc = l_w + cc * PcA;
+        if (cc == 1) {
+            if (live) { float o[1]; t3d_net_fwd<ACT, SA, 1, true, false>(wcc, H, prelu, xcr, mycol, o, my_lo, my_hi); }
+            __syncthreads();
+        }
+        T3D_SUB(7);
+        // output layer: gWout[j] = sum_i dq[i] h[i][j], gbout = sum_i dq[i]
+        if (tid < H) gcr[oWo + tid] = t3d_batch_dot<1, 1>(dqv, l_act + tid * T3D_BP, B);
+        else if (tid == 256) gcr[obo] = t3d_batch_sum<1>(dqv, B);
         __syncthreads();
         T3D_SUB(8);
-    T3D_SUB(7);
-        // output layer: gWout[j] = sum_i dq[i] h[i][j], gbout = sum_i dq[i]
-        if (tid < H) gcr[oWo + tid] = t3d_batch_dot(dqv, 1, l_act + tid, HP1, B);
-        else if (tid == H) gcr[obo] = t3d_batch_sum(dqv, 1, B);
+        // hidden gradient in place: act'(h) * (dq * Wout[j]), half of the units per half
+        if (live) { const float g[1] = { dqv[b] }; t3d_dz<ACT, 1>(mycol, wcc + oWo, H, prelu, g, my_lo, my_hi); }
         __syncthreads();
         T3D_SUB(9);
-    T3D_SUB(8);
-        // hidden gradient in place: act'(h) * (dq * Wout[j])   (the queued product's single k-step: fma(dq, W, +0))
-        if (half == 0 && live) {
-            const float dq = dqv[b];
-#pragma unroll 8
-            for (int j = 0; j < H; ++j) myrow[j] = act_bwd(ACT, prelu, myrow[j], fma32(dq, Wo[j], 0.0f));
+        // first layer: gW0[j][k] = sum_i dz[i][j] x[i][k], gb0[j] = sum_i dz[i][j]
+        for (int pp = tid; pp < H * SA + H; pp += DNT) {
+            if (pp < H * SA) { const int j = pp / SA, k = pp - j * SA; gcr[oW0 + pp] = t3d_batch_dot<1, SA>(l_act + j * T3D_BP, l_x + k, B); }
+            else { const int j = pp - H * SA; gcr[ob0 + j] = t3d_batch_sum<1>(l_act + j * T3D_BP, B); }
         }
         __syncthreads();
         T3D_SUB(10);
-    T3D_SUB(9);
-        // first layer: gW0[j][k] = sum_i dz[i][j] x[i][k], gb0[j] = sum_i dz[i][j]
-        for (int pp = tid; pp < H * SA + H; pp += DNT) {
-            if (pp < H * SA) { const int j = pp / SA, k = pp - j * SA; gcr[oW0 + pp] = t3d_batch_dot(l_act + j, HP1, l_x + k, SA, B); }
-            else { const int j = pp - H * SA; gcr[ob0 + j] = t3d_batch_sum(l_act + j, HP1, B); }
-        }
-        __syncthreads();
-        T3D_SUB(11);
-    T3D_SUB(10);
     }
     return bad;
 }
@@ -321,87 +444,114 @@ __device__ __noinline__ void t3_direct_actor(const T3DirectCtx *ctx_)
     typedef __attribute__((address_space(3))) const T3DirectCtx LCtx;
     LCtx *c = (LCtx *)uni_ptr(ctx_);
     const int tid = threadIdx.x, half = uni(tid >> 8), b = tid & 255;
-    const int H = uni(c->H), B = uni(c->B), Pa = uni(c->Pa), Pc = uni(c->Pc), HP1 = H + 1;
+    const int H = uni(c->H), B = uni(c->B), Pa = uni(c->Pa), Pc = uni(c->Pc), PaA = (Pa + 3) & ~3;
     const float prelu = unif(c->prelu), ma = unif(c->ma);
     lfloat *l_act = (lfloat *)uni_ptr(c->l_act), *l_x = (lfloat *)uni_ptr(c->l_x), *l_na = (lfloat *)uni_ptr(c->l_na), *l_w = (lfloat *)uni_ptr(c->l_w);
     const float *params = uni_ptr(c->params), *xc = uni_ptr(c->xc);
     float *grad = uni_ptr(c->grad);
     const bool live = b < B;
-    lfloat *myrow = l_act + b * HP1;
+    lfloat *mycol = l_act + b;
+    const int Hs = t3d_split(H), my_lo = half ? Hs : 0, my_hi = half ? H : Hs;
     const int oW0 = 0, ob0 = H * S, oWo = ob0 + H, obo = oWo + A * H;  // state-dict offsets of the one-hidden-layer actor
-    t3d_stage(params, Pa + Pc, l_w, tid);                              // actor | critic_1 (contiguous in the parameter vector)
+    t3d_stage(params, Pa, l_w, tid);                                   // actor | critic_1, each at a multiple of four floats
+    t3d_stage(params + Pa, Pc, l_w + PaA, tid);
     __syncthreads();
-    float dza[A];
-#pragma unroll
-    for (int k = 0; k < A; ++k) dza[k] = 0.0f;
     if (half == 0 && live) {
         float xr[SA], xs[S], o[A], th[A];
 #pragma unroll
         for (int k = 0; k < S; ++k) { xs[k] = xc[b * SA + k]; xr[k] = xs[k]; }
-        t3d_net_fwd<ACT, S, A, true>(l_w, H, prelu, xs, myrow, o);          // the actor's activations stay in the sample's row
+        t3d_net_fwd<ACT, S, A, true, true>(l_w, H, prelu, xs, mycol, o, 0, H);          // the actor's activations stay in the sample's column
 #pragma unroll
         for (int k = 0; k < A; ++k) { th[k] = det_tanhf(lenv_tanh_table, o[k]); xr[S + k] = th[k] * ma; }
         // critic_1 forward on (s, actor(s)) and, unit by unit, its backward down to the action inputs: dq = -1/B per sample,
         // dz1[j] = act'(h1[j]) * (dq * Wout[j]), dx[k] = sum_j dz1[j] W0[j][S + k]  (j ascending)
         const float dqa = -(1.0f / (float)B);
-        const lfloat *W0c = l_w + Pa, *b0c = W0c + H * SA, *Woc = b0c + H;
+        const lfloat *W0c = l_w + PaA, *b0c = W0c + H * SA, *Woc = b0c + H;
         float dx[A];
 #pragma unroll
         for (int k = 0; k < A; ++k) dx[k] = 0.0f;
+        constexpr int JB = SA <= 8 ? 8 : 4;
+        const bool fast = (H & 7) == 0;
 #pragma unroll 1
-        for (int j0 = 0; j0 < H; j0 += 8) {
-            float w0[8][SA], bv[8], wo[8];
+        for (int j0 = 0; j0 < H; j0 += JB) {
+            float w0[JB * SA], bv[JB], wo[JB];
+            if (fast) { t3d_ld4<JB * SA>(W0c + j0 * SA, w0); t3d_ld4<JB>(b0c + j0, bv); t3d_ld4<JB>(Woc + j0, wo); }
+            else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u < H ? j0 + u : H - 1;
+                for (int u = 0; u < JB; ++u) {
+                    const int j = j0 + u < H ? j0 + u : H - 1;
 #pragma unroll
-                for (int k = 0; k < SA; ++k) w0[u][k] = W0c[j * SA + k];
-                bv[u] = b0c[j]; wo[u] = Woc[j];
+                    for (int k = 0; k < SA; ++k) w0[u * SA + k] = W0c[j * SA + k];
+                    bv[u] = b0c[j]; wo[u] = Woc[j];
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < JB; ++u) {
                 if (j0 + u < H) {
                     float z = 0.0f;
 #pragma unroll
-                    for (int k = 0; k < SA; ++k) z = fma32(xr[k], w0[u][k], z);
+                    for (int k = 0; k < SA; ++k) z = fma32(xr[k], w0[u * SA + k], z);
                     z = z + bv[u];
                     const float dz1 = act_bwd(ACT, prelu, act_fwd(ACT, prelu, z), fma32(dqa, wo[u], 0.0f));
 #pragma unroll
-                    for (int k = 0; k < A; ++k) dx[k] = fma32(dz1, w0[u][S + k], dx[k]);
+                    for (int k = 0; k < A; ++k) dx[k] = fma32(dz1, w0[u * SA + S + k], dx[k]);
                 }
             }
         }
 #pragma unroll
-        for (int k = 0; k < A; ++k) {
-            dza[k] = (dx[k] * ma) * fma32(-th[k], th[k], 1.0f);       // d(tanh(z)*max_action)
-            l_na[b * A + k] = dza[k];
-        }
+        for (int k = 0; k < A; ++k) l_na[b * A + k] = (dx[k] * ma) * fma32(-th[k], th[k], 1.0f);       // d(tanh(z)*max_action)
 #pragma unroll
         for (int k = 0; k < S; ++k) l_x[b * S + k] = xs[k];
     }
     __syncthreads();
     // actor output layer: gWout[c][j] = sum_i dza[i][c] h[i][j], gbout[c] = sum_i dza[i][c]
     for (int pp = tid; pp < A * H + A; pp += DNT) {
-        if (pp < A * H) { const int cidx = pp / H, j = pp - cidx * H; grad[oWo + pp] = t3d_batch_dot(l_na + cidx, A, l_act + j, HP1, B); }
-        else { const int cidx = pp - A * H; grad[obo + cidx] = t3d_batch_sum(l_na + cidx, A, B); }
+        if (pp < A * H) { const int cidx = pp / H, j = pp - cidx * H; grad[oWo + pp] = t3d_batch_dot<A, 1>(l_na + cidx, l_act + j * T3D_BP, B); }
+        else { const int cidx = pp - A * H; grad[obo + cidx] = t3d_batch_sum<A>(l_na + cidx, B); }
     }
     __syncthreads();
-    if (half == 0 && live) {
-        const lfloat *Woa = l_w + oWo;
-#pragma unroll 2
-        for (int j = 0; j < H; ++j) {
-            float acc = 0.0f;
+    if (live) {                                                        // hidden gradient in place, half of the units per half
+        float dza[A];
 #pragma unroll
-            for (int cidx = 0; cidx < A; ++cidx) acc = fma32(dza[cidx], Woa[cidx * H + j], acc);
-            myrow[j] = act_bwd(ACT, prelu, myrow[j], acc);
-        }
+        for (int k = 0; k < A; ++k) dza[k] = l_na[b * A + k];
+        t3d_dz<ACT, A>(mycol, l_w + oWo, H, prelu, dza, my_lo, my_hi);
     }
     __syncthreads();
     for (int pp = tid; pp < H * S + H; pp += DNT) {
-        if (pp < H * S) { const int j = pp / S, k = pp - j * S; grad[oW0 + pp] = t3d_batch_dot(l_act + j, HP1, l_x + k, S, B); }
-        else { const int j = pp - H * S; grad[ob0 + j] = t3d_batch_sum(l_act + j, HP1, B); }
+        if (pp < H * S) { const int j = pp / S, k = pp - j * S; grad[oW0 + pp] = t3d_batch_dot<1, S>(l_act + j * T3D_BP, l_x + k, B); }
+        else { const int j = pp - H * S; grad[ob0 + j] = t3d_batch_sum<1>(l_act + j * T3D_BP, B); }
     }
     __syncthreads();
+}
+
+// sum_{k < 128} x[k] * Wt[k][j] as ONE k-ascending chain from 0: x in LDS (16-byte aligned), Wt = the transposed matrix in the arena (wt points at
+// column j; STRIDE = its row length as a literal, 0 = stride_rt), 64 weights in flight per thread (two register blocks refilled alternately)
+template <int STRIDE>
+__device__ __forceinline__ float se_chain128(const gfloat *wt, int stride_rt, const lfloat *xin)
+{
+    const int stride = STRIDE ? STRIDE : stride_rt;
+    float wa[32], wb[32], xv[32], z = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) wa[u] = wt[u * stride];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) wb[u] = wt[(32 + u) * stride];
+    t3d_ld4<32>(xin, xv);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) z = fma32(xv[u], wa[u], z);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) wa[u] = wt[(64 + u) * stride];
+    t3d_ld4<32>(xin + 32, xv);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) z = fma32(xv[u], wb[u], z);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) wb[u] = wt[(96 + u) * stride];
+    t3d_ld4<32>(xin + 64, xv);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) z = fma32(xv[u], wa[u], z);
+    t3d_ld4<32>(xin + 96, xv);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) z = fma32(xv[u], wb[u], z);
+    return z;
 }
 
 // DIRECT (round 6) = launches whose agent nets have ONE hidden layer of at most T3_DIRECT_H units, no LayerNorm, no ICM, batch <= T3_DIRECT_B
@@ -409,8 +559,8 @@ __device__ __noinline__ void t3_direct_actor(const T3DirectCtx *ctx_)
 // cycles whatever its size (staging through LDS, workgroup barriers, a global round trip between products: profiles/r05_generic_shapes.log --
 // 456 us per learn step for a 64-wide TD3).  Here ONE THREAD OWNS ONE MINIBATCH SAMPLE: it runs the sample's forward passes with the nets'
 // weights broadcast from LDS (the hidden activations stay in its registers), forms the TD target and the per-sample output gradients; the batch
-// sums of the parameter gradients then run as one i-ascending chain per parameter over an LDS copy of the activations ([B][H + 1]: the odd row
-// stride keeps writers = samples and readers = units conflict-free).  Every chain is the queued product's own k- / i-ascending fmaf chain from 0
+// sums of the parameter gradients then run as one i-ascending chain per parameter over an LDS copy of the activations (unit-major, row stride 257:
+// writers = samples and readers = units are both conflict-free, see t3d_layout).  Every chain is the queued product's own k- / i-ascending fmaf chain from 0
 // with the epilogues' bias / activation / derivative arithmetic, so the bits are those of the GEMM-queue path and of the oracle.  Its own
 // instantiations: as a run-time branch next to the queued learn step the extra live state pushed the Pendulum instantiation into SGPR spills, where
 // the ROCm 7.2 backend emits an illegal VALU compare on the LDS aperture register.
@@ -584,7 +734,15 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 const float *w = W + (int64_t)j * n_in;
                 float z = 0.0f;
                 if ((n_in & 3) == 0) {
-                    for (int k = 0; k < n_in; k += 4) {
+                    int k = 0;
+                    for (; k + 32 <= n_in; k += 32) {          // 32 terms requested before the first fmaf (one round trip instead of eight)
+                        float4 wv[8], xv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { wv[u] = *reinterpret_cast<const float4 *>(w + k + 4 * u); xv[u] = *reinterpret_cast<const float4 *>(in + k + 4 * u); }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { z = fma32(xv[u].x, wv[u].x, z); z = fma32(xv[u].y, wv[u].y, z); z = fma32(xv[u].z, wv[u].z, z); z = fma32(xv[u].w, wv[u].w, z); }
+                    }
+                    for (; k < n_in; k += 4) {
                         const float4 wv = *reinterpret_cast<const float4 *>(w + k);
                         const float4 xv = *reinterpret_cast<const float4 *>(in + k);
                         z = fma32(xv.x, wv.x, z); z = fma32(xv.y, wv.y, z); z = fma32(xv.z, wv.z, z); z = fma32(xv.w, wv.w, z);
@@ -632,6 +790,36 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
         const MlpOff &mo = mo_se[g < 3 ? g : 0];
         const gfloat *par = (const gfloat *)(arena + a.a_seT) + (g == 0 ? 0 : (g == 1 ? mo_se[0].P : mo_se[0].P + mo_se[1].P));
         const int ocol = g == 0 ? 0 : S + g - 1;
+        if (Hrn == 128 && mo_se[0].in <= 32) {
+            // 128-wide nets (what the YAMLs ship): the hidden rows live in the idle product-staging buffer (LDS, two sets of three), the transposed
+            // matrices are walked with literal strides, 64 weights in flight per thread (two register blocks refilled alternately).  The chains
+            // are the ones below: k ascending from 0, bias added after.  (The general loop -- input row and weights from the arena, 32 terms
+            // requested, waited for, consumed -- took ~50 k cycles per step of a three-layer SE: 56 % of a small-net TD3 generation.)
+            lfloat *hb = (lfloat *)uni_ptr(Ps);
+            if (g < 3) {                                   // first layer: the input row (at most 32 words) from the arena
+                const gfloat *wt = par + mo.oW[0] + j, *in0 = (const gfloat *)x;
+                const int n_in = mo.in;
+                float wv[32], xv[32], z = 0.0f;
+#pragma unroll
+                for (int u = 0; u < 32; ++u) { const int k = u < n_in ? u : n_in - 1; wv[u] = wt[k * 128]; xv[u] = in0[k]; }
+#pragma unroll
+                for (int u = 0; u < 32; ++u) if (u < n_in) z = fma32(xv[u], wv[u], z);
+                hb[g * 128 + j] = act_fwd(rn_act, cfg.rn_prelu, z + par[mo.ob[0] + j]);
+            }
+            __syncthreads();
+            int cur = 0;
+            for (int l = 1; l < mo.L; ++l) {
+                if (g < 3) {
+                    const float z = se_chain128<128>(par + mo.oW[l] + j, 128, hb + cur * 384 + g * 128);
+                    hb[(cur ^ 1) * 384 + g * 128 + j] = act_fwd(rn_act, cfg.rn_prelu, z + par[mo.ob[l] + j]);
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
+            if (g < 3 && j < mo.out) out[ocol + j] = se_chain128<0>(par + mo.oW[mo.L] + j, mo.out, hb + cur * 384 + g * 128) + par[mo.ob[mo.L] + j];
+            __syncthreads();
+            return;
+        }
         const gfloat *in = (const gfloat *)x;              // (the SE's input row and the hidden rows: arena)
         int n_in = mo.in;
         for (int l = 0; l <= mo.L; ++l) {
@@ -902,6 +1090,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                 ++n_actn;
                 __syncthreads();
             }
+            T3D_ENV_SUB(12);                               // select_train_action
             if (virtual_env) {
                 // ---- EnvWrapper.step -> VirtualEnv.step (virtual_env.py:43-54): the three SE nets on cat(action, state) as queued
                 // single-row products; reward / done see the pre-transition state; the learned done flag ends the episode ----
@@ -967,6 +1156,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             }
             }
             __syncthreads();
+            T3D_ENV_SUB(13);                               // the env step(s)
             if (tid < 2 * S + A + 2) rb[(int64_t)new_pos * RS + tid] = newrow[tid];
             if (!FIXED && a.out.trace_reward && train_steps < a.out.trace_cap) {
                 const int64_t k = chain * a.out.trace_cap + train_steps;
@@ -981,6 +1171,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             ep_len += k_rep; ++train_steps;                  // base_agent.py:122: episode_length += same_action_num
             __syncthreads();
 
+            T3D_ENV_SUB(14);                               // append + trace + bookkeeping
             PT_MARK(0);                                   // act + env step + reward net + append
             if (learning) {
                 // ================= TD3.learn (TD3.py:63-116) =================
@@ -1007,11 +1198,12 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                     // ================= TD3.learn, DIRECT (t3_direct_critics / t3_direct_actor above the kernel) =================
                     // the context record sits behind the work areas in the queue's staging buffers (which the test phases' products overwrite):
                     // thread 0 writes it at every learn step
-                    T3DirectCtx *dctx = reinterpret_cast<T3DirectCtx *>(Ps + ((B * (H + 1) + B * SA + B * A + 2 * (Pa > Pc ? Pa : Pc) + 3) & ~3));
+                    const T3DirectLayout dl = t3d_layout(S, A, H, B);
+                    T3DirectCtx *dctx = reinterpret_cast<T3DirectCtx *>(Ps + dl.ctx);
                     if (tid == 0) {
                         T3DirectCtx d;
                         d.params = params; d.targets = targets; d.grad = grad; d.xc = xc; d.xn = xn;
-                        d.l_act = Ps; d.l_x = d.l_act + B * (H + 1); d.l_na = d.l_x + B * SA; d.l_w = d.l_na + B * A;
+                        d.l_act = Ps; d.l_x = Ps + dl.x; d.l_na = Ps + dl.na; d.l_w = Ps + dl.w;
                         d.rr = rr; d.dd = dd; d.q1 = q1; d.q2 = q2; d.tq1 = tq1; d.tq2 = tq2; d.dq1 = dq1; d.dq2 = dq2;
                         d.policy_noise = tape ? a.tapes.policy_noise + chain * a.tapes.policy_noise_stride * A : nullptr;
                         d.policy_noise_rows = tape ? a.tapes.policy_noise_stride : 0;
@@ -1021,13 +1213,13 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                         *dctx = d;
                     }
                     __syncthreads();
-                    // (the routines carry the activation as a template parameter: one uniform switch per call instead of one per hidden unit)
+                    // (the routines carry the activation as a template parameter: one uniform switch per call instead of one per hidden unit;
+                    // an agent PReLU is refused by inner_check)
                     int dbad = 0;
                     switch (act_id) {
                     case LENV_ACT_RELU: dbad = t3_direct_critics<S, A, LENV_ACT_RELU>(dctx, learn_it); break;
                     case LENV_ACT_LEAKYRELU: dbad = t3_direct_critics<S, A, LENV_ACT_LEAKYRELU>(dctx, learn_it); break;
                     case LENV_ACT_TANH: dbad = t3_direct_critics<S, A, LENV_ACT_TANH>(dctx, learn_it); break;
-                    case LENV_ACT_PRELU: dbad = t3_direct_critics<S, A, LENV_ACT_PRELU>(dctx, learn_it); break;
                     default: dbad = t3_direct_critics<S, A, LENV_ACT_IDENTITY>(dctx, learn_it); break;
                     }
                     if (dbad) status = -8;
@@ -1040,7 +1232,6 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
                         case LENV_ACT_RELU: t3_direct_actor<S, A, LENV_ACT_RELU>(dctx); break;
                         case LENV_ACT_LEAKYRELU: t3_direct_actor<S, A, LENV_ACT_LEAKYRELU>(dctx); break;
                         case LENV_ACT_TANH: t3_direct_actor<S, A, LENV_ACT_TANH>(dctx); break;
-                        case LENV_ACT_PRELU: t3_direct_actor<S, A, LENV_ACT_PRELU>(dctx); break;
                         default: t3_direct_actor<S, A, LENV_ACT_IDENTITY>(dctx); break;
                         }
                         PT_MARK(7);                           // policy update: forwards + backwards
@@ -1417,9 +1608,7 @@ extern "C" int lenv_td3_rn_inner_loop_icm(const lenv_td3_cfg *cfg, const lenv_ch
     bool direct = false;
     {
         const int S = cfg->state_dim, A = cfg->action_dim, H = cfg->hidden, B = cfg->batch_size;
-        const int64_t Pa_ = (int64_t)S * H + H + (int64_t)A * H + A, Pc_ = (int64_t)(S + A) * H + H + H + 1;      // one hidden layer
-        const int64_t staged = 2 * (Pa_ > Pc_ ? Pa_ : Pc_);                                                          // two nets at a time
-        const int64_t need = (int64_t)B * (H + 1) + (int64_t)B * (S + A) + (int64_t)B * A + staged + 4 + (int64_t)(sizeof(T3DirectCtx) + 3) / 4;   // + the context record
+        const int64_t need = H <= T3_DIRECT_H && B <= T3_DIRECT_B ? t3d_layout(S, A, H, B).total : INT64_MAX;      // activation matrix + rows + two staged nets + the context record
         direct = !cfg->icm_enabled && !cfg->use_layer_norm && cfg->layers == 1 && H <= T3_DIRECT_H && B <= T3_DIRECT_B && !(cfg->kernel_variant & LENV_VARIANT_NO_DIRECT) &&
                  need <= (int64_t)(GemmShape<T3_MAXI>::PS_FLOATS + GemmShape<T3_MAXI>::QS_FLOATS);
     }

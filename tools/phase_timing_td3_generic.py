@@ -26,6 +26,9 @@ def run(label, c):
     m = GTN_Master(c, bohb_id=0, seed=7)
     m.step(0)
     torch.cuda.synchronize()
+    buf0 = (C.c_ulonglong * 32)()
+    _lib.lib().lenv_debug_td3_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
+    assert _lib.lib().lenv_debug_td3_phase_cycles(buf0) == 0      # (the sub-phase counters are never reset: the first generation's share is subtracted)
     t0 = time.time(); m.step(1); torch.cuda.synchronize(); dt = time.time() - t0
     buf = (C.c_ulonglong * 32)()
     _lib.lib().lenv_debug_td3_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
@@ -38,12 +41,15 @@ def run(label, c):
         print("  %-22s %12d cycles  %5.1f%%  %9.0f per %s" % (n, buf[i], 100.0 * buf[i] / max(1, tot), per,
                                                                "learn step" if 1 <= i <= 8 else ("env step" if i == 0 else "test step")))
     sub = ["stage actor_t", "actor_t fwd + noise", "stage target critics", "target critics fwd", "stage critics", "critics fwd", "TD error",
-           "-", "recompute fwd into rows (x2)", "output-layer grads (x2)", "in-place dz (x2)", "first-layer grads (x2)"]
+           "critic_2 fwd again into the matrix (split)", "output-layer grads (x2)", "in-place dz (x2, split)", "first-layer grads (x2)", "-",
+           "env step: cumulative at 'action selected'", "env step: cumulative at 'env stepped'", "env step: cumulative at 'appended'"]
+    for i in range(16):
+        buf[16 + i] -= buf0[16 + i]
     if any(buf[16 + i] for i in range(16)):
         print("  t3_direct_critics sub-phases (thread 0 of chain 0), cycles per learn step:")
         for i, n in enumerate(sub):
             if buf[16 + i]:
-                print("    %-34s %9.0f" % (n, buf[16 + i] / max(1, st[2])))
+                print("    %-46s %9.0f" % (n, buf[16 + i] / max(1, st[2] if i < 12 else st[1])))
 
 
 c = configs.fixed_work(configs.cmc_syn_env_td3(16), 3)
