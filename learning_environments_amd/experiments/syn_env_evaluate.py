@@ -150,9 +150,17 @@ def _pad_rows(rows, dtype, width=None):
 def _replay_launch(task, inner, theta, eps, worker, sign, keys_t, agent_init, replay):
     """One tape-mode launch with the recorded hyper-parameters, fresh agents and RNG draws of a reference run."""
     t = replay["tapes"]
-    tapes = dict(eps_uniform=_pad_rows(t["eps_uniform"], np.float64), rand_action=_pad_rows(t["rand_action"], np.int32),
-                 replay_idx=_pad_rows(t["replay_idx"], np.int32), train_reset=_pad_rows(t["train_reset"], np.float64, 4),
-                 test_reset=_pad_rows(t["test_reset"], np.float64, 4))
+    if "gumbel_act" in t:
+        # the TD3-discrete loop's tapes (agents/TD3_discrete_vary.py: Gaussian action / policy noise and the Gumbel draws, one row per draw)
+        A = int(np.asarray(t["act_noise"][0]).reshape(len(t["act_noise"][0]), -1).shape[1]) if len(t["act_noise"][0]) else 2
+        tapes = dict(rand_action=_pad_rows(t["rand_action"], np.int32), replay_idx=_pad_rows(t["replay_idx"], np.int32),
+                     train_reset=_pad_rows(t["train_reset"], np.float64, 4), test_reset=_pad_rows(t["test_reset"], np.float64, 4))
+        for k in ("act_noise", "test_noise", "policy_noise", "gumbel_act", "gumbel_test", "gumbel_target", "gumbel_actor"):
+            tapes[k] = _pad_rows(t[k], np.float32, A)
+    else:
+        tapes = dict(eps_uniform=_pad_rows(t["eps_uniform"], np.float64), rand_action=_pad_rows(t["rand_action"], np.int32),
+                     replay_idx=_pad_rows(t["replay_idx"], np.int32), train_reset=_pad_rows(t["train_reset"], np.float64, 4),
+                     test_reset=_pad_rows(t["test_reset"], np.float64, 4))
     if getattr(inner, "vary", False):
         hp = task.last_hp = task.draw_hp(None)
         inner.set_hp([h["lr"] for h in hp], [h["batch_size"] for h in hp], [h["hidden_size"] for h in hp], [h["hidden_layer"] for h in hp])

@@ -1611,6 +1611,189 @@ def gen_g12(name, mode, seed, agents_num=2, vary=True, vary_seed=77, ckpt="ckpt_
           "hp", [h["hp"] for h in holders], "reward_test", [np.mean(r) for r in reward_list])
 
 
+def gen_g12t(name, seed, vary_seed, agents_num=2, ckpt="ckpt_cartpole_se_reference_b.pt",
+             module="experiments.syn_env_evaluate_cartpole_vary_hp_2_TD3_discrete"):
+    """G12T: the TD3_discrete sibling script's train_test_agents (experiments/syn_env_evaluate_cartpole_vary_hp_2_TD3_discrete.py:44-67:
+    `td3_discrete_vary` agents configured from default_config_cartpole.yaml's `td3_discrete_vary_layer_norm_2` section, comparability
+    settings init_episodes 10 / early_out_num 10 / early_out_virtual_diff 0.01, agent.train(env=train_env) without a test env, one
+    agent.test on the real env) on the loaded SE (mode 2 of syn_env_run_vary_hp.py).  Taps as in gen_g8td, one recorder per agent."""
+    import importlib
+    import json
+    import shutil
+    import tempfile
+    import ConfigSpace
+    ev = importlib.import_module(module)
+    import gym.envs as genvs
+    import gym.spaces as gspaces
+    tmp = tempfile.mkdtemp(prefix="lenv_g12t_")
+    shutil.copy(os.path.join(OUT, ckpt), os.path.join(tmp, "model.pt"))
+    cwd = os.getcwd()
+    os.chdir(os.path.join(REF, "experiments"))      # (the script reads "../default_config_cartpole.yaml"; nothing is written there)
+    try:
+        with quiet():
+            venv, real_env, config = ev.load_envs_and_config(file_name="model.pt", model_dir=tmp, device="cpu")
+    finally:
+        os.chdir(cwd)
+    theta = se_theta(venv)
+    train_env = venv
+    A = real_env.get_action_dim()
+    recs, holders = [], []
+    state = {"rec": None, "phase": None}
+    tap = _GumbelTap()
+    orig_randn, orig_randn_like, orig_randint = torch.randn, torch.randn_like, np.random.randint
+    cls = genvs.CartPoleEnv
+    orig_reset, orig_sample = cls.reset, gspaces.Discrete.sample
+    orig_cs_sample = ConfigSpace.ConfigurationSpace.sample_configuration
+    drawn = []
+
+    def rec_cs_sample(self):
+        d = orig_cs_sample(self)
+        drawn.append(dict(d))
+        return d
+
+    def rec_randn(*a, **k):
+        v = orig_randn(*a, **k)
+        rec = state["rec"]
+        if rec is not None and rec["purpose"] in ("act_noise", "test_noise"):
+            rec[rec["purpose"]].append(v.numpy().copy())
+        return v
+
+    def rec_randn_like(t, *a, **k):
+        v = orig_randn_like(t, *a, **k)
+        rec = state["rec"]
+        if rec is not None and rec["purpose"] == "learn":
+            rec["policy_noise"].append(v.numpy().copy())
+        return v
+
+    def rec_randint(*a, **k):
+        v = orig_randint(*a, **k)
+        if state["phase"] == "train":
+            state["rec"]["replay"].append(np.asarray(v).copy())
+        return v
+
+    def rec_sample(self):
+        v = orig_sample(self)
+        if state["phase"] == "train":
+            state["rec"]["rand"].append(int(v))
+        return v
+
+    def rec_reset(self):
+        obs = orig_reset(self)
+        if state["phase"] is not None:
+            state["rec"]["resets"].append((state["phase"], np.array(self.state, np.float64).copy()))
+        return obs
+
+    orig_step = train_env.step
+
+    def rec_step(action, state_=None):
+        ns, r, d = orig_step(action=action, state=state_)
+        if state["phase"] == "train":
+            state["rec"]["steps"].append(dict(action=action.detach().numpy().reshape(-1).astype(np.float32).copy(),
+                                              next_state=ns.detach().numpy().reshape(-1).copy(), reward=float(r.item()), done=float(d.item())))
+        return ns, r, d
+
+    orig_select_agent = ev.select_agent
+
+    def wrapped_select_agent(config, agent_name):
+        agent = orig_select_agent(config=config, agent_name=agent_name)
+        rec = dict(rand=[], act_noise=[], test_noise=[], policy_noise=[], replay=[], resets=[], steps=[], gumbel_act=[], gumbel_test=[],
+                   gumbel_learn=[], learn_calls=[], purpose=None)
+        state["rec"] = rec
+        recs.append(rec)
+        h = {"agent": agent, "hp": dict(drawn[-1]), "init": _pack_td3d(agent)}
+        holders.append(h)
+
+        def wrap(fn, purpose, sink_name):
+            def inner(*a, **k):
+                prev, prev_sink = rec["purpose"], tap.sink
+                rec["purpose"] = purpose
+                tap.sink = rec[sink_name]
+                n0 = len(rec[sink_name])
+                try:
+                    return fn(*a, **k)
+                finally:
+                    rec["purpose"], tap.sink = prev, prev_sink
+                    if purpose == "learn":
+                        rec["learn_calls"].append(len(rec[sink_name]) - n0)       # 1 = critics only, 2 = policy update too
+            return inner
+        agent.select_train_action = wrap(agent.select_train_action, "act_noise", "gumbel_act")
+        agent.select_test_action = wrap(agent.select_test_action, "test_noise", "gumbel_test")
+        agent.learn = wrap(agent.learn, "learn", "gumbel_learn")
+        orig_train, orig_test = agent.train, agent.test
+
+        def train(env, test_env=None, time_remaining=1e9):
+            assert test_env is None                       # the harness calls agent.train(env=train_env) (:56)
+            state["phase"] = "train"
+            out = orig_train(env=env, test_env=test_env, time_remaining=time_remaining)
+            state["phase"] = None
+            h["reward_train"], h["episode_length"] = list(out[0]), list(out[1])
+            h["rb_action"] = out[2].action[:out[2].size].numpy().astype(np.float32).copy()
+            return out
+
+        def test(env, time_remaining=1e9):
+            state["phase"] = "test"
+            out = orig_test(env=env, time_remaining=time_remaining)
+            state["phase"] = None
+            h["final_params"] = _pack_td3d(agent)
+            return out
+
+        agent.train, agent.test = train, test
+        return agent
+
+    seed_all(seed)
+    ConfigSpace.RANDOM.seed(vary_seed)
+    train_env.step = rec_step
+    torch.randn, torch.randn_like, np.random.randint = rec_randn, rec_randn_like, rec_randint
+    cls.reset, gspaces.Discrete.sample = rec_reset, rec_sample
+    ConfigSpace.ConfigurationSpace.sample_configuration = rec_cs_sample
+    ev.select_agent = wrapped_select_agent
+    try:
+        with quiet(), tap:
+            reward_list, train_steps_needed, episodes_needed = ev.train_test_agents(train_env=train_env, test_env=real_env, config=config,
+                                                                                   agents_num=agents_num)
+    finally:
+        torch.randn, torch.randn_like, np.random.randint = orig_randn, orig_randn_like, orig_randint
+        cls.reset, gspaces.Discrete.sample = orig_reset, orig_sample
+        ConfigSpace.ConfigurationSpace.sample_configuration = orig_cs_sample
+        ev.select_agent = orig_select_agent
+        shutil.rmtree(tmp, ignore_errors=True)
+    config["agents"]["gtn"]["agent_name"] = "TD3_discrete_vary"
+    config["agents"]["gtn"]["synthetic_env_type"] = 0
+    out = dict(config_json=np.array(json.dumps(config)), mode=np.array(2), agents_num=np.array(agents_num), theta=theta,
+               reward_list=np.array(reward_list, np.float64), train_steps_needed=np.array(train_steps_needed, np.int64),
+               episodes_needed=np.array(episodes_needed, np.int64))
+
+    def rows_of(lst):
+        return np.concatenate([np.asarray(v, np.float32).reshape(-1, A) for v in lst]) if lst else np.zeros((0, A), np.float32)
+    for i, (rec, h) in enumerate(zip(recs, holders)):
+        pre = "a%d_" % i
+        gt, ga, k = [], [], 0
+        for n in rec["learn_calls"]:                        # first Gumbel draw of a learn call: actor_target(next_states); second: actor(states)
+            gt.append(rec["gumbel_learn"][k])
+            if n > 1:
+                ga.append(rec["gumbel_learn"][k + 1])
+            k += n
+        out.update({pre + "hp_json": np.array(json.dumps(h["hp"])), pre + "agent_init": h["init"], pre + "final_params": h["final_params"],
+                    pre + "tape_rand_action": np.array(rec["rand"], np.int32), pre + "tape_act_noise": rows_of(rec["act_noise"]),
+                    pre + "tape_test_noise": rows_of(rec["test_noise"]), pre + "tape_policy_noise": rows_of(rec["policy_noise"]),
+                    pre + "tape_gumbel_act": rows_of(rec["gumbel_act"]), pre + "tape_gumbel_test": rows_of(rec["gumbel_test"]),
+                    pre + "tape_gumbel_target": rows_of(gt), pre + "tape_gumbel_actor": rows_of(ga),
+                    pre + "tape_replay_idx": (np.concatenate([np.asarray(v, np.int32).reshape(-1) for v in rec["replay"]]) if rec["replay"]
+                                              else np.zeros(0, np.int32)),
+                    pre + "tape_train_reset": np.array([s_ for (ph, s_) in rec["resets"] if ph == "train"], np.float64).reshape(-1, 4),
+                    pre + "tape_test_reset": np.array([s_ for (ph, s_) in rec["resets"] if ph == "test"], np.float64).reshape(-1, 4),
+                    pre + "tr_action": np.stack([s_["action"] for s_ in rec["steps"]]).astype(np.float32),
+                    pre + "tr_next_state": np.stack([s_["next_state"] for s_ in rec["steps"]]).astype(np.float32),
+                    pre + "tr_reward": np.array([s_["reward"] for s_ in rec["steps"]], np.float32),
+                    pre + "tr_done": np.array([s_["done"] for s_ in rec["steps"]], np.float32),
+                    pre + "rb_action": h["rb_action"],
+                    pre + "reward_train": np.array(h["reward_train"], np.float64),
+                    pre + "episode_length": np.array(h["episode_length"], np.int32)})
+    save(name, **out)
+    print(name, "episodes", [int(e[0]) for e in episodes_needed], "steps", [int(t[0]) for t in train_steps_needed],
+          "hp", [h["hp"] for h in holders], "reward_test", [np.mean(r) for r in reward_list])
+
+
 def main():
     # no arguments (or "all"): every fixture under tests/golden is regenerated (the full-shape runs g8df / g8tf take minutes each)
     ALL = ["g1", "g1ln", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x",
@@ -1629,6 +1812,10 @@ def main():
         # (batch 105 / width 42 / 3 layers and 58 / 63 / 1) so that the CPU oracle replays the run in seconds
         gen_g12("g12d_train_test_agents_cartpole_mode2_dueling_vary", mode=2, seed=1204, vary=True, vary_seed=1,
                 module="experiments.syn_env_evaluate_cartpole_vary_hp_2_DuelingDDQN", agent_key="duelingddqn")
+    if "g12t" in which:
+        # the TD3_discrete sibling script (td3_discrete_vary + LayerNorm section of default_config_cartpole.yaml); a vary_seed whose draws are
+        # small nets so that the CPU oracle replays the run in seconds
+        gen_g12t("g12t_train_test_agents_cartpole_mode2_td3_discrete_vary", seed=1205, vary_seed=int(os.environ.get("LENV_G12T_VARY_SEED", "1")))
     if "g1" in which:
         gen_g1()
     if "g1ln" in which:

@@ -24,6 +24,11 @@ G12 = ["g12_train_test_agents_cartpole_mode2_vary", "g12_train_test_agents_cartp
 G12D = "g12d_train_test_agents_cartpole_mode2_dueling_vary"
 
 
+# the TD3_discrete sibling script (experiments/syn_env_evaluate_cartpole_vary_hp_2_TD3_discrete.py: td3_discrete_vary from the LayerNorm section of
+# default_config_cartpole.yaml; drawn shapes 42 x 3 / batch 105 and 63 x 1 / batch 58; 32 and 36 episodes = 880 and 1 040 learn steps)
+G12T = "g12t_train_test_agents_cartpole_mode2_td3_discrete_vary"
+
+
 def g12_agent(name):
     """(agent_name of the harness, config section, base agent name) of a G12 fixture."""
     return ("DuelingDDQN_vary", "duelingddqn", "DuelingDDQN") if "dueling" in name else ("DDQN_vary", "ddqn", "DDQN")
@@ -78,6 +83,50 @@ def test_g12_oracle_reproduces_the_reference_train_test_agents(golden, name):
         np.testing.assert_allclose(out["final_test_returns"], g["reward_list"][i], rtol=0, atol=1e-4)
         # no per-episode tests ran: the only real-env test steps are the final test's
         assert out["test_steps"] == int(np.sum(g["reward_list"][i]))          # CartPole: return == episode length
+
+
+def g12t_oracle_cfg(g, i):
+    cfgd, hp = json.loads(str(g["config_json"])), json.loads(str(g["a%d_hp_json" % i]))
+    a = cfgd["agents"]["td3_discrete_vary"]
+    assert (a["train_episodes"], a["init_episodes"], a["early_out_num"], a["test_episodes"], a["early_out_virtual_diff"]) == (1000, 10, 10, 10, 0.01)
+    assert a["use_layer_norm"] is True and a["vary_hp"] is True
+    return orc.td3d_cfg_from_config(cfgd, rng_mode=1, hp=hp, test_mode=1), cfgd, hp
+
+
+def g12t_tapes(g, i):
+    return {k: g["a%d_tape_%s" % (i, k)] for k in orc.TD3D_TAPE_KEYS}
+
+
+def test_g12t_oracle_reproduces_the_td3_discrete_sibling_script(golden):
+    """The reference's TD3_discrete harness run replayed by the oracle chain with test_mode 1: the replay buffer's action vectors (Gumbel
+    softmax + Gaussian noise) within 1e-5 -- LayerNorm nets, 880 / 1 040 learn steps --, the env's view of them (argmax) exact, the per-episode
+    training rewards and the final test within 1e-4, the two counters the function returns EXACTLY."""
+    g = golden(G12T)
+    assert int(g["agents_num"]) == 2 and g["reward_list"].shape == (2, 10)
+    assert g["episodes_needed"].ravel().tolist() == [32, 36]            # the virtual rule said "no" 12 / 16 times before "yes"
+    for i in range(2):
+        pre = "a%d_" % i
+        cfg, cfgd, hp = g12t_oracle_cfg(g, i)
+        assert cfg.test_mode == 1 and cfg.early_out_virtual_diff == 0.01 and cfg.use_layer_norm == 1
+        assert (cfg.batch_size, cfg.hidden, cfg.layers) == (hp["batch_size"], hp["hidden_size"], hp["hidden_layer"])
+        assert orc.td3d_num_params(cfg)[0] == g[pre + "agent_init"].size
+        n = g[pre + "tr_reward"].size
+        out = orc.td3d_chain(cfg, g["theta"], g[pre + "agent_init"], tapes=orc.make_td3d_tapes(cfg.action_dim, **g12t_tapes(g, i)), trace_cap=n + 4)
+        assert out["rc"] == 0
+        e = int(g["episodes_needed"][i, 0])
+        assert out["episodes_run"] == e and out["train_steps"] == int(g["train_steps_needed"][i, 0]) == n
+        assert np.array_equal(out["episode_len"][:e], g[pre + "episode_length"])
+        assert out["learn_steps"] == g[pre + "tape_gumbel_target"].shape[0] // cfg.batch_size
+        tr = out["trace"]
+        np.testing.assert_allclose(tr["action"], g[pre + "rb_action"][:n], rtol=0, atol=1e-5)
+        assert np.array_equal(tr["action"].argmax(1), g[pre + "tr_action"].reshape(-1).astype(np.int64))
+        np.testing.assert_allclose(tr["next_state"], g[pre + "tr_next_state"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(tr["reward"], g[pre + "tr_reward"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(out["episode_test_mean"][:e], g[pre + "reward_train"], rtol=0, atol=1e-4)
+        assert np.isnan(out["episode_test_mean"][e:]).all()
+        np.testing.assert_allclose(out["final_test_returns"], g["reward_list"][i], rtol=0, atol=1e-4)
+        assert out["test_steps"] == int(np.sum(g["reward_list"][i]))          # no per-episode tests; CartPole: return == episode length
+        np.testing.assert_allclose(out["final_params"], g[pre + "final_params"], rtol=0, atol=2e-5)      # measured 3.6e-7
 
 
 def test_g12_fixtures_exercise_the_early_out_rules(golden):
@@ -153,6 +202,39 @@ def test_g12_product_train_test_agents_replays_the_reference_run(golden, tmp_pat
         assert last["episode_length"][i] == g[pre + "episode_length"].tolist()
         ocfg, _, _ = g12_oracle_cfg(g, i, grad_chunk=last["inner"].cfg.grad_chunk, dueling="dueling" in name)
         o = orc.ddqn_se_chain(ocfg, g["theta"], g[pre + "agent_init"], tapes=orc.make_tapes(*g12_tapes(g, i)))
+        assert rewards[i] == o["final_test_returns"].tolist()
+        assert last["reward_train"][i] == o["episode_test_mean"][:o["episodes_run"]].tolist()
+        assert last["inner"].stats[i].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
+@pytest.mark.gpu
+def test_g12t_product_train_test_agents_replays_the_td3_discrete_sibling_run(golden, tmp_path):
+    """The TD3_discrete sibling script's reference run replayed through the product function (agent_name "td3_discrete_vary": the fused
+    TD3-discrete loop in tape mode, the two drawn shapes in one launch): equal to the oracle bit for bit, to the reference within the bars of
+    the CPU half."""
+    from learning_environments_amd.experiments.syn_env_evaluate import train_test_agents
+    g = golden(G12T)
+    venv, real_env, config = _load_ckpt_b(tmp_path)
+    assert np.array_equal(venv.env.flat_params().cpu().numpy(), g["theta"])
+    # the sibling script takes its agent section from default_config_cartpole.yaml's `td3_discrete_vary_layer_norm_2` (:35-40); the fixture's
+    # config_json holds what load_envs_and_config produced there
+    config["agents"]["td3_discrete_vary"] = dict(json.loads(str(g["config_json"]))["agents"]["td3_discrete_vary"], train_episodes=5, vary_hp=False)
+    hps = [json.loads(str(g["a%d_hp_json" % i])) for i in range(2)]
+    replay = dict(hp=hps, agent_init=[g["a%d_agent_init" % i] for i in range(2)],
+                  tapes={k: [g["a%d_tape_%s" % (i, k)] for i in range(2)] for k in orc.TD3D_TAPE_KEYS})
+    rewards, steps, episodes = train_test_agents(venv, real_env, config, agents_num=2, agent_name="td3_discrete_vary", replay=replay)
+    a = config["agents"]["td3_discrete_vary"]
+    assert (a["train_episodes"], a["init_episodes"], a["early_out_num"], a["test_episodes"], a["early_out_virtual_diff"], a["vary_hp"]) == (1000, 10, 10, 10, 0.01, True)
+    last = train_test_agents.last
+    assert last["inner"].cfg.test_mode == 1
+    assert steps == g["train_steps_needed"].tolist() and episodes == g["episodes_needed"].tolist()
+    np.testing.assert_allclose(np.array(rewards), g["reward_list"], rtol=0, atol=1e-4)
+    for i in range(2):
+        pre = "a%d_" % i
+        np.testing.assert_allclose(last["reward_train"][i], g[pre + "reward_train"], rtol=0, atol=1e-4)
+        assert last["episode_length"][i] == g[pre + "episode_length"].tolist()
+        ocfg, _, _ = g12t_oracle_cfg(g, i)
+        o = orc.td3d_chain(ocfg, g["theta"], g[pre + "agent_init"], tapes=orc.make_td3d_tapes(ocfg.action_dim, **g12t_tapes(g, i)))
         assert rewards[i] == o["final_test_returns"].tolist()
         assert last["reward_train"][i] == o["episode_test_mean"][:o["episodes_run"]].tolist()
         assert last["inner"].stats[i].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
