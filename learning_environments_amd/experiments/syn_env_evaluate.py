@@ -79,15 +79,31 @@ def _task_config(train_env, config, agent_name):
     return cfg, torch.zeros(n, dtype=torch.float32, device=HipNesEngine().device)
 
 
-def train_test_agents(train_env, test_env, config, agents_num, agent_name="DDQN_vary", train_episodes=1000, vary_hp=True, seed=0, replay=None):
+def train_test_agents(train_env, test_env, config, agents_num, agent_name="DDQN_vary", train_episodes=1000, vary_hp=True, seed=0, replay=None,
+                      model_index=0):
     """Returns (reward_list, train_steps_needed, episodes_needed) like the reference: reward_list[i] = the i-th agent's list of
     real-env test returns (BaseAgent.test), train_steps_needed[i] = [sum(episode_length)], episodes_needed[i] = [len(reward_train)].
 
     agent_name / train_episodes select the sibling script (HARNESS_AGENTS); vary_hp=False keeps the base hyper-parameters (the
-    `_vary` agent with vary_hp off IS its base agent, DDQN_vary.py:16-21).  `seed` keys the agents' counter RNG streams (the reference
-    draws from the process-global generators).  replay = dict(hp=[...], agent_init=[...], tapes={name: [per-agent array]}): the
-    recorded draws of a reference run, replayed in tape mode (parity tests); the returned dict `train_test_agents.last` holds the
+    `_vary` agent with vary_hp off IS its base agent, DDQN_vary.py:16-21).  `seed` / `model_index` key the agents' counter RNG streams
+    (the reference draws from the process-global generators).  replay = dict(hp=[...], agent_init=[...], tapes={name: [per-agent array]}):
+    the recorded draws of a reference run, replayed in tape mode (parity tests); the returned dict `train_test_agents.last` holds the
     per-agent training lists (reward_train, episode_length) of the last call."""
+    return _launch([train_env], test_env, config, agents_num, agent_name, train_episodes, vary_hp, seed, replay, [model_index])[0]
+
+
+def train_test_agents_models(train_envs, test_env, config, agents_num, agent_name="DDQN_vary", train_episodes=1000, vary_hp=True, seed=0,
+                             model_indices=None):
+    """The model loop of experiments/syn_env_run_vary_hp.py:47-117 as ONE fused launch: `agents_num` agents on every env of `train_envs`
+    (loaded SE checkpoints of one experiment -- same shapes --, or the real env repeated: mode 0) = len(train_envs) * agents_num chains, chain
+    (m, i) reading model m's weights.  Returns [train_test_agents(train_envs[m], ..., model_index=model_indices[m]) for m], bit for bit
+    (tests/test_run_vary_hp.py) -- where the reference spreads the models over a multiprocessing pool (:66-72,102-110), here they fill the GPU."""
+    if model_indices is None:
+        model_indices = list(range(len(train_envs)))
+    return _launch(list(train_envs), test_env, config, agents_num, agent_name, train_episodes, vary_hp, seed, None, list(model_indices))
+
+
+def _launch(train_envs, test_env, config, agents_num, agent_name, train_episodes, vary_hp, seed, replay, model_indices):
     key = agent_name.lower()
     if key not in HARNESS_AGENTS:
         raise NotImplementedError("train_test_agents: agent '%s' (the harness scripts train %s)" % (agent_name, sorted(HARNESS_AGENTS)))
@@ -97,26 +113,42 @@ def train_test_agents(train_env, test_env, config, agents_num, agent_name="DDQN_
     section, vary_section = HARNESS_AGENTS[key]
     if not vary_hp:
         config['agents'][vary_section]['vary_hp'] = False
-    cfg, theta = _task_config(train_env, config, agent_name)
+    M, n_ag = len(train_envs), int(agents_num)
+    cfg, theta = _task_config(train_envs[0], config, agent_name)
     engine = HipNesEngine()
-    task = tasks.select_task(cfg, engine, train_env, test_mode=1)
+    task = tasks.select_task(cfg, engine, train_envs[0], test_mode=1)
     dev = engine.device
-    chains = int(agents_num)
+    chains = M * n_ag
     if replay is not None:
+        assert M == 1
         task.cfg.rng_mode = 1
         if hasattr(task, "fixed_hp"):
             task.fixed_hp = list(replay["hp"])
     inner = task.make_inner(chains, want_episode_stats=True)
-    keys = chain_keys(int(seed), 0, np.arange(chains), np.zeros(chains, np.int64))
+    keys = np.concatenate([chain_keys(int(seed), int(mi), np.arange(n_ag), np.zeros(n_ag, np.int64)) for mi in model_indices])
     keys_t = torch.from_numpy(keys.view(np.int64)).to(dev)
-    worker = torch.zeros(chains, dtype=torch.int32, device=dev)
-    sign = torch.zeros(chains, dtype=torch.float32, device=dev)
-    eps = torch.zeros((1, theta.numel()), dtype=torch.float32, device=dev)
+    if M == 1:
+        # one model: its weights are theta itself, sign 0 (the unperturbed checkpoint)
+        worker = torch.zeros(chains, dtype=torch.int32, device=dev)
+        sign = torch.zeros(chains, dtype=torch.float32, device=dev)
+        eps = torch.zeros((1, theta.numel()), dtype=torch.float32, device=dev)
+    else:
+        # several models: chain (m, i) reads 0 + 1 * weights[m] (exact; a stored -0.0 becomes +0.0, which no sum downstream can tell apart)
+        thetas = [theta] + [_task_config(e, config, agent_name)[1] for e in train_envs[1:]]
+        if any(t.numel() != theta.numel() for t in thetas) or any(e.is_virtual_env() != train_envs[0].is_virtual_env() for e in train_envs):
+            raise ValueError("train_test_agents_models: the models of one launch must have the same shapes")
+        eps = torch.stack([t.to(device=dev, dtype=torch.float32) for t in thetas])
+        theta = torch.zeros_like(eps[0])
+        worker = torch.arange(chains, dtype=torch.int32, device=dev) // n_ag
+        sign = torch.ones(chains, dtype=torch.float32, device=dev)
     agent_init = None
     if task.needs_agent_init():
-        g = torch.Generator(device=dev)
-        g.manual_seed(int(seed))
-        agent_init = fresh_agent_init(task.agent_bounds, chains, g, dev)
+        rows = []
+        for mi in model_indices:
+            g = torch.Generator(device=dev)
+            g.manual_seed(int(seed) + 1000003 * int(mi))
+            rows.append(fresh_agent_init(task.agent_bounds, n_ag, g, dev))
+        agent_init = torch.cat(rows)
     if replay is None:
         task.scores(inner, theta, eps, worker, sign, keys_t, agent_init)
     else:
@@ -130,11 +162,13 @@ def train_test_agents(train_env, test_env, config, agents_num, agent_name="DDQN_
     episodes_needed = [[int(stats[i, 0])] for i in range(chains)]
     train_test_agents.last = dict(reward_train=[ep_mean[i, :int(stats[i, 0])].tolist() for i in range(chains)],
                                   episode_length=[ep_len[i, :int(stats[i, 0])].tolist() for i in range(chains)],
-                                  hp=getattr(task, "last_hp", None), inner=inner, task=task)
-    return reward_list, train_steps_needed, episodes_needed
+                                  hp=getattr(task, "last_hp", None), inner=inner, task=task, keys=keys)
+    return [(reward_list[m * n_ag:(m + 1) * n_ag], train_steps_needed[m * n_ag:(m + 1) * n_ag], episodes_needed[m * n_ag:(m + 1) * n_ag])
+            for m in range(M)]
 
 
 train_test_agents.last = None
+train_test_agents.fused = train_test_agents_models       # run_vary_hp (syn_env_run_vary_hp.py) takes the one-launch path when it finds this
 
 
 def _pad_rows(rows, dtype, width=None):

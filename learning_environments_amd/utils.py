@@ -66,3 +66,20 @@ class AverageMeter:
 
     def get_raw_data(self):
         return self.vals
+
+
+def save_lists(mode, config, reward_list, train_steps_needed, episode_length_needed, env_reward_overview, experiment_name=None, out_dir=None):
+    """The harness's result file `<mode>_<experiment_name>.pt` (reference utils.py:144-160: same keys, the overview as a DataFrame with one
+    row per model / real-env repetition)."""
+    import os
+    import pandas as pd
+    if experiment_name is None:
+        experiment_name = "_experiment_"
+    if out_dir is None:
+        out_dir = os.getcwd()
+    file_name = os.path.join(out_dir, str(mode) + '_' + experiment_name + '.pt')
+    save_dict = {'config': config, 'reward_list': reward_list, 'train_steps_needed': train_steps_needed,
+                 'episode_length_needed': episode_length_needed,
+                 'env_reward_overview': pd.DataFrame.from_dict(env_reward_overview, orient="index")}
+    torch.save(save_dict, file_name)
+    return file_name

@@ -1,0 +1,156 @@
+"""SURVEY.md §8(f).1, one row up: the caller of the evaluation harness -- reference experiments/syn_env_run_vary_hp.py
+(`get_all_files` :8-29, `run_vary_hp` :32-139) and its result file (utils.py:144-160 `save_lists`).
+
+CPU half: the file selection rules and the list / file shapes with a stand-in harness function (no GPU work).
+GPU half: the product's train_test_agents behind it -- all models of a mode in ONE fused launch (model_num * agents_num chains, chain (m, i)
+reading model m's weights) equal to the model-by-model calls bit for bit, and to the oracle chain of that (model, agent)."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from learning_environments_amd.experiments import syn_env_run_vary_hp as rv      # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _fake_loader(vary_of):
+    def load(file_name, model_dir, device):
+        real = types.SimpleNamespace(env=types.SimpleNamespace(env_name="CartPole-v0"))
+        return "venv:" + file_name, real, {"agents": {"ddqn_vary": {"vary_hp": vary_of[file_name]}}, "file": file_name}
+    return load
+
+
+def test_get_all_files_rules(tmp_path):
+    """:10-29: files of the env only, vary_hp flag of the checkpoint's config, sorted by the LAST NINE characters (the random tag + '.pt'),
+    the first model_num of them; too few -> ValueError unless a filter list is given; the filter keeps the sorted order."""
+    vary_of = {"CartPole-v0_3_ZZZZZZ.pt": True, "CartPole-v0_25_AAAAAB.pt": True, "CartPole-v0_9_MMMMMM.pt": True, "CartPole-v0_1_BBBBBB.pt": False,
+               "Acrobot-v1_1_AAAAAA.pt": True}
+    for f in vary_of:
+        (tmp_path / f).write_bytes(b"")
+    load = _fake_loader(vary_of)
+    got = rv.get_all_files(True, 2, str(tmp_path), load, "CartPole", "cpu")
+    assert got == ["CartPole-v0_25_AAAAAB.pt", "CartPole-v0_9_MMMMMM.pt"]
+    assert rv.get_all_files(False, 1, str(tmp_path), load, "CartPole", "cpu") == ["CartPole-v0_1_BBBBBB.pt"]
+    assert rv.get_all_files(True, 1, str(tmp_path), load, "Acrobot", "cpu") == ["Acrobot-v1_1_AAAAAA.pt"]
+    with pytest.raises(ValueError):
+        rv.get_all_files(True, 4, str(tmp_path), load, "CartPole", "cpu")
+    flt = ["CartPole-v0_3_ZZZZZZ.pt", "CartPole-v0_25_AAAAAB.pt", "CartPole-v0_1_BBBBBB.pt"]
+    assert rv.get_all_files(True, 40, str(tmp_path), load, "CartPole", "cpu", filter_models_list=flt) == ["CartPole-v0_25_AAAAAB.pt", "CartPole-v0_3_ZZZZZZ.pt"]
+
+
+@pytest.mark.parametrize("mode,correlation", [(0, False), (1, False), (2, False), (2, True)])
+def test_run_vary_hp_lists_and_result_file_with_a_stand_in_harness(tmp_path, mode, correlation):
+    """A callable without `.fused` is called model by model like the reference's pool-less branch (:47-63,84-98); the three lists are the
+    concatenation over the models (one entry per model with correlation_exp on a syn. env, :112-117); the file holds what save_lists writes."""
+    vary_of = {"CartPole-v0_3_ZZZZZZ.pt": True, "CartPole-v0_25_AAAAAB.pt": True, "CartPole-v0_1_BBBBBB.pt": False}
+    model_dir = tmp_path / "models"
+    model_dir.mkdir()
+    for f in vary_of:
+        (model_dir / f).write_bytes(b"")
+    calls = []
+
+    def harness(train_env, test_env, config, agents_num):
+        calls.append(train_env)
+        k = len(calls)
+        return [[float(10 * k + i)] * 3 for i in range(agents_num)], [[100 * k + i] for i in range(agents_num)], [[k] for _ in range(agents_num)]
+    model_num = {0: 2, 1: 1, 2: 2}[mode]
+    out = rv.run_vary_hp(mode, "exp", model_num, 2, str(model_dir), _fake_loader(vary_of), harness, "CartPole", device="cpu",
+                         correlation_exp=correlation, out_dir=str(tmp_path))
+    assert len(calls) == model_num
+    if mode == 0:
+        assert all(not isinstance(c, str) for c in calls)                   # the real env itself is the training env
+        rows = ["CartPole-v0_0", "CartPole-v0_1"]
+    elif mode == 1:
+        assert calls == ["venv:CartPole-v0_1_BBBBBB.pt"]
+        rows = ["CartPole-v0_1_BBBBBB.pt"]
+    else:
+        assert calls == ["venv:CartPole-v0_25_AAAAAB.pt", "venv:CartPole-v0_3_ZZZZZZ.pt"]
+        rows = ["CartPole-v0_25_AAAAAB.pt", "CartPole-v0_3_ZZZZZZ.pt"]
+    saved = torch.load(str(tmp_path / ("%d_exp.pt" % mode)), weights_only=False)
+    assert set(saved) == {"config", "reward_list", "train_steps_needed", "episode_length_needed", "env_reward_overview"}
+    assert saved["reward_list"] == out[0] and saved["train_steps_needed"] == out[1] and saved["episode_length_needed"] == out[2]
+    if correlation:
+        assert len(out[0]) == model_num and len(out[0][0]) == 2 and saved["env_reward_overview"].shape[1] == 0      # (:114: empty dicts)
+    else:
+        assert list(saved["env_reward_overview"].index) == rows
+        assert len(out[0]) == 2 * model_num and out[1][0] == [100] and out[2][-1] == [model_num]
+        assert saved["env_reward_overview"].shape == (model_num, 6)          # np.hstack of the model's agents' return lists
+    with pytest.raises(ValueError):
+        rv.run_vary_hp(3, "exp", 1, 1, str(model_dir), _fake_loader(vary_of), harness, "CartPole")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# GPU half
+# ------------------------------------------------------------------------------------------------------------------------------
+def _write_models(tmp_path):
+    """Three CartPole SE checkpoints in the reference's format: the reference-written one of G12 and two perturbed copies; the vary_hp
+    flag of `ddqn_vary` (what get_all_files selects on) on for two, off for one."""
+    from learning_environments_amd.experiments.syn_env_evaluate import load_envs_and_config
+    src = os.path.join(HERE, "golden", "ckpt_cartpole_se_reference_b.pt")
+    d = tmp_path / "models"
+    d.mkdir()
+    base = torch.load(src, map_location="cpu", weights_only=False)
+    gen = torch.Generator().manual_seed(9)
+    for name, vary, amp in (("CartPole-v0_4_QQQQQQ.pt", True, 0.0), ("CartPole-v0_7_CCCCCC.pt", True, 0.02), ("CartPole-v0_2_HHHHHH.pt", False, 0.03)):
+        sd = {k: (v + amp * torch.randn(v.shape, generator=gen)) if v.dtype.is_floating_point else v for k, v in base["model"].items()}
+        cfg = json.loads(json.dumps(base["config"]))
+        cfg["agents"]["ddqn_vary"]["vary_hp"] = vary
+        torch.save({"model": sd, "config": cfg}, str(d / name))
+    return str(d), load_envs_and_config
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [2, 1, 0])
+def test_run_vary_hp_one_launch_equals_model_by_model_and_the_oracle(tmp_path, mode):
+    from oracle import oracle as orc
+    from learning_environments_amd.agents.nes_common import chain_keys
+    from learning_environments_amd.experiments.syn_env_evaluate import train_test_agents
+    model_dir, load = _write_models(tmp_path)
+    model_num, agents_num = {2: 2, 1: 1, 0: 2}[mode], 3
+    rewards, steps, episodes = rv.run_vary_hp(mode, "t", model_num, agents_num, model_dir, load, train_test_agents, "CartPole", out_dir=str(tmp_path))
+    last = train_test_agents.last
+    assert last["inner"].chains == model_num * agents_num and last["inner"].cfg.test_mode == 1          # ONE launch for all models
+    assert len(rewards) == len(steps) == len(episodes) == model_num * agents_num
+    fused_train = last["reward_train"]
+    hps = last["hp"]
+    # model by model through the same function (what a harness callable without `.fused` gets)
+    if mode == 0:
+        _, real_env, config = load(os.listdir(model_dir)[0], model_dir, "cuda")
+        seq = [train_test_agents(real_env, real_env, config, agents_num, model_index=m) for m in range(model_num)]
+        files = [None] * model_num
+    else:
+        files = rv.get_all_files(mode == 2, model_num, model_dir, load, "CartPole", "cuda")
+        assert files == (["CartPole-v0_7_CCCCCC.pt", "CartPole-v0_4_QQQQQQ.pt"] if mode == 2 else ["CartPole-v0_2_HHHHHH.pt"])
+        seq = []
+        for m, f in enumerate(files):
+            venv, real_env, config = load(f, model_dir, "cuda")
+            # (mode 1 selects the checkpoints whose `vary_hp` is off; the harness function switches it on for its agents all the same,
+            # syn_env_evaluate_cartpole_vary_hp_2.py:30 -- the reference's behaviour)
+            seq.append(train_test_agents(venv, real_env, config, agents_num, model_index=m))
+    assert [r for s_ in seq for r in s_[0]] == rewards and [r for s_ in seq for r in s_[1]] == steps and [r for s_ in seq for r in s_[2]] == episodes
+    # one (model, agent) pair against the oracle chain: its model's weights, its key (seed 0, model index, agent index), its draw
+    m, i = model_num - 1, agents_num - 1
+    c = m * agents_num + i
+    cfgd = json.loads(json.dumps(load(os.listdir(model_dir)[0] if mode == 0 else files[m], model_dir, "cuda")[2]))
+    from learning_environments_amd.experiments.syn_env_evaluate import apply_comparability_settings
+    apply_comparability_settings(cfgd)
+    cfgd["agents"]["gtn"]["agent_name"] = "DDQN"
+    over = dict(synthetic_env_type=1, reward_env_type=0) if mode == 0 else {}
+    over.update(orc.hp_overrides(hps[c]))
+    inner = last["inner"]
+    ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=inner.cfg.grad_chunk, rng_mode=0, test_mode=1, **over)
+    key = int(chain_keys(0, m, np.array([i]), np.zeros(1, np.int64))[0])
+    assert key == int(last["keys"][c])
+    theta = np.zeros(1, np.float32) if mode == 0 else load(files[m], model_dir, "cuda")[0].env.flat_params().cpu().numpy()
+    p_c = orc.mlp_num_params(orc.mlp_desc(4, ocfg.q_hidden, ocfg.q_layers, 2, ocfg.q_act))
+    o = orc.ddqn_se_chain(ocfg, theta, inner.agent_init[c].cpu().numpy()[:p_c], rng_key=key)
+    assert o["rc"] == 0
+    assert rewards[c] == o["final_test_returns"].tolist() and steps[c] == [o["train_steps"]] and episodes[c] == [o["episodes_run"]]
+    assert fused_train[c] == o["episode_test_mean"][:o["episodes_run"]].tolist()
+    saved = torch.load(os.path.join(str(tmp_path), "%d_t.pt" % mode), weights_only=False)
+    assert saved["reward_list"] == rewards and saved["env_reward_overview"].shape == (model_num, 10 * agents_num)

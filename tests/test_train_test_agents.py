@@ -287,6 +287,43 @@ def test_product_train_test_agents_counter_mode_vs_oracle(tmp_path, mode, vary):
 
 
 @pytest.mark.gpu
+def test_product_train_test_agents_acrobot_script_vs_oracle():
+    """experiments/syn_env_evaluate_acrobot_vary_hp_2.py: the same function on an Acrobot-v1 SE (DDQN_vary over default_config_acrobot.yaml's
+    128-wide two-layer DDQN; here shrunk so that the CPU oracle finishes in seconds).  Three agents with drawn shapes in one launch, each
+    bit-identical to the oracle chain with test_mode 1; training ends on the virtual rule, the final test runs on the real Acrobot."""
+    import torch
+    from learning_environments_amd import configs
+    from learning_environments_amd.agents.nes_common import chain_keys
+    from learning_environments_amd.envs.env_factory import EnvFactory
+    from learning_environments_amd.experiments.syn_env_evaluate import train_test_agents
+    config = configs.with_vary(configs.acrobot_syn_env_ddqn(num_workers=1))
+    config["device"] = "cuda"
+    config["agents"]["ddqn"].update(hidden_size=24, batch_size=16)
+    config["envs"]["Acrobot-v1"].update(max_steps=30, hidden_size=32)
+    torch.manual_seed(3)
+    fac = EnvFactory(config)
+    venv, real_env = fac.generate_virtual_env(), fac.generate_real_env()
+    rewards, steps, episodes = train_test_agents(venv, real_env, config, agents_num=3, train_episodes=40, seed=21)
+    last = train_test_agents.last
+    inner, hps = last["inner"], last["hp"]
+    assert inner.cfg.test_mode == 1 and inner.cfg.env_id == 1 and len(hps) == 3
+    keys = chain_keys(21, 0, np.arange(3), np.zeros(3, np.int64))
+    theta = venv.env.flat_params().cpu().numpy()
+    inits = inner.agent_init.cpu().numpy()
+    cfgd = json.loads(json.dumps(config))
+    cfgd["agents"]["gtn"]["agent_name"] = "DDQN"
+    for c in range(3):
+        ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=inner.cfg.grad_chunk, rng_mode=0, test_mode=1, **orc.hp_overrides(hps[c]))
+        p_c = orc.mlp_num_params(orc.mlp_desc(6, ocfg.q_hidden, ocfg.q_layers, 3, ocfg.q_act))
+        o = orc.ddqn_se_chain(ocfg, theta, inits[c][:p_c], rng_key=int(keys[c]))
+        assert o["rc"] == 0 and o["episodes_run"] >= 21
+        assert rewards[c] == o["final_test_returns"].tolist() and len(rewards[c]) == 10
+        assert steps[c] == [o["train_steps"]] and episodes[c] == [o["episodes_run"]]
+        assert last["reward_train"][c] == o["episode_test_mean"][:o["episodes_run"]].tolist()
+        assert inner.stats[c].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+
+
+@pytest.mark.gpu
 def test_product_train_test_agents_refuses_what_the_harness_does_not_train(tmp_path):
     from learning_environments_amd.experiments.syn_env_evaluate import train_test_agents
     venv, real_env, config = _load_ckpt_b(tmp_path)
