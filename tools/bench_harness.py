@@ -1,0 +1,51 @@
+"""The evaluation harness as an experiment runs it (reference experiments/syn_env_evaluate_cartpole_vary_hp_2.py __main__: 40 models x 10
+DDQN_vary agents per mode): run_vary_hp with all models in ONE fused launch against the model-by-model calls the reference's loop makes.
+Models: CartPole SEs of default_config_cartpole.yaml's shape whose reward net says ~1 per step (a stand-in for trained SEs: 200-step episodes,
+the virtual early-out after 20-30 episodes).  usage: python tools/bench_harness.py [model_num] [agents_num]"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from learning_environments_amd.experiments import syn_env_run_vary_hp as rv                      # noqa: E402
+from learning_environments_amd.experiments.syn_env_evaluate import load_envs_and_config, train_test_agents   # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    model_num = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    agents_num = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    base = torch.load(os.path.join(HERE, "..", "tests", "golden", "ckpt_cartpole_se_reference_b.pt"), map_location="cpu", weights_only=False)
+    d = tempfile.mkdtemp(prefix="lenv_harness_")
+    gen = torch.Generator().manual_seed(1)
+    for m in range(model_num):
+        sd = {k: (v + 0.01 * torch.randn(v.shape, generator=gen)) if v.dtype.is_floating_point else v for k, v in base["model"].items()}
+        cfg = json.loads(json.dumps(base["config"]))
+        cfg["envs"]["CartPole-v0"].update(max_steps=200, solved_reward=195.0)
+        cfg["agents"]["ddqn_vary"]["vary_hp"] = True
+        torch.save({"model": sd, "config": cfg}, os.path.join(d, "CartPole-v0_%d_%06d.pt" % (m, m)))
+    for mode in (2, 0):
+        for label, fn in (("one fused launch", train_test_agents), ("model by model", lambda **k: train_test_agents(**k))):
+            n = model_num if label == "one fused launch" or mode == 2 else min(model_num, 8)
+            if label == "model by model":
+                n = min(n, 8)                               # (a sample: the loop is model_num times this)
+            rv.run_vary_hp(mode, "warm", 1, agents_num, d, load_envs_and_config, fn, "CartPole", out_dir=d)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            rewards, steps, episodes = rv.run_vary_hp(mode, "b", n, agents_num, d, load_envs_and_config, fn, "CartPole", out_dir=d)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            tot_steps = sum(s[0] for s in steps)
+            print(json.dumps({"mode": mode, "path": label, "models": n, "agents": n * agents_num, "seconds": round(dt, 3),
+                              "agents_per_s": round(n * agents_num / dt, 2), "train_steps": tot_steps,
+                              "mean_episodes": round(sum(e[0] for e in episodes) / len(episodes), 1),
+                              "mean_test_return": round(sum(sum(r) / len(r) for r in rewards) / len(rewards), 1)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
