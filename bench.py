@@ -457,6 +457,77 @@ def secondary_configs(only=None, team_size=0):
     return out
 
 
+def next_row_records():
+    """SURVEY.md §8(f) rows measured next to the contract line (never part of `value`): the evaluation harness at the experiment's size
+    (reference experiments/syn_env_evaluate_cartpole_vary_hp_2.py __main__: 40 checkpoints x 10 DDQN_vary agents, mode 2, through run_vary_hp
+    = ONE fused launch of 400 chains) and the two shipped small-net shapes that got their own kernel paths in round 6."""
+    import copy
+    import shutil
+    import tempfile
+    from learning_environments_amd import configs as C
+    from learning_environments_amd.agents.GTN import GTN_Master
+    from learning_environments_amd.experiments import syn_env_run_vary_hp as rv
+    from learning_environments_amd.experiments.syn_env_evaluate import load_envs_and_config, train_test_agents
+    out = []
+    ck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "ckpt_cartpole_se_reference_b.pt")
+    if os.path.exists(ck):
+        base = torch.load(ck, map_location="cpu", weights_only=False)
+        d = tempfile.mkdtemp(prefix="lenv_bench_harness_")
+        try:
+            gen = torch.Generator().manual_seed(1)
+            for m in range(40):
+                sd = {k: (v + 0.01 * torch.randn(v.shape, generator=gen)) if v.dtype.is_floating_point else v for k, v in base["model"].items()}
+                cfg = copy.deepcopy(base["config"])
+                cfg["envs"]["CartPole-v0"].update(max_steps=200, solved_reward=195.0)
+                cfg["agents"]["ddqn_vary"]["vary_hp"] = True
+                torch.save({"model": sd, "config": cfg}, os.path.join(d, "CartPole-v0_%d_%06d.pt" % (m, m)))
+            rv.run_vary_hp(2, "warm", 1, 10, d, load_envs_and_config, train_test_agents, "CartPole", out_dir=d)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rewards, steps, episodes = rv.run_vary_hp(2, "b", 40, 10, d, load_envs_and_config, train_test_agents, "CartPole", out_dir=d)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out.append({"row": "SURVEY 8(f).1 evaluation harness: run_vary_hp mode 2, 40 SE checkpoints x 10 DDQN_vary agents (drawn shapes) in one fused launch, "
+                               "checkpoint loading and the result file inside the time", "agents": 400, "seconds": dt, "agents_per_s": 400 / dt,
+                        "train_steps": int(sum(s_[0] for s_ in steps)), "mean_episodes": float(np.mean([e[0] for e in episodes])),
+                        "models": "stand-ins for trained SEs: default_config_cartpole.yaml's shape, reward ~1 per step, 200-step episodes"})
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
+    def generation(name, cfg, kernel, gens=3):
+        torch.manual_seed(0)
+        cwd = os.getcwd()
+        work = os.path.join("/tmp", "lenv_bench_%d" % os.getpid())
+        os.makedirs(work, exist_ok=True)
+        os.chdir(work)
+        try:
+            m = GTN_Master(cfg, bohb_id=0, seed=7)
+        finally:
+            os.chdir(cwd)
+        m.step(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(1, 1 + gens):
+            m.step(it)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / gens
+        st = m.inner.stats.cpu().numpy()
+        out.append({"row": name, "kernel": kernel, "chains": int(st.shape[0]), "ms_per_generation": dt * 1e3,
+                    "train_steps": int(st[:, 1].sum()), "learn_steps": int(st[:, 2].sum()), "test_steps": int(st[:, 3].sum())})
+        del m
+        torch.cuda.empty_cache()
+    c = C.fixed_work(C.cmc_syn_env_td3(16), 3)
+    c["agents"]["td3"].update(init_episodes=1, hidden_size=64, hidden_layer=1, activation_fn="leakyrelu")
+    c["envs"]["MountainCarContinuous-v0"].update(max_steps=200, hidden_size=128, hidden_layer=3, activation_fn="relu")
+    generation("default_config_cmc_syn_env_opt.yaml-like TD3 (actor 2-64-1, critics 3-64-1, B 256) on a 128x3 VirtualEnv, pop 16 = 48 chains, "
+               "3 episodes x 100 agent steps", c, "td3_rn_inner_kernel<DIRECT>")
+    c = C.fixed_work(C.cartpole_reward_env_ddqn(16), 6)
+    c["agents"]["gtn"]["quit_when_solved"] = False
+    generation("default_config_cartpole_reward_env.yaml: DDQN 4-64-2 on the real CartPole + reward net, pop 16 = 48 chains, 6 episodes", c,
+               "ddqn_se_inner_kernel<RENV>")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # one rank
 # ----------------------------------------------------------------------------------------------------------------------
@@ -591,6 +662,12 @@ def run_rank(args):
     others = None
     if world == 1 and not plumbing and not args.no_configs:
         others = secondary_configs()           # the other BASELINE configurations, one shard each (not part of `value`)
+    next_rows = None
+    if world == 1 and not plumbing and not args.no_configs:
+        try:
+            next_rows = next_row_records()
+        except Exception as e:                 # (never let an extra record cost the contract line)
+            next_rows = [{"error": repr(e)[:300]}]
     gpu_section_s = time.perf_counter() - t_start
 
     if rank == 0:
@@ -655,6 +732,8 @@ def run_rank(args):
             line["config"] = {"workload": "plumbing self-test of the multi-rank path"}
         if others is not None:
             line["configs"] = others
+        if next_rows is not None:
+            line["next_rows"] = next_rows
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
