@@ -30,6 +30,7 @@ from ..envs.env_factory import EnvFactory
 from ..envs.reward_env import RewardEnv
 
 # agent_name -> (config section the harness's settings go to, section that carries vary_hp); the sibling scripts differ in these only
+LPT_MIN_CHAINS = 256      # launches above this many chains (= the compute units of an MI355X) run their expensive draws first (see _launch)
 HARNESS_AGENTS = {"ddqn_vary": ("ddqn", "ddqn_vary"), "duelingddqn_vary": ("duelingddqn", "duelingddqn_vary"),
                   "td3_discrete_vary": ("td3_discrete_vary", "td3_discrete_vary")}
 
@@ -141,6 +142,17 @@ def _launch(train_envs, test_env, config, agents_num, agent_name, train_episodes
         theta = torch.zeros_like(eps[0])
         worker = torch.arange(chains, dtype=torch.int32, device=dev) // n_ag
         sign = torch.ones(chains, dtype=torch.float32, device=dev)
+    # More chains than compute units (one workgroup per CU): the hardware hands the waiting workgroups out in launch order, so the expensive
+    # draws go first (longest-processing-time-first; the chains are independent and keyed, the order changes nothing but the makespan).
+    # Results are returned in (model, agent) order; `last["order"][k]` = the (model, agent) index that ran as chain k of `last["inner"]`.
+    order = None
+    if replay is None and chains > LPT_MIN_CHAINS and getattr(task, "fixed_hp", 0) is None:
+        hp_pre = task.draw_hp(keys)
+        cost = np.array([(h["hidden_layer"] + 1) * (20000.0 + h["batch_size"] * h["hidden_size"] * (h["hidden_size"] if h["hidden_layer"] > 1 else 8) / 8.0)
+                         for h in hp_pre])
+        order = np.argsort(-cost, kind="stable")
+        idx = torch.from_numpy(order.copy()).to(dev)
+        keys_t, worker, sign = keys_t[idx], worker[idx], sign[idx]
     agent_init = None
     if task.needs_agent_init():
         rows = []
@@ -157,12 +169,17 @@ def _launch(train_envs, test_env, config, agents_num, agent_name, train_episodes
     stats = inner.stats.cpu().numpy()
     finals = inner.final_returns.cpu().numpy()
     ep_mean, ep_len = inner.episode_test_mean.cpu().numpy(), inner.episode_len.cpu().numpy()
+    hp_last = getattr(task, "last_hp", None)
+    if order is not None:
+        inv = np.argsort(order)
+        stats, finals, ep_mean, ep_len = stats[inv], finals[inv], ep_mean[inv], ep_len[inv]
+        hp_last = [hp_last[k] for k in inv] if hp_last is not None else None
     reward_list = [finals[i].tolist() for i in range(chains)]
     train_steps_needed = [[int(ep_len[i, :int(stats[i, 0])].sum())] for i in range(chains)]
     episodes_needed = [[int(stats[i, 0])] for i in range(chains)]
     train_test_agents.last = dict(reward_train=[ep_mean[i, :int(stats[i, 0])].tolist() for i in range(chains)],
                                   episode_length=[ep_len[i, :int(stats[i, 0])].tolist() for i in range(chains)],
-                                  hp=getattr(task, "last_hp", None), inner=inner, task=task, keys=keys)
+                                  hp=hp_last, inner=inner, task=task, keys=keys, order=order)
     return [(reward_list[m * n_ag:(m + 1) * n_ag], train_steps_needed[m * n_ag:(m + 1) * n_ag], episodes_needed[m * n_ag:(m + 1) * n_ag])
             for m in range(M)]
 

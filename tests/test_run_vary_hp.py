@@ -105,11 +105,16 @@ def _write_models(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [2, 1, 0])
-def test_run_vary_hp_one_launch_equals_model_by_model_and_the_oracle(tmp_path, mode):
+@pytest.mark.parametrize("mode,lpt", [(2, False), (1, False), (0, False), (2, True), (0, True)])
+def test_run_vary_hp_one_launch_equals_model_by_model_and_the_oracle(tmp_path, monkeypatch, mode, lpt):
+    """lpt: the launch order of big launches (more chains than compute units: the expensive draws first) forced on for this small one --
+    the returned lists stay in (model, agent) order."""
     from oracle import oracle as orc
     from learning_environments_amd.agents.nes_common import chain_keys
+    from learning_environments_amd.experiments import syn_env_evaluate as se
     from learning_environments_amd.experiments.syn_env_evaluate import train_test_agents
+    if lpt:
+        monkeypatch.setattr(se, "LPT_MIN_CHAINS", 4)
     model_dir, load = _write_models(tmp_path)
     model_num, agents_num = {2: 2, 1: 1, 0: 2}[mode], 3
     rewards, steps, episodes = rv.run_vary_hp(mode, "t", model_num, agents_num, model_dir, load, train_test_agents, "CartPole", out_dir=str(tmp_path))
@@ -118,6 +123,12 @@ def test_run_vary_hp_one_launch_equals_model_by_model_and_the_oracle(tmp_path, m
     assert len(rewards) == len(steps) == len(episodes) == model_num * agents_num
     fused_train = last["reward_train"]
     hps = last["hp"]
+    assert (last["order"] is not None) == lpt
+    if lpt:
+        assert sorted(last["order"].tolist()) == list(range(model_num * agents_num))
+        monkeypatch.setattr(se, "LPT_MIN_CHAINS", 256)
+    slot = (lambda c_: c_) if not lpt else (lambda c_, inv=np.argsort(last["order"]): int(inv[c_]))       # chain of `inner` that ran pair c_
+    fused_inner = last["inner"]
     # model by model through the same function (what a harness callable without `.fused` gets)
     if mode == 0:
         _, real_env, config = load(os.listdir(model_dir)[0], model_dir, "cuda")
@@ -142,13 +153,13 @@ def test_run_vary_hp_one_launch_equals_model_by_model_and_the_oracle(tmp_path, m
     cfgd["agents"]["gtn"]["agent_name"] = "DDQN"
     over = dict(synthetic_env_type=1, reward_env_type=0) if mode == 0 else {}
     over.update(orc.hp_overrides(hps[c]))
-    inner = last["inner"]
+    inner = fused_inner
     ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=inner.cfg.grad_chunk, rng_mode=0, test_mode=1, **over)
     key = int(chain_keys(0, m, np.array([i]), np.zeros(1, np.int64))[0])
     assert key == int(last["keys"][c])
     theta = np.zeros(1, np.float32) if mode == 0 else load(files[m], model_dir, "cuda")[0].env.flat_params().cpu().numpy()
     p_c = orc.mlp_num_params(orc.mlp_desc(4, ocfg.q_hidden, ocfg.q_layers, 2, ocfg.q_act))
-    o = orc.ddqn_se_chain(ocfg, theta, inner.agent_init[c].cpu().numpy()[:p_c], rng_key=key)
+    o = orc.ddqn_se_chain(ocfg, theta, inner.agent_init[slot(c)].cpu().numpy()[:p_c], rng_key=key)
     assert o["rc"] == 0
     assert rewards[c] == o["final_test_returns"].tolist() and steps[c] == [o["train_steps"]] and episodes[c] == [o["episodes_run"]]
     assert fused_train[c] == o["episode_test_mean"][:o["episodes_run"]].tolist()

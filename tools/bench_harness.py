@@ -29,9 +29,13 @@ def main():
         cfg["envs"]["CartPole-v0"].update(max_steps=200, solved_reward=195.0)
         cfg["agents"]["ddqn_vary"]["vary_hp"] = True
         torch.save({"model": sd, "config": cfg}, os.path.join(d, "CartPole-v0_%d_%06d.pt" % (m, m)))
-    for mode in (2, 0):
-        for label, fn in (("one fused launch", train_test_agents), ("model by model", lambda **k: train_test_agents(**k))):
-            n = model_num if label == "one fused launch" or mode == 2 else min(model_num, 8)
+    from learning_environments_amd.experiments import syn_env_evaluate as se
+    for mode in (2, 2, 0):
+        lpt = se.LPT_MIN_CHAINS
+        for label, fn in (("one fused launch", train_test_agents), ("one fused launch, launch order = (model, agent) order", train_test_agents),
+                          ("model by model", lambda **k: train_test_agents(**k))):
+            se.LPT_MIN_CHAINS = 10 ** 9 if "launch order" in label else lpt
+            n = model_num
             if label == "model by model":
                 n = min(n, 8)                               # (a sample: the loop is model_num times this)
             rv.run_vary_hp(mode, "warm", 1, agents_num, d, load_envs_and_config, fn, "CartPole", out_dir=d)
