@@ -17,7 +17,19 @@
 #include "lenv_gemm.cuh"
 #include "lenv_ln.cuh"
 
+// Diagnostic build only (-DLENV_PHASE_TIMING): per-phase shader-clock totals of chain 0, never in the shipped library.
+#ifdef LENV_PHASE_TIMING
+#define TDP_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TDP_MARK(i) do { unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
+#else
+#define TDP_DECL
+#define TDP_MARK(i)
+#endif
+
 namespace lenv {
+#ifdef LENV_PHASE_TIMING
+__device__ unsigned long long g_td3d_phase_cycles[8];
+#endif
 
 constexpr int TD_MAXL = 3;     // hidden layers of actor / critic (vary_hyperparameters draws hidden_layer + 1)
 constexpr int TD_MAXW = 512;   // max hidden_size
@@ -397,6 +409,7 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
     const bool budgeted = cfg.step_budget > 0;
     int timed_out_at = -1;
     const bool no_test_env = cfg.test_mode == 1;      // BaseAgent.train(env, test_env=None): lenv_ddqn_cfg::test_mode
+    TDP_DECL;
     for (int episode = 0; episode < cfg.train_episodes; ++episode) {
         if (budgeted && (int64_t)train_steps + test_steps > cfg.step_budget) { timed_out_at = episode; break; }   // uniform
         const bool learning = episode >= cfg.init_episodes;
@@ -429,12 +442,14 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
                 ++n_rand;
                 __syncthreads();
             } else {
+                TDP_MARK(7);
                 mlp_row1(params, mo_actor, state, nse, 0, act_id, prelu);               // raw actor outputs -> nse[0..A)
                 const int64_t c0 = n_actn;
                 noisy_actions(nse, action, 1, [&](int) { return c0; }, a.tapes.gumbel_act, a.tapes.gumbel_act_stride, STREAM_TD3D_GUMBEL_ACT,
                               a.tapes.act_noise, a.tapes.act_noise_stride, STREAM_TD3_ACT_NOISE);
                 ++n_actn;
             }
+            TDP_MARK(0);                                   // select_train_action
             // ---- env.step(action.argmax()) -> EnvWrapper.step: one-hot of the index -> VirtualEnv.step (virtual_env.py:43-54): the
             // three SE nets on cat(one_hot, state); reward / done see the pre-transition state ----
             if (tid == 0) {
@@ -464,6 +479,7 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
             ++ep_len; ++train_steps;
             __syncthreads();
 
+            TDP_MARK(1);                                   // SE step + append
             if (learning) {
                 // ================= TD3_discrete_vary.learn (:62-117) =================
                 temp = td3d_temperature(cfg.gumbel_temp, learn_it);                   // read before total_it += 1 (:64-69)
@@ -524,7 +540,9 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
                 gq.run<TD_MAXI>(Ps, Qs);                                             // dbuf is shared by the two backward passes
                 mlp_backward(params + Pa + Pc, mo_critic, xc, SA, B, hc2, xh2, rs2, dq2, grad + Pa + Pc, nullptr);
                 gq.run<TD_MAXI>(Ps, Qs);
+                TDP_MARK(2);                               // critics: forwards, TD error, backwards
                 adam(Pa, 2 * Pc, 0);                       // critic_optimizer: critic_1 then critic_2 parameters
+                TDP_MARK(3);
                 ++learn_it;
                 if (policy_step) {
                     // actor_loss = (-critic_1(states, actor(states, temp))).mean() with the updated critic_1
@@ -563,6 +581,7 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
                     wg_polyak(params, targets, P, tau, omt);
                     __syncthreads();
                     ++policy_it;
+                    TDP_MARK(4);                           // policy update
                 }
             }
             if (done_now > 0.5f) break;
@@ -570,7 +589,9 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
         ++episodes_run;
         if (tid == 0 && a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + episode] = ep_len;
         __syncthreads();
+        TDP_MARK(7);
         if (!no_test_env) test_phase();                    // per-episode test on the real env (base_agent.py:134-136)
+        TDP_MARK(5);
         if (tid == 0) {
             double tm;
             if (no_test_env) tm = (double)tr_reward;       // train(env, test_env=None): avg_meter_reward.update(episode_reward) (base_agent.py:138)
@@ -633,6 +654,9 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
             if (a.out.episode_len) a.out.episode_len[chain * cfg.train_episodes + e] = pad_l;
         }
     }
+#ifdef LENV_PHASE_TIMING
+    if (tid == 0 && chain == 0) for (int pi = 0; pi < 8; ++pi) g_td3d_phase_cycles[pi] = pt_acc[pi];
+#endif
     if (a.out.final_params) for (int p = tid; p < P; p += DNT) a.out.final_params[chain * a.P + p] = params[p];
     if (a.out.status && status != 0) atomicMin(&a.out.status[chain], status);
 }
@@ -799,3 +823,10 @@ extern "C" int lenv_td3d_inner_loop(const lenv_td3d_cfg *cfg, const lenv_chain_h
     hipLaunchKernelGGL(kern, dim3((unsigned)chains), dim3(DNT), lds_bytes, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? LENV_OK : LENV_ERR_LAUNCH;
 }
+
+#ifdef LENV_PHASE_TIMING
+extern "C" int lenv_debug_td3d_phase_cycles(unsigned long long *host_out)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_td3d_phase_cycles), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -4;
+}
+#endif

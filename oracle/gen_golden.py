@@ -1797,7 +1797,7 @@ def gen_g12t(name, seed, vary_seed, agents_num=2, ckpt="ckpt_cartpole_se_referen
 def main():
     # no arguments (or "all"): every fixture under tests/golden is regenerated (the full-shape runs g8df / g8tf take minutes each)
     ALL = ["g1", "g1ln", "g2", "g3", "g4", "g4d", "g4t", "g6", "g7", "g8", "g8d", "g8t", "g9", "g10", "g2f", "ckpt", "g8w", "g6m", "g9x",
-           "g8tv", "g8ts", "g8p", "g8c", "g8cf", "g8pf", "g8ti", "g8tf", "g8tln", "g8df", "g8l2", "g8ln", "g8seln", "g8tseln", "g8tdseln", "g9ln", "g8m", "g8r", "g8rl", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k", "g8long"]
+           "g8tv", "g8ts", "g8p", "g8c", "g8cf", "g8co", "g8pf", "g8ti", "g8tf", "g8tln", "g8df", "g8l2", "g8ln", "g8seln", "g8tseln", "g8tdseln", "g9ln", "g8m", "g8r", "g8rl", "g8i", "g8v", "g11", "g4td", "g8td", "g8k", "g9k", "g8long"]
     which = sys.argv[1:] or ALL
     if "all" in which:
         which = ALL
@@ -1914,6 +1914,13 @@ def main():
         gen_g8t("g8cf_calc_score_cmc_td3_virtual_env_fullshape", seed=883, virtual=True, cfg_yaml="default_config_cmc.yaml",
                 env_name="MountainCarContinuous-v0", env_cls="Continuous_MountainCarEnv",
                 agent_over={"train_episodes": 3, "init_episodes": 1, "test_episodes": 1}, env_over={"max_steps": 30})
+    if "g8co" in which:
+        # default_config_cmc_syn_env_opt.yaml at its REAL shapes (actor 2-64-1, twin critics 3-64-1 leakyrelu -- ONE hidden layer --, batch 256,
+        # policy_delay 2, same_action_num 2, SE nets 3-128-128-128-{2,1,1} relu): two learning episodes of 20 agent steps = 40 learn steps,
+        # 20 policy steps -- the shape the DIRECT instantiations of the TD3 GEMM-queue kernel run
+        gen_g8t("g8co_calc_score_cmc_td3_syn_env_opt_fullshape", seed=886, virtual=True, cfg_yaml="default_config_cmc_syn_env_opt.yaml",
+                env_name="MountainCarContinuous-v0", env_cls="Continuous_MountainCarEnv",
+                agent_over={"train_episodes": 3, "init_episodes": 1, "test_episodes": 1}, env_over={"max_steps": 40})
     if "g8pf" in which:
         # the td3 sections of default_config_pendulum.yaml (SE nets 4-32-32-x) and default_config_halfcheetah.yaml (SE nets
         # 23-128-128-128-x) at their REAL shapes: batch 256, policy_delay 2, ten test episodes per test phase

@@ -702,7 +702,7 @@ def test_g8p_td3_on_pendulum(golden, name):
 
 
 @pytest.mark.parametrize("name", ["g8c_calc_score_cmc_td3_virtual_env", "g8cr_calc_score_cmc_td3_reward_env",
-                                  "g8cf_calc_score_cmc_td3_virtual_env_fullshape"])
+                                  "g8cf_calc_score_cmc_td3_virtual_env_fullshape", "g8co_calc_score_cmc_td3_syn_env_opt_fullshape"])
 def test_g8c_td3_on_mountaincar_continuous(golden, name):
     """default_config_cmc.yaml / default_config_cmc_reward_env.yaml's env with their same_action_num = 2: TD3 on a VirtualEnv of
     MountainCarContinuous-v0 and on a RewardEnv (type 2, tanh) over the real env.  Every chosen action is applied twice
@@ -722,7 +722,13 @@ def test_g8c_td3_on_mountaincar_continuous(golden, name):
     np.testing.assert_allclose(out["trace"]["action"], g["tr_action"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(out["trace"]["next_state"], g["tr_next_state"], rtol=0, atol=2e-6 if cfg.virtual_env else 1e-9)
     np.testing.assert_allclose(out["trace"]["reward"], g["tr_reward"], rtol=0, atol=2e-6)
-    if full:
+    if full and "syn_env_opt" in name:
+        # g8co: default_config_cmc_syn_env_opt.yaml at its REAL shapes (actor 2-64-1, critics 3-64-1 leakyrelu: ONE hidden layer; SE nets
+        # 3-128-128-128-x relu) -- the shape the DIRECT instantiations of the TD3 GEMM-queue kernel run: 40 learn steps, 20 policy updates
+        assert (cfg.hidden, cfg.layers, cfg.batch_size, cfg.policy_delay, cfg.rn_hidden, cfg.rn_layers, cfg.virtual_env) == (64, 1, 256, 2, 128, 3, 1)
+        assert out["learn_steps"] == 40 and g["agent_init"].size == 899 and g["theta"].size == 101124
+        np.testing.assert_allclose(out["final_params"], g["final_params"], rtol=0, atol=2e-6)
+    elif full:
         assert (cfg.hidden, cfg.layers, cfg.batch_size, cfg.policy_delay, cfg.rn_hidden, cfg.rn_layers, cfg.virtual_env) == (128, 2, 256, 2, 96, 2, 1)
         assert out["learn_steps"] == 30 and g["agent_init"].size == 51331
         # all 51 331 parameters after 30 critic steps and 15 actor steps + soft updates (Adam's first steps move every weight by ~lr)

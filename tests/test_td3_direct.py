@@ -127,3 +127,51 @@ def test_direct_is_not_taken_where_it_does_not_apply(eng, orc, golden):
             assert il.status.cpu().tolist() == [0]
             outs.append(il.final_params.cpu().numpy().copy())
         assert np.array_equal(outs[0], outs[1], equal_nan=True)
+
+
+def test_direct_replays_the_reference_run_of_the_syn_env_opt_shape(eng, orc, golden):
+    """Fixture G8CO: the reference's own TD3 run at default_config_cmc_syn_env_opt.yaml's REAL shapes (actor 2-64-1, critics 3-64-1 leakyrelu,
+    batch 256, policy_delay 2, same_action_num 2, SE nets 3-128-128-128-x relu; 40 learn steps, 20 policy updates) replayed in tape mode by
+    the DIRECT instantiation (thread-per-sample learn step + the LDS-row SE step): bit-equal to the oracle and to the queued products incl.
+    all final parameters, within the fixture tolerances of the reference's own numbers."""
+    from learning_environments_amd import _lib
+    g = golden("g8co_calc_score_cmc_td3_syn_env_opt_fullshape")
+    cfgd = json.loads(str(g["config_json"]))
+    n = g["tr_reward"].size
+    o_cfg = orc.td3_cfg_from_config(cfgd, rng_mode=1)
+    assert (o_cfg.hidden, o_cfg.layers, o_cfg.batch_size, o_cfg.policy_delay, o_cfg.rn_hidden, o_cfg.rn_layers, o_cfg.virtual_env) == (64, 1, 256, 2, 128, 3, 1)
+    otapes = orc.make_td3_tapes(g["tape_rand_action"], g["tape_act_noise"], g["tape_test_noise"], g["tape_policy_noise"],
+                                g["tape_replay_idx"], g["tape_train_reset"], g["tape_test_reset"], A=1, S=2)
+    o = orc.td3_rn_chain(o_cfg, g["theta"], g["agent_init"], tapes=otapes, trace_cap=n + 4, want_final_params=True)
+    assert o["rc"] == 0 and o["learn_steps"] == 40
+    chains = 2
+    rep = lambda a: dev(np.tile(np.ascontiguousarray(a)[None], (chains,) + (1,) * np.ndim(a)))
+    tapes = dict(rand_action=rep(g["tape_rand_action"]), act_noise=rep(g["tape_act_noise"]), test_noise=rep(g["tape_test_noise"]),
+                 policy_noise=rep(g["tape_policy_noise"]), replay_idx=rep(g["tape_replay_idx"].reshape(-1)),
+                 train_reset=rep(g["tape_train_reset"]), test_reset=rep(g["tape_test_reset"]))
+    finals = {}
+    for variant in (0, _lib.VARIANT_NO_WAVECHAIN, _lib.VARIANT_NO_WAVECHAIN | _lib.VARIANT_NO_DIRECT):
+        c = _lib.Td3Cfg()
+        for f, _ in _lib.Td3Cfg._fields_:
+            setattr(c, f, getattr(o_cfg, f, 0))
+        c.kernel_variant = variant
+        il = eng.Td3InnerLoop(c, chains, trace_cap=n + 4, want_episode_stats=True, want_final_params=True)
+        assert il.p_agent == g["agent_init"].size
+        il.run(dev(g["theta"]), None, None, None, dev(np.tile(g["agent_init"], (chains, 1))), tapes=tapes)
+        torch.cuda.synchronize()
+        assert il.status.cpu().tolist() == [0] * chains
+        for ch in range(chains):
+            assert np.array_equal(il.trace["action"][ch, :n].cpu().numpy(), o["trace"]["action"])
+            assert np.array_equal(il.trace["next_state"][ch, :n].cpu().numpy(), o["trace"]["next_state"])
+            assert np.array_equal(il.trace["reward"][ch, :n].cpu().numpy(), o["trace"]["reward"])
+            assert np.array_equal(il.episode_len[ch].cpu().numpy(), o["episode_len"])
+            assert np.array_equal(il.final_params[ch].cpu().numpy(), o["final_params"])
+            assert float(il.score[ch]) == o["score"]
+            assert il.stats[ch].cpu().tolist() == [o["episodes_run"], o["train_steps"], o["learn_steps"], o["test_steps"]]
+            np.testing.assert_allclose(il.trace["action"][ch, :n].cpu().numpy(), g["tr_action"], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(il.trace["next_state"][ch, :n].cpu().numpy(), g["tr_next_state"], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(il.trace["reward"][ch, :n].cpu().numpy(), g["tr_reward"], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(il.final_params[ch].cpu().numpy(), g["final_params"], rtol=0, atol=2e-6)
+            assert abs(float(il.score[ch]) - float(g["score"])) <= 1e-4
+        finals[variant] = il.final_params.cpu().numpy().copy()
+    assert len({f.tobytes() for f in finals.values()}) == 1
