@@ -19,7 +19,7 @@
 
 // Diagnostic build only (-DLENV_PHASE_TIMING): per-phase shader-clock totals of chain 0, never in the shipped library.
 #ifdef LENV_PHASE_TIMING
-#define TDP_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TDP_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define TDP_MARK(i) do { unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
 #else
 #define TDP_DECL
@@ -28,7 +28,7 @@
 
 namespace lenv {
 #ifdef LENV_PHASE_TIMING
-__device__ unsigned long long g_td3d_phase_cycles[8];
+__device__ unsigned long long g_td3d_phase_cycles[16];
 #endif
 
 constexpr int TD_MAXL = 3;     // hidden layers of actor / critic (vary_hyperparameters draws hidden_layer + 1)
@@ -255,7 +255,15 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
             for (int j = tid; j < n_out; j += DNT) {
                 const float *w = W + (int64_t)j * n_in;
                 float z = 0.0f;
-                for (int k = 0; k < n_in; ++k) z = fma32(in[k], w[k], z);
+                int k = 0;
+                for (; k + 32 <= n_in; k += 32) {              // 32 terms requested before the first fmaf (one round trip instead of 32)
+                    float wv[32], xv[32];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) { wv[u] = w[k + u]; xv[u] = in[k + u]; }
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) z = fma32(xv[u], wv[u], z);
+                }
+                for (; k < n_in; ++k) z = fma32(in[k], w[k], z);
                 z = z + bb[j];
                 h[j] = (last || lnl) ? z : act_fwd(act, pr, z);
             }
@@ -500,6 +508,7 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
                 // next_actions = actor_target(s', temp) + (randn_like * policy_std).clamp(-clip, clip)   (no clamp to the action range)
                 mlp_forward(targets, mo_actor, xn, SA, B, ht, nullptr, nullptr, rawb, A, 0);
                 gq.run<TD_MAXI>(Ps, Qs);
+                TDP_MARK(8);                               // (sub) gather + actor_target forward
                 for (int b = tid; b < B; b += DNT) {
                     const int64_t n = learn_it * B + b;
                     float gm[TD_MAXA], na[TD_MAXA];
@@ -526,6 +535,7 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
                 mlp_forward(params + Pa, mo_critic, xc, SA, B, hc1, xh1, rs1, q1, 1, 0);
                 mlp_forward(params + Pa + Pc, mo_critic, xc, SA, B, hc2, xh2, rs2, q2, 1, 0);
                 gq.run<TD_MAXI>(Ps, Qs);
+                TDP_MARK(9);                               // (sub) gumbel/noise + four critic forwards
                 {
                     const float norm = (float)(2.0 / (double)B);
                     for (int b = tid; b < B; b += DNT) {
@@ -538,6 +548,7 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
                 __syncthreads();
                 mlp_backward(params + Pa, mo_critic, xc, SA, B, hc1, xh1, rs1, dq1, grad + Pa, nullptr);
                 gq.run<TD_MAXI>(Ps, Qs);                                             // dbuf is shared by the two backward passes
+                TDP_MARK(10);                              // (sub) TD error + critic_1 backward
                 mlp_backward(params + Pa + Pc, mo_critic, xc, SA, B, hc2, xh2, rs2, dq2, grad + Pa + Pc, nullptr);
                 gq.run<TD_MAXI>(Ps, Qs);
                 TDP_MARK(2);                               // critics: forwards, TD error, backwards
@@ -655,7 +666,7 @@ __global__ __launch_bounds__(DNT) void td3_discrete_inner_kernel(const Td3dArgs 
         }
     }
 #ifdef LENV_PHASE_TIMING
-    if (tid == 0 && chain == 0) for (int pi = 0; pi < 8; ++pi) g_td3d_phase_cycles[pi] = pt_acc[pi];
+    if (tid == 0 && chain == 0) for (int pi = 0; pi < 16; ++pi) g_td3d_phase_cycles[pi] = pt_acc[pi];
 #endif
     if (a.out.final_params) for (int p = tid; p < P; p += DNT) a.out.final_params[chain * a.P + p] = params[p];
     if (a.out.status && status != 0) atomicMin(&a.out.status[chain], status);
@@ -827,6 +838,6 @@ extern "C" int lenv_td3d_inner_loop(const lenv_td3d_cfg *cfg, const lenv_chain_h
 #ifdef LENV_PHASE_TIMING
 extern "C" int lenv_debug_td3d_phase_cycles(unsigned long long *host_out)
 {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_td3d_phase_cycles), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -4;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lenv::g_td3d_phase_cycles), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;
 }
 #endif

@@ -17,7 +17,8 @@ os.chdir("/tmp/lenv_bench")
 from learning_environments_amd.agents.GTN import GTN_Master  # noqa: E402
 from learning_environments_amd import configs  # noqa: E402
 
-names = ["select action (actor row + noise)", "SE step + append", "critics fwd/TD/bwd", "critic adam", "policy update", "tests", "-", "other"]
+names = ["select action (actor row + noise)", "SE step + append", "critics: critic_2 backward (rest of the phase)", "critic adam", "policy update", "tests", "-", "other",
+         "critics: gather + actor_target forward", "critics: gumbel / noise + four critic forwards", "critics: TD error + critic_1 backward"]
 
 
 def run(label, c):
@@ -25,7 +26,7 @@ def run(label, c):
     m.step(0)
     torch.cuda.synchronize()
     t0 = time.time(); m.step(1); torch.cuda.synchronize(); dt = time.time() - t0
-    buf = (C.c_ulonglong * 8)()
+    buf = (C.c_ulonglong * 16)()
     _lib.lib().lenv_debug_td3d_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
     assert _lib.lib().lenv_debug_td3d_phase_cycles(buf) == 0
     st = m.inner.stats[0].tolist()
@@ -33,7 +34,7 @@ def run(label, c):
     print("%s: generation wall %.1f ms; stats %s; total %.1f Mcycles" % (label, dt * 1e3, st, tot / 1e6))
     for i, n in enumerate(names):
         if buf[i]:
-            per = buf[i] / max(1, st[1] if i in (0, 1) else (st[2] if i in (2, 3, 4) else st[3]))
+            per = buf[i] / max(1, st[1] if i in (0, 1) else (st[2] if i in (2, 3, 4, 8, 9, 10) else st[3]))
             print("  %-36s %12d cycles  %5.1f%%  %9.0f per step" % (n, buf[i], 100.0 * buf[i] / max(1, tot), per))
 
 
