@@ -12,28 +12,51 @@ namespace lenv {
 // -- LNBUF floats from Ps on -- are free between queue runs; odd row stride = conflict-free), thread b then owns row b: sequential mean /
 // variance and the normalised row in place, and the copy back applies weight, bias and activation: xh <- normalised rows, rstd[b],
 // z <- act(fma(xn, w, b)) ----
+// (round 6: the copies request eight rows' words before the first LDS store -- one round trip per eight rows instead of one per row, which was
+// ~30 k of the routine's ~55 k cycles at 128 x 128 --, and the staged rows are addressed as LDS (ds_ instead of flat instructions); the
+// arithmetic and its order are unchanged)
+template <int NB>
+__device__ __forceinline__ void ln_copy_rows_in(const float *src, int ld, int nr, int Hh, lfloat *buf, int Hp, int lane_, int wave_)
+{
+    for (int b0 = wave_; b0 < nr; b0 += DNW * NB)
+        for (int jj = lane_; jj < Hh; jj += 64) {
+            float v[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) { const int b = b0 + DNW * u; v[u] = b < nr ? src[(int64_t)b * ld + jj] : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) { const int b = b0 + DNW * u; if (b < nr) buf[b * Hp + jj] = v[u]; }
+        }
+}
+
 template <int LNBUF>
 __device__ __forceinline__ void ln_rows_forward(float *Ps, float *z, int I, int Hh, const float *w, const float *bb, float *xh, float *rstd, int act, float pr)
 {
-    const int tid = threadIdx.x, lane_ = tid & 63, wave_ = tid >> 6;
+    const int tid = threadIdx.x, lane_ = tid & 63, wave_ = uni(tid >> 6);
     const int Hp = Hh | 1, R = LNBUF / Hp;
-    float *buf = Ps;
+    lfloat *buf = (lfloat *)uni_ptr(Ps);
     for (int r0 = 0; r0 < I; r0 += R) {
         const int nr = I - r0 < R ? I - r0 : R;
-        for (int b = wave_; b < nr; b += DNW) {
-            const float *src = z + (int64_t)(r0 + b) * Hh;
-            for (int jj = lane_; jj < Hh; jj += 64) buf[b * Hp + jj] = src[jj];
-        }
+        ln_copy_rows_in<8>(z + (int64_t)r0 * Hh, Hh, nr, Hh, buf, Hp, lane_, wave_);
         __syncthreads();
         for (int b = tid; b < nr; b += DNT) {
-            float *zr = buf + b * Hp;
+            lfloat *zr = buf + b * Hp;
             float sm = 0.0f, sv = 0.0f;
+#pragma unroll 16
             for (int jj = 0; jj < Hh; ++jj) sm = sm + zr[jj];
             const float mean = sm / (float)Hh;
+#pragma unroll 16
             for (int jj = 0; jj < Hh; ++jj) { const float dj = zr[jj] - mean; sv = fma32(dj, dj, sv); }
             const float r = 1.0f / __builtin_sqrtf(sv / (float)Hh + 1e-5f);
             if (rstd) rstd[r0 + b] = r;
-            for (int jj = 0; jj < Hh; ++jj) zr[jj] = (zr[jj] - mean) * r;
+            int jj = 0;
+            for (; jj + 8 <= Hh; jj += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = zr[jj + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) zr[jj + u] = (v[u] - mean) * r;
+            }
+            for (; jj < Hh; ++jj) zr[jj] = (zr[jj] - mean) * r;
         }
         __syncthreads();
         for (int b = wave_; b < nr; b += DNW) {
@@ -55,7 +78,7 @@ __device__ __forceinline__ void ln_rows_forward(float *Ps, float *z, int I, int 
 template <int LNBUF, int MAXW>
 __device__ __forceinline__ void ln_rows_backward(float *Ps, float *d, int I, int Hh, const float *w, const float *xh, const float *rstd, float *g_w, float *g_b, bool first)
 {
-    const int tid = threadIdx.x, lane_ = tid & 63, wave_ = tid >> 6;
+    const int tid = threadIdx.x, lane_ = tid & 63, wave_ = uni(tid >> 6);
     if (g_w) {
         for (int jj = tid; jj < Hh; jj += DNT) {
             float sw = 0.0f, sb = 0.0f;
@@ -78,24 +101,44 @@ __device__ __forceinline__ void ln_rows_backward(float *Ps, float *d, int I, int
         __syncthreads();
     }
     const int Hp = Hh | 1, R = (LNBUF - MAXW) / (2 * Hp);
-    float *wl = Ps, *bufd = Ps + MAXW, *bufx = bufd + R * Hp;
+    lfloat *wl = (lfloat *)uni_ptr(Ps), *bufd = wl + MAXW, *bufx = bufd + R * Hp;
     for (int jj = tid; jj < Hh; jj += DNT) wl[jj] = w[jj];
     for (int r0 = 0; r0 < I; r0 += R) {
         const int nr = I - r0 < R ? I - r0 : R;
-        for (int b = wave_; b < nr; b += DNW) {
-            const float *sd = d + (int64_t)(r0 + b) * Hh, *sx = xh + (int64_t)(r0 + b) * Hh;
-            for (int jj = lane_; jj < Hh; jj += 64) { bufd[b * Hp + jj] = sd[jj]; bufx[b * Hp + jj] = sx[jj]; }
-        }
+        ln_copy_rows_in<4>(d + (int64_t)r0 * Hh, Hh, nr, Hh, bufd, Hp, lane_, wave_);
+        ln_copy_rows_in<4>(xh + (int64_t)r0 * Hh, Hh, nr, Hh, bufx, Hp, lane_, wave_);
         __syncthreads();
         for (int b = tid; b < nr; b += DNT) {
-            float *dr = bufd + b * Hp;
-            const float *xr = bufx + b * Hp;
+            lfloat *dr = bufd + b * Hp;
+            const lfloat *xr = bufx + b * Hp;
             float s1 = 0.0f, s2 = 0.0f;
-            for (int jj = 0; jj < Hh; ++jj) dr[jj] = dr[jj] * wl[jj];
+            {
+                int jj = 0;
+                for (; jj + 8 <= Hh; jj += 8) {
+                    float v[8], wv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { v[u] = dr[jj + u]; wv[u] = wl[jj + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) dr[jj + u] = v[u] * wv[u];
+                }
+                for (; jj < Hh; ++jj) dr[jj] = dr[jj] * wl[jj];
+            }
+#pragma unroll 16
             for (int jj = 0; jj < Hh; ++jj) s1 = s1 + dr[jj];
+#pragma unroll 16
             for (int jj = 0; jj < Hh; ++jj) s2 = fma32(dr[jj], xr[jj], s2);
             const float m1 = s1 / (float)Hh, m2 = s2 / (float)Hh, r = rstd[r0 + b];
-            for (int jj = 0; jj < Hh; ++jj) dr[jj] = fma32(-xr[jj], m2, dr[jj] - m1) * r;
+            {
+                int jj = 0;
+                for (; jj + 8 <= Hh; jj += 8) {
+                    float v[8], xv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { v[u] = dr[jj + u]; xv[u] = xr[jj + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) dr[jj + u] = fma32(-xv[u], m2, v[u] - m1) * r;
+                }
+                for (; jj < Hh; ++jj) dr[jj] = fma32(-xr[jj], m2, dr[jj] - m1) * r;
+            }
         }
         __syncthreads();
         for (int b = wave_; b < nr; b += DNW) {
