@@ -16,6 +16,7 @@
 #include "lenv_gemm.cuh"
 
 #include <type_traits>
+#define LENV_LN_GENERIC_ROWS 1      // see lenv_ln.cuh: this kernel keeps the LayerNorm row routines in their generic-pointer form (compiler bug)
 #include "lenv_ln.cuh"
 #include "lenv_icm.cuh"
 #include "lenv_wavechain_host.h"
