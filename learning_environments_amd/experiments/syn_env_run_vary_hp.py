@@ -78,3 +78,42 @@ def run_vary_hp(mode, experiment_name, model_num, agents_num, model_dir, custom_
                episode_length_needed=episode_length_needed, env_reward_overview=env_reward_overview, experiment_name=experiment_name,
                out_dir=out_dir)
     return reward_list, train_steps_needed, episode_length_needed
+
+
+def main(argv=None):
+    """The `__main__` block the harness scripts share (syn_env_evaluate_cartpole_vary_hp_2.py:51-101 and siblings): same flags, plus --model_dir /
+    --env_name / --agent (the scripts hard-code a results directory, "CartPole" or "Acrobot", and one agent each) and --out_dir.
+        python -m learning_environments_amd.experiments.syn_env_run_vary_hp --model_dir DIR [--mode 0|1|2] [--agents_num 10] [--model_num 40]
+    Without --mode the three modes run one after the other, like the scripts do."""
+    import argparse
+    from functools import partial
+    from .syn_env_evaluate import HARNESS_AGENTS, load_envs_and_config, train_test_agents, train_test_agents_models
+    parser = argparse.ArgumentParser(description=main.__doc__)
+    parser.add_argument('--mode', type=int, help='mode 0: real env, mode 1: syn. env. (no vary), mode 2: syn. env. (vary)')
+    parser.add_argument('--pool', type=int, help='size of the multiprocessing pool (accepted, unused: one process drives the GPU)')
+    parser.add_argument('--agents_num', type=int, help='number of agents evaluated', default=10)
+    parser.add_argument('--model_num', type=int, help='number of models evaluated', default=40)
+    parser.add_argument('--device', type=str, help='device to be used', default='cuda')
+    parser.add_argument('--model_dir', type=str, required=True, help='directory of the saved GTN models (reference format)')
+    parser.add_argument('--env_name', type=str, default='CartPole', help='substring of the checkpoints\' file names ("CartPole", "Acrobot")')
+    parser.add_argument('--agent', type=str, default='DDQN_vary', help='the sibling script: ' + ', '.join(sorted(HARNESS_AGENTS)))
+    parser.add_argument('--train_episodes', type=int, default=1000, help='1000; the Acrobot TD3_discrete script uses 500')
+    parser.add_argument('--out_dir', type=str, default=None)
+    args = parser.parse_args(argv)
+    if args.agent.lower() not in HARNESS_AGENTS:
+        parser.error("unknown --agent %r (one of %s)" % (args.agent, sorted(HARNESS_AGENTS)))
+    print("model_num:", args.model_num, "agents_num:", args.agents_num, "pool size:", args.pool, "device:", args.device)
+    experiment_name = "%s_transfer_reward_overview_%d_agents_num_%d_model_num" % (args.agent.lower(), args.agents_num, args.model_num)
+    harness = partial(train_test_agents, agent_name=args.agent, train_episodes=args.train_episodes)
+    harness.fused = partial(train_test_agents_models, agent_name=args.agent, train_episodes=args.train_episodes)
+    out = {}
+    for mode in ([args.mode] if args.mode is not None else range(3)):
+        out[mode] = run_vary_hp(mode=mode, experiment_name=experiment_name, model_num=args.model_num, agents_num=args.agents_num,
+                                model_dir=args.model_dir, custom_load_envs_and_config=load_envs_and_config, custom_train_test_agents=harness,
+                                env_name=args.env_name, pool=None, device=args.device, out_dir=args.out_dir)
+        print("mode %d: %d agents, mean test return %.2f" % (mode, len(out[mode][0]), float(np.mean([np.mean(r) for r in out[mode][0]]))))
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -165,3 +165,22 @@ def test_run_vary_hp_one_launch_equals_model_by_model_and_the_oracle(tmp_path, m
     assert fused_train[c] == o["episode_test_mean"][:o["episodes_run"]].tolist()
     saved = torch.load(os.path.join(str(tmp_path), "%d_t.pt" % mode), weights_only=False)
     assert saved["reward_list"] == rewards and saved["env_reward_overview"].shape == (model_num, 10 * agents_num)
+
+
+def test_cli_flags_are_the_scripts_flags():
+    """`python -m learning_environments_amd.experiments.syn_env_run_vary_hp`: the flags of the scripts' __main__ (--mode, --pool, --agents_num,
+    --model_num, --device) plus where the models are; an unknown agent is refused before any GPU work."""
+    with pytest.raises(SystemExit):
+        rv.main(["--model_dir", "/nonexistent", "--agent", "PPO"])
+    with pytest.raises(SystemExit):
+        rv.main([])                                            # --model_dir is required
+
+
+@pytest.mark.gpu
+def test_cli_runs_a_mode_end_to_end(tmp_path):
+    model_dir, _ = _write_models(tmp_path)
+    out = rv.main(["--model_dir", model_dir, "--mode", "2", "--agents_num", "2", "--model_num", "2", "--out_dir", str(tmp_path)])
+    rewards, steps, episodes = out[2]
+    assert len(rewards) == 4 and all(len(r) == 10 for r in rewards) and all(e[0] >= 21 for e in episodes)
+    saved = torch.load(os.path.join(str(tmp_path), "2_ddqn_vary_transfer_reward_overview_2_agents_num_2_model_num.pt"), weights_only=False)
+    assert saved["reward_list"] == rewards and saved["env_reward_overview"].shape == (2, 20)
