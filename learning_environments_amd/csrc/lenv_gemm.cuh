@@ -442,6 +442,31 @@ __device__ __noinline__ void gemm_run_queue(const GemmCmd *cmds_, int n_, float 
     }
 }
 
+// ---- two idioms that keep ROCm 7.2's backend away from "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base" ----
+// Where the compiler can SEE that a generic pointer was derived from an LDS array, it folds (a) the aperture test of __builtin_amdgcn_is_shared and
+// (b) the null test inside a generic -> LDS address-space cast into a compare of the aperture register with a constant; under scalar-register
+// pressure the backend then moves that compare to the vector unit with an operand it may not have there, and the build fails.  (a): the pointer
+// goes through an empty asm first (the test stays a run-time compare of the pointer's high word); (b): lds_offset_ptr takes the low 32 bits of
+// the generic address -- they ARE the LDS offset -- instead of casting.
+__device__ __forceinline__ bool ptr_in_lds(const void *p)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    uint64_t v = reinterpret_cast<uint64_t>(p);
+    asm volatile("" : "+v"(v));
+    return __builtin_amdgcn_is_shared(reinterpret_cast<const void *>(v));
+#else
+    return false;
+#endif
+}
+__device__ __forceinline__ lfloat *lds_offset_ptr(float *p)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    return (lfloat *)(uint32_t)(uintptr_t)uni_ptr(p);
+#else
+    return nullptr;
+#endif
+}
+
 // Per-thread handle of the command queue (the count is uniform; thread 0 writes the records).
 struct GemmQueue {
     GemmCmd *cmds;
@@ -453,8 +478,8 @@ struct GemmQueue {
             GemmCmd &c = cmds[n];                          // written field by field straight into LDS
             int flags = ep.flags;
 #ifdef __HIP_DEVICE_COMPILE__
-            if (__builtin_amdgcn_is_shared(P)) flags |= GEMM_GENERIC_P;
-            if (__builtin_amdgcn_is_shared(ep.out)) flags |= GEMM_GENERIC_OUT;
+            if (ptr_in_lds(P)) flags |= GEMM_GENERIC_P;
+            if (ptr_in_lds(ep.out)) flags |= GEMM_GENERIC_OUT;
 #endif
             c.kind = CMD_GEMM; c.sPi = sPi; c.sPr = sPr; c.sQj = sQj; c.sQr = sQr; c.I = I; c.J = J; c.R = R; c.P = P; c.Q = Q;
             c.ekind = ep.kind; c.ldo = ep.ldo; c.ocol = ep.ocol; c.ldaux = ep.ldaux; c.ldo2 = ep.ldo2; c.act = ep.act; c.flags = flags;

@@ -12,11 +12,10 @@ namespace lenv {
 // -- LNBUF floats from Ps on -- are free between queue runs; odd row stride = conflict-free), thread b then owns row b: sequential mean /
 // variance and the normalised row in place, and the copy back applies weight, bias and activation: xh <- normalised rows, rstd[b],
 // z <- act(fma(xn, w, b)) ----
-#ifndef LENV_LN_GENERIC_ROWS
 // (round 6: the copies request eight rows' words before the first LDS store -- one round trip per eight rows instead of one per row, which was
 // ~30 k of the routine's ~55 k cycles at 128 x 128 --, and the staged rows are addressed as LDS (ds_ instead of flat instructions); the
 // arithmetic and its order are unchanged)
-__device__ __forceinline__ lfloat *ln_lds_ptr(float *p) { return (lfloat *)uni_ptr(p); }
+__device__ __forceinline__ lfloat *ln_lds_ptr(float *p) { return lds_offset_ptr(p); }      // (not a cast: see lenv_gemm.cuh)
 
 template <int NB>
 __device__ __forceinline__ void ln_copy_rows_in(const float *src, int ld, int nr, int Hh, lfloat *buf, int Hp, int lane_, int wave_)
@@ -152,104 +151,5 @@ __device__ __forceinline__ void ln_rows_backward(float *Ps, float *d, int I, int
     }
 }
 
-#else
-// LENV_LN_GENERIC_ROWS (td3_rn_inner_loop.hip): the routines as they were before round 6 -- one row per round trip, staged rows addressed through
-// generic pointers.  The TD3 GEMM-queue kernel's Pendulum instantiation sits at the edge of scalar-register spilling, where ROCm 7.2's backend emits
-// an illegal `V_CMP_NE_U32 0, src_shared_base`; the LDS-typed rows (inlined or out of line) tip it over, these do not.
-template <int LNBUF>
-__device__ __forceinline__ void ln_rows_forward(float *Ps, float *z, int I, int Hh, const float *w, const float *bb, float *xh, float *rstd, int act, float pr)
-{
-    const int tid = threadIdx.x, lane_ = tid & 63, wave_ = tid >> 6;
-    const int Hp = Hh | 1, R = LNBUF / Hp;
-    float *buf = Ps;
-    for (int r0 = 0; r0 < I; r0 += R) {
-        const int nr = I - r0 < R ? I - r0 : R;
-        for (int b = wave_; b < nr; b += DNW) {
-            const float *src = z + (int64_t)(r0 + b) * Hh;
-            for (int jj = lane_; jj < Hh; jj += 64) buf[b * Hp + jj] = src[jj];
-        }
-        __syncthreads();
-        for (int b = tid; b < nr; b += DNT) {
-            float *zr = buf + b * Hp;
-            float sm = 0.0f, sv = 0.0f;
-            for (int jj = 0; jj < Hh; ++jj) sm = sm + zr[jj];
-            const float mean = sm / (float)Hh;
-            for (int jj = 0; jj < Hh; ++jj) { const float dj = zr[jj] - mean; sv = fma32(dj, dj, sv); }
-            const float r = 1.0f / __builtin_sqrtf(sv / (float)Hh + 1e-5f);
-            if (rstd) rstd[r0 + b] = r;
-            for (int jj = 0; jj < Hh; ++jj) zr[jj] = (zr[jj] - mean) * r;
-        }
-        __syncthreads();
-        for (int b = wave_; b < nr; b += DNW) {
-            float *dst = z + (int64_t)(r0 + b) * Hh;
-            float *dxh = xh ? xh + (int64_t)(r0 + b) * Hh : nullptr;
-            for (int jj = lane_; jj < Hh; jj += 64) {
-                const float xnrm = buf[b * Hp + jj];
-                if (dxh) dxh[jj] = xnrm;
-                dst[jj] = act_fwd(act, pr, fma32(xnrm, w[jj], bb[jj]));
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ---- LayerNorm rows (backward): d [I][H] holds the gradient of the LayerNorm OUTPUT.  Column sums first (the shared weight / bias gradient
-// of this position, rows ascending; first: store, else add to what the positions above left), then -- chunks of rows of d and xh staged
-// in LDS as above -- thread b turns row b into the gradient of the LayerNorm input ----
-template <int LNBUF, int MAXW>
-__device__ __forceinline__ void ln_rows_backward(float *Ps, float *d, int I, int Hh, const float *w, const float *xh, const float *rstd, float *g_w, float *g_b, bool first)
-{
-    const int tid = threadIdx.x, lane_ = tid & 63, wave_ = tid >> 6;
-    if (g_w) {
-        for (int jj = tid; jj < Hh; jj += DNT) {
-            float sw = 0.0f, sb = 0.0f;
-            int b = 0;
-            for (; b + 8 <= I; b += 8) {
-                float dv[8], xv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { dv[u] = d[(int64_t)(b + u) * Hh + jj]; xv[u] = xh[(int64_t)(b + u) * Hh + jj]; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { sw = fma32(dv[u], xv[u], sw); sb = sb + dv[u]; }
-            }
-            for (; b < I; ++b) {
-                const float dv = d[(int64_t)b * Hh + jj];
-                sw = fma32(dv, xh[(int64_t)b * Hh + jj], sw);
-                sb = sb + dv;
-            }
-            if (first) { g_w[jj] = sw; g_b[jj] = sb; }
-            else { g_w[jj] = g_w[jj] + sw; g_b[jj] = g_b[jj] + sb; }
-        }
-        __syncthreads();
-    }
-    const int Hp = Hh | 1, R = (LNBUF - MAXW) / (2 * Hp);
-    float *wl = Ps, *bufd = Ps + MAXW, *bufx = bufd + R * Hp;
-    for (int jj = tid; jj < Hh; jj += DNT) wl[jj] = w[jj];
-    for (int r0 = 0; r0 < I; r0 += R) {
-        const int nr = I - r0 < R ? I - r0 : R;
-        for (int b = wave_; b < nr; b += DNW) {
-            const float *sd = d + (int64_t)(r0 + b) * Hh, *sx = xh + (int64_t)(r0 + b) * Hh;
-            for (int jj = lane_; jj < Hh; jj += 64) { bufd[b * Hp + jj] = sd[jj]; bufx[b * Hp + jj] = sx[jj]; }
-        }
-        __syncthreads();
-        for (int b = tid; b < nr; b += DNT) {
-            float *dr = bufd + b * Hp;
-            const float *xr = bufx + b * Hp;
-            float s1 = 0.0f, s2 = 0.0f;
-            for (int jj = 0; jj < Hh; ++jj) dr[jj] = dr[jj] * wl[jj];
-            for (int jj = 0; jj < Hh; ++jj) s1 = s1 + dr[jj];
-            for (int jj = 0; jj < Hh; ++jj) s2 = fma32(dr[jj], xr[jj], s2);
-            const float m1 = s1 / (float)Hh, m2 = s2 / (float)Hh, r = rstd[r0 + b];
-            for (int jj = 0; jj < Hh; ++jj) dr[jj] = fma32(-xr[jj], m2, dr[jj] - m1) * r;
-        }
-        __syncthreads();
-        for (int b = wave_; b < nr; b += DNW) {
-            float *dst = d + (int64_t)(r0 + b) * Hh;
-            for (int jj = lane_; jj < Hh; jj += 64) dst[jj] = bufd[b * Hp + jj];
-        }
-        __syncthreads();
-    }
-}
-
-#endif
 
 }  // namespace lenv

@@ -16,7 +16,6 @@
 #include "lenv_gemm.cuh"
 
 #include <type_traits>
-#define LENV_LN_GENERIC_ROWS 1      // see lenv_ln.cuh: this kernel keeps the LayerNorm row routines in their generic-pointer form (compiler bug)
 #include "lenv_ln.cuh"
 #include "lenv_icm.cuh"
 #include "lenv_wavechain_host.h"
@@ -796,7 +795,7 @@ __global__ __launch_bounds__(DNT) void td3_rn_inner_kernel(const Td3Args a)
             // matrices are walked with literal strides, 64 weights in flight per thread (two register blocks refilled alternately).  The chains
             // are the ones below: k ascending from 0, bias added after.  (The general loop -- input row and weights from the arena, 32 terms
             // requested, waited for, consumed -- took ~50 k cycles per step of a three-layer SE: 56 % of a small-net TD3 generation.)
-            lfloat *hb = (lfloat *)uni_ptr(Ps);
+            lfloat *hb = lds_offset_ptr(Ps);                // (not a cast: see lenv_gemm.cuh)
             if (g < 3) {                                   // first layer: the input row (at most 32 words) from the arena
                 const gfloat *wt = par + mo.oW[0] + j, *in0 = (const gfloat *)x;
                 const int n_in = mo.in;
