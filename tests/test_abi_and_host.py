@@ -371,3 +371,34 @@ def test_config_builders_take_layer_norm_sections():
     assert b.size == 17795 + 256 and not b[17408:17664].any() and b[17407] > 0 and b[17664] > 0
     c["agents"]["ddqn"]["hidden_layer"] = 1                  # one hidden layer: no position, no parameters
     assert config.agent_layer_norm_slice(config.ddqn_cfg_from_config(c, grad_chunk=4)) is None
+
+
+def test_team_exchange_area_is_sized_for_every_launch_that_may_be_teamed():
+    """the team picker and the exchange area of the DDQN kernel share ONE bound (DDQN_TEAM_MAX_CHAINS = 128 chains): the
+    workspace carries chains * team_stride floats for every counter-mode launch of at most 128 chains -- whatever the occupancy API would say --
+    and none above; the picker (GPU half: tests/test_gpu_parity.py team tests) returns 1 above the bound before it asks the occupancy API.
+    Host-only: the size query does no device work."""
+    from learning_environments_amd import _lib, config, configs
+    L = _lib.lib()
+    cfg = config.ddqn_cfg_from_config(configs.fixed_work(configs.cartpole_syn_env_ddqn(), 20))
+    tape = _lib.DdqnCfg.from_buffer_copy(cfg)
+    tape.rng_mode = 1                                          # tape mode: never teamed, never an exchange area
+    per_chain = None
+    for chains in (1, 24, 48, 96, 128):
+        extra = L.lenv_ddqn_se_workspace_bytes(C.byref(cfg), chains) - L.lenv_ddqn_se_workspace_bytes(C.byref(tape), chains)
+        assert extra > 0 and extra % chains == 0
+        per_chain = per_chain or extra // chains
+        assert extra == chains * per_chain
+    for chains in (129, 192, 400):
+        assert L.lenv_ddqn_se_workspace_bytes(C.byref(cfg), chains) == L.lenv_ddqn_se_workspace_bytes(C.byref(tape), chains)
+
+
+@pytest.mark.gpu
+def test_team_picker_respects_the_exchange_area_bound():
+    from learning_environments_amd import _lib, config, configs, engine
+    engine.require_device()
+    L = _lib.lib()
+    cfg = config.ddqn_cfg_from_config(configs.fixed_work(configs.cartpole_syn_env_ddqn(), 20))
+    assert L.lenv_ddqn_se_team_size(C.byref(cfg), 24) > 1 and L.lenv_ddqn_se_team_size(C.byref(cfg), 96) > 1     # the 8- / 2-GPU shards are teamed
+    for chains in (129, 192, 400):
+        assert L.lenv_ddqn_se_team_size(C.byref(cfg), chains) == 1
