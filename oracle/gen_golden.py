@@ -1464,7 +1464,7 @@ def gen_ckpt_b():
 
 
 def gen_g12(name, mode, seed, agents_num=2, vary=True, vary_seed=77, ckpt="ckpt_cartpole_se_reference_b.pt",
-            module="experiments.syn_env_evaluate_cartpole_vary_hp_2", agent_key="ddqn"):
+            module="experiments.syn_env_evaluate_cartpole_vary_hp_2", agent_key="ddqn", env_cls="CartPoleEnv"):
     """module / agent_key: the sibling script and the config section its agent reads (experiments/syn_env_evaluate_cartpole_vary_hp_2_DuelingDDQN.py:
     DuelingDDQN_vary, section `duelingddqn`)."""
     import importlib
@@ -1490,7 +1490,7 @@ def gen_g12(name, mode, seed, agents_num=2, vary=True, vary_seed=77, ckpt="ckpt_
     recs, holders = [], []
     state = {"rec": None, "phase": None}
     orig_random, orig_randint = random.random, np.random.randint
-    cls = genvs.CartPoleEnv
+    cls = getattr(genvs, env_cls)
     orig_reset, orig_sample = cls.reset, gspaces.Discrete.sample
 
     def rec_random():
@@ -1609,6 +1609,24 @@ def gen_g12(name, mode, seed, agents_num=2, vary=True, vary_seed=77, ckpt="ckpt_
     save(name, **out)
     print(name, "episodes", [int(e[0]) for e in episodes_needed], "steps", [int(t[0]) for t in train_steps_needed],
           "hp", [h["hp"] for h in holders], "reward_test", [np.mean(r) for r in reward_list])
+
+
+def gen_ckpt_c():
+    """A reference-written Acrobot-v1 SE checkpoint for G12A (the Acrobot harness script): default_config_acrobot.yaml's shapes, 30-step
+    episodes, reward net biased to about -1 per step (the real env's reward) and a done net that rarely fires, so that the virtual rule says
+    "no" a few times before "yes"."""
+    from envs.env_factory import EnvFactory
+    cfg = load_cfg("default_config_acrobot.yaml")
+    cfg["envs"]["Acrobot-v1"].update(max_steps=30)
+    seed_all(4300)
+    with quiet():
+        venv = EnvFactory(cfg).generate_virtual_env()
+    with torch.no_grad():
+        venv.env.reward_net[-1].bias.add_(-1.0)
+        venv.env.done_net[-1].bias.add_(-0.3)
+    path = os.path.join(OUT, "ckpt_acrobot_se_reference_c.pt")
+    torch.save({'model': venv.state_dict(), 'config': cfg}, path)           # exactly GTN_Master.save_model's payload
+    print("wrote", path, os.path.getsize(path))
 
 
 def gen_g12t(name, seed, vary_seed, agents_num=2, ckpt="ckpt_cartpole_se_reference_b.pt",
@@ -1812,6 +1830,12 @@ def main():
         # (batch 105 / width 42 / 3 layers and 58 / 63 / 1) so that the CPU oracle replays the run in seconds
         gen_g12("g12d_train_test_agents_cartpole_mode2_dueling_vary", mode=2, seed=1204, vary=True, vary_seed=1,
                 module="experiments.syn_env_evaluate_cartpole_vary_hp_2_DuelingDDQN", agent_key="duelingddqn")
+    if "g12a" in which:
+        # the Acrobot harness script (experiments/syn_env_evaluate_acrobot_vary_hp_2.py: the same function on an Acrobot-v1 SE; DDQN_vary over
+        # default_config_acrobot.yaml's 128 x 2 DDQN, vary_seed 1 draws 42 x 3 / batch 105 and 63 x 1 / batch 58)
+        gen_ckpt_c()
+        gen_g12("g12a_train_test_agents_acrobot_mode2_vary", mode=2, seed=1206, vary=True, vary_seed=1, ckpt="ckpt_acrobot_se_reference_c.pt",
+                module="experiments.syn_env_evaluate_acrobot_vary_hp_2", env_cls="AcrobotEnv")
     if "g12t" in which:
         # the TD3_discrete sibling script (td3_discrete_vary + LayerNorm section of default_config_cartpole.yaml); a vary_seed whose draws are
         # small nets so that the CPU oracle replays the run in seconds

@@ -29,6 +29,11 @@ G12D = "g12d_train_test_agents_cartpole_mode2_dueling_vary"
 G12T = "g12t_train_test_agents_cartpole_mode2_td3_discrete_vary"
 
 
+# the Acrobot script (experiments/syn_env_evaluate_acrobot_vary_hp_2.py: the same function on an Acrobot-v1 SE -- 6-dim states, 3 actions --,
+# DDQN_vary over default_config_acrobot.yaml's 128 x 2 DDQN; drawn shapes 42 x 3 / 63 x 1; stops at episodes 28 / 21)
+G12A = "g12a_train_test_agents_acrobot_mode2_vary"
+
+
 def g12_agent(name):
     """(agent_name of the harness, config section, base agent name) of a G12 fixture."""
     return ("DuelingDDQN_vary", "duelingddqn", "DuelingDDQN") if "dueling" in name else ("DDQN_vary", "ddqn", "DDQN")
@@ -53,7 +58,7 @@ def g12_tapes(g, i):
     return [g[pre + "tape_" + k] for k in ("eps_uniform", "rand_action", "replay_idx", "train_reset", "test_reset")]
 
 
-@pytest.mark.parametrize("name", G12 + [G12D])
+@pytest.mark.parametrize("name", G12 + [G12D, G12A])
 def test_g12_oracle_reproduces_the_reference_train_test_agents(golden, name):
     g = golden(name)
     n_agents = int(g["agents_num"])
@@ -73,7 +78,7 @@ def test_g12_oracle_reproduces_the_reference_train_test_agents(golden, name):
         np.testing.assert_allclose(tr["done"], g[pre + "tr_done"], rtol=1e-5, atol=1e-5)      # (a VirtualEnv's done is the raw net output)
         assert np.array_equal(tr["done"] > 0.5, g[pre + "tr_done"] > 0.5)
         losses = tr["loss"][~np.isnan(tr["loss"])]
-        np.testing.assert_allclose(losses, g[pre + "losses"], rtol=2e-3, atol=1e-6)
+        np.testing.assert_allclose(losses, g[pre + "losses"], rtol=2e-3, atol=5e-5)      # (the Acrobot run's late losses are ~3e-3: 2e-5 absolute there)
         # what the function returns: reward_list (the final test's returns), [sum(episode_length)], [len(reward_train)] -- the two counters EXACTLY
         e = int(g["episodes_needed"][i, 0])
         assert out["episodes_run"] == e and out["train_steps"] == int(g["train_steps_needed"][i, 0])
@@ -82,7 +87,7 @@ def test_g12_oracle_reproduces_the_reference_train_test_agents(golden, name):
         assert np.isnan(out["episode_test_mean"][e:]).all()
         np.testing.assert_allclose(out["final_test_returns"], g["reward_list"][i], rtol=0, atol=1e-4)
         # no per-episode tests ran: the only real-env test steps are the final test's
-        assert out["test_steps"] == int(np.sum(g["reward_list"][i]))          # CartPole: return == episode length
+        assert out["test_steps"] == abs(int(np.sum(g["reward_list"][i])))     # CartPole: return == episode length (Acrobot: its negative)
 
 
 def g12t_oracle_cfg(g, i):
@@ -163,15 +168,15 @@ def test_meter_rules_against_a_python_restatement():
 # ------------------------------------------------------------------------------------------------------------------------------
 # GPU half: the product's train_test_agents (learning_environments_amd/experiments/syn_env_evaluate.py), one fused launch per call
 # ------------------------------------------------------------------------------------------------------------------------------
-def _load_ckpt_b(tmp_path):
+def _load_ckpt_b(tmp_path, ckpt="ckpt_cartpole_se_reference_b.pt"):
     import shutil
     from learning_environments_amd.experiments.syn_env_evaluate import load_envs_and_config
-    shutil.copy(os.path.join(HERE, "golden", "ckpt_cartpole_se_reference_b.pt"), tmp_path / "model.pt")
+    shutil.copy(os.path.join(HERE, "golden", ckpt), tmp_path / "model.pt")
     return load_envs_and_config("model.pt", str(tmp_path), "cuda")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", G12 + [G12D])
+@pytest.mark.parametrize("name", G12 + [G12D, G12A])
 def test_g12_product_train_test_agents_replays_the_reference_run(golden, tmp_path, name):
     """The reference's recorded draws (hyper-parameters, fresh agents, RNG tapes) replayed through the product function: the three returned
     lists equal the reference's (`reward_list` within 1e-4, `train_steps_needed` / `episodes_needed` EXACTLY) and the oracle's bit for bit,
@@ -179,7 +184,7 @@ def test_g12_product_train_test_agents_replays_the_reference_run(golden, tmp_pat
     from learning_environments_amd.experiments.syn_env_evaluate import train_test_agents
     g = golden(name)
     mode, n_agents = int(g["mode"]), int(g["agents_num"])
-    venv, real_env, config = _load_ckpt_b(tmp_path)
+    venv, real_env, config = _load_ckpt_b(tmp_path, "ckpt_acrobot_se_reference_c.pt" if "acrobot" in name else "ckpt_cartpole_se_reference_b.pt")
     assert np.array_equal(venv.env.flat_params().cpu().numpy(), g["theta"])
     hps = [json.loads(str(g["a%d_hp_json" % i])) for i in range(n_agents)]
     replay = dict(hp=hps, agent_init=[g["a%d_agent_init" % i] for i in range(n_agents)],
