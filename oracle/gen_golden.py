@@ -1629,6 +1629,45 @@ def gen_ckpt_c():
     print("wrote", path, os.path.getsize(path))
 
 
+def gen_g13():
+    """G13: the result file the REFERENCE's run_vary_hp writes (experiments/syn_env_run_vary_hp.py:32-139 -> utils.save_lists, utils.py:144-160)
+    for mode 2 on two copies of the G12 checkpoint, two agents each -- the payload itself is the fixture (plain lists, a config dict and a
+    pandas DataFrame: data), like the G11 sync files."""
+    import importlib
+    import shutil
+    import tempfile
+    import ConfigSpace
+    ev = importlib.import_module("experiments.syn_env_evaluate_cartpole_vary_hp_2")
+    rv = importlib.import_module("experiments.syn_env_run_vary_hp")
+    tmp = tempfile.mkdtemp(prefix="lenv_g13_")
+    for nm in ("CartPole-v0_4_QQQQQQ.pt", "CartPole-v0_7_CCCCCC.pt"):
+        shutil.copy(os.path.join(OUT, "ckpt_cartpole_se_reference_b.pt"), os.path.join(tmp, nm))
+    cwd = os.getcwd()
+    out_dir = tempfile.mkdtemp(prefix="lenv_g13_out_")
+    try:
+        # the script reads "../default_config_cartpole.yaml" relative to experiments/; save_lists writes into the CURRENT directory: the
+        # loader runs with cwd = experiments/ (nothing is written there), run_vary_hp's save with cwd = out_dir
+        def load(file_name, model_dir, device):
+            os.chdir(os.path.join(REF, "experiments"))
+            try:
+                return ev.load_envs_and_config(file_name=file_name, model_dir=model_dir, device=device)
+            finally:
+                os.chdir(out_dir)
+        os.chdir(out_dir)
+        seed_all(1300)
+        ConfigSpace.RANDOM.seed(77)
+        with quiet():
+            rv.run_vary_hp(mode=2, experiment_name="g13", model_num=2, agents_num=2, model_dir=tmp, custom_load_envs_and_config=load,
+                           custom_train_test_agents=ev.train_test_agents, env_name="CartPole", pool=None, device="cpu")
+    finally:
+        os.chdir(cwd)
+    shutil.copyfile(os.path.join(out_dir, "2_g13.pt"), os.path.join(OUT, "g13_ref_run_vary_hp_mode2.pt"))
+    d = torch.load(os.path.join(OUT, "g13_ref_run_vary_hp_mode2.pt"), weights_only=False)
+    print("g13:", {k: type(v).__name__ for k, v in d.items()}, d["env_reward_overview"].shape, list(d["env_reward_overview"].index), d["episode_length_needed"])
+    shutil.rmtree(tmp, ignore_errors=True)
+    shutil.rmtree(out_dir, ignore_errors=True)
+
+
 def gen_g12t(name, seed, vary_seed, agents_num=2, ckpt="ckpt_cartpole_se_reference_b.pt",
              module="experiments.syn_env_evaluate_cartpole_vary_hp_2_TD3_discrete"):
     """G12T: the TD3_discrete sibling script's train_test_agents (experiments/syn_env_evaluate_cartpole_vary_hp_2_TD3_discrete.py:44-67:
@@ -1830,6 +1869,8 @@ def main():
         # (batch 105 / width 42 / 3 layers and 58 / 63 / 1) so that the CPU oracle replays the run in seconds
         gen_g12("g12d_train_test_agents_cartpole_mode2_dueling_vary", mode=2, seed=1204, vary=True, vary_seed=1,
                 module="experiments.syn_env_evaluate_cartpole_vary_hp_2_DuelingDDQN", agent_key="duelingddqn")
+    if "g13" in which:
+        gen_g13()
     if "g12a" in which:
         # the Acrobot harness script (experiments/syn_env_evaluate_acrobot_vary_hp_2.py: the same function on an Acrobot-v1 SE; DDQN_vary over
         # default_config_acrobot.yaml's 128 x 2 DDQN, vary_seed 1 draws 42 x 3 / batch 105 and 63 x 1 / batch 58)
