@@ -9,7 +9,12 @@ Same names, arguments, list shapes and output file (`<mode>_<experiment_name>.pt
 whose config has vary_hp off / on.  Where the reference loops over the models or spreads them over a multiprocessing pool (:66-72,102-110), a
 `custom_train_test_agents` that carries a `.fused` attribute (this package's train_test_agents does) gets ALL models in one fused launch:
 model_num * agents_num chains, which is what fills an MI355X (40 models x 10 agents = 400 chains); any other callable is called model by
-model like the reference's pool-less branch.  `pool` is accepted and ignored (one process drives the GPU)."""
+model like the reference's pool-less branch.  `pool` is accepted and ignored (one process drives the GPU).
+
+Several GPUs: inside a torch.distributed process group (one process per GPU, `torchrun ... -m learning_environments_amd.experiments.syn_env_run_vary_hp`)
+the models are dealt to the ranks round-robin (model m -> rank m mod N; the chains are keyed by (seed, model index, agent index), so the lists do not
+depend on N), every rank runs its share as one launch, ONE all_gather_object of the per-model lists puts the full result on every rank, and rank 0
+writes the file.  There is no other communication: the unit (a model's agents) is independent (tests/test_run_vary_hp.py, two gloo ranks)."""
 import os
 
 import numpy as np
@@ -34,6 +39,17 @@ def get_all_files(with_vary_hp, model_num, model_dir, custom_load_envs_and_confi
     return file_list[:model_num]
 
 
+def _ranks():
+    """(rank, world) of the torch.distributed process group this process belongs to, (0, 1) without one."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1
+
+
 def run_vary_hp(mode, experiment_name, model_num, agents_num, model_dir, custom_load_envs_and_config, custom_train_test_agents, env_name,
                 pool=None, device="cuda", filter_models_list=None, correlation_exp=False, out_dir=None):
     if mode not in (0, 1, 2):
@@ -41,28 +57,47 @@ def run_vary_hp(mode, experiment_name, model_num, agents_num, model_dir, custom_
     train_on_venv = mode != 0
     with_vary_hp = mode == 2
     fused = getattr(custom_train_test_agents, "fused", None)
+    rank, world = _ranks()
     env_reward_overview = {}
     reward_list, train_steps_needed, episode_length_needed = [], [], []
     if not train_on_venv:
-        file_name = os.listdir(model_dir)[0]
+        file_name = sorted(os.listdir(model_dir))[0] if world > 1 else os.listdir(model_dir)[0]      # (every rank must pick the same file)
         _, real_env, config = custom_load_envs_and_config(file_name=file_name, model_dir=model_dir, device=device)
         names = [real_env.env.env_name + "_" + str(i) for i in range(model_num)]
+        mine = list(range(rank, model_num, world))
         if fused is not None:
-            per_model = fused([real_env] * model_num, real_env, config, agents_num)
+            per_mine = fused([real_env] * len(mine), real_env, config, agents_num, model_indices=mine) if mine else []
         else:
-            per_model = [custom_train_test_agents(train_env=real_env, test_env=real_env, config=config, agents_num=agents_num) for _ in range(model_num)]
+            per_mine = [custom_train_test_agents(train_env=real_env, test_env=real_env, config=config, agents_num=agents_num) for _ in mine]
     else:
         names = get_all_files(with_vary_hp=with_vary_hp, model_num=model_num, model_dir=model_dir,
                               custom_load_envs_and_config=custom_load_envs_and_config, env_name=env_name, device=device,
                               filter_models_list=filter_models_list)
-        loaded = [custom_load_envs_and_config(file_name=f, model_dir=model_dir, device=device) for f in names]
+        mine = list(range(rank, len(names), world))
+        loaded = [custom_load_envs_and_config(file_name=names[m], model_dir=model_dir, device=device) for m in mine]
+        if world > 1 or not loaded:
+            config = custom_load_envs_and_config(file_name=names[0], model_dir=model_dir, device=device)[2] if names else None
         if fused is not None and loaded:
-            config = loaded[0][2]                          # (the pool branch of the reference keeps the first file's config too, :100)
-            per_model = fused([l[0] for l in loaded], loaded[0][1], config, agents_num)
+            if world == 1:
+                config = loaded[0][2]                      # (the pool branch of the reference keeps the first file's config too, :100)
+            per_mine = fused([l[0] for l in loaded], loaded[0][1], config, agents_num, model_indices=mine)
         else:
-            per_model = []
-            for virtual_env, real_env, config in loaded:
-                per_model.append(custom_train_test_agents(train_env=virtual_env, test_env=real_env, config=config, agents_num=agents_num))
+            per_mine = []
+            for virtual_env, real_env, cfg_m in loaded:
+                per_mine.append(custom_train_test_agents(train_env=virtual_env, test_env=real_env, config=cfg_m, agents_num=agents_num))
+                if world == 1:
+                    config = cfg_m
+    if world > 1:
+        # the one exchange step: every rank's (model index, lists) pairs -> the full result on every rank, in model order
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, list(zip(mine, per_mine)))
+        per_model = [None] * len(names)
+        for part in gathered:
+            for m, lists in part:
+                per_model[m] = lists
+    else:
+        per_model = per_mine
     for name, (reward_list_i, train_steps_needed_i, episode_length_needed_i) in zip(names, per_model):
         if correlation_exp and train_on_venv:
             # (:112-117: one entry per model)
@@ -74,9 +109,10 @@ def run_vary_hp(mode, experiment_name, model_num, agents_num, model_dir, custom_
             train_steps_needed += train_steps_needed_i
             episode_length_needed += episode_length_needed_i
         env_reward_overview[name] = {} if correlation_exp else np.hstack(reward_list_i)
-    save_lists(mode=mode, config=config, reward_list=reward_list, train_steps_needed=train_steps_needed,
-               episode_length_needed=episode_length_needed, env_reward_overview=env_reward_overview, experiment_name=experiment_name,
-               out_dir=out_dir)
+    if rank == 0:
+        save_lists(mode=mode, config=config, reward_list=reward_list, train_steps_needed=train_steps_needed,
+                   episode_length_needed=episode_length_needed, env_reward_overview=env_reward_overview, experiment_name=experiment_name,
+                   out_dir=out_dir)
     return reward_list, train_steps_needed, episode_length_needed
 
 
@@ -102,6 +138,13 @@ def main(argv=None):
     args = parser.parse_args(argv)
     if args.agent.lower() not in HARNESS_AGENTS:
         parser.error("unknown --agent %r (one of %s)" % (args.agent, sorted(HARNESS_AGENTS)))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # under torchrun: one process per GPU; the only exchange is one all_gather_object of python lists per mode (gloo carries it)
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if not dist.is_initialized():
+            dist.init_process_group("gloo")
     print("model_num:", args.model_num, "agents_num:", args.agents_num, "pool size:", args.pool, "device:", args.device)
     experiment_name = "%s_transfer_reward_overview_%d_agents_num_%d_model_num" % (args.agent.lower(), args.agents_num, args.model_num)
     harness = partial(train_test_agents, agent_name=args.agent, train_episodes=args.train_episodes)

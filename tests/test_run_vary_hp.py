@@ -6,6 +6,7 @@ GPU half: the product's train_test_agents behind it -- all models of a mode in O
 reading model m's weights) equal to the model-by-model calls bit for bit, and to the oracle chain of that (model, agent)."""
 import json
 import os
+import sys
 import types
 
 import numpy as np
@@ -118,6 +119,58 @@ def test_result_file_has_the_layout_of_the_reference_written_one(tmp_path):
     assert mine["config"]["agents"]["ddqn_vary"]["vary_hp"] is True and ref["config"]["agents"]["ddqn_vary"]["vary_hp"] is True
 
 
+def _stand_in_harness(train_env, test_env, config, agents_num):
+    """deterministic in the model it is given (its file name), so that any dealing of the models over ranks must reproduce the same lists"""
+    k = sum(ord(c) for c in str(train_env)) % 97
+    return [[float(k + i)] * 3 for i in range(agents_num)], [[100 * k + i] for i in range(agents_num)], [[k] for _ in range(agents_num)]
+
+
+def _rv_rank(rank, world, port, model_dir, out_dir, q):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(HERE))
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from learning_environments_amd.experiments import syn_env_run_vary_hp as rv_
+    vary_of = {f: True for f in os.listdir(model_dir)}
+    out = rv_.run_vary_hp(2, "mr", 5, 2, model_dir, _fake_loader(vary_of), _stand_in_harness, "CartPole", device="cpu", out_dir=out_dir)
+    q.put((rank, out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_deal_the_models_and_gather_the_same_lists(tmp_path):
+    """SURVEY.md §8(e) for this row: the unit (a checkpoint's agents) is independent, so N ranks take the models round-robin, exchange the per-model
+    lists once (all_gather_object) and rank 0 writes the file -- the lists and the file equal the single-process run's."""
+    import torch.multiprocessing as mp
+    model_dir = tmp_path / "models"
+    model_dir.mkdir()
+    for i, tag in enumerate(("QQQQQQ", "CCCCCC", "HHHHHH", "AAAAAA", "ZZZZZZ")):
+        (model_dir / ("CartPole-v0_%d_%s.pt" % (i, tag))).write_bytes(b"")
+    results = {}
+    for world, port in ((1, 29731), (2, 29732)):
+        out_dir = tmp_path / ("out%d" % world)
+        out_dir.mkdir()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_rv_rank, args=(r, world, port, str(model_dir), str(out_dir), q)) for r in range(world)]
+        for p_ in procs:
+            p_.start()
+        got = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+        for p_ in procs:
+            p_.join(timeout=60)
+            assert p_.exitcode == 0
+        results[world] = (got, torch.load(str(out_dir / "2_mr.pt"), weights_only=False))
+        assert sorted(os.listdir(str(out_dir))) == ["2_mr.pt"]                                   # written once, by rank 0
+    single, double = results[1][0][0][1], results[2][0]
+    assert len(single[0]) == 10
+    for rank, out in double:
+        assert out == single                                                                     # every rank holds the full lists
+    assert results[2][1]["reward_list"] == results[1][1]["reward_list"]
+    assert results[2][1]["env_reward_overview"].equals(results[1][1]["env_reward_overview"])
+
+
 # ------------------------------------------------------------------------------------------------------------------------------
 # GPU half
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -218,3 +271,46 @@ def test_cli_runs_a_mode_end_to_end(tmp_path):
     assert len(rewards) == 4 and all(len(r) == 10 for r in rewards) and all(e[0] >= 21 for e in episodes)
     saved = torch.load(os.path.join(str(tmp_path), "2_ddqn_vary_transfer_reward_overview_2_agents_num_2_model_num.pt"), weights_only=False)
     assert saved["reward_list"] == rewards and saved["env_reward_overview"].shape == (2, 20)
+
+
+def _rv_rank_gpu(rank, world, port, model_dir, out_dir, q):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from learning_environments_amd.experiments import syn_env_run_vary_hp as rv_
+    from learning_environments_amd.experiments.syn_env_evaluate import load_envs_and_config, train_test_agents
+    out = rv_.run_vary_hp(2, "mg", 2, 2, model_dir, load_envs_and_config, train_test_agents, "CartPole", out_dir=out_dir)
+    q.put((rank, out, train_test_agents.last["inner"].chains))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_equal_the_single_process_launch(tmp_path):
+    """The product's harness behind run_vary_hp with two ranks (both on this box's one GPU, gloo for the list exchange): each rank launches ITS
+    model's agents (2 chains instead of 4), the gathered lists equal the one-process launch of all four bit for bit -- the chains are keyed by
+    (seed, model index, agent index), not by where they run."""
+    import torch.multiprocessing as mp
+    model_dir, _ = _write_models(tmp_path)
+    res = {}
+    for world, port in ((1, 29741), (2, 29742)):
+        out_dir = tmp_path / ("o%d" % world)
+        out_dir.mkdir()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_rv_rank_gpu, args=(r, world, port, model_dir, str(out_dir), q)) for r in range(world)]
+        for p_ in procs:
+            p_.start()
+        got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+        for p_ in procs:
+            p_.join(timeout=120)
+            assert p_.exitcode == 0
+        res[world] = got
+    single = res[1][0]
+    assert single[2] == 4 and [g_[2] for g_ in res[2]] == [2, 2]
+    for g_ in res[2]:
+        assert g_[1] == single[1]
