@@ -47,16 +47,17 @@ def load_envs_and_config(file_name, model_dir, device):
     return virtual_env, real_env, config
 
 
-def apply_comparability_settings(config, agent_name="DDQN_vary", train_episodes=1000):
+def apply_comparability_settings(config, agent_name="DDQN_vary", train_episodes=1000, test_episodes=10, early_out_num=10):
     """The block every harness script opens with (syn_env_evaluate_cartpole_vary_hp_2.py:29-36; 500 train episodes in
-    syn_env_evaluate_acrobot_vary_hp_2_TD3_discrete.py).  Mutates `config` like the reference."""
+    syn_env_evaluate_acrobot_vary_hp_2_TD3_discrete.py; 100 test episodes and early_out_num 1000 in the *_correlation scripts, :41-43
+    there).  Mutates `config` like the reference."""
     section, vary_section = HARNESS_AGENTS[agent_name.lower()]
     config['agents'][vary_section]['vary_hp'] = True
     config['agents'][section]['print_rate'] = 10
-    config['agents'][section]['early_out_num'] = 10
+    config['agents'][section]['early_out_num'] = early_out_num
     config['agents'][section]['train_episodes'] = train_episodes
     config['agents'][section]['init_episodes'] = 10
-    config['agents'][section]['test_episodes'] = 10
+    config['agents'][section]['test_episodes'] = test_episodes
     config['agents'][section]['early_out_virtual_diff'] = 0.01
     return config
 
@@ -104,13 +105,13 @@ def train_test_agents_models(train_envs, test_env, config, agents_num, agent_nam
     return _launch(list(train_envs), test_env, config, agents_num, agent_name, train_episodes, vary_hp, seed, None, list(model_indices))
 
 
-def _launch(train_envs, test_env, config, agents_num, agent_name, train_episodes, vary_hp, seed, replay, model_indices):
+def _launch(train_envs, test_env, config, agents_num, agent_name, train_episodes, vary_hp, seed, replay, model_indices, settings=None):
     key = agent_name.lower()
     if key not in HARNESS_AGENTS:
         raise NotImplementedError("train_test_agents: agent '%s' (the harness scripts train %s)" % (agent_name, sorted(HARNESS_AGENTS)))
     if test_env.is_virtual_env():
         raise ValueError("test_env must be the real environment")
-    apply_comparability_settings(config, agent_name, train_episodes)
+    apply_comparability_settings(config, agent_name, train_episodes, **(settings or {}))
     section, vary_section = HARNESS_AGENTS[key]
     if not vary_hp:
         config['agents'][vary_section]['vary_hp'] = False
@@ -182,6 +183,36 @@ def _launch(train_envs, test_env, config, agents_num, agent_name, train_episodes
                                   hp=hp_last, inner=inner, task=task, keys=keys, order=order)
     return [(reward_list[m * n_ag:(m + 1) * n_ag], train_steps_needed[m * n_ag:(m + 1) * n_ag], episodes_needed[m * n_ag:(m + 1) * n_ag])
             for m in range(M)]
+
+
+def train_test_agents_correlation(train_env, test_env, config, agents_num, repeats=100, train_episodes=1000, seed=0, model_index=0):
+    """The `train_test_agents` of the *_correlation scripts (experiments/syn_env_evaluate_cartpole_vary_hp_2_correlation.py:25-87): for each of
+    `agents_num` drawn DDQN configurations, `repeats` (100) fresh DDQN agents with THAT configuration are trained on `train_env` and as many on
+    the real env (`test_env`), each tested 100 episodes on the real env; early_out_num 1000 (:43).  Returns the three dicts of the reference:
+    {"config", "synthetic": [...], "real": [...]} for the test returns, [sum(episode_length)] and [len(reward_train)] -- entries in the
+    reference's order (configuration by configuration, its `repeats` agents).  Here a configuration's `repeats` agents share their shapes, so they
+    are the chains of ONE launch of the fixed-shape kernels (the register-resident one where the drawn net fits it): two launches per
+    configuration."""
+    from ..agents import vary
+    settings = dict(test_episodes=100, early_out_num=1000)
+    apply_comparability_settings(config, "DDQN_vary", train_episodes, **settings)
+    out = {"synthetic": ([], [], []), "real": ([], [], [])}
+    drawn = []
+    for i in range(int(agents_num)):
+        key = chain_keys(int(seed), int(model_index), np.array([i]), np.array([1], np.int64))[0]           # kind 1: the configuration draws
+        hp = vary.vary_hyperparameters(config["agents"]["ddqn"], vary.chain_units(key))
+        drawn.append(hp)
+        cfg_i = copy.deepcopy(config)
+        cfg_i["agents"]["ddqn"].update(hp)
+        for name, env in (("synthetic", train_env), ("real", test_env)):
+            # agent j of configuration i: DDQN(config_varied) (:49,60) = the `_vary` agent with vary_hp off on the varied section
+            r, t, e = _launch([env], test_env, copy.deepcopy(cfg_i), int(repeats), "DDQN_vary", train_episodes, False, int(seed) + 7919 * (i + 1),
+                              None, [model_index], settings=settings)[0]
+            out[name][0].extend(r)
+            out[name][1].extend(t)
+            out[name][2].extend(e)
+    train_test_agents_correlation.last = dict(hp=drawn)
+    return tuple({"config": config, "synthetic": out["synthetic"][k], "real": out["real"][k]} for k in range(3))
 
 
 train_test_agents.last = None

@@ -135,6 +135,8 @@ def main(argv=None):
     parser.add_argument('--agent', type=str, default='DDQN_vary', help='the sibling script: ' + ', '.join(sorted(HARNESS_AGENTS)))
     parser.add_argument('--train_episodes', type=int, default=1000, help='1000; the Acrobot TD3_discrete script uses 500')
     parser.add_argument('--out_dir', type=str, default=None)
+    parser.add_argument('--correlation', action='store_true',
+                        help='the *_correlation scripts: per drawn configuration 100 DDQN agents on the SE and 100 on the real env (mode 2, correlation_exp)')
     args = parser.parse_args(argv)
     if args.agent.lower() not in HARNESS_AGENTS:
         parser.error("unknown --agent %r (one of %s)" % (args.agent, sorted(HARNESS_AGENTS)))
@@ -150,6 +152,14 @@ def main(argv=None):
     harness = partial(train_test_agents, agent_name=args.agent, train_episodes=args.train_episodes)
     harness.fused = partial(train_test_agents_models, agent_name=args.agent, train_episodes=args.train_episodes)
     out = {}
+    if args.correlation:
+        from .syn_env_evaluate import train_test_agents_correlation
+        experiment_name = "ddqn_vary_correlation_syn_real_early_out_num_1000_%d_agents_num_%d_model_num" % (args.agents_num, args.model_num)
+        harness = partial(train_test_agents_correlation, train_episodes=args.train_episodes)
+        out[2] = run_vary_hp(mode=2, experiment_name=experiment_name, model_num=args.model_num, agents_num=args.agents_num, model_dir=args.model_dir,
+                             custom_load_envs_and_config=load_envs_and_config, custom_train_test_agents=harness, env_name=args.env_name, pool=None,
+                             device=args.device, correlation_exp=True, out_dir=args.out_dir)
+        return out
     for mode in ([args.mode] if args.mode is not None else range(3)):
         out[mode] = run_vary_hp(mode=mode, experiment_name=experiment_name, model_num=args.model_num, agents_num=args.agents_num,
                                 model_dir=args.model_dir, custom_load_envs_and_config=load_envs_and_config, custom_train_test_agents=harness,

@@ -329,6 +329,49 @@ def test_product_train_test_agents_acrobot_script_vs_oracle():
 
 
 @pytest.mark.gpu
+def test_product_train_test_agents_correlation_variant(tmp_path):
+    """experiments/syn_env_evaluate_cartpole_vary_hp_2_correlation.py:25-87: per drawn configuration, `repeats` DDQN agents with THAT configuration on
+    the SE and as many on the real env, 100 test episodes each, early_out_num 1000; three dicts {"config", "synthetic", "real"}.  Shapes and
+    settings as the reference's; the last launch (last configuration, real env) against the oracle chain of one of its agents."""
+    import torch
+    from learning_environments_amd.agents.nes_common import chain_keys, fresh_agent_init
+    from learning_environments_amd.experiments.syn_env_evaluate import train_test_agents, train_test_agents_correlation
+    venv, real_env, config = _load_ckpt_b(tmp_path)
+    rewards, steps, episodes = train_test_agents_correlation(venv, real_env, config, agents_num=2, repeats=3, train_episodes=14, seed=4)
+    a = config["agents"]["ddqn"]
+    assert (a["train_episodes"], a["init_episodes"], a["early_out_num"], a["test_episodes"], a["early_out_virtual_diff"]) == (14, 10, 1000, 100, 0.01)
+    for d in (rewards, steps, episodes):
+        assert set(d) == {"config", "synthetic", "real"} and d["config"] is config and len(d["synthetic"]) == len(d["real"]) == 6
+    assert all(len(r) == 100 for r in rewards["synthetic"] + rewards["real"])
+    assert all(e == [14] for e in episodes["synthetic"])              # early_out_num 1000: the virtual rule can never fire, every agent trains all its episodes
+    assert all(11 <= e[0] <= 14 for e in episodes["real"])            # (on the real env the REAL rule applies: mean reward >= solved_reward, 16 in this checkpoint)
+    hps = train_test_agents_correlation.last["hp"]
+    assert len(hps) == 2 and hps[0] != hps[1]
+    # the last launch: configuration 1 on the real env, three agents of ONE shape (a fixed-shape launch, not the per-chain-shape kernel)
+    last = train_test_agents.last
+    inner = last["inner"]
+    assert inner.chains == 3 and inner.cfg.test_mode == 1 and inner.cfg.synthetic_env_type == 1
+    assert (inner.cfg.batch_size, inner.cfg.q_hidden, inner.cfg.q_layers) == (hps[1]["batch_size"], hps[1]["hidden_size"], max(1, hps[1]["hidden_layer"]))
+    seed_l = 4 + 7919 * 2
+    keys = chain_keys(seed_l, 0, np.arange(3), np.zeros(3, np.int64))
+    cfgd = json.loads(json.dumps(config))
+    cfgd["agents"]["ddqn"].update(hps[1])
+    cfgd["agents"]["gtn"]["agent_name"] = "DDQN"
+    ocfg = orc.ddqn_cfg_from_config(cfgd, grad_chunk=inner.cfg.grad_chunk, rng_mode=0, test_mode=1, synthetic_env_type=1, reward_env_type=0)
+    if last["task"].needs_agent_init():
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(seed_l)
+        inits = fresh_agent_init(last["task"].agent_bounds, 3, gen, torch.device("cuda")).cpu().numpy()
+    else:
+        inits = inner.agent_init.cpu().numpy()
+    c = 2
+    p_c = orc.mlp_num_params(orc.mlp_desc(4, ocfg.q_hidden, ocfg.q_layers, 2, ocfg.q_act))
+    o = orc.ddqn_se_chain(ocfg, np.zeros(1, np.float32), inits[c][:p_c], rng_key=int(keys[c]))
+    assert o["rc"] == 0 and episodes["real"][3 + c] == [o["episodes_run"]]
+    assert rewards["real"][3 + c] == o["final_test_returns"].tolist() and steps["real"][3 + c] == [o["train_steps"]]
+
+
+@pytest.mark.gpu
 def test_product_train_test_agents_refuses_what_the_harness_does_not_train(tmp_path):
     from learning_environments_amd.experiments.syn_env_evaluate import train_test_agents
     venv, real_env, config = _load_ckpt_b(tmp_path)
