@@ -487,6 +487,16 @@ def next_row_records():
             rewards, steps, episodes = rv.run_vary_hp(2, "b", 40, 10, d, load_envs_and_config, train_test_agents, "CartPole", out_dir=d)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            from learning_environments_amd.experiments.syn_env_evaluate import train_test_agents_generalization_gap
+            rv.run_vary_hp(2, "warm2", 1, 10, d, load_envs_and_config, train_test_agents_generalization_gap, "CartPole", out_dir=d)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _, steps_g, _ = rv.run_vary_hp(2, "g", 40, 10, d, load_envs_and_config, train_test_agents_generalization_gap, "CartPole", out_dir=d)
+            torch.cuda.synchronize()
+            dtg = time.perf_counter() - t1
+            out.append({"row": "the same with the *_eval_generalization_gap script's agents (vary_hp off, the optimised DDQN 4-57-2 tanh, batch 199 = the headline "
+                               "kernel's shape with test_mode 1): 400 agents in one launch of ddqn_se_inner_kernel", "agents": 400, "seconds": dtg,
+                        "agents_per_s": 400 / dtg, "train_steps": int(sum(s_[0] for s_ in steps_g))})
             out.append({"row": "SURVEY 8(f).1 evaluation harness: run_vary_hp mode 2, 40 SE checkpoints x 10 DDQN_vary agents (drawn shapes) in one fused launch, "
                                "checkpoint loading and the result file inside the time", "agents": 400, "seconds": dt, "agents_per_s": 400 / dt,
                         "train_steps": int(sum(s_[0] for s_ in steps)), "mean_episodes": float(np.mean([e[0] for e in episodes])),

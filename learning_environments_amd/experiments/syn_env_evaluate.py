@@ -215,6 +215,25 @@ def train_test_agents_correlation(train_env, test_env, config, agents_num, repea
     return tuple({"config": config, "synthetic": out["synthetic"][k], "real": out["real"][k]} for k in range(3))
 
 
+# experiments/syn_env_evaluate_cartpole_vary_hp_2_eval_generalization_gap.py:31,39-50: vary_hp off and these DDQN hyper-parameters (the optimised
+# CartPole agent of default_config_cartpole_syn_env.yaml = BASELINE configs[1]'s 4-57-2 tanh net, batch 199)
+GENERALIZATION_GAP_HP = dict(batch_size=199, gamma=0.988, lr=0.000304, tau=0.00848, eps_init=0.809, eps_min=0.0371, eps_decay=0.961,
+                             same_action_num=1, activation_fn="tanh", hidden_size=57, hidden_layer=1)
+
+
+def train_test_agents_generalization_gap(train_env, test_env, config, agents_num, seed=0, model_index=0):
+    """The `train_test_agents` of the *_eval_generalization_gap script: the same function with vary_hp OFF and the fixed hyper-parameters above --
+    every agent has the headline kernel's shape, so the launch runs on the register-resident kernel (test_mode 1)."""
+    config['agents']['ddqn'].update(GENERALIZATION_GAP_HP)
+    return train_test_agents(train_env, test_env, config, agents_num, vary_hp=False, seed=seed, model_index=model_index)
+
+
+def _generalization_gap_models(train_envs, test_env, config, agents_num, model_indices=None, seed=0):
+    config['agents']['ddqn'].update(GENERALIZATION_GAP_HP)
+    return train_test_agents_models(train_envs, test_env, config, agents_num, vary_hp=False, seed=seed, model_indices=model_indices)
+
+
+train_test_agents_generalization_gap.fused = _generalization_gap_models
 train_test_agents.last = None
 train_test_agents.fused = train_test_agents_models       # run_vary_hp (syn_env_run_vary_hp.py) takes the one-launch path when it finds this
 

@@ -135,6 +135,8 @@ def main(argv=None):
     parser.add_argument('--agent', type=str, default='DDQN_vary', help='the sibling script: ' + ', '.join(sorted(HARNESS_AGENTS)))
     parser.add_argument('--train_episodes', type=int, default=1000, help='1000; the Acrobot TD3_discrete script uses 500')
     parser.add_argument('--out_dir', type=str, default=None)
+    parser.add_argument('--generalization_gap', action='store_true',
+                        help='the *_eval_generalization_gap script: vary_hp off, the fixed optimised DDQN hyper-parameters (4-57-2 tanh, batch 199)')
     parser.add_argument('--correlation', action='store_true',
                         help='the *_correlation scripts: per drawn configuration 100 DDQN agents on the SE and 100 on the real env (mode 2, correlation_exp)')
     args = parser.parse_args(argv)
@@ -160,6 +162,10 @@ def main(argv=None):
                              custom_load_envs_and_config=load_envs_and_config, custom_train_test_agents=harness, env_name=args.env_name, pool=None,
                              device=args.device, correlation_exp=True, out_dir=args.out_dir)
         return out
+    if args.generalization_gap:
+        from .syn_env_evaluate import train_test_agents_generalization_gap
+        experiment_name = "ddqn_generalization_gap_%d_agents_num_%d_model_num" % (args.agents_num, args.model_num)
+        harness = train_test_agents_generalization_gap
     for mode in ([args.mode] if args.mode is not None else range(3)):
         out[mode] = run_vary_hp(mode=mode, experiment_name=experiment_name, model_num=args.model_num, agents_num=args.agents_num,
                                 model_dir=args.model_dir, custom_load_envs_and_config=load_envs_and_config, custom_train_test_agents=harness,

@@ -314,3 +314,35 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_launch(tmp_path):
     assert single[2] == 4 and [g_[2] for g_ in res[2]] == [2, 2]
     for g_ in res[2]:
         assert g_[1] == single[1]
+
+
+@pytest.mark.gpu
+def test_generalization_gap_script_runs_on_the_register_resident_kernel(tmp_path):
+    """experiments/syn_env_evaluate_cartpole_vary_hp_2_eval_generalization_gap.py: vary_hp off + the fixed optimised DDQN hyper-parameters = the
+    headline kernel's shape (4-57-2 tanh, batch 199) with test_mode 1: all models in one launch of `ddqn_se_inner_kernel`, one (model, agent)
+    pair against the oracle chain."""
+    from oracle import oracle as orc
+    from learning_environments_amd.agents.nes_common import chain_keys, fresh_agent_init
+    from learning_environments_amd.experiments.syn_env_evaluate import GENERALIZATION_GAP_HP, train_test_agents, train_test_agents_generalization_gap
+    model_dir, load = _write_models(tmp_path)
+    rewards, steps, episodes = rv.run_vary_hp(2, "gg", 2, 3, model_dir, load, train_test_agents_generalization_gap, "CartPole", out_dir=str(tmp_path))
+    last = train_test_agents.last
+    inner = last["inner"]
+    assert inner.chains == 6 and not inner.dueling and inner.cfg.grad_chunk > 0 and inner.cfg.test_mode == 1
+    assert (inner.cfg.batch_size, inner.cfg.q_hidden, inner.cfg.q_layers) == (199, 57, 1)
+    files = rv.get_all_files(True, 2, model_dir, load, "CartPole", "cuda")
+    m, i = 1, 2
+    c = m * 3 + i
+    venv, _, cfgd = load(files[m], model_dir, "cuda")
+    from learning_environments_amd.experiments.syn_env_evaluate import apply_comparability_settings
+    apply_comparability_settings(cfgd)
+    cfgd["agents"]["ddqn"].update(GENERALIZATION_GAP_HP)
+    cfgd["agents"]["gtn"]["agent_name"] = "DDQN"
+    ocfg = orc.ddqn_cfg_from_config(json.loads(json.dumps(cfgd)), grad_chunk=inner.cfg.grad_chunk, rng_mode=0, test_mode=1)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0 + 1000003 * m)
+    init = fresh_agent_init(last["task"].agent_bounds, 3, gen, torch.device("cuda")).cpu().numpy()[i]
+    key = int(chain_keys(0, m, np.array([i]), np.zeros(1, np.int64))[0])
+    o = orc.ddqn_se_chain(ocfg, venv.env.flat_params().cpu().numpy(), init, rng_key=key)
+    assert o["rc"] == 0
+    assert rewards[c] == o["final_test_returns"].tolist() and steps[c] == [o["train_steps"]] and episodes[c] == [o["episodes_run"]]

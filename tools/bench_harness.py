@@ -33,8 +33,11 @@ def main():
     from learning_environments_amd.experiments import syn_env_evaluate as se
     if agent is not None:
         from functools import partial
-        fn = partial(train_test_agents, agent_name=agent)
-        fn.fused = partial(se.train_test_agents_models, agent_name=agent)
+        if agent == "generalization_gap":                     # the *_eval_generalization_gap script: fixed optimised DDQN = the headline kernel's shape
+            fn = se.train_test_agents_generalization_gap
+        else:
+            fn = partial(train_test_agents, agent_name=agent)
+            fn.fused = partial(se.train_test_agents_models, agent_name=agent)
         if agent.lower() == "td3_discrete_vary":            # the script takes this section from default_config_cartpole.yaml (`td3_discrete_vary_layer_norm_2`)
             sect = {"train_episodes": 1000, "test_episodes": 10, "init_episodes": 10, "batch_size": 128, "gamma": 0.99, "lr": 5e-4, "tau": 0.01,
                     "policy_delay": 2, "rb_size": 1000000, "same_action_num": 1, "activation_fn": "tanh", "hidden_size": 128, "hidden_layer": 2,
