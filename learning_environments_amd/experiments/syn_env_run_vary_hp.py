@@ -75,11 +75,10 @@ def run_vary_hp(mode, experiment_name, model_num, agents_num, model_dir, custom_
                               filter_models_list=filter_models_list)
         mine = list(range(rank, len(names), world))
         loaded = [custom_load_envs_and_config(file_name=names[m], model_dir=model_dir, device=device) for m in mine]
-        if world > 1 or not loaded:
-            config = custom_load_envs_and_config(file_name=names[0], model_dir=model_dir, device=device)[2] if names else None
+        # the config that is saved: the first file's (the pool branch of the reference keeps it too, :100; rank 0 always holds model 0, and the
+        # harness function writes its settings for comparability into this very dict)
+        config = loaded[0][2] if loaded else (custom_load_envs_and_config(file_name=names[0], model_dir=model_dir, device=device)[2] if names else None)
         if fused is not None and loaded:
-            if world == 1:
-                config = loaded[0][2]                      # (the pool branch of the reference keeps the first file's config too, :100)
             per_mine = fused([l[0] for l in loaded], loaded[0][1], config, agents_num, model_indices=mine)
         else:
             per_mine = []
